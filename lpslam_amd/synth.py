@@ -1,0 +1,203 @@
+"""Seeded synthetic stereo sequences and bundle-adjustment problems.
+
+Host-side test/bench input generation only (numpy); nothing here is on the measured path.
+PRNG: numpy PCG64 seeded with 0x5EED0000 + sequence_id.
+"""
+import math
+import numpy as np
+
+SEED_BASE = 0x5EED0000
+
+INTRINSICS = {
+    (640, 480): dict(fx=525.0, fy=525.0, cx=320.0, cy=240.0),
+    (1280, 720): dict(fx=700.0, fy=700.0, cx=640.0, cy=360.0),
+    (1920, 1080): dict(fx=1050.0, fy=1050.0, cx=960.0, cy=540.0),
+}
+BASELINE_M = 0.12  # cf. /root/reference/src/Sources/OpenCVCameraSource.cpp:68-75
+
+
+def intrinsics(width, height):
+    if (width, height) in INTRINSICS:
+        k = dict(INTRINSICS[(width, height)])
+    else:  # small test sizes: same field of view as 640x480
+        f = 525.0 * width / 640.0
+        k = dict(fx=f, fy=f, cx=width / 2.0, cy=height / 2.0)
+    k["fxb"] = k["fx"] * BASELINE_M
+    k["baseline"] = BASELINE_M
+    return k
+
+
+def _value_noise(rng, h, w, octaves=3, mean=110.0, sigma=25.0):
+    """Three octaves of bilinearly interpolated random lattices."""
+    out = np.zeros((h, w), np.float64)
+    amp, total = 1.0, 0.0
+    for o in range(octaves):
+        cell = 64 >> o
+        gh, gw = h // cell + 2, w // cell + 2
+        g = rng.standard_normal((gh, gw))
+        ys = np.arange(h) / cell
+        xs = np.arange(w) / cell
+        y0 = ys.astype(int); x0 = xs.astype(int)
+        fy = (ys - y0)[:, None]; fx = (xs - x0)[None, :]
+        a = g[y0][:, x0]; b = g[y0][:, x0 + 1]; c = g[y0 + 1][:, x0]; d = g[y0 + 1][:, x0 + 1]
+        out += amp * ((a * (1 - fx) + b * fx) * (1 - fy) + (c * (1 - fx) + d * fx) * fy)
+        total += amp * amp
+        amp *= 0.5
+    out *= sigma / math.sqrt(total) / 0.6
+    return out + mean
+
+
+class StereoSequence:
+    """Rectified, distortion-free synthetic stereo sequence."""
+
+    def __init__(self, width, height, seq_id=0, n_points=20000):
+        self.w, self.h = int(width), int(height)
+        self.k = intrinsics(width, height)
+        self.rng = np.random.Generator(np.random.PCG64(SEED_BASE + int(seq_id)))
+        r = self.rng
+        self.pts = np.stack([r.uniform(-20, 20, n_points), r.uniform(-5, 5, n_points),
+                             r.uniform(1.0, 41.0, n_points)], axis=1)
+        self.amp = r.uniform(60, 120, n_points)
+        self.quad = r.integers(0, 2, (n_points, 2, 2)) * 2 - 1     # +-1 per quadrant
+        same = (self.quad.reshape(n_points, 4) == self.quad[:, :1, 0]).all(axis=1)
+        self.quad[same, 0, 0] *= -1                                 # never a flat patch
+        self.bg = _value_noise(r, self.h, self.w)
+
+    def pose(self, k):
+        """World->camera (R, t) of the left camera at frame k: +z at 0.05 m/frame, small yaw."""
+        yaw = math.radians(0.2) * math.sin(2 * math.pi * k / 100.0)
+        c, s = math.cos(yaw), math.sin(yaw)
+        R_wc = np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]])        # camera->world
+        C = np.array([0.0, 0.0, 0.05 * k])
+        R = R_wc.T
+        return R, -R @ C
+
+    def _render(self, R, t, noise_rng):
+        img = self.bg.copy()
+        pc = self.pts @ R.T + t
+        z = pc[:, 2]
+        ok = z > 0.5
+        u = np.where(ok, self.k["fx"] * pc[:, 0] / np.where(ok, z, 1) + self.k["cx"], -100)
+        v = np.where(ok, self.k["fy"] * pc[:, 1] / np.where(ok, z, 1) + self.k["cy"], -100)
+        ui = np.rint(u).astype(int); vi = np.rint(v).astype(int)
+        ok &= (ui >= 4) & (ui < self.w - 4) & (vi >= 4) & (vi < self.h - 4)
+        idx = np.nonzero(ok)[0]
+        idx = idx[np.argsort(-z[idx], kind="stable")]              # far first, near overwrites
+        flat = img.reshape(-1)
+        for dy in range(-3, 4):
+            for dx in range(-3, 4):
+                q = self.quad[idx, int(dy >= 0), int(dx >= 0)]
+                flat[(vi[idx] + dy) * self.w + ui[idx] + dx] = 110.0 + q * self.amp[idx]
+        img += noise_rng.normal(0.0, 2.0, img.shape)
+        return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+
+    def frame(self, k):
+        """Returns (left, right) uint8 images of frame k (deterministic per (seq_id, k))."""
+        R, t = self.pose(k)
+        nrng = np.random.Generator(np.random.PCG64([SEED_BASE, 77, int(k)]))
+        left = self._render(R, t, nrng)
+        right = self._render(R, t - np.array([self.k["baseline"], 0.0, 0.0]), nrng)
+        return left, right
+
+
+def random_image(width, height, seed=0):
+    """Left image of frame 0 of a small sequence (unit tests)."""
+    n = max(200, int(20000 * (width * height) / (1280.0 * 720.0)))
+    return StereoSequence(width, height, seq_id=seed, n_points=n).frame(0)[0]
+
+
+def rot_to_quat(R):
+    tr = np.trace(R)
+    if tr > 0:
+        s = math.sqrt(tr + 1.0) * 2
+        q = [0.25 * s, (R[2, 1] - R[1, 2]) / s, (R[0, 2] - R[2, 0]) / s, (R[1, 0] - R[0, 1]) / s]
+    else:
+        i = int(np.argmax(np.diag(R)))
+        j, k = (i + 1) % 3, (i + 2) % 3
+        s = math.sqrt(1.0 + R[i, i] - R[j, j] - R[k, k]) * 2
+        q = [0.0, 0.0, 0.0, 0.0]
+        q[0] = (R[k, j] - R[j, k]) / s
+        q[1 + i] = 0.25 * s
+        q[1 + j] = (R[j, i] + R[i, j]) / s
+        q[1 + k] = (R[k, i] + R[i, k]) / s
+    q = np.array(q)
+    return q / np.linalg.norm(q)
+
+
+def _small_rot(w):
+    th = np.linalg.norm(w)
+    if th < 1e-12:
+        return np.eye(3)
+    k = w / th
+    K = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    return np.eye(3) + math.sin(th) * K + (1 - math.cos(th)) * K @ K
+
+
+def ba_problem(n_kf=50, n_points=5000, n_obs=40000, width=1280, height=720, seq_id=0,
+               kf_stride=6, pose_noise=(0.01, 0.05), point_noise=0.05, pix_noise=1.0):
+    """Bundle-adjustment problem of SURVEY.md section 8(d) config 3 / 5.
+
+    Returns dict with ground-truth and perturbed poses (n_kf x 7: qw qx qy qz tx ty tz, world->camera),
+    points (n x 3), observations (pose, point, u, v, ur, inv_sigma2), `fixed` flags (first KF fixed)
+    and the camera dict.  Stereo observations throughout; octave drawn to give sigma^2 = 1.2^(2*level).
+    """
+    rng = np.random.Generator(np.random.PCG64([SEED_BASE + int(seq_id), 3]))
+    k = intrinsics(width, height)
+    seq = StereoSequence(width, height, seq_id, n_points=1)
+    Rs, ts = zip(*[seq.pose(i * kf_stride) for i in range(n_kf)])
+    depth_span = 0.05 * kf_stride * n_kf
+    cand = np.stack([rng.uniform(-20, 20, n_points * 6), rng.uniform(-5, 5, n_points * 6),
+                     rng.uniform(1.0, 41.0 + depth_span, n_points * 6)], axis=1)
+    vis = np.zeros((len(cand), n_kf), bool)
+    uvs = np.zeros((len(cand), n_kf, 3))
+    for i in range(n_kf):
+        pc = cand @ Rs[i].T + ts[i]
+        z = pc[:, 2]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            u = k["fx"] * pc[:, 0] / z + k["cx"]
+            v = k["fy"] * pc[:, 1] / z + k["cy"]
+        vis[:, i] = (z > 1.0) & (z < 40.0) & (u >= 20) & (u < width - 20) & (v >= 20) & (v < height - 20)
+        uvs[:, i, 0] = u; uvs[:, i, 1] = v; uvs[:, i, 2] = u - k["fxb"] / np.where(z > 0, z, 1)
+    good = np.nonzero(vis.sum(1) >= 3)[0]
+    if len(good) < n_points:
+        raise RuntimeError("not enough visible landmarks: %d" % len(good))
+    good = good[:n_points]
+    cap = max(3, int(math.ceil(n_obs / n_points)))
+    obs = []
+    for pi, ci in enumerate(good):
+        kfs = np.nonzero(vis[ci])[0]
+        if len(kfs) > cap:
+            kfs = np.sort(rng.choice(kfs, cap, replace=False))
+        for f in kfs:
+            obs.append((f, pi, ci))
+    obs = np.array(obs)
+    if len(obs) > n_obs:     # trim observations of the longest tracks but keep >= 3 per landmark
+        counts = np.bincount(obs[:, 1], minlength=n_points)
+        order = rng.permutation(len(obs))
+        keep = np.ones(len(obs), bool)
+        excess = len(obs) - n_obs
+        for j in order:
+            if excess == 0:
+                break
+            p = obs[j, 1]
+            if counts[p] > 3:
+                counts[p] -= 1; keep[j] = False; excess -= 1
+        obs = obs[keep]
+    obs = obs[np.lexsort((obs[:, 0], obs[:, 1]))]      # by landmark, then by keyframe
+    level = rng.integers(0, 8, len(obs))
+    sigma = 1.2 ** level
+    meas = uvs[obs[:, 2], obs[:, 0]] + rng.normal(0, pix_noise, (len(obs), 3)) * sigma[:, None]
+    poses_gt = np.array([np.concatenate([rot_to_quat(Rs[i]), ts[i]]) for i in range(n_kf)])
+    poses = poses_gt.copy()
+    for i in range(1, n_kf):
+        dR = _small_rot(rng.normal(0, pose_noise[0], 3))
+        R = dR @ Rs[i]
+        t = dR @ ts[i] + rng.normal(0, pose_noise[1], 3)
+        poses[i] = np.concatenate([rot_to_quat(R), t])
+    pts_gt = cand[good]
+    pts = pts_gt + rng.normal(0, point_noise, pts_gt.shape)
+    fixed = np.zeros(n_kf, np.uint8); fixed[0] = 1
+    return dict(poses_gt=poses_gt, poses=poses, points_gt=pts_gt, points=pts, fixed=fixed,
+                obs_pose=obs[:, 0].astype(np.int32), obs_point=obs[:, 1].astype(np.int32),
+                obs_uvr=meas.astype(np.float64), obs_inv_sigma2=(1.0 / sigma ** 2).astype(np.float64),
+                cam=dict(fx=k["fx"], fy=k["fy"], cx=k["cx"], cy=k["cy"], fxb=k["fxb"]))

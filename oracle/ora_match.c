@@ -1,0 +1,186 @@
+/*
+ * oracle/ora_match.c -- CPU restatement of descriptor matching.  TEST INFRASTRUCTURE ONLY (see ora.h).
+ * PARITY UNPINNED (see ora.h).  [UPSTREAM] OpenVSLAM match::compute_descriptor_distance_32,
+ * match::robust (brute force), match::stereo::compute; thresholds HAMMING_DIST_THR_LOW = 50,
+ * HAMMING_DIST_THR_HIGH = 100 (stereo accepts best < 75).  Parameters reach the path through
+ * src/Trackers/OpenVSLAMTrackerBase.cpp:188-201 (focal_x_baseline, depth_threshold, y margin).
+ */
+#include "ora.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <limits.h>
+
+int ora_hamming256(const uint8_t* a, const uint8_t* b)
+{
+    uint64_t x[4], y[4];
+    memcpy(x, a, 32); memcpy(y, b, 32);
+    return __builtin_popcountll(x[0] ^ y[0]) + __builtin_popcountll(x[1] ^ y[1]) +
+           __builtin_popcountll(x[2] ^ y[2]) + __builtin_popcountll(x[3] ^ y[3]);
+}
+
+void ora_match_bf_knn2(const uint8_t* q, int nq, const uint8_t* t, int nt,
+                       int32_t* best_idx, int32_t* best_dist, int32_t* second_dist)
+{
+    for (int i = 0; i < nq; ++i) {
+        int best = 256 + 1, second = 256 + 1, bi = -1;
+        for (int j = 0; j < nt; ++j) {
+            const int d = ora_hamming256(q + (size_t)i * 32, t + (size_t)j * 32);
+            if (d < best) { second = best; best = d; bi = j; }
+            else if (d < second) second = d;
+        }
+        best_idx[i] = bi; best_dist[i] = best; second_dist[i] = second;
+    }
+}
+
+int ora_match_bf(const uint8_t* q, int nq, const uint8_t* t, int nt, int max_dist, float ratio,
+                 int cross_check, int32_t* out_q, int32_t* out_t, int32_t* out_d)
+{
+    int32_t* bi = (int32_t*)malloc(sizeof(int32_t) * 3 * (size_t)(nq > 0 ? nq : 1));
+    int32_t* bd = bi + nq; int32_t* sd = bd + nq;
+    ora_match_bf_knn2(q, nq, t, nt, bi, bd, sd);
+    int32_t* rbi = NULL;
+    if (cross_check) {
+        rbi = (int32_t*)malloc(sizeof(int32_t) * 3 * (size_t)(nt > 0 ? nt : 1));
+        ora_match_bf_knn2(t, nt, q, nq, rbi, rbi + nt, rbi + 2 * nt);
+    }
+    int n = 0;
+    for (int i = 0; i < nq; ++i) {
+        if (bi[i] < 0) continue;
+        if (bd[i] > max_dist) continue;
+        if (ratio > 0.f && ratio * (float)sd[i] < (float)bd[i]) continue;
+        if (cross_check && rbi[bi[i]] != i) continue;
+        out_q[n] = i; out_t[n] = bi[i]; out_d[n] = bd[i]; ++n;
+    }
+    free(bi); free(rbi);
+    return n;
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * [UPSTREAM] match::stereo
+ */
+typedef struct { int corr; int idx; } corr_entry;
+static int corr_cmp(const void* a, const void* b) {
+    const corr_entry* x = (const corr_entry*)a; const corr_entry* y = (const corr_entry*)b;
+    if (x->corr != y->corr) return (x->corr > y->corr) - (x->corr < y->corr);
+    return (x->idx > y->idx) - (x->idx < y->idx);
+}
+static inline int iround_half_even(double v) { return (int)nearbyint(v); }
+
+static int subpixel_disparity(const uint8_t* img_l, const uint8_t* img_r, int w, int h,
+                              const ora_keypoint* kl, const ora_keypoint* kr, float scale, float inv_scale,
+                              float min_disp, float max_disp,
+                              float* best_x_right, float* best_disp, float* best_corr)
+{
+    enum { WIN = 5, SLIDE = 5 };
+    const float x_right = kr->x;
+    const int sxl = iround_half_even(kl->x * inv_scale);
+    const int syl = iround_half_even(kl->y * inv_scale);
+    const int sxr = iround_half_even(x_right * inv_scale);
+    (void)h;
+    const int ini_x = sxr - SLIDE - WIN;
+    const int end_x = sxr + SLIDE + WIN + 1;
+    if (ini_x < 0 || w <= end_x) return 0;
+
+    const int cl = img_l[(size_t)syl * w + sxl];
+    float corr[2 * SLIDE + 1];
+    int best_off = 0;
+    *best_corr = (float)UINT_MAX;
+    for (int off = -SLIDE; off <= SLIDE; ++off) {
+        const int cr = img_r[(size_t)syl * w + sxr + off];
+        int sum = 0;     /* L1 norm of (patch_l - centre_l) - (patch_r - centre_r): integer valued, exact in float */
+        for (int dy = -WIN; dy <= WIN; ++dy)
+            for (int dx = -WIN; dx <= WIN; ++dx) {
+                const int a = img_l[(size_t)(syl + dy) * w + sxl + dx] - cl;
+                const int b = img_r[(size_t)(syl + dy) * w + sxr + off + dx] - cr;
+                sum += abs(a - b);
+            }
+        const float c = (float)sum;
+        if (c < *best_corr) { *best_corr = c; best_off = off; }
+        corr[SLIDE + off] = c;
+    }
+    if (best_off == -SLIDE || best_off == SLIDE) return 0;
+    const float c1 = corr[SLIDE + best_off - 1], c2 = corr[SLIDE + best_off], c3 = corr[SLIDE + best_off + 1];
+    const float x_delta = (float)((c1 - c3) / (2.0 * (c1 + c3 - 2.0 * c2)));
+    if (x_delta < -1.0 || 1.0 < x_delta) return 0;   /* NaN (flat parabola) compares false -> kept, as upstream */
+    *best_x_right = scale * ((float)(sxr + best_off) + x_delta);
+    *best_disp = kl->x - *best_x_right;
+    if (*best_disp < min_disp || max_disp <= *best_disp) return 0;
+    if (*best_disp <= 0.0f) { *best_disp = 0.01f; *best_x_right = kl->x - *best_disp; }
+    return 1;
+}
+
+int ora_match_stereo(const uint8_t* const* pyr_l, const uint8_t* const* pyr_r,
+                     const int* lw, const int* lh, const ora_orb_params* p,
+                     const ora_keypoint* kl, const uint8_t* dl, int nl,
+                     const ora_keypoint* kr, const uint8_t* dr, int nr,
+                     float focal_x_baseline, float true_baseline,
+                     float* stereo_x_right, float* depths, int32_t* best_right_idx)
+{
+    float sf[ORA_MAX_LEVELS], isf[ORA_MAX_LEVELS];
+    ora_scale_factors(p, sf, isf);
+    const int rows = lh[0];
+    const float min_disp = 0.0f, max_disp = focal_x_baseline / true_baseline;
+    const unsigned hamm_thr = (100 + 50) / 2;
+
+    /* get_right_keypoint_indices_in_each_row(margin = 2.0) */
+    int* row_cnt = (int*)calloc(rows + 1, sizeof(int));
+    for (int pass = 0; pass < 1; ++pass)
+        for (int i = 0; i < nr; ++i) {
+            const float r = 2.0f * sf[kr[i].octave];
+            const int max_r = (int)ceilf(kr[i].y + r), min_r = (int)floorf(kr[i].y - r);
+            for (int y = min_r; y <= max_r; ++y) if (y >= 0 && y < rows) row_cnt[y]++;
+        }
+    int* row_ofs = (int*)malloc(sizeof(int) * (rows + 1));
+    int tot = 0;
+    for (int y = 0; y < rows; ++y) { row_ofs[y] = tot; tot += row_cnt[y]; }
+    row_ofs[rows] = tot;
+    int* row_idx = (int*)malloc(sizeof(int) * (tot > 0 ? tot : 1));
+    memset(row_cnt, 0, sizeof(int) * rows);
+    for (int i = 0; i < nr; ++i) {
+        const float r = 2.0f * sf[kr[i].octave];
+        const int max_r = (int)ceilf(kr[i].y + r), min_r = (int)floorf(kr[i].y - r);
+        for (int y = min_r; y <= max_r; ++y) if (y >= 0 && y < rows) row_idx[row_ofs[y] + row_cnt[y]++] = i;
+    }
+
+    corr_entry* corr = (corr_entry*)malloc(sizeof(corr_entry) * (nl > 0 ? nl : 1));
+    int ncorr = 0;
+    for (int i = 0; i < nl; ++i) {
+        stereo_x_right[i] = -1.0f; depths[i] = -1.0f;
+        if (best_right_idx) best_right_idx[i] = -1;
+        const int lvl = kl[i].octave;
+        const float yl = kl[i].y, xl = kl[i].x;
+        const int row = (int)yl;                 /* indices_right_in_row.at(y_left): float -> index truncation */
+        if (row < 0 || row >= rows) continue;
+        if (row_cnt[row] == 0) continue;
+        const float min_xr = xl - max_disp, max_xr = xl - min_disp;
+        if (max_xr < 0) continue;
+        unsigned best_j = 0, best_d = hamm_thr;
+        for (int c = 0; c < row_cnt[row]; ++c) {
+            const int j = row_idx[row_ofs[row] + c];
+            if (kr[j].octave < lvl - 1 || kr[j].octave > lvl + 1) continue;
+            const float xr = kr[j].x;
+            if (xr < min_xr || max_xr < xr) continue;
+            const unsigned d = (unsigned)ora_hamming256(dl + (size_t)i * 32, dr + (size_t)j * 32);
+            if (d < best_d) { best_j = j; best_d = d; }
+        }
+        if (hamm_thr <= best_d) continue;
+        if (best_right_idx) best_right_idx[i] = (int32_t)best_j;
+        float bx = -1.0f, bd = -1.0f, bc = 0.f;
+        if (!subpixel_disparity(pyr_l[lvl], pyr_r[lvl], lw[lvl], lh[lvl], &kl[i], &kr[best_j],
+                                sf[lvl], isf[lvl], min_disp, max_disp, &bx, &bd, &bc)) continue;
+        stereo_x_right[i] = bx;
+        depths[i] = focal_x_baseline / bd;
+        corr[ncorr].corr = (int)bc; corr[ncorr].idx = i; ++ncorr;
+    }
+    /* reject correlations weaker than 2 x median */
+    qsort(corr, ncorr, sizeof(corr_entry), corr_cmp);
+    const int median_i = ncorr / 2;
+    const float median = ncorr == 0 ? 0.0f : (float)corr[median_i].corr;
+    const float thr = (float)(2.0 * median);
+    int valid = ncorr;
+    for (int k = median_i; k < ncorr; ++k)
+        if (thr < (float)corr[k].corr) { stereo_x_right[corr[k].idx] = -1; depths[corr[k].idx] = -1; --valid; }
+    free(corr); free(row_cnt); free(row_ofs); free(row_idx);
+    return valid;
+}

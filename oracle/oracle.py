@@ -1,0 +1,241 @@
+"""ctypes binding of the CPU oracle (oracle/liblpslam_oracle.so).  TEST INFRASTRUCTURE ONLY.
+
+Importable from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg only; the product
+package lpslam_amd never imports this module.  PARITY UNPINNED: see oracle/ora.h.
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "liblpslam_oracle.so")
+MAX_LEVELS = 16
+
+
+def build(force=False):
+    srcs = [os.path.join(_HERE, f) for f in ("ora_orb.c", "ora_match.c", "ora_ba.c", "ora.h", "orb_pattern.inc")]
+    if force or not os.path.exists(_LIB) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in srcs if os.path.exists(s)):
+        subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s"], stdout=subprocess.DEVNULL)
+    return _LIB
+
+
+class Keypoint(C.Structure):
+    _fields_ = [("x", C.c_float), ("y", C.c_float), ("size", C.c_float), ("angle", C.c_float),
+                ("response", C.c_float), ("octave", C.c_int32), ("class_id", C.c_int32)]
+
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                     ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+CORNER_DTYPE = np.dtype([("x", "<i4"), ("y", "<i4"), ("score", "<i4")])
+OBS_DTYPE = np.dtype([("pose", "<i4"), ("point", "<i4"), ("u", "<f8"), ("v", "<f8"), ("ur", "<f8"),
+                      ("inv_sigma2", "<f8")])
+LOG_DTYPE = np.dtype([("chi2_before", "<f8"), ("chi2_after", "<f8"), ("lambda", "<f8"),
+                      ("trials", "<i4"), ("status", "<i4")])
+
+
+class OrbParams(C.Structure):
+    _fields_ = [("max_num_keypts", C.c_int32), ("scale_factor", C.c_float), ("num_levels", C.c_int32),
+                ("ini_fast_thr", C.c_int32), ("min_fast_thr", C.c_int32)]
+
+
+class BaCam(C.Structure):
+    _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
+                ("fxb", C.c_double), ("huber_mono", C.c_double), ("huber_stereo", C.c_double)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB)
+        _lib.ora_fast_atan2.restype = C.c_float
+        _lib.ora_fast_atan2.argtypes = [C.c_float, C.c_float]
+        _lib.ora_ic_angle.restype = C.c_float
+    return _lib
+
+
+def _p(a, t=C.c_void_p):
+    return a.ctypes.data_as(t) if a is not None else None
+
+
+def params(max_kpts=2000, scale=1.2, levels=8, ini=20, mn=7):
+    return OrbParams(int(max_kpts), float(scale), int(levels), int(ini), int(mn))
+
+
+def pyramid_sizes(w, h, p):
+    lw = (C.c_int * MAX_LEVELS)(); lh = (C.c_int * MAX_LEVELS)()
+    lib().ora_pyramid_sizes(w, h, C.byref(p), lw, lh)
+    return list(lw[:p.num_levels]), list(lh[:p.num_levels])
+
+
+def scale_factors(p):
+    s = (C.c_float * MAX_LEVELS)(); i = (C.c_float * MAX_LEVELS)()
+    lib().ora_scale_factors(C.byref(p), s, i)
+    return np.array(s[:p.num_levels], np.float32), np.array(i[:p.num_levels], np.float32)
+
+
+def keypts_per_level(p):
+    q = (C.c_int * MAX_LEVELS)()
+    lib().ora_keypts_per_level(C.byref(p), q)
+    return list(q[:p.num_levels])
+
+
+def resize(src, dw, dh):
+    src = np.ascontiguousarray(src, np.uint8)
+    dst = np.empty((dh, dw), np.uint8)
+    lib().ora_resize_linear_u8(_p(src), src.shape[1], src.shape[0], src.shape[1], _p(dst), dw, dh, dw)
+    return dst
+
+
+def fast_level(img, ini=20, mn=7):
+    img = np.ascontiguousarray(img, np.uint8)
+    cap = img.size // 4 + 16
+    out = np.zeros(cap, CORNER_DTYPE)
+    n = lib().ora_fast_level(_p(img), img.shape[1], img.shape[0], img.shape[1], ini, mn, _p(out), cap)
+    return out[:n].copy()
+
+
+def fast(img, thr, nms=True):
+    img = np.ascontiguousarray(img, np.uint8)
+    cap = img.size + 16
+    out = np.zeros(cap, CORNER_DTYPE)
+    n = lib().ora_fast9_16(_p(img), img.shape[1], img.shape[0], img.shape[1], thr, int(nms), _p(out), cap)
+    return out[:n].copy()
+
+
+def distribute(cand, w, h, quota):
+    cand = np.ascontiguousarray(cand, CORNER_DTYPE)
+    out = np.zeros(len(cand) + 8, np.int32)
+    n = lib().ora_distribute(_p(cand), len(cand), 19, w - 19, 19, h - 19, quota, _p(out), len(out))
+    return out[:n].copy()
+
+
+def gauss7(img):
+    img = np.ascontiguousarray(img, np.uint8)
+    out = np.empty_like(img)
+    lib().ora_gauss7x7_u8(_p(img), img.shape[1], img.shape[0], img.shape[1], _p(out), img.shape[1])
+    return out
+
+
+def ic_angle(img, x, y):
+    img = np.ascontiguousarray(img, np.uint8)
+    f = lib().ora_ic_angle
+    f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+    return f(_p(img), img.shape[1], int(x), int(y))
+
+
+def sincos_deg(a):
+    s = C.c_float(); c = C.c_float()
+    f = lib().ora_sincos_deg
+    f.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    f(float(a), C.byref(s), C.byref(c))
+    return s.value, c.value
+
+
+def extract(img, p, want_pyramid=False):
+    """Returns (keypoints[KP_DTYPE], descriptors[n,32], cand_count[levels], pyramid levels or None)."""
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    cap = p.max_num_keypts + 4 * p.num_levels + 64
+    kp = np.zeros(cap, KP_DTYPE); desc = np.zeros((cap, 32), np.uint8)
+    cc = np.zeros(p.num_levels, np.int32)
+    lw, lh = pyramid_sizes(w, h, p)
+    pyr = np.zeros(sum(a * b for a, b in zip(lw, lh)), np.uint8) if want_pyramid else None
+    n = lib().ora_orb_extract(_p(img), w, h, w, C.byref(p), _p(kp), _p(desc), cap, _p(pyr), _p(cc))
+    assert n <= cap
+    levels = None
+    if want_pyramid:
+        levels, off = [], 0
+        for a, b in zip(lw, lh):
+            levels.append(pyr[off:off + a * b].reshape(b, a)); off += a * b
+    return kp[:n].copy(), desc[:n].copy(), cc, levels
+
+
+def match_bf_knn2(q, t):
+    q = np.ascontiguousarray(q, np.uint8); t = np.ascontiguousarray(t, np.uint8)
+    bi = np.zeros(len(q), np.int32); bd = np.zeros(len(q), np.int32); sd = np.zeros(len(q), np.int32)
+    lib().ora_match_bf_knn2(_p(q), len(q), _p(t), len(t), _p(bi), _p(bd), _p(sd))
+    return bi, bd, sd
+
+
+def match_bf(q, t, max_dist=50, ratio=0.0, cross_check=False):
+    q = np.ascontiguousarray(q, np.uint8); t = np.ascontiguousarray(t, np.uint8)
+    oq = np.zeros(len(q), np.int32); ot = np.zeros(len(q), np.int32); od = np.zeros(len(q), np.int32)
+    f = lib().ora_match_bf
+    f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int,
+                  C.c_void_p, C.c_void_p, C.c_void_p]
+    n = f(_p(q), len(q), _p(t), len(t), int(max_dist), float(ratio), int(cross_check), _p(oq), _p(ot), _p(od))
+    return oq[:n].copy(), ot[:n].copy(), od[:n].copy()
+
+
+def match_stereo(pyr_l, pyr_r, p, kl, dl, kr, dr, fxb, baseline):
+    L = p.num_levels
+    keep = [np.ascontiguousarray(a, np.uint8) for a in list(pyr_l) + list(pyr_r)]
+    pl = (C.c_void_p * L)(*[a.ctypes.data for a in keep[:L]])
+    pr = (C.c_void_p * L)(*[a.ctypes.data for a in keep[L:]])
+    lw = (C.c_int * L)(*[a.shape[1] for a in keep[:L]]); lh = (C.c_int * L)(*[a.shape[0] for a in keep[:L]])
+    kl = np.ascontiguousarray(kl, KP_DTYPE); kr = np.ascontiguousarray(kr, KP_DTYPE)
+    dl = np.ascontiguousarray(dl, np.uint8); dr = np.ascontiguousarray(dr, np.uint8)
+    xr = np.zeros(len(kl), np.float32); dep = np.zeros(len(kl), np.float32); bi = np.zeros(len(kl), np.int32)
+    f = lib().ora_match_stereo
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                  C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
+    n = f(pl, pr, lw, lh, C.byref(p), _p(kl), _p(dl), len(kl), _p(kr), _p(dr), len(kr),
+          float(fxb), float(baseline), _p(xr), _p(dep), _p(bi))
+    return xr, dep, bi, n
+
+
+def ba_cam(cam, robust=True):
+    return BaCam(cam["fx"], cam["fy"], cam["cx"], cam["cy"], cam["fxb"],
+                 np.sqrt(5.991) if robust else 0.0, np.sqrt(7.815) if robust else 0.0)
+
+
+def ba_obs(prob):
+    o = np.zeros(len(prob["obs_pose"]), OBS_DTYPE)
+    o["pose"] = prob["obs_pose"]; o["point"] = prob["obs_point"]
+    o["u"] = prob["obs_uvr"][:, 0]; o["v"] = prob["obs_uvr"][:, 1]; o["ur"] = prob["obs_uvr"][:, 2]
+    o["inv_sigma2"] = prob["obs_inv_sigma2"]
+    return o
+
+
+def ba_optimize(poses, fixed, points, obs, cam, robust=True, iters=10, active=None):
+    poses = np.ascontiguousarray(poses, np.float64).copy(); points = np.ascontiguousarray(points, np.float64).copy()
+    fixed = np.ascontiguousarray(fixed, np.uint8); obs = np.ascontiguousarray(obs, OBS_DTYPE)
+    log = np.zeros(iters, LOG_DTYPE)
+    c = ba_cam(cam)
+    act = np.ascontiguousarray(active, np.uint8) if active is not None else None
+    n = lib().ora_ba_optimize(_p(poses), _p(fixed), len(poses), _p(points), len(points), _p(obs), _p(act),
+                              len(obs), C.byref(c), int(robust), int(iters), _p(log))
+    return poses, points, log[:n].copy()
+
+
+def ba_local(poses, fixed, points, obs, cam, first=5, second=10):
+    poses = np.ascontiguousarray(poses, np.float64).copy(); points = np.ascontiguousarray(points, np.float64).copy()
+    fixed = np.ascontiguousarray(fixed, np.uint8); obs = np.ascontiguousarray(obs, OBS_DTYPE)
+    out = np.zeros(len(obs), np.uint8)
+    c = ba_cam(cam)
+    lib().ora_ba_local(_p(poses), _p(fixed), len(poses), _p(points), len(points), _p(obs), len(obs),
+                       C.byref(c), int(first), int(second), _p(out))
+    return poses, points, out
+
+
+def ba_chi2(poses, points, obs, cam):
+    poses = np.ascontiguousarray(poses, np.float64); points = np.ascontiguousarray(points, np.float64)
+    obs = np.ascontiguousarray(obs, OBS_DTYPE)
+    chi = np.zeros(len(obs)); pos = np.zeros(len(obs), np.uint8)
+    c = ba_cam(cam)
+    lib().ora_ba_chi2(_p(poses), _p(points), _p(obs), len(obs), C.byref(c), _p(chi), _p(pos))
+    return chi, pos
+
+
+def pose_optimize(pose7, points, obs, cam):
+    pose = np.ascontiguousarray(pose7, np.float64).copy(); points = np.ascontiguousarray(points, np.float64)
+    obs = np.ascontiguousarray(obs, OBS_DTYPE)
+    out = np.zeros(len(obs), np.uint8)
+    c = ba_cam(cam)
+    n = lib().ora_pose_optimize(_p(pose), _p(points), _p(obs), len(obs), C.byref(c), _p(out))
+    return pose, out, n
