@@ -1,0 +1,178 @@
+/*
+ * lpslam_hip.h -- C ABI of the MI355X (gfx950) hot path of lpslam: ORB extraction, descriptor matching and
+ * SE3 bundle adjustment.  This is the "thin HIP C-ABI layer" beneath the C++ host mirror of the reference's
+ * Interface / Tracker plugin surface (lpslam_amd/host/).  Plain pointers and sizes only; every entry point
+ * returns an int status (0 = LPSLAM_HIP_OK) and never throws; lpslam_hip_last_error() gives the message.
+ *
+ * What each group replaces in the reference (paths relative to /root/reference):
+ *   context / frames    openvslam::system construction + feed_stereo_frame / feed_monocular_frame
+ *                       (src/Trackers/OpenVSLAMTrackerBase.cpp:238-239,
+ *                        src/Trackers/OpenVSLAMStereoTracker.cpp:293-295, src/Trackers/OpenVSLAMTracker.cpp:120)
+ *   front-end config    the Feature.* block of the generated tracker YAML
+ *                       (src/Trackers/OpenVSLAMTrackerBase.cpp:193-198) and Camera.* (:161-190)
+ *   keypoint readback   get_frame_state().curr_keypts (src/Trackers/OpenVSLAMStereoTracker.cpp:302-317)
+ *   stereo matching     depth_threshold / focal_x_baseline parameters (src/Trackers/OpenVSLAMTrackerBase.cpp:188-201,
+ *                       src/Interface/LpSlamTypes.h:219-222)
+ *   bundle adjustment   the mapping / global-optimisation threads started by startup()
+ *                       (src/Trackers/OpenVSLAMTrackerBase.cpp:239,250-255)
+ * The arithmetic itself lives in absent third-party code (OpenVSLAM fork, g2o@691dc51, OpenCV); see DESIGN.md.
+ */
+#ifndef LPSLAM_HIP_H
+#define LPSLAM_HIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LPSLAM_HIP_OK 0
+#define LPSLAM_HIP_ERR_INVALID 1      /* bad argument / unsupported configuration */
+#define LPSLAM_HIP_ERR_DEVICE 2       /* HIP runtime error (no device, allocation, launch) */
+#define LPSLAM_HIP_ERR_CAPACITY 3     /* caller buffer too small / batch exceeds context capacity */
+
+#define LPSLAM_HIP_MAX_LEVELS 16
+
+/* Memory layout of cv::KeyPoint (what get_frame_state().curr_keypts holds). */
+typedef struct lpslam_hip_keypoint {
+    float x, y;        /* level-0 pixel coordinates                          */
+    float size;        /* 31 * scale_factor^octave, truncated                */
+    float angle;       /* degrees [0,360)                                    */
+    float response;    /* FAST score                                         */
+    int32_t octave;
+    int32_t class_id;  /* -1                                                 */
+} lpslam_hip_keypoint;
+
+/* FAST candidate in border-relative coordinates of its pyramid level (parity/debug readback). */
+typedef struct lpslam_hip_corner {
+    int32_t x, y, score;
+} lpslam_hip_corner;
+
+typedef struct lpslam_hip_frontend_config {
+    int32_t width, height;        /* Camera.cols / Camera.rows                               */
+    int32_t max_keypoints;        /* Feature.max_num_keypoints  (slamKeypoints)              */
+    float   scale_factor;         /* Feature.scale_factor       (1.2)                        */
+    int32_t num_levels;           /* Feature.num_levels         (3 generated, 8 in BASELINE) */
+    int32_t ini_fast_threshold;   /* Feature.ini_fast_threshold (20)                         */
+    int32_t min_fast_threshold;   /* Feature.min_fast_threshold (7)                          */
+    int32_t max_images;           /* images resident per batch (a stereo frame is 2 images)  */
+    int32_t device;               /* HIP device ordinal                                      */
+} lpslam_hip_frontend_config;
+
+typedef struct lpslam_hip_ctx lpslam_hip_ctx;
+
+const char* lpslam_hip_last_error(void);
+int lpslam_hip_device_count(int* count);
+
+/* ---- context ------------------------------------------------------------------------------------------- */
+int lpslam_hip_create(const lpslam_hip_frontend_config* cfg, lpslam_hip_ctx** out);
+void lpslam_hip_destroy(lpslam_hip_ctx* ctx);
+/* hipStream_t all work of this context is enqueued on (for event timing / interop). */
+void* lpslam_hip_stream(lpslam_hip_ctx* ctx);
+int lpslam_hip_sync(lpslam_hip_ctx* ctx);
+/* Geometry derived from the configuration (pyramid sizes, per-level keypoint quota). */
+int lpslam_hip_level_info(lpslam_hip_ctx* ctx, int32_t* widths, int32_t* heights, int32_t* pitches,
+                          int32_t* quotas, float* scale_factors);
+/* Upper bound of keypoints one image can yield (sum of quota+3 over levels). */
+int lpslam_hip_max_keypoints_per_image(lpslam_hip_ctx* ctx);
+
+/* ---- frames: images resident in HBM --------------------------------------------------------------------- */
+/* Device address and row pitch of level 0 of image slot `image` (write frames there directly, e.g. from a
+ * capture DMA or another kernel), or upload from host memory (tightly packed rows of `stride` bytes). */
+int lpslam_hip_image_ptr(lpslam_hip_ctx* ctx, int image, void** dev_ptr, int32_t* pitch);
+int lpslam_hip_upload_image(lpslam_hip_ctx* ctx, int image, const uint8_t* host, int32_t stride);
+
+/* ---- ORB front end (asynchronous on the context stream) -------------------------------------------------- */
+/* pyramid -> FAST (64-px cells, ini/min threshold) -> quad-tree distribution -> orientation + rBRIEF,
+ * for image slots [0, n_images). */
+int lpslam_hip_extract(lpslam_hip_ctx* ctx, int n_images);
+/* Individual stages (lpslam_hip_extract = these four in order); exposed for profiling and parity tests. */
+int lpslam_hip_stage_pyramid(lpslam_hip_ctx* ctx, int n_images);
+int lpslam_hip_stage_fast(lpslam_hip_ctx* ctx, int n_images);
+int lpslam_hip_stage_distribute(lpslam_hip_ctx* ctx, int n_images);
+int lpslam_hip_stage_describe(lpslam_hip_ctx* ctx, int n_images);
+
+/* Synchronising readbacks (device -> caller memory). */
+int lpslam_hip_keypoint_count(lpslam_hip_ctx* ctx, int image, int32_t* count);
+int lpslam_hip_get_keypoints(lpslam_hip_ctx* ctx, int image, lpslam_hip_keypoint* kpts, uint8_t* desc32,
+                             int32_t capacity, int32_t* count);
+int lpslam_hip_get_pyramid_level(lpslam_hip_ctx* ctx, int image, int level, uint8_t* out, int32_t out_stride);
+int lpslam_hip_get_candidates(lpslam_hip_ctx* ctx, int image, int level, lpslam_hip_corner* out,
+                              int32_t capacity, int32_t* count);
+/* Device-resident results (valid until the next extract on this context): keypoints [max_per_image],
+ * descriptors [max_per_image][32], count (int32). */
+int lpslam_hip_keypoint_buffers(lpslam_hip_ctx* ctx, int image, void** kpts_dev, void** desc_dev, void** count_dev);
+
+/* ---- matching -------------------------------------------------------------------------------------------- */
+/* Brute-force Hamming 2-NN of the descriptors of image slot `query` against those of slot `train`
+ * (first minimum wins).  Results stay on the device until fetched. */
+int lpslam_hip_match_bf(lpslam_hip_ctx* ctx, int query, int train);
+int lpslam_hip_get_bf_knn2(lpslam_hip_ctx* ctx, int query, int32_t* best_idx, int32_t* best_dist,
+                           int32_t* second_dist, int32_t capacity, int32_t* count);
+/* knn2 + max distance + Lowe ratio (<= 0 disables) + optional cross check -> (query, train, distance). */
+int lpslam_hip_get_bf_matches(lpslam_hip_ctx* ctx, int query, int train, int32_t max_dist, float ratio,
+                              int32_t cross_check, int32_t* out_q, int32_t* out_t, int32_t* out_d,
+                              int32_t capacity, int32_t* count);
+/* Batched form: pairs (query0 + i*stride, train0 + i*stride), i in [0, n_pairs), in one launch. */
+int lpslam_hip_match_bf_strided(lpslam_hip_ctx* ctx, int query0, int train0, int stride, int n_pairs);
+/* Loads a caller-provided descriptor set (host memory, n x 32 bytes) into image slot `image`, replacing the
+ * slot's extraction result: matching of descriptors that were produced elsewhere (map points, other frames). */
+int lpslam_hip_set_descriptors(lpslam_hip_ctx* ctx, int image, const uint8_t* desc32, int32_t n);
+
+/* Stereo: left slot vs right slot; row-band candidates, Hamming < 75, 11x11 SAD sub-pixel refinement,
+ * 2 x median correlation cut.  focal_x_baseline as in LpSlamCameraConfiguration. */
+int lpslam_hip_match_stereo(lpslam_hip_ctx* ctx, int left, int right, float focal_x_baseline, float true_baseline);
+int lpslam_hip_match_stereo_strided(lpslam_hip_ctx* ctx, int left0, int right0, int stride, int n_pairs,
+                                    float focal_x_baseline, float true_baseline);
+int lpslam_hip_get_stereo(lpslam_hip_ctx* ctx, int left, float* stereo_x_right, float* depths,
+                          int32_t* best_right_idx, int32_t capacity, int32_t* count);
+
+/* ---- bundle adjustment (FP64) ------------------------------------------------------------------------------ */
+typedef struct lpslam_hip_ba_obs {
+    int32_t pose, point;
+    double u, v, ur;          /* ur < 0: monocular edge (2 rows); else stereo (3 rows) */
+    double inv_sigma2;        /* information = inv_sigma2 * I (1 / 1.2^(2*octave))      */
+} lpslam_hip_ba_obs;
+
+typedef struct lpslam_hip_ba_camera {
+    double fx, fy, cx, cy, focal_x_baseline;
+    double huber_mono, huber_stereo;   /* sqrt(5.991) / sqrt(7.815); <= 0: no robust kernel */
+} lpslam_hip_ba_camera;
+
+typedef struct lpslam_hip_ba_iter_log {
+    double chi2_before, chi2_after, lambda;
+    int32_t trials, status;            /* status 0 = OK, 1 = terminate */
+} lpslam_hip_ba_iter_log;
+
+typedef struct lpslam_hip_ba lpslam_hip_ba;
+
+/* Builds the device-side problem (structure phase = g2o buildStructure): poses n x 7 (qw qx qy qz tx ty tz,
+ * world->camera), fixed flags, points n x 3, observations.  Copies everything to HBM. */
+int lpslam_hip_ba_create(lpslam_hip_ctx* ctx, const double* poses, const uint8_t* fixed, int32_t n_poses,
+                         const double* points, int32_t n_points, const lpslam_hip_ba_obs* obs, int32_t n_obs,
+                         const lpslam_hip_ba_camera* cam, lpslam_hip_ba** out);
+void lpslam_hip_ba_destroy(lpslam_hip_ba* ba);
+/* Observation activity mask (0 = level 1 / ignored); NULL = all active. */
+int lpslam_hip_ba_set_active(lpslam_hip_ba* ba, const uint8_t* active);
+/* Levenberg-Marquardt with landmark Schur complement, `iters` outer iterations (g2o semantics: lambda_0 =
+ * 1e-5 max diag H, rho-controlled lambda, <= 10 trials).  log may be NULL.  Returns iterations run in *done. */
+int lpslam_hip_ba_optimize(lpslam_hip_ba* ba, int32_t robust, int32_t iters, lpslam_hip_ba_iter_log* log,
+                           int32_t* done);
+/* local_bundle_adjuster flow: first_iters robust, outlier classification, second_iters plain. */
+int lpslam_hip_ba_local(lpslam_hip_ba* ba, int32_t first_iters, int32_t second_iters, uint8_t* outlier);
+int lpslam_hip_ba_get(lpslam_hip_ba* ba, double* poses, double* points);
+int lpslam_hip_ba_chi2(lpslam_hip_ba* ba, double* chi2, uint8_t* depth_positive);
+
+/* Partitioned (multi-GPU) global BA: each rank holds a landmark partition and all poses.
+ * begin -> caller all-reduces (sum) the buffer returned by reduced_buffer() -> end.  One LM trial each. */
+int lpslam_hip_ba_reduced_buffer(lpslam_hip_ba* ba, void** dev_ptr, int64_t* n_doubles);
+int lpslam_hip_ba_step_begin(lpslam_hip_ba* ba, int32_t robust, int32_t first);
+int lpslam_hip_ba_step_solve(lpslam_hip_ba* ba);
+int lpslam_hip_ba_scalar_buffer(lpslam_hip_ba* ba, void** dev_ptr, int64_t* n_doubles);
+int lpslam_hip_ba_step_end(lpslam_hip_ba* ba, int32_t* accepted, int32_t* iteration_finished);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LPSLAM_HIP_H */

@@ -1,0 +1,30 @@
+"""Builds the HIP/C-ABI shared library in-tree for gfx950 (no JIT cache: the .so travels with the repo snapshot)."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "liblpslam_hip.so")
+HIP_SOURCES = ["api.hip", "frontend.hip", "match.hip", "ba.hip"]
+DEPS = ["internal.h", "orb_pattern.inc", os.path.join("..", "..", "include", "lpslam_hip.h")]
+# -ffp-contract=off: parity with the CPU definition forbids FMA contraction ("Numerics").
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+         "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
+
+
+def hip_library(force=False, verbose=False):
+    srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    deps = srcs + [os.path.join(CSRC, d) for d in DEPS]
+    if not force and os.path.exists(LIB) and all(os.path.getmtime(d) <= os.path.getmtime(LIB) for d in deps if os.path.exists(d)):
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc] + FLAGS + ["-o", LIB] + srcs
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(hip_library(force="-f" in sys.argv, verbose=True))

@@ -1,0 +1,369 @@
+// api.hip -- C ABI of the lpslam HIP library: context life cycle, geometry tables, frame upload, stage launches and
+// readbacks.  Declarations and the reference interfaces they replace: include/lpslam_hip.h.
+#include "internal.h"
+#include <cmath>
+#include <cstdarg>
+#include <algorithm>
+
+namespace lpslam {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int hip_fail(hipError_t e, const char* what)
+{
+    set_error("HIP error %d (%s) in %s", (int)e, hipGetErrorString(e), what);
+    return LPSLAM_HIP_ERR_DEVICE;
+}
+
+static inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
+
+// cv::resize INTER_LINEAR coefficient table for one axis: offset and two 11-bit weights per destination index
+// ([UPSTREAM] resizeGeneric_: fx = (float)((d + 0.5) * scale - 0.5); weights = cvRound(w * 2048)).
+static void resize_axis(int ssize, int dsize, std::vector<int16_t>& ofs, std::vector<int16_t>& coef)
+{
+    const double scale = 1.0 / ((double)dsize / ssize);
+    for (int d = 0; d < dsize; ++d) {
+        float f = (float)((d + 0.5) * scale - 0.5);
+        int s = (int)std::floor(f);
+        f -= (float)s;
+        if (s < 0) { f = 0.f; s = 0; }
+        if (s >= ssize - 1) { f = 0.f; s = ssize - 1; }
+        ofs.push_back((int16_t)s);
+        coef.push_back((int16_t)std::nearbyint((1.f - f) * 2048.f));
+        coef.push_back((int16_t)std::nearbyint(f * 2048.f));
+    }
+}
+
+// Geometry of the path: pyramid sizes, FAST cell grid, per-level quota, quad-tree roots.
+static int build_level_table(const lpslam_hip_frontend_config& cfg, LevelTable& lt, size_t& image_slab,
+                             std::vector<int16_t>& ofs, std::vector<int16_t>& coef)
+{
+    const int L = cfg.num_levels;
+    lt.n_levels = L;
+    lt.scale[0] = 1.0f;
+    for (int l = 1; l < L; ++l) lt.scale[l] = cfg.scale_factor * lt.scale[l - 1];
+    for (int l = 0; l < L; ++l) lt.inv_scale[l] = 1.0f / lt.scale[l];
+    unsigned off = 0;
+    lt.cell_start[0] = 0; lt.slot_start[0] = 0; lt.cand_start[0] = 0;
+    // quota per level: geometric share, remainder on the last level
+    {
+        const double f = 1.0 / (double)cfg.scale_factor;
+        double desired = cfg.max_keypoints * (1.0 - f) / (1.0 - std::pow(f, (double)L));
+        int total = 0;
+        for (int l = 0; l < L - 1; ++l) { lt.quota[l] = (int)std::round(desired); total += lt.quota[l]; desired *= f; }
+        lt.quota[L - 1] = std::max(cfg.max_keypoints - total, 0);
+    }
+    for (int l = 0; l < L; ++l) {
+        if (l == 0) { lt.w[0] = cfg.width; lt.h[0] = cfg.height; }
+        else {
+            const double s = lt.scale[l];
+            lt.w[l] = (int)std::round(cfg.width * 1.0 / s);
+            lt.h[l] = (int)std::round(cfg.height * 1.0 / s);
+        }
+        if (lt.w[l] <= 2 * kEdge + 7 || lt.h[l] <= 2 * kEdge + 7) {
+            set_error("level %d (%dx%d) is too small for the 19-px border; reduce num_levels", l, lt.w[l], lt.h[l]);
+            return LPSLAM_HIP_ERR_INVALID;
+        }
+        lt.pitch[l] = align_up(lt.w[l], 64);
+        lt.off[l] = off;
+        off += (unsigned)lt.pitch[l] * (unsigned)align_up(lt.h[l], 4);
+        // FAST cells: rows/cols whose start lies more than `overlap` px before the far border
+        const int max_bx = lt.w[l] - kEdge, max_by = lt.h[l] - kEdge;
+        const int ncols = (max_bx - kEdge) / kCell + 1, nrows = (max_by - kEdge) / kCell + 1;
+        int cx = 0, cy = 0;
+        for (int j = 0; j < ncols; ++j) if (!(max_bx - kOverlap <= kEdge + j * kCell)) cx = j + 1;
+        for (int i = 0; i < nrows; ++i) if (!(max_by - kOverlap <= kEdge + i * kCell)) cy = i + 1;
+        lt.cells_x[l] = cx; lt.cells_y[l] = cy;
+        lt.cell_start[l + 1] = lt.cell_start[l] + cx * cy;
+        lt.cand_start[l + 1] = lt.cand_start[l] + cx * cy * kCellSlots;
+        // quad-tree roots
+        const int width = max_bx - kEdge, height = max_by - kEdge;
+        const double ratio = (double)width / (double)height;
+        if (ratio > 1) { lt.nxg[l] = (int)std::round(ratio); lt.nyg[l] = 1; lt.delta_x[l] = (double)width / lt.nxg[l]; lt.delta_y[l] = height; }
+        else { lt.nxg[l] = 1; lt.nyg[l] = (int)std::round(1 / ratio); lt.delta_x[l] = width; lt.delta_y[l] = (double)height / lt.nyg[l]; }
+        const int roots = lt.nxg[l] * lt.nyg[l];
+        lt.qcap[l] = std::max(lt.quota[l], 4 * roots) + 4;
+        lt.slot_start[l + 1] = lt.slot_start[l] + std::max(lt.quota[l] + 3, 4 * roots);
+        if (lt.quota[l] > kQuotaMax || lt.qcap[l] >= 2048) {
+            set_error("per-level keypoint quota %d exceeds the supported %d", lt.quota[l], kQuotaMax);
+            return LPSLAM_HIP_ERR_INVALID;
+        }
+        if (cx * cy * kCellSlots >= (1 << 21) || lt.w[l] >= 4096 + 2 * kEdge || lt.h[l] >= 4096 + 2 * kEdge) {
+            set_error("level %d (%dx%d) exceeds the supported image size", l, lt.w[l], lt.h[l]);
+            return LPSLAM_HIP_ERR_INVALID;
+        }
+        if (l >= 1) {
+            lt.xtab_start[l] = (int)ofs.size();
+            resize_axis(lt.w[l - 1], lt.w[l], ofs, coef);
+            lt.ytab_start[l] = (int)ofs.size();
+            resize_axis(lt.h[l - 1], lt.h[l], ofs, coef);
+        } else { lt.xtab_start[0] = lt.ytab_start[0] = 0; }
+    }
+    image_slab = (size_t)align_up((int)off, 256);
+    return LPSLAM_HIP_OK;
+}
+
+}  // namespace lpslam
+
+using namespace lpslam;
+
+extern "C" {
+
+const char* lpslam_hip_last_error(void) { return g_err; }
+
+int lpslam_hip_device_count(int* count)
+{
+    if (!count) { set_error("null argument"); return LPSLAM_HIP_ERR_INVALID; }
+    *count = 0;
+    LP_HIP(hipGetDeviceCount(count));
+    return LPSLAM_HIP_OK;
+}
+
+static int ctx_alloc(lpslam_hip_ctx* c)
+{
+    const size_t B = (size_t)c->cfg.max_images;
+    const int L = c->lt.n_levels;
+    LP_HIP(hipMalloc((void**)&c->d_pyr, B * c->image_slab));
+    LP_HIP(hipMemsetAsync(c->d_pyr, 0, B * c->image_slab, c->stream));
+    LP_HIP(hipMalloc((void**)&c->d_cell_keys, B * c->cells_per_image * kCellSlots * sizeof(uint32_t)));
+    LP_HIP(hipMalloc((void**)&c->d_cell_count, B * c->cells_per_image * sizeof(int32_t)));
+    LP_HIP(hipMalloc((void**)&c->d_cand_key, B * c->cand_per_image * sizeof(uint32_t)));
+    LP_HIP(hipMalloc((void**)&c->d_cand_node, B * c->cand_per_image * sizeof(uint32_t)));
+    LP_HIP(hipMalloc((void**)&c->d_cand_count, B * L * sizeof(int32_t)));
+    LP_HIP(hipMalloc((void**)&c->d_node_box, B * L * 2 * (size_t)c->node_cap * sizeof(uint2)));
+    LP_HIP(hipMalloc((void**)&c->d_node_cnt, B * L * 2 * (size_t)c->node_cap * sizeof(int32_t)));
+    LP_HIP(hipMalloc((void**)&c->d_sel_key, B * c->slots_per_image * sizeof(uint32_t)));
+    LP_HIP(hipMalloc((void**)&c->d_sel_count, B * L * sizeof(int32_t)));
+    LP_HIP(hipMalloc((void**)&c->d_kpts, B * c->slots_per_image * sizeof(lpslam_hip_keypoint)));
+    LP_HIP(hipMalloc((void**)&c->d_desc, B * c->slots_per_image * 32));
+    LP_HIP(hipMalloc((void**)&c->d_kp_count, B * sizeof(int32_t)));
+    LP_HIP(hipMemsetAsync(c->d_kp_count, 0, B * sizeof(int32_t), c->stream));
+    LP_HIP(hipMemsetAsync(c->d_sel_count, 0, B * L * sizeof(int32_t), c->stream));
+    LP_HIP(hipMemsetAsync(c->d_cand_count, 0, B * L * sizeof(int32_t), c->stream));
+    LP_HIP(hipMalloc((void**)&c->d_bf, B * 3 * c->slots_per_image * sizeof(int32_t)));
+    LP_HIP(hipMalloc((void**)&c->d_stereo, B * 2 * c->slots_per_image * sizeof(float)));
+    LP_HIP(hipMalloc((void**)&c->d_stereo_idx, B * c->slots_per_image * sizeof(int32_t)));
+    LP_HIP(hipMalloc((void**)&c->d_stereo_corr, B * c->slots_per_image * sizeof(int32_t)));
+    return LPSLAM_HIP_OK;
+}
+
+int lpslam_hip_create(const lpslam_hip_frontend_config* cfg, lpslam_hip_ctx** out)
+{
+    if (!cfg || !out) { set_error("null argument"); return LPSLAM_HIP_ERR_INVALID; }
+    *out = nullptr;
+    if (cfg->num_levels < 1 || cfg->num_levels > kMaxLevels || cfg->width < 64 || cfg->height < 64 ||
+        cfg->max_keypoints < 1 || cfg->max_images < 1 || !(cfg->scale_factor > 1.0f) ||
+        cfg->ini_fast_threshold < 0 || cfg->min_fast_threshold < 0) {
+        set_error("invalid front-end configuration (%dx%d, %d levels, scale %.3f, %d keypoints, %d images)", cfg->width,
+                  cfg->height, cfg->num_levels, (double)cfg->scale_factor, cfg->max_keypoints, cfg->max_images);
+        return LPSLAM_HIP_ERR_INVALID;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        set_error("no HIP device available: the lpslam hot path requires an MI355X (gfx950) GPU; there is no CPU fallback");
+        return LPSLAM_HIP_ERR_DEVICE;
+    }
+    if (cfg->device < 0 || cfg->device >= ndev) { set_error("device %d out of range (%d devices)", cfg->device, ndev); return LPSLAM_HIP_ERR_INVALID; }
+    LP_HIP(hipSetDevice(cfg->device));
+
+    lpslam_hip_ctx* c = new lpslam_hip_ctx();
+    c->cfg = *cfg;
+    std::vector<int16_t> ofs, coef;
+    int rc = build_level_table(*cfg, c->lt, c->image_slab, ofs, coef);
+    if (rc != LPSLAM_HIP_OK) { delete c; return rc; }
+    const int L = c->lt.n_levels;
+    c->cells_per_image = c->lt.cell_start[L];
+    c->cand_per_image = c->lt.cand_start[L];
+    c->slots_per_image = c->lt.slot_start[L];
+    int qmax = 0; size_t lds = 0;
+    for (int l = 0; l < L; ++l) {
+        qmax = std::max(qmax, c->lt.qcap[l]);
+        lds = std::max(lds, lp_distribute_lds_bytes(c->lt.qcap[l], c->lt.cells_x[l] * c->lt.cells_y[l]));
+    }
+    c->node_cap = qmax;
+    c->distribute_lds = lds;
+    if (lds > 160 * 1024) { set_error("distribution kernel needs %zu B of LDS (> 160 KiB)", lds); delete c; return LPSLAM_HIP_ERR_INVALID; }
+
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete c; return hip_fail(e, "hipStreamCreate"); }
+    rc = ctx_alloc(c);
+    if (rc == LPSLAM_HIP_OK && !ofs.empty()) {
+        e = hipMalloc((void**)&c->d_rs_ofs, ofs.size() * sizeof(int16_t));
+        if (e == hipSuccess) e = hipMalloc((void**)&c->d_rs_coef, coef.size() * sizeof(int16_t));
+        if (e == hipSuccess) e = hipMemcpy(c->d_rs_ofs, ofs.data(), ofs.size() * sizeof(int16_t), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(c->d_rs_coef, coef.data(), coef.size() * sizeof(int16_t), hipMemcpyHostToDevice);
+        if (e != hipSuccess) rc = hip_fail(e, "resize tables");
+    }
+    if (rc == LPSLAM_HIP_OK) {
+        e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) rc = hip_fail(e, "hipStreamSynchronize");
+    }
+    if (rc != LPSLAM_HIP_OK) { lpslam_hip_destroy(c); return rc; }
+    *out = c;
+    return LPSLAM_HIP_OK;
+}
+
+void lpslam_hip_destroy(lpslam_hip_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->cfg.device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    void* bufs[] = {c->d_pyr, c->d_rs_ofs, c->d_rs_coef, c->d_cell_keys, c->d_cell_count, c->d_cand_key, c->d_cand_node,
+                    c->d_cand_count, c->d_node_box, c->d_node_cnt, c->d_sel_key, c->d_sel_count, c->d_kpts, c->d_desc,
+                    c->d_kp_count, c->d_bf, c->d_stereo, c->d_stereo_idx, c->d_stereo_corr, c->d_tmp_desc, c->d_tmp_res};
+    for (void* b : bufs) if (b) (void)hipFree(b);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+void* lpslam_hip_stream(lpslam_hip_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+int lpslam_hip_sync(lpslam_hip_ctx* c)
+{
+    if (!c) { set_error("null context"); return LPSLAM_HIP_ERR_INVALID; }
+    LP_HIP(hipStreamSynchronize(c->stream));
+    return LPSLAM_HIP_OK;
+}
+
+int lpslam_hip_level_info(lpslam_hip_ctx* c, int32_t* widths, int32_t* heights, int32_t* pitches, int32_t* quotas,
+                          float* scale_factors)
+{
+    if (!c) { set_error("null context"); return LPSLAM_HIP_ERR_INVALID; }
+    for (int l = 0; l < c->lt.n_levels; ++l) {
+        if (widths) widths[l] = c->lt.w[l];
+        if (heights) heights[l] = c->lt.h[l];
+        if (pitches) pitches[l] = c->lt.pitch[l];
+        if (quotas) quotas[l] = c->lt.quota[l];
+        if (scale_factors) scale_factors[l] = c->lt.scale[l];
+    }
+    return LPSLAM_HIP_OK;
+}
+
+int lpslam_hip_max_keypoints_per_image(lpslam_hip_ctx* c) { return c ? c->slots_per_image : 0; }
+
+static int check_image(lpslam_hip_ctx* c, int image)
+{
+    if (!c) { set_error("null context"); return LPSLAM_HIP_ERR_INVALID; }
+    if (image < 0 || image >= c->cfg.max_images) { set_error("image slot %d out of range [0,%d)", image, c->cfg.max_images); return LPSLAM_HIP_ERR_CAPACITY; }
+    return LPSLAM_HIP_OK;
+}
+static int check_batch(lpslam_hip_ctx* c, int n)
+{
+    if (!c) { set_error("null context"); return LPSLAM_HIP_ERR_INVALID; }
+    if (n < 1 || n > c->cfg.max_images) { set_error("batch of %d images exceeds the context capacity %d", n, c->cfg.max_images); return LPSLAM_HIP_ERR_CAPACITY; }
+    LP_HIP(hipSetDevice(c->cfg.device));
+    return LPSLAM_HIP_OK;
+}
+
+int lpslam_hip_image_ptr(lpslam_hip_ctx* c, int image, void** dev_ptr, int32_t* pitch)
+{
+    int rc = check_image(c, image); if (rc) return rc;
+    if (dev_ptr) *dev_ptr = c->d_pyr + (size_t)image * c->image_slab;
+    if (pitch) *pitch = c->lt.pitch[0];
+    return LPSLAM_HIP_OK;
+}
+
+int lpslam_hip_upload_image(lpslam_hip_ctx* c, int image, const uint8_t* host, int32_t stride)
+{
+    int rc = check_image(c, image); if (rc) return rc;
+    if (!host || stride < c->lt.w[0]) { set_error("bad host image (stride %d < width %d)", stride, c->lt.w[0]); return LPSLAM_HIP_ERR_INVALID; }
+    LP_HIP(hipSetDevice(c->cfg.device));
+    LP_HIP(hipMemcpy2DAsync(c->d_pyr + (size_t)image * c->image_slab, c->lt.pitch[0], host, stride, c->lt.w[0], c->lt.h[0],
+                            hipMemcpyHostToDevice, c->stream));
+    return LPSLAM_HIP_OK;
+}
+
+int lpslam_hip_stage_pyramid(lpslam_hip_ctx* c, int n) { int rc = check_batch(c, n); return rc ? rc : lp_launch_pyramid(c, n); }
+int lpslam_hip_stage_fast(lpslam_hip_ctx* c, int n) { int rc = check_batch(c, n); return rc ? rc : lp_launch_fast(c, n); }
+int lpslam_hip_stage_distribute(lpslam_hip_ctx* c, int n) { int rc = check_batch(c, n); return rc ? rc : lp_launch_distribute(c, n); }
+int lpslam_hip_stage_describe(lpslam_hip_ctx* c, int n) { int rc = check_batch(c, n); return rc ? rc : lp_launch_describe(c, n); }
+
+int lpslam_hip_extract(lpslam_hip_ctx* c, int n)
+{
+    int rc = check_batch(c, n); if (rc) return rc;
+    if ((rc = lp_launch_pyramid(c, n))) return rc;
+    if ((rc = lp_launch_fast(c, n))) return rc;
+    if ((rc = lp_launch_distribute(c, n))) return rc;
+    return lp_launch_describe(c, n);
+}
+
+int lpslam_hip_keypoint_count(lpslam_hip_ctx* c, int image, int32_t* count)
+{
+    int rc = check_image(c, image); if (rc) return rc;
+    if (!count) { set_error("null argument"); return LPSLAM_HIP_ERR_INVALID; }
+    LP_HIP(hipMemcpyAsync(count, c->d_kp_count + image, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    LP_HIP(hipStreamSynchronize(c->stream));
+    return LPSLAM_HIP_OK;
+}
+
+int lpslam_hip_get_keypoints(lpslam_hip_ctx* c, int image, lpslam_hip_keypoint* kpts, uint8_t* desc32, int32_t capacity,
+                             int32_t* count)
+{
+    int32_t n = 0;
+    int rc = lpslam_hip_keypoint_count(c, image, &n); if (rc) return rc;
+    if (count) *count = n;
+    if (n > capacity) { set_error("keypoint buffer too small (%d < %d)", capacity, n); return LPSLAM_HIP_ERR_CAPACITY; }
+    const size_t o = (size_t)image * c->slots_per_image;
+    if (kpts && n) LP_HIP(hipMemcpyAsync(kpts, c->d_kpts + o, (size_t)n * sizeof(lpslam_hip_keypoint), hipMemcpyDeviceToHost, c->stream));
+    if (desc32 && n) LP_HIP(hipMemcpyAsync(desc32, c->d_desc + o * 32, (size_t)n * 32, hipMemcpyDeviceToHost, c->stream));
+    LP_HIP(hipStreamSynchronize(c->stream));
+    return LPSLAM_HIP_OK;
+}
+
+int lpslam_hip_get_pyramid_level(lpslam_hip_ctx* c, int image, int level, uint8_t* out, int32_t out_stride)
+{
+    int rc = check_image(c, image); if (rc) return rc;
+    if (level < 0 || level >= c->lt.n_levels || !out || out_stride < c->lt.w[level]) { set_error("bad level/stride"); return LPSLAM_HIP_ERR_INVALID; }
+    LP_HIP(hipMemcpy2DAsync(out, out_stride, c->d_pyr + (size_t)image * c->image_slab + c->lt.off[level], c->lt.pitch[level],
+                            c->lt.w[level], c->lt.h[level], hipMemcpyDeviceToHost, c->stream));
+    LP_HIP(hipStreamSynchronize(c->stream));
+    return LPSLAM_HIP_OK;
+}
+
+int lpslam_hip_get_candidates(lpslam_hip_ctx* c, int image, int level, lpslam_hip_corner* out, int32_t capacity, int32_t* count)
+{
+    int rc = check_image(c, image); if (rc) return rc;
+    if (level < 0 || level >= c->lt.n_levels) { set_error("bad level"); return LPSLAM_HIP_ERR_INVALID; }
+    int32_t n = 0;
+    LP_HIP(hipMemcpyAsync(&n, c->d_cand_count + image * c->lt.n_levels + level, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    LP_HIP(hipStreamSynchronize(c->stream));
+    if (count) *count = n;
+    if (!out) return LPSLAM_HIP_OK;
+    if (n > capacity) { set_error("candidate buffer too small (%d < %d)", capacity, n); return LPSLAM_HIP_ERR_CAPACITY; }
+    std::vector<uint32_t> keys((size_t)n);
+    if (n) LP_HIP(hipMemcpy(keys.data(), c->d_cand_key + (size_t)image * c->cand_per_image + c->lt.cand_start[level],
+                            (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; ++i) { out[i].x = keys[i] & 0xFFF; out[i].y = (keys[i] >> 12) & 0xFFF; out[i].score = keys[i] >> 24; }
+    return LPSLAM_HIP_OK;
+}
+
+int lpslam_hip_keypoint_buffers(lpslam_hip_ctx* c, int image, void** kpts_dev, void** desc_dev, void** count_dev)
+{
+    int rc = check_image(c, image); if (rc) return rc;
+    const size_t o = (size_t)image * c->slots_per_image;
+    if (kpts_dev) *kpts_dev = c->d_kpts + o;
+    if (desc_dev) *desc_dev = c->d_desc + o * 32;
+    if (count_dev) *count_dev = c->d_kp_count + image;
+    return LPSLAM_HIP_OK;
+}
+
+int lpslam_hip_set_descriptors(lpslam_hip_ctx* c, int image, const uint8_t* desc32, int32_t n)
+{
+    int rc = check_image(c, image); if (rc) return rc;
+    if (n < 0 || n > c->slots_per_image || (n && !desc32)) { set_error("descriptor count %d out of range [0,%d]", n, c->slots_per_image); return LPSLAM_HIP_ERR_CAPACITY; }
+    LP_HIP(hipSetDevice(c->cfg.device));
+    if (n) LP_HIP(hipMemcpyAsync(c->d_desc + (size_t)image * c->slots_per_image * 32, desc32, (size_t)n * 32, hipMemcpyHostToDevice, c->stream));
+    LP_HIP(hipMemcpyAsync(c->d_kp_count + image, &n, sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    LP_HIP(hipStreamSynchronize(c->stream));
+    return LPSLAM_HIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,679 @@
+// frontend.hip -- ORB front end for gfx950 (MI355X): image pyramid, FAST-9/16 in 64-px cells, quad-tree keypoint
+// distribution, intensity-centroid orientation + fused 7x7 Gaussian + rotated BRIEF-256.
+//
+// Replaces what the reference reaches through feed_stereo_frame / feed_monocular_frame
+// (/root/reference/src/Trackers/OpenVSLAMStereoTracker.cpp:293-295, src/Trackers/OpenVSLAMTracker.cpp:120):
+// [UPSTREAM] openvslam::feature::orb_extractor::extract with the Feature.* parameters of
+// src/Trackers/OpenVSLAMTrackerBase.cpp:193-198.  All pixel arithmetic is integer / fixed point and all float
+// arithmetic is written without FMA contraction, so results are bit-identical to the CPU definition.
+//
+// Layout in HBM: one slab per image holding all pyramid levels (row pitch = width rounded up to 64 B), images of a
+// batch back to back; FAST results in fixed 1024-entry slots per 64x64 cell; keypoints/descriptors per image.
+#include "internal.h"
+
+#pragma clang fp contract(off)
+
+using namespace lpslam;
+
+// ------------------------------------------------------------------------------------------------------------
+// K1  pyramid: level l = bilinear resize of level l-1, 11-bit fixed-point coefficients (cv::resize INTER_LINEAR 8u)
+//     HBM-bound: reads ~1.44 B and writes 1 B per output pixel.  One thread = 4 output pixels = one dword store.
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pyr_down(uint8_t* __restrict__ pyr, size_t image_slab, LevelTable lt, int level,
+                                                  const int16_t* __restrict__ rs_ofs, const int16_t* __restrict__ rs_coef)
+{
+    const int dw = lt.w[level], dh = lt.h[level], dp = lt.pitch[level];
+    const int sw = lt.w[level - 1], sh = lt.h[level - 1], sp = lt.pitch[level - 1];
+    const int dx0 = (blockIdx.x * 64 + threadIdx.x) * 4;
+    const int dy = blockIdx.y * 4 + threadIdx.y;
+    if (dy >= dh || dx0 >= dp) return;
+    uint8_t* img = pyr + (size_t)blockIdx.z * image_slab;
+    const uint8_t* src = img + lt.off[level - 1];
+    uint8_t* dst = img + lt.off[level];
+    const int yt = lt.ytab_start[level] + dy;
+    const int sy0 = rs_ofs[yt];
+    const int sy1 = min(sy0 + 1, sh - 1);
+    const int b0 = rs_coef[2 * yt], b1 = rs_coef[2 * yt + 1];
+    const uint8_t* S0 = src + (size_t)sy0 * sp;
+    const uint8_t* S1 = src + (size_t)sy1 * sp;
+    uint32_t packed = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int dx = dx0 + k;
+        if (dx < dw) {
+            const int xt = lt.xtab_start[level] + dx;
+            const int sx0 = rs_ofs[xt];
+            const int sx1 = min(sx0 + 1, sw - 1);
+            const int a0 = rs_coef[2 * xt], a1 = rs_coef[2 * xt + 1];
+            const int r0 = S0[sx0] * a0 + S0[sx1] * a1;
+            const int r1 = S1[sx0] * a0 + S1[sx1] * a1;
+            const int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+            packed |= (uint32_t)(v & 0xFF) << (8 * k);
+        }
+    }
+    *reinterpret_cast<uint32_t*>(dst + (size_t)dy * dp + dx0) = packed;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// K2  FAST-9/16 + score + 3x3 NMS per 64-px cell (cv::FAST on the cell sub-image, ini threshold then min threshold)
+//     One 256-thread workgroup per cell; the (64+6)^2 tile is staged in LDS with aligned dword loads.
+//     S(p) = max over the 16 arcs of 9 contiguous ring pixels of min(v - ring) resp. min(ring - v):
+//     p is a corner at threshold t iff S > t, and cv's cornerScore is S - 1.
+// ------------------------------------------------------------------------------------------------------------
+#define TILE_PITCH 80
+#define SMAP_PITCH 72
+
+__device__ __forceinline__ int min3i(int a, int b, int c) { return min(min(a, b), c); }
+__device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b), c); }
+
+__device__ __forceinline__ int fast_strength(const uint8_t* t /* points at centre in LDS tile */)
+{
+    const int v = t[0];
+    int d[16];
+    d[0] = v - t[3 * TILE_PITCH + 0];   d[1] = v - t[3 * TILE_PITCH + 1];   d[2] = v - t[2 * TILE_PITCH + 2];
+    d[3] = v - t[1 * TILE_PITCH + 3];   d[4] = v - t[3];                    d[5] = v - t[-1 * TILE_PITCH + 3];
+    d[6] = v - t[-2 * TILE_PITCH + 2];  d[7] = v - t[-3 * TILE_PITCH + 1];  d[8] = v - t[-3 * TILE_PITCH];
+    d[9] = v - t[-3 * TILE_PITCH - 1];  d[10] = v - t[-2 * TILE_PITCH - 2]; d[11] = v - t[-1 * TILE_PITCH - 3];
+    d[12] = v - t[-3];                  d[13] = v - t[1 * TILE_PITCH - 3];  d[14] = v - t[2 * TILE_PITCH - 2];
+    d[15] = v - t[3 * TILE_PITCH - 1];
+    int lo3[16], hi3[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        lo3[i] = min3i(d[i], d[(i + 1) & 15], d[(i + 2) & 15]);
+        hi3[i] = max3i(d[i], d[(i + 1) & 15], d[(i + 2) & 15]);
+    }
+    int a = -512, b = 512;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        a = max(a, min3i(lo3[i], lo3[(i + 3) & 15], lo3[(i + 6) & 15]));
+        b = min(b, max3i(hi3[i], hi3[(i + 3) & 15], hi3[(i + 6) & 15]));
+    }
+    return max(a, -b);
+}
+
+__global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ pyr, size_t image_slab, LevelTable lt,
+                                                    int ini_thr, int min_thr, uint32_t* __restrict__ cell_keys,
+                                                    int32_t* __restrict__ cell_count, int cells_per_image)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t tile[70 * TILE_PITCH];
+    __shared__ __attribute__((aligned(16))) uint8_t smap[66 * SMAP_PITCH];
+    __shared__ unsigned long long m_ini[64], m_min[64], m_sel[64];
+    __shared__ int rowoff[64];
+
+    const int cell = blockIdx.x, image = blockIdx.y;
+    int level = 0;
+    while (level + 1 < lt.n_levels && cell >= lt.cell_start[level + 1]) ++level;
+    const int lc = cell - lt.cell_start[level];
+    const int ci = lc / lt.cells_x[level], cj = lc - ci * lt.cells_x[level];
+    const int W = lt.w[level], H = lt.h[level], P = lt.pitch[level];
+    const int min_x = kEdge + cj * kCell, min_y = kEdge + ci * kCell;
+    const int cw = min(min_x + kCell + kOverlap, W - kEdge) - min_x;   // 7..70 (cells narrower than 7 px hold no corner)
+    const int ch = min(min_y + kCell + kOverlap, H - kEdge) - min_y;
+    const uint8_t* src = pyr + (size_t)image * image_slab + lt.off[level];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    // stage the tile: aligned dwords covering [min_x, min_x + cw) of rows [min_y, min_y + ch)
+    const int x_al = min_x & ~3, shift = min_x - x_al;
+    const int ndw = (shift + cw + 3) >> 2;                              // <= 19
+    for (int i = tid; i < ch * 20; i += 256) {
+        const int r = i / 20, c = i - r * 20;
+        uint32_t v = 0;
+        if (c < ndw) v = *reinterpret_cast<const uint32_t*>(src + (size_t)(min_y + r) * P + x_al + 4 * c);
+        *reinterpret_cast<uint32_t*>(&tile[r * TILE_PITCH + 4 * c]) = v;
+    }
+    for (int i = tid; i < 66 * SMAP_PITCH / 4; i += 256) reinterpret_cast<uint32_t*>(smap)[i] = 0;
+    if (tid < 64) { m_ini[tid] = 0; m_min[tid] = 0; }
+    __syncthreads();
+
+    const int vw = cw - 6, vh = ch - 6;          // valid (corner-tested) interior, <= 64 x 64; may be <= 0
+    const int thr_lo = min(ini_thr, min_thr);
+    for (int r = wave; r < vh; r += 4) {
+        if (lane < vw) {
+            const int s = fast_strength(&tile[(r + 3) * TILE_PITCH + shift + lane + 3]);
+            smap[(r + 1) * SMAP_PITCH + lane + 1] = (uint8_t)(s > thr_lo ? s : 0);
+        }
+    }
+    __syncthreads();
+    for (int r = wave; r < vh; r += 4) {
+        bool nms = false;
+        int s = 0;
+        if (lane < vw) {
+            const uint8_t* q = &smap[(r + 1) * SMAP_PITCH + lane + 1];
+            s = q[0];
+            nms = s > 0 && s > q[-1] && s > q[1] && s > q[-SMAP_PITCH - 1] && s > q[-SMAP_PITCH] &&
+                  s > q[-SMAP_PITCH + 1] && s > q[SMAP_PITCH - 1] && s > q[SMAP_PITCH] && s > q[SMAP_PITCH + 1];
+        }
+        const unsigned long long bi = __ballot(nms && s > ini_thr);
+        const unsigned long long bm = __ballot(nms && s > min_thr);
+        if (lane == 0) { m_ini[r] = bi; m_min[r] = bm; }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        int ci_ = __popcll(m_ini[lane]);
+        int tot = ci_;
+        for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
+        const unsigned long long sel = tot > 0 ? m_ini[lane] : m_min[lane];
+        const int c = __popcll(sel);
+        int incl = c;
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+        rowoff[lane] = incl - c;
+        m_sel[lane] = sel;
+        if (lane == 63) cell_count[(size_t)image * cells_per_image + cell] = incl;
+    }
+    __syncthreads();
+    uint32_t* out = cell_keys + ((size_t)image * cells_per_image + cell) * kCellSlots;
+    for (int r = wave; r < vh; r += 4) {
+        const unsigned long long sel = m_sel[r];
+        if ((sel >> lane) & 1ull) {
+            const int pos = rowoff[r] + __popcll(sel & ((1ull << lane) - 1ull));
+            const uint32_t score = (uint32_t)smap[(r + 1) * SMAP_PITCH + lane + 1] - 1u;   // cornerScore = S - 1
+            const uint32_t x = (uint32_t)(lane + 3 + cj * kCell), y = (uint32_t)(r + 3 + ci * kCell);
+            out[pos] = (score << 24) | (y << 12) | x;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// K3  quad-tree distribution (orb_extractor::distribute_keypoints_via_tree), one 1024-thread workgroup per
+//     (image, level).  Nodes are kept in ascending creation order (= reverse of the upstream std::list); every
+//     pass splits an ordered "visit list" of nodes with scans instead of list surgery:
+//       breadth-first passes: all nodes with > 1 corner, visited from the newest to the oldest;
+//       final passes: the pool of new children sorted by (count, creation) descending, cut where the node count
+//       reaches the quota.  Ties go to the node created last.
+// ------------------------------------------------------------------------------------------------------------
+struct DistLds {
+    int* cnt4;      // [16*Q]   quadrant histograms of the visit list
+    int* order;     // [4*Q pow2] visit list (node index), doubles as bitonic sort buffer
+    int* nodepos;   // [Q]      node -> position in visit list or -1
+    int* kpre;      // [4*Q+1]  prefix of children count over the visit list
+    int* keptrank;  // [Q+1]
+    int* misc;      // [64]
+};
+
+__device__ __forceinline__ int block_excl_scan_1024(int v, int* wave_tot /* LDS[16] */, int* total)
+{
+    // exclusive scan of one value per thread over a 1024-thread block
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int incl = v;
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    int base = 0, tot = 0;
+    for (int w = 0; w < 16; ++w) { const int t = wave_tot[w]; if (w < wave) base += t; tot += t; }
+    __syncthreads();
+    *total = tot;
+    return base + incl - v;
+}
+
+// exclusive scan in place of a[0..n) (n <= per_thread*1024), returns total via *total; all threads call
+__device__ void block_scan_array(int* a, int n, int* wave_tot, int* total)
+{
+    const int per = (n + 1023) / 1024;
+    const int b = threadIdx.x * per, e = min(b + per, n);
+    int s = 0;
+    for (int i = b; i < e; ++i) s += a[i];
+    int tot;
+    int base = block_excl_scan_1024(s, wave_tot, &tot);
+    for (int i = b; i < e; ++i) { const int v = a[i]; a[i] = base; base += v; }
+    __syncthreads();
+    *total = tot;
+}
+
+__global__ __launch_bounds__(1024) void k_distribute(LevelTable lt, const uint32_t* __restrict__ cell_keys,
+                                                     const int32_t* __restrict__ cell_count, int cells_per_image,
+                                                     uint32_t* __restrict__ cand_key, uint32_t* __restrict__ cand_node,
+                                                     int32_t* __restrict__ cand_count, int cand_per_image,
+                                                     uint2* __restrict__ node_box, int32_t* __restrict__ node_cnt, int node_cap,
+                                                     uint32_t* __restrict__ sel_key, int32_t* __restrict__ sel_count,
+                                                     int slots_per_image)
+{
+    extern __shared__ __attribute__((aligned(16))) int lds[];
+    const int level = blockIdx.x, image = blockIdx.y;
+    const int tid = threadIdx.x;
+    const int N = lt.quota[level];
+    const int Q = lt.qcap[level];          // node count never exceeds max(N + 2, 4 * roots) < Q
+    int sortcap = 1; while (sortcap < Q) sortcap <<= 1;
+    const int ncell0 = lt.cells_x[level] * lt.cells_y[level];
+    int* cnt4 = lds;                                   // max(4*Q, ncell): quadrant histograms / scratch
+    int* order = cnt4 + max(4 * Q, ncell0);            // sortcap: visit list, bitonic sort buffer
+    int* nodepos = order + sortcap;                    // Q
+    int* kpre = nodepos + Q;                           // Q + 1
+    int* keptrank = kpre + Q + 1;                      // Q + 1
+    int* misc = keptrank + Q + 1;                      // 64
+    int* wave_tot = misc + 32;
+
+    const int ncell = lt.cells_x[level] * lt.cells_y[level];
+    const uint32_t* ckeys = cell_keys + ((size_t)image * cells_per_image + lt.cell_start[level]) * kCellSlots;
+    const int32_t* ccnt = cell_count + (size_t)image * cells_per_image + lt.cell_start[level];
+    uint32_t* ckey = cand_key + (size_t)image * cand_per_image + lt.cand_start[level];
+    uint32_t* cnode = cand_node + (size_t)image * cand_per_image + lt.cand_start[level];
+    uint2* nbox[2]; int32_t* ncnt[2];
+    {
+        const size_t base = ((size_t)image * lt.n_levels + level) * 2 * (size_t)node_cap;
+        nbox[0] = node_box + base; nbox[1] = node_box + base + node_cap;
+        ncnt[0] = node_cnt + base; ncnt[1] = node_cnt + base + node_cap;
+    }
+    uint32_t* out_sel = sel_key + (size_t)image * slots_per_image + lt.slot_start[level];
+
+    // ---- compact the per-cell slots into one candidate list (cells row-major, corners row-major inside a cell)
+    int n_cand;
+    {
+        int* coff = cnt4;
+        for (int i = tid; i < ncell; i += 1024) coff[i] = ccnt[i];
+        __syncthreads();
+        block_scan_array(coff, ncell, wave_tot, &n_cand);
+        // copy: one wave per cell
+        const int wave = tid >> 6, lane = tid & 63;
+        for (int c = wave; c < ncell; c += 16) {
+            const int n = ccnt[c], o = coff[c];
+            for (int k = lane; k < n; k += 64) ckey[o + k] = ckeys[(size_t)c * kCellSlots + k];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) cand_count[image * lt.n_levels + level] = n_cand;
+    if (n_cand == 0) { if (tid == 0) sel_count[image * lt.n_levels + level] = 0; return; }
+
+    // ---- initialize_nodes
+    const int nxg = lt.nxg[level], nyg = lt.nyg[level];
+    const double delta_x = lt.delta_x[level], delta_y = lt.delta_y[level];
+    const int nini = nxg * nyg;             // 4 * nini + 4 <= Q
+    for (int i = tid; i < nini; i += 1024) cnt4[i] = 0;
+    __syncthreads();
+    for (int c = tid; c < n_cand; c += 1024) {
+        const uint32_t k = ckey[c];
+        const float x = (float)(k & 0xFFF), y = (float)((k >> 12) & 0xFFF);
+        unsigned ix = (unsigned)((double)x / delta_x), iy = (unsigned)((double)y / delta_y);
+        unsigned root = ix + iy * nxg;
+        if (root >= (unsigned)nini) root = nini - 1;
+        cnode[c] = root;
+        atomicAdd(&cnt4[root], 1);
+    }
+    __syncthreads();
+    // array position a <-> root (nini-1-a); drop empty roots
+    for (int a = tid; a < nini; a += 1024) keptrank[a] = cnt4[nini - 1 - a] > 0 ? 1 : 0;
+    __syncthreads();
+    int alive;
+    block_scan_array(keptrank, nini, wave_tot, &alive);
+    int cur = 0;
+    for (int a = tid; a < nini; a += 1024) {
+        const int root = nini - 1 - a;
+        if (cnt4[root] > 0) {
+            const int ix = root % nxg, iy = root / nxg;
+            const unsigned bx = (unsigned)(int)(delta_x * ix), by = (unsigned)(int)(delta_y * iy);
+            const unsigned ex = (unsigned)(int)(delta_x * (ix + 1)), ey = (unsigned)(int)(delta_y * (iy + 1));
+            nbox[cur][keptrank[a]] = make_uint2(bx | (by << 16), ex | (ey << 16));
+            ncnt[cur][keptrank[a]] = cnt4[root];
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < n_cand; c += 1024) cnode[c] = keptrank[nini - 1 - (int)cnode[c]];
+    __syncthreads();
+
+    // ---- split passes
+    bool sorted_phase = false;
+    int pool_begin = 0;          // in sorted phase: the pool is the nodes [pool_begin, alive) with count > 1
+    for (int pass = 0; pass < 64; ++pass) {
+        const int prev_alive = alive;
+        // 1. visit list
+        int m = 0;               // visit-list length
+        if (!sorted_phase) {
+            // all nodes with count > 1, newest first
+            for (int i = tid; i < alive; i += 1024) keptrank[i] = ncnt[cur][i] > 1 ? 1 : 0;
+            __syncthreads();
+            block_scan_array(keptrank, alive, wave_tot, &m);
+            for (int i = tid; i < alive; i += 1024) {
+                if (ncnt[cur][i] > 1) { const int pos = m - 1 - keptrank[i]; order[pos] = i; nodepos[i] = pos; }
+                else nodepos[i] = -1;
+            }
+            __syncthreads();
+        } else {
+            // pool sorted by (count, index) descending -> bitonic sort of keys (count << 11 | index); index < 2048, count < 2^21
+            for (int i = tid; i < alive; i += 1024) { nodepos[i] = -1; keptrank[i] = (i >= pool_begin && ncnt[cur][i] > 1) ? 1 : 0; }
+            __syncthreads();
+            block_scan_array(keptrank, alive, wave_tot, &m);
+            int cap2 = 1; while (cap2 < m) cap2 <<= 1;
+            for (int i = tid; i < cap2; i += 1024) order[i] = 0;     // padding sorts last (descending)
+            __syncthreads();
+            for (int i = tid; i < alive; i += 1024)
+                if (i >= pool_begin && ncnt[cur][i] > 1) order[keptrank[i]] = (ncnt[cur][i] << 11) | i;
+            __syncthreads();
+            for (int k = 2; k <= cap2; k <<= 1) {
+                for (int j = k >> 1; j > 0; j >>= 1) {
+                    for (int i = tid; i < cap2; i += 1024) {
+                        const int p = i ^ j;
+                        if (p > i) {
+                            const unsigned a = (unsigned)order[i], b = (unsigned)order[p];
+                            const bool desc = (i & k) == 0;
+                            if (desc ? (a < b) : (a > b)) { order[i] = (int)b; order[p] = (int)a; }
+                        }
+                    }
+                    __syncthreads();
+                }
+            }
+            for (int i = tid; i < m; i += 1024) { const int node = order[i] & 0x7FF; order[i] = node; nodepos[node] = i; }
+            __syncthreads();
+        }
+        if (m == 0) break;       // nothing dividable: node count cannot change any more
+
+        // 2. quadrant histograms of every visit-list node
+        for (int i = tid; i < 4 * m; i += 1024) cnt4[i] = 0;
+        __syncthreads();
+        for (int c = tid; c < n_cand; c += 1024) {
+            const int node = (int)(cnode[c] & 0x3FFFFFFFu);
+            const int pos = nodepos[node];
+            if (pos >= 0) {
+                const uint2 bb = nbox[cur][node];
+                const int bx = bb.x & 0xFFFF, by = bb.x >> 16, ex = bb.y & 0xFFFF, ey = bb.y >> 16;
+                const int hx = (ex - bx + 1) >> 1, hy = (ey - by + 1) >> 1;
+                const uint32_t k = ckey[c];
+                const int x = k & 0xFFF, y = (k >> 12) & 0xFFF;
+                const int q = (bx + hx <= x ? 1 : 0) + (by + hy <= y ? 2 : 0);
+                atomicAdd(&cnt4[4 * pos + q], 1);
+                cnode[c] = (uint32_t)node | ((uint32_t)q << 30);
+            }
+        }
+        __syncthreads();
+        // 3. children per visit position, prefix, cut (sorted phase)
+        for (int i = tid; i < m; i += 1024)
+            kpre[i] = (cnt4[4 * i] > 0) + (cnt4[4 * i + 1] > 0) + (cnt4[4 * i + 2] > 0) + (cnt4[4 * i + 3] > 0);
+        __syncthreads();
+        int ktotal;
+        block_scan_array(kpre, m, wave_tot, &ktotal);
+        if (tid == 0) kpre[m] = ktotal;
+        int jcut = m;
+        if (sorted_phase) {
+            // smallest j >= 1 with alive + kpre[j] - j >= N (the node count after j splits; non-decreasing in j)
+            if (tid == 0) misc[0] = m;
+            __syncthreads();
+            for (int j = tid + 1; j <= m; j += 1024)
+                if (alive + kpre[j] - j >= N) atomicMin(&misc[0], j);
+            __syncthreads();
+            jcut = misc[0];
+        }
+        __syncthreads();
+        // 4. kept ranks
+        for (int i = tid; i < alive; i += 1024) { const int p = nodepos[i]; keptrank[i] = (p >= 0 && p < jcut) ? 0 : 1; }
+        __syncthreads();
+        int n_kept;
+        block_scan_array(keptrank, alive, wave_tot, &n_kept);
+        const int n_children = kpre[jcut];
+        const int nxt = cur ^ 1;
+        // 5. new node arrays
+        for (int i = tid; i < alive; i += 1024) {
+            const int p = nodepos[i];
+            if (!(p >= 0 && p < jcut)) { nbox[nxt][keptrank[i]] = nbox[cur][i]; ncnt[nxt][keptrank[i]] = ncnt[cur][i]; }
+        }
+        for (int p = tid; p < jcut; p += 1024) {
+            const int node = order[p];
+            const uint2 bb = nbox[cur][node];
+            const int bx = bb.x & 0xFFFF, by = bb.x >> 16, ex = bb.y & 0xFFFF, ey = bb.y >> 16;
+            const int hx = (ex - bx + 1) >> 1, hy = (ey - by + 1) >> 1;
+            int idx = n_kept + kpre[p];
+            const int cbx[4] = {bx, bx + hx, bx, bx + hx}, cby[4] = {by, by, by + hy, by + hy};
+            const int cex[4] = {bx + hx, ex, bx + hx, ex}, cey[4] = {by + hy, by + hy, ey, ey};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = cnt4[4 * p + q];
+                if (n > 0) {
+                    nbox[nxt][idx] = make_uint2((unsigned)cbx[q] | ((unsigned)cby[q] << 16), (unsigned)cex[q] | ((unsigned)cey[q] << 16));
+                    ncnt[nxt][idx] = n;
+                    ++idx;
+                }
+            }
+        }
+        // 6. remap candidates
+        for (int c = tid; c < n_cand; c += 1024) {
+            const uint32_t v = cnode[c];
+            const int node = (int)(v & 0x3FFFFFFFu), q = (int)(v >> 30);
+            const int p = nodepos[node];
+            int nn;
+            if (p >= 0 && p < jcut) {
+                int rank = 0;
+                for (int qq = 0; qq < q; ++qq) rank += cnt4[4 * p + qq] > 0;
+                nn = n_kept + kpre[p] + rank;
+            } else nn = keptrank[node];
+            cnode[c] = (uint32_t)nn;
+        }
+        __syncthreads();
+        alive = n_kept + n_children;
+        cur = nxt;
+        pool_begin = n_kept;
+        // pool size for the phase decision: children with more than one corner
+        if (tid == 0) misc[1] = 0;
+        __syncthreads();
+        {
+            int local = 0;
+            for (int i = pool_begin + tid; i < alive; i += 1024) local += ncnt[cur][i] > 1;
+            if (local) atomicAdd(&misc[1], local);
+        }
+        __syncthreads();
+        const int pool_n = misc[1];
+        __syncthreads();
+        if (N <= alive || alive == prev_alive) break;
+        if (!sorted_phase && N < alive + 3 * pool_n) sorted_phase = true;
+    }
+
+    // ---- best response per node (first maximum in candidate order), nodes newest first
+    int* win = cnt4;      // alive <= 4*Q <= 16*Q
+    for (int i = tid; i < alive; i += 1024) win[i] = 0;
+    __syncthreads();
+    for (int c = tid; c < n_cand; c += 1024) {
+        const uint32_t k = ckey[c];
+        const unsigned key = ((k >> 24) << 24) | (0xFFFFFFu - (unsigned)c);
+        atomicMax(reinterpret_cast<unsigned*>(&win[cnode[c]]), key);
+    }
+    __syncthreads();
+    const int cap = lt.slot_start[level + 1] - lt.slot_start[level];     // >= max(N + 3, 4 * roots) >= alive
+    for (int i = tid; i < alive && i < cap; i += 1024) {
+        const unsigned w = (unsigned)win[alive - 1 - i];
+        out_sel[i] = ckey[0xFFFFFFu - (w & 0xFFFFFFu)];
+    }
+    if (tid == 0) sel_count[image * lt.n_levels + level] = min(alive, cap);
+}
+
+size_t lp_distribute_lds_bytes(int Q, int ncell)
+{
+    int sortcap = 1; while (sortcap < Q) sortcap <<= 1;
+    const int c4 = 4 * Q > ncell ? 4 * Q : ncell;
+    return sizeof(int) * ((size_t)c4 + sortcap + Q + (Q + 1) + (Q + 1) + 64);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// K4+K5+K6  per keypoint: intensity-centroid angle (radius-15 disc, cv::fastAtan2), 7x7 sigma-2 fixed-point Gaussian
+//           of the 37x37 neighbourhood computed in LDS (never written to HBM), 256 rotated BRIEF tests.
+//           One wavefront per keypoint; the descriptor's four 64-bit words are four wave ballots.
+// ------------------------------------------------------------------------------------------------------------
+__constant__ int8_t c_pattern[256 * 4] = {
+#include "orb_pattern.inc"
+};
+__constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+
+__device__ __forceinline__ float fast_atan2_deg(float y, float x)
+{
+    const float scale = (float)(180.0 / 3.14159265358979323846);
+    const float p1 = 0.9997878412794807f * scale, p3 = -0.3258083974640975f * scale;
+    const float p5 = 0.1555786518463281f * scale, p7 = -0.04432655554792128f * scale;
+    const float ax = fabsf(x), ay = fabsf(y);
+    float a, c, c2;
+    if (ax >= ay) {
+        c = ay / (ax + 2.2204460492503131e-16f);
+        c2 = c * c;
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    } else {
+        c = ax / (ay + 2.2204460492503131e-16f);
+        c2 = c * c;
+        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    }
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
+}
+
+// sin/cos of an angle in degrees as one fixed sequence of IEEE double operations (the CPU definition uses the
+// same sequence); rounded to float.
+__device__ __forceinline__ void sincos_deg(float angle_deg, float* s_out, float* c_out)
+{
+    const double a = (double)angle_deg * 0.017453292519943295;
+    const double qf = floor(a * 0.63661977236758138 + 0.5);
+    const int q = (int)qf;
+    double r = a - qf * 1.5707963267948966;
+    r = r - qf * 6.123233995736766e-17;
+    const double z = r * r;
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
+                 S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
+                 C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    double ps = S6; ps = ps * z + S5; ps = ps * z + S4; ps = ps * z + S3; ps = ps * z + S2; ps = ps * z + S1;
+    const double sn = r + r * (z * ps);
+    double pc = C6; pc = pc * z + C5; pc = pc * z + C4; pc = pc * z + C3; pc = pc * z + C2; pc = pc * z + C1;
+    const double cs = 1.0 - 0.5 * z + z * (z * pc);
+    double s, c;
+    switch (q & 3) {
+    case 0: s = sn; c = cs; break;
+    case 1: s = cs; c = -sn; break;
+    case 2: s = -sn; c = -cs; break;
+    default: s = -cs; c = sn; break;
+    }
+    *s_out = (float)s; *c_out = (float)c;
+}
+
+#define PR 21                 // raw patch radius: 18 (max rotated pattern radius) + 3 (blur)
+#define PW 43                 // raw patch width
+#define BW 37                 // blurred patch width (radius 18)
+#define RAW_PITCH 44
+#define DESC_WAVES 4
+
+__global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const uint8_t* __restrict__ pyr, size_t image_slab, LevelTable lt,
+                                                              const uint32_t* __restrict__ sel_key,
+                                                              const int32_t* __restrict__ sel_count, int slots_per_image,
+                                                              lpslam_hip_keypoint* __restrict__ kpts, uint8_t* __restrict__ desc,
+                                                              int32_t* __restrict__ kp_count)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t s_raw[DESC_WAVES][PW * RAW_PITCH];
+    __shared__ __attribute__((aligned(16))) uint16_t s_h[DESC_WAVES][PW * BW];
+    __shared__ __attribute__((aligned(16))) uint8_t s_blur[DESC_WAVES][BW * BW];
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int image = blockIdx.y;
+    const int slot = blockIdx.x * DESC_WAVES + wave;
+    if (slot >= slots_per_image) return;          // wave-uniform; no block barriers below
+    int level = 0;
+    while (level + 1 < lt.n_levels && slot >= lt.slot_start[level + 1]) ++level;
+    const int k = slot - lt.slot_start[level];
+    const int32_t* cnt = sel_count + image * lt.n_levels;
+    int dense = k;
+    for (int l = 0; l < level; ++l) dense += cnt[l];
+    if (slot == 0 && lane == 0) { int t = 0; for (int l = 0; l < lt.n_levels; ++l) t += cnt[l]; kp_count[image] = t; }
+    if (k >= cnt[level]) return;
+
+    const uint32_t key = sel_key[(size_t)image * slots_per_image + slot];
+    const int cx = (int)(key & 0xFFF) + kEdge, cy = (int)((key >> 12) & 0xFFF) + kEdge;
+    const float score = (float)(key >> 24);
+    const int P = lt.pitch[level];
+    const uint8_t* src = pyr + (size_t)image * image_slab + lt.off[level] + (size_t)(cy - PR) * P + (cx - PR);
+    uint8_t* raw = s_raw[wave];
+    uint16_t* hb = s_h[wave];
+    uint8_t* bl = s_blur[wave];
+
+    for (int i = lane; i < PW * PW; i += 64) { const int r = i / PW, c = i - r * PW; raw[r * RAW_PITCH + c] = src[(size_t)r * P + c]; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+
+    // orientation: m10 = sum u*I, m01 = sum v*I over the disc |u| <= umax[|v|], |v| <= 15
+    int m10 = 0, m01 = 0;
+    for (int i = lane; i < 31 * 31; i += 64) {
+        const int r = i / 31, c = i - r * 31;
+        const int v = r - 15, u = c - 15;
+        if (abs(u) <= c_umax[abs(v)]) {
+            const int I = raw[(PR + v) * RAW_PITCH + PR + u];
+            m10 += u * I; m01 += v * I;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) { m10 += __shfl_xor(m10, o); m01 += __shfl_xor(m01, o); }
+    const float angle = fast_atan2_deg((float)m01, (float)m10);
+
+    // separable fixed-point Gaussian {18,34,48,56,48,34,18}/256: rows 0..42 x cols 3..39, then rows 3..39
+    for (int i = lane; i < PW * BW; i += 64) {
+        const int r = i / BW, c = i - r * BW;
+        const uint8_t* p = &raw[r * RAW_PITCH + c];
+        hb[i] = (uint16_t)(18 * (p[0] + p[6]) + 34 * (p[1] + p[5]) + 48 * (p[2] + p[4]) + 56 * p[3]);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    for (int i = lane; i < BW * BW; i += 64) {
+        const int r = i / BW, c = i - r * BW;
+        const uint16_t* p = &hb[r * BW + c];
+        const uint32_t s = 18u * (p[0] + p[6 * BW]) + 34u * (p[BW] + p[5 * BW]) + 48u * (p[2 * BW] + p[4 * BW]) + 56u * p[3 * BW];
+        bl[i] = (uint8_t)((s + (1u << 15)) >> 16);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+
+    float sa, ca;
+    sincos_deg(angle, &sa, &ca);
+    const uint8_t* centre = &bl[18 * BW + 18];
+    unsigned long long words[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int8_t* pp = &c_pattern[(64 * j + lane) * 4];
+        const float x0 = pp[0], y0 = pp[1], x1 = pp[2], y1 = pp[3];
+        const int r0 = (int)rintf(x0 * sa + y0 * ca), c0 = (int)rintf(x0 * ca - y0 * sa);
+        const int r1 = (int)rintf(x1 * sa + y1 * ca), c1 = (int)rintf(x1 * ca - y1 * sa);
+        const int t0 = centre[r0 * BW + c0], t1 = centre[r1 * BW + c1];
+        words[j] = __ballot(t0 < t1);
+    }
+    const size_t o = (size_t)image * slots_per_image + dense;
+    if (lane < 4) reinterpret_cast<unsigned long long*>(desc + o * 32)[lane] = words[lane];
+    if (lane == 0) {
+        lpslam_hip_keypoint kp;
+        const float sf = lt.scale[level];
+        kp.x = (float)cx * sf; kp.y = (float)cy * sf;
+        kp.size = (float)(unsigned)(31.0f * sf);
+        kp.angle = angle; kp.response = score; kp.octave = level; kp.class_id = -1;
+        kpts[o] = kp;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// host launchers
+// ------------------------------------------------------------------------------------------------------------
+int lp_launch_pyramid(lpslam_hip_ctx* c, int n_images)
+{
+    for (int l = 1; l < c->lt.n_levels; ++l) {
+        dim3 block(64, 4), grid((c->lt.pitch[l] / 4 + 63) / 64, (c->lt.h[l] + 3) / 4, n_images);
+        hipLaunchKernelGGL(k_pyr_down, grid, block, 0, c->stream, c->d_pyr, c->image_slab, c->lt, l, c->d_rs_ofs, c->d_rs_coef);
+    }
+    LP_HIP(hipGetLastError());
+    return LPSLAM_HIP_OK;
+}
+
+int lp_launch_fast(lpslam_hip_ctx* c, int n_images)
+{
+    dim3 grid(c->cells_per_image, n_images);
+    hipLaunchKernelGGL(k_fast_cells, grid, dim3(256), 0, c->stream, c->d_pyr, c->image_slab, c->lt, c->cfg.ini_fast_threshold,
+                       c->cfg.min_fast_threshold, c->d_cell_keys, c->d_cell_count, c->cells_per_image);
+    LP_HIP(hipGetLastError());
+    return LPSLAM_HIP_OK;
+}
+
+int lp_launch_distribute(lpslam_hip_ctx* c, int n_images)
+{
+    dim3 grid(c->lt.n_levels, n_images);
+    hipLaunchKernelGGL(k_distribute, grid, dim3(1024), c->distribute_lds, c->stream, c->lt, c->d_cell_keys, c->d_cell_count,
+                       c->cells_per_image, c->d_cand_key, c->d_cand_node, c->d_cand_count, c->cand_per_image, c->d_node_box,
+                       c->d_node_cnt, c->node_cap, c->d_sel_key, c->d_sel_count, c->slots_per_image);
+    LP_HIP(hipGetLastError());
+    return LPSLAM_HIP_OK;
+}
+
+int lp_launch_describe(lpslam_hip_ctx* c, int n_images)
+{
+    dim3 grid((c->slots_per_image + DESC_WAVES - 1) / DESC_WAVES, n_images);
+    hipLaunchKernelGGL(k_describe, grid, dim3(64 * DESC_WAVES), 0, c->stream, c->d_pyr, c->image_slab, c->lt, c->d_sel_key,
+                       c->d_sel_count, c->slots_per_image, c->d_kpts, c->d_desc, c->d_kp_count);
+    LP_HIP(hipGetLastError());
+    return LPSLAM_HIP_OK;
+}

@@ -1,0 +1,95 @@
+// internal.h -- shared host-side definitions of the lpslam HIP library (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../include/lpslam_hip.h"
+
+namespace lpslam {
+
+constexpr int kMaxLevels = LPSLAM_HIP_MAX_LEVELS;
+constexpr int kEdge = 19;          // orb_patch_radius_: cells start 19 px inside the level
+constexpr int kCell = 64;          // FAST cell size
+constexpr int kOverlap = 6;        // FAST cell overlap (2 x 3-px FAST border)
+constexpr int kCellSlots = 1024;   // max NMS survivors in a 64x64 cell (no two 8-adjacent)
+constexpr int kQuotaMax = 2000;    // per-level quota supported by the distribution kernel (node index < 2048)
+
+// Per-level geometry, passed to kernels by value.
+struct LevelTable {
+    int n_levels;
+    int w[kMaxLevels], h[kMaxLevels], pitch[kMaxLevels];
+    unsigned off[kMaxLevels];          // byte offset of the level inside one image's pyramid slab
+    int cells_x[kMaxLevels], cells_y[kMaxLevels];
+    int cell_start[kMaxLevels + 1];    // prefix of cells over levels (per image)
+    int quota[kMaxLevels];
+    int slot_start[kMaxLevels + 1];    // prefix of (quota+3) over levels: selected-keypoint slots per image
+    int cand_start[kMaxLevels + 1];    // prefix of candidate capacity (cells*kCellSlots) over levels
+    float scale[kMaxLevels], inv_scale[kMaxLevels];
+    int xtab_start[kMaxLevels], ytab_start[kMaxLevels];  // offsets into the resize tables (level >= 1)
+    // quad-tree roots (initialize_nodes): grid and patch size per level, node capacity Q = max(quota, 4*roots) + 4
+    int nxg[kMaxLevels], nyg[kMaxLevels], qcap[kMaxLevels];
+    double delta_x[kMaxLevels], delta_y[kMaxLevels];
+};
+
+void set_error(const char* fmt, ...);
+int hip_fail(hipError_t e, const char* what);
+
+#define LP_HIP(call)                                              \
+    do {                                                          \
+        hipError_t e_ = (call);                                   \
+        if (e_ != hipSuccess) return ::lpslam::hip_fail(e_, #call); \
+    } while (0)
+
+}  // namespace lpslam
+
+struct lpslam_hip_ctx {
+    lpslam_hip_frontend_config cfg{};
+    lpslam::LevelTable lt{};
+    hipStream_t stream = nullptr;
+    size_t image_slab = 0;             // bytes of one image's pyramid (all levels, pitched)
+    int slots_per_image = 0;           // sum(quota+3)
+    int cells_per_image = 0;
+    int cand_per_image = 0;
+
+    uint8_t* d_pyr = nullptr;          // [max_images][image_slab]
+    // resize tables: xofs/yofs (int16) and 11-bit coefficient pairs (int16 x2) per output column/row
+    int16_t* d_rs_ofs = nullptr;
+    int16_t* d_rs_coef = nullptr;
+    // FAST output: per cell fixed slots + counts
+    uint32_t* d_cell_keys = nullptr;   // [max_images][cells_per_image][kCellSlots]  score<<24 | y<<12 | x
+    int32_t* d_cell_count = nullptr;   // [max_images][cells_per_image]
+    // distribution scratch
+    uint32_t* d_cand_key = nullptr;    // [max_images][cand_per_image]
+    uint32_t* d_cand_node = nullptr;   // [max_images][cand_per_image]
+    int32_t* d_cand_count = nullptr;   // [max_images][levels]
+    uint2* d_node_box = nullptr;       // [max_images][levels][2][4*(quota_max+4)]
+    int32_t* d_node_cnt = nullptr;
+    int node_cap = 0;
+    uint32_t* d_sel_key = nullptr;     // [max_images][slots_per_image] selected corners (level slots)
+    int32_t* d_sel_count = nullptr;    // [max_images][levels]
+    // final keypoints
+    lpslam_hip_keypoint* d_kpts = nullptr;  // [max_images][slots_per_image]
+    uint8_t* d_desc = nullptr;              // [max_images][slots_per_image][32]
+    int32_t* d_kp_count = nullptr;          // [max_images]
+    // matching results
+    int32_t* d_bf = nullptr;           // [max_images][3][slots_per_image] best idx, best dist, second dist
+    float* d_stereo = nullptr;         // [max_images][2][slots_per_image] x_right, depth
+    int32_t* d_stereo_idx = nullptr;   // [max_images][slots_per_image]
+    int32_t* d_stereo_corr = nullptr;  // [max_images][slots_per_image]
+    // staging for *_host convenience calls
+    uint8_t* d_tmp_desc = nullptr; size_t tmp_desc_bytes = 0;
+    int32_t* d_tmp_res = nullptr;  size_t tmp_res_bytes = 0;
+    size_t distribute_lds = 0;
+};
+
+// kernel launchers (frontend.hip / match.hip)
+int lp_launch_pyramid(lpslam_hip_ctx* c, int n_images);
+int lp_launch_fast(lpslam_hip_ctx* c, int n_images);
+int lp_launch_distribute(lpslam_hip_ctx* c, int n_images);
+int lp_launch_describe(lpslam_hip_ctx* c, int n_images);
+int lp_launch_bf_strided(lpslam_hip_ctx* c, int q0, int t0, int stride, int n_pairs);
+int lp_launch_stereo_strided(lpslam_hip_ctx* c, int left0, int right0, int stride, int n_pairs, float fxb, float baseline);
+size_t lp_distribute_lds_bytes(int qcap_max, int ncell_max);

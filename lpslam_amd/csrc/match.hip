@@ -1,0 +1,349 @@
+// match.hip -- descriptor matching on gfx950: brute-force Hamming 2-NN and the stereo row-band matcher with SAD
+// sub-pixel refinement.
+//
+// [UPSTREAM] openvslam::match::compute_descriptor_distance_32, match::robust (brute force), match::stereo::compute,
+// reached from the reference through feed_stereo_frame (/root/reference/src/Trackers/OpenVSLAMStereoTracker.cpp:293-295);
+// stereo parameters: focal_x_baseline (src/Trackers/OpenVSLAMTrackerBase.cpp:188-190, src/Interface/LpSlamTypes.h:219-222).
+// Integer work (xor + popcount + argmin) is bit-exact; the few float operations are written without contraction.
+#include "internal.h"
+
+#pragma clang fp contract(off)
+
+using namespace lpslam;
+
+// ------------------------------------------------------------------------------------------------------------
+// K7  brute-force Hamming 2-NN.  Workgroup = 64 queries (one per lane, descriptor in 8 VGPRs) x 4 waves that split
+//     each 256-descriptor LDS tile of the train set; train descriptors are LDS broadcasts (ds_read_b128 x 2).
+//     Integer-VALU bound: 8 v_xor + 8 v_bcnt per pair.  "First minimum wins", second = second smallest distance.
+// ------------------------------------------------------------------------------------------------------------
+#define BF_TILE 256
+
+__global__ __launch_bounds__(256) void k_bf_knn2(const uint8_t* __restrict__ desc, const int32_t* __restrict__ counts,
+                                                 int slots_per_image, int q0, int t0, int stride, int32_t* __restrict__ out)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t tile[BF_TILE * 8];
+    __shared__ int m_best[4][64], m_second[4][64], m_idx[4][64];
+    const int pair = blockIdx.y;
+    const int qs = q0 + pair * stride, ts = t0 + pair * stride;
+    const int nq = counts[qs], nt = counts[ts];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = blockIdx.x * 64 + lane;
+    if (blockIdx.x * 64 >= nq) return;                                  // block-uniform
+    const uint32_t* qd = reinterpret_cast<const uint32_t*>(desc + ((size_t)qs * slots_per_image + min(q, nq - 1)) * 32);
+    uint32_t a[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] = qd[k];
+    const uint32_t* td = reinterpret_cast<const uint32_t*>(desc + (size_t)ts * slots_per_image * 32);
+    int best = 257, second = 257, bidx = -1;
+    for (int base = 0; base < nt; base += BF_TILE) {
+        const int n = min(BF_TILE, nt - base);
+        __syncthreads();
+        for (int i = threadIdx.x; i < n * 8; i += 256) tile[i] = td[(size_t)base * 8 + i];
+        __syncthreads();
+        const int jb = wave * 64, je = min(jb + 64, n);
+        for (int j = jb; j < je; ++j) {
+            const uint4 b0 = *reinterpret_cast<const uint4*>(&tile[j * 8]);
+            const uint4 b1 = *reinterpret_cast<const uint4*>(&tile[j * 8 + 4]);
+            int d = __popc(a[0] ^ b0.x) + __popc(a[1] ^ b0.y) + __popc(a[2] ^ b0.z) + __popc(a[3] ^ b0.w) +
+                    __popc(a[4] ^ b1.x) + __popc(a[5] ^ b1.y) + __popc(a[6] ^ b1.z) + __popc(a[7] ^ b1.w);
+            if (d < best) { second = best; best = d; bidx = base + j; }
+            else if (d < second) second = d;
+        }
+    }
+    m_best[wave][lane] = best; m_second[wave][lane] = second; m_idx[wave][lane] = bidx;
+    __syncthreads();
+    if (wave == 0 && q < nq) {
+        // merge the four partial 2-NN lists: best = smallest (distance, index); second = second smallest distance overall
+        int b = 257, s = 257, bi = -1;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const int wb = m_best[w][lane], ws = m_second[w][lane], wi = m_idx[w][lane];
+            if (wi < 0) continue;
+            if (wb < b || (wb == b && wi < bi)) { s = min(s, b); b = wb; bi = wi; }
+            else s = min(s, wb);
+            s = min(s, ws);
+        }
+        int32_t* o = out + (size_t)qs * 3 * slots_per_image;
+        o[q] = bi; o[slots_per_image + q] = b; o[2 * slots_per_image + q] = s;
+    }
+}
+
+int lp_launch_bf_strided(lpslam_hip_ctx* c, int q0, int t0, int stride, int n_pairs)
+{
+    dim3 grid((c->slots_per_image + 63) / 64, n_pairs);
+    hipLaunchKernelGGL(k_bf_knn2, grid, dim3(256), 0, c->stream, c->d_desc, c->d_kp_count, c->slots_per_image, q0, t0, stride, c->d_bf);
+    LP_HIP(hipGetLastError());
+    return LPSLAM_HIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// K8  stereo matcher: one wavefront per left keypoint.
+//     (1) candidates = right keypoints whose row band [floor(y_r - 2 s_r), ceil(y_r + 2 s_r)] contains (int)y_l,
+//         octave within +-1, x_r in [x_l - max_disp, x_l]; best Hamming < 75, first minimum in index order.
+//     (2) 11x11 SAD (centre-subtracted, L1) over offsets -5..5 at the left keypoint's level, parabola fit.
+//     (3) a second kernel applies the 2 x median correlation cut per image.
+// ------------------------------------------------------------------------------------------------------------
+#define ST_WAVES 4
+
+__global__ __launch_bounds__(64 * ST_WAVES) void k_stereo(const uint8_t* __restrict__ pyr, size_t image_slab, LevelTable lt,
+                                                          const lpslam_hip_keypoint* __restrict__ kpts, const uint8_t* __restrict__ desc,
+                                                          const int32_t* __restrict__ counts, int slots_per_image, int left0, int right0,
+                                                          int stride, float fxb, float max_disp, float* __restrict__ out_f,
+                                                          int32_t* __restrict__ out_idx, int32_t* __restrict__ out_corr)
+{
+    __shared__ uint8_t s_r[ST_WAVES][11 * 24];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int left = left0 + blockIdx.y * stride, right = right0 + blockIdx.y * stride;
+    const int i = blockIdx.x * ST_WAVES + wave;
+    const int nl = counts[left], nr = counts[right];
+    if (i >= nl) return;                                  // wave-uniform
+    const lpslam_hip_keypoint kl = kpts[(size_t)left * slots_per_image + i];
+    const lpslam_hip_keypoint* kr = kpts + (size_t)right * slots_per_image;
+    const uint32_t* dl = reinterpret_cast<const uint32_t*>(desc + ((size_t)left * slots_per_image + i) * 32);
+    const uint8_t* dr = desc + (size_t)right * slots_per_image * 32;
+    float* o_xr = out_f + (size_t)left * 2 * slots_per_image;
+    float* o_depth = o_xr + slots_per_image;
+    int32_t* o_idx = out_idx + (size_t)left * slots_per_image;
+    int32_t* o_corr = out_corr + (size_t)left * slots_per_image;
+
+    uint32_t a[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] = dl[k];
+    const int row = (int)kl.y;
+    const float min_xr = kl.x - max_disp, max_xr = kl.x - 0.0f;
+    unsigned best = 0xFFFFFFFFu;                          // (distance << 16) | index
+    if (!(max_xr < 0)) {
+        for (int j = lane; j < nr; j += 64) {
+            const lpslam_hip_keypoint r = kr[j];
+            const float rad = 2.0f * lt.scale[r.octave];
+            const int max_r = (int)ceilf(r.y + rad), min_r = (int)floorf(r.y - rad);
+            if (row < min_r || row > max_r) continue;
+            if (r.octave < kl.octave - 1 || r.octave > kl.octave + 1) continue;
+            if (r.x < min_xr || max_xr < r.x) continue;
+            const uint32_t* b = reinterpret_cast<const uint32_t*>(dr + (size_t)j * 32);
+            unsigned d = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) d += __popc(a[k] ^ b[k]);
+            best = min(best, (d << 16) | (unsigned)j);
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) best = min(best, (unsigned)__shfl_xor((int)best, o));
+    const unsigned best_d = best >> 16;
+    float res_xr = -1.0f, res_depth = -1.0f;
+    int res_idx = -1, res_corr = -1;
+    if (best != 0xFFFFFFFFu && best_d < 75u) {
+        const int bj = (int)(best & 0xFFFFu);
+        res_idx = bj;
+        const int lvl = kl.octave;
+        const float inv = lt.inv_scale[lvl], sc = lt.scale[lvl];
+        const float x_right = kr[bj].x;
+        const int sxl = (int)rintf(kl.x * inv), syl = (int)rintf(kl.y * inv), sxr = (int)rintf(x_right * inv);
+        const int W = lt.w[lvl], P = lt.pitch[lvl];
+        const int ini_x = sxr - 10, end_x = sxr + 11;
+        if (!(ini_x < 0 || W <= end_x)) {
+            const uint8_t* IL = pyr + (size_t)left * image_slab + lt.off[lvl];
+            const uint8_t* IR = pyr + (size_t)right * image_slab + lt.off[lvl];
+            // right strip 11 rows x 21 cols -> LDS; left patch values in registers (2 per lane)
+            uint8_t* sr = s_r[wave];
+            for (int t = lane; t < 11 * 21; t += 64) { const int r = t / 21, cc = t - r * 21; sr[r * 24 + cc] = IR[(size_t)(syl - 5 + r) * P + sxr - 10 + cc]; }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            const int cl = IL[(size_t)syl * P + sxl];
+            int lv[2], lr[2], lc[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int t = lane + 64 * u;
+                lr[u] = t / 11; lc[u] = t - lr[u] * 11;
+                lv[u] = t < 121 ? (int)IL[(size_t)(syl - 5 + lr[u]) * P + sxl - 5 + lc[u]] - cl : 0;
+            }
+            float corr[11];
+            float best_c = 4294967295.0f;
+            int best_off = 0;
+#pragma unroll
+            for (int off = -5; off <= 5; ++off) {
+                const int cr = sr[5 * 24 + 10 + off];
+                int s = 0;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int t = lane + 64 * u;
+                    if (t < 121) s += abs(lv[u] - ((int)sr[lr[u] * 24 + 5 + off + lc[u]] - cr));
+                }
+                for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+                const float c = (float)s;
+                if (c < best_c) { best_c = c; best_off = off; }
+                corr[off + 5] = c;
+            }
+            if (!(best_off == -5 || best_off == 5)) {
+                float c1 = 0.f, c2 = 0.f, c3 = 0.f;
+#pragma unroll
+                for (int k = 1; k < 10; ++k) if (k == best_off + 5) { c1 = corr[k - 1]; c2 = corr[k]; c3 = corr[k + 1]; }
+                const float x_delta = (float)((double)(c1 - c3) / (2.0 * ((double)(c1 + c3) - 2.0 * (double)c2)));
+                if (!(x_delta < -1.0f || 1.0f < x_delta)) {
+                    float bx = sc * ((float)(sxr + best_off) + x_delta);
+                    float bd = kl.x - bx;
+                    if (!(bd < 0.0f || max_disp <= bd)) {
+                        if (bd <= 0.0f) { bd = 0.01f; bx = kl.x - bd; }
+                        res_xr = bx; res_depth = fxb / bd; res_corr = (int)best_c;
+                    }
+                }
+            }
+        }
+    }
+    if (lane == 0) { o_xr[i] = res_xr; o_depth[i] = res_depth; o_idx[i] = res_idx; o_corr[i] = res_corr; }
+}
+
+// 2 x median cut: sort the correlations of the accepted matches of one image, read the median, invalidate weaker ones
+__global__ __launch_bounds__(1024) void k_stereo_median(const int32_t* __restrict__ counts, int slots_per_image, int left0, int stride,
+                                                        float* __restrict__ out_f, const int32_t* __restrict__ corr, int sortcap)
+{
+    extern __shared__ int keys[];
+    __shared__ int s_n;
+    const int left = left0 + blockIdx.x * stride;
+    const int nl = counts[left];
+    const int32_t* cr = corr + (size_t)left * slots_per_image;
+    float* o_xr = out_f + (size_t)left * 2 * slots_per_image;
+    float* o_depth = o_xr + slots_per_image;
+    const int tid = threadIdx.x;
+    if (tid == 0) s_n = 0;
+    for (int i = tid; i < sortcap; i += 1024) keys[i] = 0x7FFFFFFF;
+    __syncthreads();
+    for (int i = tid; i < nl; i += 1024) if (cr[i] >= 0) keys[atomicAdd(&s_n, 1)] = cr[i];
+    __syncthreads();
+    const int n = s_n;
+    if (n == 0) return;
+    for (int k = 2; k <= sortcap; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < sortcap; i += 1024) {
+                const int p = i ^ j;
+                if (p > i) {
+                    const int x = keys[i], y = keys[p];
+                    const bool asc = (i & k) == 0;
+                    if (asc ? (x > y) : (x < y)) { keys[i] = y; keys[p] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    const float median = (float)keys[n / 2];
+    const float thr = (float)(2.0 * (double)median);
+    for (int i = tid; i < nl; i += 1024)
+        if (cr[i] >= 0 && thr < (float)cr[i]) { o_xr[i] = -1.0f; o_depth[i] = -1.0f; }
+}
+
+int lp_launch_stereo_strided(lpslam_hip_ctx* c, int left0, int right0, int stride, int n_pairs, float fxb, float baseline)
+{
+    const float max_disp = fxb / baseline;
+    dim3 grid((c->slots_per_image + ST_WAVES - 1) / ST_WAVES, n_pairs);
+    hipLaunchKernelGGL(k_stereo, grid, dim3(64 * ST_WAVES), 0, c->stream, c->d_pyr, c->image_slab, c->lt, c->d_kpts, c->d_desc,
+                       c->d_kp_count, c->slots_per_image, left0, right0, stride, fxb, max_disp, c->d_stereo, c->d_stereo_idx,
+                       c->d_stereo_corr);
+    int sortcap = 1; while (sortcap < c->slots_per_image) sortcap <<= 1;
+    hipLaunchKernelGGL(k_stereo_median, dim3(n_pairs), dim3(1024), sortcap * sizeof(int), c->stream, c->d_kp_count,
+                       c->slots_per_image, left0, stride, c->d_stereo, c->d_stereo_corr, sortcap);
+    LP_HIP(hipGetLastError());
+    return LPSLAM_HIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------------------
+extern "C" {
+
+static int chk(lpslam_hip_ctx* c, int a, int b)
+{
+    if (!c) { set_error("null context"); return LPSLAM_HIP_ERR_INVALID; }
+    if (a < 0 || a >= c->cfg.max_images || b < 0 || b >= c->cfg.max_images) {
+        set_error("image slot out of range [0,%d)", c->cfg.max_images); return LPSLAM_HIP_ERR_CAPACITY;
+    }
+    LP_HIP(hipSetDevice(c->cfg.device));
+    return LPSLAM_HIP_OK;
+}
+
+int lpslam_hip_match_bf(lpslam_hip_ctx* c, int query, int train)
+{
+    int rc = chk(c, query, train); if (rc) return rc;
+    return lp_launch_bf_strided(c, query, train, 0, 1);
+}
+
+int lpslam_hip_match_bf_strided(lpslam_hip_ctx* c, int query0, int train0, int stride, int n_pairs)
+{
+    if (n_pairs < 1) { set_error("n_pairs < 1"); return LPSLAM_HIP_ERR_INVALID; }
+    int rc = chk(c, query0, train0); if (rc) return rc;
+    if ((rc = chk(c, query0 + (n_pairs - 1) * stride, train0 + (n_pairs - 1) * stride))) return rc;
+    return lp_launch_bf_strided(c, query0, train0, stride, n_pairs);
+}
+
+int lpslam_hip_get_bf_knn2(lpslam_hip_ctx* c, int query, int32_t* best_idx, int32_t* best_dist, int32_t* second_dist,
+                           int32_t capacity, int32_t* count)
+{
+    int32_t n = 0;
+    int rc = lpslam_hip_keypoint_count(c, query, &n); if (rc) return rc;
+    if (count) *count = n;
+    if (n > capacity) { set_error("result buffer too small (%d < %d)", capacity, n); return LPSLAM_HIP_ERR_CAPACITY; }
+    const int32_t* src = c->d_bf + (size_t)query * 3 * c->slots_per_image;
+    if (n && best_idx) LP_HIP(hipMemcpyAsync(best_idx, src, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    if (n && best_dist) LP_HIP(hipMemcpyAsync(best_dist, src + c->slots_per_image, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    if (n && second_dist) LP_HIP(hipMemcpyAsync(second_dist, src + 2 * c->slots_per_image, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    LP_HIP(hipStreamSynchronize(c->stream));
+    return LPSLAM_HIP_OK;
+}
+
+int lpslam_hip_get_bf_matches(lpslam_hip_ctx* c, int query, int train, int32_t max_dist, float ratio, int32_t cross_check,
+                              int32_t* out_q, int32_t* out_t, int32_t* out_d, int32_t capacity, int32_t* count)
+{
+    int rc = chk(c, query, train); if (rc) return rc;
+    int32_t nq = 0, nt = 0;
+    if ((rc = lpslam_hip_keypoint_count(c, query, &nq))) return rc;
+    if ((rc = lpslam_hip_keypoint_count(c, train, &nt))) return rc;
+    std::vector<int32_t> bi(nq), bd(nq), sd(nq), rbi;
+    if ((rc = lpslam_hip_get_bf_knn2(c, query, bi.data(), bd.data(), sd.data(), nq, nullptr))) return rc;
+    if (cross_check) {       // reverse direction (train -> query) computed on the device as well
+        if ((rc = lp_launch_bf_strided(c, train, query, 0, 1))) return rc;
+        rbi.resize(nt);
+        if ((rc = lpslam_hip_get_bf_knn2(c, train, rbi.data(), nullptr, nullptr, nt, nullptr))) return rc;
+    }
+    int n = 0;
+    for (int i = 0; i < nq; ++i) {
+        if (bi[i] < 0) continue;
+        if (bd[i] > max_dist) continue;
+        if (ratio > 0.f && ratio * (float)sd[i] < (float)bd[i]) continue;
+        if (cross_check && rbi[bi[i]] != i) continue;
+        if (n >= capacity) { set_error("match buffer too small"); return LPSLAM_HIP_ERR_CAPACITY; }
+        out_q[n] = i; out_t[n] = bi[i]; out_d[n] = bd[i]; ++n;
+    }
+    if (count) *count = n;
+    return LPSLAM_HIP_OK;
+}
+
+int lpslam_hip_match_stereo(lpslam_hip_ctx* c, int left, int right, float fxb, float baseline)
+{
+    int rc = chk(c, left, right); if (rc) return rc;
+    if (!(baseline > 0.f) || !(fxb > 0.f)) { set_error("focal_x_baseline and baseline must be positive"); return LPSLAM_HIP_ERR_INVALID; }
+    return lp_launch_stereo_strided(c, left, right, 0, 1, fxb, baseline);
+}
+
+int lpslam_hip_match_stereo_strided(lpslam_hip_ctx* c, int left0, int right0, int stride, int n_pairs, float fxb, float baseline)
+{
+    if (n_pairs < 1) { set_error("n_pairs < 1"); return LPSLAM_HIP_ERR_INVALID; }
+    int rc = chk(c, left0, right0); if (rc) return rc;
+    if ((rc = chk(c, left0 + (n_pairs - 1) * stride, right0 + (n_pairs - 1) * stride))) return rc;
+    if (!(baseline > 0.f) || !(fxb > 0.f)) { set_error("focal_x_baseline and baseline must be positive"); return LPSLAM_HIP_ERR_INVALID; }
+    return lp_launch_stereo_strided(c, left0, right0, stride, n_pairs, fxb, baseline);
+}
+
+int lpslam_hip_get_stereo(lpslam_hip_ctx* c, int left, float* stereo_x_right, float* depths, int32_t* best_right_idx,
+                          int32_t capacity, int32_t* count)
+{
+    int32_t n = 0;
+    int rc = lpslam_hip_keypoint_count(c, left, &n); if (rc) return rc;
+    if (count) *count = n;
+    if (n > capacity) { set_error("result buffer too small (%d < %d)", capacity, n); return LPSLAM_HIP_ERR_CAPACITY; }
+    const float* f = c->d_stereo + (size_t)left * 2 * c->slots_per_image;
+    if (n && stereo_x_right) LP_HIP(hipMemcpyAsync(stereo_x_right, f, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    if (n && depths) LP_HIP(hipMemcpyAsync(depths, f + c->slots_per_image, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    if (n && best_right_idx) LP_HIP(hipMemcpyAsync(best_right_idx, c->d_stereo_idx + (size_t)left * c->slots_per_image, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    LP_HIP(hipStreamSynchronize(c->stream));
+    return LPSLAM_HIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,188 @@
+"""ctypes binding of the C ABI in include/lpslam_hip.h (lpslam_amd/liblpslam_hip.so).
+
+This is the thin Python face of the HIP library used by the tests and bench.py; the product's host side is the
+C++ mirror of the reference interface in lpslam_amd/host/.  There is no CPU fallback: a missing library or a
+missing GPU raises.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblpslam_hip.so")
+MAX_LEVELS = 16
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                     ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+CORNER_DTYPE = np.dtype([("x", "<i4"), ("y", "<i4"), ("score", "<i4")])
+BA_OBS_DTYPE = np.dtype([("pose", "<i4"), ("point", "<i4"), ("u", "<f8"), ("v", "<f8"), ("ur", "<f8"),
+                         ("inv_sigma2", "<f8")])
+BA_LOG_DTYPE = np.dtype([("chi2_before", "<f8"), ("chi2_after", "<f8"), ("lambda", "<f8"),
+                         ("trials", "<i4"), ("status", "<i4")])
+
+# every symbol include/lpslam_hip.h declares (checked by tests/test_abi.py against the header text)
+SYMBOLS = [
+    "lpslam_hip_last_error", "lpslam_hip_device_count", "lpslam_hip_create", "lpslam_hip_destroy",
+    "lpslam_hip_stream", "lpslam_hip_sync", "lpslam_hip_level_info", "lpslam_hip_max_keypoints_per_image",
+    "lpslam_hip_image_ptr", "lpslam_hip_upload_image", "lpslam_hip_extract", "lpslam_hip_stage_pyramid",
+    "lpslam_hip_stage_fast", "lpslam_hip_stage_distribute", "lpslam_hip_stage_describe",
+    "lpslam_hip_keypoint_count", "lpslam_hip_get_keypoints", "lpslam_hip_get_pyramid_level",
+    "lpslam_hip_get_candidates", "lpslam_hip_keypoint_buffers", "lpslam_hip_match_bf", "lpslam_hip_get_bf_knn2",
+    "lpslam_hip_get_bf_matches", "lpslam_hip_match_bf_strided", "lpslam_hip_set_descriptors",
+    "lpslam_hip_match_stereo", "lpslam_hip_match_stereo_strided", "lpslam_hip_get_stereo",
+]
+
+
+class LpslamHipError(RuntimeError):
+    pass
+
+
+class FrontendConfig(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("max_keypoints", C.c_int32),
+                ("scale_factor", C.c_float), ("num_levels", C.c_int32), ("ini_fast_threshold", C.c_int32),
+                ("min_fast_threshold", C.c_int32), ("max_images", C.c_int32), ("device", C.c_int32)]
+
+
+class BaCamera(C.Structure):
+    _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
+                ("focal_x_baseline", C.c_double), ("huber_mono", C.c_double), ("huber_stereo", C.c_double)]
+
+
+_lib = None
+
+
+def load():
+    """Loads the in-tree HIP library; raises if it has not been built (no silent fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise LpslamHipError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                                 "(hipcc --offload-arch=gfx950); the lpslam hot path has no CPU fallback" % LIB_PATH)
+        _lib = C.CDLL(LIB_PATH)
+        _lib.lpslam_hip_last_error.restype = C.c_char_p
+        _lib.lpslam_hip_stream.restype = C.c_void_p
+        _lib.lpslam_hip_stream.argtypes = [C.c_void_p]
+        for name in ("lpslam_hip_match_stereo",):
+            getattr(_lib, name).argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float]
+        _lib.lpslam_hip_match_stereo_strided.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float]
+        _lib.lpslam_hip_get_bf_matches.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int32, C.c_float, C.c_int32,
+                                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise LpslamHipError("lpslam_hip error %d: %s" % (rc, load().lpslam_hip_last_error().decode()))
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def device_count():
+    n = C.c_int(0)
+    rc = load().lpslam_hip_device_count(C.byref(n))
+    return n.value if rc == 0 else 0
+
+
+class Context:
+    """One front-end context = one GPU, one stream, `max_images` resident image slots."""
+
+    def __init__(self, width, height, max_keypoints=2000, scale_factor=1.2, num_levels=8, ini_thr=20, min_thr=7,
+                 max_images=2, device=0):
+        self.lib = load()
+        self.cfg = FrontendConfig(width, height, max_keypoints, scale_factor, num_levels, ini_thr, min_thr, max_images, device)
+        h = C.c_void_p()
+        _check(self.lib.lpslam_hip_create(C.byref(self.cfg), C.byref(h)))
+        self.h = h
+        self.max_kp = self.lib.lpslam_hip_max_keypoints_per_image(self.h)
+        L = num_levels
+        w = (C.c_int32 * MAX_LEVELS)(); hh = (C.c_int32 * MAX_LEVELS)(); p = (C.c_int32 * MAX_LEVELS)()
+        q = (C.c_int32 * MAX_LEVELS)(); s = (C.c_float * MAX_LEVELS)()
+        _check(self.lib.lpslam_hip_level_info(self.h, w, hh, p, q, s))
+        self.level_w, self.level_h, self.level_pitch = list(w[:L]), list(hh[:L]), list(p[:L])
+        self.quota, self.scale = list(q[:L]), list(s[:L])
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.lpslam_hip_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    @property
+    def stream(self):
+        return self.lib.lpslam_hip_stream(self.h)
+
+    def sync(self):
+        _check(self.lib.lpslam_hip_sync(self.h))
+
+    def image_ptr(self, image):
+        ptr = C.c_void_p(); pitch = C.c_int32()
+        _check(self.lib.lpslam_hip_image_ptr(self.h, image, C.byref(ptr), C.byref(pitch)))
+        return ptr.value, pitch.value
+
+    def upload(self, image, arr):
+        arr = np.ascontiguousarray(arr, np.uint8)
+        assert arr.shape == (self.cfg.height, self.cfg.width), arr.shape
+        _check(self.lib.lpslam_hip_upload_image(self.h, image, _p(arr), arr.shape[1]))
+        self.sync()      # host array may be freed by the caller
+
+    def extract(self, n_images):
+        _check(self.lib.lpslam_hip_extract(self.h, n_images))
+
+    def stage(self, name, n_images):
+        _check(getattr(self.lib, "lpslam_hip_stage_" + name)(self.h, n_images))
+
+    def keypoints(self, image):
+        kp = np.zeros(self.max_kp, KP_DTYPE); desc = np.zeros((self.max_kp, 32), np.uint8)
+        n = C.c_int32()
+        _check(self.lib.lpslam_hip_get_keypoints(self.h, image, _p(kp), _p(desc), self.max_kp, C.byref(n)))
+        return kp[:n.value].copy(), desc[:n.value].copy()
+
+    def pyramid_level(self, image, level):
+        out = np.zeros((self.level_h[level], self.level_w[level]), np.uint8)
+        _check(self.lib.lpslam_hip_get_pyramid_level(self.h, image, level, _p(out), out.shape[1]))
+        return out
+
+    def candidates(self, image, level):
+        n = C.c_int32()
+        _check(self.lib.lpslam_hip_get_candidates(self.h, image, level, None, 0, C.byref(n)))
+        out = np.zeros(max(n.value, 1), CORNER_DTYPE)
+        _check(self.lib.lpslam_hip_get_candidates(self.h, image, level, _p(out), len(out), C.byref(n)))
+        return out[:n.value].copy()
+
+    def set_descriptors(self, image, desc):
+        desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        _check(self.lib.lpslam_hip_set_descriptors(self.h, image, _p(desc), len(desc)))
+
+    def match_bf(self, query, train):
+        _check(self.lib.lpslam_hip_match_bf(self.h, query, train))
+
+    def match_bf_strided(self, q0, t0, stride, n):
+        _check(self.lib.lpslam_hip_match_bf_strided(self.h, q0, t0, stride, n))
+
+    def bf_knn2(self, query):
+        bi = np.zeros(self.max_kp, np.int32); bd = np.zeros(self.max_kp, np.int32); sd = np.zeros(self.max_kp, np.int32)
+        n = C.c_int32()
+        _check(self.lib.lpslam_hip_get_bf_knn2(self.h, query, _p(bi), _p(bd), _p(sd), self.max_kp, C.byref(n)))
+        return bi[:n.value].copy(), bd[:n.value].copy(), sd[:n.value].copy()
+
+    def bf_matches(self, query, train, max_dist=50, ratio=0.0, cross_check=False):
+        oq = np.zeros(self.max_kp, np.int32); ot = np.zeros(self.max_kp, np.int32); od = np.zeros(self.max_kp, np.int32)
+        n = C.c_int32()
+        _check(self.lib.lpslam_hip_get_bf_matches(self.h, query, train, int(max_dist), float(ratio), int(cross_check),
+                                                  _p(oq), _p(ot), _p(od), self.max_kp, C.addressof(n)))
+        return oq[:n.value].copy(), ot[:n.value].copy(), od[:n.value].copy()
+
+    def match_stereo(self, left, right, fxb, baseline):
+        _check(self.lib.lpslam_hip_match_stereo(self.h, left, right, float(fxb), float(baseline)))
+
+    def match_stereo_strided(self, l0, r0, stride, n, fxb, baseline):
+        _check(self.lib.lpslam_hip_match_stereo_strided(self.h, l0, r0, stride, n, float(fxb), float(baseline)))
+
+    def stereo(self, left):
+        xr = np.zeros(self.max_kp, np.float32); dep = np.zeros(self.max_kp, np.float32); bi = np.zeros(self.max_kp, np.int32)
+        n = C.c_int32()
+        _check(self.lib.lpslam_hip_get_stereo(self.h, left, _p(xr), _p(dep), _p(bi), self.max_kp, C.byref(n)))
+        return xr[:n.value].copy(), dep[:n.value].copy(), bi[:n.value].copy()
