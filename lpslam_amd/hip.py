@@ -30,6 +30,9 @@ SYMBOLS = [
     "lpslam_hip_get_candidates", "lpslam_hip_keypoint_buffers", "lpslam_hip_match_bf", "lpslam_hip_get_bf_knn2",
     "lpslam_hip_get_bf_matches", "lpslam_hip_match_bf_strided", "lpslam_hip_set_descriptors",
     "lpslam_hip_match_stereo", "lpslam_hip_match_stereo_strided", "lpslam_hip_get_stereo",
+    "lpslam_hip_ba_create", "lpslam_hip_ba_destroy", "lpslam_hip_ba_set_active", "lpslam_hip_ba_optimize",
+    "lpslam_hip_ba_local", "lpslam_hip_ba_get", "lpslam_hip_ba_chi2", "lpslam_hip_ba_reduced_buffer",
+    "lpslam_hip_ba_step_begin", "lpslam_hip_ba_step_solve", "lpslam_hip_ba_scalar_buffer", "lpslam_hip_ba_step_end",
 ]
 
 
@@ -186,3 +189,59 @@ class Context:
         n = C.c_int32()
         _check(self.lib.lpslam_hip_get_stereo(self.h, left, _p(xr), _p(dep), _p(bi), self.max_kp, C.byref(n)))
         return xr[:n.value].copy(), dep[:n.value].copy(), bi[:n.value].copy()
+
+
+class BundleAdjuster:
+    """Device-resident bundle-adjustment problem (lpslam_hip_ba_*)."""
+
+    def __init__(self, ctx, poses, fixed, points, obs, cam, robust_kernel=True):
+        self.ctx = ctx
+        self.lib = ctx.lib
+        poses = np.ascontiguousarray(poses, np.float64); points = np.ascontiguousarray(points, np.float64)
+        fixed = np.ascontiguousarray(fixed, np.uint8); obs = np.ascontiguousarray(obs, BA_OBS_DTYPE)
+        self.n_poses, self.n_points, self.n_obs = len(poses), len(points), len(obs)
+        c = BaCamera(cam["fx"], cam["fy"], cam["cx"], cam["cy"], cam["fxb"],
+                     float(np.sqrt(5.991)) if robust_kernel else 0.0, float(np.sqrt(7.815)) if robust_kernel else 0.0)
+        h = C.c_void_p()
+        _check(self.lib.lpslam_hip_ba_create(ctx.h, _p(poses), _p(fixed), self.n_poses, _p(points), self.n_points,
+                                             _p(obs), self.n_obs, C.byref(c), C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.lpslam_hip_ba_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def set_active(self, active=None):
+        a = np.ascontiguousarray(active, np.uint8) if active is not None else None
+        _check(self.lib.lpslam_hip_ba_set_active(self.h, _p(a)))
+
+    def optimize(self, robust=True, iters=10):
+        log = np.zeros(max(iters, 1), BA_LOG_DTYPE); done = C.c_int32()
+        _check(self.lib.lpslam_hip_ba_optimize(self.h, int(robust), int(iters), _p(log), C.byref(done)))
+        return log[:done.value].copy()
+
+    def local(self, first=5, second=10):
+        out = np.zeros(max(self.n_obs, 1), np.uint8)
+        _check(self.lib.lpslam_hip_ba_local(self.h, int(first), int(second), _p(out)))
+        return out[:self.n_obs]
+
+    def state(self):
+        poses = np.zeros((self.n_poses, 7)); points = np.zeros((self.n_points, 3))
+        _check(self.lib.lpslam_hip_ba_get(self.h, _p(poses), _p(points)))
+        return poses, points
+
+    def chi2(self):
+        chi = np.zeros(max(self.n_obs, 1)); pos = np.zeros(max(self.n_obs, 1), np.uint8)
+        _check(self.lib.lpslam_hip_ba_chi2(self.h, _p(chi), _p(pos)))
+        return chi[:self.n_obs], pos[:self.n_obs]
+
+
+def ba_obs_array(prob):
+    o = np.zeros(len(prob["obs_pose"]), BA_OBS_DTYPE)
+    o["pose"] = prob["obs_pose"]; o["point"] = prob["obs_point"]
+    o["u"] = prob["obs_uvr"][:, 0]; o["v"] = prob["obs_uvr"][:, 1]; o["ur"] = prob["obs_uvr"][:, 2]
+    o["inv_sigma2"] = prob["obs_inv_sigma2"]
+    return o
