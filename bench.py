@@ -1,0 +1,231 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the lpslam hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1] + configs[2], the configuration the metric is quoted on): 1280x720 stereo,
+2000 keypoints / image, 8 pyramid levels.  One "step" = one keyframe interval of the path:
+    6 stereo frames: ORB extraction of 12 images, 6 stereo matches, 6 temporal brute-force matches (2000 x 2000),
+    1 local bundle adjustment: 50 keyframes / 5000 landmarks / ~40k stereo observations, 10 LM iterations (Huber).
+Inputs (frames, BA problem) are synthetic and resident in HBM before the timed region.
+value = frames/s over the whole job (all ranks); N > 1 runs one independent sequence per GPU (replicas, no data-path
+collective, "weak" scaling).  The JSON line also carries the roofline of the dominant front-end kernel (HIP-event
+timed on the stream it runs on) and the CPU oracle timed on a bounded sample (rank 0, N = 1).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+W, H, KPTS, LEVELS = 1280, 720, 2000, 8
+FRAMES_PER_STEP = 6
+BA_KF, BA_PTS, BA_OBS, BA_ITERS = 50, 5000, 40000, 10
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 measured copy)
+
+# timer slots
+T_PYR, T_FAST, T_DIST, T_DESC, T_STEREO, T_BF, T_BA = range(7)
+STAGE_NAMES = ["pyramid", "fast", "distribute", "describe", "stereo", "bf", "ba"]
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=FRAMES_PER_STEP, help="stereo frames per step")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-ba", action="store_true", help="front end only (BASELINE configs[1])")
+    return ap.parse_args()
+
+
+class Workload:
+    def __init__(self, device, seq_id, frames, with_ba=True):
+        from lpslam_amd import hip, synth
+        self.hip, self.synth = hip, synth
+        self.F = frames
+        self.k = synth.intrinsics(W, H)
+        self.ctx = hip.Context(W, H, KPTS, 1.2, LEVELS, max_images=2 * frames, device=device)
+        seq = synth.StereoSequence(W, H, seq_id)
+        self.host_frames = [seq.frame(i) for i in range(frames)]
+        for i, (l, r) in enumerate(self.host_frames):
+            self.ctx.upload(2 * i, l); self.ctx.upload(2 * i + 1, r)
+        self.ba = None
+        if with_ba:
+            self.prob = synth.ba_problem(BA_KF, BA_PTS, BA_OBS, W, H, seq_id)
+            self.ba = hip.BundleAdjuster(self.ctx, self.prob["poses"], self.prob["fixed"], self.prob["points"],
+                                         hip.ba_obs_array(self.prob), self.prob["cam"])
+        self.ctx.sync()
+
+    def step(self, timers=False):
+        c, F = self.ctx, self.F
+        if not timers:
+            c.extract(2 * F)
+            c.match_stereo_strided(0, 1, 2, F, self.k["fxb"], self.k["baseline"])
+            if F > 1:
+                c.match_bf_strided(2, 0, 2, F - 1)
+            c.match_bf(0, 2 * F - 2)              # first frame of this interval against the last of the previous one
+            if self.ba is not None:
+                self.ba.reset()
+                self.ba.optimize(True, BA_ITERS)
+            return
+        for slot, stage in ((T_PYR, "pyramid"), (T_FAST, "fast"), (T_DIST, "distribute"), (T_DESC, "describe")):
+            c.timer_begin(slot); c.stage(stage, 2 * F); c.timer_end(slot)
+        c.timer_begin(T_STEREO); c.match_stereo_strided(0, 1, 2, F, self.k["fxb"], self.k["baseline"]); c.timer_end(T_STEREO)
+        c.timer_begin(T_BF)
+        if F > 1:
+            c.match_bf_strided(2, 0, 2, F - 1)
+        c.match_bf(0, 2 * F - 2)
+        c.timer_end(T_BF)
+        if self.ba is not None:
+            c.timer_begin(T_BA); self.ba.reset(); self.ba.optimize(True, BA_ITERS); c.timer_end(T_BA)
+
+    def algorithmic_bytes(self):
+        """per-image pass-structured bytes of each front-end kernel group."""
+        P = [w * h for w, h in zip(self.ctx.level_w, self.ctx.level_h)]
+        Psum = sum(P)
+        n_img = 2 * self.F
+        K = KPTS
+        return {
+            "pyramid": n_img * ((Psum - P[-1]) + (Psum - P[0])),
+            "fast": n_img * Psum,
+            "describe": n_img * (2 * K * 31 * 31 + K * 60),
+        }
+
+
+def cpu_baseline(frames_sample=12, ba_solves=2):
+    """Oracle (CPU restatement, 1 thread, -O3 without -march=native) on a bounded sample of the same workload."""
+    from oracle import oracle as O
+    from lpslam_amd import synth
+    p = O.params(KPTS, 1.2, LEVELS)
+    seq = synth.StereoSequence(W, H, 0)
+    k = synth.intrinsics(W, H)
+    frames = [seq.frame(i) for i in range(frames_sample)]
+    prob = synth.ba_problem(BA_KF, BA_PTS, BA_OBS, W, H, 0)
+    obs = O.ba_obs(prob)
+    t0 = time.perf_counter()
+    prev = None
+    for l, r in frames:
+        kl, dl, _, pl = O.extract(l, p, True)
+        kr, dr, _, pr = O.extract(r, p, True)
+        O.match_stereo(pl, pr, p, kl, dl, kr, dr, k["fxb"], k["baseline"])
+        if prev is not None:
+            O.match_bf_knn2(dl, prev)
+        else:
+            O.match_bf_knn2(dl, dl)
+        prev = dl
+    t_front = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for _ in range(ba_solves):
+        O.ba_optimize(prob["poses"], prob["fixed"], prob["points"], obs, prob["cam"], True, BA_ITERS)
+    t_ba = (time.perf_counter() - t0) / ba_solves
+    per_frame = t_front / frames_sample + t_ba / FRAMES_PER_STEP
+    return {"value": round(1.0 / per_frame, 3), "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": "%d stereo frames (extract L+R, stereo match, 2000x2000 BF) + %d local-BA solves of %d LM iterations "
+                      "amortised 1 per %d frames; single thread" % (frames_sample, ba_solves, BA_ITERS, FRAMES_PER_STEP),
+            "front_end_ms_per_frame": round(1e3 * t_front / frames_sample, 2), "ba_ms_per_iter": round(1e3 * t_ba / BA_ITERS, 3)}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    from lpslam_amd import hip
+    if hip.device_count() < 1:
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+
+    wl = Workload(local_rank, rank, args.frames, with_ba=not args.no_ba)
+
+    def barrier():
+        wl.ctx.sync()
+        if dist is not None:
+            import torch
+            t = torch.zeros(1, device="cuda")
+            dist.all_reduce(t)
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        wl.step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        wl.step()
+    wl.ctx.sync()
+    elapsed = time.perf_counter() - t0
+    barrier()
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # instrumented pass (same steps, HIP events around every stage on the context stream)
+    stage_ms = np.zeros(len(STAGE_NAMES))
+    n_inst = max(3, min(args.steps, 10))
+    for _ in range(n_inst):
+        wl.step(timers=True)
+        wl.ctx.sync()
+        for s in range(len(STAGE_NAMES)):
+            if s == T_BA and wl.ba is None:
+                continue
+            stage_ms[s] += wl.ctx.timer_ms(s)
+    stage_ms /= n_inst
+
+    # PCIe-inclusive rate (host frames uploaded inside the loop) -- reported beside, never as `value`
+    t1 = time.perf_counter()
+    n_pcie = max(2, min(args.steps, 5))
+    for _ in range(n_pcie):
+        for i, (l, r) in enumerate(wl.host_frames):
+            wl.ctx.upload(2 * i, l); wl.ctx.upload(2 * i + 1, r)
+        wl.step()
+    wl.ctx.sync()
+    pcie_fps = n_pcie * args.frames / (time.perf_counter() - t1)
+
+    if rank == 0:
+        frames_total = world * args.frames * args.steps
+        value = frames_total / elapsed
+        ab = wl.algorithmic_bytes()
+        dom = max(ab.keys(), key=lambda k_: stage_ms[STAGE_NAMES.index(k_)])
+        dom_ms = stage_ms[STAGE_NAMES.index(dom)]
+        launches = {"pyramid": LEVELS - 1, "fast": 1, "describe": 1}[dom]
+        achieved = ab[dom] / (dom_ms * 1e-3) / 1e9
+        out = {
+            "metric": "frames/sec (ORB+match+local-BA), 1280x720 stereo",
+            "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8 front end / f64 BA", "data": "synthetic",
+            "config": {"workload": "configs[1]+configs[2]: 1280x720 stereo, 2000 kpts, 8 levels; step = %d stereo frames "
+                                   "(extract L+R, stereo match, 2000x2000 BF temporal match) + one 50-KF/5k-landmark/%d-obs "
+                                   "local BA of %d LM iterations" % (args.frames, wl.ba.n_obs if wl.ba else 0, BA_ITERS),
+                       "frames_per_step": args.frames, "replicas": world, "parallelism": "replicas x%d" % world},
+            "ba_ms_per_iter": round(stage_ms[T_BA] / BA_ITERS, 4) if wl.ba is not None else None,
+            "roofline": {"bound": "hbm", "kernel": dom, "launches_per_step": launches,
+                         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "algorithmic_bytes_per_step": int(ab[dom]), "avg_ms_per_step": round(float(dom_ms), 4)},
+            "stage_ms_per_step": {n: round(float(v), 4) for n, v in zip(STAGE_NAMES, stage_ms)},
+            "pcie_inclusive_frames_per_s": round(pcie_fps, 2),
+        }
+        if world == 1 and not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline()
+            out["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 2)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -77,6 +77,13 @@ int lpslam_hip_level_info(lpslam_hip_ctx* ctx, int32_t* widths, int32_t* heights
 /* Upper bound of keypoints one image can yield (sum of quota+3 over levels). */
 int lpslam_hip_max_keypoints_per_image(lpslam_hip_ctx* ctx);
 
+/* Event timers on the context stream (HIP events; used by bench.py to time individual kernels in place). */
+#define LPSLAM_HIP_MAX_TIMERS 64
+int lpslam_hip_timer_begin(lpslam_hip_ctx* ctx, int slot);
+int lpslam_hip_timer_end(lpslam_hip_ctx* ctx, int slot);
+/* Waits for the end event of `slot` and returns the elapsed milliseconds. */
+int lpslam_hip_timer_read(lpslam_hip_ctx* ctx, int slot, float* ms);
+
 /* ---- frames: images resident in HBM --------------------------------------------------------------------- */
 /* Device address and row pitch of level 0 of image slot `image` (write frames there directly, e.g. from a
  * capture DMA or another kernel), or upload from host memory (tightly packed rows of `stride` bytes). */
@@ -161,6 +168,8 @@ int lpslam_hip_ba_optimize(lpslam_hip_ba* ba, int32_t robust, int32_t iters, lps
                            int32_t* done);
 /* local_bundle_adjuster flow: first_iters robust, outlier classification, second_iters plain. */
 int lpslam_hip_ba_local(lpslam_hip_ba* ba, int32_t first_iters, int32_t second_iters, uint8_t* outlier);
+/* Restores the poses / points / activity mask given at creation (kept in HBM) and clears the LM state. */
+int lpslam_hip_ba_reset(lpslam_hip_ba* ba);
 int lpslam_hip_ba_get(lpslam_hip_ba* ba, double* poses, double* points);
 int lpslam_hip_ba_chi2(lpslam_hip_ba* ba, double* chi2, uint8_t* depth_positive);
 

@@ -220,11 +220,40 @@ void lpslam_hip_destroy(lpslam_hip_ctx* c)
                     c->d_cand_count, c->d_node_box, c->d_node_cnt, c->d_sel_key, c->d_sel_count, c->d_kpts, c->d_desc,
                     c->d_kp_count, c->d_bf, c->d_stereo, c->d_stereo_idx, c->d_stereo_corr, c->d_tmp_desc, c->d_tmp_res};
     for (void* b : bufs) if (b) (void)hipFree(b);
+    for (int i = 0; i < LPSLAM_HIP_MAX_TIMERS; ++i) { if (c->ev_begin[i]) (void)hipEventDestroy(c->ev_begin[i]); if (c->ev_end[i]) (void)hipEventDestroy(c->ev_end[i]); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
 
 void* lpslam_hip_stream(lpslam_hip_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+static int timer_slot(lpslam_hip_ctx* c, int slot)
+{
+    if (!c) { set_error("null context"); return LPSLAM_HIP_ERR_INVALID; }
+    if (slot < 0 || slot >= LPSLAM_HIP_MAX_TIMERS) { set_error("timer slot %d out of range", slot); return LPSLAM_HIP_ERR_INVALID; }
+    if (!c->ev_begin[slot]) { LP_HIP(hipEventCreate(&c->ev_begin[slot])); LP_HIP(hipEventCreate(&c->ev_end[slot])); }
+    return LPSLAM_HIP_OK;
+}
+int lpslam_hip_timer_begin(lpslam_hip_ctx* c, int slot)
+{
+    int rc = timer_slot(c, slot); if (rc) return rc;
+    LP_HIP(hipEventRecord(c->ev_begin[slot], c->stream));
+    return LPSLAM_HIP_OK;
+}
+int lpslam_hip_timer_end(lpslam_hip_ctx* c, int slot)
+{
+    int rc = timer_slot(c, slot); if (rc) return rc;
+    LP_HIP(hipEventRecord(c->ev_end[slot], c->stream));
+    return LPSLAM_HIP_OK;
+}
+int lpslam_hip_timer_read(lpslam_hip_ctx* c, int slot, float* ms)
+{
+    int rc = timer_slot(c, slot); if (rc) return rc;
+    if (!ms) { set_error("null argument"); return LPSLAM_HIP_ERR_INVALID; }
+    LP_HIP(hipEventSynchronize(c->ev_end[slot]));
+    LP_HIP(hipEventElapsedTime(ms, c->ev_begin[slot], c->ev_end[slot]));
+    return LPSLAM_HIP_OK;
+}
 
 int lpslam_hip_sync(lpslam_hip_ctx* c)
 {

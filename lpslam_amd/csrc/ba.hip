@@ -580,6 +580,7 @@ struct lpslam_hip_ba {
     int n_poses = 0, n_points = 0, n_obs = 0, n_free = 0, dim = 0, dim_pad = 0, n_blocks = 0;
     int cur = 0;                                  // index of the accepted state
     double *d_poses[2] = {nullptr, nullptr}, *d_points[2] = {nullptr, nullptr};
+    double *d_poses0 = nullptr, *d_points0 = nullptr;      // state given at creation (lpslam_hip_ba_reset)
     int *d_pose_slot = nullptr, *d_free_pose = nullptr, *d_o_pose = nullptr, *d_o_point = nullptr;
     double *d_o_u = nullptr, *d_o_v = nullptr, *d_o_ur = nullptr, *d_o_w = nullptr;
     uint8_t* d_o_active = nullptr;
@@ -817,6 +818,11 @@ int lpslam_hip_ba_create(lpslam_hip_ctx* ctx, const double* poses, const uint8_t
         (n_points && hipMemcpy(b->d_points[0], points, 3 * (size_t)n_points * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)) {
         set_error("state upload failed"); return fail(LPSLAM_HIP_ERR_DEVICE);
     }
+    BA_TRY(dalloc(b, &b->d_poses0, 7 * (size_t)n_poses)); BA_TRY(dalloc(b, &b->d_points0, 3 * (size_t)n_points));
+    if (hipMemcpy(b->d_poses0, poses, 7 * (size_t)n_poses * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
+        (n_points && hipMemcpy(b->d_points0, points, 3 * (size_t)n_points * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)) {
+        set_error("state upload failed"); return fail(LPSLAM_HIP_ERR_DEVICE);
+    }
     BA_TRY(dalloc(b, &b->d_W, 18 * (size_t)n_obs)); BA_TRY(dalloc(b, &b->d_Y, 18 * (size_t)n_obs)); BA_TRY(dalloc(b, &b->d_Ybl, 6 * (size_t)n_obs));
     BA_TRY(dalloc(b, &b->d_Hll, 6 * (size_t)n_points)); BA_TRY(dalloc(b, &b->d_bl, 3 * (size_t)n_points)); BA_TRY(dalloc(b, &b->d_Hinv, 6 * (size_t)n_points));
     BA_TRY(dalloc(b, &b->d_Hpp, 36 * (size_t)b->n_free));
@@ -953,6 +959,16 @@ int lpslam_hip_ba_optimize(lpslam_hip_ba* b, int32_t robust, int32_t iters, lpsl
         if (terminate) { ++it; break; }
     }
     if (done_out) *done_out = it;
+    return LPSLAM_HIP_OK;
+}
+
+int lpslam_hip_ba_reset(lpslam_hip_ba* b)
+{
+    if (!b) { set_error("null problem"); return LPSLAM_HIP_ERR_INVALID; }
+    b->cur = 0; b->lambda = 0; b->ni = 2; b->qmax = 0; b->rho = 0;
+    LP_HIP(hipMemcpyAsync(b->d_poses[0], b->d_poses0, 7 * (size_t)b->n_poses * sizeof(double), hipMemcpyDeviceToDevice, b->stream));
+    if (b->n_points) LP_HIP(hipMemcpyAsync(b->d_points[0], b->d_points0, 3 * (size_t)b->n_points * sizeof(double), hipMemcpyDeviceToDevice, b->stream));
+    if (b->n_obs) LP_HIP(hipMemsetAsync(b->d_o_active, 1, b->n_obs, b->stream));
     return LPSLAM_HIP_OK;
 }
 

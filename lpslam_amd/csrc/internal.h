@@ -83,6 +83,7 @@ struct lpslam_hip_ctx {
     uint8_t* d_tmp_desc = nullptr; size_t tmp_desc_bytes = 0;
     int32_t* d_tmp_res = nullptr;  size_t tmp_res_bytes = 0;
     size_t distribute_lds = 0;
+    hipEvent_t ev_begin[LPSLAM_HIP_MAX_TIMERS] = {}, ev_end[LPSLAM_HIP_MAX_TIMERS] = {};
 };
 
 // kernel launchers (frontend.hip / match.hip)

@@ -23,7 +23,7 @@ BA_LOG_DTYPE = np.dtype([("chi2_before", "<f8"), ("chi2_after", "<f8"), ("lambda
 # every symbol include/lpslam_hip.h declares (checked by tests/test_abi.py against the header text)
 SYMBOLS = [
     "lpslam_hip_last_error", "lpslam_hip_device_count", "lpslam_hip_create", "lpslam_hip_destroy",
-    "lpslam_hip_stream", "lpslam_hip_sync", "lpslam_hip_level_info", "lpslam_hip_max_keypoints_per_image",
+    "lpslam_hip_stream", "lpslam_hip_sync", "lpslam_hip_timer_begin", "lpslam_hip_timer_end", "lpslam_hip_timer_read", "lpslam_hip_level_info", "lpslam_hip_max_keypoints_per_image",
     "lpslam_hip_image_ptr", "lpslam_hip_upload_image", "lpslam_hip_extract", "lpslam_hip_stage_pyramid",
     "lpslam_hip_stage_fast", "lpslam_hip_stage_distribute", "lpslam_hip_stage_describe",
     "lpslam_hip_keypoint_count", "lpslam_hip_get_keypoints", "lpslam_hip_get_pyramid_level",
@@ -31,7 +31,7 @@ SYMBOLS = [
     "lpslam_hip_get_bf_matches", "lpslam_hip_match_bf_strided", "lpslam_hip_set_descriptors",
     "lpslam_hip_match_stereo", "lpslam_hip_match_stereo_strided", "lpslam_hip_get_stereo",
     "lpslam_hip_ba_create", "lpslam_hip_ba_destroy", "lpslam_hip_ba_set_active", "lpslam_hip_ba_optimize",
-    "lpslam_hip_ba_local", "lpslam_hip_ba_get", "lpslam_hip_ba_chi2", "lpslam_hip_ba_reduced_buffer",
+    "lpslam_hip_ba_local", "lpslam_hip_ba_reset", "lpslam_hip_ba_get", "lpslam_hip_ba_chi2", "lpslam_hip_ba_reduced_buffer",
     "lpslam_hip_ba_step_begin", "lpslam_hip_ba_step_solve", "lpslam_hip_ba_scalar_buffer", "lpslam_hip_ba_step_end",
 ]
 
@@ -119,6 +119,17 @@ class Context:
 
     def sync(self):
         _check(self.lib.lpslam_hip_sync(self.h))
+
+    def timer_begin(self, slot):
+        _check(self.lib.lpslam_hip_timer_begin(self.h, slot))
+
+    def timer_end(self, slot):
+        _check(self.lib.lpslam_hip_timer_end(self.h, slot))
+
+    def timer_ms(self, slot):
+        ms = C.c_float()
+        _check(self.lib.lpslam_hip_timer_read(self.h, slot, C.byref(ms)))
+        return ms.value
 
     def image_ptr(self, image):
         ptr = C.c_void_p(); pitch = C.c_int32()
@@ -222,6 +233,9 @@ class BundleAdjuster:
         log = np.zeros(max(iters, 1), BA_LOG_DTYPE); done = C.c_int32()
         _check(self.lib.lpslam_hip_ba_optimize(self.h, int(robust), int(iters), _p(log), C.byref(done)))
         return log[:done.value].copy()
+
+    def reset(self):
+        _check(self.lib.lpslam_hip_ba_reset(self.h))
 
     def local(self, first=5, second=10):
         out = np.zeros(max(self.n_obs, 1), np.uint8)

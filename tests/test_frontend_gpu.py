@@ -1,0 +1,122 @@
+"""GPU parity tests of the ORB front end, through the C ABI, against the CPU oracle and the golden fixtures.
+Bar: bit-exact pyramid bytes, FAST candidates (x, y, score, order), keypoint fields and descriptors."""
+import numpy as np
+import pytest
+
+from conftest import golden
+from lpslam_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _assert_same_keypoints(okp, od, gkp, gd):
+    assert len(okp) == len(gkp)
+    for f in okp.dtype.names:
+        assert np.array_equal(okp[f], gkp[f]), "keypoint field %s" % f
+    assert np.array_equal(od, gd)
+
+
+def _run(hiplib, img, kpts, levels, scale=1.2, ini=20, mn=7):
+    h, w = img.shape
+    ctx = hiplib.Context(w, h, kpts, scale, levels, ini, mn, max_images=1)
+    ctx.upload(0, img)
+    ctx.extract(1)
+    return ctx
+
+
+@pytest.mark.parametrize("w,h,kpts,levels", [(160, 120, 150, 3), (333, 251, 400, 4), (640, 480, 1000, 8), (1280, 720, 2000, 8)])
+def test_extract_parity(hiplib, oracle, w, h, kpts, levels):
+    img = synth.random_image(w, h, seed=w)
+    p = oracle.params(kpts, 1.2, levels)
+    okp, od, occ, opyr = oracle.extract(img, p, True)
+    ctx = _run(hiplib, img, kpts, levels)
+    for l in range(levels):
+        assert np.array_equal(ctx.pyramid_level(0, l), opyr[l]), "pyramid level %d" % l
+        oc = oracle.fast_level(opyr[l])
+        gc = ctx.candidates(0, l)
+        assert len(gc) == occ[l] == len(oc)
+        assert np.array_equal(oc, gc), "FAST candidates level %d" % l
+    gkp, gd = ctx.keypoints(0)
+    _assert_same_keypoints(okp, od, gkp, gd)
+    assert len(gkp) >= min(kpts, 50)
+
+
+def test_golden_vectors(hiplib):
+    g = golden("g3_orb.npz")
+    ctx = _run(hiplib, g["image"], 150, 3)
+    kp, desc = ctx.keypoints(0)
+    for f in ("x", "y", "size", "angle", "response", "octave"):
+        assert np.array_equal(kp[f], g[f]), f
+    assert np.array_equal(desc, g["desc"])
+    c = ctx.candidates(0, 0)
+    g2 = golden("g2_fast.npz")
+    assert np.array_equal(c["x"], g2["x"]) and np.array_equal(c["y"], g2["y"]) and np.array_equal(c["score"], g2["score"])
+    g1 = golden("g1_pyramid.npz")
+    ctx1 = _run(hiplib, g1["image"], 60, 3)
+    assert np.array_equal(ctx1.pyramid_level(0, 1), g1["level1"]) and np.array_equal(ctx1.pyramid_level(0, 2), g1["level2"])
+
+
+def test_blank_and_weak_images(hiplib, oracle):
+    flat = np.full((240, 320), 100, np.uint8)
+    ctx = _run(hiplib, flat, 300, 4)
+    kp, desc = ctx.keypoints(0)
+    assert len(kp) == 0 and len(desc) == 0
+    yy, xx = np.mgrid[0:240, 0:320]
+    weak = flat.copy(); weak[100:, 150:] = 112
+    weak = (weak + (xx * 7 + yy * 13) % 3).astype(np.uint8)           # only min-threshold corners exist
+    okp, od, _, _ = oracle.extract(weak, oracle.params(300, 1.2, 4))
+    ctx = _run(hiplib, weak, 300, 4)
+    gkp, gd = ctx.keypoints(0)
+    assert len(okp) > 0 and (okp["response"] < 20).all()
+    _assert_same_keypoints(okp, od, gkp, gd)
+
+
+@pytest.mark.parametrize("ini,mn,scale,levels,kpts", [(30, 5, 1.2, 5, 700), (12, 12, 1.5, 3, 1200), (20, 7, 1.2, 1, 500)])
+def test_parameter_variants(hiplib, oracle, ini, mn, scale, levels, kpts):
+    """Feature.* are runtime parameters: reference default is 3 levels / 1200 keypoints."""
+    img = synth.random_image(480, 360, seed=77)
+    okp, od, _, _ = oracle.extract(img, oracle.params(kpts, scale, levels, ini, mn))
+    ctx = _run(hiplib, img, kpts, levels, scale, ini, mn)
+    gkp, gd = ctx.keypoints(0)
+    _assert_same_keypoints(okp, od, gkp, gd)
+
+
+def test_batch_of_images_and_slots(hiplib, oracle):
+    """A batch is processed in one set of launches; every image slot gives what it gives alone."""
+    w, h, kpts, levels, n = 320, 240, 400, 4, 6
+    seq = synth.StereoSequence(w, h, 9, n_points=1500)
+    imgs = [im for k in range(n // 2) for im in seq.frame(k)]
+    ctx = hiplib.Context(w, h, kpts, 1.2, levels, max_images=n)
+    for i, im in enumerate(imgs):
+        ctx.upload(i, im)
+    ctx.extract(n)
+    p = oracle.params(kpts, 1.2, levels)
+    for i, im in enumerate(imgs):
+        okp, od, _, _ = oracle.extract(im, p)
+        gkp, gd = ctx.keypoints(i)
+        _assert_same_keypoints(okp, od, gkp, gd)
+    with pytest.raises(hiplib.LpslamHipError):
+        ctx.extract(n + 1)
+
+
+def test_full_size_properties(hiplib):
+    """1280x720 / 2000 keypoints (BASELINE configs[1]): size-independent invariants of the result."""
+    seq = synth.StereoSequence(1280, 720, 1)
+    l, r = seq.frame(3)
+    ctx = hiplib.Context(1280, 720, 2000, 1.2, 8, max_images=2)
+    ctx.upload(0, l); ctx.upload(1, r)
+    ctx.extract(2)
+    kp, desc = ctx.keypoints(0)
+    assert 2000 <= len(kp) <= 2000 + 3 * 8
+    assert (np.diff(kp["octave"]) >= 0).all()                      # levels are emitted in order
+    quota = ctx.quota
+    counts = np.bincount(kp["octave"], minlength=8)
+    assert all(q <= c <= q + 3 for q, c in zip(quota, counts))
+    sc = np.array(ctx.scale)[kp["octave"]]
+    assert (kp["x"] >= 22 * sc - 1e-3).all() and (kp["x"] <= (np.array(ctx.level_w)[kp["octave"]] - 23) * sc + 1e-3).all()
+    assert (kp["angle"] >= 0).all() and (kp["angle"] < 360).all() and (kp["response"] >= 7).all()
+    assert len({(a, b, c) for a, b, c in zip(kp["x"], kp["y"], kp["octave"])}) == len(kp)     # no duplicates
+    # idempotence: a second extraction of the same resident frame gives the same bytes
+    ctx.extract(2)
+    kp2, desc2 = ctx.keypoints(0)
+    assert np.array_equal(kp, kp2) and np.array_equal(desc, desc2)

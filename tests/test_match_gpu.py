@@ -1,0 +1,103 @@
+"""GPU parity tests of the matchers (bit-exact index / distance / depth results)."""
+import numpy as np
+import pytest
+
+from conftest import golden
+from lpslam_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx(hiplib):
+    return hiplib.Context(320, 240, 400, 1.2, 4, max_images=4)
+
+
+def test_bf_golden(ctx, oracle):
+    g = golden("g4_bf.npz")
+    ctx.set_descriptors(0, g["q"]); ctx.set_descriptors(1, g["t"])
+    ctx.match_bf(0, 1)
+    bi, bd, sd = ctx.bf_knn2(0)
+    assert np.array_equal(bi, g["best_idx"]) and np.array_equal(bd, g["best_dist"]) and np.array_equal(sd, g["second_dist"])
+    mq, mt, md = ctx.bf_matches(0, 1, 50, 0.9, True)
+    assert np.array_equal(mq, g["mq"]) and np.array_equal(mt, g["mt"]) and np.array_equal(md, g["md"])
+
+
+@pytest.mark.parametrize("nq,nt", [(1, 1), (63, 65), (64, 256), (257, 300), (421, 421), (5, 0), (0, 7)])
+def test_bf_ragged_sizes(ctx, oracle, nq, nt):
+    rng = np.random.default_rng(nq * 1000 + nt)
+    q = rng.integers(0, 256, (nq, 32), dtype=np.uint8); t = rng.integers(0, 256, (nt, 32), dtype=np.uint8)
+    if nq > 3 and nt > 3:
+        t[1] = t[2]; q[0] = t[2]; q[3] = q[0]                       # exact ties: first minimum must win
+    ctx.set_descriptors(2, q); ctx.set_descriptors(3, t)
+    ctx.match_bf(2, 3)
+    g = ctx.bf_knn2(2)
+    o = oracle.match_bf_knn2(q, t)
+    assert all(np.array_equal(a, b) for a, b in zip(o, g))
+
+
+def test_bf_symmetry_property(hiplib):
+    """Full-size 2000 x 2000: distance symmetry d(q,t)=d(t,q) and self-match distance 0."""
+    c = hiplib.Context(1280, 720, 2000, 1.2, 8, max_images=2)
+    rng = np.random.default_rng(5)
+    a = rng.integers(0, 256, (2000, 32), dtype=np.uint8); b = rng.integers(0, 256, (2000, 32), dtype=np.uint8)
+    c.set_descriptors(0, a); c.set_descriptors(1, b)
+    c.match_bf(0, 1); c.match_bf(1, 0)
+    ia, da, _ = c.bf_knn2(0); ib, db, _ = c.bf_knn2(1)
+    assert da.min() == db.min()
+    mutual = ib[ia] == np.arange(2000)
+    assert (db[ia][mutual] == da[mutual]).all()
+    c.match_bf(0, 0)
+    i0, d0, s0 = c.bf_knn2(0)
+    assert (d0 == 0).all() and (i0 == np.arange(2000)).all() and (s0 > 0).all()
+
+
+def test_stereo_golden_and_oracle(hiplib, oracle):
+    g = golden("g6_stereo.npz")
+    c = hiplib.Context(320, 240, 400, 1.2, 4, max_images=2)
+    c.upload(0, g["left"]); c.upload(1, g["right"])
+    c.extract(2)
+    k = synth.intrinsics(320, 240)
+    c.match_stereo(0, 1, k["fxb"], k["baseline"])
+    xr, dep, bi = c.stereo(0)
+    assert np.array_equal(xr, g["x_right"]) and np.array_equal(dep, g["depth"]) and np.array_equal(bi, g["best_idx"])
+
+
+def test_stereo_full_size(hiplib, oracle):
+    seq = synth.StereoSequence(1280, 720, 2)
+    l, r = seq.frame(1)
+    p = oracle.params(2000, 1.2, 8)
+    kl, dl, _, pl = oracle.extract(l, p, True); kr, dr, _, pr = oracle.extract(r, p, True)
+    k = synth.intrinsics(1280, 720)
+    oxr, odep, obi, nv = oracle.match_stereo(pl, pr, p, kl, dl, kr, dr, k["fxb"], k["baseline"])
+    c = hiplib.Context(1280, 720, 2000, 1.2, 8, max_images=4)
+    c.upload(2, l); c.upload(3, r)                                  # non-zero slots
+    c.upload(0, r); c.upload(1, l)
+    c.extract(4)
+    c.match_stereo_strided(0, 1, 2, 2, k["fxb"], k["baseline"])
+    xr, dep, bi = c.stereo(2)
+    assert np.array_equal(xr, oxr) and np.array_equal(dep, odep) and np.array_equal(bi, obi)
+    ok = dep > 0
+    assert ok.sum() == nv and ok.sum() > 100
+    assert (xr[ok] <= kl["x"][ok]).all()                            # positive disparity
+    # swapped pair (right as left): disparities are negative, nothing may survive the range test with depth > 0 ... mostly
+    xr2, dep2, _ = c.stereo(0)
+    assert (dep2 > 0).sum() < ok.sum()
+
+
+def test_temporal_match_batch(hiplib, oracle):
+    w, h, F = 320, 240, 4
+    seq = synth.StereoSequence(w, h, 5, n_points=1500)
+    c = hiplib.Context(w, h, 400, 1.2, 4, max_images=2 * F)
+    p = oracle.params(400, 1.2, 4)
+    descs = []
+    for f in range(F):
+        l, r = seq.frame(f)
+        c.upload(2 * f, l); c.upload(2 * f + 1, r)
+        descs.append(oracle.extract(l, p)[1])
+    c.extract(2 * F)
+    c.match_bf_strided(2, 0, 2, F - 1)
+    for f in range(1, F):
+        g = c.bf_knn2(2 * f)
+        o = oracle.match_bf_knn2(descs[f], descs[f - 1])
+        assert all(np.array_equal(a, b) for a, b in zip(o, g))

@@ -1,0 +1,267 @@
+"""CPU tests of the oracle: golden vectors (tests/golden, made by tools/make_golden.py) and independent
+cross-checks of every building block against plain numpy/scipy restatements of the published definitions.
+The reference has no fixtures for this path (parity unpinned)."""
+import numpy as np
+import pytest
+
+from conftest import golden
+from lpslam_amd import synth
+
+
+def test_geometry_matches_survey(oracle):
+    p = oracle.params(2000, 1.2, 8)
+    lw, lh = oracle.pyramid_sizes(1280, 720, p)
+    assert lw == [1280, 1067, 889, 741, 617, 514, 429, 357]
+    assert lh == [720, 600, 500, 417, 347, 289, 241, 201]
+    assert oracle.keypts_per_level(p) == [434, 362, 302, 251, 209, 175, 145, 122]
+    assert sum(oracle.keypts_per_level(p)) == 2000
+
+
+def test_golden_pyramid(oracle):
+    g = golden("g1_pyramid.npz")
+    p = oracle.params(60, 1.2, 3)
+    lw, lh = oracle.pyramid_sizes(96, 96, p)
+    l1 = oracle.resize(g["image"], lw[1], lh[1])
+    l2 = oracle.resize(l1, lw[2], lh[2])
+    assert np.array_equal(l1, g["level1"]) and np.array_equal(l2, g["level2"])
+
+
+def test_resize_close_to_float_bilinear(oracle):
+    img = synth.random_image(200, 150, seed=3)
+    dw, dh = 167, 125
+    out = oracle.resize(img, dw, dh).astype(np.float64)
+    sx, sy = 200 / dw, 150 / dh
+    xs = np.clip((np.arange(dw) + 0.5) * sx - 0.5, 0, 199); ys = np.clip((np.arange(dh) + 0.5) * sy - 0.5, 0, 149)
+    x0 = np.floor(xs).astype(int); y0 = np.floor(ys).astype(int)
+    x1 = np.minimum(x0 + 1, 199); y1 = np.minimum(y0 + 1, 149)
+    fx = (xs - x0)[None, :]; fy = (ys - y0)[:, None]
+    f = img.astype(np.float64)
+    ref = (f[y0][:, x0] * (1 - fx) + f[y0][:, x1] * fx) * (1 - fy) + (f[y1][:, x0] * (1 - fx) + f[y1][:, x1] * fx) * fy
+    assert np.abs(out - ref).max() <= 1.0
+
+
+def _is_fast_corner(img, x, y, t):
+    ring = [(0, 3), (1, 3), (2, 2), (3, 1), (3, 0), (3, -1), (2, -2), (1, -3), (0, -3), (-1, -3), (-2, -2), (-3, -1),
+            (-3, 0), (-3, 1), (-2, 2), (-1, 3)]
+    v = int(img[y, x])
+    vals = [int(img[y + dy, x + dx]) for dx, dy in ring]
+    for sign in (1, -1):
+        flags = [(sign * (v - p)) > t for p in vals]
+        ff = flags + flags
+        run = 0
+        for b in ff:
+            run = run + 1 if b else 0
+            if run >= 9:
+                return True
+    return False
+
+
+def test_fast_matches_definition(oracle):
+    img = synth.random_image(70, 70, seed=5)
+    got = oracle.fast(img, 20, nms=False)
+    got_set = {(int(c["x"]), int(c["y"])) for c in got}
+    ref = {(x, y) for y in range(3, 67) for x in range(3, 67) if _is_fast_corner(img, x, y, 20)}
+    assert got_set == ref and len(ref) > 5
+    # score = largest threshold for which the pixel is still a corner
+    for c in got[:40]:
+        s = int(c["score"])
+        assert _is_fast_corner(img, c["x"], c["y"], s) and not _is_fast_corner(img, c["x"], c["y"], s + 1)
+
+
+def test_fast_nms_strict(oracle):
+    img = synth.random_image(70, 70, seed=6)
+    allc = oracle.fast(img, 7, nms=False); kept = oracle.fast(img, 7, nms=True)
+    score = np.zeros((70, 70), int)
+    for c in allc:
+        score[c["y"], c["x"]] = c["score"]
+    ref = []
+    for c in allc:
+        x, y, s = c["x"], c["y"], c["score"]
+        nb = score[y - 1:y + 2, x - 1:x + 2].copy(); nb[1, 1] = -1
+        if s > nb.max():
+            ref.append((x, y, s))
+    assert [(c["x"], c["y"], c["score"]) for c in kept] == ref
+
+
+def test_golden_fast_level(oracle):
+    g = golden("g2_fast.npz")
+    c = oracle.fast_level(g["image"], 20, 7)
+    assert np.array_equal(c["x"], g["x"]) and np.array_equal(c["y"], g["y"]) and np.array_equal(c["score"], g["score"])
+
+
+def test_fast_level_empty_and_fallback(oracle):
+    flat = np.full((120, 160), 100, np.uint8)
+    assert len(oracle.fast_level(flat)) == 0
+    weak = flat.copy(); weak[60:, 80:] = 112          # a 12-level step: invisible at 20, a corner at 7
+    yy, xx = np.mgrid[0:120, 0:160]
+    weak = (weak + (xx * 7 + yy * 13) % 3).astype(np.uint8)           # break score plateaus (strict NMS)
+    c = oracle.fast_level(weak, 20, 7)
+    assert len(c) > 0 and (c["score"] < 20).all()
+
+
+def test_distribute_properties(oracle):
+    img = synth.random_image(320, 240, seed=8)
+    c = oracle.fast_level(img)
+    for quota in (1, 7, 50, 200):
+        sel = oracle.distribute(c, 320, 240, quota)
+        assert len(set(sel.tolist())) == len(sel)
+        assert quota <= len(sel) <= max(quota + 3, 8) or len(sel) == len(c)
+    far = c[[0, len(c) // 2, len(c) - 1]]                      # fewer, well separated candidates than the quota: all kept
+    assert sorted(oracle.distribute(far, 320, 240, 50).tolist()) == [0, 1, 2]
+    # upstream stops as soon as a pass creates no new node: neighbours sharing one quadrant collapse to the best one
+    near = far[[0, 0, 0]].copy(); near["x"] += [0, 1, 0]; near["y"] += [0, 0, 1]; near["score"] = [10, 30, 20]
+    assert oracle.distribute(near, 320, 240, 50).tolist() == [1]
+    assert len(oracle.distribute(c[:0], 320, 240, 50)) == 0
+
+
+def test_gauss_close_to_float(oracle):
+    from scipy import ndimage
+    img = synth.random_image(96, 80, seed=9)
+    out = oracle.gauss7(img).astype(np.float64)
+    k = np.exp(-np.arange(-3, 4) ** 2 / 8.0); k /= k.sum()
+    ref = ndimage.correlate1d(ndimage.correlate1d(img.astype(np.float64), k, axis=1, mode="mirror"), k, axis=0, mode="mirror")
+    assert np.abs(out - ref).max() <= 2.0
+    assert oracle.gauss7(np.full((40, 40), 77, np.uint8)).min() == 77     # weights sum to exactly 1
+
+
+def test_atan2_and_sincos(oracle):
+    rng = np.random.default_rng(1)
+    for _ in range(200):
+        y, x = rng.normal(size=2) * 1000
+        ref = np.degrees(np.arctan2(y, x)) % 360
+        got = oracle.lib().ora_fast_atan2(np.float32(y), np.float32(x))
+        assert abs((got - ref + 180) % 360 - 180) < 0.3
+    for a in np.linspace(0, 360, 721):
+        s, c = oracle.sincos_deg(a)
+        r = np.radians(np.float64(np.float32(a)))
+        assert abs(s - np.sin(r)) < 7e-8 and abs(c - np.cos(r)) < 7e-8        # float rounding of the exact value
+
+
+def test_ic_angle_follows_gradient(oracle):
+    yy, xx = np.mgrid[0:64, 0:64]
+    img = np.clip(100 + 3 * (xx - 32), 0, 255).astype(np.uint8)       # brighter to the right -> 0 degrees
+    assert min(oracle.ic_angle(img, 32, 32), 360 - oracle.ic_angle(img, 32, 32)) < 1.0
+    assert abs(oracle.ic_angle(img.T.copy(), 32, 32) - 90) < 1.0        # brighter downwards -> 90 degrees
+
+
+def test_golden_orb(oracle):
+    g = golden("g3_orb.npz")
+    kp, desc, cc, _ = oracle.extract(g["image"], oracle.params(150, 1.2, 3))
+    for f in ("x", "y", "size", "angle", "response", "octave"):
+        assert np.array_equal(kp[f], g[f]), f
+    assert np.array_equal(desc, g["desc"]) and np.array_equal(cc, g["cand_count"])
+
+
+def test_descriptor_rotation_invariance(oracle):
+    """A keypoint's descriptor on a 90-degree rotated image stays close (rBRIEF steers by the patch orientation)."""
+    img = synth.random_image(200, 200, seed=21)
+    p = oracle.params(120, 1.2, 1)
+    k0, d0, _, _ = oracle.extract(img, p)
+    rot = np.ascontiguousarray(np.rot90(img))                         # (x, y) -> (y, W-1-x)
+    k1, d1, _, _ = oracle.extract(rot, p)
+    pos1 = {(int(a["x"]), int(a["y"])): i for i, a in enumerate(k1)}
+    dists = []
+    for i, a in enumerate(k0):
+        j = pos1.get((int(a["y"]), 199 - int(a["x"])))
+        if j is not None:
+            dists.append(int(np.unpackbits(d0[i] ^ d1[j]).sum()))
+    assert len(dists) > 30 and np.median(dists) < 40
+
+
+def test_hamming_and_golden_bf(oracle):
+    g = golden("g4_bf.npz")
+    q, t = g["q"], g["t"]
+    d = np.unpackbits(q[:, None, :] ^ t[None, :, :], axis=2).sum(axis=2)
+    bi, bd, sd = oracle.match_bf_knn2(q, t)
+    assert np.array_equal(bi, d.argmin(axis=1)) and np.array_equal(bd, d.min(axis=1))
+    assert np.array_equal(sd, np.sort(d, axis=1)[:, 1])
+    assert np.array_equal(bi, g["best_idx"]) and np.array_equal(bd, g["best_dist"]) and np.array_equal(sd, g["second_dist"])
+    mq, mt, md = oracle.match_bf(q, t, 50, 0.9, True)
+    assert np.array_equal(mq, g["mq"]) and np.array_equal(mt, g["mt"]) and np.array_equal(md, g["md"])
+    e = oracle.match_bf_knn2(q[:0], t)
+    assert len(e[0]) == 0
+    bi0, bd0, sd0 = oracle.match_bf_knn2(q, t[:0])
+    assert (bi0 == -1).all() and (bd0 == 257).all()
+
+
+def test_golden_stereo_and_depth_truth(oracle):
+    g = golden("g6_stereo.npz")
+    p = oracle.params(400, 1.2, 4)
+    kl, dl, _, pl = oracle.extract(g["left"], p, True)
+    kr, dr, _, pr = oracle.extract(g["right"], p, True)
+    k = synth.intrinsics(320, 240)
+    xr, dep, bi, nv = oracle.match_stereo(pl, pr, p, kl, dl, kr, dr, k["fxb"], k["baseline"])
+    assert np.array_equal(xr, g["x_right"]) and np.array_equal(dep, g["depth"]) and np.array_equal(bi, g["best_idx"])
+    ok = dep > 0
+    assert ok.sum() > 30
+    disp = kl["x"][ok] - xr[ok]
+    assert np.allclose(dep[ok], k["fxb"] / disp, rtol=1e-5) and (disp > 0).all()
+
+
+def test_golden_ba(oracle):
+    g = golden("g5_ba.npz")
+    cam = dict(zip(("fx", "fy", "cx", "cy", "fxb"), g["cam"]))
+    obs = np.zeros(len(g["obs_pose"]), oracle.OBS_DTYPE)
+    obs["pose"] = g["obs_pose"]; obs["point"] = g["obs_point"]; obs["u"] = g["obs_uvr"][:, 0]; obs["v"] = g["obs_uvr"][:, 1]
+    obs["ur"] = g["obs_uvr"][:, 2]; obs["inv_sigma2"] = g["obs_inv_sigma2"]
+    poses, points, log = oracle.ba_optimize(g["poses0"], g["fixed"], g["points0"], obs, cam, True, 10)
+    assert np.allclose(log["chi2_after"], g["chi2_after"], rtol=1e-12) and np.array_equal(log["trials"], g["trials"])
+    assert np.allclose(poses, g["poses"], atol=1e-12) and np.allclose(points, g["points"], atol=1e-10)
+    assert (np.diff(np.r_[log["chi2_before"][0], log["chi2_after"]]) <= 0).all()
+
+
+def test_ba_jacobians_by_finite_differences(oracle):
+    """One Gauss-Newton step with lambda ~ 0 on a noise-free, slightly perturbed problem must land on the optimum:
+    this only holds if residual and analytic Jacobians (sign conventions of SURVEY.md section 8(a)) are consistent."""
+    prob = synth.ba_problem(5, 80, 320, 640, 480, seq_id=2, pose_noise=(1e-3, 1e-2), point_noise=1e-2, pix_noise=0.0)
+    obs = oracle.ba_obs(prob)
+    chi0, _ = oracle.ba_chi2(prob["poses"], prob["points"], obs, prob["cam"])
+    poses, points, log = oracle.ba_optimize(prob["poses"], prob["fixed"], prob["points"], obs, prob["cam"], False, 8)
+    chi1, pos = oracle.ba_chi2(poses, points, obs, prob["cam"])
+    assert chi0.sum() > 1.0 and chi1.sum() < 1e-5 * chi0.sum() and pos.all()
+    # every damped Gauss-Newton step is accepted and contracts strongly: needs residual-consistent Jacobians
+    assert (log["trials"] == 1).all() and log["chi2_after"][2] < 1e-4 * log["chi2_before"][0]
+
+
+def test_ba_matches_scipy_least_squares(oracle):
+    from scipy.optimize import least_squares
+    prob = synth.ba_problem(3, 25, 70, 640, 480, seq_id=4, pose_noise=(2e-3, 1e-2), point_noise=1e-2)
+    obs = oracle.ba_obs(prob)
+    cam = prob["cam"]
+    poses, points, log = oracle.ba_optimize(prob["poses"], prob["fixed"], prob["points"], obs, cam, False, 60)
+
+    def unpack(x):
+        P = prob["poses"].copy(); P[1:] = x[:14].reshape(2, 7); P[1:, :4] /= np.linalg.norm(P[1:, :4], axis=1, keepdims=True)
+        return P, x[14:].reshape(-1, 3)
+
+    def resid(x):        # independent numpy restatement of the stereo reprojection residual
+        P, X = unpack(x)
+        q = P[obs["pose"], :4]; t = P[obs["pose"], 4:]
+        w, qx, qy, qz = q.T
+        R = np.stack([1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - w * qz), 2 * (qx * qz + w * qy),
+                      2 * (qx * qy + w * qz), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - w * qx),
+                      2 * (qx * qz - w * qy), 2 * (qy * qz + w * qx), 1 - 2 * (qx * qx + qy * qy)], axis=1).reshape(-1, 3, 3)
+        pc = np.einsum("nij,nj->ni", R, X[obs["point"]]) + t
+        u = cam["fx"] * pc[:, 0] / pc[:, 2] + cam["cx"]; v = cam["fy"] * pc[:, 1] / pc[:, 2] + cam["cy"]
+        ur = u - cam["fxb"] / pc[:, 2]
+        sw = np.sqrt(obs["inv_sigma2"])
+        return np.r_[(obs["u"] - u) * sw, (obs["v"] - v) * sw, (obs["ur"] - ur) * sw]
+    # start MINPACK's LM at the oracle's answer: an independent optimiser must not find a lower cost nearby
+    x0 = np.r_[poses[1:].ravel(), points.ravel()]
+    assert abs(resid(x0).dot(resid(x0)) - log["chi2_after"][-1]) < 1e-9 * log["chi2_after"][-1]
+    sol = least_squares(resid, x0, method="lm", max_nfev=4000)
+    assert 2 * sol.cost > log["chi2_after"][-1] * (1 - 1e-5)
+    assert log["chi2_after"][-1] < 0.5 * log["chi2_before"][0]
+
+
+def test_ba_local_and_pose_optimizer(oracle):
+    prob = synth.ba_problem(6, 150, 700, 640, 480, seq_id=7)
+    obs = oracle.ba_obs(prob)
+    bad = np.arange(0, len(obs), 37)
+    obs["u"][bad] += 40.0                                              # gross outliers
+    poses, points, out = oracle.ba_local(prob["poses"], prob["fixed"], prob["points"], obs, prob["cam"])
+    assert out[bad].mean() > 0.9 and out.mean() < 0.3
+    # motion-only: recover one keyframe's pose from the ground-truth landmarks
+    sel = obs[obs["pose"] == 3].copy(); sel["pose"] = 0
+    pose, outl, n_in = oracle.pose_optimize(prob["poses"][3], prob["points_gt"], sel, prob["cam"])
+    assert np.abs(pose[4:] - prob["poses_gt"][3, 4:]).max() < 0.05 and n_in > 0.6 * len(sel)
