@@ -158,11 +158,12 @@ def ba_problem(n_kf=50, n_points=5000, n_obs=40000, width=1280, height=720, seq_
             v = k["fy"] * pc[:, 1] / z + k["cy"]
         vis[:, i] = (z > 1.0) & (z < 40.0) & (u >= 20) & (u < width - 20) & (v >= 20) & (v < height - 20)
         uvs[:, i, 0] = u; uvs[:, i, 1] = v; uvs[:, i, 2] = u - k["fxb"] / np.where(z > 0, z, 1)
-    good = np.nonzero(vis.sum(1) >= 3)[0]
+    min_views = min(3, n_kf)
+    good = np.nonzero(vis.sum(1) >= min_views)[0]
     if len(good) < n_points:
         raise RuntimeError("not enough visible landmarks: %d" % len(good))
     good = good[:n_points]
-    cap = max(3, int(math.ceil(n_obs / n_points)))
+    cap = max(min_views, int(math.ceil(n_obs / n_points)))
     obs = []
     for pi, ci in enumerate(good):
         kfs = np.nonzero(vis[ci])[0]
@@ -180,7 +181,7 @@ def ba_problem(n_kf=50, n_points=5000, n_obs=40000, width=1280, height=720, seq_
             if excess == 0:
                 break
             p = obs[j, 1]
-            if counts[p] > 3:
+            if counts[p] > min_views:
                 counts[p] -= 1; keep[j] = False; excess -= 1
         obs = obs[keep]
     obs = obs[np.lexsort((obs[:, 0], obs[:, 1]))]      # by landmark, then by keyframe

@@ -23,7 +23,7 @@ def test_bf_golden(ctx, oracle):
     assert np.array_equal(mq, g["mq"]) and np.array_equal(mt, g["mt"]) and np.array_equal(md, g["md"])
 
 
-@pytest.mark.parametrize("nq,nt", [(1, 1), (63, 65), (64, 256), (257, 300), (421, 421), (5, 0), (0, 7)])
+@pytest.mark.parametrize("nq,nt", [(1, 1), (63, 65), (64, 256), (257, 300), (411, 412), (5, 0), (0, 7)])
 def test_bf_ragged_sizes(ctx, oracle, nq, nt):
     rng = np.random.default_rng(nq * 1000 + nt)
     q = rng.integers(0, 256, (nq, 32), dtype=np.uint8); t = rng.integers(0, 256, (nt, 32), dtype=np.uint8)
