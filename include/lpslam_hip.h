@@ -94,6 +94,8 @@ int lpslam_hip_upload_image(lpslam_hip_ctx* ctx, int image, const uint8_t* host,
 /* pyramid -> FAST (64-px cells, ini/min threshold) -> quad-tree distribution -> orientation + rBRIEF,
  * for image slots [0, n_images). */
 int lpslam_hip_extract(lpslam_hip_ctx* ctx, int n_images);
+/* Same for image slots [first, first + n_images): lets a tracker keep the previous frame resident (ping-pong). */
+int lpslam_hip_extract_range(lpslam_hip_ctx* ctx, int first, int n_images);
 /* Individual stages (lpslam_hip_extract = these four in order); exposed for profiling and parity tests. */
 int lpslam_hip_stage_pyramid(lpslam_hip_ctx* ctx, int n_images);
 int lpslam_hip_stage_fast(lpslam_hip_ctx* ctx, int n_images);
@@ -166,6 +168,12 @@ int lpslam_hip_ba_set_active(lpslam_hip_ba* ba, const uint8_t* active);
  * 1e-5 max diag H, rho-controlled lambda, <= 10 trials).  log may be NULL.  Returns iterations run in *done. */
 int lpslam_hip_ba_optimize(lpslam_hip_ba* ba, int32_t robust, int32_t iters, lpslam_hip_ba_iter_log* log,
                            int32_t* done);
+/* Motion-only mode: landmarks are held fixed (unary edges), only the free poses move. */
+int lpslam_hip_ba_set_points_fixed(lpslam_hip_ba* ba, int32_t points_fixed);
+/* optimize::pose_optimizer flow on a problem created with ONE free pose: 4 rounds x 10 iterations, outliers
+ * (chi2 > 5.991 mono / 7.815 stereo) re-classified after every round, Huber dropped after the third round.
+ * outlier may be NULL; *n_inliers receives the number of inlier observations. */
+int lpslam_hip_ba_pose_optimize(lpslam_hip_ba* ba, uint8_t* outlier, int32_t* n_inliers);
 /* local_bundle_adjuster flow: first_iters robust, outlier classification, second_iters plain. */
 int lpslam_hip_ba_local(lpslam_hip_ba* ba, int32_t first_iters, int32_t second_iters, uint8_t* outlier);
 /* Restores the poses / points / activity mask given at creation (kept in HBM) and clears the LM state. */

@@ -26,5 +26,27 @@ def hip_library(force=False, verbose=False):
     return LIB
 
 
+HOST_LIB = os.path.join(HERE, "liblpslam.so")
+HOST_SOURCES = ["slam_manager.cpp", "hip_tracker.cpp", "interface.cpp"]
+
+
+def host_library(force=False, verbose=False):
+    """C++ host mirror of the reference interface (g++), linked against the HIP C-ABI library next to it."""
+    hdir = os.path.join(HERE, "host")
+    srcs = [os.path.join(hdir, s) for s in HOST_SOURCES]
+    deps = srcs + [os.path.join(hdir, h) for h in ("core.h", "json_min.h", "hip_tracker.h", "slam_manager.h")] + \
+        [os.path.join(HERE, "..", "include", h) for h in ("lpslam_types.h", "lpslam_manager.h", "lpslam_hip.h")] + [LIB]
+    if not force and os.path.exists(HOST_LIB) and all(os.path.getmtime(d) <= os.path.getmtime(HOST_LIB) for d in deps if os.path.exists(d)):
+        return HOST_LIB
+    hip_library(force=False, verbose=verbose)
+    cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-Wall", "-Wextra",
+           "-Wno-unused-parameter", "-pthread", "-o", HOST_LIB] + srcs + ["-L" + HERE, "-llpslam_hip", "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return HOST_LIB
+
+
 if __name__ == "__main__":
     print(hip_library(force="-f" in sys.argv, verbose=True))
+    print(host_library(force="-f" in sys.argv, verbose=True))

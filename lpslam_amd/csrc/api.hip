@@ -310,19 +310,31 @@ int lpslam_hip_upload_image(lpslam_hip_ctx* c, int image, const uint8_t* host, i
     return LPSLAM_HIP_OK;
 }
 
-int lpslam_hip_stage_pyramid(lpslam_hip_ctx* c, int n) { int rc = check_batch(c, n); return rc ? rc : lp_launch_pyramid(c, n); }
-int lpslam_hip_stage_fast(lpslam_hip_ctx* c, int n) { int rc = check_batch(c, n); return rc ? rc : lp_launch_fast(c, n); }
-int lpslam_hip_stage_distribute(lpslam_hip_ctx* c, int n) { int rc = check_batch(c, n); return rc ? rc : lp_launch_distribute(c, n); }
-int lpslam_hip_stage_describe(lpslam_hip_ctx* c, int n) { int rc = check_batch(c, n); return rc ? rc : lp_launch_describe(c, n); }
-
-int lpslam_hip_extract(lpslam_hip_ctx* c, int n)
+static int check_range(lpslam_hip_ctx* c, int first, int n)
 {
-    int rc = check_batch(c, n); if (rc) return rc;
-    if ((rc = lp_launch_pyramid(c, n))) return rc;
-    if ((rc = lp_launch_fast(c, n))) return rc;
-    if ((rc = lp_launch_distribute(c, n))) return rc;
-    return lp_launch_describe(c, n);
+    if (!c) { set_error("null context"); return LPSLAM_HIP_ERR_INVALID; }
+    if (first < 0 || n < 1 || first + n > c->cfg.max_images) {
+        set_error("image slots [%d,%d) exceed the context capacity %d", first, first + n, c->cfg.max_images); return LPSLAM_HIP_ERR_CAPACITY;
+    }
+    LP_HIP(hipSetDevice(c->cfg.device));
+    return LPSLAM_HIP_OK;
 }
+
+int lpslam_hip_stage_pyramid(lpslam_hip_ctx* c, int n) { int rc = check_batch(c, n); return rc ? rc : lp_launch_pyramid(c, 0, n); }
+int lpslam_hip_stage_fast(lpslam_hip_ctx* c, int n) { int rc = check_batch(c, n); return rc ? rc : lp_launch_fast(c, 0, n); }
+int lpslam_hip_stage_distribute(lpslam_hip_ctx* c, int n) { int rc = check_batch(c, n); return rc ? rc : lp_launch_distribute(c, 0, n); }
+int lpslam_hip_stage_describe(lpslam_hip_ctx* c, int n) { int rc = check_batch(c, n); return rc ? rc : lp_launch_describe(c, 0, n); }
+
+int lpslam_hip_extract_range(lpslam_hip_ctx* c, int first, int n)
+{
+    int rc = check_range(c, first, n); if (rc) return rc;
+    if ((rc = lp_launch_pyramid(c, first, n))) return rc;
+    if ((rc = lp_launch_fast(c, first, n))) return rc;
+    if ((rc = lp_launch_distribute(c, first, n))) return rc;
+    return lp_launch_describe(c, first, n);
+}
+
+int lpslam_hip_extract(lpslam_hip_ctx* c, int n) { return lpslam_hip_extract_range(c, 0, n); }
 
 int lpslam_hip_keypoint_count(lpslam_hip_ctx* c, int image, int32_t* count)
 {

@@ -112,10 +112,16 @@ __device__ __forceinline__ double ba_weight(const BaView& v, int k, int D, const
 }
 
 // ---- point pass: H_ll, b_l, W per observation ------------------------------------------------------------------
-__global__ __launch_bounds__(128) void k_ba_point_pass(BaView v, int robust)
+__global__ __launch_bounds__(128) void k_ba_point_pass(BaView v, int robust, int points_fixed)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= v.n_points) return;
+    if (points_fixed) {        // motion-only: landmarks are constants, no landmark blocks (x_l = 0)
+        for (int s = v.pt_start[j]; s < v.pt_start[j + 1]; ++s) { double* Wk = v.W + 18 * (size_t)v.pt_obs[s]; for (int i = 0; i < 18; ++i) Wk[i] = 0.0; }
+        for (int i = 0; i < 6; ++i) v.Hll[6 * (size_t)j + i] = 0.0;
+        for (int i = 0; i < 3; ++i) v.bl[3 * (size_t)j + i] = 0.0;
+        return;
+    }
     const double X[3] = {v.points[3 * j], v.points[3 * j + 1], v.points[3 * j + 2]};
     double h[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
     for (int s = v.pt_start[j]; s < v.pt_start[j + 1]; ++s) {
@@ -596,6 +602,7 @@ struct lpslam_hip_ba {
     // LM state (g2o OptimizationAlgorithmLevenberg)
     double lambda = 0, ni = 2, current_chi = 0, rho = 0;
     int qmax = 0; int robust = 1; double chi_before = 0;
+    int points_fixed = 0;
     std::vector<void*> allocs;
 };
 
@@ -638,7 +645,7 @@ int ba_linearize(lpslam_hip_ba* b)
 {
     BaView v = make_view(b, b->cur);
     hipStream_t s = b->stream;
-    if (b->n_points) hipLaunchKernelGGL(k_ba_point_pass, dim3((b->n_points + 127) / 128), dim3(128), 0, s, v, b->robust);
+    if (b->n_points) hipLaunchKernelGGL(k_ba_point_pass, dim3((b->n_points + 127) / 128), dim3(128), 0, s, v, b->robust, b->points_fixed);
     hipLaunchKernelGGL(k_ba_pose_pass, dim3((b->n_poses + 3) / 4), dim3(256), 0, s, v, b->robust, 0, b->d_chi_pose);
     hipLaunchKernelGGL(k_ba_reduce, dim3(1), dim3(64), 0, s, b->d_chi_pose, b->n_poses, 1, v.chi_cur, 0);
     if (b->n_points) {
@@ -991,6 +998,41 @@ int lpslam_hip_ba_chi2(lpslam_hip_ba* b, double* chi2, uint8_t* depth_positive)
     if (chi2) LP_HIP(hipMemcpyAsync(chi2, b->d_chi_obs, (size_t)b->n_obs * sizeof(double), hipMemcpyDeviceToHost, b->stream));
     if (depth_positive) LP_HIP(hipMemcpyAsync(depth_positive, b->d_depth, (size_t)b->n_obs, hipMemcpyDeviceToHost, b->stream));
     LP_HIP(hipStreamSynchronize(b->stream));
+    return LPSLAM_HIP_OK;
+}
+
+int lpslam_hip_ba_set_points_fixed(lpslam_hip_ba* b, int32_t points_fixed)
+{
+    if (!b) { set_error("null problem"); return LPSLAM_HIP_ERR_INVALID; }
+    b->points_fixed = points_fixed ? 1 : 0;
+    return LPSLAM_HIP_OK;
+}
+
+int lpslam_hip_ba_pose_optimize(lpslam_hip_ba* b, uint8_t* outlier, int32_t* n_inliers)
+{
+    if (!b) { set_error("null problem"); return LPSLAM_HIP_ERR_INVALID; }
+    const int n = b->n_obs;
+    std::vector<uint8_t> active((size_t)std::max(n, 1), 1), out((size_t)std::max(n, 1), 0);
+    std::vector<double> chi((size_t)std::max(n, 1));
+    const int keep_fixed = b->points_fixed;
+    b->points_fixed = 1;
+    int rc, done, bad = 0, robust = 1;
+    if ((rc = lpslam_hip_ba_set_active(b, nullptr))) return rc;
+    for (int trial = 0; trial < 4; ++trial) {
+        if ((rc = lpslam_hip_ba_optimize(b, robust, 10, nullptr, &done))) return rc;
+        if ((rc = lpslam_hip_ba_chi2(b, chi.data(), nullptr))) return rc;
+        bad = 0;
+        for (int k = 0; k < n; ++k) {
+            const double thr = b->h_ur[k] < 0 ? 5.99146 : 7.81473;
+            if (thr < chi[k]) { out[k] = 1; active[k] = 0; ++bad; } else { out[k] = 0; active[k] = 1; }
+        }
+        if ((rc = lpslam_hip_ba_set_active(b, active.data()))) return rc;
+        if (trial == 4 - 2) robust = 0;
+        if (n - bad < 5) break;
+    }
+    b->points_fixed = keep_fixed;
+    if (outlier) std::copy(out.begin(), out.begin() + n, outlier);
+    if (n_inliers) *n_inliers = n - bad;
     return LPSLAM_HIP_OK;
 }
 

@@ -19,7 +19,7 @@ using namespace lpslam;
 // K1  pyramid: level l = bilinear resize of level l-1, 11-bit fixed-point coefficients (cv::resize INTER_LINEAR 8u)
 //     HBM-bound: reads ~1.44 B and writes 1 B per output pixel.  One thread = 4 output pixels = one dword store.
 // ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_pyr_down(uint8_t* __restrict__ pyr, size_t image_slab, LevelTable lt, int level,
+__global__ __launch_bounds__(256) void k_pyr_down(uint8_t* __restrict__ pyr, size_t image_slab, LevelTable lt, int level, int image0,
                                                   const int16_t* __restrict__ rs_ofs, const int16_t* __restrict__ rs_coef)
 {
     const int dw = lt.w[level], dh = lt.h[level], dp = lt.pitch[level];
@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256) void k_pyr_down(uint8_t* __restrict__ pyr, siz
     const int dx0 = (blockIdx.x * 64 + threadIdx.x) * 4;
     const int dy = blockIdx.y * 4 + threadIdx.y;
     if (dy >= dh || dx0 >= dp) return;
-    uint8_t* img = pyr + (size_t)blockIdx.z * image_slab;
+    uint8_t* img = pyr + (size_t)(image0 + blockIdx.z) * image_slab;
     const uint8_t* src = img + lt.off[level - 1];
     uint8_t* dst = img + lt.off[level];
     const int yt = lt.ytab_start[level] + dy;
@@ -93,14 +93,14 @@ __device__ __forceinline__ int fast_strength(const uint8_t* t /* points at centr
 
 __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ pyr, size_t image_slab, LevelTable lt,
                                                     int ini_thr, int min_thr, uint32_t* __restrict__ cell_keys,
-                                                    int32_t* __restrict__ cell_count, int cells_per_image)
+                                                    int32_t* __restrict__ cell_count, int cells_per_image, int image0)
 {
     __shared__ __attribute__((aligned(16))) uint8_t tile[70 * TILE_PITCH];
     __shared__ __attribute__((aligned(16))) uint8_t smap[66 * SMAP_PITCH];
     __shared__ unsigned long long m_ini[64], m_min[64], m_sel[64];
     __shared__ int rowoff[64];
 
-    const int cell = blockIdx.x, image = blockIdx.y;
+    const int cell = blockIdx.x, image = image0 + blockIdx.y;
     int level = 0;
     while (level + 1 < lt.n_levels && cell >= lt.cell_start[level + 1]) ++level;
     const int lc = cell - lt.cell_start[level];
@@ -225,10 +225,10 @@ __global__ __launch_bounds__(1024) void k_distribute(LevelTable lt, const uint32
                                                      int32_t* __restrict__ cand_count, int cand_per_image,
                                                      uint2* __restrict__ node_box, int32_t* __restrict__ node_cnt, int node_cap,
                                                      uint32_t* __restrict__ sel_key, int32_t* __restrict__ sel_count,
-                                                     int slots_per_image)
+                                                     int slots_per_image, int image0)
 {
     extern __shared__ __attribute__((aligned(16))) int lds[];
-    const int level = blockIdx.x, image = blockIdx.y;
+    const int level = blockIdx.x, image = image0 + blockIdx.y;
     const int tid = threadIdx.x;
     const int N = lt.quota[level];
     const int Q = lt.qcap[level];          // node count never exceeds max(N + 2, 4 * roots) < Q
@@ -547,14 +547,14 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const uint8_t* __r
                                                               const uint32_t* __restrict__ sel_key,
                                                               const int32_t* __restrict__ sel_count, int slots_per_image,
                                                               lpslam_hip_keypoint* __restrict__ kpts, uint8_t* __restrict__ desc,
-                                                              int32_t* __restrict__ kp_count)
+                                                              int32_t* __restrict__ kp_count, int image0)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_raw[DESC_WAVES][PW * RAW_PITCH];
     __shared__ __attribute__((aligned(16))) uint16_t s_h[DESC_WAVES][PW * BW];
     __shared__ __attribute__((aligned(16))) uint8_t s_blur[DESC_WAVES][BW * BW];
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int image = blockIdx.y;
+    const int image = image0 + blockIdx.y;
     const int slot = blockIdx.x * DESC_WAVES + wave;
     if (slot >= slots_per_image) return;          // wave-uniform; no block barriers below
     int level = 0;
@@ -640,40 +640,40 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const uint8_t* __r
 // ------------------------------------------------------------------------------------------------------------
 // host launchers
 // ------------------------------------------------------------------------------------------------------------
-int lp_launch_pyramid(lpslam_hip_ctx* c, int n_images)
+int lp_launch_pyramid(lpslam_hip_ctx* c, int first, int n_images)
 {
     for (int l = 1; l < c->lt.n_levels; ++l) {
         dim3 block(64, 4), grid((c->lt.pitch[l] / 4 + 63) / 64, (c->lt.h[l] + 3) / 4, n_images);
-        hipLaunchKernelGGL(k_pyr_down, grid, block, 0, c->stream, c->d_pyr, c->image_slab, c->lt, l, c->d_rs_ofs, c->d_rs_coef);
+        hipLaunchKernelGGL(k_pyr_down, grid, block, 0, c->stream, c->d_pyr, c->image_slab, c->lt, l, first, c->d_rs_ofs, c->d_rs_coef);
     }
     LP_HIP(hipGetLastError());
     return LPSLAM_HIP_OK;
 }
 
-int lp_launch_fast(lpslam_hip_ctx* c, int n_images)
+int lp_launch_fast(lpslam_hip_ctx* c, int first, int n_images)
 {
     dim3 grid(c->cells_per_image, n_images);
     hipLaunchKernelGGL(k_fast_cells, grid, dim3(256), 0, c->stream, c->d_pyr, c->image_slab, c->lt, c->cfg.ini_fast_threshold,
-                       c->cfg.min_fast_threshold, c->d_cell_keys, c->d_cell_count, c->cells_per_image);
+                       c->cfg.min_fast_threshold, c->d_cell_keys, c->d_cell_count, c->cells_per_image, first);
     LP_HIP(hipGetLastError());
     return LPSLAM_HIP_OK;
 }
 
-int lp_launch_distribute(lpslam_hip_ctx* c, int n_images)
+int lp_launch_distribute(lpslam_hip_ctx* c, int first, int n_images)
 {
     dim3 grid(c->lt.n_levels, n_images);
     hipLaunchKernelGGL(k_distribute, grid, dim3(1024), c->distribute_lds, c->stream, c->lt, c->d_cell_keys, c->d_cell_count,
                        c->cells_per_image, c->d_cand_key, c->d_cand_node, c->d_cand_count, c->cand_per_image, c->d_node_box,
-                       c->d_node_cnt, c->node_cap, c->d_sel_key, c->d_sel_count, c->slots_per_image);
+                       c->d_node_cnt, c->node_cap, c->d_sel_key, c->d_sel_count, c->slots_per_image, first);
     LP_HIP(hipGetLastError());
     return LPSLAM_HIP_OK;
 }
 
-int lp_launch_describe(lpslam_hip_ctx* c, int n_images)
+int lp_launch_describe(lpslam_hip_ctx* c, int first, int n_images)
 {
     dim3 grid((c->slots_per_image + DESC_WAVES - 1) / DESC_WAVES, n_images);
     hipLaunchKernelGGL(k_describe, grid, dim3(64 * DESC_WAVES), 0, c->stream, c->d_pyr, c->image_slab, c->lt, c->d_sel_key,
-                       c->d_sel_count, c->slots_per_image, c->d_kpts, c->d_desc, c->d_kp_count);
+                       c->d_sel_count, c->slots_per_image, c->d_kpts, c->d_desc, c->d_kp_count, first);
     LP_HIP(hipGetLastError());
     return LPSLAM_HIP_OK;
 }

@@ -87,10 +87,10 @@ struct lpslam_hip_ctx {
 };
 
 // kernel launchers (frontend.hip / match.hip)
-int lp_launch_pyramid(lpslam_hip_ctx* c, int n_images);
-int lp_launch_fast(lpslam_hip_ctx* c, int n_images);
-int lp_launch_distribute(lpslam_hip_ctx* c, int n_images);
-int lp_launch_describe(lpslam_hip_ctx* c, int n_images);
+int lp_launch_pyramid(lpslam_hip_ctx* c, int first, int n_images);
+int lp_launch_fast(lpslam_hip_ctx* c, int first, int n_images);
+int lp_launch_distribute(lpslam_hip_ctx* c, int first, int n_images);
+int lp_launch_describe(lpslam_hip_ctx* c, int first, int n_images);
 int lp_launch_bf_strided(lpslam_hip_ctx* c, int q0, int t0, int stride, int n_pairs);
 int lp_launch_stereo_strided(lpslam_hip_ctx* c, int left0, int right0, int stride, int n_pairs, float fxb, float baseline);
 size_t lp_distribute_lds_bytes(int qcap_max, int ncell_max);

@@ -24,14 +24,14 @@ BA_LOG_DTYPE = np.dtype([("chi2_before", "<f8"), ("chi2_after", "<f8"), ("lambda
 SYMBOLS = [
     "lpslam_hip_last_error", "lpslam_hip_device_count", "lpslam_hip_create", "lpslam_hip_destroy",
     "lpslam_hip_stream", "lpslam_hip_sync", "lpslam_hip_timer_begin", "lpslam_hip_timer_end", "lpslam_hip_timer_read", "lpslam_hip_level_info", "lpslam_hip_max_keypoints_per_image",
-    "lpslam_hip_image_ptr", "lpslam_hip_upload_image", "lpslam_hip_extract", "lpslam_hip_stage_pyramid",
+    "lpslam_hip_image_ptr", "lpslam_hip_upload_image", "lpslam_hip_extract", "lpslam_hip_extract_range", "lpslam_hip_stage_pyramid",
     "lpslam_hip_stage_fast", "lpslam_hip_stage_distribute", "lpslam_hip_stage_describe",
     "lpslam_hip_keypoint_count", "lpslam_hip_get_keypoints", "lpslam_hip_get_pyramid_level",
     "lpslam_hip_get_candidates", "lpslam_hip_keypoint_buffers", "lpslam_hip_match_bf", "lpslam_hip_get_bf_knn2",
     "lpslam_hip_get_bf_matches", "lpslam_hip_match_bf_strided", "lpslam_hip_set_descriptors",
     "lpslam_hip_match_stereo", "lpslam_hip_match_stereo_strided", "lpslam_hip_get_stereo",
     "lpslam_hip_ba_create", "lpslam_hip_ba_destroy", "lpslam_hip_ba_set_active", "lpslam_hip_ba_optimize",
-    "lpslam_hip_ba_local", "lpslam_hip_ba_reset", "lpslam_hip_ba_get", "lpslam_hip_ba_chi2", "lpslam_hip_ba_reduced_buffer",
+    "lpslam_hip_ba_local", "lpslam_hip_ba_set_points_fixed", "lpslam_hip_ba_pose_optimize", "lpslam_hip_ba_reset", "lpslam_hip_ba_get", "lpslam_hip_ba_chi2", "lpslam_hip_ba_reduced_buffer",
     "lpslam_hip_ba_step_begin", "lpslam_hip_ba_step_solve", "lpslam_hip_ba_scalar_buffer", "lpslam_hip_ba_step_end",
 ]
 
@@ -145,6 +145,9 @@ class Context:
     def extract(self, n_images):
         _check(self.lib.lpslam_hip_extract(self.h, n_images))
 
+    def extract_range(self, first, n_images):
+        _check(self.lib.lpslam_hip_extract_range(self.h, first, n_images))
+
     def stage(self, name, n_images):
         _check(getattr(self.lib, "lpslam_hip_stage_" + name)(self.h, n_images))
 
@@ -236,6 +239,11 @@ class BundleAdjuster:
 
     def reset(self):
         _check(self.lib.lpslam_hip_ba_reset(self.h))
+
+    def pose_optimize(self):
+        out = np.zeros(max(self.n_obs, 1), np.uint8); n = C.c_int32()
+        _check(self.lib.lpslam_hip_ba_pose_optimize(self.h, _p(out), C.byref(n)))
+        return out[:self.n_obs], n.value
 
     def local(self, first=5, second=10):
         out = np.zeros(max(self.n_obs, 1), np.uint8)

@@ -1,0 +1,463 @@
+// hip_tracker.cpp -- see hip_tracker.h.  Host-side tracking glue around the HIP C ABI (the arithmetic runs on the GPU).
+#include "hip_tracker.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <fstream>
+
+namespace LpSlam {
+
+namespace {
+
+struct Mat3 { double m[9]; };
+
+Mat3 quatToRot(const double* q)
+{
+    const double n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    const double w = q[0] / n, x = q[1] / n, y = q[2] / n, z = q[3] / n;
+    return {{1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
+             2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
+             2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)}};
+}
+
+void quatMul(const double* a, const double* b, double* o)
+{
+    const double r[4] = {a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3], a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2],
+                         a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1], a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0]};
+    const double n = std::sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3]);
+    for (int i = 0; i < 4; ++i) o[i] = r[i] / n;
+}
+
+// Eigen::Quaterniond(R) for a rotation matrix
+void rotToQuat(const Mat3& R, double* q)
+{
+    const double* m = R.m;
+    const double tr = m[0] + m[4] + m[8];
+    if (tr > 0) {
+        const double s = std::sqrt(tr + 1.0) * 2;
+        q[0] = 0.25 * s; q[1] = (m[7] - m[5]) / s; q[2] = (m[2] - m[6]) / s; q[3] = (m[3] - m[1]) / s;
+    } else if (m[0] > m[4] && m[0] > m[8]) {
+        const double s = std::sqrt(1.0 + m[0] - m[4] - m[8]) * 2;
+        q[0] = (m[7] - m[5]) / s; q[1] = 0.25 * s; q[2] = (m[1] + m[3]) / s; q[3] = (m[2] + m[6]) / s;
+    } else if (m[4] > m[8]) {
+        const double s = std::sqrt(1.0 + m[4] - m[0] - m[8]) * 2;
+        q[0] = (m[2] - m[6]) / s; q[1] = (m[1] + m[3]) / s; q[2] = 0.25 * s; q[3] = (m[5] + m[7]) / s;
+    } else {
+        const double s = std::sqrt(1.0 + m[8] - m[0] - m[4]) * 2;
+        q[0] = (m[3] - m[1]) / s; q[1] = (m[2] + m[6]) / s; q[2] = (m[5] + m[7]) / s; q[3] = 0.25 * s;
+    }
+}
+
+}  // namespace
+
+HipVslamTrackerBase::HipVslamTrackerBase()
+{
+    auto& o = getConfigOptions();
+    // keys and defaults of the reference tracker (src/Trackers/OpenVSLAMTrackerBase.cpp:31-50)
+    o.optional("liveView", false); o.optional("useMapDb", true); o.optional("configFromFile", "");
+    o.optional("cameraSetup", "monocular"); o.optional("slamKeypoints", 1200); o.optional("vocabFile", m_vocabFile);
+    o.optional("forwardNavState", true); o.optional("forwardImu", true); o.optional("emitMap", false);
+    o.optional("enableMapping", true); o.optional("waitForNavigation", false); o.optional("viewerFps", 10);
+    o.optional("forwardHighResNav", false); o.optional("loopClosure", true); o.optional("useOpenCL", false);
+    o.optional("useCUDA", false); o.optional("relocWithNavigation", true); o.optional("baselineDistThresh", 0.1);
+    o.optional("mapFilename", "map.db"); o.optional("maxLaserAge", 1.0);
+    // runtime ORB parameters the reference hard-codes in its generated YAML (:193-198), plus device selection
+    o.optional("numLevels", 3); o.optional("scaleFactor", 1.2); o.optional("iniFastThr", 20); o.optional("minFastThr", 7);
+    o.optional("device", 0); o.optional("keyframeInterval", 6); o.optional("localWindow", 10);
+}
+
+HipVslamTrackerBase::~HipVslamTrackerBase() { stop(); }
+
+void HipVslamTrackerBase::OnConfigurationUpdate()
+{
+    auto& o = getConfigOptions();
+    m_useLiveView = o.getBool("liveView"); m_useMapDb = o.getBool("useMapDb"); m_configFromFile = o.getString("configFromFile");
+    m_slamKeypoints = o.getInteger("slamKeypoints"); m_cameraSetup = o.getString("cameraSetup"); m_vocabFile = o.getString("vocabFile");
+    m_forwardNavState = o.getBool("forwardNavState"); m_forwardImu = o.getBool("forwardImu"); m_emitMap = o.getBool("emitMap");
+    m_enableMapping = o.getBool("enableMapping"); m_mapFilename = o.getString("mapFilename");
+    m_waitForNavigation = o.getBool("waitForNavigation"); m_viewerFps = o.getInteger("viewerFps");
+    m_forwardHighResNav = o.getBool("forwardHighResNav"); m_loopClosure = o.getBool("loopClosure");
+    m_useOpenCL = o.getBool("useOpenCL"); m_useCUDA = o.getBool("useCUDA"); m_relocWithNavigation = o.getBool("relocWithNavigation");
+    m_baselineDistThresh = o.getDouble("baselineDistThresh"); m_maxLaserAge = o.getDouble("maxLaserAge");
+    m_numLevels = o.getInteger("numLevels"); m_scaleFactor = o.getDouble("scaleFactor");
+    m_iniFastThr = o.getInteger("iniFastThr"); m_minFastThr = o.getInteger("minFastThr"); m_device = o.getInteger("device");
+    m_keyframeInterval = std::max(1, o.getInteger("keyframeInterval")); m_localWindow = std::max(2, o.getInteger("localWindow"));
+}
+
+bool HipVslamTrackerBase::startContext(bool stereo)
+{
+    std::scoped_lock lock(m_slamLock);
+    if (m_ctx) return true;
+    if (!m_configFromFile.empty()) {
+        logMessage(LpSlamLogLevel_Error, "configFromFile (raw OpenVSLAM YAML) is not supported; use the tracker's JSON keys");
+        return false;
+    }
+    CameraRegistry* reg = getCameraRegistry();
+    if (!reg) { logMessage(LpSlamLogLevel_Error, "Cannot process image without camera registry"); return false; }
+    auto left = reg->getConfiguration(0);
+    if (!left) { logMessage(LpSlamLogLevel_Error, "Cannot load camera configuration for camera with number 0"); return false; }
+    if (stereo && !reg->getConfiguration(1)) { logMessage(LpSlamLogLevel_Error, "Cannot load camera configuration for right camera with number 1"); return false; }
+    m_cam = *left;
+    if (m_cam.distortion_function != LpSlamCameraDistortionFunction_NoDistortion) {
+        logMessage(LpSlamLogLevel_Error, "Camera distortion not supported: on-device rectification is not implemented; feed rectified frames (no_distortion)");
+        return false;
+    }
+    if (m_cam.resolution_x <= 0 || m_cam.resolution_y <= 0 || !(m_cam.f_x > 0) || (stereo && !(m_cam.focal_x_baseline > 0))) {
+        logMessage(LpSlamLogLevel_Error, "Camera configuration incomplete (resolution, focal length, focal_x_baseline)");
+        return false;
+    }
+    lpslam_hip_frontend_config cfg{};
+    cfg.width = m_cam.resolution_x; cfg.height = m_cam.resolution_y; cfg.max_keypoints = m_slamKeypoints;
+    cfg.scale_factor = (float)m_scaleFactor; cfg.num_levels = m_numLevels; cfg.ini_fast_threshold = m_iniFastThr;
+    cfg.min_fast_threshold = m_minFastThr; cfg.max_images = 4; cfg.device = m_device;
+    if (lpslam_hip_create(&cfg, &m_ctx) != LPSLAM_HIP_OK) {
+        logMessage(LpSlamLogLevel_Error, std::string("Cannot create the HIP context: ") + lpslam_hip_last_error());
+        m_ctx = nullptr;
+        return false;
+    }
+    m_maxKp = lpslam_hip_max_keypoints_per_image(m_ctx);
+    m_stereo = stereo;
+    m_state = TrackerState::NotInitialized;
+    m_started = true;
+    return true;
+}
+
+bool HipVslamTrackerBase::stop()
+{
+    std::scoped_lock lock(m_slamLock);
+    if (m_ctx) { lpslam_hip_destroy(m_ctx); m_ctx = nullptr; }
+    m_started = false;
+    return true;
+}
+
+std::array<double, 16> HipVslamTrackerBase::currentCamPose()
+{
+    std::scoped_lock lock(m_slamLock);
+    const Mat3 R = quatToRot(m_prev.pose.q);
+    return {R.m[0], R.m[1], R.m[2], m_prev.pose.t[0], R.m[3], R.m[4], R.m[5], m_prev.pose.t[1],
+            R.m[6], R.m[7], R.m[8], m_prev.pose.t[2], 0, 0, 0, 1};
+}
+
+// T_cw -> camera centre, optical axes (x right, y down, z forward) -> lpslam axes: p_lp = (-y, x, z), q_lp = (w, -y, x, z)
+// (src/Trackers/OpenVSLAMTrackerBase.cpp:307-329)
+TrackerResult HipVslamTrackerBase::createTrackerResult(const Pose& p, TimeStamp timestamp) const
+{
+    const Mat3 R = quatToRot(p.q);
+    const double cx = -(R.m[0] * p.t[0] + R.m[3] * p.t[1] + R.m[6] * p.t[2]);
+    const double cy = -(R.m[1] * p.t[0] + R.m[4] * p.t[1] + R.m[7] * p.t[2]);
+    const double cz = -(R.m[2] * p.t[0] + R.m[5] * p.t[1] + R.m[8] * p.t[2]);
+    double q[4];
+    rotToQuat(R, q);
+    TrackerResult t;
+    t.type = ResultType::TrackedVehicle;
+    t.id = 0;
+    t.position.value = {-cy, cx, cz};
+    t.orientation.value = {q[0], -q[2], q[1], q[3]};
+    t.timestamp.system_time = timestamp;
+    return t;
+}
+
+bool HipVslamTrackerBase::initializeMap(FrameData& f)
+{
+    // stereo initialisation: every keypoint with a valid, close-enough depth becomes a landmark (Initializer.num_min_triangulated_pts = 40,
+    // depth_threshold = 40 baselines; src/Trackers/OpenVSLAMTrackerBase.cpp:181-182,200)
+    const double baseline = m_cam.focal_x_baseline / m_cam.f_x;
+    const double depth_thr = 40.0 * baseline;
+    int n = 0;
+    for (size_t i = 0; i < f.kpts.size(); ++i) if (f.depth[i] > 0 && f.depth[i] < depth_thr) ++n;
+    if (n < 40) return false;
+    m_landmarks.clear(); m_keyframes.clear(); m_nextLandmarkId = 0;
+    f.pose = Pose();
+    insertKeyframe(f);
+    return true;
+}
+
+void HipVslamTrackerBase::insertKeyframe(FrameData& f)
+{
+    const double baseline = m_cam.focal_x_baseline / m_cam.f_x;
+    const double depth_thr = 40.0 * baseline;
+    const Mat3 R = quatToRot(f.pose.q);
+    float scales[LPSLAM_HIP_MAX_LEVELS];
+    lpslam_hip_level_info(m_ctx, nullptr, nullptr, nullptr, nullptr, scales);
+    Keyframe kf;
+    kf.pose = f.pose;
+    for (size_t i = 0; i < f.kpts.size(); ++i) {
+        int id = f.landmark[i];
+        if (id < 0 && f.depth[i] > 0 && f.depth[i] < depth_thr) {
+            // back-project into the world: X_w = R^T (X_c - t)
+            const double z = f.depth[i];
+            const double xc = (f.kpts[i].x - m_cam.c_x) * z / m_cam.f_x, yc = (f.kpts[i].y - m_cam.c_y) * z / m_cam.f_y;
+            const double d[3] = {xc - f.pose.t[0], yc - f.pose.t[1], z - f.pose.t[2]};
+            Landmark lm;
+            lm.p[0] = R.m[0] * d[0] + R.m[3] * d[1] + R.m[6] * d[2];
+            lm.p[1] = R.m[1] * d[0] + R.m[4] * d[1] + R.m[7] * d[2];
+            lm.p[2] = R.m[2] * d[0] + R.m[5] * d[1] + R.m[8] * d[2];
+            id = m_nextLandmarkId++;
+            m_landmarks[id] = lm;
+            f.landmark[i] = id;
+        }
+        if (id >= 0) {
+            const double s = scales[f.kpts[i].octave];
+            kf.obs.push_back({id, f.kpts[i].x, f.kpts[i].y, f.x_right[i] >= 0 ? (double)f.x_right[i] : -1.0, 1.0 / (s * s)});
+            m_landmarks[id].n_obs++;
+        }
+    }
+    m_keyframes.push_back(std::move(kf));
+    ++m_keyframeCount;
+    while ((int)m_keyframes.size() > m_localWindow) {
+        for (auto& o : m_keyframes.front().obs) {
+            auto it = m_landmarks.find(o.landmark);
+            if (it != m_landmarks.end() && --it->second.n_obs <= 0) m_landmarks.erase(it);
+        }
+        m_keyframes.pop_front();
+    }
+    m_framesSinceKeyframe = 0;
+}
+
+// motion-only pose optimisation of `cur` against the landmarks seen in the previous frame
+bool HipVslamTrackerBase::trackAgainstPrevious(FrameData& cur, int& n_inliers)
+{
+    n_inliers = 0;
+    if (lpslam_hip_match_bf(m_ctx, cur.slot, m_prev.slot) != LPSLAM_HIP_OK) return false;
+    std::vector<int32_t> mq(m_maxKp), mt(m_maxKp), md(m_maxKp);
+    int32_t nm = 0;
+    // HAMMING_DIST_THR_LOW = 50, Lowe ratio 0.9, mutual best
+    if (lpslam_hip_get_bf_matches(m_ctx, cur.slot, m_prev.slot, 50, 0.9f, 1, mq.data(), mt.data(), md.data(), m_maxKp, &nm) != LPSLAM_HIP_OK) return false;
+    float scales[LPSLAM_HIP_MAX_LEVELS];
+    lpslam_hip_level_info(m_ctx, nullptr, nullptr, nullptr, nullptr, scales);
+    std::vector<double> pts;
+    std::vector<lpslam_hip_ba_obs> obs;
+    std::vector<int> cur_idx, obs_lm;
+    for (int k = 0; k < nm; ++k) {
+        const int id = m_prev.landmark[mt[k]];
+        if (id < 0) continue;
+        auto it = m_landmarks.find(id);
+        if (it == m_landmarks.end()) continue;
+        const int i = mq[k];
+        const double s = scales[cur.kpts[i].octave];
+        lpslam_hip_ba_obs o{};
+        o.pose = 0; o.point = (int32_t)cur_idx.size();
+        o.u = cur.kpts[i].x; o.v = cur.kpts[i].y; o.ur = cur.x_right[i] >= 0 ? (double)cur.x_right[i] : -1.0; o.inv_sigma2 = 1.0 / (s * s);
+        obs.push_back(o);
+        pts.insert(pts.end(), it->second.p, it->second.p + 3);
+        cur_idx.push_back(i);
+        obs_lm.push_back(id);
+    }
+    if (obs.size() < 10) return false;
+    // prediction: constant velocity, else the previous pose
+    Pose init = m_prev.pose;
+    if (m_haveVelocity) {
+        quatMul(m_velocity.q, m_prev.pose.q, init.q);
+        const Mat3 Rv = quatToRot(m_velocity.q);
+        for (int r = 0; r < 3; ++r) init.t[r] = Rv.m[r * 3] * m_prev.pose.t[0] + Rv.m[r * 3 + 1] * m_prev.pose.t[1] + Rv.m[r * 3 + 2] * m_prev.pose.t[2] + m_velocity.t[r];
+    }
+    double pose7[7] = {init.q[0], init.q[1], init.q[2], init.q[3], init.t[0], init.t[1], init.t[2]};
+    const uint8_t fixed = 0;
+    lpslam_hip_ba_camera cam{m_cam.f_x, m_cam.f_y, m_cam.c_x, m_cam.c_y, m_cam.focal_x_baseline, std::sqrt(5.991), std::sqrt(7.815)};
+    lpslam_hip_ba* ba = nullptr;
+    if (lpslam_hip_ba_create(m_ctx, pose7, &fixed, 1, pts.data(), (int32_t)cur_idx.size(), obs.data(), (int32_t)obs.size(), &cam, &ba) != LPSLAM_HIP_OK) return false;
+    std::vector<uint8_t> outlier(obs.size());
+    int32_t inl = 0;
+    const int rc = lpslam_hip_ba_pose_optimize(ba, outlier.data(), &inl);
+    if (rc == LPSLAM_HIP_OK) lpslam_hip_ba_get(ba, pose7, nullptr);
+    lpslam_hip_ba_destroy(ba);
+    if (rc != LPSLAM_HIP_OK) return false;
+    n_inliers = inl;
+    if (inl < 10) return false;
+    for (int k = 0; k < 4; ++k) cur.pose.q[k] = pose7[k];
+    for (int k = 0; k < 3; ++k) cur.pose.t[k] = pose7[4 + k];
+    for (size_t k = 0; k < cur_idx.size(); ++k) cur.landmark[cur_idx[k]] = outlier[k] ? -1 : obs_lm[k];   // inliers keep their landmark
+    return true;
+}
+
+void HipVslamTrackerBase::localBundleAdjust()
+{
+    if (!m_enableMapping || m_keyframes.size() < 2) return;
+    // landmarks observed by at least two keyframes of the window
+    std::unordered_map<int, int> seen, index;
+    for (auto& kf : m_keyframes) for (auto& o : kf.obs) seen[o.landmark]++;
+    std::vector<double> pts; std::vector<int> ids;
+    for (auto& kv : seen) {
+        if (kv.second < 2) continue;
+        auto it = m_landmarks.find(kv.first);
+        if (it == m_landmarks.end()) continue;
+        index[kv.first] = (int)ids.size(); ids.push_back(kv.first);
+        pts.insert(pts.end(), it->second.p, it->second.p + 3);
+    }
+    if (ids.size() < 20) return;
+    std::vector<double> poses; std::vector<uint8_t> fixed;
+    std::vector<lpslam_hip_ba_obs> obs;
+    std::vector<std::pair<int, int>> origin;          // (keyframe, obs index) of every BA observation
+    for (size_t f = 0; f < m_keyframes.size(); ++f) {
+        const Pose& p = m_keyframes[f].pose;
+        poses.insert(poses.end(), {p.q[0], p.q[1], p.q[2], p.q[3], p.t[0], p.t[1], p.t[2]});
+        fixed.push_back(f == 0 ? 1 : 0);              // the oldest keyframe anchors the gauge
+        for (size_t k = 0; k < m_keyframes[f].obs.size(); ++k) {
+            const KeyframeObs& o = m_keyframes[f].obs[k];
+            auto it = index.find(o.landmark);
+            if (it == index.end()) continue;
+            obs.push_back({(int32_t)f, it->second, o.u, o.v, o.ur, o.inv_sigma2});
+            origin.emplace_back((int)f, (int)k);
+        }
+    }
+    lpslam_hip_ba_camera cam{m_cam.f_x, m_cam.f_y, m_cam.c_x, m_cam.c_y, m_cam.focal_x_baseline, std::sqrt(5.991), std::sqrt(7.815)};
+    lpslam_hip_ba* ba = nullptr;
+    if (lpslam_hip_ba_create(m_ctx, poses.data(), fixed.data(), (int32_t)m_keyframes.size(), pts.data(), (int32_t)ids.size(), obs.data(),
+                             (int32_t)obs.size(), &cam, &ba) != LPSLAM_HIP_OK) return;
+    std::vector<uint8_t> outlier(obs.size());
+    if (lpslam_hip_ba_local(ba, 5, 10, outlier.data()) == LPSLAM_HIP_OK && lpslam_hip_ba_get(ba, poses.data(), pts.data()) == LPSLAM_HIP_OK) {
+        for (size_t f = 0; f < m_keyframes.size(); ++f) {
+            for (int k = 0; k < 4; ++k) m_keyframes[f].pose.q[k] = poses[7 * f + k];
+            for (int k = 0; k < 3; ++k) m_keyframes[f].pose.t[k] = poses[7 * f + 4 + k];
+        }
+        for (size_t j = 0; j < ids.size(); ++j) { Landmark& lm = m_landmarks[ids[j]]; lm.p[0] = pts[3 * j]; lm.p[1] = pts[3 * j + 1]; lm.p[2] = pts[3 * j + 2]; }
+        // erase outlier observations (back to front so indices stay valid)
+        for (size_t k = obs.size(); k-- > 0;) {
+            if (!outlier[k]) continue;
+            auto& v = m_keyframes[origin[k].first].obs;
+            auto it = m_landmarks.find(v[origin[k].second].landmark);
+            if (it != m_landmarks.end() && --it->second.n_obs <= 0) m_landmarks.erase(it);
+            v.erase(v.begin() + origin[k].second);
+        }
+    }
+    lpslam_hip_ba_destroy(ba);
+}
+
+TrackerBase::ProcessImageResult HipVslamTrackerBase::trackFrame(CameraQueueEntry& cam, bool stereo)
+{
+    ProcessImageResult res;
+    std::scoped_lock lock(m_slamLock);
+    if (!m_ctx) { logMessage(LpSlamLogLevel_Error, "VSLAM instance not created"); return res; }
+    if (stereo && !cam.image_second.has_value()) { logMessage(LpSlamLogLevel_Error, "VSLAM stereo needs two images"); return res; }
+    if (cam.image.width != m_cam.resolution_x || cam.image.height != m_cam.resolution_y ||
+        (stereo && (cam.image_second->width != cam.image.width || cam.image_second->height != cam.image.height))) {
+        logMessage(LpSlamLogLevel_Error, "Image size does not match the camera configuration");
+        return res;
+    }
+    if (!m_firstImageTimestamp) m_firstImageTimestamp = cam.timestamp;
+    const auto t0 = std::chrono::steady_clock::now();
+
+    FrameData cur;
+    cur.slot = (int)(m_imageTracked % 2) * 2;
+    bool ok = lpslam_hip_upload_image(m_ctx, cur.slot, cam.image.pixels.data(), cam.image.width) == LPSLAM_HIP_OK;
+    if (ok && stereo) ok = lpslam_hip_upload_image(m_ctx, cur.slot + 1, cam.image_second->pixels.data(), cam.image.width) == LPSLAM_HIP_OK;
+    if (ok) ok = lpslam_hip_extract_range(m_ctx, cur.slot, stereo ? 2 : 1) == LPSLAM_HIP_OK;
+    if (ok && stereo) {
+        const float baseline = (float)(m_cam.focal_x_baseline / m_cam.f_x);
+        ok = lpslam_hip_match_stereo(m_ctx, cur.slot, cur.slot + 1, (float)m_cam.focal_x_baseline, baseline) == LPSLAM_HIP_OK;
+    }
+    int32_t n = 0;
+    cur.kpts.resize(m_maxKp);
+    if (ok) ok = lpslam_hip_get_keypoints(m_ctx, cur.slot, cur.kpts.data(), nullptr, m_maxKp, &n) == LPSLAM_HIP_OK;
+    if (!ok) { logMessage(LpSlamLogLevel_Error, std::string("HIP front end failed: ") + lpslam_hip_last_error()); return res; }
+    cur.kpts.resize(n);
+    cur.x_right.assign(n, -1.0f); cur.depth.assign(n, -1.0f); cur.landmark.assign(n, -1);
+    if (stereo && n > 0) lpslam_hip_get_stereo(m_ctx, cur.slot, cur.x_right.data(), cur.depth.data(), nullptr, n, nullptr);
+    ++m_imageTracked;
+
+    if (!stereo) {
+        // monocular initialisation (two-view geometry) is outside the accelerated path: frames are extracted and matched, no pose yet
+        m_state = TrackerState::Initializing;
+        if (m_havePrev) lpslam_hip_match_bf(m_ctx, cur.slot, m_prev.slot);
+        m_prev = std::move(cur); m_havePrev = true;
+    } else if (m_state != TrackerState::Tracking) {
+        m_state = TrackerState::Initializing;
+        if (initializeMap(cur)) m_state = TrackerState::Tracking;
+        m_haveVelocity = false;
+        m_prev = std::move(cur); m_havePrev = true;
+    } else {
+        int inliers = 0;
+        if (trackAgainstPrevious(cur, inliers)) {
+            // velocity = T_cur * T_prev^-1
+            const Mat3 Rc = quatToRot(cur.pose.q), Rp = quatToRot(m_prev.pose.q);
+            Mat3 Rv;
+            for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) Rv.m[r * 3 + c] = Rc.m[r * 3] * Rp.m[c * 3] + Rc.m[r * 3 + 1] * Rp.m[c * 3 + 1] + Rc.m[r * 3 + 2] * Rp.m[c * 3 + 2];
+            rotToQuat(Rv, m_velocity.q);
+            for (int r = 0; r < 3; ++r) m_velocity.t[r] = cur.pose.t[r] - (Rv.m[r * 3] * m_prev.pose.t[0] + Rv.m[r * 3 + 1] * m_prev.pose.t[1] + Rv.m[r * 3 + 2] * m_prev.pose.t[2]);
+            m_haveVelocity = true;
+            ++m_framesSinceKeyframe;
+            if (m_framesSinceKeyframe >= m_keyframeInterval || inliers < 50) {
+                insertKeyframe(cur);
+                localBundleAdjust();
+                cur.pose = m_keyframes.back().pose;
+            }
+            m_prev = std::move(cur);
+        } else {
+            m_state = TrackerState::Lost;
+            logMessage(LpSlamLogLevel_Info, "VSLAM tracking lost; re-initialising from the next stereo frame");
+            m_prev = std::move(cur);
+            m_haveVelocity = false;
+        }
+    }
+    m_lastFrameSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (m_state == TrackerState::Tracking) {
+        TrackerResult tres = createTrackerResult(m_prev.pose, cam.timestamp);
+        tres.timestamp.ros_timestamp = cam.ros_timestamp;
+        res.push_back(tres);
+    }
+    return res;
+}
+
+std::size_t HipVslamTrackerBase::mappingGetFeatures(LpSlamMapBoundary, LpSlamFeatureEntry* entry, std::size_t entry_count, LpSlamMatrix9x9 transform)
+{
+    std::scoped_lock lock(m_slamLock);
+    std::size_t copied = 0;
+    for (auto const& kv : m_landmarks) {
+        if (copied >= entry_count) break;
+        const float p[3] = {(float)-kv.second.p[1], (float)kv.second.p[0], (float)kv.second.p[2]};     // optical -> lpslam axes
+        entry[copied].position = {transform[0] * p[0] + transform[1] * p[1] + transform[2] * p[2],
+                                  transform[3] * p[0] + transform[4] * p[1] + transform[5] * p[2],
+                                  transform[6] * p[0] + transform[7] * p[1] + transform[8] * p[2]};
+        ++copied;
+    }
+    return copied;
+}
+
+std::size_t HipVslamTrackerBase::mappingGetFeaturesCount(LpSlamMapBoundary)
+{
+    std::scoped_lock lock(m_slamLock);
+    return m_landmarks.size();
+}
+
+bool HipVslamTrackerBase::mappingExportCSV(std::string csv_filename)
+{
+    std::scoped_lock lock(m_slamLock);
+    std::ofstream f(csv_filename);
+    if (!f) return false;
+    for (auto const& kv : m_landmarks) f << kv.first << "," << kv.second.p[0] << "," << kv.second.p[1] << "," << kv.second.p[2] << "\n";
+    return true;
+}
+
+LpSlamStatus HipVslamTrackerBase::getSlamStatus()
+{
+    std::scoped_lock lock(m_slamLock);
+    LpSlamStatus s{};
+    s.localization = LpSlamLocalization_Off; s.fps = 0.0;
+    if (!m_ctx) return s;
+    switch (m_state) {
+    case TrackerState::Tracking: s.localization = LpSlamLocalization_Tracking; break;
+    case TrackerState::Lost: s.localization = LpSlamLocalization_Lost; break;
+    default: s.localization = LpSlamLocalization_Initializing; break;
+    }
+    s.frame_time = m_lastFrameSeconds;
+    s.key_frames = m_keyframeCount;
+    s.feature_points = (long)m_landmarks.size();
+    return s;
+}
+
+TrackerBase::ProcessImageResult HipStereoTracker::processImage(CameraQueueEntry& cam, std::optional<GlobalStateInTime>, std::optional<GlobalStateInTime>,
+                                                               std::vector<SensorQueueEntry> const&)
+{
+    return trackFrame(cam, true);
+}
+bool HipStereoTracker::start(SensorQueue&) { return startContext(true); }
+
+TrackerBase::ProcessImageResult HipMonoTracker::processImage(CameraQueueEntry& cam, std::optional<GlobalStateInTime>, std::optional<GlobalStateInTime>,
+                                                             std::vector<SensorQueueEntry> const&)
+{
+    return trackFrame(cam, false);
+}
+bool HipMonoTracker::start(SensorQueue&) { return startContext(false); }
+
+}  // namespace LpSlam

@@ -1,0 +1,108 @@
+// hip_tracker.h -- tracker plugins "VSLAMStereo" / "VSLAMMono" backed by the MI355X hot path.
+//
+// Drop-in for the reference's OpenVSLAM adapters (src/Trackers/OpenVSLAMTrackerBase.{h,cpp},
+// src/Trackers/OpenVSLAMStereoTracker.{h,cpp}, src/Trackers/OpenVSLAMTracker.{h,cpp}): same type() strings, same JSON
+// configuration keys (OpenVSLAMTrackerBase.cpp:31-50), same pose conventions on the way out (createTrackerResult,
+// :307-329).  Where the reference holds an openvslam::system, this class holds a lpslam_hip_ctx: per frame it runs the
+// HIP front end (ORB on both eyes, stereo match, brute-force match against the previous frame), a motion-only pose
+// optimisation, and on keyframes a local bundle adjustment over a sliding window (include/lpslam_hip.h).
+#pragma once
+#include "core.h"
+#include "../../include/lpslam_hip.h"
+
+#include <array>
+#include <unordered_map>
+
+namespace LpSlam {
+
+enum class TrackerState { NotInitialized, Initializing, Tracking, Lost };     // openvslam::tracker_state_t
+
+class HipVslamTrackerBase : public TrackerBase {
+public:
+    HipVslamTrackerBase();
+    ~HipVslamTrackerBase() override;
+    void OnConfigurationUpdate() override;
+    bool stop() override;
+
+    // what the manager down-casts for (src/Manager/SlamManager.cpp:1316-1366)
+    bool mappingSetMode(bool enableMapping) { m_enableMapping = enableMapping; return true; }
+    bool mappingSetFilename(std::string const& filename) { m_mapFilename = filename; return true; }
+    bool mappingExportCSV(std::string csv_filename);
+    std::size_t mappingGetFeatures(LpSlamMapBoundary boundary, LpSlamFeatureEntry* entry, std::size_t entry_count, LpSlamMatrix9x9 transform);
+    std::size_t mappingGetFeaturesCount(LpSlamMapBoundary boundary);
+    LpSlamStatus getSlamStatus();
+
+    TrackerState state() const { return m_state; }
+    std::array<double, 16> currentCamPose();          // T_cw, row-major 4x4 (get_current_cam_pose)
+
+protected:
+    struct Pose { double q[4] = {1, 0, 0, 0}; double t[3] = {0, 0, 0}; };   // world -> camera
+    struct FrameData {
+        std::vector<lpslam_hip_keypoint> kpts;
+        std::vector<float> x_right, depth;
+        std::vector<int> landmark;                    // landmark id per keypoint or -1
+        Pose pose;
+        int slot = 0;
+    };
+    struct KeyframeObs { int landmark; double u, v, ur, inv_sigma2; };
+    struct Keyframe { Pose pose; std::vector<KeyframeObs> obs; };
+    struct Landmark { double p[3]; int n_obs = 0; };
+
+    bool startContext(bool stereo);
+    ProcessImageResult trackFrame(CameraQueueEntry& cam, bool stereo);
+    TrackerResult createTrackerResult(const Pose& pose_cw, TimeStamp timestamp) const;
+    bool initializeMap(FrameData& f);
+    bool trackAgainstPrevious(FrameData& cur, int& n_inliers);
+    void insertKeyframe(FrameData& f);
+    void localBundleAdjust();
+
+    // configuration (names as in the reference tracker)
+    bool m_useLiveView = false, m_useMapDb = true, m_forwardNavState = true, m_forwardImu = true, m_emitMap = false;
+    bool m_enableMapping = true, m_waitForNavigation = false, m_forwardHighResNav = false, m_loopClosure = true;
+    bool m_useOpenCL = false, m_useCUDA = false, m_relocWithNavigation = true;
+    std::string m_configFromFile, m_cameraSetup = "monocular", m_vocabFile = "orb_vocab.dbow2", m_mapFilename = "map.db";
+    int m_slamKeypoints = 1200, m_viewerFps = 10;
+    double m_baselineDistThresh = 0.1, m_maxLaserAge = 1.0;
+    // MI355X additions: the generated reference config hard-codes these
+    int m_numLevels = 3, m_iniFastThr = 20, m_minFastThr = 7, m_device = 0, m_keyframeInterval = 6, m_localWindow = 10;
+    double m_scaleFactor = 1.2;
+
+    std::mutex m_slamLock;
+    lpslam_hip_ctx* m_ctx = nullptr;
+    LpSlamCameraConfiguration m_cam{};
+    bool m_started = false, m_stereo = false;
+    TrackerState m_state = TrackerState::NotInitialized;
+    std::optional<TimeStamp> m_firstImageTimestamp;
+    uint64_t m_imageTracked = 0;
+    double m_lastFrameSeconds = 0;
+    int m_maxKp = 0;
+    FrameData m_prev;
+    bool m_havePrev = false;
+    Pose m_velocity;                                  // last inter-frame motion (constant-velocity prediction)
+    bool m_haveVelocity = false;
+    int m_framesSinceKeyframe = 0;
+    std::unordered_map<int, Landmark> m_landmarks;
+    int m_nextLandmarkId = 0;
+    std::deque<Keyframe> m_keyframes;
+    long m_keyframeCount = 0;
+};
+
+class HipStereoTracker : public HipVslamTrackerBase {
+public:
+    ProcessImageResult processImage(CameraQueueEntry& cam, std::optional<GlobalStateInTime> navResultOdom = std::nullopt,
+                                    std::optional<GlobalStateInTime> navResultMap = std::nullopt,
+                                    std::vector<SensorQueueEntry> const& sensorValues = {}) override;
+    bool start(SensorQueue&) override;
+    std::string type() override { return "VSLAMStereo"; }       // src/Trackers/OpenVSLAMStereoTracker.h:35-39
+};
+
+class HipMonoTracker : public HipVslamTrackerBase {
+public:
+    ProcessImageResult processImage(CameraQueueEntry& cam, std::optional<GlobalStateInTime> navResultOdom = std::nullopt,
+                                    std::optional<GlobalStateInTime> navResultMap = std::nullopt,
+                                    std::vector<SensorQueueEntry> const& sensorValues = {}) override;
+    bool start(SensorQueue&) override;
+    std::string type() override { return "VSLAMMono"; }
+};
+
+}  // namespace LpSlam

@@ -1,0 +1,75 @@
+// slam_manager.h -- runtime behind LpSlamManager: plugin factories, configuration file, frame ingest, the worker and
+// notify threads (mirror of /root/reference/src/Manager/SlamManager.{h,cpp}; call stack in SURVEY.md section 3.1).
+#pragma once
+#include "core.h"
+#include "hip_tracker.h"
+
+#include <atomic>
+#include <thread>
+
+namespace LpSlam {
+
+class SlamManager {
+public:
+    SlamManager();
+    ~SlamManager();
+
+    void logToFile(std::string const& filename);
+    void setLogLevel(LpSlamLogLevel l);
+
+    void addOnReconstructionCallback(OnReconstructionCallback_t cb, void* ud) { m_onReconstruction = cb; m_onReconstructionData = ud; }
+    void addRequestNavDataCallback(RequestNavDataCallback_t cb, void* ud) { m_requestNavData = cb; m_requestNavDataData = ud; }
+    void addRequestNavTransformation(RequestNavTransformationCallback_t cb, void* ud) { m_requestNavTransformation = cb; m_requestNavTransformationData = ud; }
+    void addOnImageCallback(OnImageCallback_t cb, void* ud) { m_onImage = cb; m_onImageData = ud; }
+
+    bool addImageFromBuffer(uint32_t cameraNumber, LpSlamTimestamp timestamp, uint8_t* buffer, LpSlamImageDescription desc);
+    bool addStereoImageFromBuffer(uint32_t cameraNumber, LpSlamTimestamp timestamp, uint8_t* left, uint8_t* right, LpSlamImageDescription desc);
+
+    void setCameraConfiguration(LpSlamCameraConfiguration const& c) { m_camRegistry.setConfiguration(c); }
+    bool readConfigurationFile(std::string const& filename);
+    bool addSource(std::string const& name, std::string const& jsonConfig);
+    bool addTracker(std::string const& name, std::string const& jsonConfig);
+    bool addProcessor(std::string const& name, std::string const& jsonConfig);
+
+    void start();
+    void stop();
+    LpSlamStatus getSlamStatus();
+
+    std::size_t mappingGetFeatures(LpSlamMapBoundary b, LpSlamFeatureEntry* e, std::size_t n, LpSlamMatrix9x9 t);
+    std::size_t mappingGetFeaturesCount(LpSlamMapBoundary b);
+    bool mappingSetMode(bool enable);
+    bool mappingSetFilename(std::string const& f);
+    bool mappingExportCSV(std::string const& f);
+
+    // test hooks
+    size_t trackerCount() const { return m_trackers.size(); }
+    CameraRegistry& cameraRegistry() { return m_camRegistry; }
+    uint64_t framesProcessed() const { return m_framesProcessed.load(); }
+    uint64_t framesSkipped() const { return m_framesSkipped.load(); }
+
+private:
+    bool workerStep();
+    bool notifyStep();
+
+    CameraRegistry m_camRegistry;
+    CameraQueue m_camQueue;
+    SensorQueue m_sensorQueue;
+    ResultQueue m_resultQueue;
+    std::vector<std::unique_ptr<TrackerBase>> m_trackers;
+    std::vector<std::unique_ptr<ProcessorBase>> m_processors;
+    HipVslamTrackerBase* m_vslamTracker = nullptr;
+    std::thread m_worker, m_notifyWorker;
+    bool m_running = false;
+    bool m_requireOdometry = true;       // reference behaviour: frames without odometry are skipped (SlamManager.cpp:193-196)
+    int m_thread_num = -1;
+    std::atomic<uint64_t> m_framesProcessed{0}, m_framesSkipped{0};
+    double m_currentFps = 0.0;
+    std::optional<std::chrono::steady_clock::time_point> m_lastFrame;
+
+    OnReconstructionCallback_t m_onReconstruction = nullptr; void* m_onReconstructionData = nullptr;
+    RequestNavDataCallback_t m_requestNavData = nullptr; void* m_requestNavDataData = nullptr;
+    RequestNavTransformationCallback_t m_requestNavTransformation = nullptr; void* m_requestNavTransformationData = nullptr;
+    OnImageCallback_t m_onImage = nullptr; void* m_onImageData = nullptr;
+};
+
+}  // namespace LpSlam

@@ -1,0 +1,159 @@
+"""ctypes face of the host library (lpslam_amd/liblpslam.so): the plain-C shim over the C++ LpSlamManager mirror
+(lpslam_amd/host/interface.cpp).  Used by the tests; C++ clients include include/lpslam_manager.h instead."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblpslam.so")
+
+
+class ROSTimestamp(C.Structure):
+    _fields_ = [("seconds", C.c_int32), ("nanoseconds", C.c_int64)]
+
+
+class Position(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("x", "y", "z", "x_sigma", "y_sigma", "z_sigma")]
+
+
+class OrientationS(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("w", "x", "y", "z", "sigma")]
+
+
+class GlobalState(C.Structure):
+    _fields_ = [("position", Position), ("orientation", OrientationS), ("valid", C.c_bool)]
+
+
+class GlobalStateInTime(C.Structure):
+    _fields_ = [("timestamp", C.c_int64), ("ros_timestamp", ROSTimestamp), ("has_ros_timestamp", C.c_uint8), ("state", GlobalState)]
+
+
+class ImageDescription(C.Structure):
+    _fields_ = [("structure", C.c_int), ("format", C.c_int), ("image_conversion", C.c_int), ("height", C.c_uint32),
+                ("width", C.c_uint32), ("imageSize", C.c_uint32), ("imageSizeSecond", C.c_uint32),
+                ("hasRosTimestamp", C.c_uint8), ("rosTimestamp", ROSTimestamp)]
+
+
+class CameraConfiguration(C.Structure):
+    _fields_ = [("camera_number", C.c_uint32), ("distortion_function", C.c_int), ("f_x", C.c_double), ("f_y", C.c_double),
+                ("c_x", C.c_double), ("c_y", C.c_double), ("dist", C.c_double * 8), ("mask_type", C.c_int),
+                ("mask_parameter", C.c_double), ("resolution_x", C.c_int), ("resolution_y", C.c_int), ("fps", C.c_double),
+                ("focal_x_baseline", C.c_double), ("rotation", C.c_double * 9), ("translation", C.c_double * 3)]
+
+
+class Status(C.Structure):
+    _fields_ = [("localization", C.c_int), ("feature_points", C.c_long), ("key_frames", C.c_long), ("frame_time", C.c_double), ("fps", C.c_double)]
+
+
+class FeatureEntry(C.Structure):
+    _fields_ = [("x", C.c_float), ("y", C.c_float), ("z", C.c_float)]
+
+
+RECON_CB = C.CFUNCTYPE(None, C.POINTER(GlobalStateInTime), C.c_void_p)
+NAV_CB = C.CFUNCTYPE(C.c_int, ROSTimestamp, C.POINTER(GlobalStateInTime), C.POINTER(GlobalStateInTime), C.c_void_p)
+
+STEREO_TWO_BUFFER, FORMAT_8UC1, FORMAT_8UC3, NO_DISTORTION, ODOM_ONLY = 3, 1, 2, 3, 1
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("%s is missing: run __graft_entry__.build()" % LIB_PATH)
+        _lib = C.CDLL(LIB_PATH)
+        _lib.lpslam_manager_create.restype = C.c_void_p
+        for name in ("destroy", "start", "stop"):
+            getattr(_lib, "lpslam_manager_" + name).argtypes = [C.c_void_p]
+        _lib.lpslam_manager_set_log_level.argtypes = [C.c_void_p, C.c_int]
+        for name in ("add_tracker", "add_processor", "add_source"):
+            getattr(_lib, "lpslam_manager_" + name).argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
+        _lib.lpslam_manager_read_configuration_file.argtypes = [C.c_void_p, C.c_char_p]
+        _lib.lpslam_manager_set_camera_configuration.argtypes = [C.c_void_p, C.POINTER(CameraConfiguration)]
+        _lib.lpslam_manager_default_camera_configuration.argtypes = [C.POINTER(CameraConfiguration)]
+        _lib.lpslam_manager_on_reconstruction.argtypes = [C.c_void_p, RECON_CB, C.c_void_p]
+        _lib.lpslam_manager_request_nav_data.argtypes = [C.c_void_p, NAV_CB, C.c_void_p]
+        _lib.lpslam_manager_add_stereo_image.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p, C.POINTER(ImageDescription)]
+        _lib.lpslam_manager_add_image.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.POINTER(ImageDescription)]
+        _lib.lpslam_manager_status.argtypes = [C.c_void_p, C.POINTER(Status)]
+        _lib.lpslam_manager_features.argtypes = [C.c_void_p, C.POINTER(FeatureEntry), C.c_size_t, C.POINTER(C.c_float)]
+        _lib.lpslam_manager_features.restype = C.c_size_t
+        _lib.lpslam_manager_features_count.argtypes = [C.c_void_p]
+        _lib.lpslam_manager_features_count.restype = C.c_size_t
+        _lib.lpslam_roundtrip_state.argtypes = [C.POINTER(GlobalStateInTime), C.POINTER(GlobalStateInTime)]
+    return _lib
+
+
+def default_camera():
+    c = CameraConfiguration()
+    load().lpslam_manager_default_camera_configuration(C.byref(c))
+    return c
+
+
+class Manager:
+    def __init__(self, log_level=2):
+        self.lib = load()
+        self.h = self.lib.lpslam_manager_create()
+        self.lib.lpslam_manager_set_log_level(self.h, log_level)
+        self.results = []
+        self._keep = []
+
+    def close(self):
+        if self.h:
+            self.lib.lpslam_manager_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def read_configuration_file(self, path):
+        return bool(self.lib.lpslam_manager_read_configuration_file(self.h, path.encode()))
+
+    def add_tracker(self, name, cfg=""):
+        return bool(self.lib.lpslam_manager_add_tracker(self.h, name.encode(), cfg.encode()))
+
+    def add_processor(self, name, cfg=""):
+        return bool(self.lib.lpslam_manager_add_processor(self.h, name.encode(), cfg.encode()))
+
+    def add_source(self, name, cfg=""):
+        return bool(self.lib.lpslam_manager_add_source(self.h, name.encode(), cfg.encode()))
+
+    def set_camera(self, cam):
+        self.lib.lpslam_manager_set_camera_configuration(self.h, C.byref(cam))
+
+    def collect_results(self):
+        def cb(state, _):
+            s = state.contents
+            self.results.append(dict(timestamp=s.timestamp, valid=bool(s.state.valid),
+                                     p=(s.state.position.x, s.state.position.y, s.state.position.z),
+                                     q=(s.state.orientation.w, s.state.orientation.x, s.state.orientation.y, s.state.orientation.z)))
+        f = RECON_CB(cb); self._keep.append(f)
+        self.lib.lpslam_manager_on_reconstruction(self.h, f, None)
+
+    def provide_odometry(self):
+        def cb(ts, odom, mp, _):
+            odom.contents.state.valid = True
+            odom.contents.state.orientation.w = 1.0
+            return ODOM_ONLY
+        f = NAV_CB(cb); self._keep.append(f)
+        self.lib.lpslam_manager_request_nav_data(self.h, f, None)
+
+    def add_stereo(self, ts_ns, left, right, ros=True):
+        d = ImageDescription(STEREO_TWO_BUFFER, FORMAT_8UC1, 0, left.shape[0], left.shape[1], left.size, right.size,
+                             1 if ros else 0, ROSTimestamp(int(ts_ns // 10**9), int(ts_ns)))
+        return bool(self.lib.lpslam_manager_add_stereo_image(self.h, 0, int(ts_ns), left.ctypes.data, right.ctypes.data, C.byref(d)))
+
+    def start(self):
+        self.lib.lpslam_manager_start(self.h)
+
+    def stop(self):
+        self.lib.lpslam_manager_stop(self.h)
+
+    def status(self):
+        s = Status()
+        self.lib.lpslam_manager_status(self.h, C.byref(s))
+        return s
+
+    def features(self, cap=100000):
+        buf = (FeatureEntry * cap)()
+        t = (C.c_float * 9)(1, 0, 0, 0, 1, 0, 0, 0, 1)
+        n = self.lib.lpslam_manager_features(self.h, buf, cap, t)
+        return [(buf[i].x, buf[i].y, buf[i].z) for i in range(n)]

@@ -1,0 +1,112 @@
+"""CPU tests of the host mirror (lpslam_amd/host, through its C shim).  The first block restates the reference's own
+boundary tests: slam_manager.read_config_file / read_camera_calibration (src/test/SlamManagerTest.cpp:13-197),
+interface.type_conversion / add_marker-style smoke (src/test/InterfaceTest.cpp:14-44)."""
+import json
+import os
+import time
+
+import numpy as np
+import pytest
+
+
+@pytest.fixture(scope="module")
+def mgrlib(hiplib):
+    from lpslam_amd import _build, manager
+    _build.host_library()
+    manager.load()
+    return manager
+
+
+def _write(tmp_path, name, text):
+    p = tmp_path / name
+    p.write_text(text)
+    return str(p)
+
+
+def test_read_config_file(mgrlib, tmp_path):
+    m = mgrlib.Manager()
+    assert m.read_configuration_file(str(tmp_path / "does_not_exist.json")) is False
+    assert m.read_configuration_file(_write(tmp_path, "a.json", '{"datasources": [{"type": "FileSource"}]}')) is True
+    assert m.read_configuration_file(_write(tmp_path, "b.json", '{"datasources": [{"type": "FileSource" ')) is False
+    assert m.read_configuration_file(_write(tmp_path, "c.json", json.dumps(
+        {"datasources": [{"type": "FileSource", "configuration": {"file_names": ["a.jpg", "b.jpg"]}}]}))) is True
+
+
+def _cam(**over):
+    c = {"number": 0, "model": "fisheye", "fx": 286.18, "fy": 286.39, "cx": 416.94, "cy": 403.27,
+         "resolution_x": 848, "resolution_y": 800, "distortion": [-0.0115, 0.0479, -0.0451, 0.0083]}
+    c.update(over)
+    return c
+
+
+def test_read_camera_calibration(mgrlib, tmp_path):
+    m = mgrlib.Manager()
+    assert m.read_configuration_file(_write(tmp_path, "ok.json", json.dumps({"cameras": [_cam(), _cam(number=1, model="perspective")]})))
+    assert m.read_configuration_file(_write(tmp_path, "nd.json", json.dumps({"cameras": [_cam(model="no_distortion", focal_x_baseline=84.0)]})))
+    too_many = _cam(distortion=[0.1] * 9)
+    assert not m.read_configuration_file(_write(tmp_path, "d9.json", json.dumps({"cameras": [too_many]})))
+    no_res = _cam(distortion=[0.1] * 7); del no_res["resolution_x"]
+    assert not m.read_configuration_file(_write(tmp_path, "nr.json", json.dumps({"cameras": [no_res]})))
+    assert not m.read_configuration_file(_write(tmp_path, "um.json", json.dumps({"cameras": [_cam(model="pinhole9000")]})))
+    assert not m.read_configuration_file(_write(tmp_path, "nm.json", json.dumps({"cameras": [{"number": 0}]})))
+    assert m.read_configuration_file(_write(tmp_path, "rv.json", json.dumps({"cameras": [_cam(rotation_vec=[0.0, 0.1, 0.0], translation=[0.1, 0, 0])]})))
+    assert not m.read_configuration_file(_write(tmp_path, "rv4.json", json.dumps({"cameras": [_cam(rotation_vec=[0, 0, 0, 1])]})))
+
+
+def test_type_conversion_roundtrip(mgrlib):
+    import ctypes as C
+    s = mgrlib.GlobalStateInTime()
+    s.timestamp = 1234567890123; s.has_ros_timestamp = 1; s.ros_timestamp.seconds = 12; s.ros_timestamp.nanoseconds = 12000000345
+    s.state.valid = True
+    s.state.position.x, s.state.position.y, s.state.position.z = 1.5, -2.25, 3.0
+    s.state.position.x_sigma, s.state.position.y_sigma, s.state.position.z_sigma = 0.1, 0.2, 0.3
+    s.state.orientation.w, s.state.orientation.x, s.state.orientation.y, s.state.orientation.z, s.state.orientation.sigma = 0.5, 0.5, -0.5, 0.5, 0.01
+    out = mgrlib.GlobalStateInTime()
+    mgrlib.load().lpslam_roundtrip_state(C.byref(s), C.byref(out))
+    assert bytes(s)[:8] == bytes(out)[:8] and out.ros_timestamp.nanoseconds == 12000000345 and out.has_ros_timestamp == 1
+    for f in ("x", "y", "z", "x_sigma", "y_sigma", "z_sigma"):
+        assert getattr(out.state.position, f) == getattr(s.state.position, f)
+    for f in ("w", "x", "y", "z", "sigma"):
+        assert getattr(out.state.orientation, f) == getattr(s.state.orientation, f)
+    assert out.state.valid
+    assert C.sizeof(mgrlib.GlobalStateInTime) == 128 and C.sizeof(mgrlib.CameraConfiguration) == 240 and C.sizeof(mgrlib.ImageDescription) == 48
+    assert C.sizeof(mgrlib.Status) == 40
+
+
+def test_plugin_factories_and_config_keys(mgrlib, tmp_path):
+    m = mgrlib.Manager()
+    assert m.add_tracker("VSLAMStereo", '{"slamKeypoints": 2000, "cameraSetup": "stereo", "numLevels": 8, "_comment": "ignored"}')
+    assert m.add_tracker("VSLAMMono", "")
+    assert not m.add_tracker("VSLAMStereo", '{"noSuchKey": 1}')             # unknown key -> rejected (ConfigOptions)
+    assert not m.add_tracker("VSLAMStereo", '{"slamKeypoints": "many"}')    # wrong type
+    assert not m.add_tracker("Marker9000", "")                               # unknown plugin -> false
+    assert not m.add_processor("BlackoutImage", "") and not m.add_source("Zed", "")
+    cfg = {"manager": {"thread_num": 2, "record": False},
+           "trackers": [{"type": "VSLAMStereo", "configuration": {"slamKeypoints": 1000}}, {"_type": "VSLAMMono"}],
+           "cameras": [_cam(model="no_distortion", focal_x_baseline=84.0)]}
+    assert m.read_configuration_file(_write(tmp_path, "full.json", json.dumps(cfg)))
+    assert not m.read_configuration_file(_write(tmp_path, "bad.json", json.dumps({"trackers": [{"configuration": {}}]})))
+    assert not m.read_configuration_file(_write(tmp_path, "bad2.json", json.dumps({"trackers": [{"type": "Nope"}]})))
+
+
+def test_frames_without_odometry_are_skipped_and_reported(mgrlib):
+    """No nav callback -> every frame is skipped but the client still gets one (invalid) result per frame
+    (src/Manager/SlamManager.cpp:193-196,230-236).  Runs without a GPU: the tracker is never reached."""
+    m = mgrlib.Manager()
+    assert m.add_tracker("VSLAMStereo", '{"cameraSetup": "stereo"}')
+    m.collect_results()
+    m.start()                      # tracker start fails without camera configuration / GPU: logged, not fatal
+    img = np.zeros((120, 160), np.uint8)
+    for k in range(3):
+        assert m.add_stereo(1000 * (k + 1), img, img)
+    t0 = time.time()
+    while len(m.results) < 3 and time.time() - t0 < 5:
+        time.sleep(0.01)
+    m.stop()
+    assert len(m.results) == 3 and not any(r["valid"] for r in m.results)
+    assert m.status().localization == 0          # Off
+
+
+def test_default_camera_configuration(mgrlib):
+    c = mgrlib.default_camera()
+    assert c.fps == 25.0 and c.distortion_function == mgrlib.NO_DISTORTION and list(c.rotation) == [1, 0, 0, 0, 1, 0, 0, 0, 1]

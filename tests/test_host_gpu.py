@@ -1,0 +1,46 @@
+"""GPU test of the drop-in boundary end to end: stereo frames in through the manager, poses out through the callback."""
+import time
+
+import numpy as np
+import pytest
+
+from lpslam_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def test_stereo_sequence_through_the_manager(hiplib):
+    from lpslam_amd import _build, manager
+    _build.host_library()
+    w, h, n_frames = 640, 480, 24
+    k = synth.intrinsics(w, h)
+    seq = synth.StereoSequence(w, h, 4, n_points=6000)
+    m = manager.Manager()
+    for num in (0, 1):
+        c = manager.default_camera()
+        c.camera_number = num; c.f_x = k["fx"]; c.f_y = k["fy"]; c.c_x = k["cx"]; c.c_y = k["cy"]
+        c.resolution_x = w; c.resolution_y = h; c.focal_x_baseline = k["fxb"]
+        m.set_camera(c)
+    assert m.add_tracker("VSLAMStereo", '{"cameraSetup": "stereo", "slamKeypoints": 1000, "numLevels": 4, "keyframeInterval": 4}')
+    m.collect_results(); m.provide_odometry()
+    m.start()
+    frames = [seq.frame(i) for i in range(n_frames)]
+    for i, (l, r) in enumerate(frames):
+        assert m.add_stereo((i + 1) * 40_000_000, l, r)
+    t0 = time.time()
+    while len(m.results) < n_frames and time.time() - t0 < 60:
+        time.sleep(0.01)
+    st = m.status()
+    feats = m.features()
+    m.stop()
+    assert len(m.results) == n_frames
+    valid = [r for r in m.results if r["valid"]]
+    assert len(valid) >= n_frames - 2 and st.localization == 2 and st.key_frames >= 3 and st.feature_points > 100
+    assert len(feats) == st.feature_points
+    # ground truth: camera centre = (0, 0, 0.05 k) in optical axes -> lpslam axes (-y, x, z); first frame is the origin
+    last = valid[-1]
+    kf = n_frames - 1
+    assert abs(last["p"][2] - 0.05 * kf) < 0.05 and abs(last["p"][0]) < 0.05 and abs(last["p"][1]) < 0.05
+    zs = [r["p"][2] for r in valid]
+    assert all(b > a - 0.01 for a, b in zip(zs, zs[1:]))           # moving forward
+    assert abs(last["q"][0]) > 0.999                                # yaw stays below 0.2 degrees
