@@ -160,12 +160,10 @@ TrackerResult HipVslamTrackerBase::createTrackerResult(const Pose& p, TimeStamp 
 
 bool HipVslamTrackerBase::initializeMap(FrameData& f)
 {
-    // stereo initialisation: every keypoint with a valid, close-enough depth becomes a landmark (Initializer.num_min_triangulated_pts = 40,
-    // depth_threshold = 40 baselines; src/Trackers/OpenVSLAMTrackerBase.cpp:181-182,200)
-    const double baseline = m_cam.focal_x_baseline / m_cam.f_x;
-    const double depth_thr = 40.0 * baseline;
+    // stereo initialisation: every keypoint with a valid depth becomes a landmark once at least
+    // Initializer.num_min_triangulated_pts = 40 exist (src/Trackers/OpenVSLAMTrackerBase.cpp:181)
     int n = 0;
-    for (size_t i = 0; i < f.kpts.size(); ++i) if (f.depth[i] > 0 && f.depth[i] < depth_thr) ++n;
+    for (size_t i = 0; i < f.kpts.size(); ++i) if (f.depth[i] > 0) ++n;
     if (n < 40) return false;
     m_landmarks.clear(); m_keyframes.clear(); m_nextLandmarkId = 0;
     f.pose = Pose();
@@ -182,9 +180,19 @@ void HipVslamTrackerBase::insertKeyframe(FrameData& f)
     lpslam_hip_level_info(m_ctx, nullptr, nullptr, nullptr, nullptr, scales);
     Keyframe kf;
     kf.pose = f.pose;
+    // new landmarks: unmatched keypoints closer than depth_threshold (40 baselines, OpenVSLAMTrackerBase.cpp:200); when fewer
+    // than 100 landmarks would result, the closest ones beyond the threshold are taken too; the first keyframe takes all
+    std::vector<std::pair<float, int>> by_depth;
+    for (size_t i = 0; i < f.kpts.size(); ++i) if (f.landmark[i] < 0 && f.depth[i] > 0) by_depth.emplace_back(f.depth[i], (int)i);
+    std::sort(by_depth.begin(), by_depth.end());
+    std::vector<char> create(f.kpts.size(), 0);
+    int tracked = 0;
+    for (size_t i = 0; i < f.kpts.size(); ++i) tracked += f.landmark[i] >= 0;
+    for (size_t r = 0; r < by_depth.size(); ++r)
+        if (m_keyframes.empty() || by_depth[r].first < depth_thr || tracked + (int)r < 100) create[by_depth[r].second] = 1;
     for (size_t i = 0; i < f.kpts.size(); ++i) {
         int id = f.landmark[i];
-        if (id < 0 && f.depth[i] > 0 && f.depth[i] < depth_thr) {
+        if (id < 0 && create[i]) {
             // back-project into the world: X_w = R^T (X_c - t)
             const double z = f.depth[i];
             const double xc = (f.kpts[i].x - m_cam.c_x) * z / m_cam.f_x, yc = (f.kpts[i].y - m_cam.c_y) * z / m_cam.f_y;
