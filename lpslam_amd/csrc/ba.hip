@@ -111,61 +111,8 @@ __device__ __forceinline__ double ba_weight(const BaView& v, int k, int D, const
     return w;
 }
 
-// ---- point pass: H_ll, b_l, W per observation ------------------------------------------------------------------
-__global__ __launch_bounds__(128) void k_ba_point_pass(BaView v, int robust, int points_fixed)
-{
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= v.n_points) return;
-    if (points_fixed) {        // motion-only: landmarks are constants, no landmark blocks (x_l = 0)
-        for (int s = v.pt_start[j]; s < v.pt_start[j + 1]; ++s) { double* Wk = v.W + 18 * (size_t)v.pt_obs[s]; for (int i = 0; i < 18; ++i) Wk[i] = 0.0; }
-        for (int i = 0; i < 6; ++i) v.Hll[6 * (size_t)j + i] = 0.0;
-        for (int i = 0; i < 3; ++i) v.bl[3 * (size_t)j + i] = 0.0;
-        return;
-    }
-    const double X[3] = {v.points[3 * j], v.points[3 * j + 1], v.points[3 * j + 2]};
-    double h[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
-    for (int s = v.pt_start[j]; s < v.pt_start[j + 1]; ++s) {
-        const int k = v.pt_obs[s];
-        double* Wk = v.W + 18 * (size_t)k;
-        const int p = v.o_pose[k];
-        const int slot = v.pose_slot[p];
-        if (!v.o_active[k]) {
-#pragma unroll
-            for (int i = 0; i < 18; ++i) Wk[i] = 0.0;
-            continue;
-        }
-        double R[9], e[3], pc[3], A[3][3], B[3][6], rho0;
-        quat_to_rot(v.poses + 7 * p, R);
-        const int D = ba_residual(v, k, R, v.poses + 7 * p + 4, X, e, pc);
-        ba_jacobians(v.cam, R, pc, D, A, B);
-        const double w = ba_weight(v, k, D, e, robust, &rho0);
-        int idx = 0;
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-#pragma unroll
-            for (int c = a; c < 3; ++c) {
-                double s2 = 0;
-                _Pragma("unroll") for (int r = 0; r < 3; ++r) s2 += A[r][a] * w * A[r][c];
-                h[idx++] += s2;
-            }
-            double s3 = 0;
-            _Pragma("unroll") for (int r = 0; r < 3; ++r) s3 += A[r][a] * (-w * e[r]);
-            b[a] += s3;
-        }
-#pragma unroll
-        for (int a = 0; a < 6; ++a)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                double s2 = 0;
-                if (slot >= 0) _Pragma("unroll") for (int r = 0; r < 3; ++r) s2 += B[r][a] * w * A[r][c];
-                Wk[a * 3 + c] = s2;
-            }
-    }
-#pragma unroll
-    for (int i = 0; i < 6; ++i) v.Hll[6 * (size_t)j + i] = h[i];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) v.bl[3 * (size_t)j + i] = b[i];
-}
+constexpr int SPLIT = 8;              // wavefronts per keyframe in the pose pass
+constexpr int PV = 28;                // partial values per wavefront: 21 (H_pp upper) + 6 (b_p) + 1 (chi2)
 
 __device__ __forceinline__ double wave_sum(double x)
 {
@@ -173,11 +120,88 @@ __device__ __forceinline__ double wave_sum(double x)
     return x;
 }
 
-// ---- pose pass: H_pp, b_p, chi2 (one wavefront per keyframe; fixed keyframes only contribute chi2) ---------------
-__global__ __launch_bounds__(256) void k_ba_pose_pass(BaView v, int robust, int chi_only, double* chi_out)
+// ---- linearisation 1/4: one thread per observation: W = B^T w A and the observation's share of H_ll, b_l --------------
+__global__ __launch_bounds__(256) void k_ba_obs_lin(BaView v, int robust, int points_fixed, double* hl_obs)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= v.n_obs) return;
+    double* Wk = v.W + 18 * (size_t)k;
+    double* ho = hl_obs + 9 * (size_t)k;
+    const int p = v.o_pose[k];
+    const int slot = v.pose_slot[p];
+    if (!v.o_active[k] || points_fixed) {       // inactive edge, or motion-only mode (landmarks are constants: x_l = 0)
+#pragma unroll
+        for (int i = 0; i < 18; ++i) Wk[i] = 0.0;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) ho[i] = 0.0;
+        return;
+    }
+    const int j = v.o_point[k];
+    const double X[3] = {v.points[3 * j], v.points[3 * j + 1], v.points[3 * j + 2]};
+    double R[9], e[3], pc[3], A[3][3], B[3][6], rho0;
+    quat_to_rot(v.poses + 7 * p, R);
+    const int D = ba_residual(v, k, R, v.poses + 7 * p + 4, X, e, pc);
+    ba_jacobians(v.cam, R, pc, D, A, B);
+    const double w = ba_weight(v, k, D, e, robust, &rho0);
+    int idx = 0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int c = a; c < 3; ++c) {
+            double s2 = 0;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) s2 += A[r][a] * w * A[r][c];
+            ho[idx++] = s2;
+        }
+        double s3 = 0;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) s3 += A[r][a] * (-w * e[r]);
+        ho[6 + a] = s3;
+    }
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            double s2 = 0;
+            if (slot >= 0) {
+#pragma unroll
+                for (int r = 0; r < 3; ++r) s2 += B[r][a] * w * A[r][c];
+            }
+            Wk[a * 3 + c] = s2;
+        }
+}
+
+// ---- linearisation 2/4: H_ll, b_l per landmark = fixed-order sum over its observations; block maxima of diag H_ll ------
+__global__ __launch_bounds__(256) void k_ba_point_sum(BaView v, const double* hl_obs)
+{
+    __shared__ double sm[4];
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    double m = 0;
+    if (j < v.n_points) {
+        double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int s = v.pt_start[j]; s < v.pt_start[j + 1]; ++s) {
+            const double* ho = hl_obs + 9 * (size_t)v.pt_obs[s];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) acc[i] += ho[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) v.Hll[6 * (size_t)j + i] = acc[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) v.bl[3 * (size_t)j + i] = acc[6 + i];
+        m = fmax(fabs(acc[0]), fmax(fabs(acc[3]), fabs(acc[5])));
+    }
+    for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) v.part[blockIdx.x] = fmax(fmax(sm[0], sm[1]), fmax(sm[2], sm[3]));
+}
+
+// ---- linearisation 3/4 (and trial chi2): SPLIT wavefronts per keyframe, each over a slice of its observations ----------
+__global__ __launch_bounds__(256) void k_ba_pose_part(BaView v, int robust, int chi_only, double* partial)
 {
     const int lane = threadIdx.x & 63;
-    const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int wv = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int p = wv / SPLIT, sp = wv - p * SPLIT;
     if (p >= v.n_poses) return;
     double R[9];
     quat_to_rot(v.poses + 7 * p, R);
@@ -188,7 +212,8 @@ __global__ __launch_bounds__(256) void k_ba_pose_pass(BaView v, int robust, int 
     for (int i = 0; i < 21; ++i) h[i] = 0;
 #pragma unroll
     for (int i = 0; i < 6; ++i) b[i] = 0;
-    for (int s = v.ps_start[p] + lane; s < v.ps_start[p + 1]; s += 64) {
+    const bool full = !chi_only && slot >= 0;
+    for (int s = v.ps_start[p] + sp * 64 + lane; s < v.ps_start[p + 1]; s += 64 * SPLIT) {
         const int k = v.ps_obs[s];
         if (!v.o_active[k]) continue;
         const int j = v.o_point[k];
@@ -197,7 +222,7 @@ __global__ __launch_bounds__(256) void k_ba_pose_pass(BaView v, int robust, int 
         const int D = ba_residual(v, k, R, t, X, e, pc);
         const double w = ba_weight(v, k, D, e, robust, &rho0);
         chi += rho0;
-        if (chi_only || slot < 0) continue;
+        if (!full) continue;
         double A[3][3], B[3][6];
         ba_jacobians(v.cam, R, pc, D, A, B);
         int idx = 0;
@@ -206,105 +231,152 @@ __global__ __launch_bounds__(256) void k_ba_pose_pass(BaView v, int robust, int 
 #pragma unroll
             for (int c = a; c < 6; ++c) {
                 double s2 = 0;
-                _Pragma("unroll") for (int r = 0; r < 3; ++r) s2 += B[r][a] * w * B[r][c];
+#pragma unroll
+                for (int r = 0; r < 3; ++r) s2 += B[r][a] * w * B[r][c];
                 h[idx++] += s2;
             }
             double s3 = 0;
-            _Pragma("unroll") for (int r = 0; r < 3; ++r) s3 += B[r][a] * (-w * e[r]);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) s3 += B[r][a] * (-w * e[r]);
             b[a] += s3;
         }
     }
+    double* out = partial + ((size_t)p * SPLIT + sp) * PV;
     chi = wave_sum(chi);
-    if (lane == 0) chi_out[p] = chi;
-    if (chi_only || slot < 0) return;
+    if (lane == 0) out[27] = chi;
+    if (!full) return;
 #pragma unroll
     for (int i = 0; i < 21; ++i) h[i] = wave_sum(h[i]);
 #pragma unroll
     for (int i = 0; i < 6; ++i) b[i] = wave_sum(b[i]);
     if (lane == 0) {
-        double* H = v.Hpp + 36 * (size_t)slot;
-        int idx = 0;
-        for (int a = 0; a < 6; ++a)
-            for (int c = a; c < 6; ++c) { H[a * 6 + c] = h[idx]; H[c * 6 + a] = h[idx]; ++idx; }
-        for (int a = 0; a < 6; ++a) { v.bp[6 * slot + a] = b[a]; v.hppdiag[6 * slot + a] = H[a * 7]; }
+#pragma unroll
+        for (int i = 0; i < 21; ++i) out[i] = h[i];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) out[21 + i] = b[i];
     }
 }
 
-// ---- small deterministic reductions (single workgroup of one wavefront) -------------------------------------------
-// mode 0: out[0] = sum(in[0..n));  mode 1: out[0] = max |in|
-__global__ __launch_bounds__(64) void k_ba_reduce(const double* in, int n, int stride, double* out, int mode)
+// ---- linearisation 4/4 (and trial chi2): single workgroup combines the SPLIT partials in order, totals chi2, and
+//      reduces the landmark-side partials left in v.part (max diag H_ll after linearisation; scale terms after a trial)
+__global__ __launch_bounds__(1024) void k_ba_pose_combine(BaView v, int chi_only, const double* partial, double* chi_total,
+                                                          int part_n, int part_mode, double* part_out)
 {
-    const int lane = threadIdx.x;
-    double acc = 0;
-    for (int i = lane; i < n; i += 64) { const double x = in[(size_t)i * stride]; acc = mode ? fmax(acc, fabs(x)) : acc + x; }
-    for (int o = 32; o > 0; o >>= 1) { const double y = __shfl_xor(acc, o); acc = mode ? fmax(acc, y) : acc + y; }
-    if (lane == 0) out[0] = acc;
-}
-
-// max |diag H_ll| over landmarks: block partial maxima (max is order independent)
-__global__ __launch_bounds__(256) void k_ba_maxdiag_ll(BaView v, double* part)
-{
-    __shared__ double sm[4];
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    double m = 0;
-    if (j < v.n_points) { const double* h = v.Hll + 6 * (size_t)j; m = fmax(fabs(h[0]), fmax(fabs(h[3]), fabs(h[5]))); }
-    for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
-    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < v.n_poses * PV; i += 1024) {
+        const int p = i / PV, q = i - p * PV;
+        const int slot = v.pose_slot[p];
+        if (q != 27 && (chi_only || slot < 0)) continue;
+        double s = 0;
+        for (int sp = 0; sp < SPLIT; ++sp) s += partial[((size_t)p * SPLIT + sp) * PV + q];
+        if (q == 27) v.chi_pose[p] = s;
+        else if (q >= 21) v.bp[6 * slot + (q - 21)] = s;
+        else {
+            // upper-triangle index q -> (a, c)
+            int a = 0, rem = q;
+            while (rem >= 6 - a) { rem -= 6 - a; ++a; }
+            const int c = a + rem;
+            double* H = v.Hpp + 36 * (size_t)slot;
+            H[a * 6 + c] = s; H[c * 6 + a] = s;
+            if (a == c) v.hppdiag[6 * slot + a] = s;
+        }
+    }
     __syncthreads();
-    if (threadIdx.x == 0) part[blockIdx.x] = fmax(fmax(sm[0], sm[1]), fmax(sm[2], sm[3]));
+    if (tid < 64) {
+        double acc = 0;
+        for (int p = tid; p < v.n_poses; p += 64) acc += v.chi_pose[p];
+        acc = wave_sum(acc);
+        if (tid == 0) *chi_total = acc;
+    } else if (tid < 128 && part_n > 0) {
+        const int lane = tid - 64;
+        double acc = 0;
+        for (int i = lane; i < part_n; i += 64) acc = part_mode ? fmax(acc, v.part[i]) : acc + v.part[i];
+        for (int o = 32; o > 0; o >>= 1) { const double y = __shfl_xor(acc, o); acc = part_mode ? fmax(acc, y) : acc + y; }
+        if (lane == 0) *part_out = acc;
+    }
 }
 
-// ---- per trial: (H_ll + lambda I)^-1, Y = W H^-1, Y b_l -----------------------------------------------------------
-__global__ __launch_bounds__(128) void k_ba_point_inv(BaView v, double lambda)
+// ---- per trial 1/..: (H_ll + lambda I)^-1 ------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_ba_point_inv(BaView v, double lambda)
 {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= v.n_points) return;
     const double* hl = v.Hll + 6 * (size_t)j;
     const double a = hl[0] + lambda, b = hl[1], c = hl[2], d = hl[3] + lambda, e = hl[4], f = hl[5] + lambda;
     const double c00 = d * f - e * e, c01 = c * e - b * f, c02 = b * e - c * d;
     const double det = a * c00 + b * c01 + c * c02;
-    double Hi[9];
+    double* ho = v.Hinv + 6 * (size_t)j;
     if (fabs(det) > 0) {
         const double id = 1.0 / det;
-        Hi[0] = c00 * id; Hi[1] = c01 * id; Hi[2] = c02 * id;
-        Hi[3] = Hi[1]; Hi[4] = (a * f - c * c) * id; Hi[5] = (b * c - a * e) * id;
-        Hi[6] = Hi[2]; Hi[7] = Hi[5]; Hi[8] = (a * d - b * b) * id;
+        ho[0] = c00 * id; ho[1] = c01 * id; ho[2] = c02 * id;
+        ho[3] = (a * f - c * c) * id; ho[4] = (b * c - a * e) * id; ho[5] = (a * d - b * b) * id;
     } else {
-        for (int i = 0; i < 9; ++i) Hi[i] = 0;
-    }
-    double* ho = v.Hinv + 6 * (size_t)j;
-    ho[0] = Hi[0]; ho[1] = Hi[1]; ho[2] = Hi[2]; ho[3] = Hi[4]; ho[4] = Hi[5]; ho[5] = Hi[8];
-    const double b0 = v.bl[3 * (size_t)j], b1 = v.bl[3 * (size_t)j + 1], b2 = v.bl[3 * (size_t)j + 2];
-    for (int s = v.pt_start[j]; s < v.pt_start[j + 1]; ++s) {
-        const int k = v.pt_obs[s];
-        const double* Wk = v.W + 18 * (size_t)k;
-        double* Yk = v.Y + 18 * (size_t)k;
-        double* yb = v.Ybl + 6 * (size_t)k;
 #pragma unroll
-        for (int r = 0; r < 6; ++r) {
-            const double w0 = Wk[r * 3], w1 = Wk[r * 3 + 1], w2 = Wk[r * 3 + 2];
-            const double y0 = w0 * Hi[0] + w1 * Hi[3] + w2 * Hi[6];
-            const double y1 = w0 * Hi[1] + w1 * Hi[4] + w2 * Hi[7];
-            const double y2 = w0 * Hi[2] + w1 * Hi[5] + w2 * Hi[8];
-            Yk[r * 3] = y0; Yk[r * 3 + 1] = y1; Yk[r * 3 + 2] = y2;
-            yb[r] = y0 * b0 + y1 * b1 + y2 * b2;
-        }
+        for (int i = 0; i < 6; ++i) ho[i] = 0;
     }
 }
 
-// ---- Schur complement: one wavefront per block pair (i <= k) -------------------------------------------------------
-// S_ik = [i == k] H_pp,i - sum_terms Y_a W_b^T ; rhs_i = b_p,i - sum_{obs of i} Y b_l (diagonal blocks)
-__global__ __launch_bounds__(64) void k_ba_schur(BaView v)
+// ---- per trial 2/..: Y = W H_ll^-1 and Y b_l per observation -------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_ba_obs_y(BaView v)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= v.n_obs) return;
+    const int j = v.o_point[k];
+    const double* h = v.Hinv + 6 * (size_t)j;
+    const double H0 = h[0], H1 = h[1], H2 = h[2], H4 = h[3], H5 = h[4], H8 = h[5];
+    const double b0 = v.bl[3 * (size_t)j], b1 = v.bl[3 * (size_t)j + 1], b2 = v.bl[3 * (size_t)j + 2];
+    const double* Wk = v.W + 18 * (size_t)k;
+    double* Yk = v.Y + 18 * (size_t)k;
+    double* yb = v.Ybl + 6 * (size_t)k;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+        const double w0 = Wk[r * 3], w1 = Wk[r * 3 + 1], w2 = Wk[r * 3 + 2];
+        const double y0 = w0 * H0 + w1 * H1 + w2 * H2;
+        const double y1 = w0 * H1 + w1 * H4 + w2 * H5;
+        const double y2 = w0 * H2 + w1 * H5 + w2 * H8;
+        Yk[r * 3] = y0; Yk[r * 3 + 1] = y1; Yk[r * 3 + 2] = y2;
+        yb[r] = y0 * b0 + y1 * b1 + y2 * b2;
+    }
+}
+
+// ---- per trial 3/..: Schur complement.  Blocks [0, n_blocks): one wavefront per pose-block pair (i <= k); lane q < 36 owns
+//      output element (q / 6, q % 6) and walks the pair list in order (no cross-lane reduction, fixed summation order).
+//      Blocks [n_blocks, n_blocks + n_free): rhs_i = b_p,i - sum Y b_l over the observations of keyframe i.
+//      fused != 0 (single-GPU solve): lambda is added to the pose diagonal, rhs goes straight into row `dim` of S and the
+//      failure flag / rhs pivot are reset here, so no separate preparation launch is needed.
+__global__ __launch_bounds__(64) void k_ba_schur(BaView v, int n_blocks, double lambda, int fused)
 {
     const int lane = threadIdx.x;
-    // block pair index -> (i, k), i <= k, row-major upper triangle
-    int pidx = blockIdx.x;
-    int i = 0;
+    const int n = v.dim_pad;
+    if ((int)blockIdx.x >= n_blocks) {
+        const int i = blockIdx.x - n_blocks;
+        const int p = v.free_pose[i];
+        double r6[6] = {0, 0, 0, 0, 0, 0};
+        for (int s = v.ps_start[p] + lane; s < v.ps_start[p + 1]; s += 64) {
+            const double* yb = v.Ybl + 6 * (size_t)v.ps_obs[s];
+#pragma unroll
+            for (int q = 0; q < 6; ++q) r6[q] += yb[q];
+        }
+#pragma unroll
+        for (int q = 0; q < 6; ++q) r6[q] = wave_sum(r6[q]);
+        if (lane < 6) {
+            double val = 0;
+#pragma unroll
+            for (int q = 0; q < 6; ++q) if (q == lane) val = v.bp[6 * i + q] - r6[q];
+            v.rhs[6 * i + lane] = val;
+            if (fused) v.S[(size_t)v.dim * n + 6 * i + lane] = val;
+        }
+        if (fused && i == 0 && lane == 63) { v.S[(size_t)v.dim * n + v.dim] = 1e200; v.scal[5] = 0.0; }
+        return;
+    }
+    int pidx = blockIdx.x, i = 0;
     {
         int rowlen = v.n_free;
         while (pidx >= rowlen) { pidx -= rowlen; --rowlen; ++i; }
     }
     const int k = i + pidx;
+    // lanes stride over the pair list with 36 private accumulators; partials are then summed in lane order through LDS
+    __shared__ double part[64 * 37];
     double acc[36];
 #pragma unroll
     for (int q = 0; q < 36; ++q) acc[q] = 0;
@@ -322,191 +394,28 @@ __global__ __launch_bounds__(64) void k_ba_schur(BaView v)
                 acc[r * 6 + c] += y[r * 3] * w[c * 3] + y[r * 3 + 1] * w[c * 3 + 1] + y[r * 3 + 2] * w[c * 3 + 2];
     }
 #pragma unroll
-    for (int q = 0; q < 36; ++q) acc[q] = wave_sum(acc[q]);
-    const int n = v.dim_pad;
+    for (int q = 0; q < 36; ++q) part[lane * 37 + q] = acc[q];
+    __syncthreads();
+    if (lane >= 36) return;
+    const int r = lane / 6, c = lane - r * 6;
+    double sum = 0;
+    for (int l = 0; l < 64; ++l) sum += part[l * 37 + lane];
     if (i == k) {
-        const int p = v.free_pose[i];
-        double r6[6] = {0, 0, 0, 0, 0, 0};
-        for (int s = v.ps_start[p] + lane; s < v.ps_start[p + 1]; s += 64) {
-            const double* yb = v.Ybl + 6 * (size_t)v.ps_obs[s];
-#pragma unroll
-            for (int q = 0; q < 6; ++q) r6[q] += yb[q];
-        }
-#pragma unroll
-        for (int q = 0; q < 6; ++q) r6[q] = wave_sum(r6[q]);
-        if (lane == 0) {
-            for (int q = 0; q < 6; ++q) v.rhs[6 * i + q] = v.bp[6 * i + q] - r6[q];
-            const double* H = v.Hpp + 36 * (size_t)i;
-            for (int r = 0; r < 6; ++r)
-                for (int c = 0; c < 6; ++c) v.S[(size_t)(6 * i + r) * n + 6 * i + c] = H[r * 6 + c] - acc[r * 6 + c];
-        }
-    } else if (lane == 0) {
-        for (int r = 0; r < 6; ++r)
-            for (int c = 0; c < 6; ++c) {
-                const double val = -acc[r * 6 + c];
-                v.S[(size_t)(6 * i + r) * n + 6 * k + c] = val;
-                v.S[(size_t)(6 * k + c) * n + 6 * i + r] = val;
-            }
+        double val = v.Hpp[36 * (size_t)i + lane] - sum;
+        if (fused && r == c) val += lambda;
+        v.S[(size_t)(6 * i + r) * n + 6 * i + c] = val;
+    } else {
+        v.S[(size_t)(6 * i + r) * n + 6 * k + c] = -sum;
+        v.S[(size_t)(6 * k + c) * n + 6 * i + r] = -sum;
     }
 }
 
-// ---- blocked Cholesky of (S + lambda I), rhs carried as row `dim` so that L[dim][0..dim) = L^-1 rhs ------------------
+// preparation for the partitioned (all-reduced) solve: lambda on the diagonal, rhs row, flag / pivot reset
 __global__ __launch_bounds__(256) void k_chol_prep(double* S, const double* rhs, int dim, int n, double lambda, double* scal)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i == 0) scal[5] = 0.0;                      // failure flag
+    if (i == 0) { scal[5] = 0.0; S[(size_t)dim * n + dim] = 1e200; }
     if (i < dim) { S[(size_t)i * n + i] += lambda; S[(size_t)dim * n + i] = rhs[i]; }
-    else if (i < n) {
-        for (int c = 0; c < i; ++c) if (i != dim || c >= dim) S[(size_t)i * n + c] = 0.0;
-        S[(size_t)i * n + i] = (i == dim) ? 1e200 : 1.0;
-    }
-}
-
-// panel step kb: every workgroup (one wavefront) factors the diagonal block in LDS; workgroup b > 0 then solves
-// row block kb + b against it.
-__global__ __launch_bounds__(64) void k_chol_panel(double* S, int n, int kb, double* scal)
-{
-    __shared__ double Lk[NB][NB + 1];
-    __shared__ double Ai[NB][NB + 1];
-    const int lane = threadIdx.x;
-    const int ib = kb + blockIdx.x;
-    const size_t d0 = (size_t)kb * NB;
-    for (int t = lane; t < NB * NB; t += 64) { const int r = t / NB, c = t % NB; Lk[r][c] = S[(d0 + r) * n + d0 + c]; }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    bool fail = false;
-    for (int j = 0; j < NB; ++j) {
-        double d = Lk[j][j];
-        if (!(d > 0.0)) { fail = true; d = 1.0; }
-        d = sqrt(d);
-        const double lij = lane > j && lane < NB ? Lk[lane][j] / d : 0.0;
-        __builtin_amdgcn_wave_barrier();
-        if (lane == j) Lk[j][j] = d;
-        if (lane > j && lane < NB) Lk[lane][j] = lij;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        // trailing update of the block: rows lane (and lane+32 half handles the upper column range)
-        const int r = lane & 31, half = lane >> 5;
-        if (r > j) {
-            const double lr = Lk[r][j];
-            for (int c = j + 1 + half; c <= r; c += 2) Lk[r][c] -= lr * Lk[c][j];
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    }
-    if (blockIdx.x == 0) {
-        if (fail && lane == 0) scal[5] = 1.0;
-        for (int t = lane; t < NB * NB; t += 64) { const int r = t / NB, c = t % NB; if (c <= r) S[(d0 + r) * n + d0 + c] = Lk[r][c]; }
-        return;
-    }
-    const size_t r0 = (size_t)ib * NB;
-    for (int t = lane; t < NB * NB; t += 64) { const int r = t / NB, c = t % NB; Ai[r][c] = S[(r0 + r) * n + d0 + c]; }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    if (lane < NB) {
-        // X L^T = A  ->  x[c] = (a[c] - sum_{m<c} x[m] L[c][m]) / L[c][c]
-        for (int c = 0; c < NB; ++c) {
-            double s = Ai[lane][c];
-            for (int m = 0; m < c; ++m) s -= Ai[lane][m] * Lk[c][m];
-            Ai[lane][c] = s / Lk[c][c];
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    for (int t = lane; t < NB * NB; t += 64) { const int r = t / NB, c = t % NB; S[(r0 + r) * n + d0 + c] = Ai[r][c]; }
-}
-
-// trailing update after panel kb: A_ij -= L_ik L_jk^T for block pairs i >= j > kb (lower triangle)
-__global__ __launch_bounds__(256) void k_chol_update(double* S, int n, int kb)
-{
-    __shared__ double Li[NB][NB + 1];
-    __shared__ double Lj[NB][NB + 1];
-    // pair index -> (i, j) in the lower triangle of the trailing (nb - kb - 1) blocks
-    int pidx = blockIdx.x, bi = 0;
-    while (pidx > bi) { pidx -= bi + 1; ++bi; }
-    const int i = kb + 1 + bi, j = kb + 1 + pidx;
-    const size_t ri = (size_t)i * NB, rj = (size_t)j * NB, ck = (size_t)kb * NB;
-    for (int t = threadIdx.x; t < NB * NB; t += 256) {
-        const int r = t / NB, c = t % NB;
-        Li[r][c] = S[(ri + r) * n + ck + c];
-        Lj[r][c] = S[(rj + r) * n + ck + c];
-    }
-    __syncthreads();
-    const int r = threadIdx.x / 8, c0 = (threadIdx.x % 8) * 4;
-    double acc[4] = {0, 0, 0, 0};
-    for (int m = 0; m < NB; ++m) {
-        const double a = Li[r][m];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc[q] += a * Lj[c0 + q][m];
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) S[(ri + r) * n + rj + c0 + q] -= acc[q];
-}
-
-// backward substitution L^T x = y with y = L[dim][0..dim); single workgroup, x in LDS
-__global__ __launch_bounds__(256) void k_chol_backsolve(const double* S, int n, int dim, double* xp)
-{
-    extern __shared__ double xs[];                 // [n]
-    __shared__ double part[8][NB];
-    const int tid = threadIdx.x;
-    for (int i = tid; i < n; i += 256) xs[i] = i < dim ? S[(size_t)dim * n + i] : 0.0;
-    __syncthreads();
-    const int nb = (dim + NB - 1) / NB;
-    for (int kb = nb - 1; kb >= 0; --kb) {
-        const int c0 = kb * NB;
-        // s_c = sum_{i >= c0 + NB, i < dim} L[i][c] x[i] : 32 columns x 8 row groups
-        const int c = tid & 31, g = tid >> 5;
-        double s = 0;
-        for (int i = c0 + NB + g; i < dim; i += 8) s += S[(size_t)i * n + c0 + c] * xs[i];
-        part[g][c] = s;
-        __syncthreads();
-        if (tid < 64) {
-            // diagonal block back-solve by one wavefront, columns from the last to the first
-            double y = 0;
-            if (tid < NB) { y = xs[c0 + tid]; for (int q = 0; q < 8; ++q) y -= part[q][tid]; }
-            for (int cc = NB - 1; cc >= 0; --cc) {
-                const int gi = c0 + cc;
-                double xv = 0;
-                if (gi < dim) xv = __shfl(y, cc) / S[(size_t)gi * n + gi];
-                else xv = 0;
-                if (tid == cc) y = xv;
-                if (tid < cc && gi < dim) y -= S[(size_t)gi * n + c0 + tid] * xv;
-            }
-            if (tid < NB) xs[c0 + tid] = y;
-        }
-        __syncthreads();
-    }
-    for (int i = tid; i < dim; i += 256) xp[i] = xs[i];
-}
-
-// ---- landmark back substitution, state update, scale terms ----------------------------------------------------------
-__global__ __launch_bounds__(128) void k_ba_backsub(BaView v, double lambda, double* points_out)
-{
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    double sc = 0;
-    if (j < v.n_points) {
-        double r[3] = {v.bl[3 * (size_t)j], v.bl[3 * (size_t)j + 1], v.bl[3 * (size_t)j + 2]};
-        for (int s = v.pt_start[j]; s < v.pt_start[j + 1]; ++s) {
-            const int k = v.pt_obs[s];
-            const int slot = v.pose_slot[v.o_pose[k]];
-            if (slot < 0) continue;
-            const double* Wk = v.W + 18 * (size_t)k;
-            const double* x = v.xp + 6 * slot;
-#pragma unroll
-            for (int c = 0; c < 3; ++c)
-#pragma unroll
-                for (int rr = 0; rr < 6; ++rr) r[c] -= Wk[rr * 3 + c] * x[rr];
-        }
-        const double* h = v.Hinv + 6 * (size_t)j;
-        const double x0 = h[0] * r[0] + h[1] * r[1] + h[2] * r[2];
-        const double x1 = h[1] * r[0] + h[3] * r[1] + h[4] * r[2];
-        const double x2 = h[2] * r[0] + h[4] * r[1] + h[5] * r[2];
-        points_out[3 * (size_t)j] = v.points[3 * (size_t)j] + x0;
-        points_out[3 * (size_t)j + 1] = v.points[3 * (size_t)j + 1] + x1;
-        points_out[3 * (size_t)j + 2] = v.points[3 * (size_t)j + 2] + x2;
-        sc = x0 * (lambda * x0 + v.bl[3 * (size_t)j]) + x1 * (lambda * x1 + v.bl[3 * (size_t)j + 1]) + x2 * (lambda * x2 + v.bl[3 * (size_t)j + 2]);
-    }
-    // per-block partial of the landmark part of computeScale (fixed order inside the block)
-    __shared__ double sm[2];
-    sc = wave_sum(sc);
-    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = sc;
-    __syncthreads();
-    if (threadIdx.x == 0) v.part[blockIdx.x] = sm[0] + sm[1];
 }
 
 __device__ __forceinline__ void pose_oplus(const double* pose, const double* d, double* out)
@@ -546,19 +455,224 @@ __device__ __forceinline__ void pose_oplus(const double* pose, const double* d, 
     for (int i = 0; i < 3; ++i) out[4 + i] = tn[i];
 }
 
-// poses_out = exp(x_p) * poses; scal[3] = pose part of computeScale (single workgroup, fixed order)
-__global__ __launch_bounds__(64) void k_ba_pose_update(BaView v, double lambda, double* poses_out)
+__device__ __forceinline__ double readlane_f64(double v, int lane)
 {
-    const int lane = threadIdx.x;
-    double sc = 0;
-    for (int p = lane; p < v.n_poses; p += 64) {
-        const int slot = v.pose_slot[p];
-        if (slot < 0) { for (int i = 0; i < 7; ++i) poses_out[7 * p + i] = v.poses[7 * p + i]; continue; }
-        pose_oplus(v.poses + 7 * p, v.xp + 6 * slot, poses_out + 7 * p);
-        for (int a = 0; a < 6; ++a) { const double x = v.xp[6 * slot + a]; sc += x * (lambda * x + v.bp[6 * slot + a]); }
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, lane);
+    hi = __builtin_amdgcn_readlane(hi, lane);
+    return __hiloint2double(hi, lo);
+}
+
+// One launch per panel column.  Launch kb (= -1 .. nb-2) produces panel column j = kb + 1 and applies panel kb to the rest
+// of the trailing matrix (one-step lookahead fused into a single launch, so the chain costs one kernel boundary per panel):
+//   panel workgroups (one per row block i >= j): D = A_jj - L_jk L_jk^T, B = A_ij - L_ik L_jk^T (256 threads), then ONE
+//     wavefront holds D's rows in lanes 0-31 and B's rows in lanes 32-63 (a 64 x 32 tall panel, one row per lane in 32
+//     registers) and runs the unblocked factorisation with v_readlane broadcasts: the same rank-1 update factors D and
+//     solves B L_jj^T = B at once.  D is factored redundantly by every panel workgroup (no cross-workgroup dependency).
+//   update workgroups: A_i2,j2 -= L_i2,k L_j2,k^T for i2 >= j2 >= j + 1.
+__global__ __launch_bounds__(256) void k_chol_step(double* S, int n, int nb, int kb, double* scal)
+{
+    __shared__ double Lj[NB][NB + 1];
+    __shared__ double Li[NB][NB + 1];
+    __shared__ double Dm[NB][NB + 1];
+    __shared__ double Bm[NB][NB + 1];
+    const int j = kb + 1;
+    const int n_panel = nb - j;
+    const int tid = threadIdx.x;
+    const size_t ck = (size_t)(kb < 0 ? 0 : kb) * NB;
+    if ((int)blockIdx.x >= n_panel) {
+        // ---- trailing update with panel kb
+        int pidx = blockIdx.x - n_panel, bi = 0;
+        while (pidx > bi) { pidx -= bi + 1; ++bi; }
+        const int i2 = j + 1 + bi, j2 = j + 1 + pidx;
+        const size_t ri = (size_t)i2 * NB, rj = (size_t)j2 * NB;
+        for (int t = tid; t < NB * NB; t += 256) {
+            const int r = t / NB, c = t % NB;
+            Li[r][c] = S[(ri + r) * n + ck + c];
+            Lj[r][c] = S[(rj + r) * n + ck + c];
+        }
+        __syncthreads();
+        const int r = tid / 8, c0 = (tid % 8) * 4;
+        double acc[4] = {0, 0, 0, 0};
+        for (int m = 0; m < NB; ++m) {
+            const double a = Li[r][m];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] = fma(a, Lj[c0 + q][m], acc[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) S[(ri + r) * n + rj + c0 + q] -= acc[q];
+        return;
     }
+    // ---- panel column j, row block i
+    const int i = j + blockIdx.x;
+    const size_t rj = (size_t)j * NB, ri = (size_t)i * NB;
+    const bool has_b = i > j;
+    for (int t = tid; t < NB * NB; t += 256) {
+        const int r = t / NB, c = t % NB;
+        Dm[r][c] = S[(rj + r) * n + rj + c];
+        Bm[r][c] = has_b ? S[(ri + r) * n + rj + c] : 0.0;
+        if (kb >= 0) { Lj[r][c] = S[(rj + r) * n + ck + c]; Li[r][c] = has_b ? S[(ri + r) * n + ck + c] : 0.0; }
+    }
+    __syncthreads();
+    if (kb >= 0) {
+        const int r = tid / 8, c0 = (tid % 8) * 4;
+        double accd[4] = {0, 0, 0, 0}, accb[4] = {0, 0, 0, 0};
+        for (int m = 0; m < NB; ++m) {
+            const double a = Lj[r][m], b = Li[r][m];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const double l = Lj[c0 + q][m]; accd[q] = fma(a, l, accd[q]); accb[q] = fma(b, l, accb[q]); }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { Dm[r][c0 + q] -= accd[q]; Bm[r][c0 + q] -= accb[q]; }
+        __syncthreads();
+    }
+    if (tid >= 64) return;
+    const int lane = tid;
+    double a[NB];
+#pragma unroll
+    for (int c = 0; c < NB; ++c) a[c] = lane < NB ? Dm[lane][c] : Bm[lane - NB][c];
+    bool fail = false;
+#pragma unroll
+    for (int jj = 0; jj < NB; ++jj) {
+        double djj = readlane_f64(a[jj], jj);
+        if (!(djj > 0.0)) { fail = true; djj = 1.0; }
+        // 1/sqrt by v_rsq_f64 + two Newton steps (full double precision), so the column scaling is a multiply
+        double rs = __builtin_amdgcn_rsq(djj);
+        rs = rs * fma(-0.5 * djj * rs, rs, 1.5);
+        rs = rs * fma(-0.5 * djj * rs, rs, 1.5);
+        const double lcol = a[jj] * rs;
+        a[jj] = lane == jj ? djj * rs : lcol;
+#pragma unroll
+        for (int c = jj + 1; c < NB; ++c) {
+            const double lc = readlane_f64(lcol, c);
+            a[c] = fma(-lcol, lc, a[c]);
+        }
+    }
+    if (lane < NB) {
+        if (!has_b) {        // the diagonal workgroup publishes L_jj (lower triangle) and the failure flag
+#pragma unroll
+            for (int c = 0; c < NB; ++c) if (c <= lane) S[(rj + lane) * n + rj + c] = a[c];
+            if (fail && lane == 0) scal[5] = 1.0;
+        }
+    } else if (has_b) {
+#pragma unroll
+        for (int c = 0; c < NB; ++c) S[(ri + lane - NB) * n + rj + c] = a[c];
+    }
+}
+
+// backward substitution L^T x = y with y = L[dim][0..dim), then the pose update x_p -> trial poses and the pose part of
+// computeScale.  Single 1024-thread workgroup; per 32-block: one wavefront solves the diagonal block from registers (column
+// values preloaded, v_readlane broadcasts, reciprocal pivots) while the next diagonal block is staged into the other LDS
+// buffer; then all threads push x_k into the earlier part of y (4 row groups per column, combined in fixed order).
+__global__ __launch_bounds__(1024) void k_chol_backsolve(BaView v, double lambda, double* poses_out)
+{
+    extern __shared__ double xs[];                 // [n]
+    __shared__ double Ld[2][NB][NB + 1];
+    __shared__ double upd[4][320];
+    const double* S = v.S;
+    const int n = v.dim_pad, dim = v.dim;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < n; i += 1024) xs[i] = i < dim ? S[(size_t)dim * n + i] : 0.0;
+    const int nb = (dim + NB - 1) / NB;
+    auto stage = [&](int kb, int buf) {
+        const int c0 = kb * NB;
+        const int r = tid / NB, c = tid % NB;      // 1024 threads = one element each
+        Ld[buf][r][c] = (c0 + r < dim && c <= r) ? S[(size_t)(c0 + r) * n + c0 + c] : (r == c ? 1.0 : 0.0);
+    };
+    stage(nb - 1, (nb - 1) & 1);
+    __syncthreads();
+    for (int kb = nb - 1; kb >= 0; --kb) {
+        const int c0 = kb * NB, buf = kb & 1;
+        if (tid < 64) {
+            const int lane = tid;
+            double col[NB];                        // col[cc] = L[c0+cc][c0+lane]
+#pragma unroll
+            for (int cc = 0; cc < NB; ++cc) col[cc] = lane < NB ? Ld[buf][cc][lane] : 0.0;
+            const double invd = lane < NB ? 1.0 / Ld[buf][lane][lane] : 0.0;
+            double y = lane < NB ? xs[c0 + lane] : 0.0;
+#pragma unroll
+            for (int cc = NB - 1; cc >= 0; --cc) {
+                const double xv = readlane_f64(y, cc) * readlane_f64(invd, cc);
+                if (lane == cc) y = xv;
+                if (lane < cc) y = fma(-col[cc], xv, y);
+            }
+            if (lane < NB) xs[c0 + lane] = (c0 + lane < dim) ? y : 0.0;
+        }
+        if (kb > 0) stage(kb - 1, (kb - 1) & 1);   // every thread stages one element of the next diagonal block
+        __syncthreads();
+        // y[c] -= sum_{r in block} L[c0+r][c] x[c0+r] for every earlier column c < c0; rows split into 4 groups of 8
+        for (int cbase = 0; cbase < c0; cbase += 256) {
+            const int c = cbase + (tid & 255), g = tid >> 8;
+            double sacc = 0;
+            if (c < c0) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) { const int rr = c0 + g * 8 + r; if (rr < dim) sacc = fma(S[(size_t)rr * n + c], xs[rr], sacc); }
+            }
+            upd[g][tid & 255] = sacc;
+            __syncthreads();
+            if (tid < 256 && c < c0) xs[c] -= (upd[0][tid] + upd[1][tid]) + (upd[2][tid] + upd[3][tid]);
+            __syncthreads();
+        }
+    }
+    for (int i = tid; i < dim; i += 1024) v.xp[i] = xs[i];
+    // pose update: poses_out = exp(x_p) * poses; scal[3] = sum x_p (lambda x_p + b_p) (fixed order, one wavefront)
+    if (tid < 64) {
+        double sc = 0;
+        for (int p = tid; p < v.n_poses; p += 64) {
+            const int slot = v.pose_slot[p];
+            if (slot < 0) { for (int i = 0; i < 7; ++i) poses_out[7 * p + i] = v.poses[7 * p + i]; continue; }
+            pose_oplus(v.poses + 7 * p, xs + 6 * slot, poses_out + 7 * p);
+            for (int a = 0; a < 6; ++a) { const double x = xs[6 * slot + a]; sc += x * (lambda * x + v.bp[6 * slot + a]); }
+        }
+        sc = wave_sum(sc);
+        if (tid == 0) v.scal[3] = sc;
+    }
+}
+
+// ---- landmark back substitution and update; block partials of the landmark part of computeScale -----------------------------
+__global__ __launch_bounds__(256) void k_ba_backsub(BaView v, double lambda, double* points_out)
+{
+    // 4 lanes per landmark: each takes every fourth observation, partial sums combined in lane order
+    const int g = blockIdx.x * 64 + (threadIdx.x >> 2), sub = threadIdx.x & 3;
+    double sc = 0;
+    double r[3] = {0, 0, 0};
+    if (g < v.n_points) {
+        for (int s = v.pt_start[g] + sub; s < v.pt_start[g + 1]; s += 4) {
+            const int k = v.pt_obs[s];
+            const int slot = v.pose_slot[v.o_pose[k]];
+            if (slot < 0) continue;
+            const double* Wk = v.W + 18 * (size_t)k;
+            const double* x = v.xp + 6 * slot;
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int rr = 0; rr < 6; ++rr) r[c] += Wk[rr * 3 + c] * x[rr];
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const double a1 = __shfl_xor(r[c], 1);
+        const double lo = (sub & 1) ? a1 + r[c] : r[c] + a1;      // (s0 + s1) and (s2 + s3), same order in both lanes
+        const double a2 = __shfl_xor(lo, 2);
+        r[c] = (sub & 2) ? a2 + lo : lo + a2;                     // (s0 + s1) + (s2 + s3)
+    }
+    if (g < v.n_points && sub == 0) {
+        const double b0 = v.bl[3 * (size_t)g], b1 = v.bl[3 * (size_t)g + 1], b2 = v.bl[3 * (size_t)g + 2];
+        const double q0 = b0 - r[0], q1 = b1 - r[1], q2 = b2 - r[2];
+        const double* h = v.Hinv + 6 * (size_t)g;
+        const double x0 = h[0] * q0 + h[1] * q1 + h[2] * q2;
+        const double x1 = h[1] * q0 + h[3] * q1 + h[4] * q2;
+        const double x2 = h[2] * q0 + h[4] * q1 + h[5] * q2;
+        points_out[3 * (size_t)g] = v.points[3 * (size_t)g] + x0;
+        points_out[3 * (size_t)g + 1] = v.points[3 * (size_t)g + 1] + x1;
+        points_out[3 * (size_t)g + 2] = v.points[3 * (size_t)g + 2] + x2;
+        sc = x0 * (lambda * x0 + b0) + x1 * (lambda * x1 + b1) + x2 * (lambda * x2 + b2);
+    }
+    __shared__ double sm[4];
     sc = wave_sum(sc);
-    if (lane == 0) v.scal[3] = sc;
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = sc;
+    __syncthreads();
+    if (threadIdx.x == 0) v.part[blockIdx.x] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
 }
 
 // per-observation chi2 (non robust) and depth sign
@@ -595,6 +709,7 @@ struct lpslam_hip_ba {
     double* d_red = nullptr; int64_t red_n = 0; bool red_external = false;
     double *d_xp = nullptr, *d_xl = nullptr, *d_chi_pose = nullptr, *d_part = nullptr, *d_scal = nullptr;
     double* d_chi_obs = nullptr; uint8_t* d_depth = nullptr;
+    double *d_hl_obs = nullptr, *d_partial = nullptr;
     int* d_blk_start = nullptr; int2* d_blk_terms = nullptr;
     int part_n = 0;
     BaCam cam{};
@@ -640,59 +755,57 @@ BaView make_view(lpslam_hip_ba* b, int state)
     return v;
 }
 
-// linearise at the accepted state: blocks, b, chi2 (-> chi_cur), max diagonal (-> scal[4] = landmark part)
+// linearise at the accepted state: blocks, b, chi2 (-> chi_cur), max diag H_ll (-> scal[4])
 int ba_linearize(lpslam_hip_ba* b)
 {
     BaView v = make_view(b, b->cur);
     hipStream_t s = b->stream;
-    if (b->n_points) hipLaunchKernelGGL(k_ba_point_pass, dim3((b->n_points + 127) / 128), dim3(128), 0, s, v, b->robust, b->points_fixed);
-    hipLaunchKernelGGL(k_ba_pose_pass, dim3((b->n_poses + 3) / 4), dim3(256), 0, s, v, b->robust, 0, b->d_chi_pose);
-    hipLaunchKernelGGL(k_ba_reduce, dim3(1), dim3(64), 0, s, b->d_chi_pose, b->n_poses, 1, v.chi_cur, 0);
-    if (b->n_points) {
-        const int nb = (b->n_points + 255) / 256;
-        hipLaunchKernelGGL(k_ba_maxdiag_ll, dim3(nb), dim3(256), 0, s, v, b->d_part);
-        hipLaunchKernelGGL(k_ba_reduce, dim3(1), dim3(64), 0, s, b->d_part, nb, 1, b->d_scal + 4, 1);
-    }
+    if (b->n_obs) hipLaunchKernelGGL(k_ba_obs_lin, dim3((b->n_obs + 255) / 256), dim3(256), 0, s, v, b->robust, b->points_fixed, b->d_hl_obs);
+    hipLaunchKernelGGL(k_ba_pose_part, dim3((b->n_poses * SPLIT + 3) / 4), dim3(256), 0, s, v, b->robust, 0, b->d_partial);
+    const int pb = (b->n_points + 255) / 256;
+    if (b->n_points) hipLaunchKernelGGL(k_ba_point_sum, dim3(pb), dim3(256), 0, s, v, b->d_hl_obs);
+    hipLaunchKernelGGL(k_ba_pose_combine, dim3(1), dim3(1024), 0, s, v, 0, b->d_partial, v.chi_cur, pb, 1, b->d_scal + 4);
     LP_HIP(hipGetLastError());
     return LPSLAM_HIP_OK;
 }
 
-// Schur complement for the current lambda into the reduced buffer (pose diagonal WITHOUT lambda)
-int ba_reduce_system(lpslam_hip_ba* b)
+// Schur complement for the current lambda into the reduced buffer.  fused: single-GPU solve (lambda, rhs row and flags are
+// written by the Schur kernel itself); otherwise the pose diagonal stays without lambda for the all-reduce.
+int ba_reduce_system(lpslam_hip_ba* b, int fused)
 {
     BaView v = make_view(b, b->cur);
     hipStream_t s = b->stream;
-    if (b->n_points) hipLaunchKernelGGL(k_ba_point_inv, dim3((b->n_points + 127) / 128), dim3(128), 0, s, v, b->lambda);
-    if (b->n_blocks) hipLaunchKernelGGL(k_ba_schur, dim3(b->n_blocks), dim3(64), 0, s, v);
+    if (b->n_points) hipLaunchKernelGGL(k_ba_point_inv, dim3((b->n_points + 255) / 256), dim3(256), 0, s, v, b->lambda);
+    if (b->n_obs) hipLaunchKernelGGL(k_ba_obs_y, dim3((b->n_obs + 255) / 256), dim3(256), 0, s, v);
+    if (b->n_free) hipLaunchKernelGGL(k_ba_schur, dim3(b->n_blocks + b->n_free), dim3(64), 0, s, v, b->n_blocks, b->lambda, fused);
     LP_HIP(hipGetLastError());
     return LPSLAM_HIP_OK;
 }
 
-// factor + solve the (all-reduced) system, update into the trial state, trial chi2 -> scal[1], scale parts -> scal[2], scal[3]
-int ba_solve_update(lpslam_hip_ba* b)
+// factor + solve the reduced system, update into the trial state, trial chi2 -> scal[1], scale parts -> scal[2], scal[3]
+int ba_solve_update(lpslam_hip_ba* b, int fused)
 {
     BaView v = make_view(b, b->cur);
     hipStream_t s = b->stream;
     const int n = b->dim_pad, nb = n / NB;
     const int trial = b->cur ^ 1;
     if (b->dim > 0) {
-        hipLaunchKernelGGL(k_chol_prep, dim3((n + 255) / 256), dim3(256), 0, s, v.S, v.rhs, b->dim, n, b->lambda, b->d_scal);
-        for (int kb = 0; kb < nb; ++kb) {
-            hipLaunchKernelGGL(k_chol_panel, dim3(nb - kb), dim3(64), 0, s, v.S, n, kb, b->d_scal);
-            const int t = nb - kb - 1;
-            if (t > 0) hipLaunchKernelGGL(k_chol_update, dim3(t * (t + 1) / 2), dim3(256), 0, s, v.S, n, kb);
+        if (!fused) hipLaunchKernelGGL(k_chol_prep, dim3((b->dim + 255) / 256), dim3(256), 0, s, v.S, v.rhs, b->dim, n, b->lambda, b->d_scal);
+        for (int kb = -1; kb <= nb - 2; ++kb) {
+            const int n_panel = nb - (kb + 1), t = nb - (kb + 2);
+            const int n_update = kb >= 0 ? t * (t + 1) / 2 : 0;
+            hipLaunchKernelGGL(k_chol_step, dim3(n_panel + n_update), dim3(256), 0, s, v.S, n, nb, kb, b->d_scal);
         }
-        hipLaunchKernelGGL(k_chol_backsolve, dim3(1), dim3(256), n * sizeof(double), s, v.S, n, b->dim, b->d_xp);
+        hipLaunchKernelGGL(k_chol_backsolve, dim3(1), dim3(1024), n * sizeof(double), s, v, b->lambda, b->d_poses[trial]);
+    } else {
+        LP_HIP(hipMemcpyAsync(b->d_poses[trial], b->d_poses[b->cur], 7 * (size_t)b->n_poses * sizeof(double), hipMemcpyDeviceToDevice, s));
+        LP_HIP(hipMemsetAsync(b->d_scal + 3, 0, sizeof(double), s));
     }
-    const int pb = (b->n_points + 127) / 128;
-    if (b->n_points) {
-        hipLaunchKernelGGL(k_ba_backsub, dim3(pb), dim3(128), 0, s, v, b->lambda, b->d_points[trial]);
-        hipLaunchKernelGGL(k_ba_reduce, dim3(1), dim3(64), 0, s, b->d_part, pb, 1, b->d_scal + 2, 0);
-    }
-    hipLaunchKernelGGL(k_ba_pose_update, dim3(1), dim3(64), 0, s, v, b->lambda, b->d_poses[trial]);
+    const int pb = (b->n_points + 63) / 64;
+    if (b->n_points) hipLaunchKernelGGL(k_ba_backsub, dim3(pb), dim3(256), 0, s, v, b->lambda, b->d_points[trial]);
     BaView vt = make_view(b, trial);
-    hipLaunchKernelGGL(k_ba_pose_pass, dim3((b->n_poses + 3) / 4), dim3(256), 0, s, vt, b->robust, 1, b->d_chi_pose);
-    hipLaunchKernelGGL(k_ba_reduce, dim3(1), dim3(64), 0, s, b->d_chi_pose, b->n_poses, 1, b->d_scal + 1, 0);
+    hipLaunchKernelGGL(k_ba_pose_part, dim3((b->n_poses * SPLIT + 3) / 4), dim3(256), 0, s, vt, b->robust, 1, b->d_partial);
+    hipLaunchKernelGGL(k_ba_pose_combine, dim3(1), dim3(1024), 0, s, vt, 1, b->d_partial, b->d_scal + 1, pb, 0, b->d_scal + 2);
     LP_HIP(hipGetLastError());
     return LPSLAM_HIP_OK;
 }
@@ -749,7 +862,9 @@ int lpslam_hip_ba_create(lpslam_hip_ctx* ctx, const double* poses, const uint8_t
         }
     LP_HIP(hipSetDevice(ctx->cfg.device));
     lpslam_hip_ba* b = new lpslam_hip_ba();
-    b->ctx = ctx; b->stream = ctx->stream;
+    b->ctx = ctx;
+    // own stream: a bundle adjustment runs beside the front end of later frames (the reference's mapping thread)
+    if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) { delete b; set_error("hipStreamCreate failed"); return LPSLAM_HIP_ERR_DEVICE; }
     b->n_poses = n_poses; b->n_points = n_points; b->n_obs = n_obs;
     b->cam = BaCam{cam->fx, cam->fy, cam->cx, cam->cy, cam->focal_x_baseline, cam->huber_mono, cam->huber_stereo};
     std::vector<int> slot(n_poses), free_pose;
@@ -836,9 +951,16 @@ int lpslam_hip_ba_create(lpslam_hip_ctx* ctx, const double* poses, const uint8_t
     b->red_n = (int64_t)b->dim_pad * b->dim_pad + 3 * (int64_t)b->dim_pad + 8;
     BA_TRY(dalloc(b, &b->d_red, (size_t)b->red_n));
     if (hipMemset(b->d_red, 0, (size_t)b->red_n * sizeof(double)) != hipSuccess) { set_error("memset failed"); return fail(LPSLAM_HIP_ERR_DEVICE); }
+    {   // rows beyond the rhs row: identity (they stay 1 / 0 through every factorisation)
+        std::vector<double> one(1, 1.0);
+        for (int r = b->dim + 1; r < b->dim_pad; ++r)
+            if (hipMemcpy(b->d_red + (size_t)r * b->dim_pad + r, one.data(), sizeof(double), hipMemcpyHostToDevice) != hipSuccess) { set_error("pad init failed"); return fail(LPSLAM_HIP_ERR_DEVICE); }
+    }
     BA_TRY(dalloc(b, &b->d_xp, (size_t)b->dim_pad)); BA_TRY(dalloc(b, &b->d_xl, 3 * (size_t)n_points));
     BA_TRY(dalloc(b, &b->d_chi_pose, (size_t)n_poses));
-    b->part_n = std::max((n_points + 127) / 128, 1);
+    b->part_n = std::max((n_points + 63) / 64, 1);
+    BA_TRY(dalloc(b, &b->d_hl_obs, 9 * (size_t)n_obs)); BA_TRY(dalloc(b, &b->d_partial, (size_t)n_poses * SPLIT * PV));
+    if (hipMemset(b->d_partial, 0, (size_t)n_poses * SPLIT * PV * sizeof(double)) != hipSuccess) { set_error("memset failed"); return fail(LPSLAM_HIP_ERR_DEVICE); }
     BA_TRY(dalloc(b, &b->d_part, (size_t)b->part_n)); BA_TRY(dalloc(b, &b->d_scal, 8));
     if (hipMemset(b->d_scal, 0, 8 * sizeof(double)) != hipSuccess || hipMemset(b->d_xp, 0, b->dim_pad * sizeof(double)) != hipSuccess) {
         set_error("memset failed"); return fail(LPSLAM_HIP_ERR_DEVICE);
@@ -854,6 +976,7 @@ void lpslam_hip_ba_destroy(lpslam_hip_ba* b)
     if (!b) return;
     if (b->stream) (void)hipStreamSynchronize(b->stream);
     for (void* p : b->allocs) (void)hipFree(p);
+    if (b->stream) (void)hipStreamDestroy(b->stream);
     delete b;
 }
 
@@ -908,13 +1031,13 @@ int lpslam_hip_ba_step_begin(lpslam_hip_ba* b, int32_t robust, int32_t first)
         (void)v;
         return LPSLAM_HIP_OK;
     }
-    return ba_reduce_system(b);
+    return ba_reduce_system(b, 0);
 }
 
 int lpslam_hip_ba_step_solve(lpslam_hip_ba* b)
 {
     if (!b) { set_error("null problem"); return LPSLAM_HIP_ERR_INVALID; }
-    return ba_solve_update(b);
+    return ba_solve_update(b, 0);
 }
 
 int lpslam_hip_ba_step_end(lpslam_hip_ba* b, int32_t* accepted, int32_t* iteration_finished)
@@ -955,8 +1078,8 @@ int lpslam_hip_ba_optimize(lpslam_hip_ba* b, int32_t robust, int32_t iters, lpsl
         b->qmax = 0;
         bool finished = false;
         while (!finished) {
-            if ((rc = ba_reduce_system(b))) return rc;
-            if ((rc = ba_solve_update(b))) return rc;
+            if ((rc = ba_reduce_system(b, 1))) return rc;
+            if ((rc = ba_solve_update(b, 1))) return rc;
             if ((rc = read_scal(b, h))) return rc;
             int acc;
             finished = lm_decide(b, h[1], h[2] + h[3], h[5] == 0.0, &acc);
