@@ -181,12 +181,18 @@ int lpslam_hip_ba_reset(lpslam_hip_ba* ba);
 int lpslam_hip_ba_get(lpslam_hip_ba* ba, double* poses, double* points);
 int lpslam_hip_ba_chi2(lpslam_hip_ba* ba, double* chi2, uint8_t* depth_positive);
 
-/* Partitioned (multi-GPU) global BA: each rank holds a landmark partition and all poses.
- * begin -> caller all-reduces (sum) the buffer returned by reduced_buffer() -> end.  One LM trial each. */
+/* Partitioned (multi-GPU) global BA: every rank holds a landmark partition (its observations) and all poses.  One LM
+ * trial is three device phases with the caller's collectives in between (each phase ends synchronised):
+ *   step_begin(robust, first=1)   linearise                -> all-reduce SUM reduced_buffer, MAX scalar_buffer[4]
+ *   step_lambda0()                lambda_0 from the reduced diagonals (first trial of an optimisation only)
+ *   step_begin(robust, first=0)   (linearise if the state changed) + partial Schur complement -> all-reduce SUM reduced_buffer
+ *   step_solve()                  factor, solve, update, trial chi2  -> all-reduce SUM scalar_buffer[1..2]
+ *   step_end()                    accept / reject (identical on every rank) */
 int lpslam_hip_ba_reduced_buffer(lpslam_hip_ba* ba, void** dev_ptr, int64_t* n_doubles);
-int lpslam_hip_ba_step_begin(lpslam_hip_ba* ba, int32_t robust, int32_t first);
-int lpslam_hip_ba_step_solve(lpslam_hip_ba* ba);
 int lpslam_hip_ba_scalar_buffer(lpslam_hip_ba* ba, void** dev_ptr, int64_t* n_doubles);
+int lpslam_hip_ba_step_begin(lpslam_hip_ba* ba, int32_t robust, int32_t first);
+int lpslam_hip_ba_step_lambda0(lpslam_hip_ba* ba);
+int lpslam_hip_ba_step_solve(lpslam_hip_ba* ba);
 int lpslam_hip_ba_step_end(lpslam_hip_ba* ba, int32_t* accepted, int32_t* iteration_finished);
 
 #ifdef __cplusplus

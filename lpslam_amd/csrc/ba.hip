@@ -4,15 +4,18 @@
 // OpenVSLAM reprojection edges, which the reference runs on its mapping / global-optimisation threads
 // (/root/reference/src/Trackers/OpenVSLAMTrackerBase.cpp:239,250-255; pin conan-packages/g2o-conan/conanfile.py:6).
 //
-// Device pipeline of one LM iteration (all sums are fixed-order segmented reductions: no float atomics, results are
-// reproducible run to run):
-//   point pass   one thread per landmark   : H_ll (3x3), b_l, W = B^T w A (6x3 per observation)
-//   pose pass    one wavefront per keyframe: H_pp (6x6), b_p, robust chi2
-//   per trial    point inverse (H_ll + lambda I)^-1, Y = W H_ll^-1;  Schur blocks S_ik = H_pp - sum Y W^T, one
-//                wavefront per block pair over a precomputed pair list;  blocked Cholesky (32x32 panels, right-
-//                looking, rhs carried as an extra row);  back substitution;  landmark update;  trial chi2.
-// The reduced system [S | rhs | b_p | diag H_pp | chi2] is one contiguous buffer so a landmark-partitioned multi-GPU
-// solve only needs one sum all-reduce of it per trial (lpslam_hip_ba_step_*).
+// The whole LM loop is device driven: lambda, nu, the accepted-state index and the accept / reject decision live in a
+// small control block in HBM, every kernel reads it, and the host only enqueues "trial units" and looks at the control
+// block once per optimize() call.  A unit = [linearise if the state changed] + one LM trial:
+//   linearise   k_ba_obs_lin (thread / observation: W = B^T w A, shares of H_ll, b_l), k_ba_pose_part (8 wavefronts /
+//               keyframe: H_pp, b_p, chi2), k_ba_point_sum, k_ba_pose_combine (fixed-order sums, lambda_0)
+//   trial       k_ba_point_inv, k_ba_obs_y (Y = W H_ll^-1), k_ba_schur (wavefront / pose-block pair over a pair list),
+//               k_chol_step x nb (32-wide panels; the rhs is carried as an extra row and L^-T as extra row blocks, so
+//               no triangular substitution is needed), k_chol_xsolve (x_p = L^-T y), k_ba_backsub (landmarks, trial
+//               poses), k_ba_pose_part / k_ba_pose_combine (trial chi2, g2o lambda control)
+// All sums are fixed-order segmented reductions (no float atomics): results are reproducible run to run.
+// The reduced system [S | rhs | b_p | diag H_pp | chi2] is one contiguous buffer, so a landmark-partitioned multi-GPU
+// solve needs one sum all-reduce of it per trial (lpslam_hip_ba_step_*).
 #include "internal.h"
 #include <cmath>
 #include <cfloat>
@@ -24,24 +27,49 @@ using namespace lpslam;
 
 namespace {
 
-constexpr int NB = 32;                 // Cholesky panel width
+constexpr int NB = 32;                // Cholesky panel width
+constexpr int SPLIT = 8;              // wavefronts per keyframe in the pose pass
+constexpr int PV = 28;                // partial values per wavefront: 21 (H_pp upper) + 6 (b_p) + 1 (chi2)
+constexpr int MAX_LOG = 64;
 
 struct BaCam { double fx, fy, cx, cy, fxb, hub_mono, hub_stereo; };
 
-struct BaView {                        // device pointers handed to kernels by value
+struct BaCtl {                        // device-resident LM state (g2o OptimizationAlgorithmLevenberg)
+    double lambda, ni, current_chi, chi_before, rho;
+    int cur;                          // buffer index of the accepted state
+    int need_lin;                     // the next unit must linearise first
+    int first;                        // lambda_0 not yet computed in this optimize() call
+    int qmax;                         // trials of the running outer iteration
+    int outer_done, max_outer;
+    int stopped;                      // g2o "Terminate"
+    int last_accepted;
+};
+
+struct BaView {                       // device pointers handed to kernels by value
     int n_poses, n_points, n_obs, n_free, dim, dim_pad;
-    const double* poses; const double* points;      // state being evaluated
+    double* poses_buf[2]; double* points_buf[2];
+    const double* poses; const double* points;        // set by the kernel prologue (state being evaluated)
     const int* pose_slot; const int* free_pose;
     const int* o_pose; const int* o_point;
     const double* o_u; const double* o_v; const double* o_ur; const double* o_w;
     const uint8_t* o_active;
     const int* pt_start; const int* pt_obs; const int* ps_start; const int* ps_obs;
-    double* W; double* Y; double* Ybl; double* Hll; double* bl; double* Hinv; double* Hpp;
+    double* W; double* Y; double* Ybl; double* Hll; double* bl; double* Hinv; double* Hpp; double* hl_obs; double* partial;
     double* S; double* rhs; double* bp; double* hppdiag; double* chi_cur;   // reduced buffer sections
-    double* xp; double* xl; double* chi_pose; double* part; double* scal;
+    double* Minv;                                                            // L^-T row blocks (dim_pad x dim_pad)
+    double* xp; double* chi_pose; double* part; double* scal;
     const int* blk_start; const int2* blk_terms;
+    BaCtl* ctl; lpslam_hip_ba_iter_log* log;
     BaCam cam;
 };
+
+__device__ __forceinline__ bool ba_idle(const BaCtl* c) { return c->stopped || c->outer_done >= c->max_outer; }
+// selects the evaluated state: the accepted one (trial = 0) or the trial one
+__device__ __forceinline__ void ba_select(BaView& v, int trial)
+{
+    const int s = v.ctl->cur ^ trial;
+    v.poses = v.poses_buf[s]; v.points = v.points_buf[s];
+}
 
 __device__ __forceinline__ void quat_to_rot(const double* q, double* R)
 {
@@ -111,22 +139,27 @@ __device__ __forceinline__ double ba_weight(const BaView& v, int k, int D, const
     return w;
 }
 
-constexpr int SPLIT = 8;              // wavefronts per keyframe in the pose pass
-constexpr int PV = 28;                // partial values per wavefront: 21 (H_pp upper) + 6 (b_p) + 1 (chi2)
 
 __device__ __forceinline__ double wave_sum(double x)
 {
     for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
     return x;
 }
+__device__ __forceinline__ double wave_max(double x)
+{
+    for (int o = 32; o > 0; o >>= 1) x = fmax(x, __shfl_xor(x, o));
+    return x;
+}
 
 // ---- linearisation 1/4: one thread per observation: W = B^T w A and the observation's share of H_ll, b_l --------------
-__global__ __launch_bounds__(256) void k_ba_obs_lin(BaView v, int robust, int points_fixed, double* hl_obs)
+__global__ __launch_bounds__(256) void k_ba_obs_lin(BaView v, int robust, int points_fixed)
 {
+    if (ba_idle(v.ctl) || !v.ctl->need_lin) return;
+    ba_select(v, 0);
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= v.n_obs) return;
     double* Wk = v.W + 18 * (size_t)k;
-    double* ho = hl_obs + 9 * (size_t)k;
+    double* ho = v.hl_obs + 9 * (size_t)k;
     const int p = v.o_pose[k];
     const int slot = v.pose_slot[p];
     if (!v.o_active[k] || points_fixed) {       // inactive edge, or motion-only mode (landmarks are constants: x_l = 0)
@@ -172,15 +205,16 @@ __global__ __launch_bounds__(256) void k_ba_obs_lin(BaView v, int robust, int po
 }
 
 // ---- linearisation 2/4: H_ll, b_l per landmark = fixed-order sum over its observations; block maxima of diag H_ll ------
-__global__ __launch_bounds__(256) void k_ba_point_sum(BaView v, const double* hl_obs)
+__global__ __launch_bounds__(256) void k_ba_point_sum(BaView v)
 {
+    if (ba_idle(v.ctl) || !v.ctl->need_lin) return;
     __shared__ double sm[4];
     const int j = blockIdx.x * 256 + threadIdx.x;
     double m = 0;
     if (j < v.n_points) {
         double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
         for (int s = v.pt_start[j]; s < v.pt_start[j + 1]; ++s) {
-            const double* ho = hl_obs + 9 * (size_t)v.pt_obs[s];
+            const double* ho = v.hl_obs + 9 * (size_t)v.pt_obs[s];
 #pragma unroll
             for (int i = 0; i < 9; ++i) acc[i] += ho[i];
         }
@@ -190,15 +224,17 @@ __global__ __launch_bounds__(256) void k_ba_point_sum(BaView v, const double* hl
         for (int i = 0; i < 3; ++i) v.bl[3 * (size_t)j + i] = acc[6 + i];
         m = fmax(fabs(acc[0]), fmax(fabs(acc[3]), fabs(acc[5])));
     }
-    for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
+    m = wave_max(m);
     if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
     __syncthreads();
     if (threadIdx.x == 0) v.part[blockIdx.x] = fmax(fmax(sm[0], sm[1]), fmax(sm[2], sm[3]));
 }
 
-// ---- linearisation 3/4 (and trial chi2): SPLIT wavefronts per keyframe, each over a slice of its observations ----------
-__global__ __launch_bounds__(256) void k_ba_pose_part(BaView v, int robust, int chi_only, double* partial)
+// ---- linearisation 3/4 (mode 0) and trial chi2 (mode 1): SPLIT wavefronts per keyframe over slices of its observations --
+__global__ __launch_bounds__(256) void k_ba_pose_part(BaView v, int robust, int mode)
 {
+    if (ba_idle(v.ctl) || (mode == 0 && !v.ctl->need_lin)) return;
+    ba_select(v, mode);
     const int lane = threadIdx.x & 63;
     const int wv = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int p = wv / SPLIT, sp = wv - p * SPLIT;
@@ -212,7 +248,7 @@ __global__ __launch_bounds__(256) void k_ba_pose_part(BaView v, int robust, int 
     for (int i = 0; i < 21; ++i) h[i] = 0;
 #pragma unroll
     for (int i = 0; i < 6; ++i) b[i] = 0;
-    const bool full = !chi_only && slot >= 0;
+    const bool full = mode == 0 && slot >= 0;
     for (int s = v.ps_start[p] + sp * 64 + lane; s < v.ps_start[p + 1]; s += 64 * SPLIT) {
         const int k = v.ps_obs[s];
         if (!v.o_active[k]) continue;
@@ -241,7 +277,7 @@ __global__ __launch_bounds__(256) void k_ba_pose_part(BaView v, int robust, int 
             b[a] += s3;
         }
     }
-    double* out = partial + ((size_t)p * SPLIT + sp) * PV;
+    double* out = v.partial + ((size_t)p * SPLIT + sp) * PV;
     chi = wave_sum(chi);
     if (lane == 0) out[27] = chi;
     if (!full) return;
@@ -257,23 +293,82 @@ __global__ __launch_bounds__(256) void k_ba_pose_part(BaView v, int robust, int 
     }
 }
 
-// ---- linearisation 4/4 (and trial chi2): single workgroup combines the SPLIT partials in order, totals chi2, and
-//      reduces the landmark-side partials left in v.part (max diag H_ll after linearisation; scale terms after a trial)
-__global__ __launch_bounds__(1024) void k_ba_pose_combine(BaView v, int chi_only, const double* partial, double* chi_total,
-                                                          int part_n, int part_mode, double* part_out)
+// ---- g2o's lambda control (one thread) ----------------------------------------------------------------------------------
+// start of an outer iteration / after a linearisation: lambda_0 = tau * max diag(H) on the first one, chi2 bookkeeping
+__device__ void lm_begin(BaView& v, double max_diag_pp)
 {
+    BaCtl* c = v.ctl;
+    if (c->first) {
+        double maxd = v.n_points ? v.scal[4] : 0.0;
+        maxd = fmax(maxd, max_diag_pp);
+        c->lambda = 1e-5 * maxd;
+        c->ni = 2;
+        c->first = 0;
+    }
+    c->current_chi = *v.chi_cur;
+    if (c->qmax == 0) c->chi_before = *v.chi_cur;
+    c->need_lin = 0;
+}
+// after a trial: rho, accept / reject, lambda update, iteration and termination bookkeeping
+__device__ void lm_decide(BaView& v)
+{
+    BaCtl* c = v.ctl;
+    double temp_chi = v.scal[1];
+    if (v.scal[5] != 0.0) temp_chi = DBL_MAX;              // factorisation failed
+    double rho = c->current_chi - temp_chi;
+    const double scale = (v.scal[2] + v.scal[3]) + 1e-3;
+    rho /= scale;
+    const bool accepted = rho > 0 && isfinite(temp_chi);
+    if (accepted) {
+        const double t = 2 * rho - 1;
+        double alpha = 1. - t * t * t;
+        alpha = fmin(alpha, 2. / 3.);
+        const double sf = fmax(1. / 3., alpha);
+        c->lambda *= sf;
+        c->ni = 2;
+        c->current_chi = temp_chi;
+        c->cur ^= 1;                                       // discardTop: the trial state becomes the accepted one
+    } else {
+        c->lambda *= c->ni;
+        c->ni *= 2;                                        // pop: the accepted state stays
+    }
+    c->rho = rho;
+    c->last_accepted = accepted ? 1 : 0;
+    c->qmax++;
+    const bool finished = !(rho < 0 && c->qmax < 10);
+    if (finished) {
+        const int terminate = (c->qmax == 10 || rho == 0) ? 1 : 0;
+        if (c->outer_done < MAX_LOG) {
+            lpslam_hip_ba_iter_log* l = v.log + c->outer_done;
+            l->chi2_before = c->chi_before; l->chi2_after = c->current_chi; l->lambda = c->lambda; l->trials = c->qmax; l->status = terminate;
+        }
+        c->outer_done++;
+        c->qmax = 0;
+        c->need_lin = 1;
+        if (terminate) c->stopped = 1;
+    } else {
+        c->need_lin = 0;
+    }
+}
+
+// ---- linearisation 4/4 (mode 0) and trial chi2 (mode 1): single workgroup combines the SPLIT partials in order, totals
+//      chi2, reduces the landmark-side block partials in v.part (max diag H_ll / scale terms) and, in the single-GPU
+//      ("fused") solve, runs the lambda control.  The partitioned solve runs k_lm_begin / k_lm_decide after its all-reduce.
+__global__ __launch_bounds__(1024) void k_ba_pose_combine(BaView v, int mode, int part_n, int fused)
+{
+    if (ba_idle(v.ctl) || (mode == 0 && !v.ctl->need_lin)) return;
+    __shared__ double s_maxpp;
     const int tid = threadIdx.x;
     for (int i = tid; i < v.n_poses * PV; i += 1024) {
         const int p = i / PV, q = i - p * PV;
         const int slot = v.pose_slot[p];
-        if (q != 27 && (chi_only || slot < 0)) continue;
+        if (q != 27 && (mode == 1 || slot < 0)) continue;
         double s = 0;
-        for (int sp = 0; sp < SPLIT; ++sp) s += partial[((size_t)p * SPLIT + sp) * PV + q];
+        for (int sp = 0; sp < SPLIT; ++sp) s += v.partial[((size_t)p * SPLIT + sp) * PV + q];
         if (q == 27) v.chi_pose[p] = s;
         else if (q >= 21) v.bp[6 * slot + (q - 21)] = s;
         else {
-            // upper-triangle index q -> (a, c)
-            int a = 0, rem = q;
+            int a = 0, rem = q;                    // upper-triangle index q -> (a, c)
             while (rem >= 6 - a) { rem -= 6 - a; ++a; }
             const int c = a + rem;
             double* H = v.Hpp + 36 * (size_t)slot;
@@ -286,19 +381,44 @@ __global__ __launch_bounds__(1024) void k_ba_pose_combine(BaView v, int chi_only
         double acc = 0;
         for (int p = tid; p < v.n_poses; p += 64) acc += v.chi_pose[p];
         acc = wave_sum(acc);
-        if (tid == 0) *chi_total = acc;
-    } else if (tid < 128 && part_n > 0) {
+        if (tid == 0) { if (mode == 0) *v.chi_cur = acc; else v.scal[1] = acc; }
+    } else if (tid < 128) {
         const int lane = tid - 64;
         double acc = 0;
-        for (int i = lane; i < part_n; i += 64) acc = part_mode ? fmax(acc, v.part[i]) : acc + v.part[i];
-        for (int o = 32; o > 0; o >>= 1) { const double y = __shfl_xor(acc, o); acc = part_mode ? fmax(acc, y) : acc + y; }
-        if (lane == 0) *part_out = acc;
+        for (int i = lane; i < part_n; i += 64) acc = mode == 0 ? fmax(acc, v.part[i]) : acc + v.part[i];
+        acc = mode == 0 ? wave_max(acc) : wave_sum(acc);
+        if (lane == 0) v.scal[mode == 0 ? 4 : 2] = acc;
+    } else if (tid < 192 && mode == 0) {
+        const int lane = tid - 128;
+        double m = 0;
+        for (int i = lane; i < v.dim; i += 64) m = fmax(m, fabs(v.hppdiag[i]));
+        m = wave_max(m);
+        if (lane == 0) s_maxpp = m;
     }
+    __syncthreads();
+    if (tid == 0 && fused) { if (mode == 0) lm_begin(v, s_maxpp); else lm_decide(v); }
 }
 
-// ---- per trial 1/..: (H_ll + lambda I)^-1 ------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_ba_point_inv(BaView v, double lambda)
+// partitioned solve: lambda control on the all-reduced quantities
+__global__ __launch_bounds__(64) void k_lm_begin(BaView v)
 {
+    if (ba_idle(v.ctl) || !v.ctl->need_lin) return;
+    double m = 0;
+    for (int i = threadIdx.x; i < v.dim; i += 64) m = fmax(m, fabs(v.hppdiag[i]));
+    m = wave_max(m);
+    if (threadIdx.x == 0) lm_begin(v, m);
+}
+__global__ void k_lm_decide(BaView v)
+{
+    if (ba_idle(v.ctl)) return;
+    if (threadIdx.x == 0 && blockIdx.x == 0) lm_decide(v);
+}
+
+// ---- per trial: (H_ll + lambda I)^-1 ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_ba_point_inv(BaView v)
+{
+    if (ba_idle(v.ctl)) return;
+    const double lambda = v.ctl->lambda;
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= v.n_points) return;
     const double* hl = v.Hll + 6 * (size_t)j;
@@ -316,9 +436,10 @@ __global__ __launch_bounds__(256) void k_ba_point_inv(BaView v, double lambda)
     }
 }
 
-// ---- per trial 2/..: Y = W H_ll^-1 and Y b_l per observation -------------------------------------------------------------
+// ---- per trial: Y = W H_ll^-1 and Y b_l per observation -------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_ba_obs_y(BaView v)
 {
+    if (ba_idle(v.ctl)) return;
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= v.n_obs) return;
     const int j = v.o_point[k];
@@ -339,13 +460,15 @@ __global__ __launch_bounds__(256) void k_ba_obs_y(BaView v)
     }
 }
 
-// ---- per trial 3/..: Schur complement.  Blocks [0, n_blocks): one wavefront per pose-block pair (i <= k); lane q < 36 owns
-//      output element (q / 6, q % 6) and walks the pair list in order (no cross-lane reduction, fixed summation order).
+// ---- per trial: Schur complement.  Blocks [0, n_blocks): one wavefront per pose-block pair (i <= k): lanes stride over the
+//      pair list with 36 private accumulators, partials are summed in lane order through LDS (fixed summation order).
 //      Blocks [n_blocks, n_blocks + n_free): rhs_i = b_p,i - sum Y b_l over the observations of keyframe i.
-//      fused != 0 (single-GPU solve): lambda is added to the pose diagonal, rhs goes straight into row `dim` of S and the
-//      failure flag / rhs pivot are reset here, so no separate preparation launch is needed.
-__global__ __launch_bounds__(64) void k_ba_schur(BaView v, int n_blocks, double lambda, int fused)
+//      fused != 0 (single-GPU solve): lambda goes onto the pose diagonal, rhs straight into row `dim` of S and the failure
+//      flag / rhs pivot are reset here, so no separate preparation launch is needed.
+__global__ __launch_bounds__(64) void k_ba_schur(BaView v, int n_blocks, int fused)
 {
+    if (ba_idle(v.ctl)) return;
+    const double lambda = v.ctl->lambda;
     const int lane = threadIdx.x;
     const int n = v.dim_pad;
     if ((int)blockIdx.x >= n_blocks) {
@@ -375,7 +498,6 @@ __global__ __launch_bounds__(64) void k_ba_schur(BaView v, int n_blocks, double 
         while (pidx >= rowlen) { pidx -= rowlen; --rowlen; ++i; }
     }
     const int k = i + pidx;
-    // lanes stride over the pair list with 36 private accumulators; partials are then summed in lane order through LDS
     __shared__ double part[64 * 37];
     double acc[36];
 #pragma unroll
@@ -411,11 +533,15 @@ __global__ __launch_bounds__(64) void k_ba_schur(BaView v, int n_blocks, double 
 }
 
 // preparation for the partitioned (all-reduced) solve: lambda on the diagonal, rhs row, flag / pivot reset
-__global__ __launch_bounds__(256) void k_chol_prep(double* S, const double* rhs, int dim, int n, double lambda, double* scal)
+__global__ __launch_bounds__(256) void k_chol_prep(BaView v)
 {
+    if (ba_idle(v.ctl)) return;
+    const double lambda = v.ctl->lambda;
+    const int n = v.dim_pad, dim = v.dim;
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i == 0) { scal[5] = 0.0; S[(size_t)dim * n + dim] = 1e200; }
-    if (i < dim) { S[(size_t)i * n + i] += lambda; S[(size_t)dim * n + i] = rhs[i]; }
+    if (i == 0) { v.scal[5] = 0.0; v.S[(size_t)dim * n + dim] = 1e200; }
+    if (i < dim) { v.S[(size_t)i * n + i] += lambda; v.S[(size_t)dim * n + i] = v.rhs[i]; }
+    else if (i < n && i > dim) v.S[(size_t)i * n + i] = 1.0;      // the all-reduce summed the identity padding
 }
 
 __device__ __forceinline__ void pose_oplus(const double* pose, const double* d, double* out)
@@ -455,6 +581,7 @@ __device__ __forceinline__ void pose_oplus(const double* pose, const double* d, 
     for (int i = 0; i < 3; ++i) out[4 + i] = tn[i];
 }
 
+
 __device__ __forceinline__ double readlane_f64(double v, int lane)
 {
     int lo = __double2loint(v), hi = __double2hiint(v);
@@ -463,32 +590,54 @@ __device__ __forceinline__ double readlane_f64(double v, int lane)
     return __hiloint2double(hi, lo);
 }
 
-// One launch per panel column.  Launch kb (= -1 .. nb-2) produces panel column j = kb + 1 and applies panel kb to the rest
-// of the trailing matrix (one-step lookahead fused into a single launch, so the chain costs one kernel boundary per panel):
-//   panel workgroups (one per row block i >= j): D = A_jj - L_jk L_jk^T, B = A_ij - L_ik L_jk^T (256 threads), then ONE
-//     wavefront holds D's rows in lanes 0-31 and B's rows in lanes 32-63 (a 64 x 32 tall panel, one row per lane in 32
-//     registers) and runs the unblocked factorisation with v_readlane broadcasts: the same rank-1 update factors D and
-//     solves B L_jj^T = B at once.  D is factored redundantly by every panel workgroup (no cross-workgroup dependency).
-//   update workgroups: A_i2,j2 -= L_i2,k L_j2,k^T for i2 >= j2 >= j + 1.
-__global__ __launch_bounds__(256) void k_chol_step(double* S, int n, int nb, int kb, double* scal)
+// ---- blocked Cholesky of S (+ lambda I), one launch per 32-wide panel column ------------------------------------------------
+// Launch kb (= -1 .. nb-2) produces panel column j = kb + 1 and applies panel kb to the rest of the trailing matrix (one-step
+// lookahead fused into the same launch: one kernel boundary per panel on the critical path).
+//   Two kinds of extra rows ride along so that no triangular substitution is ever run:
+//     row `dim` of S carries the rhs            -> after the last panel it holds y = L^-1 rhs,
+//     Minv starts as the identity (synthesised) -> its row blocks become L^-T; block (e, .) only exists from column e on.
+//   panel workgroups (square row blocks i >= j, extra row blocks e <= j): D = A_jj - L_jk L_jk^T, B = A_ij - L_ik L_jk^T with
+//     256 threads, then ONE wavefront holds D's rows in lanes 0-31 and B's rows in lanes 32-63 (one row per lane in 32
+//     registers) and runs the unblocked factorisation with v_readlane broadcasts and a v_rsq_f64 + Newton reciprocal square
+//     root: the same rank-1 update factors D and solves B L_jj^T = B.  D is factored redundantly by every panel workgroup.
+//   update workgroups: A_i2,j2 -= L_i2,k L_j2,k^T for square i2 >= j2 >= j + 1 and for the extra row blocks e <= kb.
+// Explicit FMAs are used here (the contraction pragma only governs implicit fusing); the factorisation is not a parity
+// quantity, the solve's effect on chi2 / poses is (tolerances in DESIGN.md).
+__global__ __launch_bounds__(256) void k_chol_step(BaView v, int nb, int kb)
 {
+    if (ba_idle(v.ctl)) return;
     __shared__ double Lj[NB][NB + 1];
     __shared__ double Li[NB][NB + 1];
     __shared__ double Dm[NB][NB + 1];
     __shared__ double Bm[NB][NB + 1];
+    double* S = v.S;
+    double* M = v.Minv;
+    const int n = v.dim_pad;
     const int j = kb + 1;
-    const int n_panel = nb - j;
+    const int n_sq = nb - j;              // square panel row blocks j..nb-1
+    const int n_panel = n_sq + j + 1;     // + extra row blocks 0..j
     const int tid = threadIdx.x;
     const size_t ck = (size_t)(kb < 0 ? 0 : kb) * NB;
     if ((int)blockIdx.x >= n_panel) {
         // ---- trailing update with panel kb
-        int pidx = blockIdx.x - n_panel, bi = 0;
-        while (pidx > bi) { pidx -= bi + 1; ++bi; }
-        const int i2 = j + 1 + bi, j2 = j + 1 + pidx;
-        const size_t ri = (size_t)i2 * NB, rj = (size_t)j2 * NB;
+        const int T = nb - (kb + 2);
+        int u = blockIdx.x - n_panel;
+        const int n_sq_upd = T * (T + 1) / 2;
+        double* dst; const double* srcI; size_t ri, rj; bool overwrite = false;
+        if (u < n_sq_upd) {
+            int bi = 0;
+            while (u > bi) { u -= bi + 1; ++bi; }
+            const int i2 = j + 1 + bi, j2 = j + 1 + u;
+            ri = (size_t)i2 * NB; rj = (size_t)j2 * NB; dst = S; srcI = S;
+        } else {
+            u -= n_sq_upd;
+            const int e = u / T, j2 = j + 1 + (u - e * T);
+            ri = (size_t)e * NB; rj = (size_t)j2 * NB; dst = M; srcI = M;
+            overwrite = (e == kb);          // first contribution to this block: it holds no value yet
+        }
         for (int t = tid; t < NB * NB; t += 256) {
             const int r = t / NB, c = t % NB;
-            Li[r][c] = S[(ri + r) * n + ck + c];
+            Li[r][c] = srcI[(ri + r) * n + ck + c];
             Lj[r][c] = S[(rj + r) * n + ck + c];
         }
         __syncthreads();
@@ -500,18 +649,26 @@ __global__ __launch_bounds__(256) void k_chol_step(double* S, int n, int nb, int
             for (int q = 0; q < 4; ++q) acc[q] = fma(a, Lj[c0 + q][m], acc[q]);
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) S[(ri + r) * n + rj + c0 + q] -= acc[q];
+        for (int q = 0; q < 4; ++q) {
+            double* d = &dst[(ri + r) * n + rj + c0 + q];
+            *d = overwrite ? -acc[q] : *d - acc[q];
+        }
         return;
     }
-    // ---- panel column j, row block i
-    const int i = j + blockIdx.x;
+    // ---- panel column j
+    const bool extra = (int)blockIdx.x >= n_sq;
+    const int i = extra ? (int)blockIdx.x - n_sq : j + (int)blockIdx.x;      // extra: block row e of Minv
     const size_t rj = (size_t)j * NB, ri = (size_t)i * NB;
-    const bool has_b = i > j;
+    const bool has_b = extra || i > j;
+    const double* Bsrc = extra ? M : S;
+    const bool b_identity = extra && i == j;          // block (e, e) of Minv: identity, never stored before
+    const bool b_zero = extra && i == kb;             // block (e, e + 1): no update has written it yet (stale memory)
+    const bool li_zero = extra && i > kb;             // (only i == j): no panel-kb block
     for (int t = tid; t < NB * NB; t += 256) {
         const int r = t / NB, c = t % NB;
         Dm[r][c] = S[(rj + r) * n + rj + c];
-        Bm[r][c] = has_b ? S[(ri + r) * n + rj + c] : 0.0;
-        if (kb >= 0) { Lj[r][c] = S[(rj + r) * n + ck + c]; Li[r][c] = has_b ? S[(ri + r) * n + ck + c] : 0.0; }
+        Bm[r][c] = (!has_b || b_zero) ? 0.0 : (b_identity ? (r == c ? 1.0 : 0.0) : Bsrc[(ri + r) * n + rj + c]);
+        if (kb >= 0) { Lj[r][c] = S[(rj + r) * n + ck + c]; Li[r][c] = (!has_b || li_zero) ? 0.0 : Bsrc[(ri + r) * n + ck + c]; }
     }
     __syncthreads();
     if (kb >= 0) {
@@ -536,7 +693,6 @@ __global__ __launch_bounds__(256) void k_chol_step(double* S, int n, int nb, int
     for (int jj = 0; jj < NB; ++jj) {
         double djj = readlane_f64(a[jj], jj);
         if (!(djj > 0.0)) { fail = true; djj = 1.0; }
-        // 1/sqrt by v_rsq_f64 + two Newton steps (full double precision), so the column scaling is a multiply
         double rs = __builtin_amdgcn_rsq(djj);
         rs = rs * fma(-0.5 * djj * rs, rs, 1.5);
         rs = rs * fma(-0.5 * djj * rs, rs, 1.5);
@@ -552,87 +708,53 @@ __global__ __launch_bounds__(256) void k_chol_step(double* S, int n, int nb, int
         if (!has_b) {        // the diagonal workgroup publishes L_jj (lower triangle) and the failure flag
 #pragma unroll
             for (int c = 0; c < NB; ++c) if (c <= lane) S[(rj + lane) * n + rj + c] = a[c];
-            if (fail && lane == 0) scal[5] = 1.0;
+            if (fail && lane == 0) v.scal[5] = 1.0;
         }
     } else if (has_b) {
+        double* out = extra ? M : S;
 #pragma unroll
-        for (int c = 0; c < NB; ++c) S[(ri + lane - NB) * n + rj + c] = a[c];
+        for (int c = 0; c < NB; ++c) out[(ri + lane - NB) * n + rj + c] = a[c];
     }
 }
 
-// backward substitution L^T x = y with y = L[dim][0..dim), then the pose update x_p -> trial poses and the pose part of
-// computeScale.  Single 1024-thread workgroup; per 32-block: one wavefront solves the diagonal block from registers (column
-// values preloaded, v_readlane broadcasts, reciprocal pivots) while the next diagonal block is staged into the other LDS
-// buffer; then all threads push x_k into the earlier part of y (4 row groups per column, combined in fixed order).
-__global__ __launch_bounds__(1024) void k_chol_backsolve(BaView v, double lambda, double* poses_out)
+// x_p = L^-T y with y = L[dim][0..dim): one wavefront per row of the (upper triangular) L^-T, butterfly sum
+__global__ __launch_bounds__(256) void k_chol_xsolve(BaView v)
 {
-    extern __shared__ double xs[];                 // [n]
-    __shared__ double Ld[2][NB][NB + 1];
-    __shared__ double upd[4][320];
-    const double* S = v.S;
-    const int n = v.dim_pad, dim = v.dim;
-    const int tid = threadIdx.x;
-    for (int i = tid; i < n; i += 1024) xs[i] = i < dim ? S[(size_t)dim * n + i] : 0.0;
-    const int nb = (dim + NB - 1) / NB;
-    auto stage = [&](int kb, int buf) {
-        const int c0 = kb * NB;
-        const int r = tid / NB, c = tid % NB;      // 1024 threads = one element each
-        Ld[buf][r][c] = (c0 + r < dim && c <= r) ? S[(size_t)(c0 + r) * n + c0 + c] : (r == c ? 1.0 : 0.0);
-    };
-    stage(nb - 1, (nb - 1) & 1);
-    __syncthreads();
-    for (int kb = nb - 1; kb >= 0; --kb) {
-        const int c0 = kb * NB, buf = kb & 1;
-        if (tid < 64) {
-            const int lane = tid;
-            double col[NB];                        // col[cc] = L[c0+cc][c0+lane]
-#pragma unroll
-            for (int cc = 0; cc < NB; ++cc) col[cc] = lane < NB ? Ld[buf][cc][lane] : 0.0;
-            const double invd = lane < NB ? 1.0 / Ld[buf][lane][lane] : 0.0;
-            double y = lane < NB ? xs[c0 + lane] : 0.0;
-#pragma unroll
-            for (int cc = NB - 1; cc >= 0; --cc) {
-                const double xv = readlane_f64(y, cc) * readlane_f64(invd, cc);
-                if (lane == cc) y = xv;
-                if (lane < cc) y = fma(-col[cc], xv, y);
-            }
-            if (lane < NB) xs[c0 + lane] = (c0 + lane < dim) ? y : 0.0;
-        }
-        if (kb > 0) stage(kb - 1, (kb - 1) & 1);   // every thread stages one element of the next diagonal block
-        __syncthreads();
-        // y[c] -= sum_{r in block} L[c0+r][c] x[c0+r] for every earlier column c < c0; rows split into 4 groups of 8
-        for (int cbase = 0; cbase < c0; cbase += 256) {
-            const int c = cbase + (tid & 255), g = tid >> 8;
-            double sacc = 0;
-            if (c < c0) {
-#pragma unroll
-                for (int r = 0; r < 8; ++r) { const int rr = c0 + g * 8 + r; if (rr < dim) sacc = fma(S[(size_t)rr * n + c], xs[rr], sacc); }
-            }
-            upd[g][tid & 255] = sacc;
-            __syncthreads();
-            if (tid < 256 && c < c0) xs[c] -= (upd[0][tid] + upd[1][tid]) + (upd[2][tid] + upd[3][tid]);
-            __syncthreads();
-        }
-    }
-    for (int i = tid; i < dim; i += 1024) v.xp[i] = xs[i];
-    // pose update: poses_out = exp(x_p) * poses; scal[3] = sum x_p (lambda x_p + b_p) (fixed order, one wavefront)
-    if (tid < 64) {
+    if (ba_idle(v.ctl)) return;
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= v.dim) return;
+    const int n = v.dim_pad;
+    const double* y = v.S + (size_t)v.dim * n;
+    const double* m = v.Minv + (size_t)i * n;
+    double acc = 0;
+    for (int c = (i / NB) * NB + lane; c < v.dim; c += 64) acc += m[c] * y[c];     // blocks left of the diagonal block are empty
+    acc = wave_sum(acc);
+    if (lane == 0) v.xp[i] = acc;
+}
+
+// ---- landmark back substitution and update (4 lanes per landmark); the last block applies x_p to the poses -------------------
+__global__ __launch_bounds__(256) void k_ba_backsub(BaView v, int point_blocks)
+{
+    if (ba_idle(v.ctl)) return;
+    const double lambda = v.ctl->lambda;
+    ba_select(v, 0);
+    double* poses_out = v.poses_buf[v.ctl->cur ^ 1];
+    double* points_out = v.points_buf[v.ctl->cur ^ 1];
+    if ((int)blockIdx.x == point_blocks) {
+        // trial poses = exp(x_p) * poses; scal[3] = sum x_p (lambda x_p + b_p) (fixed order, one wavefront)
+        if (threadIdx.x >= 64) return;
         double sc = 0;
-        for (int p = tid; p < v.n_poses; p += 64) {
+        for (int p = threadIdx.x; p < v.n_poses; p += 64) {
             const int slot = v.pose_slot[p];
             if (slot < 0) { for (int i = 0; i < 7; ++i) poses_out[7 * p + i] = v.poses[7 * p + i]; continue; }
-            pose_oplus(v.poses + 7 * p, xs + 6 * slot, poses_out + 7 * p);
-            for (int a = 0; a < 6; ++a) { const double x = xs[6 * slot + a]; sc += x * (lambda * x + v.bp[6 * slot + a]); }
+            pose_oplus(v.poses + 7 * p, v.xp + 6 * slot, poses_out + 7 * p);
+            for (int a = 0; a < 6; ++a) { const double x = v.xp[6 * slot + a]; sc += x * (lambda * x + v.bp[6 * slot + a]); }
         }
         sc = wave_sum(sc);
-        if (tid == 0) v.scal[3] = sc;
+        if (threadIdx.x == 0) v.scal[3] = sc;
+        return;
     }
-}
-
-// ---- landmark back substitution and update; block partials of the landmark part of computeScale -----------------------------
-__global__ __launch_bounds__(256) void k_ba_backsub(BaView v, double lambda, double* points_out)
-{
-    // 4 lanes per landmark: each takes every fourth observation, partial sums combined in lane order
     const int g = blockIdx.x * 64 + (threadIdx.x >> 2), sub = threadIdx.x & 3;
     double sc = 0;
     double r[3] = {0, 0, 0};
@@ -675,9 +797,10 @@ __global__ __launch_bounds__(256) void k_ba_backsub(BaView v, double lambda, dou
     if (threadIdx.x == 0) v.part[blockIdx.x] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
 }
 
-// per-observation chi2 (non robust) and depth sign
+// per-observation chi2 (non robust) and depth sign of the accepted state
 __global__ __launch_bounds__(256) void k_ba_obs_chi2(BaView v, double* chi2, uint8_t* depth_pos)
 {
+    ba_select(v, 0);
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= v.n_obs) return;
     const int p = v.o_pose[k], j = v.o_point[k];
@@ -698,7 +821,6 @@ struct lpslam_hip_ba {
     lpslam_hip_ctx* ctx = nullptr;
     hipStream_t stream = nullptr;
     int n_poses = 0, n_points = 0, n_obs = 0, n_free = 0, dim = 0, dim_pad = 0, n_blocks = 0;
-    int cur = 0;                                  // index of the accepted state
     double *d_poses[2] = {nullptr, nullptr}, *d_points[2] = {nullptr, nullptr};
     double *d_poses0 = nullptr, *d_points0 = nullptr;      // state given at creation (lpslam_hip_ba_reset)
     int *d_pose_slot = nullptr, *d_free_pose = nullptr, *d_o_pose = nullptr, *d_o_point = nullptr;
@@ -706,18 +828,17 @@ struct lpslam_hip_ba {
     uint8_t* d_o_active = nullptr;
     int *d_pt_start = nullptr, *d_pt_obs = nullptr, *d_ps_start = nullptr, *d_ps_obs = nullptr;
     double *d_W = nullptr, *d_Y = nullptr, *d_Ybl = nullptr, *d_Hll = nullptr, *d_bl = nullptr, *d_Hinv = nullptr, *d_Hpp = nullptr;
-    double* d_red = nullptr; int64_t red_n = 0; bool red_external = false;
-    double *d_xp = nullptr, *d_xl = nullptr, *d_chi_pose = nullptr, *d_part = nullptr, *d_scal = nullptr;
+    double *d_hl_obs = nullptr, *d_partial = nullptr, *d_minv = nullptr;
+    double* d_red = nullptr; int64_t red_n = 0;
+    double *d_xp = nullptr, *d_chi_pose = nullptr, *d_part = nullptr, *d_scal = nullptr;
     double* d_chi_obs = nullptr; uint8_t* d_depth = nullptr;
-    double *d_hl_obs = nullptr, *d_partial = nullptr;
     int* d_blk_start = nullptr; int2* d_blk_terms = nullptr;
+    BaCtl* d_ctl = nullptr; lpslam_hip_ba_iter_log* d_log = nullptr;
     int part_n = 0;
     BaCam cam{};
     std::vector<double> h_ur;                      // mono/stereo classification for the outlier thresholds
-    // LM state (g2o OptimizationAlgorithmLevenberg)
-    double lambda = 0, ni = 2, current_chi = 0, rho = 0;
-    int qmax = 0; int robust = 1; double chi_before = 0;
-    int points_fixed = 0;
+    BaCtl h_ctl{};                                 // last control block read back
+    int robust = 1, points_fixed = 0;
     std::vector<void*> allocs;
 };
 
@@ -738,109 +859,101 @@ int upload(lpslam_hip_ba* b, T** p, const std::vector<T>& h)
     return LPSLAM_HIP_OK;
 }
 
-BaView make_view(lpslam_hip_ba* b, int state)
+BaView make_view(lpslam_hip_ba* b)
 {
     BaView v{};
     v.n_poses = b->n_poses; v.n_points = b->n_points; v.n_obs = b->n_obs; v.n_free = b->n_free; v.dim = b->dim; v.dim_pad = b->dim_pad;
-    v.poses = b->d_poses[state]; v.points = b->d_points[state];
+    for (int s = 0; s < 2; ++s) { v.poses_buf[s] = b->d_poses[s]; v.points_buf[s] = b->d_points[s]; }
     v.pose_slot = b->d_pose_slot; v.free_pose = b->d_free_pose; v.o_pose = b->d_o_pose; v.o_point = b->d_o_point;
     v.o_u = b->d_o_u; v.o_v = b->d_o_v; v.o_ur = b->d_o_ur; v.o_w = b->d_o_w; v.o_active = b->d_o_active;
     v.pt_start = b->d_pt_start; v.pt_obs = b->d_pt_obs; v.ps_start = b->d_ps_start; v.ps_obs = b->d_ps_obs;
     v.W = b->d_W; v.Y = b->d_Y; v.Ybl = b->d_Ybl; v.Hll = b->d_Hll; v.bl = b->d_bl; v.Hinv = b->d_Hinv; v.Hpp = b->d_Hpp;
+    v.hl_obs = b->d_hl_obs; v.partial = b->d_partial; v.Minv = b->d_minv;
     const size_t n = (size_t)b->dim_pad;
     v.S = b->d_red; v.rhs = b->d_red + n * n; v.bp = v.rhs + n; v.hppdiag = v.bp + n; v.chi_cur = v.hppdiag + n;
-    v.xp = b->d_xp; v.xl = b->d_xl; v.chi_pose = b->d_chi_pose; v.part = b->d_part; v.scal = b->d_scal;
+    v.xp = b->d_xp; v.chi_pose = b->d_chi_pose; v.part = b->d_part; v.scal = b->d_scal;
     v.blk_start = b->d_blk_start; v.blk_terms = b->d_blk_terms;
+    v.ctl = b->d_ctl; v.log = b->d_log;
     v.cam = b->cam;
     return v;
 }
 
-// linearise at the accepted state: blocks, b, chi2 (-> chi_cur), max diag H_ll (-> scal[4])
-int ba_linearize(lpslam_hip_ba* b)
+// linearisation of the accepted state (skipped on the device when the previous trial was rejected)
+int enqueue_linearize(lpslam_hip_ba* b, int fused)
 {
-    BaView v = make_view(b, b->cur);
+    BaView v = make_view(b);
     hipStream_t s = b->stream;
-    if (b->n_obs) hipLaunchKernelGGL(k_ba_obs_lin, dim3((b->n_obs + 255) / 256), dim3(256), 0, s, v, b->robust, b->points_fixed, b->d_hl_obs);
-    hipLaunchKernelGGL(k_ba_pose_part, dim3((b->n_poses * SPLIT + 3) / 4), dim3(256), 0, s, v, b->robust, 0, b->d_partial);
+    if (b->n_obs) hipLaunchKernelGGL(k_ba_obs_lin, dim3((b->n_obs + 255) / 256), dim3(256), 0, s, v, b->robust, b->points_fixed);
+    hipLaunchKernelGGL(k_ba_pose_part, dim3((b->n_poses * SPLIT + 3) / 4), dim3(256), 0, s, v, b->robust, 0);
     const int pb = (b->n_points + 255) / 256;
-    if (b->n_points) hipLaunchKernelGGL(k_ba_point_sum, dim3(pb), dim3(256), 0, s, v, b->d_hl_obs);
-    hipLaunchKernelGGL(k_ba_pose_combine, dim3(1), dim3(1024), 0, s, v, 0, b->d_partial, v.chi_cur, pb, 1, b->d_scal + 4);
+    if (b->n_points) hipLaunchKernelGGL(k_ba_point_sum, dim3(pb), dim3(256), 0, s, v);
+    hipLaunchKernelGGL(k_ba_pose_combine, dim3(1), dim3(1024), 0, s, v, 0, pb, fused);
     LP_HIP(hipGetLastError());
     return LPSLAM_HIP_OK;
 }
 
-// Schur complement for the current lambda into the reduced buffer.  fused: single-GPU solve (lambda, rhs row and flags are
-// written by the Schur kernel itself); otherwise the pose diagonal stays without lambda for the all-reduce.
-int ba_reduce_system(lpslam_hip_ba* b, int fused)
+// Schur complement for the device's current lambda into the reduced buffer
+int enqueue_reduce(lpslam_hip_ba* b, int fused)
 {
-    BaView v = make_view(b, b->cur);
+    BaView v = make_view(b);
     hipStream_t s = b->stream;
-    if (b->n_points) hipLaunchKernelGGL(k_ba_point_inv, dim3((b->n_points + 255) / 256), dim3(256), 0, s, v, b->lambda);
+    if (b->n_points) hipLaunchKernelGGL(k_ba_point_inv, dim3((b->n_points + 255) / 256), dim3(256), 0, s, v);
     if (b->n_obs) hipLaunchKernelGGL(k_ba_obs_y, dim3((b->n_obs + 255) / 256), dim3(256), 0, s, v);
-    if (b->n_free) hipLaunchKernelGGL(k_ba_schur, dim3(b->n_blocks + b->n_free), dim3(64), 0, s, v, b->n_blocks, b->lambda, fused);
+    if (b->n_free) hipLaunchKernelGGL(k_ba_schur, dim3(b->n_blocks + b->n_free), dim3(64), 0, s, v, b->n_blocks, fused);
     LP_HIP(hipGetLastError());
     return LPSLAM_HIP_OK;
 }
 
-// factor + solve the reduced system, update into the trial state, trial chi2 -> scal[1], scale parts -> scal[2], scal[3]
-int ba_solve_update(lpslam_hip_ba* b, int fused)
+// factor + solve, update into the trial state, trial chi2 and scale terms (+ the lambda control when fused)
+int enqueue_solve(lpslam_hip_ba* b, int fused)
 {
-    BaView v = make_view(b, b->cur);
+    BaView v = make_view(b);
     hipStream_t s = b->stream;
     const int n = b->dim_pad, nb = n / NB;
-    const int trial = b->cur ^ 1;
     if (b->dim > 0) {
-        if (!fused) hipLaunchKernelGGL(k_chol_prep, dim3((b->dim + 255) / 256), dim3(256), 0, s, v.S, v.rhs, b->dim, n, b->lambda, b->d_scal);
-        for (int kb = -1; kb <= nb - 2; ++kb) {
-            const int n_panel = nb - (kb + 1), t = nb - (kb + 2);
-            const int n_update = kb >= 0 ? t * (t + 1) / 2 : 0;
-            hipLaunchKernelGGL(k_chol_step, dim3(n_panel + n_update), dim3(256), 0, s, v.S, n, nb, kb, b->d_scal);
+        if (!fused) {
+            hipLaunchKernelGGL(k_lm_begin, dim3(1), dim3(64), 0, s, v);
+            hipLaunchKernelGGL(k_chol_prep, dim3((n + 255) / 256), dim3(256), 0, s, v);
         }
-        hipLaunchKernelGGL(k_chol_backsolve, dim3(1), dim3(1024), n * sizeof(double), s, v, b->lambda, b->d_poses[trial]);
-    } else {
-        LP_HIP(hipMemcpyAsync(b->d_poses[trial], b->d_poses[b->cur], 7 * (size_t)b->n_poses * sizeof(double), hipMemcpyDeviceToDevice, s));
-        LP_HIP(hipMemsetAsync(b->d_scal + 3, 0, sizeof(double), s));
+        for (int kb = -1; kb <= nb - 2; ++kb) {
+            const int j = kb + 1, T = nb - (kb + 2);
+            const int n_panel = (nb - j) + (j + 1);
+            const int n_update = kb >= 0 ? T * (T + 1) / 2 + (kb + 1) * T : 0;
+            hipLaunchKernelGGL(k_chol_step, dim3(n_panel + n_update), dim3(256), 0, s, v, nb, kb);
+        }
+        hipLaunchKernelGGL(k_chol_xsolve, dim3((b->dim + 3) / 4), dim3(256), 0, s, v);
+    } else if (!fused) {
+        hipLaunchKernelGGL(k_lm_begin, dim3(1), dim3(64), 0, s, v);
     }
     const int pb = (b->n_points + 63) / 64;
-    if (b->n_points) hipLaunchKernelGGL(k_ba_backsub, dim3(pb), dim3(256), 0, s, v, b->lambda, b->d_points[trial]);
-    BaView vt = make_view(b, trial);
-    hipLaunchKernelGGL(k_ba_pose_part, dim3((b->n_poses * SPLIT + 3) / 4), dim3(256), 0, s, vt, b->robust, 1, b->d_partial);
-    hipLaunchKernelGGL(k_ba_pose_combine, dim3(1), dim3(1024), 0, s, vt, 1, b->d_partial, b->d_scal + 1, pb, 0, b->d_scal + 2);
+    hipLaunchKernelGGL(k_ba_backsub, dim3(pb + 1), dim3(256), 0, s, v, pb);
+    hipLaunchKernelGGL(k_ba_pose_part, dim3((b->n_poses * SPLIT + 3) / 4), dim3(256), 0, s, v, b->robust, 1);
+    hipLaunchKernelGGL(k_ba_pose_combine, dim3(1), dim3(1024), 0, s, v, 1, pb, fused);
     LP_HIP(hipGetLastError());
     return LPSLAM_HIP_OK;
 }
 
-int read_scal(lpslam_hip_ba* b, double* h8)
+int write_ctl(lpslam_hip_ba* b, const BaCtl& c)
 {
-    LP_HIP(hipMemcpyAsync(h8, b->d_scal, 8 * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+    LP_HIP(hipMemcpyAsync(b->d_ctl, &c, sizeof(BaCtl), hipMemcpyHostToDevice, b->stream));
+    LP_HIP(hipStreamSynchronize(b->stream));      // &c is a stack object
+    return LPSLAM_HIP_OK;
+}
+int read_ctl(lpslam_hip_ba* b)
+{
+    LP_HIP(hipMemcpyAsync(&b->h_ctl, b->d_ctl, sizeof(BaCtl), hipMemcpyDeviceToHost, b->stream));
     LP_HIP(hipStreamSynchronize(b->stream));
     return LPSLAM_HIP_OK;
 }
 
-// g2o's lambda control for one finished trial; returns true when the outer iteration is over
-bool lm_decide(lpslam_hip_ba* b, double temp_chi, double scale, bool ok2, int* accepted)
+// arms the control block for an optimize() call of `iters` outer iterations (g2o: lambda_0 is recomputed per call)
+int begin_optimize(lpslam_hip_ba* b, int robust, int iters)
 {
-    if (!ok2) temp_chi = DBL_MAX;
-    double rho = b->current_chi - temp_chi;
-    scale += 1e-3;
-    rho /= scale;
-    if (rho > 0 && std::isfinite(temp_chi)) {
-        double alpha = 1. - std::pow((2 * rho - 1), 3);
-        alpha = std::min(alpha, 2. / 3.);
-        const double sf = std::max(1. / 3., alpha);
-        b->lambda *= sf;
-        b->ni = 2;
-        b->current_chi = temp_chi;
-        b->cur ^= 1;                                 // discardTop: the trial state becomes the accepted one
-        *accepted = 1;
-    } else {
-        b->lambda *= b->ni;
-        b->ni *= 2;
-        *accepted = 0;                               // pop: keep the accepted state
-    }
-    b->rho = rho;
-    b->qmax++;
-    return !(rho < 0 && b->qmax < 10);
+    b->robust = robust;
+    BaCtl c = b->h_ctl;
+    c.max_outer = iters; c.outer_done = 0; c.need_lin = 1; c.first = 1; c.qmax = 0; c.stopped = 0; c.ni = 2; c.rho = 0; c.last_accepted = 0;
+    b->h_ctl = c;
+    return write_ctl(b, c);
 }
 
 }  // namespace
@@ -907,7 +1020,7 @@ int lpslam_hip_ba_create(lpslam_hip_ctx* ctx, const double* poses, const uint8_t
             for (size_t a = 0; a < tmp.size(); ++a)
                 for (size_t c = a; c < tmp.size(); ++c) {
                     if (c > a && tmp[c].first == tmp[a].first) {
-                        // two observations of one landmark in the same keyframe: contributes to the diagonal block twice (a,c) and (c,a)
+                        // two observations of one landmark in the same keyframe: both orders go to the diagonal block
                         const int q = blk_index(tmp[a].first, tmp[a].first);
                         if (pass == 0) blk_count[q + 1] += 2;
                         else { terms[fill[q]++] = make_int2(tmp[a].second, tmp[c].second); terms[fill[q]++] = make_int2(tmp[c].second, tmp[a].second); }
@@ -926,6 +1039,7 @@ int lpslam_hip_ba_create(lpslam_hip_ctx* ctx, const double* poses, const uint8_t
     int rc = 0;
     auto fail = [&](int code) { lpslam_hip_ba_destroy(b); return code; };
 #define BA_TRY(x) do { rc = (x); if (rc) return fail(rc); } while (0)
+#define BA_HIP(x) do { if ((x) != hipSuccess) { set_error("HIP call failed: %s", #x); return fail(LPSLAM_HIP_ERR_DEVICE); } } while (0)
     BA_TRY(upload(b, &b->d_blk_start, blk_count));
     BA_TRY(upload(b, &b->d_pose_slot, slot));
     BA_TRY(upload(b, &b->d_free_pose, free_pose));
@@ -936,37 +1050,40 @@ int lpslam_hip_ba_create(lpslam_hip_ctx* ctx, const double* poses, const uint8_t
     std::vector<uint8_t> act((size_t)std::max(n_obs, 1), 1);
     BA_TRY(upload(b, &b->d_o_active, act));
     for (int s = 0; s < 2; ++s) { BA_TRY(dalloc(b, &b->d_poses[s], 7 * (size_t)n_poses)); BA_TRY(dalloc(b, &b->d_points[s], 3 * (size_t)n_points)); }
-    if (hipMemcpy(b->d_poses[0], poses, 7 * (size_t)n_poses * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
-        (n_points && hipMemcpy(b->d_points[0], points, 3 * (size_t)n_points * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)) {
-        set_error("state upload failed"); return fail(LPSLAM_HIP_ERR_DEVICE);
-    }
     BA_TRY(dalloc(b, &b->d_poses0, 7 * (size_t)n_poses)); BA_TRY(dalloc(b, &b->d_points0, 3 * (size_t)n_points));
-    if (hipMemcpy(b->d_poses0, poses, 7 * (size_t)n_poses * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
-        (n_points && hipMemcpy(b->d_points0, points, 3 * (size_t)n_points * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)) {
-        set_error("state upload failed"); return fail(LPSLAM_HIP_ERR_DEVICE);
+    BA_HIP(hipMemcpy(b->d_poses0, poses, 7 * (size_t)n_poses * sizeof(double), hipMemcpyHostToDevice));
+    BA_HIP(hipMemcpy(b->d_poses[0], poses, 7 * (size_t)n_poses * sizeof(double), hipMemcpyHostToDevice));
+    if (n_points) {
+        BA_HIP(hipMemcpy(b->d_points0, points, 3 * (size_t)n_points * sizeof(double), hipMemcpyHostToDevice));
+        BA_HIP(hipMemcpy(b->d_points[0], points, 3 * (size_t)n_points * sizeof(double), hipMemcpyHostToDevice));
     }
     BA_TRY(dalloc(b, &b->d_W, 18 * (size_t)n_obs)); BA_TRY(dalloc(b, &b->d_Y, 18 * (size_t)n_obs)); BA_TRY(dalloc(b, &b->d_Ybl, 6 * (size_t)n_obs));
     BA_TRY(dalloc(b, &b->d_Hll, 6 * (size_t)n_points)); BA_TRY(dalloc(b, &b->d_bl, 3 * (size_t)n_points)); BA_TRY(dalloc(b, &b->d_Hinv, 6 * (size_t)n_points));
     BA_TRY(dalloc(b, &b->d_Hpp, 36 * (size_t)b->n_free));
+    BA_TRY(dalloc(b, &b->d_hl_obs, 9 * (size_t)n_obs)); BA_TRY(dalloc(b, &b->d_partial, (size_t)n_poses * SPLIT * PV));
+    BA_HIP(hipMemset(b->d_partial, 0, (size_t)n_poses * SPLIT * PV * sizeof(double)));
     b->red_n = (int64_t)b->dim_pad * b->dim_pad + 3 * (int64_t)b->dim_pad + 8;
     BA_TRY(dalloc(b, &b->d_red, (size_t)b->red_n));
-    if (hipMemset(b->d_red, 0, (size_t)b->red_n * sizeof(double)) != hipSuccess) { set_error("memset failed"); return fail(LPSLAM_HIP_ERR_DEVICE); }
+    BA_HIP(hipMemset(b->d_red, 0, (size_t)b->red_n * sizeof(double)));
     {   // rows beyond the rhs row: identity (they stay 1 / 0 through every factorisation)
-        std::vector<double> one(1, 1.0);
-        for (int r = b->dim + 1; r < b->dim_pad; ++r)
-            if (hipMemcpy(b->d_red + (size_t)r * b->dim_pad + r, one.data(), sizeof(double), hipMemcpyHostToDevice) != hipSuccess) { set_error("pad init failed"); return fail(LPSLAM_HIP_ERR_DEVICE); }
+        const double one = 1.0;
+        for (int r = b->dim + 1; r < b->dim_pad; ++r) BA_HIP(hipMemcpy(b->d_red + (size_t)r * b->dim_pad + r, &one, sizeof(double), hipMemcpyHostToDevice));
     }
-    BA_TRY(dalloc(b, &b->d_xp, (size_t)b->dim_pad)); BA_TRY(dalloc(b, &b->d_xl, 3 * (size_t)n_points));
+    BA_TRY(dalloc(b, &b->d_minv, (size_t)b->dim_pad * b->dim_pad));
+    BA_HIP(hipMemset(b->d_minv, 0, (size_t)b->dim_pad * b->dim_pad * sizeof(double)));
+    BA_TRY(dalloc(b, &b->d_xp, (size_t)b->dim_pad));
+    BA_HIP(hipMemset(b->d_xp, 0, b->dim_pad * sizeof(double)));
     BA_TRY(dalloc(b, &b->d_chi_pose, (size_t)n_poses));
     b->part_n = std::max((n_points + 63) / 64, 1);
-    BA_TRY(dalloc(b, &b->d_hl_obs, 9 * (size_t)n_obs)); BA_TRY(dalloc(b, &b->d_partial, (size_t)n_poses * SPLIT * PV));
-    if (hipMemset(b->d_partial, 0, (size_t)n_poses * SPLIT * PV * sizeof(double)) != hipSuccess) { set_error("memset failed"); return fail(LPSLAM_HIP_ERR_DEVICE); }
     BA_TRY(dalloc(b, &b->d_part, (size_t)b->part_n)); BA_TRY(dalloc(b, &b->d_scal, 8));
-    if (hipMemset(b->d_scal, 0, 8 * sizeof(double)) != hipSuccess || hipMemset(b->d_xp, 0, b->dim_pad * sizeof(double)) != hipSuccess) {
-        set_error("memset failed"); return fail(LPSLAM_HIP_ERR_DEVICE);
-    }
+    BA_HIP(hipMemset(b->d_scal, 0, 8 * sizeof(double)));
     BA_TRY(dalloc(b, &b->d_chi_obs, (size_t)n_obs)); BA_TRY(dalloc(b, &b->d_depth, (size_t)n_obs));
+    BA_TRY(dalloc(b, &b->d_ctl, 1)); BA_TRY(dalloc(b, &b->d_log, MAX_LOG));
+    BA_HIP(hipMemset(b->d_ctl, 0, sizeof(BaCtl)));
 #undef BA_TRY
+#undef BA_HIP
+    b->h_ctl = BaCtl{};
+    b->h_ctl.ni = 2; b->h_ctl.need_lin = 1; b->h_ctl.first = 1;
     *out = b;
     return LPSLAM_HIP_OK;
 }
@@ -990,6 +1107,90 @@ int lpslam_hip_ba_set_active(lpslam_hip_ba* b, const uint8_t* active)
     return LPSLAM_HIP_OK;
 }
 
+int lpslam_hip_ba_set_points_fixed(lpslam_hip_ba* b, int32_t points_fixed)
+{
+    if (!b) { set_error("null problem"); return LPSLAM_HIP_ERR_INVALID; }
+    b->points_fixed = points_fixed ? 1 : 0;
+    return LPSLAM_HIP_OK;
+}
+
+int lpslam_hip_ba_optimize(lpslam_hip_ba* b, int32_t robust, int32_t iters, lpslam_hip_ba_iter_log* log, int32_t* done_out)
+{
+    if (!b) { set_error("null problem"); return LPSLAM_HIP_ERR_INVALID; }
+    if (iters < 0 || iters > MAX_LOG) { set_error("iterations must be in [0,%d]", MAX_LOG); return LPSLAM_HIP_ERR_INVALID; }
+    LP_HIP(hipSetDevice(b->ctx->cfg.device));
+    int rc = begin_optimize(b, robust, iters); if (rc) return rc;
+    // One unit = one LM trial.  Without rejected steps `iters` units finish the call with a single look at the control
+    // block; every rejected trial costs one more unit, enqueued after that look.
+    int guard = 0;
+    while (!b->h_ctl.stopped && b->h_ctl.outer_done < iters && guard++ < 16 * MAX_LOG) {
+        const int units = iters - b->h_ctl.outer_done;
+        for (int u = 0; u < units; ++u) {
+            if ((rc = enqueue_linearize(b, 1))) return rc;
+            if ((rc = enqueue_reduce(b, 1))) return rc;
+            if ((rc = enqueue_solve(b, 1))) return rc;
+        }
+        if ((rc = read_ctl(b))) return rc;
+    }
+    const int done = b->h_ctl.outer_done;
+    if (log && done) LP_HIP(hipMemcpy(log, b->d_log, std::min(done, MAX_LOG) * sizeof(lpslam_hip_ba_iter_log), hipMemcpyDeviceToHost));
+    if (done_out) *done_out = done;
+    return LPSLAM_HIP_OK;
+}
+
+// ---- partitioned (multi-GPU) solve: one LM trial in three phases with the caller's all-reduces in between ------------------
+//   lpslam_hip_ba_step_begin : (linearise if needed) + partial Schur complement -> reduced buffer [S | rhs | b_p | diag H_pp |
+//                              chi2]: SUM all-reduce; scalar buffer entry [4] = max diag H_ll: MAX all-reduce (first trial)
+//   lpslam_hip_ba_step_solve : lambda control start, factor, solve, update into the trial state; scalar buffer [1] = trial
+//                              chi2 and [2] = landmark scale term: SUM all-reduce ([3], the pose term, is identical on all ranks)
+//   lpslam_hip_ba_step_end   : accept / reject; reports the control state
+// Every phase ends with a stream synchronise so the caller's collective may touch the buffers right away.
+int lpslam_hip_ba_step_begin(lpslam_hip_ba* b, int32_t robust, int32_t first)
+{
+    if (!b) { set_error("null problem"); return LPSLAM_HIP_ERR_INVALID; }
+    LP_HIP(hipSetDevice(b->ctx->cfg.device));
+    int rc;
+    if (first) { if ((rc = begin_optimize(b, robust, MAX_LOG))) return rc; }
+    b->robust = robust;
+    // lambda is needed by the Schur complement but lambda_0 depends on all-reduced diagonals: on the very first trial the
+    // caller runs begin twice (first = 1: linearisation only; first = 0 after the reduction of the diagonals)
+    if ((rc = enqueue_linearize(b, 0))) return rc;
+    if (!first) { if ((rc = enqueue_reduce(b, 0))) return rc; }
+    LP_HIP(hipStreamSynchronize(b->stream));
+    return LPSLAM_HIP_OK;
+}
+
+int lpslam_hip_ba_step_lambda0(lpslam_hip_ba* b)
+{
+    if (!b) { set_error("null problem"); return LPSLAM_HIP_ERR_INVALID; }
+    BaView v = make_view(b);
+    hipLaunchKernelGGL(k_lm_begin, dim3(1), dim3(64), 0, b->stream, v);
+    LP_HIP(hipGetLastError());
+    LP_HIP(hipStreamSynchronize(b->stream));
+    return LPSLAM_HIP_OK;
+}
+
+int lpslam_hip_ba_step_solve(lpslam_hip_ba* b)
+{
+    if (!b) { set_error("null problem"); return LPSLAM_HIP_ERR_INVALID; }
+    int rc = enqueue_solve(b, 0); if (rc) return rc;
+    LP_HIP(hipStreamSynchronize(b->stream));
+    return LPSLAM_HIP_OK;
+}
+
+int lpslam_hip_ba_step_end(lpslam_hip_ba* b, int32_t* accepted, int32_t* iteration_finished)
+{
+    if (!b) { set_error("null problem"); return LPSLAM_HIP_ERR_INVALID; }
+    const int before = b->h_ctl.outer_done;
+    BaView v = make_view(b);
+    hipLaunchKernelGGL(k_lm_decide, dim3(1), dim3(64), 0, b->stream, v);
+    LP_HIP(hipGetLastError());
+    int rc = read_ctl(b); if (rc) return rc;
+    if (accepted) *accepted = b->h_ctl.last_accepted;
+    if (iteration_finished) *iteration_finished = (b->h_ctl.outer_done != before || b->h_ctl.stopped) ? 1 : 0;
+    return LPSLAM_HIP_OK;
+}
+
 int lpslam_hip_ba_reduced_buffer(lpslam_hip_ba* b, void** dev_ptr, int64_t* n_doubles)
 {
     if (!b) { set_error("null problem"); return LPSLAM_HIP_ERR_INVALID; }
@@ -1006,96 +1207,11 @@ int lpslam_hip_ba_scalar_buffer(lpslam_hip_ba* b, void** dev_ptr, int64_t* n_dou
     return LPSLAM_HIP_OK;
 }
 
-// One LM trial in three device phases so that a landmark-partitioned multi-GPU solve can all-reduce in between:
-//   step_begin : (first trial of an iteration: linearise) + Schur complement for the current lambda -> reduced buffer
-//                [S | rhs | b_p | diag H_pp | chi2] (sum all-reduce) and scal[4] = max diag H_ll (max all-reduce, first only)
-//   step_solve : lambda_0 (first iteration), factor, solve, update into the trial state; scal[1] = trial chi2 and
-//                scal[2] = landmark part of computeScale (sum all-reduce), scal[3] = pose part (identical on all ranks)
-//   step_end   : lambda control; *accepted, *iteration_finished
-int lpslam_hip_ba_step_begin(lpslam_hip_ba* b, int32_t robust, int32_t first)
-{
-    if (!b) { set_error("null problem"); return LPSLAM_HIP_ERR_INVALID; }
-    LP_HIP(hipSetDevice(b->ctx->cfg.device));
-    b->robust = robust;
-    int rc;
-    if (b->qmax == 0 || first) {
-        if (first) { b->lambda = -1.0; b->ni = 2; }
-        b->qmax = 0;
-        if ((rc = ba_linearize(b))) return rc;
-    }
-    if (b->lambda < 0) {
-        // lambda_0 needs max diag over H_pp (all-reduced) and H_ll: Schur complement is built after it is known.
-        // Single-GPU callers go through lpslam_hip_ba_optimize, which handles this; the multi-GPU protocol runs
-        // step_begin twice on the first trial (first with lambda unknown -> only the linearisation is published).
-        BaView v = make_view(b, b->cur);
-        (void)v;
-        return LPSLAM_HIP_OK;
-    }
-    return ba_reduce_system(b, 0);
-}
-
-int lpslam_hip_ba_step_solve(lpslam_hip_ba* b)
-{
-    if (!b) { set_error("null problem"); return LPSLAM_HIP_ERR_INVALID; }
-    return ba_solve_update(b, 0);
-}
-
-int lpslam_hip_ba_step_end(lpslam_hip_ba* b, int32_t* accepted, int32_t* iteration_finished)
-{
-    if (!b) { set_error("null problem"); return LPSLAM_HIP_ERR_INVALID; }
-    double h[8];
-    int rc = read_scal(b, h); if (rc) return rc;
-    int acc = 0;
-    const bool done = lm_decide(b, h[1], h[2] + h[3], h[5] == 0.0, &acc);
-    if (accepted) *accepted = acc;
-    if (iteration_finished) *iteration_finished = done ? 1 : 0;
-    if (done) b->qmax = 0;
-    return LPSLAM_HIP_OK;
-}
-
-int lpslam_hip_ba_optimize(lpslam_hip_ba* b, int32_t robust, int32_t iters, lpslam_hip_ba_iter_log* log, int32_t* done_out)
-{
-    if (!b) { set_error("null problem"); return LPSLAM_HIP_ERR_INVALID; }
-    LP_HIP(hipSetDevice(b->ctx->cfg.device));
-    b->robust = robust;
-    int it = 0, rc;
-    for (; it < iters; ++it) {
-        if ((rc = ba_linearize(b))) return rc;
-        double h[8];
-        // chi2 of the accepted state and the diagonal maxima
-        std::vector<double> tail(b->dim_pad + 1);
-        BaView v = make_view(b, b->cur);
-        LP_HIP(hipMemcpyAsync(tail.data(), v.hppdiag, (b->dim_pad + 1) * sizeof(double), hipMemcpyDeviceToHost, b->stream));
-        if ((rc = read_scal(b, h))) return rc;
-        b->current_chi = tail[b->dim_pad];
-        if (it == 0) {
-            double maxd = b->n_points ? h[4] : 0.0;
-            for (int i = 0; i < b->dim; ++i) maxd = std::max(maxd, std::fabs(tail[i]));
-            b->lambda = 1e-5 * maxd;
-            b->ni = 2;
-        }
-        b->chi_before = b->current_chi;
-        b->qmax = 0;
-        bool finished = false;
-        while (!finished) {
-            if ((rc = ba_reduce_system(b, 1))) return rc;
-            if ((rc = ba_solve_update(b, 1))) return rc;
-            if ((rc = read_scal(b, h))) return rc;
-            int acc;
-            finished = lm_decide(b, h[1], h[2] + h[3], h[5] == 0.0, &acc);
-        }
-        const bool terminate = (b->qmax == 10 || b->rho == 0);
-        if (log) { log[it].chi2_before = b->chi_before; log[it].chi2_after = b->current_chi; log[it].lambda = b->lambda; log[it].trials = b->qmax; log[it].status = terminate; }
-        if (terminate) { ++it; break; }
-    }
-    if (done_out) *done_out = it;
-    return LPSLAM_HIP_OK;
-}
-
 int lpslam_hip_ba_reset(lpslam_hip_ba* b)
 {
     if (!b) { set_error("null problem"); return LPSLAM_HIP_ERR_INVALID; }
-    b->cur = 0; b->lambda = 0; b->ni = 2; b->qmax = 0; b->rho = 0;
+    b->h_ctl = BaCtl{};
+    b->h_ctl.ni = 2; b->h_ctl.need_lin = 1; b->h_ctl.first = 1;
     LP_HIP(hipMemcpyAsync(b->d_poses[0], b->d_poses0, 7 * (size_t)b->n_poses * sizeof(double), hipMemcpyDeviceToDevice, b->stream));
     if (b->n_points) LP_HIP(hipMemcpyAsync(b->d_points[0], b->d_points0, 3 * (size_t)b->n_points * sizeof(double), hipMemcpyDeviceToDevice, b->stream));
     if (b->n_obs) LP_HIP(hipMemsetAsync(b->d_o_active, 1, b->n_obs, b->stream));
@@ -1105,8 +1221,9 @@ int lpslam_hip_ba_reset(lpslam_hip_ba* b)
 int lpslam_hip_ba_get(lpslam_hip_ba* b, double* poses, double* points)
 {
     if (!b) { set_error("null problem"); return LPSLAM_HIP_ERR_INVALID; }
-    if (poses) LP_HIP(hipMemcpyAsync(poses, b->d_poses[b->cur], 7 * (size_t)b->n_poses * sizeof(double), hipMemcpyDeviceToHost, b->stream));
-    if (points && b->n_points) LP_HIP(hipMemcpyAsync(points, b->d_points[b->cur], 3 * (size_t)b->n_points * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+    const int cur = b->h_ctl.cur;
+    if (poses) LP_HIP(hipMemcpyAsync(poses, b->d_poses[cur], 7 * (size_t)b->n_poses * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+    if (points && b->n_points) LP_HIP(hipMemcpyAsync(points, b->d_points[cur], 3 * (size_t)b->n_points * sizeof(double), hipMemcpyDeviceToHost, b->stream));
     LP_HIP(hipStreamSynchronize(b->stream));
     return LPSLAM_HIP_OK;
 }
@@ -1115,19 +1232,13 @@ int lpslam_hip_ba_chi2(lpslam_hip_ba* b, double* chi2, uint8_t* depth_positive)
 {
     if (!b) { set_error("null problem"); return LPSLAM_HIP_ERR_INVALID; }
     if (!b->n_obs) return LPSLAM_HIP_OK;
-    BaView v = make_view(b, b->cur);
+    int rc = write_ctl(b, b->h_ctl); if (rc) return rc;      // the device copy may predate a reset
+    BaView v = make_view(b);
     hipLaunchKernelGGL(k_ba_obs_chi2, dim3((b->n_obs + 255) / 256), dim3(256), 0, b->stream, v, b->d_chi_obs, b->d_depth);
     LP_HIP(hipGetLastError());
     if (chi2) LP_HIP(hipMemcpyAsync(chi2, b->d_chi_obs, (size_t)b->n_obs * sizeof(double), hipMemcpyDeviceToHost, b->stream));
     if (depth_positive) LP_HIP(hipMemcpyAsync(depth_positive, b->d_depth, (size_t)b->n_obs, hipMemcpyDeviceToHost, b->stream));
     LP_HIP(hipStreamSynchronize(b->stream));
-    return LPSLAM_HIP_OK;
-}
-
-int lpslam_hip_ba_set_points_fixed(lpslam_hip_ba* b, int32_t points_fixed)
-{
-    if (!b) { set_error("null problem"); return LPSLAM_HIP_ERR_INVALID; }
-    b->points_fixed = points_fixed ? 1 : 0;
     return LPSLAM_HIP_OK;
 }
 

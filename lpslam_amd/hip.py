@@ -32,7 +32,7 @@ SYMBOLS = [
     "lpslam_hip_match_stereo", "lpslam_hip_match_stereo_strided", "lpslam_hip_get_stereo",
     "lpslam_hip_ba_create", "lpslam_hip_ba_destroy", "lpslam_hip_ba_set_active", "lpslam_hip_ba_optimize",
     "lpslam_hip_ba_local", "lpslam_hip_ba_set_points_fixed", "lpslam_hip_ba_pose_optimize", "lpslam_hip_ba_reset", "lpslam_hip_ba_get", "lpslam_hip_ba_chi2", "lpslam_hip_ba_reduced_buffer",
-    "lpslam_hip_ba_step_begin", "lpslam_hip_ba_step_solve", "lpslam_hip_ba_scalar_buffer", "lpslam_hip_ba_step_end",
+    "lpslam_hip_ba_step_begin", "lpslam_hip_ba_step_lambda0", "lpslam_hip_ba_step_solve", "lpslam_hip_ba_scalar_buffer", "lpslam_hip_ba_step_end",
 ]
 
 
