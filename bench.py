@@ -145,24 +145,35 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
+    from lpslam_amd import hip
+    ndev = hip.device_count()
+    if ndev < 1:
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    device = local_rank % ndev
+    backend = os.environ.get("LPSLAM_BENCH_BACKEND", "nccl")      # "nccl" is RCCL on ROCm; "gloo" only for single-GPU rehearsals
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    from lpslam_amd import hip
-    if hip.device_count() < 1:
-        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+        torch.cuda.set_device(device)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group(backend=backend)
 
-    wl = Workload(local_rank, rank, args.frames, with_ba=not args.no_ba)
+    wl = Workload(device, rank, args.frames, with_ba=not args.no_ba)
+
+    def sync_tensor(values, op=None):
+        import torch
+        t = torch.tensor(values, dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=op or dist.ReduceOp.SUM)
+        if backend == "nccl":
+            torch.cuda.synchronize()
+        return t
 
     def barrier():
         wl.ctx.sync()
         if dist is not None:
-            import torch
-            t = torch.zeros(1, device="cuda")
-            dist.all_reduce(t)
-            torch.cuda.synchronize()
+            sync_tensor([0.0])
 
     import threading
 
@@ -198,10 +209,7 @@ def main():
     elapsed = time.perf_counter() - t0
     barrier()
     if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = float(sync_tensor([elapsed], dist.ReduceOp.MAX).item())
 
     # instrumented pass (same steps, HIP events around every stage on the context stream)
     stage_ms = np.zeros(len(STAGE_NAMES))

@@ -194,6 +194,8 @@ int lpslam_hip_ba_step_begin(lpslam_hip_ba* ba, int32_t robust, int32_t first);
 int lpslam_hip_ba_step_lambda0(lpslam_hip_ba* ba);
 int lpslam_hip_ba_step_solve(lpslam_hip_ba* ba);
 int lpslam_hip_ba_step_end(lpslam_hip_ba* ba, int32_t* accepted, int32_t* iteration_finished);
+/* Control state after the last optimize / step_end: finished outer iterations, g2o "Terminate", lambda, robust chi2. */
+int lpslam_hip_ba_status(lpslam_hip_ba* ba, int32_t* outer_done, int32_t* stopped, double* lambda, double* chi2);
 
 #ifdef __cplusplus
 }

@@ -55,7 +55,8 @@ struct BaView {                       // device pointers handed to kernels by va
     const uint8_t* o_active;
     const int* pt_start; const int* pt_obs; const int* ps_start; const int* ps_obs;
     double* W; double* Y; double* Ybl; double* Hll; double* bl; double* Hinv; double* Hpp; double* hl_obs; double* partial;
-    double* S; double* rhs; double* bp; double* hppdiag; double* chi_cur;   // reduced buffer sections
+    double* S; double* rhs; double* bp; double* hppdiag; double* chi_cur;   // reduced buffer sections (all-reduced when partitioned)
+    double* bp_loc; double* hppdiag_loc; double* chi_loc;                    // this rank's own sums (equal to the above on one GPU)
     double* Minv;                                                            // L^-T row blocks (dim_pad x dim_pad)
     double* xp; double* chi_pose; double* part; double* scal;
     const int* blk_start; const int2* blk_terms;
@@ -366,14 +367,14 @@ __global__ __launch_bounds__(1024) void k_ba_pose_combine(BaView v, int mode, in
         double s = 0;
         for (int sp = 0; sp < SPLIT; ++sp) s += v.partial[((size_t)p * SPLIT + sp) * PV + q];
         if (q == 27) v.chi_pose[p] = s;
-        else if (q >= 21) v.bp[6 * slot + (q - 21)] = s;
+        else if (q >= 21) { v.bp[6 * slot + (q - 21)] = s; v.bp_loc[6 * slot + (q - 21)] = s; }
         else {
             int a = 0, rem = q;                    // upper-triangle index q -> (a, c)
             while (rem >= 6 - a) { rem -= 6 - a; ++a; }
             const int c = a + rem;
             double* H = v.Hpp + 36 * (size_t)slot;
             H[a * 6 + c] = s; H[c * 6 + a] = s;
-            if (a == c) v.hppdiag[6 * slot + a] = s;
+            if (a == c) { v.hppdiag[6 * slot + a] = s; v.hppdiag_loc[6 * slot + a] = s; }
         }
     }
     __syncthreads();
@@ -381,7 +382,7 @@ __global__ __launch_bounds__(1024) void k_ba_pose_combine(BaView v, int mode, in
         double acc = 0;
         for (int p = tid; p < v.n_poses; p += 64) acc += v.chi_pose[p];
         acc = wave_sum(acc);
-        if (tid == 0) { if (mode == 0) *v.chi_cur = acc; else v.scal[1] = acc; }
+        if (tid == 0) { if (mode == 0) { *v.chi_cur = acc; *v.chi_loc = acc; } else v.scal[1] = acc; }
     } else if (tid < 128) {
         const int lane = tid - 64;
         double acc = 0;
@@ -485,10 +486,12 @@ __global__ __launch_bounds__(64) void k_ba_schur(BaView v, int n_blocks, int fus
         if (lane < 6) {
             double val = 0;
 #pragma unroll
-            for (int q = 0; q < 6; ++q) if (q == lane) val = v.bp[6 * i + q] - r6[q];
+            for (int q = 0; q < 6; ++q) if (q == lane) val = v.bp_loc[6 * i + q] - r6[q];
             v.rhs[6 * i + lane] = val;
             if (fused) v.S[(size_t)v.dim * n + 6 * i + lane] = val;
+            else { v.bp[6 * i + lane] = v.bp_loc[6 * i + lane]; v.hppdiag[6 * i + lane] = v.hppdiag_loc[6 * i + lane]; }   // fresh partials for the all-reduce
         }
+        if (!fused && i == 0 && lane == 62) *v.chi_cur = *v.chi_loc;
         if (fused && i == 0 && lane == 63) { v.S[(size_t)v.dim * n + v.dim] = 1e200; v.scal[5] = 0.0; }
         return;
     }
@@ -830,7 +833,7 @@ struct lpslam_hip_ba {
     double *d_W = nullptr, *d_Y = nullptr, *d_Ybl = nullptr, *d_Hll = nullptr, *d_bl = nullptr, *d_Hinv = nullptr, *d_Hpp = nullptr;
     double *d_hl_obs = nullptr, *d_partial = nullptr, *d_minv = nullptr;
     double* d_red = nullptr; int64_t red_n = 0;
-    double *d_xp = nullptr, *d_chi_pose = nullptr, *d_part = nullptr, *d_scal = nullptr;
+    double *d_xp = nullptr, *d_chi_pose = nullptr, *d_part = nullptr, *d_scal = nullptr, *d_loc = nullptr;
     double* d_chi_obs = nullptr; uint8_t* d_depth = nullptr;
     int* d_blk_start = nullptr; int2* d_blk_terms = nullptr;
     BaCtl* d_ctl = nullptr; lpslam_hip_ba_iter_log* d_log = nullptr;
@@ -871,6 +874,7 @@ BaView make_view(lpslam_hip_ba* b)
     v.hl_obs = b->d_hl_obs; v.partial = b->d_partial; v.Minv = b->d_minv;
     const size_t n = (size_t)b->dim_pad;
     v.S = b->d_red; v.rhs = b->d_red + n * n; v.bp = v.rhs + n; v.hppdiag = v.bp + n; v.chi_cur = v.hppdiag + n;
+    v.bp_loc = b->d_loc; v.hppdiag_loc = b->d_loc + n; v.chi_loc = b->d_loc + 2 * n;
     v.xp = b->d_xp; v.chi_pose = b->d_chi_pose; v.part = b->d_part; v.scal = b->d_scal;
     v.blk_start = b->d_blk_start; v.blk_terms = b->d_blk_terms;
     v.ctl = b->d_ctl; v.log = b->d_log;
@@ -1074,6 +1078,8 @@ int lpslam_hip_ba_create(lpslam_hip_ctx* ctx, const double* poses, const uint8_t
     BA_TRY(dalloc(b, &b->d_xp, (size_t)b->dim_pad));
     BA_HIP(hipMemset(b->d_xp, 0, b->dim_pad * sizeof(double)));
     BA_TRY(dalloc(b, &b->d_chi_pose, (size_t)n_poses));
+    BA_TRY(dalloc(b, &b->d_loc, 2 * (size_t)b->dim_pad + 8));
+    BA_HIP(hipMemset(b->d_loc, 0, (2 * (size_t)b->dim_pad + 8) * sizeof(double)));
     b->part_n = std::max((n_points + 63) / 64, 1);
     BA_TRY(dalloc(b, &b->d_part, (size_t)b->part_n)); BA_TRY(dalloc(b, &b->d_scal, 8));
     BA_HIP(hipMemset(b->d_scal, 0, 8 * sizeof(double)));
@@ -1188,6 +1194,16 @@ int lpslam_hip_ba_step_end(lpslam_hip_ba* b, int32_t* accepted, int32_t* iterati
     int rc = read_ctl(b); if (rc) return rc;
     if (accepted) *accepted = b->h_ctl.last_accepted;
     if (iteration_finished) *iteration_finished = (b->h_ctl.outer_done != before || b->h_ctl.stopped) ? 1 : 0;
+    return LPSLAM_HIP_OK;
+}
+
+int lpslam_hip_ba_status(lpslam_hip_ba* b, int32_t* outer_done, int32_t* stopped, double* lambda, double* chi2)
+{
+    if (!b) { set_error("null problem"); return LPSLAM_HIP_ERR_INVALID; }
+    if (outer_done) *outer_done = b->h_ctl.outer_done;
+    if (stopped) *stopped = b->h_ctl.stopped;
+    if (lambda) *lambda = b->h_ctl.lambda;
+    if (chi2) *chi2 = b->h_ctl.current_chi;
     return LPSLAM_HIP_OK;
 }
 

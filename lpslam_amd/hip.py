@@ -32,7 +32,7 @@ SYMBOLS = [
     "lpslam_hip_match_stereo", "lpslam_hip_match_stereo_strided", "lpslam_hip_get_stereo",
     "lpslam_hip_ba_create", "lpslam_hip_ba_destroy", "lpslam_hip_ba_set_active", "lpslam_hip_ba_optimize",
     "lpslam_hip_ba_local", "lpslam_hip_ba_set_points_fixed", "lpslam_hip_ba_pose_optimize", "lpslam_hip_ba_reset", "lpslam_hip_ba_get", "lpslam_hip_ba_chi2", "lpslam_hip_ba_reduced_buffer",
-    "lpslam_hip_ba_step_begin", "lpslam_hip_ba_step_lambda0", "lpslam_hip_ba_step_solve", "lpslam_hip_ba_scalar_buffer", "lpslam_hip_ba_step_end",
+    "lpslam_hip_ba_step_begin", "lpslam_hip_ba_step_lambda0", "lpslam_hip_ba_step_solve", "lpslam_hip_ba_scalar_buffer", "lpslam_hip_ba_step_end", "lpslam_hip_ba_status",
 ]
 
 
@@ -259,6 +259,37 @@ class BundleAdjuster:
         chi = np.zeros(max(self.n_obs, 1)); pos = np.zeros(max(self.n_obs, 1), np.uint8)
         _check(self.lib.lpslam_hip_ba_chi2(self.h, _p(chi), _p(pos)))
         return chi[:self.n_obs], pos[:self.n_obs]
+
+
+    # ---- partitioned (multi-GPU) solve: phases of one LM trial (see include/lpslam_hip.h) ----
+    def reduced_buffer(self):
+        ptr = C.c_void_p(); n = C.c_int64()
+        _check(self.lib.lpslam_hip_ba_reduced_buffer(self.h, C.byref(ptr), C.byref(n)))
+        return ptr.value, n.value
+
+    def scalar_buffer(self):
+        ptr = C.c_void_p(); n = C.c_int64()
+        _check(self.lib.lpslam_hip_ba_scalar_buffer(self.h, C.byref(ptr), C.byref(n)))
+        return ptr.value, n.value
+
+    def step_begin(self, robust, first):
+        _check(self.lib.lpslam_hip_ba_step_begin(self.h, int(robust), int(first)))
+
+    def step_lambda0(self):
+        _check(self.lib.lpslam_hip_ba_step_lambda0(self.h))
+
+    def step_solve(self):
+        _check(self.lib.lpslam_hip_ba_step_solve(self.h))
+
+    def step_end(self):
+        a = C.c_int32(); f = C.c_int32()
+        _check(self.lib.lpslam_hip_ba_step_end(self.h, C.byref(a), C.byref(f)))
+        return bool(a.value), bool(f.value)
+
+    def status(self):
+        o = C.c_int32(); st = C.c_int32(); lam = C.c_double(); chi = C.c_double()
+        _check(self.lib.lpslam_hip_ba_status(self.h, C.byref(o), C.byref(st), C.byref(lam), C.byref(chi)))
+        return dict(outer_done=o.value, stopped=bool(st.value), lam=lam.value, chi2=chi.value)
 
 
 def ba_obs_array(prob):
