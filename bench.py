@@ -145,6 +145,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
+    if world > 1:
+        import torch            # noqa: F401  (before the HIP library: both must share one HIP runtime, torch's loads first)
+        import torch.distributed  # noqa: F401
     from lpslam_amd import hip
     ndev = hip.device_count()
     if ndev < 1:

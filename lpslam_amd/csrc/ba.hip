@@ -58,6 +58,7 @@ struct BaView {                       // device pointers handed to kernels by va
     double* S; double* rhs; double* bp; double* hppdiag; double* chi_cur;   // reduced buffer sections (all-reduced when partitioned)
     double* bp_loc; double* hppdiag_loc; double* chi_loc;                    // this rank's own sums (equal to the above on one GPU)
     double* Minv;                                                            // L^-T row blocks (dim_pad x dim_pad)
+    double* Ldiag;                                                           // factored diagonal blocks [nb][32][32]
     double* xp; double* chi_pose; double* part; double* scal;
     const int* blk_start; const int2* blk_terms;
     BaCtl* ctl; lpslam_hip_ba_iter_log* log;
@@ -708,9 +709,11 @@ __global__ __launch_bounds__(256) void k_chol_step(BaView v, int nb, int kb)
         }
     }
     if (lane < NB) {
-        if (!has_b) {        // the diagonal workgroup publishes L_jj (lower triangle) and the failure flag
+        if (!has_b) {
+            // The diagonal workgroup publishes L_jj and the failure flag.  L_jj goes to a side buffer, NOT over A_jj:
+            // the other panel workgroups of this launch read A_jj and may be scheduled after this store.
 #pragma unroll
-            for (int c = 0; c < NB; ++c) if (c <= lane) S[(rj + lane) * n + rj + c] = a[c];
+            for (int c = 0; c < NB; ++c) v.Ldiag[((size_t)j * NB + lane) * NB + c] = c <= lane ? a[c] : 0.0;
             if (fail && lane == 0) v.scal[5] = 1.0;
         }
     } else if (has_b) {
@@ -728,10 +731,13 @@ __global__ __launch_bounds__(256) void k_chol_xsolve(BaView v)
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= v.dim) return;
     const int n = v.dim_pad;
+    // y = L^-1 rhs is row `dim` of L: off-diagonal blocks live in S, the part inside the row's own diagonal block in Ldiag
+    const int yb = v.dim / NB;
     const double* y = v.S + (size_t)v.dim * n;
+    const double* yd = v.Ldiag + ((size_t)yb * NB + (v.dim - yb * NB)) * NB - (size_t)yb * NB;
     const double* m = v.Minv + (size_t)i * n;
     double acc = 0;
-    for (int c = (i / NB) * NB + lane; c < v.dim; c += 64) acc += m[c] * y[c];     // blocks left of the diagonal block are empty
+    for (int c = (i / NB) * NB + lane; c < v.dim; c += 64) acc += m[c] * (c < yb * NB ? y[c] : yd[c]);     // blocks left of the diagonal are empty
     acc = wave_sum(acc);
     if (lane == 0) v.xp[i] = acc;
 }
@@ -831,7 +837,7 @@ struct lpslam_hip_ba {
     uint8_t* d_o_active = nullptr;
     int *d_pt_start = nullptr, *d_pt_obs = nullptr, *d_ps_start = nullptr, *d_ps_obs = nullptr;
     double *d_W = nullptr, *d_Y = nullptr, *d_Ybl = nullptr, *d_Hll = nullptr, *d_bl = nullptr, *d_Hinv = nullptr, *d_Hpp = nullptr;
-    double *d_hl_obs = nullptr, *d_partial = nullptr, *d_minv = nullptr;
+    double *d_hl_obs = nullptr, *d_partial = nullptr, *d_minv = nullptr, *d_ldiag = nullptr;
     double* d_red = nullptr; int64_t red_n = 0;
     double *d_xp = nullptr, *d_chi_pose = nullptr, *d_part = nullptr, *d_scal = nullptr, *d_loc = nullptr;
     double* d_chi_obs = nullptr; uint8_t* d_depth = nullptr;
@@ -871,7 +877,7 @@ BaView make_view(lpslam_hip_ba* b)
     v.o_u = b->d_o_u; v.o_v = b->d_o_v; v.o_ur = b->d_o_ur; v.o_w = b->d_o_w; v.o_active = b->d_o_active;
     v.pt_start = b->d_pt_start; v.pt_obs = b->d_pt_obs; v.ps_start = b->d_ps_start; v.ps_obs = b->d_ps_obs;
     v.W = b->d_W; v.Y = b->d_Y; v.Ybl = b->d_Ybl; v.Hll = b->d_Hll; v.bl = b->d_bl; v.Hinv = b->d_Hinv; v.Hpp = b->d_Hpp;
-    v.hl_obs = b->d_hl_obs; v.partial = b->d_partial; v.Minv = b->d_minv;
+    v.hl_obs = b->d_hl_obs; v.partial = b->d_partial; v.Minv = b->d_minv; v.Ldiag = b->d_ldiag;
     const size_t n = (size_t)b->dim_pad;
     v.S = b->d_red; v.rhs = b->d_red + n * n; v.bp = v.rhs + n; v.hppdiag = v.bp + n; v.chi_cur = v.hppdiag + n;
     v.bp_loc = b->d_loc; v.hppdiag_loc = b->d_loc + n; v.chi_loc = b->d_loc + 2 * n;
@@ -1075,6 +1081,7 @@ int lpslam_hip_ba_create(lpslam_hip_ctx* ctx, const double* poses, const uint8_t
     }
     BA_TRY(dalloc(b, &b->d_minv, (size_t)b->dim_pad * b->dim_pad));
     BA_HIP(hipMemset(b->d_minv, 0, (size_t)b->dim_pad * b->dim_pad * sizeof(double)));
+    BA_TRY(dalloc(b, &b->d_ldiag, (size_t)b->dim_pad * NB));
     BA_TRY(dalloc(b, &b->d_xp, (size_t)b->dim_pad));
     BA_HIP(hipMemset(b->d_xp, 0, b->dim_pad * sizeof(double)));
     BA_TRY(dalloc(b, &b->d_chi_pose, (size_t)n_poses));

@@ -17,7 +17,7 @@ def _port():
     return p
 
 
-def _torchrun(args, env_extra, timeout=600):
+def _torchrun(args, env_extra, timeout=150):
     env = dict(os.environ); env.update(env_extra)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_port())] + args
