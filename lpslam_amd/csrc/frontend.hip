@@ -97,8 +97,10 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
 {
     __shared__ __attribute__((aligned(16))) uint8_t tile[70 * TILE_PITCH];
     __shared__ __attribute__((aligned(16))) uint8_t smap[66 * SMAP_PITCH];
-    __shared__ unsigned long long m_ini[64], m_min[64], m_sel[64];
+    __shared__ unsigned long long m_sel[64];     // per-row masks of the NMS survivors (LDS atomics)
     __shared__ int rowoff[64];
+    __shared__ uint16_t queue[64 * 64];
+    __shared__ int q_count, n_keep;
 
     const int cell = blockIdx.x, image = image0 + blockIdx.y;
     int level = 0;
@@ -122,42 +124,68 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
         *reinterpret_cast<uint32_t*>(&tile[r * TILE_PITCH + 4 * c]) = v;
     }
     for (int i = tid; i < 66 * SMAP_PITCH / 4; i += 256) reinterpret_cast<uint32_t*>(smap)[i] = 0;
-    if (tid < 64) { m_ini[tid] = 0; m_min[tid] = 0; }
     __syncthreads();
 
     const int vw = cw - 6, vh = ch - 6;          // valid (corner-tested) interior, <= 64 x 64; may be <= 0
-    const int thr_lo = min(ini_thr, min_thr);
-    for (int r = wave; r < vh; r += 4) {
-        if (lane < vw) {
-            const int s = fast_strength(&tile[(r + 3) * TILE_PITCH + shift + lane + 3]);
-            smap[(r + 1) * SMAP_PITCH + lane + 1] = (uint8_t)(s > thr_lo ? s : 0);
+    const unsigned long long lane_ok = vw >= 64 ? ~0ull : ((1ull << max(vw, 0)) - 1ull);
+    // cv::FAST at the initial threshold; a cell without a single NMS survivor is redone at the minimum threshold.
+    // The arc strength S does not depend on the threshold (corner at t  <=>  S > t), so each pass is:
+    //   1. pre-test, every pixel: a 9-arc of the 16-ring always contains two neighbouring compass points (ring positions
+    //      0, 4, 8, 12), so a corner needs two neighbouring compass pixels both darker or both brighter than the centre by
+    //      more than t.  One v_cmp per compass pixel gives a 64-lane mask; the pairing is scalar 64-bit logic.
+    //   2. survivors only, dense lanes from an LDS queue: S (16 arcs of 9, v_min3 / v_max3), stored if S > t;
+    //   3. survivors only: strict 3x3 non-maximum suppression on the S map, survivors set their bit in the row mask.
+    int thr = ini_thr;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if (tid < 64) m_sel[tid] = 0;
+        if (tid == 0) { q_count = 0; n_keep = 0; }
+        __syncthreads();
+        for (int r = wave; r < vh; r += 4) {
+            const uint8_t* t = &tile[(r + 3) * TILE_PITCH + shift + lane + 3];
+            const int c = t[0];
+            const int lo = c - thr, hi = c + thr;
+            const int p0 = t[3 * TILE_PITCH], p4 = t[3], p8 = t[-3 * TILE_PITCH], p12 = t[-3];
+            const unsigned long long d0 = __ballot(p0 < lo), d4 = __ballot(p4 < lo), d8 = __ballot(p8 < lo), d12 = __ballot(p12 < lo);
+            const unsigned long long b0 = __ballot(p0 > hi), b4 = __ballot(p4 > hi), b8 = __ballot(p8 > hi), b12 = __ballot(p12 > hi);
+            // neighbouring compass pairs always take one point of {0, 8} and one of {4, 12}
+            const unsigned long long any = (((d0 | d8) & (d4 | d12)) | ((b0 | b8) & (b4 | b12))) & lane_ok;
+            if (any) {
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&q_count, __popcll(any));
+                base = __shfl(base, 0);
+                if ((any >> lane) & 1ull) queue[base + __popcll(any & ((1ull << lane) - 1ull))] = (uint16_t)((r << 6) | lane);
+            }
         }
-    }
-    __syncthreads();
-    for (int r = wave; r < vh; r += 4) {
-        bool nms = false;
-        int s = 0;
-        if (lane < vw) {
-            const uint8_t* q = &smap[(r + 1) * SMAP_PITCH + lane + 1];
-            s = q[0];
-            nms = s > 0 && s > q[-1] && s > q[1] && s > q[-SMAP_PITCH - 1] && s > q[-SMAP_PITCH] &&
-                  s > q[-SMAP_PITCH + 1] && s > q[SMAP_PITCH - 1] && s > q[SMAP_PITCH] && s > q[SMAP_PITCH + 1];
+        __syncthreads();
+        const int n_q = q_count;
+        for (int i = tid; i < n_q; i += 256) {
+            const int r = queue[i] >> 6, x = queue[i] & 63;
+            const int sv = fast_strength(&tile[(r + 3) * TILE_PITCH + shift + x + 3]);
+            smap[(r + 1) * SMAP_PITCH + x + 1] = (uint8_t)(sv > thr ? sv : 0);
         }
-        const unsigned long long bi = __ballot(nms && s > ini_thr);
-        const unsigned long long bm = __ballot(nms && s > min_thr);
-        if (lane == 0) { m_ini[r] = bi; m_min[r] = bm; }
+        __syncthreads();
+        int kept = 0;
+        for (int i = tid; i < n_q; i += 256) {
+            const int r = queue[i] >> 6, x = queue[i] & 63;
+            const uint8_t* q = &smap[(r + 1) * SMAP_PITCH + x + 1];
+            const int sc = q[0];
+            if (sc > 0 && sc > q[-1] && sc > q[1] && sc > q[-SMAP_PITCH - 1] && sc > q[-SMAP_PITCH] && sc > q[-SMAP_PITCH + 1] &&
+                sc > q[SMAP_PITCH - 1] && sc > q[SMAP_PITCH] && sc > q[SMAP_PITCH + 1]) {
+                atomicOr(&m_sel[r], 1ull << x);
+                kept = 1;
+            }
+        }
+        if (kept) n_keep = 1;              // benign race: every writer stores 1
+        __syncthreads();
+        if (n_keep || min_thr >= thr) break;
+        thr = min_thr;
     }
-    __syncthreads();
     if (wave == 0) {
-        int ci_ = __popcll(m_ini[lane]);
-        int tot = ci_;
-        for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
-        const unsigned long long sel = tot > 0 ? m_ini[lane] : m_min[lane];
+        const unsigned long long sel = m_sel[lane];
         const int c = __popcll(sel);
         int incl = c;
         for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
         rowoff[lane] = incl - c;
-        m_sel[lane] = sel;
         if (lane == 63) cell_count[(size_t)image * cells_per_image + cell] = incl;
     }
     __syncthreads();
@@ -219,11 +247,31 @@ __device__ void block_scan_array(int* a, int n, int* wave_tot, int* total)
     *total = tot;
 }
 
+// Candidates live in registers: thread t owns candidates t, t + 1024, ... (CPT slots, fully unrolled so every slot is a
+// fixed register); levels with more than 1024 * CPT candidates keep the rest in the global scratch arrays.  Nodes (box,
+// count; ping-pong) live in LDS.  A pass therefore touches HBM/L2 only for the overflow candidates.
+#define DIST_CPT 24
+
+// (kept for reference) LDS histogram increment with wave-level aggregation: lanes that hit the same counter are counted with one ballot and one
+// atomic.  Corners arrive in cell order, so neighbouring lanes almost always share a quad-tree node while the tree is small;
+// un-aggregated, 24 k same-address LDS atomics serialise (64 cycles per wave instruction).  key < 0: lane inactive.
+__device__ __forceinline__ void hist_add_aggregated(int* counters, int key)
+{
+    const int lane = threadIdx.x & 63;
+    unsigned long long active = __ballot(key >= 0);
+    while (active) {
+        const int leader = __ffsll((long long)active) - 1;
+        const int k0 = __shfl(key, leader);
+        const unsigned long long same = __ballot(key == k0);
+        if (lane == leader) atomicAdd(&counters[k0], __popcll(same));
+        active &= ~same;
+    }
+}
+
 __global__ __launch_bounds__(1024) void k_distribute(LevelTable lt, const uint32_t* __restrict__ cell_keys,
                                                      const int32_t* __restrict__ cell_count, int cells_per_image,
                                                      uint32_t* __restrict__ cand_key, uint32_t* __restrict__ cand_node,
                                                      int32_t* __restrict__ cand_count, int cand_per_image,
-                                                     uint2* __restrict__ node_box, int32_t* __restrict__ node_cnt, int node_cap,
                                                      uint32_t* __restrict__ sel_key, int32_t* __restrict__ sel_count,
                                                      int slots_per_image, int image0)
 {
@@ -233,45 +281,68 @@ __global__ __launch_bounds__(1024) void k_distribute(LevelTable lt, const uint32
     const int N = lt.quota[level];
     const int Q = lt.qcap[level];          // node count never exceeds max(N + 2, 4 * roots) < Q
     int sortcap = 1; while (sortcap < Q) sortcap <<= 1;
-    const int ncell0 = lt.cells_x[level] * lt.cells_y[level];
-    int* cnt4 = lds;                                   // max(4*Q, ncell): quadrant histograms / scratch
-    int* order = cnt4 + max(4 * Q, ncell0);            // sortcap: visit list, bitonic sort buffer
+    const int ncell = lt.cells_x[level] * lt.cells_y[level];
+    int* cnt4 = lds;                                   // max(4*Q, ncell + 1): quadrant histograms / cell offsets / winners
+    int* order = cnt4 + max(4 * Q, ncell + 1);         // sortcap: visit list, bitonic sort buffer
     int* nodepos = order + sortcap;                    // Q
     int* kpre = nodepos + Q;                           // Q + 1
     int* keptrank = kpre + Q + 1;                      // Q + 1
     int* misc = keptrank + Q + 1;                      // 64
     int* wave_tot = misc + 32;
+    uint2* nbox[2]; int* ncnt[2];
+    nbox[0] = reinterpret_cast<uint2*>(misc + 64); nbox[1] = nbox[0] + Q;
+    ncnt[0] = reinterpret_cast<int*>(nbox[1] + Q); ncnt[1] = ncnt[0] + Q;
 
-    const int ncell = lt.cells_x[level] * lt.cells_y[level];
     const uint32_t* ckeys = cell_keys + ((size_t)image * cells_per_image + lt.cell_start[level]) * kCellSlots;
     const int32_t* ccnt = cell_count + (size_t)image * cells_per_image + lt.cell_start[level];
     uint32_t* ckey = cand_key + (size_t)image * cand_per_image + lt.cand_start[level];
     uint32_t* cnode = cand_node + (size_t)image * cand_per_image + lt.cand_start[level];
-    uint2* nbox[2]; int32_t* ncnt[2];
-    {
-        const size_t base = ((size_t)image * lt.n_levels + level) * 2 * (size_t)node_cap;
-        nbox[0] = node_box + base; nbox[1] = node_box + base + node_cap;
-        ncnt[0] = node_cnt + base; ncnt[1] = node_cnt + base + node_cap;
-    }
     uint32_t* out_sel = sel_key + (size_t)image * slots_per_image + lt.slot_start[level];
 
-    // ---- compact the per-cell slots into one candidate list (cells row-major, corners row-major inside a cell)
+    // ---- candidate list = per-cell slots in cell order (cells row-major, corners row-major inside a cell)
     int n_cand;
-    {
-        int* coff = cnt4;
-        for (int i = tid; i < ncell; i += 1024) coff[i] = ccnt[i];
-        __syncthreads();
-        block_scan_array(coff, ncell, wave_tot, &n_cand);
-        // copy: one wave per cell
-        const int wave = tid >> 6, lane = tid & 63;
-        for (int c = wave; c < ncell; c += 16) {
-            const int n = ccnt[c], o = coff[c];
-            for (int k = lane; k < n; k += 64) ckey[o + k] = ckeys[(size_t)c * kCellSlots + k];
-        }
-        __syncthreads();
-    }
-    if (tid == 0) cand_count[image * lt.n_levels + level] = n_cand;
+    int* coff = cnt4;
+    for (int i = tid; i < ncell; i += 1024) coff[i] = ccnt[i];
+    __syncthreads();
+    block_scan_array(coff, ncell, wave_tot, &n_cand);
+    if (tid == 0) { coff[ncell] = n_cand; cand_count[image * lt.n_levels + level] = n_cand; }
+    __syncthreads();
     if (n_cand == 0) { if (tid == 0) sel_count[image * lt.n_levels + level] = 0; return; }
+
+    // Thread t owns the CONTIGUOUS candidates [t * cpt, t * cpt + cpt): corners arrive in cell order, so a thread's corners
+    // mostly share one quad-tree node and every histogram / maximum below is run-length aggregated inside the thread
+    // (2-3 LDS atomics per thread and sweep instead of one per corner).
+    uint32_t rk[DIST_CPT];     // key: score << 24 | y << 12 | x
+    uint32_t rn[DIST_CPT];     // node index (bits 30..31: quadrant scratch)
+    const int cpt = min(DIST_CPT, (n_cand + 1023) / 1024);
+    const int n_reg = min(n_cand, 1024 * cpt);
+    const int c_first = tid * cpt;
+    {
+        int cell = 0;
+        if (c_first < n_reg) {
+            int lo = 0, hi = ncell;                    // largest cell with coff[cell] <= c_first
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (coff[mid] <= c_first) lo = mid; else hi = mid; }
+            cell = lo;
+        }
+#pragma unroll
+        for (int s = 0; s < DIST_CPT; ++s) {
+            const int c = c_first + s;
+            uint32_t k = 0;
+            if (s < cpt && c < n_reg) {
+                while (coff[cell + 1] <= c) ++cell;    // coff[ncell] = n_cand > c
+                k = ckeys[(size_t)cell * kCellSlots + (c - coff[cell])];
+                ckey[c] = k;
+            }
+            rk[s] = k; rn[s] = 0;
+        }
+    }
+    for (int c = n_reg + tid; c < n_cand; c += 1024) {
+        int lo = 0, hi = ncell;
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (coff[mid] <= c) lo = mid; else hi = mid; }
+        ckey[c] = ckeys[(size_t)lo * kCellSlots + (c - coff[lo])];
+    }
+    __syncthreads();
+#define DIST_VALID(s) ((s) < cpt && c_first + (s) < n_reg)
 
     // ---- initialize_nodes
     const int nxg = lt.nxg[level], nyg = lt.nyg[level];
@@ -279,15 +350,25 @@ __global__ __launch_bounds__(1024) void k_distribute(LevelTable lt, const uint32
     const int nini = nxg * nyg;             // 4 * nini + 4 <= Q
     for (int i = tid; i < nini; i += 1024) cnt4[i] = 0;
     __syncthreads();
-    for (int c = tid; c < n_cand; c += 1024) {
-        const uint32_t k = ckey[c];
+    auto root_of = [&](uint32_t k) -> uint32_t {
         const float x = (float)(k & 0xFFF), y = (float)((k >> 12) & 0xFFF);
-        unsigned ix = (unsigned)((double)x / delta_x), iy = (unsigned)((double)y / delta_y);
+        const unsigned ix = (unsigned)((double)x / delta_x), iy = (unsigned)((double)y / delta_y);
         unsigned root = ix + iy * nxg;
         if (root >= (unsigned)nini) root = nini - 1;
-        cnode[c] = root;
-        atomicAdd(&cnt4[root], 1);
+        return root;
+    };
+    {
+        int run_key = -1, run_cnt = 0;
+#pragma unroll
+        for (int s = 0; s < DIST_CPT; ++s) {
+            int key = -1;
+            if (DIST_VALID(s)) { rn[s] = root_of(rk[s]); key = (int)rn[s]; }
+            if (key != run_key) { if (run_key >= 0) atomicAdd(&cnt4[run_key], run_cnt); run_key = key; run_cnt = 0; }
+            run_cnt += key >= 0;
+        }
+        if (run_key >= 0) atomicAdd(&cnt4[run_key], run_cnt);
     }
+    for (int c = n_reg + tid; c < n_cand; c += 1024) { const uint32_t r = root_of(ckey[c]); cnode[c] = r; atomicAdd(&cnt4[r], 1); }
     __syncthreads();
     // array position a <-> root (nini-1-a); drop empty roots
     for (int a = tid; a < nini; a += 1024) keptrank[a] = cnt4[nini - 1 - a] > 0 ? 1 : 0;
@@ -306,162 +387,199 @@ __global__ __launch_bounds__(1024) void k_distribute(LevelTable lt, const uint32
         }
     }
     __syncthreads();
-    for (int c = tid; c < n_cand; c += 1024) cnode[c] = keptrank[nini - 1 - (int)cnode[c]];
+#pragma unroll
+    for (int s = 0; s < DIST_CPT; ++s) if (DIST_VALID(s)) rn[s] = (uint32_t)keptrank[nini - 1 - (int)rn[s]];
+    for (int c = n_reg + tid; c < n_cand; c += 1024) cnode[c] = (uint32_t)keptrank[nini - 1 - (int)cnode[c]];
     __syncthreads();
 
-    // ---- split passes
-    bool sorted_phase = false;
-    int pool_begin = 0;          // in sorted phase: the pool is the nodes [pool_begin, alive) with count > 1
+    // ---- split passes.  Node bookkeeping (a few hundred entries) is done by wavefront 0 alone with wave-level scans, so a
+    //      pass costs four workgroup barriers; the candidate sweeps (histogram, remap) use all 16 wavefronts.
+    const int lane = tid & 63, wave = tid >> 6;
+    auto wsync = [&]() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); };
+    auto wave_scan = [&](int* arr, int n) -> int {      // exclusive scan in place by one wavefront; returns the total
+        const int per = (n + 63) >> 6;
+        const int b0 = lane * per, e0 = min(b0 + per, n);
+        int sum = 0;
+        for (int i = b0; i < e0; ++i) sum += arr[i];
+        int incl = sum;
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+        int run = incl - sum;
+        for (int i = b0; i < e0; ++i) { const int v = arr[i]; arr[i] = run; run += v; }
+        const int total = __shfl(incl, 63);
+        wsync();
+        return total;
+    };
+    // misc: [0] m (visit-list length)  [1] jcut  [2] n_kept  [3] n_children  [4] pool_n
+    if (tid == 0) { misc[5] = alive; misc[6] = 0 /* sorted_phase */; misc[7] = 0 /* pool_begin */; misc[8] = cur; }
+    __syncthreads();
     for (int pass = 0; pass < 64; ++pass) {
-        const int prev_alive = alive;
-        // 1. visit list
-        int m = 0;               // visit-list length
-        if (!sorted_phase) {
-            // all nodes with count > 1, newest first
-            for (int i = tid; i < alive; i += 1024) keptrank[i] = ncnt[cur][i] > 1 ? 1 : 0;
-            __syncthreads();
-            block_scan_array(keptrank, alive, wave_tot, &m);
-            for (int i = tid; i < alive; i += 1024) {
-                if (ncnt[cur][i] > 1) { const int pos = m - 1 - keptrank[i]; order[pos] = i; nodepos[i] = pos; }
-                else nodepos[i] = -1;
-            }
-            __syncthreads();
-        } else {
-            // pool sorted by (count, index) descending -> bitonic sort of keys (count << 11 | index); index < 2048, count < 2^21
-            for (int i = tid; i < alive; i += 1024) { nodepos[i] = -1; keptrank[i] = (i >= pool_begin && ncnt[cur][i] > 1) ? 1 : 0; }
-            __syncthreads();
-            block_scan_array(keptrank, alive, wave_tot, &m);
-            int cap2 = 1; while (cap2 < m) cap2 <<= 1;
-            for (int i = tid; i < cap2; i += 1024) order[i] = 0;     // padding sorts last (descending)
-            __syncthreads();
-            for (int i = tid; i < alive; i += 1024)
-                if (i >= pool_begin && ncnt[cur][i] > 1) order[keptrank[i]] = (ncnt[cur][i] << 11) | i;
-            __syncthreads();
-            for (int k = 2; k <= cap2; k <<= 1) {
-                for (int j = k >> 1; j > 0; j >>= 1) {
-                    for (int i = tid; i < cap2; i += 1024) {
-                        const int p = i ^ j;
-                        if (p > i) {
-                            const unsigned a = (unsigned)order[i], b = (unsigned)order[p];
-                            const bool desc = (i & k) == 0;
-                            if (desc ? (a < b) : (a > b)) { order[i] = (int)b; order[p] = (int)a; }
-                        }
-                    }
-                    __syncthreads();
+        alive = misc[5];
+        const bool sorted_phase = misc[6] != 0;
+        const int pool_begin = misc[7];
+        cur = misc[8];
+        // 1. visit list (wavefront 0)
+        if (wave == 0) {
+            int m;
+            if (!sorted_phase) {
+                // all nodes with count > 1, newest first
+                for (int i = lane; i < alive; i += 64) keptrank[i] = ncnt[cur][i] > 1 ? 1 : 0;
+                wsync();
+                m = wave_scan(keptrank, alive);
+                for (int i = lane; i < alive; i += 64) {
+                    if (ncnt[cur][i] > 1) { const int pos = m - 1 - keptrank[i]; order[pos] = i; nodepos[i] = pos; }
+                    else nodepos[i] = -1;
                 }
+            } else {
+                // pool = new children with more than one corner; keys (count << 11 | index) into kpre, ranked below by all threads
+                for (int i = lane; i < alive; i += 64) { nodepos[i] = -1; keptrank[i] = (i >= pool_begin && ncnt[cur][i] > 1) ? 1 : 0; }
+                wsync();
+                m = wave_scan(keptrank, alive);
+                for (int i = lane; i < alive; i += 64)
+                    if (i >= pool_begin && ncnt[cur][i] > 1) kpre[keptrank[i]] = (ncnt[cur][i] << 11) | i;
             }
-            for (int i = tid; i < m; i += 1024) { const int node = order[i] & 0x7FF; order[i] = node; nodepos[node] = i; }
-            __syncthreads();
+            for (int i = lane; i < 4 * m; i += 64) cnt4[i] = 0;
+            if (lane == 0) misc[0] = m;
         }
+        __syncthreads();
+        const int m = misc[0];
         if (m == 0) break;       // nothing dividable: node count cannot change any more
-
-        // 2. quadrant histograms of every visit-list node
-        for (int i = tid; i < 4 * m; i += 1024) cnt4[i] = 0;
-        __syncthreads();
-        for (int c = tid; c < n_cand; c += 1024) {
-            const int node = (int)(cnode[c] & 0x3FFFFFFFu);
-            const int pos = nodepos[node];
-            if (pos >= 0) {
-                const uint2 bb = nbox[cur][node];
-                const int bx = bb.x & 0xFFFF, by = bb.x >> 16, ex = bb.y & 0xFFFF, ey = bb.y >> 16;
-                const int hx = (ex - bx + 1) >> 1, hy = (ey - by + 1) >> 1;
-                const uint32_t k = ckey[c];
-                const int x = k & 0xFFF, y = (k >> 12) & 0xFFF;
-                const int q = (bx + hx <= x ? 1 : 0) + (by + hy <= y ? 2 : 0);
-                atomicAdd(&cnt4[4 * pos + q], 1);
-                cnode[c] = (uint32_t)node | ((uint32_t)q << 30);
-            }
-        }
-        __syncthreads();
-        // 3. children per visit position, prefix, cut (sorted phase)
-        for (int i = tid; i < m; i += 1024)
-            kpre[i] = (cnt4[4 * i] > 0) + (cnt4[4 * i + 1] > 0) + (cnt4[4 * i + 2] > 0) + (cnt4[4 * i + 3] > 0);
-        __syncthreads();
-        int ktotal;
-        block_scan_array(kpre, m, wave_tot, &ktotal);
-        if (tid == 0) kpre[m] = ktotal;
-        int jcut = m;
         if (sorted_phase) {
-            // smallest j >= 1 with alive + kpre[j] - j >= N (the node count after j splits; non-decreasing in j)
-            if (tid == 0) misc[0] = m;
+            // order by (count, index) descending = rank of every key among the m distinct keys (all threads, m^2 / 1024 compares
+            // each, LDS broadcast reads) instead of a sorting network with log^2 m barriers
+            for (int i = tid; i < m; i += 1024) {
+                const unsigned ki = (unsigned)kpre[i];
+                int rank = 0;
+                for (int j = 0; j < m; ++j) rank += (unsigned)kpre[j] > ki;
+                const int node = (int)(ki & 0x7FFu);
+                order[rank] = node; nodepos[node] = rank;
+            }
             __syncthreads();
-            for (int j = tid + 1; j <= m; j += 1024)
-                if (alive + kpre[j] - j >= N) atomicMin(&misc[0], j);
-            __syncthreads();
-            jcut = misc[0];
         }
-        __syncthreads();
-        // 4. kept ranks
-        for (int i = tid; i < alive; i += 1024) { const int p = nodepos[i]; keptrank[i] = (p >= 0 && p < jcut) ? 0 : 1; }
-        __syncthreads();
-        int n_kept;
-        block_scan_array(keptrank, alive, wave_tot, &n_kept);
-        const int n_children = kpre[jcut];
-        const int nxt = cur ^ 1;
-        // 5. new node arrays
-        for (int i = tid; i < alive; i += 1024) {
-            const int p = nodepos[i];
-            if (!(p >= 0 && p < jcut)) { nbox[nxt][keptrank[i]] = nbox[cur][i]; ncnt[nxt][keptrank[i]] = ncnt[cur][i]; }
-        }
-        for (int p = tid; p < jcut; p += 1024) {
-            const int node = order[p];
+
+        // 2. quadrant histograms of every visit-list node (all wavefronts)
+        auto quadrant = [&](uint32_t node, uint32_t k, int* key) -> uint32_t {
+            const int pos = nodepos[node];
+            *key = -1;
+            if (pos < 0) return node;
             const uint2 bb = nbox[cur][node];
             const int bx = bb.x & 0xFFFF, by = bb.x >> 16, ex = bb.y & 0xFFFF, ey = bb.y >> 16;
             const int hx = (ex - bx + 1) >> 1, hy = (ey - by + 1) >> 1;
-            int idx = n_kept + kpre[p];
-            const int cbx[4] = {bx, bx + hx, bx, bx + hx}, cby[4] = {by, by, by + hy, by + hy};
-            const int cex[4] = {bx + hx, ex, bx + hx, ex}, cey[4] = {by + hy, by + hy, ey, ey};
+            const int x = k & 0xFFF, y = (k >> 12) & 0xFFF;
+            const int q = (bx + hx <= x ? 1 : 0) + (by + hy <= y ? 2 : 0);
+            *key = 4 * pos + q;
+            return node | ((uint32_t)q << 30);
+        };
+        {
+            int run_key = -1, run_cnt = 0;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int n = cnt4[4 * p + q];
-                if (n > 0) {
-                    nbox[nxt][idx] = make_uint2((unsigned)cbx[q] | ((unsigned)cby[q] << 16), (unsigned)cex[q] | ((unsigned)cey[q] << 16));
-                    ncnt[nxt][idx] = n;
-                    ++idx;
+            for (int s2 = 0; s2 < DIST_CPT; ++s2) {
+                int key = -1;
+                if (DIST_VALID(s2)) rn[s2] = quadrant(rn[s2] & 0x3FFFFFFFu, rk[s2], &key);
+                if (key != run_key) { if (run_key >= 0) atomicAdd(&cnt4[run_key], run_cnt); run_key = key; run_cnt = 0; }
+                run_cnt += key >= 0;
+            }
+            if (run_key >= 0) atomicAdd(&cnt4[run_key], run_cnt);
+        }
+        for (int c = n_reg + tid; c < n_cand; c += 1024) { int key; cnode[c] = quadrant(cnode[c] & 0x3FFFFFFFu, ckey[c], &key); if (key >= 0) atomicAdd(&cnt4[key], 1); }
+        __syncthreads();
+
+        // 3.-5. children per visit position, cut, kept ranks, new node arrays, phase decision (wavefront 0)
+        const int nxt = cur ^ 1;
+        if (wave == 0) {
+            for (int i = lane; i < m; i += 64)
+                kpre[i] = (cnt4[4 * i] > 0) + (cnt4[4 * i + 1] > 0) + (cnt4[4 * i + 2] > 0) + (cnt4[4 * i + 3] > 0);
+            wsync();
+            const int ktotal = wave_scan(kpre, m);
+            if (lane == 0) kpre[m] = ktotal;
+            wsync();
+            int jcut = m;
+            if (sorted_phase) {
+                // smallest j >= 1 with alive + kpre[j] - j >= N (the node count after j splits; non-decreasing in j)
+                int best = m;
+                for (int j = lane + 1; j <= m; j += 64) if (alive + kpre[j] - j >= N) { best = j; break; }
+                for (int o = 32; o > 0; o >>= 1) best = min(best, __shfl_xor(best, o));
+                jcut = best;
+            }
+            for (int i = lane; i < alive; i += 64) { const int p = nodepos[i]; keptrank[i] = (p >= 0 && p < jcut) ? 0 : 1; }
+            wsync();
+            const int n_kept = wave_scan(keptrank, alive);
+            const int n_children = kpre[jcut];
+            for (int i = lane; i < alive; i += 64) {
+                const int p = nodepos[i];
+                if (!(p >= 0 && p < jcut)) { nbox[nxt][keptrank[i]] = nbox[cur][i]; ncnt[nxt][keptrank[i]] = ncnt[cur][i]; }
+            }
+            for (int p = lane; p < jcut; p += 64) {
+                const int node = order[p];
+                const uint2 bb = nbox[cur][node];
+                const int bx = bb.x & 0xFFFF, by = bb.x >> 16, ex = bb.y & 0xFFFF, ey = bb.y >> 16;
+                const int hx = (ex - bx + 1) >> 1, hy = (ey - by + 1) >> 1;
+                int idx = n_kept + kpre[p];
+                const int cbx[4] = {bx, bx + hx, bx, bx + hx}, cby[4] = {by, by, by + hy, by + hy};
+                const int cex[4] = {bx + hx, ex, bx + hx, ex}, cey[4] = {by + hy, by + hy, ey, ey};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int n = cnt4[4 * p + q];
+                    if (n > 0) {
+                        nbox[nxt][idx] = make_uint2((unsigned)cbx[q] | ((unsigned)cby[q] << 16), (unsigned)cex[q] | ((unsigned)cey[q] << 16));
+                        ncnt[nxt][idx] = n;
+                        ++idx;
+                    }
                 }
             }
+            wsync();
+            const int new_alive = n_kept + n_children;
+            int local = 0;       // pool for the phase decision: new children with more than one corner
+            for (int i = n_kept + lane; i < new_alive; i += 64) local += ncnt[nxt][i] > 1;
+            for (int o = 32; o > 0; o >>= 1) local += __shfl_xor(local, o);
+            if (lane == 0) {
+                misc[1] = jcut; misc[2] = n_kept; misc[3] = n_children; misc[4] = local;
+                const bool done = (N <= new_alive) || (new_alive == alive);
+                misc[9] = done ? 1 : 0;
+                misc[5] = new_alive; misc[7] = n_kept; misc[8] = nxt;
+                if (!sorted_phase && N < new_alive + 3 * local) misc[6] = 1;
+            }
         }
-        // 6. remap candidates
-        for (int c = tid; c < n_cand; c += 1024) {
-            const uint32_t v = cnode[c];
+        __syncthreads();
+        // 6. remap candidates (all wavefronts)
+        const int jcut = misc[1], n_kept = misc[2];
+        auto remap = [&](uint32_t v) -> uint32_t {
             const int node = (int)(v & 0x3FFFFFFFu), q = (int)(v >> 30);
             const int p = nodepos[node];
-            int nn;
             if (p >= 0 && p < jcut) {
                 int rank = 0;
                 for (int qq = 0; qq < q; ++qq) rank += cnt4[4 * p + qq] > 0;
-                nn = n_kept + kpre[p] + rank;
-            } else nn = keptrank[node];
-            cnode[c] = (uint32_t)nn;
-        }
+                return (uint32_t)(n_kept + kpre[p] + rank);
+            }
+            return (uint32_t)keptrank[node];
+        };
+#pragma unroll
+        for (int s2 = 0; s2 < DIST_CPT; ++s2) if (DIST_VALID(s2)) rn[s2] = remap(rn[s2]);
+        for (int c = n_reg + tid; c < n_cand; c += 1024) cnode[c] = remap(cnode[c]);
+        const bool done = misc[9] != 0;
         __syncthreads();
-        alive = n_kept + n_children;
-        cur = nxt;
-        pool_begin = n_kept;
-        // pool size for the phase decision: children with more than one corner
-        if (tid == 0) misc[1] = 0;
-        __syncthreads();
-        {
-            int local = 0;
-            for (int i = pool_begin + tid; i < alive; i += 1024) local += ncnt[cur][i] > 1;
-            if (local) atomicAdd(&misc[1], local);
-        }
-        __syncthreads();
-        const int pool_n = misc[1];
-        __syncthreads();
-        if (N <= alive || alive == prev_alive) break;
-        if (!sorted_phase && N < alive + 3 * pool_n) sorted_phase = true;
+        if (done) break;
     }
+    alive = misc[5];
+    cur = misc[8];
+    (void)cur;
 
     // ---- best response per node (first maximum in candidate order), nodes newest first
-    int* win = cnt4;      // alive <= 4*Q <= 16*Q
+    int* win = cnt4;      // alive <= Q
     for (int i = tid; i < alive; i += 1024) win[i] = 0;
     __syncthreads();
-    for (int c = tid; c < n_cand; c += 1024) {
-        const uint32_t k = ckey[c];
-        const unsigned key = ((k >> 24) << 24) | (0xFFFFFFu - (unsigned)c);
-        atomicMax(reinterpret_cast<unsigned*>(&win[cnode[c]]), key);
+    {
+        int run_node = -1; unsigned run_best = 0;
+#pragma unroll
+        for (int s = 0; s < DIST_CPT; ++s) {
+            int node = -1; unsigned key = 0;
+            if (DIST_VALID(s)) { node = (int)(rn[s] & 0x3FFFFFFFu); key = ((rk[s] >> 24) << 24) | (0xFFFFFFu - (unsigned)(c_first + s)); }
+            if (node != run_node) { if (run_node >= 0) atomicMax(reinterpret_cast<unsigned*>(&win[run_node]), run_best); run_node = node; run_best = 0; }
+            run_best = max(run_best, key);
+        }
+        if (run_node >= 0) atomicMax(reinterpret_cast<unsigned*>(&win[run_node]), run_best);
     }
+    for (int c = n_reg + tid; c < n_cand; c += 1024)
+        atomicMax(reinterpret_cast<unsigned*>(&win[cnode[c] & 0x3FFFFFFFu]), ((ckey[c] >> 24) << 24) | (0xFFFFFFu - (unsigned)c));
     __syncthreads();
     const int cap = lt.slot_start[level + 1] - lt.slot_start[level];     // >= max(N + 3, 4 * roots) >= alive
     for (int i = tid; i < alive && i < cap; i += 1024) {
@@ -474,8 +592,9 @@ __global__ __launch_bounds__(1024) void k_distribute(LevelTable lt, const uint32
 size_t lp_distribute_lds_bytes(int Q, int ncell)
 {
     int sortcap = 1; while (sortcap < Q) sortcap <<= 1;
-    const int c4 = 4 * Q > ncell ? 4 * Q : ncell;
-    return sizeof(int) * ((size_t)c4 + sortcap + Q + (Q + 1) + (Q + 1) + 64);
+    const int c4 = 4 * Q > ncell + 1 ? 4 * Q : ncell + 1;
+    // cnt4 | order | nodepos | kpre | keptrank | misc | node boxes (2 x Q x uint2) | node counts (2 x Q)
+    return sizeof(int) * ((size_t)c4 + sortcap + Q + (Q + 1) + (Q + 1) + 64 + 4 * (size_t)Q + 2 * (size_t)Q + 2);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -663,8 +782,8 @@ int lp_launch_distribute(lpslam_hip_ctx* c, int first, int n_images)
 {
     dim3 grid(c->lt.n_levels, n_images);
     hipLaunchKernelGGL(k_distribute, grid, dim3(1024), c->distribute_lds, c->stream, c->lt, c->d_cell_keys, c->d_cell_count,
-                       c->cells_per_image, c->d_cand_key, c->d_cand_node, c->d_cand_count, c->cand_per_image, c->d_node_box,
-                       c->d_node_cnt, c->node_cap, c->d_sel_key, c->d_sel_count, c->slots_per_image, first);
+                       c->cells_per_image, c->d_cand_key, c->d_cand_node, c->d_cand_count, c->cand_per_image, c->d_sel_key, c->d_sel_count,
+                       c->slots_per_image, first);
     LP_HIP(hipGetLastError());
     return LPSLAM_HIP_OK;
 }
