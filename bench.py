@@ -245,6 +245,15 @@ def main():
         dom_ms = stage_ms[STAGE_NAMES.index(dom)]
         launches = {"pyramid": LEVELS - 1, "fast": 1, "describe": 1}[dom]
         achieved = ab[dom] / (dom_ms * 1e-3) / 1e9
+        # HBM traffic of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
+        # runs of this command; profiles/r01b_pmc_hbm.json); only quoted for the launch shape it was measured on
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01b_pmc_hbm.json")))
+            if dom == "fast" and args.frames == FRAMES_PER_STEP:
+                traffic = pmc["k_fast_cells_traffic_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            pass
         out = {
             "metric": "frames/sec (ORB+match+local-BA), 1280x720 stereo",
             "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -257,7 +266,7 @@ def main():
             "ba_ms_per_iter": round(stage_ms[T_BA] / BA_ITERS, 4) if wl.ba is not None else None,
             "roofline": {"bound": "hbm", "kernel": dom, "launches_per_step": launches,
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "algorithmic_bytes_per_step": int(ab[dom]), "avg_ms_per_step": round(float(dom_ms), 4)},
             "stage_ms_per_step": {n: round(float(v), 4) for n, v in zip(STAGE_NAMES, stage_ms)},
             "pcie_inclusive_frames_per_s": round(pcie_fps, 2),
