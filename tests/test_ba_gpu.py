@@ -109,3 +109,40 @@ def test_baseline_config3_full_size(hiplib, oracle):
     ba.reset(); ba.optimize(True, 10)
     gp2, gx2 = ba.state()
     assert np.array_equal(gp, gp2) and np.array_equal(gx, gx2)
+
+
+def test_pose_optimizer_parity(hiplib, oracle, ctx):
+    """Motion-only optimisation (optimize::pose_optimizer): 4 rounds x 10 iterations on ONE pose with outlier re-classification."""
+    prob = synth.ba_problem(6, 250, 1500, 640, 480, seq_id=12)
+    kf = 4
+    sel = prob["obs_pose"] == kf
+    obs = oracle.ba_obs(prob)[sel].copy()
+    obs["pose"] = 0
+    bad = np.arange(0, len(obs), 9)
+    obs["v"][bad] += 25.0                                           # gross outliers that the rounds must reject
+    pts = prob["points_gt"] + np.random.default_rng(5).normal(0, 0.01, prob["points_gt"].shape)
+    start = prob["poses"][kf]
+    opose, oout, oin = oracle.pose_optimize(start, pts, obs, prob["cam"])
+    hobs = np.zeros(len(obs), hiplib.BA_OBS_DTYPE)
+    for f in hobs.dtype.names:
+        hobs[f] = obs[f]
+    ba = hiplib.BundleAdjuster(ctx, start[None, :], np.zeros(1, np.uint8), pts, hobs, prob["cam"])
+    gout, gin = ba.pose_optimize()
+    gpose, gpts = ba.state()
+    assert gin == oin and np.array_equal(gout, oout) and gout[bad].mean() > 0.9
+    assert rot_err(gpose[:, :4], opose[None, :4]).max() < ROT_TOL and np.abs(gpose[0, 4:] - opose[4:]).max() < TRANS_TOL
+    assert np.array_equal(gpts, pts)                                # landmarks are constants in this mode
+    assert np.abs(gpose[0, 4:] - prob["poses_gt"][kf, 4:]).max() < 0.05
+
+
+def test_global_ba_size_runs(hiplib, oracle):
+    """BASELINE configs[4] problem size on one GPU: 200 keyframes / 30 000 landmarks / ~240 k observations (dim 1194)."""
+    c = hiplib.Context(640, 480, 500, 1.2, 4, max_images=1)
+    prob = synth.ba_problem(200, 30000, 240000, 1920, 1080, seq_id=2, kf_stride=2)
+    assert abs(len(prob["obs_pose"]) - 240000) <= 0.05 * 240000
+    ba = hiplib.BundleAdjuster(c, prob["poses"], prob["fixed"], prob["points"], hiplib.ba_obs_array(prob), prob["cam"])
+    log = ba.optimize(True, 3)
+    op, ox, olog = oracle.ba_optimize(prob["poses"], prob["fixed"], prob["points"], oracle.ba_obs(prob), prob["cam"], True, 3)
+    assert len(log) == 3 and np.allclose(log["chi2_after"], olog["chi2_after"], rtol=CHI_RTOL) and np.array_equal(log["trials"], olog["trials"])
+    gp, gx = ba.state()
+    assert rot_err(gp[:, :4], op[:, :4]).max() < ROT_TOL and np.abs(gp[:, 4:] - op[:, 4:]).max() < TRANS_TOL
