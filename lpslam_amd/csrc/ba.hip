@@ -609,7 +609,11 @@ __device__ __forceinline__ double readlane_f64(double v, int lane)
 // quantity, the solve's effect on chi2 / poses is (tolerances in DESIGN.md).
 __global__ __launch_bounds__(256) void k_chol_step(BaView v, int nb, int kb)
 {
-    if (ba_idle(v.ctl)) return;
+    // The grid is launched 8x oversized and only every 8th workgroup works: workgroups go round-robin to the 8 XCDs, so all
+    // working ones share XCD 0's L2 and the panel written by one launch is an L2 hit for the next (measured: -1 us per launch).
+    if (blockIdx.x & 7) return;
+    const int bid = blockIdx.x >> 3;
+    const bool idle = ba_idle(v.ctl);     // tested after the loads below are in flight, before the first store
     __shared__ double Lj[NB][NB + 1];
     __shared__ double Li[NB][NB + 1];
     __shared__ double Dm[NB][NB + 1];
@@ -622,10 +626,10 @@ __global__ __launch_bounds__(256) void k_chol_step(BaView v, int nb, int kb)
     const int n_panel = n_sq + j + 1;     // + extra row blocks 0..j
     const int tid = threadIdx.x;
     const size_t ck = (size_t)(kb < 0 ? 0 : kb) * NB;
-    if ((int)blockIdx.x >= n_panel) {
+    if (bid >= n_panel) {
         // ---- trailing update with panel kb
         const int T = nb - (kb + 2);
-        int u = blockIdx.x - n_panel;
+        int u = bid - n_panel;
         const int n_sq_upd = T * (T + 1) / 2;
         double* dst; const double* srcI; size_t ri, rj; bool overwrite = false;
         if (u < n_sq_upd) {
@@ -644,6 +648,7 @@ __global__ __launch_bounds__(256) void k_chol_step(BaView v, int nb, int kb)
             Li[r][c] = srcI[(ri + r) * n + ck + c];
             Lj[r][c] = S[(rj + r) * n + ck + c];
         }
+        if (idle) return;
         __syncthreads();
         const int r = tid / 8, c0 = (tid % 8) * 4;
         double acc[4] = {0, 0, 0, 0};
@@ -660,8 +665,8 @@ __global__ __launch_bounds__(256) void k_chol_step(BaView v, int nb, int kb)
         return;
     }
     // ---- panel column j
-    const bool extra = (int)blockIdx.x >= n_sq;
-    const int i = extra ? (int)blockIdx.x - n_sq : j + (int)blockIdx.x;      // extra: block row e of Minv
+    const bool extra = bid >= n_sq;
+    const int i = extra ? bid - n_sq : j + bid;      // extra: block row e of Minv
     const size_t rj = (size_t)j * NB, ri = (size_t)i * NB;
     const bool has_b = extra || i > j;
     const double* Bsrc = extra ? M : S;
@@ -674,6 +679,7 @@ __global__ __launch_bounds__(256) void k_chol_step(BaView v, int nb, int kb)
         Bm[r][c] = (!has_b || b_zero) ? 0.0 : (b_identity ? (r == c ? 1.0 : 0.0) : Bsrc[(ri + r) * n + rj + c]);
         if (kb >= 0) { Lj[r][c] = S[(rj + r) * n + ck + c]; Li[r][c] = (!has_b || li_zero) ? 0.0 : Bsrc[(ri + r) * n + ck + c]; }
     }
+    if (idle) return;
     __syncthreads();
     if (kb >= 0) {
         const int r = tid / 8, c0 = (tid % 8) * 4;
@@ -693,19 +699,24 @@ __global__ __launch_bounds__(256) void k_chol_step(BaView v, int nb, int kb)
 #pragma unroll
     for (int c = 0; c < NB; ++c) a[c] = lane < NB ? Dm[lane][c] : Bm[lane - NB][c];
     bool fail = false;
+    // 1/sqrt(pivot) by v_rsq_f64 + two Newton steps (full double precision): the column scaling is a multiply.  The pivot of
+    // column jj+1 is finished right after that column's own update, so its latency chain overlaps the remaining rank-1 updates.
+    auto pivot_rsqrt = [&](double d) { double rs = __builtin_amdgcn_rsq(d); rs = rs * fma(-0.5 * d * rs, rs, 1.5); return rs * fma(-0.5 * d * rs, rs, 1.5); };
+    double dcur = readlane_f64(a[0], 0);
+    if (!(dcur > 0.0)) { fail = true; dcur = 1.0; }
+    double rs = pivot_rsqrt(dcur);
 #pragma unroll
     for (int jj = 0; jj < NB; ++jj) {
-        double djj = readlane_f64(a[jj], jj);
-        if (!(djj > 0.0)) { fail = true; djj = 1.0; }
-        double rs = __builtin_amdgcn_rsq(djj);
-        rs = rs * fma(-0.5 * djj * rs, rs, 1.5);
-        rs = rs * fma(-0.5 * djj * rs, rs, 1.5);
         const double lcol = a[jj] * rs;
-        a[jj] = lane == jj ? djj * rs : lcol;
+        a[jj] = lane == jj ? dcur * rs : lcol;
+        if (jj + 1 < NB) {
+            a[jj + 1] = fma(-lcol, readlane_f64(lcol, jj + 1), a[jj + 1]);
+            double dn = readlane_f64(a[jj + 1], jj + 1);
+            if (!(dn > 0.0)) { fail = true; dn = 1.0; }
+            const double rn = pivot_rsqrt(dn);
 #pragma unroll
-        for (int c = jj + 1; c < NB; ++c) {
-            const double lc = readlane_f64(lcol, c);
-            a[c] = fma(-lcol, lc, a[c]);
+            for (int c = jj + 2; c < NB; ++c) a[c] = fma(-lcol, readlane_f64(lcol, c), a[c]);
+            dcur = dn; rs = rn;
         }
     }
     if (lane < NB) {
@@ -726,9 +737,10 @@ __global__ __launch_bounds__(256) void k_chol_step(BaView v, int nb, int kb)
 // x_p = L^-T y with y = L[dim][0..dim): one wavefront per row of the (upper triangular) L^-T, butterfly sum
 __global__ __launch_bounds__(256) void k_chol_xsolve(BaView v)
 {
+    if (blockIdx.x & 7) return;           // XCD 0 only, like k_chol_step: its inputs sit in that L2
     if (ba_idle(v.ctl)) return;
     const int lane = threadIdx.x & 63;
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int i = (blockIdx.x >> 3) * 4 + (threadIdx.x >> 6);
     if (i >= v.dim) return;
     const int n = v.dim_pad;
     // y = L^-1 rhs is row `dim` of L: off-diagonal blocks live in S, the part inside the row's own diagonal block in Ldiag
@@ -929,9 +941,9 @@ int enqueue_solve(lpslam_hip_ba* b, int fused)
             const int j = kb + 1, T = nb - (kb + 2);
             const int n_panel = (nb - j) + (j + 1);
             const int n_update = kb >= 0 ? T * (T + 1) / 2 + (kb + 1) * T : 0;
-            hipLaunchKernelGGL(k_chol_step, dim3(n_panel + n_update), dim3(256), 0, s, v, nb, kb);
+            hipLaunchKernelGGL(k_chol_step, dim3((n_panel + n_update) * 8), dim3(256), 0, s, v, nb, kb);
         }
-        hipLaunchKernelGGL(k_chol_xsolve, dim3((b->dim + 3) / 4), dim3(256), 0, s, v);
+        hipLaunchKernelGGL(k_chol_xsolve, dim3((b->dim + 3) / 4 * 8), dim3(256), 0, s, v);
     } else if (!fused) {
         hipLaunchKernelGGL(k_lm_begin, dim3(1), dim3(64), 0, s, v);
     }
