@@ -32,6 +32,8 @@ constexpr int SPLIT = 8;              // wavefronts per keyframe in the pose pas
 constexpr int PV = 28;                // partial values per wavefront: 21 (H_pp upper) + 6 (b_p) + 1 (chi2)
 constexpr int MAX_LOG = 64;
 
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
 struct BaCam { double fx, fy, cx, cy, fxb, hub_mono, hub_stereo; };
 
 struct BaCtl {                        // device-resident LM state (g2o OptimizationAlgorithmLevenberg)
@@ -650,16 +652,14 @@ __global__ __launch_bounds__(256) void k_chol_step(BaView v, int nb, int kb)
         }
         if (idle) return;
         __syncthreads();
-        const int r = tid / 8, c0 = (tid % 8) * 4;
-        double acc[4] = {0, 0, 0, 0};
-        for (int m = 0; m < NB; ++m) {
-            const double a = Li[r][m];
+        // 32x32x32 product L_i L_j^T on the f64 matrix cores: one 16x16 tile per wavefront, 8 k-steps of v_mfma_f64_16x16x4
+        const int tr = (tid >> 7) * 16, tc = ((tid >> 6) & 1) * 16, lr = tid & 15, lk = (tid & 63) >> 4;
+        f64x4 acc = {0, 0, 0, 0};
 #pragma unroll
-            for (int q = 0; q < 4; ++q) acc[q] = fma(a, Lj[c0 + q][m], acc[q]);
-        }
+        for (int s4 = 0; s4 < NB; s4 += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Li[tr + lr][s4 + lk], Lj[tc + lr][s4 + lk], acc, 0, 0, 0);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            double* d = &dst[(ri + r) * n + rj + c0 + q];
+        for (int q = 0; q < 4; ++q) {             // result element q of a lane: row (lane >> 4) + 4 q, column lane & 15
+            double* d = &dst[(ri + tr + lk + 4 * q) * n + rj + tc + lr];
             *d = overwrite ? -acc[q] : *d - acc[q];
         }
         return;
@@ -682,15 +682,17 @@ __global__ __launch_bounds__(256) void k_chol_step(BaView v, int nb, int kb)
     if (idle) return;
     __syncthreads();
     if (kb >= 0) {
-        const int r = tid / 8, c0 = (tid % 8) * 4;
-        double accd[4] = {0, 0, 0, 0}, accb[4] = {0, 0, 0, 0};
-        for (int m = 0; m < NB; ++m) {
-            const double a = Lj[r][m], b = Li[r][m];
+        // lookahead update of this launch's own blocks with panel kb: D -= L_j L_j^T, B -= L_i L_j^T (matrix cores, as above)
+        const int tr = (tid >> 7) * 16, tc = ((tid >> 6) & 1) * 16, lr = tid & 15, lk = (tid & 63) >> 4;
+        f64x4 accd = {0, 0, 0, 0}, accb = {0, 0, 0, 0};
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { const double l = Lj[c0 + q][m]; accd[q] = fma(a, l, accd[q]); accb[q] = fma(b, l, accb[q]); }
+        for (int s4 = 0; s4 < NB; s4 += 4) {
+            const double bj = Lj[tc + lr][s4 + lk];
+            accd = __builtin_amdgcn_mfma_f64_16x16x4f64(Lj[tr + lr][s4 + lk], bj, accd, 0, 0, 0);
+            if (has_b) accb = __builtin_amdgcn_mfma_f64_16x16x4f64(Li[tr + lr][s4 + lk], bj, accb, 0, 0, 0);
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { Dm[r][c0 + q] -= accd[q]; Bm[r][c0 + q] -= accb[q]; }
+        for (int q = 0; q < 4; ++q) { Dm[tr + lk + 4 * q][tc + lr] -= accd[q]; Bm[tr + lk + 4 * q][tc + lr] -= accb[q]; }
         __syncthreads();
     }
     if (tid >= 64) return;
