@@ -7,12 +7,13 @@
 // The whole LM loop is device driven: lambda, nu, the accepted-state index and the accept / reject decision live in a
 // small control block in HBM, every kernel reads it, and the host only enqueues "trial units" and looks at the control
 // block once per optimize() call.  A unit = [linearise if the state changed] + one LM trial:
-//   linearise   k_ba_obs_lin (thread / observation: W = B^T w A, shares of H_ll, b_l), k_ba_pose_part (8 wavefronts /
-//               keyframe: H_pp, b_p, chi2), k_ba_point_sum, k_ba_pose_combine (fixed-order sums, lambda_0)
-//   trial       k_ba_point_inv, k_ba_obs_y (Y = W H_ll^-1), k_ba_schur (wavefront / pose-block pair over a pair list),
-//               k_chol_step x nb (32-wide panels; the rhs is carried as an extra row and L^-T as extra row blocks, so
-//               no triangular substitution is needed), k_chol_xsolve (x_p = L^-T y), k_ba_backsub (landmarks, trial
-//               poses), k_ba_pose_part / k_ba_pose_combine (trial chi2, g2o lambda control)
+//   linearise   k_ba_lin (observation side: thread / observation, W = B^T w A and shares of H_ll, b_l; pose side: 8
+//               wavefronts / keyframe, H_pp, b_p, chi2; both in one launch), k_ba_point_sum (H_ll, b_l; its last workgroup
+//               combines the pose partials in fixed order and computes lambda_0)
+//   trial       k_ba_obs_y (Y = W (H_ll + lambda)^-1), k_ba_schur (wavefront / pose-block pair over a pair list),
+//               k_chol_step x nb (32-wide panels, block products on the f64 matrix cores; the rhs is carried as an extra
+//               row and L^-T as extra row blocks, so no triangular substitution is needed), k_chol_xsolve (x_p = L^-T y),
+//               k_ba_backsub (landmarks, trial poses), k_ba_trial (trial chi2; its last workgroup runs g2o's lambda control)
 // All sums are fixed-order segmented reductions (no float atomics): results are reproducible run to run.
 // The reduced system [S | rhs | b_p | diag H_pp | chi2] is one contiguous buffer, so a landmark-partitioned multi-GPU
 // solve needs one sum all-reduce of it per trial (lpslam_hip_ba_step_*).
@@ -45,6 +46,7 @@ struct BaCtl {                        // device-resident LM state (g2o Optimizat
     int outer_done, max_outer;
     int stopped;                      // g2o "Terminate"
     int last_accepted;
+    int ticket;                       // workgroups of the running pass that have published their partials (last one combines)
 };
 
 struct BaView {                       // device pointers handed to kernels by value
@@ -56,7 +58,7 @@ struct BaView {                       // device pointers handed to kernels by va
     const double* o_u; const double* o_v; const double* o_ur; const double* o_w;
     const uint8_t* o_active;
     const int* pt_start; const int* pt_obs; const int* ps_start; const int* ps_obs;
-    double* W; double* Y; double* Ybl; double* Hll; double* bl; double* Hinv; double* Hpp; double* hl_obs; double* partial;
+    double* W; double* Y; double* Ybl; double* Hll; double* bl; double* Hpp; double* hl_obs; double* partial;
     double* S; double* rhs; double* bp; double* hppdiag; double* chi_cur;   // reduced buffer sections (all-reduced when partitioned)
     double* bp_loc; double* hppdiag_loc; double* chi_loc;                    // this rank's own sums (equal to the above on one GPU)
     double* Minv;                                                            // L^-T row blocks (dim_pad x dim_pad)
@@ -144,6 +146,40 @@ __device__ __forceinline__ double ba_weight(const BaView& v, int k, int D, const
 }
 
 
+// "Last workgroup done" hand-over: every workgroup of a pass calls this after its partials are stored.  Returns true in
+// exactly one workgroup -- the one that arrives last -- with all other workgroups' stores visible; that workgroup then runs the
+// single-workgroup combine, which saves a launch.  No spinning, so the grid always drains.
+__device__ __forceinline__ bool ba_last_block(BaCtl* c, int total)
+{
+    __shared__ int s_last;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int t = __hip_atomic_fetch_add(&c->ticket, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (t == total - 1);
+        if (s_last) c->ticket = 0;
+    }
+    __syncthreads();
+    const bool last = s_last != 0;
+    if (last) __threadfence();
+    return last;
+}
+
+// (H_ll + lambda I)^-1 of one landmark, symmetric 3x3 stored as 6 (zero when singular)
+__device__ __forceinline__ void point_hinv(const double* hl, double lambda, double* ho)
+{
+    const double a = hl[0] + lambda, b = hl[1], c = hl[2], d = hl[3] + lambda, e = hl[4], f = hl[5] + lambda;
+    const double c00 = d * f - e * e, c01 = c * e - b * f, c02 = b * e - c * d;
+    const double det = a * c00 + b * c01 + c * c02;
+    if (fabs(det) > 0) {
+        const double id = 1.0 / det;
+        ho[0] = c00 * id; ho[1] = c01 * id; ho[2] = c02 * id;
+        ho[3] = (a * f - c * c) * id; ho[4] = (b * c - a * e) * id; ho[5] = (a * d - b * b) * id;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) ho[i] = 0;
+    }
+}
+
 __device__ __forceinline__ double wave_sum(double x)
 {
     for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
@@ -155,12 +191,11 @@ __device__ __forceinline__ double wave_max(double x)
     return x;
 }
 
-// ---- linearisation 1/4: one thread per observation: W = B^T w A and the observation's share of H_ll, b_l --------------
-__global__ __launch_bounds__(256) void k_ba_obs_lin(BaView v, int robust, int points_fixed)
+// ---- linearisation, observation side: one thread per observation: W = B^T w A and the observation's share of H_ll, b_l --
+__device__ __forceinline__ void obs_lin_body(BaView& v, int bid, int robust, int points_fixed)
 {
-    if (ba_idle(v.ctl) || !v.ctl->need_lin) return;
     ba_select(v, 0);
-    const int k = blockIdx.x * 256 + threadIdx.x;
+    const int k = bid * 256 + threadIdx.x;
     if (k >= v.n_obs) return;
     double* Wk = v.W + 18 * (size_t)k;
     double* ho = v.hl_obs + 9 * (size_t)k;
@@ -208,8 +243,10 @@ __global__ __launch_bounds__(256) void k_ba_obs_lin(BaView v, int robust, int po
         }
 }
 
-// ---- linearisation 2/4: H_ll, b_l per landmark = fixed-order sum over its observations; block maxima of diag H_ll ------
-__global__ __launch_bounds__(256) void k_ba_point_sum(BaView v)
+// ---- linearisation 2/2: H_ll, b_l per landmark = fixed-order sum over its observations; block maxima of diag H_ll.  The
+//      workgroup that finishes last combines the pose partials of k_ba_lin (pose_combine_body, defined below).
+__device__ void pose_combine_body(BaView& v, int mode, int part_n, int fused);
+__global__ __launch_bounds__(256) void k_ba_point_sum(BaView v, int part_n, int fused)
 {
     if (ba_idle(v.ctl) || !v.ctl->need_lin) return;
     __shared__ double sm[4];
@@ -231,16 +268,17 @@ __global__ __launch_bounds__(256) void k_ba_point_sum(BaView v)
     m = wave_max(m);
     if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
     __syncthreads();
-    if (threadIdx.x == 0) v.part[blockIdx.x] = fmax(fmax(sm[0], sm[1]), fmax(sm[2], sm[3]));
+    if (threadIdx.x == 0 && (int)blockIdx.x < part_n) v.part[blockIdx.x] = fmax(fmax(sm[0], sm[1]), fmax(sm[2], sm[3]));
+    if (ba_last_block(v.ctl, gridDim.x)) pose_combine_body(v, 0, part_n, fused);
 }
 
-// ---- linearisation 3/4 (mode 0) and trial chi2 (mode 1): SPLIT wavefronts per keyframe over slices of its observations --
-__global__ __launch_bounds__(256) void k_ba_pose_part(BaView v, int robust, int mode)
+// ---- linearisation, pose side (mode 0) and trial chi2 (mode 1): SPLIT wavefronts per keyframe over slices of its
+//      observations
+__device__ __forceinline__ void pose_part_body(BaView& v, int bid, int robust, int mode)
 {
-    if (ba_idle(v.ctl) || (mode == 0 && !v.ctl->need_lin)) return;
     ba_select(v, mode);
     const int lane = threadIdx.x & 63;
-    const int wv = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int wv = bid * 4 + (threadIdx.x >> 6);
     const int p = wv / SPLIT, sp = wv - p * SPLIT;
     if (p >= v.n_poses) return;
     double R[9];
@@ -355,15 +393,15 @@ __device__ void lm_decide(BaView& v)
     }
 }
 
-// ---- linearisation 4/4 (mode 0) and trial chi2 (mode 1): single workgroup combines the SPLIT partials in order, totals
+// ---- after the linearisation (mode 0) and the trial chi2 (mode 1): one workgroup (the last one of the pass that produced
+//      the partials, see ba_last_block) combines the SPLIT partials in order, totals
 //      chi2, reduces the landmark-side block partials in v.part (max diag H_ll / scale terms) and, in the single-GPU
 //      ("fused") solve, runs the lambda control.  The partitioned solve runs k_lm_begin / k_lm_decide after its all-reduce.
-__global__ __launch_bounds__(1024) void k_ba_pose_combine(BaView v, int mode, int part_n, int fused)
+__device__ void pose_combine_body(BaView& v, int mode, int part_n, int fused)
 {
-    if (ba_idle(v.ctl) || (mode == 0 && !v.ctl->need_lin)) return;
     __shared__ double s_maxpp;
     const int tid = threadIdx.x;
-    for (int i = tid; i < v.n_poses * PV; i += 1024) {
+    for (int i = tid; i < v.n_poses * PV; i += 256) {
         const int p = i / PV, q = i - p * PV;
         const int slot = v.pose_slot[p];
         if (q != 27 && (mode == 1 || slot < 0)) continue;
@@ -403,6 +441,23 @@ __global__ __launch_bounds__(1024) void k_ba_pose_combine(BaView v, int mode, in
     if (tid == 0 && fused) { if (mode == 0) lm_begin(v, s_maxpp); else lm_decide(v); }
 }
 
+// ---- linearisation 1/2: the observation side (blocks [0, obs_blocks)) and the pose side (the rest) of the accepted state in one
+//      launch: both only read the state, so they run side by side
+__global__ __launch_bounds__(256) void k_ba_lin(BaView v, int robust, int points_fixed, int obs_blocks)
+{
+    if (ba_idle(v.ctl) || !v.ctl->need_lin) return;
+    if ((int)blockIdx.x < obs_blocks) obs_lin_body(v, blockIdx.x, robust, points_fixed);
+    else pose_part_body(v, (int)blockIdx.x - obs_blocks, robust, 0);
+}
+
+// ---- chi2 of the trial state per keyframe; the last workgroup totals it and (fused) runs the lambda control
+__global__ __launch_bounds__(256) void k_ba_trial(BaView v, int robust, int part_n, int fused)
+{
+    if (ba_idle(v.ctl)) return;
+    pose_part_body(v, blockIdx.x, robust, 1);
+    if (ba_last_block(v.ctl, gridDim.x)) pose_combine_body(v, 1, part_n, fused);
+}
+
 // partitioned solve: lambda control on the all-reduced quantities
 __global__ __launch_bounds__(64) void k_lm_begin(BaView v)
 {
@@ -418,36 +473,15 @@ __global__ void k_lm_decide(BaView v)
     if (threadIdx.x == 0 && blockIdx.x == 0) lm_decide(v);
 }
 
-// ---- per trial: (H_ll + lambda I)^-1 ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_ba_point_inv(BaView v)
-{
-    if (ba_idle(v.ctl)) return;
-    const double lambda = v.ctl->lambda;
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= v.n_points) return;
-    const double* hl = v.Hll + 6 * (size_t)j;
-    const double a = hl[0] + lambda, b = hl[1], c = hl[2], d = hl[3] + lambda, e = hl[4], f = hl[5] + lambda;
-    const double c00 = d * f - e * e, c01 = c * e - b * f, c02 = b * e - c * d;
-    const double det = a * c00 + b * c01 + c * c02;
-    double* ho = v.Hinv + 6 * (size_t)j;
-    if (fabs(det) > 0) {
-        const double id = 1.0 / det;
-        ho[0] = c00 * id; ho[1] = c01 * id; ho[2] = c02 * id;
-        ho[3] = (a * f - c * c) * id; ho[4] = (b * c - a * e) * id; ho[5] = (a * d - b * b) * id;
-    } else {
-#pragma unroll
-        for (int i = 0; i < 6; ++i) ho[i] = 0;
-    }
-}
-
-// ---- per trial: Y = W H_ll^-1 and Y b_l per observation -------------------------------------------------------------------
+// ---- per trial: Y = W (H_ll + lambda I)^-1 and Y b_l per observation -------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_ba_obs_y(BaView v)
 {
     if (ba_idle(v.ctl)) return;
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= v.n_obs) return;
     const int j = v.o_point[k];
-    const double* h = v.Hinv + 6 * (size_t)j;
+    double h[6];
+    point_hinv(v.Hll + 6 * (size_t)j, v.ctl->lambda, h);       // recomputed per observation: cheaper than a launch of its own
     const double H0 = h[0], H1 = h[1], H2 = h[2], H4 = h[3], H5 = h[4], H8 = h[5];
     const double b0 = v.bl[3 * (size_t)j], b1 = v.bl[3 * (size_t)j + 1], b2 = v.bl[3 * (size_t)j + 2];
     const double* Wk = v.W + 18 * (size_t)k;
@@ -804,7 +838,8 @@ __global__ __launch_bounds__(256) void k_ba_backsub(BaView v, int point_blocks)
     if (g < v.n_points && sub == 0) {
         const double b0 = v.bl[3 * (size_t)g], b1 = v.bl[3 * (size_t)g + 1], b2 = v.bl[3 * (size_t)g + 2];
         const double q0 = b0 - r[0], q1 = b1 - r[1], q2 = b2 - r[2];
-        const double* h = v.Hinv + 6 * (size_t)g;
+        double h[6];
+        point_hinv(v.Hll + 6 * (size_t)g, lambda, h);
         const double x0 = h[0] * q0 + h[1] * q1 + h[2] * q2;
         const double x1 = h[1] * q0 + h[3] * q1 + h[4] * q2;
         const double x2 = h[2] * q0 + h[4] * q1 + h[5] * q2;
@@ -850,7 +885,7 @@ struct lpslam_hip_ba {
     double *d_o_u = nullptr, *d_o_v = nullptr, *d_o_ur = nullptr, *d_o_w = nullptr;
     uint8_t* d_o_active = nullptr;
     int *d_pt_start = nullptr, *d_pt_obs = nullptr, *d_ps_start = nullptr, *d_ps_obs = nullptr;
-    double *d_W = nullptr, *d_Y = nullptr, *d_Ybl = nullptr, *d_Hll = nullptr, *d_bl = nullptr, *d_Hinv = nullptr, *d_Hpp = nullptr;
+    double *d_W = nullptr, *d_Y = nullptr, *d_Ybl = nullptr, *d_Hll = nullptr, *d_bl = nullptr, *d_Hpp = nullptr;
     double *d_hl_obs = nullptr, *d_partial = nullptr, *d_minv = nullptr, *d_ldiag = nullptr;
     double* d_red = nullptr; int64_t red_n = 0;
     double *d_xp = nullptr, *d_chi_pose = nullptr, *d_part = nullptr, *d_scal = nullptr, *d_loc = nullptr;
@@ -890,7 +925,7 @@ BaView make_view(lpslam_hip_ba* b)
     v.pose_slot = b->d_pose_slot; v.free_pose = b->d_free_pose; v.o_pose = b->d_o_pose; v.o_point = b->d_o_point;
     v.o_u = b->d_o_u; v.o_v = b->d_o_v; v.o_ur = b->d_o_ur; v.o_w = b->d_o_w; v.o_active = b->d_o_active;
     v.pt_start = b->d_pt_start; v.pt_obs = b->d_pt_obs; v.ps_start = b->d_ps_start; v.ps_obs = b->d_ps_obs;
-    v.W = b->d_W; v.Y = b->d_Y; v.Ybl = b->d_Ybl; v.Hll = b->d_Hll; v.bl = b->d_bl; v.Hinv = b->d_Hinv; v.Hpp = b->d_Hpp;
+    v.W = b->d_W; v.Y = b->d_Y; v.Ybl = b->d_Ybl; v.Hll = b->d_Hll; v.bl = b->d_bl; v.Hpp = b->d_Hpp;
     v.hl_obs = b->d_hl_obs; v.partial = b->d_partial; v.Minv = b->d_minv; v.Ldiag = b->d_ldiag;
     const size_t n = (size_t)b->dim_pad;
     v.S = b->d_red; v.rhs = b->d_red + n * n; v.bp = v.rhs + n; v.hppdiag = v.bp + n; v.chi_cur = v.hppdiag + n;
@@ -907,11 +942,9 @@ int enqueue_linearize(lpslam_hip_ba* b, int fused)
 {
     BaView v = make_view(b);
     hipStream_t s = b->stream;
-    if (b->n_obs) hipLaunchKernelGGL(k_ba_obs_lin, dim3((b->n_obs + 255) / 256), dim3(256), 0, s, v, b->robust, b->points_fixed);
-    hipLaunchKernelGGL(k_ba_pose_part, dim3((b->n_poses * SPLIT + 3) / 4), dim3(256), 0, s, v, b->robust, 0);
-    const int pb = (b->n_points + 255) / 256;
-    if (b->n_points) hipLaunchKernelGGL(k_ba_point_sum, dim3(pb), dim3(256), 0, s, v);
-    hipLaunchKernelGGL(k_ba_pose_combine, dim3(1), dim3(1024), 0, s, v, 0, pb, fused);
+    const int ob = (b->n_obs + 255) / 256, pb = (b->n_points + 255) / 256;
+    hipLaunchKernelGGL(k_ba_lin, dim3(ob + (b->n_poses * SPLIT + 3) / 4), dim3(256), 0, s, v, b->robust, b->points_fixed, ob);
+    hipLaunchKernelGGL(k_ba_point_sum, dim3(pb > 0 ? pb : 1), dim3(256), 0, s, v, pb, fused);
     LP_HIP(hipGetLastError());
     return LPSLAM_HIP_OK;
 }
@@ -921,7 +954,6 @@ int enqueue_reduce(lpslam_hip_ba* b, int fused)
 {
     BaView v = make_view(b);
     hipStream_t s = b->stream;
-    if (b->n_points) hipLaunchKernelGGL(k_ba_point_inv, dim3((b->n_points + 255) / 256), dim3(256), 0, s, v);
     if (b->n_obs) hipLaunchKernelGGL(k_ba_obs_y, dim3((b->n_obs + 255) / 256), dim3(256), 0, s, v);
     if (b->n_free) hipLaunchKernelGGL(k_ba_schur, dim3(b->n_blocks + b->n_free), dim3(64), 0, s, v, b->n_blocks, fused);
     LP_HIP(hipGetLastError());
@@ -951,8 +983,7 @@ int enqueue_solve(lpslam_hip_ba* b, int fused)
     }
     const int pb = (b->n_points + 63) / 64;
     hipLaunchKernelGGL(k_ba_backsub, dim3(pb + 1), dim3(256), 0, s, v, pb);
-    hipLaunchKernelGGL(k_ba_pose_part, dim3((b->n_poses * SPLIT + 3) / 4), dim3(256), 0, s, v, b->robust, 1);
-    hipLaunchKernelGGL(k_ba_pose_combine, dim3(1), dim3(1024), 0, s, v, 1, pb, fused);
+    hipLaunchKernelGGL(k_ba_trial, dim3((b->n_poses * SPLIT + 3) / 4), dim3(256), 0, s, v, b->robust, pb, fused);
     LP_HIP(hipGetLastError());
     return LPSLAM_HIP_OK;
 }
@@ -975,7 +1006,7 @@ int begin_optimize(lpslam_hip_ba* b, int robust, int iters)
 {
     b->robust = robust;
     BaCtl c = b->h_ctl;
-    c.max_outer = iters; c.outer_done = 0; c.need_lin = 1; c.first = 1; c.qmax = 0; c.stopped = 0; c.ni = 2; c.rho = 0; c.last_accepted = 0;
+    c.max_outer = iters; c.outer_done = 0; c.need_lin = 1; c.first = 1; c.qmax = 0; c.stopped = 0; c.ni = 2; c.rho = 0; c.last_accepted = 0; c.ticket = 0;
     b->h_ctl = c;
     return write_ctl(b, c);
 }
@@ -1082,7 +1113,7 @@ int lpslam_hip_ba_create(lpslam_hip_ctx* ctx, const double* poses, const uint8_t
         BA_HIP(hipMemcpy(b->d_points[0], points, 3 * (size_t)n_points * sizeof(double), hipMemcpyHostToDevice));
     }
     BA_TRY(dalloc(b, &b->d_W, 18 * (size_t)n_obs)); BA_TRY(dalloc(b, &b->d_Y, 18 * (size_t)n_obs)); BA_TRY(dalloc(b, &b->d_Ybl, 6 * (size_t)n_obs));
-    BA_TRY(dalloc(b, &b->d_Hll, 6 * (size_t)n_points)); BA_TRY(dalloc(b, &b->d_bl, 3 * (size_t)n_points)); BA_TRY(dalloc(b, &b->d_Hinv, 6 * (size_t)n_points));
+    BA_TRY(dalloc(b, &b->d_Hll, 6 * (size_t)n_points)); BA_TRY(dalloc(b, &b->d_bl, 3 * (size_t)n_points));
     BA_TRY(dalloc(b, &b->d_Hpp, 36 * (size_t)b->n_free));
     BA_TRY(dalloc(b, &b->d_hl_obs, 9 * (size_t)n_obs)); BA_TRY(dalloc(b, &b->d_partial, (size_t)n_poses * SPLIT * PV));
     BA_HIP(hipMemset(b->d_partial, 0, (size_t)n_poses * SPLIT * PV * sizeof(double)));
