@@ -30,7 +30,7 @@ namespace {
 
 constexpr int NB = 32;                // Cholesky panel width
 constexpr int SPLIT = 8;              // wavefronts per keyframe in the pose pass
-constexpr int PV = 28;                // partial values per wavefront: 21 (H_pp upper) + 6 (b_p) + 1 (chi2)
+constexpr int PV = 28;                // partial-row stride per wavefront: 21 (H_pp upper) + 6 (b_p) (+1 pad; chi2 is kept apart)
 constexpr int MAX_LOG = 64;
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
@@ -319,10 +319,12 @@ __device__ __forceinline__ void pose_part_body(BaView& v, int bid, int robust, i
             b[a] += s3;
         }
     }
-    double* out = v.partial + ((size_t)p * SPLIT + sp) * PV;
+    // partials: chi2 per (keyframe, slice) in the tail of v.partial, H_pp / b_p per (free-pose slot, slice) in its head,
+    // so the combine addresses both without an index lookup
     chi = wave_sum(chi);
-    if (lane == 0) out[27] = chi;
+    if (lane == 0) v.partial[(size_t)v.n_poses * SPLIT * PV + (size_t)p * SPLIT + sp] = chi;
     if (!full) return;
+    double* out = v.partial + ((size_t)slot * SPLIT + sp) * PV;
 #pragma unroll
     for (int i = 0; i < 21; ++i) h[i] = wave_sum(h[i]);
 #pragma unroll
@@ -337,28 +339,27 @@ __device__ __forceinline__ void pose_part_body(BaView& v, int bid, int robust, i
 
 // ---- g2o's lambda control (one thread) ----------------------------------------------------------------------------------
 // start of an outer iteration / after a linearisation: lambda_0 = tau * max diag(H) on the first one, chi2 bookkeeping
-__device__ void lm_begin(BaView& v, double max_diag_pp)
+__device__ void lm_begin(BaView& v, double max_diag_pp, double max_diag_ll, double chi_cur)
 {
-    BaCtl* c = v.ctl;
-    if (c->first) {
-        double maxd = v.n_points ? v.scal[4] : 0.0;
-        maxd = fmax(maxd, max_diag_pp);
-        c->lambda = 1e-5 * maxd;
-        c->ni = 2;
-        c->first = 0;
+    BaCtl c = *v.ctl;                                      // one batch of loads, one batch of stores
+    if (c.first) {
+        const double maxd = fmax(v.n_points ? max_diag_ll : 0.0, max_diag_pp);
+        c.lambda = 1e-5 * maxd;
+        c.ni = 2;
+        c.first = 0;
     }
-    c->current_chi = *v.chi_cur;
-    if (c->qmax == 0) c->chi_before = *v.chi_cur;
-    c->need_lin = 0;
+    c.current_chi = chi_cur;
+    if (c.qmax == 0) c.chi_before = chi_cur;
+    c.need_lin = 0;
+    *v.ctl = c;
 }
 // after a trial: rho, accept / reject, lambda update, iteration and termination bookkeeping
-__device__ void lm_decide(BaView& v)
+__device__ void lm_decide(BaView& v, double temp_chi, double chol_failed, double scale_l, double scale_p)
 {
-    BaCtl* c = v.ctl;
-    double temp_chi = v.scal[1];
-    if (v.scal[5] != 0.0) temp_chi = DBL_MAX;              // factorisation failed
-    double rho = c->current_chi - temp_chi;
-    const double scale = (v.scal[2] + v.scal[3]) + 1e-3;
+    BaCtl c = *v.ctl;
+    if (chol_failed != 0.0) temp_chi = DBL_MAX;            // factorisation failed
+    double rho = c.current_chi - temp_chi;
+    const double scale = (scale_l + scale_p) + 1e-3;
     rho /= scale;
     const bool accepted = rho > 0 && isfinite(temp_chi);
     if (accepted) {
@@ -366,31 +367,32 @@ __device__ void lm_decide(BaView& v)
         double alpha = 1. - t * t * t;
         alpha = fmin(alpha, 2. / 3.);
         const double sf = fmax(1. / 3., alpha);
-        c->lambda *= sf;
-        c->ni = 2;
-        c->current_chi = temp_chi;
-        c->cur ^= 1;                                       // discardTop: the trial state becomes the accepted one
+        c.lambda *= sf;
+        c.ni = 2;
+        c.current_chi = temp_chi;
+        c.cur ^= 1;                                        // discardTop: the trial state becomes the accepted one
     } else {
-        c->lambda *= c->ni;
-        c->ni *= 2;                                        // pop: the accepted state stays
+        c.lambda *= c.ni;
+        c.ni *= 2;                                         // pop: the accepted state stays
     }
-    c->rho = rho;
-    c->last_accepted = accepted ? 1 : 0;
-    c->qmax++;
-    const bool finished = !(rho < 0 && c->qmax < 10);
+    c.rho = rho;
+    c.last_accepted = accepted ? 1 : 0;
+    c.qmax++;
+    const bool finished = !(rho < 0 && c.qmax < 10);
     if (finished) {
-        const int terminate = (c->qmax == 10 || rho == 0) ? 1 : 0;
-        if (c->outer_done < MAX_LOG) {
-            lpslam_hip_ba_iter_log* l = v.log + c->outer_done;
-            l->chi2_before = c->chi_before; l->chi2_after = c->current_chi; l->lambda = c->lambda; l->trials = c->qmax; l->status = terminate;
+        const int terminate = (c.qmax == 10 || rho == 0) ? 1 : 0;
+        if (c.outer_done < MAX_LOG) {
+            lpslam_hip_ba_iter_log* l = v.log + c.outer_done;
+            l->chi2_before = c.chi_before; l->chi2_after = c.current_chi; l->lambda = c.lambda; l->trials = c.qmax; l->status = terminate;
         }
-        c->outer_done++;
-        c->qmax = 0;
-        c->need_lin = 1;
-        if (terminate) c->stopped = 1;
+        c.outer_done++;
+        c.qmax = 0;
+        c.need_lin = 1;
+        if (terminate) c.stopped = 1;
     } else {
-        c->need_lin = 0;
+        c.need_lin = 0;
     }
+    *v.ctl = c;
 }
 
 // ---- after the linearisation (mode 0) and the trial chi2 (mode 1): one workgroup (the last one of the pass that produced
@@ -399,46 +401,79 @@ __device__ void lm_decide(BaView& v)
 //      ("fused") solve, runs the lambda control.  The partitioned solve runs k_lm_begin / k_lm_decide after its all-reduce.
 __device__ void pose_combine_body(BaView& v, int mode, int part_n, int fused)
 {
-    __shared__ double s_maxpp;
-    const int tid = threadIdx.x;
-    for (int i = tid; i < v.n_poses * PV; i += 256) {
-        const int p = i / PV, q = i - p * PV;
-        const int slot = v.pose_slot[p];
-        if (q != 27 && (mode == 1 || slot < 0)) continue;
-        double s = 0;
-        for (int sp = 0; sp < SPLIT; ++sp) s += v.partial[((size_t)p * SPLIT + sp) * PV + q];
-        if (q == 27) v.chi_pose[p] = s;
-        else if (q >= 21) { v.bp[6 * slot + (q - 21)] = s; v.bp_loc[6 * slot + (q - 21)] = s; }
-        else {
-            int a = 0, rem = q;                    // upper-triangle index q -> (a, c)
-            while (rem >= 6 - a) { rem -= 6 - a; ++a; }
-            const int c = a + rem;
-            double* H = v.Hpp + 36 * (size_t)slot;
-            H[a * 6 + c] = s; H[c * 6 + a] = s;
-            if (a == c) { v.hppdiag[6 * slot + a] = s; v.hppdiag_loc[6 * slot + a] = s; }
-        }
-    }
-    __syncthreads();
-    if (tid < 64) {
+    __shared__ double s_val[3];            // chi2, landmark-side term (max diag H_ll / scale term), max diag H_pp
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    if (wave == 0) {                       // chi2 = sum over keyframes (64-strided, then butterfly) of the in-order sum of its SPLIT partials
         double acc = 0;
-        for (int p = tid; p < v.n_poses; p += 64) acc += v.chi_pose[p];
+        for (int p = lane; p < v.n_poses; p += 64) {
+            double s = 0;
+            for (int sp = 0; sp < SPLIT; ++sp) s += v.partial[(size_t)v.n_poses * SPLIT * PV + (size_t)p * SPLIT + sp];
+            v.chi_pose[p] = s;
+            acc += s;
+        }
         acc = wave_sum(acc);
-        if (tid == 0) { if (mode == 0) { *v.chi_cur = acc; *v.chi_loc = acc; } else v.scal[1] = acc; }
-    } else if (tid < 128) {
-        const int lane = tid - 64;
+        if (lane == 0) s_val[0] = acc;
+    } else if (wave == 1) {
         double acc = 0;
         for (int i = lane; i < part_n; i += 64) acc = mode == 0 ? fmax(acc, v.part[i]) : acc + v.part[i];
         acc = mode == 0 ? wave_max(acc) : wave_sum(acc);
-        if (lane == 0) v.scal[mode == 0 ? 4 : 2] = acc;
-    } else if (tid < 192 && mode == 0) {
-        const int lane = tid - 128;
+        if (lane == 0) s_val[1] = acc;
+    } else if (wave == 2 && mode == 0) {   // max |diag H_pp| straight from the partials (same sums as the loop below)
         double m = 0;
-        for (int i = lane; i < v.dim; i += 64) m = fmax(m, fabs(v.hppdiag[i]));
+        for (int i = lane; i < v.dim; i += 64) {
+            const int slot = i / 6, a = i - 6 * slot;
+            const int q = 6 * a - a * (a - 1) / 2;          // (a, a) in the row-major upper triangle
+            double s = 0;
+            for (int sp = 0; sp < SPLIT; ++sp) s += v.partial[((size_t)slot * SPLIT + sp) * PV + q];
+            m = fmax(m, fabs(s));
+        }
         m = wave_max(m);
-        if (lane == 0) s_maxpp = m;
+        if (lane == 0) s_val[2] = m;
+    }
+    if (mode == 0) {
+        // H_pp (21) and b_p (6) per free pose: in-order sums of the SPLIT partials; three items per thread and pass so that
+        // their 24 loads are in flight together
+        const int items = v.n_free * 27;
+        for (int i0 = tid; i0 < items; i0 += 3 * 256) {
+            double sum[3];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int i = i0 + u * 256;
+                sum[u] = 0;
+                if (i < items) {
+                    const int slot = i / 27, q = i - slot * 27;
+                    for (int sp = 0; sp < SPLIT; ++sp) sum[u] += v.partial[((size_t)slot * SPLIT + sp) * PV + q];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int i = i0 + u * 256;
+                if (i >= items) continue;
+                const int slot = i / 27, q = i - slot * 27;
+                const double sv = sum[u];
+                if (q >= 21) { v.bp[6 * slot + (q - 21)] = sv; v.bp_loc[6 * slot + (q - 21)] = sv; }
+                else {
+                    int a = 0, rem = q;                    // upper-triangle index q -> (a, c)
+                    while (rem >= 6 - a) { rem -= 6 - a; ++a; }
+                    const int c = a + rem;
+                    double* H = v.Hpp + 36 * (size_t)slot;
+                    H[a * 6 + c] = sv; H[c * 6 + a] = sv;
+                    if (a == c) { v.hppdiag[6 * slot + a] = sv; v.hppdiag_loc[6 * slot + a] = sv; }
+                }
+            }
+        }
     }
     __syncthreads();
-    if (tid == 0 && fused) { if (mode == 0) lm_begin(v, s_maxpp); else lm_decide(v); }
+    if (tid == 0) {
+        if (mode == 0) {
+            *v.chi_cur = s_val[0]; *v.chi_loc = s_val[0]; v.scal[4] = s_val[1];
+            if (fused) lm_begin(v, s_val[2], s_val[1], s_val[0]);
+        } else {
+            const double fail = v.scal[5], scale_p = v.scal[3];
+            v.scal[1] = s_val[0]; v.scal[2] = s_val[1];
+            if (fused) lm_decide(v, s_val[0], fail, s_val[1], scale_p);
+        }
+    }
 }
 
 // ---- linearisation 1/2: the observation side (blocks [0, obs_blocks)) and the pose side (the rest) of the accepted state in one
@@ -465,12 +500,12 @@ __global__ __launch_bounds__(64) void k_lm_begin(BaView v)
     double m = 0;
     for (int i = threadIdx.x; i < v.dim; i += 64) m = fmax(m, fabs(v.hppdiag[i]));
     m = wave_max(m);
-    if (threadIdx.x == 0) lm_begin(v, m);
+    if (threadIdx.x == 0) lm_begin(v, m, v.scal[4], *v.chi_cur);
 }
 __global__ void k_lm_decide(BaView v)
 {
     if (ba_idle(v.ctl)) return;
-    if (threadIdx.x == 0 && blockIdx.x == 0) lm_decide(v);
+    if (threadIdx.x == 0 && blockIdx.x == 0) lm_decide(v, v.scal[1], v.scal[5], v.scal[2], v.scal[3]);
 }
 
 // ---- per trial: Y = W (H_ll + lambda I)^-1 and Y b_l per observation -------------------------------------------------------------------
@@ -1115,8 +1150,8 @@ int lpslam_hip_ba_create(lpslam_hip_ctx* ctx, const double* poses, const uint8_t
     BA_TRY(dalloc(b, &b->d_W, 18 * (size_t)n_obs)); BA_TRY(dalloc(b, &b->d_Y, 18 * (size_t)n_obs)); BA_TRY(dalloc(b, &b->d_Ybl, 6 * (size_t)n_obs));
     BA_TRY(dalloc(b, &b->d_Hll, 6 * (size_t)n_points)); BA_TRY(dalloc(b, &b->d_bl, 3 * (size_t)n_points));
     BA_TRY(dalloc(b, &b->d_Hpp, 36 * (size_t)b->n_free));
-    BA_TRY(dalloc(b, &b->d_hl_obs, 9 * (size_t)n_obs)); BA_TRY(dalloc(b, &b->d_partial, (size_t)n_poses * SPLIT * PV));
-    BA_HIP(hipMemset(b->d_partial, 0, (size_t)n_poses * SPLIT * PV * sizeof(double)));
+    BA_TRY(dalloc(b, &b->d_hl_obs, 9 * (size_t)n_obs)); BA_TRY(dalloc(b, &b->d_partial, (size_t)n_poses * SPLIT * (PV + 1)));
+    BA_HIP(hipMemset(b->d_partial, 0, (size_t)n_poses * SPLIT * (PV + 1) * sizeof(double)));
     b->red_n = (int64_t)b->dim_pad * b->dim_pad + 3 * (int64_t)b->dim_pad + 8;
     BA_TRY(dalloc(b, &b->d_red, (size_t)b->red_n));
     BA_HIP(hipMemset(b->d_red, 0, (size_t)b->red_n * sizeof(double)));
