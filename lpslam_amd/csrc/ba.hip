@@ -57,7 +57,7 @@ struct BaView {                       // device pointers handed to kernels by va
     const int* o_pose; const int* o_point;
     const double* o_u; const double* o_v; const double* o_ur; const double* o_w;
     const uint8_t* o_active;
-    const int* pt_start; const int* pt_obs; const int* ps_start; const int* ps_obs;
+    const int* pt_start; const int* pt_obs; const int* ps_start; const int* o_orig;
     double* W; double* Y; double* Ybl; double* Hll; double* bl; double* Hpp; double* hl_obs; double* partial;
     double* S; double* rhs; double* bp; double* hppdiag; double* chi_cur;   // reduced buffer sections (all-reduced when partitioned)
     double* bp_loc; double* hppdiag_loc; double* chi_loc;                    // this rank's own sums (equal to the above on one GPU)
@@ -292,7 +292,7 @@ __device__ __forceinline__ void pose_part_body(BaView& v, int bid, int robust, i
     for (int i = 0; i < 6; ++i) b[i] = 0;
     const bool full = mode == 0 && slot >= 0;
     for (int s = v.ps_start[p] + sp * 64 + lane; s < v.ps_start[p + 1]; s += 64 * SPLIT) {
-        const int k = v.ps_obs[s];
+        const int k = s;                        // observations are stored keyframe by keyframe
         if (!v.o_active[k]) continue;
         const int j = v.o_point[k];
         const double X[3] = {v.points[3 * j], v.points[3 * j + 1], v.points[3 * j + 2]};
@@ -549,7 +549,7 @@ __global__ __launch_bounds__(64) void k_ba_schur(BaView v, int n_blocks, int fus
         const int p = v.free_pose[i];
         double r6[6] = {0, 0, 0, 0, 0, 0};
         for (int s = v.ps_start[p] + lane; s < v.ps_start[p + 1]; s += 64) {
-            const double* yb = v.Ybl + 6 * (size_t)v.ps_obs[s];
+            const double* yb = v.Ybl + 6 * (size_t)s;
 #pragma unroll
             for (int q = 0; q < 6; ++q) r6[q] += yb[q];
         }
@@ -901,8 +901,9 @@ __global__ __launch_bounds__(256) void k_ba_obs_chi2(BaView v, double* chi2, uin
     quat_to_rot(v.poses + 7 * p, R);
     const double X[3] = {v.points[3 * j], v.points[3 * j + 1], v.points[3 * j + 2]};
     const int D = ba_residual(v, k, R, v.poses + 7 * p + 4, X, e, pc);
-    chi2[k] = v.o_w[k] * (e[0] * e[0] + e[1] * e[1] + (D == 3 ? e[2] * e[2] : 0.0));
-    depth_pos[k] = pc[2] > 0 ? 1 : 0;
+    const int ko = v.o_orig[k];                 // the caller's observation index
+    chi2[ko] = v.o_w[k] * (e[0] * e[0] + e[1] * e[1] + (D == 3 ? e[2] * e[2] : 0.0));
+    depth_pos[ko] = pc[2] > 0 ? 1 : 0;
 }
 
 }  // namespace
@@ -918,8 +919,8 @@ struct lpslam_hip_ba {
     double *d_poses0 = nullptr, *d_points0 = nullptr;      // state given at creation (lpslam_hip_ba_reset)
     int *d_pose_slot = nullptr, *d_free_pose = nullptr, *d_o_pose = nullptr, *d_o_point = nullptr;
     double *d_o_u = nullptr, *d_o_v = nullptr, *d_o_ur = nullptr, *d_o_w = nullptr;
-    uint8_t* d_o_active = nullptr;
-    int *d_pt_start = nullptr, *d_pt_obs = nullptr, *d_ps_start = nullptr, *d_ps_obs = nullptr;
+    uint8_t* d_o_active = nullptr; uint8_t* d_act_in = nullptr; int* d_o_orig = nullptr;
+    int *d_pt_start = nullptr, *d_pt_obs = nullptr, *d_ps_start = nullptr;
     double *d_W = nullptr, *d_Y = nullptr, *d_Ybl = nullptr, *d_Hll = nullptr, *d_bl = nullptr, *d_Hpp = nullptr;
     double *d_hl_obs = nullptr, *d_partial = nullptr, *d_minv = nullptr, *d_ldiag = nullptr;
     double* d_red = nullptr; int64_t red_n = 0;
@@ -959,7 +960,7 @@ BaView make_view(lpslam_hip_ba* b)
     for (int s = 0; s < 2; ++s) { v.poses_buf[s] = b->d_poses[s]; v.points_buf[s] = b->d_points[s]; }
     v.pose_slot = b->d_pose_slot; v.free_pose = b->d_free_pose; v.o_pose = b->d_o_pose; v.o_point = b->d_o_point;
     v.o_u = b->d_o_u; v.o_v = b->d_o_v; v.o_ur = b->d_o_ur; v.o_w = b->d_o_w; v.o_active = b->d_o_active;
-    v.pt_start = b->d_pt_start; v.pt_obs = b->d_pt_obs; v.ps_start = b->d_ps_start; v.ps_obs = b->d_ps_obs;
+    v.pt_start = b->d_pt_start; v.pt_obs = b->d_pt_obs; v.ps_start = b->d_ps_start; v.o_orig = b->d_o_orig;
     v.W = b->d_W; v.Y = b->d_Y; v.Ybl = b->d_Ybl; v.Hll = b->d_Hll; v.bl = b->d_bl; v.Hpp = b->d_Hpp;
     v.hl_obs = b->d_hl_obs; v.partial = b->d_partial; v.Minv = b->d_minv; v.Ldiag = b->d_ldiag;
     const size_t n = (size_t)b->dim_pad;
@@ -1076,20 +1077,28 @@ int lpslam_hip_ba_create(lpslam_hip_ctx* ctx, const double* poses, const uint8_t
     b->dim = 6 * b->n_free;
     b->dim_pad = ((b->dim + 1 + NB - 1) / NB) * NB;           // room for the rhs row
     b->n_blocks = b->n_free * (b->n_free + 1) / 2;
-    // structure: CSR by landmark and by keyframe (observation order inside a segment = input order)
+    // Observations are stored keyframe by keyframe and, inside a keyframe, by landmark (stable in the input order): the pose-side
+    // passes then index them directly and coalesced, and the Schur pair lists -- by far the largest gather -- walk Y and W in
+    // ascending order.  o_orig maps back to the caller's indices for the per-observation inputs / outputs of the API.
+    std::vector<int> order(n_obs);
+    for (int k = 0; k < n_obs; ++k) order[k] = k;
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
+        return obs[x].pose != obs[y].pose ? obs[x].pose < obs[y].pose : obs[x].point < obs[y].point; });
     std::vector<int> o_pose(n_obs), o_point(n_obs);
     std::vector<double> ou(n_obs), ov(n_obs), our(n_obs), ow(n_obs);
-    std::vector<int> pt_start(n_points + 1, 0), ps_start(n_poses + 1, 0), pt_obs(n_obs), ps_obs(n_obs);
+    std::vector<int> pt_start(n_points + 1, 0), ps_start(n_poses + 1, 0), pt_obs(n_obs);
+    b->h_ur.resize(n_obs);
     for (int k = 0; k < n_obs; ++k) {
-        o_pose[k] = obs[k].pose; o_point[k] = obs[k].point; ou[k] = obs[k].u; ov[k] = obs[k].v; our[k] = obs[k].ur; ow[k] = obs[k].inv_sigma2;
-        pt_start[obs[k].point + 1]++; ps_start[obs[k].pose + 1]++;
+        const lpslam_hip_ba_obs& o = obs[order[k]];
+        o_pose[k] = o.pose; o_point[k] = o.point; ou[k] = o.u; ov[k] = o.v; our[k] = o.ur; ow[k] = o.inv_sigma2;
+        pt_start[o.point + 1]++; ps_start[o.pose + 1]++;
+        b->h_ur[k] = obs[k].ur;                  // caller order (host-side outlier thresholds)
     }
-    b->h_ur = our;
     for (int j = 0; j < n_points; ++j) pt_start[j + 1] += pt_start[j];
     for (int i = 0; i < n_poses; ++i) ps_start[i + 1] += ps_start[i];
     {
-        std::vector<int> fp(pt_start.begin(), pt_start.end() - 1), fs(ps_start.begin(), ps_start.end() - 1);
-        for (int k = 0; k < n_obs; ++k) { pt_obs[fp[o_point[k]]++] = k; ps_obs[fs[o_pose[k]]++] = k; }
+        std::vector<int> fp(pt_start.begin(), pt_start.end() - 1);
+        for (int k = 0; k < n_obs; ++k) pt_obs[fp[o_point[k]]++] = k;
     }
     // pair lists per block pair (slot_a <= slot_b), terms in landmark order
     std::vector<int> blk_count((size_t)b->n_blocks + 1, 0);
@@ -1136,9 +1145,9 @@ int lpslam_hip_ba_create(lpslam_hip_ctx* ctx, const double* poses, const uint8_t
     BA_TRY(upload(b, &b->d_o_pose, o_pose)); BA_TRY(upload(b, &b->d_o_point, o_point));
     BA_TRY(upload(b, &b->d_o_u, ou)); BA_TRY(upload(b, &b->d_o_v, ov)); BA_TRY(upload(b, &b->d_o_ur, our)); BA_TRY(upload(b, &b->d_o_w, ow));
     BA_TRY(upload(b, &b->d_pt_start, pt_start)); BA_TRY(upload(b, &b->d_pt_obs, pt_obs));
-    BA_TRY(upload(b, &b->d_ps_start, ps_start)); BA_TRY(upload(b, &b->d_ps_obs, ps_obs));
+    BA_TRY(upload(b, &b->d_ps_start, ps_start)); BA_TRY(upload(b, &b->d_o_orig, order));
     std::vector<uint8_t> act((size_t)std::max(n_obs, 1), 1);
-    BA_TRY(upload(b, &b->d_o_active, act));
+    BA_TRY(upload(b, &b->d_o_active, act)); BA_TRY(upload(b, &b->d_act_in, act));
     for (int s = 0; s < 2; ++s) { BA_TRY(dalloc(b, &b->d_poses[s], 7 * (size_t)n_poses)); BA_TRY(dalloc(b, &b->d_points[s], 3 * (size_t)n_points)); }
     BA_TRY(dalloc(b, &b->d_poses0, 7 * (size_t)n_poses)); BA_TRY(dalloc(b, &b->d_points0, 3 * (size_t)n_points));
     BA_HIP(hipMemcpy(b->d_poses0, poses, 7 * (size_t)n_poses * sizeof(double), hipMemcpyHostToDevice));
@@ -1190,12 +1199,22 @@ void lpslam_hip_ba_destroy(lpslam_hip_ba* b)
     delete b;
 }
 
+// caller-order activity flags -> storage order
+__global__ __launch_bounds__(256) void k_ba_gather_active(const uint8_t* in, const int* o_orig, uint8_t* out, int n)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k < n) out[k] = in[o_orig[k]];
+}
+
 int lpslam_hip_ba_set_active(lpslam_hip_ba* b, const uint8_t* active)
 {
     if (!b) { set_error("null problem"); return LPSLAM_HIP_ERR_INVALID; }
     if (!b->n_obs) return LPSLAM_HIP_OK;
-    if (active) LP_HIP(hipMemcpyAsync(b->d_o_active, active, b->n_obs, hipMemcpyHostToDevice, b->stream));
-    else LP_HIP(hipMemsetAsync(b->d_o_active, 1, b->n_obs, b->stream));
+    if (active) {
+        LP_HIP(hipMemcpyAsync(b->d_act_in, active, b->n_obs, hipMemcpyHostToDevice, b->stream));
+        hipLaunchKernelGGL(k_ba_gather_active, dim3((b->n_obs + 255) / 256), dim3(256), 0, b->stream, b->d_act_in, b->d_o_orig, b->d_o_active, b->n_obs);
+        LP_HIP(hipGetLastError());
+    } else LP_HIP(hipMemsetAsync(b->d_o_active, 1, b->n_obs, b->stream));
     LP_HIP(hipStreamSynchronize(b->stream));
     return LPSLAM_HIP_OK;
 }
