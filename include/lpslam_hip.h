@@ -197,6 +197,29 @@ int lpslam_hip_ba_step_end(lpslam_hip_ba* ba, int32_t* accepted, int32_t* iterat
 /* Control state after the last optimize / step_end: finished outer iterations, g2o "Terminate", lambda, robust chi2. */
 int lpslam_hip_ba_status(lpslam_hip_ba* ba, int32_t* outer_done, int32_t* stopped, double* lambda, double* chi2);
 
+/* ---- Sim3 pose graph ---------------------------------------------------------------------------------------------
+ * Replaces what openvslam::system runs on its global-optimisation thread after a loop closure while the loop detector
+ * is enabled (reference: src/Trackers/OpenVSLAMTrackerBase.cpp:250-255): [UPSTREAM] optimize::graph_optimizer on
+ * g2o@691dc51 types_sim3 (VertexSim3Expmap / EdgeSim3, numeric Jacobians, Levenberg, BlockSolver_7_3); SURVEY.md 8(a) a23.
+ * A Sim3 is 8 doubles qw qx qy qz tx ty tz s (world -> camera: x_c = s R x_w + t). */
+typedef struct lpslam_hip_sim3_edge {
+    int32_t i, j;          /* vertices: error = log(meas * S_i * S_j^-1), information = identity */
+    double meas[8];
+} lpslam_hip_sim3_edge;
+
+typedef struct lpslam_hip_sim3 lpslam_hip_sim3;
+
+/* verts n x 8, fixed flags (NULL = none fixed; the loop keyframe should be), edges; fix_scale != 0 zeroes the scale
+ * component of every update (stereo / RGBD).  Copies everything to HBM. */
+int lpslam_hip_sim3_create(lpslam_hip_ctx* ctx, const double* verts, const uint8_t* fixed, int32_t n,
+                           const lpslam_hip_sim3_edge* edges, int32_t n_edges, int32_t fix_scale, lpslam_hip_sim3** out);
+void lpslam_hip_sim3_destroy(lpslam_hip_sim3* graph);
+/* `iters` outer Levenberg iterations (graph_optimizer: 50), g2o lambda control; log may be NULL. */
+int lpslam_hip_sim3_optimize(lpslam_hip_sim3* graph, int32_t iters, lpslam_hip_ba_iter_log* log, int32_t* done);
+int lpslam_hip_sim3_get(lpslam_hip_sim3* graph, double* verts);
+/* chi2 (= |error|^2) per edge of the current estimate */
+int lpslam_hip_sim3_chi2(lpslam_hip_sim3* graph, double* chi2);
+
 #ifdef __cplusplus
 }
 #endif

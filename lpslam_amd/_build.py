@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "liblpslam_hip.so")
 HIP_SOURCES = ["api.hip", "frontend.hip", "match.hip", "ba.hip"]
-DEPS = ["internal.h", "orb_pattern.inc", os.path.join("..", "..", "include", "lpslam_hip.h")]
+DEPS = ["internal.h", "orb_pattern.inc", os.path.join("..", "..", "include", "lpslam_hip.h"), "sim3.inl"]
 # -ffp-contract=off: parity with the CPU definition forbids FMA contraction ("Numerics").
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
          "-Wall", "-Wno-unused-function", "-Wno-unused-result"]

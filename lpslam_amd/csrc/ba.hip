@@ -1411,3 +1411,5 @@ int lpslam_hip_ba_local(lpslam_hip_ba* b, int32_t first_iters, int32_t second_it
 }
 
 }  // extern "C"
+
+#include "sim3.inl"

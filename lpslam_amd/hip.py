@@ -17,6 +17,7 @@ KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4
 CORNER_DTYPE = np.dtype([("x", "<i4"), ("y", "<i4"), ("score", "<i4")])
 BA_OBS_DTYPE = np.dtype([("pose", "<i4"), ("point", "<i4"), ("u", "<f8"), ("v", "<f8"), ("ur", "<f8"),
                          ("inv_sigma2", "<f8")])
+SIM3_EDGE_DTYPE = np.dtype([("i", "<i4"), ("j", "<i4"), ("meas", "<f8", (8,))])
 BA_LOG_DTYPE = np.dtype([("chi2_before", "<f8"), ("chi2_after", "<f8"), ("lambda", "<f8"),
                          ("trials", "<i4"), ("status", "<i4")])
 
@@ -33,6 +34,7 @@ SYMBOLS = [
     "lpslam_hip_ba_create", "lpslam_hip_ba_destroy", "lpslam_hip_ba_set_active", "lpslam_hip_ba_optimize",
     "lpslam_hip_ba_local", "lpslam_hip_ba_set_points_fixed", "lpslam_hip_ba_pose_optimize", "lpslam_hip_ba_reset", "lpslam_hip_ba_get", "lpslam_hip_ba_chi2", "lpslam_hip_ba_reduced_buffer",
     "lpslam_hip_ba_step_begin", "lpslam_hip_ba_step_lambda0", "lpslam_hip_ba_step_solve", "lpslam_hip_ba_scalar_buffer", "lpslam_hip_ba_step_end", "lpslam_hip_ba_status",
+    "lpslam_hip_sim3_create", "lpslam_hip_sim3_destroy", "lpslam_hip_sim3_optimize", "lpslam_hip_sim3_get", "lpslam_hip_sim3_chi2",
 ]
 
 
@@ -298,3 +300,45 @@ def ba_obs_array(prob):
     o["u"] = prob["obs_uvr"][:, 0]; o["v"] = prob["obs_uvr"][:, 1]; o["ur"] = prob["obs_uvr"][:, 2]
     o["inv_sigma2"] = prob["obs_inv_sigma2"]
     return o
+
+
+def sim3_edges(ei, ej, meas):
+    e = np.zeros(len(ei), SIM3_EDGE_DTYPE)
+    e["i"] = ei; e["j"] = ej; e["meas"] = meas
+    return e
+
+
+class PoseGraph:
+    """Device-resident Sim3 pose graph (lpslam_hip_sim3_*): vertices n x 8 (qw qx qy qz tx ty tz s)."""
+
+    def __init__(self, ctx, verts, fixed, edges, fix_scale=True):
+        self.ctx = ctx
+        self.lib = ctx.lib
+        verts = np.ascontiguousarray(verts, np.float64); fixed = np.ascontiguousarray(fixed, np.uint8)
+        edges = np.ascontiguousarray(edges, SIM3_EDGE_DTYPE)
+        self.n, self.n_edges = len(verts), len(edges)
+        h = C.c_void_p()
+        _check(self.lib.lpslam_hip_sim3_create(ctx.h, _p(verts), _p(fixed), self.n, _p(edges), self.n_edges, int(fix_scale), C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.lpslam_hip_sim3_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def optimize(self, iters=50):
+        log = np.zeros(max(iters, 1), BA_LOG_DTYPE); done = C.c_int32()
+        _check(self.lib.lpslam_hip_sim3_optimize(self.h, int(iters), _p(log), C.byref(done)))
+        return log[:done.value].copy()
+
+    def get(self):
+        v = np.zeros((self.n, 8))
+        _check(self.lib.lpslam_hip_sim3_get(self.h, _p(v)))
+        return v
+
+    def chi2(self):
+        c = np.zeros(self.n_edges)
+        _check(self.lib.lpslam_hip_sim3_chi2(self.h, _p(c)))
+        return c

@@ -202,3 +202,52 @@ def ba_problem(n_kf=50, n_points=5000, n_obs=40000, width=1280, height=720, seq_
                 obs_pose=obs[:, 0].astype(np.int32), obs_point=obs[:, 1].astype(np.int32),
                 obs_uvr=meas.astype(np.float64), obs_inv_sigma2=(1.0 / sigma ** 2).astype(np.float64),
                 cam=dict(fx=k["fx"], fy=k["fy"], cx=k["cx"], cy=k["cy"], fxb=k["fxb"]))
+
+
+def pose_graph_problem(n_kf=200, seq_id=0, radius=20.0, drift_rot=0.002, drift_trans=0.02, drift_scale=0.0,
+                       meas_noise=1e-3, covis=3, n_loop=5):
+    """Sim3 essential graph after a loop closure (BASELINE config 5's keyframe count): keyframes on a closed circuit,
+    vertex estimates from drifting odometry (random walk in rotation / translation / log-scale), edges = spanning
+    chain + `covis` covisibility neighbours + `n_loop` loop edges joining the end of the circuit to its start, with
+    measurements S_j S_i^-1 taken from the ground truth plus a small perturbation.  Vertices are world->camera Sim3
+    as (qw, qx, qy, qz, tx, ty, tz, s); keyframe 0 is fixed (the loop keyframe of [UPSTREAM] graph_optimizer)."""
+    rng = np.random.default_rng(0x5EED0000 + 7919 * seq_id + 13)
+
+    def compose(a, b):      # (R, t, s) * (R, t, s)
+        return a[0] @ b[0], a[2] * (a[0] @ b[1]) + a[1], a[2] * b[2]
+
+    def inverse(a):
+        Ri = a[0].T
+        return Ri, Ri @ (-a[1] / a[2]), 1.0 / a[2]
+
+    gt = []
+    for i in range(n_kf):
+        ang = 2 * math.pi * i / n_kf
+        c = np.array([radius * math.sin(ang), 0.3 * math.sin(3 * ang), radius * (1 - math.cos(ang))])   # camera centre
+        R_wc = _small_rot(np.array([0.0, ang, 0.0]))        # heading along the circuit
+        R = R_wc.T
+        gt.append((R, -R @ c, 1.0))
+    est = [gt[0]]
+    for i in range(1, n_kf):
+        rel = compose(gt[i], inverse(gt[i - 1]))              # S_i S_{i-1}^-1
+        d = (_small_rot(rng.normal(0, drift_rot, 3)), rng.normal(0, drift_trans, 3), math.exp(rng.normal(0, drift_scale)))
+        est.append(compose(compose(d, rel), est[i - 1]))
+    ei, ej = [], []
+    for i in range(n_kf):
+        for d in range(1, covis + 1):
+            if i + d < n_kf:
+                ei.append(i); ej.append(i + d)
+    for l in range(n_loop):
+        ei.append(n_kf - 1 - l); ej.append(l)
+    meas = []
+    for i, j in zip(ei, ej):
+        m = compose(gt[j], inverse(gt[i]))
+        d = (_small_rot(rng.normal(0, meas_noise, 3)), rng.normal(0, meas_noise, 3), 1.0)
+        meas.append(compose(d, m))
+
+    def pack(a):
+        return np.concatenate([rot_to_quat(a[0]), a[1], [a[2]]])
+
+    fixed = np.zeros(n_kf, np.uint8); fixed[0] = 1
+    return dict(verts_gt=np.array([pack(a) for a in gt]), verts=np.array([pack(a) for a in est]), fixed=fixed,
+                edge_i=np.array(ei, np.int32), edge_j=np.array(ej, np.int32), meas=np.array([pack(a) for a in meas]))

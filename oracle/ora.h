@@ -138,6 +138,21 @@ int ora_ba_local(double* poses, const uint8_t* fixed, int n_poses, double* point
 int ora_pose_optimize(double* pose7, const double* points, const ora_ba_obs* obs, int n_obs,
                       const ora_ba_cam* cam, uint8_t* outlier);
 
+/* ---- Sim3 pose graph (g2o types_sim3 + OpenVSLAM graph_optimizer; ora_sim3.c) ----------------- */
+typedef struct {
+    int32_t i, j;      /* vertices: error = log(meas * S_i * S_j^-1) */
+    double meas[8];    /* Sim3 as qw qx qy qz tx ty tz s */
+} ora_sim3_edge;
+void ora_sim3_exp(const double* update7, double* sim3_out);
+void ora_sim3_log(const double* sim3_in, double* log7);
+void ora_sim3_mul(const double* a, const double* b, double* out);
+void ora_sim3_inv(const double* a, double* out);
+double ora_sim3_graph_chi2(const double* verts, const ora_sim3_edge* edges, int n_edges);
+/* verts: n x 8 (in/out); fixed[i] != 0 => not optimised; fix_scale != 0 => the scale component of every update is zeroed
+ * (stereo / RGBD).  g2o Levenberg, numeric Jacobians, dense solve.  Returns iterations performed. */
+int ora_sim3_graph_optimize(double* verts, const uint8_t* fixed, int n, const ora_sim3_edge* edges, int n_edges,
+                            int fix_scale, int iters, ora_ba_iter_log* log);
+
 #ifdef __cplusplus
 }
 #endif

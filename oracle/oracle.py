@@ -239,3 +239,51 @@ def pose_optimize(pose7, points, obs, cam):
     c = ba_cam(cam)
     n = lib().ora_pose_optimize(_p(pose), _p(points), _p(obs), len(obs), C.byref(c), _p(out))
     return pose, out, n
+
+
+# ---- Sim3 pose graph -------------------------------------------------------------------------
+SIM3_EDGE_DTYPE = np.dtype([("i", "<i4"), ("j", "<i4"), ("meas", "<f8", (8,))])
+
+
+def sim3_edges(ei, ej, meas):
+    e = np.zeros(len(ei), SIM3_EDGE_DTYPE)
+    e["i"] = ei; e["j"] = ej; e["meas"] = meas
+    return e
+
+
+def _sim3_unary(fn, a, n_out):
+    a = np.ascontiguousarray(a, np.float64); out = np.zeros(n_out)
+    fn(_p(a), _p(out))
+    return out
+
+
+def sim3_exp(update7):
+    return _sim3_unary(lib().ora_sim3_exp, update7, 8)
+
+
+def sim3_log(s):
+    return _sim3_unary(lib().ora_sim3_log, s, 7)
+
+
+def sim3_inv(s):
+    return _sim3_unary(lib().ora_sim3_inv, s, 8)
+
+
+def sim3_mul(a, b):
+    a = np.ascontiguousarray(a, np.float64); b = np.ascontiguousarray(b, np.float64); out = np.zeros(8)
+    lib().ora_sim3_mul(_p(a), _p(b), _p(out))
+    return out
+
+
+def sim3_graph_chi2(verts, edges):
+    verts = np.ascontiguousarray(verts, np.float64); edges = np.ascontiguousarray(edges, SIM3_EDGE_DTYPE)
+    f = lib().ora_sim3_graph_chi2; f.restype = C.c_double
+    return f(_p(verts), _p(edges), len(edges))
+
+
+def sim3_graph_optimize(verts, fixed, edges, fix_scale=True, iters=50):
+    verts = np.ascontiguousarray(verts, np.float64).copy(); fixed = np.ascontiguousarray(fixed, np.uint8)
+    edges = np.ascontiguousarray(edges, SIM3_EDGE_DTYPE)
+    log = np.zeros(iters, LOG_DTYPE)
+    n = lib().ora_sim3_graph_optimize(_p(verts), _p(fixed), len(verts), _p(edges), len(edges), int(fix_scale), int(iters), _p(log))
+    return verts, log[:n].copy()

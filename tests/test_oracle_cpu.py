@@ -265,3 +265,70 @@ def test_ba_local_and_pose_optimizer(oracle):
     sel = obs[obs["pose"] == 3].copy(); sel["pose"] = 0
     pose, outl, n_in = oracle.pose_optimize(prob["poses"][3], prob["points_gt"], sel, prob["cam"])
     assert np.abs(pose[4:] - prob["poses_gt"][3, 4:]).max() < 0.05 and n_in > 0.6 * len(sel)
+
+
+# ---- Sim3 pose graph (ora_sim3.c) ------------------------------------------------------------------------------------
+def _sim3_matrix(s):
+    q = s[:4] / np.linalg.norm(s[:4])
+    w, x, y, z = q
+    R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                  [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                  [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+    M = np.eye(4); M[:3, :3] = s[7] * R; M[:3, 3] = s[4:7]
+    return M
+
+
+def test_sim3_exp_is_the_matrix_exponential_and_log_inverts_it(oracle):
+    from scipy.linalg import expm
+    rng = np.random.default_rng(3)
+    for scale in (1.0, 0.3, 1e-3):
+        for _ in range(5):
+            u = rng.normal(0, scale, 7)
+            th = np.linalg.norm(u[:3])
+            if th > 3.0:                  # log returns the rotation below pi
+                u[:3] *= 3.0 / th
+            G = np.zeros((4, 4))
+            G[:3, :3] = np.array([[0, -u[2], u[1]], [u[2], 0, -u[0]], [-u[1], u[0], 0]]) + u[6] * np.eye(3)
+            G[:3, 3] = u[3:6]
+            s = oracle.sim3_exp(u)
+            assert np.allclose(_sim3_matrix(s), expm(G), atol=1e-12)
+            assert np.allclose(oracle.sim3_log(s), u, atol=1e-10)
+    # pure scale / pure rotation branches of the coefficient table
+    for u in ([0, 0, 0, 1, 2, 3, 0.5], [0.4, 0, 0, 1, 2, 3, 0.0], [0, 0, 0, 1, 2, 3, 0.0]):
+        u = np.array(u, float)
+        assert np.allclose(oracle.sim3_log(oracle.sim3_exp(u)), u, atol=1e-12)
+
+
+def test_sim3_group_operations(oracle):
+    rng = np.random.default_rng(4)
+    a, b = oracle.sim3_exp(rng.normal(0, 0.5, 7)), oracle.sim3_exp(rng.normal(0, 0.5, 7))
+    assert np.allclose(_sim3_matrix(oracle.sim3_mul(a, b)), _sim3_matrix(a) @ _sim3_matrix(b), atol=1e-12)
+    assert np.allclose(_sim3_matrix(oracle.sim3_inv(a)), np.linalg.inv(_sim3_matrix(a)), atol=1e-12)
+
+
+def test_golden_sim3_graph(oracle):
+    g = golden("g7_sim3.npz")
+    assert np.allclose(oracle.sim3_exp(g["exp_in"]), g["exp_out"], atol=1e-15)
+    e = oracle.sim3_edges(g["edge_i"], g["edge_j"], g["meas"])
+    v, log = oracle.sim3_graph_optimize(g["verts0"], g["fixed"], e, True, 10)
+    assert np.allclose(log["chi2_after"], g["chi2_after"], rtol=1e-9) and np.array_equal(log["trials"], g["trials"])
+    assert np.allclose(v, g["verts"], atol=1e-9)
+    assert np.array_equal(v[0], g["verts0"][0]) and np.all(v[:, 7] == 1.0)        # fixed vertex, fixed scale
+    ef = oracle.sim3_edges(g["f_edge_i"], g["f_edge_j"], g["f_meas"])
+    vf, logf = oracle.sim3_graph_optimize(g["f_verts0"], g["fixed"], ef, False, 10)
+    assert np.allclose(logf["chi2_after"], g["f_chi2_after"], rtol=1e-9) and np.allclose(vf, g["f_verts"], atol=1e-9)
+    assert np.abs(vf[1:, 7] - 1.0).max() > 1e-4                                   # free scale moves
+
+
+def test_sim3_graph_recovers_the_loop(oracle):
+    from lpslam_amd import synth
+    p = synth.pose_graph_problem(30, 2, meas_noise=0.0, drift_scale=0.01)
+    e = oracle.sim3_edges(p["edge_i"], p["edge_j"], p["meas"])
+    chi0 = oracle.sim3_graph_chi2(p["verts"], e)
+    v, log = oracle.sim3_graph_optimize(p["verts"], p["fixed"], e, False, 50)
+    assert (np.diff(np.r_[chi0, log["chi2_after"]]) <= 1e-15).all()
+    assert log["chi2_after"][-1] < 1e-12 * chi0 + 1e-14
+    # exact measurements: the optimum is the ground truth (up to the quaternion sign)
+    sign = np.sign(np.sum(v[:, :4] * p["verts_gt"][:, :4], axis=1))[:, None]
+    assert np.abs(v[:, :4] * sign - p["verts_gt"][:, :4]).max() < 1e-6
+    assert np.abs(v[:, 4:] - p["verts_gt"][:, 4:]).max() < 1e-5

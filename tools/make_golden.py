@@ -64,6 +64,18 @@ def main():
     k = synth.intrinsics(320, 240)
     xr, dep, bi, nv = O.match_stereo(pl, pr, p6, kl, dl, kr, dr, k["fxb"], k["baseline"])
     np.savez_compressed(os.path.join(OUT, "g6_stereo.npz"), left=l, right=r, x_right=xr, depth=dep, best_idx=bi, n_left=len(kl), n_right=len(kr))
+    # G7: Sim3 pose graph, 12 keyframes, loop closed (10 Levenberg iterations, scale fixed) + one free-scale variant
+    pg = synth.pose_graph_problem(12, 7, n_loop=2)
+    e7 = O.sim3_edges(pg["edge_i"], pg["edge_j"], pg["meas"])
+    v7, log7 = O.sim3_graph_optimize(pg["verts"], pg["fixed"], e7, True, 10)
+    pg2 = synth.pose_graph_problem(12, 8, drift_scale=0.01, n_loop=2)
+    e8 = O.sim3_edges(pg2["edge_i"], pg2["edge_j"], pg2["meas"])
+    v8, log8 = O.sim3_graph_optimize(pg2["verts"], pg2["fixed"], e8, False, 10)
+    np.savez_compressed(os.path.join(OUT, "g7_sim3.npz"), verts0=pg["verts"], fixed=pg["fixed"], edge_i=pg["edge_i"], edge_j=pg["edge_j"],
+                        meas=pg["meas"], verts=v7, chi2_after=log7["chi2_after"], lam=log7["lambda"], trials=log7["trials"],
+                        f_verts0=pg2["verts"], f_edge_i=pg2["edge_i"], f_edge_j=pg2["edge_j"], f_meas=pg2["meas"], f_verts=v8,
+                        f_chi2_after=log8["chi2_after"],
+                        exp_in=np.array([0.3, -0.2, 0.1, 1.0, -2.0, 0.5, 0.2]), exp_out=O.sim3_exp([0.3, -0.2, 0.1, 1.0, -2.0, 0.5, 0.2]))
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 
