@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--frames", type=int, default=FRAMES_PER_STEP, help="stereo frames per step")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-ba", action="store_true", help="front end only (BASELINE configs[1])")
+    ap.add_argument("--no-extras", action="store_true", help="skip the untimed extras (front end alone, BA spread, pose graph): profiling runs")
     return ap.parse_args()
 
 
@@ -237,6 +238,38 @@ def main():
     wl.ctx.sync()
     pcie_fps = n_pcie * args.frames / (time.perf_counter() - t1)
 
+    # SURVEY.md 8(d) extras, outside the timed region: front end alone in batched and single-frame-latency mode, the spread of
+    # the BA time per LM iteration, and the Sim3 pose graph of BASELINE config 5's keyframe count
+    extras = {}
+    if rank == 0 and not args.no_extras:
+        n_fe = max(3, min(args.steps, 10))
+        wl.ctx.sync(); t2 = time.perf_counter()
+        for _ in range(n_fe):
+            wl.front_end()
+        wl.ctx.sync()
+        fe_batched = n_fe * args.frames / (time.perf_counter() - t2)
+        lat = []
+        for _ in range(20):
+            t2 = time.perf_counter()
+            wl.ctx.extract(2)
+            wl.ctx.match_stereo_strided(0, 1, 2, 1, wl.k["fxb"], wl.k["baseline"])
+            wl.ctx.match_bf(0, 2)
+            wl.ctx.sync()
+            lat.append(1e3 * (time.perf_counter() - t2))
+        extras["front_end"] = {"batched_frames_per_s": round(fe_batched, 1), "frames_per_launch": args.frames,
+                               "single_frame_latency_ms": round(float(np.median(lat)), 4)}
+        if wl.ba is not None:
+            per = []
+            for _ in range(10):
+                t2 = time.perf_counter(); wl.bundle_adjust(); per.append(1e3 * (time.perf_counter() - t2) / BA_ITERS)
+            extras["ba_ms_per_iter_spread"] = {"mean": round(float(np.mean(per)), 4), "p50": round(float(np.median(per)), 4)}
+        pg = wl.synth.pose_graph_problem(200, 0)
+        graph = wl.hip.PoseGraph(wl.ctx, pg["verts"], pg["fixed"], wl.hip.sim3_edges(pg["edge_i"], pg["edge_j"], pg["meas"]), True)
+        graph.optimize(2)
+        t2 = time.perf_counter(); glog = graph.optimize(10); t_pg = time.perf_counter() - t2
+        extras["pose_graph"] = {"keyframes": 200, "edges": int(len(pg["edge_i"])), "ms_per_iter": round(1e3 * t_pg / max(len(glog), 1), 4)}
+        graph.close()
+
     if rank == 0:
         frames_total = world * args.frames * args.steps
         value = frames_total / elapsed
@@ -271,6 +304,7 @@ def main():
             "stage_ms_per_step": {n: round(float(v), 4) for n, v in zip(STAGE_NAMES, stage_ms)},
             "pcie_inclusive_frames_per_s": round(pcie_fps, 2),
         }
+        out.update(extras)
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline()
             out["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 2)

@@ -220,6 +220,21 @@ int lpslam_hip_sim3_get(lpslam_hip_sim3* graph, double* verts);
 /* chi2 (= |error|^2) per edge of the current estimate */
 int lpslam_hip_sim3_chi2(lpslam_hip_sim3* graph, double* chi2);
 
+/* Sim3 between two keyframes ([UPSTREAM] optimize::transform_optimizer, called by the loop detector for every loop candidate):
+ * matched landmark pairs k = landmark 1 in camera-1 coordinates, landmark 2 in camera-2 coordinates, both keypoints and
+ * 1 / sigma^2 of their pyramid levels.  A batch of candidates is solved in one launch (one workgroup each): problem i owns
+ * pairs [pair_start[i], pair_start[i+1]) and s12[8 i .. 8 i + 7] (Sim3 camera 2 -> camera 1, in / out).  Flow per problem:
+ * 5 Levenberg iterations (Huber sqrt(chi_sq)), pairs with chi2 > chi_sq on either edge dropped, 10 more iterations if any was
+ * dropped (else 5); n_inliers[i] = 0 when fewer than 10 pairs survive the first cut.  cam = fx fy cx cy.  inlier may be NULL. */
+typedef struct lpslam_hip_sim3_pair {
+    double p1c[3], p2c[3];
+    double obs1[2], obs2[2];
+    double inv_sigma2_1, inv_sigma2_2;
+} lpslam_hip_sim3_pair;
+int lpslam_hip_sim3_transform_optimize(lpslam_hip_ctx* ctx, int32_t n_problems, double* s12, const lpslam_hip_sim3_pair* pairs,
+                                       const int32_t* pair_start, const double* cam1, const double* cam2, double chi_sq,
+                                       int32_t fix_scale, uint8_t* inlier, int32_t* n_inliers);
+
 #ifdef __cplusplus
 }
 #endif

@@ -147,21 +147,24 @@ __device__ __forceinline__ double ba_weight(const BaView& v, int k, int D, const
 
 
 // "Last workgroup done" hand-over: every workgroup of a pass calls this after its partials are stored.  Returns true in
-// exactly one workgroup -- the one that arrives last -- with all other workgroups' stores visible; that workgroup then runs the
-// single-workgroup combine, which saves a launch.  No spinning, so the grid always drains.
+// exactly one workgroup -- the one that arrives last -- with all other workgroups' stores visible (producer: every wavefront
+// drains its stores, barrier, one lane's agent-scope release + ticket; consumer: agent-scope acquire by that lane, its wait,
+// barrier, plain loads -- MI355X_MICROARCH.md, inter-workgroup visibility); that workgroup then runs the single-workgroup
+// combine, which saves a launch.  No spinning, so the grid always drains.
 __device__ __forceinline__ bool ba_last_block(BaCtl* c, int total)
 {
     __shared__ int s_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wavefront drains its own stores (a barrier alone does not)
     __syncthreads();
     if (threadIdx.x == 0) {
+        // release: the workgroup's stores leave this XCD's L2; acquire (only the last arrival needs it): stale lines are dropped
         const int t = __hip_atomic_fetch_add(&c->ticket, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
         s_last = (t == total - 1);
         if (s_last) c->ticket = 0;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // holds the barrier below until the invalidate has completed
     }
     __syncthreads();
-    const bool last = s_last != 0;
-    if (last) __threadfence();
-    return last;
+    return s_last != 0;
 }
 
 // (H_ll + lambda I)^-1 of one landmark, symmetric 3x3 stored as 6 (zero when singular)

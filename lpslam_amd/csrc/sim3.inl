@@ -440,6 +440,230 @@ __global__ __launch_bounds__(256) void k_sim3_chi2(Sim3View v, double* chi2)
     chi2[k] = chi;
 }
 
+// ---- Sim3 between two keyframes ([UPSTREAM] optimize::transform_optimizer / ORB-SLAM2 OptimizeSim3) --------------------------
+// One workgroup per candidate pair of keyframes runs the whole flow -- 5 Levenberg iterations, outlier cut, 5 / 10 more --
+// without returning to the host: the 7x7 system lives in LDS, the 14 perturbed transforms of the numeric Jacobian are built
+// once per iteration and shared by all pairs, sums are butterflies + the four wavefronts in order (reproducible).
+struct S3Pair { double p1c[3], p2c[3], obs1[2], obs2[2], w1, w2; };
+
+__device__ __forceinline__ void s3_t_error(const Sim3d& S, const Sim3d& Sinv, const S3Pair& p, const double* c1, const double* c2, double* e)
+{
+    double r[3], x[3];
+    s3_q_rot(S.q, p.p2c, r);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) x[i] = S.s * r[i] + S.t[i];
+    e[0] = p.obs1[0] - (c1[0] * x[0] / x[2] + c1[2]);
+    e[1] = p.obs1[1] - (c1[1] * x[1] / x[2] + c1[3]);
+    s3_q_rot(Sinv.q, p.p1c, r);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) x[i] = Sinv.s * r[i] + Sinv.t[i];
+    e[2] = p.obs2[0] - (c2[0] * x[0] / x[2] + c2[2]);
+    e[3] = p.obs2[1] - (c2[1] * x[1] / x[2] + c2[3]);
+}
+
+struct S3TShared {
+    Sim3d S, Si, St, Sti, Sp[14], Spi[14];
+    double red[4][36];
+    double H[49], b[7], x[7];
+    double lambda, ni, current_chi, rho;
+    int ok, accepted, again, stop, n_bad, n_in;
+};
+
+// sum of one value over the workgroup, returned to every thread (fixed order)
+__device__ __forceinline__ double s3_block_sum(double v, S3TShared& sh)
+{
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh.red[threadIdx.x >> 6][35] = v;
+    __syncthreads();
+    return ((sh.red[0][35] + sh.red[1][35]) + sh.red[2][35]) + sh.red[3][35];
+}
+
+__device__ double s3_t_chi2(const Sim3d& S, const Sim3d& Si, const S3Pair* pairs, const uint8_t* active, int n, const double* c1, const double* c2,
+                            double delta, S3TShared& sh)
+{
+    double chi = 0;
+    for (int k = threadIdx.x; k < n; k += 256) {
+        if (!active[k]) continue;
+        double e[4], r0, r1;
+        s3_t_error(S, Si, pairs[k], c1, c2, e);
+        huber(pairs[k].w1 * (e[0] * e[0] + e[1] * e[1]), delta, &r0, &r1); chi += r0;
+        huber(pairs[k].w2 * (e[2] * e[2] + e[3] * e[3]), delta, &r0, &r1); chi += r0;
+    }
+    return s3_block_sum(chi, sh);
+}
+
+__device__ void s3_t_levenberg(const S3Pair* pairs, const uint8_t* active, int n, const double* c1, const double* c2, double delta,
+                               int fix_scale, int iters, S3TShared& sh)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) sh.stop = 0;
+    __syncthreads();
+    for (int it = 0; it < iters; ++it) {
+        if (sh.stop) break;                                            // uniform: written before the barrier that ends an iteration
+        const double cur = s3_t_chi2(sh.S, sh.Si, pairs, active, n, c1, c2, delta, sh);
+        if (tid < 14) {
+            double add[7];
+#pragma unroll
+            for (int i = 0; i < 7; ++i) add[i] = (i == (tid >> 1)) ? ((tid & 1) ? -1e-9 : 1e-9) : 0.0;
+            Sim3d pert, pinv;
+            s3_oplus(sh.S, add, fix_scale, pert);
+            s3_inv(pert, pinv);
+            sh.Sp[tid] = pert; sh.Spi[tid] = pinv;
+        }
+        __syncthreads();
+        double acc[35];                                                // upper triangle of H (28) and b (7)
+#pragma unroll
+        for (int q = 0; q < 35; ++q) acc[q] = 0;
+        for (int k = tid; k < n; k += 256) {
+            if (!active[k]) continue;
+            const S3Pair p = pairs[k];
+            double e[4], J[4][7];
+            s3_t_error(sh.S, sh.Si, p, c1, c2, e);
+#pragma unroll
+            for (int d = 0; d < 7; ++d) {
+                double e1[4], e2[4];
+                s3_t_error(sh.Sp[2 * d], sh.Spi[2 * d], p, c1, c2, e1);
+                s3_t_error(sh.Sp[2 * d + 1], sh.Spi[2 * d + 1], p, c1, c2, e2);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) J[r][d] = (1.0 / (2 * 1e-9)) * (e1[r] - e2[r]);
+            }
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const double om = half ? p.w2 : p.w1;
+                double r0, r1;
+                huber(om * (e[2 * half] * e[2 * half] + e[2 * half + 1] * e[2 * half + 1]), delta, &r0, &r1);
+                const double w = om * r1;
+                int idx = 0;
+#pragma unroll
+                for (int a = 0; a < 7; ++a) {
+#pragma unroll
+                    for (int c = a; c < 7; ++c) acc[idx++] += J[2 * half][a] * w * J[2 * half][c] + J[2 * half + 1][a] * w * J[2 * half + 1][c];
+                    acc[28 + a] -= J[2 * half][a] * w * e[2 * half] + J[2 * half + 1][a] * w * e[2 * half + 1];
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 35; ++q) { const double sq = wave_sum(acc[q]); if (lane == 0) sh.red[wave][q] = sq; }
+        __syncthreads();
+        if (tid == 0) {
+            int idx = 0;
+            double maxd = 0;
+            for (int a = 0; a < 7; ++a) {
+                for (int c = a; c < 7; ++c, ++idx) {
+                    const double hv = ((sh.red[0][idx] + sh.red[1][idx]) + sh.red[2][idx]) + sh.red[3][idx];
+                    sh.H[a * 7 + c] = hv; sh.H[c * 7 + a] = hv;
+                }
+                sh.b[a] = ((sh.red[0][28 + a] + sh.red[1][28 + a]) + sh.red[2][28 + a]) + sh.red[3][28 + a];
+                maxd = fmax(maxd, fabs(sh.H[a * 8]));
+            }
+            if (it == 0) { sh.lambda = 1e-5 * maxd; sh.ni = 2; }
+            sh.current_chi = cur;
+        }
+        __syncthreads();
+        for (int qmax = 1; qmax <= 10; ++qmax) {
+            if (tid == 0) {
+                double A[49];
+                for (int i = 0; i < 49; ++i) A[i] = sh.H[i];
+                for (int j = 0; j < 7; ++j) A[j * 8] += sh.lambda;
+                int ok = 1;
+                for (int j = 0; j < 7 && ok; ++j) {                     // dense Cholesky, lower
+                    double d = A[j * 7 + j];
+                    for (int k = 0; k < j; ++k) d -= A[j * 7 + k] * A[j * 7 + k];
+                    if (!(d > 0.0)) { ok = 0; break; }
+                    d = sqrt(d);
+                    A[j * 7 + j] = d;
+                    for (int i = j + 1; i < 7; ++i) {
+                        double s2 = A[i * 7 + j];
+                        for (int k = 0; k < j; ++k) s2 -= A[i * 7 + k] * A[j * 7 + k];
+                        A[i * 7 + j] = s2 / d;
+                    }
+                }
+                if (ok) {
+                    double x[7];
+                    for (int i = 0; i < 7; ++i) { double s2 = sh.b[i]; for (int k = 0; k < i; ++k) s2 -= A[i * 7 + k] * x[k]; x[i] = s2 / A[i * 8]; }
+                    for (int i = 6; i >= 0; --i) { double s2 = x[i]; for (int k = i + 1; k < 7; ++k) s2 -= A[k * 7 + i] * x[k]; x[i] = s2 / A[i * 8]; }
+                    for (int i = 0; i < 7; ++i) sh.x[i] = x[i];
+                    Sim3d upd, uinv;
+                    s3_oplus(sh.S, x, fix_scale, upd);
+                    s3_inv(upd, uinv);
+                    sh.St = upd; sh.Sti = uinv;
+                } else { sh.St = sh.S; sh.Sti = sh.Si; }
+                sh.ok = ok;
+            }
+            __syncthreads();
+            double temp = s3_t_chi2(sh.St, sh.Sti, pairs, active, n, c1, c2, delta, sh);
+            if (tid == 0) {
+                if (!sh.ok) temp = DBL_MAX;
+                double rho = sh.current_chi - temp, scale = 0;
+                if (sh.ok) for (int j = 0; j < 7; ++j) scale += sh.x[j] * (sh.lambda * sh.x[j] + sh.b[j]);
+                scale += 1e-3;
+                rho /= scale;
+                if (rho > 0 && isfinite(temp)) {
+                    const double t3 = 2 * rho - 1;
+                    double alpha = 1. - t3 * t3 * t3;
+                    alpha = fmin(alpha, 2. / 3.);
+                    sh.lambda *= fmax(1. / 3., alpha);
+                    sh.ni = 2;
+                    sh.current_chi = temp;
+                    sh.S = sh.St; sh.Si = sh.Sti;
+                } else {
+                    sh.lambda *= sh.ni; sh.ni *= 2;
+                }
+                sh.rho = rho;
+                sh.again = (rho < 0 && qmax < 10) ? 1 : 0;
+                if (!sh.again && (qmax == 10 || rho == 0)) sh.stop = 1;
+            }
+            __syncthreads();
+            if (!sh.again) break;
+        }
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void k_sim3_transform(double* s12, const S3Pair* pairs_all, const int* pair_start, const double* cams,
+                                                        double chi_sq, int fix_scale, uint8_t* active_all, uint8_t* inlier_all, int* n_inliers)
+{
+    __shared__ S3TShared sh;
+    const int pb = blockIdx.x, tid = threadIdx.x;
+    const S3Pair* pairs = pairs_all + pair_start[pb];
+    const int n = pair_start[pb + 1] - pair_start[pb];
+    uint8_t* active = active_all + pair_start[pb];
+    uint8_t* inlier = inlier_all + pair_start[pb];
+    const double* c1 = cams; const double* c2 = cams + 4;
+    const double delta = sqrt(chi_sq);
+    if (tid == 0) { Sim3d S, Si; s3_load(s12 + 8 * (size_t)pb, S); s3_inv(S, Si); sh.S = S; sh.Si = Si; sh.n_bad = 0; sh.n_in = 0; }
+    for (int k = tid; k < n; k += 256) active[k] = 1;
+    __syncthreads();
+    s3_t_levenberg(pairs, active, n, c1, c2, delta, fix_scale, 5, sh);
+    int bad = 0;
+    for (int k = tid; k < n; k += 256) {
+        double e[4];
+        s3_t_error(sh.S, sh.Si, pairs[k], c1, c2, e);
+        if (pairs[k].w1 * (e[0] * e[0] + e[1] * e[1]) > chi_sq || pairs[k].w2 * (e[2] * e[2] + e[3] * e[3]) > chi_sq) { active[k] = 0; ++bad; }
+    }
+    const int n_bad = (int)s3_block_sum((double)bad, sh);
+    int n_in = 0;
+    if (n - n_bad >= 10) {
+        s3_t_levenberg(pairs, active, n, c1, c2, delta, fix_scale, n_bad > 0 ? 10 : 5, sh);
+        int in_cnt = 0;
+        for (int k = tid; k < n; k += 256) {
+            int in = 0;
+            if (active[k]) {
+                double e[4];
+                s3_t_error(sh.S, sh.Si, pairs[k], c1, c2, e);
+                in = !(pairs[k].w1 * (e[0] * e[0] + e[1] * e[1]) > chi_sq || pairs[k].w2 * (e[2] * e[2] + e[3] * e[3]) > chi_sq);
+            }
+            inlier[k] = (uint8_t)in;
+            in_cnt += in;
+        }
+        n_in = (int)s3_block_sum((double)in_cnt, sh);
+    } else {
+        for (int k = tid; k < n; k += 256) inlier[k] = 0;
+    }
+    if (tid == 0) { s3_store(sh.S, s12 + 8 * (size_t)pb); n_inliers[pb] = n_in; }
+}
+
 }  // namespace
 
 struct lpslam_hip_sim3 {
@@ -625,6 +849,46 @@ int lpslam_hip_sim3_chi2(lpslam_hip_sim3* g, double* chi2)
     LP_HIP(hipGetLastError());
     LP_HIP(hipMemcpyAsync(chi2, g->d_chi, (size_t)g->view.n_edges * sizeof(double), hipMemcpyDeviceToHost, g->stream));
     LP_HIP(hipStreamSynchronize(g->stream));
+    return LPSLAM_HIP_OK;
+}
+
+int lpslam_hip_sim3_transform_optimize(lpslam_hip_ctx* ctx, int32_t n_problems, double* s12, const lpslam_hip_sim3_pair* pairs,
+                                       const int32_t* pair_start, const double* cam1, const double* cam2, double chi_sq,
+                                       int32_t fix_scale, uint8_t* inlier, int32_t* n_inliers)
+{
+    if (!ctx || n_problems < 0 || (n_problems > 0 && (!s12 || !pair_start || !cam1 || !cam2 || !n_inliers)) || !(chi_sq > 0)) {
+        set_error("invalid Sim3 transform arguments"); return LPSLAM_HIP_ERR_INVALID;
+    }
+    if (n_problems == 0) return LPSLAM_HIP_OK;
+    for (int i = 0; i < n_problems; ++i) if (pair_start[i + 1] < pair_start[i] || pair_start[0] != 0) { set_error("pair_start must be a non-decreasing prefix sum from 0"); return LPSLAM_HIP_ERR_INVALID; }
+    const size_t total = (size_t)pair_start[n_problems];
+    if (total > 0 && !pairs) { set_error("pairs is NULL"); return LPSLAM_HIP_ERR_INVALID; }
+    static_assert(sizeof(lpslam_hip_sim3_pair) == sizeof(S3Pair), "pair layout");
+    LP_HIP(hipSetDevice(ctx->cfg.device));
+    hipStream_t s = ctx->stream;
+    double* d_s = nullptr; S3Pair* d_p = nullptr; int* d_start = nullptr; double* d_cam = nullptr; uint8_t* d_act = nullptr; uint8_t* d_in = nullptr; int* d_n = nullptr;
+    auto release = [&]() { for (void* p : {(void*)d_s, (void*)d_p, (void*)d_start, (void*)d_cam, (void*)d_act, (void*)d_in, (void*)d_n}) if (p) (void)hipFree(p); };
+#define T_HIP(x) do { if ((x) != hipSuccess) { release(); set_error("HIP call failed: %s", #x); return LPSLAM_HIP_ERR_DEVICE; } } while (0)
+    T_HIP(hipMalloc((void**)&d_s, 8 * (size_t)n_problems * sizeof(double)));
+    T_HIP(hipMalloc((void**)&d_p, std::max<size_t>(total, 1) * sizeof(S3Pair)));
+    T_HIP(hipMalloc((void**)&d_start, ((size_t)n_problems + 1) * sizeof(int)));
+    T_HIP(hipMalloc((void**)&d_cam, 8 * sizeof(double)));
+    T_HIP(hipMalloc((void**)&d_act, std::max<size_t>(total, 1)));
+    T_HIP(hipMalloc((void**)&d_in, std::max<size_t>(total, 1)));
+    T_HIP(hipMalloc((void**)&d_n, (size_t)n_problems * sizeof(int)));
+    T_HIP(hipMemcpyAsync(d_s, s12, 8 * (size_t)n_problems * sizeof(double), hipMemcpyHostToDevice, s));
+    if (total) T_HIP(hipMemcpyAsync(d_p, pairs, total * sizeof(S3Pair), hipMemcpyHostToDevice, s));
+    T_HIP(hipMemcpyAsync(d_start, pair_start, ((size_t)n_problems + 1) * sizeof(int), hipMemcpyHostToDevice, s));
+    T_HIP(hipMemcpyAsync(d_cam, cam1, 4 * sizeof(double), hipMemcpyHostToDevice, s));
+    T_HIP(hipMemcpyAsync(d_cam + 4, cam2, 4 * sizeof(double), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_sim3_transform, dim3(n_problems), dim3(256), 0, s, d_s, d_p, d_start, d_cam, chi_sq, fix_scale ? 1 : 0, d_act, d_in, d_n);
+    T_HIP(hipGetLastError());
+    T_HIP(hipMemcpyAsync(s12, d_s, 8 * (size_t)n_problems * sizeof(double), hipMemcpyDeviceToHost, s));
+    T_HIP(hipMemcpyAsync(n_inliers, d_n, (size_t)n_problems * sizeof(int), hipMemcpyDeviceToHost, s));
+    if (inlier && total) T_HIP(hipMemcpyAsync(inlier, d_in, total, hipMemcpyDeviceToHost, s));
+    T_HIP(hipStreamSynchronize(s));
+#undef T_HIP
+    release();
     return LPSLAM_HIP_OK;
 }
 

@@ -18,6 +18,8 @@ CORNER_DTYPE = np.dtype([("x", "<i4"), ("y", "<i4"), ("score", "<i4")])
 BA_OBS_DTYPE = np.dtype([("pose", "<i4"), ("point", "<i4"), ("u", "<f8"), ("v", "<f8"), ("ur", "<f8"),
                          ("inv_sigma2", "<f8")])
 SIM3_EDGE_DTYPE = np.dtype([("i", "<i4"), ("j", "<i4"), ("meas", "<f8", (8,))])
+SIM3_PAIR_DTYPE = np.dtype([("p1c", "<f8", (3,)), ("p2c", "<f8", (3,)), ("obs1", "<f8", (2,)), ("obs2", "<f8", (2,)),
+                            ("inv_sigma2_1", "<f8"), ("inv_sigma2_2", "<f8")])
 BA_LOG_DTYPE = np.dtype([("chi2_before", "<f8"), ("chi2_after", "<f8"), ("lambda", "<f8"),
                          ("trials", "<i4"), ("status", "<i4")])
 
@@ -34,7 +36,7 @@ SYMBOLS = [
     "lpslam_hip_ba_create", "lpslam_hip_ba_destroy", "lpslam_hip_ba_set_active", "lpslam_hip_ba_optimize",
     "lpslam_hip_ba_local", "lpslam_hip_ba_set_points_fixed", "lpslam_hip_ba_pose_optimize", "lpslam_hip_ba_reset", "lpslam_hip_ba_get", "lpslam_hip_ba_chi2", "lpslam_hip_ba_reduced_buffer",
     "lpslam_hip_ba_step_begin", "lpslam_hip_ba_step_lambda0", "lpslam_hip_ba_step_solve", "lpslam_hip_ba_scalar_buffer", "lpslam_hip_ba_step_end", "lpslam_hip_ba_status",
-    "lpslam_hip_sim3_create", "lpslam_hip_sim3_destroy", "lpslam_hip_sim3_optimize", "lpslam_hip_sim3_get", "lpslam_hip_sim3_chi2",
+    "lpslam_hip_sim3_create", "lpslam_hip_sim3_destroy", "lpslam_hip_sim3_optimize", "lpslam_hip_sim3_get", "lpslam_hip_sim3_chi2", "lpslam_hip_sim3_transform_optimize",
 ]
 
 
@@ -342,3 +344,25 @@ class PoseGraph:
         c = np.zeros(self.n_edges)
         _check(self.lib.lpslam_hip_sim3_chi2(self.h, _p(c)))
         return c
+
+
+def sim3_pairs(prob):
+    p = np.zeros(len(prob["p1c"]), SIM3_PAIR_DTYPE)
+    for k in ("p1c", "p2c", "obs1", "obs2", "inv_sigma2_1", "inv_sigma2_2"):
+        p[k] = prob[k]
+    return p
+
+
+def sim3_transform_optimize(ctx, s12, pairs_list, cam1, cam2, chi_sq=10.0, fix_scale=True):
+    """Batch of loop candidates (lpslam_hip_sim3_transform_optimize): s12 (n x 8), one pair array per candidate.
+    Returns (s12 n x 8, list of inlier masks, inlier counts)."""
+    s = np.ascontiguousarray(np.atleast_2d(s12), np.float64).copy()
+    n = len(pairs_list)
+    start = np.zeros(n + 1, np.int32); start[1:] = np.cumsum([len(p) for p in pairs_list])
+    pairs = np.ascontiguousarray(np.concatenate(pairs_list) if n else np.zeros(0, SIM3_PAIR_DTYPE), SIM3_PAIR_DTYPE)
+    c1 = np.ascontiguousarray(cam1, np.float64); c2 = np.ascontiguousarray(cam2, np.float64)
+    inl = np.zeros(max(len(pairs), 1), np.uint8); cnt = np.zeros(max(n, 1), np.int32)
+    f = ctx.lib.lpslam_hip_sim3_transform_optimize
+    f.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int32, C.c_void_p, C.c_void_p]
+    _check(f(ctx.h, n, _p(s), _p(pairs), _p(start), _p(c1), _p(c2), float(chi_sq), int(fix_scale), _p(inl), _p(cnt)))
+    return s, [inl[start[i]:start[i + 1]].astype(bool) for i in range(n)], cnt[:n].copy()

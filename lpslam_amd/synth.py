@@ -251,3 +251,32 @@ def pose_graph_problem(n_kf=200, seq_id=0, radius=20.0, drift_rot=0.002, drift_t
     fixed = np.zeros(n_kf, np.uint8); fixed[0] = 1
     return dict(verts_gt=np.array([pack(a) for a in gt]), verts=np.array([pack(a) for a in est]), fixed=fixed,
                 edge_i=np.array(ei, np.int32), edge_j=np.array(ej, np.int32), meas=np.array([pack(a) for a in meas]))
+
+
+def sim3_pair_problem(n=120, seq_id=0, width=1280, height=720, scale=1.0, outlier_frac=0.1, pix_noise=0.7, init_noise=(0.02, 0.15, 0.0)):
+    """Loop-candidate alignment ([UPSTREAM] transform_optimizer): landmarks seen by keyframe 2 (camera-2 coordinates p2c) and
+    their matches in keyframe 1 (p1c = S12 p2c), keypoints of both with level-dependent noise, a fraction of wrong matches,
+    and a perturbed initial S12 = (qw qx qy qz tx ty tz s)."""
+    rng = np.random.default_rng(0x5EED0000 + 104729 * seq_id + 29)
+    k = intrinsics(width, height)
+    cam = np.array([k["fx"], k["fy"], k["cx"], k["cy"]])
+    R = _small_rot(rng.normal(0, 0.1, 3)); t = rng.normal(0, 0.5, 3)
+    p2 = np.stack([rng.uniform(-6, 6, n), rng.uniform(-3, 3, n), rng.uniform(4, 25, n)], axis=1)
+    p1 = scale * (p2 @ R.T) + t
+    ok = p1[:, 2] > 1.0
+    p1, p2 = p1[ok], p2[ok]; n = len(p1)
+
+    def proj(p):
+        return np.stack([cam[0] * p[:, 0] / p[:, 2] + cam[2], cam[1] * p[:, 1] / p[:, 2] + cam[3]], axis=1)
+
+    lv1, lv2 = rng.integers(0, 8, n), rng.integers(0, 8, n)
+    s1, s2 = 1.2 ** lv1, 1.2 ** lv2
+    o1 = proj(p1) + rng.normal(0, pix_noise, (n, 2)) * s1[:, None]
+    o2 = proj(p2) + rng.normal(0, pix_noise, (n, 2)) * s2[:, None]
+    bad = rng.random(n) < outlier_frac
+    o1[bad] += rng.uniform(-80, 80, (int(bad.sum()), 2))
+    dR = _small_rot(rng.normal(0, init_noise[0], 3))
+    s12 = np.concatenate([rot_to_quat(dR @ R), dR @ t + rng.normal(0, init_noise[1], 3), [scale * math.exp(rng.normal(0, init_noise[2])) if init_noise[2] else scale]])
+    return dict(p1c=p1 + rng.normal(0, 0.01, p1.shape), p2c=p2 + rng.normal(0, 0.01, p2.shape), obs1=o1, obs2=o2,
+                inv_sigma2_1=1.0 / s1 ** 2, inv_sigma2_2=1.0 / s2 ** 2, cam1=cam, cam2=cam.copy(), s12=s12,
+                s12_gt=np.concatenate([rot_to_quat(R), t, [scale]]), outlier=bad)

@@ -153,6 +153,17 @@ double ora_sim3_graph_chi2(const double* verts, const ora_sim3_edge* edges, int 
 int ora_sim3_graph_optimize(double* verts, const uint8_t* fixed, int n, const ora_sim3_edge* edges, int n_edges,
                             int fix_scale, int iters, ora_ba_iter_log* log);
 
+/* Sim3 between two keyframes (optimize::transform_optimizer): matched landmark pair k = landmark 1 in camera-1 coordinates,
+ * landmark 2 in camera-2 coordinates, their keypoints and 1/sigma^2 of the keypoints' pyramid levels. */
+typedef struct {
+    double p1c[3], p2c[3];
+    double obs1[2], obs2[2];
+    double inv_sigma2_1, inv_sigma2_2;
+} ora_sim3_pair;
+/* s12: Sim3 camera 2 -> camera 1 (in/out); cam = fx fy cx cy; returns the number of inlier pairs (0 = rejected). */
+int ora_sim3_transform_optimize(double* s12, const ora_sim3_pair* pairs, int n, const double* cam1, const double* cam2,
+                                double chi_sq, int fix_scale, uint8_t* inlier);
+
 #ifdef __cplusplus
 }
 #endif

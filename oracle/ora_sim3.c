@@ -405,3 +405,164 @@ int ora_sim3_graph_optimize(double* verts, const uint8_t* fixed, int n, const or
     free(slot); free(H); free(A); free(b); free(x); free(bak);
     return it;
 }
+
+/* ---- Sim3 between two keyframes ([UPSTREAM] OpenVSLAM optimize::transform_optimizer; ORB-SLAM2 Optimizer::OptimizeSim3) ----
+ * One Sim3 vertex S12 (camera 2 -> camera 1); per matched landmark pair two reprojection edges with identity-scaled
+ * information and Huber kernel sqrt(chi_sq): forward  e = obs1 - proj1(S12 * P2c), backward e = obs2 - proj2(S12^-1 * P1c)
+ * (g2o EdgeSim3ProjectXYZ / EdgeInverseSim3ProjectXYZ: numeric Jacobians).  Flow: 5 Levenberg iterations, pairs with
+ * chi2 > chi_sq on either edge are dropped, 10 more iterations if any was dropped (else 5), 0 is returned when fewer than
+ * 10 pairs survive the first cut; inlier[k] = both edges within chi_sq at the end. */
+static void t_error(const sim3* S, const sim3* Sinv, const ora_sim3_pair* p, const double* cam1, const double* cam2, double* e)
+{
+    double x[3];
+    sim3 tmp = *S;
+    double r[3];
+    q_rot(tmp.q, p->p2c, r);
+    for (int i = 0; i < 3; ++i) x[i] = tmp.s * r[i] + tmp.t[i];
+    e[0] = p->obs1[0] - (cam1[0] * x[0] / x[2] + cam1[2]);
+    e[1] = p->obs1[1] - (cam1[1] * x[1] / x[2] + cam1[3]);
+    q_rot(Sinv->q, p->p1c, r);
+    for (int i = 0; i < 3; ++i) x[i] = Sinv->s * r[i] + Sinv->t[i];
+    e[2] = p->obs2[0] - (cam2[0] * x[0] / x[2] + cam2[2]);
+    e[3] = p->obs2[1] - (cam2[1] * x[1] / x[2] + cam2[3]);
+}
+static void huber2(double e2, double delta, double* rho0, double* rho1)
+{
+    const double dsqr = delta * delta;
+    if (e2 <= dsqr) { *rho0 = e2; *rho1 = 1.0; }
+    else { const double sq = sqrt(e2); *rho0 = 2 * sq * delta - dsqr; *rho1 = delta / sq; }
+}
+static double t_chi2(const sim3* S, const ora_sim3_pair* pairs, const uint8_t* active, int n, const double* cam1, const double* cam2, double delta)
+{
+    sim3 Si; sim3_inv(S, &Si);
+    double chi = 0;
+    for (int k = 0; k < n; ++k) {
+        if (!active[k]) continue;
+        double e[4], r0, r1;
+        t_error(S, &Si, &pairs[k], cam1, cam2, e);
+        huber2(pairs[k].inv_sigma2_1 * (e[0] * e[0] + e[1] * e[1]), delta, &r0, &r1); chi += r0;
+        huber2(pairs[k].inv_sigma2_2 * (e[2] * e[2] + e[3] * e[3]), delta, &r0, &r1); chi += r0;
+    }
+    return chi;
+}
+static int t_levenberg(sim3* S, const ora_sim3_pair* pairs, const uint8_t* active, int n, const double* cam1, const double* cam2,
+                       double delta, int fix_scale, int iters)
+{
+    double lambda = 0, ni = 2;
+    int it = 0;
+    for (; it < iters; ++it) {
+        double current_chi = t_chi2(S, pairs, active, n, cam1, cam2, delta), temp_chi;
+        double H[49], b[7];
+        memset(H, 0, sizeof(H)); memset(b, 0, sizeof(b));
+        sim3 Sp[14], Spi[14], Si;
+        sim3_inv(S, &Si);
+        for (int d = 0; d < 7; ++d)
+            for (int sgn = 0; sgn < 2; ++sgn) {
+                double add[7] = {0, 0, 0, 0, 0, 0, 0};
+                add[d] = sgn ? -1e-9 : 1e-9;
+                vertex_oplus(S, add, fix_scale, &Sp[2 * d + sgn]);
+                sim3_inv(&Sp[2 * d + sgn], &Spi[2 * d + sgn]);
+            }
+        for (int k = 0; k < n; ++k) {
+            if (!active[k]) continue;
+            double e[4], J[4][7];
+            t_error(S, &Si, &pairs[k], cam1, cam2, e);
+            for (int d = 0; d < 7; ++d) {
+                double e1[4], e2[4];
+                t_error(&Sp[2 * d], &Spi[2 * d], &pairs[k], cam1, cam2, e1);
+                t_error(&Sp[2 * d + 1], &Spi[2 * d + 1], &pairs[k], cam1, cam2, e2);
+                for (int r = 0; r < 4; ++r) J[r][d] = (1.0 / (2 * 1e-9)) * (e1[r] - e2[r]);
+            }
+            for (int half = 0; half < 2; ++half) {          /* the two edges of the pair, forward first */
+                const double om = half ? pairs[k].inv_sigma2_2 : pairs[k].inv_sigma2_1;
+                const double* eh = e + 2 * half;
+                double r0, r1;
+                huber2(om * (eh[0] * eh[0] + eh[1] * eh[1]), delta, &r0, &r1);
+                const double w = om * r1;
+                for (int a = 0; a < 7; ++a) {
+                    b[a] -= J[2 * half][a] * w * eh[0] + J[2 * half + 1][a] * w * eh[1];
+                    for (int c = 0; c < 7; ++c) H[a * 7 + c] += J[2 * half][a] * w * J[2 * half][c] + J[2 * half + 1][a] * w * J[2 * half + 1][c];
+                }
+            }
+        }
+        if (it == 0) {
+            double maxd = 0;
+            for (int j = 0; j < 7; ++j) if (fabs(H[j * 8]) > maxd) maxd = fabs(H[j * 8]);
+            lambda = 1e-5 * maxd; ni = 2;
+        }
+        double rho = 0;
+        int qmax = 0;
+        do {
+            const sim3 bak = *S;
+            double A[49], x[7];
+            memcpy(A, H, sizeof(A));
+            for (int j = 0; j < 7; ++j) A[j * 8] += lambda;
+            const int ok = chol_factor(A, 7);
+            if (ok) {
+                memcpy(x, b, sizeof(x));
+                chol_solve(A, 7, x);
+                sim3 upd;
+                vertex_oplus(S, x, fix_scale, &upd);
+                *S = upd;
+            }
+            temp_chi = t_chi2(S, pairs, active, n, cam1, cam2, delta);
+            if (!ok) temp_chi = DBL_MAX;
+            rho = current_chi - temp_chi;
+            double scale = 0;
+            if (ok) for (int j = 0; j < 7; ++j) scale += x[j] * (lambda * x[j] + b[j]);
+            scale += 1e-3;
+            rho /= scale;
+            if (rho > 0 && isfinite(temp_chi)) {
+                double alpha = 1. - pow((2 * rho - 1), 3);
+                alpha = alpha < 2. / 3. ? alpha : 2. / 3.;
+                lambda *= alpha > 1. / 3. ? alpha : 1. / 3.;
+                ni = 2;
+                current_chi = temp_chi;
+            } else {
+                lambda *= ni; ni *= 2;
+                *S = bak;
+            }
+            qmax++;
+        } while (rho < 0 && qmax < 10);
+        if (qmax == 10 || rho == 0) { ++it; break; }
+    }
+    return it;
+}
+
+int ora_sim3_transform_optimize(double* s12, const ora_sim3_pair* pairs, int n, const double* cam1, const double* cam2,
+                                double chi_sq, int fix_scale, uint8_t* inlier)
+{
+    sim3 S; load(s12, &S);
+    const double delta = sqrt(chi_sq);
+    uint8_t* active = (uint8_t*)malloc((size_t)(n > 0 ? n : 1));
+    memset(active, 1, (size_t)(n > 0 ? n : 1));
+    t_levenberg(&S, pairs, active, n, cam1, cam2, delta, fix_scale, 5);
+    int n_bad = 0;
+    {
+        sim3 Si; sim3_inv(&S, &Si);
+        for (int k = 0; k < n; ++k) {
+            double e[4];
+            t_error(&S, &Si, &pairs[k], cam1, cam2, e);
+            if (pairs[k].inv_sigma2_1 * (e[0] * e[0] + e[1] * e[1]) > chi_sq || pairs[k].inv_sigma2_2 * (e[2] * e[2] + e[3] * e[3]) > chi_sq) { active[k] = 0; ++n_bad; }
+        }
+    }
+    if (n - n_bad < 10) { if (inlier) memset(inlier, 0, (size_t)n); store(&S, s12); free(active); return 0; }
+    t_levenberg(&S, pairs, active, n, cam1, cam2, delta, fix_scale, n_bad > 0 ? 10 : 5);
+    int n_in = 0;
+    {
+        sim3 Si; sim3_inv(&S, &Si);
+        for (int k = 0; k < n; ++k) {
+            int in = 0;
+            if (active[k]) {
+                double e[4];
+                t_error(&S, &Si, &pairs[k], cam1, cam2, e);
+                in = !(pairs[k].inv_sigma2_1 * (e[0] * e[0] + e[1] * e[1]) > chi_sq || pairs[k].inv_sigma2_2 * (e[2] * e[2] + e[3] * e[3]) > chi_sq);
+            }
+            if (inlier) inlier[k] = (uint8_t)in;
+            n_in += in;
+        }
+    }
+    store(&S, s12);
+    free(active);
+    return n_in;
+}

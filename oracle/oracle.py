@@ -287,3 +287,24 @@ def sim3_graph_optimize(verts, fixed, edges, fix_scale=True, iters=50):
     log = np.zeros(iters, LOG_DTYPE)
     n = lib().ora_sim3_graph_optimize(_p(verts), _p(fixed), len(verts), _p(edges), len(edges), int(fix_scale), int(iters), _p(log))
     return verts, log[:n].copy()
+
+
+SIM3_PAIR_DTYPE = np.dtype([("p1c", "<f8", (3,)), ("p2c", "<f8", (3,)), ("obs1", "<f8", (2,)), ("obs2", "<f8", (2,)),
+                            ("inv_sigma2_1", "<f8"), ("inv_sigma2_2", "<f8")])
+
+
+def sim3_pairs(prob):
+    p = np.zeros(len(prob["p1c"]), SIM3_PAIR_DTYPE)
+    for k in ("p1c", "p2c", "obs1", "obs2", "inv_sigma2_1", "inv_sigma2_2"):
+        p[k] = prob[k]
+    return p
+
+
+def sim3_transform_optimize(s12, pairs, cam1, cam2, chi_sq=10.0, fix_scale=True):
+    s = np.ascontiguousarray(s12, np.float64).copy(); pairs = np.ascontiguousarray(pairs, SIM3_PAIR_DTYPE)
+    c1 = np.ascontiguousarray(cam1, np.float64); c2 = np.ascontiguousarray(cam2, np.float64)
+    inl = np.zeros(len(pairs), np.uint8)
+    f = lib().ora_sim3_transform_optimize
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_void_p]
+    n = f(_p(s), _p(pairs), len(pairs), _p(c1), _p(c2), float(chi_sq), int(fix_scale), _p(inl))
+    return s, inl, n

@@ -93,3 +93,32 @@ def test_baseline_config5_keyframe_count(hiplib, ctx):
     assert (np.diff(np.r_[chi0, log["chi2_after"]]) <= 0).all() and log["chi2_after"][-1] < 1e-3 * chi0
     before = np.abs(p["verts"][:, 4:7] - p["verts_gt"][:, 4:7]).max()
     assert np.abs(v[:, 4:7] - p["verts_gt"][:, 4:7]).max() < 0.2 * before
+
+
+# ---- Sim3 between two keyframes (transform_optimizer) -----------------------------------------------------------------
+@pytest.mark.parametrize("scale,fix_scale", [(1.0, True), (1.15, False)])
+def test_transform_optimizer_parity_batch(hiplib, oracle, ctx, scale, fix_scale):
+    probs = [synth.sim3_pair_problem(n, sid, scale=scale, init_noise=(0.02, 0.15, 0.0 if fix_scale else 0.03))
+             for sid, n in enumerate((150, 40, 300, 700))]
+    s0 = np.array([p["s12"] for p in probs])
+    sg, inl_g, cnt_g = hiplib.sim3_transform_optimize(ctx, s0, [hiplib.sim3_pairs(p) for p in probs], probs[0]["cam1"], probs[0]["cam2"], 10.0, fix_scale)
+    for i, p in enumerate(probs):
+        so, inl_o, cnt_o = oracle.sim3_transform_optimize(p["s12"], oracle.sim3_pairs(p), p["cam1"], p["cam2"], 10.0, fix_scale)
+        assert cnt_g[i] == cnt_o and np.array_equal(inl_g[i], inl_o.astype(bool))              # identical inlier sets
+        assert rot_err(sg[i:i + 1, :4], so[None, :4]).max() < ROT_TOL and np.abs(sg[i, 4:7] - so[4:7]).max() < TRANS_TOL
+        assert abs(sg[i, 7] - so[7]) < 1e-4
+        assert np.abs(sg[i] - p["s12_gt"]).max() < 0.5 * np.abs(p["s12"] - p["s12_gt"]).max()  # and it moved towards the truth
+        if fix_scale:
+            assert sg[i, 7] == p["s12"][7]
+
+
+def test_transform_optimizer_rejects_and_edge_cases(hiplib, oracle, ctx):
+    p = synth.sim3_pair_problem(30, 9, outlier_frac=0.8)                # mostly wrong matches: < 10 survive the first cut
+    so, inl_o, cnt_o = oracle.sim3_transform_optimize(p["s12"], oracle.sim3_pairs(p), p["cam1"], p["cam2"], 10.0, True)
+    few = synth.sim3_pair_problem(6, 10)
+    sg, inl, cnt = hiplib.sim3_transform_optimize(ctx, [p["s12"], few["s12"]], [hiplib.sim3_pairs(p), hiplib.sim3_pairs(few)],
+                                                  p["cam1"], p["cam2"], 10.0, True)
+    assert cnt[0] == cnt_o and np.array_equal(inl[0], inl_o.astype(bool))
+    assert cnt[1] == 0 and not inl[1].any()
+    s_empty, _, cnt_e = hiplib.sim3_transform_optimize(ctx, [p["s12"]], [hiplib.sim3_pairs(p)[:0]], p["cam1"], p["cam2"], 10.0, True)
+    assert cnt_e[0] == 0 and np.allclose(s_empty[0], p["s12"])
