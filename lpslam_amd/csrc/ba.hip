@@ -11,7 +11,7 @@
 //               wavefronts / keyframe, H_pp, b_p, chi2; both in one launch), k_ba_point_sum (H_ll, b_l; its last workgroup
 //               combines the pose partials in fixed order and computes lambda_0)
 //   trial       k_ba_obs_y (Y = W (H_ll + lambda)^-1), k_ba_schur (wavefront / pose-block pair over a pair list),
-//               k_chol_step x nb (32-wide panels, block products on the f64 matrix cores; the rhs is carried as an extra
+//               k_chol_pair x nb/2 (32-wide panels, two per launch, block products on the f64 matrix cores; the rhs is carried as an extra
 //               row and L^-T as extra row blocks, so no triangular substitution is needed), k_chol_xsolve (x_p = L^-T y),
 //               k_ba_backsub (landmarks, trial poses), k_ba_trial (trial chi2; its last workgroup runs g2o's lambda control)
 // All sums are fixed-order segmented reductions (no float atomics): results are reproducible run to run.
@@ -63,6 +63,7 @@ struct BaView {                       // device pointers handed to kernels by va
     double* bp_loc; double* hppdiag_loc; double* chi_loc;                    // this rank's own sums (equal to the above on one GPU)
     double* Minv;                                                            // L^-T row blocks (dim_pad x dim_pad)
     double* Ldiag;                                                           // factored diagonal blocks [nb][32][32]
+    double* Lsub;                                                            // L_j1,j of every panel pair, stored at [j1][32][32]
     double* xp; double* chi_pose; double* part; double* scal;
     const int* blk_start; const int2* blk_terms;
     BaCtl* ctl; lpslam_hip_ba_iter_log* log;
@@ -668,117 +669,46 @@ __device__ __forceinline__ double readlane_f64(double v, int lane)
     return __hiloint2double(hi, lo);
 }
 
-// ---- blocked Cholesky of S (+ lambda I), one launch per 32-wide panel column ------------------------------------------------
-// Launch kb (= -1 .. nb-2) produces panel column j = kb + 1 and applies panel kb to the rest of the trailing matrix (one-step
-// lookahead fused into the same launch: one kernel boundary per panel on the critical path).
+// ---- blocked Cholesky of S (+ lambda I), 32-wide panel columns, two per launch ------------------------------------------------
 //   Two kinds of extra rows ride along so that no triangular substitution is ever run:
 //     row `dim` of S carries the rhs            -> after the last panel it holds y = L^-1 rhs,
 //     Minv starts as the identity (synthesised) -> its row blocks become L^-T; block (e, .) only exists from column e on.
-//   panel workgroups (square row blocks i >= j, extra row blocks e <= j): D = A_jj - L_jk L_jk^T, B = A_ij - L_ik L_jk^T with
-//     256 threads, then ONE wavefront holds D's rows in lanes 0-31 and B's rows in lanes 32-63 (one row per lane in 32
-//     registers) and runs the unblocked factorisation with v_readlane broadcasts and a v_rsq_f64 + Newton reciprocal square
-//     root: the same rank-1 update factors D and solves B L_jj^T = B.  D is factored redundantly by every panel workgroup.
-//   update workgroups: A_i2,j2 -= L_i2,k L_j2,k^T for square i2 >= j2 >= j + 1 and for the extra row blocks e <= kb.
+//   A panel is factored by ONE wavefront that holds the diagonal block's rows in lanes 0-31 and the workgroup's own rows in
+//   lanes 32-63 (one row per lane in 32 registers): the unblocked factorisation with v_readlane broadcasts and a v_rsq_f64 +
+//   Newton reciprocal square root factors D and solves B L_jj^T = B with the same rank-1 updates.  The diagonal block is
+//   factored redundantly by every panel workgroup, which removes every dependence between workgroups of a launch.
+//   All working workgroups run on one XCD: the grid is launched 8x oversized and only every 8th workgroup works (workgroups go
+//   round-robin to the 8 XCDs), so the panel written by one launch is an L2 hit for the next (measured: -1 us per launch).
 // Explicit FMAs are used here (the contraction pragma only governs implicit fusing); the factorisation is not a parity
 // quantity, the solve's effect on chi2 / poses is (tolerances in DESIGN.md).
-__global__ __launch_bounds__(256) void k_chol_step(BaView v, int nb, int kb)
+// Launch m factors panel columns j = 2m and j1 = 2m + 1 and applies the previous pair (kb0 = 2m - 2, kb1 = 2m - 1) to the rest of
+// the trailing matrix: one kernel boundary per two panels on the critical path.  A panel workgroup (row block i, or
+// Minv row block e) keeps its five blocks  D_j, X = A_j1,j, D_j1, B0 = A_i,j, B1 = A_i,j1  in LDS:
+//   1. lookahead with the previous pair (K = 64, matrix cores): D_j, X, B0 on all four wavefronts;
+//   2. wavefront 0 factors [D_j; X] -> L_jj, L_j1,j and wavefront 1 [D_j; B0] -> L_i,j in registers, while
+//      wavefronts 2 and 3 finish the lookahead of D_j1 and B1;
+//   3. D_j1 -= L_j1,j L_j1,j^T, B1 -= L_i,j L_j1,j^T (matrix cores);
+//   4. wavefront 0 factors [D_j1; B1] -> L_j1,j1, L_i,j1.
+// D_j, X and D_j1 are factored redundantly by every panel workgroup; nobody overwrites them in S during the launch (the
+// diagonal workgroup publishes L_jj, L_j1,j1 into Ldiag; L_j1,j is needed by no later launch).  With an odd number of panels
+// the last launch is `single`: only column j.
+constexpr int CP_BLK = NB * (NB + 1);                  // one padded 32x32 block in LDS
+constexpr int CP_LDS_BYTES = 11 * CP_BLK * (int)sizeof(double);
+
+__device__ __forceinline__ double pivot_rsqrt64(double d)
 {
-    // The grid is launched 8x oversized and only every 8th workgroup works: workgroups go round-robin to the 8 XCDs, so all
-    // working ones share XCD 0's L2 and the panel written by one launch is an L2 hit for the next (measured: -1 us per launch).
-    if (blockIdx.x & 7) return;
-    const int bid = blockIdx.x >> 3;
-    const bool idle = ba_idle(v.ctl);     // tested after the loads below are in flight, before the first store
-    __shared__ double Lj[NB][NB + 1];
-    __shared__ double Li[NB][NB + 1];
-    __shared__ double Dm[NB][NB + 1];
-    __shared__ double Bm[NB][NB + 1];
-    double* S = v.S;
-    double* M = v.Minv;
-    const int n = v.dim_pad;
-    const int j = kb + 1;
-    const int n_sq = nb - j;              // square panel row blocks j..nb-1
-    const int n_panel = n_sq + j + 1;     // + extra row blocks 0..j
-    const int tid = threadIdx.x;
-    const size_t ck = (size_t)(kb < 0 ? 0 : kb) * NB;
-    if (bid >= n_panel) {
-        // ---- trailing update with panel kb
-        const int T = nb - (kb + 2);
-        int u = bid - n_panel;
-        const int n_sq_upd = T * (T + 1) / 2;
-        double* dst; const double* srcI; size_t ri, rj; bool overwrite = false;
-        if (u < n_sq_upd) {
-            int bi = 0;
-            while (u > bi) { u -= bi + 1; ++bi; }
-            const int i2 = j + 1 + bi, j2 = j + 1 + u;
-            ri = (size_t)i2 * NB; rj = (size_t)j2 * NB; dst = S; srcI = S;
-        } else {
-            u -= n_sq_upd;
-            const int e = u / T, j2 = j + 1 + (u - e * T);
-            ri = (size_t)e * NB; rj = (size_t)j2 * NB; dst = M; srcI = M;
-            overwrite = (e == kb);          // first contribution to this block: it holds no value yet
-        }
-        for (int t = tid; t < NB * NB; t += 256) {
-            const int r = t / NB, c = t % NB;
-            Li[r][c] = srcI[(ri + r) * n + ck + c];
-            Lj[r][c] = S[(rj + r) * n + ck + c];
-        }
-        if (idle) return;
-        __syncthreads();
-        // 32x32x32 product L_i L_j^T on the f64 matrix cores: one 16x16 tile per wavefront, 8 k-steps of v_mfma_f64_16x16x4
-        const int tr = (tid >> 7) * 16, tc = ((tid >> 6) & 1) * 16, lr = tid & 15, lk = (tid & 63) >> 4;
-        f64x4 acc = {0, 0, 0, 0};
-#pragma unroll
-        for (int s4 = 0; s4 < NB; s4 += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Li[tr + lr][s4 + lk], Lj[tc + lr][s4 + lk], acc, 0, 0, 0);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {             // result element q of a lane: row (lane >> 4) + 4 q, column lane & 15
-            double* d = &dst[(ri + tr + lk + 4 * q) * n + rj + tc + lr];
-            *d = overwrite ? -acc[q] : *d - acc[q];
-        }
-        return;
-    }
-    // ---- panel column j
-    const bool extra = bid >= n_sq;
-    const int i = extra ? bid - n_sq : j + bid;      // extra: block row e of Minv
-    const size_t rj = (size_t)j * NB, ri = (size_t)i * NB;
-    const bool has_b = extra || i > j;
-    const double* Bsrc = extra ? M : S;
-    const bool b_identity = extra && i == j;          // block (e, e) of Minv: identity, never stored before
-    const bool b_zero = extra && i == kb;             // block (e, e + 1): no update has written it yet (stale memory)
-    const bool li_zero = extra && i > kb;             // (only i == j): no panel-kb block
-    for (int t = tid; t < NB * NB; t += 256) {
-        const int r = t / NB, c = t % NB;
-        Dm[r][c] = S[(rj + r) * n + rj + c];
-        Bm[r][c] = (!has_b || b_zero) ? 0.0 : (b_identity ? (r == c ? 1.0 : 0.0) : Bsrc[(ri + r) * n + rj + c]);
-        if (kb >= 0) { Lj[r][c] = S[(rj + r) * n + ck + c]; Li[r][c] = (!has_b || li_zero) ? 0.0 : Bsrc[(ri + r) * n + ck + c]; }
-    }
-    if (idle) return;
-    __syncthreads();
-    if (kb >= 0) {
-        // lookahead update of this launch's own blocks with panel kb: D -= L_j L_j^T, B -= L_i L_j^T (matrix cores, as above)
-        const int tr = (tid >> 7) * 16, tc = ((tid >> 6) & 1) * 16, lr = tid & 15, lk = (tid & 63) >> 4;
-        f64x4 accd = {0, 0, 0, 0}, accb = {0, 0, 0, 0};
-#pragma unroll
-        for (int s4 = 0; s4 < NB; s4 += 4) {
-            const double bj = Lj[tc + lr][s4 + lk];
-            accd = __builtin_amdgcn_mfma_f64_16x16x4f64(Lj[tr + lr][s4 + lk], bj, accd, 0, 0, 0);
-            if (has_b) accb = __builtin_amdgcn_mfma_f64_16x16x4f64(Li[tr + lr][s4 + lk], bj, accb, 0, 0, 0);
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { Dm[tr + lk + 4 * q][tc + lr] -= accd[q]; Bm[tr + lk + 4 * q][tc + lr] -= accb[q]; }
-        __syncthreads();
-    }
-    if (tid >= 64) return;
-    const int lane = tid;
-    double a[NB];
-#pragma unroll
-    for (int c = 0; c < NB; ++c) a[c] = lane < NB ? Dm[lane][c] : Bm[lane - NB][c];
+    double rs = __builtin_amdgcn_rsq(d);
+    rs = rs * fma(-0.5 * d * rs, rs, 1.5);
+    return rs * fma(-0.5 * d * rs, rs, 1.5);
+}
+// register Cholesky of a 64-row x 32-column panel (lane = row, rows 0..31 = the diagonal block).  The pivot of column jj+1 is
+// finished right after that column's own update, so its latency chain overlaps the remaining rank-1 updates.
+__device__ __forceinline__ bool chol_panel_regs(double (&a)[NB], int lane)
+{
     bool fail = false;
-    // 1/sqrt(pivot) by v_rsq_f64 + two Newton steps (full double precision): the column scaling is a multiply.  The pivot of
-    // column jj+1 is finished right after that column's own update, so its latency chain overlaps the remaining rank-1 updates.
-    auto pivot_rsqrt = [&](double d) { double rs = __builtin_amdgcn_rsq(d); rs = rs * fma(-0.5 * d * rs, rs, 1.5); return rs * fma(-0.5 * d * rs, rs, 1.5); };
     double dcur = readlane_f64(a[0], 0);
     if (!(dcur > 0.0)) { fail = true; dcur = 1.0; }
-    double rs = pivot_rsqrt(dcur);
+    double rs = pivot_rsqrt64(dcur);
 #pragma unroll
     for (int jj = 0; jj < NB; ++jj) {
         const double lcol = a[jj] * rs;
@@ -787,31 +717,234 @@ __global__ __launch_bounds__(256) void k_chol_step(BaView v, int nb, int kb)
             a[jj + 1] = fma(-lcol, readlane_f64(lcol, jj + 1), a[jj + 1]);
             double dn = readlane_f64(a[jj + 1], jj + 1);
             if (!(dn > 0.0)) { fail = true; dn = 1.0; }
-            const double rn = pivot_rsqrt(dn);
+            const double rn = pivot_rsqrt64(dn);
 #pragma unroll
             for (int c = jj + 2; c < NB; ++c) a[c] = fma(-lcol, readlane_f64(lcol, c), a[c]);
             dcur = dn; rs = rn;
         }
     }
-    if (lane < NB) {
-        if (!has_b) {
-            // The diagonal workgroup publishes L_jj and the failure flag.  L_jj goes to a side buffer, NOT over A_jj:
-            // the other panel workgroups of this launch read A_jj and may be scheduled after this store.
+    return fail;
+}
+// acc += A[tr.., :] B[tc.., :]^T over one 32-wide k-block (16x16 tile, 8 x v_mfma_f64_16x16x4)
+__device__ __forceinline__ f64x4 mfma_tile32(const double* A, const double* B, int tr, int tc, int lr, int lk, f64x4 acc)
+{
+#pragma unroll
+    for (int s4 = 0; s4 < NB; s4 += 4)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A[(tr + lr) * (NB + 1) + s4 + lk], B[(tc + lr) * (NB + 1) + s4 + lk], acc, 0, 0, 0);
+    return acc;
+}
+__device__ __forceinline__ void tile_sub(double* D, int tr, int tc, int lr, int lk, f64x4 acc)
+{
+#pragma unroll
+    for (int q = 0; q < 4; ++q) D[(tr + lk + 4 * q) * (NB + 1) + tc + lr] -= acc[q];
+}
+
+__global__ __launch_bounds__(256) void k_chol_pair(BaView v, int nb, int m, int pin)
+{
+    if (pin && (blockIdx.x & 7)) return;                 // small launches: XCD 0 only (see above); large ones use the whole chip
+    const int bid = pin ? blockIdx.x >> 3 : blockIdx.x;
+    const bool idle = ba_idle(v.ctl);
+    extern __shared__ double cp_lds[];
+    double* S = v.S;
+    double* M = v.Minv;
+    const int n = v.dim_pad;
+    const int j = 2 * m, j1 = j + 1;
+    const bool single = j1 >= nb;
+    const bool prev = m > 0;
+    const int kb0 = j - 2, kb1 = j - 1;
+    const int ncol = single ? 1 : 2;
+    const int n_rows = nb - j - ncol;                    // square row blocks below the pair
+    const int n_extra = j + ncol;                        // Minv row blocks 0 .. j (j1)
+    const int n_panel = 1 + n_rows + n_extra;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tr = (wave >> 1) * 16, tc = (wave & 1) * 16, lr = tid & 15, lk = lane >> 4;
+    // one element of a block: mode 0 copy from memory, 1 zero, 2 identity.  All blocks of a workgroup are fetched in the same
+    // four passes so that their loads are in flight together (one round trip per pass, not one per block).
+    auto elem = [&](const double* src, size_t r0, size_t c0, int mode, int r, int c) -> double {
+        return mode == 0 ? src[(r0 + r) * n + c0 + c] : (mode == 2 && r == c ? 1.0 : 0.0);
+    };
+    if (bid >= n_panel) {
+        // ---- trailing update of block (i2, j2), j2 >= j + ncol, with the previous pair
+        const int T = nb - j - ncol;
+        int u = bid - n_panel;
+        const int n_sq_upd = T * (T + 1) / 2;
+        double* dst; const double* srcI; size_t ri, rj; bool overwrite = false; int e = -1;
+        if (u < n_sq_upd) {
+            int bi = 0;
+            while (u > bi) { u -= bi + 1; ++bi; }
+            ri = (size_t)(j + ncol + bi) * NB; rj = (size_t)(j + ncol + u) * NB; dst = S; srcI = S;
+        } else {
+            u -= n_sq_upd;
+            e = u / T;
+            ri = (size_t)e * NB; rj = (size_t)(j + ncol + (u - e * T)) * NB; dst = M; srcI = M;
+            overwrite = e >= kb0;                        // first contribution to this block: it holds no value yet
+        }
+        double* Li0 = cp_lds; double* Li1 = cp_lds + CP_BLK; double* Lj0 = cp_lds + 2 * CP_BLK; double* Lj1 = cp_lds + 3 * CP_BLK;
+        const int mi0 = e > kb0 ? 1 : 0, mi1 = e > kb1 ? 1 : 0;              // Minv block (e, k) is structurally zero for k < e
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int t = tid + it * 256, r = t / NB, c = t % NB, o = r * (NB + 1) + c;
+            const double a0 = elem(srcI, ri, (size_t)kb0 * NB, mi0, r, c), a1 = elem(srcI, ri, (size_t)kb1 * NB, mi1, r, c);
+            const double b0 = elem(S, rj, (size_t)kb0 * NB, 0, r, c), b1 = elem(S, rj, (size_t)kb1 * NB, 0, r, c);
+            Li0[o] = a0; Li1[o] = a1; Lj0[o] = b0; Lj1[o] = b1;
+        }
+        if (idle) return;
+        __syncthreads();
+        f64x4 acc = {0, 0, 0, 0};
+        acc = mfma_tile32(Li0, Lj0, tr, tc, lr, lk, acc);
+        acc = mfma_tile32(Li1, Lj1, tr, tc, lr, lk, acc);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            double* d = &dst[(ri + tr + lk + 4 * q) * n + rj + tc + lr];
+            *d = overwrite ? -acc[q] : *d - acc[q];
+        }
+        return;
+    }
+    // ---- panel workgroup
+    const bool diag = bid == 0;
+    const bool extra = bid > n_rows;
+    const int i = diag ? j : (extra ? bid - 1 - n_rows : j + ncol + bid - 1);       // row block (extra: Minv row e)
+    const size_t rj = (size_t)j * NB, rj1 = (size_t)j1 * NB, ri = (size_t)i * NB;
+    const bool has_b = !diag;
+    const double* Bsrc = extra ? M : S;
+    double* Dj = cp_lds;               double* X = cp_lds + CP_BLK;        double* Dj1 = cp_lds + 2 * CP_BLK;
+    double* B0 = cp_lds + 3 * CP_BLK;  double* B1 = cp_lds + 4 * CP_BLK;
+    double* Ljk0 = cp_lds + 5 * CP_BLK; double* Ljk1 = cp_lds + 6 * CP_BLK;      // row j of the previous pair (later: L_j1,j and L_i,j)
+    double* Lj1k0 = cp_lds + 7 * CP_BLK; double* Lj1k1 = cp_lds + 8 * CP_BLK;
+    double* Lik0 = cp_lds + 9 * CP_BLK; double* Lik1 = cp_lds + 10 * CP_BLK;
+    // Minv row e: block (e, e) starts as the identity, blocks left of it are zero, blocks right of it hold a value only once a
+    // trailing update of an earlier launch has written them (e < kb0)
+    const int mode0 = !has_b ? 1 : (!extra ? 0 : (i == j ? 2 : (i > j || i >= kb0 ? 1 : 0)));
+    const int mode1 = (!has_b || single) ? 1 : (!extra ? 0 : (i == j1 ? 2 : (i >= kb0 ? 1 : 0)));
+    const int ms = single ? 1 : 0;                                             // second-column blocks do not exist
+    const int mp = prev ? 0 : 1, mps = (prev && !single) ? 0 : 1;
+    const int mi0 = (!prev || !has_b || (extra && i > kb0)) ? 1 : 0, mi1 = (!prev || !has_b || (extra && i > kb1)) ? 1 : 0;
+    const size_t c0 = (size_t)(prev ? kb0 : 0) * NB, c1 = (size_t)(prev ? kb1 : 0) * NB;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int t = tid + it * 256, r = t / NB, c = t % NB, o = r * (NB + 1) + c;
+        const double vDj = elem(S, rj, rj, 0, r, c), vX = elem(S, rj1, rj, ms, r, c), vDj1 = elem(S, rj1, rj1, ms, r, c);
+        const double vB0 = elem(Bsrc, ri, rj, mode0, r, c), vB1 = elem(Bsrc, ri, rj1, mode1, r, c);
+        const double vj0 = elem(S, rj, c0, mp, r, c), vj1 = elem(S, rj, c1, mp, r, c);
+        const double vq0 = elem(S, rj1, c0, mps, r, c), vq1 = elem(S, rj1, c1, mps, r, c);
+        const double vi0 = elem(Bsrc, ri, c0, mi0, r, c), vi1 = elem(Bsrc, ri, c1, mi1, r, c);
+        Dj[o] = vDj; X[o] = vX; Dj1[o] = vDj1; B0[o] = vB0; B1[o] = vB1;
+        Ljk0[o] = vj0; Ljk1[o] = vj1; Lj1k0[o] = vq0; Lj1k1[o] = vq1; Lik0[o] = vi0; Lik1[o] = vi1;
+    }
+    if (idle) return;
+    __syncthreads();
+    if (prev) {                                          // 1. lookahead of the blocks the first factorisations need
+        f64x4 acc = {0, 0, 0, 0};
+        acc = mfma_tile32(Ljk0, Ljk0, tr, tc, lr, lk, acc); acc = mfma_tile32(Ljk1, Ljk1, tr, tc, lr, lk, acc);
+        tile_sub(Dj, tr, tc, lr, lk, acc);
+        if (!single) {
+            f64x4 ax = {0, 0, 0, 0};
+            ax = mfma_tile32(Lj1k0, Ljk0, tr, tc, lr, lk, ax); ax = mfma_tile32(Lj1k1, Ljk1, tr, tc, lr, lk, ax);
+            tile_sub(X, tr, tc, lr, lk, ax);
+        }
+        if (has_b) {
+            f64x4 ab = {0, 0, 0, 0};
+            ab = mfma_tile32(Lik0, Ljk0, tr, tc, lr, lk, ab); ab = mfma_tile32(Lik1, Ljk1, tr, tc, lr, lk, ab);
+            tile_sub(B0, tr, tc, lr, lk, ab);
+        }
+    }
+    __syncthreads();
+    bool fail = false;
+    if (wave == 0 && (!single || diag)) {                // 2a. [D_j; X] -> L_jj, L_j1,j   (single: the diagonal workgroup only needs L_jj)
+        double a[NB];
+#pragma unroll
+        for (int c = 0; c < NB; ++c) a[c] = lane < NB ? Dj[lane * (NB + 1) + c] : (single ? 0.0 : X[(lane - NB) * (NB + 1) + c]);
+        fail = chol_panel_regs(a, lane);
+        if (lane >= NB) {
+#pragma unroll
+            for (int c = 0; c < NB; ++c) Ljk0[(lane - NB) * (NB + 1) + c] = a[c];            // L_j1,j for step 3
+            if (diag && !single) {
+                // ... and for k_chol_xsolve when the rhs row lives in block j1.  Not into S: the other panel workgroups read A_j1,j.
+#pragma unroll
+                for (int c = 0; c < NB; ++c) v.Lsub[((size_t)j1 * NB + lane - NB) * NB + c] = a[c];
+            }
+        } else if (diag) {
 #pragma unroll
             for (int c = 0; c < NB; ++c) v.Ldiag[((size_t)j * NB + lane) * NB + c] = c <= lane ? a[c] : 0.0;
+            if (fail && lane == 0) v.scal[5] = 1.0;
+        }
+    } else if (wave == 1 && has_b) {                     // 2b. [D_j; B0] -> L_i,j
+        double a[NB];
+#pragma unroll
+        for (int c = 0; c < NB; ++c) a[c] = lane < NB ? Dj[lane * (NB + 1) + c] : B0[(lane - NB) * (NB + 1) + c];
+        chol_panel_regs(a, lane);
+        if (lane >= NB) {
+            double* out = extra ? M : S;
+#pragma unroll
+            for (int c = 0; c < NB; ++c) { Ljk1[(lane - NB) * (NB + 1) + c] = a[c]; out[(ri + lane - NB) * n + rj + c] = a[c]; }
+        }
+    } else if (prev && !single && wave >= 2) {           // 2c. the rest of the lookahead, beside the factorisations
+        if (wave == 2) {
+            for (int t4 = 0; t4 < 4; ++t4) {
+                const int r2 = (t4 >> 1) * 16, c2 = (t4 & 1) * 16;
+                f64x4 acc = {0, 0, 0, 0};
+                acc = mfma_tile32(Lj1k0, Lj1k0, r2, c2, lr, lk, acc); acc = mfma_tile32(Lj1k1, Lj1k1, r2, c2, lr, lk, acc);
+                tile_sub(Dj1, r2, c2, lr, lk, acc);
+            }
+        } else if (has_b) {
+            for (int t4 = 0; t4 < 4; ++t4) {
+                const int r2 = (t4 >> 1) * 16, c2 = (t4 & 1) * 16;
+                f64x4 acc = {0, 0, 0, 0};
+                acc = mfma_tile32(Lik0, Lj1k0, r2, c2, lr, lk, acc); acc = mfma_tile32(Lik1, Lj1k1, r2, c2, lr, lk, acc);
+                tile_sub(B1, r2, c2, lr, lk, acc);
+            }
+        }
+    }
+    if (single) return;
+    __syncthreads();
+    {                                                    // 3. the second column sees the first: K = 32
+        f64x4 acc = {0, 0, 0, 0};
+        acc = mfma_tile32(Ljk0, Ljk0, tr, tc, lr, lk, acc);
+        tile_sub(Dj1, tr, tc, lr, lk, acc);
+        if (has_b) {
+            f64x4 ab = {0, 0, 0, 0};
+            ab = mfma_tile32(Ljk1, Ljk0, tr, tc, lr, lk, ab);
+            tile_sub(B1, tr, tc, lr, lk, ab);
+        }
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    double a[NB];                                        // 4. [D_j1; B1] -> L_j1,j1, L_i,j1
+#pragma unroll
+    for (int c = 0; c < NB; ++c) a[c] = lane < NB ? Dj1[lane * (NB + 1) + c] : (has_b ? B1[(lane - NB) * (NB + 1) + c] : 0.0);
+    fail = chol_panel_regs(a, lane);
+    if (lane < NB) {
+        if (diag) {
+#pragma unroll
+            for (int c = 0; c < NB; ++c) v.Ldiag[((size_t)j1 * NB + lane) * NB + c] = c <= lane ? a[c] : 0.0;
             if (fail && lane == 0) v.scal[5] = 1.0;
         }
     } else if (has_b) {
         double* out = extra ? M : S;
 #pragma unroll
-        for (int c = 0; c < NB; ++c) out[(ri + lane - NB) * n + rj + c] = a[c];
+        for (int c = 0; c < NB; ++c) out[(ri + lane - NB) * n + rj1 + c] = a[c];
+    }
+}
+
+// the whole factorisation + L^-T rows: ceil(nb / 2) launches
+void enqueue_cholesky(hipStream_t s, const BaView& v, int nb)
+{
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_chol_pair, hipFuncAttributeMaxDynamicSharedMemorySize, CP_LDS_BYTES); attr_set = true; }
+    for (int m = 0; 2 * m < nb; ++m) {
+        const int j = 2 * m, ncol = (j + 1 < nb) ? 2 : 1;
+        const int T = nb - j - ncol;
+        const int n_panel = 1 + (nb - j - ncol) + (j + ncol);
+        const int n_update = m > 0 ? T * (T + 1) / 2 + j * T : 0;
+        const int pin = (n_panel + n_update) <= 96 ? 1 : 0;       // 32 CUs of one XCD hold a latency-bound launch; a throughput-bound one needs all 256
+        hipLaunchKernelGGL(k_chol_pair, dim3((n_panel + n_update) * (pin ? 8 : 1)), dim3(256), CP_LDS_BYTES, s, v, nb, m, pin);
     }
 }
 
 // x_p = L^-T y with y = L[dim][0..dim): one wavefront per row of the (upper triangular) L^-T, butterfly sum
 __global__ __launch_bounds__(256) void k_chol_xsolve(BaView v)
 {
-    if (blockIdx.x & 7) return;           // XCD 0 only, like k_chol_step: its inputs sit in that L2
+    if (blockIdx.x & 7) return;           // XCD 0 only, like k_chol_pair: its inputs sit in that L2
     if (ba_idle(v.ctl)) return;
     const int lane = threadIdx.x & 63;
     const int i = (blockIdx.x >> 3) * 4 + (threadIdx.x >> 6);
@@ -821,9 +954,12 @@ __global__ __launch_bounds__(256) void k_chol_xsolve(BaView v)
     const int yb = v.dim / NB;
     const double* y = v.S + (size_t)v.dim * n;
     const double* yd = v.Ldiag + ((size_t)yb * NB + (v.dim - yb * NB)) * NB - (size_t)yb * NB;
+    // an odd block is the second column of a panel pair: its block left of the diagonal went to Lsub (see k_chol_pair)
+    const int ys0 = (yb & 1) ? (yb - 1) * NB : yb * NB;
+    const double* ys = v.Lsub + ((size_t)yb * NB + (v.dim - yb * NB)) * NB - (size_t)ys0;
     const double* m = v.Minv + (size_t)i * n;
     double acc = 0;
-    for (int c = (i / NB) * NB + lane; c < v.dim; c += 64) acc += m[c] * (c < yb * NB ? y[c] : yd[c]);     // blocks left of the diagonal are empty
+    for (int c = (i / NB) * NB + lane; c < v.dim; c += 64) acc += m[c] * (c < ys0 ? y[c] : (c < yb * NB ? ys[c] : yd[c]));     // blocks left of the diagonal are empty
     acc = wave_sum(acc);
     if (lane == 0) v.xp[i] = acc;
 }
@@ -925,7 +1061,7 @@ struct lpslam_hip_ba {
     uint8_t* d_o_active = nullptr; uint8_t* d_act_in = nullptr; int* d_o_orig = nullptr;
     int *d_pt_start = nullptr, *d_pt_obs = nullptr, *d_ps_start = nullptr;
     double *d_W = nullptr, *d_Y = nullptr, *d_Ybl = nullptr, *d_Hll = nullptr, *d_bl = nullptr, *d_Hpp = nullptr;
-    double *d_hl_obs = nullptr, *d_partial = nullptr, *d_minv = nullptr, *d_ldiag = nullptr;
+    double *d_hl_obs = nullptr, *d_partial = nullptr, *d_minv = nullptr, *d_ldiag = nullptr, *d_lsub = nullptr;
     double* d_red = nullptr; int64_t red_n = 0;
     double *d_xp = nullptr, *d_chi_pose = nullptr, *d_part = nullptr, *d_scal = nullptr, *d_loc = nullptr;
     double* d_chi_obs = nullptr; uint8_t* d_depth = nullptr;
@@ -965,7 +1101,7 @@ BaView make_view(lpslam_hip_ba* b)
     v.o_u = b->d_o_u; v.o_v = b->d_o_v; v.o_ur = b->d_o_ur; v.o_w = b->d_o_w; v.o_active = b->d_o_active;
     v.pt_start = b->d_pt_start; v.pt_obs = b->d_pt_obs; v.ps_start = b->d_ps_start; v.o_orig = b->d_o_orig;
     v.W = b->d_W; v.Y = b->d_Y; v.Ybl = b->d_Ybl; v.Hll = b->d_Hll; v.bl = b->d_bl; v.Hpp = b->d_Hpp;
-    v.hl_obs = b->d_hl_obs; v.partial = b->d_partial; v.Minv = b->d_minv; v.Ldiag = b->d_ldiag;
+    v.hl_obs = b->d_hl_obs; v.partial = b->d_partial; v.Minv = b->d_minv; v.Ldiag = b->d_ldiag; v.Lsub = b->d_lsub;
     const size_t n = (size_t)b->dim_pad;
     v.S = b->d_red; v.rhs = b->d_red + n * n; v.bp = v.rhs + n; v.hppdiag = v.bp + n; v.chi_cur = v.hppdiag + n;
     v.bp_loc = b->d_loc; v.hppdiag_loc = b->d_loc + n; v.chi_loc = b->d_loc + 2 * n;
@@ -1010,12 +1146,7 @@ int enqueue_solve(lpslam_hip_ba* b, int fused)
             hipLaunchKernelGGL(k_lm_begin, dim3(1), dim3(64), 0, s, v);
             hipLaunchKernelGGL(k_chol_prep, dim3((n + 255) / 256), dim3(256), 0, s, v);
         }
-        for (int kb = -1; kb <= nb - 2; ++kb) {
-            const int j = kb + 1, T = nb - (kb + 2);
-            const int n_panel = (nb - j) + (j + 1);
-            const int n_update = kb >= 0 ? T * (T + 1) / 2 + (kb + 1) * T : 0;
-            hipLaunchKernelGGL(k_chol_step, dim3((n_panel + n_update) * 8), dim3(256), 0, s, v, nb, kb);
-        }
+        enqueue_cholesky(s, v, nb);
         hipLaunchKernelGGL(k_chol_xsolve, dim3((b->dim + 3) / 4 * 8), dim3(256), 0, s, v);
     } else if (!fused) {
         hipLaunchKernelGGL(k_lm_begin, dim3(1), dim3(64), 0, s, v);
@@ -1173,7 +1304,7 @@ int lpslam_hip_ba_create(lpslam_hip_ctx* ctx, const double* poses, const uint8_t
     }
     BA_TRY(dalloc(b, &b->d_minv, (size_t)b->dim_pad * b->dim_pad));
     BA_HIP(hipMemset(b->d_minv, 0, (size_t)b->dim_pad * b->dim_pad * sizeof(double)));
-    BA_TRY(dalloc(b, &b->d_ldiag, (size_t)b->dim_pad * NB));
+    BA_TRY(dalloc(b, &b->d_ldiag, (size_t)b->dim_pad * NB)); BA_TRY(dalloc(b, &b->d_lsub, (size_t)b->dim_pad * NB));
     BA_TRY(dalloc(b, &b->d_xp, (size_t)b->dim_pad));
     BA_HIP(hipMemset(b->d_xp, 0, b->dim_pad * sizeof(double)));
     BA_TRY(dalloc(b, &b->d_chi_pose, (size_t)n_poses));

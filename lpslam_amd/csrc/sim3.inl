@@ -7,7 +7,7 @@
 // reaches through openvslam::system when the loop detector is on (/root/reference/src/Trackers/OpenVSLAMTrackerBase.cpp:250-255).
 // SURVEY.md section 8(a) row a23.
 //
-// One LM unit = [k_sim3_lin if the state changed] k_sim3_assemble, k_chol_step x nb, k_chol_xsolve, k_sim3_update, k_sim3_trial.
+// One LM unit = [k_sim3_lin if the state changed] k_sim3_assemble, k_chol_pair x nb/2, k_chol_xsolve, k_sim3_update, k_sim3_trial.
 //   k_sim3_lin       one workgroup per edge: 28 perturbed error evaluations side by side (central differences of both
 //                    vertices), J_i, J_j, then the edge's J^T J blocks / J^T e; the last workgroup totals chi2, finds
 //                    max diag H and starts the outer iteration (lambda_0)
@@ -783,6 +783,7 @@ int lpslam_hip_sim3_create(lpslam_hip_ctx* ctx, const double* verts, const uint8
     }
     S3_TRY(s3_alloc(g, &cv.Minv, (size_t)v.dim_pad * v.dim_pad, true));
     S3_TRY(s3_alloc(g, &cv.Ldiag, (size_t)v.dim_pad * NB, true));
+    S3_TRY(s3_alloc(g, &cv.Lsub, (size_t)v.dim_pad * NB, true));
     S3_TRY(s3_alloc(g, &cv.xp, (size_t)v.dim_pad, true));
     S3_TRY(s3_alloc(g, &cv.scal, 8, true));
     S3_TRY(s3_alloc(g, &cv.ctl, 1, true));
@@ -812,12 +813,7 @@ int lpslam_hip_sim3_optimize(lpslam_hip_sim3* g, int32_t iters, lpslam_hip_ba_it
             if (v.n_edges) hipLaunchKernelGGL(k_sim3_lin, dim3(v.n_edges), dim3(64), 0, s, v);
             if (v.dim > 0) {
                 hipLaunchKernelGGL(k_sim3_assemble, dim3(v.n_blocks + v.n_free), dim3(64), 0, s, v);
-                for (int kb = -1; kb <= g->nb - 2; ++kb) {
-                    const int j = kb + 1, T = g->nb - (kb + 2);
-                    const int n_panel = (g->nb - j) + (j + 1);
-                    const int n_update = kb >= 0 ? T * (T + 1) / 2 + (kb + 1) * T : 0;
-                    hipLaunchKernelGGL(k_chol_step, dim3((n_panel + n_update) * 8), dim3(256), 0, s, v.cv, g->nb, kb);
-                }
+                enqueue_cholesky(s, v.cv, g->nb);
                 hipLaunchKernelGGL(k_chol_xsolve, dim3((v.dim + 3) / 4 * 8), dim3(256), 0, s, v.cv);
             }
             hipLaunchKernelGGL(k_sim3_update, dim3(vb + 1), dim3(256), 0, s, v, vb);
