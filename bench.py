@@ -258,6 +258,22 @@ def main():
             lat.append(1e3 * (time.perf_counter() - t2))
         extras["front_end"] = {"batched_frames_per_s": round(fe_batched, 1), "frames_per_launch": args.frames,
                                "single_frame_latency_ms": round(float(np.median(lat)), 4)}
+        # K0 on-device undistort / rectify: 12 remaps of a staged raw frame, 8 B per pixel algorithmic
+        yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
+        for eye in (0, 1):
+            wl.ctx.set_rectify_map(eye, xx * 0.97 + 15 + 3 * np.sin(yy / 50), yy * 0.97 + 9 + 3 * np.cos(xx / 70))
+        wl.ctx.upload_raw(0, 0, wl.host_frames[0][0])
+        for i in range(2 * args.frames):
+            wl.ctx.remap_staged(i, i & 1)
+        wl.ctx.sync(); t2 = time.perf_counter()
+        for _ in range(10):
+            for i in range(2 * args.frames):
+                wl.ctx.remap_staged(i, i & 1)
+        wl.ctx.sync()
+        t_rm = (time.perf_counter() - t2) / (10 * 2 * args.frames)
+        extras["remap"] = {"us_per_image": round(1e6 * t_rm, 2), "algorithmic_GBps": round(8.0 * W * H / t_rm / 1e9, 1)}
+        for i, (l, r) in enumerate(wl.host_frames):          # restore the resident frames
+            wl.ctx.upload(2 * i, l); wl.ctx.upload(2 * i + 1, r)
         if wl.ba is not None:
             per = []
             for _ in range(10):

@@ -89,6 +89,16 @@ int lpslam_hip_timer_read(lpslam_hip_ctx* ctx, int slot, float* ms);
  * capture DMA or another kernel), or upload from host memory (tightly packed rows of `stride` bytes). */
 int lpslam_hip_image_ptr(lpslam_hip_ctx* ctx, int image, void** dev_ptr, int32_t* pitch);
 int lpslam_hip_upload_image(lpslam_hip_ctx* ctx, int image, const uint8_t* host, int32_t stride);
+/* On-device undistort / rectify: replaces the per-frame cv::remap(INTER_LINEAR) of ImageProcessing::Undistort::undistort
+ * (reference: src/Utils/ImageProcessing.h:245-249; called for both eyes per frame, src/Trackers/OpenVSLAMStereoTracker.cpp:
+ * 198-213).  map_x / map_y are the CV_32FC1 maps of one eye (0 = left, 1 = right), width x height floats, as
+ * cv::initUndistortRectifyMap / cv::fisheye::initUndistortRectifyMap produce them (the host library builds them from the
+ * LpSlamCameraConfiguration pair, lpslam_amd/host/rectify.h).  upload_raw_image copies the distorted frame to HBM and remaps it
+ * into level 0 of the image slot, bit-identical to cv::remap with BORDER_CONSTANT 0. */
+int lpslam_hip_set_rectify_map(lpslam_hip_ctx* ctx, int32_t eye, const float* map_x, const float* map_y);
+int lpslam_hip_upload_raw_image(lpslam_hip_ctx* ctx, int image, int32_t eye, const uint8_t* host, int32_t stride);
+/* remaps the raw frame already staged in HBM (the last upload_raw_image) into another slot: the device-side step alone */
+int lpslam_hip_remap_staged(lpslam_hip_ctx* ctx, int image, int32_t eye);
 
 /* ---- ORB front end (asynchronous on the context stream) -------------------------------------------------- */
 /* pyramid -> FAST (64-px cells, ini/min threshold) -> quad-tree distribution -> orientation + rBRIEF,

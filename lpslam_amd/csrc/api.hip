@@ -1,6 +1,9 @@
 // api.hip -- C ABI of the lpslam HIP library: context life cycle, geometry tables, frame upload, stage launches and
 // readbacks.  Declarations and the reference interfaces they replace: include/lpslam_hip.h.
 #include "internal.h"
+#include <vector>
+#include <cmath>
+#include <climits>
 #include <cmath>
 #include <cstdarg>
 #include <algorithm>
@@ -218,7 +221,8 @@ void lpslam_hip_destroy(lpslam_hip_ctx* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void* bufs[] = {c->d_pyr, c->d_rs_ofs, c->d_rs_coef, c->d_cell_keys, c->d_cell_count, c->d_cand_key, c->d_cand_node,
                     c->d_cand_count, c->d_node_box, c->d_node_cnt, c->d_sel_key, c->d_sel_count, c->d_kpts, c->d_desc,
-                    c->d_kp_count, c->d_bf, c->d_stereo, c->d_stereo_idx, c->d_stereo_corr, c->d_tmp_desc, c->d_tmp_res};
+                    c->d_kp_count, c->d_bf, c->d_stereo, c->d_stereo_idx, c->d_stereo_corr, c->d_tmp_desc, c->d_tmp_res,
+                    c->d_map_xy[0], c->d_map_xy[1], c->d_map_frac[0], c->d_map_frac[1], c->d_raw};
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (int i = 0; i < LPSLAM_HIP_MAX_TIMERS; ++i) { if (c->ev_begin[i]) (void)hipEventDestroy(c->ev_begin[i]); if (c->ev_end[i]) (void)hipEventDestroy(c->ev_end[i]); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -308,6 +312,51 @@ int lpslam_hip_upload_image(lpslam_hip_ctx* c, int image, const uint8_t* host, i
     LP_HIP(hipMemcpy2DAsync(c->d_pyr + (size_t)image * c->image_slab, c->lt.pitch[0], host, stride, c->lt.w[0], c->lt.h[0],
                             hipMemcpyHostToDevice, c->stream));
     return LPSLAM_HIP_OK;
+}
+
+int lpslam_hip_set_rectify_map(lpslam_hip_ctx* c, int32_t eye, const float* map_x, const float* map_y)
+{
+    if (!c || eye < 0 || eye > 1 || !map_x || !map_y) { set_error("bad rectify map arguments"); return LPSLAM_HIP_ERR_INVALID; }
+    LP_HIP(hipSetDevice(c->cfg.device));
+    const int w = c->lt.w[0], h = c->lt.h[0];
+    const size_t n = (size_t)w * h;
+    // cv::remap's own conversion of CV_32FC1 maps: sx = cvRound(x * INTER_TAB_SIZE) in float, round half to even,
+    // integer part saturated to short (imgwarp.cpp, remap: "sx = cvRound(sX[x1]*INTER_TAB_SIZE)")
+    std::vector<short2> xy(n);
+    std::vector<uint16_t> frac(n);
+    for (size_t i = 0; i < n; ++i) {
+        const float fx = map_x[i] * 32.0f, fy = map_y[i] * 32.0f;
+        auto rnd = [](float v) -> int { if (!(v > -2.0e9f)) return INT32_MIN; if (!(v < 2.0e9f)) return INT32_MIN; return (int)nearbyintf(v); };   // cvRound of NaN / overflow: INT_MIN as _mm_cvtss_si32
+        const int sx = rnd(fx), sy = rnd(fy);
+        auto sat = [](int v) -> short { return (short)(v < -32768 ? -32768 : (v > 32767 ? 32767 : v)); };
+        xy[i] = make_short2(sat(sx >> 5), sat(sy >> 5));
+        frac[i] = (uint16_t)((sy & 31) * 32 + (sx & 31));
+    }
+    if (!c->d_map_xy[eye]) { LP_HIP(hipMalloc((void**)&c->d_map_xy[eye], n * sizeof(short2))); LP_HIP(hipMalloc((void**)&c->d_map_frac[eye], n * sizeof(uint16_t))); }
+    if (!c->d_raw) LP_HIP(hipMalloc((void**)&c->d_raw, n));
+    LP_HIP(hipStreamSynchronize(c->stream));              // a remap using the old map may be in flight
+    LP_HIP(hipMemcpy(c->d_map_xy[eye], xy.data(), n * sizeof(short2), hipMemcpyHostToDevice));
+    LP_HIP(hipMemcpy(c->d_map_frac[eye], frac.data(), n * sizeof(uint16_t), hipMemcpyHostToDevice));
+    return LPSLAM_HIP_OK;
+}
+
+int lpslam_hip_upload_raw_image(lpslam_hip_ctx* c, int image, int32_t eye, const uint8_t* host, int32_t stride)
+{
+    int rc = check_image(c, image); if (rc) return rc;
+    if (eye < 0 || eye > 1 || !c->d_map_xy[eye]) { set_error("no rectify map set for eye %d", eye); return LPSLAM_HIP_ERR_INVALID; }
+    if (!host || stride < c->lt.w[0]) { set_error("bad host image (stride %d < width %d)", stride, c->lt.w[0]); return LPSLAM_HIP_ERR_INVALID; }
+    LP_HIP(hipSetDevice(c->cfg.device));
+    // the staging buffer is reused by every upload: copy and remap are ordered on the context stream
+    LP_HIP(hipMemcpy2DAsync(c->d_raw, c->lt.w[0], host, stride, c->lt.w[0], c->lt.h[0], hipMemcpyHostToDevice, c->stream));
+    return lp_launch_remap(c, image, eye);
+}
+
+int lpslam_hip_remap_staged(lpslam_hip_ctx* c, int image, int32_t eye)
+{
+    int rc = check_image(c, image); if (rc) return rc;
+    if (eye < 0 || eye > 1 || !c->d_map_xy[eye] || !c->d_raw) { set_error("no rectify map / staged frame for eye %d", eye); return LPSLAM_HIP_ERR_INVALID; }
+    LP_HIP(hipSetDevice(c->cfg.device));
+    return lp_launch_remap(c, image, eye);
 }
 
 static int check_range(lpslam_hip_ctx* c, int first, int n)

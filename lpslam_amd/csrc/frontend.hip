@@ -757,6 +757,39 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const uint8_t* __r
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// K0: undistort / rectify.  cv::remap(INTER_LINEAR, BORDER_CONSTANT 0) with CV_32FC1 maps, which OpenCV first turns
+// into fixed point (sx = cvRound(map_x * 32), integer part + 5-bit fraction; done once at lpslam_hip_set_rectify_map) and
+// then interpolates with 15-bit weights (32 - fx)(32 - fy) * 32 ...: dst = (sum + 2^14) >> 15.
+// Replaces the per-frame call of /root/reference/src/Utils/ImageProcessing.h:245-249.  One thread = 4 output pixels = one
+// dword store; 6 map bytes + <= 4 gathered source bytes per pixel: HBM bound (8 B / pixel algorithmic).
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_remap(const uint8_t* __restrict__ raw, const short2* __restrict__ map_xy,
+                                               const uint16_t* __restrict__ map_frac, uint8_t* __restrict__ dst, int w, int h, int pitch)
+{
+    const int x0 = (blockIdx.x * 64 + threadIdx.x) * 4, y = blockIdx.y * 4 + threadIdx.y;
+    if (x0 >= pitch || y >= h) return;
+    uint32_t out = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int x = x0 + q;
+        uint32_t val = 0;
+        if (x < w) {
+            const short2 xy = map_xy[(size_t)y * w + x];
+            const int f = map_frac[(size_t)y * w + x], fx = f & 31, fy = f >> 5;
+            const int sx = xy.x, sy = xy.y;
+            if (!(sx >= w || sx + 1 < 0 || sy >= h || sy + 1 < 0)) {
+                auto tap = [&](int xx, int yy) -> int { return (xx >= 0 && yy >= 0 && xx < w && yy < h) ? (int)raw[(size_t)yy * w + xx] : 0; };
+                const int w00 = (32 - fx) * (32 - fy) * 32, w01 = fx * (32 - fy) * 32, w10 = (32 - fx) * fy * 32, w11 = fx * fy * 32;
+                const int sum = tap(sx, sy) * w00 + tap(sx + 1, sy) * w01 + tap(sx, sy + 1) * w10 + tap(sx + 1, sy + 1) * w11;
+                val = (uint32_t)((sum + (1 << 14)) >> 15);
+            }
+        }
+        out |= val << (8 * q);
+    }
+    *reinterpret_cast<uint32_t*>(dst + (size_t)y * pitch + x0) = out;
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // host launchers
 // ------------------------------------------------------------------------------------------------------------
 int lp_launch_pyramid(lpslam_hip_ctx* c, int first, int n_images)
@@ -765,6 +798,15 @@ int lp_launch_pyramid(lpslam_hip_ctx* c, int first, int n_images)
         dim3 block(64, 4), grid((c->lt.pitch[l] / 4 + 63) / 64, (c->lt.h[l] + 3) / 4, n_images);
         hipLaunchKernelGGL(k_pyr_down, grid, block, 0, c->stream, c->d_pyr, c->image_slab, c->lt, l, first, c->d_rs_ofs, c->d_rs_coef);
     }
+    LP_HIP(hipGetLastError());
+    return LPSLAM_HIP_OK;
+}
+
+int lp_launch_remap(lpslam_hip_ctx* c, int image, int eye)
+{
+    dim3 block(64, 4), grid((c->lt.pitch[0] / 4 + 63) / 64, (c->lt.h[0] + 3) / 4);
+    hipLaunchKernelGGL(k_remap, grid, block, 0, c->stream, c->d_raw, c->d_map_xy[eye], c->d_map_frac[eye],
+                       c->d_pyr + (size_t)image * c->image_slab, c->lt.w[0], c->lt.h[0], c->lt.pitch[0]);
     LP_HIP(hipGetLastError());
     return LPSLAM_HIP_OK;
 }

@@ -79,6 +79,10 @@ struct lpslam_hip_ctx {
     float* d_stereo = nullptr;         // [max_images][2][slots_per_image] x_right, depth
     int32_t* d_stereo_idx = nullptr;   // [max_images][slots_per_image]
     int32_t* d_stereo_corr = nullptr;  // [max_images][slots_per_image]
+    // on-device undistort / rectify: per eye the fixed-point map (cv::convertMaps form) and one raw-frame staging buffer
+    short2* d_map_xy[2] = {nullptr, nullptr};      // [h][w] integer source coordinate (sx >> 5, sy >> 5)
+    uint16_t* d_map_frac[2] = {nullptr, nullptr};  // [h][w] (sy & 31) * 32 + (sx & 31)
+    uint8_t* d_raw = nullptr;                      // [h][w] distorted frame of the upload in flight
     // staging for *_host convenience calls
     uint8_t* d_tmp_desc = nullptr; size_t tmp_desc_bytes = 0;
     int32_t* d_tmp_res = nullptr;  size_t tmp_res_bytes = 0;
@@ -88,6 +92,7 @@ struct lpslam_hip_ctx {
 
 // kernel launchers (frontend.hip / match.hip)
 int lp_launch_pyramid(lpslam_hip_ctx* c, int first, int n_images);
+int lp_launch_remap(lpslam_hip_ctx* c, int image, int eye);
 int lp_launch_fast(lpslam_hip_ctx* c, int first, int n_images);
 int lp_launch_distribute(lpslam_hip_ctx* c, int first, int n_images);
 int lp_launch_describe(lpslam_hip_ctx* c, int first, int n_images);

@@ -27,7 +27,7 @@ BA_LOG_DTYPE = np.dtype([("chi2_before", "<f8"), ("chi2_after", "<f8"), ("lambda
 SYMBOLS = [
     "lpslam_hip_last_error", "lpslam_hip_device_count", "lpslam_hip_create", "lpslam_hip_destroy",
     "lpslam_hip_stream", "lpslam_hip_sync", "lpslam_hip_timer_begin", "lpslam_hip_timer_end", "lpslam_hip_timer_read", "lpslam_hip_level_info", "lpslam_hip_max_keypoints_per_image",
-    "lpslam_hip_image_ptr", "lpslam_hip_upload_image", "lpslam_hip_extract", "lpslam_hip_extract_range", "lpslam_hip_stage_pyramid",
+    "lpslam_hip_image_ptr", "lpslam_hip_upload_image", "lpslam_hip_set_rectify_map", "lpslam_hip_upload_raw_image", "lpslam_hip_remap_staged", "lpslam_hip_extract", "lpslam_hip_extract_range", "lpslam_hip_stage_pyramid",
     "lpslam_hip_stage_fast", "lpslam_hip_stage_distribute", "lpslam_hip_stage_describe",
     "lpslam_hip_keypoint_count", "lpslam_hip_get_keypoints", "lpslam_hip_get_pyramid_level",
     "lpslam_hip_get_candidates", "lpslam_hip_keypoint_buffers", "lpslam_hip_match_bf", "lpslam_hip_get_bf_knn2",
@@ -145,6 +145,20 @@ class Context:
         assert arr.shape == (self.cfg.height, self.cfg.width), arr.shape
         _check(self.lib.lpslam_hip_upload_image(self.h, image, _p(arr), arr.shape[1]))
         self.sync()      # host array may be freed by the caller
+
+    def set_rectify_map(self, eye, map_x, map_y):
+        mx = np.ascontiguousarray(map_x, np.float32); my = np.ascontiguousarray(map_y, np.float32)
+        assert mx.shape == (self.cfg.height, self.cfg.width) and my.shape == mx.shape
+        _check(self.lib.lpslam_hip_set_rectify_map(self.h, int(eye), _p(mx), _p(my)))
+
+    def upload_raw(self, image, eye, arr):
+        arr = np.ascontiguousarray(arr, np.uint8)
+        assert arr.shape == (self.cfg.height, self.cfg.width), arr.shape
+        _check(self.lib.lpslam_hip_upload_raw_image(self.h, image, int(eye), _p(arr), arr.shape[1]))
+        self.sync()
+
+    def remap_staged(self, image, eye):
+        _check(self.lib.lpslam_hip_remap_staged(self.h, image, int(eye)))
 
     def extract(self, n_images):
         _check(self.lib.lpslam_hip_extract(self.h, n_images))

@@ -1,5 +1,6 @@
 // hip_tracker.cpp -- see hip_tracker.h.  Host-side tracking glue around the HIP C ABI (the arithmetic runs on the GPU).
 #include "hip_tracker.h"
+#include "rectify.h"
 
 #include <algorithm>
 #include <cmath>
@@ -99,9 +100,19 @@ bool HipVslamTrackerBase::startContext(bool stereo)
     if (!left) { logMessage(LpSlamLogLevel_Error, "Cannot load camera configuration for camera with number 0"); return false; }
     if (stereo && !reg->getConfiguration(1)) { logMessage(LpSlamLogLevel_Error, "Cannot load camera configuration for right camera with number 1"); return false; }
     m_cam = *left;
-    if (m_cam.distortion_function != LpSlamCameraDistortionFunction_NoDistortion) {
-        logMessage(LpSlamLogLevel_Error, "Camera distortion not supported: on-device rectification is not implemented; feed rectified frames (no_distortion)");
-        return false;
+    // ImageProcessing::Undistort (reference: src/Utils/ImageProcessing.h:134-250): the maps are built once from the camera
+    // pair and every frame is remapped -- here on the device (lpslam_hip_upload_raw_image).  The reference does this for the
+    // stereo tracker only (src/Trackers/OpenVSLAMStereoTracker.cpp:198-213); the monocular one feeds frames as they come.
+    m_rectify = stereo && m_cam.distortion_function != LpSlamCameraDistortionFunction_NoDistortion;
+    RectifyMaps maps[2];
+    if (m_rectify) {
+        auto right = reg->getConfiguration(1);
+        std::string err;
+        for (int eye = 0; eye < 2; ++eye)
+            if (!build_rectify_maps(*left, *right, eye == 0, maps[eye], &err)) {
+                logMessage(LpSlamLogLevel_Error, "Cannot build the rectification maps: " + err);
+                return false;
+            }
     }
     if (m_cam.resolution_x <= 0 || m_cam.resolution_y <= 0 || !(m_cam.f_x > 0) || (stereo && !(m_cam.focal_x_baseline > 0))) {
         logMessage(LpSlamLogLevel_Error, "Camera configuration incomplete (resolution, focal length, focal_x_baseline)");
@@ -116,6 +127,12 @@ bool HipVslamTrackerBase::startContext(bool stereo)
         m_ctx = nullptr;
         return false;
     }
+    for (int eye = 0; m_rectify && eye < 2; ++eye)
+        if (lpslam_hip_set_rectify_map(m_ctx, eye, maps[eye].map_x.data(), maps[eye].map_y.data()) != LPSLAM_HIP_OK) {
+            logMessage(LpSlamLogLevel_Error, std::string("Cannot upload the rectification maps: ") + lpslam_hip_last_error());
+            lpslam_hip_destroy(m_ctx); m_ctx = nullptr;
+            return false;
+        }
     m_maxKp = lpslam_hip_max_keypoints_per_image(m_ctx);
     m_stereo = stereo;
     m_state = TrackerState::NotInitialized;
@@ -348,8 +365,14 @@ TrackerBase::ProcessImageResult HipVslamTrackerBase::trackFrame(CameraQueueEntry
 
     FrameData cur;
     cur.slot = (int)(m_imageTracked % 2) * 2;
-    bool ok = lpslam_hip_upload_image(m_ctx, cur.slot, cam.image.pixels.data(), cam.image.width) == LPSLAM_HIP_OK;
-    if (ok && stereo) ok = lpslam_hip_upload_image(m_ctx, cur.slot + 1, cam.image_second->pixels.data(), cam.image.width) == LPSLAM_HIP_OK;
+    bool ok;
+    if (m_rectify) {       // raw frames: undistort + rectify on the device
+        ok = lpslam_hip_upload_raw_image(m_ctx, cur.slot, 0, cam.image.pixels.data(), cam.image.width) == LPSLAM_HIP_OK;
+        if (ok && stereo) ok = lpslam_hip_upload_raw_image(m_ctx, cur.slot + 1, 1, cam.image_second->pixels.data(), cam.image.width) == LPSLAM_HIP_OK;
+    } else {
+        ok = lpslam_hip_upload_image(m_ctx, cur.slot, cam.image.pixels.data(), cam.image.width) == LPSLAM_HIP_OK;
+        if (ok && stereo) ok = lpslam_hip_upload_image(m_ctx, cur.slot + 1, cam.image_second->pixels.data(), cam.image.width) == LPSLAM_HIP_OK;
+    }
     if (ok) ok = lpslam_hip_extract_range(m_ctx, cur.slot, stereo ? 2 : 1) == LPSLAM_HIP_OK;
     if (ok && stereo) {
         const float baseline = (float)(m_cam.focal_x_baseline / m_cam.f_x);

@@ -70,7 +70,7 @@ protected:
     std::mutex m_slamLock;
     lpslam_hip_ctx* m_ctx = nullptr;
     LpSlamCameraConfiguration m_cam{};
-    bool m_started = false, m_stereo = false;
+    bool m_started = false, m_stereo = false, m_rectify = false;
     TrackerState m_state = TrackerState::NotInitialized;
     std::optional<TimeStamp> m_firstImageTimestamp;
     uint64_t m_imageTracked = 0;

@@ -52,6 +52,7 @@ RECON_CB = C.CFUNCTYPE(None, C.POINTER(GlobalStateInTime), C.c_void_p)
 NAV_CB = C.CFUNCTYPE(C.c_int, ROSTimestamp, C.POINTER(GlobalStateInTime), C.POINTER(GlobalStateInTime), C.c_void_p)
 
 STEREO_TWO_BUFFER, FORMAT_8UC1, FORMAT_8UC3, NO_DISTORTION, ODOM_ONLY = 3, 1, 2, 3, 1
+PINHOLE, FISHEYE, OMNI = 0, 1, 2          # LpSlamCameraDistortionFunction
 _lib = None
 
 
