@@ -141,8 +141,6 @@ static int ctx_alloc(lpslam_hip_ctx* c)
     LP_HIP(hipMalloc((void**)&c->d_cand_key, B * c->cand_per_image * sizeof(uint32_t)));
     LP_HIP(hipMalloc((void**)&c->d_cand_node, B * c->cand_per_image * sizeof(uint32_t)));
     LP_HIP(hipMalloc((void**)&c->d_cand_count, B * L * sizeof(int32_t)));
-    LP_HIP(hipMalloc((void**)&c->d_node_box, B * L * 2 * (size_t)c->node_cap * sizeof(uint2)));
-    LP_HIP(hipMalloc((void**)&c->d_node_cnt, B * L * 2 * (size_t)c->node_cap * sizeof(int32_t)));
     LP_HIP(hipMalloc((void**)&c->d_sel_key, B * c->slots_per_image * sizeof(uint32_t)));
     LP_HIP(hipMalloc((void**)&c->d_sel_count, B * L * sizeof(int32_t)));
     LP_HIP(hipMalloc((void**)&c->d_kpts, B * c->slots_per_image * sizeof(lpslam_hip_keypoint)));
@@ -186,12 +184,10 @@ int lpslam_hip_create(const lpslam_hip_frontend_config* cfg, lpslam_hip_ctx** ou
     c->cells_per_image = c->lt.cell_start[L];
     c->cand_per_image = c->lt.cand_start[L];
     c->slots_per_image = c->lt.slot_start[L];
-    int qmax = 0; size_t lds = 0;
+    size_t lds = 0;
     for (int l = 0; l < L; ++l) {
-        qmax = std::max(qmax, c->lt.qcap[l]);
         lds = std::max(lds, lp_distribute_lds_bytes(c->lt.qcap[l], c->lt.cells_x[l] * c->lt.cells_y[l]));
     }
-    c->node_cap = qmax;
     c->distribute_lds = lds;
     if (lds > 160 * 1024) { set_error("distribution kernel needs %zu B of LDS (> 160 KiB)", lds); delete c; return LPSLAM_HIP_ERR_INVALID; }
 
@@ -220,7 +216,7 @@ void lpslam_hip_destroy(lpslam_hip_ctx* c)
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void* bufs[] = {c->d_pyr, c->d_rs_ofs, c->d_rs_coef, c->d_cell_keys, c->d_cell_count, c->d_cand_key, c->d_cand_node,
-                    c->d_cand_count, c->d_node_box, c->d_node_cnt, c->d_sel_key, c->d_sel_count, c->d_kpts, c->d_desc,
+                    c->d_cand_count, c->d_sel_key, c->d_sel_count, c->d_kpts, c->d_desc,
                     c->d_kp_count, c->d_bf, c->d_stereo, c->d_stereo_idx, c->d_stereo_corr, c->d_tmp_desc, c->d_tmp_res,
                     c->d_map_xy[0], c->d_map_xy[1], c->d_map_frac[0], c->d_map_frac[1], c->d_raw};
     for (void* b : bufs) if (b) (void)hipFree(b);

@@ -252,22 +252,6 @@ __device__ void block_scan_array(int* a, int n, int* wave_tot, int* total)
 // count; ping-pong) live in LDS.  A pass therefore touches HBM/L2 only for the overflow candidates.
 #define DIST_CPT 24
 
-// (kept for reference) LDS histogram increment with wave-level aggregation: lanes that hit the same counter are counted with one ballot and one
-// atomic.  Corners arrive in cell order, so neighbouring lanes almost always share a quad-tree node while the tree is small;
-// un-aggregated, 24 k same-address LDS atomics serialise (64 cycles per wave instruction).  key < 0: lane inactive.
-__device__ __forceinline__ void hist_add_aggregated(int* counters, int key)
-{
-    const int lane = threadIdx.x & 63;
-    unsigned long long active = __ballot(key >= 0);
-    while (active) {
-        const int leader = __ffsll((long long)active) - 1;
-        const int k0 = __shfl(key, leader);
-        const unsigned long long same = __ballot(key == k0);
-        if (lane == leader) atomicAdd(&counters[k0], __popcll(same));
-        active &= ~same;
-    }
-}
-
 __global__ __launch_bounds__(1024) void k_distribute(LevelTable lt, const uint32_t* __restrict__ cell_keys,
                                                      const int32_t* __restrict__ cell_count, int cells_per_image,
                                                      uint32_t* __restrict__ cand_key, uint32_t* __restrict__ cand_node,

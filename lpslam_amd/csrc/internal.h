@@ -65,9 +65,6 @@ struct lpslam_hip_ctx {
     uint32_t* d_cand_key = nullptr;    // [max_images][cand_per_image]
     uint32_t* d_cand_node = nullptr;   // [max_images][cand_per_image]
     int32_t* d_cand_count = nullptr;   // [max_images][levels]
-    uint2* d_node_box = nullptr;       // [max_images][levels][2][4*(quota_max+4)]
-    int32_t* d_node_cnt = nullptr;
-    int node_cap = 0;
     uint32_t* d_sel_key = nullptr;     // [max_images][slots_per_image] selected corners (level slots)
     int32_t* d_sel_count = nullptr;    // [max_images][levels]
     // final keypoints

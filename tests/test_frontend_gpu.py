@@ -24,7 +24,7 @@ def _run(hiplib, img, kpts, levels, scale=1.2, ini=20, mn=7):
     return ctx
 
 
-@pytest.mark.parametrize("w,h,kpts,levels", [(160, 120, 150, 3), (333, 251, 400, 4), (640, 480, 1000, 8), (1280, 720, 2000, 8)])
+@pytest.mark.parametrize("w,h,kpts,levels", [(160, 120, 150, 3), (333, 251, 400, 4), (640, 480, 1000, 8), (1280, 720, 2000, 8), (1920, 1080, 2000, 8)])
 def test_extract_parity(hiplib, oracle, w, h, kpts, levels):
     img = synth.random_image(w, h, seed=w)
     p = oracle.params(kpts, 1.2, levels)
