@@ -207,6 +207,26 @@ int lpslam_hip_ba_step_end(lpslam_hip_ba* ba, int32_t* accepted, int32_t* iterat
 /* Control state after the last optimize / step_end: finished outer iterations, g2o "Terminate", lambda, robust chi2. */
 int lpslam_hip_ba_status(lpslam_hip_ba* ba, int32_t* outer_done, int32_t* stopped, double* lambda, double* chi2);
 
+/* ---- projection matching ---------------------------------------------------------------------------------------------
+ * [UPSTREAM] match::projection::match_frame_and_landmarks (local-map tracking) and match_current_and_last_frames (motion-model
+ * tracking), which openvslam::system runs inside feed_stereo_frame / feed_monocular_frame
+ * (reference call sites: src/Trackers/OpenVSLAMStereoTracker.cpp:293-295, src/Trackers/OpenVSLAMTracker.cpp:120).
+ * Query k = predicted pixel position, predicted right-image x (< 0: none), search radius (margin x scale factor of the
+ * predicted level) and level range (-1: open) + its 32-byte descriptor.  Queries are matched IN ORDER against the keypoints of
+ * image slot `image`: a keypoint taken by an earlier query (or flagged in `taken`, may be NULL) is invisible to later ones;
+ * best distance <= hamming_thr; Lowe ratio only between candidates of the same level.  use_stereo != 0 applies the right-image
+ * check against the slot's last stereo match.  match_idx[k] = keypoint index or -1. */
+typedef struct lpslam_hip_proj_query {
+    float x, y, x_right, radius;
+    int32_t min_level, max_level;
+} lpslam_hip_proj_query;
+int lpslam_hip_match_projection(lpslam_hip_ctx* ctx, int image, const lpslam_hip_proj_query* queries, const uint8_t* q_desc32, int32_t nq,
+                                int32_t hamming_thr, float lowe_ratio, const uint8_t* taken, int32_t use_stereo,
+                                int32_t* match_idx, int32_t* match_dist, int32_t* n_matches);
+/* match::angle_checker: drops the matches whose angle difference (query - keypoint, degrees) lies outside the three most
+ * populated 30-degree bins.  Host-side (a few thousand matches). */
+int lpslam_hip_match_orientation_filter(const float* angle_q, const float* angle_t, int32_t* match_idx, int32_t nq, int32_t* n_kept);
+
 /* ---- Sim3 pose graph ---------------------------------------------------------------------------------------------
  * Replaces what openvslam::system runs on its global-optimisation thread after a loop closure while the loop detector
  * is enabled (reference: src/Trackers/OpenVSLAMTrackerBase.cpp:250-255): [UPSTREAM] optimize::graph_optimizer on

@@ -6,6 +6,9 @@
 // stereo parameters: focal_x_baseline (src/Trackers/OpenVSLAMTrackerBase.cpp:188-190, src/Interface/LpSlamTypes.h:219-222).
 // Integer work (xor + popcount + argmin) is bit-exact; the few float operations are written without contraction.
 #include "internal.h"
+#include <vector>
+#include <algorithm>
+#include <cmath>
 
 #pragma clang fp contract(off)
 
@@ -247,6 +250,74 @@ int lp_launch_stereo_strided(lpslam_hip_ctx* c, int left0, int right0, int strid
 // ------------------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------------------------
+// K8  projection matching ([UPSTREAM] match::projection::match_frame_and_landmarks / match_current_and_last_frames).
+//     One wavefront per query: lanes stride over the image's keypoints, test the search window (|dx|, |dy| < radius, level
+//     range, right-image x), compute the Hamming distance and keep their four smallest keys; the wavefront then merges them
+//     into the query's four best candidates.  key = distance << 32 | grid cell << 20 | index << 4 | level, so "smallest key"
+//     is upstream's "first strictly smaller distance in cell-scan order" (64 x 48 grid, column-major, index inside a cell).
+//     `taken` keypoints are skipped before any distance is computed.  The sequential part of the algorithm (a keypoint
+//     taken by an earlier query is invisible to later ones) is replayed on the host over these short lists.
+// ------------------------------------------------------------------------------------------------------------
+struct ProjQuery { float x, y, x_right, radius; int min_level, max_level; };
+
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
+{
+    for (int o = 32; o > 0; o >>= 1) { const unsigned long long t = __shfl_xor(v, o); v = t < v ? t : v; }
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_proj_topk(const lpslam_hip_keypoint* __restrict__ kp, const uint8_t* __restrict__ desc,
+                                                   const float* __restrict__ stereo_xr, const int32_t* __restrict__ kp_count,
+                                                   const ProjQuery* __restrict__ queries, const uint8_t* __restrict__ q_desc,
+                                                   const int* __restrict__ q_ids, int nq, const uint8_t* __restrict__ taken,
+                                                   float inv_w, float inv_h, unsigned long long* __restrict__ out_keys, int* __restrict__ out_count)
+{
+    const int lane = threadIdx.x & 63, qslot = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (qslot >= nq) return;
+    const int qi = q_ids ? q_ids[qslot] : qslot;
+    const ProjQuery q = queries[qi];
+    const uint32_t* qd = reinterpret_cast<const uint32_t*>(q_desc + 32 * (size_t)qi);
+    uint32_t a[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] = qd[k];
+    const int n = *kp_count;
+    const unsigned long long NONE = ~0ull;
+    unsigned long long top[4] = {NONE, NONE, NONE, NONE};
+    int cnt = 0;
+    for (int i = lane; i < n; i += 64) {
+        const lpslam_hip_keypoint k = kp[i];
+        if (!(fabsf(k.x - q.x) < q.radius && fabsf(k.y - q.y) < q.radius)) continue;
+        if (q.min_level >= 0 && k.octave < q.min_level) continue;
+        if (q.max_level >= 0 && k.octave > q.max_level) continue;
+        if (taken && taken[i]) continue;
+        if (stereo_xr) { const float xr = stereo_xr[i]; if (0 < xr && q.x_right >= 0 && q.radius < fabsf(q.x_right - xr)) continue; }
+        const uint32_t* d = reinterpret_cast<const uint32_t*>(desc + 32 * (size_t)i);
+        int dist = 0;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) dist += __popc(a[w] ^ d[w]);
+        int cx = (int)floorf(k.x * inv_w), cy = (int)floorf(k.y * inv_h);
+        cx = min(max(cx, 0), 63); cy = min(max(cy, 0), 47);
+        unsigned long long key = ((unsigned long long)dist << 32) | ((unsigned long long)(cx * 48 + cy) << 20) | ((unsigned long long)i << 4) | (unsigned)k.octave;
+        ++cnt;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) if (key < top[t]) { const unsigned long long tmp = top[t]; top[t] = key; key = tmp; }     // sorted insert
+    }
+    for (int o2 = 32; o2 > 0; o2 >>= 1) cnt += __shfl_xor(cnt, o2);
+    unsigned long long res[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const unsigned long long m = wave_min_u64(top[0]);
+        res[r] = m;
+        if (top[0] == m && m != NONE) { top[0] = top[1]; top[1] = top[2]; top[2] = top[3]; top[3] = NONE; }      // keys are unique (index bits)
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out_keys[4 * (size_t)qslot + r] = res[r];
+        out_count[qslot] = cnt;
+    }
+}
+
 extern "C" {
 
 static int chk(lpslam_hip_ctx* c, int a, int b)
@@ -343,6 +414,112 @@ int lpslam_hip_get_stereo(lpslam_hip_ctx* c, int left, float* stereo_x_right, fl
     if (n && depths) LP_HIP(hipMemcpyAsync(depths, f + c->slots_per_image, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     if (n && best_right_idx) LP_HIP(hipMemcpyAsync(best_right_idx, c->d_stereo_idx + (size_t)left * c->slots_per_image, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     LP_HIP(hipStreamSynchronize(c->stream));
+    return LPSLAM_HIP_OK;
+}
+
+// ---- projection matching: device top-4 per query + the sequential replay ------------------------------------------------------
+int lpslam_hip_match_projection(lpslam_hip_ctx* c, int image, const lpslam_hip_proj_query* queries, const uint8_t* q_desc32, int32_t nq,
+                                int32_t hamming_thr, float lowe_ratio, const uint8_t* taken_in, int32_t use_stereo,
+                                int32_t* match_idx, int32_t* match_dist, int32_t* n_matches)
+{
+    int rc = chk(c, image, image); if (rc) return rc;
+    if (nq < 0 || (nq > 0 && (!queries || !q_desc32 || !match_idx))) { set_error("bad projection-match arguments"); return LPSLAM_HIP_ERR_INVALID; }
+    static_assert(sizeof(lpslam_hip_proj_query) == sizeof(ProjQuery), "query layout");
+    if (n_matches) *n_matches = 0;
+    if (nq == 0) return LPSLAM_HIP_OK;
+    int32_t n_kp = 0;
+    rc = lpslam_hip_keypoint_count(c, image, &n_kp); if (rc) return rc;
+    hipStream_t s = c->stream;
+    const size_t o = (size_t)image * c->slots_per_image;
+    ProjQuery* d_q = nullptr; uint8_t* d_qd = nullptr; uint8_t* d_taken = nullptr; unsigned long long* d_keys = nullptr; int* d_cnt = nullptr; int* d_ids = nullptr;
+    auto release = [&]() { for (void* p : {(void*)d_q, (void*)d_qd, (void*)d_taken, (void*)d_keys, (void*)d_cnt, (void*)d_ids}) if (p) (void)hipFree(p); };
+#define P_HIP(x) do { if ((x) != hipSuccess) { release(); set_error("HIP call failed: %s", #x); return LPSLAM_HIP_ERR_DEVICE; } } while (0)
+    P_HIP(hipMalloc((void**)&d_q, (size_t)nq * sizeof(ProjQuery)));
+    P_HIP(hipMalloc((void**)&d_qd, (size_t)nq * 32));
+    P_HIP(hipMalloc((void**)&d_taken, (size_t)std::max(n_kp, 1)));
+    P_HIP(hipMalloc((void**)&d_keys, (size_t)nq * 4 * sizeof(unsigned long long)));
+    P_HIP(hipMalloc((void**)&d_cnt, (size_t)nq * sizeof(int)));
+    P_HIP(hipMalloc((void**)&d_ids, sizeof(int)));
+    std::vector<uint8_t> taken((size_t)std::max(n_kp, 1), 0);
+    if (taken_in) std::copy(taken_in, taken_in + n_kp, taken.begin());
+    P_HIP(hipMemcpyAsync(d_q, queries, (size_t)nq * sizeof(ProjQuery), hipMemcpyHostToDevice, s));
+    P_HIP(hipMemcpyAsync(d_qd, q_desc32, (size_t)nq * 32, hipMemcpyHostToDevice, s));
+    P_HIP(hipMemcpyAsync(d_taken, taken.data(), taken.size(), hipMemcpyHostToDevice, s));
+    const float inv_w = (float)(64.0 / c->lt.w[0]), inv_h = (float)(48.0 / c->lt.h[0]);
+    const float* sxr = use_stereo ? c->d_stereo + (size_t)image * 2 * c->slots_per_image : nullptr;
+    hipLaunchKernelGGL(k_proj_topk, dim3((nq + 3) / 4), dim3(256), 0, s, c->d_kpts + o, c->d_desc + o * 32, sxr, c->d_kp_count + image,
+                       d_q, d_qd, (const int*)nullptr, nq, d_taken, inv_w, inv_h, d_keys, d_cnt);
+    P_HIP(hipGetLastError());
+    std::vector<unsigned long long> keys((size_t)nq * 4);
+    std::vector<int> cnt((size_t)nq);
+    P_HIP(hipMemcpyAsync(keys.data(), d_keys, keys.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    P_HIP(hipMemcpyAsync(cnt.data(), d_cnt, cnt.size() * sizeof(int), hipMemcpyDeviceToHost, s));
+    P_HIP(hipStreamSynchronize(s));
+    int found = 0;
+    for (int k = 0; k < nq; ++k) {
+        match_idx[k] = -1;
+        if (match_dist) match_dist[k] = 256;
+        unsigned long long cand[4] = {keys[4 * (size_t)k], keys[4 * (size_t)k + 1], keys[4 * (size_t)k + 2], keys[4 * (size_t)k + 3]};
+        auto free_ones = [&](unsigned long long* out) { int m = 0; for (int r = 0; r < 4; ++r) if (cand[r] != ~0ull && !taken[(size_t)((cand[r] >> 4) & 0xffff)]) out[m++] = cand[r]; return m; };
+        unsigned long long fr[4];
+        int m = free_ones(fr);
+        if (m < 2 && cnt[k] > 4) {
+            // the short list was eaten by earlier queries: scan again for this query with the current assignment
+            P_HIP(hipMemcpyAsync(d_taken, taken.data(), taken.size(), hipMemcpyHostToDevice, s));
+            P_HIP(hipMemcpyAsync(d_ids, &k, sizeof(int), hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(k_proj_topk, dim3(1), dim3(256), 0, s, c->d_kpts + o, c->d_desc + o * 32, sxr, c->d_kp_count + image,
+                               d_q, d_qd, (const int*)d_ids, 1, d_taken, inv_w, inv_h, d_keys, d_cnt);
+            P_HIP(hipGetLastError());
+            P_HIP(hipMemcpyAsync(cand, d_keys, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+            P_HIP(hipStreamSynchronize(s));
+            m = free_ones(fr);
+        }
+        if (m == 0) continue;
+        const int best = (int)(fr[0] >> 32), best_idx = (int)((fr[0] >> 4) & 0xffff), best_lvl = (int)(fr[0] & 15);
+        const int second = m > 1 ? (int)(fr[1] >> 32) : 256, second_lvl = m > 1 ? (int)(fr[1] & 15) : -1;
+        if (best > hamming_thr) continue;
+        if (best_lvl == second_lvl && (float)best > lowe_ratio * (float)second) continue;
+        match_idx[k] = best_idx;
+        if (match_dist) match_dist[k] = best;
+        taken[(size_t)best_idx] = 1;
+        ++found;
+    }
+#undef P_HIP
+    release();
+    if (n_matches) *n_matches = found;
+    return LPSLAM_HIP_OK;
+}
+
+int lpslam_hip_match_orientation_filter(const float* angle_q, const float* angle_t, int32_t* match_idx, int32_t nq, int32_t* n_kept)
+{
+    if (nq < 0 || (nq > 0 && (!angle_q || !angle_t || !match_idx))) { set_error("bad orientation-filter arguments"); return LPSLAM_HIP_ERR_INVALID; }
+    constexpr int HL = 30;                       // match::angle_checker: bin = round(delta / 30), three best bins survive
+    int hist[HL + 1] = {0};
+    std::vector<int> bin_of((size_t)std::max(nq, 1), -1);
+    for (int k = 0; k < nq; ++k) {
+        if (match_idx[k] < 0) continue;
+        float rot = angle_q[k] - angle_t[match_idx[k]];
+        if (rot < 0.0f) rot += 360.0f;
+        if (360.0f <= rot) rot -= 360.0f;
+        int b = (int)lrintf(rot * (1.0f / HL));
+        if (b == HL) b = 0;
+        bin_of[k] = b; hist[b]++;
+    }
+    int i1 = -1, i2 = -1, i3 = -1, m1 = 0, m2 = 0, m3 = 0;
+    for (int b = 0; b < HL; ++b) {
+        const int sz = hist[b];
+        if (sz > m1) { m3 = m2; m2 = m1; m1 = sz; i3 = i2; i2 = i1; i1 = b; }
+        else if (sz > m2) { m3 = m2; m2 = sz; i3 = i2; i2 = b; }
+        else if (sz > m3) { m3 = sz; i3 = b; }
+    }
+    if (m2 < 0.1f * (float)m1) { i2 = -1; i3 = -1; }
+    else if (m3 < 0.1f * (float)m1) i3 = -1;
+    int kept = 0;
+    for (int k = 0; k < nq; ++k) {
+        if (match_idx[k] < 0) continue;
+        if (bin_of[k] == i1 || bin_of[k] == i2 || bin_of[k] == i3) ++kept; else match_idx[k] = -1;
+    }
+    if (n_kept) *n_kept = kept;
     return LPSLAM_HIP_OK;
 }
 

@@ -20,6 +20,7 @@ BA_OBS_DTYPE = np.dtype([("pose", "<i4"), ("point", "<i4"), ("u", "<f8"), ("v", 
 SIM3_EDGE_DTYPE = np.dtype([("i", "<i4"), ("j", "<i4"), ("meas", "<f8", (8,))])
 SIM3_PAIR_DTYPE = np.dtype([("p1c", "<f8", (3,)), ("p2c", "<f8", (3,)), ("obs1", "<f8", (2,)), ("obs2", "<f8", (2,)),
                             ("inv_sigma2_1", "<f8"), ("inv_sigma2_2", "<f8")])
+PROJ_QUERY_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("x_right", "<f4"), ("radius", "<f4"), ("min_level", "<i4"), ("max_level", "<i4")])
 BA_LOG_DTYPE = np.dtype([("chi2_before", "<f8"), ("chi2_after", "<f8"), ("lambda", "<f8"),
                          ("trials", "<i4"), ("status", "<i4")])
 
@@ -33,6 +34,7 @@ SYMBOLS = [
     "lpslam_hip_get_candidates", "lpslam_hip_keypoint_buffers", "lpslam_hip_match_bf", "lpslam_hip_get_bf_knn2",
     "lpslam_hip_get_bf_matches", "lpslam_hip_match_bf_strided", "lpslam_hip_set_descriptors",
     "lpslam_hip_match_stereo", "lpslam_hip_match_stereo_strided", "lpslam_hip_get_stereo",
+    "lpslam_hip_match_projection", "lpslam_hip_match_orientation_filter",
     "lpslam_hip_ba_create", "lpslam_hip_ba_destroy", "lpslam_hip_ba_set_active", "lpslam_hip_ba_optimize",
     "lpslam_hip_ba_local", "lpslam_hip_ba_set_points_fixed", "lpslam_hip_ba_pose_optimize", "lpslam_hip_ba_reset", "lpslam_hip_ba_get", "lpslam_hip_ba_chi2", "lpslam_hip_ba_reduced_buffer",
     "lpslam_hip_ba_step_begin", "lpslam_hip_ba_step_lambda0", "lpslam_hip_ba_step_solve", "lpslam_hip_ba_scalar_buffer", "lpslam_hip_ba_step_end", "lpslam_hip_ba_status",
@@ -156,6 +158,17 @@ class Context:
         assert arr.shape == (self.cfg.height, self.cfg.width), arr.shape
         _check(self.lib.lpslam_hip_upload_raw_image(self.h, image, int(eye), _p(arr), arr.shape[1]))
         self.sync()
+
+    def match_projection(self, image, queries, q_desc, hamming_thr=100, lowe_ratio=0.8, taken=None, use_stereo=False):
+        q = np.ascontiguousarray(queries, PROJ_QUERY_DTYPE); d = np.ascontiguousarray(q_desc, np.uint8)
+        assert d.shape == (len(q), 32)
+        t = np.ascontiguousarray(taken, np.uint8) if taken is not None else None
+        idx = np.full(max(len(q), 1), -1, np.int32); dist = np.zeros(max(len(q), 1), np.int32); n = C.c_int32()
+        f = self.lib.lpslam_hip_match_projection
+        f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_int32,
+                      C.c_void_p, C.c_void_p, C.c_void_p]
+        _check(f(self.h, image, _p(q), _p(d), len(q), int(hamming_thr), float(lowe_ratio), _p(t), int(use_stereo), _p(idx), _p(dist), C.byref(n)))
+        return idx[:len(q)].copy(), dist[:len(q)].copy(), n.value
 
     def remap_staged(self, image, eye):
         _check(self.lib.lpslam_hip_remap_staged(self.h, image, int(eye)))
@@ -380,3 +393,10 @@ def sim3_transform_optimize(ctx, s12, pairs_list, cam1, cam2, chi_sq=10.0, fix_s
     f.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int32, C.c_void_p, C.c_void_p]
     _check(f(ctx.h, n, _p(s), _p(pairs), _p(start), _p(c1), _p(c2), float(chi_sq), int(fix_scale), _p(inl), _p(cnt)))
     return s, [inl[start[i]:start[i + 1]].astype(bool) for i in range(n)], cnt[:n].copy()
+
+
+def match_orientation_filter(angle_q, angle_t, match_idx):
+    aq = np.ascontiguousarray(angle_q, np.float32); at = np.ascontiguousarray(angle_t, np.float32)
+    m = np.ascontiguousarray(match_idx, np.int32).copy(); n = C.c_int32()
+    _check(load().lpslam_hip_match_orientation_filter(_p(aq), _p(at), _p(m), len(m), C.byref(n)))
+    return m, n.value

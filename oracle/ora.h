@@ -99,6 +99,17 @@ int ora_match_stereo(const uint8_t* const* pyr_l, const uint8_t* const* pyr_r,
                      float focal_x_baseline, float true_baseline,
                      float* stereo_x_right, float* depths, int32_t* best_right_idx);
 
+/* projection matching (match::projection): query = predicted position, right-image x (< 0: none), search radius (margin x
+ * scale factor of the predicted level) and level range (-1: open) */
+typedef struct {
+    float x, y, x_right, radius;
+    int32_t min_level, max_level;
+} ora_proj_query;
+int ora_match_projection(const ora_keypoint* kp, const uint8_t* desc, const float* stereo_x_right, int n_kp, int width, int height,
+                         const ora_proj_query* q, const uint8_t* q_desc, int nq, int hamming_thr, float lowe_ratio,
+                         uint8_t* taken, int32_t* match_idx, int32_t* match_dist);
+int ora_match_orientation_filter(const float* angle_q, const float* angle_t, int32_t* match_idx, int nq);
+
 /* ---- bundle adjustment ---------------------------------------------------------------------- */
 typedef struct {
     int32_t pose;      /* index into poses   */

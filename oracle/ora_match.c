@@ -184,3 +184,104 @@ int ora_match_stereo(const uint8_t* const* pyr_l, const uint8_t* const* pyr_r,
     free(corr); free(row_cnt); free(row_ofs); free(row_idx);
     return valid;
 }
+
+/* ---- projection matching --------------------------------------------------------------------------------------------
+ * [UPSTREAM] OpenVSLAM match::projection::match_frame_and_landmarks (local-map tracking) / match_current_and_last_frames
+ * (motion-model tracking), data::frame::get_keypoints_in_cell (64 x 48 grid over the image bounds), match::angle_checker.
+ * Queries are processed IN ORDER: a keypoint taken by an earlier query is skipped by the later ones before any distance is
+ * computed (upstream: "if (frm.landmarks_.at(idx) && ...has_observation()) continue").  Candidates are visited cell column by
+ * cell column, inside a column cell row by cell row, inside a cell by keypoint index; the first strictly smaller distance
+ * wins.  Thresholds come from the caller (upstream: HAMMING_DIST_THR_HIGH = 100, lowe_ratio per call site). */
+static int proj_cell(float v, float vmin, double inv, int n)
+{
+    int c = (int)floor((v - vmin) * inv);
+    return c < 0 ? 0 : (c >= n ? n - 1 : c);
+}
+
+int ora_match_projection(const ora_keypoint* kp, const uint8_t* desc, const float* stereo_x_right, int n_kp, int width, int height,
+                         const ora_proj_query* q, const uint8_t* q_desc, int nq, int hamming_thr, float lowe_ratio,
+                         uint8_t* taken /* n_kp, in/out, may be NULL */, int32_t* match_idx, int32_t* match_dist)
+{
+    const int GC = 64, GR = 48;
+    const double inv_w = (double)GC / (double)width, inv_h = (double)GR / (double)height;
+    uint8_t* own_taken = NULL;
+    if (!taken) { own_taken = (uint8_t*)calloc((size_t)(n_kp > 0 ? n_kp : 1), 1); taken = own_taken; }
+    /* grid: keypoint indices per cell (CSR), index order inside a cell */
+    int* cell_of = (int*)malloc(sizeof(int) * (size_t)(n_kp > 0 ? n_kp : 1));
+    int* cstart = (int*)calloc((size_t)GC * GR + 1, sizeof(int));
+    int* clist = (int*)malloc(sizeof(int) * (size_t)(n_kp > 0 ? n_kp : 1));
+    for (int i = 0; i < n_kp; ++i) { cell_of[i] = proj_cell(kp[i].x, 0.f, inv_w, GC) * GR + proj_cell(kp[i].y, 0.f, inv_h, GR); cstart[cell_of[i] + 1]++; }
+    for (int c = 0; c < GC * GR; ++c) cstart[c + 1] += cstart[c];
+    {
+        int* fill = (int*)malloc(sizeof(int) * (size_t)GC * GR);
+        memcpy(fill, cstart, sizeof(int) * (size_t)GC * GR);
+        for (int i = 0; i < n_kp; ++i) clist[fill[cell_of[i]]++] = i;
+        free(fill);
+    }
+    int n_match = 0;
+    for (int k = 0; k < nq; ++k) {
+        match_idx[k] = -1; match_dist[k] = 256;
+        int best = 256, second = 256, best_lvl = -1, second_lvl = -1, best_idx = -1;
+        /* cells that can hold a keypoint of the window (a superset is harmless: every keypoint is tested itself) */
+        const int cx0 = proj_cell(q[k].x - q[k].radius, 0.f, inv_w, GC), cx1 = proj_cell(q[k].x + q[k].radius, 0.f, inv_w, GC);
+        const int cy0 = proj_cell(q[k].y - q[k].radius, 0.f, inv_h, GR), cy1 = proj_cell(q[k].y + q[k].radius, 0.f, inv_h, GR);
+        for (int cx = cx0; cx <= cx1; ++cx)
+            for (int cy = cy0; cy <= cy1; ++cy)
+                for (int s = cstart[cx * GR + cy]; s < cstart[cx * GR + cy + 1]; ++s) {
+                    const int i = clist[s];
+                    if (!(fabsf(kp[i].x - q[k].x) < q[k].radius && fabsf(kp[i].y - q[k].y) < q[k].radius)) continue;
+                    if (q[k].min_level >= 0 && kp[i].octave < q[k].min_level) continue;
+                    if (q[k].max_level >= 0 && kp[i].octave > q[k].max_level) continue;
+                    if (taken[i]) continue;
+                    if (stereo_x_right && 0 < stereo_x_right[i] && q[k].x_right >= 0) {
+                        if (q[k].radius < fabsf(q[k].x_right - stereo_x_right[i])) continue;
+                    }
+                    const int d = ora_hamming256(q_desc + 32 * (size_t)k, desc + 32 * (size_t)i);
+                    if (d < best) { second = best; second_lvl = best_lvl; best = d; best_lvl = kp[i].octave; best_idx = i; }
+                    else if (d < second) { second = d; second_lvl = kp[i].octave; }
+                }
+        if (best_idx >= 0 && best <= hamming_thr) {
+            if (best_lvl == second_lvl && (float)best > lowe_ratio * (float)second) continue;
+            match_idx[k] = best_idx; match_dist[k] = best;
+            taken[best_idx] = 1;
+            ++n_match;
+        }
+    }
+    free(cell_of); free(cstart); free(clist); free(own_taken);
+    return n_match;
+}
+
+/* match::angle_checker (ORB-SLAM2 ComputeThreeMaxima): matches whose angle difference falls outside the three most populated
+ * bins (the second / third kept only if >= 0.1 x the first) are dropped.  bin = round(delta / 30), delta in [0, 360). */
+int ora_match_orientation_filter(const float* angle_q, const float* angle_t, int32_t* match_idx, int nq)
+{
+    enum { HL = 30 };
+    int hist[HL + 1]; memset(hist, 0, sizeof(hist));
+    int* bin_of = (int*)malloc(sizeof(int) * (size_t)(nq > 0 ? nq : 1));
+    for (int k = 0; k < nq; ++k) {
+        bin_of[k] = -1;
+        if (match_idx[k] < 0) continue;
+        float rot = angle_q[k] - angle_t[match_idx[k]];
+        if (rot < 0.0f) rot += 360.0f;
+        if (360.0f <= rot) rot -= 360.0f;
+        int b = (int)lrintf(rot * (1.0f / HL));
+        if (b == HL) b = 0;
+        bin_of[k] = b; hist[b]++;
+    }
+    int i1 = -1, i2 = -1, i3 = -1, m1 = 0, m2 = 0, m3 = 0;
+    for (int b = 0; b < HL; ++b) {
+        const int s = hist[b];
+        if (s > m1) { m3 = m2; m2 = m1; m1 = s; i3 = i2; i2 = i1; i1 = b; }
+        else if (s > m2) { m3 = m2; m2 = s; i3 = i2; i2 = b; }
+        else if (s > m3) { m3 = s; i3 = b; }
+    }
+    if (m2 < 0.1f * (float)m1) { i2 = -1; i3 = -1; }
+    else if (m3 < 0.1f * (float)m1) i3 = -1;
+    int kept = 0;
+    for (int k = 0; k < nq; ++k) {
+        if (match_idx[k] < 0) continue;
+        if (bin_of[k] == i1 || bin_of[k] == i2 || bin_of[k] == i3) ++kept; else match_idx[k] = -1;
+    }
+    free(bin_of);
+    return kept;
+}

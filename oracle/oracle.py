@@ -308,3 +308,26 @@ def sim3_transform_optimize(s12, pairs, cam1, cam2, chi_sq=10.0, fix_scale=True)
     f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_void_p]
     n = f(_p(s), _p(pairs), len(pairs), _p(c1), _p(c2), float(chi_sq), int(fix_scale), _p(inl))
     return s, inl, n
+
+
+PROJ_QUERY_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("x_right", "<f4"), ("radius", "<f4"), ("min_level", "<i4"), ("max_level", "<i4")])
+
+
+def match_projection(kp, desc, stereo_xr, width, height, queries, q_desc, hamming_thr=100, lowe_ratio=0.8, taken=None):
+    kp = np.ascontiguousarray(kp, KP_DTYPE); desc = np.ascontiguousarray(desc, np.uint8)
+    q = np.ascontiguousarray(queries, PROJ_QUERY_DTYPE); qd = np.ascontiguousarray(q_desc, np.uint8)
+    sx = np.ascontiguousarray(stereo_xr, np.float32) if stereo_xr is not None else None
+    t = np.ascontiguousarray(taken, np.uint8).copy() if taken is not None else None
+    idx = np.full(max(len(q), 1), -1, np.int32); dist = np.zeros(max(len(q), 1), np.int32)
+    f = lib().ora_match_projection
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float,
+                  C.c_void_p, C.c_void_p, C.c_void_p]
+    n = f(_p(kp), _p(desc), _p(sx), len(kp), width, height, _p(q), _p(qd), len(q), int(hamming_thr), float(lowe_ratio), _p(t), _p(idx), _p(dist))
+    return idx[:len(q)].copy(), dist[:len(q)].copy(), n
+
+
+def match_orientation_filter(angle_q, angle_t, match_idx):
+    aq = np.ascontiguousarray(angle_q, np.float32); at = np.ascontiguousarray(angle_t, np.float32)
+    m = np.ascontiguousarray(match_idx, np.int32).copy()
+    n = lib().ora_match_orientation_filter(_p(aq), _p(at), _p(m), len(m))
+    return m, n

@@ -101,3 +101,62 @@ def test_temporal_match_batch(hiplib, oracle):
         g = c.bf_knn2(2 * f)
         o = oracle.match_bf_knn2(descs[f], descs[f - 1])
         assert all(np.array_equal(a, b) for a, b in zip(o, g))
+
+
+# ---- projection matching (match::projection) ----------------------------------------------------------------------------
+def _proj_case(hiplib, oracle, w, h, kpts, levels, seed, radius_scale=15.0, n_queries=None, jitter=6.0):
+    """Frame k+1 is matched from the keypoints of frame k displaced by a known flow (as the motion model would predict)."""
+    seq = synth.StereoSequence(w, h, seed)
+    l0, r0 = seq.frame(0); l1, r1 = seq.frame(1)
+    ctx = hiplib.Context(w, h, kpts, 1.2, levels, max_images=4)
+    for i, im in enumerate((l0, r0, l1, r1)):
+        ctx.upload(i, im)
+    ctx.extract(4)
+    k = synth.intrinsics(w, h)
+    ctx.match_stereo_strided(0, 1, 2, 2, k["fxb"], k["baseline"])
+    kp0, d0 = ctx.keypoints(0); kp1, d1 = ctx.keypoints(2)
+    xr1, _, _ = ctx.stereo(2)
+    xr0, _, _ = ctx.stereo(0)
+    rng = np.random.default_rng(seed)
+    n = len(kp0) if n_queries is None else min(n_queries, len(kp0))
+    q = np.zeros(n, hiplib.PROJ_QUERY_DTYPE)
+    q["x"] = kp0["x"][:n] + rng.normal(0, jitter, n).astype(np.float32); q["y"] = kp0["y"][:n] + rng.normal(0, jitter, n).astype(np.float32)
+    q["x_right"] = np.where(xr0[:n] > 0, xr0[:n] + (q["x"] - kp0["x"][:n]), -1.0)
+    q["radius"] = (radius_scale * np.float32(1.2) ** kp0["octave"][:n]).astype(np.float32)
+    q["min_level"] = kp0["octave"][:n] - 1; q["max_level"] = kp0["octave"][:n] + 1
+    return ctx, q, d0[:n], kp0[:n], kp1, d1, xr1
+
+
+@pytest.mark.parametrize("w,h,kpts,levels,radius", [(320, 240, 400, 4, 15.0), (640, 480, 1000, 8, 15.0), (640, 480, 1000, 8, 60.0)])
+def test_projection_match_parity(hiplib, oracle, w, h, kpts, levels, radius):
+    ctx, q, qd, kp0, kp1, d1, xr1 = _proj_case(hiplib, oracle, w, h, kpts, levels, 3, radius)
+    for use_stereo in (False, True):
+        gi, gd, gn = ctx.match_projection(2, q, qd, 100, 0.8, None, use_stereo)
+        oi, od, on = oracle.match_projection(kp1, d1, xr1 if use_stereo else None, w, h, q, qd, 100, 0.8)
+        assert gn == on and np.array_equal(gi, oi) and np.array_equal(gd[gi >= 0], od[oi >= 0])       # identical match pairs
+        assert gn > 0.3 * len(q)
+        m = gi[gi >= 0]
+        assert len(np.unique(m)) == len(m)                                                         # one landmark per keypoint
+    # orientation histogram filter on top
+    fg, ng = hiplib.match_orientation_filter(kp0["angle"], kp1["angle"], gi)
+    fo, no = oracle.match_orientation_filter(kp0["angle"], kp1["angle"], oi)
+    assert ng == no and np.array_equal(fg, fo) and 0 < ng <= gn
+
+
+def test_projection_match_sequential_semantics_and_rescans(hiplib, oracle):
+    """Many queries compete for the same few keypoints (identical predictions, wide window): later queries must see the
+    earlier assignments; short candidate lists get exhausted, which exercises the single-query re-scan."""
+    ctx, q, qd, kp0, kp1, d1, xr1 = _proj_case(hiplib, oracle, 320, 240, 400, 4, 5, radius_scale=80.0, n_queries=120, jitter=0.0)
+    q["x"][:] = q["x"][0]; q["y"][:] = q["y"][0]; q["min_level"][:] = -1; q["max_level"][:] = -1
+    qd = np.repeat(qd[:1], len(q), axis=0)                                      # every query has the same descriptor
+    gi, gd, gn = ctx.match_projection(2, q, qd, 256, 1.0, None, False)
+    oi, od, on = oracle.match_projection(kp1, d1, None, 320, 240, q, qd, 256, 1.0)
+    assert gn == on and np.array_equal(gi, oi)
+    m = gi[gi >= 0]
+    assert len(m) > 20 and len(np.unique(m)) == len(m) and (np.diff(gd[gi >= 0]) >= 0).all()       # greedy: distances only grow
+    taken = np.zeros(len(kp1), np.uint8); taken[m[:10]] = 1
+    gi2, _, _ = ctx.match_projection(2, q, qd, 256, 1.0, taken, False)
+    oi2, _, _ = oracle.match_projection(kp1, d1, None, 320, 240, q, qd, 256, 1.0, taken)
+    assert np.array_equal(gi2, oi2) and not np.isin(gi2[gi2 >= 0], m[:10]).any()
+    e_i, _, e_n = ctx.match_projection(2, q[:0], qd[:0])
+    assert e_n == 0 and len(e_i) == 0

@@ -346,3 +346,49 @@ def test_sim3_transform_optimizer_flow(oracle):
     assert nf > 100 and abs(sf[7] - 1.15) < 0.02
     bad = synth.sim3_pair_problem(30, 9, outlier_frac=0.8)
     assert oracle.sim3_transform_optimize(bad["s12"], oracle.sim3_pairs(bad), bad["cam1"], bad["cam2"], 10.0, True)[2] == 0
+
+
+def test_projection_match_against_a_plain_restatement(oracle):
+    """ora_match_projection vs a direct Python loop of the published algorithm (cell-scan order, sequential assignment)."""
+    rng = np.random.default_rng(11)
+    w, h, n = 320, 240, 150
+    kp = np.zeros(n, oracle.KP_DTYPE)
+    kp["x"] = rng.uniform(0, w, n).astype(np.float32); kp["y"] = rng.uniform(0, h, n).astype(np.float32); kp["octave"] = rng.integers(0, 4, n)
+    desc = rng.integers(0, 256, (n, 32)).astype(np.uint8)
+    desc[1::2] = desc[0::2]                                     # pairs of identical descriptors: ties decided by scan order
+    xr = np.where(rng.random(n) < 0.7, kp["x"] - rng.uniform(2, 20, n), -1).astype(np.float32)
+    nq = 80
+    q = np.zeros(nq, oracle.PROJ_QUERY_DTYPE)
+    src = rng.integers(0, n, nq)
+    q["x"] = kp["x"][src] + rng.normal(0, 5, nq); q["y"] = kp["y"][src] + rng.normal(0, 5, nq)
+    q["x_right"] = np.where(xr[src] > 0, xr[src] + rng.normal(0, 5, nq), -1); q["radius"] = 40.0
+    q["min_level"] = kp["octave"][src] - 1; q["max_level"] = kp["octave"][src]
+    qd = desc[src].copy(); qd[:, 0] ^= rng.integers(0, 8, nq).astype(np.uint8)
+    got_i, got_d, got_n = oracle.match_projection(kp, desc, xr, w, h, q, qd, 60, 0.9)
+    cell = np.minimum(np.floor(kp["x"] * (64.0 / w)).astype(int), 63) * 48 + np.minimum(np.floor(kp["y"] * (48.0 / h)).astype(int), 47)
+    order = np.lexsort((np.arange(n), cell))
+    taken = np.zeros(n, bool); want = np.full(nq, -1)
+    for k in range(nq):
+        best, second, bl, sl, bi = 256, 256, -1, -1, -1
+        for i in order:
+            if not (abs(kp["x"][i] - q["x"][k]) < q["radius"][k] and abs(kp["y"][i] - q["y"][k]) < q["radius"][k]):
+                continue
+            if kp["octave"][i] < q["min_level"][k] or kp["octave"][i] > q["max_level"][k] or taken[i]:
+                continue
+            if xr[i] > 0 and q["x_right"][k] >= 0 and q["radius"][k] < abs(q["x_right"][k] - xr[i]):
+                continue
+            d = int(np.unpackbits(qd[k] ^ desc[i]).sum())
+            if d < best:
+                second, sl, best, bl, bi = best, bl, d, kp["octave"][i], i
+            elif d < second:
+                second, sl = d, kp["octave"][i]
+        if bi >= 0 and best <= 60 and not (bl == sl and best > np.float32(0.9) * np.float32(second)):
+            want[k] = bi; taken[bi] = True
+    assert np.array_equal(got_i, want) and got_n == (want >= 0).sum() and got_n > 20
+    # orientation filter keeps the dominant bins only
+    aq = rng.uniform(0, 360, nq).astype(np.float32); at = rng.uniform(0, 360, n).astype(np.float32)
+    good = got_i >= 0
+    aq[good] = (at[got_i[good]] + 33.0) % 360                  # consistent rotation ...
+    spoil = np.flatnonzero(good)[:3]; aq[spoil] = (aq[spoil] + 170.0) % 360      # ... except three matches
+    filt, kept = oracle.match_orientation_filter(aq, at, got_i)
+    assert kept == good.sum() - 3 and (filt[spoil] == -1).all()
