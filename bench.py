@@ -279,6 +279,33 @@ def main():
             for _ in range(10):
                 t2 = time.perf_counter(); wl.bundle_adjust(); per.append(1e3 * (time.perf_counter() - t2) / BA_ITERS)
             extras["ba_ms_per_iter_spread"] = {"mean": round(float(np.mean(per)), 4), "p50": round(float(np.median(per)), 4)}
+        # several independent SLAM sessions on the one GPU (each its own context, streams and BA): the single session above is
+        # latency bound and leaves most CUs idle; this is what one MI355X sustains when it serves S sequences at once
+        S = 4
+        others = [Workload(device, 100 + i, args.frames, with_ba=wl.ba is not None) for i in range(S - 1)]
+        sessions = [wl] + others
+
+        def session_steps(w_, k_):
+            ths = []
+            if w_.ba is not None:
+                ths.append(threading.Thread(target=lambda: [w_.bundle_adjust() for _ in range(k_)]))
+                ths[-1].start()
+            for _ in range(k_):
+                w_.front_end()
+            w_.ctx.sync()
+            for th in ths:
+                th.join()
+        for w_ in sessions:
+            session_steps(w_, 1)
+        k_ms = max(5, min(args.steps, 20))
+        t2 = time.perf_counter()
+        ths = [threading.Thread(target=session_steps, args=(w_, k_ms)) for w_ in sessions]
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+        extras["multi_session"] = {"sessions_per_gpu": S, "frames_per_s": round(S * k_ms * args.frames / (time.perf_counter() - t2), 1)}
+        del others
         pg = wl.synth.pose_graph_problem(200, 0)
         graph = wl.hip.PoseGraph(wl.ctx, pg["verts"], pg["fixed"], wl.hip.sim3_edges(pg["edge_i"], pg["edge_j"], pg["meas"]), True)
         graph.optimize(2)
