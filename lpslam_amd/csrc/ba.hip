@@ -693,7 +693,7 @@ __device__ __forceinline__ double readlane_f64(double v, int lane)
 // diagonal workgroup publishes L_jj, L_j1,j1 into Ldiag; L_j1,j is needed by no later launch).  With an odd number of panels
 // the last launch is `single`: only column j.
 constexpr int CP_BLK = NB * (NB + 1);                  // one padded 32x32 block in LDS
-constexpr int CP_LDS_BYTES = 11 * CP_BLK * (int)sizeof(double);
+constexpr int CP_LDS_BYTES = (11 * CP_BLK + 2 * (64 * 17 + 64 * 17)) * (int)sizeof(double);      // 11 blocks + the factor scratch of two wavefronts
 
 __device__ __forceinline__ double pivot_rsqrt64(double d)
 {
@@ -701,28 +701,56 @@ __device__ __forceinline__ double pivot_rsqrt64(double d)
     rs = rs * fma(-0.5 * d * rs, rs, 1.5);
     return rs * fma(-0.5 * d * rs, rs, 1.5);
 }
-// register Cholesky of a 64-row x 32-column panel (lane = row, rows 0..31 = the diagonal block).  The pivot of column jj+1 is
-// finished right after that column's own update, so its latency chain overlaps the remaining rank-1 updates.
-__device__ __forceinline__ bool chol_panel_regs(double (&a)[NB], int lane)
+// Register Cholesky of a 64-row x 32-column panel (lane = row, rows 0..31 = the diagonal block), in two halves of 16 columns.
+// Inside a half the rank-1 multipliers travel by v_readlane and the pivot of column jj+1 is finished right after that
+// column's own update, so its latency chain overlaps the remaining updates.  Between the halves the finished 16 columns
+// update the other 16 as ONE block product on the matrix cores (64x16x16, through a 16 KB LDS scratch of this wavefront):
+// that replaces 256 of the 496 readlane-fed rank-1 updates (4 issue slots each) by 16 MFMAs.
+template <int C0>
+__device__ __forceinline__ bool chol_half_regs(double (&a)[NB], int lane)
 {
     bool fail = false;
-    double dcur = readlane_f64(a[0], 0);
+    double dcur = readlane_f64(a[C0], C0);
     if (!(dcur > 0.0)) { fail = true; dcur = 1.0; }
     double rs = pivot_rsqrt64(dcur);
 #pragma unroll
-    for (int jj = 0; jj < NB; ++jj) {
+    for (int jj = C0; jj < C0 + 16; ++jj) {
         const double lcol = a[jj] * rs;
         a[jj] = lane == jj ? dcur * rs : lcol;
-        if (jj + 1 < NB) {
+        if (jj + 1 < C0 + 16) {
             a[jj + 1] = fma(-lcol, readlane_f64(lcol, jj + 1), a[jj + 1]);
             double dn = readlane_f64(a[jj + 1], jj + 1);
             if (!(dn > 0.0)) { fail = true; dn = 1.0; }
             const double rn = pivot_rsqrt64(dn);
 #pragma unroll
-            for (int c = jj + 2; c < NB; ++c) a[c] = fma(-lcol, readlane_f64(lcol, c), a[c]);
+            for (int c = jj + 2; c < C0 + 16; ++c) a[c] = fma(-lcol, readlane_f64(lcol, c), a[c]);
             dcur = dn; rs = rn;
         }
     }
+    return fail;
+}
+constexpr int CH_SCR = 64 * 17 + 64 * 17;              // doubles of scratch per factoring wavefront: L1 [64][17] and U [64][17]
+__device__ __forceinline__ bool chol_panel_regs(double (&a)[NB], int lane, double* scr)
+{
+    bool fail = chol_half_regs<0>(a, lane);
+    double* Ls = scr; double* Us = scr + 64 * 17;
+    // the diagonal entry of a finished column sits in a[jj] of lane jj, the strict upper part of the block holds garbage
+    // that is never read (lanes r < k of column k): zero it for the product
+#pragma unroll
+    for (int k = 0; k < 16; ++k) Ls[lane * 17 + k] = (lane < k) ? 0.0 : a[k];
+    const int lr = lane & 15, lk = lane >> 4;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {                        // U[16t.., :] = L1[16t.., :] (L1[16..31, :])^T, K = 16
+        f64x4 acc = {0, 0, 0, 0};
+#pragma unroll
+        for (int s4 = 0; s4 < 16; s4 += 4)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ls[(16 * t + lr) * 17 + s4 + lk], Ls[(16 + lr) * 17 + s4 + lk], acc, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Us[(16 * t + lk + 4 * q) * 17 + lr] = acc[q];
+    }
+#pragma unroll
+    for (int c = 0; c < 16; ++c) a[16 + c] -= Us[lane * 17 + c];
+    fail |= chol_half_regs<16>(a, lane);
     return fail;
 }
 // acc += A[tr.., :] B[tc.., :]^T over one 32-wide k-block (16x16 tile, 8 x v_mfma_f64_16x16x4)
@@ -854,7 +882,7 @@ __global__ __launch_bounds__(256) void k_chol_pair(BaView v, int nb, int m, int 
         double a[NB];
 #pragma unroll
         for (int c = 0; c < NB; ++c) a[c] = lane < NB ? Dj[lane * (NB + 1) + c] : (single ? 0.0 : X[(lane - NB) * (NB + 1) + c]);
-        fail = chol_panel_regs(a, lane);
+        fail = chol_panel_regs(a, lane, cp_lds + 11 * CP_BLK);
         if (lane >= NB) {
 #pragma unroll
             for (int c = 0; c < NB; ++c) Ljk0[(lane - NB) * (NB + 1) + c] = a[c];            // L_j1,j for step 3
@@ -872,7 +900,7 @@ __global__ __launch_bounds__(256) void k_chol_pair(BaView v, int nb, int m, int 
         double a[NB];
 #pragma unroll
         for (int c = 0; c < NB; ++c) a[c] = lane < NB ? Dj[lane * (NB + 1) + c] : B0[(lane - NB) * (NB + 1) + c];
-        chol_panel_regs(a, lane);
+        chol_panel_regs(a, lane, cp_lds + 11 * CP_BLK + CH_SCR);
         if (lane >= NB) {
             double* out = extra ? M : S;
 #pragma unroll
@@ -912,7 +940,7 @@ __global__ __launch_bounds__(256) void k_chol_pair(BaView v, int nb, int m, int 
     double a[NB];                                        // 4. [D_j1; B1] -> L_j1,j1, L_i,j1
 #pragma unroll
     for (int c = 0; c < NB; ++c) a[c] = lane < NB ? Dj1[lane * (NB + 1) + c] : (has_b ? B1[(lane - NB) * (NB + 1) + c] : 0.0);
-    fail = chol_panel_regs(a, lane);
+    fail = chol_panel_regs(a, lane, cp_lds + 11 * CP_BLK);
     if (lane < NB) {
         if (diag) {
 #pragma unroll
