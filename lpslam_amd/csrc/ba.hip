@@ -66,6 +66,7 @@ struct BaView {                       // device pointers handed to kernels by va
     double* Lsub;                                                            // L_j1,j of every panel pair, stored at [j1][32][32]
     double* xp; double* chi_pose; double* part; double* scal;
     const int* blk_start; const int2* blk_terms;
+    const int4* blk_work; double* blk_part; int* blk_ticket;      // Schur work items (block, part, parts, first item), partial sums, per-block tickets
     BaCtl* ctl; lpslam_hip_ba_iter_log* log;
     BaCam cam;
 };
@@ -537,19 +538,19 @@ __global__ __launch_bounds__(256) void k_ba_obs_y(BaView v)
     }
 }
 
-// ---- per trial: Schur complement.  Blocks [0, n_blocks): one wavefront per pose-block pair (i <= k): lanes stride over the
+// ---- per trial: Schur complement.  Work items [0, n_work): one wavefront per pose-block pair (i <= k) or part of one: lanes stride over the
 //      pair list with 36 private accumulators, partials are summed in lane order through LDS (fixed summation order).
-//      Blocks [n_blocks, n_blocks + n_free): rhs_i = b_p,i - sum Y b_l over the observations of keyframe i.
+//      Blocks [n_work, n_work + n_free): rhs_i = b_p,i - sum Y b_l over the observations of keyframe i.
 //      fused != 0 (single-GPU solve): lambda goes onto the pose diagonal, rhs straight into row `dim` of S and the failure
 //      flag / rhs pivot are reset here, so no separate preparation launch is needed.
-__global__ __launch_bounds__(64) void k_ba_schur(BaView v, int n_blocks, int fused)
+__global__ __launch_bounds__(64) void k_ba_schur(BaView v, int n_work, int fused)
 {
     if (ba_idle(v.ctl)) return;
     const double lambda = v.ctl->lambda;
     const int lane = threadIdx.x;
     const int n = v.dim_pad;
-    if ((int)blockIdx.x >= n_blocks) {
-        const int i = blockIdx.x - n_blocks;
+    if ((int)blockIdx.x >= n_work) {
+        const int i = blockIdx.x - n_work;
         const int p = v.free_pose[i];
         double r6[6] = {0, 0, 0, 0, 0, 0};
         for (int s = v.ps_start[p] + lane; s < v.ps_start[p + 1]; s += 64) {
@@ -571,7 +572,12 @@ __global__ __launch_bounds__(64) void k_ba_schur(BaView v, int n_blocks, int fus
         if (fused && i == 0 && lane == 63) { v.S[(size_t)v.dim * n + v.dim] = 1e200; v.scal[5] = 0.0; }
         return;
     }
-    int pidx = blockIdx.x, i = 0;
+    // work item = (block pair, part, parts): pair lists longer than 256 terms are cut into up to 4 interleaved parts (64-term
+    // chunks round-robin), so that the longest list -- a keyframe's diagonal block, one term per observation -- no longer sets
+    // the kernel's duration; the part that finishes last adds the parts up in order (fixed summation order).
+    const int4 wk = v.blk_work[blockIdx.x];
+    const int blk = wk.x, part_id = wk.y, parts = wk.z;
+    int pidx = blk, i = 0;
     {
         int rowlen = v.n_free;
         while (pidx >= rowlen) { pidx -= rowlen; --rowlen; ++i; }
@@ -581,13 +587,15 @@ __global__ __launch_bounds__(64) void k_ba_schur(BaView v, int n_blocks, int fus
     double acc[36];
 #pragma unroll
     for (int q = 0; q < 36; ++q) acc[q] = 0;
-    for (int t = v.blk_start[blockIdx.x] + lane; t < v.blk_start[blockIdx.x + 1]; t += 64) {
+    for (int t = v.blk_start[blk] + part_id * 64 + lane; t < v.blk_start[blk + 1]; t += 64 * parts) {
         const int2 ab = v.blk_terms[t];
-        const double* Ya = v.Y + 18 * (size_t)ab.x;
-        const double* Wb = v.W + 18 * (size_t)ab.y;
+        // rows are 144 bytes = nine 16-byte pieces: dwordx4 loads halve the number of cache-line lookups, which -- every lane
+        // in a different line -- are what this kernel is made of
+        const double2* Ya = reinterpret_cast<const double2*>(v.Y + 18 * (size_t)ab.x);
+        const double2* Wb = reinterpret_cast<const double2*>(v.W + 18 * (size_t)ab.y);
         double y[18], w[18];
 #pragma unroll
-        for (int q = 0; q < 18; ++q) { y[q] = Ya[q]; w[q] = Wb[q]; }
+        for (int q = 0; q < 9; ++q) { const double2 a2 = Ya[q], b2 = Wb[q]; y[2 * q] = a2.x; y[2 * q + 1] = a2.y; w[2 * q] = b2.x; w[2 * q + 1] = b2.y; }
 #pragma unroll
         for (int r = 0; r < 6; ++r)
 #pragma unroll
@@ -597,10 +605,28 @@ __global__ __launch_bounds__(64) void k_ba_schur(BaView v, int n_blocks, int fus
 #pragma unroll
     for (int q = 0; q < 36; ++q) part[lane * 37 + q] = acc[q];
     __syncthreads();
+    double sum = 0;
+    if (lane < 36) for (int l = 0; l < 64; ++l) sum += part[l * 37 + lane];
+    if (parts > 1) {
+        double* mine = v.blk_part + (size_t)(wk.w + part_id) * 36;
+        if (lane < 36) mine[lane] = sum;
+        // hand-over as in ba_last_block, one ticket per block pair
+        __shared__ int s_last;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (lane == 0) {
+            const int tk = __hip_atomic_fetch_add(&v.blk_ticket[blk], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = (tk == parts - 1);
+            if (s_last) v.blk_ticket[blk] = 0;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        if (!s_last) return;
+        sum = 0;
+        if (lane < 36) for (int p = 0; p < parts; ++p) sum += v.blk_part[(size_t)(wk.w + p) * 36 + lane];
+    }
     if (lane >= 36) return;
     const int r = lane / 6, c = lane - r * 6;
-    double sum = 0;
-    for (int l = 0; l < 64; ++l) sum += part[l * 37 + lane];
     if (i == k) {
         double val = v.Hpp[36 * (size_t)i + lane] - sum;
         if (fused && r == c) val += lambda;
@@ -1081,7 +1107,7 @@ __global__ __launch_bounds__(256) void k_ba_obs_chi2(BaView v, double* chi2, uin
 struct lpslam_hip_ba {
     lpslam_hip_ctx* ctx = nullptr;
     hipStream_t stream = nullptr;
-    int n_poses = 0, n_points = 0, n_obs = 0, n_free = 0, dim = 0, dim_pad = 0, n_blocks = 0;
+    int n_poses = 0, n_points = 0, n_obs = 0, n_free = 0, dim = 0, dim_pad = 0, n_blocks = 0, n_work = 0;
     double *d_poses[2] = {nullptr, nullptr}, *d_points[2] = {nullptr, nullptr};
     double *d_poses0 = nullptr, *d_points0 = nullptr;      // state given at creation (lpslam_hip_ba_reset)
     int *d_pose_slot = nullptr, *d_free_pose = nullptr, *d_o_pose = nullptr, *d_o_point = nullptr;
@@ -1093,7 +1119,7 @@ struct lpslam_hip_ba {
     double* d_red = nullptr; int64_t red_n = 0;
     double *d_xp = nullptr, *d_chi_pose = nullptr, *d_part = nullptr, *d_scal = nullptr, *d_loc = nullptr;
     double* d_chi_obs = nullptr; uint8_t* d_depth = nullptr;
-    int* d_blk_start = nullptr; int2* d_blk_terms = nullptr;
+    int* d_blk_start = nullptr; int2* d_blk_terms = nullptr; int4* d_blk_work = nullptr; double* d_blk_part = nullptr; int* d_blk_ticket = nullptr;
     BaCtl* d_ctl = nullptr; lpslam_hip_ba_iter_log* d_log = nullptr;
     int part_n = 0;
     BaCam cam{};
@@ -1134,7 +1160,7 @@ BaView make_view(lpslam_hip_ba* b)
     v.S = b->d_red; v.rhs = b->d_red + n * n; v.bp = v.rhs + n; v.hppdiag = v.bp + n; v.chi_cur = v.hppdiag + n;
     v.bp_loc = b->d_loc; v.hppdiag_loc = b->d_loc + n; v.chi_loc = b->d_loc + 2 * n;
     v.xp = b->d_xp; v.chi_pose = b->d_chi_pose; v.part = b->d_part; v.scal = b->d_scal;
-    v.blk_start = b->d_blk_start; v.blk_terms = b->d_blk_terms;
+    v.blk_start = b->d_blk_start; v.blk_terms = b->d_blk_terms; v.blk_work = b->d_blk_work; v.blk_part = b->d_blk_part; v.blk_ticket = b->d_blk_ticket;
     v.ctl = b->d_ctl; v.log = b->d_log;
     v.cam = b->cam;
     return v;
@@ -1158,7 +1184,7 @@ int enqueue_reduce(lpslam_hip_ba* b, int fused)
     BaView v = make_view(b);
     hipStream_t s = b->stream;
     if (b->n_obs) hipLaunchKernelGGL(k_ba_obs_y, dim3((b->n_obs + 255) / 256), dim3(256), 0, s, v);
-    if (b->n_free) hipLaunchKernelGGL(k_ba_schur, dim3(b->n_blocks + b->n_free), dim3(64), 0, s, v, b->n_blocks, fused);
+    if (b->n_free) hipLaunchKernelGGL(k_ba_schur, dim3(b->n_work + b->n_free), dim3(64), 0, s, v, b->n_work, fused);
     LP_HIP(hipGetLastError());
     return LPSLAM_HIP_OK;
 }
@@ -1302,6 +1328,20 @@ int lpslam_hip_ba_create(lpslam_hip_ctx* ctx, const double* poses, const uint8_t
 #define BA_TRY(x) do { rc = (x); if (rc) return fail(rc); } while (0)
 #define BA_HIP(x) do { if ((x) != hipSuccess) { set_error("HIP call failed: %s", #x); return fail(LPSLAM_HIP_ERR_DEVICE); } } while (0)
     BA_TRY(upload(b, &b->d_blk_start, blk_count));
+    {   // Schur work items: (block, part, parts, index of the block's first item)
+        std::vector<int4> work;
+        for (int q = 0; q < b->n_blocks; ++q) {
+            const int terms_q = blk_count[q + 1] - blk_count[q];
+            const int parts = std::min(4, std::max(1, (terms_q + 255) / 256));
+            const int first = (int)work.size();
+            for (int p = 0; p < parts; ++p) work.push_back(make_int4(q, p, parts, first));
+        }
+        b->n_work = (int)work.size();
+        BA_TRY(upload(b, &b->d_blk_work, work));
+        BA_TRY(dalloc(b, &b->d_blk_part, (size_t)std::max(b->n_work, 1) * 36));
+        BA_TRY(dalloc(b, &b->d_blk_ticket, (size_t)std::max(b->n_blocks, 1)));
+        BA_HIP(hipMemset(b->d_blk_ticket, 0, (size_t)std::max(b->n_blocks, 1) * sizeof(int)));
+    }
     BA_TRY(upload(b, &b->d_pose_slot, slot));
     BA_TRY(upload(b, &b->d_free_pose, free_pose));
     BA_TRY(upload(b, &b->d_o_pose, o_pose)); BA_TRY(upload(b, &b->d_o_point, o_point));
