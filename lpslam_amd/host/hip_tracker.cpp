@@ -7,6 +7,10 @@
 #include <cstdio>
 #include <fstream>
 
+#include <atomic>
+static std::atomic<long> g_motion_tracked{0};      // process-wide count of frames tracked by the motion model (introspection for the tests)
+extern "C" __attribute__((visibility("default"))) long lpslam_debug_motion_tracked(void) { return g_motion_tracked.load(); }
+
 namespace LpSlam {
 
 namespace {
@@ -241,47 +245,34 @@ void HipVslamTrackerBase::insertKeyframe(FrameData& f)
 }
 
 // motion-only pose optimisation of `cur` against the landmarks seen in the previous frame
-bool HipVslamTrackerBase::trackAgainstPrevious(FrameData& cur, int& n_inliers)
+// motion-only pose optimisation ([UPSTREAM] optimize::pose_optimizer) over keypoint <-> landmark associations
+bool HipVslamTrackerBase::poseFromMatches(FrameData& cur, const std::vector<int>& cur_idx, const std::vector<int>& lm_ids, const Pose& init, int& n_inliers)
 {
     n_inliers = 0;
-    if (lpslam_hip_match_bf(m_ctx, cur.slot, m_prev.slot) != LPSLAM_HIP_OK) return false;
-    std::vector<int32_t> mq(m_maxKp), mt(m_maxKp), md(m_maxKp);
-    int32_t nm = 0;
-    // HAMMING_DIST_THR_LOW = 50, Lowe ratio 0.9, mutual best
-    if (lpslam_hip_get_bf_matches(m_ctx, cur.slot, m_prev.slot, 50, 0.9f, 1, mq.data(), mt.data(), md.data(), m_maxKp, &nm) != LPSLAM_HIP_OK) return false;
     float scales[LPSLAM_HIP_MAX_LEVELS];
     lpslam_hip_level_info(m_ctx, nullptr, nullptr, nullptr, nullptr, scales);
     std::vector<double> pts;
     std::vector<lpslam_hip_ba_obs> obs;
-    std::vector<int> cur_idx, obs_lm;
-    for (int k = 0; k < nm; ++k) {
-        const int id = m_prev.landmark[mt[k]];
-        if (id < 0) continue;
-        auto it = m_landmarks.find(id);
+    std::vector<int> kept_idx, kept_lm;
+    for (size_t k = 0; k < cur_idx.size(); ++k) {
+        auto it = m_landmarks.find(lm_ids[k]);
         if (it == m_landmarks.end()) continue;
-        const int i = mq[k];
+        const int i = cur_idx[k];
         const double s = scales[cur.kpts[i].octave];
         lpslam_hip_ba_obs o{};
-        o.pose = 0; o.point = (int32_t)cur_idx.size();
+        o.pose = 0; o.point = (int32_t)kept_idx.size();
         o.u = cur.kpts[i].x; o.v = cur.kpts[i].y; o.ur = cur.x_right[i] >= 0 ? (double)cur.x_right[i] : -1.0; o.inv_sigma2 = 1.0 / (s * s);
         obs.push_back(o);
         pts.insert(pts.end(), it->second.p, it->second.p + 3);
-        cur_idx.push_back(i);
-        obs_lm.push_back(id);
+        kept_idx.push_back(i);
+        kept_lm.push_back(lm_ids[k]);
     }
     if (obs.size() < 10) return false;
-    // prediction: constant velocity, else the previous pose
-    Pose init = m_prev.pose;
-    if (m_haveVelocity) {
-        quatMul(m_velocity.q, m_prev.pose.q, init.q);
-        const Mat3 Rv = quatToRot(m_velocity.q);
-        for (int r = 0; r < 3; ++r) init.t[r] = Rv.m[r * 3] * m_prev.pose.t[0] + Rv.m[r * 3 + 1] * m_prev.pose.t[1] + Rv.m[r * 3 + 2] * m_prev.pose.t[2] + m_velocity.t[r];
-    }
     double pose7[7] = {init.q[0], init.q[1], init.q[2], init.q[3], init.t[0], init.t[1], init.t[2]};
     const uint8_t fixed = 0;
     lpslam_hip_ba_camera cam{m_cam.f_x, m_cam.f_y, m_cam.c_x, m_cam.c_y, m_cam.focal_x_baseline, std::sqrt(5.991), std::sqrt(7.815)};
     lpslam_hip_ba* ba = nullptr;
-    if (lpslam_hip_ba_create(m_ctx, pose7, &fixed, 1, pts.data(), (int32_t)cur_idx.size(), obs.data(), (int32_t)obs.size(), &cam, &ba) != LPSLAM_HIP_OK) return false;
+    if (lpslam_hip_ba_create(m_ctx, pose7, &fixed, 1, pts.data(), (int32_t)kept_idx.size(), obs.data(), (int32_t)obs.size(), &cam, &ba) != LPSLAM_HIP_OK) return false;
     std::vector<uint8_t> outlier(obs.size());
     int32_t inl = 0;
     const int rc = lpslam_hip_ba_pose_optimize(ba, outlier.data(), &inl);
@@ -292,8 +283,95 @@ bool HipVslamTrackerBase::trackAgainstPrevious(FrameData& cur, int& n_inliers)
     if (inl < 10) return false;
     for (int k = 0; k < 4; ++k) cur.pose.q[k] = pose7[k];
     for (int k = 0; k < 3; ++k) cur.pose.t[k] = pose7[4 + k];
-    for (size_t k = 0; k < cur_idx.size(); ++k) cur.landmark[cur_idx[k]] = outlier[k] ? -1 : obs_lm[k];   // inliers keep their landmark
+    std::fill(cur.landmark.begin(), cur.landmark.end(), -1);
+    for (size_t k = 0; k < kept_idx.size(); ++k) cur.landmark[kept_idx[k]] = outlier[k] ? -1 : kept_lm[k];   // inliers keep their landmark
     return true;
+}
+
+// [UPSTREAM] frame_tracker::motion_based_track: pose predicted with the constant-velocity model, the last frame's landmarks are
+// projected into the current frame and matched inside a window around the prediction (match::projection::
+// match_current_and_last_frames: margin 10 px x scale factor for stereo, doubled once if fewer than 20 matches), matches
+// with an inconsistent keypoint rotation are dropped (angle_checker), then the motion-only pose optimiser runs.
+bool HipVslamTrackerBase::trackWithMotionModel(FrameData& cur, int& n_inliers)
+{
+    n_inliers = 0;
+    if (!m_haveVelocity) return false;
+    Pose init;
+    quatMul(m_velocity.q, m_prev.pose.q, init.q);
+    const Mat3 Rv = quatToRot(m_velocity.q);
+    for (int r = 0; r < 3; ++r) init.t[r] = Rv.m[r * 3] * m_prev.pose.t[0] + Rv.m[r * 3 + 1] * m_prev.pose.t[1] + Rv.m[r * 3 + 2] * m_prev.pose.t[2] + m_velocity.t[r];
+    const Mat3 R = quatToRot(init.q);
+    float scales[LPSLAM_HIP_MAX_LEVELS];
+    int32_t n_levels = 0;
+    lpslam_hip_level_info(m_ctx, &n_levels, nullptr, nullptr, nullptr, scales);
+    std::vector<lpslam_hip_proj_query> q;
+    std::vector<uint8_t> qd;
+    std::vector<float> q_angle;
+    std::vector<int> q_lm;
+    for (size_t i = 0; i < m_prev.kpts.size(); ++i) {
+        const int id = m_prev.landmark[i];
+        if (id < 0) continue;
+        auto it = m_landmarks.find(id);
+        if (it == m_landmarks.end()) continue;
+        const double* X = it->second.p;
+        const double pc[3] = {R.m[0] * X[0] + R.m[1] * X[1] + R.m[2] * X[2] + init.t[0], R.m[3] * X[0] + R.m[4] * X[1] + R.m[5] * X[2] + init.t[1],
+                              R.m[6] * X[0] + R.m[7] * X[1] + R.m[8] * X[2] + init.t[2]};
+        if (!(pc[2] > 0)) continue;
+        const double u = m_cam.f_x * pc[0] / pc[2] + m_cam.c_x, v = m_cam.f_y * pc[1] / pc[2] + m_cam.c_y;
+        if (u < 0 || v < 0 || u >= m_cam.resolution_x || v >= m_cam.resolution_y) continue;
+        const int lvl = m_prev.kpts[i].octave;
+        lpslam_hip_proj_query e{};
+        e.x = (float)u; e.y = (float)v; e.x_right = (float)(u - m_cam.focal_x_baseline / pc[2]);
+        e.radius = 10.0f * scales[lvl];
+        e.min_level = std::max(0, lvl - 1); e.max_level = std::min(n_levels - 1, lvl + 1);
+        q.push_back(e);
+        qd.insert(qd.end(), m_prev.desc.begin() + 32 * i, m_prev.desc.begin() + 32 * (i + 1));
+        q_angle.push_back(m_prev.kpts[i].angle);
+        q_lm.push_back(id);
+    }
+    if (q.size() < 20) return false;
+    std::vector<int32_t> idx(q.size()), dist(q.size());
+    std::vector<float> cur_angle(cur.kpts.size());
+    for (size_t i = 0; i < cur.kpts.size(); ++i) cur_angle[i] = cur.kpts[i].angle;
+    int32_t n_m = 0;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if (lpslam_hip_match_projection(m_ctx, cur.slot, q.data(), qd.data(), (int32_t)q.size(), 100 /* HAMMING_DIST_THR_HIGH */, 1.0f, nullptr, 1,
+                                        idx.data(), dist.data(), &n_m) != LPSLAM_HIP_OK) return false;
+        lpslam_hip_match_orientation_filter(q_angle.data(), cur_angle.data(), idx.data(), (int32_t)q.size(), &n_m);
+        if (n_m >= 20) break;
+        for (auto& e : q) e.radius *= 2.0f;
+    }
+    if (n_m < 20) return false;
+    std::vector<int> cur_idx, lm_ids;
+    for (size_t k = 0; k < q.size(); ++k) if (idx[k] >= 0) { cur_idx.push_back(idx[k]); lm_ids.push_back(q_lm[k]); }
+    return poseFromMatches(cur, cur_idx, lm_ids, init, n_inliers);
+}
+
+bool HipVslamTrackerBase::trackAgainstPrevious(FrameData& cur, int& n_inliers)
+{
+    // motion model first; descriptor matching against the whole previous frame is the fallback (upstream falls back to
+    // BoW / robust matching, frame_tracker::bow_match_based_track / robust_match_based_track)
+    if (trackWithMotionModel(cur, n_inliers)) { ++m_motionTracked; ++g_motion_tracked; return true; }
+    n_inliers = 0;
+    if (lpslam_hip_match_bf(m_ctx, cur.slot, m_prev.slot) != LPSLAM_HIP_OK) return false;
+    std::vector<int32_t> mq(m_maxKp), mt(m_maxKp), md(m_maxKp);
+    int32_t nm = 0;
+    // HAMMING_DIST_THR_LOW = 50, Lowe ratio 0.9, mutual best
+    if (lpslam_hip_get_bf_matches(m_ctx, cur.slot, m_prev.slot, 50, 0.9f, 1, mq.data(), mt.data(), md.data(), m_maxKp, &nm) != LPSLAM_HIP_OK) return false;
+    std::vector<int> cur_idx, lm_ids;
+    for (int k = 0; k < nm; ++k) {
+        const int id = m_prev.landmark[mt[k]];
+        if (id < 0) continue;
+        cur_idx.push_back(mq[k]); lm_ids.push_back(id);
+    }
+    // prediction: constant velocity, else the previous pose
+    Pose init = m_prev.pose;
+    if (m_haveVelocity) {
+        quatMul(m_velocity.q, m_prev.pose.q, init.q);
+        const Mat3 Rv = quatToRot(m_velocity.q);
+        for (int r = 0; r < 3; ++r) init.t[r] = Rv.m[r * 3] * m_prev.pose.t[0] + Rv.m[r * 3 + 1] * m_prev.pose.t[1] + Rv.m[r * 3 + 2] * m_prev.pose.t[2] + m_velocity.t[r];
+    }
+    return poseFromMatches(cur, cur_idx, lm_ids, init, n_inliers);
 }
 
 void HipVslamTrackerBase::localBundleAdjust()
@@ -379,10 +457,10 @@ TrackerBase::ProcessImageResult HipVslamTrackerBase::trackFrame(CameraQueueEntry
         ok = lpslam_hip_match_stereo(m_ctx, cur.slot, cur.slot + 1, (float)m_cam.focal_x_baseline, baseline) == LPSLAM_HIP_OK;
     }
     int32_t n = 0;
-    cur.kpts.resize(m_maxKp);
-    if (ok) ok = lpslam_hip_get_keypoints(m_ctx, cur.slot, cur.kpts.data(), nullptr, m_maxKp, &n) == LPSLAM_HIP_OK;
+    cur.kpts.resize(m_maxKp); cur.desc.resize((size_t)m_maxKp * 32);
+    if (ok) ok = lpslam_hip_get_keypoints(m_ctx, cur.slot, cur.kpts.data(), cur.desc.data(), m_maxKp, &n) == LPSLAM_HIP_OK;
     if (!ok) { logMessage(LpSlamLogLevel_Error, std::string("HIP front end failed: ") + lpslam_hip_last_error()); return res; }
-    cur.kpts.resize(n);
+    cur.kpts.resize(n); cur.desc.resize((size_t)n * 32);
     cur.x_right.assign(n, -1.0f); cur.depth.assign(n, -1.0f); cur.landmark.assign(n, -1);
     if (stereo && n > 0) lpslam_hip_get_stereo(m_ctx, cur.slot, cur.x_right.data(), cur.depth.data(), nullptr, n, nullptr);
     ++m_imageTracked;

@@ -39,6 +39,7 @@ protected:
     struct Pose { double q[4] = {1, 0, 0, 0}; double t[3] = {0, 0, 0}; };   // world -> camera
     struct FrameData {
         std::vector<lpslam_hip_keypoint> kpts;
+        std::vector<uint8_t> desc;                    // 32 bytes per keypoint
         std::vector<float> x_right, depth;
         std::vector<int> landmark;                    // landmark id per keypoint or -1
         Pose pose;
@@ -52,6 +53,8 @@ protected:
     ProcessImageResult trackFrame(CameraQueueEntry& cam, bool stereo);
     TrackerResult createTrackerResult(const Pose& pose_cw, TimeStamp timestamp) const;
     bool initializeMap(FrameData& f);
+    bool poseFromMatches(FrameData& cur, const std::vector<int>& cur_idx, const std::vector<int>& lm_ids, const Pose& init, int& n_inliers);
+    bool trackWithMotionModel(FrameData& cur, int& n_inliers);
     bool trackAgainstPrevious(FrameData& cur, int& n_inliers);
     void insertKeyframe(FrameData& f);
     void localBundleAdjust();
@@ -71,6 +74,7 @@ protected:
     lpslam_hip_ctx* m_ctx = nullptr;
     LpSlamCameraConfiguration m_cam{};
     bool m_started = false, m_stereo = false, m_rectify = false;
+    long m_motionTracked = 0;                         // frames tracked by the motion model (projection matching)
     TrackerState m_state = TrackerState::NotInitialized;
     std::optional<TimeStamp> m_firstImageTimestamp;
     uint64_t m_imageTracked = 0;

@@ -23,6 +23,10 @@ def test_stereo_sequence_through_the_manager(hiplib):
         m.set_camera(c)
     assert m.add_tracker("VSLAMStereo", '{"cameraSetup": "stereo", "slamKeypoints": 1000, "numLevels": 4, "keyframeInterval": 4}')
     m.collect_results(); m.provide_odometry()
+    import ctypes
+    counter = ctypes.CDLL(_build.host_library()).lpslam_debug_motion_tracked
+    counter.restype = ctypes.c_long
+    tracked0 = counter()
     m.start()
     frames = [seq.frame(i) for i in range(n_frames)]
     for i, (l, r) in enumerate(frames):
@@ -34,6 +38,7 @@ def test_stereo_sequence_through_the_manager(hiplib):
     feats = m.features()
     m.stop()
     assert len(m.results) == n_frames
+    assert counter() - tracked0 >= n_frames - 6          # constant-velocity prediction + projection matching carried most frames
     valid = [r for r in m.results if r["valid"]]
     assert len(valid) >= n_frames - 2 and st.localization == 2 and st.key_frames >= 3 and st.feature_points > 100
     assert len(feats) == st.feature_points
