@@ -1256,7 +1256,10 @@ int lpslam_hip_ba_create(lpslam_hip_ctx* ctx, const double* poses, const uint8_t
     lpslam_hip_ba* b = new lpslam_hip_ba();
     b->ctx = ctx;
     // own stream: a bundle adjustment runs beside the front end of later frames (the reference's mapping thread)
-    if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) { delete b; set_error("hipStreamCreate failed"); return LPSLAM_HIP_ERR_DEVICE; }
+    // ... at the highest priority: its kernels are small and latency bound, the front end's fill the chip for 100 us at a time
+    int prio_least = 0, prio_greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    if (hipStreamCreateWithPriority(&b->stream, hipStreamNonBlocking, prio_greatest) != hipSuccess) { delete b; set_error("hipStreamCreate failed"); return LPSLAM_HIP_ERR_DEVICE; }
     b->n_poses = n_poses; b->n_points = n_points; b->n_obs = n_obs;
     b->cam = BaCam{cam->fx, cam->fy, cam->cx, cam->cy, cam->focal_x_baseline, cam->huber_mono, cam->huber_stereo};
     std::vector<int> slot(n_poses), free_pose;
