@@ -15,35 +15,49 @@
 using namespace lpslam;
 
 // ------------------------------------------------------------------------------------------------------------
-// K7  brute-force Hamming 2-NN.  Workgroup = 64 queries (one per lane, descriptor in 8 VGPRs) x 4 waves that split
-//     each 256-descriptor LDS tile of the train set; train descriptors are LDS broadcasts (ds_read_b128 x 2).
+// K7  brute-force Hamming 2-NN.  Workgroup = 16 queries (descriptor in 8 VGPRs), each spread over 16 lanes that split
+//     each 1024-descriptor LDS tile of the train set; train descriptors are LDS broadcasts (ds_read_b128 x 2).
 //     Integer-VALU bound: 8 v_xor + 8 v_bcnt per pair.  "First minimum wins", second = second smallest distance.
 // ------------------------------------------------------------------------------------------------------------
-#define BF_TILE 256
+#define BF_TILE 1024
+#define BF_QPW 16                      // queries per workgroup
+
+// merge of two partial 2-NN lists: best = smallest (distance, index); second = second smallest distance overall
+__device__ __forceinline__ void bf_merge(int& b, int& s, int& bi, int wb, int ws, int wi)
+{
+    if (wi < 0) return;
+    if (wb < b || (wb == b && wi < bi)) { s = min(s, b); b = wb; bi = wi; }
+    else s = min(s, wb);
+    s = min(s, ws);
+}
 
 __global__ __launch_bounds__(256) void k_bf_knn2(const uint8_t* __restrict__ desc, const int32_t* __restrict__ counts,
                                                  int slots_per_image, int q0, int t0, int stride, int32_t* __restrict__ out)
 {
+    // Workgroup = 16 queries; lane = (query, sub): the four wavefronts take the four quarters of each 1024-descriptor LDS tile
+    // and the four subs of a wavefront the four sixteenths of a quarter, so a query is spread over 16 lanes and 2000 queries
+    // make 125 workgroups per pair (the 64-queries-per-workgroup version left two thirds of the CUs idle).  A b128 LDS read
+    // sees four distinct addresses per wavefront, one per 16-lane group: broadcast, conflict free.
     __shared__ __attribute__((aligned(16))) uint32_t tile[BF_TILE * 8];
-    __shared__ int m_best[4][64], m_second[4][64], m_idx[4][64];
+    __shared__ int m_best[4][BF_QPW], m_second[4][BF_QPW], m_idx[4][BF_QPW];
     const int pair = blockIdx.y;
     const int qs = q0 + pair * stride, ts = t0 + pair * stride;
     const int nq = counts[qs], nt = counts[ts];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int q = blockIdx.x * 64 + lane;
-    if (blockIdx.x * 64 >= nq) return;                                  // block-uniform
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, ql = lane & 15, sub = lane >> 4;
+    const int q = blockIdx.x * BF_QPW + ql;
+    if (blockIdx.x * BF_QPW >= nq) return;                              // block-uniform
     const uint32_t* qd = reinterpret_cast<const uint32_t*>(desc + ((size_t)qs * slots_per_image + min(q, nq - 1)) * 32);
     uint32_t a[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) a[k] = qd[k];
-    const uint32_t* td = reinterpret_cast<const uint32_t*>(desc + (size_t)ts * slots_per_image * 32);
+    const uint4* td = reinterpret_cast<const uint4*>(desc + (size_t)ts * slots_per_image * 32);
     int best = 257, second = 257, bidx = -1;
     for (int base = 0; base < nt; base += BF_TILE) {
         const int n = min(BF_TILE, nt - base);
         __syncthreads();
-        for (int i = threadIdx.x; i < n * 8; i += 256) tile[i] = td[(size_t)base * 8 + i];
+        for (int i = threadIdx.x; i < n * 2; i += 256) reinterpret_cast<uint4*>(tile)[i] = td[(size_t)base * 2 + i];
         __syncthreads();
-        const int jb = wave * 64, je = min(jb + 64, n);
+        const int jb = wave * (BF_TILE / 4) + sub * (BF_TILE / 16), je = min(jb + BF_TILE / 16, n);
         for (int j = jb; j < je; ++j) {
             const uint4 b0 = *reinterpret_cast<const uint4*>(&tile[j * 8]);
             const uint4 b1 = *reinterpret_cast<const uint4*>(&tile[j * 8 + 4]);
@@ -53,19 +67,21 @@ __global__ __launch_bounds__(256) void k_bf_knn2(const uint8_t* __restrict__ des
             else if (d < second) second = d;
         }
     }
-    m_best[wave][lane] = best; m_second[wave][lane] = second; m_idx[wave][lane] = bidx;
+    // the four subs of a wavefront (lanes ql, ql + 16, ql + 32, ql + 48), then the four wavefronts
+#pragma unroll
+    for (int o = 16; o < 64; o <<= 1) {
+        const int wb = __shfl_xor(best, o), ws = __shfl_xor(second, o), wi = __shfl_xor(bidx, o);
+        int b = best, s2 = second, bi = bidx;
+        if (bi < 0) { b = 257; s2 = 257; }
+        bf_merge(b, s2, bi, wb, ws, wi);
+        best = b; second = s2; bidx = bi;
+    }
+    if (sub == 0) { m_best[wave][ql] = best; m_second[wave][ql] = second; m_idx[wave][ql] = bidx; }
     __syncthreads();
-    if (wave == 0 && q < nq) {
-        // merge the four partial 2-NN lists: best = smallest (distance, index); second = second smallest distance overall
+    if (threadIdx.x < BF_QPW && q < nq) {
         int b = 257, s = 257, bi = -1;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const int wb = m_best[w][lane], ws = m_second[w][lane], wi = m_idx[w][lane];
-            if (wi < 0) continue;
-            if (wb < b || (wb == b && wi < bi)) { s = min(s, b); b = wb; bi = wi; }
-            else s = min(s, wb);
-            s = min(s, ws);
-        }
+        for (int w = 0; w < 4; ++w) bf_merge(b, s, bi, m_best[w][ql], m_second[w][ql], m_idx[w][ql]);
         int32_t* o = out + (size_t)qs * 3 * slots_per_image;
         o[q] = bi; o[slots_per_image + q] = b; o[2 * slots_per_image + q] = s;
     }
@@ -73,7 +89,7 @@ __global__ __launch_bounds__(256) void k_bf_knn2(const uint8_t* __restrict__ des
 
 int lp_launch_bf_strided(lpslam_hip_ctx* c, int q0, int t0, int stride, int n_pairs)
 {
-    dim3 grid((c->slots_per_image + 63) / 64, n_pairs);
+    dim3 grid((c->slots_per_image + BF_QPW - 1) / BF_QPW, n_pairs);
     hipLaunchKernelGGL(k_bf_knn2, grid, dim3(256), 0, c->stream, c->d_desc, c->d_kp_count, c->slots_per_image, q0, t0, stride, c->d_bf);
     LP_HIP(hipGetLastError());
     return LPSLAM_HIP_OK;
