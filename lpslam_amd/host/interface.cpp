@@ -25,7 +25,7 @@ bool LpSlamManager::addStereoImageFromBuffer(uint32_t n, LpSlamTimestamp t, uint
 bool LpSlamManager::compressImage(uint8_t*, LpSlamImageDescription, uint8_t*, uint32_t*) { return false; }        // JPEG codec: out of scope
 void LpSlamManager::setCameraConfiguration(LpSlamCameraConfiguration c) { m_impl->setCameraConfiguration(c); }
 bool LpSlamManager::readConfigurationFile(char const* f) { return m_impl->readConfigurationFile(f ? f : ""); }
-bool LpSlamManager::readReplayItems(char const*) { return false; }
+bool LpSlamManager::readReplayItems(char const* f) { return m_impl->loadReplayItems(f ? f : ""); }
 bool LpSlamManager::addSource(char const* n, char const* c) { return m_impl->addSource(n ? n : "", c ? c : ""); }
 bool LpSlamManager::addTracker(char const* n, char const* c) { return m_impl->addTracker(n ? n : "", c ? c : ""); }
 bool LpSlamManager::addProcessor(char const* n, char const* c) { return m_impl->addProcessor(n ? n : "", c ? c : ""); }
@@ -65,6 +65,7 @@ LPS_API void lpslam_manager_on_reconstruction(lpslam_c_manager* m, lpslam_c_reco
 LPS_API void lpslam_manager_request_nav_data(lpslam_c_manager* m, RequestNavDataCallback_t cb, void* user) { m->mgr.addRequestNavDataCallback(cb, user); }
 LPS_API int lpslam_manager_add_stereo_image(lpslam_c_manager* m, uint32_t cam, uint64_t ts, uint8_t* l, uint8_t* r, const LpSlamImageDescription* d) { return m->mgr.addStereoImageFromBuffer(cam, ts, l, r, *d); }
 LPS_API int lpslam_manager_add_image(lpslam_c_manager* m, uint32_t cam, uint64_t ts, uint8_t* b, const LpSlamImageDescription* d) { return m->mgr.addImageFromBuffer(cam, ts, b, *d); }
+LPS_API int lpslam_manager_read_replay_items(lpslam_c_manager* m, const char* f) { return m->mgr.readReplayItems(f); }
 LPS_API void lpslam_manager_start(lpslam_c_manager* m) { m->mgr.start(); }
 LPS_API void lpslam_manager_stop(lpslam_c_manager* m) { m->mgr.stop(); }
 LPS_API void lpslam_manager_status(lpslam_c_manager* m, LpSlamStatus* out) { *out = m->mgr.getSlamStatus(); }

@@ -1,5 +1,6 @@
 // slam_manager.cpp -- see slam_manager.h.
 #include "slam_manager.h"
+#include "replay.h"
 
 #include <cmath>
 #include <cstdio>
@@ -249,6 +250,30 @@ bool SlamManager::addImageFromBuffer(uint32_t cameraNumber, LpSlamTimestamp time
         q.cameraNumberSecond = cameraNumber + 1;
     } else { logMessage(LpSlamLogLevel_Error, "Image structure not supported"); return false; }
     m_camQueue.push(std::move(q));
+    return true;
+}
+
+// ---- replay (src/Manager/ReplayEngine.cpp:61-242) ---------------------------------------------------------------------------
+// The reference streams the file in chunks of `replay_chunks` camera records as the camera queue drains; frames are small here
+// and the whole file is queued at once.  As there, replayed frames carry no ROS time stamp, so the navigation callback is
+// not asked for them (SlamManager.cpp:148): trackers see them only with "require_odometry": false.
+bool SlamManager::loadReplayItems(std::string const& filename)
+{
+    logMessage(LpSlamLogLevel_Info, "Loading replay items from file " + filename);
+    std::vector<ReplayFrame> frames;
+    ReplayStats st;
+    std::string err;
+    if (!read_replay_file(filename, frames, st, &err)) { logMessage(LpSlamLogLevel_Info, "Cannot load replay from file " + filename); return false; }
+    for (auto& f : frames) {
+        CameraQueueEntry q;
+        q.valid = true; q.timestamp = int64ToTimeStamp(f.timestamp);
+        q.cameraNumber = (uint32_t)f.camera; q.cameraNumberSecond = (uint32_t)f.camera_second;
+        q.image = std::move(f.image);
+        if (f.image_second) q.image_second = std::move(*f.image_second);
+        m_camQueue.push(std::move(q));
+    }
+    logMessage(LpSlamLogLevel_Info, "Loaded " + std::to_string(frames.size()) + " replay items (" + std::to_string(st.records) + " records, " +
+               std::to_string(st.undecodable_images) + " frames with an image codec this library does not carry" + (st.truncated ? ", stream truncated)" : ")"));
     return true;
 }
 

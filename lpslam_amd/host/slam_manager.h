@@ -28,6 +28,7 @@ public:
     void setCameraConfiguration(LpSlamCameraConfiguration const& c) { m_camRegistry.setConfiguration(c); }
     bool readConfigurationFile(std::string const& filename);
     bool addSource(std::string const& name, std::string const& jsonConfig);
+    bool loadReplayItems(std::string const& filename);      // SlamManager::loadReplayItems (reference SlamManager.cpp:503-505)
     bool addTracker(std::string const& name, std::string const& jsonConfig);
     bool addProcessor(std::string const& name, std::string const& jsonConfig);
 

@@ -69,6 +69,7 @@ def load():
         for name in ("add_tracker", "add_processor", "add_source"):
             getattr(_lib, "lpslam_manager_" + name).argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
         _lib.lpslam_manager_read_configuration_file.argtypes = [C.c_void_p, C.c_char_p]
+        _lib.lpslam_manager_read_replay_items.argtypes = [C.c_void_p, C.c_char_p]
         _lib.lpslam_manager_set_camera_configuration.argtypes = [C.c_void_p, C.POINTER(CameraConfiguration)]
         _lib.lpslam_manager_default_camera_configuration.argtypes = [C.POINTER(CameraConfiguration)]
         _lib.lpslam_manager_on_reconstruction.argtypes = [C.c_void_p, RECON_CB, C.c_void_p]
@@ -113,6 +114,9 @@ class Manager:
 
     def add_processor(self, name, cfg=""):
         return bool(self.lib.lpslam_manager_add_processor(self.h, name.encode(), cfg.encode()))
+
+    def read_replay_items(self, path):
+        return bool(self.lib.lpslam_manager_read_replay_items(self.h, str(path).encode()))
 
     def add_source(self, name, cfg=""):
         return bool(self.lib.lpslam_manager_add_source(self.h, name.encode(), cfg.encode()))

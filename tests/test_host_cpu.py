@@ -3,6 +3,7 @@ boundary tests: slam_manager.read_config_file / read_camera_calibration (src/tes
 interface.type_conversion / add_marker-style smoke (src/test/InterfaceTest.cpp:14-44)."""
 import json
 import os
+import struct
 import time
 
 import numpy as np
@@ -110,3 +111,33 @@ def test_frames_without_odometry_are_skipped_and_reported(mgrlib):
 def test_default_camera_configuration(mgrlib):
     c = mgrlib.default_camera()
     assert c.fps == 25.0 and c.distortion_function == mgrlib.NO_DISTORTION and list(c.rotation) == [1, 0, 0, 0, 1, 0, 0, 0, 1]
+
+
+def test_replay_stream_reader(tmp_path):
+    """src/Serialize/ProtoStream.h framing + SlamSerialize.proto CameraImage records (ReplayEngine.cpp:83-242)."""
+    import ctypes
+    import replay_format as rf
+    from lpslam_amd import _build
+    lib = ctypes.CDLL(_build.host_library())
+    rng = np.random.default_rng(0)
+    l = rng.integers(0, 256, (48, 64)).astype(np.uint8); r = rng.integers(0, 256, (48, 64)).astype(np.uint8)
+    imu = rf.f_varint(1, 5) + rf.f_bytes(2, rf.vec3(0, 0, 9.81)) + rf.f_bytes(3, rf.vec3(0.1, 0, 0))
+    stream = b"".join([
+        rf.record(rf.SENSOR_IMU, imu),
+        rf.record(rf.CAMERA_IMAGE, rf.camera_image(1_000_000_123, l, r, cam=4, odom=((1.5, -2.0, 0.25), (0.5, 0.5, -0.5, 0.5)), data_number=7)),
+        rf.record(rf.RESULT, rf.f_varint(1, 9)),
+        rf.record(rf.CAMERA_IMAGE, rf.camera_image(2_000_000_000, l, None, cam=2, map_=((3, 4, 5), (1, 0, 0, 0)))),
+        rf.record(rf.CAMERA_IMAGE, rf.camera_image(3_000_000_000, l, raw_left=b"\\xff\\xd8\\xff\\xe0JFIF-not-decodable")),     # what the recorder writes
+        rf.record(rf.SENSOR_GLOBAL_STATE, rf.f_varint(1, 11)), rf.record(rf.SENSOR_FEATURE, rf.f_varint(1, 12)),
+        struct.pack("<QQ", 77, 3) + b"abc",                                                                                 # corrupt tail
+    ])
+    path = tmp_path / "rec.pb"; path.write_bytes(stream)
+    stats = (ctypes.c_long * 8)(); first = (ctypes.c_long * 6)(); state = (ctypes.c_double * 14)()
+    lib.lpslam_replay_probe.restype = ctypes.c_long
+    n = lib.lpslam_replay_probe(str(path).encode(), stats, first, state)
+    assert n == 2 and list(stats) == [7, 3, 1, 1, 1, 1, 1, 1]
+    assert list(first) == [1_000_000_123, 4, 5, 64, 48, 1]
+    assert list(state)[:7] == [1.5, -2.0, 0.25, 0.5, 0.5, -0.5, 0.5] and all(np.isnan(list(state)[7:]))
+    assert lib.lpslam_replay_probe(str(tmp_path / "missing.pb").encode(), stats, first, state) == -1
+    empty = tmp_path / "empty.pb"; empty.write_bytes(b"")
+    assert lib.lpslam_replay_probe(str(empty).encode(), stats, first, state) == 0 and list(stats)[:2] == [0, 0]

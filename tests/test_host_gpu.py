@@ -50,3 +50,39 @@ def test_stereo_sequence_through_the_manager(hiplib):
     zs = [r["p"][2] for r in valid]
     assert all(b > a - 0.01 for a, b in zip(zs, zs[1:]))           # moving forward
     assert abs(last["q"][0]) > 0.999                                # yaw stays below 0.2 degrees
+
+
+def test_replay_file_through_the_manager(hiplib, tmp_path):
+    """A recording in the reference's stream format (src/Serialize/ProtoStream.h, SlamSerialize.proto; images as PGM) is read
+    by LpSlamManager::readReplayItems and tracked; replayed frames carry no ROS stamp, hence "require_odometry": false."""
+    import json
+    import replay_format as rf
+    from lpslam_amd import _build, manager
+    _build.host_library()
+    w, h, n_frames = 640, 480, 10
+    k = synth.intrinsics(w, h)
+    seq = synth.StereoSequence(w, h, 6, n_points=6000)
+    stream = b"".join(rf.record(rf.CAMERA_IMAGE, rf.camera_image((i + 1) * 40_000_000, *seq.frame(i), cam=0, data_number=i)) for i in range(n_frames))
+    rec = tmp_path / "drive.pb"; rec.write_bytes(stream)
+    cfg = {"manager": {"require_odometry": False}}
+    cfg_path = tmp_path / "replay.json"; cfg_path.write_text(json.dumps(cfg))
+    m = manager.Manager()
+    assert m.read_configuration_file(str(cfg_path))
+    for num in (0, 1):
+        c = manager.default_camera()
+        c.camera_number = num; c.f_x = k["fx"]; c.f_y = k["fy"]; c.c_x = k["cx"]; c.c_y = k["cy"]
+        c.resolution_x = w; c.resolution_y = h; c.focal_x_baseline = k["fxb"]
+        m.set_camera(c)
+    assert m.add_tracker("VSLAMStereo", '{"cameraSetup": "stereo", "slamKeypoints": 1000, "numLevels": 4, "keyframeInterval": 4}')
+    m.collect_results()
+    m.start()
+    assert m.read_replay_items(rec) and not m.read_replay_items(tmp_path / "nope.pb")
+    t0 = time.time()
+    while len(m.results) < n_frames and time.time() - t0 < 60:
+        time.sleep(0.01)
+    st = m.status()
+    m.stop()
+    assert len(m.results) == n_frames
+    valid = [r for r in m.results if r["valid"]]
+    assert len(valid) >= n_frames - 2 and st.key_frames >= 2
+    assert [r["timestamp"] for r in m.results] == [(i + 1) * 40_000_000 for i in range(n_frames)]
