@@ -306,6 +306,34 @@ def main():
             th.join()
         extras["multi_session"] = {"sessions_per_gpu": S, "frames_per_s": round(S * k_ms * args.frames / (time.perf_counter() - t2), 1)}
         del others
+        # the integrated path: the same sequence through the drop-in boundary (LpSlamManager -> stereo tracker: upload, extract,
+        # stereo + projection matching, one-launch pose optimiser, keyframe every 6th frame with a windowed local BA)
+        try:
+            from lpslam_amd import manager, _build
+            _build.host_library()
+            mg = manager.Manager()
+            for num in (0, 1):
+                c = manager.default_camera()
+                c.camera_number = num; c.f_x = wl.k["fx"]; c.f_y = wl.k["fy"]; c.c_x = wl.k["cx"]; c.c_y = wl.k["cy"]
+                c.resolution_x = W; c.resolution_y = H; c.focal_x_baseline = wl.k["fxb"]
+                mg.set_camera(c)
+            mg.add_tracker("VSLAMStereo", '{"cameraSetup": "stereo", "slamKeypoints": %d, "numLevels": %d, "keyframeInterval": %d, "device": %d}' % (KPTS, LEVELS, FRAMES_PER_STEP, device))
+            mg.collect_results(); mg.provide_odometry()
+            mg.start()
+            seq_t = wl.synth.StereoSequence(W, H, 4)
+            tr_frames = [seq_t.frame(i) for i in range(30)]
+            t2 = time.perf_counter()
+            for i, (l, r) in enumerate(tr_frames):
+                mg.add_stereo((i + 1) * 40_000_000, l, r)
+            while len(mg.results) < len(tr_frames) and time.perf_counter() - t2 < 60:
+                time.sleep(0.0005)
+            t_tr = time.perf_counter() - t2
+            st_tr = mg.status()
+            mg.stop()
+            extras["tracker"] = {"frames": len(mg.results), "valid": int(sum(r["valid"] for r in mg.results)), "frames_per_s": round(len(mg.results) / t_tr, 1),
+                                 "last_frame_ms": round(1e3 * st_tr.frame_time, 3), "key_frames": int(st_tr.key_frames)}
+        except Exception as e:      # noqa: BLE001 -- an extra must not take the benchmark line down
+            extras["tracker"] = {"error": str(e)}
         pg = wl.synth.pose_graph_problem(200, 0)
         graph = wl.hip.PoseGraph(wl.ctx, pg["verts"], pg["fixed"], wl.hip.sim3_edges(pg["edge_i"], pg["edge_j"], pg["meas"]), True)
         graph.optimize(2)

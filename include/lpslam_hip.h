@@ -184,6 +184,10 @@ int lpslam_hip_ba_set_points_fixed(lpslam_hip_ba* ba, int32_t points_fixed);
  * (chi2 > 5.991 mono / 7.815 stereo) re-classified after every round, Huber dropped after the third round.
  * outlier may be NULL; *n_inliers receives the number of inlier observations. */
 int lpslam_hip_ba_pose_optimize(lpslam_hip_ba* ba, uint8_t* outlier, int32_t* n_inliers);
+/* The same flow for the tracker's per-frame call, without a problem object: one launch, one workgroup, the whole 4 x 10
+ * iteration flow on the device (pose7 in / out; obs[k].point indexes `points`, obs[k].pose is ignored). */
+int lpslam_hip_pose_optimize(lpslam_hip_ctx* ctx, double* pose7, const double* points, int32_t n_points, const lpslam_hip_ba_obs* obs,
+                             int32_t n_obs, const lpslam_hip_ba_camera* cam, uint8_t* outlier, int32_t* n_inliers);
 /* local_bundle_adjuster flow: first_iters robust, outlier classification, second_iters plain. */
 int lpslam_hip_ba_local(lpslam_hip_ba* ba, int32_t first_iters, int32_t second_iters, uint8_t* outlier);
 /* Restores the poses / points / activity mask given at creation (kept in HBM) and clears the LM state. */

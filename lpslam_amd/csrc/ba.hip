@@ -1099,6 +1099,199 @@ __global__ __launch_bounds__(256) void k_ba_obs_chi2(BaView v, double* chi2, uin
     depth_pos[ko] = pc[2] > 0 ? 1 : 0;
 }
 
+// ---- motion-only pose optimisation, the whole flow in one workgroup ---------------------------------------------------------
+// [UPSTREAM] optimize::pose_optimizer: one SE3 vertex, unary reprojection edges to fixed landmarks, 4 rounds of 10 Levenberg
+// iterations (g2o lambda control), after every round the observations with chi2 > 5.991 (mono) / 7.815 (stereo) become
+// outliers (and may come back), Huber is dropped after the third round, the flow stops when fewer than 5 inliers remain.
+// The tracker needs this once per frame: instead of ~600 launches through the general BA machinery the 6x6 system lives in
+// LDS and one launch returns the pose (one workgroup; several frames / candidates could share a launch, one workgroup each).
+struct PoShared {
+    double pose[7], trial[7];
+    double red[4][28];
+    double H[36], b[6], x[6];
+    double lambda, ni, current_chi, rho;
+    int ok, again, stop, bad;
+};
+
+__device__ __forceinline__ double po_block_sum(double v, PoShared& sh)
+{
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh.red[threadIdx.x >> 6][27] = v;
+    __syncthreads();
+    return ((sh.red[0][27] + sh.red[1][27]) + sh.red[2][27]) + sh.red[3][27];
+}
+// residual of observation k at pose p7; returns the dimension (2 / 3)
+__device__ __forceinline__ int po_residual(const BaCam& cam, const double* R, const double* t, const double* X, const lpslam_hip_ba_obs& o, double* e, double* pc)
+{
+#pragma unroll
+    for (int i = 0; i < 3; ++i) pc[i] = R[i * 3] * X[0] + R[i * 3 + 1] * X[1] + R[i * 3 + 2] * X[2] + t[i];
+    const double iz = 1.0 / pc[2];
+    const double u = cam.fx * pc[0] * iz + cam.cx, vv = cam.fy * pc[1] * iz + cam.cy;
+    e[0] = o.u - u; e[1] = o.v - vv;
+    if (o.ur < 0) { e[2] = 0; return 2; }
+    e[2] = o.ur - (u - cam.fxb * iz);
+    return 3;
+}
+__device__ double po_chi2(const BaCam& cam, const double* p7, const double* pts, const lpslam_hip_ba_obs* obs, const uint8_t* active, int n, int robust, PoShared& sh)
+{
+    double R[9];
+    quat_to_rot(p7, R);
+    double chi = 0;
+    for (int k = threadIdx.x; k < n; k += 256) {
+        if (!active[k]) continue;
+        double e[3], pc[3];
+        const int D = po_residual(cam, R, p7 + 4, pts + 3 * (size_t)obs[k].point, obs[k], e, pc);
+        double c = obs[k].inv_sigma2 * (e[0] * e[0] + e[1] * e[1] + (D == 3 ? e[2] * e[2] : 0.0));
+        const double delta = D == 3 ? cam.hub_stereo : cam.hub_mono;
+        if (robust && delta > 0) { double r0, r1; huber(c, delta, &r0, &r1); c = r0; }
+        chi += c;
+    }
+    return po_block_sum(chi, sh);
+}
+
+__global__ __launch_bounds__(256) void k_pose_optimize(double* pose7, const double* pts, const lpslam_hip_ba_obs* obs, int n, BaCam cam,
+                                                       uint8_t* active, uint8_t* outlier, int* n_inliers)
+{
+    __shared__ PoShared sh;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < 7) sh.pose[tid] = pose7[tid];
+    for (int k = tid; k < n; k += 256) { active[k] = 1; outlier[k] = 0; }
+    if (tid == 0) sh.bad = 0;
+    __syncthreads();
+    int robust = 1;
+    for (int round = 0; round < 4; ++round) {
+        if (tid == 0) sh.stop = 0;
+        __syncthreads();
+        for (int it = 0; it < 10; ++it) {
+            if (sh.stop) break;
+            const double cur = po_chi2(cam, sh.pose, pts, obs, active, n, robust, sh);
+            double R[9];
+            quat_to_rot(sh.pose, R);
+            double acc[27];
+#pragma unroll
+            for (int q = 0; q < 27; ++q) acc[q] = 0;
+            for (int k = tid; k < n; k += 256) {
+                if (!active[k]) continue;
+                double e[3], pc[3], A[3][3], B[3][6];
+                const int D = po_residual(cam, R, sh.pose + 4, pts + 3 * (size_t)obs[k].point, obs[k], e, pc);
+                const double om = obs[k].inv_sigma2;
+                const double chi = om * (e[0] * e[0] + e[1] * e[1] + (D == 3 ? e[2] * e[2] : 0.0));
+                const double delta = D == 3 ? cam.hub_stereo : cam.hub_mono;
+                double w = om;
+                if (robust && delta > 0) { double r0, r1; huber(chi, delta, &r0, &r1); w *= r1; }
+                ba_jacobians(cam, R, pc, D, A, B);
+                int idx = 0;
+#pragma unroll
+                for (int a = 0; a < 6; ++a) {
+#pragma unroll
+                    for (int c = a; c < 6; ++c) {
+                        double s2 = 0;
+#pragma unroll
+                        for (int r = 0; r < 3; ++r) s2 += B[r][a] * w * B[r][c];
+                        acc[idx++] += s2;
+                    }
+                    double s3 = 0;
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) s3 += B[r][a] * (-w * e[r]);
+                    acc[21 + a] += s3;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 27; ++q) { const double sq = wave_sum(acc[q]); if (lane == 0) sh.red[wave][q] = sq; }
+            __syncthreads();
+            if (tid == 0) {
+                int idx = 0;
+                double maxd = 0;
+                for (int a = 0; a < 6; ++a) {
+                    for (int c = a; c < 6; ++c, ++idx) {
+                        const double hv = ((sh.red[0][idx] + sh.red[1][idx]) + sh.red[2][idx]) + sh.red[3][idx];
+                        sh.H[a * 6 + c] = hv; sh.H[c * 6 + a] = hv;
+                    }
+                    sh.b[a] = ((sh.red[0][21 + a] + sh.red[1][21 + a]) + sh.red[2][21 + a]) + sh.red[3][21 + a];
+                    maxd = fmax(maxd, fabs(sh.H[a * 7]));
+                }
+                if (it == 0) { sh.lambda = 1e-5 * maxd; sh.ni = 2; }
+                sh.current_chi = cur;
+            }
+            __syncthreads();
+            for (int qmax = 1; qmax <= 10; ++qmax) {
+                if (tid == 0) {
+                    double A[36];
+                    for (int i = 0; i < 36; ++i) A[i] = sh.H[i];
+                    for (int j = 0; j < 6; ++j) A[j * 7] += sh.lambda;
+                    int ok = 1;
+                    for (int j = 0; j < 6 && ok; ++j) {
+                        double d = A[j * 6 + j];
+                        for (int k = 0; k < j; ++k) d -= A[j * 6 + k] * A[j * 6 + k];
+                        if (!(d > 0.0)) { ok = 0; break; }
+                        d = sqrt(d);
+                        A[j * 6 + j] = d;
+                        for (int i = j + 1; i < 6; ++i) {
+                            double s2 = A[i * 6 + j];
+                            for (int k = 0; k < j; ++k) s2 -= A[i * 6 + k] * A[j * 6 + k];
+                            A[i * 6 + j] = s2 / d;
+                        }
+                    }
+                    if (ok) {
+                        double x[6];
+                        for (int i = 0; i < 6; ++i) { double s2 = sh.b[i]; for (int k = 0; k < i; ++k) s2 -= A[i * 6 + k] * x[k]; x[i] = s2 / A[i * 7]; }
+                        for (int i = 5; i >= 0; --i) { double s2 = x[i]; for (int k = i + 1; k < 6; ++k) s2 -= A[k * 6 + i] * x[k]; x[i] = s2 / A[i * 7]; }
+                        for (int i = 0; i < 6; ++i) sh.x[i] = x[i];
+                        pose_oplus(sh.pose, x, sh.trial);
+                    } else { for (int i = 0; i < 7; ++i) sh.trial[i] = sh.pose[i]; }
+                    sh.ok = ok;
+                }
+                __syncthreads();
+                double temp = po_chi2(cam, sh.trial, pts, obs, active, n, robust, sh);
+                if (tid == 0) {
+                    if (!sh.ok) temp = DBL_MAX;
+                    double rho = sh.current_chi - temp, scale = 0;
+                    if (sh.ok) for (int j = 0; j < 6; ++j) scale += sh.x[j] * (sh.lambda * sh.x[j] + sh.b[j]);
+                    scale += 1e-3;
+                    rho /= scale;
+                    if (rho > 0 && isfinite(temp)) {
+                        const double t3 = 2 * rho - 1;
+                        double alpha = 1. - t3 * t3 * t3;
+                        alpha = fmin(alpha, 2. / 3.);
+                        sh.lambda *= fmax(1. / 3., alpha);
+                        sh.ni = 2;
+                        sh.current_chi = temp;
+                        for (int i = 0; i < 7; ++i) sh.pose[i] = sh.trial[i];
+                    } else {
+                        sh.lambda *= sh.ni; sh.ni *= 2;
+                    }
+                    sh.again = (rho < 0 && qmax < 10) ? 1 : 0;
+                    if (!sh.again && (qmax == 10 || rho == 0)) sh.stop = 1;
+                }
+                __syncthreads();
+                if (!sh.again) break;
+            }
+        }
+        __syncthreads();
+        // classification with the plain chi2 of this round's pose
+        double R[9];
+        quat_to_rot(sh.pose, R);
+        int bad = 0;
+        for (int k = tid; k < n; k += 256) {
+            double e[3], pc[3];
+            const int D = po_residual(cam, R, sh.pose + 4, pts + 3 * (size_t)obs[k].point, obs[k], e, pc);
+            const double chi = obs[k].inv_sigma2 * (e[0] * e[0] + e[1] * e[1] + (D == 3 ? e[2] * e[2] : 0.0));
+            const double thr = D == 3 ? 7.81473 : 5.99146;
+            const int out = thr < chi ? 1 : 0;
+            outlier[k] = (uint8_t)out; active[k] = (uint8_t)!out;
+            bad += out;
+        }
+        const int n_bad = (int)po_block_sum((double)bad, sh);
+        if (tid == 0) sh.bad = n_bad;
+        if (round == 2) robust = 0;
+        __syncthreads();
+        if (n - n_bad < 5) break;
+    }
+    if (tid < 7) pose7[tid] = sh.pose[tid];
+    if (tid == 0) *n_inliers = n - sh.bad;
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1566,6 +1759,38 @@ int lpslam_hip_ba_chi2(lpslam_hip_ba* b, double* chi2, uint8_t* depth_positive)
     if (chi2) LP_HIP(hipMemcpyAsync(chi2, b->d_chi_obs, (size_t)b->n_obs * sizeof(double), hipMemcpyDeviceToHost, b->stream));
     if (depth_positive) LP_HIP(hipMemcpyAsync(depth_positive, b->d_depth, (size_t)b->n_obs, hipMemcpyDeviceToHost, b->stream));
     LP_HIP(hipStreamSynchronize(b->stream));
+    return LPSLAM_HIP_OK;
+}
+
+int lpslam_hip_pose_optimize(lpslam_hip_ctx* ctx, double* pose7, const double* points, int32_t n_points, const lpslam_hip_ba_obs* obs, int32_t n_obs,
+                             const lpslam_hip_ba_camera* cam, uint8_t* outlier, int32_t* n_inliers)
+{
+    if (!ctx || !pose7 || !cam || n_obs < 0 || n_points < 0 || (n_obs > 0 && (!points || !obs))) { set_error("invalid pose-optimiser arguments"); return LPSLAM_HIP_ERR_INVALID; }
+    for (int k = 0; k < n_obs; ++k) if (obs[k].point < 0 || obs[k].point >= n_points) { set_error("observation %d references point %d out of range", k, obs[k].point); return LPSLAM_HIP_ERR_INVALID; }
+    LP_HIP(hipSetDevice(ctx->cfg.device));
+    hipStream_t s = ctx->stream;
+    double* d_pose = nullptr; double* d_pts = nullptr; lpslam_hip_ba_obs* d_obs = nullptr; uint8_t* d_act = nullptr; uint8_t* d_out = nullptr; int* d_n = nullptr;
+    auto release = [&]() { for (void* p : {(void*)d_pose, (void*)d_pts, (void*)d_obs, (void*)d_act, (void*)d_out, (void*)d_n}) if (p) (void)hipFree(p); };
+#define PO_HIP(x) do { if ((x) != hipSuccess) { release(); set_error("HIP call failed: %s", #x); return LPSLAM_HIP_ERR_DEVICE; } } while (0)
+    const size_t no = (size_t)std::max(n_obs, 1), np = (size_t)std::max(n_points, 1);
+    PO_HIP(hipMalloc((void**)&d_pose, 7 * sizeof(double)));
+    PO_HIP(hipMalloc((void**)&d_pts, 3 * np * sizeof(double)));
+    PO_HIP(hipMalloc((void**)&d_obs, no * sizeof(lpslam_hip_ba_obs)));
+    PO_HIP(hipMalloc((void**)&d_act, no)); PO_HIP(hipMalloc((void**)&d_out, no)); PO_HIP(hipMalloc((void**)&d_n, sizeof(int)));
+    PO_HIP(hipMemcpyAsync(d_pose, pose7, 7 * sizeof(double), hipMemcpyHostToDevice, s));
+    if (n_points) PO_HIP(hipMemcpyAsync(d_pts, points, 3 * (size_t)n_points * sizeof(double), hipMemcpyHostToDevice, s));
+    if (n_obs) PO_HIP(hipMemcpyAsync(d_obs, obs, (size_t)n_obs * sizeof(lpslam_hip_ba_obs), hipMemcpyHostToDevice, s));
+    const BaCam c{cam->fx, cam->fy, cam->cx, cam->cy, cam->focal_x_baseline, cam->huber_mono, cam->huber_stereo};
+    hipLaunchKernelGGL(k_pose_optimize, dim3(1), dim3(256), 0, s, d_pose, d_pts, d_obs, n_obs, c, d_act, d_out, d_n);
+    PO_HIP(hipGetLastError());
+    int32_t inl = 0;
+    PO_HIP(hipMemcpyAsync(pose7, d_pose, 7 * sizeof(double), hipMemcpyDeviceToHost, s));
+    PO_HIP(hipMemcpyAsync(&inl, d_n, sizeof(int), hipMemcpyDeviceToHost, s));
+    if (outlier && n_obs) PO_HIP(hipMemcpyAsync(outlier, d_out, (size_t)n_obs, hipMemcpyDeviceToHost, s));
+    PO_HIP(hipStreamSynchronize(s));
+#undef PO_HIP
+    release();
+    if (n_inliers) *n_inliers = inl;
     return LPSLAM_HIP_OK;
 }
 

@@ -36,7 +36,7 @@ SYMBOLS = [
     "lpslam_hip_match_stereo", "lpslam_hip_match_stereo_strided", "lpslam_hip_get_stereo",
     "lpslam_hip_match_projection", "lpslam_hip_match_orientation_filter",
     "lpslam_hip_ba_create", "lpslam_hip_ba_destroy", "lpslam_hip_ba_set_active", "lpslam_hip_ba_optimize",
-    "lpslam_hip_ba_local", "lpslam_hip_ba_set_points_fixed", "lpslam_hip_ba_pose_optimize", "lpslam_hip_ba_reset", "lpslam_hip_ba_get", "lpslam_hip_ba_chi2", "lpslam_hip_ba_reduced_buffer",
+    "lpslam_hip_ba_local", "lpslam_hip_ba_set_points_fixed", "lpslam_hip_ba_pose_optimize", "lpslam_hip_pose_optimize", "lpslam_hip_ba_reset", "lpslam_hip_ba_get", "lpslam_hip_ba_chi2", "lpslam_hip_ba_reduced_buffer",
     "lpslam_hip_ba_step_begin", "lpslam_hip_ba_step_lambda0", "lpslam_hip_ba_step_solve", "lpslam_hip_ba_scalar_buffer", "lpslam_hip_ba_step_end", "lpslam_hip_ba_status",
     "lpslam_hip_sim3_create", "lpslam_hip_sim3_destroy", "lpslam_hip_sim3_optimize", "lpslam_hip_sim3_get", "lpslam_hip_sim3_chi2", "lpslam_hip_sim3_transform_optimize",
 ]
@@ -400,3 +400,14 @@ def match_orientation_filter(angle_q, angle_t, match_idx):
     m = np.ascontiguousarray(match_idx, np.int32).copy(); n = C.c_int32()
     _check(load().lpslam_hip_match_orientation_filter(_p(aq), _p(at), _p(m), len(m), C.byref(n)))
     return m, n.value
+
+
+def pose_optimize(ctx, pose7, points, obs, cam, robust_kernel=True):
+    """optimize::pose_optimizer in one launch (lpslam_hip_pose_optimize): returns (pose7, outlier mask, inliers)."""
+    pose = np.ascontiguousarray(pose7, np.float64).copy(); pts = np.ascontiguousarray(points, np.float64)
+    o = np.ascontiguousarray(obs, BA_OBS_DTYPE)
+    c = BaCamera(cam["fx"], cam["fy"], cam["cx"], cam["cy"], cam["fxb"],
+                 float(np.sqrt(5.991)) if robust_kernel else 0.0, float(np.sqrt(7.815)) if robust_kernel else 0.0)
+    out = np.zeros(max(len(o), 1), np.uint8); n = C.c_int32()
+    _check(ctx.lib.lpslam_hip_pose_optimize(ctx.h, _p(pose), _p(pts), len(pts), _p(o), len(o), C.byref(c), _p(out), C.byref(n)))
+    return pose, out[:len(o)].astype(bool), n.value

@@ -269,16 +269,11 @@ bool HipVslamTrackerBase::poseFromMatches(FrameData& cur, const std::vector<int>
     }
     if (obs.size() < 10) return false;
     double pose7[7] = {init.q[0], init.q[1], init.q[2], init.q[3], init.t[0], init.t[1], init.t[2]};
-    const uint8_t fixed = 0;
     lpslam_hip_ba_camera cam{m_cam.f_x, m_cam.f_y, m_cam.c_x, m_cam.c_y, m_cam.focal_x_baseline, std::sqrt(5.991), std::sqrt(7.815)};
-    lpslam_hip_ba* ba = nullptr;
-    if (lpslam_hip_ba_create(m_ctx, pose7, &fixed, 1, pts.data(), (int32_t)kept_idx.size(), obs.data(), (int32_t)obs.size(), &cam, &ba) != LPSLAM_HIP_OK) return false;
     std::vector<uint8_t> outlier(obs.size());
     int32_t inl = 0;
-    const int rc = lpslam_hip_ba_pose_optimize(ba, outlier.data(), &inl);
-    if (rc == LPSLAM_HIP_OK) lpslam_hip_ba_get(ba, pose7, nullptr);
-    lpslam_hip_ba_destroy(ba);
-    if (rc != LPSLAM_HIP_OK) return false;
+    // one launch: the whole 4 x 10 iteration flow runs in one workgroup on the device
+    if (lpslam_hip_pose_optimize(m_ctx, pose7, pts.data(), (int32_t)kept_idx.size(), obs.data(), (int32_t)obs.size(), &cam, outlier.data(), &inl) != LPSLAM_HIP_OK) return false;
     n_inliers = inl;
     if (inl < 10) return false;
     for (int k = 0; k < 4; ++k) cur.pose.q[k] = pose7[k];

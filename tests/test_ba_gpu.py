@@ -133,6 +133,24 @@ def test_pose_optimizer_parity(hiplib, oracle, ctx):
     assert rot_err(gpose[:, :4], opose[None, :4]).max() < ROT_TOL and np.abs(gpose[0, 4:] - opose[4:]).max() < TRANS_TOL
     assert np.array_equal(gpts, pts)                                # landmarks are constants in this mode
     assert np.abs(gpose[0, 4:] - prob["poses_gt"][kf, 4:]).max() < 0.05
+    # the tracker's entry point: the same flow as ONE launch (one workgroup, 6x6 system in LDS)
+    kpose, kout, kin = hiplib.pose_optimize(ctx, start, pts, hobs, prob["cam"])
+    assert kin == oin and np.array_equal(kout, oout.astype(bool))
+    assert rot_err(kpose[None, :4], opose[None, :4]).max() < ROT_TOL and np.abs(kpose[4:] - opose[4:]).max() < TRANS_TOL
+    # few observations: the flow stops as soon as fewer than 5 inliers remain; none: the pose is returned unchanged
+    few = hobs[:6].copy(); few["v"][:3] += 60.0
+    fp, fo, fi = hiplib.pose_optimize(ctx, start, pts, few, prob["cam"])
+    op2, oo2, oi2 = oracle.pose_optimize(start, pts, _as_oracle_obs(oracle, few), prob["cam"])
+    assert fi == oi2 and np.array_equal(fo, oo2.astype(bool))
+    ep, eo, ei = hiplib.pose_optimize(ctx, start, pts, hobs[:0], prob["cam"])
+    assert ei == 0 and np.array_equal(ep, start)
+
+
+def _as_oracle_obs(oracle, hobs):
+    o = np.zeros(len(hobs), oracle.OBS_DTYPE)
+    for f in o.dtype.names:
+        o[f] = hobs[f]
+    return o
 
 
 def test_global_ba_size_runs(hiplib, oracle):
