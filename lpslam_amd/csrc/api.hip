@@ -118,6 +118,38 @@ static int build_level_table(const lpslam_hip_frontend_config& cfg, LevelTable& 
 
 using namespace lpslam;
 
+// ---- block cache ---------------------------------------------------------------------------------------------------------
+int lp_pool_alloc(lpslam_hip_ctx* c, size_t bytes, void** out, size_t* capacity)
+{
+    const size_t want = ((std::max<size_t>(bytes, 1) + 4095) / 4096) * 4096;
+    {
+        std::lock_guard<std::mutex> lock(c->pool_mutex);
+        size_t best = c->pool.size();
+        for (size_t i = 0; i < c->pool.size(); ++i)
+            if (c->pool[i].first >= want && c->pool[i].first <= 2 * want + 65536 && (best == c->pool.size() || c->pool[i].first < c->pool[best].first)) best = i;
+        if (best != c->pool.size()) {
+            *out = c->pool[best].second; *capacity = c->pool[best].first;
+            c->pool_bytes -= c->pool[best].first;
+            c->pool[best] = c->pool.back(); c->pool.pop_back();
+            return LPSLAM_HIP_OK;
+        }
+    }
+    LP_HIP(hipMalloc(out, want));
+    *capacity = want;
+    return LPSLAM_HIP_OK;
+}
+
+void lp_pool_free(lpslam_hip_ctx* c, void* p, size_t capacity)
+{
+    if (!p) return;
+    constexpr size_t kMaxCached = 2ull << 30;            // of 288 GB
+    {
+        std::lock_guard<std::mutex> lock(c->pool_mutex);
+        if (c->pool_bytes + capacity <= kMaxCached) { c->pool.emplace_back(capacity, p); c->pool_bytes += capacity; return; }
+    }
+    (void)hipFree(p);
+}
+
 extern "C" {
 
 const char* lpslam_hip_last_error(void) { return g_err; }
@@ -215,6 +247,8 @@ void lpslam_hip_destroy(lpslam_hip_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto& blk : c->pool) (void)hipFree(blk.second);
+    c->pool.clear();
     void* bufs[] = {c->d_pyr, c->d_rs_ofs, c->d_rs_coef, c->d_cell_keys, c->d_cell_count, c->d_cand_key, c->d_cand_node,
                     c->d_cand_count, c->d_sel_key, c->d_sel_count, c->d_kpts, c->d_desc,
                     c->d_kp_count, c->d_bf, c->d_stereo, c->d_stereo_idx, c->d_stereo_corr, c->d_tmp_desc, c->d_tmp_res,

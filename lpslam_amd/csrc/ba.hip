@@ -1319,7 +1319,7 @@ struct lpslam_hip_ba {
     std::vector<double> h_ur;                      // mono/stereo classification for the outlier thresholds
     BaCtl h_ctl{};                                 // last control block read back
     int robust = 1, points_fixed = 0;
-    std::vector<void*> allocs;
+    std::vector<std::pair<void*, size_t>> allocs;      // blocks of the context's cache (lp_pool_alloc)
 };
 
 namespace {
@@ -1327,8 +1327,10 @@ namespace {
 template <class T>
 int dalloc(lpslam_hip_ba* b, T** p, size_t n)
 {
-    LP_HIP(hipMalloc((void**)p, std::max<size_t>(n, 1) * sizeof(T)));
-    b->allocs.push_back(*p);
+    void* d = nullptr; size_t cap = 0;
+    int rc = lp_pool_alloc(b->ctx, std::max<size_t>(n, 1) * sizeof(T), &d, &cap); if (rc) return rc;
+    *p = (T*)d;
+    b->allocs.emplace_back(d, cap);
     return LPSLAM_HIP_OK;
 }
 template <class T>
@@ -1592,7 +1594,7 @@ void lpslam_hip_ba_destroy(lpslam_hip_ba* b)
 {
     if (!b) return;
     if (b->stream) (void)hipStreamSynchronize(b->stream);
-    for (void* p : b->allocs) (void)hipFree(p);
+    for (auto& blk : b->allocs) lp_pool_free(b->ctx, blk.first, blk.second);
     if (b->stream) (void)hipStreamDestroy(b->stream);
     delete b;
 }
@@ -1769,14 +1771,16 @@ int lpslam_hip_pose_optimize(lpslam_hip_ctx* ctx, double* pose7, const double* p
     for (int k = 0; k < n_obs; ++k) if (obs[k].point < 0 || obs[k].point >= n_points) { set_error("observation %d references point %d out of range", k, obs[k].point); return LPSLAM_HIP_ERR_INVALID; }
     LP_HIP(hipSetDevice(ctx->cfg.device));
     hipStream_t s = ctx->stream;
-    double* d_pose = nullptr; double* d_pts = nullptr; lpslam_hip_ba_obs* d_obs = nullptr; uint8_t* d_act = nullptr; uint8_t* d_out = nullptr; int* d_n = nullptr;
-    auto release = [&]() { for (void* p : {(void*)d_pose, (void*)d_pts, (void*)d_obs, (void*)d_act, (void*)d_out, (void*)d_n}) if (p) (void)hipFree(p); };
-#define PO_HIP(x) do { if ((x) != hipSuccess) { release(); set_error("HIP call failed: %s", #x); return LPSLAM_HIP_ERR_DEVICE; } } while (0)
+    // one block of the context's cache holds everything: pose | n_inliers | points | observations | active | outlier
     const size_t no = (size_t)std::max(n_obs, 1), np = (size_t)std::max(n_points, 1);
-    PO_HIP(hipMalloc((void**)&d_pose, 7 * sizeof(double)));
-    PO_HIP(hipMalloc((void**)&d_pts, 3 * np * sizeof(double)));
-    PO_HIP(hipMalloc((void**)&d_obs, no * sizeof(lpslam_hip_ba_obs)));
-    PO_HIP(hipMalloc((void**)&d_act, no)); PO_HIP(hipMalloc((void**)&d_out, no)); PO_HIP(hipMalloc((void**)&d_n, sizeof(int)));
+    const size_t off_pts = 128, off_obs = off_pts + 3 * np * sizeof(double), off_act = off_obs + no * sizeof(lpslam_hip_ba_obs), off_out = off_act + ((no + 63) / 64) * 64;
+    void* blk = nullptr; size_t cap = 0;
+    { const int rc = lp_pool_alloc(ctx, off_out + no, &blk, &cap); if (rc) return rc; }
+    auto release = [&]() { lp_pool_free(ctx, blk, cap); };
+#define PO_HIP(x) do { if ((x) != hipSuccess) { release(); set_error("HIP call failed: %s", #x); return LPSLAM_HIP_ERR_DEVICE; } } while (0)
+    uint8_t* base = (uint8_t*)blk;
+    double* d_pose = (double*)base; int* d_n = (int*)(base + 64); double* d_pts = (double*)(base + off_pts);
+    lpslam_hip_ba_obs* d_obs = (lpslam_hip_ba_obs*)(base + off_obs); uint8_t* d_act = base + off_act; uint8_t* d_out = base + off_out;
     PO_HIP(hipMemcpyAsync(d_pose, pose7, 7 * sizeof(double), hipMemcpyHostToDevice, s));
     if (n_points) PO_HIP(hipMemcpyAsync(d_pts, points, 3 * (size_t)n_points * sizeof(double), hipMemcpyHostToDevice, s));
     if (n_obs) PO_HIP(hipMemcpyAsync(d_obs, obs, (size_t)n_obs * sizeof(lpslam_hip_ba_obs), hipMemcpyHostToDevice, s));

@@ -1,6 +1,9 @@
 // internal.h -- shared host-side definitions of the lpslam HIP library (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <mutex>
+#include <vector>
+#include <utility>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -80,6 +83,11 @@ struct lpslam_hip_ctx {
     short2* d_map_xy[2] = {nullptr, nullptr};      // [h][w] integer source coordinate (sx >> 5, sy >> 5)
     uint16_t* d_map_frac[2] = {nullptr, nullptr};  // [h][w] (sy & 31) * 32 + (sx & 31)
     uint8_t* d_raw = nullptr;                      // [h][w] distorted frame of the upload in flight
+    // cache of device blocks for the short-lived objects the tracker makes every frame / keyframe (bundle-adjustment problems, pose
+    // optimiser and projection-matcher staging): hipMalloc / hipFree cost ~50-100 us each and a problem needs ~40 buffers
+    std::vector<std::pair<size_t, void*>> pool;        // (capacity, block), free blocks only
+    size_t pool_bytes = 0;
+    std::mutex pool_mutex;
     // staging for *_host convenience calls
     uint8_t* d_tmp_desc = nullptr; size_t tmp_desc_bytes = 0;
     int32_t* d_tmp_res = nullptr;  size_t tmp_res_bytes = 0;
@@ -88,6 +96,9 @@ struct lpslam_hip_ctx {
 };
 
 // kernel launchers (frontend.hip / match.hip)
+// block cache (api.hip): capacity-rounded first fit; *capacity receives the size to hand back to lp_pool_free
+int lp_pool_alloc(lpslam_hip_ctx* c, size_t bytes, void** out, size_t* capacity);
+void lp_pool_free(lpslam_hip_ctx* c, void* p, size_t capacity);
 int lp_launch_pyramid(lpslam_hip_ctx* c, int first, int n_images);
 int lp_launch_remap(lpslam_hip_ctx* c, int image, int eye);
 int lp_launch_fast(lpslam_hip_ctx* c, int first, int n_images);

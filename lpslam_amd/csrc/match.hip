@@ -447,15 +447,16 @@ int lpslam_hip_match_projection(lpslam_hip_ctx* c, int image, const lpslam_hip_p
     rc = lpslam_hip_keypoint_count(c, image, &n_kp); if (rc) return rc;
     hipStream_t s = c->stream;
     const size_t o = (size_t)image * c->slots_per_image;
-    ProjQuery* d_q = nullptr; uint8_t* d_qd = nullptr; uint8_t* d_taken = nullptr; unsigned long long* d_keys = nullptr; int* d_cnt = nullptr; int* d_ids = nullptr;
-    auto release = [&]() { for (void* p : {(void*)d_q, (void*)d_qd, (void*)d_taken, (void*)d_keys, (void*)d_cnt, (void*)d_ids}) if (p) (void)hipFree(p); };
+    // one block of the context's cache: keys | queries | descriptors | counts | ids | taken
+    const size_t o_keys = 0, o_q = o_keys + (size_t)nq * 4 * sizeof(unsigned long long), o_qd = o_q + (size_t)nq * sizeof(ProjQuery), o_cnt = o_qd + (size_t)nq * 32,
+                 o_ids = o_cnt + (size_t)nq * sizeof(int), o_taken = o_ids + 64;
+    void* blk = nullptr; size_t cap = 0;
+    { const int rc2 = lp_pool_alloc(c, o_taken + (size_t)std::max(n_kp, 1), &blk, &cap); if (rc2) return rc2; }
+    auto release = [&]() { lp_pool_free(c, blk, cap); };
 #define P_HIP(x) do { if ((x) != hipSuccess) { release(); set_error("HIP call failed: %s", #x); return LPSLAM_HIP_ERR_DEVICE; } } while (0)
-    P_HIP(hipMalloc((void**)&d_q, (size_t)nq * sizeof(ProjQuery)));
-    P_HIP(hipMalloc((void**)&d_qd, (size_t)nq * 32));
-    P_HIP(hipMalloc((void**)&d_taken, (size_t)std::max(n_kp, 1)));
-    P_HIP(hipMalloc((void**)&d_keys, (size_t)nq * 4 * sizeof(unsigned long long)));
-    P_HIP(hipMalloc((void**)&d_cnt, (size_t)nq * sizeof(int)));
-    P_HIP(hipMalloc((void**)&d_ids, sizeof(int)));
+    uint8_t* base = (uint8_t*)blk;
+    unsigned long long* d_keys = (unsigned long long*)(base + o_keys); ProjQuery* d_q = (ProjQuery*)(base + o_q); uint8_t* d_qd = base + o_qd;
+    int* d_cnt = (int*)(base + o_cnt); int* d_ids = (int*)(base + o_ids); uint8_t* d_taken = base + o_taken;
     std::vector<uint8_t> taken((size_t)std::max(n_kp, 1), 0);
     if (taken_in) std::copy(taken_in, taken_in + n_kp, taken.begin());
     P_HIP(hipMemcpyAsync(d_q, queries, (size_t)nq * sizeof(ProjQuery), hipMemcpyHostToDevice, s));
