@@ -94,6 +94,12 @@ class Workload:
             c.sync()
             t0 = time.perf_counter(); self.bundle_adjust(); self.ba_wall_ms = 1e3 * (time.perf_counter() - t0)
 
+    def extract_bytes(self):
+        """B_img = (P - P_7) + (P - P_0) + P + 2P + 2 K 31^2 + 60 K per image (17 236 083 B at 1280x720 / 2000)."""
+        P = [w * h for w, h in zip(self.ctx.level_w, self.ctx.level_h)]
+        Ps = sum(P)
+        return 2 * self.F * ((Ps - P[-1]) + (Ps - P[0]) + Ps + 2 * Ps + 2 * KPTS * 31 * 31 + 60 * KPTS)
+
     def algorithmic_bytes(self):
         """per-image pass-structured bytes of each front-end kernel group."""
         P = [w * h for w, h in zip(self.ctx.level_w, self.ctx.level_h)]
@@ -373,6 +379,12 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "algorithmic_bytes_per_step": int(ab[dom]), "avg_ms_per_step": round(float(dom_ms), 4)},
             "stage_ms_per_step": {n: round(float(v), 4) for n, v in zip(STAGE_NAMES, stage_ms)},
+            # SURVEY.md 8(d) whole-extraction figure: B_img = pyramid + FAST + blur + patches + outputs per image, over the
+            # summed time of the four extraction kernels (the blur's 2P bytes are part of B_img although it is fused away here)
+            "front_end_roofline": (lambda b_img, t_ms: {"algorithmic_bytes_per_step": int(b_img), "extract_ms_per_step": round(float(t_ms), 4),
+                                                         "achieved": round(b_img / (t_ms * 1e-3) / 1e9, 1), "unit": "GB/s",
+                                                         "frac": round(b_img / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)})(
+                wl.extract_bytes(), stage_ms[T_PYR] + stage_ms[T_FAST] + stage_ms[T_DIST] + stage_ms[T_DESC]),
             "pcie_inclusive_frames_per_s": round(pcie_fps, 2),
         }
         out.update(extras)
