@@ -47,6 +47,8 @@ struct BaCtl {                        // device-resident LM state (g2o Optimizat
     int stopped;                      // g2o "Terminate"
     int last_accepted;
     int ticket;                       // workgroups of the running pass that have published their partials (last one combines)
+    int cur_launch;                   // copy of `cur` that stays put while a trial launch runs (the decision flips `cur` inside it)
+    int spec;                         // linearisation set [cur] already holds the linearisation of state cur (speculated beside the trial)
 };
 
 struct BaView {                       // device pointers handed to kernels by value
@@ -58,7 +60,8 @@ struct BaView {                       // device pointers handed to kernels by va
     const double* o_u; const double* o_v; const double* o_ur; const double* o_w;
     const uint8_t* o_active;
     const int* pt_start; const int* pt_obs; const int* ps_start; const int* o_orig;
-    double* W; double* Y; double* Ybl; double* Hll; double* bl; double* Hpp; double* hl_obs; double* partial;
+    double* W; double* Y; double* Ybl; double* Hll; double* bl; double* Hpp; double* hl_obs; double* partial;   // linearisation set in use (ba_lin_set)
+    double* W2[2]; double* hl2[2]; double* partial2[2]; double* partial_trial;   // both sets (indexed like the state buffers) + trial chi2 partials
     double* S; double* rhs; double* bp; double* hppdiag; double* chi_cur;   // reduced buffer sections (all-reduced when partitioned)
     double* bp_loc; double* hppdiag_loc; double* chi_loc;                    // this rank's own sums (equal to the above on one GPU)
     double* Minv;                                                            // L^-T row blocks (dim_pad x dim_pad)
@@ -76,7 +79,17 @@ __device__ __forceinline__ bool ba_idle(const BaCtl* c) { return c->stopped || c
 __device__ __forceinline__ void ba_select(BaView& v, int trial)
 {
     const int s = v.ctl->cur ^ trial;
-    v.poses = v.poses_buf[s]; v.points = v.points_buf[s];
+    v.poses = s ? v.poses_buf[1] : v.poses_buf[0]; v.points = s ? v.points_buf[1] : v.points_buf[0];
+}
+// state buffer and linearisation set by explicit index (kernels that must not follow a `cur` flipping under them)
+__device__ __forceinline__ void ba_select_idx(BaView& v, int idx)
+{
+    v.poses = idx ? v.poses_buf[1] : v.poses_buf[0]; v.points = idx ? v.points_buf[1] : v.points_buf[0];
+}
+__device__ __forceinline__ void ba_lin_set(BaView& v, int idx)
+{
+    // selects, not array indexing: a dynamically indexed member array would push the by-value view out of the scalar registers
+    v.W = idx ? v.W2[1] : v.W2[0]; v.hl_obs = idx ? v.hl2[1] : v.hl2[0]; v.partial = idx ? v.partial2[1] : v.partial2[0];
 }
 
 __device__ __forceinline__ void quat_to_rot(const double* q, double* R)
@@ -197,9 +210,9 @@ __device__ __forceinline__ double wave_max(double x)
 }
 
 // ---- linearisation, observation side: one thread per observation: W = B^T w A and the observation's share of H_ll, b_l --
-__device__ __forceinline__ void obs_lin_body(BaView& v, int bid, int robust, int points_fixed)
+__device__ __forceinline__ void obs_lin_body(BaView& v, int bid, int robust, int points_fixed, int set)
 {
-    ba_select(v, 0);
+    ba_select_idx(v, set); ba_lin_set(v, set);
     const int k = bid * 256 + threadIdx.x;
     if (k >= v.n_obs) return;
     double* Wk = v.W + 18 * (size_t)k;
@@ -254,6 +267,7 @@ __device__ void pose_combine_body(BaView& v, int mode, int part_n, int fused);
 __global__ __launch_bounds__(256) void k_ba_point_sum(BaView v, int part_n, int fused)
 {
     if (ba_idle(v.ctl) || !v.ctl->need_lin) return;
+    ba_lin_set(v, v.ctl->cur);
     __shared__ double sm[4];
     const int j = blockIdx.x * 256 + threadIdx.x;
     double m = 0;
@@ -279,9 +293,10 @@ __global__ __launch_bounds__(256) void k_ba_point_sum(BaView v, int part_n, int 
 
 // ---- linearisation, pose side (mode 0) and trial chi2 (mode 1): SPLIT wavefronts per keyframe over slices of its
 //      observations
-__device__ __forceinline__ void pose_part_body(BaView& v, int bid, int robust, int mode)
+__device__ __forceinline__ void pose_part_body(BaView& v, int bid, int robust, int mode, int set)
 {
-    ba_select(v, mode);
+    ba_select_idx(v, set); ba_lin_set(v, set);
+    double* chi_out = mode == 0 ? v.partial + (size_t)v.n_poses * SPLIT * PV : v.partial_trial;
     const int lane = threadIdx.x & 63;
     const int wv = bid * 4 + (threadIdx.x >> 6);
     const int p = wv / SPLIT, sp = wv - p * SPLIT;
@@ -327,7 +342,7 @@ __device__ __forceinline__ void pose_part_body(BaView& v, int bid, int robust, i
     // partials: chi2 per (keyframe, slice) in the tail of v.partial, H_pp / b_p per (free-pose slot, slice) in its head,
     // so the combine addresses both without an index lookup
     chi = wave_sum(chi);
-    if (lane == 0) v.partial[(size_t)v.n_poses * SPLIT * PV + (size_t)p * SPLIT + sp] = chi;
+    if (lane == 0) chi_out[(size_t)p * SPLIT + sp] = chi;
     if (!full) return;
     double* out = v.partial + ((size_t)slot * SPLIT + sp) * PV;
 #pragma unroll
@@ -356,10 +371,11 @@ __device__ void lm_begin(BaView& v, double max_diag_pp, double max_diag_ll, doub
     c.current_chi = chi_cur;
     if (c.qmax == 0) c.chi_before = chi_cur;
     c.need_lin = 0;
+    c.spec = 0;
     *v.ctl = c;
 }
 // after a trial: rho, accept / reject, lambda update, iteration and termination bookkeeping
-__device__ void lm_decide(BaView& v, double temp_chi, double chol_failed, double scale_l, double scale_p)
+__device__ void lm_decide(BaView& v, double temp_chi, double chol_failed, double scale_l, double scale_p, bool spec_ran = false)
 {
     BaCtl c = *v.ctl;
     if (chol_failed != 0.0) temp_chi = DBL_MAX;            // factorisation failed
@@ -376,6 +392,7 @@ __device__ void lm_decide(BaView& v, double temp_chi, double chol_failed, double
         c.ni = 2;
         c.current_chi = temp_chi;
         c.cur ^= 1;                                        // discardTop: the trial state becomes the accepted one
+        c.spec = spec_ran ? 1 : 0;                         // ... and its linearisation is already in its set
     } else {
         c.lambda *= c.ni;
         c.ni *= 2;                                         // pop: the accepted state stays
@@ -412,7 +429,8 @@ __device__ void pose_combine_body(BaView& v, int mode, int part_n, int fused)
         double acc = 0;
         for (int p = lane; p < v.n_poses; p += 64) {
             double s = 0;
-            for (int sp = 0; sp < SPLIT; ++sp) s += v.partial[(size_t)v.n_poses * SPLIT * PV + (size_t)p * SPLIT + sp];
+            const double* chi_in = mode == 0 ? v.partial + (size_t)v.n_poses * SPLIT * PV : v.partial_trial;
+            for (int sp = 0; sp < SPLIT; ++sp) s += chi_in[(size_t)p * SPLIT + sp];
             v.chi_pose[p] = s;
             acc += s;
         }
@@ -476,26 +494,39 @@ __device__ void pose_combine_body(BaView& v, int mode, int part_n, int fused)
         } else {
             const double fail = v.scal[5], scale_p = v.scal[3];
             v.scal[1] = s_val[0]; v.scal[2] = s_val[1];
-            if (fused) lm_decide(v, s_val[0], fail, s_val[1], scale_p);
+            if (fused) lm_decide(v, s_val[0], fail, s_val[1], scale_p, fused == 2);
         }
     }
 }
 
 // ---- linearisation 1/2: the observation side (blocks [0, obs_blocks)) and the pose side (the rest) of the accepted state in one
-//      launch: both only read the state, so they run side by side
+//      launch: both only read the state, so they run side by side.  Skipped when the previous trial launch already linearised
+//      this state on speculation (ctl->spec).
 __global__ __launch_bounds__(256) void k_ba_lin(BaView v, int robust, int points_fixed, int obs_blocks)
 {
-    if (ba_idle(v.ctl) || !v.ctl->need_lin) return;
-    if ((int)blockIdx.x < obs_blocks) obs_lin_body(v, blockIdx.x, robust, points_fixed);
-    else pose_part_body(v, (int)blockIdx.x - obs_blocks, robust, 0);
+    if (ba_idle(v.ctl) || !v.ctl->need_lin || v.ctl->spec) return;
+    const int idx = v.ctl->cur;
+    if ((int)blockIdx.x < obs_blocks) obs_lin_body(v, blockIdx.x, robust, points_fixed, idx);
+    else pose_part_body(v, (int)blockIdx.x - obs_blocks, robust, 0, idx);
 }
 
-// ---- chi2 of the trial state per keyframe; the last workgroup totals it and (fused) runs the lambda control
-__global__ __launch_bounds__(256) void k_ba_trial(BaView v, int robust, int part_n, int fused)
+// ---- chi2 of the trial state per keyframe (blocks [0, trial_blocks)); the last of them totals it and (fused) runs the lambda
+//      control.  With spec != 0 the rest of the grid linearises the TRIAL state into the other linearisation set beside it: a
+//      trial is accepted far more often than not, and then the next iteration starts with its linearisation done (the sets are
+//      double buffered like the states, a rejected trial leaves the accepted state's set untouched).  These workgroups read
+//      ctl->cur_launch, not ctl->cur, which the decision may flip while they run.
+__global__ __launch_bounds__(256) void k_ba_trial(BaView v, int robust, int part_n, int fused, int trial_blocks, int obs_blocks, int points_fixed, int spec)
 {
     if (ba_idle(v.ctl)) return;
-    pose_part_body(v, blockIdx.x, robust, 1);
-    if (ba_last_block(v.ctl, gridDim.x)) pose_combine_body(v, 1, part_n, fused);
+    const int idx = v.ctl->cur_launch ^ 1;
+    if ((int)blockIdx.x >= trial_blocks) {
+        const int bid = (int)blockIdx.x - trial_blocks;
+        if (bid < obs_blocks) obs_lin_body(v, bid, robust, points_fixed, idx);
+        else pose_part_body(v, bid - obs_blocks, robust, 0, idx);
+        return;
+    }
+    pose_part_body(v, blockIdx.x, robust, 1, idx);
+    if (ba_last_block(v.ctl, trial_blocks)) pose_combine_body(v, 1, part_n, fused ? (spec ? 2 : 1) : 0);
 }
 
 // partitioned solve: lambda control on the all-reduced quantities
@@ -519,6 +550,7 @@ __global__ __launch_bounds__(256) void k_ba_obs_y(BaView v)
     if (ba_idle(v.ctl)) return;
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= v.n_obs) return;
+    ba_lin_set(v, v.ctl->cur);
     const int j = v.o_point[k];
     double h[6];
     point_hinv(v.Hll + 6 * (size_t)j, v.ctl->lambda, h);       // recomputed per observation: cheaper than a launch of its own
@@ -547,6 +579,7 @@ __global__ __launch_bounds__(64) void k_ba_schur(BaView v, int n_work, int fused
 {
     if (ba_idle(v.ctl)) return;
     const double lambda = v.ctl->lambda;
+    ba_lin_set(v, v.ctl->cur);
     const int lane = threadIdx.x;
     const int n = v.dim_pad;
     if ((int)blockIdx.x >= n_work) {
@@ -1023,11 +1056,12 @@ __global__ __launch_bounds__(256) void k_ba_backsub(BaView v, int point_blocks)
 {
     if (ba_idle(v.ctl)) return;
     const double lambda = v.ctl->lambda;
-    ba_select(v, 0);
-    double* poses_out = v.poses_buf[v.ctl->cur ^ 1];
-    double* points_out = v.points_buf[v.ctl->cur ^ 1];
+    ba_select(v, 0); ba_lin_set(v, v.ctl->cur);
+    double* poses_out = v.ctl->cur ? v.poses_buf[0] : v.poses_buf[1];
+    double* points_out = v.ctl->cur ? v.points_buf[0] : v.points_buf[1];
     if ((int)blockIdx.x == point_blocks) {
         // trial poses = exp(x_p) * poses; scal[3] = sum x_p (lambda x_p + b_p) (fixed order, one wavefront)
+        if (threadIdx.x == 0) v.ctl->cur_launch = v.ctl->cur;      // what the trial launch reads while the decision flips `cur`
         if (threadIdx.x >= 64) return;
         double sc = 0;
         for (int p = threadIdx.x; p < v.n_poses; p += 64) {
@@ -1307,8 +1341,9 @@ struct lpslam_hip_ba {
     double *d_o_u = nullptr, *d_o_v = nullptr, *d_o_ur = nullptr, *d_o_w = nullptr;
     uint8_t* d_o_active = nullptr; uint8_t* d_act_in = nullptr; int* d_o_orig = nullptr;
     int *d_pt_start = nullptr, *d_pt_obs = nullptr, *d_ps_start = nullptr;
-    double *d_W = nullptr, *d_Y = nullptr, *d_Ybl = nullptr, *d_Hll = nullptr, *d_bl = nullptr, *d_Hpp = nullptr;
-    double *d_hl_obs = nullptr, *d_partial = nullptr, *d_minv = nullptr, *d_ldiag = nullptr, *d_lsub = nullptr;
+    double *d_Y = nullptr, *d_Ybl = nullptr, *d_Hll = nullptr, *d_bl = nullptr, *d_Hpp = nullptr;
+    double *d_W2[2] = {nullptr, nullptr}, *d_hl2[2] = {nullptr, nullptr}, *d_partial2[2] = {nullptr, nullptr}, *d_partial_trial = nullptr;
+    double *d_minv = nullptr, *d_ldiag = nullptr, *d_lsub = nullptr;
     double* d_red = nullptr; int64_t red_n = 0;
     double *d_xp = nullptr, *d_chi_pose = nullptr, *d_part = nullptr, *d_scal = nullptr, *d_loc = nullptr;
     double* d_chi_obs = nullptr; uint8_t* d_depth = nullptr;
@@ -1349,8 +1384,10 @@ BaView make_view(lpslam_hip_ba* b)
     v.pose_slot = b->d_pose_slot; v.free_pose = b->d_free_pose; v.o_pose = b->d_o_pose; v.o_point = b->d_o_point;
     v.o_u = b->d_o_u; v.o_v = b->d_o_v; v.o_ur = b->d_o_ur; v.o_w = b->d_o_w; v.o_active = b->d_o_active;
     v.pt_start = b->d_pt_start; v.pt_obs = b->d_pt_obs; v.ps_start = b->d_ps_start; v.o_orig = b->d_o_orig;
-    v.W = b->d_W; v.Y = b->d_Y; v.Ybl = b->d_Ybl; v.Hll = b->d_Hll; v.bl = b->d_bl; v.Hpp = b->d_Hpp;
-    v.hl_obs = b->d_hl_obs; v.partial = b->d_partial; v.Minv = b->d_minv; v.Ldiag = b->d_ldiag; v.Lsub = b->d_lsub;
+    v.Y = b->d_Y; v.Ybl = b->d_Ybl; v.Hll = b->d_Hll; v.bl = b->d_bl; v.Hpp = b->d_Hpp;
+    v.hl_obs = b->d_hl2[0]; v.partial = b->d_partial2[0]; v.W = b->d_W2[0];
+    for (int k2 = 0; k2 < 2; ++k2) { v.W2[k2] = b->d_W2[k2]; v.hl2[k2] = b->d_hl2[k2]; v.partial2[k2] = b->d_partial2[k2]; }
+    v.partial_trial = b->d_partial_trial; v.Minv = b->d_minv; v.Ldiag = b->d_ldiag; v.Lsub = b->d_lsub;
     const size_t n = (size_t)b->dim_pad;
     v.S = b->d_red; v.rhs = b->d_red + n * n; v.bp = v.rhs + n; v.hppdiag = v.bp + n; v.chi_cur = v.hppdiag + n;
     v.bp_loc = b->d_loc; v.hppdiag_loc = b->d_loc + n; v.chi_loc = b->d_loc + 2 * n;
@@ -1362,12 +1399,13 @@ BaView make_view(lpslam_hip_ba* b)
 }
 
 // linearisation of the accepted state (skipped on the device when the previous trial was rejected)
-int enqueue_linearize(lpslam_hip_ba* b, int fused)
+int enqueue_linearize(lpslam_hip_ba* b, int fused, bool explicit_lin = true)
 {
     BaView v = make_view(b);
     hipStream_t s = b->stream;
     const int ob = (b->n_obs + 255) / 256, pb = (b->n_points + 255) / 256;
-    hipLaunchKernelGGL(k_ba_lin, dim3(ob + (b->n_poses * SPLIT + 3) / 4), dim3(256), 0, s, v, b->robust, b->points_fixed, ob);
+    // fused solve: only the first unit of an optimize() call linearises here, every later state is linearised beside its trial
+    if (explicit_lin) hipLaunchKernelGGL(k_ba_lin, dim3(ob + (b->n_poses * SPLIT + 3) / 4), dim3(256), 0, s, v, b->robust, b->points_fixed, ob);
     hipLaunchKernelGGL(k_ba_point_sum, dim3(pb > 0 ? pb : 1), dim3(256), 0, s, v, pb, fused);
     LP_HIP(hipGetLastError());
     return LPSLAM_HIP_OK;
@@ -1402,7 +1440,11 @@ int enqueue_solve(lpslam_hip_ba* b, int fused)
     }
     const int pb = (b->n_points + 63) / 64;
     hipLaunchKernelGGL(k_ba_backsub, dim3(pb + 1), dim3(256), 0, s, v, pb);
-    hipLaunchKernelGGL(k_ba_trial, dim3((b->n_poses * SPLIT + 3) / 4), dim3(256), 0, s, v, b->robust, pb, fused);
+    {
+        // fused solve: the trial launch also linearises the trial state on speculation (observation side + pose side)
+        const int tb = (b->n_poses * SPLIT + 3) / 4, ob = (b->n_obs + 255) / 256, spec = fused ? 1 : 0;
+        hipLaunchKernelGGL(k_ba_trial, dim3(tb + (spec ? ob + tb : 0)), dim3(256), 0, s, v, b->robust, pb, fused, tb, ob, b->points_fixed, spec);
+    }
     LP_HIP(hipGetLastError());
     return LPSLAM_HIP_OK;
 }
@@ -1425,7 +1467,7 @@ int begin_optimize(lpslam_hip_ba* b, int robust, int iters)
 {
     b->robust = robust;
     BaCtl c = b->h_ctl;
-    c.max_outer = iters; c.outer_done = 0; c.need_lin = 1; c.first = 1; c.qmax = 0; c.stopped = 0; c.ni = 2; c.rho = 0; c.last_accepted = 0; c.ticket = 0;
+    c.max_outer = iters; c.outer_done = 0; c.need_lin = 1; c.first = 1; c.qmax = 0; c.stopped = 0; c.ni = 2; c.rho = 0; c.last_accepted = 0; c.ticket = 0; c.spec = 0; c.cur_launch = c.cur;
     b->h_ctl = c;
     return write_ctl(b, c);
 }
@@ -1556,11 +1598,15 @@ int lpslam_hip_ba_create(lpslam_hip_ctx* ctx, const double* poses, const uint8_t
         BA_HIP(hipMemcpy(b->d_points0, points, 3 * (size_t)n_points * sizeof(double), hipMemcpyHostToDevice));
         BA_HIP(hipMemcpy(b->d_points[0], points, 3 * (size_t)n_points * sizeof(double), hipMemcpyHostToDevice));
     }
-    BA_TRY(dalloc(b, &b->d_W, 18 * (size_t)n_obs)); BA_TRY(dalloc(b, &b->d_Y, 18 * (size_t)n_obs)); BA_TRY(dalloc(b, &b->d_Ybl, 6 * (size_t)n_obs));
+    for (int k2 = 0; k2 < 2; ++k2) BA_TRY(dalloc(b, &b->d_W2[k2], 18 * (size_t)n_obs));
+    BA_TRY(dalloc(b, &b->d_Y, 18 * (size_t)n_obs)); BA_TRY(dalloc(b, &b->d_Ybl, 6 * (size_t)n_obs));
     BA_TRY(dalloc(b, &b->d_Hll, 6 * (size_t)n_points)); BA_TRY(dalloc(b, &b->d_bl, 3 * (size_t)n_points));
     BA_TRY(dalloc(b, &b->d_Hpp, 36 * (size_t)b->n_free));
-    BA_TRY(dalloc(b, &b->d_hl_obs, 9 * (size_t)n_obs)); BA_TRY(dalloc(b, &b->d_partial, (size_t)n_poses * SPLIT * (PV + 1)));
-    BA_HIP(hipMemset(b->d_partial, 0, (size_t)n_poses * SPLIT * (PV + 1) * sizeof(double)));
+    for (int k2 = 0; k2 < 2; ++k2) {
+        BA_TRY(dalloc(b, &b->d_hl2[k2], 9 * (size_t)n_obs)); BA_TRY(dalloc(b, &b->d_partial2[k2], (size_t)n_poses * SPLIT * (PV + 1)));
+        BA_HIP(hipMemset(b->d_partial2[k2], 0, (size_t)n_poses * SPLIT * (PV + 1) * sizeof(double)));
+    }
+    BA_TRY(dalloc(b, &b->d_partial_trial, (size_t)n_poses * SPLIT));
     b->red_n = (int64_t)b->dim_pad * b->dim_pad + 3 * (int64_t)b->dim_pad + 8;
     BA_TRY(dalloc(b, &b->d_red, (size_t)b->red_n));
     BA_HIP(hipMemset(b->d_red, 0, (size_t)b->red_n * sizeof(double)));
@@ -1638,7 +1684,7 @@ int lpslam_hip_ba_optimize(lpslam_hip_ba* b, int32_t robust, int32_t iters, lpsl
     while (!b->h_ctl.stopped && b->h_ctl.outer_done < iters && guard++ < 16 * MAX_LOG) {
         const int units = iters - b->h_ctl.outer_done;
         for (int u = 0; u < units; ++u) {
-            if ((rc = enqueue_linearize(b, 1))) return rc;
+            if ((rc = enqueue_linearize(b, 1, guard == 1 && u == 0))) return rc;
             if ((rc = enqueue_reduce(b, 1))) return rc;
             if ((rc = enqueue_solve(b, 1))) return rc;
         }

@@ -253,7 +253,7 @@ __global__ __launch_bounds__(64) void k_sim3_lin(Sim3View v)
 {
     BaCtl* ctl = v.cv.ctl;
     if (ba_idle(ctl) || !ctl->need_lin) return;
-    const double* verts = v.verts_buf[ctl->cur];
+    const double* verts = ctl->cur ? v.verts_buf[1] : v.verts_buf[0];      // selects: see ba_lin_set
     const int k = blockIdx.x, t = threadIdx.x;
     __shared__ double err[29][7];
     __shared__ double J[2][7][7];
@@ -365,8 +365,8 @@ __global__ __launch_bounds__(256) void k_sim3_update(Sim3View v, int vert_blocks
     BaCtl* ctl = v.cv.ctl;
     if (ba_idle(ctl)) return;
     const int cur = ctl->cur;
-    const double* verts = v.verts_buf[cur];
-    double* out = v.verts_buf[cur ^ 1];
+    const double* verts = cur ? v.verts_buf[1] : v.verts_buf[0];
+    double* out = cur ? v.verts_buf[0] : v.verts_buf[1];
     const double* xp = v.cv.xp;
     if ((int)blockIdx.x < vert_blocks) {
         const int i = blockIdx.x * 256 + threadIdx.x;
@@ -393,7 +393,7 @@ __global__ __launch_bounds__(256) void k_sim3_trial(Sim3View v)
 {
     BaCtl* ctl = v.cv.ctl;
     if (ba_idle(ctl)) return;
-    const double* verts = v.verts_buf[ctl->cur ^ 1];
+    const double* verts = ctl->cur ? v.verts_buf[0] : v.verts_buf[1];
     const int k = blockIdx.x * 256 + threadIdx.x;
     double chi = 0;
     if (k < v.n_edges) {
@@ -426,7 +426,7 @@ __global__ __launch_bounds__(256) void k_sim3_trial(Sim3View v)
 // chi2 per edge of the accepted state (API read-back)
 __global__ __launch_bounds__(256) void k_sim3_chi2(Sim3View v, double* chi2)
 {
-    const double* verts = v.verts_buf[v.cv.ctl->cur];
+    const double* verts = v.cv.ctl->cur ? v.verts_buf[1] : v.verts_buf[0];
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= v.n_edges) return;
     Sim3d m, vi, vj; double e[7];
