@@ -145,10 +145,11 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
             const int c = t[0];
             const int lo = c - thr, hi = c + thr;
             const int p0 = t[3 * TILE_PITCH], p4 = t[3], p8 = t[-3 * TILE_PITCH], p12 = t[-3];
-            const unsigned long long d0 = __ballot(p0 < lo), d4 = __ballot(p4 < lo), d8 = __ballot(p8 < lo), d12 = __ballot(p12 < lo);
-            const unsigned long long b0 = __ballot(p0 > hi), b4 = __ballot(p4 > hi), b8 = __ballot(p8 > hi), b12 = __ballot(p12 > hi);
-            // neighbouring compass pairs always take one point of {0, 8} and one of {4, 12}
-            const unsigned long long any = (((d0 | d8) & (d4 | d12)) | ((b0 | b8) & (b4 | b12))) & lane_ok;
+            // neighbouring compass pairs always take one point of {0, 8} and one of {4, 12}: "some pair both darker than lo" is
+            // min over the pairs of max(pair) < lo, i.e. max(min(p0, p8), min(p4, p12)) < lo; brighter likewise -- four VALU ops
+            // per polarity and one ballot per row instead of eight compares and 64-bit scalar mask logic
+            const int dk = max(min(p0, p8), min(p4, p12)), br = min(max(p0, p8), max(p4, p12));
+            const unsigned long long any = __ballot(dk < lo || br > hi) & lane_ok;
             if (any) {
                 int base = 0;
                 if (lane == 0) base = atomicAdd(&q_count, __popcll(any));
