@@ -27,55 +27,48 @@ public:
 
 class LPSLAM_EXPORT LpSlamManager {
 public:
-    LpSlamManager();
-    ~LpSlamManager();
+    /* life cycle: configure, start(), feed frames from one producer thread, stop()  (reference :19-20, :79-80) */
+    LpSlamManager();  ~LpSlamManager();
+    void start();  void stop();
 
-    void logToFile(char const* filename);
-    void setLogLevel(LpSlamLogLevel);
+    /* configuration: cameras 0 / 1 (stereo: left = n, right = n + 1), JSON file with the reference's schema, plugins by name
+       (reference :62-71; factories src/Manager/SlamManager.cpp:393-501) */
+    void setCameraConfiguration(LpSlamCameraConfiguration camera);
+    bool readConfigurationFile(char const* json_path);
+    bool addTracker(char const* plugin, char const* json);   bool addProcessor(char const* plugin, char const* json);
+    bool addSource(char const* plugin, char const* json);    bool readReplayItems(char const* recording_path);
+    void setLogLevel(LpSlamLogLevel level);                   void logToFile(char const* path);
 
-    void addOnReconstructionCallback(OnReconstructionCallback_t callback, void* userData);      /* notify thread */
-    void addRequestNavDataCallback(RequestNavDataCallback_t callback, void* userData);          /* worker thread, per frame */
-    void addRequestNavTransformation(RequestNavTransformationCallback_t callback, void* userData);
-    void addOnImageCallback(OnImageCallback_t callback, void* userData);
-    void updateGlobalReferenceState(LpSlamGlobalStateInTime globalStateInTime);
+    /* callbacks, one slot each, set before start(): poses leave on the notify thread, navigation data is asked for on the
+       worker thread once per frame (reference :27-42; src/Manager/SlamManager.cpp:148-156,240-257) */
+    void addOnReconstructionCallback(OnReconstructionCallback_t on_pose, void* user);
+    void addRequestNavDataCallback(RequestNavDataCallback_t nav_request, void* user);
+    void addRequestNavTransformation(RequestNavTransformationCallback_t transform_request, void* user);
+    void addOnImageCallback(OnImageCallback_t on_image, void* user);
+    void updateGlobalReferenceState(LpSlamGlobalStateInTime reference_state);
 
-    void addImageFromFile(char const* filename);
-    void addStereoImageFromFiles(char const* filename_left, char const* filename_right);
-    void addMarker(LpSlamMarkerIdentifier id, LpSlamMarkerState state);
+    /* frames in: pixel buffers are copied at the call (the reference aliases 8UC1 stereo buffers until processed) */
+    bool addStereoImageFromBuffer(uint32_t left_camera, LpSlamTimestamp t_ns, uint8_t* left, uint8_t* right, LpSlamImageDescription layout);
+    bool addImageFromBuffer(uint32_t camera, LpSlamTimestamp t_ns, uint8_t* pixels, LpSlamImageDescription layout);
 
-    /* stereo: the second camera is cameraNumber + 1 */
-    bool addImageFromBuffer(uint32_t cameraNumber, LpSlamTimestamp timestamp, uint8_t* buffer, LpSlamImageDescription desc);
-    bool addStereoImageFromBuffer(uint32_t cameraNumber, LpSlamTimestamp timestamp, uint8_t* buffer_left, uint8_t* buffer_right,
-                                  LpSlamImageDescription desc);
-    static bool compressImage(uint8_t* buffer, LpSlamImageDescription desc, uint8_t* bufferOut, uint32_t* bufferOutSize);
-
-    void setCameraConfiguration(LpSlamCameraConfiguration conf);
-    bool readConfigurationFile(char const* filename);
-    bool readReplayItems(char const* filename);
-    bool addSource(char const* name, char const* config);
-    bool addTracker(char const* name, char const* config);
-    bool addProcessor(char const* name, char const* config);
-    void setShowLiveStream(bool b);
-    void setWriteImageFiles(bool b);
-    void setRecord(bool b);
-    void setRecordImages(bool b);
-
-    void start();
-    void stop();
+    /* state out: tracker status, landmarks of the map in lpslam axes */
     LpSlamStatus getSlamStatus();
+    std::size_t mappingGetFeaturesCount(LpSlamMapBoundary region);
+    std::size_t mappingGetFeatures(LpSlamMapBoundary region, LpSlamFeatureEntry* out, std::size_t capacity, LpSlamMatrix9x9 rotation);
+    bool mappingExportCSV(const char* csv_path);
 
-    void mappingAddLaserScan(LpSlamGlobalStateInTime origin, float* ranges, size_t rangeCount, float start_range, float end_range,
-                             float start_angle, float end_angle, float increment, float range_threshold);
-    unsigned long mappingGetMapRawSize();
-    LpMapInfo mappingGetMapRaw(int8_t* map, std::size_t mapSize);
-    std::size_t mappingGetFeatures(LpSlamMapBoundary boundary, LpSlamFeatureEntry* entry, std::size_t entry_count, LpSlamMatrix9x9 transform);
-    std::size_t mappingGetFeaturesCount(LpSlamMapBoundary boundary);
-    bool mappingSetMode(bool enableMapping);
-    bool mappingSetFilename(const char* filename);
-    bool mappingExportCSV(const char* csv_filename);
+    /* belong to subsystems outside the accelerated path; signatures kept, behaviour of the reference without the backing plugin */
+    void addImageFromFile(char const* image_path);  void addStereoImageFromFiles(char const* left_path, char const* right_path);
+    void addMarker(LpSlamMarkerIdentifier marker, LpSlamMarkerState state);
+    static bool compressImage(uint8_t* pixels, LpSlamImageDescription layout, uint8_t* jpeg_out, uint32_t* jpeg_size);
+    void setShowLiveStream(bool on);  void setWriteImageFiles(bool on);  void setRecord(bool on);  void setRecordImages(bool on);
+    bool mappingSetMode(bool mapping_on);  bool mappingSetFilename(const char* map_path);
+    unsigned long mappingGetMapRawSize();  LpMapInfo mappingGetMapRaw(int8_t* cells, std::size_t capacity);
+    void mappingAddLaserScan(LpSlamGlobalStateInTime origin, float* ranges, size_t n_ranges, float range_min, float range_max,
+                             float angle_min, float angle_max, float angle_step, float range_threshold);
 
 private:
-    LpSlam::SlamManager* m_impl;
+    LpSlam::SlamManager* m_impl;       /* the single data member, as in the reference (pimpl) */
 };
 
 #endif
