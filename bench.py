@@ -340,6 +340,18 @@ def main():
                                  "last_frame_ms": round(1e3 * st_tr.frame_time, 3), "key_frames": int(st_tr.key_frames)}
         except Exception as e:      # noqa: BLE001 -- an extra must not take the benchmark line down
             extras["tracker"] = {"error": str(e)}
+        # BASELINE configs[4]'s global BA on ONE GPU (all landmarks on this rank; the partitioned solve adds one all-reduce of
+        # the 1200^2 reduced system per trial): 200 keyframes, 30 k landmarks, ~240 k observations, 10 LM iterations
+        try:
+            gprob = wl.synth.ba_problem(200, 30000, 240000, 1920, 1080, seq_id=2, kf_stride=2)
+            gba = wl.hip.BundleAdjuster(wl.ctx, gprob["poses"], gprob["fixed"], gprob["points"], wl.hip.ba_obs_array(gprob), gprob["cam"])
+            gba.optimize(True, 2); gba.reset()
+            t2 = time.perf_counter(); glog2 = gba.optimize(True, BA_ITERS); t_g = time.perf_counter() - t2
+            extras["global_ba"] = {"keyframes": 200, "landmarks": 30000, "observations": int(gba.n_obs), "ms_per_iter": round(1e3 * t_g / max(len(glog2), 1), 4),
+                                   "chi2_first": float(glog2["chi2_before"][0]), "chi2_last": float(glog2["chi2_after"][-1])}
+            gba.close()
+        except Exception as e:      # noqa: BLE001
+            extras["global_ba"] = {"error": str(e)}
         pg = wl.synth.pose_graph_problem(200, 0)
         graph = wl.hip.PoseGraph(wl.ctx, pg["verts"], pg["fixed"], wl.hip.sim3_edges(pg["edge_i"], pg["edge_j"], pg["meas"]), True)
         graph.optimize(2)
