@@ -263,33 +263,53 @@ __device__ __forceinline__ void obs_lin_body(BaView& v, int bid, int robust, int
 }
 
 // ---- linearisation 2/2: H_ll, b_l per landmark = fixed-order sum over its observations; block maxima of diag H_ll.  The
-//      workgroup that finishes last combines the pose partials of k_ba_lin (pose_combine_body, defined below).
+//      One extra workgroup combines the pose partials of the linearisation (pose_combine_body, defined below); the workgroup
+//      that finishes last starts the outer iteration.
 __device__ void pose_combine_body(BaView& v, int mode, int part_n, int fused);
+__device__ void lm_begin(BaView& v, double max_diag_pp, double max_diag_ll, double chi_cur);
 __global__ __launch_bounds__(256) void k_ba_point_sum(BaView v, int part_n, int fused)
 {
     if (ba_idle(v.ctl) || !v.ctl->need_lin) return;
     ba_lin_set(v, v.ctl->cur);
     __shared__ double sm[4];
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    double m = 0;
-    if (j < v.n_points) {
-        double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-        for (int s = v.pt_start[j]; s < v.pt_start[j + 1]; ++s) {
-            const double* ho = v.hl_obs + 9 * (size_t)v.pt_obs[s];
+    if ((int)blockIdx.x == (int)gridDim.x - 1) {
+        // the extra workgroup: the pose partials of the linearisation are complete before this launch, so they are combined
+        // here, beside the landmark sums, instead of on the critical path of the workgroup that finishes last
+        pose_combine_body(v, 0, part_n, 0);
+    } else {
+        const int j = blockIdx.x * 256 + threadIdx.x;
+        double m = 0;
+        if (j < v.n_points) {
+            double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+            for (int s = v.pt_start[j]; s < v.pt_start[j + 1]; ++s) {
+                const double* ho = v.hl_obs + 9 * (size_t)v.pt_obs[s];
 #pragma unroll
-            for (int i = 0; i < 9; ++i) acc[i] += ho[i];
+                for (int i = 0; i < 9; ++i) acc[i] += ho[i];
+            }
+#pragma unroll
+            for (int i = 0; i < 6; ++i) v.Hll[6 * (size_t)j + i] = acc[i];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) v.bl[3 * (size_t)j + i] = acc[6 + i];
+            m = fmax(fabs(acc[0]), fmax(fabs(acc[3]), fabs(acc[5])));
         }
-#pragma unroll
-        for (int i = 0; i < 6; ++i) v.Hll[6 * (size_t)j + i] = acc[i];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) v.bl[3 * (size_t)j + i] = acc[6 + i];
-        m = fmax(fabs(acc[0]), fmax(fabs(acc[3]), fabs(acc[5])));
+        m = wave_max(m);
+        if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+        __syncthreads();
+        if (threadIdx.x == 0 && (int)blockIdx.x < part_n) v.part[blockIdx.x] = fmax(fmax(sm[0], sm[1]), fmax(sm[2], sm[3]));
     }
-    m = wave_max(m);
-    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
-    __syncthreads();
-    if (threadIdx.x == 0 && (int)blockIdx.x < part_n) v.part[blockIdx.x] = fmax(fmax(sm[0], sm[1]), fmax(sm[2], sm[3]));
-    if (ba_last_block(v.ctl, gridDim.x)) pose_combine_body(v, 0, part_n, fused);
+    if (!ba_last_block(v.ctl, gridDim.x)) return;
+    // last workgroup: max diag H_ll over the block maxima, then the start of the outer iteration (lambda_0)
+    if (threadIdx.x < 64) {
+        double acc = 0;
+        for (int i = threadIdx.x; i < part_n; i += 64) acc = fmax(acc, v.part[i]);
+        acc = wave_max(acc);
+        if (threadIdx.x == 0) {
+            v.scal[4] = acc;
+            const double chi = v.scal[6], max_pp = v.scal[7];
+            *v.chi_cur = chi; *v.chi_loc = chi;
+            if (fused) lm_begin(v, max_pp, acc, chi);
+        }
+    }
 }
 
 // ---- linearisation, pose side (mode 0) and trial chi2 (mode 1): SPLIT wavefronts per keyframe over slices of its
@@ -437,10 +457,10 @@ __device__ void pose_combine_body(BaView& v, int mode, int part_n, int fused)
         }
         acc = wave_sum(acc);
         if (lane == 0) s_val[0] = acc;
-    } else if (wave == 1) {
+    } else if (wave == 1 && mode == 1) {
         double acc = 0;
-        for (int i = lane; i < part_n; i += 64) acc = mode == 0 ? fmax(acc, v.part[i]) : acc + v.part[i];
-        acc = mode == 0 ? wave_max(acc) : wave_sum(acc);
+        for (int i = lane; i < part_n; i += 64) acc += v.part[i];
+        acc = wave_sum(acc);
         if (lane == 0) s_val[1] = acc;
     } else if (wave == 2 && mode == 0) {   // max |diag H_pp| straight from the partials (same sums as the loop below)
         double m = 0;
@@ -490,8 +510,7 @@ __device__ void pose_combine_body(BaView& v, int mode, int part_n, int fused)
     __syncthreads();
     if (tid == 0) {
         if (mode == 0) {
-            *v.chi_cur = s_val[0]; *v.chi_loc = s_val[0]; v.scal[4] = s_val[1];
-            if (fused) lm_begin(v, s_val[2], s_val[1], s_val[0]);
+            v.scal[6] = s_val[0]; v.scal[7] = s_val[2];        // chi2 and max diag H_pp for the last workgroup of k_ba_point_sum
         } else {
             const double fail = v.scal[5], scale_p = v.scal[3];
             v.scal[1] = s_val[0]; v.scal[2] = s_val[1];
@@ -1408,7 +1427,7 @@ int enqueue_linearize(lpslam_hip_ba* b, int fused, bool explicit_lin = true)
     const int ob = (b->n_obs + 255) / 256, pb = (b->n_points + 255) / 256;
     // fused solve: only the first unit of an optimize() call linearises here, every later state is linearised beside its trial
     if (explicit_lin) hipLaunchKernelGGL(k_ba_lin, dim3(ob + (b->n_poses * SPLIT + 3) / 4), dim3(256), 0, s, v, b->robust, b->points_fixed, ob);
-    hipLaunchKernelGGL(k_ba_point_sum, dim3(pb > 0 ? pb : 1), dim3(256), 0, s, v, pb, fused);
+    hipLaunchKernelGGL(k_ba_point_sum, dim3(pb + 1), dim3(256), 0, s, v, pb, fused);      // + the workgroup that combines the pose partials
     LP_HIP(hipGetLastError());
     return LPSLAM_HIP_OK;
 }
