@@ -367,14 +367,18 @@ def main():
         dom_ms = stage_ms[STAGE_NAMES.index(dom)]
         launches = {"pyramid": LEVELS - 1, "fast": 1, "describe": 1}[dom]
         achieved = ab[dom] / (dom_ms * 1e-3) / 1e9
-        # HBM traffic of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
-        # runs of this command; profiles/r01b_pmc_hbm.json); only quoted for the launch shape it was measured on
+        # HBM traffic of the dominant kernel group from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+        # separate runs of this command, condensed by tools/pmc_summary.py into profiles/<round>_pmc.json: KB per launch as
+        # rocprofv3 reports them, no x2 correction for these dword / dwordx2 loads -- profiles/r01b_pmc_hbm.json calibrates that);
+        # per step = per launch x launches of the group; only quoted for the launch shape it was measured on
         traffic = None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01b_pmc_hbm.json")))
-            if dom == "fast" and args.frames == FRAMES_PER_STEP:
-                traffic = pmc["k_fast_cells_traffic_bytes_per_launch"]
-        except (OSError, KeyError, ValueError):
+            pmc_files = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc.json"))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_files[-1])))["kernels"]
+            kname = {"pyramid": "k_pyr_down", "fast": "k_fast_cells", "describe": "k_describe"}[dom]
+            if args.frames == FRAMES_PER_STEP:
+                traffic = int(round(launches * 1024.0 * (pmc[kname]["FETCH_SIZE"]["mean_per_launch"] + pmc[kname]["WRITE_SIZE"]["mean_per_launch"])))
+        except (OSError, KeyError, ValueError, IndexError):
             pass
         out = {
             "metric": "frames/sec (ORB+match+local-BA), 1280x720 stereo",
