@@ -1373,6 +1373,7 @@ struct lpslam_hip_ba {
     BaCam cam{};
     std::vector<double> h_ur;                      // mono/stereo classification for the outlier thresholds
     BaCtl h_ctl{};                                 // last control block read back
+    BaCtl h_ctl_out{};                             // staging of the control block on its way to the device
     int robust = 1, points_fixed = 0;
     std::vector<std::pair<void*, size_t>> allocs;      // blocks of the context's cache (lp_pool_alloc)
     std::map<long, hipGraphExec_t> graphs;             // captured first batches by (units, robust, points_fixed); nullptr = seen once
@@ -1472,8 +1473,8 @@ int enqueue_solve(lpslam_hip_ba* b, int fused)
 
 int write_ctl(lpslam_hip_ba* b, const BaCtl& c)
 {
-    LP_HIP(hipMemcpyAsync(b->d_ctl, &c, sizeof(BaCtl), hipMemcpyHostToDevice, b->stream));
-    LP_HIP(hipStreamSynchronize(b->stream));      // &c is a stack object
+    b->h_ctl_out = c;        // the source must outlive the copy: a member, rewritten only after the next read_ctl (which synchronises)
+    LP_HIP(hipMemcpyAsync(b->d_ctl, &b->h_ctl_out, sizeof(BaCtl), hipMemcpyHostToDevice, b->stream));
     return LPSLAM_HIP_OK;
 }
 int read_ctl(lpslam_hip_ba* b)
