@@ -227,6 +227,18 @@ typedef struct lpslam_hip_proj_query {
 int lpslam_hip_match_projection(lpslam_hip_ctx* ctx, int image, const lpslam_hip_proj_query* queries, const uint8_t* q_desc32, int32_t nq,
                                 int32_t hamming_thr, float lowe_ratio, const uint8_t* taken, int32_t use_stereo,
                                 int32_t* match_idx, int32_t* match_dist, int32_t* n_matches);
+/* [UPSTREAM] match::fuse (mapping module: detect / replace duplication): for every landmark projected into a keyframe the best
+ * keypoint inside the window whose reprojection error passes the chi-square gate of the keypoint's level (5.99146 / 7.81473 with
+ * the right-image x, use_stereo != 0), Hamming distance <= hamming_thr (50).  No exclusivity: what happens to a keypoint that
+ * already carries a landmark is the caller's rule. */
+int lpslam_hip_match_fuse(lpslam_hip_ctx* ctx, int image, const lpslam_hip_proj_query* queries, const uint8_t* q_desc32, int32_t nq,
+                          int32_t hamming_thr, int32_t use_stereo, int32_t* match_idx, int32_t* match_dist, int32_t* n_matches);
+/* [UPSTREAM] match::area::match_in_consistent_area (monocular initialiser): queries = level-0 keypoints of frame 1 at the position
+ * they were matched to before (radius = margin, levels 0..0), image = frame 2.  A keypoint already matched at an equal or
+ * smaller distance is not a candidate; best <= hamming_thr and best < lowe_ratio x second; a better later query takes the
+ * keypoint away from the earlier one (whose match_idx becomes -1). */
+int lpslam_hip_match_area(lpslam_hip_ctx* ctx, int image, const lpslam_hip_proj_query* queries, const uint8_t* q_desc32, int32_t nq,
+                          int32_t hamming_thr, float lowe_ratio, int32_t* match_idx, int32_t* match_dist, int32_t* n_matches);
 /* match::angle_checker: drops the matches whose angle difference (query - keypoint, degrees) lies outside the three most
  * populated 30-degree bins.  Host-side (a few thousand matches). */
 int lpslam_hip_match_orientation_filter(const float* angle_q, const float* angle_t, int32_t* match_idx, int32_t nq, int32_t* n_kept);

@@ -276,6 +276,8 @@ int lp_launch_stereo_strided(lpslam_hip_ctx* c, int left0, int right0, int strid
 //     taken by an earlier query is invisible to later ones) is replayed on the host over these short lists.
 // ------------------------------------------------------------------------------------------------------------
 struct ProjQuery { float x, y, x_right, radius; int min_level, max_level; };
+// mode 0: window + right-image window (projection / area matching); mode 1: chi-square gate of the keypoint's level (match::fuse)
+struct ProjGate { int mode; float inv_sigma_sq[LPSLAM_HIP_MAX_LEVELS]; };
 
 __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
 {
@@ -286,8 +288,8 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
 __global__ __launch_bounds__(256) void k_proj_topk(const lpslam_hip_keypoint* __restrict__ kp, const uint8_t* __restrict__ desc,
                                                    const float* __restrict__ stereo_xr, const int32_t* __restrict__ kp_count,
                                                    const ProjQuery* __restrict__ queries, const uint8_t* __restrict__ q_desc,
-                                                   const int* __restrict__ q_ids, int nq, const uint8_t* __restrict__ taken,
-                                                   float inv_w, float inv_h, unsigned long long* __restrict__ out_keys, int* __restrict__ out_count)
+                                                   const int* __restrict__ q_ids, int nq, const int16_t* __restrict__ best_so_far,
+                                                   float inv_w, float inv_h, ProjGate gate, unsigned long long* __restrict__ out_keys, int* __restrict__ out_count)
 {
     const int lane = threadIdx.x & 63, qslot = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (qslot >= nq) return;
@@ -306,12 +308,22 @@ __global__ __launch_bounds__(256) void k_proj_topk(const lpslam_hip_keypoint* __
         if (!(fabsf(k.x - q.x) < q.radius && fabsf(k.y - q.y) < q.radius)) continue;
         if (q.min_level >= 0 && k.octave < q.min_level) continue;
         if (q.max_level >= 0 && k.octave > q.max_level) continue;
-        if (taken && taken[i]) continue;
-        if (stereo_xr) { const float xr = stereo_xr[i]; if (0 < xr && q.x_right >= 0 && q.radius < fabsf(q.x_right - xr)) continue; }
+        if (gate.mode == 0) {
+            if (stereo_xr) { const float xr = stereo_xr[i]; if (0 < xr && q.x_right >= 0 && q.radius < fabsf(q.x_right - xr)) continue; }
+        } else {
+            const float ex = q.x - k.x, ey = q.y - k.y;
+            float isq = gate.inv_sigma_sq[0];
+#pragma unroll
+            for (int l = 1; l < LPSLAM_HIP_MAX_LEVELS; ++l) isq = k.octave == l ? gate.inv_sigma_sq[l] : isq;
+            const float xr = stereo_xr ? stereo_xr[i] : -1.0f;
+            if (0 <= xr && q.x_right >= 0) { const float er = q.x_right - xr; if ((ex * ex + ey * ey + er * er) * isq > 7.81473f) continue; }
+            else if ((ex * ex + ey * ey) * isq > 5.99146f) continue;
+        }
         const uint32_t* d = reinterpret_cast<const uint32_t*>(desc + 32 * (size_t)i);
         int dist = 0;
 #pragma unroll
         for (int w = 0; w < 8; ++w) dist += __popc(a[w] ^ d[w]);
+        if (best_so_far && best_so_far[i] <= dist) continue;           // taken (0), or already matched at an equal or smaller distance
         int cx = (int)floorf(k.x * inv_w), cy = (int)floorf(k.y * inv_h);
         cx = min(max(cx, 0), 63); cy = min(max(cy, 0), 47);
         unsigned long long key = ((unsigned long long)dist << 32) | ((unsigned long long)(cx * 48 + cy) << 20) | ((unsigned long long)i << 4) | (unsigned)k.octave;
@@ -433,13 +445,17 @@ int lpslam_hip_get_stereo(lpslam_hip_ctx* c, int left, float* stereo_x_right, fl
     return LPSLAM_HIP_OK;
 }
 
-// ---- projection matching: device top-4 per query + the sequential replay ------------------------------------------------------
-int lpslam_hip_match_projection(lpslam_hip_ctx* c, int image, const lpslam_hip_proj_query* queries, const uint8_t* q_desc32, int32_t nq,
-                                int32_t hamming_thr, float lowe_ratio, const uint8_t* taken_in, int32_t use_stereo,
-                                int32_t* match_idx, int32_t* match_dist, int32_t* n_matches)
+// ---- window matchers: device top-4 per query + the order-dependent part replayed on the host ----------------------------------
+// policy 0  match::projection: a keypoint taken by an earlier query is invisible (best_so_far = 0), Lowe ratio between equal levels
+// policy 1  match::fuse:       no exclusivity, chi-square gate in the kernel, best only
+// policy 2  match::area:       a keypoint matched at an equal or smaller distance is invisible; strict ratio; a better later
+//                              query takes the keypoint away from the earlier one
+static int window_match(lpslam_hip_ctx* c, int image, const lpslam_hip_proj_query* queries, const uint8_t* q_desc32, int32_t nq,
+                        int32_t hamming_thr, float lowe_ratio, const uint8_t* taken_in, int32_t use_stereo, int policy,
+                        int32_t* match_idx, int32_t* match_dist, int32_t* n_matches)
 {
     int rc = chk(c, image, image); if (rc) return rc;
-    if (nq < 0 || (nq > 0 && (!queries || !q_desc32 || !match_idx))) { set_error("bad projection-match arguments"); return LPSLAM_HIP_ERR_INVALID; }
+    if (nq < 0 || (nq > 0 && (!queries || !q_desc32 || !match_idx))) { set_error("bad window-match arguments"); return LPSLAM_HIP_ERR_INVALID; }
     static_assert(sizeof(lpslam_hip_proj_query) == sizeof(ProjQuery), "query layout");
     if (n_matches) *n_matches = 0;
     if (nq == 0) return LPSLAM_HIP_OK;
@@ -447,25 +463,30 @@ int lpslam_hip_match_projection(lpslam_hip_ctx* c, int image, const lpslam_hip_p
     rc = lpslam_hip_keypoint_count(c, image, &n_kp); if (rc) return rc;
     hipStream_t s = c->stream;
     const size_t o = (size_t)image * c->slots_per_image;
-    // one block of the context's cache: keys | queries | descriptors | counts | ids | taken
+    // one block of the context's cache: keys | queries | descriptors | counts | ids | best-so-far
+    const size_t nk = (size_t)std::max(n_kp, 1);
     const size_t o_keys = 0, o_q = o_keys + (size_t)nq * 4 * sizeof(unsigned long long), o_qd = o_q + (size_t)nq * sizeof(ProjQuery), o_cnt = o_qd + (size_t)nq * 32,
-                 o_ids = o_cnt + (size_t)nq * sizeof(int), o_taken = o_ids + 64;
+                 o_ids = o_cnt + (size_t)nq * sizeof(int), o_bsf = o_ids + 64;
     void* blk = nullptr; size_t cap = 0;
-    { const int rc2 = lp_pool_alloc(c, o_taken + (size_t)std::max(n_kp, 1), &blk, &cap); if (rc2) return rc2; }
+    { const int rc2 = lp_pool_alloc(c, o_bsf + nk * sizeof(int16_t), &blk, &cap); if (rc2) return rc2; }
     auto release = [&]() { lp_pool_free(c, blk, cap); };
 #define P_HIP(x) do { if ((x) != hipSuccess) { release(); set_error("HIP call failed: %s", #x); return LPSLAM_HIP_ERR_DEVICE; } } while (0)
     uint8_t* base = (uint8_t*)blk;
     unsigned long long* d_keys = (unsigned long long*)(base + o_keys); ProjQuery* d_q = (ProjQuery*)(base + o_q); uint8_t* d_qd = base + o_qd;
-    int* d_cnt = (int*)(base + o_cnt); int* d_ids = (int*)(base + o_ids); uint8_t* d_taken = base + o_taken;
-    std::vector<uint8_t> taken((size_t)std::max(n_kp, 1), 0);
-    if (taken_in) std::copy(taken_in, taken_in + n_kp, taken.begin());
+    int* d_cnt = (int*)(base + o_cnt); int* d_ids = (int*)(base + o_ids); int16_t* d_bsf = (int16_t*)(base + o_bsf);
+    std::vector<int16_t> bsf(nk, (int16_t)32767);
+    if (taken_in) for (int i = 0; i < n_kp; ++i) if (taken_in[i]) bsf[(size_t)i] = 0;
+    std::vector<int> owner(policy == 2 ? nk : 0, -1);
     P_HIP(hipMemcpyAsync(d_q, queries, (size_t)nq * sizeof(ProjQuery), hipMemcpyHostToDevice, s));
     P_HIP(hipMemcpyAsync(d_qd, q_desc32, (size_t)nq * 32, hipMemcpyHostToDevice, s));
-    P_HIP(hipMemcpyAsync(d_taken, taken.data(), taken.size(), hipMemcpyHostToDevice, s));
+    P_HIP(hipMemcpyAsync(d_bsf, bsf.data(), nk * sizeof(int16_t), hipMemcpyHostToDevice, s));
     const float inv_w = (float)(64.0 / c->lt.w[0]), inv_h = (float)(48.0 / c->lt.h[0]);
     const float* sxr = use_stereo ? c->d_stereo + (size_t)image * 2 * c->slots_per_image : nullptr;
+    ProjGate gate{};
+    gate.mode = policy == 1 ? 1 : 0;
+    for (int l = 0; l < LPSLAM_HIP_MAX_LEVELS; ++l) { const float sc = l < c->lt.n_levels ? c->lt.scale[l] : 1.0f; gate.inv_sigma_sq[l] = 1.0f / (sc * sc); }
     hipLaunchKernelGGL(k_proj_topk, dim3((nq + 3) / 4), dim3(256), 0, s, c->d_kpts + o, c->d_desc + o * 32, sxr, c->d_kp_count + image,
-                       d_q, d_qd, (const int*)nullptr, nq, d_taken, inv_w, inv_h, d_keys, d_cnt);
+                       d_q, d_qd, (const int*)nullptr, nq, (const int16_t*)d_bsf, inv_w, inv_h, gate, d_keys, d_cnt);
     P_HIP(hipGetLastError());
     std::vector<unsigned long long> keys((size_t)nq * 4);
     std::vector<int> cnt((size_t)nq);
@@ -477,15 +498,18 @@ int lpslam_hip_match_projection(lpslam_hip_ctx* c, int image, const lpslam_hip_p
         match_idx[k] = -1;
         if (match_dist) match_dist[k] = 256;
         unsigned long long cand[4] = {keys[4 * (size_t)k], keys[4 * (size_t)k + 1], keys[4 * (size_t)k + 2], keys[4 * (size_t)k + 3]};
-        auto free_ones = [&](unsigned long long* out) { int m = 0; for (int r = 0; r < 4; ++r) if (cand[r] != ~0ull && !taken[(size_t)((cand[r] >> 4) & 0xffff)]) out[m++] = cand[r]; return m; };
+        auto free_ones = [&](unsigned long long* out) {
+            int m = 0;
+            for (int r = 0; r < 4; ++r) if (cand[r] != ~0ull && (int)bsf[(size_t)((cand[r] >> 4) & 0xffff)] > (int)(cand[r] >> 32)) out[m++] = cand[r];
+            return m; };
         unsigned long long fr[4];
         int m = free_ones(fr);
-        if (m < 2 && cnt[k] > 4) {
+        if (policy != 1 && m < 2 && cnt[k] > 4) {
             // the short list was eaten by earlier queries: scan again for this query with the current assignment
-            P_HIP(hipMemcpyAsync(d_taken, taken.data(), taken.size(), hipMemcpyHostToDevice, s));
+            P_HIP(hipMemcpyAsync(d_bsf, bsf.data(), nk * sizeof(int16_t), hipMemcpyHostToDevice, s));
             P_HIP(hipMemcpyAsync(d_ids, &k, sizeof(int), hipMemcpyHostToDevice, s));
             hipLaunchKernelGGL(k_proj_topk, dim3(1), dim3(256), 0, s, c->d_kpts + o, c->d_desc + o * 32, sxr, c->d_kp_count + image,
-                               d_q, d_qd, (const int*)d_ids, 1, d_taken, inv_w, inv_h, d_keys, d_cnt);
+                               d_q, d_qd, (const int*)d_ids, 1, (const int16_t*)d_bsf, inv_w, inv_h, gate, d_keys, d_cnt);
             P_HIP(hipGetLastError());
             P_HIP(hipMemcpyAsync(cand, d_keys, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
             P_HIP(hipStreamSynchronize(s));
@@ -495,16 +519,43 @@ int lpslam_hip_match_projection(lpslam_hip_ctx* c, int image, const lpslam_hip_p
         const int best = (int)(fr[0] >> 32), best_idx = (int)((fr[0] >> 4) & 0xffff), best_lvl = (int)(fr[0] & 15);
         const int second = m > 1 ? (int)(fr[1] >> 32) : 256, second_lvl = m > 1 ? (int)(fr[1] & 15) : -1;
         if (best > hamming_thr) continue;
-        if (best_lvl == second_lvl && (float)best > lowe_ratio * (float)second) continue;
+        if (policy == 0 && best_lvl == second_lvl && (float)best > lowe_ratio * (float)second) continue;
+        if (policy == 2 && !((float)best < lowe_ratio * (float)second)) continue;
+        if (policy == 2) {
+            const int prev = owner[(size_t)best_idx];
+            if (prev >= 0) { match_idx[prev] = -1; if (match_dist) match_dist[prev] = 256; --found; }
+            owner[(size_t)best_idx] = k;
+            bsf[(size_t)best_idx] = (int16_t)best;
+        } else if (policy == 0) {
+            bsf[(size_t)best_idx] = 0;
+        }
         match_idx[k] = best_idx;
         if (match_dist) match_dist[k] = best;
-        taken[(size_t)best_idx] = 1;
         ++found;
     }
 #undef P_HIP
     release();
     if (n_matches) *n_matches = found;
     return LPSLAM_HIP_OK;
+}
+
+int lpslam_hip_match_projection(lpslam_hip_ctx* c, int image, const lpslam_hip_proj_query* queries, const uint8_t* q_desc32, int32_t nq,
+                                int32_t hamming_thr, float lowe_ratio, const uint8_t* taken_in, int32_t use_stereo,
+                                int32_t* match_idx, int32_t* match_dist, int32_t* n_matches)
+{
+    return window_match(c, image, queries, q_desc32, nq, hamming_thr, lowe_ratio, taken_in, use_stereo, 0, match_idx, match_dist, n_matches);
+}
+
+int lpslam_hip_match_fuse(lpslam_hip_ctx* c, int image, const lpslam_hip_proj_query* queries, const uint8_t* q_desc32, int32_t nq,
+                          int32_t hamming_thr, int32_t use_stereo, int32_t* match_idx, int32_t* match_dist, int32_t* n_matches)
+{
+    return window_match(c, image, queries, q_desc32, nq, hamming_thr, 1.0f, nullptr, use_stereo, 1, match_idx, match_dist, n_matches);
+}
+
+int lpslam_hip_match_area(lpslam_hip_ctx* c, int image, const lpslam_hip_proj_query* queries, const uint8_t* q_desc32, int32_t nq,
+                          int32_t hamming_thr, float lowe_ratio, int32_t* match_idx, int32_t* match_dist, int32_t* n_matches)
+{
+    return window_match(c, image, queries, q_desc32, nq, hamming_thr, lowe_ratio, nullptr, 0, 2, match_idx, match_dist, n_matches);
 }
 
 int lpslam_hip_match_orientation_filter(const float* angle_q, const float* angle_t, int32_t* match_idx, int32_t nq, int32_t* n_kept)

@@ -34,7 +34,7 @@ SYMBOLS = [
     "lpslam_hip_get_candidates", "lpslam_hip_keypoint_buffers", "lpslam_hip_match_bf", "lpslam_hip_get_bf_knn2",
     "lpslam_hip_get_bf_matches", "lpslam_hip_match_bf_strided", "lpslam_hip_set_descriptors",
     "lpslam_hip_match_stereo", "lpslam_hip_match_stereo_strided", "lpslam_hip_get_stereo",
-    "lpslam_hip_match_projection", "lpslam_hip_match_orientation_filter",
+    "lpslam_hip_match_projection", "lpslam_hip_match_fuse", "lpslam_hip_match_area", "lpslam_hip_match_orientation_filter",
     "lpslam_hip_ba_create", "lpslam_hip_ba_destroy", "lpslam_hip_ba_set_active", "lpslam_hip_ba_optimize",
     "lpslam_hip_ba_local", "lpslam_hip_ba_set_points_fixed", "lpslam_hip_ba_pose_optimize", "lpslam_hip_pose_optimize", "lpslam_hip_ba_reset", "lpslam_hip_ba_get", "lpslam_hip_ba_chi2", "lpslam_hip_ba_reduced_buffer",
     "lpslam_hip_ba_step_begin", "lpslam_hip_ba_step_lambda0", "lpslam_hip_ba_step_solve", "lpslam_hip_ba_scalar_buffer", "lpslam_hip_ba_step_end", "lpslam_hip_ba_status",
@@ -168,6 +168,22 @@ class Context:
         f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_int32,
                       C.c_void_p, C.c_void_p, C.c_void_p]
         _check(f(self.h, image, _p(q), _p(d), len(q), int(hamming_thr), float(lowe_ratio), _p(t), int(use_stereo), _p(idx), _p(dist), C.byref(n)))
+        return idx[:len(q)].copy(), dist[:len(q)].copy(), n.value
+
+    def match_fuse(self, image, queries, q_desc, hamming_thr=50, use_stereo=False):
+        q = np.ascontiguousarray(queries, PROJ_QUERY_DTYPE); d = np.ascontiguousarray(q_desc, np.uint8)
+        idx = np.full(max(len(q), 1), -1, np.int32); dist = np.zeros(max(len(q), 1), np.int32); n = C.c_int32()
+        f = self.lib.lpslam_hip_match_fuse
+        f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+        _check(f(self.h, image, _p(q), _p(d), len(q), int(hamming_thr), int(use_stereo), _p(idx), _p(dist), C.byref(n)))
+        return idx[:len(q)].copy(), dist[:len(q)].copy(), n.value
+
+    def match_area(self, image, queries, q_desc, hamming_thr=50, lowe_ratio=0.9):
+        q = np.ascontiguousarray(queries, PROJ_QUERY_DTYPE); d = np.ascontiguousarray(q_desc, np.uint8)
+        idx = np.full(max(len(q), 1), -1, np.int32); dist = np.zeros(max(len(q), 1), np.int32); n = C.c_int32()
+        f = self.lib.lpslam_hip_match_area
+        f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
+        _check(f(self.h, image, _p(q), _p(d), len(q), int(hamming_thr), float(lowe_ratio), _p(idx), _p(dist), C.byref(n)))
         return idx[:len(q)].copy(), dist[:len(q)].copy(), n.value
 
     def remap_staged(self, image, eye):

@@ -109,6 +109,13 @@ int ora_match_projection(const ora_keypoint* kp, const uint8_t* desc, const floa
                          const ora_proj_query* q, const uint8_t* q_desc, int nq, int hamming_thr, float lowe_ratio,
                          uint8_t* taken, int32_t* match_idx, int32_t* match_dist);
 int ora_match_orientation_filter(const float* angle_q, const float* angle_t, int32_t* match_idx, int nq);
+/* match::fuse: best keypoint per projected landmark inside the chi-square gate (no exclusivity) */
+int ora_match_fuse(const ora_keypoint* kp, const uint8_t* desc, const float* stereo_x_right, int n_kp, int width, int height,
+                   const float* inv_level_sigma_sq, const ora_proj_query* q, const uint8_t* q_desc, int nq, int hamming_thr,
+                   int32_t* match_idx, int32_t* match_dist);
+/* match::area::match_in_consistent_area: window match with "a better later query takes the keypoint" */
+int ora_match_area(const ora_keypoint* kp2, const uint8_t* desc2, int n2, int width, int height,
+                   const ora_proj_query* q, const uint8_t* q_desc, int nq, int hamming_thr, float lowe_ratio, int32_t* match_idx);
 
 /* ---- bundle adjustment ---------------------------------------------------------------------- */
 typedef struct {

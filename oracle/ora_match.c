@@ -285,3 +285,77 @@ int ora_match_orientation_filter(const float* angle_q, const float* angle_t, int
     free(bin_of);
     return kept;
 }
+
+/* ---- [UPSTREAM] match::fuse (detect / replace duplication): for every landmark projected into a keyframe the best keypoint
+ * inside the window, level in [pred - 1, pred], reprojection error inside the chi-square gate of the keypoint's level
+ * (5.99146 with two residuals, 7.81473 with the right-image x as third), smallest Hamming distance <= hamming_thr
+ * (HAMMING_DIST_THR_LOW = 50).  No exclusivity: what happens to a keypoint that already has a landmark is the caller's
+ * decision (the one with more observations survives).  Candidates in cell-scan order, first strictly smaller wins. */
+int ora_match_fuse(const ora_keypoint* kp, const uint8_t* desc, const float* stereo_x_right, int n_kp, int width, int height,
+                   const float* inv_level_sigma_sq, const ora_proj_query* q, const uint8_t* q_desc, int nq, int hamming_thr,
+                   int32_t* match_idx, int32_t* match_dist)
+{
+    const int GC = 64, GR = 48;
+    const double inv_w = (double)GC / (double)width, inv_h = (double)GR / (double)height;
+    int n_match = 0;
+    for (int k = 0; k < nq; ++k) {
+        long best_key = -1; int best = 256, best_idx = -1;
+        for (int i = 0; i < n_kp; ++i) {
+            if (!(fabsf(kp[i].x - q[k].x) < q[k].radius && fabsf(kp[i].y - q[k].y) < q[k].radius)) continue;
+            if (q[k].min_level >= 0 && kp[i].octave < q[k].min_level) continue;
+            if (q[k].max_level >= 0 && kp[i].octave > q[k].max_level) continue;
+            const float ex = q[k].x - kp[i].x, ey = q[k].y - kp[i].y;
+            if (stereo_x_right && 0 <= stereo_x_right[i] && q[k].x_right >= 0) {
+                const float er = q[k].x_right - stereo_x_right[i];
+                if ((ex * ex + ey * ey + er * er) * inv_level_sigma_sq[kp[i].octave] > 7.81473f) continue;
+            } else {
+                if ((ex * ex + ey * ey) * inv_level_sigma_sq[kp[i].octave] > 5.99146f) continue;
+            }
+            const int d = ora_hamming256(q_desc + 32 * (size_t)k, desc + 32 * (size_t)i);
+            const long key = (long)(proj_cell(kp[i].x, 0.f, inv_w, GC) * GR + proj_cell(kp[i].y, 0.f, inv_h, GR)) * 65536 + i;
+            if (d < best || (d == best && key < best_key)) { best = d; best_idx = i; best_key = key; }
+        }
+        match_idx[k] = -1; match_dist[k] = 256;
+        if (best_idx >= 0 && best <= hamming_thr) { match_idx[k] = best_idx; match_dist[k] = best; ++n_match; }
+    }
+    return n_match;
+}
+
+/* ---- [UPSTREAM] match::area::match_in_consistent_area (monocular initialiser): every level-0 keypoint of frame 1 looks for
+ * its match among the level-0 keypoints of frame 2 inside a window around the position it was matched to before; a frame-2
+ * keypoint already matched at an equal or smaller distance is not a candidate; best <= hamming_thr and best < ratio * second;
+ * a frame-2 keypoint won by a later, better query is taken away from the earlier one.  Queries in order; candidates in
+ * cell-scan order.  The angle check is ora_match_orientation_filter. */
+int ora_match_area(const ora_keypoint* kp2, const uint8_t* desc2, int n2, int width, int height,
+                   const ora_proj_query* q, const uint8_t* q_desc, int nq, int hamming_thr, float lowe_ratio, int32_t* match_idx)
+{
+    const int GC = 64, GR = 48;
+    const double inv_w = (double)GC / (double)width, inv_h = (double)GR / (double)height;
+    int* dist2 = (int*)malloc(sizeof(int) * (size_t)(n2 > 0 ? n2 : 1));
+    int* owner2 = (int*)malloc(sizeof(int) * (size_t)(n2 > 0 ? n2 : 1));
+    long* key2 = (long*)malloc(sizeof(long) * (size_t)(n2 > 0 ? n2 : 1));
+    for (int i = 0; i < n2; ++i) { dist2[i] = 256; owner2[i] = -1; key2[i] = (long)(proj_cell(kp2[i].x, 0.f, inv_w, GC) * GR + proj_cell(kp2[i].y, 0.f, inv_h, GR)) * 65536 + i; }
+    int n_match = 0;
+    for (int k = 0; k < nq; ++k) {
+        match_idx[k] = -1;
+        int best = 256, second = 256, best_idx = -1; long best_key = -1, second_key = -1;
+        for (int i = 0; i < n2; ++i) {
+            if (!(fabsf(kp2[i].x - q[k].x) < q[k].radius && fabsf(kp2[i].y - q[k].y) < q[k].radius)) continue;
+            if (q[k].min_level >= 0 && kp2[i].octave < q[k].min_level) continue;
+            if (q[k].max_level >= 0 && kp2[i].octave > q[k].max_level) continue;
+            const int d = ora_hamming256(q_desc + 32 * (size_t)k, desc2 + 32 * (size_t)i);
+            if (dist2[i] <= d) continue;
+            /* scan order = ascending key: "d < best" on a scan in key order == lexicographic minimum of (d, key) */
+            if (d < best || (d == best && key2[i] < best_key)) { second = best; second_key = best_key; best = d; best_key = key2[i]; best_idx = i; }
+            else if (d < second || (d == second && key2[i] < second_key)) { second = d; second_key = key2[i]; }
+        }
+        if (best_idx >= 0 && best <= hamming_thr && (float)best < lowe_ratio * (float)second) {
+            const int prev = owner2[best_idx];
+            if (prev >= 0) { match_idx[prev] = -1; --n_match; }
+            match_idx[k] = best_idx; owner2[best_idx] = k; dist2[best_idx] = best;
+            ++n_match;
+        }
+    }
+    free(dist2); free(owner2); free(key2);
+    return n_match;
+}

@@ -331,3 +331,25 @@ def match_orientation_filter(angle_q, angle_t, match_idx):
     m = np.ascontiguousarray(match_idx, np.int32).copy()
     n = lib().ora_match_orientation_filter(_p(aq), _p(at), _p(m), len(m))
     return m, n
+
+
+def match_fuse(kp, desc, stereo_xr, width, height, inv_level_sigma_sq, queries, q_desc, hamming_thr=50):
+    kp = np.ascontiguousarray(kp, KP_DTYPE); desc = np.ascontiguousarray(desc, np.uint8)
+    q = np.ascontiguousarray(queries, PROJ_QUERY_DTYPE); qd = np.ascontiguousarray(q_desc, np.uint8)
+    sx = np.ascontiguousarray(stereo_xr, np.float32) if stereo_xr is not None else None
+    isq = np.ascontiguousarray(inv_level_sigma_sq, np.float32)
+    idx = np.full(max(len(q), 1), -1, np.int32); dist = np.zeros(max(len(q), 1), np.int32)
+    f = lib().ora_match_fuse
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    n = f(_p(kp), _p(desc), _p(sx), len(kp), width, height, _p(isq), _p(q), _p(qd), len(q), int(hamming_thr), _p(idx), _p(dist))
+    return idx[:len(q)].copy(), dist[:len(q)].copy(), n
+
+
+def match_area(kp2, desc2, width, height, queries, q_desc, hamming_thr=50, lowe_ratio=0.9):
+    kp2 = np.ascontiguousarray(kp2, KP_DTYPE); desc2 = np.ascontiguousarray(desc2, np.uint8)
+    q = np.ascontiguousarray(queries, PROJ_QUERY_DTYPE); qd = np.ascontiguousarray(q_desc, np.uint8)
+    idx = np.full(max(len(q), 1), -1, np.int32)
+    f = lib().ora_match_area
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p]
+    n = f(_p(kp2), _p(desc2), len(kp2), width, height, _p(q), _p(qd), len(q), int(hamming_thr), float(lowe_ratio), _p(idx))
+    return idx[:len(q)].copy(), n

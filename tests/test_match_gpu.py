@@ -160,3 +160,38 @@ def test_projection_match_sequential_semantics_and_rescans(hiplib, oracle):
     assert np.array_equal(gi2, oi2) and not np.isin(gi2[gi2 >= 0], m[:10]).any()
     e_i, _, e_n = ctx.match_projection(2, q[:0], qd[:0])
     assert e_n == 0 and len(e_i) == 0
+
+
+def test_fuse_match_parity(hiplib, oracle):
+    """match::fuse: landmarks projected into a keyframe, chi-square gate of the keypoint's level, no exclusivity."""
+    w, h = 640, 480
+    ctx, q, qd, kp0, kp1, d1, xr1 = _proj_case(hiplib, oracle, w, h, 1000, 8, 7, radius_scale=3.0, jitter=1.2)
+    q["min_level"] = np.maximum(kp0["octave"] - 1, 0); q["max_level"] = kp0["octave"]
+    isq = (np.float32(1.0) / (np.array(ctx.scale, np.float32) ** 2)).astype(np.float32)
+    for use_stereo in (False, True):
+        gi, gd, gn = ctx.match_fuse(2, q, qd, 50, use_stereo)
+        oi, od, on = oracle.match_fuse(kp1, d1, xr1 if use_stereo else None, w, h, isq, q, qd, 50)
+        assert gn == on > 50 and np.array_equal(gi, oi) and np.array_equal(gd[gi >= 0], od[oi >= 0])
+    assert len(np.unique(gi[gi >= 0])) <= (gi >= 0).sum()                     # duplicates are allowed here
+
+
+def test_area_match_parity_with_stealing(hiplib, oracle):
+    """match::area (monocular initialiser): level-0 keypoints, a better later query takes the keypoint from an earlier one."""
+    w, h = 640, 480
+    ctx, q, qd, kp0, kp1, d1, xr1 = _proj_case(hiplib, oracle, w, h, 1000, 8, 9, radius_scale=40.0, jitter=3.0)
+    lvl0 = kp0["octave"] == 0
+    q = q[lvl0].copy(); qd = qd[lvl0].copy()
+    q["radius"] = 100.0; q["min_level"] = 0; q["max_level"] = 0
+    # the first 40 queries get a few bits flipped and come back unspoilt at the end: the later, better ones take the keypoint
+    n0 = len(q)
+    extra = q[:40].copy(); extra_d = qd[:40].copy()
+    qd[:40, 0] ^= 0x15; qd[:40, 7] ^= 0x81
+    q = np.concatenate([q, extra]); qd = np.concatenate([qd, extra_d])
+    gi, gd, gn = ctx.match_area(2, q, qd, 50, 0.9)
+    oi, on = oracle.match_area(kp1, d1, w, h, q, qd, 50, 0.9)
+    assert gn == on > 30 and np.array_equal(gi, oi)
+    m = gi[gi >= 0]
+    assert len(np.unique(m)) == len(m)                                        # one query per keypoint at the end
+    assert (kp1["octave"][m] == 0).all()
+    stolen = (gi[:40] == -1) & (gi[n0:n0 + 40] >= 0)
+    assert stolen.sum() >= 5                                                  # the steal rule was exercised

@@ -392,3 +392,27 @@ def test_projection_match_against_a_plain_restatement(oracle):
     spoil = np.flatnonzero(good)[:3]; aq[spoil] = (aq[spoil] + 170.0) % 360      # ... except three matches
     filt, kept = oracle.match_orientation_filter(aq, at, got_i)
     assert kept == good.sum() - 3 and (filt[spoil] == -1).all()
+
+
+def test_fuse_and_area_match_semantics(oracle):
+    rng = np.random.default_rng(21)
+    w, h, n = 320, 240, 120
+    kp = np.zeros(n, oracle.KP_DTYPE)
+    kp["x"] = rng.uniform(0, w, n).astype(np.float32); kp["y"] = rng.uniform(0, h, n).astype(np.float32); kp["octave"] = rng.integers(0, 3, n)
+    desc = rng.integers(0, 256, (n, 32)).astype(np.uint8)
+    isq = (1.0 / (1.2 ** np.arange(8)) ** 2).astype(np.float32)
+    # fuse: a query exactly on a keypoint with its descriptor matches it; 3 px off at level 0 fails the 5.99 gate (9 > 5.99)
+    q = np.zeros(2, oracle.PROJ_QUERY_DTYPE)
+    k0 = int(np.flatnonzero(kp["octave"] == 0)[0])
+    q["x"] = kp["x"][k0] + np.array([0.5, 3.0], np.float32); q["y"] = kp["y"][k0]; q["x_right"] = -1; q["radius"] = 10
+    q["min_level"] = 0; q["max_level"] = 0
+    idx, dist, nm = oracle.match_fuse(kp, desc, None, w, h, isq, q, desc[[k0, k0]], 50)
+    assert idx[0] == k0 and dist[0] == 0 and idx[1] != k0
+    # area: two queries for the same keypoint, the second one closer -> the first loses it
+    q2 = np.zeros(2, oracle.PROJ_QUERY_DTYPE)
+    q2["x"] = kp["x"][k0]; q2["y"] = kp["y"][k0]; q2["radius"] = 5; q2["min_level"] = 0; q2["max_level"] = 0
+    worse = desc[k0].copy(); worse[0] ^= 0x07
+    idx2, n2 = oracle.match_area(kp, desc, w, h, q2, np.stack([worse, desc[k0]]), 50, 0.9)
+    assert list(idx2) == [-1, k0] and n2 == 1
+    idx3, n3 = oracle.match_area(kp, desc, w, h, q2, np.stack([desc[k0], worse]), 50, 0.9)
+    assert list(idx3) == [k0, -1] and n3 == 1
