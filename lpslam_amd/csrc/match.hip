@@ -214,10 +214,12 @@ __global__ __launch_bounds__(64 * ST_WAVES) void k_stereo(const uint8_t* __restr
 
 // 2 x median cut: sort the correlations of the accepted matches of one image, read the median, invalidate weaker ones
 __global__ __launch_bounds__(1024) void k_stereo_median(const int32_t* __restrict__ counts, int slots_per_image, int left0, int stride,
-                                                        float* __restrict__ out_f, const int32_t* __restrict__ corr, int sortcap)
+                                                        float* __restrict__ out_f, const int32_t* __restrict__ corr)
 {
-    extern __shared__ int keys[];
-    __shared__ int s_n;
+    // median = element n / 2 of the sorted correlations, found by a four-pass radix select (8 bits per pass, LDS histogram +
+    // one wavefront scan) instead of sorting them: the same value, 8 barriers instead of 66
+    __shared__ int hist[256];
+    __shared__ int s_n, s_prefix, s_target;
     const int left = left0 + blockIdx.x * stride;
     const int nl = counts[left];
     const int32_t* cr = corr + (size_t)left * slots_per_image;
@@ -225,25 +227,41 @@ __global__ __launch_bounds__(1024) void k_stereo_median(const int32_t* __restric
     float* o_depth = o_xr + slots_per_image;
     const int tid = threadIdx.x;
     if (tid == 0) s_n = 0;
-    for (int i = tid; i < sortcap; i += 1024) keys[i] = 0x7FFFFFFF;
     __syncthreads();
-    for (int i = tid; i < nl; i += 1024) if (cr[i] >= 0) keys[atomicAdd(&s_n, 1)] = cr[i];
+    int mine = 0;
+    for (int i = tid; i < nl; i += 1024) mine += cr[i] >= 0 ? 1 : 0;
+    if (mine) atomicAdd(&s_n, mine);
     __syncthreads();
     const int n = s_n;
     if (n == 0) return;
-    for (int k = 2; k <= sortcap; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < sortcap; i += 1024) {
-                const int p = i ^ j;
-                if (p > i) {
-                    const int x = keys[i], y = keys[p];
-                    const bool asc = (i & k) == 0;
-                    if (asc ? (x > y) : (x < y)) { keys[i] = y; keys[p] = x; }
-                }
-            }
-            __syncthreads();
+    if (tid == 0) { s_prefix = 0; s_target = n / 2; }
+    unsigned mask = 0;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        if (tid < 256) hist[tid] = 0;
+        __syncthreads();
+        const unsigned prefix = (unsigned)s_prefix;
+        for (int i = tid; i < nl; i += 1024) {
+            const int v = cr[i];
+            if (v >= 0 && ((unsigned)v & mask) == prefix) atomicAdd(&hist[((unsigned)v >> shift) & 255u], 1);
         }
-    const float median = (float)keys[n / 2];
+        __syncthreads();
+        if (tid < 64) {
+            const int h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
+            const int sum = h0 + h1 + h2 + h3;
+            int incl = sum;
+            for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (tid >= o) incl += t; }
+            const int target = s_target, excl = incl - sum;
+            if (excl <= target && target < incl) {                  // exactly one lane
+                int r = target - excl, bin = 4 * tid;
+                if (r >= h0) { r -= h0; ++bin; if (r >= h1) { r -= h1; ++bin; if (r >= h2) { r -= h2; ++bin; } } }
+                s_prefix = (int)(prefix | ((unsigned)bin << shift));
+                s_target = r;
+            }
+        }
+        mask |= 255u << shift;
+        __syncthreads();
+    }
+    const float median = (float)s_prefix;
     const float thr = (float)(2.0 * (double)median);
     for (int i = tid; i < nl; i += 1024)
         if (cr[i] >= 0 && thr < (float)cr[i]) { o_xr[i] = -1.0f; o_depth[i] = -1.0f; }
@@ -256,9 +274,8 @@ int lp_launch_stereo_strided(lpslam_hip_ctx* c, int left0, int right0, int strid
     hipLaunchKernelGGL(k_stereo, grid, dim3(64 * ST_WAVES), 0, c->stream, c->d_pyr, c->image_slab, c->lt, c->d_kpts, c->d_desc,
                        c->d_kp_count, c->slots_per_image, left0, right0, stride, fxb, max_disp, c->d_stereo, c->d_stereo_idx,
                        c->d_stereo_corr);
-    int sortcap = 1; while (sortcap < c->slots_per_image) sortcap <<= 1;
-    hipLaunchKernelGGL(k_stereo_median, dim3(n_pairs), dim3(1024), sortcap * sizeof(int), c->stream, c->d_kp_count,
-                       c->slots_per_image, left0, stride, c->d_stereo, c->d_stereo_corr, sortcap);
+    hipLaunchKernelGGL(k_stereo_median, dim3(n_pairs), dim3(1024), 0, c->stream, c->d_kp_count,
+                       c->slots_per_image, left0, stride, c->d_stereo, c->d_stereo_corr);
     LP_HIP(hipGetLastError());
     return LPSLAM_HIP_OK;
 }
