@@ -393,7 +393,7 @@ def main():
         ab = wl.algorithmic_bytes()
         dom = max(ab.keys(), key=lambda k_: stage_ms[STAGE_NAMES.index(k_)])
         dom_ms = stage_ms[STAGE_NAMES.index(dom)]
-        launches = {"pyramid": LEVELS - 1, "fast": 1, "describe": 1}[dom]
+        launches = {"pyramid": 1, "fast": 1, "describe": 1, "distribute": 1}[dom]
         achieved = ab[dom] / (dom_ms * 1e-3) / 1e9
         # HBM traffic of the dominant kernel group from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
         # separate runs of this command, condensed by tools/pmc_summary.py into profiles/<round>_pmc.json: KB per launch as
@@ -403,7 +403,7 @@ def main():
         try:
             pmc_files = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc.json"))
             pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_files[-1])))["kernels"]
-            kname = {"pyramid": "k_pyr_down", "fast": "k_fast_cells", "describe": "k_describe"}[dom]
+            kname = {"pyramid": "k_pyr_bands", "fast": "k_fast_cells", "describe": "k_describe", "distribute": "k_distribute"}[dom]
             if args.frames == FRAMES_PER_STEP:
                 traffic = int(round(launches * 1024.0 * (pmc[kname]["FETCH_SIZE"]["mean_per_launch"] + pmc[kname]["WRITE_SIZE"]["mean_per_launch"])))
         except (OSError, KeyError, ValueError, IndexError):

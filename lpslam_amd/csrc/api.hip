@@ -227,11 +227,48 @@ int lpslam_hip_create(const lpslam_hip_frontend_config* cfg, lpslam_hip_ctx** ou
     if (e != hipSuccess) { delete c; return hip_fail(e, "hipStreamCreate"); }
     rc = ctx_alloc(c);
     if (rc == LPSLAM_HIP_OK && !ofs.empty()) {
-        e = hipMalloc((void**)&c->d_rs_ofs, ofs.size() * sizeof(int16_t));
-        if (e == hipSuccess) e = hipMalloc((void**)&c->d_rs_coef, coef.size() * sizeof(int16_t));
-        if (e == hipSuccess) e = hipMemcpy(c->d_rs_ofs, ofs.data(), ofs.size() * sizeof(int16_t), hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(c->d_rs_coef, coef.data(), coef.size() * sizeof(int16_t), hipMemcpyHostToDevice);
+        std::vector<int2> pack(ofs.size());
+        for (int l = 1; l < L; ++l) {
+            for (int axis = 0; axis < 2; ++axis) {
+                const int start = axis ? c->lt.ytab_start[l] : c->lt.xtab_start[l];
+                const int n = axis ? c->lt.h[l] : c->lt.w[l], src_n = axis ? c->lt.h[l - 1] : c->lt.w[l - 1];
+                for (int i = 0; i < n; ++i) {
+                    const int s0 = ofs[start + i], s1 = std::min(s0 + 1, src_n - 1);
+                    pack[start + i] = make_int2(s0 | (s1 << 16), (int)(uint16_t)coef[2 * (start + i)] | ((int)coef[2 * (start + i) + 1] << 16));
+                }
+            }
+        }
+        c->rs_entries = (int)pack.size();
+        e = hipMalloc((void**)&c->d_rs_pack, pack.size() * sizeof(int2));
+        if (e == hipSuccess) e = hipMemcpy(c->d_rs_pack, pack.data(), pack.size() * sizeof(int2), hipMemcpyHostToDevice);
         if (e != hipSuccess) rc = hip_fail(e, "resize tables");
+    }
+    if (rc == LPSLAM_HIP_OK && L > 1) {
+        // Row ranges of the banded pyramid kernel: band b owns rows [h*b/B, h*(b+1)/B) of every level and also computes the rows
+        // of the finer levels its own coarser rows are interpolated from, so a band never waits for a neighbour.
+        std::vector<int2> rows((size_t)(kPyrMaxBands + 1) * kMaxLevels * kPyrMaxBands, make_int2(0, -1));
+        for (int s = 1; s <= kPyrMaxBands; ++s) {      // one table per band count
+            const int B = s;
+            for (int b = 0; b < B; ++b) {
+                int lo = 0, hi = -1;
+                for (int l = L - 1; l >= 1; --l) {
+                    const int h = c->lt.h[l];
+                    int own_lo = (int)((long)h * b / B), own_hi = (int)((long)h * (b + 1) / B) - 1;
+                    if (own_hi >= own_lo) {
+                        if (hi < lo) { lo = own_lo; hi = own_hi; } else { lo = std::min(lo, own_lo); hi = std::max(hi, own_hi); }
+                    }
+                    rows[((size_t)s * kMaxLevels + l) * kPyrMaxBands + b] = make_int2(lo, hi);
+                    if (hi >= lo && l > 1) {      // rows of level l-1 these rows read
+                        const int yt = c->lt.ytab_start[l];
+                        const int nlo = ofs[yt + lo], nhi = std::min(ofs[yt + hi] + 1, c->lt.h[l - 1] - 1);
+                        lo = nlo; hi = nhi;
+                    }
+                }
+            }
+        }
+        e = hipMalloc((void**)&c->d_band_rows, rows.size() * sizeof(int2));
+        if (e == hipSuccess) e = hipMemcpy(c->d_band_rows, rows.data(), rows.size() * sizeof(int2), hipMemcpyHostToDevice);
+        if (e != hipSuccess) rc = hip_fail(e, "pyramid band table");
     }
     if (rc == LPSLAM_HIP_OK) {
         e = hipStreamSynchronize(c->stream);
@@ -249,7 +286,7 @@ void lpslam_hip_destroy(lpslam_hip_ctx* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto& blk : c->pool) (void)hipFree(blk.second);
     c->pool.clear();
-    void* bufs[] = {c->d_pyr, c->d_rs_ofs, c->d_rs_coef, c->d_cell_keys, c->d_cell_count, c->d_cand_key, c->d_cand_node,
+    void* bufs[] = {c->d_pyr, c->d_band_rows, c->d_rs_pack, c->d_cell_keys, c->d_cell_count, c->d_cand_key, c->d_cand_node,
                     c->d_cand_count, c->d_sel_key, c->d_sel_count, c->d_kpts, c->d_desc,
                     c->d_kp_count, c->d_bf, c->d_stereo, c->d_stereo_idx, c->d_stereo_corr, c->d_tmp_desc, c->d_tmp_res,
                     c->d_map_xy[0], c->d_map_xy[1], c->d_map_frac[0], c->d_map_frac[1], c->d_raw};

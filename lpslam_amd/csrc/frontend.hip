@@ -19,39 +19,76 @@ using namespace lpslam;
 // K1  pyramid: level l = bilinear resize of level l-1, 11-bit fixed-point coefficients (cv::resize INTER_LINEAR 8u)
 //     HBM-bound: reads ~1.44 B and writes 1 B per output pixel.  One thread = 4 output pixels = one dword store.
 // ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_pyr_down(uint8_t* __restrict__ pyr, size_t image_slab, LevelTable lt, int level, int image0,
-                                                  const int16_t* __restrict__ rs_ofs, const int16_t* __restrict__ rs_coef)
+// One launch builds levels 1..L-1 of every image.  A work-group is one horizontal band of one image: it computes its rows of
+// level 1 from the input, synchronises itself, computes level 2 from those, and so on.  The row ranges (host table, see
+// lpslam_hip_create) include the few rows above and below the band that its coarser rows are interpolated from, so bands never
+// wait for one another; the overlap rows are written by both neighbours with identical bytes.
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+
+// Four destination pixels of one row.  The right tap is always column sx0 + 1 and the lower tap the next row (where the table
+// clamps them their weight is 0), so one unaligned 16-bit load fetches both taps of a source row, v_perm spreads them to 16-bit
+// lanes and v_dot2_u32_u16 applies the weight pair (w0 | w1 << 16) as the table stores it.  (One 8-byte load per row with 64-bit
+// shifts was measured slower.)
+template <typename Tab>
+__device__ __forceinline__ uint32_t pyr_down_dword(const uint8_t* __restrict__ src, int sp, int dw, int dx0, int2 ey, Tab xtab)
 {
-    const int dw = lt.w[level], dh = lt.h[level], dp = lt.pitch[level];
-    const int sw = lt.w[level - 1], sh = lt.h[level - 1], sp = lt.pitch[level - 1];
-    const int dx0 = (blockIdx.x * 64 + threadIdx.x) * 4;
-    const int dy = blockIdx.y * 4 + threadIdx.y;
-    if (dy >= dh || dx0 >= dp) return;
-    uint8_t* img = pyr + (size_t)(image0 + blockIdx.z) * image_slab;
-    const uint8_t* src = img + lt.off[level - 1];
-    uint8_t* dst = img + lt.off[level];
-    const int yt = lt.ytab_start[level] + dy;
-    const int sy0 = rs_ofs[yt];
-    const int sy1 = min(sy0 + 1, sh - 1);
-    const int b0 = rs_coef[2 * yt], b1 = rs_coef[2 * yt + 1];
-    const uint8_t* S0 = src + (size_t)sy0 * sp;
-    const uint8_t* S1 = src + (size_t)sy1 * sp;
+    const int b0 = ey.y & 0xFFFF, b1 = ey.y >> 16;
+    const unsigned o0 = (unsigned)(ey.x & 0xFFFF) * (unsigned)sp, o1 = o0 + (unsigned)sp;   // uniform base + 32-bit offsets
     uint32_t packed = 0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int dx = dx0 + k;
-        if (dx < dw) {
-            const int xt = lt.xtab_start[level] + dx;
-            const int sx0 = rs_ofs[xt];
-            const int sx1 = min(sx0 + 1, sw - 1);
-            const int a0 = rs_coef[2 * xt], a1 = rs_coef[2 * xt + 1];
-            const int r0 = S0[sx0] * a0 + S0[sx1] * a1;
-            const int r1 = S1[sx0] * a0 + S1[sx1] * a1;
-            const int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
-            packed |= (uint32_t)(v & 0xFF) << (8 * k);
-        }
+    for (int k = 0; k < 4; ++k) {       // branch-free: pad columns compute the last column and are zeroed by a select
+        const int2 ex = xtab[min(dx0 + k, dw - 1)];
+        const unsigned sx0 = (unsigned)ex.x & 0xFFFFu;
+        const unsigned t0 = *reinterpret_cast<const unsigned short*>(src + o0 + sx0);
+        const unsigned t1 = *reinterpret_cast<const unsigned short*>(src + o1 + sx0);
+        const int r0 = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(us2, __builtin_amdgcn_perm(0u, t0, 0x0c010c00u)), __builtin_bit_cast(us2, ex.y), 0u, false);
+        const int r1 = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(us2, __builtin_amdgcn_perm(0u, t1, 0x0c010c00u)), __builtin_bit_cast(us2, ex.y), 0u, false);
+        const int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+        packed |= (dx0 + k < dw ? (uint32_t)(v & 0xFF) : 0u) << (8 * k);
     }
-    *reinterpret_cast<uint32_t*>(dst + (size_t)dy * dp + dx0) = packed;
+    return packed;
+}
+
+template <bool kTablesInLds>
+__global__ __launch_bounds__(1024) void k_pyr_bands(uint8_t* __restrict__ pyr, size_t image_slab, LevelTable lt, int image0,
+                                                    const int2* __restrict__ rs_pack, int rs_entries,
+                                                    const int2* __restrict__ band_rows)
+{
+    extern __shared__ int2 s_tab[];      // the resize tables of all levels (57 KB at 1280x720, 8 levels)
+    if (kTablesInLds) {
+        for (int i = threadIdx.x; i < rs_entries; i += 1024) s_tab[i] = rs_pack[i];
+        __syncthreads();
+    }
+    uint8_t* img = pyr + (size_t)(image0 + blockIdx.y) * image_slab;
+    for (int level = 1; level < lt.n_levels; ++level) {
+        const int2 rows = band_rows[level * kPyrMaxBands + blockIdx.x];
+        const int dw = lt.w[level], dp = lt.pitch[level], sp = lt.pitch[level - 1];
+        const uint8_t* src = img + lt.off[level - 1];
+        uint8_t* dst = img + lt.off[level];
+        const int per_row = dp >> 2;
+        const int total = (rows.y - rows.x + 1) * per_row;
+        const float inv = 1.0f / (float)per_row;
+        const int ytab = lt.ytab_start[level] + rows.x, xtab = lt.xtab_start[level];
+        constexpr int kIlp = 4;          // dwords in flight per thread: the loop is a chain of table read -> pixel loads
+        for (int t = threadIdx.x; t < total; t += 1024 * kIlp) {
+            uint32_t v[kIlp];
+            int r[kIlp], q[kIlp];
+#pragma unroll
+            for (int u = 0; u < kIlp; ++u) {
+                const int tu = min(t + 1024 * u, total - 1);     // past the end: recompute the last dword, store nothing
+                r[u] = (int)(((float)tu + 0.5f) * inv);
+                q[u] = tu - r[u] * per_row;
+                if (q[u] < 0) { --r[u]; q[u] += per_row; } else if (q[u] >= per_row) { ++r[u]; q[u] -= per_row; }
+                if (kTablesInLds) v[u] = pyr_down_dword(src, sp, dw, q[u] * 4, s_tab[ytab + r[u]], s_tab + xtab);
+                else v[u] = pyr_down_dword(src, sp, dw, q[u] * 4, rs_pack[ytab + r[u]], rs_pack + xtab);
+            }
+#pragma unroll
+            for (int u = 0; u < kIlp; ++u)
+                if (t + 1024 * u < total) *reinterpret_cast<uint32_t*>(dst + (size_t)(rows.x + r[u]) * dp + q[u] * 4) = v[u];
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -779,10 +816,18 @@ __global__ __launch_bounds__(256) void k_remap(const uint8_t* __restrict__ raw, 
 // ------------------------------------------------------------------------------------------------------------
 int lp_launch_pyramid(lpslam_hip_ctx* c, int first, int n_images)
 {
-    for (int l = 1; l < c->lt.n_levels; ++l) {
-        dim3 block(64, 4), grid((c->lt.pitch[l] / 4 + 63) / 64, (c->lt.h[l] + 3) / 4, n_images);
-        hipLaunchKernelGGL(k_pyr_down, grid, block, 0, c->stream, c->d_pyr, c->image_slab, c->lt, l, first, c->d_rs_ofs, c->d_rs_coef);
-    }
+    if (c->lt.n_levels < 2 || n_images <= 0) return LPSLAM_HIP_OK;
+    // one band work-group per CU (256 CUs): more bands would only add rows computed twice, fewer would leave CUs idle
+    const int bands = std::max(4, std::min(kPyrMaxBands, 256 / n_images));
+    const int set = bands;
+    const int2* rows = c->d_band_rows + (size_t)set * kMaxLevels * kPyrMaxBands;
+    const size_t lds = (size_t)c->rs_entries * sizeof(int2);
+    if (lds <= 64 * 1024)
+        hipLaunchKernelGGL(k_pyr_bands<true>, dim3(bands, n_images), dim3(1024), lds, c->stream, c->d_pyr, c->image_slab, c->lt, first,
+                           c->d_rs_pack, c->rs_entries, rows);
+    else        // larger images: tables read through the cache instead
+        hipLaunchKernelGGL(k_pyr_bands<false>, dim3(bands, n_images), dim3(1024), 0, c->stream, c->d_pyr, c->image_slab, c->lt, first,
+                           c->d_rs_pack, c->rs_entries, rows);
     LP_HIP(hipGetLastError());
     return LPSLAM_HIP_OK;
 }

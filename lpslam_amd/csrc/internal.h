@@ -21,6 +21,8 @@ constexpr int kCellSlots = 1024;   // max NMS survivors in a 64x64 cell (no two 
 constexpr int kQuotaMax = 2000;    // per-level quota supported by the distribution kernel (node index < 2048)
 
 // Per-level geometry, passed to kernels by value.
+constexpr int kPyrMaxBands = 32;   // banded pyramid kernel: up to 32 bands per image
+
 struct LevelTable {
     int n_levels;
     int w[kMaxLevels], h[kMaxLevels], pitch[kMaxLevels];
@@ -59,8 +61,10 @@ struct lpslam_hip_ctx {
 
     uint8_t* d_pyr = nullptr;          // [max_images][image_slab]
     // resize tables: xofs/yofs (int16) and 11-bit coefficient pairs (int16 x2) per output column/row
-    int16_t* d_rs_ofs = nullptr;
-    int16_t* d_rs_coef = nullptr;
+    int2* d_rs_pack = nullptr;         // resize tables, one entry per destination column / row: (s0 | s1 << 16, w0 | w1 << 16)
+    int rs_entries = 0;
+    int2* d_band_rows = nullptr;       // [band count 0..32][levels][bands]: rows of each level a band work-group computes
+
     // FAST output: per cell fixed slots + counts
     uint32_t* d_cell_keys = nullptr;   // [max_images][cells_per_image][kCellSlots]  score<<24 | y<<12 | x
     int32_t* d_cell_count = nullptr;   // [max_images][cells_per_image]
