@@ -78,9 +78,14 @@ class Workload:
     def step(self, timers=False):
         c, F = self.ctx, self.F
         if not timers:
+            # the local BA of this interval runs on its own stream beside the front end of the interval's frames, as the
+            # reference's mapping thread runs beside tracking: enqueue it, enqueue the frames, then wait for both
+            if self.ba is not None:
+                self.ba.reset()
+                self.ba.optimize_begin(True, BA_ITERS)
             self.front_end()
             if self.ba is not None:
-                self.bundle_adjust()
+                self.ba.optimize_end()
             return
         for slot, stage in ((T_PYR, "pyramid"), (T_FAST, "fast"), (T_DIST, "distribute"), (T_DESC, "describe")):
             c.timer_begin(slot); c.stage(stage, 2 * F); c.timer_end(slot)

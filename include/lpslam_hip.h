@@ -178,6 +178,13 @@ int lpslam_hip_ba_set_active(lpslam_hip_ba* ba, const uint8_t* active);
  * 1e-5 max diag H, rho-controlled lambda, <= 10 trials).  log may be NULL.  Returns iterations run in *done. */
 int lpslam_hip_ba_optimize(lpslam_hip_ba* ba, int32_t robust, int32_t iters, lpslam_hip_ba_iter_log* log,
                            int32_t* done);
+/* The same call in two halves.  begin enqueues the work on the problem's own stream and returns at once; end waits
+ * for it, runs the extra trials rejected steps need and fetches the log.  Between the two the caller may enqueue
+ * front-end work on the context: that is the reference's mapping thread running local BA beside tracking
+ * ([UPSTREAM] mapping_module::run; lpslam only sees it through feed_stereo_frame,
+ * src/Trackers/OpenVSLAMStereoTracker.cpp:293-295).  No other call on `ba` is allowed in between. */
+int lpslam_hip_ba_optimize_begin(lpslam_hip_ba* ba, int32_t robust, int32_t iters);
+int lpslam_hip_ba_optimize_end(lpslam_hip_ba* ba, lpslam_hip_ba_iter_log* log, int32_t* done);
 /* Motion-only mode: landmarks are held fixed (unary edges), only the free poses move. */
 int lpslam_hip_ba_set_points_fixed(lpslam_hip_ba* ba, int32_t points_fixed);
 /* optimize::pose_optimizer flow on a problem created with ONE free pose: 4 rounds x 10 iterations, outliers

@@ -1376,6 +1376,7 @@ struct lpslam_hip_ba {
     BaCtl h_ctl_out{};                             // staging of the control block on its way to the device
     int robust = 1, points_fixed = 0;
     std::vector<std::pair<void*, size_t>> allocs;      // blocks of the context's cache (lp_pool_alloc)
+    int pending_iters = -1;                            // >= 0 between optimize_begin and optimize_end
     std::map<long, hipGraphExec_t> graphs;             // captured first batches by (units, robust, points_fixed); nullptr = seen once
 };
 
@@ -1695,59 +1696,86 @@ int lpslam_hip_ba_set_points_fixed(lpslam_hip_ba* b, int32_t points_fixed)
     return LPSLAM_HIP_OK;
 }
 
-int lpslam_hip_ba_optimize(lpslam_hip_ba* b, int32_t robust, int32_t iters, lpslam_hip_ba_iter_log* log, int32_t* done_out)
+// One unit = one LM trial.  Without rejected steps `iters` units finish the call with a single look at the control block;
+// every rejected trial costs one more unit, enqueued after that look.
+static int enqueue_batch(lpslam_hip_ba* b, int units, bool first_batch)
+{
+    for (int u = 0; u < units; ++u) {
+        int rc;
+        if ((rc = enqueue_linearize(b, 1, first_batch && u == 0))) return rc;
+        if ((rc = enqueue_reduce(b, 1))) return rc;
+        if ((rc = enqueue_solve(b, 1))) return rc;
+    }
+    return LPSLAM_HIP_OK;
+}
+
+// optimize() in two halves: begin enqueues the whole first batch on the problem's stream and returns (the mapping side of the
+// reference runs beside tracking: the caller can enqueue front-end work of the next frames meanwhile), end waits, handles
+// rejected trials and fetches the log.
+int lpslam_hip_ba_optimize_begin(lpslam_hip_ba* b, int32_t robust, int32_t iters)
 {
     if (!b) { set_error("null problem"); return LPSLAM_HIP_ERR_INVALID; }
     if (iters < 0 || iters > MAX_LOG) { set_error("iterations must be in [0,%d]", MAX_LOG); return LPSLAM_HIP_ERR_INVALID; }
+    if (b->pending_iters >= 0) { set_error("optimize_begin: the previous optimize_begin has not been ended"); return LPSLAM_HIP_ERR_INVALID; }
     LP_HIP(hipSetDevice(b->ctx->cfg.device));
     int rc = begin_optimize(b, robust, iters); if (rc) return rc;
-    // One unit = one LM trial.  Without rejected steps `iters` units finish the call with a single look at the control
-    // block; every rejected trial costs one more unit, enqueued after that look.
     // The first batch of a call -- `iters` units, the first with its explicit linearisation -- has a fixed launch sequence for a
     // given (robust, iters, points_fixed): the second time a problem asks for the same one it is captured into a hipGraph and
     // from then on replayed with one hipGraphLaunch (a reused problem: the bench's local BA, a tracker window that is re-solved).
-    auto enqueue_batch = [&](int units, bool first_batch) -> int {
-        for (int u = 0; u < units; ++u) {
-            int r2;
-            if ((r2 = enqueue_linearize(b, 1, first_batch && u == 0))) return r2;
-            if ((r2 = enqueue_reduce(b, 1))) return r2;
-            if ((r2 = enqueue_solve(b, 1))) return r2;
-        }
-        return LPSLAM_HIP_OK;
-    };
-    int guard = 0;
-    while (!b->h_ctl.stopped && b->h_ctl.outer_done < iters && guard++ < 16 * MAX_LOG) {
-        const int units = iters - b->h_ctl.outer_done;
-        const bool first_batch = guard == 1;
+    const int units = iters;
+    if (units > 0) {
         bool launched = false;
-        if (first_batch && units > 0) {
-            const long key = ((long)units << 2) | ((long)(robust ? 1 : 0) << 1) | (long)(b->points_fixed ? 1 : 0);
-            auto it = b->graphs.find(key);
-            if (it == b->graphs.end()) b->graphs.emplace(key, nullptr);          // seen once: run directly (also sets function attributes)
-            else {
-                if (!it->second) {
-                    hipGraph_t graph = nullptr;
-                    if (hipStreamBeginCapture(b->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-                        const int r2 = enqueue_batch(units, true);
-                        const hipError_t e2 = hipStreamEndCapture(b->stream, &graph);
-                        if (r2 == LPSLAM_HIP_OK && e2 == hipSuccess && graph) {
-                            hipGraphExec_t exec = nullptr;
-                            if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) it->second = exec;
-                        }
-                        if (graph) (void)hipGraphDestroy(graph);
+        const long key = ((long)units << 2) | ((long)(robust ? 1 : 0) << 1) | (long)(b->points_fixed ? 1 : 0);
+        auto it = b->graphs.find(key);
+        if (it == b->graphs.end()) b->graphs.emplace(key, nullptr);          // seen once: run directly (also sets function attributes)
+        else {
+            if (!it->second) {
+                hipGraph_t graph = nullptr;
+                if (hipStreamBeginCapture(b->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                    const int r2 = enqueue_batch(b, units, true);
+                    const hipError_t e2 = hipStreamEndCapture(b->stream, &graph);
+                    if (r2 == LPSLAM_HIP_OK && e2 == hipSuccess && graph) {
+                        hipGraphExec_t exec = nullptr;
+                        if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) it->second = exec;
                     }
-                    (void)hipGetLastError();
+                    if (graph) (void)hipGraphDestroy(graph);
                 }
-                if (it->second) { LP_HIP(hipGraphLaunch(it->second, b->stream)); launched = true; }
+                (void)hipGetLastError();
             }
+            if (it->second) { LP_HIP(hipGraphLaunch(it->second, b->stream)); launched = true; }
         }
-        if (!launched && (rc = enqueue_batch(units, first_batch))) return rc;
+        if (!launched && (rc = enqueue_batch(b, units, true))) return rc;
+    }
+    b->pending_iters = iters;
+    return LPSLAM_HIP_OK;
+}
+
+int lpslam_hip_ba_optimize_end(lpslam_hip_ba* b, lpslam_hip_ba_iter_log* log, int32_t* done_out)
+{
+    if (!b) { set_error("null problem"); return LPSLAM_HIP_ERR_INVALID; }
+    if (b->pending_iters < 0) { set_error("optimize_end without optimize_begin"); return LPSLAM_HIP_ERR_INVALID; }
+    LP_HIP(hipSetDevice(b->ctx->cfg.device));
+    const int iters = b->pending_iters;
+    b->pending_iters = -1;
+    int rc;
+    if (iters > 0) {
         if ((rc = read_ctl(b))) return rc;
+        int guard = 0;
+        while (!b->h_ctl.stopped && b->h_ctl.outer_done < iters && guard++ < 16 * MAX_LOG) {
+            if ((rc = enqueue_batch(b, iters - b->h_ctl.outer_done, false))) return rc;
+            if ((rc = read_ctl(b))) return rc;
+        }
     }
     const int done = b->h_ctl.outer_done;
     if (log && done) LP_HIP(hipMemcpy(log, b->d_log, std::min(done, MAX_LOG) * sizeof(lpslam_hip_ba_iter_log), hipMemcpyDeviceToHost));
     if (done_out) *done_out = done;
     return LPSLAM_HIP_OK;
+}
+
+int lpslam_hip_ba_optimize(lpslam_hip_ba* b, int32_t robust, int32_t iters, lpslam_hip_ba_iter_log* log, int32_t* done_out)
+{
+    const int rc = lpslam_hip_ba_optimize_begin(b, robust, iters);
+    return rc ? rc : lpslam_hip_ba_optimize_end(b, log, done_out);
 }
 
 // ---- partitioned (multi-GPU) solve: one LM trial in three phases with the caller's all-reduces in between ------------------

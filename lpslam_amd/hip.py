@@ -35,7 +35,7 @@ SYMBOLS = [
     "lpslam_hip_get_bf_matches", "lpslam_hip_match_bf_strided", "lpslam_hip_set_descriptors",
     "lpslam_hip_match_stereo", "lpslam_hip_match_stereo_strided", "lpslam_hip_get_stereo",
     "lpslam_hip_match_projection", "lpslam_hip_match_fuse", "lpslam_hip_match_area", "lpslam_hip_match_orientation_filter",
-    "lpslam_hip_ba_create", "lpslam_hip_ba_destroy", "lpslam_hip_ba_set_active", "lpslam_hip_ba_optimize",
+    "lpslam_hip_ba_create", "lpslam_hip_ba_destroy", "lpslam_hip_ba_set_active", "lpslam_hip_ba_optimize", "lpslam_hip_ba_optimize_begin", "lpslam_hip_ba_optimize_end",
     "lpslam_hip_ba_local", "lpslam_hip_ba_set_points_fixed", "lpslam_hip_ba_pose_optimize", "lpslam_hip_pose_optimize", "lpslam_hip_ba_reset", "lpslam_hip_ba_get", "lpslam_hip_ba_chi2", "lpslam_hip_ba_reduced_buffer",
     "lpslam_hip_ba_step_begin", "lpslam_hip_ba_step_lambda0", "lpslam_hip_ba_step_solve", "lpslam_hip_ba_scalar_buffer", "lpslam_hip_ba_step_end", "lpslam_hip_ba_status",
     "lpslam_hip_sim3_create", "lpslam_hip_sim3_destroy", "lpslam_hip_sim3_optimize", "lpslam_hip_sim3_get", "lpslam_hip_sim3_chi2", "lpslam_hip_sim3_transform_optimize",
@@ -282,6 +282,15 @@ class BundleAdjuster:
     def optimize(self, robust=True, iters=10):
         log = np.zeros(max(iters, 1), BA_LOG_DTYPE); done = C.c_int32()
         _check(self.lib.lpslam_hip_ba_optimize(self.h, int(robust), int(iters), _p(log), C.byref(done)))
+        return log[:done.value].copy()
+
+    def optimize_begin(self, robust=True, iters=10):
+        self._iters = int(iters)
+        _check(self.lib.lpslam_hip_ba_optimize_begin(self.h, int(robust), int(iters)))
+
+    def optimize_end(self):
+        log = np.zeros(max(self._iters, 1), BA_LOG_DTYPE); done = C.c_int32()
+        _check(self.lib.lpslam_hip_ba_optimize_end(self.h, _p(log), C.byref(done)))
         return log[:done.value].copy()
 
     def reset(self):

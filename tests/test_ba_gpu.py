@@ -164,3 +164,26 @@ def test_global_ba_size_runs(hiplib, oracle):
     assert len(log) == 3 and np.allclose(log["chi2_after"], olog["chi2_after"], rtol=CHI_RTOL) and np.array_equal(log["trials"], olog["trials"])
     gp, gx = ba.state()
     assert rot_err(gp[:, :4], op[:, :4]).max() < ROT_TOL and np.abs(gp[:, 4:] - op[:, 4:]).max() < TRANS_TOL
+
+
+def test_optimize_in_two_halves_beside_front_end_work(hiplib, oracle, ctx):
+    """optimize_begin / optimize_end give what optimize gives (also with rejected trials, which need extra units after the
+    wait), while front-end work is enqueued on the context in between; misuse is refused."""
+    prob = synth.ba_problem(6, 150, 800, 640, 480, seq_id=6, pose_noise=(0.08, 0.5), point_noise=0.5)
+    obs = hiplib.ba_obs_array(prob)
+    one = hiplib.BundleAdjuster(ctx, prob["poses"], prob["fixed"], prob["points"], obs, prob["cam"])
+    want = one.optimize(True, 10); wp, wx = one.state()
+    two = hiplib.BundleAdjuster(ctx, prob["poses"], prob["fixed"], prob["points"], obs, prob["cam"])
+    img = synth.StereoSequence(320, 240, 1).frame(0)[0]
+    ctx.upload(0, img)
+    for _ in range(3):                      # the third round replays the captured graph
+        two.reset()
+        two.optimize_begin(True, 10)
+        with pytest.raises(hiplib.LpslamHipError):
+            two.optimize_begin(True, 10)
+        ctx.extract(1)
+        got = two.optimize_end()
+        gp, gx = two.state()
+        assert got.tobytes() == want.tobytes() and np.array_equal(gp, wp) and np.array_equal(gx, wx)
+    with pytest.raises(hiplib.LpslamHipError):
+        two.optimize_end()
