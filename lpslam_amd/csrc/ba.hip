@@ -10,7 +10,7 @@
 //   linearise   k_ba_lin (observation side: thread / observation, W = B^T w A and shares of H_ll, b_l; pose side: 8
 //               wavefronts / keyframe, H_pp, b_p, chi2; both in one launch), k_ba_point_sum (H_ll, b_l; its last workgroup
 //               combines the pose partials in fixed order and computes lambda_0)
-//   trial       k_ba_obs_y (Y = W (H_ll + lambda)^-1), k_ba_schur (wavefront / pose-block pair over a pair list),
+//   trial       k_ba_schur (wavefront / pose-block pair over a pair list; Y = W (H_ll + lambda)^-1 formed per term),
 //               k_chol_pair x nb/2 (32-wide panels, two per launch, block products on the f64 matrix cores; the rhs is carried as an extra
 //               row and L^-T as extra row blocks, so no triangular substitution is needed), k_chol_xsolve (x_p = L^-T y),
 //               k_ba_backsub (landmarks, trial poses), k_ba_trial (trial chi2; its last workgroup runs g2o's lambda control)
@@ -61,7 +61,7 @@ struct BaView {                       // device pointers handed to kernels by va
     const double* o_u; const double* o_v; const double* o_ur; const double* o_w;
     const uint8_t* o_active;
     const int* pt_start; const int* pt_obs; const int* ps_start; const int* o_orig;
-    double* W; double* Y; double* Ybl; double* Hll; double* bl; double* Hpp; double* hl_obs; double* partial;   // linearisation set in use (ba_lin_set)
+    double* W; double* Hll; double* bl; double* Hpp; double* hl_obs; double* partial;   // linearisation set in use (ba_lin_set)
     double* W2[2]; double* hl2[2]; double* partial2[2]; double* partial_trial;   // both sets (indexed like the state buffers) + trial chi2 partials
     double* S; double* rhs; double* bp; double* hppdiag; double* chi_cur;   // reduced buffer sections (all-reduced when partitioned)
     double* bp_loc; double* hppdiag_loc; double* chi_loc;                    // this rank's own sums (equal to the above on one GPU)
@@ -69,7 +69,7 @@ struct BaView {                       // device pointers handed to kernels by va
     double* Ldiag;                                                           // factored diagonal blocks [nb][32][32]
     double* Lsub;                                                            // L_j1,j of every panel pair, stored at [j1][32][32]
     double* xp; double* chi_pose; double* part; double* scal;
-    const int* blk_start; const int2* blk_terms;
+    const int* blk_start; const int4* blk_terms;                  // Schur pair lists: (observation a, observation b, their landmark, -)
     const int4* blk_work; double* blk_part; int* blk_ticket;      // Schur work items (block, part, parts, first item), partial sums, per-block tickets
     BaCtl* ctl; lpslam_hip_ba_iter_log* log;
     BaCam cam;
@@ -564,33 +564,16 @@ __global__ void k_lm_decide(BaView v)
     if (threadIdx.x == 0 && blockIdx.x == 0) lm_decide(v, v.scal[1], v.scal[5], v.scal[2], v.scal[3]);
 }
 
-// ---- per trial: Y = W (H_ll + lambda I)^-1 and Y b_l per observation -------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_ba_obs_y(BaView v)
+// Y = W (H_ll + lambda I)^-1 of one observation (6x3 times symmetric 3x3), in the operation order every user shares
+__device__ __forceinline__ void obs_y_row(const double* h, double w0, double w1, double w2, double& y0, double& y1, double& y2)
 {
-    if (ba_idle(v.ctl)) return;
-    const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= v.n_obs) return;
-    ba_lin_set(v, v.ctl->cur);
-    const int j = v.o_point[k];
-    double h[6];
-    point_hinv(v.Hll + 6 * (size_t)j, v.ctl->lambda, h);       // recomputed per observation: cheaper than a launch of its own
-    const double H0 = h[0], H1 = h[1], H2 = h[2], H4 = h[3], H5 = h[4], H8 = h[5];
-    const double b0 = v.bl[3 * (size_t)j], b1 = v.bl[3 * (size_t)j + 1], b2 = v.bl[3 * (size_t)j + 2];
-    const double* Wk = v.W + 18 * (size_t)k;
-    double* Yk = v.Y + 18 * (size_t)k;
-    double* yb = v.Ybl + 6 * (size_t)k;
-#pragma unroll
-    for (int r = 0; r < 6; ++r) {
-        const double w0 = Wk[r * 3], w1 = Wk[r * 3 + 1], w2 = Wk[r * 3 + 2];
-        const double y0 = w0 * H0 + w1 * H1 + w2 * H2;
-        const double y1 = w0 * H1 + w1 * H4 + w2 * H5;
-        const double y2 = w0 * H2 + w1 * H5 + w2 * H8;
-        Yk[r * 3] = y0; Yk[r * 3 + 1] = y1; Yk[r * 3 + 2] = y2;
-        yb[r] = y0 * b0 + y1 * b1 + y2 * b2;
-    }
+    y0 = w0 * h[0] + w1 * h[1] + w2 * h[2];
+    y1 = w0 * h[1] + w1 * h[3] + w2 * h[4];
+    y2 = w0 * h[2] + w1 * h[4] + w2 * h[5];
 }
 
-// ---- per trial: Schur complement.  Work items [0, n_work): one wavefront per pose-block pair (i <= k) or part of one: lanes stride over the
+// ---- per trial: Schur complement; Y = W (H_ll + lambda I)^-1 is formed per term from W and the landmark's 3x3 block (a launch
+//      and the 18 doubles per observation it wrote and this kernel read back are gone).  Work items [0, n_work): one wavefront per pose-block pair (i <= k) or part of one: lanes stride over the
 //      pair list with 36 private accumulators, partials are summed in lane order through LDS (fixed summation order).
 //      Blocks [n_work, n_work + n_free): rhs_i = b_p,i - sum Y b_l over the observations of keyframe i.
 //      fused != 0 (single-GPU solve): lambda goes onto the pose diagonal, rhs straight into row `dim` of S and the failure
@@ -606,10 +589,38 @@ __global__ __launch_bounds__(64) void k_ba_schur(BaView v, int n_work, int fused
         const int i = blockIdx.x - n_work;
         const int p = v.free_pose[i];
         double r6[6] = {0, 0, 0, 0, 0, 0};
-        for (int s = v.ps_start[p] + lane; s < v.ps_start[p + 1]; s += 64) {
-            const double* yb = v.Ybl + 6 * (size_t)s;
+        // four observations per lane and round: their index -> landmark -> (H_ll, b_l) load chains run side by side
+        const int s_end = v.ps_start[p + 1];
+        for (int s0 = v.ps_start[p] + lane; s0 < s_end; s0 += 256) {
+            int jj[4];
 #pragma unroll
-            for (int q = 0; q < 6; ++q) r6[q] += yb[q];
+            for (int u = 0; u < 4; ++u) jj[u] = v.o_point[min(s0 + 64 * u, s_end - 1)];
+            double hh[4][6], bb[4][3], ww[4][18];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int s = min(s0 + 64 * u, s_end - 1);
+                const double* hl = v.Hll + 6 * (size_t)jj[u];
+#pragma unroll
+                for (int q = 0; q < 6; ++q) hh[u][q] = hl[q];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) bb[u][q] = v.bl[3 * (size_t)jj[u] + q];
+                const double2* Wa = reinterpret_cast<const double2*>(v.W + 18 * (size_t)s);
+#pragma unroll
+                for (int q = 0; q < 9; ++q) { const double2 a2 = Wa[q]; ww[u][2 * q] = a2.x; ww[u][2 * q + 1] = a2.y; }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (s0 + 64 * u < s_end) {
+                    double h[6];
+                    point_hinv(hh[u], lambda, h);
+#pragma unroll
+                    for (int r = 0; r < 6; ++r) {
+                        double y0, y1, y2;
+                        obs_y_row(h, ww[u][r * 3], ww[u][r * 3 + 1], ww[u][r * 3 + 2], y0, y1, y2);
+                        r6[r] += y0 * bb[u][0] + y1 * bb[u][1] + y2 * bb[u][2];
+                    }
+                }
+            }
         }
 #pragma unroll
         for (int q = 0; q < 6; ++q) r6[q] = wave_sum(r6[q]);
@@ -641,14 +652,21 @@ __global__ __launch_bounds__(64) void k_ba_schur(BaView v, int n_work, int fused
 #pragma unroll
     for (int q = 0; q < 36; ++q) acc[q] = 0;
     for (int t = v.blk_start[blk] + part_id * 64 + lane; t < v.blk_start[blk + 1]; t += 64 * parts) {
-        const int2 ab = v.blk_terms[t];
+        const int4 ab = v.blk_terms[t];
         // rows are 144 bytes = nine 16-byte pieces: dwordx4 loads halve the number of cache-line lookups, which -- every lane
         // in a different line -- are what this kernel is made of
-        const double2* Ya = reinterpret_cast<const double2*>(v.Y + 18 * (size_t)ab.x);
+        const double2* Wa = reinterpret_cast<const double2*>(v.W + 18 * (size_t)ab.x);
         const double2* Wb = reinterpret_cast<const double2*>(v.W + 18 * (size_t)ab.y);
-        double y[18], w[18];
+        const double* hl = v.Hll + 6 * (size_t)ab.z;
+        double hraw[6], y[18], w[18];
 #pragma unroll
-        for (int q = 0; q < 9; ++q) { const double2 a2 = Ya[q], b2 = Wb[q]; y[2 * q] = a2.x; y[2 * q + 1] = a2.y; w[2 * q] = b2.x; w[2 * q + 1] = b2.y; }
+        for (int q = 0; q < 6; ++q) hraw[q] = hl[q];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) { const double2 a2 = Wa[q], b2 = Wb[q]; y[2 * q] = a2.x; y[2 * q + 1] = a2.y; w[2 * q] = b2.x; w[2 * q + 1] = b2.y; }
+        double h[6];
+        point_hinv(hraw, lambda, h);
+#pragma unroll
+        for (int r = 0; r < 6; ++r) obs_y_row(h, y[r * 3], y[r * 3 + 1], y[r * 3 + 2], y[r * 3], y[r * 3 + 1], y[r * 3 + 2]);
 #pragma unroll
         for (int r = 0; r < 6; ++r)
 #pragma unroll
@@ -1361,13 +1379,13 @@ struct lpslam_hip_ba {
     double *d_o_u = nullptr, *d_o_v = nullptr, *d_o_ur = nullptr, *d_o_w = nullptr;
     uint8_t* d_o_active = nullptr; uint8_t* d_act_in = nullptr; int* d_o_orig = nullptr;
     int *d_pt_start = nullptr, *d_pt_obs = nullptr, *d_ps_start = nullptr;
-    double *d_Y = nullptr, *d_Ybl = nullptr, *d_Hll = nullptr, *d_bl = nullptr, *d_Hpp = nullptr;
+    double *d_Hll = nullptr, *d_bl = nullptr, *d_Hpp = nullptr;
     double *d_W2[2] = {nullptr, nullptr}, *d_hl2[2] = {nullptr, nullptr}, *d_partial2[2] = {nullptr, nullptr}, *d_partial_trial = nullptr;
     double *d_minv = nullptr, *d_ldiag = nullptr, *d_lsub = nullptr;
     double* d_red = nullptr; int64_t red_n = 0;
     double *d_xp = nullptr, *d_chi_pose = nullptr, *d_part = nullptr, *d_scal = nullptr, *d_loc = nullptr;
     double* d_chi_obs = nullptr; uint8_t* d_depth = nullptr;
-    int* d_blk_start = nullptr; int2* d_blk_terms = nullptr; int4* d_blk_work = nullptr; double* d_blk_part = nullptr; int* d_blk_ticket = nullptr;
+    int* d_blk_start = nullptr; int4* d_blk_terms = nullptr; int4* d_blk_work = nullptr; double* d_blk_part = nullptr; int* d_blk_ticket = nullptr;
     BaCtl* d_ctl = nullptr; lpslam_hip_ba_iter_log* d_log = nullptr;
     int part_n = 0;
     BaCam cam{};
@@ -1407,7 +1425,7 @@ BaView make_view(lpslam_hip_ba* b)
     v.pose_slot = b->d_pose_slot; v.free_pose = b->d_free_pose; v.o_pose = b->d_o_pose; v.o_point = b->d_o_point;
     v.o_u = b->d_o_u; v.o_v = b->d_o_v; v.o_ur = b->d_o_ur; v.o_w = b->d_o_w; v.o_active = b->d_o_active;
     v.pt_start = b->d_pt_start; v.pt_obs = b->d_pt_obs; v.ps_start = b->d_ps_start; v.o_orig = b->d_o_orig;
-    v.Y = b->d_Y; v.Ybl = b->d_Ybl; v.Hll = b->d_Hll; v.bl = b->d_bl; v.Hpp = b->d_Hpp;
+    v.Hll = b->d_Hll; v.bl = b->d_bl; v.Hpp = b->d_Hpp;
     v.hl_obs = b->d_hl2[0]; v.partial = b->d_partial2[0]; v.W = b->d_W2[0];
     for (int k2 = 0; k2 < 2; ++k2) { v.W2[k2] = b->d_W2[k2]; v.hl2[k2] = b->d_hl2[k2]; v.partial2[k2] = b->d_partial2[k2]; }
     v.partial_trial = b->d_partial_trial; v.Minv = b->d_minv; v.Ldiag = b->d_ldiag; v.Lsub = b->d_lsub;
@@ -1439,7 +1457,6 @@ int enqueue_reduce(lpslam_hip_ba* b, int fused)
 {
     BaView v = make_view(b);
     hipStream_t s = b->stream;
-    if (b->n_obs) hipLaunchKernelGGL(k_ba_obs_y, dim3((b->n_obs + 255) / 256), dim3(256), 0, s, v);
     if (b->n_free) hipLaunchKernelGGL(k_ba_schur, dim3(b->n_work + b->n_free), dim3(64), 0, s, v, b->n_work, fused);
     LP_HIP(hipGetLastError());
     return LPSLAM_HIP_OK;
@@ -1557,7 +1574,7 @@ int lpslam_hip_ba_create(lpslam_hip_ctx* ctx, const double* poses, const uint8_t
     std::vector<std::pair<int, int>> tmp;      // (slot, obs) of one landmark
     for (int pass = 0; pass < 2; ++pass) {
         std::vector<int> fill;
-        std::vector<int2> terms;
+        std::vector<int4> terms;
         if (pass == 1) {
             for (int q = 0; q < b->n_blocks; ++q) blk_count[q + 1] += blk_count[q];
             fill.assign(blk_count.begin(), blk_count.end() - 1);
@@ -1573,12 +1590,12 @@ int lpslam_hip_ba_create(lpslam_hip_ctx* ctx, const double* poses, const uint8_t
                         // two observations of one landmark in the same keyframe: both orders go to the diagonal block
                         const int q = blk_index(tmp[a].first, tmp[a].first);
                         if (pass == 0) blk_count[q + 1] += 2;
-                        else { terms[fill[q]++] = make_int2(tmp[a].second, tmp[c].second); terms[fill[q]++] = make_int2(tmp[c].second, tmp[a].second); }
+                        else { terms[fill[q]++] = make_int4(tmp[a].second, tmp[c].second, j, 0); terms[fill[q]++] = make_int4(tmp[c].second, tmp[a].second, j, 0); }
                         continue;
                     }
                     const int q = blk_index(tmp[a].first, tmp[c].first);
                     if (pass == 0) blk_count[q + 1]++;
-                    else terms[fill[q]++] = make_int2(tmp[a].second, tmp[c].second);
+                    else terms[fill[q]++] = make_int4(tmp[a].second, tmp[c].second, j, 0);
                 }
         }
         if (pass == 1) {
@@ -1622,7 +1639,6 @@ int lpslam_hip_ba_create(lpslam_hip_ctx* ctx, const double* poses, const uint8_t
         BA_HIP(hipMemcpy(b->d_points[0], points, 3 * (size_t)n_points * sizeof(double), hipMemcpyHostToDevice));
     }
     for (int k2 = 0; k2 < 2; ++k2) BA_TRY(dalloc(b, &b->d_W2[k2], 18 * (size_t)n_obs));
-    BA_TRY(dalloc(b, &b->d_Y, 18 * (size_t)n_obs)); BA_TRY(dalloc(b, &b->d_Ybl, 6 * (size_t)n_obs));
     BA_TRY(dalloc(b, &b->d_Hll, 6 * (size_t)n_points)); BA_TRY(dalloc(b, &b->d_bl, 3 * (size_t)n_points));
     BA_TRY(dalloc(b, &b->d_Hpp, 36 * (size_t)b->n_free));
     for (int k2 = 0; k2 < 2; ++k2) {
