@@ -167,6 +167,28 @@ __device__ __forceinline__ double ba_weight(const BaView& v, int k, int D, const
 // drains its stores, barrier, one lane's agent-scope release + ticket; consumer: agent-scope acquire by that lane, its wait,
 // barrier, plain loads -- MI355X_MICROARCH.md, inter-workgroup visibility); that workgroup then runs the single-workgroup
 // combine, which saves a launch.  No spinning, so the grid always drains.
+// Hand-over to the workgroup that finishes last, without cache maintenance: every byte the last workgroup reads from the others
+// is stored write-through (st_sc1) and read L1-bypassing (ld_sc1); each storing wavefront drains its stores, the workgroup
+// meets at a barrier and one lane takes a relaxed agent-scope ticket (MI355X_MICROARCH, valid forms: one unsharded counter, the
+// consumer is the workgroup whose add came last).  An acquire-release pair here would cost a buffer_wbl2 + buffer_inv, ~3.5 us.
+__device__ __forceinline__ void st_sc1(double* p, double x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double ld_sc1(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ bool ba_last_block_sc1(BaCtl* c, int total)
+{
+    __shared__ int s_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wavefront drains its own stores (a barrier alone does not)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int t = __hip_atomic_fetch_add(&c->ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (t == total - 1);
+        if (s_last) c->ticket = 0;
+    }
+    __syncthreads();
+    return s_last != 0;
+}
+// The general form (any plain stores before it are visible to the last workgroup's plain loads after it): agent-scope
+// acquire-release on the ticket, i.e. an L2 write-back and an L1 invalidate per workgroup.  Used where the handed-over data
+// are not confined to a few words (sim3.inl).
 __device__ __forceinline__ bool ba_last_block(BaCtl* c, int total)
 {
     __shared__ int s_last;
@@ -295,17 +317,17 @@ __global__ __launch_bounds__(256) void k_ba_point_sum(BaView v, int part_n, int 
         m = wave_max(m);
         if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
         __syncthreads();
-        if (threadIdx.x == 0 && (int)blockIdx.x < part_n) v.part[blockIdx.x] = fmax(fmax(sm[0], sm[1]), fmax(sm[2], sm[3]));
+        if (threadIdx.x == 0 && (int)blockIdx.x < part_n) st_sc1(&v.part[blockIdx.x], fmax(fmax(sm[0], sm[1]), fmax(sm[2], sm[3])));
     }
-    if (!ba_last_block(v.ctl, gridDim.x)) return;
+    if (!ba_last_block_sc1(v.ctl, gridDim.x)) return;
     // last workgroup: max diag H_ll over the block maxima, then the start of the outer iteration (lambda_0)
     if (threadIdx.x < 64) {
         double acc = 0;
-        for (int i = threadIdx.x; i < part_n; i += 64) acc = fmax(acc, v.part[i]);
+        for (int i = threadIdx.x; i < part_n; i += 64) acc = fmax(acc, ld_sc1(&v.part[i]));
         acc = wave_max(acc);
         if (threadIdx.x == 0) {
             v.scal[4] = acc;
-            const double chi = v.scal[6], max_pp = v.scal[7];
+            const double chi = ld_sc1(&v.scal[6]), max_pp = ld_sc1(&v.scal[7]);
             *v.chi_cur = chi; *v.chi_loc = chi;
             if (fused) lm_begin(v, max_pp, acc, chi);
         }
@@ -363,7 +385,7 @@ __device__ __forceinline__ void pose_part_body(BaView& v, int bid, int robust, i
     // partials: chi2 per (keyframe, slice) in the tail of v.partial, H_pp / b_p per (free-pose slot, slice) in its head,
     // so the combine addresses both without an index lookup
     chi = wave_sum(chi);
-    if (lane == 0) chi_out[(size_t)p * SPLIT + sp] = chi;
+    if (lane == 0) st_sc1(&chi_out[(size_t)p * SPLIT + sp], chi);       // mode 1: read by the last workgroup of this launch
     if (!full) return;
     double* out = v.partial + ((size_t)slot * SPLIT + sp) * PV;
 #pragma unroll
@@ -451,7 +473,7 @@ __device__ void pose_combine_body(BaView& v, int mode, int part_n, int fused)
         for (int p = lane; p < v.n_poses; p += 64) {
             double s = 0;
             const double* chi_in = mode == 0 ? v.partial + (size_t)v.n_poses * SPLIT * PV : v.partial_trial;
-            for (int sp = 0; sp < SPLIT; ++sp) s += chi_in[(size_t)p * SPLIT + sp];
+            for (int sp = 0; sp < SPLIT; ++sp) s += mode == 1 ? ld_sc1(&chi_in[(size_t)p * SPLIT + sp]) : chi_in[(size_t)p * SPLIT + sp];
             v.chi_pose[p] = s;
             acc += s;
         }
@@ -510,7 +532,7 @@ __device__ void pose_combine_body(BaView& v, int mode, int part_n, int fused)
     __syncthreads();
     if (tid == 0) {
         if (mode == 0) {
-            v.scal[6] = s_val[0]; v.scal[7] = s_val[2];        // chi2 and max diag H_pp for the last workgroup of k_ba_point_sum
+            st_sc1(&v.scal[6], s_val[0]); st_sc1(&v.scal[7], s_val[2]);        // chi2 and max diag H_pp for the last workgroup of k_ba_point_sum
         } else {
             const double fail = v.scal[5], scale_p = v.scal[3];
             v.scal[1] = s_val[0]; v.scal[2] = s_val[1];
@@ -546,7 +568,7 @@ __global__ __launch_bounds__(256) void k_ba_trial(BaView v, int robust, int part
         return;
     }
     pose_part_body(v, blockIdx.x, robust, 1, idx);
-    if (ba_last_block(v.ctl, trial_blocks)) pose_combine_body(v, 1, part_n, fused ? (spec ? 2 : 1) : 0);
+    if (ba_last_block_sc1(v.ctl, trial_blocks)) pose_combine_body(v, 1, part_n, fused ? (spec ? 2 : 1) : 0);
 }
 
 // partitioned solve: lambda control on the all-reduced quantities
