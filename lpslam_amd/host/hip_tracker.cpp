@@ -69,7 +69,7 @@ HipVslamTrackerBase::HipVslamTrackerBase()
     o.optional("mapFilename", "map.db"); o.optional("maxLaserAge", 1.0);
     // runtime ORB parameters the reference hard-codes in its generated YAML (:193-198), plus device selection
     o.optional("numLevels", 3); o.optional("scaleFactor", 1.2); o.optional("iniFastThr", 20); o.optional("minFastThr", 7);
-    o.optional("device", 0); o.optional("keyframeInterval", 6); o.optional("localWindow", 10);
+    o.optional("device", 0); o.optional("keyframeInterval", 6); o.optional("localWindow", 10); o.optional("asyncMapping", true);
 }
 
 HipVslamTrackerBase::~HipVslamTrackerBase() { stop(); }
@@ -88,6 +88,7 @@ void HipVslamTrackerBase::OnConfigurationUpdate()
     m_numLevels = o.getInteger("numLevels"); m_scaleFactor = o.getDouble("scaleFactor");
     m_iniFastThr = o.getInteger("iniFastThr"); m_minFastThr = o.getInteger("minFastThr"); m_device = o.getInteger("device");
     m_keyframeInterval = std::max(1, o.getInteger("keyframeInterval")); m_localWindow = std::max(2, o.getInteger("localWindow"));
+    m_asyncMapping = o.getBool("asyncMapping");
 }
 
 bool HipVslamTrackerBase::startContext(bool stereo)
@@ -147,6 +148,7 @@ bool HipVslamTrackerBase::startContext(bool stereo)
 bool HipVslamTrackerBase::stop()
 {
     std::scoped_lock lock(m_slamLock);
+    stopMappingThread();                               // the mapping thread uses the context
     if (m_ctx) { lpslam_hip_destroy(m_ctx); m_ctx = nullptr; }
     m_started = false;
     return true;
@@ -186,6 +188,7 @@ bool HipVslamTrackerBase::initializeMap(FrameData& f)
     int n = 0;
     for (size_t i = 0; i < f.kpts.size(); ++i) if (f.depth[i] > 0) ++n;
     if (n < 40) return false;
+    { std::unique_lock<std::mutex> lk(m_mapMutex); m_mapCv.wait(lk, [this] { return !m_mapBusy; }); m_mapOut.reset(); }   // a solve of the map that is being dropped
     m_landmarks.clear(); m_keyframes.clear(); m_nextLandmarkId = 0;
     f.pose = Pose();
     insertKeyframe(f);
@@ -369,57 +372,120 @@ bool HipVslamTrackerBase::trackAgainstPrevious(FrameData& cur, int& n_inliers)
     return poseFromMatches(cur, cur_idx, lm_ids, init, n_inliers);
 }
 
-void HipVslamTrackerBase::localBundleAdjust()
+std::unique_ptr<HipVslamTrackerBase::MappingJob> HipVslamTrackerBase::prepareMapping()
 {
-    if (!m_enableMapping || m_keyframes.size() < 2) return;
+    if (!m_enableMapping || m_keyframes.size() < 2) return nullptr;
+    auto job = std::make_unique<MappingJob>();
     // landmarks observed by at least two keyframes of the window
     std::unordered_map<int, int> seen, index;
     for (auto& kf : m_keyframes) for (auto& o : kf.obs) seen[o.landmark]++;
-    std::vector<double> pts; std::vector<int> ids;
     for (auto& kv : seen) {
         if (kv.second < 2) continue;
         auto it = m_landmarks.find(kv.first);
         if (it == m_landmarks.end()) continue;
-        index[kv.first] = (int)ids.size(); ids.push_back(kv.first);
-        pts.insert(pts.end(), it->second.p, it->second.p + 3);
+        index[kv.first] = (int)job->ids.size(); job->ids.push_back(kv.first);
+        job->pts.insert(job->pts.end(), it->second.p, it->second.p + 3);
     }
-    if (ids.size() < 20) return;
-    std::vector<double> poses; std::vector<uint8_t> fixed;
-    std::vector<lpslam_hip_ba_obs> obs;
-    std::vector<std::pair<int, int>> origin;          // (keyframe, obs index) of every BA observation
+    if (job->ids.size() < 20) return nullptr;
+    job->n_keyframes = (int)m_keyframes.size();
     for (size_t f = 0; f < m_keyframes.size(); ++f) {
         const Pose& p = m_keyframes[f].pose;
-        poses.insert(poses.end(), {p.q[0], p.q[1], p.q[2], p.q[3], p.t[0], p.t[1], p.t[2]});
-        fixed.push_back(f == 0 ? 1 : 0);              // the oldest keyframe anchors the gauge
+        job->poses.insert(job->poses.end(), {p.q[0], p.q[1], p.q[2], p.q[3], p.t[0], p.t[1], p.t[2]});
+        job->fixed.push_back(f == 0 ? 1 : 0);         // the oldest keyframe anchors the gauge
         for (size_t k = 0; k < m_keyframes[f].obs.size(); ++k) {
             const KeyframeObs& o = m_keyframes[f].obs[k];
             auto it = index.find(o.landmark);
             if (it == index.end()) continue;
-            obs.push_back({(int32_t)f, it->second, o.u, o.v, o.ur, o.inv_sigma2});
-            origin.emplace_back((int)f, (int)k);
+            job->obs.push_back({(int32_t)f, it->second, o.u, o.v, o.ur, o.inv_sigma2});
+            job->origin.emplace_back((int)f, (int)k);
         }
     }
+    job->outlier.assign(job->obs.size(), 0);
+    return job;
+}
+
+// runs on the mapping thread: touches the job and the GPU only
+void HipVslamTrackerBase::solveMapping(MappingJob& job) const
+{
     lpslam_hip_ba_camera cam{m_cam.f_x, m_cam.f_y, m_cam.c_x, m_cam.c_y, m_cam.focal_x_baseline, std::sqrt(5.991), std::sqrt(7.815)};
     lpslam_hip_ba* ba = nullptr;
-    if (lpslam_hip_ba_create(m_ctx, poses.data(), fixed.data(), (int32_t)m_keyframes.size(), pts.data(), (int32_t)ids.size(), obs.data(),
-                             (int32_t)obs.size(), &cam, &ba) != LPSLAM_HIP_OK) return;
-    std::vector<uint8_t> outlier(obs.size());
-    if (lpslam_hip_ba_local(ba, 5, 10, outlier.data()) == LPSLAM_HIP_OK && lpslam_hip_ba_get(ba, poses.data(), pts.data()) == LPSLAM_HIP_OK) {
-        for (size_t f = 0; f < m_keyframes.size(); ++f) {
-            for (int k = 0; k < 4; ++k) m_keyframes[f].pose.q[k] = poses[7 * f + k];
-            for (int k = 0; k < 3; ++k) m_keyframes[f].pose.t[k] = poses[7 * f + 4 + k];
-        }
-        for (size_t j = 0; j < ids.size(); ++j) { Landmark& lm = m_landmarks[ids[j]]; lm.p[0] = pts[3 * j]; lm.p[1] = pts[3 * j + 1]; lm.p[2] = pts[3 * j + 2]; }
-        // erase outlier observations (back to front so indices stay valid)
-        for (size_t k = obs.size(); k-- > 0;) {
-            if (!outlier[k]) continue;
-            auto& v = m_keyframes[origin[k].first].obs;
-            auto it = m_landmarks.find(v[origin[k].second].landmark);
-            if (it != m_landmarks.end() && --it->second.n_obs <= 0) m_landmarks.erase(it);
-            v.erase(v.begin() + origin[k].second);
-        }
-    }
+    if (lpslam_hip_ba_create(m_ctx, job.poses.data(), job.fixed.data(), job.n_keyframes, job.pts.data(), (int32_t)job.ids.size(), job.obs.data(),
+                             (int32_t)job.obs.size(), &cam, &ba) != LPSLAM_HIP_OK) return;
+    job.solved = lpslam_hip_ba_local(ba, 5, 10, job.outlier.data()) == LPSLAM_HIP_OK &&
+                 lpslam_hip_ba_get(ba, job.poses.data(), job.pts.data()) == LPSLAM_HIP_OK;
     lpslam_hip_ba_destroy(ba);
+}
+
+void HipVslamTrackerBase::applyMapping(const MappingJob& job)
+{
+    if (!job.solved || job.n_keyframes != (int)m_keyframes.size()) return;
+    for (size_t f = 0; f < m_keyframes.size(); ++f) {
+        for (int k = 0; k < 4; ++k) m_keyframes[f].pose.q[k] = job.poses[7 * f + k];
+        for (int k = 0; k < 3; ++k) m_keyframes[f].pose.t[k] = job.poses[7 * f + 4 + k];
+    }
+    for (size_t j = 0; j < job.ids.size(); ++j) {
+        auto it = m_landmarks.find(job.ids[j]);
+        if (it != m_landmarks.end()) { it->second.p[0] = job.pts[3 * j]; it->second.p[1] = job.pts[3 * j + 1]; it->second.p[2] = job.pts[3 * j + 2]; }
+    }
+    // erase outlier observations (back to front so indices stay valid)
+    for (size_t k = job.obs.size(); k-- > 0;) {
+        if (!job.outlier[k]) continue;
+        auto& v = m_keyframes[job.origin[k].first].obs;
+        auto it = m_landmarks.find(v[job.origin[k].second].landmark);
+        if (it != m_landmarks.end() && --it->second.n_obs <= 0) m_landmarks.erase(it);
+        v.erase(v.begin() + job.origin[k].second);
+    }
+}
+
+void HipVslamTrackerBase::mappingLoop()
+{
+    std::unique_lock<std::mutex> lk(m_mapMutex);
+    for (;;) {
+        m_mapCv.wait(lk, [this] { return m_mapQuit || m_mapIn; });
+        if (m_mapQuit) return;
+        std::unique_ptr<MappingJob> job = std::move(m_mapIn);
+        lk.unlock();
+        solveMapping(*job);
+        lk.lock();
+        m_mapOut = std::move(job);
+        m_mapBusy = false;
+        m_mapCv.notify_all();
+    }
+}
+
+void HipVslamTrackerBase::stopMappingThread()
+{
+    if (!m_mapThread.joinable()) return;
+    {
+        std::unique_lock<std::mutex> lk(m_mapMutex);
+        m_mapCv.wait(lk, [this] { return !m_mapBusy; });
+        m_mapQuit = true;
+        m_mapCv.notify_all();
+    }
+    m_mapThread.join();
+    m_mapQuit = false; m_mapOut.reset();
+}
+
+void HipVslamTrackerBase::startMapping()
+{
+    auto job = prepareMapping();
+    if (!job) return;
+    if (!m_asyncMapping) { solveMapping(*job); applyMapping(*job); return; }
+    if (!m_mapThread.joinable()) m_mapThread = std::thread([this] { mappingLoop(); });
+    std::lock_guard<std::mutex> lk(m_mapMutex);
+    m_mapIn = std::move(job); m_mapBusy = true;
+    m_mapCv.notify_all();
+}
+
+void HipVslamTrackerBase::finishMapping()
+{
+    std::unique_ptr<MappingJob> job;
+    {
+        std::unique_lock<std::mutex> lk(m_mapMutex);
+        m_mapCv.wait(lk, [this] { return !m_mapBusy; });
+        job = std::move(m_mapOut);
+    }
+    if (job) applyMapping(*job);
 }
 
 TrackerBase::ProcessImageResult HipVslamTrackerBase::trackFrame(CameraQueueEntry& cam, bool stereo)
@@ -482,12 +548,14 @@ TrackerBase::ProcessImageResult HipVslamTrackerBase::trackFrame(CameraQueueEntry
             m_haveVelocity = true;
             ++m_framesSinceKeyframe;
             if (m_framesSinceKeyframe >= m_keyframeInterval || inliers < 50) {
+                finishMapping();                    // the previous keyframe's solve enters the map before the window moves
                 insertKeyframe(cur);
-                localBundleAdjust();
-                cur.pose = m_keyframes.back().pose;
+                startMapping();
+                if (!m_asyncMapping) cur.pose = m_keyframes.back().pose;
             }
             m_prev = std::move(cur);
         } else {
+            finishMapping();
             m_state = TrackerState::Lost;
             logMessage(LpSlamLogLevel_Info, "VSLAM tracking lost; re-initialising from the next stereo frame");
             m_prev = std::move(cur);

@@ -11,6 +11,9 @@
 #include "../../include/lpslam_hip.h"
 
 #include <array>
+#include <condition_variable>
+#include <memory>
+#include <thread>
 #include <unordered_map>
 
 namespace LpSlam {
@@ -57,12 +60,29 @@ protected:
     bool trackWithMotionModel(FrameData& cur, int& n_inliers);
     bool trackAgainstPrevious(FrameData& cur, int& n_inliers);
     void insertKeyframe(FrameData& f);
-    void localBundleAdjust();
+    // Local bundle adjustment of the keyframe window ([UPSTREAM] mapping_module -> optimize::local_bundle_adjuster).  As in the
+    // reference it runs beside tracking: the window is copied when a keyframe is inserted, a mapping thread solves it on the GPU
+    // (the BA object has its own stream) while the tracking thread takes the next frames, and the result enters the map right
+    // before the next keyframe is inserted -- a fixed point of the frame sequence, so a run is reproducible.
+    struct MappingJob {
+        std::vector<double> poses, pts;
+        std::vector<uint8_t> fixed, outlier;
+        std::vector<lpslam_hip_ba_obs> obs;
+        std::vector<std::pair<int, int>> origin;      // (keyframe, obs index) of every BA observation
+        std::vector<int> ids;                         // landmark id of every BA point
+        int n_keyframes = 0;
+        bool solved = false;
+    };
+    std::unique_ptr<MappingJob> prepareMapping();
+    void solveMapping(MappingJob& job) const;
+    void applyMapping(const MappingJob& job);
+    void startMapping();                              // prepare + solve on the mapping thread (or inline when asyncMapping is off)
+    void finishMapping();                             // wait for the mapping thread and apply its result
 
     // configuration (names as in the reference tracker)
     bool m_useLiveView = false, m_useMapDb = true, m_forwardNavState = true, m_forwardImu = true, m_emitMap = false;
     bool m_enableMapping = true, m_waitForNavigation = false, m_forwardHighResNav = false, m_loopClosure = true;
-    bool m_useOpenCL = false, m_useCUDA = false, m_relocWithNavigation = true;
+    bool m_useOpenCL = false, m_useCUDA = false, m_relocWithNavigation = true, m_asyncMapping = true;
     std::string m_configFromFile, m_cameraSetup = "monocular", m_vocabFile = "orb_vocab.dbow2", m_mapFilename = "map.db";
     int m_slamKeypoints = 1200, m_viewerFps = 10;
     double m_baselineDistThresh = 0.1, m_maxLaserAge = 1.0;
@@ -89,6 +109,14 @@ protected:
     int m_nextLandmarkId = 0;
     std::deque<Keyframe> m_keyframes;
     long m_keyframeCount = 0;
+    // the mapping thread (one per tracker, started with the context): a one-slot mailbox each way
+    std::thread m_mapThread;
+    std::mutex m_mapMutex;
+    std::condition_variable m_mapCv;
+    std::unique_ptr<MappingJob> m_mapIn, m_mapOut;
+    bool m_mapBusy = false, m_mapQuit = false;
+    void mappingLoop();
+    void stopMappingThread();
 };
 
 class HipStereoTracker : public HipVslamTrackerBase {

@@ -9,7 +9,9 @@ from lpslam_amd import synth
 pytestmark = pytest.mark.gpu
 
 
-def test_stereo_sequence_through_the_manager(hiplib):
+@pytest.mark.parametrize("async_mapping", [True, False])
+def test_stereo_sequence_through_the_manager(hiplib, async_mapping):
+    """Local BA beside tracking (the default, as the reference's mapping thread) and inline: both track the sequence."""
     from lpslam_amd import _build, manager
     _build.host_library()
     w, h, n_frames = 640, 480, 24
@@ -21,7 +23,8 @@ def test_stereo_sequence_through_the_manager(hiplib):
         c.camera_number = num; c.f_x = k["fx"]; c.f_y = k["fy"]; c.c_x = k["cx"]; c.c_y = k["cy"]
         c.resolution_x = w; c.resolution_y = h; c.focal_x_baseline = k["fxb"]
         m.set_camera(c)
-    assert m.add_tracker("VSLAMStereo", '{"cameraSetup": "stereo", "slamKeypoints": 1000, "numLevels": 4, "keyframeInterval": 4}')
+    assert m.add_tracker("VSLAMStereo", '{"cameraSetup": "stereo", "slamKeypoints": 1000, "numLevels": 4, "keyframeInterval": 4, "asyncMapping": %s}'
+                         % ("true" if async_mapping else "false"))
     m.collect_results(); m.provide_odometry()
     import ctypes
     counter = ctypes.CDLL(_build.host_library()).lpslam_debug_motion_tracked
