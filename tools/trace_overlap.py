@@ -39,3 +39,13 @@ for (n, ov) in sorted(acc):
 for ov in (False, True):
     c, d, g = tot[ov]
     if c: print("ALL %-9s n %6d  dur %7.2f us  gap %6.2f us" % ("beside-FE" if ov else "alone", c, d / c / 1e3, g / c / 1e3))
+
+# which front-end kernel a slowed k_chol_pair ran beside
+by = defaultdict(lambda: [0, 0.0])
+for s_, e_, n in ba:
+    if n != "k_chol_pair": continue
+    names = sorted({fn for fs_, fe_, fn in fe if fs_ < e_ and fe_ > s_})
+    key = "+".join(names) if names else "(alone)"
+    by[key][0] += 1; by[key][1] += e_ - s_
+for k in sorted(by, key=lambda k: -by[k][0]):
+    print("k_chol_pair beside %-60s n %5d  dur %7.2f us" % (k, by[k][0], by[k][1] / by[k][0] / 1e3))
