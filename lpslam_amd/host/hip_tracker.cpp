@@ -5,11 +5,14 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <fstream>
 
 #include <atomic>
 static std::atomic<long> g_motion_tracked{0};      // process-wide count of frames tracked by the motion model (introspection for the tests)
 extern "C" __attribute__((visibility("default"))) long lpslam_debug_motion_tracked(void) { return g_motion_tracked.load(); }
+static std::atomic<long> g_local_map_joined{0};   // landmarks local-map tracking brought back into frames
+extern "C" __attribute__((visibility("default"))) long lpslam_debug_local_map_joined(void) { return g_local_map_joined.load(); }
 
 namespace LpSlam {
 
@@ -225,6 +228,19 @@ void HipVslamTrackerBase::insertKeyframe(FrameData& f)
             lm.p[0] = R.m[0] * d[0] + R.m[3] * d[1] + R.m[6] * d[2];
             lm.p[1] = R.m[1] * d[0] + R.m[4] * d[1] + R.m[7] * d[2];
             lm.p[2] = R.m[2] * d[0] + R.m[5] * d[1] + R.m[8] * d[2];
+            {
+                // camera centre C = -R^T t; viewing ray and valid distances of this (the reference) observation
+                const double C[3] = {-(R.m[0] * f.pose.t[0] + R.m[3] * f.pose.t[1] + R.m[6] * f.pose.t[2]),
+                                     -(R.m[1] * f.pose.t[0] + R.m[4] * f.pose.t[1] + R.m[7] * f.pose.t[2]),
+                                     -(R.m[2] * f.pose.t[0] + R.m[5] * f.pose.t[1] + R.m[8] * f.pose.t[2])};
+                const double ray[3] = {lm.p[0] - C[0], lm.p[1] - C[1], lm.p[2] - C[2]};
+                const double dist = std::sqrt(ray[0] * ray[0] + ray[1] * ray[1] + ray[2] * ray[2]);
+                for (int a = 0; a < 3; ++a) lm.normal[a] = dist > 0 ? ray[a] / dist : 0.0;
+                const int n_lv = m_numLevels;
+                lm.max_valid = dist * scales[f.kpts[i].octave];
+                lm.min_valid = lm.max_valid / scales[std::max(n_lv - 1, 0)];
+                std::copy(f.desc.begin() + 32 * i, f.desc.begin() + 32 * (i + 1), lm.desc);
+            }
             id = m_nextLandmarkId++;
             m_landmarks[id] = lm;
             f.landmark[i] = id;
@@ -300,8 +316,8 @@ bool HipVslamTrackerBase::trackWithMotionModel(FrameData& cur, int& n_inliers)
     for (int r = 0; r < 3; ++r) init.t[r] = Rv.m[r * 3] * m_prev.pose.t[0] + Rv.m[r * 3 + 1] * m_prev.pose.t[1] + Rv.m[r * 3 + 2] * m_prev.pose.t[2] + m_velocity.t[r];
     const Mat3 R = quatToRot(init.q);
     float scales[LPSLAM_HIP_MAX_LEVELS];
-    int32_t n_levels = 0;
-    lpslam_hip_level_info(m_ctx, &n_levels, nullptr, nullptr, nullptr, scales);
+    const int32_t n_levels = m_numLevels;               // (the first array argument of level_info is the widths, not a count)
+    lpslam_hip_level_info(m_ctx, nullptr, nullptr, nullptr, nullptr, scales);
     std::vector<lpslam_hip_proj_query> q;
     std::vector<uint8_t> qd;
     std::vector<float> q_angle;
@@ -343,6 +359,73 @@ bool HipVslamTrackerBase::trackWithMotionModel(FrameData& cur, int& n_inliers)
     std::vector<int> cur_idx, lm_ids;
     for (size_t k = 0; k < q.size(); ++k) if (idx[k] >= 0) { cur_idx.push_back(idx[k]); lm_ids.push_back(q_lm[k]); }
     return poseFromMatches(cur, cur_idx, lm_ids, init, n_inliers);
+}
+
+// [UPSTREAM] tracking_module::optimize_current_frame_with_local_map: the landmarks of the local keyframes that the frame does not
+// hold yet are projected with the pose just found and searched in a window of margin x scale factor of the predicted level
+// (match::projection::match_frame_and_landmarks: margin 5 px for stereo, levels [predicted - 1, predicted], Lowe ratio 0.8 between
+// candidates of one level, right-image check); then the motion-only optimiser runs again over all associations.
+bool HipVslamTrackerBase::trackLocalMap(FrameData& cur, int& n_inliers)
+{
+    float scales[LPSLAM_HIP_MAX_LEVELS];
+    const int32_t n_levels = m_numLevels;               // (the first array argument of level_info is the widths, not a count)
+    lpslam_hip_level_info(m_ctx, nullptr, nullptr, nullptr, nullptr, scales);
+    const double log_sf = std::log((double)m_scaleFactor);
+    const Mat3 R = quatToRot(cur.pose.q);
+    const double C[3] = {-(R.m[0] * cur.pose.t[0] + R.m[3] * cur.pose.t[1] + R.m[6] * cur.pose.t[2]),
+                         -(R.m[1] * cur.pose.t[0] + R.m[4] * cur.pose.t[1] + R.m[7] * cur.pose.t[2]),
+                         -(R.m[2] * cur.pose.t[0] + R.m[5] * cur.pose.t[1] + R.m[8] * cur.pose.t[2])};
+    std::vector<uint8_t> taken(cur.kpts.size(), 0);
+    std::unordered_map<int, char> held;
+    size_t held_on_entry = 0; int n_new = 0;
+    for (size_t i = 0; i < cur.kpts.size(); ++i) if (cur.landmark[i] >= 0) { taken[i] = 1; held[cur.landmark[i]] = 1; ++held_on_entry; }
+    std::vector<lpslam_hip_proj_query> q;
+    std::vector<uint8_t> qd;
+    std::vector<int> q_lm;
+    for (auto& kf : m_keyframes) {                       // local landmarks in keyframe / observation order (deterministic)
+        for (auto& o : kf.obs) {
+            if (held.count(o.landmark)) continue;
+            held[o.landmark] = 1;
+            auto it = m_landmarks.find(o.landmark);
+            if (it == m_landmarks.end()) continue;
+            const Landmark& lm = it->second;
+            const double* X = lm.p;
+            const double pc[3] = {R.m[0] * X[0] + R.m[1] * X[1] + R.m[2] * X[2] + cur.pose.t[0], R.m[3] * X[0] + R.m[4] * X[1] + R.m[5] * X[2] + cur.pose.t[1],
+                                  R.m[6] * X[0] + R.m[7] * X[1] + R.m[8] * X[2] + cur.pose.t[2]};
+            if (!(pc[2] > 0)) continue;
+            const double u = m_cam.f_x * pc[0] / pc[2] + m_cam.c_x, v = m_cam.f_y * pc[1] / pc[2] + m_cam.c_y;
+            if (u < 0 || v < 0 || u >= m_cam.resolution_x || v >= m_cam.resolution_y) continue;
+            const double ray[3] = {X[0] - C[0], X[1] - C[1], X[2] - C[2]};
+            const double dist = std::sqrt(ray[0] * ray[0] + ray[1] * ray[1] + ray[2] * ray[2]);
+            if (!(dist > 0) || dist < 0.8 * lm.min_valid || dist > 1.2 * lm.max_valid) continue;           // can_observe: scale range
+            if ((ray[0] * lm.normal[0] + ray[1] * lm.normal[1] + ray[2] * lm.normal[2]) / dist < 0.5) continue;    // viewing angle < 60 deg
+            const int lvl = std::min(std::max((int)std::ceil(std::log(lm.max_valid / dist) / log_sf), 0), n_levels - 1);
+            lpslam_hip_proj_query e{};
+            e.x = (float)u; e.y = (float)v; e.x_right = (float)(u - m_cam.focal_x_baseline / pc[2]);
+            e.radius = 5.0f * scales[lvl];
+            e.min_level = std::max(0, lvl - 1); e.max_level = lvl;
+            q.push_back(e);
+            qd.insert(qd.end(), lm.desc, lm.desc + 32);
+            q_lm.push_back(o.landmark);
+        }
+    }
+    if (!q.empty()) {
+        std::vector<int32_t> idx(q.size()), dist(q.size());
+        int32_t n_m = 0;
+        if (lpslam_hip_match_projection(m_ctx, cur.slot, q.data(), qd.data(), (int32_t)q.size(), 100 /* HAMMING_DIST_THR_HIGH */, 0.8f, taken.data(), 1,
+                                        idx.data(), dist.data(), &n_m) != LPSLAM_HIP_OK) return false;
+        for (size_t k = 0; k < q.size(); ++k) if (idx[k] >= 0) { cur.landmark[idx[k]] = q_lm[k]; ++n_new; }
+    }
+    g_local_map_joined += n_new;
+    if (n_new == 0) { n_inliers = (int)held_on_entry; return true; }      // nothing joined: the pose found from the same associations stands
+    std::vector<int> cur_idx, lm_ids;
+    for (size_t i = 0; i < cur.kpts.size(); ++i) if (cur.landmark[i] >= 0) { cur_idx.push_back((int)i); lm_ids.push_back(cur.landmark[i]); }
+    const Pose init = cur.pose;
+    const std::vector<int> before = cur.landmark;
+    for (size_t i = 0; i < cur.kpts.size(); ++i) if (!taken[i]) const_cast<std::vector<int>&>(before)[i] = -1;    // what the frame held on entry
+    if (poseFromMatches(cur, cur_idx, lm_ids, init, n_inliers)) return true;
+    cur.pose = init; cur.landmark = before;
+    return false;
 }
 
 bool HipVslamTrackerBase::trackAgainstPrevious(FrameData& cur, int& n_inliers)
@@ -539,6 +622,8 @@ TrackerBase::ProcessImageResult HipVslamTrackerBase::trackFrame(CameraQueueEntry
     } else {
         int inliers = 0;
         if (trackAgainstPrevious(cur, inliers)) {
+            int with_local_map = 0;
+            if (trackLocalMap(cur, with_local_map)) inliers = with_local_map;      // else: the motion-model result stands
             // velocity = T_cur * T_prev^-1
             const Mat3 Rc = quatToRot(cur.pose.q), Rp = quatToRot(m_prev.pose.q);
             Mat3 Rv;

@@ -50,7 +50,14 @@ protected:
     };
     struct KeyframeObs { int landmark; double u, v, ur, inv_sigma2; };
     struct Keyframe { Pose pose; std::vector<KeyframeObs> obs; };
-    struct Landmark { double p[3]; int n_obs = 0; };
+    struct Landmark {
+        double p[3]; int n_obs = 0;
+        // what local-map tracking needs ([UPSTREAM] data::landmark): the descriptor, the viewing direction and the valid
+        // distance range of the observation that created it (scale prediction: level = ceil(log(max_valid / d) / log s))
+        uint8_t desc[32] = {0};
+        double normal[3] = {0, 0, 1};
+        double max_valid = 0, min_valid = 0;
+    };
 
     bool startContext(bool stereo);
     ProcessImageResult trackFrame(CameraQueueEntry& cam, bool stereo);
@@ -59,6 +66,7 @@ protected:
     bool poseFromMatches(FrameData& cur, const std::vector<int>& cur_idx, const std::vector<int>& lm_ids, const Pose& init, int& n_inliers);
     bool trackWithMotionModel(FrameData& cur, int& n_inliers);
     bool trackAgainstPrevious(FrameData& cur, int& n_inliers);
+    bool trackLocalMap(FrameData& cur, int& n_inliers);
     void insertKeyframe(FrameData& f);
     // Local bundle adjustment of the keyframe window ([UPSTREAM] mapping_module -> optimize::local_bundle_adjuster).  As in the
     // reference it runs beside tracking: the window is copied when a keyframe is inserted, a mapping thread solves it on the GPU

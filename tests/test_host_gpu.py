@@ -89,3 +89,38 @@ def test_replay_file_through_the_manager(hiplib, tmp_path):
     valid = [r for r in m.results if r["valid"]]
     assert len(valid) >= n_frames - 2 and st.key_frames >= 2
     assert [r["timestamp"] for r in m.results] == [(i + 1) * 40_000_000 for i in range(n_frames)]
+
+
+def test_local_map_tracking_brings_landmarks_back(hiplib):
+    """One frame with its left half blanked: the frame after it cannot get those landmarks from the motion model (the previous
+    frame does not hold them), local-map tracking projects them from the keyframes and matches them again
+    ([UPSTREAM] tracking_module::optimize_current_frame_with_local_map)."""
+    import ctypes
+    from lpslam_amd import _build, manager
+    lib = ctypes.CDLL(_build.host_library())
+    lib.lpslam_debug_local_map_joined.restype = ctypes.c_long
+    w, h = 640, 480
+    k = synth.intrinsics(w, h)
+    seq = synth.StereoSequence(w, h, 4, n_points=6000)
+    m = manager.Manager()
+    for num in (0, 1):
+        c = manager.default_camera()
+        c.camera_number = num; c.f_x = k["fx"]; c.f_y = k["fy"]; c.c_x = k["cx"]; c.c_y = k["cy"]
+        c.resolution_x = w; c.resolution_y = h; c.focal_x_baseline = k["fxb"]
+        m.set_camera(c)
+    assert m.add_tracker("VSLAMStereo", '{"cameraSetup": "stereo", "slamKeypoints": 1000, "numLevels": 4, "keyframeInterval": 8}')
+    m.collect_results(); m.provide_odometry()
+    joined0 = lib.lpslam_debug_local_map_joined()
+    m.start()
+    frames = [list(seq.frame(i)) for i in range(6)]
+    for eye in (0, 1):
+        frames[3][eye] = frames[3][eye].copy(); frames[3][eye][:, : w // 2] = 0
+    for i, (l, r) in enumerate(frames):
+        assert m.add_stereo((i + 1) * 40_000_000, l, r)
+    t0 = time.time()
+    while len(m.results) < len(frames) and time.time() - t0 < 60:
+        time.sleep(0.01)
+    m.stop()
+    assert len(m.results) == len(frames) and all(r["valid"] for r in m.results)
+    assert lib.lpslam_debug_local_map_joined() - joined0 >= 20
+    assert abs(m.results[-1]["p"][2] - 0.05 * 5) < 0.05
