@@ -1708,6 +1708,16 @@ void lpslam_hip_ba_destroy(lpslam_hip_ba* b)
 }
 
 // caller-order activity flags -> storage order
+// state given at creation back into buffer 0, every observation active
+__global__ __launch_bounds__(256) void k_ba_reset(double* poses, const double* poses0, int n_pose_doubles, double* points, const double* points0,
+                                                  int n_point_doubles, uint8_t* active, int n_obs)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n_pose_doubles) poses[i] = poses0[i];
+    if (i < n_point_doubles) points[i] = points0[i];
+    if (i < n_obs) active[i] = 1;
+}
+
 __global__ __launch_bounds__(256) void k_ba_gather_active(const uint8_t* in, const int* o_orig, uint8_t* out, int n)
 {
     const int k = blockIdx.x * 256 + threadIdx.x;
@@ -1900,9 +1910,11 @@ int lpslam_hip_ba_reset(lpslam_hip_ba* b)
     if (!b) { set_error("null problem"); return LPSLAM_HIP_ERR_INVALID; }
     b->h_ctl = BaCtl{};
     b->h_ctl.ni = 2; b->h_ctl.need_lin = 1; b->h_ctl.first = 1;
-    LP_HIP(hipMemcpyAsync(b->d_poses[0], b->d_poses0, 7 * (size_t)b->n_poses * sizeof(double), hipMemcpyDeviceToDevice, b->stream));
-    if (b->n_points) LP_HIP(hipMemcpyAsync(b->d_points[0], b->d_points0, 3 * (size_t)b->n_points * sizeof(double), hipMemcpyDeviceToDevice, b->stream));
-    if (b->n_obs) LP_HIP(hipMemsetAsync(b->d_o_active, 1, b->n_obs, b->stream));
+    // one launch instead of two device copies and a fill (three runtime operations of ~4 us each on the solve's stream)
+    const long n_max = std::max<long>(std::max<long>(7L * b->n_poses, 3L * b->n_points), b->n_obs);
+    hipLaunchKernelGGL(k_ba_reset, dim3((unsigned)((n_max + 255) / 256)), dim3(256), 0, b->stream, b->d_poses[0], b->d_poses0, 7 * b->n_poses,
+                       b->d_points[0], b->d_points0, 3 * b->n_points, b->d_o_active, b->n_obs);
+    LP_HIP(hipGetLastError());
     return LPSLAM_HIP_OK;
 }
 
