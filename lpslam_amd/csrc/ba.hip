@@ -21,6 +21,7 @@
 #include <cmath>
 #include <cfloat>
 #include <algorithm>
+#include <atomic>
 #include <map>
 
 #pragma clang fp contract(off)
@@ -1076,8 +1077,14 @@ __global__ __launch_bounds__(256) void k_chol_pair(BaView v, int nb, int m, int 
 // the whole factorisation + L^-T rows: ceil(nb / 2) launches
 void enqueue_cholesky(hipStream_t s, const BaView& v, int nb)
 {
-    static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_chol_pair, hipFuncAttributeMaxDynamicSharedMemorySize, CP_LDS_BYTES); attr_set = true; }
+    // the attribute belongs to the (function, device) pair: once per device this process uses
+    static std::atomic<bool> attr_set[64];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && !attr_set[dev].load()) {
+        (void)hipFuncSetAttribute((const void*)k_chol_pair, hipFuncAttributeMaxDynamicSharedMemorySize, CP_LDS_BYTES);
+        attr_set[dev].store(true);
+    }
     for (int m = 0; 2 * m < nb; ++m) {
         const int j = 2 * m, ncol = (j + 1 < nb) ? 2 : 1;
         const int T = nb - j - ncol;
