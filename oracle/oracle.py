@@ -140,7 +140,8 @@ def extract(img, p, want_pyramid=False):
     """Returns (keypoints[KP_DTYPE], descriptors[n,32], cand_count[levels], pyramid levels or None)."""
     img = np.ascontiguousarray(img, np.uint8)
     h, w = img.shape
-    cap = p.max_num_keypts + 4 * p.num_levels + 64
+    roots = max(1, int(round(w / h)), int(round(h / w)))          # a level returns up to max(quota + 3, 4 * roots) corners
+    cap = p.max_num_keypts + (4 * roots + 8) * p.num_levels + 64
     kp = np.zeros(cap, KP_DTYPE); desc = np.zeros((cap, 32), np.uint8)
     cc = np.zeros(p.num_levels, np.int32)
     lw, lh = pyramid_sizes(w, h, p)

@@ -16,6 +16,8 @@ bad = 0
 t0 = time.time()
 for case in range(n_cases):
     w = int(rng.integers(96, 900)); h = int(rng.integers(96, 600))
+    if case % 7 == 3: w, h = int(rng.integers(700, 1600)), int(rng.integers(96, 170))        # very wide: many quad-tree roots
+    if case % 11 == 5: w, h = int(rng.integers(96, 170)), int(rng.integers(500, 1000))       # very tall
     levels = int(rng.integers(1, 9))
     scale = float(rng.choice([1.1, 1.2, 1.2, 1.3, 1.5, 2.0]))
     while levels > 1 and min(w, h) / scale ** (levels - 1) < 64: levels -= 1
