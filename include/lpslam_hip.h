@@ -116,6 +116,12 @@ int lpslam_hip_stage_describe(lpslam_hip_ctx* ctx, int n_images);
 int lpslam_hip_keypoint_count(lpslam_hip_ctx* ctx, int image, int32_t* count);
 int lpslam_hip_get_keypoints(lpslam_hip_ctx* ctx, int image, lpslam_hip_keypoint* kpts, uint8_t* desc32,
                              int32_t capacity, int32_t* count);
+/* Everything the tracker reads back per frame in one round trip: keypoints, descriptors and (after lpslam_hip_match_stereo on
+ * this slot as the left image) the stereo columns of lpslam_hip_get_stereo.  Any output pointer may be NULL.  What
+ * openvslam::data::frame holds after extraction: keypoints, descriptors, stereo_x_right, depths ([UPSTREAM] data/frame.h;
+ * reached through feed_stereo_frame, src/Trackers/OpenVSLAMStereoTracker.cpp:293-295).  Not re-entrant per context. */
+int lpslam_hip_get_frame(lpslam_hip_ctx* ctx, int image, lpslam_hip_keypoint* kpts, uint8_t* desc32, float* stereo_x_right,
+                         float* depths, int32_t capacity, int32_t* count);
 int lpslam_hip_get_pyramid_level(lpslam_hip_ctx* ctx, int image, int level, uint8_t* out, int32_t out_stride);
 int lpslam_hip_get_candidates(lpslam_hip_ctx* ctx, int image, int level, lpslam_hip_corner* out,
                               int32_t capacity, int32_t* count);

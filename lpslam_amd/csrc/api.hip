@@ -1,6 +1,7 @@
 // api.hip -- C ABI of the lpslam HIP library: context life cycle, geometry tables, frame upload, stage launches and
 // readbacks.  Declarations and the reference interfaces they replace: include/lpslam_hip.h.
 #include "internal.h"
+#include <cstring>
 #include <vector>
 #include <cmath>
 #include <climits>
@@ -292,6 +293,7 @@ void lpslam_hip_destroy(lpslam_hip_ctx* c)
                     c->d_map_xy[0], c->d_map_xy[1], c->d_map_frac[0], c->d_map_frac[1], c->d_raw};
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (int i = 0; i < LPSLAM_HIP_MAX_TIMERS; ++i) { if (c->ev_begin[i]) (void)hipEventDestroy(c->ev_begin[i]); if (c->ev_end[i]) (void)hipEventDestroy(c->ev_end[i]); }
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -472,6 +474,42 @@ int lpslam_hip_get_keypoints(lpslam_hip_ctx* c, int image, lpslam_hip_keypoint* 
     if (kpts && n) LP_HIP(hipMemcpyAsync(kpts, c->d_kpts + o, (size_t)n * sizeof(lpslam_hip_keypoint), hipMemcpyDeviceToHost, c->stream));
     if (desc32 && n) LP_HIP(hipMemcpyAsync(desc32, c->d_desc + o * 32, (size_t)n * 32, hipMemcpyDeviceToHost, c->stream));
     LP_HIP(hipStreamSynchronize(c->stream));
+    return LPSLAM_HIP_OK;
+}
+
+// One frame's results in one round trip: count, keypoints, descriptors and the stereo columns are copied (whole slots, the count
+// is not known yet) into a pinned staging block of the context with a single synchronisation, then the first `count` entries go
+// to the caller's arrays.  The separate getters cost a synchronisation each and stage pageable memory copy by copy.
+int lpslam_hip_get_frame(lpslam_hip_ctx* c, int image, lpslam_hip_keypoint* kpts, uint8_t* desc32, float* stereo_x_right, float* depths,
+                         int32_t capacity, int32_t* count)
+{
+    int rc = check_image(c, image); if (rc) return rc;
+    const size_t S = (size_t)c->slots_per_image;
+    const size_t o_kp = 64, o_desc = o_kp + ((S * sizeof(lpslam_hip_keypoint) + 63) / 64) * 64, o_xr = o_desc + S * 32, o_dep = o_xr + ((S * 4 + 63) / 64) * 64;
+    const size_t need = o_dep + S * 4;
+    if (c->h_stage_bytes < need) {
+        if (c->h_stage) (void)hipHostFree(c->h_stage);
+        c->h_stage = nullptr; c->h_stage_bytes = 0;
+        LP_HIP(hipHostMalloc((void**)&c->h_stage, need, hipHostMallocDefault));
+        c->h_stage_bytes = need;
+    }
+    uint8_t* st = c->h_stage;
+    const size_t o = (size_t)image * S;
+    LP_HIP(hipMemcpyAsync(st, c->d_kp_count + image, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    if (kpts) LP_HIP(hipMemcpyAsync(st + o_kp, c->d_kpts + o, S * sizeof(lpslam_hip_keypoint), hipMemcpyDeviceToHost, c->stream));
+    if (desc32) LP_HIP(hipMemcpyAsync(st + o_desc, c->d_desc + o * 32, S * 32, hipMemcpyDeviceToHost, c->stream));
+    const float* f = c->d_stereo + o * 2;
+    if (stereo_x_right) LP_HIP(hipMemcpyAsync(st + o_xr, f, S * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    if (depths) LP_HIP(hipMemcpyAsync(st + o_dep, f + S, S * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    LP_HIP(hipStreamSynchronize(c->stream));
+    int32_t n = 0;
+    memcpy(&n, st, sizeof(n));
+    if (count) *count = n;
+    if (n > capacity) { set_error("frame buffers too small (%d < %d)", capacity, n); return LPSLAM_HIP_ERR_CAPACITY; }
+    if (kpts && n) memcpy(kpts, st + o_kp, (size_t)n * sizeof(lpslam_hip_keypoint));
+    if (desc32 && n) memcpy(desc32, st + o_desc, (size_t)n * 32);
+    if (stereo_x_right && n) memcpy(stereo_x_right, st + o_xr, (size_t)n * sizeof(float));
+    if (depths && n) memcpy(depths, st + o_dep, (size_t)n * sizeof(float));
     return LPSLAM_HIP_OK;
 }
 

@@ -1234,16 +1234,39 @@ __device__ __forceinline__ int po_residual(const BaCam& cam, const double* R, co
     e[2] = o.ur - (u - cam.fxb * iz);
     return 3;
 }
-__device__ double po_chi2(const BaCam& cam, const double* p7, const double* pts, const lpslam_hip_ba_obs* obs, const uint8_t* active, int n, int robust, PoShared& sh)
+// One observation as the kernel keeps it in LDS: measurement, weight and the landmark it sees (56 bytes); the first `cache_n`
+// observations live there, the rest (only very large n) is read from global memory like before.
+struct PoObs { double u, v, ur, w, X[3]; };
+constexpr int PO_TR = 257;                 // padded row of the transposed reduction buffer [27][256]
+
+struct PoData {
+    const double* pts; const lpslam_hip_ba_obs* obs; const PoObs* cache; const uint8_t* act; int n, cache_n;
+    __device__ __forceinline__ void get(int k, lpslam_hip_ba_obs& o, double* X) const
+    {
+        if (k < cache_n) {
+            const PoObs c = cache[k];
+            o.pose = 0; o.point = 0; o.u = c.u; o.v = c.v; o.ur = c.ur; o.inv_sigma2 = c.w;
+            X[0] = c.X[0]; X[1] = c.X[1]; X[2] = c.X[2];
+        } else {
+            o = obs[k];
+            const double* p = pts + 3 * (size_t)o.point;
+            X[0] = p[0]; X[1] = p[1]; X[2] = p[2];
+        }
+    }
+};
+
+__device__ double po_chi2(const BaCam& cam, const double* p7, const PoData& d, int robust, PoShared& sh)
 {
     double R[9];
     quat_to_rot(p7, R);
     double chi = 0;
-    for (int k = threadIdx.x; k < n; k += 256) {
-        if (!active[k]) continue;
-        double e[3], pc[3];
-        const int D = po_residual(cam, R, p7 + 4, pts + 3 * (size_t)obs[k].point, obs[k], e, pc);
-        double c = obs[k].inv_sigma2 * (e[0] * e[0] + e[1] * e[1] + (D == 3 ? e[2] * e[2] : 0.0));
+    for (int k = threadIdx.x; k < d.n; k += 256) {
+        if (!d.act[k]) continue;
+        double e[3], pc[3], X[3];
+        lpslam_hip_ba_obs o;
+        d.get(k, o, X);
+        const int D = po_residual(cam, R, p7 + 4, X, o, e, pc);
+        double c = o.inv_sigma2 * (e[0] * e[0] + e[1] * e[1] + (D == 3 ? e[2] * e[2] : 0.0));
         const double delta = D == 3 ? cam.hub_stereo : cam.hub_mono;
         if (robust && delta > 0) { double r0, r1; huber(c, delta, &r0, &r1); c = r0; }
         chi += c;
@@ -1251,22 +1274,58 @@ __device__ double po_chi2(const BaCam& cam, const double* p7, const double* pts,
     return po_block_sum(chi, sh);
 }
 
+// the 27 sums of H (upper triangle) and b over the 256 threads: transposed through LDS -- 27 stores per thread, then 216 threads
+// add 32 partials each and three shuffles finish the 8 parts of a value (one barrier pair instead of 27 six-step wave sums)
+__device__ __forceinline__ void po_reduce27(const double (&acc)[27], double* tr, PoShared& sh)
+{
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int q = 0; q < 27; ++q) tr[q * PO_TR + tid] = acc[q];
+    __syncthreads();
+    const int q = tid >> 3, part = tid & 7;
+    double s = 0;
+    if (q < 27) {
+        const double* row = tr + q * PO_TR + part * 32;
+#pragma unroll 8
+        for (int i = 0; i < 32; ++i) s += row[i];
+    }
+    s += __shfl_down(s, 4, 8);
+    s += __shfl_down(s, 2, 8);
+    s += __shfl_down(s, 1, 8);
+    if (q < 27 && part == 0) sh.red[0][q] = s;
+    __syncthreads();
+}
+
+// Dynamic LDS: the transposed reduction buffer, the observation cache, the activity flags.
 __global__ __launch_bounds__(256) void k_pose_optimize(double* pose7, const double* pts, const lpslam_hip_ba_obs* obs, int n, BaCam cam,
-                                                       uint8_t* active, uint8_t* outlier, int* n_inliers)
+                                                       uint8_t* outlier, int* n_inliers, int cache_n)
 {
     __shared__ PoShared sh;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    extern __shared__ double po_dyn[];
+    double* tr = po_dyn;
+    PoObs* cache = reinterpret_cast<PoObs*>(po_dyn + 27 * PO_TR);
+    uint8_t* active = reinterpret_cast<uint8_t*>(cache + cache_n);
+    const int tid = threadIdx.x;
     if (tid < 7) sh.pose[tid] = pose7[tid];
-    for (int k = tid; k < n; k += 256) { active[k] = 1; outlier[k] = 0; }
+    for (int k = tid; k < n; k += 256) {
+        active[k] = 1; outlier[k] = 0;
+        if (k < cache_n) {
+            const lpslam_hip_ba_obs o = obs[k];
+            const double* p = pts + 3 * (size_t)o.point;
+            PoObs c; c.u = o.u; c.v = o.v; c.ur = o.ur; c.w = o.inv_sigma2; c.X[0] = p[0]; c.X[1] = p[1]; c.X[2] = p[2];
+            cache[k] = c;
+        }
+    }
     if (tid == 0) sh.bad = 0;
     __syncthreads();
+    const PoData d{pts, obs, cache, active, n, cache_n};
     int robust = 1;
     for (int round = 0; round < 4; ++round) {
         if (tid == 0) sh.stop = 0;
         __syncthreads();
         for (int it = 0; it < 10; ++it) {
             if (sh.stop) break;
-            const double cur = po_chi2(cam, sh.pose, pts, obs, active, n, robust, sh);
+            const double cur = po_chi2(cam, sh.pose, d, robust, sh);
             double R[9];
             quat_to_rot(sh.pose, R);
             double acc[27];
@@ -1274,9 +1333,11 @@ __global__ __launch_bounds__(256) void k_pose_optimize(double* pose7, const doub
             for (int q = 0; q < 27; ++q) acc[q] = 0;
             for (int k = tid; k < n; k += 256) {
                 if (!active[k]) continue;
-                double e[3], pc[3], A[3][3], B[3][6];
-                const int D = po_residual(cam, R, sh.pose + 4, pts + 3 * (size_t)obs[k].point, obs[k], e, pc);
-                const double om = obs[k].inv_sigma2;
+                double e[3], pc[3], A[3][3], B[3][6], X[3];
+                lpslam_hip_ba_obs o;
+                d.get(k, o, X);
+                const int D = po_residual(cam, R, sh.pose + 4, X, o, e, pc);
+                const double om = o.inv_sigma2;
                 const double chi = om * (e[0] * e[0] + e[1] * e[1] + (D == 3 ? e[2] * e[2] : 0.0));
                 const double delta = D == 3 ? cam.hub_stereo : cam.hub_mono;
                 double w = om;
@@ -1298,18 +1359,16 @@ __global__ __launch_bounds__(256) void k_pose_optimize(double* pose7, const doub
                     acc[21 + a] += s3;
                 }
             }
-#pragma unroll
-            for (int q = 0; q < 27; ++q) { const double sq = wave_sum(acc[q]); if (lane == 0) sh.red[wave][q] = sq; }
-            __syncthreads();
+            po_reduce27(acc, tr, sh);
             if (tid == 0) {
                 int idx = 0;
                 double maxd = 0;
                 for (int a = 0; a < 6; ++a) {
                     for (int c = a; c < 6; ++c, ++idx) {
-                        const double hv = ((sh.red[0][idx] + sh.red[1][idx]) + sh.red[2][idx]) + sh.red[3][idx];
+                        const double hv = sh.red[0][idx];
                         sh.H[a * 6 + c] = hv; sh.H[c * 6 + a] = hv;
                     }
-                    sh.b[a] = ((sh.red[0][21 + a] + sh.red[1][21 + a]) + sh.red[2][21 + a]) + sh.red[3][21 + a];
+                    sh.b[a] = sh.red[0][21 + a];
                     maxd = fmax(maxd, fabs(sh.H[a * 7]));
                 }
                 if (it == 0) { sh.lambda = 1e-5 * maxd; sh.ni = 2; }
@@ -1318,33 +1377,57 @@ __global__ __launch_bounds__(256) void k_pose_optimize(double* pose7, const doub
             __syncthreads();
             for (int qmax = 1; qmax <= 10; ++qmax) {
                 if (tid == 0) {
+                    // 6x6 Cholesky + two substitutions, fully unrolled with constant indices: the matrix stays in registers (with
+                    // run-time loop bounds and the early exit it lived in scratch memory, ~100 dependent memory round trips per solve)
                     double A[36];
+#pragma unroll
                     for (int i = 0; i < 36; ++i) A[i] = sh.H[i];
+#pragma unroll
                     for (int j = 0; j < 6; ++j) A[j * 7] += sh.lambda;
                     int ok = 1;
-                    for (int j = 0; j < 6 && ok; ++j) {
-                        double d = A[j * 6 + j];
-                        for (int k = 0; k < j; ++k) d -= A[j * 6 + k] * A[j * 6 + k];
-                        if (!(d > 0.0)) { ok = 0; break; }
-                        d = sqrt(d);
-                        A[j * 6 + j] = d;
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) {
+                        double d2 = A[j * 6 + j];
+#pragma unroll
+                        for (int k = 0; k < j; ++k) d2 -= A[j * 6 + k] * A[j * 6 + k];
+                        if (!(d2 > 0.0)) { ok = 0; d2 = 1.0; }         // keep going on harmless numbers; the result is discarded
+                        d2 = sqrt(d2);
+                        A[j * 6 + j] = d2;
+#pragma unroll
                         for (int i = j + 1; i < 6; ++i) {
                             double s2 = A[i * 6 + j];
+#pragma unroll
                             for (int k = 0; k < j; ++k) s2 -= A[i * 6 + k] * A[j * 6 + k];
-                            A[i * 6 + j] = s2 / d;
+                            A[i * 6 + j] = s2 / d2;
                         }
                     }
                     if (ok) {
                         double x[6];
-                        for (int i = 0; i < 6; ++i) { double s2 = sh.b[i]; for (int k = 0; k < i; ++k) s2 -= A[i * 6 + k] * x[k]; x[i] = s2 / A[i * 7]; }
-                        for (int i = 5; i >= 0; --i) { double s2 = x[i]; for (int k = i + 1; k < 6; ++k) s2 -= A[k * 6 + i] * x[k]; x[i] = s2 / A[i * 7]; }
+#pragma unroll
+                        for (int i = 0; i < 6; ++i) {
+                            double s2 = sh.b[i];
+#pragma unroll
+                            for (int k = 0; k < i; ++k) s2 -= A[i * 6 + k] * x[k];
+                            x[i] = s2 / A[i * 7];
+                        }
+#pragma unroll
+                        for (int i = 5; i >= 0; --i) {
+                            double s2 = x[i];
+#pragma unroll
+                            for (int k = i + 1; k < 6; ++k) s2 -= A[k * 6 + i] * x[k];
+                            x[i] = s2 / A[i * 7];
+                        }
+#pragma unroll
                         for (int i = 0; i < 6; ++i) sh.x[i] = x[i];
                         pose_oplus(sh.pose, x, sh.trial);
-                    } else { for (int i = 0; i < 7; ++i) sh.trial[i] = sh.pose[i]; }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 7; ++i) sh.trial[i] = sh.pose[i];
+                    }
                     sh.ok = ok;
                 }
                 __syncthreads();
-                double temp = po_chi2(cam, sh.trial, pts, obs, active, n, robust, sh);
+                double temp = po_chi2(cam, sh.trial, d, robust, sh);
                 if (tid == 0) {
                     if (!sh.ok) temp = DBL_MAX;
                     double rho = sh.current_chi - temp, scale = 0;
@@ -1375,9 +1458,11 @@ __global__ __launch_bounds__(256) void k_pose_optimize(double* pose7, const doub
         quat_to_rot(sh.pose, R);
         int bad = 0;
         for (int k = tid; k < n; k += 256) {
-            double e[3], pc[3];
-            const int D = po_residual(cam, R, sh.pose + 4, pts + 3 * (size_t)obs[k].point, obs[k], e, pc);
-            const double chi = obs[k].inv_sigma2 * (e[0] * e[0] + e[1] * e[1] + (D == 3 ? e[2] * e[2] : 0.0));
+            double e[3], pc[3], X[3];
+            lpslam_hip_ba_obs o;
+            d.get(k, o, X);
+            const int D = po_residual(cam, R, sh.pose + 4, X, o, e, pc);
+            const double chi = o.inv_sigma2 * (e[0] * e[0] + e[1] * e[1] + (D == 3 ? e[2] * e[2] : 0.0));
             const double thr = D == 3 ? 7.81473 : 5.99146;
             const int out = thr < chi ? 1 : 0;
             outlier[k] = (uint8_t)out; active[k] = (uint8_t)!out;
@@ -1958,19 +2043,30 @@ int lpslam_hip_pose_optimize(lpslam_hip_ctx* ctx, double* pose7, const double* p
     hipStream_t s = ctx->stream;
     // one block of the context's cache holds everything: pose | n_inliers | points | observations | active | outlier
     const size_t no = (size_t)std::max(n_obs, 1), np = (size_t)std::max(n_points, 1);
-    const size_t off_pts = 128, off_obs = off_pts + 3 * np * sizeof(double), off_act = off_obs + no * sizeof(lpslam_hip_ba_obs), off_out = off_act + ((no + 63) / 64) * 64;
+    const size_t off_pts = 128, off_obs = off_pts + 3 * np * sizeof(double), off_out = off_obs + no * sizeof(lpslam_hip_ba_obs);
     void* blk = nullptr; size_t cap = 0;
     { const int rc = lp_pool_alloc(ctx, off_out + no, &blk, &cap); if (rc) return rc; }
     auto release = [&]() { lp_pool_free(ctx, blk, cap); };
 #define PO_HIP(x) do { if ((x) != hipSuccess) { release(); set_error("HIP call failed: %s", #x); return LPSLAM_HIP_ERR_DEVICE; } } while (0)
     uint8_t* base = (uint8_t*)blk;
     double* d_pose = (double*)base; int* d_n = (int*)(base + 64); double* d_pts = (double*)(base + off_pts);
-    lpslam_hip_ba_obs* d_obs = (lpslam_hip_ba_obs*)(base + off_obs); uint8_t* d_act = base + off_act; uint8_t* d_out = base + off_out;
+    lpslam_hip_ba_obs* d_obs = (lpslam_hip_ba_obs*)(base + off_obs); uint8_t* d_out = base + off_out;
     PO_HIP(hipMemcpyAsync(d_pose, pose7, 7 * sizeof(double), hipMemcpyHostToDevice, s));
     if (n_points) PO_HIP(hipMemcpyAsync(d_pts, points, 3 * (size_t)n_points * sizeof(double), hipMemcpyHostToDevice, s));
     if (n_obs) PO_HIP(hipMemcpyAsync(d_obs, obs, (size_t)n_obs * sizeof(lpslam_hip_ba_obs), hipMemcpyHostToDevice, s));
     const BaCam c{cam->fx, cam->fy, cam->cx, cam->cy, cam->focal_x_baseline, cam->huber_mono, cam->huber_stereo};
-    hipLaunchKernelGGL(k_pose_optimize, dim3(1), dim3(256), 0, s, d_pose, d_pts, d_obs, n_obs, c, d_act, d_out, d_n);
+    // dynamic LDS: transposed reduction buffer + as many observations as fit beside it + one activity byte per observation
+    constexpr size_t kPoLdsBudget = 150 * 1024;
+    const size_t fixed_lds = 27 * PO_TR * sizeof(double) + no + 64;
+    const int cache_n = (int)std::min<size_t>((size_t)n_obs, fixed_lds < kPoLdsBudget ? (kPoLdsBudget - fixed_lds) / sizeof(PoObs) : 0);
+    const size_t lds = 27 * PO_TR * sizeof(double) + (size_t)cache_n * sizeof(PoObs) + no + 64;
+    if (lds > kPoLdsBudget + 4096) { release(); set_error("pose optimiser: %d observations exceed the LDS activity array", n_obs); return LPSLAM_HIP_ERR_CAPACITY; }
+    {
+        static std::atomic<bool> po_attr[64];
+        int dev = 0; (void)hipGetDevice(&dev);
+        if (dev >= 0 && dev < 64 && !po_attr[dev].load()) { (void)hipFuncSetAttribute((const void*)k_pose_optimize, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kPoLdsBudget + 4096)); po_attr[dev].store(true); }
+    }
+    hipLaunchKernelGGL(k_pose_optimize, dim3(1), dim3(256), lds, s, d_pose, d_pts, d_obs, n_obs, c, d_out, d_n, cache_n);
     PO_HIP(hipGetLastError());
     int32_t inl = 0;
     PO_HIP(hipMemcpyAsync(pose7, d_pose, 7 * sizeof(double), hipMemcpyDeviceToHost, s));

@@ -63,6 +63,8 @@ struct lpslam_hip_ctx {
     // resize tables: xofs/yofs (int16) and 11-bit coefficient pairs (int16 x2) per output column/row
     int2* d_rs_pack = nullptr;         // resize tables, one entry per destination column / row: (s0 | s1 << 16, w0 | w1 << 16)
     int rs_entries = 0;
+    uint8_t* h_stage = nullptr;        // pinned host staging of lpslam_hip_get_frame (one frame's results)
+    size_t h_stage_bytes = 0;
     int2* d_band_rows = nullptr;       // [band count 0..32][levels][bands]: rows of each level a band work-group computes
 
     // FAST output: per cell fixed slots + counts

@@ -30,7 +30,7 @@ SYMBOLS = [
     "lpslam_hip_stream", "lpslam_hip_sync", "lpslam_hip_timer_begin", "lpslam_hip_timer_end", "lpslam_hip_timer_read", "lpslam_hip_level_info", "lpslam_hip_max_keypoints_per_image",
     "lpslam_hip_image_ptr", "lpslam_hip_upload_image", "lpslam_hip_set_rectify_map", "lpslam_hip_upload_raw_image", "lpslam_hip_remap_staged", "lpslam_hip_extract", "lpslam_hip_extract_range", "lpslam_hip_stage_pyramid",
     "lpslam_hip_stage_fast", "lpslam_hip_stage_distribute", "lpslam_hip_stage_describe",
-    "lpslam_hip_keypoint_count", "lpslam_hip_get_keypoints", "lpslam_hip_get_pyramid_level",
+    "lpslam_hip_keypoint_count", "lpslam_hip_get_keypoints", "lpslam_hip_get_frame", "lpslam_hip_get_pyramid_level",
     "lpslam_hip_get_candidates", "lpslam_hip_keypoint_buffers", "lpslam_hip_match_bf", "lpslam_hip_get_bf_knn2",
     "lpslam_hip_get_bf_matches", "lpslam_hip_match_bf_strided", "lpslam_hip_set_descriptors",
     "lpslam_hip_match_stereo", "lpslam_hip_match_stereo_strided", "lpslam_hip_get_stereo",
@@ -203,6 +203,14 @@ class Context:
         n = C.c_int32()
         _check(self.lib.lpslam_hip_get_keypoints(self.h, image, _p(kp), _p(desc), self.max_kp, C.byref(n)))
         return kp[:n.value].copy(), desc[:n.value].copy()
+
+    def frame(self, image):
+        """keypoints, descriptors, x_right, depth of one slot in one round trip (lpslam_hip_get_frame)"""
+        kp = np.zeros(self.max_kp, KP_DTYPE); desc = np.zeros((self.max_kp, 32), np.uint8)
+        xr = np.zeros(self.max_kp, np.float32); dep = np.zeros(self.max_kp, np.float32)
+        n = C.c_int32()
+        _check(self.lib.lpslam_hip_get_frame(self.h, image, _p(kp), _p(desc), _p(xr), _p(dep), self.max_kp, C.byref(n)))
+        return kp[:n.value].copy(), desc[:n.value].copy(), xr[:n.value].copy(), dep[:n.value].copy()
 
     def pyramid_level(self, image, level):
         out = np.zeros((self.level_h[level], self.level_w[level]), np.uint8)

@@ -602,11 +602,12 @@ TrackerBase::ProcessImageResult HipVslamTrackerBase::trackFrame(CameraQueueEntry
     }
     int32_t n = 0;
     cur.kpts.resize(m_maxKp); cur.desc.resize((size_t)m_maxKp * 32);
-    if (ok) ok = lpslam_hip_get_keypoints(m_ctx, cur.slot, cur.kpts.data(), cur.desc.data(), m_maxKp, &n) == LPSLAM_HIP_OK;
+    cur.x_right.assign(m_maxKp, -1.0f); cur.depth.assign(m_maxKp, -1.0f);
+    if (ok) ok = lpslam_hip_get_frame(m_ctx, cur.slot, cur.kpts.data(), cur.desc.data(), stereo ? cur.x_right.data() : nullptr,
+                                      stereo ? cur.depth.data() : nullptr, m_maxKp, &n) == LPSLAM_HIP_OK;
     if (!ok) { logMessage(LpSlamLogLevel_Error, std::string("HIP front end failed: ") + lpslam_hip_last_error()); return res; }
     cur.kpts.resize(n); cur.desc.resize((size_t)n * 32);
-    cur.x_right.assign(n, -1.0f); cur.depth.assign(n, -1.0f); cur.landmark.assign(n, -1);
-    if (stereo && n > 0) lpslam_hip_get_stereo(m_ctx, cur.slot, cur.x_right.data(), cur.depth.data(), nullptr, n, nullptr);
+    cur.x_right.resize(n); cur.depth.resize(n); cur.landmark.assign(n, -1);
     ++m_imageTracked;
 
     if (!stereo) {

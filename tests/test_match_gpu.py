@@ -195,3 +195,18 @@ def test_area_match_parity_with_stealing(hiplib, oracle):
     assert (kp1["octave"][m] == 0).all()
     stolen = (gi[:40] == -1) & (gi[n0:n0 + 40] >= 0)
     assert stolen.sum() >= 5                                                  # the steal rule was exercised
+
+
+def test_frame_readback_in_one_round_trip(hiplib):
+    """lpslam_hip_get_frame returns what get_keypoints + get_stereo return."""
+    w, h = 640, 480
+    k = synth.intrinsics(w, h)
+    l, r = synth.StereoSequence(w, h, 2, n_points=4000).frame(0)
+    ctx = hiplib.Context(w, h, 800, 1.2, 5, max_images=2)
+    ctx.upload(0, l); ctx.upload(1, r); ctx.extract(2)
+    ctx.match_stereo(0, 1, k["fxb"], k["baseline"])
+    kp, desc = ctx.keypoints(0)
+    xr, dep, _ = ctx.stereo(0)
+    fkp, fdesc, fxr, fdep = ctx.frame(0)
+    assert len(fkp) == len(kp) > 100 and fkp.tobytes() == kp.tobytes() and np.array_equal(fdesc, desc)
+    assert np.array_equal(fxr, xr) and np.array_equal(fdep, dep) and (fdep > 0).sum() > 20
