@@ -563,26 +563,45 @@ __device__ void s3_t_levenberg(const S3Pair* pairs, const uint8_t* active, int n
         __syncthreads();
         for (int qmax = 1; qmax <= 10; ++qmax) {
             if (tid == 0) {
+                // 7x7 Cholesky + substitutions fully unrolled with constant indices: registers, not scratch memory
                 double A[49];
+#pragma unroll
                 for (int i = 0; i < 49; ++i) A[i] = sh.H[i];
+#pragma unroll
                 for (int j = 0; j < 7; ++j) A[j * 8] += sh.lambda;
                 int ok = 1;
-                for (int j = 0; j < 7 && ok; ++j) {                     // dense Cholesky, lower
+#pragma unroll
+                for (int j = 0; j < 7; ++j) {                           // dense Cholesky, lower
                     double d = A[j * 7 + j];
+#pragma unroll
                     for (int k = 0; k < j; ++k) d -= A[j * 7 + k] * A[j * 7 + k];
-                    if (!(d > 0.0)) { ok = 0; break; }
+                    if (!(d > 0.0)) { ok = 0; d = 1.0; }                // keep going on harmless numbers; the result is discarded
                     d = sqrt(d);
                     A[j * 7 + j] = d;
+#pragma unroll
                     for (int i = j + 1; i < 7; ++i) {
                         double s2 = A[i * 7 + j];
+#pragma unroll
                         for (int k = 0; k < j; ++k) s2 -= A[i * 7 + k] * A[j * 7 + k];
                         A[i * 7 + j] = s2 / d;
                     }
                 }
                 if (ok) {
                     double x[7];
-                    for (int i = 0; i < 7; ++i) { double s2 = sh.b[i]; for (int k = 0; k < i; ++k) s2 -= A[i * 7 + k] * x[k]; x[i] = s2 / A[i * 8]; }
-                    for (int i = 6; i >= 0; --i) { double s2 = x[i]; for (int k = i + 1; k < 7; ++k) s2 -= A[k * 7 + i] * x[k]; x[i] = s2 / A[i * 8]; }
+#pragma unroll
+                    for (int i = 0; i < 7; ++i) {
+                        double s2 = sh.b[i];
+#pragma unroll
+                        for (int k = 0; k < i; ++k) s2 -= A[i * 7 + k] * x[k];
+                        x[i] = s2 / A[i * 8];
+                    }
+#pragma unroll
+                    for (int i = 6; i >= 0; --i) {
+                        double s2 = x[i];
+#pragma unroll
+                        for (int k = i + 1; k < 7; ++k) s2 -= A[k * 7 + i] * x[k];
+                        x[i] = s2 / A[i * 8];
+                    }
                     for (int i = 0; i < 7; ++i) sh.x[i] = x[i];
                     Sim3d upd, uinv;
                     s3_oplus(sh.S, x, fix_scale, upd);
