@@ -1325,7 +1325,11 @@ __global__ __launch_bounds__(256) void k_pose_optimize(double* pose7, const doub
         __syncthreads();
         for (int it = 0; it < 10; ++it) {
             if (sh.stop) break;
-            const double cur = po_chi2(cam, sh.pose, d, robust, sh);
+            // chi2 of the accepted pose: computed at the start of a round (the kernel / the active set may have changed); later it
+            // is the value the accepted trial produced -- same pose, same data, same summation order, so not computed again.
+            // (Fusing the trial's chi2 with a speculative linearisation, as the window BA does, was measured slower here:
+            // the 27-sum pass costs more than the two passes it replaces save.)
+            const double cur = it == 0 ? po_chi2(cam, sh.pose, d, robust, sh) : sh.current_chi;
             double R[9];
             quat_to_rot(sh.pose, R);
             double acc[27];
