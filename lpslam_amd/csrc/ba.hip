@@ -1389,6 +1389,7 @@ __global__ __launch_bounds__(256) void k_pose_optimize(double* pose7, const doub
 #pragma unroll
                     for (int j = 0; j < 6; ++j) A[j * 7] += sh.lambda;
                     int ok = 1;
+                    double inv[6];                                     // 1 / L_jj: six divisions per solve instead of twenty-seven
 #pragma unroll
                     for (int j = 0; j < 6; ++j) {
                         double d2 = A[j * 6 + j];
@@ -1397,12 +1398,13 @@ __global__ __launch_bounds__(256) void k_pose_optimize(double* pose7, const doub
                         if (!(d2 > 0.0)) { ok = 0; d2 = 1.0; }         // keep going on harmless numbers; the result is discarded
                         d2 = sqrt(d2);
                         A[j * 6 + j] = d2;
+                        inv[j] = 1.0 / d2;
 #pragma unroll
                         for (int i = j + 1; i < 6; ++i) {
                             double s2 = A[i * 6 + j];
 #pragma unroll
                             for (int k = 0; k < j; ++k) s2 -= A[i * 6 + k] * A[j * 6 + k];
-                            A[i * 6 + j] = s2 / d2;
+                            A[i * 6 + j] = s2 * inv[j];
                         }
                     }
                     if (ok) {
@@ -1412,14 +1414,14 @@ __global__ __launch_bounds__(256) void k_pose_optimize(double* pose7, const doub
                             double s2 = sh.b[i];
 #pragma unroll
                             for (int k = 0; k < i; ++k) s2 -= A[i * 6 + k] * x[k];
-                            x[i] = s2 / A[i * 7];
+                            x[i] = s2 * inv[i];
                         }
 #pragma unroll
                         for (int i = 5; i >= 0; --i) {
                             double s2 = x[i];
 #pragma unroll
                             for (int k = i + 1; k < 6; ++k) s2 -= A[k * 6 + i] * x[k];
-                            x[i] = s2 / A[i * 7];
+                            x[i] = s2 * inv[i];
                         }
 #pragma unroll
                         for (int i = 0; i < 6; ++i) sh.x[i] = x[i];
