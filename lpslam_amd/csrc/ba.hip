@@ -1378,7 +1378,7 @@ __global__ __launch_bounds__(256) void k_pose_optimize(double* pose7, const doub
                 if (it == 0) { sh.lambda = 1e-5 * maxd; sh.ni = 2; }
                 sh.current_chi = cur;
             }
-            __syncthreads();
+            // (no barrier: the system just assembled is read by the same thread below)
             for (int qmax = 1; qmax <= 10; ++qmax) {
                 if (tid == 0) {
                     // 6x6 Cholesky + two substitutions, fully unrolled with constant indices: the matrix stays in registers (with
