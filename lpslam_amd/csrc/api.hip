@@ -210,6 +210,7 @@ int lpslam_hip_create(const lpslam_hip_frontend_config* cfg, lpslam_hip_ctx** ou
 
     lpslam_hip_ctx* c = new lpslam_hip_ctx();
     c->cfg = *cfg;
+    c->h_kp_count.assign((size_t)cfg->max_images, 0); c->h_kp_valid.assign((size_t)cfg->max_images, 0);
     std::vector<int16_t> ofs, coef;
     int rc = build_level_table(*cfg, c->lt, c->image_slab, ofs, coef);
     if (rc != LPSLAM_HIP_OK) { delete c; return rc; }
@@ -294,6 +295,7 @@ void lpslam_hip_destroy(lpslam_hip_ctx* c)
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (int i = 0; i < LPSLAM_HIP_MAX_TIMERS; ++i) { if (c->ev_begin[i]) (void)hipEventDestroy(c->ev_begin[i]); if (c->ev_end[i]) (void)hipEventDestroy(c->ev_end[i]); }
     if (c->h_stage) (void)hipHostFree(c->h_stage);
+    if (c->h_match) (void)hipHostFree(c->h_match);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -458,8 +460,10 @@ int lpslam_hip_keypoint_count(lpslam_hip_ctx* c, int image, int32_t* count)
 {
     int rc = check_image(c, image); if (rc) return rc;
     if (!count) { set_error("null argument"); return LPSLAM_HIP_ERR_INVALID; }
+    if ((size_t)image < c->h_kp_valid.size() && c->h_kp_valid[(size_t)image]) { *count = c->h_kp_count[(size_t)image]; return LPSLAM_HIP_OK; }
     LP_HIP(hipMemcpyAsync(count, c->d_kp_count + image, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     LP_HIP(hipStreamSynchronize(c->stream));
+    if ((size_t)image < c->h_kp_valid.size()) { c->h_kp_count[(size_t)image] = *count; c->h_kp_valid[(size_t)image] = 1; }
     return LPSLAM_HIP_OK;
 }
 
@@ -504,6 +508,7 @@ int lpslam_hip_get_frame(lpslam_hip_ctx* c, int image, lpslam_hip_keypoint* kpts
     LP_HIP(hipStreamSynchronize(c->stream));
     int32_t n = 0;
     memcpy(&n, st, sizeof(n));
+    if ((size_t)image < c->h_kp_valid.size()) { c->h_kp_count[(size_t)image] = n; c->h_kp_valid[(size_t)image] = 1; }
     if (count) *count = n;
     if (n > capacity) { set_error("frame buffers too small (%d < %d)", capacity, n); return LPSLAM_HIP_ERR_CAPACITY; }
     if (kpts && n) memcpy(kpts, st + o_kp, (size_t)n * sizeof(lpslam_hip_keypoint));
@@ -546,7 +551,7 @@ int lpslam_hip_keypoint_buffers(lpslam_hip_ctx* c, int image, void** kpts_dev, v
     const size_t o = (size_t)image * c->slots_per_image;
     if (kpts_dev) *kpts_dev = c->d_kpts + o;
     if (desc_dev) *desc_dev = c->d_desc + o * 32;
-    if (count_dev) *count_dev = c->d_kp_count + image;
+    if (count_dev) { *count_dev = c->d_kp_count + image; if ((size_t)image < c->h_kp_valid.size()) c->h_kp_valid[(size_t)image] = 0; }
     return LPSLAM_HIP_OK;
 }
 
@@ -558,6 +563,7 @@ int lpslam_hip_set_descriptors(lpslam_hip_ctx* c, int image, const uint8_t* desc
     if (n) LP_HIP(hipMemcpyAsync(c->d_desc + (size_t)image * c->slots_per_image * 32, desc32, (size_t)n * 32, hipMemcpyHostToDevice, c->stream));
     LP_HIP(hipMemcpyAsync(c->d_kp_count + image, &n, sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     LP_HIP(hipStreamSynchronize(c->stream));
+    if ((size_t)image < c->h_kp_valid.size()) { c->h_kp_count[(size_t)image] = n; c->h_kp_valid[(size_t)image] = 1; }
     return LPSLAM_HIP_OK;
 }
 

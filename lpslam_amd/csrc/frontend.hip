@@ -862,6 +862,7 @@ int lp_launch_distribute(lpslam_hip_ctx* c, int first, int n_images)
 
 int lp_launch_describe(lpslam_hip_ctx* c, int first, int n_images)
 {
+    for (int i = first; i < first + n_images && (size_t)i < c->h_kp_valid.size(); ++i) c->h_kp_valid[(size_t)i] = 0;      // counts are rewritten
     dim3 grid((c->slots_per_image + DESC_WAVES - 1) / DESC_WAVES, n_images);
     hipLaunchKernelGGL(k_describe, grid, dim3(64 * DESC_WAVES), 0, c->stream, c->d_pyr, c->image_slab, c->lt, c->d_sel_key,
                        c->d_sel_count, c->slots_per_image, c->d_kpts, c->d_desc, c->d_kp_count, first);

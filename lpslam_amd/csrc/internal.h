@@ -65,6 +65,10 @@ struct lpslam_hip_ctx {
     int rs_entries = 0;
     uint8_t* h_stage = nullptr;        // pinned host staging of lpslam_hip_get_frame (one frame's results)
     size_t h_stage_bytes = 0;
+    // host mirror of d_kp_count: valid after any call that fetched it, invalidated by whatever rewrites it on the device
+    std::vector<int32_t> h_kp_count; std::vector<uint8_t> h_kp_valid;
+    uint8_t* h_match = nullptr;        // pinned host staging of the window matchers (queries in, candidate lists out)
+    size_t h_match_bytes = 0;
     int2* d_band_rows = nullptr;       // [band count 0..32][levels][bands]: rows of each level a band work-group computes
 
     // FAST output: per cell fixed slots + counts

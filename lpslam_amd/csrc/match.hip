@@ -476,27 +476,41 @@ static int window_match(lpslam_hip_ctx* c, int image, const lpslam_hip_proj_quer
     static_assert(sizeof(lpslam_hip_proj_query) == sizeof(ProjQuery), "query layout");
     if (n_matches) *n_matches = 0;
     if (nq == 0) return LPSLAM_HIP_OK;
-    int32_t n_kp = 0;
-    rc = lpslam_hip_keypoint_count(c, image, &n_kp); if (rc) return rc;
     hipStream_t s = c->stream;
     const size_t o = (size_t)image * c->slots_per_image;
-    // one block of the context's cache: keys | queries | descriptors | counts | ids | best-so-far
-    const size_t nk = (size_t)std::max(n_kp, 1);
+    // one block of the context's cache: keys | queries | descriptors | counts | ids | best-so-far (one entry per keypoint SLOT:
+    // the keypoint count stays on the device, the kernel reads it there, so no round trip is needed before the launch)
+    const size_t nk = (size_t)std::max(c->slots_per_image, 1);
     const size_t o_keys = 0, o_q = o_keys + (size_t)nq * 4 * sizeof(unsigned long long), o_qd = o_q + (size_t)nq * sizeof(ProjQuery), o_cnt = o_qd + (size_t)nq * 32,
                  o_ids = o_cnt + (size_t)nq * sizeof(int), o_bsf = o_ids + 64;
+    const size_t total = o_bsf + nk * sizeof(int16_t);
     void* blk = nullptr; size_t cap = 0;
-    { const int rc2 = lp_pool_alloc(c, o_bsf + nk * sizeof(int16_t), &blk, &cap); if (rc2) return rc2; }
+    { const int rc2 = lp_pool_alloc(c, total, &blk, &cap); if (rc2) return rc2; }
     auto release = [&]() { lp_pool_free(c, blk, cap); };
 #define P_HIP(x) do { if ((x) != hipSuccess) { release(); set_error("HIP call failed: %s", #x); return LPSLAM_HIP_ERR_DEVICE; } } while (0)
+    // pinned mirror of that block on the host: inputs are assembled there and go down as ONE copy (queries, descriptors,
+    // counts, ids and best-so-far are contiguous), the candidate lists come back as one copy
+    if (c->h_match_bytes < total) {
+        if (c->h_match) (void)hipHostFree(c->h_match);
+        c->h_match = nullptr; c->h_match_bytes = 0;
+        P_HIP(hipHostMalloc((void**)&c->h_match, total + total / 2, hipHostMallocDefault));
+        c->h_match_bytes = total + total / 2;
+    }
     uint8_t* base = (uint8_t*)blk;
+    uint8_t* hb = c->h_match;
     unsigned long long* d_keys = (unsigned long long*)(base + o_keys); ProjQuery* d_q = (ProjQuery*)(base + o_q); uint8_t* d_qd = base + o_qd;
     int* d_cnt = (int*)(base + o_cnt); int* d_ids = (int*)(base + o_ids); int16_t* d_bsf = (int16_t*)(base + o_bsf);
-    std::vector<int16_t> bsf(nk, (int16_t)32767);
-    if (taken_in) for (int i = 0; i < n_kp; ++i) if (taken_in[i]) bsf[(size_t)i] = 0;
+    int16_t* bsf = (int16_t*)(hb + o_bsf);
+    for (size_t i = 0; i < nk; ++i) bsf[i] = (int16_t)32767;
+    if (taken_in) {                        // one byte per keypoint of the image: the count is needed (host mirror, else one round trip)
+        int32_t n_kp = 0;
+        { const int rc3 = lpslam_hip_keypoint_count(c, image, &n_kp); if (rc3) { release(); return rc3; } }
+        for (int i = 0; i < n_kp; ++i) if (taken_in[i]) bsf[(size_t)i] = 0;
+    }
     std::vector<int> owner(policy == 2 ? nk : 0, -1);
-    P_HIP(hipMemcpyAsync(d_q, queries, (size_t)nq * sizeof(ProjQuery), hipMemcpyHostToDevice, s));
-    P_HIP(hipMemcpyAsync(d_qd, q_desc32, (size_t)nq * 32, hipMemcpyHostToDevice, s));
-    P_HIP(hipMemcpyAsync(d_bsf, bsf.data(), nk * sizeof(int16_t), hipMemcpyHostToDevice, s));
+    memcpy(hb + o_q, queries, (size_t)nq * sizeof(ProjQuery));
+    memcpy(hb + o_qd, q_desc32, (size_t)nq * 32);
+    P_HIP(hipMemcpyAsync(base + o_q, hb + o_q, total - o_q, hipMemcpyHostToDevice, s));
     const float inv_w = (float)(64.0 / c->lt.w[0]), inv_h = (float)(48.0 / c->lt.h[0]);
     const float* sxr = use_stereo ? c->d_stereo + (size_t)image * 2 * c->slots_per_image : nullptr;
     ProjGate gate{};
@@ -505,10 +519,10 @@ static int window_match(lpslam_hip_ctx* c, int image, const lpslam_hip_proj_quer
     hipLaunchKernelGGL(k_proj_topk, dim3((nq + 3) / 4), dim3(256), 0, s, c->d_kpts + o, c->d_desc + o * 32, sxr, c->d_kp_count + image,
                        d_q, d_qd, (const int*)nullptr, nq, (const int16_t*)d_bsf, inv_w, inv_h, gate, d_keys, d_cnt);
     P_HIP(hipGetLastError());
-    std::vector<unsigned long long> keys((size_t)nq * 4);
-    std::vector<int> cnt((size_t)nq);
-    P_HIP(hipMemcpyAsync(keys.data(), d_keys, keys.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-    P_HIP(hipMemcpyAsync(cnt.data(), d_cnt, cnt.size() * sizeof(int), hipMemcpyDeviceToHost, s));
+    const unsigned long long* keys = (const unsigned long long*)(hb + o_keys);
+    const int* cnt = (const int*)(hb + o_cnt);
+    P_HIP(hipMemcpyAsync(hb + o_keys, d_keys, (size_t)nq * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    P_HIP(hipMemcpyAsync(hb + o_cnt, d_cnt, (size_t)nq * sizeof(int), hipMemcpyDeviceToHost, s));
     P_HIP(hipStreamSynchronize(s));
     int found = 0;
     for (int k = 0; k < nq; ++k) {
@@ -523,7 +537,7 @@ static int window_match(lpslam_hip_ctx* c, int image, const lpslam_hip_proj_quer
         int m = free_ones(fr);
         if (policy != 1 && m < 2 && cnt[k] > 4) {
             // the short list was eaten by earlier queries: scan again for this query with the current assignment
-            P_HIP(hipMemcpyAsync(d_bsf, bsf.data(), nk * sizeof(int16_t), hipMemcpyHostToDevice, s));
+            P_HIP(hipMemcpyAsync(d_bsf, bsf, nk * sizeof(int16_t), hipMemcpyHostToDevice, s));
             P_HIP(hipMemcpyAsync(d_ids, &k, sizeof(int), hipMemcpyHostToDevice, s));
             hipLaunchKernelGGL(k_proj_topk, dim3(1), dim3(256), 0, s, c->d_kpts + o, c->d_desc + o * 32, sxr, c->d_kp_count + image,
                                d_q, d_qd, (const int*)d_ids, 1, (const int16_t*)d_bsf, inv_w, inv_h, gate, d_keys, d_cnt);
