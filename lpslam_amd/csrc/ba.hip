@@ -19,6 +19,7 @@
 // solve needs one sum all-reduce of it per trial (lpslam_hip_ba_step_*).
 #include "internal.h"
 #include <cmath>
+#include <cstring>
 #include <cfloat>
 #include <algorithm>
 #include <atomic>
@@ -2057,9 +2058,18 @@ int lpslam_hip_pose_optimize(lpslam_hip_ctx* ctx, double* pose7, const double* p
     uint8_t* base = (uint8_t*)blk;
     double* d_pose = (double*)base; int* d_n = (int*)(base + 64); double* d_pts = (double*)(base + off_pts);
     lpslam_hip_ba_obs* d_obs = (lpslam_hip_ba_obs*)(base + off_obs); uint8_t* d_out = base + off_out;
-    PO_HIP(hipMemcpyAsync(d_pose, pose7, 7 * sizeof(double), hipMemcpyHostToDevice, s));
-    if (n_points) PO_HIP(hipMemcpyAsync(d_pts, points, 3 * (size_t)n_points * sizeof(double), hipMemcpyHostToDevice, s));
-    if (n_obs) PO_HIP(hipMemcpyAsync(d_obs, obs, (size_t)n_obs * sizeof(lpslam_hip_ba_obs), hipMemcpyHostToDevice, s));
+    // inputs assembled in the context's pinned mirror of the block and sent as one copy (pose | - | points | observations)
+    if (ctx->h_match_bytes < off_out + no) {
+        if (ctx->h_match) (void)hipHostFree(ctx->h_match);
+        ctx->h_match = nullptr; ctx->h_match_bytes = 0;
+        PO_HIP(hipHostMalloc((void**)&ctx->h_match, (off_out + no) * 2, hipHostMallocDefault));
+        ctx->h_match_bytes = (off_out + no) * 2;
+    }
+    uint8_t* hb = ctx->h_match;
+    memcpy(hb, pose7, 7 * sizeof(double));
+    if (n_points) memcpy(hb + off_pts, points, 3 * (size_t)n_points * sizeof(double));
+    if (n_obs) memcpy(hb + off_obs, obs, (size_t)n_obs * sizeof(lpslam_hip_ba_obs));
+    PO_HIP(hipMemcpyAsync(base, hb, off_out, hipMemcpyHostToDevice, s));
     const BaCam c{cam->fx, cam->fy, cam->cx, cam->cy, cam->focal_x_baseline, cam->huber_mono, cam->huber_stereo};
     // dynamic LDS: transposed reduction buffer + as many observations as fit beside it + one activity byte per observation
     constexpr size_t kPoLdsBudget = 150 * 1024;
@@ -2075,10 +2085,12 @@ int lpslam_hip_pose_optimize(lpslam_hip_ctx* ctx, double* pose7, const double* p
     hipLaunchKernelGGL(k_pose_optimize, dim3(1), dim3(256), lds, s, d_pose, d_pts, d_obs, n_obs, c, d_out, d_n, cache_n);
     PO_HIP(hipGetLastError());
     int32_t inl = 0;
-    PO_HIP(hipMemcpyAsync(pose7, d_pose, 7 * sizeof(double), hipMemcpyDeviceToHost, s));
-    PO_HIP(hipMemcpyAsync(&inl, d_n, sizeof(int), hipMemcpyDeviceToHost, s));
-    if (outlier && n_obs) PO_HIP(hipMemcpyAsync(outlier, d_out, (size_t)n_obs, hipMemcpyDeviceToHost, s));
+    PO_HIP(hipMemcpyAsync(hb, base, 128, hipMemcpyDeviceToHost, s));                    // pose and inlier count
+    if (outlier && n_obs) PO_HIP(hipMemcpyAsync(hb + off_out, d_out, (size_t)n_obs, hipMemcpyDeviceToHost, s));
     PO_HIP(hipStreamSynchronize(s));
+    memcpy(pose7, hb, 7 * sizeof(double));
+    memcpy(&inl, hb + 64, sizeof(int));
+    if (outlier && n_obs) memcpy(outlier, hb + off_out, (size_t)n_obs);
 #undef PO_HIP
     release();
     if (n_inliers) *n_inliers = inl;
