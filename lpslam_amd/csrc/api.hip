@@ -140,6 +140,24 @@ int lp_pool_alloc(lpslam_hip_ctx* c, size_t bytes, void** out, size_t* capacity)
     return LPSLAM_HIP_OK;
 }
 
+void* lp_pin_alloc(lpslam_hip_ctx* c)
+{
+    {
+        std::lock_guard<std::mutex> lock(c->pool_mutex);
+        if (!c->pin_free.empty()) { void* p = c->pin_free.back(); c->pin_free.pop_back(); return p; }
+    }
+    void* p = nullptr;
+    if (hipHostMalloc(&p, 8192, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
+
+void lp_pin_free(lpslam_hip_ctx* c, void* p)
+{
+    if (!p) return;
+    std::lock_guard<std::mutex> lock(c->pool_mutex);
+    c->pin_free.push_back(p);
+}
+
 void lp_pool_free(lpslam_hip_ctx* c, void* p, size_t capacity)
 {
     if (!p) return;
@@ -294,6 +312,8 @@ void lpslam_hip_destroy(lpslam_hip_ctx* c)
                     c->d_map_xy[0], c->d_map_xy[1], c->d_map_frac[0], c->d_map_frac[1], c->d_raw};
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (int i = 0; i < LPSLAM_HIP_MAX_TIMERS; ++i) { if (c->ev_begin[i]) (void)hipEventDestroy(c->ev_begin[i]); if (c->ev_end[i]) (void)hipEventDestroy(c->ev_end[i]); }
+    for (void* p : c->pin_free) (void)hipHostFree(p);
+    c->pin_free.clear();
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->h_match) (void)hipHostFree(c->h_match);
     if (c->stream) (void)hipStreamDestroy(c->stream);

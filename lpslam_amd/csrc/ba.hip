@@ -1513,6 +1513,8 @@ struct lpslam_hip_ba {
     std::vector<double> h_ur;                      // mono/stereo classification for the outlier thresholds
     BaCtl h_ctl{};                                 // last control block read back
     BaCtl h_ctl_out{};                             // staging of the control block on its way to the device
+    struct Pinned { BaCtl ctl; BaCtl ctl_out; lpslam_hip_ba_iter_log log[MAX_LOG]; };
+    Pinned* pin = nullptr;                         // page-locked: control block and iteration log come back in one round trip
     int robust = 1, points_fixed = 0;
     std::vector<std::pair<void*, size_t>> allocs;      // blocks of the context's cache (lp_pool_alloc)
     int pending_iters = -1;                            // >= 0 between optimize_begin and optimize_end
@@ -1613,11 +1615,22 @@ int enqueue_solve(lpslam_hip_ba* b, int fused)
 int write_ctl(lpslam_hip_ba* b, const BaCtl& c)
 {
     b->h_ctl_out = c;        // the source must outlive the copy: a member, rewritten only after the next read_ctl (which synchronises)
-    LP_HIP(hipMemcpyAsync(b->d_ctl, &b->h_ctl_out, sizeof(BaCtl), hipMemcpyHostToDevice, b->stream));
+    BaCtl* src = &b->h_ctl_out;
+    if (b->pin) { b->pin->ctl_out = c; src = &b->pin->ctl_out; }
+    LP_HIP(hipMemcpyAsync(b->d_ctl, src, sizeof(BaCtl), hipMemcpyHostToDevice, b->stream));
     return LPSLAM_HIP_OK;
 }
-int read_ctl(lpslam_hip_ba* b)
+// control block (and, with log_entries > 0, that many entries of the iteration log) to the host: one synchronisation
+int read_ctl(lpslam_hip_ba* b, int log_entries = 0)
 {
+    if (b->pin) {
+        LP_HIP(hipMemcpyAsync(&b->pin->ctl, b->d_ctl, sizeof(BaCtl), hipMemcpyDeviceToHost, b->stream));
+        if (log_entries > 0)
+            LP_HIP(hipMemcpyAsync(b->pin->log, b->d_log, (size_t)std::min(log_entries, MAX_LOG) * sizeof(lpslam_hip_ba_iter_log), hipMemcpyDeviceToHost, b->stream));
+        LP_HIP(hipStreamSynchronize(b->stream));
+        b->h_ctl = b->pin->ctl;
+        return LPSLAM_HIP_OK;
+    }
     LP_HIP(hipMemcpyAsync(&b->h_ctl, b->d_ctl, sizeof(BaCtl), hipMemcpyDeviceToHost, b->stream));
     LP_HIP(hipStreamSynchronize(b->stream));
     return LPSLAM_HIP_OK;
@@ -1653,6 +1666,8 @@ int lpslam_hip_ba_create(lpslam_hip_ctx* ctx, const double* poses, const uint8_t
     LP_HIP(hipSetDevice(ctx->cfg.device));
     lpslam_hip_ba* b = new lpslam_hip_ba();
     b->ctx = ctx;
+    static_assert(sizeof(lpslam_hip_ba::Pinned) <= 8192, "pinned block size");
+    b->pin = static_cast<lpslam_hip_ba::Pinned*>(lp_pin_alloc(ctx));      // nullptr: the pageable path stays
     // own stream: a bundle adjustment runs beside the front end of later frames (the reference's mapping thread)
     // ... at the highest priority: its kernels are small and latency bound, the front end's fill the chip for 100 us at a time
     int prio_least = 0, prio_greatest = 0;
@@ -1802,6 +1817,7 @@ void lpslam_hip_ba_destroy(lpslam_hip_ba* b)
     if (b->stream) (void)hipStreamSynchronize(b->stream);
     for (auto& g : b->graphs) if (g.second) (void)hipGraphExecDestroy(g.second);
     for (auto& blk : b->allocs) lp_pool_free(b->ctx, blk.first, blk.second);
+    if (b->pin) lp_pin_free(b->ctx, b->pin);
     if (b->stream) (void)hipStreamDestroy(b->stream);
     delete b;
 }
@@ -1905,16 +1921,20 @@ int lpslam_hip_ba_optimize_end(lpslam_hip_ba* b, lpslam_hip_ba_iter_log* log, in
     const int iters = b->pending_iters;
     b->pending_iters = -1;
     int rc;
+    const int want_log = (log && b->pin) ? iters : 0;
     if (iters > 0) {
-        if ((rc = read_ctl(b))) return rc;
+        if ((rc = read_ctl(b, want_log))) return rc;
         int guard = 0;
         while (!b->h_ctl.stopped && b->h_ctl.outer_done < iters && guard++ < 16 * MAX_LOG) {
             if ((rc = enqueue_batch(b, iters - b->h_ctl.outer_done, false))) return rc;
-            if ((rc = read_ctl(b))) return rc;
+            if ((rc = read_ctl(b, want_log))) return rc;
         }
     }
     const int done = b->h_ctl.outer_done;
-    if (log && done) LP_HIP(hipMemcpy(log, b->d_log, std::min(done, MAX_LOG) * sizeof(lpslam_hip_ba_iter_log), hipMemcpyDeviceToHost));
+    if (log && done) {
+        if (want_log) memcpy(log, b->pin->log, (size_t)std::min(done, MAX_LOG) * sizeof(lpslam_hip_ba_iter_log));     // came with the control block
+        else LP_HIP(hipMemcpy(log, b->d_log, std::min(done, MAX_LOG) * sizeof(lpslam_hip_ba_iter_log), hipMemcpyDeviceToHost));
+    }
     if (done_out) *done_out = done;
     return LPSLAM_HIP_OK;
 }

@@ -67,6 +67,7 @@ struct lpslam_hip_ctx {
     size_t h_stage_bytes = 0;
     // host mirror of d_kp_count: valid after any call that fetched it, invalidated by whatever rewrites it on the device
     std::vector<int32_t> h_kp_count; std::vector<uint8_t> h_kp_valid;
+    std::vector<void*> pin_free;       // page-locked 8 KB blocks handed to bundle-adjustment objects (lp_pin_alloc / lp_pin_free)
     uint8_t* h_match = nullptr;        // pinned host staging of the window matchers (queries in, candidate lists out)
     size_t h_match_bytes = 0;
     int2* d_band_rows = nullptr;       // [band count 0..32][levels][bands]: rows of each level a band work-group computes
@@ -109,6 +110,8 @@ struct lpslam_hip_ctx {
 // block cache (api.hip): capacity-rounded first fit; *capacity receives the size to hand back to lp_pool_free
 int lp_pool_alloc(lpslam_hip_ctx* c, size_t bytes, void** out, size_t* capacity);
 void lp_pool_free(lpslam_hip_ctx* c, void* p, size_t capacity);
+void* lp_pin_alloc(lpslam_hip_ctx* c);          // 8 KB of page-locked host memory, recycled through the context (nullptr on failure)
+void lp_pin_free(lpslam_hip_ctx* c, void* p);
 int lp_launch_pyramid(lpslam_hip_ctx* c, int first, int n_images);
 int lp_launch_remap(lpslam_hip_ctx* c, int image, int eye);
 int lp_launch_fast(lpslam_hip_ctx* c, int first, int n_images);
