@@ -451,6 +451,14 @@ __global__ __launch_bounds__(1024) void k_distribute(LevelTable lt, const uint32
                     if (ncnt[cur][i] > 1) { const int pos = m - 1 - keptrank[i]; order[pos] = i; nodepos[i] = pos; }
                     else nodepos[i] = -1;
                 }
+                wsync();
+                // split centre of every visit-list node, by visit position (keptrank is free until the bookkeeping after the
+                // histogram sweep): the sweep then needs one table read instead of the node's box and its halving
+                for (int i = lane; i < m; i += 64) {
+                    const uint2 bb = nbox[cur][order[i]];
+                    const int bx = bb.x & 0xFFFF, by = bb.x >> 16, ex = bb.y & 0xFFFF, ey = bb.y >> 16;
+                    keptrank[i] = (bx + ((ex - bx + 1) >> 1)) | ((by + ((ey - by + 1) >> 1)) << 16);
+                }
             } else {
                 // pool = new children with more than one corner; keys (count << 11 | index) into kpre, ranked below by all threads
                 for (int i = lane; i < alive; i += 64) { nodepos[i] = -1; keptrank[i] = (i >= pool_begin && ncnt[cur][i] > 1) ? 1 : 0; }
@@ -474,6 +482,9 @@ __global__ __launch_bounds__(1024) void k_distribute(LevelTable lt, const uint32
                 for (int j = 0; j < m; ++j) rank += (unsigned)kpre[j] > ki;
                 const int node = (int)(ki & 0x7FFu);
                 order[rank] = node; nodepos[node] = rank;
+                const uint2 bb = nbox[cur][node];
+                const int bx = bb.x & 0xFFFF, by = bb.x >> 16, ex = bb.y & 0xFFFF, ey = bb.y >> 16;
+                keptrank[rank] = (bx + ((ex - bx + 1) >> 1)) | ((by + ((ey - by + 1) >> 1)) << 16);      // split centre, see above
             }
             __syncthreads();
         }
@@ -483,11 +494,9 @@ __global__ __launch_bounds__(1024) void k_distribute(LevelTable lt, const uint32
             const int pos = nodepos[node];
             *key = -1;
             if (pos < 0) return node;
-            const uint2 bb = nbox[cur][node];
-            const int bx = bb.x & 0xFFFF, by = bb.x >> 16, ex = bb.y & 0xFFFF, ey = bb.y >> 16;
-            const int hx = (ex - bx + 1) >> 1, hy = (ey - by + 1) >> 1;
+            const int centre = keptrank[pos];              // (bx + hx) | (by + hy) << 16 of the node at this visit position
             const int x = k & 0xFFF, y = (k >> 12) & 0xFFF;
-            const int q = (bx + hx <= x ? 1 : 0) + (by + hy <= y ? 2 : 0);
+            const int q = ((centre & 0xFFFF) <= x ? 1 : 0) + ((centre >> 16) <= y ? 2 : 0);
             *key = 4 * pos + q;
             return node | ((uint32_t)q << 30);
         };
@@ -541,6 +550,7 @@ __global__ __launch_bounds__(1024) void k_distribute(LevelTable lt, const uint32
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int n = cnt4[4 * p + q];
+                    cnt4[4 * p + q] = idx;                 // the histogram entry becomes the child's node index: the remap sweep reads it
                     if (n > 0) {
                         nbox[nxt][idx] = make_uint2((unsigned)cbx[q] | ((unsigned)cby[q] << 16), (unsigned)cex[q] | ((unsigned)cey[q] << 16));
                         ncnt[nxt][idx] = n;
@@ -563,15 +573,11 @@ __global__ __launch_bounds__(1024) void k_distribute(LevelTable lt, const uint32
         }
         __syncthreads();
         // 6. remap candidates (all wavefronts)
-        const int jcut = misc[1], n_kept = misc[2];
+        const int jcut = misc[1];
         auto remap = [&](uint32_t v) -> uint32_t {
             const int node = (int)(v & 0x3FFFFFFFu), q = (int)(v >> 30);
             const int p = nodepos[node];
-            if (p >= 0 && p < jcut) {
-                int rank = 0;
-                for (int qq = 0; qq < q; ++qq) rank += cnt4[4 * p + qq] > 0;
-                return (uint32_t)(n_kept + kpre[p] + rank);
-            }
+            if (p >= 0 && p < jcut) return (uint32_t)cnt4[4 * p + q];     // child index written by the bookkeeping above
             return (uint32_t)keptrank[node];
         };
 #pragma unroll
