@@ -186,7 +186,11 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
             // min over the pairs of max(pair) < lo, i.e. max(min(p0, p8), min(p4, p12)) < lo; brighter likewise -- four VALU ops
             // per polarity and one ballot per row instead of eight compares and 64-bit scalar mask logic
             const int dk = max(min(p0, p8), min(p4, p12)), br = min(max(p0, p8), max(p4, p12));
-            const unsigned long long any = __ballot(dk < lo || br > hi) & lane_ok;
+            // the same holds for the diagonal ring positions 2, 6, 10, 14 (also spaced four apart, so a 9-arc holds two neighbouring
+            // ones), and with the same polarity: fewer pixels reach the 16-arc evaluation
+            const int p2 = t[2 * TILE_PITCH + 2], p6 = t[-2 * TILE_PITCH + 2], p10 = t[-2 * TILE_PITCH - 2], p14 = t[2 * TILE_PITCH - 2];
+            const int dk2 = max(min(p2, p10), min(p6, p14)), br2 = min(max(p2, p10), max(p6, p14));
+            const unsigned long long any = __ballot((dk < lo && dk2 < lo) || (br > hi && br2 > hi)) & lane_ok;
             if (any) {
                 int base = 0;
                 if (lane == 0) base = atomicAdd(&q_count, __popcll(any));
