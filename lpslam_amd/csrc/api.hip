@@ -204,6 +204,9 @@ static int ctx_alloc(lpslam_hip_ctx* c)
     LP_HIP(hipMalloc((void**)&c->d_stereo, B * 2 * c->slots_per_image * sizeof(float)));
     LP_HIP(hipMalloc((void**)&c->d_stereo_idx, B * c->slots_per_image * sizeof(int32_t)));
     LP_HIP(hipMalloc((void**)&c->d_stereo_corr, B * c->slots_per_image * sizeof(int32_t)));
+    c->st_row_cap = c->slots_per_image * ((int)(4.0f * c->lt.scale[c->lt.n_levels - 1]) + 4);      // rows per keypoint <= 4 * scale + 3
+    LP_HIP(hipMalloc((void**)&c->d_st_row_start, B * (size_t)(c->lt.h[0] + 1) * sizeof(int32_t)));
+    LP_HIP(hipMalloc((void**)&c->d_st_row_list, B * (size_t)c->st_row_cap * sizeof(int32_t)));
     return LPSLAM_HIP_OK;
 }
 
@@ -308,7 +311,7 @@ void lpslam_hip_destroy(lpslam_hip_ctx* c)
     c->pool.clear();
     void* bufs[] = {c->d_pyr, c->d_band_rows, c->d_rs_pack, c->d_cell_keys, c->d_cell_count, c->d_cand_key, c->d_cand_node,
                     c->d_cand_count, c->d_sel_key, c->d_sel_count, c->d_kpts, c->d_desc,
-                    c->d_kp_count, c->d_bf, c->d_stereo, c->d_stereo_idx, c->d_stereo_corr, c->d_tmp_desc, c->d_tmp_res,
+                    c->d_kp_count, c->d_bf, c->d_stereo, c->d_stereo_idx, c->d_stereo_corr, c->d_st_row_start, c->d_st_row_list, c->d_tmp_desc, c->d_tmp_res,
                     c->d_map_xy[0], c->d_map_xy[1], c->d_map_frac[0], c->d_map_frac[1], c->d_raw};
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (int i = 0; i < LPSLAM_HIP_MAX_TIMERS; ++i) { if (c->ev_begin[i]) (void)hipEventDestroy(c->ev_begin[i]); if (c->ev_end[i]) (void)hipEventDestroy(c->ev_end[i]); }

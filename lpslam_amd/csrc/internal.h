@@ -90,6 +90,9 @@ struct lpslam_hip_ctx {
     float* d_stereo = nullptr;         // [max_images][2][slots_per_image] x_right, depth
     int32_t* d_stereo_idx = nullptr;   // [max_images][slots_per_image]
     int32_t* d_stereo_corr = nullptr;  // [max_images][slots_per_image]
+    int32_t* d_st_row_start = nullptr; // [max_images][H + 1]: per image row, where its candidate list starts (stereo matcher)
+    int32_t* d_st_row_list = nullptr;  // [max_images][st_row_cap]: right-image keypoints whose row band covers the row
+    int st_row_cap = 0;
     // on-device undistort / rectify: per eye the fixed-point map (cv::convertMaps form) and one raw-frame staging buffer
     short2* d_map_xy[2] = {nullptr, nullptr};      // [h][w] integer source coordinate (sx >> 5, sy >> 5)
     uint16_t* d_map_frac[2] = {nullptr, nullptr};  // [h][w] (sy & 31) * 32 + (sx & 31)

@@ -104,11 +104,72 @@ int lp_launch_bf_strided(lpslam_hip_ctx* c, int q0, int t0, int stride, int n_pa
 // ------------------------------------------------------------------------------------------------------------
 #define ST_WAVES 4
 
+// exclusive scan in place of a[0..n) by a 1024-thread workgroup
+__device__ void block_scan_rows(int* a, int n, int* wave_tot /* LDS[16] */, int* total)
+{
+    const int per = (n + 1023) / 1024;
+    const int b = threadIdx.x * per, e = min(b + per, n);
+    int s = 0;
+    for (int i = b; i < e; ++i) s += a[i];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int incl = s;
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    int base = 0, tot = 0;
+    for (int w = 0; w < 16; ++w) { const int t = wave_tot[w]; if (w < wave) base += t; tot += t; }
+    base += incl - s;
+    for (int i = b; i < e; ++i) { const int v = a[i]; a[i] = base; base += v; }
+    __syncthreads();
+    *total = tot;
+}
+
+// Row index of the right image ([UPSTREAM] match::stereo::get_right_keypoint_indices_in_each_row): keypoint j is a candidate for
+// every row in [floor(y - r), ceil(y + r)], r = 2 x scale factor of its level.  One workgroup per stereo pair: histogram of the
+// rows in LDS, scan, fill.  The order inside a row list is arbitrary (LDS atomics) and does not matter: the matcher takes the
+// minimum of (distance << 16 | index).
+__global__ __launch_bounds__(1024) void k_stereo_rows(LevelTable lt, const lpslam_hip_keypoint* __restrict__ kpts, const int32_t* __restrict__ counts,
+                                                      int slots_per_image, int right0, int stride, int32_t* __restrict__ row_start_all,
+                                                      int32_t* __restrict__ row_list_all, int row_cap)
+{
+    extern __shared__ int st_rows[];                     // [H + 1] counts -> starts, [H] cursors
+    __shared__ int wave_tot[16];
+    const int H = lt.h[0];
+    int* cnt = st_rows; int* cursor = st_rows + H + 1;
+    const int right = right0 + blockIdx.x * stride;
+    const int nr = counts[right];
+    const lpslam_hip_keypoint* kr = kpts + (size_t)right * slots_per_image;
+    int32_t* row_start = row_start_all + (size_t)right * (H + 1);
+    int32_t* row_list = row_list_all + (size_t)right * row_cap;
+    for (int r = threadIdx.x; r <= H; r += 1024) cnt[r] = 0;
+    __syncthreads();
+    for (int j = threadIdx.x; j < nr; j += 1024) {
+        const lpslam_hip_keypoint k = kr[j];
+        const float rad = 2.0f * lt.scale[k.octave];
+        const int max_r = min((int)ceilf(k.y + rad), H - 1), min_r = max((int)floorf(k.y - rad), 0);
+        for (int r = min_r; r <= max_r; ++r) atomicAdd(&cnt[r], 1);
+    }
+    __syncthreads();
+    int total;
+    block_scan_rows(cnt, H, wave_tot, &total);
+    if (threadIdx.x == 0) cnt[H] = total;
+    __syncthreads();
+    for (int r = threadIdx.x; r <= H; r += 1024) { row_start[r] = cnt[r]; if (r < H) cursor[r] = cnt[r]; }
+    __syncthreads();
+    for (int j = threadIdx.x; j < nr; j += 1024) {
+        const lpslam_hip_keypoint k = kr[j];
+        const float rad = 2.0f * lt.scale[k.octave];
+        const int max_r = min((int)ceilf(k.y + rad), H - 1), min_r = max((int)floorf(k.y - rad), 0);
+        for (int r = min_r; r <= max_r; ++r) { const int pos = atomicAdd(&cursor[r], 1); if (pos < row_cap) row_list[pos] = j; }
+    }
+}
+
 __global__ __launch_bounds__(64 * ST_WAVES) void k_stereo(const uint8_t* __restrict__ pyr, size_t image_slab, LevelTable lt,
                                                           const lpslam_hip_keypoint* __restrict__ kpts, const uint8_t* __restrict__ desc,
                                                           const int32_t* __restrict__ counts, int slots_per_image, int left0, int right0,
                                                           int stride, float fxb, float max_disp, float* __restrict__ out_f,
-                                                          int32_t* __restrict__ out_idx, int32_t* __restrict__ out_corr)
+                                                          int32_t* __restrict__ out_idx, int32_t* __restrict__ out_corr,
+                                                          const int32_t* __restrict__ row_start_all, const int32_t* __restrict__ row_list_all, int row_cap)
 {
     __shared__ uint8_t s_r[ST_WAVES][11 * 24];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -131,12 +192,14 @@ __global__ __launch_bounds__(64 * ST_WAVES) void k_stereo(const uint8_t* __restr
     const int row = (int)kl.y;
     const float min_xr = kl.x - max_disp, max_xr = kl.x - 0.0f;
     unsigned best = 0xFFFFFFFFu;                          // (distance << 16) | index
-    if (!(max_xr < 0)) {
-        for (int j = lane; j < nr; j += 64) {
+    if (!(max_xr < 0) && nr > 0 && row >= 0 && row < lt.h[0]) {
+        // candidates: the right keypoints whose row band covers this row (k_stereo_rows), not all of them
+        const int32_t* row_start = row_start_all + (size_t)right * (lt.h[0] + 1);
+        const int32_t* row_list = row_list_all + (size_t)right * row_cap;
+        const int t_end = min(row_start[row + 1], row_cap);
+        for (int t = row_start[row] + lane; t < t_end; t += 64) {
+            const int j = row_list[t];
             const lpslam_hip_keypoint r = kr[j];
-            const float rad = 2.0f * lt.scale[r.octave];
-            const int max_r = (int)ceilf(r.y + rad), min_r = (int)floorf(r.y - rad);
-            if (row < min_r || row > max_r) continue;
             if (r.octave < kl.octave - 1 || r.octave > kl.octave + 1) continue;
             if (r.x < min_xr || max_xr < r.x) continue;
             const uint32_t* b = reinterpret_cast<const uint32_t*>(dr + (size_t)j * 32);
@@ -270,10 +333,12 @@ __global__ __launch_bounds__(1024) void k_stereo_median(const int32_t* __restric
 int lp_launch_stereo_strided(lpslam_hip_ctx* c, int left0, int right0, int stride, int n_pairs, float fxb, float baseline)
 {
     const float max_disp = fxb / baseline;
+    hipLaunchKernelGGL(k_stereo_rows, dim3(n_pairs), dim3(1024), (size_t)(2 * c->lt.h[0] + 2) * sizeof(int), c->stream, c->lt, c->d_kpts, c->d_kp_count,
+                       c->slots_per_image, right0, stride, c->d_st_row_start, c->d_st_row_list, c->st_row_cap);
     dim3 grid((c->slots_per_image + ST_WAVES - 1) / ST_WAVES, n_pairs);
     hipLaunchKernelGGL(k_stereo, grid, dim3(64 * ST_WAVES), 0, c->stream, c->d_pyr, c->image_slab, c->lt, c->d_kpts, c->d_desc,
                        c->d_kp_count, c->slots_per_image, left0, right0, stride, fxb, max_disp, c->d_stereo, c->d_stereo_idx,
-                       c->d_stereo_corr);
+                       c->d_stereo_corr, c->d_st_row_start, c->d_st_row_list, c->st_row_cap);
     hipLaunchKernelGGL(k_stereo_median, dim3(n_pairs), dim3(1024), 0, c->stream, c->d_kp_count,
                        c->slots_per_image, left0, stride, c->d_stereo, c->d_stereo_corr);
     LP_HIP(hipGetLastError());
