@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One-off randomised parity sweep on a GPU box (not part of the test suite): random image sizes, keypoint budgets, level
-counts, scale factors and FAST thresholds; ORB extraction, stereo and brute-force matching against the CPU oracle, bit for bit.
+counts, scale factors and FAST thresholds; ORB extraction, brute-force and stereo matching against the CPU oracle, bit for bit.
 usage: fuzz_parity.py [n_cases] [seed]"""
 import os, sys, time
 import numpy as np
@@ -44,6 +44,15 @@ for case in range(n_cases):
             gq, gt, gdist = ctx.bf_matches(0, 1, 64, 0.8, True)
             oq, ot, odist = O.match_bf(gd, d1, 64, 0.8, True)
             ok = ok and np.array_equal(gq, oq) and np.array_equal(gt, ot) and np.array_equal(gdist, odist)
+        # stereo: image 1 is image 0 shifted 3 px to the left, so disparities of 3 px exist; oracle on its own extraction of both
+        right_img = np.roll(img, -3, axis=1)
+        rkp, rd, _, rpyr = O.extract(right_img, p, True)
+        fxb, base = 40.0 * w / 640.0, 0.1
+        if len(okp) and len(rkp):
+            oxr, odep, obi, _ = O.match_stereo(opyr, rpyr, p, okp, od, rkp, rd, fxb, base)
+            ctx.match_stereo(0, 1, fxb, base)
+            gxr, gdep, gbi = ctx.stereo(0)
+            ok = ok and np.array_equal(gxr, oxr) and np.array_equal(gdep, odep) and np.array_equal(gbi, obi)
         print(("ok   " if ok else "FAIL ") + tag + "  -> %d keypoints" % len(gkp), flush=True)
         bad += not ok
         del ctx
