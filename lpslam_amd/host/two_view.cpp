@@ -1,0 +1,488 @@
+// two_view.cpp -- see two_view.h
+#include "two_view.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+namespace LpSlam {
+
+namespace {
+
+struct M3 { double m[9]; };
+
+inline M3 mul(const M3& a, const M3& b)
+{
+    M3 r;
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) r.m[i * 3 + j] = a.m[i * 3] * b.m[j] + a.m[i * 3 + 1] * b.m[3 + j] + a.m[i * 3 + 2] * b.m[6 + j];
+    return r;
+}
+inline M3 transpose(const M3& a) { M3 r; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) r.m[i * 3 + j] = a.m[j * 3 + i]; return r; }
+inline double det(const M3& a)
+{
+    return a.m[0] * (a.m[4] * a.m[8] - a.m[5] * a.m[7]) - a.m[1] * (a.m[3] * a.m[8] - a.m[5] * a.m[6]) + a.m[2] * (a.m[3] * a.m[7] - a.m[4] * a.m[6]);
+}
+inline M3 inverse(const M3& a)
+{
+    const double d = det(a), id = 1.0 / d;
+    M3 r;
+    r.m[0] = (a.m[4] * a.m[8] - a.m[5] * a.m[7]) * id; r.m[1] = (a.m[2] * a.m[7] - a.m[1] * a.m[8]) * id; r.m[2] = (a.m[1] * a.m[5] - a.m[2] * a.m[4]) * id;
+    r.m[3] = (a.m[5] * a.m[6] - a.m[3] * a.m[8]) * id; r.m[4] = (a.m[0] * a.m[8] - a.m[2] * a.m[6]) * id; r.m[5] = (a.m[2] * a.m[3] - a.m[0] * a.m[5]) * id;
+    r.m[6] = (a.m[3] * a.m[7] - a.m[4] * a.m[6]) * id; r.m[7] = (a.m[1] * a.m[6] - a.m[0] * a.m[7]) * id; r.m[8] = (a.m[0] * a.m[4] - a.m[1] * a.m[3]) * id;
+    return r;
+}
+
+// M = U diag(s) V^T, s descending; U, V proper or improper as they come (callers fix signs)
+void svd3(const M3& M, M3& U, double* s, M3& V)
+{
+    const M3 MtM = mul(transpose(M), M);
+    double ev[3], evec[9];
+    sym_eigen_jacobi(MtM.m, 3, ev, evec);                       // ascending
+    for (int c = 0; c < 3; ++c) {
+        const int src = 2 - c;
+        s[c] = std::sqrt(std::max(ev[src], 0.0));
+        for (int r = 0; r < 3; ++r) V.m[r * 3 + c] = evec[r * 3 + src];
+    }
+    for (int c = 0; c < 2; ++c) {
+        double u[3] = {0, 0, 0};
+        for (int r = 0; r < 3; ++r) u[r] = M.m[r * 3] * V.m[c] + M.m[r * 3 + 1] * V.m[3 + c] + M.m[r * 3 + 2] * V.m[6 + c];
+        const double n = std::sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+        for (int r = 0; r < 3; ++r) U.m[r * 3 + c] = n > 0 ? u[r] / n : (r == c ? 1.0 : 0.0);
+    }
+    // second column re-orthogonalised against the first, third = first x second (valid for rank 2 and rank 3 alike up to sign)
+    double d01 = U.m[0] * U.m[1] + U.m[3] * U.m[4] + U.m[6] * U.m[7];
+    for (int r = 0; r < 3; ++r) U.m[r * 3 + 1] -= d01 * U.m[r * 3];
+    double n1 = std::sqrt(U.m[1] * U.m[1] + U.m[4] * U.m[4] + U.m[7] * U.m[7]);
+    for (int r = 0; r < 3; ++r) U.m[r * 3 + 1] /= n1;
+    U.m[2] = U.m[3] * U.m[7] - U.m[6] * U.m[4];
+    U.m[5] = U.m[6] * U.m[1] - U.m[0] * U.m[7];
+    U.m[8] = U.m[0] * U.m[4] - U.m[3] * U.m[1];
+    // sign of the third column such that M v3 = s3 u3 where s3 is not negligible
+    double mv[3];
+    for (int r = 0; r < 3; ++r) mv[r] = M.m[r * 3] * V.m[2] + M.m[r * 3 + 1] * V.m[5] + M.m[r * 3 + 2] * V.m[8];
+    if (mv[0] * U.m[2] + mv[1] * U.m[5] + mv[2] * U.m[8] < 0) for (int r = 0; r < 3; ++r) U.m[r * 3 + 2] = -U.m[r * 3 + 2];
+}
+
+// Hartley normalisation as ORB-SLAM / OpenVSLAM do it: centroid to the origin, mean absolute deviation 1 per axis
+void normalize_points(const std::vector<double>& in, std::vector<double>& out, M3& T)
+{
+    const size_t n = in.size() / 2;
+    double mx = 0, my = 0;
+    for (size_t i = 0; i < n; ++i) { mx += in[2 * i]; my += in[2 * i + 1]; }
+    mx /= (double)n; my /= (double)n;
+    double dx = 0, dy = 0;
+    out.resize(in.size());
+    for (size_t i = 0; i < n; ++i) { out[2 * i] = in[2 * i] - mx; out[2 * i + 1] = in[2 * i + 1] - my; dx += std::fabs(out[2 * i]); dy += std::fabs(out[2 * i + 1]); }
+    dx /= (double)n; dy /= (double)n;
+    const double sx = 1.0 / dx, sy = 1.0 / dy;
+    for (size_t i = 0; i < n; ++i) { out[2 * i] *= sx; out[2 * i + 1] *= sy; }
+    T = M3{{sx, 0, -mx * sx, 0, sy, -my * sy, 0, 0, 1}};
+}
+
+struct Rng {
+    uint32_t s;
+    uint32_t next() { s ^= s << 13; s ^= s >> 17; s ^= s << 5; return s; }
+};
+
+double check_homography(const M3& H21, const M3& H12, const std::vector<double>& p1, const std::vector<double>& p2, double sigma, std::vector<uint8_t>& inl)
+{
+    const size_t n = p1.size() / 2;
+    const double th = 5.991, inv_s2 = 1.0 / (sigma * sigma);
+    double score = 0;
+    inl.assign(n, 0);
+    for (size_t i = 0; i < n; ++i) {
+        const double u1 = p1[2 * i], v1 = p1[2 * i + 1], u2 = p2[2 * i], v2 = p2[2 * i + 1];
+        bool in = true;
+        {   // second image point into the first
+            const double w = 1.0 / (H12.m[6] * u2 + H12.m[7] * v2 + H12.m[8]);
+            const double x = (H12.m[0] * u2 + H12.m[1] * v2 + H12.m[2]) * w, y = (H12.m[3] * u2 + H12.m[4] * v2 + H12.m[5]) * w;
+            const double c = ((u1 - x) * (u1 - x) + (v1 - y) * (v1 - y)) * inv_s2;
+            if (c > th) in = false; else score += th - c;
+        }
+        {   // first image point into the second
+            const double w = 1.0 / (H21.m[6] * u1 + H21.m[7] * v1 + H21.m[8]);
+            const double x = (H21.m[0] * u1 + H21.m[1] * v1 + H21.m[2]) * w, y = (H21.m[3] * u1 + H21.m[4] * v1 + H21.m[5]) * w;
+            const double c = ((u2 - x) * (u2 - x) + (v2 - y) * (v2 - y)) * inv_s2;
+            if (c > th) in = false; else score += th - c;
+        }
+        inl[i] = in ? 1 : 0;
+    }
+    return score;
+}
+
+double check_fundamental(const M3& F21, const std::vector<double>& p1, const std::vector<double>& p2, double sigma, std::vector<uint8_t>& inl)
+{
+    const size_t n = p1.size() / 2;
+    const double th = 3.841, th_score = 5.991, inv_s2 = 1.0 / (sigma * sigma);
+    double score = 0;
+    inl.assign(n, 0);
+    for (size_t i = 0; i < n; ++i) {
+        const double u1 = p1[2 * i], v1 = p1[2 * i + 1], u2 = p2[2 * i], v2 = p2[2 * i + 1];
+        bool in = true;
+        {   // epipolar line of x1 in the second image: l2 = F21 x1
+            const double a = F21.m[0] * u1 + F21.m[1] * v1 + F21.m[2], b = F21.m[3] * u1 + F21.m[4] * v1 + F21.m[5], c = F21.m[6] * u1 + F21.m[7] * v1 + F21.m[8];
+            const double num = a * u2 + b * v2 + c;
+            const double chi = num * num / (a * a + b * b) * inv_s2;
+            if (chi > th) in = false; else score += th_score - chi;
+        }
+        {   // epipolar line of x2 in the first image: l1 = F21^T x2
+            const double a = F21.m[0] * u2 + F21.m[3] * v2 + F21.m[6], b = F21.m[1] * u2 + F21.m[4] * v2 + F21.m[7], c = F21.m[2] * u2 + F21.m[5] * v2 + F21.m[8];
+            const double num = a * u1 + b * v1 + c;
+            const double chi = num * num / (a * a + b * b) * inv_s2;
+            if (chi > th) in = false; else score += th_score - chi;
+        }
+        inl[i] = in ? 1 : 0;
+    }
+    return score;
+}
+
+struct Hypothesis { M3 R; double t[3]; };
+
+// triangulates the inlier matches under (R, t), counts the plausible ones (ORB-SLAM CheckRT / OpenVSLAM check_triangulated_pts)
+int check_pose(const Hypothesis& h, const double* K, const std::vector<double>& p1, const std::vector<double>& p2, const std::vector<uint8_t>& inl,
+               double th2, std::vector<double>& pts, std::vector<uint8_t>& good, double& parallax_deg)
+{
+    const double fx = K[0], fy = K[1], cx = K[2], cy = K[3];
+    const size_t n = p1.size() / 2;
+    double P1[12] = {fx, 0, cx, 0, 0, fy, cy, 0, 0, 0, 1, 0}, P2[12];
+    for (int c = 0; c < 3; ++c) {
+        P2[c] = fx * h.R.m[c] + cx * h.R.m[6 + c]; P2[4 + c] = fy * h.R.m[3 + c] + cy * h.R.m[6 + c]; P2[8 + c] = h.R.m[6 + c];
+    }
+    P2[3] = fx * h.t[0] + cx * h.t[2]; P2[7] = fy * h.t[1] + cy * h.t[2]; P2[11] = h.t[2];
+    const double O2[3] = {-(h.R.m[0] * h.t[0] + h.R.m[3] * h.t[1] + h.R.m[6] * h.t[2]), -(h.R.m[1] * h.t[0] + h.R.m[4] * h.t[1] + h.R.m[7] * h.t[2]),
+                          -(h.R.m[2] * h.t[0] + h.R.m[5] * h.t[1] + h.R.m[8] * h.t[2])};
+    pts.assign(3 * n, std::numeric_limits<double>::quiet_NaN());
+    good.assign(n, 0);
+    std::vector<double> cosines;
+    int n_good = 0;
+    for (size_t i = 0; i < n; ++i) {
+        if (!inl[i]) continue;
+        double X[3];
+        if (!triangulate_point(P1, P2, &p1[2 * i], &p2[2 * i], X)) continue;
+        if (!std::isfinite(X[0]) || !std::isfinite(X[1]) || !std::isfinite(X[2])) continue;
+        const double n1 = std::sqrt(X[0] * X[0] + X[1] * X[1] + X[2] * X[2]);
+        const double d2[3] = {X[0] - O2[0], X[1] - O2[1], X[2] - O2[2]};
+        const double n2 = std::sqrt(d2[0] * d2[0] + d2[1] * d2[1] + d2[2] * d2[2]);
+        const double cosp = (X[0] * d2[0] + X[1] * d2[1] + X[2] * d2[2]) / (n1 * n2);
+        if (X[2] <= 0 && cosp < 0.99998) continue;
+        const double X2[3] = {h.R.m[0] * X[0] + h.R.m[1] * X[1] + h.R.m[2] * X[2] + h.t[0], h.R.m[3] * X[0] + h.R.m[4] * X[1] + h.R.m[5] * X[2] + h.t[1],
+                              h.R.m[6] * X[0] + h.R.m[7] * X[1] + h.R.m[8] * X[2] + h.t[2]};
+        if (X2[2] <= 0 && cosp < 0.99998) continue;
+        const double e1x = fx * X[0] / X[2] + cx - p1[2 * i], e1y = fy * X[1] / X[2] + cy - p1[2 * i + 1];
+        if (e1x * e1x + e1y * e1y > th2) continue;
+        const double e2x = fx * X2[0] / X2[2] + cx - p2[2 * i], e2y = fy * X2[1] / X2[2] + cy - p2[2 * i + 1];
+        if (e2x * e2x + e2y * e2y > th2) continue;
+        cosines.push_back(cosp);
+        pts[3 * i] = X[0]; pts[3 * i + 1] = X[1]; pts[3 * i + 2] = X[2];
+        ++n_good;
+        if (cosp < 0.99998) good[i] = 1;
+    }
+    parallax_deg = 0;
+    if (!cosines.empty()) {
+        std::sort(cosines.begin(), cosines.end());
+        const size_t idx = std::min<size_t>(50, cosines.size() - 1);
+        parallax_deg = std::acos(std::min(1.0, std::max(-1.0, cosines[idx]))) * 180.0 / M_PI;
+    }
+    return n_good;
+}
+
+void hypotheses_from_fundamental(const M3& F21, const double* K, std::vector<Hypothesis>& out)
+{
+    const M3 Km{{K[0], 0, K[2], 0, K[1], K[3], 0, 0, 1}};
+    const M3 E = mul(mul(transpose(Km), F21), Km);
+    M3 U, V; double s[3];
+    svd3(E, U, s, V);
+    if (det(U) < 0) for (int r = 0; r < 3; ++r) U.m[r * 3 + 2] = -U.m[r * 3 + 2];
+    if (det(V) < 0) for (int r = 0; r < 3; ++r) V.m[r * 3 + 2] = -V.m[r * 3 + 2];
+    const M3 W{{0, -1, 0, 1, 0, 0, 0, 0, 1}};
+    M3 R1 = mul(mul(U, W), transpose(V)), R2 = mul(mul(U, transpose(W)), transpose(V));
+    if (det(R1) < 0) for (double& v : R1.m) v = -v;
+    if (det(R2) < 0) for (double& v : R2.m) v = -v;
+    double t[3] = {U.m[2], U.m[5], U.m[8]};
+    const double nt = std::sqrt(t[0] * t[0] + t[1] * t[1] + t[2] * t[2]);
+    for (double& v : t) v /= nt;
+    out.clear();
+    out.push_back({R1, {t[0], t[1], t[2]}}); out.push_back({R2, {t[0], t[1], t[2]}});
+    out.push_back({R1, {-t[0], -t[1], -t[2]}}); out.push_back({R2, {-t[0], -t[1], -t[2]}});
+}
+
+// Faugeras & Lustman, "Motion and structure from motion in a piecewise planar environment" (1988): 8 motion hypotheses
+bool hypotheses_from_homography(const M3& H21, const double* K, std::vector<Hypothesis>& out)
+{
+    const M3 Km{{K[0], 0, K[2], 0, K[1], K[3], 0, 0, 1}};
+    const M3 A = mul(mul(inverse(Km), H21), Km);
+    M3 U, V; double w[3];
+    svd3(A, U, w, V);
+    const double s = det(U) * det(V);
+    const double d1 = w[0], d2 = w[1], d3 = w[2];
+    out.clear();
+    if (d1 / d2 < 1.00001 || d2 / d3 < 1.00001) return false;
+    const double aux1 = std::sqrt((d1 * d1 - d2 * d2) / (d1 * d1 - d3 * d3)), aux3 = std::sqrt((d2 * d2 - d3 * d3) / (d1 * d1 - d3 * d3));
+    const double x1[4] = {aux1, aux1, -aux1, -aux1}, x3[4] = {aux3, -aux3, aux3, -aux3};
+    {   // d' = d2
+        const double aux_s = std::sqrt((d1 * d1 - d2 * d2) * (d2 * d2 - d3 * d3)) / ((d1 + d3) * d2);
+        const double ct = (d2 * d2 + d1 * d3) / ((d1 + d3) * d2);
+        const double st[4] = {aux_s, -aux_s, -aux_s, aux_s};
+        for (int i = 0; i < 4; ++i) {
+            const M3 Rp{{ct, 0, -st[i], 0, 1, 0, st[i], 0, ct}};
+            M3 R = mul(mul(U, Rp), transpose(V));
+            for (double& v : R.m) v *= s;
+            const double tp[3] = {x1[i] * (d1 - d3), 0, -x3[i] * (d1 - d3)};
+            double t[3];
+            for (int r = 0; r < 3; ++r) t[r] = U.m[r * 3] * tp[0] + U.m[r * 3 + 1] * tp[1] + U.m[r * 3 + 2] * tp[2];
+            const double nt = std::sqrt(t[0] * t[0] + t[1] * t[1] + t[2] * t[2]);
+            out.push_back({R, {t[0] / nt, t[1] / nt, t[2] / nt}});
+        }
+    }
+    {   // d' = -d2
+        const double aux_s = std::sqrt((d1 * d1 - d2 * d2) * (d2 * d2 - d3 * d3)) / ((d1 - d3) * d2);
+        const double cp = (d1 * d3 - d2 * d2) / ((d1 - d3) * d2);
+        const double sp[4] = {aux_s, -aux_s, -aux_s, aux_s};
+        for (int i = 0; i < 4; ++i) {
+            const M3 Rp{{cp, 0, sp[i], 0, -1, 0, sp[i], 0, -cp}};
+            M3 R = mul(mul(U, Rp), transpose(V));
+            for (double& v : R.m) v *= s;
+            const double tp[3] = {x1[i] * (d1 + d3), 0, x3[i] * (d1 + d3)};
+            double t[3];
+            for (int r = 0; r < 3; ++r) t[r] = U.m[r * 3] * tp[0] + U.m[r * 3 + 1] * tp[1] + U.m[r * 3 + 2] * tp[2];
+            const double nt = std::sqrt(t[0] * t[0] + t[1] * t[1] + t[2] * t[2]);
+            out.push_back({R, {t[0] / nt, t[1] / nt, t[2] / nt}});
+        }
+    }
+    return true;
+}
+
+}  // namespace
+
+void sym_eigen_jacobi(const double* A, int n, double* eigval, double* eigvec)
+{
+    std::vector<double> a(A, A + n * n), v((size_t)n * n, 0.0);
+    for (int i = 0; i < n; ++i) v[(size_t)i * n + i] = 1.0;
+    for (int sweep = 0; sweep < 64; ++sweep) {
+        double off = 0, diag = 0;
+        for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) (i == j ? diag : off) += a[(size_t)i * n + j] * a[(size_t)i * n + j];
+        if (off <= 1e-30 * (diag + 1e-300)) break;
+        for (int p = 0; p < n - 1; ++p) for (int q = p + 1; q < n; ++q) {
+            const double apq = a[(size_t)p * n + q];
+            if (apq == 0.0) continue;
+            const double theta = (a[(size_t)q * n + q] - a[(size_t)p * n + p]) / (2.0 * apq);
+            const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+            const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
+            for (int k = 0; k < n; ++k) {                   // columns p, q
+                const double akp = a[(size_t)k * n + p], akq = a[(size_t)k * n + q];
+                a[(size_t)k * n + p] = c * akp - s * akq; a[(size_t)k * n + q] = s * akp + c * akq;
+            }
+            for (int k = 0; k < n; ++k) {                   // rows p, q
+                const double apk = a[(size_t)p * n + k], aqk = a[(size_t)q * n + k];
+                a[(size_t)p * n + k] = c * apk - s * aqk; a[(size_t)q * n + k] = s * apk + c * aqk;
+            }
+            for (int k = 0; k < n; ++k) {
+                const double vkp = v[(size_t)k * n + p], vkq = v[(size_t)k * n + q];
+                v[(size_t)k * n + p] = c * vkp - s * vkq; v[(size_t)k * n + q] = s * vkp + c * vkq;
+            }
+        }
+    }
+    std::vector<int> order(n);
+    for (int i = 0; i < n; ++i) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](int x, int y) { return a[(size_t)x * n + x] < a[(size_t)y * n + y]; });
+    for (int c = 0; c < n; ++c) {
+        eigval[c] = a[(size_t)order[c] * n + order[c]];
+        for (int r = 0; r < n; ++r) eigvec[(size_t)r * n + c] = v[(size_t)r * n + order[c]];
+    }
+}
+
+void homography_from_matches(const double* x1, const double* x2, int n, double* H)
+{
+    double AtA[81] = {0};
+    for (int i = 0; i < n; ++i) {
+        const double u1 = x1[2 * i], v1 = x1[2 * i + 1], u2 = x2[2 * i], v2 = x2[2 * i + 1];
+        const double r1[9] = {0, 0, 0, -u1, -v1, -1, v2 * u1, v2 * v1, v2};
+        const double r2[9] = {u1, v1, 1, 0, 0, 0, -u2 * u1, -u2 * v1, -u2};
+        for (int a = 0; a < 9; ++a) for (int b = 0; b < 9; ++b) AtA[a * 9 + b] += r1[a] * r1[b] + r2[a] * r2[b];
+    }
+    double ev[9], evec[81];
+    sym_eigen_jacobi(AtA, 9, ev, evec);
+    for (int k = 0; k < 9; ++k) H[k] = evec[k * 9];
+}
+
+void fundamental_from_matches(const double* x1, const double* x2, int n, double* F)
+{
+    double AtA[81] = {0};
+    for (int i = 0; i < n; ++i) {
+        const double u1 = x1[2 * i], v1 = x1[2 * i + 1], u2 = x2[2 * i], v2 = x2[2 * i + 1];
+        const double r[9] = {u2 * u1, u2 * v1, u2, v2 * u1, v2 * v1, v2, u1, v1, 1};
+        for (int a = 0; a < 9; ++a) for (int b = 0; b < 9; ++b) AtA[a * 9 + b] += r[a] * r[b];
+    }
+    double ev[9], evec[81];
+    sym_eigen_jacobi(AtA, 9, ev, evec);
+    M3 Fp;
+    for (int k = 0; k < 9; ++k) Fp.m[k] = evec[k * 9];
+    // rank 2: F <- F (I - v3 v3^T), v3 the right singular vector of the smallest singular value
+    const M3 FtF = mul(transpose(Fp), Fp);
+    double e3[3], v3[9];
+    sym_eigen_jacobi(FtF.m, 3, e3, v3);
+    const double v[3] = {v3[0], v3[3], v3[6]};
+    for (int r = 0; r < 3; ++r) {
+        const double fv = Fp.m[r * 3] * v[0] + Fp.m[r * 3 + 1] * v[1] + Fp.m[r * 3 + 2] * v[2];
+        for (int c = 0; c < 3; ++c) F[r * 3 + c] = Fp.m[r * 3 + c] - fv * v[c];
+    }
+}
+
+bool triangulate_point(const double* P1, const double* P2, const double* x1, const double* x2, double* X)
+{
+    double A[16];
+    for (int c = 0; c < 4; ++c) {
+        A[c] = x1[0] * P1[8 + c] - P1[c];
+        A[4 + c] = x1[1] * P1[8 + c] - P1[4 + c];
+        A[8 + c] = x2[0] * P2[8 + c] - P2[c];
+        A[12 + c] = x2[1] * P2[8 + c] - P2[4 + c];
+    }
+    double AtA[16] = {0};
+    for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b) for (int r = 0; r < 4; ++r) AtA[a * 4 + b] += A[r * 4 + a] * A[r * 4 + b];
+    double ev[4], evec[16];
+    sym_eigen_jacobi(AtA, 4, ev, evec);
+    const double w = evec[12];
+    if (w == 0.0) return false;
+    X[0] = evec[0] / w; X[1] = evec[4] / w; X[2] = evec[8] / w;
+    return true;
+}
+
+bool two_view_initialize(const double* K, const float* kp_ref, const float* kp_cur, const int32_t* matches, int n_matches,
+                         const TwoViewParams& prm, TwoViewResult& out)
+{
+    out = TwoViewResult();
+    out.inlier.assign((size_t)std::max(n_matches, 0), 0);
+    out.triangulated.assign((size_t)std::max(n_matches, 0), 0);
+    out.points.assign(3 * (size_t)std::max(n_matches, 0), std::numeric_limits<double>::quiet_NaN());
+    if (n_matches < 8) return false;
+    const size_t n = (size_t)n_matches;
+    std::vector<double> p1(2 * n), p2(2 * n);
+    for (size_t i = 0; i < n; ++i) {
+        p1[2 * i] = kp_ref[2 * matches[2 * i]]; p1[2 * i + 1] = kp_ref[2 * matches[2 * i] + 1];
+        p2[2 * i] = kp_cur[2 * matches[2 * i + 1]]; p2[2 * i + 1] = kp_cur[2 * matches[2 * i + 1] + 1];
+    }
+    std::vector<double> n1, n2;
+    M3 T1, T2;
+    normalize_points(p1, n1, T1);
+    normalize_points(p2, n2, T2);
+    const M3 T2inv = inverse(T2), T2t = transpose(T2);
+
+    // the same 8-match samples serve both models (ORB-SLAM draws them once); sampling without replacement
+    Rng rng{prm.seed ? prm.seed : 1u};
+    std::vector<uint8_t> inl, best_inl_h(n, 0), best_inl_f(n, 0);
+    double best_h = -1, best_f = -1;
+    M3 best_H{}, best_F{};
+    std::vector<int> avail(n);
+    for (int it = 0; it < prm.ransac_iters; ++it) {
+        for (size_t i = 0; i < n; ++i) avail[i] = (int)i;
+        double s1[16], s2[16];
+        size_t left = n;
+        for (int k = 0; k < 8; ++k) {
+            const size_t r = rng.next() % left;
+            const int idx = avail[r];
+            avail[r] = avail[left - 1]; --left;
+            s1[2 * k] = n1[2 * idx]; s1[2 * k + 1] = n1[2 * idx + 1]; s2[2 * k] = n2[2 * idx]; s2[2 * k + 1] = n2[2 * idx + 1];
+        }
+        M3 Hn, Fn;
+        homography_from_matches(s1, s2, 8, Hn.m);
+        fundamental_from_matches(s1, s2, 8, Fn.m);
+        const M3 H21 = mul(mul(T2inv, Hn), T1);
+        const M3 F21 = mul(mul(T2t, Fn), T1);
+        if (std::fabs(det(H21)) > 1e-300) {
+            const double sh = check_homography(H21, inverse(H21), p1, p2, prm.sigma, inl);
+            if (sh > best_h) { best_h = sh; best_H = H21; best_inl_h = inl; }
+        }
+        const double sf = check_fundamental(F21, p1, p2, prm.sigma, inl);
+        if (sf > best_f) { best_f = sf; best_F = F21; best_inl_f = inl; }
+    }
+    // [UPSTREAM] find_via_ransac(..., recompute = true): the best model of each kind is estimated again from all its inliers
+    // (normalised coordinates) and its inliers and score are taken from that estimate
+    auto gather = [&](const std::vector<uint8_t>& mask, std::vector<double>& a, std::vector<double>& b) {
+        a.clear(); b.clear();
+        for (size_t i = 0; i < n; ++i) if (mask[i]) { a.push_back(n1[2 * i]); a.push_back(n1[2 * i + 1]); b.push_back(n2[2 * i]); b.push_back(n2[2 * i + 1]); }
+    };
+    std::vector<double> ga, gb;
+    if (best_h >= 0) {
+        gather(best_inl_h, ga, gb);
+        if (ga.size() >= 16) {
+            M3 Hn; homography_from_matches(ga.data(), gb.data(), (int)(ga.size() / 2), Hn.m);
+            const M3 H21 = mul(mul(T2inv, Hn), T1);
+            if (std::fabs(det(H21)) > 1e-300) { best_h = check_homography(H21, inverse(H21), p1, p2, prm.sigma, inl); best_H = H21; best_inl_h = inl; }
+        }
+    }
+    if (best_f >= 0) {
+        gather(best_inl_f, ga, gb);
+        if (ga.size() >= 16) {
+            M3 Fn; fundamental_from_matches(ga.data(), gb.data(), (int)(ga.size() / 2), Fn.m);
+            const M3 F21 = mul(mul(T2t, Fn), T1);
+            best_f = check_fundamental(F21, p1, p2, prm.sigma, inl); best_F = F21; best_inl_f = inl;
+        }
+    }
+    out.score_h = std::max(best_h, 0.0); out.score_f = std::max(best_f, 0.0);
+    std::memcpy(out.H, best_H.m, sizeof(out.H)); std::memcpy(out.F, best_F.m, sizeof(out.F));
+    if (out.score_h + out.score_f <= 0) return false;
+    const bool use_h = out.score_h / (out.score_h + out.score_f) > 0.40;
+    out.model = use_h ? 0 : 1;
+    const std::vector<uint8_t>& model_inl = use_h ? best_inl_h : best_inl_f;
+    out.inlier = model_inl;
+    out.n_inliers = (int)std::count(model_inl.begin(), model_inl.end(), (uint8_t)1);
+
+    std::vector<Hypothesis> hyps;
+    if (use_h) { if (!hypotheses_from_homography(best_H, K, hyps)) return false; }
+    else hypotheses_from_fundamental(best_F, K, hyps);
+
+    const double th2 = prm.reproj_err_thr * prm.sigma * prm.sigma;       // ORB-SLAM: 4 sigma^2
+    int best_good = 0, second_good = 0, best_i = -1;
+    double best_parallax = 0;
+    std::vector<double> pts, best_pts;
+    std::vector<uint8_t> good, best_goodmask;
+    for (size_t i = 0; i < hyps.size(); ++i) {
+        double parallax = 0;
+        const int ng = check_pose(hyps[i], K, p1, p2, model_inl, th2, pts, good, parallax);
+        if (ng > best_good) { second_good = best_good; best_good = ng; best_i = (int)i; best_parallax = parallax; best_pts = pts; best_goodmask = good; }
+        else if (ng > second_good) second_good = ng;
+    }
+    out.n_valid = best_good; out.parallax_deg = best_parallax;
+    // one clear winner with enough plausible points and enough parallax ([UPSTREAM] initialize::base::find_most_plausible_pose)
+    const int min_valid = std::max(prm.min_triangulated, (int)(0.9 * out.n_inliers));
+    if (best_i < 0 || best_good < min_valid) return false;
+    if ((double)second_good > 0.8 * (double)best_good) return false;
+    if (best_parallax < prm.parallax_deg_thr) return false;
+    std::memcpy(out.R, hyps[(size_t)best_i].R.m, sizeof(out.R));
+    std::memcpy(out.t, hyps[(size_t)best_i].t, sizeof(out.t));
+    out.points = best_pts; out.triangulated = best_goodmask;
+    out.ok = true;
+    return true;
+}
+
+}  // namespace LpSlam
+
+// ---- C shim for the ctypes tests ------------------------------------------------------------------------------------------
+extern "C" {
+__attribute__((visibility("default"))) int lpslam_two_view_initialize(const double* K, const float* kp_ref, const float* kp_cur, const int32_t* matches,
+                                                                        int n_matches, double sigma, int ransac_iters, uint32_t seed,
+                                                                        double* R9, double* t3, double* H9, double* F9, double* scores2, double* parallax_deg,
+                                                                        int32_t* model, uint8_t* inlier, uint8_t* triangulated, double* points3)
+{
+    LpSlam::TwoViewParams prm;
+    prm.sigma = sigma; prm.ransac_iters = ransac_iters; prm.seed = seed;
+    LpSlam::TwoViewResult res;
+    const bool ok = LpSlam::two_view_initialize(K, kp_ref, kp_cur, matches, n_matches, prm, res);
+    if (R9) std::memcpy(R9, res.R, sizeof(res.R));
+    if (t3) std::memcpy(t3, res.t, sizeof(res.t));
+    if (H9) std::memcpy(H9, res.H, sizeof(res.H));
+    if (F9) std::memcpy(F9, res.F, sizeof(res.F));
+    if (scores2) { scores2[0] = res.score_h; scores2[1] = res.score_f; }
+    if (parallax_deg) *parallax_deg = res.parallax_deg;
+    if (model) *model = res.model;
+    for (int i = 0; i < n_matches; ++i) {
+        if (inlier) inlier[i] = res.inlier.size() > (size_t)i ? res.inlier[(size_t)i] : 0;
+        if (triangulated) triangulated[i] = res.triangulated.size() > (size_t)i ? res.triangulated[(size_t)i] : 0;
+        if (points3) for (int c = 0; c < 3; ++c) points3[3 * i + c] = res.points.size() > (size_t)(3 * i + c) ? res.points[(size_t)(3 * i + c)] : 0.0;
+    }
+    return ok ? 1 : 0;
+}
+
+__attribute__((visibility("default"))) void lpslam_sym_eigen(const double* A, int n, double* eigval, double* eigvec) { LpSlam::sym_eigen_jacobi(A, n, eigval, eigvec); }
+}

@@ -1,0 +1,49 @@
+// two_view.h -- monocular map initialisation from two views (host, init only).
+// What openvslam::system does inside feed_monocular_frame until a map exists (reference call site:
+// /root/reference/src/Trackers/OpenVSLAMTracker.cpp:120; parameters of the generated configuration,
+// src/Trackers/OpenVSLAMTrackerBase.cpp:161-201): [UPSTREAM] initialize::perspective -- homography and fundamental matrix by
+// RANSAC over 8-match samples on Hartley-normalised keypoints (solve::homography_solver / solve::fundamental_solver), model
+// choice by the score ratio (H if S_H / (S_H + S_F) > 0.40), motion hypotheses from the chosen model (4 from E = K^T F K, 8 from
+// H by Faugeras' decomposition), linear triangulation of the inlier matches and the plausibility test of
+// initialize::base::find_most_plausible_pose (positive depth, reprojection error, parallax, one clear winner).
+// The upstream sources are absent from the reference tree; this restates the published algorithm (ORB-SLAM's Initializer, which
+// OpenVSLAM follows) in FP64 with a deterministic sampler.  `oracle/two_view.py` is the numpy restatement the tests compare with.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+namespace LpSlam {
+
+struct TwoViewParams {
+    double sigma = 1.0;                  // keypoint standard deviation in pixels (level 0)
+    int ransac_iters = 100;              // Initializer.num_ransac_iterations
+    int min_triangulated = 50;           // Initializer.num_min_triangulated_pts
+    double parallax_deg_thr = 1.0;       // Initializer.parallax_deg_threshold
+    double reproj_err_thr = 4.0;         // Initializer.reprojection_error_threshold
+    uint32_t seed = 0x9E3779B9u;         // sampler (xorshift32); upstream seeds from std::random_device
+};
+
+struct TwoViewResult {
+    bool ok = false;
+    int model = -1;                      // 0 = homography, 1 = fundamental matrix
+    double score_h = 0, score_f = 0;
+    double H[9] = {0}, F[9] = {0};       // reference -> current, row-major
+    double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, t[3] = {0, 0, 0};     // reference -> current (|t| = 1)
+    double parallax_deg = 0;
+    int n_inliers = 0, n_valid = 0;
+    std::vector<uint8_t> inlier;         // per match: inlier of the chosen model
+    std::vector<uint8_t> triangulated;   // per match: landmark accepted
+    std::vector<double> points;          // per match: X Y Z in the reference camera frame (valid where triangulated)
+};
+
+// K = (fx, fy, cx, cy), shared by both views; keypoints (x, y) in pixels; matches = (index in ref, index in cur) pairs
+bool two_view_initialize(const double* K, const float* kp_ref, const float* kp_cur, const int32_t* matches, int n_matches,
+                         const TwoViewParams& prm, TwoViewResult& out);
+
+// building blocks (exposed for the tests)
+void sym_eigen_jacobi(const double* A, int n, double* eigval, double* eigvec);        // A symmetric n x n; eigvec columns, ascending eigval
+void homography_from_matches(const double* x1, const double* x2, int n, double* H);   // DLT, x2 ~ H x1 (already normalised points)
+void fundamental_from_matches(const double* x1, const double* x2, int n, double* F);  // 8-point + rank 2, x2^T F x1 = 0
+bool triangulate_point(const double* P1, const double* P2, const double* x1, const double* x2, double* X);
+
+}  // namespace LpSlam

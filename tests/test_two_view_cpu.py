@@ -1,0 +1,127 @@
+"""CPU tests of the monocular two-view initialisation (lpslam_amd/host/two_view.cpp through its C shim) against the numpy
+restatement (oracle/two_view.py) and against the synthetic ground truth.  [UPSTREAM] initialize::perspective; reference call site
+src/Trackers/OpenVSLAMTracker.cpp:120 (feed_monocular_frame)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+K = np.array([525.0, 525.0, 320.0, 240.0])
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from lpslam_amd import _build
+    l = C.CDLL(_build.host_library())
+    l.lpslam_two_view_initialize.restype = C.c_int
+    l.lpslam_two_view_initialize.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_uint32] + [C.c_void_p] * 10
+    return l
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _rot(axis, ang):
+    axis = np.asarray(axis, float) / np.linalg.norm(axis)
+    kx = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+    return np.eye(3) + np.sin(ang) * kx + (1 - np.cos(ang)) * kx @ kx
+
+
+def scene(n=300, planar=False, seed=0, r=None, t=None, noise=0.3, outliers=0.0, slope=(0.25, -0.1)):
+    rng = np.random.default_rng(seed)
+    r = _rot([0.1, 1.0, 0.2], 0.06) if r is None else r
+    t = np.array([-0.4, 0.05, 0.1]) if t is None else np.asarray(t, float)
+    x = np.column_stack([rng.uniform(-3, 3, n), rng.uniform(-2, 2, n), rng.uniform(4, 9, n)])
+    if planar:
+        x[:, 2] = 6.0 + slope[0] * x[:, 0] + slope[1] * x[:, 1]
+    x2 = x @ r.T + t
+    p1 = np.column_stack([K[0] * x[:, 0] / x[:, 2] + K[2], K[1] * x[:, 1] / x[:, 2] + K[3]]) + rng.normal(0, noise, (n, 2))
+    p2 = np.column_stack([K[0] * x2[:, 0] / x2[:, 2] + K[2], K[1] * x2[:, 1] / x2[:, 2] + K[3]]) + rng.normal(0, noise, (n, 2))
+    bad = rng.random(n) < outliers
+    p2[bad] = np.column_stack([rng.uniform(0, 640, bad.sum()), rng.uniform(0, 480, bad.sum())])
+    perm = rng.permutation(n)                        # the current frame lists its keypoints in another order
+    kp_cur = np.zeros((n, 2), np.float32); kp_cur[perm] = p2
+    matches = np.column_stack([np.arange(n), perm]).astype(np.int32)
+    return p1.astype(np.float32), kp_cur, matches, r, t / np.linalg.norm(t), x, bad
+
+
+def run(lib, kp_ref, kp_cur, matches, sigma=1.0, iters=100, seed=12345):
+    n = len(matches)
+    out = dict(R=np.zeros(9), t=np.zeros(3), H=np.zeros(9), F=np.zeros(9), scores=np.zeros(2), par=C.c_double(), model=C.c_int32(),
+               inl=np.zeros(max(n, 1), np.uint8), tri=np.zeros(max(n, 1), np.uint8), pts=np.zeros((max(n, 1), 3)))
+    k = np.ascontiguousarray(K); a = np.ascontiguousarray(kp_ref, np.float32); b = np.ascontiguousarray(kp_cur, np.float32)
+    m = np.ascontiguousarray(matches, np.int32)
+    ok = lib.lpslam_two_view_initialize(_p(k), _p(a), _p(b), _p(m), n, sigma, iters, seed, _p(out["R"]), _p(out["t"]), _p(out["H"]), _p(out["F"]),
+                                        _p(out["scores"]), C.addressof(out["par"]), C.addressof(out["model"]), _p(out["inl"]), _p(out["tri"]), _p(out["pts"]))
+    out["ok"] = bool(ok); out["model"] = out["model"].value; out["par"] = out["par"].value
+    out["R"] = out["R"].reshape(3, 3)
+    return out
+
+
+def rot_angle(a, b):
+    return np.arccos(np.clip((np.trace(a.T @ b) - 1) / 2, -1, 1))
+
+
+def test_symmetric_eigen_solver(lib):
+    rng = np.random.default_rng(1)
+    for n in (3, 4, 9):
+        a = rng.normal(size=(n, n)); a = a @ a.T
+        ev = np.zeros(n); vec = np.zeros((n, n))
+        lib.lpslam_sym_eigen(_p(np.ascontiguousarray(a)), n, _p(ev), _p(vec))
+        w, _ = np.linalg.eigh(a)
+        assert np.allclose(ev, w, rtol=1e-12, atol=1e-12 * w.max())
+        assert np.allclose(a @ vec, vec * ev, atol=1e-10 * w.max()) and np.allclose(vec.T @ vec, np.eye(n), atol=1e-12)
+
+
+@pytest.mark.parametrize("planar,model", [(False, 1), (True, 0)])
+def test_general_and_planar_scene(lib, planar, model):
+    from oracle import two_view as O
+    if planar:      # a strongly tilted plane and a motion for which only one of Faugeras' solutions keeps the points in front
+        kp_ref, kp_cur, matches, r, t, x, _ = scene(planar=True, seed=21, r=_rot([0.1, 1.0, 0.2], 0.14), t=[-0.6, -0.34, 0.14], slope=(1.16, -0.82))
+    else:
+        kp_ref, kp_cur, matches, r, t, x, _ = scene(seed=2)
+    g = run(lib, kp_ref, kp_cur, matches)
+    o = O.initialize(K, kp_ref, kp_cur, matches, seed=12345)
+    assert g["ok"] and o["ok"] and g["model"] == o["model"] == model
+    # the two implementations agree ...
+    assert np.allclose(g["scores"], [o["score_h"], o["score_f"]], rtol=1e-6)
+    assert rot_angle(g["R"], o["R"]) < 1e-6 and np.abs(g["t"] - o["t"]).max() < 1e-6
+    assert np.array_equal(g["inl"].astype(bool), o["inlier"]) and np.array_equal(g["tri"].astype(bool), o["triangulated"])
+    ok = g["tri"].astype(bool)
+    assert np.allclose(g["pts"][ok], o["points"][ok], rtol=1e-6, atol=1e-6)
+    # ... and with the truth: rotation within 0.3 degrees, translation direction within 3 degrees, structure up to the scale |t|
+    assert rot_angle(g["R"], r) < np.radians(0.3)
+    assert np.arccos(np.clip(g["t"] @ t, -1, 1)) < np.radians(3.0)
+    assert ok.sum() > 0.9 * len(matches)
+    scale = np.median(x[ok][:, 2] / g["pts"][ok][:, 2])
+    err = np.linalg.norm(g["pts"][ok] * scale - x[ok], axis=1)          # 0.3 px noise over a 0.4 / 6 baseline-to-depth ratio
+    assert np.median(err) < 0.1 and err.max() < 1.5
+    assert g["par"] > 1.0
+
+
+def test_outliers_are_left_out(lib):
+    from oracle import two_view as O
+    kp_ref, kp_cur, matches, r, t, x, bad = scene(n=400, seed=5, outliers=0.25)
+    g = run(lib, kp_ref, kp_cur, matches, iters=200)
+    o = O.initialize(K, kp_ref, kp_cur, matches, ransac_iters=200, seed=12345)
+    assert g["ok"] and o["ok"] and np.array_equal(g["inl"].astype(bool), o["inlier"])
+    inl = g["inl"].astype(bool)
+    assert inl[~bad].mean() > 0.9 and inl[bad].mean() < 0.1
+    assert rot_angle(g["R"], r) < np.radians(0.5)
+
+
+def test_rejections(lib):
+    from oracle import two_view as O
+    # a plane seen under a motion that leaves both of Faugeras' solutions plausible: no clear winner, both sides refuse
+    kp_ref, kp_cur, matches, *_ = scene(planar=True, seed=3)
+    g = run(lib, kp_ref, kp_cur, matches); o = O.initialize(K, kp_ref, kp_cur, matches, seed=12345)
+    assert g["model"] == o["model"] == 0 and not g["ok"] and not o["ok"] and g["par"] > 1.0
+    kp_ref, kp_cur, matches, *_ = scene(seed=7)
+    assert not run(lib, kp_ref, kp_cur, matches[:7])["ok"]                                # fewer than eight matches
+    # (nearly) no baseline: low parallax, no reconstruction
+    kp_ref, kp_cur, matches, *_ = scene(seed=8, t=[1e-4, 0, 0])
+    assert not run(lib, kp_ref, kp_cur, matches)["ok"]
+    # few points: below Initializer.num_min_triangulated_pts
+    kp_ref, kp_cur, matches, *_ = scene(n=30, seed=9)
+    assert not run(lib, kp_ref, kp_cur, matches)["ok"]
