@@ -7,7 +7,7 @@
 // H by Faugeras' decomposition), linear triangulation of the inlier matches and the plausibility test of
 // initialize::base::find_most_plausible_pose (positive depth, reprojection error, parallax, one clear winner).
 // The upstream sources are absent from the reference tree; this restates the published algorithm (ORB-SLAM's Initializer, which
-// OpenVSLAM follows) in FP64 with a deterministic sampler.  `oracle/two_view.py` is the numpy restatement the tests compare with.
+// OpenVSLAM follows) in FP64 with a deterministic sampler.
 #pragma once
 #include <cstdint>
 #include <vector>
