@@ -1,6 +1,7 @@
 // hip_tracker.cpp -- see hip_tracker.h.  Host-side tracking glue around the HIP C ABI (the arithmetic runs on the GPU).
 #include "hip_tracker.h"
 #include "rectify.h"
+#include "two_view.h"
 
 #include <algorithm>
 #include <cmath>
@@ -198,6 +199,25 @@ bool HipVslamTrackerBase::initializeMap(FrameData& f)
     return true;
 }
 
+// descriptor, viewing direction and valid distance range of the observation that creates a landmark ([UPSTREAM] data::landmark::
+// update_normal_and_depth / compute_descriptor, reference observation only)
+void HipVslamTrackerBase::initLandmarkView(Landmark& lm, const Pose& pose, const lpslam_hip_keypoint& kp, const uint8_t* desc32) const
+{
+    float scales[LPSLAM_HIP_MAX_LEVELS];
+    lpslam_hip_level_info(m_ctx, nullptr, nullptr, nullptr, nullptr, scales);
+    const Mat3 R = quatToRot(pose.q);
+    // camera centre C = -R^T t
+    const double C[3] = {-(R.m[0] * pose.t[0] + R.m[3] * pose.t[1] + R.m[6] * pose.t[2]), -(R.m[1] * pose.t[0] + R.m[4] * pose.t[1] + R.m[7] * pose.t[2]),
+                         -(R.m[2] * pose.t[0] + R.m[5] * pose.t[1] + R.m[8] * pose.t[2])};
+    const double ray[3] = {lm.p[0] - C[0], lm.p[1] - C[1], lm.p[2] - C[2]};
+    const double dist = std::sqrt(ray[0] * ray[0] + ray[1] * ray[1] + ray[2] * ray[2]);
+    for (int a = 0; a < 3; ++a) lm.normal[a] = dist > 0 ? ray[a] / dist : 0.0;
+    const int lvl = std::min(std::max(kp.octave, 0), m_numLevels - 1);
+    lm.max_valid = dist * scales[lvl];
+    lm.min_valid = lm.max_valid / scales[std::max(m_numLevels - 1, 0)];
+    std::copy(desc32, desc32 + 32, lm.desc);
+}
+
 void HipVslamTrackerBase::insertKeyframe(FrameData& f)
 {
     const double baseline = m_cam.focal_x_baseline / m_cam.f_x;
@@ -228,19 +248,7 @@ void HipVslamTrackerBase::insertKeyframe(FrameData& f)
             lm.p[0] = R.m[0] * d[0] + R.m[3] * d[1] + R.m[6] * d[2];
             lm.p[1] = R.m[1] * d[0] + R.m[4] * d[1] + R.m[7] * d[2];
             lm.p[2] = R.m[2] * d[0] + R.m[5] * d[1] + R.m[8] * d[2];
-            {
-                // camera centre C = -R^T t; viewing ray and valid distances of this (the reference) observation
-                const double C[3] = {-(R.m[0] * f.pose.t[0] + R.m[3] * f.pose.t[1] + R.m[6] * f.pose.t[2]),
-                                     -(R.m[1] * f.pose.t[0] + R.m[4] * f.pose.t[1] + R.m[7] * f.pose.t[2]),
-                                     -(R.m[2] * f.pose.t[0] + R.m[5] * f.pose.t[1] + R.m[8] * f.pose.t[2])};
-                const double ray[3] = {lm.p[0] - C[0], lm.p[1] - C[1], lm.p[2] - C[2]};
-                const double dist = std::sqrt(ray[0] * ray[0] + ray[1] * ray[1] + ray[2] * ray[2]);
-                for (int a = 0; a < 3; ++a) lm.normal[a] = dist > 0 ? ray[a] / dist : 0.0;
-                const int n_lv = m_numLevels;
-                lm.max_valid = dist * scales[f.kpts[i].octave];
-                lm.min_valid = lm.max_valid / scales[std::max(n_lv - 1, 0)];
-                std::copy(f.desc.begin() + 32 * i, f.desc.begin() + 32 * (i + 1), lm.desc);
-            }
+            initLandmarkView(lm, f.pose, f.kpts[i], f.desc.data() + 32 * i);
             id = m_nextLandmarkId++;
             m_landmarks[id] = lm;
             f.landmark[i] = id;
@@ -250,6 +258,10 @@ void HipVslamTrackerBase::insertKeyframe(FrameData& f)
             kf.obs.push_back({id, f.kpts[i].x, f.kpts[i].y, f.x_right[i] >= 0 ? (double)f.x_right[i] : -1.0, 1.0 / (s * s)});
             m_landmarks[id].n_obs++;
         }
+    }
+    if (!m_stereo) {
+        if (!m_keyframes.empty()) monoTriangulate(m_keyframes.back(), kf, f);
+        kf.kpts = f.kpts; kf.desc = f.desc; kf.landmark = f.landmark;
     }
     m_keyframes.push_back(std::move(kf));
     ++m_keyframeCount;
@@ -335,8 +347,8 @@ bool HipVslamTrackerBase::trackWithMotionModel(FrameData& cur, int& n_inliers)
         if (u < 0 || v < 0 || u >= m_cam.resolution_x || v >= m_cam.resolution_y) continue;
         const int lvl = m_prev.kpts[i].octave;
         lpslam_hip_proj_query e{};
-        e.x = (float)u; e.y = (float)v; e.x_right = (float)(u - m_cam.focal_x_baseline / pc[2]);
-        e.radius = 10.0f * scales[lvl];
+        e.x = (float)u; e.y = (float)v; e.x_right = m_stereo ? (float)(u - m_cam.focal_x_baseline / pc[2]) : -1.0f;
+        e.radius = (m_stereo ? 10.0f : 20.0f) * scales[lvl];       // match_current_and_last_frames: margin 10 (stereo) / 20 (monocular)
         e.min_level = std::max(0, lvl - 1); e.max_level = std::min(n_levels - 1, lvl + 1);
         q.push_back(e);
         qd.insert(qd.end(), m_prev.desc.begin() + 32 * i, m_prev.desc.begin() + 32 * (i + 1));
@@ -349,7 +361,7 @@ bool HipVslamTrackerBase::trackWithMotionModel(FrameData& cur, int& n_inliers)
     for (size_t i = 0; i < cur.kpts.size(); ++i) cur_angle[i] = cur.kpts[i].angle;
     int32_t n_m = 0;
     for (int attempt = 0; attempt < 2; ++attempt) {
-        if (lpslam_hip_match_projection(m_ctx, cur.slot, q.data(), qd.data(), (int32_t)q.size(), 100 /* HAMMING_DIST_THR_HIGH */, 1.0f, nullptr, 1,
+        if (lpslam_hip_match_projection(m_ctx, cur.slot, q.data(), qd.data(), (int32_t)q.size(), 100 /* HAMMING_DIST_THR_HIGH */, 1.0f, nullptr, m_stereo ? 1 : 0,
                                         idx.data(), dist.data(), &n_m) != LPSLAM_HIP_OK) return false;
         lpslam_hip_match_orientation_filter(q_angle.data(), cur_angle.data(), idx.data(), (int32_t)q.size(), &n_m);
         if (n_m >= 20) break;
@@ -401,7 +413,7 @@ bool HipVslamTrackerBase::trackLocalMap(FrameData& cur, int& n_inliers)
             if ((ray[0] * lm.normal[0] + ray[1] * lm.normal[1] + ray[2] * lm.normal[2]) / dist < 0.5) continue;    // viewing angle < 60 deg
             const int lvl = std::min(std::max((int)std::ceil(std::log(lm.max_valid / dist) / log_sf), 0), n_levels - 1);
             lpslam_hip_proj_query e{};
-            e.x = (float)u; e.y = (float)v; e.x_right = (float)(u - m_cam.focal_x_baseline / pc[2]);
+            e.x = (float)u; e.y = (float)v; e.x_right = m_stereo ? (float)(u - m_cam.focal_x_baseline / pc[2]) : -1.0f;
             e.radius = 5.0f * scales[lvl];
             e.min_level = std::max(0, lvl - 1); e.max_level = lvl;
             q.push_back(e);
@@ -412,7 +424,7 @@ bool HipVslamTrackerBase::trackLocalMap(FrameData& cur, int& n_inliers)
     if (!q.empty()) {
         std::vector<int32_t> idx(q.size()), dist(q.size());
         int32_t n_m = 0;
-        if (lpslam_hip_match_projection(m_ctx, cur.slot, q.data(), qd.data(), (int32_t)q.size(), 100 /* HAMMING_DIST_THR_HIGH */, 0.8f, taken.data(), 1,
+        if (lpslam_hip_match_projection(m_ctx, cur.slot, q.data(), qd.data(), (int32_t)q.size(), 100 /* HAMMING_DIST_THR_HIGH */, 0.8f, taken.data(), m_stereo ? 1 : 0,
                                         idx.data(), dist.data(), &n_m) != LPSLAM_HIP_OK) return false;
         for (size_t k = 0; k < q.size(); ++k) if (idx[k] >= 0) { cur.landmark[idx[k]] = q_lm[k]; ++n_new; }
     }
@@ -520,6 +532,206 @@ void HipVslamTrackerBase::applyMapping(const MappingJob& job)
     }
 }
 
+// ---- monocular initialisation ([UPSTREAM] module::initializer::initialize for Monocular setups) ---------------------------------
+// The first frame with enough keypoints becomes the reference.  Every later frame is matched against it in a 100-px window
+// around where each level-0 reference keypoint was last matched (match::area::match_in_consistent_area, Hamming <= 50, ratio 0.9,
+// orientation check); with fewer than 100 matches the reference is dropped.  Two-view geometry (two_view.h) decides whether the
+// pair has enough parallax; on success the map is the two keyframes and the triangulated landmarks, scaled to a median scene
+// depth of 1 and refined by a global bundle adjustment of 20 iterations.
+bool HipVslamTrackerBase::monoInitialize(FrameData& cur)
+{
+    const int n_cur = (int)cur.kpts.size();
+    if (!m_haveMonoRef) {
+        if (n_cur < 100) return false;
+        m_monoRef = cur; m_haveMonoRef = true;
+        m_monoPrevMatched.resize(2 * (size_t)n_cur);
+        for (int i = 0; i < n_cur; ++i) { m_monoPrevMatched[2 * i] = cur.kpts[i].x; m_monoPrevMatched[2 * i + 1] = cur.kpts[i].y; }
+        return false;
+    }
+    if (n_cur < 100) { m_haveMonoRef = false; return false; }
+    const FrameData& ref = m_monoRef;
+    std::vector<lpslam_hip_proj_query> q;
+    std::vector<uint8_t> qd;
+    std::vector<int> q_ref;
+    std::vector<float> q_angle;
+    for (size_t i = 0; i < ref.kpts.size(); ++i) {
+        if (ref.kpts[i].octave > 0) continue;
+        lpslam_hip_proj_query e{};
+        e.x = m_monoPrevMatched[2 * i]; e.y = m_monoPrevMatched[2 * i + 1]; e.x_right = -1.0f; e.radius = 100.0f;
+        e.min_level = 0; e.max_level = 0;
+        q.push_back(e);
+        qd.insert(qd.end(), ref.desc.begin() + 32 * i, ref.desc.begin() + 32 * (i + 1));
+        q_ref.push_back((int)i); q_angle.push_back(ref.kpts[i].angle);
+    }
+    if (q.size() < 100) { m_haveMonoRef = false; return false; }
+    std::vector<int32_t> idx(q.size()), dist(q.size());
+    int32_t n_m = 0;
+    if (lpslam_hip_match_area(m_ctx, cur.slot, q.data(), qd.data(), (int32_t)q.size(), 50 /* HAMMING_DIST_THR_LOW */, 0.9f, idx.data(), dist.data(), &n_m) != LPSLAM_HIP_OK) return false;
+    std::vector<float> cur_angle(cur.kpts.size());
+    for (size_t i = 0; i < cur.kpts.size(); ++i) cur_angle[i] = cur.kpts[i].angle;
+    lpslam_hip_match_orientation_filter(q_angle.data(), cur_angle.data(), idx.data(), (int32_t)q.size(), &n_m);
+    if (n_m < 100) { m_haveMonoRef = false; return false; }          // too few: a new reference with the next frame
+    std::vector<int32_t> matches;
+    for (size_t k = 0; k < q.size(); ++k) {
+        if (idx[k] < 0) continue;
+        matches.push_back(q_ref[k]); matches.push_back(idx[k]);
+        m_monoPrevMatched[2 * (size_t)q_ref[k]] = cur.kpts[idx[k]].x; m_monoPrevMatched[2 * (size_t)q_ref[k] + 1] = cur.kpts[idx[k]].y;
+    }
+    std::vector<float> kr(2 * ref.kpts.size()), kc(2 * cur.kpts.size());
+    for (size_t i = 0; i < ref.kpts.size(); ++i) { kr[2 * i] = ref.kpts[i].x; kr[2 * i + 1] = ref.kpts[i].y; }
+    for (size_t i = 0; i < cur.kpts.size(); ++i) { kc[2 * i] = cur.kpts[i].x; kc[2 * i + 1] = cur.kpts[i].y; }
+    const double K[4] = {m_cam.f_x, m_cam.f_y, m_cam.c_x, m_cam.c_y};
+    TwoViewParams prm;
+    TwoViewResult tv;
+    if (!two_view_initialize(K, kr.data(), kc.data(), matches.data(), (int)(matches.size() / 2), prm, tv)) return false;
+
+    // ---- the initial map: reference keyframe at the origin, current keyframe at (R, t), scale: median depth in the reference = 1
+    std::vector<double> depths;
+    for (size_t m = 0; m < tv.triangulated.size(); ++m) if (tv.triangulated[m]) depths.push_back(tv.points[3 * m + 2]);
+    if (depths.size() < 50) return false;
+    std::nth_element(depths.begin(), depths.begin() + depths.size() / 2, depths.end());
+    const double median = depths[depths.size() / 2];
+    if (!(median > 0)) return false;
+    const double inv = 1.0 / median;
+    if (m_mapThread.joinable()) finishMapping();
+    m_landmarks.clear(); m_keyframes.clear(); m_nextLandmarkId = 0;
+    FrameData reff = ref;
+    reff.pose = Pose();
+    reff.landmark.assign(reff.kpts.size(), -1);
+    Mat3 Rm; std::copy(tv.R, tv.R + 9, Rm.m);
+    rotToQuat(Rm, cur.pose.q);
+    for (int a = 0; a < 3; ++a) cur.pose.t[a] = tv.t[a] * inv;
+    cur.landmark.assign(cur.kpts.size(), -1);
+    float scales[LPSLAM_HIP_MAX_LEVELS];
+    lpslam_hip_level_info(m_ctx, nullptr, nullptr, nullptr, nullptr, scales);
+    Keyframe k0, k1;
+    k0.pose = reff.pose; k1.pose = cur.pose;
+    for (size_t m = 0; m < tv.triangulated.size(); ++m) {
+        if (!tv.triangulated[m]) continue;
+        const int ir = matches[2 * m], ic = matches[2 * m + 1];
+        Landmark lm;
+        for (int a = 0; a < 3; ++a) lm.p[a] = tv.points[3 * m + a] * inv;
+        initLandmarkView(lm, reff.pose, reff.kpts[ir], reff.desc.data() + 32 * (size_t)ir);
+        lm.n_obs = 2;
+        const int id = m_nextLandmarkId++;
+        m_landmarks[id] = lm;
+        reff.landmark[ir] = id; cur.landmark[ic] = id;
+        const double s0 = scales[reff.kpts[ir].octave], s1 = scales[cur.kpts[ic].octave];
+        k0.obs.push_back({id, reff.kpts[ir].x, reff.kpts[ir].y, -1.0, 1.0 / (s0 * s0)});
+        k1.obs.push_back({id, cur.kpts[ic].x, cur.kpts[ic].y, -1.0, 1.0 / (s1 * s1)});
+    }
+    k0.kpts = reff.kpts; k0.desc = reff.desc; k0.landmark = reff.landmark;
+    k1.kpts = cur.kpts; k1.desc = cur.desc; k1.landmark = cur.landmark;
+    m_keyframes.push_back(std::move(k0)); m_keyframes.push_back(std::move(k1));
+    m_keyframeCount += 2;
+    m_framesSinceKeyframe = 0;
+    // global bundle adjustment of the two-keyframe map (20 iterations, Huber), inline: nothing can be tracked before it
+    {
+        const bool keep_async = m_asyncMapping;
+        m_asyncMapping = false;
+        auto job = prepareMapping();
+        m_asyncMapping = keep_async;
+        if (job) {
+            lpslam_hip_ba_camera cam{m_cam.f_x, m_cam.f_y, m_cam.c_x, m_cam.c_y, 0.0, std::sqrt(5.991), std::sqrt(7.815)};
+            lpslam_hip_ba* ba = nullptr;
+            if (lpslam_hip_ba_create(m_ctx, job->poses.data(), job->fixed.data(), job->n_keyframes, job->pts.data(), (int32_t)job->ids.size(), job->obs.data(),
+                                     (int32_t)job->obs.size(), &cam, &ba) == LPSLAM_HIP_OK) {
+                int32_t done = 0;
+                job->solved = lpslam_hip_ba_optimize(ba, 1, 20, nullptr, &done) == LPSLAM_HIP_OK && lpslam_hip_ba_get(ba, job->poses.data(), job->pts.data()) == LPSLAM_HIP_OK;
+                lpslam_hip_ba_destroy(ba);
+                if (job->solved) applyMapping(*job);
+            }
+        }
+    }
+    cur.pose = m_keyframes.back().pose;
+    m_haveMonoRef = false;
+    logMessage(LpSlamLogLevel_Info, "VSLAM monocular map initialised: " + std::to_string(m_landmarks.size()) + " landmarks, model " + (tv.model == 0 ? "H" : "F"));
+    return m_landmarks.size() >= 50;
+}
+
+// New landmarks for a monocular keyframe: keypoints without a landmark are matched by descriptor against the previous keyframe's
+// (brute force on the device, mutual best, ratio 0.8), kept when they satisfy the epipolar constraint of the two poses, and
+// triangulated; the checks are upstream's (positive depth in both views, reprojection chi2 <= 5.991 per view, parallax, scale
+// consistency of the distances with the pyramid levels).
+void HipVslamTrackerBase::monoTriangulate(Keyframe& prev, Keyframe& kf, FrameData& f)
+{
+    if (prev.kpts.empty() || f.kpts.empty()) return;
+    const int scratch = f.slot ^ 1;                      // monocular frames use slots 0 / 2
+    if (lpslam_hip_set_descriptors(m_ctx, scratch, prev.desc.data(), (int32_t)prev.kpts.size()) != LPSLAM_HIP_OK) return;
+    if (lpslam_hip_match_bf(m_ctx, f.slot, scratch) != LPSLAM_HIP_OK) return;
+    std::vector<int32_t> mq(m_maxKp), mt(m_maxKp), md(m_maxKp);
+    int32_t nm = 0;
+    if (lpslam_hip_get_bf_matches(m_ctx, f.slot, scratch, 50, 0.8f, 1, mq.data(), mt.data(), md.data(), m_maxKp, &nm) != LPSLAM_HIP_OK) return;
+    float scales[LPSLAM_HIP_MAX_LEVELS];
+    lpslam_hip_level_info(m_ctx, nullptr, nullptr, nullptr, nullptr, scales);
+    const double fx = m_cam.f_x, fy = m_cam.f_y, cx = m_cam.c_x, cy = m_cam.c_y;
+    const Mat3 R1 = quatToRot(prev.pose.q), R2 = quatToRot(f.pose.q);
+    auto proj = [&](const Mat3& R, const double* t, double* P) {
+        for (int c = 0; c < 3; ++c) { P[c] = fx * R.m[c] + cx * R.m[6 + c]; P[4 + c] = fy * R.m[3 + c] + cy * R.m[6 + c]; P[8 + c] = R.m[6 + c]; }
+        P[3] = fx * t[0] + cx * t[2]; P[7] = fy * t[1] + cy * t[2]; P[11] = t[2];
+    };
+    double P1[12], P2[12];
+    proj(R1, prev.pose.t, P1); proj(R2, f.pose.t, P2);
+    auto centre = [](const Mat3& R, const double* t, double* C) { for (int a = 0; a < 3; ++a) C[a] = -(R.m[a] * t[0] + R.m[3 + a] * t[1] + R.m[6 + a] * t[2]); };
+    double C1[3], C2[3];
+    centre(R1, prev.pose.t, C1); centre(R2, f.pose.t, C2);
+    // relative pose prev -> cur and the fundamental matrix x2^T F x1 = 0
+    double R21[9], t21[3];
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) R21[r * 3 + c] = R2.m[r * 3] * R1.m[c * 3] + R2.m[r * 3 + 1] * R1.m[c * 3 + 1] + R2.m[r * 3 + 2] * R1.m[c * 3 + 2];
+    for (int r = 0; r < 3; ++r) t21[r] = f.pose.t[r] - (R21[r * 3] * prev.pose.t[0] + R21[r * 3 + 1] * prev.pose.t[1] + R21[r * 3 + 2] * prev.pose.t[2]);
+    const double tx[9] = {0, -t21[2], t21[1], t21[2], 0, -t21[0], -t21[1], t21[0], 0};
+    double E[9];
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) E[r * 3 + c] = tx[r * 3] * R21[c] + tx[r * 3 + 1] * R21[3 + c] + tx[r * 3 + 2] * R21[6 + c];
+    const double ratio_factor = 1.5 * m_scaleFactor;
+    int created = 0;
+    for (int k = 0; k < nm; ++k) {
+        const int ic = mq[k], ip = mt[k];
+        if (f.landmark[ic] >= 0 || prev.landmark[(size_t)ip] >= 0) continue;
+        const lpslam_hip_keypoint& k1 = prev.kpts[(size_t)ip]; const lpslam_hip_keypoint& k2 = f.kpts[(size_t)ic];
+        const double x1n[3] = {(k1.x - cx) / fx, (k1.y - cy) / fy, 1.0}, x2n[3] = {(k2.x - cx) / fx, (k2.y - cy) / fy, 1.0};
+        // epipolar line of x1 in the current image (normalised coordinates -> pixels: a / fx, b / fy)
+        const double l[3] = {E[0] * x1n[0] + E[1] * x1n[1] + E[2], E[3] * x1n[0] + E[4] * x1n[1] + E[5], E[6] * x1n[0] + E[7] * x1n[1] + E[8]};
+        const double num = l[0] * x2n[0] + l[1] * x2n[1] + l[2];
+        const double a = l[0] / fx, b = l[1] / fy;
+        const double s2 = scales[k2.octave] * scales[k2.octave];
+        if (num * num / (a * a + b * b) > 3.84 * s2) continue;
+        // parallax of the two rays (world frame)
+        double r1[3], r2[3];
+        for (int a2 = 0; a2 < 3; ++a2) { r1[a2] = R1.m[a2] * x1n[0] + R1.m[3 + a2] * x1n[1] + R1.m[6 + a2]; r2[a2] = R2.m[a2] * x2n[0] + R2.m[3 + a2] * x2n[1] + R2.m[6 + a2]; }
+        const double cosr = (r1[0] * r2[0] + r1[1] * r2[1] + r1[2] * r2[2]) / (std::sqrt(r1[0] * r1[0] + r1[1] * r1[1] + r1[2] * r1[2]) * std::sqrt(r2[0] * r2[0] + r2[1] * r2[1] + r2[2] * r2[2]));
+        if (!(cosr > 0 && cosr < 0.9998)) continue;
+        const double p1[2] = {k1.x, k1.y}, p2[2] = {k2.x, k2.y};
+        double X[3];
+        if (!triangulate_point(P1, P2, p1, p2, X)) continue;
+        const double Xc1[3] = {R1.m[0] * X[0] + R1.m[1] * X[1] + R1.m[2] * X[2] + prev.pose.t[0], R1.m[3] * X[0] + R1.m[4] * X[1] + R1.m[5] * X[2] + prev.pose.t[1],
+                               R1.m[6] * X[0] + R1.m[7] * X[1] + R1.m[8] * X[2] + prev.pose.t[2]};
+        const double Xc2[3] = {R2.m[0] * X[0] + R2.m[1] * X[1] + R2.m[2] * X[2] + f.pose.t[0], R2.m[3] * X[0] + R2.m[4] * X[1] + R2.m[5] * X[2] + f.pose.t[1],
+                               R2.m[6] * X[0] + R2.m[7] * X[1] + R2.m[8] * X[2] + f.pose.t[2]};
+        if (!(Xc1[2] > 0) || !(Xc2[2] > 0)) continue;
+        const double s1 = scales[k1.octave] * scales[k1.octave];
+        const double e1x = fx * Xc1[0] / Xc1[2] + cx - k1.x, e1y = fy * Xc1[1] / Xc1[2] + cy - k1.y;
+        if (e1x * e1x + e1y * e1y > 5.991 * s1) continue;
+        const double e2x = fx * Xc2[0] / Xc2[2] + cx - k2.x, e2y = fy * Xc2[1] / Xc2[2] + cy - k2.y;
+        if (e2x * e2x + e2y * e2y > 5.991 * s2) continue;
+        const double d1 = std::sqrt((X[0] - C1[0]) * (X[0] - C1[0]) + (X[1] - C1[1]) * (X[1] - C1[1]) + (X[2] - C1[2]) * (X[2] - C1[2]));
+        const double d2 = std::sqrt((X[0] - C2[0]) * (X[0] - C2[0]) + (X[1] - C2[1]) * (X[1] - C2[1]) + (X[2] - C2[2]) * (X[2] - C2[2]));
+        if (!(d1 > 0) || !(d2 > 0)) continue;
+        const double ratio_d = d2 / d1, ratio_o = (double)scales[k1.octave] / (double)scales[k2.octave];
+        if (ratio_d * ratio_factor < ratio_o || ratio_d > ratio_o * ratio_factor) continue;
+        Landmark lm;
+        lm.p[0] = X[0]; lm.p[1] = X[1]; lm.p[2] = X[2];
+        initLandmarkView(lm, f.pose, k2, f.desc.data() + 32 * (size_t)ic);
+        lm.n_obs = 2;
+        const int id = m_nextLandmarkId++;
+        m_landmarks[id] = lm;
+        f.landmark[ic] = id; prev.landmark[(size_t)ip] = id;
+        prev.obs.push_back({id, k1.x, k1.y, -1.0, 1.0 / s1});
+        kf.obs.push_back({id, k2.x, k2.y, -1.0, 1.0 / s2});
+        ++created;
+    }
+    (void)created;
+}
+
 void HipVslamTrackerBase::mappingLoop()
 {
     std::unique_lock<std::mutex> lk(m_mapMutex);
@@ -610,10 +822,11 @@ TrackerBase::ProcessImageResult HipVslamTrackerBase::trackFrame(CameraQueueEntry
     cur.x_right.resize(n); cur.depth.resize(n); cur.landmark.assign(n, -1);
     ++m_imageTracked;
 
-    if (!stereo) {
-        // monocular initialisation (two-view geometry) is outside the accelerated path: frames are extracted and matched, no pose yet
+    if (!stereo && m_state != TrackerState::Tracking) {
+        // monocular: no map until two views with enough parallax have been found
         m_state = TrackerState::Initializing;
-        if (m_havePrev) lpslam_hip_match_bf(m_ctx, cur.slot, m_prev.slot);
+        if (monoInitialize(cur)) m_state = TrackerState::Tracking;
+        m_haveVelocity = false;
         m_prev = std::move(cur); m_havePrev = true;
     } else if (m_state != TrackerState::Tracking) {
         m_state = TrackerState::Initializing;
@@ -642,6 +855,7 @@ TrackerBase::ProcessImageResult HipVslamTrackerBase::trackFrame(CameraQueueEntry
             m_prev = std::move(cur);
         } else {
             finishMapping();
+            m_haveMonoRef = false;
             m_state = TrackerState::Lost;
             logMessage(LpSlamLogLevel_Info, "VSLAM tracking lost; re-initialising from the next stereo frame");
             m_prev = std::move(cur);

@@ -49,7 +49,11 @@ protected:
         int slot = 0;
     };
     struct KeyframeObs { int landmark; double u, v, ur, inv_sigma2; };
-    struct Keyframe { Pose pose; std::vector<KeyframeObs> obs; };
+    struct Keyframe {
+        Pose pose; std::vector<KeyframeObs> obs;
+        // monocular only: what triangulating new landmarks against the next keyframe needs
+        std::vector<lpslam_hip_keypoint> kpts; std::vector<uint8_t> desc; std::vector<int> landmark;
+    };
     struct Landmark {
         double p[3]; int n_obs = 0;
         // what local-map tracking needs ([UPSTREAM] data::landmark): the descriptor, the viewing direction and the valid
@@ -67,6 +71,11 @@ protected:
     bool trackWithMotionModel(FrameData& cur, int& n_inliers);
     bool trackAgainstPrevious(FrameData& cur, int& n_inliers);
     bool trackLocalMap(FrameData& cur, int& n_inliers);
+    // monocular: map initialisation from two views ([UPSTREAM] module::initializer + initialize::perspective) and new landmarks
+    // by triangulation between consecutive keyframes ([UPSTREAM] mapping_module::create_new_landmarks, previous keyframe only)
+    bool monoInitialize(FrameData& cur);
+    void monoTriangulate(Keyframe& prev, Keyframe& kf, FrameData& f);
+    void initLandmarkView(Landmark& lm, const Pose& pose, const lpslam_hip_keypoint& kp, const uint8_t* desc32) const;
     void insertKeyframe(FrameData& f);
     // Local bundle adjustment of the keyframe window ([UPSTREAM] mapping_module -> optimize::local_bundle_adjuster).  As in the
     // reference it runs beside tracking: the window is copied when a keyframe is inserted, a mapping thread solves it on the GPU
@@ -117,6 +126,9 @@ protected:
     int m_nextLandmarkId = 0;
     std::deque<Keyframe> m_keyframes;
     long m_keyframeCount = 0;
+    FrameData m_monoRef;                              // monocular initialisation: the reference frame ...
+    bool m_haveMonoRef = false;
+    std::vector<float> m_monoPrevMatched;             // ... and where each of its keypoints was last matched (x, y)
     // the mapping thread (one per tracker, started with the context): a one-slot mailbox each way
     std::thread m_mapThread;
     std::mutex m_mapMutex;

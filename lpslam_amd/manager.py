@@ -146,6 +146,10 @@ class Manager:
                              1 if ros else 0, ROSTimestamp(int(ts_ns // 10**9), int(ts_ns)))
         return bool(self.lib.lpslam_manager_add_stereo_image(self.h, 0, int(ts_ns), left.ctypes.data, right.ctypes.data, C.byref(d)))
 
+    def add_image(self, ts_ns, img, camera=0, ros=True):
+        d = ImageDescription(0, FORMAT_8UC1, 0, img.shape[0], img.shape[1], img.size, 0, 1 if ros else 0, ROSTimestamp(int(ts_ns // 10**9), int(ts_ns)))
+        return bool(self.lib.lpslam_manager_add_image(self.h, camera, int(ts_ns), img.ctypes.data, C.byref(d)))
+
     def start(self):
         self.lib.lpslam_manager_start(self.h)
 

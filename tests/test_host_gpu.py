@@ -124,3 +124,62 @@ def test_local_map_tracking_brings_landmarks_back(hiplib):
     assert len(m.results) == len(frames) and all(r["valid"] for r in m.results)
     assert lib.lpslam_debug_local_map_joined() - joined0 >= 20
     assert abs(m.results[-1]["p"][2] - 0.05 * 5) < 0.05
+
+
+def test_monocular_sequence_initialises_and_tracks(hiplib):
+    """VSLAMMono through the manager: two-view initialisation ([UPSTREAM] initialize::perspective) on a sideways-moving camera,
+    then motion-model / local-map tracking and keyframes whose new landmarks are triangulated against the previous keyframe.
+    The map's scale is arbitrary (median depth 1), so the trajectory is checked in direction and proportion."""
+    from lpslam_amd import _build, manager
+    _build.host_library()
+    w, h, n_frames = 640, 480, 30
+    k = synth.intrinsics(w, h)
+    # three fronto-parallel textured walls at 6, 9 and 14 m, one per horizontal band of the image; the camera moves sideways, so
+    # every wall slides by f * dx / depth pixels per frame (whole pixels here) and descriptors do not change between frames
+    rng = np.random.default_rng(11)
+    depths = (14.0, 9.0, 6.0)
+    band_h = h // 3
+    margin = 400
+    walls = []
+    for _ in depths:
+        t = rng.integers(0, 256, (band_h, w + margin)).astype(np.float64)
+        t = (t + np.roll(t, 1, 0) + np.roll(t, 1, 1) + np.roll(t, (1, 1), (0, 1))) / 4.0          # 2x2 box: corners FAST still likes
+        walls.append(60 + (t - t.min()) * (150.0 / (t.max() - t.min())))
+    centres = [np.array([0.1 * i, 0.0, 0.0]) for i in range(n_frames)]
+
+    def render(cc, i):
+        img = np.zeros((h, w))
+        for b, (z, wall) in enumerate(zip(depths, walls)):
+            shift = int(round(k["fx"] * cc[0] / z))                       # the wall moves left as the camera moves right
+            img[b * band_h:(b + 1) * band_h] = wall[:, shift:shift + w]
+        img += np.random.Generator(np.random.PCG64([9, i])).normal(0, 1.0, img.shape)
+        return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+    frames = [render(cc, i) for i, cc in enumerate(centres)]
+    m = manager.Manager()
+    c = manager.default_camera()
+    c.camera_number = 0; c.f_x = k["fx"]; c.f_y = k["fy"]; c.c_x = k["cx"]; c.c_y = k["cy"]; c.resolution_x = w; c.resolution_y = h
+    m.set_camera(c)
+    assert m.add_tracker("VSLAMMono", '{"cameraSetup": "monocular", "slamKeypoints": 2000, "numLevels": 3, "keyframeInterval": 4}')
+    m.collect_results(); m.provide_odometry()
+    m.start()
+    for i, img in enumerate(frames):
+        assert m.add_image((i + 1) * 40_000_000, img)
+    t0 = time.time()
+    while len(m.results) < n_frames and time.time() - t0 < 60:
+        time.sleep(0.01)
+    st = m.status()
+    m.stop()
+    valid = [(i, r) for i, r in enumerate(m.results) if r["valid"]]
+    assert len(m.results) == n_frames and len(valid) >= n_frames - 12          # a few frames pass before the parallax suffices
+    assert st.localization == 2 and st.key_frames >= 4 and st.feature_points > 150
+    # lpslam axes: p_lp = (-y, x, z) of the optical-frame camera centre; the first valid pose defines origin and scale
+    i0, r0 = valid[0]; i1, r1 = valid[-1]
+    d = np.array(r1["p"]) - np.array(r0["p"])
+    truth = centres[i1] - centres[i0]
+    truth_lp = np.array([-truth[1], truth[0], truth[2]])
+    cosang = d @ truth_lp / (np.linalg.norm(d) * np.linalg.norm(truth_lp))
+    assert cosang > 0.995                                                         # direction of travel within ~6 degrees
+    mid_i, mid_r = valid[len(valid) // 2]
+    frac = np.linalg.norm(np.array(mid_r["p"]) - np.array(r0["p"])) / np.linalg.norm(d)
+    frac_true = np.linalg.norm(centres[mid_i] - centres[i0]) / np.linalg.norm(truth)
+    assert abs(frac - frac_true) < 0.1                                            # constant speed: no scale jump along the way
