@@ -373,6 +373,29 @@ def main():
                                  "last_frame_ms": round(1e3 * st_tr.frame_time, 3), "key_frames": int(st_tr.key_frames)}
         except Exception as e:      # noqa: BLE001 -- an extra must not take the benchmark line down
             extras["tracker"] = {"error": str(e)}
+        # the monocular tracker on the same boundary: two-view initialisation, then tracking with triangulated keyframes
+        try:
+            mg = manager.Manager()
+            c = manager.default_camera()
+            c.camera_number = 0; c.f_x = wl.k["fx"]; c.f_y = wl.k["fy"]; c.c_x = wl.k["cx"]; c.c_y = wl.k["cy"]; c.resolution_x = W; c.resolution_y = H
+            mg.set_camera(c)
+            mg.add_tracker("VSLAMMono", '{"cameraSetup": "monocular", "slamKeypoints": %d, "numLevels": 3, "keyframeInterval": %d, "device": %d}' % (KPTS, FRAMES_PER_STEP, device))
+            mg.collect_results(); mg.provide_odometry()
+            mg.start()
+            walls = wl.synth.WallSequence(W, H, 4, step=0.05)
+            mono_frames = [walls.frame(i) for i in range(30)]
+            t2 = time.perf_counter()
+            for i, img in enumerate(mono_frames):
+                mg.add_image((i + 1) * 40_000_000, img)
+            while len(mg.results) < len(mono_frames) and time.perf_counter() - t2 < 60:
+                time.sleep(0.0005)
+            t_tr = time.perf_counter() - t2
+            st_tr = mg.status()
+            mg.stop()
+            extras["tracker_mono"] = {"frames": len(mg.results), "valid": int(sum(r["valid"] for r in mg.results)),
+                                      "frames_per_s": round(len(mg.results) / t_tr, 1), "key_frames": int(st_tr.key_frames), "landmarks": int(st_tr.feature_points)}
+        except Exception as e:      # noqa: BLE001
+            extras["tracker_mono"] = {"error": str(e)}
         # BASELINE configs[4]'s global BA on ONE GPU (all landmarks on this rank; the partitioned solve adds one all-reduce of
         # the 1200^2 reduced system per trial): 200 keyframes, 30 k landmarks, ~240 k observations, 10 LM iterations
         try:

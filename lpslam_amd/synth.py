@@ -100,6 +100,36 @@ class StereoSequence:
         return left, right
 
 
+class WallSequence:
+    """Monocular test scene: three fronto-parallel textured walls at 14, 9 and 6 m, one per horizontal band of the image, seen by a
+    camera that moves sideways by `step` metres per frame.  Every wall slides by a whole number of pixels (f * x / depth, rounded),
+    so descriptors do not change between frames, while the three depths give the parallax a two-view initialisation needs."""
+
+    def __init__(self, width, height, seq_id=0, step=0.1, depths=(14.0, 9.0, 6.0), margin=None):
+        self.w, self.h, self.step, self.depths = int(width), int(height), float(step), tuple(depths)
+        self.k = intrinsics(width, height)
+        rng = np.random.default_rng(SEED_BASE + 7919 * int(seq_id) + 3)
+        self.band_h = self.h // len(self.depths)
+        self.margin = int(margin if margin is not None else 0.75 * self.w)
+        self.walls = []
+        for _ in self.depths:
+            t = rng.integers(0, 256, (self.band_h, self.w + self.margin)).astype(np.float64)
+            t = (t + np.roll(t, 1, 0) + np.roll(t, 1, 1) + np.roll(t, (1, 1), (0, 1))) / 4.0        # 2x2 box: corners FAST still likes
+            self.walls.append(60 + (t - t.min()) * (150.0 / (t.max() - t.min())))
+
+    def centre(self, i):
+        return np.array([self.step * i, 0.0, 0.0])
+
+    def frame(self, i):
+        img = np.zeros((self.h, self.w))
+        for b, (z, wall) in enumerate(zip(self.depths, self.walls)):
+            shift = min(int(round(self.k["fx"] * self.step * i / z)), self.margin)       # the wall moves left as the camera moves right
+            img[b * self.band_h:(b + 1) * self.band_h] = wall[:, shift:shift + self.w]
+        img[len(self.depths) * self.band_h:] = 110.0
+        img += np.random.Generator(np.random.PCG64([SEED_BASE, 91, int(i)])).normal(0, 1.0, img.shape)
+        return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+
+
 def random_image(width, height, seed=0):
     """Left image of frame 0 of a small sequence (unit tests)."""
     n = max(200, int(20000 * (width * height) / (1280.0 * 720.0)))

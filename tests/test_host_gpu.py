@@ -134,27 +134,9 @@ def test_monocular_sequence_initialises_and_tracks(hiplib):
     _build.host_library()
     w, h, n_frames = 640, 480, 30
     k = synth.intrinsics(w, h)
-    # three fronto-parallel textured walls at 6, 9 and 14 m, one per horizontal band of the image; the camera moves sideways, so
-    # every wall slides by f * dx / depth pixels per frame (whole pixels here) and descriptors do not change between frames
-    rng = np.random.default_rng(11)
-    depths = (14.0, 9.0, 6.0)
-    band_h = h // 3
-    margin = 400
-    walls = []
-    for _ in depths:
-        t = rng.integers(0, 256, (band_h, w + margin)).astype(np.float64)
-        t = (t + np.roll(t, 1, 0) + np.roll(t, 1, 1) + np.roll(t, (1, 1), (0, 1))) / 4.0          # 2x2 box: corners FAST still likes
-        walls.append(60 + (t - t.min()) * (150.0 / (t.max() - t.min())))
-    centres = [np.array([0.1 * i, 0.0, 0.0]) for i in range(n_frames)]
-
-    def render(cc, i):
-        img = np.zeros((h, w))
-        for b, (z, wall) in enumerate(zip(depths, walls)):
-            shift = int(round(k["fx"] * cc[0] / z))                       # the wall moves left as the camera moves right
-            img[b * band_h:(b + 1) * band_h] = wall[:, shift:shift + w]
-        img += np.random.Generator(np.random.PCG64([9, i])).normal(0, 1.0, img.shape)
-        return np.clip(np.rint(img), 0, 255).astype(np.uint8)
-    frames = [render(cc, i) for i, cc in enumerate(centres)]
+    seq = synth.WallSequence(w, h, 11)                   # three textured walls at 14 / 9 / 6 m, camera moving sideways
+    centres = [seq.centre(i) for i in range(n_frames)]
+    frames = [seq.frame(i) for i in range(n_frames)]
     m = manager.Manager()
     c = manager.default_camera()
     c.camera_number = 0; c.f_x = k["fx"]; c.f_y = k["fy"]; c.c_x = k["cx"]; c.c_y = k["cy"]; c.resolution_x = w; c.resolution_y = h
