@@ -8,10 +8,13 @@
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
+#include <limits>
 
 #include <atomic>
 static std::atomic<long> g_motion_tracked{0};      // process-wide count of frames tracked by the motion model (introspection for the tests)
 extern "C" __attribute__((visibility("default"))) long lpslam_debug_motion_tracked(void) { return g_motion_tracked.load(); }
+static std::atomic<long> g_loops_closed{0};       // loops closed by any tracker of this process
+extern "C" __attribute__((visibility("default"))) long lpslam_debug_loops_closed(void) { return g_loops_closed.load(); }
 static std::atomic<long> g_local_map_joined{0};   // landmarks local-map tracking brought back into frames
 extern "C" __attribute__((visibility("default"))) long lpslam_debug_local_map_joined(void) { return g_local_map_joined.load(); }
 
@@ -193,7 +196,7 @@ bool HipVslamTrackerBase::initializeMap(FrameData& f)
     for (size_t i = 0; i < f.kpts.size(); ++i) if (f.depth[i] > 0) ++n;
     if (n < 40) return false;
     { std::unique_lock<std::mutex> lk(m_mapMutex); m_mapCv.wait(lk, [this] { return !m_mapBusy; }); m_mapOut.reset(); }   // a solve of the map that is being dropped
-    m_landmarks.clear(); m_keyframes.clear(); m_nextLandmarkId = 0;
+    m_landmarks.clear(); m_keyframes.clear(); m_archive.clear(); m_nextLandmarkId = 0;
     f.pose = Pose();
     insertKeyframe(f);
     return true;
@@ -249,6 +252,7 @@ void HipVslamTrackerBase::insertKeyframe(FrameData& f)
             lm.p[1] = R.m[1] * d[0] + R.m[4] * d[1] + R.m[7] * d[2];
             lm.p[2] = R.m[2] * d[0] + R.m[5] * d[1] + R.m[8] * d[2];
             initLandmarkView(lm, f.pose, f.kpts[i], f.desc.data() + 32 * i);
+            lm.ref_kf = (long)m_archive.size();
             id = m_nextLandmarkId++;
             m_landmarks[id] = lm;
             f.landmark[i] = id;
@@ -263,6 +267,7 @@ void HipVslamTrackerBase::insertKeyframe(FrameData& f)
         if (!m_keyframes.empty()) monoTriangulate(m_keyframes.back(), kf, f);
         kf.kpts = f.kpts; kf.desc = f.desc; kf.landmark = f.landmark;
     }
+    if (m_stereo && m_loopClosure) archiveKeyframe(kf, f);
     m_keyframes.push_back(std::move(kf));
     ++m_keyframeCount;
     while ((int)m_keyframes.size() > m_localWindow) {
@@ -517,6 +522,8 @@ void HipVslamTrackerBase::applyMapping(const MappingJob& job)
     for (size_t f = 0; f < m_keyframes.size(); ++f) {
         for (int k = 0; k < 4; ++k) m_keyframes[f].pose.q[k] = job.poses[7 * f + k];
         for (int k = 0; k < 3; ++k) m_keyframes[f].pose.t[k] = job.poses[7 * f + 4 + k];
+        const long ai = m_keyframes[f].archive_index;
+        if (ai >= 0 && (size_t)ai < m_archive.size()) m_archive[(size_t)ai].pose = m_keyframes[f].pose;
     }
     for (size_t j = 0; j < job.ids.size(); ++j) {
         auto it = m_landmarks.find(job.ids[j]);
@@ -732,6 +739,175 @@ void HipVslamTrackerBase::monoTriangulate(Keyframe& prev, Keyframe& kf, FrameDat
     (void)created;
 }
 
+// ---- loop closing ([UPSTREAM] module::loop_detector + loop_bundle_adjuster's pose-graph stage, global_optimization_module) -----
+// Candidates: archived keyframes that are old enough and whose camera centre lies near the current estimate (the vocabulary of
+// the reference is replaced by position gating + brute-force descriptor matching on the device).  A candidate's mutual matches
+// with landmarks on both sides feed the Sim3 optimiser of the loop detector (lpslam_hip_sim3_transform_optimize, scale fixed for
+// stereo); with >= 20 inliers the loop is closed: pose graph over the keyframes of the loop (consecutive edges + the loop edge,
+// lpslam_hip_sim3_optimize, 50 iterations), landmarks move with the keyframe that created them.
+void HipVslamTrackerBase::archiveKeyframe(Keyframe& kf, const FrameData& f)
+{
+    ArchivedKeyframe a;
+    a.pose = kf.pose; a.kpts = f.kpts; a.desc = f.desc;
+    a.pc.assign(3 * f.kpts.size(), std::numeric_limits<double>::quiet_NaN());
+    const Mat3 R = quatToRot(kf.pose.q);
+    for (size_t i = 0; i < f.kpts.size(); ++i) {
+        if (f.landmark[i] < 0) continue;
+        auto it = m_landmarks.find(f.landmark[i]);
+        if (it == m_landmarks.end()) continue;
+        const double* X = it->second.p;
+        for (int r = 0; r < 3; ++r) a.pc[3 * i + r] = R.m[r * 3] * X[0] + R.m[r * 3 + 1] * X[1] + R.m[r * 3 + 2] * X[2] + kf.pose.t[r];
+    }
+    kf.archive_index = (long)m_archive.size();
+    m_archive.push_back(std::move(a));
+}
+
+namespace {
+// SE3 as (q, t): x_c = R x_w + t
+struct Se3 { double q[4]; double t[3]; };
+Se3 se3_mul(const Se3& a, const Se3& b)            // a after b
+{
+    Se3 o;
+    quatMul(a.q, b.q, o.q);
+    const Mat3 Ra = quatToRot(a.q);
+    for (int r = 0; r < 3; ++r) o.t[r] = Ra.m[r * 3] * b.t[0] + Ra.m[r * 3 + 1] * b.t[1] + Ra.m[r * 3 + 2] * b.t[2] + a.t[r];
+    return o;
+}
+Se3 se3_inv(const Se3& a)
+{
+    Se3 o;
+    o.q[0] = a.q[0]; o.q[1] = -a.q[1]; o.q[2] = -a.q[2]; o.q[3] = -a.q[3];
+    const Mat3 R = quatToRot(a.q);
+    for (int r = 0; r < 3; ++r) o.t[r] = -(R.m[r] * a.t[0] + R.m[3 + r] * a.t[1] + R.m[6 + r] * a.t[2]);
+    return o;
+}
+}  // namespace
+
+bool HipVslamTrackerBase::detectAndCloseLoop(FrameData& cur)
+{
+    const long cur_ai = m_keyframes.back().archive_index;
+    if (cur_ai < 0) return false;
+    const long newest_candidate = cur_ai - 2L * m_localWindow;          // well outside the local window
+    if (newest_candidate < 0) return false;
+    const ArchivedKeyframe& ca = m_archive[(size_t)cur_ai];
+    auto centre = [](const Pose& p, double* C) { const Mat3 R = quatToRot(p.q); for (int a = 0; a < 3; ++a) C[a] = -(R.m[a] * p.t[0] + R.m[3 + a] * p.t[1] + R.m[6 + a] * p.t[2]); };
+    double Cc[3];
+    centre(ca.pose, Cc);
+    const double radius = 10.0 * m_cam.focal_x_baseline / m_cam.f_x + 1.0;              // metres: ten baselines + 1
+    std::vector<std::pair<double, long>> near;
+    for (long a = 0; a <= newest_candidate; ++a) {
+        double C[3];
+        centre(m_archive[(size_t)a].pose, C);
+        const double d = std::sqrt((C[0] - Cc[0]) * (C[0] - Cc[0]) + (C[1] - Cc[1]) * (C[1] - Cc[1]) + (C[2] - Cc[2]) * (C[2] - Cc[2]));
+        if (d < radius) near.emplace_back(d, a);
+    }
+    if (near.empty()) return false;
+    std::sort(near.begin(), near.end());
+    if (near.size() > 3) near.resize(3);
+    float scales[LPSLAM_HIP_MAX_LEVELS];
+    lpslam_hip_level_info(m_ctx, nullptr, nullptr, nullptr, nullptr, scales);
+    const int scratch = cur.slot ^ 2;                  // the previous frame's slot pair is free for the descriptors of a candidate ...
+    std::vector<lpslam_hip_sim3_pair> pairs;
+    std::vector<int32_t> start{0};
+    std::vector<double> s12;
+    std::vector<long> cand;
+    std::vector<int32_t> mq(m_maxKp), mt(m_maxKp), md(m_maxKp);
+    const Se3 Tc{{ca.pose.q[0], ca.pose.q[1], ca.pose.q[2], ca.pose.q[3]}, {ca.pose.t[0], ca.pose.t[1], ca.pose.t[2]}};
+    for (auto& nc : near) {
+        const ArchivedKeyframe& ka = m_archive[(size_t)nc.second];
+        if (lpslam_hip_set_descriptors(m_ctx, scratch, ka.desc.data(), (int32_t)ka.kpts.size()) != LPSLAM_HIP_OK) continue;
+        if (lpslam_hip_match_bf(m_ctx, cur.slot, scratch) != LPSLAM_HIP_OK) continue;
+        int32_t nm = 0;
+        if (lpslam_hip_get_bf_matches(m_ctx, cur.slot, scratch, 50, 0.75f, 1, mq.data(), mt.data(), md.data(), m_maxKp, &nm) != LPSLAM_HIP_OK) continue;
+        const size_t first = pairs.size();
+        for (int k = 0; k < nm; ++k) {
+            const size_t ic = (size_t)mq[k], ia = (size_t)mt[k];
+            if (!std::isfinite(ca.pc[3 * ic]) || !std::isfinite(ka.pc[3 * ia])) continue;
+            lpslam_hip_sim3_pair pr{};
+            for (int r = 0; r < 3; ++r) { pr.p1c[r] = ca.pc[3 * ic + r]; pr.p2c[r] = ka.pc[3 * ia + r]; }
+            pr.obs1[0] = ca.kpts[ic].x; pr.obs1[1] = ca.kpts[ic].y; pr.obs2[0] = ka.kpts[ia].x; pr.obs2[1] = ka.kpts[ia].y;
+            const double s1 = scales[ca.kpts[ic].octave], s2 = scales[ka.kpts[ia].octave];
+            pr.inv_sigma2_1 = 1.0 / (s1 * s1); pr.inv_sigma2_2 = 1.0 / (s2 * s2);
+            pairs.push_back(pr);
+        }
+        if (pairs.size() - first < 20) { pairs.resize(first); continue; }               // [UPSTREAM] num_matches >= 20 to try a candidate
+        start.push_back((int32_t)pairs.size());
+        cand.push_back(nc.second);
+        const Se3 Ta{{ka.pose.q[0], ka.pose.q[1], ka.pose.q[2], ka.pose.q[3]}, {ka.pose.t[0], ka.pose.t[1], ka.pose.t[2]}};
+        const Se3 T12 = se3_mul(Tc, se3_inv(Ta));                                        // candidate camera -> current camera
+        s12.insert(s12.end(), {T12.q[0], T12.q[1], T12.q[2], T12.q[3], T12.t[0], T12.t[1], T12.t[2], 1.0});
+    }
+    // the scratch slot's keypoint count no longer describes an extracted image; the next extraction into it rewrites it
+    if (cand.empty()) return false;
+    const double cam[4] = {m_cam.f_x, m_cam.f_y, m_cam.c_x, m_cam.c_y};
+    std::vector<uint8_t> inl(pairs.size());
+    std::vector<int32_t> n_inl(cand.size(), 0);
+    if (lpslam_hip_sim3_transform_optimize(m_ctx, (int32_t)cand.size(), s12.data(), pairs.data(), start.data(), cam, cam, 10.0, 1, inl.data(), n_inl.data()) != LPSLAM_HIP_OK) return false;
+    int best = -1;
+    for (size_t i = 0; i < cand.size(); ++i) if (n_inl[i] >= 20 && (best < 0 || n_inl[i] > n_inl[(size_t)best])) best = (int)i;
+    if (best < 0) return false;
+
+    // ---- pose graph over the keyframes of the loop: a = candidate (fixed) ... cur
+    const long a0 = cand[(size_t)best];
+    const int n = (int)(cur_ai - a0 + 1);
+    std::vector<double> verts(8 * (size_t)n);
+    std::vector<uint8_t> fixed((size_t)n, 0);
+    fixed[0] = 1;
+    std::vector<Se3> old((size_t)n);
+    for (int v = 0; v < n; ++v) {
+        const Pose& p = m_archive[(size_t)(a0 + v)].pose;
+        old[(size_t)v] = Se3{{p.q[0], p.q[1], p.q[2], p.q[3]}, {p.t[0], p.t[1], p.t[2]}};
+        const double row[8] = {p.q[0], p.q[1], p.q[2], p.q[3], p.t[0], p.t[1], p.t[2], 1.0};
+        std::copy(row, row + 8, verts.begin() + 8 * (size_t)v);
+    }
+    std::vector<lpslam_hip_sim3_edge> edges;
+    for (int v = 0; v + 1 < n; ++v) {                    // consecutive keyframes: measurement = S_j S_i^-1 of the current estimates
+        const Se3 m = se3_mul(old[(size_t)v + 1], se3_inv(old[(size_t)v]));
+        lpslam_hip_sim3_edge e{};
+        e.i = v; e.j = v + 1;
+        const double row[8] = {m.q[0], m.q[1], m.q[2], m.q[3], m.t[0], m.t[1], m.t[2], 1.0};
+        std::copy(row, row + 8, e.meas);
+        edges.push_back(e);
+    }
+    {   // the loop edge: current <- candidate as the transform optimiser found it
+        lpslam_hip_sim3_edge e{};
+        e.i = 0; e.j = n - 1;
+        std::copy(s12.begin() + 8 * (size_t)best, s12.begin() + 8 * (size_t)best + 8, e.meas);
+        edges.push_back(e);
+    }
+    lpslam_hip_sim3* graph = nullptr;
+    if (lpslam_hip_sim3_create(m_ctx, verts.data(), fixed.data(), n, edges.data(), (int32_t)edges.size(), 1, &graph) != LPSLAM_HIP_OK) return false;
+    int32_t done = 0;
+    const bool ok = lpslam_hip_sim3_optimize(graph, 50, nullptr, &done) == LPSLAM_HIP_OK && lpslam_hip_sim3_get(graph, verts.data()) == LPSLAM_HIP_OK;
+    lpslam_hip_sim3_destroy(graph);
+    if (!ok) return false;
+    finishMapping();                                     // no window solve may be in flight while the map moves
+    std::vector<Se3> neu((size_t)n);
+    for (int v = 0; v < n; ++v) {
+        const double* r = &verts[8 * (size_t)v];
+        const double qn = std::sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3]), s = r[7] > 0 ? r[7] : 1.0;
+        neu[(size_t)v] = Se3{{r[0] / qn, r[1] / qn, r[2] / qn, r[3] / qn}, {r[4] / s, r[5] / s, r[6] / s}};
+        Pose& p = m_archive[(size_t)(a0 + v)].pose;
+        for (int k = 0; k < 4; ++k) p.q[k] = neu[(size_t)v].q[k];
+        for (int k = 0; k < 3; ++k) p.t[k] = neu[(size_t)v].t[k];
+    }
+    for (auto& kv : m_landmarks) {                       // X_new = T_ref_new^-1 (T_ref_old X)
+        const long rk = kv.second.ref_kf;
+        if (rk < a0 || rk > cur_ai) continue;
+        const Se3& To = old[(size_t)(rk - a0)]; const Se3 Tni = se3_inv(neu[(size_t)(rk - a0)]);
+        const Mat3 Ro = quatToRot(To.q), Rn = quatToRot(Tni.q);
+        double xc[3], xw[3];
+        for (int r = 0; r < 3; ++r) xc[r] = Ro.m[r * 3] * kv.second.p[0] + Ro.m[r * 3 + 1] * kv.second.p[1] + Ro.m[r * 3 + 2] * kv.second.p[2] + To.t[r];
+        for (int r = 0; r < 3; ++r) xw[r] = Rn.m[r * 3] * xc[0] + Rn.m[r * 3 + 1] * xc[1] + Rn.m[r * 3 + 2] * xc[2] + Tni.t[r];
+        for (int r = 0; r < 3; ++r) kv.second.p[r] = xw[r];
+    }
+    for (auto& kf : m_keyframes) if (kf.archive_index >= a0 && kf.archive_index <= cur_ai) kf.pose = m_archive[(size_t)kf.archive_index].pose;
+    cur.pose = m_archive[(size_t)cur_ai].pose;
+    ++m_loopsClosed; ++g_loops_closed;
+    logMessage(LpSlamLogLevel_Info, "VSLAM loop closed: keyframe " + std::to_string(cur_ai) + " with " + std::to_string(a0) + ", " + std::to_string(n_inl[(size_t)best]) + " inliers");
+    return true;
+}
+
 void HipVslamTrackerBase::mappingLoop()
 {
     std::unique_lock<std::mutex> lk(m_mapMutex);
@@ -849,6 +1025,7 @@ TrackerBase::ProcessImageResult HipVslamTrackerBase::trackFrame(CameraQueueEntry
             if (m_framesSinceKeyframe >= m_keyframeInterval || inliers < 50) {
                 finishMapping();                    // the previous keyframe's solve enters the map before the window moves
                 insertKeyframe(cur);
+                if (m_stereo && m_loopClosure) detectAndCloseLoop(cur);
                 startMapping();
                 if (!m_asyncMapping) cur.pose = m_keyframes.back().pose;
             }

@@ -53,6 +53,13 @@ protected:
         Pose pose; std::vector<KeyframeObs> obs;
         // monocular only: what triangulating new landmarks against the next keyframe needs
         std::vector<lpslam_hip_keypoint> kpts; std::vector<uint8_t> desc; std::vector<int> landmark;
+        long archive_index = -1;
+    };
+    // every keyframe ever inserted, for loop detection ([UPSTREAM] module::loop_detector works on the keyframe database; here the
+    // candidates are found by position and brute-force descriptor matching on the device instead of a DBoW2 vocabulary)
+    struct ArchivedKeyframe {
+        Pose pose; std::vector<lpslam_hip_keypoint> kpts; std::vector<uint8_t> desc;
+        std::vector<double> pc;                       // per keypoint: its landmark in this keyframe's camera frame (NaN: none)
     };
     struct Landmark {
         double p[3]; int n_obs = 0;
@@ -61,6 +68,7 @@ protected:
         uint8_t desc[32] = {0};
         double normal[3] = {0, 0, 1};
         double max_valid = 0, min_valid = 0;
+        long ref_kf = -1;                             // archive index of the keyframe that created it (loop correction moves it with that keyframe)
     };
 
     bool startContext(bool stereo);
@@ -75,6 +83,8 @@ protected:
     // by triangulation between consecutive keyframes ([UPSTREAM] mapping_module::create_new_landmarks, previous keyframe only)
     bool monoInitialize(FrameData& cur);
     void monoTriangulate(Keyframe& prev, Keyframe& kf, FrameData& f);
+    void archiveKeyframe(Keyframe& kf, const FrameData& f);
+    bool detectAndCloseLoop(FrameData& cur);
     void initLandmarkView(Landmark& lm, const Pose& pose, const lpslam_hip_keypoint& kp, const uint8_t* desc32) const;
     void insertKeyframe(FrameData& f);
     // Local bundle adjustment of the keyframe window ([UPSTREAM] mapping_module -> optimize::local_bundle_adjuster).  As in the
@@ -126,6 +136,8 @@ protected:
     int m_nextLandmarkId = 0;
     std::deque<Keyframe> m_keyframes;
     long m_keyframeCount = 0;
+    std::vector<ArchivedKeyframe> m_archive;
+    long m_loopsClosed = 0;
     FrameData m_monoRef;                              // monocular initialisation: the reference frame ...
     bool m_haveMonoRef = false;
     std::vector<float> m_monoPrevMatched;             // ... and where each of its keypoints was last matched (x, y)

@@ -165,3 +165,45 @@ def test_monocular_sequence_initialises_and_tracks(hiplib):
     frac = np.linalg.norm(np.array(mid_r["p"]) - np.array(r0["p"])) / np.linalg.norm(d)
     frac_true = np.linalg.norm(centres[mid_i] - centres[i0]) / np.linalg.norm(truth)
     assert abs(frac - frac_true) < 0.1                                            # constant speed: no scale jump along the way
+
+
+def test_loop_is_detected_and_closed(hiplib):
+    """Out and back along the same line: when the camera returns, archived keyframes near the current position are matched by
+    descriptor on the device, verified with the Sim3 optimiser of the loop detector and the loop is closed by the Sim3 pose graph
+    ([UPSTREAM] module::loop_detector / optimize::transform_optimizer / optimize::graph_optimizer; the reference switches the
+    detector with the tracker's loopClosure key, src/Trackers/OpenVSLAMTrackerBase.cpp:250-255).  The tracker barely drifts on
+    this sequence, so closing the loop must leave the trajectory where it was."""
+    import ctypes
+    from lpslam_amd import _build, manager
+    lib = ctypes.CDLL(_build.host_library())
+    lib.lpslam_debug_loops_closed.restype = ctypes.c_long
+    w, h = 640, 480
+    k = synth.intrinsics(w, h)
+    seq = synth.StereoSequence(w, h, 4, n_points=6000)
+    zs = [0.05 * i for i in range(25)] + [0.05 * (24 - i) for i in range(1, 25)]
+    frames = []
+    for i, z in enumerate(zs):
+        rng = np.random.Generator(np.random.PCG64([5, i]))
+        t = -np.array([0.0, 0.0, z])
+        frames.append((seq._render(np.eye(3), t, rng), seq._render(np.eye(3), t - np.array([k["baseline"], 0.0, 0.0]), rng)))
+    m = manager.Manager()
+    for num in (0, 1):
+        c = manager.default_camera()
+        c.camera_number = num; c.f_x = k["fx"]; c.f_y = k["fy"]; c.c_x = k["cx"]; c.c_y = k["cy"]
+        c.resolution_x = w; c.resolution_y = h; c.focal_x_baseline = k["fxb"]
+        m.set_camera(c)
+    assert m.add_tracker("VSLAMStereo", '{"cameraSetup": "stereo", "slamKeypoints": 1000, "numLevels": 4, "keyframeInterval": 3, "localWindow": 4, "loopClosure": true}')
+    m.collect_results(); m.provide_odometry()
+    closed0 = lib.lpslam_debug_loops_closed()
+    m.start()
+    for i, (l, r) in enumerate(frames):
+        assert m.add_stereo((i + 1) * 40_000_000, l, r)
+    t0 = time.time()
+    while len(m.results) < len(frames) and time.time() - t0 < 60:
+        time.sleep(0.01)
+    m.stop()
+    assert len(m.results) == len(frames) and sum(r["valid"] for r in m.results) >= len(frames) - 2
+    assert lib.lpslam_debug_loops_closed() - closed0 >= 1
+    valid = [(i, r) for i, r in enumerate(m.results) if r["valid"]]
+    for i, r in valid[5:]:
+        assert abs(r["p"][2] - zs[i]) < 0.12 * max(zs[i], 0.25) + 0.02 and abs(r["p"][0]) < 0.06 and abs(r["p"][1]) < 0.06, (i, r["p"], zs[i])
