@@ -280,7 +280,7 @@ def main():
     # SURVEY.md 8(d) extras, outside the timed region: front end alone in batched and single-frame-latency mode, the spread of
     # the BA time per LM iteration, and the Sim3 pose graph of BASELINE config 5's keyframe count
     extras = {}
-    if rank == 0 and not args.no_extras:
+    if rank == 0 and not args.no_extras and world == 1:          # the scaling runs (N > 1) print the timed line only
         n_fe = max(3, min(args.steps, 10))
         wl.ctx.sync(); t2 = time.perf_counter()
         for _ in range(n_fe):
