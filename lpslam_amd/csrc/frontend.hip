@@ -691,7 +691,8 @@ __device__ __forceinline__ void sincos_deg(float angle_deg, float* s_out, float*
 #define PR 21                 // raw patch radius: 18 (max rotated pattern radius) + 3 (blur)
 #define PW 43                 // raw patch width
 #define BW 37                 // blurred patch width (radius 18)
-#define RAW_PITCH 44
+#define RAW_PITCH 48           // multiple of 4, and 12 bytes can be read from column 36 of any row
+#define HB_PITCH 40            // row pitch of the horizontally blurred patch (u16): rows start 8-byte aligned
 #define DESC_WAVES 4
 
 __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const uint8_t* __restrict__ pyr, size_t image_slab, LevelTable lt,
@@ -701,7 +702,7 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const uint8_t* __r
                                                               int32_t* __restrict__ kp_count, int image0)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_raw[DESC_WAVES][PW * RAW_PITCH];
-    __shared__ __attribute__((aligned(16))) uint16_t s_h[DESC_WAVES][PW * BW];
+    __shared__ __attribute__((aligned(16))) uint16_t s_h[DESC_WAVES][PW * HB_PITCH];
     __shared__ __attribute__((aligned(16))) uint8_t s_blur[DESC_WAVES][BW * BW];
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -726,7 +727,14 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const uint8_t* __r
     uint16_t* hb = s_h[wave];
     uint8_t* bl = s_blur[wave];
 
-    for (int i = lane; i < PW * PW; i += 64) { const int r = i / PW, c = i - r * PW; raw[r * RAW_PITCH + c] = src[(size_t)r * P + c]; }
+    // the 43 x 43 patch: ten (unaligned) dword loads and three byte loads per row instead of 43 byte loads
+    for (int i = lane; i < PW * 10; i += 64) {
+        const int r = i / 10, c4 = i - r * 10;
+        uint32_t w;
+        __builtin_memcpy(&w, src + (size_t)r * P + 4 * c4, 4);
+        *reinterpret_cast<uint32_t*>(&raw[r * RAW_PITCH + 4 * c4]) = w;
+    }
+    for (int i = lane; i < PW * 3; i += 64) { const int r = i / 3, c = 40 + (i - r * 3); raw[r * RAW_PITCH + c] = src[(size_t)r * P + c]; }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -745,19 +753,34 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const uint8_t* __r
     const float angle = fast_atan2_deg((float)m01, (float)m10);
 
     // separable fixed-point Gaussian {18,34,48,56,48,34,18}/256: rows 0..42 x cols 3..39, then rows 3..39
-    for (int i = lane; i < PW * BW; i += 64) {
-        const int r = i / BW, c = i - r * BW;
-        const uint8_t* p = &raw[r * RAW_PITCH + c];
-        hb[i] = (uint16_t)(18 * (p[0] + p[6]) + 34 * (p[1] + p[5]) + 48 * (p[2] + p[4]) + 56 * p[3]);
+    // horizontal pass: a lane takes four neighbouring columns of a row -- three dword reads feed 28 taps
+    for (int i = lane; i < PW * 10; i += 64) {
+        const int r = i / 10, g = i - r * 10;
+        const uint32_t* p = reinterpret_cast<const uint32_t*>(&raw[r * RAW_PITCH + 4 * g]);
+        const uint32_t w0 = p[0], w1 = p[1], w2 = p[2];
+        unsigned b[12];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { b[k] = (w0 >> (8 * k)) & 0xFF; b[4 + k] = (w1 >> (8 * k)) & 0xFF; b[8 + k] = (w2 >> (8 * k)) & 0xFF; }
+        unsigned o4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o4[j] = 18 * (b[j] + b[j + 6]) + 34 * (b[j + 1] + b[j + 5]) + 48 * (b[j + 2] + b[j + 4]) + 56 * b[j + 3];
+        uint32_t* out = reinterpret_cast<uint32_t*>(&hb[r * HB_PITCH + 4 * g]);
+        out[0] = o4[0] | (o4[1] << 16); out[1] = o4[2] | (o4[3] << 16);      // columns 37..39 of the last group are never read
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    for (int i = lane; i < BW * BW; i += 64) {
-        const int r = i / BW, c = i - r * BW;
-        const uint16_t* p = &hb[r * BW + c];
-        const uint32_t s = 18u * (p[0] + p[6 * BW]) + 34u * (p[BW] + p[5 * BW]) + 48u * (p[2 * BW] + p[4 * BW]) + 56u * p[3 * BW];
-        bl[i] = (uint8_t)((s + (1u << 15)) >> 16);
+    // vertical pass: a lane takes two neighbouring columns -- seven dword reads feed 14 taps
+    for (int i = lane; i < BW * 19; i += 64) {
+        const int r = i / 19, c = 2 * (i - r * 19);
+        const uint32_t* p = reinterpret_cast<const uint32_t*>(&hb[r * HB_PITCH + c]);
+        uint32_t v[7];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) v[k] = p[k * (HB_PITCH / 2)];
+        const uint32_t lo = 18u * ((v[0] & 0xFFFF) + (v[6] & 0xFFFF)) + 34u * ((v[1] & 0xFFFF) + (v[5] & 0xFFFF)) + 48u * ((v[2] & 0xFFFF) + (v[4] & 0xFFFF)) + 56u * (v[3] & 0xFFFF);
+        const uint32_t hi = 18u * ((v[0] >> 16) + (v[6] >> 16)) + 34u * ((v[1] >> 16) + (v[5] >> 16)) + 48u * ((v[2] >> 16) + (v[4] >> 16)) + 56u * (v[3] >> 16);
+        bl[r * BW + c] = (uint8_t)((lo + (1u << 15)) >> 16);
+        if (c + 1 < BW) bl[r * BW + c + 1] = (uint8_t)((hi + (1u << 15)) >> 16);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
