@@ -741,11 +741,14 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const uint8_t* __r
 
     // orientation: m10 = sum u*I, m01 = sum v*I over the disc |u| <= umax[|v|], |v| <= 15
     int m10 = 0, m01 = 0;
-    for (int i = lane; i < 31 * 31; i += 64) {
-        const int r = i / 31, c = i - r * 31;
-        const int v = r - 15, u = c - 15;
-        if (abs(u) <= c_umax[abs(v)]) {
-            const int I = raw[(PR + v) * RAW_PITCH + PR + u];
+    for (int i = lane; i < 31 * 9; i += 64) {            // a lane takes four neighbouring columns (4 .. 39 cover u = -15 .. 15)
+        const int r = i / 9, g = i - r * 9;
+        const int v = r - 15, lim = c_umax[abs(v)];
+        const uint32_t w = *reinterpret_cast<const uint32_t*>(&raw[(PR + v) * RAW_PITCH + 4 + 4 * g]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int u = 4 + 4 * g + k - PR;
+            const int I = abs(u) <= lim ? (int)((w >> (8 * k)) & 0xFF) : 0;
             m10 += u * I; m01 += v * I;
         }
     }
