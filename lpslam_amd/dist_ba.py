@@ -81,7 +81,7 @@ class PartitionedBA:
         self._sum(self.t_red)                            # diag H_pp, b_p, chi2 of every rank
         self.red.all_reduce(self.t_scal[4:5], "max"); self.all_reduce_calls += 1     # max diag H_ll
         ba.step_lambda0()
-        outer, trials = 0, 0
+        outer, trials, chi_log = 0, 0, []
         while outer < iters:
             ba.step_begin(robust, False)                 # (re-linearise if the state moved) + partial Schur complement
             self._sum(self.t_red)
@@ -91,6 +91,8 @@ class PartitionedBA:
             trials += 1
             if finished:
                 outer += 1
-                if ba.status()["stopped"]:
+                st = ba.status()
+                chi_log.append(st["chi2"])               # chi2 after this outer iteration (the g2o log's chi2_after)
+                if st["stopped"]:
                     break
-        return dict(outer=outer, trials=trials, **ba.status())
+        return dict(outer=outer, trials=trials, chi2_after=np.array(chi_log), **ba.status())

@@ -16,11 +16,13 @@ def main():
     from lpslam_amd.dist_ba import PartitionedBA, TorchReducer, shard_problem
     out_dir = sys.argv[1]
     n_kf, n_pts, n_obs, iters = (int(x) for x in sys.argv[2:6])
+    # optional: image size, sequence id and keyframe stride of the generator (defaults: the small cases)
+    gw, gh, seq_id, kf_stride = (int(x) for x in sys.argv[6:10]) if len(sys.argv) >= 10 else (1280, 720, 11, 1)
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dev = int(os.environ.get("LOCAL_RANK", "0")) % max(hip.device_count(), 1)
     torch.cuda.set_device(dev)
     dist.init_process_group(os.environ.get("LPSLAM_DIST_BACKEND", "gloo"))
-    prob = synth.ba_problem(n_kf, n_pts, n_obs, 1280, 720, seq_id=11)
+    prob = synth.ba_problem(n_kf, n_pts, n_obs, gw, gh, seq_id=seq_id, kf_stride=kf_stride)
     shard = shard_problem(prob, rank, world)
     ctx = hip.Context(640, 480, 500, 1.2, 4, max_images=1, device=dev)
     ba = hip.BundleAdjuster(ctx, shard["poses"], shard["fixed"], shard["points"], hip.ba_obs_array(shard), shard["cam"])
@@ -28,7 +30,7 @@ def main():
     res = drv.optimize(True, iters)
     poses, pts = ba.state()
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), poses=poses, points=pts, ids=shard["landmark_ids"], chi2=res["chi2"],
-             lam=res["lam"], outer=res["outer"], trials=res["trials"], reduces=drv.all_reduce_calls)
+             lam=res["lam"], outer=res["outer"], trials=res["trials"], reduces=drv.all_reduce_calls, chi2_after=res["chi2_after"])
     if rank == 0:       # the same problem on one GPU, unpartitioned
         full = hip.BundleAdjuster(ctx, prob["poses"], prob["fixed"], prob["points"], hip.ba_obs_array(prob), prob["cam"])
         log = full.optimize(True, iters)

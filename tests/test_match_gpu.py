@@ -36,6 +36,52 @@ def test_bf_ragged_sizes(ctx, oracle, nq, nt):
     assert all(np.array_equal(a, b) for a, b in zip(o, g))
 
 
+@pytest.fixture(scope="module")
+def big_ctx(hiplib):
+    """2100 keypoints / 8 levels: 2124 descriptor slots, i.e. train sets of more than two 1024-descriptor LDS tiles."""
+    return hiplib.Context(1280, 720, 2100, 1.2, 8, max_images=2)
+
+
+@pytest.mark.parametrize("nq,nt", [(2000, 2000), (1025, 1023), (1024, 2048), (1500, 1025), (7, 2049), (2124, 2124)])
+def test_bf_multi_tile_sizes(big_ctx, oracle, nq, nt):
+    """The shapes the bench and the tracker run: the train set spans several 1024-descriptor LDS tiles, so the cross-tile
+    (distance, index) merge decides best index, best distance and second distance.  Exact ties are planted across tile
+    boundaries (first minimum must win, the second distance of a tied query is the tie's distance)."""
+    rng = np.random.default_rng(nq * 7919 + nt)
+    q = rng.integers(0, 256, (nq, 32), dtype=np.uint8); t = rng.integers(0, 256, (nt, 32), dtype=np.uint8)
+    if nt > 1030:
+        t[1030] = t[5]; q[0] = t[5]                  # tie across the first tile boundary, exact match: idx 5, dist 0, second 0
+        t[1024] = t[1023]; q[1] = t[1023]            # tie between the last descriptor of tile 0 and the first of tile 1
+        q[2] = t[1030] ^ np.uint8(1)                 # one bit off a tied pair: best 5 (first minimum), second equal
+        t[nt - 1] = t[0]; q[3] = t[0]                # first descriptor against the very last one
+    if nt > 2048:
+        t[2048] = t[1024]; q[4] = t[1024]; t[nt - 1] = t[0] if nt > 2049 else t[nt - 1]     # three-way tie over three tiles (1023, 1024, 2048)
+    big_ctx.set_descriptors(0, q); big_ctx.set_descriptors(1, t)
+    big_ctx.match_bf(0, 1)
+    g = big_ctx.bf_knn2(0)
+    o = oracle.match_bf_knn2(q, t)
+    for name, a, b in zip(("best_idx", "best_dist", "second_dist"), o, g):
+        assert np.array_equal(a, b), name
+    if nt > 1030:
+        assert g[0][0] == 5 and g[1][0] == 0 and g[2][0] == 0
+        assert g[0][1] == 1023 and g[2][1] == 0
+        if nt != 2049:
+            assert g[0][3] == 0 and g[2][3] == 0
+    if nt > 2048:
+        assert g[0][4] == 1023 and g[1][4] == 0 and g[2][4] == 0
+
+
+def test_bf_golden_full_size(big_ctx):
+    """G8: the benchmark's 2000 x 2000 shape against the committed oracle output (tools/make_golden.py)."""
+    g = golden("g8_bf2000.npz")
+    big_ctx.set_descriptors(0, g["q"]); big_ctx.set_descriptors(1, g["t"])
+    big_ctx.match_bf(0, 1)
+    bi, bd, sd = big_ctx.bf_knn2(0)
+    assert np.array_equal(bi, g["best_idx"]) and np.array_equal(bd, g["best_dist"]) and np.array_equal(sd, g["second_dist"])
+    mq, mt, md = big_ctx.bf_matches(0, 1, 100, 0.9, True)
+    assert np.array_equal(mq, g["mq"]) and np.array_equal(mt, g["mt"]) and np.array_equal(md, g["md"])
+
+
 def test_bf_symmetry_property(hiplib):
     """Full-size 2000 x 2000: distance symmetry d(q,t)=d(t,q) and self-match distance 0."""
     c = hiplib.Context(1280, 720, 2000, 1.2, 8, max_images=2)
@@ -61,6 +107,29 @@ def test_stereo_golden_and_oracle(hiplib, oracle):
     c.match_stereo(0, 1, k["fxb"], k["baseline"])
     xr, dep, bi = c.stereo(0)
     assert np.array_equal(xr, g["x_right"]) and np.array_equal(dep, g["depth"]) and np.array_equal(bi, g["best_idx"])
+
+
+def test_stereo_golden_720(hiplib):
+    """G9: 1280x720 / 2000 keypoints / 8 levels against the committed oracle output: keypoints, descriptors, x_right, depth."""
+    import hashlib
+    g = golden("g9_stereo720.npz")
+    l, r = synth.StereoSequence(1280, 720, 9).frame(2)
+    assert hashlib.sha256(l.tobytes()).hexdigest() == str(g["sha_left"]) and hashlib.sha256(r.tobytes()).hexdigest() == str(g["sha_right"])
+    c = hiplib.Context(1280, 720, 2000, 1.2, 8, max_images=2)
+    c.upload(0, l); c.upload(1, r)
+    c.extract(2)
+    k = synth.intrinsics(1280, 720)
+    c.match_stereo(0, 1, k["fxb"], k["baseline"])
+    for slot, kk, dd in ((0, g["kl"], g["dl"]), (1, g["kr"], g["dr"])):
+        kp, desc = c.keypoints(slot)
+        assert len(kp) == len(kk)
+        for f in kk.dtype.names:
+            assert np.array_equal(kp[f], kk[f]), f
+        assert np.array_equal(desc, dd)
+    xr, dep, bi = c.stereo(0)
+    assert np.array_equal(xr, g["x_right"]) and np.array_equal(dep, g["depth"]) and np.array_equal(bi, g["best_idx"])
+    assert int((dep > 0).sum()) == int(g["n_valid"])
+    c.close()
 
 
 def test_stereo_full_size(hiplib, oracle):

@@ -184,6 +184,41 @@ def test_hamming_and_golden_bf(oracle):
     assert (bi0 == -1).all() and (bd0 == 257).all()
 
 
+def test_golden_bf_full_size(oracle):
+    """G8, the benchmark's 2000 x 2000 shape: the oracle against numpy's unpackbits Hamming matrix and the committed vector."""
+    g = golden("g8_bf2000.npz")
+    q, t = g["q"], g["t"]
+    bi, bd, sd = oracle.match_bf_knn2(q, t)
+    assert np.array_equal(bi, g["best_idx"]) and np.array_equal(bd, g["best_dist"]) and np.array_equal(sd, g["second_dist"])
+    pop = np.array([bin(i).count("1") for i in range(256)], np.int32)
+    for lo in range(0, 2000, 250):                      # independent restatement, in slabs to bound memory
+        d = pop[q[lo:lo + 250, None, :] ^ t[None, :, :]].sum(axis=2)
+        assert np.array_equal(bi[lo:lo + 250], d.argmin(axis=1)) and np.array_equal(bd[lo:lo + 250], d.min(axis=1))
+        assert np.array_equal(sd[lo:lo + 250], np.partition(d, 1, axis=1)[:, 1])
+    assert bi[0] == 5 and bd[0] == 0 and sd[0] == 0 and bi[1] == 1023 and bi[3] == 0       # planted ties: first minimum wins
+    mq, mt, md = oracle.match_bf(q, t, 100, 0.9, True)
+    assert np.array_equal(mq, g["mq"]) and np.array_equal(mt, g["mt"]) and np.array_equal(md, g["md"])
+
+
+def test_golden_stereo_720(oracle):
+    """G9: a 1280x720 pair at the benchmark's configuration; images regenerated by the committed generator and pinned by hash."""
+    import hashlib
+    g = golden("g9_stereo720.npz")
+    l, r = synth.StereoSequence(1280, 720, 9).frame(2)
+    assert hashlib.sha256(l.tobytes()).hexdigest() == str(g["sha_left"]) and hashlib.sha256(r.tobytes()).hexdigest() == str(g["sha_right"])
+    p = oracle.params(2000, 1.2, 8)
+    kl, dl, _, pl = oracle.extract(l, p, True)
+    kr, dr, _, pr = oracle.extract(r, p, True)
+    for f in kl.dtype.names:
+        assert np.array_equal(kl[f], g["kl"][f]) and np.array_equal(kr[f], g["kr"][f])
+    assert np.array_equal(dl, g["dl"]) and np.array_equal(dr, g["dr"])
+    k = synth.intrinsics(1280, 720)
+    xr, dep, bi, nv = oracle.match_stereo(pl, pr, p, kl, dl, kr, dr, k["fxb"], k["baseline"])
+    assert np.array_equal(xr, g["x_right"]) and np.array_equal(dep, g["depth"]) and np.array_equal(bi, g["best_idx"]) and nv == int(g["n_valid"])
+    ok = dep > 0
+    assert ok.sum() > 300 and np.allclose(dep[ok], k["fxb"] / (kl["x"][ok] - xr[ok]), rtol=1e-5)
+
+
 def test_golden_stereo_and_depth_truth(oracle):
     g = golden("g6_stereo.npz")
     p = oracle.params(400, 1.2, 4)

@@ -76,6 +76,30 @@ def main():
                         f_verts0=pg2["verts"], f_edge_i=pg2["edge_i"], f_edge_j=pg2["edge_j"], f_meas=pg2["meas"], f_verts=v8,
                         f_chi2_after=log8["chi2_after"],
                         exp_in=np.array([0.3, -0.2, 0.1, 1.0, -2.0, 0.5, 0.2]), exp_out=O.sim3_exp([0.3, -0.2, 0.1, 1.0, -2.0, 0.5, 0.2]))
+    # G8: the benchmark's brute-force shape, 2000 x 2000 (the train set spans two 1024-descriptor tiles of the HIP kernel):
+    # train = random descriptors, query = a permutation of them with a few flipped bits, plus planted exact ties
+    rng = np.random.Generator(np.random.PCG64(88))
+    t8 = rng.integers(0, 256, (2000, 32), dtype=np.uint8)
+    q8 = t8[rng.permutation(2000)].copy()
+    q8 ^= (rng.integers(0, 256, (2000, 32), dtype=np.uint8) & rng.integers(0, 256, (2000, 32), dtype=np.uint8) &
+           rng.integers(0, 256, (2000, 32), dtype=np.uint8) & rng.integers(0, 256, (2000, 32), dtype=np.uint8))
+    t8[1030] = t8[5]; q8[0] = t8[5]; t8[1024] = t8[1023]; q8[1] = t8[1023]; t8[1999] = t8[0]; q8[3] = t8[0]; q8[1999] = q8[17]
+    bi, bd, sd = O.match_bf_knn2(q8, t8)
+    mq, mt, md = O.match_bf(q8, t8, 100, 0.9, True)
+    np.savez_compressed(os.path.join(OUT, "g8_bf2000.npz"), q=q8, t=t8, best_idx=bi, best_dist=bd, second_dist=sd, mq=mq, mt=mt, md=md)
+    # G9: a 1280x720 stereo pair at the benchmark's configuration (2000 keypoints, 8 levels).  The images come from the committed
+    # generator (lpslam_amd/synth.py, sequence 9, frame 2) and are pinned by their SHA-256; the fixture holds the oracle's
+    # keypoints, descriptors, x_right and depth.
+    import hashlib
+    seq9 = synth.StereoSequence(1280, 720, 9)
+    l9, r9 = seq9.frame(2)
+    p9 = O.params(2000, 1.2, 8)
+    kl9, dl9, _, pl9 = O.extract(l9, p9, True)
+    kr9, dr9, _, pr9 = O.extract(r9, p9, True)
+    k9 = synth.intrinsics(1280, 720)
+    xr9, dep9, bi9, nv9 = O.match_stereo(pl9, pr9, p9, kl9, dl9, kr9, dr9, k9["fxb"], k9["baseline"])
+    np.savez_compressed(os.path.join(OUT, "g9_stereo720.npz"), sha_left=hashlib.sha256(l9.tobytes()).hexdigest(),
+                        sha_right=hashlib.sha256(r9.tobytes()).hexdigest(), kl=kl9, dl=dl9, kr=kr9, dr=dr9, x_right=xr9, depth=dep9, best_idx=bi9, n_valid=nv9)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 
