@@ -173,7 +173,9 @@ typedef struct lpslam_hip_ba_iter_log {
 typedef struct lpslam_hip_ba lpslam_hip_ba;
 
 /* Builds the device-side problem (structure phase = g2o buildStructure): poses n x 7 (qw qx qy qz tx ty tz,
- * world->camera), fixed flags, points n x 3, observations.  Copies everything to HBM. */
+ * world->camera), fixed flags, points n x 3, observations.  One copy takes the inputs to HBM; the index structures (storage
+ * order, CSR by landmark, pair lists of the Schur complement) are built there by kernels.  Asynchronous: returns once the work
+ * is enqueued on the problem's stream. */
 int lpslam_hip_ba_create(lpslam_hip_ctx* ctx, const double* poses, const uint8_t* fixed, int32_t n_poses,
                          const double* points, int32_t n_points, const lpslam_hip_ba_obs* obs, int32_t n_obs,
                          const lpslam_hip_ba_camera* cam, lpslam_hip_ba** out);
@@ -191,6 +193,15 @@ int lpslam_hip_ba_optimize(lpslam_hip_ba* ba, int32_t robust, int32_t iters, lps
  * src/Trackers/OpenVSLAMStereoTracker.cpp:293-295).  No other call on `ba` is allowed in between. */
 int lpslam_hip_ba_optimize_begin(lpslam_hip_ba* ba, int32_t robust, int32_t iters);
 int lpslam_hip_ba_optimize_end(lpslam_hip_ba* ba, lpslam_hip_ba_iter_log* log, int32_t* done);
+/* Batched solve -- north star: "a batched Levenberg-Marquardt local-BA".  n independent problems (the keyframe windows of
+ * several SLAM sessions served by one GPU, [UPSTREAM] mapping_module::run of each session; lpslam reaches it through
+ * feed_stereo_frame, src/Trackers/OpenVSLAMStereoTracker.cpp:293-295) are advanced by ONE launch chain: every kernel runs once
+ * for the whole batch (blockIdx.y = problem) and each problem follows its own lambda control.  Results are identical to n calls of
+ * lpslam_hip_ba_optimize.  All problems must live on one device; logs (may be NULL) receives log_stride entries per problem,
+ * done (may be NULL) the iterations each problem ran.  reset_batch = lpslam_hip_ba_reset of every problem in one launch. */
+int lpslam_hip_ba_optimize_batch(lpslam_hip_ba* const* problems, int32_t n, int32_t robust, int32_t iters,
+                                 lpslam_hip_ba_iter_log* logs, int32_t log_stride, int32_t* done);
+int lpslam_hip_ba_reset_batch(lpslam_hip_ba* const* problems, int32_t n);
 /* Motion-only mode: landmarks are held fixed (unary edges), only the free poses move. */
 int lpslam_hip_ba_set_points_fixed(lpslam_hip_ba* ba, int32_t points_fixed);
 /* optimize::pose_optimizer flow on a problem created with ONE free pose: 4 rounds x 10 iterations, outliers

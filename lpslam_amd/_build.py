@@ -13,16 +13,37 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp
          "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
 
 
+OBJ_DIR = os.path.join(CSRC, "_obj")
+# what each translation unit includes (beyond itself): a change there recompiles only that unit
+UNIT_DEPS = {"ba.hip": ["sim3.inl", "ba_build.inl", "ba_solve.inl"], "frontend.hip": ["orb_pattern.inc"], "match.hip": [], "api.hip": []}
+COMMON_DEPS = ["internal.h", os.path.join("..", "..", "include", "lpslam_hip.h")]
+
+
 def hip_library(force=False, verbose=False):
-    srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    deps = srcs + [os.path.join(CSRC, d) for d in DEPS]
-    if not force and os.path.exists(LIB) and all(os.path.getmtime(d) <= os.path.getmtime(LIB) for d in deps if os.path.exists(d)):
-        return LIB
+    """One object per translation unit (compiled in parallel, rebuilt only when its sources changed), then the link."""
+    srcs = [s for s in HIP_SOURCES if os.path.exists(os.path.join(CSRC, s))]
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + ["-o", LIB] + srcs
-    if verbose:
-        print(" ".join(cmd), file=sys.stderr)
-    subprocess.check_call(cmd)
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    compile_flags = [f for f in FLAGS if f != "-shared"]
+    jobs, objs = [], []
+    for src in srcs:
+        obj = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
+        objs.append(obj)
+        deps = [os.path.join(CSRC, d) for d in [src] + UNIT_DEPS.get(src, []) + COMMON_DEPS]
+        deps = [d for d in deps if os.path.exists(d)] + [os.path.abspath(__file__)]
+        if force or not os.path.exists(obj) or any(os.path.getmtime(d) > os.path.getmtime(obj) for d in deps):
+            cmd = [hipcc] + compile_flags + ["-c", "-o", obj, os.path.join(CSRC, src)]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            jobs.append((cmd, subprocess.Popen(cmd)))
+    failed = [cmd for cmd, p in jobs if p.wait() != 0]
+    if failed:
+        raise subprocess.CalledProcessError(1, failed[0])
+    if jobs or not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
     return LIB
 
 

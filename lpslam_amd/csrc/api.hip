@@ -140,6 +140,56 @@ int lp_pool_alloc(lpslam_hip_ctx* c, size_t bytes, void** out, size_t* capacity)
     return LPSLAM_HIP_OK;
 }
 
+hipStream_t lp_stream_acquire(lpslam_hip_ctx* c)
+{
+    {
+        std::lock_guard<std::mutex> lock(c->pool_mutex);
+        if (!c->ba_streams.empty()) { hipStream_t s = c->ba_streams.back(); c->ba_streams.pop_back(); return s; }
+    }
+    // a bundle adjustment runs beside the front end of later frames (the reference's mapping thread), at the highest priority: its
+    // kernels are small and latency bound, the front end's fill the chip for 100 us at a time
+    int prio_least = 0, prio_greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    hipStream_t s = nullptr;
+    if (hipStreamCreateWithPriority(&s, hipStreamNonBlocking, prio_greatest) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return s;
+}
+
+void lp_stream_release(lpslam_hip_ctx* c, hipStream_t s)
+{
+    if (!s) return;
+    std::lock_guard<std::mutex> lock(c->pool_mutex);
+    c->ba_streams.push_back(s);
+}
+
+void* lp_pin_big_alloc(lpslam_hip_ctx* c, size_t bytes, size_t* capacity)
+{
+    const size_t want = ((std::max<size_t>(bytes, 1) + 65535) / 65536) * 65536;
+    {
+        std::lock_guard<std::mutex> lock(c->pool_mutex);
+        for (size_t i = 0; i < c->pin_big.size(); ++i)
+            if (c->pin_big[i].first >= want && c->pin_big[i].first <= 4 * want) {
+                void* p = c->pin_big[i].second; *capacity = c->pin_big[i].first;
+                c->pin_big[i] = c->pin_big.back(); c->pin_big.pop_back();
+                return p;
+            }
+    }
+    void* p = nullptr;
+    if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    *capacity = want;
+    return p;
+}
+
+void lp_pin_big_free(lpslam_hip_ctx* c, void* p, size_t capacity)
+{
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> lock(c->pool_mutex);
+        if (c->pin_big.size() < 16) { c->pin_big.emplace_back(capacity, p); return; }
+    }
+    (void)hipHostFree(p);
+}
+
 void* lp_pin_alloc(lpslam_hip_ctx* c)
 {
     {
@@ -317,6 +367,10 @@ void lpslam_hip_destroy(lpslam_hip_ctx* c)
     for (int i = 0; i < LPSLAM_HIP_MAX_TIMERS; ++i) { if (c->ev_begin[i]) (void)hipEventDestroy(c->ev_begin[i]); if (c->ev_end[i]) (void)hipEventDestroy(c->ev_end[i]); }
     for (void* p : c->pin_free) (void)hipHostFree(p);
     c->pin_free.clear();
+    for (auto& pb : c->pin_big) (void)hipHostFree(pb.second);
+    c->pin_big.clear();
+    for (hipStream_t st : c->ba_streams) (void)hipStreamDestroy(st);
+    c->ba_streams.clear();
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->h_match) (void)hipHostFree(c->h_match);
     if (c->stream) (void)hipStreamDestroy(c->stream);

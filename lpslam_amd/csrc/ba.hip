@@ -54,28 +54,51 @@ struct BaCtl {                        // device-resident LM state (g2o Optimizat
     int spec;                         // linearisation set [cur] already holds the linearisation of state cur (speculated beside the trial)
 };
 
-struct BaView {                       // device pointers handed to kernels by value
+// Pointer members of the view are typed as global-address-space pointers in the device pass: a view is read from device memory
+// (views[blockIdx.y], scalar loads), and a pointer that comes out of memory is a generic ("flat") pointer to the compiler --
+// flat loads count on both vmcnt and lgkmcnt and return out of order, so every wait on them is a full drain.  With the address
+// space in the type every access through the view is a global_load / global_store with counted waits, as with by-value kernel
+// arguments.  The host pass sees plain pointers of the same size and layout.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define GPTR(T) __attribute__((address_space(1))) T*
+#else
+#define GPTR(T) T*
+#endif
+template <class D, class S> inline void vset(D& d, S* s) { d = (D)s; }       // host side: generic pointer into a view member
+
+struct BaView {                       // one problem, resident in device memory (kernels index an array of them by blockIdx.y)
     int n_poses, n_points, n_obs, n_free, dim, dim_pad;
-    double* poses_buf[2]; double* points_buf[2];
-    const double* poses; const double* points;        // set by the kernel prologue (state being evaluated)
-    const int* pose_slot; const int* free_pose;
-    const int* o_pose; const int* o_point;
-    const double* o_u; const double* o_v; const double* o_ur; const double* o_w;
-    const uint8_t* o_active;
-    const int* pt_start; const int* pt_obs; const int* ps_start; const int* o_orig;
-    double* W; double* Hll; double* bl; double* Hpp; double* hl_obs; double* partial;   // linearisation set in use (ba_lin_set)
-    double* W2[2]; double* hl2[2]; double* partial2[2]; double* partial_trial;   // both sets (indexed like the state buffers) + trial chi2 partials
-    double* S; double* rhs; double* bp; double* hppdiag; double* chi_cur;   // reduced buffer sections (all-reduced when partitioned)
-    double* bp_loc; double* hppdiag_loc; double* chi_loc;                    // this rank's own sums (equal to the above on one GPU)
-    double* Minv;                                                            // L^-T row blocks (dim_pad x dim_pad)
-    double* Ldiag;                                                           // factored diagonal blocks [nb][32][32]
-    double* Lsub;                                                            // L_j1,j of every panel pair, stored at [j1][32][32]
-    double* xp; double* chi_pose; double* part; double* scal;
-    const int* blk_start; const int4* blk_terms;                  // Schur pair lists: (observation a, observation b, their landmark, -)
-    const int4* blk_work; double* blk_part; int* blk_ticket;      // Schur work items (block, part, parts, first item), partial sums, per-block tickets
-    BaCtl* ctl; lpslam_hip_ba_iter_log* log;
+    // launch extents of this problem (a batch launches the maximum over its problems; surplus workgroups exit at once)
+    int obs_blocks;                   // ceil(n_obs / 256): observation-side linearisation
+    int pose_blocks;                  // ceil(n_poses * SPLIT / 4): pose-side linearisation / trial chi2
+    int point_blocks;                 // ceil(n_points / 256): k_ba_point_sum
+    int part_n;                       // max(ceil(n_points / 64), 1): k_ba_backsub landmark blocks = entries of `part`
+    int n_blocks;                     // pose-block pairs (n_free (n_free + 1) / 2)
+    int pad0;
+    GPTR(double) poses_buf[2]; GPTR(double) points_buf[2];
+    GPTR(const double) poses; GPTR(const double) points;        // set by the kernel prologue (state being evaluated)
+    GPTR(const double) poses0; GPTR(const double) points0;      // state given at creation (reset)
+    GPTR(const int) pose_slot; GPTR(const int) free_pose;
+    GPTR(const int) o_pose; GPTR(const int) o_point;
+    GPTR(const double) o_u; GPTR(const double) o_v; GPTR(const double) o_ur; GPTR(const double) o_w;
+    GPTR(uint8_t) o_active;
+    GPTR(const int) pt_start; GPTR(const int) pt_obs; GPTR(const int) ps_start; GPTR(const int) o_orig;
+    GPTR(double) W; GPTR(double) Hll; GPTR(double) bl; GPTR(double) Hpp; GPTR(double) hl_obs; GPTR(double) partial;   // linearisation set in use (ba_lin_set)
+    GPTR(double) W2[2]; GPTR(double) hl2[2]; GPTR(double) partial2[2]; GPTR(double) partial_trial;   // both sets (indexed like the state buffers) + trial chi2 partials
+    GPTR(double) S; GPTR(double) rhs; GPTR(double) bp; GPTR(double) hppdiag; GPTR(double) chi_cur;   // reduced buffer sections (all-reduced when partitioned)
+    GPTR(double) bp_loc; GPTR(double) hppdiag_loc; GPTR(double) chi_loc;                    // this rank's own sums (equal to the above on one GPU)
+    GPTR(double) Minv;                                                            // L^-T row blocks (dim_pad x dim_pad)
+    GPTR(double) Ldiag;                                                           // factored diagonal blocks [nb][32][32]
+    GPTR(double) Lsub;                                                            // L_j1,j of every panel pair, stored at [j1][32][32]
+    GPTR(double) xp; GPTR(double) chi_pose; GPTR(double) part; GPTR(double) scal;
+    GPTR(const int) blk_start; GPTR(const int4) blk_terms;        // Schur pair lists: (observation a, observation b, their landmark, -)
+    GPTR(double) blk_part; GPTR(int) blk_ticket;                  // Schur partial sums [block][4][36], per-block tickets
+    GPTR(BaCtl) ctl; GPTR(lpslam_hip_ba_iter_log) log;
     BaCam cam;
 };
+
+// The view of problem blockIdx.y.  `views` is const __restrict__ and read before any store of the kernel: scalar loads.
+#define BA_VIEW(v) BaView v = views[blockIdx.y]
 
 __device__ __forceinline__ bool ba_idle(const BaCtl* c) { return c->stopped || c->outer_done >= c->max_outer; }
 // selects the evaluated state: the accepted one (trial = 0) or the trial one
@@ -291,12 +314,15 @@ __device__ __forceinline__ void obs_lin_body(BaView& v, int bid, int robust, int
 //      that finishes last starts the outer iteration.
 __device__ void pose_combine_body(BaView& v, int mode, int part_n, int fused);
 __device__ void lm_begin(BaView& v, double max_diag_pp, double max_diag_ll, double chi_cur);
-__global__ __launch_bounds__(256) void k_ba_point_sum(BaView v, int part_n, int fused)
+__global__ __launch_bounds__(256) void k_ba_point_sum(const BaView* __restrict__ views, int fused)
 {
+    BA_VIEW(v);
+    const int part_n = v.point_blocks;                     // landmark workgroups of this problem; workgroup part_n combines the pose partials
+    if ((int)blockIdx.x > part_n) return;
     if (ba_idle(v.ctl) || !v.ctl->need_lin) return;
     ba_lin_set(v, v.ctl->cur);
     __shared__ double sm[4];
-    if ((int)blockIdx.x == (int)gridDim.x - 1) {
+    if ((int)blockIdx.x == part_n) {
         // the extra workgroup: the pose partials of the linearisation are complete before this launch, so they are combined
         // here, beside the landmark sums, instead of on the critical path of the workgroup that finishes last
         pose_combine_body(v, 0, part_n, 0);
@@ -321,7 +347,7 @@ __global__ __launch_bounds__(256) void k_ba_point_sum(BaView v, int part_n, int 
         __syncthreads();
         if (threadIdx.x == 0 && (int)blockIdx.x < part_n) st_sc1(&v.part[blockIdx.x], fmax(fmax(sm[0], sm[1]), fmax(sm[2], sm[3])));
     }
-    if (!ba_last_block_sc1(v.ctl, gridDim.x)) return;
+    if (!ba_last_block_sc1(v.ctl, part_n + 1)) return;
     // last workgroup: max diag H_ll over the block maxima, then the start of the outer iteration (lambda_0)
     if (threadIdx.x < 64) {
         double acc = 0;
@@ -546,8 +572,11 @@ __device__ void pose_combine_body(BaView& v, int mode, int part_n, int fused)
 // ---- linearisation 1/2: the observation side (blocks [0, obs_blocks)) and the pose side (the rest) of the accepted state in one
 //      launch: both only read the state, so they run side by side.  Skipped when the previous trial launch already linearised
 //      this state on speculation (ctl->spec).
-__global__ __launch_bounds__(256) void k_ba_lin(BaView v, int robust, int points_fixed, int obs_blocks)
+__global__ __launch_bounds__(256) void k_ba_lin(const BaView* __restrict__ views, int robust, int points_fixed)
 {
+    BA_VIEW(v);
+    const int obs_blocks = v.obs_blocks;
+    if ((int)blockIdx.x >= obs_blocks + v.pose_blocks) return;
     if (ba_idle(v.ctl) || !v.ctl->need_lin || v.ctl->spec) return;
     const int idx = v.ctl->cur;
     if ((int)blockIdx.x < obs_blocks) obs_lin_body(v, blockIdx.x, robust, points_fixed, idx);
@@ -559,8 +588,11 @@ __global__ __launch_bounds__(256) void k_ba_lin(BaView v, int robust, int points
 //      trial is accepted far more often than not, and then the next iteration starts with its linearisation done (the sets are
 //      double buffered like the states, a rejected trial leaves the accepted state's set untouched).  These workgroups read
 //      ctl->cur_launch, not ctl->cur, which the decision may flip while they run.
-__global__ __launch_bounds__(256) void k_ba_trial(BaView v, int robust, int part_n, int fused, int trial_blocks, int obs_blocks, int points_fixed, int spec)
+__global__ __launch_bounds__(256) void k_ba_trial(const BaView* __restrict__ views, int robust, int fused, int points_fixed, int spec)
 {
+    BA_VIEW(v);
+    const int part_n = v.part_n, trial_blocks = v.pose_blocks, obs_blocks = v.obs_blocks;
+    if ((int)blockIdx.x >= trial_blocks + (spec ? obs_blocks + trial_blocks : 0)) return;
     if (ba_idle(v.ctl)) return;
     const int idx = v.ctl->cur_launch ^ 1;
     if ((int)blockIdx.x >= trial_blocks) {
@@ -574,16 +606,18 @@ __global__ __launch_bounds__(256) void k_ba_trial(BaView v, int robust, int part
 }
 
 // partitioned solve: lambda control on the all-reduced quantities
-__global__ __launch_bounds__(64) void k_lm_begin(BaView v)
+__global__ __launch_bounds__(64) void k_lm_begin(const BaView* __restrict__ views)
 {
+    BA_VIEW(v);
     if (ba_idle(v.ctl) || !v.ctl->need_lin) return;
     double m = 0;
     for (int i = threadIdx.x; i < v.dim; i += 64) m = fmax(m, fabs(v.hppdiag[i]));
     m = wave_max(m);
     if (threadIdx.x == 0) lm_begin(v, m, v.scal[4], *v.chi_cur);
 }
-__global__ void k_lm_decide(BaView v)
+__global__ void k_lm_decide(const BaView* __restrict__ views)
 {
+    BA_VIEW(v);
     if (ba_idle(v.ctl)) return;
     if (threadIdx.x == 0 && blockIdx.x == 0) lm_decide(v, v.scal[1], v.scal[5], v.scal[2], v.scal[3]);
 }
@@ -602,8 +636,11 @@ __device__ __forceinline__ void obs_y_row(const double* h, double w0, double w1,
 //      Blocks [n_work, n_work + n_free): rhs_i = b_p,i - sum Y b_l over the observations of keyframe i.
 //      fused != 0 (single-GPU solve): lambda goes onto the pose diagonal, rhs straight into row `dim` of S and the failure
 //      flag / rhs pivot are reset here, so no separate preparation launch is needed.
-__global__ __launch_bounds__(64) void k_ba_schur(BaView v, int n_work, int fused)
+__global__ __launch_bounds__(64) void k_ba_schur(const BaView* __restrict__ views, int fused)
 {
+    BA_VIEW(v);
+    const int n_work = 4 * v.n_blocks;                     // work item = (block pair, part): see below
+    if ((int)blockIdx.x >= n_work + v.n_free) return;
     if (ba_idle(v.ctl)) return;
     const double lambda = v.ctl->lambda;
     ba_lin_set(v, v.ctl->cur);
@@ -663,8 +700,14 @@ __global__ __launch_bounds__(64) void k_ba_schur(BaView v, int n_work, int fused
     // work item = (block pair, part, parts): pair lists longer than 256 terms are cut into up to 4 interleaved parts (64-term
     // chunks round-robin), so that the longest list -- a keyframe's diagonal block, one term per observation -- no longer sets
     // the kernel's duration; the part that finishes last adds the parts up in order (fixed summation order).
-    const int4 wk = v.blk_work[blockIdx.x];
-    const int blk = wk.x, part_id = wk.y, parts = wk.z;
+    // Items [0, n_blocks) are part 0 of every block, items n_blocks + 3 blk + (part - 1) the further parts: no work table, the
+    // number of parts follows from the length of the block's list (a surplus item exits here).
+    const int nblk = v.n_blocks;
+    const int blk = (int)blockIdx.x < nblk ? (int)blockIdx.x : ((int)blockIdx.x - nblk) / 3;
+    const int part_id = (int)blockIdx.x < nblk ? 0 : 1 + ((int)blockIdx.x - nblk) % 3;
+    const int n_terms = v.blk_start[blk + 1] - v.blk_start[blk];
+    const int parts = min(4, max(1, (n_terms + 255) / 256));
+    if (part_id >= parts) return;
     int pidx = blk, i = 0;
     {
         int rowlen = v.n_free;
@@ -706,7 +749,7 @@ __global__ __launch_bounds__(64) void k_ba_schur(BaView v, int n_work, int fused
         // hand-over without cache maintenance: the partial sums are stored write-through (sc1) and read back L1-bypassing (sc1),
         // the ticket is a relaxed agent-scope add made after this (single) wavefront's stores have drained -- no buffer_wbl2 /
         // buffer_inv, which cost more than the part they guard (MI355X_MICROARCH: valid forms, one unsharded counter)
-        double* mine = v.blk_part + (size_t)(wk.w + part_id) * 36;
+        double* mine = v.blk_part + (size_t)(4 * blk + part_id) * 36;
         if (lane < 36) __hip_atomic_store(&mine[lane], sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __shared__ int s_last;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -718,7 +761,7 @@ __global__ __launch_bounds__(64) void k_ba_schur(BaView v, int n_work, int fused
         __syncthreads();
         if (!s_last) return;
         sum = 0;
-        if (lane < 36) for (int p = 0; p < parts; ++p) sum += __hip_atomic_load(&v.blk_part[(size_t)(wk.w + p) * 36 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane < 36) for (int p = 0; p < parts; ++p) sum += __hip_atomic_load(&v.blk_part[(size_t)(4 * blk + p) * 36 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (lane >= 36) return;
     const int r = lane / 6, c = lane - r * 6;
@@ -733,8 +776,9 @@ __global__ __launch_bounds__(64) void k_ba_schur(BaView v, int n_work, int fused
 }
 
 // preparation for the partitioned (all-reduced) solve: lambda on the diagonal, rhs row, flag / pivot reset
-__global__ __launch_bounds__(256) void k_chol_prep(BaView v)
+__global__ __launch_bounds__(256) void k_chol_prep(const BaView* __restrict__ views)
 {
+    BA_VIEW(v);
     if (ba_idle(v.ctl)) return;
     const double lambda = v.ctl->lambda;
     const int n = v.dim_pad, dim = v.dim;
@@ -888,14 +932,21 @@ __device__ __forceinline__ void tile_sub(double* D, int tr, int tc, int lr, int 
     for (int q = 0; q < 4; ++q) D[(tr + lk + 4 * q) * (NB + 1) + tc + lr] -= acc[q];
 }
 
-__global__ __launch_bounds__(256) void k_chol_pair(BaView v, int nb, int m, int pin)
+__global__ __launch_bounds__(256) void k_chol_pair(const BaView* __restrict__ views, int m, int pin)
 {
     if (pin && (blockIdx.x & 7)) return;                 // small launches: XCD 0 only (see above); large ones use the whole chip
+    BA_VIEW(v);
+    const int nb = v.dim_pad / NB;
+    if (2 * m >= nb || v.dim == 0) return;               // a batch runs the panel pairs of its largest system; a problem without free poses has none
     const int bid = pin ? blockIdx.x >> 3 : blockIdx.x;
+    {
+        const int ncol0 = (2 * m + 1 < nb) ? 2 : 1, T0 = nb - 2 * m - ncol0;
+        if (bid >= 1 + T0 + 2 * m + ncol0 + (m > 0 ? T0 * (T0 + 1) / 2 + 2 * m * T0 : 0)) return;
+    }
     const bool idle = ba_idle(v.ctl);
     extern __shared__ double cp_lds[];
-    double* S = v.S;
-    double* M = v.Minv;
+    GPTR(double) S = v.S;
+    GPTR(double) M = v.Minv;
     const int n = v.dim_pad;
     const int j = 2 * m, j1 = j + 1;
     const bool single = j1 >= nb;
@@ -1076,7 +1127,8 @@ __global__ __launch_bounds__(256) void k_chol_pair(BaView v, int nb, int m, int 
 }
 
 // the whole factorisation + L^-T rows: ceil(nb / 2) launches
-void enqueue_cholesky(hipStream_t s, const BaView& v, int nb)
+// nb = panels of the (largest) system, count = problems (grid.y; every problem reads its own size from its view)
+void enqueue_cholesky(hipStream_t s, const BaView* d_views, int count, int nb)
 {
     // the attribute belongs to the (function, device) pair: once per device this process uses
     static std::atomic<bool> attr_set[64];
@@ -1091,18 +1143,19 @@ void enqueue_cholesky(hipStream_t s, const BaView& v, int nb)
         const int T = nb - j - ncol;
         const int n_panel = 1 + (nb - j - ncol) + (j + ncol);
         const int n_update = m > 0 ? T * (T + 1) / 2 + j * T : 0;
-        const int pin = (n_panel + n_update) <= 96 ? 1 : 0;       // 32 CUs of one XCD hold a latency-bound launch; a throughput-bound one needs all 256
-        hipLaunchKernelGGL(k_chol_pair, dim3((n_panel + n_update) * (pin ? 8 : 1)), dim3(256), CP_LDS_BYTES, s, v, nb, m, pin);
+        // 32 CUs of one XCD hold a latency-bound launch of one problem; a throughput-bound one (or a batch) needs all 256
+        const int pin = (count == 1 && (n_panel + n_update) <= 96) ? 1 : 0;
+        hipLaunchKernelGGL(k_chol_pair, dim3((n_panel + n_update) * (pin ? 8 : 1), count), dim3(256), CP_LDS_BYTES, s, d_views, m, pin);
     }
 }
-
 // x_p = L^-T y with y = L[dim][0..dim): one wavefront per row of the (upper triangular) L^-T, butterfly sum
-__global__ __launch_bounds__(256) void k_chol_xsolve(BaView v)
+__global__ __launch_bounds__(256) void k_chol_xsolve(const BaView* __restrict__ views, int pin)
 {
-    if (blockIdx.x & 7) return;           // XCD 0 only, like k_chol_pair: its inputs sit in that L2
+    if (pin && (blockIdx.x & 7)) return;  // XCD 0 only, like k_chol_pair: its inputs sit in that L2
+    BA_VIEW(v);
     if (ba_idle(v.ctl)) return;
     const int lane = threadIdx.x & 63;
-    const int i = (blockIdx.x >> 3) * 4 + (threadIdx.x >> 6);
+    const int i = (pin ? blockIdx.x >> 3 : blockIdx.x) * 4 + (threadIdx.x >> 6);
     if (i >= v.dim) return;
     const int n = v.dim_pad;
     // y = L^-1 rhs is row `dim` of L: off-diagonal blocks live in S, the part inside the row's own diagonal block in Ldiag
@@ -1119,14 +1172,23 @@ __global__ __launch_bounds__(256) void k_chol_xsolve(BaView v)
     if (lane == 0) v.xp[i] = acc;
 }
 
-// ---- landmark back substitution and update (4 lanes per landmark); the last block applies x_p to the poses -------------------
-__global__ __launch_bounds__(256) void k_ba_backsub(BaView v, int point_blocks)
+void enqueue_xsolve(hipStream_t s, const BaView* d_views, int count, int dim)
 {
+    const int pin = count == 1 ? 1 : 0;
+    hipLaunchKernelGGL(k_chol_xsolve, dim3((dim + 3) / 4 * (pin ? 8 : 1), count), dim3(256), 0, s, d_views, pin);
+}
+
+// ---- landmark back substitution and update (4 lanes per landmark); the last block applies x_p to the poses -------------------
+__global__ __launch_bounds__(256) void k_ba_backsub(const BaView* __restrict__ views)
+{
+    BA_VIEW(v);
+    const int point_blocks = v.part_n;
+    if ((int)blockIdx.x > point_blocks) return;
     if (ba_idle(v.ctl)) return;
     const double lambda = v.ctl->lambda;
     ba_select(v, 0); ba_lin_set(v, v.ctl->cur);
-    double* poses_out = v.ctl->cur ? v.poses_buf[0] : v.poses_buf[1];
-    double* points_out = v.ctl->cur ? v.points_buf[0] : v.points_buf[1];
+    GPTR(double) poses_out = v.ctl->cur ? v.poses_buf[0] : v.poses_buf[1];
+    GPTR(double) points_out = v.ctl->cur ? v.points_buf[0] : v.points_buf[1];
     if ((int)blockIdx.x == point_blocks) {
         // trial poses = exp(x_p) * poses; scal[3] = sum x_p (lambda x_p + b_p) (fixed order, one wavefront)
         if (threadIdx.x == 0) v.ctl->cur_launch = v.ctl->cur;      // what the trial launch reads while the decision flips `cur`
@@ -1186,8 +1248,9 @@ __global__ __launch_bounds__(256) void k_ba_backsub(BaView v, int point_blocks)
 }
 
 // per-observation chi2 (non robust) and depth sign of the accepted state
-__global__ __launch_bounds__(256) void k_ba_obs_chi2(BaView v, double* chi2, uint8_t* depth_pos)
+__global__ __launch_bounds__(256) void k_ba_obs_chi2(const BaView* __restrict__ views, double* chi2, uint8_t* depth_pos)
 {
+    BA_VIEW(v);
     ba_select(v, 0);
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= v.n_obs) return;
@@ -1485,6 +1548,8 @@ __global__ __launch_bounds__(256) void k_pose_optimize(double* pose7, const doub
     if (tid == 0) *n_inliers = n - sh.bad;
 }
 
+#include "ba_build.inl"
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1493,132 +1558,138 @@ __global__ __launch_bounds__(256) void k_pose_optimize(double* pose7, const doub
 struct lpslam_hip_ba {
     lpslam_hip_ctx* ctx = nullptr;
     hipStream_t stream = nullptr;
-    int n_poses = 0, n_points = 0, n_obs = 0, n_free = 0, dim = 0, dim_pad = 0, n_blocks = 0, n_work = 0;
+    hipEvent_t ev = nullptr;                       // orders this problem's stream before a batch that runs on another one
+    int n_poses = 0, n_points = 0, n_obs = 0, n_free = 0, dim = 0, dim_pad = 0, n_blocks = 0;
+    // one block of the context's cache holds everything (carved at creation); the members below point into it
+    void* block = nullptr; size_t block_cap = 0;
+    BaView h_view{};                               // host copy of the device-resident view
+    BaView* d_view = nullptr;
     double *d_poses[2] = {nullptr, nullptr}, *d_points[2] = {nullptr, nullptr};
-    double *d_poses0 = nullptr, *d_points0 = nullptr;      // state given at creation (lpslam_hip_ba_reset)
-    int *d_pose_slot = nullptr, *d_free_pose = nullptr, *d_o_pose = nullptr, *d_o_point = nullptr;
-    double *d_o_u = nullptr, *d_o_v = nullptr, *d_o_ur = nullptr, *d_o_w = nullptr;
     uint8_t* d_o_active = nullptr; uint8_t* d_act_in = nullptr; int* d_o_orig = nullptr;
-    int *d_pt_start = nullptr, *d_pt_obs = nullptr, *d_ps_start = nullptr;
-    double *d_Hll = nullptr, *d_bl = nullptr, *d_Hpp = nullptr;
-    double *d_W2[2] = {nullptr, nullptr}, *d_hl2[2] = {nullptr, nullptr}, *d_partial2[2] = {nullptr, nullptr}, *d_partial_trial = nullptr;
-    double *d_minv = nullptr, *d_ldiag = nullptr, *d_lsub = nullptr;
     double* d_red = nullptr; int64_t red_n = 0;
-    double *d_xp = nullptr, *d_chi_pose = nullptr, *d_part = nullptr, *d_scal = nullptr, *d_loc = nullptr;
+    double* d_scal = nullptr;
     double* d_chi_obs = nullptr; uint8_t* d_depth = nullptr;
-    int* d_blk_start = nullptr; int4* d_blk_terms = nullptr; int4* d_blk_work = nullptr; double* d_blk_part = nullptr; int* d_blk_ticket = nullptr;
     BaCtl* d_ctl = nullptr; lpslam_hip_ba_iter_log* d_log = nullptr;
-    int part_n = 0;
-    BaCam cam{};
     std::vector<double> h_ur;                      // mono/stereo classification for the outlier thresholds
     BaCtl h_ctl{};                                 // last control block read back
-    BaCtl h_ctl_out{};                             // staging of the control block on its way to the device
-    struct Pinned { BaCtl ctl; BaCtl ctl_out; lpslam_hip_ba_iter_log log[MAX_LOG]; };
+    struct Pinned { BaCtl ctl; lpslam_hip_ba_iter_log log[MAX_LOG]; };
     Pinned* pin = nullptr;                         // page-locked: control block and iteration log come back in one round trip
+    void* stage = nullptr; size_t stage_cap = 0;   // page-locked staging of the creation inputs, handed back at the first synchronisation
     int robust = 1, points_fixed = 0;
-    std::vector<std::pair<void*, size_t>> allocs;      // blocks of the context's cache (lp_pool_alloc)
     int pending_iters = -1;                            // >= 0 between optimize_begin and optimize_end
     std::map<long, hipGraphExec_t> graphs;             // captured first batches by (units, robust, points_fixed); nullptr = seen once
 };
 
 namespace {
 
-template <class T>
-int dalloc(lpslam_hip_ba* b, T** p, size_t n)
+// what a launch chain needs to know: the view array, how many problems it holds and the launch extents (maxima over them)
+struct BaLaunch {
+    const BaView* d_views = nullptr; int count = 0; hipStream_t s = nullptr;
+    int obs_blocks = 0, pose_blocks = 0, point_blocks = 0, part_n = 0, n_free = 0, n_blocks = 0, dim = 0, nb = 0;
+    int robust = 1, points_fixed = 0;
+    void add(const lpslam_hip_ba* b)
+    {
+        const BaView& v = b->h_view;
+        obs_blocks = std::max(obs_blocks, v.obs_blocks); pose_blocks = std::max(pose_blocks, v.pose_blocks);
+        point_blocks = std::max(point_blocks, v.point_blocks); part_n = std::max(part_n, v.part_n);
+        n_free = std::max(n_free, v.n_free); n_blocks = std::max(n_blocks, v.n_blocks); dim = std::max(dim, v.dim);
+        nb = std::max(nb, v.dim_pad / NB);
+        ++count;
+    }
+};
+BaLaunch single_launch(lpslam_hip_ba* b)
 {
-    void* d = nullptr; size_t cap = 0;
-    int rc = lp_pool_alloc(b->ctx, std::max<size_t>(n, 1) * sizeof(T), &d, &cap); if (rc) return rc;
-    *p = (T*)d;
-    b->allocs.emplace_back(d, cap);
-    return LPSLAM_HIP_OK;
-}
-template <class T>
-int upload(lpslam_hip_ba* b, T** p, const std::vector<T>& h)
-{
-    int rc = dalloc(b, p, h.size()); if (rc) return rc;
-    if (!h.empty()) LP_HIP(hipMemcpy(*p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
-    return LPSLAM_HIP_OK;
-}
-
-BaView make_view(lpslam_hip_ba* b)
-{
-    BaView v{};
-    v.n_poses = b->n_poses; v.n_points = b->n_points; v.n_obs = b->n_obs; v.n_free = b->n_free; v.dim = b->dim; v.dim_pad = b->dim_pad;
-    for (int s = 0; s < 2; ++s) { v.poses_buf[s] = b->d_poses[s]; v.points_buf[s] = b->d_points[s]; }
-    v.pose_slot = b->d_pose_slot; v.free_pose = b->d_free_pose; v.o_pose = b->d_o_pose; v.o_point = b->d_o_point;
-    v.o_u = b->d_o_u; v.o_v = b->d_o_v; v.o_ur = b->d_o_ur; v.o_w = b->d_o_w; v.o_active = b->d_o_active;
-    v.pt_start = b->d_pt_start; v.pt_obs = b->d_pt_obs; v.ps_start = b->d_ps_start; v.o_orig = b->d_o_orig;
-    v.Hll = b->d_Hll; v.bl = b->d_bl; v.Hpp = b->d_Hpp;
-    v.hl_obs = b->d_hl2[0]; v.partial = b->d_partial2[0]; v.W = b->d_W2[0];
-    for (int k2 = 0; k2 < 2; ++k2) { v.W2[k2] = b->d_W2[k2]; v.hl2[k2] = b->d_hl2[k2]; v.partial2[k2] = b->d_partial2[k2]; }
-    v.partial_trial = b->d_partial_trial; v.Minv = b->d_minv; v.Ldiag = b->d_ldiag; v.Lsub = b->d_lsub;
-    const size_t n = (size_t)b->dim_pad;
-    v.S = b->d_red; v.rhs = b->d_red + n * n; v.bp = v.rhs + n; v.hppdiag = v.bp + n; v.chi_cur = v.hppdiag + n;
-    v.bp_loc = b->d_loc; v.hppdiag_loc = b->d_loc + n; v.chi_loc = b->d_loc + 2 * n;
-    v.xp = b->d_xp; v.chi_pose = b->d_chi_pose; v.part = b->d_part; v.scal = b->d_scal;
-    v.blk_start = b->d_blk_start; v.blk_terms = b->d_blk_terms; v.blk_work = b->d_blk_work; v.blk_part = b->d_blk_part; v.blk_ticket = b->d_blk_ticket;
-    v.ctl = b->d_ctl; v.log = b->d_log;
-    v.cam = b->cam;
-    return v;
+    BaLaunch L;
+    L.d_views = b->d_view; L.s = b->stream; L.robust = b->robust; L.points_fixed = b->points_fixed;
+    L.add(b);
+    return L;
 }
 
 // linearisation of the accepted state (skipped on the device when the previous trial was rejected)
-int enqueue_linearize(lpslam_hip_ba* b, int fused, bool explicit_lin = true)
+int enqueue_linearize(const BaLaunch& L, int fused, bool explicit_lin = true)
 {
-    BaView v = make_view(b);
-    hipStream_t s = b->stream;
-    const int ob = (b->n_obs + 255) / 256, pb = (b->n_points + 255) / 256;
     // fused solve: only the first unit of an optimize() call linearises here, every later state is linearised beside its trial
-    if (explicit_lin) hipLaunchKernelGGL(k_ba_lin, dim3(ob + (b->n_poses * SPLIT + 3) / 4), dim3(256), 0, s, v, b->robust, b->points_fixed, ob);
-    hipLaunchKernelGGL(k_ba_point_sum, dim3(pb + 1), dim3(256), 0, s, v, pb, fused);      // + the workgroup that combines the pose partials
+    if (explicit_lin) hipLaunchKernelGGL(k_ba_lin, dim3(L.obs_blocks + L.pose_blocks, L.count), dim3(256), 0, L.s, L.d_views, L.robust, L.points_fixed);
+    hipLaunchKernelGGL(k_ba_point_sum, dim3(L.point_blocks + 1, L.count), dim3(256), 0, L.s, L.d_views, fused);      // + the workgroup that combines the pose partials
     LP_HIP(hipGetLastError());
     return LPSLAM_HIP_OK;
 }
 
 // Schur complement for the device's current lambda into the reduced buffer
-int enqueue_reduce(lpslam_hip_ba* b, int fused)
+int enqueue_reduce(const BaLaunch& L, int fused)
 {
-    BaView v = make_view(b);
-    hipStream_t s = b->stream;
-    if (b->n_free) hipLaunchKernelGGL(k_ba_schur, dim3(b->n_work + b->n_free), dim3(64), 0, s, v, b->n_work, fused);
+    if (L.n_free) hipLaunchKernelGGL(k_ba_schur, dim3(4 * L.n_blocks + L.n_free, L.count), dim3(64), 0, L.s, L.d_views, fused);
     LP_HIP(hipGetLastError());
     return LPSLAM_HIP_OK;
 }
 
 // factor + solve, update into the trial state, trial chi2 and scale terms (+ the lambda control when fused)
-int enqueue_solve(lpslam_hip_ba* b, int fused)
+int enqueue_solve(const BaLaunch& L, int fused)
 {
-    BaView v = make_view(b);
-    hipStream_t s = b->stream;
-    const int n = b->dim_pad, nb = n / NB;
-    if (b->dim > 0) {
+    hipStream_t s = L.s;
+    if (L.dim > 0) {
         if (!fused) {
-            hipLaunchKernelGGL(k_lm_begin, dim3(1), dim3(64), 0, s, v);
-            hipLaunchKernelGGL(k_chol_prep, dim3((n + 255) / 256), dim3(256), 0, s, v);
+            hipLaunchKernelGGL(k_lm_begin, dim3(1, L.count), dim3(64), 0, s, L.d_views);
+            hipLaunchKernelGGL(k_chol_prep, dim3((L.nb * NB + 255) / 256, L.count), dim3(256), 0, s, L.d_views);
         }
-        enqueue_cholesky(s, v, nb);
-        hipLaunchKernelGGL(k_chol_xsolve, dim3((b->dim + 3) / 4 * 8), dim3(256), 0, s, v);
+        enqueue_cholesky(s, L.d_views, L.count, L.nb);
+        enqueue_xsolve(s, L.d_views, L.count, L.dim);
     } else if (!fused) {
-        hipLaunchKernelGGL(k_lm_begin, dim3(1), dim3(64), 0, s, v);
+        hipLaunchKernelGGL(k_lm_begin, dim3(1, L.count), dim3(64), 0, s, L.d_views);
     }
-    const int pb = (b->n_points + 63) / 64;
-    hipLaunchKernelGGL(k_ba_backsub, dim3(pb + 1), dim3(256), 0, s, v, pb);
+    hipLaunchKernelGGL(k_ba_backsub, dim3(L.part_n + 1, L.count), dim3(256), 0, s, L.d_views);
     {
         // fused solve: the trial launch also linearises the trial state on speculation (observation side + pose side)
-        const int tb = (b->n_poses * SPLIT + 3) / 4, ob = (b->n_obs + 255) / 256, spec = fused ? 1 : 0;
-        hipLaunchKernelGGL(k_ba_trial, dim3(tb + (spec ? ob + tb : 0)), dim3(256), 0, s, v, b->robust, pb, fused, tb, ob, b->points_fixed, spec);
+        const int spec = fused ? 1 : 0;
+        hipLaunchKernelGGL(k_ba_trial, dim3(L.pose_blocks + (spec ? L.obs_blocks + L.pose_blocks : 0), L.count), dim3(256), 0, s, L.d_views, L.robust, fused, L.points_fixed, spec);
     }
     LP_HIP(hipGetLastError());
     return LPSLAM_HIP_OK;
 }
 
-int write_ctl(lpslam_hip_ba* b, const BaCtl& c)
+// ---- control block on the device: armed, reset and collected by kernels (one launch for any number of problems) -------------
+// arms the control block for an optimize() call of `iters` outer iterations (g2o: lambda_0 is recomputed per call)
+__global__ __launch_bounds__(64) void k_ba_arm(const BaView* __restrict__ views, int iters)
 {
-    b->h_ctl_out = c;        // the source must outlive the copy: a member, rewritten only after the next read_ctl (which synchronises)
-    BaCtl* src = &b->h_ctl_out;
-    if (b->pin) { b->pin->ctl_out = c; src = &b->pin->ctl_out; }
-    LP_HIP(hipMemcpyAsync(b->d_ctl, src, sizeof(BaCtl), hipMemcpyHostToDevice, b->stream));
-    return LPSLAM_HIP_OK;
+    BA_VIEW(v);
+    if (threadIdx.x != 0) return;
+    BaCtl c = *v.ctl;
+    c.max_outer = iters; c.outer_done = 0; c.need_lin = 1; c.first = 1; c.qmax = 0; c.stopped = 0; c.ni = 2; c.rho = 0; c.last_accepted = 0;
+    c.ticket = 0; c.spec = 0; c.cur_launch = c.cur;
+    *v.ctl = c;
+}
+// state given at creation back into buffer 0, every observation active, LM state cleared
+__global__ __launch_bounds__(256) void k_ba_reset(const BaView* __restrict__ views)
+{
+    BA_VIEW(v);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < 7 * v.n_poses) v.poses_buf[0][i] = v.poses0[i];
+    if (i < 3 * v.n_points) v.points_buf[0][i] = v.points0[i];
+    if (i < v.n_obs) v.o_active[i] = 1;
+    if (i == 0) {
+        BaCtl c{};
+        c.ni = 2; c.need_lin = 1; c.first = 1;
+        *v.ctl = c;
+    }
+}
+// control block + iteration log of every problem of a batch into one contiguous buffer (one copy to the host)
+constexpr int COLLECT_STRIDE = (int)((sizeof(BaCtl) + MAX_LOG * sizeof(lpslam_hip_ba_iter_log) + 15) / 16 * 16);
+__global__ __launch_bounds__(64) void k_ba_collect(const BaView* __restrict__ views, uint8_t* out, int n_log)
+{
+    BA_VIEW(v);
+    uint8_t* dst = out + (size_t)blockIdx.y * COLLECT_STRIDE;
+    const int* src_c = reinterpret_cast<const int*>((const BaCtl*)v.ctl);
+    int* dst_c = reinterpret_cast<int*>(dst);
+    for (int i = threadIdx.x; i < (int)(sizeof(BaCtl) / 4); i += 64) dst_c[i] = src_c[i];
+    const int* src_l = reinterpret_cast<const int*>((const lpslam_hip_ba_iter_log*)v.log);
+    int* dst_l = reinterpret_cast<int*>(dst + sizeof(BaCtl));
+    const int words = min(n_log, MAX_LOG) * (int)(sizeof(lpslam_hip_ba_iter_log) / 4);
+    for (int i = threadIdx.x; i < words; i += 64) dst_l[i] = src_l[i];
+}
+
+void release_stage(lpslam_hip_ba* b)
+{
+    if (b->stage) { lp_pin_big_free(b->ctx, b->stage, b->stage_cap); b->stage = nullptr; b->stage_cap = 0; }
 }
 // control block (and, with log_entries > 0, that many entries of the iteration log) to the host: one synchronisation
 int read_ctl(lpslam_hip_ba* b, int log_entries = 0)
@@ -1629,22 +1700,27 @@ int read_ctl(lpslam_hip_ba* b, int log_entries = 0)
             LP_HIP(hipMemcpyAsync(b->pin->log, b->d_log, (size_t)std::min(log_entries, MAX_LOG) * sizeof(lpslam_hip_ba_iter_log), hipMemcpyDeviceToHost, b->stream));
         LP_HIP(hipStreamSynchronize(b->stream));
         b->h_ctl = b->pin->ctl;
+        release_stage(b);
         return LPSLAM_HIP_OK;
     }
     LP_HIP(hipMemcpyAsync(&b->h_ctl, b->d_ctl, sizeof(BaCtl), hipMemcpyDeviceToHost, b->stream));
     LP_HIP(hipStreamSynchronize(b->stream));
+    release_stage(b);
     return LPSLAM_HIP_OK;
 }
 
-// arms the control block for an optimize() call of `iters` outer iterations (g2o: lambda_0 is recomputed per call)
 int begin_optimize(lpslam_hip_ba* b, int robust, int iters)
 {
     b->robust = robust;
-    BaCtl c = b->h_ctl;
-    c.max_outer = iters; c.outer_done = 0; c.need_lin = 1; c.first = 1; c.qmax = 0; c.stopped = 0; c.ni = 2; c.rho = 0; c.last_accepted = 0; c.ticket = 0; c.spec = 0; c.cur_launch = c.cur;
-    b->h_ctl = c;
-    return write_ctl(b, c);
+    hipLaunchKernelGGL(k_ba_arm, dim3(1, 1), dim3(64), 0, b->stream, b->d_view, iters);
+    LP_HIP(hipGetLastError());
+    return LPSLAM_HIP_OK;
 }
+
+struct Carve {
+    size_t off = 0;
+    size_t take(size_t bytes) { const size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; }
+};
 
 }  // namespace
 
@@ -1658,152 +1734,146 @@ int lpslam_hip_ba_create(lpslam_hip_ctx* ctx, const double* poses, const uint8_t
         set_error("invalid bundle-adjustment arguments"); return LPSLAM_HIP_ERR_INVALID;
     }
     *out = nullptr;
-    for (int k = 0; k < n_obs; ++k)
+    // range check + landmark degrees (bound of the pair lists: every ordered pair of observations of a landmark)
+    std::vector<int> deg((size_t)std::max(n_points, 1), 0);
+    for (int k = 0; k < n_obs; ++k) {
         if (obs[k].pose < 0 || obs[k].pose >= n_poses || obs[k].point < 0 || obs[k].point >= n_points) {
             set_error("observation %d references pose %d / point %d out of range", k, obs[k].pose, obs[k].point);
             return LPSLAM_HIP_ERR_INVALID;
         }
+        deg[obs[k].point]++;
+    }
+    size_t terms_cap = 0;
+    for (int j = 0; j < n_points; ++j) { terms_cap += (size_t)deg[j] * deg[j]; if (deg[j] > 0xFFFF) { set_error("landmark %d has more than 65535 observations", j); return LPSLAM_HIP_ERR_INVALID; } }
     LP_HIP(hipSetDevice(ctx->cfg.device));
     lpslam_hip_ba* b = new lpslam_hip_ba();
     b->ctx = ctx;
     static_assert(sizeof(lpslam_hip_ba::Pinned) <= 8192, "pinned block size");
     b->pin = static_cast<lpslam_hip_ba::Pinned*>(lp_pin_alloc(ctx));      // nullptr: the pageable path stays
-    // own stream: a bundle adjustment runs beside the front end of later frames (the reference's mapping thread)
-    // ... at the highest priority: its kernels are small and latency bound, the front end's fill the chip for 100 us at a time
-    int prio_least = 0, prio_greatest = 0;
-    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
-    if (hipStreamCreateWithPriority(&b->stream, hipStreamNonBlocking, prio_greatest) != hipSuccess) { delete b; set_error("hipStreamCreate failed"); return LPSLAM_HIP_ERR_DEVICE; }
+    // own stream (from the context's cache): a bundle adjustment runs beside the front end of later frames
+    b->stream = lp_stream_acquire(ctx);
+    if (!b->stream) { lpslam_hip_ba_destroy(b); set_error("hipStreamCreate failed"); return LPSLAM_HIP_ERR_DEVICE; }
     b->n_poses = n_poses; b->n_points = n_points; b->n_obs = n_obs;
-    b->cam = BaCam{cam->fx, cam->fy, cam->cx, cam->cy, cam->focal_x_baseline, cam->huber_mono, cam->huber_stereo};
     std::vector<int> slot(n_poses), free_pose;
     for (int i = 0; i < n_poses; ++i) { if (fixed && fixed[i]) slot[i] = -1; else { slot[i] = (int)free_pose.size(); free_pose.push_back(i); } }
     b->n_free = (int)free_pose.size();
     b->dim = 6 * b->n_free;
     b->dim_pad = ((b->dim + 1 + NB - 1) / NB) * NB;           // room for the rhs row
     b->n_blocks = b->n_free * (b->n_free + 1) / 2;
-    // Observations are stored keyframe by keyframe and, inside a keyframe, by landmark (stable in the input order): the pose-side
-    // passes then index them directly and coalesced, and the Schur pair lists -- by far the largest gather -- walk Y and W in
-    // ascending order.  o_orig maps back to the caller's indices for the per-observation inputs / outputs of the API.
-    std::vector<int> order(n_obs);
-    for (int k = 0; k < n_obs; ++k) order[k] = k;
-    std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
-        return obs[x].pose != obs[y].pose ? obs[x].pose < obs[y].pose : obs[x].point < obs[y].point; });
-    std::vector<int> o_pose(n_obs), o_point(n_obs);
-    std::vector<double> ou(n_obs), ov(n_obs), our(n_obs), ow(n_obs);
-    std::vector<int> pt_start(n_points + 1, 0), ps_start(n_poses + 1, 0), pt_obs(n_obs);
-    b->h_ur.resize(n_obs);
-    for (int k = 0; k < n_obs; ++k) {
-        const lpslam_hip_ba_obs& o = obs[order[k]];
-        o_pose[k] = o.pose; o_point[k] = o.point; ou[k] = o.u; ov[k] = o.v; our[k] = o.ur; ow[k] = o.inv_sigma2;
-        pt_start[o.point + 1]++; ps_start[o.pose + 1]++;
-        b->h_ur[k] = obs[k].ur;                  // caller order (host-side outlier thresholds)
-    }
-    for (int j = 0; j < n_points; ++j) pt_start[j + 1] += pt_start[j];
-    for (int i = 0; i < n_poses; ++i) ps_start[i + 1] += ps_start[i];
+    b->h_ur.resize((size_t)n_obs);
+    for (int k = 0; k < n_obs; ++k) b->h_ur[k] = obs[k].ur;   // caller order (host-side outlier thresholds)
+
+    // ---- one block: [view | inputs as staged | zero-initialised part | the rest]
+    const size_t np = (size_t)n_poses, npt = (size_t)std::max(n_points, 1), no = (size_t)std::max(n_obs, 1), n = (size_t)b->dim_pad;
+    const size_t nblk = (size_t)std::max(b->n_blocks, 1), nfree = (size_t)std::max(b->n_free, 1);
+    b->red_n = (int64_t)(n * n + 3 * n + 8);
+    const int part_n = std::max((n_points + 63) / 64, 1);
+    Carve cv;
+    const size_t o_view = cv.take(sizeof(BaView));
+    const size_t o_poses0 = cv.take(7 * np * 8), o_points0 = cv.take(3 * npt * 8), o_slot = cv.take(np * 4), o_free = cv.take(nfree * 4);
+    const size_t o_obs_in = cv.take(no * sizeof(lpslam_hip_ba_obs));
+    const size_t staged_bytes = cv.off;
+    const size_t z_begin = cv.off;
+    const size_t o_A = cv.take(np * npt * 4), o_ptcount = cv.take(npt * 4);
+    const size_t o_partial0 = cv.take(np * SPLIT * (PV + 1) * 8), o_partial1 = cv.take(np * SPLIT * (PV + 1) * 8);
+    const size_t o_red = cv.take((size_t)b->red_n * 8), o_minv = cv.take(n * n * 8), o_xp = cv.take(n * 8), o_loc = cv.take((2 * n + 8) * 8);
+    const size_t o_scal = cv.take(8 * 8), o_ctl = cv.take(sizeof(BaCtl)), o_ticket = cv.take(nblk * 4), o_log = cv.take(MAX_LOG * sizeof(lpslam_hip_ba_iter_log));
+    const size_t z_end = cv.off;
+    const size_t o_R = cv.take(np * npt * 4), o_pscount = cv.take(np * 4), o_slotof = cv.take(no * 4);
+    const size_t o_ps_start = cv.take((np + 1) * 4), o_pt_start = cv.take((npt + 1) * 4), o_pt_obs = cv.take(no * 4), o_orig = cv.take(no * 4);
+    const size_t o_opose = cv.take(no * 4), o_opoint = cv.take(no * 4), o_u = cv.take(no * 8), o_v = cv.take(no * 8), o_ur = cv.take(no * 8), o_w = cv.take(no * 8);
+    const size_t o_active = cv.take(no), o_actin = cv.take(no);
+    const size_t o_poses_a = cv.take(7 * np * 8), o_poses_b = cv.take(7 * np * 8), o_points_a = cv.take(3 * npt * 8), o_points_b = cv.take(3 * npt * 8);
+    const size_t o_W0 = cv.take(18 * no * 8), o_W1 = cv.take(18 * no * 8), o_hl0 = cv.take(9 * no * 8), o_hl1 = cv.take(9 * no * 8);
+    const size_t o_Hll = cv.take(6 * npt * 8), o_bl = cv.take(3 * npt * 8), o_Hpp = cv.take(36 * nfree * 8), o_ptrial = cv.take(np * SPLIT * 8);
+    const size_t o_ldiag = cv.take(n * NB * 8), o_lsub = cv.take(n * NB * 8), o_chipose = cv.take(np * 8), o_part = cv.take((size_t)part_n * 8);
+    const size_t o_chiobs = cv.take(no * 8), o_depth = cv.take(no);
+    const size_t o_blk_count = cv.take(nblk * 4), o_blk_start = cv.take((nblk + 1) * 4), o_blk_part = cv.take(nblk * 4 * 36 * 8);
+    const size_t o_terms = cv.take(std::max<size_t>(terms_cap, 1) * sizeof(int4));
     {
-        std::vector<int> fp(pt_start.begin(), pt_start.end() - 1);
-        for (int k = 0; k < n_obs; ++k) pt_obs[fp[o_point[k]]++] = k;
+        const int rc = lp_pool_alloc(ctx, cv.off, &b->block, &b->block_cap);
+        if (rc) { lpslam_hip_ba_destroy(b); return rc; }
     }
-    // pair lists per block pair (slot_a <= slot_b), terms in landmark order
-    std::vector<int> blk_count((size_t)b->n_blocks + 1, 0);
-    auto blk_index = [&](int i, int k) { return i * b->n_free - i * (i - 1) / 2 + (k - i); };
-    std::vector<std::pair<int, int>> tmp;      // (slot, obs) of one landmark
-    for (int pass = 0; pass < 2; ++pass) {
-        std::vector<int> fill;
-        std::vector<int4> terms;
-        if (pass == 1) {
-            for (int q = 0; q < b->n_blocks; ++q) blk_count[q + 1] += blk_count[q];
-            fill.assign(blk_count.begin(), blk_count.end() - 1);
-            terms.resize((size_t)blk_count[b->n_blocks]);
-        }
-        for (int j = 0; j < n_points; ++j) {
-            tmp.clear();
-            for (int s = pt_start[j]; s < pt_start[j + 1]; ++s) { const int k = pt_obs[s]; if (slot[o_pose[k]] >= 0) tmp.emplace_back(slot[o_pose[k]], k); }
-            std::stable_sort(tmp.begin(), tmp.end(), [](const std::pair<int, int>& x, const std::pair<int, int>& y) { return x.first < y.first; });
-            for (size_t a = 0; a < tmp.size(); ++a)
-                for (size_t c = a; c < tmp.size(); ++c) {
-                    if (c > a && tmp[c].first == tmp[a].first) {
-                        // two observations of one landmark in the same keyframe: both orders go to the diagonal block
-                        const int q = blk_index(tmp[a].first, tmp[a].first);
-                        if (pass == 0) blk_count[q + 1] += 2;
-                        else { terms[fill[q]++] = make_int4(tmp[a].second, tmp[c].second, j, 0); terms[fill[q]++] = make_int4(tmp[c].second, tmp[a].second, j, 0); }
-                        continue;
-                    }
-                    const int q = blk_index(tmp[a].first, tmp[c].first);
-                    if (pass == 0) blk_count[q + 1]++;
-                    else terms[fill[q]++] = make_int4(tmp[a].second, tmp[c].second, j, 0);
-                }
-        }
-        if (pass == 1) {
-            int rc = upload(b, &b->d_blk_terms, terms);
-            if (rc) { lpslam_hip_ba_destroy(b); return rc; }
-        }
-    }
-    int rc = 0;
+    uint8_t* base = (uint8_t*)b->block;
     auto fail = [&](int code) { lpslam_hip_ba_destroy(b); return code; };
-#define BA_TRY(x) do { rc = (x); if (rc) return fail(rc); } while (0)
 #define BA_HIP(x) do { if ((x) != hipSuccess) { set_error("HIP call failed: %s", #x); return fail(LPSLAM_HIP_ERR_DEVICE); } } while (0)
-    BA_TRY(upload(b, &b->d_blk_start, blk_count));
-    {   // Schur work items: (block, part, parts, index of the block's first item)
-        std::vector<int4> work;
-        for (int q = 0; q < b->n_blocks; ++q) {
-            const int terms_q = blk_count[q + 1] - blk_count[q];
-            const int parts = std::min(4, std::max(1, (terms_q + 255) / 256));
-            const int first = (int)work.size();
-            for (int p = 0; p < parts; ++p) work.push_back(make_int4(q, p, parts, first));
-        }
-        b->n_work = (int)work.size();
-        BA_TRY(upload(b, &b->d_blk_work, work));
-        BA_TRY(dalloc(b, &b->d_blk_part, (size_t)std::max(b->n_work, 1) * 36));
-        BA_TRY(dalloc(b, &b->d_blk_ticket, (size_t)std::max(b->n_blocks, 1)));
-        BA_HIP(hipMemset(b->d_blk_ticket, 0, (size_t)std::max(b->n_blocks, 1) * sizeof(int)));
+    // ---- the view
+    BaView& v = b->h_view;
+    v = BaView{};
+    v.n_poses = n_poses; v.n_points = n_points; v.n_obs = n_obs; v.n_free = b->n_free; v.dim = b->dim; v.dim_pad = b->dim_pad;
+    v.obs_blocks = (n_obs + 255) / 256; v.pose_blocks = (n_poses * SPLIT + 3) / 4; v.point_blocks = (n_points + 255) / 256; v.part_n = part_n;
+    v.n_blocks = b->n_blocks;
+    b->d_poses[0] = (double*)(base + o_poses_a); b->d_poses[1] = (double*)(base + o_poses_b);
+    b->d_points[0] = (double*)(base + o_points_a); b->d_points[1] = (double*)(base + o_points_b);
+    for (int s2 = 0; s2 < 2; ++s2) { vset(v.poses_buf[s2], b->d_poses[s2]); vset(v.points_buf[s2], b->d_points[s2]); }
+    vset(v.poses0, (const double*)(base + o_poses0)); vset(v.points0, (const double*)(base + o_points0));
+    vset(v.pose_slot, (const int*)(base + o_slot)); vset(v.free_pose, (const int*)(base + o_free));
+    vset(v.o_pose, (const int*)(base + o_opose)); vset(v.o_point, (const int*)(base + o_opoint));
+    vset(v.o_u, (const double*)(base + o_u)); vset(v.o_v, (const double*)(base + o_v)); vset(v.o_ur, (const double*)(base + o_ur)); vset(v.o_w, (const double*)(base + o_w));
+    b->d_o_active = base + o_active; b->d_act_in = base + o_actin; b->d_o_orig = (int*)(base + o_orig);
+    vset(v.o_active, b->d_o_active);
+    vset(v.pt_start, (const int*)(base + o_pt_start)); vset(v.pt_obs, (const int*)(base + o_pt_obs)); vset(v.ps_start, (const int*)(base + o_ps_start));
+    vset(v.o_orig, (const int*)b->d_o_orig);
+    vset(v.Hll, (double*)(base + o_Hll)); vset(v.bl, (double*)(base + o_bl)); vset(v.Hpp, (double*)(base + o_Hpp));
+    vset(v.W2[0], (double*)(base + o_W0)); vset(v.W2[1], (double*)(base + o_W1)); vset(v.hl2[0], (double*)(base + o_hl0)); vset(v.hl2[1], (double*)(base + o_hl1));
+    vset(v.partial2[0], (double*)(base + o_partial0)); vset(v.partial2[1], (double*)(base + o_partial1));
+    v.W = v.W2[0]; v.hl_obs = v.hl2[0]; v.partial = v.partial2[0];
+    vset(v.partial_trial, (double*)(base + o_ptrial));
+    b->d_red = (double*)(base + o_red);
+    vset(v.S, b->d_red); vset(v.rhs, b->d_red + n * n); vset(v.bp, b->d_red + n * n + n); vset(v.hppdiag, b->d_red + n * n + 2 * n); vset(v.chi_cur, b->d_red + n * n + 3 * n);
+    { double* loc = (double*)(base + o_loc); vset(v.bp_loc, loc); vset(v.hppdiag_loc, loc + n); vset(v.chi_loc, loc + 2 * n); }
+    vset(v.Minv, (double*)(base + o_minv)); vset(v.Ldiag, (double*)(base + o_ldiag)); vset(v.Lsub, (double*)(base + o_lsub));
+    b->d_scal = (double*)(base + o_scal);
+    vset(v.xp, (double*)(base + o_xp)); vset(v.chi_pose, (double*)(base + o_chipose)); vset(v.part, (double*)(base + o_part)); vset(v.scal, b->d_scal);
+    vset(v.blk_start, (const int*)(base + o_blk_start)); vset(v.blk_terms, (const int4*)(base + o_terms));
+    vset(v.blk_part, (double*)(base + o_blk_part)); vset(v.blk_ticket, (int*)(base + o_ticket));
+    b->d_ctl = (BaCtl*)(base + o_ctl); b->d_log = (lpslam_hip_ba_iter_log*)(base + o_log);
+    vset(v.ctl, b->d_ctl); vset(v.log, b->d_log);
+    v.cam = BaCam{cam->fx, cam->fy, cam->cx, cam->cy, cam->focal_x_baseline, cam->huber_mono, cam->huber_stereo};
+    b->d_view = (BaView*)(base + o_view);
+    b->d_chi_obs = (double*)(base + o_chiobs); b->d_depth = base + o_depth;
+    // ---- inputs through one page-locked staging block, one copy
+    b->stage = lp_pin_big_alloc(ctx, staged_bytes, &b->stage_cap);
+    if (!b->stage) { set_error("page-locked staging of %zu bytes failed", staged_bytes); return fail(LPSLAM_HIP_ERR_DEVICE); }
+    uint8_t* hs = (uint8_t*)b->stage;
+    memcpy(hs + o_view, &v, sizeof(BaView));
+    memcpy(hs + o_poses0, poses, 7 * np * 8);
+    if (n_points) memcpy(hs + o_points0, points, 3 * (size_t)n_points * 8);
+    memcpy(hs + o_slot, slot.data(), np * 4);
+    if (b->n_free) memcpy(hs + o_free, free_pose.data(), (size_t)b->n_free * 4);
+    if (n_obs) memcpy(hs + o_obs_in, obs, (size_t)n_obs * sizeof(lpslam_hip_ba_obs));
+    hipStream_t s = b->stream;
+    BA_HIP(hipMemcpyAsync(base, hs, staged_bytes, hipMemcpyHostToDevice, s));
+    BA_HIP(hipMemsetAsync(base + z_begin, 0, z_end - z_begin, s));
+    // ---- structure on the device (ba_build.inl)
+    const lpslam_hip_ba_obs* d_obs = (const lpslam_hip_ba_obs*)(base + o_obs_in);
+    int* A = (int*)(base + o_A); int* R = (int*)(base + o_R);
+    int* ps_start = (int*)(base + o_ps_start); int* pt_start = (int*)(base + o_pt_start);
+    if (b->dim_pad > b->dim + 1) hipLaunchKernelGGL(k_bs_identity, dim3((b->dim_pad - b->dim - 1 + 255) / 256), dim3(256), 0, s, b->d_red, b->dim, b->dim_pad);
+    if (n_obs) hipLaunchKernelGGL(k_bs_count, dim3((n_obs + 255) / 256), dim3(256), 0, s, d_obs, n_obs, n_points, A, (int*)(base + o_ptcount));
+    if (n_points) hipLaunchKernelGGL(k_bs_rowscan, dim3(n_poses), dim3(BS_THREADS), 0, s, A, R, n_points, (int*)(base + o_pscount));
+    else BA_HIP(hipMemsetAsync(base + o_pscount, 0, np * 4, s));
+    hipLaunchKernelGGL(k_bs_starts, dim3(2), dim3(BS_THREADS), 0, s, (const int*)(base + o_pscount), ps_start, n_poses, (const int*)(base + o_ptcount), pt_start, n_points);
+    if (n_obs) {
+        hipLaunchKernelGGL(k_bs_scatter, dim3((n_obs + 255) / 256), dim3(256), 0, s, d_obs, n_obs, n_points, A, R, ps_start, (int*)(base + o_slotof));
+        hipLaunchKernelGGL(k_bs_gather, dim3((n_obs + 255) / 256), dim3(256), 0, s, d_obs, n_obs, n_points, A, R, ps_start, (const int*)(base + o_slotof),
+                           b->d_o_orig, (int*)(base + o_opose), (int*)(base + o_opoint), (double*)(base + o_u), (double*)(base + o_v), (double*)(base + o_ur),
+                           (double*)(base + o_w), b->d_o_active, b->d_act_in);
+        hipLaunchKernelGGL(k_bs_ptfill, dim3((n_points + 255) / 256), dim3(256), 0, s, A, R, n_poses, n_points, ps_start, pt_start, (int*)(base + o_pt_obs));
     }
-    BA_TRY(upload(b, &b->d_pose_slot, slot));
-    BA_TRY(upload(b, &b->d_free_pose, free_pose));
-    BA_TRY(upload(b, &b->d_o_pose, o_pose)); BA_TRY(upload(b, &b->d_o_point, o_point));
-    BA_TRY(upload(b, &b->d_o_u, ou)); BA_TRY(upload(b, &b->d_o_v, ov)); BA_TRY(upload(b, &b->d_o_ur, our)); BA_TRY(upload(b, &b->d_o_w, ow));
-    BA_TRY(upload(b, &b->d_pt_start, pt_start)); BA_TRY(upload(b, &b->d_pt_obs, pt_obs));
-    BA_TRY(upload(b, &b->d_ps_start, ps_start)); BA_TRY(upload(b, &b->d_o_orig, order));
-    std::vector<uint8_t> act((size_t)std::max(n_obs, 1), 1);
-    BA_TRY(upload(b, &b->d_o_active, act)); BA_TRY(upload(b, &b->d_act_in, act));
-    for (int s = 0; s < 2; ++s) { BA_TRY(dalloc(b, &b->d_poses[s], 7 * (size_t)n_poses)); BA_TRY(dalloc(b, &b->d_points[s], 3 * (size_t)n_points)); }
-    BA_TRY(dalloc(b, &b->d_poses0, 7 * (size_t)n_poses)); BA_TRY(dalloc(b, &b->d_points0, 3 * (size_t)n_points));
-    BA_HIP(hipMemcpy(b->d_poses0, poses, 7 * (size_t)n_poses * sizeof(double), hipMemcpyHostToDevice));
-    BA_HIP(hipMemcpy(b->d_poses[0], poses, 7 * (size_t)n_poses * sizeof(double), hipMemcpyHostToDevice));
-    if (n_points) {
-        BA_HIP(hipMemcpy(b->d_points0, points, 3 * (size_t)n_points * sizeof(double), hipMemcpyHostToDevice));
-        BA_HIP(hipMemcpy(b->d_points[0], points, 3 * (size_t)n_points * sizeof(double), hipMemcpyHostToDevice));
+    if (b->n_blocks) {
+        hipLaunchKernelGGL(k_bs_paircount, dim3((b->n_blocks + 3) / 4), dim3(256), 0, s, A, n_points, b->n_free, b->n_blocks, (const int*)(base + o_free), ps_start,
+                           (const int*)(base + o_opoint), (int*)(base + o_blk_count));
+        hipLaunchKernelGGL(k_bs_blkscan, dim3(1), dim3(BS_THREADS), 0, s, (const int*)(base + o_blk_count), (int*)(base + o_blk_start), (int*)(base + o_ticket), b->n_blocks);
+        hipLaunchKernelGGL(k_bs_pairfill, dim3((b->n_blocks + 3) / 4), dim3(256), 0, s, A, R, n_points, b->n_free, b->n_blocks, (const int*)(base + o_free), ps_start,
+                           (const int*)(base + o_opoint), (const int*)(base + o_blk_start), (int4*)(base + o_terms));
+    } else BA_HIP(hipMemsetAsync(base + o_blk_start, 0, 2 * 4, s));
+    // state buffers <- the inputs, control block cleared
+    {
+        const long n_max = std::max<long>(std::max<long>(7L * n_poses, 3L * n_points), n_obs);
+        hipLaunchKernelGGL(k_ba_reset, dim3((unsigned)((n_max + 255) / 256), 1), dim3(256), 0, s, b->d_view);
     }
-    for (int k2 = 0; k2 < 2; ++k2) BA_TRY(dalloc(b, &b->d_W2[k2], 18 * (size_t)n_obs));
-    BA_TRY(dalloc(b, &b->d_Hll, 6 * (size_t)n_points)); BA_TRY(dalloc(b, &b->d_bl, 3 * (size_t)n_points));
-    BA_TRY(dalloc(b, &b->d_Hpp, 36 * (size_t)b->n_free));
-    for (int k2 = 0; k2 < 2; ++k2) {
-        BA_TRY(dalloc(b, &b->d_hl2[k2], 9 * (size_t)n_obs)); BA_TRY(dalloc(b, &b->d_partial2[k2], (size_t)n_poses * SPLIT * (PV + 1)));
-        BA_HIP(hipMemset(b->d_partial2[k2], 0, (size_t)n_poses * SPLIT * (PV + 1) * sizeof(double)));
-    }
-    BA_TRY(dalloc(b, &b->d_partial_trial, (size_t)n_poses * SPLIT));
-    b->red_n = (int64_t)b->dim_pad * b->dim_pad + 3 * (int64_t)b->dim_pad + 8;
-    BA_TRY(dalloc(b, &b->d_red, (size_t)b->red_n));
-    BA_HIP(hipMemset(b->d_red, 0, (size_t)b->red_n * sizeof(double)));
-    {   // rows beyond the rhs row: identity (they stay 1 / 0 through every factorisation)
-        const double one = 1.0;
-        for (int r = b->dim + 1; r < b->dim_pad; ++r) BA_HIP(hipMemcpy(b->d_red + (size_t)r * b->dim_pad + r, &one, sizeof(double), hipMemcpyHostToDevice));
-    }
-    BA_TRY(dalloc(b, &b->d_minv, (size_t)b->dim_pad * b->dim_pad));
-    BA_HIP(hipMemset(b->d_minv, 0, (size_t)b->dim_pad * b->dim_pad * sizeof(double)));
-    BA_TRY(dalloc(b, &b->d_ldiag, (size_t)b->dim_pad * NB)); BA_TRY(dalloc(b, &b->d_lsub, (size_t)b->dim_pad * NB));
-    BA_TRY(dalloc(b, &b->d_xp, (size_t)b->dim_pad));
-    BA_HIP(hipMemset(b->d_xp, 0, b->dim_pad * sizeof(double)));
-    BA_TRY(dalloc(b, &b->d_chi_pose, (size_t)n_poses));
-    BA_TRY(dalloc(b, &b->d_loc, 2 * (size_t)b->dim_pad + 8));
-    BA_HIP(hipMemset(b->d_loc, 0, (2 * (size_t)b->dim_pad + 8) * sizeof(double)));
-    b->part_n = std::max((n_points + 63) / 64, 1);
-    BA_TRY(dalloc(b, &b->d_part, (size_t)b->part_n)); BA_TRY(dalloc(b, &b->d_scal, 8));
-    BA_HIP(hipMemset(b->d_scal, 0, 8 * sizeof(double)));
-    BA_TRY(dalloc(b, &b->d_chi_obs, (size_t)n_obs)); BA_TRY(dalloc(b, &b->d_depth, (size_t)n_obs));
-    BA_TRY(dalloc(b, &b->d_ctl, 1)); BA_TRY(dalloc(b, &b->d_log, MAX_LOG));
-    BA_HIP(hipMemset(b->d_ctl, 0, sizeof(BaCtl)));
-#undef BA_TRY
+    BA_HIP(hipGetLastError());
 #undef BA_HIP
     b->h_ctl = BaCtl{};
     b->h_ctl.ni = 2; b->h_ctl.need_lin = 1; b->h_ctl.first = 1;
@@ -1816,23 +1886,15 @@ void lpslam_hip_ba_destroy(lpslam_hip_ba* b)
     if (!b) return;
     if (b->stream) (void)hipStreamSynchronize(b->stream);
     for (auto& g : b->graphs) if (g.second) (void)hipGraphExecDestroy(g.second);
-    for (auto& blk : b->allocs) lp_pool_free(b->ctx, blk.first, blk.second);
+    if (b->block) lp_pool_free(b->ctx, b->block, b->block_cap);
+    release_stage(b);
     if (b->pin) lp_pin_free(b->ctx, b->pin);
-    if (b->stream) (void)hipStreamDestroy(b->stream);
+    if (b->ev) (void)hipEventDestroy(b->ev);
+    if (b->stream) lp_stream_release(b->ctx, b->stream);
     delete b;
 }
 
 // caller-order activity flags -> storage order
-// state given at creation back into buffer 0, every observation active
-__global__ __launch_bounds__(256) void k_ba_reset(double* poses, const double* poses0, int n_pose_doubles, double* points, const double* points0,
-                                                  int n_point_doubles, uint8_t* active, int n_obs)
-{
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n_pose_doubles) poses[i] = poses0[i];
-    if (i < n_point_doubles) points[i] = points0[i];
-    if (i < n_obs) active[i] = 1;
-}
-
 __global__ __launch_bounds__(256) void k_ba_gather_active(const uint8_t* in, const int* o_orig, uint8_t* out, int n)
 {
     const int k = blockIdx.x * 256 + threadIdx.x;
@@ -1849,6 +1911,7 @@ int lpslam_hip_ba_set_active(lpslam_hip_ba* b, const uint8_t* active)
         LP_HIP(hipGetLastError());
     } else LP_HIP(hipMemsetAsync(b->d_o_active, 1, b->n_obs, b->stream));
     LP_HIP(hipStreamSynchronize(b->stream));
+    release_stage(b);
     return LPSLAM_HIP_OK;
 }
 
@@ -1861,13 +1924,13 @@ int lpslam_hip_ba_set_points_fixed(lpslam_hip_ba* b, int32_t points_fixed)
 
 // One unit = one LM trial.  Without rejected steps `iters` units finish the call with a single look at the control block;
 // every rejected trial costs one more unit, enqueued after that look.
-static int enqueue_batch(lpslam_hip_ba* b, int units, bool first_batch)
+static int enqueue_batch(const BaLaunch& L, int units, bool first_batch)
 {
     for (int u = 0; u < units; ++u) {
         int rc;
-        if ((rc = enqueue_linearize(b, 1, first_batch && u == 0))) return rc;
-        if ((rc = enqueue_reduce(b, 1))) return rc;
-        if ((rc = enqueue_solve(b, 1))) return rc;
+        if ((rc = enqueue_linearize(L, 1, first_batch && u == 0))) return rc;
+        if ((rc = enqueue_reduce(L, 1))) return rc;
+        if ((rc = enqueue_solve(L, 1))) return rc;
     }
     return LPSLAM_HIP_OK;
 }
@@ -1881,13 +1944,14 @@ int lpslam_hip_ba_optimize_begin(lpslam_hip_ba* b, int32_t robust, int32_t iters
     if (iters < 0 || iters > MAX_LOG) { set_error("iterations must be in [0,%d]", MAX_LOG); return LPSLAM_HIP_ERR_INVALID; }
     if (b->pending_iters >= 0) { set_error("optimize_begin: the previous optimize_begin has not been ended"); return LPSLAM_HIP_ERR_INVALID; }
     LP_HIP(hipSetDevice(b->ctx->cfg.device));
-    int rc = begin_optimize(b, robust, iters); if (rc) return rc;
-    // The first batch of a call -- `iters` units, the first with its explicit linearisation -- has a fixed launch sequence for a
-    // given (robust, iters, points_fixed): the second time a problem asks for the same one it is captured into a hipGraph and
-    // from then on replayed with one hipGraphLaunch (a reused problem: the bench's local BA, a tracker window that is re-solved).
+    b->robust = robust;
+    // The first batch of a call -- the arming of the control block and `iters` units, the first with its explicit linearisation --
+    // has a fixed launch sequence for a given (robust, iters, points_fixed): the second time a problem asks for the same one it is
+    // captured into a hipGraph and from then on replayed with one hipGraphLaunch (a reused problem: a window that is re-solved).
     const int units = iters;
+    bool launched = false;
+    int rc;
     if (units > 0) {
-        bool launched = false;
         const long key = ((long)units << 2) | ((long)(robust ? 1 : 0) << 1) | (long)(b->points_fixed ? 1 : 0);
         auto it = b->graphs.find(key);
         if (it == b->graphs.end()) b->graphs.emplace(key, nullptr);          // seen once: run directly (also sets function attributes)
@@ -1895,7 +1959,8 @@ int lpslam_hip_ba_optimize_begin(lpslam_hip_ba* b, int32_t robust, int32_t iters
             if (!it->second) {
                 hipGraph_t graph = nullptr;
                 if (hipStreamBeginCapture(b->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-                    const int r2 = enqueue_batch(b, units, true);
+                    int r2 = begin_optimize(b, robust, iters);
+                    if (r2 == LPSLAM_HIP_OK) r2 = enqueue_batch(single_launch(b), units, true);
                     const hipError_t e2 = hipStreamEndCapture(b->stream, &graph);
                     if (r2 == LPSLAM_HIP_OK && e2 == hipSuccess && graph) {
                         hipGraphExec_t exec = nullptr;
@@ -1907,7 +1972,10 @@ int lpslam_hip_ba_optimize_begin(lpslam_hip_ba* b, int32_t robust, int32_t iters
             }
             if (it->second) { LP_HIP(hipGraphLaunch(it->second, b->stream)); launched = true; }
         }
-        if (!launched && (rc = enqueue_batch(b, units, true))) return rc;
+    }
+    if (!launched) {
+        if ((rc = begin_optimize(b, robust, iters))) return rc;
+        if (units > 0 && (rc = enqueue_batch(single_launch(b), units, true))) return rc;
     }
     b->pending_iters = iters;
     return LPSLAM_HIP_OK;
@@ -1922,11 +1990,11 @@ int lpslam_hip_ba_optimize_end(lpslam_hip_ba* b, lpslam_hip_ba_iter_log* log, in
     b->pending_iters = -1;
     int rc;
     const int want_log = (log && b->pin) ? iters : 0;
+    if ((rc = read_ctl(b, want_log))) return rc;
     if (iters > 0) {
-        if ((rc = read_ctl(b, want_log))) return rc;
         int guard = 0;
         while (!b->h_ctl.stopped && b->h_ctl.outer_done < iters && guard++ < 16 * MAX_LOG) {
-            if ((rc = enqueue_batch(b, iters - b->h_ctl.outer_done, false))) return rc;
+            if ((rc = enqueue_batch(single_launch(b), iters - b->h_ctl.outer_done, false))) return rc;
             if ((rc = read_ctl(b, want_log))) return rc;
         }
     }
@@ -1945,6 +2013,117 @@ int lpslam_hip_ba_optimize(lpslam_hip_ba* b, int32_t robust, int32_t iters, lpsl
     return rc ? rc : lpslam_hip_ba_optimize_end(b, log, done_out);
 }
 
+// ---- batched solve: B independent problems, ONE launch chain (blockIdx.y = problem) ------------------------------------------
+// What a host that serves several SLAM sessions (or several windows of one map) on one GPU calls: every kernel of the chain is
+// launched once for the whole batch with the launch extents of its largest problem, each problem follows its own control block
+// (a problem that has finished, or terminated, idles through the remaining launches), and the control blocks and logs of all
+// problems come back in one copy.  The single-problem chain is latency bound; a batch fills the chip.
+static int batch_sync_streams(lpslam_hip_ba* const* ps, int n, hipStream_t s)
+{
+    for (int i = 0; i < n; ++i) {
+        if (ps[i]->stream == s) continue;
+        if (!ps[i]->ev) LP_HIP(hipEventCreateWithFlags(&ps[i]->ev, hipEventDisableTiming));
+        LP_HIP(hipEventRecord(ps[i]->ev, ps[i]->stream));
+        LP_HIP(hipStreamWaitEvent(s, ps[i]->ev, 0));
+    }
+    return LPSLAM_HIP_OK;
+}
+static int batch_check(lpslam_hip_ba* const* ps, int n)
+{
+    if (!ps || n < 1) { set_error("empty batch"); return LPSLAM_HIP_ERR_INVALID; }
+    for (int i = 0; i < n; ++i) {
+        if (!ps[i]) { set_error("null problem in batch (entry %d)", i); return LPSLAM_HIP_ERR_INVALID; }
+        if (ps[i]->ctx->cfg.device != ps[0]->ctx->cfg.device) { set_error("batch spans devices (entry %d)", i); return LPSLAM_HIP_ERR_INVALID; }
+        if (ps[i]->pending_iters >= 0) { set_error("batch entry %d has an optimize_begin pending", i); return LPSLAM_HIP_ERR_INVALID; }
+        for (int k = 0; k < i; ++k) if (ps[k] == ps[i]) { set_error("problem listed twice in a batch (entries %d, %d)", k, i); return LPSLAM_HIP_ERR_INVALID; }
+    }
+    return LPSLAM_HIP_OK;
+}
+// device array of the problems' views (a block of the first problem's context) + its launch extents
+struct BatchViews {
+    lpslam_hip_ctx* ctx = nullptr; void* blk = nullptr; size_t cap = 0; void* hst = nullptr; size_t hcap = 0;
+    BaLaunch L;
+    ~BatchViews() { if (blk) lp_pool_free(ctx, blk, cap); if (hst) lp_pin_big_free(ctx, hst, hcap); }
+};
+static int batch_views(lpslam_hip_ba* const* ps, int n, size_t extra_bytes, BatchViews* bv)
+{
+    bv->ctx = ps[0]->ctx;
+    const size_t view_bytes = (size_t)n * sizeof(BaView), total = ((view_bytes + 255) & ~(size_t)255) + extra_bytes;
+    int rc = lp_pool_alloc(bv->ctx, total, &bv->blk, &bv->cap); if (rc) return rc;
+    bv->hst = lp_pin_big_alloc(bv->ctx, total, &bv->hcap);
+    if (!bv->hst) { set_error("page-locked staging of %zu bytes failed", total); return LPSLAM_HIP_ERR_DEVICE; }
+    BaLaunch& L = bv->L;
+    L.d_views = (const BaView*)bv->blk; L.s = ps[0]->stream;
+    for (int i = 0; i < n; ++i) { memcpy((uint8_t*)bv->hst + (size_t)i * sizeof(BaView), &ps[i]->h_view, sizeof(BaView)); L.add(ps[i]); }
+    LP_HIP(hipMemcpyAsync(bv->blk, bv->hst, view_bytes, hipMemcpyHostToDevice, L.s));
+    return LPSLAM_HIP_OK;
+}
+
+int lpslam_hip_ba_reset_batch(lpslam_hip_ba* const* ps, int32_t n)
+{
+    int rc = batch_check(ps, n); if (rc) return rc;
+    LP_HIP(hipSetDevice(ps[0]->ctx->cfg.device));
+    BatchViews bv;
+    if ((rc = batch_sync_streams(ps, n, ps[0]->stream))) return rc;
+    if ((rc = batch_views(ps, n, 0, &bv))) return rc;
+    long n_max = 1;
+    for (int i = 0; i < n; ++i) {
+        n_max = std::max<long>(n_max, std::max<long>(std::max<long>(7L * ps[i]->n_poses, 3L * ps[i]->n_points), ps[i]->n_obs));
+        ps[i]->h_ctl = BaCtl{}; ps[i]->h_ctl.ni = 2; ps[i]->h_ctl.need_lin = 1; ps[i]->h_ctl.first = 1;
+    }
+    hipLaunchKernelGGL(k_ba_reset, dim3((unsigned)((n_max + 255) / 256), n), dim3(256), 0, bv.L.s, bv.L.d_views);
+    LP_HIP(hipGetLastError());
+    LP_HIP(hipStreamSynchronize(bv.L.s));          // the view array is released on return
+    for (int i = 0; i < n; ++i) release_stage(ps[i]);
+    return LPSLAM_HIP_OK;
+}
+
+int lpslam_hip_ba_optimize_batch(lpslam_hip_ba* const* ps, int32_t n, int32_t robust, int32_t iters, lpslam_hip_ba_iter_log* logs,
+                                 int32_t log_stride, int32_t* done)
+{
+    int rc = batch_check(ps, n); if (rc) return rc;
+    if (iters < 0 || iters > MAX_LOG) { set_error("iterations must be in [0,%d]", MAX_LOG); return LPSLAM_HIP_ERR_INVALID; }
+    if (logs && log_stride < iters) { set_error("log_stride %d is smaller than the iteration count %d", log_stride, iters); return LPSLAM_HIP_ERR_INVALID; }
+    for (int i = 1; i < n; ++i)
+        if (ps[i]->points_fixed != ps[0]->points_fixed) { set_error("batch mixes motion-only and full problems (entry %d)", i); return LPSLAM_HIP_ERR_INVALID; }
+    LP_HIP(hipSetDevice(ps[0]->ctx->cfg.device));
+    BatchViews bv;
+    const size_t collect_bytes = (size_t)n * COLLECT_STRIDE;
+    if ((rc = batch_sync_streams(ps, n, ps[0]->stream))) return rc;
+    if ((rc = batch_views(ps, n, collect_bytes, &bv))) return rc;
+    BaLaunch& L = bv.L;
+    L.robust = robust; L.points_fixed = ps[0]->points_fixed;
+    for (int i = 0; i < n; ++i) ps[i]->robust = robust;
+    const size_t coll_off = ((size_t)n * sizeof(BaView) + 255) & ~(size_t)255;
+    uint8_t* d_coll = (uint8_t*)bv.blk + coll_off;
+    uint8_t* h_coll = (uint8_t*)bv.hst + coll_off;
+    hipLaunchKernelGGL(k_ba_arm, dim3(1, n), dim3(64), 0, L.s, L.d_views, iters);
+    auto collect = [&]() -> int {
+        hipLaunchKernelGGL(k_ba_collect, dim3(1, n), dim3(64), 0, L.s, L.d_views, d_coll, iters);
+        LP_HIP(hipGetLastError());
+        LP_HIP(hipMemcpyAsync(h_coll, d_coll, collect_bytes, hipMemcpyDeviceToHost, L.s));
+        LP_HIP(hipStreamSynchronize(L.s));
+        for (int i = 0; i < n; ++i) memcpy(&ps[i]->h_ctl, h_coll + (size_t)i * COLLECT_STRIDE, sizeof(BaCtl));
+        return LPSLAM_HIP_OK;
+    };
+    if (iters > 0 && (rc = enqueue_batch(L, iters, true))) return rc;
+    if ((rc = collect())) return rc;
+    for (int guard = 0; iters > 0 && guard < 16 * MAX_LOG; ++guard) {
+        int remaining = 0;
+        for (int i = 0; i < n; ++i) if (!ps[i]->h_ctl.stopped) remaining = std::max(remaining, iters - ps[i]->h_ctl.outer_done);
+        if (remaining <= 0) break;
+        if ((rc = enqueue_batch(L, remaining, false))) return rc;
+        if ((rc = collect())) return rc;
+    }
+    for (int i = 0; i < n; ++i) {
+        release_stage(ps[i]);
+        const int d = ps[i]->h_ctl.outer_done;
+        if (done) done[i] = d;
+        if (logs && d) memcpy(logs + (size_t)i * log_stride, h_coll + (size_t)i * COLLECT_STRIDE + sizeof(BaCtl), (size_t)std::min(d, MAX_LOG) * sizeof(lpslam_hip_ba_iter_log));
+    }
+    return LPSLAM_HIP_OK;
+}
+
 // ---- partitioned (multi-GPU) solve: one LM trial in three phases with the caller's all-reduces in between ------------------
 //   lpslam_hip_ba_step_begin : (linearise if needed) + partial Schur complement -> reduced buffer [S | rhs | b_p | diag H_pp |
 //                              chi2]: SUM all-reduce; scalar buffer entry [4] = max diag H_ll: MAX all-reduce (first trial)
@@ -1961,17 +2140,17 @@ int lpslam_hip_ba_step_begin(lpslam_hip_ba* b, int32_t robust, int32_t first)
     b->robust = robust;
     // lambda is needed by the Schur complement but lambda_0 depends on all-reduced diagonals: on the very first trial the
     // caller runs begin twice (first = 1: linearisation only; first = 0 after the reduction of the diagonals)
-    if ((rc = enqueue_linearize(b, 0))) return rc;
-    if (!first) { if ((rc = enqueue_reduce(b, 0))) return rc; }
+    if ((rc = enqueue_linearize(single_launch(b), 0))) return rc;
+    if (!first) { if ((rc = enqueue_reduce(single_launch(b), 0))) return rc; }
     LP_HIP(hipStreamSynchronize(b->stream));
+    release_stage(b);
     return LPSLAM_HIP_OK;
 }
 
 int lpslam_hip_ba_step_lambda0(lpslam_hip_ba* b)
 {
     if (!b) { set_error("null problem"); return LPSLAM_HIP_ERR_INVALID; }
-    BaView v = make_view(b);
-    hipLaunchKernelGGL(k_lm_begin, dim3(1), dim3(64), 0, b->stream, v);
+    hipLaunchKernelGGL(k_lm_begin, dim3(1, 1), dim3(64), 0, b->stream, b->d_view);
     LP_HIP(hipGetLastError());
     LP_HIP(hipStreamSynchronize(b->stream));
     return LPSLAM_HIP_OK;
@@ -1980,7 +2159,7 @@ int lpslam_hip_ba_step_lambda0(lpslam_hip_ba* b)
 int lpslam_hip_ba_step_solve(lpslam_hip_ba* b)
 {
     if (!b) { set_error("null problem"); return LPSLAM_HIP_ERR_INVALID; }
-    int rc = enqueue_solve(b, 0); if (rc) return rc;
+    int rc = enqueue_solve(single_launch(b), 0); if (rc) return rc;
     LP_HIP(hipStreamSynchronize(b->stream));
     return LPSLAM_HIP_OK;
 }
@@ -1989,8 +2168,7 @@ int lpslam_hip_ba_step_end(lpslam_hip_ba* b, int32_t* accepted, int32_t* iterati
 {
     if (!b) { set_error("null problem"); return LPSLAM_HIP_ERR_INVALID; }
     const int before = b->h_ctl.outer_done;
-    BaView v = make_view(b);
-    hipLaunchKernelGGL(k_lm_decide, dim3(1), dim3(64), 0, b->stream, v);
+    hipLaunchKernelGGL(k_lm_decide, dim3(1, 1), dim3(64), 0, b->stream, b->d_view);
     LP_HIP(hipGetLastError());
     int rc = read_ctl(b); if (rc) return rc;
     if (accepted) *accepted = b->h_ctl.last_accepted;
@@ -2031,8 +2209,7 @@ int lpslam_hip_ba_reset(lpslam_hip_ba* b)
     b->h_ctl.ni = 2; b->h_ctl.need_lin = 1; b->h_ctl.first = 1;
     // one launch instead of two device copies and a fill (three runtime operations of ~4 us each on the solve's stream)
     const long n_max = std::max<long>(std::max<long>(7L * b->n_poses, 3L * b->n_points), b->n_obs);
-    hipLaunchKernelGGL(k_ba_reset, dim3((unsigned)((n_max + 255) / 256)), dim3(256), 0, b->stream, b->d_poses[0], b->d_poses0, 7 * b->n_poses,
-                       b->d_points[0], b->d_points0, 3 * b->n_points, b->d_o_active, b->n_obs);
+    hipLaunchKernelGGL(k_ba_reset, dim3((unsigned)((n_max + 255) / 256), 1), dim3(256), 0, b->stream, b->d_view);
     LP_HIP(hipGetLastError());
     return LPSLAM_HIP_OK;
 }
@@ -2044,6 +2221,7 @@ int lpslam_hip_ba_get(lpslam_hip_ba* b, double* poses, double* points)
     if (poses) LP_HIP(hipMemcpyAsync(poses, b->d_poses[cur], 7 * (size_t)b->n_poses * sizeof(double), hipMemcpyDeviceToHost, b->stream));
     if (points && b->n_points) LP_HIP(hipMemcpyAsync(points, b->d_points[cur], 3 * (size_t)b->n_points * sizeof(double), hipMemcpyDeviceToHost, b->stream));
     LP_HIP(hipStreamSynchronize(b->stream));
+    release_stage(b);
     return LPSLAM_HIP_OK;
 }
 
@@ -2051,13 +2229,12 @@ int lpslam_hip_ba_chi2(lpslam_hip_ba* b, double* chi2, uint8_t* depth_positive)
 {
     if (!b) { set_error("null problem"); return LPSLAM_HIP_ERR_INVALID; }
     if (!b->n_obs) return LPSLAM_HIP_OK;
-    int rc = write_ctl(b, b->h_ctl); if (rc) return rc;      // the device copy may predate a reset
-    BaView v = make_view(b);
-    hipLaunchKernelGGL(k_ba_obs_chi2, dim3((b->n_obs + 255) / 256), dim3(256), 0, b->stream, v, b->d_chi_obs, b->d_depth);
+    hipLaunchKernelGGL(k_ba_obs_chi2, dim3((b->n_obs + 255) / 256, 1), dim3(256), 0, b->stream, b->d_view, b->d_chi_obs, b->d_depth);
     LP_HIP(hipGetLastError());
     if (chi2) LP_HIP(hipMemcpyAsync(chi2, b->d_chi_obs, (size_t)b->n_obs * sizeof(double), hipMemcpyDeviceToHost, b->stream));
     if (depth_positive) LP_HIP(hipMemcpyAsync(depth_positive, b->d_depth, (size_t)b->n_obs, hipMemcpyDeviceToHost, b->stream));
     LP_HIP(hipStreamSynchronize(b->stream));
+    release_stage(b);
     return LPSLAM_HIP_OK;
 }
 

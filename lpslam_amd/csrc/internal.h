@@ -68,6 +68,8 @@ struct lpslam_hip_ctx {
     // host mirror of d_kp_count: valid after any call that fetched it, invalidated by whatever rewrites it on the device
     std::vector<int32_t> h_kp_count; std::vector<uint8_t> h_kp_valid;
     std::vector<void*> pin_free;       // page-locked 8 KB blocks handed to bundle-adjustment objects (lp_pin_alloc / lp_pin_free)
+    std::vector<hipStream_t> ba_streams;   // idle high-priority streams of destroyed bundle-adjustment problems (lp_stream_acquire / release)
+    std::vector<std::pair<size_t, void*>> pin_big;   // idle page-locked staging blocks (capacity, block) of lp_pin_big_alloc / free
     uint8_t* h_match = nullptr;        // pinned host staging of the window matchers (queries in, candidate lists out)
     size_t h_match_bytes = 0;
     int2* d_band_rows = nullptr;       // [band count 0..32][levels][bands]: rows of each level a band work-group computes
@@ -113,6 +115,10 @@ struct lpslam_hip_ctx {
 // block cache (api.hip): capacity-rounded first fit; *capacity receives the size to hand back to lp_pool_free
 int lp_pool_alloc(lpslam_hip_ctx* c, size_t bytes, void** out, size_t* capacity);
 void lp_pool_free(lpslam_hip_ctx* c, void* p, size_t capacity);
+hipStream_t lp_stream_acquire(lpslam_hip_ctx* c);   // high-priority non-blocking stream from the context's cache (nullptr on failure)
+void lp_stream_release(lpslam_hip_ctx* c, hipStream_t s);
+void* lp_pin_big_alloc(lpslam_hip_ctx* c, size_t bytes, size_t* capacity);      // page-locked staging of any size, recycled through the context
+void lp_pin_big_free(lpslam_hip_ctx* c, void* p, size_t capacity);
 void* lp_pin_alloc(lpslam_hip_ctx* c);          // 8 KB of page-locked host memory, recycled through the context (nullptr on failure)
 void lp_pin_free(lpslam_hip_ctx* c, void* p);
 int lp_launch_pyramid(lpslam_hip_ctx* c, int first, int n_images);

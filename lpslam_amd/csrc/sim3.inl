@@ -691,6 +691,7 @@ struct lpslam_hip_sim3 {
     Sim3View view{};
     int nb = 0, trial_blocks = 0;
     BaCtl h_ctl{};
+    BaView* d_cv = nullptr;                 // device copy of view.cv: the Cholesky kernels read their view from device memory
     double* d_chi = nullptr;
     std::vector<void*> allocs;
 };
@@ -807,6 +808,8 @@ int lpslam_hip_sim3_create(lpslam_hip_ctx* ctx, const double* verts, const uint8
     S3_TRY(s3_alloc(g, &cv.scal, 8, true));
     S3_TRY(s3_alloc(g, &cv.ctl, 1, true));
     S3_TRY(s3_alloc(g, &cv.log, MAX_LOG, true));
+    S3_TRY(s3_alloc(g, &g->d_cv, 1));
+    if (hipMemcpy(g->d_cv, &cv, sizeof(BaView), hipMemcpyHostToDevice) != hipSuccess) { set_error("hipMemcpy failed"); return fail(LPSLAM_HIP_ERR_DEVICE); }
 #undef S3_TRY
     *out = g;
     return LPSLAM_HIP_OK;
@@ -832,8 +835,8 @@ int lpslam_hip_sim3_optimize(lpslam_hip_sim3* g, int32_t iters, lpslam_hip_ba_it
             if (v.n_edges) hipLaunchKernelGGL(k_sim3_lin, dim3(v.n_edges), dim3(64), 0, s, v);
             if (v.dim > 0) {
                 hipLaunchKernelGGL(k_sim3_assemble, dim3(v.n_blocks + v.n_free), dim3(64), 0, s, v);
-                enqueue_cholesky(s, v.cv, g->nb);
-                hipLaunchKernelGGL(k_chol_xsolve, dim3((v.dim + 3) / 4 * 8), dim3(256), 0, s, v.cv);
+                enqueue_cholesky(s, g->d_cv, 1, g->nb);
+                enqueue_xsolve(s, g->d_cv, 1, v.dim);
             }
             hipLaunchKernelGGL(k_sim3_update, dim3(vb + 1), dim3(256), 0, s, v, vb);
             hipLaunchKernelGGL(k_sim3_trial, dim3(g->trial_blocks), dim3(256), 0, s, v);

@@ -36,6 +36,7 @@ SYMBOLS = [
     "lpslam_hip_match_stereo", "lpslam_hip_match_stereo_strided", "lpslam_hip_get_stereo",
     "lpslam_hip_match_projection", "lpslam_hip_match_fuse", "lpslam_hip_match_area", "lpslam_hip_match_orientation_filter",
     "lpslam_hip_ba_create", "lpslam_hip_ba_destroy", "lpslam_hip_ba_set_active", "lpslam_hip_ba_optimize", "lpslam_hip_ba_optimize_begin", "lpslam_hip_ba_optimize_end",
+    "lpslam_hip_ba_optimize_batch", "lpslam_hip_ba_reset_batch",
     "lpslam_hip_ba_local", "lpslam_hip_ba_set_points_fixed", "lpslam_hip_ba_pose_optimize", "lpslam_hip_pose_optimize", "lpslam_hip_ba_reset", "lpslam_hip_ba_get", "lpslam_hip_ba_chi2", "lpslam_hip_ba_reduced_buffer",
     "lpslam_hip_ba_step_begin", "lpslam_hip_ba_step_lambda0", "lpslam_hip_ba_step_solve", "lpslam_hip_ba_scalar_buffer", "lpslam_hip_ba_step_end", "lpslam_hip_ba_status",
     "lpslam_hip_sim3_create", "lpslam_hip_sim3_destroy", "lpslam_hip_sim3_optimize", "lpslam_hip_sim3_get", "lpslam_hip_sim3_chi2", "lpslam_hip_sim3_transform_optimize",
@@ -111,9 +112,13 @@ class Context:
         _check(self.lib.lpslam_hip_level_info(self.h, w, hh, p, q, s))
         self.level_w, self.level_h, self.level_pitch = list(w[:L]), list(hh[:L]), list(p[:L])
         self.quota, self.scale = list(q[:L]), list(s[:L])
+        import weakref
+        self._children = weakref.WeakSet()      # objects that hand memory back to this context when they are destroyed
 
     def close(self):
         if getattr(self, "h", None):
+            for child in list(getattr(self, "_children", ())):
+                child.close()
             self.lib.lpslam_hip_destroy(self.h)
             self.h = None
 
@@ -275,6 +280,7 @@ class BundleAdjuster:
         _check(self.lib.lpslam_hip_ba_create(ctx.h, _p(poses), _p(fixed), self.n_poses, _p(points), self.n_points,
                                              _p(obs), self.n_obs, C.byref(c), C.byref(h)))
         self.h = h
+        ctx._children.add(self)
 
     def close(self):
         if getattr(self, "h", None):
@@ -356,6 +362,24 @@ class BundleAdjuster:
         return dict(outer_done=o.value, stopped=bool(st.value), lam=lam.value, chi2=chi.value)
 
 
+def ba_optimize_batch(problems, robust=True, iters=10):
+    """lpslam_hip_ba_optimize_batch: the problems (BundleAdjuster objects on one device) advanced by one launch chain.
+    Returns one iteration log per problem."""
+    n = len(problems)
+    lib = problems[0].lib
+    hs = (C.c_void_p * n)(*[p.h for p in problems])
+    stride = max(int(iters), 1)
+    logs = np.zeros((n, stride), BA_LOG_DTYPE); done = np.zeros(n, np.int32)
+    _check(lib.lpslam_hip_ba_optimize_batch(hs, n, int(robust), int(iters), _p(logs), stride, _p(done)))
+    return [logs[i, :done[i]].copy() for i in range(n)]
+
+
+def ba_reset_batch(problems):
+    n = len(problems)
+    hs = (C.c_void_p * n)(*[p.h for p in problems])
+    _check(problems[0].lib.lpslam_hip_ba_reset_batch(hs, n))
+
+
 def ba_obs_array(prob):
     o = np.zeros(len(prob["obs_pose"]), BA_OBS_DTYPE)
     o["pose"] = prob["obs_pose"]; o["point"] = prob["obs_point"]
@@ -382,6 +406,7 @@ class PoseGraph:
         h = C.c_void_p()
         _check(self.lib.lpslam_hip_sim3_create(ctx.h, _p(verts), _p(fixed), self.n, _p(edges), self.n_edges, int(fix_scale), C.byref(h)))
         self.h = h
+        ctx._children.add(self)
 
     def close(self):
         if getattr(self, "h", None):

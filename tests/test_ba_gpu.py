@@ -63,9 +63,9 @@ def test_mono_and_inactive_observations(hiplib, oracle, ctx):
 
 def test_rejected_steps_follow_g2o_lambda_control(hiplib, oracle, ctx):
     """Large perturbation: trials with rho < 0 must be rejected and lambda raised by nu, identically on both sides."""
-    prob = synth.ba_problem(6, 150, 800, 640, 480, seq_id=6, pose_noise=(0.08, 0.5), point_noise=0.5)
+    prob = synth.ba_problem(6, 150, 800, 640, 480, seq_id=46, pose_noise=(0.5, 3.0), point_noise=3.0)
     ba, gp, gx, glog = _compare(hiplib, oracle, ctx, prob, True, 10)
-    assert glog["trials"].max() >= 1
+    assert glog["trials"].max() > 1                                 # the fifth iteration needs four trials
 
 
 def test_all_poses_fixed_and_no_observations(hiplib, oracle, ctx):
@@ -169,7 +169,7 @@ def test_global_ba_size_runs(hiplib, oracle):
 def test_optimize_in_two_halves_beside_front_end_work(hiplib, oracle, ctx):
     """optimize_begin / optimize_end give what optimize gives (also with rejected trials, which need extra units after the
     wait), while front-end work is enqueued on the context in between; misuse is refused."""
-    prob = synth.ba_problem(6, 150, 800, 640, 480, seq_id=6, pose_noise=(0.08, 0.5), point_noise=0.5)
+    prob = synth.ba_problem(6, 150, 800, 640, 480, seq_id=46, pose_noise=(0.5, 3.0), point_noise=3.0)
     obs = hiplib.ba_obs_array(prob)
     one = hiplib.BundleAdjuster(ctx, prob["poses"], prob["fixed"], prob["points"], obs, prob["cam"])
     want = one.optimize(True, 10); wp, wx = one.state()
@@ -187,3 +187,63 @@ def test_optimize_in_two_halves_beside_front_end_work(hiplib, oracle, ctx):
         assert got.tobytes() == want.tobytes() and np.array_equal(gp, wp) and np.array_equal(gx, wx)
     with pytest.raises(hiplib.LpslamHipError):
         two.optimize_end()
+
+
+def test_batched_solve_equals_single_solves(hiplib, oracle, ctx):
+    """lpslam_hip_ba_optimize_batch: problems of different sizes (different panel counts, one with rejected trials, one with all
+    poses fixed) advanced by one launch chain give the bytes the single-problem calls give, and follow the oracle."""
+    specs = [dict(n_kf=12, n_pts=600, n_obs=4000, seq=21), dict(n_kf=5, n_pts=80, n_obs=320, seq=22), dict(n_kf=33, n_pts=900, n_obs=6000, seq=23),
+             dict(n_kf=6, n_pts=150, n_obs=800, seq=46, pose_noise=(0.5, 3.0), point_noise=3.0), dict(n_kf=2, n_pts=20, n_obs=40, seq=25),
+             dict(n_kf=4, n_pts=60, n_obs=200, seq=8, all_fixed=True)]
+    probs = []
+    for sp in specs:
+        kw = {k: sp[k] for k in ("pose_noise", "point_noise") if k in sp}
+        pr = synth.ba_problem(sp["n_kf"], sp["n_pts"], sp["n_obs"], 640, 480, seq_id=sp["seq"], **kw)
+        if sp.get("all_fixed"):
+            pr["fixed"][:] = 1
+        probs.append(pr)
+    iters = 8
+    make = lambda pr: hiplib.BundleAdjuster(ctx, pr["poses"], pr["fixed"], pr["points"], hiplib.ba_obs_array(pr), pr["cam"])
+    singles = [make(pr) for pr in probs]
+    want = [(b.optimize(True, iters), b.state()) for b in singles]
+    batch = [make(pr) for pr in probs]
+    logs = hiplib.ba_optimize_batch(batch, True, iters)
+    for pr, b, lg, (wl, (wp, wx)) in zip(probs, batch, logs, want):
+        gp, gx = b.state()
+        assert lg.tobytes() == wl.tobytes() and np.array_equal(gp, wp) and np.array_equal(gx, wx)
+        op, ox, olog = oracle.ba_optimize(pr["poses"], pr["fixed"], pr["points"], oracle.ba_obs(pr), pr["cam"], True, iters)
+        assert len(lg) == len(olog) and np.allclose(lg["chi2_after"], olog["chi2_after"], rtol=CHI_RTOL) and np.array_equal(lg["trials"], olog["trials"])
+        assert rot_err(gp[:, :4], op[:, :4]).max() < ROT_TOL and np.abs(gp[:, 4:] - op[:, 4:]).max() < TRANS_TOL
+    assert max(l["trials"].max() for l in logs) > 1                   # the batch did contain rejected trials
+    # a second round on the same objects after a batched reset: same bytes again
+    hiplib.ba_reset_batch(batch)
+    logs2 = hiplib.ba_optimize_batch(batch, True, iters)
+    for lg, lg2 in zip(logs, logs2):
+        assert lg.tobytes() == lg2.tobytes()
+    # misuse: the same problem twice, an empty batch
+    with pytest.raises(hiplib.LpslamHipError):
+        hiplib.ba_optimize_batch([batch[0], batch[0]], True, 2)
+
+
+def test_structure_built_on_the_device_handles_any_observation_order(hiplib, oracle, ctx):
+    """The device-side structure phase (storage order, CSR, pair lists) must not depend on the order the caller lists the
+    observations in, and must cope with a landmark seen twice by one keyframe (duplicate (keyframe, landmark) pairs)."""
+    prob = synth.ba_problem(9, 300, 2000, 640, 480, seq_id=31)
+    rng = np.random.default_rng(3)
+    # duplicates: a second observation of the same landmark in the same keyframe (slightly different measurement)
+    dup = rng.choice(len(prob["obs_pose"]), 25, replace=False)
+    for key in ("obs_pose", "obs_point", "obs_uvr", "obs_inv_sigma2"):
+        prob[key] = np.concatenate([prob[key], prob[key][dup]])
+    prob["obs_uvr"][-25:, :2] += rng.normal(0, 0.3, (25, 2))
+    perm = rng.permutation(len(prob["obs_pose"]))
+    shuf = dict(prob)
+    for key in ("obs_pose", "obs_point", "obs_uvr", "obs_inv_sigma2"):
+        shuf[key] = prob[key][perm]
+    ba, gp, gx, glog = _compare(hiplib, oracle, ctx, shuf, True, 8)
+    # per-observation outputs come back in the caller's order
+    gchi, gpos = ba.chi2()
+    ochi, opos = oracle.ba_chi2(gp, gx, oracle.ba_obs(shuf), shuf["cam"])
+    assert np.allclose(gchi, ochi, rtol=1e-9, atol=1e-12) and np.array_equal(gpos, opos)
+    # the activity mask is given in the caller's order too
+    active = np.ones(len(perm), np.uint8); active[::7] = 0
+    _compare(hiplib, oracle, ctx, shuf, True, 5, active)
