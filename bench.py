@@ -3,19 +3,24 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[1] + configs[2], the configuration the metric is quoted on): 1280x720 stereo,
-2000 keypoints / image, 8 pyramid levels.  One "step" = one keyframe interval of the path:
-    6 stereo frames: ORB extraction of 12 images, 6 stereo matches, 6 temporal brute-force matches (2000 x 2000),
-    1 local bundle adjustment: 50 keyframes / 5000 landmarks / ~40k stereo observations, 10 LM iterations (Huber).
-Inputs (frames, BA problem) are synthetic and resident in HBM before the timed region.
-value = frames/s over the whole job (all ranks); N > 1 runs one independent sequence per GPU (replicas, no data-path
-collective, "weak" scaling).  The JSON line also carries the roofline of the dominant front-end kernel (HIP-event
-timed on the stream it runs on) and the CPU oracle timed on a bounded sample (rank 0, N = 1).
+Workload (BASELINE.json configs[1] + configs[2], the configuration the metric is quoted on): ONE SLAM session per GPU,
+1280x720 stereo, 2000 keypoints / image, 8 pyramid levels, a 300-frame synthetic sequence of which a
+ring of RESIDENT frames lives in HBM.  One "step" = 16 stereo frames in one launch (frames_per_launch 16):
+    ORB extraction of 32 images, 16 stereo matches, 16 temporal brute-force matches (2000 x 2000, frame k vs k-1),
+    + the local bundle adjustment of every keyframe among them (every 6th frame: 2.67 per step on average): a FRESH
+      problem each time -- lpslam_hip_ba_create (structure phase, g2o's buildStructure, inside the timed region),
+      10 LM iterations with Huber, destroy -- 50 keyframes / 5000 landmarks / ~39k stereo observations.
+The bundle adjustments run on their own stream and host thread beside the front end, as the reference's mapping thread
+runs beside tracking; a session's windows are solved one after the other (they depend on each other).
+value = frames/s over the whole job (all ranks); N > 1 runs one independent session per GPU (replicas, no data-path
+collective, "weak" scaling).  The JSON line carries the roofline of the kernel with the largest share of GPU time
+(every timed kernel is a candidate: HIP events on the stream the kernel runs on) and the CPU oracle on a bounded sample.
 """
 import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -24,13 +29,20 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 W, H, KPTS, LEVELS = 1280, 720, 2000, 8
-FRAMES_PER_STEP = 6
+FRAMES_PER_STEP = 16          # batched mode, B = 16 frames per launch
+KF_INTERVAL = 6               # keyframe every 6th frame
+RESIDENT = 48                 # stereo frames of the sequence resident in HBM (3 steps of 16; the ring is re-walked)
 BA_KF, BA_PTS, BA_OBS, BA_ITERS = 50, 5000, 40000, 10
-HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 measured copy)
+BA_VARIANTS = 4               # distinct windows (problem seeds) the keyframes rotate through
+HBM_PEAK_GBS = 8000.0         # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 measured copy)
+FP64_PEAK_TFLOPS = 78.6       # MI355X FP64 matrix = vector peak (MI355X_MICROARCH.md / SURVEY.md 8(d))
+INT_PEAK_TOPS = 39.3          # 256 CU x 64 lanes x 2.4 GHz int32 VALU ops (matching)
 
-# timer slots
-T_PYR, T_FAST, T_DIST, T_DESC, T_STEREO, T_BF, T_BA = range(7)
-STAGE_NAMES = ["pyramid", "fast", "distribute", "describe", "stereo", "bf", "ba"]
+# timer slots of the front-end stages
+T_PYR, T_FAST, T_DIST, T_DESC, T_STEREO, T_BF = range(6)
+FE_STAGES = ["pyramid", "fast", "distribute", "describe", "stereo", "bf"]
+FE_KERNEL = {"pyramid": "k_pyr_bands", "fast": "k_fast_cells", "distribute": "k_distribute", "describe": "k_describe",
+             "stereo": "k_stereo", "bf": "k_bf_knn2"}
 
 
 def parse():
@@ -38,55 +50,90 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames", type=int, default=FRAMES_PER_STEP, help="stereo frames per step")
+    ap.add_argument("--frames", type=int, default=FRAMES_PER_STEP, help="stereo frames per step (per launch)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-ba", action="store_true", help="front end only (BASELINE configs[1])")
-    ap.add_argument("--no-extras", action="store_true", help="skip the untimed extras (front end alone, BA spread, pose graph): profiling runs")
+    ap.add_argument("--no-extras", action="store_true", help="skip the untimed extras (latency mode, batched sessions, trackers, global BA): profiling runs")
     return ap.parse_args()
 
 
 class Workload:
-    def __init__(self, device, seq_id, frames, with_ba=True):
+    """One SLAM session: a ring of resident stereo frames + the windows its keyframes trigger."""
+
+    def __init__(self, device, seq_id, frames, with_ba=True, resident=RESIDENT):
         from lpslam_amd import hip, synth
         self.hip, self.synth = hip, synth
         self.F = frames
+        self.R = max(resident // frames, 1) * frames           # ring length: a whole number of steps
         self.k = synth.intrinsics(W, H)
-        self.ctx = hip.Context(W, H, KPTS, 1.2, LEVELS, max_images=2 * frames, device=device)
+        self.ctx = hip.Context(W, H, KPTS, 1.2, LEVELS, max_images=2 * self.R, device=device)
         seq = synth.StereoSequence(W, H, seq_id)
-        self.host_frames = [seq.frame(i) for i in range(frames)]
+        self.host_frames = [seq.frame(i) for i in range(self.R)]
         for i, (l, r) in enumerate(self.host_frames):
             self.ctx.upload(2 * i, l); self.ctx.upload(2 * i + 1, r)
-        self.ba = None
+        self.with_ba = with_ba
+        self.frame_counter = 0          # frames fed so far (front-end thread)
+        self.kf_counter = 0             # keyframes solved so far (BA thread)
         if with_ba:
-            self.prob = synth.ba_problem(BA_KF, BA_PTS, BA_OBS, W, H, seq_id)
-            self.ba = hip.BundleAdjuster(self.ctx, self.prob["poses"], self.prob["fixed"], self.prob["points"],
-                                         hip.ba_obs_array(self.prob), self.prob["cam"])
+            self.probs = [synth.ba_problem(BA_KF, BA_PTS, BA_OBS, W, H, seq_id * BA_VARIANTS + v) for v in range(BA_VARIANTS)]
+            self.obs = [hip.ba_obs_array(p) for p in self.probs]
+            self.n_obs = int(np.mean([len(o) for o in self.obs]))
         self.ctx.sync()
 
-    def front_end(self):
+    # ---- front end: one launch sequence for the F frames of step `s` (ring position)
+    def front_end(self, s):
         c, F = self.ctx, self.F
-        c.extract(2 * F)
-        c.match_stereo_strided(0, 1, 2, F, self.k["fxb"], self.k["baseline"])
+        f0 = (s * F) % self.R
+        c.extract_range(2 * f0, 2 * F)
+        c.match_stereo_strided(2 * f0, 2 * f0 + 1, 2, F, self.k["fxb"], self.k["baseline"])
         if F > 1:
-            c.match_bf_strided(2, 0, 2, F - 1)
-        c.match_bf(0, 2 * F - 2)                  # first frame of this interval against the last of the previous one
+            c.match_bf_strided(2 * f0 + 2, 2 * f0, 2, F - 1)
+        c.match_bf(2 * f0, 2 * ((f0 - 1) % self.R))          # first frame of this step against the last frame before it
 
-    def bundle_adjust(self):
-        self.ba.reset()
-        self.ba.optimize(True, BA_ITERS)
+    def keyframes_of_step(self, s):
+        g0 = s * self.F
+        return sum(1 for g in range(g0, g0 + self.F) if g % KF_INTERVAL == 0)
 
-    def step(self, timers=False):
-        c, F = self.ctx, self.F
-        if not timers:
-            # the local BA of this interval runs on its own stream beside the front end of the interval's frames, as the
-            # reference's mapping thread runs beside tracking: enqueue it, enqueue the frames, then wait for both
-            if self.ba is not None:
-                self.ba.reset()
-                self.ba.optimize_begin(True, BA_ITERS)
-            self.front_end()
-            if self.ba is not None:
-                self.ba.optimize_end()
+    def new_problem(self, v):
+        p = self.probs[v % BA_VARIANTS]
+        return self.hip.BundleAdjuster(self.ctx, p["poses"], p["fixed"], p["points"], self.obs[v % BA_VARIANTS], p["cam"])
+
+    def bundle_adjust_fresh(self):
+        """what a keyframe costs the mapping side: structure phase + 10 LM iterations + release"""
+        ba = self.new_problem(self.kf_counter)
+        self.kf_counter += 1
+        log = ba.optimize(True, BA_ITERS)
+        ba.close()
+        return log
+
+    def run_steps(self, first_step, k):
+        """k steps: the front end on this thread, the keyframes' bundle adjustments on a second one (own stream)"""
+        if not self.with_ba:
+            for s in range(first_step, first_step + k):
+                self.front_end(s)
+            self.ctx.sync()
             return
+        err = []
+        n_kf = sum(self.keyframes_of_step(s) for s in range(first_step, first_step + k))
+
+        def ba_loop():
+            try:
+                for _ in range(n_kf):
+                    self.bundle_adjust_fresh()
+            except Exception as e:      # noqa: BLE001
+                err.append(e)
+        th = threading.Thread(target=ba_loop)
+        th.start()
+        for s in range(first_step, first_step + k):
+            self.front_end(s)
+        self.ctx.sync()
+        th.join()
+        if err:
+            raise err[0]
+
+    # ---- instrumented pass: HIP events around every front-end stage on the context stream
+    def front_end_timed(self):
+        c, F = self.ctx, self.F
         for slot, stage in ((T_PYR, "pyramid"), (T_FAST, "fast"), (T_DIST, "distribute"), (T_DESC, "describe")):
             c.timer_begin(slot); c.stage(stage, 2 * F); c.timer_end(slot)
         c.timer_begin(T_STEREO); c.match_stereo_strided(0, 1, 2, F, self.k["fxb"], self.k["baseline"]); c.timer_end(T_STEREO)
@@ -95,70 +142,96 @@ class Workload:
             c.match_bf_strided(2, 0, 2, F - 1)
         c.match_bf(0, 2 * F - 2)
         c.timer_end(T_BF)
-        if self.ba is not None:
-            c.sync()
-            t0 = time.perf_counter(); self.bundle_adjust(); self.ba_wall_ms = 1e3 * (time.perf_counter() - t0)
+        c.sync()
+        return [c.timer_ms(s) for s in range(len(FE_STAGES))]
+
+    # ---- algorithmic work per step
+    def level_pixels(self):
+        return [w * h for w, h in zip(self.ctx.level_w, self.ctx.level_h)]
 
     def extract_bytes(self):
-        """SURVEY.md 8(d): B_img = (P - P_7) + (P - P_0) + P + 2P + 2 K 31^2 + 60 K per image (17 236 083 B at 1280x720 / 2000)."""
-        P = [w * h for w, h in zip(self.ctx.level_w, self.ctx.level_h)]
-        Ps = sum(P)
+        """B_img = (P - P_7) + (P - P_0) + P + 2P + 2 K 31^2 + 60 K per image (17 236 083 B at 1280x720 / 2000)."""
+        P = self.level_pixels(); Ps = sum(P)
         return 2 * self.F * ((Ps - P[-1]) + (Ps - P[0]) + Ps + 2 * Ps + 2 * KPTS * 31 * 31 + 60 * KPTS)
 
-    def algorithmic_bytes(self):
-        """per-image pass-structured bytes of each front-end kernel group."""
-        P = [w * h for w, h in zip(self.ctx.level_w, self.ctx.level_h)]
-        Psum = sum(P)
-        n_img = 2 * self.F
-        K = KPTS
+    def stage_work(self):
+        """algorithmic work of one launch of each front-end stage: (amount, unit, bound, peak)"""
+        P = self.level_pixels(); Ps = sum(P); n_img = 2 * self.F; K = KPTS
         return {
-            "pyramid": n_img * ((Psum - P[-1]) + (Psum - P[0])),
-            "fast": n_img * Psum,
-            "describe": n_img * (2 * K * 31 * 31 + K * 60),
+            "pyramid": (n_img * ((Ps - P[-1]) + (Ps - P[0])), "B", "hbm", HBM_PEAK_GBS * 1e9),
+            "fast": (n_img * Ps, "B", "hbm", HBM_PEAK_GBS * 1e9),
+            "distribute": (None, "B", "hbm", HBM_PEAK_GBS * 1e9),          # 4 B x candidates: data dependent, filled in by the caller
+            "describe": (n_img * (2 * K * 31 * 31 + K * 60), "B", "hbm", HBM_PEAK_GBS * 1e9),
+            "stereo": (None, "B", "hbm", HBM_PEAK_GBS * 1e9),
+            "bf": (self.F * 2 * K * K * 8, "op", "valu", INT_PEAK_TOPS * 1e12),   # xor + popcount per 32-bit word pair
         }
 
 
-_CPU_MT = None
+def ba_flops(prob, dim):
+    """linearise ~520 FLOP/obs, Schur sum_j(216 n_j^2 + 108 n_j + 50), Cholesky dim^3/3, back-sub + chi2 ~150 FLOP/obs"""
+    n_obs = len(prob["obs_pose"])
+    nj = np.bincount(prob["obs_point"], minlength=len(prob["points"])).astype(np.float64)
+    schur = float((216 * nj * nj + 108 * nj + 50).sum())
+    n = dim + 1                      # the rhs rides along as one more row
+    return {"linearise": 520.0 * n_obs, "schur": schur, "cholesky": n ** 3 / 3.0 + 2.0 * n * n, "backsub": 150.0 * n_obs}
 
 
-def cpu_baseline(frames_sample=12, ba_solves=2):
-    """Oracle (CPU restatement, 1 thread, -O3 without -march=native) on a bounded sample of the same workload."""
-    from oracle import oracle as O
-    from lpslam_amd import synth
-    p = O.params(KPTS, 1.2, LEVELS)
+# ---------------------------------------------------------------------------------------------------------------------------------
+# CPU baseline: the oracle (CPU restatement of the OpenVSLAM / g2o algorithms) on a bounded sample of the same workload
+# ---------------------------------------------------------------------------------------------------------------------------------
+def _cpu_frames(O, synth, n):
     seq = synth.StereoSequence(W, H, 0)
-    k = synth.intrinsics(W, H)
-    frames = [seq.frame(i) for i in range(frames_sample)]
-    prob = synth.ba_problem(BA_KF, BA_PTS, BA_OBS, W, H, 0)
-    obs = O.ba_obs(prob)
-    t0 = time.perf_counter()
+    return [seq.frame(i) for i in range(n)]
+
+
+def _cpu_front_end(O, p, k, frames):
     prev = None
     for l, r in frames:
         kl, dl, _, pl = O.extract(l, p, True)
         kr, dr, _, pr = O.extract(r, p, True)
         O.match_stereo(pl, pr, p, kl, dl, kr, dr, k["fxb"], k["baseline"])
-        if prev is not None:
-            O.match_bf_knn2(dl, prev)
-        else:
-            O.match_bf_knn2(dl, dl)
+        O.match_bf_knn2(dl, prev if prev is not None else dl)
         prev = dl
-    t_front = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    for _ in range(ba_solves):
-        O.ba_optimize(prob["poses"], prob["fixed"], prob["points"], obs, prob["cam"], True, BA_ITERS)
-    t_ba = (time.perf_counter() - t0) / ba_solves
-    per_frame = t_front / frames_sample + t_ba / FRAMES_PER_STEP
-    # the reference's own threading (SURVEY.md 8(d)): left / right extraction on two threads (the std::async pair of
-    # src/Trackers/OpenVSLAMStereoTracker.cpp:199-213), the local BA on a third (OpenVSLAM's mapping thread); ctypes releases the GIL
-    import threading
-    n_mt = 6
 
-    def ba_thread():
+
+def cpu_baseline():
+    """Legs: (1) one thread, -O3 (the reference builds with BUILD_WITH_MARCH_NATIVE=OFF); (2) one thread,
+    -march=native; (3) the reference's own threading: left / right extraction on two threads, local BA on a third; (4) all host
+    cores, -march=native: independent frames and windows in parallel (ctypes releases the GIL).  Bounded: ~20 s of CPU in all."""
+    from oracle import oracle as O
+    from lpslam_amd import synth
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip(); break
+    except OSError:
+        pass
+    p = O.params(KPTS, 1.2, LEVELS)
+    k = synth.intrinsics(W, H)
+    frames = _cpu_frames(O, synth, 8)
+    prob = synth.ba_problem(BA_KF, BA_PTS, BA_OBS, W, H, 0)
+    obs = O.ba_obs(prob)
+
+    def ba_once():
         O.ba_optimize(prob["poses"], prob["fixed"], prob["points"], obs, prob["cam"], True, BA_ITERS)
+
+    def single(n_frames):
+        t0 = time.perf_counter(); _cpu_front_end(O, p, k, frames[:n_frames]); t_front = (time.perf_counter() - t0) / n_frames
+        t0 = time.perf_counter(); ba_once(); t_ba = time.perf_counter() - t0
+        return t_front, t_ba
+
+    legs = {}
+    t_front, t_ba = single(6)
+    legs["1_thread_O3"] = {"value": round(1.0 / (t_front + t_ba / KF_INTERVAL), 3), "unit": "frames/s", "cores": 1, "flags": "-O3",
+                           "front_end_ms_per_frame": round(1e3 * t_front, 2), "ba_ms_per_iter": round(1e3 * t_ba / BA_ITERS, 3)}
+    # the reference's own threading: left / right extraction on two threads (the std::async pair of
+    # src/Trackers/OpenVSLAMStereoTracker.cpp:199-213), the local BA on a third (OpenVSLAM's mapping thread)
     t0 = time.perf_counter()
-    th_ba = threading.Thread(target=ba_thread); th_ba.start()
+    th_ba = threading.Thread(target=ba_once); th_ba.start()
     prev = None
-    for l, r in frames[:n_mt]:
+    for l, r in frames[:KF_INTERVAL]:
         res = {}
         th_r = threading.Thread(target=lambda: res.__setitem__("r", O.extract(r, p, True))); th_r.start()
         kl, dl, _, pl = O.extract(l, p, True)
@@ -168,17 +241,35 @@ def cpu_baseline(frames_sample=12, ba_solves=2):
         O.match_bf_knn2(dl, prev if prev is not None else dl)
         prev = dl
     th_ba.join()
-    t_mt = time.perf_counter() - t0
-    global _CPU_MT
-    _CPU_MT = {"value": round(n_mt / t_mt, 3), "unit": "frames/s", "cores": 3, "kind": "port",
-               "sample": "%d stereo frames with left / right extraction on two threads beside one local-BA solve of %d LM iterations on a third "
-                         "(one keyframe interval of the workload)" % (n_mt, BA_ITERS)}
-    return {"value": round(1.0 / per_frame, 3), "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": "%d stereo frames (extract L+R, stereo match, 2000x2000 BF) + %d local-BA solves of %d LM iterations "
-                      "amortised 1 per %d frames; single thread" % (frames_sample, ba_solves, BA_ITERS, FRAMES_PER_STEP),
-            "front_end_ms_per_frame": round(1e3 * t_front / frames_sample, 2), "ba_ms_per_iter": round(1e3 * t_ba / BA_ITERS, 3)}
+    legs["3_threads_reference_threading_O3"] = {"value": round(KF_INTERVAL / (time.perf_counter() - t0), 3), "unit": "frames/s", "cores": 3, "flags": "-O3"}
+    native_ok = True
+    try:
+        O.use_native_build(True)
+    except Exception as e:      # noqa: BLE001 -- no compiler on the box: the default build stays
+        native_ok = False
+        legs["native_build_error"] = str(e)[:200]
+    flags = "-O3 -march=native" if native_ok else "-O3"
+    t_front_n, t_ba_n = single(6)
+    legs["1_thread_native"] = {"value": round(1.0 / (t_front_n + t_ba_n / KF_INTERVAL), 3), "unit": "frames/s", "cores": 1, "flags": flags,
+                               "front_end_ms_per_frame": round(1e3 * t_front_n, 2), "ba_ms_per_iter": round(1e3 * t_ba_n / BA_ITERS, 3)}
+    # all cores: every thread runs whole keyframe intervals (6 frames + 1 window) of its own -- independent sequences in parallel
+    n_thr = max(ncpu, 1)
+    t0 = time.perf_counter()
+    ths = [threading.Thread(target=lambda: (_cpu_front_end(O, p, k, frames[:KF_INTERVAL]), ba_once())) for _ in range(n_thr)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    t_all = time.perf_counter() - t0
+    best = {"value": round(n_thr * KF_INTERVAL / t_all, 3), "unit": "frames/s", "cores": n_thr, "kind": "port", "flags": flags,
+            "sample": "%d threads, each one keyframe interval of the workload (6 stereo frames: extract L+R, stereo match, 2000x2000 BF; one local BA of "
+                      "%d LM iterations); CPU restatement of the OpenVSLAM / g2o algorithms, not OpenVSLAM itself" % (n_thr, BA_ITERS),
+            "host": {"nproc": ncpu, "cpu_model": model}}
+    O.use_native_build(False)
+    return best, legs
 
 
+# ---------------------------------------------------------------------------------------------------------------------------------
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -204,6 +295,7 @@ def main():
             dist.init_process_group(backend=backend)
 
     wl = Workload(device, rank, args.frames, with_ba=not args.no_ba)
+    F = args.frames
 
     def sync_tensor(values, op=None):
         import torch
@@ -218,75 +310,152 @@ def main():
         if dist is not None:
             sync_tensor([0.0])
 
-    import threading
-
-    def run_steps(k):
-        # the local BA runs on its own stream and host thread beside the front end of the following frames, as the
-        # reference's mapping thread does; both finish their k units before the step count is met
-        if wl.ba is None:
-            for _ in range(k):
-                wl.front_end()
-            wl.ctx.sync()
-            return
-        err = []
-
-        def ba_loop():
-            try:
-                for _ in range(k):
-                    wl.bundle_adjust()
-            except Exception as e:      # noqa: BLE001
-                err.append(e)
-        th = threading.Thread(target=ba_loop)
-        th.start()
-        for _ in range(k):
-            wl.front_end()
-        wl.ctx.sync()
-        th.join()
-        if err:
-            raise err[0]
-
-    run_steps(args.warmup)
+    wl.run_steps(0, args.warmup)
     barrier()
     t0 = time.perf_counter()
-    run_steps(args.steps)
+    wl.run_steps(args.warmup, args.steps)
     elapsed = time.perf_counter() - t0
     barrier()
     if dist is not None:
         elapsed = float(sync_tensor([elapsed], dist.ReduceOp.MAX).item())
+    n_kf_timed = sum(wl.keyframes_of_step(s) for s in range(args.warmup, args.warmup + args.steps)) if wl.with_ba else 0
 
-    # instrumented pass (same steps, HIP events around every stage on the context stream)
-    stage_ms = np.zeros(len(STAGE_NAMES))
-    n_inst = max(3, min(args.steps, 10))
-    for _ in range(n_inst):
-        wl.step(timers=True)
-        wl.ctx.sync()
-        for s in range(len(STAGE_NAMES)):
-            if s == T_BA:
-                stage_ms[s] += wl.ba_wall_ms if wl.ba is not None else 0.0      # BA: host wall time of reset + 10 LM iterations
-                continue
-            stage_ms[s] += wl.ctx.timer_ms(s)
-    stage_ms /= n_inst
+    out = None
+    if rank == 0:
+        # ---- instrumented passes, outside the timed region: HIP events on the streams the kernels run on
+        n_inst = max(3, min(args.steps, 10))
+        fe_ms = np.mean([wl.front_end_timed() for _ in range(n_inst)], axis=0)
+        ba_prof, ba_setup_ms, ba_total_ms, ba_iters_done, ba_dim = None, None, None, 0, 0
+        if wl.with_ba:
+            # set-up alone: create until the structure is ready on the device (a state read synchronises)
+            ts = []
+            for v in range(6):
+                t1 = time.perf_counter(); b = wl.new_problem(v); b.state(); ts.append(1e3 * (time.perf_counter() - t1)); b.close()
+            ba_setup_ms = float(np.median(ts[1:]))
+            acc = {}
+            for v in range(n_inst):
+                b = wl.new_problem(v)
+                prof, ba_iters_done, ba_dim = b.optimize_profiled(True, BA_ITERS)
+                b.close()
+                for name, (ms, marks, per) in prof.items():
+                    a = acc.setdefault(name, [0.0, 0, per]); a[0] += ms; a[1] += marks
+            ba_prof = {n: {"ms_per_solve": a[0] / n_inst, "marks_per_solve": a[1] / n_inst, "launches_per_mark": a[2]} for n, a in acc.items()}
+            ts = []
+            for v in range(n_inst):
+                t1 = time.perf_counter(); wl.bundle_adjust_fresh(); ts.append(1e3 * (time.perf_counter() - t1))
+            ba_total_ms = float(np.median(ts))
 
-    # PCIe-inclusive rate (host frames uploaded inside the loop) -- reported beside, never as `value`
-    t1 = time.perf_counter()
-    n_pcie = max(2, min(args.steps, 5))
-    for _ in range(n_pcie):
-        for i, (l, r) in enumerate(wl.host_frames):
-            wl.ctx.upload(2 * i, l); wl.ctx.upload(2 * i + 1, r)
-        wl.step()
-    wl.ctx.sync()
-    pcie_fps = n_pcie * args.frames / (time.perf_counter() - t1)
+        # ---- GPU time per step by kernel: the dominant one gets the roofline
+        kf_per_step = n_kf_timed / max(args.steps, 1)
+        per_step = {FE_KERNEL[n]: float(ms) for n, ms in zip(FE_STAGES, fe_ms)}
+        if ba_prof:
+            for n, d in ba_prof.items():
+                per_step["k_chol_factor" if n == "chol" else n] = d["ms_per_solve"] * kf_per_step
+        dom = max(per_step, key=per_step.get)
+        work = wl.stage_work()
+        flops = ba_flops(wl.probs[0], ba_dim) if wl.with_ba else None
+        roof = None
+        if dom == "k_chol_factor":
+            d = ba_prof["chol"]
+            launches = d["marks_per_solve"] * d["launches_per_mark"]          # kernel launches per solve
+            avg_ms = d["ms_per_solve"] / max(launches, 1)
+            fl_per_launch = flops["cholesky"] * d["marks_per_solve"] / max(launches, 1)
+            ach = fl_per_launch / (avg_ms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": hip.ba_factor_kernel_name(ba_dim), "launches_per_step": round(launches * kf_per_step, 2),
+                    "achieved": round(ach, 4), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / FP64_PEAK_TFLOPS, 6),
+                    "algorithmic_flops_per_launch": int(fl_per_launch), "avg_launch_us": round(1e3 * avg_ms, 3), "traffic": None,
+                    "note": "FP64 dense factorisation of the %d x %d reduced system (n^3/3 + 2 n^2 FLOP per factorisation, SURVEY 8(d)) over the "
+                            "launches of one factorisation; latency bound (serial panel chain), see DESIGN.md section 5" % (ba_dim + 1, ba_dim + 1)}
+        elif dom in ("k_ba_schur", "k_ba_point_sum", "k_ba_backsub", "k_ba_trial", "k_ba_lin", "k_chol_xsolve"):
+            d = ba_prof[dom]
+            avg_ms = d["ms_per_solve"] / max(d["marks_per_solve"], 1)
+            n_obs = len(wl.probs[0]["obs_pose"])
+            nj = np.bincount(wl.probs[0]["obs_point"], minlength=len(wl.probs[0]["points"])).astype(np.float64)
+            terms = float((nj * (nj + 1) / 2).sum())
+            bytes_per_launch = {"k_ba_schur": 336.0 * terms, "k_ba_point_sum": 72.0 * n_obs, "k_ba_backsub": 144.0 * n_obs + 8.0 * (ba_dim + 1) ** 2,
+                                "k_ba_trial": (64.0 + 40 + 144 + 72) * n_obs, "k_ba_lin": (40.0 + 144 + 72) * n_obs, "k_chol_xsolve": 8.0 * (ba_dim + 1) ** 2}[dom]
+            ach = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": dom, "launches_per_step": round(d["marks_per_solve"] * kf_per_step, 2), "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "algorithmic_bytes_per_launch": int(bytes_per_launch), "avg_launch_us": round(1e3 * avg_ms, 3), "traffic": None}
+        else:
+            stage = [n for n in FE_STAGES if FE_KERNEL[n] == dom][0]
+            amount, unit, bound, peak = work[stage]
+            ms = per_step[dom]
+            if amount is None:
+                amount = 0
+            if bound == "hbm":
+                ach = amount / (ms * 1e-3) / 1e9
+                roof = {"bound": "hbm", "kernel": dom, "launches_per_step": 1, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(ach / HBM_PEAK_GBS, 5), "algorithmic_bytes_per_launch": int(amount), "avg_launch_us": round(1e3 * ms, 3), "traffic": None}
+            else:
+                ach = amount / (ms * 1e-3) / 1e12
+                roof = {"bound": "valu", "kernel": dom, "launches_per_step": 2, "achieved": round(ach, 3), "peak": INT_PEAK_TOPS, "unit": "Tint32op/s",
+                        "frac": round(ach / INT_PEAK_TOPS, 5), "algorithmic_ops_per_step": int(amount), "avg_ms_per_step": round(ms, 4), "traffic": None}
+        # HBM traffic of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs
+        # of this command, tools/refresh_profiles.sh -> profiles/<round>_pmc.json); profile-derived, not measured in this run
+        try:
+            pmc_files = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc.json"))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_files[-1])))
+            kn = roof["kernel"]
+            if kn in pmc["kernels"] and pmc.get("frames_per_launch", 6) == F:
+                e = pmc["kernels"][kn]
+                roof["traffic"] = int(round(1024.0 * (e["FETCH_SIZE"]["mean_per_launch"] + e["WRITE_SIZE"]["mean_per_launch"])))
+                roof["traffic_source"] = "profiles/" + pmc_files[-1] + " (FETCH_SIZE + WRITE_SIZE per launch, uncorrected; see DESIGN.md section 6)"
+        except (OSError, KeyError, ValueError, IndexError):
+            pass
 
-    # SURVEY.md 8(d) extras, outside the timed region: front end alone in batched and single-frame-latency mode, the spread of
-    # the BA time per LM iteration, and the Sim3 pose graph of BASELINE config 5's keyframe count
-    extras = {}
-    if rank == 0 and not args.no_extras and world == 1:          # the scaling runs (N > 1) print the timed line only
+        # PCIe-inclusive rate (host frames uploaded inside the loop) -- reported beside, never as `value`
+        t1 = time.perf_counter()
+        n_pcie = 2
+        for it in range(n_pcie):
+            f0 = (it * F) % wl.R
+            for i in range(F):
+                l, r = wl.host_frames[f0 + i]
+                wl.ctx.upload(2 * (f0 + i), l); wl.ctx.upload(2 * (f0 + i) + 1, r)
+            wl.run_steps(it, 1)
+        pcie_fps = n_pcie * F / (time.perf_counter() - t1)
+
+        frames_total = world * F * args.steps
+        value = frames_total / elapsed
+        fe_extract_ms = float(fe_ms[T_PYR] + fe_ms[T_FAST] + fe_ms[T_DIST] + fe_ms[T_DESC])
+        out = {
+            "metric": "frames/sec (ORB+match+local-BA), 1280x720 stereo",
+            "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8 front end / f64 BA", "data": "synthetic",
+            "config": {"workload": "configs[1]+configs[2]: one session, 1280x720 stereo, 2000 kpts, 8 levels; step = %d stereo frames in one launch "
+                                   "(extract L+R, stereo match, 2000x2000 BF temporal match; ring of %d resident frames of the 300-frame sequence) + a fresh "
+                                   "50-KF/5k-landmark/%d-obs local BA (create + %d LM iterations + destroy) per keyframe (every %dth frame)"
+                                   % (F, wl.R, wl.n_obs if wl.with_ba else 0, BA_ITERS, KF_INTERVAL),
+                       "frames_per_step": F, "frames_per_launch": F, "keyframes_per_step": round(kf_per_step, 3), "replicas": world, "parallelism": "replicas x%d" % world},
+            "ba_ms_per_iter": round(sum(d["ms_per_solve"] for d in ba_prof.values()) / max(ba_iters_done, 1), 4) if ba_prof else None,
+            "ba_setup_ms": round(ba_setup_ms, 4) if ba_setup_ms is not None else None,
+            "ba_ms_per_keyframe": round(ba_total_ms, 4) if ba_total_ms is not None else None,
+            "roofline": roof,
+            "gpu_ms_per_step_by_kernel": {k: round(v, 4) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1])},
+            "ba_kernel_us_per_iteration": {("k_chol_factor" if n == "chol" else n): round(1e3 * d["ms_per_solve"] / max(ba_iters_done, 1), 2) for n, d in ba_prof.items()} if ba_prof else None,
+            # SURVEY.md 8(d) whole-extraction figure: B_img = pyramid + FAST + blur + patches + outputs per image, over the
+            # summed time of the four extraction kernels (the blur's 2P bytes are part of B_img although it is fused away here)
+            "front_end_roofline": {"algorithmic_bytes_per_step": int(wl.extract_bytes()), "extract_ms_per_step": round(fe_extract_ms, 4),
+                                   "achieved": round(wl.extract_bytes() / (fe_extract_ms * 1e-3) / 1e9, 1), "unit": "GB/s",
+                                   "frac": round(wl.extract_bytes() / (fe_extract_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
+            "pcie_inclusive_frames_per_s": round(pcie_fps, 2),
+        }
+        if flops:
+            tot = sum(flops.values())
+            it_ms = sum(d["ms_per_solve"] for d in ba_prof.values()) / max(ba_iters_done, 1)
+            out["ba_roofline"] = {"flop_per_iteration": int(tot), "ms_per_iteration": round(it_ms, 4), "achieved_TFLOPs": round(tot / (it_ms * 1e-3) / 1e12, 4),
+                                  "frac_of_fp64_peak": round(tot / (it_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, 5)}
+
+    # ---- extras, outside the timed region; the scaling runs (N > 1) print the timed line only
+    if rank == 0 and not args.no_extras and world == 1:
+        extras = {}
         n_fe = max(3, min(args.steps, 10))
         wl.ctx.sync(); t2 = time.perf_counter()
-        for _ in range(n_fe):
-            wl.front_end()
+        for s in range(n_fe):
+            wl.front_end(s)
         wl.ctx.sync()
-        fe_batched = n_fe * args.frames / (time.perf_counter() - t2)
+        fe_batched = n_fe * F / (time.perf_counter() - t2)
         lat = []
         for _ in range(20):
             t2 = time.perf_counter()
@@ -295,56 +464,67 @@ def main():
             wl.ctx.match_bf(0, 2)
             wl.ctx.sync()
             lat.append(1e3 * (time.perf_counter() - t2))
-        extras["front_end"] = {"batched_frames_per_s": round(fe_batched, 1), "frames_per_launch": args.frames,
+        extras["front_end"] = {"batched_frames_per_s": round(fe_batched, 1), "frames_per_launch": F,
                                "single_frame_latency_ms": round(float(np.median(lat)), 4)}
-        # K0 on-device undistort / rectify: 12 remaps of a staged raw frame, 8 B per pixel algorithmic
+        # K0 on-device undistort / rectify: remaps of a staged raw frame, 8 B per pixel algorithmic
         yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
         for eye in (0, 1):
             wl.ctx.set_rectify_map(eye, xx * 0.97 + 15 + 3 * np.sin(yy / 50), yy * 0.97 + 9 + 3 * np.cos(xx / 70))
         wl.ctx.upload_raw(0, 0, wl.host_frames[0][0])
-        for i in range(2 * args.frames):
+        for i in range(2 * F):
             wl.ctx.remap_staged(i, i & 1)
         wl.ctx.sync(); t2 = time.perf_counter()
         for _ in range(10):
-            for i in range(2 * args.frames):
+            for i in range(2 * F):
                 wl.ctx.remap_staged(i, i & 1)
         wl.ctx.sync()
-        t_rm = (time.perf_counter() - t2) / (10 * 2 * args.frames)
+        t_rm = (time.perf_counter() - t2) / (10 * 2 * F)
         extras["remap"] = {"us_per_image": round(1e6 * t_rm, 2), "algorithmic_GBps": round(8.0 * W * H / t_rm / 1e9, 1)}
-        for i, (l, r) in enumerate(wl.host_frames):          # restore the resident frames
+        for i in range(F):          # restore the resident frames
+            l, r = wl.host_frames[i]
             wl.ctx.upload(2 * i, l); wl.ctx.upload(2 * i + 1, r)
-        if wl.ba is not None:
-            per = []
-            for _ in range(10):
-                t2 = time.perf_counter(); wl.bundle_adjust(); per.append(1e3 * (time.perf_counter() - t2) / BA_ITERS)
-            extras["ba_ms_per_iter_spread"] = {"mean": round(float(np.mean(per)), 4), "p50": round(float(np.median(per)), 4)}
-        # several independent SLAM sessions on the one GPU (each its own context, streams and BA): the single session above is
-        # latency bound and leaves most CUs idle; this is what one MI355X sustains when it serves S sequences at once
-        S = 4
-        others = [Workload(device, 100 + i, args.frames, with_ba=wl.ba is not None) for i in range(S - 1)]
-        sessions = [wl] + others
+        # ---- S independent sessions served by the one GPU (north star: "batched sequences"): every session's frames go through the
+        # front end, the windows of all sessions are solved as ONE batch per keyframe round (lpslam_hip_ba_optimize_batch: one launch
+        # chain, blockIdx.y = session), fresh problems every round (create inside the loop)
+        if wl.with_ba:
+            try:
+                S = 16
+                rounds = 3
+                fe_ctx = wl.ctx                                  # the sessions' frames: the resident ring, KF_INTERVAL frames per session and round
 
-        def session_steps(w_, k_):
-            ths = []
-            if w_.ba is not None:
-                ths.append(threading.Thread(target=lambda: [w_.bundle_adjust() for _ in range(k_)]))
-                ths[-1].start()
-            for _ in range(k_):
-                w_.front_end()
-            w_.ctx.sync()
-            for th in ths:
+                def session_round(v0):
+                    bas = [wl.new_problem(v0 + i) for i in range(S)]
+                    hip.ba_optimize_batch(bas, True, BA_ITERS)
+                    for b in bas:
+                        b.close()
+
+                def fe_round():
+                    n_frames = S * KF_INTERVAL                  # 96 stereo frames per round, in launches of the ring's size
+                    done = 0
+                    while done < n_frames:
+                        n = min(wl.R, n_frames - done)
+                        fe_ctx.extract_range(0, 2 * n)
+                        fe_ctx.match_stereo_strided(0, 1, 2, n, wl.k["fxb"], wl.k["baseline"])
+                        fe_ctx.match_bf_strided(2, 0, 2, n - 1)
+                        done += n
+                    fe_ctx.sync()
+                session_round(0); fe_round()
+                t2 = time.perf_counter()
+                th = threading.Thread(target=lambda: [session_round(r * S) for r in range(rounds)])
+                th.start()
+                for _ in range(rounds):
+                    fe_round()
                 th.join()
-        for w_ in sessions:
-            session_steps(w_, 1)
-        k_ms = max(5, min(args.steps, 20))
-        t2 = time.perf_counter()
-        ths = [threading.Thread(target=session_steps, args=(w_, k_ms)) for w_ in sessions]
-        for th in ths:
-            th.start()
-        for th in ths:
-            th.join()
-        extras["multi_session"] = {"sessions_per_gpu": S, "frames_per_s": round(S * k_ms * args.frames / (time.perf_counter() - t2), 1)}
-        del others
+                t_ms = time.perf_counter() - t2
+                t3 = time.perf_counter()
+                for r in range(rounds):
+                    session_round(r * S)
+                t_ba_only = (time.perf_counter() - t3) / rounds
+                extras["multi_session"] = {"sessions_per_gpu": S, "frames_per_s": round(rounds * S * KF_INTERVAL / t_ms, 1),
+                                           "batched_ba_ms_per_round": round(1e3 * t_ba_only, 3), "ba_windows_per_s": round(S / t_ba_only, 1),
+                                           "note": "16 sessions, 6 stereo frames + 1 fresh local BA each per round; the 16 windows are one lpslam_hip_ba_optimize_batch call"}
+            except Exception as e:      # noqa: BLE001
+                extras["multi_session"] = {"error": str(e)}
         # the integrated path: the same sequence through the drop-in boundary (LpSlamManager -> stereo tracker: upload, extract,
         # stereo + projection matching, one-launch pose optimiser, keyframe every 6th frame with a windowed local BA)
         try:
@@ -356,7 +536,7 @@ def main():
                 c.camera_number = num; c.f_x = wl.k["fx"]; c.f_y = wl.k["fy"]; c.c_x = wl.k["cx"]; c.c_y = wl.k["cy"]
                 c.resolution_x = W; c.resolution_y = H; c.focal_x_baseline = wl.k["fxb"]
                 mg.set_camera(c)
-            mg.add_tracker("VSLAMStereo", '{"cameraSetup": "stereo", "slamKeypoints": %d, "numLevels": %d, "keyframeInterval": %d, "device": %d}' % (KPTS, LEVELS, FRAMES_PER_STEP, device))
+            mg.add_tracker("VSLAMStereo", '{"cameraSetup": "stereo", "slamKeypoints": %d, "numLevels": %d, "keyframeInterval": %d, "device": %d}' % (KPTS, LEVELS, KF_INTERVAL, device))
             mg.collect_results(); mg.provide_odometry()
             mg.start()
             seq_t = wl.synth.StereoSequence(W, H, 4)
@@ -379,7 +559,7 @@ def main():
             c = manager.default_camera()
             c.camera_number = 0; c.f_x = wl.k["fx"]; c.f_y = wl.k["fy"]; c.c_x = wl.k["cx"]; c.c_y = wl.k["cy"]; c.resolution_x = W; c.resolution_y = H
             mg.set_camera(c)
-            mg.add_tracker("VSLAMMono", '{"cameraSetup": "monocular", "slamKeypoints": %d, "numLevels": 3, "keyframeInterval": %d, "device": %d}' % (KPTS, FRAMES_PER_STEP, device))
+            mg.add_tracker("VSLAMMono", '{"cameraSetup": "monocular", "slamKeypoints": %d, "numLevels": 3, "keyframeInterval": %d, "device": %d}' % (KPTS, KF_INTERVAL, device))
             mg.collect_results(); mg.provide_odometry()
             mg.start()
             walls = wl.synth.WallSequence(W, H, 4, step=0.05)
@@ -397,14 +577,17 @@ def main():
         except Exception as e:      # noqa: BLE001
             extras["tracker_mono"] = {"error": str(e)}
         # BASELINE configs[4]'s global BA on ONE GPU (all landmarks on this rank; the partitioned solve adds one all-reduce of
-        # the 1200^2 reduced system per trial): 200 keyframes, 30 k landmarks, ~240 k observations, 10 LM iterations
+        # the reduced system per trial): 200 keyframes, 30 k landmarks, ~240 k observations, 10 LM iterations
         try:
             gprob = wl.synth.ba_problem(200, 30000, 240000, 1920, 1080, seq_id=2, kf_stride=2)
-            gba = wl.hip.BundleAdjuster(wl.ctx, gprob["poses"], gprob["fixed"], gprob["points"], wl.hip.ba_obs_array(gprob), gprob["cam"])
+            gobs = wl.hip.ba_obs_array(gprob)
+            t2 = time.perf_counter()
+            gba = wl.hip.BundleAdjuster(wl.ctx, gprob["poses"], gprob["fixed"], gprob["points"], gobs, gprob["cam"])
+            gba.state(); t_gsetup = time.perf_counter() - t2
             gba.optimize(True, 2); gba.reset()
             t2 = time.perf_counter(); glog2 = gba.optimize(True, BA_ITERS); t_g = time.perf_counter() - t2
             extras["global_ba"] = {"keyframes": 200, "landmarks": 30000, "observations": int(gba.n_obs), "ms_per_iter": round(1e3 * t_g / max(len(glog2), 1), 4),
-                                   "chi2_first": float(glog2["chi2_before"][0]), "chi2_last": float(glog2["chi2_after"][-1])}
+                                   "setup_ms": round(1e3 * t_gsetup, 3), "chi2_first": float(glog2["chi2_before"][0]), "chi2_last": float(glog2["chi2_after"][-1])}
             gba.close()
         except Exception as e:      # noqa: BLE001
             extras["global_ba"] = {"error": str(e)}
@@ -414,57 +597,14 @@ def main():
         t2 = time.perf_counter(); glog = graph.optimize(10); t_pg = time.perf_counter() - t2
         extras["pose_graph"] = {"keyframes": 200, "edges": int(len(pg["edge_i"])), "ms_per_iter": round(1e3 * t_pg / max(len(glog), 1), 4)}
         graph.close()
+        out.update(extras)
 
     if rank == 0:
-        frames_total = world * args.frames * args.steps
-        value = frames_total / elapsed
-        ab = wl.algorithmic_bytes()
-        dom = max(ab.keys(), key=lambda k_: stage_ms[STAGE_NAMES.index(k_)])
-        dom_ms = stage_ms[STAGE_NAMES.index(dom)]
-        launches = {"pyramid": 1, "fast": 1, "describe": 1, "distribute": 1}[dom]
-        achieved = ab[dom] / (dom_ms * 1e-3) / 1e9
-        # HBM traffic of the dominant kernel group from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
-        # separate runs of this command, condensed by tools/pmc_summary.py into profiles/<round>_pmc.json: KB per launch as
-        # rocprofv3 reports them, no x2 correction for these dword / dwordx2 loads -- profiles/r01b_pmc_hbm.json calibrates that);
-        # per step = per launch x launches of the group; only quoted for the launch shape it was measured on
-        traffic = None
-        try:
-            pmc_files = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc.json"))
-            pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_files[-1])))["kernels"]
-            kname = {"pyramid": "k_pyr_bands", "fast": "k_fast_cells", "describe": "k_describe", "distribute": "k_distribute"}[dom]
-            if args.frames == FRAMES_PER_STEP:
-                traffic = int(round(launches * 1024.0 * (pmc[kname]["FETCH_SIZE"]["mean_per_launch"] + pmc[kname]["WRITE_SIZE"]["mean_per_launch"])))
-        except (OSError, KeyError, ValueError, IndexError):
-            pass
-        out = {
-            "metric": "frames/sec (ORB+match+local-BA), 1280x720 stereo",
-            "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u8 front end / f64 BA", "data": "synthetic",
-            "config": {"workload": "configs[1]+configs[2]: 1280x720 stereo, 2000 kpts, 8 levels; step = %d stereo frames "
-                                   "(extract L+R, stereo match, 2000x2000 BF temporal match) + one 50-KF/5k-landmark/%d-obs "
-                                   "local BA of %d LM iterations" % (args.frames, wl.ba.n_obs if wl.ba else 0, BA_ITERS),
-                       "frames_per_step": args.frames, "replicas": world, "parallelism": "replicas x%d" % world},
-            "ba_ms_per_iter": round(stage_ms[T_BA] / BA_ITERS, 4) if wl.ba is not None else None,
-            "roofline": {"bound": "hbm", "kernel": dom, "launches_per_step": launches,
-                         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "algorithmic_bytes_per_step": int(ab[dom]), "avg_ms_per_step": round(float(dom_ms), 4)},
-            "stage_ms_per_step": {n: round(float(v), 4) for n, v in zip(STAGE_NAMES, stage_ms)},
-            # SURVEY.md 8(d) whole-extraction figure: B_img = pyramid + FAST + blur + patches + outputs per image, over the
-            # summed time of the four extraction kernels (the blur's 2P bytes are part of B_img although it is fused away here)
-            "front_end_roofline": (lambda b_img, t_ms: {"algorithmic_bytes_per_step": int(b_img), "extract_ms_per_step": round(float(t_ms), 4),
-                                                         "achieved": round(b_img / (t_ms * 1e-3) / 1e9, 1), "unit": "GB/s",
-                                                         "frac": round(b_img / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)})(
-                wl.extract_bytes(), stage_ms[T_PYR] + stage_ms[T_FAST] + stage_ms[T_DIST] + stage_ms[T_DESC]),
-            "pcie_inclusive_frames_per_s": round(pcie_fps, 2),
-        }
-        out.update(extras)
         if world == 1 and not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline()
-            out["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 2)
-            if _CPU_MT:
-                out["cpu_baseline_threads"] = _CPU_MT
+            best, legs = cpu_baseline()
+            out["cpu_baseline"] = best
+            out["cpu_baseline_legs"] = legs
+            out["gpu_over_cpu"] = round(out["value"] / best["value"], 2)
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

@@ -197,11 +197,29 @@ int lpslam_hip_ba_optimize_end(lpslam_hip_ba* ba, lpslam_hip_ba_iter_log* log, i
  * several SLAM sessions served by one GPU, [UPSTREAM] mapping_module::run of each session; lpslam reaches it through
  * feed_stereo_frame, src/Trackers/OpenVSLAMStereoTracker.cpp:293-295) are advanced by ONE launch chain: every kernel runs once
  * for the whole batch (blockIdx.y = problem) and each problem follows its own lambda control.  Results are identical to n calls of
- * lpslam_hip_ba_optimize.  All problems must live on one device; logs (may be NULL) receives log_stride entries per problem,
+ * lpslam_hip_ba_optimize for batches of fewer than 24 problems; from 24 on the reduced systems of local windows are factored by one
+ * workgroup each (another summation order: equal within rounding, chi2 to 1e-12 relative).  All problems must live on one device; logs (may be NULL) receives log_stride entries per problem,
  * done (may be NULL) the iterations each problem ran.  reset_batch = lpslam_hip_ba_reset of every problem in one launch. */
 int lpslam_hip_ba_optimize_batch(lpslam_hip_ba* const* problems, int32_t n, int32_t robust, int32_t iters,
                                  lpslam_hip_ba_iter_log* logs, int32_t log_stride, int32_t* done);
 int lpslam_hip_ba_reset_batch(lpslam_hip_ba* const* problems, int32_t n);
+/* lpslam_hip_ba_optimize with a HIP event after every launch of the chain, on the problem's stream: time per kernel, summed over
+ * the call (measurement hook of bench.py, like lpslam_hip_timer_*; no reference counterpart). */
+#define LPSLAM_HIP_BA_KERNELS 8
+#define LPSLAM_HIP_BA_K_LIN 0         /* k_ba_lin       (first unit of a call only; later linearisations ride in k_ba_trial) */
+#define LPSLAM_HIP_BA_K_POINT_SUM 1   /* k_ba_point_sum */
+#define LPSLAM_HIP_BA_K_SCHUR 2       /* k_ba_schur     */
+#define LPSLAM_HIP_BA_K_CHOL 3        /* the factorisation: k_chol_pair x ceil(panels / 2), or k_chol_wg (one launch) */
+#define LPSLAM_HIP_BA_K_XSOLVE 4      /* k_chol_xsolve  */
+#define LPSLAM_HIP_BA_K_BACKSUB 5     /* k_ba_backsub   */
+#define LPSLAM_HIP_BA_K_TRIAL 6       /* k_ba_trial     */
+typedef struct lpslam_hip_ba_kernel_times {
+    float ms[LPSLAM_HIP_BA_KERNELS];                  /* summed over the call                                    */
+    int32_t launches[LPSLAM_HIP_BA_KERNELS];          /* marks (= LM trials the kernel ran in)                   */
+    int32_t launches_per_mark[LPSLAM_HIP_BA_KERNELS]; /* kernel launches behind one mark (factorisation: several) */
+    int32_t iterations, dim;
+} lpslam_hip_ba_kernel_times;
+int lpslam_hip_ba_optimize_profiled(lpslam_hip_ba* ba, int32_t robust, int32_t iters, lpslam_hip_ba_kernel_times* out);
 /* Motion-only mode: landmarks are held fixed (unary edges), only the free poses move. */
 int lpslam_hip_ba_set_points_fixed(lpslam_hip_ba* ba, int32_t points_fixed);
 /* optimize::pose_optimizer flow on a problem created with ONE free pose: 4 rounds x 10 iterations, outliers

@@ -35,6 +35,7 @@ constexpr int NB = 32;                // Cholesky panel width
 constexpr int SPLIT = 8;              // wavefronts per keyframe in the pose pass
 constexpr int PV = 28;                // partial-row stride per wavefront: 21 (H_pp upper) + 6 (b_p) (+1 pad; chi2 is kept apart)
 constexpr int MAX_LOG = 64;
+__host__ __device__ inline bool cw_fits(int dim);      // the system fits the single-workgroup factorisation (ba_solve.inl)
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
@@ -932,12 +933,12 @@ __device__ __forceinline__ void tile_sub(double* D, int tr, int tc, int lr, int 
     for (int q = 0; q < 4; ++q) D[(tr + lk + 4 * q) * (NB + 1) + tc + lr] -= acc[q];
 }
 
-__global__ __launch_bounds__(256) void k_chol_pair(const BaView* __restrict__ views, int m, int pin)
+__global__ __launch_bounds__(256) void k_chol_pair(const BaView* __restrict__ views, int m, int pin, int skip_small)
 {
     if (pin && (blockIdx.x & 7)) return;                 // small launches: XCD 0 only (see above); large ones use the whole chip
     BA_VIEW(v);
     const int nb = v.dim_pad / NB;
-    if (2 * m >= nb || v.dim == 0) return;               // a batch runs the panel pairs of its largest system; a problem without free poses has none
+    if (2 * m >= nb || v.dim == 0 || (skip_small && cw_fits(v.dim))) return;   // a batch runs the panel pairs of its largest system; small systems may be k_chol_wg's
     const int bid = pin ? blockIdx.x >> 3 : blockIdx.x;
     {
         const int ncol0 = (2 * m + 1 < nb) ? 2 : 1, T0 = nb - 2 * m - ncol0;
@@ -1128,7 +1129,7 @@ __global__ __launch_bounds__(256) void k_chol_pair(const BaView* __restrict__ vi
 
 // the whole factorisation + L^-T rows: ceil(nb / 2) launches
 // nb = panels of the (largest) system, count = problems (grid.y; every problem reads its own size from its view)
-void enqueue_cholesky(hipStream_t s, const BaView* d_views, int count, int nb)
+void enqueue_cholesky(hipStream_t s, const BaView* d_views, int count, int nb, int skip_small = 0)
 {
     // the attribute belongs to the (function, device) pair: once per device this process uses
     static std::atomic<bool> attr_set[64];
@@ -1145,15 +1146,15 @@ void enqueue_cholesky(hipStream_t s, const BaView* d_views, int count, int nb)
         const int n_update = m > 0 ? T * (T + 1) / 2 + j * T : 0;
         // 32 CUs of one XCD hold a latency-bound launch of one problem; a throughput-bound one (or a batch) needs all 256
         const int pin = (count == 1 && (n_panel + n_update) <= 96) ? 1 : 0;
-        hipLaunchKernelGGL(k_chol_pair, dim3((n_panel + n_update) * (pin ? 8 : 1), count), dim3(256), CP_LDS_BYTES, s, d_views, m, pin);
+        hipLaunchKernelGGL(k_chol_pair, dim3((n_panel + n_update) * (pin ? 8 : 1), count), dim3(256), CP_LDS_BYTES, s, d_views, m, pin, skip_small);
     }
 }
 // x_p = L^-T y with y = L[dim][0..dim): one wavefront per row of the (upper triangular) L^-T, butterfly sum
-__global__ __launch_bounds__(256) void k_chol_xsolve(const BaView* __restrict__ views, int pin)
+__global__ __launch_bounds__(256) void k_chol_xsolve(const BaView* __restrict__ views, int pin, int skip_small)
 {
     if (pin && (blockIdx.x & 7)) return;  // XCD 0 only, like k_chol_pair: its inputs sit in that L2
     BA_VIEW(v);
-    if (ba_idle(v.ctl)) return;
+    if (ba_idle(v.ctl) || (skip_small && cw_fits(v.dim))) return;
     const int lane = threadIdx.x & 63;
     const int i = (pin ? blockIdx.x >> 3 : blockIdx.x) * 4 + (threadIdx.x >> 6);
     if (i >= v.dim) return;
@@ -1172,10 +1173,41 @@ __global__ __launch_bounds__(256) void k_chol_xsolve(const BaView* __restrict__ 
     if (lane == 0) v.xp[i] = acc;
 }
 
-void enqueue_xsolve(hipStream_t s, const BaView* d_views, int count, int dim)
+void enqueue_xsolve(hipStream_t s, const BaView* d_views, int count, int dim, int skip_small = 0)
 {
     const int pin = count == 1 ? 1 : 0;
-    hipLaunchKernelGGL(k_chol_xsolve, dim3((dim + 3) / 4 * (pin ? 8 : 1), count), dim3(256), 0, s, d_views, pin);
+    hipLaunchKernelGGL(k_chol_xsolve, dim3((dim + 3) / 4 * (pin ? 8 : 1), count), dim3(256), 0, s, d_views, pin, skip_small);
+}
+
+#include "ba_solve.inl"
+
+// factorisation + solve of `count` reduced systems.  `wg`: the systems that fit one compute unit go to k_chol_wg (one workgroup
+// each, one launch), the others through the panel-pair chain and k_chol_xsolve (each kernel skips the problems of the other
+// kind).  Measured (MI355X, 295 x 295): one problem takes 170 us in k_chol_wg against 100 us in the chain (the chain spreads
+// the trailing updates and the L^-T rows over 20-60 workgroups; in one workgroup the ten diagonal-block factorisations,
+// 4.5 us each, the triangular solves and the hand-overs between them sit in series), a batch of 64 takes 14.5 ms against
+// 16.9 ms: k_chol_wg pays from about 24 problems on, where the chain's redundant panel work fills the chip.
+constexpr int CW_MIN_BATCH = 24;
+void enqueue_factor_solve(hipStream_t s, const BaView* d_views, int count, int nb_max, int dim_max, bool wg, bool any_small, bool any_large)
+{
+    if (!wg) { any_large = any_large || any_small; any_small = false; }
+    if (any_small) {
+        static std::atomic<bool> attr_set[64];
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (dev >= 0 && dev < 64 && !attr_set[dev].load()) {
+            (void)hipFuncSetAttribute((const void*)k_chol_wg<false>, hipFuncAttributeMaxDynamicSharedMemorySize, CW_LDS_BYTES);
+            (void)hipFuncSetAttribute((const void*)k_chol_wg<true>, hipFuncAttributeMaxDynamicSharedMemorySize, CW_LDS_BYTES);
+            attr_set[dev].store(true);
+        }
+        static const bool stamp = getenv("LPSLAM_CW_STAMP") != nullptr;
+        if (stamp) hipLaunchKernelGGL(k_chol_wg<true>, dim3(1, count), dim3(CW_THREADS), CW_LDS_BYTES, s, d_views);
+        else hipLaunchKernelGGL(k_chol_wg<false>, dim3(1, count), dim3(CW_THREADS), CW_LDS_BYTES, s, d_views);
+    }
+    if (any_large) {
+        enqueue_cholesky(s, d_views, count, nb_max, any_small ? 1 : 0);
+        enqueue_xsolve(s, d_views, count, dim_max, any_small ? 1 : 0);
+    }
 }
 
 // ---- landmark back substitution and update (4 lanes per landmark); the last block applies x_p to the poses -------------------
@@ -1587,6 +1619,17 @@ struct BaLaunch {
     const BaView* d_views = nullptr; int count = 0; hipStream_t s = nullptr;
     int obs_blocks = 0, pose_blocks = 0, point_blocks = 0, part_n = 0, n_free = 0, n_blocks = 0, dim = 0, nb = 0;
     int robust = 1, points_fixed = 0;
+    bool any_small = false, any_large = false;          // systems for k_chol_wg / for the panel-pair chain
+    // profiled run (lpslam_hip_ba_optimize_profiled): an event after every launch, tagged with the kernel it closes
+    std::vector<std::pair<hipEvent_t, int>>* marks = nullptr;
+    void mark(int kernel) const
+    {
+        if (!marks) return;
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) return;
+        (void)hipEventRecord(e, s);
+        marks->emplace_back(e, kernel);
+    }
     void add(const lpslam_hip_ba* b)
     {
         const BaView& v = b->h_view;
@@ -1594,6 +1637,7 @@ struct BaLaunch {
         point_blocks = std::max(point_blocks, v.point_blocks); part_n = std::max(part_n, v.part_n);
         n_free = std::max(n_free, v.n_free); n_blocks = std::max(n_blocks, v.n_blocks); dim = std::max(dim, v.dim);
         nb = std::max(nb, v.dim_pad / NB);
+        if (v.dim > 0) { if (cw_fits(v.dim)) any_small = true; else any_large = true; }
         ++count;
     }
 };
@@ -1609,8 +1653,9 @@ BaLaunch single_launch(lpslam_hip_ba* b)
 int enqueue_linearize(const BaLaunch& L, int fused, bool explicit_lin = true)
 {
     // fused solve: only the first unit of an optimize() call linearises here, every later state is linearised beside its trial
-    if (explicit_lin) hipLaunchKernelGGL(k_ba_lin, dim3(L.obs_blocks + L.pose_blocks, L.count), dim3(256), 0, L.s, L.d_views, L.robust, L.points_fixed);
+    if (explicit_lin) { hipLaunchKernelGGL(k_ba_lin, dim3(L.obs_blocks + L.pose_blocks, L.count), dim3(256), 0, L.s, L.d_views, L.robust, L.points_fixed); L.mark(LPSLAM_HIP_BA_K_LIN); }
     hipLaunchKernelGGL(k_ba_point_sum, dim3(L.point_blocks + 1, L.count), dim3(256), 0, L.s, L.d_views, fused);      // + the workgroup that combines the pose partials
+    L.mark(LPSLAM_HIP_BA_K_POINT_SUM);
     LP_HIP(hipGetLastError());
     return LPSLAM_HIP_OK;
 }
@@ -1618,7 +1663,7 @@ int enqueue_linearize(const BaLaunch& L, int fused, bool explicit_lin = true)
 // Schur complement for the device's current lambda into the reduced buffer
 int enqueue_reduce(const BaLaunch& L, int fused)
 {
-    if (L.n_free) hipLaunchKernelGGL(k_ba_schur, dim3(4 * L.n_blocks + L.n_free, L.count), dim3(64), 0, L.s, L.d_views, fused);
+    if (L.n_free) { hipLaunchKernelGGL(k_ba_schur, dim3(4 * L.n_blocks + L.n_free, L.count), dim3(64), 0, L.s, L.d_views, fused); L.mark(LPSLAM_HIP_BA_K_SCHUR); }
     LP_HIP(hipGetLastError());
     return LPSLAM_HIP_OK;
 }
@@ -1632,16 +1677,26 @@ int enqueue_solve(const BaLaunch& L, int fused)
             hipLaunchKernelGGL(k_lm_begin, dim3(1, L.count), dim3(64), 0, s, L.d_views);
             hipLaunchKernelGGL(k_chol_prep, dim3((L.nb * NB + 255) / 256, L.count), dim3(256), 0, s, L.d_views);
         }
-        enqueue_cholesky(s, L.d_views, L.count, L.nb);
-        enqueue_xsolve(s, L.d_views, L.count, L.dim);
+        const bool wg = L.count >= CW_MIN_BATCH;
+        if (L.marks && !(wg && L.any_small)) {              // profiled run through the panel-pair chain: factorisation and solve timed apart
+            enqueue_cholesky(s, L.d_views, L.count, L.nb);
+            L.mark(LPSLAM_HIP_BA_K_CHOL);
+            enqueue_xsolve(s, L.d_views, L.count, L.dim);
+            L.mark(LPSLAM_HIP_BA_K_XSOLVE);
+        } else {
+            enqueue_factor_solve(s, L.d_views, L.count, L.nb, L.dim, wg, L.any_small, L.any_large);
+            L.mark(LPSLAM_HIP_BA_K_CHOL);
+        }
     } else if (!fused) {
         hipLaunchKernelGGL(k_lm_begin, dim3(1, L.count), dim3(64), 0, s, L.d_views);
     }
     hipLaunchKernelGGL(k_ba_backsub, dim3(L.part_n + 1, L.count), dim3(256), 0, s, L.d_views);
+    L.mark(LPSLAM_HIP_BA_K_BACKSUB);
     {
         // fused solve: the trial launch also linearises the trial state on speculation (observation side + pose side)
         const int spec = fused ? 1 : 0;
         hipLaunchKernelGGL(k_ba_trial, dim3(L.pose_blocks + (spec ? L.obs_blocks + L.pose_blocks : 0), L.count), dim3(256), 0, s, L.d_views, L.robust, fused, L.points_fixed, spec);
+        L.mark(LPSLAM_HIP_BA_K_TRIAL);
     }
     LP_HIP(hipGetLastError());
     return LPSLAM_HIP_OK;
@@ -2013,6 +2068,44 @@ int lpslam_hip_ba_optimize(lpslam_hip_ba* b, int32_t robust, int32_t iters, lpsl
     return rc ? rc : lpslam_hip_ba_optimize_end(b, log, done_out);
 }
 
+// optimize() with a HIP event after every launch: where the time of the chain goes, kernel by kernel, measured in place on the
+// problem's stream (bench.py's roofline of the dominant kernel).  No graph replay; the events serialise nothing the chain does
+// not serialise itself (every launch depends on its predecessor).
+int lpslam_hip_ba_optimize_profiled(lpslam_hip_ba* b, int32_t robust, int32_t iters, lpslam_hip_ba_kernel_times* out)
+{
+    if (!b || !out) { set_error("null argument"); return LPSLAM_HIP_ERR_INVALID; }
+    if (iters < 0 || iters > MAX_LOG) { set_error("iterations must be in [0,%d]", MAX_LOG); return LPSLAM_HIP_ERR_INVALID; }
+    if (b->pending_iters >= 0) { set_error("optimize_begin pending"); return LPSLAM_HIP_ERR_INVALID; }
+    LP_HIP(hipSetDevice(b->ctx->cfg.device));
+    memset(out, 0, sizeof(*out));
+    std::vector<std::pair<hipEvent_t, int>> marks;
+    BaLaunch L = single_launch(b);
+    L.robust = robust; b->robust = robust;
+    L.marks = &marks;
+    int rc = begin_optimize(b, robust, iters);
+    L.mark(-1);                                            // start of the chain
+    if (!rc && iters > 0) rc = enqueue_batch(L, iters, true);
+    if (!rc) rc = read_ctl(b);
+    for (int guard = 0; !rc && iters > 0 && !b->h_ctl.stopped && b->h_ctl.outer_done < iters && guard < 16 * MAX_LOG; ++guard) {
+        L.mark(-1);
+        rc = enqueue_batch(L, iters - b->h_ctl.outer_done, false);
+        if (!rc) rc = read_ctl(b);
+    }
+    for (size_t i = 1; i < marks.size() && !rc; ++i) {
+        const int k = marks[i].second;
+        if (k < 0 || k >= LPSLAM_HIP_BA_KERNELS) continue;
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, marks[i - 1].first, marks[i].first) == hipSuccess) { out->ms[k] += ms; out->launches[k] += 1; }
+    }
+    for (auto& m : marks) (void)hipEventDestroy(m.first);
+    out->iterations = b->h_ctl.outer_done;
+    // launches of the factorisation per mark: the panel-pair chain is several launches behind one mark
+    out->launches_per_mark[LPSLAM_HIP_BA_K_CHOL] = (b->dim_pad / NB + 1) / 2;
+    for (int k = 0; k < LPSLAM_HIP_BA_KERNELS; ++k) if (k != LPSLAM_HIP_BA_K_CHOL) out->launches_per_mark[k] = 1;
+    out->dim = b->dim;
+    return rc;
+}
+
 // ---- batched solve: B independent problems, ONE launch chain (blockIdx.y = problem) ------------------------------------------
 // What a host that serves several SLAM sessions (or several windows of one map) on one GPU calls: every kernel of the chain is
 // launched once for the whole batch with the launch extents of its largest problem, each problem follows its own control block
@@ -2199,6 +2292,15 @@ int lpslam_hip_ba_scalar_buffer(lpslam_hip_ba* b, void** dev_ptr, int64_t* n_dou
     if (!b) { set_error("null problem"); return LPSLAM_HIP_ERR_INVALID; }
     if (dev_ptr) *dev_ptr = b->d_scal;
     if (n_doubles) *n_doubles = 8;
+    return LPSLAM_HIP_OK;
+}
+
+// diagnostic read of the L^-T / W scratch (in-kernel stamps of the LPSLAM_CW_STAMP build); not part of the public header
+int lpslam_hip_debug_ba_scratch(lpslam_hip_ba* b, int64_t offset, int64_t n, double* out)
+{
+    if (!b || !out) return LPSLAM_HIP_ERR_INVALID;
+    LP_HIP(hipStreamSynchronize(b->stream));
+    LP_HIP(hipMemcpy(out, (const double*)b->h_view.Minv + offset, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
     return LPSLAM_HIP_OK;
 }
 

@@ -835,8 +835,7 @@ int lpslam_hip_sim3_optimize(lpslam_hip_sim3* g, int32_t iters, lpslam_hip_ba_it
             if (v.n_edges) hipLaunchKernelGGL(k_sim3_lin, dim3(v.n_edges), dim3(64), 0, s, v);
             if (v.dim > 0) {
                 hipLaunchKernelGGL(k_sim3_assemble, dim3(v.n_blocks + v.n_free), dim3(64), 0, s, v);
-                enqueue_cholesky(s, g->d_cv, 1, g->nb);
-                enqueue_xsolve(s, g->d_cv, 1, v.dim);
+                enqueue_factor_solve(s, g->d_cv, 1, g->nb, v.dim, false, cw_fits(v.dim), !cw_fits(v.dim));
             }
             hipLaunchKernelGGL(k_sim3_update, dim3(vb + 1), dim3(256), 0, s, v, vb);
             hipLaunchKernelGGL(k_sim3_trial, dim3(g->trial_blocks), dim3(256), 0, s, v);

@@ -36,7 +36,7 @@ SYMBOLS = [
     "lpslam_hip_match_stereo", "lpslam_hip_match_stereo_strided", "lpslam_hip_get_stereo",
     "lpslam_hip_match_projection", "lpslam_hip_match_fuse", "lpslam_hip_match_area", "lpslam_hip_match_orientation_filter",
     "lpslam_hip_ba_create", "lpslam_hip_ba_destroy", "lpslam_hip_ba_set_active", "lpslam_hip_ba_optimize", "lpslam_hip_ba_optimize_begin", "lpslam_hip_ba_optimize_end",
-    "lpslam_hip_ba_optimize_batch", "lpslam_hip_ba_reset_batch",
+    "lpslam_hip_ba_optimize_batch", "lpslam_hip_ba_reset_batch", "lpslam_hip_ba_optimize_profiled",
     "lpslam_hip_ba_local", "lpslam_hip_ba_set_points_fixed", "lpslam_hip_ba_pose_optimize", "lpslam_hip_pose_optimize", "lpslam_hip_ba_reset", "lpslam_hip_ba_get", "lpslam_hip_ba_chi2", "lpslam_hip_ba_reduced_buffer",
     "lpslam_hip_ba_step_begin", "lpslam_hip_ba_step_lambda0", "lpslam_hip_ba_step_solve", "lpslam_hip_ba_scalar_buffer", "lpslam_hip_ba_step_end", "lpslam_hip_ba_status",
     "lpslam_hip_sim3_create", "lpslam_hip_sim3_destroy", "lpslam_hip_sim3_optimize", "lpslam_hip_sim3_get", "lpslam_hip_sim3_chi2", "lpslam_hip_sim3_transform_optimize",
@@ -56,6 +56,10 @@ class FrontendConfig(C.Structure):
 class BaCamera(C.Structure):
     _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
                 ("focal_x_baseline", C.c_double), ("huber_mono", C.c_double), ("huber_stereo", C.c_double)]
+
+
+class BaKernelTimes(C.Structure):
+    _fields_ = [("ms", C.c_float * 8), ("launches", C.c_int32 * 8), ("launches_per_mark", C.c_int32 * 8), ("iterations", C.c_int32), ("dim", C.c_int32)]
 
 
 _lib = None
@@ -310,6 +314,13 @@ class BundleAdjuster:
     def reset(self):
         _check(self.lib.lpslam_hip_ba_reset(self.h))
 
+    def optimize_profiled(self, robust=True, iters=10):
+        """per-kernel HIP-event times of one optimize() call: {kernel: (ms summed, marks, launches per mark)}, iterations"""
+        t = BaKernelTimes()
+        _check(self.lib.lpslam_hip_ba_optimize_profiled(self.h, int(robust), int(iters), C.byref(t)))
+        names = ["k_ba_lin", "k_ba_point_sum", "k_ba_schur", "chol", "k_chol_xsolve", "k_ba_backsub", "k_ba_trial"]
+        return {n: (t.ms[i], t.launches[i], t.launches_per_mark[i]) for i, n in enumerate(names)}, t.iterations, t.dim
+
     def pose_optimize(self):
         out = np.zeros(max(self.n_obs, 1), np.uint8); n = C.c_int32()
         _check(self.lib.lpslam_hip_ba_pose_optimize(self.h, _p(out), C.byref(n)))
@@ -360,6 +371,11 @@ class BundleAdjuster:
         o = C.c_int32(); st = C.c_int32(); lam = C.c_double(); chi = C.c_double()
         _check(self.lib.lpslam_hip_ba_status(self.h, C.byref(o), C.byref(st), C.byref(lam), C.byref(chi)))
         return dict(outer_done=o.value, stopped=bool(st.value), lam=lam.value, chi2=chi.value)
+
+
+def ba_factor_kernel_name(dim):
+    """name of the kernel that factors a reduced system of `dim` unknowns (rule of enqueue_solve in csrc/ba.hip)"""
+    return "k_chol_pair"          # k_chol_wg takes over only in batches of 24 problems and more
 
 
 def ba_optimize_batch(problems, robust=True, iters=10):

@@ -47,14 +47,35 @@ class BaCam(C.Structure):
 _lib = None
 
 
+def use_native_build(on=True):
+    """Switches every later call to the -march=native build (bench.py's second CPU-baseline leg; same sources, built with
+    `make native` on the machine that runs it) or back to the default build."""
+    global _lib
+    if on:
+        path = os.path.join(_HERE, "liblpslam_oracle_native.so")
+        # always rebuilt: a library made on another machine (the repository snapshot travels) may use instructions this CPU lacks
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "native"], stdout=subprocess.DEVNULL)
+        _lib = None
+        _load(path)
+    else:
+        _lib = None
+        lib()
+
+
 def lib():
     global _lib
     if _lib is None:
         build()
-        _lib = C.CDLL(_LIB)
-        _lib.ora_fast_atan2.restype = C.c_float
-        _lib.ora_fast_atan2.argtypes = [C.c_float, C.c_float]
-        _lib.ora_ic_angle.restype = C.c_float
+        _load(_LIB)
+    return _lib
+
+
+def _load(path):
+    global _lib
+    _lib = C.CDLL(path)
+    _lib.ora_fast_atan2.restype = C.c_float
+    _lib.ora_fast_atan2.argtypes = [C.c_float, C.c_float]
+    _lib.ora_ic_angle.restype = C.c_float
     return _lib
 
 

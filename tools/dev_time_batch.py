@@ -1,0 +1,32 @@
+"""Scratch: BA set-up time and batched-solve throughput (local BA 50 KF / 5000 landmarks / ~39k observations, 10 LM iterations)."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from lpslam_amd import hip, synth
+ctx = hip.Context(1280, 720, 2000, 1.2, 8, max_images=2)
+probs = [synth.ba_problem(50, 5000, 40000, 1280, 720, seq_id=s) for s in range(4)]
+obs = [hip.ba_obs_array(p) for p in probs]
+def make(i):
+    p = probs[i % 4]
+    return hip.BundleAdjuster(ctx, p["poses"], p["fixed"], p["points"], obs[i % 4], p["cam"])
+# set-up
+for rep in range(3):
+    t = time.perf_counter(); b = make(0); b.state(); t1 = time.perf_counter() - t
+    b.close()
+ts = []
+for rep in range(10):
+    t = time.perf_counter(); b = make(rep); t_enq = time.perf_counter() - t; b.state(); ts.append((t_enq, time.perf_counter() - t)); b.close()
+print("create: enqueue %.3f ms, until ready %.3f ms (median)" % (1e3 * np.median([a for a, _ in ts]), 1e3 * np.median([b for _, b in ts])))
+t = time.perf_counter(); b = make(0); b.optimize(True, 10); t1 = time.perf_counter() - t; b.close()
+print("create + first optimize(10): %.3f ms" % (1e3 * t1))
+for B in (1, 2, 4, 8, 16, 32, 64):
+    bas = [make(i) for i in range(B)]
+    hip.ba_optimize_batch(bas, True, 10)
+    tt = []
+    for rep in range(5):
+        hip.ba_reset_batch(bas)
+        t = time.perf_counter(); logs = hip.ba_optimize_batch(bas, True, 10); tt.append(time.perf_counter() - t)
+    m = np.median(tt)
+    print("batch %3d: %.3f ms per batch, %.4f ms per problem-iteration, %.1f problems/s; iters %s" % (B, 1e3 * m, 1e3 * m / B / 10, B / m, sorted(set(len(l) for l in logs))))
+    for b in bas:
+        b.close()
