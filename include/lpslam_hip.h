@@ -250,6 +250,13 @@ int lpslam_hip_ba_step_begin(lpslam_hip_ba* ba, int32_t robust, int32_t first);
 int lpslam_hip_ba_step_lambda0(lpslam_hip_ba* ba);
 int lpslam_hip_ba_step_solve(lpslam_hip_ba* ba);
 int lpslam_hip_ba_step_end(lpslam_hip_ba* ba, int32_t* accepted, int32_t* iteration_finished);
+/* The same partitioned solve driven from C++ with RCCL (ncclAllReduce of the packed triangle of S + b per LM
+ * trial, a 2-double all-reduce for the trial chi2): `nccl_comm` is this rank's ncclComm_t, created by the caller
+ * (ncclCommInitRank / ncclCommInitAll), one rank per GPU.  All collectives are enqueued on the problem's own stream between the
+ * kernels -- no host synchronisation inside a trial; the host looks at the control block once per call (once more per batch of
+ * rejected trials).  RCCL is bound at run time (dlopen).  Every rank must call with the same robust / iters. */
+int lpslam_hip_ba_optimize_partitioned(lpslam_hip_ba* ba, void* nccl_comm, int32_t robust, int32_t iters,
+                                       lpslam_hip_ba_iter_log* log, int32_t* done);
 /* Control state after the last optimize / step_end: finished outer iterations, g2o "Terminate", lambda, robust chi2. */
 int lpslam_hip_ba_status(lpslam_hip_ba* ba, int32_t* outer_done, int32_t* stopped, double* lambda, double* chi2);
 

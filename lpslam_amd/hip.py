@@ -36,7 +36,7 @@ SYMBOLS = [
     "lpslam_hip_match_stereo", "lpslam_hip_match_stereo_strided", "lpslam_hip_get_stereo",
     "lpslam_hip_match_projection", "lpslam_hip_match_fuse", "lpslam_hip_match_area", "lpslam_hip_match_orientation_filter",
     "lpslam_hip_ba_create", "lpslam_hip_ba_destroy", "lpslam_hip_ba_set_active", "lpslam_hip_ba_optimize", "lpslam_hip_ba_optimize_begin", "lpslam_hip_ba_optimize_end",
-    "lpslam_hip_ba_optimize_batch", "lpslam_hip_ba_reset_batch", "lpslam_hip_ba_optimize_profiled",
+    "lpslam_hip_ba_optimize_batch", "lpslam_hip_ba_reset_batch", "lpslam_hip_ba_optimize_profiled", "lpslam_hip_ba_optimize_partitioned",
     "lpslam_hip_ba_local", "lpslam_hip_ba_set_points_fixed", "lpslam_hip_ba_pose_optimize", "lpslam_hip_pose_optimize", "lpslam_hip_ba_reset", "lpslam_hip_ba_get", "lpslam_hip_ba_chi2", "lpslam_hip_ba_reduced_buffer",
     "lpslam_hip_ba_step_begin", "lpslam_hip_ba_step_lambda0", "lpslam_hip_ba_step_solve", "lpslam_hip_ba_scalar_buffer", "lpslam_hip_ba_step_end", "lpslam_hip_ba_status",
     "lpslam_hip_sim3_create", "lpslam_hip_sim3_destroy", "lpslam_hip_sim3_optimize", "lpslam_hip_sim3_get", "lpslam_hip_sim3_chi2", "lpslam_hip_sim3_transform_optimize",
@@ -342,6 +342,14 @@ class BundleAdjuster:
         return chi[:self.n_obs], pos[:self.n_obs]
 
 
+    def optimize_partitioned(self, comm, robust=True, iters=10):
+        """lpslam_hip_ba_optimize_partitioned: `comm` is an RcclComm (or a raw ncclComm_t value)"""
+        log = np.zeros(max(iters, 1), BA_LOG_DTYPE); done = C.c_int32()
+        f = self.lib.lpslam_hip_ba_optimize_partitioned
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+        _check(f(self.h, getattr(comm, "comm", comm), int(robust), int(iters), _p(log), C.addressof(done)))
+        return log[:done.value].copy()
+
     # ---- partitioned (multi-GPU) solve: phases of one LM trial (see include/lpslam_hip.h) ----
     def reduced_buffer(self):
         ptr = C.c_void_p(); n = C.c_int64()
@@ -371,6 +379,50 @@ class BundleAdjuster:
         o = C.c_int32(); st = C.c_int32(); lam = C.c_double(); chi = C.c_double()
         _check(self.lib.lpslam_hip_ba_status(self.h, C.byref(o), C.byref(st), C.byref(lam), C.byref(chi)))
         return dict(outer_done=o.value, stopped=bool(st.value), lam=lam.value, chi2=chi.value)
+
+
+class RcclComm:
+    """An ncclComm_t made through ctypes (tests and bench.py: the product's caller is C++ and links RCCL itself).  `unique_id` is the
+    128-byte id of rank 0 (RcclComm.unique_id()), handed to the other ranks by the caller's own means."""
+    _lib = None
+
+    @classmethod
+    def lib(cls):
+        if cls._lib is None:
+            last = None
+            for name in ("librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so"):
+                try:
+                    cls._lib = C.CDLL(name, mode=C.RTLD_GLOBAL); break
+                except OSError as e:
+                    last = e
+            if cls._lib is None:
+                raise LpslamHipError("RCCL not found: %s" % last)
+        return cls._lib
+
+    @classmethod
+    def unique_id(cls):
+        buf = C.create_string_buffer(128)
+        rc = cls.lib().ncclGetUniqueId(buf)
+        if rc != 0:
+            raise LpslamHipError("ncclGetUniqueId failed: %d" % rc)
+        return buf.raw
+
+    def __init__(self, unique_id, world, rank):
+        class Uid(C.Structure):
+            _fields_ = [("internal", C.c_char * 128)]
+        uid = Uid(); C.memmove(C.byref(uid), unique_id, 128)
+        comm = C.c_void_p()
+        f = self.lib().ncclCommInitRank
+        f.argtypes = [C.POINTER(C.c_void_p), C.c_int, Uid, C.c_int]
+        rc = f(C.byref(comm), int(world), uid, int(rank))
+        if rc != 0:
+            raise LpslamHipError("ncclCommInitRank failed: %d" % rc)
+        self.comm = comm
+
+    def close(self):
+        if getattr(self, "comm", None):
+            f = self.lib().ncclCommDestroy; f.argtypes = [C.c_void_p]
+            f(self.comm); self.comm = None
 
 
 def ba_factor_kernel_name(dim):
