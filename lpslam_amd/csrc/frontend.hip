@@ -130,14 +130,14 @@ __device__ __forceinline__ int fast_strength(const uint8_t* t /* points at centr
 
 __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ pyr, size_t image_slab, LevelTable lt,
                                                     int ini_thr, int min_thr, uint32_t* __restrict__ cell_keys,
-                                                    int32_t* __restrict__ cell_count, int cells_per_image, int image0)
+                                                    int32_t* __restrict__ cell_count, int cells_per_image, int image0, int dbg)
 {
     __shared__ __attribute__((aligned(16))) uint8_t tile[70 * TILE_PITCH];
     __shared__ __attribute__((aligned(16))) uint8_t smap[66 * SMAP_PITCH];
     __shared__ unsigned long long m_sel[64];     // per-row masks of the NMS survivors (LDS atomics)
     __shared__ int rowoff[64];
-    __shared__ uint16_t queue[64 * 64];
-    __shared__ int q_count, n_keep;
+    __shared__ uint16_t queue[4][16 * 64];       // pre-test survivors, one queue per wavefront (its 16 rows): no shared counter
+    __shared__ int n_keep;
 
     const int cell = blockIdx.x, image = image0 + blockIdx.y;
     int level = 0;
@@ -151,64 +151,104 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
     const uint8_t* src = pyr + (size_t)image * image_slab + lt.off[level];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
-    // stage the tile: aligned dwords covering [min_x, min_x + cw) of rows [min_y, min_y + ch)
+    // stage the tile: LDS column 1 + j holds pixel min_x + j, so that the first tested pixel (min_x + 3) sits on a dword boundary
+    // (column 4) and a lane of the pre-test owns one aligned dword = four pixels.  Global reads stay aligned dwords; the byte shift
+    // between the two alignments is a v_alignbyte per staged dword.
     const int x_al = min_x & ~3, shift = min_x - x_al;
-    const int ndw = (shift + cw + 3) >> 2;                              // <= 19
-    for (int i = tid; i < ch * 20; i += 256) {
-        const int r = i / 20, c = i - r * 20;
-        uint32_t v = 0;
-        if (c < ndw) v = *reinterpret_cast<const uint32_t*>(src + (size_t)(min_y + r) * P + x_al + 4 * c);
-        *reinterpret_cast<uint32_t*>(&tile[r * TILE_PITCH + 4 * c]) = v;
+    const int s_al = (shift + 3) & 3, k_al = shift == 0 ? -1 : 0;          // LDS dword d = global dwords (d + k_al, d + k_al + 1) >> 8 s_al
+    {
+        const int ndw = (cw + 4) >> 2;                   // the dwords that hold pixels: at most 7 bytes are read past the cell's last pixel
+        uint32_t g0[6], g1[6];
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {                    // 70 rows x 20 dwords = 1400 <= 6 x 256: every load of a thread is in flight before the first store
+            const int i = tid + 256 * u, r = i / 20, c = i - r * 20;
+            g0[u] = 0; g1[u] = 0;
+            if (r < ch && c < ndw) {
+                // 4-byte words at x_al + 4 (c + k_al): the first may start 4 bytes left of x_al (>= 16)
+                const uint32_t* g = reinterpret_cast<const uint32_t*>(src + (size_t)(min_y + r) * P + x_al) + c + k_al;
+                g0[u] = g[0]; g1[u] = g[1];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+            const int i = tid + 256 * u, r = i / 20, c = i - r * 20;
+            if (r < ch) *reinterpret_cast<uint32_t*>(&tile[r * TILE_PITCH + 4 * c]) = __builtin_amdgcn_alignbyte(g1[u], g0[u], s_al);
+        }
     }
     for (int i = tid; i < 66 * SMAP_PITCH / 4; i += 256) reinterpret_cast<uint32_t*>(smap)[i] = 0;
     __syncthreads();
 
     const int vw = cw - 6, vh = ch - 6;          // valid (corner-tested) interior, <= 64 x 64; may be <= 0
-    const unsigned long long lane_ok = vw >= 64 ? ~0ull : ((1ull << max(vw, 0)) - 1ull);
     // cv::FAST at the initial threshold; a cell without a single NMS survivor is redone at the minimum threshold.
     // The arc strength S does not depend on the threshold (corner at t  <=>  S > t), so each pass is:
     //   1. pre-test, every pixel: a 9-arc of the 16-ring always contains two neighbouring compass points (ring positions
-    //      0, 4, 8, 12), so a corner needs two neighbouring compass pixels both darker or both brighter than the centre by
-    //      more than t.  One v_cmp per compass pixel gives a 64-lane mask; the pairing is scalar 64-bit logic.
+    //      0, 4, 8, 12) and two neighbouring diagonal ones (2, 6, 10, 14), so a corner needs such a pair both darker or both
+    //      brighter than the centre by more than t.  A lane tests FOUR neighbouring pixels from eleven dword LDS reads (the
+    //      byte-per-pixel form issued nine ds_read_u8 per pixel: LDS instruction issue was what the kernel was made of);
+    //      a wavefront covers four rows of 64 pixels;
     //   2. survivors only, dense lanes from an LDS queue: S (16 arcs of 9, v_min3 / v_max3), stored if S > t;
     //   3. survivors only: strict 3x3 non-maximum suppression on the S map, survivors set their bit in the row mask.
     int thr = ini_thr;
     for (int attempt = 0; attempt < 2; ++attempt) {
         if (tid < 64) m_sel[tid] = 0;
-        if (tid == 0) { q_count = 0; n_keep = 0; }
+        if (tid == 0) n_keep = 0;
         __syncthreads();
-        for (int r = wave; r < vh; r += 4) {
-            const uint8_t* t = &tile[(r + 3) * TILE_PITCH + shift + lane + 3];
-            const int c = t[0];
-            const int lo = c - thr, hi = c + thr;
-            const int p0 = t[3 * TILE_PITCH], p4 = t[3], p8 = t[-3 * TILE_PITCH], p12 = t[-3];
-            // neighbouring compass pairs always take one point of {0, 8} and one of {4, 12}: "some pair both darker than lo" is
-            // min over the pairs of max(pair) < lo, i.e. max(min(p0, p8), min(p4, p12)) < lo; brighter likewise -- four VALU ops
-            // per polarity and one ballot per row instead of eight compares and 64-bit scalar mask logic
-            const int dk = max(min(p0, p8), min(p4, p12)), br = min(max(p0, p8), max(p4, p12));
-            // the same holds for the diagonal ring positions 2, 6, 10, 14 (also spaced four apart, so a 9-arc holds two neighbouring
-            // ones), and with the same polarity: fewer pixels reach the 16-arc evaluation
-            const int p2 = t[2 * TILE_PITCH + 2], p6 = t[-2 * TILE_PITCH + 2], p10 = t[-2 * TILE_PITCH - 2], p14 = t[2 * TILE_PITCH - 2];
-            const int dk2 = max(min(p2, p10), min(p6, p14)), br2 = min(max(p2, p10), max(p6, p14));
-            const unsigned long long any = __ballot((dk < lo && dk2 < lo) || (br > hi && br2 > hi)) & lane_ok;
-            if (any) {
-                int base = 0;
-                if (lane == 0) base = atomicAdd(&q_count, __popcll(any));
-                base = __shfl(base, 0);
-                if ((any >> lane) & 1ull) queue[base + __popcll(any & ((1ull << lane) - 1ull))] = (uint16_t)((r << 6) | lane);
+        const int l16 = lane & 15, rs = lane >> 4;
+        int n_mine = 0;                                  // entries of this wavefront's queue (uniform)
+        for (int r4 = wave * 4; r4 < ((dbg & 1) ? 0 : vh); r4 += 16) {
+            const int r = r4 + rs;                       // tested row (tile row r + 3); rows past vh read inside the tile and are masked out
+            const uint32_t* t = reinterpret_cast<const uint32_t*>(&tile[min(r + 3, 66) * TILE_PITCH]) + 1 + l16;      // the lane's own dword
+            const uint32_t* tu = t - 2 * (TILE_PITCH / 4), *td = t + 2 * (TILE_PITCH / 4);
+            const uint32_t C = t[0], Cl = t[-1], Cr = t[1];
+            const uint32_t P0 = t[3 * (TILE_PITCH / 4)], P8 = t[-3 * (TILE_PITCH / 4)];
+            const uint32_t P4 = __builtin_amdgcn_alignbyte(Cr, C, 3), P12 = __builtin_amdgcn_alignbyte(C, Cl, 1);
+            const uint32_t P2 = __builtin_amdgcn_alignbyte(td[1], td[0], 2), P14 = __builtin_amdgcn_alignbyte(td[0], td[-1], 2);
+            const uint32_t P6 = __builtin_amdgcn_alignbyte(tu[1], tu[0], 2), P10 = __builtin_amdgcn_alignbyte(tu[0], tu[-1], 2);
+            // two pixels per instruction: bytes spread to 16-bit halves (v_perm), then v_pk_min / v_pk_max / v_pk_add / v_pk_sub_u16.
+            // "some neighbouring pair both darker than c - t" is max(min(p0, p8), min(p4, p12)) < c - t (a pair takes one point of
+            // {0, 8} and one of {4, 12}); brighter likewise; the same for the diagonals, with the same polarity.  The comparisons are
+            // saturating subtractions: x < y  <=>  sat(y - x) != 0.
+            unsigned flags = 0;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const uint32_t sel = h ? 0x0c030c02u : 0x0c010c00u;
+#define PK(x) __builtin_bit_cast(us2, __builtin_amdgcn_perm(0u, (x), sel))
+                const us2 c = PK(C), thr2 = {(unsigned short)thr, (unsigned short)thr};
+                const us2 lo = __builtin_elementwise_sub_sat(c, thr2), hi = c + thr2;
+                const us2 p0 = PK(P0), p4 = PK(P4), p8 = PK(P8), p12 = PK(P12), p2 = PK(P2), p6 = PK(P6), p10 = PK(P10), p14 = PK(P14);
+#undef PK
+                const us2 dk = __builtin_elementwise_max(__builtin_elementwise_max(__builtin_elementwise_min(p0, p8), __builtin_elementwise_min(p4, p12)),
+                                                         __builtin_elementwise_max(__builtin_elementwise_min(p2, p10), __builtin_elementwise_min(p6, p14)));
+                const us2 br = __builtin_elementwise_min(__builtin_elementwise_min(__builtin_elementwise_max(p0, p8), __builtin_elementwise_max(p4, p12)),
+                                                         __builtin_elementwise_min(__builtin_elementwise_max(p2, p10), __builtin_elementwise_max(p6, p14)));
+                const uint32_t f = __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(lo, dk)) | __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(br, hi));
+                flags |= ((f & 0xFFFFu) ? 1u : 0u) << (2 * h) | ((f >> 16) ? 2u : 0u) << (2 * h);
+            }
+            // rows / columns outside the tested interior
+            const int nvalid = r < vh ? min(max(vw - 4 * l16, 0), 4) : 0;
+            flags &= (1u << nvalid) - 1u;
+            // queue slots by ballot: pixel k of every lane, k = 0..3 (any order would do: the S map and the masks are positional)
+            if (__ballot(flags != 0)) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const unsigned long long b = __ballot((flags >> k) & 1u);
+                    if ((flags >> k) & 1u) queue[wave][n_mine + __builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0u))] = (uint16_t)((r << 6) | (4 * l16 + k));
+                    n_mine += __popcll(b);
+                }
             }
         }
-        __syncthreads();
-        const int n_q = q_count;
-        for (int i = tid; i < n_q; i += 256) {
-            const int r = queue[i] >> 6, x = queue[i] & 63;
-            const int sv = fast_strength(&tile[(r + 3) * TILE_PITCH + shift + x + 3]);
+        if (dbg & 2) n_mine = 0;
+        // every wavefront works through its own queue straight away (its rows interleave with the others': the load is even; the
+        // strength reads the tile only, so no barrier is needed here)
+        for (int i = lane; i < n_mine; i += 64) {
+            const int e = queue[wave][i], r = e >> 6, x = e & 63;
+            const int sv = fast_strength(&tile[(r + 3) * TILE_PITCH + 4 + x]);
             smap[(r + 1) * SMAP_PITCH + x + 1] = (uint8_t)(sv > thr ? sv : 0);
         }
         __syncthreads();
         int kept = 0;
-        for (int i = tid; i < n_q; i += 256) {
-            const int r = queue[i] >> 6, x = queue[i] & 63;
+        for (int i = lane; i < n_mine; i += 64) {
+            const int e = queue[wave][i], r = e >> 6, x = e & 63;
             const uint8_t* q = &smap[(r + 1) * SMAP_PITCH + x + 1];
             const int sc = q[0];
             if (sc > 0 && sc > q[-1] && sc > q[1] && sc > q[-SMAP_PITCH - 1] && sc > q[-SMAP_PITCH] && sc > q[-SMAP_PITCH + 1] &&
@@ -881,7 +921,7 @@ int lp_launch_fast(lpslam_hip_ctx* c, int first, int n_images)
 {
     dim3 grid(c->cells_per_image, n_images);
     hipLaunchKernelGGL(k_fast_cells, grid, dim3(256), 0, c->stream, c->d_pyr, c->image_slab, c->lt, c->cfg.ini_fast_threshold,
-                       c->cfg.min_fast_threshold, c->d_cell_keys, c->d_cell_count, c->cells_per_image, first);
+                       c->cfg.min_fast_threshold, c->d_cell_keys, c->d_cell_count, c->cells_per_image, first, getenv("LPSLAM_FAST_DBG") ? atoi(getenv("LPSLAM_FAST_DBG")) : 0);
     LP_HIP(hipGetLastError());
     return LPSLAM_HIP_OK;
 }
