@@ -100,6 +100,12 @@ int lpslam_hip_upload_raw_image(lpslam_hip_ctx* ctx, int image, int32_t eye, con
 /* remaps the raw frame already staged in HBM (the last upload_raw_image) into another slot: the device-side step alone */
 int lpslam_hip_remap_staged(lpslam_hip_ctx* ctx, int image, int32_t eye);
 
+/* Camera mask of one eye (0 = left: even image slots, 1 = right: odd image slots): a width x height byte image, 0 = masked out,
+ * NULL removes it.  Replaces the `mask` argument of feed_stereo_frame / feed_monocular_frame
+ * (src/Trackers/OpenVSLAMStereoTracker.cpp:293, masks built by OpenVSLAMTrackerBase::configureMasks, OpenVSLAMTrackerBase.cpp:331-380):
+ * [UPSTREAM] orb_extractor skips a FAST cell with a corner in the mask and drops every corner whose own position is masked. */
+int lpslam_hip_set_mask(lpslam_hip_ctx* ctx, int32_t eye, const uint8_t* mask, int32_t stride);
+
 /* ---- ORB front end (asynchronous on the context stream) -------------------------------------------------- */
 /* pyramid -> FAST (64-px cells, ini/min threshold) -> quad-tree distribution -> orientation + rBRIEF,
  * for image slots [0, n_images). */

@@ -362,7 +362,7 @@ void lpslam_hip_destroy(lpslam_hip_ctx* c)
     void* bufs[] = {c->d_pyr, c->d_band_rows, c->d_rs_pack, c->d_cell_keys, c->d_cell_count, c->d_cand_key, c->d_cand_node,
                     c->d_cand_count, c->d_sel_key, c->d_sel_count, c->d_kpts, c->d_desc,
                     c->d_kp_count, c->d_bf, c->d_stereo, c->d_stereo_idx, c->d_stereo_corr, c->d_st_row_start, c->d_st_row_list, c->d_tmp_desc, c->d_tmp_res,
-                    c->d_map_xy[0], c->d_map_xy[1], c->d_map_frac[0], c->d_map_frac[1], c->d_raw};
+                    c->d_map_xy[0], c->d_map_xy[1], c->d_map_frac[0], c->d_map_frac[1], c->d_raw, c->d_mask[0], c->d_mask[1]};
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (int i = 0; i < LPSLAM_HIP_MAX_TIMERS; ++i) { if (c->ev_begin[i]) (void)hipEventDestroy(c->ev_begin[i]); if (c->ev_end[i]) (void)hipEventDestroy(c->ev_end[i]); }
     for (void* p : c->pin_free) (void)hipHostFree(p);
@@ -378,6 +378,21 @@ void lpslam_hip_destroy(lpslam_hip_ctx* c)
 }
 
 void* lpslam_hip_stream(lpslam_hip_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+int lpslam_hip_set_mask(lpslam_hip_ctx* c, int32_t eye, const uint8_t* mask, int32_t stride)
+{
+    if (!c || eye < 0 || eye > 1) { set_error("invalid mask arguments"); return LPSLAM_HIP_ERR_INVALID; }
+    LP_HIP(hipSetDevice(c->cfg.device));
+    LP_HIP(hipStreamSynchronize(c->stream));             // no extraction may be reading the old mask
+    if (!mask) {
+        if (c->d_mask[eye]) { (void)hipFree(c->d_mask[eye]); c->d_mask[eye] = nullptr; }
+        return LPSLAM_HIP_OK;
+    }
+    if (stride < c->cfg.width) { set_error("mask stride %d smaller than the image width %d", stride, c->cfg.width); return LPSLAM_HIP_ERR_INVALID; }
+    if (!c->d_mask[eye]) LP_HIP(hipMalloc((void**)&c->d_mask[eye], (size_t)c->cfg.width * c->cfg.height));
+    LP_HIP(hipMemcpy2D(c->d_mask[eye], (size_t)c->cfg.width, mask, (size_t)stride, (size_t)c->cfg.width, (size_t)c->cfg.height, hipMemcpyHostToDevice));
+    return LPSLAM_HIP_OK;
+}
 
 static int timer_slot(lpslam_hip_ctx* c, int slot)
 {

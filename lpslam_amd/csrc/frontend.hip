@@ -130,7 +130,8 @@ __device__ __forceinline__ int fast_strength(const uint8_t* t /* points at centr
 
 __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ pyr, size_t image_slab, LevelTable lt,
                                                     int ini_thr, int min_thr, uint32_t* __restrict__ cell_keys,
-                                                    int32_t* __restrict__ cell_count, int cells_per_image, int image0, int dbg)
+                                                    int32_t* __restrict__ cell_count, int cells_per_image, int image0, int dbg,
+                                                    const uint8_t* __restrict__ mask0, const uint8_t* __restrict__ mask1)
 {
     __shared__ __attribute__((aligned(16))) uint8_t tile[70 * TILE_PITCH];
     __shared__ __attribute__((aligned(16))) uint8_t smap[66 * SMAP_PITCH];
@@ -150,6 +151,22 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
     const int ch = min(min_y + kCell + kOverlap, H - kEdge) - min_y;
     const uint8_t* src = pyr + (size_t)image * image_slab + lt.off[level];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // camera mask ([UPSTREAM] orb_extractor::is_in_mask: level coordinate x scale factor, truncated, looked up in the level-0 mask,
+    // 0 = masked out): even image slots are left eyes, odd ones right eyes.  A cell with a corner in the mask is skipped.
+    const uint8_t* mask = (image & 1) ? mask1 : mask0;
+    const float mscale = lt.scale[level];
+    const int W0 = lt.w[0], H0 = lt.h[0];
+    auto masked = [&](int y, int x) -> bool {
+        const int my = min(max((int)((float)y * mscale), 0), H0 - 1), mx = min(max((int)((float)x * mscale), 0), W0 - 1);
+        return mask[(size_t)my * W0 + mx] == 0;
+    };
+    if (mask) {
+        const int max_x = min_x + cw, max_y = min_y + ch;
+        if (masked(min_y, min_x) || masked(max_y, min_x) || masked(min_y, max_x) || masked(max_y, max_x)) {
+            if (tid == 0) cell_count[(size_t)image * cells_per_image + cell] = 0;
+            return;
+        }
+    }
 
     // stage the tile: LDS column 1 + j holds pixel min_x + j, so that the first tested pixel (min_x + 3) sits on a dword boundary
     // (column 4) and a lane of the pre-test owns one aligned dword = four pixels.  Global reads stay aligned dwords; the byte shift
@@ -195,7 +212,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
         __syncthreads();
         const int l16 = lane & 15, rs = lane >> 4;
         int n_mine = 0;                                  // entries of this wavefront's queue (uniform)
-        for (int r4 = wave * 4; r4 < ((dbg & 1) ? 0 : vh); r4 += 16) {
+        for (int r4 = wave * 4; r4 < vh; r4 += 16) {
             const int r = r4 + rs;                       // tested row (tile row r + 3); rows past vh read inside the tile and are masked out
             const uint32_t* t = reinterpret_cast<const uint32_t*>(&tile[min(r + 3, 66) * TILE_PITCH]) + 1 + l16;      // the lane's own dword
             const uint32_t* tu = t - 2 * (TILE_PITCH / 4), *td = t + 2 * (TILE_PITCH / 4);
@@ -237,7 +254,6 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
                 }
             }
         }
-        if (dbg & 2) n_mine = 0;
         // every wavefront works through its own queue straight away (its rows interleave with the others': the load is even; the
         // strength reads the tile only, so no barrier is needed here)
         for (int i = lane; i < n_mine; i += 64) {
@@ -253,7 +269,8 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
             const int sc = q[0];
             if (sc > 0 && sc > q[-1] && sc > q[1] && sc > q[-SMAP_PITCH - 1] && sc > q[-SMAP_PITCH] && sc > q[-SMAP_PITCH + 1] &&
                 sc > q[SMAP_PITCH - 1] && sc > q[SMAP_PITCH] && sc > q[SMAP_PITCH + 1]) {
-                atomicOr(&m_sel[r], 1ull << x);
+                // the threshold fallback looks at what FAST found; a corner whose own position is masked out is dropped afterwards
+                if (!mask || !masked(min_y + r + 3, min_x + x + 3)) atomicOr(&m_sel[r], 1ull << x);
                 kept = 1;
             }
         }
@@ -921,7 +938,7 @@ int lp_launch_fast(lpslam_hip_ctx* c, int first, int n_images)
 {
     dim3 grid(c->cells_per_image, n_images);
     hipLaunchKernelGGL(k_fast_cells, grid, dim3(256), 0, c->stream, c->d_pyr, c->image_slab, c->lt, c->cfg.ini_fast_threshold,
-                       c->cfg.min_fast_threshold, c->d_cell_keys, c->d_cell_count, c->cells_per_image, first, getenv("LPSLAM_FAST_DBG") ? atoi(getenv("LPSLAM_FAST_DBG")) : 0);
+                       c->cfg.min_fast_threshold, c->d_cell_keys, c->d_cell_count, c->cells_per_image, first, 0, c->d_mask[0], c->d_mask[1]);
     LP_HIP(hipGetLastError());
     return LPSLAM_HIP_OK;
 }

@@ -99,6 +99,7 @@ struct lpslam_hip_ctx {
     short2* d_map_xy[2] = {nullptr, nullptr};      // [h][w] integer source coordinate (sx >> 5, sy >> 5)
     uint16_t* d_map_frac[2] = {nullptr, nullptr};  // [h][w] (sy & 31) * 32 + (sx & 31)
     uint8_t* d_raw = nullptr;                      // [h][w] distorted frame of the upload in flight
+    uint8_t* d_mask[2] = {nullptr, nullptr};       // camera masks (level-0 size, pitch = width, 0 = masked out), left / right eye; nullptr = none
     // cache of device blocks for the short-lived objects the tracker makes every frame / keyframe (bundle-adjustment problems, pose
     // optimiser and projection-matcher staging): hipMalloc / hipFree cost ~50-100 us each and a problem needs ~40 buffers
     std::vector<std::pair<size_t, void*>> pool;        // (capacity, block), free blocks only

@@ -28,7 +28,7 @@ BA_LOG_DTYPE = np.dtype([("chi2_before", "<f8"), ("chi2_after", "<f8"), ("lambda
 SYMBOLS = [
     "lpslam_hip_last_error", "lpslam_hip_device_count", "lpslam_hip_create", "lpslam_hip_destroy",
     "lpslam_hip_stream", "lpslam_hip_sync", "lpslam_hip_timer_begin", "lpslam_hip_timer_end", "lpslam_hip_timer_read", "lpslam_hip_level_info", "lpslam_hip_max_keypoints_per_image",
-    "lpslam_hip_image_ptr", "lpslam_hip_upload_image", "lpslam_hip_set_rectify_map", "lpslam_hip_upload_raw_image", "lpslam_hip_remap_staged", "lpslam_hip_extract", "lpslam_hip_extract_range", "lpslam_hip_stage_pyramid",
+    "lpslam_hip_image_ptr", "lpslam_hip_upload_image", "lpslam_hip_set_rectify_map", "lpslam_hip_set_mask", "lpslam_hip_upload_raw_image", "lpslam_hip_remap_staged", "lpslam_hip_extract", "lpslam_hip_extract_range", "lpslam_hip_stage_pyramid",
     "lpslam_hip_stage_fast", "lpslam_hip_stage_distribute", "lpslam_hip_stage_describe",
     "lpslam_hip_keypoint_count", "lpslam_hip_get_keypoints", "lpslam_hip_get_frame", "lpslam_hip_get_pyramid_level",
     "lpslam_hip_get_candidates", "lpslam_hip_keypoint_buffers", "lpslam_hip_match_bf", "lpslam_hip_get_bf_knn2",
@@ -161,6 +161,14 @@ class Context:
         mx = np.ascontiguousarray(map_x, np.float32); my = np.ascontiguousarray(map_y, np.float32)
         assert mx.shape == (self.cfg.height, self.cfg.width) and my.shape == mx.shape
         _check(self.lib.lpslam_hip_set_rectify_map(self.h, int(eye), _p(mx), _p(my)))
+
+    def set_mask(self, eye, mask):
+        """camera mask of one eye (uint8, image size, 0 = masked out); None removes it"""
+        if mask is None:
+            _check(self.lib.lpslam_hip_set_mask(self.h, int(eye), None, 0)); return
+        m = np.ascontiguousarray(mask, np.uint8)
+        assert m.shape == (self.cfg.height, self.cfg.width), m.shape
+        _check(self.lib.lpslam_hip_set_mask(self.h, int(eye), _p(m), m.shape[1]))
 
     def upload_raw(self, image, eye, arr):
         arr = np.ascontiguousarray(arr, np.uint8)

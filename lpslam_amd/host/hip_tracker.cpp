@@ -10,13 +10,6 @@
 #include <fstream>
 #include <limits>
 
-#include <atomic>
-static std::atomic<long> g_motion_tracked{0};      // process-wide count of frames tracked by the motion model (introspection for the tests)
-extern "C" __attribute__((visibility("default"))) long lpslam_debug_motion_tracked(void) { return g_motion_tracked.load(); }
-static std::atomic<long> g_loops_closed{0};       // loops closed by any tracker of this process
-extern "C" __attribute__((visibility("default"))) long lpslam_debug_loops_closed(void) { return g_loops_closed.load(); }
-static std::atomic<long> g_local_map_joined{0};   // landmarks local-map tracking brought back into frames
-extern "C" __attribute__((visibility("default"))) long lpslam_debug_local_map_joined(void) { return g_local_map_joined.load(); }
 
 namespace LpSlam {
 
@@ -145,7 +138,22 @@ bool HipVslamTrackerBase::startContext(bool stereo)
             lpslam_hip_destroy(m_ctx); m_ctx = nullptr;
             return false;
         }
+    // camera masks (OpenVSLAMTrackerBase::configureMasks, src/Trackers/OpenVSLAMTrackerBase.cpp:331-380): a filled circle around the
+    // image centre (mask_type Radial, radius mask_parameter) or camera_mask_left.bmp / camera_mask_right.bmp (mask_type Image)
+    for (int eye = 0; eye < (stereo ? 2 : 1); ++eye) {
+        auto cfg_eye = reg->getConfiguration((LpSlamCameraNumber)eye);
+        if (!cfg_eye || cfg_eye->mask_type == LpSlamCameraMaskType_None) continue;
+        std::vector<uint8_t> mask;
+        std::string err;
+        if (!build_camera_mask(*cfg_eye, eye == 0, mask, &err)) { logMessage(LpSlamLogLevel_Error, "Cannot build the camera mask: " + err); continue; }
+        if (lpslam_hip_set_mask(m_ctx, eye, mask.data(), cfg_eye->resolution_x) != LPSLAM_HIP_OK)
+            logMessage(LpSlamLogLevel_Error, std::string("Cannot upload the camera mask: ") + lpslam_hip_last_error());
+        else logMessage(LpSlamLogLevel_Info, std::string("Camera mask set for the ") + (eye == 0 ? "left" : "right") + " camera");
+    }
     m_maxKp = lpslam_hip_max_keypoints_per_image(m_ctx);
+    lpslam_hip_level_info(m_ctx, nullptr, nullptr, nullptr, nullptr, m_scales);
+    m_stats = Statistics{};
+    m_kfs.clear(); m_landmarks.clear(); m_replaced.clear(); m_nextLandmarkId = 0; m_refKf = -1; m_segment = 0; m_segmentStart = 0;
     m_stereo = stereo;
     m_state = TrackerState::NotInitialized;
     m_started = true;
@@ -156,7 +164,7 @@ bool HipVslamTrackerBase::stop()
 {
     std::scoped_lock lock(m_slamLock);
     stopMappingThread();                               // the mapping thread uses the context
-    if (m_ctx) { lpslam_hip_destroy(m_ctx); m_ctx = nullptr; }
+    if (m_ctx) { logStatistics(); lpslam_hip_destroy(m_ctx); m_ctx = nullptr; }
     m_started = false;
     return true;
 }
@@ -188,16 +196,49 @@ TrackerResult HipVslamTrackerBase::createTrackerResult(const Pose& p, TimeStamp 
     return t;
 }
 
-bool HipVslamTrackerBase::initializeMap(FrameData& f)
+int HipVslamTrackerBase::resolve(int id) const
+{
+    for (int guard = 0; id >= 0 && guard < 64; ++guard) {
+        auto it = m_replaced.find(id);
+        if (it == m_replaced.end()) break;
+        id = it->second;
+    }
+    return id;
+}
+
+// [UPSTREAM] graph_node::get_top_n_covisibilities: the keyframes that share landmarks with `kf`, by weight (number of shared
+// landmarks) descending, ties to the newer keyframe; at most top_n with weight >= min_weight, returned in ascending id order
+std::vector<int> HipVslamTrackerBase::covisible(int kf, int top_n, int min_weight) const
+{
+    std::unordered_map<int, int> w;
+    for (int id : m_kfs[(size_t)kf].landmark) {
+        if (id < 0) continue;
+        auto it = m_landmarks.find(id);
+        if (it == m_landmarks.end()) continue;
+        for (auto& o : it->second.obs) if (o.first != kf) w[o.first]++;
+    }
+    std::vector<std::pair<int, int>> v;
+    for (auto& kv : w) if (kv.second >= min_weight) v.emplace_back(kv.second, kv.first);
+    std::sort(v.begin(), v.end(), [](const std::pair<int, int>& a, const std::pair<int, int>& b) { return a.first != b.first ? a.first > b.first : a.second > b.second; });
+    if ((int)v.size() > top_n) v.resize((size_t)std::max(top_n, 0));
+    std::vector<int> out;
+    for (auto& e : v) out.push_back(e.second);
+    std::sort(out.begin(), out.end());
+    return out;
+}
+
+bool HipVslamTrackerBase::initializeMap(FrameData& f, const Pose& at)
 {
     // stereo initialisation: every keypoint with a valid depth becomes a landmark once at least
-    // Initializer.num_min_triangulated_pts = 40 exist (src/Trackers/OpenVSLAMTrackerBase.cpp:181)
+    // Initializer.num_min_triangulated_pts = 40 exist (src/Trackers/OpenVSLAMTrackerBase.cpp:181).  The map that exists stays:
+    // after a loss the new keyframes open a new segment at the pose handed in, and a loop closure can join the segments later.
     int n = 0;
     for (size_t i = 0; i < f.kpts.size(); ++i) if (f.depth[i] > 0) ++n;
     if (n < 40) return false;
-    { std::unique_lock<std::mutex> lk(m_mapMutex); m_mapCv.wait(lk, [this] { return !m_mapBusy; }); m_mapOut.reset(); }   // a solve of the map that is being dropped
-    m_landmarks.clear(); m_keyframes.clear(); m_archive.clear(); m_nextLandmarkId = 0;
-    f.pose = Pose();
+    finishMapping();
+    f.pose = at;
+    std::fill(f.landmark.begin(), f.landmark.end(), -1);
+    m_segmentStart = (int)m_kfs.size();
     insertKeyframe(f);
     return true;
 }
@@ -206,8 +247,6 @@ bool HipVslamTrackerBase::initializeMap(FrameData& f)
 // update_normal_and_depth / compute_descriptor, reference observation only)
 void HipVslamTrackerBase::initLandmarkView(Landmark& lm, const Pose& pose, const lpslam_hip_keypoint& kp, const uint8_t* desc32) const
 {
-    float scales[LPSLAM_HIP_MAX_LEVELS];
-    lpslam_hip_level_info(m_ctx, nullptr, nullptr, nullptr, nullptr, scales);
     const Mat3 R = quatToRot(pose.q);
     // camera centre C = -R^T t
     const double C[3] = {-(R.m[0] * pose.t[0] + R.m[3] * pose.t[1] + R.m[6] * pose.t[2]), -(R.m[1] * pose.t[0] + R.m[4] * pose.t[1] + R.m[7] * pose.t[2]),
@@ -216,30 +255,113 @@ void HipVslamTrackerBase::initLandmarkView(Landmark& lm, const Pose& pose, const
     const double dist = std::sqrt(ray[0] * ray[0] + ray[1] * ray[1] + ray[2] * ray[2]);
     for (int a = 0; a < 3; ++a) lm.normal[a] = dist > 0 ? ray[a] / dist : 0.0;
     const int lvl = std::min(std::max(kp.octave, 0), m_numLevels - 1);
-    lm.max_valid = dist * scales[lvl];
-    lm.min_valid = lm.max_valid / scales[std::max(m_numLevels - 1, 0)];
+    lm.max_valid = dist * m_scales[lvl];
+    lm.min_valid = lm.max_valid / m_scales[std::max(m_numLevels - 1, 0)];
     std::copy(desc32, desc32 + 32, lm.desc);
 }
 
-void HipVslamTrackerBase::insertKeyframe(FrameData& f)
+// the landmark `drop` becomes `keep` everywhere ([UPSTREAM] landmark::replace): its observations move over unless the keyframe
+// already sees `keep`; frames in flight follow through m_replaced
+void HipVslamTrackerBase::mergeLandmarks(int keep, int drop, FrameData* f)
 {
+    auto ik = m_landmarks.find(keep), id = m_landmarks.find(drop);
+    if (ik == m_landmarks.end() || id == m_landmarks.end() || keep == drop) return;
+    for (auto& o : id->second.obs) {
+        Keyframe& kf = m_kfs[(size_t)o.first];
+        bool sees_keep = false;
+        for (auto& ko : ik->second.obs) if (ko.first == o.first) { sees_keep = true; break; }
+        if (sees_keep) kf.landmark[(size_t)o.second] = -1;
+        else { kf.landmark[(size_t)o.second] = keep; ik->second.obs.push_back(o); }
+    }
+    m_landmarks.erase(id);
+    m_replaced[drop] = keep;
+    if (f) for (auto& l : f->landmark) if (l == drop) l = keep;
+}
+
+void HipVslamTrackerBase::fuseInto(int c, int slot, const std::vector<int>& landmark_ids, FrameData& f, long& added, long& merged)
+{
+    Keyframe& kc = m_kfs[(size_t)c];
+    const Mat3 R = quatToRot(kc.pose.q);
+    const double C[3] = {-(R.m[0] * kc.pose.t[0] + R.m[3] * kc.pose.t[1] + R.m[6] * kc.pose.t[2]), -(R.m[1] * kc.pose.t[0] + R.m[4] * kc.pose.t[1] + R.m[7] * kc.pose.t[2]),
+                         -(R.m[2] * kc.pose.t[0] + R.m[5] * kc.pose.t[1] + R.m[8] * kc.pose.t[2])};
+    const double log_sf = std::log((double)m_scaleFactor);
+    std::vector<lpslam_hip_proj_query> q;
+    std::vector<uint8_t> qd;
+    std::vector<int> q_lm;
+    for (int id : landmark_ids) {
+        auto it = m_landmarks.find(id);
+        if (it == m_landmarks.end()) continue;
+        const Landmark& lm = it->second;
+        const double* X = lm.p;
+        const double pc[3] = {R.m[0] * X[0] + R.m[1] * X[1] + R.m[2] * X[2] + kc.pose.t[0], R.m[3] * X[0] + R.m[4] * X[1] + R.m[5] * X[2] + kc.pose.t[1],
+                              R.m[6] * X[0] + R.m[7] * X[1] + R.m[8] * X[2] + kc.pose.t[2]};
+        if (!(pc[2] > 0)) continue;
+        const double u = m_cam.f_x * pc[0] / pc[2] + m_cam.c_x, v = m_cam.f_y * pc[1] / pc[2] + m_cam.c_y;
+        if (u < 0 || v < 0 || u >= m_cam.resolution_x || v >= m_cam.resolution_y) continue;
+        const double ray[3] = {X[0] - C[0], X[1] - C[1], X[2] - C[2]};
+        const double dist = std::sqrt(ray[0] * ray[0] + ray[1] * ray[1] + ray[2] * ray[2]);
+        if (!(dist > 0) || dist < 0.8 * lm.min_valid || dist > 1.2 * lm.max_valid) continue;
+        if ((ray[0] * lm.normal[0] + ray[1] * lm.normal[1] + ray[2] * lm.normal[2]) / dist < 0.5) continue;
+        const int lvl = std::min(std::max((int)std::ceil(std::log(lm.max_valid / dist) / log_sf), 0), m_numLevels - 1);
+        lpslam_hip_proj_query e{};
+        e.x = (float)u; e.y = (float)v; e.x_right = m_stereo ? (float)(u - m_cam.focal_x_baseline / pc[2]) : -1.0f;
+        e.radius = 3.0f * m_scales[lvl];                 // match::fuse: margin 3 px x scale factor of the predicted level
+        e.min_level = std::max(0, lvl - 1); e.max_level = lvl;
+        q.push_back(e);
+        qd.insert(qd.end(), lm.desc, lm.desc + 32);
+        q_lm.push_back(id);
+    }
+    if (q.empty()) return;
+    std::vector<int32_t> idx(q.size()), dist(q.size());
+    int32_t n_m = 0;
+    if (lpslam_hip_match_fuse(m_ctx, slot, q.data(), qd.data(), (int32_t)q.size(), 50 /* HAMMING_DIST_THR_LOW */, m_stereo ? 1 : 0, idx.data(), dist.data(), &n_m) != LPSLAM_HIP_OK) return;
+    for (size_t k = 0; k < q.size(); ++k) {
+        if (idx[k] < 0) continue;
+        const int kp = idx[k];
+        const int id = resolve(q_lm[k]);
+        auto it = m_landmarks.find(id);
+        if (it == m_landmarks.end()) continue;
+        bool seen = false;                               // the keyframe may see this landmark already (through another keypoint)
+        for (auto& o : it->second.obs) if (o.first == c) { seen = true; break; }
+        const int have = kc.landmark[(size_t)kp];
+        if (have < 0) {
+            if (seen) continue;
+            kc.landmark[(size_t)kp] = id; it->second.obs.emplace_back(c, kp);
+            if ((size_t)kp < f.landmark.size()) f.landmark[(size_t)kp] = id;
+            ++added;
+        } else if (have != id) {
+            if (seen) continue;
+            auto ih = m_landmarks.find(have);
+            if (ih == m_landmarks.end()) continue;
+            // the one with more observations stays (ties: the older landmark)
+            const bool keep_have = ih->second.obs.size() > it->second.obs.size() || (ih->second.obs.size() == it->second.obs.size() && have < id);
+            mergeLandmarks(keep_have ? have : id, keep_have ? id : have, &f);
+            for (auto& l : m_prev.landmark) if (l == (keep_have ? id : have)) l = keep_have ? have : id;
+            ++merged;
+        }
+    }
+}
+
+int HipVslamTrackerBase::insertKeyframe(FrameData& f)
+{
+    const int c = (int)m_kfs.size();
     const double baseline = m_cam.focal_x_baseline / m_cam.f_x;
     const double depth_thr = 40.0 * baseline;
     const Mat3 R = quatToRot(f.pose.q);
-    float scales[LPSLAM_HIP_MAX_LEVELS];
-    lpslam_hip_level_info(m_ctx, nullptr, nullptr, nullptr, nullptr, scales);
     Keyframe kf;
-    kf.pose = f.pose;
+    kf.pose = f.pose; kf.segment = m_segment;
+    for (auto& l : f.landmark) { l = resolve(l); if (l >= 0 && !m_landmarks.count(l)) l = -1; }
     // new landmarks: unmatched keypoints closer than depth_threshold (40 baselines, OpenVSLAMTrackerBase.cpp:200); when fewer
-    // than 100 landmarks would result, the closest ones beyond the threshold are taken too; the first keyframe takes all
+    // than 100 landmarks would result, the closest ones beyond the threshold are taken too; a segment's first keyframe takes all
     std::vector<std::pair<float, int>> by_depth;
     for (size_t i = 0; i < f.kpts.size(); ++i) if (f.landmark[i] < 0 && f.depth[i] > 0) by_depth.emplace_back(f.depth[i], (int)i);
     std::sort(by_depth.begin(), by_depth.end());
     std::vector<char> create(f.kpts.size(), 0);
     int tracked = 0;
     for (size_t i = 0; i < f.kpts.size(); ++i) tracked += f.landmark[i] >= 0;
+    const bool first = c == m_segmentStart;
     for (size_t r = 0; r < by_depth.size(); ++r)
-        if (m_keyframes.empty() || by_depth[r].first < depth_thr || tracked + (int)r < 100) create[by_depth[r].second] = 1;
+        if (first || by_depth[r].first < depth_thr || tracked + (int)r < 100) create[(size_t)by_depth[r].second] = 1;
     for (size_t i = 0; i < f.kpts.size(); ++i) {
         int id = f.landmark[i];
         if (id < 0 && create[i]) {
@@ -252,41 +374,39 @@ void HipVslamTrackerBase::insertKeyframe(FrameData& f)
             lm.p[1] = R.m[1] * d[0] + R.m[4] * d[1] + R.m[7] * d[2];
             lm.p[2] = R.m[2] * d[0] + R.m[5] * d[1] + R.m[8] * d[2];
             initLandmarkView(lm, f.pose, f.kpts[i], f.desc.data() + 32 * i);
-            lm.ref_kf = (long)m_archive.size();
+            lm.ref_kf = c;
             id = m_nextLandmarkId++;
-            m_landmarks[id] = lm;
+            lm.obs.emplace_back(c, (int)i);
+            m_landmarks[id] = std::move(lm);
             f.landmark[i] = id;
-        }
-        if (id >= 0) {
-            const double s = scales[f.kpts[i].octave];
-            kf.obs.push_back({id, f.kpts[i].x, f.kpts[i].y, f.x_right[i] >= 0 ? (double)f.x_right[i] : -1.0, 1.0 / (s * s)});
-            m_landmarks[id].n_obs++;
+        } else if (id >= 0) {
+            m_landmarks[id].obs.emplace_back(c, (int)i);
         }
     }
-    if (!m_stereo) {
-        if (!m_keyframes.empty()) monoTriangulate(m_keyframes.back(), kf, f);
-        kf.kpts = f.kpts; kf.desc = f.desc; kf.landmark = f.landmark;
+    if (!m_stereo && c > m_segmentStart) monoTriangulate(c - 1, kf, f);
+    kf.kpts = f.kpts; kf.desc = f.desc; kf.x_right = f.x_right; kf.depth = f.depth; kf.landmark = f.landmark;
+    m_kfs.push_back(std::move(kf));
+    // duplicates: the landmarks of the covisible keyframes that this keyframe does not hold are searched in it (match::fuse)
+    {
+        const std::vector<int> nb = covisible(c, m_localWindow - 1, 15);
+        std::unordered_map<int, char> held;
+        for (int id : m_kfs[(size_t)c].landmark) if (id >= 0) held[id] = 1;
+        std::vector<int> ids;
+        for (int k : nb) for (int id : m_kfs[(size_t)k].landmark) if (id >= 0 && !held.count(id)) { held[id] = 1; ids.push_back(id); }
+        fuseInto(c, f.slot, ids, f, m_stats.fused_added, m_stats.fused_merged);
     }
-    if (m_stereo && m_loopClosure) archiveKeyframe(kf, f);
-    m_keyframes.push_back(std::move(kf));
-    ++m_keyframeCount;
-    while ((int)m_keyframes.size() > m_localWindow) {
-        for (auto& o : m_keyframes.front().obs) {
-            auto it = m_landmarks.find(o.landmark);
-            if (it != m_landmarks.end() && --it->second.n_obs <= 0) m_landmarks.erase(it);
-        }
-        m_keyframes.pop_front();
-    }
+    m_refKf = c;
+    m_refTracked = 0;
+    for (int id : m_kfs[(size_t)c].landmark) m_refTracked += id >= 0;
     m_framesSinceKeyframe = 0;
+    ++m_stats.keyframes;
+    return c;
 }
 
-// motion-only pose optimisation of `cur` against the landmarks seen in the previous frame
 // motion-only pose optimisation ([UPSTREAM] optimize::pose_optimizer) over keypoint <-> landmark associations
-bool HipVslamTrackerBase::poseFromMatches(FrameData& cur, const std::vector<int>& cur_idx, const std::vector<int>& lm_ids, const Pose& init, int& n_inliers)
+bool HipVslamTrackerBase::poseFromMatches(FrameData& cur, const std::vector<int>& cur_idx, const std::vector<int>& lm_ids, const Pose& init, int& n_inliers, int min_inliers)
 {
     n_inliers = 0;
-    float scales[LPSLAM_HIP_MAX_LEVELS];
-    lpslam_hip_level_info(m_ctx, nullptr, nullptr, nullptr, nullptr, scales);
     std::vector<double> pts;
     std::vector<lpslam_hip_ba_obs> obs;
     std::vector<int> kept_idx, kept_lm;
@@ -294,10 +414,10 @@ bool HipVslamTrackerBase::poseFromMatches(FrameData& cur, const std::vector<int>
         auto it = m_landmarks.find(lm_ids[k]);
         if (it == m_landmarks.end()) continue;
         const int i = cur_idx[k];
-        const double s = scales[cur.kpts[i].octave];
+        const double s = m_scales[cur.kpts[(size_t)i].octave];
         lpslam_hip_ba_obs o{};
         o.pose = 0; o.point = (int32_t)kept_idx.size();
-        o.u = cur.kpts[i].x; o.v = cur.kpts[i].y; o.ur = cur.x_right[i] >= 0 ? (double)cur.x_right[i] : -1.0; o.inv_sigma2 = 1.0 / (s * s);
+        o.u = cur.kpts[(size_t)i].x; o.v = cur.kpts[(size_t)i].y; o.ur = cur.x_right[(size_t)i] >= 0 ? (double)cur.x_right[(size_t)i] : -1.0; o.inv_sigma2 = 1.0 / (s * s);
         obs.push_back(o);
         pts.insert(pts.end(), it->second.p, it->second.p + 3);
         kept_idx.push_back(i);
@@ -311,11 +431,46 @@ bool HipVslamTrackerBase::poseFromMatches(FrameData& cur, const std::vector<int>
     // one launch: the whole 4 x 10 iteration flow runs in one workgroup on the device
     if (lpslam_hip_pose_optimize(m_ctx, pose7, pts.data(), (int32_t)kept_idx.size(), obs.data(), (int32_t)obs.size(), &cam, outlier.data(), &inl) != LPSLAM_HIP_OK) return false;
     n_inliers = inl;
-    if (inl < 10) return false;
+    if (inl < min_inliers) return false;
     for (int k = 0; k < 4; ++k) cur.pose.q[k] = pose7[k];
     for (int k = 0; k < 3; ++k) cur.pose.t[k] = pose7[4 + k];
     std::fill(cur.landmark.begin(), cur.landmark.end(), -1);
-    for (size_t k = 0; k < kept_idx.size(); ++k) cur.landmark[kept_idx[k]] = outlier[k] ? -1 : kept_lm[k];   // inliers keep their landmark
+    for (size_t k = 0; k < kept_idx.size(); ++k) cur.landmark[(size_t)kept_idx[k]] = outlier[k] ? -1 : kept_lm[k];   // inliers keep their landmark
+    return true;
+}
+
+// prediction of the current pose: constant velocity from the last two tracked frames; when that is unknown (first frame of a
+// segment, first frame after a loss) the relative motion of the navigation prior, if the host hands one in
+// (src/Trackers/OpenVSLAMStereoTracker.cpp:70-179: odometry forwarded with feed_stereo_frame)
+bool HipVslamTrackerBase::navDelta(Pose& v) const
+{
+    if (!(m_forwardNavState && m_navPrev && m_navCur)) return false;
+    // v = T_nav_cur * T_nav_prev^-1
+    const Mat3 Rc = quatToRot(m_navCur->q), Rp = quatToRot(m_navPrev->q);
+    Mat3 Rv;
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) Rv.m[r * 3 + c] = Rc.m[r * 3] * Rp.m[c * 3] + Rc.m[r * 3 + 1] * Rp.m[c * 3 + 1] + Rc.m[r * 3 + 2] * Rp.m[c * 3 + 2];
+    rotToQuat(Rv, v.q);
+    for (int r = 0; r < 3; ++r) v.t[r] = m_navCur->t[r] - (Rv.m[r * 3] * m_navPrev->t[0] + Rv.m[r * 3 + 1] * m_navPrev->t[1] + Rv.m[r * 3 + 2] * m_navPrev->t[2]);
+    return true;
+}
+
+void HipVslamTrackerBase::movePose(const Pose& v, const Pose& from, Pose& to)        // to = v * from
+{
+    double q[4];
+    quatMul(v.q, from.q, q);
+    const Mat3 Rv = quatToRot(v.q);
+    double t[3];
+    for (int r = 0; r < 3; ++r) t[r] = Rv.m[r * 3] * from.t[0] + Rv.m[r * 3 + 1] * from.t[1] + Rv.m[r * 3 + 2] * from.t[2] + v.t[r];
+    for (int k = 0; k < 4; ++k) to.q[k] = q[k];
+    for (int k = 0; k < 3; ++k) to.t[k] = t[k];
+}
+
+bool HipVslamTrackerBase::predictedPose(Pose& init) const
+{
+    Pose v;
+    if (m_haveVelocity) v = m_velocity;
+    else if (!navDelta(v)) return false;
+    movePose(v, m_prev.pose, init);
     return true;
 }
 
@@ -326,21 +481,17 @@ bool HipVslamTrackerBase::poseFromMatches(FrameData& cur, const std::vector<int>
 bool HipVslamTrackerBase::trackWithMotionModel(FrameData& cur, int& n_inliers)
 {
     n_inliers = 0;
-    if (!m_haveVelocity) return false;
     Pose init;
-    quatMul(m_velocity.q, m_prev.pose.q, init.q);
-    const Mat3 Rv = quatToRot(m_velocity.q);
-    for (int r = 0; r < 3; ++r) init.t[r] = Rv.m[r * 3] * m_prev.pose.t[0] + Rv.m[r * 3 + 1] * m_prev.pose.t[1] + Rv.m[r * 3 + 2] * m_prev.pose.t[2] + m_velocity.t[r];
+    if (!predictedPose(init)) return false;
+    if (!m_haveVelocity) ++m_stats.nav_priors;
     const Mat3 R = quatToRot(init.q);
-    float scales[LPSLAM_HIP_MAX_LEVELS];
-    const int32_t n_levels = m_numLevels;               // (the first array argument of level_info is the widths, not a count)
-    lpslam_hip_level_info(m_ctx, nullptr, nullptr, nullptr, nullptr, scales);
+    const int32_t n_levels = m_numLevels;
     std::vector<lpslam_hip_proj_query> q;
     std::vector<uint8_t> qd;
     std::vector<float> q_angle;
     std::vector<int> q_lm;
     for (size_t i = 0; i < m_prev.kpts.size(); ++i) {
-        const int id = m_prev.landmark[i];
+        const int id = resolve(m_prev.landmark[i]);
         if (id < 0) continue;
         auto it = m_landmarks.find(id);
         if (it == m_landmarks.end()) continue;
@@ -353,10 +504,10 @@ bool HipVslamTrackerBase::trackWithMotionModel(FrameData& cur, int& n_inliers)
         const int lvl = m_prev.kpts[i].octave;
         lpslam_hip_proj_query e{};
         e.x = (float)u; e.y = (float)v; e.x_right = m_stereo ? (float)(u - m_cam.focal_x_baseline / pc[2]) : -1.0f;
-        e.radius = (m_stereo ? 10.0f : 20.0f) * scales[lvl];       // match_current_and_last_frames: margin 10 (stereo) / 20 (monocular)
+        e.radius = (m_stereo ? 10.0f : 20.0f) * m_scales[lvl];       // match_current_and_last_frames: margin 10 (stereo) / 20 (monocular)
         e.min_level = std::max(0, lvl - 1); e.max_level = std::min(n_levels - 1, lvl + 1);
         q.push_back(e);
-        qd.insert(qd.end(), m_prev.desc.begin() + 32 * i, m_prev.desc.begin() + 32 * (i + 1));
+        qd.insert(qd.end(), m_prev.desc.begin() + 32 * (long)i, m_prev.desc.begin() + 32 * (long)(i + 1));
         q_angle.push_back(m_prev.kpts[i].angle);
         q_lm.push_back(id);
     }
@@ -378,15 +529,14 @@ bool HipVslamTrackerBase::trackWithMotionModel(FrameData& cur, int& n_inliers)
     return poseFromMatches(cur, cur_idx, lm_ids, init, n_inliers);
 }
 
-// [UPSTREAM] tracking_module::optimize_current_frame_with_local_map: the landmarks of the local keyframes that the frame does not
-// hold yet are projected with the pose just found and searched in a window of margin x scale factor of the predicted level
-// (match::projection::match_frame_and_landmarks: margin 5 px for stereo, levels [predicted - 1, predicted], Lowe ratio 0.8 between
-// candidates of one level, right-image check); then the motion-only optimiser runs again over all associations.
+// [UPSTREAM] tracking_module::optimize_current_frame_with_local_map: the landmarks of the local keyframes (the reference keyframe
+// and its covisible keyframes) that the frame does not hold yet are projected with the pose just found and searched in a window
+// of margin x scale factor of the predicted level (match::projection::match_frame_and_landmarks: margin 5 px for stereo, levels
+// [predicted - 1, predicted], Lowe ratio 0.8 between candidates of one level, right-image check); then the motion-only optimiser
+// runs again over all associations.
 bool HipVslamTrackerBase::trackLocalMap(FrameData& cur, int& n_inliers)
 {
-    float scales[LPSLAM_HIP_MAX_LEVELS];
-    const int32_t n_levels = m_numLevels;               // (the first array argument of level_info is the widths, not a count)
-    lpslam_hip_level_info(m_ctx, nullptr, nullptr, nullptr, nullptr, scales);
+    const int32_t n_levels = m_numLevels;
     const double log_sf = std::log((double)m_scaleFactor);
     const Mat3 R = quatToRot(cur.pose.q);
     const double C[3] = {-(R.m[0] * cur.pose.t[0] + R.m[3] * cur.pose.t[1] + R.m[6] * cur.pose.t[2]),
@@ -399,11 +549,15 @@ bool HipVslamTrackerBase::trackLocalMap(FrameData& cur, int& n_inliers)
     std::vector<lpslam_hip_proj_query> q;
     std::vector<uint8_t> qd;
     std::vector<int> q_lm;
-    for (auto& kf : m_keyframes) {                       // local landmarks in keyframe / observation order (deterministic)
-        for (auto& o : kf.obs) {
-            if (held.count(o.landmark)) continue;
-            held[o.landmark] = 1;
-            auto it = m_landmarks.find(o.landmark);
+    if (m_refKf < 0) { n_inliers = (int)held_on_entry; return true; }
+    std::vector<int> local = covisible(m_refKf, m_localWindow - 1, 15);
+    local.push_back(m_refKf);
+    std::sort(local.begin(), local.end());
+    for (int kfi : local) {                              // local landmarks in keyframe / keypoint order (deterministic)
+        for (int lid : m_kfs[(size_t)kfi].landmark) {
+            if (lid < 0 || held.count(lid)) continue;
+            held[lid] = 1;
+            auto it = m_landmarks.find(lid);
             if (it == m_landmarks.end()) continue;
             const Landmark& lm = it->second;
             const double* X = lm.p;
@@ -419,11 +573,11 @@ bool HipVslamTrackerBase::trackLocalMap(FrameData& cur, int& n_inliers)
             const int lvl = std::min(std::max((int)std::ceil(std::log(lm.max_valid / dist) / log_sf), 0), n_levels - 1);
             lpslam_hip_proj_query e{};
             e.x = (float)u; e.y = (float)v; e.x_right = m_stereo ? (float)(u - m_cam.focal_x_baseline / pc[2]) : -1.0f;
-            e.radius = 5.0f * scales[lvl];
+            e.radius = 5.0f * m_scales[lvl];
             e.min_level = std::max(0, lvl - 1); e.max_level = lvl;
             q.push_back(e);
             qd.insert(qd.end(), lm.desc, lm.desc + 32);
-            q_lm.push_back(o.landmark);
+            q_lm.push_back(lid);
         }
     }
     if (!q.empty()) {
@@ -431,15 +585,15 @@ bool HipVslamTrackerBase::trackLocalMap(FrameData& cur, int& n_inliers)
         int32_t n_m = 0;
         if (lpslam_hip_match_projection(m_ctx, cur.slot, q.data(), qd.data(), (int32_t)q.size(), 100 /* HAMMING_DIST_THR_HIGH */, 0.8f, taken.data(), m_stereo ? 1 : 0,
                                         idx.data(), dist.data(), &n_m) != LPSLAM_HIP_OK) return false;
-        for (size_t k = 0; k < q.size(); ++k) if (idx[k] >= 0) { cur.landmark[idx[k]] = q_lm[k]; ++n_new; }
+        for (size_t k = 0; k < q.size(); ++k) if (idx[k] >= 0) { cur.landmark[(size_t)idx[k]] = q_lm[k]; ++n_new; }
     }
-    g_local_map_joined += n_new;
+    m_stats.local_map_joined += n_new;
     if (n_new == 0) { n_inliers = (int)held_on_entry; return true; }      // nothing joined: the pose found from the same associations stands
     std::vector<int> cur_idx, lm_ids;
     for (size_t i = 0; i < cur.kpts.size(); ++i) if (cur.landmark[i] >= 0) { cur_idx.push_back((int)i); lm_ids.push_back(cur.landmark[i]); }
     const Pose init = cur.pose;
-    const std::vector<int> before = cur.landmark;
-    for (size_t i = 0; i < cur.kpts.size(); ++i) if (!taken[i]) const_cast<std::vector<int>&>(before)[i] = -1;    // what the frame held on entry
+    std::vector<int> before = cur.landmark;
+    for (size_t i = 0; i < cur.kpts.size(); ++i) if (!taken[i]) before[i] = -1;    // what the frame held on entry
     if (poseFromMatches(cur, cur_idx, lm_ids, init, n_inliers)) return true;
     cur.pose = init; cur.landmark = before;
     return false;
@@ -449,94 +603,162 @@ bool HipVslamTrackerBase::trackAgainstPrevious(FrameData& cur, int& n_inliers)
 {
     // motion model first; descriptor matching against the whole previous frame is the fallback (upstream falls back to
     // BoW / robust matching, frame_tracker::bow_match_based_track / robust_match_based_track)
-    if (trackWithMotionModel(cur, n_inliers)) { ++m_motionTracked; ++g_motion_tracked; return true; }
+    if (trackWithMotionModel(cur, n_inliers)) { ++m_stats.motion_tracked; return true; }
     n_inliers = 0;
     if (lpslam_hip_match_bf(m_ctx, cur.slot, m_prev.slot) != LPSLAM_HIP_OK) return false;
-    std::vector<int32_t> mq(m_maxKp), mt(m_maxKp), md(m_maxKp);
+    std::vector<int32_t> mq((size_t)m_maxKp), mt((size_t)m_maxKp), md((size_t)m_maxKp);
     int32_t nm = 0;
     // HAMMING_DIST_THR_LOW = 50, Lowe ratio 0.9, mutual best
     if (lpslam_hip_get_bf_matches(m_ctx, cur.slot, m_prev.slot, 50, 0.9f, 1, mq.data(), mt.data(), md.data(), m_maxKp, &nm) != LPSLAM_HIP_OK) return false;
     std::vector<int> cur_idx, lm_ids;
     for (int k = 0; k < nm; ++k) {
-        const int id = m_prev.landmark[mt[k]];
+        const int id = resolve(m_prev.landmark[(size_t)mt[k]]);
         if (id < 0) continue;
         cur_idx.push_back(mq[k]); lm_ids.push_back(id);
     }
-    // prediction: constant velocity, else the previous pose
     Pose init = m_prev.pose;
-    if (m_haveVelocity) {
-        quatMul(m_velocity.q, m_prev.pose.q, init.q);
-        const Mat3 Rv = quatToRot(m_velocity.q);
-        for (int r = 0; r < 3; ++r) init.t[r] = Rv.m[r * 3] * m_prev.pose.t[0] + Rv.m[r * 3 + 1] * m_prev.pose.t[1] + Rv.m[r * 3 + 2] * m_prev.pose.t[2] + m_velocity.t[r];
-    }
-    return poseFromMatches(cur, cur_idx, lm_ids, init, n_inliers);
+    (void)predictedPose(init);                           // constant velocity / navigation prior, else the previous pose
+    if (!poseFromMatches(cur, cur_idx, lm_ids, init, n_inliers)) return false;
+    ++m_stats.bf_tracked;
+    return true;
 }
 
-std::unique_ptr<HipVslamTrackerBase::MappingJob> HipVslamTrackerBase::prepareMapping()
+// [UPSTREAM] keyframe_inserter::new_keyframe_is_needed, reduced to what this tracker knows: the interval, too few tracked
+// landmarks in absolute terms or against what the reference keyframe held when it was inserted
+bool HipVslamTrackerBase::keyframeNeeded(int inliers) const
 {
-    if (!m_enableMapping || m_keyframes.size() < 2) return nullptr;
+    if (m_framesSinceKeyframe >= m_keyframeInterval) return true;
+    if (inliers < 50) return true;
+    if (m_refTracked > 0 && inliers < m_refTracked / 4) return true;
+    if (m_framesSinceKeyframe >= std::max(1, m_keyframeInterval / 2) && m_refTracked > 0 && 10 * inliers < 6 * m_refTracked) return true;
+    return false;
+}
+
+// a bundle-adjustment problem over the given keyframes: landmarks seen by the free keyframes, observed at least twice among all
+std::unique_ptr<HipVslamTrackerBase::MappingJob> HipVslamTrackerBase::prepareBundle(const std::vector<int>& free_kfs, const std::vector<int>& fixed_kfs)
+{
     auto job = std::make_unique<MappingJob>();
-    // landmarks observed by at least two keyframes of the window
+    std::vector<int> all = free_kfs;
+    all.insert(all.end(), fixed_kfs.begin(), fixed_kfs.end());
+    std::sort(all.begin(), all.end());
+    std::unordered_map<int, int> kf_index, fixed_set;
+    for (int k : fixed_kfs) fixed_set[k] = 1;
+    for (size_t i = 0; i < all.size(); ++i) kf_index[all[i]] = (int)i;
     std::unordered_map<int, int> seen, index;
-    for (auto& kf : m_keyframes) for (auto& o : kf.obs) seen[o.landmark]++;
-    for (auto& kv : seen) {
-        if (kv.second < 2) continue;
-        auto it = m_landmarks.find(kv.first);
-        if (it == m_landmarks.end()) continue;
-        index[kv.first] = (int)job->ids.size(); job->ids.push_back(kv.first);
-        job->pts.insert(job->pts.end(), it->second.p, it->second.p + 3);
-    }
-    if (job->ids.size() < 20) return nullptr;
-    job->n_keyframes = (int)m_keyframes.size();
-    for (size_t f = 0; f < m_keyframes.size(); ++f) {
-        const Pose& p = m_keyframes[f].pose;
+    std::unordered_map<int, char> of_free;
+    for (int k : free_kfs) for (int id : m_kfs[(size_t)k].landmark) if (id >= 0) of_free[id] = 1;
+    for (int k : all) for (int id : m_kfs[(size_t)k].landmark) if (id >= 0 && of_free.count(id)) seen[id]++;
+    for (int k : all)                                    // point order: first appearance in keyframe / keypoint order
+        for (int id : m_kfs[(size_t)k].landmark) {
+            if (id < 0 || index.count(id)) continue;
+            auto s = seen.find(id);
+            if (s == seen.end() || s->second < 2) continue;
+            auto it = m_landmarks.find(id);
+            if (it == m_landmarks.end()) continue;
+            index[id] = (int)job->ids.size(); job->ids.push_back(id);
+            job->pts.insert(job->pts.end(), it->second.p, it->second.p + 3);
+        }
+    if (job->ids.size() < 20 || all.size() < 2) return nullptr;
+    job->kfs = all;
+    bool any_fixed = false;
+    for (size_t f = 0; f < all.size(); ++f) {
+        const Keyframe& kf = m_kfs[(size_t)all[f]];
+        const Pose& p = kf.pose;
         job->poses.insert(job->poses.end(), {p.q[0], p.q[1], p.q[2], p.q[3], p.t[0], p.t[1], p.t[2]});
-        job->fixed.push_back(f == 0 ? 1 : 0);         // the oldest keyframe anchors the gauge
-        for (size_t k = 0; k < m_keyframes[f].obs.size(); ++k) {
-            const KeyframeObs& o = m_keyframes[f].obs[k];
-            auto it = index.find(o.landmark);
+        bool fx = fixed_set.count(all[f]) != 0;
+        // the first keyframe of a segment anchors the gauge
+        if (all[f] == 0 || m_kfs[(size_t)all[f] - 1].segment != kf.segment) fx = true;
+        job->fixed.push_back(fx ? 1 : 0);
+        any_fixed = any_fixed || fx;
+        for (size_t k = 0; k < kf.landmark.size(); ++k) {
+            if (kf.landmark[k] < 0) continue;
+            auto it = index.find(kf.landmark[k]);
             if (it == index.end()) continue;
-            job->obs.push_back({(int32_t)f, it->second, o.u, o.v, o.ur, o.inv_sigma2});
-            job->origin.emplace_back((int)f, (int)k);
+            const double s = m_scales[kf.kpts[k].octave];
+            const double ur = (!kf.x_right.empty() && kf.x_right[k] >= 0) ? (double)kf.x_right[k] : -1.0;
+            job->obs.push_back({(int32_t)f, it->second, kf.kpts[k].x, kf.kpts[k].y, ur, 1.0 / (s * s)});
+            job->origin.emplace_back(all[f], (int)k);
         }
     }
+    if (!any_fixed) job->fixed[0] = 1;                   // no anchor in the set: the oldest keyframe holds the gauge
     job->outlier.assign(job->obs.size(), 0);
     return job;
+}
+
+std::unique_ptr<HipVslamTrackerBase::MappingJob> HipVslamTrackerBase::prepareMapping(int c)
+{
+    if (!m_enableMapping || m_kfs.size() < 2 || c < 0) return nullptr;
+    // [UPSTREAM] local_bundle_adjuster: the keyframe and its covisible keyframes move, every other keyframe that sees one of
+    // their landmarks is held fixed (here: the localWindow keyframes with the most such observations)
+    std::vector<int> local = covisible(c, m_localWindow - 1, 15);
+    local.push_back(c);
+    std::sort(local.begin(), local.end());
+    std::unordered_map<int, char> is_local;
+    for (int k : local) is_local[k] = 1;
+    std::unordered_map<int, int> cnt;
+    std::unordered_map<int, char> done;
+    for (int k : local)
+        for (int id : m_kfs[(size_t)k].landmark) {
+            if (id < 0 || done.count(id)) continue;
+            done[id] = 1;
+            auto it = m_landmarks.find(id);
+            if (it == m_landmarks.end()) continue;
+            for (auto& o : it->second.obs) if (!is_local.count(o.first)) cnt[o.first]++;
+        }
+    std::vector<std::pair<int, int>> v;
+    for (auto& kv : cnt) v.emplace_back(kv.second, kv.first);
+    std::sort(v.begin(), v.end(), [](const std::pair<int, int>& a, const std::pair<int, int>& b) { return a.first != b.first ? a.first > b.first : a.second > b.second; });
+    if ((int)v.size() > m_localWindow) v.resize((size_t)m_localWindow);
+    std::vector<int> fixed;
+    for (auto& e : v) fixed.push_back(e.second);
+    return prepareBundle(local, fixed);
 }
 
 // runs on the mapping thread: touches the job and the GPU only
 void HipVslamTrackerBase::solveMapping(MappingJob& job) const
 {
-    lpslam_hip_ba_camera cam{m_cam.f_x, m_cam.f_y, m_cam.c_x, m_cam.c_y, m_cam.focal_x_baseline, std::sqrt(5.991), std::sqrt(7.815)};
+    lpslam_hip_ba_camera cam{m_cam.f_x, m_cam.f_y, m_cam.c_x, m_cam.c_y, m_stereo ? m_cam.focal_x_baseline : 0.0, std::sqrt(5.991), std::sqrt(7.815)};
     lpslam_hip_ba* ba = nullptr;
-    if (lpslam_hip_ba_create(m_ctx, job.poses.data(), job.fixed.data(), job.n_keyframes, job.pts.data(), (int32_t)job.ids.size(), job.obs.data(),
+    if (lpslam_hip_ba_create(m_ctx, job.poses.data(), job.fixed.data(), (int32_t)job.kfs.size(), job.pts.data(), (int32_t)job.ids.size(), job.obs.data(),
                              (int32_t)job.obs.size(), &cam, &ba) != LPSLAM_HIP_OK) return;
-    job.solved = lpslam_hip_ba_local(ba, 5, 10, job.outlier.data()) == LPSLAM_HIP_OK &&
-                 lpslam_hip_ba_get(ba, job.poses.data(), job.pts.data()) == LPSLAM_HIP_OK;
+    if (job.global) {
+        int32_t done = 0;
+        job.solved = lpslam_hip_ba_optimize(ba, 1, 10, nullptr, &done) == LPSLAM_HIP_OK && lpslam_hip_ba_get(ba, job.poses.data(), job.pts.data()) == LPSLAM_HIP_OK;
+    } else {
+        job.solved = lpslam_hip_ba_local(ba, 5, 10, job.outlier.data()) == LPSLAM_HIP_OK &&
+                     lpslam_hip_ba_get(ba, job.poses.data(), job.pts.data()) == LPSLAM_HIP_OK;
+    }
     lpslam_hip_ba_destroy(ba);
 }
 
 void HipVslamTrackerBase::applyMapping(const MappingJob& job)
 {
-    if (!job.solved || job.n_keyframes != (int)m_keyframes.size()) return;
-    for (size_t f = 0; f < m_keyframes.size(); ++f) {
-        for (int k = 0; k < 4; ++k) m_keyframes[f].pose.q[k] = job.poses[7 * f + k];
-        for (int k = 0; k < 3; ++k) m_keyframes[f].pose.t[k] = job.poses[7 * f + 4 + k];
-        const long ai = m_keyframes[f].archive_index;
-        if (ai >= 0 && (size_t)ai < m_archive.size()) m_archive[(size_t)ai].pose = m_keyframes[f].pose;
+    if (!job.solved) return;
+    for (size_t f = 0; f < job.kfs.size(); ++f) {
+        if (job.fixed[f]) continue;
+        Pose& p = m_kfs[(size_t)job.kfs[f]].pose;
+        for (int k = 0; k < 4; ++k) p.q[k] = job.poses[7 * f + (size_t)k];
+        for (int k = 0; k < 3; ++k) p.t[k] = job.poses[7 * f + 4 + (size_t)k];
     }
     for (size_t j = 0; j < job.ids.size(); ++j) {
-        auto it = m_landmarks.find(job.ids[j]);
+        auto it = m_landmarks.find(resolve(job.ids[j]));
         if (it != m_landmarks.end()) { it->second.p[0] = job.pts[3 * j]; it->second.p[1] = job.pts[3 * j + 1]; it->second.p[2] = job.pts[3 * j + 2]; }
     }
-    // erase outlier observations (back to front so indices stay valid)
-    for (size_t k = job.obs.size(); k-- > 0;) {
+    // outlier observations leave the map ([UPSTREAM] local_bundle_adjuster: erase_observation on both sides)
+    for (size_t k = 0; k < job.obs.size(); ++k) {
         if (!job.outlier[k]) continue;
-        auto& v = m_keyframes[job.origin[k].first].obs;
-        auto it = m_landmarks.find(v[job.origin[k].second].landmark);
-        if (it != m_landmarks.end() && --it->second.n_obs <= 0) m_landmarks.erase(it);
-        v.erase(v.begin() + job.origin[k].second);
+        Keyframe& kf = m_kfs[(size_t)job.origin[k].first];
+        const int kp = job.origin[k].second;
+        const int id = kf.landmark[(size_t)kp];
+        if (id < 0 || id != resolve(job.ids[(size_t)job.obs[k].point])) continue;        // changed since the problem was copied
+        kf.landmark[(size_t)kp] = -1;
+        auto it = m_landmarks.find(id);
+        if (it == m_landmarks.end()) continue;
+        auto& ob = it->second.obs;
+        for (size_t o = 0; o < ob.size(); ++o) if (ob[o].first == job.origin[k].first && ob[o].second == kp) { ob.erase(ob.begin() + (long)o); break; }
+        if (ob.empty()) m_landmarks.erase(it);
     }
+    ++m_stats.local_ba;
 }
 
 // ---- monocular initialisation ([UPSTREAM] module::initializer::initialize for Monocular setups) ---------------------------------
@@ -552,7 +774,7 @@ bool HipVslamTrackerBase::monoInitialize(FrameData& cur)
         if (n_cur < 100) return false;
         m_monoRef = cur; m_haveMonoRef = true;
         m_monoPrevMatched.resize(2 * (size_t)n_cur);
-        for (int i = 0; i < n_cur; ++i) { m_monoPrevMatched[2 * i] = cur.kpts[i].x; m_monoPrevMatched[2 * i + 1] = cur.kpts[i].y; }
+        for (int i = 0; i < n_cur; ++i) { m_monoPrevMatched[2 * (size_t)i] = cur.kpts[(size_t)i].x; m_monoPrevMatched[2 * (size_t)i + 1] = cur.kpts[(size_t)i].y; }
         return false;
     }
     if (n_cur < 100) { m_haveMonoRef = false; return false; }
@@ -567,7 +789,7 @@ bool HipVslamTrackerBase::monoInitialize(FrameData& cur)
         e.x = m_monoPrevMatched[2 * i]; e.y = m_monoPrevMatched[2 * i + 1]; e.x_right = -1.0f; e.radius = 100.0f;
         e.min_level = 0; e.max_level = 0;
         q.push_back(e);
-        qd.insert(qd.end(), ref.desc.begin() + 32 * i, ref.desc.begin() + 32 * (i + 1));
+        qd.insert(qd.end(), ref.desc.begin() + 32 * (long)i, ref.desc.begin() + 32 * (long)(i + 1));
         q_ref.push_back((int)i); q_angle.push_back(ref.kpts[i].angle);
     }
     if (q.size() < 100) { m_haveMonoRef = false; return false; }
@@ -582,7 +804,7 @@ bool HipVslamTrackerBase::monoInitialize(FrameData& cur)
     for (size_t k = 0; k < q.size(); ++k) {
         if (idx[k] < 0) continue;
         matches.push_back(q_ref[k]); matches.push_back(idx[k]);
-        m_monoPrevMatched[2 * (size_t)q_ref[k]] = cur.kpts[idx[k]].x; m_monoPrevMatched[2 * (size_t)q_ref[k] + 1] = cur.kpts[idx[k]].y;
+        m_monoPrevMatched[2 * (size_t)q_ref[k]] = cur.kpts[(size_t)idx[k]].x; m_monoPrevMatched[2 * (size_t)q_ref[k] + 1] = cur.kpts[(size_t)idx[k]].y;
     }
     std::vector<float> kr(2 * ref.kpts.size()), kc(2 * cur.kpts.size());
     for (size_t i = 0; i < ref.kpts.size(); ++i) { kr[2 * i] = ref.kpts[i].x; kr[2 * i + 1] = ref.kpts[i].y; }
@@ -592,16 +814,17 @@ bool HipVslamTrackerBase::monoInitialize(FrameData& cur)
     TwoViewResult tv;
     if (!two_view_initialize(K, kr.data(), kc.data(), matches.data(), (int)(matches.size() / 2), prm, tv)) return false;
 
-    // ---- the initial map: reference keyframe at the origin, current keyframe at (R, t), scale: median depth in the reference = 1
+    // ---- the initial map: reference keyframe at the last good pose (the origin for the first segment), current keyframe at (R, t)
+    // relative to it, scale: median depth in the reference = 1
     std::vector<double> depths;
     for (size_t m = 0; m < tv.triangulated.size(); ++m) if (tv.triangulated[m]) depths.push_back(tv.points[3 * m + 2]);
     if (depths.size() < 50) return false;
-    std::nth_element(depths.begin(), depths.begin() + depths.size() / 2, depths.end());
+    std::nth_element(depths.begin(), depths.begin() + (long)(depths.size() / 2), depths.end());
     const double median = depths[depths.size() / 2];
     if (!(median > 0)) return false;
     const double inv = 1.0 / median;
-    if (m_mapThread.joinable()) finishMapping();
-    m_landmarks.clear(); m_keyframes.clear(); m_nextLandmarkId = 0;
+    finishMapping();
+    m_segmentStart = (int)m_kfs.size();
     FrameData reff = ref;
     reff.pose = Pose();
     reff.landmark.assign(reff.kpts.size(), -1);
@@ -609,39 +832,36 @@ bool HipVslamTrackerBase::monoInitialize(FrameData& cur)
     rotToQuat(Rm, cur.pose.q);
     for (int a = 0; a < 3; ++a) cur.pose.t[a] = tv.t[a] * inv;
     cur.landmark.assign(cur.kpts.size(), -1);
-    float scales[LPSLAM_HIP_MAX_LEVELS];
-    lpslam_hip_level_info(m_ctx, nullptr, nullptr, nullptr, nullptr, scales);
     Keyframe k0, k1;
-    k0.pose = reff.pose; k1.pose = cur.pose;
+    const int i0 = m_segmentStart, i1 = m_segmentStart + 1;
+    k0.pose = reff.pose; k1.pose = cur.pose; k0.segment = k1.segment = m_segment;
     for (size_t m = 0; m < tv.triangulated.size(); ++m) {
         if (!tv.triangulated[m]) continue;
         const int ir = matches[2 * m], ic = matches[2 * m + 1];
         Landmark lm;
-        for (int a = 0; a < 3; ++a) lm.p[a] = tv.points[3 * m + a] * inv;
-        initLandmarkView(lm, reff.pose, reff.kpts[ir], reff.desc.data() + 32 * (size_t)ir);
-        lm.n_obs = 2;
+        for (int a = 0; a < 3; ++a) lm.p[a] = tv.points[3 * m + (size_t)a] * inv;
+        initLandmarkView(lm, reff.pose, reff.kpts[(size_t)ir], reff.desc.data() + 32 * (size_t)ir);
+        lm.ref_kf = i0;
+        lm.obs.emplace_back(i0, ir); lm.obs.emplace_back(i1, ic);
         const int id = m_nextLandmarkId++;
-        m_landmarks[id] = lm;
-        reff.landmark[ir] = id; cur.landmark[ic] = id;
-        const double s0 = scales[reff.kpts[ir].octave], s1 = scales[cur.kpts[ic].octave];
-        k0.obs.push_back({id, reff.kpts[ir].x, reff.kpts[ir].y, -1.0, 1.0 / (s0 * s0)});
-        k1.obs.push_back({id, cur.kpts[ic].x, cur.kpts[ic].y, -1.0, 1.0 / (s1 * s1)});
+        m_landmarks[id] = std::move(lm);
+        reff.landmark[(size_t)ir] = id; cur.landmark[(size_t)ic] = id;
     }
-    k0.kpts = reff.kpts; k0.desc = reff.desc; k0.landmark = reff.landmark;
-    k1.kpts = cur.kpts; k1.desc = cur.desc; k1.landmark = cur.landmark;
-    m_keyframes.push_back(std::move(k0)); m_keyframes.push_back(std::move(k1));
-    m_keyframeCount += 2;
+    k0.kpts = reff.kpts; k0.desc = reff.desc; k0.landmark = reff.landmark; k0.x_right.assign(reff.kpts.size(), -1.0f); k0.depth.assign(reff.kpts.size(), -1.0f);
+    k1.kpts = cur.kpts; k1.desc = cur.desc; k1.landmark = cur.landmark; k1.x_right.assign(cur.kpts.size(), -1.0f); k1.depth.assign(cur.kpts.size(), -1.0f);
+    m_kfs.push_back(std::move(k0)); m_kfs.push_back(std::move(k1));
+    m_stats.keyframes += 2;
     m_framesSinceKeyframe = 0;
+    m_refKf = i1;
+    m_refTracked = 0;
+    for (int id : m_kfs[(size_t)i1].landmark) m_refTracked += id >= 0;
     // global bundle adjustment of the two-keyframe map (20 iterations, Huber), inline: nothing can be tracked before it
     {
-        const bool keep_async = m_asyncMapping;
-        m_asyncMapping = false;
-        auto job = prepareMapping();
-        m_asyncMapping = keep_async;
+        auto job = prepareBundle({i0, i1}, {});
         if (job) {
             lpslam_hip_ba_camera cam{m_cam.f_x, m_cam.f_y, m_cam.c_x, m_cam.c_y, 0.0, std::sqrt(5.991), std::sqrt(7.815)};
             lpslam_hip_ba* ba = nullptr;
-            if (lpslam_hip_ba_create(m_ctx, job->poses.data(), job->fixed.data(), job->n_keyframes, job->pts.data(), (int32_t)job->ids.size(), job->obs.data(),
+            if (lpslam_hip_ba_create(m_ctx, job->poses.data(), job->fixed.data(), (int32_t)job->kfs.size(), job->pts.data(), (int32_t)job->ids.size(), job->obs.data(),
                                      (int32_t)job->obs.size(), &cam, &ba) == LPSLAM_HIP_OK) {
                 int32_t done = 0;
                 job->solved = lpslam_hip_ba_optimize(ba, 1, 20, nullptr, &done) == LPSLAM_HIP_OK && lpslam_hip_ba_get(ba, job->poses.data(), job->pts.data()) == LPSLAM_HIP_OK;
@@ -650,31 +870,34 @@ bool HipVslamTrackerBase::monoInitialize(FrameData& cur)
             }
         }
     }
-    cur.pose = m_keyframes.back().pose;
+    cur.pose = m_kfs.back().pose;
     m_haveMonoRef = false;
-    logMessage(LpSlamLogLevel_Info, "VSLAM monocular map initialised: " + std::to_string(m_landmarks.size()) + " landmarks, model " + (tv.model == 0 ? "H" : "F"));
-    return m_landmarks.size() >= 50;
+    size_t n_seg = 0;
+    for (int id : m_kfs[(size_t)i1].landmark) n_seg += id >= 0;
+    logMessage(LpSlamLogLevel_Info, "VSLAM monocular map initialised: " + std::to_string(n_seg) + " landmarks, model " + (tv.model == 0 ? "H" : "F"));
+    return n_seg >= 50;
 }
 
 // New landmarks for a monocular keyframe: keypoints without a landmark are matched by descriptor against the previous keyframe's
 // (brute force on the device, mutual best, ratio 0.8), kept when they satisfy the epipolar constraint of the two poses, and
 // triangulated; the checks are upstream's (positive depth in both views, reprojection chi2 <= 5.991 per view, parallax, scale
-// consistency of the distances with the pyramid levels).
-void HipVslamTrackerBase::monoTriangulate(Keyframe& prev, Keyframe& kf, FrameData& f)
+// consistency of the distances with the pyramid levels).  `kf` is the keyframe being inserted (id = m_kfs.size()).
+void HipVslamTrackerBase::monoTriangulate(int prev_kf, Keyframe& kf, FrameData& f)
 {
+    Keyframe& prev = m_kfs[(size_t)prev_kf];
+    const int c = (int)m_kfs.size();
     if (prev.kpts.empty() || f.kpts.empty()) return;
     const int scratch = f.slot ^ 1;                      // monocular frames use slots 0 / 2
     if (lpslam_hip_set_descriptors(m_ctx, scratch, prev.desc.data(), (int32_t)prev.kpts.size()) != LPSLAM_HIP_OK) return;
     if (lpslam_hip_match_bf(m_ctx, f.slot, scratch) != LPSLAM_HIP_OK) return;
-    std::vector<int32_t> mq(m_maxKp), mt(m_maxKp), md(m_maxKp);
+    std::vector<int32_t> mq((size_t)m_maxKp), mt((size_t)m_maxKp), md((size_t)m_maxKp);
     int32_t nm = 0;
     if (lpslam_hip_get_bf_matches(m_ctx, f.slot, scratch, 50, 0.8f, 1, mq.data(), mt.data(), md.data(), m_maxKp, &nm) != LPSLAM_HIP_OK) return;
-    float scales[LPSLAM_HIP_MAX_LEVELS];
-    lpslam_hip_level_info(m_ctx, nullptr, nullptr, nullptr, nullptr, scales);
+    const float* scales = m_scales;
     const double fx = m_cam.f_x, fy = m_cam.f_y, cx = m_cam.c_x, cy = m_cam.c_y;
     const Mat3 R1 = quatToRot(prev.pose.q), R2 = quatToRot(f.pose.q);
     auto proj = [&](const Mat3& R, const double* t, double* P) {
-        for (int c = 0; c < 3; ++c) { P[c] = fx * R.m[c] + cx * R.m[6 + c]; P[4 + c] = fy * R.m[3 + c] + cy * R.m[6 + c]; P[8 + c] = R.m[6 + c]; }
+        for (int c2 = 0; c2 < 3; ++c2) { P[c2] = fx * R.m[c2] + cx * R.m[6 + c2]; P[4 + c2] = fy * R.m[3 + c2] + cy * R.m[6 + c2]; P[8 + c2] = R.m[6 + c2]; }
         P[3] = fx * t[0] + cx * t[2]; P[7] = fy * t[1] + cy * t[2]; P[11] = t[2];
     };
     double P1[12], P2[12];
@@ -684,16 +907,15 @@ void HipVslamTrackerBase::monoTriangulate(Keyframe& prev, Keyframe& kf, FrameDat
     centre(R1, prev.pose.t, C1); centre(R2, f.pose.t, C2);
     // relative pose prev -> cur and the fundamental matrix x2^T F x1 = 0
     double R21[9], t21[3];
-    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) R21[r * 3 + c] = R2.m[r * 3] * R1.m[c * 3] + R2.m[r * 3 + 1] * R1.m[c * 3 + 1] + R2.m[r * 3 + 2] * R1.m[c * 3 + 2];
+    for (int r = 0; r < 3; ++r) for (int c2 = 0; c2 < 3; ++c2) R21[r * 3 + c2] = R2.m[r * 3] * R1.m[c2 * 3] + R2.m[r * 3 + 1] * R1.m[c2 * 3 + 1] + R2.m[r * 3 + 2] * R1.m[c2 * 3 + 2];
     for (int r = 0; r < 3; ++r) t21[r] = f.pose.t[r] - (R21[r * 3] * prev.pose.t[0] + R21[r * 3 + 1] * prev.pose.t[1] + R21[r * 3 + 2] * prev.pose.t[2]);
     const double tx[9] = {0, -t21[2], t21[1], t21[2], 0, -t21[0], -t21[1], t21[0], 0};
     double E[9];
-    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) E[r * 3 + c] = tx[r * 3] * R21[c] + tx[r * 3 + 1] * R21[3 + c] + tx[r * 3 + 2] * R21[6 + c];
+    for (int r = 0; r < 3; ++r) for (int c2 = 0; c2 < 3; ++c2) E[r * 3 + c2] = tx[r * 3] * R21[c2] + tx[r * 3 + 1] * R21[3 + c2] + tx[r * 3 + 2] * R21[6 + c2];
     const double ratio_factor = 1.5 * m_scaleFactor;
-    int created = 0;
     for (int k = 0; k < nm; ++k) {
         const int ic = mq[k], ip = mt[k];
-        if (f.landmark[ic] >= 0 || prev.landmark[(size_t)ip] >= 0) continue;
+        if (f.landmark[(size_t)ic] >= 0 || prev.landmark[(size_t)ip] >= 0) continue;
         const lpslam_hip_keypoint& k1 = prev.kpts[(size_t)ip]; const lpslam_hip_keypoint& k2 = f.kpts[(size_t)ic];
         const double x1n[3] = {(k1.x - cx) / fx, (k1.y - cy) / fy, 1.0}, x2n[3] = {(k2.x - cx) / fx, (k2.y - cy) / fy, 1.0};
         // epipolar line of x1 in the current image (normalised coordinates -> pixels: a / fx, b / fy)
@@ -728,38 +950,13 @@ void HipVslamTrackerBase::monoTriangulate(Keyframe& prev, Keyframe& kf, FrameDat
         Landmark lm;
         lm.p[0] = X[0]; lm.p[1] = X[1]; lm.p[2] = X[2];
         initLandmarkView(lm, f.pose, k2, f.desc.data() + 32 * (size_t)ic);
-        lm.n_obs = 2;
+        lm.ref_kf = c;
+        lm.obs.emplace_back(prev_kf, ip); lm.obs.emplace_back(c, ic);
         const int id = m_nextLandmarkId++;
-        m_landmarks[id] = lm;
-        f.landmark[ic] = id; prev.landmark[(size_t)ip] = id;
-        prev.obs.push_back({id, k1.x, k1.y, -1.0, 1.0 / s1});
-        kf.obs.push_back({id, k2.x, k2.y, -1.0, 1.0 / s2});
-        ++created;
+        m_landmarks[id] = std::move(lm);
+        f.landmark[(size_t)ic] = id; prev.landmark[(size_t)ip] = id;
     }
-    (void)created;
-}
-
-// ---- loop closing ([UPSTREAM] module::loop_detector + loop_bundle_adjuster's pose-graph stage, global_optimization_module) -----
-// Candidates: archived keyframes that are old enough and whose camera centre lies near the current estimate (the vocabulary of
-// the reference is replaced by position gating + brute-force descriptor matching on the device).  A candidate's mutual matches
-// with landmarks on both sides feed the Sim3 optimiser of the loop detector (lpslam_hip_sim3_transform_optimize, scale fixed for
-// stereo); with >= 20 inliers the loop is closed: pose graph over the keyframes of the loop (consecutive edges + the loop edge,
-// lpslam_hip_sim3_optimize, 50 iterations), landmarks move with the keyframe that created them.
-void HipVslamTrackerBase::archiveKeyframe(Keyframe& kf, const FrameData& f)
-{
-    ArchivedKeyframe a;
-    a.pose = kf.pose; a.kpts = f.kpts; a.desc = f.desc;
-    a.pc.assign(3 * f.kpts.size(), std::numeric_limits<double>::quiet_NaN());
-    const Mat3 R = quatToRot(kf.pose.q);
-    for (size_t i = 0; i < f.kpts.size(); ++i) {
-        if (f.landmark[i] < 0) continue;
-        auto it = m_landmarks.find(f.landmark[i]);
-        if (it == m_landmarks.end()) continue;
-        const double* X = it->second.p;
-        for (int r = 0; r < 3; ++r) a.pc[3 * i + r] = R.m[r * 3] * X[0] + R.m[r * 3 + 1] * X[1] + R.m[r * 3 + 2] * X[2] + kf.pose.t[r];
-    }
-    kf.archive_index = (long)m_archive.size();
-    m_archive.push_back(std::move(a));
+    (void)kf;
 }
 
 namespace {
@@ -781,84 +978,151 @@ Se3 se3_inv(const Se3& a)
     for (int r = 0; r < 3; ++r) o.t[r] = -(R.m[r] * a.t[0] + R.m[3 + r] * a.t[1] + R.m[6 + r] * a.t[2]);
     return o;
 }
+void pose_centre(const double* q, const double* t, double* C)
+{
+    const Mat3 R = quatToRot(q);
+    for (int a = 0; a < 3; ++a) C[a] = -(R.m[a] * t[0] + R.m[3 + a] * t[1] + R.m[6 + a] * t[2]);
+}
 }  // namespace
 
-bool HipVslamTrackerBase::detectAndCloseLoop(FrameData& cur)
+// ---- relocalisation ([UPSTREAM] module::relocalizer, reached while the tracker state is Lost) -----------------------------------
+// Candidates: the keyframes nearest to the last pose that was tracked (the reference picks them from the BoW database; with
+// relocWithNavigation the navigation prior moves that pose along).  Each candidate's descriptors are matched against the frame
+// on the device (mutual best, Hamming <= 50, ratio 0.75); the matched keypoints' landmarks and the candidate's pose start the
+// motion-only optimiser, and 30 inliers bring the tracker back.
+bool HipVslamTrackerBase::relocalise(FrameData& cur)
 {
-    const long cur_ai = m_keyframes.back().archive_index;
-    if (cur_ai < 0) return false;
-    const long newest_candidate = cur_ai - 2L * m_localWindow;          // well outside the local window
-    if (newest_candidate < 0) return false;
-    const ArchivedKeyframe& ca = m_archive[(size_t)cur_ai];
-    auto centre = [](const Pose& p, double* C) { const Mat3 R = quatToRot(p.q); for (int a = 0; a < 3; ++a) C[a] = -(R.m[a] * p.t[0] + R.m[3 + a] * p.t[1] + R.m[6 + a] * p.t[2]); };
-    double Cc[3];
-    centre(ca.pose, Cc);
-    const double radius = 10.0 * m_cam.focal_x_baseline / m_cam.f_x + 1.0;              // metres: ten baselines + 1
-    std::vector<std::pair<double, long>> near;
-    for (long a = 0; a <= newest_candidate; ++a) {
+    if (m_kfs.empty()) return false;
+    double Cl[3];
+    pose_centre(m_lastGoodPose.q, m_lastGoodPose.t, Cl);
+    std::vector<std::pair<double, int>> near;
+    for (size_t k = 0; k < m_kfs.size(); ++k) {
         double C[3];
-        centre(m_archive[(size_t)a].pose, C);
-        const double d = std::sqrt((C[0] - Cc[0]) * (C[0] - Cc[0]) + (C[1] - Cc[1]) * (C[1] - Cc[1]) + (C[2] - Cc[2]) * (C[2] - Cc[2]));
-        if (d < radius) near.emplace_back(d, a);
+        pose_centre(m_kfs[k].pose.q, m_kfs[k].pose.t, C);
+        near.emplace_back(std::sqrt((C[0] - Cl[0]) * (C[0] - Cl[0]) + (C[1] - Cl[1]) * (C[1] - Cl[1]) + (C[2] - Cl[2]) * (C[2] - Cl[2])), (int)k);
     }
-    if (near.empty()) return false;
     std::sort(near.begin(), near.end());
-    if (near.size() > 3) near.resize(3);
-    float scales[LPSLAM_HIP_MAX_LEVELS];
-    lpslam_hip_level_info(m_ctx, nullptr, nullptr, nullptr, nullptr, scales);
-    const int scratch = cur.slot ^ 2;                  // the previous frame's slot pair is free for the descriptors of a candidate ...
-    std::vector<lpslam_hip_sim3_pair> pairs;
-    std::vector<int32_t> start{0};
-    std::vector<double> s12;
-    std::vector<long> cand;
-    std::vector<int32_t> mq(m_maxKp), mt(m_maxKp), md(m_maxKp);
-    const Se3 Tc{{ca.pose.q[0], ca.pose.q[1], ca.pose.q[2], ca.pose.q[3]}, {ca.pose.t[0], ca.pose.t[1], ca.pose.t[2]}};
+    if (near.size() > 8) near.resize(8);
+    const int scratch = cur.slot ^ 2;                    // the previous frame's slot pair: its device data is not needed while lost
+    std::vector<int32_t> mq((size_t)m_maxKp), mt((size_t)m_maxKp), md((size_t)m_maxKp);
     for (auto& nc : near) {
-        const ArchivedKeyframe& ka = m_archive[(size_t)nc.second];
+        const Keyframe& kf = m_kfs[(size_t)nc.second];
+        if (kf.kpts.empty()) continue;
+        if (lpslam_hip_set_descriptors(m_ctx, scratch, kf.desc.data(), (int32_t)kf.kpts.size()) != LPSLAM_HIP_OK) continue;
+        if (lpslam_hip_match_bf(m_ctx, cur.slot, scratch) != LPSLAM_HIP_OK) continue;
+        int32_t nm = 0;
+        if (lpslam_hip_get_bf_matches(m_ctx, cur.slot, scratch, 50, 0.75f, 1, mq.data(), mt.data(), md.data(), m_maxKp, &nm) != LPSLAM_HIP_OK) continue;
+        std::vector<int> cur_idx, lm_ids;
+        for (int k = 0; k < nm; ++k) {
+            const int id = resolve(kf.landmark[(size_t)mt[k]]);
+            if (id < 0) continue;
+            cur_idx.push_back(mq[k]); lm_ids.push_back(id);
+        }
+        if (cur_idx.size() < 15) continue;
+        int inl = 0;
+        FrameData trial = cur;
+        if (!poseFromMatches(trial, cur_idx, lm_ids, kf.pose, inl, 30)) continue;
+        cur.pose = trial.pose; cur.landmark = trial.landmark;
+        logMessage(LpSlamLogLevel_Info, "VSLAM relocalised against keyframe " + std::to_string(nc.second) + " with " + std::to_string(inl) + " inliers");
+        return true;
+    }
+    return false;
+}
+
+// ---- loop closing ([UPSTREAM] module::loop_detector + loop_bundle_adjuster, global_optimization_module) -------------------------
+// Candidates: keyframes well outside the covisibility of the new keyframe, chosen by descriptor voting -- every candidate's
+// descriptors are matched against the keyframe's on the device (mutual best, Hamming <= 50, ratio 0.75) and the three with the
+// most matches that carry landmarks on both sides go on (the reference asks its DBoW2 vocabulary, which is absent; when the map
+// holds more than 48 such keyframes only the 48 nearest to the current estimate are asked).  The Sim3 optimiser of the loop
+// detector verifies a candidate (>= 20 inliers, scale fixed for stereo); the loop is closed by the Sim3 pose graph over the
+// keyframes in between (consecutive edges + the loop edge, 50 iterations), landmarks move with the keyframe that created them,
+// the candidate's landmarks are fused into the new keyframe (duplicates of the revisited structure merge), and a global bundle
+// adjustment over the keyframes of the loop (10 iterations, the candidate fixed) refines the result.
+bool HipVslamTrackerBase::detectAndCloseLoop(FrameData& cur, int c)
+{
+    const int newest_candidate = c - 2 * m_localWindow;                 // well outside the local window
+    if (newest_candidate < 0) return false;
+    const Keyframe& kc = m_kfs[(size_t)c];
+    std::unordered_map<int, char> covis;
+    for (int k : covisible(c, (int)m_kfs.size(), 15)) covis[k] = 1;      // the covisibility graph's neighbours (edges of weight >= 15) are no loop
+    double Cc[3];
+    pose_centre(kc.pose.q, kc.pose.t, Cc);
+    std::vector<std::pair<double, int>> cands;
+    for (int a = 0; a <= newest_candidate; ++a) {
+        if (covis.count(a)) continue;
+        double C[3];
+        pose_centre(m_kfs[(size_t)a].pose.q, m_kfs[(size_t)a].pose.t, C);
+        cands.emplace_back(std::sqrt((C[0] - Cc[0]) * (C[0] - Cc[0]) + (C[1] - Cc[1]) * (C[1] - Cc[1]) + (C[2] - Cc[2]) * (C[2] - Cc[2])), a);
+    }
+    if (cands.empty()) return false;
+    std::sort(cands.begin(), cands.end());
+    if (cands.size() > 48) cands.resize(48);
+    const int scratch = cur.slot ^ 2;                  // the previous frame's slot pair is free for the descriptors of a candidate
+    std::vector<int32_t> mq((size_t)m_maxKp), mt((size_t)m_maxKp), md((size_t)m_maxKp);
+    struct Vote { int kf; std::vector<std::pair<int, int>> pairs; };        // (keypoint of c, keypoint of the candidate), landmarks on both sides
+    std::vector<Vote> votes;
+    for (auto& cd : cands) {
+        const Keyframe& ka = m_kfs[(size_t)cd.second];
+        if (ka.kpts.empty()) continue;
         if (lpslam_hip_set_descriptors(m_ctx, scratch, ka.desc.data(), (int32_t)ka.kpts.size()) != LPSLAM_HIP_OK) continue;
         if (lpslam_hip_match_bf(m_ctx, cur.slot, scratch) != LPSLAM_HIP_OK) continue;
         int32_t nm = 0;
         if (lpslam_hip_get_bf_matches(m_ctx, cur.slot, scratch, 50, 0.75f, 1, mq.data(), mt.data(), md.data(), m_maxKp, &nm) != LPSLAM_HIP_OK) continue;
-        const size_t first = pairs.size();
-        for (int k = 0; k < nm; ++k) {
-            const size_t ic = (size_t)mq[k], ia = (size_t)mt[k];
-            if (!std::isfinite(ca.pc[3 * ic]) || !std::isfinite(ka.pc[3 * ia])) continue;
+        Vote v; v.kf = cd.second;
+        for (int k = 0; k < nm; ++k)
+            if (kc.landmark[(size_t)mq[k]] >= 0 && ka.landmark[(size_t)mt[k]] >= 0 && resolve(kc.landmark[(size_t)mq[k]]) != resolve(ka.landmark[(size_t)mt[k]])) v.pairs.emplace_back(mq[k], mt[k]);
+        if (v.pairs.size() >= 20) votes.push_back(std::move(v));         // [UPSTREAM] num_matches >= 20 to try a candidate
+    }
+    if (votes.empty()) return false;
+    std::sort(votes.begin(), votes.end(), [](const Vote& a, const Vote& b) { return a.pairs.size() != b.pairs.size() ? a.pairs.size() > b.pairs.size() : a.kf > b.kf; });
+    if (votes.size() > 3) votes.resize(3);
+    std::vector<lpslam_hip_sim3_pair> pairs;
+    std::vector<int32_t> start{0};
+    std::vector<double> s12;
+    const Se3 Tc{{kc.pose.q[0], kc.pose.q[1], kc.pose.q[2], kc.pose.q[3]}, {kc.pose.t[0], kc.pose.t[1], kc.pose.t[2]}};
+    const Mat3 Rc = quatToRot(kc.pose.q);
+    for (auto& v : votes) {
+        const Keyframe& ka = m_kfs[(size_t)v.kf];
+        const Mat3 Ra = quatToRot(ka.pose.q);
+        for (auto& pr2 : v.pairs) {
+            const size_t ic = (size_t)pr2.first, ia = (size_t)pr2.second;
+            const Landmark& lc = m_landmarks.at(resolve(kc.landmark[ic]));
+            const Landmark& la = m_landmarks.at(resolve(ka.landmark[ia]));
             lpslam_hip_sim3_pair pr{};
-            for (int r = 0; r < 3; ++r) { pr.p1c[r] = ca.pc[3 * ic + r]; pr.p2c[r] = ka.pc[3 * ia + r]; }
-            pr.obs1[0] = ca.kpts[ic].x; pr.obs1[1] = ca.kpts[ic].y; pr.obs2[0] = ka.kpts[ia].x; pr.obs2[1] = ka.kpts[ia].y;
-            const double s1 = scales[ca.kpts[ic].octave], s2 = scales[ka.kpts[ia].octave];
+            for (int r = 0; r < 3; ++r) {
+                pr.p1c[r] = Rc.m[r * 3] * lc.p[0] + Rc.m[r * 3 + 1] * lc.p[1] + Rc.m[r * 3 + 2] * lc.p[2] + kc.pose.t[r];
+                pr.p2c[r] = Ra.m[r * 3] * la.p[0] + Ra.m[r * 3 + 1] * la.p[1] + Ra.m[r * 3 + 2] * la.p[2] + ka.pose.t[r];
+            }
+            pr.obs1[0] = kc.kpts[ic].x; pr.obs1[1] = kc.kpts[ic].y; pr.obs2[0] = ka.kpts[ia].x; pr.obs2[1] = ka.kpts[ia].y;
+            const double s1 = m_scales[kc.kpts[ic].octave], s2 = m_scales[ka.kpts[ia].octave];
             pr.inv_sigma2_1 = 1.0 / (s1 * s1); pr.inv_sigma2_2 = 1.0 / (s2 * s2);
             pairs.push_back(pr);
         }
-        if (pairs.size() - first < 20) { pairs.resize(first); continue; }               // [UPSTREAM] num_matches >= 20 to try a candidate
         start.push_back((int32_t)pairs.size());
-        cand.push_back(nc.second);
         const Se3 Ta{{ka.pose.q[0], ka.pose.q[1], ka.pose.q[2], ka.pose.q[3]}, {ka.pose.t[0], ka.pose.t[1], ka.pose.t[2]}};
         const Se3 T12 = se3_mul(Tc, se3_inv(Ta));                                        // candidate camera -> current camera
         s12.insert(s12.end(), {T12.q[0], T12.q[1], T12.q[2], T12.q[3], T12.t[0], T12.t[1], T12.t[2], 1.0});
     }
-    // the scratch slot's keypoint count no longer describes an extracted image; the next extraction into it rewrites it
-    if (cand.empty()) return false;
     const double cam[4] = {m_cam.f_x, m_cam.f_y, m_cam.c_x, m_cam.c_y};
     std::vector<uint8_t> inl(pairs.size());
-    std::vector<int32_t> n_inl(cand.size(), 0);
-    if (lpslam_hip_sim3_transform_optimize(m_ctx, (int32_t)cand.size(), s12.data(), pairs.data(), start.data(), cam, cam, 10.0, 1, inl.data(), n_inl.data()) != LPSLAM_HIP_OK) return false;
+    std::vector<int32_t> n_inl(votes.size(), 0);
+    if (lpslam_hip_sim3_transform_optimize(m_ctx, (int32_t)votes.size(), s12.data(), pairs.data(), start.data(), cam, cam, 10.0, 1, inl.data(), n_inl.data()) != LPSLAM_HIP_OK) return false;
     int best = -1;
-    for (size_t i = 0; i < cand.size(); ++i) if (n_inl[i] >= 20 && (best < 0 || n_inl[i] > n_inl[(size_t)best])) best = (int)i;
+    for (size_t i = 0; i < votes.size(); ++i) if (n_inl[i] >= 20 && (best < 0 || n_inl[i] > n_inl[(size_t)best])) best = (int)i;
     if (best < 0) return false;
 
-    // ---- pose graph over the keyframes of the loop: a = candidate (fixed) ... cur
-    const long a0 = cand[(size_t)best];
-    const int n = (int)(cur_ai - a0 + 1);
+    // ---- pose graph over the keyframes of the loop: a0 = candidate (fixed) ... c
+    const int a0 = votes[(size_t)best].kf;
+    const int n = c - a0 + 1;
     std::vector<double> verts(8 * (size_t)n);
     std::vector<uint8_t> fixed((size_t)n, 0);
     fixed[0] = 1;
     std::vector<Se3> old((size_t)n);
     for (int v = 0; v < n; ++v) {
-        const Pose& p = m_archive[(size_t)(a0 + v)].pose;
+        const Pose& p = m_kfs[(size_t)(a0 + v)].pose;
         old[(size_t)v] = Se3{{p.q[0], p.q[1], p.q[2], p.q[3]}, {p.t[0], p.t[1], p.t[2]}};
         const double row[8] = {p.q[0], p.q[1], p.q[2], p.q[3], p.t[0], p.t[1], p.t[2], 1.0};
-        std::copy(row, row + 8, verts.begin() + 8 * (size_t)v);
+        std::copy(row, row + 8, verts.begin() + 8 * (long)v);
     }
     std::vector<lpslam_hip_sim3_edge> edges;
     for (int v = 0; v + 1 < n; ++v) {                    // consecutive keyframes: measurement = S_j S_i^-1 of the current estimates
@@ -872,7 +1136,7 @@ bool HipVslamTrackerBase::detectAndCloseLoop(FrameData& cur)
     {   // the loop edge: current <- candidate as the transform optimiser found it
         lpslam_hip_sim3_edge e{};
         e.i = 0; e.j = n - 1;
-        std::copy(s12.begin() + 8 * (size_t)best, s12.begin() + 8 * (size_t)best + 8, e.meas);
+        std::copy(s12.begin() + 8 * (long)best, s12.begin() + 8 * (long)best + 8, e.meas);
         edges.push_back(e);
     }
     lpslam_hip_sim3* graph = nullptr;
@@ -887,13 +1151,13 @@ bool HipVslamTrackerBase::detectAndCloseLoop(FrameData& cur)
         const double* r = &verts[8 * (size_t)v];
         const double qn = std::sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3]), s = r[7] > 0 ? r[7] : 1.0;
         neu[(size_t)v] = Se3{{r[0] / qn, r[1] / qn, r[2] / qn, r[3] / qn}, {r[4] / s, r[5] / s, r[6] / s}};
-        Pose& p = m_archive[(size_t)(a0 + v)].pose;
+        Pose& p = m_kfs[(size_t)(a0 + v)].pose;
         for (int k = 0; k < 4; ++k) p.q[k] = neu[(size_t)v].q[k];
         for (int k = 0; k < 3; ++k) p.t[k] = neu[(size_t)v].t[k];
     }
     for (auto& kv : m_landmarks) {                       // X_new = T_ref_new^-1 (T_ref_old X)
-        const long rk = kv.second.ref_kf;
-        if (rk < a0 || rk > cur_ai) continue;
+        const int rk = kv.second.ref_kf;
+        if (rk < a0 || rk > c) continue;
         const Se3& To = old[(size_t)(rk - a0)]; const Se3 Tni = se3_inv(neu[(size_t)(rk - a0)]);
         const Mat3 Ro = quatToRot(To.q), Rn = quatToRot(Tni.q);
         double xc[3], xw[3];
@@ -901,10 +1165,34 @@ bool HipVslamTrackerBase::detectAndCloseLoop(FrameData& cur)
         for (int r = 0; r < 3; ++r) xw[r] = Rn.m[r * 3] * xc[0] + Rn.m[r * 3 + 1] * xc[1] + Rn.m[r * 3 + 2] * xc[2] + Tni.t[r];
         for (int r = 0; r < 3; ++r) kv.second.p[r] = xw[r];
     }
-    for (auto& kf : m_keyframes) if (kf.archive_index >= a0 && kf.archive_index <= cur_ai) kf.pose = m_archive[(size_t)kf.archive_index].pose;
-    cur.pose = m_archive[(size_t)cur_ai].pose;
-    ++m_loopsClosed; ++g_loops_closed;
-    logMessage(LpSlamLogLevel_Info, "VSLAM loop closed: keyframe " + std::to_string(cur_ai) + " with " + std::to_string(a0) + ", " + std::to_string(n_inl[(size_t)best]) + " inliers");
+    cur.pose = m_kfs[(size_t)c].pose;
+    // ---- the revisited structure exists twice: the landmarks of the candidate and of its covisible keyframes are searched in the
+    // new keyframe and merged with what it holds ([UPSTREAM] loop_detector -> fuse with the loop's landmarks)
+    {
+        std::vector<int> nb = covisible(a0, m_localWindow - 1, 15);
+        nb.push_back(a0);
+        std::sort(nb.begin(), nb.end());
+        std::unordered_map<int, char> held;
+        for (int id : m_kfs[(size_t)c].landmark) if (id >= 0) held[id] = 1;
+        std::vector<int> ids;
+        for (int k : nb) for (int id : m_kfs[(size_t)k].landmark) if (id >= 0 && !held.count(id)) { held[id] = 1; ids.push_back(id); }
+        long added = 0, merged = 0;
+        fuseInto(c, cur.slot, ids, cur, added, merged);
+        m_stats.loop_fused += added + merged;
+    }
+    // ---- global bundle adjustment over the keyframes of the loop ([UPSTREAM] loop_bundle_adjuster: 10 iterations), inline
+    {
+        std::vector<int> free_kfs, fixed_kfs{a0};
+        for (int k = a0 + 1; k <= c; ++k) free_kfs.push_back(k);
+        auto job = prepareBundle(free_kfs, fixed_kfs);
+        if (job) {
+            job->global = true;
+            solveMapping(*job);
+            if (job->solved) { applyMapping(*job); --m_stats.local_ba; ++m_stats.global_ba; cur.pose = m_kfs[(size_t)c].pose; }
+        }
+    }
+    ++m_stats.loops_closed;
+    logMessage(LpSlamLogLevel_Info, "VSLAM loop closed: keyframe " + std::to_string(c) + " with " + std::to_string(a0) + ", " + std::to_string(n_inl[(size_t)best]) + " inliers");
     return true;
 }
 
@@ -937,9 +1225,9 @@ void HipVslamTrackerBase::stopMappingThread()
     m_mapQuit = false; m_mapOut.reset();
 }
 
-void HipVslamTrackerBase::startMapping()
+void HipVslamTrackerBase::startMapping(int c)
 {
-    auto job = prepareMapping();
+    auto job = prepareMapping(c);
     if (!job) return;
     if (!m_asyncMapping) { solveMapping(*job); applyMapping(*job); return; }
     if (!m_mapThread.joinable()) m_mapThread = std::thread([this] { mappingLoop(); });
@@ -959,7 +1247,18 @@ void HipVslamTrackerBase::finishMapping()
     if (job) applyMapping(*job);
 }
 
-TrackerBase::ProcessImageResult HipVslamTrackerBase::trackFrame(CameraQueueEntry& cam, bool stereo)
+void HipVslamTrackerBase::logStatistics() const
+{
+    const Statistics& s = m_stats;
+    char buf[512];
+    std::snprintf(buf, sizeof(buf), "VSLAM statistics: frames=%ld motion_tracked=%ld bf_tracked=%ld local_map_joined=%ld keyframes=%ld fused_added=%ld fused_merged=%ld "
+                  "local_ba=%ld loops_closed=%ld loop_fused=%ld global_ba=%ld lost=%ld relocalised=%ld reinitialised=%ld nav_priors=%ld landmarks=%zu",
+                  s.frames, s.motion_tracked, s.bf_tracked, s.local_map_joined, s.keyframes, s.fused_added, s.fused_merged, s.local_ba, s.loops_closed, s.loop_fused,
+                  s.global_ba, s.lost, s.relocalised, s.reinitialised, s.nav_priors, m_landmarks.size());
+    logMessage(LpSlamLogLevel_Info, buf);
+}
+
+TrackerBase::ProcessImageResult HipVslamTrackerBase::trackFrame(CameraQueueEntry& cam, bool stereo, const std::optional<GlobalStateInTime>& navOdom)
 {
     ProcessImageResult res;
     std::scoped_lock lock(m_slamLock);
@@ -972,6 +1271,23 @@ TrackerBase::ProcessImageResult HipVslamTrackerBase::trackFrame(CameraQueueEntry
     }
     if (!m_firstImageTimestamp) m_firstImageTimestamp = cam.timestamp;
     const auto t0 = std::chrono::steady_clock::now();
+    // navigation prior: lpslam axes -> optical axes (q_ov = (w, y, -x, z), p_ov = (y, -x, z): src/Trackers/OpenVSLAMStereoTracker.cpp:
+    // 117-135), kept as world -> camera
+    m_navPrev = m_navCur;
+    m_navCur.reset();
+    if (navOdom && m_forwardNavState && navOdom->second.stateValid) {
+        const Quaternion& ql = navOdom->second.orientation.value; const Vector3& pl = navOdom->second.position.value;
+        const double qwc[4] = {ql.w, ql.y, -ql.x, ql.z};            // camera orientation in the world
+        const double Cw[3] = {pl.y, -pl.x, pl.z};
+        const double nn = std::sqrt(qwc[0] * qwc[0] + qwc[1] * qwc[1] + qwc[2] * qwc[2] + qwc[3] * qwc[3]);
+        if (nn > 0) {
+            Pose p;
+            p.q[0] = qwc[0] / nn; p.q[1] = -qwc[1] / nn; p.q[2] = -qwc[2] / nn; p.q[3] = -qwc[3] / nn;      // world -> camera rotation
+            const Mat3 R = quatToRot(p.q);
+            for (int r = 0; r < 3; ++r) p.t[r] = -(R.m[r * 3] * Cw[0] + R.m[r * 3 + 1] * Cw[1] + R.m[r * 3 + 2] * Cw[2]);
+            m_navCur = p;
+        }
+    }
 
     FrameData cur;
     cur.slot = (int)(m_imageTracked % 2) * 2;
@@ -989,16 +1305,43 @@ TrackerBase::ProcessImageResult HipVslamTrackerBase::trackFrame(CameraQueueEntry
         ok = lpslam_hip_match_stereo(m_ctx, cur.slot, cur.slot + 1, (float)m_cam.focal_x_baseline, baseline) == LPSLAM_HIP_OK;
     }
     int32_t n = 0;
-    cur.kpts.resize(m_maxKp); cur.desc.resize((size_t)m_maxKp * 32);
-    cur.x_right.assign(m_maxKp, -1.0f); cur.depth.assign(m_maxKp, -1.0f);
+    cur.kpts.resize((size_t)m_maxKp); cur.desc.resize((size_t)m_maxKp * 32);
+    cur.x_right.assign((size_t)m_maxKp, -1.0f); cur.depth.assign((size_t)m_maxKp, -1.0f);
     if (ok) ok = lpslam_hip_get_frame(m_ctx, cur.slot, cur.kpts.data(), cur.desc.data(), stereo ? cur.x_right.data() : nullptr,
                                       stereo ? cur.depth.data() : nullptr, m_maxKp, &n) == LPSLAM_HIP_OK;
     if (!ok) { logMessage(LpSlamLogLevel_Error, std::string("HIP front end failed: ") + lpslam_hip_last_error()); return res; }
-    cur.kpts.resize(n); cur.desc.resize((size_t)n * 32);
-    cur.x_right.resize(n); cur.depth.resize(n); cur.landmark.assign(n, -1);
-    ++m_imageTracked;
+    cur.kpts.resize((size_t)n); cur.desc.resize((size_t)n * 32);
+    cur.x_right.resize((size_t)n); cur.depth.resize((size_t)n); cur.landmark.assign((size_t)n, -1);
+    ++m_imageTracked; ++m_stats.frames;
 
-    if (!stereo && m_state != TrackerState::Tracking) {
+    if (m_state == TrackerState::Lost) {
+        // the map stays; every frame tries to relocalise against the keyframes, and the state stays Lost (no pose goes out) until
+        // that succeeds or time_to_relocalize has passed -- then a new map segment starts at the pose the tracker last believed
+        // in, moved along by the navigation prior where there is one
+        Pose nav_step;
+        if (m_relocWithNavigation && navDelta(nav_step)) movePose(nav_step, m_lastGoodPose, m_lastGoodPose);
+        if (relocalise(cur)) {
+            m_state = TrackerState::Tracking;
+            ++m_stats.relocalised;
+            const int c = insertKeyframe(cur);
+            startMapping(c);
+            m_haveVelocity = false;
+            m_prev = std::move(cur); m_havePrev = true;
+        } else {
+            const double lost_for = std::chrono::duration<double>(cam.timestamp - m_lostSince).count();
+            if (lost_for > m_timeToRelocalize) {
+                bool started = false;
+                if (stereo) { ++m_segment; started = initializeMap(cur, m_lastGoodPose); if (!started) --m_segment; }
+                else { m_state = TrackerState::Initializing; }            // monocular: the two-view initialiser takes over (scale is lost)
+                if (started) {
+                    m_state = TrackerState::Tracking; ++m_stats.reinitialised;
+                    logMessage(LpSlamLogLevel_Info, "VSLAM not relocalised within " + std::to_string(m_timeToRelocalize) + " s: new map segment at the last known pose");
+                }
+            }
+            m_haveVelocity = false;
+            m_prev = std::move(cur); m_havePrev = true;
+        }
+    } else if (!stereo && m_state != TrackerState::Tracking) {
         // monocular: no map until two views with enough parallax have been found
         m_state = TrackerState::Initializing;
         if (monoInitialize(cur)) m_state = TrackerState::Tracking;
@@ -1006,7 +1349,7 @@ TrackerBase::ProcessImageResult HipVslamTrackerBase::trackFrame(CameraQueueEntry
         m_prev = std::move(cur); m_havePrev = true;
     } else if (m_state != TrackerState::Tracking) {
         m_state = TrackerState::Initializing;
-        if (initializeMap(cur)) m_state = TrackerState::Tracking;
+        if (initializeMap(cur, Pose())) m_state = TrackerState::Tracking;
         m_haveVelocity = false;
         m_prev = std::move(cur); m_havePrev = true;
     } else {
@@ -1022,19 +1365,26 @@ TrackerBase::ProcessImageResult HipVslamTrackerBase::trackFrame(CameraQueueEntry
             for (int r = 0; r < 3; ++r) m_velocity.t[r] = cur.pose.t[r] - (Rv.m[r * 3] * m_prev.pose.t[0] + Rv.m[r * 3 + 1] * m_prev.pose.t[1] + Rv.m[r * 3 + 2] * m_prev.pose.t[2]);
             m_haveVelocity = true;
             ++m_framesSinceKeyframe;
-            if (m_framesSinceKeyframe >= m_keyframeInterval || inliers < 50) {
-                finishMapping();                    // the previous keyframe's solve enters the map before the window moves
-                insertKeyframe(cur);
-                if (m_stereo && m_loopClosure) detectAndCloseLoop(cur);
-                startMapping();
-                if (!m_asyncMapping) cur.pose = m_keyframes.back().pose;
+            if (keyframeNeeded(inliers)) {
+                finishMapping();                    // the previous keyframe's solve enters the map before the next one is inserted
+                const int c = insertKeyframe(cur);
+                if (m_stereo && m_loopClosure) detectAndCloseLoop(cur, c);
+                startMapping(c);
+                if (!m_asyncMapping) cur.pose = m_kfs[(size_t)c].pose;
             }
+            m_lastGoodPose = cur.pose;
             m_prev = std::move(cur);
         } else {
             finishMapping();
             m_haveMonoRef = false;
             m_state = TrackerState::Lost;
-            logMessage(LpSlamLogLevel_Info, "VSLAM tracking lost; re-initialising from the next stereo frame");
+            m_lostSince = cam.timestamp;
+            ++m_stats.lost;
+            // the pose the tracker believes in for this frame: the prediction
+            Pose pred = m_prev.pose;
+            (void)predictedPose(pred);
+            m_lastGoodPose = pred;
+            logMessage(LpSlamLogLevel_Info, "VSLAM tracking lost; the map is kept, relocalising");
             m_prev = std::move(cur);
             m_haveVelocity = false;
         }
@@ -1090,22 +1440,22 @@ LpSlamStatus HipVslamTrackerBase::getSlamStatus()
     default: s.localization = LpSlamLocalization_Initializing; break;
     }
     s.frame_time = m_lastFrameSeconds;
-    s.key_frames = m_keyframeCount;
+    s.key_frames = (long)m_kfs.size();
     s.feature_points = (long)m_landmarks.size();
     return s;
 }
 
-TrackerBase::ProcessImageResult HipStereoTracker::processImage(CameraQueueEntry& cam, std::optional<GlobalStateInTime>, std::optional<GlobalStateInTime>,
+TrackerBase::ProcessImageResult HipStereoTracker::processImage(CameraQueueEntry& cam, std::optional<GlobalStateInTime> navResultOdom, std::optional<GlobalStateInTime>,
                                                                std::vector<SensorQueueEntry> const&)
 {
-    return trackFrame(cam, true);
+    return trackFrame(cam, true, navResultOdom);
 }
 bool HipStereoTracker::start(SensorQueue&) { return startContext(true); }
 
-TrackerBase::ProcessImageResult HipMonoTracker::processImage(CameraQueueEntry& cam, std::optional<GlobalStateInTime>, std::optional<GlobalStateInTime>,
+TrackerBase::ProcessImageResult HipMonoTracker::processImage(CameraQueueEntry& cam, std::optional<GlobalStateInTime> navResultOdom, std::optional<GlobalStateInTime>,
                                                              std::vector<SensorQueueEntry> const&)
 {
-    return trackFrame(cam, false);
+    return trackFrame(cam, false, navResultOdom);
 }
 bool HipMonoTracker::start(SensorQueue&) { return startContext(false); }
 

@@ -48,63 +48,79 @@ protected:
         Pose pose;
         int slot = 0;
     };
-    struct KeyframeObs { int landmark; double u, v, ur, inv_sigma2; };
+    // The map ([UPSTREAM] data::map_database): every keyframe ever inserted with its keypoints, descriptors, stereo columns and
+    // the landmark of every keypoint; every landmark with the list of its observations.  Covisibility ([UPSTREAM]
+    // data::graph_node: keyframes weighted by the landmarks they share) is computed from the observation lists when it is needed.
     struct Keyframe {
-        Pose pose; std::vector<KeyframeObs> obs;
-        // monocular only: what triangulating new landmarks against the next keyframe needs
-        std::vector<lpslam_hip_keypoint> kpts; std::vector<uint8_t> desc; std::vector<int> landmark;
-        long archive_index = -1;
-    };
-    // every keyframe ever inserted, for loop detection ([UPSTREAM] module::loop_detector works on the keyframe database; here the
-    // candidates are found by position and brute-force descriptor matching on the device instead of a DBoW2 vocabulary)
-    struct ArchivedKeyframe {
-        Pose pose; std::vector<lpslam_hip_keypoint> kpts; std::vector<uint8_t> desc;
-        std::vector<double> pc;                       // per keypoint: its landmark in this keyframe's camera frame (NaN: none)
+        Pose pose;
+        std::vector<lpslam_hip_keypoint> kpts; std::vector<uint8_t> desc; std::vector<float> x_right, depth;
+        std::vector<int> landmark;                    // per keypoint: landmark id or -1
+        int segment = 0;                              // map segment: a re-initialisation after a loss opens a new one
     };
     struct Landmark {
-        double p[3]; int n_obs = 0;
+        double p[3]; 
         // what local-map tracking needs ([UPSTREAM] data::landmark): the descriptor, the viewing direction and the valid
         // distance range of the observation that created it (scale prediction: level = ceil(log(max_valid / d) / log s))
         uint8_t desc[32] = {0};
         double normal[3] = {0, 0, 1};
         double max_valid = 0, min_valid = 0;
-        long ref_kf = -1;                             // archive index of the keyframe that created it (loop correction moves it with that keyframe)
+        int ref_kf = -1;                              // the keyframe that created it (loop correction moves it with that keyframe)
+        std::vector<std::pair<int, int>> obs;         // (keyframe, keypoint) in insertion order
+    };
+    struct Statistics {                               // logged at stop() ("VSLAM statistics: ..."): what the tracker did, for logs and tests
+        long frames = 0, motion_tracked = 0, bf_tracked = 0, local_map_joined = 0, keyframes = 0, fused_added = 0, fused_merged = 0;
+        long local_ba = 0, loops_closed = 0, loop_fused = 0, global_ba = 0, lost = 0, relocalised = 0, reinitialised = 0, nav_priors = 0;
     };
 
     bool startContext(bool stereo);
-    ProcessImageResult trackFrame(CameraQueueEntry& cam, bool stereo);
+    ProcessImageResult trackFrame(CameraQueueEntry& cam, bool stereo, const std::optional<GlobalStateInTime>& navOdom);
     TrackerResult createTrackerResult(const Pose& pose_cw, TimeStamp timestamp) const;
-    bool initializeMap(FrameData& f);
-    bool poseFromMatches(FrameData& cur, const std::vector<int>& cur_idx, const std::vector<int>& lm_ids, const Pose& init, int& n_inliers);
+    bool initializeMap(FrameData& f, const Pose& at);
+    bool poseFromMatches(FrameData& cur, const std::vector<int>& cur_idx, const std::vector<int>& lm_ids, const Pose& init, int& n_inliers, int min_inliers = 10);
+    bool predictedPose(Pose& init) const;
+    bool navDelta(Pose& v) const;                     // motion of the navigation prior between the last two frames (world -> camera)
+    static void movePose(const Pose& v, const Pose& from, Pose& to);
     bool trackWithMotionModel(FrameData& cur, int& n_inliers);
     bool trackAgainstPrevious(FrameData& cur, int& n_inliers);
     bool trackLocalMap(FrameData& cur, int& n_inliers);
+    bool relocalise(FrameData& cur);
     // monocular: map initialisation from two views ([UPSTREAM] module::initializer + initialize::perspective) and new landmarks
     // by triangulation between consecutive keyframes ([UPSTREAM] mapping_module::create_new_landmarks, previous keyframe only)
     bool monoInitialize(FrameData& cur);
-    void monoTriangulate(Keyframe& prev, Keyframe& kf, FrameData& f);
-    void archiveKeyframe(Keyframe& kf, const FrameData& f);
-    bool detectAndCloseLoop(FrameData& cur);
+    void monoTriangulate(int prev_kf, Keyframe& kf, FrameData& f);
+    bool detectAndCloseLoop(FrameData& cur, int c);
     void initLandmarkView(Landmark& lm, const Pose& pose, const lpslam_hip_keypoint& kp, const uint8_t* desc32) const;
-    void insertKeyframe(FrameData& f);
-    // Local bundle adjustment of the keyframe window ([UPSTREAM] mapping_module -> optimize::local_bundle_adjuster).  As in the
-    // reference it runs beside tracking: the window is copied when a keyframe is inserted, a mapping thread solves it on the GPU
-    // (the BA object has its own stream) while the tracking thread takes the next frames, and the result enters the map right
-    // before the next keyframe is inserted -- a fixed point of the frame sequence, so a run is reproducible.
+    int insertKeyframe(FrameData& f);
+    int resolve(int id) const;                        // follows the replacements of merged landmarks
+    std::vector<int> covisible(int kf, int top_n, int min_weight) const;
+    // [UPSTREAM] mapping_module::fuse_landmark_duplication / match::fuse: the given landmarks are projected into keyframe `c`
+    // (whose keypoints sit in image slot `slot`); a match with a keypoint that has no landmark adds an observation, a match with
+    // one that has another landmark merges the two (the one with more observations stays)
+    void fuseInto(int c, int slot, const std::vector<int>& landmark_ids, FrameData& f, long& added, long& merged);
+    void mergeLandmarks(int keep, int drop, FrameData* f);
+    bool keyframeNeeded(int inliers) const;
+    // Local bundle adjustment ([UPSTREAM] mapping_module -> optimize::local_bundle_adjuster): the new keyframe and its covisible
+    // keyframes are free, every other keyframe that sees their landmarks is held fixed.  As in the reference it runs beside
+    // tracking: the problem is copied when a keyframe is inserted, a mapping thread solves it on the GPU (the BA object has its own
+    // stream) while the tracking thread takes the next frames, and the result enters the map right before the next keyframe is
+    // inserted -- a fixed point of the frame sequence, so a run is reproducible.
     struct MappingJob {
         std::vector<double> poses, pts;
         std::vector<uint8_t> fixed, outlier;
         std::vector<lpslam_hip_ba_obs> obs;
-        std::vector<std::pair<int, int>> origin;      // (keyframe, obs index) of every BA observation
+        std::vector<std::pair<int, int>> origin;      // (keyframe, keypoint) of every BA observation
         std::vector<int> ids;                         // landmark id of every BA point
-        int n_keyframes = 0;
+        std::vector<int> kfs;                         // keyframe of every BA pose
+        bool global = false;                          // loop-time global BA: plain robust iterations, no outlier pass
         bool solved = false;
     };
-    std::unique_ptr<MappingJob> prepareMapping();
+    std::unique_ptr<MappingJob> prepareMapping(int c);
+    std::unique_ptr<MappingJob> prepareBundle(const std::vector<int>& free_kfs, const std::vector<int>& fixed_kfs);
     void solveMapping(MappingJob& job) const;
     void applyMapping(const MappingJob& job);
-    void startMapping();                              // prepare + solve on the mapping thread (or inline when asyncMapping is off)
+    void startMapping(int c);                         // prepare + solve on the mapping thread (or inline when asyncMapping is off)
     void finishMapping();                             // wait for the mapping thread and apply its result
+    void logStatistics() const;
 
     // configuration (names as in the reference tracker)
     bool m_useLiveView = false, m_useMapDb = true, m_forwardNavState = true, m_forwardImu = true, m_emitMap = false;
@@ -121,23 +137,31 @@ protected:
     lpslam_hip_ctx* m_ctx = nullptr;
     LpSlamCameraConfiguration m_cam{};
     bool m_started = false, m_stereo = false, m_rectify = false;
-    long m_motionTracked = 0;                         // frames tracked by the motion model (projection matching)
     TrackerState m_state = TrackerState::NotInitialized;
     std::optional<TimeStamp> m_firstImageTimestamp;
     uint64_t m_imageTracked = 0;
     double m_lastFrameSeconds = 0;
     int m_maxKp = 0;
+    float m_scales[LPSLAM_HIP_MAX_LEVELS] = {0};
     FrameData m_prev;
     bool m_havePrev = false;
     Pose m_velocity;                                  // last inter-frame motion (constant-velocity prediction)
     bool m_haveVelocity = false;
     int m_framesSinceKeyframe = 0;
+    std::vector<Keyframe> m_kfs;                      // the map's keyframes, index = id
     std::unordered_map<int, Landmark> m_landmarks;
+    std::unordered_map<int, int> m_replaced;          // merged landmark -> the one that took its observations
     int m_nextLandmarkId = 0;
-    std::deque<Keyframe> m_keyframes;
-    long m_keyframeCount = 0;
-    std::vector<ArchivedKeyframe> m_archive;
-    long m_loopsClosed = 0;
+    int m_refKf = -1;                                 // reference keyframe of tracking (the last one inserted)
+    int m_refTracked = 0;                             // landmarks the reference keyframe held when it was inserted
+    int m_segment = 0, m_segmentStart = 0;            // current map segment and its first keyframe
+    // loss and relocalisation (the reference forwards time_to_relocalize = 3.0 s, src/Trackers/OpenVSLAMTrackerBase.cpp:210-211)
+    Pose m_lastGoodPose;
+    TimeStamp m_lostSince{};
+    double m_timeToRelocalize = 3.0;
+    // navigation prior (src/Trackers/OpenVSLAMStereoTracker.cpp:70-179): camera pose of the odometry, optical axes, world -> camera
+    std::optional<Pose> m_navPrev, m_navCur;
+    Statistics m_stats;
     FrameData m_monoRef;                              // monocular initialisation: the reference frame ...
     bool m_haveMonoRef = false;
     std::vector<float> m_monoPrevMatched;             // ... and where each of its keypoints was last matched (x, y)

@@ -55,6 +55,7 @@ static void c_trampoline(LpSlamGlobalStateInTime const& s, void* p) { auto* m = 
 LPS_API lpslam_c_manager* lpslam_manager_create(void) { return new lpslam_c_manager(); }
 LPS_API void lpslam_manager_destroy(lpslam_c_manager* m) { delete m; }
 LPS_API void lpslam_manager_set_log_level(lpslam_c_manager* m, int level) { m->mgr.setLogLevel((LpSlamLogLevel)level); }
+LPS_API void lpslam_manager_log_to_file(lpslam_c_manager* m, const char* f) { m->mgr.logToFile(f); }
 LPS_API int lpslam_manager_read_configuration_file(lpslam_c_manager* m, const char* f) { return m->mgr.readConfigurationFile(f); }
 LPS_API int lpslam_manager_add_tracker(lpslam_c_manager* m, const char* n, const char* c) { return m->mgr.addTracker(n, c); }
 LPS_API int lpslam_manager_add_processor(lpslam_c_manager* m, const char* n, const char* c) { return m->mgr.addProcessor(n, c); }

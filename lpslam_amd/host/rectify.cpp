@@ -1,6 +1,8 @@
 // rectify.cpp -- see rectify.h.  OpenCV routines restated: calib3d cvStereoRectify / icvGetRectangles / cvUndistortPoints /
 // cvRodrigues2, imgproc initUndistortRectifyMap, calib3d fisheye::initUndistortRectifyMap.
 #include "rectify.h"
+#include <fstream>
+#include <iterator>
 #include <cmath>
 #include <cfloat>
 #include <algorithm>
@@ -257,6 +259,53 @@ bool build_rectify_maps(const LpSlamCameraConfiguration& left, const LpSlamCamer
     if (fn == LpSlamCameraDistortionFunction_Fisheye) fisheye_init_undistort_rectify_map(K, D, R, P, w, h, out.map_x.data(), out.map_y.data());
     else init_undistort_rectify_map(K, D, n_dist(is_left ? left : right), R, P, w, h, out.map_x.data(), out.map_y.data());
     return true;
+}
+
+bool build_camera_mask(const LpSlamCameraConfiguration& cam, bool is_left, std::vector<uint8_t>& mask, std::string* err)
+{
+    const int w = cam.resolution_x, h = cam.resolution_y;
+    if (w <= 0 || h <= 0) { if (err) *err = "camera resolution missing"; return false; }
+    if (cam.mask_type == LpSlamCameraMaskType_Radial) {
+        // cv::circle(mask, (w/2, h/2), int(radius), 255, FILLED): every pixel whose centre lies within the radius
+        const int cx = w / 2, cy = h / 2, r = (int)cam.mask_parameter;
+        mask.assign((size_t)w * h, 0);
+        for (int y = 0; y < h; ++y)
+            for (int x = 0; x < w; ++x)
+                if ((long)(x - cx) * (x - cx) + (long)(y - cy) * (y - cy) <= (long)r * r) mask[(size_t)y * w + x] = 255;
+        return true;
+    }
+    if (cam.mask_type == LpSlamCameraMaskType_Image) {
+        const std::string name = std::string("camera_mask_") + (is_left ? "left" : "right") + ".bmp";
+        std::ifstream f(name, std::ios::binary);
+        if (!f) { if (err) *err = "cannot open " + name; return false; }
+        std::vector<uint8_t> d((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+        auto u16 = [&](size_t o) { return (uint32_t)d[o] | ((uint32_t)d[o + 1] << 8); };
+        auto u32 = [&](size_t o) { return (uint32_t)d[o] | ((uint32_t)d[o + 1] << 8) | ((uint32_t)d[o + 2] << 16) | ((uint32_t)d[o + 3] << 24); };
+        if (d.size() < 54 || d[0] != 'B' || d[1] != 'M') { if (err) *err = name + " is not a BMP file"; return false; }
+        const uint32_t off = u32(10), hdr = u32(14), bpp = u16(28), comp = u32(30);
+        const int bw = (int)u32(18); int bh = (int)u32(22);
+        const bool top_down = bh < 0;
+        if (top_down) bh = -bh;
+        if (hdr < 40 || comp != 0 || (bpp != 8 && bpp != 24 && bpp != 32)) { if (err) *err = name + ": only uncompressed 8 / 24 / 32-bit BMP is read"; return false; }
+        if (bw != w || bh != h) { if (err) *err = name + " does not have the camera's resolution"; return false; }
+        const size_t row = ((size_t)bw * bpp / 8 + 3) & ~(size_t)3;
+        if (d.size() < off + row * (size_t)bh) { if (err) *err = name + " is truncated"; return false; }
+        const size_t pal = 14 + hdr;                     // 8-bit: palette of BGRA quads
+        mask.assign((size_t)w * h, 0);
+        for (int y = 0; y < h; ++y) {
+            const uint8_t* src = d.data() + off + row * (size_t)(top_down ? y : h - 1 - y);
+            for (int x = 0; x < w; ++x) {
+                int b, g, r;
+                if (bpp == 8) { const size_t e = pal + 4 * (size_t)src[x]; if (e + 2 >= d.size()) { b = g = r = src[x]; } else { b = d[e]; g = d[e + 1]; r = d[e + 2]; } }
+                else { const uint8_t* px = src + (size_t)x * (bpp / 8); b = px[0]; g = px[1]; r = px[2]; }
+                // cv::cvtColor BGR2GRAY fixed point: (b * 1868 + g * 9617 + r * 4899 + 8192) >> 14
+                mask[(size_t)y * w + x] = (uint8_t)((b * 1868 + g * 9617 + r * 4899 + 8192) >> 14);
+            }
+        }
+        return true;
+    }
+    if (err) *err = "no mask configured";
+    return false;
 }
 
 }  // namespace LpSlam

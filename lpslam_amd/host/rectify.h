@@ -29,4 +29,10 @@ void fisheye_init_undistort_rectify_map(const double* K, const double* D4, const
 bool build_rectify_maps(const LpSlamCameraConfiguration& left, const LpSlamCameraConfiguration& right, bool is_left,
                         RectifyMaps& out, std::string* err);
 
+
+// Camera mask of one eye (OpenVSLAMTrackerBase::configureMasks, /root/reference/src/Trackers/OpenVSLAMTrackerBase.cpp:331-380):
+// mask_type Radial = filled circle of radius int(mask_parameter) around the image centre (cv::circle, FILLED), 255 inside, 0 outside;
+// mask_type Image = camera_mask_left.bmp / camera_mask_right.bmp in the working directory, read as grey (cv::imread GRAYSCALE:
+// uncompressed 8 / 24 / 32-bit BMP here), must have the camera's resolution.  Row-major width x height, 0 = masked out.
+bool build_camera_mask(const LpSlamCameraConfiguration& cam, bool is_left, std::vector<uint8_t>& mask, std::string* err);
 }  // namespace LpSlam

@@ -69,6 +69,7 @@ def load():
         for name in ("add_tracker", "add_processor", "add_source"):
             getattr(_lib, "lpslam_manager_" + name).argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
         _lib.lpslam_manager_read_configuration_file.argtypes = [C.c_void_p, C.c_char_p]
+        _lib.lpslam_manager_log_to_file.argtypes = [C.c_void_p, C.c_char_p]
         _lib.lpslam_manager_read_replay_items.argtypes = [C.c_void_p, C.c_char_p]
         _lib.lpslam_manager_set_camera_configuration.argtypes = [C.c_void_p, C.POINTER(CameraConfiguration)]
         _lib.lpslam_manager_default_camera_configuration.argtypes = [C.POINTER(CameraConfiguration)]
@@ -105,6 +106,20 @@ class Manager:
             self.h = None
 
     __del__ = close
+
+    def log_to_file(self, path, level=1):
+        """LpSlamManager::logToFile + setLogLevel (1 = Info): the tracker's statistics line is read back from it by the tests"""
+        self.lib.lpslam_manager_set_log_level(self.h, level)
+        self.lib.lpslam_manager_log_to_file(self.h, str(path).encode())
+
+    @staticmethod
+    def statistics(path):
+        """the last "VSLAM statistics: key=value ..." line of a log file as a dict of ints"""
+        out = {}
+        for line in open(path, errors="replace"):
+            if "VSLAM statistics:" in line:
+                out = {k: int(v) for k, v in (kv.split("=") for kv in line.split("VSLAM statistics:")[1].split())}
+        return out
 
     def read_configuration_file(self, path):
         return bool(self.lib.lpslam_manager_read_configuration_file(self.h, path.encode()))

@@ -67,6 +67,10 @@ int ora_fast9_16(const uint8_t* img, int w, int h, int stride, int thr, int nms,
 /* all cells of one level (64-px cells, 6-px overlap, 19-px border, ini->min threshold fallback) */
 int ora_fast_level(const uint8_t* img, int w, int h, int stride, int ini_thr, int min_thr,
                    ora_corner* out, int max_out);
+/* the same with a level-0 mask (0 = masked out): [UPSTREAM] is_in_mask on the cell corners and on every corner found */
+int ora_fast_level_masked(const uint8_t* img, int w, int h, int stride, int ini_thr, int min_thr,
+                          const uint8_t* mask, int mw, int mh, int mstride, float scale,
+                          ora_corner* out, int max_out);
 /* quad-tree distribution; writes indices into `cand` of the selected corners, in result order */
 int ora_distribute(const ora_corner* cand, int n, int min_x, int max_x, int min_y, int max_y,
                    int num_keypts, int32_t* out_idx, int max_out);
@@ -82,6 +86,11 @@ void ora_brief256(const uint8_t* blurred, int stride, int x, int y, float angle_
 int ora_orb_extract(const uint8_t* img, int w, int h, int stride, const ora_orb_params* p,
                     ora_keypoint* kpts, uint8_t* descs, int max_out,
                     uint8_t* pyr_out, int32_t* cand_count);
+/* the same with a mask image of the level-0 size (0 = masked out; NULL = none) */
+int ora_orb_extract_masked(const uint8_t* img, int w, int h, int stride, const ora_orb_params* p,
+                           const uint8_t* mask, int mask_stride,
+                           ora_keypoint* kpts, uint8_t* descs, int max_out,
+                           uint8_t* pyr_out, int32_t* cand_count);
 
 /* ---- matching ------------------------------------------------------------------------------- */
 int ora_hamming256(const uint8_t* a, const uint8_t* b);

@@ -217,9 +217,24 @@ int ora_fast9_16(const uint8_t* img, int w, int h, int stride, int thr, int nms,
     return n;
 }
 
-/* [UPSTREAM] orb_extractor::compute_fast_keypoints, per-level cell loop (serial order: rows, then cols) */
-int ora_fast_level(const uint8_t* img, int w, int h, int stride, int ini_thr, int min_thr,
-                   ora_corner* out, int max_out)
+/* [UPSTREAM] orb_extractor::is_in_mask: mask.at<uchar>(y * scale_factor, x * scale_factor) == 0 -- the level coordinate times the
+ * level's scale factor (float), truncated to the level-0 pixel (clamped here; upstream trusts the range) */
+static int in_mask(const uint8_t* mask, int mw, int mh, int mstride, float y, float x, float scale)
+{
+    int my = (int)(y * scale), mx = (int)(x * scale);
+    if (my < 0) my = 0;
+    if (my >= mh) my = mh - 1;
+    if (mx < 0) mx = 0;
+    if (mx >= mw) mx = mw - 1;
+    return mask[(size_t)my * mstride + mx] == 0;
+}
+
+/* [UPSTREAM] orb_extractor::compute_fast_keypoints, per-level cell loop (serial order: rows, then cols).  With a mask (level-0
+ * size, 0 = masked out): a cell with one of its four corners in the mask is skipped; the threshold fallback looks at what
+ * cv::FAST found, then every corner is dropped whose own position is masked. */
+int ora_fast_level_masked(const uint8_t* img, int w, int h, int stride, int ini_thr, int min_thr,
+                          const uint8_t* mask, int mw, int mh, int mstride, float scale,
+                          ora_corner* out, int max_out)
 {
     const int min_bx = EDGE, min_by = EDGE;
     const int max_bx = w - EDGE, max_by = h - EDGE;
@@ -239,11 +254,14 @@ int ora_fast_level(const uint8_t* img, int w, int h, int stride, int ini_thr, in
             if (max_bx - OVERLAP <= min_x) continue;
             int max_x = min_x + CELL + OVERLAP;
             if (max_bx < max_x) max_x = max_bx;
+            if (mask && (in_mask(mask, mw, mh, mstride, (float)min_y, (float)min_x, scale) || in_mask(mask, mw, mh, mstride, (float)max_y, (float)min_x, scale) ||
+                         in_mask(mask, mw, mh, mstride, (float)min_y, (float)max_x, scale) || in_mask(mask, mw, mh, mstride, (float)max_y, (float)max_x, scale))) continue;
             const uint8_t* sub = img + (size_t)min_y * stride + min_x;
             const int cap = (CELL + OVERLAP) * (CELL + OVERLAP);
             int m = ora_fast9_16(sub, max_x - min_x, max_y - min_y, stride, ini_thr, 1, tmp, cap);
             if (m == 0) m = ora_fast9_16(sub, max_x - min_x, max_y - min_y, stride, min_thr, 1, tmp, cap);
             for (int k = 0; k < m; ++k) {
+                if (mask && in_mask(mask, mw, mh, mstride, (float)(min_y + tmp[k].y), (float)(min_x + tmp[k].x), scale)) continue;
                 if (n < max_out) {
                     out[n].x = tmp[k].x + j * CELL;
                     out[n].y = tmp[k].y + i * CELL;
@@ -255,6 +273,12 @@ int ora_fast_level(const uint8_t* img, int w, int h, int stride, int ini_thr, in
     }
     free(tmp);
     return n;
+}
+
+int ora_fast_level(const uint8_t* img, int w, int h, int stride, int ini_thr, int min_thr,
+                   ora_corner* out, int max_out)
+{
+    return ora_fast_level_masked(img, w, h, stride, ini_thr, min_thr, NULL, 0, 0, 0, 1.0f, out, max_out);
 }
 
 /* ---------------------------------------------------------------------------------------------
@@ -563,11 +587,22 @@ void ora_brief256(const uint8_t* blurred, int stride, int x, int y, float angle_
 }
 
 /* ---------------------------------------------------------------------------------------------
- * [UPSTREAM] orb_extractor::extract (no mask)
+ * [UPSTREAM] orb_extractor::extract; mask (optional): level-0 size, stride `mask_stride`, 0 = masked out
  */
+int ora_orb_extract_masked(const uint8_t* img, int w, int h, int stride, const ora_orb_params* p,
+                           const uint8_t* mask, int mask_stride,
+                           ora_keypoint* kpts, uint8_t* descs, int max_out,
+                           uint8_t* pyr_out, int32_t* cand_count);
 int ora_orb_extract(const uint8_t* img, int w, int h, int stride, const ora_orb_params* p,
                     ora_keypoint* kpts, uint8_t* descs, int max_out,
                     uint8_t* pyr_out, int32_t* cand_count)
+{
+    return ora_orb_extract_masked(img, w, h, stride, p, NULL, 0, kpts, descs, max_out, pyr_out, cand_count);
+}
+int ora_orb_extract_masked(const uint8_t* img, int w, int h, int stride, const ora_orb_params* p,
+                           const uint8_t* mask, int mask_stride,
+                           ora_keypoint* kpts, uint8_t* descs, int max_out,
+                           uint8_t* pyr_out, int32_t* cand_count)
 {
     const int L = p->num_levels;
     int lw[ORA_MAX_LEVELS], lh[ORA_MAX_LEVELS], quota[ORA_MAX_LEVELS];
@@ -593,7 +628,7 @@ int ora_orb_extract(const uint8_t* img, int w, int h, int stride, const ora_orb_
         const int W = lw[l], H = lh[l];
         int cap = W * H / 4 + 16;
         ora_corner* cand = (ora_corner*)malloc(sizeof(ora_corner) * cap);
-        int nc = ora_fast_level(pyr[l], W, H, W, p->ini_fast_thr, p->min_fast_thr, cand, cap);
+        int nc = ora_fast_level_masked(pyr[l], W, H, W, p->ini_fast_thr, p->min_fast_thr, mask, w, h, mask_stride, sf[l], cand, cap);
         if (cand_count) cand_count[l] = nc;
         if (nc == 0) { free(cand); continue; }
         int32_t* sel = (int32_t*)malloc(sizeof(int32_t) * ((size_t)nc + 8));

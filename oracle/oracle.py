@@ -112,11 +112,18 @@ def resize(src, dw, dh):
     return dst
 
 
-def fast_level(img, ini=20, mn=7):
+def fast_level(img, ini=20, mn=7, mask=None, scale=1.0):
+    """mask: level-0 mask (0 = masked out), scale: this level's scale factor"""
     img = np.ascontiguousarray(img, np.uint8)
     cap = img.size // 4 + 16
     out = np.zeros(cap, CORNER_DTYPE)
-    n = lib().ora_fast_level(_p(img), img.shape[1], img.shape[0], img.shape[1], ini, mn, _p(out), cap)
+    if mask is None:
+        n = lib().ora_fast_level(_p(img), img.shape[1], img.shape[0], img.shape[1], ini, mn, _p(out), cap)
+    else:
+        mask = np.ascontiguousarray(mask, np.uint8)
+        f = lib().ora_fast_level_masked
+        f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_int]
+        n = f(_p(img), img.shape[1], img.shape[0], img.shape[1], ini, mn, _p(mask), mask.shape[1], mask.shape[0], mask.shape[1], float(scale), _p(out), cap)
     return out[:n].copy()
 
 
@@ -157,17 +164,21 @@ def sincos_deg(a):
     return s.value, c.value
 
 
-def extract(img, p, want_pyramid=False):
-    """Returns (keypoints[KP_DTYPE], descriptors[n,32], cand_count[levels], pyramid levels or None)."""
+def extract(img, p, want_pyramid=False, mask=None):
+    """Returns (keypoints[KP_DTYPE], descriptors[n,32], cand_count[levels], pyramid levels or None).
+    mask: optional uint8 image of the same size, 0 = masked out ([UPSTREAM] orb_extractor::extract's mask argument)."""
     img = np.ascontiguousarray(img, np.uint8)
     h, w = img.shape
+    if mask is not None:
+        mask = np.ascontiguousarray(mask, np.uint8)
+        assert mask.shape == img.shape
     roots = max(1, int(round(w / h)), int(round(h / w)))          # a level returns up to max(quota + 3, 4 * roots) corners
     cap = p.max_num_keypts + (4 * roots + 8) * p.num_levels + 64
     kp = np.zeros(cap, KP_DTYPE); desc = np.zeros((cap, 32), np.uint8)
     cc = np.zeros(p.num_levels, np.int32)
     lw, lh = pyramid_sizes(w, h, p)
     pyr = np.zeros(sum(a * b for a, b in zip(lw, lh)), np.uint8) if want_pyramid else None
-    n = lib().ora_orb_extract(_p(img), w, h, w, C.byref(p), _p(kp), _p(desc), cap, _p(pyr), _p(cc))
+    n = lib().ora_orb_extract_masked(_p(img), w, h, w, C.byref(p), _p(mask), w, _p(kp), _p(desc), cap, _p(pyr), _p(cc))
     assert n <= cap
     levels = None
     if want_pyramid:

@@ -120,3 +120,42 @@ def test_full_size_properties(hiplib):
     ctx.extract(2)
     kp2, desc2 = ctx.keypoints(0)
     assert np.array_equal(kp, kp2) and np.array_equal(desc, desc2)
+
+
+@pytest.mark.parametrize("w,h,kpts,levels", [(320, 240, 300, 4), (640, 480, 1000, 8)])
+def test_extract_with_camera_mask(hiplib, oracle, w, h, kpts, levels):
+    """Camera masks (mask_type Radial / Image of the reference's camera configuration): cells with a masked corner are skipped,
+    corners at masked positions dropped after the threshold fallback; per eye (even slots: left mask, odd slots: right mask)."""
+    img = synth.random_image(w, h, seed=77)
+    yy, xx = np.mgrid[0:h, 0:w]
+    radial = np.where((xx - w // 2) ** 2 + (yy - h // 2) ** 2 <= (0.42 * w) ** 2, 255, 0).astype(np.uint8)
+    stripes = np.where(((xx // 37) + (yy // 29)) % 3 == 0, 0, 255).astype(np.uint8)
+    c = hiplib.Context(w, h, kpts, 1.2, levels, max_images=2)
+    c.upload(0, img); c.upload(1, img)
+    c.set_mask(0, radial); c.set_mask(1, stripes)
+    c.extract(2)
+    p = oracle.params(kpts, 1.2, levels)
+    for slot, mask in ((0, radial), (1, stripes)):
+        ok, od, occ, _ = oracle.extract(img, p, mask=mask)
+        gk, gd = c.keypoints(slot)
+        assert len(gk) == len(ok) and len(ok) > 20
+        for f in ok.dtype.names:
+            assert np.array_equal(gk[f], ok[f]), f
+        assert np.array_equal(gd, od)
+        assert (mask[gk["y"].astype(int), gk["x"].astype(int)] > 0).all()          # nothing survives inside the mask
+        for l in range(levels):
+            sc = np.float32(1.2) ** l
+            oc = oracle.fast_level(oracle_pyramid(oracle, img, p)[l], 20, 7, mask=mask, scale=c.scale[l])
+            gc = c.candidates(slot, l)
+            assert len(gc) == len(oc) and np.array_equal(np.sort(gc, order=("y", "x")), np.sort(oc, order=("y", "x"))), l
+    # removing the masks restores the plain result
+    c.set_mask(0, None); c.set_mask(1, None)
+    c.extract(2)
+    ok, od, _, _ = oracle.extract(img, p)
+    gk, gd = c.keypoints(1)
+    assert np.array_equal(gd, od) and np.array_equal(gk["x"], ok["x"])
+    c.close()
+
+
+def oracle_pyramid(oracle, img, p):
+    return oracle.extract(img, p, True)[3]

@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("async_mapping", [True, False])
-def test_stereo_sequence_through_the_manager(hiplib, async_mapping):
+def test_stereo_sequence_through_the_manager(hiplib, async_mapping, tmp_path):
     """Local BA beside tracking (the default, as the reference's mapping thread) and inline: both track the sequence."""
     from lpslam_amd import _build, manager
     _build.host_library()
@@ -26,10 +26,8 @@ def test_stereo_sequence_through_the_manager(hiplib, async_mapping):
     assert m.add_tracker("VSLAMStereo", '{"cameraSetup": "stereo", "slamKeypoints": 1000, "numLevels": 4, "keyframeInterval": 4, "asyncMapping": %s}'
                          % ("true" if async_mapping else "false"))
     m.collect_results(); m.provide_odometry()
-    import ctypes
-    counter = ctypes.CDLL(_build.host_library()).lpslam_debug_motion_tracked
-    counter.restype = ctypes.c_long
-    tracked0 = counter()
+    log = tmp_path / "slam.log"
+    m.log_to_file(log)
     m.start()
     frames = [seq.frame(i) for i in range(n_frames)]
     for i, (l, r) in enumerate(frames):
@@ -41,7 +39,10 @@ def test_stereo_sequence_through_the_manager(hiplib, async_mapping):
     feats = m.features()
     m.stop()
     assert len(m.results) == n_frames
-    assert counter() - tracked0 >= n_frames - 6          # constant-velocity prediction + projection matching carried most frames
+    st_log = manager.Manager.statistics(log)
+    assert st_log["motion_tracked"] >= n_frames - 6      # constant-velocity prediction + projection matching carried most frames
+    assert st_log["keyframes"] == st.key_frames and st_log["local_ba"] >= 2 and st_log["lost"] == 0
+    assert st_log["fused_added"] + st_log["fused_merged"] > 0          # match::fuse found landmarks of the covisible keyframes in new keyframes
     valid = [r for r in m.results if r["valid"]]
     assert len(valid) >= n_frames - 2 and st.localization == 2 and st.key_frames >= 3 and st.feature_points > 100
     assert len(feats) == st.feature_points
@@ -91,14 +92,12 @@ def test_replay_file_through_the_manager(hiplib, tmp_path):
     assert [r["timestamp"] for r in m.results] == [(i + 1) * 40_000_000 for i in range(n_frames)]
 
 
-def test_local_map_tracking_brings_landmarks_back(hiplib):
+def test_local_map_tracking_brings_landmarks_back(hiplib, tmp_path):
     """One frame with its left half blanked: the frame after it cannot get those landmarks from the motion model (the previous
     frame does not hold them), local-map tracking projects them from the keyframes and matches them again
     ([UPSTREAM] tracking_module::optimize_current_frame_with_local_map)."""
-    import ctypes
     from lpslam_amd import _build, manager
-    lib = ctypes.CDLL(_build.host_library())
-    lib.lpslam_debug_local_map_joined.restype = ctypes.c_long
+    _build.host_library()
     w, h = 640, 480
     k = synth.intrinsics(w, h)
     seq = synth.StereoSequence(w, h, 4, n_points=6000)
@@ -110,7 +109,8 @@ def test_local_map_tracking_brings_landmarks_back(hiplib):
         m.set_camera(c)
     assert m.add_tracker("VSLAMStereo", '{"cameraSetup": "stereo", "slamKeypoints": 1000, "numLevels": 4, "keyframeInterval": 8}')
     m.collect_results(); m.provide_odometry()
-    joined0 = lib.lpslam_debug_local_map_joined()
+    log = tmp_path / "slam.log"
+    m.log_to_file(log)
     m.start()
     frames = [list(seq.frame(i)) for i in range(6)]
     for eye in (0, 1):
@@ -122,7 +122,7 @@ def test_local_map_tracking_brings_landmarks_back(hiplib):
         time.sleep(0.01)
     m.stop()
     assert len(m.results) == len(frames) and all(r["valid"] for r in m.results)
-    assert lib.lpslam_debug_local_map_joined() - joined0 >= 20
+    assert manager.Manager.statistics(log)["local_map_joined"] >= 20
     assert abs(m.results[-1]["p"][2] - 0.05 * 5) < 0.05
 
 
@@ -167,43 +167,161 @@ def test_monocular_sequence_initialises_and_tracks(hiplib):
     assert abs(frac - frac_true) < 0.1                                            # constant speed: no scale jump along the way
 
 
-def test_loop_is_detected_and_closed(hiplib):
-    """Out and back along the same line: when the camera returns, archived keyframes near the current position are matched by
-    descriptor on the device, verified with the Sim3 optimiser of the loop detector and the loop is closed by the Sim3 pose graph
-    ([UPSTREAM] module::loop_detector / optimize::transform_optimizer / optimize::graph_optimizer; the reference switches the
-    detector with the tracker's loopClosure key, src/Trackers/OpenVSLAMTrackerBase.cpp:250-255).  The tracker barely drifts on
-    this sequence, so closing the loop must leave the trajectory where it was."""
-    import ctypes
+def test_loop_is_detected_and_closed(hiplib, tmp_path):
+    """A full turn on the spot inside a ring of structure: when the camera faces its starting direction again, the first
+    keyframes are not covisible with the new ones (the map holds that structure a second time, from the other end of the chain),
+    descriptor voting on the device finds them, the Sim3 optimiser of the loop detector verifies the match, the loop is closed by
+    the Sim3 pose graph, the duplicated landmarks are fused and a global bundle adjustment over the loop's keyframes follows
+    ([UPSTREAM] module::loop_detector / optimize::transform_optimizer / optimize::graph_optimizer / loop_bundle_adjuster; the
+    reference switches the detector with the tracker's loopClosure key, src/Trackers/OpenVSLAMTrackerBase.cpp:250-255)."""
+    import math
     from lpslam_amd import _build, manager
-    lib = ctypes.CDLL(_build.host_library())
-    lib.lpslam_debug_loops_closed.restype = ctypes.c_long
+    _build.host_library()
     w, h = 640, 480
     k = synth.intrinsics(w, h)
-    seq = synth.StereoSequence(w, h, 4, n_points=6000)
-    zs = [0.05 * i for i in range(25)] + [0.05 * (24 - i) for i in range(1, 25)]
-    frames = []
-    for i, z in enumerate(zs):
-        rng = np.random.Generator(np.random.PCG64([5, i]))
-        t = -np.array([0.0, 0.0, z])
-        frames.append((seq._render(np.eye(3), t, rng), seq._render(np.eye(3), t - np.array([k["baseline"], 0.0, 0.0]), rng)))
+    seq = synth.StereoSequence(w, h, 4, n_points=9000)
+    rng = np.random.default_rng(21)
+    az = rng.uniform(0, 2 * np.pi, 9000); rad = rng.uniform(5.0, 25.0, 9000)
+    seq.pts = np.stack([rad * np.sin(az), rng.uniform(-4, 4, 9000), rad * np.cos(az)], axis=1)       # structure all around the camera
+    # the generator's background is fixed to the image; a turning camera needs one fixed to the world: a panorama at infinity
+    pano = synth._value_noise(np.random.Generator(np.random.PCG64(77)), 1200, 7200)                  # 0.05 degrees per pixel
+    uu, vv = np.meshgrid((np.arange(w) - k["cx"]) / k["fx"], (np.arange(h) - k["cy"]) / k["fy"])
+    def world_background(R):
+        d = np.stack([uu, vv, np.ones_like(uu)], axis=-1) @ R                  # camera ray -> world (R is world -> camera)
+        a = (np.arctan2(d[..., 0], d[..., 2]) + np.pi) * (7200 / (2 * np.pi))
+        e = (np.arctan2(d[..., 1], np.hypot(d[..., 0], d[..., 2])) + np.pi / 6) * (1200 / (np.pi / 3))
+        a0 = np.floor(a).astype(int); e0 = np.clip(np.floor(e).astype(int), 0, 1198)
+        fa = a - a0; fe = np.clip(e - e0, 0, 1)
+        a0 %= 7200; a1 = (a0 + 1) % 7200
+        return (pano[e0, a0] * (1 - fa) + pano[e0, a1] * fa) * (1 - fe) + (pano[e0 + 1, a0] * (1 - fa) + pano[e0 + 1, a1] * fa) * fe
+    n_frames, step = 132, math.radians(3.0)
+    frames, yaws = [], []
+    for i in range(n_frames):
+        yaw = step * i
+        c, s_ = math.cos(yaw), math.sin(yaw)
+        R = np.array([[c, 0, s_], [0, 1, 0], [-s_, 0, c]]).T          # world -> camera for a camera turned by `yaw` about y
+        nr = np.random.Generator(np.random.PCG64([5, i]))
+        seq.bg = world_background(R)
+        frames.append((seq._render(R, np.zeros(3), nr), seq._render(R, -np.array([k["baseline"], 0.0, 0.0]), nr)))
+        yaws.append(yaw)
+    log = tmp_path / "slam.log"
+    m = _stereo_manager(manager, w, h, '{"cameraSetup": "stereo", "slamKeypoints": 1000, "numLevels": 4, "keyframeInterval": 3, "localWindow": 4, "loopClosure": true}', log)
+    m.start()
+    _feed(m, frames)
+    m.stop()
+    assert len(m.results) == len(frames) and sum(r["valid"] for r in m.results) >= len(frames) - 2
+    st_log = manager.Manager.statistics(log)
+    assert st_log["loops_closed"] >= 1 and st_log["lost"] == 0
+    assert st_log["global_ba"] >= 1 and st_log["loop_fused"] > 0       # the loop-time global BA ran; the revisited landmarks were fused
+    # the camera never leaves the origin and, after the turn, looks where it looked first: orientation in lpslam axes, yaw about
+    # the optical y axis = rotation about the lpslam -x axis... checked through the angle of the relative rotation
+    last = m.results[-1]
+    assert max(abs(last["p"][0]), abs(last["p"][1]), abs(last["p"][2])) < 0.15
+    q0, q1 = np.array(m.results[0]["q"]), np.array(last["q"])
+    ang = 2 * math.degrees(math.acos(min(1.0, abs(float(q0 @ q1)))))
+    want = math.degrees(yaws[-1]) % 360.0
+    want = min(want, 360.0 - want)
+    assert abs(ang - want) < 1.0, (ang, want)
+
+
+def _stereo_manager(manager, w, h, tracker_cfg, log=None, mask=None):
+    k = synth.intrinsics(w, h)
     m = manager.Manager()
     for num in (0, 1):
         c = manager.default_camera()
         c.camera_number = num; c.f_x = k["fx"]; c.f_y = k["fy"]; c.c_x = k["cx"]; c.c_y = k["cy"]
         c.resolution_x = w; c.resolution_y = h; c.focal_x_baseline = k["fxb"]
+        if mask is not None:
+            c.mask_type, c.mask_parameter = mask
         m.set_camera(c)
-    assert m.add_tracker("VSLAMStereo", '{"cameraSetup": "stereo", "slamKeypoints": 1000, "numLevels": 4, "keyframeInterval": 3, "localWindow": 4, "loopClosure": true}')
+    assert m.add_tracker("VSLAMStereo", tracker_cfg)
     m.collect_results(); m.provide_odometry()
-    closed0 = lib.lpslam_debug_loops_closed()
-    m.start()
+    if log is not None:
+        m.log_to_file(log)
+    return m
+
+
+def _feed(m, frames, t0_ns=0, step_ns=40_000_000, expect=None):
     for i, (l, r) in enumerate(frames):
-        assert m.add_stereo((i + 1) * 40_000_000, l, r)
+        assert m.add_stereo(t0_ns + (i + 1) * step_ns, l, r)
+    n = len(frames) if expect is None else expect
     t0 = time.time()
-    while len(m.results) < len(frames) and time.time() - t0 < 60:
+    while len(m.results) < n and time.time() - t0 < 60:
         time.sleep(0.01)
+
+
+def test_tracking_loss_keeps_the_map_and_relocalises(hiplib, tmp_path):
+    """Textureless frames in the middle of a sequence: the tracker reports Lost (no pose goes out, the status says so), keeps
+    the map, and comes back by relocalising against its keyframes -- the trajectory continues where it was instead of jumping
+    to the origin (the reference keeps the map and forwards time_to_relocalize, src/Trackers/OpenVSLAMTrackerBase.cpp:210-211)."""
+    from lpslam_amd import _build, manager
+    _build.host_library()
+    w, h = 640, 480
+    seq = synth.StereoSequence(w, h, 4, n_points=6000)
+    frames = [list(seq.frame(i)) for i in range(20)]
+    blank = np.full((h, w), 110, np.uint8)
+    for i in (10, 11, 12):
+        frames[i] = [blank.copy(), blank.copy()]
+    log = tmp_path / "slam.log"
+    m = _stereo_manager(manager, w, h, '{"cameraSetup": "stereo", "slamKeypoints": 1000, "numLevels": 4, "keyframeInterval": 4}', log)
+    m.start()
+    _feed(m, frames)
+    st = m.status()
     m.stop()
-    assert len(m.results) == len(frames) and sum(r["valid"] for r in m.results) >= len(frames) - 2
-    assert lib.lpslam_debug_loops_closed() - closed0 >= 1
-    valid = [(i, r) for i, r in enumerate(m.results) if r["valid"]]
-    for i, r in valid[5:]:
-        assert abs(r["p"][2] - zs[i]) < 0.12 * max(zs[i], 0.25) + 0.02 and abs(r["p"][0]) < 0.06 and abs(r["p"][1]) < 0.06, (i, r["p"], zs[i])
+    assert len(m.results) == len(frames)
+    valid = [r["valid"] for r in m.results]
+    assert all(valid[:10]) and not any(valid[10:13]) and all(valid[13:])          # Lost while blind, back with the first textured frame
+    s = manager.Manager.statistics(log)
+    assert s["lost"] == 1 and s["relocalised"] == 1 and s["reinitialised"] == 0
+    # pose continuity: the camera moves 0.05 m per frame along z; no jump to the origin, no scale change
+    zs = [r["p"][2] for r in m.results]
+    assert abs(zs[13] - 0.05 * 13) < 0.06 and abs(zs[19] - 0.05 * 19) < 0.08
+    assert abs(m.results[13]["p"][0]) < 0.05 and abs(m.results[13]["p"][1]) < 0.05
+    assert st.localization == 2
+
+
+def test_long_loss_starts_a_new_segment_at_the_last_pose(hiplib, tmp_path):
+    """When relocalisation does not succeed within time_to_relocalize (3 s) a new map segment starts at the pose the tracker last
+    believed in -- not at the origin -- and the old keyframes stay in the map."""
+    from lpslam_amd import _build, manager
+    _build.host_library()
+    w, h = 640, 480
+    seq = synth.StereoSequence(w, h, 4, n_points=6000)
+    other = synth.StereoSequence(w, h, 9, n_points=6000)              # a different scene: nothing to relocalise against
+    blank = np.full((h, w), 110, np.uint8)
+    frames = [seq.frame(i) for i in range(8)] + [(blank, blank)] * 2 + [other.frame(i) for i in range(6)]
+    log = tmp_path / "slam.log"
+    m = _stereo_manager(manager, w, h, '{"cameraSetup": "stereo", "slamKeypoints": 1000, "numLevels": 4, "keyframeInterval": 4}', log)
+    m.start()
+    # 1 s between frames: the third frame after the loss is past time_to_relocalize
+    _feed(m, frames, step_ns=1_000_000_000)
+    st = m.status()
+    m.stop()
+    s = manager.Manager.statistics(log)
+    assert s["lost"] == 1 and s["reinitialised"] == 1 and s["relocalised"] == 0
+    valid = [r["valid"] for r in m.results]
+    assert all(valid[:8]) and not valid[8] and valid[-1]
+    first_back = next(i for i in range(8, len(valid)) if valid[i])
+    assert abs(m.results[first_back]["p"][2] - m.results[7]["p"][2]) < 0.2          # continues near where it was, not at the origin
+    assert st.key_frames >= 3
+
+
+def test_radial_camera_mask_through_the_tracker(hiplib, tmp_path):
+    """mask_type Radial of the camera configuration reaches the extractor: every landmark of the map lies inside the circle."""
+    from lpslam_amd import _build, manager
+    _build.host_library()
+    w, h = 640, 480
+    k = synth.intrinsics(w, h)
+    seq = synth.StereoSequence(w, h, 4, n_points=6000)
+    m = _stereo_manager(manager, w, h, '{"cameraSetup": "stereo", "slamKeypoints": 1000, "numLevels": 4, "keyframeInterval": 4}', tmp_path / "slam.log", mask=(1, 180.0))
+    m.start()
+    _feed(m, [seq.frame(i) for i in range(3)])
+    feats = m.features()
+    m.stop()
+    assert len(feats) > 100
+    # features come out in lpslam axes (-y, x, z) of the optical frame; project back into the first image
+    pts = np.array(feats)
+    xo, yo, zo = pts[:, 1], -pts[:, 0], pts[:, 2]
+    u = k["fx"] * xo / zo + k["cx"]; v = k["fy"] * yo / zo + k["cy"]
+    r = np.hypot(u - w // 2, v - h // 2)
+    assert np.percentile(r, 99) < 185 and r.max() < 215            # later frames see the landmarks a little further out
