@@ -1,0 +1,524 @@
+"""Closed-loop oracle of the stereo tracker.  TEST INFRASTRUCTURE ONLY (PARITY UNPINNED: see oracle/ora.h).
+
+The per-frame flow that lpslam reaches through feed_stereo_frame (/root/reference/src/Trackers/OpenVSLAMStereoTracker.cpp:293-321)
+restated on the CPU from the oracle's pieces -- extraction, stereo matching, projection matching, the motion-only pose optimiser,
+duplicate fusion and the local bundle adjustment -- with the keyframe, covisibility and window rules of
+lpslam_amd/host/hip_tracker.cpp (the product's tracker), function by function, so that a sequence tracked by the HIP path can be
+compared pose by pose (tests/test_track_gpu.py, tests/golden/g10_track.npz; tolerance 1e-4 rad / 1e-3 m per frame).
+Covered: stereo initialisation, motion-model tracking with the brute-force fallback, local-map tracking, the keyframe decision,
+keyframe insertion with new landmarks, match::fuse with landmark merging, the covisibility-window local BA solved inline
+(asyncMapping = false) and its outlier removal.  Not covered (and switched off in the comparison): loop closing, relocalisation.
+
+Arithmetic follows the C++ operation by operation where a rounding could change a discrete decision (float32 query fields,
+float32 level scales); everything else is float64 as there.
+"""
+import math
+
+import numpy as np
+
+from . import oracle as O
+
+F32 = np.float32
+
+
+def quat_to_rot(q):
+    n = math.sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3])
+    w, x, y, z = q[0] / n, q[1] / n, q[2] / n, q[3] / n
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                     [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                     [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+
+
+def quat_mul(a, b):
+    r = [a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3], a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2],
+         a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1], a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0]]
+    n = math.sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3])
+    return [v / n for v in r]
+
+
+def rot_to_quat(R):
+    m = R.reshape(9)
+    tr = m[0] + m[4] + m[8]
+    if tr > 0:
+        s = math.sqrt(tr + 1.0) * 2
+        return [0.25 * s, (m[7] - m[5]) / s, (m[2] - m[6]) / s, (m[3] - m[1]) / s]
+    if m[0] > m[4] and m[0] > m[8]:
+        s = math.sqrt(1.0 + m[0] - m[4] - m[8]) * 2
+        return [(m[7] - m[5]) / s, 0.25 * s, (m[1] + m[3]) / s, (m[2] + m[6]) / s]
+    if m[4] > m[8]:
+        s = math.sqrt(1.0 + m[4] - m[0] - m[8]) * 2
+        return [(m[2] - m[6]) / s, (m[1] + m[3]) / s, 0.25 * s, (m[5] + m[7]) / s]
+    s = math.sqrt(1.0 + m[8] - m[0] - m[4]) * 2
+    return [(m[3] - m[1]) / s, (m[2] + m[6]) / s, (m[5] + m[7]) / s, 0.25 * s]
+
+
+class Pose:
+    def __init__(self, q=(1.0, 0.0, 0.0, 0.0), t=(0.0, 0.0, 0.0)):
+        self.q = [float(v) for v in q]; self.t = [float(v) for v in t]
+
+    def copy(self):
+        return Pose(self.q, self.t)
+
+    def seven(self):
+        return np.array(self.q + self.t, np.float64)
+
+
+def move_pose(v, frm):
+    """to = v * from (HipVslamTrackerBase::movePose)"""
+    q = quat_mul(v.q, frm.q)
+    Rv = quat_to_rot(v.q)
+    t = [Rv[r, 0] * frm.t[0] + Rv[r, 1] * frm.t[1] + Rv[r, 2] * frm.t[2] + v.t[r] for r in range(3)]
+    return Pose(q, t)
+
+
+class Frame:
+    def __init__(self, kpts, desc, x_right, depth):
+        self.kpts, self.desc, self.x_right, self.depth = kpts, desc, x_right, depth
+        self.landmark = [-1] * len(kpts)
+        self.pose = Pose()
+
+
+class StereoTracker:
+    """Mirror of HipStereoTracker with asyncMapping = false, loopClosure = false; frames fed one by one with feed(left, right)."""
+
+    def __init__(self, width, height, cam, max_keypoints=1000, num_levels=4, scale_factor=1.2, keyframe_interval=4, local_window=10,
+                 nav_identity=True):
+        self.w, self.h, self.cam = width, height, dict(cam)
+        self.p = O.params(max_keypoints, scale_factor, num_levels)
+        self.scales = O.scale_factors(self.p)[0]                   # float32, as lpslam_hip_level_info returns them
+        self.n_levels, self.sf = num_levels, float(scale_factor)
+        self.kf_interval, self.local_window = max(1, keyframe_interval), max(2, local_window)
+        self.nav_identity = nav_identity                            # the host hands in an odometry that never moves (tests: provide_odometry)
+        self.kfs, self.landmarks, self.replaced = [], {}, {}
+        self.next_id = 0
+        self.ref_kf, self.ref_tracked, self.since_kf = -1, 0, 0
+        self.segment_start = 0
+        self.prev = None
+        self.velocity = None
+        self.tracking = False
+        self.n_frames = 0
+        self.stats = dict(motion_tracked=0, bf_tracked=0, local_map_joined=0, keyframes=0, fused_added=0, fused_merged=0, local_ba=0)
+
+    # ---- helpers ---------------------------------------------------------------------------------------------------------------
+    def resolve(self, i):
+        guard = 0
+        while i >= 0 and i in self.replaced and guard < 64:
+            i = self.replaced[i]; guard += 1
+        return i
+
+    def covisible(self, kf, top_n, min_weight):
+        w = {}
+        for i in self.kfs[kf]["landmark"]:
+            if i < 0 or i not in self.landmarks:
+                continue
+            for (k, _) in self.landmarks[i]["obs"]:
+                if k != kf:
+                    w[k] = w.get(k, 0) + 1
+        v = sorted(((c, k) for k, c in w.items() if c >= min_weight), key=lambda e: (-e[0], -e[1]))
+        v = v[:max(top_n, 0)]
+        return sorted(k for _, k in v)
+
+    def init_landmark_view(self, lm, pose, kp_octave, desc32):
+        R = quat_to_rot(pose.q)
+        C = [-(R[0, a] * pose.t[0] + R[1, a] * pose.t[1] + R[2, a] * pose.t[2]) for a in range(3)]
+        ray = [lm["p"][a] - C[a] for a in range(3)]
+        dist = math.sqrt(ray[0] * ray[0] + ray[1] * ray[1] + ray[2] * ray[2])
+        lm["normal"] = [ray[a] / dist if dist > 0 else 0.0 for a in range(3)]
+        lvl = min(max(int(kp_octave), 0), self.n_levels - 1)
+        lm["max_valid"] = dist * float(self.scales[lvl])
+        lm["min_valid"] = lm["max_valid"] / float(self.scales[max(self.n_levels - 1, 0)])
+        lm["desc"] = np.array(desc32, np.uint8).copy()
+
+    def _project_query(self, X, R, t, need_view=None):
+        """shared part of the query construction: camera point, pixel, in-image test; returns (pc, u, v) or None"""
+        pc = [R[r, 0] * X[0] + R[r, 1] * X[1] + R[r, 2] * X[2] + t[r] for r in range(3)]
+        if not (pc[2] > 0):
+            return None
+        u = self.cam["fx"] * pc[0] / pc[2] + self.cam["cx"]; v = self.cam["fy"] * pc[1] / pc[2] + self.cam["cy"]
+        if u < 0 or v < 0 or u >= self.w or v >= self.h:
+            return None
+        return pc, u, v
+
+    def _view_level(self, lm, X, C):
+        """can_observe + predicted level (local-map tracking and fuse); None when the landmark cannot be seen"""
+        ray = [X[a] - C[a] for a in range(3)]
+        dist = math.sqrt(ray[0] * ray[0] + ray[1] * ray[1] + ray[2] * ray[2])
+        if not (dist > 0) or dist < 0.8 * lm["min_valid"] or dist > 1.2 * lm["max_valid"]:
+            return None
+        if (ray[0] * lm["normal"][0] + ray[1] * lm["normal"][1] + ray[2] * lm["normal"][2]) / dist < 0.5:
+            return None
+        return min(max(int(math.ceil(math.log(lm["max_valid"] / dist) / math.log(self.sf))), 0), self.n_levels - 1)
+
+    # ---- pose optimiser over keypoint <-> landmark associations (poseFromMatches) -------------------------------------------------
+    def pose_from_matches(self, cur, cur_idx, lm_ids, init, min_inliers=10):
+        pts, obs_rows, kept_idx, kept_lm = [], [], [], []
+        for i, lid in zip(cur_idx, lm_ids):
+            if lid not in self.landmarks:
+                continue
+            s = float(self.scales[int(cur.kpts["octave"][i])])
+            xr = float(cur.x_right[i])
+            obs_rows.append((0, len(kept_idx), float(cur.kpts["x"][i]), float(cur.kpts["y"][i]), xr if xr >= 0 else -1.0, 1.0 / (s * s)))
+            pts.append(list(self.landmarks[lid]["p"]))
+            kept_idx.append(i); kept_lm.append(lid)
+        if len(obs_rows) < 10:
+            return False, 0
+        obs = np.array(obs_rows, O.OBS_DTYPE)
+        pose, outlier, inl = O.pose_optimize(init.seven(), np.array(pts, np.float64), obs, self.cam)
+        if inl < min_inliers:
+            return False, inl
+        cur.pose = Pose(pose[:4], pose[4:])
+        cur.landmark = [-1] * len(cur.kpts)
+        for k, i in enumerate(kept_idx):
+            cur.landmark[i] = -1 if outlier[k] else kept_lm[k]
+        return True, inl
+
+    def predicted_pose(self):
+        if self.velocity is not None:
+            return move_pose(self.velocity, self.prev.pose)
+        if self.nav_identity and self.n_frames >= 2:             # navigation prior of an odometry that stands still: identity step
+            return move_pose(Pose(), self.prev.pose)
+        return None
+
+    # ---- motion model (trackWithMotionModel) ---------------------------------------------------------------------------------------
+    def track_with_motion_model(self, cur):
+        init = self.predicted_pose()
+        if init is None:
+            return False, 0
+        R = quat_to_rot(init.q)
+        q_rows, qd, q_angle, q_lm = [], [], [], []
+        for i in range(len(self.prev.kpts)):
+            lid = self.resolve(self.prev.landmark[i])
+            if lid < 0 or lid not in self.landmarks:
+                continue
+            pr = self._project_query(self.landmarks[lid]["p"], R, init.t)
+            if pr is None:
+                continue
+            pc, u, v = pr
+            lvl = int(self.prev.kpts["octave"][i])
+            radius = F32(10.0) * self.scales[lvl]
+            q_rows.append((F32(u), F32(v), F32(u - self.cam["fxb"] / pc[2]), radius, max(0, lvl - 1), min(self.n_levels - 1, lvl + 1)))
+            qd.append(self.prev.desc[i]); q_angle.append(self.prev.kpts["angle"][i]); q_lm.append(lid)
+        if len(q_rows) < 20:
+            return False, 0
+        q = np.array(q_rows, O.PROJ_QUERY_DTYPE); qd = np.array(qd, np.uint8)
+        idx = None; n_m = 0
+        for attempt in range(2):
+            idx, _, n_m = O.match_projection(cur.kpts, cur.desc, cur.x_right, self.w, self.h, q, qd, 100, 1.0, None)
+            idx, n_m = O.match_orientation_filter(np.array(q_angle, np.float32), cur.kpts["angle"], idx)
+            if n_m >= 20:
+                break
+            q["radius"] = (q["radius"] * F32(2.0)).astype(np.float32)
+        if n_m < 20:
+            return False, 0
+        cur_idx = [int(idx[k]) for k in range(len(q)) if idx[k] >= 0]
+        lm_ids = [q_lm[k] for k in range(len(q)) if idx[k] >= 0]
+        return self.pose_from_matches(cur, cur_idx, lm_ids, init)
+
+    def track_against_previous(self, cur):
+        ok, inl = self.track_with_motion_model(cur)
+        if ok:
+            self.stats["motion_tracked"] += 1
+            return True, inl
+        mq, mt, _ = O.match_bf(cur.desc, self.prev.desc, 50, 0.9, True)
+        cur_idx, lm_ids = [], []
+        for a, b in zip(mq, mt):
+            lid = self.resolve(self.prev.landmark[int(b)])
+            if lid < 0:
+                continue
+            cur_idx.append(int(a)); lm_ids.append(lid)
+        init = self.predicted_pose() or self.prev.pose.copy()
+        ok, inl = self.pose_from_matches(cur, cur_idx, lm_ids, init)
+        if ok:
+            self.stats["bf_tracked"] += 1
+        return ok, inl
+
+    # ---- local map (trackLocalMap) ---------------------------------------------------------------------------------------------
+    def track_local_map(self, cur):
+        R = quat_to_rot(cur.pose.q)
+        C = [-(R[0, a] * cur.pose.t[0] + R[1, a] * cur.pose.t[1] + R[2, a] * cur.pose.t[2]) for a in range(3)]
+        taken = np.zeros(len(cur.kpts), np.uint8)
+        held = set()
+        held_on_entry = 0
+        for i, lid in enumerate(cur.landmark):
+            if lid >= 0:
+                taken[i] = 1; held.add(lid); held_on_entry += 1
+        if self.ref_kf < 0:
+            return True, held_on_entry
+        local = sorted(self.covisible(self.ref_kf, self.local_window - 1, 15) + [self.ref_kf])
+        q_rows, qd, q_lm = [], [], []
+        for kfi in local:
+            for lid in self.kfs[kfi]["landmark"]:
+                if lid < 0 or lid in held:
+                    continue
+                held.add(lid)
+                if lid not in self.landmarks:
+                    continue
+                lm = self.landmarks[lid]
+                pr = self._project_query(lm["p"], R, cur.pose.t)
+                if pr is None:
+                    continue
+                pc, u, v = pr
+                lvl = self._view_level(lm, lm["p"], C)
+                if lvl is None:
+                    continue
+                q_rows.append((F32(u), F32(v), F32(u - self.cam["fxb"] / pc[2]), F32(5.0) * self.scales[lvl], max(0, lvl - 1), lvl))
+                qd.append(lm["desc"]); q_lm.append(lid)
+        n_new = 0
+        if q_rows:
+            q = np.array(q_rows, O.PROJ_QUERY_DTYPE)
+            idx, _, _ = O.match_projection(cur.kpts, cur.desc, cur.x_right, self.w, self.h, q, np.array(qd, np.uint8), 100, 0.8, taken)
+            for k in range(len(q)):
+                if idx[k] >= 0:
+                    cur.landmark[int(idx[k])] = q_lm[k]; n_new += 1
+        self.stats["local_map_joined"] += n_new
+        if n_new == 0:
+            return True, held_on_entry
+        cur_idx = [i for i, lid in enumerate(cur.landmark) if lid >= 0]
+        lm_ids = [cur.landmark[i] for i in cur_idx]
+        init = cur.pose.copy()
+        before = [lid if taken[i] else -1 for i, lid in enumerate(cur.landmark)]
+        ok, inl = self.pose_from_matches(cur, cur_idx, lm_ids, init)
+        if ok:
+            return True, inl
+        cur.pose = init; cur.landmark = before
+        return False, 0
+
+    def keyframe_needed(self, inliers):
+        if self.since_kf >= self.kf_interval:
+            return True
+        if inliers < 50:
+            return True
+        if self.ref_tracked > 0 and inliers < self.ref_tracked // 4:
+            return True
+        if self.since_kf >= max(1, self.kf_interval // 2) and self.ref_tracked > 0 and 10 * inliers < 6 * self.ref_tracked:
+            return True
+        return False
+
+    # ---- map ---------------------------------------------------------------------------------------------------------------------
+    def merge_landmarks(self, keep, drop, f):
+        if keep not in self.landmarks or drop not in self.landmarks or keep == drop:
+            return
+        lk, ld = self.landmarks[keep], self.landmarks[drop]
+        for (k, kp) in ld["obs"]:
+            sees_keep = any(ko[0] == k for ko in lk["obs"])
+            if sees_keep:
+                self.kfs[k]["landmark"][kp] = -1
+            else:
+                self.kfs[k]["landmark"][kp] = keep; lk["obs"].append((k, kp))
+        del self.landmarks[drop]
+        self.replaced[drop] = keep
+        if f is not None:
+            f.landmark = [keep if l == drop else l for l in f.landmark]
+
+    def fuse_into(self, c, ids, f):
+        kc = self.kfs[c]
+        pose = kc["pose"]
+        R = quat_to_rot(pose.q)
+        C = [-(R[0, a] * pose.t[0] + R[1, a] * pose.t[1] + R[2, a] * pose.t[2]) for a in range(3)]
+        q_rows, qd, q_lm = [], [], []
+        for lid in ids:
+            if lid not in self.landmarks:
+                continue
+            lm = self.landmarks[lid]
+            pr = self._project_query(lm["p"], R, pose.t)
+            if pr is None:
+                continue
+            pc, u, v = pr
+            lvl = self._view_level(lm, lm["p"], C)
+            if lvl is None:
+                continue
+            q_rows.append((F32(u), F32(v), F32(u - self.cam["fxb"] / pc[2]), F32(3.0) * self.scales[lvl], max(0, lvl - 1), lvl))
+            qd.append(lm["desc"]); q_lm.append(lid)
+        if not q_rows:
+            return
+        q = np.array(q_rows, O.PROJ_QUERY_DTYPE)
+        isq = (F32(1.0) / (self.scales.astype(np.float32) ** 2)).astype(np.float32)
+        idx, _, _ = O.match_fuse(kc["kpts"], kc["desc"], kc["x_right"], self.w, self.h, isq, q, np.array(qd, np.uint8), 50)
+        for k in range(len(q)):
+            if idx[k] < 0:
+                continue
+            kp = int(idx[k])
+            lid = self.resolve(q_lm[k])
+            if lid not in self.landmarks:
+                continue
+            lm = self.landmarks[lid]
+            seen = any(o[0] == c for o in lm["obs"])
+            have = kc["landmark"][kp]
+            if have < 0:
+                if seen:
+                    continue
+                kc["landmark"][kp] = lid; lm["obs"].append((c, kp))
+                if kp < len(f.landmark):
+                    f.landmark[kp] = lid
+                self.stats["fused_added"] += 1
+            elif have != lid:
+                if seen or have not in self.landmarks:
+                    continue
+                lh = self.landmarks[have]
+                keep_have = len(lh["obs"]) > len(lm["obs"]) or (len(lh["obs"]) == len(lm["obs"]) and have < lid)
+                keep, drop = (have, lid) if keep_have else (lid, have)
+                self.merge_landmarks(keep, drop, f)
+                if self.prev is not None:
+                    self.prev.landmark = [keep if l == drop else l for l in self.prev.landmark]
+                self.stats["fused_merged"] += 1
+
+    def insert_keyframe(self, f):
+        c = len(self.kfs)
+        baseline = self.cam["fxb"] / self.cam["fx"]
+        depth_thr = 40.0 * baseline
+        R = quat_to_rot(f.pose.q)
+        f.landmark = [self.resolve(l) for l in f.landmark]
+        f.landmark = [l if (l < 0 or l in self.landmarks) else -1 for l in f.landmark]
+        cand = [(float(f.depth[i]), i) for i in range(len(f.kpts)) if f.landmark[i] < 0 and f.depth[i] > 0]
+        cand.sort()
+        tracked = sum(1 for l in f.landmark if l >= 0)
+        first = c == self.segment_start
+        create = set()
+        for r, (d, i) in enumerate(cand):
+            if first or np.float32(d) < depth_thr or tracked + r < 100:
+                create.add(i)
+        for i in range(len(f.kpts)):
+            lid = f.landmark[i]
+            if lid < 0 and i in create:
+                z = float(f.depth[i])
+                xc = (float(f.kpts["x"][i]) - self.cam["cx"]) * z / self.cam["fx"]; yc = (float(f.kpts["y"][i]) - self.cam["cy"]) * z / self.cam["fy"]
+                d = [xc - f.pose.t[0], yc - f.pose.t[1], z - f.pose.t[2]]
+                lm = dict(p=[R[0, a] * d[0] + R[1, a] * d[1] + R[2, a] * d[2] for a in range(3)], ref_kf=c, obs=[(c, i)])
+                self.init_landmark_view(lm, f.pose, f.kpts["octave"][i], f.desc[i])
+                lid = self.next_id; self.next_id += 1
+                self.landmarks[lid] = lm
+                f.landmark[i] = lid
+            elif lid >= 0:
+                self.landmarks[lid]["obs"].append((c, i))
+        self.kfs.append(dict(pose=f.pose.copy(), kpts=f.kpts, desc=f.desc, x_right=f.x_right, depth=f.depth, landmark=list(f.landmark)))
+        nb = self.covisible(c, self.local_window - 1, 15)
+        held = set(l for l in self.kfs[c]["landmark"] if l >= 0)
+        ids = []
+        for k in nb:
+            for lid in self.kfs[k]["landmark"]:
+                if lid >= 0 and lid not in held:
+                    held.add(lid); ids.append(lid)
+        self.fuse_into(c, ids, f)
+        self.ref_kf = c
+        self.ref_tracked = sum(1 for l in self.kfs[c]["landmark"] if l >= 0)
+        self.since_kf = 0
+        self.stats["keyframes"] += 1
+        return c
+
+    # ---- local bundle adjustment, inline (prepareMapping / prepareBundle / solveMapping / applyMapping) ------------------------
+    def local_ba(self, c):
+        if len(self.kfs) < 2:
+            return
+        local = sorted(self.covisible(c, self.local_window - 1, 15) + [c])
+        is_local = set(local)
+        cnt, done = {}, set()
+        for k in local:
+            for lid in self.kfs[k]["landmark"]:
+                if lid < 0 or lid in done:
+                    continue
+                done.add(lid)
+                if lid not in self.landmarks:
+                    continue
+                for (ok_, _) in self.landmarks[lid]["obs"]:
+                    if ok_ not in is_local:
+                        cnt[ok_] = cnt.get(ok_, 0) + 1
+        v = sorted(((n, k) for k, n in cnt.items()), key=lambda e: (-e[0], -e[1]))[:self.local_window]
+        fixed_kfs = [k for _, k in v]
+        allk = sorted(local + fixed_kfs)
+        fixed_set = set(fixed_kfs)
+        of_free = set(l for k in local for l in self.kfs[k]["landmark"] if l >= 0)
+        seen = {}
+        for k in allk:
+            for lid in self.kfs[k]["landmark"]:
+                if lid >= 0 and lid in of_free:
+                    seen[lid] = seen.get(lid, 0) + 1
+        index, ids, pts = {}, [], []
+        for k in allk:
+            for lid in self.kfs[k]["landmark"]:
+                if lid < 0 or lid in index or seen.get(lid, 0) < 2 or lid not in self.landmarks:
+                    continue
+                index[lid] = len(ids); ids.append(lid); pts.append(list(self.landmarks[lid]["p"]))
+        if len(ids) < 20 or len(allk) < 2:
+            return
+        poses, fixed, obs_rows, origin = [], [], [], []
+        any_fixed = False
+        for f_i, k in enumerate(allk):
+            kf = self.kfs[k]
+            poses.append(kf["pose"].seven())
+            fx = k in fixed_set or k == 0 or k == self.segment_start
+            fixed.append(1 if fx else 0)
+            any_fixed = any_fixed or fx
+            for kp, lid in enumerate(kf["landmark"]):
+                if lid < 0 or lid not in index:
+                    continue
+                s = float(self.scales[int(kf["kpts"]["octave"][kp])])
+                xr = float(kf["x_right"][kp])
+                obs_rows.append((f_i, index[lid], float(kf["kpts"]["x"][kp]), float(kf["kpts"]["y"][kp]), xr if xr >= 0 else -1.0, 1.0 / (s * s)))
+                origin.append((k, kp))
+        if not any_fixed:
+            fixed[0] = 1
+        obs = np.array(obs_rows, O.OBS_DTYPE)
+        op, ox, outlier = O.ba_local(np.array(poses), np.array(fixed, np.uint8), np.array(pts, np.float64), obs, self.cam, 5, 10)
+        for f_i, k in enumerate(allk):
+            if not fixed[f_i]:
+                self.kfs[k]["pose"] = Pose(op[f_i][:4], op[f_i][4:])
+        for j, lid in enumerate(ids):
+            r = self.resolve(lid)
+            if r in self.landmarks:
+                self.landmarks[r]["p"] = [float(ox[j][0]), float(ox[j][1]), float(ox[j][2])]
+        for kk in range(len(obs)):
+            if not outlier[kk]:
+                continue
+            k, kp = origin[kk]
+            lid = self.kfs[k]["landmark"][kp]
+            if lid < 0 or lid != self.resolve(ids[int(obs["point"][kk])]):
+                continue
+            self.kfs[k]["landmark"][kp] = -1
+            if lid not in self.landmarks:
+                continue
+            ob = self.landmarks[lid]["obs"]
+            for o_i, o in enumerate(ob):
+                if o == (k, kp):
+                    del ob[o_i]; break
+            if not ob:
+                del self.landmarks[lid]
+        self.stats["local_ba"] += 1
+
+    # ---- one frame ---------------------------------------------------------------------------------------------------------------
+    def extract(self, left, right):
+        kl, dl, _, pl = O.extract(left, self.p, True)
+        kr, dr, _, pr = O.extract(right, self.p, True)
+        fxb = float(np.float32(self.cam["fxb"])); baseline = float(np.float32(self.cam["fxb"] / self.cam["fx"]))
+        xr, dep, _, _ = O.match_stereo(pl, pr, self.p, kl, dl, kr, dr, fxb, baseline)
+        return Frame(kl, dl, xr, dep)
+
+    def feed(self, left, right):
+        """returns the world -> camera pose (7 doubles) reported for this frame, or None while there is none"""
+        cur = self.extract(left, right)
+        self.n_frames += 1
+        if not self.tracking:
+            if int((cur.depth > 0).sum()) >= 40:
+                cur.pose = Pose()
+                self.segment_start = len(self.kfs)
+                self.insert_keyframe(cur)
+                self.tracking = True
+            self.velocity = None
+            self.prev = cur
+        else:
+            ok, inliers = self.track_against_previous(cur)
+            if not ok:
+                raise RuntimeError("the closed-loop oracle does not cover tracking loss (frame %d)" % self.n_frames)
+            ok2, wl = self.track_local_map(cur)
+            if ok2:
+                inliers = wl
+            Rc, Rp = quat_to_rot(cur.pose.q), quat_to_rot(self.prev.pose.q)
+            Rv = np.array([[Rc[r, 0] * Rp[c, 0] + Rc[r, 1] * Rp[c, 1] + Rc[r, 2] * Rp[c, 2] for c in range(3)] for r in range(3)])
+            vt = [cur.pose.t[r] - (Rv[r, 0] * self.prev.pose.t[0] + Rv[r, 1] * self.prev.pose.t[1] + Rv[r, 2] * self.prev.pose.t[2]) for r in range(3)]
+            self.velocity = Pose(rot_to_quat(Rv), vt)
+            self.since_kf += 1
+            if self.keyframe_needed(inliers):
+                c = self.insert_keyframe(cur)
+                self.local_ba(c)
+                cur.pose = self.kfs[c]["pose"].copy()
+            self.prev = cur
+        return self.prev.pose.seven() if self.tracking else None

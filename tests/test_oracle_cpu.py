@@ -451,3 +451,16 @@ def test_fuse_and_area_match_semantics(oracle):
     assert list(idx2) == [-1, k0] and n2 == 1
     idx3, n3 = oracle.match_area(kp, desc, w, h, q2, np.stack([desc[k0], worse]), 50, 0.9)
     assert list(idx3) == [k0, -1] and n3 == 1
+
+
+def test_closed_loop_oracle_is_reproducible(oracle):
+    """the golden is what oracle/tracker.py makes today (first 8 frames; the whole sequence is regenerated by tools/make_golden_track.py)"""
+    from oracle import tracker as T
+    g = golden("g10_track.npz")
+    W, H = 640, 480
+    k = synth.intrinsics(W, H)
+    seq = synth.StereoSequence(W, H, 4, n_points=6000)
+    trk = T.StereoTracker(W, H, k, max_keypoints=1000, num_levels=4, scale_factor=1.2, keyframe_interval=4, local_window=10)
+    for i in range(8):
+        pose = trk.feed(*seq.frame(i))
+        assert np.allclose(pose, g["poses"][i], rtol=0, atol=1e-12), i
