@@ -201,6 +201,12 @@ def cpu_baseline():
     from oracle import oracle as O
     from lpslam_amd import synth
     ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    n_visible = ncpu
+    try:        # the cores this job may actually use: the cgroup's CPU quota where there is one, else the one-GPU share of the box (16)
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        ncpu = min(ncpu, max(1, int(int(quota) / int(period)))) if quota != "max" else min(ncpu, 16)
+    except (OSError, ValueError):
+        ncpu = min(ncpu, 16)
     model = "unknown"
     try:
         for line in open("/proc/cpuinfo"):
@@ -264,7 +270,7 @@ def cpu_baseline():
     best = {"value": round(n_thr * KF_INTERVAL / t_all, 3), "unit": "frames/s", "cores": n_thr, "kind": "port", "flags": flags,
             "sample": "%d threads, each one keyframe interval of the workload (6 stereo frames: extract L+R, stereo match, 2000x2000 BF; one local BA of "
                       "%d LM iterations); CPU restatement of the OpenVSLAM / g2o algorithms, not OpenVSLAM itself" % (n_thr, BA_ITERS),
-            "host": {"nproc": ncpu, "cpu_model": model}}
+            "host": {"nproc": n_visible, "cores_used": ncpu, "cpu_model": model}}
     O.use_native_build(False)
     return best, legs
 
