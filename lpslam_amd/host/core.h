@@ -89,6 +89,7 @@ public:
     void pop(T& out) { std::unique_lock<std::mutex> l(m_); cv_.wait(l, [&] { return !q_.empty(); }); out = std::move(q_.front()); q_.pop_front(); }
     bool try_pop(T& out) { std::lock_guard<std::mutex> l(m_); if (q_.empty()) return false; out = std::move(q_.front()); q_.pop_front(); return true; }
     size_t size() { std::lock_guard<std::mutex> l(m_); return q_.size(); }
+    void clear() { std::lock_guard<std::mutex> l(m_); q_.clear(); }
 private:
     std::mutex m_; std::condition_variable cv_; std::deque<T> q_;
 };

@@ -86,13 +86,23 @@ bool decode_pgm(const uint8_t* d, size_t size, GrayImage& out)
     return true;
 }
 
-bool read_replay_file(const std::string& path, std::vector<ReplayFrame>& frames, ReplayStats& stats, std::string* err)
+bool ReplayReader::open(const std::string& path, std::string* err)
 {
-    std::ifstream in(path, std::ios::binary);
-    if (!in) { if (err) *err = "cannot open " + path; return false; }
+    m_in.close(); m_in.clear();
+    m_in.open(path, std::ios::binary);
+    m_done = false; m_stats = ReplayStats{};
+    if (!m_in) { if (err) *err = "cannot open " + path; m_done = true; return false; }
+    return true;
+}
+
+// The next decodable camera frame; false at the end of the stream (clean, or the first record the format does not know).
+bool ReplayReader::next(ReplayFrame& out)
+{
     constexpr uint64_t kMaxMessage = 1ull << 30;                    // ProtoStream refuses larger buffers as corrupt
-    std::vector<uint8_t> buf;
-    for (;;) {
+    std::ifstream& in = m_in;
+    ReplayStats& stats = m_stats;
+    std::vector<uint8_t>& buf = m_buf;
+    while (!m_done) {
         uint64_t type = 0, size = 0;
         if (!in.read(reinterpret_cast<char*>(&type), 8)) break;     // clean end of file
         if (!in.read(reinterpret_cast<char*>(&size), 8) || size > kMaxMessage) { stats.truncated = true; break; }
@@ -137,8 +147,20 @@ bool read_replay_file(const std::string& path, std::vector<ReplayFrame>& frames,
         }
         if (has_odom && flag_odom) fr.odom = odom;
         if (has_map && flag_map) fr.map = map;
-        frames.push_back(std::move(fr));
+        out = std::move(fr);
+        return true;
     }
+    m_done = true;
+    return false;
+}
+
+bool read_replay_file(const std::string& path, std::vector<ReplayFrame>& frames, ReplayStats& stats, std::string* err)
+{
+    ReplayReader r;
+    if (!r.open(path, err)) return false;
+    ReplayFrame f;
+    while (r.next(f)) frames.push_back(std::move(f));
+    stats = r.stats();
     return true;
 }
 

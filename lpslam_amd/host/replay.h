@@ -10,6 +10,7 @@
 // carry: those frames are counted and skipped.
 #pragma once
 #include <cstdint>
+#include <fstream>
 #include <optional>
 #include <string>
 #include <vector>
@@ -34,6 +35,21 @@ struct ReplayFrame {
 struct ReplayStats {
     size_t records = 0, camera = 0, imu = 0, global_state = 0, result = 0, feature = 0, undecodable_images = 0;
     bool truncated = false;              // the reference also stops at the first unknown record type (corrupt tails happen)
+};
+
+// Walks the stream one camera frame at a time, so a long recording is never resident as a whole (the reference reads
+// `replay_chunks` camera records at a time as its camera queue drains, ReplayEngine.cpp:77-100).
+class ReplayReader {
+public:
+    bool open(const std::string& path, std::string* err);
+    bool next(ReplayFrame& out);
+    bool done() const { return m_done; }
+    const ReplayStats& stats() const { return m_stats; }
+private:
+    std::ifstream m_in;
+    std::vector<uint8_t> m_buf;
+    ReplayStats m_stats;
+    bool m_done = true;
 };
 
 bool read_replay_file(const std::string& path, std::vector<ReplayFrame>& frames, ReplayStats& stats, std::string* err);

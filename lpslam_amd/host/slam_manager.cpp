@@ -106,6 +106,7 @@ bool SlamManager::readConfigurationFile(std::string const& filename)
         if (const Json* m = j.find("manager")) {
             if (const Json* t = m->find("thread_num")) m_thread_num = (int)t->asNumber();
             if (const Json* r = m->find("require_odometry")) m_requireOdometry = r->asBool();
+            if (const Json* c = m->find("replay_chunks")) m_replayChunk = (size_t)std::max(1.0, c->asNumber());   // SlamManager.cpp:668-671
             // record / show_live / record_raw / replay_chunks belong to subsystems outside the accelerated path: accepted, ignored
         }
         auto plugin_list = [&](const char* section, const char* what, auto add) -> bool {
@@ -254,37 +255,57 @@ bool SlamManager::addImageFromBuffer(uint32_t cameraNumber, LpSlamTimestamp time
 }
 
 // ---- replay (src/Manager/ReplayEngine.cpp:61-242) ---------------------------------------------------------------------------
-// The reference streams the file in chunks of `replay_chunks` camera records as the camera queue drains; frames are small here
-// and the whole file is queued at once.  As there, replayed frames carry no ROS time stamp, so the navigation callback is
-// not asked for them (SlamManager.cpp:148): trackers see them only with "require_odometry": false.
+// As in the reference, the file is streamed: `replay_chunks` camera records (manager section of the configuration, 500 by
+// default) are decoded now, and the worker asks for the next chunk whenever the camera queue has drained below half a chunk
+// (ReplayEngine.cpp:77-100), so a long recording is never resident as a whole.  Replayed frames carry no ROS time stamp, so the
+// navigation callback is not asked for them (SlamManager.cpp:148): trackers see them only with "require_odometry": false.
 bool SlamManager::loadReplayItems(std::string const& filename)
 {
     logMessage(LpSlamLogLevel_Info, "Loading replay items from file " + filename);
-    std::vector<ReplayFrame> frames;
-    ReplayStats st;
-    std::string err;
-    if (!read_replay_file(filename, frames, st, &err)) { logMessage(LpSlamLogLevel_Info, "Cannot load replay from file " + filename); return false; }
-    for (auto& f : frames) {
+    {
+        ReplayReader r;
+        std::string err;
+        if (!r.open(filename, &err)) { logMessage(LpSlamLogLevel_Info, "Cannot load replay from file " + filename); return false; }
+        std::lock_guard<std::mutex> l(m_replayMutex);
+        m_replay = std::move(r);
+    }
+    streamMoreReplayItems();
+    return true;
+}
+
+void SlamManager::streamMoreReplayItems()
+{
+    std::lock_guard<std::mutex> l(m_replayMutex);
+    if (m_replay.done() || m_camQueue.size() >= (m_replayChunk + 1) / 2) return;
+    size_t loaded = 0;
+    ReplayFrame f;
+    while (loaded < m_replayChunk && m_replay.next(f)) {
         CameraQueueEntry q;
         q.valid = true; q.timestamp = int64ToTimeStamp(f.timestamp);
         q.cameraNumber = (uint32_t)f.camera; q.cameraNumberSecond = (uint32_t)f.camera_second;
         q.image = std::move(f.image);
         if (f.image_second) q.image_second = std::move(*f.image_second);
         m_camQueue.push(std::move(q));
+        ++loaded;
     }
-    logMessage(LpSlamLogLevel_Info, "Loaded " + std::to_string(frames.size()) + " replay items (" + std::to_string(st.records) + " records, " +
-               std::to_string(st.undecodable_images) + " frames with an image codec this library does not carry" + (st.truncated ? ", stream truncated)" : ")"));
-    return true;
+    const ReplayStats& st = m_replay.stats();
+    logMessage(LpSlamLogLevel_Info, "Loaded " + std::to_string(loaded) + " replay items (" + std::to_string(st.records) + " records so far, " +
+               std::to_string(st.undecodable_images) + " frames with an image codec this library does not carry" +
+               (st.truncated ? ", stream truncated)" : m_replay.done() ? ", end of stream)" : ")"));
 }
 
 // ---- threads (src/Manager/SlamManager.cpp:54-257) ----------------------------------------------------------------------
 bool SlamManager::workerStep()
 {
+    streamMoreReplayItems();                           // SlamManager.cpp:56-57
     CameraQueueEntry cam;
     m_camQueue.pop(cam);
-    if (!cam.valid) return false;                      // exit signal
+    if (!cam.valid || m_stopRequested.load()) return false;   // exit signal; a stop abandons the backlog (SlamManager::stop)
     const auto now = std::chrono::steady_clock::now();
-    if (m_lastFrame) { const double dt = std::chrono::duration<double>(now - *m_lastFrame).count(); if (dt > 0) m_currentFps = 0.9 * m_currentFps + 0.1 / dt; }
+    if (m_lastFrame) {                                  // m_lastFrame belongs to this thread; the rate is read by getSlamStatus
+        const double dt = std::chrono::duration<double>(now - *m_lastFrame).count();
+        if (dt > 0) m_currentFps.store(0.9 * m_currentFps.load() + 0.1 / dt);
+    }
     m_lastFrame = now;
 
     std::vector<SensorQueueEntry> sensors;
@@ -342,6 +363,7 @@ void SlamManager::start()
         t->addRequestNavTransformationCallback(m_requestNavTransformation, m_requestNavTransformationData);
     }
     m_running = true;
+    m_stopRequested.store(false);
     m_worker = std::thread([this] { while (workerStep()) {} });
     m_notifyWorker = std::thread([this] { while (notifyStep()) {} });
 }
@@ -349,6 +371,10 @@ void SlamManager::start()
 void SlamManager::stop()
 {
     if (!m_running) return;
+    // the reference stops its worker and clears the camera queue (SlamManager::stop -> stopAsync + m_camQueue.clear()): frames
+    // still queued are dropped, not tracked
+    m_stopRequested.store(true);
+    m_camQueue.clear();
     CameraQueueEntry poison; poison.valid = false;
     m_camQueue.push(std::move(poison));
     if (m_worker.joinable()) m_worker.join();
@@ -364,7 +390,7 @@ LpSlamStatus SlamManager::getSlamStatus()
     LpSlamStatus s{};
     s.localization = LpSlamLocalization_Off;
     if (m_vslamTracker) s = m_vslamTracker->getSlamStatus();
-    s.fps = m_currentFps;
+    s.fps = m_currentFps.load();
     return s;
 }
 

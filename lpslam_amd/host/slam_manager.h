@@ -3,6 +3,7 @@
 #pragma once
 #include "core.h"
 #include "hip_tracker.h"
+#include "replay.h"
 
 #include <atomic>
 #include <thread>
@@ -49,6 +50,7 @@ public:
     uint64_t framesSkipped() const { return m_framesSkipped.load(); }
 
 private:
+    void streamMoreReplayItems();
     bool workerStep();
     bool notifyStep();
 
@@ -64,7 +66,11 @@ private:
     bool m_requireOdometry = true;       // reference behaviour: frames without odometry are skipped (SlamManager.cpp:193-196)
     int m_thread_num = -1;
     std::atomic<uint64_t> m_framesProcessed{0}, m_framesSkipped{0};
-    double m_currentFps = 0.0;
+    std::atomic<double> m_currentFps{0.0};
+    std::atomic<bool> m_stopRequested{false};
+    ReplayReader m_replay;
+    std::mutex m_replayMutex;
+    size_t m_replayChunk = 500;          // ReplayEngine.h:53
     std::optional<std::chrono::steady_clock::time_point> m_lastFrame;
 
     OnReconstructionCallback_t m_onReconstruction = nullptr; void* m_onReconstructionData = nullptr;

@@ -68,7 +68,7 @@ def test_replay_file_through_the_manager(hiplib, tmp_path):
     seq = synth.StereoSequence(w, h, 6, n_points=6000)
     stream = b"".join(rf.record(rf.CAMERA_IMAGE, rf.camera_image((i + 1) * 40_000_000, *seq.frame(i), cam=0, data_number=i)) for i in range(n_frames))
     rec = tmp_path / "drive.pb"; rec.write_bytes(stream)
-    cfg = {"manager": {"require_odometry": False}}
+    cfg = {"manager": {"require_odometry": False, "replay_chunks": 4}}     # streamed: 4 records at a time as the queue drains
     cfg_path = tmp_path / "replay.json"; cfg_path.write_text(json.dumps(cfg))
     m = manager.Manager()
     assert m.read_configuration_file(str(cfg_path))
@@ -325,3 +325,56 @@ def test_radial_camera_mask_through_the_tracker(hiplib, tmp_path):
     u = k["fx"] * xo / zo + k["cx"]; v = k["fy"] * yo / zo + k["cy"]
     r = np.hypot(u - w // 2, v - h // 2)
     assert np.percentile(r, 99) < 185 and r.max() < 215            # later frames see the landmarks a little further out
+
+
+def test_two_managers_in_one_process(hiplib):
+    """Two LpSlamManagers (two HIP contexts, two workers, two BA streams) tracking at the same time in one process -- the shape
+    of `bench.py --gpus N` replicas and of a host with two camera rigs: with inline mapping both give the trajectory one gives
+    alone, bit for bit."""
+    import threading
+    from lpslam_amd import _build, manager
+    _build.host_library()
+    w, h, n_frames = 640, 480, 16
+    seq = synth.StereoSequence(w, h, 4, n_points=6000)
+    frames = [seq.frame(i) for i in range(n_frames)]
+    cfg = '{"cameraSetup": "stereo", "slamKeypoints": 1000, "numLevels": 4, "keyframeInterval": 4, "asyncMapping": false}'
+
+    def run(m):
+        m.start()
+        _feed(m, frames)
+        m.stop()
+
+    alone = _stereo_manager(manager, w, h, cfg)
+    run(alone)
+    pair = [_stereo_manager(manager, w, h, cfg) for _ in range(2)]
+    threads = [threading.Thread(target=run, args=(m,)) for m in pair]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    ref = [(r["valid"], tuple(r["p"]), tuple(r["q"])) for r in alone.results]
+    assert len(ref) == n_frames and sum(v for v, _, _ in ref) >= n_frames - 2
+    for m in pair:
+        assert [(r["valid"], tuple(r["p"]), tuple(r["q"])) for r in m.results] == ref
+
+
+def test_stop_abandons_the_backlog(hiplib):
+    """LpSlamManager::stop drops the frames still queued instead of tracking them (the reference stops its worker and clears the
+    camera queue, src/Manager/SlamManager.cpp stop()), and the manager starts again afterwards."""
+    from lpslam_amd import _build, manager
+    _build.host_library()
+    w, h = 640, 480
+    seq = synth.StereoSequence(w, h, 4, n_points=6000)
+    frames = [seq.frame(i % 8) for i in range(200)]
+    m = _stereo_manager(manager, w, h, '{"cameraSetup": "stereo", "slamKeypoints": 1000, "numLevels": 4, "keyframeInterval": 4}')
+    m.start()
+    for i, (l, r) in enumerate(frames):
+        assert m.add_stereo((i + 1) * 40_000_000, l, r)
+    t0 = time.time()
+    m.stop()
+    assert time.time() - t0 < 5.0 and len(m.results) < len(frames)
+    done = len(m.results)
+    m.start()
+    _feed(m, frames[:4], t0_ns=300 * 40_000_000, expect=done + 4)
+    m.stop()
+    assert len(m.results) == done + 4
