@@ -39,6 +39,7 @@ constexpr int MAX_LOG = 64;
 __host__ __device__ inline bool cw_fits(int dim);      // the system fits the single-workgroup factorisation (ba_solve.inl)
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
 
 struct BaCam { double fx, fy, cx, cy, fxb, hub_mono, hub_stereo; };
 
@@ -920,6 +921,126 @@ __device__ __forceinline__ bool chol_panel_regs(double (&a)[NB], int lane, doubl
     fail |= chol_half_regs<16>(a, lane);
     return fail;
 }
+// ---- 16-column strip of a panel, rank-1 multipliers by DPP ---------------------------------------------------------------
+// The diagonal block D (16 x 16) is held REPLICATED: lane l keeps row l & 15 in d[0..15], so every 16-lane DPP row owns a full
+// copy, and x[0..15] is the lane's own row of whatever rides along below D (64 rows per wavefront).  The rank-1 update of column
+// jj, a[c] -= l[c] * l[row], then is ONE instruction per column and register set: v_fmac_f64_dpp with row_newbcast:c fetches
+// l[c] from lane c of the lane's own DPP row (the DP ALU only knows this DPP control, gfx90a+).  The readlane form it replaces
+// costs three issue slots per column (two v_readlane_b32 + the fma) and keeps the multipliers in SGPRs, which spilled; on
+// MI355X a strip with 64 riding rows takes 2.4k cycles against 3.4k (micro-benchmark) and 7.4k inside k_chol_pair.
+// Hazard: a VALU write of the DPP source needs two wait states before the DPP read and the compiler does not look into inline
+// assembly, so every block starts with s_nop 1.
+#define LP_DPPF(c) "v_fmac_f64_dpp %" #c ", %16, -%17 row_newbcast:" #c " row_mask:0xf bank_mask:0xf\n\t"
+#define LP_F15 LP_DPPF(15)
+#define LP_F14 LP_DPPF(14) LP_F15
+#define LP_F13 LP_DPPF(13) LP_F14
+#define LP_F12 LP_DPPF(12) LP_F13
+#define LP_F11 LP_DPPF(11) LP_F12
+#define LP_F10 LP_DPPF(10) LP_F11
+#define LP_F9 LP_DPPF(9) LP_F10
+#define LP_F8 LP_DPPF(8) LP_F9
+#define LP_F7 LP_DPPF(7) LP_F8
+#define LP_F6 LP_DPPF(6) LP_F7
+#define LP_F5 LP_DPPF(5) LP_F6
+#define LP_F4 LP_DPPF(4) LP_F5
+#define LP_F3 LP_DPPF(3) LP_F4
+#define LP_F2 LP_DPPF(2) LP_F3
+#define LP_F1 LP_DPPF(1) LP_F2
+#define LP_ACC16(a) "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15])
+// a[c] -= (src of lane c of this DPP row) * mul   for c = FROM .. 15
+template <int FROM>
+__device__ __forceinline__ void dpp_rank1(double (&a)[16], double src, double mul)
+{
+#define LP_CASE(k, S) if constexpr (FROM == k) asm("s_nop 1\n\t" S : LP_ACC16(a) : "v"(src), "v"(mul));
+    LP_CASE(1, LP_F1) LP_CASE(2, LP_F2) LP_CASE(3, LP_F3) LP_CASE(4, LP_F4) LP_CASE(5, LP_F5) LP_CASE(6, LP_F6) LP_CASE(7, LP_F7) LP_CASE(8, LP_F8)
+    LP_CASE(9, LP_F9) LP_CASE(10, LP_F10) LP_CASE(11, LP_F11) LP_CASE(12, LP_F12) LP_CASE(13, LP_F13) LP_CASE(14, LP_F14) LP_CASE(15, LP_F15)
+#undef LP_CASE
+}
+template <int L>
+__device__ __forceinline__ double dpp_bcast(double v)          // the value of lane L of this lane's DPP row
+{
+    double r;
+    asm("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "n"(L));
+    return r;
+}
+// 1 / sqrt(d): v_rsq_f64 (about 2^-23) + two Goldschmidt steps; five dependent levels instead of the eight of two Newton steps
+__device__ __forceinline__ double pivot_rsqrt_gs(double d)
+{
+    const double y = __builtin_amdgcn_rsq(d);
+    double g = d * y, h = 0.5 * y;
+    double r = fma(-h, g, 0.5);
+    g = fma(g, r, g); h = fma(h, r, h);
+    r = fma(-h, g, 0.5);
+    h = fma(h, r, h);
+    return h + h;
+}
+template <int JJ>
+__device__ __forceinline__ void strip_step(double (&d)[16], double (&x)[16], double piv, bool& fail)
+{
+    if (!(piv > 0.0)) { fail = true; piv = 1.0; }
+    const double rs = pivot_rsqrt_gs(piv);
+    const double l = d[JJ] * rs, lx = x[JJ] * rs;
+    d[JJ] = l; x[JJ] = lx;
+    if constexpr (JJ < 15) {
+        // column JJ + 1 of D first and alone: the next pivot comes out of it, and its reciprocal square root (the longest
+        // dependent chain of a step) runs beside the rest of this step's updates
+        asm("s_nop 1\n\tv_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(d[JJ + 1]) : "v"(l), "v"(l), "n"(JJ + 1));
+        const double next = dpp_bcast<JJ + 1>(d[JJ + 1]);
+        if constexpr (JJ < 14) dpp_rank1<JJ + 2>(d, l, l);
+        dpp_rank1<JJ + 1>(x, l, lx);
+        strip_step<JJ + 1>(d, x, next, fail);
+    }
+}
+// d <- chol(D) (lower part; rows above the diagonal of a column hold values nobody reads), x <- x chol(D)^-T
+__device__ __forceinline__ bool strip_factor(double (&d)[16], double (&x)[16])
+{
+    bool fail = false;
+    strip_step<0>(d, x, dpp_bcast<0>(d[0]), fail);
+    return fail;
+}
+// Register Cholesky of a 32-column panel [D; B] from two padded LDS blocks (B may be absent): two strips with the block product
+// between them on the matrix cores (through this wavefront's scratch).  Lane l carries row l & 15 of the replicated diagonal
+// block of each strip, and in x / y its own row of the stack  [D rows 16..31 (lanes 0-15); B rows 0..31 (lanes 16-47)]:
+//   dA = L00, x = [L10; L_B,0], dB = L11, y = [L11; L_B,1]  (lanes 48-63 idle along with zeros)
+struct PanelRegs { double dA[16], x[16], dB[16], y[16]; };
+__device__ __forceinline__ bool chol_panel_dpp(PanelRegs& p, const double* Dblk, const double* Bblk, int lane, double* scr)
+{
+    const int r = lane & 15;
+    const double* own = lane < 16 ? Dblk + (16 + lane) * (NB + 1) : (Bblk != nullptr && lane < 48 ? Bblk + (lane - 16) * (NB + 1) : nullptr);
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        p.dA[c] = Dblk[r * (NB + 1) + c];
+        p.x[c] = own ? own[c] : 0.0;
+        p.y[c] = own ? own[16 + c] : 0.0;
+    }
+    bool fail = strip_factor(p.dA, p.x);
+    double* Ls = scr; double* Us = scr + 64 * 17;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) Ls[lane * 17 + k] = p.x[k];
+    const int lr = lane & 15, lk = lane >> 4;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {                        // U[16t.., :] = X[16t.., :] (X[0..15, :])^T, K = 16 (rows 48.. are zero)
+        f64x4 acc = {0, 0, 0, 0};
+#pragma unroll
+        for (int s4 = 0; s4 < 16; s4 += 4)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ls[(16 * t + lr) * 17 + s4 + lk], Ls[lr * 17 + s4 + lk], acc, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Us[(16 * t + lk + 4 * q) * 17 + lr] = acc[q];
+    }
+    if (lane < 48) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) p.y[c] -= Us[lane * 17 + c];
+    }
+    // the second diagonal block, updated, goes back out to every DPP row
+    if (lane < 16) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) Ls[lane * 17 + c] = p.y[c];
+    }
+#pragma unroll
+    for (int c = 0; c < 16; ++c) p.dB[c] = Ls[r * 17 + c];
+    fail |= strip_factor(p.dB, p.y);
+    return fail;
+}
 // acc += A[tr.., :] B[tc.., :]^T over one 32-wide k-block (16x16 tile, 8 x v_mfma_f64_16x16x4)
 __device__ __forceinline__ f64x4 mfma_tile32(const double* A, const double* B, int tr, int tc, int lr, int lk, f64x4 acc)
 {
@@ -937,19 +1058,24 @@ __device__ __forceinline__ void tile_sub(double* D, int tr, int tc, int lr, int 
 __global__ __launch_bounds__(256) void k_chol_pair(const BaView* __restrict__ views, int m, int pin, int skip_small)
 {
     if (pin && (blockIdx.x & 7)) return;                 // small launches: XCD 0 only (see above); large ones use the whole chip
-    BA_VIEW(v);
-    const int nb = v.dim_pad / NB;
-    if (2 * m >= nb || v.dim == 0 || (skip_small && cw_fits(v.dim))) return;   // a batch runs the panel pairs of its largest system; small systems may be k_chol_wg's
+    // Everything this kernel reads of its view, fetched in ONE round trip: left to itself the compiler loads each member where it
+    // is first used, and the prologue becomes a chain of dependent round trips (measured: 3 us of an 18 us launch went into ten
+    // of them -- arguments, sizes, control block, pointers, four passes of block loads).
+    const BaView& vw = views[blockIdx.y];
+    const int dim = vw.dim, n = vw.dim_pad;
+    GPTR(double) S = vw.S; GPTR(double) M = vw.Minv; GPTR(double) Ldiag = vw.Ldiag; GPTR(double) Lsub = vw.Lsub; GPTR(double) scal = vw.scal;
+    GPTR(BaCtl) ctl = vw.ctl;
+    asm volatile("" :: "s"(dim), "s"(n), "s"(S), "s"(M), "s"(Ldiag), "s"(Lsub), "s"(scal), "s"(ctl));
+    const int nb = n / NB;
+    if (2 * m >= nb || dim == 0 || (skip_small && cw_fits(dim))) return;   // a batch runs the panel pairs of its largest system; small systems may be k_chol_wg's
     const int bid = pin ? blockIdx.x >> 3 : blockIdx.x;
     {
         const int ncol0 = (2 * m + 1 < nb) ? 2 : 1, T0 = nb - 2 * m - ncol0;
         if (bid >= 1 + T0 + 2 * m + ncol0 + (m > 0 ? T0 * (T0 + 1) / 2 + 2 * m * T0 : 0)) return;
     }
-    const bool idle = ba_idle(v.ctl);
+    // the control block travels with the block loads below (no short circuit: one round trip, awaited after they are issued)
+    const int c_stopped = ctl->stopped, c_done = ctl->outer_done, c_max = ctl->max_outer;
     extern __shared__ double cp_lds[];
-    GPTR(double) S = v.S;
-    GPTR(double) M = v.Minv;
-    const int n = v.dim_pad;
     const int j = 2 * m, j1 = j + 1;
     const bool single = j1 >= nb;
     const bool prev = m > 0;
@@ -960,11 +1086,14 @@ __global__ __launch_bounds__(256) void k_chol_pair(const BaView* __restrict__ vi
     const int n_panel = 1 + n_rows + n_extra;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int tr = (wave >> 1) * 16, tc = (wave & 1) * 16, lr = tid & 15, lk = lane >> 4;
-    // one element of a block: mode 0 copy from memory, 1 zero, 2 identity.  All blocks of a workgroup are fetched in the same
-    // four passes so that their loads are in flight together (one round trip per pass, not one per block).
-    auto elem = [&](const double* src, size_t r0, size_t c0, int mode, int r, int c) -> double {
-        return mode == 0 ? src[(r0 + r) * n + c0 + c] : (mode == 2 && r == c ? 1.0 : 0.0);
+    // A block of the matrix on its way into LDS: mode 0 copy from memory, 1 zero, 2 identity.  Every block is LOADED, whatever
+    // its mode (blocks that are not read point at the pair's own diagonal block, which always exists): with the loads
+    // unconditional all of them -- 44 per thread in a panel workgroup -- are in flight together, one round trip.
+    struct Blk { const double* p; int mode; };
+    auto blk = [&](const double* src, size_t r0, size_t c0, int mode) -> Blk {
+        return mode == 0 ? Blk{src + r0 * n + c0, 0} : Blk{S + (size_t)j * NB * n + (size_t)j * NB, mode};
     };
+    auto fill = [&](int mode, double ld, int r, int c) -> double { return mode == 0 ? ld : (mode == 2 && r == c ? 1.0 : 0.0); };
     if (bid >= n_panel) {
         // ---- trailing update of block (i2, j2), j2 >= j + ncol, with the previous pair
         const int T = nb - j - ncol;
@@ -982,24 +1111,37 @@ __global__ __launch_bounds__(256) void k_chol_pair(const BaView* __restrict__ vi
             overwrite = e >= kb0;                        // first contribution to this block: it holds no value yet
         }
         double* Li0 = cp_lds; double* Li1 = cp_lds + CP_BLK; double* Lj0 = cp_lds + 2 * CP_BLK; double* Lj1 = cp_lds + 3 * CP_BLK;
-        const int mi0 = e > kb0 ? 1 : 0, mi1 = e > kb1 ? 1 : 0;              // Minv block (e, k) is structurally zero for k < e
+        // Minv block (e, k) is structurally zero for k < e
+        const Blk bk[4] = {blk(srcI, ri, (size_t)kb0 * NB, e > kb0 ? 1 : 0), blk(srcI, ri, (size_t)kb1 * NB, e > kb1 ? 1 : 0),
+                           blk(S, rj, (size_t)kb0 * NB, 0), blk(S, rj, (size_t)kb1 * NB, 0)};
+        f64x2 ld[2][4];                                  // two adjacent columns per lane: 16-byte loads, 16 lanes to a 256-byte row
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int t = tid + it * 256, r = t / NB, c = t % NB, o = r * (NB + 1) + c;
-            const double a0 = elem(srcI, ri, (size_t)kb0 * NB, mi0, r, c), a1 = elem(srcI, ri, (size_t)kb1 * NB, mi1, r, c);
-            const double b0 = elem(S, rj, (size_t)kb0 * NB, 0, r, c), b1 = elem(S, rj, (size_t)kb1 * NB, 0, r, c);
-            Li0[o] = a0; Li1[o] = a1; Lj0[o] = b0; Lj1[o] = b1;
+        for (int it = 0; it < 2; ++it) {
+            const int t = 2 * tid + it * 512, r = t / NB, c = t % NB;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) ld[it][q] = *reinterpret_cast<const f64x2*>(bk[q].p + (size_t)r * n + c);
         }
-        if (idle) return;
+        double old[4];
+        if (!overwrite) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) old[q] = dst[(ri + tr + lk + 4 * q) * n + rj + tc + lr];
+        }
+        if (c_stopped | (c_done >= c_max)) return;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int t = 2 * tid + it * 512, r = t / NB, c = t % NB, o = r * (NB + 1) + c;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                Li0[o + h] = fill(bk[0].mode, ld[it][0][h], r, c + h); Li1[o + h] = fill(bk[1].mode, ld[it][1][h], r, c + h);
+                Lj0[o + h] = ld[it][2][h]; Lj1[o + h] = ld[it][3][h];
+            }
+        }
         __syncthreads();
         f64x4 acc = {0, 0, 0, 0};
         acc = mfma_tile32(Li0, Lj0, tr, tc, lr, lk, acc);
         acc = mfma_tile32(Li1, Lj1, tr, tc, lr, lk, acc);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            double* d = &dst[(ri + tr + lk + 4 * q) * n + rj + tc + lr];
-            *d = overwrite ? -acc[q] : *d - acc[q];
-        }
+        for (int q = 0; q < 4; ++q) dst[(ri + tr + lk + 4 * q) * n + rj + tc + lr] = overwrite ? -acc[q] : old[q] - acc[q];
         return;
     }
     // ---- panel workgroup
@@ -1022,18 +1164,28 @@ __global__ __launch_bounds__(256) void k_chol_pair(const BaView* __restrict__ vi
     const int mp = prev ? 0 : 1, mps = (prev && !single) ? 0 : 1;
     const int mi0 = (!prev || !has_b || (extra && i > kb0)) ? 1 : 0, mi1 = (!prev || !has_b || (extra && i > kb1)) ? 1 : 0;
     const size_t c0 = (size_t)(prev ? kb0 : 0) * NB, c1 = (size_t)(prev ? kb1 : 0) * NB;
+    // in the order of the LDS blocks: Dj X Dj1 B0 B1 Ljk0 Ljk1 Lj1k0 Lj1k1 Lik0 Lik1
+    const Blk bk[11] = {blk(S, rj, rj, 0), blk(S, rj1, rj, ms), blk(S, rj1, rj1, ms), blk(Bsrc, ri, rj, mode0), blk(Bsrc, ri, rj1, mode1),
+                        blk(S, rj, c0, mp), blk(S, rj, c1, mp), blk(S, rj1, c0, mps), blk(S, rj1, c1, mps), blk(Bsrc, ri, c0, mi0), blk(Bsrc, ri, c1, mi1)};
+    {
+        f64x2 ld[2][11];
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int t = tid + it * 256, r = t / NB, c = t % NB, o = r * (NB + 1) + c;
-        const double vDj = elem(S, rj, rj, 0, r, c), vX = elem(S, rj1, rj, ms, r, c), vDj1 = elem(S, rj1, rj1, ms, r, c);
-        const double vB0 = elem(Bsrc, ri, rj, mode0, r, c), vB1 = elem(Bsrc, ri, rj1, mode1, r, c);
-        const double vj0 = elem(S, rj, c0, mp, r, c), vj1 = elem(S, rj, c1, mp, r, c);
-        const double vq0 = elem(S, rj1, c0, mps, r, c), vq1 = elem(S, rj1, c1, mps, r, c);
-        const double vi0 = elem(Bsrc, ri, c0, mi0, r, c), vi1 = elem(Bsrc, ri, c1, mi1, r, c);
-        Dj[o] = vDj; X[o] = vX; Dj1[o] = vDj1; B0[o] = vB0; B1[o] = vB1;
-        Ljk0[o] = vj0; Ljk1[o] = vj1; Lj1k0[o] = vq0; Lj1k1[o] = vq1; Lik0[o] = vi0; Lik1[o] = vi1;
+        for (int it = 0; it < 2; ++it) {
+            const int t = 2 * tid + it * 512, r = t / NB, c = t % NB;
+#pragma unroll
+            for (int q = 0; q < 11; ++q) ld[it][q] = *reinterpret_cast<const f64x2*>(bk[q].p + (size_t)r * n + c);
+        }
+        if (c_stopped | (c_done >= c_max)) return;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int t = 2 * tid + it * 512, r = t / NB, c = t % NB, o = r * (NB + 1) + c;
+#pragma unroll
+            for (int q = 0; q < 11; ++q) {
+                cp_lds[q * CP_BLK + o] = fill(bk[q].mode, ld[it][q][0], r, c);
+                cp_lds[q * CP_BLK + o + 1] = fill(bk[q].mode, ld[it][q][1], r, c + 1);
+            }
+        }
     }
-    if (idle) return;
     __syncthreads();
     if (prev) {                                          // 1. lookahead of the blocks the first factorisations need
         f64x4 acc = {0, 0, 0, 0};
@@ -1052,34 +1204,39 @@ __global__ __launch_bounds__(256) void k_chol_pair(const BaView* __restrict__ vi
     }
     __syncthreads();
     bool fail = false;
-    if (wave == 0 && (!single || diag)) {                // 2a. [D_j; X] -> L_jj, L_j1,j   (single: the diagonal workgroup only needs L_jj)
-        double a[NB];
+    // The factored blocks leave the registers through LDS (every lane owns a ROW there): the workgroup then stores them to memory
+    // 32 lanes to a row, where a lane-per-row store touched one cache line per lane (2.4k cycles of the factoring wavefront).
+    // L_jj goes into X's place (wavefront 0 alone reads X, at the start of 2a), L_j1,j1 into D_j1's, L_i,j1 into B1's.
+    auto panel_to_lds = [&](const PanelRegs& p, double* Ld, double* Lb) {
+        if (lane < 16) {
+            if (Ld) {
 #pragma unroll
-        for (int c = 0; c < NB; ++c) a[c] = lane < NB ? Dj[lane * (NB + 1) + c] : (single ? 0.0 : X[(lane - NB) * (NB + 1) + c]);
-        fail = chol_panel_regs(a, lane, cp_lds + 11 * CP_BLK);
-        if (lane >= NB) {
-#pragma unroll
-            for (int c = 0; c < NB; ++c) Ljk0[(lane - NB) * (NB + 1) + c] = a[c];            // L_j1,j for step 3
-            if (diag && !single) {
-                // ... and for k_chol_xsolve when the rhs row lives in block j1.  Not into S: the other panel workgroups read A_j1,j.
-#pragma unroll
-                for (int c = 0; c < NB; ++c) v.Lsub[((size_t)j1 * NB + lane - NB) * NB + c] = a[c];
+                for (int c = 0; c < 16; ++c) {
+                    Ld[lane * (NB + 1) + c] = c <= lane ? p.dA[c] : 0.0;        Ld[lane * (NB + 1) + 16 + c] = 0.0;
+                    Ld[(16 + lane) * (NB + 1) + c] = p.x[c];                     Ld[(16 + lane) * (NB + 1) + 16 + c] = c <= lane ? p.dB[c] : 0.0;
+                }
             }
-        } else if (diag) {
+        } else if (lane < 48 && Lb) {
 #pragma unroll
-            for (int c = 0; c < NB; ++c) v.Ldiag[((size_t)j * NB + lane) * NB + c] = c <= lane ? a[c] : 0.0;
-            if (fail && lane == 0) v.scal[5] = 1.0;
+            for (int c = 0; c < 16; ++c) { Lb[(lane - 16) * (NB + 1) + c] = p.x[c]; Lb[(lane - 16) * (NB + 1) + 16 + c] = p.y[c]; }
         }
+    };
+    auto block_to_memory = [&](const double* L, double* dst, size_t pitch) {       // all four wavefronts
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int t = tid + it * 256, r = t / NB, c = t % NB;
+            dst[(size_t)r * pitch + c] = L[r * (NB + 1) + c];
+        }
+    };
+    if (wave == 0 && (!single || diag)) {                // 2a. [D_j; X] -> L_jj, L_j1,j   (single: the diagonal workgroup only needs L_jj)
+        PanelRegs p;
+        fail = chol_panel_dpp(p, Dj, single ? nullptr : X, lane, cp_lds + 11 * CP_BLK);
+        panel_to_lds(p, diag ? X : nullptr, single ? nullptr : Ljk0);                  // L_j1,j for step 3
+        if (diag && fail && lane == 0) scal[5] = 1.0;
     } else if (wave == 1 && has_b) {                     // 2b. [D_j; B0] -> L_i,j
-        double a[NB];
-#pragma unroll
-        for (int c = 0; c < NB; ++c) a[c] = lane < NB ? Dj[lane * (NB + 1) + c] : B0[(lane - NB) * (NB + 1) + c];
-        chol_panel_regs(a, lane, cp_lds + 11 * CP_BLK + CH_SCR);
-        if (lane >= NB) {
-            double* out = extra ? M : S;
-#pragma unroll
-            for (int c = 0; c < NB; ++c) { Ljk1[(lane - NB) * (NB + 1) + c] = a[c]; out[(ri + lane - NB) * n + rj + c] = a[c]; }
-        }
+        PanelRegs p;
+        chol_panel_dpp(p, Dj, B0, lane, cp_lds + 11 * CP_BLK + CH_SCR);
+        panel_to_lds(p, nullptr, Ljk1);
     } else if (prev && !single && wave >= 2) {           // 2c. the rest of the lookahead, beside the factorisations
         if (wave == 2) {
             for (int t4 = 0; t4 < 4; ++t4) {
@@ -1097,8 +1254,15 @@ __global__ __launch_bounds__(256) void k_chol_pair(const BaView* __restrict__ vi
             }
         }
     }
-    if (single) return;
     __syncthreads();
+    if (diag) {
+        block_to_memory(X, Ldiag + (size_t)j * NB * NB, NB);
+        // L_j1,j for k_chol_xsolve when the rhs row lives in block j1.  Not into S: the other panel workgroups read A_j1,j.
+        if (!single) block_to_memory(Ljk0, Lsub + (size_t)j1 * NB * NB, NB);
+    } else {
+        block_to_memory(Ljk1, (extra ? M : S) + ri * n + rj, n);
+    }
+    if (single) return;
     {                                                    // 3. the second column sees the first: K = 32
         f64x4 acc = {0, 0, 0, 0};
         acc = mfma_tile32(Ljk0, Ljk0, tr, tc, lr, lk, acc);
@@ -1110,22 +1274,15 @@ __global__ __launch_bounds__(256) void k_chol_pair(const BaView* __restrict__ vi
         }
     }
     __syncthreads();
-    if (wave != 0) return;
-    double a[NB];                                        // 4. [D_j1; B1] -> L_j1,j1, L_i,j1
-#pragma unroll
-    for (int c = 0; c < NB; ++c) a[c] = lane < NB ? Dj1[lane * (NB + 1) + c] : (has_b ? B1[(lane - NB) * (NB + 1) + c] : 0.0);
-    fail = chol_panel_regs(a, lane, cp_lds + 11 * CP_BLK);
-    if (lane < NB) {
-        if (diag) {
-#pragma unroll
-            for (int c = 0; c < NB; ++c) v.Ldiag[((size_t)j1 * NB + lane) * NB + c] = c <= lane ? a[c] : 0.0;
-            if (fail && lane == 0) v.scal[5] = 1.0;
-        }
-    } else if (has_b) {
-        double* out = extra ? M : S;
-#pragma unroll
-        for (int c = 0; c < NB; ++c) out[(ri + lane - NB) * n + rj1 + c] = a[c];
+    if (wave == 0) {                                     // 4. [D_j1; B1] -> L_j1,j1, L_i,j1
+        PanelRegs p;
+        fail = chol_panel_dpp(p, Dj1, has_b ? B1 : nullptr, lane, cp_lds + 11 * CP_BLK);
+        panel_to_lds(p, diag ? Dj1 : nullptr, has_b ? B1 : nullptr);
+        if (diag && fail && lane == 0) scal[5] = 1.0;
     }
+    __syncthreads();
+    if (diag) block_to_memory(Dj1, Ldiag + (size_t)j1 * NB * NB, NB);
+    else block_to_memory(B1, (extra ? M : S) + ri * n + rj1, n);
 }
 
 // the whole factorisation + L^-T rows: ceil(nb / 2) launches
