@@ -99,12 +99,37 @@ class Workload:
         return self.hip.BundleAdjuster(self.ctx, p["poses"], p["fixed"], p["points"], self.obs[v % BA_VARIANTS], p["cam"])
 
     def bundle_adjust_fresh(self):
-        """what a keyframe costs the mapping side: structure phase + 10 LM iterations + release"""
-        ba = self.new_problem(self.kf_counter)
+        """what a keyframe costs the mapping side, unpipelined: structure phase + 10 LM iterations + read-back + release"""
+        v = self.kf_counter
+        ba = self.new_problem(v)
         self.kf_counter += 1
         log = ba.optimize(True, BA_ITERS)
+        ba.state()
         ba.close()
         return log
+
+    def bundle_adjust_pipelined(self, n_kf):
+        """The mapping thread as a pipeline: the structure of window k+1 (upload + device-side build, asynchronous on its own stream)
+        is set up while window k is being solved; when k is done its poses / landmarks are read back and window k+1 receives its
+        values (lpslam_hip_ba_set_state) -- in a tracker the observations the previous solve classified as outliers would be masked
+        with set_active at the same point.  Every window is still created, solved, read back and released inside the timed region."""
+        if n_kf <= 0:
+            return
+        def start(ba, v):
+            p = self.probs[v % BA_VARIANTS]
+            ba.set_state(p["poses"], p["points"])
+            ba.optimize_begin(True, BA_ITERS)
+        cur = self.new_problem(self.kf_counter)
+        start(cur, self.kf_counter)
+        for i in range(n_kf):
+            self.kf_counter += 1
+            nxt = self.new_problem(self.kf_counter) if i + 1 < n_kf else None     # builds beside the running solve
+            cur.optimize_end()
+            if nxt is not None:
+                start(nxt, self.kf_counter)                  # the next solve is on its way before the finished one is read back
+            cur.state()
+            cur.close()
+            cur = nxt
 
     def run_steps(self, first_step, k):
         """k steps: the front end on this thread, the keyframes' bundle adjustments on a second one (own stream)"""
@@ -118,8 +143,7 @@ class Workload:
 
         def ba_loop():
             try:
-                for _ in range(n_kf):
-                    self.bundle_adjust_fresh()
+                self.bundle_adjust_pipelined(n_kf)
             except Exception as e:      # noqa: BLE001
                 err.append(e)
         th = threading.Thread(target=ba_loop)
@@ -332,7 +356,7 @@ def main():
         # ---- instrumented passes, outside the timed region: HIP events on the streams the kernels run on
         n_inst = max(3, min(args.steps, 10))
         fe_ms = np.mean([wl.front_end_timed() for _ in range(n_inst)], axis=0)
-        ba_prof, ba_setup_ms, ba_total_ms, ba_iters_done, ba_dim = None, None, None, 0, 0
+        ba_prof, ba_setup_ms, ba_total_ms, ba_iters_done, ba_dim, ba_pipe_ms = None, None, None, 0, 0, None
         if wl.with_ba:
             # set-up alone: create until the structure is ready on the device (a state read synchronises)
             ts = []
@@ -351,6 +375,7 @@ def main():
             for v in range(n_inst):
                 t1 = time.perf_counter(); wl.bundle_adjust_fresh(); ts.append(1e3 * (time.perf_counter() - t1))
             ba_total_ms = float(np.median(ts))
+            t1 = time.perf_counter(); wl.bundle_adjust_pipelined(8); ba_pipe_ms = 1e3 * (time.perf_counter() - t1) / 8
 
         # ---- GPU time per step by kernel: the dominant one gets the roofline
         kf_per_step = n_kf_timed / max(args.steps, 1)
@@ -438,6 +463,7 @@ def main():
             "ba_ms_per_iter": round(sum(d["ms_per_solve"] for d in ba_prof.values()) / max(ba_iters_done, 1), 4) if ba_prof else None,
             "ba_setup_ms": round(ba_setup_ms, 4) if ba_setup_ms is not None else None,
             "ba_ms_per_keyframe": round(ba_total_ms, 4) if ba_total_ms is not None else None,
+            "ba_ms_per_keyframe_pipelined": round(ba_pipe_ms, 4) if ba_pipe_ms is not None else None,
             "roofline": roof,
             "gpu_ms_per_step_by_kernel": {k: round(v, 4) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1])},
             "ba_kernel_us_per_iteration": {("k_chol_factor" if n == "chol" else n): round(1e3 * d["ms_per_solve"] / max(ba_iters_done, 1), 2) for n, d in ba_prof.items()} if ba_prof else None,

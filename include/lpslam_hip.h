@@ -240,6 +240,11 @@ int lpslam_hip_pose_optimize(lpslam_hip_ctx* ctx, double* pose7, const double* p
 int lpslam_hip_ba_local(lpslam_hip_ba* ba, int32_t first_iters, int32_t second_iters, uint8_t* outlier);
 /* Restores the poses / points / activity mask given at creation (kept in HBM) and clears the LM state. */
 int lpslam_hip_ba_reset(lpslam_hip_ba* ba);
+/* Replaces the creation-time poses (n_poses x 7) and / or landmarks (n_points x 3) of an existing problem (NULL keeps them) and
+ * resets it: the observation graph and its device-built structure stay.  A mapping thread creates the next window while the
+ * previous one is being solved (lpslam_hip_ba_create only enqueues) and hands it the state that solve produced
+ * ([UPSTREAM] local_bundle_adjuster reads the map after the previous run has written it back). */
+int lpslam_hip_ba_set_state(lpslam_hip_ba* ba, const double* poses, const double* points);
 int lpslam_hip_ba_get(lpslam_hip_ba* ba, double* poses, double* points);
 int lpslam_hip_ba_chi2(lpslam_hip_ba* ba, double* chi2, uint8_t* depth_positive);
 

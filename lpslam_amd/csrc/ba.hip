@@ -2474,6 +2474,18 @@ int lpslam_hip_ba_reset(lpslam_hip_ba* b)
     return LPSLAM_HIP_OK;
 }
 
+// New creation-time values for an existing structure (the observation graph stays): what lets a mapping thread build the
+// structure of the next window (lpslam_hip_ba_create is asynchronous) while the previous window is still being solved, and hand
+// over the poses / landmarks that solve produced when it is done.
+int lpslam_hip_ba_set_state(lpslam_hip_ba* b, const double* poses, const double* points)
+{
+    if (!b) { set_error("null problem"); return LPSLAM_HIP_ERR_INVALID; }
+    if (b->pending_iters >= 0) { set_error("lpslam_hip_ba_set_state while a solve is in flight"); return LPSLAM_HIP_ERR_INVALID; }
+    if (poses) LP_HIP(hipMemcpyAsync((void*)b->h_view.poses0, poses, 7 * (size_t)b->n_poses * sizeof(double), hipMemcpyHostToDevice, b->stream));
+    if (points && b->n_points) LP_HIP(hipMemcpyAsync((void*)b->h_view.points0, points, 3 * (size_t)b->n_points * sizeof(double), hipMemcpyHostToDevice, b->stream));
+    return lpslam_hip_ba_reset(b);
+}
+
 int lpslam_hip_ba_get(lpslam_hip_ba* b, double* poses, double* points)
 {
     if (!b) { set_error("null problem"); return LPSLAM_HIP_ERR_INVALID; }

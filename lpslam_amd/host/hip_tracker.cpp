@@ -404,6 +404,14 @@ int HipVslamTrackerBase::insertKeyframe(FrameData& f)
 }
 
 // motion-only pose optimisation ([UPSTREAM] optimize::pose_optimizer) over keypoint <-> landmark associations
+namespace {
+struct ScopedSeconds {                                   // adds the scope's wall time to a statistics field
+    double& acc; std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    explicit ScopedSeconds(double& a) : acc(a) {}
+    ~ScopedSeconds() { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+};
+}  // namespace
+
 bool HipVslamTrackerBase::poseFromMatches(FrameData& cur, const std::vector<int>& cur_idx, const std::vector<int>& lm_ids, const Pose& init, int& n_inliers, int min_inliers)
 {
     n_inliers = 0;
@@ -429,6 +437,7 @@ bool HipVslamTrackerBase::poseFromMatches(FrameData& cur, const std::vector<int>
     std::vector<uint8_t> outlier(obs.size());
     int32_t inl = 0;
     // one launch: the whole 4 x 10 iteration flow runs in one workgroup on the device
+    ScopedSeconds timed(m_stats.t_dev_pose);
     if (lpslam_hip_pose_optimize(m_ctx, pose7, pts.data(), (int32_t)kept_idx.size(), obs.data(), (int32_t)obs.size(), &cam, outlier.data(), &inl) != LPSLAM_HIP_OK) return false;
     n_inliers = inl;
     if (inl < min_inliers) return false;
@@ -517,6 +526,7 @@ bool HipVslamTrackerBase::trackWithMotionModel(FrameData& cur, int& n_inliers)
     for (size_t i = 0; i < cur.kpts.size(); ++i) cur_angle[i] = cur.kpts[i].angle;
     int32_t n_m = 0;
     for (int attempt = 0; attempt < 2; ++attempt) {
+        ScopedSeconds timed(m_stats.t_dev_match);
         if (lpslam_hip_match_projection(m_ctx, cur.slot, q.data(), qd.data(), (int32_t)q.size(), 100 /* HAMMING_DIST_THR_HIGH */, 1.0f, nullptr, m_stereo ? 1 : 0,
                                         idx.data(), dist.data(), &n_m) != LPSLAM_HIP_OK) return false;
         lpslam_hip_match_orientation_filter(q_angle.data(), cur_angle.data(), idx.data(), (int32_t)q.size(), &n_m);
@@ -583,6 +593,7 @@ bool HipVslamTrackerBase::trackLocalMap(FrameData& cur, int& n_inliers)
     if (!q.empty()) {
         std::vector<int32_t> idx(q.size()), dist(q.size());
         int32_t n_m = 0;
+        ScopedSeconds timed(m_stats.t_dev_match);
         if (lpslam_hip_match_projection(m_ctx, cur.slot, q.data(), qd.data(), (int32_t)q.size(), 100 /* HAMMING_DIST_THR_HIGH */, 0.8f, taken.data(), m_stereo ? 1 : 0,
                                         idx.data(), dist.data(), &n_m) != LPSLAM_HIP_OK) return false;
         for (size_t k = 0; k < q.size(); ++k) if (idx[k] >= 0) { cur.landmark[(size_t)idx[k]] = q_lm[k]; ++n_new; }
@@ -1250,11 +1261,15 @@ void HipVslamTrackerBase::finishMapping()
 void HipVslamTrackerBase::logStatistics() const
 {
     const Statistics& s = m_stats;
-    char buf[512];
+    char buf[768];
+    const double per = s.frames > 0 ? 1e3 / (double)s.frames : 0.0;
     std::snprintf(buf, sizeof(buf), "VSLAM statistics: frames=%ld motion_tracked=%ld bf_tracked=%ld local_map_joined=%ld keyframes=%ld fused_added=%ld fused_merged=%ld "
-                  "local_ba=%ld loops_closed=%ld loop_fused=%ld global_ba=%ld lost=%ld relocalised=%ld reinitialised=%ld nav_priors=%ld landmarks=%zu",
+                  "local_ba=%ld loops_closed=%ld loop_fused=%ld global_ba=%ld lost=%ld relocalised=%ld reinitialised=%ld nav_priors=%ld landmarks=%zu "
+                  "ms_per_frame=%.4f ms_front_end=%.4f ms_track=%.4f ms_local_map=%.4f ms_keyframe=%.4f ms_dev_upload=%.4f ms_dev_extract=%.4f ms_dev_get=%.4f ms_dev_match=%.4f ms_dev_pose=%.4f",
                   s.frames, s.motion_tracked, s.bf_tracked, s.local_map_joined, s.keyframes, s.fused_added, s.fused_merged, s.local_ba, s.loops_closed, s.loop_fused,
-                  s.global_ba, s.lost, s.relocalised, s.reinitialised, s.nav_priors, m_landmarks.size());
+                  s.global_ba, s.lost, s.relocalised, s.reinitialised, s.nav_priors, m_landmarks.size(),
+                  s.t_total * per, s.t_front * per, s.t_track * per, s.t_local * per, s.t_keyframe * per,
+                  s.t_dev_upload * per, s.t_dev_extract * per, s.t_dev_get * per, s.t_dev_match * per, s.t_dev_pose * per);
     logMessage(LpSlamLogLevel_Info, buf);
 }
 
@@ -1292,6 +1307,8 @@ TrackerBase::ProcessImageResult HipVslamTrackerBase::trackFrame(CameraQueueEntry
     FrameData cur;
     cur.slot = (int)(m_imageTracked % 2) * 2;
     bool ok;
+    auto t_dev = std::chrono::steady_clock::now();
+    auto dev_lap = [&t_dev](double& acc) { const auto now = std::chrono::steady_clock::now(); acc += std::chrono::duration<double>(now - t_dev).count(); t_dev = now; };
     if (m_rectify) {       // raw frames: undistort + rectify on the device
         ok = lpslam_hip_upload_raw_image(m_ctx, cur.slot, 0, cam.image.pixels.data(), cam.image.width) == LPSLAM_HIP_OK;
         if (ok && stereo) ok = lpslam_hip_upload_raw_image(m_ctx, cur.slot + 1, 1, cam.image_second->pixels.data(), cam.image.width) == LPSLAM_HIP_OK;
@@ -1299,20 +1316,26 @@ TrackerBase::ProcessImageResult HipVslamTrackerBase::trackFrame(CameraQueueEntry
         ok = lpslam_hip_upload_image(m_ctx, cur.slot, cam.image.pixels.data(), cam.image.width) == LPSLAM_HIP_OK;
         if (ok && stereo) ok = lpslam_hip_upload_image(m_ctx, cur.slot + 1, cam.image_second->pixels.data(), cam.image.width) == LPSLAM_HIP_OK;
     }
+    dev_lap(m_stats.t_dev_upload);
     if (ok) ok = lpslam_hip_extract_range(m_ctx, cur.slot, stereo ? 2 : 1) == LPSLAM_HIP_OK;
     if (ok && stereo) {
         const float baseline = (float)(m_cam.focal_x_baseline / m_cam.f_x);
         ok = lpslam_hip_match_stereo(m_ctx, cur.slot, cur.slot + 1, (float)m_cam.focal_x_baseline, baseline) == LPSLAM_HIP_OK;
     }
+    dev_lap(m_stats.t_dev_extract);
     int32_t n = 0;
     cur.kpts.resize((size_t)m_maxKp); cur.desc.resize((size_t)m_maxKp * 32);
     cur.x_right.assign((size_t)m_maxKp, -1.0f); cur.depth.assign((size_t)m_maxKp, -1.0f);
     if (ok) ok = lpslam_hip_get_frame(m_ctx, cur.slot, cur.kpts.data(), cur.desc.data(), stereo ? cur.x_right.data() : nullptr,
                                       stereo ? cur.depth.data() : nullptr, m_maxKp, &n) == LPSLAM_HIP_OK;
+    dev_lap(m_stats.t_dev_get);
     if (!ok) { logMessage(LpSlamLogLevel_Error, std::string("HIP front end failed: ") + lpslam_hip_last_error()); return res; }
     cur.kpts.resize((size_t)n); cur.desc.resize((size_t)n * 32);
     cur.x_right.resize((size_t)n); cur.depth.resize((size_t)n); cur.landmark.assign((size_t)n, -1);
     ++m_imageTracked; ++m_stats.frames;
+    auto t_mark = std::chrono::steady_clock::now();
+    auto lap = [&t_mark](double& acc) { const auto now = std::chrono::steady_clock::now(); acc += std::chrono::duration<double>(now - t_mark).count(); t_mark = now; };
+    m_stats.t_front += std::chrono::duration<double>(t_mark - t0).count();
 
     if (m_state == TrackerState::Lost) {
         // the map stays; every frame tries to relocalise against the keyframes, and the state stays Lost (no pose goes out) until
@@ -1354,9 +1377,12 @@ TrackerBase::ProcessImageResult HipVslamTrackerBase::trackFrame(CameraQueueEntry
         m_prev = std::move(cur); m_havePrev = true;
     } else {
         int inliers = 0;
-        if (trackAgainstPrevious(cur, inliers)) {
+        const bool tracked = trackAgainstPrevious(cur, inliers);
+        lap(m_stats.t_track);
+        if (tracked) {
             int with_local_map = 0;
             if (trackLocalMap(cur, with_local_map)) inliers = with_local_map;      // else: the motion-model result stands
+            lap(m_stats.t_local);
             // velocity = T_cur * T_prev^-1
             const Mat3 Rc = quatToRot(cur.pose.q), Rp = quatToRot(m_prev.pose.q);
             Mat3 Rv;
@@ -1371,6 +1397,7 @@ TrackerBase::ProcessImageResult HipVslamTrackerBase::trackFrame(CameraQueueEntry
                 if (m_stereo && m_loopClosure) detectAndCloseLoop(cur, c);
                 startMapping(c);
                 if (!m_asyncMapping) cur.pose = m_kfs[(size_t)c].pose;
+                lap(m_stats.t_keyframe);
             }
             m_lastGoodPose = cur.pose;
             m_prev = std::move(cur);
@@ -1390,6 +1417,7 @@ TrackerBase::ProcessImageResult HipVslamTrackerBase::trackFrame(CameraQueueEntry
         }
     }
     m_lastFrameSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    m_stats.t_total += m_lastFrameSeconds;
     if (m_state == TrackerState::Tracking) {
         TrackerResult tres = createTrackerResult(m_prev.pose, cam.timestamp);
         tres.timestamp.ros_timestamp = cam.ros_timestamp;

@@ -70,6 +70,10 @@ protected:
     struct Statistics {                               // logged at stop() ("VSLAM statistics: ..."): what the tracker did, for logs and tests
         long frames = 0, motion_tracked = 0, bf_tracked = 0, local_map_joined = 0, keyframes = 0, fused_added = 0, fused_merged = 0;
         long local_ba = 0, loops_closed = 0, loop_fused = 0, global_ba = 0, lost = 0, relocalised = 0, reinitialised = 0, nav_priors = 0;
+        // where the frames' time went (seconds, summed): front end (upload, extraction, stereo, read-back), tracking against the
+        // previous frame, local-map tracking, keyframe work on the tracking thread (insertion, fusion, loop search, BA set-up / wait)
+        double t_front = 0, t_track = 0, t_local = 0, t_keyframe = 0, t_total = 0;
+        double t_dev_match = 0, t_dev_pose = 0, t_dev_upload = 0, t_dev_extract = 0, t_dev_get = 0;      // inside the above: device calls
     };
 
     bool startContext(bool stereo);

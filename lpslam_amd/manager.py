@@ -114,11 +114,11 @@ class Manager:
 
     @staticmethod
     def statistics(path):
-        """the last "VSLAM statistics: key=value ..." line of a log file as a dict of ints"""
+        """the last "VSLAM statistics: key=value ..." line of a log file as a dict (counters as ints, ms_* timings as floats)"""
         out = {}
         for line in open(path, errors="replace"):
             if "VSLAM statistics:" in line:
-                out = {k: int(v) for k, v in (kv.split("=") for kv in line.split("VSLAM statistics:")[1].split())}
+                out = {k: (float(v) if k.startswith("ms_") else int(v)) for k, v in (kv.split("=") for kv in line.split("VSLAM statistics:")[1].split())}
         return out
 
     def read_configuration_file(self, path):

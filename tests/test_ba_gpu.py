@@ -189,6 +189,29 @@ def test_optimize_in_two_halves_beside_front_end_work(hiplib, oracle, ctx):
         two.optimize_end()
 
 
+def test_set_state_hands_a_prebuilt_window_its_values(hiplib, oracle, ctx):
+    """The mapping pipeline: the next window's structure is built (asynchronously) from placeholder values while the previous
+    window is being solved, then lpslam_hip_ba_set_state hands it the real poses / landmarks -- bit for bit what creating the
+    problem with those values gives.  Refused while a solve is in flight; None keeps a part."""
+    prob = synth.ba_problem(6, 150, 800, 640, 480, seq_id=46, pose_noise=(0.5, 3.0), point_noise=3.0)
+    obs = hiplib.ba_obs_array(prob)
+    direct = hiplib.BundleAdjuster(ctx, prob["poses"], prob["fixed"], prob["points"], obs, prob["cam"])
+    prev = hiplib.BundleAdjuster(ctx, prob["poses"], prob["fixed"], prob["points"], obs, prob["cam"])
+    prev.optimize_begin(True, 10)           # "the previous window" in flight while the next one is created
+    junk_poses = prob["poses"].copy(); junk_poses[:, 4:] += 0.3
+    late = hiplib.BundleAdjuster(ctx, junk_poses, prob["fixed"], prob["points"] + 0.5, obs, prob["cam"])
+    with pytest.raises(hiplib.LpslamHipError):
+        prev.set_state(prob["poses"], prob["points"])
+    prev.optimize_end()
+    late.set_state(prob["poses"], prob["points"])
+    want = direct.optimize(True, 10); wp, wx = direct.state()
+    got = late.optimize(True, 10); gp, gx = late.state()
+    assert got.tobytes() == want.tobytes() and np.array_equal(gp, wp) and np.array_equal(gx, wx)
+    late.set_state(None, prob["points"])    # poses kept (the creation-time ones set above), LM state cleared
+    again = late.optimize(True, 10); ap, ax = late.state()
+    assert again.tobytes() == want.tobytes() and np.array_equal(ap, wp) and np.array_equal(ax, wx)
+
+
 def test_batched_solve_equals_single_solves(hiplib, oracle, ctx):
     """lpslam_hip_ba_optimize_batch: problems of different sizes (different panel counts, one with rejected trials, one with all
     poses fixed) advanced by one launch chain give the bytes the single-problem calls give, and follow the oracle."""

@@ -1,0 +1,29 @@
+"""Scratch: stage times of the stereo tracker on the bench sequence."""
+import sys, os, time, tempfile
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from lpslam_amd import manager, _build, synth
+_build.host_library()
+W, H, KPTS, LEVELS, KF = 1280, 720, 2000, 8, 6
+k = synth.intrinsics(W, H)
+for async_map in ("true", "false", "true", "false"):
+    mg = manager.Manager()
+    for num in (0, 1):
+        c = manager.default_camera()
+        c.camera_number = num; c.f_x = k["fx"]; c.f_y = k["fy"]; c.c_x = k["cx"]; c.c_y = k["cy"]
+        c.resolution_x = W; c.resolution_y = H; c.focal_x_baseline = k["fxb"]
+        mg.set_camera(c)
+    mg.add_tracker("VSLAMStereo", '{"cameraSetup": "stereo", "slamKeypoints": %d, "numLevels": %d, "keyframeInterval": %d, "asyncMapping": %s}' % (KPTS, LEVELS, KF, async_map))
+    mg.collect_results(); mg.provide_odometry()
+    log = os.path.join(tempfile.mkdtemp(), "slam.log")
+    mg.log_to_file(log)
+    mg.start()
+    seq = synth.StereoSequence(W, H, 4)
+    frames = [seq.frame(i) for i in range(30)]
+    t0 = time.perf_counter()
+    for i, (l, r) in enumerate(frames):
+        mg.add_stereo((i + 1) * 40_000_000, l, r)
+    while len(mg.results) < len(frames) and time.perf_counter() - t0 < 60:
+        time.sleep(0.0005)
+    dt = time.perf_counter() - t0
+    mg.stop()
+    print("asyncMapping", async_map, "%.1f frames/s" % (len(frames) / dt), manager.Manager.statistics(log))
