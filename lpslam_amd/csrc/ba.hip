@@ -963,30 +963,39 @@ __device__ __forceinline__ double dpp_bcast(double v)          // the value of l
     asm("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "n"(L));
     return r;
 }
-// 1 / sqrt(d): v_rsq_f64 (about 2^-23) + two Goldschmidt steps; five dependent levels instead of the eight of two Newton steps
-__device__ __forceinline__ double pivot_rsqrt_gs(double d)
+// One pivot of a strip.  What every later pivot waits for is the chain  pivot -> 1 / sqrt -> scaled column -> next pivot, so it is
+// kept as short as the arithmetic allows (measured: 190 cycles per pivot with two Goldschmidt steps and the next pivot read back
+// from the updated column; a dependent FP64 operation costs 8-9 cycles here, not its 4 issue cycles):
+//   * 1 / sqrt(d) = y0 (1 + e / 2 + 3 e^2 / 8), e = 1 - d y0^2, y0 = v_rsq_f64 (2^-24, measured): one cubic step, four dependent
+//     levels, 1.4e-16 relative error over 4M samples (two Goldschmidt steps: seven levels, 2.1e-16);
+//   * the positivity test runs beside v_rsq_f64 and costs one select after it (a failed pivot continues on 1.0: harmless finite
+//     numbers, the factorisation is flagged and its result discarded);
+//   * the next pivot is a(jj+1, jj+1) - l(jj+1)^2 with both operands broadcast BEFORE this pivot's root is known, so it follows
+//     the root by two operations instead of waiting for the column update and a DPP read-back (same fma as the update: same bits).
+__device__ __forceinline__ double pivot_rsqrt_cubic(double d, bool ok)
 {
-    const double y = __builtin_amdgcn_rsq(d);
-    double g = d * y, h = 0.5 * y;
-    double r = fma(-h, g, 0.5);
-    g = fma(g, r, g); h = fma(h, r, h);
-    r = fma(-h, g, 0.5);
-    h = fma(h, r, h);
-    return h + h;
+    double y0 = __builtin_amdgcn_rsq(d);
+    y0 = ok ? y0 : 1.0;
+    const double dg = ok ? d : 1.0;
+    const double t = dg * y0;
+    const double e = fma(-t, y0, 1.0);
+    const double pp = fma(0.375, e, 0.5), ye = y0 * e;
+    return fma(ye, pp, y0);
 }
 template <int JJ>
 __device__ __forceinline__ void strip_step(double (&d)[16], double (&x)[16], double piv, bool& fail)
 {
-    if (!(piv > 0.0)) { fail = true; piv = 1.0; }
-    const double rs = pivot_rsqrt_gs(piv);
+    double p = 0.0, q = 0.0;
+    if constexpr (JJ < 15) { p = dpp_bcast<JJ + 1>(d[JJ]); q = dpp_bcast<JJ + 1>(d[JJ + 1]); }
+    const bool ok = piv > 0.0;
+    fail |= !ok;
+    const double rs = pivot_rsqrt_cubic(piv, ok);
     const double l = d[JJ] * rs, lx = x[JJ] * rs;
     d[JJ] = l; x[JJ] = lx;
     if constexpr (JJ < 15) {
-        // column JJ + 1 of D first and alone: the next pivot comes out of it, and its reciprocal square root (the longest
-        // dependent chain of a step) runs beside the rest of this step's updates
-        asm("s_nop 1\n\tv_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(d[JJ + 1]) : "v"(l), "v"(l), "n"(JJ + 1));
-        const double next = dpp_bcast<JJ + 1>(d[JJ + 1]);
-        if constexpr (JJ < 14) dpp_rank1<JJ + 2>(d, l, l);
+        const double lp = p * rs;
+        const double next = fma(-lp, lp, q);
+        dpp_rank1<JJ + 1>(d, l, l);
         dpp_rank1<JJ + 1>(x, l, lx);
         strip_step<JJ + 1>(d, x, next, fail);
     }
