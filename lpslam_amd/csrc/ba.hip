@@ -1363,13 +1363,10 @@ void enqueue_factor_solve(hipStream_t s, const BaView* d_views, int count, int n
         int dev = 0;
         (void)hipGetDevice(&dev);
         if (dev >= 0 && dev < 64 && !attr_set[dev].load()) {
-            (void)hipFuncSetAttribute((const void*)k_chol_wg<false>, hipFuncAttributeMaxDynamicSharedMemorySize, CW_LDS_BYTES);
-            (void)hipFuncSetAttribute((const void*)k_chol_wg<true>, hipFuncAttributeMaxDynamicSharedMemorySize, CW_LDS_BYTES);
+            (void)hipFuncSetAttribute((const void*)k_chol_wg, hipFuncAttributeMaxDynamicSharedMemorySize, CW_LDS_BYTES);
             attr_set[dev].store(true);
         }
-        static const bool stamp = getenv("LPSLAM_CW_STAMP") != nullptr;
-        if (stamp) hipLaunchKernelGGL(k_chol_wg<true>, dim3(1, count), dim3(CW_THREADS), CW_LDS_BYTES, s, d_views);
-        else hipLaunchKernelGGL(k_chol_wg<false>, dim3(1, count), dim3(CW_THREADS), CW_LDS_BYTES, s, d_views);
+        hipLaunchKernelGGL(k_chol_wg, dim3(1, count), dim3(CW_THREADS), CW_LDS_BYTES, s, d_views);
     }
     if (any_large) {
         enqueue_cholesky(s, d_views, count, nb_max, any_small ? 1 : 0);
@@ -1471,26 +1468,124 @@ __global__ __launch_bounds__(256) void k_ba_obs_chi2(const BaView* __restrict__ 
 // LDS and one launch returns the pose (one workgroup; several frames / candidates could share a launch, one workgroup each).
 struct PoShared {
     double pose[7], trial[7];
-    double red[4][28];
+    double red[8][28];
     double H[36], b[6], x[6];
     double lambda, ni, current_chi, rho;
     int ok, again, stop, bad;
 };
 
+// The kernel is one workgroup whose passes over the observations are its duration (measured with four wavefronts: 0.4 us per
+// observation and call, 470 us for 1000 observations): eight wavefronts -- one or two observations per thread at tracker sizes --
+// and, in the per-observation arithmetic, reciprocals and reciprocal square roots from v_rcp_f64 / v_rsq_f64 plus one cubic
+// correction step (1.4e-16 relative error, measured) where IEEE division and sqrt cost ~30 instructions each (a Jacobian held
+// thirteen of them).
+constexpr int PO_T = 512;
+constexpr int PO_W = PO_T / 64;
+__device__ __forceinline__ double po_rcp(double d)       // 1 / d
+{
+    const double y0 = __builtin_amdgcn_rcp(d);
+    const double e = fma(-d, y0, 1.0);
+    return fma(y0, fma(e, e, e), y0);                   // y0 (1 + e + e^2)
+}
+__device__ __forceinline__ double po_rsqrt(double d)     // 1 / sqrt(d), d > 0
+{
+    const double y0 = __builtin_amdgcn_rsq(d);
+    const double e = fma(-(d * y0), y0, 1.0);
+    return fma(y0 * e, fma(0.375, e, 0.5), y0);         // y0 (1 + e / 2 + 3 e^2 / 8)
+}
 __device__ __forceinline__ double po_block_sum(double v, PoShared& sh)
 {
     v = wave_sum(v);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) sh.red[threadIdx.x >> 6][27] = v;
     __syncthreads();
-    return ((sh.red[0][27] + sh.red[1][27]) + sh.red[2][27]) + sh.red[3][27];
+    double s = sh.red[0][27];
+#pragma unroll
+    for (int w = 1; w < PO_W; ++w) s += sh.red[w][27];
+    return s;
+}
+__device__ __forceinline__ void po_quat_to_rot(const double* q, double* R)
+{
+    const double rn = po_rsqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    const double w = q[0] * rn, x = q[1] * rn, y = q[2] * rn, z = q[3] * rn;
+    R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - w * z);     R[2] = 2 * (x * z + w * y);
+    R[3] = 2 * (x * y + w * z);     R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - w * x);
+    R[6] = 2 * (x * z - w * y);     R[7] = 2 * (y * z + w * x);     R[8] = 1 - 2 * (x * x + y * y);
+}
+__device__ __forceinline__ void po_huber(double e2, double delta, double* rho0, double* rho1)
+{
+    const double dsqr = delta * delta;
+    if (e2 <= dsqr) { *rho0 = e2; *rho1 = 1.0; }
+    else { const double rs = po_rsqrt(e2); *rho0 = 2 * (e2 * rs) * delta - dsqr; *rho1 = delta * rs; }
+}
+// pose_oplus with one sincos of the half angle and the fast reciprocals (this runs in one thread between two barriers)
+__device__ __forceinline__ void po_oplus(const double* pose, const double* d, double* out)
+{
+    const double wx = d[0], wy = d[1], wz = d[2];
+    const double theta2 = wx * wx + wy * wy + wz * wz;
+    double a, b, c, qe[4];
+    if (theta2 < 1e-10) {
+        a = 1.0; b = 0.5; c = 1.0 / 6.0;
+        qe[0] = 1.0; qe[1] = 0.5 * wx; qe[2] = 0.5 * wy; qe[3] = 0.5 * wz;
+    } else {
+        const double rt = po_rsqrt(theta2), theta = theta2 * rt, rt2 = rt * rt;
+        double sh2, ch2;
+        sincos(0.5 * theta, &sh2, &ch2);
+        const double st = 2.0 * sh2 * ch2, omc = 2.0 * sh2 * sh2;        // sin(theta), 1 - cos(theta)
+        a = st * rt;
+        b = omc * rt2;
+        c = (theta - st) * (rt2 * rt);
+        const double shq = sh2 * rt;
+        qe[0] = ch2; qe[1] = shq * wx; qe[2] = shq * wy; qe[3] = shq * wz;
+    }
+    const double Wm[9] = {0, -wz, wy, wz, 0, -wx, -wy, wx, 0};
+    double W2[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { double s2 = 0; for (int k = 0; k < 3; ++k) s2 += Wm[i * 3 + k] * Wm[k * 3 + j]; W2[i * 3 + j] = s2; }
+    double Re[9], V[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { const double I = (i % 4 == 0) ? 1.0 : 0.0; Re[i] = I + a * Wm[i] + b * W2[i]; V[i] = I + b * Wm[i] + c * W2[i]; }
+    const double* t = pose + 4;
+    double tn[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        tn[i] = V[i * 3] * d[3] + V[i * 3 + 1] * d[4] + V[i * 3 + 2] * d[5] + Re[i * 3] * t[0] + Re[i * 3 + 1] * t[1] + Re[i * 3 + 2] * t[2];
+    const double* q = pose;
+    double qn[4];
+    qn[0] = qe[0] * q[0] - qe[1] * q[1] - qe[2] * q[2] - qe[3] * q[3];
+    qn[1] = qe[0] * q[1] + qe[1] * q[0] + qe[2] * q[3] - qe[3] * q[2];
+    qn[2] = qe[0] * q[2] - qe[1] * q[3] + qe[2] * q[0] + qe[3] * q[1];
+    qn[3] = qe[0] * q[3] + qe[1] * q[2] - qe[2] * q[1] + qe[3] * q[0];
+    const double rn = po_rsqrt(qn[0] * qn[0] + qn[1] * qn[1] + qn[2] * qn[2] + qn[3] * qn[3]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) out[i] = qn[i] * rn;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) out[4 + i] = tn[i];
+}
+// pose half of ba_jacobians (the landmark is a constant here), with one reciprocal
+__device__ __forceinline__ void po_jacobian(const BaCam& c, const double* pc, double iz, int D, double B[3][6])
+{
+    const double x = pc[0], y = pc[1], iz2 = iz * iz;
+    B[0][0] = x * y * iz2 * c.fx;          B[0][1] = -(1.0 + (x * x * iz2)) * c.fx; B[0][2] = y * iz * c.fx;
+    B[0][3] = -iz * c.fx;                  B[0][4] = 0.0;                            B[0][5] = x * iz2 * c.fx;
+    B[1][0] = (1.0 + y * y * iz2) * c.fy;  B[1][1] = -x * y * iz2 * c.fy;            B[1][2] = -x * iz * c.fy;
+    B[1][3] = 0.0;                         B[1][4] = -iz * c.fy;                     B[1][5] = y * iz2 * c.fy;
+    B[2][0] = B[0][0] - c.fxb * y * iz2;   B[2][1] = B[0][1] + c.fxb * x * iz2;      B[2][2] = B[0][2];
+    B[2][3] = B[0][3];                     B[2][4] = 0.0;                            B[2][5] = B[0][5] - c.fxb * iz2;
+    if (D == 2) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) B[2][k] = 0.0;
+    }
 }
 // residual of observation k at pose p7; returns the dimension (2 / 3)
-__device__ __forceinline__ int po_residual(const BaCam& cam, const double* R, const double* t, const double* X, const lpslam_hip_ba_obs& o, double* e, double* pc)
+__device__ __forceinline__ int po_residual(const BaCam& cam, const double* R, const double* t, const double* X, const lpslam_hip_ba_obs& o, double* e, double* pc, double* iz_out = nullptr)
 {
 #pragma unroll
     for (int i = 0; i < 3; ++i) pc[i] = R[i * 3] * X[0] + R[i * 3 + 1] * X[1] + R[i * 3 + 2] * X[2] + t[i];
-    const double iz = 1.0 / pc[2];
+    const double iz = po_rcp(pc[2]);
+    if (iz_out) *iz_out = iz;
     const double u = cam.fx * pc[0] * iz + cam.cx, vv = cam.fy * pc[1] * iz + cam.cy;
     e[0] = o.u - u; e[1] = o.v - vv;
     if (o.ur < 0) { e[2] = 0; return 2; }
@@ -1500,7 +1595,6 @@ __device__ __forceinline__ int po_residual(const BaCam& cam, const double* R, co
 // One observation as the kernel keeps it in LDS: measurement, weight and the landmark it sees (56 bytes); the first `cache_n`
 // observations live there, the rest (only very large n) is read from global memory like before.
 struct PoObs { double u, v, ur, w, X[3]; };
-constexpr int PO_TR = 257;                 // padded row of the transposed reduction buffer [27][256]
 
 struct PoData {
     const double* pts; const lpslam_hip_ba_obs* obs; const PoObs* cache; const uint8_t* act; int n, cache_n;
@@ -1521,9 +1615,9 @@ struct PoData {
 __device__ double po_chi2(const BaCam& cam, const double* p7, const PoData& d, int robust, PoShared& sh)
 {
     double R[9];
-    quat_to_rot(p7, R);
+    po_quat_to_rot(p7, R);
     double chi = 0;
-    for (int k = threadIdx.x; k < d.n; k += 256) {
+    for (int k = threadIdx.x; k < d.n; k += PO_T) {
         if (!d.act[k]) continue;
         double e[3], pc[3], X[3];
         lpslam_hip_ba_obs o;
@@ -1531,36 +1625,54 @@ __device__ double po_chi2(const BaCam& cam, const double* p7, const PoData& d, i
         const int D = po_residual(cam, R, p7 + 4, X, o, e, pc);
         double c = o.inv_sigma2 * (e[0] * e[0] + e[1] * e[1] + (D == 3 ? e[2] * e[2] : 0.0));
         const double delta = D == 3 ? cam.hub_stereo : cam.hub_mono;
-        if (robust && delta > 0) { double r0, r1; huber(c, delta, &r0, &r1); c = r0; }
+        if (robust && delta > 0) { double r0, r1; po_huber(c, delta, &r0, &r1); c = r0; }
         chi += c;
     }
     return po_block_sum(chi, sh);
 }
 
-// the 27 sums of H (upper triangle) and b over the 256 threads: transposed through LDS -- 27 stores per thread, then 216 threads
-// add 32 partials each and three shuffles finish the 8 parts of a value (one barrier pair instead of 27 six-step wave sums)
-__device__ __forceinline__ void po_reduce27(const double (&acc)[27], double* tr, PoShared& sh)
+// the 27 sums of H (upper triangle) and b over the PO_T threads: first over each quad of lanes in registers (two DPP exchanges per
+// value), then one lane of four stores its 27 partials transposed into LDS, 27 x PO_Q / 32 threads add 32 of them each
+// (interleaved: neighbouring lanes read neighbouring words -- with a contiguous chunk per lane every lane of a value hit the same
+// LDS bank, and this reduction was half the kernel) and shuffles finish the parts of a value.
+template <int CTRL>
+__device__ __forceinline__ double quad_swap(double v)     // DPP quad_perm exchange (a shuffle would go through the LDS crossbar)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+constexpr int PO_Q = PO_T / 4;             // partials per value after the quad step
+constexpr int PO_TR = PO_Q + 1;            // padded row of the transposed reduction buffer [27][PO_Q]
+__device__ __forceinline__ void po_reduce27(double (&acc)[27], double* tr, PoShared& sh)
 {
     const int tid = threadIdx.x;
 #pragma unroll
-    for (int q = 0; q < 27; ++q) tr[q * PO_TR + tid] = acc[q];
+    for (int q = 0; q < 27; ++q) {
+        acc[q] += quad_swap<0xB1>(acc[q]);               // lanes 0<->1, 2<->3
+        acc[q] += quad_swap<0x4E>(acc[q]);               // lanes 0<->2, 1<->3
+    }
+    if ((tid & 3) == 0) {
+#pragma unroll
+        for (int q = 0; q < 27; ++q) tr[q * PO_TR + (tid >> 2)] = acc[q];
+    }
     __syncthreads();
-    const int q = tid >> 3, part = tid & 7;
+    constexpr int PARTS = PO_Q / 32;
+    const int q = tid / PARTS, part = tid % PARTS;
     double s = 0;
     if (q < 27) {
-        const double* row = tr + q * PO_TR + part * 32;
+        const double* row = tr + q * PO_TR + part;
 #pragma unroll 8
-        for (int i = 0; i < 32; ++i) s += row[i];
+        for (int i = 0; i < 32; ++i) s += row[i * PARTS];
     }
-    s += __shfl_down(s, 4, 8);
-    s += __shfl_down(s, 2, 8);
-    s += __shfl_down(s, 1, 8);
+#pragma unroll
+    for (int o = PARTS / 2; o > 0; o >>= 1) s += __shfl_down(s, o, PARTS);
     if (q < 27 && part == 0) sh.red[0][q] = s;
     __syncthreads();
 }
 
-// Dynamic LDS: the transposed reduction buffer, the observation cache, the activity flags.
-__global__ __launch_bounds__(256) void k_pose_optimize(double* pose7, const double* pts, const lpslam_hip_ba_obs* obs, int n, BaCam cam,
+
+__global__ __launch_bounds__(PO_T) void k_pose_optimize(double* pose7, const double* pts, const lpslam_hip_ba_obs* obs, int n, BaCam cam,
                                                        uint8_t* outlier, int* n_inliers, int cache_n)
 {
     __shared__ PoShared sh;
@@ -1570,7 +1682,7 @@ __global__ __launch_bounds__(256) void k_pose_optimize(double* pose7, const doub
     uint8_t* active = reinterpret_cast<uint8_t*>(cache + cache_n);
     const int tid = threadIdx.x;
     if (tid < 7) sh.pose[tid] = pose7[tid];
-    for (int k = tid; k < n; k += 256) {
+    for (int k = tid; k < n; k += PO_T) {
         active[k] = 1; outlier[k] = 0;
         if (k < cache_n) {
             const lpslam_hip_ba_obs o = obs[k];
@@ -1594,36 +1706,51 @@ __global__ __launch_bounds__(256) void k_pose_optimize(double* pose7, const doub
             // the 27-sum pass costs more than the two passes it replaces save.)
             const double cur = it == 0 ? po_chi2(cam, sh.pose, d, robust, sh) : sh.current_chi;
             double R[9];
-            quat_to_rot(sh.pose, R);
+            po_quat_to_rot(sh.pose, R);
             double acc[27];
 #pragma unroll
             for (int q = 0; q < 27; ++q) acc[q] = 0;
-            for (int k = tid; k < n; k += 256) {
+            for (int k = tid; k < n; k += PO_T) {
                 if (!active[k]) continue;
-                double e[3], pc[3], A[3][3], B[3][6], X[3];
+                double e[3], pc[3], B[3][6], X[3], iz;
                 lpslam_hip_ba_obs o;
                 d.get(k, o, X);
-                const int D = po_residual(cam, R, sh.pose + 4, X, o, e, pc);
+                const int D = po_residual(cam, R, sh.pose + 4, X, o, e, pc, &iz);
                 const double om = o.inv_sigma2;
                 const double chi = om * (e[0] * e[0] + e[1] * e[1] + (D == 3 ? e[2] * e[2] : 0.0));
                 const double delta = D == 3 ? cam.hub_stereo : cam.hub_mono;
                 double w = om;
-                if (robust && delta > 0) { double r0, r1; huber(chi, delta, &r0, &r1); w *= r1; }
-                ba_jacobians(cam, R, pc, D, A, B);
+                if (robust && delta > 0) { double r0, r1; po_huber(chi, delta, &r0, &r1); w *= r1; }
+                po_jacobian(cam, pc, iz, D, B);
+                // w B once (18 products), then every entry is three fused multiply-adds onto its running sum; the columns that
+                // are structurally zero (B[0][4], B[1][3], B[2][4]) are skipped by hand -- the compiler may not drop x * 0
+                double wB[3][6], we[3];
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    we[r] = -w * e[r];
+#pragma unroll
+                    for (int a = 0; a < 6; ++a) wB[r][a] = w * B[r][a];
+                }
                 int idx = 0;
 #pragma unroll
                 for (int a = 0; a < 6; ++a) {
 #pragma unroll
                     for (int c = a; c < 6; ++c) {
-                        double s2 = 0;
+                        double s2 = acc[idx];
 #pragma unroll
-                        for (int r = 0; r < 3; ++r) s2 += B[r][a] * w * B[r][c];
-                        acc[idx++] += s2;
+                        for (int r = 0; r < 3; ++r) {
+                            const bool zero = (r == 0 && (a == 4 || c == 4)) || (r == 1 && (a == 3 || c == 3)) || (r == 2 && (a == 4 || c == 4));
+                            if (!zero) s2 = fma(wB[r][a], B[r][c], s2);
+                        }
+                        acc[idx++] = s2;
                     }
-                    double s3 = 0;
+                    double s3 = acc[21 + a];
 #pragma unroll
-                    for (int r = 0; r < 3; ++r) s3 += B[r][a] * (-w * e[r]);
-                    acc[21 + a] += s3;
+                    for (int r = 0; r < 3; ++r) {
+                        const bool zero = (r == 0 && a == 4) || (r == 1 && a == 3) || (r == 2 && a == 4);
+                        if (!zero) s3 = fma(B[r][a], we[r], s3);
+                    }
+                    acc[21 + a] = s3;
                 }
             }
             po_reduce27(acc, tr, sh);
@@ -1659,9 +1786,8 @@ __global__ __launch_bounds__(256) void k_pose_optimize(double* pose7, const doub
 #pragma unroll
                         for (int k = 0; k < j; ++k) d2 -= A[j * 6 + k] * A[j * 6 + k];
                         if (!(d2 > 0.0)) { ok = 0; d2 = 1.0; }         // keep going on harmless numbers; the result is discarded
-                        d2 = sqrt(d2);
-                        A[j * 6 + j] = d2;
-                        inv[j] = 1.0 / d2;
+                        inv[j] = po_rsqrt(d2);
+                        A[j * 6 + j] = d2 * inv[j];
 #pragma unroll
                         for (int i = j + 1; i < 6; ++i) {
                             double s2 = A[i * 6 + j];
@@ -1688,7 +1814,7 @@ __global__ __launch_bounds__(256) void k_pose_optimize(double* pose7, const doub
                         }
 #pragma unroll
                         for (int i = 0; i < 6; ++i) sh.x[i] = x[i];
-                        pose_oplus(sh.pose, x, sh.trial);
+                        po_oplus(sh.pose, x, sh.trial);
                     } else {
 #pragma unroll
                         for (int i = 0; i < 7; ++i) sh.trial[i] = sh.pose[i];
@@ -1724,9 +1850,9 @@ __global__ __launch_bounds__(256) void k_pose_optimize(double* pose7, const doub
         __syncthreads();
         // classification with the plain chi2 of this round's pose
         double R[9];
-        quat_to_rot(sh.pose, R);
+        po_quat_to_rot(sh.pose, R);
         int bad = 0;
-        for (int k = tid; k < n; k += 256) {
+        for (int k = tid; k < n; k += PO_T) {
             double e[3], pc[3], X[3];
             lpslam_hip_ba_obs o;
             d.get(k, o, X);
@@ -2462,15 +2588,6 @@ int lpslam_hip_ba_scalar_buffer(lpslam_hip_ba* b, void** dev_ptr, int64_t* n_dou
     return LPSLAM_HIP_OK;
 }
 
-// diagnostic read of the L^-T / W scratch (in-kernel stamps of the LPSLAM_CW_STAMP build); not part of the public header
-int lpslam_hip_debug_ba_scratch(lpslam_hip_ba* b, int64_t offset, int64_t n, double* out)
-{
-    if (!b || !out) return LPSLAM_HIP_ERR_INVALID;
-    LP_HIP(hipStreamSynchronize(b->stream));
-    LP_HIP(hipMemcpy(out, (const double*)b->h_view.Minv + offset, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
-    return LPSLAM_HIP_OK;
-}
-
 int lpslam_hip_ba_reset(lpslam_hip_ba* b)
 {
     if (!b) { set_error("null problem"); return LPSLAM_HIP_ERR_INVALID; }
@@ -2560,7 +2677,7 @@ int lpslam_hip_pose_optimize(lpslam_hip_ctx* ctx, double* pose7, const double* p
         int dev = 0; (void)hipGetDevice(&dev);
         if (dev >= 0 && dev < 64 && !po_attr[dev].load()) { (void)hipFuncSetAttribute((const void*)k_pose_optimize, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kPoLdsBudget + 4096)); po_attr[dev].store(true); }
     }
-    hipLaunchKernelGGL(k_pose_optimize, dim3(1), dim3(256), lds, s, d_pose, d_pts, d_obs, n_obs, c, d_out, d_n, cache_n);
+    hipLaunchKernelGGL(k_pose_optimize, dim3(1), dim3(PO_T), lds, s, d_pose, d_pts, d_obs, n_obs, c, d_out, d_n, cache_n);
     PO_HIP(hipGetLastError());
     int32_t inl = 0;
     PO_HIP(hipMemcpyAsync(hb, base, 128, hipMemcpyDeviceToHost, s));                    // pose and inlier count

@@ -114,14 +114,9 @@ __device__ __forceinline__ void cw_trsm(int q, int T, int wave, const double* X,
     }
 }
 
-// STAMP: diagnostic build (LPSLAM_CW_STAMP=1): wavefronts 0 and 7 leave s_memtime stamps at the phase boundaries behind the W blocks
-template <bool STAMP>
 __global__ __launch_bounds__(CW_THREADS) void k_chol_wg(const BaView* __restrict__ views)
 {
     BA_VIEW(v);
-    unsigned long long* stamps = reinterpret_cast<unsigned long long*>((double*)v.Minv + 16384);
-    int n_stamp = 0;
-#define CW_STAMP() do { if (STAMP && (threadIdx.x == 0 || threadIdx.x == 448)) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); stamps[(threadIdx.x ? 128 : 0) + n_stamp] = t_; } ++n_stamp; } while (0)
     if (!cw_fits(v.dim)) return;                         // larger systems go through the panel-pair chain
     if (ba_idle(v.ctl)) return;
     extern __shared__ __attribute__((aligned(16))) double cw_lds[];
@@ -153,7 +148,6 @@ __global__ __launch_bounds__(CW_THREADS) void k_chol_wg(const BaView* __restrict
                 tab[2 * (w * CW_SLOTS + s)] = (unsigned char)ti; tab[2 * (w * CW_SLOTS + s) + 1] = (unsigned char)tk;
             }
     }
-    CW_STAMP();
 
     if (wave == CW_UW) {
         // ======================= wavefront 7: the diagonal blocks =======================
@@ -187,16 +181,13 @@ __global__ __launch_bounds__(CW_THREADS) void k_chol_wg(const BaView* __restrict
                     }
                 }
             }
-            CW_STAMP();
             const bool fail = cw_diag_factor(a, lane, Wb);
-            CW_STAMP();
             if (__ballot(fail && lane < 32) != 0 && lane == 0) *s_fail = 1;
             if (lane >= 32) {
                 const int r = lane - 32;
 #pragma unroll
                 for (int c = 0; c < NB; ++c) Wb[cw_swz(r, c)] = c >= r ? a[c] : 0.0;
             }
-            CW_STAMP();
             __syncthreads();                             // (2) W_q is in LDS, panel q's raw strips are in X, nobody reads Y any more
             cw_trsm(q, T, wave, X, Y, Wb, S, n, lr, lk);
             // the block itself to memory, off the critical path: L (the row of the right-hand side may live here) and W_q
@@ -251,7 +242,6 @@ __global__ __launch_bounds__(CW_THREADS) void k_chol_wg(const BaView* __restrict
                         }
                     }
                 }
-                CW_STAMP();
                 // 2. lookahead: the rest of the trailing matrix sees panel q - 1 while wavefront 7 factors the diagonal block
 #pragma unroll
                 for (int s = 0; s < CW_SLOTS; ++s) {
@@ -259,12 +249,9 @@ __global__ __launch_bounds__(CW_THREADS) void k_chol_wg(const BaView* __restrict
                         acc[s] = cw_tile_update(Y + (s_ti_(s) - 2 * q) * CW_STRIP, Y + (s_tk_(s) - 2 * q) * CW_STRIP, lr, lk, acc[s]);
                 }
             }
-            CW_STAMP();
             __syncthreads();                             // (2)
-            CW_STAMP();
             // 3. strips below the diagonal block: L = A W_q on the matrix cores, X -> Y (all eight wavefronts share the items)
             cw_trsm(q, T, wave, X, Y, Wb, S, n, lr, lk);
-            CW_STAMP();
             __syncthreads();                             // (3)
         }
 #undef s_ti_
@@ -272,8 +259,6 @@ __global__ __launch_bounds__(CW_THREADS) void k_chol_wg(const BaView* __restrict
     }
 
     // ======================= backward substitution: x = L^-T y, y = row `dim` of L =======================
-    n_stamp = 100;
-    CW_STAMP();
     __syncthreads();                                     // every strip / block of L and every W_q is in memory (workgroup scope: one CU)
     if (tid < CW_VEC) tvec[tid] = tid < dim ? S[(size_t)dim * n + tid] : 0.0;
     // prefetch for the last panel: W_q (two entries per thread) and the rows of L left of the block (thread = column)
@@ -313,7 +298,5 @@ __global__ __launch_bounds__(CW_THREADS) void k_chol_wg(const BaView* __restrict
         }
         __syncthreads();
     }
-    CW_STAMP();
     if (tid == 0 && *s_fail) v.scal[5] = 1.0;
-#undef CW_STAMP
 }
