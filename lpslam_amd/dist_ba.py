@@ -6,8 +6,12 @@ reduced system [S | rhs | b_p | diag H_pp | chi2], a redundant factorisation on 
 substitution, and a 2-double sum all-reduce of (trial chi2, landmark scale term).  The accept / reject decision runs on
 every rank's device on identical inputs, so the ranks stay in lock step without a broadcast.
 
-torch.distributed is the transport: backend "nccl" (= RCCL over xGMI) reduces the device buffers in place; with
-backend "gloo" (CPU tests, or two ranks sharing one GPU) the buffers are staged through host memory.
+The PRODUCT path for this solve is C++: lpslam_hip_ba_optimize_partitioned (csrc/ba.hip) takes an ncclComm_t, all-reduces the
+packed lower triangle on the problem's own stream and drives the trials from the device control block -- bench.py and a host
+application use that (hip.BundleAdjuster.optimize_partitioned, tests/cpp/partitioned_rccl_main.cpp).  This module is the
+REHEARSAL of the same partition through the step-wise entry points with torch.distributed as the transport (backend "gloo":
+CPU tests with world size 2, or two ranks sharing one GPU, buffers staged through host memory; its per-step host
+synchronisations are why it is not the product path) -- and shard_problem / merge helpers that both paths share.
 """
 import numpy as np
 
