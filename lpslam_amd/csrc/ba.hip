@@ -121,10 +121,27 @@ __device__ __forceinline__ void ba_lin_set(BaView& v, int idx)
     v.W = idx ? v.W2[1] : v.W2[0]; v.hl_obs = idx ? v.hl2[1] : v.hl2[0]; v.partial = idx ? v.partial2[1] : v.partial2[0];
 }
 
+// Reciprocal and reciprocal square root for the per-observation arithmetic: v_rcp_f64 / v_rsq_f64 (2^-24, measured) plus ONE cubic
+// correction step -- five instructions and 1.4e-16 maximum relative error (4M samples, tools/dev/rsq_acc.hip) where IEEE division
+// and sqrt are ~30 instructions each.  A reprojection Jacobian held thirteen divisions: across a window's 39 k observations and
+// their three passes per LM iteration that was most of the arithmetic of the linearising kernels.  Not correctly rounded: results
+// move in the last bits against a libm evaluation (tests: chi2 trajectories 1e-9 relative, poses 1e-4 rad / 1e-3 m).
+__device__ __forceinline__ double fast_rcp(double d)       // 1 / d
+{
+    const double y0 = __builtin_amdgcn_rcp(d);
+    const double e = fma(-d, y0, 1.0);
+    return fma(y0, fma(e, e, e), y0);                   // y0 (1 + e + e^2)
+}
+__device__ __forceinline__ double fast_rsqrt(double d)     // 1 / sqrt(d), d > 0
+{
+    const double y0 = __builtin_amdgcn_rsq(d);
+    const double e = fma(-(d * y0), y0, 1.0);
+    return fma(y0 * e, fma(0.375, e, 0.5), y0);         // y0 (1 + e / 2 + 3 e^2 / 8)
+}
 __device__ __forceinline__ void quat_to_rot(const double* q, double* R)
 {
-    const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
-    const double w = q[0] / n, x = q[1] / n, y = q[2] / n, z = q[3] / n;
+    const double rn = fast_rsqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    const double w = q[0] * rn, x = q[1] * rn, y = q[2] * rn, z = q[3] * rn;
     R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - w * z);     R[2] = 2 * (x * z + w * y);
     R[3] = 2 * (x * y + w * z);     R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - w * x);
     R[6] = 2 * (x * z - w * y);     R[7] = 2 * (y * z + w * x);     R[8] = 1 - 2 * (x * x + y * y);
@@ -136,7 +153,7 @@ __device__ __forceinline__ int ba_residual(const BaView& v, int k, const double*
 {
 #pragma unroll
     for (int i = 0; i < 3; ++i) pc[i] = R[i * 3] * X[0] + R[i * 3 + 1] * X[1] + R[i * 3 + 2] * X[2] + t[i];
-    const double iz = 1.0 / pc[2];
+    const double iz = fast_rcp(pc[2]);
     const double u = v.cam.fx * pc[0] * iz + v.cam.cx;
     const double vv = v.cam.fy * pc[1] * iz + v.cam.cy;
     e[0] = v.o_u[k] - u; e[1] = v.o_v[k] - vv;
@@ -150,25 +167,25 @@ __device__ __forceinline__ void huber(double e2, double delta, double* rho0, dou
 {
     const double dsqr = delta * delta;
     if (e2 <= dsqr) { *rho0 = e2; *rho1 = 1.0; }
-    else { const double sq = sqrt(e2); *rho0 = 2 * sq * delta - dsqr; *rho1 = delta / sq; }
+    else { const double rs = fast_rsqrt(e2); *rho0 = 2 * (e2 * rs) * delta - dsqr; *rho1 = delta * rs; }
 }
 
 // Jacobians of the reprojection error: A (D x 3, landmark), B (D x 6, pose, rotation first)
 __device__ __forceinline__ void ba_jacobians(const BaCam& c, const double* R, const double* pc, int D, double A[3][3], double B[3][6])
 {
-    const double x = pc[0], y = pc[1], z = pc[2], z2 = z * z;
+    const double x = pc[0], y = pc[1], iz = fast_rcp(pc[2]), iz2 = iz * iz;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        A[0][k] = -c.fx * R[k] / z + c.fx * x * R[6 + k] / z2;
-        A[1][k] = -c.fy * R[3 + k] / z + c.fy * y * R[6 + k] / z2;
-        A[2][k] = A[0][k] - c.fxb * R[6 + k] / z2;
+        A[0][k] = -c.fx * R[k] * iz + c.fx * x * R[6 + k] * iz2;
+        A[1][k] = -c.fy * R[3 + k] * iz + c.fy * y * R[6 + k] * iz2;
+        A[2][k] = A[0][k] - c.fxb * R[6 + k] * iz2;
     }
-    B[0][0] = x * y / z2 * c.fx;          B[0][1] = -(1.0 + (x * x / z2)) * c.fx; B[0][2] = y / z * c.fx;
-    B[0][3] = -1.0 / z * c.fx;            B[0][4] = 0.0;                           B[0][5] = x / z2 * c.fx;
-    B[1][0] = (1.0 + y * y / z2) * c.fy;  B[1][1] = -x * y / z2 * c.fy;            B[1][2] = -x / z * c.fy;
-    B[1][3] = 0.0;                        B[1][4] = -1.0 / z * c.fy;               B[1][5] = y / z2 * c.fy;
-    B[2][0] = B[0][0] - c.fxb * y / z2;   B[2][1] = B[0][1] + c.fxb * x / z2;      B[2][2] = B[0][2];
-    B[2][3] = B[0][3];                    B[2][4] = 0.0;                           B[2][5] = B[0][5] - c.fxb / z2;
+    B[0][0] = x * y * iz2 * c.fx;          B[0][1] = -(1.0 + (x * x * iz2)) * c.fx; B[0][2] = y * iz * c.fx;
+    B[0][3] = -iz * c.fx;                  B[0][4] = 0.0;                            B[0][5] = x * iz2 * c.fx;
+    B[1][0] = (1.0 + y * y * iz2) * c.fy;  B[1][1] = -x * y * iz2 * c.fy;            B[1][2] = -x * iz * c.fy;
+    B[1][3] = 0.0;                         B[1][4] = -iz * c.fy;                     B[1][5] = y * iz2 * c.fy;
+    B[2][0] = B[0][0] - c.fxb * y * iz2;   B[2][1] = B[0][1] + c.fxb * x * iz2;      B[2][2] = B[0][2];
+    B[2][3] = B[0][3];                     B[2][4] = 0.0;                            B[2][5] = B[0][5] - c.fxb * iz2;
     if (D == 2) {      // monocular edge: the third row does not exist; zero rows keep every sum exact and loops unrolled
 #pragma unroll
         for (int k = 0; k < 3; ++k) A[2][k] = 0.0;
@@ -240,7 +257,7 @@ __device__ __forceinline__ void point_hinv(const double* hl, double lambda, doub
     const double c00 = d * f - e * e, c01 = c * e - b * f, c02 = b * e - c * d;
     const double det = a * c00 + b * c01 + c * c02;
     if (fabs(det) > 0) {
-        const double id = 1.0 / det;
+        const double id = fast_rcp(det);
         ho[0] = c00 * id; ho[1] = c01 * id; ho[2] = c02 * id;
         ho[3] = (a * f - c * c) * id; ho[4] = (b * c - a * e) * id; ho[5] = (a * d - b * b) * id;
     } else {
@@ -1481,18 +1498,8 @@ struct PoShared {
 // thirteen of them).
 constexpr int PO_T = 512;
 constexpr int PO_W = PO_T / 64;
-__device__ __forceinline__ double po_rcp(double d)       // 1 / d
-{
-    const double y0 = __builtin_amdgcn_rcp(d);
-    const double e = fma(-d, y0, 1.0);
-    return fma(y0, fma(e, e, e), y0);                   // y0 (1 + e + e^2)
-}
-__device__ __forceinline__ double po_rsqrt(double d)     // 1 / sqrt(d), d > 0
-{
-    const double y0 = __builtin_amdgcn_rsq(d);
-    const double e = fma(-(d * y0), y0, 1.0);
-    return fma(y0 * e, fma(0.375, e, 0.5), y0);         // y0 (1 + e / 2 + 3 e^2 / 8)
-}
+__device__ __forceinline__ double po_rcp(double d) { return fast_rcp(d); }
+__device__ __forceinline__ double po_rsqrt(double d) { return fast_rsqrt(d); }
 __device__ __forceinline__ double po_block_sum(double v, PoShared& sh)
 {
     v = wave_sum(v);
