@@ -573,7 +573,7 @@ def main():
             mg.collect_results(); mg.provide_odometry()
             mg.start()
             seq_t = wl.synth.StereoSequence(W, H, 4)
-            tr_frames = [seq_t.frame(i) for i in range(30)]
+            tr_frames = [seq_t.frame(i) for i in range(90)]
             t2 = time.perf_counter()
             for i, (l, r) in enumerate(tr_frames):
                 mg.add_stereo((i + 1) * 40_000_000, l, r)

@@ -100,6 +100,15 @@ int lpslam_hip_upload_raw_image(lpslam_hip_ctx* ctx, int image, int32_t eye, con
 /* remaps the raw frame already staged in HBM (the last upload_raw_image) into another slot: the device-side step alone */
 int lpslam_hip_remap_staged(lpslam_hip_ctx* ctx, int image, int32_t eye);
 
+/* Prefetch: between prefetch_begin and prefetch_end every upload / remap / extract / stereo-match call of this context is enqueued
+ * on a second stream, so the front end of the NEXT frame (into image slots nothing else touches) runs on the GPU beside the
+ * matching and pose optimisation of the current one; prefetch_join makes the context's main stream wait (on the device, not the
+ * host) for the last prefetch section before the first call that reads those slots.  The reference overlaps the same way with
+ * its frame queue and worker thread (src/Manager/SlamManager.cpp:54-61: the next frame is decoded while the tracker runs). */
+int lpslam_hip_prefetch_begin(lpslam_hip_ctx* ctx);
+int lpslam_hip_prefetch_end(lpslam_hip_ctx* ctx);
+int lpslam_hip_prefetch_join(lpslam_hip_ctx* ctx);
+
 /* Camera mask of one eye (0 = left: even image slots, 1 = right: odd image slots): a width x height byte image, 0 = masked out,
  * NULL removes it.  Replaces the `mask` argument of feed_stereo_frame / feed_monocular_frame
  * (src/Trackers/OpenVSLAMStereoTracker.cpp:293, masks built by OpenVSLAMTrackerBase::configureMasks, OpenVSLAMTrackerBase.cpp:331-380):

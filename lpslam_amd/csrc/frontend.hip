@@ -916,10 +916,10 @@ int lp_launch_pyramid(lpslam_hip_ctx* c, int first, int n_images)
     const int2* rows = c->d_band_rows + (size_t)set * kMaxLevels * kPyrMaxBands;
     const size_t lds = (size_t)c->rs_entries * sizeof(int2);
     if (lds <= 64 * 1024)
-        hipLaunchKernelGGL(k_pyr_bands<true>, dim3(bands, n_images), dim3(1024), lds, c->stream, c->d_pyr, c->image_slab, c->lt, first,
+        hipLaunchKernelGGL(k_pyr_bands<true>, dim3(bands, n_images), dim3(1024), lds, lp_fe_stream(c), c->d_pyr, c->image_slab, c->lt, first,
                            c->d_rs_pack, c->rs_entries, rows);
     else        // larger images: tables read through the cache instead
-        hipLaunchKernelGGL(k_pyr_bands<false>, dim3(bands, n_images), dim3(1024), 0, c->stream, c->d_pyr, c->image_slab, c->lt, first,
+        hipLaunchKernelGGL(k_pyr_bands<false>, dim3(bands, n_images), dim3(1024), 0, lp_fe_stream(c), c->d_pyr, c->image_slab, c->lt, first,
                            c->d_rs_pack, c->rs_entries, rows);
     LP_HIP(hipGetLastError());
     return LPSLAM_HIP_OK;
@@ -928,7 +928,7 @@ int lp_launch_pyramid(lpslam_hip_ctx* c, int first, int n_images)
 int lp_launch_remap(lpslam_hip_ctx* c, int image, int eye)
 {
     dim3 block(64, 4), grid((c->lt.pitch[0] / 4 + 63) / 64, (c->lt.h[0] + 3) / 4);
-    hipLaunchKernelGGL(k_remap, grid, block, 0, c->stream, c->d_raw, c->d_map_xy[eye], c->d_map_frac[eye],
+    hipLaunchKernelGGL(k_remap, grid, block, 0, lp_fe_stream(c), c->d_raw, c->d_map_xy[eye], c->d_map_frac[eye],
                        c->d_pyr + (size_t)image * c->image_slab, c->lt.w[0], c->lt.h[0], c->lt.pitch[0]);
     LP_HIP(hipGetLastError());
     return LPSLAM_HIP_OK;
@@ -937,7 +937,7 @@ int lp_launch_remap(lpslam_hip_ctx* c, int image, int eye)
 int lp_launch_fast(lpslam_hip_ctx* c, int first, int n_images)
 {
     dim3 grid(c->cells_per_image, n_images);
-    hipLaunchKernelGGL(k_fast_cells, grid, dim3(256), 0, c->stream, c->d_pyr, c->image_slab, c->lt, c->cfg.ini_fast_threshold,
+    hipLaunchKernelGGL(k_fast_cells, grid, dim3(256), 0, lp_fe_stream(c), c->d_pyr, c->image_slab, c->lt, c->cfg.ini_fast_threshold,
                        c->cfg.min_fast_threshold, c->d_cell_keys, c->d_cell_count, c->cells_per_image, first, 0, c->d_mask[0], c->d_mask[1]);
     LP_HIP(hipGetLastError());
     return LPSLAM_HIP_OK;
@@ -946,7 +946,7 @@ int lp_launch_fast(lpslam_hip_ctx* c, int first, int n_images)
 int lp_launch_distribute(lpslam_hip_ctx* c, int first, int n_images)
 {
     dim3 grid(c->lt.n_levels, n_images);
-    hipLaunchKernelGGL(k_distribute, grid, dim3(1024), c->distribute_lds, c->stream, c->lt, c->d_cell_keys, c->d_cell_count,
+    hipLaunchKernelGGL(k_distribute, grid, dim3(1024), c->distribute_lds, lp_fe_stream(c), c->lt, c->d_cell_keys, c->d_cell_count,
                        c->cells_per_image, c->d_cand_key, c->d_cand_node, c->d_cand_count, c->cand_per_image, c->d_sel_key, c->d_sel_count,
                        c->slots_per_image, first);
     LP_HIP(hipGetLastError());
@@ -957,7 +957,7 @@ int lp_launch_describe(lpslam_hip_ctx* c, int first, int n_images)
 {
     for (int i = first; i < first + n_images && (size_t)i < c->h_kp_valid.size(); ++i) c->h_kp_valid[(size_t)i] = 0;      // counts are rewritten
     dim3 grid((c->slots_per_image + DESC_WAVES - 1) / DESC_WAVES, n_images);
-    hipLaunchKernelGGL(k_describe, grid, dim3(64 * DESC_WAVES), 0, c->stream, c->d_pyr, c->image_slab, c->lt, c->d_sel_key,
+    hipLaunchKernelGGL(k_describe, grid, dim3(64 * DESC_WAVES), 0, lp_fe_stream(c), c->d_pyr, c->image_slab, c->lt, c->d_sel_key,
                        c->d_sel_count, c->slots_per_image, c->d_kpts, c->d_desc, c->d_kp_count, first);
     LP_HIP(hipGetLastError());
     return LPSLAM_HIP_OK;

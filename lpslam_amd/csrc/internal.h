@@ -40,6 +40,9 @@ struct LevelTable {
 };
 
 void set_error(const char* fmt, ...);
+// Between lpslam_hip_prefetch_begin and _end the CALLING THREAD's upload / remap / extraction / stereo launches go to the context's
+// prefetch stream; other threads (the tracking thread) keep using the main stream of the same context.
+extern thread_local hipStream_t lp_tls_stream;
 int hip_fail(hipError_t e, const char* what);
 
 #define LP_HIP(call)                                              \
@@ -53,7 +56,11 @@ int hip_fail(hipError_t e, const char* what);
 struct lpslam_hip_ctx {
     lpslam_hip_frontend_config cfg{};
     lpslam::LevelTable lt{};
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;      // the stream every entry point enqueues on
+    hipStream_t fe_stream = nullptr;   // prefetch: front end of the NEXT frame beside the tracking of this one (lp_fe_stream)
+    hipEvent_t fe_done = nullptr;
+    std::vector<uint8_t*> h_upload;    // per image slot: page-locked staging of the last uploaded frame (uploads are asynchronous)
+    std::vector<hipEvent_t> ev_upload; // ... and the event after its copy
     size_t image_slab = 0;             // bytes of one image's pyramid (all levels, pitched)
     int slots_per_image = 0;           // sum(quota+3)
     int cells_per_image = 0;
@@ -114,6 +121,7 @@ struct lpslam_hip_ctx {
 
 // kernel launchers (frontend.hip / match.hip)
 // block cache (api.hip): capacity-rounded first fit; *capacity receives the size to hand back to lp_pool_free
+inline hipStream_t lp_fe_stream(lpslam_hip_ctx* c) { return lpslam::lp_tls_stream ? lpslam::lp_tls_stream : c->stream; }
 int lp_pool_alloc(lpslam_hip_ctx* c, size_t bytes, void** out, size_t* capacity);
 void lp_pool_free(lpslam_hip_ctx* c, void* p, size_t capacity);
 hipStream_t lp_stream_acquire(lpslam_hip_ctx* c);   // high-priority non-blocking stream from the context's cache (nullptr on failure)

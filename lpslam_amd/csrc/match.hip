@@ -333,13 +333,13 @@ __global__ __launch_bounds__(1024) void k_stereo_median(const int32_t* __restric
 int lp_launch_stereo_strided(lpslam_hip_ctx* c, int left0, int right0, int stride, int n_pairs, float fxb, float baseline)
 {
     const float max_disp = fxb / baseline;
-    hipLaunchKernelGGL(k_stereo_rows, dim3(n_pairs), dim3(1024), (size_t)(2 * c->lt.h[0] + 2) * sizeof(int), c->stream, c->lt, c->d_kpts, c->d_kp_count,
+    hipLaunchKernelGGL(k_stereo_rows, dim3(n_pairs), dim3(1024), (size_t)(2 * c->lt.h[0] + 2) * sizeof(int), lp_fe_stream(c), c->lt, c->d_kpts, c->d_kp_count,
                        c->slots_per_image, right0, stride, c->d_st_row_start, c->d_st_row_list, c->st_row_cap);
     dim3 grid((c->slots_per_image + ST_WAVES - 1) / ST_WAVES, n_pairs);
-    hipLaunchKernelGGL(k_stereo, grid, dim3(64 * ST_WAVES), 0, c->stream, c->d_pyr, c->image_slab, c->lt, c->d_kpts, c->d_desc,
+    hipLaunchKernelGGL(k_stereo, grid, dim3(64 * ST_WAVES), 0, lp_fe_stream(c), c->d_pyr, c->image_slab, c->lt, c->d_kpts, c->d_desc,
                        c->d_kp_count, c->slots_per_image, left0, right0, stride, fxb, max_disp, c->d_stereo, c->d_stereo_idx,
                        c->d_stereo_corr, c->d_st_row_start, c->d_st_row_list, c->st_row_cap);
-    hipLaunchKernelGGL(k_stereo_median, dim3(n_pairs), dim3(1024), 0, c->stream, c->d_kp_count,
+    hipLaunchKernelGGL(k_stereo_median, dim3(n_pairs), dim3(1024), 0, lp_fe_stream(c), c->d_kp_count,
                        c->slots_per_image, left0, stride, c->d_stereo, c->d_stereo_corr);
     LP_HIP(hipGetLastError());
     return LPSLAM_HIP_OK;

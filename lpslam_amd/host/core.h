@@ -89,6 +89,7 @@ public:
     void pop(T& out) { std::unique_lock<std::mutex> l(m_); cv_.wait(l, [&] { return !q_.empty(); }); out = std::move(q_.front()); q_.pop_front(); }
     bool try_pop(T& out) { std::lock_guard<std::mutex> l(m_); if (q_.empty()) return false; out = std::move(q_.front()); q_.pop_front(); return true; }
     size_t size() { std::lock_guard<std::mutex> l(m_); return q_.size(); }
+    template <class F> void with_front(F&& f) { std::lock_guard<std::mutex> l(m_); if (!q_.empty()) f(q_.front()); }   // the entry stays queued
     void clear() { std::lock_guard<std::mutex> l(m_); q_.clear(); }
 private:
     std::mutex m_; std::condition_variable cv_; std::deque<T> q_;
@@ -131,6 +132,10 @@ public:
     virtual ProcessImageResult processImage(CameraQueueEntry& cam, std::optional<GlobalStateInTime> navResultOdom = std::nullopt,
                                             std::optional<GlobalStateInTime> navResultMap = std::nullopt,
                                             std::vector<SensorQueueEntry> const& sensorValues = {}) = 0;
+    // The frame that will be processed after the one handed to the next processImage call (nullptr: none is queued yet).  A tracker
+    // may start that frame's device-side front end once its own has finished, so that it runs beside the tracking of the current
+    // frame; the pointer is valid during that processImage call only.
+    virtual void setNextFrame(CameraQueueEntry const*) {}
     virtual void addRequestNavTransformationCallback(RequestNavTransformationCallback_t, void*) {}
     virtual std::optional<unsigned long> mappingGetMapRawSize() { return std::nullopt; }
     virtual std::optional<LpMapInfo> mappingGetMapRaw(int8_t*, std::size_t) { return std::nullopt; }

@@ -1,5 +1,6 @@
 // hip_tracker.cpp -- see hip_tracker.h.  Host-side tracking glue around the HIP C ABI (the arithmetic runs on the GPU).
 #include "hip_tracker.h"
+#include <future>
 #include "rectify.h"
 #include "two_view.h"
 
@@ -69,7 +70,7 @@ HipVslamTrackerBase::HipVslamTrackerBase()
     o.optional("mapFilename", "map.db"); o.optional("maxLaserAge", 1.0);
     // runtime ORB parameters the reference hard-codes in its generated YAML (:193-198), plus device selection
     o.optional("numLevels", 3); o.optional("scaleFactor", 1.2); o.optional("iniFastThr", 20); o.optional("minFastThr", 7);
-    o.optional("device", 0); o.optional("keyframeInterval", 6); o.optional("localWindow", 10); o.optional("asyncMapping", true);
+    o.optional("device", 0); o.optional("keyframeInterval", 6); o.optional("localWindow", 10); o.optional("asyncMapping", true); o.optional("prefetch", true);
 }
 
 HipVslamTrackerBase::~HipVslamTrackerBase() { stop(); }
@@ -89,10 +90,12 @@ void HipVslamTrackerBase::OnConfigurationUpdate()
     m_iniFastThr = o.getInteger("iniFastThr"); m_minFastThr = o.getInteger("minFastThr"); m_device = o.getInteger("device");
     m_keyframeInterval = std::max(1, o.getInteger("keyframeInterval")); m_localWindow = std::max(2, o.getInteger("localWindow"));
     m_asyncMapping = o.getBool("asyncMapping");
+    m_prefetch = o.getBool("prefetch");
 }
 
 bool HipVslamTrackerBase::startContext(bool stereo)
 {
+    m_prefetched.valid = false; m_nextFrame = nullptr;
     std::scoped_lock lock(m_slamLock);
     if (m_ctx) return true;
     if (!m_configFromFile.empty()) {
@@ -126,7 +129,7 @@ bool HipVslamTrackerBase::startContext(bool stereo)
     lpslam_hip_frontend_config cfg{};
     cfg.width = m_cam.resolution_x; cfg.height = m_cam.resolution_y; cfg.max_keypoints = m_slamKeypoints;
     cfg.scale_factor = (float)m_scaleFactor; cfg.num_levels = m_numLevels; cfg.ini_fast_threshold = m_iniFastThr;
-    cfg.min_fast_threshold = m_minFastThr; cfg.max_images = 4; cfg.device = m_device;
+    cfg.min_fast_threshold = m_minFastThr; cfg.max_images = 6; cfg.device = m_device;
     if (lpslam_hip_create(&cfg, &m_ctx) != LPSLAM_HIP_OK) {
         logMessage(LpSlamLogLevel_Error, std::string("Cannot create the HIP context: ") + lpslam_hip_last_error());
         m_ctx = nullptr;
@@ -1014,7 +1017,7 @@ bool HipVslamTrackerBase::relocalise(FrameData& cur)
     }
     std::sort(near.begin(), near.end());
     if (near.size() > 8) near.resize(8);
-    const int scratch = cur.slot ^ 2;                    // the previous frame's slot pair: its device data is not needed while lost
+    const int scratch = previousSlot(cur.slot);                    // the previous frame's slot pair: its device data is not needed while lost
     std::vector<int32_t> mq((size_t)m_maxKp), mt((size_t)m_maxKp), md((size_t)m_maxKp);
     for (auto& nc : near) {
         const Keyframe& kf = m_kfs[(size_t)nc.second];
@@ -1068,7 +1071,7 @@ bool HipVslamTrackerBase::detectAndCloseLoop(FrameData& cur, int c)
     if (cands.empty()) return false;
     std::sort(cands.begin(), cands.end());
     if (cands.size() > 48) cands.resize(48);
-    const int scratch = cur.slot ^ 2;                  // the previous frame's slot pair is free for the descriptors of a candidate
+    const int scratch = previousSlot(cur.slot);                  // the previous frame's slot pair is free for the descriptors of a candidate
     std::vector<int32_t> mq((size_t)m_maxKp), mt((size_t)m_maxKp), md((size_t)m_maxKp);
     struct Vote { int kf; std::vector<std::pair<int, int>> pairs; };        // (keypoint of c, keypoint of the candidate), landmarks on both sides
     std::vector<Vote> votes;
@@ -1265,12 +1268,51 @@ void HipVslamTrackerBase::logStatistics() const
     const double per = s.frames > 0 ? 1e3 / (double)s.frames : 0.0;
     std::snprintf(buf, sizeof(buf), "VSLAM statistics: frames=%ld motion_tracked=%ld bf_tracked=%ld local_map_joined=%ld keyframes=%ld fused_added=%ld fused_merged=%ld "
                   "local_ba=%ld loops_closed=%ld loop_fused=%ld global_ba=%ld lost=%ld relocalised=%ld reinitialised=%ld nav_priors=%ld landmarks=%zu "
-                  "ms_per_frame=%.4f ms_front_end=%.4f ms_track=%.4f ms_local_map=%.4f ms_keyframe=%.4f ms_dev_upload=%.4f ms_dev_extract=%.4f ms_dev_get=%.4f ms_dev_match=%.4f ms_dev_pose=%.4f",
+                  "prefetched=%ld ms_per_frame=%.4f ms_front_end=%.4f ms_track=%.4f ms_local_map=%.4f ms_keyframe=%.4f ms_dev_upload=%.4f ms_dev_extract=%.4f ms_dev_get=%.4f ms_dev_match=%.4f ms_dev_pose=%.4f",
                   s.frames, s.motion_tracked, s.bf_tracked, s.local_map_joined, s.keyframes, s.fused_added, s.fused_merged, s.local_ba, s.loops_closed, s.loop_fused,
-                  s.global_ba, s.lost, s.relocalised, s.reinitialised, s.nav_priors, m_landmarks.size(),
+                  s.global_ba, s.lost, s.relocalised, s.reinitialised, s.nav_priors, m_landmarks.size(), s.prefetched,
                   s.t_total * per, s.t_front * per, s.t_track * per, s.t_local * per, s.t_keyframe * per,
                   s.t_dev_upload * per, s.t_dev_extract * per, s.t_dev_get * per, s.t_dev_match * per, s.t_dev_pose * per);
     logMessage(LpSlamLogLevel_Info, buf);
+}
+
+// upload (raw frames: + undistortion / rectification on the device), extraction, stereo matching of one frame into a slot pair;
+// everything is only enqueued
+bool HipVslamTrackerBase::frontEnd(CameraQueueEntry const& cam, bool stereo, int slot)
+{
+    bool ok;
+    if (m_rectify) {       // raw frames: undistort + rectify on the device
+        ok = lpslam_hip_upload_raw_image(m_ctx, slot, 0, cam.image.pixels.data(), cam.image.width) == LPSLAM_HIP_OK;
+        if (ok && stereo) ok = lpslam_hip_upload_raw_image(m_ctx, slot + 1, 1, cam.image_second->pixels.data(), cam.image.width) == LPSLAM_HIP_OK;
+    } else {
+        ok = lpslam_hip_upload_image(m_ctx, slot, cam.image.pixels.data(), cam.image.width) == LPSLAM_HIP_OK;
+        if (ok && stereo) ok = lpslam_hip_upload_image(m_ctx, slot + 1, cam.image_second->pixels.data(), cam.image.width) == LPSLAM_HIP_OK;
+    }
+    if (ok) ok = lpslam_hip_extract_range(m_ctx, slot, stereo ? 2 : 1) == LPSLAM_HIP_OK;
+    if (ok && stereo) {
+        const float baseline = (float)(m_cam.focal_x_baseline / m_cam.f_x);
+        ok = lpslam_hip_match_stereo(m_ctx, slot, slot + 1, (float)m_cam.focal_x_baseline, baseline) == LPSLAM_HIP_OK;
+    }
+    return ok;
+}
+
+// The front end of the frame that comes next, on the context's prefetch stream: issued right after this frame's own front end has
+// come back, it runs on the GPU while this frame is matched and optimised (LpSlamManager hands the queued frame over with
+// setNextFrame).
+void HipVslamTrackerBase::prefetchFrame(CameraQueueEntry const& cam, bool stereo)
+{
+    m_prefetched.valid = false;
+    if (!m_ctx || !m_prefetch) return;
+    if (stereo && !cam.image_second.has_value()) return;
+    if (cam.image.width != m_cam.resolution_x || cam.image.height != m_cam.resolution_y ||
+        (stereo && (cam.image_second->width != cam.image.width || cam.image_second->height != cam.image.height))) return;
+    const int slot = slotOf(m_imageTracked);              // the current frame has been counted already
+    if (lpslam_hip_prefetch_begin(m_ctx) != LPSLAM_HIP_OK) { logMessage(LpSlamLogLevel_Error, std::string("prefetch_begin: ") + lpslam_hip_last_error()); return; }
+    const bool ok = frontEnd(cam, stereo, slot);
+    if (!ok) logMessage(LpSlamLogLevel_Error, std::string("prefetch front end: ") + lpslam_hip_last_error());
+    if (lpslam_hip_prefetch_end(m_ctx) != LPSLAM_HIP_OK || !ok) return;
+    m_prefetched.valid = true; m_prefetched.data = cam.image.pixels.data(); m_prefetched.timestamp = cam.timestamp;
+    m_prefetched.slot = slot; m_prefetched.stereo = stereo;
 }
 
 TrackerBase::ProcessImageResult HipVslamTrackerBase::trackFrame(CameraQueueEntry& cam, bool stereo, const std::optional<GlobalStateInTime>& navOdom)
@@ -1305,22 +1347,23 @@ TrackerBase::ProcessImageResult HipVslamTrackerBase::trackFrame(CameraQueueEntry
     }
 
     FrameData cur;
-    cur.slot = (int)(m_imageTracked % 2) * 2;
+    cur.slot = slotOf(m_imageTracked);
     bool ok;
     auto t_dev = std::chrono::steady_clock::now();
     auto dev_lap = [&t_dev](double& acc) { const auto now = std::chrono::steady_clock::now(); acc += std::chrono::duration<double>(now - t_dev).count(); t_dev = now; };
-    if (m_rectify) {       // raw frames: undistort + rectify on the device
-        ok = lpslam_hip_upload_raw_image(m_ctx, cur.slot, 0, cam.image.pixels.data(), cam.image.width) == LPSLAM_HIP_OK;
-        if (ok && stereo) ok = lpslam_hip_upload_raw_image(m_ctx, cur.slot + 1, 1, cam.image_second->pixels.data(), cam.image.width) == LPSLAM_HIP_OK;
+    if (m_prefetched.valid && m_prefetched.data == cam.image.pixels.data() && m_prefetched.timestamp == cam.timestamp &&
+        m_prefetched.slot == cur.slot && m_prefetched.stereo == stereo) {
+        // this frame's front end was started while the previous frame was tracked: the main stream waits for it on the device
+        ok = lpslam_hip_prefetch_join(m_ctx) == LPSLAM_HIP_OK;
+        ++m_stats.prefetched;
+        m_prefetched.valid = false;
     } else {
-        ok = lpslam_hip_upload_image(m_ctx, cur.slot, cam.image.pixels.data(), cam.image.width) == LPSLAM_HIP_OK;
-        if (ok && stereo) ok = lpslam_hip_upload_image(m_ctx, cur.slot + 1, cam.image_second->pixels.data(), cam.image.width) == LPSLAM_HIP_OK;
-    }
-    dev_lap(m_stats.t_dev_upload);
-    if (ok) ok = lpslam_hip_extract_range(m_ctx, cur.slot, stereo ? 2 : 1) == LPSLAM_HIP_OK;
-    if (ok && stereo) {
-        const float baseline = (float)(m_cam.focal_x_baseline / m_cam.f_x);
-        ok = lpslam_hip_match_stereo(m_ctx, cur.slot, cur.slot + 1, (float)m_cam.focal_x_baseline, baseline) == LPSLAM_HIP_OK;
+        if (m_prefetched.valid && m_prefetched.slot == cur.slot) {
+            // a prefetch into this slot pair for a frame that did not come next (skipped, queue cleared): let it drain first
+            (void)lpslam_hip_prefetch_join(m_ctx);
+            m_prefetched.valid = false;
+        }
+        ok = frontEnd(cam, stereo, cur.slot);
     }
     dev_lap(m_stats.t_dev_extract);
     int32_t n = 0;
@@ -1333,6 +1376,11 @@ TrackerBase::ProcessImageResult HipVslamTrackerBase::trackFrame(CameraQueueEntry
     cur.kpts.resize((size_t)n); cur.desc.resize((size_t)n * 32);
     cur.x_right.resize((size_t)n); cur.depth.resize((size_t)n); cur.landmark.assign((size_t)n, -1);
     ++m_imageTracked; ++m_stats.frames;
+    // The next frame's upload + front end: a helper thread stages and enqueues it (0.2 ms of host time at 1280x720 stereo, mostly the
+    // copy of the cold frame into page-locked memory) on the context's prefetch stream while this thread goes on tracking; the
+    // future joins before this call returns (the frame is only valid that long) and on every early return.
+    std::future<void> prefetching;
+    if (m_nextFrame && m_prefetch) prefetching = std::async(std::launch::async, [this, next = m_nextFrame, stereo] { prefetchFrame(*next, stereo); });
     auto t_mark = std::chrono::steady_clock::now();
     auto lap = [&t_mark](double& acc) { const auto now = std::chrono::steady_clock::now(); acc += std::chrono::duration<double>(now - t_mark).count(); t_mark = now; };
     m_stats.t_front += std::chrono::duration<double>(t_mark - t0).count();

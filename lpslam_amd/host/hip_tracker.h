@@ -69,7 +69,7 @@ protected:
     };
     struct Statistics {                               // logged at stop() ("VSLAM statistics: ..."): what the tracker did, for logs and tests
         long frames = 0, motion_tracked = 0, bf_tracked = 0, local_map_joined = 0, keyframes = 0, fused_added = 0, fused_merged = 0;
-        long local_ba = 0, loops_closed = 0, loop_fused = 0, global_ba = 0, lost = 0, relocalised = 0, reinitialised = 0, nav_priors = 0;
+        long local_ba = 0, loops_closed = 0, loop_fused = 0, global_ba = 0, lost = 0, relocalised = 0, reinitialised = 0, nav_priors = 0, prefetched = 0;
         // where the frames' time went (seconds, summed): front end (upload, extraction, stereo, read-back), tracking against the
         // previous frame, local-map tracking, keyframe work on the tracking thread (insertion, fusion, loop search, BA set-up / wait)
         double t_front = 0, t_track = 0, t_local = 0, t_keyframe = 0, t_total = 0;
@@ -129,7 +129,7 @@ protected:
     // configuration (names as in the reference tracker)
     bool m_useLiveView = false, m_useMapDb = true, m_forwardNavState = true, m_forwardImu = true, m_emitMap = false;
     bool m_enableMapping = true, m_waitForNavigation = false, m_forwardHighResNav = false, m_loopClosure = true;
-    bool m_useOpenCL = false, m_useCUDA = false, m_relocWithNavigation = true, m_asyncMapping = true;
+    bool m_useOpenCL = false, m_useCUDA = false, m_relocWithNavigation = true, m_asyncMapping = true, m_prefetch = true;
     std::string m_configFromFile, m_cameraSetup = "monocular", m_vocabFile = "orb_vocab.dbow2", m_mapFilename = "map.db";
     int m_slamKeypoints = 1200, m_viewerFps = 10;
     double m_baselineDistThresh = 0.1, m_maxLaserAge = 1.0;
@@ -144,6 +144,15 @@ protected:
     TrackerState m_state = TrackerState::NotInitialized;
     std::optional<TimeStamp> m_firstImageTimestamp;
     uint64_t m_imageTracked = 0;
+    // Image slots: a ring of three slot pairs -- the frame being tracked, the previous one (brute-force fallback, scratch for
+    // relocalisation / loop candidates once it is no longer needed) and the next one, whose front end is prefetched.
+    static int slotOf(uint64_t frame_index) { return (int)(frame_index % 3) * 2; }
+    static int previousSlot(int slot) { return ((slot / 2 + 2) % 3) * 2; }
+    struct Prefetched { bool valid = false; const uint8_t* data = nullptr; TimeStamp timestamp{}; int slot = 0; bool stereo = false; } m_prefetched;
+    void prefetchFrame(CameraQueueEntry const& cam, bool stereo);      // m_slamLock held
+    CameraQueueEntry const* m_nextFrame = nullptr;
+    void setNextFrame(CameraQueueEntry const* next) override { m_nextFrame = next; }
+    bool frontEnd(CameraQueueEntry const& cam, bool stereo, int slot);
     double m_lastFrameSeconds = 0;
     int m_maxKp = 0;
     float m_scales[LPSLAM_HIP_MAX_LEVELS] = {0};

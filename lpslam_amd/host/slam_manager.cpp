@@ -299,8 +299,16 @@ bool SlamManager::workerStep()
 {
     streamMoreReplayItems();                           // SlamManager.cpp:56-57
     CameraQueueEntry cam;
-    m_camQueue.pop(cam);
+    if (m_lookahead) { cam = std::move(*m_lookahead); m_lookahead.reset(); }
+    else m_camQueue.pop(cam);
     if (!cam.valid || m_stopRequested.load()) return false;   // exit signal; a stop abandons the backlog (SlamManager::stop)
+    // one frame of lookahead, owned by this thread: if another frame is already queued the trackers learn about it, and may start
+    // its upload and extraction on the GPU beside the tracking of this frame
+    {
+        CameraQueueEntry next;
+        if (m_camQueue.try_pop(next)) m_lookahead = std::move(next);
+    }
+    const CameraQueueEntry* next_frame = (m_lookahead && m_lookahead->valid) ? &*m_lookahead : nullptr;
     const auto now = std::chrono::steady_clock::now();
     if (m_lastFrame) {                                  // m_lastFrame belongs to this thread; the rate is read by getSlamStatus
         const double dt = std::chrono::duration<double>(now - *m_lastFrame).count();
@@ -327,7 +335,9 @@ bool SlamManager::workerStep()
             ++m_framesSkipped;
             break;
         }
+        tracker->setNextFrame(next_frame);
         auto results = tracker->processImage(cam, odom, map, sensors);
+        tracker->setNextFrame(nullptr);
         for (auto& tr : results) {
             GlobalStateInTime st;
             st.first = tr.timestamp;
@@ -378,6 +388,8 @@ void SlamManager::stop()
     CameraQueueEntry poison; poison.valid = false;
     m_camQueue.push(std::move(poison));
     if (m_worker.joinable()) m_worker.join();
+    m_lookahead.reset();                                // the frame the worker had taken ahead is part of the abandoned backlog
+    m_camQueue.clear();                                 // ... and so is the exit signal if the worker left on the stop flag
     ResultQueueEntry rp; rp.exitSignal = true;
     m_resultQueue.push(rp);
     if (m_notifyWorker.joinable()) m_notifyWorker.join();

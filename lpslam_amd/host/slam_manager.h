@@ -68,6 +68,7 @@ private:
     std::atomic<uint64_t> m_framesProcessed{0}, m_framesSkipped{0};
     std::atomic<double> m_currentFps{0.0};
     std::atomic<bool> m_stopRequested{false};
+    std::optional<CameraQueueEntry> m_lookahead;       // worker thread only: the frame after the one being processed
     ReplayReader m_replay;
     std::mutex m_replayMutex;
     size_t m_replayChunk = 500;          // ReplayEngine.h:53

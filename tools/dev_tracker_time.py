@@ -16,14 +16,17 @@ for async_map in ("true", "false", "true", "false"):
     mg.collect_results(); mg.provide_odometry()
     log = os.path.join(tempfile.mkdtemp(), "slam.log")
     mg.log_to_file(log)
-    mg.start()
     seq = synth.StereoSequence(W, H, 4)
     frames = [seq.frame(i) for i in range(30)]
-    t0 = time.perf_counter()
+    ta = time.perf_counter()
     for i, (l, r) in enumerate(frames):
         mg.add_stereo((i + 1) * 40_000_000, l, r)
+    print("enqueue of 30 frames: %.2f ms" % (1e3 * (time.perf_counter() - ta)))
+    t0 = time.perf_counter()
+    mg.start()
     while len(mg.results) < len(frames) and time.perf_counter() - t0 < 60:
         time.sleep(0.0005)
     dt = time.perf_counter() - t0
     mg.stop()
+    print([l.strip() for l in open(log, errors="replace") if "prefetch" in l][:3])
     print("asyncMapping", async_map, "%.1f frames/s" % (len(frames) / dt), manager.Manager.statistics(log))
