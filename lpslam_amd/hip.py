@@ -206,6 +206,20 @@ class Context:
     def remap_staged(self, image, eye):
         _check(self.lib.lpslam_hip_remap_staged(self.h, image, int(eye)))
 
+    def prefetch(self):
+        """context manager: upload / remap / extract / stereo calls of THIS thread go to the context's prefetch stream"""
+        ctx = self
+        class _Section:
+            def __enter__(self_inner):
+                _check(ctx.lib.lpslam_hip_prefetch_begin(ctx.h))
+            def __exit__(self_inner, *exc):
+                _check(ctx.lib.lpslam_hip_prefetch_end(ctx.h))
+                return False
+        return _Section()
+
+    def prefetch_join(self):
+        _check(self.lib.lpslam_hip_prefetch_join(self.h))
+
     def extract(self, n_images):
         _check(self.lib.lpslam_hip_extract(self.h, n_images))
 

@@ -159,3 +159,46 @@ def test_extract_with_camera_mask(hiplib, oracle, w, h, kpts, levels):
 
 def oracle_pyramid(oracle, img, p):
     return oracle.extract(img, p, True)[3]
+
+
+def test_prefetch_stream_gives_the_same_frame(hiplib, oracle):
+    """lpslam_hip_prefetch_begin / _end / _join: the front end of the NEXT stereo frame is enqueued on the context's second stream
+    (from a helper thread, as the tracker does) while the main stream matches the current one; after the join the prefetched slots
+    hold exactly what the ordinary path gives.  Misuse is refused."""
+    import threading
+    w, h, kpts, levels = 640, 480, 1000, 4
+    k = synth.intrinsics(w, h)
+    seq = synth.StereoSequence(w, h, 5, n_points=4000)
+    f0, f1 = seq.frame(0), seq.frame(1)
+    ref = hiplib.Context(w, h, kpts, 1.2, levels, max_images=6)
+    for s, im in ((0, f0[0]), (1, f0[1]), (2, f1[0]), (3, f1[1])):
+        ref.upload(s, im)
+    ref.extract_range(0, 4)
+    ref.match_stereo(0, 1, k["fxb"], k["baseline"]); ref.match_stereo(2, 3, k["fxb"], k["baseline"])
+    want = [ref.frame(0), ref.frame(2)]
+
+    ctx = hiplib.Context(w, h, kpts, 1.2, levels, max_images=6)
+    ctx.upload(0, f0[0]); ctx.upload(1, f0[1])
+    ctx.extract_range(0, 2); ctx.match_stereo(0, 1, k["fxb"], k["baseline"])
+    err = []
+
+    def helper():                                    # the next frame, on the prefetch stream
+        try:
+            with ctx.prefetch():
+                ctx.upload(2, f1[0]); ctx.upload(3, f1[1])
+                ctx.extract_range(2, 2); ctx.match_stereo(2, 3, k["fxb"], k["baseline"])
+        except Exception as e:                       # noqa: BLE001
+            err.append(e)
+    th = threading.Thread(target=helper); th.start()
+    for _ in range(5):                               # meanwhile the main stream works on the current frame
+        ctx.match_bf(0, 1)
+    got0 = ctx.frame(0)
+    th.join()
+    assert not err
+    ctx.prefetch_join()
+    got1 = ctx.frame(2)
+    for g, wnt in ((got0, want[0]), (got1, want[1])):
+        for a, b in zip(g, wnt):
+            assert np.array_equal(a, b)
+    with pytest.raises(hiplib.LpslamHipError):       # end without begin
+        hiplib._check(hiplib.load().lpslam_hip_prefetch_end(ctx.h))

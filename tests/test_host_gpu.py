@@ -378,3 +378,29 @@ def test_stop_abandons_the_backlog(hiplib):
     _feed(m, frames[:4], t0_ns=300 * 40_000_000, expect=done + 4)
     m.stop()
     assert len(m.results) == done + 4
+
+
+def test_prefetch_does_not_change_the_trajectory(hiplib):
+    """The tracker starts the next queued frame's front end on a second stream while it tracks the current one (`prefetch`, default
+    on); with inline mapping the poses are bit for bit those of a run without it, and the statistics show that it happened."""
+    import tempfile, os
+    from lpslam_amd import _build, manager
+    _build.host_library()
+    w, h, n_frames = 640, 480, 16
+    seq = synth.StereoSequence(w, h, 4, n_points=6000)
+    frames = [seq.frame(i) for i in range(n_frames)]
+    runs = {}
+    for prefetch in ("true", "false"):
+        log = os.path.join(tempfile.mkdtemp(), "slam.log")
+        m = _stereo_manager(manager, w, h, '{"cameraSetup": "stereo", "slamKeypoints": 1000, "numLevels": 4, "keyframeInterval": 4, "asyncMapping": false, '
+                            '"prefetch": %s}' % prefetch, log)
+        for i, (l, r) in enumerate(frames):           # queued before the worker starts: every frame has a successor waiting
+            assert m.add_stereo((i + 1) * 40_000_000, l, r)
+        m.start()
+        t0 = time.time()
+        while len(m.results) < n_frames and time.time() - t0 < 60:
+            time.sleep(0.01)
+        m.stop()
+        runs[prefetch] = ([(r["valid"], tuple(r["p"]), tuple(r["q"])) for r in m.results], manager.Manager.statistics(log))
+    assert len(runs["true"][0]) == n_frames and runs["true"][0] == runs["false"][0]
+    assert runs["true"][1]["prefetched"] == n_frames - 1 and runs["false"][1]["prefetched"] == 0

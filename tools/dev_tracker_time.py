@@ -17,7 +17,7 @@ for async_map in ("true", "false", "true", "false"):
     log = os.path.join(tempfile.mkdtemp(), "slam.log")
     mg.log_to_file(log)
     seq = synth.StereoSequence(W, H, 4)
-    frames = [seq.frame(i) for i in range(30)]
+    frames = [seq.frame(i) for i in range(90)]
     ta = time.perf_counter()
     for i, (l, r) in enumerate(frames):
         mg.add_stereo((i + 1) * 40_000_000, l, r)
