@@ -102,8 +102,25 @@ struct BaView {                       // one problem, resident in device memory 
 
 // The view of problem blockIdx.y.  `views` is const __restrict__ and read before any store of the kernel: scalar loads.
 #define BA_VIEW(v) BaView v = views[blockIdx.y]
+// The members a kernel needs before its first branch, made live together: one scalar round trip for the extents AND the control
+// block pointer (left alone the compiler loads the pointer only behind the extent test, one round trip later).
+#define BA_VIEW_HEAD(...) asm volatile("" :: __VA_ARGS__)
 
 __device__ __forceinline__ bool ba_idle(const BaCtl* c) { return c->stopped || c->outer_done >= c->max_outer; }
+// What the kernels read of the control block, fetched in ONE round trip (straight-line loads, no branch between them): written as
+// `if (ba_idle(ctl) || !ctl->need_lin) return; idx = ctl->cur;` every member was a dependent round trip of its own in front of the
+// kernel's real work.
+struct BaFlags {
+    double lambda; int cur, need_lin, outer_done, max_outer, stopped, cur_launch, spec;
+    __device__ __forceinline__ bool idle() const { return (stopped != 0) | (outer_done >= max_outer); }
+};
+__device__ __forceinline__ BaFlags ba_flags(const BaCtl* c)
+{
+    BaFlags f;
+    f.lambda = c->lambda; f.cur = c->cur; f.need_lin = c->need_lin; f.outer_done = c->outer_done; f.max_outer = c->max_outer;
+    f.stopped = c->stopped; f.cur_launch = c->cur_launch; f.spec = c->spec;
+    return f;
+}
 // selects the evaluated state: the accepted one (trial = 0) or the trial one
 __device__ __forceinline__ void ba_select(BaView& v, int trial)
 {
@@ -337,10 +354,12 @@ __device__ void lm_begin(BaView& v, double max_diag_pp, double max_diag_ll, doub
 __global__ __launch_bounds__(256) void k_ba_point_sum(const BaView* __restrict__ views, int fused)
 {
     BA_VIEW(v);
+    BA_VIEW_HEAD("s"(v.point_blocks), "s"(v.ctl));
     const int part_n = v.point_blocks;                     // landmark workgroups of this problem; workgroup part_n combines the pose partials
     if ((int)blockIdx.x > part_n) return;
-    if (ba_idle(v.ctl) || !v.ctl->need_lin) return;
-    ba_lin_set(v, v.ctl->cur);
+    const BaFlags fl = ba_flags(v.ctl);
+    if (fl.idle() || !fl.need_lin) return;
+    ba_lin_set(v, fl.cur);
     __shared__ double sm[4];
     if ((int)blockIdx.x == part_n) {
         // the extra workgroup: the pose partials of the linearisation are complete before this launch, so they are combined
@@ -595,10 +614,12 @@ __device__ void pose_combine_body(BaView& v, int mode, int part_n, int fused)
 __global__ __launch_bounds__(256) void k_ba_lin(const BaView* __restrict__ views, int robust, int points_fixed)
 {
     BA_VIEW(v);
+    BA_VIEW_HEAD("s"(v.obs_blocks), "s"(v.pose_blocks), "s"(v.ctl));
     const int obs_blocks = v.obs_blocks;
     if ((int)blockIdx.x >= obs_blocks + v.pose_blocks) return;
-    if (ba_idle(v.ctl) || !v.ctl->need_lin || v.ctl->spec) return;
-    const int idx = v.ctl->cur;
+    const BaFlags fl = ba_flags(v.ctl);
+    if (fl.idle() || !fl.need_lin || fl.spec) return;
+    const int idx = fl.cur;
     if ((int)blockIdx.x < obs_blocks) obs_lin_body(v, blockIdx.x, robust, points_fixed, idx);
     else pose_part_body(v, (int)blockIdx.x - obs_blocks, robust, 0, idx);
 }
@@ -611,10 +632,12 @@ __global__ __launch_bounds__(256) void k_ba_lin(const BaView* __restrict__ views
 __global__ __launch_bounds__(256) void k_ba_trial(const BaView* __restrict__ views, int robust, int fused, int points_fixed, int spec)
 {
     BA_VIEW(v);
+    BA_VIEW_HEAD("s"(v.part_n), "s"(v.pose_blocks), "s"(v.obs_blocks), "s"(v.ctl));
     const int part_n = v.part_n, trial_blocks = v.pose_blocks, obs_blocks = v.obs_blocks;
     if ((int)blockIdx.x >= trial_blocks + (spec ? obs_blocks + trial_blocks : 0)) return;
-    if (ba_idle(v.ctl)) return;
-    const int idx = v.ctl->cur_launch ^ 1;
+    const BaFlags fl = ba_flags(v.ctl);
+    if (fl.idle()) return;
+    const int idx = fl.cur_launch ^ 1;
     if ((int)blockIdx.x >= trial_blocks) {
         const int bid = (int)blockIdx.x - trial_blocks;
         if (bid < obs_blocks) obs_lin_body(v, bid, robust, points_fixed, idx);
@@ -661,9 +684,10 @@ __global__ __launch_bounds__(64) void k_ba_schur(const BaView* __restrict__ view
     BA_VIEW(v);
     const int n_work = 4 * v.n_blocks;                     // work item = (block pair, part): see below
     if ((int)blockIdx.x >= n_work + v.n_free) return;
-    if (ba_idle(v.ctl)) return;
-    const double lambda = v.ctl->lambda;
-    ba_lin_set(v, v.ctl->cur);
+    const BaFlags fl = ba_flags(v.ctl);
+    if (fl.idle()) return;
+    const double lambda = fl.lambda;
+    ba_lin_set(v, fl.cur);
     const int lane = threadIdx.x;
     const int n = v.dim_pad;
     if ((int)blockIdx.x >= n_work) {
@@ -1338,7 +1362,8 @@ __global__ __launch_bounds__(256) void k_chol_xsolve(const BaView* __restrict__ 
 {
     if (pin && (blockIdx.x & 7)) return;  // XCD 0 only, like k_chol_pair: its inputs sit in that L2
     BA_VIEW(v);
-    if (ba_idle(v.ctl) || (skip_small && cw_fits(v.dim))) return;
+    BA_VIEW_HEAD("s"(v.dim), "s"(v.dim_pad), "s"(v.ctl), "s"(v.S), "s"(v.Ldiag), "s"(v.Lsub), "s"(v.Minv), "s"(v.xp));
+    if (ba_flags(v.ctl).idle() || (skip_small && cw_fits(v.dim))) return;
     const int lane = threadIdx.x & 63;
     const int i = (pin ? blockIdx.x >> 3 : blockIdx.x) * 4 + (threadIdx.x >> 6);
     if (i >= v.dim) return;
@@ -1395,16 +1420,18 @@ void enqueue_factor_solve(hipStream_t s, const BaView* d_views, int count, int n
 __global__ __launch_bounds__(256) void k_ba_backsub(const BaView* __restrict__ views)
 {
     BA_VIEW(v);
+    BA_VIEW_HEAD("s"(v.part_n), "s"(v.ctl));
     const int point_blocks = v.part_n;
     if ((int)blockIdx.x > point_blocks) return;
-    if (ba_idle(v.ctl)) return;
-    const double lambda = v.ctl->lambda;
-    ba_select(v, 0); ba_lin_set(v, v.ctl->cur);
-    GPTR(double) poses_out = v.ctl->cur ? v.poses_buf[0] : v.poses_buf[1];
-    GPTR(double) points_out = v.ctl->cur ? v.points_buf[0] : v.points_buf[1];
+    const BaFlags fl = ba_flags(v.ctl);
+    if (fl.idle()) return;
+    const double lambda = fl.lambda;
+    ba_select_idx(v, fl.cur); ba_lin_set(v, fl.cur);
+    GPTR(double) poses_out = fl.cur ? v.poses_buf[0] : v.poses_buf[1];
+    GPTR(double) points_out = fl.cur ? v.points_buf[0] : v.points_buf[1];
     if ((int)blockIdx.x == point_blocks) {
         // trial poses = exp(x_p) * poses; scal[3] = sum x_p (lambda x_p + b_p) (fixed order, one wavefront)
-        if (threadIdx.x == 0) v.ctl->cur_launch = v.ctl->cur;      // what the trial launch reads while the decision flips `cur`
+        if (threadIdx.x == 0) v.ctl->cur_launch = fl.cur;          // what the trial launch reads while the decision flips `cur`
         if (threadIdx.x >= 64) return;
         double sc = 0;
         for (int p = threadIdx.x; p < v.n_poses; p += 64) {
