@@ -1004,39 +1004,31 @@ __device__ __forceinline__ double dpp_bcast(double v)          // the value of l
     asm("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "n"(L));
     return r;
 }
-// One pivot of a strip.  What every later pivot waits for is the chain  pivot -> 1 / sqrt -> scaled column -> next pivot, so it is
-// kept as short as the arithmetic allows (measured: 190 cycles per pivot with two Goldschmidt steps and the next pivot read back
-// from the updated column; a dependent FP64 operation costs 8-9 cycles here, not its 4 issue cycles):
-//   * 1 / sqrt(d) = y0 (1 + e / 2 + 3 e^2 / 8), e = 1 - d y0^2, y0 = v_rsq_f64 (2^-24, measured): one cubic step, four dependent
-//     levels, 1.4e-16 relative error over 4M samples (two Goldschmidt steps: seven levels, 2.1e-16);
-//   * the positivity test runs beside v_rsq_f64 and costs one select after it (a failed pivot continues on 1.0: harmless finite
+// One pivot of a strip.  The strip is bound by its instruction COUNT (measured, tools/dev/strip_bench2.hip: 240 DPP updates at
+// 5.5 cycles + the per-pivot instructions at 4 to 5 cycles each; placing the next pivot's root between the updates by hand changes
+// nothing), so a pivot is written with as few instructions as the arithmetic allows:
+//   * 1 / sqrt(d) = y0 (1 + e / 2 + 3 e^2 / 8), e = 1 - d y0^2, y0 = v_rsq_f64 (2^-24, measured): one cubic step, five operations,
+//     1.4e-16 relative error over 4M samples (two Goldschmidt steps: eight operations, 2.1e-16);
+//   * the positivity guard sits BEFORE the root (compare + one 64-bit select; a failed pivot continues on 1.0: harmless finite
 //     numbers, the factorisation is flagged and its result discarded);
-//   * the next pivot is a(jj+1, jj+1) - l(jj+1)^2 with both operands broadcast BEFORE this pivot's root is known, so it follows
-//     the root by two operations instead of waiting for the column update and a DPP read-back (same fma as the update: same bits).
-__device__ __forceinline__ double pivot_rsqrt_cubic(double d, bool ok)
-{
-    double y0 = __builtin_amdgcn_rsq(d);
-    y0 = ok ? y0 : 1.0;
-    const double dg = ok ? d : 1.0;
-    const double t = dg * y0;
-    const double e = fma(-t, y0, 1.0);
-    const double pp = fma(0.375, e, 0.5), ye = y0 * e;
-    return fma(ye, pp, y0);
-}
+//   * the next pivot is read back from the updated column with one DPP broadcast (a recurrence a(jj+1,jj+1) - l(jj+1)^2 on values
+//     broadcast beforehand shortens the dependent chain but costs four more instructions: 3.15 k against 2.84 k cycles per strip).
 template <int JJ>
 __device__ __forceinline__ void strip_step(double (&d)[16], double (&x)[16], double piv, bool& fail)
 {
-    double p = 0.0, q = 0.0;
-    if constexpr (JJ < 15) { p = dpp_bcast<JJ + 1>(d[JJ]); q = dpp_bcast<JJ + 1>(d[JJ + 1]); }
     const bool ok = piv > 0.0;
     fail |= !ok;
-    const double rs = pivot_rsqrt_cubic(piv, ok);
+    const double pg = ok ? piv : 1.0;
+    const double y0 = __builtin_amdgcn_rsq(pg);
+    const double t = pg * y0;
+    const double e = fma(-t, y0, 1.0);
+    const double pp = fma(0.375, e, 0.5), ye = y0 * e;
+    const double rs = fma(ye, pp, y0);
     const double l = d[JJ] * rs, lx = x[JJ] * rs;
     d[JJ] = l; x[JJ] = lx;
     if constexpr (JJ < 15) {
-        const double lp = p * rs;
-        const double next = fma(-lp, lp, q);
         dpp_rank1<JJ + 1>(d, l, l);
+        const double next = dpp_bcast<JJ + 1>(d[JJ + 1]);
         dpp_rank1<JJ + 1>(x, l, lx);
         strip_step<JJ + 1>(d, x, next, fail);
     }

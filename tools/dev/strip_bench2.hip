@@ -205,6 +205,30 @@ __device__ __forceinline__ bool strip_factor3(double (&d)[16], double (&x)[16])
     strip_step3<0>(d, x, pivot_rsqrt_cubic(piv, ok), p, q, fail);
     return fail;
 }
+
+// ---- variant 3: fewest instructions per pivot -- pivot read back from the updated column (one broadcast), guard before the root
+// (compare + one 64-bit select), cubic root step; block asm for the updates
+template <int JJ>
+__device__ __forceinline__ void strip_step4(double (&d)[16], double (&x)[16], double piv, bool& fail)
+{
+    const bool ok = piv > 0.0;
+    fail |= !ok;
+    const double pg = ok ? piv : 1.0;
+    const double y0 = __builtin_amdgcn_rsq(pg);
+    const double t = pg * y0;
+    const double e = fma(-t, y0, 1.0);
+    const double pp = fma(0.375, e, 0.5), ye = y0 * e;
+    const double rs = fma(ye, pp, y0);
+    const double l = d[JJ] * rs, lx = x[JJ] * rs;
+    d[JJ] = l; x[JJ] = lx;
+    if constexpr (JJ < 15) {
+        dpp_rank1<JJ + 1>(d, l, l);
+        const double next = dpp_bcast<JJ + 1>(d[JJ + 1]);
+        dpp_rank1<JJ + 1>(x, l, lx);
+        strip_step4<JJ + 1>(d, x, next, fail);
+    }
+}
+__device__ __forceinline__ bool strip_factor4(double (&d)[16], double (&x)[16]) { bool fail = false; strip_step4<0>(d, x, dpp_bcast<0>(d[0]), fail); return fail; }
 template <int V>
 __global__ __launch_bounds__(64) void k_bench(const double* A, double* out, int reps, long long* cyc)
 {
@@ -217,7 +241,7 @@ __global__ __launch_bounds__(64) void k_bench(const double* A, double* out, int 
     for (int rep = 0; rep < reps; ++rep) {
 #pragma unroll
         for (int c = 0; c < 16; ++c) { d[c] = d0[c] + carry; x[c] = x0[c]; }
-        if (V == 0) strip_factor(d, x); else if (V == 1) strip_factor2(d, x); else strip_factor3(d, x);
+        if (V == 0) strip_factor(d, x); else if (V == 1) strip_factor2(d, x); else if (V == 2) strip_factor3(d, x); else strip_factor4(d, x);
         carry = d[15] * 1e-300;
     }
     const long long t1 = __builtin_readcyclecounter();
@@ -243,16 +267,16 @@ int main()
     hipMalloc(&dA, 8 * rows * n); hipMalloc(&dO, 8 * rows * n); hipMalloc(&dC, 8);
     hipMemcpy(dA, A.data(), 8 * rows * n, hipMemcpyHostToDevice);
     const int reps = 2000;
-    for (int v = 0; v < 3; ++v) {
+    for (int v = 0; v < 4; ++v) {
         for (int pass = 0; pass < 2; ++pass) {
-            if (v == 0) hipLaunchKernelGGL(k_bench<0>, 1, 64, 0, 0, dA, dO, reps, dC); else if (v == 1) hipLaunchKernelGGL(k_bench<1>, 1, 64, 0, 0, dA, dO, reps, dC); else hipLaunchKernelGGL(k_bench<2>, 1, 64, 0, 0, dA, dO, reps, dC);
+            if (v == 0) hipLaunchKernelGGL(k_bench<0>, 1, 64, 0, 0, dA, dO, reps, dC); else if (v == 1) hipLaunchKernelGGL(k_bench<1>, 1, 64, 0, 0, dA, dO, reps, dC); else if (v == 2) hipLaunchKernelGGL(k_bench<2>, 1, 64, 0, 0, dA, dO, reps, dC); else hipLaunchKernelGGL(k_bench<3>, 1, 64, 0, 0, dA, dO, reps, dC);
             hipDeviceSynchronize();
         }
         std::vector<double> O(rows * n); long long cyc = 0;
         hipMemcpy(O.data(), dO, 8 * rows * n, hipMemcpyDeviceToHost); hipMemcpy(&cyc, dC, 8, hipMemcpyDeviceToHost);
         double err = 0;
         for (int i = 0; i < rows; ++i) for (int j = 0; j < n; ++j) if (i >= j) err = fmax(err, fabs(O[i * n + j] - L[i * n + j]));
-        printf("%s: %.0f cycles per strip (%.1f per pivot), max err %.3e\n", v == 0 ? "block asm (committed)      " : v == 1 ? "one asm per instruction    " : "software pipelined by hand ", (double)cyc / reps, (double)cyc / reps / 16, err);
+        printf("%s: %.0f cycles per strip (%.1f per pivot), max err %.3e\n", v == 0 ? "block asm (committed)      " : v == 1 ? "one asm per instruction    " : v == 2 ? "software pipelined by hand " : "read-back, guard first     ", (double)cyc / reps, (double)cyc / reps / 16, err);
     }
     return 0;
 }
