@@ -400,29 +400,61 @@ __global__ __launch_bounds__(1024) void k_distribute(LevelTable lt, const uint32
     const int cpt = min(DIST_CPT, (n_cand + 1023) / 1024);
     const int n_reg = min(n_cand, 1024 * cpt);
     const int c_first = tid * cpt;
+    // 1. the per-cell slots are compacted into the level's candidate array
+    //    with coalesced loads and stores (below);
+    // 2. every thread then fetches its own contiguous run from the compact array, 16 bytes at a time when the run length allows.
+    //    (Before, each thread walked the cell offsets for its run and gathered straight from the cell slots: 24 scattered
+    //    4-byte loads per thread, each touching 48 cache lines per wavefront -- 75 k of the level-0 workgroup's 218 k cycles.)
     {
+        // wavefront w compacts candidates [w * 64 cpt, (w + 1) * 64 cpt): in step u its lanes take 64 consecutive candidates (coalesced on
+        // both sides), so from step to step a lane's candidate moves on by 64 and its cell by one at most now and then -- one binary
+        // search per lane, then a short walk; offsets first, then the loads of all steps together, then the stores
+        const int wv = tid >> 6, ln = tid & 63;
+        const int wbase = wv * 64 * cpt;
         int cell = 0;
-        if (c_first < n_reg) {
-            int lo = 0, hi = ncell;                    // largest cell with coff[cell] <= c_first
-            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (coff[mid] <= c_first) lo = mid; else hi = mid; }
+        {
+            const int c = min(wbase + ln, n_cand - 1);
+            int lo = 0, hi = ncell;                    // largest cell with coff[cell] <= c
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (coff[mid] <= c) lo = mid; else hi = mid; }
             cell = lo;
         }
+        int src_off[DIST_CPT];
 #pragma unroll
-        for (int s = 0; s < DIST_CPT; ++s) {
-            const int c = c_first + s;
-            uint32_t k = 0;
-            if (s < cpt && c < n_reg) {
-                while (coff[cell + 1] <= c) ++cell;    // coff[ncell] = n_cand > c
-                k = ckeys[(size_t)cell * kCellSlots + (c - coff[cell])];
-                ckey[c] = k;
-            }
-            rk[s] = k; rn[s] = 0;
+        for (int u = 0; u < DIST_CPT; ++u) {
+            const int c = min(wbase + 64 * u + ln, n_cand - 1);
+            while (coff[cell + 1] <= c) ++cell;        // coff[ncell] = n_cand > c
+            src_off[u] = cell * kCellSlots + (c - coff[cell]);
         }
+        uint32_t kv[DIST_CPT];
+#pragma unroll
+        for (int u = 0; u < DIST_CPT; ++u) kv[u] = ckeys[src_off[u]];
+#pragma unroll
+        for (int u = 0; u < DIST_CPT; ++u) { const int c = wbase + 64 * u + ln; if (u < cpt && c < n_reg) ckey[c] = kv[u]; }
     }
-    for (int c = n_reg + tid; c < n_cand; c += 1024) {
+    for (int c = n_reg + tid; c < n_cand; c += 1024) {      // beyond the register-resident part (more than 1024 x 24 candidates)
         int lo = 0, hi = ncell;
         while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (coff[mid] <= c) lo = mid; else hi = mid; }
         ckey[c] = ckeys[(size_t)lo * kCellSlots + (c - coff[lo])];
+    }
+    __threadfence_block();
+    __syncthreads();
+    if ((cpt & 3) == 0) {
+        const uint4* run = reinterpret_cast<const uint4*>(ckey + c_first);        // candidate arrays start on 4 KB boundaries
+#pragma unroll
+        for (int s4 = 0; s4 < DIST_CPT / 4; ++s4) {
+            uint4 q4 = make_uint4(0, 0, 0, 0);
+            if (4 * s4 < cpt && c_first + 4 * s4 < n_reg) q4 = run[s4];              // may run past n_cand inside the level's array: masked below
+            rk[4 * s4] = q4.x; rk[4 * s4 + 1] = q4.y; rk[4 * s4 + 2] = q4.z; rk[4 * s4 + 3] = q4.w;
+        }
+#pragma unroll
+        for (int s = 0; s < DIST_CPT; ++s) { if (!(s < cpt && c_first + s < n_reg)) rk[s] = 0; rn[s] = 0; }
+    } else {
+#pragma unroll
+        for (int s = 0; s < DIST_CPT; ++s) {
+            const int c = c_first + s;
+            rk[s] = (s < cpt && c < n_reg) ? ckey[c] : 0u;
+            rn[s] = 0;
+        }
     }
     __syncthreads();
 #define DIST_VALID(s) ((s) < cpt && c_first + (s) < n_reg)
@@ -433,9 +465,15 @@ __global__ __launch_bounds__(1024) void k_distribute(LevelTable lt, const uint32
     const int nini = nxg * nyg;             // 4 * nini + 4 <= Q
     for (int i = tid; i < nini; i += 1024) cnt4[i] = 0;
     __syncthreads();
+    // root column / row of every pixel coordinate of this level, tabulated once: two FP64 divisions per candidate were 26 k cycles of
+    // the level-0 workgroup (four wavefronts per SIMD, 24 candidates per thread)
+    uint8_t* rtab_x = reinterpret_cast<uint8_t*>(ncnt[1] + Q);
+    uint8_t* rtab_y = rtab_x + lt.w[level];
+    for (int i = tid; i < lt.w[level]; i += 1024) rtab_x[i] = (uint8_t)min(255u, (unsigned)((double)(float)i / delta_x));
+    for (int i = tid; i < lt.h[level]; i += 1024) rtab_y[i] = (uint8_t)min(255u, (unsigned)((double)(float)i / delta_y));
+    __syncthreads();
     auto root_of = [&](uint32_t k) -> uint32_t {
-        const float x = (float)(k & 0xFFF), y = (float)((k >> 12) & 0xFFF);
-        const unsigned ix = (unsigned)((double)x / delta_x), iy = (unsigned)((double)y / delta_y);
+        const unsigned ix = rtab_x[k & 0xFFF], iy = rtab_y[(k >> 12) & 0xFFF];
         unsigned root = ix + iy * nxg;
         if (root >= (unsigned)nini) root = nini - 1;
         return root;
@@ -682,8 +720,8 @@ size_t lp_distribute_lds_bytes(int Q, int ncell)
 {
     int sortcap = 1; while (sortcap < Q) sortcap <<= 1;
     const int c4 = 4 * Q > ncell + 1 ? 4 * Q : ncell + 1;
-    // cnt4 | order | nodepos | kpre | keptrank | misc | node boxes (2 x Q x uint2) | node counts (2 x Q)
-    return sizeof(int) * ((size_t)c4 + sortcap + Q + (Q + 1) + (Q + 1) + 64 + 4 * (size_t)Q + 2 * (size_t)Q + 2);
+    // cnt4 | order | nodepos | kpre | keptrank | misc | node boxes (2 x Q x uint2) | node counts (2 x Q) | root tables (w + h bytes, <= 8192)
+    return sizeof(int) * ((size_t)c4 + sortcap + Q + (Q + 1) + (Q + 1) + 64 + 4 * (size_t)Q + 2 * (size_t)Q + 2) + 8192 + 16;
 }
 
 // ------------------------------------------------------------------------------------------------------------
