@@ -370,10 +370,27 @@ __global__ __launch_bounds__(256) void k_ba_point_sum(const BaView* __restrict__
         double m = 0;
         if (j < v.n_points) {
             double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-            for (int s = v.pt_start[j]; s < v.pt_start[j + 1]; ++s) {
-                const double* ho = v.hl_obs + 9 * (size_t)v.pt_obs[s];
+            // four observations at a time: their index loads together, then their 36 doubles together, then the sums in the fixed
+            // order (one observation per pass meant two dependent round trips each: the kernel was their latency)
+            const int s_end = v.pt_start[j + 1];
+            for (int s = v.pt_start[j]; s < s_end; s += 4) {
+                int kk[4];
 #pragma unroll
-                for (int i = 0; i < 9; ++i) acc[i] += ho[i];
+                for (int u = 0; u < 4; ++u) kk[u] = v.pt_obs[min(s + u, s_end - 1)];
+                double hv[4][9];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const double* ho = v.hl_obs + 9 * (size_t)kk[u];
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) hv[u][i] = ho[i];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (s + u < s_end) {
+#pragma unroll
+                        for (int i = 0; i < 9; ++i) acc[i] += hv[u][i];
+                    }
+                }
             }
 #pragma unroll
             for (int i = 0; i < 6; ++i) v.Hll[6 * (size_t)j + i] = acc[i];
@@ -1440,16 +1457,33 @@ __global__ __launch_bounds__(256) void k_ba_backsub(const BaView* __restrict__ v
     double sc = 0;
     double r[3] = {0, 0, 0};
     if (g < v.n_points) {
-        for (int s = v.pt_start[g] + sub; s < v.pt_start[g + 1]; s += 4) {
-            const int k = v.pt_obs[s];
-            const int slot = v.pose_slot[v.o_pose[k]];
-            if (slot < 0) continue;
-            const double* Wk = v.W + 18 * (size_t)k;
-            const double* x = v.xp + 6 * slot;
+        // two observations of the lane at a time, their index / slot / W / x_p load chains side by side (same order of the sums)
+        const int s_end = v.pt_start[g + 1];
+        for (int s = v.pt_start[g] + sub; s < s_end; s += 8) {
+            int kk[2], slot[2];
 #pragma unroll
-            for (int c = 0; c < 3; ++c)
+            for (int u = 0; u < 2; ++u) kk[u] = v.pt_obs[min(s + 4 * u, s_end - 1)];
 #pragma unroll
-                for (int rr = 0; rr < 6; ++rr) r[c] += Wk[rr * 3 + c] * x[rr];
+            for (int u = 0; u < 2; ++u) slot[u] = v.pose_slot[v.o_pose[kk[u]]];
+            double wv[2][18], xv[2][6];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const double* Wk = v.W + 18 * (size_t)kk[u];
+                const double* x = v.xp + 6 * (size_t)max(slot[u], 0);
+#pragma unroll
+                for (int i = 0; i < 18; ++i) wv[u][i] = Wk[i];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) xv[u][i] = x[i];
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (s + 4 * u < s_end && slot[u] >= 0) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+#pragma unroll
+                        for (int rr = 0; rr < 6; ++rr) r[c] += wv[u][rr * 3 + c] * xv[u][rr];
+                }
+            }
         }
     }
 #pragma unroll
