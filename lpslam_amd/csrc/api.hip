@@ -303,17 +303,23 @@ int lpslam_hip_create(const lpslam_hip_frontend_config* cfg, lpslam_hip_ctx** ou
     if (e != hipSuccess) { delete c; return hip_fail(e, "hipStreamCreate"); }
     rc = ctx_alloc(c);
     if (rc == LPSLAM_HIP_OK && !ofs.empty()) {
-        std::vector<int2> pack(ofs.size());
+        std::vector<int2> pack;
+        pack.reserve(2 * ofs.size());
         for (int l = 1; l < L; ++l) {
-            for (int axis = 0; axis < 2; ++axis) {
+            auto entry = [&](int axis, int i) {
                 const int start = axis ? c->lt.ytab_start[l] : c->lt.xtab_start[l];
-                const int n = axis ? c->lt.h[l] : c->lt.w[l], src_n = axis ? c->lt.h[l - 1] : c->lt.w[l - 1];
-                for (int i = 0; i < n; ++i) {
-                    const int s0 = ofs[start + i], s1 = std::min(s0 + 1, src_n - 1);
-                    pack[start + i] = make_int2(s0 | (s1 << 16), (int)(uint16_t)coef[2 * (start + i)] | ((int)coef[2 * (start + i) + 1] << 16));
-                }
-            }
+                const int src_n = axis ? c->lt.h[l - 1] : c->lt.w[l - 1];
+                const int s0 = ofs[start + i], s1 = std::min(s0 + 1, src_n - 1);
+                return make_int2(s0 | (s1 << 16), (int)(uint16_t)coef[2 * (start + i)] | ((int)coef[2 * (start + i) + 1] << 16));
+            };
+            const int per_row = c->lt.pitch[l] >> 2;
+            c->lt.dx_start[l] = (int)pack.size();
+            for (int k = 0; k < 4; ++k)
+                for (int q = 0; q < per_row; ++q) pack.push_back(entry(0, std::min(4 * q + k, c->lt.w[l] - 1)));
+            c->lt.dy_start[l] = (int)pack.size();
+            for (int i = 0; i < c->lt.h[l]; ++i) pack.push_back(entry(1, i));
         }
+        c->lt.dx_start[0] = c->lt.dy_start[0] = 0;
         c->rs_entries = (int)pack.size();
         e = hipMalloc((void**)&c->d_rs_pack, pack.size() * sizeof(int2));
         if (e == hipSuccess) e = hipMemcpy(c->d_rs_pack, pack.data(), pack.size() * sizeof(int2), hipMemcpyHostToDevice);

@@ -30,14 +30,14 @@ typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 // lanes and v_dot2_u32_u16 applies the weight pair (w0 | w1 << 16) as the table stores it.  (One 8-byte load per row with 64-bit
 // shifts was measured slower.)
 template <typename Tab>
-__device__ __forceinline__ uint32_t pyr_down_dword(const uint8_t* __restrict__ src, int sp, int dw, int dx0, int2 ey, Tab xtab)
+__device__ __forceinline__ uint32_t pyr_down_dword(const uint8_t* __restrict__ src, int sp, int dw, int dx0, int2 ey, Tab xplanes, int per_row)
 {
     const int b0 = ey.y & 0xFFFF, b1 = ey.y >> 16;
     const unsigned o0 = (unsigned)(ey.x & 0xFFFF) * (unsigned)sp, o1 = o0 + (unsigned)sp;   // uniform base + 32-bit offsets
     uint32_t packed = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {       // branch-free: pad columns compute the last column and are zeroed by a select
-        const int2 ex = xtab[min(dx0 + k, dw - 1)];
+        const int2 ex = xplanes[k * per_row + (dx0 >> 2)];       // plane k, dword q: column min(4 q + k, dw - 1)
         const unsigned sx0 = (unsigned)ex.x & 0xFFFFu;
         const unsigned t0 = *reinterpret_cast<const unsigned short*>(src + o0 + sx0);
         const unsigned t1 = *reinterpret_cast<const unsigned short*>(src + o1 + sx0);
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(1024) void k_pyr_bands(uint8_t* __restrict__ pyr, s
         const int per_row = dp >> 2;
         const int total = (rows.y - rows.x + 1) * per_row;
         const float inv = 1.0f / (float)per_row;
-        const int ytab = lt.ytab_start[level] + rows.x, xtab = lt.xtab_start[level];
+        const int ytab = lt.dy_start[level] + rows.x, xtab = lt.dx_start[level];
         constexpr int kIlp = 4;          // dwords in flight per thread: the loop is a chain of table read -> pixel loads
         for (int t = threadIdx.x; t < total; t += 1024 * kIlp) {
             uint32_t v[kIlp];
@@ -79,8 +79,8 @@ __global__ __launch_bounds__(1024) void k_pyr_bands(uint8_t* __restrict__ pyr, s
                 r[u] = (int)(((float)tu + 0.5f) * inv);
                 q[u] = tu - r[u] * per_row;
                 if (q[u] < 0) { --r[u]; q[u] += per_row; } else if (q[u] >= per_row) { ++r[u]; q[u] -= per_row; }
-                if (kTablesInLds) v[u] = pyr_down_dword(src, sp, dw, q[u] * 4, s_tab[ytab + r[u]], s_tab + xtab);
-                else v[u] = pyr_down_dword(src, sp, dw, q[u] * 4, rs_pack[ytab + r[u]], rs_pack + xtab);
+                if (kTablesInLds) v[u] = pyr_down_dword(src, sp, dw, q[u] * 4, s_tab[ytab + r[u]], s_tab + xtab, per_row);
+                else v[u] = pyr_down_dword(src, sp, dw, q[u] * 4, rs_pack[ytab + r[u]], rs_pack + xtab, per_row);
             }
 #pragma unroll
             for (int u = 0; u < kIlp; ++u)

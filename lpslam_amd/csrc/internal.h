@@ -33,7 +33,8 @@ struct LevelTable {
     int slot_start[kMaxLevels + 1];    // prefix of (quota+3) over levels: selected-keypoint slots per image
     int cand_start[kMaxLevels + 1];    // prefix of candidate capacity (cells*kCellSlots) over levels
     float scale[kMaxLevels], inv_scale[kMaxLevels];
-    int xtab_start[kMaxLevels], ytab_start[kMaxLevels];  // offsets into the resize tables (level >= 1)
+    int xtab_start[kMaxLevels], ytab_start[kMaxLevels];  // offsets into the host-side resize tables (level >= 1)
+    int dx_start[kMaxLevels], dy_start[kMaxLevels];      // offsets into the device copy: x as four planes (below), y linear
     // quad-tree roots (initialize_nodes): grid and patch size per level, node capacity Q = max(quota, 4*roots) + 4
     int nxg[kMaxLevels], nyg[kMaxLevels], qcap[kMaxLevels];
     double delta_x[kMaxLevels], delta_y[kMaxLevels];
@@ -68,7 +69,9 @@ struct lpslam_hip_ctx {
 
     uint8_t* d_pyr = nullptr;          // [max_images][image_slab]
     // resize tables: xofs/yofs (int16) and 11-bit coefficient pairs (int16 x2) per output column/row
-    int2* d_rs_pack = nullptr;         // resize tables, one entry per destination column / row: (s0 | s1 << 16, w0 | w1 << 16)
+    int2* d_rs_pack = nullptr;         // resize tables, entries (s0 | s1 << 16, w0 | w1 << 16); per level: the columns as FOUR PLANES
+                                       // [k][q] = column min(4 q + k, w - 1) (a lane produces the four pixels of dword q: neighbouring lanes
+                                       // read neighbouring entries of a plane -- the linear table was an 8-way LDS bank conflict), then the rows
     int rs_entries = 0;
     uint8_t* h_stage = nullptr;        // pinned host staging of lpslam_hip_get_frame (one frame's results)
     size_t h_stage_bytes = 0;
