@@ -799,7 +799,6 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const uint8_t* __r
     __shared__ __attribute__((aligned(16))) uint8_t s_raw[DESC_WAVES][PW * RAW_PITCH];
     __shared__ __attribute__((aligned(16))) uint16_t s_h[DESC_WAVES][PW * HB_PITCH];
     __shared__ __attribute__((aligned(16))) uint8_t s_blur[DESC_WAVES][BW * BW];
-
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int image = image0 + blockIdx.y;
     const int slot = blockIdx.x * DESC_WAVES + wave;
@@ -821,19 +820,34 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const uint8_t* __r
     uint8_t* raw = s_raw[wave];
     uint16_t* hb = s_h[wave];
     uint8_t* bl = s_blur[wave];
-
     // the 43 x 43 patch: ten (unaligned) dword loads and three byte loads per row instead of 43 byte loads
-    for (int i = lane; i < PW * 10; i += 64) {
-        const int r = i / 10, c4 = i - r * 10;
-        uint32_t w;
-        __builtin_memcpy(&w, src + (size_t)r * P + 4 * c4, 4);
-        *reinterpret_cast<uint32_t*>(&raw[r * RAW_PITCH + 4 * c4]) = w;
+    // (all of a lane's loads first, then its LDS stores: one round trip to memory instead of ten in a row)
+    {
+        uint32_t wv[7]; uint8_t bv[3];
+#pragma unroll
+        for (int it = 0; it < 7; ++it) {
+            const int i = min(lane + 64 * it, PW * 10 - 1), r = i / 10, c4 = i - r * 10;
+            __builtin_memcpy(&wv[it], src + (size_t)r * P + 4 * c4, 4);
+        }
+#pragma unroll
+        for (int it = 0; it < 3; ++it) {
+            const int i = min(lane + 64 * it, PW * 3 - 1), r = i / 3, c = 40 + (i - r * 3);
+            bv[it] = src[(size_t)r * P + c];
+        }
+#pragma unroll
+        for (int it = 0; it < 7; ++it) {
+            const int i = lane + 64 * it, r = i / 10, c4 = i - r * 10;
+            if (i < PW * 10) *reinterpret_cast<uint32_t*>(&raw[r * RAW_PITCH + 4 * c4]) = wv[it];
+        }
+#pragma unroll
+        for (int it = 0; it < 3; ++it) {
+            const int i = lane + 64 * it, r = i / 3, c = 40 + (i - r * 3);
+            if (i < PW * 3) raw[r * RAW_PITCH + c] = bv[it];
+        }
     }
-    for (int i = lane; i < PW * 3; i += 64) { const int r = i / 3, c = 40 + (i - r * 3); raw[r * RAW_PITCH + c] = src[(size_t)r * P + c]; }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-
     // orientation: m10 = sum u*I, m01 = sum v*I over the disc |u| <= umax[|v|], |v| <= 15
     int m10 = 0, m01 = 0;
     for (int i = lane; i < 31 * 9; i += 64) {            // a lane takes four neighbouring columns (4 .. 39 cover u = -15 .. 15)
@@ -849,19 +863,21 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const uint8_t* __r
     }
     for (int o = 32; o > 0; o >>= 1) { m10 += __shfl_xor(m10, o); m01 += __shfl_xor(m01, o); }
     const float angle = fast_atan2_deg((float)m01, (float)m10);
-
     // separable fixed-point Gaussian {18,34,48,56,48,34,18}/256: rows 0..42 x cols 3..39, then rows 3..39
     // horizontal pass: a lane takes four neighbouring columns of a row -- three dword reads feed 28 taps
     for (int i = lane; i < PW * 10; i += 64) {
         const int r = i / 10, g = i - r * 10;
         const uint32_t* p = reinterpret_cast<const uint32_t*>(&raw[r * RAW_PITCH + 4 * g]);
         const uint32_t w0 = p[0], w1 = p[1], w2 = p[2];
-        unsigned b[12];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { b[k] = (w0 >> (8 * k)) & 0xFF; b[4 + k] = (w1 >> (8 * k)) & 0xFF; b[8 + k] = (w2 >> (8 * k)) & 0xFF; }
+        // output j = taps j .. j + 6 of the 12 loaded bytes: two byte windows (v_alignbyte) and two 4-element dot products
+        // (v_dot4_u32_u8) with the coefficient words {18, 34, 48, 56} and {48, 34, 18, 0} -- integer arithmetic, the same sums
         unsigned o4[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o4[j] = 18 * (b[j] + b[j + 6]) + 34 * (b[j + 1] + b[j + 5]) + 48 * (b[j + 2] + b[j + 4]) + 56 * b[j + 3];
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t a = j == 0 ? w0 : __builtin_amdgcn_alignbyte(w1, w0, j);
+            const uint32_t b = j == 0 ? w1 : __builtin_amdgcn_alignbyte(w2, w1, j);
+            o4[j] = __builtin_amdgcn_udot4(b, 0x00122230u, __builtin_amdgcn_udot4(a, 0x38302212u, 0u, false), false);
+        }
         uint32_t* out = reinterpret_cast<uint32_t*>(&hb[r * HB_PITCH + 4 * g]);
         out[0] = o4[0] | (o4[1] << 16); out[1] = o4[2] | (o4[3] << 16);      // columns 37..39 of the last group are never read
     }
@@ -875,15 +891,23 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const uint8_t* __r
         uint32_t v[7];
 #pragma unroll
         for (int k = 0; k < 7; ++k) v[k] = p[k * (HB_PITCH / 2)];
-        const uint32_t lo = 18u * ((v[0] & 0xFFFF) + (v[6] & 0xFFFF)) + 34u * ((v[1] & 0xFFFF) + (v[5] & 0xFFFF)) + 48u * ((v[2] & 0xFFFF) + (v[4] & 0xFFFF)) + 56u * (v[3] & 0xFFFF);
-        const uint32_t hi = 18u * ((v[0] >> 16) + (v[6] >> 16)) + 34u * ((v[1] >> 16) + (v[5] >> 16)) + 48u * ((v[2] >> 16) + (v[4] >> 16)) + 56u * (v[3] >> 16);
-        bl[r * BW + c] = (uint8_t)((lo + (1u << 15)) >> 16);
-        if (c + 1 < BW) bl[r * BW + c + 1] = (uint8_t)((hi + (1u << 15)) >> 16);
+        // the low and the high halves are two columns: v_perm gathers the same half of two rows, v_dot2_u32_u16 applies a pair of taps
+        uint32_t lo = 1u << 15, hi = 1u << 15;
+        const uint32_t cpair[4] = {18u | (34u << 16), 48u | (56u << 16), 48u | (34u << 16), 18u};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t va = v[2 * k], vb = k < 3 ? v[2 * k + 1] : 0u;
+            const uint32_t pl = __builtin_amdgcn_perm(vb, va, 0x05040100u);      // (lo16 of va) | (lo16 of vb) << 16
+            const uint32_t ph = __builtin_amdgcn_perm(vb, va, 0x07060302u);      // (hi16 of va) | (hi16 of vb) << 16
+            lo = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, pl), __builtin_bit_cast(us2, cpair[k]), lo, false);
+            hi = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, ph), __builtin_bit_cast(us2, cpair[k]), hi, false);
+        }
+        bl[r * BW + c] = (uint8_t)(lo >> 16);
+        if (c + 1 < BW) bl[r * BW + c + 1] = (uint8_t)(hi >> 16);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-
     float sa, ca;
     sincos_deg(angle, &sa, &ca);
     const uint8_t* centre = &bl[18 * BW + 18];
