@@ -1814,17 +1814,15 @@ __global__ __launch_bounds__(PO_T) void k_pose_optimize(double* pose7, const dou
                 }
             }
             po_reduce27(acc, tr, sh);
+            // thread 0 keeps the system it solves (up to ten times per iteration, with growing lambda) in registers: 27 LDS reads here
+            // instead of 42 stores and 42 loads through sh.H / sh.b per solve
+            double Hs[21], bs[6];
             if (tid == 0) {
-                int idx = 0;
-                double maxd = 0;
-                for (int a = 0; a < 6; ++a) {
-                    for (int c = a; c < 6; ++c, ++idx) {
-                        const double hv = sh.red[0][idx];
-                        sh.H[a * 6 + c] = hv; sh.H[c * 6 + a] = hv;
-                    }
-                    sh.b[a] = sh.red[0][21 + a];
-                    maxd = fmax(maxd, fabs(sh.H[a * 7]));
-                }
+#pragma unroll
+                for (int q = 0; q < 21; ++q) Hs[q] = sh.red[0][q];
+#pragma unroll
+                for (int a = 0; a < 6; ++a) bs[a] = sh.red[0][21 + a];
+                const double maxd = fmax(fmax(fmax(fabs(Hs[0]), fabs(Hs[6])), fmax(fabs(Hs[11]), fabs(Hs[15]))), fmax(fabs(Hs[18]), fabs(Hs[20])));
                 if (it == 0) { sh.lambda = 1e-5 * maxd; sh.ni = 2; }
                 sh.current_chi = cur;
             }
@@ -1834,10 +1832,16 @@ __global__ __launch_bounds__(PO_T) void k_pose_optimize(double* pose7, const dou
                     // 6x6 Cholesky + two substitutions, fully unrolled with constant indices: the matrix stays in registers (with
                     // run-time loop bounds and the early exit it lived in scratch memory, ~100 dependent memory round trips per solve)
                     double A[36];
+                    {
+                        int idx = 0;
 #pragma unroll
-                    for (int i = 0; i < 36; ++i) A[i] = sh.H[i];
+                        for (int a = 0; a < 6; ++a)
 #pragma unroll
-                    for (int j = 0; j < 6; ++j) A[j * 7] += sh.lambda;
+                            for (int c = a; c < 6; ++c, ++idx) { A[a * 6 + c] = Hs[idx]; A[c * 6 + a] = Hs[idx]; }
+                    }
+                    const double lam = sh.lambda;
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) A[j * 7] += lam;
                     int ok = 1;
                     double inv[6];                                     // 1 / L_jj: six divisions per solve instead of twenty-seven
 #pragma unroll
@@ -1860,7 +1864,7 @@ __global__ __launch_bounds__(PO_T) void k_pose_optimize(double* pose7, const dou
                         double x[6];
 #pragma unroll
                         for (int i = 0; i < 6; ++i) {
-                            double s2 = sh.b[i];
+                            double s2 = bs[i];
 #pragma unroll
                             for (int k = 0; k < i; ++k) s2 -= A[i * 6 + k] * x[k];
                             x[i] = s2 * inv[i];
@@ -1886,9 +1890,9 @@ __global__ __launch_bounds__(PO_T) void k_pose_optimize(double* pose7, const dou
                 if (tid == 0) {
                     if (!sh.ok) temp = DBL_MAX;
                     double rho = sh.current_chi - temp, scale = 0;
-                    if (sh.ok) for (int j = 0; j < 6; ++j) scale += sh.x[j] * (sh.lambda * sh.x[j] + sh.b[j]);
+                    if (sh.ok) for (int j = 0; j < 6; ++j) scale += sh.x[j] * (sh.lambda * sh.x[j] + bs[j]);
                     scale += 1e-3;
-                    rho /= scale;
+                    rho *= po_rcp(scale);
                     if (rho > 0 && isfinite(temp)) {
                         const double t3 = 2 * rho - 1;
                         double alpha = 1. - t3 * t3 * t3;
