@@ -383,6 +383,10 @@ void lpslam_hip_destroy(lpslam_hip_ctx* c)
     c->pin_free.clear();
     for (auto& pb : c->pin_big) (void)hipHostFree(pb.second);
     c->pin_big.clear();
+    for (auto& g : c->ba_graphs) if (g.second) (void)hipGraphExecDestroy(g.second);
+    c->ba_graphs.clear();
+    for (auto& v : c->ba_view_slot) if (v.second) (void)hipFree(v.second);
+    c->ba_view_slot.clear();
     for (hipStream_t st : c->ba_streams) (void)hipStreamDestroy(st);
     c->ba_streams.clear();
     if (c->h_stage) (void)hipHostFree(c->h_stage);

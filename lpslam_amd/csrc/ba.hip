@@ -1966,7 +1966,6 @@ struct lpslam_hip_ba {
     void* stage = nullptr; size_t stage_cap = 0;   // page-locked staging of the creation inputs, handed back at the first synchronisation
     int robust = 1, points_fixed = 0;
     int pending_iters = -1;                            // >= 0 between optimize_begin and optimize_end
-    std::map<long, hipGraphExec_t> graphs;             // captured first batches by (units, robust, points_fixed); nullptr = seen once
 };
 
 namespace {
@@ -2297,7 +2296,6 @@ void lpslam_hip_ba_destroy(lpslam_hip_ba* b)
 {
     if (!b) return;
     if (b->stream) (void)hipStreamSynchronize(b->stream);
-    for (auto& g : b->graphs) if (g.second) (void)hipGraphExecDestroy(g.second);
     if (b->block) lp_pool_free(b->ctx, b->block, b->block_cap);
     release_stage(b);
     if (b->pin) lp_pin_free(b->ctx, b->pin);
@@ -2358,31 +2356,58 @@ int lpslam_hip_ba_optimize_begin(lpslam_hip_ba* b, int32_t robust, int32_t iters
     LP_HIP(hipSetDevice(b->ctx->cfg.device));
     b->robust = robust;
     // The first batch of a call -- the arming of the control block and `iters` units, the first with its explicit linearisation --
-    // has a fixed launch sequence for a given (robust, iters, points_fixed): the second time a problem asks for the same one it is
-    // captured into a hipGraph and from then on replayed with one hipGraphLaunch (a reused problem: a window that is re-solved).
+    // has a fixed launch sequence for a given (launch extents, robust, iters, points_fixed).  The second time a stream of this context
+    // sees a signature the sequence is captured into a hipGraph whose kernels read their view from the STREAM's slot, and from then
+    // on every problem with that signature on that stream -- the same window solved again, or the next keyframe's new window --
+    // copies its view into the slot and replays the graph with one hipGraphLaunch.  Extents are rounded up (surplus workgroups
+    // exit on the view's own extents, as in a batch), so windows of slightly different size share a graph.
     const int units = iters;
     bool launched = false;
     int rc;
     if (units > 0) {
-        const long key = ((long)units << 2) | ((long)(robust ? 1 : 0) << 1) | (long)(b->points_fixed ? 1 : 0);
-        auto it = b->graphs.find(key);
-        if (it == b->graphs.end()) b->graphs.emplace(key, nullptr);          // seen once: run directly (also sets function attributes)
-        else {
-            if (!it->second) {
-                hipGraph_t graph = nullptr;
-                if (hipStreamBeginCapture(b->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-                    int r2 = begin_optimize(b, robust, iters);
-                    if (r2 == LPSLAM_HIP_OK) r2 = enqueue_batch(single_launch(b), units, true);
-                    const hipError_t e2 = hipStreamEndCapture(b->stream, &graph);
-                    if (r2 == LPSLAM_HIP_OK && e2 == hipSuccess && graph) {
-                        hipGraphExec_t exec = nullptr;
-                        if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) it->second = exec;
-                    }
-                    if (graph) (void)hipGraphDestroy(graph);
+        BaLaunch L = single_launch(b);
+        auto up = [](int x, int m) { return (x + m - 1) / m * m; };
+        L.obs_blocks = up(L.obs_blocks, 8); L.pose_blocks = up(L.pose_blocks, 4); L.point_blocks = up(L.point_blocks, 4); L.part_n = up(L.part_n, 8);
+        const std::array<int, 16> sig = {units, robust ? 1 : 0, b->points_fixed ? 1 : 0, L.obs_blocks, L.pose_blocks, L.point_blocks, L.part_n, L.n_free,
+                                         L.n_blocks, L.dim, L.nb, L.any_small ? 1 : 0, L.any_large ? 1 : 0, 0, 0, 0};
+        lpslam_hip_ctx* c = b->ctx;
+        hipGraphExec_t exec = nullptr;
+        void* slot = nullptr;
+        bool capture = false;
+        {
+            std::lock_guard<std::mutex> lock(c->pool_mutex);
+            auto key = std::make_pair(b->stream, sig);
+            auto it = c->ba_graphs.find(key);
+            if (it == c->ba_graphs.end()) { if (c->ba_graphs.size() < 256) c->ba_graphs.emplace(key, nullptr); }   // seen once: run directly (also sets function attributes); the cache is bounded, never evicted (an entry may be in flight on its stream)
+            else { exec = it->second; capture = exec == nullptr; }
+            auto sl = c->ba_view_slot.find(b->stream);
+            if (sl != c->ba_view_slot.end()) slot = sl->second;
+        }
+        if ((exec || capture) && !slot) {
+            if (hipMalloc(&slot, sizeof(BaView)) == hipSuccess) { std::lock_guard<std::mutex> lock(c->pool_mutex); c->ba_view_slot[b->stream] = slot; }
+            else { slot = nullptr; (void)hipGetLastError(); }
+        }
+        if (capture && slot) {
+            hipGraph_t graph = nullptr;
+            if (hipStreamBeginCapture(b->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                L.d_views = (const BaView*)slot;
+                hipLaunchKernelGGL(k_ba_arm, dim3(1, 1), dim3(64), 0, b->stream, (const BaView*)slot, iters);
+                int r2 = enqueue_batch(L, units, true);
+                const hipError_t e2 = hipStreamEndCapture(b->stream, &graph);
+                if (r2 == LPSLAM_HIP_OK && e2 == hipSuccess && graph) {
+                    if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+                        std::lock_guard<std::mutex> lock(c->pool_mutex);
+                        c->ba_graphs[std::make_pair(b->stream, sig)] = exec;
+                    } else exec = nullptr;
                 }
-                (void)hipGetLastError();
+                if (graph) (void)hipGraphDestroy(graph);
             }
-            if (it->second) { LP_HIP(hipGraphLaunch(it->second, b->stream)); launched = true; }
+            (void)hipGetLastError();
+        }
+        if (exec && slot) {
+            LP_HIP(hipMemcpyAsync(slot, b->d_view, sizeof(BaView), hipMemcpyDeviceToDevice, b->stream));
+            LP_HIP(hipGraphLaunch(exec, b->stream));
+            launched = true;
         }
     }
     if (!launched) {

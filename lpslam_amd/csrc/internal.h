@@ -1,6 +1,8 @@
 // internal.h -- shared host-side definitions of the lpslam HIP library (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <array>
+#include <map>
 #include <mutex>
 #include <vector>
 #include <utility>
@@ -79,6 +81,12 @@ struct lpslam_hip_ctx {
     std::vector<int32_t> h_kp_count; std::vector<uint8_t> h_kp_valid;
     std::vector<void*> pin_free;       // page-locked 8 KB blocks handed to bundle-adjustment objects (lp_pin_alloc / lp_pin_free)
     std::vector<hipStream_t> ba_streams;   // idle high-priority streams of destroyed bundle-adjustment problems (lp_stream_acquire / release)
+    // Captured launch chains of the bundle adjustment, shared by every problem that runs on a stream: the graph's kernels read their
+    // view from a per-stream device slot, the problem's own view is copied there (device to device) in front of the launch.  A
+    // mapping thread makes a NEW problem per keyframe: with per-problem graphs each ran on direct launches (2.8 us per dependent
+    // kernel against 1.7 us inside a graph, 120+ kernels per solve).
+    std::map<hipStream_t, void*> ba_view_slot;
+    std::map<std::pair<hipStream_t, std::array<int, 16>>, hipGraphExec_t> ba_graphs;      // nullptr = signature seen once
     std::vector<std::pair<size_t, void*>> pin_big;   // idle page-locked staging blocks (capacity, block) of lp_pin_big_alloc / free
     uint8_t* h_match = nullptr;        // pinned host staging of the window matchers (queries in, candidate lists out)
     size_t h_match_bytes = 0;
