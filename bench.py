@@ -300,8 +300,24 @@ def cpu_baseline():
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher around it: start the N ranks ourselves, exactly as the driver does
+    (torch.distributed.run, one process per GPU, rendezvous on 127.0.0.1), as a CHILD process -- nothing in this process has
+    touched torch or the GPU yet -- and leave with its exit code.  The ranks print the JSON line (rank 0) to our stdout."""
+    import socket
+    import subprocess
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -316,6 +332,9 @@ def main():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
     device = local_rank % ndev
     backend = os.environ.get("LPSLAM_BENCH_BACKEND", "nccl")      # "nccl" is RCCL on ROCm; "gloo" only for single-GPU rehearsals
+    if world > ndev and backend == "nccl":
+        raise SystemExit("bench.py --gpus %d: only %d HIP device(s) visible (one rank per GPU over RCCL; LPSLAM_BENCH_BACKEND=gloo "
+                         "rehearses several ranks on one GPU)" % (world, ndev))
     if use_dist:
         import torch
         import torch.distributed as dist
@@ -640,7 +659,7 @@ def main():
 
     # ---- N > 1, outside the timed region: BASELINE configs[4], the landmark-partitioned global BA over all ranks with the C++ RCCL
     # driver (lpslam_hip_ba_optimize_partitioned: packed-triangle all-reduce on the problem's stream).  A watchdog prints the timed
-    # line and leaves if the section does not finish: the headline must not depend on it.
+    # line and leaves with a NON-ZERO status if the section does not finish (the measured headline is kept, the run is not green).
     if dist is not None and not args.no_extras and backend == "nccl":
         done_flag = threading.Event()
 
@@ -649,7 +668,7 @@ def main():
                 if rank == 0:
                     out["global_ba_partitioned"] = {"error": "timed out"}
                     print(json.dumps(out), flush=True)
-                os._exit(0)
+                os._exit(3)         # every rank: a hung collective must not read as a green run
         threading.Thread(target=watchdog, daemon=True).start()
         try:
             from lpslam_amd.dist_ba import shard_problem

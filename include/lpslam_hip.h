@@ -208,6 +208,10 @@ int lpslam_hip_ba_optimize(lpslam_hip_ba* ba, int32_t robust, int32_t iters, lps
  * src/Trackers/OpenVSLAMStereoTracker.cpp:293-295).  No other call on `ba` is allowed in between. */
 int lpslam_hip_ba_optimize_begin(lpslam_hip_ba* ba, int32_t robust, int32_t iters);
 int lpslam_hip_ba_optimize_end(lpslam_hip_ba* ba, lpslam_hip_ba_iter_log* log, int32_t* done);
+/* How many solves of this context were started by replaying a captured launch graph (optimize_begin captures the launch chain
+ * of a (stream, launch extents, robust, iters) signature the second time it sees it and replays it from then on, also for OTHER
+ * problems with that signature on that stream).  Measurement / test hook; no reference counterpart. */
+int64_t lpslam_hip_ba_graph_replays(lpslam_hip_ctx* ctx);
 /* Batched solve -- north star: "a batched Levenberg-Marquardt local-BA".  n independent problems (the keyframe windows of
  * several SLAM sessions served by one GPU, [UPSTREAM] mapping_module::run of each session; lpslam reaches it through
  * feed_stereo_frame, src/Trackers/OpenVSLAMStereoTracker.cpp:293-295) are advanced by ONE launch chain: every kernel runs once
@@ -277,6 +281,17 @@ int lpslam_hip_ba_step_end(lpslam_hip_ba* ba, int32_t* accepted, int32_t* iterat
  * rejected trials).  RCCL is bound at run time (dlopen).  Every rank must call with the same robust / iters. */
 int lpslam_hip_ba_optimize_partitioned(lpslam_hip_ba* ba, void* nccl_comm, int32_t robust, int32_t iters,
                                        lpslam_hip_ba_iter_log* log, int32_t* done);
+/* The same driver over the caller's own collective (an MPI / shared-memory host, or a test that runs several ranks on one
+ * device): `allreduce(user, buf, count, op, stream)` must enqueue an IN-PLACE all-reduce of `count` doubles at device address
+ * `buf` on HIP stream `stream` (a hipStream_t), ordered after the work already on that stream, op = LPSLAM_HIP_REDUCE_SUM or
+ * LPSLAM_HIP_REDUCE_MAX, and return 0 on success.  Every rank must produce bit-identical results (a fixed summation order):
+ * the ranks take their accept / reject decisions separately from the reduced values.  lpslam_hip_ba_optimize_partitioned is
+ * this call with ncclAllReduce behind the callback. */
+#define LPSLAM_HIP_REDUCE_SUM 0
+#define LPSLAM_HIP_REDUCE_MAX 2
+typedef int (*lpslam_hip_allreduce_fn)(void* user, void* buf, size_t count, int32_t op, void* stream);
+int lpslam_hip_ba_optimize_partitioned_with(lpslam_hip_ba* ba, lpslam_hip_allreduce_fn allreduce, void* user, int32_t robust,
+                                            int32_t iters, lpslam_hip_ba_iter_log* log, int32_t* done);
 /* Control state after the last optimize / step_end: finished outer iterations, g2o "Terminate", lambda, robust chi2. */
 int lpslam_hip_ba_status(lpslam_hip_ba* ba, int32_t* outer_done, int32_t* stopped, double* lambda, double* chi2);
 

@@ -383,7 +383,7 @@ void lpslam_hip_destroy(lpslam_hip_ctx* c)
     c->pin_free.clear();
     for (auto& pb : c->pin_big) (void)hipHostFree(pb.second);
     c->pin_big.clear();
-    for (auto& g : c->ba_graphs) if (g.second) (void)hipGraphExecDestroy(g.second);
+    for (auto& g : c->ba_graphs) if (g.second && g.second != (hipGraphExec_t)(uintptr_t)1) (void)hipGraphExecDestroy(g.second);      // 1 = the failed-capture sentinel (ba.hip)
     c->ba_graphs.clear();
     for (auto& v : c->ba_view_slot) if (v.second) (void)hipFree(v.second);
     c->ba_view_slot.clear();
@@ -405,7 +405,8 @@ int lpslam_hip_set_mask(lpslam_hip_ctx* c, int32_t eye, const uint8_t* mask, int
 {
     if (!c || eye < 0 || eye > 1) { set_error("invalid mask arguments"); return LPSLAM_HIP_ERR_INVALID; }
     LP_HIP(hipSetDevice(c->cfg.device));
-    LP_HIP(hipStreamSynchronize(c->stream));             // no extraction may be reading the old mask
+    LP_HIP(hipStreamSynchronize(c->stream));             // no extraction may be reading the old mask,
+    if (c->fe_stream) LP_HIP(hipStreamSynchronize(c->fe_stream));      // a prefetched one neither
     if (!mask) {
         if (c->d_mask[eye]) { (void)hipFree(c->d_mask[eye]); c->d_mask[eye] = nullptr; }
         return LPSLAM_HIP_OK;
@@ -586,7 +587,8 @@ int lpslam_hip_set_rectify_map(lpslam_hip_ctx* c, int32_t eye, const float* map_
     }
     if (!c->d_map_xy[eye]) { LP_HIP(hipMalloc((void**)&c->d_map_xy[eye], n * sizeof(short2))); LP_HIP(hipMalloc((void**)&c->d_map_frac[eye], n * sizeof(uint16_t))); }
     if (!c->d_raw) LP_HIP(hipMalloc((void**)&c->d_raw, n));
-    LP_HIP(hipStreamSynchronize(c->stream));              // a remap using the old map may be in flight
+    LP_HIP(hipStreamSynchronize(c->stream));              // a remap using the old map may be in flight,
+    if (c->fe_stream) LP_HIP(hipStreamSynchronize(c->fe_stream));      // on the prefetch stream too
     LP_HIP(hipMemcpy(c->d_map_xy[eye], xy.data(), n * sizeof(short2), hipMemcpyHostToDevice));
     LP_HIP(hipMemcpy(c->d_map_frac[eye], frac.data(), n * sizeof(uint16_t), hipMemcpyHostToDevice));
     return LPSLAM_HIP_OK;

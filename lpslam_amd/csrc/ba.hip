@@ -24,6 +24,7 @@
 #include <algorithm>
 #include <atomic>
 #include <map>
+#include <string>
 #include <dlfcn.h>
 
 #pragma clang fp contract(off)
@@ -2334,6 +2335,7 @@ int lpslam_hip_ba_set_points_fixed(lpslam_hip_ba* b, int32_t points_fixed)
 
 // One unit = one LM trial.  Without rejected steps `iters` units finish the call with a single look at the control block;
 // every rejected trial costs one more unit, enqueued after that look.
+static const hipGraphExec_t kGraphFailed = (hipGraphExec_t)(uintptr_t)1;      // cache sentinel: capture / instantiate failed for this signature
 static int enqueue_batch(const BaLaunch& L, int units, bool first_batch)
 {
     for (int u = 0; u < units; ++u) {
@@ -2379,7 +2381,7 @@ int lpslam_hip_ba_optimize_begin(lpslam_hip_ba* b, int32_t robust, int32_t iters
             auto key = std::make_pair(b->stream, sig);
             auto it = c->ba_graphs.find(key);
             if (it == c->ba_graphs.end()) { if (c->ba_graphs.size() < 256) c->ba_graphs.emplace(key, nullptr); }   // seen once: run directly (also sets function attributes); the cache is bounded, never evicted (an entry may be in flight on its stream)
-            else { exec = it->second; capture = exec == nullptr; }
+            else { exec = it->second; capture = exec == nullptr; if (exec == kGraphFailed) exec = nullptr; }      // a signature whose capture failed once runs direct from then on
             auto sl = c->ba_view_slot.find(b->stream);
             if (sl != c->ba_view_slot.end()) slot = sl->second;
         }
@@ -2402,12 +2404,13 @@ int lpslam_hip_ba_optimize_begin(lpslam_hip_ba* b, int32_t robust, int32_t iters
                 }
                 if (graph) (void)hipGraphDestroy(graph);
             }
+            if (!exec) { std::lock_guard<std::mutex> lock(c->pool_mutex); c->ba_graphs[std::make_pair(b->stream, sig)] = kGraphFailed; }
             (void)hipGetLastError();
         }
         if (exec && slot) {
             LP_HIP(hipMemcpyAsync(slot, b->d_view, sizeof(BaView), hipMemcpyDeviceToDevice, b->stream));
             LP_HIP(hipGraphLaunch(exec, b->stream));
-            launched = true;
+            launched = true; c->ba_graph_replays.fetch_add(1);
         }
     }
     if (!launched) {
@@ -2417,6 +2420,8 @@ int lpslam_hip_ba_optimize_begin(lpslam_hip_ba* b, int32_t robust, int32_t iters
     b->pending_iters = iters;
     return LPSLAM_HIP_OK;
 }
+
+int64_t lpslam_hip_ba_graph_replays(lpslam_hip_ctx* c) { return c ? (int64_t)c->ba_graph_replays.load() : 0; }
 
 int lpslam_hip_ba_optimize_end(lpslam_hip_ba* b, lpslam_hip_ba_iter_log* log, int32_t* done_out)
 {
@@ -2842,21 +2847,34 @@ namespace {
 
 typedef int (*nccl_allreduce_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
 constexpr int kNcclFloat64 = 8, kNcclSum = 0, kNcclMax = 2;      // rccl.h: ncclFloat64, ncclSum, ncclMax
-nccl_allreduce_fn load_nccl_allreduce()
+nccl_allreduce_fn load_nccl_allreduce(std::string* why)
 {
     static std::atomic<nccl_allreduce_fn> cached{nullptr};
     nccl_allreduce_fn f = cached.load();
     if (f) return f;
     // the copy already in the process first (a host that links RCCL, or torch's bundled one), then the system library
-    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
-    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);
-    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-    if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
-    if (!h) return nullptr;
+    void* h = nullptr;
+    const char* last = nullptr;
+    const struct { const char* name; int flags; } tries[] = {{"librccl.so.1", RTLD_NOW | RTLD_NOLOAD}, {"librccl.so", RTLD_NOW | RTLD_NOLOAD},
+        {"librccl.so.1", RTLD_NOW | RTLD_GLOBAL}, {"librccl.so", RTLD_NOW | RTLD_GLOBAL}, {"/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL}};
+    for (const auto& t : tries) {
+        (void)dlerror();
+        h = dlopen(t.name, t.flags);
+        if (h) break;
+        if (!(t.flags & RTLD_NOLOAD)) { const char* e = dlerror(); if (e) { if (why) *why = e; last = e; } }      // read once: dlerror() clears itself
+    }
+    if (!h) { if (why && !last) *why = "not found"; return nullptr; }
+    (void)dlerror();
     f = (nccl_allreduce_fn)dlsym(h, "ncclAllReduce");
+    if (!f) { const char* e = dlerror(); if (why) *why = e ? e : "ncclAllReduce: symbol not found"; return nullptr; }
     cached.store(f);
     return f;
+}
+struct NcclUser { nccl_allreduce_fn fn; void* comm; };
+int nccl_adapter(void* user, void* buf, size_t count, int32_t op, void* stream)
+{
+    const NcclUser* u = (const NcclUser*)user;
+    return u->fn(buf, buf, count, kNcclFloat64, op == LPSLAM_HIP_REDUCE_MAX ? kNcclMax : kNcclSum, u->comm, (hipStream_t)stream);
 }
 
 // lower triangle of the dim x dim reduced system (row r, columns 0..r) <-> packed [r (r + 1) / 2 + c]; the tail of the reduced
@@ -2882,10 +2900,19 @@ __global__ __launch_bounds__(256) void k_ba_pack(const BaView* __restrict__ view
 extern "C" int lpslam_hip_ba_optimize_partitioned(lpslam_hip_ba* b, void* nccl_comm, int32_t robust, int32_t iters, lpslam_hip_ba_iter_log* log, int32_t* done_out)
 {
     if (!b || !nccl_comm) { set_error("null problem / communicator"); return LPSLAM_HIP_ERR_INVALID; }
+    std::string why;
+    NcclUser u{load_nccl_allreduce(&why), nccl_comm};
+    if (!u.fn) { set_error("RCCL (librccl.so) could not be loaded: %s", why.c_str()); return LPSLAM_HIP_ERR_DEVICE; }
+    return lpslam_hip_ba_optimize_partitioned_with(b, nccl_adapter, &u, robust, iters, log, done_out);
+}
+
+extern "C" int lpslam_hip_ba_optimize_partitioned_with(lpslam_hip_ba* b, lpslam_hip_allreduce_fn allreduce_cb, void* user, int32_t robust, int32_t iters,
+                                                       lpslam_hip_ba_iter_log* log, int32_t* done_out)
+{
+    if (!b || !allreduce_cb) { set_error("null problem / all-reduce callback"); return LPSLAM_HIP_ERR_INVALID; }
     if (iters < 0 || iters > MAX_LOG) { set_error("iterations must be in [0,%d]", MAX_LOG); return LPSLAM_HIP_ERR_INVALID; }
     if (b->pending_iters >= 0) { set_error("optimize_begin pending"); return LPSLAM_HIP_ERR_INVALID; }
-    nccl_allreduce_fn allreduce = load_nccl_allreduce();
-    if (!allreduce) { set_error("RCCL (librccl.so) could not be loaded: %s", dlerror() ? dlerror() : "not found"); return LPSLAM_HIP_ERR_DEVICE; }
+    auto allreduce = [&](double* buf, size_t count, int op) -> int { return allreduce_cb(user, buf, count, op, (void*)b->stream); };      // in place, on the problem's stream
     LP_HIP(hipSetDevice(b->ctx->cfg.device));
     hipStream_t s = b->stream;
     const size_t n = (size_t)b->dim_pad, tri = (size_t)b->dim * (b->dim + 1) / 2, packed_n = tri + 3 * n + 8;
@@ -2905,18 +2932,18 @@ extern "C" int lpslam_hip_ba_optimize_partitioned(lpslam_hip_ba* b, void* nccl_c
             if ((r2 = enqueue_linearize(L, 0))) return r2;
             if (first_batch && u == 0) {
                 // lambda_0 = 1e-5 max diag H over ALL ranks' landmarks and the summed pose blocks: needed before the first Schur complement
-                if (allreduce(tail, tail, 3 * n + 8, kNcclFloat64, kNcclSum, nccl_comm, s)) { set_error("ncclAllReduce (diagonals) failed"); return LPSLAM_HIP_ERR_DEVICE; }
-                if (allreduce(b->d_scal + 4, b->d_scal + 4, 1, kNcclFloat64, kNcclMax, nccl_comm, s)) { set_error("ncclAllReduce (max diag) failed"); return LPSLAM_HIP_ERR_DEVICE; }
+                if (allreduce(tail, 3 * n + 8, LPSLAM_HIP_REDUCE_SUM)) { set_error("all-reduce (diagonals) failed"); return LPSLAM_HIP_ERR_DEVICE; }
+                if (allreduce(b->d_scal + 4, 1, LPSLAM_HIP_REDUCE_MAX)) { set_error("all-reduce (max diag) failed"); return LPSLAM_HIP_ERR_DEVICE; }
                 hipLaunchKernelGGL(k_lm_begin, dim3(1, 1), dim3(64), 0, s, L.d_views);
             }
             if ((r2 = enqueue_reduce(L, 0))) return r2;
             if (b->dim > 0) {
                 hipLaunchKernelGGL(k_ba_pack, dim3((b->dim + 255) / 256, b->dim + 1, 1), dim3(256), 0, s, L.d_views, d_packed, 0);
-                if (allreduce(d_packed, d_packed, packed_n, kNcclFloat64, kNcclSum, nccl_comm, s)) { set_error("ncclAllReduce (reduced system) failed"); return LPSLAM_HIP_ERR_DEVICE; }
+                if (allreduce(d_packed, packed_n, LPSLAM_HIP_REDUCE_SUM)) { set_error("all-reduce (reduced system) failed"); return LPSLAM_HIP_ERR_DEVICE; }
                 hipLaunchKernelGGL(k_ba_pack, dim3((b->dim + 255) / 256, b->dim + 1, 1), dim3(256), 0, s, L.d_views, d_packed, 1);
-            } else if (allreduce(tail, tail, 3 * n + 8, kNcclFloat64, kNcclSum, nccl_comm, s)) { set_error("ncclAllReduce failed"); return LPSLAM_HIP_ERR_DEVICE; }
+            } else if (allreduce(tail, 3 * n + 8, LPSLAM_HIP_REDUCE_SUM)) { set_error("all-reduce failed"); return LPSLAM_HIP_ERR_DEVICE; }
             if ((r2 = enqueue_solve(L, 0))) return r2;
-            if (allreduce(b->d_scal + 1, b->d_scal + 1, 2, kNcclFloat64, kNcclSum, nccl_comm, s)) { set_error("ncclAllReduce (trial chi2) failed"); return LPSLAM_HIP_ERR_DEVICE; }
+            if (allreduce(b->d_scal + 1, 2, LPSLAM_HIP_REDUCE_SUM)) { set_error("all-reduce (trial chi2) failed"); return LPSLAM_HIP_ERR_DEVICE; }
             hipLaunchKernelGGL(k_lm_decide, dim3(1, 1), dim3(64), 0, s, L.d_views);
             LP_HIP(hipGetLastError());
         }

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <array>
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <vector>
@@ -87,6 +88,7 @@ struct lpslam_hip_ctx {
     // kernel against 1.7 us inside a graph, 120+ kernels per solve).
     std::map<hipStream_t, void*> ba_view_slot;
     std::map<std::pair<hipStream_t, std::array<int, 16>>, hipGraphExec_t> ba_graphs;      // nullptr = signature seen once
+    std::atomic<long> ba_graph_replays{0};   // hipGraphLaunch calls so far (lpslam_hip_ba_graph_replays: lets a test see that it exercised the replay path)
     std::vector<std::pair<size_t, void*>> pin_big;   // idle page-locked staging blocks (capacity, block) of lp_pin_big_alloc / free
     uint8_t* h_match = nullptr;        // pinned host staging of the window matchers (queries in, candidate lists out)
     size_t h_match_bytes = 0;

@@ -1308,6 +1308,7 @@ void HipVslamTrackerBase::prefetchFrame(CameraQueueEntry const& cam, bool stereo
         (stereo && (cam.image_second->width != cam.image.width || cam.image_second->height != cam.image.height))) return;
     const int slot = slotOf(m_imageTracked);              // the current frame has been counted already
     if (lpslam_hip_prefetch_begin(m_ctx) != LPSLAM_HIP_OK) { logMessage(LpSlamLogLevel_Error, std::string("prefetch_begin: ") + lpslam_hip_last_error()); return; }
+    m_prefetched.issued = true;       // from here on uploads / kernels may be queued on the prefetch stream, even if a later step fails
     const bool ok = frontEnd(cam, stereo, slot);
     if (!ok) logMessage(LpSlamLogLevel_Error, std::string("prefetch front end: ") + lpslam_hip_last_error());
     if (lpslam_hip_prefetch_end(m_ctx) != LPSLAM_HIP_OK || !ok) return;
@@ -1356,12 +1357,14 @@ TrackerBase::ProcessImageResult HipVslamTrackerBase::trackFrame(CameraQueueEntry
         // this frame's front end was started while the previous frame was tracked: the main stream waits for it on the device
         ok = lpslam_hip_prefetch_join(m_ctx) == LPSLAM_HIP_OK;
         ++m_stats.prefetched;
-        m_prefetched.valid = false;
+        m_prefetched.valid = false; m_prefetched.issued = false;
     } else {
-        if (m_prefetched.valid && m_prefetched.slot == cur.slot) {
-            // a prefetch into this slot pair for a frame that did not come next (skipped, queue cleared): let it drain first
+        if (m_prefetched.issued) {
+            // a prefetch for a frame that did not come next (skipped, queue cleared) or one that failed part way: whatever it
+            // queued writes the slot pair and the shared raw-image staging this frame's front end is about to use -- the main
+            // stream waits for it first
             (void)lpslam_hip_prefetch_join(m_ctx);
-            m_prefetched.valid = false;
+            m_prefetched.valid = false; m_prefetched.issued = false;
         }
         ok = frontEnd(cam, stereo, cur.slot);
     }

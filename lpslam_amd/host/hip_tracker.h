@@ -148,7 +148,7 @@ protected:
     // relocalisation / loop candidates once it is no longer needed) and the next one, whose front end is prefetched.
     static int slotOf(uint64_t frame_index) { return (int)(frame_index % 3) * 2; }
     static int previousSlot(int slot) { return ((slot / 2 + 2) % 3) * 2; }
-    struct Prefetched { bool valid = false; const uint8_t* data = nullptr; TimeStamp timestamp{}; int slot = 0; bool stereo = false; } m_prefetched;
+    struct Prefetched { bool valid = false; bool issued = false /* work may sit on the prefetch stream, valid or not */; const uint8_t* data = nullptr; TimeStamp timestamp{}; int slot = 0; bool stereo = false; } m_prefetched;
     void prefetchFrame(CameraQueueEntry const& cam, bool stereo);      // m_slamLock held
     CameraQueueEntry const* m_nextFrame = nullptr;
     void setNextFrame(CameraQueueEntry const* next) override { m_nextFrame = next; }

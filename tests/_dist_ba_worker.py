@@ -18,11 +18,13 @@ def main():
     n_kf, n_pts, n_obs, iters = (int(x) for x in sys.argv[2:6])
     # optional: image size, sequence id and keyframe stride of the generator (defaults: the small cases)
     gw, gh, seq_id, kf_stride = (int(x) for x in sys.argv[6:10]) if len(sys.argv) >= 10 else (1280, 720, 11, 1)
+    # optional: pose noise (rotation, translation) and landmark noise of the generator (the rejected-trial case)
+    noise = dict(pose_noise=(float(sys.argv[10]), float(sys.argv[11])), point_noise=float(sys.argv[12])) if len(sys.argv) >= 13 else {}
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dev = int(os.environ.get("LOCAL_RANK", "0")) % max(hip.device_count(), 1)
     torch.cuda.set_device(dev)
     dist.init_process_group(os.environ.get("LPSLAM_DIST_BACKEND", "gloo"))
-    prob = synth.ba_problem(n_kf, n_pts, n_obs, gw, gh, seq_id=seq_id, kf_stride=kf_stride)
+    prob = synth.ba_problem(n_kf, n_pts, n_obs, gw, gh, seq_id=seq_id, kf_stride=kf_stride, **noise)
     shard = shard_problem(prob, rank, world)
     ctx = hip.Context(640, 480, 500, 1.2, 4, max_images=1, device=dev)
     ba = hip.BundleAdjuster(ctx, shard["poses"], shard["fixed"], shard["points"], hip.ba_obs_array(shard), shard["cam"])

@@ -189,6 +189,47 @@ def test_optimize_in_two_halves_beside_front_end_work(hiplib, oracle, ctx):
         two.optimize_end()
 
 
+def test_launch_graph_is_shared_by_different_problems_on_a_recycled_stream(hiplib, oracle):
+    """The captured launch chain belongs to the STREAM (its kernels read the view from a per-stream slot, launch extents are
+    rounded up): a mapping thread's NEW window replays the graph the previous window captured.  Several distinct problems whose
+    extents round to one signature -- different observation counts, different landmarks, one group with rejected trials -- are
+    created, solved and destroyed in turn (the stream is recycled), and must give, bit for bit, what direct launches give: the
+    reference context keeps every problem alive, so each sits on a stream of its own and runs direct (a signature is captured the
+    second time a stream sees it)."""
+    groups = [[synth.ba_problem(12, 600, n, 640, 480, seq_id=sid) for n, sid in ((4000, 51), (3960, 52), (4060, 53), (4000, 54))],
+              [synth.ba_problem(6, 150, n, 640, 480, seq_id=sid, pose_noise=(0.5, 3.0), point_noise=3.0) for n, sid in ((800, 46), (790, 47), (810, 46), (800, 48))]]
+    iters = 8
+    ref_ctx = hiplib.Context(320, 240, 400, 1.2, 4, max_images=1)
+    g_ctx = hiplib.Context(320, 240, 400, 1.2, 4, max_images=1)
+    rejected = 0
+    for probs in groups:
+        alive, want = [], []
+        for prob in probs:
+            ba = hiplib.BundleAdjuster(ref_ctx, prob["poses"], prob["fixed"], prob["points"], hiplib.ba_obs_array(prob), prob["cam"])
+            alive.append(ba)
+            log = ba.optimize(True, iters)
+            want.append((log, ) + ba.state())
+            rejected += int((log["trials"] > 1).sum())
+        assert ref_ctx.ba_graph_replays() == 0
+        before = g_ctx.ba_graph_replays()
+        for prob, (wlog, wp, wx) in zip(probs, want):
+            ba = hiplib.BundleAdjuster(g_ctx, prob["poses"], prob["fixed"], prob["points"], hiplib.ba_obs_array(prob), prob["cam"])
+            log = ba.optimize(True, iters)
+            gp, gx = ba.state()
+            ba.close()                                      # hands the stream back: the next problem runs on it
+            assert log.tobytes() == wlog.tobytes() and np.array_equal(gp, wp) and np.array_equal(gx, wx)
+        # the first problem runs direct, the second captures (and replays), the others replay
+        assert g_ctx.ba_graph_replays() - before == len(probs) - 1, "the problems of a group were meant to share one launch signature"
+        for ba in alive:
+            ba.close()
+    assert rejected > 0, "one group is meant to contain rejected trials"
+    # one of them against the oracle as well
+    prob = groups[1][0]
+    op, ox, olog = oracle.ba_optimize(prob["poses"], prob["fixed"], prob["points"], oracle.ba_obs(prob), prob["cam"], True, iters)
+    assert np.allclose(want[0][0]["chi2_after"], olog["chi2_after"], rtol=CHI_RTOL) and np.array_equal(want[0][0]["trials"], olog["trials"])
+    ref_ctx.close(); g_ctx.close()
+
+
 def test_set_state_hands_a_prebuilt_window_its_values(hiplib, oracle, ctx):
     """The mapping pipeline: the next window's structure is built (asynchronously) from placeholder values while the previous
     window is being solved, then lpslam_hip_ba_set_state hands it the real poses / landmarks -- bit for bit what creating the
