@@ -89,6 +89,20 @@ int lpslam_hip_timer_read(lpslam_hip_ctx* ctx, int slot, float* ms);
  * capture DMA or another kernel), or upload from host memory (tightly packed rows of `stride` bytes). */
 int lpslam_hip_image_ptr(lpslam_hip_ctx* ctx, int image, void** dev_ptr, int32_t* pitch);
 int lpslam_hip_upload_image(lpslam_hip_ctx* ctx, int image, const uint8_t* host, int32_t stride);
+/* Page-locked frames and asynchronous uploads.  The reference aliases the caller's 8-bit frame (zero copy, the caller keeps it
+ * alive until it is consumed: src/Manager/SlamManager.cpp:1082-1085); the counterpart on a discrete GPU is a frame in page-locked
+ * host memory -- lpslam_hip_host_alloc (what a capture layer fills) or the caller's own buffer pinned in place with
+ * lpslam_hip_host_register -- copied by the DMA engines on a copy stream of the context while kernels of earlier frames run.
+ * lpslam_hip_upload_images_async enqueues the copies of n frames (hosts[i] -> slot first + i; every frame `stride` bytes per row)
+ * and returns at once.  Ordering: the copies start after the work enqueued on the context BEFORE this call (it may still read the
+ * slots); lpslam_hip_extract* / stage_pyramid of a slot wait for its copy on the device.  The frames must stay valid and unchanged
+ * until such an extraction has been synchronised (lpslam_hip_sync, a get_* call).  Frames in pageable memory work but are staged by
+ * the runtime inside the call. */
+int lpslam_hip_host_alloc(lpslam_hip_ctx* ctx, size_t bytes, void** out);
+int lpslam_hip_host_free(lpslam_hip_ctx* ctx, void* p);
+int lpslam_hip_host_register(lpslam_hip_ctx* ctx, void* p, size_t bytes);
+int lpslam_hip_host_unregister(lpslam_hip_ctx* ctx, void* p);
+int lpslam_hip_upload_images_async(lpslam_hip_ctx* ctx, int first, int n, const uint8_t* const* hosts, int32_t stride);
 /* On-device undistort / rectify: replaces the per-frame cv::remap(INTER_LINEAR) of ImageProcessing::Undistort::undistort
  * (reference: src/Utils/ImageProcessing.h:245-249; called for both eyes per frame, src/Trackers/OpenVSLAMStereoTracker.cpp:
  * 198-213).  map_x / map_y are the CV_32FC1 maps of one eye (0 = left, 1 = right), width x height floats, as

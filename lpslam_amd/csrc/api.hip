@@ -262,6 +262,7 @@ static int ctx_alloc(lpslam_hip_ctx* c)
 }
 
 static bool ensure_upload_staging(lpslam_hip_ctx* c, int image);
+int lp_wait_uploads(lpslam_hip_ctx* c, int first, int n);
 
 int lpslam_hip_create(const lpslam_hip_frontend_config* cfg, lpslam_hip_ctx** out)
 {
@@ -371,6 +372,7 @@ void lpslam_hip_destroy(lpslam_hip_ctx* c)
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->fe_stream) (void)hipStreamSynchronize(c->fe_stream);
+    if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     for (auto& blk : c->pool) (void)hipFree(blk.second);
     c->pool.clear();
     void* bufs[] = {c->d_pyr, c->d_band_rows, c->d_rs_pack, c->d_cell_keys, c->d_cell_count, c->d_cand_key, c->d_cand_node,
@@ -393,6 +395,11 @@ void lpslam_hip_destroy(lpslam_hip_ctx* c)
     if (c->h_match) (void)hipHostFree(c->h_match);
     for (uint8_t* b : c->h_upload) if (b) (void)hipHostFree(b);
     for (hipEvent_t e : c->ev_upload) if (e) (void)hipEventDestroy(e);
+    if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
+    if (c->ev_copy_mark) (void)hipEventDestroy(c->ev_copy_mark);
+    for (hipEvent_t e : c->ev_copy_pool) if (e) (void)hipEventDestroy(e);
+    for (auto& a : c->host_allocs) if (a.first) (void)hipHostFree(a.first);
+    c->host_allocs.clear();
     if (c->fe_stream) { (void)hipStreamSynchronize(c->fe_stream); (void)hipStreamDestroy(c->fe_stream); }
     if (c->fe_done) (void)hipEventDestroy(c->fe_done);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -450,6 +457,7 @@ int lpslam_hip_sync(lpslam_hip_ctx* c)
     if (!c) { set_error("null context"); return LPSLAM_HIP_ERR_INVALID; }
     LP_HIP(hipStreamSynchronize(c->stream));
     if (c->fe_stream) LP_HIP(hipStreamSynchronize(c->fe_stream));
+    if (c->copy_stream) LP_HIP(hipStreamSynchronize(c->copy_stream));
     return LPSLAM_HIP_OK;
 }
 
@@ -567,6 +575,99 @@ int lpslam_hip_upload_image(lpslam_hip_ctx* c, int image, const uint8_t* host, i
     return LPSLAM_HIP_OK;
 }
 
+// ---- page-locked frames and asynchronous uploads ----------------------------------------------------------------------------
+// The reference hands the tracker an alias of the caller's 8-bit frame (src/Manager/SlamManager.cpp:1082-1085: zero copy, the
+// caller keeps it alive until consumed).  On a discrete GPU the equivalent is a frame in page-locked host memory -- the capture
+// layer's DMA target, or the caller's own buffer registered in place -- copied by the DMA engines on a stream of its own while the
+// kernels of earlier frames run.
+int lpslam_hip_host_alloc(lpslam_hip_ctx* c, size_t bytes, void** out)
+{
+    if (!c || !out || !bytes) { set_error("invalid host_alloc arguments"); return LPSLAM_HIP_ERR_INVALID; }
+    LP_HIP(hipSetDevice(c->cfg.device));
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); set_error("page-locked allocation of %zu bytes failed", bytes); return LPSLAM_HIP_ERR_DEVICE; }
+    { std::lock_guard<std::mutex> lock(c->pool_mutex); c->host_allocs.emplace_back(p, bytes); }
+    *out = p;
+    return LPSLAM_HIP_OK;
+}
+int lpslam_hip_host_free(lpslam_hip_ctx* c, void* p)
+{
+    if (!c || !p) return LPSLAM_HIP_OK;
+    LP_HIP(hipSetDevice(c->cfg.device));
+    if (c->copy_stream) LP_HIP(hipStreamSynchronize(c->copy_stream));      // no copy may still be reading it
+    {
+        std::lock_guard<std::mutex> lock(c->pool_mutex);
+        auto it = std::find_if(c->host_allocs.begin(), c->host_allocs.end(), [p](const std::pair<void*, size_t>& a) { return a.first == p; });
+        if (it == c->host_allocs.end()) { set_error("host_free: not a block of lpslam_hip_host_alloc of this context"); return LPSLAM_HIP_ERR_INVALID; }
+        c->host_allocs.erase(it);
+    }
+    LP_HIP(hipHostFree(p));
+    return LPSLAM_HIP_OK;
+}
+int lpslam_hip_host_register(lpslam_hip_ctx* c, void* p, size_t bytes)
+{
+    if (!c || !p || !bytes) { set_error("invalid host_register arguments"); return LPSLAM_HIP_ERR_INVALID; }
+    LP_HIP(hipSetDevice(c->cfg.device));
+    if (hipHostRegister(p, bytes, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); set_error("hipHostRegister of %zu bytes failed", bytes); return LPSLAM_HIP_ERR_DEVICE; }
+    return LPSLAM_HIP_OK;
+}
+int lpslam_hip_host_unregister(lpslam_hip_ctx* c, void* p)
+{
+    if (!c || !p) return LPSLAM_HIP_OK;
+    LP_HIP(hipSetDevice(c->cfg.device));
+    if (c->copy_stream) LP_HIP(hipStreamSynchronize(c->copy_stream));
+    LP_HIP(hipHostUnregister(p));
+    return LPSLAM_HIP_OK;
+}
+
+// main stream waits (on the device) for uploads of slots [first, first + n) it has not waited for yet
+int lp_wait_uploads(lpslam_hip_ctx* c, int first, int n)
+{
+    if (c->slot_copy_event.empty()) return LPSLAM_HIP_OK;
+    hipStream_t s = lp_fe_stream(c);
+    hipEvent_t last = nullptr;
+    for (int i = first; i < first + n; ++i) {
+        hipEvent_t e = c->slot_copy_event[(size_t)i];
+        if (!e) continue;
+        c->slot_copy_event[(size_t)i] = nullptr;
+        if (e != last) { LP_HIP(hipStreamWaitEvent(s, e, 0)); last = e; }
+    }
+    return LPSLAM_HIP_OK;
+}
+
+int lpslam_hip_upload_images_async(lpslam_hip_ctx* c, int first, int n, const uint8_t* const* hosts, int32_t stride)
+{
+    if (!c || !hosts) { set_error("null argument"); return LPSLAM_HIP_ERR_INVALID; }
+    if (first < 0 || n < 1 || first + n > c->cfg.max_images) { set_error("image slots [%d,%d) exceed the context capacity %d", first, first + n, c->cfg.max_images); return LPSLAM_HIP_ERR_CAPACITY; }
+    if (stride < c->lt.w[0]) { set_error("bad host image (stride %d < width %d)", stride, c->lt.w[0]); return LPSLAM_HIP_ERR_INVALID; }
+    for (int i = 0; i < n; ++i) if (!hosts[i]) { set_error("null frame %d", i); return LPSLAM_HIP_ERR_INVALID; }
+    LP_HIP(hipSetDevice(c->cfg.device));
+    if (!c->copy_stream) {
+        LP_HIP(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+        LP_HIP(hipEventCreateWithFlags(&c->ev_copy_mark, hipEventDisableTiming));
+        c->ev_copy_pool.assign(16, nullptr);
+        for (auto& e : c->ev_copy_pool) LP_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        c->slot_copy_event.assign((size_t)c->cfg.max_images, nullptr);
+    }
+    // whatever has been enqueued on the context's stream so far may still read these slots: the copies start behind it
+    LP_HIP(hipEventRecord(c->ev_copy_mark, c->stream));
+    LP_HIP(hipStreamWaitEvent(c->copy_stream, c->ev_copy_mark, 0));
+    const size_t w = (size_t)c->lt.w[0], h = (size_t)c->lt.h[0], pitch = (size_t)c->lt.pitch[0];
+    for (int i = 0; i < n; ++i) {
+        uint8_t* dst = c->d_pyr + (size_t)(first + i) * c->image_slab;
+        if (pitch == w && (size_t)stride == w) LP_HIP(hipMemcpyAsync(dst, hosts[i], w * h, hipMemcpyHostToDevice, c->copy_stream));
+        else LP_HIP(hipMemcpy2DAsync(dst, pitch, hosts[i], (size_t)stride, w, h, hipMemcpyHostToDevice, c->copy_stream));
+    }
+    // an event of the ring: one still referenced by a slot (an upload nobody extracted) is waited for by the main stream first
+    hipEvent_t e = c->ev_copy_pool[c->ev_copy_next % c->ev_copy_pool.size()];
+    ++c->ev_copy_next;
+    for (size_t i = 0; i < c->slot_copy_event.size(); ++i)
+        if (c->slot_copy_event[i] == e) { LP_HIP(hipStreamWaitEvent(c->stream, e, 0)); for (auto& x : c->slot_copy_event) if (x == e) x = nullptr; break; }
+    LP_HIP(hipEventRecord(e, c->copy_stream));
+    for (int i = 0; i < n; ++i) c->slot_copy_event[(size_t)(first + i)] = e;
+    return LPSLAM_HIP_OK;
+}
+
 int lpslam_hip_set_rectify_map(lpslam_hip_ctx* c, int32_t eye, const float* map_x, const float* map_y)
 {
     if (!c || eye < 0 || eye > 1 || !map_x || !map_y) { set_error("bad rectify map arguments"); return LPSLAM_HIP_ERR_INVALID; }
@@ -626,7 +727,7 @@ static int check_range(lpslam_hip_ctx* c, int first, int n)
     return LPSLAM_HIP_OK;
 }
 
-int lpslam_hip_stage_pyramid(lpslam_hip_ctx* c, int n) { int rc = check_batch(c, n); return rc ? rc : lp_launch_pyramid(c, 0, n); }
+int lpslam_hip_stage_pyramid(lpslam_hip_ctx* c, int n) { int rc = check_batch(c, n); if (!rc) rc = lp_wait_uploads(c, 0, n); return rc ? rc : lp_launch_pyramid(c, 0, n); }
 int lpslam_hip_stage_fast(lpslam_hip_ctx* c, int n) { int rc = check_batch(c, n); return rc ? rc : lp_launch_fast(c, 0, n); }
 int lpslam_hip_stage_distribute(lpslam_hip_ctx* c, int n) { int rc = check_batch(c, n); return rc ? rc : lp_launch_distribute(c, 0, n); }
 int lpslam_hip_stage_describe(lpslam_hip_ctx* c, int n) { int rc = check_batch(c, n); return rc ? rc : lp_launch_describe(c, 0, n); }
@@ -634,6 +735,7 @@ int lpslam_hip_stage_describe(lpslam_hip_ctx* c, int n) { int rc = check_batch(c
 int lpslam_hip_extract_range(lpslam_hip_ctx* c, int first, int n)
 {
     int rc = check_range(c, first, n); if (rc) return rc;
+    if ((rc = lp_wait_uploads(c, first, n))) return rc;
     if ((rc = lp_launch_pyramid(c, first, n))) return rc;
     if ((rc = lp_launch_fast(c, first, n))) return rc;
     if ((rc = lp_launch_distribute(c, first, n))) return rc;

@@ -20,6 +20,7 @@
 #include "internal.h"
 #include <cmath>
 #include <cstring>
+#include <cstddef>
 #include <cfloat>
 #include <algorithm>
 #include <atomic>
@@ -1965,6 +1966,12 @@ struct lpslam_hip_ba {
     struct Pinned { BaCtl ctl; lpslam_hip_ba_iter_log log[MAX_LOG]; };
     Pinned* pin = nullptr;                         // page-locked: control block and iteration log come back in one round trip
     void* stage = nullptr; size_t stage_cap = 0;   // page-locked staging of the creation inputs, handed back at the first synchronisation
+    // page-locked, device-mapped exchange block [poses in | points in | poses out | points out]: the small per-keyframe transfers
+    // (set_state, get, control block) are done by KERNELS that read / write host memory over PCIe, not by the DMA engines -- a
+    // hipMemcpyAsync of a few KB queues behind whatever the engine is busy with (the 0.9 MB image uploads of the front end:
+    // +0.08 ms per keyframe, measured) and costs a packet round trip of its own even on an idle engine
+    uint8_t* xfer = nullptr; size_t xfer_cap = 0;
+    hipEvent_t xfer_in_read = nullptr; bool xfer_in_pending = false;      // the kernel that reads the "in" half has been enqueued
     int robust = 1, points_fixed = 0;
     int pending_iters = -1;                            // >= 0 between optimize_begin and optimize_end
 };
@@ -2099,6 +2106,39 @@ __global__ __launch_bounds__(64) void k_ba_collect(const BaView* __restrict__ vi
     for (int i = threadIdx.x; i < words; i += 64) dst_l[i] = src_l[i];
 }
 
+// current state -> page-locked host memory (kernel stores over PCIe: no DMA packet, no engine queue)
+__global__ __launch_bounds__(256) void k_ba_state_to_host(const BaView* __restrict__ views, double* poses, double* points)
+{
+    BA_VIEW(v);
+    const int cur = v.ctl->cur;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (poses && i < 7 * v.n_poses) poses[i] = v.poses_buf[cur][i];
+    if (points && i < 3 * v.n_points) points[i] = v.points_buf[cur][i];
+}
+// k_ba_reset with new creation-time values read from page-locked host memory (lpslam_hip_ba_set_state)
+__global__ __launch_bounds__(256) void k_ba_reset_from_host(const BaView* __restrict__ views, const double* poses, const double* points)
+{
+    BA_VIEW(v);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < 7 * v.n_poses) { const double x = poses ? poses[i] : v.poses0[i]; if (poses) const_cast<double*>((const double*)v.poses0)[i] = x; v.poses_buf[0][i] = x; }
+    if (i < 3 * v.n_points) { const double x = points ? points[i] : v.points0[i]; if (points) const_cast<double*>((const double*)v.points0)[i] = x; v.points_buf[0][i] = x; }
+    if (i < v.n_obs) v.o_active[i] = 1;
+    if (i == 0) {
+        BaCtl c{};
+        c.ni = 2; c.need_lin = 1; c.first = 1;
+        *v.ctl = c;
+    }
+}
+
+uint8_t* ensure_xfer(lpslam_hip_ba* b)
+{
+    if (b->xfer) return b->xfer;
+    const size_t bytes = 2 * (7 * (size_t)b->n_poses + 3 * (size_t)std::max(b->n_points, 1)) * sizeof(double);
+    b->xfer = (uint8_t*)lp_pin_big_alloc(b->ctx, bytes, &b->xfer_cap);
+    if (b->xfer && hipEventCreateWithFlags(&b->xfer_in_read, hipEventDisableTiming) != hipSuccess) { lp_pin_big_free(b->ctx, b->xfer, b->xfer_cap); b->xfer = nullptr; }
+    return b->xfer;
+}
+
 void release_stage(lpslam_hip_ba* b)
 {
     if (b->stage) { lp_pin_big_free(b->ctx, b->stage, b->stage_cap); b->stage = nullptr; b->stage_cap = 0; }
@@ -2107,9 +2147,10 @@ void release_stage(lpslam_hip_ba* b)
 int read_ctl(lpslam_hip_ba* b, int log_entries = 0)
 {
     if (b->pin) {
-        LP_HIP(hipMemcpyAsync(&b->pin->ctl, b->d_ctl, sizeof(BaCtl), hipMemcpyDeviceToHost, b->stream));
-        if (log_entries > 0)
-            LP_HIP(hipMemcpyAsync(b->pin->log, b->d_log, (size_t)std::min(log_entries, MAX_LOG) * sizeof(lpslam_hip_ba_iter_log), hipMemcpyDeviceToHost, b->stream));
+        // one small kernel stores the control block and the log entries straight into the page-locked block
+        static_assert(offsetof(lpslam_hip_ba::Pinned, log) == sizeof(BaCtl), "k_ba_collect writes the log right behind the control block");
+        hipLaunchKernelGGL(k_ba_collect, dim3(1, 1), dim3(64), 0, b->stream, b->d_view, (uint8_t*)b->pin, std::max(log_entries, 0));
+        LP_HIP(hipGetLastError());
         LP_HIP(hipStreamSynchronize(b->stream));
         b->h_ctl = b->pin->ctl;
         release_stage(b);
@@ -2300,6 +2341,8 @@ void lpslam_hip_ba_destroy(lpslam_hip_ba* b)
     if (b->block) lp_pool_free(b->ctx, b->block, b->block_cap);
     release_stage(b);
     if (b->pin) lp_pin_free(b->ctx, b->pin);
+    if (b->xfer) lp_pin_big_free(b->ctx, b->xfer, b->xfer_cap);
+    if (b->xfer_in_read) (void)hipEventDestroy(b->xfer_in_read);
     if (b->ev) (void)hipEventDestroy(b->ev);
     if (b->stream) lp_stream_release(b->ctx, b->stream);
     delete b;
@@ -2701,6 +2744,22 @@ int lpslam_hip_ba_set_state(lpslam_hip_ba* b, const double* poses, const double*
 {
     if (!b) { set_error("null problem"); return LPSLAM_HIP_ERR_INVALID; }
     if (b->pending_iters >= 0) { set_error("lpslam_hip_ba_set_state while a solve is in flight"); return LPSLAM_HIP_ERR_INVALID; }
+    if (!poses && !(points && b->n_points)) return lpslam_hip_ba_reset(b);
+    if (uint8_t* x = ensure_xfer(b)) {
+        if (b->xfer_in_pending) { LP_HIP(hipEventSynchronize(b->xfer_in_read)); b->xfer_in_pending = false; }      // the previous set_state's kernel has read its values
+        double* in_poses = (double*)x; double* in_points = in_poses + 7 * (size_t)b->n_poses;
+        if (poses) memcpy(in_poses, poses, 7 * (size_t)b->n_poses * sizeof(double));
+        if (points && b->n_points) memcpy(in_points, points, 3 * (size_t)b->n_points * sizeof(double));
+        b->h_ctl = BaCtl{};
+        b->h_ctl.ni = 2; b->h_ctl.need_lin = 1; b->h_ctl.first = 1;
+        const long n_max = std::max<long>(std::max<long>(7L * b->n_poses, 3L * b->n_points), b->n_obs);
+        hipLaunchKernelGGL(k_ba_reset_from_host, dim3((unsigned)((n_max + 255) / 256), 1), dim3(256), 0, b->stream, b->d_view,
+                           poses ? in_poses : nullptr, (points && b->n_points) ? in_points : nullptr);
+        LP_HIP(hipGetLastError());
+        LP_HIP(hipEventRecord(b->xfer_in_read, b->stream));
+        b->xfer_in_pending = true;
+        return LPSLAM_HIP_OK;
+    }
     if (poses) LP_HIP(hipMemcpyAsync((void*)b->h_view.poses0, poses, 7 * (size_t)b->n_poses * sizeof(double), hipMemcpyHostToDevice, b->stream));
     if (points && b->n_points) LP_HIP(hipMemcpyAsync((void*)b->h_view.points0, points, 3 * (size_t)b->n_points * sizeof(double), hipMemcpyHostToDevice, b->stream));
     return lpslam_hip_ba_reset(b);
@@ -2709,6 +2768,21 @@ int lpslam_hip_ba_set_state(lpslam_hip_ba* b, const double* poses, const double*
 int lpslam_hip_ba_get(lpslam_hip_ba* b, double* poses, double* points)
 {
     if (!b) { set_error("null problem"); return LPSLAM_HIP_ERR_INVALID; }
+    if (uint8_t* x = ensure_xfer(b)) {
+        double* out_poses = (double*)x + 7 * (size_t)b->n_poses + 3 * (size_t)std::max(b->n_points, 1);
+        double* out_points = out_poses + 7 * (size_t)b->n_poses;
+        const bool want_points = points && b->n_points;
+        const long n_max = std::max<long>(poses ? 7L * b->n_poses : 0, want_points ? 3L * b->n_points : 0);
+        if (n_max > 0) {
+            hipLaunchKernelGGL(k_ba_state_to_host, dim3((unsigned)((n_max + 255) / 256), 1), dim3(256), 0, b->stream, b->d_view, poses ? out_poses : nullptr, want_points ? out_points : nullptr);
+            LP_HIP(hipGetLastError());
+        }
+        LP_HIP(hipStreamSynchronize(b->stream));
+        release_stage(b);
+        if (poses) memcpy(poses, out_poses, 7 * (size_t)b->n_poses * sizeof(double));
+        if (want_points) memcpy(points, out_points, 3 * (size_t)b->n_points * sizeof(double));
+        return LPSLAM_HIP_OK;
+    }
     const int cur = b->h_ctl.cur;
     if (poses) LP_HIP(hipMemcpyAsync(poses, b->d_poses[cur], 7 * (size_t)b->n_poses * sizeof(double), hipMemcpyDeviceToHost, b->stream));
     if (points && b->n_points) LP_HIP(hipMemcpyAsync(points, b->d_points[cur], 3 * (size_t)b->n_points * sizeof(double), hipMemcpyDeviceToHost, b->stream));

@@ -63,6 +63,14 @@ struct lpslam_hip_ctx {
     hipStream_t stream = nullptr;      // the stream every entry point enqueues on
     hipStream_t fe_stream = nullptr;   // prefetch: front end of the NEXT frame beside the tracking of this one (lp_fe_stream)
     hipEvent_t fe_done = nullptr;
+    // asynchronous uploads from the caller's page-locked frames (lpslam_hip_upload_images_async): a copy stream of its own, one event
+    // per call that the main stream waits for before it first reads one of the call's slots
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_copy_mark = nullptr;           // main stream -> copy stream: work enqueued before the call may still read the slots
+    std::vector<hipEvent_t> ev_copy_pool;        // events of the calls (ring)
+    size_t ev_copy_next = 0;
+    std::vector<hipEvent_t> slot_copy_event;     // per image slot: event of the upload the main stream has not yet waited for (or nullptr)
+    std::vector<std::pair<void*, size_t>> host_allocs;   // lpslam_hip_host_alloc blocks (freed with the context if the caller forgets)
     std::vector<uint8_t*> h_upload;    // per image slot: page-locked staging of the last uploaded frame (uploads are asynchronous)
     std::vector<hipEvent_t> ev_upload; // ... and the event after its copy
     size_t image_slab = 0;             // bytes of one image's pyramid (all levels, pitched)

@@ -28,7 +28,7 @@ BA_LOG_DTYPE = np.dtype([("chi2_before", "<f8"), ("chi2_after", "<f8"), ("lambda
 SYMBOLS = [
     "lpslam_hip_last_error", "lpslam_hip_device_count", "lpslam_hip_create", "lpslam_hip_destroy",
     "lpslam_hip_stream", "lpslam_hip_sync", "lpslam_hip_timer_begin", "lpslam_hip_timer_end", "lpslam_hip_timer_read", "lpslam_hip_level_info", "lpslam_hip_max_keypoints_per_image",
-    "lpslam_hip_image_ptr", "lpslam_hip_upload_image", "lpslam_hip_set_rectify_map", "lpslam_hip_set_mask", "lpslam_hip_upload_raw_image", "lpslam_hip_remap_staged", "lpslam_hip_extract", "lpslam_hip_extract_range", "lpslam_hip_stage_pyramid",
+    "lpslam_hip_image_ptr", "lpslam_hip_upload_image", "lpslam_hip_host_alloc", "lpslam_hip_host_free", "lpslam_hip_host_register", "lpslam_hip_host_unregister", "lpslam_hip_upload_images_async", "lpslam_hip_set_rectify_map", "lpslam_hip_set_mask", "lpslam_hip_upload_raw_image", "lpslam_hip_remap_staged", "lpslam_hip_extract", "lpslam_hip_extract_range", "lpslam_hip_stage_pyramid",
     "lpslam_hip_stage_fast", "lpslam_hip_stage_distribute", "lpslam_hip_stage_describe",
     "lpslam_hip_keypoint_count", "lpslam_hip_get_keypoints", "lpslam_hip_get_frame", "lpslam_hip_get_pyramid_level",
     "lpslam_hip_get_candidates", "lpslam_hip_keypoint_buffers", "lpslam_hip_match_bf", "lpslam_hip_get_bf_knn2",
@@ -161,6 +161,44 @@ class Context:
         assert arr.shape == (self.cfg.height, self.cfg.width), arr.shape
         _check(self.lib.lpslam_hip_upload_image(self.h, image, _p(arr), arr.shape[1]))
         self.sync()      # host array may be freed by the caller
+
+    def host_frame(self, arr=None):
+        """a page-locked (height, width) uint8 frame owned by the context (lpslam_hip_host_alloc), optionally filled from `arr`"""
+        hgt, wid = self.cfg.height, self.cfg.width
+        ptr = C.c_void_p()
+        f = self.lib.lpslam_hip_host_alloc
+        f.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
+        _check(f(self.h, hgt * wid, C.byref(ptr)))
+        buf = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(hgt, wid))
+        if arr is not None:
+            buf[...] = arr
+        return buf
+
+    def host_free(self, frame):
+        f = self.lib.lpslam_hip_host_free
+        f.argtypes = [C.c_void_p, C.c_void_p]
+        _check(f(self.h, frame.ctypes.data))
+
+    def host_register(self, arr):
+        f = self.lib.lpslam_hip_host_register
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        _check(f(self.h, arr.ctypes.data, arr.nbytes))
+
+    def host_unregister(self, arr):
+        f = self.lib.lpslam_hip_host_unregister
+        f.argtypes = [C.c_void_p, C.c_void_p]
+        _check(f(self.h, arr.ctypes.data))
+
+    def upload_async(self, first, frames):
+        """lpslam_hip_upload_images_async: frames[i] -> slot first + i on the copy stream; returns at once (the frames must stay
+        alive and unchanged until an extraction of the slots has been synchronised)"""
+        n = len(frames)
+        ptrs = (C.c_void_p * n)(*[fr.ctypes.data for fr in frames])
+        for fr in frames:
+            assert fr.dtype == np.uint8 and fr.shape == (self.cfg.height, self.cfg.width) and fr.strides[1] == 1, (fr.dtype, fr.shape)
+        f = self.lib.lpslam_hip_upload_images_async
+        f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int32]
+        _check(f(self.h, int(first), n, ptrs, int(frames[0].strides[0])))
 
     def set_rectify_map(self, eye, map_x, map_y):
         mx = np.ascontiguousarray(map_x, np.float32); my = np.ascontiguousarray(map_y, np.float32)

@@ -202,3 +202,41 @@ def test_prefetch_stream_gives_the_same_frame(hiplib, oracle):
             assert np.array_equal(a, b)
     with pytest.raises(hiplib.LpslamHipError):       # end without begin
         hiplib._check(hiplib.load().lpslam_hip_prefetch_end(ctx.h))
+
+
+def test_async_uploads_from_page_locked_frames(hiplib, oracle):
+    """lpslam_hip_upload_images_async: frames in page-locked memory of the context (host_alloc), in the caller's own array pinned in
+    place (host_register), with a row stride, and in pageable memory all reach their slots; an extraction waits for its slots'
+    copies on the device, and a copy into a slot starts only after the work enqueued before it (which may still read the slot)."""
+    w, h, kpts, levels = 640, 480, 800, 6
+    imgs = [synth.random_image(w, h, seed=70 + i) for i in range(6)]
+    p = oracle.params(kpts, 1.2, levels)
+    want = [oracle.extract(im, p, True)[:2] for im in imgs]
+    ctx = hiplib.Context(w, h, kpts, 1.2, levels, max_images=6)
+    owned = [ctx.host_frame(imgs[0]), ctx.host_frame(imgs[1])]
+    mine = imgs[2].copy(); ctx.host_register(mine)
+    wide = np.zeros((h, w + 64), np.uint8); wide[:, :w] = imgs[3]; ctx.host_register(wide)
+    ctx.upload_async(0, owned)
+    ctx.upload_async(2, [mine])
+    ctx.upload_async(3, [wide[:, :w]])                       # stride w + 64
+    ctx.upload_async(4, [imgs[4], imgs[5]])                  # pageable: staged by the runtime
+    ctx.extract_range(0, 6)
+    for i in range(6):
+        gk, gd = ctx.keypoints(i)
+        _assert_same_keypoints(want[i][0], want[i][1], gk, gd)
+    # re-use of a slot: the extraction enqueued BEFORE the new upload still sees the old frame, the one after it the new frame
+    for rounds in range(3):
+        a, b = owned
+        ctx.upload_async(0, [a]); ctx.extract_range(0, 1)
+        ctx.upload_async(0, [b])                             # ordered behind the extraction above
+        ka, da = ctx.keypoints(0)                            # synchronises: results of the FIRST extraction
+        _assert_same_keypoints(want[0][0], want[0][1], ka, da)
+        ctx.extract_range(0, 1)
+        kb, db = ctx.keypoints(0)
+        _assert_same_keypoints(want[1][0], want[1][1], kb, db)
+    ctx.sync()
+    ctx.host_unregister(mine); ctx.host_unregister(wide)
+    ctx.host_free(owned[0])
+    with pytest.raises(hiplib.LpslamHipError):
+        ctx.host_free(mine)                                  # not a block of host_alloc
+    ctx.close()                                              # frees owned[1] with the context
