@@ -79,7 +79,7 @@ struct BaView {                       // one problem, resident in device memory 
     int point_blocks;                 // ceil(n_points / 256): k_ba_point_sum
     int part_n;                       // max(ceil(n_points / 64), 1): k_ba_backsub landmark blocks = entries of `part`
     int n_blocks;                     // pose-block pairs (n_free (n_free + 1) / 2)
-    int pad0;
+    int land_blocks;                  // ceil(n_points / LAND_B): landmark-major linearisation beside a trial (land_lin_body)
     GPTR(double) poses_buf[2]; GPTR(double) points_buf[2];
     GPTR(const double) poses; GPTR(const double) points;        // set by the kernel prologue (state being evaluated)
     GPTR(const double) poses0; GPTR(const double) points0;      // state given at creation (reset)
@@ -89,7 +89,12 @@ struct BaView {                       // one problem, resident in device memory 
     GPTR(uint8_t) o_active;
     GPTR(const int) pt_start; GPTR(const int) pt_obs; GPTR(const int) ps_start; GPTR(const int) o_orig;
     GPTR(double) W; GPTR(double) Hll; GPTR(double) bl; GPTR(double) Hpp; GPTR(double) hl_obs; GPTR(double) partial;   // linearisation set in use (ba_lin_set)
-    GPTR(double) W2[2]; GPTR(double) hl2[2]; GPTR(double) partial2[2]; GPTR(double) partial_trial;   // both sets (indexed like the state buffers) + trial chi2 partials
+    // Both linearisation sets (indexed like the state buffers), each as TWO blocks whose sub-arrays sit at offsets that follow from
+    // the problem's sizes (SetOff): set_z = [partial | b_p, diag H_pp, chi2] (zero-initialised), set_d = [H_ll | b_l | H_pp | W | hl].
+    // One pointer pair per set instead of seven keeps the by-value view small enough to live in scalar registers (at 672 bytes the
+    // compiler kept a copy in scratch memory and every member access became a scratch load: trial launch 14 -> 41 us).
+    GPTR(double) set_z[2]; GPTR(double) set_d[2]; GPTR(double) partial_trial;     // + trial chi2 partials
+    GPTR(const double) csr;            // observation constants once more in CSR (landmark-major) order [u | v | ur | w | pose, point (int)]: CsrOff
     GPTR(double) S; GPTR(double) rhs; GPTR(double) bp; GPTR(double) hppdiag; GPTR(double) chi_cur;   // reduced buffer sections (all-reduced when partitioned)
     GPTR(double) bp_loc; GPTR(double) hppdiag_loc; GPTR(double) chi_loc;                    // this rank's own sums (equal to the above on one GPU)
     GPTR(double) Minv;                                                            // L^-T row blocks (dim_pad x dim_pad)
@@ -123,21 +128,42 @@ __device__ __forceinline__ BaFlags ba_flags(const BaCtl* c)
     f.stopped = c->stopped; f.cur_launch = c->cur_launch; f.spec = c->spec;
     return f;
 }
+// Member [idx] of a two-element pointer array of the view, by ARITHMETIC on its two constant-index members: a select between two
+// members (or a dynamic index) can end up as an indexed load from a copy of the whole view in scratch memory -- it did when the
+// view grew (552 bytes of scratch per lane, every member access a scratch load, trial launch 14 -> 41 us).
+template <class P> __device__ __forceinline__ P sel2(P a0, P a1, int idx) { return a0 + (ptrdiff_t)idx * (a1 - a0); }
 // selects the evaluated state: the accepted one (trial = 0) or the trial one
 __device__ __forceinline__ void ba_select(BaView& v, int trial)
 {
     const int s = v.ctl->cur ^ trial;
-    v.poses = s ? v.poses_buf[1] : v.poses_buf[0]; v.points = s ? v.points_buf[1] : v.points_buf[0];
+    v.poses = sel2(v.poses_buf[0], v.poses_buf[1], s); v.points = sel2(v.points_buf[0], v.points_buf[1], s);
 }
 // state buffer and linearisation set by explicit index (kernels that must not follow a `cur` flipping under them)
 __device__ __forceinline__ void ba_select_idx(BaView& v, int idx)
 {
-    v.poses = idx ? v.poses_buf[1] : v.poses_buf[0]; v.points = idx ? v.points_buf[1] : v.points_buf[0];
+    v.poses = sel2(v.poses_buf[0], v.poses_buf[1], idx); v.points = sel2(v.points_buf[0], v.points_buf[1], idx);
 }
+// offsets (in doubles, multiples of 32 = 256 bytes) of the sub-arrays of a linearisation set's two blocks and of the CSR copies
+struct SetOff { size_t loc, z_total, bl, Hpp, W, hl, d_total; };
+__host__ __device__ inline size_t al32(size_t x) { return (x + 31) & ~(size_t)31; }
+__host__ __device__ inline SetOff set_offsets(int n_poses, int n_points, int n_obs, int n_free, int dim_pad)
+{
+    const size_t np = (size_t)n_poses, npt = (size_t)(n_points > 1 ? n_points : 1), no = (size_t)(n_obs > 1 ? n_obs : 1), nf = (size_t)(n_free > 1 ? n_free : 1);
+    SetOff o;
+    o.loc = al32(np * SPLIT * (PV + 1)); o.z_total = o.loc + al32(2 * (size_t)dim_pad + 8);
+    o.bl = al32(6 * npt); o.Hpp = o.bl + al32(3 * npt); o.W = o.Hpp + al32(36 * nf); o.hl = o.W + al32(18 * no); o.d_total = o.hl + al32(9 * no);
+    return o;
+}
+__host__ __device__ inline size_t csr_stride(int n_obs) { return al32((size_t)(n_obs > 1 ? n_obs : 1)); }
 __device__ __forceinline__ void ba_lin_set(BaView& v, int idx)
 {
-    // selects, not array indexing: a dynamically indexed member array would push the by-value view out of the scalar registers
-    v.W = idx ? v.W2[1] : v.W2[0]; v.hl_obs = idx ? v.hl2[1] : v.hl2[0]; v.partial = idx ? v.partial2[1] : v.partial2[0];
+    GPTR(double) z = sel2(v.set_z[0], v.set_z[1], idx);
+    GPTR(double) d = sel2(v.set_d[0], v.set_d[1], idx);
+    const SetOff o = set_offsets(v.n_poses, v.n_points, v.n_obs, v.n_free, v.dim_pad);
+    v.partial = z;
+    GPTR(double) loc = z + o.loc;
+    v.bp_loc = loc; v.hppdiag_loc = loc + v.dim_pad; v.chi_loc = loc + 2 * v.dim_pad;
+    v.Hll = d; v.bl = d + o.bl; v.Hpp = d + o.Hpp; v.W = d + o.W; v.hl_obs = d + o.hl;
 }
 
 // Reciprocal and reciprocal square root for the per-observation arithmetic: v_rcp_f64 / v_rsq_f64 (2^-24, measured) plus ONE cubic
@@ -166,20 +192,25 @@ __device__ __forceinline__ void quat_to_rot(const double* q, double* R)
     R[6] = 2 * (x * z - w * y);     R[7] = 2 * (y * z + w * x);     R[8] = 1 - 2 * (x * x + y * y);
 }
 
-// residual e = obs - projection, camera-frame point pc; returns 2 (mono) or 3 (stereo)
-__device__ __forceinline__ int ba_residual(const BaView& v, int k, const double* R, const double* t, const double* X,
-                                           double* e, double* pc)
+// residual e = obs - projection, camera-frame point pc; returns 2 (mono) or 3 (stereo).  The camera travels BY VALUE through these
+// helpers: handed on as a reference into the by-value view, the compiler kept the whole view in scratch memory (552 bytes per lane).
+__device__ __forceinline__ int ba_residual_vals(const BaCam cam, double ou, double ov, double ur, const double* R, const double* t, const double* X,
+                                                double* e, double* pc)
 {
 #pragma unroll
     for (int i = 0; i < 3; ++i) pc[i] = R[i * 3] * X[0] + R[i * 3 + 1] * X[1] + R[i * 3 + 2] * X[2] + t[i];
     const double iz = fast_rcp(pc[2]);
-    const double u = v.cam.fx * pc[0] * iz + v.cam.cx;
-    const double vv = v.cam.fy * pc[1] * iz + v.cam.cy;
-    e[0] = v.o_u[k] - u; e[1] = v.o_v[k] - vv;
-    const double ur = v.o_ur[k];
+    const double u = cam.fx * pc[0] * iz + cam.cx;
+    const double vv = cam.fy * pc[1] * iz + cam.cy;
+    e[0] = ou - u; e[1] = ov - vv;
     if (ur < 0) { e[2] = 0; return 2; }
-    e[2] = ur - (u - v.cam.fxb * iz);
+    e[2] = ur - (u - cam.fxb * iz);
     return 3;
+}
+__device__ __forceinline__ int ba_residual(const BaView& v, int k, const double* R, const double* t, const double* X,
+                                           double* e, double* pc)
+{
+    return ba_residual_vals(v.cam, v.o_u[k], v.o_v[k], v.o_ur[k], R, t, X, e, pc);
 }
 
 __device__ __forceinline__ void huber(double e2, double delta, double* rho0, double* rho1)
@@ -190,7 +221,7 @@ __device__ __forceinline__ void huber(double e2, double delta, double* rho0, dou
 }
 
 // Jacobians of the reprojection error: A (D x 3, landmark), B (D x 6, pose, rotation first)
-__device__ __forceinline__ void ba_jacobians(const BaCam& c, const double* R, const double* pc, int D, double A[3][3], double B[3][6])
+__device__ __forceinline__ void ba_jacobians(const BaCam c, const double* R, const double* pc, int D, double A[3][3], double B[3][6])
 {
     const double x = pc[0], y = pc[1], iz = fast_rcp(pc[2]), iz2 = iz * iz;
 #pragma unroll
@@ -214,15 +245,18 @@ __device__ __forceinline__ void ba_jacobians(const BaCam& c, const double* R, co
 }
 
 // weight (rho1 * inv_sigma2) and robustified chi2 of one observation
-__device__ __forceinline__ double ba_weight(const BaView& v, int k, int D, const double* e, int robust, double* rho0)
+__device__ __forceinline__ double ba_weight_vals(const BaCam cam, double om, int D, const double* e, int robust, double* rho0)
 {
-    const double om = v.o_w[k];
     const double chi = om * (e[0] * e[0] + e[1] * e[1] + (D == 3 ? e[2] * e[2] : 0.0));
-    const double delta = D == 3 ? v.cam.hub_stereo : v.cam.hub_mono;
+    const double delta = D == 3 ? cam.hub_stereo : cam.hub_mono;
     double w = om;
     *rho0 = chi;
     if (robust && delta > 0) { double r1; huber(chi, delta, rho0, &r1); w *= r1; }
     return w;
+}
+__device__ __forceinline__ double ba_weight(const BaView& v, int k, int D, const double* e, int robust, double* rho0)
+{
+    return ba_weight_vals(v.cam, v.o_w[k], D, e, robust, rho0);
 }
 
 
@@ -237,19 +271,20 @@ __device__ __forceinline__ double ba_weight(const BaView& v, int k, int D, const
 // consumer is the workgroup whose add came last).  An acquire-release pair here would cost a buffer_wbl2 + buffer_inv, ~3.5 us.
 __device__ __forceinline__ void st_sc1(double* p, double x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ double ld_sc1(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ bool ba_last_block_sc1(BaCtl* c, int total)
+__device__ __forceinline__ bool ba_last_block_sc1(int* ticket, int total)
 {
     __shared__ int s_last;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wavefront drains its own stores (a barrier alone does not)
     __syncthreads();
     if (threadIdx.x == 0) {
-        const int t = __hip_atomic_fetch_add(&c->ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int t = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_last = (t == total - 1);
-        if (s_last) c->ticket = 0;
+        if (s_last) *ticket = 0;
     }
     __syncthreads();
     return s_last != 0;
 }
+__device__ __forceinline__ bool ba_last_block_sc1(BaCtl* c, int total) { return ba_last_block_sc1(&c->ticket, total); }
 // The general form (any plain stores before it are visible to the last workgroup's plain loads after it): agent-scope
 // acquire-release on the ticket, i.e. an L2 write-back and an L1 invalidate per workgroup.  Used where the handed-over data
 // are not confined to a few words (sim3.inl).
@@ -348,11 +383,98 @@ __device__ __forceinline__ void obs_lin_body(BaView& v, int bid, int robust, int
         }
 }
 
+// ---- linearisation, observation side, LANDMARK-MAJOR: what obs_lin_body + the landmark sums of k_ba_point_sum compute, in one pass.
+//      A workgroup owns LAND_B consecutive landmarks and walks their observations in CSR order (= the order k_ba_point_sum adds
+//      them in), 256 at a time: thread = observation -> W (to the observation's storage slot) and its 9 shares of (H_ll, b_l) into
+//      LDS; then thread (landmark l, component c) adds the shares of its landmark's segment of the chunk in ascending order -- the
+//      same sums, bit for bit, without the 72 bytes per observation going to memory and coming back in a launch of their own.
+//      The observation constants are read from their CSR-ordered copies (c_*), coalesced.
+constexpr int LAND_B = 16;
+__device__ __forceinline__ void land_lin_body(BaView& v, int bid, int robust, int points_fixed, int set)
+{
+    ba_select_idx(v, set); ba_lin_set(v, set);
+    __shared__ double sh[256 * 9];
+    __shared__ int s_start[LAND_B + 1];
+    const int tid = threadIdx.x;
+    const int j0 = bid * LAND_B, j1 = min(j0 + LAND_B, v.n_points);
+    if (tid <= LAND_B) s_start[tid] = v.pt_start[min(j0 + tid, j1)];
+    __syncthreads();
+    const int s_lo = s_start[0], s_hi = s_start[j1 - j0];
+    const size_t cs = csr_stride(v.n_obs);
+    GPTR(const double) c_u = v.csr; GPTR(const double) c_v = v.csr + cs; GPTR(const double) c_ur = v.csr + 2 * cs; GPTR(const double) c_w = v.csr + 3 * cs;
+    GPTR(const int) c_pose = (GPTR(const int))(v.csr + 4 * cs); GPTR(const int) c_point = c_pose + cs;
+    const int l = tid >> 3, c = tid & 7;                   // the sums: landmark j0 + l, components c (and 8 with c == 0)
+    const int seg_lo = s_start[min(l, j1 - j0)], seg_hi = s_start[min(l + 1, j1 - j0)];
+    double acc = 0, acc8 = 0;
+    for (int chunk = s_lo; chunk < s_hi; chunk += 256) {
+        const int s = chunk + tid;
+        double hs[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if (s < s_hi) {
+            const int k = v.pt_obs[s];
+            const int p = c_pose[s];
+            const int slot = v.pose_slot[p];
+            double* Wk = v.W + 18 * (size_t)k;
+            if (!v.o_active[k] || points_fixed) {
+#pragma unroll
+                for (int i = 0; i < 18; ++i) Wk[i] = 0.0;
+            } else {
+                const int j = c_point[s];
+                const double X[3] = {v.points[3 * j], v.points[3 * j + 1], v.points[3 * j + 2]};
+                double R[9], e[3], pc[3], A[3][3], B[3][6], rho0;
+                quat_to_rot(v.poses + 7 * p, R);
+                const int D = ba_residual_vals(v.cam, c_u[s], c_v[s], c_ur[s], R, v.poses + 7 * p + 4, X, e, pc);
+                ba_jacobians(v.cam, R, pc, D, A, B);
+                const double w = ba_weight_vals(v.cam, c_w[s], D, e, robust, &rho0);
+                int idx = 0;
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+#pragma unroll
+                    for (int cc = a; cc < 3; ++cc) {
+                        double s2 = 0;
+#pragma unroll
+                        for (int r = 0; r < 3; ++r) s2 += A[r][a] * w * A[r][cc];
+                        hs[idx++] = s2;
+                    }
+                    double s3 = 0;
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) s3 += A[r][a] * (-w * e[r]);
+                    hs[6 + a] = s3;
+                }
+#pragma unroll
+                for (int a = 0; a < 6; ++a)
+#pragma unroll
+                    for (int cc = 0; cc < 3; ++cc) {
+                        double s2 = 0;
+                        if (slot >= 0) {
+#pragma unroll
+                            for (int r = 0; r < 3; ++r) s2 += B[r][a] * w * A[r][cc];
+                        }
+                        Wk[a * 3 + cc] = s2;
+                    }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 9; ++i) sh[tid * 9 + i] = hs[i];
+        __syncthreads();
+        const int a0 = max(seg_lo, chunk), a1 = min(seg_hi, chunk + 256);
+        for (int t = a0; t < a1; ++t) {
+            acc += sh[(t - chunk) * 9 + c];
+            if (c == 0) acc8 += sh[(t - chunk) * 9 + 8];
+        }
+        __syncthreads();
+    }
+    const int j = j0 + l;
+    if (j < j1) {
+        if (c < 6) v.Hll[6 * (size_t)j + c] = acc; else v.bl[3 * (size_t)j + (c - 6)] = acc;
+        if (c == 0) v.bl[3 * (size_t)j + 2] = acc8;
+    }
+}
+
 // ---- linearisation 2/2: H_ll, b_l per landmark = fixed-order sum over its observations; block maxima of diag H_ll.  The
 //      One extra workgroup combines the pose partials of the linearisation (pose_combine_body, defined below); the workgroup
 //      that finishes last starts the outer iteration.
-__device__ void pose_combine_body(BaView& v, int mode, int part_n, int fused);
-__device__ void lm_begin(BaView& v, double max_diag_pp, double max_diag_ll, double chi_cur);
+__device__ __forceinline__ void pose_combine_body(BaView& v, int mode, int part_n, int fused);
+__device__ __forceinline__ void lm_begin(BaView& v, double max_diag_pp, double max_diag_ll, double chi_cur);
 __global__ __launch_bounds__(256) void k_ba_point_sum(const BaView* __restrict__ views, int fused)
 {
     BA_VIEW(v);
@@ -488,7 +610,7 @@ __device__ __forceinline__ void pose_part_body(BaView& v, int bid, int robust, i
 
 // ---- g2o's lambda control (one thread) ----------------------------------------------------------------------------------
 // start of an outer iteration / after a linearisation: lambda_0 = tau * max diag(H) on the first one, chi2 bookkeeping
-__device__ void lm_begin(BaView& v, double max_diag_pp, double max_diag_ll, double chi_cur)
+__device__ __forceinline__ void lm_begin(BaView& v, double max_diag_pp, double max_diag_ll, double chi_cur)
 {
     BaCtl c = *v.ctl;                                      // one batch of loads, one batch of stores
     if (c.first) {
@@ -504,7 +626,7 @@ __device__ void lm_begin(BaView& v, double max_diag_pp, double max_diag_ll, doub
     *v.ctl = c;
 }
 // after a trial: rho, accept / reject, lambda update, iteration and termination bookkeeping
-__device__ void lm_decide(BaView& v, double temp_chi, double chol_failed, double scale_l, double scale_p, bool spec_ran = false)
+__device__ __forceinline__ void lm_decide(BaView& v, double temp_chi, double chol_failed, double scale_l, double scale_p, bool spec_ran = false)
 {
     BaCtl c = *v.ctl;
     if (chol_failed != 0.0) temp_chi = DBL_MAX;            // factorisation failed
@@ -538,7 +660,11 @@ __device__ void lm_decide(BaView& v, double temp_chi, double chol_failed, double
         }
         c.outer_done++;
         c.qmax = 0;
-        c.need_lin = 1;
+        if (accepted && spec_ran) {
+            // the trial launch linearised the accepted state completely (W, landmark and pose sums, combined by its last workgroup):
+            // the next outer iteration starts at the Schur complement.  What lm_begin would do: chi2 bookkeeping of a fresh iteration
+            c.need_lin = 0; c.spec = 0; c.chi_before = c.current_chi;
+        } else c.need_lin = 1;
         if (terminate) c.stopped = 1;
     } else {
         c.need_lin = 0;
@@ -550,7 +676,7 @@ __device__ void lm_decide(BaView& v, double temp_chi, double chol_failed, double
 //      the partials, see ba_last_block) combines the SPLIT partials in order, totals
 //      chi2, reduces the landmark-side block partials in v.part (max diag H_ll / scale terms) and, in the single-GPU
 //      ("fused") solve, runs the lambda control.  The partitioned solve runs k_lm_begin / k_lm_decide after its all-reduce.
-__device__ void pose_combine_body(BaView& v, int mode, int part_n, int fused)
+__device__ __forceinline__ void pose_combine_body(BaView& v, int mode, int part_n, int fused)
 {
     __shared__ double s_val[3];            // chi2, landmark-side term (max diag H_ll / scale term), max diag H_pp
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -651,20 +777,26 @@ __global__ __launch_bounds__(256) void k_ba_lin(const BaView* __restrict__ views
 __global__ __launch_bounds__(256) void k_ba_trial(const BaView* __restrict__ views, int robust, int fused, int points_fixed, int spec)
 {
     BA_VIEW(v);
-    BA_VIEW_HEAD("s"(v.part_n), "s"(v.pose_blocks), "s"(v.obs_blocks), "s"(v.ctl));
-    const int part_n = v.part_n, trial_blocks = v.pose_blocks, obs_blocks = v.obs_blocks;
-    if ((int)blockIdx.x >= trial_blocks + (spec ? obs_blocks + trial_blocks : 0)) return;
+    BA_VIEW_HEAD("s"(v.part_n), "s"(v.pose_blocks), "s"(v.land_blocks), "s"(v.ctl));
+    const int part_n = v.part_n, trial_blocks = v.pose_blocks, land_blocks = v.land_blocks;
+    if ((int)blockIdx.x >= trial_blocks + (spec ? land_blocks + trial_blocks : 0)) return;
     const BaFlags fl = ba_flags(v.ctl);
     if (fl.idle()) return;
     const int idx = fl.cur_launch ^ 1;
+    int combine = -1;
     if ((int)blockIdx.x >= trial_blocks) {
+        // the complete linearisation of the trial state into the other set: observations landmark-major with the landmark sums
+        // (land_lin_body), the pose side per keyframe and slice (its partial sums are added up by their readers in k_ba_schur)
         const int bid = (int)blockIdx.x - trial_blocks;
-        if (bid < obs_blocks) obs_lin_body(v, bid, robust, points_fixed, idx);
-        else pose_part_body(v, bid - obs_blocks, robust, 0, idx);
-        return;
+        if (bid < land_blocks) land_lin_body(v, bid, robust, points_fixed, idx);
+        else pose_part_body(v, bid - land_blocks, robust, 0, idx);
+        return;                          // read by the next launch only (k_ba_schur adds the pose partials up itself): no hand-over
+    } else {
+        pose_part_body(v, blockIdx.x, robust, 1, idx);
+        if (ba_last_block_sc1(v.ctl, trial_blocks)) combine = 1;
     }
-    pose_part_body(v, blockIdx.x, robust, 1, idx);
-    if (ba_last_block_sc1(v.ctl, trial_blocks)) pose_combine_body(v, 1, part_n, fused ? (spec ? 2 : 1) : 0);
+    if (combine < 0) return;
+    pose_combine_body(v, 1, part_n, fused ? (spec ? 2 : 1) : 0);
 }
 
 // partitioned solve: lambda control on the all-reduced quantities
@@ -750,11 +882,16 @@ __global__ __launch_bounds__(64) void k_ba_schur(const BaView* __restrict__ view
         for (int q = 0; q < 6; ++q) r6[q] = wave_sum(r6[q]);
         if (lane < 6) {
             double val = 0;
+            // b_p and diag H_pp of keyframe i: the SPLIT partial sums of the set's pose-side linearisation, added in order (what
+            // pose_combine_body does after an explicit linearisation; a linearisation made beside a trial has no combine of its own)
+            const int qd = 6 * lane - lane * (lane - 1) / 2;      // (lane, lane) in the row-major upper triangle
+            double bsum = 0, dsum = 0;
+            for (int sp = 0; sp < SPLIT; ++sp) { const double* pr = v.partial + ((size_t)i * SPLIT + sp) * PV; bsum += pr[21 + lane]; dsum += pr[qd]; }
 #pragma unroll
-            for (int q = 0; q < 6; ++q) if (q == lane) val = v.bp_loc[6 * i + q] - r6[q];
+            for (int q = 0; q < 6; ++q) if (q == lane) val = bsum - r6[q];
             v.rhs[6 * i + lane] = val;
             if (fused) v.S[(size_t)v.dim * n + 6 * i + lane] = val;
-            else { v.bp[6 * i + lane] = v.bp_loc[6 * i + lane]; v.hppdiag[6 * i + lane] = v.hppdiag_loc[6 * i + lane]; }   // fresh partials for the all-reduce
+            v.bp[6 * i + lane] = bsum; v.hppdiag[6 * i + lane] = dsum;      // the solved set's sums (partitioned: fresh partials for the all-reduce)
         }
         if (!fused && i == 0 && lane == 62) *v.chi_cur = *v.chi_loc;
         if (fused && i == 0 && lane == 63) { v.S[(size_t)v.dim * n + v.dim] = 1e200; v.scal[5] = 0.0; }
@@ -829,7 +966,11 @@ __global__ __launch_bounds__(64) void k_ba_schur(const BaView* __restrict__ view
     if (lane >= 36) return;
     const int r = lane / 6, c = lane - r * 6;
     if (i == k) {
-        double val = v.Hpp[36 * (size_t)i + lane] - sum;
+        const int ra = min(r, c), rc = max(r, c);
+        const int q = 6 * ra - ra * (ra - 1) / 2 + (rc - ra);      // H_pp(r, c) in the row-major upper triangle of the pose partials
+        double hpp = 0;
+        for (int sp = 0; sp < SPLIT; ++sp) hpp += v.partial[((size_t)i * SPLIT + sp) * PV + q];
+        double val = hpp - sum;
         if (fused && r == c) val += lambda;
         v.S[(size_t)(6 * i + r) * n + 6 * i + c] = val;
     } else {
@@ -1438,8 +1579,8 @@ __global__ __launch_bounds__(256) void k_ba_backsub(const BaView* __restrict__ v
     if (fl.idle()) return;
     const double lambda = fl.lambda;
     ba_select_idx(v, fl.cur); ba_lin_set(v, fl.cur);
-    GPTR(double) poses_out = fl.cur ? v.poses_buf[0] : v.poses_buf[1];
-    GPTR(double) points_out = fl.cur ? v.points_buf[0] : v.points_buf[1];
+    GPTR(double) poses_out = sel2(v.poses_buf[0], v.poses_buf[1], fl.cur ^ 1);
+    GPTR(double) points_out = sel2(v.points_buf[0], v.points_buf[1], fl.cur ^ 1);
     if ((int)blockIdx.x == point_blocks) {
         // trial poses = exp(x_p) * poses; scal[3] = sum x_p (lambda x_p + b_p) (fixed order, one wavefront)
         if (threadIdx.x == 0) v.ctl->cur_launch = fl.cur;          // what the trial launch reads while the decision flips `cur`
@@ -1981,7 +2122,7 @@ namespace {
 // what a launch chain needs to know: the view array, how many problems it holds and the launch extents (maxima over them)
 struct BaLaunch {
     const BaView* d_views = nullptr; int count = 0; hipStream_t s = nullptr;
-    int obs_blocks = 0, pose_blocks = 0, point_blocks = 0, part_n = 0, n_free = 0, n_blocks = 0, dim = 0, nb = 0;
+    int obs_blocks = 0, pose_blocks = 0, point_blocks = 0, part_n = 0, n_free = 0, n_blocks = 0, dim = 0, nb = 0, land_blocks = 0;
     int robust = 1, points_fixed = 0;
     bool any_small = false, any_large = false;          // systems for k_chol_wg / for the panel-pair chain
     // profiled run (lpslam_hip_ba_optimize_profiled): an event after every launch, tagged with the kernel it closes
@@ -1998,7 +2139,7 @@ struct BaLaunch {
     {
         const BaView& v = b->h_view;
         obs_blocks = std::max(obs_blocks, v.obs_blocks); pose_blocks = std::max(pose_blocks, v.pose_blocks);
-        point_blocks = std::max(point_blocks, v.point_blocks); part_n = std::max(part_n, v.part_n);
+        point_blocks = std::max(point_blocks, v.point_blocks); part_n = std::max(part_n, v.part_n); land_blocks = std::max(land_blocks, v.land_blocks);
         n_free = std::max(n_free, v.n_free); n_blocks = std::max(n_blocks, v.n_blocks); dim = std::max(dim, v.dim);
         nb = std::max(nb, v.dim_pad / NB);
         if (v.dim > 0) { if (cw_fits(v.dim)) any_small = true; else any_large = true; }
@@ -2016,8 +2157,10 @@ BaLaunch single_launch(lpslam_hip_ba* b)
 // linearisation of the accepted state (skipped on the device when the previous trial was rejected)
 int enqueue_linearize(const BaLaunch& L, int fused, bool explicit_lin = true)
 {
-    // fused solve: only the first unit of an optimize() call linearises here, every later state is linearised beside its trial
-    if (explicit_lin) { hipLaunchKernelGGL(k_ba_lin, dim3(L.obs_blocks + L.pose_blocks, L.count), dim3(256), 0, L.s, L.d_views, L.robust, L.points_fixed); L.mark(LPSLAM_HIP_BA_K_LIN); }
+    // fused solve: only the first unit of an optimize() call linearises here; every later state is linearised COMPLETELY beside its
+    // trial (k_ba_trial: observation side with the landmark sums, pose side, combine), so later units start at the Schur complement
+    if (!explicit_lin) return LPSLAM_HIP_OK;
+    hipLaunchKernelGGL(k_ba_lin, dim3(L.obs_blocks + L.pose_blocks, L.count), dim3(256), 0, L.s, L.d_views, L.robust, L.points_fixed); L.mark(LPSLAM_HIP_BA_K_LIN);
     hipLaunchKernelGGL(k_ba_point_sum, dim3(L.point_blocks + 1, L.count), dim3(256), 0, L.s, L.d_views, fused);      // + the workgroup that combines the pose partials
     L.mark(LPSLAM_HIP_BA_K_POINT_SUM);
     LP_HIP(hipGetLastError());
@@ -2059,7 +2202,7 @@ int enqueue_solve(const BaLaunch& L, int fused)
     {
         // fused solve: the trial launch also linearises the trial state on speculation (observation side + pose side)
         const int spec = fused ? 1 : 0;
-        hipLaunchKernelGGL(k_ba_trial, dim3(L.pose_blocks + (spec ? L.obs_blocks + L.pose_blocks : 0), L.count), dim3(256), 0, s, L.d_views, L.robust, fused, L.points_fixed, spec);
+        hipLaunchKernelGGL(k_ba_trial, dim3(L.pose_blocks + (spec ? L.land_blocks + L.pose_blocks : 0), L.count), dim3(256), 0, s, L.d_views, L.robust, fused, L.points_fixed, spec);
         L.mark(LPSLAM_HIP_BA_K_TRIAL);
     }
     LP_HIP(hipGetLastError());
@@ -2112,8 +2255,8 @@ __global__ __launch_bounds__(256) void k_ba_state_to_host(const BaView* __restri
     BA_VIEW(v);
     const int cur = v.ctl->cur;
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (poses && i < 7 * v.n_poses) poses[i] = v.poses_buf[cur][i];
-    if (points && i < 3 * v.n_points) points[i] = v.points_buf[cur][i];
+    if (poses && i < 7 * v.n_poses) poses[i] = sel2(v.poses_buf[0], v.poses_buf[1], cur)[i];
+    if (points && i < 3 * v.n_points) points[i] = sel2(v.points_buf[0], v.points_buf[1], cur)[i];
 }
 // k_ba_reset with new creation-time values read from page-locked host memory (lpslam_hip_ba_set_state)
 __global__ __launch_bounds__(256) void k_ba_reset_from_host(const BaView* __restrict__ views, const double* poses, const double* points)
@@ -2228,8 +2371,9 @@ int lpslam_hip_ba_create(lpslam_hip_ctx* ctx, const double* poses, const uint8_t
     const size_t staged_bytes = cv.off;
     const size_t z_begin = cv.off;
     const size_t o_A = cv.take(np * npt * 4), o_ptcount = cv.take(npt * 4);
-    const size_t o_partial0 = cv.take(np * SPLIT * (PV + 1) * 8), o_partial1 = cv.take(np * SPLIT * (PV + 1) * 8);
-    const size_t o_red = cv.take((size_t)b->red_n * 8), o_minv = cv.take(n * n * 8), o_xp = cv.take(n * 8), o_loc = cv.take((2 * n + 8) * 8);
+    const SetOff so = set_offsets(n_poses, n_points, n_obs, b->n_free, b->dim_pad);
+    const size_t o_setz0 = cv.take(so.z_total * 8), o_setz1 = cv.take(so.z_total * 8);
+    const size_t o_red = cv.take((size_t)b->red_n * 8), o_minv = cv.take(n * n * 8), o_xp = cv.take(n * 8);
     const size_t o_scal = cv.take(8 * 8), o_ctl = cv.take(sizeof(BaCtl)), o_ticket = cv.take(nblk * 4), o_log = cv.take(MAX_LOG * sizeof(lpslam_hip_ba_iter_log));
     const size_t z_end = cv.off;
     const size_t o_R = cv.take(np * npt * 4), o_pscount = cv.take(np * 4), o_slotof = cv.take(no * 4);
@@ -2237,8 +2381,8 @@ int lpslam_hip_ba_create(lpslam_hip_ctx* ctx, const double* poses, const uint8_t
     const size_t o_opose = cv.take(no * 4), o_opoint = cv.take(no * 4), o_u = cv.take(no * 8), o_v = cv.take(no * 8), o_ur = cv.take(no * 8), o_w = cv.take(no * 8);
     const size_t o_active = cv.take(no), o_actin = cv.take(no);
     const size_t o_poses_a = cv.take(7 * np * 8), o_poses_b = cv.take(7 * np * 8), o_points_a = cv.take(3 * npt * 8), o_points_b = cv.take(3 * npt * 8);
-    const size_t o_W0 = cv.take(18 * no * 8), o_W1 = cv.take(18 * no * 8), o_hl0 = cv.take(9 * no * 8), o_hl1 = cv.take(9 * no * 8);
-    const size_t o_Hll = cv.take(6 * npt * 8), o_bl = cv.take(3 * npt * 8), o_Hpp = cv.take(36 * nfree * 8), o_ptrial = cv.take(np * SPLIT * 8);
+    const size_t o_setd0 = cv.take(so.d_total * 8), o_setd1 = cv.take(so.d_total * 8), o_ptrial = cv.take(np * SPLIT * 8);
+    const size_t cst = csr_stride(n_obs), o_csr = cv.take(5 * cst * 8);          // u, v, ur, w (doubles) + pose, point (ints)
     const size_t o_ldiag = cv.take(n * NB * 8), o_lsub = cv.take(n * NB * 8), o_chipose = cv.take(np * 8), o_part = cv.take((size_t)part_n * 8);
     const size_t o_chiobs = cv.take(no * 8), o_depth = cv.take(no);
     const size_t o_blk_count = cv.take(nblk * 4), o_blk_start = cv.take((nblk + 1) * 4), o_blk_part = cv.take(nblk * 4 * 36 * 8);
@@ -2255,7 +2399,7 @@ int lpslam_hip_ba_create(lpslam_hip_ctx* ctx, const double* poses, const uint8_t
     v = BaView{};
     v.n_poses = n_poses; v.n_points = n_points; v.n_obs = n_obs; v.n_free = b->n_free; v.dim = b->dim; v.dim_pad = b->dim_pad;
     v.obs_blocks = (n_obs + 255) / 256; v.pose_blocks = (n_poses * SPLIT + 3) / 4; v.point_blocks = (n_points + 255) / 256; v.part_n = part_n;
-    v.n_blocks = b->n_blocks;
+    v.n_blocks = b->n_blocks; v.land_blocks = (n_points + LAND_B - 1) / LAND_B;
     b->d_poses[0] = (double*)(base + o_poses_a); b->d_poses[1] = (double*)(base + o_poses_b);
     b->d_points[0] = (double*)(base + o_points_a); b->d_points[1] = (double*)(base + o_points_b);
     for (int s2 = 0; s2 < 2; ++s2) { vset(v.poses_buf[s2], b->d_poses[s2]); vset(v.points_buf[s2], b->d_points[s2]); }
@@ -2267,14 +2411,17 @@ int lpslam_hip_ba_create(lpslam_hip_ctx* ctx, const double* poses, const uint8_t
     vset(v.o_active, b->d_o_active);
     vset(v.pt_start, (const int*)(base + o_pt_start)); vset(v.pt_obs, (const int*)(base + o_pt_obs)); vset(v.ps_start, (const int*)(base + o_ps_start));
     vset(v.o_orig, (const int*)b->d_o_orig);
-    vset(v.Hll, (double*)(base + o_Hll)); vset(v.bl, (double*)(base + o_bl)); vset(v.Hpp, (double*)(base + o_Hpp));
-    vset(v.W2[0], (double*)(base + o_W0)); vset(v.W2[1], (double*)(base + o_W1)); vset(v.hl2[0], (double*)(base + o_hl0)); vset(v.hl2[1], (double*)(base + o_hl1));
-    vset(v.partial2[0], (double*)(base + o_partial0)); vset(v.partial2[1], (double*)(base + o_partial1));
-    v.W = v.W2[0]; v.hl_obs = v.hl2[0]; v.partial = v.partial2[0];
+    vset(v.set_z[0], (double*)(base + o_setz0)); vset(v.set_z[1], (double*)(base + o_setz1));
+    vset(v.set_d[0], (double*)(base + o_setd0)); vset(v.set_d[1], (double*)(base + o_setd1));
+    vset(v.csr, (const double*)(base + o_csr));
+    {   // the selected set's pointers (kernels set them with ba_lin_set before use): set 0
+        double* z = (double*)(base + o_setz0); double* d = (double*)(base + o_setd0);
+        vset(v.partial, z); vset(v.bp_loc, z + so.loc); vset(v.hppdiag_loc, z + so.loc + n); vset(v.chi_loc, z + so.loc + 2 * n);
+        vset(v.Hll, d); vset(v.bl, d + so.bl); vset(v.Hpp, d + so.Hpp); vset(v.W, d + so.W); vset(v.hl_obs, d + so.hl);
+    }
     vset(v.partial_trial, (double*)(base + o_ptrial));
     b->d_red = (double*)(base + o_red);
     vset(v.S, b->d_red); vset(v.rhs, b->d_red + n * n); vset(v.bp, b->d_red + n * n + n); vset(v.hppdiag, b->d_red + n * n + 2 * n); vset(v.chi_cur, b->d_red + n * n + 3 * n);
-    { double* loc = (double*)(base + o_loc); vset(v.bp_loc, loc); vset(v.hppdiag_loc, loc + n); vset(v.chi_loc, loc + 2 * n); }
     vset(v.Minv, (double*)(base + o_minv)); vset(v.Ldiag, (double*)(base + o_ldiag)); vset(v.Lsub, (double*)(base + o_lsub));
     b->d_scal = (double*)(base + o_scal);
     vset(v.xp, (double*)(base + o_xp)); vset(v.chi_pose, (double*)(base + o_chipose)); vset(v.part, (double*)(base + o_part)); vset(v.scal, b->d_scal);
@@ -2313,6 +2460,9 @@ int lpslam_hip_ba_create(lpslam_hip_ctx* ctx, const double* poses, const uint8_t
                            b->d_o_orig, (int*)(base + o_opose), (int*)(base + o_opoint), (double*)(base + o_u), (double*)(base + o_v), (double*)(base + o_ur),
                            (double*)(base + o_w), b->d_o_active, b->d_act_in);
         hipLaunchKernelGGL(k_bs_ptfill, dim3((n_points + 255) / 256), dim3(256), 0, s, A, R, n_poses, n_points, ps_start, pt_start, (int*)(base + o_pt_obs));
+        hipLaunchKernelGGL(k_bs_csrcopy, dim3((n_obs + 255) / 256), dim3(256), 0, s, n_obs, (const int*)(base + o_pt_obs), (const int*)(base + o_opose), (const int*)(base + o_opoint),
+                           (const double*)(base + o_u), (const double*)(base + o_v), (const double*)(base + o_ur), (const double*)(base + o_w),
+                           (int*)(base + o_csr + 4 * cst * 8), (int*)(base + o_csr + 4 * cst * 8) + cst, (double*)(base + o_csr), (double*)(base + o_csr) + cst, (double*)(base + o_csr) + 2 * cst, (double*)(base + o_csr) + 3 * cst);
     }
     if (b->n_blocks) {
         hipLaunchKernelGGL(k_bs_paircount, dim3((b->n_blocks + 3) / 4), dim3(256), 0, s, A, n_points, b->n_free, b->n_blocks, (const int*)(base + o_free), ps_start,
@@ -2412,9 +2562,9 @@ int lpslam_hip_ba_optimize_begin(lpslam_hip_ba* b, int32_t robust, int32_t iters
     if (units > 0) {
         BaLaunch L = single_launch(b);
         auto up = [](int x, int m) { return (x + m - 1) / m * m; };
-        L.obs_blocks = up(L.obs_blocks, 8); L.pose_blocks = up(L.pose_blocks, 4); L.point_blocks = up(L.point_blocks, 4); L.part_n = up(L.part_n, 8);
+        L.obs_blocks = up(L.obs_blocks, 8); L.pose_blocks = up(L.pose_blocks, 4); L.point_blocks = up(L.point_blocks, 4); L.part_n = up(L.part_n, 8); L.land_blocks = up(L.land_blocks, 8);
         const std::array<int, 16> sig = {units, robust ? 1 : 0, b->points_fixed ? 1 : 0, L.obs_blocks, L.pose_blocks, L.point_blocks, L.part_n, L.n_free,
-                                         L.n_blocks, L.dim, L.nb, L.any_small ? 1 : 0, L.any_large ? 1 : 0, 0, 0, 0};
+                                         L.n_blocks, L.dim, L.nb, L.any_small ? 1 : 0, L.any_large ? 1 : 0, L.land_blocks, 0, 0};
         lpslam_hip_ctx* c = b->ctx;
         hipGraphExec_t exec = nullptr;
         void* slot = nullptr;
