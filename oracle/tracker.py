@@ -6,8 +6,10 @@ duplicate fusion and the local bundle adjustment -- with the keyframe, covisibil
 lpslam_amd/host/hip_tracker.cpp (the product's tracker), function by function, so that a sequence tracked by the HIP path can be
 compared pose by pose (tests/test_track_gpu.py, tests/golden/g10_track.npz; tolerance 1e-4 rad / 1e-3 m per frame).
 Covered: stereo initialisation, motion-model tracking with the brute-force fallback, local-map tracking, the keyframe decision,
-keyframe insertion with new landmarks, match::fuse with landmark merging, the covisibility-window local BA solved inline
-(asyncMapping = false) and its outlier removal.  Not covered (and switched off in the comparison): loop closing, relocalisation.
+keyframe insertion with new landmarks, match::fuse with landmark merging, the covisibility-window local BA -- solved inline
+(asyncMapping = false) or entering the map right before the next keyframe (asyncMapping = true, the product's default) -- and its
+outlier removal, loss of tracking (the map is kept), relocalisation against the nearest keyframes and the new map segment after
+time_to_relocalize.  Not covered (and switched off in the comparison): loop closing.
 
 Arithmetic follows the C++ operation by operation where a rounding could change a discrete decision (float32 query fields,
 float32 level scales); everything else is float64 as there.
@@ -79,10 +81,10 @@ class Frame:
 
 
 class StereoTracker:
-    """Mirror of HipStereoTracker with asyncMapping = false, loopClosure = false; frames fed one by one with feed(left, right)."""
+    """Mirror of HipStereoTracker (loopClosure = false), asyncMapping false or true; frames fed one by one with feed(left, right[, t])."""
 
     def __init__(self, width, height, cam, max_keypoints=1000, num_levels=4, scale_factor=1.2, keyframe_interval=4, local_window=10,
-                 nav_identity=True):
+                 nav_identity=True, async_mapping=False, time_to_relocalize=3.0):
         self.w, self.h, self.cam = width, height, dict(cam)
         self.p = O.params(max_keypoints, scale_factor, num_levels)
         self.scales = O.scale_factors(self.p)[0]                   # float32, as lpslam_hip_level_info returns them
@@ -97,7 +99,17 @@ class StereoTracker:
         self.velocity = None
         self.tracking = False
         self.n_frames = 0
-        self.stats = dict(motion_tracked=0, bf_tracked=0, local_map_joined=0, keyframes=0, fused_added=0, fused_merged=0, local_ba=0)
+        self.stats = dict(motion_tracked=0, bf_tracked=0, local_map_joined=0, keyframes=0, fused_added=0, fused_merged=0, local_ba=0,
+                          lost=0, relocalised=0, reinitialised=0)
+        # asyncMapping (the product's default): the local BA of keyframe c is prepared from the map as it is right after c's insertion,
+        # solved beside the tracking of the following frames, and ENTERS the map right before the next keyframe is inserted
+        # (HipVslamTrackerBase::startMapping / finishMapping) -- the order of events does not depend on how long the solve takes
+        self.async_mapping = async_mapping
+        self.pending = None
+        self.time_to_relocalize = float(time_to_relocalize)
+        self.lost = False
+        self.lost_since = 0.0
+        self.last_good = Pose()
 
     # ---- helpers ---------------------------------------------------------------------------------------------------------------
     def resolve(self, i):
@@ -407,8 +419,30 @@ class StereoTracker:
 
     # ---- local bundle adjustment, inline (prepareMapping / prepareBundle / solveMapping / applyMapping) ------------------------
     def local_ba(self, c):
-        if len(self.kfs) < 2:
+        """prepareMapping + solveMapping + applyMapping in one go (asyncMapping = false)"""
+        job = self.prepare_mapping(c)
+        if job is not None:
+            self.solve_mapping(job)
+            self.apply_mapping(job)
+
+    def start_mapping(self, c):
+        job = self.prepare_mapping(c)
+        if job is None:
             return
+        self.solve_mapping(job)
+        if self.async_mapping:
+            self.pending = job                                  # enters the map at the next finish_mapping()
+        else:
+            self.apply_mapping(job)
+
+    def finish_mapping(self):
+        if self.pending is not None:
+            job, self.pending = self.pending, None
+            self.apply_mapping(job)
+
+    def prepare_mapping(self, c):
+        if len(self.kfs) < 2:
+            return None
         local = sorted(self.covisible(c, self.local_window - 1, 15) + [c])
         is_local = set(local)
         cnt, done = {}, set()
@@ -439,7 +473,7 @@ class StereoTracker:
                     continue
                 index[lid] = len(ids); ids.append(lid); pts.append(list(self.landmarks[lid]["p"]))
         if len(ids) < 20 or len(allk) < 2:
-            return
+            return None
         poses, fixed, obs_rows, origin = [], [], [], []
         any_fixed = False
         for f_i, k in enumerate(allk):
@@ -458,7 +492,13 @@ class StereoTracker:
         if not any_fixed:
             fixed[0] = 1
         obs = np.array(obs_rows, O.OBS_DTYPE)
-        op, ox, outlier = O.ba_local(np.array(poses), np.array(fixed, np.uint8), np.array(pts, np.float64), obs, self.cam, 5, 10)
+        return dict(allk=allk, fixed=fixed, ids=ids, origin=origin, obs=obs, poses=np.array(poses), pts=np.array(pts, np.float64))
+
+    def solve_mapping(self, job):
+        job["op"], job["ox"], job["outlier"] = O.ba_local(job["poses"], np.array(job["fixed"], np.uint8), job["pts"], job["obs"], self.cam, 5, 10)
+
+    def apply_mapping(self, job):
+        allk, fixed, ids, origin, obs, op, ox, outlier = (job[k] for k in ("allk", "fixed", "ids", "origin", "obs", "op", "ox", "outlier"))
         for f_i, k in enumerate(allk):
             if not fixed[f_i]:
                 self.kfs[k]["pose"] = Pose(op[f_i][:4], op[f_i][4:])
@@ -492,12 +532,68 @@ class StereoTracker:
         xr, dep, _, _ = O.match_stereo(pl, pr, self.p, kl, dl, kr, dr, fxb, baseline)
         return Frame(kl, dl, xr, dep)
 
-    def feed(self, left, right):
-        """returns the world -> camera pose (7 doubles) reported for this frame, or None while there is none"""
+    # ---- loss of tracking (HipVslamTrackerBase::relocalise and the Lost branch of trackFrame) --------------------------------------
+    @staticmethod
+    def _centre(pose):
+        R = quat_to_rot(pose.q)
+        return [-(R[0, a] * pose.t[0] + R[1, a] * pose.t[1] + R[2, a] * pose.t[2]) for a in range(3)]
+
+    def relocalise(self, cur):
+        if not self.kfs:
+            return False
+        Cl = self._centre(self.last_good)
+        near = []
+        for k, kf in enumerate(self.kfs):
+            C = self._centre(kf["pose"])
+            near.append((math.sqrt((C[0] - Cl[0]) * (C[0] - Cl[0]) + (C[1] - Cl[1]) * (C[1] - Cl[1]) + (C[2] - Cl[2]) * (C[2] - Cl[2])), k))
+        near.sort()
+        for _, k in near[:8]:
+            kf = self.kfs[k]
+            if len(kf["kpts"]) == 0 or len(cur.kpts) == 0:
+                continue
+            mq, mt, _ = O.match_bf(cur.desc, kf["desc"], 50, 0.75, True)
+            cur_idx, lm_ids = [], []
+            for a, b in zip(mq, mt):
+                lid = self.resolve(kf["landmark"][int(b)])
+                if lid < 0:
+                    continue
+                cur_idx.append(int(a)); lm_ids.append(lid)
+            if len(cur_idx) < 15:
+                continue
+            keep_pose, keep_lm = cur.pose, list(cur.landmark)
+            ok, _ = self.pose_from_matches(cur, cur_idx, lm_ids, kf["pose"], 30)
+            if ok:
+                return True
+            cur.pose, cur.landmark = keep_pose, keep_lm
+        return False
+
+    def feed(self, left, right, t=None):
+        """returns the world -> camera pose (7 doubles) reported for this frame, or None while there is none (initialising, lost);
+        t: the frame's timestamp in seconds (only the loss handling looks at it)"""
         cur = self.extract(left, right)
         self.n_frames += 1
+        t = 0.04 * self.n_frames if t is None else float(t)
+        if self.lost:
+            if self.relocalise(cur):
+                self.lost = False
+                self.stats["relocalised"] += 1
+                c = self.insert_keyframe(cur)
+                self.start_mapping(c)
+            elif t - self.lost_since > self.time_to_relocalize and int((cur.depth > 0).sum()) >= 40:
+                # a new map segment at the pose the tracker last believed in (initializeMap(cur, m_lastGoodPose))
+                self.finish_mapping()
+                cur.pose = self.last_good.copy()
+                cur.landmark = [-1] * len(cur.kpts)
+                self.segment_start = len(self.kfs)
+                self.insert_keyframe(cur)
+                self.lost = False
+                self.stats["reinitialised"] += 1
+            self.velocity = None
+            self.prev = cur
+            return None if self.lost else self.prev.pose.seven()
         if not self.tracking:
             if int((cur.depth > 0).sum()) >= 40:
+                self.finish_mapping()
                 cur.pose = Pose()
                 self.segment_start = len(self.kfs)
                 self.insert_keyframe(cur)
@@ -505,9 +601,16 @@ class StereoTracker:
             self.velocity = None
             self.prev = cur
         else:
-            ok, inliers = self.track_against_previous(cur)
+            ok, inliers = (False, 0) if len(cur.kpts) == 0 else self.track_against_previous(cur)
             if not ok:
-                raise RuntimeError("the closed-loop oracle does not cover tracking loss (frame %d)" % self.n_frames)
+                self.finish_mapping()
+                self.lost = True
+                self.lost_since = t
+                self.stats["lost"] += 1
+                self.last_good = self.predicted_pose() or self.prev.pose.copy()
+                self.prev = cur
+                self.velocity = None
+                return None
             ok2, wl = self.track_local_map(cur)
             if ok2:
                 inliers = wl
@@ -517,8 +620,11 @@ class StereoTracker:
             self.velocity = Pose(rot_to_quat(Rv), vt)
             self.since_kf += 1
             if self.keyframe_needed(inliers):
+                self.finish_mapping()                           # the previous keyframe's solve enters the map before the next one is inserted
                 c = self.insert_keyframe(cur)
-                self.local_ba(c)
-                cur.pose = self.kfs[c]["pose"].copy()
+                self.start_mapping(c)
+                if not self.async_mapping:
+                    cur.pose = self.kfs[c]["pose"].copy()
+            self.last_good = cur.pose.copy()
             self.prev = cur
         return self.prev.pose.seven() if self.tracking else None

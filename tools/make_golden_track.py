@@ -1,6 +1,13 @@
 #!/usr/bin/env python3
-"""Generates tests/golden/g10_track.npz: per-frame poses of a 24-frame 640x480 stereo sequence from the closed-loop oracle
-(oracle/tracker.py).  The images come from the committed generator (lpslam_amd/synth.py, sequence 4) and are pinned by a hash."""
+"""Generates the closed-loop goldens tests/golden/g10..g13_*.npz: per-frame poses of synthetic stereo sequences from the closed-loop
+oracle (oracle/tracker.py).  The images come from the committed generator (lpslam_amd/synth.py) and are pinned by a hash.
+
+  g10_track        640x480, 1000 keypoints, 4 levels, 24 frames, asyncMapping false                     (round 2)
+  g11_track_async  the same sequence with asyncMapping true -- the product's default
+  g12_track720     1280x720, 2000 keypoints, 8 levels (the configuration the benchmark is quoted on), 20 frames, asyncMapping true
+  g13_track_lost   640x480, 20 frames of which 10..12 are blank: Lost -> the map is kept -> relocalisation, asyncMapping true
+
+usage: make_golden_track.py [g10 g11 g12 g13]      (default: all)"""
 import hashlib
 import os
 import sys
@@ -14,27 +21,48 @@ from oracle import oracle as O           # noqa: E402
 from oracle import tracker as T          # noqa: E402
 from lpslam_amd import synth             # noqa: E402
 
-W, H, N = 640, 480, 24
-CFG = dict(max_keypoints=1000, num_levels=4, scale_factor=1.2, keyframe_interval=4, local_window=10)
+CASES = {
+    "g10_track": dict(w=640, h=480, n=24, seq=4, points=6000, blank=(),
+                      cfg=dict(max_keypoints=1000, num_levels=4, scale_factor=1.2, keyframe_interval=4, local_window=10, async_mapping=False)),
+    "g11_track_async": dict(w=640, h=480, n=24, seq=4, points=6000, blank=(),
+                            cfg=dict(max_keypoints=1000, num_levels=4, scale_factor=1.2, keyframe_interval=4, local_window=10, async_mapping=True)),
+    "g12_track720": dict(w=1280, h=720, n=20, seq=4, points=None, blank=(),
+                         cfg=dict(max_keypoints=2000, num_levels=8, scale_factor=1.2, keyframe_interval=6, local_window=10, async_mapping=True)),
+    "g13_track_lost": dict(w=640, h=480, n=20, seq=4, points=6000, blank=(10, 11, 12),
+                           cfg=dict(max_keypoints=1000, num_levels=4, scale_factor=1.2, keyframe_interval=4, local_window=10, async_mapping=True)),
+}
 
 
-def main():
-    O.build()
-    k = synth.intrinsics(W, H)
-    seq = synth.StereoSequence(W, H, 4, n_points=6000)
-    trk = T.StereoTracker(W, H, k, **CFG)
-    poses, sha = [], hashlib.sha256()
+def frames_of(case):
+    c = CASES[case]
+    seq = synth.StereoSequence(c["w"], c["h"], c["seq"], n_points=c["points"]) if c["points"] else synth.StereoSequence(c["w"], c["h"], c["seq"])
+    frames = [list(seq.frame(i)) for i in range(c["n"])]
+    blank = np.full((c["h"], c["w"]), 110, np.uint8)
+    for i in c["blank"]:
+        frames[i] = [blank.copy(), blank.copy()]
+    return frames
+
+
+def make(case):
+    c = CASES[case]
+    k = synth.intrinsics(c["w"], c["h"])
+    trk = T.StereoTracker(c["w"], c["h"], k, **c["cfg"])
+    poses, valid, sha = [], [], hashlib.sha256()
     t0 = time.time()
-    for i in range(N):
-        l, r = seq.frame(i)
+    for i, (l, r) in enumerate(frames_of(case)):
         sha.update(l.tobytes()); sha.update(r.tobytes())
-        poses.append(trk.feed(l, r))
-    print("tracked %d frames in %.1f s; statistics %s; landmarks %d" % (N, time.time() - t0, trk.stats, len(trk.landmarks)))
+        p = trk.feed(l, r, 0.04 * (i + 1))
+        valid.append(p is not None)
+        poses.append(p if p is not None else np.zeros(7))
+    print("%s: %d frames in %.1f s; statistics %s; landmarks %d" % (case, c["n"], time.time() - t0, trk.stats, len(trk.landmarks)))
     poses = np.array(poses)
-    print("last pose", poses[-1])
-    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "g10_track.npz"), poses=poses, sha=sha.hexdigest(), frames=N,
-                        keyframes=trk.stats["keyframes"], **{"stat_" + k_: v for k_, v in trk.stats.items()})
+    print("  last pose", poses[-1], "valid", "".join("1" if v else "0" for v in valid))
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", case + ".npz"), poses=poses, valid=np.array(valid), sha=sha.hexdigest(), frames=c["n"],
+                        **{"stat_" + k_: v for k_, v in trk.stats.items()})
 
 
 if __name__ == "__main__":
-    main()
+    O.build()
+    for case in (sys.argv[1:] or list(CASES)):
+        name = [k for k in CASES if k.startswith(case)][0]
+        make(name)
