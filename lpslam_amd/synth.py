@@ -100,6 +100,39 @@ class StereoSequence:
         return left, right
 
 
+def turning_sequence(width, height, n_frames=132, step_deg=3.0, seq_id=4, n_points=9000):
+    """A full turn on the spot inside a ring of structure (loop-closure tests, tests/golden/g14_track_loop.npz): stereo frames of a
+    camera at the origin turning by `step_deg` per frame about its y axis; the background is a panorama fixed to the WORLD (the
+    generator's own background is fixed to the image).  Returns (frames, yaws)."""
+    k = intrinsics(width, height)
+    seq = StereoSequence(width, height, seq_id, n_points=n_points)
+    rng = np.random.default_rng(21)
+    az = rng.uniform(0, 2 * np.pi, n_points); rad = rng.uniform(5.0, 25.0, n_points)
+    seq.pts = np.stack([rad * np.sin(az), rng.uniform(-4, 4, n_points), rad * np.cos(az)], axis=1)       # structure all around the camera
+    pano = _value_noise(np.random.Generator(np.random.PCG64(77)), 1200, 7200)                            # 0.05 degrees per pixel
+    uu, vv = np.meshgrid((np.arange(width) - k["cx"]) / k["fx"], (np.arange(height) - k["cy"]) / k["fy"])
+
+    def world_background(R):
+        d = np.stack([uu, vv, np.ones_like(uu)], axis=-1) @ R                  # camera ray -> world (R is world -> camera)
+        a = (np.arctan2(d[..., 0], d[..., 2]) + np.pi) * (7200 / (2 * np.pi))
+        e = (np.arctan2(d[..., 1], np.hypot(d[..., 0], d[..., 2])) + np.pi / 6) * (1200 / (np.pi / 3))
+        a0 = np.floor(a).astype(int); e0 = np.clip(np.floor(e).astype(int), 0, 1198)
+        fa = a - a0; fe = np.clip(e - e0, 0, 1)
+        a0 %= 7200; a1 = (a0 + 1) % 7200
+        return (pano[e0, a0] * (1 - fa) + pano[e0, a1] * fa) * (1 - fe) + (pano[e0 + 1, a0] * (1 - fa) + pano[e0 + 1, a1] * fa) * fe
+    step = math.radians(step_deg)
+    frames, yaws = [], []
+    for i in range(n_frames):
+        yaw = step * i
+        c, s_ = math.cos(yaw), math.sin(yaw)
+        R = np.array([[c, 0, s_], [0, 1, 0], [-s_, 0, c]]).T          # world -> camera for a camera turned by `yaw` about y
+        nr = np.random.Generator(np.random.PCG64([5, i]))
+        seq.bg = world_background(R)
+        frames.append((seq._render(R, np.zeros(3), nr), seq._render(R, -np.array([k["baseline"], 0.0, 0.0]), nr)))
+        yaws.append(yaw)
+    return frames, yaws
+
+
 class WallSequence:
     """Monocular test scene: three fronto-parallel textured walls at 14, 9 and 6 m, one per horizontal band of the image, seen by a
     camera that moves sideways by `step` metres per frame.  Every wall slides by a whole number of pixels (f * x / depth, rounded),

@@ -9,7 +9,8 @@ Covered: stereo initialisation, motion-model tracking with the brute-force fallb
 keyframe insertion with new landmarks, match::fuse with landmark merging, the covisibility-window local BA -- solved inline
 (asyncMapping = false) or entering the map right before the next keyframe (asyncMapping = true, the product's default) -- and its
 outlier removal, loss of tracking (the map is kept), relocalisation against the nearest keyframes and the new map segment after
-time_to_relocalize.  Not covered (and switched off in the comparison): loop closing.
+time_to_relocalize, and loop closing (descriptor voting, Sim3 verification, pose graph, fusion of the revisited landmarks, global
+bundle adjustment over the loop's keyframes).
 
 Arithmetic follows the C++ operation by operation where a rounding could change a discrete decision (float32 query fields,
 float32 level scales); everything else is float64 as there.
@@ -81,10 +82,10 @@ class Frame:
 
 
 class StereoTracker:
-    """Mirror of HipStereoTracker (loopClosure = false), asyncMapping false or true; frames fed one by one with feed(left, right[, t])."""
+    """Mirror of HipStereoTracker, asyncMapping false or true, loopClosure false or true; frames fed one by one with feed(left, right[, t])."""
 
     def __init__(self, width, height, cam, max_keypoints=1000, num_levels=4, scale_factor=1.2, keyframe_interval=4, local_window=10,
-                 nav_identity=True, async_mapping=False, time_to_relocalize=3.0):
+                 nav_identity=True, async_mapping=False, time_to_relocalize=3.0, loop_closure=False):
         self.w, self.h, self.cam = width, height, dict(cam)
         self.p = O.params(max_keypoints, scale_factor, num_levels)
         self.scales = O.scale_factors(self.p)[0]                   # float32, as lpslam_hip_level_info returns them
@@ -100,11 +101,13 @@ class StereoTracker:
         self.tracking = False
         self.n_frames = 0
         self.stats = dict(motion_tracked=0, bf_tracked=0, local_map_joined=0, keyframes=0, fused_added=0, fused_merged=0, local_ba=0,
-                          lost=0, relocalised=0, reinitialised=0)
+                          lost=0, relocalised=0, reinitialised=0, loops_closed=0, loop_fused=0, global_ba=0)
         # asyncMapping (the product's default): the local BA of keyframe c is prepared from the map as it is right after c's insertion,
         # solved beside the tracking of the following frames, and ENTERS the map right before the next keyframe is inserted
         # (HipVslamTrackerBase::startMapping / finishMapping) -- the order of events does not depend on how long the solve takes
         self.async_mapping = async_mapping
+        self.loop_closure = loop_closure
+        self.segment = 0
         self.pending = None
         self.time_to_relocalize = float(time_to_relocalize)
         self.lost = False
@@ -342,7 +345,8 @@ class StereoTracker:
             q_rows.append((F32(u), F32(v), F32(u - self.cam["fxb"] / pc[2]), F32(3.0) * self.scales[lvl], max(0, lvl - 1), lvl))
             qd.append(lm["desc"]); q_lm.append(lid)
         if not q_rows:
-            return
+            return 0
+        n_fused = 0
         q = np.array(q_rows, O.PROJ_QUERY_DTYPE)
         isq = (F32(1.0) / (self.scales.astype(np.float32) ** 2)).astype(np.float32)
         idx, _, _ = O.match_fuse(kc["kpts"], kc["desc"], kc["x_right"], self.w, self.h, isq, q, np.array(qd, np.uint8), 50)
@@ -362,7 +366,7 @@ class StereoTracker:
                 kc["landmark"][kp] = lid; lm["obs"].append((c, kp))
                 if kp < len(f.landmark):
                     f.landmark[kp] = lid
-                self.stats["fused_added"] += 1
+                self.stats["fused_added"] += 1; n_fused += 1
             elif have != lid:
                 if seen or have not in self.landmarks:
                     continue
@@ -372,7 +376,8 @@ class StereoTracker:
                 self.merge_landmarks(keep, drop, f)
                 if self.prev is not None:
                     self.prev.landmark = [keep if l == drop else l for l in self.prev.landmark]
-                self.stats["fused_merged"] += 1
+                self.stats["fused_merged"] += 1; n_fused += 1
+        return n_fused
 
     def insert_keyframe(self, f):
         c = len(self.kfs)
@@ -402,7 +407,7 @@ class StereoTracker:
                 f.landmark[i] = lid
             elif lid >= 0:
                 self.landmarks[lid]["obs"].append((c, i))
-        self.kfs.append(dict(pose=f.pose.copy(), kpts=f.kpts, desc=f.desc, x_right=f.x_right, depth=f.depth, landmark=list(f.landmark)))
+        self.kfs.append(dict(pose=f.pose.copy(), kpts=f.kpts, desc=f.desc, x_right=f.x_right, depth=f.depth, landmark=list(f.landmark), segment=self.segment))
         nb = self.covisible(c, self.local_window - 1, 15)
         held = set(l for l in self.kfs[c]["landmark"] if l >= 0)
         ids = []
@@ -458,9 +463,13 @@ class StereoTracker:
                         cnt[ok_] = cnt.get(ok_, 0) + 1
         v = sorted(((n, k) for k, n in cnt.items()), key=lambda e: (-e[0], -e[1]))[:self.local_window]
         fixed_kfs = [k for _, k in v]
-        allk = sorted(local + fixed_kfs)
+        return self.prepare_bundle(local, fixed_kfs)
+
+    def prepare_bundle(self, free_kfs, fixed_kfs):
+        """HipVslamTrackerBase::prepareBundle: landmarks seen by the free keyframes and observed at least twice among all"""
+        allk = sorted(list(free_kfs) + list(fixed_kfs))
         fixed_set = set(fixed_kfs)
-        of_free = set(l for k in local for l in self.kfs[k]["landmark"] if l >= 0)
+        of_free = set(l for k in free_kfs for l in self.kfs[k]["landmark"] if l >= 0)
         seen = {}
         for k in allk:
             for lid in self.kfs[k]["landmark"]:
@@ -479,7 +488,7 @@ class StereoTracker:
         for f_i, k in enumerate(allk):
             kf = self.kfs[k]
             poses.append(kf["pose"].seven())
-            fx = k in fixed_set or k == 0 or k == self.segment_start
+            fx = k in fixed_set or k == 0 or self.kfs[k - 1]["segment"] != kf["segment"]      # the first keyframe of a segment anchors the gauge
             fixed.append(1 if fx else 0)
             any_fixed = any_fixed or fx
             for kp, lid in enumerate(kf["landmark"]):
@@ -492,10 +501,14 @@ class StereoTracker:
         if not any_fixed:
             fixed[0] = 1
         obs = np.array(obs_rows, O.OBS_DTYPE)
-        return dict(allk=allk, fixed=fixed, ids=ids, origin=origin, obs=obs, poses=np.array(poses), pts=np.array(pts, np.float64))
+        return dict(allk=allk, fixed=fixed, ids=ids, origin=origin, obs=obs, poses=np.array(poses), pts=np.array(pts, np.float64), is_global=False)
 
     def solve_mapping(self, job):
-        job["op"], job["ox"], job["outlier"] = O.ba_local(job["poses"], np.array(job["fixed"], np.uint8), job["pts"], job["obs"], self.cam, 5, 10)
+        if job["is_global"]:            # loop_bundle_adjuster: 10 robust iterations over the loop's keyframes, no outlier removal
+            job["op"], job["ox"], _ = O.ba_optimize(job["poses"], np.array(job["fixed"], np.uint8), job["pts"], job["obs"], self.cam, True, 10)
+            job["outlier"] = np.zeros(len(job["obs"]), np.uint8)
+        else:
+            job["op"], job["ox"], job["outlier"] = O.ba_local(job["poses"], np.array(job["fixed"], np.uint8), job["pts"], job["obs"], self.cam, 5, 10)
 
     def apply_mapping(self, job):
         allk, fixed, ids, origin, obs, op, ox, outlier = (job[k] for k in ("allk", "fixed", "ids", "origin", "obs", "op", "ox", "outlier"))
@@ -523,6 +536,120 @@ class StereoTracker:
             if not ob:
                 del self.landmarks[lid]
         self.stats["local_ba"] += 1
+
+    # ---- loop closing (HipVslamTrackerBase::detectAndCloseLoop) ---------------------------------------------------------------------
+    @staticmethod
+    def _se3_mul(a, b):
+        return move_pose(a, b)                                   # a after b: (q_a q_b normalised, R_a t_b + t_a)
+
+    @staticmethod
+    def _se3_inv(a):
+        R = quat_to_rot(a.q)
+        return Pose([a.q[0], -a.q[1], -a.q[2], -a.q[3]], [-(R[0, r] * a.t[0] + R[1, r] * a.t[1] + R[2, r] * a.t[2]) for r in range(3)])
+
+    def detect_and_close_loop(self, cur, c):
+        newest = c - 2 * self.local_window
+        if newest < 0:
+            return False
+        kc = self.kfs[c]
+        covis = set(self.covisible(c, len(self.kfs), 15))
+        Cc = self._centre(kc["pose"])
+        cands = []
+        for a in range(newest + 1):
+            if a in covis:
+                continue
+            C = self._centre(self.kfs[a]["pose"])
+            cands.append((math.sqrt((C[0] - Cc[0]) * (C[0] - Cc[0]) + (C[1] - Cc[1]) * (C[1] - Cc[1]) + (C[2] - Cc[2]) * (C[2] - Cc[2])), a))
+        if not cands:
+            return False
+        cands.sort()
+        votes = []
+        for _, a in cands[:48]:
+            ka = self.kfs[a]
+            if len(ka["kpts"]) == 0:
+                continue
+            mq, mt, _ = O.match_bf(kc["desc"], ka["desc"], 50, 0.75, True)
+            pairs = [(int(q_), int(t_)) for q_, t_ in zip(mq, mt)
+                     if kc["landmark"][int(q_)] >= 0 and ka["landmark"][int(t_)] >= 0 and self.resolve(kc["landmark"][int(q_)]) != self.resolve(ka["landmark"][int(t_)])]
+            if len(pairs) >= 20:
+                votes.append((a, pairs))
+        if not votes:
+            return False
+        votes.sort(key=lambda v: (-len(v[1]), -v[0]))
+        votes = votes[:3]
+        Rc = quat_to_rot(kc["pose"].q)
+        cam4 = [self.cam["fx"], self.cam["fy"], self.cam["cx"], self.cam["cy"]]
+        results = []
+        for a, pairs in votes:
+            ka = self.kfs[a]
+            Ra = quat_to_rot(ka["pose"].q)
+            rows = np.zeros(len(pairs), O.SIM3_PAIR_DTYPE)
+            for n_, (ic, ia) in enumerate(pairs):
+                lc = self.landmarks[self.resolve(kc["landmark"][ic])]; la = self.landmarks[self.resolve(ka["landmark"][ia])]
+                rows["p1c"][n_] = [Rc[r, 0] * lc["p"][0] + Rc[r, 1] * lc["p"][1] + Rc[r, 2] * lc["p"][2] + kc["pose"].t[r] for r in range(3)]
+                rows["p2c"][n_] = [Ra[r, 0] * la["p"][0] + Ra[r, 1] * la["p"][1] + Ra[r, 2] * la["p"][2] + ka["pose"].t[r] for r in range(3)]
+                rows["obs1"][n_] = [float(kc["kpts"]["x"][ic]), float(kc["kpts"]["y"][ic])]
+                rows["obs2"][n_] = [float(ka["kpts"]["x"][ia]), float(ka["kpts"]["y"][ia])]
+                s1 = float(self.scales[int(kc["kpts"]["octave"][ic])]); s2 = float(self.scales[int(ka["kpts"]["octave"][ia])])
+                rows["inv_sigma2_1"][n_] = 1.0 / (s1 * s1); rows["inv_sigma2_2"][n_] = 1.0 / (s2 * s2)
+            T12 = self._se3_mul(kc["pose"], self._se3_inv(ka["pose"]))                 # candidate camera -> current camera
+            s12, _, n_inl = O.sim3_transform_optimize(np.array(T12.q + T12.t + [1.0]), rows, cam4, cam4, 10.0, True)
+            results.append((n_inl, s12))
+        best = -1
+        for i, (n_inl, _) in enumerate(results):
+            if n_inl >= 20 and (best < 0 or n_inl > results[best][0]):
+                best = i
+        if best < 0:
+            return False
+        # ---- pose graph over the keyframes of the loop: a0 = candidate (fixed) ... c
+        a0 = votes[best][0]
+        n = c - a0 + 1
+        old = [self.kfs[a0 + v]["pose"].copy() for v in range(n)]
+        verts = np.array([p_.q + p_.t + [1.0] for p_ in old], np.float64)
+        fixed = np.zeros(n, np.uint8); fixed[0] = 1
+        ei, ej, meas = [], [], []
+        for v in range(n - 1):
+            m = self._se3_mul(old[v + 1], self._se3_inv(old[v]))
+            ei.append(v); ej.append(v + 1); meas.append(m.q + m.t + [1.0])
+        ei.append(0); ej.append(n - 1); meas.append(list(results[best][1]))
+        verts, _ = O.sim3_graph_optimize(verts, fixed, O.sim3_edges(np.array(ei, np.int32), np.array(ej, np.int32), np.array(meas, np.float64)), True, 50)
+        self.finish_mapping()
+        neu = []
+        for v in range(n):
+            r = verts[v]
+            qn = math.sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3]); sc = r[7] if r[7] > 0 else 1.0
+            neu.append(Pose([r[0] / qn, r[1] / qn, r[2] / qn, r[3] / qn], [r[4] / sc, r[5] / sc, r[6] / sc]))
+            self.kfs[a0 + v]["pose"] = neu[v].copy()
+        for lm in self.landmarks.values():                   # X_new = T_ref_new^-1 (T_ref_old X)
+            rk = lm["ref_kf"]
+            if rk < a0 or rk > c:
+                continue
+            To, Tni = old[rk - a0], self._se3_inv(neu[rk - a0])
+            Ro, Rn = quat_to_rot(To.q), quat_to_rot(Tni.q)
+            xc = [Ro[r, 0] * lm["p"][0] + Ro[r, 1] * lm["p"][1] + Ro[r, 2] * lm["p"][2] + To.t[r] for r in range(3)]
+            lm["p"] = [Rn[r, 0] * xc[0] + Rn[r, 1] * xc[1] + Rn[r, 2] * xc[2] + Tni.t[r] for r in range(3)]
+        cur.pose = self.kfs[c]["pose"].copy()
+        # ---- the revisited structure exists twice: fuse the candidate's neighbourhood into the new keyframe
+        nb = sorted(self.covisible(a0, self.local_window - 1, 15) + [a0])
+        held = set(l for l in self.kfs[c]["landmark"] if l >= 0)
+        ids = []
+        for k in nb:
+            for lid in self.kfs[k]["landmark"]:
+                if lid >= 0 and lid not in held:
+                    held.add(lid); ids.append(lid)
+        before = (self.stats["fused_added"], self.stats["fused_merged"])
+        self.stats["loop_fused"] += self.fuse_into(c, ids, cur)
+        self.stats["fused_added"], self.stats["fused_merged"] = before       # the loop's fusions are counted apart (loop_fused)
+        # ---- global bundle adjustment over the keyframes of the loop, inline
+        job = self.prepare_bundle(list(range(a0 + 1, c + 1)), [a0])
+        if job is not None:
+            job["is_global"] = True
+            self.solve_mapping(job)
+            self.apply_mapping(job)
+            self.stats["local_ba"] -= 1; self.stats["global_ba"] += 1
+            cur.pose = self.kfs[c]["pose"].copy()
+        self.stats["loops_closed"] += 1
+        return True
 
     # ---- one frame ---------------------------------------------------------------------------------------------------------------
     def extract(self, left, right):
@@ -582,6 +709,7 @@ class StereoTracker:
             elif t - self.lost_since > self.time_to_relocalize and int((cur.depth > 0).sum()) >= 40:
                 # a new map segment at the pose the tracker last believed in (initializeMap(cur, m_lastGoodPose))
                 self.finish_mapping()
+                self.segment += 1
                 cur.pose = self.last_good.copy()
                 cur.landmark = [-1] * len(cur.kpts)
                 self.segment_start = len(self.kfs)
@@ -622,6 +750,8 @@ class StereoTracker:
             if self.keyframe_needed(inliers):
                 self.finish_mapping()                           # the previous keyframe's solve enters the map before the next one is inserted
                 c = self.insert_keyframe(cur)
+                if self.loop_closure:
+                    self.detect_and_close_loop(cur, c)
                 self.start_mapping(c)
                 if not self.async_mapping:
                     cur.pose = self.kfs[c]["pose"].copy()

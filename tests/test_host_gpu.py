@@ -178,32 +178,7 @@ def test_loop_is_detected_and_closed(hiplib, tmp_path):
     from lpslam_amd import _build, manager
     _build.host_library()
     w, h = 640, 480
-    k = synth.intrinsics(w, h)
-    seq = synth.StereoSequence(w, h, 4, n_points=9000)
-    rng = np.random.default_rng(21)
-    az = rng.uniform(0, 2 * np.pi, 9000); rad = rng.uniform(5.0, 25.0, 9000)
-    seq.pts = np.stack([rad * np.sin(az), rng.uniform(-4, 4, 9000), rad * np.cos(az)], axis=1)       # structure all around the camera
-    # the generator's background is fixed to the image; a turning camera needs one fixed to the world: a panorama at infinity
-    pano = synth._value_noise(np.random.Generator(np.random.PCG64(77)), 1200, 7200)                  # 0.05 degrees per pixel
-    uu, vv = np.meshgrid((np.arange(w) - k["cx"]) / k["fx"], (np.arange(h) - k["cy"]) / k["fy"])
-    def world_background(R):
-        d = np.stack([uu, vv, np.ones_like(uu)], axis=-1) @ R                  # camera ray -> world (R is world -> camera)
-        a = (np.arctan2(d[..., 0], d[..., 2]) + np.pi) * (7200 / (2 * np.pi))
-        e = (np.arctan2(d[..., 1], np.hypot(d[..., 0], d[..., 2])) + np.pi / 6) * (1200 / (np.pi / 3))
-        a0 = np.floor(a).astype(int); e0 = np.clip(np.floor(e).astype(int), 0, 1198)
-        fa = a - a0; fe = np.clip(e - e0, 0, 1)
-        a0 %= 7200; a1 = (a0 + 1) % 7200
-        return (pano[e0, a0] * (1 - fa) + pano[e0, a1] * fa) * (1 - fe) + (pano[e0 + 1, a0] * (1 - fa) + pano[e0 + 1, a1] * fa) * fe
-    n_frames, step = 132, math.radians(3.0)
-    frames, yaws = [], []
-    for i in range(n_frames):
-        yaw = step * i
-        c, s_ = math.cos(yaw), math.sin(yaw)
-        R = np.array([[c, 0, s_], [0, 1, 0], [-s_, 0, c]]).T          # world -> camera for a camera turned by `yaw` about y
-        nr = np.random.Generator(np.random.PCG64([5, i]))
-        seq.bg = world_background(R)
-        frames.append((seq._render(R, np.zeros(3), nr), seq._render(R, -np.array([k["baseline"], 0.0, 0.0]), nr)))
-        yaws.append(yaw)
+    frames, yaws = synth.turning_sequence(w, h)
     log = tmp_path / "slam.log"
     m = _stereo_manager(manager, w, h, '{"cameraSetup": "stereo", "slamKeypoints": 1000, "numLevels": 4, "keyframeInterval": 3, "localWindow": 4, "loopClosure": true}', log)
     m.start()

@@ -1,7 +1,7 @@
 """Closed-loop parity of the stereo tracker: the product path (LpSlamManager -> VSLAMStereo tracker -> HIP kernels) against the
-closed-loop oracle (oracle/tracker.py, goldens tests/golden/g10..g13_*.npz made by tools/make_golden_track.py), pose by pose:
-synchronous and asynchronous mapping at 640x480, the benchmark configuration (1280x720, 2000 keypoints, 8 levels), and a sequence
-with a loss of tracking and a relocalisation.  Tolerance: the north star's 1e-4 rad / 1e-3 m, per tracked frame."""
+closed-loop oracle (oracle/tracker.py, goldens tests/golden/g10..g14_*.npz made by tools/make_golden_track.py), pose by pose:
+synchronous and asynchronous mapping at 640x480, the benchmark configuration (1280x720, 2000 keypoints, 8 levels), a sequence
+with a loss of tracking and a relocalisation, and a full turn that closes a loop.  Tolerance: the north star's 1e-4 rad / 1e-3 m, per tracked frame."""
 import hashlib
 import math
 import time
@@ -25,6 +25,9 @@ CASES = {
     "g12_track720": (1280, 720, 4, None, (), '{"cameraSetup": "stereo", "slamKeypoints": 2000, "numLevels": 8, "keyframeInterval": 6, "localWindow": 10, "asyncMapping": true, "loopClosure": false}'),
     # three blank frames: Lost (no pose goes out), the map is kept, relocalisation against the nearest keyframes
     "g13_track_lost": (640, 480, 4, 6000, (10, 11, 12), '{"cameraSetup": "stereo", "slamKeypoints": 1000, "numLevels": 4, "keyframeInterval": 4, "localWindow": 10, "asyncMapping": true, "loopClosure": false}'),
+    # a full turn on the spot with loopClosure true: descriptor voting, Sim3 verification, pose graph, fusion of the revisited
+    # landmarks, global bundle adjustment over the loop's keyframes (the Sim3 optimisers differentiate numerically: DESIGN.md section 3)
+    "g14_track_loop": (640, 480, "turn", None, (), '{"cameraSetup": "stereo", "slamKeypoints": 1000, "numLevels": 4, "keyframeInterval": 3, "localWindow": 4, "asyncMapping": true, "loopClosure": true}'),
 }
 
 
@@ -68,8 +71,11 @@ def test_tracked_poses_follow_the_closed_loop_oracle(hiplib, tmp_path, case):
     w, h, seq_id, n_points, blank_at, cfg = CASES[case]
     g = golden(case + ".npz")
     n = int(g["frames"])
-    seq = synth.StereoSequence(w, h, seq_id, n_points=n_points) if n_points else synth.StereoSequence(w, h, seq_id)
-    frames = [list(seq.frame(i)) for i in range(n)]
+    if seq_id == "turn":
+        frames = [list(f) for f in synth.turning_sequence(w, h, n)[0]]
+    else:
+        seq = synth.StereoSequence(w, h, seq_id, n_points=n_points) if n_points else synth.StereoSequence(w, h, seq_id)
+        frames = [list(seq.frame(i)) for i in range(n)]
     blank = np.full((h, w), 110, np.uint8)
     for i in blank_at:
         frames[i] = [blank.copy(), blank.copy()]
@@ -91,7 +97,8 @@ def test_tracked_poses_follow_the_closed_loop_oracle(hiplib, tmp_path, case):
         worst_rot, worst_pos = max(worst_rot, ang), max(worst_pos, dp)
         assert ang < ROT_TOL and dp < TRANS_TOL, (i, ang, dp)
     # the same discrete history: keyframes, motion-model frames, local BA runs, fused duplicates, losses
-    for key in ("keyframes", "motion_tracked", "bf_tracked", "local_map_joined", "fused_added", "fused_merged", "local_ba", "lost", "relocalised", "reinitialised"):
+    for key in ("keyframes", "motion_tracked", "bf_tracked", "local_map_joined", "fused_added", "fused_merged", "local_ba", "lost", "relocalised", "reinitialised",
+                "loops_closed", "loop_fused", "global_ba"):
         if "stat_" + key in g.files:
             assert stats[key] == int(g["stat_" + key]), (key, stats[key], int(g["stat_" + key]))
     print("closed loop %s: worst rotation %.2e rad, worst position %.2e m over %d frames" % (case, worst_rot, worst_pos, n))
