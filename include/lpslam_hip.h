@@ -309,6 +309,37 @@ int lpslam_hip_ba_optimize_partitioned_with(lpslam_hip_ba* ba, lpslam_hip_allred
 /* Control state after the last optimize / step_end: finished outer iterations, g2o "Terminate", lambda, robust chi2. */
 int lpslam_hip_ba_status(lpslam_hip_ba* ba, int32_t* outer_done, int32_t* stopped, double* lambda, double* chi2);
 
+/* ---- bag-of-words vocabulary and match::bow_tree ------------------------------------------------------------------------------
+ * [UPSTREAM] DBoW2 TemplatedVocabulary<ORB> (shinsumicco/DBoW2 @ e8cc74d: conan-packages/dbow2-conan/conanfile.py:30-31), which the
+ * reference requires at start-up (src/Trackers/OpenVSLAMTrackerBase.cpp:224-227: "Vocab file ... not present" -> start fails;
+ * handed to openvslam::system at :238), and [UPSTREAM] openvslam match::bow_tree, which the relocaliser and the loop detector
+ * (toggled at :250-255) match keypoints with.
+ * lpslam_hip_vocab_create takes the tree as DBoW2 stores it -- nodes 1 .. n_nodes in file order, each naming its parent (0 = the
+ * root, which precedes every node), its 32-byte descriptor, its weight and whether it is a leaf (= a word; word ids count the
+ * leaves in node order) -- and keeps it in HBM.  The file formats are read by the host mirror (lpslam_amd/host/bow.h).
+ * lpslam_hip_bow_transform walks the descriptors of an image slot down the tree on the device (TemplatedVocabulary::transform with
+ * a FeatureVector: at every level the child at the smallest Hamming distance, the first on ties): per keypoint the word id, the
+ * word's weight and the id of the node `levels_up` levels above the leaves (0 = the root when the tree is not that deep).  The
+ * result buffers must hold lpslam_hip_max_keypoints_per_image() entries.  _host: the same for descriptors in host memory. */
+typedef struct lpslam_hip_vocab lpslam_hip_vocab;
+int lpslam_hip_vocab_create(lpslam_hip_ctx* ctx, int32_t k, int32_t L, int32_t n_nodes, const int32_t* parent, const uint8_t* desc32,
+                            const float* weight, const uint8_t* is_leaf, lpslam_hip_vocab** out);
+void lpslam_hip_vocab_destroy(lpslam_hip_vocab* vocab);
+int lpslam_hip_vocab_info(lpslam_hip_vocab* vocab, int32_t* k, int32_t* L, int32_t* n_nodes, int32_t* n_words);
+int lpslam_hip_bow_transform(lpslam_hip_ctx* ctx, lpslam_hip_vocab* vocab, int image, int32_t levels_up, int32_t* word_id, float* word_weight,
+                             int32_t* node_id, int32_t capacity, int32_t* count);
+int lpslam_hip_bow_transform_host(lpslam_hip_ctx* ctx, lpslam_hip_vocab* vocab, const uint8_t* desc32, int32_t n, int32_t levels_up,
+                                  int32_t* word_id, float* word_weight, int32_t* node_id);
+/* match::bow_tree (match_frame_and_keyframe / match_keyframes): query k (descriptor + the node it falls under, q_node[k] < 0 =
+ * not a query, e.g. a keypoint without a landmark) is compared with the targets under the same node.  Queries are served node by
+ * node (ascending id) and in keypoint order inside a node; a target matched by an earlier query (or flagged in t_taken, may be
+ * NULL) is invisible to later ones; the nearest free target wins (the first on ties), accepted when best <= hamming_thr and
+ * best <= lowe_ratio * second (second = 256 when there is no other).  match_idx[k] = target index or -1.  The orientation check
+ * of upstream is lpslam_hip_match_orientation_filter on the result. */
+int lpslam_hip_match_bow_tree(lpslam_hip_ctx* ctx, const uint8_t* q_desc32, const int32_t* q_node, int32_t nq, const uint8_t* t_desc32,
+                              const int32_t* t_node, int32_t nt, const uint8_t* t_taken, int32_t hamming_thr, float lowe_ratio,
+                              int32_t* match_idx, int32_t* match_dist, int32_t* n_matches);
+
 /* ---- projection matching ---------------------------------------------------------------------------------------------
  * [UPSTREAM] match::projection::match_frame_and_landmarks (local-map tracking) and match_current_and_last_frames (motion-model
  * tracking), which openvslam::system runs inside feed_stereo_frame / feed_monocular_frame

@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "liblpslam_hip.so")
-HIP_SOURCES = ["api.hip", "frontend.hip", "match.hip", "ba.hip"]
+HIP_SOURCES = ["api.hip", "frontend.hip", "match.hip", "ba.hip", "bow.hip"]
 DEPS = ["internal.h", "orb_pattern.inc", os.path.join("..", "..", "include", "lpslam_hip.h"), "sim3.inl"]
 # -ffp-contract=off: parity with the CPU definition forbids FMA contraction ("Numerics").
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
@@ -15,7 +15,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp
 
 OBJ_DIR = os.path.join(CSRC, "_obj")
 # what each translation unit includes (beyond itself): a change there recompiles only that unit
-UNIT_DEPS = {"ba.hip": ["sim3.inl", "ba_build.inl", "ba_solve.inl"], "frontend.hip": ["orb_pattern.inc"], "match.hip": [], "api.hip": []}
+UNIT_DEPS = {"ba.hip": ["sim3.inl", "ba_build.inl", "ba_solve.inl"], "frontend.hip": ["orb_pattern.inc"], "match.hip": [], "api.hip": [], "bow.hip": []}
 COMMON_DEPS = ["internal.h", os.path.join("..", "..", "include", "lpslam_hip.h")]
 
 
@@ -48,14 +48,14 @@ def hip_library(force=False, verbose=False):
 
 
 HOST_LIB = os.path.join(HERE, "liblpslam.so")
-HOST_SOURCES = ["slam_manager.cpp", "hip_tracker.cpp", "interface.cpp", "rectify.cpp", "replay.cpp", "two_view.cpp"]
+HOST_SOURCES = ["slam_manager.cpp", "hip_tracker.cpp", "interface.cpp", "rectify.cpp", "replay.cpp", "two_view.cpp", "bow.cpp"]
 
 
 def host_library(force=False, verbose=False):
     """C++ host mirror of the reference interface (g++), linked against the HIP C-ABI library next to it."""
     hdir = os.path.join(HERE, "host")
     srcs = [os.path.join(hdir, s) for s in HOST_SOURCES]
-    deps = srcs + [os.path.join(hdir, h) for h in ("core.h", "json_min.h", "hip_tracker.h", "slam_manager.h", "rectify.h", "replay.h", "two_view.h")] + \
+    deps = srcs + [os.path.join(hdir, h) for h in ("core.h", "json_min.h", "hip_tracker.h", "slam_manager.h", "rectify.h", "replay.h", "two_view.h", "bow.h")] + \
         [os.path.join(HERE, "..", "include", h) for h in ("lpslam_types.h", "lpslam_manager.h", "lpslam_hip.h")] + [LIB]
     if not force and os.path.exists(HOST_LIB) and all(os.path.getmtime(d) <= os.path.getmtime(HOST_LIB) for d in deps if os.path.exists(d)):
         return HOST_LIB

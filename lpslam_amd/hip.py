@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblpslam_hip.so")
+LIB_PATH = os.environ.get("LPSLAM_HIP_LIB") or os.path.join(_HERE, "liblpslam_hip.so")      # the override: A/B timing of two builds on one box
 MAX_LEVELS = 16
 
 KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
@@ -34,6 +34,7 @@ SYMBOLS = [
     "lpslam_hip_get_candidates", "lpslam_hip_keypoint_buffers", "lpslam_hip_match_bf", "lpslam_hip_get_bf_knn2",
     "lpslam_hip_get_bf_matches", "lpslam_hip_match_bf_strided", "lpslam_hip_set_descriptors",
     "lpslam_hip_match_stereo", "lpslam_hip_match_stereo_strided", "lpslam_hip_get_stereo",
+    "lpslam_hip_vocab_create", "lpslam_hip_vocab_destroy", "lpslam_hip_vocab_info", "lpslam_hip_bow_transform", "lpslam_hip_bow_transform_host", "lpslam_hip_match_bow_tree",
     "lpslam_hip_match_projection", "lpslam_hip_match_fuse", "lpslam_hip_match_area", "lpslam_hip_match_orientation_filter",
     "lpslam_hip_ba_create", "lpslam_hip_ba_destroy", "lpslam_hip_ba_set_active", "lpslam_hip_ba_optimize", "lpslam_hip_ba_optimize_begin", "lpslam_hip_ba_optimize_end", "lpslam_hip_ba_graph_replays",
     "lpslam_hip_ba_optimize_batch", "lpslam_hip_ba_reset_batch", "lpslam_hip_ba_optimize_profiled", "lpslam_hip_ba_optimize_partitioned", "lpslam_hip_ba_optimize_partitioned_with",
@@ -452,6 +453,63 @@ class BundleAdjuster:
         o = C.c_int32(); st = C.c_int32(); lam = C.c_double(); chi = C.c_double()
         _check(self.lib.lpslam_hip_ba_status(self.h, C.byref(o), C.byref(st), C.byref(lam), C.byref(chi)))
         return dict(outer_done=o.value, stopped=bool(st.value), lam=lam.value, chi2=chi.value)
+
+
+class Vocabulary:
+    """lpslam_hip_vocab: a DBoW2 vocabulary tree in HBM.  nodes: structured array (parent, desc[32], weight, is_leaf) in file order."""
+
+    def __init__(self, ctx, k, L, parent, desc, weight, is_leaf):
+        self.ctx, self.lib = ctx, ctx.lib
+        parent = np.ascontiguousarray(parent, np.int32); desc = np.ascontiguousarray(desc, np.uint8)
+        weight = np.ascontiguousarray(weight, np.float32); is_leaf = np.ascontiguousarray(is_leaf, np.uint8)
+        assert desc.shape == (len(parent), 32)
+        h = C.c_void_p()
+        f = self.lib.lpslam_hip_vocab_create
+        f.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
+        _check(f(ctx.h, int(k), int(L), len(parent), _p(parent), _p(desc), _p(weight), _p(is_leaf), C.byref(h)))
+        self.h = h
+        ctx._children.add(self)
+        k_, L_, nn, nw = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        self.lib.lpslam_hip_vocab_info.argtypes = [C.c_void_p] + [C.POINTER(C.c_int32)] * 4
+        _check(self.lib.lpslam_hip_vocab_info(self.h, C.byref(k_), C.byref(L_), C.byref(nn), C.byref(nw)))
+        self.k, self.L, self.n_nodes, self.n_words = k_.value, L_.value, nn.value, nw.value
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.lpslam_hip_vocab_destroy.argtypes = [C.c_void_p]
+            self.lib.lpslam_hip_vocab_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def transform(self, image, levels_up=4):
+        """word id, word weight, node id per keypoint of an image slot"""
+        cap = self.ctx.max_kp
+        w = np.zeros(cap, np.int32); wt = np.zeros(cap, np.float32); nd = np.zeros(cap, np.int32); n = C.c_int32()
+        f = self.lib.lpslam_hip_bow_transform
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
+        _check(f(self.ctx.h, self.h, int(image), int(levels_up), _p(w), _p(wt), _p(nd), cap, C.byref(n)))
+        return w[:n.value].copy(), wt[:n.value].copy(), nd[:n.value].copy()
+
+    def transform_host(self, desc, levels_up=4):
+        d = np.ascontiguousarray(desc, np.uint8)
+        n = len(d)
+        w = np.zeros(max(n, 1), np.int32); wt = np.zeros(max(n, 1), np.float32); nd = np.zeros(max(n, 1), np.int32)
+        f = self.lib.lpslam_hip_bow_transform_host
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+        _check(f(self.ctx.h, self.h, _p(d), n, int(levels_up), _p(w), _p(wt), _p(nd)))
+        return w[:n], wt[:n], nd[:n]
+
+
+def match_bow_tree(ctx, q_desc, q_node, t_desc, t_node, hamming_thr=50, lowe_ratio=0.75, t_taken=None):
+    qd = np.ascontiguousarray(q_desc, np.uint8); qn = np.ascontiguousarray(q_node, np.int32)
+    td = np.ascontiguousarray(t_desc, np.uint8); tn = np.ascontiguousarray(t_node, np.int32)
+    tk = np.ascontiguousarray(t_taken, np.uint8) if t_taken is not None else None
+    idx = np.full(max(len(qn), 1), -1, np.int32); dist = np.zeros(max(len(qn), 1), np.int32); n = C.c_int32()
+    f = ctx.lib.lpslam_hip_match_bow_tree
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_float, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]
+    _check(f(ctx.h, _p(qd), _p(qn), len(qn), _p(td), _p(tn), len(tn), _p(tk), int(hamming_thr), float(lowe_ratio), _p(idx), _p(dist), C.byref(n)))
+    return idx[:len(qn)], dist[:len(qn)], n.value
 
 
 class RcclComm:

@@ -14,7 +14,7 @@ MAX_LEVELS = 16
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, f) for f in ("ora_orb.c", "ora_match.c", "ora_ba.c", "ora.h", "orb_pattern.inc")]
+    srcs = [os.path.join(_HERE, f) for f in ("ora_orb.c", "ora_match.c", "ora_ba.c", "ora_sim3.c", "ora_bow.c", "ora.h", "orb_pattern.inc")]
     if force or not os.path.exists(_LIB) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in srcs if os.path.exists(s)):
         subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s"], stdout=subprocess.DEVNULL)
     return _LIB
@@ -386,3 +386,51 @@ def match_area(kp2, desc2, width, height, queries, q_desc, hamming_thr=50, lowe_
     f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p]
     n = f(_p(kp2), _p(desc2), len(kp2), width, height, _p(q), _p(qd), len(q), int(hamming_thr), float(lowe_ratio), _p(idx))
     return idx[:len(q)].copy(), n
+
+
+# ---- bag of words (ora_bow.c; [UPSTREAM] DBoW2 TemplatedVocabulary, openvslam match::bow_tree) -----------------------------------
+def bow_transform(vocab, desc, levels_up=4):
+    """vocab: dict(k, L, parent, desc, weight, is_leaf) with the nodes in DBoW2 file order; returns word id, word weight, node id"""
+    d = np.ascontiguousarray(desc, np.uint8); n = len(d)
+    parent = np.ascontiguousarray(vocab["parent"], np.int32); nd = np.ascontiguousarray(vocab["desc"], np.uint8)
+    wt = np.ascontiguousarray(vocab["weight"], np.float32); leaf = np.ascontiguousarray(vocab["is_leaf"], np.uint8)
+    w = np.zeros(max(n, 1), np.int32); ww = np.zeros(max(n, 1), np.float32); node = np.zeros(max(n, 1), np.int32)
+    f = lib().ora_bow_transform
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    nw = f(_p(parent), _p(nd), _p(wt), _p(leaf), len(parent), int(vocab["L"]), _p(d), n, int(levels_up), _p(w), _p(ww), _p(node))
+    assert nw >= 0
+    return w[:n], ww[:n], node[:n]
+
+
+def bow_tree_match(q_desc, q_node, t_desc, t_node, hamming_thr=50, lowe_ratio=0.75, t_taken=None):
+    qd = np.ascontiguousarray(q_desc, np.uint8); qn = np.ascontiguousarray(q_node, np.int32)
+    td = np.ascontiguousarray(t_desc, np.uint8); tn = np.ascontiguousarray(t_node, np.int32)
+    tk = np.ascontiguousarray(t_taken, np.uint8) if t_taken is not None else None
+    idx = np.full(max(len(qn), 1), -1, np.int32); dist = np.zeros(max(len(qn), 1), np.int32)
+    f = lib().ora_bow_tree_match
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p]
+    n = f(_p(qd), _p(qn), len(qn), _p(td), _p(tn), len(tn), _p(tk), int(hamming_thr), float(lowe_ratio), _p(idx), _p(dist))
+    return idx[:len(qn)], dist[:len(qn)], n
+
+
+def bow_vector(word_id, word_weight):
+    """BowVector of DBoW2 with TF_IDF weighting and L1 scoring: the weights of a word add up, then the vector is L1-normalised;
+    returns (sorted word ids, values)"""
+    acc = {}
+    for w, x in zip(word_id, word_weight):
+        if x > 0:
+            acc[int(w)] = acc.get(int(w), 0.0) + float(x)
+    ids = np.array(sorted(acc), np.int32)
+    val = np.array([acc[i] for i in ids], np.float64)
+    s = np.abs(val).sum()
+    return ids, (val / s if s > 0 else val)
+
+
+def bow_score_l1(a, b):
+    """DBoW2 L1Scoring::score: 1 - 0.5 |a - b|_1 over the common words' contribution (-sum(|ai - bi| - |ai| - |bi|) / 2)"""
+    ia, va = a; ib, vb = b
+    common, xa, xb = np.intersect1d(ia, ib, return_indices=True)
+    if len(common) == 0:
+        return 0.0
+    s = np.sum(np.abs(va[xa] - vb[xb]) - np.abs(va[xa]) - np.abs(vb[xb]))
+    return float(-s / 2.0)
