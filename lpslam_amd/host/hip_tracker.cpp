@@ -155,6 +155,24 @@ bool HipVslamTrackerBase::startContext(bool stereo)
     }
     m_maxKp = lpslam_hip_max_keypoints_per_image(m_ctx);
     lpslam_hip_level_info(m_ctx, nullptr, nullptr, nullptr, nullptr, m_scales);
+    // the DBoW2 vocabulary (reference: src/Trackers/OpenVSLAMTrackerBase.cpp:224-227 refuses to start without the file).  Here a
+    // missing file is not fatal: relocalisation and loop detection then pick their candidates by position.
+    m_bowDb.clear();
+    if (!m_vocabFile.empty()) {
+        Vocabulary voc; std::string err;
+        std::ifstream probe(m_vocabFile, std::ios::binary);
+        if (!probe) logMessage(LpSlamLogLevel_Info, "Vocab file " + m_vocabFile + " not present: place recognition by position instead of bag of words");
+        else if (!voc.load(m_vocabFile, err)) { logMessage(LpSlamLogLevel_Error, "Vocab file " + m_vocabFile + ": " + err); lpslam_hip_destroy(m_ctx); m_ctx = nullptr; return false; }
+        else if (lpslam_hip_vocab_create(m_ctx, voc.k, voc.L, voc.nodes(), voc.parent.data(), voc.desc.data(), voc.weight.data(), voc.is_leaf.data(), &m_vocab) != LPSLAM_HIP_OK) {
+            logMessage(LpSlamLogLevel_Error, std::string("Cannot load the vocabulary onto the device: ") + lpslam_hip_last_error());
+            lpslam_hip_destroy(m_ctx); m_ctx = nullptr; return false;
+        } else {
+            m_bowLevelsUp = voc.L - std::min(2, voc.L - 1);       // the FeatureVector groups at tree level 2 (upstream: L = 6, levels_up = 4)
+            int32_t nw = 0;
+            lpslam_hip_vocab_info(m_vocab, nullptr, nullptr, nullptr, &nw);
+            logMessage(LpSlamLogLevel_Info, "VSLAM vocabulary " + m_vocabFile + ": k=" + std::to_string(voc.k) + " L=" + std::to_string(voc.L) + " nodes=" + std::to_string(voc.nodes()) + " words=" + std::to_string(nw));
+        }
+    }
     m_stats = Statistics{};
     m_kfs.clear(); m_landmarks.clear(); m_replaced.clear(); m_nextLandmarkId = 0; m_refKf = -1; m_segment = 0; m_segmentStart = 0;
     m_stereo = stereo;
@@ -167,6 +185,7 @@ bool HipVslamTrackerBase::stop()
 {
     std::scoped_lock lock(m_slamLock);
     stopMappingThread();                               // the mapping thread uses the context
+    if (m_vocab) { lpslam_hip_vocab_destroy(m_vocab); m_vocab = nullptr; }
     if (m_ctx) { logStatistics(); lpslam_hip_destroy(m_ctx); m_ctx = nullptr; }
     m_started = false;
     return true;
@@ -345,6 +364,34 @@ void HipVslamTrackerBase::fuseInto(int c, int slot, const std::vector<int>& land
     }
 }
 
+// [UPSTREAM] data::keyframe::compute_bow: the BoW vector and the FeatureVector (node per keypoint) of a keyframe, on the device
+void HipVslamTrackerBase::computeBow(Keyframe& kf) const
+{
+    kf.bow.clear(); kf.node.clear();
+    if (!m_vocab || kf.kpts.empty()) return;
+    const int n = (int)kf.kpts.size();
+    std::vector<int32_t> word((size_t)n), node((size_t)n);
+    std::vector<float> weight((size_t)n);
+    if (lpslam_hip_bow_transform_host(m_ctx, m_vocab, kf.desc.data(), n, m_bowLevelsUp, word.data(), weight.data(), node.data()) != LPSLAM_HIP_OK) return;
+    kf.bow = make_bow_vector(word.data(), weight.data(), n);
+    kf.node = std::move(node);
+}
+
+// the same for the frame being tracked (its descriptors are on the device already)
+bool HipVslamTrackerBase::frameNodes(const FrameData& f, std::vector<int32_t>& node, BowVector* bow) const
+{
+    if (!m_vocab) return false;
+    std::vector<int32_t> word((size_t)m_maxKp), nd((size_t)m_maxKp);
+    std::vector<float> weight((size_t)m_maxKp);
+    int32_t n = 0;
+    if (lpslam_hip_bow_transform(m_ctx, m_vocab, f.slot, m_bowLevelsUp, word.data(), weight.data(), nd.data(), m_maxKp, &n) != LPSLAM_HIP_OK) return false;
+    if (n != (int32_t)f.kpts.size()) return false;
+    nd.resize((size_t)n);
+    node = std::move(nd);
+    if (bow) *bow = make_bow_vector(word.data(), weight.data(), n);
+    return true;
+}
+
 int HipVslamTrackerBase::insertKeyframe(FrameData& f)
 {
     const int c = (int)m_kfs.size();
@@ -388,6 +435,7 @@ int HipVslamTrackerBase::insertKeyframe(FrameData& f)
     }
     if (!m_stereo && c > m_segmentStart) monoTriangulate(c - 1, kf, f);
     kf.kpts = f.kpts; kf.desc = f.desc; kf.x_right = f.x_right; kf.depth = f.depth; kf.landmark = f.landmark;
+    if (m_vocab) { computeBow(kf); m_bowDb.add(c, kf.bow); }
     m_kfs.push_back(std::move(kf));
     // duplicates: the landmarks of the covisible keyframes that this keyframe does not hold are searched in it (match::fuse)
     {
@@ -863,6 +911,7 @@ bool HipVslamTrackerBase::monoInitialize(FrameData& cur)
     }
     k0.kpts = reff.kpts; k0.desc = reff.desc; k0.landmark = reff.landmark; k0.x_right.assign(reff.kpts.size(), -1.0f); k0.depth.assign(reff.kpts.size(), -1.0f);
     k1.kpts = cur.kpts; k1.desc = cur.desc; k1.landmark = cur.landmark; k1.x_right.assign(cur.kpts.size(), -1.0f); k1.depth.assign(cur.kpts.size(), -1.0f);
+    if (m_vocab) { computeBow(k0); m_bowDb.add((int)m_kfs.size(), k0.bow); computeBow(k1); m_bowDb.add((int)m_kfs.size() + 1, k1.bow); }
     m_kfs.push_back(std::move(k0)); m_kfs.push_back(std::move(k1));
     m_stats.keyframes += 2;
     m_framesSinceKeyframe = 0;
@@ -1017,20 +1066,46 @@ bool HipVslamTrackerBase::relocalise(FrameData& cur)
     }
     std::sort(near.begin(), near.end());
     if (near.size() > 8) near.resize(8);
+    // with a vocabulary the candidates come from the BoW database instead ([UPSTREAM] bow_database::acquire_relocalization_candidates):
+    // the keyframes that share the most words with the frame, best L1 score first -- wherever they are in the map
+    std::vector<int32_t> cur_node;
+    BowVector cur_bow;
+    const bool use_bow = m_vocab && !cur.kpts.empty() && frameNodes(cur, cur_node, &cur_bow);
+    if (use_bow) {
+        near.clear();
+        for (auto& sc : m_bowDb.query(cur_bow, {}, -1.0, std::numeric_limits<int>::max())) { near.emplace_back(-sc.first, sc.second); if (near.size() >= 8) break; }
+    }
     const int scratch = previousSlot(cur.slot);                    // the previous frame's slot pair: its device data is not needed while lost
     std::vector<int32_t> mq((size_t)m_maxKp), mt((size_t)m_maxKp), md((size_t)m_maxKp);
     for (auto& nc : near) {
         const Keyframe& kf = m_kfs[(size_t)nc.second];
         if (kf.kpts.empty()) continue;
-        if (lpslam_hip_set_descriptors(m_ctx, scratch, kf.desc.data(), (int32_t)kf.kpts.size()) != LPSLAM_HIP_OK) continue;
-        if (lpslam_hip_match_bf(m_ctx, cur.slot, scratch) != LPSLAM_HIP_OK) continue;
-        int32_t nm = 0;
-        if (lpslam_hip_get_bf_matches(m_ctx, cur.slot, scratch, 50, 0.75f, 1, mq.data(), mt.data(), md.data(), m_maxKp, &nm) != LPSLAM_HIP_OK) continue;
         std::vector<int> cur_idx, lm_ids;
-        for (int k = 0; k < nm; ++k) {
-            const int id = resolve(kf.landmark[(size_t)mt[k]]);
-            if (id < 0) continue;
-            cur_idx.push_back(mq[k]); lm_ids.push_back(id);
+        if (use_bow && kf.node.size() == kf.kpts.size()) {
+            // [UPSTREAM] match::bow_tree::match_frame_and_keyframe: the keyframe's keypoints that carry a landmark against the
+            // frame's keypoints under the same vocabulary node (Hamming <= 50, ratio 0.75), then the orientation check
+            std::vector<int32_t> qn(kf.node);
+            for (size_t i = 0; i < qn.size(); ++i) if (resolve(kf.landmark[i]) < 0) qn[i] = -1;
+            std::vector<int32_t> idx(kf.kpts.size(), -1);
+            int32_t nm = 0;
+            if (lpslam_hip_match_bow_tree(m_ctx, kf.desc.data(), qn.data(), (int32_t)qn.size(), cur.desc.data(), cur_node.data(), (int32_t)cur_node.size(), nullptr, 50, 0.75f,
+                                          idx.data(), nullptr, &nm) != LPSLAM_HIP_OK) continue;
+            std::vector<float> aq(kf.kpts.size()), at(cur.kpts.size());
+            for (size_t i = 0; i < aq.size(); ++i) aq[i] = kf.kpts[i].angle;
+            for (size_t i = 0; i < at.size(); ++i) at[i] = cur.kpts[i].angle;
+            int32_t kept = 0;
+            (void)lpslam_hip_match_orientation_filter(aq.data(), at.data(), idx.data(), (int32_t)idx.size(), &kept);
+            for (size_t i = 0; i < idx.size(); ++i) if (idx[i] >= 0) { cur_idx.push_back(idx[i]); lm_ids.push_back(resolve(kf.landmark[i])); }
+        } else {
+            if (lpslam_hip_set_descriptors(m_ctx, scratch, kf.desc.data(), (int32_t)kf.kpts.size()) != LPSLAM_HIP_OK) continue;
+            if (lpslam_hip_match_bf(m_ctx, cur.slot, scratch) != LPSLAM_HIP_OK) continue;
+            int32_t nm = 0;
+            if (lpslam_hip_get_bf_matches(m_ctx, cur.slot, scratch, 50, 0.75f, 1, mq.data(), mt.data(), md.data(), m_maxKp, &nm) != LPSLAM_HIP_OK) continue;
+            for (int k = 0; k < nm; ++k) {
+                const int id = resolve(kf.landmark[(size_t)mt[k]]);
+                if (id < 0) continue;
+                cur_idx.push_back(mq[k]); lm_ids.push_back(id);
+            }
         }
         if (cur_idx.size() < 15) continue;
         int inl = 0;
@@ -1071,6 +1146,19 @@ bool HipVslamTrackerBase::detectAndCloseLoop(FrameData& cur, int c)
     if (cands.empty()) return false;
     std::sort(cands.begin(), cands.end());
     if (cands.size() > 48) cands.resize(48);
+    // with a vocabulary: [UPSTREAM] loop_detector::detect_loop_candidates -- keyframes outside the covisibility that share words with
+    // the new keyframe and score (L1) at least as well as its worst covisible neighbour, best first, wherever the estimate puts them
+    const bool use_bow = m_vocab && kc.node.size() == kc.kpts.size() && !kc.bow.empty();
+    if (use_bow) {
+        double min_score = 1.0;
+        for (auto& kv : covis) { const BowVector* nb = m_bowDb.vector_of(kv.first); if (nb) min_score = std::min(min_score, bow_score_l1(kc.bow, *nb)); }
+        if (covis.empty()) min_score = 0.0;
+        std::unordered_map<int, char> exclude = covis;
+        exclude[c] = 1;
+        cands.clear();
+        for (auto& sc : m_bowDb.query(kc.bow, exclude, min_score, newest_candidate)) { cands.emplace_back(-sc.first, sc.second); if (cands.size() >= 8) break; }
+        if (cands.empty()) return false;
+    }
     const int scratch = previousSlot(cur.slot);                  // the previous frame's slot pair is free for the descriptors of a candidate
     std::vector<int32_t> mq((size_t)m_maxKp), mt((size_t)m_maxKp), md((size_t)m_maxKp);
     struct Vote { int kf; std::vector<std::pair<int, int>> pairs; };        // (keypoint of c, keypoint of the candidate), landmarks on both sides
@@ -1078,10 +1166,26 @@ bool HipVslamTrackerBase::detectAndCloseLoop(FrameData& cur, int c)
     for (auto& cd : cands) {
         const Keyframe& ka = m_kfs[(size_t)cd.second];
         if (ka.kpts.empty()) continue;
-        if (lpslam_hip_set_descriptors(m_ctx, scratch, ka.desc.data(), (int32_t)ka.kpts.size()) != LPSLAM_HIP_OK) continue;
-        if (lpslam_hip_match_bf(m_ctx, cur.slot, scratch) != LPSLAM_HIP_OK) continue;
         int32_t nm = 0;
-        if (lpslam_hip_get_bf_matches(m_ctx, cur.slot, scratch, 50, 0.75f, 1, mq.data(), mt.data(), md.data(), m_maxKp, &nm) != LPSLAM_HIP_OK) continue;
+        if (use_bow && ka.node.size() == ka.kpts.size()) {
+            // [UPSTREAM] match::bow_tree::match_keyframes: landmark-carrying keypoints of both keyframes under the same vocabulary node
+            std::vector<int32_t> qn(kc.node), tn(ka.node), idx(kc.kpts.size(), -1);
+            for (size_t i = 0; i < qn.size(); ++i) if (kc.landmark[i] < 0) qn[i] = -1;
+            for (size_t i = 0; i < tn.size(); ++i) if (ka.landmark[i] < 0) tn[i] = -1;
+            int32_t found = 0;
+            if (lpslam_hip_match_bow_tree(m_ctx, kc.desc.data(), qn.data(), (int32_t)qn.size(), ka.desc.data(), tn.data(), (int32_t)tn.size(), nullptr, 50, 0.75f,
+                                          idx.data(), nullptr, &found) != LPSLAM_HIP_OK) continue;
+            std::vector<float> aq(kc.kpts.size()), at(ka.kpts.size());
+            for (size_t i = 0; i < aq.size(); ++i) aq[i] = kc.kpts[i].angle;
+            for (size_t i = 0; i < at.size(); ++i) at[i] = ka.kpts[i].angle;
+            int32_t kept = 0;
+            (void)lpslam_hip_match_orientation_filter(aq.data(), at.data(), idx.data(), (int32_t)idx.size(), &kept);
+            for (size_t i = 0; i < idx.size(); ++i) if (idx[i] >= 0) { mq[(size_t)nm] = (int32_t)i; mt[(size_t)nm] = idx[i]; ++nm; }
+        } else {
+            if (lpslam_hip_set_descriptors(m_ctx, scratch, ka.desc.data(), (int32_t)ka.kpts.size()) != LPSLAM_HIP_OK) continue;
+            if (lpslam_hip_match_bf(m_ctx, cur.slot, scratch) != LPSLAM_HIP_OK) continue;
+            if (lpslam_hip_get_bf_matches(m_ctx, cur.slot, scratch, 50, 0.75f, 1, mq.data(), mt.data(), md.data(), m_maxKp, &nm) != LPSLAM_HIP_OK) continue;
+        }
         Vote v; v.kf = cd.second;
         for (int k = 0; k < nm; ++k)
             if (kc.landmark[(size_t)mq[k]] >= 0 && ka.landmark[(size_t)mt[k]] >= 0 && resolve(kc.landmark[(size_t)mq[k]]) != resolve(ka.landmark[(size_t)mt[k]])) v.pairs.emplace_back(mq[k], mt[k]);

@@ -8,6 +8,7 @@
 // optimisation, and on keyframes a local bundle adjustment over a sliding window (include/lpslam_hip.h).
 #pragma once
 #include "core.h"
+#include "bow.h"
 #include "../../include/lpslam_hip.h"
 
 #include <array>
@@ -56,6 +57,8 @@ protected:
         std::vector<lpslam_hip_keypoint> kpts; std::vector<uint8_t> desc; std::vector<float> x_right, depth;
         std::vector<int> landmark;                    // per keypoint: landmark id or -1
         int segment = 0;                              // map segment: a re-initialisation after a loss opens a new one
+        BowVector bow;                                // with a vocabulary: the keyframe's BoW vector and, per keypoint, the tree node it falls under
+        std::vector<int32_t> node;
     };
     struct Landmark {
         double p[3]; 
@@ -148,6 +151,12 @@ protected:
     // relocalisation / loop candidates once it is no longer needed) and the next one, whose front end is prefetched.
     static int slotOf(uint64_t frame_index) { return (int)(frame_index % 3) * 2; }
     static int previousSlot(int slot) { return ((slot / 2 + 2) % 3) * 2; }
+    // bag-of-words place recognition ([UPSTREAM] data::bow_vocabulary / bow_database): loaded from vocabFile when that file exists
+    lpslam_hip_vocab* m_vocab = nullptr;
+    int m_bowLevelsUp = 4;                              // FeatureVector level: 4 levels above the leaves as upstream, less for shallow trees
+    BowDatabase m_bowDb;
+    void computeBow(Keyframe& kf) const;
+    bool frameNodes(const FrameData& f, std::vector<int32_t>& node, BowVector* bow) const;
     struct Prefetched { bool valid = false; bool issued = false /* work may sit on the prefetch stream, valid or not */; const uint8_t* data = nullptr; TimeStamp timestamp{}; int slot = 0; bool stereo = false; } m_prefetched;
     void prefetchFrame(CameraQueueEntry const& cam, bool stereo);      // m_slamLock held
     CameraQueueEntry const* m_nextFrame = nullptr;

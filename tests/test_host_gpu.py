@@ -199,6 +199,32 @@ def test_loop_is_detected_and_closed(hiplib, tmp_path):
     assert abs(ang - want) < 1.0, (ang, want)
 
 
+def test_loop_is_closed_with_vocabulary_candidates(hiplib, tmp_path):
+    """The same full turn with a vocabulary: the loop candidates come from the BoW database (shared words, L1 score at least the
+    worst covisible neighbour's), their keypoints are matched with match::bow_tree, and the loop closes as it does with voting."""
+    import math
+    from lpslam_amd import _build, manager
+    from bow_util import VOCAB
+    _build.host_library()
+    w, h = 640, 480
+    frames, yaws = synth.turning_sequence(w, h)
+    log = tmp_path / "slam.log"
+    m = _stereo_manager(manager, w, h, '{"cameraSetup": "stereo", "vocabFile": "%s", "slamKeypoints": 1000, "numLevels": 4, "keyframeInterval": 3, "localWindow": 4, "loopClosure": true}' % VOCAB, log)
+    m.start()
+    _feed(m, frames)
+    m.stop()
+    st_log = manager.Manager.statistics(log)
+    assert "VSLAM vocabulary" in open(log, errors="replace").read()
+    assert st_log["loops_closed"] >= 1 and st_log["lost"] == 0 and st_log["global_ba"] >= 1 and st_log["loop_fused"] > 0
+    last = m.results[-1]
+    assert max(abs(last["p"][0]), abs(last["p"][1]), abs(last["p"][2])) < 0.15
+    q0, q1 = np.array(m.results[0]["q"]), np.array(last["q"])
+    ang = 2 * math.degrees(math.acos(min(1.0, abs(float(q0 @ q1)))))
+    want = math.degrees(yaws[-1]) % 360.0
+    want = min(want, 360.0 - want)
+    assert abs(ang - want) < 1.0, (ang, want)
+
+
 def _stereo_manager(manager, w, h, tracker_cfg, log=None, mask=None):
     k = synth.intrinsics(w, h)
     m = manager.Manager()
@@ -253,6 +279,39 @@ def test_tracking_loss_keeps_the_map_and_relocalises(hiplib, tmp_path):
     assert abs(zs[13] - 0.05 * 13) < 0.06 and abs(zs[19] - 0.05 * 19) < 0.08
     assert abs(m.results[13]["p"][0]) < 0.05 and abs(m.results[13]["p"][1]) < 0.05
     assert st.localization == 2
+
+
+def test_kidnapped_camera_relocalises_through_the_vocabulary(hiplib, tmp_path):
+    """After a loss the camera reappears at the START of its path, far from where it was lost: the eight keyframes nearest to the
+    last believed pose do not see that place, so relocalisation by position fails -- with a vocabulary (vocabFile, the reference's
+    required key: src/Trackers/OpenVSLAMTrackerBase.cpp:224-227) the candidates come from the BoW database, are matched with
+    match::bow_tree, and the tracker is back with the first textured frame."""
+    from lpslam_amd import _build, manager
+    from bow_util import VOCAB
+    _build.host_library()
+    w, h = 640, 480
+    seq = synth.StereoSequence(w, h, 4, n_points=6000)
+    blank = np.full((h, w), 110, np.uint8)
+    n_fwd = 64                                                       # 0.05 m per frame: 3.2 m of travel, ~16 keyframes
+    frames = [seq.frame(i) for i in range(n_fwd)] + [(blank, blank)] * 2 + [seq.frame(i) for i in (1, 2, 3, 4)]
+    results = {}
+    for name, cfg in (("bow", '"vocabFile": "%s", ' % VOCAB), ("position", '"vocabFile": "", ')):
+        log = tmp_path / (name + ".log")
+        m = _stereo_manager(manager, w, h, '{"cameraSetup": "stereo", %s"slamKeypoints": 1000, "numLevels": 4, "keyframeInterval": 4}' % cfg, log)
+        m.start()
+        _feed(m, frames)
+        m.stop()
+        results[name] = (m.results, manager.Manager.statistics(log), open(log, errors="replace").read())
+    res, st, text = results["bow"]
+    assert "VSLAM vocabulary" in text and "words=1000" in text
+    assert st["lost"] == 1 and st["relocalised"] == 1 and st["keyframes"] >= 12
+    valid = [r["valid"] for r in res]
+    assert all(valid[:n_fwd]) and not any(valid[n_fwd:n_fwd + 2]) and all(valid[n_fwd + 2:])
+    back = res[n_fwd + 2]                                             # frame 1 of the sequence again: 0.05 m from the origin along z
+    assert abs(back["p"][2] - 0.05) < 0.06 and abs(back["p"][0]) < 0.05 and abs(back["p"][1]) < 0.05
+    # without a vocabulary the nearest-by-position gate cannot find the place
+    res_p, st_p, _ = results["position"]
+    assert st_p["lost"] == 1 and st_p["relocalised"] == 0 and not any(r["valid"] for r in res_p[n_fwd:])
 
 
 def test_long_loss_starts_a_new_segment_at_the_last_pose(hiplib, tmp_path):
