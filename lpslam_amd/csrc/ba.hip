@@ -2249,6 +2249,11 @@ __global__ __launch_bounds__(64) void k_ba_collect(const BaView* __restrict__ vi
     for (int i = threadIdx.x; i < words; i += 64) dst_l[i] = src_l[i];
 }
 
+// host (page-locked, device-mapped) -> device by load / store: 16 bytes per lane and round, grid-stride
+__global__ __launch_bounds__(256) void k_copy_from_host(uint4* __restrict__ dst, const uint4* __restrict__ src, size_t n16)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
 // current state -> page-locked host memory (kernel stores over PCIe: no DMA packet, no engine queue)
 __global__ __launch_bounds__(256) void k_ba_state_to_host(const BaView* __restrict__ views, double* poses, double* points)
 {
@@ -2446,7 +2451,10 @@ int lpslam_hip_ba_create(lpslam_hip_ctx* ctx, const double* poses, const uint8_t
     if (b->n_free) memcpy(hs + o_free, free_pose.data(), (size_t)b->n_free * 4);
     if (n_obs) memcpy(hs + o_obs_in, obs, (size_t)n_obs * sizeof(lpslam_hip_ba_obs));
     hipStream_t s = b->stream;
-    BA_HIP(hipMemcpyAsync(base, hs, staged_bytes, hipMemcpyHostToDevice, s));
+    // the inputs come over PCIe by a KERNEL that reads the page-locked staging block, not by the DMA engine: a copy packet queues
+    // behind whatever the engine is busy with -- the front end's image uploads (0.9 ms per 16-frame step) held the next window's
+    // build back until the running solve had finished, and the mapping pipeline stalled (PCIe-inclusive rate 0.84 of the resident)
+    hipLaunchKernelGGL(k_copy_from_host, dim3(64), dim3(256), 0, s, (uint4*)base, (const uint4*)hs, (staged_bytes + 15) / 16);
     BA_HIP(hipMemsetAsync(base + z_begin, 0, z_end - z_begin, s));
     // ---- structure on the device (ba_build.inl)
     const lpslam_hip_ba_obs* d_obs = (const lpslam_hip_ba_obs*)(base + o_obs_in);
