@@ -389,7 +389,7 @@ __device__ __forceinline__ void obs_lin_body(BaView& v, int bid, int robust, int
 //      LDS; then thread (landmark l, component c) adds the shares of its landmark's segment of the chunk in ascending order -- the
 //      same sums, bit for bit, without the 72 bytes per observation going to memory and coming back in a launch of their own.
 //      The observation constants are read from their CSR-ordered copies (c_*), coalesced.
-constexpr int LAND_B = 16;
+constexpr int LAND_B = 32;
 __device__ __forceinline__ void land_lin_body(BaView& v, int bid, int robust, int points_fixed, int set)
 {
     ba_select_idx(v, set); ba_lin_set(v, set);

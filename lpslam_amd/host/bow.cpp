@@ -94,6 +94,19 @@ void BowDatabase::add(int kf, const BowVector& v)
     for (auto& e : v) m_inv[e.first].push_back(kf);
 }
 
+void BowDatabase::remove(int kf)
+{
+    auto it = m_vec.find(kf);
+    if (it == m_vec.end()) return;
+    for (auto& e : it->second) {
+        auto pl = m_inv.find(e.first);
+        if (pl == m_inv.end()) continue;
+        auto& v = pl->second;
+        v.erase(std::remove(v.begin(), v.end(), kf), v.end());
+    }
+    m_vec.erase(it);
+}
+
 std::vector<std::pair<double, int>> BowDatabase::query(const BowVector& q, const std::unordered_map<int, char>& exclude, double min_score, int max_kf_id) const
 {
     std::unordered_map<int, int> common;

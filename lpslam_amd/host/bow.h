@@ -38,6 +38,7 @@ double bow_score_l1(const BowVector& a, const BowVector& b);
 class BowDatabase {
 public:
     void add(int kf, const BowVector& v);
+    void remove(int kf);
     void clear() { m_inv.clear(); m_vec.clear(); }
     const BowVector* vector_of(int kf) const { auto it = m_vec.find(kf); return it == m_vec.end() ? nullptr : &it->second; }
     // keyframes that share words with `q`, without those in `exclude`: the ones with at least 0.8 x the largest number of common

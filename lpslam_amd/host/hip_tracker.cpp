@@ -70,7 +70,7 @@ HipVslamTrackerBase::HipVslamTrackerBase()
     o.optional("mapFilename", "map.db"); o.optional("maxLaserAge", 1.0);
     // runtime ORB parameters the reference hard-codes in its generated YAML (:193-198), plus device selection
     o.optional("numLevels", 3); o.optional("scaleFactor", 1.2); o.optional("iniFastThr", 20); o.optional("minFastThr", 7);
-    o.optional("device", 0); o.optional("keyframeInterval", 6); o.optional("localWindow", 10); o.optional("asyncMapping", true); o.optional("prefetch", true);
+    o.optional("device", 0); o.optional("keyframeInterval", 6); o.optional("localWindow", 10); o.optional("asyncMapping", true); o.optional("prefetch", true); o.optional("mapCulling", true);
 }
 
 HipVslamTrackerBase::~HipVslamTrackerBase() { stop(); }
@@ -90,7 +90,7 @@ void HipVslamTrackerBase::OnConfigurationUpdate()
     m_iniFastThr = o.getInteger("iniFastThr"); m_minFastThr = o.getInteger("minFastThr"); m_device = o.getInteger("device");
     m_keyframeInterval = std::max(1, o.getInteger("keyframeInterval")); m_localWindow = std::max(2, o.getInteger("localWindow"));
     m_asyncMapping = o.getBool("asyncMapping");
-    m_prefetch = o.getBool("prefetch");
+    m_prefetch = o.getBool("prefetch"); m_mapCulling = o.getBool("mapCulling");
 }
 
 bool HipVslamTrackerBase::startContext(bool stereo)
@@ -174,7 +174,7 @@ bool HipVslamTrackerBase::startContext(bool stereo)
         }
     }
     m_stats = Statistics{};
-    m_kfs.clear(); m_landmarks.clear(); m_replaced.clear(); m_nextLandmarkId = 0; m_refKf = -1; m_segment = 0; m_segmentStart = 0;
+    m_kfs.clear(); m_landmarks.clear(); m_replaced.clear(); m_freshLandmarks.clear(); m_nextLandmarkId = 0; m_refKf = -1; m_segment = 0; m_segmentStart = 0;
     m_stereo = stereo;
     m_state = TrackerState::NotInitialized;
     m_started = true;
@@ -185,6 +185,7 @@ bool HipVslamTrackerBase::stop()
 {
     std::scoped_lock lock(m_slamLock);
     stopMappingThread();                               // the mapping thread uses the context
+    stopPrefetchThread();
     if (m_vocab) { lpslam_hip_vocab_destroy(m_vocab); m_vocab = nullptr; }
     if (m_ctx) { logStatistics(); lpslam_hip_destroy(m_ctx); m_ctx = nullptr; }
     m_started = false;
@@ -428,6 +429,7 @@ int HipVslamTrackerBase::insertKeyframe(FrameData& f)
             id = m_nextLandmarkId++;
             lm.obs.emplace_back(c, (int)i);
             m_landmarks[id] = std::move(lm);
+            m_freshLandmarks.push_back(id);
             f.landmark[i] = id;
         } else if (id >= 0) {
             m_landmarks[id].obs.emplace_back(c, (int)i);
@@ -437,6 +439,10 @@ int HipVslamTrackerBase::insertKeyframe(FrameData& f)
     kf.kpts = f.kpts; kf.desc = f.desc; kf.x_right = f.x_right; kf.depth = f.depth; kf.landmark = f.landmark;
     if (m_vocab) { computeBow(kf); m_bowDb.add(c, kf.bow); }
     m_kfs.push_back(std::move(kf));
+    if (m_mapCulling) {
+        cullLandmarks(c);                                 // [UPSTREAM] mapping_module: remove_redundant_landmarks once the new keyframe is stored
+        for (size_t i = 0; i < f.landmark.size(); ++i) if (f.landmark[i] >= 0 && !m_landmarks.count(f.landmark[i])) f.landmark[i] = -1;
+    }
     // duplicates: the landmarks of the covisible keyframes that this keyframe does not hold are searched in it (match::fuse)
     {
         const std::vector<int> nb = covisible(c, m_localWindow - 1, 15);
@@ -606,7 +612,11 @@ bool HipVslamTrackerBase::trackLocalMap(FrameData& cur, int& n_inliers)
     std::vector<uint8_t> taken(cur.kpts.size(), 0);
     std::unordered_map<int, char> held;
     size_t held_on_entry = 0; int n_new = 0;
-    for (size_t i = 0; i < cur.kpts.size(); ++i) if (cur.landmark[i] >= 0) { taken[i] = 1; held[cur.landmark[i]] = 1; ++held_on_entry; }
+    for (size_t i = 0; i < cur.kpts.size(); ++i) if (cur.landmark[i] >= 0) {
+        taken[i] = 1; held[cur.landmark[i]] = 1; ++held_on_entry;
+        auto it = m_landmarks.find(cur.landmark[i]);
+        if (it != m_landmarks.end()) ++it->second.n_observable;      // [UPSTREAM] search_local_landmarks: the frame's own landmarks are observable
+    }
     std::vector<lpslam_hip_proj_query> q;
     std::vector<uint8_t> qd;
     std::vector<int> q_lm;
@@ -620,7 +630,7 @@ bool HipVslamTrackerBase::trackLocalMap(FrameData& cur, int& n_inliers)
             held[lid] = 1;
             auto it = m_landmarks.find(lid);
             if (it == m_landmarks.end()) continue;
-            const Landmark& lm = it->second;
+            Landmark& lm = it->second;
             const double* X = lm.p;
             const double pc[3] = {R.m[0] * X[0] + R.m[1] * X[1] + R.m[2] * X[2] + cur.pose.t[0], R.m[3] * X[0] + R.m[4] * X[1] + R.m[5] * X[2] + cur.pose.t[1],
                                   R.m[6] * X[0] + R.m[7] * X[1] + R.m[8] * X[2] + cur.pose.t[2]};
@@ -632,6 +642,7 @@ bool HipVslamTrackerBase::trackLocalMap(FrameData& cur, int& n_inliers)
             if (!(dist > 0) || dist < 0.8 * lm.min_valid || dist > 1.2 * lm.max_valid) continue;           // can_observe: scale range
             if ((ray[0] * lm.normal[0] + ray[1] * lm.normal[1] + ray[2] * lm.normal[2]) / dist < 0.5) continue;    // viewing angle < 60 deg
             const int lvl = std::min(std::max((int)std::ceil(std::log(lm.max_valid / dist) / log_sf), 0), n_levels - 1);
+            ++lm.n_observable;                           // in the frustum at a plausible scale: tracking expects to find it
             lpslam_hip_proj_query e{};
             e.x = (float)u; e.y = (float)v; e.x_right = m_stereo ? (float)(u - m_cam.focal_x_baseline / pc[2]) : -1.0f;
             e.radius = 5.0f * m_scales[lvl];
@@ -694,6 +705,88 @@ bool HipVslamTrackerBase::keyframeNeeded(int inliers) const
     if (m_refTracked > 0 && inliers < m_refTracked / 4) return true;
     if (m_framesSinceKeyframe >= std::max(1, m_keyframeInterval / 2) && m_refTracked > 0 && 10 * inliers < 6 * m_refTracked) return true;
     return false;
+}
+
+// ---- map maintenance ([UPSTREAM] module::local_map_cleaner) ---------------------------------------------------------------------
+// What keeps a long session bounded: landmarks that tracking keeps missing or that never gained a second (stereo) / third
+// (monocular) keyframe are dropped two keyframes after their creation; a keyframe 90 % of whose landmarks are seen by three other
+// keyframes at the same or a finer scale is redundant and leaves the map.  The reference reports the resulting counts
+// (/root/reference/src/Trackers/OpenVSLAMTrackerBase.cpp:438-452).
+void HipVslamTrackerBase::eraseLandmark(int id)
+{
+    auto it = m_landmarks.find(id);
+    if (it == m_landmarks.end()) return;
+    for (auto& o : it->second.obs) {
+        Keyframe& kf = m_kfs[(size_t)o.first];
+        if ((size_t)o.second < kf.landmark.size() && kf.landmark[(size_t)o.second] == id) kf.landmark[(size_t)o.second] = -1;
+    }
+    m_landmarks.erase(it);
+    ++m_stats.culled_landmarks;
+}
+
+void HipVslamTrackerBase::cullLandmarks(int cur_kf)
+{
+    const int num_obs_thr = m_stereo ? 3 : 2;
+    std::vector<int> keep;
+    for (int id : m_freshLandmarks) {
+        auto it = m_landmarks.find(id);
+        if (it == m_landmarks.end()) continue;                          // merged away or erased already
+        const Landmark& lm = it->second;
+        int n_obs = 0;
+        for (auto& o : lm.obs) { const Keyframe& kf = m_kfs[(size_t)o.first]; n_obs += (!kf.x_right.empty() && kf.x_right[(size_t)o.second] >= 0) ? 2 : 1; }
+        if ((double)lm.n_observed / (double)lm.n_observable < 0.3) eraseLandmark(id);
+        else if (lm.ref_kf + 2 <= cur_kf && n_obs <= num_obs_thr) eraseLandmark(id);
+        else if (lm.ref_kf + 3 <= cur_kf) continue;                   // reliable from now on
+        else keep.push_back(id);
+    }
+    m_freshLandmarks.swap(keep);
+}
+
+void HipVslamTrackerBase::cullKeyframes(int cur_kf)
+{
+    if (!m_mapCulling || cur_kf < 0 || cur_kf >= (int)m_kfs.size()) return;
+    const double depth_thr = m_stereo ? 40.0 * m_cam.focal_x_baseline / m_cam.f_x : 0.0;
+    for (int k : covisible(cur_kf, (int)m_kfs.size(), 15)) {
+        Keyframe& kf = m_kfs[(size_t)k];
+        if (kf.erased || k == 0 || k == m_refKf || m_kfs[(size_t)k - 1].segment != kf.segment) continue;      // the origin of a segment stays
+        int n_valid = 0, n_redundant = 0;
+        for (size_t i = 0; i < kf.landmark.size(); ++i) {
+            const int id = kf.landmark[i];
+            if (id < 0) continue;
+            auto it = m_landmarks.find(id);
+            if (it == m_landmarks.end()) continue;
+            if (m_stereo && (kf.depth[i] > depth_thr || kf.depth[i] < 0)) continue;
+            ++n_valid;
+            int n_obs = 0;
+            for (auto& o : it->second.obs) { const Keyframe& ko = m_kfs[(size_t)o.first]; n_obs += (!ko.x_right.empty() && ko.x_right[(size_t)o.second] >= 0) ? 2 : 1; }
+            if (n_obs <= 3) continue;
+            const int level = kf.kpts[i].octave;
+            int better = 0;
+            for (auto& o : it->second.obs) {
+                if (o.first == k) continue;
+                if (m_kfs[(size_t)o.first].kpts[(size_t)o.second].octave <= level + 1 && ++better >= 3) break;
+            }
+            if (better >= 3) ++n_redundant;
+        }
+        if (n_valid == 0 || (double)n_redundant < 0.9 * (double)n_valid) continue;
+        // erase: its observations leave the landmarks (a landmark left with two observation counts or fewer goes with it)
+        for (size_t i = 0; i < kf.landmark.size(); ++i) {
+            const int id = kf.landmark[i];
+            if (id < 0) continue;
+            kf.landmark[i] = -1;
+            auto it = m_landmarks.find(id);
+            if (it == m_landmarks.end()) continue;
+            auto& ob = it->second.obs;
+            for (size_t o = 0; o < ob.size(); ++o) if (ob[o].first == k && ob[o].second == (int)i) { ob.erase(ob.begin() + (long)o); break; }
+            int n_obs = 0;
+            for (auto& o : ob) { const Keyframe& ko = m_kfs[(size_t)o.first]; n_obs += (!ko.x_right.empty() && ko.x_right[(size_t)o.second] >= 0) ? 2 : 1; }
+            if (n_obs <= 2) eraseLandmark(id);
+        }
+        kf.erased = true;
+        kf.kpts.clear(); kf.kpts.shrink_to_fit(); kf.desc.clear(); kf.desc.shrink_to_fit(); kf.x_right.clear(); kf.depth.clear(); kf.landmark.clear(); kf.node.clear(); kf.bow.clear();
+        m_bowDb.remove(k);
+        ++m_stats.culled_keyframes;
+    }
 }
 
 // a bundle-adjustment problem over the given keyframes: landmarks seen by the free keyframes, observed at least twice among all
@@ -773,7 +866,9 @@ std::unique_ptr<HipVslamTrackerBase::MappingJob> HipVslamTrackerBase::prepareMap
     if ((int)v.size() > m_localWindow) v.resize((size_t)m_localWindow);
     std::vector<int> fixed;
     for (auto& e : v) fixed.push_back(e.second);
-    return prepareBundle(local, fixed);
+    auto job = prepareBundle(local, fixed);
+    if (job) job->keyframe = c;
+    return job;
 }
 
 // runs on the mapping thread: touches the job and the GPU only
@@ -821,6 +916,7 @@ void HipVslamTrackerBase::applyMapping(const MappingJob& job)
         if (ob.empty()) m_landmarks.erase(it);
     }
     ++m_stats.local_ba;
+    if (!job.global && job.keyframe >= 0) cullKeyframes(job.keyframe);      // [UPSTREAM] mapping_module: remove_redundant_keyframes after the local BA
 }
 
 // ---- monocular initialisation ([UPSTREAM] module::initializer::initialize for Monocular setups) ---------------------------------
@@ -1017,6 +1113,7 @@ void HipVslamTrackerBase::monoTriangulate(int prev_kf, Keyframe& kf, FrameData& 
         lm.obs.emplace_back(prev_kf, ip); lm.obs.emplace_back(c, ic);
         const int id = m_nextLandmarkId++;
         m_landmarks[id] = std::move(lm);
+        m_freshLandmarks.push_back(id);
         f.landmark[(size_t)ic] = id; prev.landmark[(size_t)ip] = id;
     }
     (void)kf;
@@ -1060,6 +1157,7 @@ bool HipVslamTrackerBase::relocalise(FrameData& cur)
     pose_centre(m_lastGoodPose.q, m_lastGoodPose.t, Cl);
     std::vector<std::pair<double, int>> near;
     for (size_t k = 0; k < m_kfs.size(); ++k) {
+        if (m_kfs[k].erased) continue;
         double C[3];
         pose_centre(m_kfs[k].pose.q, m_kfs[k].pose.t, C);
         near.emplace_back(std::sqrt((C[0] - Cl[0]) * (C[0] - Cl[0]) + (C[1] - Cl[1]) * (C[1] - Cl[1]) + (C[2] - Cl[2]) * (C[2] - Cl[2])), (int)k);
@@ -1138,7 +1236,7 @@ bool HipVslamTrackerBase::detectAndCloseLoop(FrameData& cur, int c)
     pose_centre(kc.pose.q, kc.pose.t, Cc);
     std::vector<std::pair<double, int>> cands;
     for (int a = 0; a <= newest_candidate; ++a) {
-        if (covis.count(a)) continue;
+        if (covis.count(a) || m_kfs[(size_t)a].erased) continue;
         double C[3];
         pose_centre(m_kfs[(size_t)a].pose.q, m_kfs[(size_t)a].pose.t, C);
         cands.emplace_back(std::sqrt((C[0] - Cc[0]) * (C[0] - Cc[0]) + (C[1] - Cc[1]) * (C[1] - Cc[1]) + (C[2] - Cc[2]) * (C[2] - Cc[2])), a);
@@ -1301,7 +1399,7 @@ bool HipVslamTrackerBase::detectAndCloseLoop(FrameData& cur, int c)
     // ---- global bundle adjustment over the keyframes of the loop ([UPSTREAM] loop_bundle_adjuster: 10 iterations), inline
     {
         std::vector<int> free_kfs, fixed_kfs{a0};
-        for (int k = a0 + 1; k <= c; ++k) free_kfs.push_back(k);
+        for (int k = a0 + 1; k <= c; ++k) if (!m_kfs[(size_t)k].erased) free_kfs.push_back(k);
         auto job = prepareBundle(free_kfs, fixed_kfs);
         if (job) {
             job->global = true;
@@ -1368,13 +1466,14 @@ void HipVslamTrackerBase::finishMapping()
 void HipVslamTrackerBase::logStatistics() const
 {
     const Statistics& s = m_stats;
-    char buf[768];
+    char buf[1024];
     const double per = s.frames > 0 ? 1e3 / (double)s.frames : 0.0;
     std::snprintf(buf, sizeof(buf), "VSLAM statistics: frames=%ld motion_tracked=%ld bf_tracked=%ld local_map_joined=%ld keyframes=%ld fused_added=%ld fused_merged=%ld "
                   "local_ba=%ld loops_closed=%ld loop_fused=%ld global_ba=%ld lost=%ld relocalised=%ld reinitialised=%ld nav_priors=%ld landmarks=%zu "
-                  "prefetched=%ld ms_per_frame=%.4f ms_front_end=%.4f ms_track=%.4f ms_local_map=%.4f ms_keyframe=%.4f ms_dev_upload=%.4f ms_dev_extract=%.4f ms_dev_get=%.4f ms_dev_match=%.4f ms_dev_pose=%.4f",
+                  "culled_landmarks=%ld culled_keyframes=%ld live_keyframes=%ld prefetched=%ld ms_per_frame=%.4f ms_front_end=%.4f ms_track=%.4f ms_local_map=%.4f ms_keyframe=%.4f ms_dev_upload=%.4f ms_dev_extract=%.4f ms_dev_get=%.4f ms_dev_match=%.4f ms_dev_pose=%.4f",
                   s.frames, s.motion_tracked, s.bf_tracked, s.local_map_joined, s.keyframes, s.fused_added, s.fused_merged, s.local_ba, s.loops_closed, s.loop_fused,
-                  s.global_ba, s.lost, s.relocalised, s.reinitialised, s.nav_priors, m_landmarks.size(), s.prefetched,
+                  s.global_ba, s.lost, s.relocalised, s.reinitialised, s.nav_priors, m_landmarks.size(), s.culled_landmarks, s.culled_keyframes,
+                  (long)std::count_if(m_kfs.begin(), m_kfs.end(), [](const Keyframe& k) { return !k.erased; }), s.prefetched,
                   s.t_total * per, s.t_front * per, s.t_track * per, s.t_local * per, s.t_keyframe * per,
                   s.t_dev_upload * per, s.t_dev_extract * per, s.t_dev_get * per, s.t_dev_match * per, s.t_dev_pose * per);
     logMessage(LpSlamLogLevel_Info, buf);
@@ -1418,6 +1517,49 @@ void HipVslamTrackerBase::prefetchFrame(CameraQueueEntry const& cam, bool stereo
     if (lpslam_hip_prefetch_end(m_ctx) != LPSLAM_HIP_OK || !ok) return;
     m_prefetched.valid = true; m_prefetched.data = cam.image.pixels.data(); m_prefetched.timestamp = cam.timestamp;
     m_prefetched.slot = slot; m_prefetched.stereo = stereo;
+}
+
+void HipVslamTrackerBase::prefetchLoop()
+{
+    std::unique_lock<std::mutex> lk(m_pfMutex);
+    for (;;) {
+        m_pfCv.wait(lk, [this] { return m_pfQuit || m_pfJob; });
+        if (m_pfQuit) return;
+        const CameraQueueEntry* job = m_pfJob;
+        const bool stereo = m_pfStereo;
+        lk.unlock();
+        prefetchFrame(*job, stereo);
+        lk.lock();
+        m_pfJob = nullptr; m_pfBusy = false;
+        m_pfCv.notify_all();
+    }
+}
+
+void HipVslamTrackerBase::prefetchSubmit(const CameraQueueEntry* next, bool stereo)
+{
+    if (!m_pfThread.joinable()) m_pfThread = std::thread([this] { prefetchLoop(); });
+    std::lock_guard<std::mutex> lk(m_pfMutex);
+    m_pfJob = next; m_pfStereo = stereo; m_pfBusy = true;
+    m_pfCv.notify_all();
+}
+
+void HipVslamTrackerBase::prefetchWait()
+{
+    std::unique_lock<std::mutex> lk(m_pfMutex);
+    m_pfCv.wait(lk, [this] { return !m_pfBusy; });
+}
+
+void HipVslamTrackerBase::stopPrefetchThread()
+{
+    if (!m_pfThread.joinable()) return;
+    {
+        std::unique_lock<std::mutex> lk(m_pfMutex);
+        m_pfCv.wait(lk, [this] { return !m_pfBusy; });
+        m_pfQuit = true;
+        m_pfCv.notify_all();
+    }
+    m_pfThread.join();
+    m_pfQuit = false;
 }
 
 TrackerBase::ProcessImageResult HipVslamTrackerBase::trackFrame(CameraQueueEntry& cam, bool stereo, const std::optional<GlobalStateInTime>& navOdom)
@@ -1486,8 +1628,8 @@ TrackerBase::ProcessImageResult HipVslamTrackerBase::trackFrame(CameraQueueEntry
     // The next frame's upload + front end: a helper thread stages and enqueues it (0.2 ms of host time at 1280x720 stereo, mostly the
     // copy of the cold frame into page-locked memory) on the context's prefetch stream while this thread goes on tracking; the
     // future joins before this call returns (the frame is only valid that long) and on every early return.
-    std::future<void> prefetching;
-    if (m_nextFrame && m_prefetch) prefetching = std::async(std::launch::async, [this, next = m_nextFrame, stereo] { prefetchFrame(*next, stereo); });
+    struct PrefetchJoin { HipVslamTrackerBase* t; ~PrefetchJoin() { t->prefetchWait(); } } prefetching{this};
+    if (m_nextFrame && m_prefetch) prefetchSubmit(m_nextFrame, stereo);
     auto t_mark = std::chrono::steady_clock::now();
     auto lap = [&t_mark](double& acc) { const auto now = std::chrono::steady_clock::now(); acc += std::chrono::duration<double>(now - t_mark).count(); t_mark = now; };
     m_stats.t_front += std::chrono::duration<double>(t_mark - t0).count();
@@ -1537,6 +1679,7 @@ TrackerBase::ProcessImageResult HipVslamTrackerBase::trackFrame(CameraQueueEntry
         if (tracked) {
             int with_local_map = 0;
             if (trackLocalMap(cur, with_local_map)) inliers = with_local_map;      // else: the motion-model result stands
+            for (int id : cur.landmark) if (id >= 0) { auto it = m_landmarks.find(id); if (it != m_landmarks.end()) ++it->second.n_observed; }      // inliers of the final pose optimisation
             lap(m_stats.t_local);
             // velocity = T_cur * T_prev^-1
             const Mat3 Rc = quatToRot(cur.pose.q), Rp = quatToRot(m_prev.pose.q);
@@ -1623,7 +1766,7 @@ LpSlamStatus HipVslamTrackerBase::getSlamStatus()
     default: s.localization = LpSlamLocalization_Initializing; break;
     }
     s.frame_time = m_lastFrameSeconds;
-    s.key_frames = (long)m_kfs.size();
+    s.key_frames = (long)std::count_if(m_kfs.begin(), m_kfs.end(), [](const Keyframe& k) { return !k.erased; });      // redundant keyframes leave the map
     s.feature_points = (long)m_landmarks.size();
     return s;
 }

@@ -57,6 +57,7 @@ protected:
         std::vector<lpslam_hip_keypoint> kpts; std::vector<uint8_t> desc; std::vector<float> x_right, depth;
         std::vector<int> landmark;                    // per keypoint: landmark id or -1
         int segment = 0;                              // map segment: a re-initialisation after a loss opens a new one
+        bool erased = false;                          // culled as redundant: holds no keypoints and no observations any more (the index stays)
         BowVector bow;                                // with a vocabulary: the keyframe's BoW vector and, per keypoint, the tree node it falls under
         std::vector<int32_t> node;
     };
@@ -68,10 +69,14 @@ protected:
         double normal[3] = {0, 0, 1};
         double max_valid = 0, min_valid = 0;
         int ref_kf = -1;                              // the keyframe that created it (loop correction moves it with that keyframe)
+        // [UPSTREAM] data::landmark num_observable_ / num_observed_ (both start at 1): how often tracking expected to see the landmark
+        // and how often it did -- local_map_cleaner::remove_redundant_landmarks drops the ones seen less than 30 % of the time
+        int n_observable = 1, n_observed = 1;
         std::vector<std::pair<int, int>> obs;         // (keyframe, keypoint) in insertion order
     };
     struct Statistics {                               // logged at stop() ("VSLAM statistics: ..."): what the tracker did, for logs and tests
         long frames = 0, motion_tracked = 0, bf_tracked = 0, local_map_joined = 0, keyframes = 0, fused_added = 0, fused_merged = 0;
+        long culled_landmarks = 0, culled_keyframes = 0;
         long local_ba = 0, loops_closed = 0, loop_fused = 0, global_ba = 0, lost = 0, relocalised = 0, reinitialised = 0, nav_priors = 0, prefetched = 0;
         // where the frames' time went (seconds, summed): front end (upload, extraction, stereo, read-back), tracking against the
         // previous frame, local-map tracking, keyframe work on the tracking thread (insertion, fusion, loop search, BA set-up / wait)
@@ -119,6 +124,7 @@ protected:
         std::vector<int> ids;                         // landmark id of every BA point
         std::vector<int> kfs;                         // keyframe of every BA pose
         bool global = false;                          // loop-time global BA: plain robust iterations, no outlier pass
+        int keyframe = -1;                            // local BA: the keyframe it was started for (redundant-keyframe culling follows it)
         bool solved = false;
     };
     std::unique_ptr<MappingJob> prepareMapping(int c);
@@ -151,6 +157,12 @@ protected:
     // relocalisation / loop candidates once it is no longer needed) and the next one, whose front end is prefetched.
     static int slotOf(uint64_t frame_index) { return (int)(frame_index % 3) * 2; }
     static int previousSlot(int slot) { return ((slot / 2 + 2) % 3) * 2; }
+    // map maintenance ([UPSTREAM] module::local_map_cleaner, run by the mapping module around every local BA)
+    bool m_mapCulling = true;
+    std::vector<int> m_freshLandmarks;                  // landmarks younger than three keyframes
+    void cullLandmarks(int cur_kf);
+    void cullKeyframes(int cur_kf);
+    void eraseLandmark(int id);
     // bag-of-words place recognition ([UPSTREAM] data::bow_vocabulary / bow_database): loaded from vocabFile when that file exists
     lpslam_hip_vocab* m_vocab = nullptr;
     int m_bowLevelsUp = 4;                              // FeatureVector level: 4 levels above the leaves as upstream, less for shallow trees
@@ -188,6 +200,15 @@ protected:
     bool m_haveMonoRef = false;
     std::vector<float> m_monoPrevMatched;             // ... and where each of its keypoints was last matched (x, y)
     // the mapping thread (one per tracker, started with the context): a one-slot mailbox each way
+    // the prefetch helper: ONE persistent thread (a std::async per frame spawned and joined a thread every frame)
+    std::thread m_pfThread;
+    std::mutex m_pfMutex;
+    std::condition_variable m_pfCv;
+    const CameraQueueEntry* m_pfJob = nullptr; bool m_pfStereo = false, m_pfBusy = false, m_pfQuit = false;
+    void prefetchLoop();
+    void prefetchSubmit(const CameraQueueEntry* next, bool stereo);
+    void prefetchWait();
+    void stopPrefetchThread();
     std::thread m_mapThread;
     std::mutex m_mapMutex;
     std::condition_variable m_mapCv;

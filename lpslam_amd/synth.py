@@ -100,14 +100,14 @@ class StereoSequence:
         return left, right
 
 
-def turning_sequence(width, height, n_frames=132, step_deg=3.0, seq_id=4, n_points=9000):
+def turning_sequence(width, height, n_frames=132, step_deg=3.0, seq_id=4, n_points=9000, radius=(5.0, 25.0)):
     """A full turn on the spot inside a ring of structure (loop-closure tests, tests/golden/g14_track_loop.npz): stereo frames of a
     camera at the origin turning by `step_deg` per frame about its y axis; the background is a panorama fixed to the WORLD (the
     generator's own background is fixed to the image).  Returns (frames, yaws)."""
     k = intrinsics(width, height)
     seq = StereoSequence(width, height, seq_id, n_points=n_points)
     rng = np.random.default_rng(21)
-    az = rng.uniform(0, 2 * np.pi, n_points); rad = rng.uniform(5.0, 25.0, n_points)
+    az = rng.uniform(0, 2 * np.pi, n_points); rad = rng.uniform(radius[0], radius[1], n_points)
     seq.pts = np.stack([rad * np.sin(az), rng.uniform(-4, 4, n_points), rad * np.cos(az)], axis=1)       # structure all around the camera
     pano = _value_noise(np.random.Generator(np.random.PCG64(77)), 1200, 7200)                            # 0.05 degrees per pixel
     uu, vv = np.meshgrid((np.arange(width) - k["cx"]) / k["fx"], (np.arange(height) - k["cy"]) / k["fy"])

@@ -85,7 +85,7 @@ class StereoTracker:
     """Mirror of HipStereoTracker, asyncMapping false or true, loopClosure false or true; frames fed one by one with feed(left, right[, t])."""
 
     def __init__(self, width, height, cam, max_keypoints=1000, num_levels=4, scale_factor=1.2, keyframe_interval=4, local_window=10,
-                 nav_identity=True, async_mapping=False, time_to_relocalize=3.0, loop_closure=False):
+                 nav_identity=True, async_mapping=False, time_to_relocalize=3.0, loop_closure=False, map_culling=True):
         self.w, self.h, self.cam = width, height, dict(cam)
         self.p = O.params(max_keypoints, scale_factor, num_levels)
         self.scales = O.scale_factors(self.p)[0]                   # float32, as lpslam_hip_level_info returns them
@@ -101,12 +101,15 @@ class StereoTracker:
         self.tracking = False
         self.n_frames = 0
         self.stats = dict(motion_tracked=0, bf_tracked=0, local_map_joined=0, keyframes=0, fused_added=0, fused_merged=0, local_ba=0,
-                          lost=0, relocalised=0, reinitialised=0, loops_closed=0, loop_fused=0, global_ba=0)
+                          lost=0, relocalised=0, reinitialised=0, loops_closed=0, loop_fused=0, global_ba=0,
+                          culled_landmarks=0, culled_keyframes=0)
         # asyncMapping (the product's default): the local BA of keyframe c is prepared from the map as it is right after c's insertion,
         # solved beside the tracking of the following frames, and ENTERS the map right before the next keyframe is inserted
         # (HipVslamTrackerBase::startMapping / finishMapping) -- the order of events does not depend on how long the solve takes
         self.async_mapping = async_mapping
         self.loop_closure = loop_closure
+        self.map_culling = map_culling
+        self.fresh = []                                             # landmarks younger than three keyframes (local_map_cleaner)
         self.segment = 0
         self.pending = None
         self.time_to_relocalize = float(time_to_relocalize)
@@ -257,6 +260,8 @@ class StereoTracker:
         for i, lid in enumerate(cur.landmark):
             if lid >= 0:
                 taken[i] = 1; held.add(lid); held_on_entry += 1
+                if lid in self.landmarks:
+                    self.landmarks[lid]["n_observable"] += 1
         if self.ref_kf < 0:
             return True, held_on_entry
         local = sorted(self.covisible(self.ref_kf, self.local_window - 1, 15) + [self.ref_kf])
@@ -276,6 +281,7 @@ class StereoTracker:
                 lvl = self._view_level(lm, lm["p"], C)
                 if lvl is None:
                     continue
+                lm["n_observable"] += 1
                 q_rows.append((F32(u), F32(v), F32(u - self.cam["fxb"] / pc[2]), F32(5.0) * self.scales[lvl], max(0, lvl - 1), lvl))
                 qd.append(lm["desc"]); q_lm.append(lid)
         n_new = 0
@@ -379,6 +385,84 @@ class StereoTracker:
                 self.stats["fused_merged"] += 1; n_fused += 1
         return n_fused
 
+    # ---- map maintenance (HipVslamTrackerBase::cullLandmarks / cullKeyframes; [UPSTREAM] module::local_map_cleaner) -------------------
+    def _n_obs(self, lm):
+        """data::landmark::num_observations: a stereo observation counts twice"""
+        return sum(2 if self.kfs[k]["x_right"][kp] >= 0 else 1 for (k, kp) in lm["obs"])
+
+    def erase_landmark(self, lid):
+        lm = self.landmarks.pop(lid, None)
+        if lm is None:
+            return
+        for (k, kp) in lm["obs"]:
+            kl = self.kfs[k]["landmark"]
+            if kp < len(kl) and kl[kp] == lid:
+                kl[kp] = -1
+        self.stats["culled_landmarks"] += 1
+
+    def cull_landmarks(self, cur_kf):
+        keep = []
+        for lid in self.fresh:
+            lm = self.landmarks.get(lid)
+            if lm is None:
+                continue
+            if lm["n_observed"] / lm["n_observable"] < 0.3:
+                self.erase_landmark(lid)
+            elif lm["ref_kf"] + 2 <= cur_kf and self._n_obs(lm) <= 3:
+                self.erase_landmark(lid)
+            elif lm["ref_kf"] + 3 <= cur_kf:
+                continue
+            else:
+                keep.append(lid)
+        self.fresh = keep
+
+    def cull_keyframes(self, cur_kf):
+        if not self.map_culling or cur_kf < 0 or cur_kf >= len(self.kfs):
+            return
+        depth_thr = 40.0 * self.cam["fxb"] / self.cam["fx"]
+        for k in self.covisible(cur_kf, len(self.kfs), 15):
+            kf = self.kfs[k]
+            if kf["erased"] or k == 0 or k == self.ref_kf or self.kfs[k - 1]["segment"] != kf["segment"]:
+                continue
+            n_valid = n_red = 0
+            for i, lid in enumerate(kf["landmark"]):
+                if lid < 0 or lid not in self.landmarks:
+                    continue
+                if kf["depth"][i] > depth_thr or kf["depth"][i] < 0:
+                    continue
+                n_valid += 1
+                lm = self.landmarks[lid]
+                if self._n_obs(lm) <= 3:
+                    continue
+                level = int(kf["kpts"]["octave"][i])
+                better = 0
+                for (ko, kp) in lm["obs"]:
+                    if ko == k:
+                        continue
+                    if int(self.kfs[ko]["kpts"]["octave"][kp]) <= level + 1:
+                        better += 1
+                        if better >= 3:
+                            break
+                if better >= 3:
+                    n_red += 1
+            if n_valid == 0 or n_red < 0.9 * n_valid:
+                continue
+            for i, lid in enumerate(list(kf["landmark"])):
+                if lid < 0:
+                    continue
+                kf["landmark"][i] = -1
+                lm = self.landmarks.get(lid)
+                if lm is None:
+                    continue
+                for o_i, o in enumerate(lm["obs"]):
+                    if o == (k, i):
+                        del lm["obs"][o_i]; break
+                if self._n_obs(lm) <= 2:
+                    self.erase_landmark(lid)
+            kf["erased"] = True
+            kf["kpts"] = kf["kpts"][:0]; kf["desc"] = kf["desc"][:0]; kf["x_right"] = kf["x_right"][:0]; kf["depth"] = kf["depth"][:0]; kf["landmark"] = []
+            self.stats["culled_keyframes"] += 1
+
     def insert_keyframe(self, f):
         c = len(self.kfs)
         baseline = self.cam["fxb"] / self.cam["fx"]
@@ -400,14 +484,18 @@ class StereoTracker:
                 z = float(f.depth[i])
                 xc = (float(f.kpts["x"][i]) - self.cam["cx"]) * z / self.cam["fx"]; yc = (float(f.kpts["y"][i]) - self.cam["cy"]) * z / self.cam["fy"]
                 d = [xc - f.pose.t[0], yc - f.pose.t[1], z - f.pose.t[2]]
-                lm = dict(p=[R[0, a] * d[0] + R[1, a] * d[1] + R[2, a] * d[2] for a in range(3)], ref_kf=c, obs=[(c, i)])
+                lm = dict(p=[R[0, a] * d[0] + R[1, a] * d[1] + R[2, a] * d[2] for a in range(3)], ref_kf=c, obs=[(c, i)], n_observable=1, n_observed=1)
                 self.init_landmark_view(lm, f.pose, f.kpts["octave"][i], f.desc[i])
                 lid = self.next_id; self.next_id += 1
                 self.landmarks[lid] = lm
+                self.fresh.append(lid)
                 f.landmark[i] = lid
             elif lid >= 0:
                 self.landmarks[lid]["obs"].append((c, i))
-        self.kfs.append(dict(pose=f.pose.copy(), kpts=f.kpts, desc=f.desc, x_right=f.x_right, depth=f.depth, landmark=list(f.landmark), segment=self.segment))
+        self.kfs.append(dict(pose=f.pose.copy(), kpts=f.kpts, desc=f.desc, x_right=f.x_right, depth=f.depth, landmark=list(f.landmark), segment=self.segment, erased=False))
+        if self.map_culling:
+            self.cull_landmarks(c)
+            f.landmark = [l if (l < 0 or l in self.landmarks) else -1 for l in f.landmark]
         nb = self.covisible(c, self.local_window - 1, 15)
         held = set(l for l in self.kfs[c]["landmark"] if l >= 0)
         ids = []
@@ -463,7 +551,10 @@ class StereoTracker:
                         cnt[ok_] = cnt.get(ok_, 0) + 1
         v = sorted(((n, k) for k, n in cnt.items()), key=lambda e: (-e[0], -e[1]))[:self.local_window]
         fixed_kfs = [k for _, k in v]
-        return self.prepare_bundle(local, fixed_kfs)
+        job = self.prepare_bundle(local, fixed_kfs)
+        if job is not None:
+            job["keyframe"] = c
+        return job
 
     def prepare_bundle(self, free_kfs, fixed_kfs):
         """HipVslamTrackerBase::prepareBundle: landmarks seen by the free keyframes and observed at least twice among all"""
@@ -536,6 +627,8 @@ class StereoTracker:
             if not ob:
                 del self.landmarks[lid]
         self.stats["local_ba"] += 1
+        if not job["is_global"] and job.get("keyframe", -1) >= 0:
+            self.cull_keyframes(job["keyframe"])
 
     # ---- loop closing (HipVslamTrackerBase::detectAndCloseLoop) ---------------------------------------------------------------------
     @staticmethod
@@ -556,7 +649,7 @@ class StereoTracker:
         Cc = self._centre(kc["pose"])
         cands = []
         for a in range(newest + 1):
-            if a in covis:
+            if a in covis or self.kfs[a]["erased"]:
                 continue
             C = self._centre(self.kfs[a]["pose"])
             cands.append((math.sqrt((C[0] - Cc[0]) * (C[0] - Cc[0]) + (C[1] - Cc[1]) * (C[1] - Cc[1]) + (C[2] - Cc[2]) * (C[2] - Cc[2])), a))
@@ -641,7 +734,7 @@ class StereoTracker:
         self.stats["loop_fused"] += self.fuse_into(c, ids, cur)
         self.stats["fused_added"], self.stats["fused_merged"] = before       # the loop's fusions are counted apart (loop_fused)
         # ---- global bundle adjustment over the keyframes of the loop, inline
-        job = self.prepare_bundle(list(range(a0 + 1, c + 1)), [a0])
+        job = self.prepare_bundle([k for k in range(a0 + 1, c + 1) if not self.kfs[k]["erased"]], [a0])
         if job is not None:
             job["is_global"] = True
             self.solve_mapping(job)
@@ -671,6 +764,8 @@ class StereoTracker:
         Cl = self._centre(self.last_good)
         near = []
         for k, kf in enumerate(self.kfs):
+            if kf["erased"]:
+                continue
             C = self._centre(kf["pose"])
             near.append((math.sqrt((C[0] - Cl[0]) * (C[0] - Cl[0]) + (C[1] - Cl[1]) * (C[1] - Cl[1]) + (C[2] - Cl[2]) * (C[2] - Cl[2])), k))
         near.sort()
@@ -742,6 +837,9 @@ class StereoTracker:
             ok2, wl = self.track_local_map(cur)
             if ok2:
                 inliers = wl
+            for lid in cur.landmark:
+                if lid >= 0 and lid in self.landmarks:
+                    self.landmarks[lid]["n_observed"] += 1
             Rc, Rp = quat_to_rot(cur.pose.q), quat_to_rot(self.prev.pose.q)
             Rv = np.array([[Rc[r, 0] * Rp[c, 0] + Rc[r, 1] * Rp[c, 1] + Rc[r, 2] * Rp[c, 2] for c in range(3)] for r in range(3)])
             vt = [cur.pose.t[r] - (Rv[r, 0] * self.prev.pose.t[0] + Rv[r, 1] * self.prev.pose.t[1] + Rv[r, 2] * self.prev.pose.t[2]) for r in range(3)]

@@ -199,6 +199,41 @@ def test_loop_is_detected_and_closed(hiplib, tmp_path):
     assert abs(ang - want) < 1.0, (ang, want)
 
 
+def test_map_stays_bounded_over_a_long_session(hiplib, tmp_path):
+    """Two and a half turns inside the same ring of structure (300 frames): after the first lap the camera sees nothing new, so
+    the map must stop growing -- landmarks that are not confirmed and keyframes that have become redundant leave it ([UPSTREAM]
+    module::local_map_cleaner; the reference reports the counts, src/Trackers/OpenVSLAMTrackerBase.cpp:438-452) -- and a frame of
+    the last lap must not cost more than a frame of the first."""
+    from lpslam_amd import _build, manager
+    _build.host_library()
+    w, h = 640, 480
+    frames, _ = synth.turning_sequence(w, h, 300, radius=(1.5, 4.5))      # close structure: redundancy only counts landmarks within 40 baselines
+    log = tmp_path / "slam.log"
+    from bow_util import VOCAB
+    m = _stereo_manager(manager, w, h, '{"cameraSetup": "stereo", "vocabFile": "%s", "slamKeypoints": 1000, "numLevels": 4, "keyframeInterval": 3, "localWindow": 10, "loopClosure": true}' % VOCAB, log)
+    m.start()
+    marks = []
+    for lo, hi in ((0, 90), (90, 150), (150, 210), (210, 300)):
+        t0 = time.time()
+        for i in range(lo, hi):
+            assert m.add_stereo((i + 1) * 40_000_000, frames[i][0], frames[i][1])
+        while len(m.results) < hi and time.time() - t0 < 60:
+            time.sleep(0.002)
+        st = m.status()
+        marks.append(((time.time() - t0) / (hi - lo), int(st.key_frames), int(st.feature_points)))
+    m.stop()
+    s = manager.Manager.statistics(log)
+    assert len(m.results) == 300 and s["lost"] == 0
+    assert s["culled_landmarks"] > 500 and s["culled_keyframes"] >= 10
+    (t_first, kf_a, lm_a), (_, kf_lap, lm_lap), _, (t_last, kf_end, lm_end) = marks
+    # one lap is 120 frames: at frame 150 the ring has been seen once; 150 more frames add (almost) nothing
+    assert kf_end <= 1.25 * kf_lap and lm_end <= 1.25 * lm_lap, (marks,)
+    assert s["live_keyframes"] == kf_end and s["keyframes"] > kf_end
+    assert t_last <= 1.3 * t_first, (marks,)
+    print("long session: %.3f -> %.3f ms per frame, keyframes %d -> %d -> %d live of %d inserted, landmarks %d -> %d -> %d" %
+          (1e3 * t_first, 1e3 * t_last, kf_a, kf_lap, kf_end, s["keyframes"], lm_a, lm_lap, lm_end))
+
+
 def test_loop_is_closed_with_vocabulary_candidates(hiplib, tmp_path):
     """The same full turn with a vocabulary: the loop candidates come from the BoW database (shared words, L1 score at least the
     worst covisible neighbour's), their keypoints are matched with match::bow_tree, and the loop closes as it does with voting."""

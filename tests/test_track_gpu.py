@@ -98,7 +98,7 @@ def test_tracked_poses_follow_the_closed_loop_oracle(hiplib, tmp_path, case):
         assert ang < ROT_TOL and dp < TRANS_TOL, (i, ang, dp)
     # the same discrete history: keyframes, motion-model frames, local BA runs, fused duplicates, losses
     for key in ("keyframes", "motion_tracked", "bf_tracked", "local_map_joined", "fused_added", "fused_merged", "local_ba", "lost", "relocalised", "reinitialised",
-                "loops_closed", "loop_fused", "global_ba"):
+                "loops_closed", "loop_fused", "global_ba", "culled_landmarks", "culled_keyframes"):
         if "stat_" + key in g.files:
             assert stats[key] == int(g["stat_" + key]), (key, stats[key], int(g["stat_" + key]))
     print("closed loop %s: worst rotation %.2e rad, worst position %.2e m over %d frames" % (case, worst_rot, worst_pos, n))
