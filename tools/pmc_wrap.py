@@ -8,14 +8,23 @@ src = os.path.join(root, "gpurun_out")
 dst = os.path.join(root, "profiles")
 k = json.load(open(os.path.join(src, tag + "_pmc_kernels.json")))
 k = {name.replace("void ", "").replace("<true>", "").replace("<false>", ""): v for name, v in k.items()}
+# MI355X_MICROARCH.md, HBM: on gfx950 FETCH_SIZE reports exactly half of the bytes of a wide coalesced read (16 B per lane); other
+# access widths are uncalibrated.  Kernels whose global reads are 16-byte per lane get fetch_correction 2, the others stay as counted.
+WIDE16 = {"k_chol_pair", "k_chol_wg", "k_ba_schur", "k_copy_from_host", "k_ba_lin", "k_ba_trial", "k_distribute"}
+for name, v in k.items():
+    if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+        corr = 2.0 if name in WIDE16 else 1.0
+        v["hbm_bytes_per_launch"] = {"raw": int(round(1024 * (v["FETCH_SIZE"]["mean_per_launch"] + v["WRITE_SIZE"]["mean_per_launch"]))),
+                                     "corrected": int(round(1024 * (corr * v["FETCH_SIZE"]["mean_per_launch"] + v["WRITE_SIZE"]["mean_per_launch"]))),
+                                     "fetch_correction": corr, "read_class": "16 B per lane (x2, guide)" if corr == 2.0 else "narrower than 16 B per lane (uncalibrated: as counted)"}
 bench = json.loads(open(os.path.join(src, tag + "_bench.json")).read().strip().splitlines()[-1])
 out = {
     "command": "rocprofv3 --kernel-trace --pmc <set> --output-format csv -- python3 bench.py --no-cpu --no-extras --steps 4 --warmup 1; four separate passes: "
                "{SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES}, {FETCH_SIZE}, {WRITE_SIZE}, "
                "{SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_WAVES}; condensed by tools/pmc_summary.py "
                "(values summed over XCDs, mean per launch); script: tools/refresh_profiles.sh",
-    "units": "FETCH_SIZE / WRITE_SIZE in KB as reported by rocprofv3 (no x2 correction: these kernels load dwords / dwordx2, see r01b_pmc_hbm.json); "
-             "SQ_* in the counter's own units",
+    "units": "FETCH_SIZE / WRITE_SIZE in KB as reported by rocprofv3; hbm_bytes_per_launch.corrected applies the guide's gfx950 rule (FETCH_SIZE x 2 for "
+             "reads of 16 B per lane; narrower reads are uncalibrated and kept as counted); SQ_* in the counter's own units",
     "frames_per_launch": bench["config"]["frames_per_launch"],
     "workload": "%d images 1280x720 per front-end launch (%d stereo frames, 8 levels); BA 50 KF / 5000 landmarks / ~39k observations, a fresh problem per keyframe"
                 % (2 * bench["config"]["frames_per_launch"], bench["config"]["frames_per_launch"]),

@@ -2,7 +2,7 @@
 # bench line, rocprofv3 kernel statistics of the same command, and four separate PMC passes (the guide's HBM / rocprofv3 recipe:
 # FETCH_SIZE and WRITE_SIZE each in a pass of their own, never combined with tracing domains) -> gpurun_out/<tag>_*
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 timeout -k 10 900 python bench.py > gpurun_out/${TAG}_bench.log 2>&1
 tail -1 gpurun_out/${TAG}_bench.log > gpurun_out/${TAG}_bench.json
