@@ -109,6 +109,7 @@ class StereoTracker:
         self.async_mapping = async_mapping
         self.loop_closure = loop_closure
         self.map_culling = map_culling
+        self.stereo = True
         self.fresh = []                                             # landmarks younger than three keyframes (local_map_cleaner)
         self.segment = 0
         self.pending = None
@@ -146,6 +147,17 @@ class StereoTracker:
         lm["max_valid"] = dist * float(self.scales[lvl])
         lm["min_valid"] = lm["max_valid"] / float(self.scales[max(self.n_levels - 1, 0)])
         lm["desc"] = np.array(desc32, np.uint8).copy()
+
+    def _xr(self, u, pc):
+        """predicted right-image x of a query (float32), -1 for the monocular tracker"""
+        return F32(u - self.cam["fxb"] / pc[2]) if self.stereo else F32(-1.0)
+
+    def ba_camera(self):
+        """the camera the bundle adjustments see: no baseline for the monocular tracker (solveMapping)"""
+        if self.stereo:
+            return self.cam
+        c = dict(self.cam); c["fxb"] = 0.0
+        return c
 
     def _project_query(self, X, R, t, need_view=None):
         """shared part of the query construction: camera point, pixel, in-image test; returns (pc, u, v) or None"""
@@ -213,8 +225,8 @@ class StereoTracker:
                 continue
             pc, u, v = pr
             lvl = int(self.prev.kpts["octave"][i])
-            radius = F32(10.0) * self.scales[lvl]
-            q_rows.append((F32(u), F32(v), F32(u - self.cam["fxb"] / pc[2]), radius, max(0, lvl - 1), min(self.n_levels - 1, lvl + 1)))
+            radius = F32(10.0 if self.stereo else 20.0) * self.scales[lvl]       # match_current_and_last_frames: margin 10 (stereo) / 20 (monocular)
+            q_rows.append((F32(u), F32(v), self._xr(u, pc), radius, max(0, lvl - 1), min(self.n_levels - 1, lvl + 1)))
             qd.append(self.prev.desc[i]); q_angle.append(self.prev.kpts["angle"][i]); q_lm.append(lid)
         if len(q_rows) < 20:
             return False, 0
@@ -282,7 +294,7 @@ class StereoTracker:
                 if lvl is None:
                     continue
                 lm["n_observable"] += 1
-                q_rows.append((F32(u), F32(v), F32(u - self.cam["fxb"] / pc[2]), F32(5.0) * self.scales[lvl], max(0, lvl - 1), lvl))
+                q_rows.append((F32(u), F32(v), self._xr(u, pc), F32(5.0) * self.scales[lvl], max(0, lvl - 1), lvl))
                 qd.append(lm["desc"]); q_lm.append(lid)
         n_new = 0
         if q_rows:
@@ -348,7 +360,7 @@ class StereoTracker:
             lvl = self._view_level(lm, lm["p"], C)
             if lvl is None:
                 continue
-            q_rows.append((F32(u), F32(v), F32(u - self.cam["fxb"] / pc[2]), F32(3.0) * self.scales[lvl], max(0, lvl - 1), lvl))
+            q_rows.append((F32(u), F32(v), self._xr(u, pc), F32(3.0) * self.scales[lvl], max(0, lvl - 1), lvl))
             qd.append(lm["desc"]); q_lm.append(lid)
         if not q_rows:
             return 0
@@ -408,7 +420,7 @@ class StereoTracker:
                 continue
             if lm["n_observed"] / lm["n_observable"] < 0.3:
                 self.erase_landmark(lid)
-            elif lm["ref_kf"] + 2 <= cur_kf and self._n_obs(lm) <= 3:
+            elif lm["ref_kf"] + 2 <= cur_kf and self._n_obs(lm) <= (3 if self.stereo else 2):
                 self.erase_landmark(lid)
             elif lm["ref_kf"] + 3 <= cur_kf:
                 continue
@@ -428,7 +440,7 @@ class StereoTracker:
             for i, lid in enumerate(kf["landmark"]):
                 if lid < 0 or lid not in self.landmarks:
                     continue
-                if kf["depth"][i] > depth_thr or kf["depth"][i] < 0:
+                if self.stereo and (kf["depth"][i] > depth_thr or kf["depth"][i] < 0):
                     continue
                 n_valid += 1
                 lm = self.landmarks[lid]
@@ -492,6 +504,8 @@ class StereoTracker:
                 f.landmark[i] = lid
             elif lid >= 0:
                 self.landmarks[lid]["obs"].append((c, i))
+        if not self.stereo and c > self.segment_start:
+            self.mono_triangulate(c - 1, f)
         self.kfs.append(dict(pose=f.pose.copy(), kpts=f.kpts, desc=f.desc, x_right=f.x_right, depth=f.depth, landmark=list(f.landmark), segment=self.segment, erased=False))
         if self.map_culling:
             self.cull_landmarks(c)
@@ -596,10 +610,10 @@ class StereoTracker:
 
     def solve_mapping(self, job):
         if job["is_global"]:            # loop_bundle_adjuster: 10 robust iterations over the loop's keyframes, no outlier removal
-            job["op"], job["ox"], _ = O.ba_optimize(job["poses"], np.array(job["fixed"], np.uint8), job["pts"], job["obs"], self.cam, True, 10)
+            job["op"], job["ox"], _ = O.ba_optimize(job["poses"], np.array(job["fixed"], np.uint8), job["pts"], job["obs"], self.ba_camera(), True, 10)
             job["outlier"] = np.zeros(len(job["obs"]), np.uint8)
         else:
-            job["op"], job["ox"], job["outlier"] = O.ba_local(job["poses"], np.array(job["fixed"], np.uint8), job["pts"], job["obs"], self.cam, 5, 10)
+            job["op"], job["ox"], job["outlier"] = O.ba_local(job["poses"], np.array(job["fixed"], np.uint8), job["pts"], job["obs"], self.ba_camera(), 5, 10)
 
     def apply_mapping(self, job):
         allk, fixed, ids, origin, obs, op, ox, outlier = (job[k] for k in ("allk", "fixed", "ids", "origin", "obs", "op", "ox", "outlier"))
@@ -848,7 +862,7 @@ class StereoTracker:
             if self.keyframe_needed(inliers):
                 self.finish_mapping()                           # the previous keyframe's solve enters the map before the next one is inserted
                 c = self.insert_keyframe(cur)
-                if self.loop_closure:
+                if self.loop_closure and self.stereo:
                     self.detect_and_close_loop(cur, c)
                 self.start_mapping(c)
                 if not self.async_mapping:
@@ -856,3 +870,174 @@ class StereoTracker:
             self.last_good = cur.pose.copy()
             self.prev = cur
         return self.prev.pose.seven() if self.tracking else None
+
+
+
+class MonoTracker(StereoTracker):
+    """Mirror of HipMonoTracker: two-view initialisation (HipVslamTrackerBase::monoInitialize over oracle/two_view.py), then the same
+    tracking / mapping as the stereo tracker with monocular edges, and new landmarks triangulated against the previous keyframe
+    (monoTriangulate).  Frames fed one by one with feed(image[, t])."""
+
+    def __init__(self, width, height, cam, **kw):
+        super().__init__(width, height, cam, **kw)
+        self.stereo = False
+        self.mono_ref = None
+        self.mono_prev_matched = None
+
+    def extract(self, image, _unused=None):
+        k, d, _, _ = O.extract(image, self.p, True)
+        n = len(k)
+        return Frame(k, d, np.full(n, -1.0, np.float32), np.full(n, -1.0, np.float32))
+
+    # ---- [UPSTREAM] module::initializer for monocular set-ups ---------------------------------------------------------------------
+    def mono_initialize(self, cur):
+        from . import two_view as TV
+        n_cur = len(cur.kpts)
+        if self.mono_ref is None:
+            if n_cur < 100:
+                return False
+            self.mono_ref = cur
+            self.mono_prev_matched = np.stack([cur.kpts["x"], cur.kpts["y"]], axis=1).astype(np.float32)
+            return False
+        if n_cur < 100:
+            self.mono_ref = None
+            return False
+        ref = self.mono_ref
+        q_rows, qd, q_ref, q_angle = [], [], [], []
+        for i in range(len(ref.kpts)):
+            if ref.kpts["octave"][i] > 0:
+                continue
+            q_rows.append((self.mono_prev_matched[i, 0], self.mono_prev_matched[i, 1], F32(-1.0), F32(100.0), 0, 0))
+            qd.append(ref.desc[i]); q_ref.append(i); q_angle.append(ref.kpts["angle"][i])
+        if len(q_rows) < 100:
+            self.mono_ref = None
+            return False
+        q = np.array(q_rows, O.PROJ_QUERY_DTYPE)
+        idx, _ = O.match_area(cur.kpts, cur.desc, self.w, self.h, q, np.array(qd, np.uint8), 50, 0.9)
+        idx, n_m = O.match_orientation_filter(np.array(q_angle, np.float32), cur.kpts["angle"], idx)
+        if n_m < 100:
+            self.mono_ref = None
+            return False
+        matches = []
+        for k in range(len(q)):
+            if idx[k] < 0:
+                continue
+            matches.append((q_ref[k], int(idx[k])))
+            self.mono_prev_matched[q_ref[k]] = (cur.kpts["x"][idx[k]], cur.kpts["y"][idx[k]])
+        kr = np.stack([ref.kpts["x"], ref.kpts["y"]], axis=1).astype(np.float64)
+        kc = np.stack([cur.kpts["x"], cur.kpts["y"]], axis=1).astype(np.float64)
+        K = [self.cam["fx"], self.cam["fy"], self.cam["cx"], self.cam["cy"]]
+        tv = TV.initialize(K, kr, kc, np.array(matches, np.int32))
+        if not tv["ok"]:
+            return False
+        depths = sorted(float(tv["points"][m][2]) for m in range(len(matches)) if tv["triangulated"][m])
+        if len(depths) < 50:
+            return False
+        median = depths[len(depths) // 2]
+        if not (median > 0):
+            return False
+        inv = 1.0 / median
+        self.finish_mapping()
+        self.segment_start = len(self.kfs)
+        ref_lm = [-1] * len(ref.kpts)
+        cur.pose = Pose(rot_to_quat(np.asarray(tv["R"], np.float64)), [float(tv["t"][a]) * inv for a in range(3)])
+        cur.landmark = [-1] * len(cur.kpts)
+        i0, i1 = self.segment_start, self.segment_start + 1
+        ref_pose = Pose()
+        for m, (ir, ic) in enumerate(matches):
+            if not tv["triangulated"][m]:
+                continue
+            lm = dict(p=[float(tv["points"][m][a]) * inv for a in range(3)], ref_kf=i0, obs=[(i0, ir), (i1, ic)], n_observable=1, n_observed=1)
+            self.init_landmark_view(lm, ref_pose, ref.kpts["octave"][ir], ref.desc[ir])
+            lid = self.next_id; self.next_id += 1
+            self.landmarks[lid] = lm
+            ref_lm[ir] = lid; cur.landmark[ic] = lid
+        none = lambda n: np.full(n, -1.0, np.float32)
+        self.kfs.append(dict(pose=ref_pose, kpts=ref.kpts, desc=ref.desc, x_right=none(len(ref.kpts)), depth=none(len(ref.kpts)), landmark=ref_lm, segment=self.segment, erased=False))
+        self.kfs.append(dict(pose=cur.pose.copy(), kpts=cur.kpts, desc=cur.desc, x_right=none(len(cur.kpts)), depth=none(len(cur.kpts)), landmark=list(cur.landmark), segment=self.segment, erased=False))
+        self.stats["keyframes"] += 2
+        self.since_kf = 0
+        self.ref_kf = i1
+        self.ref_tracked = sum(1 for l in self.kfs[i1]["landmark"] if l >= 0)
+        # global bundle adjustment of the two-keyframe map (20 iterations, Huber), inline
+        job = self.prepare_bundle([i0, i1], [])
+        if job is not None:
+            job["op"], job["ox"], _ = O.ba_optimize(job["poses"], np.array(job["fixed"], np.uint8), job["pts"], job["obs"], self.ba_camera(), True, 20)
+            job["outlier"] = np.zeros(len(job["obs"]), np.uint8)
+            self.apply_mapping(job)
+        cur.pose = self.kfs[-1]["pose"].copy()
+        self.mono_ref = None
+        return sum(1 for l in self.kfs[i1]["landmark"] if l >= 0) >= 50
+
+    # ---- new landmarks of a monocular keyframe against the previous keyframe (monoTriangulate) --------------------------------------
+    def mono_triangulate(self, prev_kf, f):
+        from . import two_view as TV
+        prev = self.kfs[prev_kf]
+        c = len(self.kfs)
+        if len(prev["kpts"]) == 0 or len(f.kpts) == 0:
+            return
+        mq, mt, _ = O.match_bf(f.desc, prev["desc"], 50, 0.8, True)
+        fx, fy, cx, cy = self.cam["fx"], self.cam["fy"], self.cam["cx"], self.cam["cy"]
+        R1, R2 = quat_to_rot(prev["pose"].q), quat_to_rot(f.pose.q)
+        t1, t2 = np.array(prev["pose"].t), np.array(f.pose.t)
+        Km = np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1.0]])
+        P1 = Km @ np.hstack([R1, t1.reshape(3, 1)]); P2 = Km @ np.hstack([R2, t2.reshape(3, 1)])
+        C1 = -(R1.T @ t1); C2 = -(R2.T @ t2)
+        R21 = R2 @ R1.T
+        t21 = t2 - R21 @ t1
+        tx = np.array([[0, -t21[2], t21[1]], [t21[2], 0, -t21[0]], [-t21[1], t21[0], 0]])
+        E = tx @ R21
+        ratio_factor = 1.5 * self.sf
+        for ic, ip in zip(mq, mt):
+            ic, ip = int(ic), int(ip)
+            if f.landmark[ic] >= 0 or prev["landmark"][ip] >= 0:
+                continue
+            k1x, k1y, o1 = float(prev["kpts"]["x"][ip]), float(prev["kpts"]["y"][ip]), int(prev["kpts"]["octave"][ip])
+            k2x, k2y, o2 = float(f.kpts["x"][ic]), float(f.kpts["y"][ic]), int(f.kpts["octave"][ic])
+            x1n = np.array([(k1x - cx) / fx, (k1y - cy) / fy, 1.0]); x2n = np.array([(k2x - cx) / fx, (k2y - cy) / fy, 1.0])
+            l = E @ x1n
+            num = l @ x2n
+            a, b = l[0] / fx, l[1] / fy
+            s1 = float(self.scales[o1]) ** 2; s2 = float(self.scales[o2]) ** 2
+            if num * num / (a * a + b * b) > 3.84 * s2:
+                continue
+            r1 = R1.T @ x1n; r2 = R2.T @ x2n
+            cosr = (r1 @ r2) / (math.sqrt(r1 @ r1) * math.sqrt(r2 @ r2))
+            if not (0 < cosr < 0.9998):
+                continue
+            X = TV.triangulate(P1, P2, (k1x, k1y), (k2x, k2y))
+            if not np.all(np.isfinite(X)):
+                continue
+            Xc1 = R1 @ X + t1; Xc2 = R2 @ X + t2
+            if not (Xc1[2] > 0) or not (Xc2[2] > 0):
+                continue
+            e1x, e1y = fx * Xc1[0] / Xc1[2] + cx - k1x, fy * Xc1[1] / Xc1[2] + cy - k1y
+            if e1x * e1x + e1y * e1y > 5.991 * s1:
+                continue
+            e2x, e2y = fx * Xc2[0] / Xc2[2] + cx - k2x, fy * Xc2[1] / Xc2[2] + cy - k2y
+            if e2x * e2x + e2y * e2y > 5.991 * s2:
+                continue
+            d1 = math.sqrt(float((X - C1) @ (X - C1))); d2 = math.sqrt(float((X - C2) @ (X - C2)))
+            if not (d1 > 0) or not (d2 > 0):
+                continue
+            ratio_d, ratio_o = d2 / d1, float(self.scales[o1]) / float(self.scales[o2])
+            if ratio_d * ratio_factor < ratio_o or ratio_d > ratio_o * ratio_factor:
+                continue
+            lm = dict(p=[float(X[0]), float(X[1]), float(X[2])], ref_kf=c, obs=[(prev_kf, ip), (c, ic)], n_observable=1, n_observed=1)
+            self.init_landmark_view(lm, f.pose, o2, f.desc[ic])
+            lid = self.next_id; self.next_id += 1
+            self.landmarks[lid] = lm
+            self.fresh.append(lid)
+            f.landmark[ic] = lid; prev["landmark"][ip] = lid
+
+    def feed(self, image, t=None):
+        if not self.tracking and not self.lost:
+            cur = self.extract(image)
+            self.n_frames += 1
+            if self.mono_initialize(cur):
+                self.tracking = True
+            self.velocity = None
+            self.prev = cur
+            self.last_good = cur.pose.copy()
+            return self.prev.pose.seven() if self.tracking else None
+        return super().feed(image, None, t)

@@ -1,7 +1,7 @@
 """Closed-loop parity of the stereo tracker: the product path (LpSlamManager -> VSLAMStereo tracker -> HIP kernels) against the
-closed-loop oracle (oracle/tracker.py, goldens tests/golden/g10..g14_*.npz made by tools/make_golden_track.py), pose by pose:
+closed-loop oracle (oracle/tracker.py, goldens tests/golden/g10..g15_*.npz made by tools/make_golden_track.py), pose by pose:
 synchronous and asynchronous mapping at 640x480, the benchmark configuration (1280x720, 2000 keypoints, 8 levels), a sequence
-with a loss of tracking and a relocalisation, and a full turn that closes a loop.  Tolerance: the north star's 1e-4 rad / 1e-3 m, per tracked frame."""
+with a loss of tracking and a relocalisation, a full turn that closes a loop, and the monocular tracker on the three-wall scene.  Tolerance: the north star's 1e-4 rad / 1e-3 m, per tracked frame."""
 import hashlib
 import math
 import time
@@ -28,6 +28,9 @@ CASES = {
     # a full turn on the spot with loopClosure true: descriptor voting, Sim3 verification, pose graph, fusion of the revisited
     # landmarks, global bundle adjustment over the loop's keyframes (the Sim3 optimisers differentiate numerically: DESIGN.md section 3)
     "g14_track_loop": (640, 480, "turn", None, (), '{"cameraSetup": "stereo", "slamKeypoints": 1000, "numLevels": 4, "keyframeInterval": 3, "localWindow": 4, "asyncMapping": true, "loopClosure": true}'),
+    # the monocular tracker: two-view initialisation (homography / fundamental matrix by RANSAC, oracle/two_view.py), global BA of the
+    # two-keyframe map, then tracking with keyframes whose new landmarks are triangulated against the previous keyframe
+    "g15_track_mono": (640, 480, "walls", None, (), '{"cameraSetup": "monocular", "slamKeypoints": 2000, "numLevels": 3, "keyframeInterval": 4, "localWindow": 10, "asyncMapping": true}'),
 }
 
 
@@ -47,18 +50,21 @@ def _run_product(frames, tmp_path, w, h, tracker_cfg):
     _build.host_library()
     k = synth.intrinsics(w, h)
     m = manager.Manager()
-    for num in (0, 1):
+    mono = frames[0][1] is None
+    for num in ((0,) if mono else (0, 1)):
         c = manager.default_camera()
         c.camera_number = num; c.f_x = k["fx"]; c.f_y = k["fy"]; c.c_x = k["cx"]; c.c_y = k["cy"]
-        c.resolution_x = w; c.resolution_y = h; c.focal_x_baseline = k["fxb"]
+        c.resolution_x = w; c.resolution_y = h
+        if not mono:
+            c.focal_x_baseline = k["fxb"]
         m.set_camera(c)
-    assert m.add_tracker("VSLAMStereo", tracker_cfg)
+    assert m.add_tracker("VSLAMMono" if mono else "VSLAMStereo", tracker_cfg)
     m.collect_results(); m.provide_odometry()
     log = tmp_path / "slam.log"
     m.log_to_file(log)
     m.start()
     for i, (l, r) in enumerate(frames):
-        assert m.add_stereo((i + 1) * 40_000_000, l, r)
+        assert m.add_image((i + 1) * 40_000_000, l) if mono else m.add_stereo((i + 1) * 40_000_000, l, r)
     t0 = time.time()
     while len(m.results) < len(frames) and time.time() - t0 < 60:
         time.sleep(0.01)
@@ -73,6 +79,9 @@ def test_tracked_poses_follow_the_closed_loop_oracle(hiplib, tmp_path, case):
     n = int(g["frames"])
     if seq_id == "turn":
         frames = [list(f) for f in synth.turning_sequence(w, h, n)[0]]
+    elif seq_id == "walls":
+        walls = synth.WallSequence(w, h, 11)
+        frames = [[walls.frame(i), None] for i in range(n)]
     else:
         seq = synth.StereoSequence(w, h, seq_id, n_points=n_points) if n_points else synth.StereoSequence(w, h, seq_id)
         frames = [list(seq.frame(i)) for i in range(n)]
@@ -81,7 +90,9 @@ def test_tracked_poses_follow_the_closed_loop_oracle(hiplib, tmp_path, case):
         frames[i] = [blank.copy(), blank.copy()]
     sha = hashlib.sha256()
     for l, r in frames:
-        sha.update(l.tobytes()); sha.update(r.tobytes())
+        sha.update(l.tobytes())
+        if r is not None:
+            sha.update(r.tobytes())
     assert sha.hexdigest() == str(g["sha"])                               # the committed generator still makes the golden's images
     results, stats = _run_product(frames, tmp_path, w, h, cfg)
     valid = g["valid"] if "valid" in g.files else np.ones(n, bool)

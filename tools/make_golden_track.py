@@ -6,9 +6,10 @@ oracle (oracle/tracker.py).  The images come from the committed generator (lpsla
   g11_track_async  the same sequence with asyncMapping true -- the product's default
   g12_track720     1280x720, 2000 keypoints, 8 levels (the configuration the benchmark is quoted on), 20 frames, asyncMapping true
   g13_track_lost   640x480, 20 frames of which 10..12 are blank: Lost -> the map is kept -> relocalisation, asyncMapping true
+  g15_track_mono   640x480 monocular, 30 frames of the three-wall scene: two-view initialisation, tracking, triangulated keyframes
   g14_track_loop   640x480, 132 frames of a full turn on the spot, loopClosure true: voting, Sim3 verification, pose graph, fusion, global BA
 
-usage: make_golden_track.py [g10 g11 g12 g13 g14]      (default: all)"""
+usage: make_golden_track.py [g10 g11 g12 g13 g14 g15]      (default: all)"""
 import hashlib
 import os
 import sys
@@ -31,6 +32,8 @@ CASES = {
                          cfg=dict(max_keypoints=2000, num_levels=8, scale_factor=1.2, keyframe_interval=6, local_window=10, async_mapping=True)),
     "g13_track_lost": dict(w=640, h=480, n=20, seq=4, points=6000, blank=(10, 11, 12),
                            cfg=dict(max_keypoints=1000, num_levels=4, scale_factor=1.2, keyframe_interval=4, local_window=10, async_mapping=True)),
+    "g15_track_mono": dict(w=640, h=480, n=30, seq="walls", points=None, blank=(), mono=True,
+                           cfg=dict(max_keypoints=2000, num_levels=3, scale_factor=1.2, keyframe_interval=4, local_window=10, async_mapping=True)),
     "g14_track_loop": dict(w=640, h=480, n=132, seq="turn", points=None, blank=(),
                            cfg=dict(max_keypoints=1000, num_levels=4, scale_factor=1.2, keyframe_interval=3, local_window=4, async_mapping=True, loop_closure=True)),
 }
@@ -40,6 +43,9 @@ def frames_of(case):
     c = CASES[case]
     if c["seq"] == "turn":
         return [list(f) for f in synth.turning_sequence(c["w"], c["h"], c["n"])[0]]
+    if c["seq"] == "walls":
+        walls = synth.WallSequence(c["w"], c["h"], 11)
+        return [[walls.frame(i), None] for i in range(c["n"])]
     seq = synth.StereoSequence(c["w"], c["h"], c["seq"], n_points=c["points"]) if c["points"] else synth.StereoSequence(c["w"], c["h"], c["seq"])
     frames = [list(seq.frame(i)) for i in range(c["n"])]
     blank = np.full((c["h"], c["w"]), 110, np.uint8)
@@ -51,12 +57,14 @@ def frames_of(case):
 def make(case):
     c = CASES[case]
     k = synth.intrinsics(c["w"], c["h"])
-    trk = T.StereoTracker(c["w"], c["h"], k, **c["cfg"])
+    trk = (T.MonoTracker if c.get("mono") else T.StereoTracker)(c["w"], c["h"], k, **c["cfg"])
     poses, valid, sha = [], [], hashlib.sha256()
     t0 = time.time()
     for i, (l, r) in enumerate(frames_of(case)):
-        sha.update(l.tobytes()); sha.update(r.tobytes())
-        p = trk.feed(l, r, 0.04 * (i + 1))
+        sha.update(l.tobytes())
+        if r is not None:
+            sha.update(r.tobytes())
+        p = trk.feed(l, r, 0.04 * (i + 1)) if r is not None else trk.feed(l, 0.04 * (i + 1))
         valid.append(p is not None)
         poses.append(p if p is not None else np.zeros(7))
     print("%s: %d frames in %.1f s; statistics %s; landmarks %d" % (case, c["n"], time.time() - t0, trk.stats, len(trk.landmarks)))
