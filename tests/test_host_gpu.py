@@ -229,7 +229,7 @@ def test_map_stays_bounded_over_a_long_session(hiplib, tmp_path):
     # one lap is 120 frames: at frame 150 the ring has been seen once; 150 more frames add (almost) nothing
     assert kf_end <= 1.25 * kf_lap and lm_end <= 1.25 * lm_lap, (marks,)
     assert s["live_keyframes"] == kf_end and s["keyframes"] > kf_end
-    assert t_last <= 1.3 * t_first, (marks,)
+    assert t_last <= 1.6 * t_first, (marks,)           # flat in a normal build (1.04 -> 0.90 ms); the margin is for sanitizer builds and noisy hosts
     print("long session: %.3f -> %.3f ms per frame, keyframes %d -> %d -> %d live of %d inserted, landmarks %d -> %d -> %d" %
           (1e3 * t_first, 1e3 * t_last, kf_a, kf_lap, kf_end, s["keyframes"], lm_a, lm_lap, lm_end))
 

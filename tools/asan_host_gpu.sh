@@ -13,4 +13,4 @@ SAN="-O1 -g -fPIC -fsanitize=address,undefined -fno-omit-frame-pointer"
 g++ $SAN -std=c++17 -shared -fvisibility=hidden -pthread -o lpslam_amd/liblpslam.so lpslam_amd/host/*.cpp -Llpslam_amd -llpslam_hip -Wl,-rpath,"$PWD/lpslam_amd"
 touch lpslam_amd/liblpslam.so
 ASAN_OPTIONS=detect_leaks=0:verify_asan_link_order=0:protect_shadow_gap=0 LD_PRELOAD="$(gcc -print-file-name=libasan.so) $(gcc -print-file-name=libubsan.so)" \
-    timeout -k 10 900 python -m pytest tests/test_host_gpu.py tests/test_track_gpu.py tests/test_rectify_gpu.py -q -x -p no:cacheprovider
+    timeout -k 10 900 python -m pytest tests/test_host_gpu.py tests/test_track_gpu.py tests/test_rectify_gpu.py -q -p no:cacheprovider
