@@ -98,16 +98,62 @@ bool HipVslamTrackerBase::startContext(bool stereo)
     m_prefetched.valid = false; m_nextFrame = nullptr;
     std::scoped_lock lock(m_slamLock);
     if (m_ctx) return true;
+    // configFromFile: the OpenVSLAM configuration as a YAML file instead of the one the adapter generates
+    // (src/Trackers/OpenVSLAMTrackerBase.cpp:114-123: a file that cannot be loaded fails the start).  The keys this path has a use for
+    // are read -- Camera.{fx, fy, cx, cy, cols, rows, focal_x_baseline}, Feature.{max_num_keypoints, scale_factor, num_levels,
+    // ini_fast_threshold, min_fast_threshold}, Initializer.{num_min_triangulated_pts, parallax_deg_threshold}, time_to_relocalize,
+    // relocalize_with_nav_data -- nested ("Camera:" + indented "fx: ...") or flat ("Camera.fx: ..."); the rest is ignored.
+    std::unordered_map<std::string, std::string> yaml;
     if (!m_configFromFile.empty()) {
-        logMessage(LpSlamLogLevel_Error, "configFromFile (raw OpenVSLAM YAML) is not supported; use the tracker's JSON keys");
-        return false;
+        std::ifstream f(m_configFromFile);
+        if (!f) { logMessage(LpSlamLogLevel_Error, "Failed to load OpenVSLAM config file " + m_configFromFile); return false; }
+        std::string line, section;
+        auto trim = [](std::string v) { const size_t a = v.find_first_not_of(" \t\r\"'"), b = v.find_last_not_of(" \t\r\"'"); return a == std::string::npos ? std::string() : v.substr(a, b - a + 1); };
+        while (std::getline(f, line)) {
+            const size_t hash = line.find('#');
+            if (hash != std::string::npos) line.erase(hash);
+            if (trim(line).empty() || line[0] == '%' || line.rfind("---", 0) == 0) continue;
+            const size_t colon = line.find(':');
+            if (colon == std::string::npos) { logMessage(LpSlamLogLevel_Error, "OpenVSLAM config file " + m_configFromFile + ": cannot parse \"" + trim(line) + "\""); return false; }
+            const bool indented = line[0] == ' ' || line[0] == '\t';
+            const std::string key = trim(line.substr(0, colon)), val = trim(line.substr(colon + 1));
+            if (!indented) section.clear();
+            if (val.empty()) { if (!indented) section = key; continue; }
+            yaml[(indented && !section.empty()) ? section + "." + key : key] = val;
+        }
+        logMessage(LpSlamLogLevel_Info, "VSLAM config loaded from file " + m_configFromFile + " (" + std::to_string(yaml.size()) + " keys)");
     }
+    auto ynum = [&yaml](const char* k, double& out) { auto it = yaml.find(k); if (it == yaml.end()) return false; char* e = nullptr; const double v = std::strtod(it->second.c_str(), &e); if (e == it->second.c_str()) return false; out = v; return true; };
     CameraRegistry* reg = getCameraRegistry();
     if (!reg) { logMessage(LpSlamLogLevel_Error, "Cannot process image without camera registry"); return false; }
     auto left = reg->getConfiguration(0);
     if (!left) { logMessage(LpSlamLogLevel_Error, "Cannot load camera configuration for camera with number 0"); return false; }
     if (stereo && !reg->getConfiguration(1)) { logMessage(LpSlamLogLevel_Error, "Cannot load camera configuration for right camera with number 1"); return false; }
     m_cam = *left;
+    if (!yaml.empty()) {
+        double v;
+        if (ynum("Camera.fx", v)) m_cam.f_x = v;
+        if (ynum("Camera.fy", v)) m_cam.f_y = v;
+        if (ynum("Camera.cx", v)) m_cam.c_x = v;
+        if (ynum("Camera.cy", v)) m_cam.c_y = v;
+        if (ynum("Camera.cols", v)) m_cam.resolution_x = (int)v;
+        if (ynum("Camera.rows", v)) m_cam.resolution_y = (int)v;
+        if (ynum("Camera.focal_x_baseline", v)) m_cam.focal_x_baseline = v;
+        if (ynum("Feature.max_num_keypoints", v)) m_slamKeypoints = (int)v;
+        if (ynum("Feature.scale_factor", v)) m_scaleFactor = v;
+        if (ynum("Feature.num_levels", v)) m_numLevels = (int)v;
+        if (ynum("Feature.ini_fast_threshold", v)) m_iniFastThr = (int)v;
+        if (ynum("Feature.min_fast_threshold", v)) m_minFastThr = (int)v;
+        if (ynum("Initializer.num_min_triangulated_pts", v)) m_initMinTriangulated = (int)v;
+        if (ynum("Initializer.parallax_deg_threshold", v)) m_initParallaxDeg = v;
+        if (ynum("time_to_relocalize", v)) m_timeToRelocalize = v;
+        auto it = yaml.find("relocalize_with_nav_data");
+        if (it != yaml.end()) m_relocWithNavigation = it->second == "true" || it->second == "1";
+        if (m_numLevels < 1 || m_numLevels > 16 || !(m_scaleFactor > 1.0) || m_slamKeypoints < 1) {
+            logMessage(LpSlamLogLevel_Error, "OpenVSLAM config file " + m_configFromFile + ": Feature.* values out of range");
+            return false;
+        }
+    }
     // ImageProcessing::Undistort (reference: src/Utils/ImageProcessing.h:134-250): the maps are built once from the camera
     // pair and every frame is remapped -- here on the device (lpslam_hip_upload_raw_image).  The reference does this for the
     // stereo tracker only (src/Trackers/OpenVSLAMStereoTracker.cpp:198-213); the monocular one feeds frames as they come.
@@ -257,7 +303,7 @@ bool HipVslamTrackerBase::initializeMap(FrameData& f, const Pose& at)
     // after a loss the new keyframes open a new segment at the pose handed in, and a loop closure can join the segments later.
     int n = 0;
     for (size_t i = 0; i < f.kpts.size(); ++i) if (f.depth[i] > 0) ++n;
-    if (n < 40) return false;
+    if (n < m_initMinTriangulated) return false;
     finishMapping();
     f.pose = at;
     std::fill(f.landmark.begin(), f.landmark.end(), -1);
@@ -969,6 +1015,8 @@ bool HipVslamTrackerBase::monoInitialize(FrameData& cur)
     for (size_t i = 0; i < cur.kpts.size(); ++i) { kc[2 * i] = cur.kpts[i].x; kc[2 * i + 1] = cur.kpts[i].y; }
     const double K[4] = {m_cam.f_x, m_cam.f_y, m_cam.c_x, m_cam.c_y};
     TwoViewParams prm;
+    prm.min_triangulated = m_initMinTriangulated;       // the reference's Initializer.* values (src/Trackers/OpenVSLAMTrackerBase.cpp:181-182)
+    prm.parallax_deg_thr = m_initParallaxDeg;
     TwoViewResult tv;
     if (!two_view_initialize(K, kr.data(), kc.data(), matches.data(), (int)(matches.size() / 2), prm, tv)) return false;
 
@@ -976,7 +1024,7 @@ bool HipVslamTrackerBase::monoInitialize(FrameData& cur)
     // relative to it, scale: median depth in the reference = 1
     std::vector<double> depths;
     for (size_t m = 0; m < tv.triangulated.size(); ++m) if (tv.triangulated[m]) depths.push_back(tv.points[3 * m + 2]);
-    if (depths.size() < 50) return false;
+    if ((int)depths.size() < m_initMinTriangulated) return false;
     std::nth_element(depths.begin(), depths.begin() + (long)(depths.size() / 2), depths.end());
     const double median = depths[depths.size() / 2];
     if (!(median > 0)) return false;
@@ -1034,7 +1082,7 @@ bool HipVslamTrackerBase::monoInitialize(FrameData& cur)
     size_t n_seg = 0;
     for (int id : m_kfs[(size_t)i1].landmark) n_seg += id >= 0;
     logMessage(LpSlamLogLevel_Info, "VSLAM monocular map initialised: " + std::to_string(n_seg) + " landmarks, model " + (tv.model == 0 ? "H" : "F"));
-    return n_seg >= 50;
+    return (int)n_seg >= m_initMinTriangulated;
 }
 
 // New landmarks for a monocular keyframe: keypoints without a landmark are matched by descriptor against the previous keyframe's

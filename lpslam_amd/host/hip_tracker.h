@@ -193,6 +193,9 @@ protected:
     Pose m_lastGoodPose;
     TimeStamp m_lostSince{};
     double m_timeToRelocalize = 3.0;
+    // Initializer.num_min_triangulated_pts / parallax_deg_threshold as the reference sets them (src/Trackers/OpenVSLAMTrackerBase.cpp:181-182)
+    int m_initMinTriangulated = 40;
+    double m_initParallaxDeg = 0.2;
     // navigation prior (src/Trackers/OpenVSLAMStereoTracker.cpp:70-179): camera pose of the odometry, optical axes, world -> camera
     std::optional<Pose> m_navPrev, m_navCur;
     Statistics m_stats;

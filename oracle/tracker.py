@@ -927,11 +927,11 @@ class MonoTracker(StereoTracker):
         kr = np.stack([ref.kpts["x"], ref.kpts["y"]], axis=1).astype(np.float64)
         kc = np.stack([cur.kpts["x"], cur.kpts["y"]], axis=1).astype(np.float64)
         K = [self.cam["fx"], self.cam["fy"], self.cam["cx"], self.cam["cy"]]
-        tv = TV.initialize(K, kr, kc, np.array(matches, np.int32))
+        tv = TV.initialize(K, kr, kc, np.array(matches, np.int32), min_triangulated=40, parallax_thr=0.2)      # the reference's Initializer.* values
         if not tv["ok"]:
             return False
         depths = sorted(float(tv["points"][m][2]) for m in range(len(matches)) if tv["triangulated"][m])
-        if len(depths) < 50:
+        if len(depths) < 40:
             return False
         median = depths[len(depths) // 2]
         if not (median > 0):
@@ -967,7 +967,7 @@ class MonoTracker(StereoTracker):
             self.apply_mapping(job)
         cur.pose = self.kfs[-1]["pose"].copy()
         self.mono_ref = None
-        return sum(1 for l in self.kfs[i1]["landmark"] if l >= 0) >= 50
+        return sum(1 for l in self.kfs[i1]["landmark"] if l >= 0) >= 40
 
     # ---- new landmarks of a monocular keyframe against the previous keyframe (monoTriangulate) --------------------------------------
     def mono_triangulate(self, prev_kf, f):

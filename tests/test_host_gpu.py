@@ -349,6 +349,61 @@ def test_kidnapped_camera_relocalises_through_the_vocabulary(hiplib, tmp_path):
     assert st_p["lost"] == 1 and st_p["relocalised"] == 0 and not any(r["valid"] for r in res_p[n_fwd:])
 
 
+def test_config_from_file_reads_the_openvslam_yaml(hiplib, tmp_path):
+    """configFromFile (src/Trackers/OpenVSLAMTrackerBase.cpp:114-123): the OpenVSLAM configuration comes from a YAML file -- nested or
+    flat keys -- instead of the generated one; a file that cannot be loaded fails the start, as in the reference.  The same frames
+    through the JSON keys and through the file give the same trajectory."""
+    from lpslam_amd import _build, manager
+    _build.host_library()
+    w, h = 640, 480
+    k = synth.intrinsics(w, h)
+    seq = synth.StereoSequence(w, h, 4, n_points=6000)
+    frames = [seq.frame(i) for i in range(10)]
+    nested = tmp_path / "nested.yaml"
+    nested.write_text("""# OpenVSLAM configuration
+Camera:
+  name: "synthetic"
+  model: perspective
+  fx: %r
+  fy: %r
+  cx: %r
+  cy: %r
+  cols: %d
+  rows: %d
+  focal_x_baseline: %r
+Feature:
+  max_num_keypoints: 1000
+  scale_factor: 1.2
+  num_levels: 4
+  ini_fast_threshold: 20
+  min_fast_threshold: 7
+Initializer:
+  num_min_triangulated_pts: 40
+depth_threshold: 40
+""" % (k["fx"], k["fy"], k["cx"], k["cy"], w, h, k["fxb"]))
+    flat = tmp_path / "flat.yaml"
+    flat.write_text("Feature.max_num_keypoints: 1000\nFeature.num_levels: 4   # as above\nFeature.scale_factor: 1.2\n")
+    runs = {}
+    for name, cfg in (("json", '{"cameraSetup": "stereo", "slamKeypoints": 1000, "numLevels": 4, "keyframeInterval": 4}'),
+                      ("nested", '{"cameraSetup": "stereo", "slamKeypoints": 333, "numLevels": 2, "keyframeInterval": 4, "configFromFile": "%s"}' % nested),
+                      ("flat", '{"cameraSetup": "stereo", "slamKeypoints": 333, "numLevels": 2, "keyframeInterval": 4, "configFromFile": "%s"}' % flat)):
+        m = _stereo_manager(manager, w, h, cfg, tmp_path / (name + ".log"))
+        m.start()
+        _feed(m, frames)
+        m.stop()
+        assert len(m.results) == len(frames) and all(r["valid"] for r in m.results)
+        runs[name] = m.results
+    for name in ("nested", "flat"):
+        for a, b in zip(runs["json"], runs[name]):
+            assert a["p"] == b["p"] and a["q"] == b["q"], name                   # the file's values replaced the JSON keys
+    assert "VSLAM config loaded from file" in open(tmp_path / "nested.log", errors="replace").read()
+    m = _stereo_manager(manager, w, h, '{"cameraSetup": "stereo", "configFromFile": "%s"}' % (tmp_path / "missing.yaml"), tmp_path / "missing.log")
+    m.start()
+    _feed(m, frames[:2], expect=0)
+    m.stop()
+    assert "Failed to load OpenVSLAM config file" in open(tmp_path / "missing.log", errors="replace").read() and not any(r["valid"] for r in m.results)
+
+
 def test_long_loss_starts_a_new_segment_at_the_last_pose(hiplib, tmp_path):
     """When relocalisation does not succeed within time_to_relocalize (3 s) a new map segment starts at the pose the tracker last
     believed in -- not at the origin -- and the old keyframes stay in the map."""
