@@ -1340,43 +1340,58 @@ bool HipVslamTrackerBase::detectAndCloseLoop(FrameData& cur, int c)
     if (votes.empty()) return false;
     std::sort(votes.begin(), votes.end(), [](const Vote& a, const Vote& b) { return a.pairs.size() != b.pairs.size() ? a.pairs.size() > b.pairs.size() : a.kf > b.kf; });
     if (votes.size() > 3) votes.resize(3);
+    // [UPSTREAM] solve::sim3_solver: the similarity candidate camera -> current camera from the matched landmarks alone (Horn on
+    // 3-match samples, RANSAC over the reprojection error in both images), independent of the drifted estimates; the Sim3 optimiser
+    // on the device refines it.  Monocular maps drift in scale, so the scale is free there and fixed for stereo.
+    const bool fix_scale = m_stereo;
     std::vector<lpslam_hip_sim3_pair> pairs;
     std::vector<int32_t> start{0};
     std::vector<double> s12;
-    const Se3 Tc{{kc.pose.q[0], kc.pose.q[1], kc.pose.q[2], kc.pose.q[3]}, {kc.pose.t[0], kc.pose.t[1], kc.pose.t[2]}};
+    std::vector<int> vote_kf;
     const Mat3 Rc = quatToRot(kc.pose.q);
+    const double cam[4] = {m_cam.f_x, m_cam.f_y, m_cam.c_x, m_cam.c_y};
     for (auto& v : votes) {
         const Keyframe& ka = m_kfs[(size_t)v.kf];
         const Mat3 Ra = quatToRot(ka.pose.q);
-        for (auto& pr2 : v.pairs) {
-            const size_t ic = (size_t)pr2.first, ia = (size_t)pr2.second;
+        const size_t first = pairs.size(), np_ = v.pairs.size();
+        std::vector<double> p1((size_t)3 * np_), p2((size_t)3 * np_), o1((size_t)2 * np_), o2((size_t)2 * np_), w1(np_), w2(np_);
+        for (size_t n_ = 0; n_ < np_; ++n_) {
+            const size_t ic = (size_t)v.pairs[n_].first, ia = (size_t)v.pairs[n_].second;
             const Landmark& lc = m_landmarks.at(resolve(kc.landmark[ic]));
             const Landmark& la = m_landmarks.at(resolve(ka.landmark[ia]));
             lpslam_hip_sim3_pair pr{};
             for (int r = 0; r < 3; ++r) {
                 pr.p1c[r] = Rc.m[r * 3] * lc.p[0] + Rc.m[r * 3 + 1] * lc.p[1] + Rc.m[r * 3 + 2] * lc.p[2] + kc.pose.t[r];
                 pr.p2c[r] = Ra.m[r * 3] * la.p[0] + Ra.m[r * 3 + 1] * la.p[1] + Ra.m[r * 3 + 2] * la.p[2] + ka.pose.t[r];
+                p1[3 * n_ + (size_t)r] = pr.p1c[r]; p2[3 * n_ + (size_t)r] = pr.p2c[r];
             }
             pr.obs1[0] = kc.kpts[ic].x; pr.obs1[1] = kc.kpts[ic].y; pr.obs2[0] = ka.kpts[ia].x; pr.obs2[1] = ka.kpts[ia].y;
             const double s1 = m_scales[kc.kpts[ic].octave], s2 = m_scales[ka.kpts[ia].octave];
             pr.inv_sigma2_1 = 1.0 / (s1 * s1); pr.inv_sigma2_2 = 1.0 / (s2 * s2);
+            o1[2 * n_] = pr.obs1[0]; o1[2 * n_ + 1] = pr.obs1[1]; o2[2 * n_] = pr.obs2[0]; o2[2 * n_ + 1] = pr.obs2[1];
+            w1[n_] = pr.inv_sigma2_1; w2[n_] = pr.inv_sigma2_2;
             pairs.push_back(pr);
         }
+        double seed12[8];
+        std::vector<uint8_t> seed_inl(np_);
+        const int found = sim3_solve_ransac(p1.data(), p2.data(), o1.data(), o2.data(), w1.data(), w2.data(), (int)np_, cam, cam, fix_scale, 200, 0x9E3779B9u, seed12, seed_inl.data());
+        // a seed needs 12 inliers ([UPSTREAM] asks the solver for 20 of its several hundred bag-of-words matches); the count that
+        // decides stays the optimiser's: 20
+        if (found < 12) { pairs.resize(first); continue; }
         start.push_back((int32_t)pairs.size());
-        const Se3 Ta{{ka.pose.q[0], ka.pose.q[1], ka.pose.q[2], ka.pose.q[3]}, {ka.pose.t[0], ka.pose.t[1], ka.pose.t[2]}};
-        const Se3 T12 = se3_mul(Tc, se3_inv(Ta));                                        // candidate camera -> current camera
-        s12.insert(s12.end(), {T12.q[0], T12.q[1], T12.q[2], T12.q[3], T12.t[0], T12.t[1], T12.t[2], 1.0});
+        s12.insert(s12.end(), seed12, seed12 + 8);
+        vote_kf.push_back(v.kf);
     }
-    const double cam[4] = {m_cam.f_x, m_cam.f_y, m_cam.c_x, m_cam.c_y};
+    if (vote_kf.empty()) return false;
     std::vector<uint8_t> inl(pairs.size());
-    std::vector<int32_t> n_inl(votes.size(), 0);
-    if (lpslam_hip_sim3_transform_optimize(m_ctx, (int32_t)votes.size(), s12.data(), pairs.data(), start.data(), cam, cam, 10.0, 1, inl.data(), n_inl.data()) != LPSLAM_HIP_OK) return false;
+    std::vector<int32_t> n_inl(vote_kf.size(), 0);
+    if (lpslam_hip_sim3_transform_optimize(m_ctx, (int32_t)vote_kf.size(), s12.data(), pairs.data(), start.data(), cam, cam, 10.0, fix_scale ? 1 : 0, inl.data(), n_inl.data()) != LPSLAM_HIP_OK) return false;
     int best = -1;
-    for (size_t i = 0; i < votes.size(); ++i) if (n_inl[i] >= 20 && (best < 0 || n_inl[i] > n_inl[(size_t)best])) best = (int)i;
+    for (size_t i = 0; i < vote_kf.size(); ++i) if (n_inl[i] >= 20 && (best < 0 || n_inl[i] > n_inl[(size_t)best])) best = (int)i;
     if (best < 0) return false;
 
     // ---- pose graph over the keyframes of the loop: a0 = candidate (fixed) ... c
-    const int a0 = votes[(size_t)best].kf;
+    const int a0 = vote_kf[(size_t)best];
     const int n = c - a0 + 1;
     std::vector<double> verts(8 * (size_t)n);
     std::vector<uint8_t> fixed((size_t)n, 0);
@@ -1404,16 +1419,18 @@ bool HipVslamTrackerBase::detectAndCloseLoop(FrameData& cur, int c)
         edges.push_back(e);
     }
     lpslam_hip_sim3* graph = nullptr;
-    if (lpslam_hip_sim3_create(m_ctx, verts.data(), fixed.data(), n, edges.data(), (int32_t)edges.size(), 1, &graph) != LPSLAM_HIP_OK) return false;
+    if (lpslam_hip_sim3_create(m_ctx, verts.data(), fixed.data(), n, edges.data(), (int32_t)edges.size(), fix_scale ? 1 : 0, &graph) != LPSLAM_HIP_OK) return false;
     int32_t done = 0;
     const bool ok = lpslam_hip_sim3_optimize(graph, 50, nullptr, &done) == LPSLAM_HIP_OK && lpslam_hip_sim3_get(graph, verts.data()) == LPSLAM_HIP_OK;
     lpslam_hip_sim3_destroy(graph);
     if (!ok) return false;
     finishMapping();                                     // no window solve may be in flight while the map moves
     std::vector<Se3> neu((size_t)n);
+    std::vector<double> scale((size_t)n, 1.0);
     for (int v = 0; v < n; ++v) {
         const double* r = &verts[8 * (size_t)v];
         const double qn = std::sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3]), s = r[7] > 0 ? r[7] : 1.0;
+        scale[(size_t)v] = s;                            // Sim3 (R, t, s) -> SE3 (R, t / s): camera coordinates shrink by s
         neu[(size_t)v] = Se3{{r[0] / qn, r[1] / qn, r[2] / qn, r[3] / qn}, {r[4] / s, r[5] / s, r[6] / s}};
         Pose& p = m_kfs[(size_t)(a0 + v)].pose;
         for (int k = 0; k < 4; ++k) p.q[k] = neu[(size_t)v].q[k];
@@ -1425,7 +1442,8 @@ bool HipVslamTrackerBase::detectAndCloseLoop(FrameData& cur, int c)
         const Se3& To = old[(size_t)(rk - a0)]; const Se3 Tni = se3_inv(neu[(size_t)(rk - a0)]);
         const Mat3 Ro = quatToRot(To.q), Rn = quatToRot(Tni.q);
         double xc[3], xw[3];
-        for (int r = 0; r < 3; ++r) xc[r] = Ro.m[r * 3] * kv.second.p[0] + Ro.m[r * 3 + 1] * kv.second.p[1] + Ro.m[r * 3 + 2] * kv.second.p[2] + To.t[r];
+        const double sc = scale[(size_t)(rk - a0)];
+        for (int r = 0; r < 3; ++r) xc[r] = (Ro.m[r * 3] * kv.second.p[0] + Ro.m[r * 3 + 1] * kv.second.p[1] + Ro.m[r * 3 + 2] * kv.second.p[2] + To.t[r]) / sc;
         for (int r = 0; r < 3; ++r) xw[r] = Rn.m[r * 3] * xc[0] + Rn.m[r * 3 + 1] * xc[1] + Rn.m[r * 3 + 2] * xc[2] + Tni.t[r];
         for (int r = 0; r < 3; ++r) kv.second.p[r] = xw[r];
     }
@@ -1740,7 +1758,7 @@ TrackerBase::ProcessImageResult HipVslamTrackerBase::trackFrame(CameraQueueEntry
             if (keyframeNeeded(inliers)) {
                 finishMapping();                    // the previous keyframe's solve enters the map before the next one is inserted
                 const int c = insertKeyframe(cur);
-                if (m_stereo && m_loopClosure) detectAndCloseLoop(cur, c);
+                if (m_loopClosure) detectAndCloseLoop(cur, c);
                 startMapping(c);
                 if (!m_asyncMapping) cur.pose = m_kfs[(size_t)c].pose;
                 lap(m_stats.t_keyframe);

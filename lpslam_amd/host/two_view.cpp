@@ -456,6 +456,91 @@ bool two_view_initialize(const double* K, const float* kp_ref, const float* kp_c
     return true;
 }
 
+
+bool horn_absolute_orientation(const double* x1, const double* x2, int n, bool fix_scale, double* R, double* t, double* s_out)
+{
+    if (n < 3) return false;
+    double o1[3] = {0, 0, 0}, o2[3] = {0, 0, 0};
+    for (int i = 0; i < n; ++i) for (int a = 0; a < 3; ++a) { o1[a] += x1[3 * i + a]; o2[a] += x2[3 * i + a]; }
+    for (int a = 0; a < 3; ++a) { o1[a] /= n; o2[a] /= n; }
+    double M[9] = {0};                                   // M[a][b] = sum (x2 - o2)[a] (x1 - o1)[b]
+    for (int i = 0; i < n; ++i)
+        for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) M[a * 3 + b] += (x2[3 * i + a] - o2[a]) * (x1[3 * i + b] - o1[b]);
+    const double N[16] = {M[0] + M[4] + M[8], M[5] - M[7], M[6] - M[2], M[1] - M[3],
+                          M[5] - M[7], M[0] - M[4] - M[8], M[1] + M[3], M[6] + M[2],
+                          M[6] - M[2], M[1] + M[3], -M[0] + M[4] - M[8], M[5] + M[7],
+                          M[1] - M[3], M[6] + M[2], M[5] + M[7], -M[0] - M[4] + M[8]};
+    double ev[4], evec[16];
+    sym_eigen_jacobi(N, 4, ev, evec);                    // ascending: the last column belongs to the largest eigenvalue
+    double q[4] = {evec[3], evec[7], evec[11], evec[15]};
+    const double qn = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    if (!(qn > 0)) return false;
+    for (double& v : q) v /= qn;
+    const double w = q[0], x = q[1], y = q[2], z = q[3];
+    const double Rm[9] = {1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
+                          2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
+                          2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)};
+    double sc = 1.0;
+    if (!fix_scale) {
+        double nom = 0, den = 0;
+        for (int i = 0; i < n; ++i) {
+            double p3[3];
+            for (int r = 0; r < 3; ++r) p3[r] = Rm[r * 3] * (x2[3 * i] - o2[0]) + Rm[r * 3 + 1] * (x2[3 * i + 1] - o2[1]) + Rm[r * 3 + 2] * (x2[3 * i + 2] - o2[2]);
+            for (int r = 0; r < 3; ++r) { nom += (x1[3 * i + r] - o1[r]) * p3[r]; den += p3[r] * p3[r]; }
+        }
+        if (!(den > 0) || !(nom > 0)) return false;
+        sc = nom / den;
+    }
+    for (int k = 0; k < 9; ++k) R[k] = Rm[k];
+    for (int r = 0; r < 3; ++r) t[r] = o1[r] - sc * (Rm[r * 3] * o2[0] + Rm[r * 3 + 1] * o2[1] + Rm[r * 3 + 2] * o2[2]);
+    *s_out = sc;
+    return true;
+}
+
+int sim3_solve_ransac(const double* p1c, const double* p2c, const double* obs1, const double* obs2, const double* inv_sigma2_1, const double* inv_sigma2_2,
+                      int n, const double* cam1, const double* cam2, bool fix_scale, int iterations, uint32_t seed, double* s12, uint8_t* inlier)
+{
+    if (n < 3) return 0;
+    Rng rng{seed ? seed : 1u};
+    std::vector<int> avail((size_t)n);
+    std::vector<uint8_t> cur((size_t)n);
+    int best = 0;
+    for (int it = 0; it < iterations; ++it) {
+        for (int i = 0; i < n; ++i) avail[(size_t)i] = i;
+        int left = n, idx[3];
+        for (int k = 0; k < 3; ++k) { const int r = (int)(rng.next() % (uint32_t)left); idx[k] = avail[(size_t)r]; avail[(size_t)r] = avail[(size_t)left - 1]; --left; }
+        double a1[9], a2[9], R[9], t[3], sc;
+        for (int k = 0; k < 3; ++k) for (int a = 0; a < 3; ++a) { a1[3 * k + a] = p1c[3 * idx[k] + a]; a2[3 * k + a] = p2c[3 * idx[k] + a]; }
+        if (!horn_absolute_orientation(a1, a2, 3, fix_scale, R, t, &sc)) continue;
+        int count = 0;
+        for (int i = 0; i < n; ++i) {
+            cur[(size_t)i] = 0;
+            // 2 -> 1: x1 = s R x2 + t;  1 -> 2: x2 = R^T (x1 - t) / s
+            double q1[3], q2[3];
+            for (int r = 0; r < 3; ++r) q1[r] = sc * (R[r * 3] * p2c[3 * i] + R[r * 3 + 1] * p2c[3 * i + 1] + R[r * 3 + 2] * p2c[3 * i + 2]) + t[r];
+            const double d[3] = {p1c[3 * i] - t[0], p1c[3 * i + 1] - t[1], p1c[3 * i + 2] - t[2]};
+            for (int r = 0; r < 3; ++r) q2[r] = (R[r] * d[0] + R[3 + r] * d[1] + R[6 + r] * d[2]) / sc;
+            if (!(q1[2] > 0) || !(q2[2] > 0)) continue;
+            const double e1x = cam1[0] * q1[0] / q1[2] + cam1[2] - obs1[2 * i], e1y = cam1[1] * q1[1] / q1[2] + cam1[3] - obs1[2 * i + 1];
+            const double e2x = cam2[0] * q2[0] / q2[2] + cam2[2] - obs2[2 * i], e2y = cam2[1] * q2[1] / q2[2] + cam2[3] - obs2[2 * i + 1];
+            if ((e1x * e1x + e1y * e1y) * inv_sigma2_1[i] < 9.210 && (e2x * e2x + e2y * e2y) * inv_sigma2_2[i] < 9.210) { cur[(size_t)i] = 1; ++count; }
+        }
+        if (count > best) {
+            best = count;
+            // rotation matrix -> quaternion (Eigen::Quaterniond(R))
+            const double tr = R[0] + R[4] + R[8];
+            double q[4];
+            if (tr > 0) { const double s4 = std::sqrt(tr + 1.0) * 2; q[0] = 0.25 * s4; q[1] = (R[7] - R[5]) / s4; q[2] = (R[2] - R[6]) / s4; q[3] = (R[3] - R[1]) / s4; }
+            else if (R[0] > R[4] && R[0] > R[8]) { const double s4 = std::sqrt(1.0 + R[0] - R[4] - R[8]) * 2; q[0] = (R[7] - R[5]) / s4; q[1] = 0.25 * s4; q[2] = (R[1] + R[3]) / s4; q[3] = (R[2] + R[6]) / s4; }
+            else if (R[4] > R[8]) { const double s4 = std::sqrt(1.0 + R[4] - R[0] - R[8]) * 2; q[0] = (R[2] - R[6]) / s4; q[1] = (R[1] + R[3]) / s4; q[2] = 0.25 * s4; q[3] = (R[5] + R[7]) / s4; }
+            else { const double s4 = std::sqrt(1.0 + R[8] - R[0] - R[4]) * 2; q[0] = (R[3] - R[1]) / s4; q[1] = (R[2] + R[6]) / s4; q[2] = (R[5] + R[7]) / s4; q[3] = 0.25 * s4; }
+            s12[0] = q[0]; s12[1] = q[1]; s12[2] = q[2]; s12[3] = q[3]; s12[4] = t[0]; s12[5] = t[1]; s12[6] = t[2]; s12[7] = sc;
+            if (inlier) std::copy(cur.begin(), cur.end(), inlier);
+        }
+    }
+    return best;
+}
+
 }  // namespace LpSlam
 
 // ---- C shim for the ctypes tests ------------------------------------------------------------------------------------------
@@ -485,4 +570,11 @@ __attribute__((visibility("default"))) int lpslam_two_view_initialize(const doub
 }
 
 __attribute__((visibility("default"))) void lpslam_sym_eigen(const double* A, int n, double* eigval, double* eigvec) { LpSlam::sym_eigen_jacobi(A, n, eigval, eigvec); }
+}
+
+extern "C" __attribute__((visibility("default"))) int lpslam_sim3_solve_ransac(const double* p1c, const double* p2c, const double* obs1, const double* obs2,
+                                                                                const double* is1, const double* is2, int n, const double* cam1, const double* cam2,
+                                                                                int fix_scale, int iterations, uint32_t seed, double* s12, uint8_t* inlier)
+{
+    return LpSlam::sim3_solve_ransac(p1c, p2c, obs1, obs2, is1, is2, n, cam1, cam2, fix_scale != 0, iterations, seed, s12, inlier);
 }

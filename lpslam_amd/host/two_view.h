@@ -46,4 +46,15 @@ void homography_from_matches(const double* x1, const double* x2, int n, double* 
 void fundamental_from_matches(const double* x1, const double* x2, int n, double* F);  // 8-point + rank 2, x2^T F x1 = 0
 bool triangulate_point(const double* P1, const double* P2, const double* x1, const double* x2, double* X);
 
+// [UPSTREAM] solve::sim3_solver (ORB-SLAM Sim3Solver): the similarity (or rigid, fix_scale) transform between two keyframes from
+// matched landmarks given in each keyframe's camera frame -- x1 = s R x2 + t -- by Horn's closed-form absolute orientation on
+// 3-match samples (RANSAC, xorshift32 sampler as in two_view_initialize), scored by the reprojection error in BOTH images
+// (chi-square 9.210 x the keypoint's level sigma^2).  This is what gives a loop candidate a transform WITHOUT trusting the current
+// (drifted) pose estimates; the Sim3 optimiser on the device refines it.  p1c / p2c: n x 3, obs1 / obs2: n x 2 pixels,
+// inv_sigma2_*: n.  Returns the number of inliers of the best hypothesis (0: none found); s12 = (qw qx qy qz tx ty tz s).
+int sim3_solve_ransac(const double* p1c, const double* p2c, const double* obs1, const double* obs2, const double* inv_sigma2_1, const double* inv_sigma2_2,
+                      int n, const double* cam1 /* fx fy cx cy */, const double* cam2, bool fix_scale, int iterations, uint32_t seed, double* s12, uint8_t* inlier);
+// Horn's absolute orientation of n >= 3 matched points: x1 = s R x2 + t (R row major)
+bool horn_absolute_orientation(const double* x1, const double* x2, int n, bool fix_scale, double* R, double* t, double* s);
+
 }  // namespace LpSlam

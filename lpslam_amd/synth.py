@@ -136,28 +136,52 @@ def turning_sequence(width, height, n_frames=132, step_deg=3.0, seq_id=4, n_poin
 class WallSequence:
     """Monocular test scene: three fronto-parallel textured walls at 14, 9 and 6 m, one per horizontal band of the image, seen by a
     camera that moves sideways by `step` metres per frame.  Every wall slides by a whole number of pixels (f * x / depth, rounded),
-    so descriptors do not change between frames, while the three depths give the parallax a two-view initialisation needs."""
+    so descriptors do not change between frames, while the three depths give the parallax a two-view initialisation needs.
 
-    def __init__(self, width, height, seq_id=0, step=0.1, depths=(14.0, 9.0, 6.0), margin=None):
+    rectangle = (a, b): the camera goes a frames to the right, b frames up, a frames to the left and b frames down -- never turning --
+    and is back where it started at frame 2 (a + b): a real loop for the monocular loop-closure tests.  The walls then slide
+    vertically as well, behind the same three bands of the image."""
+
+    def __init__(self, width, height, seq_id=0, step=0.1, depths=(14.0, 9.0, 6.0), margin=None, rectangle=None):
         self.w, self.h, self.step, self.depths = int(width), int(height), float(step), tuple(depths)
         self.k = intrinsics(width, height)
         rng = np.random.default_rng(SEED_BASE + 7919 * int(seq_id) + 3)
         self.band_h = self.h // len(self.depths)
         self.margin = int(margin if margin is not None else 0.75 * self.w)
+        self.rectangle = rectangle
         self.walls = []
-        for _ in self.depths:
-            t = rng.integers(0, 256, (self.band_h, self.w + self.margin)).astype(np.float64)
+        for z in self.depths:
+            extra_x, extra_y = self.margin, 0
+            if rectangle:
+                extra_x = int(round(self.k["fx"] * self.step * rectangle[0] / z)) + 1
+                extra_y = int(round(self.k["fy"] * self.step * rectangle[1] / z)) + 1
+            t = rng.integers(0, 256, (self.band_h + extra_y, self.w + extra_x)).astype(np.float64)
             t = (t + np.roll(t, 1, 0) + np.roll(t, 1, 1) + np.roll(t, (1, 1), (0, 1))) / 4.0        # 2x2 box: corners FAST still likes
             self.walls.append(60 + (t - t.min()) * (150.0 / (t.max() - t.min())))
 
     def centre(self, i):
-        return np.array([self.step * i, 0.0, 0.0])
+        if not self.rectangle:
+            return np.array([self.step * i, 0.0, 0.0])
+        a, b = self.rectangle
+        i = int(i) % (2 * (a + b))
+        if i <= a:
+            return np.array([self.step * i, 0.0, 0.0])
+        if i <= a + b:
+            return np.array([self.step * a, -self.step * (i - a), 0.0])                  # image y points down: "up" is -y
+        if i <= 2 * a + b:
+            return np.array([self.step * (2 * a + b - i), -self.step * b, 0.0])
+        return np.array([0.0, -self.step * (2 * (a + b) - i), 0.0])
 
     def frame(self, i):
         img = np.zeros((self.h, self.w))
+        c = self.centre(i)
         for b, (z, wall) in enumerate(zip(self.depths, self.walls)):
-            shift = min(int(round(self.k["fx"] * self.step * i / z)), self.margin)       # the wall moves left as the camera moves right
-            img[b * self.band_h:(b + 1) * self.band_h] = wall[:, shift:shift + self.w]
+            if self.rectangle:
+                sx = int(round(self.k["fx"] * c[0] / z))                 # the wall moves left as the camera moves right
+            else:
+                sx = min(int(round(self.k["fx"] * self.step * i / z)), self.margin)
+            sy = wall.shape[0] - self.band_h - int(round(self.k["fy"] * -c[1] / z))       # ... and down as the camera moves up
+            img[b * self.band_h:(b + 1) * self.band_h] = wall[sy:sy + self.band_h, sx:sx + self.w]
         img[len(self.depths) * self.band_h:] = 110.0
         img += np.random.Generator(np.random.PCG64([SEED_BASE, 91, int(i)])).normal(0, 1.0, img.shape)
         return np.clip(np.rint(img), 0, 255).astype(np.uint8)

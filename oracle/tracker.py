@@ -20,6 +20,7 @@ import math
 import numpy as np
 
 from . import oracle as O
+from . import two_view as TV
 
 F32 = np.float32
 
@@ -699,17 +700,21 @@ class StereoTracker:
                 rows["obs2"][n_] = [float(ka["kpts"]["x"][ia]), float(ka["kpts"]["y"][ia])]
                 s1 = float(self.scales[int(kc["kpts"]["octave"][ic])]); s2 = float(self.scales[int(ka["kpts"]["octave"][ia])])
                 rows["inv_sigma2_1"][n_] = 1.0 / (s1 * s1); rows["inv_sigma2_2"][n_] = 1.0 / (s2 * s2)
-            T12 = self._se3_mul(kc["pose"], self._se3_inv(ka["pose"]))                 # candidate camera -> current camera
-            s12, _, n_inl = O.sim3_transform_optimize(np.array(T12.q + T12.t + [1.0]), rows, cam4, cam4, 10.0, True)
-            results.append((n_inl, s12))
+            # [UPSTREAM] solve::sim3_solver: candidate camera -> current camera from the matched landmarks alone (Horn + RANSAC)
+            found, seed12, _ = TV.sim3_solve_ransac(rows["p1c"], rows["p2c"], rows["obs1"], rows["obs2"], rows["inv_sigma2_1"], rows["inv_sigma2_2"],
+                                                    cam4, cam4, self.stereo, 200, 0x9E3779B9)
+            if found < 12:                             # the seed's minimum; the deciding count is the optimiser's (20)
+                continue
+            s12, _, n_inl = O.sim3_transform_optimize(seed12, rows, cam4, cam4, 10.0, self.stereo)      # monocular: the scale is free
+            results.append((n_inl, s12, a))
         best = -1
-        for i, (n_inl, _) in enumerate(results):
+        for i, (n_inl, _, _) in enumerate(results):
             if n_inl >= 20 and (best < 0 or n_inl > results[best][0]):
                 best = i
         if best < 0:
             return False
         # ---- pose graph over the keyframes of the loop: a0 = candidate (fixed) ... c
-        a0 = votes[best][0]
+        a0 = results[best][2]
         n = c - a0 + 1
         old = [self.kfs[a0 + v]["pose"].copy() for v in range(n)]
         verts = np.array([p_.q + p_.t + [1.0] for p_ in old], np.float64)
@@ -719,13 +724,14 @@ class StereoTracker:
             m = self._se3_mul(old[v + 1], self._se3_inv(old[v]))
             ei.append(v); ej.append(v + 1); meas.append(m.q + m.t + [1.0])
         ei.append(0); ej.append(n - 1); meas.append(list(results[best][1]))
-        verts, _ = O.sim3_graph_optimize(verts, fixed, O.sim3_edges(np.array(ei, np.int32), np.array(ej, np.int32), np.array(meas, np.float64)), True, 50)
+        verts, _ = O.sim3_graph_optimize(verts, fixed, O.sim3_edges(np.array(ei, np.int32), np.array(ej, np.int32), np.array(meas, np.float64)), self.stereo, 50)
         self.finish_mapping()
-        neu = []
+        neu, scale = [], []
         for v in range(n):
             r = verts[v]
             qn = math.sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3]); sc = r[7] if r[7] > 0 else 1.0
             neu.append(Pose([r[0] / qn, r[1] / qn, r[2] / qn, r[3] / qn], [r[4] / sc, r[5] / sc, r[6] / sc]))
+            scale.append(sc)
             self.kfs[a0 + v]["pose"] = neu[v].copy()
         for lm in self.landmarks.values():                   # X_new = T_ref_new^-1 (T_ref_old X)
             rk = lm["ref_kf"]
@@ -733,7 +739,8 @@ class StereoTracker:
                 continue
             To, Tni = old[rk - a0], self._se3_inv(neu[rk - a0])
             Ro, Rn = quat_to_rot(To.q), quat_to_rot(Tni.q)
-            xc = [Ro[r, 0] * lm["p"][0] + Ro[r, 1] * lm["p"][1] + Ro[r, 2] * lm["p"][2] + To.t[r] for r in range(3)]
+            sc = scale[rk - a0]                                # Sim3 (R, t, s) -> SE3 (R, t / s): camera coordinates shrink by s
+            xc = [(Ro[r, 0] * lm["p"][0] + Ro[r, 1] * lm["p"][1] + Ro[r, 2] * lm["p"][2] + To.t[r]) / sc for r in range(3)]
             lm["p"] = [Rn[r, 0] * xc[0] + Rn[r, 1] * xc[1] + Rn[r, 2] * xc[2] + Tni.t[r] for r in range(3)]
         cur.pose = self.kfs[c]["pose"].copy()
         # ---- the revisited structure exists twice: fuse the candidate's neighbourhood into the new keyframe
@@ -862,7 +869,7 @@ class StereoTracker:
             if self.keyframe_needed(inliers):
                 self.finish_mapping()                           # the previous keyframe's solve enters the map before the next one is inserted
                 c = self.insert_keyframe(cur)
-                if self.loop_closure and self.stereo:
+                if self.loop_closure:
                     self.detect_and_close_loop(cur, c)
                 self.start_mapping(c)
                 if not self.async_mapping:

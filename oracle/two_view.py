@@ -204,3 +204,70 @@ def initialize(k, kp_ref, kp_cur, matches, sigma=1.0, ransac_iters=100, seed=0x9
         return res
     res.update(ok=True, R=r, t=t, points=pts, triangulated=good)
     return res
+
+
+# ---- [UPSTREAM] solve::sim3_solver: Horn's absolute orientation on 3-match samples, RANSAC over the reprojection error in both images
+def horn(x1, x2, fix_scale):
+    """x1 = s R x2 + t from n >= 3 matched 3D points (rows); returns (R, t, s) or None"""
+    x1 = np.asarray(x1, float); x2 = np.asarray(x2, float)
+    o1, o2 = x1.mean(axis=0), x2.mean(axis=0)
+    a, b = x2 - o2, x1 - o1
+    m = a.T @ b                                          # m[i, j] = sum a_i b_j
+    n = np.array([[m[0, 0] + m[1, 1] + m[2, 2], m[1, 2] - m[2, 1], m[2, 0] - m[0, 2], m[0, 1] - m[1, 0]],
+                  [m[1, 2] - m[2, 1], m[0, 0] - m[1, 1] - m[2, 2], m[0, 1] + m[1, 0], m[2, 0] + m[0, 2]],
+                  [m[2, 0] - m[0, 2], m[0, 1] + m[1, 0], -m[0, 0] + m[1, 1] - m[2, 2], m[1, 2] + m[2, 1]],
+                  [m[0, 1] - m[1, 0], m[2, 0] + m[0, 2], m[1, 2] + m[2, 1], -m[0, 0] - m[1, 1] + m[2, 2]]])
+    _, vec = np.linalg.eigh(n)
+    q = vec[:, -1]
+    q = q / np.linalg.norm(q)
+    w, x, y, z = q
+    r = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                  [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                  [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+    s = 1.0
+    if not fix_scale:
+        p3 = a @ r.T
+        nom, den = float((b * p3).sum()), float((p3 * p3).sum())
+        if not (den > 0) or not (nom > 0):
+            return None
+        s = nom / den
+    return r, o1 - s * (r @ o2), s
+
+
+def sim3_solve_ransac(p1c, p2c, obs1, obs2, is1, is2, cam1, cam2, fix_scale, iterations=200, seed=0x9E3779B9):
+    """returns (n_inliers, s12 (qw qx qy qz tx ty tz s) or None, inlier flags)"""
+    p1c = np.asarray(p1c, float); p2c = np.asarray(p2c, float); obs1 = np.asarray(obs1, float); obs2 = np.asarray(obs2, float)
+    n = len(p1c)
+    best, best_s12, best_inl = 0, None, np.zeros(n, bool)
+    if n < 3:
+        return 0, None, best_inl
+    rng = _Rng(seed)
+    for _ in range(iterations):
+        avail = list(range(n)); left = n; idx = []
+        for _k in range(3):
+            r = rng.next() % left
+            idx.append(avail[r]); avail[r] = avail[left - 1]; left -= 1
+        h = horn(p1c[idx], p2c[idx], fix_scale)
+        if h is None:
+            continue
+        r, t, s = h
+        q1 = s * (p2c @ r.T) + t
+        q2 = ((p1c - t) @ r) / s
+        with np.errstate(divide="ignore", invalid="ignore"):
+            e1 = np.stack([cam1[0] * q1[:, 0] / q1[:, 2] + cam1[2], cam1[1] * q1[:, 1] / q1[:, 2] + cam1[3]], 1) - obs1
+            e2 = np.stack([cam2[0] * q2[:, 0] / q2[:, 2] + cam2[2], cam2[1] * q2[:, 1] / q2[:, 2] + cam2[3]], 1) - obs2
+            inl = (q1[:, 2] > 0) & (q2[:, 2] > 0) & ((e1 * e1).sum(1) * is1 < 9.210) & ((e2 * e2).sum(1) * is2 < 9.210)
+        c = int(inl.sum())
+        if c > best:
+            m = r.reshape(9)
+            tr = m[0] + m[4] + m[8]
+            if tr > 0:
+                s4 = np.sqrt(tr + 1.0) * 2; q = [0.25 * s4, (m[7] - m[5]) / s4, (m[2] - m[6]) / s4, (m[3] - m[1]) / s4]
+            elif m[0] > m[4] and m[0] > m[8]:
+                s4 = np.sqrt(1.0 + m[0] - m[4] - m[8]) * 2; q = [(m[7] - m[5]) / s4, 0.25 * s4, (m[1] + m[3]) / s4, (m[2] + m[6]) / s4]
+            elif m[4] > m[8]:
+                s4 = np.sqrt(1.0 + m[4] - m[0] - m[8]) * 2; q = [(m[2] - m[6]) / s4, (m[1] + m[3]) / s4, 0.25 * s4, (m[5] + m[7]) / s4]
+            else:
+                s4 = np.sqrt(1.0 + m[8] - m[0] - m[4]) * 2; q = [(m[3] - m[1]) / s4, (m[2] + m[6]) / s4, (m[5] + m[7]) / s4, 0.25 * s4]
+            best, best_s12, best_inl = c, np.array(q + [t[0], t[1], t[2], s], float), inl.copy()
+    return best, best_s12, best_inl

@@ -1,7 +1,7 @@
 """Closed-loop parity of the stereo tracker: the product path (LpSlamManager -> VSLAMStereo tracker -> HIP kernels) against the
-closed-loop oracle (oracle/tracker.py, goldens tests/golden/g10..g15_*.npz made by tools/make_golden_track.py), pose by pose:
+closed-loop oracle (oracle/tracker.py, goldens tests/golden/g10..g16_*.npz made by tools/make_golden_track.py), pose by pose:
 synchronous and asynchronous mapping at 640x480, the benchmark configuration (1280x720, 2000 keypoints, 8 levels), a sequence
-with a loss of tracking and a relocalisation, a full turn that closes a loop, and the monocular tracker on the three-wall scene.  Tolerance: the north star's 1e-4 rad / 1e-3 m, per tracked frame."""
+with a loss of tracking and a relocalisation, a full turn that closes a loop, the monocular tracker on the three-wall scene, and a monocular loop (a rectangular path back to the start).  Tolerance: the north star's 1e-4 rad / 1e-3 m, per tracked frame."""
 import hashlib
 import math
 import time
@@ -31,6 +31,9 @@ CASES = {
     # the monocular tracker: two-view initialisation (homography / fundamental matrix by RANSAC, oracle/two_view.py), global BA of the
     # two-keyframe map, then tracking with keyframes whose new landmarks are triangulated against the previous keyframe
     "g15_track_mono": (640, 480, "walls", None, (), '{"cameraSetup": "monocular", "slamKeypoints": 2000, "numLevels": 3, "keyframeInterval": 4, "localWindow": 10, "asyncMapping": true}'),
+    # a monocular loop: the camera walks a rectangle (never turning) and is back at the start after 190 frames; the similarity to the
+    # revisited keyframe comes from the Sim3 solver (Horn + RANSAC, host/two_view.cpp) with the scale free, then pose graph, fusion, global BA
+    "g16_mono_loop": (640, 480, "rectangle", None, (), '{"cameraSetup": "monocular", "slamKeypoints": 2000, "numLevels": 3, "keyframeInterval": 4, "localWindow": 6, "asyncMapping": true, "loopClosure": true}'),
 }
 
 
@@ -79,8 +82,8 @@ def test_tracked_poses_follow_the_closed_loop_oracle(hiplib, tmp_path, case):
     n = int(g["frames"])
     if seq_id == "turn":
         frames = [list(f) for f in synth.turning_sequence(w, h, n)[0]]
-    elif seq_id == "walls":
-        walls = synth.WallSequence(w, h, 11)
+    elif seq_id in ("walls", "rectangle"):
+        walls = synth.WallSequence(w, h, 11, rectangle=(50, 45) if seq_id == "rectangle" else None)
         frames = [[walls.frame(i), None] for i in range(n)]
     else:
         seq = synth.StereoSequence(w, h, seq_id, n_points=n_points) if n_points else synth.StereoSequence(w, h, seq_id)

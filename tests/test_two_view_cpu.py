@@ -125,3 +125,36 @@ def test_rejections(lib):
     # few points: below Initializer.num_min_triangulated_pts
     kp_ref, kp_cur, matches, *_ = scene(n=30, seed=9)
     assert not run(lib, kp_ref, kp_cur, matches)["ok"]
+
+
+def test_sim3_solver_recovers_a_similarity_and_follows_the_oracle():
+    """[UPSTREAM] solve::sim3_solver (Horn's absolute orientation + RANSAC over the reprojection error in both images): the host
+    mirror (lpslam_amd/host/two_view.cpp through its C shim) recovers a known Sim3 between two keyframes from matched landmarks
+    with 30 % wrong matches, with and without a free scale, and agrees with the numpy restatement (same sampler)."""
+    from lpslam_amd import _build
+    from oracle import two_view as TV
+    l = C.CDLL(_build.host_library())
+    l.lpslam_sim3_solve_ransac.restype = C.c_int
+    l.lpslam_sim3_solve_ransac.argtypes = [C.c_void_p] * 6 + [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(3)
+    cam = np.array([525.0, 525.0, 320.0, 240.0])
+    for fix_scale, s_true in ((True, 1.0), (False, 1.37)):
+        n = 120
+        x2 = np.column_stack([rng.uniform(-3, 3, n), rng.uniform(-2, 2, n), rng.uniform(4, 9, n)])          # landmarks in camera 2
+        r = _rot([0.2, 1.0, -0.1], 0.4); t = np.array([0.8, -0.1, 0.3])
+        x1 = s_true * (x2 @ r.T) + t                                                                           # ... and in camera 1
+        obs1 = np.column_stack([cam[0] * x1[:, 0] / x1[:, 2] + cam[2], cam[1] * x1[:, 1] / x1[:, 2] + cam[3]]) + rng.normal(0, 0.3, (n, 2))
+        obs2 = np.column_stack([cam[0] * x2[:, 0] / x2[:, 2] + cam[2], cam[1] * x2[:, 1] / x2[:, 2] + cam[3]]) + rng.normal(0, 0.3, (n, 2))
+        bad = rng.random(n) < 0.3
+        x1n = x1 + rng.normal(0, 0.01, x1.shape); x1n[bad] += rng.normal(0, 1.5, (int(bad.sum()), 3))          # wrong matches
+        is1 = np.ones(n); is2 = np.ones(n)
+        s12 = np.zeros(8); inl = np.zeros(n, np.uint8)
+        got = l.lpslam_sim3_solve_ransac(_p(np.ascontiguousarray(x1n)), _p(np.ascontiguousarray(x2)), _p(np.ascontiguousarray(obs1)), _p(np.ascontiguousarray(obs2)),
+                                         _p(is1), _p(is2), n, _p(cam), _p(cam), int(fix_scale), 200, 0x9E3779B9, _p(s12), _p(inl))
+        want, os12, oinl = TV.sim3_solve_ransac(x1n, x2, obs1, obs2, is1, is2, cam, cam, fix_scale, 200, 0x9E3779B9)
+        assert got == want and np.array_equal(inl.astype(bool), oinl) and np.allclose(s12, os12, atol=1e-9)
+        assert got >= 0.55 * n and not np.any(inl.astype(bool) & bad & (np.linalg.norm(x1n - x1, axis=1) > 0.5))
+        q = s12[:4]; w, x, y, z = q
+        rr = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)], [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                       [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+        assert np.abs(rr - r).max() < 0.02 and np.abs(s12[4:7] - t).max() < 0.1 and abs(s12[7] - s_true) < 0.02

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Generates the closed-loop goldens tests/golden/g10..g13_*.npz: per-frame poses of synthetic stereo sequences from the closed-loop
+"""Generates the closed-loop goldens tests/golden/g10..g16_*.npz: per-frame poses of synthetic stereo sequences from the closed-loop
 oracle (oracle/tracker.py).  The images come from the committed generator (lpslam_amd/synth.py) and are pinned by a hash.
 
   g10_track        640x480, 1000 keypoints, 4 levels, 24 frames, asyncMapping false                     (round 2)
@@ -9,7 +9,10 @@ oracle (oracle/tracker.py).  The images come from the committed generator (lpsla
   g15_track_mono   640x480 monocular, 30 frames of the three-wall scene: two-view initialisation, tracking, triangulated keyframes
   g14_track_loop   640x480, 132 frames of a full turn on the spot, loopClosure true: voting, Sim3 verification, pose graph, fusion, global BA
 
-usage: make_golden_track.py [g10 g11 g12 g13 g14 g15]      (default: all)"""
+  g16_mono_loop    640x480 monocular, 210 frames of the three-wall scene on a rectangular path (right, up, left, down, back at the start):
+                   a monocular loop -- Sim3 with a free scale from the Sim3 solver, pose graph, fusion, global BA
+
+usage: make_golden_track.py [g10 g11 g12 g13 g14 g15 g16]      (default: all)"""
 import hashlib
 import os
 import sys
@@ -34,6 +37,8 @@ CASES = {
                            cfg=dict(max_keypoints=1000, num_levels=4, scale_factor=1.2, keyframe_interval=4, local_window=10, async_mapping=True)),
     "g15_track_mono": dict(w=640, h=480, n=30, seq="walls", points=None, blank=(), mono=True,
                            cfg=dict(max_keypoints=2000, num_levels=3, scale_factor=1.2, keyframe_interval=4, local_window=10, async_mapping=True)),
+    "g16_mono_loop": dict(w=640, h=480, n=210, seq="rectangle", points=None, blank=(), mono=True,
+                          cfg=dict(max_keypoints=2000, num_levels=3, scale_factor=1.2, keyframe_interval=4, local_window=6, async_mapping=True, loop_closure=True)),
     "g14_track_loop": dict(w=640, h=480, n=132, seq="turn", points=None, blank=(),
                            cfg=dict(max_keypoints=1000, num_levels=4, scale_factor=1.2, keyframe_interval=3, local_window=4, async_mapping=True, loop_closure=True)),
 }
@@ -43,8 +48,8 @@ def frames_of(case):
     c = CASES[case]
     if c["seq"] == "turn":
         return [list(f) for f in synth.turning_sequence(c["w"], c["h"], c["n"])[0]]
-    if c["seq"] == "walls":
-        walls = synth.WallSequence(c["w"], c["h"], 11)
+    if c["seq"] in ("walls", "rectangle"):
+        walls = synth.WallSequence(c["w"], c["h"], 11, rectangle=(50, 45) if c["seq"] == "rectangle" else None)
         return [[walls.frame(i), None] for i in range(c["n"])]
     seq = synth.StereoSequence(c["w"], c["h"], c["seq"], n_points=c["points"]) if c["points"] else synth.StereoSequence(c["w"], c["h"], c["seq"])
     frames = [list(seq.frame(i)) for i in range(c["n"])]
