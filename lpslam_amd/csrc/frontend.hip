@@ -212,8 +212,11 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
         __syncthreads();
         const int l16 = lane & 15, rs = lane >> 4;
         int n_mine = 0;                                  // entries of this wavefront's queue (uniform)
-        for (int r4 = wave * 4; r4 < vh; r4 += 16) {
-            const int r = r4 + rs;                       // tested row (tile row r + 3); rows past vh read inside the tile and are masked out
+        // Rows of the four 16-lane groups: the two groups of a 32-lane half (the unit the LDS serves a dword read in) take rows FOUR
+        // apart -- 4 x 20 dwords = 80 = 16 (mod 32 banks), so their 16 consecutive dwords fall on disjoint banks; neighbouring rows
+        // (20 dwords apart) shared four banks and every one of the eleven reads below took two passes.
+        for (int r4 = wave * 8; r4 < vh; r4 += (r4 & 2) ? 30 : 2) {
+            const int r = r4 + (rs >> 1) + 4 * (rs & 1);  // tested row (tile row r + 3); rows past vh read inside the tile and are masked out
             const uint32_t* t = reinterpret_cast<const uint32_t*>(&tile[min(r + 3, 66) * TILE_PITCH]) + 1 + l16;      // the lane's own dword
             const uint32_t* tu = t - 2 * (TILE_PITCH / 4), *td = t + 2 * (TILE_PITCH / 4);
             const uint32_t C = t[0], Cl = t[-1], Cr = t[1];

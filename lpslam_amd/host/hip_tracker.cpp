@@ -1254,9 +1254,30 @@ bool HipVslamTrackerBase::relocalise(FrameData& cur)
             }
         }
         if (cur_idx.size() < 15) continue;
+        // [UPSTREAM] solve::pnp_solver: the pose from the matches alone -- no prior, the camera may be anywhere that sees these
+        // landmarks -- refined by the pose optimiser ([UPSTREAM] min_num_inliers 10 for the solver)
+        Pose seed = kf.pose;
+        {
+            const size_t nm2 = cur_idx.size();
+            std::vector<double> pw(3 * nm2), ob(2 * nm2), w(nm2);
+            for (size_t k = 0; k < nm2; ++k) {
+                const Landmark& lm = m_landmarks.at(lm_ids[k]);
+                const lpslam_hip_keypoint& kp = cur.kpts[(size_t)cur_idx[k]];
+                for (int a = 0; a < 3; ++a) pw[3 * k + (size_t)a] = lm.p[a];
+                ob[2 * k] = kp.x; ob[2 * k + 1] = kp.y;
+                const double sc = m_scales[kp.octave];
+                w[k] = 1.0 / (sc * sc);
+            }
+            const double cam4[4] = {m_cam.f_x, m_cam.f_y, m_cam.c_x, m_cam.c_y};
+            double p7[7];
+            std::vector<uint8_t> pnp_inl(nm2);
+            if (pnp_solve_ransac(pw.data(), ob.data(), w.data(), (int)nm2, cam4, 100, 0x9E3779B9u, p7, pnp_inl.data()) < 10) continue;
+            for (int a = 0; a < 4; ++a) seed.q[a] = p7[a];
+            for (int a = 0; a < 3; ++a) seed.t[a] = p7[4 + a];
+        }
         int inl = 0;
         FrameData trial = cur;
-        if (!poseFromMatches(trial, cur_idx, lm_ids, kf.pose, inl, 30)) continue;
+        if (!poseFromMatches(trial, cur_idx, lm_ids, seed, inl, 30)) continue;
         cur.pose = trial.pose; cur.landmark = trial.landmark;
         logMessage(LpSlamLogLevel_Info, "VSLAM relocalised against keyframe " + std::to_string(nc.second) + " with " + std::to_string(inl) + " inliers");
         return true;

@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <complex>
 #include <cstring>
 #include <limits>
 
@@ -497,6 +498,16 @@ bool horn_absolute_orientation(const double* x1, const double* x2, int n, bool f
     return true;
 }
 
+// rotation matrix (row major) -> quaternion w x y z (Eigen::Quaterniond(R))
+static void rot_to_quat(const double* R, double* q)
+{
+    const double tr = R[0] + R[4] + R[8];
+    if (tr > 0) { const double s4 = std::sqrt(tr + 1.0) * 2; q[0] = 0.25 * s4; q[1] = (R[7] - R[5]) / s4; q[2] = (R[2] - R[6]) / s4; q[3] = (R[3] - R[1]) / s4; }
+    else if (R[0] > R[4] && R[0] > R[8]) { const double s4 = std::sqrt(1.0 + R[0] - R[4] - R[8]) * 2; q[0] = (R[7] - R[5]) / s4; q[1] = 0.25 * s4; q[2] = (R[1] + R[3]) / s4; q[3] = (R[2] + R[6]) / s4; }
+    else if (R[4] > R[8]) { const double s4 = std::sqrt(1.0 + R[4] - R[0] - R[8]) * 2; q[0] = (R[2] - R[6]) / s4; q[1] = (R[1] + R[3]) / s4; q[2] = 0.25 * s4; q[3] = (R[5] + R[7]) / s4; }
+    else { const double s4 = std::sqrt(1.0 + R[8] - R[0] - R[4]) * 2; q[0] = (R[3] - R[1]) / s4; q[1] = (R[2] + R[6]) / s4; q[2] = (R[5] + R[7]) / s4; q[3] = 0.25 * s4; }
+}
+
 int sim3_solve_ransac(const double* p1c, const double* p2c, const double* obs1, const double* obs2, const double* inv_sigma2_1, const double* inv_sigma2_2,
                       int n, const double* cam1, const double* cam2, bool fix_scale, int iterations, uint32_t seed, double* s12, uint8_t* inlier)
 {
@@ -527,15 +538,134 @@ int sim3_solve_ransac(const double* p1c, const double* p2c, const double* obs1, 
         }
         if (count > best) {
             best = count;
-            // rotation matrix -> quaternion (Eigen::Quaterniond(R))
-            const double tr = R[0] + R[4] + R[8];
             double q[4];
-            if (tr > 0) { const double s4 = std::sqrt(tr + 1.0) * 2; q[0] = 0.25 * s4; q[1] = (R[7] - R[5]) / s4; q[2] = (R[2] - R[6]) / s4; q[3] = (R[3] - R[1]) / s4; }
-            else if (R[0] > R[4] && R[0] > R[8]) { const double s4 = std::sqrt(1.0 + R[0] - R[4] - R[8]) * 2; q[0] = (R[7] - R[5]) / s4; q[1] = 0.25 * s4; q[2] = (R[1] + R[3]) / s4; q[3] = (R[2] + R[6]) / s4; }
-            else if (R[4] > R[8]) { const double s4 = std::sqrt(1.0 + R[4] - R[0] - R[8]) * 2; q[0] = (R[2] - R[6]) / s4; q[1] = (R[1] + R[3]) / s4; q[2] = 0.25 * s4; q[3] = (R[5] + R[7]) / s4; }
-            else { const double s4 = std::sqrt(1.0 + R[8] - R[0] - R[4]) * 2; q[0] = (R[3] - R[1]) / s4; q[1] = (R[2] + R[6]) / s4; q[2] = (R[5] + R[7]) / s4; q[3] = 0.25 * s4; }
+            rot_to_quat(R, q);
             s12[0] = q[0]; s12[1] = q[1]; s12[2] = q[2]; s12[3] = q[3]; s12[4] = t[0]; s12[5] = t[1]; s12[6] = t[2]; s12[7] = sc;
             if (inlier) std::copy(cur.begin(), cur.end(), inlier);
+        }
+    }
+    return best;
+}
+
+
+// ---- [UPSTREAM] solve::pnp_solver (relocalisation without a pose prior) -------------------------------------------------------------
+// The upstream solver is EPnP inside a RANSAC over 4-match samples; here the minimal solver is the classical three-point one
+// (Grunert's formulation: the two depth ratios u = s2 / s1, v = s3 / s1 from the law of cosines; v is a root of a quartic that is
+// built by polynomial arithmetic, u follows linearly, the pose from Horn's absolute orientation of the three points), the fourth
+// match of a sample picks among its up to four solutions, and inliers are counted by the reprojection error (chi-square 5.991 at
+// the keypoint's level).  The pose optimiser on the device refines the winner, as upstream refines EPnP's.
+namespace {
+typedef std::complex<double> Cx;
+// roots of c[0] + c[1] x + ... + c[4] x^4 (c[4] != 0) by Durand-Kerner, a fixed number of sweeps from fixed starting points
+void quartic_roots(const double* c, Cx* r)
+{
+    const double a3 = c[3] / c[4], a2 = c[2] / c[4], a1 = c[1] / c[4], a0 = c[0] / c[4];
+    const double rad = 1.0 + std::max(std::max(std::fabs(a3), std::fabs(a2)), std::max(std::fabs(a1), std::fabs(a0)));
+    const Cx seed(0.4, 0.9);
+    Cx w(1.0, 0.0);
+    for (int i = 0; i < 4; ++i) { r[i] = w * rad * 0.5; w *= seed; }
+    for (int it = 0; it < 80; ++it) {
+        for (int i = 0; i < 4; ++i) {
+            const Cx x = r[i];
+            const Cx px = (((x + a3) * x + a2) * x + a1) * x + a0;
+            Cx den(1.0, 0.0);
+            for (int k = 0; k < 4; ++k) if (k != i) den *= (x - r[k]);
+            if (std::abs(den) > 0) r[i] = x - px / den;
+        }
+    }
+}
+// up to four (R, t) world -> camera from three world points and their unit bearings; returns the number of solutions
+int p3p_grunert(const double* pw /* 3 x 3 */, const double* f /* 3 x 3 unit bearings */, double (*Rs)[9], double (*ts)[3])
+{
+    auto d2 = [&](int i, int k) { double s = 0; for (int a = 0; a < 3; ++a) { const double d = pw[3 * i + a] - pw[3 * k + a]; s += d * d; } return s; };
+    auto dot = [&](int i, int k) { return f[3 * i] * f[3 * k] + f[3 * i + 1] * f[3 * k + 1] + f[3 * i + 2] * f[3 * k + 2]; };
+    const double a2 = d2(1, 2), b2 = d2(0, 2), c2 = d2(0, 1);
+    if (!(a2 > 1e-12 && b2 > 1e-12 && c2 > 1e-12)) return 0;
+    const double ca = dot(1, 2), cb = dot(0, 2), cg = dot(0, 1);
+    const double q1 = (a2 - c2) / b2, kc = c2 / b2;
+    // u = N(v) / D(v);  1 + u^2 - 2 u cos(gamma) = kc (1 + v^2 - 2 v cos(beta))  ->  D^2 + N^2 - 2 cos(gamma) N D - kc K D^2 = 0
+    const double N[3] = {1.0 + q1, -2.0 * q1 * cb, q1 - 1.0}, D[2] = {2.0 * cg, -2.0 * ca}, K[3] = {1.0, -2.0 * cb, 1.0};
+    double DD[3] = {D[0] * D[0], 2.0 * D[0] * D[1], D[1] * D[1]};
+    double poly[5] = {0, 0, 0, 0, 0};
+    for (int i = 0; i < 3; ++i) poly[i] += DD[i];
+    for (int i = 0; i < 3; ++i) for (int k = 0; k < 3; ++k) poly[i + k] += N[i] * N[k];
+    for (int i = 0; i < 3; ++i) for (int k = 0; k < 2; ++k) poly[i + k] -= 2.0 * cg * N[i] * D[k];
+    for (int i = 0; i < 3; ++i) for (int k = 0; k < 3; ++k) poly[i + k] -= kc * K[i] * DD[k];
+    double big = 0;
+    for (int i = 0; i < 5; ++i) big = std::max(big, std::fabs(poly[i]));
+    if (!(std::fabs(poly[4]) > 1e-12 * big)) return 0;
+    Cx roots[4];
+    quartic_roots(poly, roots);
+    int n_sol = 0;
+    for (int r = 0; r < 4; ++r) {
+        const double v = roots[r].real();
+        if (!(std::fabs(roots[r].imag()) < 1e-6 * (1.0 + std::fabs(v))) || !(v > 0)) continue;
+        const double den = D[0] + D[1] * v;
+        if (!(std::fabs(den) > 1e-12)) continue;
+        const double u = (N[0] + N[1] * v + N[2] * v * v) / den;
+        if (!(u > 0)) continue;
+        const double kk = 1.0 + v * v - 2.0 * v * cb;
+        if (!(kk > 0)) continue;
+        const double s1 = std::sqrt(b2 / kk), sc[3] = {s1, u * s1, v * s1};
+        double pc[9];
+        for (int i = 0; i < 3; ++i) for (int a = 0; a < 3; ++a) pc[3 * i + a] = sc[i] * f[3 * i + a];
+        double sdummy = 1.0;
+        if (!horn_absolute_orientation(pc, pw, 3, true, Rs[n_sol], ts[n_sol], &sdummy)) continue;
+        ++n_sol;
+    }
+    return n_sol;
+}
+}  // namespace
+
+int pnp_solve_ransac(const double* pw, const double* obs, const double* inv_sigma2, int n, const double* cam, int iterations, uint32_t seed, double* pose7, uint8_t* inlier)
+{
+    for (int i = 0; i < n; ++i) inlier[i] = 0;
+    if (n < 4) return 0;
+    std::vector<double> f((size_t)3 * n);
+    for (int i = 0; i < n; ++i) {
+        const double x = (obs[2 * i] - cam[2]) / cam[0], y = (obs[2 * i + 1] - cam[3]) / cam[1], nn = std::sqrt(x * x + y * y + 1.0);
+        f[3 * (size_t)i] = x / nn; f[3 * (size_t)i + 1] = y / nn; f[3 * (size_t)i + 2] = 1.0 / nn;
+    }
+    Rng rng{seed ? seed : 1u};
+    std::vector<int> avail((size_t)n);
+    std::vector<uint8_t> cur((size_t)n);
+    int best = 0;
+    auto reproj2 = [&](const double* R, const double* t, int i, double& z) {
+        const double* X = pw + 3 * (size_t)i;
+        const double xc = R[0] * X[0] + R[1] * X[1] + R[2] * X[2] + t[0], yc = R[3] * X[0] + R[4] * X[1] + R[5] * X[2] + t[1];
+        z = R[6] * X[0] + R[7] * X[1] + R[8] * X[2] + t[2];
+        const double du = cam[0] * xc / z + cam[2] - obs[2 * i], dv = cam[1] * yc / z + cam[3] - obs[2 * i + 1];
+        return du * du + dv * dv;
+    };
+    for (int it = 0; it < iterations; ++it) {
+        for (int i = 0; i < n; ++i) avail[(size_t)i] = i;
+        int left = n, idx[4];
+        for (int k = 0; k < 4; ++k) { const int r = (int)(rng.next() % (uint32_t)left); idx[k] = avail[(size_t)r]; avail[(size_t)r] = avail[(size_t)left - 1]; --left; }
+        double p3[9], f3[9], Rs[4][9], ts[4][3];
+        for (int k = 0; k < 3; ++k) for (int a = 0; a < 3; ++a) { p3[3 * k + a] = pw[3 * (size_t)idx[k] + a]; f3[3 * k + a] = f[3 * (size_t)idx[k] + a]; }
+        const int ns = p3p_grunert(p3, f3, Rs, ts);
+        int pick = -1;
+        double pick_err = 0;
+        for (int s = 0; s < ns; ++s) {                   // the fourth match of the sample decides among the solutions
+            double z;
+            const double e = reproj2(Rs[s], ts[s], idx[3], z);
+            if (z > 0 && (pick < 0 || e < pick_err)) { pick = s; pick_err = e; }
+        }
+        if (pick < 0) continue;
+        int count = 0;
+        for (int i = 0; i < n; ++i) {
+            double z;
+            const double e = reproj2(Rs[pick], ts[pick], i, z);
+            cur[(size_t)i] = (z > 0 && e * inv_sigma2[i] < 5.991) ? 1 : 0;
+            count += cur[(size_t)i];
+        }
+        if (count > best) {
+            best = count;
+            for (int i = 0; i < n; ++i) inlier[i] = cur[(size_t)i];
+            double q[4];
+            rot_to_quat(Rs[pick], q);
+            for (int k = 0; k < 4; ++k) pose7[k] = q[k];
+            for (int k = 0; k < 3; ++k) pose7[4 + k] = ts[pick][k];
         }
     }
     return best;
@@ -577,4 +707,10 @@ extern "C" __attribute__((visibility("default"))) int lpslam_sim3_solve_ransac(c
                                                                                 int fix_scale, int iterations, uint32_t seed, double* s12, uint8_t* inlier)
 {
     return LpSlam::sim3_solve_ransac(p1c, p2c, obs1, obs2, is1, is2, n, cam1, cam2, fix_scale != 0, iterations, seed, s12, inlier);
+}
+
+extern "C" __attribute__((visibility("default"))) int lpslam_pnp_solve_ransac(const double* pw, const double* obs, const double* inv_sigma2, int n, const double* cam,
+                                                                             int iterations, uint32_t seed, double* pose7, uint8_t* inlier)
+{
+    return LpSlam::pnp_solve_ransac(pw, obs, inv_sigma2, n, cam, iterations, seed, pose7, inlier);
 }

@@ -803,8 +803,15 @@ class StereoTracker:
                 cur_idx.append(int(a)); lm_ids.append(lid)
             if len(cur_idx) < 15:
                 continue
+            # [UPSTREAM] solve::pnp_solver: the pose from the matches alone (no prior), refined by the pose optimiser
+            pw = np.array([self.landmarks[lid]["p"] for lid in lm_ids], float)
+            ob = np.array([[float(cur.kpts["x"][i]), float(cur.kpts["y"][i])] for i in cur_idx], float)
+            w = np.array([1.0 / float(self.scales[int(cur.kpts["octave"][i])]) ** 2 for i in cur_idx], float)
+            found, p7, _ = TV.pnp_solve_ransac(pw, ob, w, [self.cam["fx"], self.cam["fy"], self.cam["cx"], self.cam["cy"]], 100, 0x9E3779B9)
+            if found < 10:
+                continue
             keep_pose, keep_lm = cur.pose, list(cur.landmark)
-            ok, _ = self.pose_from_matches(cur, cur_idx, lm_ids, kf["pose"], 30)
+            ok, _ = self.pose_from_matches(cur, cur_idx, lm_ids, Pose(list(p7[:4]), list(p7[4:])), 30)
             if ok:
                 return True
             cur.pose, cur.landmark = keep_pose, keep_lm

@@ -271,3 +271,118 @@ def sim3_solve_ransac(p1c, p2c, obs1, obs2, is1, is2, cam1, cam2, fix_scale, ite
                 s4 = np.sqrt(1.0 + m[8] - m[0] - m[4]) * 2; q = [(m[3] - m[1]) / s4, (m[2] + m[6]) / s4, (m[5] + m[7]) / s4, 0.25 * s4]
             best, best_s12, best_inl = c, np.array(q + [t[0], t[1], t[2], s], float), inl.copy()
     return best, best_s12, best_inl
+
+
+# ---- [UPSTREAM] solve::pnp_solver, as host/two_view.cpp restates it: three-point solver (Grunert) + the fourth match of a sample + RANSAC
+def _quartic_roots(c):
+    """roots of c[0] + ... + c[4] x^4 by Durand-Kerner (80 sweeps from fixed starting points, Gauss-Seidel order)"""
+    a3, a2, a1, a0 = c[3] / c[4], c[2] / c[4], c[1] / c[4], c[0] / c[4]
+    rad = 1.0 + max(abs(a3), abs(a2), abs(a1), abs(a0))
+    seed, w, r = complex(0.4, 0.9), complex(1.0, 0.0), []
+    for _ in range(4):
+        r.append(w * rad * 0.5); w *= seed
+    for _ in range(80):
+        for i in range(4):
+            x = r[i]
+            px = (((x + a3) * x + a2) * x + a1) * x + a0
+            den = complex(1.0, 0.0)
+            for k in range(4):
+                if k != i:
+                    den *= (x - r[k])
+            if abs(den) > 0:
+                r[i] = x - px / den
+    return r
+
+
+def p3p_grunert(pw, f):
+    """up to four (R, t) world -> camera from three world points (rows of pw) and their unit bearings (rows of f)"""
+    d2 = lambda i, k: float(((pw[i] - pw[k]) ** 2).sum())
+    a2, b2, c2 = d2(1, 2), d2(0, 2), d2(0, 1)
+    if not (a2 > 1e-12 and b2 > 1e-12 and c2 > 1e-12):
+        return []
+    ca, cb, cg = float(f[1] @ f[2]), float(f[0] @ f[2]), float(f[0] @ f[1])
+    q1, kc = (a2 - c2) / b2, c2 / b2
+    N = [1.0 + q1, -2.0 * q1 * cb, q1 - 1.0]; D = [2.0 * cg, -2.0 * ca]; K = [1.0, -2.0 * cb, 1.0]
+    DD = [D[0] * D[0], 2.0 * D[0] * D[1], D[1] * D[1]]
+    poly = [0.0] * 5
+    for i in range(3):
+        poly[i] += DD[i]
+    for i in range(3):
+        for k in range(3):
+            poly[i + k] += N[i] * N[k]
+    for i in range(3):
+        for k in range(2):
+            poly[i + k] -= 2.0 * cg * N[i] * D[k]
+    for i in range(3):
+        for k in range(3):
+            poly[i + k] -= kc * K[i] * DD[k]
+    big = max(abs(v) for v in poly)
+    if not (abs(poly[4]) > 1e-12 * big):
+        return []
+    sols = []
+    for root in _quartic_roots(poly):
+        v = root.real
+        if not (abs(root.imag) < 1e-6 * (1.0 + abs(v))) or not (v > 0):
+            continue
+        den = D[0] + D[1] * v
+        if not (abs(den) > 1e-12):
+            continue
+        u = (N[0] + N[1] * v + N[2] * v * v) / den
+        if not (u > 0):
+            continue
+        kk = 1.0 + v * v - 2.0 * v * cb
+        if not (kk > 0):
+            continue
+        s1 = np.sqrt(b2 / kk)
+        pc = np.array([s1 * f[0], u * s1 * f[1], v * s1 * f[2]])
+        h = horn(pc, pw, True)
+        if h is not None:
+            sols.append((h[0], h[1]))
+    return sols
+
+
+def pnp_solve_ransac(pw, obs, inv_sigma2, cam, iterations=100, seed=0x9E3779B9):
+    """returns (n_inliers, pose7 (qw qx qy qz tx ty tz, world -> camera) or None, inlier flags)"""
+    pw = np.asarray(pw, float); obs = np.asarray(obs, float); inv_sigma2 = np.asarray(inv_sigma2, float)
+    n = len(pw)
+    best, best_pose, best_inl = 0, None, np.zeros(n, bool)
+    if n < 4:
+        return 0, None, best_inl
+    x = (obs[:, 0] - cam[2]) / cam[0]; y = (obs[:, 1] - cam[3]) / cam[1]; nn = np.sqrt(x * x + y * y + 1.0)
+    f = np.stack([x / nn, y / nn, 1.0 / nn], 1)
+    rng = _Rng(seed)
+
+    def reproj2(R, t, idx):
+        pc = pw[idx] @ R.T + t
+        with np.errstate(divide="ignore", invalid="ignore"):
+            du = cam[0] * pc[..., 0] / pc[..., 2] + cam[2] - obs[idx, 0]; dv = cam[1] * pc[..., 1] / pc[..., 2] + cam[3] - obs[idx, 1]
+        return du * du + dv * dv, pc[..., 2]
+    every = np.arange(n)
+    for _ in range(iterations):
+        avail = list(range(n)); left = n; idx = []
+        for _k in range(4):
+            r = rng.next() % left
+            idx.append(avail[r]); avail[r] = avail[left - 1]; left -= 1
+        pick, pick_err = None, 0.0
+        for R, t in p3p_grunert(pw[idx[:3]], f[idx[:3]]):
+            e, z = reproj2(R, t, idx[3])
+            if z > 0 and (pick is None or e < pick_err):
+                pick, pick_err = (R, t), float(e)
+        if pick is None:
+            continue
+        e, z = reproj2(pick[0], pick[1], every)
+        inl = (z > 0) & (e * inv_sigma2 < 5.991)
+        c = int(inl.sum())
+        if c > best:
+            m = pick[0].reshape(9)
+            tr = m[0] + m[4] + m[8]
+            if tr > 0:
+                s4 = np.sqrt(tr + 1.0) * 2; q = [0.25 * s4, (m[7] - m[5]) / s4, (m[2] - m[6]) / s4, (m[3] - m[1]) / s4]
+            elif m[0] > m[4] and m[0] > m[8]:
+                s4 = np.sqrt(1.0 + m[0] - m[4] - m[8]) * 2; q = [(m[7] - m[5]) / s4, 0.25 * s4, (m[1] + m[3]) / s4, (m[2] + m[6]) / s4]
+            elif m[4] > m[8]:
+                s4 = np.sqrt(1.0 + m[4] - m[0] - m[8]) * 2; q = [(m[2] - m[6]) / s4, (m[1] + m[3]) / s4, 0.25 * s4, (m[5] + m[7]) / s4]
+            else:
+                s4 = np.sqrt(1.0 + m[8] - m[0] - m[4]) * 2; q = [(m[3] - m[1]) / s4, (m[2] + m[6]) / s4, (m[5] + m[7]) / s4, 0.25 * s4]
+            best, best_pose, best_inl = c, np.array(q + list(pick[1]), float), inl.copy()
+    return best, best_pose, best_inl

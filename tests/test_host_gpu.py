@@ -1,6 +1,8 @@
 """GPU test of the drop-in boundary end to end: stereo frames in through the manager, poses out through the callback."""
 import time
 
+import math
+
 import numpy as np
 import pytest
 
@@ -347,6 +349,32 @@ def test_kidnapped_camera_relocalises_through_the_vocabulary(hiplib, tmp_path):
     # without a vocabulary the nearest-by-position gate cannot find the place
     res_p, st_p, _ = results["position"]
     assert st_p["lost"] == 1 and st_p["relocalised"] == 0 and not any(r["valid"] for r in res_p[n_fwd:])
+
+
+def test_relocalisation_needs_no_pose_prior(hiplib, tmp_path):
+    """[UPSTREAM] relocalizer: BoW / nearby candidates -> matches -> solve::pnp_solver -> pose optimiser.  The camera turns on the
+    spot, loses tracking at 120 degrees and reappears at 15 degrees: every keyframe is "near" (same position), the ones asked first
+    look 6 to 15 degrees (55 to 140 pixels) elsewhere.  The pose comes from the matched landmarks alone (three-point solver +
+    RANSAC, host/two_view.cpp), the optimiser only refines it: the frame is placed where the first pass had it."""
+    from lpslam_amd import _build, manager
+    _build.host_library()
+    w, h = 640, 480
+    turn = [tuple(f) for f in synth.turning_sequence(w, h, 41)[0]]
+    blank = np.full((h, w), 110, np.uint8)
+    frames = turn + [(blank, blank)] * 2 + turn[5:9]
+    log = tmp_path / "pnp.log"
+    m = _stereo_manager(manager, w, h, '{"cameraSetup": "stereo", "slamKeypoints": 1000, "numLevels": 4, "keyframeInterval": 3, "localWindow": 4}', log)
+    m.start()
+    _feed(m, frames)
+    m.stop()
+    st = manager.Manager.statistics(log)
+    assert st["lost"] == 1 and st["relocalised"] == 1
+    valid = [r["valid"] for r in m.results]
+    assert all(valid[:41]) and not any(valid[41:43]) and all(valid[43:])
+    first, again = m.results[5], m.results[43]                            # the same image twice: before the loss and as the relocalised frame
+    assert np.abs(np.array(first["p"]) - np.array(again["p"])).max() < 0.05
+    assert abs(abs(float(np.dot(first["q"], again["q"]))) - 1.0) < 1e-4   # within 1.6 degrees of the first pass, 15 degrees from the start
+    assert abs(float(np.dot(m.results[0]["q"], again["q"]))) < math.cos(math.radians(14.0) / 2)
 
 
 def test_config_from_file_reads_the_openvslam_yaml(hiplib, tmp_path):

@@ -158,3 +158,34 @@ def test_sim3_solver_recovers_a_similarity_and_follows_the_oracle():
         rr = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)], [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
                        [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
         assert np.abs(rr - r).max() < 0.02 and np.abs(s12[4:7] - t).max() < 0.1 and abs(s12[7] - s_true) < 0.02
+
+
+def test_pnp_solver_finds_a_pose_without_a_prior_and_follows_the_oracle():
+    """[UPSTREAM] solve::pnp_solver, as restated (three-point solver on 4-match samples + RANSAC, host/two_view.cpp): a pose far from
+    the identity is recovered from landmark / keypoint matches of which 35 % are wrong, and the host mirror agrees with the numpy
+    restatement (same sampler, same quartic iteration)."""
+    from lpslam_amd import _build
+    from oracle import two_view as TV
+    l = C.CDLL(_build.host_library())
+    l.lpslam_pnp_solve_ransac.restype = C.c_int
+    l.lpslam_pnp_solve_ransac.argtypes = [C.c_void_p] * 3 + [C.c_int, C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(5)
+    cam = np.array([525.0, 525.0, 320.0, 240.0])
+    for trial in range(3):
+        n = 150
+        r = _rot(rng.normal(size=3), 0.3 + 0.5 * trial); t = rng.normal(0, 1.0, 3)
+        xc = np.column_stack([rng.uniform(-3, 3, n), rng.uniform(-2, 2, n), rng.uniform(3, 12, n)])       # in the camera
+        pw = (xc - t) @ r                                                                                  # world: xc = R pw + t
+        obs = np.column_stack([cam[0] * xc[:, 0] / xc[:, 2] + cam[2], cam[1] * xc[:, 1] / xc[:, 2] + cam[3]]) + rng.normal(0, 0.4, (n, 2))
+        bad = rng.random(n) < 0.35
+        obs[bad] = np.column_stack([rng.uniform(0, 640, int(bad.sum())), rng.uniform(0, 480, int(bad.sum()))])
+        w = np.ones(n)
+        pose = np.zeros(7); inl = np.zeros(n, np.uint8)
+        got = l.lpslam_pnp_solve_ransac(_p(np.ascontiguousarray(pw)), _p(np.ascontiguousarray(obs)), _p(w), n, _p(cam), 100, 0x9E3779B9, _p(pose), _p(inl))
+        want, opose, oinl = TV.pnp_solve_ransac(pw, obs, w, cam, 100, 0x9E3779B9)
+        assert got == want and np.array_equal(inl.astype(bool), oinl) and np.allclose(pose, opose, atol=1e-8)
+        assert got >= 0.5 * n and int((inl.astype(bool) & bad).sum()) <= 3
+        w_, x, y, z = pose[:4]
+        rr = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w_ * z), 2 * (x * z + w_ * y)], [2 * (x * y + w_ * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w_ * x)],
+                       [2 * (x * z - w_ * y), 2 * (y * z + w_ * x), 1 - 2 * (x * x + y * y)]])
+        assert np.abs(rr - r).max() < 0.02 and np.abs(pose[4:] - t).max() < 0.15
