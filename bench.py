@@ -604,6 +604,11 @@ def main():
                 t_ba_only = (time.perf_counter() - t3) / rounds
                 extras["multi_session"] = {"sessions_per_gpu": S, "frames_per_s": round(rounds * S * KF_INTERVAL / t_ms, 1),
                                            "batched_ba_ms_per_round": round(1e3 * t_ba_only, 3), "ba_windows_per_s": round(S / t_ba_only, 1),
+                                           # the batch's arithmetic against the FP64 matrix-core peak: S windows x BA_ITERS iterations of the
+                                           # per-iteration flop count above, over the whole round (create + solve + read-back + destroy)
+                                           "ba_roofline": ({"TFLOPs": round(S * BA_ITERS * out["ba_roofline"]["flop_per_iteration"] / t_ba_only / 1e12, 3),
+                                                            "frac_of_fp64_peak": round(S * BA_ITERS * out["ba_roofline"]["flop_per_iteration"] / t_ba_only / 1e12 / FP64_PEAK_TFLOPS, 5)}
+                                                           if "ba_roofline" in out else None),
                                            "note": "16 sessions, 6 stereo frames + 1 fresh local BA each per round; the 16 windows are one lpslam_hip_ba_optimize_batch call"}
             except Exception as e:      # noqa: BLE001
                 extras["multi_session"] = {"error": str(e)}

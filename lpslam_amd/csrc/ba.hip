@@ -1030,22 +1030,13 @@ __device__ __forceinline__ void pose_oplus(const double* pose, const double* d, 
 }
 
 
-__device__ __forceinline__ double readlane_f64(double v, int lane)
-{
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_readlane(lo, lane);
-    hi = __builtin_amdgcn_readlane(hi, lane);
-    return __hiloint2double(hi, lo);
-}
-
 // ---- blocked Cholesky of S (+ lambda I), 32-wide panel columns, two per launch ------------------------------------------------
 //   Two kinds of extra rows ride along so that no triangular substitution is ever run:
 //     row `dim` of S carries the rhs            -> after the last panel it holds y = L^-1 rhs,
 //     Minv starts as the identity (synthesised) -> its row blocks become L^-T; block (e, .) only exists from column e on.
-//   A panel is factored by ONE wavefront that holds the diagonal block's rows in lanes 0-31 and the workgroup's own rows in
-//   lanes 32-63 (one row per lane in 32 registers): the unblocked factorisation with v_readlane broadcasts and a v_rsq_f64 +
-//   Newton reciprocal square root factors D and solves B L_jj^T = B with the same rank-1 updates.  The diagonal block is
-//   factored redundantly by every panel workgroup, which removes every dependence between workgroups of a launch.
+//   A panel is factored by ONE wavefront in two 16-column strips (chol_panel_dpp below): the diagonal block replicated in every
+//   16-lane DPP row, the rows that ride along one per lane; the same rank-1 updates factor D and solve B L_jj^T = B.  The
+//   diagonal block is factored redundantly by every panel workgroup, which removes every dependence between workgroups of a launch.
 //   All working workgroups run on one XCD: the grid is launched 8x oversized and only every 8th workgroup works (workgroups go
 //   round-robin to the 8 XCDs), so the panel written by one launch is an L2 hit for the next (measured: -1 us per launch).
 // Explicit FMAs are used here (the contraction pragma only governs implicit fusing); the factorisation is not a parity
@@ -1064,64 +1055,7 @@ __device__ __forceinline__ double readlane_f64(double v, int lane)
 constexpr int CP_BLK = NB * (NB + 1);                  // one padded 32x32 block in LDS
 constexpr int CP_LDS_BYTES = (11 * CP_BLK + 2 * (64 * 17 + 64 * 17)) * (int)sizeof(double);      // 11 blocks + the factor scratch of two wavefronts
 
-__device__ __forceinline__ double pivot_rsqrt64(double d)
-{
-    double rs = __builtin_amdgcn_rsq(d);
-    rs = rs * fma(-0.5 * d * rs, rs, 1.5);
-    return rs * fma(-0.5 * d * rs, rs, 1.5);
-}
-// Register Cholesky of a 64-row x 32-column panel (lane = row, rows 0..31 = the diagonal block), in two halves of 16 columns.
-// Inside a half the rank-1 multipliers travel by v_readlane and the pivot of column jj+1 is finished right after that
-// column's own update, so its latency chain overlaps the remaining updates.  Between the halves the finished 16 columns
-// update the other 16 as ONE block product on the matrix cores (64x16x16, through a 16 KB LDS scratch of this wavefront):
-// that replaces 256 of the 496 readlane-fed rank-1 updates (4 issue slots each) by 16 MFMAs.
-template <int C0>
-__device__ __forceinline__ bool chol_half_regs(double (&a)[NB], int lane)
-{
-    bool fail = false;
-    double dcur = readlane_f64(a[C0], C0);
-    if (!(dcur > 0.0)) { fail = true; dcur = 1.0; }
-    double rs = pivot_rsqrt64(dcur);
-#pragma unroll
-    for (int jj = C0; jj < C0 + 16; ++jj) {
-        const double lcol = a[jj] * rs;
-        a[jj] = lane == jj ? dcur * rs : lcol;
-        if (jj + 1 < C0 + 16) {
-            a[jj + 1] = fma(-lcol, readlane_f64(lcol, jj + 1), a[jj + 1]);
-            double dn = readlane_f64(a[jj + 1], jj + 1);
-            if (!(dn > 0.0)) { fail = true; dn = 1.0; }
-            const double rn = pivot_rsqrt64(dn);
-#pragma unroll
-            for (int c = jj + 2; c < C0 + 16; ++c) a[c] = fma(-lcol, readlane_f64(lcol, c), a[c]);
-            dcur = dn; rs = rn;
-        }
-    }
-    return fail;
-}
 constexpr int CH_SCR = 64 * 17 + 64 * 17;              // doubles of scratch per factoring wavefront: L1 [64][17] and U [64][17]
-__device__ __forceinline__ bool chol_panel_regs(double (&a)[NB], int lane, double* scr)
-{
-    bool fail = chol_half_regs<0>(a, lane);
-    double* Ls = scr; double* Us = scr + 64 * 17;
-    // the diagonal entry of a finished column sits in a[jj] of lane jj, the strict upper part of the block holds garbage
-    // that is never read (lanes r < k of column k): zero it for the product
-#pragma unroll
-    for (int k = 0; k < 16; ++k) Ls[lane * 17 + k] = (lane < k) ? 0.0 : a[k];
-    const int lr = lane & 15, lk = lane >> 4;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {                        // U[16t.., :] = L1[16t.., :] (L1[16..31, :])^T, K = 16
-        f64x4 acc = {0, 0, 0, 0};
-#pragma unroll
-        for (int s4 = 0; s4 < 16; s4 += 4)
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ls[(16 * t + lr) * 17 + s4 + lk], Ls[(16 + lr) * 17 + s4 + lk], acc, 0, 0, 0);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) Us[(16 * t + lk + 4 * q) * 17 + lr] = acc[q];
-    }
-#pragma unroll
-    for (int c = 0; c < 16; ++c) a[16 + c] -= Us[lane * 17 + c];
-    fail |= chol_half_regs<16>(a, lane);
-    return fail;
-}
 // ---- 16-column strip of a panel, rank-1 multipliers by DPP ---------------------------------------------------------------
 // The diagonal block D (16 x 16) is held REPLICATED: lane l keeps row l & 15 in d[0..15], so every 16-lane DPP row owns a full
 // copy, and x[0..15] is the lane's own row of whatever rides along below D (64 rows per wavefront).  The rank-1 update of column
@@ -1205,20 +1139,18 @@ __device__ __forceinline__ bool strip_factor(double (&d)[16], double (&x)[16])
 // block of each strip, and in x / y its own row of the stack  [D rows 16..31 (lanes 0-15); B rows 0..31 (lanes 16-47)]:
 //   dA = L00, x = [L10; L_B,0], dB = L11, y = [L11; L_B,1]  (lanes 48-63 idle along with zeros)
 struct PanelRegs { double dA[16], x[16], dB[16], y[16]; };
-__device__ __forceinline__ bool chol_panel_dpp(PanelRegs& p, const double* Dblk, const double* Bblk, int lane, double* scr)
+// the two strips of a loaded panel with the block product between them; ROWS: lanes that carry rows (64, or 48 where the
+// scratch is short: 2 * ROWS * 17 doubles)
+template <int ROWS>
+__device__ __forceinline__ bool chol_panel_core(PanelRegs& p, int lane, double* scr)
 {
     const int r = lane & 15;
-    const double* own = lane < 16 ? Dblk + (16 + lane) * (NB + 1) : (Bblk != nullptr && lane < 48 ? Bblk + (lane - 16) * (NB + 1) : nullptr);
-#pragma unroll
-    for (int c = 0; c < 16; ++c) {
-        p.dA[c] = Dblk[r * (NB + 1) + c];
-        p.x[c] = own ? own[c] : 0.0;
-        p.y[c] = own ? own[16 + c] : 0.0;
-    }
     bool fail = strip_factor(p.dA, p.x);
-    double* Ls = scr; double* Us = scr + 64 * 17;
+    double* Ls = scr; double* Us = scr + ROWS * 17;
+    if (ROWS == 64 || lane < ROWS) {
 #pragma unroll
-    for (int k = 0; k < 16; ++k) Ls[lane * 17 + k] = p.x[k];
+        for (int k = 0; k < 16; ++k) Ls[lane * 17 + k] = p.x[k];
+    }
     const int lr = lane & 15, lk = lane >> 4;
 #pragma unroll
     for (int t = 0; t < 3; ++t) {                        // U[16t.., :] = X[16t.., :] (X[0..15, :])^T, K = 16 (rows 48.. are zero)
@@ -1242,6 +1174,18 @@ __device__ __forceinline__ bool chol_panel_dpp(PanelRegs& p, const double* Dblk,
     for (int c = 0; c < 16; ++c) p.dB[c] = Ls[r * 17 + c];
     fail |= strip_factor(p.dB, p.y);
     return fail;
+}
+__device__ __forceinline__ bool chol_panel_dpp(PanelRegs& p, const double* Dblk, const double* Bblk, int lane, double* scr)
+{
+    const int r = lane & 15;
+    const double* own = lane < 16 ? Dblk + (16 + lane) * (NB + 1) : (Bblk != nullptr && lane < 48 ? Bblk + (lane - 16) * (NB + 1) : nullptr);
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        p.dA[c] = Dblk[r * (NB + 1) + c];
+        p.x[c] = own ? own[c] : 0.0;
+        p.y[c] = own ? own[16 + c] : 0.0;
+    }
+    return chol_panel_core<64>(p, lane, scr);
 }
 // acc += A[tr.., :] B[tc.., :]^T over one 32-wide k-block (16x16 tile, 8 x v_mfma_f64_16x16x4)
 __device__ __forceinline__ f64x4 mfma_tile32(const double* A, const double* B, int tr, int tc, int lr, int lk, f64x4 acc)
@@ -1544,11 +1488,18 @@ void enqueue_xsolve(hipStream_t s, const BaView* d_views, int count, int dim, in
 
 // factorisation + solve of `count` reduced systems.  `wg`: the systems that fit one compute unit go to k_chol_wg (one workgroup
 // each, one launch), the others through the panel-pair chain and k_chol_xsolve (each kernel skips the problems of the other
-// kind).  Measured (MI355X, 295 x 295): one problem takes 170 us in k_chol_wg against 100 us in the chain (the chain spreads
-// the trailing updates and the L^-T rows over 20-60 workgroups; in one workgroup the ten diagonal-block factorisations,
-// 4.5 us each, the triangular solves and the hand-overs between them sit in series), a batch of 64 takes 14.5 ms against
-// 16.9 ms: k_chol_wg pays from about 24 problems on, where the chain's redundant panel work fills the chip.
-constexpr int CW_MIN_BATCH = 24;
+// kind).  Measured (MI355X, 295 x 295, 10 LM iterations per problem, round 3): batches of 4 / 16 / 32 / 48 / 64 / 96 windows take
+// 1.78 / 4.10 / 7.96 / 11.8 / 15.2 / 22.4 ms through the chain and 2.65 / 4.97 / 7.99 / 10.9 / 13.8 / 19.6 ms through k_chol_wg: the
+// chain spreads one problem's trailing updates and L^-T rows over 20-60 workgroups, which only stops paying once the batch alone
+// fills the chip.  (Factoring k_chol_wg's diagonal blocks with the DPP strips of the chain instead of the readlane form -- 2 x 2.8 k
+// cycles against 2 x 10 k -- changed none of these numbers: that wavefront works beside the seven that update tiles.)
+constexpr int CW_MIN_BATCH = 40;
+// LPSLAM_HIP_CW_MIN_BATCH overrides the threshold (measurements)
+int cw_min_batch()
+{
+    static const int v = [] { const char* e = getenv("LPSLAM_HIP_CW_MIN_BATCH"); return e ? atoi(e) : CW_MIN_BATCH; }();
+    return v;
+}
 void enqueue_factor_solve(hipStream_t s, const BaView* d_views, int count, int nb_max, int dim_max, bool wg, bool any_small, bool any_large)
 {
     if (!wg) { any_large = any_large || any_small; any_small = false; }
@@ -2184,7 +2135,7 @@ int enqueue_solve(const BaLaunch& L, int fused)
             hipLaunchKernelGGL(k_lm_begin, dim3(1, L.count), dim3(64), 0, s, L.d_views);
             hipLaunchKernelGGL(k_chol_prep, dim3((L.nb * NB + 255) / 256, L.count), dim3(256), 0, s, L.d_views);
         }
-        const bool wg = L.count >= CW_MIN_BATCH;
+        const bool wg = L.count >= cw_min_batch();
         if (L.marks && !(wg && L.any_small)) {              // profiled run through the panel-pair chain: factorisation and solve timed apart
             enqueue_cholesky(s, L.d_views, L.count, L.nb);
             L.mark(LPSLAM_HIP_BA_K_CHOL);

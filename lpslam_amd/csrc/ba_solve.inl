@@ -34,33 +34,6 @@ __host__ __device__ inline bool cw_fits(int dim) { return dim > 0 && dim + 1 <= 
 // (16 rows x 2 neighbouring columns per half wavefront, ds_read_b64) hit 32 different 8-byte banks
 __device__ __forceinline__ int cw_swz(int r, int c) { return r * 32 + (c ^ ((2 * r) & 31)); }
 
-// 32x32 diagonal block in registers: lanes 0-31 hold its rows, lanes 32-63 the identity; on return lanes 0-31 hold L (lower
-// triangle), lanes 32-63 the rows of L^-T.  Two halves of 16 columns joined by one 64x16x16 matrix-core update through `scr`
-// (1024 doubles, [row][16] swizzled; the products are kept in registers until every operand read is out, then overwrite it).
-__device__ __forceinline__ bool cw_diag_factor(double (&a)[NB], int lane, double* scr)
-{
-    bool fail = chol_half_regs<0>(a, lane);
-    const int lr = lane & 15, lk = lane >> 4;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) scr[lane * 16 + (k ^ lr)] = (lane < k) ? 0.0 : a[k];
-    f64x4 acc[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        acc[t] = f64x4{0, 0, 0, 0};
-#pragma unroll
-        for (int s4 = 0; s4 < 16; s4 += 4)
-            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(scr[(16 * t + lr) * 16 + ((s4 + lk) ^ lr)], scr[(16 + lr) * 16 + ((s4 + lk) ^ lr)], acc[t], 0, 0, 0);
-    }
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) scr[(16 * t + lk + 4 * q) * 16 + (lr ^ ((lk + 4 * q) & 15))] = acc[t][q];
-#pragma unroll
-    for (int c = 0; c < 16; ++c) a[16 + c] -= scr[lane * 16 + (c ^ lr)];
-    fail |= chol_half_regs<16>(a, lane);
-    return fail;
-}
-
 // acc -= A_strip (16 x 32) * B_strip^T (32 x 16): eight v_mfma_f64_16x16x4; the operands of four steps are fetched together
 // (sixteen registers: the 22 accumulator tiles leave no room for all eight)
 __device__ __forceinline__ f64x4 cw_tile_update(const double* sa, const double* sb, int lr, int lk, f64x4 acc)
@@ -154,52 +127,63 @@ __global__ __launch_bounds__(CW_THREADS) void k_chol_wg(const BaView* __restrict
         int want = 0;
         for (int q = 0; q < P; ++q) {
             const bool second = 2 * q + 1 < T;           // the block's second tile row exists
-            double a[NB];
+            // The block by DPP strips (chol_panel_core, the panel chain's arithmetic: 2 x 2.8 k cycles + the block product, against
+            // 2 x 10 k for the readlane form this kernel used): lane l carries row l & 15 of the replicated diagonal block of each
+            // strip, lanes 0-15 ride rows 16..31 of the block along, lanes 16-47 the identity rows 0..31 (they become L^-T).
+            PanelRegs p;
+            const int r = lane & 15, ir = lane - 16;     // ir: identity row of lanes 16-47
             if (q == 0) {
                 // the first block straight from memory, while the others bring panel 0 into LDS
-                if (lane < 32) {
-                    const bool have = lane < 16 || second;
 #pragma unroll
-                    for (int c = 0; c < NB; ++c) a[c] = have ? (c <= lane ? S[(size_t)lane * n + c] : 0.0) : (c == lane ? 1.0 : 0.0);
-                } else {
-#pragma unroll
-                    for (int c = 0; c < NB; ++c) a[c] = (c == lane - 32) ? 1.0 : 0.0;
+                for (int c = 0; c < 16; ++c) {
+                    p.dA[c] = c <= r ? S[(size_t)r * n + c] : 0.0;
+                    double xv = 0.0, yv = 0.0;
+                    if (lane < 16) { xv = second ? S[(size_t)(16 + lane) * n + c] : 0.0; yv = second ? (c <= lane ? S[(size_t)(16 + lane) * n + 16 + c] : 0.0) : (c == lane ? 1.0 : 0.0); }
+                    else if (lane < 48) { xv = c == ir ? 1.0 : 0.0; yv = 16 + c == ir ? 1.0 : 0.0; }
+                    p.x[c] = xv; p.y[c] = yv;
                 }
             } else {
                 // wait for the block's tiles (a counter in LDS: no workgroup barrier, the other wavefronts go on with the lookahead)
                 want += second ? 3 : 1;
                 while (__hip_atomic_load(s_diag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < want) __builtin_amdgcn_s_sleep(1);
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                {
-                    // every lane reads (a valid LDS address), then selects: block rows / identity rows, no branch per element
-                    const bool have = lane < 16 || (lane < 32 && second);
-                    const double* row = X + ((lane >> 4) & 1) * CW_STRIP;
+                // every lane reads (valid LDS addresses), then selects: block rows / identity rows, no branch per element
+                const double* row1 = X + CW_STRIP;
 #pragma unroll
-                    for (int c = 0; c < NB; ++c) {
-                        const double x = row[cw_swz(lane & 15, c)];
-                        a[c] = have ? (c <= lane ? x : 0.0) : (c == (lane & 31) ? 1.0 : 0.0);
-                    }
+                for (int c = 0; c < 16; ++c) {
+                    const double d0 = X[cw_swz(r, c)], x1 = row1[cw_swz(r, c)], y1 = row1[cw_swz(r, 16 + c)];
+                    p.dA[c] = c <= r ? d0 : 0.0;
+                    double xv = 0.0, yv = 0.0;
+                    if (lane < 16) { xv = second ? x1 : 0.0; yv = second ? (c <= lane ? y1 : 0.0) : (c == lane ? 1.0 : 0.0); }
+                    else if (lane < 48) { xv = c == ir ? 1.0 : 0.0; yv = 16 + c == ir ? 1.0 : 0.0; }
+                    p.x[c] = xv; p.y[c] = yv;
                 }
             }
-            const bool fail = cw_diag_factor(a, lane, Wb);
-            if (__ballot(fail && lane < 32) != 0 && lane == 0) *s_fail = 1;
-            if (lane >= 32) {
-                const int r = lane - 32;
+            const bool fail = chol_panel_core<48>(p, lane, Wb);          // scratch: Wb + the two vectors behind it (1664 >= 2 x 48 x 17 doubles)
+            if (__ballot(fail) != 0 && lane == 0) *s_fail = 1;
+            if (lane >= 16 && lane < 48) {               // W_q = L^-T: row ir = [x | y] from the diagonal on
 #pragma unroll
-                for (int c = 0; c < NB; ++c) Wb[cw_swz(r, c)] = c >= r ? a[c] : 0.0;
+                for (int c = 0; c < 16; ++c) { Wb[cw_swz(ir, c)] = c >= ir ? p.x[c] : 0.0; Wb[cw_swz(ir, 16 + c)] = 16 + c >= ir ? p.y[c] : 0.0; }
             }
             __syncthreads();                             // (2) W_q is in LDS, panel q's raw strips are in X, nobody reads Y any more
             cw_trsm(q, T, wave, X, Y, Wb, S, n, lr, lk);
             // the block itself to memory, off the critical path: L (the row of the right-hand side may live here) and W_q
-            if (lane < 32) {
-                if (lane < 16 || second) {
+            if (lane < 16) {
 #pragma unroll
-                    for (int c = 0; c < NB; ++c) if (c <= lane) S[(size_t)(32 * q + lane) * n + 32 * q + c] = a[c];
+                for (int c = 0; c < 16; ++c) if (c <= lane) S[(size_t)(32 * q + lane) * n + 32 * q + c] = p.dA[c];
+                if (second) {
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) {
+                        S[(size_t)(32 * q + 16 + lane) * n + 32 * q + c] = p.x[c];
+                        if (c <= lane) S[(size_t)(32 * q + 16 + lane) * n + 32 * q + 16 + c] = p.dB[c];
+                    }
                 }
-            } else {
-                const int r = lane - 32;
+            } else if (lane < 48) {
 #pragma unroll
-                for (int c = 0; c < NB; ++c) Wg[(size_t)q * CW_W + r * 32 + c] = c >= r ? a[c] : 0.0;
+                for (int c = 0; c < 16; ++c) {
+                    Wg[(size_t)q * CW_W + ir * 32 + c] = c >= ir ? p.x[c] : 0.0;
+                    Wg[(size_t)q * CW_W + ir * 32 + 16 + c] = 16 + c >= ir ? p.y[c] : 0.0;
+                }
             }
             __syncthreads();                             // (3) the L strips of panel q are in Y
         }

@@ -19,7 +19,7 @@ for rep in range(10):
 print("create: enqueue %.3f ms, until ready %.3f ms (median)" % (1e3 * np.median([a for a, _ in ts]), 1e3 * np.median([b for _, b in ts])))
 t = time.perf_counter(); b = make(0); b.optimize(True, 10); t1 = time.perf_counter() - t; b.close()
 print("create + first optimize(10): %.3f ms" % (1e3 * t1))
-for B in (1, 2, 4, 8, 16, 32, 64):
+for B in (tuple(int(x) for x in sys.argv[1].split(',')) if len(sys.argv) > 1 else (1, 2, 4, 8, 16, 32, 64)):
     bas = [make(i) for i in range(B)]
     hip.ba_optimize_batch(bas, True, 10)
     tt = []
