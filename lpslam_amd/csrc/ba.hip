@@ -1643,7 +1643,10 @@ struct PoShared {
 // and, in the per-observation arithmetic, reciprocals and reciprocal square roots from v_rcp_f64 / v_rsq_f64 plus one cubic
 // correction step (1.4e-16 relative error, measured) where IEEE division and sqrt cost ~30 instructions each (a Jacobian held
 // thirteen of them).
-constexpr int PO_T = 512;
+#ifndef LPSLAM_PO_T
+#define LPSLAM_PO_T 512
+#endif
+constexpr int PO_T = LPSLAM_PO_T;
 constexpr int PO_W = PO_T / 64;
 __device__ __forceinline__ double po_rcp(double d) { return fast_rcp(d); }
 __device__ __forceinline__ double po_rsqrt(double d) { return fast_rsqrt(d); }
