@@ -34,6 +34,9 @@ KF_INTERVAL = 6               # keyframe every 6th frame
 RESIDENT = 48                 # stereo frames of the sequence resident in HBM (3 steps of 16; the ring is re-walked)
 BA_KF, BA_PTS, BA_OBS, BA_ITERS = 50, 5000, 40000, 10
 BA_VARIANTS = 4               # distinct windows (problem seeds) the keyframes rotate through
+# compute units of every XCD the front end leaves to the mapping solves that run beside it (lpslam_hip_set_mapping_reserve; what the
+# tracker sets for its mapping thread).  The front-end-only and batched extras run with 0.
+MAPPING_RESERVE = int(os.environ.get("LPSLAM_BENCH_RESERVE", "4"))
 HBM_PEAK_GBS = 8000.0         # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 measured copy)
 FP64_PEAK_TFLOPS = 78.6       # MI355X FP64 matrix = vector peak (MI355X_MICROARCH.md / SURVEY.md 8(d))
 INT_PEAK_TOPS = 39.3          # 256 CU x 64 lanes x 2.4 GHz int32 VALU ops (matching)
@@ -378,6 +381,8 @@ def main():
         if dist is not None:
             sync_tensor([0.0])
 
+    if wl.with_ba:
+        wl.ctx.set_mapping_reserve(MAPPING_RESERVE)
     wl.run_steps(0, args.warmup)
     barrier()
     t0 = time.perf_counter()
@@ -504,7 +509,8 @@ def main():
                                    "(extract L+R, stereo match, 2000x2000 BF temporal match; ring of %d resident frames of the 300-frame sequence) + a fresh "
                                    "50-KF/5k-landmark/%d-obs local BA (create + %d LM iterations + destroy) per keyframe (every %dth frame)"
                                    % (F, wl.R, wl.n_obs if wl.with_ba else 0, BA_ITERS, KF_INTERVAL),
-                       "frames_per_step": F, "frames_per_launch": F, "keyframes_per_step": round(kf_per_step, 3), "replicas": world, "parallelism": "replicas x%d" % world},
+                       "frames_per_step": F, "frames_per_launch": F, "keyframes_per_step": round(kf_per_step, 3), "replicas": world, "parallelism": "replicas x%d" % world,
+                       "mapping_reserve_cus_per_xcd": MAPPING_RESERVE if wl.with_ba else 0},
             "ba_ms_per_iter": round(sum(d["ms_per_solve"] for d in ba_prof.values()) / max(ba_iters_done, 1), 4) if ba_prof else None,
             "ba_setup_ms": round(ba_setup_ms, 4) if ba_setup_ms is not None else None,
             "ba_ms_per_keyframe": round(ba_total_ms, 4) if ba_total_ms is not None else None,
@@ -533,7 +539,9 @@ def main():
     if rank == 0 and not args.no_extras and world == 1:
         extras = {}
         n_fe = max(3, min(args.steps, 10))
-        wl.ctx.sync(); t2 = time.perf_counter()
+        wl.ctx.sync()
+        wl.ctx.set_mapping_reserve(0)                    # the front end alone / a GPU-filling batch of sessions: nothing to make room for
+        t2 = time.perf_counter()
         for s in range(n_fe):
             wl.front_end(s)
         wl.ctx.sync()

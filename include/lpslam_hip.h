@@ -70,6 +70,11 @@ int lpslam_hip_create(const lpslam_hip_frontend_config* cfg, lpslam_hip_ctx** ou
 void lpslam_hip_destroy(lpslam_hip_ctx* ctx);
 /* hipStream_t all work of this context is enqueued on (for event timing / interop). */
 void* lpslam_hip_stream(lpslam_hip_ctx* ctx);
+/* Keep `cus_per_xcd` compute units of every XCD free of the front end's kernels (0 = none, the default; at most 16): a bundle
+ * adjustment that runs beside the front end -- the reference's mapping thread beside its tracking thread,
+ * src/Trackers/OpenVSLAMTrackerBase.cpp:238 (openvslam::system starts both) -- otherwise stands still while front-end workgroups
+ * fill every compute unit's LDS.  The context's streams are re-created: call it on an idle context, outside a prefetch section. */
+int lpslam_hip_set_mapping_reserve(lpslam_hip_ctx* ctx, int32_t cus_per_xcd);
 int lpslam_hip_sync(lpslam_hip_ctx* ctx);
 /* Geometry derived from the configuration (pyramid sizes, per-level keypoint quota). */
 int lpslam_hip_level_info(lpslam_hip_ctx* ctx, int32_t* widths, int32_t* heights, int32_t* pitches,

@@ -141,6 +141,16 @@ int lp_pool_alloc(lpslam_hip_ctx* c, size_t bytes, void** out, size_t* capacity)
     return LPSLAM_HIP_OK;
 }
 
+// A front-end stream of the context: an ordinary one, or -- lpslam_hip_set_mapping_reserve -- one that leaves CUs 0 .. r-1 of every
+// XCD alone (bit b of a CU mask is CU b / 8 of XCD b % 8, tools/dev/cumask_probe.hip)
+static hipError_t lp_fe_stream_create(hipStream_t* s, int reserve)
+{
+    if (reserve <= 0) return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+    uint32_t mask[8];
+    for (int w = 0; w < 8; ++w) { mask[w] = 0; for (int b = 0; b < 32; ++b) if ((32 * w + b) / 8 >= reserve) mask[w] |= 1u << b; }
+    return hipExtStreamCreateWithCUMask(s, 8, mask);
+}
+
 hipStream_t lp_stream_acquire(lpslam_hip_ctx* c)
 {
     {
@@ -300,7 +310,7 @@ int lpslam_hip_create(const lpslam_hip_frontend_config* cfg, lpslam_hip_ctx** ou
     c->distribute_lds = lds;
     if (lds > 160 * 1024) { set_error("distribution kernel needs %zu B of LDS (> 160 KiB)", lds); delete c; return LPSLAM_HIP_ERR_INVALID; }
 
-    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    hipError_t e = lp_fe_stream_create(&c->stream, 0);
     if (e != hipSuccess) { delete c; return hip_fail(e, "hipStreamCreate"); }
     rc = ctx_alloc(c);
     if (rc == LPSLAM_HIP_OK && !ofs.empty()) {
@@ -406,6 +416,31 @@ void lpslam_hip_destroy(lpslam_hip_ctx* c)
     delete c;
 }
 
+// The front end's kernels fill every compute unit's LDS with their workgroups, and a panel-pair workgroup of a running bundle
+// adjustment (128 KB of LDS) then finds no room until the kernel drains, stream priority or not: a mapping solve beside the front end
+// stands still for the front end's kernels.  With a reserve the context's front-end streams are created with a CU mask that leaves
+// `cus_per_xcd` compute units of every XCD to whoever else runs (the solves then spread their panel workgroups over all XCDs).
+// Measured, one session: 3.95 -> 3.78 ms per 16-frame step with 4; the front end alone loses 8 %.  Call it on an idle context.
+int lpslam_hip_set_mapping_reserve(lpslam_hip_ctx* c, int32_t cus_per_xcd)
+{
+    if (!c) { set_error("null context"); return LPSLAM_HIP_ERR_INVALID; }
+    if (cus_per_xcd < 0 || cus_per_xcd > 16) { set_error("mapping reserve %d out of range (0 .. 16 CUs per XCD)", cus_per_xcd); return LPSLAM_HIP_ERR_INVALID; }
+    if (lp_tls_stream) { set_error("set_mapping_reserve inside a prefetch section"); return LPSLAM_HIP_ERR_INVALID; }
+    LP_HIP(hipSetDevice(c->cfg.device));
+    if (cus_per_xcd == c->reserve_cus) return LPSLAM_HIP_OK;
+    LP_HIP(hipStreamSynchronize(c->stream));
+    if (c->fe_stream) LP_HIP(hipStreamSynchronize(c->fe_stream));
+    if (c->copy_stream) LP_HIP(hipStreamSynchronize(c->copy_stream));
+    hipStream_t ns = nullptr, nf = nullptr;
+    LP_HIP(lp_fe_stream_create(&ns, cus_per_xcd));
+    if (c->fe_stream && lp_fe_stream_create(&nf, cus_per_xcd) != hipSuccess) { (void)hipStreamDestroy(ns); set_error("stream creation failed"); return LPSLAM_HIP_ERR_DEVICE; }
+    (void)hipStreamDestroy(c->stream);
+    c->stream = ns;
+    if (c->fe_stream) { (void)hipStreamDestroy(c->fe_stream); c->fe_stream = nf; }
+    c->reserve_cus = cus_per_xcd;
+    return LPSLAM_HIP_OK;
+}
+
 void* lpslam_hip_stream(lpslam_hip_ctx* c) { return c ? (void*)c->stream : nullptr; }
 
 int lpslam_hip_set_mask(lpslam_hip_ctx* c, int32_t eye, const uint8_t* mask, int32_t stride)
@@ -468,7 +503,7 @@ int lpslam_hip_prefetch_begin(lpslam_hip_ctx* c)
     if (lp_tls_stream) { set_error("prefetch_begin: this thread is already inside a prefetch section"); return LPSLAM_HIP_ERR_INVALID; }
     LP_HIP(hipSetDevice(c->cfg.device));
     if (!c->fe_stream) {
-        LP_HIP(hipStreamCreateWithFlags(&c->fe_stream, hipStreamNonBlocking));
+        LP_HIP(lp_fe_stream_create(&c->fe_stream, c->reserve_cus));
         LP_HIP(hipEventCreateWithFlags(&c->fe_done, hipEventDisableTiming));
     }
     lp_tls_stream = c->fe_stream;

@@ -1452,7 +1452,7 @@ __global__ __launch_bounds__(256) void k_chol_pair(const BaView* __restrict__ vi
 
 // the whole factorisation + L^-T rows: ceil(nb / 2) launches
 // nb = panels of the (largest) system, count = problems (grid.y; every problem reads its own size from its view)
-void enqueue_cholesky(hipStream_t s, const BaView* d_views, int count, int nb, int skip_small = 0)
+void enqueue_cholesky(hipStream_t s, const BaView* d_views, int count, int nb, int skip_small = 0, bool spread = false)
 {
     // the attribute belongs to the (function, device) pair: once per device this process uses
     static std::atomic<bool> attr_set[64];
@@ -1468,7 +1468,8 @@ void enqueue_cholesky(hipStream_t s, const BaView* d_views, int count, int nb, i
         const int n_panel = 1 + (nb - j - ncol) + (j + ncol);
         const int n_update = m > 0 ? T * (T + 1) / 2 + j * T : 0;
         // 32 CUs of one XCD hold a latency-bound launch of one problem; a throughput-bound one (or a batch) needs all 256
-        const int pin = (count == 1 && (n_panel + n_update) <= 96) ? 1 : 0;
+        // (spread: the front end keeps a few CUs of EVERY XCD free for this chain -- lpslam_hip_set_mapping_reserve -- so its workgroups go there)
+        const int pin = (!spread && count == 1 && (n_panel + n_update) <= 96) ? 1 : 0;
         hipLaunchKernelGGL(k_chol_pair, dim3((n_panel + n_update) * (pin ? 8 : 1), count), dim3(256), CP_LDS_BYTES, s, d_views, m, pin, skip_small);
     }
 }
@@ -1497,9 +1498,9 @@ __global__ __launch_bounds__(256) void k_chol_xsolve(const BaView* __restrict__ 
     if (lane == 0) v.xp[i] = acc;
 }
 
-void enqueue_xsolve(hipStream_t s, const BaView* d_views, int count, int dim, int skip_small = 0)
+void enqueue_xsolve(hipStream_t s, const BaView* d_views, int count, int dim, int skip_small = 0, bool spread = false)
 {
-    const int pin = count == 1 ? 1 : 0;
+    const int pin = (!spread && count == 1) ? 1 : 0;
     hipLaunchKernelGGL(k_chol_xsolve, dim3((dim + 3) / 4 * (pin ? 8 : 1), count), dim3(256), 0, s, d_views, pin, skip_small);
 }
 
@@ -1519,7 +1520,7 @@ int cw_min_batch()
     static const int v = [] { const char* e = getenv("LPSLAM_HIP_CW_MIN_BATCH"); return e ? atoi(e) : CW_MIN_BATCH; }();
     return v;
 }
-void enqueue_factor_solve(hipStream_t s, const BaView* d_views, int count, int nb_max, int dim_max, bool wg, bool any_small, bool any_large)
+void enqueue_factor_solve(hipStream_t s, const BaView* d_views, int count, int nb_max, int dim_max, bool wg, bool any_small, bool any_large, bool spread = false)
 {
     if (!wg) { any_large = any_large || any_small; any_small = false; }
     if (any_small) {
@@ -1533,8 +1534,8 @@ void enqueue_factor_solve(hipStream_t s, const BaView* d_views, int count, int n
         hipLaunchKernelGGL(k_chol_wg, dim3(1, count), dim3(CW_THREADS), CW_LDS_BYTES, s, d_views);
     }
     if (any_large) {
-        enqueue_cholesky(s, d_views, count, nb_max, any_small ? 1 : 0);
-        enqueue_xsolve(s, d_views, count, dim_max, any_small ? 1 : 0);
+        enqueue_cholesky(s, d_views, count, nb_max, any_small ? 1 : 0, spread);
+        enqueue_xsolve(s, d_views, count, dim_max, any_small ? 1 : 0, spread);
     }
 }
 
@@ -2098,6 +2099,7 @@ struct BaLaunch {
     int obs_blocks = 0, pose_blocks = 0, point_blocks = 0, part_n = 0, n_free = 0, n_blocks = 0, dim = 0, nb = 0, land_blocks = 0;
     int robust = 1, points_fixed = 0;
     bool any_small = false, any_large = false;          // systems for k_chol_wg / for the panel-pair chain
+    bool spread = false;                                // the context reserves CUs of every XCD for the solves: no XCD pinning
     // profiled run (lpslam_hip_ba_optimize_profiled): an event after every launch, tagged with the kernel it closes
     std::vector<std::pair<hipEvent_t, int>>* marks = nullptr;
     void mark(int kernel) const
@@ -2124,6 +2126,7 @@ BaLaunch single_launch(lpslam_hip_ba* b)
     BaLaunch L;
     L.d_views = b->d_view; L.s = b->stream; L.robust = b->robust; L.points_fixed = b->points_fixed;
     L.add(b);
+    L.spread = b->ctx && b->ctx->reserve_cus > 0;
     return L;
 }
 
@@ -2159,12 +2162,12 @@ int enqueue_solve(const BaLaunch& L, int fused)
         }
         const bool wg = L.count >= cw_min_batch();
         if (L.marks && !(wg && L.any_small)) {              // profiled run through the panel-pair chain: factorisation and solve timed apart
-            enqueue_cholesky(s, L.d_views, L.count, L.nb);
+            enqueue_cholesky(s, L.d_views, L.count, L.nb, 0, L.spread);
             L.mark(LPSLAM_HIP_BA_K_CHOL);
-            enqueue_xsolve(s, L.d_views, L.count, L.dim);
+            enqueue_xsolve(s, L.d_views, L.count, L.dim, 0, L.spread);
             L.mark(LPSLAM_HIP_BA_K_XSOLVE);
         } else {
-            enqueue_factor_solve(s, L.d_views, L.count, L.nb, L.dim, wg, L.any_small, L.any_large);
+            enqueue_factor_solve(s, L.d_views, L.count, L.nb, L.dim, wg, L.any_small, L.any_large, L.spread);
             L.mark(LPSLAM_HIP_BA_K_CHOL);
         }
     } else if (!fused) {
@@ -2548,7 +2551,7 @@ int lpslam_hip_ba_optimize_begin(lpslam_hip_ba* b, int32_t robust, int32_t iters
         auto up = [](int x, int m) { return (x + m - 1) / m * m; };
         L.obs_blocks = up(L.obs_blocks, 8); L.pose_blocks = up(L.pose_blocks, 4); L.point_blocks = up(L.point_blocks, 4); L.part_n = up(L.part_n, 8); L.land_blocks = up(L.land_blocks, 8);
         const std::array<int, 16> sig = {units, robust ? 1 : 0, b->points_fixed ? 1 : 0, L.obs_blocks, L.pose_blocks, L.point_blocks, L.part_n, L.n_free,
-                                         L.n_blocks, L.dim, L.nb, L.any_small ? 1 : 0, L.any_large ? 1 : 0, L.land_blocks, 0, 0};
+                                         L.n_blocks, L.dim, L.nb, L.any_small ? 1 : 0, L.any_large ? 1 : 0, L.land_blocks, L.spread ? 1 : 0, 0};
         lpslam_hip_ctx* c = b->ctx;
         hipGraphExec_t exec = nullptr;
         void* slot = nullptr;

@@ -362,7 +362,7 @@ __global__ __launch_bounds__(1024) void k_distribute(LevelTable lt, const uint32
                                                      int slots_per_image, int image0)
 {
     extern __shared__ __attribute__((aligned(16))) int lds[];
-    const int level = blockIdx.x, image = image0 + blockIdx.y;
+    const int level = blockIdx.y, image = image0 + blockIdx.x;
     const int tid = threadIdx.x;
     const int N = lt.quota[level];
     const int Q = lt.qcap[level];          // node count never exceeds max(N + 2, 4 * roots) < Q
@@ -978,8 +978,9 @@ __global__ __launch_bounds__(256) void k_remap(const uint8_t* __restrict__ raw, 
 int lp_launch_pyramid(lpslam_hip_ctx* c, int first, int n_images)
 {
     if (c->lt.n_levels < 2 || n_images <= 0) return LPSLAM_HIP_OK;
-    // one band work-group per CU (256 CUs): more bands would only add rows computed twice, fewer would leave CUs idle
-    const int bands = std::max(4, std::min(kPyrMaxBands, 256 / n_images));
+    // one band work-group per CU (256 CUs, less what is reserved for the mapping solves): more bands would only add rows computed
+    // twice -- or, with fewer CUs than work-groups, a second round --, fewer would leave CUs idle
+    const int bands = std::max(4, std::min(kPyrMaxBands, (256 - 8 * c->reserve_cus) / n_images));
     const int set = bands;
     const int2* rows = c->d_band_rows + (size_t)set * kMaxLevels * kPyrMaxBands;
     const size_t lds = (size_t)c->rs_entries * sizeof(int2);
@@ -1013,7 +1014,7 @@ int lp_launch_fast(lpslam_hip_ctx* c, int first, int n_images)
 
 int lp_launch_distribute(lpslam_hip_ctx* c, int first, int n_images)
 {
-    dim3 grid(c->lt.n_levels, n_images);
+    dim3 grid(n_images, c->lt.n_levels);                 // level 0 of every image first: the long work-groups start first
     hipLaunchKernelGGL(k_distribute, grid, dim3(1024), c->distribute_lds, lp_fe_stream(c), c->lt, c->d_cell_keys, c->d_cell_count,
                        c->cells_per_image, c->d_cand_key, c->d_cand_node, c->d_cand_count, c->cand_per_image, c->d_sel_key, c->d_sel_count,
                        c->slots_per_image, first);

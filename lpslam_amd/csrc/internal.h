@@ -61,6 +61,7 @@ struct lpslam_hip_ctx {
     lpslam_hip_frontend_config cfg{};
     lpslam::LevelTable lt{};
     hipStream_t stream = nullptr;      // the stream every entry point enqueues on
+    int reserve_cus = 0;               // lpslam_hip_set_mapping_reserve: CUs of every XCD the front end's streams leave to the mapping solves
     hipStream_t fe_stream = nullptr;   // prefetch: front end of the NEXT frame beside the tracking of this one (lp_fe_stream)
     hipEvent_t fe_done = nullptr;
     // asynchronous uploads from the caller's page-locked frames (lpslam_hip_upload_images_async): a copy stream of its own, one event

@@ -27,7 +27,7 @@ BA_LOG_DTYPE = np.dtype([("chi2_before", "<f8"), ("chi2_after", "<f8"), ("lambda
 # every symbol include/lpslam_hip.h declares (checked by tests/test_abi.py against the header text)
 SYMBOLS = [
     "lpslam_hip_last_error", "lpslam_hip_device_count", "lpslam_hip_create", "lpslam_hip_destroy",
-    "lpslam_hip_stream", "lpslam_hip_sync", "lpslam_hip_timer_begin", "lpslam_hip_timer_end", "lpslam_hip_timer_read", "lpslam_hip_level_info", "lpslam_hip_max_keypoints_per_image",
+    "lpslam_hip_stream", "lpslam_hip_set_mapping_reserve", "lpslam_hip_sync", "lpslam_hip_timer_begin", "lpslam_hip_timer_end", "lpslam_hip_timer_read", "lpslam_hip_level_info", "lpslam_hip_max_keypoints_per_image",
     "lpslam_hip_image_ptr", "lpslam_hip_upload_image", "lpslam_hip_host_alloc", "lpslam_hip_host_free", "lpslam_hip_host_register", "lpslam_hip_host_unregister", "lpslam_hip_upload_images_async", "lpslam_hip_set_rectify_map", "lpslam_hip_set_mask", "lpslam_hip_upload_raw_image", "lpslam_hip_remap_staged", "lpslam_hip_extract", "lpslam_hip_extract_range", "lpslam_hip_stage_pyramid",
     "lpslam_hip_stage_fast", "lpslam_hip_stage_distribute", "lpslam_hip_stage_describe",
     "lpslam_hip_keypoint_count", "lpslam_hip_get_keypoints", "lpslam_hip_get_frame", "lpslam_hip_get_pyramid_level",
@@ -135,6 +135,12 @@ class Context:
 
     def sync(self):
         _check(self.lib.lpslam_hip_sync(self.h))
+
+    def set_mapping_reserve(self, cus_per_xcd):
+        """compute units of every XCD the front end's kernels leave to the bundle adjustments that run beside them (idle context)"""
+        f = self.lib.lpslam_hip_set_mapping_reserve
+        f.restype = C.c_int; f.argtypes = [C.c_void_p, C.c_int32]
+        _check(f(self.h, int(cus_per_xcd)))
 
     def ba_graph_replays(self):
         f = self.lib.lpslam_hip_ba_graph_replays

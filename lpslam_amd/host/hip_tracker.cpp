@@ -70,7 +70,7 @@ HipVslamTrackerBase::HipVslamTrackerBase()
     o.optional("mapFilename", "map.db"); o.optional("maxLaserAge", 1.0);
     // runtime ORB parameters the reference hard-codes in its generated YAML (:193-198), plus device selection
     o.optional("numLevels", 3); o.optional("scaleFactor", 1.2); o.optional("iniFastThr", 20); o.optional("minFastThr", 7);
-    o.optional("device", 0); o.optional("keyframeInterval", 6); o.optional("localWindow", 10); o.optional("asyncMapping", true); o.optional("prefetch", true); o.optional("mapCulling", true);
+    o.optional("device", 0); o.optional("keyframeInterval", 6); o.optional("localWindow", 10); o.optional("asyncMapping", true); o.optional("prefetch", true); o.optional("mapCulling", true); o.optional("mappingReserve", 0);
 }
 
 HipVslamTrackerBase::~HipVslamTrackerBase() { stop(); }
@@ -90,6 +90,7 @@ void HipVslamTrackerBase::OnConfigurationUpdate()
     m_iniFastThr = o.getInteger("iniFastThr"); m_minFastThr = o.getInteger("minFastThr"); m_device = o.getInteger("device");
     m_keyframeInterval = std::max(1, o.getInteger("keyframeInterval")); m_localWindow = std::max(2, o.getInteger("localWindow"));
     m_asyncMapping = o.getBool("asyncMapping");
+    m_mappingReserve = std::min(16, std::max(0, o.getInteger("mappingReserve")));
     m_prefetch = o.getBool("prefetch"); m_mapCulling = o.getBool("mapCulling");
 }
 
@@ -181,6 +182,10 @@ bool HipVslamTrackerBase::startContext(bool stereo)
         m_ctx = nullptr;
         return false;
     }
+    // mappingReserve > 0: keep compute units of every XCD free of the front end's workgroups for the mapping thread's solves
+    // (lpslam_hip.h).  Off by default: it pays where the front end runs in chip-filling batches (bench.py: +4 % frames/s at 16 frames
+    // per launch); this tracker's per-frame launches are small and every one of them is slower on a masked stream (1250 -> 950 frames/s)
+    if (m_asyncMapping && m_mappingReserve > 0) (void)lpslam_hip_set_mapping_reserve(m_ctx, m_mappingReserve);
     for (int eye = 0; m_rectify && eye < 2; ++eye)
         if (lpslam_hip_set_rectify_map(m_ctx, eye, maps[eye].map_x.data(), maps[eye].map_y.data()) != LPSLAM_HIP_OK) {
             logMessage(LpSlamLogLevel_Error, std::string("Cannot upload the rectification maps: ") + lpslam_hip_last_error());

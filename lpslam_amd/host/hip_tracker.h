@@ -139,6 +139,7 @@ protected:
     bool m_useLiveView = false, m_useMapDb = true, m_forwardNavState = true, m_forwardImu = true, m_emitMap = false;
     bool m_enableMapping = true, m_waitForNavigation = false, m_forwardHighResNav = false, m_loopClosure = true;
     bool m_useOpenCL = false, m_useCUDA = false, m_relocWithNavigation = true, m_asyncMapping = true, m_prefetch = true;
+    int m_mappingReserve = 0;                      // compute units of every XCD the front end leaves to the mapping thread's solves
     std::string m_configFromFile, m_cameraSetup = "monocular", m_vocabFile = "orb_vocab.dbow2", m_mapFilename = "map.db";
     int m_slamKeypoints = 1200, m_viewerFps = 10;
     double m_baselineDistThresh = 0.1, m_maxLaserAge = 1.0;

@@ -240,3 +240,38 @@ def test_async_uploads_from_page_locked_frames(hiplib, oracle):
     with pytest.raises(hiplib.LpslamHipError):
         ctx.host_free(mine)                                  # not a block of host_alloc
     ctx.close()                                              # frees owned[1] with the context
+
+
+def test_mapping_reserve_changes_speed_only(hiplib):
+    """lpslam_hip_set_mapping_reserve: the context's front-end streams get a CU mask that leaves compute units of every XCD to the
+    bundle adjustments beside them (and the pyramid / distribution launches adapt their grids).  Keypoints and descriptors are bit
+    for bit the same with and without it; a bundle adjustment created on such a context (its panel chain then runs unpinned) gives
+    the same result; out-of-range values are refused."""
+    from lpslam_amd import hip
+    w, h = 640, 480
+    ctx = hip.Context(w, h, 1000, 1.2, 8, max_images=4)
+    seq = synth.StereoSequence(w, h, 3, n_points=5000)
+    imgs = [seq.frame(i)[e] for i in range(2) for e in range(2)]
+
+    def run():
+        for i, im in enumerate(imgs):
+            ctx.upload(i, im)
+        ctx.extract_range(0, 4)
+        return [ctx.keypoints(i) for i in range(4)]
+    p = synth.ba_problem(12, 600, 4000, w, h, seq_id=3)
+
+    def solve():
+        b = hip.BundleAdjuster(ctx, p["poses"], p["fixed"], p["points"], hip.ba_obs_array(p), p["cam"])
+        log = b.optimize(True, 6)
+        poses, points = b.state()
+        b.close()
+        return [tuple(l) for l in log], poses, points
+    base, base_ba = run(), solve()
+    for r in (4, 8, 0):
+        ctx.set_mapping_reserve(r)
+        got, got_ba = run(), solve()
+        for (k0, d0), (k1, d1) in zip(base, got):
+            assert np.array_equal(k0, k1) and np.array_equal(d0, d1)
+        assert got_ba[0] == base_ba[0] and np.array_equal(got_ba[1], base_ba[1]) and np.array_equal(got_ba[2], base_ba[2])
+    with pytest.raises(hip.LpslamHipError):
+        ctx.set_mapping_reserve(17)

@@ -12,7 +12,7 @@ for async_map in ("true", "false", "true", "false"):
         c.camera_number = num; c.f_x = k["fx"]; c.f_y = k["fy"]; c.c_x = k["cx"]; c.c_y = k["cy"]
         c.resolution_x = W; c.resolution_y = H; c.focal_x_baseline = k["fxb"]
         mg.set_camera(c)
-    mg.add_tracker("VSLAMStereo", '{"cameraSetup": "stereo", "slamKeypoints": %d, "numLevels": %d, "keyframeInterval": %d, "asyncMapping": %s}' % (KPTS, LEVELS, KF, async_map))
+    mg.add_tracker("VSLAMStereo", '{"cameraSetup": "stereo", "slamKeypoints": %d, "numLevels": %d, "keyframeInterval": %d, "asyncMapping": %s, "mappingReserve": %s}' % (KPTS, LEVELS, KF, async_map, os.environ.get("RESERVE", "0")))
     mg.collect_results(); mg.provide_odometry()
     log = os.path.join(tempfile.mkdtemp(), "slam.log")
     mg.log_to_file(log)
