@@ -420,7 +420,8 @@ void lpslam_hip_destroy(lpslam_hip_ctx* c)
 // adjustment (128 KB of LDS) then finds no room until the kernel drains, stream priority or not: a mapping solve beside the front end
 // stands still for the front end's kernels.  With a reserve the context's front-end streams are created with a CU mask that leaves
 // `cus_per_xcd` compute units of every XCD to whoever else runs (the solves then spread their panel workgroups over all XCDs).
-// Measured, one session: 3.95 -> 3.78 ms per 16-frame step with 4; the front end alone loses 8 %.  Call it on an idle context.
+// Measured, one session at 16 frames per front-end launch: 3.90 ms per step without, 3.76 with 4, 3.65 with 12;
+// the front end alone is 11 % / 43 % slower.  Call it on an idle context.
 int lpslam_hip_set_mapping_reserve(lpslam_hip_ctx* c, int32_t cus_per_xcd)
 {
     if (!c) { set_error("null context"); return LPSLAM_HIP_ERR_INVALID; }

@@ -8,6 +8,7 @@ PACE = float(os.environ.get('PACE', '0'))
 
 def main():
     wl = bench.Workload(0, 0, 16, with_ba=True)
+    wl.ctx.set_mapping_reserve(int(os.environ.get('RESERVE', '0')))
     F = wl.F
     # (a) copies alone
     for rep in range(3):
