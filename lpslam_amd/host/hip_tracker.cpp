@@ -1263,20 +1263,21 @@ bool HipVslamTrackerBase::relocalise(FrameData& cur)
         // landmarks -- refined by the pose optimiser ([UPSTREAM] min_num_inliers 10 for the solver)
         Pose seed = kf.pose;
         {
-            const size_t nm2 = cur_idx.size();
-            std::vector<double> pw(3 * nm2), ob(2 * nm2), w(nm2);
-            for (size_t k = 0; k < nm2; ++k) {
-                const Landmark& lm = m_landmarks.at(lm_ids[k]);
+            std::vector<double> pw, ob, w;
+            for (size_t k = 0; k < cur_idx.size(); ++k) {
+                auto it = m_landmarks.find(lm_ids[k]);
+                if (it == m_landmarks.end()) continue;               // culled since the keyframe saw it (poseFromMatches skips it too)
                 const lpslam_hip_keypoint& kp = cur.kpts[(size_t)cur_idx[k]];
-                for (int a = 0; a < 3; ++a) pw[3 * k + (size_t)a] = lm.p[a];
-                ob[2 * k] = kp.x; ob[2 * k + 1] = kp.y;
+                pw.insert(pw.end(), it->second.p, it->second.p + 3);
+                ob.push_back(kp.x); ob.push_back(kp.y);
                 const double sc = m_scales[kp.octave];
-                w[k] = 1.0 / (sc * sc);
+                w.push_back(1.0 / (sc * sc));
             }
+            const size_t nm2 = w.size();
             const double cam4[4] = {m_cam.f_x, m_cam.f_y, m_cam.c_x, m_cam.c_y};
             double p7[7];
-            std::vector<uint8_t> pnp_inl(nm2);
-            if (pnp_solve_ransac(pw.data(), ob.data(), w.data(), (int)nm2, cam4, 100, 0x9E3779B9u, p7, pnp_inl.data()) < 10) continue;
+            std::vector<uint8_t> pnp_inl(std::max<size_t>(nm2, 1));
+            if (nm2 < 4 || pnp_solve_ransac(pw.data(), ob.data(), w.data(), (int)nm2, cam4, 100, 0x9E3779B9u, p7, pnp_inl.data()) < 10) continue;
             for (int a = 0; a < 4; ++a) seed.q[a] = p7[a];
             for (int a = 0; a < 3; ++a) seed.t[a] = p7[4 + a];
         }

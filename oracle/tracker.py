@@ -804,9 +804,12 @@ class StereoTracker:
             if len(cur_idx) < 15:
                 continue
             # [UPSTREAM] solve::pnp_solver: the pose from the matches alone (no prior), refined by the pose optimiser
-            pw = np.array([self.landmarks[lid]["p"] for lid in lm_ids], float)
-            ob = np.array([[float(cur.kpts["x"][i]), float(cur.kpts["y"][i])] for i in cur_idx], float)
-            w = np.array([1.0 / float(self.scales[int(cur.kpts["octave"][i])]) ** 2 for i in cur_idx], float)
+            have = [(i, lid) for i, lid in zip(cur_idx, lm_ids) if lid in self.landmarks]      # culled since the keyframe saw it
+            if len(have) < 4:
+                continue
+            pw = np.array([self.landmarks[lid]["p"] for _, lid in have], float)
+            ob = np.array([[float(cur.kpts["x"][i]), float(cur.kpts["y"][i])] for i, _ in have], float)
+            w = np.array([1.0 / float(self.scales[int(cur.kpts["octave"][i])]) ** 2 for i, _ in have], float)
             found, p7, _ = TV.pnp_solve_ransac(pw, ob, w, [self.cam["fx"], self.cam["fy"], self.cam["cx"], self.cam["cy"]], 100, 0x9E3779B9)
             if found < 10:
                 continue
