@@ -48,14 +48,14 @@ def hip_library(force=False, verbose=False):
 
 
 HOST_LIB = os.path.join(HERE, "liblpslam.so")
-HOST_SOURCES = ["slam_manager.cpp", "hip_tracker.cpp", "interface.cpp", "rectify.cpp", "replay.cpp", "two_view.cpp", "bow.cpp"]
+HOST_SOURCES = ["slam_manager.cpp", "hip_tracker.cpp", "interface.cpp", "rectify.cpp", "replay.cpp", "two_view.cpp", "bow.cpp", "jpeg.cpp"]
 
 
 def host_library(force=False, verbose=False):
     """C++ host mirror of the reference interface (g++), linked against the HIP C-ABI library next to it."""
     hdir = os.path.join(HERE, "host")
     srcs = [os.path.join(hdir, s) for s in HOST_SOURCES]
-    deps = srcs + [os.path.join(hdir, h) for h in ("core.h", "json_min.h", "hip_tracker.h", "slam_manager.h", "rectify.h", "replay.h", "two_view.h", "bow.h")] + \
+    deps = srcs + [os.path.join(hdir, h) for h in ("core.h", "json_min.h", "hip_tracker.h", "slam_manager.h", "rectify.h", "replay.h", "two_view.h", "bow.h", "jpeg.h")] + \
         [os.path.join(HERE, "..", "include", h) for h in ("lpslam_types.h", "lpslam_manager.h", "lpslam_hip.h")] + [LIB]
     if not force and os.path.exists(HOST_LIB) and all(os.path.getmtime(d) <= os.path.getmtime(HOST_LIB) for d in deps if os.path.exists(d)):
         return HOST_LIB

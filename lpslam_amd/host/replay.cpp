@@ -1,5 +1,6 @@
 // replay.cpp -- see replay.h
 #include "replay.h"
+#include "jpeg.h"
 #include <cstring>
 #include <fstream>
 
@@ -86,6 +87,12 @@ bool decode_pgm(const uint8_t* d, size_t size, GrayImage& out)
     return true;
 }
 
+// an image payload of a record: baseline JPEG (what the reference's recorder writes: cv::imencode(".jpg"), RecordEngine.cpp:93) or PGM
+bool decode_image(const uint8_t* d, size_t size, GrayImage& out)
+{
+    return looks_like_jpeg(d, size) ? decode_jpeg_gray(d, size, out) : decode_pgm(d, size, out);
+}
+
 bool ReplayReader::open(const std::string& path, std::string* err)
 {
     m_in.close(); m_in.clear();
@@ -139,10 +146,10 @@ bool ReplayReader::next(ReplayFrame& out)
             }
         }
         if (!c.ok) { stats.truncated = true; break; }
-        if (!img || !decode_pgm(img, img_n, fr.image)) { ++stats.undecodable_images; continue; }
+        if (!img || !decode_image(img, img_n, fr.image)) { ++stats.undecodable_images; continue; }
         if (has_base2) {
             GrayImage second;
-            if (!img2 || !decode_pgm(img2, img2_n, second)) { ++stats.undecodable_images; continue; }
+            if (!img2 || !decode_image(img2, img2_n, second)) { ++stats.undecodable_images; continue; }
             fr.image_second = std::move(second);
         }
         if (has_odom && flag_odom) fr.odom = odom;

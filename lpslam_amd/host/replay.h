@@ -5,9 +5,9 @@
 // (src/Manager/ReplayEngine.cpp:83-242) turns CameraImage records into camera-queue entries -- image(s) decoded with
 // cv::imdecode, camera numbers, the odometry / map state stored with the frame -- and the others into sensor-queue entries.
 // This reader walks the records with a hand-written protobuf varint / length-delimited parser (no protoc in the image) and
-// decodes image payloads that are binary PGM ("P5", maxval 255), which cv::imdecode reads natively, so such a recording plays
-// in the reference as well; JPEG / PNG payloads (what the reference's recorder writes) need a codec this library does not
-// carry: those frames are counted and skipped.
+// decodes image payloads that are baseline JPEG (what the reference's recorder writes: cv::imencode(".jpg"), RecordEngine.cpp:93;
+// jpeg.h -- libjpeg's samples, grey; a colour record gives its luma plane) or binary PGM ("P5", maxval 255), which cv::imdecode
+// reads natively too; progressive JPEG / PNG payloads are counted and skipped.
 #pragma once
 #include <cstdint>
 #include <fstream>
@@ -55,5 +55,6 @@ private:
 bool read_replay_file(const std::string& path, std::vector<ReplayFrame>& frames, ReplayStats& stats, std::string* err);
 // binary PGM (P5, maxval <= 255) -> gray image; false for anything else
 bool decode_pgm(const uint8_t* data, size_t size, GrayImage& out);
+bool decode_image(const uint8_t* data, size_t size, GrayImage& out);     // baseline JPEG (jpeg.h) or PGM
 
 }  // namespace LpSlam

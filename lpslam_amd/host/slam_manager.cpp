@@ -1,5 +1,6 @@
 // slam_manager.cpp -- see slam_manager.h.
 #include "slam_manager.h"
+#include "jpeg.h"
 #include "replay.h"
 
 #include <cmath>
@@ -223,15 +224,23 @@ bool SlamManager::addStereoImageFromBuffer(uint32_t cameraNumber, LpSlamTimestam
 
 bool SlamManager::addImageFromBuffer(uint32_t cameraNumber, LpSlamTimestamp timestamp, uint8_t* buffer, LpSlamImageDescription desc)
 {
-    if (!buffer || desc.width == 0 || desc.height == 0) { logMessage(LpSlamLogLevel_Error, "Empty frame"); return false; }
-    if (desc.format != LpSlamImageFormat_8UC1 && desc.format != LpSlamImageFormat_8UC3) {
-        // the reference decodes JPEG here (cv::imdecode, SlamManager.cpp:1139-1155); no codec in this library
-        logMessage(LpSlamLogLevel_Error, "Image format not supported: compressed frames must be decoded by the caller");
-        return false;
-    }
+    if (!buffer || (desc.format != LpSlamImageFormat_8UC1_JPEPG && (desc.width == 0 || desc.height == 0))) { logMessage(LpSlamLogLevel_Error, "Empty frame"); return false; }
     CameraQueueEntry q;
     q.valid = true; q.timestamp = int64ToTimeStamp((int64_t)timestamp); q.cameraNumber = cameraNumber;
     if (desc.hasRosTimestamp > 0) q.ros_timestamp = desc.rosTimestamp;
+    if (desc.format == LpSlamImageFormat_8UC1_JPEPG) {
+        // a compressed frame (LpGlobalFusion / Webots / a recording): cv::imdecode(..., IMREAD_GRAYSCALE) in the reference
+        // (SlamManager.cpp:1139-1146), only as LpSlamImageStructure_OneImage (:1138-1152)
+        if (desc.structure != LpSlamImageStructure_OneImage) { logMessage(LpSlamLogLevel_Error, "Image format not supported"); return false; }
+        std::string why;
+        if (desc.imageSize == 0 || !decode_jpeg_gray(buffer, desc.imageSize, q.image, &why)) {
+            logMessage(LpSlamLogLevel_Error, "Cannot decode the compressed frame: " + (desc.imageSize ? why : std::string("imageSize is 0")));
+            return false;
+        }
+        m_camQueue.push(std::move(q));
+        return true;
+    }
+    if (desc.format != LpSlamImageFormat_8UC1 && desc.format != LpSlamImageFormat_8UC3) { logMessage(LpSlamLogLevel_Error, "Image format not supported"); return false; }
     const size_t px = (desc.format == LpSlamImageFormat_8UC3) ? 3 : 1;
     if (desc.structure == LpSlamImageStructure_OneImage) q.image = toGray(buffer, desc);
     else if (desc.structure == LpSlamImageStructure_Stereo_LeftTop_RightBottom) {

@@ -165,6 +165,13 @@ class Manager:
         d = ImageDescription(0, FORMAT_8UC1, 0, img.shape[0], img.shape[1], img.size, 0, 1 if ros else 0, ROSTimestamp(int(ts_ns // 10**9), int(ts_ns)))
         return bool(self.lib.lpslam_manager_add_image(self.h, camera, int(ts_ns), img.ctypes.data, C.byref(d)))
 
+    def add_jpeg(self, ts_ns, data, camera=0, ros=True):
+        """a compressed frame (LpSlamImageFormat_8UC1_JPEPG, one image): decoded by the manager as the reference does with cv::imdecode"""
+        raw = bytes(data)
+        buf = C.create_string_buffer(raw, len(raw))
+        d = ImageDescription(0, 0, 0, 0, 0, len(raw), 0, 1 if ros else 0, ROSTimestamp(int(ts_ns // 10**9), int(ts_ns)))
+        return bool(self.lib.lpslam_manager_add_image(self.h, camera, int(ts_ns), C.cast(buf, C.c_void_p), C.byref(d)))
+
     def start(self):
         self.lib.lpslam_manager_start(self.h)
 

@@ -108,6 +108,28 @@ def test_frames_without_odometry_are_skipped_and_reported(mgrlib):
     assert m.status().localization == 0          # Off
 
 
+def test_compressed_frames_are_decoded_at_ingest(mgrlib):
+    """LpSlamImageFormat_8UC1_JPEPG frames (src/Manager/SlamManager.cpp:1139-1146: cv::imdecode, IMREAD_GRAYSCALE): the manager decodes
+    baseline JPEG itself (host/jpeg.cpp) and queues the grey image; what is not a decodable stream is refused like any unsupported
+    format.  Runs without a GPU: the frames are skipped for lack of odometry, one invalid result each."""
+    from conftest import golden
+    g = golden("g17_jpeg.npz")
+    m = mgrlib.Manager()
+    assert m.add_tracker("VSLAMMono", '{"cameraSetup": "monocular"}')
+    m.collect_results()
+    m.start()
+    assert m.add_jpeg(1000, g["jpeg_grey_201x99_q90"].tobytes())
+    assert m.add_jpeg(2000, g["jpeg_colour_420_97x61_q75"].tobytes())             # a colour stream: its luma plane
+    assert not m.add_jpeg(3000, g["progressive_refused"].tobytes())                # progressive: refused, logged
+    assert not m.add_jpeg(4000, b"\xff\xd8\xff\xd9")                              # no frame inside
+    assert not m.add_jpeg(5000, b"not a jpeg at all")
+    t0 = time.time()
+    while len(m.results) < 2 and time.time() - t0 < 5:
+        time.sleep(0.01)
+    m.stop()
+    assert len(m.results) == 2
+
+
 def test_default_camera_configuration(mgrlib):
     c = mgrlib.default_camera()
     assert c.fps == 25.0 and c.distortion_function == mgrlib.NO_DISTORTION and list(c.rotation) == [1, 0, 0, 0, 1, 0, 0, 0, 1]
@@ -121,6 +143,8 @@ def test_replay_stream_reader(tmp_path):
     lib = ctypes.CDLL(_build.host_library())
     rng = np.random.default_rng(0)
     l = rng.integers(0, 256, (48, 64)).astype(np.uint8); r = rng.integers(0, 256, (48, 64)).astype(np.uint8)
+    from conftest import golden
+    jpeg = golden("g17_jpeg.npz")["jpeg_grey_201x99_q90"].tobytes()
     imu = rf.f_varint(1, 5) + rf.f_bytes(2, rf.vec3(0, 0, 9.81)) + rf.f_bytes(3, rf.vec3(0.1, 0, 0))
     stream = b"".join([
         rf.record(rf.SENSOR_IMU, imu),
@@ -129,13 +153,14 @@ def test_replay_stream_reader(tmp_path):
         rf.record(rf.CAMERA_IMAGE, rf.camera_image(2_000_000_000, l, None, cam=2, map_=((3, 4, 5), (1, 0, 0, 0)))),
         rf.record(rf.CAMERA_IMAGE, rf.camera_image(3_000_000_000, l, raw_left=b"\\xff\\xd8\\xff\\xe0JFIF-not-decodable")),     # what the recorder writes
         rf.record(rf.SENSOR_GLOBAL_STATE, rf.f_varint(1, 11)), rf.record(rf.SENSOR_FEATURE, rf.f_varint(1, 12)),
+        rf.record(rf.CAMERA_IMAGE, rf.camera_image(4_000_000_000, l, raw_left=jpeg)),                                      # a real JPEG record
         struct.pack("<QQ", 77, 3) + b"abc",                                                                                 # corrupt tail
     ])
     path = tmp_path / "rec.pb"; path.write_bytes(stream)
     stats = (ctypes.c_long * 8)(); first = (ctypes.c_long * 6)(); state = (ctypes.c_double * 14)()
     lib.lpslam_replay_probe.restype = ctypes.c_long
     n = lib.lpslam_replay_probe(str(path).encode(), stats, first, state)
-    assert n == 2 and list(stats) == [7, 3, 1, 1, 1, 1, 1, 1]
+    assert n == 3 and list(stats) == [8, 4, 1, 1, 1, 1, 1, 1]                    # the JPEG record decodes (baseline, host/jpeg.cpp), the fake one does not
     assert list(first) == [1_000_000_123, 4, 5, 64, 48, 1]
     assert list(state)[:7] == [1.5, -2.0, 0.25, 0.5, 0.5, -0.5, 0.5] and all(np.isnan(list(state)[7:]))
     assert lib.lpslam_replay_probe(str(tmp_path / "missing.pb").encode(), stats, first, state) == -1

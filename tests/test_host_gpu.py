@@ -169,6 +169,44 @@ def test_monocular_sequence_initialises_and_tracks(hiplib):
     assert abs(frac - frac_true) < 0.1                                            # constant speed: no scale jump along the way
 
 
+def test_monocular_tracker_takes_compressed_frames(hiplib):
+    """The reference's monocular ingest accepts JPEG-compressed frames only (src/Manager/SlamManager.cpp:1139-1155:
+    LpSlamImageFormat_8UC1_JPEPG -> cv::imdecode).  The same wall sequence as above, every frame JPEG-encoded (quality 95, what
+    cv::imencode writes by default) and handed to addImageFromBuffer: decoded by host/jpeg.cpp, initialised and tracked."""
+    io = pytest.importorskip("io")
+    Image = pytest.importorskip("PIL.Image")
+    from lpslam_amd import _build, manager
+    _build.host_library()
+    w, h, n_frames = 640, 480, 30
+    k = synth.intrinsics(w, h)
+    seq = synth.WallSequence(w, h, 11)
+    centres = [seq.centre(i) for i in range(n_frames)]
+    m = manager.Manager()
+    c = manager.default_camera()
+    c.camera_number = 0; c.f_x = k["fx"]; c.f_y = k["fy"]; c.c_x = k["cx"]; c.c_y = k["cy"]; c.resolution_x = w; c.resolution_y = h
+    m.set_camera(c)
+    assert m.add_tracker("VSLAMMono", '{"cameraSetup": "monocular", "slamKeypoints": 2000, "numLevels": 3, "keyframeInterval": 4}')
+    m.collect_results(); m.provide_odometry()
+    m.start()
+    for i in range(n_frames):
+        buf = io.BytesIO()
+        Image.fromarray(seq.frame(i)).save(buf, "JPEG", quality=95)
+        assert m.add_jpeg((i + 1) * 40_000_000, buf.getvalue())
+    t0 = time.time()
+    while len(m.results) < n_frames and time.time() - t0 < 60:
+        time.sleep(0.01)
+    st = m.status()
+    m.stop()
+    valid = [(i, r) for i, r in enumerate(m.results) if r["valid"]]
+    assert len(m.results) == n_frames and len(valid) >= n_frames - 12
+    assert st.localization == 2 and st.key_frames >= 4 and st.feature_points > 150
+    i0, r0 = valid[0]; i1, r1 = valid[-1]
+    d = np.array(r1["p"]) - np.array(r0["p"])
+    truth = centres[i1] - centres[i0]
+    truth_lp = np.array([-truth[1], truth[0], truth[2]])
+    assert d @ truth_lp / (np.linalg.norm(d) * np.linalg.norm(truth_lp)) > 0.995
+
+
 def test_loop_is_detected_and_closed(hiplib, tmp_path):
     """A full turn on the spot inside a ring of structure: when the camera faces its starting direction again, the first
     keyframes are not covisible with the new ones (the map holds that structure a second time, from the other end of the chain),

@@ -1,0 +1,64 @@
+"""The host's JPEG decoder (lpslam_amd/host/jpeg.cpp) against libjpeg's samples: the reference hands its compressed frames to
+cv::imdecode (src/Manager/SlamManager.cpp:1139-1146 for LpSlamImageFormat_8UC1_JPEPG frames, src/Manager/ReplayEngine.cpp:123 for
+recorded ones).  Fixtures: tests/golden/g17_jpeg.npz (tools/make_golden_jpeg.py: streams written and decoded by Pillow =
+libjpeg-turbo).  Bit for bit."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import golden
+
+
+def _decode(lib, data):
+    data = np.ascontiguousarray(data, np.uint8)
+    w, h = C.c_int(0), C.c_int(0)
+    out = np.zeros(1 << 20, np.uint8)
+    rc = lib.lpslam_jpeg_decode_gray(data.ctypes.data_as(C.c_void_p), C.c_size_t(len(data)), out.ctypes.data_as(C.c_void_p), C.c_size_t(len(out)), C.byref(w), C.byref(h))
+    return rc, (out[:w.value * h.value].reshape(h.value, w.value).copy() if rc == 0 else None)
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from lpslam_amd import _build
+    l = C.CDLL(_build.host_library())
+    l.lpslam_jpeg_decode_gray.restype = C.c_int
+    return l
+
+
+def test_decoder_gives_libjpegs_samples(lib):
+    g = golden("g17_jpeg.npz")
+    names = [k[5:] for k in g.files if k.startswith("jpeg_")]
+    assert len(names) >= 10
+    for name in names:
+        rc, img = _decode(lib, g["jpeg_" + name])
+        assert rc == 0, name
+        want = g["grey_" + name]
+        assert img.shape == want.shape, (name, img.shape, want.shape)
+        assert np.array_equal(img, want), (name, int(np.abs(img.astype(int) - want).max()), int((img != want).sum()))
+
+
+def test_unsupported_and_damaged_streams_are_refused(lib):
+    g = golden("g17_jpeg.npz")
+    assert _decode(lib, g["progressive_refused"])[0] == 2                       # progressive: a stated limit, not a crash
+    good = g["jpeg_grey_ramp_123x77_q70"]
+    assert _decode(lib, good[:len(good) // 3])[0] in (0, 2)                     # truncated: an image of what was there, or an error
+    assert _decode(lib, np.zeros(100, np.uint8))[0] == 2
+    assert _decode(lib, good[:2])[0] == 2
+    rng = np.random.default_rng(1)
+    for _ in range(200):                                                        # random damage never crashes the decoder
+        bad = good.copy()
+        for i in rng.integers(2, len(bad), 4):
+            bad[i] = rng.integers(0, 256)
+        assert _decode(lib, bad)[0] in (0, 1, 2)                                # (1: the damaged header asks for more than the test's buffer)
+
+
+def test_pillow_agrees_when_present(lib):
+    """the fixtures again, decoded now by the Pillow of this machine (skipped where there is none)"""
+    PIL = pytest.importorskip("PIL.Image")
+    import io
+    g = golden("g17_jpeg.npz")
+    for name in ("grey_320x240_q95", "colour_420_97x61_q75"):
+        data = g["jpeg_" + name].tobytes()
+        im = PIL.open(io.BytesIO(data)); im.draft("L", im.size); im.load()
+        assert np.array_equal(np.asarray(im), _decode(lib, g["jpeg_" + name])[1])
