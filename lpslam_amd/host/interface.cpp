@@ -3,6 +3,9 @@
 // non-C++ clients and the Python tests.
 #include "../../include/lpslam_manager.h"
 #include "slam_manager.h"
+#include "jpeg.h"
+#include <cstring>
+#include <vector>
 
 namespace LpSlam { LpSlamCameraConfiguration defaultCameraConfiguration(); }
 
@@ -22,7 +25,30 @@ void LpSlamManager::addStereoImageFromFiles(char const*, char const*) {}
 void LpSlamManager::addMarker(LpSlamMarkerIdentifier, LpSlamMarkerState) {}      // no-op in the reference too (SlamManager.cpp:1311-1312)
 bool LpSlamManager::addImageFromBuffer(uint32_t n, LpSlamTimestamp t, uint8_t* b, LpSlamImageDescription d) { return m_impl->addImageFromBuffer(n, t, b, d); }
 bool LpSlamManager::addStereoImageFromBuffer(uint32_t n, LpSlamTimestamp t, uint8_t* l, uint8_t* r, LpSlamImageDescription d) { return m_impl->addStereoImageFromBuffer(n, t, l, r, d); }
-bool LpSlamManager::compressImage(uint8_t*, LpSlamImageDescription, uint8_t*, uint32_t*) { return false; }        // JPEG codec: out of scope
+// src/InterfaceImpl/LpSlamManager.cpp:133-152: the buffer is taken as BGRA (Webots), turned grey with cv::cvtColor(COLOR_BGRA2GRAY) -- fixed-point weights
+// B 1868, G 9617, R 4899, >> 14 -- and written as cv::imencode(".jpg") writes it: libjpeg, baseline, quality 95 (host/jpeg.cpp; the
+// stream is libjpeg's byte for byte).  8UC1 / 8UC3 buffers are taken as what they say they are.  `bufferOut` is as large as the input.
+bool LpSlamManager::compressImage(uint8_t* buffer, LpSlamImageDescription desc, uint8_t* bufferOut, uint32_t* bufferOutSize)
+{
+    if (!buffer || !bufferOut || !bufferOutSize || desc.width == 0 || desc.height == 0) return false;
+    LpSlam::GrayImage g; g.width = (int)desc.width; g.height = (int)desc.height;
+    const size_t n = (size_t)desc.width * desc.height;
+    g.pixels.resize(n);
+    size_t in_bytes = 4 * n;
+    if (desc.format == LpSlamImageFormat_8UC1) { std::memcpy(g.pixels.data(), buffer, n); in_bytes = n; }
+    else if (desc.format == LpSlamImageFormat_8UC3) {
+        const bool bgr = desc.image_conversion == LpSlamImageConversion_BGR2RGB;
+        for (size_t i = 0; i < n; ++i) g.pixels[i] = (uint8_t)((buffer[3 * i + (bgr ? 2 : 0)] * 4899 + buffer[3 * i + 1] * 9617 + buffer[3 * i + (bgr ? 0 : 2)] * 1868 + (1 << 13)) >> 14);
+        in_bytes = 3 * n;
+    } else {
+        for (size_t i = 0; i < n; ++i) g.pixels[i] = (uint8_t)((buffer[4 * i] * 1868 + buffer[4 * i + 1] * 9617 + buffer[4 * i + 2] * 4899 + (1 << 13)) >> 14);
+    }
+    std::vector<uint8_t> out;
+    if (!LpSlam::encode_jpeg_gray(g, 95, out) || out.size() > in_bytes) return false;      // (a stream larger than its image: tiny noise images only)
+    std::memcpy(bufferOut, out.data(), out.size());
+    *bufferOutSize = (uint32_t)out.size();
+    return true;
+}
 void LpSlamManager::setCameraConfiguration(LpSlamCameraConfiguration c) { m_impl->setCameraConfiguration(c); }
 bool LpSlamManager::readConfigurationFile(char const* f) { return m_impl->readConfigurationFile(f ? f : ""); }
 bool LpSlamManager::readReplayItems(char const* f) { return m_impl->loadReplayItems(f ? f : ""); }
@@ -66,6 +92,7 @@ LPS_API void lpslam_manager_on_reconstruction(lpslam_c_manager* m, lpslam_c_reco
 LPS_API void lpslam_manager_request_nav_data(lpslam_c_manager* m, RequestNavDataCallback_t cb, void* user) { m->mgr.addRequestNavDataCallback(cb, user); }
 LPS_API int lpslam_manager_add_stereo_image(lpslam_c_manager* m, uint32_t cam, uint64_t ts, uint8_t* l, uint8_t* r, const LpSlamImageDescription* d) { return m->mgr.addStereoImageFromBuffer(cam, ts, l, r, *d); }
 LPS_API int lpslam_manager_add_image(lpslam_c_manager* m, uint32_t cam, uint64_t ts, uint8_t* b, const LpSlamImageDescription* d) { return m->mgr.addImageFromBuffer(cam, ts, b, *d); }
+LPS_API int lpslam_manager_compress_image(uint8_t* b, const LpSlamImageDescription* d, uint8_t* out, uint32_t* out_size) { return LpSlamManager::compressImage(b, *d, out, out_size); }
 LPS_API int lpslam_manager_read_replay_items(lpslam_c_manager* m, const char* f) { return m->mgr.readReplayItems(f); }
 LPS_API void lpslam_manager_start(lpslam_c_manager* m) { m->mgr.start(); }
 LPS_API void lpslam_manager_stop(lpslam_c_manager* m) { m->mgr.stop(); }

@@ -317,6 +317,148 @@ bool decode_jpeg_gray(const uint8_t* d, size_t size, GrayImage& out, std::string
 
 }  // namespace LpSlam
 
+namespace LpSlam {
+namespace {
+
+// ---- encoder: what cv::imencode(".jpg", grey) asks libjpeg for -- one component, baseline, the standard (Annex K) tables, quality 95
+const uint8_t kStdLumQuant[64] = {16, 11, 10, 16, 24, 40, 51, 61, 12, 12, 14, 19, 26, 58, 60, 55, 14, 13, 16, 24, 40, 57, 69, 56, 14, 17, 22, 29, 51, 87, 80, 62,
+                                  18, 22, 37, 56, 68, 109, 103, 77, 24, 35, 55, 64, 81, 104, 113, 92, 49, 64, 78, 87, 103, 121, 120, 101, 72, 92, 95, 98, 112, 100, 103, 99};
+const uint8_t kDcLumBits[17] = {0, 0, 1, 5, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0};
+const uint8_t kDcLumVals[12] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11};
+const uint8_t kAcLumBits[17] = {0, 0, 2, 1, 3, 3, 2, 4, 3, 5, 5, 4, 4, 0, 0, 1, 0x7d};
+const uint8_t kAcLumVals[162] = {
+    0x01, 0x02, 0x03, 0x00, 0x04, 0x11, 0x05, 0x12, 0x21, 0x31, 0x41, 0x06, 0x13, 0x51, 0x61, 0x07, 0x22, 0x71, 0x14, 0x32, 0x81, 0x91, 0xa1, 0x08, 0x23, 0x42, 0xb1,
+    0xc1, 0x15, 0x52, 0xd1, 0xf0, 0x24, 0x33, 0x62, 0x72, 0x82, 0x09, 0x0a, 0x16, 0x17, 0x18, 0x19, 0x1a, 0x25, 0x26, 0x27, 0x28, 0x29, 0x2a, 0x34, 0x35, 0x36, 0x37,
+    0x38, 0x39, 0x3a, 0x43, 0x44, 0x45, 0x46, 0x47, 0x48, 0x49, 0x4a, 0x53, 0x54, 0x55, 0x56, 0x57, 0x58, 0x59, 0x5a, 0x63, 0x64, 0x65, 0x66, 0x67, 0x68, 0x69, 0x6a,
+    0x73, 0x74, 0x75, 0x76, 0x77, 0x78, 0x79, 0x7a, 0x83, 0x84, 0x85, 0x86, 0x87, 0x88, 0x89, 0x8a, 0x92, 0x93, 0x94, 0x95, 0x96, 0x97, 0x98, 0x99, 0x9a, 0xa2, 0xa3,
+    0xa4, 0xa5, 0xa6, 0xa7, 0xa8, 0xa9, 0xaa, 0xb2, 0xb3, 0xb4, 0xb5, 0xb6, 0xb7, 0xb8, 0xb9, 0xba, 0xc2, 0xc3, 0xc4, 0xc5, 0xc6, 0xc7, 0xc8, 0xc9, 0xca, 0xd2, 0xd3,
+    0xd4, 0xd5, 0xd6, 0xd7, 0xd8, 0xd9, 0xda, 0xe1, 0xe2, 0xe3, 0xe4, 0xe5, 0xe6, 0xe7, 0xe8, 0xe9, 0xea, 0xf1, 0xf2, 0xf3, 0xf4, 0xf5, 0xf6, 0xf7, 0xf8, 0xf9, 0xfa};
+
+struct EncTable { uint16_t code[256]; uint8_t len[256]; };
+void make_enc_table(const uint8_t* bits, const uint8_t* vals, EncTable& t)
+{
+    std::memset(&t, 0, sizeof(t));
+    int code = 0, k = 0;
+    for (int l = 1; l <= 16; ++l) {
+        for (int i = 0; i < bits[l]; ++i, ++k, ++code) { t.code[vals[k]] = (uint16_t)code; t.len[vals[k]] = (uint8_t)l; }
+        code <<= 1;
+    }
+}
+
+// libjpeg's jpeg_fdct_islow on an 8 x 8 block of level-shifted samples (the result is 8 x the DCT)
+void fdct_islow(int32_t* data)
+{
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int i = 0; i < 8; ++i) {
+            int32_t* d = pass == 0 ? data + 8 * i : data + i;
+            const int st = pass == 0 ? 1 : 8;
+            const int64_t tmp0 = d[0] + d[7 * st], tmp7 = d[0] - d[7 * st], tmp1 = d[st] + d[6 * st], tmp6 = d[st] - d[6 * st];
+            const int64_t tmp2 = d[2 * st] + d[5 * st], tmp5 = d[2 * st] - d[5 * st], tmp3 = d[3 * st] + d[4 * st], tmp4 = d[3 * st] - d[4 * st];
+            const int64_t tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+            const int sh = pass == 0 ? CONST_BITS - PASS1_BITS : CONST_BITS + PASS1_BITS;
+            if (pass == 0) { d[0] = (int32_t)((tmp10 + tmp11) * (1 << PASS1_BITS)); d[4 * st] = (int32_t)((tmp10 - tmp11) * (1 << PASS1_BITS)); }
+            else { d[0] = descale(tmp10 + tmp11, PASS1_BITS); d[4 * st] = descale(tmp10 - tmp11, PASS1_BITS); }
+            int64_t z1 = (tmp12 + tmp13) * F_0_541196100;
+            d[2 * st] = descale(z1 + tmp13 * F_0_765366865, sh);
+            d[6 * st] = descale(z1 + tmp12 * (-F_1_847759065), sh);
+            z1 = tmp4 + tmp7;
+            int64_t z2 = tmp5 + tmp6, z3 = tmp4 + tmp6, z4 = tmp5 + tmp7;
+            const int64_t z5 = (z3 + z4) * F_1_175875602;
+            const int64_t t4 = tmp4 * F_0_298631336, t5 = tmp5 * F_2_053119869, t6 = tmp6 * F_3_072711026, t7 = tmp7 * F_1_501321110;
+            z1 *= -F_0_899976223; z2 *= -F_2_562915447; z3 *= -F_1_961570560; z4 *= -F_0_390180644;
+            z3 += z5; z4 += z5;
+            d[7 * st] = descale(t4 + z1 + z3, sh); d[5 * st] = descale(t5 + z2 + z4, sh);
+            d[3 * st] = descale(t6 + z2 + z3, sh); d[st] = descale(t7 + z1 + z4, sh);
+        }
+    }
+}
+
+struct BitWriter {
+    std::vector<uint8_t>& out; uint32_t acc = 0; int n = 0;
+    void put(uint32_t code, int len)
+    {
+        acc = (acc << len) | (code & ((1u << len) - 1)); n += len;
+        while (n >= 8) { const uint8_t b = (uint8_t)(acc >> (n - 8)); out.push_back(b); if (b == 0xFF) out.push_back(0); n -= 8; }
+    }
+    void flush() { if (n) put(0x7F, 8 - n); }             // pad with ones
+};
+
+}  // namespace
+
+bool encode_jpeg_gray(const GrayImage& img, int quality, std::vector<uint8_t>& out)
+{
+    if (img.width <= 0 || img.height <= 0 || img.width > 65535 || img.height > 65535 || img.pixels.size() < (size_t)img.width * img.height) return false;
+    quality = std::min(100, std::max(1, quality));
+    const int scale = quality < 50 ? 5000 / quality : 200 - 2 * quality;          // jpeg_quality_scaling
+    uint8_t q[64];
+    for (int i = 0; i < 64; ++i) { long t = ((long)kStdLumQuant[i] * scale + 50) / 100; q[i] = (uint8_t)std::min(255L, std::max(1L, t)); }      // force_baseline
+    EncTable dct, act;
+    make_enc_table(kDcLumBits, kDcLumVals, dct); make_enc_table(kAcLumBits, kAcLumVals, act);
+    out.clear();
+    auto put16 = [&](int v) { out.push_back((uint8_t)(v >> 8)); out.push_back((uint8_t)v); };
+    auto marker = [&](int m) { out.push_back(0xFF); out.push_back((uint8_t)m); };
+    marker(0xD8);
+    marker(0xE0); put16(16); for (char c : {'J', 'F', 'I', 'F', '\0'}) out.push_back((uint8_t)c);
+    out.push_back(1); out.push_back(1); out.push_back(0); put16(1); put16(1); out.push_back(0); out.push_back(0);      // JFIF 1.01, no density unit, 1:1
+    marker(0xDB); put16(67); out.push_back(0); for (int k = 0; k < 64; ++k) out.push_back(q[kZigzag[k]]);
+    marker(0xC0); put16(11); out.push_back(8); put16(img.height); put16(img.width); out.push_back(1); out.push_back(1); out.push_back(0x11); out.push_back(0);
+    marker(0xC4); put16(2 + 1 + 16 + 12); out.push_back(0x00); for (int l = 1; l <= 16; ++l) out.push_back(kDcLumBits[l]); for (uint8_t v : kDcLumVals) out.push_back(v);
+    marker(0xC4); put16(2 + 1 + 16 + 162); out.push_back(0x10); for (int l = 1; l <= 16; ++l) out.push_back(kAcLumBits[l]); for (uint8_t v : kAcLumVals) out.push_back(v);
+    marker(0xDA); put16(8); out.push_back(1); out.push_back(1); out.push_back(0x00); out.push_back(0); out.push_back(63); out.push_back(0);
+    BitWriter bw{out};
+    const int bw_n = (img.width + 7) / 8, bh_n = (img.height + 7) / 8;
+    int pred = 0;
+    for (int by = 0; by < bh_n; ++by)
+        for (int bx = 0; bx < bw_n; ++bx) {
+            int32_t blk[64];
+            for (int r = 0; r < 8; ++r) {
+                const int y = std::min(8 * by + r, img.height - 1);                // edge blocks: the last row / column repeated (libjpeg's edge expansion)
+                for (int c = 0; c < 8; ++c) blk[8 * r + c] = (int32_t)img.pixels[(size_t)y * img.width + std::min(8 * bx + c, img.width - 1)] - 128;
+            }
+            fdct_islow(blk);
+            int16_t zz[64];
+            for (int k = 0; k < 64; ++k) {
+                const int i = kZigzag[k];
+                const int32_t qv = (int32_t)q[i] << 3;                            // the transform's output is scaled by 8
+                int32_t t = blk[i];
+                if (t < 0) { t = -t; t += qv >> 1; t = t >= qv ? t / qv : 0; t = -t; }
+                else { t += qv >> 1; t = t >= qv ? t / qv : 0; }
+                zz[k] = (int16_t)t;
+            }
+            auto category = [](int v) { int a = v < 0 ? -v : v, s = 0; while (a) { ++s; a >>= 1; } return s; };
+            const int diff = zz[0] - pred; pred = zz[0];
+            int s2 = category(diff);
+            bw.put(dct.code[s2], dct.len[s2]);
+            if (s2) bw.put((uint32_t)(diff < 0 ? diff - 1 : diff), s2);
+            int run = 0;
+            for (int k = 1; k < 64; ++k) {
+                const int v = zz[k];
+                if (v == 0) { ++run; continue; }
+                while (run > 15) { bw.put(act.code[0xF0], act.len[0xF0]); run -= 16; }
+                s2 = category(v);
+                bw.put(act.code[(run << 4) | s2], act.len[(run << 4) | s2]);
+                bw.put((uint32_t)(v < 0 ? v - 1 : v), s2);
+                run = 0;
+            }
+            if (run) bw.put(act.code[0], act.len[0]);
+        }
+    bw.flush();
+    marker(0xD9);
+    return true;
+}
+
+}  // namespace LpSlam
+
+// tests: encode a grey image; returns the number of bytes written, 0 when the buffer is too small or the image is not encodable
+extern "C" __attribute__((visibility("default"))) size_t lpslam_jpeg_encode_gray(const uint8_t* pixels, int w, int h, int quality, uint8_t* out, size_t cap)
+{
+    LpSlam::GrayImage img; img.width = w; img.height = h; img.pixels.assign(pixels, pixels + (size_t)w * h);
+    std::vector<uint8_t> buf;
+    if (!LpSlam::encode_jpeg_gray(img, quality, buf) || buf.size() > cap) return 0;
+    std::memcpy(out, buf.data(), buf.size());
+    return buf.size();
+}
+
 // tests: decode into a caller buffer; returns 0 on success, 1 when the buffer is too small (w / h are set), 2 on a decoding error
 extern "C" __attribute__((visibility("default"))) int lpslam_jpeg_decode_gray(const uint8_t* data, size_t size, uint8_t* out, size_t cap, int* w, int* h)
 {

@@ -9,12 +9,16 @@
 #include <cstddef>
 #include <cstdint>
 #include <string>
+#include <vector>
 
 #include "core.h"
 
 namespace LpSlam {
 
 bool decode_jpeg_gray(const uint8_t* data, size_t size, GrayImage& out, std::string* why = nullptr);
+// what cv::imencode(".jpg", grey) writes (LpSlamManager::compressImage, src/InterfaceImpl/LpSlamManager.cpp:133-152): one component,
+// baseline, Annex K tables scaled for `quality` (OpenCV's default: 95), libjpeg's islow forward DCT and rounding
+bool encode_jpeg_gray(const GrayImage& img, int quality, std::vector<uint8_t>& out);
 inline bool looks_like_jpeg(const uint8_t* data, size_t size) { return size >= 4 && data[0] == 0xFF && data[1] == 0xD8 && data[2] == 0xFF; }
 
 }  // namespace LpSlam

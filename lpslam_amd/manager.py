@@ -172,6 +172,21 @@ class Manager:
         d = ImageDescription(0, 0, 0, 0, 0, len(raw), 0, 1 if ros else 0, ROSTimestamp(int(ts_ns // 10**9), int(ts_ns)))
         return bool(self.lib.lpslam_manager_add_image(self.h, camera, int(ts_ns), C.cast(buf, C.c_void_p), C.byref(d)))
 
+    @staticmethod
+    def compress_image(bgra):
+        """LpSlamManager::compressImage: an (h, w, 4) BGRA image -> the JPEG stream of its grey version (bytes), or None"""
+        import numpy as np
+        bgra = np.ascontiguousarray(bgra, np.uint8)
+        h, w = bgra.shape[:2]
+        d = ImageDescription(0, 3, 0, h, w, bgra.size, 0, 0, ROSTimestamp(0, 0))          # LpSlamImageFormat_8UC4
+        out = np.zeros(bgra.size, np.uint8)
+        n = C.c_uint32(0)
+        f = load().lpslam_manager_compress_image
+        f.restype = C.c_int; f.argtypes = [C.c_void_p, C.POINTER(ImageDescription), C.c_void_p, C.POINTER(C.c_uint32)]
+        if not f(bgra.ctypes.data, C.byref(d), out.ctypes.data, C.byref(n)):
+            return None
+        return out[:n.value].tobytes()
+
     def start(self):
         self.lib.lpslam_manager_start(self.h)
 

@@ -130,6 +130,35 @@ def test_compressed_frames_are_decoded_at_ingest(mgrlib):
     assert len(m.results) == 2
 
 
+def test_compress_image_round_trip(mgrlib):
+    """LpSlamManager::compressImage (src/InterfaceImpl/LpSlamManager.cpp:133-152): BGRA -> grey (cv::cvtColor's weights) -> JPEG as
+    cv::imencode writes it, and back in through addImageFromBuffer as a LpSlamImageFormat_8UC1_JPEPG frame -- what LpGlobalFusion does
+    with its Webots frames."""
+    rng = np.random.default_rng(2)
+    grey = np.clip(np.add.outer(np.arange(96) * 2, np.arange(128)) + rng.integers(0, 20, (96, 128)), 0, 255).astype(np.uint8)
+    bgra = np.stack([np.roll(grey, 3, 1), grey, np.roll(grey, -3, 0), np.full_like(grey, 255)], axis=-1)
+    data = mgrlib.Manager.compress_image(bgra)
+    assert data is not None and data[:2] == b"\xff\xd8" and data[-2:] == b"\xff\xd9" and len(data) < bgra.size
+    want = ((bgra[..., 0].astype(np.int64) * 1868 + bgra[..., 1].astype(np.int64) * 9617 + bgra[..., 2].astype(np.int64) * 4899 + (1 << 13)) >> 14).astype(np.uint8)
+    try:                                                     # byte for byte what libjpeg writes for that grey image at quality 95
+        import io
+        from PIL import Image
+        buf = io.BytesIO(); Image.fromarray(want).save(buf, "JPEG", quality=95)
+        assert data == buf.getvalue()
+    except ImportError:
+        pass
+    m = mgrlib.Manager()
+    assert m.add_tracker("VSLAMMono", '{"cameraSetup": "monocular"}')
+    m.collect_results()
+    m.start()
+    assert m.add_jpeg(1000, data)
+    t0 = time.time()
+    while len(m.results) < 1 and time.time() - t0 < 5:
+        time.sleep(0.01)
+    m.stop()
+    assert len(m.results) == 1
+
+
 def test_default_camera_configuration(mgrlib):
     c = mgrlib.default_camera()
     assert c.fps == 25.0 and c.distortion_function == mgrlib.NO_DISTORTION and list(c.rotation) == [1, 0, 0, 0, 1, 0, 0, 0, 1]

@@ -62,3 +62,41 @@ def test_pillow_agrees_when_present(lib):
         data = g["jpeg_" + name].tobytes()
         im = PIL.open(io.BytesIO(data)); im.draft("L", im.size); im.load()
         assert np.array_equal(np.asarray(im), _decode(lib, g["jpeg_" + name])[1])
+
+
+def _encode(lib, img, quality):
+    img = np.ascontiguousarray(img, np.uint8)
+    out = np.zeros(img.size * 2 + 4096, np.uint8)
+    lib.lpslam_jpeg_encode_gray.restype = C.c_size_t
+    n = lib.lpslam_jpeg_encode_gray(img.ctypes.data_as(C.c_void_p), C.c_int(img.shape[1]), C.c_int(img.shape[0]), C.c_int(quality), out.ctypes.data_as(C.c_void_p), C.c_size_t(len(out)))
+    return out[:n].copy()
+
+
+def test_encoder_writes_what_libjpeg_writes(lib):
+    """LpSlamManager::compressImage (src/InterfaceImpl/LpSlamManager.cpp:133-152) = cv::imencode(".jpg", grey): libjpeg, baseline,
+    quality 95.  The encoder here makes the same choices (Annex K tables, quality scaling, islow forward DCT, rounding of the
+    quantiser, edge expansion): its streams are byte for byte Pillow's (= libjpeg-turbo's) where Pillow is present, and they always
+    decode -- by this library's decoder -- to the image within the quantisation error."""
+    from lpslam_amd import synth
+    frame = synth.StereoSequence(640, 480, 4, n_points=6000).frame(0)[0]
+    rng = np.random.default_rng(3)
+    cases = [(frame[:240, :320], 95), (frame[3:100, 5:206], 70), (rng.integers(0, 256, (33, 47), dtype=np.uint8), 95), (np.full((16, 16), 200, np.uint8), 50)]
+    for img, quality in cases:
+        data = _encode(lib, img, quality)
+        assert len(data) > 100 and data[0] == 0xFF and data[1] == 0xD8 and data[-2] == 0xFF and data[-1] == 0xD9
+        rc, back = _decode(lib, data)
+        assert rc == 0 and back.shape == img.shape
+        err = np.abs(back.astype(int) - img.astype(int))
+        assert err.mean() < (2.5 if quality >= 90 else 12.0), (quality, err.mean())
+    try:
+        import io
+        from PIL import Image
+    except ImportError:
+        return
+    for img, quality in cases:
+        buf = io.BytesIO()
+        Image.fromarray(img).save(buf, "JPEG", quality=quality)
+        theirs = np.frombuffer(buf.getvalue(), np.uint8)
+        ours = _encode(lib, img, quality)
+        assert np.array_equal(np.asarray(Image.open(io.BytesIO(ours.tobytes()))), np.asarray(Image.open(io.BytesIO(theirs.tobytes()))))      # the same coefficients
+        assert len(ours) == len(theirs) and np.array_equal(ours, theirs), (len(ours), len(theirs))                                        # ... and the same bytes
