@@ -864,15 +864,16 @@ __global__ __launch_bounds__(64) void k_ba_schur(const BaView* __restrict__ view
         const int i = bx - n_work;
         const int p = v.free_pose[i];
         double r6[6] = {0, 0, 0, 0, 0, 0};
-        // four observations per lane and round: their index -> landmark -> (H_ll, b_l) load chains run side by side
+        // two observations per lane and round: their index -> landmark -> (H_ll, b_l) load chains run side by side (four held 216
+        // registers; the kernel's allocation decides how many wavefronts hide each other's gathers)
         const int s_end = v.ps_start[p + 1];
-        for (int s0 = v.ps_start[p] + lane; s0 < s_end; s0 += 256) {
-            int jj[4];
+        for (int s0 = v.ps_start[p] + lane; s0 < s_end; s0 += 128) {
+            int jj[2];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) jj[u] = v.o_point[min(s0 + 64 * u, s_end - 1)];
-            double hh[4][6], bb[4][3], ww[4][18];
+            for (int u = 0; u < 2; ++u) jj[u] = v.o_point[min(s0 + 64 * u, s_end - 1)];
+            double hh[2][6], bb[2][3], ww[2][18];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < 2; ++u) {
                 const int s = min(s0 + 64 * u, s_end - 1);
                 const double* hl = v.Hll + 6 * (size_t)jj[u];
 #pragma unroll
@@ -884,7 +885,7 @@ __global__ __launch_bounds__(64) void k_ba_schur(const BaView* __restrict__ view
                 for (int q = 0; q < 9; ++q) { const double2 a2 = Wa[q]; ww[u][2 * q] = a2.x; ww[u][2 * q + 1] = a2.y; }
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < 2; ++u) {
                 if (s0 + 64 * u < s_end) {
                     double h[6];
                     point_hinv(hh[u], lambda, h);
@@ -933,37 +934,41 @@ __global__ __launch_bounds__(64) void k_ba_schur(const BaView* __restrict__ view
         while (pidx >= rowlen) { pidx -= rowlen; --rowlen; ++i; }
     }
     const int k = i + pidx;
-    __shared__ double part[64 * 37];
-    double acc[36];
+    // TWO lanes per term: lane parity p takes rows 3p .. 3p+2 of the term's 6 x 6 product (18 accumulators instead of 36, half of
+    // W_a), so the kernel fits four wavefronts per SIMD instead of two -- it is bound by the latency of its dependent gathers
+    // (term -> rows), which only other wavefronts hide.  Both lanes load W_b and the landmark's block (the second one hits the L1).
+    __shared__ double part[32 * 37];
+    const int tl = lane >> 1, hp = lane & 1;
+    double acc[18];
 #pragma unroll
-    for (int q = 0; q < 36; ++q) acc[q] = 0;
-    for (int t = v.blk_start[blk] + part_id * 64 + lane; t < v.blk_start[blk + 1]; t += 64 * parts) {
+    for (int q = 0; q < 18; ++q) acc[q] = 0;
+    for (int t = v.blk_start[blk] + part_id * 32 + tl; t < v.blk_start[blk + 1]; t += 32 * parts) {
         const int4 ab = v.blk_terms[t];
-        // rows are 144 bytes = nine 16-byte pieces: dwordx4 loads halve the number of cache-line lookups, which -- every lane
-        // in a different line -- are what this kernel is made of
-        const double2* Wa = reinterpret_cast<const double2*>(v.W + 18 * (size_t)ab.x);
+        const double* Wa = v.W + 18 * (size_t)ab.x + 9 * hp;
         const double2* Wb = reinterpret_cast<const double2*>(v.W + 18 * (size_t)ab.y);
         const double* hl = v.Hll + 6 * (size_t)ab.z;
-        double hraw[6], y[18], w[18];
+        double hraw[6], y[9], w[18];
 #pragma unroll
         for (int q = 0; q < 6; ++q) hraw[q] = hl[q];
 #pragma unroll
-        for (int q = 0; q < 9; ++q) { const double2 a2 = Wa[q], b2 = Wb[q]; y[2 * q] = a2.x; y[2 * q + 1] = a2.y; w[2 * q] = b2.x; w[2 * q + 1] = b2.y; }
+        for (int q = 0; q < 9; ++q) y[q] = Wa[q];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) { const double2 b2 = Wb[q]; w[2 * q] = b2.x; w[2 * q + 1] = b2.y; }
         double h[6];
         point_hinv(hraw, lambda, h);
 #pragma unroll
-        for (int r = 0; r < 6; ++r) obs_y_row(h, y[r * 3], y[r * 3 + 1], y[r * 3 + 2], y[r * 3], y[r * 3 + 1], y[r * 3 + 2]);
+        for (int r = 0; r < 3; ++r) obs_y_row(h, y[r * 3], y[r * 3 + 1], y[r * 3 + 2], y[r * 3], y[r * 3 + 1], y[r * 3 + 2]);
 #pragma unroll
-        for (int r = 0; r < 6; ++r)
+        for (int r = 0; r < 3; ++r)
 #pragma unroll
             for (int c = 0; c < 6; ++c)
                 acc[r * 6 + c] += y[r * 3] * w[c * 3] + y[r * 3 + 1] * w[c * 3 + 1] + y[r * 3 + 2] * w[c * 3 + 2];
     }
 #pragma unroll
-    for (int q = 0; q < 36; ++q) part[lane * 37 + q] = acc[q];
+    for (int q = 0; q < 18; ++q) part[tl * 37 + 18 * hp + q] = acc[q];
     __syncthreads();
     double sum = 0;
-    if (lane < 36) for (int l = 0; l < 64; ++l) sum += part[l * 37 + lane];
+    if (lane < 36) for (int l = 0; l < 32; ++l) sum += part[l * 37 + lane];
     if (parts > 1) {
         // hand-over without cache maintenance: the partial sums are stored write-through (sc1) and read back L1-bypassing (sc1),
         // the ticket is a relaxed agent-scope add made after this (single) wavefront's stores have drained -- no buffer_wbl2 /
