@@ -36,7 +36,7 @@ BA_KF, BA_PTS, BA_OBS, BA_ITERS = 50, 5000, 40000, 10
 BA_VARIANTS = 4               # distinct windows (problem seeds) the keyframes rotate through
 # compute units of every XCD the front end leaves to the mapping solves that run beside it (lpslam_hip_set_mapping_reserve; what the
 # tracker sets for its mapping thread).  The front-end-only and batched extras run with 0.
-MAPPING_RESERVE = int(os.environ.get("LPSLAM_BENCH_RESERVE", "12"))
+MAPPING_RESERVE = int(os.environ.get("LPSLAM_BENCH_RESERVE", "16"))
 HBM_PEAK_GBS = 8000.0         # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 measured copy)
 FP64_PEAK_TFLOPS = 78.6       # MI355X FP64 matrix = vector peak (MI355X_MICROARCH.md / SURVEY.md 8(d))
 INT_PEAK_TOPS = 39.3          # 256 CU x 64 lanes x 2.4 GHz int32 VALU ops (matching)
