@@ -231,11 +231,14 @@ int lpslam_hip_ba_optimize_end(lpslam_hip_ba* ba, lpslam_hip_ba_iter_log* log, i
  * of a (stream, launch extents, robust, iters) signature the second time it sees it and replays it from then on, also for OTHER
  * problems with that signature on that stream).  Measurement / test hook; no reference counterpart. */
 int64_t lpslam_hip_ba_graph_replays(lpslam_hip_ctx* ctx);
+/* How many launches of the one-workgroup factorisation (k_chol_wg: batches of LPSLAM_HIP_CW_MIN_BATCH = 40 problems and more) this
+ * context has enqueued.  Test hook: proves which of the two factorisations a batch went through.  No reference counterpart. */
+int64_t lpslam_hip_ba_wg_factorisations(lpslam_hip_ctx* ctx);
 /* Batched solve -- north star: "a batched Levenberg-Marquardt local-BA".  n independent problems (the keyframe windows of
  * several SLAM sessions served by one GPU, [UPSTREAM] mapping_module::run of each session; lpslam reaches it through
  * feed_stereo_frame, src/Trackers/OpenVSLAMStereoTracker.cpp:293-295) are advanced by ONE launch chain: every kernel runs once
  * for the whole batch (blockIdx.y = problem) and each problem follows its own lambda control.  Results are identical to n calls of
- * lpslam_hip_ba_optimize for batches of fewer than 24 problems; from 24 on the reduced systems of local windows are factored by one
+ * lpslam_hip_ba_optimize for batches of fewer than 40 problems; from 40 on the reduced systems of local windows are factored by one
  * workgroup each (another summation order: equal within rounding, chi2 to 1e-12 relative).  All problems must live on one device; logs (may be NULL) receives log_stride entries per problem,
  * done (may be NULL) the iterations each problem ran.  reset_batch = lpslam_hip_ba_reset of every problem in one launch. */
 int lpslam_hip_ba_optimize_batch(lpslam_hip_ba* const* problems, int32_t n, int32_t robust, int32_t iters,

@@ -407,6 +407,7 @@ void lpslam_hip_destroy(lpslam_hip_ctx* c)
     for (hipEvent_t e : c->ev_upload) if (e) (void)hipEventDestroy(e);
     if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
     if (c->ev_copy_mark) (void)hipEventDestroy(c->ev_copy_mark);
+    if (c->ev_copy_mark_fe) (void)hipEventDestroy(c->ev_copy_mark_fe);
     for (hipEvent_t e : c->ev_copy_pool) if (e) (void)hipEventDestroy(e);
     for (auto& a : c->host_allocs) if (a.first) (void)hipHostFree(a.first);
     c->host_allocs.clear();
@@ -659,6 +660,7 @@ int lpslam_hip_host_unregister(lpslam_hip_ctx* c, void* p)
 // main stream waits (on the device) for uploads of slots [first, first + n) it has not waited for yet
 int lp_wait_uploads(lpslam_hip_ctx* c, int first, int n)
 {
+    std::lock_guard<std::mutex> lock(c->copy_mutex);
     if (c->slot_copy_event.empty()) return LPSLAM_HIP_OK;
     hipStream_t s = lp_fe_stream(c);
     hipEvent_t last = nullptr;
@@ -678,9 +680,11 @@ int lpslam_hip_upload_images_async(lpslam_hip_ctx* c, int first, int n, const ui
     if (stride < c->lt.w[0]) { set_error("bad host image (stride %d < width %d)", stride, c->lt.w[0]); return LPSLAM_HIP_ERR_INVALID; }
     for (int i = 0; i < n; ++i) if (!hosts[i]) { set_error("null frame %d", i); return LPSLAM_HIP_ERR_INVALID; }
     LP_HIP(hipSetDevice(c->cfg.device));
+    std::lock_guard<std::mutex> lock(c->copy_mutex);
     if (!c->copy_stream) {
         LP_HIP(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
         LP_HIP(hipEventCreateWithFlags(&c->ev_copy_mark, hipEventDisableTiming));
+        LP_HIP(hipEventCreateWithFlags(&c->ev_copy_mark_fe, hipEventDisableTiming));
         c->ev_copy_pool.assign(16, nullptr);
         for (auto& e : c->ev_copy_pool) LP_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         c->slot_copy_event.assign((size_t)c->cfg.max_images, nullptr);
@@ -688,6 +692,10 @@ int lpslam_hip_upload_images_async(lpslam_hip_ctx* c, int first, int n, const ui
     // whatever has been enqueued on the context's stream so far may still read these slots: the copies start behind it
     LP_HIP(hipEventRecord(c->ev_copy_mark, c->stream));
     LP_HIP(hipStreamWaitEvent(c->copy_stream, c->ev_copy_mark, 0));
+    if (c->fe_stream) {                                 // ... and so may the prefetch stream's (extraction of the next frame)
+        LP_HIP(hipEventRecord(c->ev_copy_mark_fe, c->fe_stream));
+        LP_HIP(hipStreamWaitEvent(c->copy_stream, c->ev_copy_mark_fe, 0));
+    }
     const size_t w = (size_t)c->lt.w[0], h = (size_t)c->lt.h[0], pitch = (size_t)c->lt.pitch[0];
     for (int i = 0; i < n; ++i) {
         uint8_t* dst = c->d_pyr + (size_t)(first + i) * c->image_slab;

@@ -2100,7 +2100,7 @@ namespace {
 
 // what a launch chain needs to know: the view array, how many problems it holds and the launch extents (maxima over them)
 struct BaLaunch {
-    const BaView* d_views = nullptr; int count = 0; hipStream_t s = nullptr;
+    const BaView* d_views = nullptr; int count = 0; hipStream_t s = nullptr; lpslam_hip_ctx* ctx = nullptr;
     int obs_blocks = 0, pose_blocks = 0, point_blocks = 0, part_n = 0, n_free = 0, n_blocks = 0, dim = 0, nb = 0, land_blocks = 0;
     int robust = 1, points_fixed = 0;
     bool any_small = false, any_large = false;          // systems for k_chol_wg / for the panel-pair chain
@@ -2129,7 +2129,7 @@ struct BaLaunch {
 BaLaunch single_launch(lpslam_hip_ba* b)
 {
     BaLaunch L;
-    L.d_views = b->d_view; L.s = b->stream; L.robust = b->robust; L.points_fixed = b->points_fixed;
+    L.d_views = b->d_view; L.s = b->stream; L.ctx = b->ctx; L.robust = b->robust; L.points_fixed = b->points_fixed;
     L.add(b);
     // a small reserve (<= 8 CUs of every XCD) cannot hold the pinned chain's workgroups on ONE XCD: spread them over all XCDs then (4 CUs:
     // 4256 against 4145 frames/s pinned); from 12 on the pinned chain is the better one again (12: 4392 against 4336, 16: 4428 against 4357)
@@ -2168,6 +2168,7 @@ int enqueue_solve(const BaLaunch& L, int fused)
             hipLaunchKernelGGL(k_chol_prep, dim3((L.nb * NB + 255) / 256, L.count), dim3(256), 0, s, L.d_views);
         }
         const bool wg = L.count >= cw_min_batch();
+        if (wg && L.any_small && L.ctx) L.ctx->ba_wg_launches.fetch_add(1);
         if (L.marks && !(wg && L.any_small)) {              // profiled run through the panel-pair chain: factorisation and solve timed apart
             enqueue_cholesky(s, L.d_views, L.count, L.nb, 0, L.spread);
             L.mark(LPSLAM_HIP_BA_K_CHOL);
@@ -2609,6 +2610,7 @@ int lpslam_hip_ba_optimize_begin(lpslam_hip_ba* b, int32_t robust, int32_t iters
 }
 
 int64_t lpslam_hip_ba_graph_replays(lpslam_hip_ctx* c) { return c ? (int64_t)c->ba_graph_replays.load() : 0; }
+int64_t lpslam_hip_ba_wg_factorisations(lpslam_hip_ctx* c) { return c ? (int64_t)c->ba_wg_launches.load() : 0; }
 
 int lpslam_hip_ba_optimize_end(lpslam_hip_ba* b, lpslam_hip_ba_iter_log* log, int32_t* done_out)
 {
@@ -2720,7 +2722,7 @@ static int batch_views(lpslam_hip_ba* const* ps, int n, size_t extra_bytes, Batc
     bv->hst = lp_pin_big_alloc(bv->ctx, total, &bv->hcap);
     if (!bv->hst) { set_error("page-locked staging of %zu bytes failed", total); return LPSLAM_HIP_ERR_DEVICE; }
     BaLaunch& L = bv->L;
-    L.d_views = (const BaView*)bv->blk; L.s = ps[0]->stream;
+    L.d_views = (const BaView*)bv->blk; L.s = ps[0]->stream; L.ctx = bv->ctx;
     for (int i = 0; i < n; ++i) { memcpy((uint8_t*)bv->hst + (size_t)i * sizeof(BaView), &ps[i]->h_view, sizeof(BaView)); L.add(ps[i]); }
     LP_HIP(hipMemcpyAsync(bv->blk, bv->hst, view_bytes, hipMemcpyHostToDevice, L.s));
     return LPSLAM_HIP_OK;

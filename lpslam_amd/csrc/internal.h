@@ -70,6 +70,8 @@ struct lpslam_hip_ctx {
     hipEvent_t ev_copy_mark = nullptr;           // main stream -> copy stream: work enqueued before the call may still read the slots
     std::vector<hipEvent_t> ev_copy_pool;        // events of the calls (ring)
     size_t ev_copy_next = 0;
+    hipEvent_t ev_copy_mark_fe = nullptr;        // the same for the prefetch stream when one exists
+    std::mutex copy_mutex;                       // slot_copy_event / the event ring: uploads and extractions may come from different threads
     std::vector<hipEvent_t> slot_copy_event;     // per image slot: event of the upload the main stream has not yet waited for (or nullptr)
     std::vector<std::pair<void*, size_t>> host_allocs;   // lpslam_hip_host_alloc blocks (freed with the context if the caller forgets)
     std::vector<uint8_t*> h_upload;    // per image slot: page-locked staging of the last uploaded frame (uploads are asynchronous)
@@ -97,6 +99,7 @@ struct lpslam_hip_ctx {
     // kernel against 1.7 us inside a graph, 120+ kernels per solve).
     std::map<hipStream_t, void*> ba_view_slot;
     std::map<std::pair<hipStream_t, std::array<int, 16>>, hipGraphExec_t> ba_graphs;      // nullptr = signature seen once
+    std::atomic<long> ba_wg_launches{0};     // k_chol_wg launches so far (lpslam_hip_ba_wg_factorisations: a test sees which factorisation a batch took)
     std::atomic<long> ba_graph_replays{0};   // hipGraphLaunch calls so far (lpslam_hip_ba_graph_replays: lets a test see that it exercised the replay path)
     std::vector<std::pair<size_t, void*>> pin_big;   // idle page-locked staging blocks (capacity, block) of lp_pin_big_alloc / free
     uint8_t* h_match = nullptr;        // pinned host staging of the window matchers (queries in, candidate lists out)

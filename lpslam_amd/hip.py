@@ -36,7 +36,7 @@ SYMBOLS = [
     "lpslam_hip_match_stereo", "lpslam_hip_match_stereo_strided", "lpslam_hip_get_stereo",
     "lpslam_hip_vocab_create", "lpslam_hip_vocab_destroy", "lpslam_hip_vocab_info", "lpslam_hip_bow_transform", "lpslam_hip_bow_transform_host", "lpslam_hip_match_bow_tree",
     "lpslam_hip_match_projection", "lpslam_hip_match_fuse", "lpslam_hip_match_area", "lpslam_hip_match_orientation_filter",
-    "lpslam_hip_ba_create", "lpslam_hip_ba_destroy", "lpslam_hip_ba_set_active", "lpslam_hip_ba_optimize", "lpslam_hip_ba_optimize_begin", "lpslam_hip_ba_optimize_end", "lpslam_hip_ba_graph_replays",
+    "lpslam_hip_ba_create", "lpslam_hip_ba_destroy", "lpslam_hip_ba_set_active", "lpslam_hip_ba_optimize", "lpslam_hip_ba_optimize_begin", "lpslam_hip_ba_optimize_end", "lpslam_hip_ba_graph_replays", "lpslam_hip_ba_wg_factorisations",
     "lpslam_hip_ba_optimize_batch", "lpslam_hip_ba_reset_batch", "lpslam_hip_ba_optimize_profiled", "lpslam_hip_ba_optimize_partitioned", "lpslam_hip_ba_optimize_partitioned_with",
     "lpslam_hip_ba_local", "lpslam_hip_ba_set_points_fixed", "lpslam_hip_ba_pose_optimize", "lpslam_hip_pose_optimize", "lpslam_hip_ba_reset", "lpslam_hip_ba_set_state", "lpslam_hip_prefetch_begin", "lpslam_hip_prefetch_end", "lpslam_hip_prefetch_join", "lpslam_hip_ba_get", "lpslam_hip_ba_chi2", "lpslam_hip_ba_reduced_buffer",
     "lpslam_hip_ba_step_begin", "lpslam_hip_ba_step_lambda0", "lpslam_hip_ba_step_solve", "lpslam_hip_ba_scalar_buffer", "lpslam_hip_ba_step_end", "lpslam_hip_ba_status",
@@ -144,6 +144,11 @@ class Context:
 
     def ba_graph_replays(self):
         f = self.lib.lpslam_hip_ba_graph_replays
+        f.restype = C.c_int64; f.argtypes = [C.c_void_p]
+        return int(f(self.h))
+
+    def ba_wg_factorisations(self):
+        f = self.lib.lpslam_hip_ba_wg_factorisations
         f.restype = C.c_int64; f.argtypes = [C.c_void_p]
         return int(f(self.h))
 
@@ -564,7 +569,7 @@ class RcclComm:
 
 def ba_factor_kernel_name(dim):
     """name of the kernel that factors a reduced system of `dim` unknowns (rule of enqueue_solve in csrc/ba.hip)"""
-    return "k_chol_pair"          # k_chol_wg takes over only in batches of 24 problems and more
+    return "k_chol_pair"          # k_chol_wg takes over only in batches of 40 problems and more
 
 
 def ba_optimize_batch(problems, robust=True, iters=10):

@@ -19,9 +19,14 @@ bool Vocabulary::load(const std::string& path, std::string& error)
     // binary: the second header word is the record size (4 + 32 + 4 + 1); a text file starts with digits and blanks
     uint32_t hdr[6];
     memcpy(hdr, raw.data(), sizeof(hdr));
-    if (hdr[1] == 41 && (size_t)hdr[0] * 41 + 24 <= raw.size()) {
+    // The node count of the header: the DBoW2 lineage writes m_nodes.size(), which counts the ROOT, and then one record for each of
+    // the nodes 1 .. size-1 (the pinned fork's source is absent); files that count only the records (this repo's
+    // round-3 trainer) are read as well.  What decides is the file itself: records = (size - 24) / 41.
+    const size_t records = (raw.size() - 24) / 41;
+    if (hdr[1] == 41 && records > 0 && ((size_t)hdr[0] == records + 1 || (size_t)hdr[0] == records)) {
         k = (int)hdr[2]; L = (int)hdr[3]; scoring = (int)hdr[4]; weighting = (int)hdr[5];
-        const size_t n = hdr[0];
+        if (k < 2 || k > 64 || L < 1 || L > 10) { error = "vocabulary header: branching factor / depth out of range"; return false; }
+        const size_t n = records;
         parent.resize(n); desc.resize(n * 32); weight.resize(n); is_leaf.resize(n);
         const char* p = raw.data() + 24;
         for (size_t i = 0; i < n; ++i, p += 41) {
@@ -52,7 +57,7 @@ bool Vocabulary::save_binary(const std::string& path) const
 {
     std::ofstream f(path, std::ios::binary);
     if (!f) return false;
-    const uint32_t hdr[6] = {(uint32_t)parent.size(), 41u, (uint32_t)k, (uint32_t)L, (uint32_t)scoring, (uint32_t)weighting};
+    const uint32_t hdr[6] = {(uint32_t)parent.size() + 1u /* nodes incl. the root, as DBoW2 counts them */, 41u, (uint32_t)k, (uint32_t)L, (uint32_t)scoring, (uint32_t)weighting};
     f.write((const char*)hdr, sizeof(hdr));
     for (size_t i = 0; i < parent.size(); ++i) {
         const uint32_t par = (uint32_t)parent[i];

@@ -89,6 +89,7 @@ LPS_API int lpslam_manager_add_source(lpslam_c_manager* m, const char* n, const 
 LPS_API void lpslam_manager_set_camera_configuration(lpslam_c_manager* m, const LpSlamCameraConfiguration* c) { m->mgr.setCameraConfiguration(*c); }
 LPS_API void lpslam_manager_default_camera_configuration(LpSlamCameraConfiguration* out) { *out = LpSlamConfiguration().createDefaultCameraConfiguration(); }
 LPS_API void lpslam_manager_on_reconstruction(lpslam_c_manager* m, lpslam_c_reconstruction_cb cb, void* user) { m->cb = cb; m->user = user; m->mgr.addOnReconstructionCallback(c_trampoline, m); }
+LPS_API void lpslam_manager_on_image(lpslam_c_manager* m, OnImageCallback_t cb, void* user) { m->mgr.addOnImageCallback(cb, user); }
 LPS_API void lpslam_manager_request_nav_data(lpslam_c_manager* m, RequestNavDataCallback_t cb, void* user) { m->mgr.addRequestNavDataCallback(cb, user); }
 LPS_API int lpslam_manager_add_stereo_image(lpslam_c_manager* m, uint32_t cam, uint64_t ts, uint8_t* l, uint8_t* r, const LpSlamImageDescription* d) { return m->mgr.addStereoImageFromBuffer(cam, ts, l, r, *d); }
 LPS_API int lpslam_manager_add_image(lpslam_c_manager* m, uint32_t cam, uint64_t ts, uint8_t* b, const LpSlamImageDescription* d) { return m->mgr.addImageFromBuffer(cam, ts, b, *d); }

@@ -221,8 +221,12 @@ bool decode_jpeg_gray(const uint8_t* d, size_t size, GrayImage& out, std::string
                 hmax = std::max(hmax, comp[i].h); vmax = std::max(vmax, comp[i].v);
             }
             if (ncomp == 1) { comp[0].h = comp[0].v = 1; hmax = vmax = 1; }             // a single component is never interleaved
+            // the grey output is component 0's plane as it is coded: a file whose first component is SUBSAMPLED against another one
+            // (luma 1x1 beside chroma 2x2, which no camera or encoder of this code base writes) would need libjpeg's upsampling
+            if (comp[0].h != hmax || comp[0].v != vmax) return fail(why, "first component is subsampled (not supported)");
             const int mcux = (X + 8 * hmax - 1) / (8 * hmax), mcuy = (Y + 8 * vmax - 1) / (8 * vmax);
             plane_w = mcux * comp[0].h * 8; plane_h = mcuy * comp[0].v * 8;
+            if (plane_w < X || plane_h < Y) return fail(why, "frame geometry is inconsistent");
             plane.assign((size_t)plane_w * plane_h, 0);
             have_frame = true;
         } else if (m == 0xC2 || (m >= 0xC5 && m <= 0xCF && m != 0xC8 && m != 0xCC) || m == 0xC3) {
@@ -232,6 +236,7 @@ bool decode_jpeg_gray(const uint8_t* d, size_t size, GrayImage& out, std::string
             restart_interval = u16(pos + 2);
         } else if (m == 0xDA) {                                                        // SOS + entropy-coded data
             if (!have_frame) return fail(why, "scan before the frame header");
+            if (n < 1) return fail(why, "bad scan header");
             const int ns = s[0];
             if (ns < 1 || ns > ncomp || n < 1 + 2 * ns + 3) return fail(why, "bad scan header");
             int idx[4];
@@ -239,6 +244,8 @@ bool decode_jpeg_gray(const uint8_t* d, size_t size, GrayImage& out, std::string
                 int ci = -1;
                 for (int c = 0; c < ncomp; ++c) if (comp[c].id == s[1 + 2 * i]) ci = c;
                 if (ci < 0) return fail(why, "scan names an unknown component");
+                for (int k = 0; k < i; ++k) if (idx[k] == ci) return fail(why, "scan names a component twice");
+                if (ci == 0 && decoded_luma) return fail(why, "second scan of the first component in a sequential file");
                 comp[ci].td = s[2 + 2 * i] >> 4; comp[ci].ta = s[2 + 2 * i] & 15;
                 if (comp[ci].td > 3 || comp[ci].ta > 3 || !dc[comp[ci].td].present || !ac[comp[ci].ta].present || !have_q[comp[ci].tq]) return fail(why, "scan uses a missing table");
                 idx[i] = ci;
@@ -309,6 +316,7 @@ bool decode_jpeg_gray(const uint8_t* d, size_t size, GrayImage& out, std::string
         pos += (size_t)len;
     }
     if (!have_frame || !decoded_luma) return fail(why, "no image data");
+    if (plane_w < X || plane_h < Y || plane.size() < (size_t)plane_w * (size_t)Y) return fail(why, "frame geometry is inconsistent");
     out.width = X; out.height = Y;
     out.pixels.resize((size_t)X * Y);
     for (int y = 0; y < Y; ++y) std::memcpy(&out.pixels[(size_t)y * X], &plane[(size_t)y * plane_w], (size_t)X);

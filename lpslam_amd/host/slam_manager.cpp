@@ -311,6 +311,13 @@ bool SlamManager::workerStep()
     if (m_lookahead) { cam = std::move(*m_lookahead); m_lookahead.reset(); }
     else m_camQueue.pop(cam);
     if (!cam.valid || m_stopRequested.load()) return false;   // exit signal; a stop abandons the backlog (SlamManager::stop)
+    // every frame the worker takes also goes to the image-callback thread (SlamManager.cpp:64-66); a copy: the tracker consumes `cam`
+    if (m_pushToImageCallbackQueue) {
+        CameraQueueEntry copy;
+        copy.valid = true; copy.timestamp = cam.timestamp; copy.cameraNumber = cam.cameraNumber; copy.cameraNumberSecond = cam.cameraNumberSecond;
+        copy.image = cam.image; copy.image_second = cam.image_second;
+        m_imageCallbackQueue.push(std::move(copy));
+    }
     // one frame of lookahead, owned by this thread: if another frame is already queued the trackers learn about it, and may start
     // its upload and extraction on the GPU beside the tracking of this frame
     {
@@ -374,6 +381,41 @@ bool SlamManager::notifyStep()
     return true;
 }
 
+// The image-callback thread (src/Manager/SlamManager.cpp:258-314): every frame the worker took is compressed -- cv::imencode(".jpg",
+// IMWRITE_JPEG_QUALITY 70), the two eyes of a stereo frame side by side in two threads -- and handed to OnImageCallback_t as ONE buffer
+// (left stream, then right stream; desc.imageSize / imageSizeSecond give the split; structure OneImage_Compressed / Stereo_Compressed,
+// format 8UC1_JPEPG, conversion None).  The reference leaves the other members of `desc` uninitialised; here width / height carry the
+// frame's size and the rest is zero.
+bool SlamManager::imageCallbackStep()
+{
+    CameraQueueEntry q;
+    m_imageCallbackQueue.pop(q);
+    if (!q.valid) return false;
+    if (m_onImage == nullptr || q.image.empty()) return true;
+    std::vector<uint8_t> left, right;
+    const int quality = 70;
+    std::thread t_left([&] { encode_jpeg_gray(q.image, quality, left); });
+    if (q.image_second.has_value()) {
+        std::thread t_right([&] { encode_jpeg_gray(*q.image_second, quality, right); });
+        t_right.join();
+    }
+    t_left.join();
+    LpSlamImageDescription desc{};
+    desc.width = (uint32_t)q.image.width; desc.height = (uint32_t)q.image.height;
+    desc.imageSize = (uint32_t)left.size(); desc.imageSizeSecond = 0;
+    desc.image_conversion = LpSlamImageConversion_None;
+    desc.structure = LpSlamImageStructure_OneImage_Compressed;
+    desc.format = LpSlamImageFormat_8UC1_JPEPG;
+    if (q.image_second.has_value()) {
+        desc.imageSizeSecond = (uint32_t)right.size();
+        desc.structure = LpSlamImageStructure_Stereo_Compressed;
+        left.insert(left.end(), right.begin(), right.end());
+    }
+    m_onImage((LpSlamTimestamp)timeStampToInt64(q.timestamp), q.cameraNumber, left.data(), desc, m_onImageData);
+    ++m_imagesSent;
+    return true;
+}
+
 void SlamManager::start()
 {
     if (m_running) return;
@@ -383,8 +425,13 @@ void SlamManager::start()
     }
     m_running = true;
     m_stopRequested.store(false);
+    // the reference arms the image queue with `m_onRecoCallback != nullptr` (the WorkerThreadParams initialiser, SlamManager.cpp:532-548,
+    // puts that expression into pushToImageCallbackQueue) and its thread calls the image callback when that one is set: images reach a
+    // client that has set BOTH callbacks.  Same condition here, without queueing frames nobody will be handed.
+    m_pushToImageCallbackQueue = m_onReconstruction != nullptr && m_onImage != nullptr;
     m_worker = std::thread([this] { while (workerStep()) {} });
     m_notifyWorker = std::thread([this] { while (notifyStep()) {} });
+    m_imageCallbackWorker = std::thread([this] { while (imageCallbackStep()) {} });
 }
 
 void SlamManager::stop()
@@ -402,6 +449,10 @@ void SlamManager::stop()
     ResultQueueEntry rp; rp.exitSignal = true;
     m_resultQueue.push(rp);
     if (m_notifyWorker.joinable()) m_notifyWorker.join();
+    CameraQueueEntry ip; ip.valid = false;              // SlamManager.cpp:586-589: frames already handed to the image thread are still sent
+    m_imageCallbackQueue.push(std::move(ip));
+    if (m_imageCallbackWorker.joinable()) m_imageCallbackWorker.join();
+    m_imageCallbackQueue.clear();
     for (auto& t : m_trackers) t->stop();
     m_running = false;
 }

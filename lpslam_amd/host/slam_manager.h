@@ -48,24 +48,28 @@ public:
     CameraRegistry& cameraRegistry() { return m_camRegistry; }
     uint64_t framesProcessed() const { return m_framesProcessed.load(); }
     uint64_t framesSkipped() const { return m_framesSkipped.load(); }
+    uint64_t imagesSent() const { return m_imagesSent.load(); }
 
 private:
     void streamMoreReplayItems();
     bool workerStep();
     bool notifyStep();
+    bool imageCallbackStep();
 
     CameraRegistry m_camRegistry;
     CameraQueue m_camQueue;
     SensorQueue m_sensorQueue;
     ResultQueue m_resultQueue;
+    CameraQueue m_imageCallbackQueue;    // frames on their way to OnImageCallback_t (reference SlamManager.h:183)
     std::vector<std::unique_ptr<TrackerBase>> m_trackers;
     std::vector<std::unique_ptr<ProcessorBase>> m_processors;
     HipVslamTrackerBase* m_vslamTracker = nullptr;
-    std::thread m_worker, m_notifyWorker;
+    std::thread m_worker, m_notifyWorker, m_imageCallbackWorker;
+    bool m_pushToImageCallbackQueue = false;      // fixed at start(), as the reference copies its thread parameters there
     bool m_running = false;
     bool m_requireOdometry = true;       // reference behaviour: frames without odometry are skipped (SlamManager.cpp:193-196)
     int m_thread_num = -1;
-    std::atomic<uint64_t> m_framesProcessed{0}, m_framesSkipped{0};
+    std::atomic<uint64_t> m_framesProcessed{0}, m_framesSkipped{0}, m_imagesSent{0};
     std::atomic<double> m_currentFps{0.0};
     std::atomic<bool> m_stopRequested{false};
     std::optional<CameraQueueEntry> m_lookahead;       // worker thread only: the frame after the one being processed

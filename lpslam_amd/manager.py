@@ -49,6 +49,7 @@ class FeatureEntry(C.Structure):
 
 
 RECON_CB = C.CFUNCTYPE(None, C.POINTER(GlobalStateInTime), C.c_void_p)
+IMAGE_CB = C.CFUNCTYPE(None, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint8), ImageDescription, C.c_void_p)
 NAV_CB = C.CFUNCTYPE(C.c_int, ROSTimestamp, C.POINTER(GlobalStateInTime), C.POINTER(GlobalStateInTime), C.c_void_p)
 
 STEREO_TWO_BUFFER, FORMAT_8UC1, FORMAT_8UC3, NO_DISTORTION, ODOM_ONLY = 3, 1, 2, 3, 1
@@ -74,6 +75,7 @@ def load():
         _lib.lpslam_manager_set_camera_configuration.argtypes = [C.c_void_p, C.POINTER(CameraConfiguration)]
         _lib.lpslam_manager_default_camera_configuration.argtypes = [C.POINTER(CameraConfiguration)]
         _lib.lpslam_manager_on_reconstruction.argtypes = [C.c_void_p, RECON_CB, C.c_void_p]
+        _lib.lpslam_manager_on_image.argtypes = [C.c_void_p, IMAGE_CB, C.c_void_p]
         _lib.lpslam_manager_request_nav_data.argtypes = [C.c_void_p, NAV_CB, C.c_void_p]
         _lib.lpslam_manager_add_stereo_image.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p, C.POINTER(ImageDescription)]
         _lib.lpslam_manager_add_image.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.POINTER(ImageDescription)]
@@ -147,6 +149,18 @@ class Manager:
                                      q=(s.state.orientation.w, s.state.orientation.x, s.state.orientation.y, s.state.orientation.z)))
         f = RECON_CB(cb); self._keep.append(f)
         self.lib.lpslam_manager_on_reconstruction(self.h, f, None)
+
+    def collect_images(self):
+        """LpSlamManager::addOnImageCallback: every frame the worker takes comes back as JPEG (quality 70) on the image thread;
+        self.images gets (timestamp, camera, structure, format, left stream, right stream or None)"""
+        self.images = []
+
+        def cb(ts, cam, buf, desc, _):
+            n0, n1 = int(desc.imageSize), int(desc.imageSizeSecond)
+            raw = C.string_at(buf, n0 + n1)
+            self.images.append((int(ts), int(cam), int(desc.structure), int(desc.format), raw[:n0], raw[n0:] if n1 else None))
+        f = IMAGE_CB(cb); self._keep.append(f)
+        self.lib.lpslam_manager_on_image(self.h, f, None)
 
     def provide_odometry(self):
         def cb(ts, odom, mp, _):

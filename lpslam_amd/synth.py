@@ -221,12 +221,20 @@ def _small_rot(w):
 
 
 def ba_problem(n_kf=50, n_points=5000, n_obs=40000, width=1280, height=720, seq_id=0,
-               kf_stride=6, pose_noise=(0.01, 0.05), point_noise=0.05, pix_noise=1.0):
+               kf_stride=6, pose_noise=(0.01, 0.05), point_noise=0.05, pix_noise=1.0, tracks="random", top_up=False):
     """Bundle-adjustment problem of SURVEY.md section 8(d) config 3 / 5.
 
     Returns dict with ground-truth and perturbed poses (n_kf x 7: qw qx qy qz tx ty tz, world->camera),
     points (n x 3), observations (pose, point, u, v, ur, inv_sigma2), `fixed` flags (first KF fixed)
     and the camera dict.  Stereo observations throughout; octave drawn to give sigma^2 = 1.2^(2*level).
+
+    `tracks`: which of the keyframes that see a landmark keep their observation when there are more than the cap
+    (ceil(n_obs / n_points)).  "random": a random subset -- every landmark couples keyframes all over the window and the reduced
+    system is dense (the stress case, and the round-1..3 workload).  "contiguous": a run of consecutive visible keyframes starting
+    at a random one -- what a tracker produces (a landmark is followed from its first sighting until it is lost), giving a
+    block-banded reduced system ("track length capped"; the reference solves it with CSparse, row a21).
+    `top_up`: tracks of cap + 1 keyframes for as many landmarks as it takes to reach n_obs (the cap alone ends ~3 % short of
+    config 3's 40 000 +- 2 %, because landmarks near the window's ends are seen by fewer keyframes than the cap).
     """
     rng = np.random.Generator(np.random.PCG64([SEED_BASE + int(seq_id), 3]))
     k = intrinsics(width, height)
@@ -250,15 +258,39 @@ def ba_problem(n_kf=50, n_points=5000, n_obs=40000, width=1280, height=720, seq_
     if len(good) < n_points:
         raise RuntimeError("not enough visible landmarks: %d" % len(good))
     good = good[:n_points]
+    if tracks not in ("random", "contiguous"):
+        raise ValueError("tracks must be 'random' or 'contiguous'")
     cap = max(min_views, int(math.ceil(n_obs / n_points)))
-    obs = []
+    picked = []
     for pi, ci in enumerate(good):
         kfs = np.nonzero(vis[ci])[0]
         if len(kfs) > cap:
-            kfs = np.sort(rng.choice(kfs, cap, replace=False))
-        for f in kfs:
-            obs.append((f, pi, ci))
-    obs = np.array(obs)
+            if tracks == "random":
+                kfs_sel = np.sort(rng.choice(kfs, cap, replace=False))
+            else:
+                start = int(rng.integers(0, len(kfs) - cap + 1))
+                kfs_sel = kfs[start:start + cap]
+        else:
+            kfs_sel = kfs
+        picked.append((kfs, kfs_sel))
+    if top_up:
+        # its own generator: the draws above and below are those of the problem without the top-up
+        rng2 = np.random.Generator(np.random.PCG64([SEED_BASE + int(seq_id), 5]))
+        missing = n_obs - sum(len(sel) for _, sel in picked)
+        for pi in rng2.permutation(len(picked)):
+            if missing <= 0:
+                break
+            kfs, sel = picked[pi]
+            if len(sel) < cap or len(kfs) <= len(sel):
+                continue
+            if tracks == "random":
+                extra = rng2.choice(np.setdiff1d(kfs, sel))
+            else:                       # the run grows by one keyframe, at the end where there is one
+                at = int(np.searchsorted(kfs, sel[-1]))
+                extra = kfs[at + 1] if at + 1 < len(kfs) else kfs[int(np.searchsorted(kfs, sel[0])) - 1]
+            picked[pi] = (kfs, np.sort(np.append(sel, extra)))
+            missing -= 1
+    obs = np.array([(f, pi, good[pi]) for pi, (_, sel) in enumerate(picked) for f in sel])
     if len(obs) > n_obs:     # trim observations of the longest tracks but keep >= 3 per landmark
         counts = np.bincount(obs[:, 1], minlength=n_points)
         order = rng.permutation(len(obs))

@@ -50,3 +50,19 @@ def test_product_does_not_reference_the_oracle():
 def test_keypoint_layout_matches_cv_keypoint(hiplib):
     assert hiplib.KP_DTYPE.itemsize == 28 and hiplib.KP_DTYPE.names == ("x", "y", "size", "angle", "response", "octave", "class_id")
     assert hiplib.BA_OBS_DTYPE.itemsize == 40
+
+
+def test_reference_header_client_links():
+    """tests/golden/abi_symbols.txt holds the mangled names a client compiled against the REFERENCE's own interface headers
+    (src/Interface/LpSlamManager.h:17-121, LpSlamConfiguration.h) leaves undefined -- made by tools/make_abi_symbols.py in the
+    build container, where the same client is also linked and loaded against the product library.  Every one of them must be a
+    defined dynamic symbol of lpslam_amd/liblpslam.so: that is what "existing clients relink unchanged" means."""
+    import subprocess
+    from lpslam_amd import _build
+    lib = _build.host_library()
+    want = [l.strip() for l in open(os.path.join(ROOT, "tests", "golden", "abi_symbols.txt")) if l.strip()]
+    assert len(want) == 37 and sum("LpSlamManager" in s for s in want) == 36
+    out = subprocess.check_output(["nm", "-D", "--defined-only", lib], text=True)
+    have = {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
+    missing = [s for s in want if s not in have]
+    assert not missing, missing

@@ -314,21 +314,25 @@ def test_structure_built_on_the_device_handles_any_observation_order(hiplib, ora
 
 
 def test_large_batch_through_the_single_workgroup_factorisation(hiplib, oracle):
-    """From 24 problems on, the reduced systems that fit one compute unit (dim + 1 <= 304) are factored and solved by one
-    workgroup each (k_chol_wg: lower triangle in registers, panels in LDS).  Sizes cover one panel (dim 6), an odd tile-row count,
+    """From 40 problems on (CW_MIN_BATCH, ba.hip), the reduced systems that fit one compute unit (dim + 1 <= 304) are factored and
+    solved by one workgroup each (k_chol_wg: lower triangle in registers, panels in LDS); `ba_wg_factorisations` proves that this
+    batch went that way and that a batch below the threshold does not.  Sizes cover one panel (dim 6), an odd tile-row count,
     several panels and the full local window (dim 294); a system too large for it (dim 324) rides in the same batch through
     the panel-pair chain.  Every problem follows the oracle; against its single-problem solve it agrees within rounding."""
     c = hiplib.Context(640, 480, 500, 1.2, 4, max_images=1)
     shapes = [(2, 20, 40), (3, 40, 100), (5, 80, 320), (8, 300, 1800), (12, 600, 4000), (20, 800, 5000), (33, 900, 6000), (50, 2500, 16000), (55, 1500, 9000)]
     probs = []
-    for i in range(26):
+    for i in range(44):
         kf, pts, obs = shapes[i % len(shapes)]
         kw = dict(pose_noise=(0.5, 3.0), point_noise=3.0) if i == 3 else {}
         probs.append(synth.ba_problem(kf, pts, obs, 640, 480, seq_id=100 + i, **kw))
     iters = 6
     make = lambda pr: hiplib.BundleAdjuster(c, pr["poses"], pr["fixed"], pr["points"], hiplib.ba_obs_array(pr), pr["cam"])
     batch = [make(pr) for pr in probs]
+    assert c.ba_wg_factorisations() == 0
     logs = hiplib.ba_optimize_batch(batch, True, iters)
+    wg_launches = c.ba_wg_factorisations()
+    assert wg_launches >= iters, "a batch of %d problems was meant to go through k_chol_wg" % len(batch)
     for i, (pr, b, lg) in enumerate(zip(probs, batch, logs)):
         gp, gx = b.state()
         if i < 12:              # the oracle on one problem of every shape (and the one with rejected trials)
@@ -342,8 +346,16 @@ def test_large_batch_through_the_single_workgroup_factorisation(hiplib, oracle):
         assert len(wl) == len(lg) and np.allclose(wl["chi2_after"], lg["chi2_after"], rtol=1e-10) and np.array_equal(wl["trials"], lg["trials"])
         assert np.abs(wp - gp).max() < 1e-8 and np.abs(wx - gx).max() < 1e-8
         one.close()
+    assert c.ba_wg_factorisations() == wg_launches, "single problems go through the panel-pair chain"
     # determinism of the batched path: a second round gives the same bytes
     hiplib.ba_reset_batch(batch)
     logs2 = hiplib.ba_optimize_batch(batch, True, iters)
     assert all(a.tobytes() == b2.tobytes() for a, b2 in zip(logs, logs2))
+    assert c.ba_wg_factorisations() >= 2 * iters
+    # a batch below the threshold takes the chain: same results as the single solves, bit for bit
+    small = batch[:20]
+    hiplib.ba_reset_batch(small)
+    before = c.ba_wg_factorisations()
+    hiplib.ba_optimize_batch(small, True, iters)
+    assert c.ba_wg_factorisations() == before
     c.close()

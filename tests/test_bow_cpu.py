@@ -3,6 +3,7 @@ reader (binary and text layouts of DBoW2) and its BoW vector / L1 score against 
 BowVector, L1Scoring (shinsumicco/DBoW2 @ e8cc74d); the reference refuses to start without a vocabulary
 (src/Trackers/OpenVSLAMTrackerBase.cpp:224-227)."""
 import ctypes as C
+import struct
 
 import numpy as np
 import pytest
@@ -82,6 +83,19 @@ def test_host_reads_binary_and_text_vocabularies(hostlib, tmp_path):
     r2, k2, L2, parent2, desc2, weight2, leaf2 = _load(hostlib, txt)
     assert r2 == r and (k2, L2) == (10, 3) and np.array_equal(parent2, parent) and np.array_equal(desc2, desc) and np.array_equal(leaf2, leaf)
     assert np.allclose(weight2, weight, rtol=1e-7)
+    # the header's node count: DBoW2 counts the root (records + 1), the fixture's trainer did not -- both are read, anything else is not
+    raw = bytearray(open(VOCAB, "rb").read())
+    n_rec = (len(raw) - 24) // 41
+    assert struct.unpack_from("<I", raw, 0)[0] == n_rec
+    for count, ok in ((n_rec + 1, True), (n_rec, True), (n_rec + 2, False), (n_rec - 1, False)):
+        struct.pack_into("<I", raw, 0, count)
+        f2 = tmp_path / ("count_%d.dbow2" % count)
+        f2.write_bytes(bytes(raw))
+        r3 = _load(hostlib, f2)
+        assert (r3[0] == r and np.array_equal(r3[3], parent) and np.array_equal(r3[4], desc)) if ok else r3[0] == -1, count
+    struct.pack_into("<I", raw, 0, n_rec + 1); struct.pack_into("<I", raw, 8, 1)    # k = 1: refused by the header check
+    f3 = tmp_path / "k1.dbow2"; f3.write_bytes(bytes(raw))
+    assert _load(hostlib, f3)[0] == -1
     bad = tmp_path / "bad.bin"
     bad.write_bytes(b"\x00" * 100)
     assert _load(hostlib, bad)[0] == -1 and _load(hostlib, tmp_path / "missing")[0] == -1

@@ -267,7 +267,7 @@ def test_mapping_reserve_changes_speed_only(hiplib):
         b.close()
         return [tuple(l) for l in log], poses, points
     base, base_ba = run(), solve()
-    for r in (4, 8, 0):
+    for r in (4, 8, 12, 16, 0):
         ctx.set_mapping_reserve(r)
         got, got_ba = run(), solve()
         for (k0, d0), (k1, d1) in zip(base, got):
@@ -275,3 +275,41 @@ def test_mapping_reserve_changes_speed_only(hiplib):
         assert got_ba[0] == base_ba[0] and np.array_equal(got_ba[1], base_ba[1]) and np.array_equal(got_ba[2], base_ba[2])
     with pytest.raises(hip.LpslamHipError):
         ctx.set_mapping_reserve(17)
+    ctx.close()
+
+
+def test_mapping_reserve_at_the_benchmarked_shape(hiplib):
+    """The configuration `bench.py` quotes its value on: 1280x720, 2000 keypoints, 8 levels, 32 images per extraction launch, the
+    front end confined to half of the chip (reserve 16; 12 is the other setting DESIGN.md quotes), a full local window (50 keyframes /
+    5000 landmarks / 40 k observations, 10 iterations) solved on the same context.  Bit for bit the results of the unreserved chip."""
+    from lpslam_amd import hip
+    w, h, n = 1280, 720, 32
+    ctx = hip.Context(w, h, 2000, 1.2, 8, max_images=n)
+    seq = synth.StereoSequence(w, h, 0)
+    imgs = [seq.frame(i)[e] for i in range(n // 2) for e in range(2)]
+    for i, im in enumerate(imgs):
+        ctx.upload(i, im)
+    p = synth.ba_problem(50, 5000, 40000, w, h, seq_id=0)
+
+    def run():
+        ctx.extract_range(0, n)
+        for i in range(0, n, 2):
+            ctx.match_stereo(i, i + 1, synth.intrinsics(w, h)["fxb"], synth.intrinsics(w, h)["baseline"])
+        kd = [ctx.keypoints(i) for i in range(n)]
+        st = [ctx.stereo(i) for i in range(0, n, 2)]
+        b = hip.BundleAdjuster(ctx, p["poses"], p["fixed"], p["points"], hip.ba_obs_array(p), p["cam"])
+        log = b.optimize(True, 10)
+        poses, points = b.state()
+        b.close()
+        return kd, st, [tuple(l) for l in log], poses, points
+    base = run()
+    assert all(len(k) > 1500 for k, _ in base[0])
+    for r in (16, 12, 0):
+        ctx.set_mapping_reserve(r)
+        got = run()
+        for (k0, d0), (k1, d1) in zip(base[0], got[0]):
+            assert np.array_equal(k0, k1) and np.array_equal(d0, d1), r
+        for s0, s1 in zip(base[1], got[1]):
+            assert all(np.array_equal(a, b) for a, b in zip(s0, s1)), r
+        assert got[2] == base[2] and np.array_equal(got[3], base[3]) and np.array_equal(got[4], base[4]), r
+    ctx.close()

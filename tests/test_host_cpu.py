@@ -108,6 +108,49 @@ def test_frames_without_odometry_are_skipped_and_reported(mgrlib):
     assert m.status().localization == 0          # Off
 
 
+def test_image_callback_receives_every_frame_as_jpeg(mgrlib):
+    """OnImageCallback_t (src/Interface/LpSlamTypes.h:233-235; image-callback thread src/Manager/SlamManager.cpp:258-314): every frame
+    the worker takes is sent to the client as JPEG of quality 70 -- one buffer, left stream then right stream, desc.imageSize /
+    imageSizeSecond the split, structure Stereo_Compressed (one image: OneImage_Compressed), format 8UC1_JPEPG -- on its own thread.
+    The reference arms that queue only when the reconstruction callback is set as well (WorkerThreadParams, SlamManager.cpp:532-548).
+    The streams are what libjpeg writes for the frame (Pillow where present), and decode back to it.  Runs without a GPU."""
+    from lpslam_amd import synth
+    frame = synth.StereoSequence(320, 240, 4, n_points=2000).frame(0)
+    left, right = np.ascontiguousarray(frame[0]), np.ascontiguousarray(frame[1])
+    m = mgrlib.Manager()
+    m.collect_results(); m.collect_images()
+    m.start()
+    assert m.add_stereo(1000, left, right)
+    assert m.add_image(2000, left, camera=3)
+    t0 = time.time()
+    while len(m.images) < 2 and time.time() - t0 < 10:
+        time.sleep(0.01)
+    m.stop()
+    assert len(m.images) == 2
+    (ts0, cam0, st0, fmt0, l0, r0), (ts1, cam1, st1, fmt1, l1, r1) = m.images
+    assert (ts0, cam0, st0, fmt0) == (1000, 0, 5, 0) and (ts1, cam1, st1, fmt1, r1) == (2000, 3, 4, 0, None)
+    assert l0 == l1 and l0[:2] == b"\xff\xd8" and l0[-2:] == b"\xff\xd9" and r0[:2] == b"\xff\xd8" and r0 != l0
+    try:
+        import io
+        from PIL import Image
+        for img, ours in ((left, l0), (right, r0)):
+            buf = io.BytesIO()
+            Image.fromarray(img).save(buf, "JPEG", quality=70)
+            assert buf.getvalue() == ours
+            back = np.asarray(Image.open(io.BytesIO(ours)))
+            assert back.shape == img.shape and np.abs(back.astype(int) - img.astype(int)).mean() < 12
+    except ImportError:
+        pass
+    # without the reconstruction callback nothing is queued (the reference's condition); frames are still consumed
+    m2 = mgrlib.Manager()
+    m2.collect_images()
+    m2.start()
+    assert m2.add_stereo(1000, left, right)
+    time.sleep(0.3)
+    m2.stop()
+    assert m2.images == []
+
+
 def test_compressed_frames_are_decoded_at_ingest(mgrlib):
     """LpSlamImageFormat_8UC1_JPEPG frames (src/Manager/SlamManager.cpp:1139-1146: cv::imdecode, IMREAD_GRAYSCALE): the manager decodes
     baseline JPEG itself (host/jpeg.cpp) and queues the grey image; what is not a decodable stream is refused like any unsupported

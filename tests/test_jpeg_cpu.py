@@ -53,6 +53,46 @@ def test_unsupported_and_damaged_streams_are_refused(lib):
         assert _decode(lib, bad)[0] in (0, 1, 2)                                # (1: the damaged header asks for more than the test's buffer)
 
 
+def _segments(data):
+    """(marker, offset of the FF, offset behind the segment) of the header segments up to and including SOS"""
+    out, pos = [], 2
+    raw = bytes(data)
+    while pos + 4 <= len(raw):
+        assert raw[pos] == 0xFF
+        m, ln = raw[pos + 1], (raw[pos + 2] << 8) | raw[pos + 3]
+        out.append((m, pos, pos + 2 + ln))
+        if m == 0xDA:
+            break
+        pos += 2 + ln
+    return out
+
+
+def test_crafted_streams_stay_inside_their_buffers(lib):
+    """Streams an attacker of the ingest path (addImageFromBuffer, replay records) could hand in.  (i) luma 1x1 beside chroma 2x2: the
+    plane of component 0 is a quarter of the frame -- refused (it used to be copied as if it were full size: a heap over-read,
+    ADVICE round 3); (ii) a buffer that ends inside the SOS header; (iii) a second scan of component 0; (iv) a scan that names a
+    component twice.  All refused with a stated error; run under tools/asan_cpu.sh with the sanitizers."""
+    g = golden("g17_jpeg.npz")
+    col = g["jpeg_colour_420_97x61_q75"].copy()
+    sof = [x for x in _segments(col) if x[0] == 0xC0][0]
+    comps = sof[1] + 10                                   # FF C0 len(2) P Y(2) X(2) Nf, then (id, hv, tq) x 3
+    assert col[comps + 1] == 0x22 and col[comps + 4] == 0x11 and col[comps + 7] == 0x11
+    bad = col.copy(); bad[comps + 1] = 0x11; bad[comps + 4] = 0x22; bad[comps + 7] = 0x22
+    assert _decode(lib, bad)[0] == 2
+    bad = col.copy(); bad[comps + 1] = 0x21                # luma 2x1 beside ... vmax 1? (chroma 1x1): still h = hmax, v = vmax -> decodes or errors, no crash
+    assert _decode(lib, bad)[0] in (0, 2)
+    grey = g["jpeg_grey_ramp_123x77_q70"]
+    sos = [x for x in _segments(grey) if x[0] == 0xDA][0]
+    cut = np.concatenate([grey[:sos[1] + 2], np.array([0, 2], np.uint8)])          # FF DA 00 02 and nothing behind it
+    assert _decode(lib, cut)[0] == 2
+    assert _decode(lib, grey[:sos[1] + 3])[0] == 2
+    twice = np.concatenate([grey[:-2], grey[sos[1]:]])                              # ... scan, scan again, EOI
+    assert _decode(lib, twice)[0] == 2
+    csos = [x for x in _segments(col) if x[0] == 0xDA][0]
+    dup = col.copy(); dup[csos[1] + 7] = dup[csos[1] + 5]                            # second scan component = the first one's id
+    assert _decode(lib, dup)[0] == 2
+
+
 def test_pillow_agrees_when_present(lib):
     """the fixtures again, decoded now by the Pillow of this machine (skipped where there is none)"""
     PIL = pytest.importorskip("PIL.Image")
