@@ -234,6 +234,19 @@ int64_t lpslam_hip_ba_graph_replays(lpslam_hip_ctx* ctx);
 /* How many launches of the one-workgroup factorisation (k_chol_wg: batches of LPSLAM_HIP_CW_MIN_BATCH = 40 problems and more) this
  * context has enqueued.  Test hook: proves which of the two factorisations a batch went through.  No reference counterpart. */
 int64_t lpslam_hip_ba_wg_factorisations(lpslam_hip_ctx* ctx);
+/* Which linear solver a problem takes.  DENSE: Schur complement by pair lists, dense panel-pair Cholesky (any window).  BAND: when
+ * no landmark of the window spans more than 10 free keyframes the reduced system is block-banded -- the shape a tracker's windows have,
+ * and why the reference's local bundle adjuster solves with g2o's LinearSolverCSparse (SURVEY.md a21;
+ * conan-packages/g2o-conan/conanfile.py:117-124) -- and the problem takes the landmark-group Schur complement on the FP64 matrix
+ * cores and a band Cholesky in one workgroup (chosen at creation; LPSLAM_HIP_BA_SOLVER=dense in the environment keeps every problem
+ * dense).  get_solver reports the solver in use and the block half-bandwidth found at creation (-1: not banded); set_solver
+ * switches (BAND on a window that is not banded: LPSLAM_HIP_ERR_INVALID).  Both give the same optimum; their sums differ in order
+ * (chi2 agrees to ~1e-12 relative).  The partitioned solve always works on the dense buffer. */
+#define LPSLAM_HIP_BA_SOLVER_AUTO 0
+#define LPSLAM_HIP_BA_SOLVER_DENSE 1
+#define LPSLAM_HIP_BA_SOLVER_BAND 2
+int lpslam_hip_ba_get_solver(lpslam_hip_ba* ba, int32_t* solver, int32_t* block_half_bandwidth);
+int lpslam_hip_ba_set_solver(lpslam_hip_ba* ba, int32_t solver);
 /* Batched solve -- north star: "a batched Levenberg-Marquardt local-BA".  n independent problems (the keyframe windows of
  * several SLAM sessions served by one GPU, [UPSTREAM] mapping_module::run of each session; lpslam reaches it through
  * feed_stereo_frame, src/Trackers/OpenVSLAMStereoTracker.cpp:293-295) are advanced by ONE launch chain: every kernel runs once

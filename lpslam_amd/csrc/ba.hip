@@ -105,6 +105,10 @@ struct BaView {                       // one problem, resident in device memory 
     GPTR(double) blk_part; GPTR(int) blk_ticket;                  // Schur partial sums [block][4][36], per-block tickets
     GPTR(BaCtl) ctl; GPTR(lpslam_hip_ba_iter_log) log;
     BaCam cam;
+    // block-banded windows (ba_band.inl): block half-bandwidth of the reduced system when the problem takes the band path (-1: pair
+    // lists + dense chain), landmark groups, [group records | first / last candidate group per free slot], entry table, group partials
+    int band_hbw, band_groups, band_groups_cap, band_pad_;
+    GPTR(const int) band_tab; GPTR(const int) band_ent; GPTR(double) band_part;
 };
 
 // The view of problem blockIdx.y.  `views` is const __restrict__ and read before any store of the kernel: scalar loads.
@@ -853,7 +857,7 @@ __global__ __launch_bounds__(64) void k_ba_schur(const BaView* __restrict__ view
 {
     BA_VIEW_XCD(v, bx);
     const int n_work = 4 * v.n_blocks;                     // work item = (block pair, part): see below
-    if (bx >= n_work + v.n_free) return;
+    if (bx >= n_work + v.n_free || v.band_hbw >= 0) return;      // banded windows: k_schur_group / k_schur_band_reduce (ba_band.inl)
     const BaFlags fl = ba_flags(v.ctl);
     if (fl.idle()) return;
     const double lambda = fl.lambda;
@@ -1232,12 +1236,12 @@ __global__ __launch_bounds__(256) void k_chol_pair(const BaView* __restrict__ vi
     // is first used, and the prologue becomes a chain of dependent round trips (measured: 3 us of an 18 us launch went into ten
     // of them -- arguments, sizes, control block, pointers, four passes of block loads).
     const BaView& vw = views[blockIdx.y];
-    const int dim = vw.dim, n = vw.dim_pad;
+    const int dim = vw.dim, n = vw.dim_pad, band = vw.band_hbw;
     GPTR(double) S = vw.S; GPTR(double) M = vw.Minv; GPTR(double) Ldiag = vw.Ldiag; GPTR(double) Lsub = vw.Lsub; GPTR(double) scal = vw.scal;
     GPTR(BaCtl) ctl = vw.ctl;
-    asm volatile("" :: "s"(dim), "s"(n), "s"(S), "s"(M), "s"(Ldiag), "s"(Lsub), "s"(scal), "s"(ctl));
+    asm volatile("" :: "s"(dim), "s"(n), "s"(S), "s"(M), "s"(Ldiag), "s"(Lsub), "s"(scal), "s"(ctl), "s"(band));
     const int nb = n / NB;
-    if (2 * m >= nb || dim == 0 || (skip_small && cw_fits(dim))) return;   // a batch runs the panel pairs of its largest system; small systems may be k_chol_wg's
+    if (2 * m >= nb || dim == 0 || band >= 0 || (skip_small && cw_fits(dim))) return;   // a batch runs the panel pairs of its largest system; small systems may be k_chol_wg's
     const int bid = pin ? blockIdx.x >> 3 : blockIdx.x;
     {
         const int ncol0 = (2 * m + 1 < nb) ? 2 : 1, T0 = nb - 2 * m - ncol0;
@@ -1483,8 +1487,8 @@ __global__ __launch_bounds__(256) void k_chol_xsolve(const BaView* __restrict__ 
 {
     if (pin && (blockIdx.x & 7)) return;  // XCD 0 only, like k_chol_pair: its inputs sit in that L2
     BA_VIEW(v);
-    BA_VIEW_HEAD("s"(v.dim), "s"(v.dim_pad), "s"(v.ctl), "s"(v.S), "s"(v.Ldiag), "s"(v.Lsub), "s"(v.Minv), "s"(v.xp));
-    if (ba_flags(v.ctl).idle() || (skip_small && cw_fits(v.dim))) return;
+    BA_VIEW_HEAD("s"(v.dim), "s"(v.dim_pad), "s"(v.ctl), "s"(v.S), "s"(v.Ldiag), "s"(v.Lsub), "s"(v.Minv), "s"(v.xp), "s"(v.band_hbw));
+    if (v.band_hbw >= 0 || ba_flags(v.ctl).idle() || (skip_small && cw_fits(v.dim))) return;
     const int lane = threadIdx.x & 63;
     const int i = (pin ? blockIdx.x >> 3 : blockIdx.x) * 4 + (threadIdx.x >> 6);
     if (i >= v.dim) return;
@@ -1510,6 +1514,7 @@ void enqueue_xsolve(hipStream_t s, const BaView* d_views, int count, int dim, in
 }
 
 #include "ba_solve.inl"
+#include "ba_band.inl"
 
 // factorisation + solve of `count` reduced systems.  `wg`: the systems that fit one compute unit go to k_chol_wg (one workgroup
 // each, one launch), the others through the panel-pair chain and k_chol_xsolve (each kernel skips the problems of the other
@@ -2094,6 +2099,8 @@ struct lpslam_hip_ba {
     hipEvent_t xfer_in_read = nullptr; bool xfer_in_pending = false;      // the kernel that reads the "in" half has been enqueued
     int robust = 1, points_fixed = 0;
     int pending_iters = -1;                            // >= 0 between optimize_begin and optimize_end
+    int band_hbw_structure = -1;                       // block half-bandwidth of the window when the band path can take it (creation), else -1
+    int band_gmax = 0;                                 // landmarks per group at most (LDS of k_schur_group)
 };
 
 namespace {
@@ -2104,6 +2111,8 @@ struct BaLaunch {
     int obs_blocks = 0, pose_blocks = 0, point_blocks = 0, part_n = 0, n_free = 0, n_blocks = 0, dim = 0, nb = 0, land_blocks = 0;
     int robust = 1, points_fixed = 0;
     bool any_small = false, any_large = false;          // systems for k_chol_wg / for the panel-pair chain
+    bool any_band = false, any_dense = false;           // banded windows (ba_band.inl) / pair lists + dense factorisation
+    int band_groups = 0, band_blocks = 0, band_gmax = 0; // extents of k_schur_group / k_schur_band_reduce, landmarks per group
     bool spread = false;                                // the context reserves CUs of every XCD for the solves: no XCD pinning
     // profiled run (lpslam_hip_ba_optimize_profiled): an event after every launch, tagged with the kernel it closes
     std::vector<std::pair<hipEvent_t, int>>* marks = nullptr;
@@ -2120,9 +2129,17 @@ struct BaLaunch {
         const BaView& v = b->h_view;
         obs_blocks = std::max(obs_blocks, v.obs_blocks); pose_blocks = std::max(pose_blocks, v.pose_blocks);
         point_blocks = std::max(point_blocks, v.point_blocks); part_n = std::max(part_n, v.part_n); land_blocks = std::max(land_blocks, v.land_blocks);
-        n_free = std::max(n_free, v.n_free); n_blocks = std::max(n_blocks, v.n_blocks); dim = std::max(dim, v.dim);
-        nb = std::max(nb, v.dim_pad / NB);
-        if (v.dim > 0) { if (cw_fits(v.dim)) any_small = true; else any_large = true; }
+        n_free = std::max(n_free, v.n_free);
+        if (v.band_hbw >= 0) {
+            any_band = true;
+            band_groups = std::max(band_groups, v.band_groups); band_blocks = std::max(band_blocks, v.n_free * (v.band_hbw + 2));
+            band_gmax = std::max(band_gmax, b->band_gmax);
+        } else {
+            if (v.n_free) any_dense = true;
+            n_blocks = std::max(n_blocks, v.n_blocks); dim = std::max(dim, v.dim);
+            nb = std::max(nb, v.dim_pad / NB);
+            if (v.dim > 0) { if (cw_fits(v.dim)) any_small = true; else any_large = true; }
+        }
         ++count;
     }
 };
@@ -2153,7 +2170,13 @@ int enqueue_linearize(const BaLaunch& L, int fused, bool explicit_lin = true)
 // Schur complement for the device's current lambda into the reduced buffer
 int enqueue_reduce(const BaLaunch& L, int fused)
 {
-    if (L.n_free) { hipLaunchKernelGGL(k_ba_schur, dim3(4 * L.n_blocks + L.n_free, L.count), dim3(64), 0, L.s, L.d_views, fused); L.mark(LPSLAM_HIP_BA_K_SCHUR); }
+    if (L.any_dense) hipLaunchKernelGGL(k_ba_schur, dim3(4 * L.n_blocks + L.n_free, L.count), dim3(64), 0, L.s, L.d_views, fused);
+    if (L.any_band) {
+        bd_set_attributes();
+        hipLaunchKernelGGL(k_schur_group, dim3(L.band_groups, L.count), dim3(256), bd_lds_bytes(L.band_gmax), L.s, L.d_views);
+        hipLaunchKernelGGL(k_schur_band_reduce, dim3(L.band_blocks, L.count), dim3(64), 0, L.s, L.d_views, fused);
+    }
+    if (L.any_dense || L.any_band) L.mark(LPSLAM_HIP_BA_K_SCHUR);
     LP_HIP(hipGetLastError());
     return LPSLAM_HIP_OK;
 }
@@ -2162,6 +2185,11 @@ int enqueue_reduce(const BaLaunch& L, int fused)
 int enqueue_solve(const BaLaunch& L, int fused)
 {
     hipStream_t s = L.s;
+    if (L.any_band) {
+        bd_set_attributes();
+        hipLaunchKernelGGL(k_chol_band, dim3(1, L.count), dim3(256), BC_LDS_BYTES, s, L.d_views);
+        if (!L.any_dense) L.mark(LPSLAM_HIP_BA_K_CHOL);
+    }
     if (L.dim > 0) {
         if (!fused) {
             hipLaunchKernelGGL(k_lm_begin, dim3(1, L.count), dim3(64), 0, s, L.d_views);
@@ -2305,6 +2333,59 @@ int begin_optimize(lpslam_hip_ba* b, int robust, int iters)
     return LPSLAM_HIP_OK;
 }
 
+// Host-side plan of the band path (ba_band.inl), made at creation from the caller's observation list.
+struct BandPlan {
+    int hbw = -1;                               // block half-bandwidth; -1: the window does not qualify
+    std::vector<int> order, qinfo, bstart;      // landmarks with free observations by (first slot, id); (f0 << 8 | index in group); entry offsets
+    std::vector<int> groups, glo, ghi;          // BD_REC ints per group; per free slot: first / last group that can touch it
+    void build(const lpslam_hip_ba_obs* obs, int n_obs, int n_points, const int* slot, int n_free, int dim, const int* deg, int gmax)
+    {
+        if (n_free < 1 || n_obs < 1 || !bc_fits(dim)) return;
+        std::vector<int> fmin((size_t)n_points, INT32_MAX), fmax((size_t)n_points, -1);
+        for (int k = 0; k < n_obs; ++k) {
+            const int sl = slot[obs[k].pose], j = obs[k].point;
+            if (sl < 0) continue;
+            fmin[j] = std::min(fmin[j], sl); fmax[j] = std::max(fmax[j], sl);
+        }
+        int h = 0;
+        std::vector<int> first_count((size_t)n_free + 1, 0);
+        for (int j = 0; j < n_points; ++j) if (fmax[j] >= 0) { h = std::max(h, fmax[j] - fmin[j]); first_count[(size_t)fmin[j] + 1]++; }
+        if (h > BD_MAXHBW) return;
+        for (int i = 0; i < n_free; ++i) first_count[(size_t)i + 1] += first_count[(size_t)i];
+        order.resize((size_t)first_count[(size_t)n_free]);
+        {
+            std::vector<int> at(first_count.begin(), first_count.end() - 1);
+            for (int j = 0; j < n_points; ++j) if (fmax[j] >= 0) order[(size_t)at[(size_t)fmin[j]]++] = j;      // counting sort: ties stay in landmark order
+        }
+        const int n_ord = (int)order.size();
+        qinfo.resize((size_t)n_ord); bstart.resize((size_t)n_ord + 1);
+        int e = 0;
+        for (int q = 0; q < n_ord;) {
+            const int f0 = fmin[order[(size_t)q]];
+            int last = f0, cnt = 0, e0 = e;
+            while (q + cnt < n_ord && cnt < gmax) {
+                const int j = order[(size_t)(q + cnt)];
+                const int l2 = std::max(last, fmax[j]);
+                if (l2 - f0 + 1 > BD_MAXKF) break;
+                last = l2;
+                qinfo[(size_t)(q + cnt)] = (f0 << 8) | cnt; bstart[(size_t)(q + cnt)] = e;
+                e += deg[j]; ++cnt;
+            }
+            const int rec[BD_REC] = {e0, e, f0, cnt, 6 * (last - f0 + 1), 0, 0, 0};
+            groups.insert(groups.end(), rec, rec + BD_REC);
+            q += cnt;
+        }
+        bstart[(size_t)n_ord] = e;
+        // a group touches slots f0 .. f0 + rows / 6 - 1; groups are sorted by f0, so the candidates of a block (i, k), k <= i, are those
+        // with f0 > i - BD_MAXKF (first: glo[i]) and f0 <= k (last: ghi[k]); the kernel tests the cover itself
+        const int n_grp = (int)groups.size() / BD_REC;
+        glo.assign((size_t)n_free, n_grp); ghi.assign((size_t)n_free, -1);
+        for (int i = 0, g = 0; i < n_free; ++i) { while (g < n_grp && groups[(size_t)BD_REC * g + 2] <= i - BD_MAXKF) ++g; glo[(size_t)i] = g; }
+        for (int i = 0, g = -1; i < n_free; ++i) { while (g + 1 < n_grp && groups[(size_t)BD_REC * (g + 1) + 2] <= i) ++g; ghi[(size_t)i] = g; }
+        hbw = h;
+    }
+};
+
 struct Carve {
     size_t off = 0;
     size_t take(size_t bytes) { const size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; }
@@ -2351,6 +2432,18 @@ int lpslam_hip_ba_create(lpslam_hip_ctx* ctx, const double* poses, const uint8_t
     b->h_ur.resize((size_t)n_obs);
     for (int k = 0; k < n_obs; ++k) b->h_ur[k] = obs[k].ur;   // caller order (host-side outlier thresholds)
 
+    // ---- shape of the window (ba_band.inl): first / last FREE keyframe slot of every landmark.  When no landmark spans more than
+    //      BD_MAXHBW slots the reduced system is block-banded and the problem takes the band path: landmarks ordered by their first
+    //      slot, cut into groups of <= band_gmax whose observations fall into <= BD_MAXKF neighbouring keyframes.
+    BandPlan plan;
+    {
+        static const int solver_env = [] { const char* e = getenv("LPSLAM_HIP_BA_SOLVER"); return !e ? 0 : (!strcmp(e, "dense") ? 1 : 0); }();
+        static const int group_env = [] { const char* e = getenv("LPSLAM_HIP_BA_GROUP"); const int g = e ? atoi(e) : 0; return g >= 4 && g <= BD_GMAX ? g : 32; }();
+        if (solver_env != 1) plan.build(obs, n_obs, n_points, slot.data(), b->n_free, b->dim, deg.data(), group_env);
+        b->band_hbw_structure = plan.hbw;
+        b->band_gmax = plan.hbw >= 0 ? group_env : 0;
+    }
+
     // ---- one block: [view | inputs as staged | zero-initialised part | the rest]
     const size_t np = (size_t)n_poses, npt = (size_t)std::max(n_points, 1), no = (size_t)std::max(n_obs, 1), n = (size_t)b->dim_pad;
     const size_t nblk = (size_t)std::max(b->n_blocks, 1), nfree = (size_t)std::max(b->n_free, 1);
@@ -2360,6 +2453,8 @@ int lpslam_hip_ba_create(lpslam_hip_ctx* ctx, const double* poses, const uint8_t
     const size_t o_view = cv.take(sizeof(BaView));
     const size_t o_poses0 = cv.take(7 * np * 8), o_points0 = cv.take(3 * npt * 8), o_slot = cv.take(np * 4), o_free = cv.take(nfree * 4);
     const size_t o_obs_in = cv.take(no * sizeof(lpslam_hip_ba_obs));
+    const size_t n_ord = plan.order.size(), n_grp = plan.groups.size() / BD_REC;
+    const size_t o_band_tab = cv.take((BD_REC * n_grp + 2 * nfree) * 4), o_band_order = cv.take(n_ord * 4), o_band_qinfo = cv.take(n_ord * 4), o_band_bstart = cv.take((n_ord + 1) * 4);
     const size_t staged_bytes = cv.off;
     const size_t z_begin = cv.off;
     const size_t o_A = cv.take(np * npt * 4), o_ptcount = cv.take(npt * 4);
@@ -2379,6 +2474,7 @@ int lpslam_hip_ba_create(lpslam_hip_ctx* ctx, const double* poses, const uint8_t
     const size_t o_chiobs = cv.take(no * 8), o_depth = cv.take(no);
     const size_t o_blk_count = cv.take(nblk * 4), o_blk_start = cv.take((nblk + 1) * 4), o_blk_part = cv.take(nblk * 4 * 36 * 8);
     const size_t o_terms = cv.take(std::max<size_t>(terms_cap, 1) * sizeof(int4));
+    const size_t o_band_ent = cv.take(plan.hbw >= 0 ? no * sizeof(int4) : 0), o_band_part = cv.take(n_grp * BD_PART * 8);
     {
         const int rc = lp_pool_alloc(ctx, cv.off, &b->block, &b->block_cap);
         if (rc) { lpslam_hip_ba_destroy(b); return rc; }
@@ -2422,6 +2518,8 @@ int lpslam_hip_ba_create(lpslam_hip_ctx* ctx, const double* poses, const uint8_t
     b->d_ctl = (BaCtl*)(base + o_ctl); b->d_log = (lpslam_hip_ba_iter_log*)(base + o_log);
     vset(v.ctl, b->d_ctl); vset(v.log, b->d_log);
     v.cam = BaCam{cam->fx, cam->fy, cam->cx, cam->cy, cam->focal_x_baseline, cam->huber_mono, cam->huber_stereo};
+    v.band_hbw = plan.hbw; v.band_groups = (int)n_grp; v.band_groups_cap = (int)n_grp;
+    vset(v.band_tab, (const int*)(base + o_band_tab)); vset(v.band_ent, (const int*)(base + o_band_ent)); vset(v.band_part, (double*)(base + o_band_part));
     b->d_view = (BaView*)(base + o_view);
     b->d_chi_obs = (double*)(base + o_chiobs); b->d_depth = base + o_depth;
     // ---- inputs through one page-locked staging block, one copy
@@ -2434,6 +2532,13 @@ int lpslam_hip_ba_create(lpslam_hip_ctx* ctx, const double* poses, const uint8_t
     memcpy(hs + o_slot, slot.data(), np * 4);
     if (b->n_free) memcpy(hs + o_free, free_pose.data(), (size_t)b->n_free * 4);
     if (n_obs) memcpy(hs + o_obs_in, obs, (size_t)n_obs * sizeof(lpslam_hip_ba_obs));
+    if (plan.hbw >= 0) {
+        memcpy(hs + o_band_tab, plan.groups.data(), plan.groups.size() * 4);
+        memcpy(hs + o_band_tab + BD_REC * n_grp * 4, plan.glo.data(), plan.glo.size() * 4);
+        memcpy(hs + o_band_tab + (BD_REC * n_grp + nfree) * 4, plan.ghi.data(), plan.ghi.size() * 4);
+        memcpy(hs + o_band_order, plan.order.data(), n_ord * 4); memcpy(hs + o_band_qinfo, plan.qinfo.data(), n_ord * 4);
+        memcpy(hs + o_band_bstart, plan.bstart.data(), (n_ord + 1) * 4);
+    }
     hipStream_t s = b->stream;
     // the inputs come over PCIe by a KERNEL that reads the page-locked staging block, not by the DMA engine: a copy packet queues
     // behind whatever the engine is busy with -- the front end's image uploads (0.9 ms per 16-frame step) held the next window's
@@ -2466,6 +2571,10 @@ int lpslam_hip_ba_create(lpslam_hip_ctx* ctx, const double* poses, const uint8_t
         hipLaunchKernelGGL(k_bs_pairfill, dim3((b->n_blocks + 3) / 4), dim3(256), 0, s, A, R, n_points, b->n_free, b->n_blocks, (const int*)(base + o_free), ps_start,
                            (const int*)(base + o_opoint), (const int*)(base + o_blk_start), (int4*)(base + o_terms));
     } else BA_HIP(hipMemsetAsync(base + o_blk_start, 0, 2 * 4, s));
+    if (plan.hbw >= 0 && n_ord)
+        hipLaunchKernelGGL(k_bd_entries, dim3((unsigned)((n_ord + 255) / 256)), dim3(256), 0, s, (const int*)(base + o_band_order), (const int*)(base + o_band_qinfo),
+                           (const int*)(base + o_band_bstart), (int)n_ord, pt_start, (const int*)(base + o_pt_obs), (const int*)(base + o_opose), (const int*)(base + o_slot),
+                           (int4*)(base + o_band_ent));
     // state buffers <- the inputs, control block cleared
     {
         const long n_max = std::max<long>(std::max<long>(7L * n_poses, 3L * n_points), n_obs);
@@ -2558,8 +2667,10 @@ int lpslam_hip_ba_optimize_begin(lpslam_hip_ba* b, int32_t robust, int32_t iters
         BaLaunch L = single_launch(b);
         auto up = [](int x, int m) { return (x + m - 1) / m * m; };
         L.obs_blocks = up(L.obs_blocks, 8); L.pose_blocks = up(L.pose_blocks, 4); L.point_blocks = up(L.point_blocks, 4); L.part_n = up(L.part_n, 8); L.land_blocks = up(L.land_blocks, 8);
-        const std::array<int, 16> sig = {units, robust ? 1 : 0, b->points_fixed ? 1 : 0, L.obs_blocks, L.pose_blocks, L.point_blocks, L.part_n, L.n_free,
-                                         L.n_blocks, L.dim, L.nb, L.any_small ? 1 : 0, L.any_large ? 1 : 0, L.land_blocks, L.spread ? 1 : 0, 0};
+        L.band_groups = up(L.band_groups, 8); L.band_blocks = up(L.band_blocks, 8);
+        const std::array<int, 20> sig = {units, robust ? 1 : 0, b->points_fixed ? 1 : 0, L.obs_blocks, L.pose_blocks, L.point_blocks, L.part_n, L.n_free,
+                                         L.n_blocks, L.dim, L.nb, L.any_small ? 1 : 0, L.any_large ? 1 : 0, L.land_blocks, L.spread ? 1 : 0,
+                                         L.any_band ? 1 : 0, L.any_dense ? 1 : 0, L.band_groups, L.band_blocks, L.band_gmax};
         lpslam_hip_ctx* c = b->ctx;
         hipGraphExec_t exec = nullptr;
         void* slot = nullptr;
@@ -2800,11 +2911,43 @@ int lpslam_hip_ba_optimize_batch(lpslam_hip_ba* const* ps, int32_t n, int32_t ro
 //                              chi2 and [2] = landmark scale term: SUM all-reduce ([3], the pose term, is identical on all ranks)
 //   lpslam_hip_ba_step_end   : accept / reject; reports the control state
 // Every phase ends with a stream synchronise so the caller's collective may touch the buffers right away.
+int lpslam_hip_ba_get_solver(lpslam_hip_ba* b, int32_t* solver, int32_t* block_half_bandwidth)
+{
+    if (!b) { set_error("null problem"); return LPSLAM_HIP_ERR_INVALID; }
+    if (solver) *solver = b->h_view.band_hbw >= 0 ? LPSLAM_HIP_BA_SOLVER_BAND : LPSLAM_HIP_BA_SOLVER_DENSE;
+    if (block_half_bandwidth) *block_half_bandwidth = b->band_hbw_structure;
+    return LPSLAM_HIP_OK;
+}
+
+int lpslam_hip_ba_set_solver(lpslam_hip_ba* b, int32_t solver)
+{
+    if (!b) { set_error("null problem"); return LPSLAM_HIP_ERR_INVALID; }
+    if (b->pending_iters >= 0) { set_error("set_solver between optimize_begin and optimize_end"); return LPSLAM_HIP_ERR_INVALID; }
+    int want = solver == LPSLAM_HIP_BA_SOLVER_DENSE ? -1 : b->band_hbw_structure;
+    if (solver == LPSLAM_HIP_BA_SOLVER_BAND && b->band_hbw_structure < 0) { set_error("the window is not block-banded (a landmark spans more than %d free keyframes, or the system exceeds %d unknowns)", BD_MAXHBW + 1, 16 * BC_MAXS); return LPSLAM_HIP_ERR_INVALID; }
+    if (want == b->h_view.band_hbw) return LPSLAM_HIP_OK;
+    LP_HIP(hipSetDevice(b->ctx->cfg.device));
+    LP_HIP(hipStreamSynchronize(b->stream));
+    release_stage(b);
+    b->h_view.band_hbw = want;
+    LP_HIP(hipMemcpy(&b->d_view->band_hbw, &b->h_view.band_hbw, sizeof(int), hipMemcpyHostToDevice));
+    // the other solver's leftovers in S (factor entries outside the band / inside it) must not be taken for matrix entries
+    const size_t n = (size_t)b->dim_pad;
+    LP_HIP(hipMemsetAsync(b->d_red, 0, n * n * sizeof(double), b->stream));
+    if (b->dim_pad > b->dim + 1) hipLaunchKernelGGL(k_bs_identity, dim3((b->dim_pad - b->dim - 1 + 255) / 256), dim3(256), 0, b->stream, b->d_red, b->dim, b->dim_pad);
+    LP_HIP(hipStreamSynchronize(b->stream));
+    return LPSLAM_HIP_OK;
+}
+
+// the partitioned (all-reduced) solve works on the dense reduced buffer
+static int ensure_dense(lpslam_hip_ba* b) { return b->h_view.band_hbw >= 0 ? lpslam_hip_ba_set_solver(b, LPSLAM_HIP_BA_SOLVER_DENSE) : LPSLAM_HIP_OK; }
+
 int lpslam_hip_ba_step_begin(lpslam_hip_ba* b, int32_t robust, int32_t first)
 {
     if (!b) { set_error("null problem"); return LPSLAM_HIP_ERR_INVALID; }
     LP_HIP(hipSetDevice(b->ctx->cfg.device));
     int rc;
+    if ((rc = ensure_dense(b))) return rc;
     if (first) { if ((rc = begin_optimize(b, robust, MAX_LOG))) return rc; }
     b->robust = robust;
     // lambda is needed by the Schur complement but lambda_0 depends on all-reduced diagonals: on the very first trial the
@@ -3135,6 +3278,7 @@ extern "C" int lpslam_hip_ba_optimize_partitioned_with(lpslam_hip_ba* b, lpslam_
     if (b->pending_iters >= 0) { set_error("optimize_begin pending"); return LPSLAM_HIP_ERR_INVALID; }
     auto allreduce = [&](double* buf, size_t count, int op) -> int { return allreduce_cb(user, buf, count, op, (void*)b->stream); };      // in place, on the problem's stream
     LP_HIP(hipSetDevice(b->ctx->cfg.device));
+    { const int rd = ensure_dense(b); if (rd) return rd; }      // every rank all-reduces the dense reduced buffer, whatever the window's shape
     hipStream_t s = b->stream;
     const size_t n = (size_t)b->dim_pad, tri = (size_t)b->dim * (b->dim + 1) / 2, packed_n = tri + 3 * n + 8;
     void* pk = nullptr; size_t pk_cap = 0;

@@ -90,7 +90,7 @@ __device__ __forceinline__ void cw_trsm(int q, int T, int wave, const double* X,
 __global__ __launch_bounds__(CW_THREADS) void k_chol_wg(const BaView* __restrict__ views)
 {
     BA_VIEW(v);
-    if (!cw_fits(v.dim)) return;                         // larger systems go through the panel-pair chain
+    if (!cw_fits(v.dim) || v.band_hbw >= 0) return;      // larger systems go through the panel-pair chain, banded ones through k_chol_band
     if (ba_idle(v.ctl)) return;
     extern __shared__ __attribute__((aligned(16))) double cw_lds[];
     double* const X = cw_lds;                            // raw strips of the panel being factored (19)

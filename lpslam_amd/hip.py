@@ -36,7 +36,7 @@ SYMBOLS = [
     "lpslam_hip_match_stereo", "lpslam_hip_match_stereo_strided", "lpslam_hip_get_stereo",
     "lpslam_hip_vocab_create", "lpslam_hip_vocab_destroy", "lpslam_hip_vocab_info", "lpslam_hip_bow_transform", "lpslam_hip_bow_transform_host", "lpslam_hip_match_bow_tree",
     "lpslam_hip_match_projection", "lpslam_hip_match_fuse", "lpslam_hip_match_area", "lpslam_hip_match_orientation_filter",
-    "lpslam_hip_ba_create", "lpslam_hip_ba_destroy", "lpslam_hip_ba_set_active", "lpslam_hip_ba_optimize", "lpslam_hip_ba_optimize_begin", "lpslam_hip_ba_optimize_end", "lpslam_hip_ba_graph_replays", "lpslam_hip_ba_wg_factorisations",
+    "lpslam_hip_ba_create", "lpslam_hip_ba_destroy", "lpslam_hip_ba_set_active", "lpslam_hip_ba_optimize", "lpslam_hip_ba_optimize_begin", "lpslam_hip_ba_optimize_end", "lpslam_hip_ba_graph_replays", "lpslam_hip_ba_wg_factorisations", "lpslam_hip_ba_get_solver", "lpslam_hip_ba_set_solver",
     "lpslam_hip_ba_optimize_batch", "lpslam_hip_ba_reset_batch", "lpslam_hip_ba_optimize_profiled", "lpslam_hip_ba_optimize_partitioned", "lpslam_hip_ba_optimize_partitioned_with",
     "lpslam_hip_ba_local", "lpslam_hip_ba_set_points_fixed", "lpslam_hip_ba_pose_optimize", "lpslam_hip_pose_optimize", "lpslam_hip_ba_reset", "lpslam_hip_ba_set_state", "lpslam_hip_prefetch_begin", "lpslam_hip_prefetch_end", "lpslam_hip_prefetch_join", "lpslam_hip_ba_get", "lpslam_hip_ba_chi2", "lpslam_hip_ba_reduced_buffer",
     "lpslam_hip_ba_step_begin", "lpslam_hip_ba_step_lambda0", "lpslam_hip_ba_step_solve", "lpslam_hip_ba_scalar_buffer", "lpslam_hip_ba_step_end", "lpslam_hip_ba_status",
@@ -369,6 +369,15 @@ class BundleAdjuster:
             self.h = None
 
     __del__ = close
+
+    def solver(self):
+        """('band' | 'dense', block half-bandwidth found at creation or -1)"""
+        sv, hb = C.c_int32(), C.c_int32()
+        _check(self.lib.lpslam_hip_ba_get_solver(self.h, C.byref(sv), C.byref(hb)))
+        return ("band" if sv.value == 2 else "dense"), hb.value
+
+    def set_solver(self, name):
+        _check(self.lib.lpslam_hip_ba_set_solver(self.h, {"auto": 0, "dense": 1, "band": 2}[name]))
 
     def set_active(self, active=None):
         a = np.ascontiguousarray(active, np.uint8) if active is not None else None
