@@ -80,10 +80,20 @@ class Workload:
         self.frame_counter = 0          # frames fed so far (front-end thread)
         self.kf_counter = 0             # keyframes solved so far (BA thread)
         if with_ba:
-            self.probs = [synth.ba_problem(BA_KF, BA_PTS, BA_OBS, W, H, seq_id * BA_VARIANTS + v) for v in range(BA_VARIANTS)]
-            self.obs = [hip.ba_obs_array(p) for p in self.probs]
-            self.n_obs = int(np.mean([len(o) for o in self.obs]))
+            # two kinds of window (synth.ba_problem): "random" -- every landmark keeps a random 8-9 of the ~50 keyframes that see it, the
+            # reduced system is dense: the stress case and the headline of rounds 1-3 -- and "contiguous" -- a landmark is seen by a run
+            # of neighbouring keyframes, as a tracker produces them: block-banded reduced system, the band path (ba_band.inl).
+            # Both at SURVEY 8(d) config 3's size: 50 KF / 5000 landmarks / 40 000 +- 2 % observations (top_up).
+            self.prob_sets = {t: [synth.ba_problem(BA_KF, BA_PTS, BA_OBS, W, H, seq_id * BA_VARIANTS + v, tracks=t, top_up=True) for v in range(BA_VARIANTS)]
+                              for t in ("random", "contiguous")}
+            self.obs_sets = {t: [hip.ba_obs_array(p) for p in ps] for t, ps in self.prob_sets.items()}
+            self.set_tracks("random")
         self.ctx.sync()
+
+    def set_tracks(self, kind):
+        self.tracks = kind
+        self.probs, self.obs = self.prob_sets[kind], self.obs_sets[kind]
+        self.n_obs = int(np.mean([len(o) for o in self.obs]))
 
     # ---- front end: one launch sequence for the F frames of step `s` (ring position)
     def front_end(self, s):
@@ -212,13 +222,19 @@ class Workload:
         }
 
 
-def ba_flops(prob, dim):
-    """linearise ~520 FLOP/obs, Schur sum_j(216 n_j^2 + 108 n_j + 50), Cholesky dim^3/3, back-sub + chi2 ~150 FLOP/obs"""
+def ba_flops(prob, dim, block_half_bandwidth=-1):
+    """linearise ~520 FLOP/obs, Schur sum_j(216 n_j^2 + 108 n_j + 50), Cholesky dim^3/3, back-sub + chi2 ~150 FLOP/obs.
+    A block-banded system (half-bandwidth hb = 6 w + 5 scalars): band Cholesky n (hb^2 + 3 hb) + the two substitutions 4 n hb."""
     n_obs = len(prob["obs_pose"])
     nj = np.bincount(prob["obs_point"], minlength=len(prob["points"])).astype(np.float64)
     schur = float((216 * nj * nj + 108 * nj + 50).sum())
     n = dim + 1                      # the rhs rides along as one more row
-    return {"linearise": 520.0 * n_obs, "schur": schur, "cholesky": n ** 3 / 3.0 + 2.0 * n * n, "backsub": 150.0 * n_obs}
+    if block_half_bandwidth >= 0:
+        hb = 6.0 * block_half_bandwidth + 5.0
+        chol = dim * (hb * hb + 3.0 * hb) + 4.0 * dim * hb
+    else:
+        chol = n ** 3 / 3.0 + 2.0 * n * n
+    return {"linearise": 520.0 * n_obs, "schur": schur, "cholesky": chol, "backsub": 150.0 * n_obs}
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------
@@ -406,6 +422,19 @@ def main():
     if dist is not None:
         elapsed_pcie = float(sync_tensor([elapsed_pcie], dist.ReduceOp.MAX).item())
     n_kf_timed = sum(wl.keyframes_of_step(s) for s in range(args.warmup, args.warmup + args.steps)) if wl.with_ba else 0
+    # the same K steps with the keyframes' windows as a tracker makes them (contiguous tracks: block-banded reduced system, band path)
+    elapsed_contig = None
+    if wl.with_ba:
+        wl.set_tracks("contiguous")
+        wl.run_steps(max(args.warmup - 2, 0), min(2, args.warmup))
+        barrier()
+        t0 = time.perf_counter()
+        wl.run_steps(args.warmup, args.steps)
+        elapsed_contig = time.perf_counter() - t0
+        barrier()
+        if dist is not None:
+            elapsed_contig = float(sync_tensor([elapsed_contig], dist.ReduceOp.MAX).item())
+        wl.set_tracks("random")
 
     out = None
     if rank == 0:
@@ -418,26 +447,30 @@ def main():
             wl.ctx.sync(); wl.ctx.set_mapping_reserve(0)
             fe_ms_free = np.mean([wl.front_end_timed() for _ in range(n_inst)], axis=0)
             wl.ctx.sync(); wl.ctx.set_mapping_reserve(MAPPING_RESERVE)
-        ba_prof, ba_setup_ms, ba_total_ms, ba_iters_done, ba_dim, ba_pipe_ms = None, None, None, 0, 0, None
-        if wl.with_ba:
-            # set-up alone: create until the structure is ready on the device (a state read synchronises)
+        def profile_ba():
+            """set-up alone, HIP-event time per kernel of a solve, a keyframe's solve unpipelined and in the mapping pipeline (current track kind)"""
             ts = []
-            for v in range(6):
+            for v in range(6):      # set-up alone: create until the structure is ready on the device (a state read synchronises)
                 t1 = time.perf_counter(); b = wl.new_problem(v); b.state(); ts.append(1e3 * (time.perf_counter() - t1)); b.close()
-            ba_setup_ms = float(np.median(ts[1:]))
-            acc = {}
+            setup_ms = float(np.median(ts[1:]))
+            acc, iters_done, dim, solver = {}, 0, 0, None
             for v in range(n_inst):
                 b = wl.new_problem(v)
-                prof, ba_iters_done, ba_dim = b.optimize_profiled(True, BA_ITERS)
+                solver = b.solver()
+                prof, iters_done, dim = b.optimize_profiled(True, BA_ITERS)
                 b.close()
                 for name, (ms, marks, per) in prof.items():
                     a = acc.setdefault(name, [0.0, 0, per]); a[0] += ms; a[1] += marks
-            ba_prof = {n: {"ms_per_solve": a[0] / n_inst, "marks_per_solve": a[1] / n_inst, "launches_per_mark": a[2]} for n, a in acc.items()}
+            prof = {n: {"ms_per_solve": a[0] / n_inst, "marks_per_solve": a[1] / n_inst, "launches_per_mark": a[2]} for n, a in acc.items()}
             ts = []
             for v in range(n_inst):
                 t1 = time.perf_counter(); wl.bundle_adjust_fresh(); ts.append(1e3 * (time.perf_counter() - t1))
-            ba_total_ms = float(np.median(ts))
-            t1 = time.perf_counter(); wl.bundle_adjust_pipelined(8); ba_pipe_ms = 1e3 * (time.perf_counter() - t1) / 8
+            total_ms = float(np.median(ts))
+            t1 = time.perf_counter(); wl.bundle_adjust_pipelined(8); pipe_ms = 1e3 * (time.perf_counter() - t1) / 8
+            return prof, setup_ms, total_ms, iters_done, dim, pipe_ms, solver
+        ba_prof, ba_setup_ms, ba_total_ms, ba_iters_done, ba_dim, ba_pipe_ms, ba_solver = None, None, None, 0, 0, None, None
+        if wl.with_ba:
+            ba_prof, ba_setup_ms, ba_total_ms, ba_iters_done, ba_dim, ba_pipe_ms, ba_solver = profile_ba()
 
         # ---- GPU time per step by kernel: the dominant one gets the roofline
         kf_per_step = n_kf_timed / max(args.steps, 1)
@@ -455,7 +488,7 @@ def main():
             avg_ms = d["ms_per_solve"] / max(launches, 1)
             fl_per_launch = flops["cholesky"] * d["marks_per_solve"] / max(launches, 1)
             ach = fl_per_launch / (avg_ms * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": hip.ba_factor_kernel_name(ba_dim), "launches_per_step": round(launches * kf_per_step, 2),
+            roof = {"bound": "mfma", "kernel": hip.ba_factor_kernel_name(ba_dim, ba_solver is not None and ba_solver[0] == "band"), "launches_per_step": round(launches * kf_per_step, 2),
                     "achieved": round(ach, 4), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / FP64_PEAK_TFLOPS, 6),
                     "algorithmic_flops_per_launch": int(fl_per_launch), "algorithmic_bytes_per_launch": int(8 * (ba_dim + 1) ** 2 * d["marks_per_solve"] / max(launches, 1)),
                     "avg_launch_us": round(1e3 * avg_ms, 3), "traffic": None,
@@ -547,6 +580,31 @@ def main():
             it_ms = sum(d["ms_per_solve"] for d in ba_prof.values()) / max(ba_iters_done, 1)
             out["ba_roofline"] = {"flop_per_iteration": int(tot), "ms_per_iteration": round(it_ms, 4), "achieved_TFLOPs": round(tot / (it_ms * 1e-3) / 1e12, 4),
                                   "frac_of_fp64_peak": round(tot / (it_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, 5)}
+        out["config"]["ba_tracks"] = "random (dense reduced system; pair lists + panel-pair chain)"
+        if wl.with_ba and elapsed_contig is not None:
+            # the same workload with windows as a tracker makes them: contiguous tracks, block-banded reduced system (ba_band.inl)
+            wl.set_tracks("contiguous")
+            c_prof, c_setup, c_total, c_iters, c_dim, c_pipe, c_solver = profile_ba()
+            c_flops = ba_flops(wl.probs[0], c_dim, c_solver[1] if c_solver[0] == "band" else -1)
+            c_it_ms = sum(d["ms_per_solve"] for d in c_prof.values()) / max(c_iters, 1)
+            c_tot = sum(c_flops.values())
+            dchol = c_prof["chol"]
+            chol_us = 1e3 * dchol["ms_per_solve"] / max(dchol["marks_per_solve"] * dchol["launches_per_mark"], 1)
+            out["value_contiguous"] = round(frames_total / elapsed_contig, 2)
+            out["contiguous"] = {
+                "frames_per_s": round(frames_total / elapsed_contig, 2), "ms_per_step": round(1e3 * elapsed_contig / args.steps, 4),
+                "observations": wl.n_obs, "solver": c_solver[0], "block_half_bandwidth": c_solver[1],
+                "ba_ms_per_iter": round(c_it_ms, 4), "ba_setup_ms": round(c_setup, 4), "ba_ms_per_keyframe": round(c_total, 4), "ba_ms_per_keyframe_pipelined": round(c_pipe, 4),
+                "ba_kernel_us_per_iteration": {("k_chol_factor" if n == "chol" else n): round(1e3 * d["ms_per_solve"] / max(c_iters, 1), 2) for n, d in c_prof.items()},
+                "ba_roofline": {"flop_per_iteration": int(c_tot), "achieved_TFLOPs": round(c_tot / (c_it_ms * 1e-3) / 1e12, 4), "frac_of_fp64_peak": round(c_tot / (c_it_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, 5)},
+                "factor_roofline": {"bound": "mfma", "kernel": hip.ba_factor_kernel_name(c_dim, c_solver[0] == "band"), "avg_launch_us": round(chol_us, 3),
+                                    "algorithmic_flops_per_launch": int(c_flops["cholesky"]), "achieved": round(c_flops["cholesky"] / (chol_us * 1e-6) / 1e12, 5), "peak": FP64_PEAK_TFLOPS,
+                                    "unit": "TFLOP/s", "frac": round(c_flops["cholesky"] / (chol_us * 1e-6) / 1e12 / FP64_PEAK_TFLOPS, 6),
+                                    "note": "band Cholesky + both substitutions of the %d x %d system, half-bandwidth %d, ONE workgroup: a serial chain of %d 16-column strips (latency bound)"
+                                            % (c_dim, c_dim, 6 * max(c_solver[1], 0) + 5, (c_dim + 15) // 16)},
+                "note": "windows with contiguous tracks (synth.ba_problem tracks='contiguous'): landmark-group Schur complement on the FP64 matrix cores + band Cholesky; "
+                        "`value` above is the random-track workload of rounds 1-3"}
+            wl.set_tracks("random")
 
     # ---- extras, outside the timed region; the scaling runs (N > 1) print the timed line only
     if rank == 0 and not args.no_extras and world == 1:
@@ -611,26 +669,28 @@ def main():
                         fe_ctx.match_bf_strided(2, 0, 2, n - 1)
                         done += n
                     fe_ctx.sync()
-                session_round(0); fe_round()
-                t2 = time.perf_counter()
-                th = threading.Thread(target=lambda: [session_round(r * S) for r in range(rounds)])
-                th.start()
-                for _ in range(rounds):
-                    fe_round()
-                th.join()
-                t_ms = time.perf_counter() - t2
-                t3 = time.perf_counter()
-                for r in range(rounds):
-                    session_round(r * S)
-                t_ba_only = (time.perf_counter() - t3) / rounds
-                extras["multi_session"] = {"sessions_per_gpu": S, "frames_per_s": round(rounds * S * KF_INTERVAL / t_ms, 1),
-                                           "batched_ba_ms_per_round": round(1e3 * t_ba_only, 3), "ba_windows_per_s": round(S / t_ba_only, 1),
-                                           # the batch's arithmetic against the FP64 matrix-core peak: S windows x BA_ITERS iterations of the
-                                           # per-iteration flop count above, over the whole round (create + solve + read-back + destroy)
-                                           "ba_roofline": ({"TFLOPs": round(S * BA_ITERS * out["ba_roofline"]["flop_per_iteration"] / t_ba_only / 1e12, 3),
-                                                            "frac_of_fp64_peak": round(S * BA_ITERS * out["ba_roofline"]["flop_per_iteration"] / t_ba_only / 1e12 / FP64_PEAK_TFLOPS, 5)}
-                                                           if "ba_roofline" in out else None),
-                                           "note": "16 sessions, 6 stereo frames + 1 fresh local BA each per round; the 16 windows are one lpslam_hip_ba_optimize_batch call"}
+                for kind, key in (("random", "multi_session"), ("contiguous", "multi_session_contiguous")):
+                    wl.set_tracks(kind)
+                    session_round(0); fe_round()
+                    t2 = time.perf_counter()
+                    th = threading.Thread(target=lambda: [session_round(r * S) for r in range(rounds)])
+                    th.start()
+                    for _ in range(rounds):
+                        fe_round()
+                    th.join()
+                    t_ms = time.perf_counter() - t2
+                    t3 = time.perf_counter()
+                    for r in range(rounds):
+                        session_round(r * S)
+                    t_ba_only = (time.perf_counter() - t3) / rounds
+                    fl = out["ba_roofline"]["flop_per_iteration"] if kind == "random" and "ba_roofline" in out else (out["contiguous"]["ba_roofline"]["flop_per_iteration"] if "contiguous" in out else None)
+                    extras[key] = {"sessions_per_gpu": S, "tracks": kind, "frames_per_s": round(rounds * S * KF_INTERVAL / t_ms, 1),
+                                   "batched_ba_ms_per_round": round(1e3 * t_ba_only, 3), "ba_windows_per_s": round(S / t_ba_only, 1),
+                                   # the batch's arithmetic against the FP64 matrix-core peak: S windows x BA_ITERS iterations of the
+                                   # per-iteration flop count above, over the whole round (create + solve + read-back + destroy)
+                                   "ba_roofline": ({"TFLOPs": round(S * BA_ITERS * fl / t_ba_only / 1e12, 3), "frac_of_fp64_peak": round(S * BA_ITERS * fl / t_ba_only / 1e12 / FP64_PEAK_TFLOPS, 5)} if fl else None),
+                                   "note": "16 sessions, 6 stereo frames + 1 fresh local BA each per round; the 16 windows are one lpslam_hip_ba_optimize_batch call"}
+                wl.set_tracks("random")
             except Exception as e:      # noqa: BLE001
                 extras["multi_session"] = {"error": str(e)}
         # the integrated path: the same sequence through the drop-in boundary (LpSlamManager -> stereo tracker: upload, extract,

@@ -267,6 +267,7 @@ int lpslam_hip_ba_reset_batch(lpslam_hip_ba* const* problems, int32_t n);
 #define LPSLAM_HIP_BA_K_XSOLVE 4      /* k_chol_xsolve  */
 #define LPSLAM_HIP_BA_K_BACKSUB 5     /* k_ba_backsub   */
 #define LPSLAM_HIP_BA_K_TRIAL 6       /* k_ba_trial     */
+#define LPSLAM_HIP_BA_K_BAND_REDUCE 7 /* k_schur_band_reduce (band path only; there K_SCHUR is k_schur_group and K_CHOL is k_chol_band, one launch) */
 typedef struct lpslam_hip_ba_kernel_times {
     float ms[LPSLAM_HIP_BA_KERNELS];                  /* summed over the call                                    */
     int32_t launches[LPSLAM_HIP_BA_KERNELS];          /* marks (= LM trials the kernel ran in)                   */

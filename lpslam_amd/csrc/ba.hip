@@ -2173,10 +2173,11 @@ int enqueue_reduce(const BaLaunch& L, int fused)
     if (L.any_dense) hipLaunchKernelGGL(k_ba_schur, dim3(4 * L.n_blocks + L.n_free, L.count), dim3(64), 0, L.s, L.d_views, fused);
     if (L.any_band) {
         bd_set_attributes();
-        hipLaunchKernelGGL(k_schur_group, dim3(L.band_groups, L.count), dim3(256), bd_lds_bytes(L.band_gmax), L.s, L.d_views);
+        hipLaunchKernelGGL(k_schur_group, dim3(std::max(L.band_groups, 1), L.count), dim3(256), bd_lds_bytes(L.band_gmax), L.s, L.d_views);
+        L.mark(LPSLAM_HIP_BA_K_SCHUR);
         hipLaunchKernelGGL(k_schur_band_reduce, dim3(L.band_blocks, L.count), dim3(64), 0, L.s, L.d_views, fused);
-    }
-    if (L.any_dense || L.any_band) L.mark(LPSLAM_HIP_BA_K_SCHUR);
+        L.mark(LPSLAM_HIP_BA_K_BAND_REDUCE);
+    } else if (L.any_dense) L.mark(LPSLAM_HIP_BA_K_SCHUR);
     LP_HIP(hipGetLastError());
     return LPSLAM_HIP_OK;
 }
@@ -2442,6 +2443,9 @@ int lpslam_hip_ba_create(lpslam_hip_ctx* ctx, const double* poses, const uint8_t
         if (solver_env != 1) plan.build(obs, n_obs, n_points, slot.data(), b->n_free, b->dim, deg.data(), group_env);
         b->band_hbw_structure = plan.hbw;
         b->band_gmax = plan.hbw >= 0 ? group_env : 0;
+        static const bool trace = getenv("LPSLAM_HIP_BA_TRACE") != nullptr;
+        if (trace) fprintf(stderr, "[lpslam_hip_ba_create] %d poses (%d free) %d points %d obs: block half-bandwidth %d, %zu groups -> %s\n", n_poses, b->n_free, n_points,
+                           n_obs, plan.hbw, plan.groups.size() / BD_REC, plan.hbw >= 0 ? "band" : "dense");
     }
 
     // ---- one block: [view | inputs as staged | zero-initialised part | the rest]
@@ -2787,7 +2791,7 @@ int lpslam_hip_ba_optimize_profiled(lpslam_hip_ba* b, int32_t robust, int32_t it
     for (auto& m : marks) (void)hipEventDestroy(m.first);
     out->iterations = b->h_ctl.outer_done;
     // launches of the factorisation per mark: the panel-pair chain is several launches behind one mark
-    out->launches_per_mark[LPSLAM_HIP_BA_K_CHOL] = (b->dim_pad / NB + 1) / 2;
+    out->launches_per_mark[LPSLAM_HIP_BA_K_CHOL] = b->h_view.band_hbw >= 0 ? 1 : (b->dim_pad / NB + 1) / 2;
     for (int k = 0; k < LPSLAM_HIP_BA_KERNELS; ++k) if (k != LPSLAM_HIP_BA_K_CHOL) out->launches_per_mark[k] = 1;
     out->dim = b->dim;
     return rc;

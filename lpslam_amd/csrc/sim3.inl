@@ -794,6 +794,7 @@ int lpslam_hip_sim3_create(lpslam_hip_ctx* ctx, const double* verts, const uint8
     S3_TRY(s3_alloc(g, &g->d_chi, (size_t)n_edges));
     BaView& cv = v.cv;
     cv = BaView{};
+    cv.band_hbw = -1;                     // the dense factorisation (a zero here would read as "banded": ba_band.inl)
     cv.dim = v.dim; cv.dim_pad = v.dim_pad; cv.n_points = 0; cv.n_poses = n; cv.n_free = v.n_free;
     S3_TRY(s3_alloc(g, &cv.S, (size_t)v.dim_pad * v.dim_pad, true));
     {   // rows beyond the rhs row: identity (they stay 1 / 0 through every factorisation)

@@ -412,8 +412,9 @@ class BundleAdjuster:
         """per-kernel HIP-event times of one optimize() call: {kernel: (ms summed, marks, launches per mark)}, iterations"""
         t = BaKernelTimes()
         _check(self.lib.lpslam_hip_ba_optimize_profiled(self.h, int(robust), int(iters), C.byref(t)))
-        names = ["k_ba_lin", "k_ba_point_sum", "k_ba_schur", "chol", "k_chol_xsolve", "k_ba_backsub", "k_ba_trial"]
-        return {n: (t.ms[i], t.launches[i], t.launches_per_mark[i]) for i, n in enumerate(names)}, t.iterations, t.dim
+        band = self.solver()[0] == "band"
+        names = ["k_ba_lin", "k_ba_point_sum", "k_schur_group" if band else "k_ba_schur", "chol", "k_chol_xsolve", "k_ba_backsub", "k_ba_trial", "k_schur_band_reduce"]
+        return {n: (t.ms[i], t.launches[i], t.launches_per_mark[i]) for i, n in enumerate(names) if t.launches[i] or n == "chol"}, t.iterations, t.dim
 
     def pose_optimize(self):
         out = np.zeros(max(self.n_obs, 1), np.uint8); n = C.c_int32()
@@ -576,9 +577,9 @@ class RcclComm:
             f(self.comm); self.comm = None
 
 
-def ba_factor_kernel_name(dim):
+def ba_factor_kernel_name(dim, band=False):
     """name of the kernel that factors a reduced system of `dim` unknowns (rule of enqueue_solve in csrc/ba.hip)"""
-    return "k_chol_pair"          # k_chol_wg takes over only in batches of 40 problems and more
+    return "k_chol_band" if band else "k_chol_pair"          # k_chol_wg takes over only in batches of 40 dense problems and more
 
 
 def ba_optimize_batch(problems, robust=True, iters=10):

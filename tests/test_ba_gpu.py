@@ -142,7 +142,7 @@ def test_contiguous_tracks_take_the_band_path(hiplib, oracle, ctx):
         name, hbw = ba.solver()
         assert name == "band" and 0 <= hbw <= 9, (kf, name, hbw)
     # rejected trials on the band path: lambda control identical to the oracle's
-    prob = synth.ba_problem(10, 200, 1000, 640, 480, seq_id=46, pose_noise=(0.5, 3.0), point_noise=3.0, tracks="contiguous")
+    prob = synth.ba_problem(8, 200, 1000, 640, 480, seq_id=41, pose_noise=(0.5, 3.0), point_noise=3.0, tracks="contiguous")
     ba, _, _, glog = _compare(hiplib, oracle, ctx, prob, True, 10)
     assert ba.solver()[0] == "band" and glog["trials"].max() > 1
     # a random-track window of the same size does not qualify and says so

@@ -22,19 +22,32 @@ for case in range(n_cases):
     n_obs = int(min(n_kf * n_pts, rng.integers(2 * n_pts, 8 * n_pts + 1)))
     robust = bool(rng.integers(0, 2)); iters = int(rng.integers(1, 12))
     noise = float(rng.choice([1.0, 1.0, 3.0, 8.0]))
-    prob = synth.ba_problem(n_kf, n_pts, n_obs, 640, 480, seq_id=int(rng.integers(1000)), pose_noise=(0.01 * noise, 0.05 * noise), point_noise=0.05 * noise)
+    tracks = "contiguous" if rng.integers(0, 3) else "random"        # two thirds as a tracker makes them: the band path (ba_band.inl)
+    prob = synth.ba_problem(n_kf, n_pts, n_obs, 640, 480, seq_id=int(rng.integers(1000)), pose_noise=(0.01 * noise, 0.05 * noise), point_noise=0.05 * noise,
+                            tracks=tracks, top_up=bool(rng.integers(0, 2)))
     m = len(prob["obs_pose"])
+    if rng.integers(0, 4) == 0:                                       # landmarks seen twice by a keyframe
+        dup = rng.choice(m, max(1, m // 50), replace=False)
+        for key in ("obs_pose", "obs_point", "obs_uvr", "obs_inv_sigma2"): prob[key] = np.concatenate([prob[key], prob[key][dup]])
+        prob["obs_uvr"][m:, :2] += rng.normal(0, 0.3, (len(dup), 2)); m = len(prob["obs_pose"])
+    if rng.integers(0, 3) == 0:                                       # caller order shuffled
+        perm = rng.permutation(m)
+        for key in ("obs_pose", "obs_point", "obs_uvr", "obs_inv_sigma2"): prob[key] = prob[key][perm]
     if rng.integers(0, 2): prob["obs_uvr"][rng.random(m) < 0.3, 2] = -1.0
     active = None
     if rng.integers(0, 2): active = (rng.random(m) > 0.15).astype(np.uint8)
-    if rng.integers(0, 3) == 0: prob["fixed"][rng.random(n_kf) < 0.3] = 1
-    tag = "case %d: %d KF %d pts %d obs robust %d iters %d noise %.0f" % (case, n_kf, n_pts, m, robust, iters, noise)
+    fx = int(rng.integers(0, 4))
+    if fx == 0: prob["fixed"][rng.random(n_kf) < 0.3] = 1
+    elif fx == 1: prob["fixed"][:int(rng.integers(1, max(2, n_kf // 2)))] = 1      # a tracker's window: the oldest observers are fixed
+    elif fx == 2: prob["fixed"][:] = 0; prob["fixed"][int(rng.integers(0, n_kf))] = 1
+    tag = "case %d: %s %d KF (%d free) %d pts %d obs robust %d iters %d noise %.0f" % (case, tracks, n_kf, int((prob["fixed"] == 0).sum()), n_pts, m, robust, iters, noise)
     try:
         obs = O.ba_obs(prob)
         op, ox, olog = O.ba_optimize(prob["poses"], prob["fixed"], prob["points"], obs, prob["cam"], robust, iters, active)
         ba = hip.BundleAdjuster(ctx, prob["poses"], prob["fixed"], prob["points"], hip.ba_obs_array(prob), prob["cam"])
         if active is not None: ba.set_active(active)
         glog = ba.optimize(robust, iters); gp, gx = ba.state()
+        tag += " [%s %d]" % ba.solver()
         checks = {"len": len(glog) == len(olog)}
         if checks["len"]:
             checks.update(chi_before=np.allclose(glog["chi2_before"], olog["chi2_before"], rtol=CHI_RTOL),
