@@ -24,7 +24,7 @@ def hip_library(force=False, verbose=False):
     srcs = [s for s in HIP_SOURCES if os.path.exists(os.path.join(CSRC, s))]
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(OBJ_DIR, exist_ok=True)
-    compile_flags = [f for f in FLAGS if f != "-shared"]
+    compile_flags = [f for f in FLAGS if f != "-shared"] + os.environ.get("LPSLAM_HIP_EXTRA_FLAGS", "").split()
     jobs, objs = [], []
     for src in srcs:
         obj = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))

@@ -294,6 +294,11 @@ __device__ __forceinline__ double ba_weight(const BaView& v, int k, int D, const
 // consumer is the workgroup whose add came last).  An acquire-release pair here would cost a buffer_wbl2 + buffer_inv, ~3.5 us.
 __device__ __forceinline__ void st_sc1(double* p, double x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ double ld_sc1(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ void st_sc1(GPTR(double) p, double x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }      // global_, not flat_
+__device__ __forceinline__ double ld_sc1(GPTR(const double) p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double ld_sc1(GPTR(double) p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#endif
 __device__ __forceinline__ bool ba_last_block_sc1(int* ticket, int total)
 {
     __shared__ int s_last;
@@ -2173,9 +2178,9 @@ int enqueue_reduce(const BaLaunch& L, int fused)
     if (L.any_dense) hipLaunchKernelGGL(k_ba_schur, dim3(4 * L.n_blocks + L.n_free, L.count), dim3(64), 0, L.s, L.d_views, fused);
     if (L.any_band) {
         bd_set_attributes();
-        hipLaunchKernelGGL(k_schur_group, dim3(std::max(L.band_groups, 1), L.count), dim3(256), bd_lds_bytes(L.band_gmax), L.s, L.d_views);
+        hipLaunchKernelGGL(k_schur_group, dim3(std::max(L.band_groups, 1), L.count), dim3(BD_THREADS), bd_lds_bytes(L.band_gmax), L.s, L.d_views);
         L.mark(LPSLAM_HIP_BA_K_SCHUR);
-        hipLaunchKernelGGL(k_schur_band_reduce, dim3(L.band_blocks, L.count), dim3(64), 0, L.s, L.d_views, fused);
+        hipLaunchKernelGGL(k_schur_band_reduce, dim3(L.band_blocks, L.count), dim3(256), 0, L.s, L.d_views, fused);
         L.mark(LPSLAM_HIP_BA_K_BAND_REDUCE);
     } else if (L.any_dense) L.mark(LPSLAM_HIP_BA_K_SCHUR);
     LP_HIP(hipGetLastError());
@@ -2188,7 +2193,7 @@ int enqueue_solve(const BaLaunch& L, int fused)
     hipStream_t s = L.s;
     if (L.any_band) {
         bd_set_attributes();
-        hipLaunchKernelGGL(k_chol_band, dim3(1, L.count), dim3(256), BC_LDS_BYTES, s, L.d_views);
+        hipLaunchKernelGGL(k_chol_band, dim3(1, L.count), dim3(BC_THREADS), BC_LDS_BYTES, s, L.d_views);
         if (!L.any_dense) L.mark(LPSLAM_HIP_BA_K_CHOL);
     }
     if (L.dim > 0) {
@@ -2464,7 +2469,7 @@ int lpslam_hip_ba_create(lpslam_hip_ctx* ctx, const double* poses, const uint8_t
     const size_t o_A = cv.take(np * npt * 4), o_ptcount = cv.take(npt * 4);
     const SetOff so = set_offsets(n_poses, n_points, n_obs, b->n_free, b->dim_pad);
     const size_t o_setz0 = cv.take(so.z_total * 8), o_setz1 = cv.take(so.z_total * 8);
-    const size_t o_red = cv.take((size_t)b->red_n * 8), o_minv = cv.take(n * n * 8), o_xp = cv.take(n * 8);
+    const size_t o_red = cv.take((size_t)b->red_n * 8), o_minv = cv.take(std::max(n * n, 64 * n) * 8) /* L^-T rows, or the band path's M blocks: 1024 doubles per 16 columns */, o_xp = cv.take(n * 8);
     const size_t o_scal = cv.take(8 * 8), o_ctl = cv.take(sizeof(BaCtl)), o_ticket = cv.take(nblk * 4), o_log = cv.take(MAX_LOG * sizeof(lpslam_hip_ba_iter_log));
     const size_t z_end = cv.off;
     const size_t o_R = cv.take(np * npt * 4), o_pscount = cv.take(np * 4), o_slotof = cv.take(no * 4);

@@ -30,6 +30,7 @@ constexpr int BD_MAXKF = 10;                // keyframes a group's window may sp
 constexpr int BD_MAXHBW = 9;                // block half-bandwidth taken: 6 * 9 + 5 = 59 <= 64 riding rows of a strip
 constexpr int BD_GMAX = 64;                 // landmarks per group at most (K = 192)
 constexpr int BD_PART = BD_ROWS * BD_ROWS + BD_ROWS;      // doubles of a group's partial: window block (lower tiles) + rhs share
+constexpr int BD_THREADS = 512;             // k_schur_group: eight wavefronts
 constexpr int BD_REC = 8;                   // ints per group record: e0, e1 (entry range), f0 (first free slot), cnt, rows, -, -, -
 
 __host__ __device__ inline int bd_stride(int cnt) { const int k4 = (3 * cnt + 3) & ~3; return ((k4 + 31) & ~31) + 4; }    // % 32 == 4: operand reads 2-way at most
@@ -38,7 +39,7 @@ __host__ __device__ inline size_t bd_lds_bytes(int gmax) { return ((size_t)BD_RO
 // ---- creation: the entry table, in group order.  Thread per ordered landmark q: its observations (CSR order = keyframe order)
 //      become entries (storage slot, window row or -1 for a fixed keyframe, column | flags, landmark).
 //      flags: bit 16 = first entry of its landmark (writes the landmark's rhs vector), bit 17 = duplicate (same landmark seen
-//      twice by one keyframe: summed by the thread of the run's first entry).
+//      twice by one keyframe: summed by the thread of the run's first entry), bit 18 = a duplicate follows.
 __global__ __launch_bounds__(256) void k_bd_entries(const int* __restrict__ order, const int* __restrict__ qinfo, const int* __restrict__ bstart, int n_ord,
                                                     const int* __restrict__ pt_start, const int* __restrict__ pt_obs, const int* __restrict__ o_pose,
                                                     const int* __restrict__ pose_slot, int4* __restrict__ entries)
@@ -54,9 +55,24 @@ __global__ __launch_bounds__(256) void k_bd_entries(const int* __restrict__ orde
         int flags = 0;
         if (o == o0) flags |= 1 << 16;
         if (p == prev_pose) flags |= 1 << 17;
+        if (o + 1 < o1 && o_pose[pt_obs[o + 1]] == p) flags |= 1 << 18;      // the next entry is a duplicate of this one
         prev_pose = p;
         out[o - o0] = make_int4(s, slot < 0 ? -1 : 6 * (slot - f0), 3 * li | flags, j);
     }
+}
+
+// sum over the 16 lanes of a DPP row, in every lane (xor 1, xor 2, half mirror, mirror: a fixed tree)
+template <int CTRL>
+__device__ __forceinline__ double bc_dpp_mov(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double bc_row16_sum(double v)
+{
+    v += bc_dpp_mov<0xB1>(v); v += bc_dpp_mov<0x4E>(v); v += bc_dpp_mov<0x141>(v); v += bc_dpp_mov<0x140>(v);
+    return v;
 }
 
 // L^-1 of H_ll + lambda I = L L^T (lower 3 x 3; zero rows from a non-positive pivot on: the landmark then contributes nothing)
@@ -83,7 +99,7 @@ __device__ __forceinline__ void bd_linv(const double* hl, double lambda, double*
     li[0] = i00; li[1] = i10; li[2] = i11; li[3] = i20; li[4] = i21; li[5] = i22;
 }
 
-__global__ __launch_bounds__(256) void k_schur_group(const BaView* __restrict__ views)
+__global__ __launch_bounds__(BD_THREADS) void k_schur_group(const BaView* __restrict__ views)
 {
     BA_VIEW_XCD(v, bx);
     BA_VIEW_HEAD("s"(v.band_hbw), "s"(v.band_groups), "s"(v.ctl), "s"(v.band_tab));
@@ -94,6 +110,12 @@ __global__ __launch_bounds__(256) void k_schur_group(const BaView* __restrict__ 
     ba_lin_set(v, fl.cur);
     extern __shared__ __attribute__((aligned(16))) double bd_lds[];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+#ifdef LPSLAM_BC_STAMPS
+#define BD_STAMP(k) do { if (bx == 0 && tid == 0) v.S[(size_t)(v.dim + 2) * v.dim_pad + 8 * 22 + (k)] = (double)wall_clock64(); } while (0)
+#else
+#define BD_STAMP(k) do {} while (0)
+#endif
+    BD_STAMP(0);
     GPTR(const int) rec = v.band_tab + (size_t)BD_REC * bx;
     const int e0 = rec[0], e1 = rec[1], cnt = rec[3], rows = rec[4];
     const int K4 = (3 * cnt + 3) & ~3, stride = bd_stride(cnt);
@@ -104,17 +126,18 @@ __global__ __launch_bounds__(256) void k_schur_group(const BaView* __restrict__ 
         f64x2* z2 = reinterpret_cast<f64x2*>(Z);
         const int n2 = (16 * row_tiles * stride) >> 1;
         const f64x2 zero = {0.0, 0.0};
-        for (int i = tid; i < n2; i += 256) z2[i] = zero;
+        for (int i = tid; i < n2; i += BD_THREADS) z2[i] = zero;
         if (tid < K4) U[tid] = 0.0;
     }
     __syncthreads();
+    BD_STAMP(1);
     GPTR(const int4) ent = reinterpret_cast<GPTR(const int4)>(v.band_ent);
     // two entries per thread and round in flight (entry -> W row / landmark block are dependent round trips)
-    for (int eb = e0 + tid; eb < e1; eb += 512) {
+    for (int eb = e0 + tid; eb < e1; eb += 2 * BD_THREADS) {
         int4 en[2];
         double w[2][18], hl[2][6], bl[2][3];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) en[u] = ent[min(eb + 256 * u, e1 - 1)];
+        for (int u = 0; u < 2; ++u) en[u] = ent[min(eb + BD_THREADS * u, e1 - 1)];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const double2* Wa = reinterpret_cast<const double2*>(v.W + 18 * (size_t)en[u].x);
@@ -125,9 +148,10 @@ __global__ __launch_bounds__(256) void k_schur_group(const BaView* __restrict__ 
 #pragma unroll
             for (int q = 0; q < 3; ++q) bl[u][q] = v.bl[3 * (size_t)en[u].w + q];
         }
+        BD_STAMP(2);
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            if (eb + 256 * u >= e1) continue;
+            if (eb + BD_THREADS * u >= e1) continue;
             const int col = en[u].z & 0xFFFF, flags = en[u].z >> 16;
             double li[6];
             bd_linv(hl[u], lambda, li);
@@ -137,7 +161,7 @@ __global__ __launch_bounds__(256) void k_schur_group(const BaView* __restrict__ 
                 U[col + 2] = li[3] * bl[u][0] + li[4] * bl[u][1] + li[5] * bl[u][2];
             }
             if (en[u].y < 0 || (flags & 2)) continue;     // fixed keyframe / summed by the first entry of its run
-            for (int e2 = eb + 256 * u + 1; e2 < e1; ++e2) {      // duplicates (rare): the same landmark seen again by this keyframe
+            for (int e2 = eb + BD_THREADS * u + 1; (flags & 4) && e2 < e1; ++e2) {      // duplicates (rare): the same landmark seen again by this keyframe
                 const int4 d = ent[e2];
                 if (!((d.z >> 16) & 2)) break;
                 const double* Wd = v.W + 18 * (size_t)d.x;
@@ -155,43 +179,51 @@ __global__ __launch_bounds__(256) void k_schur_group(const BaView* __restrict__ 
         }
     }
     __syncthreads();
-    // ---- Z Z^T (lower tiles) and Z u on the matrix cores; jobs round robin over the four wavefronts
-    const int lr = lane & 15, lk = lane >> 4;
+    BD_STAMP(3);
     GPTR(double) P = v.band_part + (size_t)bx * BD_PART;
+    // ---- the group's share of the rhs, Z u: eight lanes per row, each every eighth column, summed over the eight in a fixed tree
+    {
+        const int row = tid >> 3, part = tid & 7;
+        double a = 0;
+        if (row < 16 * row_tiles) {
+            const double* zr = Z + row * stride;
+            for (int kk = part; kk < K4; kk += 8) a += zr[kk] * U[kk];
+        }
+        a += bc_dpp_mov<0xB1>(a); a += bc_dpp_mov<0x4E>(a); a += bc_dpp_mov<0x141>(a);
+        if (part == 0 && row < 16 * row_tiles) P[BD_ROWS * BD_ROWS + row] = a;
+    }
+    // ---- Z Z^T (lower tiles) on the matrix cores: tile t -> wavefront t % 8; the operands of the next four steps are fetched while
+    //      the matrix cores work on the current four
+    const int lr = lane & 15, lk = lane >> 4;
     const int n_sym = row_tiles * (row_tiles + 1) / 2;
-    for (int job = wave; job < n_sym + row_tiles; job += 4) {
-        int tr, tc;
-        const bool is_rhs = job >= n_sym;
-        if (is_rhs) { tr = job - n_sym; tc = 0; }
-        else { tr = 0; int t = job; while (t > tr) { t -= tr + 1; ++tr; } tc = t; }
+    for (int job = wave; job < n_sym; job += BD_THREADS / 64) {
+        int tr = 0, tc;
+        { int t = job; while (t > tr) { t -= tr + 1; ++tr; } tc = t; }
         const double* za = Z + (16 * tr + lr) * stride + lk;
         const double* zb = Z + (16 * tc + lr) * stride + lk;
         f64x4 acc = {0, 0, 0, 0};
-        if (!is_rhs) {
-            for (int k = 0; k < K4; k += 16) {           // four steps' operands fetched together
-                double av[4], bv[4];
+        double av[4], bv[4], an[4], bn[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { const int kk = min(k + 4 * i, K4 - 4); av[i] = za[kk]; bv[i] = zb[kk]; }
+        for (int i = 0; i < 4; ++i) { const int kk = min(4 * i, K4 - 4); av[i] = za[kk]; bv[i] = zb[kk]; }
+        for (int k = 0; k < K4; k += 16) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) if (k + 4 * i < K4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[i], bv[i], acc, 0, 0, 0);
-            }
+            for (int i = 0; i < 4; ++i) { const int kk = min(k + 16 + 4 * i, K4 - 4); an[i] = za[kk]; bn[i] = zb[kk]; }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) P[(16 * tr + lk + 4 * q) * BD_ROWS + 16 * tc + lr] = acc[q];
-        } else {
-            for (int k = 0; k < K4; k += 4) {
-                const double bv = lr == 0 ? U[k + lk] : 0.0;
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(za[k], bv, acc, 0, 0, 0);
-            }
-            if (lr == 0) {
+            for (int i = 0; i < 4; ++i) if (k + 4 * i < K4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[i], bv[i], acc, 0, 0, 0);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) P[BD_ROWS * BD_ROWS + 16 * tr + lk + 4 * q] = acc[q];
-            }
+            for (int i = 0; i < 4; ++i) { av[i] = an[i]; bv[i] = bn[i]; }
         }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) P[(16 * tr + lk + 4 * q) * BD_ROWS + 16 * tc + lr] = acc[q];
     }
+    BD_STAMP(4);
 }
 
-// ---- the groups' shares summed into the band of S (one wavefront per 6 x 6 block, groups in order) + the rhs row ----------------
-__global__ __launch_bounds__(64) void k_schur_band_reduce(const BaView* __restrict__ views, int fused)
+// ---- the groups' shares summed into the band of S (one workgroup per 6 x 6 block) + the rhs row.  The groups that can cover a block
+//      are a contiguous range (groups are sorted by their first keyframe).  Thread t takes element t % 36 of the block and every
+//      seventh group of the range (rhs blocks: element t % 6, every 42nd group), its loads independent of each other; the seven
+//      (42) partial sums of an element are added in lane order: a fixed summation tree whatever the placement.
+__global__ __launch_bounds__(256) void k_schur_band_reduce(const BaView* __restrict__ views, int fused)
 {
     BA_VIEW_XCD(v, bx);
     BA_VIEW_HEAD("s"(v.band_hbw), "s"(v.n_free), "s"(v.ctl), "s"(v.band_tab), "s"(v.band_groups_cap));
@@ -203,7 +235,7 @@ __global__ __launch_bounds__(64) void k_schur_band_reduce(const BaView* __restri
     if (fl.idle()) return;
     const double lambda = fl.lambda;
     ba_lin_set(v, fl.cur);
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x;
     const int n = v.dim_pad;
     GPTR(const int) recs = v.band_tab;
     GPTR(const int) glo = v.band_tab + (size_t)BD_REC * v.band_groups_cap;
@@ -213,37 +245,43 @@ __global__ __launch_bounds__(64) void k_schur_band_reduce(const BaView* __restri
     const int k = is_rhs ? i : i - (bx - i * bw);
     if (k < 0) return;
     const int g0 = glo[i], g1 = ghi[k];               // groups that may cover rows of keyframe i and columns of keyframe k (inclusive)
-    const int r = lane / 6, c = lane - 6 * r;
-    const bool act = is_rhs ? lane < 6 : lane < 36;
+    const int ne = is_rhs ? 6 : 36, ngl = 252 / ne;
+    const int e = tid % ne, gl = tid / ne;
+    const int r = e / 6, c = e - 6 * r;
+    __shared__ double part[256];
     double sum = 0;
-    for (int gb = g0; gb <= g1; gb += 4) {
-        double val[4];
+    if (tid < 252) {
+        for (int gb = g0 + gl; gb <= g1; gb += 4 * ngl) {
+            double val[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int g = min(gb + u, g1);
-            const int f0 = recs[BD_REC * g + 2], rows = recs[BD_REC * g + 4];
-            const bool cover = gb + u <= g1 && 6 * (i - f0) + 6 <= rows && k >= f0 && act;
-            const size_t off = is_rhs ? (size_t)(BD_ROWS * BD_ROWS + 6 * (i - f0) + lane) : (size_t)((6 * (i - f0) + r) * BD_ROWS + 6 * (k - f0) + c);
-            val[u] = cover ? v.band_part[(size_t)g * BD_PART + off] : 0.0;
+            for (int u = 0; u < 4; ++u) {
+                const int g = min(gb + u * ngl, g1);
+                const int f0 = recs[BD_REC * g + 2], rows = recs[BD_REC * g + 4];
+                const bool cover = gb + u * ngl <= g1 && 6 * (i - f0) + 6 <= rows && k >= f0;
+                const size_t off = is_rhs ? (size_t)(BD_ROWS * BD_ROWS + 6 * (i - f0) + e) : (size_t)((6 * (i - f0) + r) * BD_ROWS + 6 * (k - f0) + c);
+                val[u] = cover ? v.band_part[(size_t)g * BD_PART + off] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) sum += val[u];
         }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) sum += val[u];
     }
+    part[tid] = sum;
+    __syncthreads();
+    if (tid >= ne) return;
+    sum = 0;
+    for (int l = 0; l < ngl; ++l) sum += part[l * ne + e];
     if (is_rhs) {
-        if (lane < 6) {
-            const int qd = 6 * lane - lane * (lane - 1) / 2;
-            double bsum = 0, dsum = 0;
-            for (int sp = 0; sp < SPLIT; ++sp) { const double* pr = v.partial + ((size_t)i * SPLIT + sp) * PV; bsum += pr[21 + lane]; dsum += pr[qd]; }
-            const double val = bsum - sum;
-            v.rhs[6 * i + lane] = val;
-            if (fused) v.S[(size_t)v.dim * n + 6 * i + lane] = val;
-            v.bp[6 * i + lane] = bsum; v.hppdiag[6 * i + lane] = dsum;
-        }
-        if (!fused && i == 0 && lane == 62) *v.chi_cur = *v.chi_loc;
-        if (fused && i == 0 && lane == 63) { v.S[(size_t)v.dim * n + v.dim] = 1e200; v.scal[5] = 0.0; }
+        const int qd = 6 * e - e * (e - 1) / 2;
+        double bsum = 0, dsum = 0;
+        for (int sp = 0; sp < SPLIT; ++sp) { const double* pr = v.partial + ((size_t)i * SPLIT + sp) * PV; bsum += pr[21 + e]; dsum += pr[qd]; }
+        const double val = bsum - sum;
+        v.rhs[6 * i + e] = val;
+        if (fused) v.S[(size_t)v.dim * n + 6 * i + e] = val;
+        v.bp[6 * i + e] = bsum; v.hppdiag[6 * i + e] = dsum;
+        if (!fused && i == 0 && e == 0) *v.chi_cur = *v.chi_loc;
+        if (fused && i == 0 && e == 1) { v.S[(size_t)v.dim * n + v.dim] = 1e200; v.scal[5] = 0.0; }
         return;
     }
-    if (lane >= 36) return;
     if (i == k) {
         const int ra = min(r, c), rc = max(r, c);
         const int q = 6 * ra - ra * (ra - 1) / 2 + (rc - ra);
@@ -259,20 +297,40 @@ __global__ __launch_bounds__(64) void k_schur_band_reduce(const BaView* __restri
 
 // ---- band Cholesky + solve in one workgroup ------------------------------------------------------------------------------------
 constexpr int BC_RING = 96;                 // rows / columns of the window ring: the 80 live ones + the 16 entering
-constexpr int BC_RS = BC_RING + 1;          // row stride (odd: the riding rows of a strip read conflict-free)
+constexpr int BC_RS = BC_RING + 2;          // row stride: rows 16-byte aligned (the strip's rows are read 16 bytes at a time)
 constexpr int BC_MAXS = 19;                 // strips: dim <= 304
-constexpr int BC_LDS_DOUBLES = BC_RING * BC_RS + 2 * 64 * 17 + BC_MAXS * 16 * 17 + 3 * 320 + 32;
+constexpr int BC_THREADS = 512;             // 8 wavefronts: 0 / 1 factor, 2 / 3 bring rows in, 4 .. 7 form the backward operands; all eight update tiles
+constexpr int BC_LDS_DOUBLES = BC_RING * BC_RS + 2 * 64 * 17 + BC_MAXS * 16 * 17 + 2 * 320;
 constexpr int BC_LDS_BYTES = BC_LDS_DOUBLES * 8;
 __host__ __device__ inline bool bc_fits(int dim) { return dim > 0 && dim <= 16 * BC_MAXS; }
 
-__device__ __forceinline__ int bc_ring(int r) { return r % BC_RING; }
+// ring index of base + k for base, k < 96 (base = first live column % 96, kept per strip: no division in the inner loops)
+__device__ __forceinline__ int bc_ring(int base, int k) { const int v = base + k; return v >= BC_RING ? v - BC_RING : v; }
 
-__global__ __launch_bounds__(256) void k_chol_band(const BaView* __restrict__ views)
+// What the backward substitution needs of strip s2, formed off the critical path (by `nw` wavefronts, this one is number w of them):
+//   M = L_ss^-T [L_below,s; y_s]^T (16 x 64, matrix cores; the rhs row is row 63 of the strip's riding rows) -> memory
+//   [s2][16][64], stored write-through.  Then x_s = M (-x_below; 1): one 16 x 64 matrix-vector product per strip on the chain
+//   instead of a product with L and one with L_ss^-T.
+__device__ __forceinline__ void bc_back_operands(int s2, int w, int nw, int lane, const double* Lx, const double* Tinv, GPTR(double) Mg)
+{
+    const int lr = lane & 15, lk = lane >> 4;
+    const double* T = Tinv + s2 * 16 * 17;
+    for (int j = w; j < 4; j += nw) {
+        f64x4 acc = {0, 0, 0, 0};
+#pragma unroll
+        for (int k4 = 0; k4 < 16; k4 += 4)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(T[lr * 17 + k4 + lk], Lx[(16 * j + lr) * 17 + k4 + lk], acc, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) st_sc1(Mg + (size_t)s2 * 1024 + (lk + 4 * q) * 64 + 16 * j + lr, acc[q]);
+    }
+}
+
+__global__ __launch_bounds__(BC_THREADS) void k_chol_band(const BaView* __restrict__ views)
 {
     const BaView& vw = views[blockIdx.y];
     const int dim = vw.dim, n = vw.dim_pad, hbw = vw.band_hbw;
     GPTR(double) S = vw.S; GPTR(double) xp = vw.xp; GPTR(double) scal = vw.scal; GPTR(BaCtl) ctl = vw.ctl;
-    asm volatile("" :: "s"(dim), "s"(n), "s"(hbw), "s"(S), "s"(xp), "s"(scal), "s"(ctl));
+    asm volatile("" :: "s"(dim), "s"(n), "s"(hbw), "s"(S), "s"(xp), "s"(scal), "s"(ctl), "s"(vw.Minv));
     if (hbw < 0 || dim == 0) return;
     if (ba_flags(ctl).idle()) return;
     extern __shared__ __attribute__((aligned(16))) double bc_lds[];
@@ -281,145 +339,169 @@ __global__ __launch_bounds__(256) void k_chol_band(const BaView* __restrict__ vi
     double* const Tinv = LxS0 + 2 * 64 * 17;             // still read strip s - 1's while wavefront 0 writes strip s's; L_ss^-T of every strip [s][16][17]
     double* const rhsv = Tinv + BC_MAXS * 16 * 17;       // the rhs row as it is updated / y
     double* const xv = rhsv + 320;                       // solution (zero beyond dim)
-    double* const vtmp = xv + 320;                       // [16] + Ly [16]
-    double* const Ly = vtmp + 16;
+    GPTR(double) Mg = vw.Minv;                           // M_s = L_ss^-T L_below,s^T of every strip [s][16][64] (the dense path's L^-T buffer)
     __shared__ int s_fail;
+    // the barrier of the strip loop: LDS traffic drained, nothing else -- __syncthreads() also waits for every global load and store
+    // in flight (the rows on their way in, the write-through stores of M, the prefetched M blocks of the backward pass)
+#define BC_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int lr = lane & 15, lk = lane >> 4;
     const int ns = (dim + 15) >> 4;
-    auto load_s = [&](int r, int c) -> double {          // S(r, c), r >= c; identity beyond dim
-        return (r < dim) ? S[(size_t)r * n + c] : (r == c ? 1.0 : 0.0);
-    };
-    // rows [r0, r1) enter the ring: their columns max(0, r - 79) .. r
-    auto load_rows = [&](int r0, int r1, int t0, int nt) {
-        const int cnt = (r1 - r0) * 80;
-        for (int i = t0; i < cnt; i += nt) {
-            const int r = r0 + i / 80, c = r - 79 + (i % 80);
-            if (c >= 0) Win[bc_ring(r) * BC_RS + bc_ring(c)] = load_s(r, c);
+    // S(r, c), r >= c, of the band; identity beyond dim.  All loads of a batch are issued before the first store to LDS: written as
+    // load -> store per element every element is a round trip of its own (ten per strip: 7 us of a 7 us strip, measured).
+    auto load_s = [&](int r, int c) -> double { return (r < dim && c >= 0) ? S[(size_t)r * n + c] : ((r == c) ? 1.0 : 0.0); };
+#ifdef LPSLAM_BC_STAMPS
+    if (tid == 0) S[(size_t)(dim + 2) * n + 8 * 20 + 4] = (double)wall_clock64();
+#endif
+    if (tid == 0) s_fail = 0;
+    for (int i = tid; i < 320; i += BC_THREADS) { rhsv[i] = i < dim ? S[(size_t)dim * n + i] : 0.0; xv[i] = 0.0; }
+    // rows 0 .. 79, columns 0 .. r (lower part; the upper part of the first window is never read): 80 columns per row, 13 per thread
+    {
+        double val[13];
+#pragma unroll
+        for (int q = 0; q < 13; ++q) { const int i = tid + BC_THREADS * q, r = i / 80, c = i - 80 * r; val[q] = (i < 6400 && c <= r) ? load_s(r, c) : 0.0; }
+#pragma unroll
+        for (int q = 0; q < 13; ++q) { const int i = tid + BC_THREADS * q, r = i / 80, c = i - 80 * r; if (i < 6400) Win[r * BC_RS + c] = val[q]; }
+    }
+    __syncthreads();
+    int base = 0;                                        // c0 % 96
+#ifdef LPSLAM_BC_STAMPS
+    // development: wall-clock stamps (100 MHz) of wavefront 0 per strip into the padding rows of S (read back by tools/dev/band_stamps.py)
+    GPTR(double) stamp = S + (size_t)(dim + 2) * n;
+#define BC_STAMP(slot) do { if (tid == 0) stamp[8 * s + (slot)] = (double)wall_clock64(); } while (0)
+#define BC_STAMP_W(w, slot) do { if (tid == 64 * (w)) stamp[8 * s + (slot)] = (double)wall_clock64(); } while (0)
+#define BC_STAMPX(idx) do { if (tid == 0) stamp[8 * 20 + (idx)] = (double)wall_clock64(); } while (0)
+#else
+#define BC_STAMPX(idx) do {} while (0)
+#define BC_STAMP(slot) do {} while (0)
+#define BC_STAMP_W(w, slot) do {} while (0)
+#endif
+    // tile (tr, tc) of the window that starts at ring offset `woff` / column `wcol`: Win -= Lx[16 tr ..] Lx[16 tc ..]^T.  Row 63 of Lx is
+    // the rhs row: its products go to rhsv, and as a COLUMN it is nobody's (the true row c0 + 79 is zero there)
+    auto tile_update = [&](const double* Lx, int tr, int tc, int woff, int wcol) __attribute__((always_inline)) {
+        // the tile's old values travel with the operands (one LDS round trip) and seed the accumulators: acc = Win - Lx Lx^T
+        const int cc = bc_ring(base, woff + 16 * tc + lr);
+        const bool col_ok = !(tc == 3 && lr == 15);
+        const int col = wcol + 16 * tc + lr;
+        double* dst[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const bool rhs_row = tr == 3 && q == 3 && lk == 3;
+            dst[q] = rhs_row ? rhsv + min(col, 319) : Win + bc_ring(base, woff + 16 * tr + lk + 4 * q) * BC_RS + cc;
+        }
+        double av[4], bv[4];
+#pragma unroll
+        for (int k4 = 0; k4 < 4; ++k4) { av[k4] = Lx[(16 * tr + lr) * 17 + 4 * k4 + lk]; bv[k4] = Lx[(16 * tc + lr) * 17 + 4 * k4 + lk]; }
+        f64x4 acc;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = *dst[q];
+#pragma unroll
+        for (int k4 = 0; k4 < 4; ++k4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[k4], bv[k4], acc, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const bool rhs_row = tr == 3 && q == 3 && lk == 3;
+            if (col_ok && (!rhs_row || col < dim)) *dst[q] = acc[q];
         }
     };
-    if (tid == 0) s_fail = 0;
-    for (int i = tid; i < 320; i += 256) { rhsv[i] = i < dim ? S[(size_t)dim * n + i] : 0.0; xv[i] = 0.0; }
-    load_rows(0, 80, tid, 256);
-    __syncthreads();
+    BC_STAMPX(0);
     for (int s = 0; s < ns; ++s) {
         const int c0 = 16 * s;
+        BC_STAMP(0);
         double* const LxS = LxS0 + (s & 1) * 64 * 17;
         const double* const LxP = LxS0 + ((s & 1) ^ 1) * 64 * 17;       // the previous strip's
         if (wave < 2) {
-            // wavefront 0: [D; rows c0+16 .. c0+79]; wavefront 1: [D; rhs row; I]
+            // wavefront 0: [D; rows c0+16 .. c0+78; the rhs row in lane 63 (a band of half-width <= 59 never reaches row c0+79)];
+            // wavefront 1: [D; I] -> L_ss^-T, needed only by the backward operands
             double d[16], x[16];
-            const int dr = bc_ring(c0 + lr) * BC_RS;
+            const f64x2* dp = reinterpret_cast<const f64x2*>(Win + bc_ring(base, lr) * BC_RS + base);
 #pragma unroll
-            for (int c = 0; c < 16; ++c) d[c] = Win[dr + bc_ring(c0 + c)];
+            for (int c = 0; c < 8; ++c) { const f64x2 t2 = dp[c]; d[2 * c] = t2.x; d[2 * c + 1] = t2.y; }
             if (wave == 0) {
-                const int xr = bc_ring(c0 + 16 + lane) * BC_RS;
+                const f64x2* xp2 = reinterpret_cast<const f64x2*>(lane < 63 ? Win + bc_ring(base, 16 + lane) * BC_RS + base : rhsv + c0);
 #pragma unroll
-                for (int c = 0; c < 16; ++c) x[c] = Win[xr + bc_ring(c0 + c)];
+                for (int c = 0; c < 8; ++c) { const f64x2 t2 = xp2[c]; x[2 * c] = t2.x; x[2 * c + 1] = t2.y; }
             } else {
 #pragma unroll
-                for (int c = 0; c < 16; ++c) x[c] = lane == 0 ? rhsv[c0 + c] : (lane == c + 1 ? 1.0 : 0.0);
+                for (int c = 0; c < 16; ++c) x[c] = lane == c ? 1.0 : 0.0;
             }
+            BC_STAMP(1);
             const bool fail = strip_factor(d, x);
+            BC_STAMP(2);
             if (wave == 0) {
                 if (fail && lane == 0) s_fail = 1;
 #pragma unroll
-                for (int c = 0; c < 16; ++c) LxS[lane * 17 + c] = x[c];
-                // L to memory (lower band of S, in place) for the backward substitution
-                if (lane < 16 && c0 + lane < dim) {
+                for (int c = 0; c < 16; ++c) LxS[lane * 17 + c] = x[c];       // row 63: y_s, which rides through the tile updates into rhsv
+            } else if (lane < 16) {
 #pragma unroll
-                    for (int c = 0; c < 16; ++c) if (c <= lane) S[(size_t)(c0 + lane) * n + c0 + c] = d[c];
-                }
-                if (c0 + 16 + lane < dim) {
-                    f64x2* dst = reinterpret_cast<f64x2*>(S + (size_t)(c0 + 16 + lane) * n + c0);
-#pragma unroll
-                    for (int c = 0; c < 16; c += 2) { const f64x2 t = {x[c], x[c + 1]}; dst[c >> 1] = t; }
-                }
-            } else {
-                if (lane == 0) {
-#pragma unroll
-                    for (int c = 0; c < 16; ++c) { rhsv[c0 + c] = x[c]; Ly[c] = x[c]; }
-                } else if (lane <= 16) {
-#pragma unroll
-                    for (int c = 0; c < 16; ++c) Tinv[(s * 16 + lane - 1) * 17 + c] = x[c];
-                }
+                for (int c = 0; c < 16; ++c) Tinv[(s * 16 + lane) * 17 + c] = x[c];
             }
-        } else {
-            // wavefronts 2, 3: the six tiles of the previous strip's trailing update the next strip does not need first, then the
-            // 16 rows that enter the window for the strip after this one
-            if (s > 0) {
-                const int w0 = c0;                       // previous strip's window starts at its c0 + 16 = this c0
-                for (int job = wave - 2; job < 6; job += 2) {
-                    const int tr = job < 3 ? job + 1 : (job < 5 ? job - 1 : 3), tc = job < 3 ? 1 : (job < 5 ? 2 : 3);
-                    f64x4 acc = {0, 0, 0, 0};
+        } else if (wave < 4) {
+            // wavefronts 2, 3: the 16 rows that enter the window for the strip after this one (rows c0+80 .. c0+95, columns r-79 .. r:
+            // 1280 values, ten per thread, in flight while ...) the last two tiles of the previous strip's trailing update are applied
+            const int t = tid - 128, rr = t >> 3, seg = t & 7;
+            const int r = c0 + 80 + rr;
+            double val[10];
 #pragma unroll
-                    for (int k4 = 0; k4 < 16; k4 += 4)
-                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(LxP[(16 * tr + lr) * 17 + k4 + lk], LxP[(16 * tc + lr) * 17 + k4 + lk], acc, 0, 0, 0);
-                    const int cc = bc_ring(w0 + 16 * tc + lr);
+            for (int q = 0; q < 10; ++q) val[q] = load_s(r, r - 79 + 10 * seg + q);
+            if (s > 0) tile_update(LxP, 3, wave, 0, c0);      // tiles (3, 2) and (3, 3) of the previous strip's window, which starts at this strip's c0
+            BC_STAMP_W(2, 6);
+            const int rrow = bc_ring(base, 80 + rr) * BC_RS;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) Win[bc_ring(w0 + 16 * tr + lk + 4 * q) * BC_RS + cc] -= acc[q];
-                }
-            }
-            load_rows(c0 + 80, c0 + 96, tid - 128, 128);
+            for (int q = 0; q < 10; ++q) Win[rrow + bc_ring(base, 1 + rr + 10 * seg + q)] = val[q];
+            BC_STAMP_W(2, 7);
+        } else if (s > 0) {
+            // wavefronts 4 .. 7: what the backward substitution needs of the previous strip
+            bc_back_operands(s - 1, wave - 4, 4, lane, LxP, Tinv, Mg);
         }
-        __syncthreads();
-        // ---- the four tiles of column 0 of this strip's window (what the next strip loads), one per wavefront; wavefront 1 also
-        //      takes the rhs row along
-        {
-            const int w0 = c0 + 16, tr = wave;
-            f64x4 acc = {0, 0, 0, 0};
-#pragma unroll
-            for (int k4 = 0; k4 < 16; k4 += 4)
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(LxS[(16 * tr + lr) * 17 + k4 + lk], LxS[lr * 17 + k4 + lk], acc, 0, 0, 0);
-            const int cc = bc_ring(w0 + lr);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) Win[bc_ring(w0 + 16 * tr + lk + 4 * q) * BC_RS + cc] -= acc[q];
-            if (wave == 1) {
-                double a = 0;
-#pragma unroll
-                for (int k = 0; k < 16; ++k) a += Ly[k] * LxS[lane * 17 + k];
-                rhsv[w0 + lane] -= a;
-            }
-        }
-        __syncthreads();
+        BC_STAMP(3);
+        BC_BARRIER();
+        BC_STAMP(4);
+        // ---- this strip's trailing update: the four tiles of column 0 of its window (what the next strip loads) on wavefronts 0 .. 3 --
+        //      wavefront 1 also takes the rhs row along --, tiles (1,1) (2,1) (3,1) (2,2) on wavefronts 4 .. 7; (3,2) and (3,3) follow
+        //      beside the next strip's factorisation
+        tile_update(LxS, wave < 4 ? wave : (wave < 7 ? wave - 3 : 2), wave < 4 ? 0 : (wave < 7 ? 1 : 2), 16, c0 + 16);
+        BC_STAMP(5);
+        BC_BARRIER();
+        base = bc_ring(base, 16);
     }
+    BC_STAMPX(1);
     if (tid == 0 && s_fail) scal[5] = 1.0;
-    // ---- backward substitution: x_s = L_ss^-T (y_s - L_below,s^T x_below), strips in reverse.  L comes back from memory (this
-    //      workgroup's own stores: visible after the barrier), one strip ahead.
+    // ---- backward substitution: x_s = w_s - M_s x_below, strips in reverse.  The last strip's operands are still to be formed; M
+    //      comes back from memory (write-through stores of this workgroup, read L1-bypassing) four strips ahead of its use.
     {
-        double lv[4];
-        auto fetch = [&](int s2) {
-            const int c0 = 16 * s2, r = c0 + 16 + lane;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) lv[q] = (s2 >= 0 && r < dim) ? __hip_atomic_load(&S[(size_t)r * n + c0 + 4 * wave + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
-        };
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // wavefront 0's stores of L have left for the L2 (the loads above bypass the L1)
+        if (wave < 4) bc_back_operands(ns - 1, wave, 4, lane, LxS0 + ((ns - 1) & 1) * 64 * 17, Tinv, Mg);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wavefront's stores of M have left for the L2
         __syncthreads();
-        fetch(ns - 1);
-        for (int s = ns - 1; s >= 0; --s) {
-            const int c0 = 16 * s;
-            double p[4];
-            const double xr = xv[c0 + 16 + lane];
+        const int bi = tid >> 4, bq = tid & 15;              // row of the strip, quarter-row of four columns
+        double mv[8][4];
+        auto fetch = [&](int s2, double (&dst)[4]) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) p[q] = lv[q] * xr;
-            fetch(s - 1);
+            for (int j = 0; j < 4; ++j) dst[j] = (s2 >= 0 && tid < 256) ? ld_sc1(Mg + (size_t)s2 * 1024 + bi * 64 + 4 * bq + j) : 0.0;
+        };
 #pragma unroll
-            for (int q = 0; q < 4; ++q) p[q] = wave_sum(p[q]);
-            if (lane == 0) {
+        for (int u = 0; u < 8; ++u) fetch(ns - 1 - u, mv[u]);
+        BC_STAMPX(2);
+        for (int sb = ns - 1; sb >= 0; sb -= 8) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) vtmp[4 * wave + q] = rhsv[c0 + 4 * wave + q] - p[q];
+            for (int u = 0; u < 8; ++u) {
+                const int s = sb - u;
+                if (s < 0) break;
+                const int c0 = 16 * s;
+                double p = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {        // column 63 of M is L_ss^-T y_s (the rhs row rode along as row 63): multiplier -1
+                    const int r = c0 + 16 + 4 * bq + j;
+                    p += mv[u][j] * ((bq == 15 && j == 3) ? -1.0 : (r < dim ? xv[r] : 0.0));
+                }
+                fetch(s - 8, mv[u]);
+                p = bc_row16_sum(p);
+                if (bq == 0 && tid < 256) xv[c0 + bi] = -p;
+                BC_BARRIER();
             }
-            __syncthreads();
-            if (tid < 16) {
-                double a = 0;
-#pragma unroll
-                for (int c = 0; c < 16; ++c) a += Tinv[(s * 16 + tid) * 17 + c] * vtmp[c];      // row tid of L_ss^-T (zero left of the diagonal)
-                xv[c0 + tid] = a;
-            }
-            __syncthreads();
         }
     }
-    for (int i = tid; i < dim; i += 256) xp[i] = xv[i];
+    BC_STAMPX(3);
+    for (int i = tid; i < dim; i += BC_THREADS) xp[i] = xv[i];
 }
 
 // dynamic LDS beyond 64 KB: the attribute belongs to the (function, device) pair

@@ -4,8 +4,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from lpslam_amd import hip, synth
 ctx = hip.Context(1280, 720, 2000, 1.2, 8, max_images=2)
-p = synth.ba_problem(50, 5000, 40000, 1280, 720, seq_id=0)
+tracks = sys.argv[1] if len(sys.argv) > 1 else "random"
+p = synth.ba_problem(50, 5000, 40000, 1280, 720, seq_id=0, tracks=tracks, top_up=True)
 b = hip.BundleAdjuster(ctx, p["poses"], p["fixed"], p["points"], hip.ba_obs_array(p), p["cam"])
+print(tracks, "solver", b.solver())
 for _ in range(3):
     b.reset(); b.optimize(True, 10)
 ts = []
