@@ -653,8 +653,11 @@ def main():
                 rounds = 3
                 fe_ctx = wl.ctx                                  # the sessions' frames: the resident ring, KF_INTERVAL frames per session and round
 
+                from concurrent.futures import ThreadPoolExecutor
+                creators = ThreadPoolExecutor(8)                 # every session has a mapping thread of its own: the windows are set up side by side
+
                 def session_round(v0):
-                    bas = [wl.new_problem(v0 + i) for i in range(S)]
+                    bas = list(creators.map(wl.new_problem, range(v0, v0 + S)))
                     hip.ba_optimize_batch(bas, True, BA_ITERS)
                     for b in bas:
                         b.close()
@@ -691,6 +694,7 @@ def main():
                                    "ba_roofline": ({"TFLOPs": round(S * BA_ITERS * fl / t_ba_only / 1e12, 3), "frac_of_fp64_peak": round(S * BA_ITERS * fl / t_ba_only / 1e12 / FP64_PEAK_TFLOPS, 5)} if fl else None),
                                    "note": "16 sessions, 6 stereo frames + 1 fresh local BA each per round; the 16 windows are one lpslam_hip_ba_optimize_batch call"}
                 wl.set_tracks("random")
+                creators.shutdown()
             except Exception as e:      # noqa: BLE001
                 extras["multi_session"] = {"error": str(e)}
         # the integrated path: the same sequence through the drop-in boundary (LpSlamManager -> stereo tracker: upload, extract,

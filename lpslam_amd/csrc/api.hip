@@ -196,7 +196,7 @@ void lp_pin_big_free(lpslam_hip_ctx* c, void* p, size_t capacity)
     if (!p) return;
     {
         std::lock_guard<std::mutex> lock(c->pool_mutex);
-        if (c->pin_big.size() < 16) { c->pin_big.emplace_back(capacity, p); return; }
+        if (c->pin_big.size() < 256) { c->pin_big.emplace_back(capacity, p); return; }      // (16 made a 16-session batch -- a staging and an exchange block per window -- free and re-allocate page-locked memory every round: milliseconds)
     }
     (void)hipHostFree(p);
 }
@@ -222,7 +222,7 @@ void lp_pin_free(lpslam_hip_ctx* c, void* p)
 void lp_pool_free(lpslam_hip_ctx* c, void* p, size_t capacity)
 {
     if (!p) return;
-    constexpr size_t kMaxCached = 2ull << 30;            // of 288 GB
+    constexpr size_t kMaxCached = 16ull << 30;           // of 288 GB (a batch of 16 local windows holds 0.7 GB; 2 GB made a multi-session server free and re-allocate its blocks every round)
     {
         std::lock_guard<std::mutex> lock(c->pool_mutex);
         if (c->pool_bytes + capacity <= kMaxCached) { c->pool.emplace_back(capacity, p); c->pool_bytes += capacity; return; }

@@ -4,7 +4,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from lpslam_amd import hip, synth
 ctx = hip.Context(1280, 720, 2000, 1.2, 8, max_images=2)
-probs = [synth.ba_problem(50, 5000, 40000, 1280, 720, seq_id=s) for s in range(4)]
+TRACKS = os.environ.get("TRACKS", "random")
+probs = [synth.ba_problem(50, 5000, 40000, 1280, 720, seq_id=s, tracks=TRACKS, top_up=True) for s in range(4)]
 obs = [hip.ba_obs_array(p) for p in probs]
 def make(i):
     p = probs[i % 4]
@@ -30,3 +31,18 @@ for B in (tuple(int(x) for x in sys.argv[1].split(',')) if len(sys.argv) > 1 els
     print("batch %3d: %.3f ms per batch, %.4f ms per problem-iteration, %.1f problems/s; iters %s" % (B, 1e3 * m, 1e3 * m / B / 10, B / m, sorted(set(len(l) for l in logs))))
     for b in bas:
         b.close()
+if os.environ.get("ROUNDS"):
+    S = 16
+    def session_round(v0):
+        t0 = time.perf_counter()
+        bas = [make(v0 + i) for i in range(S)]
+        t1 = time.perf_counter()
+        hip.ba_optimize_batch(bas, True, 10)
+        t2 = time.perf_counter()
+        for b in bas:
+            b.close()
+        t3 = time.perf_counter()
+        return 1e3 * (t1 - t0), 1e3 * (t2 - t1), 1e3 * (t3 - t2)
+    session_round(0)
+    for r in range(4):
+        print("round %d: create %.3f ms, batch %.3f ms, close %.3f ms" % ((r,) + session_round(16 * r)))
