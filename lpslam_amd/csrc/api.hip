@@ -141,14 +141,10 @@ int lp_pool_alloc(lpslam_hip_ctx* c, size_t bytes, void** out, size_t* capacity)
     return LPSLAM_HIP_OK;
 }
 
-// A front-end stream of the context: an ordinary one, or -- lpslam_hip_set_mapping_reserve -- one that leaves CUs 0 .. r-1 of every
-// XCD alone (bit b of a CU mask is CU b / 8 of XCD b % 8, tools/dev/cumask_probe.hip)
-static hipError_t lp_fe_stream_create(hipStream_t* s, int reserve)
+// A front-end stream of the context (never CU-masked: the mapping reserve is kept by the kernels themselves, frontend.hip)
+static hipError_t lp_fe_stream_create(hipStream_t* s, int)
 {
-    if (reserve <= 0) return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
-    uint32_t mask[8];
-    for (int w = 0; w < 8; ++w) { mask[w] = 0; for (int b = 0; b < 32; ++b) if ((32 * w + b) / 8 >= reserve) mask[w] |= 1u << b; }
-    return hipExtStreamCreateWithCUMask(s, 8, mask);
+    return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
 }
 
 hipStream_t lp_stream_acquire(lpslam_hip_ctx* c)
@@ -390,6 +386,8 @@ void lpslam_hip_destroy(lpslam_hip_ctx* c)
                     c->d_kp_count, c->d_bf, c->d_stereo, c->d_stereo_idx, c->d_stereo_corr, c->d_st_row_start, c->d_st_row_list, c->d_tmp_desc, c->d_tmp_res,
                     c->d_map_xy[0], c->d_map_xy[1], c->d_map_frac[0], c->d_map_frac[1], c->d_raw, c->d_mask[0], c->d_mask[1]};
     for (void* b : bufs) if (b) (void)hipFree(b);
+    if (c->d_cu_table) (void)hipFree(c->d_cu_table);
+    if (c->d_fe_counters) (void)hipFree(c->d_fe_counters);
     for (int i = 0; i < LPSLAM_HIP_MAX_TIMERS; ++i) { if (c->ev_begin[i]) (void)hipEventDestroy(c->ev_begin[i]); if (c->ev_end[i]) (void)hipEventDestroy(c->ev_end[i]); }
     for (void* p : c->pin_free) (void)hipHostFree(p);
     c->pin_free.clear();
@@ -418,11 +416,12 @@ void lpslam_hip_destroy(lpslam_hip_ctx* c)
 }
 
 // The front end's kernels fill every compute unit's LDS with their workgroups, and a panel-pair workgroup of a running bundle
-// adjustment (128 KB of LDS) then finds no room until the kernel drains, stream priority or not: a mapping solve beside the front end
-// stands still for the front end's kernels.  With a reserve the context's front-end streams are created with a CU mask that leaves
-// `cus_per_xcd` compute units of every XCD to whoever else runs (the solves then spread their panel workgroups over all XCDs).
-// Measured, one session at 16 frames per front-end launch: 3.90 ms per step without, 3.76 with 4, 3.65 with 12;
-// the front end alone is 11 % / 43 % slower.  Call it on an idle context.
+// adjustment (128 KB of LDS; the band factorisation 130 KB) then finds no room until the kernel drains, stream priority or not: a mapping
+// solve beside the front end stands still for the front end's kernels.  With a reserve the extraction kernels leave `cus_per_xcd`
+// compute units of every XCD alone -- in SOFTWARE (frontend.hip, FeQueue): persistent workgroups that find themselves on a reserved
+// compute unit leave at once, the others take their work from a queue.  (Round 3 did it with CU masks on the context's streams; a
+// masked queue in the process makes every solve beside uploads slower, DESIGN.md section 10, so no stream is masked any more.)
+// Call it on an idle context.
 int lpslam_hip_set_mapping_reserve(lpslam_hip_ctx* c, int32_t cus_per_xcd)
 {
     if (!c) { set_error("null context"); return LPSLAM_HIP_ERR_INVALID; }
@@ -433,12 +432,8 @@ int lpslam_hip_set_mapping_reserve(lpslam_hip_ctx* c, int32_t cus_per_xcd)
     LP_HIP(hipStreamSynchronize(c->stream));
     if (c->fe_stream) LP_HIP(hipStreamSynchronize(c->fe_stream));
     if (c->copy_stream) LP_HIP(hipStreamSynchronize(c->copy_stream));
-    hipStream_t ns = nullptr, nf = nullptr;
-    LP_HIP(lp_fe_stream_create(&ns, cus_per_xcd));
-    if (c->fe_stream && lp_fe_stream_create(&nf, cus_per_xcd) != hipSuccess) { (void)hipStreamDestroy(ns); set_error("stream creation failed"); return LPSLAM_HIP_ERR_DEVICE; }
-    (void)hipStreamDestroy(c->stream);
-    c->stream = ns;
-    if (c->fe_stream) { (void)hipStreamDestroy(c->fe_stream); c->fe_stream = nf; }
+    const int rc = lp_fe_calibrate(c, cus_per_xcd);
+    if (rc) return rc;
     c->reserve_cus = cus_per_xcd;
     return LPSLAM_HIP_OK;
 }

@@ -49,19 +49,71 @@ __device__ __forceinline__ uint32_t pyr_down_dword(const uint8_t* __restrict__ s
     return packed;
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Mapping reserve in software (lpslam_hip_set_mapping_reserve).  The bundle adjustments that run beside the front end need compute
+// units with their LDS free (a panel-pair workgroup: 128 KB, the band factorisation: 130 KB), which they do not find while the
+// extraction kernels keep eight workgroups on every compute unit.  A CU mask on the front end's streams gave them room (round 3) but
+// a masked queue in the process slows every solve that runs beside uploads.  Instead the extraction kernels
+// reserve compute units THEMSELVES: launched as a chip-filling grid of persistent workgroups, a workgroup that finds itself on a
+// reserved compute unit (HW_REG_XCC_ID / HW_REG_HW_ID against a table made at calibration, api.hip) leaves at once, the others take
+// chunks of work items from one counter until it runs out.  Placement independent: whatever lands where, every item is done exactly
+// once by some workgroup that stays (at least one does: the grid covers every compute unit, the table reserves at most half of them).
+// ------------------------------------------------------------------------------------------------------------
+struct FeQueue {
+    const uint32_t* cu_table;        // [8 XCC][8 words]: bit (hw_id >> 8) & 255 set = reserved compute unit
+    int* counter;                    // next chunk (zeroed in front of the launch)
+    int n_items, chunk;
+};
+__device__ __forceinline__ bool fe_on_reserved_cu(const uint32_t* table)
+{
+    unsigned xcc, hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    const unsigned id = (hw >> 8) & 0xffu;
+    return (table[(xcc & 7u) * 8u + (id >> 5)] >> (id & 31u)) & 1u;
+}
+// first item of the next chunk for the whole workgroup (every thread calls it; barriers inside)
+__device__ __forceinline__ int fe_next_chunk(const FeQueue& q)
+{
+    __shared__ int s_chunk;
+    __syncthreads();                 // the previous item is finished by everybody (its LDS may be reused) and s_chunk has been read
+    if (threadIdx.x == 0) s_chunk = atomicAdd(q.counter, 1);
+    __syncthreads();
+    return s_chunk * q.chunk;
+}
+// calibration: where does workgroup b run?  (xcc << 16 | hw_id & 0xffff)
+__global__ void k_fe_where(unsigned* out)
+{
+    if (threadIdx.x == 0) {
+        unsigned xcc, hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        out[blockIdx.x] = (xcc & 0xfu) << 16 | (hw & 0xffffu);
+    }
+    // stay a little so that the grid spreads over every compute unit instead of draining through the first ones
+    for (int i = 0; i < 200; ++i) __builtin_amdgcn_s_sleep(8);
+}
+
 template <bool kTablesInLds>
 __global__ __launch_bounds__(1024) void k_pyr_bands(uint8_t* __restrict__ pyr, size_t image_slab, LevelTable lt, int image0,
                                                     const int2* __restrict__ rs_pack, int rs_entries,
-                                                    const int2* __restrict__ band_rows)
+                                                    const int2* __restrict__ band_rows, FeQueue fq, int n_bands)
 {
     extern __shared__ int2 s_tab[];      // the resize tables of all levels (57 KB at 1280x720, 8 levels)
+    if (fq.cu_table && fe_on_reserved_cu(fq.cu_table)) return;
     if (kTablesInLds) {
         for (int i = threadIdx.x; i < rs_entries; i += 1024) s_tab[i] = rs_pack[i];
         __syncthreads();
     }
-    uint8_t* img = pyr + (size_t)(image0 + blockIdx.y) * image_slab;
+  // direct launch: workgroup (band, image), once; queued: items band + n_bands * image from the counter until it runs out
+  for (bool once = true;; once = false) {
+    int item;
+    if (fq.cu_table) { item = fe_next_chunk(fq); if (item >= fq.n_items) break; }
+    else { if (!once) break; item = (int)(blockIdx.x + n_bands * blockIdx.y); }
+    const int band_x = item % n_bands, image_y = item / n_bands;
+    uint8_t* img = pyr + (size_t)(image0 + image_y) * image_slab;
     for (int level = 1; level < lt.n_levels; ++level) {
-        const int2 rows = band_rows[level * kPyrMaxBands + blockIdx.x];
+        const int2 rows = band_rows[level * kPyrMaxBands + band_x];
         const int dw = lt.w[level], dp = lt.pitch[level], sp = lt.pitch[level - 1];
         const uint8_t* src = img + lt.off[level - 1];
         uint8_t* dst = img + lt.off[level];
@@ -89,6 +141,7 @@ __global__ __launch_bounds__(1024) void k_pyr_bands(uint8_t* __restrict__ pyr, s
         __threadfence_block();
         __syncthreads();
     }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -128,10 +181,10 @@ __device__ __forceinline__ int fast_strength(const uint8_t* t /* points at centr
     return max(a, -b);
 }
 
-__global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ pyr, size_t image_slab, LevelTable lt,
-                                                    int ini_thr, int min_thr, uint32_t* __restrict__ cell_keys,
-                                                    int32_t* __restrict__ cell_count, int cells_per_image, int image0, int dbg,
-                                                    const uint8_t* __restrict__ mask0, const uint8_t* __restrict__ mask1)
+__device__ __forceinline__ void fast_cells_body(int cell_arg, int image_arg, const uint8_t* __restrict__ pyr, size_t image_slab, const LevelTable& lt,
+                                                int ini_thr, int min_thr, uint32_t* __restrict__ cell_keys,
+                                                int32_t* __restrict__ cell_count, int cells_per_image, int image0, int dbg,
+                                                const uint8_t* __restrict__ mask0, const uint8_t* __restrict__ mask1)
 {
     __shared__ __attribute__((aligned(16))) uint8_t tile[70 * TILE_PITCH];
     __shared__ __attribute__((aligned(16))) uint8_t smap[66 * SMAP_PITCH];
@@ -140,7 +193,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
     __shared__ uint16_t queue[4][16 * 64];       // pre-test survivors, one queue per wavefront (its 16 rows): no shared counter
     __shared__ int n_keep;
 
-    const int cell = blockIdx.x, image = image0 + blockIdx.y;
+    const int cell = cell_arg, image = image0 + image_arg;
     int level = 0;
     while (level + 1 < lt.n_levels && cell >= lt.cell_start[level + 1]) ++level;
     const int lc = cell - lt.cell_start[level];
@@ -302,6 +355,23 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
         }
     }
 }
+// direct launch: one workgroup per (cell, image); queued (mapping reserve): persistent workgroups take chunks of cells
+__global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ pyr, size_t image_slab, LevelTable lt,
+                                                    int ini_thr, int min_thr, uint32_t* __restrict__ cell_keys,
+                                                    int32_t* __restrict__ cell_count, int cells_per_image, int image0, int dbg,
+                                                    const uint8_t* __restrict__ mask0, const uint8_t* __restrict__ mask1, FeQueue fq)
+{
+    if (!fq.cu_table) { fast_cells_body(blockIdx.x, blockIdx.y, pyr, image_slab, lt, ini_thr, min_thr, cell_keys, cell_count, cells_per_image, image0, dbg, mask0, mask1); return; }
+    if (fe_on_reserved_cu(fq.cu_table)) return;
+    for (;;) {
+        const int first = fe_next_chunk(fq);
+        if (first >= fq.n_items) break;
+        for (int it = first; it < min(first + fq.chunk, fq.n_items); ++it) {
+            if (it != first) __syncthreads();          // the previous cell's LDS is free
+            fast_cells_body(it % cells_per_image, it / cells_per_image, pyr, image_slab, lt, ini_thr, min_thr, cell_keys, cell_count, cells_per_image, image0, dbg, mask0, mask1);
+        }
+    }
+}
 
 // ------------------------------------------------------------------------------------------------------------
 // K3  quad-tree distribution (orb_extractor::distribute_keypoints_via_tree), one 1024-thread workgroup per
@@ -354,15 +424,15 @@ __device__ void block_scan_array(int* a, int n, int* wave_tot, int* total)
 // count; ping-pong) live in LDS.  A pass therefore touches HBM/L2 only for the overflow candidates.
 #define DIST_CPT 24
 
-__global__ __launch_bounds__(1024) void k_distribute(LevelTable lt, const uint32_t* __restrict__ cell_keys,
-                                                     const int32_t* __restrict__ cell_count, int cells_per_image,
-                                                     uint32_t* __restrict__ cand_key, uint32_t* __restrict__ cand_node,
-                                                     int32_t* __restrict__ cand_count, int cand_per_image,
-                                                     uint32_t* __restrict__ sel_key, int32_t* __restrict__ sel_count,
-                                                     int slots_per_image, int image0)
+__device__ __forceinline__ void distribute_body(int image_arg, int level_arg, const LevelTable& lt, const uint32_t* __restrict__ cell_keys,
+                                                const int32_t* __restrict__ cell_count, int cells_per_image,
+                                                uint32_t* __restrict__ cand_key, uint32_t* __restrict__ cand_node,
+                                                int32_t* __restrict__ cand_count, int cand_per_image,
+                                                uint32_t* __restrict__ sel_key, int32_t* __restrict__ sel_count,
+                                                int slots_per_image, int image0)
 {
     extern __shared__ __attribute__((aligned(16))) int lds[];
-    const int level = blockIdx.y, image = image0 + blockIdx.x;
+    const int level = level_arg, image = image0 + image_arg;
     const int tid = threadIdx.x;
     const int N = lt.quota[level];
     const int Q = lt.qcap[level];          // node count never exceeds max(N + 2, 4 * roots) < Q
@@ -718,6 +788,22 @@ __global__ __launch_bounds__(1024) void k_distribute(LevelTable lt, const uint32
     }
     if (tid == 0) sel_count[image * lt.n_levels + level] = min(alive, cap);
 }
+// direct: workgroup (image, level), level 0 of every image dispatched first; queued: items image + n_images * level in that order
+__global__ __launch_bounds__(1024) void k_distribute(LevelTable lt, const uint32_t* __restrict__ cell_keys,
+                                                     const int32_t* __restrict__ cell_count, int cells_per_image,
+                                                     uint32_t* __restrict__ cand_key, uint32_t* __restrict__ cand_node,
+                                                     int32_t* __restrict__ cand_count, int cand_per_image,
+                                                     uint32_t* __restrict__ sel_key, int32_t* __restrict__ sel_count,
+                                                     int slots_per_image, int image0, FeQueue fq, int n_images)
+{
+    if (!fq.cu_table) { distribute_body(blockIdx.x, blockIdx.y, lt, cell_keys, cell_count, cells_per_image, cand_key, cand_node, cand_count, cand_per_image, sel_key, sel_count, slots_per_image, image0); return; }
+    if (fe_on_reserved_cu(fq.cu_table)) return;
+    for (;;) {
+        const int it = fe_next_chunk(fq);                // chunk = 1
+        if (it >= fq.n_items) break;
+        distribute_body(it % n_images, it / n_images, lt, cell_keys, cell_count, cells_per_image, cand_key, cand_node, cand_count, cand_per_image, sel_key, sel_count, slots_per_image, image0);
+    }
+}
 
 size_t lp_distribute_lds_bytes(int Q, int ncell)
 {
@@ -793,11 +879,11 @@ __device__ __forceinline__ void sincos_deg(float angle_deg, float* s_out, float*
 #define HB_PITCH 40            // row pitch of the horizontally blurred patch (u16): rows start 8-byte aligned
 #define DESC_WAVES 4
 
-__global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const uint8_t* __restrict__ pyr, size_t image_slab, LevelTable lt,
-                                                              const uint32_t* __restrict__ sel_key,
-                                                              const int32_t* __restrict__ sel_count, int slots_per_image,
-                                                              lpslam_hip_keypoint* __restrict__ kpts, uint8_t* __restrict__ desc,
-                                                              int32_t* __restrict__ kp_count, int image0)
+__device__ __forceinline__ void describe_body(int slot_block, int image_arg, const uint8_t* __restrict__ pyr, size_t image_slab, const LevelTable& lt,
+                                              const uint32_t* __restrict__ sel_key,
+                                              const int32_t* __restrict__ sel_count, int slots_per_image,
+                                              lpslam_hip_keypoint* __restrict__ kpts, uint8_t* __restrict__ desc,
+                                              int32_t* __restrict__ kp_count, int image0)
 {
     // per wavefront: the raw patch (2064 B), the horizontally blurred one (3440 B); the blurred patch (1369 B) takes the raw patch's
     // place, which nobody reads after the horizontal pass -- 5.5 KB instead of 6.9 KB per wavefront is 29 instead of 23 wavefronts
@@ -806,8 +892,8 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const uint8_t* __r
     __shared__ __attribute__((aligned(16))) uint16_t s_h[DESC_WAVES][PW * HB_PITCH];
     static_assert(BW * BW <= PW * RAW_PITCH, "the blurred patch reuses the raw patch's storage");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int image = image0 + blockIdx.y;
-    const int slot = blockIdx.x * DESC_WAVES + wave;
+    const int image = image0 + image_arg;
+    const int slot = slot_block * DESC_WAVES + wave;
     if (slot >= slots_per_image) return;          // wave-uniform; no block barriers below
     int level = 0;
     while (level + 1 < lt.n_levels && slot >= lt.slot_start[level + 1]) ++level;
@@ -938,6 +1024,22 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const uint8_t* __r
         kpts[o] = kp;
     }
 }
+// direct: workgroup = four keypoint slots of one image; queued: chunks of slot blocks (slot block b of image i = item b + blocks * i)
+__global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const uint8_t* __restrict__ pyr, size_t image_slab, LevelTable lt,
+                                                              const uint32_t* __restrict__ sel_key,
+                                                              const int32_t* __restrict__ sel_count, int slots_per_image,
+                                                              lpslam_hip_keypoint* __restrict__ kpts, uint8_t* __restrict__ desc,
+                                                              int32_t* __restrict__ kp_count, int image0, FeQueue fq, int blocks_per_image)
+{
+    if (!fq.cu_table) { describe_body(blockIdx.x, blockIdx.y, pyr, image_slab, lt, sel_key, sel_count, slots_per_image, kpts, desc, kp_count, image0); return; }
+    if (fe_on_reserved_cu(fq.cu_table)) return;
+    for (;;) {
+        const int first = fe_next_chunk(fq);
+        if (first >= fq.n_items) break;
+        for (int it = first; it < min(first + fq.chunk, fq.n_items); ++it)       // a wavefront's LDS is its own: no barrier between keypoints
+            describe_body(it % blocks_per_image, it / blocks_per_image, pyr, image_slab, lt, sel_key, sel_count, slots_per_image, kpts, desc, kp_count, image0);
+    }
+}
 
 // ------------------------------------------------------------------------------------------------------------
 // K0: undistort / rectify.  cv::remap(INTER_LINEAR, BORDER_CONSTANT 0) with CV_32FC1 maps, which OpenCV first turns
@@ -975,6 +1077,59 @@ __global__ __launch_bounds__(256) void k_remap(const uint8_t* __restrict__ raw, 
 // ------------------------------------------------------------------------------------------------------------
 // host launchers
 // ------------------------------------------------------------------------------------------------------------
+// the queue of one extraction launch under a mapping reserve (its counter zeroed on the stream in front of the launch); without a
+// reserve: {nullptr, ...}, the kernels then run as plain grids
+static FeQueue lp_fe_queue(lpslam_hip_ctx* c, int n_items, int chunk)
+{
+    FeQueue q{nullptr, nullptr, n_items, chunk};
+    if (c->reserve_cus <= 0 || !c->d_cu_table) return q;
+    int* ctr = c->d_fe_counters + 32 * (c->fe_counter_next.fetch_add(1) % 64);          // a ring: 64 launches in flight would be a lot
+    if (hipMemsetAsync(ctr, 0, sizeof(int), lp_fe_stream(c)) != hipSuccess) { (void)hipGetLastError(); return q; }
+    q.cu_table = c->d_cu_table; q.counter = ctr;
+    return q;
+}
+
+// Calibration of the software reserve: where do workgroups land?  8192 one-wavefront workgroups report (XCC, hardware id); of the
+// compute units seen on every XCC (32 on an MI355X, harvesting decides which ids) the r with the smallest ids are reserved.
+int lp_fe_calibrate(lpslam_hip_ctx* c, int r)
+{
+    if (!c->d_cu_table) {
+        LP_HIP(hipMalloc((void**)&c->d_cu_table, 64 * sizeof(uint32_t)));
+        LP_HIP(hipMalloc((void**)&c->d_fe_counters, 64 * 32 * sizeof(int)));
+    }
+    std::vector<uint32_t> table(64, 0u);
+    if (r > 0) {
+        const int n = 8192;
+        unsigned* d_out = nullptr;
+        LP_HIP(hipMalloc((void**)&d_out, n * sizeof(unsigned)));
+        hipLaunchKernelGGL(k_fe_where, dim3(n), dim3(64), 0, c->stream, d_out);
+        std::vector<unsigned> h((size_t)n);
+        hipError_t e = hipStreamSynchronize(c->stream);      // (a non-blocking stream: the copy below would not wait for it)
+        if (e == hipSuccess) e = hipMemcpy(h.data(), d_out, n * sizeof(unsigned), hipMemcpyDeviceToHost);
+        (void)hipFree(d_out);
+        if (e != hipSuccess) { set_error("calibration of the mapping reserve failed"); return LPSLAM_HIP_ERR_DEVICE; }
+        std::vector<std::vector<int>> ids(8);
+        for (unsigned v : h) {
+            const int xcc = (int)((v >> 16) & 7u), id = (int)((v >> 8) & 0xffu);
+            if (std::find(ids[(size_t)xcc].begin(), ids[(size_t)xcc].end(), id) == ids[(size_t)xcc].end()) ids[(size_t)xcc].push_back(id);
+        }
+        for (int x = 0; x < 8; ++x) {
+            std::sort(ids[(size_t)x].begin(), ids[(size_t)x].end());
+            if ((int)ids[(size_t)x].size() < 2 * r) { set_error("mapping reserve %d: only %zu compute units of XCC %d were seen", r, ids[(size_t)x].size(), x); return LPSLAM_HIP_ERR_DEVICE; }
+            // evenly over the shader engines (id = se << 5 | sh << 4 | cu): every engine's dispatcher keeps free compute units --
+            // a workgroup handed to an engine whose units are all busy waits there, whatever is free elsewhere
+            std::vector<std::vector<int>> by_se(8);
+            for (int id : ids[(size_t)x]) by_se[(size_t)(id >> 5)].push_back(id);
+            int chosen = 0;
+            for (size_t depth = 0; chosen < r && depth < 32; ++depth)
+                for (size_t se = 0; se < 8 && chosen < r; ++se)
+                    if (depth < by_se[se].size()) { const int id = by_se[se][depth]; table[(size_t)(x * 8 + (id >> 5))] |= 1u << (id & 31); ++chosen; }
+        }
+    }
+    LP_HIP(hipMemcpy(c->d_cu_table, table.data(), 64 * sizeof(uint32_t), hipMemcpyHostToDevice));
+    return LPSLAM_HIP_OK;
+}
+
 int lp_launch_pyramid(lpslam_hip_ctx* c, int first, int n_images)
 {
     if (c->lt.n_levels < 2 || n_images <= 0) return LPSLAM_HIP_OK;
@@ -984,12 +1139,14 @@ int lp_launch_pyramid(lpslam_hip_ctx* c, int first, int n_images)
     const int set = bands;
     const int2* rows = c->d_band_rows + (size_t)set * kMaxLevels * kPyrMaxBands;
     const size_t lds = (size_t)c->rs_entries * sizeof(int2);
+    FeQueue fq = lp_fe_queue(c, bands * n_images, 1);
+    const dim3 grid = fq.cu_table ? dim3(256, 1) : dim3(bands, n_images);       // queued: one persistent workgroup per compute unit
     if (lds <= 64 * 1024)
-        hipLaunchKernelGGL(k_pyr_bands<true>, dim3(bands, n_images), dim3(1024), lds, lp_fe_stream(c), c->d_pyr, c->image_slab, c->lt, first,
-                           c->d_rs_pack, c->rs_entries, rows);
+        hipLaunchKernelGGL(k_pyr_bands<true>, grid, dim3(1024), lds, lp_fe_stream(c), c->d_pyr, c->image_slab, c->lt, first,
+                           c->d_rs_pack, c->rs_entries, rows, fq, bands);
     else        // larger images: tables read through the cache instead
-        hipLaunchKernelGGL(k_pyr_bands<false>, dim3(bands, n_images), dim3(1024), 0, lp_fe_stream(c), c->d_pyr, c->image_slab, c->lt, first,
-                           c->d_rs_pack, c->rs_entries, rows);
+        hipLaunchKernelGGL(k_pyr_bands<false>, grid, dim3(1024), 0, lp_fe_stream(c), c->d_pyr, c->image_slab, c->lt, first,
+                           c->d_rs_pack, c->rs_entries, rows, fq, bands);
     LP_HIP(hipGetLastError());
     return LPSLAM_HIP_OK;
 }
@@ -1005,19 +1162,21 @@ int lp_launch_remap(lpslam_hip_ctx* c, int image, int eye)
 
 int lp_launch_fast(lpslam_hip_ctx* c, int first, int n_images)
 {
-    dim3 grid(c->cells_per_image, n_images);
+    FeQueue fq = lp_fe_queue(c, c->cells_per_image * n_images, 4);
+    const dim3 grid = fq.cu_table ? dim3(256 * 8, 1) : dim3(c->cells_per_image, n_images);       // queued: the eight workgroups a compute unit holds
     hipLaunchKernelGGL(k_fast_cells, grid, dim3(256), 0, lp_fe_stream(c), c->d_pyr, c->image_slab, c->lt, c->cfg.ini_fast_threshold,
-                       c->cfg.min_fast_threshold, c->d_cell_keys, c->d_cell_count, c->cells_per_image, first, 0, c->d_mask[0], c->d_mask[1]);
+                       c->cfg.min_fast_threshold, c->d_cell_keys, c->d_cell_count, c->cells_per_image, first, 0, c->d_mask[0], c->d_mask[1], fq);
     LP_HIP(hipGetLastError());
     return LPSLAM_HIP_OK;
 }
 
 int lp_launch_distribute(lpslam_hip_ctx* c, int first, int n_images)
 {
-    dim3 grid(n_images, c->lt.n_levels);                 // level 0 of every image first: the long work-groups start first
+    FeQueue fq = lp_fe_queue(c, n_images * c->lt.n_levels, 1);
+    const dim3 grid = fq.cu_table ? dim3(256, 1) : dim3(n_images, c->lt.n_levels);       // level 0 of every image first: the long work-groups start first
     hipLaunchKernelGGL(k_distribute, grid, dim3(1024), c->distribute_lds, lp_fe_stream(c), c->lt, c->d_cell_keys, c->d_cell_count,
                        c->cells_per_image, c->d_cand_key, c->d_cand_node, c->d_cand_count, c->cand_per_image, c->d_sel_key, c->d_sel_count,
-                       c->slots_per_image, first);
+                       c->slots_per_image, first, fq, n_images);
     LP_HIP(hipGetLastError());
     return LPSLAM_HIP_OK;
 }
@@ -1025,9 +1184,11 @@ int lp_launch_distribute(lpslam_hip_ctx* c, int first, int n_images)
 int lp_launch_describe(lpslam_hip_ctx* c, int first, int n_images)
 {
     for (int i = first; i < first + n_images && (size_t)i < c->h_kp_valid.size(); ++i) c->h_kp_valid[(size_t)i] = 0;      // counts are rewritten
-    dim3 grid((c->slots_per_image + DESC_WAVES - 1) / DESC_WAVES, n_images);
+    const int blocks = (c->slots_per_image + DESC_WAVES - 1) / DESC_WAVES;
+    FeQueue fq = lp_fe_queue(c, blocks * n_images, 16);
+    const dim3 grid = fq.cu_table ? dim3(256 * 7, 1) : dim3(blocks, n_images);          // queued: seven workgroups (28 wavefronts) per compute unit
     hipLaunchKernelGGL(k_describe, grid, dim3(64 * DESC_WAVES), 0, lp_fe_stream(c), c->d_pyr, c->image_slab, c->lt, c->d_sel_key,
-                       c->d_sel_count, c->slots_per_image, c->d_kpts, c->d_desc, c->d_kp_count, first);
+                       c->d_sel_count, c->slots_per_image, c->d_kpts, c->d_desc, c->d_kp_count, first, fq, blocks);
     LP_HIP(hipGetLastError());
     return LPSLAM_HIP_OK;
 }

@@ -61,6 +61,9 @@ struct lpslam_hip_ctx {
     lpslam_hip_frontend_config cfg{};
     lpslam::LevelTable lt{};
     hipStream_t stream = nullptr;      // the stream every entry point enqueues on
+    uint32_t* d_cu_table = nullptr;    // mapping reserve in software: [8 XCC][8 words] bit per compute unit the extraction kernels leave alone (frontend.hip)
+    int* d_fe_counters = nullptr;      // work-queue counters of the queued extraction launches (ring of 64, 128 bytes apart)
+    std::atomic<unsigned> fe_counter_next{0};
     int reserve_cus = 0;               // lpslam_hip_set_mapping_reserve: CUs of every XCD the front end's streams leave to the mapping solves
     hipStream_t fe_stream = nullptr;   // prefetch: front end of the NEXT frame beside the tracking of this one (lp_fe_stream)
     hipEvent_t fe_done = nullptr;
@@ -156,6 +159,7 @@ void lp_pin_big_free(lpslam_hip_ctx* c, void* p, size_t capacity);
 void* lp_pin_alloc(lpslam_hip_ctx* c);          // 8 KB of page-locked host memory, recycled through the context (nullptr on failure)
 void lp_pin_free(lpslam_hip_ctx* c, void* p);
 int lp_launch_pyramid(lpslam_hip_ctx* c, int first, int n_images);
+int lp_fe_calibrate(lpslam_hip_ctx* c, int reserve_cus_per_xcd);
 int lp_launch_remap(lpslam_hip_ctx* c, int image, int eye);
 int lp_launch_fast(lpslam_hip_ctx* c, int first, int n_images);
 int lp_launch_distribute(lpslam_hip_ctx* c, int first, int n_images);
