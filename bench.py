@@ -34,8 +34,9 @@ KF_INTERVAL = 6               # keyframe every 6th frame
 RESIDENT = 48                 # stereo frames of the sequence resident in HBM (3 steps of 16; the ring is re-walked)
 BA_KF, BA_PTS, BA_OBS, BA_ITERS = 50, 5000, 40000, 10
 BA_VARIANTS = 4               # distinct windows (problem seeds) the keyframes rotate through
-# compute units of every XCD the front end leaves to the mapping solves that run beside it (lpslam_hip_set_mapping_reserve; what the
-# tracker sets for its mapping thread).  The front-end-only and batched extras run with 0.
+# compute units of every XCD the front end's extraction kernels leave to the mapping solves that run beside them
+# (lpslam_hip_set_mapping_reserve: kept in software by persistent work-queue grids since round 4, no CU-masked stream).  The
+# front-end-only and batched extras run with 0.
 MAPPING_RESERVE = int(os.environ.get("LPSLAM_BENCH_RESERVE", "16"))
 HBM_PEAK_GBS = 8000.0         # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 measured copy)
 FP64_PEAK_TFLOPS = 78.6       # MI355X FP64 matrix = vector peak (MI355X_MICROARCH.md / SURVEY.md 8(d))
@@ -560,7 +561,10 @@ def main():
             "ba_ms_per_keyframe": round(ba_total_ms, 4) if ba_total_ms is not None else None,
             "ba_ms_per_keyframe_pipelined": round(ba_pipe_ms, 4) if ba_pipe_ms is not None else None,
             "roofline": roof,
+            # HIP-event time between consecutive launches of an event-instrumented solve / front-end pass (each entry includes the gap in
+            # front of its kernel: the BA entries sum to more than the graph-replayed solve of the timed loop takes)
             "gpu_ms_per_step_by_kernel": {k: round(v, 4) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1])},
+            "gpu_ms_per_step_by_kernel_note": "event-instrumented passes outside the timed region, launch gaps included; not a decomposition of ms_per_step",
             "ba_kernel_us_per_iteration": {("k_chol_factor" if n == "chol" else n): round(1e3 * d["ms_per_solve"] / max(ba_iters_done, 1), 2) for n, d in ba_prof.items()} if ba_prof else None,
             # SURVEY.md 8(d) whole-extraction figure: B_img = pyramid + FAST + blur + patches + outputs per image, over the
             # summed time of the four extraction kernels (the blur's 2P bytes are part of B_img although it is fused away here)
@@ -569,6 +573,7 @@ def main():
                                    "frac": round(wl.extract_bytes() / (fe_extract_free_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                                    "extract_ms_per_step_under_mapping_reserve": round(fe_extract_ms, 4),
                                    "note": "the four extraction kernels on all 256 CUs; in the timed loop they run on 256 - 8 x mapping_reserve CUs beside the mapping solves"},
+            "value_upload_inclusive": round(pcie_fps, 2),          # the same K steps with every extracted frame copied over PCIe inside the loop (below)
             "pcie_inclusive_frames_per_s": round(pcie_fps, 2),
             "pcie_inclusive": {"frames_per_s": round(pcie_fps, 2), "ms_per_step": round(1e3 * elapsed_pcie / args.steps, 4), "ratio_to_value": round(pcie_fps / value, 4),
                                "host_bytes_per_step": 2 * F * W * H,
@@ -692,7 +697,7 @@ def main():
                                    # the batch's arithmetic against the FP64 matrix-core peak: S windows x BA_ITERS iterations of the
                                    # per-iteration flop count above, over the whole round (create + solve + read-back + destroy)
                                    "ba_roofline": ({"TFLOPs": round(S * BA_ITERS * fl / t_ba_only / 1e12, 3), "frac_of_fp64_peak": round(S * BA_ITERS * fl / t_ba_only / 1e12 / FP64_PEAK_TFLOPS, 5)} if fl else None),
-                                   "note": "16 sessions, 6 stereo frames + 1 fresh local BA each per round; the 16 windows are one lpslam_hip_ba_optimize_batch call"}
+                                   "note": "16 sessions, 6 stereo frames + 1 fresh local BA each per round; the windows are set up on 8 host threads (every session has its mapping thread) and solved by one lpslam_hip_ba_optimize_batch call"}
                 wl.set_tracks("random")
                 creators.shutdown()
             except Exception as e:      # noqa: BLE001
@@ -775,11 +780,20 @@ def main():
         best, legs = cpu_baseline()
         out["cpu_baseline"] = best
         out["cpu_baseline_legs"] = legs
-        out["gpu_over_cpu"] = round(out["value"] / best["value"], 2)
+        best["note"] = ("unoptimised scalar restatement of the OpenVSLAM / g2o algorithms (the oracle), not OpenVSLAM: front end ~%d ms per stereo frame on one thread, "
+                        "several times what an OpenCV-SIMD ORB extractor needs; a reported baseline, not the target" % round(legs["1_thread_native"]["front_end_ms_per_frame"]))
+        out["gpu_over_cpu"] = {"ratio": round(out["value"] / best["value"], 2), "cpu_leg": "%d threads, -O3 -march=native, oracle port" % best["cores"],
+                               "ratio_vs_1_thread": round(out["value"] / legs["1_thread_native"]["value"], 1)}
 
     # ---- N > 1, outside the timed region: BASELINE configs[4], the landmark-partitioned global BA over all ranks with the C++ RCCL
     # driver (lpslam_hip_ba_optimize_partitioned: packed-triangle all-reduce on the problem's stream).  A watchdog prints the timed
     # line and leaves with a NON-ZERO status if the section does not finish (the measured headline is kept, the run is not green).
+    if dist is not None and rank == 0 and backend != "nccl":
+        # rehearsal (gloo): the partitioned global BA is not run, but what its all-reduce would move is known from the sizes alone
+        n = 6 * 199
+        out["global_ba_partitioned"] = {"ranks": world, "skipped": "rehearsal backend %s" % backend,
+                                        "allreduce_bytes_per_trial": int(8 * (n * (n + 1) // 2 + 3 * 1216 + 8)),
+                                        "allreduce_calls": "2 + 2 x trials (packed system; trial chi2 + scale; once: diagonal SUM and MAX)"}
     if dist is not None and not args.no_extras and backend == "nccl":
         done_flag = threading.Event()
 

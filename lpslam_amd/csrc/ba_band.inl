@@ -309,7 +309,7 @@ __device__ __forceinline__ int bc_ring(int base, int k) { const int v = base + k
 
 // What the backward substitution needs of strip s2, formed off the critical path (by `nw` wavefronts, this one is number w of them):
 //   M = L_ss^-T [L_below,s; y_s]^T (16 x 64, matrix cores; the rhs row is row 63 of the strip's riding rows) -> memory
-//   [s2][16][64], stored write-through.  Then x_s = M (-x_below; 1): one 16 x 64 matrix-vector product per strip on the chain
+//   [s2][column % 16][row][column / 16] (the order the backward pass reads it in: lane = 4 row + column / 16), stored write-through.  Then x_s = M (-x_below; 1): one 16 x 64 matrix-vector product per strip on the chain
 //   instead of a product with L and one with L_ss^-T.
 __device__ __forceinline__ void bc_back_operands(int s2, int w, int nw, int lane, const double* Lx, const double* Tinv, GPTR(double) Mg)
 {
@@ -321,7 +321,7 @@ __device__ __forceinline__ void bc_back_operands(int s2, int w, int nw, int lane
         for (int k4 = 0; k4 < 16; k4 += 4)
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(T[lr * 17 + k4 + lk], Lx[(16 * j + lr) * 17 + k4 + lk], acc, 0, 0, 0);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) st_sc1(Mg + (size_t)s2 * 1024 + (lk + 4 * q) * 64 + 16 * j + lr, acc[q]);
+        for (int q = 0; q < 4; ++q) st_sc1(Mg + (size_t)s2 * 1024 + lr * 64 + 4 * (lk + 4 * q) + j, acc[q]);     // element (row, col = 16 j + lr) at [lr][row][j]: the backward pass reads [jj][lane]
     }
 }
 
@@ -472,33 +472,43 @@ __global__ __launch_bounds__(BC_THREADS) void k_chol_band(const BaView* __restri
         if (wave < 4) bc_back_operands(ns - 1, wave, 4, lane, LxS0 + ((ns - 1) & 1) * 64 * 17, Tinv, Mg);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wavefront's stores of M have left for the L2
         __syncthreads();
-        const int bi = tid >> 4, bq = tid & 15;              // row of the strip, quarter-row of four columns
-        double mv[8][4];
-        auto fetch = [&](int s2, double (&dst)[4]) {
+        // The strips go round robin to the eight wavefronts (the last strip to wavefront 0): every wavefront holds the M blocks of its
+        // <= 3 strips in registers, all loads issued up front, so no memory round trip sits on the chain; per strip its owner forms the
+        // 16 x 64 matrix-vector product (lane = row i, quarter q of the columns: sixteen products in four independent sums, quarters
+        // added by a quad butterfly, a fixed tree), x_s goes through LDS, one LDS-only barrier hands over to the next strip's owner.
+        {
+            const int bi = lane >> 2, bq = lane & 3;
+            double mv[3][16];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) dst[j] = (s2 >= 0 && tid < 256) ? ld_sc1(Mg + (size_t)s2 * 1024 + bi * 64 + 4 * bq + j) : 0.0;
-        };
+            for (int k = 0; k < 3; ++k) {
+                const int s2 = ns - 1 - wave - 8 * k;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) fetch(ns - 1 - u, mv[u]);
-        BC_STAMPX(2);
-        for (int sb = ns - 1; sb >= 0; sb -= 8) {
+                for (int j = 0; j < 16; ++j) mv[k][j] = s2 >= 0 ? ld_sc1(Mg + (size_t)s2 * 1024 + j * 64 + lane) : 0.0;      // 64 lanes, 512 contiguous bytes per load
+            }
+            BC_STAMPX(2);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int s = sb - u;
-                if (s < 0) break;
-                const int c0 = 16 * s;
-                double p = 0;
+            for (int k = 0; k < 3; ++k) {
+                for (int w = 0; w < 8; ++w) {
+                    const int s = ns - 1 - w - 8 * k;
+                    if (s < 0) break;
+                    if (wave == w) {
+                        const int c0 = 16 * s;
+                        double p4[4] = {0, 0, 0, 0};
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {        // column 63 of M is L_ss^-T y_s (the rhs row rode along as row 63): multiplier -1
-                    const int r = c0 + 16 + 4 * bq + j;
-                    p += mv[u][j] * ((bq == 15 && j == 3) ? -1.0 : (r < dim ? xv[r] : 0.0));
+                        for (int j = 0; j < 16; ++j) {       // column 63 of M is L_ss^-T y_s (the rhs row rode along as row 63): multiplier -1
+                            const int r = c0 + 16 + 16 * bq + j;
+                            const double xr = (bq == 3 && j == 15) ? -1.0 : (r < dim ? xv[r] : 0.0);
+                            p4[j & 3] = fma(mv[k][j], xr, p4[j & 3]);
+                        }
+                        double p = (p4[0] + p4[1]) + (p4[2] + p4[3]);
+                        p += bc_dpp_mov<0xB1>(p); p += bc_dpp_mov<0x4E>(p);
+                        if (bq == 0) xv[c0 + bi] = -p;
+                    }
+                    BC_BARRIER();
                 }
-                fetch(s - 8, mv[u]);
-                p = bc_row16_sum(p);
-                if (bq == 0 && tid < 256) xv[c0 + bi] = -p;
-                BC_BARRIER();
             }
         }
+        __syncthreads();
     }
     BC_STAMPX(3);
     for (int i = tid; i < dim; i += BC_THREADS) xp[i] = xv[i];

@@ -58,6 +58,11 @@ _SHARED_CASES = {
     "rejected_trials": (dict(n_kf=6, n_pts=150, n_obs=800, w=640, h=480, seq_id=46, pose_noise=(0.5, 3.0), point_noise=3.0), 2, 8),
     "40kf": (dict(n_kf=40, n_pts=3000, n_obs=20000, w=1280, h=720, seq_id=11), 2, 8),
     "global_200kf": (dict(n_kf=200, n_pts=30000, n_obs=240000, w=1920, h=1080, seq_id=2, kf_stride=2), 2, 10),
+    # contiguous tracks: the shards' reduced systems are block-banded (sparse); the partitioned driver all-reduces the dense buffer, so
+    # a shard that qualifies for the band path (40 keyframes) is switched to the dense solver by the driver, and the unpartitioned
+    # solve it is compared with below takes the band path
+    "contiguous_40kf": (dict(n_kf=40, n_pts=3000, n_obs=20000, w=1280, h=720, seq_id=11, tracks="contiguous", top_up=True), 2, 8),
+    "contiguous_global_200kf": (dict(n_kf=200, n_pts=30000, n_obs=240000, w=1920, h=1080, seq_id=2, kf_stride=2, tracks="contiguous"), 3, 10),
 }
 
 
