@@ -2193,7 +2193,7 @@ int enqueue_solve(const BaLaunch& L, int fused)
     hipStream_t s = L.s;
     if (L.any_band) {
         bd_set_attributes();
-        hipLaunchKernelGGL(k_chol_band, dim3(1, L.count), dim3(BC_THREADS), BC_LDS_BYTES, s, L.d_views);
+        hipLaunchKernelGGL(k_chol_band, dim3(2, L.count), dim3(BC_THREADS), BC_LDS_BYTES, s, L.d_views);      // workgroup 0: the bottom-up helper of a twisted factorisation
         if (!L.any_dense) L.mark(LPSLAM_HIP_BA_K_CHOL);
     }
     if (L.dim > 0) {
@@ -2483,7 +2483,7 @@ int lpslam_hip_ba_create(lpslam_hip_ctx* ctx, const double* poses, const uint8_t
     const size_t o_chiobs = cv.take(no * 8), o_depth = cv.take(no);
     const size_t o_blk_count = cv.take(nblk * 4), o_blk_start = cv.take((nblk + 1) * 4), o_blk_part = cv.take(nblk * 4 * 36 * 8);
     const size_t o_terms = cv.take(std::max<size_t>(terms_cap, 1) * sizeof(int4));
-    const size_t o_band_ent = cv.take(plan.hbw >= 0 ? no * sizeof(int4) : 0), o_band_part = cv.take(n_grp * BD_PART * 8);
+    const size_t o_band_ent = cv.take(plan.hbw >= 0 ? no * sizeof(int4) : 0), o_band_part = cv.take((n_grp + 1) * BD_PART * 8) /* + the exchange block of the twisted band factorisation */;
     {
         const int rc = lp_pool_alloc(ctx, cv.off, &b->block, &b->block_cap);
         if (rc) { lpslam_hip_ba_destroy(b); return rc; }

@@ -299,8 +299,9 @@ __global__ __launch_bounds__(256) void k_schur_band_reduce(const BaView* __restr
 constexpr int BC_RING = 96;                 // rows / columns of the window ring: the 80 live ones + the 16 entering
 constexpr int BC_RS = BC_RING + 2;          // row stride: rows 16-byte aligned (the strip's rows are read 16 bytes at a time)
 constexpr int BC_MAXS = 19;                 // strips: dim <= 304
+constexpr int BC_TWIST_MIN = 12;            // strips from which on the factorisation runs from both ends (k_chol_band)
 constexpr int BC_THREADS = 512;             // 8 wavefronts: 0 / 1 factor, 2 / 3 bring rows in, 4 .. 7 form the backward operands; all eight update tiles
-constexpr int BC_LDS_DOUBLES = BC_RING * BC_RS + 2 * 64 * 17 + BC_MAXS * 16 * 17 + 2 * 320;
+constexpr int BC_LDS_DOUBLES = BC_RING * BC_RS + 2 * 64 * 17 + BC_MAXS * 16 * 17 + 2 * 384;
 constexpr int BC_LDS_BYTES = BC_LDS_DOUBLES * 8;
 __host__ __device__ inline bool bc_fits(int dim) { return dim > 0 && dim <= 16 * BC_MAXS; }
 
@@ -330,47 +331,68 @@ __global__ __launch_bounds__(BC_THREADS) void k_chol_band(const BaView* __restri
     const BaView& vw = views[blockIdx.y];
     const int dim = vw.dim, n = vw.dim_pad, hbw = vw.band_hbw;
     GPTR(double) S = vw.S; GPTR(double) xp = vw.xp; GPTR(double) scal = vw.scal; GPTR(BaCtl) ctl = vw.ctl;
-    asm volatile("" :: "s"(dim), "s"(n), "s"(hbw), "s"(S), "s"(xp), "s"(scal), "s"(ctl), "s"(vw.Minv));
+    GPTR(double) Dg = vw.band_part + (size_t)vw.band_groups_cap * BD_PART;      // exchange block of the two chains (one more partial slot)
+    GPTR(int) flag = vw.blk_ticket;                      // the pair lists' tickets are idle on the band path: [0] = "the helper's block is there"
+    asm volatile("" :: "s"(dim), "s"(n), "s"(hbw), "s"(S), "s"(xp), "s"(scal), "s"(ctl), "s"(vw.Minv), "s"(Dg), "s"(flag));
     if (hbw < 0 || dim == 0) return;
+    // TWISTED factorisation (systems of >= BC_TWIST_MIN strips): workgroup 0 of the problem -- dispatched before workgroup 1 -- eliminates
+    // the LAST sB strips of the system, bottom-up, which is the same top-down algorithm on the flipped matrix F(r, c) = S(n-1-r, n-1-c);
+    // workgroup 1 eliminates from the top.  A band of half-width <= 64 decouples the two ends; where they meet the helper's Schur
+    // complement update on the 64 x 64 block in front of its end (and on the rhs there) is handed over through memory, the top-down
+    // chain adds it to its window and factors the rest.  19 strips become a chain of 12.  The helper waits for nobody; the main chain
+    // waits for a workgroup that was dispatched before it: no deadlock whatever the placement.
+    const int team = blockIdx.x;
+    const int ns_all = (dim + 15) >> 4;
+    const int sB = ns_all >= BC_TWIST_MIN ? (ns_all - 5) / 2 : 0;
+    if (team == 0 && sB == 0) return;
     if (ba_flags(ctl).idle()) return;
+    const bool flip = team == 0;
+    const int dimA = dim - 16 * sB;                      // unknowns the top-down chain factors (what lies beyond is the helper's: identity to it)
+    const int nloc = flip ? dim : dimA;
+    const int sM = sB ? (dimA - 64) / 16 : -1;           // the strip in front of which the top-down chain takes the helper's update in
     extern __shared__ __attribute__((aligned(16))) double bc_lds[];
     double* const Win = bc_lds;                          // ring window, element (r, c) at [r % 96][c % 96]
     double* const LxS0 = Win + BC_RING * BC_RS;          // riding rows of the strip just factored [64][17], two buffers: wavefronts 2 / 3
     double* const Tinv = LxS0 + 2 * 64 * 17;             // still read strip s - 1's while wavefront 0 writes strip s's; L_ss^-T of every strip [s][16][17]
     double* const rhsv = Tinv + BC_MAXS * 16 * 17;       // the rhs row as it is updated / y
-    double* const xv = rhsv + 320;                       // solution (zero beyond dim)
-    GPTR(double) Mg = vw.Minv;                           // M_s = L_ss^-T L_below,s^T of every strip [s][16][64] (the dense path's L^-T buffer)
+    double* const xv = rhsv + 384;                       // solution (zero beyond the system; 384 long: the backward pass reads 64 entries behind the last strip)
     __shared__ int s_fail;
     // the barrier of the strip loop: LDS traffic drained, nothing else -- __syncthreads() also waits for every global load and store
     // in flight (the rows on their way in, the write-through stores of M, the prefetched M blocks of the backward pass)
 #define BC_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int lr = lane & 15, lk = lane >> 4;
-    const int ns = (dim + 15) >> 4;
+    const int ns = flip ? sB : (dimA + 15) >> 4;         // strips this workgroup factors
     // S(r, c), r >= c, of the band; identity beyond dim.  All loads of a batch are issued before the first store to LDS: written as
     // load -> store per element every element is a round trip of its own (ten per strip: 7 us of a 7 us strip, measured).
-    auto load_s = [&](int r, int c) -> double { return (r < dim && c >= 0) ? S[(size_t)r * n + c] : ((r == c) ? 1.0 : 0.0); };
+    auto load_s = [&](int r, int c) -> double {
+        if (!(r < nloc && c >= 0)) return r == c ? 1.0 : 0.0;
+        return flip ? S[(size_t)(dim - 1 - c) * n + (dim - 1 - r)] : S[(size_t)r * n + c];       // flipped lower (r, c) = upper (n-1-r, n-1-c) = lower (n-1-c, n-1-r)
+    };
+    auto load_rhs = [&](int i) -> double { return i < nloc ? S[(size_t)dim * n + (flip ? dim - 1 - i : i)] : 0.0; };
+    GPTR(double) Mg = vw.Minv + (flip ? (size_t)BC_MAXS * 1024 : 0);      // M_s of every strip (the dense path's L^-T buffer); the helper's behind the main chain's
 #ifdef LPSLAM_BC_STAMPS
-    if (tid == 0) S[(size_t)(dim + 2) * n + 8 * 20 + 4] = (double)wall_clock64();
+    if (tid == 0) S[(size_t)(dim + 2) * n + 8 * (team == 1 ? 20 : 21) + 4] = (double)wall_clock64();
 #endif
     if (tid == 0) s_fail = 0;
-    for (int i = tid; i < 320; i += BC_THREADS) { rhsv[i] = i < dim ? S[(size_t)dim * n + i] : 0.0; xv[i] = 0.0; }
+    for (int i = tid; i < 384; i += BC_THREADS) { rhsv[i] = load_rhs(i); xv[i] = 0.0; }
     // rows 0 .. 79, columns 0 .. r (lower part; the upper part of the first window is never read): 80 columns per row, 13 per thread
     {
         double val[13];
 #pragma unroll
-        for (int q = 0; q < 13; ++q) { const int i = tid + BC_THREADS * q, r = i / 80, c = i - 80 * r; val[q] = (i < 6400 && c <= r) ? load_s(r, c) : 0.0; }
+        // (neighbouring threads read neighbouring addresses: along a row of S, which for the flipped matrix is along a COLUMN of F)
+        for (int q = 0; q < 13; ++q) { const int i = tid + BC_THREADS * q, a = i / 80, b2 = i - 80 * a, r = flip ? b2 : a, c = flip ? a : b2; val[q] = (i < 6400 && c <= r) ? load_s(r, c) : 0.0; }
 #pragma unroll
-        for (int q = 0; q < 13; ++q) { const int i = tid + BC_THREADS * q, r = i / 80, c = i - 80 * r; if (i < 6400) Win[r * BC_RS + c] = val[q]; }
+        for (int q = 0; q < 13; ++q) { const int i = tid + BC_THREADS * q, a = i / 80, b2 = i - 80 * a, r = flip ? b2 : a, c = flip ? a : b2; if (i < 6400) Win[r * BC_RS + c] = val[q]; }
     }
     __syncthreads();
     int base = 0;                                        // c0 % 96
 #ifdef LPSLAM_BC_STAMPS
     // development: wall-clock stamps (100 MHz) of wavefront 0 per strip into the padding rows of S (read back by tools/dev/band_stamps.py)
     GPTR(double) stamp = S + (size_t)(dim + 2) * n;
-#define BC_STAMP(slot) do { if (tid == 0) stamp[8 * s + (slot)] = (double)wall_clock64(); } while (0)
-#define BC_STAMP_W(w, slot) do { if (tid == 64 * (w)) stamp[8 * s + (slot)] = (double)wall_clock64(); } while (0)
-#define BC_STAMPX(idx) do { if (tid == 0) stamp[8 * 20 + (idx)] = (double)wall_clock64(); } while (0)
+#define BC_STAMP(slot) do { if (tid == 0 && team == 1) stamp[8 * s + (slot)] = (double)wall_clock64(); } while (0)
+#define BC_STAMP_W(w, slot) do { if (tid == 64 * (w) && team == 1) stamp[8 * s + (slot)] = (double)wall_clock64(); } while (0)
+#define BC_STAMPX(idx) do { if (tid == 0) stamp[8 * (team == 1 ? 20 : 21) + (idx)] = (double)wall_clock64(); } while (0)
 #else
 #define BC_STAMPX(idx) do {} while (0)
 #define BC_STAMP(slot) do {} while (0)
@@ -387,7 +409,7 @@ __global__ __launch_bounds__(BC_THREADS) void k_chol_band(const BaView* __restri
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const bool rhs_row = tr == 3 && q == 3 && lk == 3;
-            dst[q] = rhs_row ? rhsv + min(col, 319) : Win + bc_ring(base, woff + 16 * tr + lk + 4 * q) * BC_RS + cc;
+            dst[q] = rhs_row ? rhsv + min(col, 383) : Win + bc_ring(base, woff + 16 * tr + lk + 4 * q) * BC_RS + cc;
         }
         double av[4], bv[4];
 #pragma unroll
@@ -400,12 +422,38 @@ __global__ __launch_bounds__(BC_THREADS) void k_chol_band(const BaView* __restri
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const bool rhs_row = tr == 3 && q == 3 && lk == 3;
-            if (col_ok && (!rhs_row || col < dim)) *dst[q] = acc[q];
+            if (col_ok && (!rhs_row || col < 384)) *dst[q] = acc[q];
         }
     };
     BC_STAMPX(0);
     for (int s = 0; s < ns; ++s) {
         const int c0 = 16 * s;
+        if (s == sM && !flip) {
+            // The helper's window over the 64 x 64 block [dimA - 64, dimA) and its rhs there: our window takes (helper's value - untouched
+            // entry) on top of its own.  The untouched entries are fetched before the wait, the helper's after it (one lane polls).
+            double sv[8], dv[8];                                 // eight elements per thread, every load of a batch in flight together
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int idx = tid + BC_THREADS * q, i = idx >> 6, j = idx & 63;      // helper's window coordinates, lower part i >= j
+                sv[q] = j <= i ? S[(size_t)(dimA - 1 - j) * n + (dimA - 1 - i)] : 0.0;   // our coordinates: (pj, pi), pi <= pj
+            }
+            const double sr = tid < 64 ? S[(size_t)dim * n + (dimA - 1 - tid)] : 0.0;
+            if (tid == 0) { while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(2); }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { const int idx = tid + BC_THREADS * q; dv[q] = (idx & 63) <= (idx >> 6) ? ld_sc1(Dg + idx) : 0.0; }
+            const double dr = tid < 64 ? ld_sc1(Dg + 64 * 64 + tid) : 0.0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int idx = tid + BC_THREADS * q, i = idx >> 6, j = idx & 63;
+                if (j > i) continue;
+                const int pi = dimA - 1 - i, pj = dimA - 1 - j;
+                Win[bc_ring(base, pj - c0) * BC_RS + bc_ring(base, pi - c0)] += dv[q] - sv[q];
+            }
+            if (tid < 64) rhsv[dimA - 1 - tid] += dr - sr;
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // for the next launch
+        }
         BC_STAMP(0);
         double* const LxS = LxS0 + (s & 1) * 64 * 17;
         const double* const LxP = LxS0 + ((s & 1) ^ 1) * 64 * 17;       // the previous strip's
@@ -438,7 +486,7 @@ __global__ __launch_bounds__(BC_THREADS) void k_chol_band(const BaView* __restri
         } else if (wave < 4) {
             // wavefronts 2, 3: the 16 rows that enter the window for the strip after this one (rows c0+80 .. c0+95, columns r-79 .. r:
             // 1280 values, ten per thread, in flight while ...) the last two tiles of the previous strip's trailing update are applied
-            const int t = tid - 128, rr = t >> 3, seg = t & 7;
+            const int t = tid - 128, rr = flip ? (t & 15) : (t >> 3), seg = flip ? (t >> 4) : (t & 7);      // flipped: the row index runs along S's rows
             const int r = c0 + 80 + rr;
             double val[10];
 #pragma unroll
@@ -466,52 +514,104 @@ __global__ __launch_bounds__(BC_THREADS) void k_chol_band(const BaView* __restri
     }
     BC_STAMPX(1);
     if (tid == 0 && s_fail) scal[5] = 1.0;
-    // ---- backward substitution: x_s = w_s - M_s x_below, strips in reverse.  The last strip's operands are still to be formed; M
-    //      comes back from memory (write-through stores of this workgroup, read L1-bypassing) four strips ahead of its use.
+    if (flip) {
+        // ---- the helper: the last strip's remaining two tiles, then its window over the 64 rows / columns in front of its end goes to the
+        //      main chain (which subtracts the untouched entries itself); the last strip's backward operands follow the hand-over
+        const double* LxL = LxS0 + ((ns - 1) & 1) * 64 * 17;
+        if (wave == 2 || wave == 3) tile_update(LxL, 3, wave, 0, 16 * ns);
+        BC_BARRIER();
+        const int u0 = 16 * ns;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int idx = tid + BC_THREADS * q, i = idx >> 6, j = idx & 63;
+            if (j <= i) st_sc1(Dg + idx, Win[bc_ring(base, i) * BC_RS + bc_ring(base, j)]);
+        }
+        if (tid < 64) st_sc1(Dg + 64 * 64 + tid, rhsv[u0 + tid]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every wavefront's write-through stores (M blocks so far, the block above) have left
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (wave >= 4) bc_back_operands(ns - 1, wave - 4, 4, lane, LxL, Tinv, Mg);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(flag + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // "all M blocks are there": awaited in front of the backward pass over the helper's strips
+        BC_STAMPX(5);
+        return;
+    }
+    // ---- backward substitution: x_s = M_s (-x_below; 1), strips in reverse.  The strips go to the wavefronts in RUNS of three (the last
+    //      three to wavefront 0, ...): inside a run x_s passes through LDS within one wavefront (no barrier), a run hands over to the next
+    //      with one LDS-only barrier.  Every wavefront holds the M blocks of its run in registers; they are requested before the last
+    //      strip's own block is even formed (only wavefront 0 needs that one: a second request after the stores have drained), so no
+    //      memory round trip sits on the chain.  Lane = (row i of the strip, quarter q of its 64 columns): sixteen products in four
+    //      independent sums, the quarters added by a quad butterfly -- a fixed tree.  Then the helper's strips the same way, in its
+    //      order (flipped coordinates u = n - 1 - p), seeded with the 64 unknowns in front of them.
     {
+        const int bi = lane >> 2, bq = lane & 3;
+        GPTR(double) MgB = vw.Minv + (size_t)BC_MAXS * 1024;
+        double* const xB = rhsv;                             // the helper's unknowns, flipped order (rhsv is free after the forward pass)
+        if (sB) {
+            if (tid == 0) { while (__hip_atomic_load(flag + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(2); }
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(flag + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // wavefronts 0 .. 4 hold the main chain's runs (<= 13 strips when the helper exists, <= 11 otherwise), 5 .. 7 the helper's (<= 7)
+        const bool hold_b = wave >= 5;
+        double mv[3][16];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int s2 = hold_b ? sB - 1 - 3 * (wave - 5) - k : ns - 1 - 3 * wave - k;
+            const bool there = s2 >= 0 && (hold_b || s2 < ns - 1);
+            GPTR(double) src = (hold_b ? MgB : Mg) + (size_t)max(s2, 0) * 1024 + lane;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) mv[k][j] = there ? ld_sc1(src + j * 64) : 0.0;                   // 64 lanes, 512 contiguous bytes per load
+        }
         if (wave < 4) bc_back_operands(ns - 1, wave, 4, lane, LxS0 + ((ns - 1) & 1) * 64 * 17, Tinv, Mg);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wavefront's stores of M have left for the L2
         __syncthreads();
-        // The strips go round robin to the eight wavefronts (the last strip to wavefront 0): every wavefront holds the M blocks of its
-        // <= 3 strips in registers, all loads issued up front, so no memory round trip sits on the chain; per strip its owner forms the
-        // 16 x 64 matrix-vector product (lane = row i, quarter q of the columns: sixteen products in four independent sums, quarters
-        // added by a quad butterfly, a fixed tree), x_s goes through LDS, one LDS-only barrier hands over to the next strip's owner.
-        {
-            const int bi = lane >> 2, bq = lane & 3;
-            double mv[3][16];
+        if (wave == 0) {
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const int s2 = ns - 1 - wave - 8 * k;
-#pragma unroll
-                for (int j = 0; j < 16; ++j) mv[k][j] = s2 >= 0 ? ld_sc1(Mg + (size_t)s2 * 1024 + j * 64 + lane) : 0.0;      // 64 lanes, 512 contiguous bytes per load
-            }
-            BC_STAMPX(2);
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                for (int w = 0; w < 8; ++w) {
-                    const int s = ns - 1 - w - 8 * k;
-                    if (s < 0) break;
-                    if (wave == w) {
-                        const int c0 = 16 * s;
-                        double p4[4] = {0, 0, 0, 0};
-#pragma unroll
-                        for (int j = 0; j < 16; ++j) {       // column 63 of M is L_ss^-T y_s (the rhs row rode along as row 63): multiplier -1
-                            const int r = c0 + 16 + 16 * bq + j;
-                            const double xr = (bq == 3 && j == 15) ? -1.0 : (r < dim ? xv[r] : 0.0);
-                            p4[j & 3] = fma(mv[k][j], xr, p4[j & 3]);
-                        }
-                        double p = (p4[0] + p4[1]) + (p4[2] + p4[3]);
-                        p += bc_dpp_mov<0xB1>(p); p += bc_dpp_mov<0x4E>(p);
-                        if (bq == 0) xv[c0 + bi] = -p;
-                    }
-                    BC_BARRIER();
-                }
-            }
+            for (int j = 0; j < 16; ++j) mv[0][j] = ld_sc1(Mg + (size_t)(ns - 1) * 1024 + j * 64 + lane);
         }
-        __syncthreads();
+        BC_STAMPX(2);
+        // one strip: x[c0 .. c0+15] from the 64 entries behind it (vector v, zero beyond the system: it is 384 long)
+        auto strip_x = [&](double* v, const double (&m)[16], int c0) __attribute__((always_inline)) {
+            const f64x2* xp2 = reinterpret_cast<const f64x2*>(v + c0 + 16 + 16 * bq);
+            double p4[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const f64x2 x2 = xp2[j];
+                const double x1 = (bq == 3 && j == 7) ? -1.0 : x2.y;          // column 63 of M is L_ss^-T y_s (the rhs row rode along as row 63)
+                p4[(2 * j) & 3] = fma(m[2 * j], x2.x, p4[(2 * j) & 3]);
+                p4[(2 * j + 1) & 3] = fma(m[2 * j + 1], x1, p4[(2 * j + 1) & 3]);
+            }
+            double p = (p4[0] + p4[1]) + (p4[2] + p4[3]);
+            p += bc_dpp_mov<0xB1>(p); p += bc_dpp_mov<0x4E>(p);
+            if (bq == 0) v[c0 + bi] = -p;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the write before this wavefront's reads for its next strip
+        };
+        for (int w = 0; w < 5; ++w) {
+            if (ns - 1 - 3 * w < 0) break;
+            if (wave == w) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { const int s = ns - 1 - 3 * w - k; if (s >= 0) strip_x(xv, mv[k], 16 * s); }
+            }
+            BC_BARRIER();
+        }
+        if (sB) {
+            for (int u = tid; u < 384; u += BC_THREADS) xB[u] = (u >= 16 * sB && u < dim) ? xv[dim - 1 - u] : 0.0;
+            BC_BARRIER();
+            for (int w = 0; w < 3; ++w) {
+                if (sB - 1 - 3 * w < 0) break;
+                if (wave == 5 + w) {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) { const int sw = sB - 1 - 3 * w - k; if (sw >= 0) strip_x(xB, mv[k], 16 * sw); }
+                }
+                BC_BARRIER();
+            }
+            for (int u = tid; u < 16 * sB && u < dim; u += BC_THREADS) xp[dim - 1 - u] = xB[u];
+        }
     }
     BC_STAMPX(3);
-    for (int i = tid; i < dim; i += BC_THREADS) xp[i] = xv[i];
+    for (int i = tid; i < dimA; i += BC_THREADS) xp[i] = xv[i];
 }
 
 // dynamic LDS beyond 64 KB: the attribute belongs to the (function, device) pair
