@@ -467,6 +467,13 @@ def main():
             for v in range(n_inst):
                 t1 = time.perf_counter(); wl.bundle_adjust_fresh(); ts.append(1e3 * (time.perf_counter() - t1))
             total_ms = float(np.median(ts))
+            # wall time of the graph-replayed solve alone (what the timed loop runs): optimize(10) on a resident problem, reset in between
+            b = wl.new_problem(0); b.optimize(True, BA_ITERS); tw = []
+            for _ in range(max(n_inst, 5)):
+                b.reset(); b.state()
+                t1 = time.perf_counter(); b.optimize(True, BA_ITERS); tw.append(1e3 * (time.perf_counter() - t1))
+            b.close()
+            profile_ba.wall_ms_per_iter = float(np.median(tw)) / BA_ITERS
             t1 = time.perf_counter(); wl.bundle_adjust_pipelined(8); pipe_ms = 1e3 * (time.perf_counter() - t1) / 8
             return prof, setup_ms, total_ms, iters_done, dim, pipe_ms, solver
         ba_prof, ba_setup_ms, ba_total_ms, ba_iters_done, ba_dim, ba_pipe_ms, ba_solver = None, None, None, 0, 0, None, None
@@ -556,7 +563,8 @@ def main():
                                    % (F, wl.R, wl.n_obs if wl.with_ba else 0, BA_ITERS, KF_INTERVAL),
                        "frames_per_step": F, "frames_per_launch": F, "keyframes_per_step": round(kf_per_step, 3), "replicas": world, "parallelism": "replicas x%d" % world,
                        "mapping_reserve_cus_per_xcd": MAPPING_RESERVE if wl.with_ba else 0},
-            "ba_ms_per_iter": round(sum(d["ms_per_solve"] for d in ba_prof.values()) / max(ba_iters_done, 1), 4) if ba_prof else None,
+            "ba_ms_per_iter": round(sum(d["ms_per_solve"] for d in ba_prof.values()) / max(ba_iters_done, 1), 4) if ba_prof else None,      # event sum: every launch with the gap in front of it
+            "ba_wall_ms_per_iter": round(profile_ba.wall_ms_per_iter, 4) if ba_prof else None,      # optimize(10) by graph replay, wall / 10
             "ba_setup_ms": round(ba_setup_ms, 4) if ba_setup_ms is not None else None,
             "ba_ms_per_keyframe": round(ba_total_ms, 4) if ba_total_ms is not None else None,
             "ba_ms_per_keyframe_pipelined": round(ba_pipe_ms, 4) if ba_pipe_ms is not None else None,
@@ -599,7 +607,7 @@ def main():
             out["contiguous"] = {
                 "frames_per_s": round(frames_total / elapsed_contig, 2), "ms_per_step": round(1e3 * elapsed_contig / args.steps, 4),
                 "observations": wl.n_obs, "solver": c_solver[0], "block_half_bandwidth": c_solver[1],
-                "ba_ms_per_iter": round(c_it_ms, 4), "ba_setup_ms": round(c_setup, 4), "ba_ms_per_keyframe": round(c_total, 4), "ba_ms_per_keyframe_pipelined": round(c_pipe, 4),
+                "ba_ms_per_iter": round(c_it_ms, 4), "ba_wall_ms_per_iter": round(profile_ba.wall_ms_per_iter, 4), "ba_setup_ms": round(c_setup, 4), "ba_ms_per_keyframe": round(c_total, 4), "ba_ms_per_keyframe_pipelined": round(c_pipe, 4),
                 "ba_kernel_us_per_iteration": {("k_chol_factor" if n == "chol" else n): round(1e3 * d["ms_per_solve"] / max(c_iters, 1), 2) for n, d in c_prof.items()},
                 "ba_roofline": {"flop_per_iteration": int(c_tot), "achieved_TFLOPs": round(c_tot / (c_it_ms * 1e-3) / 1e12, 4), "frac_of_fp64_peak": round(c_tot / (c_it_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, 5)},
                 "factor_roofline": {"bound": "mfma", "kernel": hip.ba_factor_kernel_name(c_dim, c_solver[0] == "band"), "avg_launch_us": round(chol_us, 3),
@@ -655,17 +663,31 @@ def main():
         if wl.with_ba:
             try:
                 S = 16
-                rounds = 3
+                rounds = 4
                 fe_ctx = wl.ctx                                  # the sessions' frames: the resident ring, KF_INTERVAL frames per session and round
 
                 from concurrent.futures import ThreadPoolExecutor
                 creators = ThreadPoolExecutor(8)                 # every session has a mapping thread of its own: the windows are set up side by side
 
-                def session_round(v0):
-                    bas = list(creators.map(wl.new_problem, range(v0, v0 + S)))
-                    hip.ba_optimize_batch(bas, True, BA_ITERS)
-                    for b in bas:
-                        b.close()
+                ahead = ThreadPoolExecutor(1)                    # sets the NEXT round's windows up beside the running batch (the single-session pipeline, 16 wide)
+
+                def make_all(v0):
+                    return list(creators.map(wl.new_problem, range(v0, v0 + S)))
+
+                def session_rounds(n_rounds):
+                    """every round: the windows built beside the previous round's solve receive their values (set_state: what the solve
+                    before them produced), are solved as one batch, read back and released"""
+                    fut = ahead.submit(make_all, 0)
+                    for r in range(n_rounds):
+                        bas = fut.result()
+                        if r + 1 < n_rounds:
+                            fut = ahead.submit(make_all, (r + 1) * S)
+                        for i, b in enumerate(bas):
+                            p = wl.probs[(r * S + i) % BA_VARIANTS]
+                            b.set_state(p["poses"], p["points"])
+                        hip.ba_optimize_batch(bas, True, BA_ITERS)
+                        for b in bas:
+                            b.state(); b.close()
 
                 def fe_round():
                     n_frames = S * KF_INTERVAL                  # 96 stereo frames per round, in launches of the ring's size
@@ -679,17 +701,16 @@ def main():
                     fe_ctx.sync()
                 for kind, key in (("random", "multi_session"), ("contiguous", "multi_session_contiguous")):
                     wl.set_tracks(kind)
-                    session_round(0); fe_round()
+                    session_rounds(2); fe_round()          # two rounds: the pipeline holds two sets of windows, their blocks come from the cache afterwards
                     t2 = time.perf_counter()
-                    th = threading.Thread(target=lambda: [session_round(r * S) for r in range(rounds)])
+                    th = threading.Thread(target=lambda: session_rounds(rounds))
                     th.start()
                     for _ in range(rounds):
                         fe_round()
                     th.join()
                     t_ms = time.perf_counter() - t2
                     t3 = time.perf_counter()
-                    for r in range(rounds):
-                        session_round(r * S)
+                    session_rounds(rounds)
                     t_ba_only = (time.perf_counter() - t3) / rounds
                     fl = out["ba_roofline"]["flop_per_iteration"] if kind == "random" and "ba_roofline" in out else (out["contiguous"]["ba_roofline"]["flop_per_iteration"] if "contiguous" in out else None)
                     extras[key] = {"sessions_per_gpu": S, "tracks": kind, "frames_per_s": round(rounds * S * KF_INTERVAL / t_ms, 1),
@@ -697,9 +718,9 @@ def main():
                                    # the batch's arithmetic against the FP64 matrix-core peak: S windows x BA_ITERS iterations of the
                                    # per-iteration flop count above, over the whole round (create + solve + read-back + destroy)
                                    "ba_roofline": ({"TFLOPs": round(S * BA_ITERS * fl / t_ba_only / 1e12, 3), "frac_of_fp64_peak": round(S * BA_ITERS * fl / t_ba_only / 1e12 / FP64_PEAK_TFLOPS, 5)} if fl else None),
-                                   "note": "16 sessions, 6 stereo frames + 1 fresh local BA each per round; the windows are set up on 8 host threads (every session has its mapping thread) and solved by one lpslam_hip_ba_optimize_batch call"}
+                                   "note": "16 sessions, 6 stereo frames + 1 fresh local BA each per round; the windows of a round are set up on 8 host threads beside the previous round's solve (every session has its mapping thread), receive their values (set_state), are solved by one lpslam_hip_ba_optimize_batch call, read back and released"}
                 wl.set_tracks("random")
-                creators.shutdown()
+                creators.shutdown(); ahead.shutdown()
             except Exception as e:      # noqa: BLE001
                 extras["multi_session"] = {"error": str(e)}
         # the integrated path: the same sequence through the drop-in boundary (LpSlamManager -> stereo tracker: upload, extract,

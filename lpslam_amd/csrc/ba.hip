@@ -1682,6 +1682,7 @@ struct PoShared {
 #define LPSLAM_PO_T 512
 #endif
 constexpr int PO_T = LPSLAM_PO_T;
+static_assert(PO_T >= 128 && PO_T % 64 == 0, "k_pose_optimize: the 27-value reduction needs at least two wavefronts (one wavefront faulted on the device, round 4)");
 constexpr int PO_W = PO_T / 64;
 __device__ __forceinline__ double po_rcp(double d) { return fast_rcp(d); }
 __device__ __forceinline__ double po_rsqrt(double d) { return fast_rsqrt(d); }

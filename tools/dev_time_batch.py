@@ -33,9 +33,11 @@ for B in (tuple(int(x) for x in sys.argv[1].split(',')) if len(sys.argv) > 1 els
         b.close()
 if os.environ.get("ROUNDS"):
     S = 16
+    from concurrent.futures import ThreadPoolExecutor
+    pool = ThreadPoolExecutor(int(os.environ["THREADS"])) if os.environ.get("THREADS") else None
     def session_round(v0):
         t0 = time.perf_counter()
-        bas = [make(v0 + i) for i in range(S)]
+        bas = list(pool.map(make, range(v0, v0 + S))) if pool else [make(v0 + i) for i in range(S)]
         t1 = time.perf_counter()
         hip.ba_optimize_batch(bas, True, 10)
         t2 = time.perf_counter()

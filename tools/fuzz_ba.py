@@ -18,7 +18,7 @@ hip.load()
 ctx = hip.Context(320, 240, 400, 1.2, 4, max_images=1)
 bad = 0; t0 = time.time()
 for case in range(n_cases):
-    n_kf = int(rng.integers(2, 40)); n_pts = int(rng.integers(20, 1500))
+    n_kf = int(rng.integers(2, 52)); n_pts = int(rng.integers(20, 1500))      # from 31 free keyframes on the band factorisation runs from both ends
     n_obs = int(min(n_kf * n_pts, rng.integers(2 * n_pts, 8 * n_pts + 1)))
     robust = bool(rng.integers(0, 2)); iters = int(rng.integers(1, 12))
     noise = float(rng.choice([1.0, 1.0, 3.0, 8.0]))
