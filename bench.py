@@ -613,8 +613,9 @@ def main():
                 "factor_roofline": {"bound": "mfma", "kernel": hip.ba_factor_kernel_name(c_dim, c_solver[0] == "band"), "avg_launch_us": round(chol_us, 3),
                                     "algorithmic_flops_per_launch": int(c_flops["cholesky"]), "achieved": round(c_flops["cholesky"] / (chol_us * 1e-6) / 1e12, 5), "peak": FP64_PEAK_TFLOPS,
                                     "unit": "TFLOP/s", "frac": round(c_flops["cholesky"] / (chol_us * 1e-6) / 1e12 / FP64_PEAK_TFLOPS, 6),
-                                    "note": "band Cholesky + both substitutions of the %d x %d system, half-bandwidth %d, ONE workgroup: a serial chain of %d 16-column strips (latency bound)"
-                                            % (c_dim, c_dim, 6 * max(c_solver[1], 0) + 5, (c_dim + 15) // 16)},
+                                    "note": "band Cholesky + both substitutions of the %d x %d system, half-bandwidth %d: %d 16-column strips factored from both ends by two workgroups, "
+                                            "a serial chain of %d strips (latency bound: 2.3 us per strip, 1.15 of it the pivot chain)"
+                                            % (c_dim, c_dim, 6 * max(c_solver[1], 0) + 5, (c_dim + 15) // 16, (c_dim + 15) // 16 - (((c_dim + 15) // 16 - 5) // 2 if (c_dim + 15) // 16 >= 12 else 0))},
                 "note": "windows with contiguous tracks (synth.ba_problem tracks='contiguous'): landmark-group Schur complement on the FP64 matrix cores + band Cholesky; "
                         "`value` above is the random-track workload of rounds 1-3"}
             wl.set_tracks("random")
