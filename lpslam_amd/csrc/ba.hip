@@ -2157,6 +2157,8 @@ BaLaunch single_launch(lpslam_hip_ba* b)
     // a small reserve (<= 8 CUs of every XCD) cannot hold the pinned chain's workgroups on ONE XCD: spread them over all XCDs then (4 CUs:
     // 4256 against 4145 frames/s pinned); from 12 on the pinned chain is the better one again (12: 4392 against 4336, 16: 4428 against 4357)
     L.spread = b->ctx && b->ctx->reserve_cus > 0 && b->ctx->reserve_cus <= 8;
+    static const int spread_env = [] { const char* e = getenv("LPSLAM_HIP_BA_SPREAD"); return e ? atoi(e) : -1; }();      // measurements: 0 / 1 force the placement
+    if (spread_env >= 0) L.spread = spread_env != 0;
     return L;
 }
 

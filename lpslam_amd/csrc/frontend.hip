@@ -1083,7 +1083,10 @@ static FeQueue lp_fe_queue(lpslam_hip_ctx* c, int n_items, int chunk)
 {
     FeQueue q{nullptr, nullptr, n_items, chunk};
     if (c->reserve_cus <= 0 || !c->d_cu_table) return q;
-    int* ctr = c->d_fe_counters + 32 * (c->fe_counter_next.fetch_add(1) % 64);          // a ring: 64 launches in flight would be a lot
+    // a ring of 64 counters per stream (main / prefetch): a counter is zeroed and used on ONE stream, in order, so its re-use 64 launches
+    // later is ordered behind the launch that used it before
+    const bool on_prefetch = lp_fe_stream(c) != c->stream;
+    int* ctr = c->d_fe_counters + 32 * ((on_prefetch ? 64 : 0) + (on_prefetch ? c->fe_counter_next_prefetch : c->fe_counter_next).fetch_add(1) % 64);
     if (hipMemsetAsync(ctr, 0, sizeof(int), lp_fe_stream(c)) != hipSuccess) { (void)hipGetLastError(); return q; }
     q.cu_table = c->d_cu_table; q.counter = ctr;
     return q;
@@ -1095,7 +1098,7 @@ int lp_fe_calibrate(lpslam_hip_ctx* c, int r)
 {
     if (!c->d_cu_table) {
         LP_HIP(hipMalloc((void**)&c->d_cu_table, 64 * sizeof(uint32_t)));
-        LP_HIP(hipMalloc((void**)&c->d_fe_counters, 64 * 32 * sizeof(int)));
+        LP_HIP(hipMalloc((void**)&c->d_fe_counters, 2 * 64 * 32 * sizeof(int)));
     }
     std::vector<uint32_t> table(64, 0u);
     if (r > 0) {

@@ -62,8 +62,8 @@ struct lpslam_hip_ctx {
     lpslam::LevelTable lt{};
     hipStream_t stream = nullptr;      // the stream every entry point enqueues on
     uint32_t* d_cu_table = nullptr;    // mapping reserve in software: [8 XCC][8 words] bit per compute unit the extraction kernels leave alone (frontend.hip)
-    int* d_fe_counters = nullptr;      // work-queue counters of the queued extraction launches (ring of 64, 128 bytes apart)
-    std::atomic<unsigned> fe_counter_next{0};
+    int* d_fe_counters = nullptr;      // work-queue counters of the queued extraction launches (a ring of 64 per stream, 128 bytes apart)
+    std::atomic<unsigned> fe_counter_next{0}, fe_counter_next_prefetch{0};
     int reserve_cus = 0;               // lpslam_hip_set_mapping_reserve: CUs of every XCD the front end's streams leave to the mapping solves
     hipStream_t fe_stream = nullptr;   // prefetch: front end of the NEXT frame beside the tracking of this one (lp_fe_stream)
     hipEvent_t fe_done = nullptr;
