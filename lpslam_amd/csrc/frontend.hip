@@ -355,13 +355,24 @@ __device__ __forceinline__ void fast_cells_body(int cell_arg, int image_arg, con
         }
     }
 }
-// direct launch: one workgroup per (cell, image); queued (mapping reserve): persistent workgroups take chunks of cells
+// direct launch: one workgroup per (cell, image)
 __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ pyr, size_t image_slab, LevelTable lt,
                                                     int ini_thr, int min_thr, uint32_t* __restrict__ cell_keys,
                                                     int32_t* __restrict__ cell_count, int cells_per_image, int image0, int dbg,
-                                                    const uint8_t* __restrict__ mask0, const uint8_t* __restrict__ mask1, FeQueue fq)
+                                                    const uint8_t* __restrict__ mask0, const uint8_t* __restrict__ mask1)
 {
-    if (!fq.cu_table) { fast_cells_body(blockIdx.x, blockIdx.y, pyr, image_slab, lt, ini_thr, min_thr, cell_keys, cell_count, cells_per_image, image0, dbg, mask0, mask1); return; }
+    fast_cells_body(blockIdx.x, blockIdx.y, pyr, image_slab, lt, ini_thr, min_thr, cell_keys, cell_count, cells_per_image, image0, dbg, mask0, mask1);
+}
+// queued (mapping reserve): persistent workgroups take chunks of cells; a kernel of its own, so that the direct one keeps its registers
+// (both in one kernel: 110 instead of 63 VGPRs, four instead of eight wavefronts per SIMD, 246 -> 297 us per 32 images)
+#ifndef LPSLAM_FASTQ_OCC
+#define LPSLAM_FASTQ_OCC 6
+#endif
+__global__ __launch_bounds__(256, LPSLAM_FASTQ_OCC) void k_fast_cells_q(const uint8_t* __restrict__ pyr, size_t image_slab, LevelTable lt,
+                                                      int ini_thr, int min_thr, uint32_t* __restrict__ cell_keys,
+                                                      int32_t* __restrict__ cell_count, int cells_per_image, int image0, int dbg,
+                                                      const uint8_t* __restrict__ mask0, const uint8_t* __restrict__ mask1, FeQueue fq)
+{
     if (fe_on_reserved_cu(fq.cu_table)) return;
     for (;;) {
         const int first = fe_next_chunk(fq);
@@ -788,15 +799,24 @@ __device__ __forceinline__ void distribute_body(int image_arg, int level_arg, co
     }
     if (tid == 0) sel_count[image * lt.n_levels + level] = min(alive, cap);
 }
-// direct: workgroup (image, level), level 0 of every image dispatched first; queued: items image + n_images * level in that order
+// direct: workgroup (image, level), level 0 of every image dispatched first
 __global__ __launch_bounds__(1024) void k_distribute(LevelTable lt, const uint32_t* __restrict__ cell_keys,
                                                      const int32_t* __restrict__ cell_count, int cells_per_image,
                                                      uint32_t* __restrict__ cand_key, uint32_t* __restrict__ cand_node,
                                                      int32_t* __restrict__ cand_count, int cand_per_image,
                                                      uint32_t* __restrict__ sel_key, int32_t* __restrict__ sel_count,
-                                                     int slots_per_image, int image0, FeQueue fq, int n_images)
+                                                     int slots_per_image, int image0)
 {
-    if (!fq.cu_table) { distribute_body(blockIdx.x, blockIdx.y, lt, cell_keys, cell_count, cells_per_image, cand_key, cand_node, cand_count, cand_per_image, sel_key, sel_count, slots_per_image, image0); return; }
+    distribute_body(blockIdx.x, blockIdx.y, lt, cell_keys, cell_count, cells_per_image, cand_key, cand_node, cand_count, cand_per_image, sel_key, sel_count, slots_per_image, image0);
+}
+// queued: items image + n_images * level in that order
+__global__ __launch_bounds__(1024) void k_distribute_q(LevelTable lt, const uint32_t* __restrict__ cell_keys,
+                                                       const int32_t* __restrict__ cell_count, int cells_per_image,
+                                                       uint32_t* __restrict__ cand_key, uint32_t* __restrict__ cand_node,
+                                                       int32_t* __restrict__ cand_count, int cand_per_image,
+                                                       uint32_t* __restrict__ sel_key, int32_t* __restrict__ sel_count,
+                                                       int slots_per_image, int image0, FeQueue fq, int n_images)
+{
     if (fe_on_reserved_cu(fq.cu_table)) return;
     for (;;) {
         const int it = fe_next_chunk(fq);                // chunk = 1
@@ -1024,14 +1044,22 @@ __device__ __forceinline__ void describe_body(int slot_block, int image_arg, con
         kpts[o] = kp;
     }
 }
-// direct: workgroup = four keypoint slots of one image; queued: chunks of slot blocks (slot block b of image i = item b + blocks * i)
+// direct: workgroup = four keypoint slots of one image
 __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const uint8_t* __restrict__ pyr, size_t image_slab, LevelTable lt,
                                                               const uint32_t* __restrict__ sel_key,
                                                               const int32_t* __restrict__ sel_count, int slots_per_image,
                                                               lpslam_hip_keypoint* __restrict__ kpts, uint8_t* __restrict__ desc,
-                                                              int32_t* __restrict__ kp_count, int image0, FeQueue fq, int blocks_per_image)
+                                                              int32_t* __restrict__ kp_count, int image0)
 {
-    if (!fq.cu_table) { describe_body(blockIdx.x, blockIdx.y, pyr, image_slab, lt, sel_key, sel_count, slots_per_image, kpts, desc, kp_count, image0); return; }
+    describe_body(blockIdx.x, blockIdx.y, pyr, image_slab, lt, sel_key, sel_count, slots_per_image, kpts, desc, kp_count, image0);
+}
+// queued: chunks of slot blocks (slot block b of image i = item b + blocks * i)
+__global__ __launch_bounds__(64 * DESC_WAVES, 6) void k_describe_q(const uint8_t* __restrict__ pyr, size_t image_slab, LevelTable lt,
+                                                                const uint32_t* __restrict__ sel_key,
+                                                                const int32_t* __restrict__ sel_count, int slots_per_image,
+                                                                lpslam_hip_keypoint* __restrict__ kpts, uint8_t* __restrict__ desc,
+                                                                int32_t* __restrict__ kp_count, int image0, FeQueue fq, int blocks_per_image)
+{
     if (fe_on_reserved_cu(fq.cu_table)) return;
     for (;;) {
         const int first = fe_next_chunk(fq);
@@ -1166,9 +1194,12 @@ int lp_launch_remap(lpslam_hip_ctx* c, int image, int eye)
 int lp_launch_fast(lpslam_hip_ctx* c, int first, int n_images)
 {
     FeQueue fq = lp_fe_queue(c, c->cells_per_image * n_images, 4);
-    const dim3 grid = fq.cu_table ? dim3(256 * 8, 1) : dim3(c->cells_per_image, n_images);       // queued: the eight workgroups a compute unit holds
-    hipLaunchKernelGGL(k_fast_cells, grid, dim3(256), 0, lp_fe_stream(c), c->d_pyr, c->image_slab, c->lt, c->cfg.ini_fast_threshold,
-                       c->cfg.min_fast_threshold, c->d_cell_keys, c->d_cell_count, c->cells_per_image, first, 0, c->d_mask[0], c->d_mask[1], fq);
+    if (fq.cu_table)                                     // queued: the eight workgroups a compute unit holds
+        hipLaunchKernelGGL(k_fast_cells_q, dim3(256 * 8), dim3(256), 0, lp_fe_stream(c), c->d_pyr, c->image_slab, c->lt, c->cfg.ini_fast_threshold,
+                           c->cfg.min_fast_threshold, c->d_cell_keys, c->d_cell_count, c->cells_per_image, first, 0, c->d_mask[0], c->d_mask[1], fq);
+    else
+        hipLaunchKernelGGL(k_fast_cells, dim3(c->cells_per_image, n_images), dim3(256), 0, lp_fe_stream(c), c->d_pyr, c->image_slab, c->lt, c->cfg.ini_fast_threshold,
+                           c->cfg.min_fast_threshold, c->d_cell_keys, c->d_cell_count, c->cells_per_image, first, 0, c->d_mask[0], c->d_mask[1]);
     LP_HIP(hipGetLastError());
     return LPSLAM_HIP_OK;
 }
@@ -1176,10 +1207,14 @@ int lp_launch_fast(lpslam_hip_ctx* c, int first, int n_images)
 int lp_launch_distribute(lpslam_hip_ctx* c, int first, int n_images)
 {
     FeQueue fq = lp_fe_queue(c, n_images * c->lt.n_levels, 1);
-    const dim3 grid = fq.cu_table ? dim3(256, 1) : dim3(n_images, c->lt.n_levels);       // level 0 of every image first: the long work-groups start first
-    hipLaunchKernelGGL(k_distribute, grid, dim3(1024), c->distribute_lds, lp_fe_stream(c), c->lt, c->d_cell_keys, c->d_cell_count,
-                       c->cells_per_image, c->d_cand_key, c->d_cand_node, c->d_cand_count, c->cand_per_image, c->d_sel_key, c->d_sel_count,
-                       c->slots_per_image, first, fq, n_images);
+    if (fq.cu_table)
+        hipLaunchKernelGGL(k_distribute_q, dim3(256), dim3(1024), c->distribute_lds, lp_fe_stream(c), c->lt, c->d_cell_keys, c->d_cell_count,
+                           c->cells_per_image, c->d_cand_key, c->d_cand_node, c->d_cand_count, c->cand_per_image, c->d_sel_key, c->d_sel_count,
+                           c->slots_per_image, first, fq, n_images);
+    else                                                 // level 0 of every image first: the long work-groups start first
+        hipLaunchKernelGGL(k_distribute, dim3(n_images, c->lt.n_levels), dim3(1024), c->distribute_lds, lp_fe_stream(c), c->lt, c->d_cell_keys, c->d_cell_count,
+                           c->cells_per_image, c->d_cand_key, c->d_cand_node, c->d_cand_count, c->cand_per_image, c->d_sel_key, c->d_sel_count,
+                           c->slots_per_image, first);
     LP_HIP(hipGetLastError());
     return LPSLAM_HIP_OK;
 }
@@ -1189,9 +1224,12 @@ int lp_launch_describe(lpslam_hip_ctx* c, int first, int n_images)
     for (int i = first; i < first + n_images && (size_t)i < c->h_kp_valid.size(); ++i) c->h_kp_valid[(size_t)i] = 0;      // counts are rewritten
     const int blocks = (c->slots_per_image + DESC_WAVES - 1) / DESC_WAVES;
     FeQueue fq = lp_fe_queue(c, blocks * n_images, 16);
-    const dim3 grid = fq.cu_table ? dim3(256 * 7, 1) : dim3(blocks, n_images);          // queued: seven workgroups (28 wavefronts) per compute unit
-    hipLaunchKernelGGL(k_describe, grid, dim3(64 * DESC_WAVES), 0, lp_fe_stream(c), c->d_pyr, c->image_slab, c->lt, c->d_sel_key,
-                       c->d_sel_count, c->slots_per_image, c->d_kpts, c->d_desc, c->d_kp_count, first, fq, blocks);
+    if (fq.cu_table)                                     // queued: seven workgroups (28 wavefronts) per compute unit
+        hipLaunchKernelGGL(k_describe_q, dim3(256 * 7), dim3(64 * DESC_WAVES), 0, lp_fe_stream(c), c->d_pyr, c->image_slab, c->lt, c->d_sel_key,
+                           c->d_sel_count, c->slots_per_image, c->d_kpts, c->d_desc, c->d_kp_count, first, fq, blocks);
+    else
+        hipLaunchKernelGGL(k_describe, dim3(blocks, n_images), dim3(64 * DESC_WAVES), 0, lp_fe_stream(c), c->d_pyr, c->image_slab, c->lt, c->d_sel_key,
+                           c->d_sel_count, c->slots_per_image, c->d_kpts, c->d_desc, c->d_kp_count, first);
     LP_HIP(hipGetLastError());
     return LPSLAM_HIP_OK;
 }
