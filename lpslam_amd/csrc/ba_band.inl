@@ -99,7 +99,10 @@ __device__ __forceinline__ void bd_linv(const double* hl, double lambda, double*
     li[0] = i00; li[1] = i10; li[2] = i11; li[3] = i20; li[4] = i21; li[5] = i22;
 }
 
-__global__ __launch_bounds__(BD_THREADS) void k_schur_group(const BaView* __restrict__ views)
+#ifndef LPSLAM_BD_OCC
+#define LPSLAM_BD_OCC 1
+#endif
+__global__ __launch_bounds__(BD_THREADS, LPSLAM_BD_OCC) void k_schur_group(const BaView* __restrict__ views)
 {
     BA_VIEW_XCD(v, bx);
     BA_VIEW_HEAD("s"(v.band_hbw), "s"(v.band_groups), "s"(v.ctl), "s"(v.band_tab));
@@ -132,50 +135,44 @@ __global__ __launch_bounds__(BD_THREADS) void k_schur_group(const BaView* __rest
     __syncthreads();
     BD_STAMP(1);
     GPTR(const int4) ent = reinterpret_cast<GPTR(const int4)>(v.band_ent);
-    // two entries per thread and round in flight (entry -> W row / landmark block are dependent round trips)
-    for (int eb = e0 + tid; eb < e1; eb += 2 * BD_THREADS) {
-        int4 en[2];
-        double w[2][18], hl[2][6], bl[2][3];
+    // one entry per thread and round (512 threads: a group of 32 landmarks has ~290): entry -> W row / landmark block are dependent round
+    // trips; a second entry in flight per thread cost 72 registers and the second workgroup of a compute unit
+    for (int eb = e0 + tid; eb < e1; eb += BD_THREADS) {
+        const int4 en = ent[eb];
+        double w[18], hl[6], bl[3];
+        {
+            const double2* Wa = reinterpret_cast<const double2*>(v.W + 18 * (size_t)en.x);
 #pragma unroll
-        for (int u = 0; u < 2; ++u) en[u] = ent[min(eb + BD_THREADS * u, e1 - 1)];
+            for (int q = 0; q < 9; ++q) { const double2 a2 = Wa[q]; w[2 * q] = a2.x; w[2 * q + 1] = a2.y; }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const double2* Wa = reinterpret_cast<const double2*>(v.W + 18 * (size_t)en[u].x);
+            for (int q = 0; q < 6; ++q) hl[q] = v.Hll[6 * (size_t)en.w + q];
 #pragma unroll
-            for (int q = 0; q < 9; ++q) { const double2 a2 = Wa[q]; w[u][2 * q] = a2.x; w[u][2 * q + 1] = a2.y; }
-#pragma unroll
-            for (int q = 0; q < 6; ++q) hl[u][q] = v.Hll[6 * (size_t)en[u].w + q];
-#pragma unroll
-            for (int q = 0; q < 3; ++q) bl[u][q] = v.bl[3 * (size_t)en[u].w + q];
+            for (int q = 0; q < 3; ++q) bl[q] = v.bl[3 * (size_t)en.w + q];
         }
         BD_STAMP(2);
+        const int col = en.z & 0xFFFF, flags = en.z >> 16;
+        double li[6];
+        bd_linv(hl, lambda, li);
+        if (flags & 1) {                              // first entry of the landmark: u = L^-1 b_l
+            U[col] = li[0] * bl[0];
+            U[col + 1] = li[1] * bl[0] + li[2] * bl[1];
+            U[col + 2] = li[3] * bl[0] + li[4] * bl[1] + li[5] * bl[2];
+        }
+        if (en.y < 0 || (flags & 2)) continue;        // fixed keyframe / summed by the first entry of its run
+        for (int e2 = eb + 1; (flags & 4) && e2 < e1; ++e2) {      // duplicates (rare): the same landmark seen again by this keyframe
+            const int4 d = ent[e2];
+            if (!((d.z >> 16) & 2)) break;
+            const double* Wd = v.W + 18 * (size_t)d.x;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            if (eb + BD_THREADS * u >= e1) continue;
-            const int col = en[u].z & 0xFFFF, flags = en[u].z >> 16;
-            double li[6];
-            bd_linv(hl[u], lambda, li);
-            if (flags & 1) {                              // first entry of the landmark: u = L^-1 b_l
-                U[col] = li[0] * bl[u][0];
-                U[col + 1] = li[1] * bl[u][0] + li[2] * bl[u][1];
-                U[col + 2] = li[3] * bl[u][0] + li[4] * bl[u][1] + li[5] * bl[u][2];
-            }
-            if (en[u].y < 0 || (flags & 2)) continue;     // fixed keyframe / summed by the first entry of its run
-            for (int e2 = eb + BD_THREADS * u + 1; (flags & 4) && e2 < e1; ++e2) {      // duplicates (rare): the same landmark seen again by this keyframe
-                const int4 d = ent[e2];
-                if (!((d.z >> 16) & 2)) break;
-                const double* Wd = v.W + 18 * (size_t)d.x;
+            for (int q = 0; q < 18; ++q) w[q] += Wd[q];
+        }
+        double* zr = Z + en.y * stride + col;
 #pragma unroll
-                for (int q = 0; q < 18; ++q) w[u][q] += Wd[q];
-            }
-            double* zr = Z + en[u].y * stride + col;
-#pragma unroll
-            for (int r = 0; r < 6; ++r) {                 // Z = W L^-T: column c = sum_{k <= c} W[:, k] Linv[c][k]
-                const double w0 = w[u][3 * r], w1 = w[u][3 * r + 1], w2 = w[u][3 * r + 2];
-                zr[r * stride] = w0 * li[0];
-                zr[r * stride + 1] = w0 * li[1] + w1 * li[2];
-                zr[r * stride + 2] = w0 * li[3] + w1 * li[4] + w2 * li[5];
-            }
+        for (int r = 0; r < 6; ++r) {                 // Z = W L^-T: column c = sum_{k <= c} W[:, k] Linv[c][k]
+            const double w0 = w[3 * r], w1 = w[3 * r + 1], w2 = w[3 * r + 2];
+            zr[r * stride] = w0 * li[0];
+            zr[r * stride + 1] = w0 * li[1] + w1 * li[2];
+            zr[r * stride + 2] = w0 * li[3] + w1 * li[4] + w2 * li[5];
         }
     }
     __syncthreads();
