@@ -33,6 +33,9 @@ for case in range(n_cases):
         p = O.params(kpts, scale, levels, ini, mn)
         okp, od, occ, opyr = O.extract(img, p, True)
         ctx = hip.Context(w, h, kpts, scale, levels, ini, mn, max_images=2)
+        reserve = int(rng.choice([0, 0, 4, 8, 16]))                  # > 0: the extraction kernels run as persistent work-queue grids
+        if reserve: ctx.set_mapping_reserve(reserve)
+        tag += " reserve %d" % reserve
         ctx.upload(0, img); ctx.upload(1, np.roll(img, -3, axis=1)); ctx.extract(2)
         ok = all(np.array_equal(ctx.pyramid_level(0, l), opyr[l]) for l in range(levels))
         gkp, gd = ctx.keypoints(0)
