@@ -561,12 +561,22 @@ __global__ __launch_bounds__(BC_THREADS) void k_chol_band(const BaView* __restri
 #pragma unroll
             for (int j = 0; j < 16; ++j) mv[k][j] = there ? ld_sc1(src + j * 64) : 0.0;                   // 64 lanes, 512 contiguous bytes per load
         }
-        if (wave < 4) bc_back_operands(ns - 1, wave, 4, lane, LxS0 + ((ns - 1) & 1) * 64 * 17, Tinv, Mg);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wavefront's stores of M have left for the L2
-        __syncthreads();
+        // the last strip's own block goes through LDS (the window is free now), in the order the backward pass reads it: no trip to memory
+        // and back in front of the chain
+        if (wave < 4) {
+            const double* T = Tinv + (ns - 1) * 16 * 17;
+            const double* Lx = LxS0 + ((ns - 1) & 1) * 64 * 17;
+            f64x4 acc = {0, 0, 0, 0};
+#pragma unroll
+            for (int k4 = 0; k4 < 16; k4 += 4)
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(T[lr * 17 + k4 + lk], Lx[(16 * wave + lr) * 17 + k4 + lk], acc, 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Win[lr * 64 + 4 * (lk + 4 * q) + wave] = acc[q];      // element (row, col = 16 wave + lr) at [lr][row][wave]
+        }
+        BC_BARRIER();
         if (wave == 0) {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) mv[0][j] = ld_sc1(Mg + (size_t)(ns - 1) * 1024 + j * 64 + lane);
+            for (int j = 0; j < 16; ++j) mv[0][j] = Win[j * 64 + lane];
         }
         BC_STAMPX(2);
         // one strip: x[c0 .. c0+15] from the 64 entries behind it (vector v, zero beyond the system: it is 384 long)
