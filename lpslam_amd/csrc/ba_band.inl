@@ -435,7 +435,8 @@ __global__ __launch_bounds__(BC_THREADS) void k_chol_band(const BaView* __restri
                 sv[q] = j <= i ? S[(size_t)(dimA - 1 - j) * n + (dimA - 1 - i)] : 0.0;   // our coordinates: (pj, pi), pi <= pj
             }
             const double sr = tid < 64 ? S[(size_t)dim * n + (dimA - 1 - tid)] : 0.0;
-            if (tid == 0) { while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(2); }
+            // (bounded: should the helper never report -- it always does -- the factorisation is flagged as failed instead of the grid hanging)
+            if (tid == 0) { int spins = 0; while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(2); if (spins >= (1 << 22)) { s_fail = 1; scal[5] = 1.0; } }
             __syncthreads();
 #pragma unroll
             for (int q = 0; q < 8; ++q) { const int idx = tid + BC_THREADS * q; dv[q] = (idx & 63) <= (idx >> 6) ? ld_sc1(Dg + idx) : 0.0; }
@@ -546,7 +547,7 @@ __global__ __launch_bounds__(BC_THREADS) void k_chol_band(const BaView* __restri
         GPTR(double) MgB = vw.Minv + (size_t)BC_MAXS * 1024;
         double* const xB = rhsv;                             // the helper's unknowns, flipped order (rhsv is free after the forward pass)
         if (sB) {
-            if (tid == 0) { while (__hip_atomic_load(flag + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(2); }
+            if (tid == 0) { int spins = 0; while (__hip_atomic_load(flag + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(2); if (spins >= (1 << 22)) scal[5] = 1.0; }
             __syncthreads();
             if (tid == 0) __hip_atomic_store(flag + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }

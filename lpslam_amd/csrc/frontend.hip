@@ -79,7 +79,7 @@ __device__ __forceinline__ int fe_next_chunk(const FeQueue& q)
     __syncthreads();                 // the previous item is finished by everybody (its LDS may be reused) and s_chunk has been read
     if (threadIdx.x == 0) s_chunk = atomicAdd(q.counter, 1);
     __syncthreads();
-    return s_chunk * q.chunk;
+    return __builtin_amdgcn_readfirstlane(s_chunk) * q.chunk;      // uniform: what is derived from it (level, sizes, pointers) stays in scalar registers
 }
 // calibration: where does workgroup b run?  (xcc << 16 | hw_id & 0xffff)
 __global__ void k_fe_where(unsigned* out)
@@ -203,7 +203,9 @@ __device__ __forceinline__ void fast_cells_body(int cell_arg, int image_arg, con
     const int cw = min(min_x + kCell + kOverlap, W - kEdge) - min_x;   // 7..70 (cells narrower than 7 px hold no corner)
     const int ch = min(min_y + kCell + kOverlap, H - kEdge) - min_y;
     const uint8_t* src = pyr + (size_t)image * image_slab + lt.off[level];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int tid_ = threadIdx.x;
+    asm volatile("" : "+v"(tid_));          // opaque per call: inside the queued kernel's item loop the lane-derived values are recomputed per cell instead of staying live across it (113 -> 6x VGPRs)
+    const int tid = tid_, lane = tid & 63, wave = tid >> 6;
     // camera mask ([UPSTREAM] orb_extractor::is_in_mask: level coordinate x scale factor, truncated, looked up in the level-0 mask,
     // 0 = masked out): even image slots are left eyes, odd ones right eyes.  A cell with a corner in the mask is skipped.
     const uint8_t* mask = (image & 1) ? mask1 : mask0;
@@ -365,10 +367,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
 }
 // queued (mapping reserve): persistent workgroups take chunks of cells; a kernel of its own, so that the direct one keeps its registers
 // (both in one kernel: 110 instead of 63 VGPRs, four instead of eight wavefronts per SIMD, 246 -> 297 us per 32 images)
-#ifndef LPSLAM_FASTQ_OCC
-#define LPSLAM_FASTQ_OCC 6
-#endif
-__global__ __launch_bounds__(256, LPSLAM_FASTQ_OCC) void k_fast_cells_q(const uint8_t* __restrict__ pyr, size_t image_slab, LevelTable lt,
+__global__ __launch_bounds__(256) void k_fast_cells_q(const uint8_t* __restrict__ pyr, size_t image_slab, LevelTable lt,
                                                       int ini_thr, int min_thr, uint32_t* __restrict__ cell_keys,
                                                       int32_t* __restrict__ cell_count, int cells_per_image, int image0, int dbg,
                                                       const uint8_t* __restrict__ mask0, const uint8_t* __restrict__ mask1, FeQueue fq)
@@ -444,7 +443,9 @@ __device__ __forceinline__ void distribute_body(int image_arg, int level_arg, co
 {
     extern __shared__ __attribute__((aligned(16))) int lds[];
     const int level = level_arg, image = image0 + image_arg;
-    const int tid = threadIdx.x;
+    int tid_ = threadIdx.x;
+    asm volatile("" : "+v"(tid_));          // opaque per call (see fast_cells_body)
+    const int tid = tid_;
     const int N = lt.quota[level];
     const int Q = lt.qcap[level];          // node count never exceeds max(N + 2, 4 * roots) < Q
     int sortcap = 1; while (sortcap < Q) sortcap <<= 1;
@@ -911,7 +912,9 @@ __device__ __forceinline__ void describe_body(int slot_block, int image_arg, con
     __shared__ __attribute__((aligned(16))) uint8_t s_raw[DESC_WAVES][PW * RAW_PITCH];
     __shared__ __attribute__((aligned(16))) uint16_t s_h[DESC_WAVES][PW * HB_PITCH];
     static_assert(BW * BW <= PW * RAW_PITCH, "the blurred patch reuses the raw patch's storage");
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int tid_ = threadIdx.x;
+    asm volatile("" : "+v"(tid_));          // opaque per call (see fast_cells_body)
+    const int lane = tid_ & 63, wave = tid_ >> 6;
     const int image = image0 + image_arg;
     const int slot = slot_block * DESC_WAVES + wave;
     if (slot >= slots_per_image) return;          // wave-uniform; no block barriers below
@@ -1054,7 +1057,7 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const uint8_t* __r
     describe_body(blockIdx.x, blockIdx.y, pyr, image_slab, lt, sel_key, sel_count, slots_per_image, kpts, desc, kp_count, image0);
 }
 // queued: chunks of slot blocks (slot block b of image i = item b + blocks * i)
-__global__ __launch_bounds__(64 * DESC_WAVES, 6) void k_describe_q(const uint8_t* __restrict__ pyr, size_t image_slab, LevelTable lt,
+__global__ __launch_bounds__(64 * DESC_WAVES) void k_describe_q(const uint8_t* __restrict__ pyr, size_t image_slab, LevelTable lt,
                                                                 const uint32_t* __restrict__ sel_key,
                                                                 const int32_t* __restrict__ sel_count, int slots_per_image,
                                                                 lpslam_hip_keypoint* __restrict__ kpts, uint8_t* __restrict__ desc,
