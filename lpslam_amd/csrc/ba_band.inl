@@ -385,7 +385,7 @@ __global__ __launch_bounds__(BC_THREADS) void k_chol_band(const BaView* __restri
     __syncthreads();
     int base = 0;                                        // c0 % 96
 #ifdef LPSLAM_BC_STAMPS
-    // development: wall-clock stamps (100 MHz) of wavefront 0 per strip into the padding rows of S (read back by tools/dev/band_stamps.py)
+    // development: wall-clock stamps (100 MHz) of wavefront 0 per strip into the padding rows of S (read back by tools/dev_band_stamps.py)
     GPTR(double) stamp = S + (size_t)(dim + 2) * n;
 #define BC_STAMP(slot) do { if (tid == 0 && team == 1) stamp[8 * s + (slot)] = (double)wall_clock64(); } while (0)
 #define BC_STAMP_W(w, slot) do { if (tid == 64 * (w) && team == 1) stamp[8 * s + (slot)] = (double)wall_clock64(); } while (0)
