@@ -285,6 +285,9 @@ int lpslam_hip_ba_pose_optimize(lpslam_hip_ba* ba, uint8_t* outlier, int32_t* n_
  * iteration flow on the device (pose7 in / out; obs[k].point indexes `points`, obs[k].pose is ignored). */
 int lpslam_hip_pose_optimize(lpslam_hip_ctx* ctx, double* pose7, const double* points, int32_t n_points, const lpslam_hip_ba_obs* obs,
                              int32_t n_obs, const lpslam_hip_ba_camera* cam, uint8_t* outlier, int32_t* n_inliers);
+/* Diagnostic: passes over the observations the last lpslam_hip_pose_optimize on this context made (one per round + one per
+ * Levenberg trial; the call's duration is this number times the latency of a trial). */
+int32_t lpslam_hip_pose_optimize_passes(lpslam_hip_ctx* ctx);
 /* local_bundle_adjuster flow: first_iters robust, outlier classification, second_iters plain. */
 int lpslam_hip_ba_local(lpslam_hip_ba* ba, int32_t first_iters, int32_t second_iters, uint8_t* outlier);
 /* Restores the poses / points / activity mask given at creation (kept in HBM) and clears the LM state. */

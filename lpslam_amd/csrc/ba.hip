@@ -18,6 +18,7 @@
 // The reduced system [S | rhs | b_p | diag H_pp | chi2] is one contiguous buffer, so a landmark-partitioned multi-GPU
 // solve needs one sum all-reduce of it per trial (lpslam_hip_ba_step_*).
 #include "internal.h"
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <cstddef>
@@ -1666,20 +1667,20 @@ __global__ __launch_bounds__(256) void k_ba_obs_chi2(const BaView* __restrict__ 
 // The tracker needs this once per frame: instead of ~600 launches through the general BA machinery the 6x6 system lives in
 // LDS and one launch returns the pose (one workgroup; several frames / candidates could share a launch, one workgroup each).
 struct PoShared {
-    double pose[7], trial[7];
-    double red[8][28];
-    double H[36], b[6], x[6];
-    double lambda, ni, current_chi, rho;
-    int ok, again, stop, bad;
+    double pose[7];
+    double red[8];                     // the wavefronts' partial sums of po_block_sum
+    double sums[28];                   // a pass's 28 sums (upper triangle of H, b, chi2)
 };
 
-// The kernel is one workgroup whose passes over the observations are its duration (measured with four wavefronts: 0.4 us per
-// observation and call, 470 us for 1000 observations): eight wavefronts -- one or two observations per thread at tracker sizes --
-// and, in the per-observation arithmetic, reciprocals and reciprocal square roots from v_rcp_f64 / v_rsq_f64 plus one cubic
-// correction step (1.4e-16 relative error, measured) where IEEE division and sqrt cost ~30 instructions each (a Jacobian held
-// thirteen of them).
+// The kernel is one workgroup and a chain of 50 - 65 dependent Levenberg trials; a trial is ~3 us of latency, not of arithmetic
+// (round 4, in-kernel cycle stamps: pass over the observations ~2000 cycles, the 28-value reduction ~1700, decision + 6x6 solve +
+// pose update ~3500).  Four wavefronts, one per SIMD: the reduction's register step costs every SIMD half of what it costs with
+// eight, the passes are issue-bound either way, and the serial section between two passes is executed by EVERY thread on
+// replicated registers (a SIMD runs one lane as fast as 64), so nothing is published and no barrier follows it.  In the
+// per-observation arithmetic, reciprocals and reciprocal square roots come from v_rcp_f64 / v_rsq_f64 plus one cubic correction
+// step (1.4e-16 relative error, measured) where IEEE division and sqrt cost ~30 instructions each.
 #ifndef LPSLAM_PO_T
-#define LPSLAM_PO_T 512
+#define LPSLAM_PO_T 256
 #endif
 constexpr int PO_T = LPSLAM_PO_T;
 static_assert(PO_T >= 128 && PO_T % 64 == 0, "k_pose_optimize: the 27-value reduction needs at least two wavefronts (one wavefront faulted on the device, round 4)");
@@ -1690,11 +1691,11 @@ __device__ __forceinline__ double po_block_sum(double v, PoShared& sh)
 {
     v = wave_sum(v);
     __syncthreads();
-    if ((threadIdx.x & 63) == 0) sh.red[threadIdx.x >> 6][27] = v;
+    if ((threadIdx.x & 63) == 0) sh.red[threadIdx.x >> 6] = v;
     __syncthreads();
-    double s = sh.red[0][27];
+    double s = sh.red[0];
 #pragma unroll
-    for (int w = 1; w < PO_W; ++w) s += sh.red[w][27];
+    for (int w = 1; w < PO_W; ++w) s += sh.red[w];
     return s;
 }
 __device__ __forceinline__ void po_quat_to_rot(const double* q, double* R)
@@ -1789,11 +1790,14 @@ __device__ __forceinline__ int po_residual(const BaCam& cam, const double* R, co
 // observations live there, the rest (only very large n) is read from global memory like before.
 struct PoObs { double u, v, ur, w, X[3]; };
 
+template <bool ALL_CACHED>
 struct PoData {
     const double* pts; const lpslam_hip_ba_obs* obs; const PoObs* cache; const uint8_t* act; int n, cache_n;
     __device__ __forceinline__ void get(int k, lpslam_hip_ba_obs& o, double* X) const
     {
-        if (k < cache_n) {
+        // (ALL_CACHED is a compile-time fact on purpose: with both sources in one function the compiler merges them into generic
+        // pointers and every LDS read becomes a flat load)
+        if (ALL_CACHED || k < cache_n) {
             const PoObs c = cache[k];
             o.pose = 0; o.point = 0; o.u = c.u; o.v = c.v; o.ur = c.ur; o.inv_sigma2 = c.w;
             X[0] = c.X[0]; X[1] = c.X[1]; X[2] = c.X[2];
@@ -1805,269 +1809,306 @@ struct PoData {
     }
 };
 
-__device__ double po_chi2(const BaCam& cam, const double* p7, const PoData& d, int robust, PoShared& sh)
-{
-    double R[9];
-    po_quat_to_rot(p7, R);
-    double chi = 0;
-    for (int k = threadIdx.x; k < d.n; k += PO_T) {
-        if (!d.act[k]) continue;
-        double e[3], pc[3], X[3];
-        lpslam_hip_ba_obs o;
-        d.get(k, o, X);
-        const int D = po_residual(cam, R, p7 + 4, X, o, e, pc);
-        double c = o.inv_sigma2 * (e[0] * e[0] + e[1] * e[1] + (D == 3 ? e[2] * e[2] : 0.0));
-        const double delta = D == 3 ? cam.hub_stereo : cam.hub_mono;
-        if (robust && delta > 0) { double r0, r1; po_huber(c, delta, &r0, &r1); c = r0; }
-        chi += c;
-    }
-    return po_block_sum(chi, sh);
-}
-
-// the 27 sums of H (upper triangle) and b over the PO_T threads: first over each quad of lanes in registers (two DPP exchanges per
-// value), then one lane of four stores its 27 partials transposed into LDS, 27 x PO_Q / 32 threads add 32 of them each
-// (interleaved: neighbouring lanes read neighbouring words -- with a contiguous chunk per lane every lane of a value hit the same
-// LDS bank, and this reduction was half the kernel) and shuffles finish the parts of a value.
+// The 28 sums of a pass (upper triangle of H, b, chi2) over the PO_T threads: first over each quad of lanes in registers (two DPP
+// exchanges per value), then one lane of four stores its 28 partials transposed into LDS, PO_T / 32 lanes per value add eight of
+// them each (interleaved: neighbouring lanes read neighbouring words) and finish inside their DPP row.
 template <int CTRL>
-__device__ __forceinline__ double quad_swap(double v)     // DPP quad_perm exchange (a shuffle would go through the LDS crossbar)
+__device__ __forceinline__ double quad_swap(double v)     // DPP exchange inside a row (a shuffle would go through the LDS crossbar)
 {
     const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
     const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
+constexpr int PO_NV = 28;                  // values per pass
 constexpr int PO_Q = PO_T / 4;             // partials per value after the quad step
-constexpr int PO_TR = PO_Q + 1;            // padded row of the transposed reduction buffer [27][PO_Q]
-__device__ __forceinline__ void po_reduce27(double (&acc)[27], double* tr, PoShared& sh)
+constexpr int PO_TR = PO_Q + 1;            // padded row of the transposed reduction buffer [PO_NV][PO_Q]
+constexpr int PO_LPV = PO_T / 32;          // lanes per value in the second step (16 = one DPP row at 512 threads)
+static_assert(PO_NV * PO_LPV <= PO_T && PO_Q == 8 * PO_LPV && (PO_LPV == 16 || PO_LPV == 8 || PO_LPV == 4), "po_reduce28 layout");
+__device__ __forceinline__ void po_reduce28(double (&acc)[PO_NV], double* tr, double* out)
 {
     const int tid = threadIdx.x;
 #pragma unroll
-    for (int q = 0; q < 27; ++q) {
+    for (int q = 0; q < PO_NV; ++q) {
         acc[q] += quad_swap<0xB1>(acc[q]);               // lanes 0<->1, 2<->3
         acc[q] += quad_swap<0x4E>(acc[q]);               // lanes 0<->2, 1<->3
     }
     if ((tid & 3) == 0) {
 #pragma unroll
-        for (int q = 0; q < 27; ++q) tr[q * PO_TR + (tid >> 2)] = acc[q];
+        for (int q = 0; q < PO_NV; ++q) tr[q * PO_TR + (tid >> 2)] = acc[q];
     }
     __syncthreads();
-    constexpr int PARTS = PO_Q / 32;
-    const int q = tid / PARTS, part = tid % PARTS;
+    const int q = tid / PO_LPV, j = tid % PO_LPV;
     double s = 0;
-    if (q < 27) {
-        const double* row = tr + q * PO_TR + part;
-#pragma unroll 8
-        for (int i = 0; i < 32; ++i) s += row[i * PARTS];
-    }
+    if (q < PO_NV) {
+        const double* row = tr + q * PO_TR + j;
+        double v[8];
 #pragma unroll
-    for (int o = PARTS / 2; o > 0; o >>= 1) s += __shfl_down(s, o, PARTS);
-    if (q < 27 && part == 0) sh.red[0][q] = s;
+        for (int i = 0; i < 8; ++i) v[i] = row[i * PO_LPV];
+        s = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    }
+    s += quad_swap<0xB1>(s);
+    s += quad_swap<0x4E>(s);
+    if (PO_LPV >= 8) s += quad_swap<0x141>(s);           // row_half_mirror: the other quad of the eight
+    if (PO_LPV >= 16) s += quad_swap<0x140>(s);          // row_mirror: the other half of the row
+    if (q < PO_NV && j == 0) out[q] = s;
     __syncthreads();
 }
 
+#ifdef LPSLAM_PO_STAMPS
+__device__ double g_po_stamps[16];
+#define PO_STAMP(k) do { if (threadIdx.x == 0) { const double now_ = (double)clock64(); po_acc[k] += now_ - po_last; po_last = now_; } } while (0)
+#define PO_ST_PARAM , double (&po_acc)[16], double& po_last
+#define PO_ST_ARG , po_acc, po_last
+#else
+#define PO_STAMP(k) do {} while (0)
+#define PO_ST_PARAM
+#define PO_ST_ARG
+#endif
 
-__global__ __launch_bounds__(PO_T) void k_pose_optimize(double* pose7, const double* pts, const lpslam_hip_ba_obs* obs, int n, BaCam cam,
-                                                       uint8_t* outlier, int* n_inliers, int cache_n)
+// One pass over the active observations at pose p7: the 27 sums of the linearised system (upper triangle of H, then b) and the
+// (robustified) chi2 as the 28th, into every thread's `sums`.  A trial's chi2 and the NEXT iteration's linearisation are the same
+// pass: the trial is accepted nearly always, and then its pose is the pose to linearise at (one reduction less per Levenberg
+// iteration; a rejected trial wastes the 27 sums).
+template <bool ALL_CACHED>
+__device__ __forceinline__ void po_pass(const BaCam& cam, const double (&p7)[7], const PoData<ALL_CACHED>& d, int robust, double* tr, PoShared& sh, double (&sums)[PO_NV] PO_ST_PARAM)
+{
+    const int tid = threadIdx.x;
+    double R[9];
+    po_quat_to_rot(p7, R);
+    const double t[3] = {p7[4], p7[5], p7[6]};
+    double acc[PO_NV];
+#pragma unroll
+    for (int q = 0; q < PO_NV; ++q) acc[q] = 0;
+    for (int k = tid; k < d.n; k += PO_T) {
+        if (!d.act[k]) continue;
+        double e[3], pc[3], B[3][6], X[3], iz;
+        lpslam_hip_ba_obs o;
+        d.get(k, o, X);
+        const int D = po_residual(cam, R, t, X, o, e, pc, &iz);
+        const double om = o.inv_sigma2;
+        const double chi = om * (e[0] * e[0] + e[1] * e[1] + (D == 3 ? e[2] * e[2] : 0.0));
+        const double delta = D == 3 ? cam.hub_stereo : cam.hub_mono;
+        double w = om, c = chi;
+        if (robust && delta > 0) { double r0, r1; po_huber(chi, delta, &r0, &r1); w *= r1; c = r0; }
+        acc[27] += c;
+        po_jacobian(cam, pc, iz, D, B);
+        // w B once (18 products), then every entry is three fused multiply-adds onto its running sum; the columns that
+        // are structurally zero (B[0][4], B[1][3], B[2][4]) are skipped by hand -- the compiler may not drop x * 0
+        double wB[3][6], we[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            we[r] = -w * e[r];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) wB[r][a] = w * B[r][a];
+        }
+        int idx = 0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+#pragma unroll
+            for (int c2 = a; c2 < 6; ++c2) {
+                double s2 = acc[idx];
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    const bool zero = (r == 0 && (a == 4 || c2 == 4)) || (r == 1 && (a == 3 || c2 == 3)) || (r == 2 && (a == 4 || c2 == 4));
+                    if (!zero) s2 = fma(wB[r][a], B[r][c2], s2);
+                }
+                acc[idx++] = s2;
+            }
+            double s3 = acc[21 + a];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const bool zero = (r == 0 && a == 4) || (r == 1 && a == 3) || (r == 2 && a == 4);
+                if (!zero) s3 = fma(B[r][a], we[r], s3);
+            }
+            acc[21 + a] = s3;
+        }
+    }
+    PO_STAMP(1);
+    po_reduce28(acc, tr, sh.sums);
+#pragma unroll
+    for (int q = 0; q < PO_NV; ++q) sums[q] = sh.sums[q];
+    PO_STAMP(2);
+#ifdef LPSLAM_PO_STAMPS
+    if (tid == 0) po_acc[15] += 1;
+#endif
+}
+
+// (H + lambda I) x = b by a 6x6 Cholesky factorisation and two substitutions, fully unrolled with constant indices (the matrix
+// stays in registers), then the trial pose; every thread computes its own copy.  Returns 0 when the matrix is not positive definite
+// (the trial is then the pose itself and x is not meaningful).
+__device__ __forceinline__ int po_solve_trial(const double (&sys)[PO_NV], double lam, const double (&pose)[7], double (&x)[6], double (&trial)[7] PO_ST_PARAM)
+{
+    double A[36];
+    {
+        int idx = 0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int c = a; c < 6; ++c, ++idx) { A[a * 6 + c] = sys[idx]; A[c * 6 + a] = sys[idx]; }
+    }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) A[j * 7] += lam;
+    int ok = 1;
+    double inv[6];                                     // 1 / L_jj: six divisions per solve instead of twenty-seven
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        double d2 = A[j * 6 + j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) d2 -= A[j * 6 + k] * A[j * 6 + k];
+        if (!(d2 > 0.0)) { ok = 0; d2 = 1.0; }         // keep going on harmless numbers; the result is discarded
+        inv[j] = po_rsqrt(d2);
+        A[j * 6 + j] = d2 * inv[j];
+#pragma unroll
+        for (int i = j + 1; i < 6; ++i) {
+            double s2 = A[i * 6 + j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) s2 -= A[i * 6 + k] * A[j * 6 + k];
+            A[i * 6 + j] = s2 * inv[j];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        double s2 = sys[21 + i];
+#pragma unroll
+        for (int k = 0; k < i; ++k) s2 -= A[i * 6 + k] * x[k];
+        x[i] = s2 * inv[i];
+    }
+#pragma unroll
+    for (int i = 5; i >= 0; --i) {
+        double s2 = x[i];
+#pragma unroll
+        for (int k = i + 1; k < 6; ++k) s2 -= A[k * 6 + i] * x[k];
+        x[i] = s2 * inv[i];
+    }
+    PO_STAMP(4);
+    double moved[7];
+    po_oplus(pose, x, moved);
+#pragma unroll
+    for (int i = 0; i < 7; ++i) trial[i] = ok ? moved[i] : pose[i];
+    PO_STAMP(5);
+    return ok;
+}
+
+// ALL_CACHED (every tracker-sized call): pose7 / packed / outlier / n_inliers / done_flag are page-locked HOST memory -- the workgroup
+// reads its inputs over PCIe in the prologue and writes the results straight back, then releases `seq` into *done_flag, which the
+// calling thread polls (no copy-engine packet on either side, no wait for the end-of-kernel cache flush).
+template <bool ALL_CACHED>
+__global__ __launch_bounds__(PO_T) void k_pose_optimize(double* pose7, const double* pts, const lpslam_hip_ba_obs* obs, const PoObs* packed, int n, BaCam cam,
+                                                       uint8_t* outlier, int* n_inliers, int cache_n, int* done_flag, int seq)
 {
     __shared__ PoShared sh;
     extern __shared__ double po_dyn[];
     double* tr = po_dyn;
-    PoObs* cache = reinterpret_cast<PoObs*>(po_dyn + 27 * PO_TR);
+    PoObs* cache = reinterpret_cast<PoObs*>(po_dyn + PO_NV * PO_TR);
     uint8_t* active = reinterpret_cast<uint8_t*>(cache + cache_n);
     const int tid = threadIdx.x;
+#ifdef LPSLAM_PO_STAMPS
+    double po_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, po_last = (double)clock64();
+#endif
     if (tid < 7) sh.pose[tid] = pose7[tid];
+    if (ALL_CACHED) {
+        static_assert(sizeof(PoObs) == 7 * sizeof(double), "PoObs is copied as doubles");
+        for (int i = tid; i < 7 * n; i += PO_T) reinterpret_cast<double*>(cache)[i] = reinterpret_cast<const double*>(packed)[i];
+    }
     for (int k = tid; k < n; k += PO_T) {
-        active[k] = 1; outlier[k] = 0;
-        if (k < cache_n) {
+        active[k] = 1;
+        if (!ALL_CACHED && k < cache_n) {
             const lpslam_hip_ba_obs o = obs[k];
             const double* p = pts + 3 * (size_t)o.point;
             PoObs c; c.u = o.u; c.v = o.v; c.ur = o.ur; c.w = o.inv_sigma2; c.X[0] = p[0]; c.X[1] = p[1]; c.X[2] = p[2];
             cache[k] = c;
         }
     }
-    if (tid == 0) sh.bad = 0;
     __syncthreads();
-    const PoData d{pts, obs, cache, active, n, cache_n};
-    int robust = 1;
+    const PoData<ALL_CACHED> d{pts, obs, cache, active, n, cache_n};
+    // from here on every thread holds the optimiser's state (pose, trial, system, lambda control) in its own registers
+    double pose[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) pose[i] = sh.pose[i];
+    int robust = 1, n_bad_last = 0, passes = 0;
+    PO_STAMP(0);
     for (int round = 0; round < 4; ++round) {
-        if (tid == 0) sh.stop = 0;
-        __syncthreads();
-        for (int it = 0; it < 10; ++it) {
-            if (sh.stop) break;
-            // chi2 of the accepted pose: computed at the start of a round (the kernel / the active set may have changed); later it
-            // is the value the accepted trial produced -- same pose, same data, same summation order, so not computed again.
-            // (Fusing the trial's chi2 with a speculative linearisation, as the window BA does, was measured slower here:
-            // the 27-sum pass costs more than the two passes it replaces save.)
-            const double cur = it == 0 ? po_chi2(cam, sh.pose, d, robust, sh) : sh.current_chi;
-            double R[9];
-            po_quat_to_rot(sh.pose, R);
-            double acc[27];
+        // chi2 and linearisation at the round's starting pose (the kernel / the active set may have changed), then trial after
+        // trial: every pass evaluates the trial in flight AND linearises at it; g2o's Levenberg control runs between the passes:
+        // up to ten iterations, each with up to ten trials of growing lambda.
+        double sys[PO_NV], fresh[PO_NV], x[6], trial[7];
+        po_pass(cam, pose, d, robust, tr, sh, sys PO_ST_ARG);
+        ++passes;
+        double lambda = 1e-5 * fmax(fmax(fmax(fabs(sys[0]), fabs(sys[6])), fmax(fabs(sys[11]), fabs(sys[15]))), fmax(fabs(sys[18]), fabs(sys[20])));
+        double ni = 2, current_chi = sys[27];
+        int it = 0, qmax = 1;
+        PO_STAMP(3);
+        int ok = po_solve_trial(sys, lambda, pose, x, trial PO_ST_ARG);
+        for (;;) {
+            po_pass(cam, trial, d, robust, tr, sh, fresh PO_ST_ARG);
+            ++passes;
+            const double temp = ok ? fresh[27] : DBL_MAX;
+            double rho = current_chi - temp, scale = 0;
+            if (ok) {
 #pragma unroll
-            for (int q = 0; q < 27; ++q) acc[q] = 0;
-            for (int k = tid; k < n; k += PO_T) {
-                if (!active[k]) continue;
-                double e[3], pc[3], B[3][6], X[3], iz;
-                lpslam_hip_ba_obs o;
-                d.get(k, o, X);
-                const int D = po_residual(cam, R, sh.pose + 4, X, o, e, pc, &iz);
-                const double om = o.inv_sigma2;
-                const double chi = om * (e[0] * e[0] + e[1] * e[1] + (D == 3 ? e[2] * e[2] : 0.0));
-                const double delta = D == 3 ? cam.hub_stereo : cam.hub_mono;
-                double w = om;
-                if (robust && delta > 0) { double r0, r1; po_huber(chi, delta, &r0, &r1); w *= r1; }
-                po_jacobian(cam, pc, iz, D, B);
-                // w B once (18 products), then every entry is three fused multiply-adds onto its running sum; the columns that
-                // are structurally zero (B[0][4], B[1][3], B[2][4]) are skipped by hand -- the compiler may not drop x * 0
-                double wB[3][6], we[3];
-#pragma unroll
-                for (int r = 0; r < 3; ++r) {
-                    we[r] = -w * e[r];
-#pragma unroll
-                    for (int a = 0; a < 6; ++a) wB[r][a] = w * B[r][a];
-                }
-                int idx = 0;
-#pragma unroll
-                for (int a = 0; a < 6; ++a) {
-#pragma unroll
-                    for (int c = a; c < 6; ++c) {
-                        double s2 = acc[idx];
-#pragma unroll
-                        for (int r = 0; r < 3; ++r) {
-                            const bool zero = (r == 0 && (a == 4 || c == 4)) || (r == 1 && (a == 3 || c == 3)) || (r == 2 && (a == 4 || c == 4));
-                            if (!zero) s2 = fma(wB[r][a], B[r][c], s2);
-                        }
-                        acc[idx++] = s2;
-                    }
-                    double s3 = acc[21 + a];
-#pragma unroll
-                    for (int r = 0; r < 3; ++r) {
-                        const bool zero = (r == 0 && a == 4) || (r == 1 && a == 3) || (r == 2 && a == 4);
-                        if (!zero) s3 = fma(B[r][a], we[r], s3);
-                    }
-                    acc[21 + a] = s3;
-                }
+                for (int j = 0; j < 6; ++j) scale += x[j] * (lambda * x[j] + sys[21 + j]);
             }
-            po_reduce27(acc, tr, sh);
-            // thread 0 keeps the system it solves (up to ten times per iteration, with growing lambda) in registers: 27 LDS reads here
-            // instead of 42 stores and 42 loads through sh.H / sh.b per solve
-            double Hs[21], bs[6];
-            if (tid == 0) {
+            scale += 1e-3;
+            rho *= po_rcp(scale);
+            if (rho > 0 && isfinite(temp)) {
+                const double t3 = 2 * rho - 1;
+                double alpha = 1. - t3 * t3 * t3;
+                alpha = fmin(alpha, 2. / 3.);
+                lambda *= fmax(1. / 3., alpha);
+                ni = 2;
+                current_chi = temp;
 #pragma unroll
-                for (int q = 0; q < 21; ++q) Hs[q] = sh.red[0][q];
+                for (int i = 0; i < 7; ++i) pose[i] = trial[i];
 #pragma unroll
-                for (int a = 0; a < 6; ++a) bs[a] = sh.red[0][21 + a];
-                const double maxd = fmax(fmax(fmax(fabs(Hs[0]), fabs(Hs[6])), fmax(fabs(Hs[11]), fabs(Hs[15]))), fmax(fabs(Hs[18]), fabs(Hs[20])));
-                if (it == 0) { sh.lambda = 1e-5 * maxd; sh.ni = 2; }
-                sh.current_chi = cur;
+                for (int q = 0; q < PO_NV; ++q) sys[q] = fresh[q];           // the pass just made linearised at the accepted pose
+            } else {
+                lambda *= ni; ni *= 2;
             }
-            // (no barrier: the system just assembled is read by the same thread below)
-            for (int qmax = 1; qmax <= 10; ++qmax) {
-                if (tid == 0) {
-                    // 6x6 Cholesky + two substitutions, fully unrolled with constant indices: the matrix stays in registers (with
-                    // run-time loop bounds and the early exit it lived in scratch memory, ~100 dependent memory round trips per solve)
-                    double A[36];
-                    {
-                        int idx = 0;
-#pragma unroll
-                        for (int a = 0; a < 6; ++a)
-#pragma unroll
-                            for (int c = a; c < 6; ++c, ++idx) { A[a * 6 + c] = Hs[idx]; A[c * 6 + a] = Hs[idx]; }
-                    }
-                    const double lam = sh.lambda;
-#pragma unroll
-                    for (int j = 0; j < 6; ++j) A[j * 7] += lam;
-                    int ok = 1;
-                    double inv[6];                                     // 1 / L_jj: six divisions per solve instead of twenty-seven
-#pragma unroll
-                    for (int j = 0; j < 6; ++j) {
-                        double d2 = A[j * 6 + j];
-#pragma unroll
-                        for (int k = 0; k < j; ++k) d2 -= A[j * 6 + k] * A[j * 6 + k];
-                        if (!(d2 > 0.0)) { ok = 0; d2 = 1.0; }         // keep going on harmless numbers; the result is discarded
-                        inv[j] = po_rsqrt(d2);
-                        A[j * 6 + j] = d2 * inv[j];
-#pragma unroll
-                        for (int i = j + 1; i < 6; ++i) {
-                            double s2 = A[i * 6 + j];
-#pragma unroll
-                            for (int k = 0; k < j; ++k) s2 -= A[i * 6 + k] * A[j * 6 + k];
-                            A[i * 6 + j] = s2 * inv[j];
-                        }
-                    }
-                    if (ok) {
-                        double x[6];
-#pragma unroll
-                        for (int i = 0; i < 6; ++i) {
-                            double s2 = bs[i];
-#pragma unroll
-                            for (int k = 0; k < i; ++k) s2 -= A[i * 6 + k] * x[k];
-                            x[i] = s2 * inv[i];
-                        }
-#pragma unroll
-                        for (int i = 5; i >= 0; --i) {
-                            double s2 = x[i];
-#pragma unroll
-                            for (int k = i + 1; k < 6; ++k) s2 -= A[k * 6 + i] * x[k];
-                            x[i] = s2 * inv[i];
-                        }
-#pragma unroll
-                        for (int i = 0; i < 6; ++i) sh.x[i] = x[i];
-                        po_oplus(sh.pose, x, sh.trial);
-                    } else {
-#pragma unroll
-                        for (int i = 0; i < 7; ++i) sh.trial[i] = sh.pose[i];
-                    }
-                    sh.ok = ok;
-                }
-                __syncthreads();
-                double temp = po_chi2(cam, sh.trial, d, robust, sh);
-                if (tid == 0) {
-                    if (!sh.ok) temp = DBL_MAX;
-                    double rho = sh.current_chi - temp, scale = 0;
-                    if (sh.ok) for (int j = 0; j < 6; ++j) scale += sh.x[j] * (sh.lambda * sh.x[j] + bs[j]);
-                    scale += 1e-3;
-                    rho *= po_rcp(scale);
-                    if (rho > 0 && isfinite(temp)) {
-                        const double t3 = 2 * rho - 1;
-                        double alpha = 1. - t3 * t3 * t3;
-                        alpha = fmin(alpha, 2. / 3.);
-                        sh.lambda *= fmax(1. / 3., alpha);
-                        sh.ni = 2;
-                        sh.current_chi = temp;
-                        for (int i = 0; i < 7; ++i) sh.pose[i] = sh.trial[i];
-                    } else {
-                        sh.lambda *= sh.ni; sh.ni *= 2;
-                    }
-                    sh.again = (rho < 0 && qmax < 10) ? 1 : 0;
-                    if (!sh.again && (qmax == 10 || rho == 0)) sh.stop = 1;
-                }
-                __syncthreads();
-                if (!sh.again) break;
+            if (rho < 0 && qmax < 10) ++qmax;                                // another trial of this iteration
+            else {
+                ++it;
+                if (qmax == 10 || rho == 0 || it == 10) break;
+                qmax = 1;
             }
+            PO_STAMP(3);
+            ok = po_solve_trial(sys, lambda, pose, x, trial PO_ST_ARG);
         }
-        __syncthreads();
         // classification with the plain chi2 of this round's pose
         double R[9];
-        po_quat_to_rot(sh.pose, R);
+        po_quat_to_rot(pose, R);
         int bad = 0;
         for (int k = tid; k < n; k += PO_T) {
             double e[3], pc[3], X[3];
             lpslam_hip_ba_obs o;
             d.get(k, o, X);
-            const int D = po_residual(cam, R, sh.pose + 4, X, o, e, pc);
+            const int D = po_residual(cam, R, pose + 4, X, o, e, pc);
             const double chi = o.inv_sigma2 * (e[0] * e[0] + e[1] * e[1] + (D == 3 ? e[2] * e[2] : 0.0));
             const double thr = D == 3 ? 7.81473 : 5.99146;
             const int out = thr < chi ? 1 : 0;
-            outlier[k] = (uint8_t)out; active[k] = (uint8_t)!out;
+            active[k] = (uint8_t)!out;
             bad += out;
         }
-        const int n_bad = (int)po_block_sum((double)bad, sh);
-        if (tid == 0) sh.bad = n_bad;
+        n_bad_last = (int)po_block_sum((double)bad, sh);
         if (round == 2) robust = 0;
         __syncthreads();
-        if (n - n_bad < 5) break;
+        PO_STAMP(8);
+        if (n - n_bad_last < 5) break;
     }
-    if (tid < 7) pose7[tid] = sh.pose[tid];
-    if (tid == 0) *n_inliers = n - sh.bad;
+#ifdef LPSLAM_PO_STAMPS
+    if (tid == 0) for (int k = 0; k < 16; ++k) g_po_stamps[k] = po_acc[k];
+#endif
+    for (int k = tid; k < n; k += PO_T) outlier[k] = active[k] ? 0 : 1;       // the last classification made
+    if (tid == 0) {
+#pragma unroll
+        for (int i = 0; i < 7; ++i) pose7[i] = pose[i];
+        n_inliers[0] = n - n_bad_last;
+        n_inliers[1] = passes;
+    }
+    if (done_flag) {
+        __threadfence_system();
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(done_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 #include "ba_build.inl"
@@ -2734,6 +2775,7 @@ int lpslam_hip_ba_optimize_begin(lpslam_hip_ba* b, int32_t robust, int32_t iters
 
 int64_t lpslam_hip_ba_graph_replays(lpslam_hip_ctx* c) { return c ? (int64_t)c->ba_graph_replays.load() : 0; }
 int64_t lpslam_hip_ba_wg_factorisations(lpslam_hip_ctx* c) { return c ? (int64_t)c->ba_wg_launches.load() : 0; }
+int32_t lpslam_hip_pose_optimize_passes(lpslam_hip_ctx* c) { return c ? c->po_passes : 0; }
 
 int lpslam_hip_ba_optimize_end(lpslam_hip_ba* b, lpslam_hip_ba_iter_log* log, int32_t* done_out)
 {
@@ -3113,9 +3155,71 @@ int lpslam_hip_pose_optimize(lpslam_hip_ctx* ctx, double* pose7, const double* p
     for (int k = 0; k < n_obs; ++k) if (obs[k].point < 0 || obs[k].point >= n_points) { set_error("observation %d references point %d out of range", k, obs[k].point); return LPSLAM_HIP_ERR_INVALID; }
     LP_HIP(hipSetDevice(ctx->cfg.device));
     hipStream_t s = ctx->stream;
-    // one block of the context's cache holds everything: pose | n_inliers | points | observations | active | outlier
+    const BaCam c{cam->fx, cam->fy, cam->cx, cam->cy, cam->focal_x_baseline, cam->huber_mono, cam->huber_stereo};
     const size_t no = (size_t)std::max(n_obs, 1), np = (size_t)std::max(n_points, 1);
+    // dynamic LDS: transposed reduction buffer + as many observations as fit beside it + one activity byte per observation
+    constexpr size_t kPoLdsBudget = 150 * 1024;
+    const size_t fixed_lds = PO_NV * PO_TR * sizeof(double) + no + 64;
+    const int cache_n = (int)std::min<size_t>((size_t)n_obs, fixed_lds < kPoLdsBudget ? (kPoLdsBudget - fixed_lds) / sizeof(PoObs) : 0);
+    const size_t lds = PO_NV * PO_TR * sizeof(double) + (size_t)cache_n * sizeof(PoObs) + no + 64;
+    if (lds > kPoLdsBudget + 4096) { set_error("pose optimiser: %d observations exceed the LDS activity array", n_obs); return LPSLAM_HIP_ERR_CAPACITY; }
+    {
+        static std::atomic<bool> po_attr[64];
+        int dev = 0; (void)hipGetDevice(&dev);
+        if (dev >= 0 && dev < 64 && !po_attr[dev].load()) {
+            (void)hipFuncSetAttribute((const void*)k_pose_optimize<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kPoLdsBudget + 4096));
+            (void)hipFuncSetAttribute((const void*)k_pose_optimize<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kPoLdsBudget + 4096));
+            po_attr[dev].store(true);
+        }
+    }
+    const bool all_cached = cache_n == n_obs;
+    // page-locked block: pose (in and out) | inlier count | done flag | then either the packed observations and the outlier bytes
+    // (all_cached: the kernel works on this block directly) or a mirror of the device block below
     const size_t off_pts = 128, off_obs = off_pts + 3 * np * sizeof(double), off_out = off_obs + no * sizeof(lpslam_hip_ba_obs);
+    const size_t off_packed = 128, off_flags = off_packed + no * sizeof(PoObs);
+    const size_t need = all_cached ? off_flags + no : off_out + no;
+    if (ctx->h_match_bytes < need) {
+        if (ctx->h_match) { LP_HIP(hipStreamSynchronize(s)); (void)hipHostFree(ctx->h_match); }
+        ctx->h_match = nullptr; ctx->h_match_bytes = 0;
+        LP_HIP(hipHostMalloc((void**)&ctx->h_match, need * 2, hipHostMallocDefault));
+        ctx->h_match_bytes = need * 2;
+    }
+    uint8_t* hb = ctx->h_match;
+    memcpy(hb, pose7, 7 * sizeof(double));
+    int32_t inl = 0;
+    if (all_cached) {
+        PoObs* packed = (PoObs*)(hb + off_packed);
+        for (int k = 0; k < n_obs; ++k) {
+            const lpslam_hip_ba_obs& o = obs[k];
+            const double* p = points + 3 * (size_t)o.point;
+            packed[k] = PoObs{o.u, o.v, o.ur, o.inv_sigma2, {p[0], p[1], p[2]}};
+        }
+        int* flag = (int*)(hb + 64);
+        const int seq = ++ctx->po_seq;
+        __atomic_store_n(flag, 0, __ATOMIC_RELAXED);          // (the block is shared with the matchers' staging: whatever they left here is not a sequence number)
+        hipLaunchKernelGGL(k_pose_optimize<true>, dim3(1), dim3(PO_T), lds, s, (double*)hb, (const double*)nullptr, (const lpslam_hip_ba_obs*)nullptr, packed, n_obs, c,
+                           hb + off_flags, (int*)(hb + 56), cache_n, flag, seq);
+        LP_HIP(hipGetLastError());
+        // the kernel's last store releases `seq`: poll it (a few hundred microseconds at most), fall back to the stream when it does not come
+        const auto t0 = std::chrono::steady_clock::now();
+        bool seen = false;
+        for (int spin = 0; ; ++spin) {
+            if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) { seen = true; break; }
+            __builtin_ia32_pause();
+            if ((spin & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
+        }
+        if (!seen) {
+            LP_HIP(hipStreamSynchronize(s));
+            if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) { set_error("pose optimiser: the kernel did not complete"); return LPSLAM_HIP_ERR_DEVICE; }
+        }
+        memcpy(pose7, hb, 7 * sizeof(double));
+        memcpy(&inl, hb + 56, sizeof(int));
+        memcpy(&ctx->po_passes, hb + 60, sizeof(int));
+        if (outlier && n_obs) memcpy(outlier, hb + off_flags, (size_t)n_obs);
+        if (n_inliers) *n_inliers = inl;
+        return LPSLAM_HIP_OK;
+    }
+    // more observations than the LDS holds: one block of the context's cache, pose | n_inliers | points | observations | outlier
     void* blk = nullptr; size_t cap = 0;
     { const int rc = lp_pool_alloc(ctx, off_out + no, &blk, &cap); if (rc) return rc; }
     auto release = [&]() { lp_pool_free(ctx, blk, cap); };
@@ -3123,44 +3227,27 @@ int lpslam_hip_pose_optimize(lpslam_hip_ctx* ctx, double* pose7, const double* p
     uint8_t* base = (uint8_t*)blk;
     double* d_pose = (double*)base; int* d_n = (int*)(base + 64); double* d_pts = (double*)(base + off_pts);
     lpslam_hip_ba_obs* d_obs = (lpslam_hip_ba_obs*)(base + off_obs); uint8_t* d_out = base + off_out;
-    // inputs assembled in the context's pinned mirror of the block and sent as one copy (pose | - | points | observations)
-    if (ctx->h_match_bytes < off_out + no) {
-        if (ctx->h_match) (void)hipHostFree(ctx->h_match);
-        ctx->h_match = nullptr; ctx->h_match_bytes = 0;
-        PO_HIP(hipHostMalloc((void**)&ctx->h_match, (off_out + no) * 2, hipHostMallocDefault));
-        ctx->h_match_bytes = (off_out + no) * 2;
-    }
-    uint8_t* hb = ctx->h_match;
-    memcpy(hb, pose7, 7 * sizeof(double));
     if (n_points) memcpy(hb + off_pts, points, 3 * (size_t)n_points * sizeof(double));
     if (n_obs) memcpy(hb + off_obs, obs, (size_t)n_obs * sizeof(lpslam_hip_ba_obs));
     PO_HIP(hipMemcpyAsync(base, hb, off_out, hipMemcpyHostToDevice, s));
-    const BaCam c{cam->fx, cam->fy, cam->cx, cam->cy, cam->focal_x_baseline, cam->huber_mono, cam->huber_stereo};
-    // dynamic LDS: transposed reduction buffer + as many observations as fit beside it + one activity byte per observation
-    constexpr size_t kPoLdsBudget = 150 * 1024;
-    const size_t fixed_lds = 27 * PO_TR * sizeof(double) + no + 64;
-    const int cache_n = (int)std::min<size_t>((size_t)n_obs, fixed_lds < kPoLdsBudget ? (kPoLdsBudget - fixed_lds) / sizeof(PoObs) : 0);
-    const size_t lds = 27 * PO_TR * sizeof(double) + (size_t)cache_n * sizeof(PoObs) + no + 64;
-    if (lds > kPoLdsBudget + 4096) { release(); set_error("pose optimiser: %d observations exceed the LDS activity array", n_obs); return LPSLAM_HIP_ERR_CAPACITY; }
-    {
-        static std::atomic<bool> po_attr[64];
-        int dev = 0; (void)hipGetDevice(&dev);
-        if (dev >= 0 && dev < 64 && !po_attr[dev].load()) { (void)hipFuncSetAttribute((const void*)k_pose_optimize, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kPoLdsBudget + 4096)); po_attr[dev].store(true); }
-    }
-    hipLaunchKernelGGL(k_pose_optimize, dim3(1), dim3(PO_T), lds, s, d_pose, d_pts, d_obs, n_obs, c, d_out, d_n, cache_n);
+    hipLaunchKernelGGL(k_pose_optimize<false>, dim3(1), dim3(PO_T), lds, s, d_pose, d_pts, d_obs, (const PoObs*)nullptr, n_obs, c, d_out, d_n, cache_n, (int*)nullptr, 0);
     PO_HIP(hipGetLastError());
-    int32_t inl = 0;
     PO_HIP(hipMemcpyAsync(hb, base, 128, hipMemcpyDeviceToHost, s));                    // pose and inlier count
     if (outlier && n_obs) PO_HIP(hipMemcpyAsync(hb + off_out, d_out, (size_t)n_obs, hipMemcpyDeviceToHost, s));
     PO_HIP(hipStreamSynchronize(s));
     memcpy(pose7, hb, 7 * sizeof(double));
     memcpy(&inl, hb + 64, sizeof(int));
+    memcpy(&ctx->po_passes, hb + 68, sizeof(int));
     if (outlier && n_obs) memcpy(outlier, hb + off_out, (size_t)n_obs);
 #undef PO_HIP
     release();
     if (n_inliers) *n_inliers = inl;
     return LPSLAM_HIP_OK;
 }
+
+#ifdef LPSLAM_PO_STAMPS
+extern "C" __attribute__((visibility("default"))) int lpslam_hip_debug_po_stamps(double* out16) { return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_po_stamps), 16 * sizeof(double)); }
+#endif
 
 int lpslam_hip_ba_pose_optimize(lpslam_hip_ba* b, uint8_t* outlier, int32_t* n_inliers)
 {

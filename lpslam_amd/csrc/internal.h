@@ -107,6 +107,8 @@ struct lpslam_hip_ctx {
     std::vector<std::pair<size_t, void*>> pin_big;   // idle page-locked staging blocks (capacity, block) of lp_pin_big_alloc / free
     uint8_t* h_match = nullptr;        // pinned host staging of the window matchers (queries in, candidate lists out)
     size_t h_match_bytes = 0;
+    int po_passes = 0;                 // passes the last pose optimisation made (diagnostic)
+    int po_seq = 0;                    // sequence number the pose optimiser's kernel releases into its done flag (h_match + 64)
     int2* d_band_rows = nullptr;       // [band count 0..32][levels][bands]: rows of each level a band work-group computes
 
     // FAST output: per cell fixed slots + counts

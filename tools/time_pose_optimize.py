@@ -14,4 +14,5 @@ for n in (100, 200, 300, 500, 1000, 2000):
     for _ in range(2): hip.pose_optimize(ctx, pose, prob["points"], obs, prob["cam"])
     t = time.perf_counter()
     for _ in range(20): p7, out, inl = hip.pose_optimize(ctx, pose, prob["points"], obs, prob["cam"])
-    print("%5d observations: %.3f ms per call, %d inliers" % (len(obs), 1e3 * (time.perf_counter() - t) / 20, inl))
+    dt = (time.perf_counter() - t) / 20
+    print("%5d observations: %.3f ms per call, %d passes, %.2f us per pass, %d inliers" % (len(obs), 1e3 * dt, ctx.pose_optimize_passes(), 1e6 * dt / ctx.pose_optimize_passes(), inl))
