@@ -388,6 +388,7 @@ void lpslam_hip_destroy(lpslam_hip_ctx* c)
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (c->d_cu_table) (void)hipFree(c->d_cu_table);
     if (c->d_fe_counters) (void)hipFree(c->d_fe_counters);
+    if (c->d_done) (void)hipFree(c->d_done);
     for (int i = 0; i < LPSLAM_HIP_MAX_TIMERS; ++i) { if (c->ev_begin[i]) (void)hipEventDestroy(c->ev_begin[i]); if (c->ev_end[i]) (void)hipEventDestroy(c->ev_end[i]); }
     for (void* p : c->pin_free) (void)hipHostFree(p);
     c->pin_free.clear();
@@ -811,28 +812,72 @@ int lpslam_hip_get_keypoints(lpslam_hip_ctx* c, int image, lpslam_hip_keypoint* 
 // One frame's results in one round trip: count, keypoints, descriptors and the stereo columns are copied (whole slots, the count
 // is not known yet) into a pinned staging block of the context with a single synchronisation, then the first `count` entries go
 // to the caller's arrays.  The separate getters cost a synchronisation each and stage pageable memory copy by copy.
+}  // extern "C"
+
+unsigned* lp_done_counter(lpslam_hip_ctx* c, int which)
+{
+    if (!c->d_done) {
+        if (hipMalloc((void**)&c->d_done, 8 * 32 * sizeof(unsigned)) != hipSuccess) { c->d_done = nullptr; return nullptr; }
+        // (the context's streams do not synchronise with the null stream: the zeroes must be there before any of them runs a kernel)
+        if (hipMemset(c->d_done, 0, 8 * 32 * sizeof(unsigned)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { (void)hipFree(c->d_done); c->d_done = nullptr; return nullptr; }
+    }
+    return c->d_done + 32 * (which & 7);
+}
+
+namespace {
+// One frame's results into page-locked host memory: count, then the first `count` keypoints / descriptors / stereo columns / depths
+// as 32-bit words (the device knows the count; the copy engines would have to move all the slots, in five packets).
+__global__ __launch_bounds__(256) void k_frame_to_host(const int* __restrict__ d_count, const uint32_t* __restrict__ kp, const uint32_t* __restrict__ desc,
+                                                       const uint32_t* __restrict__ xr, const uint32_t* __restrict__ dep, uint32_t* __restrict__ st,
+                                                       int o_kp, int o_desc, int o_xr, int o_dep, int slots, unsigned* counter, int* flag, int seq)
+{
+    const int n = min(max(*d_count, 0), slots);
+    const int w_kp = kp ? 7 * n : 0, w_desc = desc ? 8 * n : 0, w_xr = xr ? n : 0, w_dep = dep ? n : 0;
+    const int total = w_kp + w_desc + w_xr + w_dep;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        if (i < w_kp) st[o_kp + i] = kp[i];
+        else if (i < w_kp + w_desc) st[o_desc + i - w_kp] = desc[i - w_kp];
+        else if (i < w_kp + w_desc + w_xr) st[o_xr + i - w_kp - w_desc] = xr[i - w_kp - w_desc];
+        else st[o_dep + i - w_kp - w_desc - w_xr] = dep[i - w_kp - w_desc - w_xr];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) st[0] = (uint32_t)*d_count;
+    lp_signal_done(counter, flag, seq);
+}
+}  // namespace
+
+extern "C" {
+
 int lpslam_hip_get_frame(lpslam_hip_ctx* c, int image, lpslam_hip_keypoint* kpts, uint8_t* desc32, float* stereo_x_right, float* depths,
                          int32_t capacity, int32_t* count)
 {
     int rc = check_image(c, image); if (rc) return rc;
+    static_assert(sizeof(lpslam_hip_keypoint) == 28, "k_frame_to_host moves keypoints as seven words");
     const size_t S = (size_t)c->slots_per_image;
+    // page-locked block: count | done flag | keypoints | descriptors | stereo columns | depths
     const size_t o_kp = 64, o_desc = o_kp + ((S * sizeof(lpslam_hip_keypoint) + 63) / 64) * 64, o_xr = o_desc + S * 32, o_dep = o_xr + ((S * 4 + 63) / 64) * 64;
     const size_t need = o_dep + S * 4;
     if (c->h_stage_bytes < need) {
-        if (c->h_stage) (void)hipHostFree(c->h_stage);
+        if (c->h_stage) { LP_HIP(hipStreamSynchronize(c->stream)); (void)hipHostFree(c->h_stage); }
         c->h_stage = nullptr; c->h_stage_bytes = 0;
         LP_HIP(hipHostMalloc((void**)&c->h_stage, need, hipHostMallocDefault));
         c->h_stage_bytes = need;
     }
+    unsigned* counter = lp_done_counter(c, 0);
+    if (!counter) { set_error("device memory for the completion counters"); return LPSLAM_HIP_ERR_DEVICE; }
     uint8_t* st = c->h_stage;
+    int* flag = (int*)(st + 32);
+    const int seq = ++c->done_seq;
+    __atomic_store_n(flag, 0, __ATOMIC_RELAXED);
     const size_t o = (size_t)image * S;
-    LP_HIP(hipMemcpyAsync(st, c->d_kp_count + image, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-    if (kpts) LP_HIP(hipMemcpyAsync(st + o_kp, c->d_kpts + o, S * sizeof(lpslam_hip_keypoint), hipMemcpyDeviceToHost, c->stream));
-    if (desc32) LP_HIP(hipMemcpyAsync(st + o_desc, c->d_desc + o * 32, S * 32, hipMemcpyDeviceToHost, c->stream));
     const float* f = c->d_stereo + o * 2;
-    if (stereo_x_right) LP_HIP(hipMemcpyAsync(st + o_xr, f, S * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    if (depths) LP_HIP(hipMemcpyAsync(st + o_dep, f + S, S * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    LP_HIP(hipStreamSynchronize(c->stream));
+    const int want_words = (int)S * ((kpts ? 7 : 0) + (desc32 ? 8 : 0) + (stereo_x_right ? 1 : 0) + (depths ? 1 : 0));
+    const int blocks = std::max(1, std::min(64, (want_words + 1023) / 1024));
+    hipLaunchKernelGGL(k_frame_to_host, dim3(blocks), dim3(256), 0, c->stream, (const int*)(c->d_kp_count + image),
+                       kpts ? (const uint32_t*)(c->d_kpts + o) : nullptr, desc32 ? (const uint32_t*)(c->d_desc + o * 32) : nullptr,
+                       stereo_x_right ? (const uint32_t*)f : nullptr, depths ? (const uint32_t*)(f + S) : nullptr, (uint32_t*)st,
+                       (int)(o_kp / 4), (int)(o_desc / 4), (int)(o_xr / 4), (int)(o_dep / 4), (int)S, counter, flag, seq);
+    LP_HIP(hipGetLastError());
+    if (!lp_wait_done(flag, seq, c->stream)) { set_error("lpslam_hip_get_frame: the read-back kernel did not complete"); return LPSLAM_HIP_ERR_DEVICE; }
     int32_t n = 0;
     memcpy(&n, st, sizeof(n));
     if ((size_t)image < c->h_kp_valid.size()) { c->h_kp_count[(size_t)image] = n; c->h_kp_valid[(size_t)image] = 1; }

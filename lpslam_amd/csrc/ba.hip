@@ -1678,7 +1678,9 @@ struct PoShared {
 // eight, the passes are issue-bound either way, and the serial section between two passes is executed by EVERY thread on
 // replicated registers (a SIMD runs one lane as fast as 64), so nothing is published and no barrier follows it.  In the
 // per-observation arithmetic, reciprocals and reciprocal square roots come from v_rcp_f64 / v_rsq_f64 plus one cubic correction
-// step (1.4e-16 relative error, measured) where IEEE division and sqrt cost ~30 instructions each.
+// step (1.4e-16 relative error, measured) where IEEE division and sqrt cost ~30 instructions each.  Products and sums are contracted
+// to fused multiply-adds in these functions (the rest of the file is compiled without contraction): the Cholesky solve alone went
+// from 107 multiplications + 73 additions to half as many instructions on the serial section's critical path.
 #ifndef LPSLAM_PO_T
 #define LPSLAM_PO_T 256
 #endif
@@ -1700,6 +1702,7 @@ __device__ __forceinline__ double po_block_sum(double v, PoShared& sh)
 }
 __device__ __forceinline__ void po_quat_to_rot(const double* q, double* R)
 {
+#pragma clang fp contract(fast)
     const double rn = po_rsqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
     const double w = q[0] * rn, x = q[1] * rn, y = q[2] * rn, z = q[3] * rn;
     R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - w * z);     R[2] = 2 * (x * z + w * y);
@@ -1708,13 +1711,38 @@ __device__ __forceinline__ void po_quat_to_rot(const double* q, double* R)
 }
 __device__ __forceinline__ void po_huber(double e2, double delta, double* rho0, double* rho1)
 {
+#pragma clang fp contract(fast)
     const double dsqr = delta * delta;
     if (e2 <= dsqr) { *rho0 = e2; *rho1 = 1.0; }
     else { const double rs = po_rsqrt(e2); *rho0 = 2 * (e2 * rs) * delta - dsqr; *rho1 = delta * rs; }
 }
-// pose_oplus with one sincos of the half angle and the fast reciprocals (this runs in one thread between two barriers)
+// sin and cos of a half angle up to 0.5 rad (every Levenberg step of a tracked frame) from their Taylor polynomials -- two
+// interleaved Horner chains of eight terms, truncation below 1e-18 -- instead of the library's ~130 instructions of argument
+// reduction; larger angles take the library call
+__device__ __forceinline__ void po_sincos_half(double h, double* sn, double* cs)
+{
+    if (h <= 0.5) {
+        const double z = h * h;
+        double ps = 1.0 / 355687428096000.0, pc = 1.0 / 20922789888000.0;     // 1 / 17!, 1 / 16!
+        ps = fma(ps, -z, 1.0 / 1307674368000.0);  pc = fma(pc, -z, 1.0 / 87178291200.0);       // 1 / 15!, 1 / 14!
+        ps = fma(ps, -z, 1.0 / 6227020800.0);     pc = fma(pc, -z, 1.0 / 479001600.0);         // 1 / 13!, 1 / 12!
+        ps = fma(ps, -z, 1.0 / 39916800.0);       pc = fma(pc, -z, 1.0 / 3628800.0);           // 1 / 11!, 1 / 10!
+        ps = fma(ps, -z, 1.0 / 362880.0);         pc = fma(pc, -z, 1.0 / 40320.0);             // 1 / 9!, 1 / 8!
+        ps = fma(ps, -z, 1.0 / 5040.0);           pc = fma(pc, -z, 1.0 / 720.0);               // 1 / 7!, 1 / 6!
+        ps = fma(ps, -z, 1.0 / 120.0);            pc = fma(pc, -z, 1.0 / 24.0);                // 1 / 5!, 1 / 4!
+        ps = fma(ps, -z, 1.0 / 6.0);              pc = fma(pc, -z, 0.5);                       // 1 / 3!, 1 / 2!
+        *sn = fma(h * z, -ps, h);                                                              // h - h^3 (1/3! - ...)
+        *cs = fma(z, -pc, 1.0);                                                                // 1 - h^2 (1/2! - ...)
+    } else {
+        sincos(h, sn, cs);
+    }
+}
+// pose_oplus: exp(d) * pose with one sincos of the half angle and the fast reciprocals.  The increment's rotation and its V matrix
+// are applied as Rodrigues sums (v + a w x v + b w x (w x v)), not as 3x3 matrices: 40 instructions where forming W^2, R and V took
+// 80 (this runs between two passes, on every thread's own registers).
 __device__ __forceinline__ void po_oplus(const double* pose, const double* d, double* out)
 {
+#pragma clang fp contract(fast)
     const double wx = d[0], wy = d[1], wz = d[2];
     const double theta2 = wx * wx + wy * wy + wz * wz;
     double a, b, c, qe[4];
@@ -1724,7 +1752,7 @@ __device__ __forceinline__ void po_oplus(const double* pose, const double* d, do
     } else {
         const double rt = po_rsqrt(theta2), theta = theta2 * rt, rt2 = rt * rt;
         double sh2, ch2;
-        sincos(0.5 * theta, &sh2, &ch2);
+        po_sincos_half(0.5 * theta, &sh2, &ch2);
         const double st = 2.0 * sh2 * ch2, omc = 2.0 * sh2 * sh2;        // sin(theta), 1 - cos(theta)
         a = st * rt;
         b = omc * rt2;
@@ -1732,20 +1760,15 @@ __device__ __forceinline__ void po_oplus(const double* pose, const double* d, do
         const double shq = sh2 * rt;
         qe[0] = ch2; qe[1] = shq * wx; qe[2] = shq * wy; qe[3] = shq * wz;
     }
-    const double Wm[9] = {0, -wz, wy, wz, 0, -wx, -wy, wx, 0};
-    double W2[9];
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) { double s2 = 0; for (int k = 0; k < 3; ++k) s2 += Wm[i * 3 + k] * Wm[k * 3 + j]; W2[i * 3 + j] = s2; }
-    double Re[9], V[9];
-#pragma unroll
-    for (int i = 0; i < 9; ++i) { const double I = (i % 4 == 0) ? 1.0 : 0.0; Re[i] = I + a * Wm[i] + b * W2[i]; V[i] = I + b * Wm[i] + c * W2[i]; }
     const double* t = pose + 4;
+    // w x t, w x (w x t), w x u, w x (w x u) with u the translation part of the increment
+    const double c1[3] = {wy * t[2] - wz * t[1], wz * t[0] - wx * t[2], wx * t[1] - wy * t[0]};
+    const double c2[3] = {wy * c1[2] - wz * c1[1], wz * c1[0] - wx * c1[2], wx * c1[1] - wy * c1[0]};
+    const double u1[3] = {wy * d[5] - wz * d[4], wz * d[3] - wx * d[5], wx * d[4] - wy * d[3]};
+    const double u2[3] = {wy * u1[2] - wz * u1[1], wz * u1[0] - wx * u1[2], wx * u1[1] - wy * u1[0]};
     double tn[3];
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
-        tn[i] = V[i * 3] * d[3] + V[i * 3 + 1] * d[4] + V[i * 3 + 2] * d[5] + Re[i * 3] * t[0] + Re[i * 3 + 1] * t[1] + Re[i * 3 + 2] * t[2];
+    for (int i = 0; i < 3; ++i) tn[i] = fma(c, u2[i], fma(b, u1[i], d[3 + i])) + fma(b, c2[i], fma(a, c1[i], t[i]));
     const double* q = pose;
     double qn[4];
     qn[0] = qe[0] * q[0] - qe[1] * q[1] - qe[2] * q[2] - qe[3] * q[3];
@@ -1761,6 +1784,7 @@ __device__ __forceinline__ void po_oplus(const double* pose, const double* d, do
 // pose half of ba_jacobians (the landmark is a constant here), with one reciprocal
 __device__ __forceinline__ void po_jacobian(const BaCam& c, const double* pc, double iz, int D, double B[3][6])
 {
+#pragma clang fp contract(fast)
     const double x = pc[0], y = pc[1], iz2 = iz * iz;
     B[0][0] = x * y * iz2 * c.fx;          B[0][1] = -(1.0 + (x * x * iz2)) * c.fx; B[0][2] = y * iz * c.fx;
     B[0][3] = -iz * c.fx;                  B[0][4] = 0.0;                            B[0][5] = x * iz2 * c.fx;
@@ -1776,6 +1800,7 @@ __device__ __forceinline__ void po_jacobian(const BaCam& c, const double* pc, do
 // residual of observation k at pose p7; returns the dimension (2 / 3)
 __device__ __forceinline__ int po_residual(const BaCam& cam, const double* R, const double* t, const double* X, const lpslam_hip_ba_obs& o, double* e, double* pc, double* iz_out = nullptr)
 {
+#pragma clang fp contract(fast)
 #pragma unroll
     for (int i = 0; i < 3; ++i) pc[i] = R[i * 3] * X[0] + R[i * 3 + 1] * X[1] + R[i * 3 + 2] * X[2] + t[i];
     const double iz = po_rcp(pc[2]);
@@ -1866,12 +1891,13 @@ __device__ double g_po_stamps[16];
 #endif
 
 // One pass over the active observations at pose p7: the 27 sums of the linearised system (upper triangle of H, then b) and the
-// (robustified) chi2 as the 28th, into every thread's `sums`.  A trial's chi2 and the NEXT iteration's linearisation are the same
+// (robustified) chi2 as the 28th, into sh.sums (valid until the next pass).  A trial's chi2 and the NEXT iteration's linearisation are the same
 // pass: the trial is accepted nearly always, and then its pose is the pose to linearise at (one reduction less per Levenberg
 // iteration; a rejected trial wastes the 27 sums).
 template <bool ALL_CACHED>
-__device__ __forceinline__ void po_pass(const BaCam& cam, const double (&p7)[7], const PoData<ALL_CACHED>& d, int robust, double* tr, PoShared& sh, double (&sums)[PO_NV] PO_ST_PARAM)
+__device__ __forceinline__ void po_pass(const BaCam& cam, const double (&p7)[7], const PoData<ALL_CACHED>& d, int robust, double* tr, PoShared& sh PO_ST_PARAM)
 {
+#pragma clang fp contract(fast)
     const int tid = threadIdx.x;
     double R[9];
     po_quat_to_rot(p7, R);
@@ -1925,8 +1951,6 @@ __device__ __forceinline__ void po_pass(const BaCam& cam, const double (&p7)[7],
     }
     PO_STAMP(1);
     po_reduce28(acc, tr, sh.sums);
-#pragma unroll
-    for (int q = 0; q < PO_NV; ++q) sums[q] = sh.sums[q];
     PO_STAMP(2);
 #ifdef LPSLAM_PO_STAMPS
     if (tid == 0) po_acc[15] += 1;
@@ -1938,6 +1962,7 @@ __device__ __forceinline__ void po_pass(const BaCam& cam, const double (&p7)[7],
 // (the trial is then the pose itself and x is not meaningful).
 __device__ __forceinline__ int po_solve_trial(const double (&sys)[PO_NV], double lam, const double (&pose)[7], double (&x)[6], double (&trial)[7] PO_ST_PARAM)
 {
+#pragma clang fp contract(fast)
     double A[36];
     {
         int idx = 0;
@@ -1996,6 +2021,7 @@ template <bool ALL_CACHED>
 __global__ __launch_bounds__(PO_T) void k_pose_optimize(double* pose7, const double* pts, const lpslam_hip_ba_obs* obs, const PoObs* packed, int n, BaCam cam,
                                                        uint8_t* outlier, int* n_inliers, int cache_n, int* done_flag, int seq)
 {
+#pragma clang fp contract(fast)
     __shared__ PoShared sh;
     extern __shared__ double po_dyn[];
     double* tr = po_dyn;
@@ -2031,8 +2057,10 @@ __global__ __launch_bounds__(PO_T) void k_pose_optimize(double* pose7, const dou
         // chi2 and linearisation at the round's starting pose (the kernel / the active set may have changed), then trial after
         // trial: every pass evaluates the trial in flight AND linearises at it; g2o's Levenberg control runs between the passes:
         // up to ten iterations, each with up to ten trials of growing lambda.
-        double sys[PO_NV], fresh[PO_NV], x[6], trial[7];
-        po_pass(cam, pose, d, robust, tr, sh, sys PO_ST_ARG);
+        double sys[PO_NV], x[6], trial[7];
+        po_pass(cam, pose, d, robust, tr, sh PO_ST_ARG);
+#pragma unroll
+        for (int q = 0; q < PO_NV; ++q) sys[q] = sh.sums[q];
         ++passes;
         double lambda = 1e-5 * fmax(fmax(fmax(fabs(sys[0]), fabs(sys[6])), fmax(fabs(sys[11]), fabs(sys[15]))), fmax(fabs(sys[18]), fabs(sys[20])));
         double ni = 2, current_chi = sys[27];
@@ -2040,9 +2068,9 @@ __global__ __launch_bounds__(PO_T) void k_pose_optimize(double* pose7, const dou
         PO_STAMP(3);
         int ok = po_solve_trial(sys, lambda, pose, x, trial PO_ST_ARG);
         for (;;) {
-            po_pass(cam, trial, d, robust, tr, sh, fresh PO_ST_ARG);
+            po_pass(cam, trial, d, robust, tr, sh PO_ST_ARG);
             ++passes;
-            const double temp = ok ? fresh[27] : DBL_MAX;
+            const double temp = ok ? sh.sums[27] : DBL_MAX;
             double rho = current_chi - temp, scale = 0;
             if (ok) {
 #pragma unroll
@@ -2060,7 +2088,7 @@ __global__ __launch_bounds__(PO_T) void k_pose_optimize(double* pose7, const dou
 #pragma unroll
                 for (int i = 0; i < 7; ++i) pose[i] = trial[i];
 #pragma unroll
-                for (int q = 0; q < PO_NV; ++q) sys[q] = fresh[q];           // the pass just made linearised at the accepted pose
+                for (int q = 0; q < PO_NV - 1; ++q) sys[q] = sh.sums[q];     // the pass just made linearised at the accepted pose
             } else {
                 lambda *= ni; ni *= 2;
             }
@@ -3215,6 +3243,11 @@ int lpslam_hip_pose_optimize(lpslam_hip_ctx* ctx, double* pose7, const double* p
         memcpy(pose7, hb, 7 * sizeof(double));
         memcpy(&inl, hb + 56, sizeof(int));
         memcpy(&ctx->po_passes, hb + 60, sizeof(int));
+        {
+            static const bool trace = getenv("LPSLAM_HIP_PO_TRACE") != nullptr;
+            if (trace) fprintf(stderr, "pose_optimize: %d observations, %d inliers, %d passes, %.1f us\n", n_obs, inl, ctx->po_passes,
+                               1e-3 * (double)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count());
+        }
         if (outlier && n_obs) memcpy(outlier, hb + off_flags, (size_t)n_obs);
         if (n_inliers) *n_inliers = inl;
         return LPSLAM_HIP_OK;

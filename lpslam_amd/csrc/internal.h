@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <array>
 #include <atomic>
+#include <chrono>
 #include <map>
 #include <mutex>
 #include <vector>
@@ -62,6 +63,8 @@ struct lpslam_hip_ctx {
     lpslam::LevelTable lt{};
     hipStream_t stream = nullptr;      // the stream every entry point enqueues on
     uint32_t* d_cu_table = nullptr;    // mapping reserve in software: [8 XCC][8 words] bit per compute unit the extraction kernels leave alone (frontend.hip)
+    unsigned* d_done = nullptr;        // arrival counters of the kernels that deliver results to page-locked memory (lp_signal_done), 128 bytes apart
+    int done_seq = 0;                  // sequence numbers those kernels release into their done flags
     int* d_fe_counters = nullptr;      // work-queue counters of the queued extraction launches (a ring of 64 per stream, 128 bytes apart)
     std::atomic<unsigned> fe_counter_next{0}, fe_counter_next_prefetch{0};
     int reserve_cus = 0;               // lpslam_hip_set_mapping_reserve: CUs of every XCD the front end's streams leave to the mapping solves
@@ -169,3 +172,36 @@ int lp_launch_describe(lpslam_hip_ctx* c, int first, int n_images);
 int lp_launch_bf_strided(lpslam_hip_ctx* c, int q0, int t0, int stride, int n_pairs);
 int lp_launch_stereo_strided(lpslam_hip_ctx* c, int left0, int right0, int stride, int n_pairs, float fxb, float baseline);
 size_t lp_distribute_lds_bytes(int qcap_max, int ncell_max);
+
+// ---- results delivered by the kernel itself ---------------------------------------------------------------------------------
+// A small read-back through the copy engines costs a packet round trip per transfer plus the wait for the stream (15 - 25 us for
+// the three or five copies of a tracker call).  The kernels that end such a call instead write their results into page-locked host
+// memory and release a sequence number into a flag there as their very last store; the calling thread polls the flag.
+// lp_signal_done: every thread of every workgroup calls it at the end of the kernel (after its last store to host memory).
+#ifdef __HIPCC__
+__device__ __forceinline__ void lp_signal_done(unsigned* counter, int* flag, int seq)
+{
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0 && threadIdx.y == 0) {
+        const unsigned total = gridDim.x * gridDim.y * gridDim.z;
+        if (total == 1 || atomicAdd(counter, 1u) == total - 1) {
+            if (total > 1) { *counter = 0; __threadfence(); }
+            __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+#endif
+unsigned* lp_done_counter(lpslam_hip_ctx* c, int which);      // arrival counter number `which` (0 .. 7) of the context, nullptr on failure
+// host side: true when the flag arrived; after ~20 ms without it the stream is synchronised and the flag checked once more
+inline bool lp_wait_done(int* flag, int seq, hipStream_t s)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int spin = 0; ; ++spin) {
+        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return true;
+        __builtin_ia32_pause();
+        if ((spin & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
+    }
+    if (hipStreamSynchronize(s) != hipSuccess) return false;
+    return __atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq;
+}

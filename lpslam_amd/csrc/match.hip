@@ -371,10 +371,12 @@ __global__ __launch_bounds__(256) void k_proj_topk(const lpslam_hip_keypoint* __
                                                    const float* __restrict__ stereo_xr, const int32_t* __restrict__ kp_count,
                                                    const ProjQuery* __restrict__ queries, const uint8_t* __restrict__ q_desc,
                                                    const int* __restrict__ q_ids, int nq, const int16_t* __restrict__ best_so_far,
-                                                   float inv_w, float inv_h, ProjGate gate, unsigned long long* __restrict__ out_keys, int* __restrict__ out_count)
+                                                   float inv_w, float inv_h, ProjGate gate, unsigned long long* __restrict__ out_keys, int* __restrict__ out_count,
+                                                   unsigned* done_counter, int* done_flag, int done_seq)
 {
+    // (out_keys / out_count may be page-locked host memory: with done_flag the kernel delivers the lists itself, lp_signal_done)
     const int lane = threadIdx.x & 63, qslot = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (qslot >= nq) return;
+    if (qslot < nq) {
     const int qi = q_ids ? q_ids[qslot] : qslot;
     const ProjQuery q = queries[qi];
     const uint32_t* qd = reinterpret_cast<const uint32_t*>(q_desc + 32 * (size_t)qi);
@@ -426,6 +428,8 @@ __global__ __launch_bounds__(256) void k_proj_topk(const lpslam_hip_keypoint* __
         for (int r = 0; r < 4; ++r) out_keys[4 * (size_t)qslot + r] = res[r];
         out_count[qslot] = cnt;
     }
+    }
+    if (done_flag) lp_signal_done(done_counter, done_flag, done_seq);
 }
 
 extern "C" {
@@ -581,14 +585,20 @@ static int window_match(lpslam_hip_ctx* c, int image, const lpslam_hip_proj_quer
     ProjGate gate{};
     gate.mode = policy == 1 ? 1 : 0;
     for (int l = 0; l < LPSLAM_HIP_MAX_LEVELS; ++l) { const float sc = l < c->lt.n_levels ? c->lt.scale[l] : 1.0f; gate.inv_sigma_sq[l] = 1.0f / (sc * sc); }
+    // the candidate lists and counts are written by the kernel straight into the page-locked mirror, and its last store releases a
+    // sequence number there (internal.h, lp_signal_done): no copy-engine packet on the way back
+    unsigned* done_counter = lp_done_counter(c, 1);
+    if (!done_counter) { release(); set_error("device memory for the completion counters"); return LPSLAM_HIP_ERR_DEVICE; }
+    int* done_flag = (int*)(hb + o_ids + 32);
+    const int done_seq = ++c->done_seq;
+    __atomic_store_n(done_flag, 0, __ATOMIC_RELAXED);
     hipLaunchKernelGGL(k_proj_topk, dim3((nq + 3) / 4), dim3(256), 0, s, c->d_kpts + o, c->d_desc + o * 32, sxr, c->d_kp_count + image,
-                       d_q, d_qd, (const int*)nullptr, nq, (const int16_t*)d_bsf, inv_w, inv_h, gate, d_keys, d_cnt);
+                       d_q, d_qd, (const int*)nullptr, nq, (const int16_t*)d_bsf, inv_w, inv_h, gate, (unsigned long long*)(hb + o_keys), (int*)(hb + o_cnt),
+                       done_counter, done_flag, done_seq);
     P_HIP(hipGetLastError());
     const unsigned long long* keys = (const unsigned long long*)(hb + o_keys);
     const int* cnt = (const int*)(hb + o_cnt);
-    P_HIP(hipMemcpyAsync(hb + o_keys, d_keys, (size_t)nq * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-    P_HIP(hipMemcpyAsync(hb + o_cnt, d_cnt, (size_t)nq * sizeof(int), hipMemcpyDeviceToHost, s));
-    P_HIP(hipStreamSynchronize(s));
+    if (!lp_wait_done(done_flag, done_seq, s)) { release(); set_error("window matcher: the kernel did not complete"); return LPSLAM_HIP_ERR_DEVICE; }
     int found = 0;
     for (int k = 0; k < nq; ++k) {
         match_idx[k] = -1;
@@ -605,7 +615,7 @@ static int window_match(lpslam_hip_ctx* c, int image, const lpslam_hip_proj_quer
             P_HIP(hipMemcpyAsync(d_bsf, bsf, nk * sizeof(int16_t), hipMemcpyHostToDevice, s));
             P_HIP(hipMemcpyAsync(d_ids, &k, sizeof(int), hipMemcpyHostToDevice, s));
             hipLaunchKernelGGL(k_proj_topk, dim3(1), dim3(256), 0, s, c->d_kpts + o, c->d_desc + o * 32, sxr, c->d_kp_count + image,
-                               d_q, d_qd, (const int*)d_ids, 1, (const int16_t*)d_bsf, inv_w, inv_h, gate, d_keys, d_cnt);
+                               d_q, d_qd, (const int*)d_ids, 1, (const int16_t*)d_bsf, inv_w, inv_h, gate, d_keys, d_cnt, (unsigned*)nullptr, (int*)nullptr, 0);
             P_HIP(hipGetLastError());
             P_HIP(hipMemcpyAsync(cand, d_keys, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
             P_HIP(hipStreamSynchronize(s));

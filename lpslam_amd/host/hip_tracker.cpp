@@ -1563,12 +1563,12 @@ void HipVslamTrackerBase::logStatistics() const
     const double per = s.frames > 0 ? 1e3 / (double)s.frames : 0.0;
     std::snprintf(buf, sizeof(buf), "VSLAM statistics: frames=%ld motion_tracked=%ld bf_tracked=%ld local_map_joined=%ld keyframes=%ld fused_added=%ld fused_merged=%ld "
                   "local_ba=%ld loops_closed=%ld loop_fused=%ld global_ba=%ld lost=%ld relocalised=%ld reinitialised=%ld nav_priors=%ld landmarks=%zu "
-                  "culled_landmarks=%ld culled_keyframes=%ld live_keyframes=%ld prefetched=%ld ms_per_frame=%.4f ms_front_end=%.4f ms_track=%.4f ms_local_map=%.4f ms_keyframe=%.4f ms_dev_upload=%.4f ms_dev_extract=%.4f ms_dev_get=%.4f ms_dev_match=%.4f ms_dev_pose=%.4f",
+                  "culled_landmarks=%ld culled_keyframes=%ld live_keyframes=%ld prefetched=%ld ms_per_frame=%.4f ms_front_end=%.4f ms_track=%.4f ms_local_map=%.4f ms_keyframe=%.4f ms_dev_upload=%.4f ms_dev_extract=%.4f ms_dev_get=%.4f ms_dev_match=%.4f ms_dev_pose=%.4f ms_prefetch_wait=%.4f ms_prefetch_busy=%.4f",
                   s.frames, s.motion_tracked, s.bf_tracked, s.local_map_joined, s.keyframes, s.fused_added, s.fused_merged, s.local_ba, s.loops_closed, s.loop_fused,
                   s.global_ba, s.lost, s.relocalised, s.reinitialised, s.nav_priors, m_landmarks.size(), s.culled_landmarks, s.culled_keyframes,
                   (long)std::count_if(m_kfs.begin(), m_kfs.end(), [](const Keyframe& k) { return !k.erased; }), s.prefetched,
                   s.t_total * per, s.t_front * per, s.t_track * per, s.t_local * per, s.t_keyframe * per,
-                  s.t_dev_upload * per, s.t_dev_extract * per, s.t_dev_get * per, s.t_dev_match * per, s.t_dev_pose * per);
+                  s.t_dev_upload * per, s.t_dev_extract * per, s.t_dev_get * per, s.t_dev_match * per, s.t_dev_pose * per, s.t_prefetch_wait * per, s.t_prefetch_busy * per);
     logMessage(LpSlamLogLevel_Info, buf);
 }
 
@@ -1621,8 +1621,11 @@ void HipVslamTrackerBase::prefetchLoop()
         const CameraQueueEntry* job = m_pfJob;
         const bool stereo = m_pfStereo;
         lk.unlock();
+        const auto t_job = std::chrono::steady_clock::now();
         prefetchFrame(*job, stereo);
+        const double busy = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_job).count();
         lk.lock();
+        m_stats.t_prefetch_busy += busy;
         m_pfJob = nullptr; m_pfBusy = false;
         m_pfCv.notify_all();
     }
@@ -1638,8 +1641,10 @@ void HipVslamTrackerBase::prefetchSubmit(const CameraQueueEntry* next, bool ster
 
 void HipVslamTrackerBase::prefetchWait()
 {
+    const auto t0 = std::chrono::steady_clock::now();
     std::unique_lock<std::mutex> lk(m_pfMutex);
     m_pfCv.wait(lk, [this] { return !m_pfBusy; });
+    m_stats.t_prefetch_wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
 
 void HipVslamTrackerBase::stopPrefetchThread()

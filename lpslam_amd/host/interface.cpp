@@ -91,6 +91,15 @@ LPS_API void lpslam_manager_default_camera_configuration(LpSlamCameraConfigurati
 LPS_API void lpslam_manager_on_reconstruction(lpslam_c_manager* m, lpslam_c_reconstruction_cb cb, void* user) { m->cb = cb; m->user = user; m->mgr.addOnReconstructionCallback(c_trampoline, m); }
 LPS_API void lpslam_manager_on_image(lpslam_c_manager* m, OnImageCallback_t cb, void* user) { m->mgr.addOnImageCallback(cb, user); }
 LPS_API void lpslam_manager_request_nav_data(lpslam_c_manager* m, RequestNavDataCallback_t cb, void* user) { m->mgr.addRequestNavDataCallback(cb, user); }
+// A compiled RequestNavDataCallback_t that answers every request with a valid identity odometry (what Manager.provide_odometry's
+// Python callback answers): for throughput measurements, where a Python callback per frame on the worker thread costs more than the
+// tracker's own host work.
+static LpSlamRequestNavDataResult identity_odometry(LpSlamROSTimestamp, LpSlamGlobalStateInTime* odom, LpSlamGlobalStateInTime*, void*) {
+    odom->state.valid = true;
+    odom->state.orientation.w = 1.0;
+    return LpSlamRequestNavDataResult_OdomOnly;
+}
+LPS_API void lpslam_manager_request_identity_nav_data(lpslam_c_manager* m) { m->mgr.addRequestNavDataCallback(identity_odometry, nullptr); }
 LPS_API int lpslam_manager_add_stereo_image(lpslam_c_manager* m, uint32_t cam, uint64_t ts, uint8_t* l, uint8_t* r, const LpSlamImageDescription* d) { return m->mgr.addStereoImageFromBuffer(cam, ts, l, r, *d); }
 LPS_API int lpslam_manager_add_image(lpslam_c_manager* m, uint32_t cam, uint64_t ts, uint8_t* b, const LpSlamImageDescription* d) { return m->mgr.addImageFromBuffer(cam, ts, b, *d); }
 LPS_API int lpslam_manager_compress_image(uint8_t* b, const LpSlamImageDescription* d, uint8_t* out, uint32_t* out_size) { return LpSlamManager::compressImage(b, *d, out, out_size); }

@@ -189,11 +189,40 @@ bool SlamManager::readConfigurationFile(std::string const& filename)
 }
 
 // ---- frame ingest (src/Manager/SlamManager.cpp:1038-1297): frames are copied at enqueue --------------------------------
+// The copies live in recycled buffers: a megabyte-sized std::vector is an mmap at every enqueue (plus its page faults and the
+// zero fill of resize) and a munmap on the worker thread at the end of every frame -- 0.1 ms per stereo frame on either side at
+// 1280 x 720.  The worker hands the buffers of a finished frame back (recycleFrame), the next enqueue of the same size takes them.
+namespace {
+std::mutex g_framePoolMutex;
+std::vector<std::vector<uint8_t>> g_framePool;
+constexpr size_t kFramePoolMax = 16;
+std::vector<uint8_t> takeFrameBuffer(size_t n)
+{
+    {
+        std::lock_guard<std::mutex> l(g_framePoolMutex);
+        for (size_t i = g_framePool.size(); i-- > 0;)
+            if (g_framePool[i].size() == n) { std::vector<uint8_t> v = std::move(g_framePool[i]); g_framePool.erase(g_framePool.begin() + (long)i); return v; }
+    }
+    return std::vector<uint8_t>(n);
+}
+void recycleFrameBuffer(std::vector<uint8_t>&& v)
+{
+    if (v.size() < (64u << 10)) return;      // small frames: the allocator's own free lists do
+    std::lock_guard<std::mutex> l(g_framePoolMutex);
+    if (g_framePool.size() < kFramePoolMax) g_framePool.push_back(std::move(v));
+}
+void recycleFrame(CameraQueueEntry& e)
+{
+    recycleFrameBuffer(std::move(e.image.pixels));
+    if (e.image_second) recycleFrameBuffer(std::move(e.image_second->pixels));
+}
+}  // namespace
+
 static GrayImage toGray(const uint8_t* buf, const LpSlamImageDescription& d)
 {
     GrayImage g; g.width = (int)d.width; g.height = (int)d.height;
     const size_t n = (size_t)d.width * d.height;
-    g.pixels.resize(n);
+    g.pixels = takeFrameBuffer(n);
     if (d.format == LpSlamImageFormat_8UC1) std::memcpy(g.pixels.data(), buf, n);
     else {      // 8UC3, RGB -> grey with cv::cvtColor's fixed-point weights (R 4899, G 9617, B 1868, >> 14)
         const bool bgr = d.image_conversion == LpSlamImageConversion_BGR2RGB;
@@ -310,6 +339,7 @@ bool SlamManager::workerStep()
     CameraQueueEntry cam;
     if (m_lookahead) { cam = std::move(*m_lookahead); m_lookahead.reset(); }
     else m_camQueue.pop(cam);
+    const auto t_taken = std::chrono::steady_clock::now();
     if (!cam.valid || m_stopRequested.load()) return false;   // exit signal; a stop abandons the backlog (SlamManager::stop)
     // every frame the worker takes also goes to the image-callback thread (SlamManager.cpp:64-66); a copy: the tracker consumes `cam`
     if (m_pushToImageCallbackQueue) {
@@ -352,7 +382,9 @@ bool SlamManager::workerStep()
             break;
         }
         tracker->setNextFrame(next_frame);
+        const auto t_in = std::chrono::steady_clock::now();
         auto results = tracker->processImage(cam, odom, map, sensors);
+        m_secondsInTrackers += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_in).count();
         tracker->setNextFrame(nullptr);
         for (auto& tr : results) {
             GlobalStateInTime st;
@@ -369,6 +401,8 @@ bool SlamManager::workerStep()
         m_resultQueue.push(re);
     }
     ++m_framesProcessed;
+    recycleFrame(cam);
+    m_secondsInWorker += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_taken).count();
     return true;
 }
 
@@ -454,6 +488,9 @@ void SlamManager::stop()
     if (m_imageCallbackWorker.joinable()) m_imageCallbackWorker.join();
     m_imageCallbackQueue.clear();
     for (auto& t : m_trackers) t->stop();
+    if (const uint64_t n = m_framesProcessed.load())
+        logMessage(LpSlamLogLevel_Info, "Worker statistics: frames=" + std::to_string(n) + " ms_per_frame=" + std::to_string(1e3 * m_secondsInWorker / (double)n) +
+                   " ms_in_trackers=" + std::to_string(1e3 * m_secondsInTrackers / (double)n));
     m_running = false;
 }
 

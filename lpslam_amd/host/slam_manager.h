@@ -71,6 +71,7 @@ private:
     int m_thread_num = -1;
     std::atomic<uint64_t> m_framesProcessed{0}, m_framesSkipped{0}, m_imagesSent{0};
     std::atomic<double> m_currentFps{0.0};
+    double m_secondsInWorker = 0, m_secondsInTrackers = 0;      // worker thread only (logged by stop()): a frame from the moment it is taken / inside processImage
     std::atomic<bool> m_stopRequested{false};
     std::optional<CameraQueueEntry> m_lookahead;       // worker thread only: the frame after the one being processed
     ReplayReader m_replay;

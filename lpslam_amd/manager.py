@@ -162,7 +162,14 @@ class Manager:
         f = IMAGE_CB(cb); self._keep.append(f)
         self.lib.lpslam_manager_on_image(self.h, f, None)
 
-    def provide_odometry(self):
+    def provide_odometry(self, native=False):
+        """answers every navigation request with a valid identity odometry; native=True installs the library's compiled callback
+        (lpslam_manager_request_identity_nav_data) instead of a Python one -- no interpreter on the worker thread's path"""
+        if native:
+            self.lib.lpslam_manager_request_identity_nav_data.argtypes = [C.c_void_p]
+            self.lib.lpslam_manager_request_identity_nav_data(self.h)
+            return
+
         def cb(ts, odom, mp, _):
             odom.contents.state.valid = True
             odom.contents.state.orientation.w = 1.0

@@ -13,7 +13,7 @@ for async_map in ("true", "false", "true", "false"):
         c.resolution_x = W; c.resolution_y = H; c.focal_x_baseline = k["fxb"]
         mg.set_camera(c)
     mg.add_tracker("VSLAMStereo", '{"cameraSetup": "stereo", "slamKeypoints": %d, "numLevels": %d, "keyframeInterval": %d, "asyncMapping": %s, "mappingReserve": %s}' % (KPTS, LEVELS, KF, async_map, os.environ.get("RESERVE", "0")))
-    mg.collect_results(); mg.provide_odometry()
+    mg.collect_results(); mg.provide_odometry(native=os.environ.get("NATIVE_ODOM", "1") == "1")
     log = os.path.join(tempfile.mkdtemp(), "slam.log")
     mg.log_to_file(log)
     seq = synth.StereoSequence(W, H, 4)
@@ -28,5 +28,5 @@ for async_map in ("true", "false", "true", "false"):
         time.sleep(0.0005)
     dt = time.perf_counter() - t0
     mg.stop()
-    print([l.strip() for l in open(log, errors="replace") if "prefetch" in l][:3])
+    print([l.strip() for l in open(log, errors="replace") if "Worker statistics" in l][:3])
     print("asyncMapping", async_map, "%.1f frames/s" % (len(frames) / dt), manager.Manager.statistics(log))
