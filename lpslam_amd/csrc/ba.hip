@@ -1846,16 +1846,21 @@ __device__ __forceinline__ double quad_swap(double v)     // DPP exchange inside
 }
 constexpr int PO_NV = 28;                  // values per pass
 constexpr int PO_Q = PO_T / 4;             // partials per value after the quad step
-constexpr int PO_TR = PO_Q + 1;            // padded row of the transposed reduction buffer [PO_NV][PO_Q]
+constexpr int PO_TR = PO_Q + 8;            // padded row of the transposed reduction buffer [PO_NV][PO_Q]: the second step's lanes read (value q, partial j + 8 i) --
+                                           // q 72 + j puts the eight values of a wavefront's read on different banks (with + 1 they met four to a bank)
 constexpr int PO_LPV = PO_T / 32;          // lanes per value in the second step (16 = one DPP row at 512 threads)
 static_assert(PO_NV * PO_LPV <= PO_T && PO_Q == 8 * PO_LPV && (PO_LPV == 16 || PO_LPV == 8 || PO_LPV == 4), "po_reduce28 layout");
-__device__ __forceinline__ void po_reduce28(double (&acc)[PO_NV], double* tr, double* out)
+__device__ __forceinline__ void po_reduce28(double (&acc)[PO_NV], double* tr, double* out, int lane_stride)
 {
     const int tid = threadIdx.x;
+    // (lane_stride: observations sit in every lane / every second / every fourth -- po_pass: the register step shrinks with them)
+    if (lane_stride == 1) {
 #pragma unroll
-    for (int q = 0; q < PO_NV; ++q) {
-        acc[q] += quad_swap<0xB1>(acc[q]);               // lanes 0<->1, 2<->3
-        acc[q] += quad_swap<0x4E>(acc[q]);               // lanes 0<->2, 1<->3
+        for (int q = 0; q < PO_NV; ++q) acc[q] += quad_swap<0xB1>(acc[q]);           // lanes 0<->1, 2<->3
+    }
+    if (lane_stride <= 2) {
+#pragma unroll
+        for (int q = 0; q < PO_NV; ++q) acc[q] += quad_swap<0x4E>(acc[q]);           // lanes 0<->2, 1<->3
     }
     if ((tid & 3) == 0) {
 #pragma unroll
@@ -1905,7 +1910,10 @@ __device__ __forceinline__ void po_pass(const BaCam& cam, const double (&p7)[7],
     double acc[PO_NV];
 #pragma unroll
     for (int q = 0; q < PO_NV; ++q) acc[q] = 0;
-    for (int k = tid; k < d.n; k += PO_T) {
+    // few observations are spread out, one per quad of lanes (up to PO_T / 4) or one per pair: the reduction's first step adds the
+    // four lanes of a quad in registers, 168 instructions when every lane carries sums -- none when only one lane of four does
+    const int lane_stride = d.n <= PO_T / 4 ? 4 : d.n <= PO_T / 2 ? 2 : 1;
+    for (int k = (tid % lane_stride) ? d.n : tid / lane_stride; k < d.n; k += PO_T / lane_stride) {
         if (!d.act[k]) continue;
         double e[3], pc[3], B[3][6], X[3], iz;
         lpslam_hip_ba_obs o;
@@ -1950,7 +1958,15 @@ __device__ __forceinline__ void po_pass(const BaCam& cam, const double (&p7)[7],
         }
     }
     PO_STAMP(1);
-    po_reduce28(acc, tr, sh.sums);
+#ifdef LPSLAM_PO_DUP_REDUCE
+    {   // development: the reduction twice (the first one's result is discarded) -- the difference in time per pass is its cost
+        double acc2[PO_NV];
+#pragma unroll
+        for (int q = 0; q < PO_NV; ++q) { acc2[q] = acc[q]; asm volatile("" : "+v"(acc2[q])); }
+        po_reduce28(acc2, tr, sh.sums, lane_stride);
+    }
+#endif
+    po_reduce28(acc, tr, sh.sums, lane_stride);
     PO_STAMP(2);
 #ifdef LPSLAM_PO_STAMPS
     if (tid == 0) po_acc[15] += 1;
@@ -2099,6 +2115,14 @@ __global__ __launch_bounds__(PO_T) void k_pose_optimize(double* pose7, const dou
                 qmax = 1;
             }
             PO_STAMP(3);
+#ifdef LPSLAM_PO_DUP_SERIAL
+            {   // development: solve + pose update twice
+                double lam2 = lambda; asm volatile("" : "+v"(lam2));
+                double x2[6], trial2[7];
+                const int ok2 = po_solve_trial(sys, lam2, pose, x2, trial2 PO_ST_ARG);
+                asm volatile("" :: "v"(trial2[0]), "v"(trial2[6]), "v"(x2[0]), "v"(ok2));
+            }
+#endif
             ok = po_solve_trial(sys, lambda, pose, x, trial PO_ST_ARG);
         }
         // classification with the plain chi2 of this round's pose
