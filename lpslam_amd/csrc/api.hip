@@ -141,9 +141,19 @@ int lp_pool_alloc(lpslam_hip_ctx* c, size_t bytes, void** out, size_t* capacity)
     return LPSLAM_HIP_OK;
 }
 
-// A front-end stream of the context (never CU-masked: the mapping reserve is kept by the kernels themselves, frontend.hip)
-static hipError_t lp_fe_stream_create(hipStream_t* s, int)
+// A front-end stream of the context (never CU-masked: the mapping reserve is kept by the kernels themselves, frontend.hip).  The
+// prefetch stream is created at the LOWEST priority: it carries the next frame's extraction -- 0.2 ms of chip-filling kernels --
+// beside this frame's matchers and pose optimisations on the main stream, which are a few workgroups each and latency bound.  With
+// equal priorities the two streams can end up on one hardware queue (a process that has created many streams: measured in bench.py,
+// every local-map matcher call waited 0.2 ms behind the prefetched extraction); different priorities never share a queue.
+static hipError_t lp_fe_stream_create(hipStream_t* s, bool background)
 {
+    if (background) {
+        int prio_least = 0, prio_greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) == hipSuccess && prio_least != prio_greatest &&
+            hipStreamCreateWithPriority(s, hipStreamNonBlocking, prio_least) == hipSuccess) return hipSuccess;
+        (void)hipGetLastError();
+    }
     return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
 }
 
@@ -306,7 +316,7 @@ int lpslam_hip_create(const lpslam_hip_frontend_config* cfg, lpslam_hip_ctx** ou
     c->distribute_lds = lds;
     if (lds > 160 * 1024) { set_error("distribution kernel needs %zu B of LDS (> 160 KiB)", lds); delete c; return LPSLAM_HIP_ERR_INVALID; }
 
-    hipError_t e = lp_fe_stream_create(&c->stream, 0);
+    hipError_t e = lp_fe_stream_create(&c->stream, false);
     if (e != hipSuccess) { delete c; return hip_fail(e, "hipStreamCreate"); }
     rc = ctx_alloc(c);
     if (rc == LPSLAM_HIP_OK && !ofs.empty()) {
@@ -501,7 +511,7 @@ int lpslam_hip_prefetch_begin(lpslam_hip_ctx* c)
     if (lp_tls_stream) { set_error("prefetch_begin: this thread is already inside a prefetch section"); return LPSLAM_HIP_ERR_INVALID; }
     LP_HIP(hipSetDevice(c->cfg.device));
     if (!c->fe_stream) {
-        LP_HIP(lp_fe_stream_create(&c->fe_stream, c->reserve_cus));
+        LP_HIP(lp_fe_stream_create(&c->fe_stream, true));
         LP_HIP(hipEventCreateWithFlags(&c->fe_done, hipEventDisableTiming));
     }
     lp_tls_stream = c->fe_stream;

@@ -6,6 +6,7 @@
 // stereo parameters: focal_x_baseline (src/Trackers/OpenVSLAMTrackerBase.cpp:188-190, src/Interface/LpSlamTypes.h:219-222).
 // Integer work (xor + popcount + argmin) is bit-exact; the few float operations are written without contraction.
 #include "internal.h"
+#include <chrono>
 #include <vector>
 #include <algorithm>
 #include <cmath>
@@ -542,6 +543,10 @@ static int window_match(lpslam_hip_ctx* c, int image, const lpslam_hip_proj_quer
 {
     int rc = chk(c, image, image); if (rc) return rc;
     if (nq < 0 || (nq > 0 && (!queries || !q_desc32 || !match_idx))) { set_error("bad window-match arguments"); return LPSLAM_HIP_ERR_INVALID; }
+    static const bool trace = getenv("LPSLAM_HIP_MATCH_TRACE") != nullptr;
+    const auto tr0 = std::chrono::steady_clock::now();
+    auto tr_us = [&tr0]() { return 1e-3 * (double)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - tr0).count(); };
+    double tr_alloc = 0, tr_launch = 0, tr_wait = 0; int tr_rescans = 0;
     static_assert(sizeof(lpslam_hip_proj_query) == sizeof(ProjQuery), "query layout");
     if (n_matches) *n_matches = 0;
     if (nq == 0) return LPSLAM_HIP_OK;
@@ -565,6 +570,7 @@ static int window_match(lpslam_hip_ctx* c, int image, const lpslam_hip_proj_quer
         P_HIP(hipHostMalloc((void**)&c->h_match, total + total / 2, hipHostMallocDefault));
         c->h_match_bytes = total + total / 2;
     }
+    tr_alloc = tr_us();
     uint8_t* base = (uint8_t*)blk;
     uint8_t* hb = c->h_match;
     unsigned long long* d_keys = (unsigned long long*)(base + o_keys); ProjQuery* d_q = (ProjQuery*)(base + o_q); uint8_t* d_qd = base + o_qd;
@@ -598,7 +604,9 @@ static int window_match(lpslam_hip_ctx* c, int image, const lpslam_hip_proj_quer
     P_HIP(hipGetLastError());
     const unsigned long long* keys = (const unsigned long long*)(hb + o_keys);
     const int* cnt = (const int*)(hb + o_cnt);
+    tr_launch = tr_us();
     if (!lp_wait_done(done_flag, done_seq, s)) { release(); set_error("window matcher: the kernel did not complete"); return LPSLAM_HIP_ERR_DEVICE; }
+    tr_wait = tr_us();
     int found = 0;
     for (int k = 0; k < nq; ++k) {
         match_idx[k] = -1;
@@ -612,6 +620,7 @@ static int window_match(lpslam_hip_ctx* c, int image, const lpslam_hip_proj_quer
         int m = free_ones(fr);
         if (policy != 1 && m < 2 && cnt[k] > 4) {
             // the short list was eaten by earlier queries: scan again for this query with the current assignment
+            ++tr_rescans;
             P_HIP(hipMemcpyAsync(d_bsf, bsf, nk * sizeof(int16_t), hipMemcpyHostToDevice, s));
             P_HIP(hipMemcpyAsync(d_ids, &k, sizeof(int), hipMemcpyHostToDevice, s));
             hipLaunchKernelGGL(k_proj_topk, dim3(1), dim3(256), 0, s, c->d_kpts + o, c->d_desc + o * 32, sxr, c->d_kp_count + image,
@@ -641,6 +650,8 @@ static int window_match(lpslam_hip_ctx* c, int image, const lpslam_hip_proj_quer
     }
 #undef P_HIP
     release();
+    if (trace) fprintf(stderr, "window_match: policy %d, %d queries, %d matches, %d rescans; us: setup %.1f, staged + launched %.1f, lists back %.1f, replayed %.1f\n",
+                       policy, nq, found, tr_rescans, tr_alloc, tr_launch, tr_wait, tr_us());
     if (n_matches) *n_matches = found;
     return LPSLAM_HIP_OK;
 }

@@ -1513,8 +1513,11 @@ void HipVslamTrackerBase::mappingLoop()
         if (m_mapQuit) return;
         std::unique_ptr<MappingJob> job = std::move(m_mapIn);
         lk.unlock();
+        const auto t_solve = std::chrono::steady_clock::now();
         solveMapping(*job);
+        const double solved_in = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_solve).count();
         lk.lock();
+        m_stats.t_map_solve += solved_in;
         m_mapOut = std::move(job);
         m_mapBusy = false;
         m_mapCv.notify_all();
@@ -1536,7 +1539,8 @@ void HipVslamTrackerBase::stopMappingThread()
 
 void HipVslamTrackerBase::startMapping(int c)
 {
-    auto job = prepareMapping(c);
+    std::unique_ptr<MappingJob> job;
+    { ScopedSeconds timed(m_stats.t_kf_prepare); job = prepareMapping(c); }
     if (!job) return;
     if (!m_asyncMapping) { solveMapping(*job); applyMapping(*job); return; }
     if (!m_mapThread.joinable()) m_mapThread = std::thread([this] { mappingLoop(); });
@@ -1549,26 +1553,27 @@ void HipVslamTrackerBase::finishMapping()
 {
     std::unique_ptr<MappingJob> job;
     {
+        ScopedSeconds timed(m_stats.t_kf_wait);
         std::unique_lock<std::mutex> lk(m_mapMutex);
         m_mapCv.wait(lk, [this] { return !m_mapBusy; });
         job = std::move(m_mapOut);
     }
-    if (job) applyMapping(*job);
+    if (job) { ScopedSeconds timed(m_stats.t_kf_apply); applyMapping(*job); }
 }
 
 void HipVslamTrackerBase::logStatistics() const
 {
     const Statistics& s = m_stats;
-    char buf[1024];
+    char buf[1536];
     const double per = s.frames > 0 ? 1e3 / (double)s.frames : 0.0;
     std::snprintf(buf, sizeof(buf), "VSLAM statistics: frames=%ld motion_tracked=%ld bf_tracked=%ld local_map_joined=%ld keyframes=%ld fused_added=%ld fused_merged=%ld "
                   "local_ba=%ld loops_closed=%ld loop_fused=%ld global_ba=%ld lost=%ld relocalised=%ld reinitialised=%ld nav_priors=%ld landmarks=%zu "
-                  "culled_landmarks=%ld culled_keyframes=%ld live_keyframes=%ld prefetched=%ld ms_per_frame=%.4f ms_front_end=%.4f ms_track=%.4f ms_local_map=%.4f ms_keyframe=%.4f ms_dev_upload=%.4f ms_dev_extract=%.4f ms_dev_get=%.4f ms_dev_match=%.4f ms_dev_pose=%.4f ms_prefetch_wait=%.4f ms_prefetch_busy=%.4f",
+                  "culled_landmarks=%ld culled_keyframes=%ld live_keyframes=%ld prefetched=%ld ms_per_frame=%.4f ms_front_end=%.4f ms_track=%.4f ms_local_map=%.4f ms_keyframe=%.4f ms_dev_upload=%.4f ms_dev_extract=%.4f ms_dev_get=%.4f ms_dev_match=%.4f ms_dev_pose=%.4f ms_prefetch_wait=%.4f ms_prefetch_busy=%.4f ms_kf_wait=%.4f ms_kf_apply=%.4f ms_kf_insert=%.4f ms_kf_loop=%.4f ms_kf_prepare=%.4f ms_map_solve=%.4f",
                   s.frames, s.motion_tracked, s.bf_tracked, s.local_map_joined, s.keyframes, s.fused_added, s.fused_merged, s.local_ba, s.loops_closed, s.loop_fused,
                   s.global_ba, s.lost, s.relocalised, s.reinitialised, s.nav_priors, m_landmarks.size(), s.culled_landmarks, s.culled_keyframes,
                   (long)std::count_if(m_kfs.begin(), m_kfs.end(), [](const Keyframe& k) { return !k.erased; }), s.prefetched,
                   s.t_total * per, s.t_front * per, s.t_track * per, s.t_local * per, s.t_keyframe * per,
-                  s.t_dev_upload * per, s.t_dev_extract * per, s.t_dev_get * per, s.t_dev_match * per, s.t_dev_pose * per, s.t_prefetch_wait * per, s.t_prefetch_busy * per);
+                  s.t_dev_upload * per, s.t_dev_extract * per, s.t_dev_get * per, s.t_dev_match * per, s.t_dev_pose * per, s.t_prefetch_wait * per, s.t_prefetch_busy * per, s.t_kf_wait * per, s.t_kf_apply * per, s.t_kf_insert * per, s.t_kf_loop * per, s.t_kf_prepare * per, s.t_map_solve * per);
     logMessage(LpSlamLogLevel_Info, buf);
 }
 
@@ -1789,8 +1794,9 @@ TrackerBase::ProcessImageResult HipVslamTrackerBase::trackFrame(CameraQueueEntry
             ++m_framesSinceKeyframe;
             if (keyframeNeeded(inliers)) {
                 finishMapping();                    // the previous keyframe's solve enters the map before the next one is inserted
-                const int c = insertKeyframe(cur);
-                if (m_loopClosure) detectAndCloseLoop(cur, c);
+                int c;
+                { ScopedSeconds timed(m_stats.t_kf_insert); c = insertKeyframe(cur); }
+                if (m_loopClosure) { ScopedSeconds timed(m_stats.t_kf_loop); detectAndCloseLoop(cur, c); }
                 startMapping(c);
                 if (!m_asyncMapping) cur.pose = m_kfs[(size_t)c].pose;
                 lap(m_stats.t_keyframe);

@@ -81,6 +81,7 @@ protected:
         // where the frames' time went (seconds, summed): front end (upload, extraction, stereo, read-back), tracking against the
         // previous frame, local-map tracking, keyframe work on the tracking thread (insertion, fusion, loop search, BA set-up / wait)
         double t_front = 0, t_track = 0, t_local = 0, t_keyframe = 0, t_total = 0;
+        double t_kf_wait = 0, t_kf_apply = 0, t_kf_insert = 0, t_kf_loop = 0, t_kf_prepare = 0, t_map_solve = 0;      // keyframe path: waiting for the previous window's solve, applying it, the new keyframe, the next window's set-up; the mapping thread's solve
         double t_prefetch_wait = 0, t_prefetch_busy = 0;       // this thread waiting for the prefetch thread at the end of a frame / that thread's own time per frame
         double t_dev_match = 0, t_dev_pose = 0, t_dev_upload = 0, t_dev_extract = 0, t_dev_get = 0;      // inside the above: device calls
     };

@@ -141,12 +141,14 @@ class Manager:
     def set_camera(self, cam):
         self.lib.lpslam_manager_set_camera_configuration(self.h, C.byref(cam))
 
-    def collect_results(self):
+    def collect_results(self, on_result=None):
         def cb(state, _):
             s = state.contents
             self.results.append(dict(timestamp=s.timestamp, valid=bool(s.state.valid),
                                      p=(s.state.position.x, s.state.position.y, s.state.position.z),
                                      q=(s.state.orientation.w, s.state.orientation.x, s.state.orientation.y, s.state.orientation.z)))
+            if on_result is not None:
+                on_result()
         f = RECON_CB(cb); self._keep.append(f)
         self.lib.lpslam_manager_on_reconstruction(self.h, f, None)
 

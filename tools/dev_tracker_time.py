@@ -3,6 +3,13 @@ import sys, os, time, tempfile
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from lpslam_amd import manager, _build, synth
 _build.host_library()
+if os.environ.get("WITH_TORCH") == "1":
+    import torch
+    torch.cuda.init(); _x = torch.zeros(1 << 20, device="cuda"); torch.cuda.synchronize()
+if os.environ.get("WITH_CTX") == "1":
+    from lpslam_amd import hip
+    _ctx = hip.Context(1280, 720, 2000, 1.2, 8, max_images=32)
+    _ctx.set_mapping_reserve(16)
 W, H, KPTS, LEVELS, KF = 1280, 720, 2000, 8, 6
 k = synth.intrinsics(W, H)
 for async_map in ("true", "false", "true", "false"):
@@ -17,13 +24,18 @@ for async_map in ("true", "false", "true", "false"):
     log = os.path.join(tempfile.mkdtemp(), "slam.log")
     mg.log_to_file(log)
     seq = synth.StereoSequence(W, H, 4)
-    frames = [seq.frame(i) for i in range(90)]
+    frames = [seq.frame(i) for i in range(int(os.environ.get("FRAMES", "90")))]
+    late = os.environ.get("ENQUEUE_AFTER_START", "0") == "1"
+    if late:
+        mg.start()
     ta = time.perf_counter()
+    t0 = ta
     for i, (l, r) in enumerate(frames):
         mg.add_stereo((i + 1) * 40_000_000, l, r)
-    print("enqueue of 30 frames: %.2f ms" % (1e3 * (time.perf_counter() - ta)))
-    t0 = time.perf_counter()
-    mg.start()
+    print("enqueue of %d frames: %.2f ms" % (len(frames), 1e3 * (time.perf_counter() - ta)))
+    if not late:
+        t0 = time.perf_counter()
+        mg.start()
     while len(mg.results) < len(frames) and time.perf_counter() - t0 < 60:
         time.sleep(0.0005)
     dt = time.perf_counter() - t0
