@@ -173,6 +173,13 @@ int lpslam_hip_get_bf_knn2(lpslam_hip_ctx* ctx, int query, int32_t* best_idx, in
 int lpslam_hip_get_bf_matches(lpslam_hip_ctx* ctx, int query, int train, int32_t max_dist, float ratio,
                               int32_t cross_check, int32_t* out_q, int32_t* out_t, int32_t* out_d,
                               int32_t capacity, int32_t* count);
+/* The three calls a keyframe comparison makes -- lpslam_hip_set_descriptors(scratch, train_desc32, n_train), lpslam_hip_match_bf(query,
+ * scratch), lpslam_hip_get_bf_matches(query, scratch, ...) -- as ONE call with ONE wait: the descriptors go up, both directions are
+ * matched, the result arrays are delivered by a kernel into page-locked memory.  Same matches as the three calls; the scratch slot's
+ * descriptors and count are overwritten the same way. */
+int lpslam_hip_match_bf_descriptors(lpslam_hip_ctx* ctx, int query, int scratch, const uint8_t* train_desc32, int32_t n_train,
+                                    int32_t max_dist, float ratio, int32_t cross_check, int32_t* out_q, int32_t* out_t,
+                                    int32_t* out_d, int32_t capacity, int32_t* count);
 /* Batched form: pairs (query0 + i*stride, train0 + i*stride), i in [0, n_pairs), in one launch. */
 int lpslam_hip_match_bf_strided(lpslam_hip_ctx* ctx, int query0, int train0, int stride, int n_pairs);
 /* Loads a caller-provided descriptor set (host memory, n x 32 bytes) into image slot `image`, replacing the

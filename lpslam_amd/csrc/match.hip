@@ -501,6 +501,78 @@ int lpslam_hip_get_bf_matches(lpslam_hip_ctx* c, int query, int train, int32_t m
     return LPSLAM_HIP_OK;
 }
 
+}  // extern "C"
+
+namespace {
+// up to four runs of 32-bit words into page-locked host memory, then the completion flag (internal.h, lp_signal_done)
+struct WordRuns { const uint32_t* src[4]; int n[4]; int dst[4]; };
+__global__ __launch_bounds__(256) void k_words_to_host(WordRuns r, uint32_t* __restrict__ st, unsigned* counter, int* flag, int seq)
+{
+    const int total = r.n[0] + r.n[1] + r.n[2] + r.n[3];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        int j = i, k = 0;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) if (k == q && j >= r.n[q]) { j -= r.n[q]; k = q + 1; }
+        st[r.dst[k] + j] = r.src[k][j];
+    }
+    lp_signal_done(counter, flag, seq);
+}
+}  // namespace
+
+extern "C" {
+
+int lpslam_hip_match_bf_descriptors(lpslam_hip_ctx* c, int query, int scratch, const uint8_t* train_desc32, int32_t n_train, int32_t max_dist, float ratio,
+                                    int32_t cross_check, int32_t* out_q, int32_t* out_t, int32_t* out_d, int32_t capacity, int32_t* count)
+{
+    int rc = chk(c, query, scratch); if (rc) return rc;
+    if (query == scratch || n_train < 0 || n_train > c->slots_per_image || (n_train && !train_desc32) || !out_q || !out_t || !out_d) { set_error("bad match_bf_descriptors arguments"); return LPSLAM_HIP_ERR_INVALID; }
+    int32_t nq = 0;
+    if ((rc = lpslam_hip_keypoint_count(c, query, &nq))) return rc;
+    if (count) *count = 0;
+    hipStream_t s = c->stream;
+    const size_t S = (size_t)c->slots_per_image;
+    // the scratch slot receives the descriptors and their count (lpslam_hip_set_descriptors, without its wait)
+    if (n_train) LP_HIP(hipMemcpyAsync(c->d_desc + (size_t)scratch * S * 32, train_desc32, (size_t)n_train * 32, hipMemcpyHostToDevice, s));
+    LP_HIP(hipMemcpyAsync(c->d_kp_count + scratch, &n_train, sizeof(int32_t), hipMemcpyHostToDevice, s));
+    if ((size_t)scratch < c->h_kp_valid.size()) { c->h_kp_count[(size_t)scratch] = n_train; c->h_kp_valid[(size_t)scratch] = 1; }
+    if (nq == 0 || n_train == 0) { LP_HIP(hipStreamSynchronize(s)); return LPSLAM_HIP_OK; }
+    if ((rc = lp_launch_bf_strided(c, query, scratch, 0, 1))) return rc;
+    if (cross_check && (rc = lp_launch_bf_strided(c, scratch, query, 0, 1))) return rc;
+    // page-locked block: flag | best index, best distance, second distance of the queries | best index of the train side
+    const size_t o_bi = 16, o_bd = o_bi + (size_t)nq, o_sd = o_bd + (size_t)nq, o_rbi = o_sd + (size_t)nq, words = o_rbi + (size_t)n_train;
+    if (c->h_match_bytes < words * 4) {
+        if (c->h_match) { LP_HIP(hipStreamSynchronize(s)); (void)hipHostFree(c->h_match); }
+        c->h_match = nullptr; c->h_match_bytes = 0;
+        LP_HIP(hipHostMalloc((void**)&c->h_match, words * 8, hipHostMallocDefault));
+        c->h_match_bytes = words * 8;
+    }
+    unsigned* done_counter = lp_done_counter(c, 2);
+    if (!done_counter) { set_error("device memory for the completion counters"); return LPSLAM_HIP_ERR_DEVICE; }
+    uint32_t* st = (uint32_t*)c->h_match;
+    int* flag = (int*)st;
+    const int seq = ++c->done_seq;
+    __atomic_store_n(flag, 0, __ATOMIC_RELAXED);
+    const uint32_t* fq = (const uint32_t*)(c->d_bf + (size_t)query * 3 * S);
+    const uint32_t* ft = (const uint32_t*)(c->d_bf + (size_t)scratch * 3 * S);
+    WordRuns r{{fq, fq + S, fq + 2 * S, ft}, {nq, nq, nq, cross_check ? n_train : 0}, {(int)o_bi, (int)o_bd, (int)o_sd, (int)o_rbi}};
+    hipLaunchKernelGGL(k_words_to_host, dim3(std::max(1, std::min(16, (int)(words / 1024) + 1))), dim3(256), 0, s, r, st, done_counter, flag, seq);
+    LP_HIP(hipGetLastError());
+    if (!lp_wait_done(flag, seq, s)) { set_error("lpslam_hip_match_bf_descriptors: the read-back kernel did not complete"); return LPSLAM_HIP_ERR_DEVICE; }
+    const int32_t* bi = (const int32_t*)(st + o_bi); const int32_t* bd = (const int32_t*)(st + o_bd); const int32_t* sd = (const int32_t*)(st + o_sd);
+    const int32_t* rbi = (const int32_t*)(st + o_rbi);
+    int n = 0;
+    for (int i = 0; i < nq; ++i) {       // the filter of lpslam_hip_get_bf_matches
+        if (bi[i] < 0) continue;
+        if (bd[i] > max_dist) continue;
+        if (ratio > 0.f && ratio * (float)sd[i] < (float)bd[i]) continue;
+        if (cross_check && rbi[bi[i]] != i) continue;
+        if (n >= capacity) { set_error("match buffer too small"); return LPSLAM_HIP_ERR_CAPACITY; }
+        out_q[n] = i; out_t[n] = bi[i]; out_d[n] = bd[i]; ++n;
+    }
+    if (count) *count = n;
+    return LPSLAM_HIP_OK;
+}
+
 int lpslam_hip_match_stereo(lpslam_hip_ctx* c, int left, int right, float fxb, float baseline)
 {
     int rc = chk(c, left, right); if (rc) return rc;

@@ -36,7 +36,7 @@ SYMBOLS = [
     "lpslam_hip_match_stereo", "lpslam_hip_match_stereo_strided", "lpslam_hip_get_stereo",
     "lpslam_hip_vocab_create", "lpslam_hip_vocab_destroy", "lpslam_hip_vocab_info", "lpslam_hip_bow_transform", "lpslam_hip_bow_transform_host", "lpslam_hip_match_bow_tree",
     "lpslam_hip_match_projection", "lpslam_hip_match_fuse", "lpslam_hip_match_area", "lpslam_hip_match_orientation_filter",
-    "lpslam_hip_ba_create", "lpslam_hip_ba_destroy", "lpslam_hip_ba_set_active", "lpslam_hip_ba_optimize", "lpslam_hip_ba_optimize_begin", "lpslam_hip_ba_optimize_end", "lpslam_hip_ba_graph_replays", "lpslam_hip_ba_wg_factorisations", "lpslam_hip_pose_optimize_passes", "lpslam_hip_ba_get_solver", "lpslam_hip_ba_set_solver",
+    "lpslam_hip_ba_create", "lpslam_hip_ba_destroy", "lpslam_hip_ba_set_active", "lpslam_hip_ba_optimize", "lpslam_hip_ba_optimize_begin", "lpslam_hip_ba_optimize_end", "lpslam_hip_ba_graph_replays", "lpslam_hip_ba_wg_factorisations", "lpslam_hip_pose_optimize_passes", "lpslam_hip_match_bf_descriptors", "lpslam_hip_ba_get_solver", "lpslam_hip_ba_set_solver",
     "lpslam_hip_ba_optimize_batch", "lpslam_hip_ba_reset_batch", "lpslam_hip_ba_optimize_profiled", "lpslam_hip_ba_optimize_partitioned", "lpslam_hip_ba_optimize_partitioned_with",
     "lpslam_hip_ba_local", "lpslam_hip_ba_set_points_fixed", "lpslam_hip_ba_pose_optimize", "lpslam_hip_pose_optimize", "lpslam_hip_ba_reset", "lpslam_hip_ba_set_state", "lpslam_hip_prefetch_begin", "lpslam_hip_prefetch_end", "lpslam_hip_prefetch_join", "lpslam_hip_ba_get", "lpslam_hip_ba_chi2", "lpslam_hip_ba_reduced_buffer",
     "lpslam_hip_ba_step_begin", "lpslam_hip_ba_step_lambda0", "lpslam_hip_ba_step_solve", "lpslam_hip_ba_scalar_buffer", "lpslam_hip_ba_step_end", "lpslam_hip_ba_status",
@@ -80,6 +80,8 @@ def load():
         for name in ("lpslam_hip_match_stereo",):
             getattr(_lib, name).argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float]
         _lib.lpslam_hip_match_stereo_strided.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float]
+        _lib.lpslam_hip_match_bf_descriptors.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_int32,
+                                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
         _lib.lpslam_hip_get_bf_matches.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int32, C.c_float, C.c_int32,
                                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
     return _lib
@@ -336,6 +338,15 @@ class Context:
         n = C.c_int32()
         _check(self.lib.lpslam_hip_get_bf_matches(self.h, query, train, int(max_dist), float(ratio), int(cross_check),
                                                   _p(oq), _p(ot), _p(od), self.max_kp, C.addressof(n)))
+        return oq[:n.value].copy(), ot[:n.value].copy(), od[:n.value].copy()
+
+    def match_bf_descriptors(self, query, scratch, desc, max_dist=50, ratio=0.0, cross_check=False):
+        """set_descriptors(scratch, desc) + match_bf(query, scratch) + bf_matches(query, scratch, ...) as one call with one wait"""
+        desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        oq = np.zeros(self.max_kp, np.int32); ot = np.zeros(self.max_kp, np.int32); od = np.zeros(self.max_kp, np.int32)
+        n = C.c_int32()
+        _check(self.lib.lpslam_hip_match_bf_descriptors(self.h, query, scratch, _p(desc), len(desc), int(max_dist), float(ratio), int(cross_check),
+                                                        _p(oq), _p(ot), _p(od), self.max_kp, C.addressof(n)))
         return oq[:n.value].copy(), ot[:n.value].copy(), od[:n.value].copy()
 
     def match_stereo(self, left, right, fxb, baseline):

@@ -1100,11 +1100,9 @@ void HipVslamTrackerBase::monoTriangulate(int prev_kf, Keyframe& kf, FrameData& 
     const int c = (int)m_kfs.size();
     if (prev.kpts.empty() || f.kpts.empty()) return;
     const int scratch = f.slot ^ 1;                      // monocular frames use slots 0 / 2
-    if (lpslam_hip_set_descriptors(m_ctx, scratch, prev.desc.data(), (int32_t)prev.kpts.size()) != LPSLAM_HIP_OK) return;
-    if (lpslam_hip_match_bf(m_ctx, f.slot, scratch) != LPSLAM_HIP_OK) return;
     std::vector<int32_t> mq((size_t)m_maxKp), mt((size_t)m_maxKp), md((size_t)m_maxKp);
     int32_t nm = 0;
-    if (lpslam_hip_get_bf_matches(m_ctx, f.slot, scratch, 50, 0.8f, 1, mq.data(), mt.data(), md.data(), m_maxKp, &nm) != LPSLAM_HIP_OK) return;
+    if (lpslam_hip_match_bf_descriptors(m_ctx, f.slot, scratch, prev.desc.data(), (int32_t)prev.kpts.size(), 50, 0.8f, 1, mq.data(), mt.data(), md.data(), m_maxKp, &nm) != LPSLAM_HIP_OK) return;
     const float* scales = m_scales;
     const double fx = m_cam.f_x, fy = m_cam.f_y, cx = m_cam.c_x, cy = m_cam.c_y;
     const Mat3 R1 = quatToRot(prev.pose.q), R2 = quatToRot(f.pose.q);
@@ -1248,10 +1246,8 @@ bool HipVslamTrackerBase::relocalise(FrameData& cur)
             (void)lpslam_hip_match_orientation_filter(aq.data(), at.data(), idx.data(), (int32_t)idx.size(), &kept);
             for (size_t i = 0; i < idx.size(); ++i) if (idx[i] >= 0) { cur_idx.push_back(idx[i]); lm_ids.push_back(resolve(kf.landmark[i])); }
         } else {
-            if (lpslam_hip_set_descriptors(m_ctx, scratch, kf.desc.data(), (int32_t)kf.kpts.size()) != LPSLAM_HIP_OK) continue;
-            if (lpslam_hip_match_bf(m_ctx, cur.slot, scratch) != LPSLAM_HIP_OK) continue;
             int32_t nm = 0;
-            if (lpslam_hip_get_bf_matches(m_ctx, cur.slot, scratch, 50, 0.75f, 1, mq.data(), mt.data(), md.data(), m_maxKp, &nm) != LPSLAM_HIP_OK) continue;
+            if (lpslam_hip_match_bf_descriptors(m_ctx, cur.slot, scratch, kf.desc.data(), (int32_t)kf.kpts.size(), 50, 0.75f, 1, mq.data(), mt.data(), md.data(), m_maxKp, &nm) != LPSLAM_HIP_OK) continue;
             for (int k = 0; k < nm; ++k) {
                 const int id = resolve(kf.landmark[(size_t)mt[k]]);
                 if (id < 0) continue;
@@ -1355,9 +1351,7 @@ bool HipVslamTrackerBase::detectAndCloseLoop(FrameData& cur, int c)
             (void)lpslam_hip_match_orientation_filter(aq.data(), at.data(), idx.data(), (int32_t)idx.size(), &kept);
             for (size_t i = 0; i < idx.size(); ++i) if (idx[i] >= 0) { mq[(size_t)nm] = (int32_t)i; mt[(size_t)nm] = idx[i]; ++nm; }
         } else {
-            if (lpslam_hip_set_descriptors(m_ctx, scratch, ka.desc.data(), (int32_t)ka.kpts.size()) != LPSLAM_HIP_OK) continue;
-            if (lpslam_hip_match_bf(m_ctx, cur.slot, scratch) != LPSLAM_HIP_OK) continue;
-            if (lpslam_hip_get_bf_matches(m_ctx, cur.slot, scratch, 50, 0.75f, 1, mq.data(), mt.data(), md.data(), m_maxKp, &nm) != LPSLAM_HIP_OK) continue;
+            if (lpslam_hip_match_bf_descriptors(m_ctx, cur.slot, scratch, ka.desc.data(), (int32_t)ka.kpts.size(), 50, 0.75f, 1, mq.data(), mt.data(), md.data(), m_maxKp, &nm) != LPSLAM_HIP_OK) continue;
         }
         Vote v; v.kf = cd.second;
         for (int k = 0; k < nm; ++k)

@@ -36,6 +36,24 @@ def test_bf_ragged_sizes(ctx, oracle, nq, nt):
     assert all(np.array_equal(a, b) for a, b in zip(o, g))
 
 
+@pytest.mark.parametrize("nq,nt", [(1, 1), (63, 65), (257, 300), (411, 412), (5, 0), (0, 7)])
+def test_bf_one_call_keyframe_comparison(ctx, oracle, nq, nt):
+    """lpslam_hip_match_bf_descriptors (upload + both directions + kernel-delivered read-back, one wait) returns what the three
+    calls it replaces return, and what the oracle's filtered matcher returns."""
+    rng = np.random.default_rng(nq * 977 + nt)
+    q = rng.integers(0, 256, (nq, 32), dtype=np.uint8)
+    t = np.concatenate([q[: nt // 2] ^ (rng.random((min(nt // 2, nq), 32)) < 0.05).astype(np.uint8), rng.integers(0, 256, (nt - min(nt // 2, nq), 32), dtype=np.uint8)])[:nt] if nt else np.zeros((0, 32), np.uint8)
+    ctx.set_descriptors(2, q)
+    for ratio, cross in ((0.0, False), (0.8, True), (0.75, True)):
+        one = ctx.match_bf_descriptors(2, 3, t, 60, ratio, cross)
+        ctx.set_descriptors(3, t); ctx.match_bf(2, 3)
+        three = ctx.bf_matches(2, 3, 60, ratio, cross)
+        assert all(np.array_equal(a, b) for a, b in zip(one, three))
+        if nq and nt:
+            o = oracle.match_bf(q, t, 60, ratio, cross)
+            assert np.array_equal(one[0], o[0]) and np.array_equal(one[1], o[1])
+
+
 @pytest.fixture(scope="module")
 def big_ctx(hiplib):
     """2100 keypoints / 8 levels: 2124 descriptor slots, i.e. train sets of more than two 1024-descriptor LDS tiles."""
