@@ -745,7 +745,8 @@ def main():
                     mg.set_camera(c)
                 mg.add_tracker("VSLAMStereo", '{"cameraSetup": "stereo", "slamKeypoints": %d, "numLevels": %d, "keyframeInterval": %d, "device": %d}' % (KPTS, LEVELS, KF_INTERVAL, device))
                 arrivals = []
-                mg.collect_results(on_result=lambda: arrivals.append(time.perf_counter())); mg.provide_odometry()
+                mg.collect_results(on_result=lambda: arrivals.append(time.perf_counter()))
+                mg.provide_odometry(native=True)           # the library's compiled identity-odometry callback: no interpreter (and no wait for its lock) on the worker thread
                 log = os.path.join(tempfile.mkdtemp(prefix="lpslam_bench_"), "slam.log")
                 mg.log_to_file(log)
                 mg.start()

@@ -87,6 +87,7 @@ protected:
     };
 
     bool startContext(bool stereo);
+    void warmUpContext(bool stereo);                  // one frame's worth of every per-frame call on blank images: lazily created resources exist before the first frame
     ProcessImageResult trackFrame(CameraQueueEntry& cam, bool stereo, const std::optional<GlobalStateInTime>& navOdom);
     TrackerResult createTrackerResult(const Pose& pose_cw, TimeStamp timestamp) const;
     bool initializeMap(FrameData& f, const Pose& at);

@@ -20,7 +20,8 @@ for async_map in ("true", "false", "true", "false"):
         c.resolution_x = W; c.resolution_y = H; c.focal_x_baseline = k["fxb"]
         mg.set_camera(c)
     mg.add_tracker("VSLAMStereo", '{"cameraSetup": "stereo", "slamKeypoints": %d, "numLevels": %d, "keyframeInterval": %d, "asyncMapping": %s, "mappingReserve": %s}' % (KPTS, LEVELS, KF, async_map, os.environ.get("RESERVE", "0")))
-    mg.collect_results(); mg.provide_odometry(native=os.environ.get("NATIVE_ODOM", "1") == "1")
+    arrivals = []
+    mg.collect_results(on_result=lambda: arrivals.append(time.perf_counter())); mg.provide_odometry(native=os.environ.get("NATIVE_ODOM", "1") == "1")
     log = os.path.join(tempfile.mkdtemp(), "slam.log")
     mg.log_to_file(log)
     seq = synth.StereoSequence(W, H, 4)
@@ -40,5 +41,6 @@ for async_map in ("true", "false", "true", "false"):
         time.sleep(0.0005)
     dt = time.perf_counter() - t0
     mg.stop()
+    print("first result after %.2f ms; gaps of the next 12 results, ms: %s; median gap of the rest %.3f ms" % (1e3 * (arrivals[0] - t0), " ".join("%.2f" % (1e3 * (b - a)) for a, b in zip(arrivals[:12], arrivals[1:13])), 1e3 * float(__import__("numpy").median([b - a for a, b in zip(arrivals[13:-1], arrivals[14:])]))))
     print([l.strip() for l in open(log, errors="replace") if "Worker statistics" in l][:3])
     print("asyncMapping", async_map, "%.1f frames/s" % (len(frames) / dt), manager.Manager.statistics(log))
