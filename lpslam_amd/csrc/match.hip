@@ -657,7 +657,16 @@ static int window_match(lpslam_hip_ctx* c, int image, const lpslam_hip_proj_quer
     std::vector<int> owner(policy == 2 ? nk : 0, -1);
     memcpy(hb + o_q, queries, (size_t)nq * sizeof(ProjQuery));
     memcpy(hb + o_qd, q_desc32, (size_t)nq * 32);
-    P_HIP(hipMemcpyAsync(base + o_q, hb + o_q, total - o_q, hipMemcpyHostToDevice, s));
+    // Without a `taken` mask the first scan needs no best-so-far table, and every wavefront reads its one query and descriptor once:
+    // the kernel takes them straight from the page-locked mirror (one PCIe read per wavefront, all in flight together) and the block
+    // goes down to the device only if a rescan asks for it -- one copy-engine packet less in front of every matcher call.
+    bool on_device = false;
+    auto to_device = [&]() -> bool {
+        if (on_device) return true;
+        if (hipMemcpyAsync(base + o_q, hb + o_q, total - o_q, hipMemcpyHostToDevice, s) != hipSuccess) return false;
+        on_device = true;
+        return true; };
+    if (taken_in) P_HIP(to_device() ? hipSuccess : hipErrorUnknown);
     const float inv_w = (float)(64.0 / c->lt.w[0]), inv_h = (float)(48.0 / c->lt.h[0]);
     const float* sxr = use_stereo ? c->d_stereo + (size_t)image * 2 * c->slots_per_image : nullptr;
     ProjGate gate{};
@@ -671,7 +680,8 @@ static int window_match(lpslam_hip_ctx* c, int image, const lpslam_hip_proj_quer
     const int done_seq = ++c->done_seq;
     __atomic_store_n(done_flag, 0, __ATOMIC_RELAXED);
     hipLaunchKernelGGL(k_proj_topk, dim3((nq + 3) / 4), dim3(256), 0, s, c->d_kpts + o, c->d_desc + o * 32, sxr, c->d_kp_count + image,
-                       d_q, d_qd, (const int*)nullptr, nq, (const int16_t*)d_bsf, inv_w, inv_h, gate, (unsigned long long*)(hb + o_keys), (int*)(hb + o_cnt),
+                       on_device ? d_q : (const ProjQuery*)(hb + o_q), on_device ? d_qd : (const uint8_t*)(hb + o_qd), (const int*)nullptr, nq,
+                       on_device ? (const int16_t*)d_bsf : (const int16_t*)nullptr, inv_w, inv_h, gate, (unsigned long long*)(hb + o_keys), (int*)(hb + o_cnt),
                        done_counter, done_flag, done_seq);
     P_HIP(hipGetLastError());
     const unsigned long long* keys = (const unsigned long long*)(hb + o_keys);
@@ -693,6 +703,7 @@ static int window_match(lpslam_hip_ctx* c, int image, const lpslam_hip_proj_quer
         if (policy != 1 && m < 2 && cnt[k] > 4) {
             // the short list was eaten by earlier queries: scan again for this query with the current assignment
             ++tr_rescans;
+            P_HIP(to_device() ? hipSuccess : hipErrorUnknown);
             P_HIP(hipMemcpyAsync(d_bsf, bsf, nk * sizeof(int16_t), hipMemcpyHostToDevice, s));
             P_HIP(hipMemcpyAsync(d_ids, &k, sizeof(int), hipMemcpyHostToDevice, s));
             hipLaunchKernelGGL(k_proj_topk, dim3(1), dim3(256), 0, s, c->d_kpts + o, c->d_desc + o * 32, sxr, c->d_kp_count + image,
