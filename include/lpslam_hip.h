@@ -156,6 +156,11 @@ int lpslam_hip_get_keypoints(lpslam_hip_ctx* ctx, int image, lpslam_hip_keypoint
  * reached through feed_stereo_frame, src/Trackers/OpenVSLAMStereoTracker.cpp:293-295).  Not re-entrant per context. */
 int lpslam_hip_get_frame(lpslam_hip_ctx* ctx, int image, lpslam_hip_keypoint* kpts, uint8_t* desc32, float* stereo_x_right,
                          float* depths, int32_t capacity, int32_t* count);
+/* Queues the read-back of slot `image` behind whatever the calling thread has enqueued for it (inside a prefetch section: behind the
+ * next frame's extraction and stereo match): the results are in page-locked memory before lpslam_hip_get_frame(image, ...) asks for
+ * them, which then only checks a flag.  Anything that rewrites the slot's results afterwards voids the copy (get_frame then reads
+ * back as usual). */
+int lpslam_hip_prefetch_frame(lpslam_hip_ctx* ctx, int image, int32_t with_stereo);
 int lpslam_hip_get_pyramid_level(lpslam_hip_ctx* ctx, int image, int level, uint8_t* out, int32_t out_stride);
 int lpslam_hip_get_candidates(lpslam_hip_ctx* ctx, int image, int level, lpslam_hip_corner* out,
                               int32_t capacity, int32_t* count);

@@ -411,6 +411,7 @@ void lpslam_hip_destroy(lpslam_hip_ctx* c)
     for (hipStream_t st : c->ba_streams) (void)hipStreamDestroy(st);
     c->ba_streams.clear();
     if (c->h_stage) (void)hipHostFree(c->h_stage);
+    if (c->h_stage_pf) (void)hipHostFree(c->h_stage_pf);
     if (c->h_match) (void)hipHostFree(c->h_match);
     for (uint8_t* b : c->h_upload) if (b) (void)hipHostFree(b);
     for (hipEvent_t e : c->ev_upload) if (e) (void)hipEventDestroy(e);
@@ -857,46 +858,102 @@ __global__ __launch_bounds__(256) void k_frame_to_host(const int* __restrict__ d
 
 extern "C" {
 
-int lpslam_hip_get_frame(lpslam_hip_ctx* c, int image, lpslam_hip_keypoint* kpts, uint8_t* desc32, float* stereo_x_right, float* depths,
-                         int32_t capacity, int32_t* count)
+// the page-locked block of a frame's results: count | done flag | keypoints | descriptors | stereo columns | depths
+struct FrameStage { size_t o_kp, o_desc, o_xr, o_dep, need; };
+static FrameStage frame_stage(const lpslam_hip_ctx* c)
 {
-    int rc = check_image(c, image); if (rc) return rc;
-    static_assert(sizeof(lpslam_hip_keypoint) == 28, "k_frame_to_host moves keypoints as seven words");
     const size_t S = (size_t)c->slots_per_image;
-    // page-locked block: count | done flag | keypoints | descriptors | stereo columns | depths
-    const size_t o_kp = 64, o_desc = o_kp + ((S * sizeof(lpslam_hip_keypoint) + 63) / 64) * 64, o_xr = o_desc + S * 32, o_dep = o_xr + ((S * 4 + 63) / 64) * 64;
-    const size_t need = o_dep + S * 4;
-    if (c->h_stage_bytes < need) {
-        if (c->h_stage) { LP_HIP(hipStreamSynchronize(c->stream)); (void)hipHostFree(c->h_stage); }
-        c->h_stage = nullptr; c->h_stage_bytes = 0;
-        LP_HIP(hipHostMalloc((void**)&c->h_stage, need, hipHostMallocDefault));
-        c->h_stage_bytes = need;
-    }
-    unsigned* counter = lp_done_counter(c, 0);
+    FrameStage f;
+    f.o_kp = 64; f.o_desc = f.o_kp + ((S * sizeof(lpslam_hip_keypoint) + 63) / 64) * 64; f.o_xr = f.o_desc + S * 32; f.o_dep = f.o_xr + ((S * 4 + 63) / 64) * 64;
+    f.need = f.o_dep + S * 4;
+    return f;
+}
+enum { FRAME_KPTS = 1, FRAME_DESC = 2, FRAME_XR = 4, FRAME_DEPTH = 8 };
+
+// launches the delivery of image slot `image` into the block `st` on stream `s`; returns the sequence number the kernel will release
+static int frame_deliver(lpslam_hip_ctx* c, int image, int fields, uint8_t* st, int counter_id, hipStream_t s, int* seq_out)
+{
+    static_assert(sizeof(lpslam_hip_keypoint) == 28, "k_frame_to_host moves keypoints as seven words");
+    const FrameStage f = frame_stage(c);
+    const size_t S = (size_t)c->slots_per_image;
+    unsigned* counter = lp_done_counter(c, counter_id);
     if (!counter) { set_error("device memory for the completion counters"); return LPSLAM_HIP_ERR_DEVICE; }
-    uint8_t* st = c->h_stage;
     int* flag = (int*)(st + 32);
     const int seq = ++c->done_seq;
     __atomic_store_n(flag, 0, __ATOMIC_RELAXED);
     const size_t o = (size_t)image * S;
-    const float* f = c->d_stereo + o * 2;
-    const int want_words = (int)S * ((kpts ? 7 : 0) + (desc32 ? 8 : 0) + (stereo_x_right ? 1 : 0) + (depths ? 1 : 0));
+    const float* fs = c->d_stereo + o * 2;
+    const int want_words = (int)S * (((fields & FRAME_KPTS) ? 7 : 0) + ((fields & FRAME_DESC) ? 8 : 0) + ((fields & FRAME_XR) ? 1 : 0) + ((fields & FRAME_DEPTH) ? 1 : 0));
     const int blocks = std::max(1, std::min(64, (want_words + 1023) / 1024));
-    hipLaunchKernelGGL(k_frame_to_host, dim3(blocks), dim3(256), 0, c->stream, (const int*)(c->d_kp_count + image),
-                       kpts ? (const uint32_t*)(c->d_kpts + o) : nullptr, desc32 ? (const uint32_t*)(c->d_desc + o * 32) : nullptr,
-                       stereo_x_right ? (const uint32_t*)f : nullptr, depths ? (const uint32_t*)(f + S) : nullptr, (uint32_t*)st,
-                       (int)(o_kp / 4), (int)(o_desc / 4), (int)(o_xr / 4), (int)(o_dep / 4), (int)S, counter, flag, seq);
+    hipLaunchKernelGGL(k_frame_to_host, dim3(blocks), dim3(256), 0, s, (const int*)(c->d_kp_count + image),
+                       (fields & FRAME_KPTS) ? (const uint32_t*)(c->d_kpts + o) : nullptr, (fields & FRAME_DESC) ? (const uint32_t*)(c->d_desc + o * 32) : nullptr,
+                       (fields & FRAME_XR) ? (const uint32_t*)fs : nullptr, (fields & FRAME_DEPTH) ? (const uint32_t*)(fs + S) : nullptr, (uint32_t*)st,
+                       (int)(f.o_kp / 4), (int)(f.o_desc / 4), (int)(f.o_xr / 4), (int)(f.o_dep / 4), (int)S, counter, flag, seq);
     LP_HIP(hipGetLastError());
-    if (!lp_wait_done(flag, seq, c->stream)) { set_error("lpslam_hip_get_frame: the read-back kernel did not complete"); return LPSLAM_HIP_ERR_DEVICE; }
+    *seq_out = seq;
+    return LPSLAM_HIP_OK;
+}
+
+// The read-back of a frame whose front end runs ahead (inside a prefetch section, after its extraction and stereo match): the delivery
+// kernel is queued behind them on the same stream, so the results are in page-locked memory before the caller asks --
+// lpslam_hip_get_frame for that slot then only checks the flag.  Whatever rewrites the slot's results afterwards voids the copy.
+int lpslam_hip_prefetch_frame(lpslam_hip_ctx* c, int image, int32_t with_stereo)
+{
+    int rc = check_image(c, image); if (rc) return rc;
+    const FrameStage f = frame_stage(c);
+    hipStream_t s = lp_fe_stream(c);
+    if (c->h_stage_pf_bytes < f.need) {
+        if (c->h_stage_pf) { if (c->pf_stream) LP_HIP(hipStreamSynchronize(c->pf_stream)); (void)hipHostFree(c->h_stage_pf); }
+        c->h_stage_pf = nullptr; c->h_stage_pf_bytes = 0; c->pf_image = -1; c->pf_in_flight = false;
+        LP_HIP(hipHostMalloc((void**)&c->h_stage_pf, f.need, hipHostMallocDefault));
+        c->h_stage_pf_bytes = f.need;
+    }
+    const int fields = FRAME_KPTS | FRAME_DESC | (with_stereo ? (FRAME_XR | FRAME_DEPTH) : 0);
+    int seq = 0;
+    c->pf_image = -1;
+    // one delivery into the block at a time: a copy that was voided instead of collected may still be on its way (another stream)
+    if (c->pf_in_flight && !lp_wait_done((int*)(c->h_stage_pf + 32), c->pf_seq, c->pf_stream)) { set_error("lpslam_hip_prefetch_frame: the previous read-back did not complete"); return LPSLAM_HIP_ERR_DEVICE; }
+    c->pf_in_flight = false;
+    if ((rc = frame_deliver(c, image, fields, c->h_stage_pf, 3, s, &seq))) return rc;
+    c->pf_seq = seq; c->pf_fields = fields; c->pf_stream = s; c->pf_in_flight = true;
+    c->pf_image = image;
+    return LPSLAM_HIP_OK;
+}
+
+int lpslam_hip_get_frame(lpslam_hip_ctx* c, int image, lpslam_hip_keypoint* kpts, uint8_t* desc32, float* stereo_x_right, float* depths,
+                         int32_t capacity, int32_t* count)
+{
+    int rc = check_image(c, image); if (rc) return rc;
+    const FrameStage f = frame_stage(c);
+    const int fields = (kpts ? FRAME_KPTS : 0) | (desc32 ? FRAME_DESC : 0) | (stereo_x_right ? FRAME_XR : 0) | (depths ? FRAME_DEPTH : 0);
+    uint8_t* st = nullptr;
+    if (c->pf_image == image && c->h_stage_pf && (fields & ~c->pf_fields) == 0) {
+        // delivered ahead of time by lpslam_hip_prefetch_frame
+        st = c->h_stage_pf;
+        c->pf_image = -1;
+        if (!lp_wait_done((int*)(st + 32), c->pf_seq, c->pf_stream)) { set_error("lpslam_hip_get_frame: the prefetched read-back did not complete"); return LPSLAM_HIP_ERR_DEVICE; }
+        c->pf_in_flight = false;
+    } else {
+        if (c->h_stage_bytes < f.need) {
+            if (c->h_stage) { LP_HIP(hipStreamSynchronize(c->stream)); (void)hipHostFree(c->h_stage); }
+            c->h_stage = nullptr; c->h_stage_bytes = 0;
+            LP_HIP(hipHostMalloc((void**)&c->h_stage, f.need, hipHostMallocDefault));
+            c->h_stage_bytes = f.need;
+        }
+        st = c->h_stage;
+        int seq = 0;
+        if ((rc = frame_deliver(c, image, fields, st, 0, c->stream, &seq))) return rc;
+        if (!lp_wait_done((int*)(st + 32), seq, c->stream)) { set_error("lpslam_hip_get_frame: the read-back kernel did not complete"); return LPSLAM_HIP_ERR_DEVICE; }
+    }
     int32_t n = 0;
     memcpy(&n, st, sizeof(n));
     if ((size_t)image < c->h_kp_valid.size()) { c->h_kp_count[(size_t)image] = n; c->h_kp_valid[(size_t)image] = 1; }
     if (count) *count = n;
     if (n > capacity) { set_error("frame buffers too small (%d < %d)", capacity, n); return LPSLAM_HIP_ERR_CAPACITY; }
-    if (kpts && n) memcpy(kpts, st + o_kp, (size_t)n * sizeof(lpslam_hip_keypoint));
-    if (desc32 && n) memcpy(desc32, st + o_desc, (size_t)n * 32);
-    if (stereo_x_right && n) memcpy(stereo_x_right, st + o_xr, (size_t)n * sizeof(float));
-    if (depths && n) memcpy(depths, st + o_dep, (size_t)n * sizeof(float));
+    if (kpts && n) memcpy(kpts, st + f.o_kp, (size_t)n * sizeof(lpslam_hip_keypoint));
+    if (desc32 && n) memcpy(desc32, st + f.o_desc, (size_t)n * 32);
+    if (stereo_x_right && n) memcpy(stereo_x_right, st + f.o_xr, (size_t)n * sizeof(float));
+    if (depths && n) memcpy(depths, st + f.o_dep, (size_t)n * sizeof(float));
     return LPSLAM_HIP_OK;
 }
 
@@ -934,6 +991,7 @@ int lpslam_hip_keypoint_buffers(lpslam_hip_ctx* c, int image, void** kpts_dev, v
     if (kpts_dev) *kpts_dev = c->d_kpts + o;
     if (desc_dev) *desc_dev = c->d_desc + o * 32;
     if (count_dev) { *count_dev = c->d_kp_count + image; if ((size_t)image < c->h_kp_valid.size()) c->h_kp_valid[(size_t)image] = 0; }
+    lp_pf_invalidate(c, image, 1);
     return LPSLAM_HIP_OK;
 }
 
@@ -946,6 +1004,7 @@ int lpslam_hip_set_descriptors(lpslam_hip_ctx* c, int image, const uint8_t* desc
     LP_HIP(hipMemcpyAsync(c->d_kp_count + image, &n, sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     LP_HIP(hipStreamSynchronize(c->stream));
     if ((size_t)image < c->h_kp_valid.size()) { c->h_kp_count[(size_t)image] = n; c->h_kp_valid[(size_t)image] = 1; }
+    lp_pf_invalidate(c, image, 1);
     return LPSLAM_HIP_OK;
 }
 

@@ -1225,6 +1225,7 @@ int lp_launch_distribute(lpslam_hip_ctx* c, int first, int n_images)
 int lp_launch_describe(lpslam_hip_ctx* c, int first, int n_images)
 {
     for (int i = first; i < first + n_images && (size_t)i < c->h_kp_valid.size(); ++i) c->h_kp_valid[(size_t)i] = 0;      // counts are rewritten
+    lp_pf_invalidate(c, first, n_images);
     const int blocks = (c->slots_per_image + DESC_WAVES - 1) / DESC_WAVES;
     FeQueue fq = lp_fe_queue(c, blocks * n_images, 16);
     if (fq.cu_table)                                     // queued: seven workgroups (28 wavefronts) per compute unit

@@ -333,6 +333,7 @@ __global__ __launch_bounds__(1024) void k_stereo_median(const int32_t* __restric
 
 int lp_launch_stereo_strided(lpslam_hip_ctx* c, int left0, int right0, int stride, int n_pairs, float fxb, float baseline)
 {
+    for (int i = 0; i < n_pairs; ++i) lp_pf_invalidate(c, left0 + i * stride, 1);        // the left slots' stereo columns are rewritten
     const float max_disp = fxb / baseline;
     hipLaunchKernelGGL(k_stereo_rows, dim3(n_pairs), dim3(1024), (size_t)(2 * c->lt.h[0] + 2) * sizeof(int), lp_fe_stream(c), c->lt, c->d_kpts, c->d_kp_count,
                        c->slots_per_image, right0, stride, c->d_st_row_start, c->d_st_row_list, c->st_row_cap);
@@ -535,6 +536,7 @@ int lpslam_hip_match_bf_descriptors(lpslam_hip_ctx* c, int query, int scratch, c
     if (n_train) LP_HIP(hipMemcpyAsync(c->d_desc + (size_t)scratch * S * 32, train_desc32, (size_t)n_train * 32, hipMemcpyHostToDevice, s));
     LP_HIP(hipMemcpyAsync(c->d_kp_count + scratch, &n_train, sizeof(int32_t), hipMemcpyHostToDevice, s));
     if ((size_t)scratch < c->h_kp_valid.size()) { c->h_kp_count[(size_t)scratch] = n_train; c->h_kp_valid[(size_t)scratch] = 1; }
+    lp_pf_invalidate(c, scratch, 1);
     if (nq == 0 || n_train == 0) { LP_HIP(hipStreamSynchronize(s)); return LPSLAM_HIP_OK; }
     if ((rc = lp_launch_bf_strided(c, query, scratch, 0, 1))) return rc;
     if (cross_check && (rc = lp_launch_bf_strided(c, scratch, query, 0, 1))) return rc;

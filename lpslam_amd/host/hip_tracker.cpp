@@ -1651,6 +1651,8 @@ bool HipVslamTrackerBase::frontEnd(CameraQueueEntry const& cam, bool stereo, int
         const float baseline = (float)(m_cam.focal_x_baseline / m_cam.f_x);
         ok = lpslam_hip_match_stereo(m_ctx, slot, slot + 1, (float)m_cam.focal_x_baseline, baseline) == LPSLAM_HIP_OK;
     }
+    static const bool readback_ahead = std::getenv("LPSLAM_HIP_NO_PREFETCH_READBACK") == nullptr;      // (development switch)
+    if (ok && readback_ahead) ok = lpslam_hip_prefetch_frame(m_ctx, slot, stereo ? 1 : 0) == LPSLAM_HIP_OK;      // the read-back rides behind the front end
     return ok;
 }
 

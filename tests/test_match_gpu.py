@@ -297,3 +297,25 @@ def test_frame_readback_in_one_round_trip(hiplib):
     fkp, fdesc, fxr, fdep = ctx.frame(0)
     assert len(fkp) == len(kp) > 100 and fkp.tobytes() == kp.tobytes() and np.array_equal(fdesc, desc)
     assert np.array_equal(fxr, xr) and np.array_equal(fdep, dep) and (fdep > 0).sum() > 20
+    # delivered ahead of time behind a prefetched front end (lpslam_hip_prefetch_frame): the same bytes; a copy that the slot's next
+    # extraction voids is not served (another frame goes into the slot, the late read-back must show IT)
+    l2, r2 = synth.StereoSequence(w, h, 2, n_points=4000).frame(7)
+    with ctx.prefetch():
+        ctx.upload(0, l); ctx.upload(1, r); ctx.extract(2)
+        ctx.match_stereo(0, 1, k["fxb"], k["baseline"])
+        ctx.prefetch_frame(0)
+    ctx.prefetch_join()
+    pkp, pdesc, pxr, pdep = ctx.frame(0)
+    assert pkp.tobytes() == kp.tobytes() and np.array_equal(pdesc, desc) and np.array_equal(pxr, xr) and np.array_equal(pdep, dep)
+    with ctx.prefetch():
+        ctx.prefetch_frame(0)                              # delivered ...
+        ctx.upload(0, l2); ctx.upload(1, r2); ctx.extract(2)      # ... and voided: the slot holds another frame now
+        ctx.match_stereo(0, 1, k["fxb"], k["baseline"])
+    ctx.prefetch_join()
+    qkp, qdesc, qxr, qdep = ctx.frame(0)
+    kp2, desc2 = ctx.keypoints(0)
+    xr2, dep2, _ = ctx.stereo(0)
+    assert qkp.tobytes() == kp2.tobytes() and np.array_equal(qdesc, desc2) and np.array_equal(qxr, xr2) and qkp.tobytes() != kp.tobytes()
+    ctx.prefetch_frame(0); ctx.prefetch_frame(0)            # two deliveries in a row (main stream): the second waits for the first
+    rkp, rdesc, rxr, rdep = ctx.frame(0)
+    assert rkp.tobytes() == kp2.tobytes() and np.array_equal(rdep, dep2)
