@@ -681,15 +681,21 @@ def main():
                     before them produced), are solved as one batch, read back and released"""
                     fut = ahead.submit(make_all, 0)
                     for r in range(n_rounds):
+                        ta = time.perf_counter()
                         bas = fut.result()
+                        tb = time.perf_counter()
                         if r + 1 < n_rounds:
                             fut = ahead.submit(make_all, (r + 1) * S)
-                        for i, b in enumerate(bas):
-                            p = wl.probs[(r * S + i) % BA_VARIANTS]
-                            b.set_state(p["poses"], p["points"])
+                        ps = [wl.probs[(r * S + i) % BA_VARIANTS] for i in range(S)]
+                        hip.ba_set_state_batch(bas, [p["poses"] for p in ps], [p["points"] for p in ps])
+                        tc = time.perf_counter()
                         hip.ba_optimize_batch(bas, True, BA_ITERS)
+                        td = time.perf_counter()
+                        hip.ba_state_batch(bas)
                         for b in bas:
-                            b.state(); b.close()
+                            b.close()
+                        if os.environ.get("LPSLAM_BENCH_ROUND_TRACE"):
+                            print("round %d: waited for the windows %.3f ms, set_state %.3f, batch %.3f, state + close %.3f" % (r, 1e3 * (tb - ta), 1e3 * (tc - tb), 1e3 * (td - tc), 1e3 * (time.perf_counter() - td)), file=sys.stderr)
 
                 def fe_round():
                     n_frames = S * KF_INTERVAL                  # 96 stereo frames per round, in launches of the ring's size
@@ -701,6 +707,8 @@ def main():
                         fe_ctx.match_bf_strided(2, 0, 2, n - 1)
                         done += n
                     fe_ctx.sync()
+                ms_reserve = int(os.environ.get("LPSLAM_BENCH_MS_RESERVE", "8"))       # the sessions' front ends leave 8 compute units of every XCD to the batch of windows (measured 0 / 8 / 16: 11.7-12.4 k / 12.5-12.9 k / 11.3-12.2 k frames/s, contiguous)
+                wl.ctx.set_mapping_reserve(ms_reserve)
                 for kind, key in (("random", "multi_session"), ("contiguous", "multi_session_contiguous")):
                     wl.set_tracks(kind)
                     session_rounds(2); fe_round()          # two rounds: the pipeline holds two sets of windows, their blocks come from the cache afterwards
@@ -720,8 +728,9 @@ def main():
                                    # the batch's arithmetic against the FP64 matrix-core peak: S windows x BA_ITERS iterations of the
                                    # per-iteration flop count above, over the whole round (create + solve + read-back + destroy)
                                    "ba_roofline": ({"TFLOPs": round(S * BA_ITERS * fl / t_ba_only / 1e12, 3), "frac_of_fp64_peak": round(S * BA_ITERS * fl / t_ba_only / 1e12 / FP64_PEAK_TFLOPS, 5)} if fl else None),
-                                   "note": "16 sessions, 6 stereo frames + 1 fresh local BA each per round; the windows of a round are set up on 8 host threads beside the previous round's solve (every session has its mapping thread), receive their values (set_state), are solved by one lpslam_hip_ba_optimize_batch call, read back and released"}
+                                   "note": "16 sessions, 6 stereo frames + 1 fresh local BA each per round; the windows of a round are set up on 8 host threads beside the previous round's solve (every session has its mapping thread), receive their values (one lpslam_hip_ba_set_state_batch call), are solved by one lpslam_hip_ba_optimize_batch call, read back (one lpslam_hip_ba_get_batch call) and released; the front ends leave %d compute units per XCD to the batch" % ms_reserve}
                 wl.set_tracks("random")
+                wl.ctx.set_mapping_reserve(0)
                 creators.shutdown(); ahead.shutdown()
             except Exception as e:      # noqa: BLE001
                 extras["multi_session"] = {"error": str(e)}

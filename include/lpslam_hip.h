@@ -269,6 +269,11 @@ int lpslam_hip_ba_set_solver(lpslam_hip_ba* ba, int32_t solver);
 int lpslam_hip_ba_optimize_batch(lpslam_hip_ba* const* problems, int32_t n, int32_t robust, int32_t iters,
                                  lpslam_hip_ba_iter_log* logs, int32_t log_stride, int32_t* done);
 int lpslam_hip_ba_reset_batch(lpslam_hip_ba* const* problems, int32_t n);
+/* lpslam_hip_ba_set_state / lpslam_hip_ba_get for every problem of a batch in one call (poses[i] / points[i] may be NULL as in the
+ * single calls): the per-problem kernels are all enqueued before the first wait, and a server that runs its sessions' windows from a
+ * scripting language crosses the boundary once per round instead of once per window. */
+int lpslam_hip_ba_set_state_batch(lpslam_hip_ba* const* problems, int32_t n, const double* const* poses, const double* const* points);
+int lpslam_hip_ba_get_batch(lpslam_hip_ba* const* problems, int32_t n, double* const* poses, double* const* points);
 /* lpslam_hip_ba_optimize with a HIP event after every launch of the chain, on the problem's stream: time per kernel, summed over
  * the call (measurement hook of bench.py, like lpslam_hip_timer_*; no reference counterpart). */
 #define LPSLAM_HIP_BA_KERNELS 8

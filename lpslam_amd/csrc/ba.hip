@@ -3187,6 +3187,53 @@ int lpslam_hip_ba_get(lpslam_hip_ba* b, double* poses, double* points)
     return LPSLAM_HIP_OK;
 }
 
+int lpslam_hip_ba_set_state_batch(lpslam_hip_ba* const* ps, int32_t n, const double* const* poses, const double* const* points)
+{
+    if (n < 0 || (n > 0 && !ps)) { set_error("bad batch"); return LPSLAM_HIP_ERR_INVALID; }
+    for (int i = 0; i < n; ++i) {
+        const int rc = lpslam_hip_ba_set_state(ps[i], poses ? poses[i] : nullptr, points ? points[i] : nullptr);      // (asynchronous: a copy into the exchange block + one launch)
+        if (rc) return rc;
+    }
+    return LPSLAM_HIP_OK;
+}
+
+int lpslam_hip_ba_get_batch(lpslam_hip_ba* const* ps, int32_t n, double* const* poses, double* const* points)
+{
+    if (n < 0 || (n > 0 && !ps)) { set_error("bad batch"); return LPSLAM_HIP_ERR_INVALID; }
+    auto even = [](size_t m) { return (m + 1) & ~(size_t)1; };
+    std::vector<uint8_t> through_block((size_t)n, 0);
+    // every problem's state kernel first ...
+    for (int i = 0; i < n; ++i) {
+        lpslam_hip_ba* b = ps[i];
+        if (!b) { set_error("null problem"); return LPSLAM_HIP_ERR_INVALID; }
+        double* po = poses ? poses[i] : nullptr; double* pt = points ? points[i] : nullptr;
+        uint8_t* x = ensure_xfer(b);
+        if (!x) continue;                               // no exchange block: the single call below
+        double* out_poses = (double*)x + even(7 * (size_t)b->n_poses + 3 * (size_t)std::max(b->n_points, 1));
+        double* out_points = out_poses + even(7 * (size_t)b->n_poses);
+        const bool want_points = pt && b->n_points;
+        const long n_max = std::max<long>(po ? 7L * b->n_poses : 0, want_points ? 3L * b->n_points : 0);
+        if (n_max > 0) {
+            hipLaunchKernelGGL(k_ba_state_to_host, dim3((unsigned)((n_max + 511) / 512), 1), dim3(256), 0, b->stream, b->d_view, po ? out_poses : nullptr, want_points ? out_points : nullptr);
+            LP_HIP(hipGetLastError());
+        }
+        through_block[(size_t)i] = 1;
+    }
+    // ... then the waits and the copies out
+    for (int i = 0; i < n; ++i) {
+        lpslam_hip_ba* b = ps[i];
+        double* po = poses ? poses[i] : nullptr; double* pt = points ? points[i] : nullptr;
+        if (!through_block[(size_t)i]) { const int rc = lpslam_hip_ba_get(b, po, pt); if (rc) return rc; continue; }
+        LP_HIP(hipStreamSynchronize(b->stream));
+        release_stage(b);
+        double* out_poses = (double*)b->xfer + even(7 * (size_t)b->n_poses + 3 * (size_t)std::max(b->n_points, 1));
+        double* out_points = out_poses + even(7 * (size_t)b->n_poses);
+        if (po) memcpy(po, out_poses, 7 * (size_t)b->n_poses * sizeof(double));
+        if (pt && b->n_points) memcpy(pt, out_points, 3 * (size_t)b->n_points * sizeof(double));
+    }
+    return LPSLAM_HIP_OK;
+}
+
 int lpslam_hip_ba_chi2(lpslam_hip_ba* b, double* chi2, uint8_t* depth_positive)
 {
     if (!b) { set_error("null problem"); return LPSLAM_HIP_ERR_INVALID; }

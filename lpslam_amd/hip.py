@@ -36,7 +36,7 @@ SYMBOLS = [
     "lpslam_hip_match_stereo", "lpslam_hip_match_stereo_strided", "lpslam_hip_get_stereo",
     "lpslam_hip_vocab_create", "lpslam_hip_vocab_destroy", "lpslam_hip_vocab_info", "lpslam_hip_bow_transform", "lpslam_hip_bow_transform_host", "lpslam_hip_match_bow_tree",
     "lpslam_hip_match_projection", "lpslam_hip_match_fuse", "lpslam_hip_match_area", "lpslam_hip_match_orientation_filter",
-    "lpslam_hip_ba_create", "lpslam_hip_ba_destroy", "lpslam_hip_ba_set_active", "lpslam_hip_ba_optimize", "lpslam_hip_ba_optimize_begin", "lpslam_hip_ba_optimize_end", "lpslam_hip_ba_graph_replays", "lpslam_hip_ba_wg_factorisations", "lpslam_hip_pose_optimize_passes", "lpslam_hip_match_bf_descriptors", "lpslam_hip_prefetch_frame", "lpslam_hip_ba_get_solver", "lpslam_hip_ba_set_solver",
+    "lpslam_hip_ba_create", "lpslam_hip_ba_destroy", "lpslam_hip_ba_set_active", "lpslam_hip_ba_optimize", "lpslam_hip_ba_optimize_begin", "lpslam_hip_ba_optimize_end", "lpslam_hip_ba_graph_replays", "lpslam_hip_ba_wg_factorisations", "lpslam_hip_pose_optimize_passes", "lpslam_hip_match_bf_descriptors", "lpslam_hip_prefetch_frame", "lpslam_hip_ba_set_state_batch", "lpslam_hip_ba_get_batch", "lpslam_hip_ba_get_solver", "lpslam_hip_ba_set_solver",
     "lpslam_hip_ba_optimize_batch", "lpslam_hip_ba_reset_batch", "lpslam_hip_ba_optimize_profiled", "lpslam_hip_ba_optimize_partitioned", "lpslam_hip_ba_optimize_partitioned_with",
     "lpslam_hip_ba_local", "lpslam_hip_ba_set_points_fixed", "lpslam_hip_ba_pose_optimize", "lpslam_hip_pose_optimize", "lpslam_hip_ba_reset", "lpslam_hip_ba_set_state", "lpslam_hip_prefetch_begin", "lpslam_hip_prefetch_end", "lpslam_hip_prefetch_join", "lpslam_hip_ba_get", "lpslam_hip_ba_chi2", "lpslam_hip_ba_reduced_buffer",
     "lpslam_hip_ba_step_begin", "lpslam_hip_ba_step_lambda0", "lpslam_hip_ba_step_solve", "lpslam_hip_ba_scalar_buffer", "lpslam_hip_ba_step_end", "lpslam_hip_ba_status",
@@ -600,6 +600,32 @@ class RcclComm:
 def ba_factor_kernel_name(dim, band=False):
     """name of the kernel that factors a reduced system of `dim` unknowns (rule of enqueue_solve in csrc/ba.hip)"""
     return "k_chol_band" if band else "k_chol_pair"          # k_chol_wg takes over only in batches of 40 dense problems and more
+
+
+def ba_set_state_batch(problems, poses, points):
+    """lpslam_hip_ba_set_state of every problem in one call (poses[i] / points[i]: arrays or None)"""
+    n = len(problems)
+    ps = [None if a is None else np.ascontiguousarray(a, np.float64) for a in poses]
+    pt = [None if a is None else np.ascontiguousarray(a, np.float64) for a in points]
+    hs = (C.c_void_p * n)(*[p.h for p in problems])
+    pa = (C.c_void_p * n)(*[None if a is None else a.ctypes.data for a in ps])
+    ta = (C.c_void_p * n)(*[None if a is None else a.ctypes.data for a in pt])
+    f = problems[0].lib.lpslam_hip_ba_set_state_batch
+    f.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+    _check(f(hs, n, pa, ta))
+
+
+def ba_state_batch(problems):
+    """lpslam_hip_ba_get of every problem in one call: [(poses, points)]"""
+    n = len(problems)
+    out = [(np.empty((p.n_poses, 7)), np.empty((p.n_points, 3))) for p in problems]
+    hs = (C.c_void_p * n)(*[p.h for p in problems])
+    pa = (C.c_void_p * n)(*[o[0].ctypes.data for o in out])
+    ta = (C.c_void_p * n)(*[o[1].ctypes.data for o in out])
+    f = problems[0].lib.lpslam_hip_ba_get_batch
+    f.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+    _check(f(hs, n, pa, ta))
+    return out
 
 
 def ba_optimize_batch(problems, robust=True, iters=10):

@@ -464,3 +464,22 @@ def test_large_batch_through_the_single_workgroup_factorisation(hiplib, oracle):
     hiplib.ba_optimize_batch(small, True, iters)
     assert c.ba_wg_factorisations() == before
     c.close()
+
+
+def test_state_of_a_batch_in_one_call(hiplib, ctx):
+    """lpslam_hip_ba_set_state_batch / lpslam_hip_ba_get_batch = the single calls problem by problem"""
+    probs = [synth.ba_problem(6 + i, 120, 700, 640, 480, seq_id=20 + i) for i in range(3)]
+    bas = [hiplib.BundleAdjuster(ctx, p["poses"], p["fixed"], p["points"], hiplib.ba_obs_array(p), p["cam"]) for p in probs]
+    moved = [(p["poses"] + 1e-3, p["points"] - 2e-3) for p in probs]
+    hiplib.ba_set_state_batch(bas, [m[0] for m in moved], [None, moved[1][1], moved[2][1]])
+    got = hiplib.ba_state_batch(bas)
+    for i, (b, (po, pt)) in enumerate(zip(bas, got)):
+        spo, spt = b.state()
+        assert np.array_equal(po, spo) and np.array_equal(pt, spt)
+        assert np.array_equal(po, moved[i][0]) and np.array_equal(pt, probs[i]["points"] if i == 0 else moved[i][1])
+    hiplib.ba_optimize_batch(bas, True, 3)
+    after = hiplib.ba_state_batch(bas)
+    for b, (po, pt) in zip(bas, after):
+        spo, spt = b.state()
+        assert np.array_equal(po, spo) and np.array_equal(pt, spt)
+        b.close()

@@ -39,12 +39,19 @@ if os.environ.get("ROUNDS"):
         t0 = time.perf_counter()
         bas = list(pool.map(make, range(v0, v0 + S))) if pool else [make(v0 + i) for i in range(S)]
         t1 = time.perf_counter()
+        for i, b in enumerate(bas):
+            p = probs[(v0 + i) % 4]
+            b.set_state(p["poses"], p["points"])
+        t1b = time.perf_counter()
         hip.ba_optimize_batch(bas, True, 10)
         t2 = time.perf_counter()
         for b in bas:
+            b.state()
+        t2b = time.perf_counter()
+        for b in bas:
             b.close()
         t3 = time.perf_counter()
-        return 1e3 * (t1 - t0), 1e3 * (t2 - t1), 1e3 * (t3 - t2)
+        return 1e3 * (t1 - t0), 1e3 * (t1b - t1), 1e3 * (t2 - t1b), 1e3 * (t2b - t2), 1e3 * (t3 - t2b)
     session_round(0)
     for r in range(4):
-        print("round %d: create %.3f ms, batch %.3f ms, close %.3f ms" % ((r,) + session_round(16 * r)))
+        print("round %d: create %.3f ms, set_state %.3f, batch %.3f ms, state %.3f, close %.3f ms" % ((r,) + session_round(16 * r)))
