@@ -770,9 +770,12 @@ def main():
                 return mg, t_all, st, arrivals, manager.Manager.statistics(log)
 
             tracker_session(tr_frames[:30])
-            mg, t_tr, st_tr, arrivals, tstats = tracker_session(tr_frames)
+            runs = [tracker_session(tr_frames) for _ in range(3)]       # three sessions over the same 120 frames: the median one is reported
+            runs.sort(key=lambda r: r[1])
+            mg, t_tr, st_tr, arrivals, tstats = runs[1]
             steady = (len(arrivals) - 21) / (arrivals[-1] - arrivals[20]) if len(arrivals) > 40 else None
             extras["tracker"] = {"frames": len(mg.results), "valid": int(sum(r["valid"] for r in mg.results)), "frames_per_s": round(len(mg.results) / t_tr, 1),
+                                 "frames_per_s_of_the_three_sessions": [round(len(r[0].results) / r[1], 1) for r in runs],
                                  "steady_frames_per_s": round(steady, 1) if steady else None,
                                  "last_frame_ms": round(1e3 * st_tr.frame_time, 3), "key_frames": int(st_tr.key_frames),
                                  "ms_per_frame_in_tracker": tstats.get("ms_per_frame"), "ms_pose_optimiser": tstats.get("ms_dev_pose"),
