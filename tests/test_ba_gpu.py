@@ -483,3 +483,31 @@ def test_state_of_a_batch_in_one_call(hiplib, ctx):
         spo, spt = b.state()
         assert np.array_equal(po, spo) and np.array_equal(pt, spt)
         b.close()
+
+
+@pytest.mark.parametrize("n", [5, 40, 100, 300, 600, 3000])
+def test_pose_optimizer_lane_layouts_and_sizes(hiplib, oracle, ctx, n):
+    """lpslam_hip_pose_optimize over the kernel's layouts: one observation per quad of lanes (n <= 64), per pair (<= 128), per lane,
+    two per lane, and more observations than it keeps in LDS (~2700: they are read from device memory); mono / stereo mix, outliers."""
+    rng = np.random.default_rng(n)
+    cam = dict(synth.intrinsics(640, 480))
+    pts = np.stack([rng.uniform(-4, 4, n), rng.uniform(-3, 3, n), rng.uniform(2, 20, n)], axis=1)
+    t = np.array([0.03, -0.02, 0.05])
+    pc = pts + t
+    obs = np.zeros(n, hiplib.BA_OBS_DTYPE)
+    obs["point"] = np.arange(n)
+    obs["u"] = cam["fx"] * pc[:, 0] / pc[:, 2] + cam["cx"] + rng.normal(0, 0.5, n)
+    obs["v"] = cam["fy"] * pc[:, 1] / pc[:, 2] + cam["cy"] + rng.normal(0, 0.5, n)
+    stereo = rng.random(n) < 0.6
+    obs["ur"] = np.where(stereo, obs["u"] - cam["fxb"] / pc[:, 2] + rng.normal(0, 0.5, n), -1.0)
+    obs["inv_sigma2"] = 1.0 / (1.2 ** (2 * rng.integers(0, 4, n)))
+    gross = np.arange(0, n, 7)
+    obs["v"][gross] += 30.0
+    start = np.array([1.0, 0, 0, 0, 0, 0, 0])
+    opose, oout, oin = oracle.pose_optimize(start, pts, _as_oracle_obs(oracle, obs), cam)
+    kpose, kout, kin = hiplib.pose_optimize(ctx, start, pts, obs, cam)
+    assert kin == oin and np.array_equal(kout, oout.astype(bool))
+    assert np.abs(kpose[:4] - opose[:4]).max() < 1e-7 and np.abs(kpose[4:] - opose[4:]).max() < 1e-6
+    assert 5 <= ctx.pose_optimize_passes() <= 4 * 101           # one pass per round + one per Levenberg trial
+    if n >= 40:
+        assert kout[gross].mean() > 0.9 and np.abs(kpose[4:] - t).max() < 0.02
