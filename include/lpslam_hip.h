@@ -161,6 +161,11 @@ int lpslam_hip_get_frame(lpslam_hip_ctx* ctx, int image, lpslam_hip_keypoint* kp
  * them, which then only checks a flag.  Anything that rewrites the slot's results afterwards voids the copy (get_frame then reads
  * back as usual). */
 int lpslam_hip_prefetch_frame(lpslam_hip_ctx* ctx, int image, int32_t with_stereo);
+/* lpslam_hip_get_frame without the copy out: pointers into the context's page-locked block that holds the slot's results (first
+ * *count entries each), valid until the next lpslam_hip_get_frame / _view / lpslam_hip_prefetch_frame call on this context.  The
+ * caller copies what it keeps, once, into storage of the right size. */
+int lpslam_hip_get_frame_view(lpslam_hip_ctx* ctx, int image, int32_t with_stereo, const lpslam_hip_keypoint** kpts, const uint8_t** desc32,
+                              const float** stereo_x_right, const float** depths, int32_t* count);
 int lpslam_hip_get_pyramid_level(lpslam_hip_ctx* ctx, int image, int level, uint8_t* out, int32_t out_stride);
 int lpslam_hip_get_candidates(lpslam_hip_ctx* ctx, int image, int level, lpslam_hip_corner* out,
                               int32_t capacity, int32_t* count);

@@ -920,13 +920,12 @@ int lpslam_hip_prefetch_frame(lpslam_hip_ctx* c, int image, int32_t with_stereo)
     return LPSLAM_HIP_OK;
 }
 
-int lpslam_hip_get_frame(lpslam_hip_ctx* c, int image, lpslam_hip_keypoint* kpts, uint8_t* desc32, float* stereo_x_right, float* depths,
-                         int32_t capacity, int32_t* count)
+// the block that holds `fields` of slot `image` once this returns (delivered ahead of time, or read back now)
+static int frame_collect(lpslam_hip_ctx* c, int image, int fields, uint8_t** block)
 {
-    int rc = check_image(c, image); if (rc) return rc;
     const FrameStage f = frame_stage(c);
-    const int fields = (kpts ? FRAME_KPTS : 0) | (desc32 ? FRAME_DESC : 0) | (stereo_x_right ? FRAME_XR : 0) | (depths ? FRAME_DEPTH : 0);
     uint8_t* st = nullptr;
+    int rc = 0;
     if (c->pf_image == image && c->h_stage_pf && (fields & ~c->pf_fields) == 0) {
         // delivered ahead of time by lpslam_hip_prefetch_frame
         st = c->h_stage_pf;
@@ -948,12 +947,43 @@ int lpslam_hip_get_frame(lpslam_hip_ctx* c, int image, lpslam_hip_keypoint* kpts
     int32_t n = 0;
     memcpy(&n, st, sizeof(n));
     if ((size_t)image < c->h_kp_valid.size()) { c->h_kp_count[(size_t)image] = n; c->h_kp_valid[(size_t)image] = 1; }
+    *block = st;
+    return LPSLAM_HIP_OK;
+}
+
+int lpslam_hip_get_frame(lpslam_hip_ctx* c, int image, lpslam_hip_keypoint* kpts, uint8_t* desc32, float* stereo_x_right, float* depths,
+                         int32_t capacity, int32_t* count)
+{
+    int rc = check_image(c, image); if (rc) return rc;
+    const FrameStage f = frame_stage(c);
+    const int fields = (kpts ? FRAME_KPTS : 0) | (desc32 ? FRAME_DESC : 0) | (stereo_x_right ? FRAME_XR : 0) | (depths ? FRAME_DEPTH : 0);
+    uint8_t* st = nullptr;
+    if ((rc = frame_collect(c, image, fields, &st))) return rc;
+    int32_t n = 0;
+    memcpy(&n, st, sizeof(n));
     if (count) *count = n;
     if (n > capacity) { set_error("frame buffers too small (%d < %d)", capacity, n); return LPSLAM_HIP_ERR_CAPACITY; }
     if (kpts && n) memcpy(kpts, st + f.o_kp, (size_t)n * sizeof(lpslam_hip_keypoint));
     if (desc32 && n) memcpy(desc32, st + f.o_desc, (size_t)n * 32);
     if (stereo_x_right && n) memcpy(stereo_x_right, st + f.o_xr, (size_t)n * sizeof(float));
     if (depths && n) memcpy(depths, st + f.o_dep, (size_t)n * sizeof(float));
+    return LPSLAM_HIP_OK;
+}
+
+int lpslam_hip_get_frame_view(lpslam_hip_ctx* c, int image, int32_t with_stereo, const lpslam_hip_keypoint** kpts, const uint8_t** desc32,
+                              const float** stereo_x_right, const float** depths, int32_t* count)
+{
+    int rc = check_image(c, image); if (rc) return rc;
+    if (!kpts || !desc32 || !count || (with_stereo && (!stereo_x_right || !depths))) { set_error("null argument"); return LPSLAM_HIP_ERR_INVALID; }
+    const FrameStage f = frame_stage(c);
+    uint8_t* st = nullptr;
+    if ((rc = frame_collect(c, image, FRAME_KPTS | FRAME_DESC | (with_stereo ? (FRAME_XR | FRAME_DEPTH) : 0), &st))) return rc;
+    int32_t n = 0;
+    memcpy(&n, st, sizeof(n));
+    *count = n;
+    *kpts = (const lpslam_hip_keypoint*)(st + f.o_kp); *desc32 = st + f.o_desc;
+    if (stereo_x_right) *stereo_x_right = with_stereo ? (const float*)(st + f.o_xr) : nullptr;
+    if (depths) *depths = with_stereo ? (const float*)(st + f.o_dep) : nullptr;
     return LPSLAM_HIP_OK;
 }
 

@@ -36,7 +36,7 @@ SYMBOLS = [
     "lpslam_hip_match_stereo", "lpslam_hip_match_stereo_strided", "lpslam_hip_get_stereo",
     "lpslam_hip_vocab_create", "lpslam_hip_vocab_destroy", "lpslam_hip_vocab_info", "lpslam_hip_bow_transform", "lpslam_hip_bow_transform_host", "lpslam_hip_match_bow_tree",
     "lpslam_hip_match_projection", "lpslam_hip_match_fuse", "lpslam_hip_match_area", "lpslam_hip_match_orientation_filter",
-    "lpslam_hip_ba_create", "lpslam_hip_ba_destroy", "lpslam_hip_ba_set_active", "lpslam_hip_ba_optimize", "lpslam_hip_ba_optimize_begin", "lpslam_hip_ba_optimize_end", "lpslam_hip_ba_graph_replays", "lpslam_hip_ba_wg_factorisations", "lpslam_hip_pose_optimize_passes", "lpslam_hip_match_bf_descriptors", "lpslam_hip_prefetch_frame", "lpslam_hip_ba_set_state_batch", "lpslam_hip_ba_get_batch", "lpslam_hip_ba_get_solver", "lpslam_hip_ba_set_solver",
+    "lpslam_hip_ba_create", "lpslam_hip_ba_destroy", "lpslam_hip_ba_set_active", "lpslam_hip_ba_optimize", "lpslam_hip_ba_optimize_begin", "lpslam_hip_ba_optimize_end", "lpslam_hip_ba_graph_replays", "lpslam_hip_ba_wg_factorisations", "lpslam_hip_pose_optimize_passes", "lpslam_hip_match_bf_descriptors", "lpslam_hip_prefetch_frame", "lpslam_hip_get_frame_view", "lpslam_hip_ba_set_state_batch", "lpslam_hip_ba_get_batch", "lpslam_hip_ba_get_solver", "lpslam_hip_ba_set_solver",
     "lpslam_hip_ba_optimize_batch", "lpslam_hip_ba_reset_batch", "lpslam_hip_ba_optimize_profiled", "lpslam_hip_ba_optimize_partitioned", "lpslam_hip_ba_optimize_partitioned_with",
     "lpslam_hip_ba_local", "lpslam_hip_ba_set_points_fixed", "lpslam_hip_ba_pose_optimize", "lpslam_hip_pose_optimize", "lpslam_hip_ba_reset", "lpslam_hip_ba_set_state", "lpslam_hip_prefetch_begin", "lpslam_hip_prefetch_end", "lpslam_hip_prefetch_join", "lpslam_hip_ba_get", "lpslam_hip_ba_chi2", "lpslam_hip_ba_reduced_buffer",
     "lpslam_hip_ba_step_begin", "lpslam_hip_ba_step_lambda0", "lpslam_hip_ba_step_solve", "lpslam_hip_ba_scalar_buffer", "lpslam_hip_ba_step_end", "lpslam_hip_ba_status",
@@ -308,6 +308,17 @@ class Context:
         n = C.c_int32()
         _check(self.lib.lpslam_hip_get_frame(self.h, image, _p(kp), _p(desc), _p(xr), _p(dep), self.max_kp, C.byref(n)))
         return kp[:n.value].copy(), desc[:n.value].copy(), xr[:n.value].copy(), dep[:n.value].copy()
+
+    def frame_view(self, image, with_stereo=True):
+        """lpslam_hip_get_frame_view: copies made from the context's page-locked block (valid until the next frame call)"""
+        kp = C.c_void_p(); desc = C.c_void_p(); xr = C.c_void_p(); dep = C.c_void_p(); n = C.c_int32()
+        f = self.lib.lpslam_hip_get_frame_view
+        f.argtypes = [C.c_void_p, C.c_int, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        _check(f(self.h, image, 1 if with_stereo else 0, C.byref(kp), C.byref(desc), C.byref(xr), C.byref(dep), C.byref(n)))
+        m = n.value
+        def arr(ptr, dtype, count):
+            return np.frombuffer(C.string_at(ptr.value, count * np.dtype(dtype).itemsize), dtype).copy() if (ptr.value and count) else np.zeros(0, dtype)
+        return arr(kp, KP_DTYPE, m), arr(desc, np.uint8, 32 * m).reshape(-1, 32), arr(xr, np.float32, m if with_stereo else 0), arr(dep, np.float32, m if with_stereo else 0)
 
     def pyramid_level(self, image, level):
         out = np.zeros((self.level_h[level], self.level_w[level]), np.uint8)

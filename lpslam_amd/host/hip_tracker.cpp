@@ -1778,14 +1778,16 @@ TrackerBase::ProcessImageResult HipVslamTrackerBase::trackFrame(CameraQueueEntry
     }
     dev_lap(m_stats.t_dev_extract);
     int32_t n = 0;
-    cur.kpts.resize((size_t)m_maxKp); cur.desc.resize((size_t)m_maxKp * 32);
-    cur.x_right.assign((size_t)m_maxKp, -1.0f); cur.depth.assign((size_t)m_maxKp, -1.0f);
-    if (ok) ok = lpslam_hip_get_frame(m_ctx, cur.slot, cur.kpts.data(), cur.desc.data(), stereo ? cur.x_right.data() : nullptr,
-                                      stereo ? cur.depth.data() : nullptr, m_maxKp, &n) == LPSLAM_HIP_OK;
+    // the frame's results straight out of the context's page-locked block (delivered behind the prefetched front end): one copy,
+    // into vectors of the frame's own size
+    const lpslam_hip_keypoint* v_kp = nullptr; const uint8_t* v_desc = nullptr; const float* v_xr = nullptr; const float* v_dep = nullptr;
+    if (ok) ok = lpslam_hip_get_frame_view(m_ctx, cur.slot, stereo ? 1 : 0, &v_kp, &v_desc, &v_xr, &v_dep, &n) == LPSLAM_HIP_OK && n <= m_maxKp;
+    if (!ok) { dev_lap(m_stats.t_dev_get); logMessage(LpSlamLogLevel_Error, std::string("HIP front end failed: ") + lpslam_hip_last_error()); return res; }
+    cur.kpts.assign(v_kp, v_kp + n); cur.desc.assign(v_desc, v_desc + (size_t)n * 32);
+    if (stereo) { cur.x_right.assign(v_xr, v_xr + n); cur.depth.assign(v_dep, v_dep + n); }
+    else { cur.x_right.assign((size_t)n, -1.0f); cur.depth.assign((size_t)n, -1.0f); }
+    cur.landmark.assign((size_t)n, -1);
     dev_lap(m_stats.t_dev_get);
-    if (!ok) { logMessage(LpSlamLogLevel_Error, std::string("HIP front end failed: ") + lpslam_hip_last_error()); return res; }
-    cur.kpts.resize((size_t)n); cur.desc.resize((size_t)n * 32);
-    cur.x_right.resize((size_t)n); cur.depth.resize((size_t)n); cur.landmark.assign((size_t)n, -1);
     ++m_imageTracked; ++m_stats.frames;
     // The next frame's upload + front end: a helper thread stages and enqueues it (0.2 ms of host time at 1280x720 stereo, mostly the
     // copy of the cold frame into page-locked memory) on the context's prefetch stream while this thread goes on tracking; the

@@ -319,3 +319,9 @@ def test_frame_readback_in_one_round_trip(hiplib):
     ctx.prefetch_frame(0); ctx.prefetch_frame(0)            # two deliveries in a row (main stream): the second waits for the first
     rkp, rdesc, rxr, rdep = ctx.frame(0)
     assert rkp.tobytes() == kp2.tobytes() and np.array_equal(rdep, dep2)
+    # the view: the same data without the copy into caller buffers, from a prefetched delivery and from a direct read-back
+    for ahead in (True, False):
+        if ahead:
+            ctx.prefetch_frame(0)
+        vkp, vdesc, vxr, vdep = ctx.frame_view(0)
+        assert vkp.tobytes() == kp2.tobytes() and np.array_equal(vdesc, desc2) and np.array_equal(vxr, xr2) and np.array_equal(vdep, dep2)
