@@ -827,6 +827,7 @@ int lpslam_hip_get_keypoints(lpslam_hip_ctx* c, int image, lpslam_hip_keypoint* 
 
 unsigned* lp_done_counter(lpslam_hip_ctx* c, int which)
 {
+    std::lock_guard<std::mutex> lock(c->pool_mutex);       // (a tracking thread and its prefetch thread may both arrive here first)
     if (!c->d_done) {
         if (hipMalloc((void**)&c->d_done, 8 * 32 * sizeof(unsigned)) != hipSuccess) { c->d_done = nullptr; return nullptr; }
         // (the context's streams do not synchronise with the null stream: the zeroes must be there before any of them runs a kernel)
@@ -871,7 +872,7 @@ static FrameStage frame_stage(const lpslam_hip_ctx* c)
 enum { FRAME_KPTS = 1, FRAME_DESC = 2, FRAME_XR = 4, FRAME_DEPTH = 8 };
 
 // launches the delivery of image slot `image` into the block `st` on stream `s`; returns the sequence number the kernel will release
-static int frame_deliver(lpslam_hip_ctx* c, int image, int fields, uint8_t* st, int counter_id, hipStream_t s, int* seq_out)
+static int frame_deliver(lpslam_hip_ctx* c, int image, int fields, uint8_t* st, int counter_id, hipStream_t s, int& seq_counter, int* seq_out)
 {
     static_assert(sizeof(lpslam_hip_keypoint) == 28, "k_frame_to_host moves keypoints as seven words");
     const FrameStage f = frame_stage(c);
@@ -879,7 +880,7 @@ static int frame_deliver(lpslam_hip_ctx* c, int image, int fields, uint8_t* st, 
     unsigned* counter = lp_done_counter(c, counter_id);
     if (!counter) { set_error("device memory for the completion counters"); return LPSLAM_HIP_ERR_DEVICE; }
     int* flag = (int*)(st + 32);
-    const int seq = ++c->done_seq;
+    const int seq = lp_next_seq(seq_counter);      // (the prefetch thread's deliveries count on their own: two threads never share a counter)
     __atomic_store_n(flag, 0, __ATOMIC_RELAXED);
     const size_t o = (size_t)image * S;
     const float* fs = c->d_stereo + o * 2;
@@ -914,7 +915,7 @@ int lpslam_hip_prefetch_frame(lpslam_hip_ctx* c, int image, int32_t with_stereo)
     // one delivery into the block at a time: a copy that was voided instead of collected may still be on its way (another stream)
     if (c->pf_in_flight && !lp_wait_done((int*)(c->h_stage_pf + 32), c->pf_seq, c->pf_stream)) { set_error("lpslam_hip_prefetch_frame: the previous read-back did not complete"); return LPSLAM_HIP_ERR_DEVICE; }
     c->pf_in_flight = false;
-    if ((rc = frame_deliver(c, image, fields, c->h_stage_pf, 3, s, &seq))) return rc;
+    if ((rc = frame_deliver(c, image, fields, c->h_stage_pf, 3, s, c->pf_seq_next, &seq))) return rc;
     c->pf_seq = seq; c->pf_fields = fields; c->pf_stream = s; c->pf_in_flight = true;
     c->pf_image = image;
     return LPSLAM_HIP_OK;
@@ -941,7 +942,7 @@ static int frame_collect(lpslam_hip_ctx* c, int image, int fields, uint8_t** blo
         }
         st = c->h_stage;
         int seq = 0;
-        if ((rc = frame_deliver(c, image, fields, st, 0, c->stream, &seq))) return rc;
+        if ((rc = frame_deliver(c, image, fields, st, 0, c->stream, c->done_seq, &seq))) return rc;
         if (!lp_wait_done((int*)(st + 32), seq, c->stream)) { set_error("lpslam_hip_get_frame: the read-back kernel did not complete"); return LPSLAM_HIP_ERR_DEVICE; }
     }
     int32_t n = 0;

@@ -3294,7 +3294,7 @@ int lpslam_hip_pose_optimize(lpslam_hip_ctx* ctx, double* pose7, const double* p
             packed[k] = PoObs{o.u, o.v, o.ur, o.inv_sigma2, {p[0], p[1], p[2]}};
         }
         int* flag = (int*)(hb + 64);
-        const int seq = ++ctx->po_seq;
+        const int seq = lp_next_seq(ctx->po_seq);
         __atomic_store_n(flag, 0, __ATOMIC_RELAXED);          // (the block is shared with the matchers' staging: whatever they left here is not a sequence number)
         hipLaunchKernelGGL(k_pose_optimize<true>, dim3(1), dim3(PO_T), lds, s, (double*)hb, (const double*)nullptr, (const lpslam_hip_ba_obs*)nullptr, packed, n_obs, c,
                            hb + off_flags, (int*)(hb + 56), cache_n, flag, seq);

@@ -96,7 +96,7 @@ struct lpslam_hip_ctx {
     uint8_t* h_stage = nullptr;        // pinned host staging of lpslam_hip_get_frame (one frame's results)
     size_t h_stage_bytes = 0;
     // a frame's results delivered ahead of time (lpslam_hip_prefetch_frame): block of its own, the image it holds (-1: none), what it holds
-    uint8_t* h_stage_pf = nullptr; size_t h_stage_pf_bytes = 0; std::atomic<int> pf_image{-1}; int pf_seq = 0, pf_fields = 0; bool pf_in_flight = false; hipStream_t pf_stream = nullptr;
+    uint8_t* h_stage_pf = nullptr; size_t h_stage_pf_bytes = 0; std::atomic<int> pf_image{-1}; int pf_seq = 0, pf_seq_next = 0, pf_fields = 0; bool pf_in_flight = false; hipStream_t pf_stream = nullptr;
     // host mirror of d_kp_count: valid after any call that fetched it, invalidated by whatever rewrites it on the device
     std::vector<int32_t> h_kp_count; std::vector<uint8_t> h_kp_valid;
     std::vector<void*> pin_free;       // page-locked 8 KB blocks handed to bundle-adjustment objects (lp_pin_alloc / lp_pin_free)
@@ -196,6 +196,8 @@ __device__ __forceinline__ void lp_signal_done(unsigned* counter, int* flag, int
 #endif
 inline void lp_pf_invalidate(lpslam_hip_ctx* c, int first, int n) { const int p = c->pf_image.load(std::memory_order_relaxed); if (p >= first && p < first + n) c->pf_image.store(-1, std::memory_order_relaxed); }      // the slot's results are being rewritten
 unsigned* lp_done_counter(lpslam_hip_ctx* c, int which);      // arrival counter number `which` (0 .. 7) of the context, nullptr on failure
+// the next sequence number of a completion flag: positive, never 0 (0 is what the flag is reset to before a launch)
+inline int lp_next_seq(int& s) { s = s >= 0x7ffffff0 ? 1 : s + 1; return s; }
 // host side: true when the flag arrived; after ~20 ms without it the stream is synchronised and the flag checked once more
 inline bool lp_wait_done(int* flag, int seq, hipStream_t s)
 {

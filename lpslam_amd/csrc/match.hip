@@ -552,7 +552,7 @@ int lpslam_hip_match_bf_descriptors(lpslam_hip_ctx* c, int query, int scratch, c
     if (!done_counter) { set_error("device memory for the completion counters"); return LPSLAM_HIP_ERR_DEVICE; }
     uint32_t* st = (uint32_t*)c->h_match;
     int* flag = (int*)st;
-    const int seq = ++c->done_seq;
+    const int seq = lp_next_seq(c->done_seq);
     __atomic_store_n(flag, 0, __ATOMIC_RELAXED);
     const uint32_t* fq = (const uint32_t*)(c->d_bf + (size_t)query * 3 * S);
     const uint32_t* ft = (const uint32_t*)(c->d_bf + (size_t)scratch * 3 * S);
@@ -679,7 +679,7 @@ static int window_match(lpslam_hip_ctx* c, int image, const lpslam_hip_proj_quer
     unsigned* done_counter = lp_done_counter(c, 1);
     if (!done_counter) { release(); set_error("device memory for the completion counters"); return LPSLAM_HIP_ERR_DEVICE; }
     int* done_flag = (int*)(hb + o_ids + 32);
-    const int done_seq = ++c->done_seq;
+    const int done_seq = lp_next_seq(c->done_seq);
     __atomic_store_n(done_flag, 0, __ATOMIC_RELAXED);
     hipLaunchKernelGGL(k_proj_topk, dim3((nq + 3) / 4), dim3(256), 0, s, c->d_kpts + o, c->d_desc + o * 32, sxr, c->d_kp_count + image,
                        on_device ? d_q : (const ProjQuery*)(hb + o_q), on_device ? d_qd : (const uint8_t*)(hb + o_qd), (const int*)nullptr, nq,
