@@ -190,6 +190,16 @@ int lpslam_hip_get_bf_matches(lpslam_hip_ctx* ctx, int query, int train, int32_t
 int lpslam_hip_match_bf_descriptors(lpslam_hip_ctx* ctx, int query, int scratch, const uint8_t* train_desc32, int32_t n_train,
                                     int32_t max_dist, float ratio, int32_t cross_check, int32_t* out_q, int32_t* out_t,
                                     int32_t* out_d, int32_t capacity, int32_t* count);
+/* Descriptor sets kept on the device under a caller's key -- a tracker's keyframes -- and the comparison of an image slot with MANY
+ * of them in one call: one launch matches the slot against every listed set, both directions, one kernel delivers all result arrays,
+ * the caller waits once.  out_q / out_t / out_d hold capacity_per_key entries per key (key k's matches start at k * capacity_per_key),
+ * counts[k] their number; per key the matches are those of lpslam_hip_match_bf_descriptors against that set.  A loop-candidate search
+ * over 48 old keyframes is 48 uploads and 48 waits otherwise.  put replaces an existing key; unknown keys in a match are an error. */
+int lpslam_hip_desc_store_put(lpslam_hip_ctx* ctx, int32_t key, const uint8_t* desc32, int32_t n);
+int lpslam_hip_desc_store_drop(lpslam_hip_ctx* ctx, int32_t key);
+int lpslam_hip_match_bf_stored(lpslam_hip_ctx* ctx, int query, const int32_t* keys, int32_t n_keys, int32_t max_dist, float ratio,
+                               int32_t cross_check, int32_t* out_q, int32_t* out_t, int32_t* out_d, int32_t capacity_per_key,
+                               int32_t* counts);
 /* Batched form: pairs (query0 + i*stride, train0 + i*stride), i in [0, n_pairs), in one launch. */
 int lpslam_hip_match_bf_strided(lpslam_hip_ctx* ctx, int query0, int train0, int stride, int n_pairs);
 /* Loads a caller-provided descriptor set (host memory, n x 32 bytes) into image slot `image`, replacing the

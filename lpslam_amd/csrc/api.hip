@@ -389,6 +389,8 @@ void lpslam_hip_destroy(lpslam_hip_ctx* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->fe_stream) (void)hipStreamSynchronize(c->fe_stream);
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
+    for (auto& kv : c->desc_store) if (kv.second.blk) (void)hipFree(kv.second.blk);
+    c->desc_store.clear();
     for (auto& blk : c->pool) (void)hipFree(blk.second);
     c->pool.clear();
     void* bufs[] = {c->d_pyr, c->d_band_rows, c->d_rs_pack, c->d_cell_keys, c->d_cell_count, c->d_cand_key, c->d_cand_node,

@@ -99,6 +99,9 @@ struct lpslam_hip_ctx {
     uint8_t* h_stage_pf = nullptr; size_t h_stage_pf_bytes = 0; std::atomic<int> pf_image{-1}; int pf_seq = 0, pf_seq_next = 0, pf_fields = 0; bool pf_in_flight = false; hipStream_t pf_stream = nullptr;
     // host mirror of d_kp_count: valid after any call that fetched it, invalidated by whatever rewrites it on the device
     std::vector<int32_t> h_kp_count; std::vector<uint8_t> h_kp_valid;
+    // descriptor sets kept on the device under a caller's key (lpslam_hip_desc_store_put: a tracker's keyframes), blocks of the pool
+    struct StoredDesc { void* blk = nullptr; size_t cap = 0; int n = 0; };
+    std::map<int, StoredDesc> desc_store;
     std::vector<void*> pin_free;       // page-locked 8 KB blocks handed to bundle-adjustment objects (lp_pin_alloc / lp_pin_free)
     std::vector<hipStream_t> ba_streams;   // idle high-priority streams of destroyed bundle-adjustment problems (lp_stream_acquire / release)
     // Captured launch chains of the bundle adjustment, shared by every problem that runs on a stream: the graph's kernels read their

@@ -32,8 +32,9 @@ __device__ __forceinline__ void bf_merge(int& b, int& s, int& bi, int wb, int ws
     s = min(s, ws);
 }
 
-__global__ __launch_bounds__(256) void k_bf_knn2(const uint8_t* __restrict__ desc, const int32_t* __restrict__ counts,
-                                                 int slots_per_image, int q0, int t0, int stride, int32_t* __restrict__ out)
+// one workgroup's share of the brute-force 2-NN of nq query descriptors (qdesc) against nt train descriptors (tdesc): best index /
+// best distance / second distance of query q into o[q], o[out_stride + q], o[2 out_stride + q]
+__device__ __forceinline__ void bf_knn2_body(const uint8_t* __restrict__ qdesc, int nq, const uint8_t* __restrict__ tdesc, int nt, int32_t* __restrict__ o, int out_stride)
 {
     // Workgroup = 16 queries; lane = (query, sub): the four wavefronts take the four quarters of each 1024-descriptor LDS tile
     // and the four subs of a wavefront the four sixteenths of a quarter, so a query is spread over 16 lanes and 2000 queries
@@ -41,17 +42,14 @@ __global__ __launch_bounds__(256) void k_bf_knn2(const uint8_t* __restrict__ des
     // sees four distinct addresses per wavefront, one per 16-lane group: broadcast, conflict free.
     __shared__ __attribute__((aligned(16))) uint32_t tile[BF_TILE * 8];
     __shared__ int m_best[4][BF_QPW], m_second[4][BF_QPW], m_idx[4][BF_QPW];
-    const int pair = blockIdx.y;
-    const int qs = q0 + pair * stride, ts = t0 + pair * stride;
-    const int nq = counts[qs], nt = counts[ts];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, ql = lane & 15, sub = lane >> 4;
     const int q = blockIdx.x * BF_QPW + ql;
     if (blockIdx.x * BF_QPW >= nq) return;                              // block-uniform
-    const uint32_t* qd = reinterpret_cast<const uint32_t*>(desc + ((size_t)qs * slots_per_image + min(q, nq - 1)) * 32);
+    const uint32_t* qd = reinterpret_cast<const uint32_t*>(qdesc + (size_t)min(q, nq - 1) * 32);
     uint32_t a[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) a[k] = qd[k];
-    const uint4* td = reinterpret_cast<const uint4*>(desc + (size_t)ts * slots_per_image * 32);
+    const uint4* td = reinterpret_cast<const uint4*>(tdesc);
     int best = 257, second = 257, bidx = -1;
     for (int base = 0; base < nt; base += BF_TILE) {
         const int n = min(BF_TILE, nt - base);
@@ -83,9 +81,27 @@ __global__ __launch_bounds__(256) void k_bf_knn2(const uint8_t* __restrict__ des
         int b = 257, s = 257, bi = -1;
 #pragma unroll
         for (int w = 0; w < 4; ++w) bf_merge(b, s, bi, m_best[w][ql], m_second[w][ql], m_idx[w][ql]);
-        int32_t* o = out + (size_t)qs * 3 * slots_per_image;
-        o[q] = bi; o[slots_per_image + q] = b; o[2 * slots_per_image + q] = s;
+        o[q] = bi; o[out_stride + q] = b; o[2 * out_stride + q] = s;
     }
+}
+
+
+__global__ __launch_bounds__(256) void k_bf_knn2(const uint8_t* __restrict__ desc, const int32_t* __restrict__ counts,
+                                                 int slots_per_image, int q0, int t0, int stride, int32_t* __restrict__ out)
+{
+    const int pair = blockIdx.y;
+    const int qs = q0 + pair * stride, ts = t0 + pair * stride;
+    bf_knn2_body(desc + (size_t)qs * slots_per_image * 32, counts[qs], desc + (size_t)ts * slots_per_image * 32, counts[ts],
+                 out + (size_t)qs * 3 * slots_per_image, slots_per_image);
+}
+
+// the same for a list of pairs whose descriptor sets live anywhere on the device (an image slot against stored keyframe descriptors,
+// lpslam_hip_match_bf_stored); the list itself is read from page-locked host memory
+struct BfPair { const uint8_t* q; const uint8_t* t; int32_t* out; int nq, nt, out_stride, pad_; };
+__global__ __launch_bounds__(256) void k_bf_knn2_pairs(const BfPair* __restrict__ pairs)
+{
+    const BfPair p = pairs[blockIdx.y];
+    bf_knn2_body(p.q, p.nq, p.t, p.nt, p.out, p.out_stride);
 }
 
 int lp_launch_bf_strided(lpslam_hip_ctx* c, int q0, int t0, int stride, int n_pairs)
@@ -572,6 +588,134 @@ int lpslam_hip_match_bf_descriptors(lpslam_hip_ctx* c, int query, int scratch, c
         out_q[n] = i; out_t[n] = bi[i]; out_d[n] = bd[i]; ++n;
     }
     if (count) *count = n;
+    return LPSLAM_HIP_OK;
+}
+
+int lpslam_hip_desc_store_put(lpslam_hip_ctx* c, int32_t key, const uint8_t* desc32, int32_t n)
+{
+    if (!c || n < 0 || (n > 0 && !desc32)) { set_error("bad desc_store_put arguments"); return LPSLAM_HIP_ERR_INVALID; }
+    LP_HIP(hipSetDevice(c->cfg.device));
+    lpslam_hip_ctx::StoredDesc& e = c->desc_store[key];
+    const size_t bytes = (size_t)std::max(n, 1) * 32;
+    if (e.cap < bytes) {
+        if (e.blk) { LP_HIP(hipStreamSynchronize(c->stream)); lp_pool_free(c, e.blk, e.cap); e.blk = nullptr; e.cap = 0; }
+        const int rc = lp_pool_alloc(c, bytes, &e.blk, &e.cap);
+        if (rc) { c->desc_store.erase(key); return rc; }
+    }
+    e.n = n;
+    if (n) LP_HIP(hipMemcpyAsync(e.blk, desc32, (size_t)n * 32, hipMemcpyHostToDevice, c->stream));
+    return LPSLAM_HIP_OK;
+}
+
+int lpslam_hip_desc_store_drop(lpslam_hip_ctx* c, int32_t key)
+{
+    if (!c) { set_error("null context"); return LPSLAM_HIP_ERR_INVALID; }
+    auto it = c->desc_store.find(key);
+    if (it == c->desc_store.end()) return LPSLAM_HIP_OK;
+    if (it->second.blk) { LP_HIP(hipStreamSynchronize(c->stream)); lp_pool_free(c, it->second.blk, it->second.cap); }
+    c->desc_store.erase(it);
+    return LPSLAM_HIP_OK;
+}
+
+}  // extern "C"
+
+namespace {
+// runs of 32-bit words listed in page-locked memory -> page-locked memory, one run per blockIdx.y
+struct WordRun { const uint32_t* src; int n, dst; };
+__global__ __launch_bounds__(256) void k_runs_to_host(const WordRun* __restrict__ runs, uint32_t* __restrict__ st, unsigned* counter, int* flag, int seq)
+{
+    const WordRun r = runs[blockIdx.y];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < r.n; i += gridDim.x * blockDim.x) st[r.dst + i] = r.src[i];
+    lp_signal_done(counter, flag, seq);
+}
+}  // namespace
+
+extern "C" {
+
+int lpslam_hip_match_bf_stored(lpslam_hip_ctx* c, int query, const int32_t* keys, int32_t n_keys, int32_t max_dist, float ratio, int32_t cross_check,
+                               int32_t* out_q, int32_t* out_t, int32_t* out_d, int32_t capacity_per_key, int32_t* counts)
+{
+    int rc = chk(c, query, query); if (rc) return rc;
+    if (n_keys < 0 || (n_keys > 0 && (!keys || !out_q || !out_t || !out_d || !counts)) || capacity_per_key < 0) { set_error("bad match_bf_stored arguments"); return LPSLAM_HIP_ERR_INVALID; }
+    for (int k = 0; k < n_keys; ++k) { counts[k] = 0; if (!c->desc_store.count(keys[k])) { set_error("descriptor set %d is not in the store", keys[k]); return LPSLAM_HIP_ERR_INVALID; } }
+    int32_t nq = 0;
+    if ((rc = lpslam_hip_keypoint_count(c, query, &nq))) return rc;
+    if (n_keys == 0 || nq == 0) return LPSLAM_HIP_OK;
+    hipStream_t s = c->stream;
+    const size_t S = (size_t)c->slots_per_image;
+    // device block: per key the forward arrays (best index, best distance, second distance of the nq queries) and the reverse best index
+    std::vector<size_t> o_fwd((size_t)n_keys), o_rev((size_t)n_keys);
+    size_t dev_words = 0, host_words = 16;
+    int nt_max = 1;
+    for (int k = 0; k < n_keys; ++k) {
+        const int nt = c->desc_store[keys[k]].n;
+        nt_max = std::max(nt_max, nt);
+        o_fwd[(size_t)k] = dev_words; dev_words += 3 * (size_t)nq;
+        o_rev[(size_t)k] = dev_words; dev_words += 3 * (size_t)std::max(nt, 1);
+        host_words += 3 * (size_t)nq + (size_t)(cross_check ? nt : 0);
+    }
+    // page-locked block: flag | pair list | run list | results
+    const size_t o_pairs = 64, o_runs = o_pairs + 2 * (size_t)n_keys * sizeof(BfPair), o_res = (o_runs + 2 * (size_t)n_keys * sizeof(WordRun) + 63) & ~(size_t)63;
+    const size_t host_bytes = o_res + host_words * 4;
+    if (c->h_match_bytes < host_bytes) {
+        if (c->h_match) { LP_HIP(hipStreamSynchronize(s)); (void)hipHostFree(c->h_match); }
+        c->h_match = nullptr; c->h_match_bytes = 0;
+        LP_HIP(hipHostMalloc((void**)&c->h_match, host_bytes * 2, hipHostMallocDefault));
+        c->h_match_bytes = host_bytes * 2;
+    }
+    void* blk = nullptr; size_t cap = 0;
+    if ((rc = lp_pool_alloc(c, dev_words * 4, &blk, &cap))) return rc;
+    auto release = [&]() { lp_pool_free(c, blk, cap); };
+    unsigned* done_counter = lp_done_counter(c, 2);
+    if (!done_counter) { release(); set_error("device memory for the completion counters"); return LPSLAM_HIP_ERR_DEVICE; }
+    uint8_t* hb = c->h_match;
+    BfPair* pairs = (BfPair*)(hb + o_pairs); WordRun* runs = (WordRun*)(hb + o_runs);
+    int32_t* d_res = (int32_t*)blk;
+    const uint8_t* qdesc = c->d_desc + (size_t)query * S * 32;
+    size_t w = 0;
+    std::vector<size_t> h_fwd((size_t)n_keys), h_rev((size_t)n_keys);
+    int n_pairs = 0, n_runs = 0;
+    for (int k = 0; k < n_keys; ++k) {
+        const lpslam_hip_ctx::StoredDesc& e = c->desc_store[keys[k]];
+        pairs[n_pairs++] = BfPair{qdesc, (const uint8_t*)e.blk, d_res + o_fwd[(size_t)k], nq, e.n, nq, 0};
+        if (cross_check) pairs[n_pairs++] = BfPair{(const uint8_t*)e.blk, qdesc, d_res + o_rev[(size_t)k], e.n, nq, std::max(e.n, 1), 0};
+        h_fwd[(size_t)k] = o_res / 4 + w;
+        runs[n_runs++] = WordRun{(const uint32_t*)(d_res + o_fwd[(size_t)k]), 3 * nq, (int)(o_res / 4 + w)}; w += 3 * (size_t)nq;
+        h_rev[(size_t)k] = o_res / 4 + w;
+        if (cross_check && e.n) { runs[n_runs++] = WordRun{(const uint32_t*)(d_res + o_rev[(size_t)k]), e.n, (int)(o_res / 4 + w)}; w += (size_t)e.n; }
+    }
+    // a set without descriptors leaves its forward arrays unwritten by the kernel (no train descriptor: best index -1): preset them
+    for (int k = 0; k < n_keys; ++k)
+        if (c->desc_store[keys[k]].n == 0) {
+            if (hipMemsetAsync(d_res + o_fwd[(size_t)k], 0xff, (size_t)nq * 4, s) != hipSuccess) { release(); set_error("hipMemsetAsync failed"); return LPSLAM_HIP_ERR_DEVICE; }
+        }
+    int* flag = (int*)hb;
+    const int seq = lp_next_seq(c->done_seq);
+    __atomic_store_n(flag, 0, __ATOMIC_RELAXED);
+    const int q_blocks = (std::max(nq, nt_max) + BF_QPW - 1) / BF_QPW;
+    hipLaunchKernelGGL(k_bf_knn2_pairs, dim3(q_blocks, n_pairs), dim3(256), 0, s, (const BfPair*)pairs);
+    hipLaunchKernelGGL(k_runs_to_host, dim3(4, n_runs), dim3(256), 0, s, (const WordRun*)runs, (uint32_t*)hb, done_counter, flag, seq);
+    if (hipGetLastError() != hipSuccess) { release(); set_error("launch failed"); return LPSLAM_HIP_ERR_DEVICE; }
+    if (!lp_wait_done(flag, seq, s)) { release(); set_error("lpslam_hip_match_bf_stored: the kernels did not complete"); return LPSLAM_HIP_ERR_DEVICE; }
+    release();
+    const int32_t* hw = (const int32_t*)hb;
+    for (int k = 0; k < n_keys; ++k) {
+        const int nt = c->desc_store[keys[k]].n;
+        if (nt == 0) continue;
+        const int32_t* bi = hw + h_fwd[(size_t)k]; const int32_t* bd = bi + nq; const int32_t* sd = bd + nq;
+        const int32_t* rbi = hw + h_rev[(size_t)k];
+        int n = 0;
+        for (int i = 0; i < nq; ++i) {       // the filter of lpslam_hip_get_bf_matches
+            if (bi[i] < 0) continue;
+            if (bd[i] > max_dist) continue;
+            if (ratio > 0.f && ratio * (float)sd[i] < (float)bd[i]) continue;
+            if (cross_check && rbi[bi[i]] != i) continue;
+            if (n >= capacity_per_key) { set_error("match buffer too small"); return LPSLAM_HIP_ERR_CAPACITY; }
+            const size_t at = (size_t)k * capacity_per_key + n;
+            out_q[at] = i; out_t[at] = bi[i]; out_d[at] = bd[i]; ++n;
+        }
+        counts[k] = n;
+    }
     return LPSLAM_HIP_OK;
 }
 

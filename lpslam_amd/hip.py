@@ -36,7 +36,7 @@ SYMBOLS = [
     "lpslam_hip_match_stereo", "lpslam_hip_match_stereo_strided", "lpslam_hip_get_stereo",
     "lpslam_hip_vocab_create", "lpslam_hip_vocab_destroy", "lpslam_hip_vocab_info", "lpslam_hip_bow_transform", "lpslam_hip_bow_transform_host", "lpslam_hip_match_bow_tree",
     "lpslam_hip_match_projection", "lpslam_hip_match_fuse", "lpslam_hip_match_area", "lpslam_hip_match_orientation_filter",
-    "lpslam_hip_ba_create", "lpslam_hip_ba_destroy", "lpslam_hip_ba_set_active", "lpslam_hip_ba_optimize", "lpslam_hip_ba_optimize_begin", "lpslam_hip_ba_optimize_end", "lpslam_hip_ba_graph_replays", "lpslam_hip_ba_wg_factorisations", "lpslam_hip_pose_optimize_passes", "lpslam_hip_match_bf_descriptors", "lpslam_hip_prefetch_frame", "lpslam_hip_get_frame_view", "lpslam_hip_ba_set_state_batch", "lpslam_hip_ba_get_batch", "lpslam_hip_ba_get_solver", "lpslam_hip_ba_set_solver",
+    "lpslam_hip_ba_create", "lpslam_hip_ba_destroy", "lpslam_hip_ba_set_active", "lpslam_hip_ba_optimize", "lpslam_hip_ba_optimize_begin", "lpslam_hip_ba_optimize_end", "lpslam_hip_ba_graph_replays", "lpslam_hip_ba_wg_factorisations", "lpslam_hip_pose_optimize_passes", "lpslam_hip_match_bf_descriptors", "lpslam_hip_prefetch_frame", "lpslam_hip_get_frame_view", "lpslam_hip_desc_store_put", "lpslam_hip_desc_store_drop", "lpslam_hip_match_bf_stored", "lpslam_hip_ba_set_state_batch", "lpslam_hip_ba_get_batch", "lpslam_hip_ba_get_solver", "lpslam_hip_ba_set_solver",
     "lpslam_hip_ba_optimize_batch", "lpslam_hip_ba_reset_batch", "lpslam_hip_ba_optimize_profiled", "lpslam_hip_ba_optimize_partitioned", "lpslam_hip_ba_optimize_partitioned_with",
     "lpslam_hip_ba_local", "lpslam_hip_ba_set_points_fixed", "lpslam_hip_ba_pose_optimize", "lpslam_hip_pose_optimize", "lpslam_hip_ba_reset", "lpslam_hip_ba_set_state", "lpslam_hip_prefetch_begin", "lpslam_hip_prefetch_end", "lpslam_hip_prefetch_join", "lpslam_hip_ba_get", "lpslam_hip_ba_chi2", "lpslam_hip_ba_reduced_buffer",
     "lpslam_hip_ba_step_begin", "lpslam_hip_ba_step_lambda0", "lpslam_hip_ba_step_solve", "lpslam_hip_ba_scalar_buffer", "lpslam_hip_ba_step_end", "lpslam_hip_ba_status",
@@ -363,6 +363,24 @@ class Context:
         _check(self.lib.lpslam_hip_match_bf_descriptors(self.h, query, scratch, _p(desc), len(desc), int(max_dist), float(ratio), int(cross_check),
                                                         _p(oq), _p(ot), _p(od), self.max_kp, C.addressof(n)))
         return oq[:n.value].copy(), ot[:n.value].copy(), od[:n.value].copy()
+
+    def desc_store_put(self, key, desc):
+        desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        f = self.lib.lpslam_hip_desc_store_put; f.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]
+        _check(f(self.h, int(key), _p(desc), len(desc)))
+
+    def desc_store_drop(self, key):
+        f = self.lib.lpslam_hip_desc_store_drop; f.argtypes = [C.c_void_p, C.c_int32]
+        _check(f(self.h, int(key)))
+
+    def match_bf_stored(self, query, keys, max_dist=50, ratio=0.0, cross_check=False):
+        """the slot `query` against every stored descriptor set in `keys`, one call: [(mq, mt, md)] per key"""
+        keys = np.ascontiguousarray(keys, np.int32); n = len(keys); cap = self.max_kp
+        oq = np.zeros((max(n, 1), cap), np.int32); ot = np.zeros_like(oq); od = np.zeros_like(oq); cnt = np.zeros(max(n, 1), np.int32)
+        f = self.lib.lpslam_hip_match_bf_stored
+        f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+        _check(f(self.h, int(query), _p(keys), n, int(max_dist), float(ratio), int(cross_check), _p(oq), _p(ot), _p(od), cap, _p(cnt)))
+        return [(oq[k, :cnt[k]].copy(), ot[k, :cnt[k]].copy(), od[k, :cnt[k]].copy()) for k in range(n)]
 
     def match_stereo(self, left, right, fxb, baseline):
         _check(self.lib.lpslam_hip_match_stereo(self.h, left, right, float(fxb), float(baseline)))

@@ -552,6 +552,7 @@ int HipVslamTrackerBase::insertKeyframe(FrameData& f)
     if (!m_stereo && c > m_segmentStart) monoTriangulate(c - 1, kf, f);
     kf.kpts = f.kpts; kf.desc = f.desc; kf.x_right = f.x_right; kf.depth = f.depth; kf.landmark = f.landmark;
     if (m_vocab) { computeBow(kf); m_bowDb.add(c, kf.bow); }
+    else if (m_loopClosure) (void)lpslam_hip_desc_store_put(m_ctx, c, kf.desc.data(), (int32_t)kf.kpts.size());      // without a vocabulary the loop-candidate search matches descriptors: they stay on the device
     m_kfs.push_back(std::move(kf));
     if (m_mapCulling) {
         cullLandmarks(c);                                 // [UPSTREAM] mapping_module: remove_redundant_landmarks once the new keyframe is stored
@@ -897,6 +898,7 @@ void HipVslamTrackerBase::cullKeyframes(int cur_kf)
             if (n_obs <= 2) eraseLandmark(id);
         }
         kf.erased = true;
+        (void)lpslam_hip_desc_store_drop(m_ctx, k);
         kf.kpts.clear(); kf.kpts.shrink_to_fit(); kf.desc.clear(); kf.desc.shrink_to_fit(); kf.x_right.clear(); kf.depth.clear(); kf.landmark.clear(); kf.node.clear(); kf.bow.clear();
         m_bowDb.remove(k);
         ++m_stats.culled_keyframes;
@@ -1124,6 +1126,10 @@ bool HipVslamTrackerBase::monoInitialize(FrameData& cur)
     k0.kpts = reff.kpts; k0.desc = reff.desc; k0.landmark = reff.landmark; k0.x_right.assign(reff.kpts.size(), -1.0f); k0.depth.assign(reff.kpts.size(), -1.0f);
     k1.kpts = cur.kpts; k1.desc = cur.desc; k1.landmark = cur.landmark; k1.x_right.assign(cur.kpts.size(), -1.0f); k1.depth.assign(cur.kpts.size(), -1.0f);
     if (m_vocab) { computeBow(k0); m_bowDb.add((int)m_kfs.size(), k0.bow); computeBow(k1); m_bowDb.add((int)m_kfs.size() + 1, k1.bow); }
+    else if (m_loopClosure) {
+        (void)lpslam_hip_desc_store_put(m_ctx, (int)m_kfs.size(), k0.desc.data(), (int32_t)k0.kpts.size());
+        (void)lpslam_hip_desc_store_put(m_ctx, (int)m_kfs.size() + 1, k1.desc.data(), (int32_t)k1.kpts.size());
+    }
     m_kfs.push_back(std::move(k0)); m_kfs.push_back(std::move(k1));
     m_stats.keyframes += 2;
     m_framesSinceKeyframe = 0;
@@ -1395,6 +1401,17 @@ bool HipVslamTrackerBase::detectAndCloseLoop(FrameData& cur, int c)
     std::vector<int32_t> mq((size_t)m_maxKp), mt((size_t)m_maxKp), md((size_t)m_maxKp);
     struct Vote { int kf; std::vector<std::pair<int, int>> pairs; };        // (keypoint of c, keypoint of the candidate), landmarks on both sides
     std::vector<Vote> votes;
+    // without a vocabulary every candidate is matched descriptor against descriptor: all of them in ONE call against the keyframe
+    // descriptors kept on the device (lpslam_hip_match_bf_stored; candidate by candidate this was an upload and a wait each -- 2 ms
+    // per keyframe once a session has 100 keyframes)
+    std::vector<int32_t> bq, bt, bd, bn, bkeys;
+    bool batched = false;
+    if (!use_bow) {
+        for (auto& cd : cands) if (!m_kfs[(size_t)cd.second].kpts.empty()) bkeys.push_back(cd.second);
+        bq.resize(bkeys.size() * (size_t)m_maxKp); bt.resize(bq.size()); bd.resize(bq.size()); bn.assign(bkeys.size(), 0);
+        batched = !bkeys.empty() && lpslam_hip_match_bf_stored(m_ctx, cur.slot, bkeys.data(), (int32_t)bkeys.size(), 50, 0.75f, 1, bq.data(), bt.data(), bd.data(), m_maxKp, bn.data()) == LPSLAM_HIP_OK;
+    }
+    size_t b_at = 0;
     for (auto& cd : cands) {
         const Keyframe& ka = m_kfs[(size_t)cd.second];
         if (ka.kpts.empty()) continue;
@@ -1413,6 +1430,11 @@ bool HipVslamTrackerBase::detectAndCloseLoop(FrameData& cur, int c)
             int32_t kept = 0;
             (void)lpslam_hip_match_orientation_filter(aq.data(), at.data(), idx.data(), (int32_t)idx.size(), &kept);
             for (size_t i = 0; i < idx.size(); ++i) if (idx[i] >= 0) { mq[(size_t)nm] = (int32_t)i; mt[(size_t)nm] = idx[i]; ++nm; }
+        } else if (batched) {
+            const size_t at = b_at++ * (size_t)m_maxKp;
+            nm = bn[b_at - 1];
+            std::copy(bq.begin() + (long)at, bq.begin() + (long)at + nm, mq.begin());
+            std::copy(bt.begin() + (long)at, bt.begin() + (long)at + nm, mt.begin());
         } else {
             if (lpslam_hip_match_bf_descriptors(m_ctx, cur.slot, scratch, ka.desc.data(), (int32_t)ka.kpts.size(), 50, 0.75f, 1, mq.data(), mt.data(), md.data(), m_maxKp, &nm) != LPSLAM_HIP_OK) continue;
         }

@@ -54,6 +54,32 @@ def test_bf_one_call_keyframe_comparison(ctx, oracle, nq, nt):
             assert np.array_equal(one[0], o[0]) and np.array_equal(one[1], o[1])
 
 
+def test_bf_against_stored_descriptor_sets(ctx):
+    """lpslam_hip_match_bf_stored: an image slot against many descriptor sets kept on the device, one launch and one wait -- per set
+    the matches of lpslam_hip_match_bf_descriptors; sets of different sizes, an empty one, a replaced one, a dropped one"""
+    rng = np.random.default_rng(77)
+    q = rng.integers(0, 256, (300, 32), dtype=np.uint8)
+    sets = {}
+    for key, nt in ((5, 280), (9, 0), (2, 411), (40, 17), (41, 300)):
+        base = q[rng.permutation(300)[: min(nt, 300)]] ^ (rng.random((min(nt, 300), 32)) < 0.04).astype(np.uint8)
+        sets[key] = np.concatenate([base, rng.integers(0, 256, (nt - len(base), 32), dtype=np.uint8)])[:nt]
+        ctx.desc_store_put(key, sets[key])
+    sets[41] = rng.integers(0, 256, (120, 32), dtype=np.uint8)
+    ctx.desc_store_put(41, sets[41])                         # replaces the first set under this key
+    ctx.set_descriptors(2, q)
+    keys = [2, 9, 41, 5, 40]
+    for ratio, cross in ((0.0, False), (0.75, True)):
+        got = ctx.match_bf_stored(2, keys, 60, ratio, cross)
+        for key, g in zip(keys, got):
+            want = ctx.match_bf_descriptors(2, 3, sets[key], 60, ratio, cross)
+            assert all(np.array_equal(a, b) for a, b in zip(g, want)), key
+    assert sum(len(g[0]) for g in got) > 100
+    ctx.desc_store_drop(5)
+    with pytest.raises(Exception):
+        ctx.match_bf_stored(2, [5], 60, 0.0, False)
+    assert ctx.match_bf_stored(2, [], 60, 0.0, False) == []
+
+
 @pytest.fixture(scope="module")
 def big_ctx(hiplib):
     """2100 keypoints / 8 levels: 2124 descriptor slots, i.e. train sets of more than two 1024-descriptor LDS tiles."""
