@@ -256,6 +256,36 @@ def _cpu_front_end(O, p, k, frames):
         prev = dl
 
 
+def front_end_valu_issue():
+    """The bound the extraction kernels actually run against (profile-derived, like `traffic`): a CDNA compute unit starts at most one
+    vector instruction per cycle, so SQ_INSTS_VALU / (compute units x clock) is the shortest time a kernel's vector instructions can
+    issue in.  From the newest profiles/<tag>_pmc.json and the kernel statistics of the same tag (tools/valu_roofline.py)."""
+    try:
+        import csv
+        pdir = os.path.join(ROOT, "profiles")
+        tags = sorted(f[:-len("_pmc.json")] for f in os.listdir(pdir) if f.endswith("_pmc.json") and os.path.exists(os.path.join(pdir, f[:-len("_pmc.json")] + "_bench_kernel_stats.csv")))
+        if not tags:
+            return None
+        tag = tags[-1]
+        pmc = json.load(open(os.path.join(pdir, tag + "_pmc.json")))
+        kern = pmc.get("kernels", pmc)
+        dur = {}
+        for r in csv.DictReader(open(os.path.join(pdir, tag + "_bench_kernel_stats.csv"))):
+            dur[r["Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].replace("<true>", "").replace("<false>", "")] = float(r["AverageNs"]) / 1e3
+        clock_ghz = 2.4
+        out = {"source": "profiles/%s_pmc.json + _bench_kernel_stats.csv" % tag, "clock_GHz": clock_ghz,
+               "note": "floor_us = SQ_INSTS_VALU per launch / (compute units x clock): one vector instruction per compute unit and cycle; the direct kernels use 256 compute units, the queued (_q) ones of the timed loop 128"}
+        for name in ("k_fast_cells", "k_describe", "k_fast_cells_q", "k_describe_q"):
+            v = kern.get(name)
+            if v and "SQ_INSTS_VALU" in v and name in dur:
+                cus = 128 if name.endswith("_q") else 256
+                floor_us = v["SQ_INSTS_VALU"]["mean_per_launch"] / (cus * clock_ghz * 1e3)
+                out[name] = {"valu_instructions_per_launch": int(v["SQ_INSTS_VALU"]["mean_per_launch"]), "floor_us": round(floor_us, 1), "measured_us": round(dur[name], 1), "frac": round(floor_us / dur[name], 3)}
+        return out
+    except Exception as e:      # noqa: BLE001 -- profile-derived decoration only
+        return {"error": str(e)}
+
+
 def cpu_baseline():
     """Legs: (1) one thread, -O3 (the reference builds with BUILD_WITH_MARCH_NATIVE=OFF); (2) one thread,
     -march=native; (3) the reference's own threading: left / right extraction on two threads, local BA on a third; (4) all host
@@ -580,7 +610,8 @@ def main():
                                    "achieved": round(wl.extract_bytes() / (fe_extract_free_ms * 1e-3) / 1e9, 1), "unit": "GB/s",
                                    "frac": round(wl.extract_bytes() / (fe_extract_free_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                                    "extract_ms_per_step_under_mapping_reserve": round(fe_extract_ms, 4),
-                                   "note": "the four extraction kernels on all 256 CUs; in the timed loop they run on 256 - 8 x mapping_reserve CUs beside the mapping solves"},
+                                   "note": "the four extraction kernels on all 256 CUs; in the timed loop they run on 256 - 8 x mapping_reserve CUs beside the mapping solves",
+                                   "valu_issue": front_end_valu_issue()},
             "value_upload_inclusive": round(pcie_fps, 2),          # the same K steps with every extracted frame copied over PCIe inside the loop (below)
             "pcie_inclusive_frames_per_s": round(pcie_fps, 2),
             "pcie_inclusive": {"frames_per_s": round(pcie_fps, 2), "ms_per_step": round(1e3 * elapsed_pcie / args.steps, 4), "ratio_to_value": round(pcie_fps / value, 4),
