@@ -1196,7 +1196,7 @@ int lp_launch_remap(lpslam_hip_ctx* c, int image, int eye)
 
 int lp_launch_fast(lpslam_hip_ctx* c, int first, int n_images)
 {
-    FeQueue fq = lp_fe_queue(c, c->cells_per_image * n_images, 4);
+    FeQueue fq = lp_fe_queue(c, c->cells_per_image * n_images, 1);       // one cell (~20 us of work) per fetch: chunks of 4 / 2 / 1 cells measured 1.083 / 1.064 / 1.047 ms per 16-frame step on half of the compute units -- the tail of an uneven last chunk costs more than the fetches
     if (fq.cu_table)                                     // queued: the eight workgroups a compute unit holds
         hipLaunchKernelGGL(k_fast_cells_q, dim3(256 * 8), dim3(256), 0, lp_fe_stream(c), c->d_pyr, c->image_slab, c->lt, c->cfg.ini_fast_threshold,
                            c->cfg.min_fast_threshold, c->d_cell_keys, c->d_cell_count, c->cells_per_image, first, 0, c->d_mask[0], c->d_mask[1], fq);
@@ -1227,7 +1227,7 @@ int lp_launch_describe(lpslam_hip_ctx* c, int first, int n_images)
     for (int i = first; i < first + n_images && (size_t)i < c->h_kp_valid.size(); ++i) c->h_kp_valid[(size_t)i] = 0;      // counts are rewritten
     lp_pf_invalidate(c, first, n_images);
     const int blocks = (c->slots_per_image + DESC_WAVES - 1) / DESC_WAVES;
-    FeQueue fq = lp_fe_queue(c, blocks * n_images, 16);
+    FeQueue fq = lp_fe_queue(c, blocks * n_images, 2);         // (chunks of 32 / 16 / 8 / 4 / 2 / 1 workgroup-items: 1.18 / 1.055 / 1.039 / 1.033 / 1.027 / 1.039 ms per 16-frame step on half of the compute units)
     if (fq.cu_table)                                     // queued: seven workgroups (28 wavefronts) per compute unit
         hipLaunchKernelGGL(k_describe_q, dim3(256 * 7), dim3(64 * DESC_WAVES), 0, lp_fe_stream(c), c->d_pyr, c->image_slab, c->lt, c->d_sel_key,
                            c->d_sel_count, c->slots_per_image, c->d_kpts, c->d_desc, c->d_kp_count, first, fq, blocks);

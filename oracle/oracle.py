@@ -172,7 +172,9 @@ def extract(img, p, want_pyramid=False, mask=None):
     if mask is not None:
         mask = np.ascontiguousarray(mask, np.uint8)
         assert mask.shape == img.shape
-    roots = max(1, int(round(w / h)), int(round(h / w)))          # a level returns up to max(quota + 3, 4 * roots) corners
+    # a level returns up to max(quota + 3, 4 * roots) corners, roots = the aspect ratio of the level's BORDERED area (19 px each side):
+    # a 1531 x 97 image has 23-30 root cells per level, not 16
+    roots = max(1, int(round((w - 32) / max(h - 32, 1))) + 1, int(round((h - 32) / max(w - 32, 1))) + 1)
     cap = p.max_num_keypts + (4 * roots + 8) * p.num_levels + 64
     kp = np.zeros(cap, KP_DTYPE); desc = np.zeros((cap, 32), np.uint8)
     cc = np.zeros(p.num_levels, np.int32)
