@@ -658,13 +658,18 @@ int lpslam_hip_match_bf_stored(lpslam_hip_ctx* c, int query, const int32_t* keys
     const size_t o_pairs = 64, o_runs = o_pairs + 2 * (size_t)n_keys * sizeof(BfPair), o_res = (o_runs + 2 * (size_t)n_keys * sizeof(WordRun) + 63) & ~(size_t)63;
     const size_t host_bytes = o_res + host_words * 4;
     if (c->h_match_bytes < host_bytes) {
+        // sized at once for a search over 48 full sets (a tracker's candidate list grows one keyframe at a time: growing the block with
+        // it cost a page-locked reallocation -- 1 ms -- on every frame that crossed the previous size)
+        const size_t roomy = std::max(host_bytes * 2, (size_t)4096 + 96 * (sizeof(BfPair) + sizeof(WordRun)) + (size_t)48 * 4 * S * 4);
         if (c->h_match) { LP_HIP(hipStreamSynchronize(s)); (void)hipHostFree(c->h_match); }
         c->h_match = nullptr; c->h_match_bytes = 0;
-        LP_HIP(hipHostMalloc((void**)&c->h_match, host_bytes * 2, hipHostMallocDefault));
-        c->h_match_bytes = host_bytes * 2;
+        LP_HIP(hipHostMalloc((void**)&c->h_match, roomy, hipHostMallocDefault));
+        c->h_match_bytes = roomy;
     }
     void* blk = nullptr; size_t cap = 0;
-    if ((rc = lp_pool_alloc(c, dev_words * 4, &blk, &cap))) return rc;
+    // (always the size of a 48-set search: the context's block cache then serves every call from the same block -- a request that
+    // grows by one keyframe per call would miss it every time, 1 ms of hipMalloc)
+    if ((rc = lp_pool_alloc(c, std::max(dev_words * 4, (size_t)48 * 6 * S * 4), &blk, &cap))) return rc;
     auto release = [&]() { lp_pool_free(c, blk, cap); };
     unsigned* done_counter = lp_done_counter(c, 2);
     if (!done_counter) { release(); set_error("device memory for the completion counters"); return LPSLAM_HIP_ERR_DEVICE; }

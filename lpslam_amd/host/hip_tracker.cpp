@@ -267,6 +267,12 @@ void HipVslamTrackerBase::warmUpContext(bool stereo)
         ok = lpslam_hip_match_projection(m_ctx, 0, q.data(), qd.data(), 16, 100, 0.9f, nullptr, stereo ? 1 : 0, mi.data(), md.data(), &found) == LPSLAM_HIP_OK;
         std::vector<int32_t> mq((size_t)m_maxKp), mt((size_t)m_maxKp), mdist((size_t)m_maxKp);
         if (ok) ok = lpslam_hip_match_bf_descriptors(m_ctx, 0, 1, qd.data(), 16, 50, 0.75f, 1, mq.data(), mt.data(), mdist.data(), m_maxKp, &found) == LPSLAM_HIP_OK;
+        if (ok && !m_vocab && m_loopClosure) {             // the loop-candidate search's call (and its page-locked block, sized for 48 candidates)
+            const int32_t key = -1; int32_t cnt = 0;
+            ok = lpslam_hip_desc_store_put(m_ctx, key, qd.data(), 16) == LPSLAM_HIP_OK &&
+                 lpslam_hip_match_bf_stored(m_ctx, 0, &key, 1, 50, 0.75f, 1, mq.data(), mt.data(), mdist.data(), m_maxKp, &cnt) == LPSLAM_HIP_OK;
+            (void)lpslam_hip_desc_store_drop(m_ctx, key);
+        }
     }
     if (ok) {
         const lpslam_hip_ba_camera cam{m_cam.f_x, m_cam.f_y, m_cam.c_x, m_cam.c_y, stereo ? m_cam.focal_x_baseline : 0.0, std::sqrt(5.991), std::sqrt(7.815)};
