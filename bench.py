@@ -532,14 +532,14 @@ def main():
                     "avg_launch_us": round(1e3 * avg_ms, 3), "traffic": None,
                     "note": "FP64 dense factorisation of the %d x %d reduced system (n^3/3 + 2 n^2 FLOP per factorisation, SURVEY 8(d)) over the "
                             "launches of one factorisation; latency bound (serial panel chain), see DESIGN.md section 5" % (ba_dim + 1, ba_dim + 1)}
-        elif dom in ("k_ba_schur", "k_ba_point_sum", "k_ba_backsub", "k_ba_trial", "k_ba_lin", "k_chol_xsolve"):
+        elif dom in ("k_ba_schur", "k_ba_point_sum", "k_ba_backsub", "k_ba_trial", "k_ba_update", "k_ba_lin", "k_chol_xsolve"):
             d = ba_prof[dom]
             avg_ms = d["ms_per_solve"] / max(d["marks_per_solve"], 1)
             n_obs = len(wl.probs[0]["obs_pose"])
             nj = np.bincount(wl.probs[0]["obs_point"], minlength=len(wl.probs[0]["points"])).astype(np.float64)
             terms = float((nj * (nj + 1) / 2).sum())
             bytes_per_launch = {"k_ba_schur": 336.0 * terms, "k_ba_point_sum": 72.0 * n_obs, "k_ba_backsub": 144.0 * n_obs + 8.0 * (ba_dim + 1) ** 2,
-                                "k_ba_trial": (64.0 + 40 + 144 + 72) * n_obs, "k_ba_lin": (40.0 + 144 + 72) * n_obs, "k_chol_xsolve": 8.0 * (ba_dim + 1) ** 2}[dom]
+                                "k_ba_trial": (64.0 + 40 + 144 + 72) * n_obs, "k_ba_update": (144.0 + 40 + 144 + 64) * n_obs, "k_ba_lin": (40.0 + 144 + 72) * n_obs, "k_chol_xsolve": 8.0 * (ba_dim + 1) ** 2}[dom]
             ach = bytes_per_launch / (avg_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": dom, "launches_per_step": round(d["marks_per_solve"] * kf_per_step, 2), "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "algorithmic_bytes_per_launch": int(bytes_per_launch), "avg_launch_us": round(1e3 * avg_ms, 3), "traffic": None}

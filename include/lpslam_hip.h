@@ -75,6 +75,10 @@ void* lpslam_hip_stream(lpslam_hip_ctx* ctx);
  * src/Trackers/OpenVSLAMTrackerBase.cpp:238 (openvslam::system starts both) -- otherwise stands still while front-end workgroups
  * fill every compute unit's LDS.  The context's streams are re-created: call it on an idle context, outside a prefetch section. */
 int lpslam_hip_set_mapping_reserve(lpslam_hip_ctx* ctx, int32_t cus_per_xcd);
+/* Test hook for the reserve (no reference counterpart): for `microseconds` (<= 50 000) one workgroup holds the whole LDS of every
+ * compute unit that is NOT reserved, on a stream of its own; *landed (may be NULL) = how many sit.  Extraction launched meanwhile
+ * finds room on the reserved compute units only -- the placement under which it must still complete (tests/test_frontend_gpu.py). */
+int lpslam_hip_debug_occupy_unreserved(lpslam_hip_ctx* ctx, int32_t microseconds, int32_t* landed);
 int lpslam_hip_sync(lpslam_hip_ctx* ctx);
 /* Geometry derived from the configuration (pyramid sizes, per-level keypoint quota). */
 int lpslam_hip_level_info(lpslam_hip_ctx* ctx, int32_t* widths, int32_t* heights, int32_t* pitches,
@@ -273,6 +277,11 @@ int64_t lpslam_hip_ba_wg_factorisations(lpslam_hip_ctx* ctx);
 #define LPSLAM_HIP_BA_SOLVER_DENSE 1
 #define LPSLAM_HIP_BA_SOLVER_BAND 2
 int lpslam_hip_ba_get_solver(lpslam_hip_ba* ba, int32_t* solver, int32_t* block_half_bandwidth);
+/* Hand-overs between workgroups that timed out on this problem so far: `band` -- the two chains of the twisted band factorisation
+ * (k_chol_band), `update` -- the keyframe blocks of the one-launch update waiting for the trial landmarks (k_ba_update).  Both waits
+ * are bounded so that a grid always drains; a time-out makes the optimize call that meets it fail with LPSLAM_HIP_ERR_DEVICE (its
+ * result is not valid) and is counted here.  Expected: 0, always (asserted by the batch tests).  No reference counterpart. */
+int lpslam_hip_ba_timeouts(lpslam_hip_ba* ba, int32_t* band, int32_t* update);
 int lpslam_hip_ba_set_solver(lpslam_hip_ba* ba, int32_t solver);
 /* Batched solve -- north star: "a batched Levenberg-Marquardt local-BA".  n independent problems (the keyframe windows of
  * several SLAM sessions served by one GPU, [UPSTREAM] mapping_module::run of each session; lpslam reaches it through

@@ -15,7 +15,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp
 
 OBJ_DIR = os.path.join(CSRC, "_obj")
 # what each translation unit includes (beyond itself): a change there recompiles only that unit
-UNIT_DEPS = {"ba.hip": ["sim3.inl", "ba_build.inl", "ba_solve.inl", "ba_band.inl"], "frontend.hip": ["orb_pattern.inc"], "match.hip": [], "api.hip": [], "bow.hip": []}
+UNIT_DEPS = {"ba.hip": ["sim3.inl", "ba_build.inl", "ba_solve.inl", "ba_band.inl", "ba_update.inl"], "frontend.hip": ["orb_pattern.inc"], "match.hip": [], "api.hip": [], "bow.hip": []}
 COMMON_DEPS = ["internal.h", os.path.join("..", "..", "include", "lpslam_hip.h")]
 
 

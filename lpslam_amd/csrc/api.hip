@@ -121,6 +121,49 @@ static int build_level_table(const lpslam_hip_frontend_config& cfg, LevelTable& 
 using namespace lpslam;
 
 // ---- block cache ---------------------------------------------------------------------------------------------------------
+// Every context keeps the device blocks it has released (bundle-adjustment problems, matcher scratch) for the next request of that
+// size: a hipMalloc is 0.1 - 1 ms.  The cache is bounded per context (lp_pool_cap: 1/32 of the device's memory, at most 16 GB;
+// LPSLAM_HIP_POOL_CAP_MB overrides) and gives way under pressure: an allocation that fails flushes the cached blocks of EVERY
+// context of the process on that device and is tried once more, so a server with one context per session does not fail an
+// allocation while gigabytes sit idle in its other sessions' caches.
+namespace {
+std::mutex g_ctx_mutex;
+std::vector<lpslam_hip_ctx*> g_contexts;              // live contexts of the process (registered at creation)
+size_t lp_pool_flush_locked(lpslam_hip_ctx* c)        // c->pool_mutex held
+{
+    size_t freed = 0;
+    for (auto& blk : c->pool) { (void)hipFree(blk.second); freed += blk.first; }
+    c->pool.clear(); c->pool_bytes = 0;
+    return freed;
+}
+}
+void lp_ctx_register(lpslam_hip_ctx* c, bool add)
+{
+    std::lock_guard<std::mutex> lock(g_ctx_mutex);
+    if (add) g_contexts.push_back(c);
+    else g_contexts.erase(std::remove(g_contexts.begin(), g_contexts.end(), c), g_contexts.end());
+}
+size_t lp_pool_flush_device(int device)
+{
+    size_t freed = 0;
+    std::lock_guard<std::mutex> lock(g_ctx_mutex);
+    for (lpslam_hip_ctx* o : g_contexts) {
+        if (o->cfg.device != device) continue;
+        std::lock_guard<std::mutex> l2(o->pool_mutex);
+        freed += lp_pool_flush_locked(o);
+    }
+    return freed;
+}
+static size_t lp_pool_cap(lpslam_hip_ctx* c)
+{
+    if (c->pool_cap) return c->pool_cap;
+    size_t cap = 16ull << 30;
+    if (const char* e = getenv("LPSLAM_HIP_POOL_CAP_MB")) cap = (size_t)std::max(0l, atol(e)) << 20;
+    else { size_t fr = 0, tot = 0; if (hipMemGetInfo(&fr, &tot) == hipSuccess && tot) cap = std::min(cap, tot / 32); else (void)hipGetLastError(); }
+    c->pool_cap = std::max<size_t>(cap, 1);
+    return c->pool_cap;
+}
+
 int lp_pool_alloc(lpslam_hip_ctx* c, size_t bytes, void** out, size_t* capacity)
 {
     const size_t want = ((std::max<size_t>(bytes, 1) + 4095) / 4096) * 4096;
@@ -136,7 +179,12 @@ int lp_pool_alloc(lpslam_hip_ctx* c, size_t bytes, void** out, size_t* capacity)
             return LPSLAM_HIP_OK;
         }
     }
-    LP_HIP(hipMalloc(out, want));
+    hipError_t e = hipMalloc(out, want);
+    if (e == hipErrorOutOfMemory) {          // idle blocks of this and the sibling contexts go back to the device, then once more
+        (void)hipGetLastError();
+        if (lp_pool_flush_device(c->cfg.device) > 0) e = hipMalloc(out, want);
+    }
+    LP_HIP(e);
     *capacity = want;
     return LPSLAM_HIP_OK;
 }
@@ -228,10 +276,10 @@ void lp_pin_free(lpslam_hip_ctx* c, void* p)
 void lp_pool_free(lpslam_hip_ctx* c, void* p, size_t capacity)
 {
     if (!p) return;
-    constexpr size_t kMaxCached = 16ull << 30;           // of 288 GB (a batch of 16 local windows holds 0.7 GB; 2 GB made a multi-session server free and re-allocate its blocks every round)
     {
         std::lock_guard<std::mutex> lock(c->pool_mutex);
-        if (c->pool_bytes + capacity <= kMaxCached) { c->pool.emplace_back(capacity, p); c->pool_bytes += capacity; return; }
+        // (a batch of 16 local windows holds 0.7 GB; a 2 GB bound made a multi-session server free and re-allocate its blocks every round)
+        if (c->pool_bytes + capacity <= lp_pool_cap(c)) { c->pool.emplace_back(capacity, p); c->pool_bytes += capacity; return; }
     }
     (void)hipFree(p);
 }
@@ -318,6 +366,7 @@ int lpslam_hip_create(const lpslam_hip_frontend_config* cfg, lpslam_hip_ctx** ou
 
     hipError_t e = lp_fe_stream_create(&c->stream, false);
     if (e != hipSuccess) { delete c; return hip_fail(e, "hipStreamCreate"); }
+    lp_ctx_register(c, true);
     rc = ctx_alloc(c);
     if (rc == LPSLAM_HIP_OK && !ofs.empty()) {
         std::vector<int2> pack;
@@ -385,6 +434,7 @@ int lpslam_hip_create(const lpslam_hip_frontend_config* cfg, lpslam_hip_ctx** ou
 void lpslam_hip_destroy(lpslam_hip_ctx* c)
 {
     if (!c) return;
+    lp_ctx_register(c, false);
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->fe_stream) (void)hipStreamSynchronize(c->fe_stream);
@@ -425,6 +475,7 @@ void lpslam_hip_destroy(lpslam_hip_ctx* c)
     c->host_allocs.clear();
     if (c->fe_stream) { (void)hipStreamSynchronize(c->fe_stream); (void)hipStreamDestroy(c->fe_stream); }
     if (c->fe_done) (void)hipEventDestroy(c->fe_done);
+    if (c->debug_stream) { (void)hipStreamSynchronize(c->debug_stream); (void)hipStreamDestroy(c->debug_stream); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -450,6 +501,16 @@ int lpslam_hip_set_mapping_reserve(lpslam_hip_ctx* c, int32_t cus_per_xcd)
     if (rc) return rc;
     c->reserve_cus = cus_per_xcd;
     return LPSLAM_HIP_OK;
+}
+
+int lpslam_hip_debug_occupy_unreserved(lpslam_hip_ctx* c, int32_t microseconds, int32_t* landed)
+{
+    if (!c) { set_error("null context"); return LPSLAM_HIP_ERR_INVALID; }
+    LP_HIP(hipSetDevice(c->cfg.device));
+    int n = 0;
+    const int rc = lp_fe_occupy_unreserved(c, microseconds, landed ? &n : nullptr);
+    if (landed) *landed = n;
+    return rc;
 }
 
 void* lpslam_hip_stream(lpslam_hip_ctx* c) { return c ? (void*)c->stream : nullptr; }
@@ -838,6 +899,19 @@ unsigned* lp_done_counter(lpslam_hip_ctx* c, int which)
     return c->d_done + 32 * (which & 7);
 }
 
+// After lp_wait_done reported failure on stream `s` (the flag did not arrive within 20 ms and was not there after the synchronisation
+// either).  Two cases.  The stream synchronises: its kernels are complete, so the device block they wrote may be handed back -- but
+// arrival counter `which` was left between 0 and total - 1 by whatever went wrong, and every later delivery through it would count
+// to the wrong total and never release its flag: it is zeroed here (true: safe to release).  The stream does NOT synchronise (a
+// device fault): nothing the kernels touch may be reused -- false, the caller leaks its block.
+bool lp_wait_recover(lpslam_hip_ctx* c, int which, hipStream_t s)
+{
+    if (hipStreamSynchronize(s) != hipSuccess) { (void)hipGetLastError(); return false; }
+    unsigned* counter = lp_done_counter(c, which);
+    if (counter && (hipMemsetAsync(counter, 0, sizeof(unsigned), s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)) { (void)hipGetLastError(); return false; }
+    return true;
+}
+
 namespace {
 // One frame's results into page-locked host memory: count, then the first `count` keypoints / descriptors / stereo columns / depths
 // as 32-bit words (the device knows the count; the copy engines would have to move all the slots, in five packets).
@@ -915,7 +989,7 @@ int lpslam_hip_prefetch_frame(lpslam_hip_ctx* c, int image, int32_t with_stereo)
     int seq = 0;
     c->pf_image = -1;
     // one delivery into the block at a time: a copy that was voided instead of collected may still be on its way (another stream)
-    if (c->pf_in_flight && !lp_wait_done((int*)(c->h_stage_pf + 32), c->pf_seq, c->pf_stream)) { set_error("lpslam_hip_prefetch_frame: the previous read-back did not complete"); return LPSLAM_HIP_ERR_DEVICE; }
+    if (c->pf_in_flight && !lp_wait_done((int*)(c->h_stage_pf + 32), c->pf_seq, c->pf_stream)) { c->pf_in_flight = !lp_wait_recover(c, 3, c->pf_stream); set_error("lpslam_hip_prefetch_frame: the previous read-back did not complete"); return LPSLAM_HIP_ERR_DEVICE; }
     c->pf_in_flight = false;
     if ((rc = frame_deliver(c, image, fields, c->h_stage_pf, 3, s, c->pf_seq_next, &seq))) return rc;
     c->pf_seq = seq; c->pf_fields = fields; c->pf_stream = s; c->pf_in_flight = true;
@@ -933,7 +1007,7 @@ static int frame_collect(lpslam_hip_ctx* c, int image, int fields, uint8_t** blo
         // delivered ahead of time by lpslam_hip_prefetch_frame
         st = c->h_stage_pf;
         c->pf_image = -1;
-        if (!lp_wait_done((int*)(st + 32), c->pf_seq, c->pf_stream)) { set_error("lpslam_hip_get_frame: the prefetched read-back did not complete"); return LPSLAM_HIP_ERR_DEVICE; }
+        if (!lp_wait_done((int*)(st + 32), c->pf_seq, c->pf_stream)) { c->pf_in_flight = !lp_wait_recover(c, 3, c->pf_stream); set_error("lpslam_hip_get_frame: the prefetched read-back did not complete"); return LPSLAM_HIP_ERR_DEVICE; }
         c->pf_in_flight = false;
     } else {
         if (c->h_stage_bytes < f.need) {
@@ -945,7 +1019,7 @@ static int frame_collect(lpslam_hip_ctx* c, int image, int fields, uint8_t** blo
         st = c->h_stage;
         int seq = 0;
         if ((rc = frame_deliver(c, image, fields, st, 0, c->stream, c->done_seq, &seq))) return rc;
-        if (!lp_wait_done((int*)(st + 32), seq, c->stream)) { set_error("lpslam_hip_get_frame: the read-back kernel did not complete"); return LPSLAM_HIP_ERR_DEVICE; }
+        if (!lp_wait_done((int*)(st + 32), seq, c->stream)) { (void)lp_wait_recover(c, 0, c->stream); set_error("lpslam_hip_get_frame: the read-back kernel did not complete"); return LPSLAM_HIP_ERR_DEVICE; }
     }
     int32_t n = 0;
     memcpy(&n, st, sizeof(n));

@@ -58,6 +58,7 @@ struct BaCtl {                        // device-resident LM state (g2o Optimizat
     int ticket;                       // workgroups of the running pass that have published their partials (last one combines)
     int cur_launch;                   // copy of `cur` that stays put while a trial launch runs (the decision flips `cur` inside it)
     int spec;                         // linearisation set [cur] already holds the linearisation of state cur (speculated beside the trial)
+    int faults_band, faults_update;   // host copy only (k_ba_collect fills them from ba_sync_words): hand-overs that timed out, cumulative
 };
 
 // Pointer members of the view are typed as global-address-space pointers in the device pass: a view is read from device memory
@@ -111,6 +112,17 @@ struct BaView {                       // one problem, resident in device memory 
     int band_hbw, band_groups, band_groups_cap, band_pad_;
     GPTR(const int) band_tab; GPTR(const int) band_ent; GPTR(double) band_part;
 };
+
+// Words beside the eight scalars of v.scal that are NOT part of the control block (lm_begin / lm_decide rewrite that as a whole):
+// [0] hand-overs of the twisted band factorisation that timed out, [1] keyframe blocks of k_ba_update that timed out (both stay 0;
+// lpslam_hip_ba_timeouts), [2] landmark blocks of the running k_ba_update launch that have published their trial landmarks.
+__device__ __forceinline__ int* ba_sync_words(const BaView& v) { return (int*)(double*)(v.scal + 8); }
+
+// Which problems take the one-launch update behind the fused solve (k_ba_update, ba_update.inl), decided per PROBLEM so that a problem
+// is solved by the same kernels -- to the same bytes -- alone or inside a mixed batch; the two-launch form (k_ba_backsub, k_ba_trial)
+// skips those problems when it runs beside it.
+constexpr int UPD_MAXP = 320;               // keyframes whose trial poses fit the landmark blocks' LDS (config 5: 200)
+__host__ __device__ inline bool upd_takes(int n_points, int n_free, int n_poses) { return n_points >= 1 && n_free >= 1 && n_poses <= UPD_MAXP; }
 
 // The view of problem blockIdx.y.  `views` is const __restrict__ and read before any store of the kernel: scalar loads.
 #define BA_VIEW(v) BaView v = views[blockIdx.y]
@@ -803,12 +815,13 @@ __global__ __launch_bounds__(256) void k_ba_lin(const BaView* __restrict__ views
 //      trial is accepted far more often than not, and then the next iteration starts with its linearisation done (the sets are
 //      double buffered like the states, a rejected trial leaves the accepted state's set untouched).  These workgroups read
 //      ctl->cur_launch, not ctl->cur, which the decision may flip while they run.
-__global__ __launch_bounds__(256) void k_ba_trial(const BaView* __restrict__ views, int robust, int fused, int points_fixed, int spec)
+__global__ __launch_bounds__(256) void k_ba_trial(const BaView* __restrict__ views, int robust, int fused, int points_fixed, int spec, int skip_one_pass)
 {
     BA_VIEW(v);
     BA_VIEW_HEAD("s"(v.part_n), "s"(v.pose_blocks), "s"(v.land_blocks), "s"(v.ctl));
     const int part_n = v.part_n, trial_blocks = v.pose_blocks, land_blocks = v.land_blocks;
     if ((int)blockIdx.x >= trial_blocks + (spec ? land_blocks + trial_blocks : 0)) return;
+    if (skip_one_pass && upd_takes(v.n_points, v.n_free, v.n_poses)) return;      // that problem's trial ran in k_ba_update
     const BaFlags fl = ba_flags(v.ctl);
     if (fl.idle()) return;
     const int idx = fl.cur_launch ^ 1;
@@ -925,6 +938,7 @@ __global__ __launch_bounds__(64) void k_ba_schur(const BaView* __restrict__ view
         }
         if (!fused && i == 0 && lane == 62) *v.chi_cur = *v.chi_loc;
         if (fused && i == 0 && lane == 63) { v.S[(size_t)v.dim * n + v.dim] = 1e200; v.scal[5] = 0.0; }
+        if (fused && i == 0 && lane == 61) { v.ctl->cur_launch = fl.cur; ba_sync_words(v)[2] = 0; }      // what k_ba_update of this trial reads (ba_update.inl)
         return;
     }
     // work item = (block pair, part, parts): pair lists longer than 256 terms are cut into up to 4 interleaved parts (64-term
@@ -1556,12 +1570,13 @@ void enqueue_factor_solve(hipStream_t s, const BaView* d_views, int count, int n
 }
 
 // ---- landmark back substitution and update (4 lanes per landmark); the last block applies x_p to the poses -------------------
-__global__ __launch_bounds__(256) void k_ba_backsub(const BaView* __restrict__ views)
+__global__ __launch_bounds__(256) void k_ba_backsub(const BaView* __restrict__ views, int skip_one_pass)
 {
     BA_VIEW(v);
     BA_VIEW_HEAD("s"(v.part_n), "s"(v.ctl));
     const int point_blocks = v.part_n;
     if ((int)blockIdx.x > point_blocks) return;
+    if (skip_one_pass && upd_takes(v.n_points, v.n_free, v.n_poses)) return;      // that problem's update ran in k_ba_update
     const BaFlags fl = ba_flags(v.ctl);
     if (fl.idle()) return;
     const double lambda = fl.lambda;
@@ -2163,6 +2178,7 @@ __global__ __launch_bounds__(PO_T) void k_pose_optimize(double* pose7, const dou
     }
 }
 
+#include "ba_update.inl"
 #include "ba_build.inl"
 
 }  // namespace
@@ -2200,6 +2216,7 @@ struct lpslam_hip_ba {
     int pending_iters = -1;                            // >= 0 between optimize_begin and optimize_end
     int band_hbw_structure = -1;                       // block half-bandwidth of the window when the band path can take it (creation), else -1
     int band_gmax = 0;                                 // landmarks per group at most (LDS of k_schur_group)
+    int faults_band = 0, faults_update = 0;            // timed-out hand-overs seen so far (report_faults)
 };
 
 namespace {
@@ -2213,6 +2230,7 @@ struct BaLaunch {
     bool any_band = false, any_dense = false;           // banded windows (ba_band.inl) / pair lists + dense factorisation
     int band_groups = 0, band_blocks = 0, band_gmax = 0; // extents of k_schur_group / k_schur_band_reduce, landmarks per group
     bool spread = false;                                // the context reserves CUs of every XCD for the solves: no XCD pinning
+    bool any_one_pass = false, any_two_launch = false;  // problems that take k_ba_update behind the fused solve / that keep k_ba_backsub + k_ba_trial (upd_takes)
     // profiled run (lpslam_hip_ba_optimize_profiled): an event after every launch, tagged with the kernel it closes
     std::vector<std::pair<hipEvent_t, int>>* marks = nullptr;
     void mark(int kernel) const
@@ -2229,6 +2247,7 @@ struct BaLaunch {
         obs_blocks = std::max(obs_blocks, v.obs_blocks); pose_blocks = std::max(pose_blocks, v.pose_blocks);
         point_blocks = std::max(point_blocks, v.point_blocks); part_n = std::max(part_n, v.part_n); land_blocks = std::max(land_blocks, v.land_blocks);
         n_free = std::max(n_free, v.n_free);
+        if (upd_takes(v.n_points, v.n_free, v.n_poses)) any_one_pass = true; else any_two_launch = true;
         if (v.band_hbw >= 0) {
             any_band = true;
             band_groups = std::max(band_groups, v.band_groups); band_blocks = std::max(band_blocks, v.n_free * (v.band_hbw + 2));
@@ -2273,7 +2292,7 @@ int enqueue_reduce(const BaLaunch& L, int fused)
 {
     if (L.any_dense) hipLaunchKernelGGL(k_ba_schur, dim3(4 * L.n_blocks + L.n_free, L.count), dim3(64), 0, L.s, L.d_views, fused);
     if (L.any_band) {
-        bd_set_attributes();
+        if (bd_set_attributes() != hipSuccess) return LPSLAM_HIP_ERR_DEVICE;
         hipLaunchKernelGGL(k_schur_group, dim3(std::max(L.band_groups, 1), L.count), dim3(BD_THREADS), bd_lds_bytes(L.band_gmax), L.s, L.d_views);
         L.mark(LPSLAM_HIP_BA_K_SCHUR);
         hipLaunchKernelGGL(k_schur_band_reduce, dim3(L.band_blocks, L.count), dim3(256), 0, L.s, L.d_views, fused);
@@ -2288,7 +2307,7 @@ int enqueue_solve(const BaLaunch& L, int fused)
 {
     hipStream_t s = L.s;
     if (L.any_band) {
-        bd_set_attributes();
+        if (bd_set_attributes() != hipSuccess) return LPSLAM_HIP_ERR_DEVICE;
         hipLaunchKernelGGL(k_chol_band, dim3(2, L.count), dim3(BC_THREADS), BC_LDS_BYTES, s, L.d_views);      // workgroup 0: the bottom-up helper of a twisted factorisation
         if (!L.any_dense) L.mark(LPSLAM_HIP_BA_K_CHOL);
     }
@@ -2311,12 +2330,22 @@ int enqueue_solve(const BaLaunch& L, int fused)
     } else if (!fused) {
         hipLaunchKernelGGL(k_lm_begin, dim3(1, L.count), dim3(64), 0, s, L.d_views);
     }
-    hipLaunchKernelGGL(k_ba_backsub, dim3(L.part_n + 1, L.count), dim3(256), 0, s, L.d_views);
+    static const bool two_launch_env = [] { const char* e = getenv("LPSLAM_HIP_BA_TWO_LAUNCH_UPDATE"); return e && atoi(e) != 0; }();      // measurements: the round-4 form
+    const bool one_pass = fused && !two_launch_env;
+    if (one_pass && L.any_one_pass) {
+        // back substitution, trial state, its chi2 and complete linearisation, the lambda control: one launch (ba_update.inl)
+        hipLaunchKernelGGL(k_ba_update, dim3(L.land_blocks + L.pose_blocks, L.count), dim3(256), 0, s, L.d_views, L.robust, L.points_fixed);
+        L.mark(LPSLAM_HIP_BA_K_TRIAL);
+        LP_HIP(hipGetLastError());
+        if (!L.any_two_launch) return LPSLAM_HIP_OK;
+    }
+    // (the problems k_ba_update does not take -- no landmarks, no free keyframe, more keyframes than its LDS holds -- and the partitioned solve)
+    hipLaunchKernelGGL(k_ba_backsub, dim3(L.part_n + 1, L.count), dim3(256), 0, s, L.d_views, one_pass ? 1 : 0);
     L.mark(LPSLAM_HIP_BA_K_BACKSUB);
     {
         // fused solve: the trial launch also linearises the trial state on speculation (observation side + pose side)
         const int spec = fused ? 1 : 0;
-        hipLaunchKernelGGL(k_ba_trial, dim3(L.pose_blocks + (spec ? L.land_blocks + L.pose_blocks : 0), L.count), dim3(256), 0, s, L.d_views, L.robust, fused, L.points_fixed, spec);
+        hipLaunchKernelGGL(k_ba_trial, dim3(L.pose_blocks + (spec ? L.land_blocks + L.pose_blocks : 0), L.count), dim3(256), 0, s, L.d_views, L.robust, fused, L.points_fixed, spec, one_pass ? 1 : 0);
         L.mark(LPSLAM_HIP_BA_K_TRIAL);
     }
     LP_HIP(hipGetLastError());
@@ -2356,7 +2385,9 @@ __global__ __launch_bounds__(64) void k_ba_collect(const BaView* __restrict__ vi
     uint8_t* dst = out + (size_t)blockIdx.y * COLLECT_STRIDE;
     const int* src_c = reinterpret_cast<const int*>((const BaCtl*)v.ctl);
     int* dst_c = reinterpret_cast<int*>(dst);
-    for (int i = threadIdx.x; i < (int)(sizeof(BaCtl) / 4); i += 64) dst_c[i] = src_c[i];
+    const int* sw = ba_sync_words(v);
+    for (int i = threadIdx.x; i < (int)(sizeof(BaCtl) / 4); i += 64)
+        dst_c[i] = i == (int)(offsetof(BaCtl, faults_band) / 4) ? sw[0] : (i == (int)(offsetof(BaCtl, faults_update) / 4) ? sw[1] : src_c[i]);
     const int* src_l = reinterpret_cast<const int*>((const lpslam_hip_ba_iter_log*)v.log);
     int* dst_l = reinterpret_cast<int*>(dst + sizeof(BaCtl));
     const int words = min(n_log, MAX_LOG) * (int)(sizeof(lpslam_hip_ba_iter_log) / 4);
@@ -2421,10 +2452,30 @@ int read_ctl(lpslam_hip_ba* b, int log_entries = 0)
         release_stage(b);
         return LPSLAM_HIP_OK;
     }
+    int sw[2] = {0, 0};
     LP_HIP(hipMemcpyAsync(&b->h_ctl, b->d_ctl, sizeof(BaCtl), hipMemcpyDeviceToHost, b->stream));
+    LP_HIP(hipMemcpyAsync(sw, b->d_scal + 8, sizeof(sw), hipMemcpyDeviceToHost, b->stream));
     LP_HIP(hipStreamSynchronize(b->stream));
+    b->h_ctl.faults_band = sw[0]; b->h_ctl.faults_update = sw[1];
     release_stage(b);
     return LPSLAM_HIP_OK;
+}
+
+// A hand-over between workgroups that timed out -- the two chains of the twisted band factorisation, the keyframe blocks of
+// k_ba_update -- leaves a result that must not be used: the call that sees new time-outs in the collected control block fails with
+// the reason.  The late chain may have left the band factorisation's flags set: they are cleared and the problem solves dense from
+// here on (a stale flag would let the next launch merge blocks that are not there yet).
+int report_faults(lpslam_hip_ba* b)
+{
+    const int nb = b->h_ctl.faults_band - b->faults_band, nu = b->h_ctl.faults_update - b->faults_update;
+    if (nb <= 0 && nu <= 0) return LPSLAM_HIP_OK;
+    b->faults_band = b->h_ctl.faults_band; b->faults_update = b->h_ctl.faults_update;
+    if (nb > 0) {
+        (void)hipMemsetAsync((void*)b->h_view.blk_ticket, 0, 2 * sizeof(int), b->stream);
+        if (b->h_view.band_hbw >= 0) (void)lpslam_hip_ba_set_solver(b, LPSLAM_HIP_BA_SOLVER_DENSE);
+    }
+    set_error("bundle adjustment: %d band-factorisation and %d update hand-over(s) between workgroups timed out; this call's result is not valid", std::max(nb, 0), std::max(nu, 0));
+    return LPSLAM_HIP_ERR_DEVICE;
 }
 
 int begin_optimize(lpslam_hip_ba* b, int robust, int iters)
@@ -2542,6 +2593,7 @@ int lpslam_hip_ba_create(lpslam_hip_ctx* ctx, const double* poses, const uint8_t
         static const int solver_env = [] { const char* e = getenv("LPSLAM_HIP_BA_SOLVER"); return !e ? 0 : (!strcmp(e, "dense") ? 1 : 0); }();
         static const int group_env = [] { const char* e = getenv("LPSLAM_HIP_BA_GROUP"); const int g = e ? atoi(e) : 0; return g >= 4 && g <= BD_GMAX ? g : 32; }();
         if (solver_env != 1) plan.build(obs, n_obs, n_points, slot.data(), b->n_free, b->dim, deg.data(), group_env);
+        if (plan.hbw >= 0 && bd_set_attributes() != hipSuccess) { lpslam_hip_ba_destroy(b); return LPSLAM_HIP_ERR_DEVICE; }      // (the reason is in lpslam_hip_last_error)
         b->band_hbw_structure = plan.hbw;
         b->band_gmax = plan.hbw >= 0 ? group_env : 0;
         static const bool trace = getenv("LPSLAM_HIP_BA_TRACE") != nullptr;
@@ -2566,7 +2618,7 @@ int lpslam_hip_ba_create(lpslam_hip_ctx* ctx, const double* poses, const uint8_t
     const SetOff so = set_offsets(n_poses, n_points, n_obs, b->n_free, b->dim_pad);
     const size_t o_setz0 = cv.take(so.z_total * 8), o_setz1 = cv.take(so.z_total * 8);
     const size_t o_red = cv.take((size_t)b->red_n * 8), o_minv = cv.take(std::max(n * n, 64 * n) * 8) /* L^-T rows, or the band path's M blocks: 1024 doubles per 16 columns */, o_xp = cv.take(n * 8);
-    const size_t o_scal = cv.take(8 * 8), o_ctl = cv.take(sizeof(BaCtl)), o_ticket = cv.take(nblk * 4), o_log = cv.take(MAX_LOG * sizeof(lpslam_hip_ba_iter_log));
+    const size_t o_scal = cv.take(16 * 8) /* 8 scalars + the fault words (ba_update.inl) */, o_ctl = cv.take(sizeof(BaCtl)), o_ticket = cv.take(nblk * 4), o_log = cv.take(MAX_LOG * sizeof(lpslam_hip_ba_iter_log));
     const size_t z_end = cv.off;
     const size_t o_R = cv.take(np * npt * 4), o_pscount = cv.take(np * 4), o_slotof = cv.take(no * 4);
     const size_t o_ps_start = cv.take((np + 1) * 4), o_pt_start = cv.take((npt + 1) * 4), o_pt_obs = cv.take(no * 4), o_orig = cv.take(no * 4);
@@ -2575,7 +2627,7 @@ int lpslam_hip_ba_create(lpslam_hip_ctx* ctx, const double* poses, const uint8_t
     const size_t o_poses_a = cv.take(7 * np * 8), o_poses_b = cv.take(7 * np * 8), o_points_a = cv.take(3 * npt * 8), o_points_b = cv.take(3 * npt * 8);
     const size_t o_setd0 = cv.take(so.d_total * 8), o_setd1 = cv.take(so.d_total * 8), o_ptrial = cv.take(np * SPLIT * 8);
     const size_t cst = csr_stride(n_obs), o_csr = cv.take(5 * cst * 8);          // u, v, ur, w (doubles) + pose, point (ints)
-    const size_t o_ldiag = cv.take(n * NB * 8), o_lsub = cv.take(n * NB * 8), o_chipose = cv.take(np * 8), o_part = cv.take((size_t)part_n * 8);
+    const size_t o_ldiag = cv.take(n * NB * 8), o_lsub = cv.take(n * NB * 8), o_chipose = cv.take(np * 8), o_part = cv.take((size_t)std::max(part_n, 2 * ((n_points + LAND_B - 1) / LAND_B)) * 8) /* k_ba_backsub: part_n; k_ba_update: scale term and chi2 per landmark block */;
     const size_t o_chiobs = cv.take(no * 8), o_depth = cv.take(no);
     const size_t o_blk_count = cv.take(nblk * 4), o_blk_start = cv.take((nblk + 1) * 4), o_blk_part = cv.take(nblk * 4 * 36 * 8);
     const size_t o_terms = cv.take(std::max<size_t>(terms_cap, 1) * sizeof(int4));
@@ -2773,9 +2825,9 @@ int lpslam_hip_ba_optimize_begin(lpslam_hip_ba* b, int32_t robust, int32_t iters
         auto up = [](int x, int m) { return (x + m - 1) / m * m; };
         L.obs_blocks = up(L.obs_blocks, 8); L.pose_blocks = up(L.pose_blocks, 4); L.point_blocks = up(L.point_blocks, 4); L.part_n = up(L.part_n, 8); L.land_blocks = up(L.land_blocks, 8);
         L.band_groups = up(L.band_groups, 8); L.band_blocks = up(L.band_blocks, 8);
-        const std::array<int, 20> sig = {units, robust ? 1 : 0, b->points_fixed ? 1 : 0, L.obs_blocks, L.pose_blocks, L.point_blocks, L.part_n, L.n_free,
+        const std::array<int, 22> sig = {units, robust ? 1 : 0, b->points_fixed ? 1 : 0, L.obs_blocks, L.pose_blocks, L.point_blocks, L.part_n, L.n_free,
                                          L.n_blocks, L.dim, L.nb, L.any_small ? 1 : 0, L.any_large ? 1 : 0, L.land_blocks, L.spread ? 1 : 0,
-                                         L.any_band ? 1 : 0, L.any_dense ? 1 : 0, L.band_groups, L.band_blocks, L.band_gmax};
+                                         L.any_band ? 1 : 0, L.any_dense ? 1 : 0, L.band_groups, L.band_blocks, L.band_gmax, L.any_one_pass ? 1 : 0, L.any_two_launch ? 1 : 0};
         lpslam_hip_ctx* c = b->ctx;
         hipGraphExec_t exec = nullptr;
         void* slot = nullptr;
@@ -2846,6 +2898,7 @@ int lpslam_hip_ba_optimize_end(lpslam_hip_ba* b, lpslam_hip_ba_iter_log* log, in
             if ((rc = read_ctl(b, want_log))) return rc;
         }
     }
+    if ((rc = report_faults(b))) return rc;
     const int done = b->h_ctl.outer_done;
     if (log && done) {
         if (want_log) memcpy(log, b->pin->log, (size_t)std::min(done, MAX_LOG) * sizeof(lpslam_hip_ba_iter_log));     // came with the control block
@@ -3001,6 +3054,7 @@ int lpslam_hip_ba_optimize_batch(lpslam_hip_ba* const* ps, int32_t n, int32_t ro
         if ((rc = enqueue_batch(L, remaining, false))) return rc;
         if ((rc = collect())) return rc;
     }
+    for (int i = 0; i < n; ++i) if ((rc = report_faults(ps[i]))) { for (int k = 0; k < n; ++k) release_stage(ps[k]); return rc; }
     for (int i = 0; i < n; ++i) {
         release_stage(ps[i]);
         const int d = ps[i]->h_ctl.outer_done;
@@ -3017,6 +3071,14 @@ int lpslam_hip_ba_optimize_batch(lpslam_hip_ba* const* ps, int32_t n, int32_t ro
 //                              chi2 and [2] = landmark scale term: SUM all-reduce ([3], the pose term, is identical on all ranks)
 //   lpslam_hip_ba_step_end   : accept / reject; reports the control state
 // Every phase ends with a stream synchronise so the caller's collective may touch the buffers right away.
+int lpslam_hip_ba_timeouts(lpslam_hip_ba* b, int32_t* band, int32_t* update)
+{
+    if (!b) { set_error("null problem"); return LPSLAM_HIP_ERR_INVALID; }
+    if (band) *band = b->faults_band;
+    if (update) *update = b->faults_update;
+    return LPSLAM_HIP_OK;
+}
+
 int lpslam_hip_ba_get_solver(lpslam_hip_ba* b, int32_t* solver, int32_t* block_half_bandwidth)
 {
     if (!b) { set_error("null problem"); return LPSLAM_HIP_ERR_INVALID; }
@@ -3528,6 +3590,7 @@ extern "C" int lpslam_hip_ba_optimize_partitioned_with(lpslam_hip_ba* b, lpslam_
 #undef PT_NCCL
 #undef PT_TRY
     release();
+    if ((rc = report_faults(b))) return rc;
     const int done = b->h_ctl.outer_done;
     if (log && done) {
         if (want_log) memcpy(log, b->pin->log, (size_t)std::min(done, MAX_LOG) * sizeof(lpslam_hip_ba_iter_log));

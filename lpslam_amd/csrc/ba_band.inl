@@ -277,6 +277,7 @@ __global__ __launch_bounds__(256) void k_schur_band_reduce(const BaView* __restr
         v.bp[6 * i + e] = bsum; v.hppdiag[6 * i + e] = dsum;
         if (!fused && i == 0 && e == 0) *v.chi_cur = *v.chi_loc;
         if (fused && i == 0 && e == 1) { v.S[(size_t)v.dim * n + v.dim] = 1e200; v.scal[5] = 0.0; }
+        if (fused && i == 0 && e == 2) { v.ctl->cur_launch = fl.cur; ba_sync_words(v)[2] = 0; }      // what k_ba_update of this trial reads (ba_update.inl)
         return;
     }
     if (i == k) {
@@ -436,7 +437,7 @@ __global__ __launch_bounds__(BC_THREADS) void k_chol_band(const BaView* __restri
             }
             const double sr = tid < 64 ? S[(size_t)dim * n + (dimA - 1 - tid)] : 0.0;
             // (bounded: should the helper never report -- it always does -- the factorisation is flagged as failed instead of the grid hanging)
-            if (tid == 0) { int spins = 0; while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(2); if (spins >= (1 << 22)) { s_fail = 1; scal[5] = 1.0; } }
+            if (tid == 0) { int spins = 0; while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(2); if (spins >= (1 << 22)) { s_fail = 1; scal[5] = 1.0; __hip_atomic_fetch_add(ba_sync_words(vw), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } }
             __syncthreads();
 #pragma unroll
             for (int q = 0; q < 8; ++q) { const int idx = tid + BC_THREADS * q; dv[q] = (idx & 63) <= (idx >> 6) ? ld_sc1(Dg + idx) : 0.0; }
@@ -547,7 +548,7 @@ __global__ __launch_bounds__(BC_THREADS) void k_chol_band(const BaView* __restri
         GPTR(double) MgB = vw.Minv + (size_t)BC_MAXS * 1024;
         double* const xB = rhsv;                             // the helper's unknowns, flipped order (rhsv is free after the forward pass)
         if (sB) {
-            if (tid == 0) { int spins = 0; while (__hip_atomic_load(flag + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(2); if (spins >= (1 << 22)) scal[5] = 1.0; }
+            if (tid == 0) { int spins = 0; while (__hip_atomic_load(flag + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(2); if (spins >= (1 << 22)) { scal[5] = 1.0; __hip_atomic_fetch_add(ba_sync_words(vw), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } }
             __syncthreads();
             if (tid == 0) __hip_atomic_store(flag + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -622,14 +623,20 @@ __global__ __launch_bounds__(BC_THREADS) void k_chol_band(const BaView* __restri
     for (int i = tid; i < dimA; i += BC_THREADS) xp[i] = xv[i];
 }
 
-// dynamic LDS beyond 64 KB: the attribute belongs to the (function, device) pair
-inline void bd_set_attributes()
+// dynamic LDS beyond 64 KB: the attribute belongs to the (function, device) pair.  A refusal is reported HERE, with its reason -- left
+// unchecked it would surface as a failed launch of the band kernels, far from its cause (lpslam_hip_ba_create calls this for every
+// window that takes the band path and fails with the message).
+inline hipError_t bd_set_attributes()
 {
-    static std::atomic<bool> attr_set[64];
+    static std::atomic<int> attr_state[64];             // 0: not tried, 1: set, 2: refused
     int dev = 0;
     (void)hipGetDevice(&dev);
-    if (dev < 0 || dev >= 64 || attr_set[dev].load()) return;
-    (void)hipFuncSetAttribute((const void*)k_schur_group, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bd_lds_bytes(BD_GMAX));
-    (void)hipFuncSetAttribute((const void*)k_chol_band, hipFuncAttributeMaxDynamicSharedMemorySize, BC_LDS_BYTES);
-    attr_set[dev].store(true);
+    if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    const int st = attr_state[dev].load();
+    if (st == 1) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute((const void*)k_schur_group, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bd_lds_bytes(BD_GMAX));
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_chol_band, hipFuncAttributeMaxDynamicSharedMemorySize, BC_LDS_BYTES);
+    attr_state[dev].store(e == hipSuccess ? 1 : 2);
+    if (e != hipSuccess) { (void)hipGetLastError(); set_error("band path: %zu / %d bytes of dynamic LDS for k_schur_group / k_chol_band were refused (%s)", bd_lds_bytes(BD_GMAX), BC_LDS_BYTES, hipGetErrorString(e)); }
+    return e;
 }

@@ -56,13 +56,18 @@ __device__ __forceinline__ uint32_t pyr_down_dword(const uint8_t* __restrict__ s
 // a masked queue in the process slows every solve that runs beside uploads.  Instead the extraction kernels
 // reserve compute units THEMSELVES: launched as a chip-filling grid of persistent workgroups, a workgroup that finds itself on a
 // reserved compute unit (HW_REG_XCC_ID / HW_REG_HW_ID against a table made at calibration, api.hip) leaves at once, the others take
-// chunks of work items from one counter until it runs out.  Placement independent: whatever lands where, every item is done exactly
-// once by some workgroup that stays (at least one does: the grid covers every compute unit, the table reserves at most half of them).
+// chunks of work items from one counter until it runs out.  Every item is done exactly once by some workgroup that stays -- and
+// workgroups DO stay wherever the dispatcher puts the grid: a workgroup on a reserved compute unit takes a leave ticket
+// (counter[1]) and leaves only while fewer than max_leave have left before it.  max_leave is what an evenly spread grid sheds
+// (grid x reserved / all compute units) plus half of that again, at most three quarters of the grid: when other work (a solve of
+// the mapping thread, the prefetch stream, another session) fills the unreserved compute units and the grid drains through the
+// reserved ones instead, the rest of the grid stays there and does the work -- the reserve is a preference, completion is not.
 // ------------------------------------------------------------------------------------------------------------
 struct FeQueue {
     const uint32_t* cu_table;        // [8 XCC][8 words]: bit (hw_id >> 8) & 255 set = reserved compute unit
-    int* counter;                    // next chunk (zeroed in front of the launch)
+    int* counter;                    // [0] next chunk, [1] leave tickets (both zeroed in front of the launch)
     int n_items, chunk;
+    int reserve_cus;                 // per XCD (of 32)
 };
 __device__ __forceinline__ bool fe_on_reserved_cu(const uint32_t* table)
 {
@@ -71,6 +76,17 @@ __device__ __forceinline__ bool fe_on_reserved_cu(const uint32_t* table)
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
     const unsigned id = (hw >> 8) & 0xffu;
     return (table[(xcc & 7u) * 8u + (id >> 5)] >> (id & 31u)) & 1u;
+}
+// does this workgroup leave?  (uniform over the workgroup: its wavefronts share a compute unit; a barrier inside)
+__device__ __forceinline__ bool fe_leaves(const FeQueue& q)
+{
+    if (!fe_on_reserved_cu(q.cu_table)) return false;
+    __shared__ int s_ticket;
+    if (threadIdx.x == 0) s_ticket = atomicAdd(q.counter + 1, 1);
+    __syncthreads();
+    const int grid = (int)(gridDim.x * gridDim.y);
+    const int even = grid * q.reserve_cus / 32;
+    return __builtin_amdgcn_readfirstlane(s_ticket) < min(even + even / 2, grid - grid / 4);
 }
 // first item of the next chunk for the whole workgroup (every thread calls it; barriers inside)
 __device__ __forceinline__ int fe_next_chunk(const FeQueue& q)
@@ -94,13 +110,25 @@ __global__ void k_fe_where(unsigned* out)
     for (int i = 0; i < 200; ++i) __builtin_amdgcn_s_sleep(8);
 }
 
+// Test hook (lpslam_hip_debug_occupy_unreserved): one workgroup per compute unit that claims the whole LDS; those on UNRESERVED
+// compute units hold it for `ticks` of the 100 MHz wall clock (a bounded spin), the others leave.  While it runs, a workgroup that
+// needs LDS -- every extraction kernel's -- only finds room on the reserved compute units: the placement the leave tickets exist for.
+__global__ __launch_bounds__(1024) void k_fe_occupy(const uint32_t* cu_table, unsigned long long ticks, int* landed)
+{
+    extern __shared__ int s_hold[];
+    if (fe_on_reserved_cu(cu_table)) return;
+    if (threadIdx.x == 0) { s_hold[0] = 1; atomicAdd(landed, 1); }
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+
 template <bool kTablesInLds>
 __global__ __launch_bounds__(1024) void k_pyr_bands(uint8_t* __restrict__ pyr, size_t image_slab, LevelTable lt, int image0,
                                                     const int2* __restrict__ rs_pack, int rs_entries,
                                                     const int2* __restrict__ band_rows, FeQueue fq, int n_bands)
 {
     extern __shared__ int2 s_tab[];      // the resize tables of all levels (57 KB at 1280x720, 8 levels)
-    if (fq.cu_table && fe_on_reserved_cu(fq.cu_table)) return;
+    if (fq.cu_table && fe_leaves(fq)) return;
     if (kTablesInLds) {
         for (int i = threadIdx.x; i < rs_entries; i += 1024) s_tab[i] = rs_pack[i];
         __syncthreads();
@@ -372,7 +400,7 @@ __global__ __launch_bounds__(256) void k_fast_cells_q(const uint8_t* __restrict_
                                                       int32_t* __restrict__ cell_count, int cells_per_image, int image0, int dbg,
                                                       const uint8_t* __restrict__ mask0, const uint8_t* __restrict__ mask1, FeQueue fq)
 {
-    if (fe_on_reserved_cu(fq.cu_table)) return;
+    if (fe_leaves(fq)) return;
     for (;;) {
         const int first = fe_next_chunk(fq);
         if (first >= fq.n_items) break;
@@ -818,7 +846,7 @@ __global__ __launch_bounds__(1024) void k_distribute_q(LevelTable lt, const uint
                                                        uint32_t* __restrict__ sel_key, int32_t* __restrict__ sel_count,
                                                        int slots_per_image, int image0, FeQueue fq, int n_images)
 {
-    if (fe_on_reserved_cu(fq.cu_table)) return;
+    if (fe_leaves(fq)) return;
     for (;;) {
         const int it = fe_next_chunk(fq);                // chunk = 1
         if (it >= fq.n_items) break;
@@ -1063,7 +1091,7 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe_q(const uint8_t* _
                                                                 lpslam_hip_keypoint* __restrict__ kpts, uint8_t* __restrict__ desc,
                                                                 int32_t* __restrict__ kp_count, int image0, FeQueue fq, int blocks_per_image)
 {
-    if (fe_on_reserved_cu(fq.cu_table)) return;
+    if (fe_leaves(fq)) return;
     for (;;) {
         const int first = fe_next_chunk(fq);
         if (first >= fq.n_items) break;
@@ -1112,13 +1140,13 @@ __global__ __launch_bounds__(256) void k_remap(const uint8_t* __restrict__ raw, 
 // reserve: {nullptr, ...}, the kernels then run as plain grids
 static FeQueue lp_fe_queue(lpslam_hip_ctx* c, int n_items, int chunk)
 {
-    FeQueue q{nullptr, nullptr, n_items, chunk};
+    FeQueue q{nullptr, nullptr, n_items, chunk, c->reserve_cus};
     if (c->reserve_cus <= 0 || !c->d_cu_table) return q;
     // a ring of 64 counters per stream (main / prefetch): a counter is zeroed and used on ONE stream, in order, so its re-use 64 launches
     // later is ordered behind the launch that used it before
     const bool on_prefetch = lp_fe_stream(c) != c->stream;
     int* ctr = c->d_fe_counters + 32 * ((on_prefetch ? 64 : 0) + (on_prefetch ? c->fe_counter_next_prefetch : c->fe_counter_next).fetch_add(1) % 64);
-    if (hipMemsetAsync(ctr, 0, sizeof(int), lp_fe_stream(c)) != hipSuccess) { (void)hipGetLastError(); return q; }
+    if (hipMemsetAsync(ctr, 0, 2 * sizeof(int), lp_fe_stream(c)) != hipSuccess) { (void)hipGetLastError(); return q; }
     q.cu_table = c->d_cu_table; q.counter = ctr;
     return q;
 }
@@ -1161,6 +1189,30 @@ int lp_fe_calibrate(lpslam_hip_ctx* c, int r)
         }
     }
     LP_HIP(hipMemcpy(c->d_cu_table, table.data(), 64 * sizeof(uint32_t), hipMemcpyHostToDevice));
+    return LPSLAM_HIP_OK;
+}
+
+int lp_fe_occupy_unreserved(lpslam_hip_ctx* c, int microseconds, int* landed)
+{
+    if (c->reserve_cus <= 0 || !c->d_cu_table) { set_error("debug_occupy_unreserved needs a mapping reserve"); return LPSLAM_HIP_ERR_INVALID; }
+    if (microseconds < 0 || microseconds > 50000) { set_error("debug_occupy_unreserved: 0 .. 50000 us"); return LPSLAM_HIP_ERR_INVALID; }
+    if (!c->debug_stream) LP_HIP(hipStreamCreateWithFlags(&c->debug_stream, hipStreamNonBlocking));
+    const int lds = 160 * 1024;
+    LP_HIP(hipFuncSetAttribute((const void*)k_fe_occupy, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    int* d_landed = c->d_fe_counters + 2 * 64 * 32 - 1;            // the ring's last word: no queue uses it (a queue takes [0], [1] of its 32)
+    LP_HIP(hipMemsetAsync(d_landed, 0, sizeof(int), c->debug_stream));
+    hipLaunchKernelGGL(k_fe_occupy, dim3(256), dim3(1024), lds, c->debug_stream, c->d_cu_table, (unsigned long long)microseconds * 100ull, d_landed);
+    LP_HIP(hipGetLastError());
+    if (landed) {                                            // wait until the occupiers sit (they report at once), not until they are done
+        *landed = 0;
+        int h = 0, same = 0, last = -1;
+        for (int spin = 0; spin < 2000 && same < 20; ++spin) {
+            LP_HIP(hipMemcpyAsync(&h, d_landed, sizeof(int), hipMemcpyDeviceToHost, c->copy_stream ? c->copy_stream : c->stream));
+            LP_HIP(hipStreamSynchronize(c->copy_stream ? c->copy_stream : c->stream));
+            same = (h == last && h > 0) ? same + 1 : 0; last = h;
+        }
+        *landed = h;
+    }
     return LPSLAM_HIP_OK;
 }
 

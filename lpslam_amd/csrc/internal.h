@@ -67,6 +67,7 @@ struct lpslam_hip_ctx {
     int done_seq = 0;                  // sequence numbers those kernels release into their done flags
     int* d_fe_counters = nullptr;      // work-queue counters of the queued extraction launches (a ring of 64 per stream, 128 bytes apart)
     std::atomic<unsigned> fe_counter_next{0}, fe_counter_next_prefetch{0};
+    hipStream_t debug_stream = nullptr; // lpslam_hip_debug_occupy_unreserved (test hook)
     int reserve_cus = 0;               // lpslam_hip_set_mapping_reserve: CUs of every XCD the front end's streams leave to the mapping solves
     hipStream_t fe_stream = nullptr;   // prefetch: front end of the NEXT frame beside the tracking of this one (lp_fe_stream)
     hipEvent_t fe_done = nullptr;
@@ -109,7 +110,7 @@ struct lpslam_hip_ctx {
     // mapping thread makes a NEW problem per keyframe: with per-problem graphs each ran on direct launches (2.8 us per dependent
     // kernel against 1.7 us inside a graph, 120+ kernels per solve).
     std::map<hipStream_t, void*> ba_view_slot;
-    std::map<std::pair<hipStream_t, std::array<int, 20>>, hipGraphExec_t> ba_graphs;      // nullptr = signature seen once
+    std::map<std::pair<hipStream_t, std::array<int, 22>>, hipGraphExec_t> ba_graphs;      // nullptr = signature seen once
     std::atomic<long> ba_wg_launches{0};     // k_chol_wg launches so far (lpslam_hip_ba_wg_factorisations: a test sees which factorisation a batch took)
     std::atomic<long> ba_graph_replays{0};   // hipGraphLaunch calls so far (lpslam_hip_ba_graph_replays: lets a test see that it exercised the replay path)
     std::vector<std::pair<size_t, void*>> pin_big;   // idle page-locked staging blocks (capacity, block) of lp_pin_big_alloc / free
@@ -149,6 +150,7 @@ struct lpslam_hip_ctx {
     // optimiser and projection-matcher staging): hipMalloc / hipFree cost ~50-100 us each and a problem needs ~40 buffers
     std::vector<std::pair<size_t, void*>> pool;        // (capacity, block), free blocks only
     size_t pool_bytes = 0;
+    size_t pool_cap = 0;                               // bytes the cache may hold (0: not yet derived from the device's memory, api.hip)
     std::mutex pool_mutex;
     // staging for *_host convenience calls
     uint8_t* d_tmp_desc = nullptr; size_t tmp_desc_bytes = 0;
@@ -170,6 +172,7 @@ void* lp_pin_alloc(lpslam_hip_ctx* c);          // 8 KB of page-locked host memo
 void lp_pin_free(lpslam_hip_ctx* c, void* p);
 int lp_launch_pyramid(lpslam_hip_ctx* c, int first, int n_images);
 int lp_fe_calibrate(lpslam_hip_ctx* c, int reserve_cus_per_xcd);
+int lp_fe_occupy_unreserved(lpslam_hip_ctx* c, int microseconds, int* landed);
 int lp_launch_remap(lpslam_hip_ctx* c, int image, int eye);
 int lp_launch_fast(lpslam_hip_ctx* c, int first, int n_images);
 int lp_launch_distribute(lpslam_hip_ctx* c, int first, int n_images);
@@ -199,6 +202,7 @@ __device__ __forceinline__ void lp_signal_done(unsigned* counter, int* flag, int
 #endif
 inline void lp_pf_invalidate(lpslam_hip_ctx* c, int first, int n) { const int p = c->pf_image.load(std::memory_order_relaxed); if (p >= first && p < first + n) c->pf_image.store(-1, std::memory_order_relaxed); }      // the slot's results are being rewritten
 unsigned* lp_done_counter(lpslam_hip_ctx* c, int which);      // arrival counter number `which` (0 .. 7) of the context, nullptr on failure
+bool lp_wait_recover(lpslam_hip_ctx* c, int which, hipStream_t s);      // after a failed lp_wait_done: counter re-zeroed; false = the stream is dead, leak what its kernels touch
 // the next sequence number of a completion flag: positive, never 0 (0 is what the flag is reset to before a launch)
 inline int lp_next_seq(int& s) { s = s >= 0x7ffffff0 ? 1 : s + 1; return s; }
 // host side: true when the flag arrived; after ~20 ms without it the stream is synchronised and the flag checked once more

@@ -575,7 +575,7 @@ int lpslam_hip_match_bf_descriptors(lpslam_hip_ctx* c, int query, int scratch, c
     WordRuns r{{fq, fq + S, fq + 2 * S, ft}, {nq, nq, nq, cross_check ? n_train : 0}, {(int)o_bi, (int)o_bd, (int)o_sd, (int)o_rbi}};
     hipLaunchKernelGGL(k_words_to_host, dim3(std::max(1, std::min(16, (int)(words / 1024) + 1))), dim3(256), 0, s, r, st, done_counter, flag, seq);
     LP_HIP(hipGetLastError());
-    if (!lp_wait_done(flag, seq, s)) { set_error("lpslam_hip_match_bf_descriptors: the read-back kernel did not complete"); return LPSLAM_HIP_ERR_DEVICE; }
+    if (!lp_wait_done(flag, seq, s)) { (void)lp_wait_recover(c, 2, s); set_error("lpslam_hip_match_bf_descriptors: the read-back kernel did not complete"); return LPSLAM_HIP_ERR_DEVICE; }
     const int32_t* bi = (const int32_t*)(st + o_bi); const int32_t* bd = (const int32_t*)(st + o_bd); const int32_t* sd = (const int32_t*)(st + o_sd);
     const int32_t* rbi = (const int32_t*)(st + o_rbi);
     int n = 0;
@@ -701,7 +701,9 @@ int lpslam_hip_match_bf_stored(lpslam_hip_ctx* c, int query, const int32_t* keys
     hipLaunchKernelGGL(k_bf_knn2_pairs, dim3(q_blocks, n_pairs), dim3(256), 0, s, (const BfPair*)pairs);
     hipLaunchKernelGGL(k_runs_to_host, dim3(4, n_runs), dim3(256), 0, s, (const WordRun*)runs, (uint32_t*)hb, done_counter, flag, seq);
     if (hipGetLastError() != hipSuccess) { release(); set_error("launch failed"); return LPSLAM_HIP_ERR_DEVICE; }
-    if (!lp_wait_done(flag, seq, s)) { release(); set_error("lpslam_hip_match_bf_stored: the kernels did not complete"); return LPSLAM_HIP_ERR_DEVICE; }
+    // (a failed wait: the block goes back to the pool only when the stream still synchronises -- its kernels are then complete --, and the
+    // arrival counter they left part-way is zeroed; on a dead stream the block is leaked rather than handed to the next caller)
+    if (!lp_wait_done(flag, seq, s)) { if (lp_wait_recover(c, 2, s)) release(); set_error("lpslam_hip_match_bf_stored: the kernels did not complete"); return LPSLAM_HIP_ERR_DEVICE; }
     release();
     const int32_t* hw = (const int32_t*)hb;
     for (int k = 0; k < n_keys; ++k) {
@@ -838,7 +840,7 @@ static int window_match(lpslam_hip_ctx* c, int image, const lpslam_hip_proj_quer
     const unsigned long long* keys = (const unsigned long long*)(hb + o_keys);
     const int* cnt = (const int*)(hb + o_cnt);
     tr_launch = tr_us();
-    if (!lp_wait_done(done_flag, done_seq, s)) { release(); set_error("window matcher: the kernel did not complete"); return LPSLAM_HIP_ERR_DEVICE; }
+    if (!lp_wait_done(done_flag, done_seq, s)) { if (lp_wait_recover(c, 1, s)) release(); set_error("window matcher: the kernel did not complete"); return LPSLAM_HIP_ERR_DEVICE; }
     tr_wait = tr_us();
     int found = 0;
     for (int k = 0; k < nq; ++k) {

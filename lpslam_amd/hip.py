@@ -27,7 +27,7 @@ BA_LOG_DTYPE = np.dtype([("chi2_before", "<f8"), ("chi2_after", "<f8"), ("lambda
 # every symbol include/lpslam_hip.h declares (checked by tests/test_abi.py against the header text)
 SYMBOLS = [
     "lpslam_hip_last_error", "lpslam_hip_device_count", "lpslam_hip_create", "lpslam_hip_destroy",
-    "lpslam_hip_stream", "lpslam_hip_set_mapping_reserve", "lpslam_hip_sync", "lpslam_hip_timer_begin", "lpslam_hip_timer_end", "lpslam_hip_timer_read", "lpslam_hip_level_info", "lpslam_hip_max_keypoints_per_image",
+    "lpslam_hip_stream", "lpslam_hip_set_mapping_reserve", "lpslam_hip_debug_occupy_unreserved", "lpslam_hip_sync", "lpslam_hip_timer_begin", "lpslam_hip_timer_end", "lpslam_hip_timer_read", "lpslam_hip_level_info", "lpslam_hip_max_keypoints_per_image",
     "lpslam_hip_image_ptr", "lpslam_hip_upload_image", "lpslam_hip_host_alloc", "lpslam_hip_host_free", "lpslam_hip_host_register", "lpslam_hip_host_unregister", "lpslam_hip_upload_images_async", "lpslam_hip_set_rectify_map", "lpslam_hip_set_mask", "lpslam_hip_upload_raw_image", "lpslam_hip_remap_staged", "lpslam_hip_extract", "lpslam_hip_extract_range", "lpslam_hip_stage_pyramid",
     "lpslam_hip_stage_fast", "lpslam_hip_stage_distribute", "lpslam_hip_stage_describe",
     "lpslam_hip_keypoint_count", "lpslam_hip_get_keypoints", "lpslam_hip_get_frame", "lpslam_hip_get_pyramid_level",
@@ -36,7 +36,7 @@ SYMBOLS = [
     "lpslam_hip_match_stereo", "lpslam_hip_match_stereo_strided", "lpslam_hip_get_stereo",
     "lpslam_hip_vocab_create", "lpslam_hip_vocab_destroy", "lpslam_hip_vocab_info", "lpslam_hip_bow_transform", "lpslam_hip_bow_transform_host", "lpslam_hip_match_bow_tree",
     "lpslam_hip_match_projection", "lpslam_hip_match_fuse", "lpslam_hip_match_area", "lpslam_hip_match_orientation_filter",
-    "lpslam_hip_ba_create", "lpslam_hip_ba_destroy", "lpslam_hip_ba_set_active", "lpslam_hip_ba_optimize", "lpslam_hip_ba_optimize_begin", "lpslam_hip_ba_optimize_end", "lpslam_hip_ba_graph_replays", "lpslam_hip_ba_wg_factorisations", "lpslam_hip_pose_optimize_passes", "lpslam_hip_match_bf_descriptors", "lpslam_hip_prefetch_frame", "lpslam_hip_get_frame_view", "lpslam_hip_desc_store_put", "lpslam_hip_desc_store_drop", "lpslam_hip_match_bf_stored", "lpslam_hip_ba_set_state_batch", "lpslam_hip_ba_get_batch", "lpslam_hip_ba_get_solver", "lpslam_hip_ba_set_solver",
+    "lpslam_hip_ba_create", "lpslam_hip_ba_destroy", "lpslam_hip_ba_set_active", "lpslam_hip_ba_optimize", "lpslam_hip_ba_optimize_begin", "lpslam_hip_ba_optimize_end", "lpslam_hip_ba_graph_replays", "lpslam_hip_ba_wg_factorisations", "lpslam_hip_pose_optimize_passes", "lpslam_hip_match_bf_descriptors", "lpslam_hip_prefetch_frame", "lpslam_hip_get_frame_view", "lpslam_hip_desc_store_put", "lpslam_hip_desc_store_drop", "lpslam_hip_match_bf_stored", "lpslam_hip_ba_set_state_batch", "lpslam_hip_ba_get_batch", "lpslam_hip_ba_get_solver", "lpslam_hip_ba_set_solver", "lpslam_hip_ba_timeouts",
     "lpslam_hip_ba_optimize_batch", "lpslam_hip_ba_reset_batch", "lpslam_hip_ba_optimize_profiled", "lpslam_hip_ba_optimize_partitioned", "lpslam_hip_ba_optimize_partitioned_with",
     "lpslam_hip_ba_local", "lpslam_hip_ba_set_points_fixed", "lpslam_hip_ba_pose_optimize", "lpslam_hip_pose_optimize", "lpslam_hip_ba_reset", "lpslam_hip_ba_set_state", "lpslam_hip_prefetch_begin", "lpslam_hip_prefetch_end", "lpslam_hip_prefetch_join", "lpslam_hip_ba_get", "lpslam_hip_ba_chi2", "lpslam_hip_ba_reduced_buffer",
     "lpslam_hip_ba_step_begin", "lpslam_hip_ba_step_lambda0", "lpslam_hip_ba_step_solve", "lpslam_hip_ba_scalar_buffer", "lpslam_hip_ba_step_end", "lpslam_hip_ba_status",
@@ -143,6 +143,12 @@ class Context:
         f = self.lib.lpslam_hip_set_mapping_reserve
         f.restype = C.c_int; f.argtypes = [C.c_void_p, C.c_int32]
         _check(f(self.h, int(cus_per_xcd)))
+
+    def debug_occupy_unreserved(self, microseconds):
+        """Test hook: every compute unit outside the mapping reserve is held (whole LDS) for `microseconds`; returns how many are."""
+        n = C.c_int32(0)
+        _check(self.lib.lpslam_hip_debug_occupy_unreserved(self.h, C.c_int32(int(microseconds)), C.byref(n)))
+        return n.value
 
     def ba_graph_replays(self):
         f = self.lib.lpslam_hip_ba_graph_replays
@@ -425,6 +431,12 @@ class BundleAdjuster:
         _check(self.lib.lpslam_hip_ba_get_solver(self.h, C.byref(sv), C.byref(hb)))
         return ("band" if sv.value == 2 else "dense"), hb.value
 
+    def timeouts(self):
+        """(band, update): hand-overs between workgroups that timed out on this problem so far -- expected (0, 0)"""
+        a, b = C.c_int32(0), C.c_int32(0)
+        _check(self.lib.lpslam_hip_ba_timeouts(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def set_solver(self, name):
         _check(self.lib.lpslam_hip_ba_set_solver(self.h, {"auto": 0, "dense": 1, "band": 2}[name]))
 
@@ -462,7 +474,8 @@ class BundleAdjuster:
         t = BaKernelTimes()
         _check(self.lib.lpslam_hip_ba_optimize_profiled(self.h, int(robust), int(iters), C.byref(t)))
         band = self.solver()[0] == "band"
-        names = ["k_ba_lin", "k_ba_point_sum", "k_schur_group" if band else "k_ba_schur", "chol", "k_chol_xsolve", "k_ba_backsub", "k_ba_trial", "k_schur_band_reduce"]
+        one_pass = t.launches[5] == 0 and t.launches[6] > 0      # back substitution + trial + linearisation in one launch (ba_update.inl)
+        names = ["k_ba_lin", "k_ba_point_sum", "k_schur_group" if band else "k_ba_schur", "chol", "k_chol_xsolve", "k_ba_backsub", "k_ba_update" if one_pass else "k_ba_trial", "k_schur_band_reduce"]
         return {n: (t.ms[i], t.launches[i], t.launches_per_mark[i]) for i, n in enumerate(names) if t.launches[i] or n == "chol"}, t.iterations, t.dim
 
     def pose_optimize(self):

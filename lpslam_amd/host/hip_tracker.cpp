@@ -558,7 +558,7 @@ int HipVslamTrackerBase::insertKeyframe(FrameData& f)
     if (!m_stereo && c > m_segmentStart) monoTriangulate(c - 1, kf, f);
     kf.kpts = f.kpts; kf.desc = f.desc; kf.x_right = f.x_right; kf.depth = f.depth; kf.landmark = f.landmark;
     if (m_vocab) { computeBow(kf); m_bowDb.add(c, kf.bow); }
-    else if (m_loopClosure) (void)lpslam_hip_desc_store_put(m_ctx, c, kf.desc.data(), (int32_t)kf.kpts.size());      // without a vocabulary the loop-candidate search matches descriptors: they stay on the device
+    else if (m_loopClosure) storeDescriptors(c, kf);      // without a vocabulary the loop-candidate search matches descriptors: they stay on the device
     m_kfs.push_back(std::move(kf));
     if (m_mapCulling) {
         cullLandmarks(c);                                 // [UPSTREAM] mapping_module: remove_redundant_landmarks once the new keyframe is stored
@@ -904,7 +904,7 @@ void HipVslamTrackerBase::cullKeyframes(int cur_kf)
             if (n_obs <= 2) eraseLandmark(id);
         }
         kf.erased = true;
-        (void)lpslam_hip_desc_store_drop(m_ctx, k);
+        (void)lpslam_hip_desc_store_drop(m_ctx, k); kf.desc_on_device = false;
         kf.kpts.clear(); kf.kpts.shrink_to_fit(); kf.desc.clear(); kf.desc.shrink_to_fit(); kf.x_right.clear(); kf.depth.clear(); kf.landmark.clear(); kf.node.clear(); kf.bow.clear();
         m_bowDb.remove(k);
         ++m_stats.culled_keyframes;
@@ -1133,8 +1133,8 @@ bool HipVslamTrackerBase::monoInitialize(FrameData& cur)
     k1.kpts = cur.kpts; k1.desc = cur.desc; k1.landmark = cur.landmark; k1.x_right.assign(cur.kpts.size(), -1.0f); k1.depth.assign(cur.kpts.size(), -1.0f);
     if (m_vocab) { computeBow(k0); m_bowDb.add((int)m_kfs.size(), k0.bow); computeBow(k1); m_bowDb.add((int)m_kfs.size() + 1, k1.bow); }
     else if (m_loopClosure) {
-        (void)lpslam_hip_desc_store_put(m_ctx, (int)m_kfs.size(), k0.desc.data(), (int32_t)k0.kpts.size());
-        (void)lpslam_hip_desc_store_put(m_ctx, (int)m_kfs.size() + 1, k1.desc.data(), (int32_t)k1.kpts.size());
+        storeDescriptors((int)m_kfs.size(), k0);
+        storeDescriptors((int)m_kfs.size() + 1, k1);
     }
     m_kfs.push_back(std::move(k0)); m_kfs.push_back(std::move(k1));
     m_stats.keyframes += 2;
@@ -1413,7 +1413,9 @@ bool HipVslamTrackerBase::detectAndCloseLoop(FrameData& cur, int c)
     std::vector<int32_t> bq, bt, bd, bn, bkeys;
     bool batched = false;
     if (!use_bow) {
-        for (auto& cd : cands) if (!m_kfs[(size_t)cd.second].kpts.empty()) bkeys.push_back(cd.second);
+        // (only keyframes whose descriptors did reach the device: one missing key would make the call refuse the whole batch; the others
+        // are compared one by one below)
+        for (auto& cd : cands) if (!m_kfs[(size_t)cd.second].kpts.empty() && m_kfs[(size_t)cd.second].desc_on_device) bkeys.push_back(cd.second);
         bq.resize(bkeys.size() * (size_t)m_maxKp); bt.resize(bq.size()); bd.resize(bq.size()); bn.assign(bkeys.size(), 0);
         batched = !bkeys.empty() && lpslam_hip_match_bf_stored(m_ctx, cur.slot, bkeys.data(), (int32_t)bkeys.size(), 50, 0.75f, 1, bq.data(), bt.data(), bd.data(), m_maxKp, bn.data()) == LPSLAM_HIP_OK;
     }
@@ -1436,7 +1438,7 @@ bool HipVslamTrackerBase::detectAndCloseLoop(FrameData& cur, int c)
             int32_t kept = 0;
             (void)lpslam_hip_match_orientation_filter(aq.data(), at.data(), idx.data(), (int32_t)idx.size(), &kept);
             for (size_t i = 0; i < idx.size(); ++i) if (idx[i] >= 0) { mq[(size_t)nm] = (int32_t)i; mt[(size_t)nm] = idx[i]; ++nm; }
-        } else if (batched) {
+        } else if (batched && ka.desc_on_device) {
             const size_t at = b_at++ * (size_t)m_maxKp;
             nm = bn[b_at - 1];
             std::copy(bq.begin() + (long)at, bq.begin() + (long)at + nm, mq.begin());
@@ -1644,6 +1646,13 @@ void HipVslamTrackerBase::finishMapping()
         job = std::move(m_mapOut);
     }
     if (job) { ScopedSeconds timed(m_stats.t_kf_apply); applyMapping(*job); }
+}
+
+void HipVslamTrackerBase::storeDescriptors(int key, Keyframe& kf)
+{
+    kf.desc_on_device = lpslam_hip_desc_store_put(m_ctx, key, kf.desc.data(), (int32_t)kf.kpts.size()) == LPSLAM_HIP_OK;
+    if (!kf.desc_on_device)      // (the loop-candidate search then uploads this keyframe's descriptors whenever it is a candidate: slower, same matches)
+        logMessage(LpSlamLogLevel_Error, std::string("keyframe ") + std::to_string(key) + ": descriptors not kept on the device (" + lpslam_hip_last_error() + "); compared one by one from now on");
 }
 
 void HipVslamTrackerBase::logStatistics() const

@@ -58,6 +58,7 @@ protected:
         std::vector<int> landmark;                    // per keypoint: landmark id or -1
         int segment = 0;                              // map segment: a re-initialisation after a loss opens a new one
         bool erased = false;                          // culled as redundant: holds no keypoints and no observations any more (the index stays)
+        bool desc_on_device = false;                  // lpslam_hip_desc_store_put succeeded: the loop-candidate search may name it in a batched comparison
         BowVector bow;                                // with a vocabulary: the keyframe's BoW vector and, per keypoint, the tree node it falls under
         std::vector<int32_t> node;
     };
@@ -137,6 +138,7 @@ protected:
     void startMapping(int c);                         // prepare + solve on the mapping thread (or inline when asyncMapping is off)
     void finishMapping();                             // wait for the mapping thread and apply its result
     void logStatistics() const;
+    void storeDescriptors(int key, Keyframe& kf);     // keeps the keyframe's descriptors on the device for the batched loop-candidate search
 
     // configuration (names as in the reference tracker)
     bool m_useLiveView = false, m_useMapDb = true, m_forwardNavState = true, m_forwardImu = true, m_emitMap = false;

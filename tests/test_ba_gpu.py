@@ -210,6 +210,8 @@ def test_contiguous_config3_full_size_and_batch(hiplib, oracle):
     hiplib.ba_reset_batch(batch)
     logs2 = hiplib.ba_optimize_batch(batch, True, 6)
     assert all(a.tobytes() == b2.tobytes() for a, b2 in zip(logs, logs2))
+    # no hand-over between workgroups (the two chains of the band factorisation, the keyframe blocks of the one-launch update) timed out
+    assert ba.timeouts() == (0, 0) and all(b.timeouts() == (0, 0) for b in batch)
     c.close()
 
 

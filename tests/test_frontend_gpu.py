@@ -243,10 +243,10 @@ def test_async_uploads_from_page_locked_frames(hiplib, oracle):
 
 
 def test_mapping_reserve_changes_speed_only(hiplib):
-    """lpslam_hip_set_mapping_reserve: the context's front-end streams get a CU mask that leaves compute units of every XCD to the
-    bundle adjustments beside them (and the pyramid / distribution launches adapt their grids).  Keypoints and descriptors are bit
-    for bit the same with and without it; a bundle adjustment created on such a context (its panel chain then runs unpinned) gives
-    the same result; out-of-range values are refused."""
+    """lpslam_hip_set_mapping_reserve: the extraction kernels run as queued grids of persistent workgroups that leave the reserved
+    compute units of every XCD to the bundle adjustments beside them (no stream carries a CU mask).  Keypoints and descriptors are
+    bit for bit the same with and without it; a bundle adjustment created on such a context gives the same result; out-of-range
+    values are refused."""
     from lpslam_amd import hip
     w, h = 640, 480
     ctx = hip.Context(w, h, 1000, 1.2, 8, max_images=4)
@@ -278,10 +278,12 @@ def test_mapping_reserve_changes_speed_only(hiplib):
     ctx.close()
 
 
-def test_mapping_reserve_at_the_benchmarked_shape(hiplib):
+def test_mapping_reserve_at_the_benchmarked_shape(hiplib, oracle):
     """The configuration `bench.py` quotes its value on: 1280x720, 2000 keypoints, 8 levels, 32 images per extraction launch, the
     front end confined to half of the chip (reserve 16; 12 is the other setting DESIGN.md quotes), a full local window (50 keyframes /
-    5000 landmarks / 40 k observations, 10 iterations) solved on the same context.  Bit for bit the results of the unreserved chip."""
+    5000 landmarks / 40 k observations, 10 iterations) solved on the same context.  Bit for bit the results of the unreserved chip --
+    and the QUEUED kernels' output (reserve 16: k_fast_cells_q / k_distribute_q / k_describe_q, the ones the headline times) is
+    compared with the oracle directly on six of the 32 images, stereo columns included."""
     from lpslam_amd import hip
     w, h, n = 1280, 720, 32
     ctx = hip.Context(w, h, 2000, 1.2, 8, max_images=n)
@@ -304,12 +306,59 @@ def test_mapping_reserve_at_the_benchmarked_shape(hiplib):
         return kd, st, [tuple(l) for l in log], poses, points
     base = run()
     assert all(len(k) > 1500 for k, _ in base[0])
+    k = synth.intrinsics(w, h)
+    op = oracle.params(2000, 1.2, 8)
     for r in (16, 12, 0):
         ctx.set_mapping_reserve(r)
         got = run()
+        if r == 16:
+            for i in (0, 1, 6, 7, 30, 31):
+                okp, od, _, _ = oracle.extract(imgs[i], op)
+                _assert_same_keypoints(okp, od, got[0][i][0], got[0][i][1])
+            for i in (0, 6, 30):
+                okl, odl, _, pl = oracle.extract(imgs[i], op, True)
+                okr, odr, _, pr = oracle.extract(imgs[i + 1], op, True)
+                oxr, odep, obi, _ = oracle.match_stereo(pl, pr, op, okl, odl, okr, odr, k["fxb"], k["baseline"])
+                gxr, gdep, gbi = got[1][i // 2]
+                assert np.array_equal(obi, gbi) and np.array_equal(oxr, gxr) and np.array_equal(odep, gdep), i
         for (k0, d0), (k1, d1) in zip(base[0], got[0]):
             assert np.array_equal(k0, k1) and np.array_equal(d0, d1), r
         for s0, s1 in zip(base[1], got[1]):
             assert all(np.array_equal(a, b) for a, b in zip(s0, s1)), r
         assert got[2] == base[2] and np.array_equal(got[3], base[3]) and np.array_equal(got[4], base[4]), r
+    ctx.close()
+
+
+@pytest.mark.parametrize("reserve", [8, 16])
+def test_mapping_reserve_completes_wherever_the_grid_lands(hiplib, oracle, reserve):
+    """The queued extraction must finish its work whatever compute units the dispatcher gives it.  The worst placement is forced:
+    a test hook holds the whole LDS of every UNRESERVED compute unit (as a running bundle adjustment, a prefetch stream or another
+    session can), so every extraction workgroup lands on a reserved one.  Workgroups there leave only up to a cap (leave tickets,
+    frontend.hip); the rest stay and drain the queue.  The slot held other images' results before: stale output cannot pass.
+    Checked against the oracle, pyramid and FAST candidates included."""
+    w, h, n = 640, 480, 4
+    ctx = hiplib.Context(w, h, 1000, 1.2, 8, max_images=n)
+    seq = synth.StereoSequence(w, h, 5, n_points=5000)
+    old = [seq.frame(10 + i)[e] for i in range(2) for e in range(2)]
+    new = [seq.frame(i)[e] for i in range(2) for e in range(2)]
+    ctx.set_mapping_reserve(reserve)
+    for i, im in enumerate(old):
+        ctx.upload(i, im)
+    ctx.extract_range(0, n)
+    stale = [ctx.keypoints(i) for i in range(n)]
+    for i, im in enumerate(new):
+        ctx.upload(i, im)
+    landed = ctx.debug_occupy_unreserved(20000)                 # 20 ms: several times one extraction on a quarter of the chip
+    assert landed >= (256 - 8 * reserve) * 9 // 10, landed      # (practically every unreserved unit is held)
+    ctx.extract_range(0, n)
+    p = oracle.params(1000, 1.2, 8)
+    for i in range(n):
+        okp, od, occ, opyr = oracle.extract(new[i], p, True)
+        for l in range(8):
+            assert np.array_equal(ctx.pyramid_level(i, l), opyr[l]), (i, l)
+            assert np.array_equal(oracle.fast_level(opyr[l]), ctx.candidates(i, l)), (i, l)
+        gkp, gd = ctx.keypoints(i)
+        _assert_same_keypoints(okp, od, gkp, gd)
+        assert len(gkp) != len(stale[i][0]) or not np.array_equal(gkp["x"], stale[i][0]["x"])
+    ctx.sync()
     ctx.close()
