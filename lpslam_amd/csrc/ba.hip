@@ -96,7 +96,8 @@ struct BaView {                       // one problem, resident in device memory 
     // One pointer pair per set instead of seven keeps the by-value view small enough to live in scalar registers (at 672 bytes the
     // compiler kept a copy in scratch memory and every member access became a scratch load: trial launch 14 -> 41 us).
     GPTR(double) set_z[2]; GPTR(double) set_d[2]; GPTR(double) partial_trial;     // + trial chi2 partials
-    GPTR(const double) csr;            // observation constants once more in CSR (landmark-major) order [u | v | ur | w | pose, point (int)]: CsrOff
+    GPTR(const double) csr;            // observation constants once more in CSR (landmark-major) order [u | v | ur | w | pose, point (int) | pose slot (int)]
+    GPTR(const int) land_start;        // landmark blocks of the landmark-major passes: (first landmark, first CSR entry) per block + a closing pair; <= LAND_B landmarks and -- unless one landmark alone has more -- <= 256 entries each, cut on the host at creation
     GPTR(double) S; GPTR(double) rhs; GPTR(double) bp; GPTR(double) hppdiag; GPTR(double) chi_cur;   // reduced buffer sections (all-reduced when partitioned)
     GPTR(double) bp_loc; GPTR(double) hppdiag_loc; GPTR(double) chi_loc;                    // this rank's own sums (equal to the above on one GPU)
     GPTR(double) Minv;                                                            // L^-T row blocks (dim_pad x dim_pad)
@@ -115,7 +116,9 @@ struct BaView {                       // one problem, resident in device memory 
 
 // Words beside the eight scalars of v.scal that are NOT part of the control block (lm_begin / lm_decide rewrite that as a whole):
 // [0] hand-overs of the twisted band factorisation that timed out, [1] keyframe blocks of k_ba_update that timed out (both stay 0;
-// lpslam_hip_ba_timeouts), [2] landmark blocks of the running k_ba_update launch that have published their trial landmarks.
+// lpslam_hip_ba_timeouts; [1] also counts k_ba_schur blocks whose wait for the pose side timed out), [2] unused, [3] "pose side
+// pending": the accepted state's H_pp, b_p are the next Schur launch's to compute (set by k_ba_update's decision, ba_update.inl),
+// [4] wavefronts of that launch that have stored theirs.
 __device__ __forceinline__ int* ba_sync_words(const BaView& v) { return (int*)(double*)(v.scal + 8); }
 
 // Which problems take the one-launch update behind the fused solve (k_ba_update, ba_update.inl), decided per PROBLEM so that a problem
@@ -437,7 +440,7 @@ __device__ __forceinline__ void land_lin_body(BaView& v, int bid, int robust, in
     __shared__ double sh[256 * 9];
     __shared__ int s_start[LAND_B + 1];
     const int tid = threadIdx.x;
-    const int j0 = bid * LAND_B, j1 = min(j0 + LAND_B, v.n_points);
+    const int j0 = v.land_start[2 * bid], j1 = v.land_start[2 * bid + 2];
     if (tid <= LAND_B) s_start[tid] = v.pt_start[min(j0 + tid, j1)];
     __syncthreads();
     const int s_lo = s_start[0], s_hi = s_start[j1 - j0];
@@ -872,13 +875,19 @@ __device__ __forceinline__ void obs_y_row(const double* h, double w0, double w1,
 //      Blocks [n_work, n_work + n_free): rhs_i = b_p,i - sum Y b_l over the observations of keyframe i.
 //      fused != 0 (single-GPU solve): lambda goes onto the pose diagonal, rhs straight into row `dim` of S and the failure
 //      flag / rhs pivot are reset here, so no separate preparation launch is needed.
-__global__ __launch_bounds__(64) void k_ba_schur(const BaView* __restrict__ views, int fused)
+__device__ __forceinline__ void ba_pose_side_wave(BaView& v, int p, int sp, int robust, int cur, bool publish);
+__device__ __forceinline__ void ba_pose_side_wait(const BaView& v);
+__global__ __launch_bounds__(64) void k_ba_schur(const BaView* __restrict__ views, int fused, int robust)
 {
-    BA_VIEW_XCD(v, bx);
+    BA_VIEW_XCD(v, bx0);
     const int n_work = 4 * v.n_blocks;                     // work item = (block pair, part): see below
-    if (bx >= n_work + v.n_free || v.band_hbw >= 0) return;      // banded windows: k_schur_group / k_schur_band_reduce (ba_band.inl)
+    const int lead = v.n_poses * SPLIT;                    // leading workgroups: the pose side of an accepted state's linearisation (ba_update.inl)
+    if (bx0 >= lead + n_work + v.n_free || v.band_hbw >= 0) return;      // banded windows: k_schur_group / k_schur_band_reduce (ba_band.inl)
     const BaFlags fl = ba_flags(v.ctl);
     if (fl.idle()) return;
+    const int pending = fused ? ba_sync_words(v)[3] : 0;   // raised by k_ba_update's decision: H_pp, b_p of state `cur` are this launch's to compute
+    if (bx0 < lead) { if (pending) ba_pose_side_wave(v, bx0 / SPLIT, bx0 % SPLIT, robust, fl.cur, true); return; }
+    const int bx = bx0 - lead;
     const double lambda = fl.lambda;
     ba_lin_set(v, fl.cur);
     const int lane = threadIdx.x;
@@ -923,13 +932,14 @@ __global__ __launch_bounds__(64) void k_ba_schur(const BaView* __restrict__ view
         }
 #pragma unroll
         for (int q = 0; q < 6; ++q) r6[q] = wave_sum(r6[q]);
+        if (pending) ba_pose_side_wait(v);                 // the leading workgroups of this launch have stored them (write-through)
         if (lane < 6) {
             double val = 0;
             // b_p and diag H_pp of keyframe i: the SPLIT partial sums of the set's pose-side linearisation, added in order (what
             // pose_combine_body does after an explicit linearisation; a linearisation made beside a trial has no combine of its own)
             const int qd = 6 * lane - lane * (lane - 1) / 2;      // (lane, lane) in the row-major upper triangle
             double bsum = 0, dsum = 0;
-            for (int sp = 0; sp < SPLIT; ++sp) { const double* pr = v.partial + ((size_t)i * SPLIT + sp) * PV; bsum += pr[21 + lane]; dsum += pr[qd]; }
+            for (int sp = 0; sp < SPLIT; ++sp) { const double* pr = v.partial + ((size_t)i * SPLIT + sp) * PV; bsum += pending ? ld_sc1(pr + 21 + lane) : pr[21 + lane]; dsum += pending ? ld_sc1(pr + qd) : pr[qd]; }
 #pragma unroll
             for (int q = 0; q < 6; ++q) if (q == lane) val = bsum - r6[q];
             v.rhs[6 * i + lane] = val;
@@ -938,7 +948,6 @@ __global__ __launch_bounds__(64) void k_ba_schur(const BaView* __restrict__ view
         }
         if (!fused && i == 0 && lane == 62) *v.chi_cur = *v.chi_loc;
         if (fused && i == 0 && lane == 63) { v.S[(size_t)v.dim * n + v.dim] = 1e200; v.scal[5] = 0.0; }
-        if (fused && i == 0 && lane == 61) { v.ctl->cur_launch = fl.cur; ba_sync_words(v)[2] = 0; }      // what k_ba_update of this trial reads (ba_update.inl)
         return;
     }
     // work item = (block pair, part, parts): pair lists longer than 256 terms are cut into up to 4 interleaved parts (64-term
@@ -1011,13 +1020,14 @@ __global__ __launch_bounds__(64) void k_ba_schur(const BaView* __restrict__ view
         sum = 0;
         if (lane < 36) for (int p = 0; p < parts; ++p) sum += __hip_atomic_load(&v.blk_part[(size_t)(4 * blk + p) * 36 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    if (i == k && pending) ba_pose_side_wait(v);
     if (lane >= 36) return;
     const int r = lane / 6, c = lane - r * 6;
     if (i == k) {
         const int ra = min(r, c), rc = max(r, c);
         const int q = 6 * ra - ra * (ra - 1) / 2 + (rc - ra);      // H_pp(r, c) in the row-major upper triangle of the pose partials
         double hpp = 0;
-        for (int sp = 0; sp < SPLIT; ++sp) hpp += v.partial[((size_t)i * SPLIT + sp) * PV + q];
+        for (int sp = 0; sp < SPLIT; ++sp) { const double* pr = v.partial + ((size_t)i * SPLIT + sp) * PV + q; hpp += pending ? ld_sc1(pr) : *pr; }
         double val = hpp - sum;
         if (fused && r == c) val += lambda;
         v.S[(size_t)(6 * i + r) * n + 6 * i + c] = val;
@@ -2224,7 +2234,7 @@ namespace {
 // what a launch chain needs to know: the view array, how many problems it holds and the launch extents (maxima over them)
 struct BaLaunch {
     const BaView* d_views = nullptr; int count = 0; hipStream_t s = nullptr; lpslam_hip_ctx* ctx = nullptr;
-    int obs_blocks = 0, pose_blocks = 0, point_blocks = 0, part_n = 0, n_free = 0, n_blocks = 0, dim = 0, nb = 0, land_blocks = 0;
+    int obs_blocks = 0, pose_blocks = 0, point_blocks = 0, part_n = 0, n_free = 0, n_blocks = 0, dim = 0, nb = 0, land_blocks = 0, n_poses = 0;
     int robust = 1, points_fixed = 0;
     bool any_small = false, any_large = false;          // systems for k_chol_wg / for the panel-pair chain
     bool any_band = false, any_dense = false;           // banded windows (ba_band.inl) / pair lists + dense factorisation
@@ -2246,7 +2256,7 @@ struct BaLaunch {
         const BaView& v = b->h_view;
         obs_blocks = std::max(obs_blocks, v.obs_blocks); pose_blocks = std::max(pose_blocks, v.pose_blocks);
         point_blocks = std::max(point_blocks, v.point_blocks); part_n = std::max(part_n, v.part_n); land_blocks = std::max(land_blocks, v.land_blocks);
-        n_free = std::max(n_free, v.n_free);
+        n_free = std::max(n_free, v.n_free); n_poses = std::max(n_poses, v.n_poses);
         if (upd_takes(v.n_points, v.n_free, v.n_poses)) any_one_pass = true; else any_two_launch = true;
         if (v.band_hbw >= 0) {
             any_band = true;
@@ -2290,10 +2300,10 @@ int enqueue_linearize(const BaLaunch& L, int fused, bool explicit_lin = true)
 // Schur complement for the device's current lambda into the reduced buffer
 int enqueue_reduce(const BaLaunch& L, int fused)
 {
-    if (L.any_dense) hipLaunchKernelGGL(k_ba_schur, dim3(4 * L.n_blocks + L.n_free, L.count), dim3(64), 0, L.s, L.d_views, fused);
+    if (L.any_dense) hipLaunchKernelGGL(k_ba_schur, dim3(L.n_poses * SPLIT + 4 * L.n_blocks + L.n_free, L.count), dim3(64), 0, L.s, L.d_views, fused, L.robust);
     if (L.any_band) {
         if (bd_set_attributes() != hipSuccess) return LPSLAM_HIP_ERR_DEVICE;
-        hipLaunchKernelGGL(k_schur_group, dim3(std::max(L.band_groups, 1), L.count), dim3(BD_THREADS), bd_lds_bytes(L.band_gmax), L.s, L.d_views);
+        hipLaunchKernelGGL(k_schur_group, dim3(L.n_poses + std::max(L.band_groups, 1), L.count), dim3(BD_THREADS), bd_lds_bytes(L.band_gmax), L.s, L.d_views, fused, L.robust);
         L.mark(LPSLAM_HIP_BA_K_SCHUR);
         hipLaunchKernelGGL(k_schur_band_reduce, dim3(L.band_blocks, L.count), dim3(256), 0, L.s, L.d_views, fused);
         L.mark(LPSLAM_HIP_BA_K_BAND_REDUCE);
@@ -2334,7 +2344,7 @@ int enqueue_solve(const BaLaunch& L, int fused)
     const bool one_pass = fused && !two_launch_env;
     if (one_pass && L.any_one_pass) {
         // back substitution, trial state, its chi2 and complete linearisation, the lambda control: one launch (ba_update.inl)
-        hipLaunchKernelGGL(k_ba_update, dim3(L.land_blocks + L.pose_blocks, L.count), dim3(256), 0, s, L.d_views, L.robust, L.points_fixed);
+        hipLaunchKernelGGL(k_ba_update, dim3(L.land_blocks, L.count), dim3(256), 0, s, L.d_views, L.robust, L.points_fixed);
         L.mark(LPSLAM_HIP_BA_K_TRIAL);
         LP_HIP(hipGetLastError());
         if (!L.any_two_launch) return LPSLAM_HIP_OK;
@@ -2362,6 +2372,7 @@ __global__ __launch_bounds__(64) void k_ba_arm(const BaView* __restrict__ views,
     c.max_outer = iters; c.outer_done = 0; c.need_lin = 1; c.first = 1; c.qmax = 0; c.stopped = 0; c.ni = 2; c.rho = 0; c.last_accepted = 0;
     c.ticket = 0; c.spec = 0; c.cur_launch = c.cur;
     *v.ctl = c;
+    ba_sync_words(v)[3] = 0;              // the call starts with an explicit linearisation (pose side included)
 }
 // state given at creation back into buffer 0, every observation active, LM state cleared
 __global__ __launch_bounds__(256) void k_ba_reset(const BaView* __restrict__ views)
@@ -2601,6 +2612,20 @@ int lpslam_hip_ba_create(lpslam_hip_ctx* ctx, const double* poses, const uint8_t
                            n_obs, plan.hbw, plan.groups.size() / BD_REC, plan.hbw >= 0 ? "band" : "dense");
     }
 
+    // ---- landmark blocks of the landmark-major passes (k_ba_update, land_lin_body): consecutive landmarks, at most LAND_B of them and --
+    //      unless a single landmark has more -- at most 256 CSR entries, so that a block's entries are one per thread
+    std::vector<int> land_start;
+    {
+        int cnt = 0, ent = 0, first_entry = 0;
+        land_start.push_back(0); land_start.push_back(0);
+        for (int j = 0; j < n_points; ++j) {
+            if (cnt == LAND_B || (cnt > 0 && ent + deg[j] > 256)) { first_entry += ent; land_start.push_back(j); land_start.push_back(first_entry); cnt = 0; ent = 0; }
+            ++cnt; ent += deg[j];
+        }
+        if (n_points > 0) { land_start.push_back(n_points); land_start.push_back(first_entry + ent); }
+    }
+    const int land_blocks = (int)land_start.size() / 2 - 1;
+
     // ---- one block: [view | inputs as staged | zero-initialised part | the rest]
     const size_t np = (size_t)n_poses, npt = (size_t)std::max(n_points, 1), no = (size_t)std::max(n_obs, 1), n = (size_t)b->dim_pad;
     const size_t nblk = (size_t)std::max(b->n_blocks, 1), nfree = (size_t)std::max(b->n_free, 1);
@@ -2611,6 +2636,7 @@ int lpslam_hip_ba_create(lpslam_hip_ctx* ctx, const double* poses, const uint8_t
     const size_t o_poses0 = cv.take(7 * np * 8), o_points0 = cv.take(3 * npt * 8), o_slot = cv.take(np * 4), o_free = cv.take(nfree * 4);
     const size_t o_obs_in = cv.take(no * sizeof(lpslam_hip_ba_obs));
     const size_t n_ord = plan.order.size(), n_grp = plan.groups.size() / BD_REC;
+    const size_t o_land_start = cv.take(land_start.size() * 4);
     const size_t o_band_tab = cv.take((BD_REC * n_grp + 2 * nfree) * 4), o_band_order = cv.take(n_ord * 4), o_band_qinfo = cv.take(n_ord * 4), o_band_bstart = cv.take((n_ord + 1) * 4);
     const size_t staged_bytes = cv.off;
     const size_t z_begin = cv.off;
@@ -2626,8 +2652,8 @@ int lpslam_hip_ba_create(lpslam_hip_ctx* ctx, const double* poses, const uint8_t
     const size_t o_active = cv.take(no), o_actin = cv.take(no);
     const size_t o_poses_a = cv.take(7 * np * 8), o_poses_b = cv.take(7 * np * 8), o_points_a = cv.take(3 * npt * 8), o_points_b = cv.take(3 * npt * 8);
     const size_t o_setd0 = cv.take(so.d_total * 8), o_setd1 = cv.take(so.d_total * 8), o_ptrial = cv.take(np * SPLIT * 8);
-    const size_t cst = csr_stride(n_obs), o_csr = cv.take(5 * cst * 8);          // u, v, ur, w (doubles) + pose, point (ints)
-    const size_t o_ldiag = cv.take(n * NB * 8), o_lsub = cv.take(n * NB * 8), o_chipose = cv.take(np * 8), o_part = cv.take((size_t)std::max(part_n, 2 * ((n_points + LAND_B - 1) / LAND_B)) * 8) /* k_ba_backsub: part_n; k_ba_update: scale term and chi2 per landmark block */;
+    const size_t cst = csr_stride(n_obs), o_csr = cv.take(6 * cst * 8);          // u, v, ur, w (doubles) + pose, point (ints) + pose slot (int)
+    const size_t o_ldiag = cv.take(n * NB * 8), o_lsub = cv.take(n * NB * 8), o_chipose = cv.take(np * 8), o_part = cv.take((size_t)std::max(part_n, 2 * std::max(land_blocks, 1)) * 8) /* k_ba_backsub: part_n; k_ba_update: scale term and chi2 per landmark block */;
     const size_t o_chiobs = cv.take(no * 8), o_depth = cv.take(no);
     const size_t o_blk_count = cv.take(nblk * 4), o_blk_start = cv.take((nblk + 1) * 4), o_blk_part = cv.take(nblk * 4 * 36 * 8);
     const size_t o_terms = cv.take(std::max<size_t>(terms_cap, 1) * sizeof(int4));
@@ -2644,7 +2670,8 @@ int lpslam_hip_ba_create(lpslam_hip_ctx* ctx, const double* poses, const uint8_t
     v = BaView{};
     v.n_poses = n_poses; v.n_points = n_points; v.n_obs = n_obs; v.n_free = b->n_free; v.dim = b->dim; v.dim_pad = b->dim_pad;
     v.obs_blocks = (n_obs + 255) / 256; v.pose_blocks = (n_poses * SPLIT + 3) / 4; v.point_blocks = (n_points + 255) / 256; v.part_n = part_n;
-    v.n_blocks = b->n_blocks; v.land_blocks = (n_points + LAND_B - 1) / LAND_B;
+    v.n_blocks = b->n_blocks; v.land_blocks = land_blocks;
+    vset(v.land_start, (const int*)(base + o_land_start));
     b->d_poses[0] = (double*)(base + o_poses_a); b->d_poses[1] = (double*)(base + o_poses_b);
     b->d_points[0] = (double*)(base + o_points_a); b->d_points[1] = (double*)(base + o_points_b);
     for (int s2 = 0; s2 < 2; ++s2) { vset(v.poses_buf[s2], b->d_poses[s2]); vset(v.points_buf[s2], b->d_points[s2]); }
@@ -2689,6 +2716,7 @@ int lpslam_hip_ba_create(lpslam_hip_ctx* ctx, const double* poses, const uint8_t
     memcpy(hs + o_slot, slot.data(), np * 4);
     if (b->n_free) memcpy(hs + o_free, free_pose.data(), (size_t)b->n_free * 4);
     if (n_obs) memcpy(hs + o_obs_in, obs, (size_t)n_obs * sizeof(lpslam_hip_ba_obs));
+    memcpy(hs + o_land_start, land_start.data(), land_start.size() * 4);
     if (plan.hbw >= 0) {
         memcpy(hs + o_band_tab, plan.groups.data(), plan.groups.size() * 4);
         memcpy(hs + o_band_tab + BD_REC * n_grp * 4, plan.glo.data(), plan.glo.size() * 4);
@@ -2718,8 +2746,8 @@ int lpslam_hip_ba_create(lpslam_hip_ctx* ctx, const double* poses, const uint8_t
                            (double*)(base + o_w), b->d_o_active, b->d_act_in);
         hipLaunchKernelGGL(k_bs_ptfill, dim3((n_points + 255) / 256), dim3(256), 0, s, A, R, n_poses, n_points, ps_start, pt_start, (int*)(base + o_pt_obs));
         hipLaunchKernelGGL(k_bs_csrcopy, dim3((n_obs + 255) / 256), dim3(256), 0, s, n_obs, (const int*)(base + o_pt_obs), (const int*)(base + o_opose), (const int*)(base + o_opoint),
-                           (const double*)(base + o_u), (const double*)(base + o_v), (const double*)(base + o_ur), (const double*)(base + o_w),
-                           (int*)(base + o_csr + 4 * cst * 8), (int*)(base + o_csr + 4 * cst * 8) + cst, (double*)(base + o_csr), (double*)(base + o_csr) + cst, (double*)(base + o_csr) + 2 * cst, (double*)(base + o_csr) + 3 * cst);
+                           (const double*)(base + o_u), (const double*)(base + o_v), (const double*)(base + o_ur), (const double*)(base + o_w), (const int*)(base + o_slot),
+                           (int*)(base + o_csr + 4 * cst * 8), (int*)(base + o_csr + 4 * cst * 8) + cst, (int*)(base + o_csr + 5 * cst * 8), (double*)(base + o_csr), (double*)(base + o_csr) + cst, (double*)(base + o_csr) + 2 * cst, (double*)(base + o_csr) + 3 * cst);
     }
     if (b->n_blocks) {
         hipLaunchKernelGGL(k_bs_paircount, dim3((b->n_blocks + 3) / 4), dim3(256), 0, s, A, n_points, b->n_free, b->n_blocks, (const int*)(base + o_free), ps_start,
@@ -2825,9 +2853,9 @@ int lpslam_hip_ba_optimize_begin(lpslam_hip_ba* b, int32_t robust, int32_t iters
         auto up = [](int x, int m) { return (x + m - 1) / m * m; };
         L.obs_blocks = up(L.obs_blocks, 8); L.pose_blocks = up(L.pose_blocks, 4); L.point_blocks = up(L.point_blocks, 4); L.part_n = up(L.part_n, 8); L.land_blocks = up(L.land_blocks, 8);
         L.band_groups = up(L.band_groups, 8); L.band_blocks = up(L.band_blocks, 8);
-        const std::array<int, 22> sig = {units, robust ? 1 : 0, b->points_fixed ? 1 : 0, L.obs_blocks, L.pose_blocks, L.point_blocks, L.part_n, L.n_free,
+        const std::array<int, 23> sig = {units, robust ? 1 : 0, b->points_fixed ? 1 : 0, L.obs_blocks, L.pose_blocks, L.point_blocks, L.part_n, L.n_free,
                                          L.n_blocks, L.dim, L.nb, L.any_small ? 1 : 0, L.any_large ? 1 : 0, L.land_blocks, L.spread ? 1 : 0,
-                                         L.any_band ? 1 : 0, L.any_dense ? 1 : 0, L.band_groups, L.band_blocks, L.band_gmax, L.any_one_pass ? 1 : 0, L.any_two_launch ? 1 : 0};
+                                         L.any_band ? 1 : 0, L.any_dense ? 1 : 0, L.band_groups, L.band_blocks, L.band_gmax, L.any_one_pass ? 1 : 0, L.any_two_launch ? 1 : 0, L.n_poses};
         lpslam_hip_ctx* c = b->ctx;
         hipGraphExec_t exec = nullptr;
         void* slot = nullptr;
@@ -3411,6 +3439,9 @@ int lpslam_hip_pose_optimize(lpslam_hip_ctx* ctx, double* pose7, const double* p
     return LPSLAM_HIP_OK;
 }
 
+#ifdef LPSLAM_UPD_STAMPS
+extern "C" __attribute__((visibility("default"))) int lpslam_hip_debug_upd_stamps(double* out32) { return (int)hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_upd_stamps), 32 * sizeof(double)); }
+#endif
 #ifdef LPSLAM_PO_STAMPS
 extern "C" __attribute__((visibility("default"))) int lpslam_hip_debug_po_stamps(double* out16) { return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_po_stamps), 16 * sizeof(double)); }
 #endif

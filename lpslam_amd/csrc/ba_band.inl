@@ -102,13 +102,17 @@ __device__ __forceinline__ void bd_linv(const double* hl, double lambda, double*
 #ifndef LPSLAM_BD_OCC
 #define LPSLAM_BD_OCC 1
 #endif
-__global__ __launch_bounds__(BD_THREADS, LPSLAM_BD_OCC) void k_schur_group(const BaView* __restrict__ views)
+__global__ __launch_bounds__(BD_THREADS, LPSLAM_BD_OCC) void k_schur_group(const BaView* __restrict__ views, int fused, int robust)
 {
-    BA_VIEW_XCD(v, bx);
-    BA_VIEW_HEAD("s"(v.band_hbw), "s"(v.band_groups), "s"(v.ctl), "s"(v.band_tab));
-    if (v.band_hbw < 0 || bx >= v.band_groups) return;
+    static_assert(BD_THREADS == 64 * SPLIT, "a leading workgroup is one keyframe: its SPLIT slices are the workgroup's wavefronts");
+    BA_VIEW_XCD(v, bx0);
+    BA_VIEW_HEAD("s"(v.band_hbw), "s"(v.band_groups), "s"(v.ctl), "s"(v.band_tab), "s"(v.n_poses));
+    const int lead = v.n_poses;                            // leading workgroups: the pose side of an accepted state's linearisation (ba_update.inl),
+    if (v.band_hbw < 0 || bx0 >= lead + v.band_groups) return;      // read by the reduction in the launch behind this one
     const BaFlags fl = ba_flags(v.ctl);
     if (fl.idle()) return;
+    if (bx0 < lead) { if (fused && ba_sync_words(v)[3]) ba_pose_side_wave(v, bx0, (int)(threadIdx.x >> 6), robust, fl.cur, false); return; }
+    const int bx = bx0 - lead;
     const double lambda = fl.lambda;
     ba_lin_set(v, fl.cur);
     extern __shared__ __attribute__((aligned(16))) double bd_lds[];
@@ -277,7 +281,6 @@ __global__ __launch_bounds__(256) void k_schur_band_reduce(const BaView* __restr
         v.bp[6 * i + e] = bsum; v.hppdiag[6 * i + e] = dsum;
         if (!fused && i == 0 && e == 0) *v.chi_cur = *v.chi_loc;
         if (fused && i == 0 && e == 1) { v.S[(size_t)v.dim * n + v.dim] = 1e200; v.scal[5] = 0.0; }
-        if (fused && i == 0 && e == 2) { v.ctl->cur_launch = fl.cur; ba_sync_words(v)[2] = 0; }      // what k_ba_update of this trial reads (ba_update.inl)
         return;
     }
     if (i == k) {

@@ -145,12 +145,13 @@ __global__ __launch_bounds__(256) void k_bs_ptfill(const int* __restrict__ A, co
 // the observation constants once more in CSR (landmark-major) order: the landmark-major linearisation (land_lin_body) reads them coalesced
 __global__ __launch_bounds__(256) void k_bs_csrcopy(int n_obs, const int* __restrict__ pt_obs, const int* __restrict__ o_pose, const int* __restrict__ o_point,
                                                     const double* __restrict__ o_u, const double* __restrict__ o_v, const double* __restrict__ o_ur, const double* __restrict__ o_w,
-                                                    int* c_pose, int* c_point, double* c_u, double* c_v, double* c_ur, double* c_w)
+                                                    const int* __restrict__ pose_slot, int* c_pose, int* c_point, int* c_slot, double* c_u, double* c_v, double* c_ur, double* c_w)
 {
     const int s = blockIdx.x * 256 + threadIdx.x;
     if (s >= n_obs) return;
     const int k = pt_obs[s];
-    c_pose[s] = o_pose[k]; c_point[s] = o_point[k]; c_u[s] = o_u[k]; c_v[s] = o_v[k]; c_ur[s] = o_ur[k]; c_w[s] = o_w[k];
+    const int p = o_pose[k];
+    c_pose[s] = p; c_point[s] = o_point[k]; c_slot[s] = pose_slot[p]; c_u[s] = o_u[k]; c_v[s] = o_v[k]; c_ur[s] = o_ur[k]; c_w[s] = o_w[k];
 }
 
 // pair (a, c), a <= c, of pose-block pair `blk` (row-major upper triangle of n_free x n_free)
