@@ -792,7 +792,7 @@ __device__ __forceinline__ void pose_combine_body(BaView& v, int mode, int part_
         } else {
             const double fail = v.scal[5], scale_p = v.scal[3];
             v.scal[1] = s_val[0]; v.scal[2] = s_val[1];
-            if (fused) lm_decide(v, s_val[0], fail, s_val[1], scale_p, fused == 2);
+            if (fused) { lm_decide(v, s_val[0], fail, s_val[1], scale_p, fused == 2); ba_sync_words(v)[2] = 0; }      // ([2]: groups of the next Schur launch that have stored their share, ba_band.inl)
         }
     }
 }
@@ -2303,10 +2303,18 @@ int enqueue_reduce(const BaLaunch& L, int fused)
     if (L.any_dense) hipLaunchKernelGGL(k_ba_schur, dim3(L.n_poses * SPLIT + 4 * L.n_blocks + L.n_free, L.count), dim3(64), 0, L.s, L.d_views, fused, L.robust);
     if (L.any_band) {
         if (bd_set_attributes() != hipSuccess) return LPSLAM_HIP_ERR_DEVICE;
-        hipLaunchKernelGGL(k_schur_group, dim3(L.n_poses + std::max(L.band_groups, 1), L.count), dim3(BD_THREADS), bd_lds_bytes(L.band_gmax), L.s, L.d_views, fused, L.robust);
+        // The band reduction as trailing workgroups of the group launch (LPSLAM_HIP_BA_REDUCE_IN_SCHUR=1) was measured and is OFF: the
+        // groups' shares (3.1 MB per trial) then cross from workgroup to workgroup inside one launch, which on this part means
+        // write-through stores and L2-bypassing loads -- 38.2 us for the one launch against 14.7 + 9.3 us for the two (MI355X, config 3).
+        static const bool reduce_in_schur_env = [] { const char* e = getenv("LPSLAM_HIP_BA_REDUCE_IN_SCHUR"); return e && atoi(e) != 0; }();
+        const int reduce_here = (fused && reduce_in_schur_env) ? 1 : 0;
+        hipLaunchKernelGGL(k_schur_group, dim3(L.n_poses + std::max(L.band_groups, 1) + (reduce_here ? (L.band_blocks + 1) / 2 : 0), L.count), dim3(BD_THREADS),
+                           std::max(bd_lds_bytes(L.band_gmax), (size_t)4096), L.s, L.d_views, fused, L.robust, reduce_here);
         L.mark(LPSLAM_HIP_BA_K_SCHUR);
-        hipLaunchKernelGGL(k_schur_band_reduce, dim3(L.band_blocks, L.count), dim3(256), 0, L.s, L.d_views, fused);
-        L.mark(LPSLAM_HIP_BA_K_BAND_REDUCE);
+        if (!reduce_here) {
+            hipLaunchKernelGGL(k_schur_band_reduce, dim3(L.band_blocks, L.count), dim3(256), 0, L.s, L.d_views, fused);
+            L.mark(LPSLAM_HIP_BA_K_BAND_REDUCE);
+        }
     } else if (L.any_dense) L.mark(LPSLAM_HIP_BA_K_SCHUR);
     LP_HIP(hipGetLastError());
     return LPSLAM_HIP_OK;
@@ -2373,6 +2381,7 @@ __global__ __launch_bounds__(64) void k_ba_arm(const BaView* __restrict__ views,
     c.ticket = 0; c.spec = 0; c.cur_launch = c.cur;
     *v.ctl = c;
     ba_sync_words(v)[3] = 0;              // the call starts with an explicit linearisation (pose side included)
+    ba_sync_words(v)[2] = 0; ba_sync_words(v)[4] = 0;      // counts of the Schur launch (groups / pose-side wavefronts that have stored)
 }
 // state given at creation back into buffer 0, every observation active, LM state cleared
 __global__ __launch_bounds__(256) void k_ba_reset(const BaView* __restrict__ views)

@@ -99,23 +99,128 @@ __device__ __forceinline__ void bd_linv(const double* hl, double lambda, double*
     li[0] = i00; li[1] = i10; li[2] = i11; li[3] = i20; li[4] = i21; li[5] = i22;
 }
 
+// ---- the groups' shares summed into the band of S (256 threads per 6 x 6 block) + the rhs row.  The groups that can cover a block
+//      are a contiguous range (groups are sorted by their first keyframe).  Thread t takes element t % 36 of the block and every
+//      seventh group of the range (rhs blocks: element t % 6, every 42nd group), its loads independent of each other; the seven
+//      (42) partial sums of an element are added in lane order: a fixed summation tree whatever the placement.
+//      Runs as a launch of its own (k_schur_band_reduce), or -- `same_launch`, LPSLAM_HIP_BA_REDUCE_IN_SCHUR=1, measured and slower, see
+//      enqueue_reduce -- as the trailing workgroups of the k_schur_group launch (two blocks per workgroup; they wait until every group
+//      and every pose-side wavefront has counted itself in, and read what those wrote L2-bypassing).  `bx` >= the number of blocks:
+//      an idle half.
+__device__ __forceinline__ void bd_reduce_block(BaView& v, int bx, int tid, double* part, int fused, double lambda, bool same_launch, bool pose_pending)
+{
+    const int bw = v.band_hbw + 1, nf = v.n_free;
+    const int n_blk = nf * bw;
+    const int n = v.dim_pad;
+    GPTR(const int) recs = v.band_tab;
+    GPTR(const int) glo = v.band_tab + (size_t)BD_REC * v.band_groups_cap;
+    GPTR(const int) ghi = glo + nf;
+    const bool is_rhs = bx >= n_blk;
+    const int i = is_rhs ? bx - n_blk : bx / bw;
+    const int k = is_rhs ? i : i - (bx - i * bw);
+    const bool live = bx < n_blk + nf && k >= 0;
+    const int g0 = live ? glo[i] : 0, g1 = live ? ghi[k] : -1;      // groups that may cover rows of keyframe i and columns of keyframe k (inclusive)
+    const int ne = is_rhs ? 6 : 36, ngl = 252 / ne;
+    const int e = tid % ne, gl = tid / ne;
+    const int r = e / 6, c = e - 6 * r;
+    // what does not depend on the groups' results: the covering groups' records (first keyframe, rows), four groups per round
+    if (same_launch) {
+        // every group of this problem has stored its share, every pose-side wavefront its sums: one lane polls (bounded), the workgroup follows
+        if (tid == 0) {
+            int spins = 0;
+            while (__hip_atomic_load(ba_sync_words(v) + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < v.band_groups && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(2);
+            while (pose_pending && __hip_atomic_load(ba_sync_words(v) + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nf * SPLIT && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(2);
+            if (spins >= (1 << 22)) __hip_atomic_fetch_add(ba_sync_words(v), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_barrier" ::: "memory");             // (both halves of the workgroup: uniform)
+    }
+    double sum = 0;
+    if (live && tid < 252) {
+        for (int gb = g0 + gl; gb <= g1; gb += 4 * ngl) {
+            double val[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int g = min(gb + u * ngl, g1);
+                const int f0 = recs[BD_REC * g + 2], rows = recs[BD_REC * g + 4];
+                const bool cover = gb + u * ngl <= g1 && 6 * (i - f0) + 6 <= rows && k >= f0;
+                const size_t off = is_rhs ? (size_t)(BD_ROWS * BD_ROWS + 6 * (i - f0) + e) : (size_t)((6 * (i - f0) + r) * BD_ROWS + 6 * (k - f0) + c);
+                GPTR(const double) src = v.band_part + (size_t)g * BD_PART + off;
+                val[u] = cover ? (same_launch ? ld_sc1(src) : *src) : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) sum += val[u];
+        }
+    }
+    part[tid] = sum;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (!live || tid >= ne) return;
+    sum = 0;
+    for (int l = 0; l < ngl; ++l) sum += part[l * ne + e];
+    const bool sc = same_launch && pose_pending;            // the pose-side partials were written by workgroups of this launch
+    if (is_rhs) {
+        const int qd = 6 * e - e * (e - 1) / 2;
+        double bsum = 0, dsum = 0;
+        for (int sp = 0; sp < SPLIT; ++sp) { const double* pr = v.partial + ((size_t)i * SPLIT + sp) * PV; bsum += sc ? ld_sc1(pr + 21 + e) : pr[21 + e]; dsum += sc ? ld_sc1(pr + qd) : pr[qd]; }
+        const double val = bsum - sum;
+        v.rhs[6 * i + e] = val;
+        if (fused) v.S[(size_t)v.dim * n + 6 * i + e] = val;
+        v.bp[6 * i + e] = bsum; v.hppdiag[6 * i + e] = dsum;
+        if (!fused && i == 0 && e == 0) *v.chi_cur = *v.chi_loc;
+        if (fused && i == 0 && e == 1) { v.S[(size_t)v.dim * n + v.dim] = 1e200; v.scal[5] = 0.0; }
+        return;
+    }
+    if (i == k) {
+        const int ra = min(r, c), rc = max(r, c);
+        const int q = 6 * ra - ra * (ra - 1) / 2 + (rc - ra);
+        double hpp = 0;
+        for (int sp = 0; sp < SPLIT; ++sp) { const double* pr = v.partial + ((size_t)i * SPLIT + sp) * PV + q; hpp += sc ? ld_sc1(pr) : *pr; }
+        double val = hpp - sum;
+        if (fused && r == c) val += lambda;
+        v.S[(size_t)(6 * i + r) * n + 6 * i + c] = val;
+    } else {
+        v.S[(size_t)(6 * i + r) * n + 6 * k + c] = -sum;
+    }
+}
+__global__ __launch_bounds__(256) void k_schur_band_reduce(const BaView* __restrict__ views, int fused)
+{
+    BA_VIEW_XCD(v, bx);
+    BA_VIEW_HEAD("s"(v.band_hbw), "s"(v.n_free), "s"(v.ctl), "s"(v.band_tab), "s"(v.band_groups_cap));
+    if (v.band_hbw < 0) return;
+    if (bx >= v.n_free * (v.band_hbw + 2)) return;
+    const BaFlags fl = ba_flags(v.ctl);
+    if (fl.idle()) return;
+    ba_lin_set(v, fl.cur);
+    __shared__ double part[256];
+    bd_reduce_block(v, bx, threadIdx.x, part, fused, fl.lambda, false, false);
+}
+
 #ifndef LPSLAM_BD_OCC
 #define LPSLAM_BD_OCC 1
 #endif
-__global__ __launch_bounds__(BD_THREADS, LPSLAM_BD_OCC) void k_schur_group(const BaView* __restrict__ views, int fused, int robust)
+// The launch's workgroups, in dispatch order: [0, n_poses) the pose side of an accepted state's linearisation (ba_update.inl; idle
+// otherwise), [n_poses, + band_groups) the landmark groups, then -- reduce_here -- ceil(n_free (hbw + 2) / 2) reduction workgroups, two
+// band blocks each, which wait for the first two kinds.  Waiting workgroups follow the ones they wait for in dispatch order, and those
+// wait for nobody: the launch drains whatever else occupies the chip.
+__global__ __launch_bounds__(BD_THREADS, LPSLAM_BD_OCC) void k_schur_group(const BaView* __restrict__ views, int fused, int robust, int reduce_here)
 {
     static_assert(BD_THREADS == 64 * SPLIT, "a leading workgroup is one keyframe: its SPLIT slices are the workgroup's wavefronts");
     BA_VIEW_XCD(v, bx0);
-    BA_VIEW_HEAD("s"(v.band_hbw), "s"(v.band_groups), "s"(v.ctl), "s"(v.band_tab), "s"(v.n_poses));
-    const int lead = v.n_poses;                            // leading workgroups: the pose side of an accepted state's linearisation (ba_update.inl),
-    if (v.band_hbw < 0 || bx0 >= lead + v.band_groups) return;      // read by the reduction in the launch behind this one
+    BA_VIEW_HEAD("s"(v.band_hbw), "s"(v.band_groups), "s"(v.ctl), "s"(v.band_tab), "s"(v.n_poses), "s"(v.n_free));
+    const int lead = v.n_poses;
+    const int n_red = reduce_here ? (v.n_free * (v.band_hbw + 2) + 1) / 2 : 0;
+    if (v.band_hbw < 0 || bx0 >= lead + v.band_groups + n_red) return;
     const BaFlags fl = ba_flags(v.ctl);
     if (fl.idle()) return;
-    if (bx0 < lead) { if (fused && ba_sync_words(v)[3]) ba_pose_side_wave(v, bx0, (int)(threadIdx.x >> 6), robust, fl.cur, false); return; }
+    const bool pose_pending = fused && ba_sync_words(v)[3] != 0;
+    if (bx0 < lead) { if (pose_pending) ba_pose_side_wave(v, bx0, (int)(threadIdx.x >> 6), robust, fl.cur, reduce_here != 0); return; }
     const int bx = bx0 - lead;
     const double lambda = fl.lambda;
     ba_lin_set(v, fl.cur);
     extern __shared__ __attribute__((aligned(16))) double bd_lds[];
+    if (bx >= v.band_groups) {
+        bd_reduce_block(v, 2 * (bx - v.band_groups) + (int)(threadIdx.x >> 8), threadIdx.x & 255, bd_lds + 256 * (threadIdx.x >> 8), fused, lambda, true, pose_pending);
+        return;
+    }
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
 #ifdef LPSLAM_BC_STAMPS
 #define BD_STAMP(k) do { if (bx == 0 && tid == 0) v.S[(size_t)(v.dim + 2) * v.dim_pad + 8 * 22 + (k)] = (double)wall_clock64(); } while (0)
@@ -191,7 +296,7 @@ __global__ __launch_bounds__(BD_THREADS, LPSLAM_BD_OCC) void k_schur_group(const
             for (int kk = part; kk < K4; kk += 8) a += zr[kk] * U[kk];
         }
         a += bc_dpp_mov<0xB1>(a); a += bc_dpp_mov<0x4E>(a); a += bc_dpp_mov<0x141>(a);
-        if (part == 0 && row < 16 * row_tiles) P[BD_ROWS * BD_ROWS + row] = a;
+        if (part == 0 && row < 16 * row_tiles) { if (reduce_here) st_sc1(P + BD_ROWS * BD_ROWS + row, a); else P[BD_ROWS * BD_ROWS + row] = a; }
     }
     // ---- Z Z^T (lower tiles) on the matrix cores: tile t -> wavefront t % 8; the operands of the next four steps are fetched while
     //      the matrix cores work on the current four
@@ -215,84 +320,14 @@ __global__ __launch_bounds__(BD_THREADS, LPSLAM_BD_OCC) void k_schur_group(const
             for (int i = 0; i < 4; ++i) { av[i] = an[i]; bv[i] = bn[i]; }
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) P[(16 * tr + lk + 4 * q) * BD_ROWS + 16 * tc + lr] = acc[q];
+        for (int q = 0; q < 4; ++q) { GPTR(double) dst = P + (16 * tr + lk + 4 * q) * BD_ROWS + 16 * tc + lr; if (reduce_here) st_sc1(dst, acc[q]); else *dst = acc[q]; }
     }
     BD_STAMP(4);
-}
-
-// ---- the groups' shares summed into the band of S (one workgroup per 6 x 6 block) + the rhs row.  The groups that can cover a block
-//      are a contiguous range (groups are sorted by their first keyframe).  Thread t takes element t % 36 of the block and every
-//      seventh group of the range (rhs blocks: element t % 6, every 42nd group), its loads independent of each other; the seven
-//      (42) partial sums of an element are added in lane order: a fixed summation tree whatever the placement.
-__global__ __launch_bounds__(256) void k_schur_band_reduce(const BaView* __restrict__ views, int fused)
-{
-    BA_VIEW_XCD(v, bx);
-    BA_VIEW_HEAD("s"(v.band_hbw), "s"(v.n_free), "s"(v.ctl), "s"(v.band_tab), "s"(v.band_groups_cap));
-    if (v.band_hbw < 0) return;
-    const int bw = v.band_hbw + 1, nf = v.n_free;
-    const int n_blk = nf * bw;
-    if (bx >= n_blk + nf) return;
-    const BaFlags fl = ba_flags(v.ctl);
-    if (fl.idle()) return;
-    const double lambda = fl.lambda;
-    ba_lin_set(v, fl.cur);
-    const int tid = threadIdx.x;
-    const int n = v.dim_pad;
-    GPTR(const int) recs = v.band_tab;
-    GPTR(const int) glo = v.band_tab + (size_t)BD_REC * v.band_groups_cap;
-    GPTR(const int) ghi = glo + nf;
-    const bool is_rhs = bx >= n_blk;
-    const int i = is_rhs ? bx - n_blk : bx / bw;
-    const int k = is_rhs ? i : i - (bx - i * bw);
-    if (k < 0) return;
-    const int g0 = glo[i], g1 = ghi[k];               // groups that may cover rows of keyframe i and columns of keyframe k (inclusive)
-    const int ne = is_rhs ? 6 : 36, ngl = 252 / ne;
-    const int e = tid % ne, gl = tid / ne;
-    const int r = e / 6, c = e - 6 * r;
-    __shared__ double part[256];
-    double sum = 0;
-    if (tid < 252) {
-        for (int gb = g0 + gl; gb <= g1; gb += 4 * ngl) {
-            double val[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int g = min(gb + u * ngl, g1);
-                const int f0 = recs[BD_REC * g + 2], rows = recs[BD_REC * g + 4];
-                const bool cover = gb + u * ngl <= g1 && 6 * (i - f0) + 6 <= rows && k >= f0;
-                const size_t off = is_rhs ? (size_t)(BD_ROWS * BD_ROWS + 6 * (i - f0) + e) : (size_t)((6 * (i - f0) + r) * BD_ROWS + 6 * (k - f0) + c);
-                val[u] = cover ? v.band_part[(size_t)g * BD_PART + off] : 0.0;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) sum += val[u];
-        }
-    }
-    part[tid] = sum;
-    __syncthreads();
-    if (tid >= ne) return;
-    sum = 0;
-    for (int l = 0; l < ngl; ++l) sum += part[l * ne + e];
-    if (is_rhs) {
-        const int qd = 6 * e - e * (e - 1) / 2;
-        double bsum = 0, dsum = 0;
-        for (int sp = 0; sp < SPLIT; ++sp) { const double* pr = v.partial + ((size_t)i * SPLIT + sp) * PV; bsum += pr[21 + e]; dsum += pr[qd]; }
-        const double val = bsum - sum;
-        v.rhs[6 * i + e] = val;
-        if (fused) v.S[(size_t)v.dim * n + 6 * i + e] = val;
-        v.bp[6 * i + e] = bsum; v.hppdiag[6 * i + e] = dsum;
-        if (!fused && i == 0 && e == 0) *v.chi_cur = *v.chi_loc;
-        if (fused && i == 0 && e == 1) { v.S[(size_t)v.dim * n + v.dim] = 1e200; v.scal[5] = 0.0; }
-        return;
-    }
-    if (i == k) {
-        const int ra = min(r, c), rc = max(r, c);
-        const int q = 6 * ra - ra * (ra - 1) / 2 + (rc - ra);
-        double hpp = 0;
-        for (int sp = 0; sp < SPLIT; ++sp) hpp += v.partial[((size_t)i * SPLIT + sp) * PV + q];
-        double val = hpp - sum;
-        if (fused && r == c) val += lambda;
-        v.S[(size_t)(6 * i + r) * n + 6 * i + c] = val;
-    } else {
-        v.S[(size_t)(6 * i + r) * n + 6 * k + c] = -sum;
+    if (reduce_here) {
+        // the share has left this compute unit (write-through, drained by every wavefront) before the group counts itself in
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(ba_sync_words(v) + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 

@@ -436,7 +436,7 @@ __global__ __launch_bounds__(256) void k_ba_update(const BaView* __restrict__ vi
         lm_decide(v, s_tot[0], fail, s_tot[1], s_tot[2], true);
         // the pose side of the new state's linearisation is the next Schur launch's to compute -- when there is a new state
         int* sw = ba_sync_words(v);
-        sw[3] = v.ctl->last_accepted; sw[4] = 0;
+        sw[3] = v.ctl->last_accepted; sw[4] = 0; sw[2] = 0;      // ([2]: groups of the next Schur launch that have stored their share, ba_band.inl)
     }
     UPD_STAMP(true, 18);
 }
