@@ -244,6 +244,17 @@ typedef struct lpslam_hip_ba lpslam_hip_ba;
 int lpslam_hip_ba_create(lpslam_hip_ctx* ctx, const double* poses, const uint8_t* fixed, int32_t n_poses,
                          const double* points, int32_t n_points, const lpslam_hip_ba_obs* obs, int32_t n_obs,
                          const lpslam_hip_ba_camera* cam, lpslam_hip_ba** out);
+/* The same in two halves, for a host that serves many sessions.  lpslam_hip_ba_prepare is the HOST half -- validation, the window's
+ * shape, the block carved out of the context's cache, the inputs copied into page-locked staging -- and enqueues nothing: every
+ * session's mapping thread prepares its window on its own ([UPSTREAM] mapping_module::run of each session; reached through
+ * feed_stereo_frame, src/Trackers/OpenVSLAMStereoTracker.cpp:293-295), thread safe per context.  lpslam_hip_ba_build_batch is the DEVICE
+ * half for any number of prepared problems of one device: the structure kernels once for all of them (blockIdx.y = problem, ~16
+ * launches whatever n is) on the first problem's stream; the others' streams wait for it on the device.  A prepared problem accepts
+ * no other call before it has been built (LPSLAM_HIP_ERR_INVALID).  lpslam_hip_ba_create = prepare + build_batch of one. */
+int lpslam_hip_ba_prepare(lpslam_hip_ctx* ctx, const double* poses, const uint8_t* fixed, int32_t n_poses,
+                          const double* points, int32_t n_points, const lpslam_hip_ba_obs* obs, int32_t n_obs,
+                          const lpslam_hip_ba_camera* cam, lpslam_hip_ba** out);
+int lpslam_hip_ba_build_batch(lpslam_hip_ba* const* problems, int32_t n);
 void lpslam_hip_ba_destroy(lpslam_hip_ba* ba);
 /* Observation activity mask (0 = level 1 / ignored); NULL = all active. */
 int lpslam_hip_ba_set_active(lpslam_hip_ba* ba, const uint8_t* active);

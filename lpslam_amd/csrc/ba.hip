@@ -2227,6 +2227,10 @@ struct lpslam_hip_ba {
     int band_hbw_structure = -1;                       // block half-bandwidth of the window when the band path can take it (creation), else -1
     int band_gmax = 0;                                 // landmarks per group at most (LDS of k_schur_group)
     int faults_band = 0, faults_update = 0;            // timed-out hand-overs seen so far (report_faults)
+    bool built = false;                                // the structure build has been enqueued (lpslam_hip_ba_build_batch); prepare alone leaves the block untouched
+    void* build_desc = nullptr;                        // BuildDesc of this problem (host copy), ba_build.inl
+    size_t o_descs = 0;                                // offset of the descriptor array (device: in the block; host: in the staging block)
+    hipEvent_t ev_built = nullptr;                     // a build enqueued on another problem's stream: this problem's stream waits for it
 };
 
 namespace {
@@ -2568,9 +2572,14 @@ struct Carve {
 
 extern "C" {
 
-int lpslam_hip_ba_create(lpslam_hip_ctx* ctx, const double* poses, const uint8_t* fixed, int32_t n_poses, const double* points,
-                         int32_t n_points, const lpslam_hip_ba_obs* obs, int32_t n_obs, const lpslam_hip_ba_camera* cam,
-                         lpslam_hip_ba** out)
+// Creation in two halves.  lpslam_hip_ba_prepare is the HOST half: validation, the window's shape (band plan, landmark blocks), one block of
+// the context's cache carved, the inputs copied into a page-locked staging block -- no kernel, no stream operation, safe to call from
+// several threads at once (a server's sessions prepare their windows side by side).  lpslam_hip_ba_build_batch is the DEVICE half for
+// any number of prepared problems: ~16 launches in all (blockIdx.y = problem) on the first problem's stream.  lpslam_hip_ba_create =
+// prepare + build_batch of one.
+int lpslam_hip_ba_prepare(lpslam_hip_ctx* ctx, const double* poses, const uint8_t* fixed, int32_t n_poses, const double* points,
+                          int32_t n_points, const lpslam_hip_ba_obs* obs, int32_t n_obs, const lpslam_hip_ba_camera* cam,
+                          lpslam_hip_ba** out)
 {
     if (!ctx || !poses || !points || !obs || !cam || !out || n_poses < 1 || n_points < 0 || n_obs < 0) {
         set_error("invalid bundle-adjustment arguments"); return LPSLAM_HIP_ERR_INVALID;
@@ -2647,7 +2656,9 @@ int lpslam_hip_ba_create(lpslam_hip_ctx* ctx, const double* poses, const uint8_t
     const size_t n_ord = plan.order.size(), n_grp = plan.groups.size() / BD_REC;
     const size_t o_land_start = cv.take(land_start.size() * 4);
     const size_t o_band_tab = cv.take((BD_REC * n_grp + 2 * nfree) * 4), o_band_order = cv.take(n_ord * 4), o_band_qinfo = cv.take(n_ord * 4), o_band_bstart = cv.take((n_ord + 1) * 4);
-    const size_t staged_bytes = cv.off;
+    const size_t staged_bytes = cv.off;                 // what the copy kernel moves: [0, staged_bytes)
+    const size_t o_descs = cv.take(BUILD_MAX_BATCH * sizeof(BuildDesc));      // descriptors of a batched build led by this problem (device: here; host: same offset of the staging block)
+    const size_t stage_alloc = cv.off;
     const size_t z_begin = cv.off;
     const size_t o_A = cv.take(np * npt * 4), o_ptcount = cv.take(npt * 4);
     const SetOff so = set_offsets(n_poses, n_points, n_obs, b->n_free, b->dim_pad);
@@ -2716,8 +2727,9 @@ int lpslam_hip_ba_create(lpslam_hip_ctx* ctx, const double* poses, const uint8_t
     b->d_view = (BaView*)(base + o_view);
     b->d_chi_obs = (double*)(base + o_chiobs); b->d_depth = base + o_depth;
     // ---- inputs through one page-locked staging block, one copy
-    b->stage = lp_pin_big_alloc(ctx, staged_bytes, &b->stage_cap);
-    if (!b->stage) { set_error("page-locked staging of %zu bytes failed", staged_bytes); return fail(LPSLAM_HIP_ERR_DEVICE); }
+    b->stage = lp_pin_big_alloc(ctx, stage_alloc, &b->stage_cap);
+    if (!b->stage) { set_error("page-locked staging of %zu bytes failed", stage_alloc); return fail(LPSLAM_HIP_ERR_DEVICE); }
+    b->o_descs = o_descs;
     uint8_t* hs = (uint8_t*)b->stage;
     memcpy(hs + o_view, &v, sizeof(BaView));
     memcpy(hs + o_poses0, poses, 7 * np * 8);
@@ -2733,53 +2745,104 @@ int lpslam_hip_ba_create(lpslam_hip_ctx* ctx, const double* poses, const uint8_t
         memcpy(hs + o_band_order, plan.order.data(), n_ord * 4); memcpy(hs + o_band_qinfo, plan.qinfo.data(), n_ord * 4);
         memcpy(hs + o_band_bstart, plan.bstart.data(), (n_ord + 1) * 4);
     }
-    hipStream_t s = b->stream;
-    // the inputs come over PCIe by a KERNEL that reads the page-locked staging block, not by the DMA engine: a copy packet queues
-    // behind whatever the engine is busy with -- the front end's image uploads (0.9 ms per 16-frame step) held the next window's
-    // build back until the running solve had finished, and the mapping pipeline stalled (PCIe-inclusive rate 0.84 of the resident)
-    hipLaunchKernelGGL(k_copy_from_host, dim3(64), dim3(256), 0, s, (uint4*)base, (const uint4*)hs, (staged_bytes + 15) / 16);
-    BA_HIP(hipMemsetAsync(base + z_begin, 0, z_end - z_begin, s));
-    // ---- structure on the device (ba_build.inl)
-    const lpslam_hip_ba_obs* d_obs = (const lpslam_hip_ba_obs*)(base + o_obs_in);
-    int* A = (int*)(base + o_A); int* R = (int*)(base + o_R);
-    int* ps_start = (int*)(base + o_ps_start); int* pt_start = (int*)(base + o_pt_start);
-    if (b->dim_pad > b->dim + 1) hipLaunchKernelGGL(k_bs_identity, dim3((b->dim_pad - b->dim - 1 + 255) / 256), dim3(256), 0, s, b->d_red, b->dim, b->dim_pad);
-    if (n_obs) hipLaunchKernelGGL(k_bs_count, dim3((n_obs + 255) / 256), dim3(256), 0, s, d_obs, n_obs, n_points, A, (int*)(base + o_ptcount));
-    if (n_points) hipLaunchKernelGGL(k_bs_rowscan, dim3(n_poses), dim3(BS_THREADS), 0, s, A, R, n_points, (int*)(base + o_pscount));
-    else BA_HIP(hipMemsetAsync(base + o_pscount, 0, np * 4, s));
-    hipLaunchKernelGGL(k_bs_starts, dim3(2), dim3(BS_THREADS), 0, s, (const int*)(base + o_pscount), ps_start, n_poses, (const int*)(base + o_ptcount), pt_start, n_points);
-    if (n_obs) {
-        hipLaunchKernelGGL(k_bs_scatter, dim3((n_obs + 255) / 256), dim3(256), 0, s, d_obs, n_obs, n_points, A, R, ps_start, (int*)(base + o_slotof));
-        hipLaunchKernelGGL(k_bs_gather, dim3((n_obs + 255) / 256), dim3(256), 0, s, d_obs, n_obs, n_points, A, R, ps_start, (const int*)(base + o_slotof),
-                           b->d_o_orig, (int*)(base + o_opose), (int*)(base + o_opoint), (double*)(base + o_u), (double*)(base + o_v), (double*)(base + o_ur),
-                           (double*)(base + o_w), b->d_o_active, b->d_act_in);
-        hipLaunchKernelGGL(k_bs_ptfill, dim3((n_points + 255) / 256), dim3(256), 0, s, A, R, n_poses, n_points, ps_start, pt_start, (int*)(base + o_pt_obs));
-        hipLaunchKernelGGL(k_bs_csrcopy, dim3((n_obs + 255) / 256), dim3(256), 0, s, n_obs, (const int*)(base + o_pt_obs), (const int*)(base + o_opose), (const int*)(base + o_opoint),
-                           (const double*)(base + o_u), (const double*)(base + o_v), (const double*)(base + o_ur), (const double*)(base + o_w), (const int*)(base + o_slot),
-                           (int*)(base + o_csr + 4 * cst * 8), (int*)(base + o_csr + 4 * cst * 8) + cst, (int*)(base + o_csr + 5 * cst * 8), (double*)(base + o_csr), (double*)(base + o_csr) + cst, (double*)(base + o_csr) + 2 * cst, (double*)(base + o_csr) + 3 * cst);
-    }
-    if (b->n_blocks) {
-        hipLaunchKernelGGL(k_bs_paircount, dim3((b->n_blocks + 3) / 4), dim3(256), 0, s, A, n_points, b->n_free, b->n_blocks, (const int*)(base + o_free), ps_start,
-                           (const int*)(base + o_opoint), (int*)(base + o_blk_count));
-        hipLaunchKernelGGL(k_bs_blkscan, dim3(1), dim3(BS_THREADS), 0, s, (const int*)(base + o_blk_count), (int*)(base + o_blk_start), (int*)(base + o_ticket), b->n_blocks);
-        hipLaunchKernelGGL(k_bs_pairfill, dim3((b->n_blocks + 3) / 4), dim3(256), 0, s, A, R, n_points, b->n_free, b->n_blocks, (const int*)(base + o_free), ps_start,
-                           (const int*)(base + o_opoint), (const int*)(base + o_blk_start), (int4*)(base + o_terms));
-    } else BA_HIP(hipMemsetAsync(base + o_blk_start, 0, 2 * 4, s));
-    if (plan.hbw >= 0 && n_ord)
-        hipLaunchKernelGGL(k_bd_entries, dim3((unsigned)((n_ord + 255) / 256)), dim3(256), 0, s, (const int*)(base + o_band_order), (const int*)(base + o_band_qinfo),
-                           (const int*)(base + o_band_bstart), (int)n_ord, pt_start, (const int*)(base + o_pt_obs), (const int*)(base + o_opose), (const int*)(base + o_slot),
-                           (int4*)(base + o_band_ent));
-    // state buffers <- the inputs, control block cleared
+    // ---- what the device half will need (ba_build.inl)
     {
-        const long n_max = std::max<long>(std::max<long>(7L * n_poses, 3L * n_points), n_obs);
-        hipLaunchKernelGGL(k_ba_reset, dim3((unsigned)((n_max + 255) / 256), 1), dim3(256), 0, s, b->d_view);
+        BuildDesc* d = new BuildDesc();
+        b->build_desc = d;
+        d->n_poses = n_poses; d->n_points = n_points; d->n_obs = n_obs; d->n_free = b->n_free; d->n_blocks = b->n_blocks; d->dim = b->dim; d->dim_pad = b->dim_pad;
+        d->n_ord = plan.hbw >= 0 ? (int)n_ord : 0;
+        d->obs = (const lpslam_hip_ba_obs*)(base + o_obs_in);
+        d->A = (int*)(base + o_A); d->R = (int*)(base + o_R); d->pt_count = (int*)(base + o_ptcount); d->ps_count = (int*)(base + o_pscount);
+        d->ps_start = (int*)(base + o_ps_start); d->pt_start = (int*)(base + o_pt_start); d->slot_of = (int*)(base + o_slotof); d->pt_obs = (int*)(base + o_pt_obs);
+        d->o_orig = b->d_o_orig; d->o_pose = (int*)(base + o_opose); d->o_point = (int*)(base + o_opoint);
+        d->o_u = (double*)(base + o_u); d->o_v = (double*)(base + o_v); d->o_ur = (double*)(base + o_ur); d->o_w = (double*)(base + o_w);
+        d->o_active = b->d_o_active; d->act_in = b->d_act_in;
+        d->pose_slot = (const int*)(base + o_slot); d->free_pose = (const int*)(base + o_free);
+        d->c_pose = (int*)(base + o_csr + 4 * cst * 8); d->c_point = d->c_pose + cst; d->c_slot = (int*)(base + o_csr + 5 * cst * 8);
+        d->c_u = (double*)(base + o_csr); d->c_v = d->c_u + cst; d->c_ur = d->c_u + 2 * cst; d->c_w = d->c_u + 3 * cst;
+        d->blk_count = (int*)(base + o_blk_count); d->blk_start = (int*)(base + o_blk_start); d->blk_ticket = (int*)(base + o_ticket); d->blk_terms = (int4*)(base + o_terms);
+        d->band_order = (const int*)(base + o_band_order); d->band_qinfo = (const int*)(base + o_band_qinfo); d->band_bstart = (const int*)(base + o_band_bstart);
+        d->band_ent = (int4*)(base + o_band_ent);
+        d->S = b->d_red;
+        d->copy_dst = (uint4*)base; d->copy_src = (const uint4*)hs; d->copy_n16 = (staged_bytes + 15) / 16;
+        d->zero_dst = (uint4*)(base + z_begin); d->zero_n16 = (z_end - z_begin + 15) / 16;      // (carved in multiples of 256 bytes)
+        d->view = b->d_view;
     }
-    BA_HIP(hipGetLastError());
 #undef BA_HIP
     b->h_ctl = BaCtl{};
     b->h_ctl.ni = 2; b->h_ctl.need_lin = 1; b->h_ctl.first = 1;
     *out = b;
     return LPSLAM_HIP_OK;
+}
+
+// The device half of creation for n prepared problems: the structure phase (= g2o buildStructure of every window) as ONE launch chain,
+// blockIdx.y = problem, on the first problem's stream; the other problems' streams wait for it on the device.  Asynchronous.
+int lpslam_hip_ba_build_batch(lpslam_hip_ba* const* ps, int32_t n)
+{
+    if (!ps || n < 1) { set_error("empty batch"); return LPSLAM_HIP_ERR_INVALID; }
+    for (int i = 0; i < n; ++i) {
+        if (!ps[i] || !ps[i]->build_desc) { set_error("build_batch: entry %d is not a prepared problem", i); return LPSLAM_HIP_ERR_INVALID; }
+        if (ps[i]->built) { set_error("build_batch: entry %d has been built already", i); return LPSLAM_HIP_ERR_INVALID; }
+        if (ps[i]->ctx->cfg.device != ps[0]->ctx->cfg.device) { set_error("batch spans devices (entry %d)", i); return LPSLAM_HIP_ERR_INVALID; }
+        for (int k = 0; k < i; ++k) if (ps[k] == ps[i]) { set_error("problem listed twice in a batch (entries %d, %d)", k, i); return LPSLAM_HIP_ERR_INVALID; }
+    }
+    LP_HIP(hipSetDevice(ps[0]->ctx->cfg.device));
+    for (int c0 = 0; c0 < n; c0 += BUILD_MAX_BATCH) {
+        const int m = std::min(n - c0, (int)BUILD_MAX_BATCH);
+        lpslam_hip_ba* lead = ps[c0];
+        hipStream_t s = lead->stream;
+        BuildDesc* h_descs = (BuildDesc*)((uint8_t*)lead->stage + lead->o_descs);
+        const BuildDesc* d_descs = (const BuildDesc*)((uint8_t*)lead->block + lead->o_descs);
+        int mx_obs = 0, mx_poses = 0, mx_points = 0, mx_blocks = 0, mx_ord = 0, mx_pad = 0;
+        size_t mx_copy = 0, mx_zero = 0;
+        bool any_band = false;
+        for (int i = 0; i < m; ++i) {
+            const BuildDesc& d = *(const BuildDesc*)ps[c0 + i]->build_desc;
+            h_descs[i] = d;
+            mx_obs = std::max(mx_obs, d.n_obs); mx_poses = std::max(mx_poses, d.n_poses); mx_points = std::max(mx_points, d.n_points);
+            mx_blocks = std::max(mx_blocks, d.n_blocks); mx_ord = std::max(mx_ord, d.n_ord); mx_pad = std::max(mx_pad, d.dim_pad - d.dim - 1);
+            mx_copy = std::max(mx_copy, d.copy_n16); mx_zero = std::max(mx_zero, d.zero_n16);
+            any_band = any_band || d.n_ord > 0;
+        }
+        const dim3 B256(256), BS(BS_THREADS);
+        auto blocks = [](long x) { return (unsigned)std::max<long>((x + 255) / 256, 1); };
+        hipLaunchKernelGGL(k_bs_descs_in, dim3(1), B256, 0, s, (uint4*)d_descs, (const uint4*)h_descs, (int)(((size_t)m * sizeof(BuildDesc) + 15) / 16));
+        hipLaunchKernelGGL(k_bs_copy_in, dim3(std::min<unsigned>(64, blocks((long)mx_copy)), m), B256, 0, s, d_descs);
+        hipLaunchKernelGGL(k_bs_zero, dim3(std::min<unsigned>(256, blocks((long)mx_zero)), m), B256, 0, s, d_descs);
+        hipLaunchKernelGGL(k_bs_count, dim3(blocks(std::max(mx_obs, mx_pad)), m), B256, 0, s, d_descs);
+        hipLaunchKernelGGL(k_bs_rowscan, dim3(mx_poses, m), BS, 0, s, d_descs);
+        hipLaunchKernelGGL(k_bs_starts, dim3(2, m), BS, 0, s, d_descs);
+        if (mx_obs) {
+            hipLaunchKernelGGL(k_bs_scatter, dim3(blocks(mx_obs), m), B256, 0, s, d_descs);
+            hipLaunchKernelGGL(k_bs_gather, dim3(blocks(mx_obs), m), B256, 0, s, d_descs);
+            hipLaunchKernelGGL(k_bs_ptfill, dim3(blocks(mx_points), m), B256, 0, s, d_descs);
+            hipLaunchKernelGGL(k_bs_csrcopy, dim3(blocks(mx_obs), m), B256, 0, s, d_descs);
+        }
+        hipLaunchKernelGGL(k_bs_paircount, dim3((unsigned)std::max((mx_blocks + 3) / 4, 1), m), B256, 0, s, d_descs);
+        hipLaunchKernelGGL(k_bs_blkscan, dim3(1, m), BS, 0, s, d_descs);
+        if (mx_blocks) hipLaunchKernelGGL(k_bs_pairfill, dim3((unsigned)((mx_blocks + 3) / 4), m), B256, 0, s, d_descs);
+        if (any_band && mx_ord) hipLaunchKernelGGL(k_bs_band_entries, dim3(blocks(mx_ord), m), B256, 0, s, d_descs);
+        hipLaunchKernelGGL(k_bs_reset, dim3(blocks(std::max<long>(std::max<long>(7L * mx_poses, 3L * mx_points), mx_obs)), m), B256, 0, s, d_descs);
+        LP_HIP(hipGetLastError());
+        for (int i = 0; i < m; ++i) ps[c0 + i]->built = true;
+        if (m > 1) {
+            // the other problems' own streams (their solves, reads and set_state calls) are ordered behind the build on the device
+            if (!lead->ev_built) LP_HIP(hipEventCreateWithFlags(&lead->ev_built, hipEventDisableTiming));
+            LP_HIP(hipEventRecord(lead->ev_built, s));
+            for (int i = 1; i < m; ++i) if (ps[c0 + i]->stream != s) LP_HIP(hipStreamWaitEvent(ps[c0 + i]->stream, lead->ev_built, 0));
+        }
+    }
+    return LPSLAM_HIP_OK;
+}
+
+int lpslam_hip_ba_create(lpslam_hip_ctx* ctx, const double* poses, const uint8_t* fixed, int32_t n_poses, const double* points,
+                         int32_t n_points, const lpslam_hip_ba_obs* obs, int32_t n_obs, const lpslam_hip_ba_camera* cam,
+                         lpslam_hip_ba** out)
+{
+    int rc = lpslam_hip_ba_prepare(ctx, poses, fixed, n_poses, points, n_points, obs, n_obs, cam, out);
+    if (rc) return rc;
+    if ((rc = lpslam_hip_ba_build_batch(out, 1))) { lpslam_hip_ba_destroy(*out); *out = nullptr; }
+    return rc;
 }
 
 void lpslam_hip_ba_destroy(lpslam_hip_ba* b)
@@ -2792,7 +2855,9 @@ void lpslam_hip_ba_destroy(lpslam_hip_ba* b)
     if (b->xfer) lp_pin_big_free(b->ctx, b->xfer, b->xfer_cap);
     if (b->xfer_in_read) (void)hipEventDestroy(b->xfer_in_read);
     if (b->ev) (void)hipEventDestroy(b->ev);
+    if (b->ev_built) (void)hipEventDestroy(b->ev_built);
     if (b->stream) lp_stream_release(b->ctx, b->stream);
+    delete (BuildDesc*)b->build_desc;
     delete b;
 }
 
@@ -2805,6 +2870,7 @@ __global__ __launch_bounds__(256) void k_ba_gather_active(const uint8_t* in, con
 
 int lpslam_hip_ba_set_active(lpslam_hip_ba* b, const uint8_t* active)
 {
+    if (b && !b->built) { set_error("the problem has been prepared but not built (lpslam_hip_ba_build_batch)"); return LPSLAM_HIP_ERR_INVALID; }
     if (!b) { set_error("null problem"); return LPSLAM_HIP_ERR_INVALID; }
     if (!b->n_obs) return LPSLAM_HIP_OK;
     if (active) {
@@ -2843,6 +2909,7 @@ static int enqueue_batch(const BaLaunch& L, int units, bool first_batch)
 // rejected trials and fetches the log.
 int lpslam_hip_ba_optimize_begin(lpslam_hip_ba* b, int32_t robust, int32_t iters)
 {
+    if (b && !b->built) { set_error("the problem has been prepared but not built (lpslam_hip_ba_build_batch)"); return LPSLAM_HIP_ERR_INVALID; }
     if (!b) { set_error("null problem"); return LPSLAM_HIP_ERR_INVALID; }
     if (iters < 0 || iters > MAX_LOG) { set_error("iterations must be in [0,%d]", MAX_LOG); return LPSLAM_HIP_ERR_INVALID; }
     if (b->pending_iters >= 0) { set_error("optimize_begin: the previous optimize_begin has not been ended"); return LPSLAM_HIP_ERR_INVALID; }
@@ -2956,6 +3023,7 @@ int lpslam_hip_ba_optimize(lpslam_hip_ba* b, int32_t robust, int32_t iters, lpsl
 // not serialise itself (every launch depends on its predecessor).
 int lpslam_hip_ba_optimize_profiled(lpslam_hip_ba* b, int32_t robust, int32_t iters, lpslam_hip_ba_kernel_times* out)
 {
+    if (b && !b->built) { set_error("the problem has been prepared but not built (lpslam_hip_ba_build_batch)"); return LPSLAM_HIP_ERR_INVALID; }
     if (!b || !out) { set_error("null argument"); return LPSLAM_HIP_ERR_INVALID; }
     if (iters < 0 || iters > MAX_LOG) { set_error("iterations must be in [0,%d]", MAX_LOG); return LPSLAM_HIP_ERR_INVALID; }
     if (b->pending_iters >= 0) { set_error("optimize_begin pending"); return LPSLAM_HIP_ERR_INVALID; }
@@ -3011,6 +3079,7 @@ static int batch_check(lpslam_hip_ba* const* ps, int n)
         if (!ps[i]) { set_error("null problem in batch (entry %d)", i); return LPSLAM_HIP_ERR_INVALID; }
         if (ps[i]->ctx->cfg.device != ps[0]->ctx->cfg.device) { set_error("batch spans devices (entry %d)", i); return LPSLAM_HIP_ERR_INVALID; }
         if (ps[i]->pending_iters >= 0) { set_error("batch entry %d has an optimize_begin pending", i); return LPSLAM_HIP_ERR_INVALID; }
+        if (!ps[i]->built) { set_error("batch entry %d has been prepared but not built (lpslam_hip_ba_build_batch)", i); return LPSLAM_HIP_ERR_INVALID; }
         for (int k = 0; k < i; ++k) if (ps[k] == ps[i]) { set_error("problem listed twice in a batch (entries %d, %d)", k, i); return LPSLAM_HIP_ERR_INVALID; }
     }
     return LPSLAM_HIP_OK;
@@ -3126,6 +3195,7 @@ int lpslam_hip_ba_get_solver(lpslam_hip_ba* b, int32_t* solver, int32_t* block_h
 
 int lpslam_hip_ba_set_solver(lpslam_hip_ba* b, int32_t solver)
 {
+    if (b && !b->built) { set_error("the problem has been prepared but not built (lpslam_hip_ba_build_batch)"); return LPSLAM_HIP_ERR_INVALID; }
     if (!b) { set_error("null problem"); return LPSLAM_HIP_ERR_INVALID; }
     if (b->pending_iters >= 0) { set_error("set_solver between optimize_begin and optimize_end"); return LPSLAM_HIP_ERR_INVALID; }
     int want = solver == LPSLAM_HIP_BA_SOLVER_DENSE ? -1 : b->band_hbw_structure;
@@ -3149,6 +3219,7 @@ static int ensure_dense(lpslam_hip_ba* b) { return b->h_view.band_hbw >= 0 ? lps
 
 int lpslam_hip_ba_step_begin(lpslam_hip_ba* b, int32_t robust, int32_t first)
 {
+    if (b && !b->built) { set_error("the problem has been prepared but not built (lpslam_hip_ba_build_batch)"); return LPSLAM_HIP_ERR_INVALID; }
     if (!b) { set_error("null problem"); return LPSLAM_HIP_ERR_INVALID; }
     LP_HIP(hipSetDevice(b->ctx->cfg.device));
     int rc;
@@ -3221,6 +3292,7 @@ int lpslam_hip_ba_scalar_buffer(lpslam_hip_ba* b, void** dev_ptr, int64_t* n_dou
 
 int lpslam_hip_ba_reset(lpslam_hip_ba* b)
 {
+    if (b && !b->built) { set_error("the problem has been prepared but not built (lpslam_hip_ba_build_batch)"); return LPSLAM_HIP_ERR_INVALID; }
     if (!b) { set_error("null problem"); return LPSLAM_HIP_ERR_INVALID; }
     b->h_ctl = BaCtl{};
     b->h_ctl.ni = 2; b->h_ctl.need_lin = 1; b->h_ctl.first = 1;
@@ -3236,6 +3308,7 @@ int lpslam_hip_ba_reset(lpslam_hip_ba* b)
 // over the poses / landmarks that solve produced when it is done.
 int lpslam_hip_ba_set_state(lpslam_hip_ba* b, const double* poses, const double* points)
 {
+    if (b && !b->built) { set_error("the problem has been prepared but not built (lpslam_hip_ba_build_batch)"); return LPSLAM_HIP_ERR_INVALID; }
     if (!b) { set_error("null problem"); return LPSLAM_HIP_ERR_INVALID; }
     if (b->pending_iters >= 0) { set_error("lpslam_hip_ba_set_state while a solve is in flight"); return LPSLAM_HIP_ERR_INVALID; }
     if (!poses && !(points && b->n_points)) return lpslam_hip_ba_reset(b);
@@ -3261,6 +3334,7 @@ int lpslam_hip_ba_set_state(lpslam_hip_ba* b, const double* poses, const double*
 
 int lpslam_hip_ba_get(lpslam_hip_ba* b, double* poses, double* points)
 {
+    if (b && !b->built) { set_error("the problem has been prepared but not built (lpslam_hip_ba_build_batch)"); return LPSLAM_HIP_ERR_INVALID; }
     if (!b) { set_error("null problem"); return LPSLAM_HIP_ERR_INVALID; }
     if (uint8_t* x = ensure_xfer(b)) {
         auto even = [](size_t n) { return (n + 1) & ~(size_t)1; };      // 16-byte aligned halves
@@ -3335,6 +3409,7 @@ int lpslam_hip_ba_get_batch(lpslam_hip_ba* const* ps, int32_t n, double* const* 
 
 int lpslam_hip_ba_chi2(lpslam_hip_ba* b, double* chi2, uint8_t* depth_positive)
 {
+    if (b && !b->built) { set_error("the problem has been prepared but not built (lpslam_hip_ba_build_batch)"); return LPSLAM_HIP_ERR_INVALID; }
     if (!b) { set_error("null problem"); return LPSLAM_HIP_ERR_INVALID; }
     if (!b->n_obs) return LPSLAM_HIP_OK;
     hipLaunchKernelGGL(k_ba_obs_chi2, dim3((b->n_obs + 255) / 256, 1), dim3(256), 0, b->stream, b->d_view, b->d_chi_obs, b->d_depth);
@@ -3457,6 +3532,7 @@ extern "C" __attribute__((visibility("default"))) int lpslam_hip_debug_po_stamps
 
 int lpslam_hip_ba_pose_optimize(lpslam_hip_ba* b, uint8_t* outlier, int32_t* n_inliers)
 {
+    if (b && !b->built) { set_error("the problem has been prepared but not built (lpslam_hip_ba_build_batch)"); return LPSLAM_HIP_ERR_INVALID; }
     if (!b) { set_error("null problem"); return LPSLAM_HIP_ERR_INVALID; }
     const int n = b->n_obs;
     std::vector<uint8_t> active((size_t)std::max(n, 1), 1), out((size_t)std::max(n, 1), 0);
@@ -3485,6 +3561,7 @@ int lpslam_hip_ba_pose_optimize(lpslam_hip_ba* b, uint8_t* outlier, int32_t* n_i
 
 int lpslam_hip_ba_local(lpslam_hip_ba* b, int32_t first_iters, int32_t second_iters, uint8_t* outlier)
 {
+    if (b && !b->built) { set_error("the problem has been prepared but not built (lpslam_hip_ba_build_batch)"); return LPSLAM_HIP_ERR_INVALID; }
     if (!b) { set_error("null problem"); return LPSLAM_HIP_ERR_INVALID; }
     const int n = b->n_obs;
     std::vector<uint8_t> active((size_t)std::max(n, 1), 1), pos((size_t)std::max(n, 1));
@@ -3578,6 +3655,7 @@ extern "C" int lpslam_hip_ba_optimize_partitioned(lpslam_hip_ba* b, void* nccl_c
 extern "C" int lpslam_hip_ba_optimize_partitioned_with(lpslam_hip_ba* b, lpslam_hip_allreduce_fn allreduce_cb, void* user, int32_t robust, int32_t iters,
                                                        lpslam_hip_ba_iter_log* log, int32_t* done_out)
 {
+    if (b && !b->built) { set_error("the problem has been prepared but not built (lpslam_hip_ba_build_batch)"); return LPSLAM_HIP_ERR_INVALID; }
     if (!b || !allreduce_cb) { set_error("null problem / all-reduce callback"); return LPSLAM_HIP_ERR_INVALID; }
     if (iters < 0 || iters > MAX_LOG) { set_error("iterations must be in [0,%d]", MAX_LOG); return LPSLAM_HIP_ERR_INVALID; }
     if (b->pending_iters >= 0) { set_error("optimize_begin pending"); return LPSLAM_HIP_ERR_INVALID; }

@@ -36,30 +36,7 @@ constexpr int BD_REC = 8;                   // ints per group record: e0, e1 (en
 __host__ __device__ inline int bd_stride(int cnt) { const int k4 = (3 * cnt + 3) & ~3; return ((k4 + 31) & ~31) + 4; }    // % 32 == 4: operand reads 2-way at most
 __host__ __device__ inline size_t bd_lds_bytes(int gmax) { return ((size_t)BD_ROWS * bd_stride(gmax) + 3 * (size_t)gmax + 8) * sizeof(double); }
 
-// ---- creation: the entry table, in group order.  Thread per ordered landmark q: its observations (CSR order = keyframe order)
-//      become entries (storage slot, window row or -1 for a fixed keyframe, column | flags, landmark).
-//      flags: bit 16 = first entry of its landmark (writes the landmark's rhs vector), bit 17 = duplicate (same landmark seen
-//      twice by one keyframe: summed by the thread of the run's first entry), bit 18 = a duplicate follows.
-__global__ __launch_bounds__(256) void k_bd_entries(const int* __restrict__ order, const int* __restrict__ qinfo, const int* __restrict__ bstart, int n_ord,
-                                                    const int* __restrict__ pt_start, const int* __restrict__ pt_obs, const int* __restrict__ o_pose,
-                                                    const int* __restrict__ pose_slot, int4* __restrict__ entries)
-{
-    const int q = blockIdx.x * 256 + threadIdx.x;
-    if (q >= n_ord) return;
-    const int j = order[q], info = qinfo[q], f0 = info >> 8, li = info & 255;
-    const int o0 = pt_start[j], o1 = pt_start[j + 1];
-    int4* out = entries + bstart[q];
-    int prev_pose = -1;
-    for (int o = o0; o < o1; ++o) {
-        const int s = pt_obs[o], p = o_pose[s], slot = pose_slot[p];
-        int flags = 0;
-        if (o == o0) flags |= 1 << 16;
-        if (p == prev_pose) flags |= 1 << 17;
-        if (o + 1 < o1 && o_pose[pt_obs[o + 1]] == p) flags |= 1 << 18;      // the next entry is a duplicate of this one
-        prev_pose = p;
-        out[o - o0] = make_int4(s, slot < 0 ? -1 : 6 * (slot - f0), 3 * li | flags, j);
-    }
-}
+// ---- creation: the entry table, in group order: k_bs_band_entries (ba_build.inl).
 
 // sum over the 16 lanes of a DPP row, in every lane (xor 1, xor 2, half mirror, mirror: a fixed tree)
 template <int CTRL>

@@ -33,22 +33,69 @@ __device__ __forceinline__ int bs_block_scan(int x, int* total)
     return base + incl - x;
 }
 
-// A[p][j] += 1 per observation; landmark degrees
-__global__ __launch_bounds__(256) void k_bs_count(const lpslam_hip_ba_obs* __restrict__ obs, int n_obs, int n_points, int* A, int* pt_count)
+// ---- everything the structure kernels of ONE problem need.  The kernels take an array of these and a problem index in blockIdx.y:
+//      the windows of sixteen sessions are built by the same ~16 launches as one window (lpslam_hip_ba_build_batch), where a launch
+//      chain per window was ~320 runtime calls per round from the sessions' set-up threads.  Launch extents are
+//      the maxima over the batch; a workgroup beyond its problem's extent leaves at once.
+struct BuildDesc {
+    int n_poses, n_points, n_obs, n_free, n_blocks, dim, dim_pad, n_ord;
+    const lpslam_hip_ba_obs* obs;
+    int *A, *R, *pt_count, *ps_count, *ps_start, *pt_start, *slot_of, *pt_obs, *o_orig, *o_pose, *o_point;
+    double *o_u, *o_v, *o_ur, *o_w;
+    uint8_t *o_active, *act_in;
+    const int *pose_slot, *free_pose;
+    int *c_pose, *c_point, *c_slot;
+    double *c_u, *c_v, *c_ur, *c_w;
+    int *blk_count, *blk_start, *blk_ticket;
+    int4* blk_terms;
+    const int *band_order, *band_qinfo, *band_bstart;      // n_ord > 0: the window takes the band path (ba_band.inl)
+    int4* band_ent;
+    double* S;
+    uint4* copy_dst; const uint4* copy_src; size_t copy_n16;      // inputs: page-locked staging -> the problem's block
+    uint4* zero_dst; size_t zero_n16;                               // the zero-initialised part of the block
+    const BaView* view;
+};
+constexpr int BUILD_MAX_BATCH = 64;         // descriptors a problem's block has room for (larger batches are built in chunks)
+
+// the descriptors themselves: page-locked host memory -> device (one workgroup; the first launch of a build)
+__global__ __launch_bounds__(256) void k_bs_descs_in(uint4* __restrict__ dst, const uint4* __restrict__ src, int n16)
 {
+    for (int i = threadIdx.x; i < n16; i += 256) dst[i] = src[i];
+}
+// inputs over PCIe by load / store (not by the DMA engine: a copy packet queues behind whatever the engine is busy with -- the front
+// end's image uploads held the next window's build back until the running solve had finished) and the zero fill, one launch each
+__global__ __launch_bounds__(256) void k_bs_copy_in(const BuildDesc* __restrict__ descs)
+{
+    const BuildDesc& d = descs[blockIdx.y];
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < d.copy_n16; i += (size_t)gridDim.x * 256) d.copy_dst[i] = d.copy_src[i];
+}
+__global__ __launch_bounds__(256) void k_bs_zero(const BuildDesc* __restrict__ descs)
+{
+    const BuildDesc& d = descs[blockIdx.y];
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < d.zero_n16; i += (size_t)gridDim.x * 256) d.zero_dst[i] = z;
+}
+
+// A[p][j] += 1 per observation; landmark degrees; the identity rows of the reduced system below the rhs row
+__global__ __launch_bounds__(256) void k_bs_count(const BuildDesc* __restrict__ descs)
+{
+    const BuildDesc& d = descs[blockIdx.y];
     const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= n_obs) return;
-    const int p = obs[k].pose, j = obs[k].point;
-    atomicAdd(&A[(size_t)p * n_points + j], 1);
-    atomicAdd(&pt_count[j], 1);
+    { const int r = d.dim + 1 + k; if (r < d.dim_pad) d.S[(size_t)r * d.dim_pad + r] = 1.0; }
+    if (k >= d.n_obs) return;
+    const int p = d.obs[k].pose, j = d.obs[k].point;
+    atomicAdd(&d.A[(size_t)p * d.n_points + j], 1);
+    atomicAdd(&d.pt_count[j], 1);
 }
 
 // R[p][.] = exclusive scan of A[p][.] (one workgroup per keyframe); ps_count[p] = observations of keyframe p
-__global__ __launch_bounds__(BS_THREADS) void k_bs_rowscan(const int* __restrict__ A, int* R, int n_points, int* ps_count)
+__global__ __launch_bounds__(BS_THREADS) void k_bs_rowscan(const BuildDesc* __restrict__ descs)
 {
-    const int p = blockIdx.x;
-    const int* a = A + (size_t)p * n_points;
-    int* r = R + (size_t)p * n_points;
+    const BuildDesc& d = descs[blockIdx.y];
+    const int p = blockIdx.x, n_points = d.n_points;
+    if (p >= d.n_poses) return;
+    const int* a = d.A + (size_t)p * n_points;
+    int* r = d.R + (size_t)p * n_points;
     int carry = 0;
     for (int j0 = 0; j0 < n_points; j0 += 4 * BS_THREADS) {
         const int j = j0 + 4 * (int)threadIdx.x;
@@ -61,16 +108,16 @@ __global__ __launch_bounds__(BS_THREADS) void k_bs_rowscan(const int* __restrict
         for (int u = 0; u < 4; ++u) { if (j + u < n_points) r[j + u] = pre; pre += x[u]; }
         carry += tot;
     }
-    if (threadIdx.x == 0) ps_count[p] = carry;
+    if (threadIdx.x == 0) d.ps_count[p] = carry;
 }
 
-// workgroup 0: ps_start = exclusive scan of ps_count (n_poses + 1 entries); workgroup 1: pt_start from pt_count; workgroup 2
-// (with blk_count != nullptr): blk_start from blk_count, in place
-__global__ __launch_bounds__(BS_THREADS) void k_bs_starts(const int* ps_count, int* ps_start, int n_poses, const int* pt_count, int* pt_start, int n_points)
+// workgroup 0: ps_start = exclusive scan of ps_count (n_poses + 1 entries); workgroup 1: pt_start from pt_count
+__global__ __launch_bounds__(BS_THREADS) void k_bs_starts(const BuildDesc* __restrict__ descs)
 {
-    const int* in = blockIdx.x == 0 ? ps_count : pt_count;
-    int* out = blockIdx.x == 0 ? ps_start : pt_start;
-    const int n = blockIdx.x == 0 ? n_poses : n_points;
+    const BuildDesc& d = descs[blockIdx.y];
+    const int* in = blockIdx.x == 0 ? d.ps_count : d.pt_count;
+    int* out = blockIdx.x == 0 ? d.ps_start : d.pt_start;
+    const int n = blockIdx.x == 0 ? d.n_poses : d.n_points;
     int carry = 0;
     for (int i0 = 0; i0 < n; i0 += BS_THREADS) {
         const int i = i0 + (int)threadIdx.x;
@@ -85,34 +132,33 @@ __global__ __launch_bounds__(BS_THREADS) void k_bs_starts(const int* ps_count, i
 
 // first pass of the placement: every observation takes a slot of its (keyframe, landmark) group; inside a group of duplicates
 // the slot is arbitrary here (an atomic on the high half of A) and put in caller order by k_bs_gather
-__global__ __launch_bounds__(256) void k_bs_scatter(const lpslam_hip_ba_obs* __restrict__ obs, int n_obs, int n_points, int* A, const int* __restrict__ R,
-                                                    const int* __restrict__ ps_start, int* slot_of)
+__global__ __launch_bounds__(256) void k_bs_scatter(const BuildDesc* __restrict__ descs)
 {
+    const BuildDesc& d = descs[blockIdx.y];
     const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= n_obs) return;
-    const int p = obs[k].pose, j = obs[k].point;
-    const size_t e = (size_t)p * n_points + j;
-    const int base = ps_start[p] + R[e];
-    const int c = A[e] & 0xFFFF;
-    const int d = c == 1 ? 0 : (atomicAdd(&A[e], 0x10000) >> 16);
-    slot_of[base + d] = k;
+    if (k >= d.n_obs) return;
+    const int p = d.obs[k].pose, j = d.obs[k].point;
+    const size_t e = (size_t)p * d.n_points + j;
+    const int base = d.ps_start[p] + d.R[e];
+    const int c = d.A[e] & 0xFFFF;
+    const int dd = c == 1 ? 0 : (atomicAdd(&d.A[e], 0x10000) >> 16);
+    d.slot_of[base + dd] = k;
 }
 
 // second pass: storage position s takes the (s - first)-th smallest caller index of its group and copies that observation into
 // the SoA arrays
-__global__ __launch_bounds__(256) void k_bs_gather(const lpslam_hip_ba_obs* __restrict__ obs, int n_obs, int n_points, const int* __restrict__ A,
-                                                   const int* __restrict__ R, const int* __restrict__ ps_start, const int* __restrict__ slot_of,
-                                                   int* o_orig, int* o_pose, int* o_point, double* o_u, double* o_v, double* o_ur, double* o_w, uint8_t* o_active,
-                                                   uint8_t* act_in)
+__global__ __launch_bounds__(256) void k_bs_gather(const BuildDesc* __restrict__ descs)
 {
+    const BuildDesc& d = descs[blockIdx.y];
     const int s = blockIdx.x * 256 + threadIdx.x;
-    if (s >= n_obs) return;
+    if (s >= d.n_obs) return;
+    const int* slot_of = d.slot_of;
     int k = slot_of[s];
-    const int p = obs[k].pose, j = obs[k].point;
-    const size_t e = (size_t)p * n_points + j;
-    const int c = A[e] & 0xFFFF;
+    const int p = d.obs[k].pose, j = d.obs[k].point;
+    const size_t e = (size_t)p * d.n_points + j;
+    const int c = d.A[e] & 0xFFFF;
     if (c > 1) {
-        const int first = ps_start[p] + R[e], want = s - first;
+        const int first = d.ps_start[p] + d.R[e], want = s - first;
         // rank selection among the c caller indices of the group (c is tiny; duplicates of one landmark in one keyframe are rare)
         for (int a = 0; a < c; ++a) {
             const int ka = slot_of[first + a];
@@ -121,37 +167,36 @@ __global__ __launch_bounds__(256) void k_bs_gather(const lpslam_hip_ba_obs* __re
             if (rank == want) k = ka;
         }
     }
-    const lpslam_hip_ba_obs o = obs[k];
-    o_orig[s] = k; o_pose[s] = o.pose; o_point[s] = o.point;
-    o_u[s] = o.u; o_v[s] = o.v; o_ur[s] = o.ur; o_w[s] = o.inv_sigma2;
-    o_active[s] = 1; act_in[s] = 1;
+    const lpslam_hip_ba_obs o = d.obs[k];
+    d.o_orig[s] = k; d.o_pose[s] = o.pose; d.o_point[s] = o.point;
+    d.o_u[s] = o.u; d.o_v[s] = o.v; d.o_ur[s] = o.ur; d.o_w[s] = o.inv_sigma2;
+    d.o_active[s] = 1; d.act_in[s] = 1;
 }
 
 // CSR by landmark: thread per landmark walks the keyframes in order (column of A / R)
-__global__ __launch_bounds__(256) void k_bs_ptfill(const int* __restrict__ A, const int* __restrict__ R, int n_poses, int n_points, const int* __restrict__ ps_start,
-                                                   const int* __restrict__ pt_start, int* pt_obs)
+__global__ __launch_bounds__(256) void k_bs_ptfill(const BuildDesc* __restrict__ descs)
 {
+    const BuildDesc& d = descs[blockIdx.y];
     const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= n_points) return;
-    int t = pt_start[j];
-    for (int p = 0; p < n_poses; ++p) {
-        const size_t e = (size_t)p * n_points + j;
-        const int c = A[e] & 0xFFFF;
-        const int first = ps_start[p] + R[e];
-        for (int d = 0; d < c; ++d) pt_obs[t++] = first + d;
+    if (j >= d.n_points) return;
+    int t = d.pt_start[j];
+    for (int p = 0; p < d.n_poses; ++p) {
+        const size_t e = (size_t)p * d.n_points + j;
+        const int c = d.A[e] & 0xFFFF;
+        const int first = d.ps_start[p] + d.R[e];
+        for (int dd = 0; dd < c; ++dd) d.pt_obs[t++] = first + dd;
     }
 }
 
-// the observation constants once more in CSR (landmark-major) order: the landmark-major linearisation (land_lin_body) reads them coalesced
-__global__ __launch_bounds__(256) void k_bs_csrcopy(int n_obs, const int* __restrict__ pt_obs, const int* __restrict__ o_pose, const int* __restrict__ o_point,
-                                                    const double* __restrict__ o_u, const double* __restrict__ o_v, const double* __restrict__ o_ur, const double* __restrict__ o_w,
-                                                    const int* __restrict__ pose_slot, int* c_pose, int* c_point, int* c_slot, double* c_u, double* c_v, double* c_ur, double* c_w)
+// the observation constants once more in CSR (landmark-major) order: the landmark-major passes (k_ba_update, land_lin_body) read them coalesced
+__global__ __launch_bounds__(256) void k_bs_csrcopy(const BuildDesc* __restrict__ descs)
 {
+    const BuildDesc& d = descs[blockIdx.y];
     const int s = blockIdx.x * 256 + threadIdx.x;
-    if (s >= n_obs) return;
-    const int k = pt_obs[s];
-    const int p = o_pose[k];
-    c_pose[s] = p; c_point[s] = o_point[k]; c_slot[s] = pose_slot[p]; c_u[s] = o_u[k]; c_v[s] = o_v[k]; c_ur[s] = o_ur[k]; c_w[s] = o_w[k];
+    if (s >= d.n_obs) return;
+    const int k = d.pt_obs[s];
+    const int p = d.o_pose[k];
+    d.c_pose[s] = p; d.c_point[s] = d.o_point[k]; d.c_slot[s] = d.pose_slot[p]; d.c_u[s] = d.o_u[k]; d.c_v[s] = d.o_v[k]; d.c_ur[s] = d.o_ur[k]; d.c_w[s] = d.o_w[k];
 }
 
 // pair (a, c), a <= c, of pose-block pair `blk` (row-major upper triangle of n_free x n_free)
@@ -163,67 +208,108 @@ __device__ __forceinline__ void bs_block_pair(int blk, int n_free, int* a, int* 
 }
 
 // terms per pose-block pair: one wavefront per pair sums A[keyframe c][landmark] over the observations of keyframe a
-__global__ __launch_bounds__(256) void k_bs_paircount(const int* __restrict__ A, int n_points, int n_free, int n_blocks, const int* __restrict__ free_pose,
-                                                      const int* __restrict__ ps_start, const int* __restrict__ o_point, int* blk_count)
+__global__ __launch_bounds__(256) void k_bs_paircount(const BuildDesc* __restrict__ descs)
 {
+    const BuildDesc& d = descs[blockIdx.y];
     const int blk = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (blk >= n_blocks) return;
+    if (blk >= d.n_blocks) return;
     int a, c;
-    bs_block_pair(blk, n_free, &a, &c);
-    const int pa = free_pose[a], pc = free_pose[c];
-    const int* Ac = A + (size_t)pc * n_points;
+    bs_block_pair(blk, d.n_free, &a, &c);
+    const int pa = d.free_pose[a], pc = d.free_pose[c];
+    const int* Ac = d.A + (size_t)pc * d.n_points;
     int n = 0;
-    for (int s = ps_start[pa] + lane; s < ps_start[pa + 1]; s += 64) n += Ac[o_point[s]] & 0xFFFF;
+    for (int s = d.ps_start[pa] + lane; s < d.ps_start[pa + 1]; s += 64) n += Ac[d.o_point[s]] & 0xFFFF;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o);
-    if (lane == 0) blk_count[blk] = n;
+    if (lane == 0) d.blk_count[blk] = n;
 }
 
 // blk_start = exclusive scan of blk_count (n_blocks + 1 entries), tickets cleared
-__global__ __launch_bounds__(BS_THREADS) void k_bs_blkscan(const int* blk_count, int* blk_start, int* blk_ticket, int n_blocks)
+__global__ __launch_bounds__(BS_THREADS) void k_bs_blkscan(const BuildDesc* __restrict__ descs)
 {
+    const BuildDesc& d = descs[blockIdx.y];
+    const int n_blocks = d.n_blocks;
     int carry = 0;
     for (int i0 = 0; i0 < n_blocks; i0 += BS_THREADS) {
         const int i = i0 + (int)threadIdx.x;
-        const int x = i < n_blocks ? blk_count[i] : 0;
+        const int x = i < n_blocks ? d.blk_count[i] : 0;
         int tot;
         const int pre = carry + bs_block_scan(x, &tot);
-        if (i < n_blocks) { blk_start[i] = pre; blk_ticket[i] = 0; }
+        if (i < n_blocks) { d.blk_start[i] = pre; d.blk_ticket[i] = 0; }
         carry += tot;
     }
-    if (threadIdx.x == 0) blk_start[n_blocks] = carry;
+    if (threadIdx.x == 0) { d.blk_start[n_blocks] = carry; if (n_blocks == 0) d.blk_start[1] = 0; }
 }
 
 // the pair lists: keyframe a's observations in storage (= landmark) order, each with its partner(s) in keyframe c
-__global__ __launch_bounds__(256) void k_bs_pairfill(const int* __restrict__ A, const int* __restrict__ R, int n_points, int n_free, int n_blocks,
-                                                     const int* __restrict__ free_pose, const int* __restrict__ ps_start, const int* __restrict__ o_point,
-                                                     const int* __restrict__ blk_start, int4* blk_terms)
+__global__ __launch_bounds__(256) void k_bs_pairfill(const BuildDesc* __restrict__ descs)
 {
+    const BuildDesc& d = descs[blockIdx.y];
     const int blk = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (blk >= n_blocks) return;
+    if (blk >= d.n_blocks) return;
     int a, c;
-    bs_block_pair(blk, n_free, &a, &c);
-    const int pa = free_pose[a], pc = free_pose[c];
-    const int* Ac = A + (size_t)pc * n_points;
-    const int* Rc = R + (size_t)pc * n_points;
-    const int base_c = ps_start[pc];
-    int out = blk_start[blk];
-    const int s_end = ps_start[pa + 1];
-    for (int s0 = ps_start[pa]; s0 < s_end; s0 += 64) {
+    bs_block_pair(blk, d.n_free, &a, &c);
+    const int pa = d.free_pose[a], pc = d.free_pose[c];
+    const int* Ac = d.A + (size_t)pc * d.n_points;
+    const int* Rc = d.R + (size_t)pc * d.n_points;
+    const int base_c = d.ps_start[pc];
+    int out = d.blk_start[blk];
+    const int s_end = d.ps_start[pa + 1];
+    for (int s0 = d.ps_start[pa]; s0 < s_end; s0 += 64) {
         const int s = s0 + lane;
         int n = 0, j = 0, first = 0;
-        if (s < s_end) { j = o_point[s]; n = Ac[j] & 0xFFFF; first = base_c + Rc[j]; }
+        if (s < s_end) { j = d.o_point[s]; n = Ac[j] & 0xFFFF; first = base_c + Rc[j]; }
         int incl = n;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(incl, o); if (lane >= o) incl += y; }
         const int total = __shfl(incl, 63);
         int w = out + incl - n;
-        for (int d = 0; d < n; ++d) blk_terms[w++] = make_int4(s, first + d, j, 0);
+        for (int dd = 0; dd < n; ++dd) d.blk_terms[w++] = make_int4(s, first + dd, j, 0);
         out += total;
     }
 }
 
-// fills of the problem's zero-initialised block that are not zero: the identity rows of the reduced system below the rhs row
+// the band path's entry table, in group order (ba_band.inl).  Thread per ordered landmark q: its observations (CSR order = keyframe
+// order) become entries (storage slot, window row or -1 for a fixed keyframe, column | flags, landmark).
+// flags: bit 16 = first entry of its landmark (writes the landmark's rhs vector), bit 17 = duplicate (same landmark seen
+// twice by one keyframe: summed by the thread of the run's first entry), bit 18 = a duplicate follows.
+__global__ __launch_bounds__(256) void k_bs_band_entries(const BuildDesc* __restrict__ descs)
+{
+    const BuildDesc& d = descs[blockIdx.y];
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= d.n_ord) return;
+    const int j = d.band_order[q], info = d.band_qinfo[q], f0 = info >> 8, li = info & 255;
+    const int o0 = d.pt_start[j], o1 = d.pt_start[j + 1];
+    int4* out = d.band_ent + d.band_bstart[q];
+    int prev_pose = -1;
+    for (int o = o0; o < o1; ++o) {
+        const int s = d.pt_obs[o], p = d.o_pose[s], slot = d.pose_slot[p];
+        int flags = 0;
+        if (o == o0) flags |= 1 << 16;
+        if (p == prev_pose) flags |= 1 << 17;
+        if (o + 1 < o1 && d.o_pose[d.pt_obs[o + 1]] == p) flags |= 1 << 18;      // the next entry is a duplicate of this one
+        prev_pose = p;
+        out[o - o0] = make_int4(s, slot < 0 ? -1 : 6 * (slot - f0), 3 * li | flags, j);
+    }
+}
+
+// state buffers <- the inputs, every observation active, control block cleared (k_ba_reset for every problem of the build)
+__global__ __launch_bounds__(256) void k_bs_reset(const BuildDesc* __restrict__ descs)
+{
+    const BuildDesc& d = descs[blockIdx.y];
+    const BaView& v = *d.view;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < 7 * d.n_poses) v.poses_buf[0][i] = v.poses0[i];
+    if (i < 3 * d.n_points) v.points_buf[0][i] = v.points0[i];
+    if (i < d.n_obs) v.o_active[i] = 1;
+    if (i == 0) {
+        BaCtl c{};
+        c.ni = 2; c.need_lin = 1; c.first = 1;
+        *v.ctl = c;
+    }
+}
+
+// the identity rows of the reduced system below the rhs row, on their own (lpslam_hip_ba_set_solver clears S)
 __global__ __launch_bounds__(256) void k_bs_identity(double* S, int dim, int dim_pad)
 {
     const int r = dim + 1 + blockIdx.x * 256 + threadIdx.x;

@@ -36,7 +36,7 @@ SYMBOLS = [
     "lpslam_hip_match_stereo", "lpslam_hip_match_stereo_strided", "lpslam_hip_get_stereo",
     "lpslam_hip_vocab_create", "lpslam_hip_vocab_destroy", "lpslam_hip_vocab_info", "lpslam_hip_bow_transform", "lpslam_hip_bow_transform_host", "lpslam_hip_match_bow_tree",
     "lpslam_hip_match_projection", "lpslam_hip_match_fuse", "lpslam_hip_match_area", "lpslam_hip_match_orientation_filter",
-    "lpslam_hip_ba_create", "lpslam_hip_ba_destroy", "lpslam_hip_ba_set_active", "lpslam_hip_ba_optimize", "lpslam_hip_ba_optimize_begin", "lpslam_hip_ba_optimize_end", "lpslam_hip_ba_graph_replays", "lpslam_hip_ba_wg_factorisations", "lpslam_hip_pose_optimize_passes", "lpslam_hip_match_bf_descriptors", "lpslam_hip_prefetch_frame", "lpslam_hip_get_frame_view", "lpslam_hip_desc_store_put", "lpslam_hip_desc_store_drop", "lpslam_hip_match_bf_stored", "lpslam_hip_ba_set_state_batch", "lpslam_hip_ba_get_batch", "lpslam_hip_ba_get_solver", "lpslam_hip_ba_set_solver", "lpslam_hip_ba_timeouts",
+    "lpslam_hip_ba_create", "lpslam_hip_ba_prepare", "lpslam_hip_ba_build_batch", "lpslam_hip_ba_destroy", "lpslam_hip_ba_set_active", "lpslam_hip_ba_optimize", "lpslam_hip_ba_optimize_begin", "lpslam_hip_ba_optimize_end", "lpslam_hip_ba_graph_replays", "lpslam_hip_ba_wg_factorisations", "lpslam_hip_pose_optimize_passes", "lpslam_hip_match_bf_descriptors", "lpslam_hip_prefetch_frame", "lpslam_hip_get_frame_view", "lpslam_hip_desc_store_put", "lpslam_hip_desc_store_drop", "lpslam_hip_match_bf_stored", "lpslam_hip_ba_set_state_batch", "lpslam_hip_ba_get_batch", "lpslam_hip_ba_get_solver", "lpslam_hip_ba_set_solver", "lpslam_hip_ba_timeouts",
     "lpslam_hip_ba_optimize_batch", "lpslam_hip_ba_reset_batch", "lpslam_hip_ba_optimize_profiled", "lpslam_hip_ba_optimize_partitioned", "lpslam_hip_ba_optimize_partitioned_with",
     "lpslam_hip_ba_local", "lpslam_hip_ba_set_points_fixed", "lpslam_hip_ba_pose_optimize", "lpslam_hip_pose_optimize", "lpslam_hip_ba_reset", "lpslam_hip_ba_set_state", "lpslam_hip_prefetch_begin", "lpslam_hip_prefetch_end", "lpslam_hip_prefetch_join", "lpslam_hip_ba_get", "lpslam_hip_ba_chi2", "lpslam_hip_ba_reduced_buffer",
     "lpslam_hip_ba_step_begin", "lpslam_hip_ba_step_lambda0", "lpslam_hip_ba_step_solve", "lpslam_hip_ba_scalar_buffer", "lpslam_hip_ba_step_end", "lpslam_hip_ba_status",
@@ -404,7 +404,7 @@ class Context:
 class BundleAdjuster:
     """Device-resident bundle-adjustment problem (lpslam_hip_ba_*)."""
 
-    def __init__(self, ctx, poses, fixed, points, obs, cam, robust_kernel=True):
+    def __init__(self, ctx, poses, fixed, points, obs, cam, robust_kernel=True, build=True):
         self.ctx = ctx
         self.lib = ctx.lib
         poses = np.ascontiguousarray(poses, np.float64); points = np.ascontiguousarray(points, np.float64)
@@ -413,8 +413,9 @@ class BundleAdjuster:
         c = BaCamera(cam["fx"], cam["fy"], cam["cx"], cam["cy"], cam["fxb"],
                      float(np.sqrt(5.991)) if robust_kernel else 0.0, float(np.sqrt(7.815)) if robust_kernel else 0.0)
         h = C.c_void_p()
-        _check(self.lib.lpslam_hip_ba_create(ctx.h, _p(poses), _p(fixed), self.n_poses, _p(points), self.n_points,
-                                             _p(obs), self.n_obs, C.byref(c), C.byref(h)))
+        # build=False: the host half alone (lpslam_hip_ba_prepare: no kernel, thread safe); ba_build_batch enqueues the device half of many
+        _check((self.lib.lpslam_hip_ba_create if build else self.lib.lpslam_hip_ba_prepare)(ctx.h, _p(poses), _p(fixed), self.n_poses, _p(points), self.n_points,
+                                                                                           _p(obs), self.n_obs, C.byref(c), C.byref(h)))
         self.h = h
         ctx._children.add(self)
 
@@ -642,6 +643,13 @@ class RcclComm:
 def ba_factor_kernel_name(dim, band=False):
     """name of the kernel that factors a reduced system of `dim` unknowns (rule of enqueue_solve in csrc/ba.hip)"""
     return "k_chol_band" if band else "k_chol_pair"          # k_chol_wg takes over only in batches of 40 dense problems and more
+
+
+def ba_build_batch(problems):
+    """the device half of creation (structure build) for problems made with build=False: one launch chain for all of them"""
+    lib = load()
+    arr = (C.c_void_p * len(problems))(*[p.h for p in problems])
+    _check(lib.lpslam_hip_ba_build_batch(arr, len(problems)))
 
 
 def ba_set_state_batch(problems, poses, points):

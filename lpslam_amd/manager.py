@@ -152,6 +152,17 @@ class Manager:
         f = RECON_CB(cb); self._keep.append(f)
         self.lib.lpslam_manager_on_reconstruction(self.h, f, None)
 
+    def count_results(self):
+        """installs the library's compiled counting callback (no interpreter on the notify thread): result_counts() = (results, valid)"""
+        self.lib.lpslam_manager_count_results.argtypes = [C.c_void_p]
+        self.lib.lpslam_manager_count_results(self.h)
+
+    def result_counts(self):
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        self.lib.lpslam_manager_result_counts.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        self.lib.lpslam_manager_result_counts(self.h, C.byref(a), C.byref(b))
+        return int(a.value), int(b.value)
+
     def collect_images(self):
         """LpSlamManager::addOnImageCallback: every frame the worker takes comes back as JPEG (quality 70) on the image thread;
         self.images gets (timestamp, camera, structure, format, left stream, right stream or None)"""

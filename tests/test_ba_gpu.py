@@ -513,3 +513,57 @@ def test_pose_optimizer_lane_layouts_and_sizes(hiplib, oracle, ctx, n):
     assert 5 <= ctx.pose_optimize_passes() <= 4 * 101           # one pass per round + one per Levenberg trial
     if n >= 40:
         assert kout[gross].mean() > 0.9 and np.abs(kpose[4:] - t).max() < 0.02
+
+
+def test_batched_build_equals_single_builds(hiplib, oracle, ctx):
+    """Creation in two halves: the host half of every window on threads of its own (lpslam_hip_ba_prepare enqueues nothing), the
+    device half of all of them as ONE launch chain (lpslam_hip_ba_build_batch, blockIdx.y = problem) -- a server's sessions set their
+    windows up that way.  Every problem then solves to the same bytes as a problem created alone, whatever shares the build with it:
+    banded and dense windows, a tiny one, one with duplicates and a shuffled caller order, one with fixed keyframes inside.  A
+    prepared problem refuses every other call until it has been built."""
+    from concurrent.futures import ThreadPoolExecutor
+    rng = np.random.default_rng(11)
+    probs = [synth.ba_problem(50, 5000, 40000, 1280, 720, seq_id=1, tracks="contiguous", top_up=True),
+             synth.ba_problem(30, 1500, 9000, 1280, 720, seq_id=2),
+             synth.ba_problem(3, 40, 100, 640, 480, seq_id=3),
+             synth.ba_problem(37, 2500, 17000, 1280, 720, seq_id=4, tracks="contiguous"),
+             synth.ba_problem(12, 600, 4000, 640, 480, seq_id=5),
+             synth.ba_problem(48, 4400, 36000, 1280, 720, seq_id=6, tracks="contiguous", top_up=True)]
+    pr = probs[4]
+    m = len(pr["obs_pose"])
+    dup = rng.choice(m, 40, replace=False)
+    for key in ("obs_pose", "obs_point", "obs_uvr", "obs_inv_sigma2"):
+        pr[key] = np.concatenate([pr[key], pr[key][dup]])
+    perm = rng.permutation(len(pr["obs_pose"]))
+    for key in ("obs_pose", "obs_point", "obs_uvr", "obs_inv_sigma2"):
+        pr[key] = pr[key][perm]
+    probs[3]["fixed"][[5, 9]] = 1
+    make = lambda p, build: hiplib.BundleAdjuster(ctx, p["poses"], p["fixed"], p["points"], hiplib.ba_obs_array(p), p["cam"], build=build)
+    with ThreadPoolExecutor(4) as pool:
+        batch = list(pool.map(lambda p: make(p, False), probs))
+    with pytest.raises(hiplib.LpslamHipError):
+        batch[0].optimize(True, 1)
+    with pytest.raises(hiplib.LpslamHipError):
+        hiplib.ba_optimize_batch(batch, True, 1)
+    hiplib.ba_build_batch(batch)
+    with pytest.raises(hiplib.LpslamHipError):
+        hiplib.ba_build_batch(batch[:1])                     # built already
+    assert [b.solver()[0] for b in batch] == ["band", "dense", "band", "band", "dense", "band"]
+    logs = hiplib.ba_optimize_batch(batch, True, 6)
+    for i, (p, b, lg) in enumerate(zip(probs, batch, logs)):
+        one = make(p, True)
+        wl = one.optimize(True, 6)
+        wp, wx = one.state()
+        gp, gx = b.state()
+        assert wl.tobytes() == lg.tobytes() and np.array_equal(wp, gp) and np.array_equal(wx, gx), i
+        if i == 2:                                           # and the oracle, on the problem whose build shares a launch with much larger ones
+            op, ox, olog = oracle.ba_optimize(p["poses"], p["fixed"], p["points"], oracle.ba_obs(p), p["cam"], True, 6)
+            assert np.allclose(lg["chi2_after"], olog["chi2_after"], rtol=1e-9) and np.array_equal(lg["trials"], olog["trials"])
+        one.close()
+    # a batch-built problem is an ordinary problem: solved alone afterwards, from a reset, it gives the batch's bytes again
+    batch[0].reset()
+    again = batch[0].optimize(True, 6)
+    assert again.tobytes() == logs[0].tobytes()
+    assert all(b.timeouts() == (0, 0) for b in batch)
+    for b in batch:
+        b.close()
