@@ -824,7 +824,6 @@ def main():
         # callback.  Aggregate = all results / wall time from the first enqueue to the last result.
         if "tracker_multi" not in skip and "tracker" not in skip:
             try:
-                import threading
                 from lpslam_amd import manager
                 tm = {}
                 for n_mgr in (8, 16):

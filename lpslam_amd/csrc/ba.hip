@@ -3478,7 +3478,7 @@ int lpslam_hip_pose_optimize(lpslam_hip_ctx* ctx, double* pose7, const double* p
         bool seen = false;
         for (int spin = 0; ; ++spin) {
             if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) { seen = true; break; }
-            __builtin_ia32_pause();
+            lp_poll_pause(spin);
             if ((spin & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
         }
         if (!seen) {

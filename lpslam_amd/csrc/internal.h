@@ -1,5 +1,6 @@
 // internal.h -- shared host-side definitions of the lpslam HIP library (gfx950 only).
 #pragma once
+#include <sched.h>
 #include <hip/hip_runtime.h>
 #include <array>
 #include <atomic>
@@ -205,13 +206,18 @@ unsigned* lp_done_counter(lpslam_hip_ctx* c, int which);      // arrival counter
 bool lp_wait_recover(lpslam_hip_ctx* c, int which, hipStream_t s);      // after a failed lp_wait_done: counter re-zeroed; false = the stream is dead, leak what its kernels touch
 // the next sequence number of a completion flag: positive, never 0 (0 is what the flag is reset to before a launch)
 inline int lp_next_seq(int& s) { s = s >= 0x7ffffff0 ? 1 : s + 1; return s; }
+// One step of a host-side poll: a pause while the wait is young (a tracker call's kernel is back in 20 - 130 us), then the core is
+// OFFERED to other threads between looks (sched_yield returns at once when nobody else is runnable: a lone session keeps its latency).
+// Sixteen sessions in one process are sixteen workers and sixteen prefetch threads polling: spinning without yielding, they held every
+// core of the GPU's CPU share and starved the threads that feed them (tracker_multi: 16 managers slower than one).
+inline void lp_poll_pause(int spin) { if (spin < 256) __builtin_ia32_pause(); else sched_yield(); }
 // host side: true when the flag arrived; after ~20 ms without it the stream is synchronised and the flag checked once more
 inline bool lp_wait_done(int* flag, int seq, hipStream_t s)
 {
     const auto t0 = std::chrono::steady_clock::now();
     for (int spin = 0; ; ++spin) {
         if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return true;
-        __builtin_ia32_pause();
+        lp_poll_pause(spin);
         if ((spin & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
     }
     if (hipStreamSynchronize(s) != hipSuccess) return false;

@@ -1,0 +1,52 @@
+"""development: N LpSlamManager instances in one process on one GPU, aggregate frames/s (bench.py's tracker_multi alone).
+usage: [GPU_MAX_HW_QUEUES=..] dev_tracker_multi.py 1,4,8,16 [frames]"""
+import os, sys, time, threading
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from lpslam_amd import manager, synth, _build
+_build.host_library()
+W, H, KPTS, LEVELS, KF = 1280, 720, 2000, 8, 6
+counts = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "1,4,8,16").split(",")]
+n_frames = int(sys.argv[2]) if len(sys.argv) > 2 else 120
+k = synth.intrinsics(W, H)
+seq = synth.StereoSequence(W, H, 4)
+frames = [seq.frame(i) for i in range(n_frames)]
+extra = os.environ.get("LPSLAM_DEV_TRACKER_CFG", "")
+
+
+def make():
+    mg = manager.Manager()
+    for num in (0, 1):
+        c = manager.default_camera()
+        c.camera_number = num; c.f_x = k["fx"]; c.f_y = k["fy"]; c.c_x = k["cx"]; c.c_y = k["cy"]
+        c.resolution_x = W; c.resolution_y = H; c.focal_x_baseline = k["fxb"]
+        mg.set_camera(c)
+    mg.add_tracker("VSLAMStereo", '{"cameraSetup": "stereo", "slamKeypoints": %d, "numLevels": %d, "keyframeInterval": %d, "device": 0%s}' % (KPTS, LEVELS, KF, extra))
+    mg.count_results(); mg.provide_odometry(native=True)
+    mg.start()
+    return mg
+
+
+def run(n):
+    mgs = [make() for _ in range(n)]
+
+    def feed(mg):
+        for i, (l, r) in enumerate(frames):
+            mg.add_stereo((i + 1) * 40_000_000, l, r)
+    th = [threading.Thread(target=feed, args=(mg,)) for mg in mgs]
+    t0 = time.perf_counter()
+    for t in th: t.start()
+    want = n * len(frames)
+    while sum(mg.result_counts()[0] for mg in mgs) < want and time.perf_counter() - t0 < 120:
+        time.sleep(0.001)
+    dt = time.perf_counter() - t0
+    for t in th: t.join()
+    got = sum(mg.result_counts()[0] for mg in mgs); valid = sum(mg.result_counts()[1] for mg in mgs)
+    for mg in mgs: mg.stop()
+    return got, valid, dt
+
+
+run(1)
+for n in counts:
+    got, valid, dt = run(n)
+    print("GPU_MAX_HW_QUEUES=%s  %2d managers: %5d results (%d valid) in %.3f s = %.0f frames/s aggregate, %.0f per manager" % (os.environ.get("GPU_MAX_HW_QUEUES", "-"), n, got, valid, dt, got / dt, got / dt / n), flush=True)
