@@ -257,30 +257,38 @@ def _cpu_front_end(O, p, k, frames):
 
 
 def front_end_valu_issue():
-    """The bound the extraction kernels actually run against (profile-derived, like `traffic`): a CDNA compute unit starts at most one
-    vector instruction per cycle, so SQ_INSTS_VALU / (compute units x clock) is the shortest time a kernel's vector instructions can
-    issue in.  From the newest profiles/<tag>_pmc.json and the kernel statistics of the same tag (tools/valu_roofline.py)."""
+    """The bound the extraction kernels run against, profile-derived like `traffic`: vector-instruction issue, priced against the MEASURED
+    ceiling.  tools/dev/valu_issue_bench.hip (profiles/r05_valu_issue.txt): a gfx950 compute unit issues 1.75 wave64 instructions of
+    the 32-bit encoded kind (VOP1 / VOP2) and 0.96 of the wide kinds (VOP3 / VOP3P) per shader-clock cycle, at 2.15 - 2.40 GHz under
+    load; a kernel's ceiling is the harmonic mix over its (static) instruction mix (tools/valu_mix.py).  floor_us = SQ_INSTS_VALU per
+    launch / (compute units x clock x ceiling), from the newest profiles/<tag>_pmc.json and the kernel statistics of the same tag."""
     try:
         import csv
         pdir = os.path.join(ROOT, "profiles")
         tags = sorted(f[:-len("_pmc.json")] for f in os.listdir(pdir) if f.endswith("_pmc.json") and os.path.exists(os.path.join(pdir, f[:-len("_pmc.json")] + "_bench_kernel_stats.csv")))
-        if not tags:
+        mixes = sorted(f for f in os.listdir(pdir) if f.endswith("_valu_mix.json"))
+        if not tags or not mixes:
             return None
         tag = tags[-1]
         pmc = json.load(open(os.path.join(pdir, tag + "_pmc.json")))
+        mix = json.load(open(os.path.join(pdir, mixes[-1])))
         kern = pmc.get("kernels", pmc)
         dur = {}
         for r in csv.DictReader(open(os.path.join(pdir, tag + "_bench_kernel_stats.csv"))):
             dur[r["Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].replace("<true>", "").replace("<false>", "")] = float(r["AverageNs"]) / 1e3
-        clock_ghz = 2.4
-        out = {"source": "profiles/%s_pmc.json + _bench_kernel_stats.csv" % tag, "clock_GHz": clock_ghz,
-               "note": "floor_us = SQ_INSTS_VALU per launch / (compute units x clock): one vector instruction per compute unit and cycle; the direct kernels use 256 compute units, the queued (_q) ones of the timed loop 128"}
+        clock_ghz = 2.3
+        out = {"source": "profiles/%s_pmc.json + _bench_kernel_stats.csv; ceilings: profiles/%s (rates measured: profiles/r05_valu_issue.txt)" % (tag, mixes[-1]), "clock_GHz": clock_ghz,
+               "measured_issue_rates_per_cu_cycle": mix.get("rates_per_cu_cycle"),
+               "note": "floor_us = SQ_INSTS_VALU per launch / (compute units x clock x measured issue ceiling of the kernel's instruction mix); the direct kernels use 256 compute units, the queued (_q) ones of the timed loop 128"}
         for name in ("k_fast_cells", "k_describe", "k_fast_cells_q", "k_describe_q"):
             v = kern.get(name)
-            if v and "SQ_INSTS_VALU" in v and name in dur:
+            m = mix["kernels"].get(name)
+            if v and m and "SQ_INSTS_VALU" in v and name in dur:
                 cus = 128 if name.endswith("_q") else 256
-                floor_us = v["SQ_INSTS_VALU"]["mean_per_launch"] / (cus * clock_ghz * 1e3)
-                out[name] = {"valu_instructions_per_launch": int(v["SQ_INSTS_VALU"]["mean_per_launch"]), "floor_us": round(floor_us, 1), "measured_us": round(dur[name], 1), "frac": round(floor_us / dur[name], 3)}
+                n = v["SQ_INSTS_VALU"]["mean_per_launch"]
+                floor_us = n / (cus * clock_ghz * 1e3 * m["issue_ceiling_per_cu_cycle"])
+                out[name] = {"valu_instructions_per_launch": int(n), "issue_ceiling_per_cu_cycle": m["issue_ceiling_per_cu_cycle"], "issued_per_cu_cycle": round(n / (cus * clock_ghz * 1e3 * dur[name]), 3),
+                             "floor_us": round(floor_us, 1), "measured_us": round(dur[name], 1), "frac": round(floor_us / dur[name], 3)}
         return out
     except Exception as e:      # noqa: BLE001 -- profile-derived decoration only
         return {"error": str(e)}

@@ -5,7 +5,7 @@ set -e
 TAG=${1:-r03}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 timeout -k 10 900 python bench.py > gpurun_out/${TAG}_bench.log 2>&1
-tail -1 gpurun_out/${TAG}_bench.log > gpurun_out/${TAG}_bench.json
+grep "^{\"metric\"" gpurun_out/${TAG}_bench.log | tail -1 > gpurun_out/${TAG}_bench.json
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d gpurun_out/ks -o ks --output-format csv -- python3 bench.py --no-cpu --no-extras > gpurun_out/ks.log 2>&1
 cp $(find gpurun_out/ks -name "*kernel_stats.csv" | head -1) gpurun_out/${TAG}_bench_kernel_stats.csv
 python3 tools/kstats.py gpurun_out/ks > gpurun_out/${TAG}_bench_kernel_stats.txt
