@@ -1920,6 +1920,51 @@ __device__ double g_po_stamps[16];
 #define PO_ST_ARG
 #endif
 
+// One observation's share of the 28 sums (upper triangle of H, b, robustified chi2) at the pose (R, t)
+__device__ __forceinline__ void po_accumulate(const BaCam& cam, const double (&R)[9], const double (&t)[3], const lpslam_hip_ba_obs& o, const double (&X)[3], int robust, double (&acc)[PO_NV])
+{
+#pragma clang fp contract(fast)
+    double e[3], pc[3], B[3][6], iz;
+    const int D = po_residual(cam, R, t, X, o, e, pc, &iz);
+    const double om = o.inv_sigma2;
+    const double chi = om * (e[0] * e[0] + e[1] * e[1] + (D == 3 ? e[2] * e[2] : 0.0));
+    const double delta = D == 3 ? cam.hub_stereo : cam.hub_mono;
+    double w = om, c = chi;
+    if (robust && delta > 0) { double r0, r1; po_huber(chi, delta, &r0, &r1); w *= r1; c = r0; }
+    acc[27] += c;
+    po_jacobian(cam, pc, iz, D, B);
+    // w B once (18 products), then every entry is three fused multiply-adds onto its running sum; the columns that
+    // are structurally zero (B[0][4], B[1][3], B[2][4]) are skipped by hand -- the compiler may not drop x * 0
+    double wB[3][6], we[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        we[r] = -w * e[r];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) wB[r][a] = w * B[r][a];
+    }
+    int idx = 0;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+#pragma unroll
+        for (int c2 = a; c2 < 6; ++c2) {
+            double s2 = acc[idx];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const bool zero = (r == 0 && (a == 4 || c2 == 4)) || (r == 1 && (a == 3 || c2 == 3)) || (r == 2 && (a == 4 || c2 == 4));
+                if (!zero) s2 = fma(wB[r][a], B[r][c2], s2);
+            }
+            acc[idx++] = s2;
+        }
+        double s3 = acc[21 + a];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const bool zero = (r == 0 && a == 4) || (r == 1 && a == 3) || (r == 2 && a == 4);
+            if (!zero) s3 = fma(B[r][a], we[r], s3);
+        }
+        acc[21 + a] = s3;
+    }
+}
+
 // One pass over the active observations at pose p7: the 27 sums of the linearised system (upper triangle of H, then b) and the
 // (robustified) chi2 as the 28th, into sh.sums (valid until the next pass).  A trial's chi2 and the NEXT iteration's linearisation are the same
 // pass: the trial is accepted nearly always, and then its pose is the pose to linearise at (one reduction less per Levenberg
@@ -1940,47 +1985,10 @@ __device__ __forceinline__ void po_pass(const BaCam& cam, const double (&p7)[7],
     const int lane_stride = d.n <= PO_T / 4 ? 4 : d.n <= PO_T / 2 ? 2 : 1;
     for (int k = (tid % lane_stride) ? d.n : tid / lane_stride; k < d.n; k += PO_T / lane_stride) {
         if (!d.act[k]) continue;
-        double e[3], pc[3], B[3][6], X[3], iz;
+        double X[3];
         lpslam_hip_ba_obs o;
         d.get(k, o, X);
-        const int D = po_residual(cam, R, t, X, o, e, pc, &iz);
-        const double om = o.inv_sigma2;
-        const double chi = om * (e[0] * e[0] + e[1] * e[1] + (D == 3 ? e[2] * e[2] : 0.0));
-        const double delta = D == 3 ? cam.hub_stereo : cam.hub_mono;
-        double w = om, c = chi;
-        if (robust && delta > 0) { double r0, r1; po_huber(chi, delta, &r0, &r1); w *= r1; c = r0; }
-        acc[27] += c;
-        po_jacobian(cam, pc, iz, D, B);
-        // w B once (18 products), then every entry is three fused multiply-adds onto its running sum; the columns that
-        // are structurally zero (B[0][4], B[1][3], B[2][4]) are skipped by hand -- the compiler may not drop x * 0
-        double wB[3][6], we[3];
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            we[r] = -w * e[r];
-#pragma unroll
-            for (int a = 0; a < 6; ++a) wB[r][a] = w * B[r][a];
-        }
-        int idx = 0;
-#pragma unroll
-        for (int a = 0; a < 6; ++a) {
-#pragma unroll
-            for (int c2 = a; c2 < 6; ++c2) {
-                double s2 = acc[idx];
-#pragma unroll
-                for (int r = 0; r < 3; ++r) {
-                    const bool zero = (r == 0 && (a == 4 || c2 == 4)) || (r == 1 && (a == 3 || c2 == 3)) || (r == 2 && (a == 4 || c2 == 4));
-                    if (!zero) s2 = fma(wB[r][a], B[r][c2], s2);
-                }
-                acc[idx++] = s2;
-            }
-            double s3 = acc[21 + a];
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                const bool zero = (r == 0 && a == 4) || (r == 1 && a == 3) || (r == 2 && a == 4);
-                if (!zero) s3 = fma(B[r][a], we[r], s3);
-            }
-            acc[21 + a] = s3;
-        }
+        po_accumulate(cam, R, t, o, X, robust, acc);
     }
     PO_STAMP(1);
 #ifdef LPSLAM_PO_DUP_REDUCE
@@ -2185,6 +2193,166 @@ __global__ __launch_bounds__(PO_T) void k_pose_optimize(double* pose7, const dou
         __threadfence_system();
         __syncthreads();
         if (tid == 0) __hip_atomic_store(done_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// ---- the same flow in ONE wavefront, for up to 256 observations (what a tracked frame has) --------------------------------------------
+// k_pose_optimize's trial is 2.45 us, of which the 28-value reduction across four wavefronts is 0.8-1.0 (quad step in registers, LDS
+// transposition, two workgroup barriers).  One wavefront needs no barrier at all: lane l carries observations l, l + 64, ... (OPL of
+// them, a template parameter: the loop is unrolled), every lane writes its 28 partial sums into a [28][65] LDS array (consecutive lanes,
+// consecutive words), lanes (value q, half h) add 32 partials each in a fixed tree and meet their partner by one DPP exchange, the 28
+// totals come back to every lane by broadcast reads -- ~95 instructions and four LDS round trips of a wavefront that waits for nobody.
+// The serial section (lambda control, 6 x 6 solve, pose update) is the same code on replicated registers.  Per trial: ~1.2 us at <= 64
+// observations ... ~1.8 at 256.  The sums' order differs from the four-wavefront kernel's (results move in the last bits); which kernel
+// runs depends on the observation count alone.
+constexpr int PO1_ROW = 65;                 // row of the transposition array: 64 lanes + 1 (rows start on different banks)
+__device__ __forceinline__ void po_reduce28_w1(const double (&acc)[PO_NV], double* tr, double* out, double (&sums)[PO_NV])
+{
+    const int lane = threadIdx.x;
+#pragma unroll
+    for (int q = 0; q < PO_NV; ++q) tr[q * PO1_ROW + lane] = acc[q];
+    __syncthreads();                                       // (one wavefront: an ordering point for the compiler and the LDS queue, not a wait)
+    const int q = lane >> 1, h = lane & 1;
+    double s = 0;
+    if (q < PO_NV) {
+        const double* row = tr + q * PO1_ROW + 32 * h;
+        double v[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) v[i] = row[i];
+#pragma unroll
+        for (int w = 16; w >= 1; w >>= 1)
+#pragma unroll
+            for (int i = 0; i < w; ++i) v[i] = v[2 * i] + v[2 * i + 1];
+        s = v[0];
+    }
+    s += quad_swap<0xB1>(s);                               // the other half
+    if (q < PO_NV && h == 0) out[q] = s;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < PO_NV; ++i) sums[i] = out[i];
+}
+
+template <int OPL>
+__global__ __launch_bounds__(64) void k_pose_optimize_w1(double* pose7, const PoObs* packed, int n, BaCam cam, uint8_t* outlier, int* n_inliers, int* done_flag, int seq)
+{
+#pragma clang fp contract(fast)
+    __shared__ double tr[PO_NV * PO1_ROW];
+    __shared__ double out28[32];
+    __shared__ PoObs cache[64 * OPL];
+    const int lane = threadIdx.x;
+    static_assert(sizeof(PoObs) == 7 * sizeof(double), "PoObs is copied as doubles");
+    for (int i = lane; i < 7 * n; i += 64) reinterpret_cast<double*>(cache)[i] = reinterpret_cast<const double*>(packed)[i];      // page-locked host memory, over PCIe
+    double pose[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) pose[i] = pose7[i];
+    __syncthreads();
+    unsigned act = 0;                                      // bit u: observation lane + 64 u is an inlier of the last classification
+#pragma unroll
+    for (int u = 0; u < OPL; ++u) if (lane + 64 * u < n) act |= 1u << u;
+    auto pass = [&](const double (&p7)[7], int robust, double (&sums)[PO_NV]) __attribute__((always_inline)) {
+        double R[9];
+        po_quat_to_rot(p7, R);
+        const double t[3] = {p7[4], p7[5], p7[6]};
+        double acc[PO_NV];
+#pragma unroll
+        for (int q = 0; q < PO_NV; ++q) acc[q] = 0;
+        // (a branch-free form with masked slots, so that a lane's observations interleave, measured no faster: the pass is bound by the
+        // one SIMD's issue rate, ~0.45 us per observation and lane -- which is why the four-wavefront kernel keeps the larger frames)
+#pragma unroll
+        for (int u = 0; u < OPL; ++u) {
+            if (!((act >> u) & 1u)) continue;
+            const PoObs c = cache[lane + 64 * u];
+            lpslam_hip_ba_obs o;
+            o.pose = 0; o.point = 0; o.u = c.u; o.v = c.v; o.ur = c.ur; o.inv_sigma2 = c.w;
+            const double X[3] = {c.X[0], c.X[1], c.X[2]};
+            po_accumulate(cam, R, t, o, X, robust, acc);
+        }
+        po_reduce28_w1(acc, tr, out28, sums);
+    };
+    int robust = 1, n_bad_last = 0, passes = 0;
+#ifdef LPSLAM_PO_STAMPS
+    double po_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, po_last = (double)clock64();
+#endif
+    for (int round = 0; round < 4; ++round) {
+        // (the control flow of k_pose_optimize: g2o's Levenberg between the passes, up to ten iterations of up to ten trials)
+        double sys[PO_NV], got[PO_NV], x[6], trial[7];
+        pass(pose, robust, sys);
+        ++passes;
+        double lambda = 1e-5 * fmax(fmax(fmax(fabs(sys[0]), fabs(sys[6])), fmax(fabs(sys[11]), fabs(sys[15]))), fmax(fabs(sys[18]), fabs(sys[20])));
+        double ni = 2, current_chi = sys[27];
+        int it = 0, qmax = 1;
+        int ok = po_solve_trial(sys, lambda, pose, x, trial PO_ST_ARG);
+        for (;;) {
+            pass(trial, robust, got);
+            ++passes;
+            const double temp = ok ? got[27] : DBL_MAX;
+            double rho = current_chi - temp, scale = 0;
+            if (ok) {
+#pragma unroll
+                for (int j = 0; j < 6; ++j) scale += x[j] * (lambda * x[j] + sys[21 + j]);
+            }
+            scale += 1e-3;
+            rho *= po_rcp(scale);
+            if (rho > 0 && isfinite(temp)) {
+                const double t3 = 2 * rho - 1;
+                double alpha = 1. - t3 * t3 * t3;
+                alpha = fmin(alpha, 2. / 3.);
+                lambda *= fmax(1. / 3., alpha);
+                ni = 2;
+                current_chi = temp;
+#pragma unroll
+                for (int i = 0; i < 7; ++i) pose[i] = trial[i];
+#pragma unroll
+                for (int q = 0; q < PO_NV - 1; ++q) sys[q] = got[q];         // the pass just made linearised at the accepted pose
+            } else {
+                lambda *= ni; ni *= 2;
+            }
+            if (rho < 0 && qmax < 10) ++qmax;                                // another trial of this iteration
+            else {
+                ++it;
+                if (qmax == 10 || rho == 0 || it == 10) break;
+                qmax = 1;
+            }
+            ok = po_solve_trial(sys, lambda, pose, x, trial PO_ST_ARG);
+        }
+        // classification with the plain chi2 of this round's pose
+        double R[9];
+        po_quat_to_rot(pose, R);
+        int bad = 0;
+        act = 0;
+#pragma unroll
+        for (int u = 0; u < OPL; ++u) {
+            const int k = lane + 64 * u;
+            int is_out = 0;
+            if (k < n) {
+                const PoObs c = cache[k];
+                lpslam_hip_ba_obs o;
+                o.pose = 0; o.point = 0; o.u = c.u; o.v = c.v; o.ur = c.ur; o.inv_sigma2 = c.w;
+                double e[3], pc[3];
+                const int D = po_residual(cam, R, pose + 4, c.X, o, e, pc);
+                const double chi = o.inv_sigma2 * (e[0] * e[0] + e[1] * e[1] + (D == 3 ? e[2] * e[2] : 0.0));
+                const double thr = D == 3 ? 7.81473 : 5.99146;
+                is_out = thr < chi ? 1 : 0;
+                if (!is_out) act |= 1u << u;
+            }
+            bad += __popcll(__ballot(is_out));
+        }
+        n_bad_last = bad;
+        if (round == 2) robust = 0;
+        if (n - n_bad_last < 5) break;
+    }
+#pragma unroll
+    for (int u = 0; u < OPL; ++u) if (lane + 64 * u < n) outlier[lane + 64 * u] = ((act >> u) & 1u) ? 0 : 1;       // the last classification made
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 7; ++i) pose7[i] = pose[i];
+        n_inliers[0] = n - n_bad_last;
+        n_inliers[1] = passes;
+    }
+    if (done_flag) {
+        __threadfence_system();
+        __syncthreads();
+        if (lane == 0) __hip_atomic_store(done_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -3470,6 +3638,17 @@ int lpslam_hip_pose_optimize(lpslam_hip_ctx* ctx, double* pose7, const double* p
         int* flag = (int*)(hb + 64);
         const int seq = lp_next_seq(ctx->po_seq);
         __atomic_store_n(flag, 0, __ATOMIC_RELAXED);          // (the block is shared with the matchers' staging: whatever they left here is not a sequence number)
+        static const bool four_waves_env = [] { const char* e = getenv("LPSLAM_HIP_PO_FOUR_WAVES"); return e && atoi(e) != 0; }();      // measurements: the round-4 kernel for every size
+        static const int po1_max = [] { const char* e = getenv("LPSLAM_HIP_PO_W1_MAX"); const int v = e ? atoi(e) : 128; return std::min(std::max(v, 0), 256); }();      // measurements: where the one-wavefront kernel hands over
+        if (n_obs <= po1_max && !four_waves_env) {
+            // a tracked frame: the whole flow in one wavefront, 1 .. 4 observations per lane
+            const int opl = std::max(1, (n_obs + 63) / 64);
+            double* a0 = (double*)hb; uint8_t* a4 = hb + off_flags; int* a5 = (int*)(hb + 56);
+            if (opl == 1) hipLaunchKernelGGL(k_pose_optimize_w1<1>, dim3(1), dim3(64), 0, s, a0, (const PoObs*)packed, n_obs, c, a4, a5, flag, seq);
+            else if (opl == 2) hipLaunchKernelGGL(k_pose_optimize_w1<2>, dim3(1), dim3(64), 0, s, a0, (const PoObs*)packed, n_obs, c, a4, a5, flag, seq);
+            else if (opl == 3) hipLaunchKernelGGL(k_pose_optimize_w1<3>, dim3(1), dim3(64), 0, s, a0, (const PoObs*)packed, n_obs, c, a4, a5, flag, seq);
+            else hipLaunchKernelGGL(k_pose_optimize_w1<4>, dim3(1), dim3(64), 0, s, a0, (const PoObs*)packed, n_obs, c, a4, a5, flag, seq);
+        } else
         hipLaunchKernelGGL(k_pose_optimize<true>, dim3(1), dim3(PO_T), lds, s, (double*)hb, (const double*)nullptr, (const lpslam_hip_ba_obs*)nullptr, packed, n_obs, c,
                            hb + off_flags, (int*)(hb + 56), cache_n, flag, seq);
         LP_HIP(hipGetLastError());

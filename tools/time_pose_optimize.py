@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from lpslam_amd import hip, synth
 hip.LIB_PATH = os.environ.get("LPSLAM_LIB", hip.LIB_PATH); hip.load()
 ctx = hip.Context(320, 240, 400, 1.2, 4, max_images=1)
-for n in (100, 200, 300, 500, 1000, 2000):
+for n in (30, 60, 100, 120, 180, 200, 250, 300, 500, 1000, 2000):
     prob = synth.ba_problem(2, n, 2 * n, 640, 480, seq_id=n)
     sel = prob["obs_pose"] == 1
     obs = hip.ba_obs_array(prob)[sel]
