@@ -834,6 +834,7 @@ def main():
             try:
                 from lpslam_amd import manager
                 tm = {}
+                hip.set_flat_priorities(True)                 # many sessions in one process: every stream at the default priority (lpslam_hip.h)
                 for n_mgr in (8, 16):
                     mgs = []
                     for i in range(n_mgr):
@@ -867,10 +868,13 @@ def main():
                     tm["managers_%d" % n_mgr] = {"frames": int(sum(c[0] for c in counts)), "valid": int(sum(c[1] for c in counts)),
                                                  "aggregate_frames_per_s": round(sum(c[0] for c in counts) / t_all, 1), "per_manager_frames_per_s": round(sum(c[0] for c in counts) / t_all / n_mgr, 1)}
                     del mgs
-                tm["note"] = "N LpSlamManager instances (each its own context, streams, worker and mapping pipeline) fed 120 stereo frames each by N threads; compiled odometry and result callbacks"
+                hip.set_flat_priorities(None)
+                tm["note"] = "lpslam_hip_set_flat_priorities(1); N LpSlamManager instances (each its own context, streams, worker and mapping pipeline) fed 120 stereo frames each by N threads; compiled odometry and result callbacks"
                 extras["tracker_multi"] = tm
             except Exception as e:      # noqa: BLE001
                 extras["tracker_multi"] = {"error": str(e)}
+            finally:
+                hip.set_flat_priorities(None)
         # the monocular tracker on the same boundary: two-view initialisation, then tracking with triangulated keyframes
         try:
             mg = manager.Manager()

@@ -79,6 +79,11 @@ int lpslam_hip_set_mapping_reserve(lpslam_hip_ctx* ctx, int32_t cus_per_xcd);
  * compute unit that is NOT reserved, on a stream of its own; *landed (may be NULL) = how many sit.  Extraction launched meanwhile
  * finds room on the reserved compute units only -- the placement under which it must still complete (tests/test_frontend_gpu.py). */
 int lpslam_hip_debug_occupy_unreserved(lpslam_hip_ctx* ctx, int32_t microseconds, int32_t* landed);
+/* Process-wide: create the streams of contexts made FROM NOW ON at the default priority (1) or in the three classes (0, the default: main /
+ * low-priority prefetch / high-priority solves; -1: back to the environment, LPSLAM_HIP_FLAT_PRIORITIES).  A process that hosts many
+ * sessions per GPU (one LpSlamManager per sequence, src/Manager/SlamManager.cpp:54-61) should set 1 before it creates them: every
+ * priority class takes its own set of hardware queues, and beyond a few the command processor time-slices them. */
+int lpslam_hip_set_flat_priorities(int32_t flat);
 int lpslam_hip_sync(lpslam_hip_ctx* ctx);
 /* Geometry derived from the configuration (pyramid sizes, per-level keypoint quota). */
 int lpslam_hip_level_info(lpslam_hip_ctx* ctx, int32_t* widths, int32_t* heights, int32_t* pitches,

@@ -143,6 +143,22 @@ void lp_ctx_register(lpslam_hip_ctx* c, bool add)
     if (add) g_contexts.push_back(c);
     else g_contexts.erase(std::remove(g_contexts.begin(), g_contexts.end(), c), g_contexts.end());
 }
+// Stream priorities cost hardware queues: every priority class a process uses takes its own set (four per class), and a process
+// that hosts several sessions -- a main, a low-priority prefetch and high-priority solve streams each -- then keeps twelve queues busy
+// that the command processor time-slices.  A single session wants the classes (the current frame's matchers and pose optimisations win
+// the compute units from the background extraction and never share a queue with it); a process with MANY sessions per
+// GPU does better with every stream at the default priority: lpslam_hip_set_flat_priorities(1) before the sessions are created (or
+// LPSLAM_HIP_FLAT_PRIORITIES=1).  Measured (tools/dev_tracker_multi.py, MI355X): 8 managers 2800 -> 3380 frames/s aggregate, 16 managers
+// 1980 -> 2400.  Mixing both kinds of streams in one process is worse than either (a switch at the third context: 2470 / 1590).
+static std::atomic<int> g_flat_priorities{-1};          // -1: the environment decides
+bool lp_flat_priorities()
+{
+    const int v = g_flat_priorities.load();
+    if (v >= 0) return v != 0;
+    static const bool env = [] { const char* e = getenv("LPSLAM_HIP_FLAT_PRIORITIES"); return e && atoi(e) != 0; }();
+    return env;
+}
+extern "C" int lpslam_hip_set_flat_priorities(int32_t flat) { g_flat_priorities.store(flat < 0 ? -1 : (flat ? 1 : 0)); return LPSLAM_HIP_OK; }
 size_t lp_pool_flush_device(int device)
 {
     size_t freed = 0;
@@ -196,7 +212,7 @@ int lp_pool_alloc(lpslam_hip_ctx* c, size_t bytes, void** out, size_t* capacity)
 // every local-map matcher call waited 0.2 ms behind the prefetched extraction); different priorities never share a queue.
 static hipError_t lp_fe_stream_create(hipStream_t* s, bool background)
 {
-    if (background) {
+    if (background && !lp_flat_priorities()) {
         int prio_least = 0, prio_greatest = 0;
         if (hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) == hipSuccess && prio_least != prio_greatest &&
             hipStreamCreateWithPriority(s, hipStreamNonBlocking, prio_least) == hipSuccess) return hipSuccess;
@@ -215,8 +231,9 @@ hipStream_t lp_stream_acquire(lpslam_hip_ctx* c)
     // kernels are small and latency bound, the front end's fill the chip for 100 us at a time
     int prio_least = 0, prio_greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    const bool flat = lp_flat_priorities();
     hipStream_t s = nullptr;
-    if (hipStreamCreateWithPriority(&s, hipStreamNonBlocking, prio_greatest) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if ((flat ? hipStreamCreateWithFlags(&s, hipStreamNonBlocking) : hipStreamCreateWithPriority(&s, hipStreamNonBlocking, prio_greatest)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     return s;
 }
 

@@ -172,6 +172,7 @@ void lp_pin_big_free(lpslam_hip_ctx* c, void* p, size_t capacity);
 void* lp_pin_alloc(lpslam_hip_ctx* c);          // 8 KB of page-locked host memory, recycled through the context (nullptr on failure)
 void lp_pin_free(lpslam_hip_ctx* c, void* p);
 int lp_launch_pyramid(lpslam_hip_ctx* c, int first, int n_images);
+bool lp_flat_priorities();             // several contexts live in the process: new streams at the default priority (api.hip)
 int lp_fe_calibrate(lpslam_hip_ctx* c, int reserve_cus_per_xcd);
 int lp_fe_occupy_unreserved(lpslam_hip_ctx* c, int microseconds, int* landed);
 int lp_launch_remap(lpslam_hip_ctx* c, int image, int eye);

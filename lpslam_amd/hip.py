@@ -27,7 +27,7 @@ BA_LOG_DTYPE = np.dtype([("chi2_before", "<f8"), ("chi2_after", "<f8"), ("lambda
 # every symbol include/lpslam_hip.h declares (checked by tests/test_abi.py against the header text)
 SYMBOLS = [
     "lpslam_hip_last_error", "lpslam_hip_device_count", "lpslam_hip_create", "lpslam_hip_destroy",
-    "lpslam_hip_stream", "lpslam_hip_set_mapping_reserve", "lpslam_hip_debug_occupy_unreserved", "lpslam_hip_sync", "lpslam_hip_timer_begin", "lpslam_hip_timer_end", "lpslam_hip_timer_read", "lpslam_hip_level_info", "lpslam_hip_max_keypoints_per_image",
+    "lpslam_hip_stream", "lpslam_hip_set_mapping_reserve", "lpslam_hip_set_flat_priorities", "lpslam_hip_debug_occupy_unreserved", "lpslam_hip_sync", "lpslam_hip_timer_begin", "lpslam_hip_timer_end", "lpslam_hip_timer_read", "lpslam_hip_level_info", "lpslam_hip_max_keypoints_per_image",
     "lpslam_hip_image_ptr", "lpslam_hip_upload_image", "lpslam_hip_host_alloc", "lpslam_hip_host_free", "lpslam_hip_host_register", "lpslam_hip_host_unregister", "lpslam_hip_upload_images_async", "lpslam_hip_set_rectify_map", "lpslam_hip_set_mask", "lpslam_hip_upload_raw_image", "lpslam_hip_remap_staged", "lpslam_hip_extract", "lpslam_hip_extract_range", "lpslam_hip_stage_pyramid",
     "lpslam_hip_stage_fast", "lpslam_hip_stage_distribute", "lpslam_hip_stage_describe",
     "lpslam_hip_keypoint_count", "lpslam_hip_get_keypoints", "lpslam_hip_get_frame", "lpslam_hip_get_pyramid_level",
@@ -94,6 +94,11 @@ def _check(rc):
 
 def _p(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def set_flat_priorities(flat):
+    """process-wide: streams of contexts created from now on at the default priority (True) or in the three classes (False); None: the environment"""
+    _check(load().lpslam_hip_set_flat_priorities(C.c_int32(-1 if flat is None else (1 if flat else 0))))
 
 
 def device_count():

@@ -3,7 +3,8 @@ usage: [GPU_MAX_HW_QUEUES=..] dev_tracker_multi.py 1,4,8,16 [frames]"""
 import os, sys, time, threading
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from lpslam_amd import manager, synth, _build
+from lpslam_amd import manager, synth, _build, hip
+if os.environ.get("LPSLAM_DEV_FLAT"): hip.set_flat_priorities(True)
 _build.host_library()
 W, H, KPTS, LEVELS, KF = 1280, 720, 2000, 8, 6
 counts = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "1,4,8,16").split(",")]
