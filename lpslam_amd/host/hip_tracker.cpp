@@ -1387,7 +1387,7 @@ bool HipVslamTrackerBase::detectAndCloseLoop(FrameData& cur, int c)
         pose_centre(m_kfs[(size_t)a].pose.q, m_kfs[(size_t)a].pose.t, C);
         cands.emplace_back(std::sqrt((C[0] - Cc[0]) * (C[0] - Cc[0]) + (C[1] - Cc[1]) * (C[1] - Cc[1]) + (C[2] - Cc[2]) * (C[2] - Cc[2])), a);
     }
-    if (cands.empty()) return false;
+    if (cands.empty()) { m_loopSets.clear(); return false; }
     std::sort(cands.begin(), cands.end());
     if (cands.size() > 48) cands.resize(48);
     // with a vocabulary: [UPSTREAM] loop_detector::detect_loop_candidates -- keyframes outside the covisibility that share words with
@@ -1401,7 +1401,7 @@ bool HipVslamTrackerBase::detectAndCloseLoop(FrameData& cur, int c)
         exclude[c] = 1;
         cands.clear();
         for (auto& sc : m_bowDb.query(kc.bow, exclude, min_score, newest_candidate)) { cands.emplace_back(-sc.first, sc.second); if (cands.size() >= 8) break; }
-        if (cands.empty()) return false;
+        if (cands.empty()) { m_loopSets.clear(); return false; }
     }
     const int scratch = previousSlot(cur.slot);                  // the previous frame's slot pair is free for the descriptors of a candidate
     std::vector<int32_t> mq((size_t)m_maxKp), mt((size_t)m_maxKp), md((size_t)m_maxKp);
@@ -1450,6 +1450,34 @@ bool HipVslamTrackerBase::detectAndCloseLoop(FrameData& cur, int c)
         for (int k = 0; k < nm; ++k)
             if (kc.landmark[(size_t)mq[k]] >= 0 && ka.landmark[(size_t)mt[k]] >= 0 && resolve(kc.landmark[(size_t)mq[k]]) != resolve(ka.landmark[(size_t)mt[k]])) v.pairs.emplace_back(mq[k], mt[k]);
         if (v.pairs.size() >= 20) votes.push_back(std::move(v));         // [UPSTREAM] num_matches >= 20 to try a candidate
+    }
+    if (votes.empty()) { m_loopSets.clear(); return false; }
+    // [UPSTREAM] loop_detector::find_continuously_detected_keyframe_sets (min_continuity_ = 3; ORB-SLAM's covisibility consistency,
+    // toggled with the detector at src/Trackers/OpenVSLAMTrackerBase.cpp:250-255): a candidate stands for the set of itself and its
+    // covisibility neighbours; its continuity is one more than that of a set detected at the PREVIOUS keyframe that shares a keyframe
+    // with it (0 when there is none); only candidates whose continuity has reached 3 -- detected at four keyframes in a row -- go on to
+    // the Sim3 verification.  A keyframe without a candidate breaks the chain.
+    {
+        std::vector<std::pair<std::vector<int>, int>> sets_now;
+        std::vector<Vote> accepted;
+        for (auto& v : votes) {
+            std::vector<int> group = covisible(v.kf, (int)m_kfs.size(), 15);
+            group.push_back(v.kf);
+            std::sort(group.begin(), group.end());
+            int cont = 0;
+            for (auto& prev : m_loopSets) {
+                bool shared = false;
+                for (size_t i = 0, j = 0; i < group.size() && j < prev.first.size() && !shared;) {
+                    if (group[i] == prev.first[j]) shared = true;
+                    else if (group[i] < prev.first[j]) ++i; else ++j;
+                }
+                if (shared) cont = std::max(cont, prev.second + 1);
+            }
+            sets_now.emplace_back(std::move(group), cont);
+            if (cont >= 3) accepted.push_back(std::move(v));
+        }
+        m_loopSets = std::move(sets_now);
+        votes = std::move(accepted);
     }
     if (votes.empty()) return false;
     std::sort(votes.begin(), votes.end(), [](const Vote& a, const Vote& b) { return a.pairs.size() != b.pairs.size() ? a.pairs.size() > b.pairs.size() : a.kf > b.kf; });
@@ -1588,6 +1616,7 @@ bool HipVslamTrackerBase::detectAndCloseLoop(FrameData& cur, int c)
         }
     }
     ++m_stats.loops_closed;
+    m_loopSets.clear();
     logMessage(LpSlamLogLevel_Info, "VSLAM loop closed: keyframe " + std::to_string(c) + " with " + std::to_string(a0) + ", " + std::to_string(n_inl[(size_t)best]) + " inliers");
     return true;
 }

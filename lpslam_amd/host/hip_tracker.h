@@ -189,6 +189,7 @@ protected:
     bool m_haveVelocity = false;
     int m_framesSinceKeyframe = 0;
     std::vector<Keyframe> m_kfs;                      // the map's keyframes, index = id
+    std::vector<std::pair<std::vector<int>, int>> m_loopSets;      // (keyframe set, continuity) of the loop candidates detected at the previous keyframe ([UPSTREAM] cont_detected_keyfrm_sets_)
     std::unordered_map<int, Landmark> m_landmarks;
     std::unordered_map<int, int> m_replaced;          // merged landmark -> the one that took its observations
     int m_nextLandmarkId = 0;

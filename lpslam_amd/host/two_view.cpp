@@ -549,125 +549,238 @@ int sim3_solve_ransac(const double* p1c, const double* p2c, const double* obs1, 
 
 
 // ---- [UPSTREAM] solve::pnp_solver (relocalisation without a pose prior) -------------------------------------------------------------
-// The upstream solver is EPnP inside a RANSAC over 4-match samples; here the minimal solver is the classical three-point one
-// (Grunert's formulation: the two depth ratios u = s2 / s1, v = s3 / s1 from the law of cosines; v is a root of a quartic that is
-// built by polynomial arithmetic, u follows linearly, the pose from Horn's absolute orientation of the three points), the fourth
-// match of a sample picks among its up to four solutions, and inliers are counted by the reprojection error (chi-square 5.991 at
-// the keypoint's level).  The pose optimiser on the device refines the winner, as upstream refines EPnP's.
+// EPnP (Lepetit, Moreno-Noguer, Fua: "EPnP: An Accurate O(n) Solution to the PnP Problem", IJCV 2009) inside a RANSAC over 4-match
+// samples, then a refit on the inliers of the best sample -- the structure of OpenVSLAM's solver (which follows ORB-SLAM's PnPsolver,
+// itself the authors' reference implementation).  The algorithm, as published:
+//   1. four control points in the world: the centroid and the centroid plus the principal directions scaled by sqrt(eigenvalue / n);
+//   2. every landmark as a barycentric combination of them (alphas, they sum to one);
+//   3. the projection equations are linear in the 12 camera-frame coordinates of the control points: M x = 0 (2 n x 12); the solution is
+//      a combination x = sum beta_k v_k of the eigenvectors of M^T M with the four smallest eigenvalues;
+//   4. the betas from the six pairwise distances of the control points, which the camera frame must preserve (L_6x10 beta_ij = rho):
+//      three linearised guesses (N = 1 .. 3 null vectors: approx_1 / _2 / _3), each refined by five Gauss-Newton steps;
+//   5. per guess the camera-frame landmarks, the sign that puts them in front of the camera, the rigid motion world -> camera (Horn's
+//      absolute orientation here; the reference implementation takes the SVD form), and its mean reprojection error: the best wins.
+// Inliers are counted by the reprojection error (chi-square 5.991 at the keypoint's level).  The pose optimiser on the device refines
+// the result, as upstream refines EPnP's.  The linear algebra is this file's Jacobi eigen-solver and small Gaussian eliminations,
+// written so that the tests' numpy restatement can follow it operation by operation (both sides then test the same hypotheses).
 namespace {
-typedef std::complex<double> Cx;
-// roots of c[0] + c[1] x + ... + c[4] x^4 (c[4] != 0) by Durand-Kerner, a fixed number of sweeps from fixed starting points
-void quartic_roots(const double* c, Cx* r)
+// least squares A x = b (m x k, k <= 5) by the normal equations and Gaussian elimination with partial pivoting; false when singular
+bool lsq_small(const double* A, const double* b, int m, int k, double* x)
 {
-    const double a3 = c[3] / c[4], a2 = c[2] / c[4], a1 = c[1] / c[4], a0 = c[0] / c[4];
-    const double rad = 1.0 + std::max(std::max(std::fabs(a3), std::fabs(a2)), std::max(std::fabs(a1), std::fabs(a0)));
-    const Cx seed(0.4, 0.9);
-    Cx w(1.0, 0.0);
-    for (int i = 0; i < 4; ++i) { r[i] = w * rad * 0.5; w *= seed; }
-    for (int it = 0; it < 80; ++it) {
-        for (int i = 0; i < 4; ++i) {
-            const Cx x = r[i];
-            const Cx px = (((x + a3) * x + a2) * x + a1) * x + a0;
-            Cx den(1.0, 0.0);
-            for (int k = 0; k < 4; ++k) if (k != i) den *= (x - r[k]);
-            if (std::abs(den) > 0) r[i] = x - px / den;
+    double N[5 * 6];
+    for (int i = 0; i < k; ++i) {
+        for (int j = 0; j < k; ++j) { double s = 0; for (int r = 0; r < m; ++r) s += A[r * k + i] * A[r * k + j]; N[i * (k + 1) + j] = s; }
+        double s = 0;
+        for (int r = 0; r < m; ++r) s += A[r * k + i] * b[r];
+        N[i * (k + 1) + k] = s;
+    }
+    for (int c = 0; c < k; ++c) {
+        int piv = c;
+        for (int r = c + 1; r < k; ++r) if (std::fabs(N[r * (k + 1) + c]) > std::fabs(N[piv * (k + 1) + c])) piv = r;
+        if (!(std::fabs(N[piv * (k + 1) + c]) > 1e-300)) return false;
+        if (piv != c) for (int j = 0; j <= k; ++j) std::swap(N[c * (k + 1) + j], N[piv * (k + 1) + j]);
+        for (int r = c + 1; r < k; ++r) {
+            const double f = N[r * (k + 1) + c] / N[c * (k + 1) + c];
+            for (int j = c; j <= k; ++j) N[r * (k + 1) + j] -= f * N[c * (k + 1) + j];
         }
     }
-}
-// up to four (R, t) world -> camera from three world points and their unit bearings; returns the number of solutions
-int p3p_grunert(const double* pw /* 3 x 3 */, const double* f /* 3 x 3 unit bearings */, double (*Rs)[9], double (*ts)[3])
-{
-    auto d2 = [&](int i, int k) { double s = 0; for (int a = 0; a < 3; ++a) { const double d = pw[3 * i + a] - pw[3 * k + a]; s += d * d; } return s; };
-    auto dot = [&](int i, int k) { return f[3 * i] * f[3 * k] + f[3 * i + 1] * f[3 * k + 1] + f[3 * i + 2] * f[3 * k + 2]; };
-    const double a2 = d2(1, 2), b2 = d2(0, 2), c2 = d2(0, 1);
-    if (!(a2 > 1e-12 && b2 > 1e-12 && c2 > 1e-12)) return 0;
-    const double ca = dot(1, 2), cb = dot(0, 2), cg = dot(0, 1);
-    const double q1 = (a2 - c2) / b2, kc = c2 / b2;
-    // u = N(v) / D(v);  1 + u^2 - 2 u cos(gamma) = kc (1 + v^2 - 2 v cos(beta))  ->  D^2 + N^2 - 2 cos(gamma) N D - kc K D^2 = 0
-    const double N[3] = {1.0 + q1, -2.0 * q1 * cb, q1 - 1.0}, D[2] = {2.0 * cg, -2.0 * ca}, K[3] = {1.0, -2.0 * cb, 1.0};
-    double DD[3] = {D[0] * D[0], 2.0 * D[0] * D[1], D[1] * D[1]};
-    double poly[5] = {0, 0, 0, 0, 0};
-    for (int i = 0; i < 3; ++i) poly[i] += DD[i];
-    for (int i = 0; i < 3; ++i) for (int k = 0; k < 3; ++k) poly[i + k] += N[i] * N[k];
-    for (int i = 0; i < 3; ++i) for (int k = 0; k < 2; ++k) poly[i + k] -= 2.0 * cg * N[i] * D[k];
-    for (int i = 0; i < 3; ++i) for (int k = 0; k < 3; ++k) poly[i + k] -= kc * K[i] * DD[k];
-    double big = 0;
-    for (int i = 0; i < 5; ++i) big = std::max(big, std::fabs(poly[i]));
-    if (!(std::fabs(poly[4]) > 1e-12 * big)) return 0;
-    Cx roots[4];
-    quartic_roots(poly, roots);
-    int n_sol = 0;
-    for (int r = 0; r < 4; ++r) {
-        const double v = roots[r].real();
-        if (!(std::fabs(roots[r].imag()) < 1e-6 * (1.0 + std::fabs(v))) || !(v > 0)) continue;
-        const double den = D[0] + D[1] * v;
-        if (!(std::fabs(den) > 1e-12)) continue;
-        const double u = (N[0] + N[1] * v + N[2] * v * v) / den;
-        if (!(u > 0)) continue;
-        const double kk = 1.0 + v * v - 2.0 * v * cb;
-        if (!(kk > 0)) continue;
-        const double s1 = std::sqrt(b2 / kk), sc[3] = {s1, u * s1, v * s1};
-        double pc[9];
-        for (int i = 0; i < 3; ++i) for (int a = 0; a < 3; ++a) pc[3 * i + a] = sc[i] * f[3 * i + a];
-        double sdummy = 1.0;
-        if (!horn_absolute_orientation(pc, pw, 3, true, Rs[n_sol], ts[n_sol], &sdummy)) continue;
-        ++n_sol;
+    for (int i = k - 1; i >= 0; --i) {
+        double s2 = N[i * (k + 1) + k];
+        for (int j = i + 1; j < k; ++j) s2 -= N[i * (k + 1) + j] * x[j];
+        x[i] = s2 / N[i * (k + 1) + i];
     }
-    return n_sol;
+    return true;
 }
 }  // namespace
+
+bool epnp_solve(const double* pw, const double* uv, int n, const double* cam, double* R, double* t)
+{
+    if (n < 4) return false;
+    const double fu = cam[0], fv = cam[1], uc = cam[2], vc = cam[3];
+    // 1. control points
+    double cws[4][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    for (int i = 0; i < n; ++i) for (int a = 0; a < 3; ++a) cws[0][a] += pw[3 * i + a];
+    for (int a = 0; a < 3; ++a) cws[0][a] /= n;
+    double C[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < n; ++i)
+        for (int a = 0; a < 3; ++a) for (int b2 = 0; b2 < 3; ++b2) C[a * 3 + b2] += (pw[3 * i + a] - cws[0][a]) * (pw[3 * i + b2] - cws[0][b2]);
+    double ev[3], evec[9];
+    sym_eigen_jacobi(C, 3, ev, evec);                       // ascending; the principal direction first, as the published code orders them
+    for (int j = 1; j <= 3; ++j) {
+        const int col = 3 - j;
+        const double k = std::sqrt(std::max(ev[col], 0.0) / n);
+        for (int a = 0; a < 3; ++a) cws[j][a] = cws[0][a] + k * evec[a * 3 + col];
+    }
+    // 2. barycentric coordinates: [c1 - c0, c2 - c0, c3 - c0] a = p - c0
+    double CC[9], CI[9];
+    for (int a = 0; a < 3; ++a) for (int j = 1; j <= 3; ++j) CC[a * 3 + (j - 1)] = cws[j][a] - cws[0][a];
+    const double det = CC[0] * (CC[4] * CC[8] - CC[5] * CC[7]) - CC[1] * (CC[3] * CC[8] - CC[5] * CC[6]) + CC[2] * (CC[3] * CC[7] - CC[4] * CC[6]);
+    if (!(std::fabs(det) > 1e-300)) return false;           // landmarks in a plane or on a line: no volume to span
+    CI[0] = (CC[4] * CC[8] - CC[5] * CC[7]) / det; CI[1] = (CC[2] * CC[7] - CC[1] * CC[8]) / det; CI[2] = (CC[1] * CC[5] - CC[2] * CC[4]) / det;
+    CI[3] = (CC[5] * CC[6] - CC[3] * CC[8]) / det; CI[4] = (CC[0] * CC[8] - CC[2] * CC[6]) / det; CI[5] = (CC[2] * CC[3] - CC[0] * CC[5]) / det;
+    CI[6] = (CC[3] * CC[7] - CC[4] * CC[6]) / det; CI[7] = (CC[1] * CC[6] - CC[0] * CC[7]) / det; CI[8] = (CC[0] * CC[4] - CC[1] * CC[3]) / det;
+    std::vector<double> al((size_t)4 * n);
+    for (int i = 0; i < n; ++i) {
+        const double d0 = pw[3 * i] - cws[0][0], d1 = pw[3 * i + 1] - cws[0][1], d2 = pw[3 * i + 2] - cws[0][2];
+        for (int j = 0; j < 3; ++j) al[4 * (size_t)i + 1 + j] = CI[j * 3] * d0 + CI[j * 3 + 1] * d1 + CI[j * 3 + 2] * d2;
+        al[4 * (size_t)i] = 1.0 - al[4 * (size_t)i + 1] - al[4 * (size_t)i + 2] - al[4 * (size_t)i + 3];
+    }
+    // 3. M^T M, accumulated row pair by row pair
+    double MtM[144];
+    for (double& v : MtM) v = 0;
+    for (int i = 0; i < n; ++i) {
+        double r1[12], r2[12];
+        for (int j = 0; j < 4; ++j) {
+            const double a = al[4 * (size_t)i + j];
+            r1[3 * j] = a * fu; r1[3 * j + 1] = 0.0;    r1[3 * j + 2] = a * (uc - uv[2 * i]);
+            r2[3 * j] = 0.0;    r2[3 * j + 1] = a * fv; r2[3 * j + 2] = a * (vc - uv[2 * i + 1]);
+        }
+        for (int a = 0; a < 12; ++a) for (int b2 = 0; b2 < 12; ++b2) MtM[a * 12 + b2] += r1[a] * r1[b2] + r2[a] * r2[b2];
+    }
+    double mev[12], mvec[144];
+    sym_eigen_jacobi(MtM, 12, mev, mvec);                   // ascending: columns 0 .. 3 span the (approximate) null space
+    double v[4][12];
+    for (int k = 0; k < 4; ++k) for (int a = 0; a < 12; ++a) v[k][a] = mvec[a * 12 + k];
+    // 4. distance constraints
+    static const int pa[6] = {0, 0, 0, 1, 1, 2}, pb[6] = {1, 2, 3, 2, 3, 3};
+    double dv[4][6][3], L[60], rho[6];
+    for (int k = 0; k < 4; ++k) for (int p = 0; p < 6; ++p) for (int a = 0; a < 3; ++a) dv[k][p][a] = v[k][3 * pa[p] + a] - v[k][3 * pb[p] + a];
+    auto dot3 = [](const double* x, const double* y) { return x[0] * y[0] + x[1] * y[1] + x[2] * y[2]; };
+    for (int p = 0; p < 6; ++p) {
+        double* row = L + 10 * p;
+        row[0] = dot3(dv[0][p], dv[0][p]); row[1] = 2.0 * dot3(dv[0][p], dv[1][p]); row[2] = dot3(dv[1][p], dv[1][p]);
+        row[3] = 2.0 * dot3(dv[0][p], dv[2][p]); row[4] = 2.0 * dot3(dv[1][p], dv[2][p]); row[5] = dot3(dv[2][p], dv[2][p]);
+        row[6] = 2.0 * dot3(dv[0][p], dv[3][p]); row[7] = 2.0 * dot3(dv[1][p], dv[3][p]); row[8] = 2.0 * dot3(dv[2][p], dv[3][p]);
+        row[9] = dot3(dv[3][p], dv[3][p]);
+        double d2 = 0;
+        for (int a = 0; a < 3; ++a) { const double d = cws[pa[p]][a] - cws[pb[p]][a]; d2 += d * d; }
+        rho[p] = d2;
+    }
+    double best_err = 1e300;
+    bool found = false;
+    std::vector<double> pc((size_t)3 * n);
+    for (int guess = 0; guess < 3; ++guess) {
+        double be[4] = {0, 0, 0, 0};
+        if (guess == 0) {                                   // betas 11 12 13 14 (columns 0, 1, 3, 6): N = 4 with the cross terms of beta_1 only
+            double A[24], x4[4];
+            for (int p = 0; p < 6; ++p) { A[4 * p] = L[10 * p]; A[4 * p + 1] = L[10 * p + 1]; A[4 * p + 2] = L[10 * p + 3]; A[4 * p + 3] = L[10 * p + 6]; }
+            if (!lsq_small(A, rho, 6, 4, x4)) continue;
+            if (x4[0] < 0) { be[0] = std::sqrt(-x4[0]); be[1] = -x4[1] / be[0]; be[2] = -x4[2] / be[0]; be[3] = -x4[3] / be[0]; }
+            else { be[0] = std::sqrt(x4[0]); be[1] = x4[1] / be[0]; be[2] = x4[2] / be[0]; be[3] = x4[3] / be[0]; }
+        } else if (guess == 1) {                            // betas 11 12 22 (columns 0, 1, 2): N = 2
+            double A[18], x3[3];
+            for (int p = 0; p < 6; ++p) { A[3 * p] = L[10 * p]; A[3 * p + 1] = L[10 * p + 1]; A[3 * p + 2] = L[10 * p + 2]; }
+            if (!lsq_small(A, rho, 6, 3, x3)) continue;
+            if (x3[0] < 0) { be[0] = std::sqrt(-x3[0]); be[1] = x3[2] < 0 ? std::sqrt(-x3[2]) : 0.0; }
+            else { be[0] = std::sqrt(x3[0]); be[1] = x3[2] > 0 ? std::sqrt(x3[2]) : 0.0; }
+            if (x3[1] < 0) be[0] = -be[0];
+        } else {                                            // betas 11 12 22 13 23 (columns 0 .. 4): N = 3
+            double A[30], x5[5];
+            for (int p = 0; p < 6; ++p) for (int c = 0; c < 5; ++c) A[5 * p + c] = L[10 * p + c];
+            if (!lsq_small(A, rho, 6, 5, x5)) continue;
+            if (x5[0] < 0) { be[0] = std::sqrt(-x5[0]); be[1] = x5[2] < 0 ? std::sqrt(-x5[2]) : 0.0; }
+            else { be[0] = std::sqrt(x5[0]); be[1] = x5[2] > 0 ? std::sqrt(x5[2]) : 0.0; }
+            if (x5[1] < 0) be[0] = -be[0];
+            be[2] = x5[3] / be[0];
+        }
+        if (!(be[0] == be[0]) || !std::isfinite(be[0]) || !std::isfinite(be[1]) || !std::isfinite(be[2]) || !std::isfinite(be[3])) continue;
+        bool gn_ok = true;
+        for (int it = 0; it < 5 && gn_ok; ++it) {           // Gauss-Newton on the six distance equations
+            double A[24], r6[6], dx[4];
+            for (int p = 0; p < 6; ++p) {
+                const double* l = L + 10 * p;
+                A[4 * p] = 2 * l[0] * be[0] + l[1] * be[1] + l[3] * be[2] + l[6] * be[3];
+                A[4 * p + 1] = l[1] * be[0] + 2 * l[2] * be[1] + l[4] * be[2] + l[7] * be[3];
+                A[4 * p + 2] = l[3] * be[0] + l[4] * be[1] + 2 * l[5] * be[2] + l[8] * be[3];
+                A[4 * p + 3] = l[6] * be[0] + l[7] * be[1] + l[8] * be[2] + 2 * l[9] * be[3];
+                r6[p] = rho[p] - (l[0] * be[0] * be[0] + l[1] * be[0] * be[1] + l[2] * be[1] * be[1] + l[3] * be[0] * be[2] + l[4] * be[1] * be[2] +
+                                  l[5] * be[2] * be[2] + l[6] * be[0] * be[3] + l[7] * be[1] * be[3] + l[8] * be[2] * be[3] + l[9] * be[3] * be[3]);
+            }
+            if (!lsq_small(A, r6, 6, 4, dx)) { gn_ok = false; break; }
+            for (int k = 0; k < 4; ++k) be[k] += dx[k];
+        }
+        if (!gn_ok || !std::isfinite(be[0]) || !std::isfinite(be[1]) || !std::isfinite(be[2]) || !std::isfinite(be[3])) continue;
+        // 5. camera-frame control points and landmarks, sign, rigid motion, reprojection error
+        double ccs[4][3];
+        for (int j = 0; j < 4; ++j) for (int a = 0; a < 3; ++a) ccs[j][a] = be[0] * v[0][3 * j + a] + be[1] * v[1][3 * j + a] + be[2] * v[2][3 * j + a] + be[3] * v[3][3 * j + a];
+        for (int i = 0; i < n; ++i)
+            for (int a = 0; a < 3; ++a) pc[3 * (size_t)i + a] = al[4 * (size_t)i] * ccs[0][a] + al[4 * (size_t)i + 1] * ccs[1][a] + al[4 * (size_t)i + 2] * ccs[2][a] + al[4 * (size_t)i + 3] * ccs[3][a];
+        if (pc[2] < 0) for (double& x : pc) x = -x;         // the first landmark in front of the camera
+        double Rg[9], tg[3], sdummy = 1.0;
+        if (!horn_absolute_orientation(pc.data(), pw, n, true, Rg, tg, &sdummy)) continue;
+        double err = 0;
+        bool finite = true;
+        for (int i = 0; i < n; ++i) {
+            const double* X = pw + 3 * (size_t)i;
+            const double xc = Rg[0] * X[0] + Rg[1] * X[1] + Rg[2] * X[2] + tg[0], yc = Rg[3] * X[0] + Rg[4] * X[1] + Rg[5] * X[2] + tg[1], zc = Rg[6] * X[0] + Rg[7] * X[1] + Rg[8] * X[2] + tg[2];
+            const double du = uc + fu * xc / zc - uv[2 * i], dv2 = vc + fv * yc / zc - uv[2 * i + 1];
+            const double e = std::sqrt(du * du + dv2 * dv2);
+            if (!std::isfinite(e)) { finite = false; break; }
+            err += e;
+        }
+        if (!finite) continue;
+        err /= n;
+        if (err < best_err) { best_err = err; found = true; for (int k = 0; k < 9; ++k) R[k] = Rg[k]; for (int k = 0; k < 3; ++k) t[k] = tg[k]; }
+    }
+    return found;
+}
 
 int pnp_solve_ransac(const double* pw, const double* obs, const double* inv_sigma2, int n, const double* cam, int iterations, uint32_t seed, double* pose7, uint8_t* inlier)
 {
     for (int i = 0; i < n; ++i) inlier[i] = 0;
     if (n < 4) return 0;
-    std::vector<double> f((size_t)3 * n);
-    for (int i = 0; i < n; ++i) {
-        const double x = (obs[2 * i] - cam[2]) / cam[0], y = (obs[2 * i + 1] - cam[3]) / cam[1], nn = std::sqrt(x * x + y * y + 1.0);
-        f[3 * (size_t)i] = x / nn; f[3 * (size_t)i + 1] = y / nn; f[3 * (size_t)i + 2] = 1.0 / nn;
-    }
     Rng rng{seed ? seed : 1u};
     std::vector<int> avail((size_t)n);
     std::vector<uint8_t> cur((size_t)n);
     int best = 0;
-    auto reproj2 = [&](const double* R, const double* t, int i, double& z) {
-        const double* X = pw + 3 * (size_t)i;
-        const double xc = R[0] * X[0] + R[1] * X[1] + R[2] * X[2] + t[0], yc = R[3] * X[0] + R[4] * X[1] + R[5] * X[2] + t[1];
-        z = R[6] * X[0] + R[7] * X[1] + R[8] * X[2] + t[2];
-        const double du = cam[0] * xc / z + cam[2] - obs[2 * i], dv = cam[1] * yc / z + cam[3] - obs[2 * i + 1];
-        return du * du + dv * dv;
+    double bestR[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, bestT[3] = {0, 0, 0};
+    auto count_inliers = [&](const double* R, const double* t, uint8_t* flags) {
+        int count = 0;
+        for (int i = 0; i < n; ++i) {
+            const double* X = pw + 3 * (size_t)i;
+            const double xc = R[0] * X[0] + R[1] * X[1] + R[2] * X[2] + t[0], yc = R[3] * X[0] + R[4] * X[1] + R[5] * X[2] + t[1];
+            const double z = R[6] * X[0] + R[7] * X[1] + R[8] * X[2] + t[2];
+            const double du = cam[0] * xc / z + cam[2] - obs[2 * i], dv = cam[1] * yc / z + cam[3] - obs[2 * i + 1];
+            flags[i] = (z > 0 && (du * du + dv * dv) * inv_sigma2[i] < 5.991) ? 1 : 0;
+            count += flags[i];
+        }
+        return count;
     };
     for (int it = 0; it < iterations; ++it) {
         for (int i = 0; i < n; ++i) avail[(size_t)i] = i;
         int left = n, idx[4];
         for (int k = 0; k < 4; ++k) { const int r = (int)(rng.next() % (uint32_t)left); idx[k] = avail[(size_t)r]; avail[(size_t)r] = avail[(size_t)left - 1]; --left; }
-        double p3[9], f3[9], Rs[4][9], ts[4][3];
-        for (int k = 0; k < 3; ++k) for (int a = 0; a < 3; ++a) { p3[3 * k + a] = pw[3 * (size_t)idx[k] + a]; f3[3 * k + a] = f[3 * (size_t)idx[k] + a]; }
-        const int ns = p3p_grunert(p3, f3, Rs, ts);
-        int pick = -1;
-        double pick_err = 0;
-        for (int s = 0; s < ns; ++s) {                   // the fourth match of the sample decides among the solutions
-            double z;
-            const double e = reproj2(Rs[s], ts[s], idx[3], z);
-            if (z > 0 && (pick < 0 || e < pick_err)) { pick = s; pick_err = e; }
-        }
-        if (pick < 0) continue;
-        int count = 0;
-        for (int i = 0; i < n; ++i) {
-            double z;
-            const double e = reproj2(Rs[pick], ts[pick], i, z);
-            cur[(size_t)i] = (z > 0 && e * inv_sigma2[i] < 5.991) ? 1 : 0;
-            count += cur[(size_t)i];
-        }
+        double p4[12], u4[8], R[9], t[3];
+        for (int k = 0; k < 4; ++k) { for (int a = 0; a < 3; ++a) p4[3 * k + a] = pw[3 * (size_t)idx[k] + a]; u4[2 * k] = obs[2 * (size_t)idx[k]]; u4[2 * k + 1] = obs[2 * (size_t)idx[k] + 1]; }
+        if (!epnp_solve(p4, u4, 4, cam, R, t)) continue;
+        const int count = count_inliers(R, t, cur.data());
         if (count > best) {
             best = count;
             for (int i = 0; i < n; ++i) inlier[i] = cur[(size_t)i];
-            double q[4];
-            rot_to_quat(Rs[pick], q);
-            for (int k = 0; k < 4; ++k) pose7[k] = q[k];
-            for (int k = 0; k < 3; ++k) pose7[4 + k] = ts[pick][k];
+            for (int k = 0; k < 9; ++k) bestR[k] = R[k];
+            for (int k = 0; k < 3; ++k) bestT[k] = t[k];
         }
     }
+    if (best < 4) { for (int i = 0; i < n; ++i) inlier[i] = 0; return 0; }
+    // refit on the inliers of the best sample ([UPSTREAM] refine): EPnP over all of them, kept when it explains at least as many matches
+    {
+        std::vector<double> pi, ui;
+        for (int i = 0; i < n; ++i) if (inlier[i]) { for (int a = 0; a < 3; ++a) pi.push_back(pw[3 * (size_t)i + a]); ui.push_back(obs[2 * (size_t)i]); ui.push_back(obs[2 * (size_t)i + 1]); }
+        double R[9], t[3];
+        if (epnp_solve(pi.data(), ui.data(), (int)(ui.size() / 2), cam, R, t)) {
+            const int count = count_inliers(R, t, cur.data());
+            if (count >= best) {
+                best = count;
+                for (int i = 0; i < n; ++i) inlier[i] = cur[(size_t)i];
+                for (int k = 0; k < 9; ++k) bestR[k] = R[k];
+                for (int k = 0; k < 3; ++k) bestT[k] = t[k];
+            }
+        }
+    }
+    double q[4];
+    rot_to_quat(bestR, q);
+    for (int k = 0; k < 4; ++k) pose7[k] = q[k];
+    for (int k = 0; k < 3; ++k) pose7[4 + k] = bestT[k];
     return best;
 }
 
@@ -707,6 +820,11 @@ extern "C" __attribute__((visibility("default"))) int lpslam_sim3_solve_ransac(c
                                                                                 int fix_scale, int iterations, uint32_t seed, double* s12, uint8_t* inlier)
 {
     return LpSlam::sim3_solve_ransac(p1c, p2c, obs1, obs2, is1, is2, n, cam1, cam2, fix_scale != 0, iterations, seed, s12, inlier);
+}
+
+extern "C" __attribute__((visibility("default"))) int lpslam_epnp_solve(const double* pw, const double* uv, int n, const double* cam, double* R9, double* t3)
+{
+    return LpSlam::epnp_solve(pw, uv, n, cam, R9, t3) ? 1 : 0;
 }
 
 extern "C" __attribute__((visibility("default"))) int lpslam_pnp_solve_ransac(const double* pw, const double* obs, const double* inv_sigma2, int n, const double* cam,

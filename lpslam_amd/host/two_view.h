@@ -54,9 +54,11 @@ bool triangulate_point(const double* P1, const double* P2, const double* x1, con
 // inv_sigma2_*: n.  Returns the number of inliers of the best hypothesis (0: none found); s12 = (qw qx qy qz tx ty tz s).
 int sim3_solve_ransac(const double* p1c, const double* p2c, const double* obs1, const double* obs2, const double* inv_sigma2_1, const double* inv_sigma2_2,
                       int n, const double* cam1 /* fx fy cx cy */, const double* cam2, bool fix_scale, int iterations, uint32_t seed, double* s12, uint8_t* inlier);
-// [UPSTREAM] solve::pnp_solver: world -> camera pose from n >= 4 landmark / keypoint matches, no prior (three-point solver on the
-// first three matches of a 4-match sample, the fourth picks the solution; inliers by reprojection error, chi-square 5.991).
-// pw: n x 3 world points, obs: n x 2 pixels.  Returns the inlier count of the best hypothesis; pose7 = qw qx qy qz tx ty tz.
+// EPnP (Lepetit, Moreno-Noguer, Fua 2009): world -> camera (R row major, t) from n >= 4 landmark / pixel matches; false for degenerate input
+bool epnp_solve(const double* pw, const double* uv, int n, const double* cam /* fx fy cx cy */, double* R, double* t);
+// [UPSTREAM] solve::pnp_solver: world -> camera pose from n >= 4 landmark / keypoint matches, no prior: EPnP on 4-match samples (RANSAC),
+// inliers by reprojection error (chi-square 5.991 at the keypoint's level), then EPnP once more over the inliers of the best sample.
+// pw: n x 3 world points, obs: n x 2 pixels.  Returns the inlier count of the result (0: none); pose7 = qw qx qy qz tx ty tz.
 int pnp_solve_ransac(const double* pw, const double* obs, const double* inv_sigma2, int n, const double* cam /* fx fy cx cy */, int iterations, uint32_t seed,
                      double* pose7, uint8_t* inlier);
 // Horn's absolute orientation of n >= 3 matched points: x1 = s R x2 + t (R row major)

@@ -100,8 +100,8 @@ class StereoSequence:
         return left, right
 
 
-def turning_sequence(width, height, n_frames=132, step_deg=3.0, seq_id=4, n_points=9000, radius=(5.0, 25.0)):
-    """A full turn on the spot inside a ring of structure (loop-closure tests, tests/golden/g14_track_loop.npz): stereo frames of a
+def turning_sequence(width, height, n_frames=156, step_deg=3.0, seq_id=4, n_points=9000, radius=(5.0, 25.0)):
+    """A turn on the spot, once around and 108 degrees more (the loop detector wants its candidate at four keyframes in a row), inside a ring of structure (loop-closure tests, tests/golden/g14_track_loop.npz): stereo frames of a
     camera at the origin turning by `step_deg` per frame about its y axis; the background is a panorama fixed to the WORLD (the
     generator's own background is fixed to the image).  Returns (frames, yaws)."""
     k = intrinsics(width, height)

@@ -109,6 +109,7 @@ class StereoTracker:
         # (HipVslamTrackerBase::startMapping / finishMapping) -- the order of events does not depend on how long the solve takes
         self.async_mapping = async_mapping
         self.loop_closure = loop_closure
+        self.loop_sets = []                    # (keyframe set, continuity) of the loop candidates detected at the previous keyframe
         self.map_culling = map_culling
         self.stereo = True
         self.fresh = []                                             # landmarks younger than three keyframes (local_map_cleaner)
@@ -669,6 +670,7 @@ class StereoTracker:
             C = self._centre(self.kfs[a]["pose"])
             cands.append((math.sqrt((C[0] - Cc[0]) * (C[0] - Cc[0]) + (C[1] - Cc[1]) * (C[1] - Cc[1]) + (C[2] - Cc[2]) * (C[2] - Cc[2])), a))
         if not cands:
+            self.loop_sets = []
             return False
         cands.sort()
         votes = []
@@ -681,6 +683,25 @@ class StereoTracker:
                      if kc["landmark"][int(q_)] >= 0 and ka["landmark"][int(t_)] >= 0 and self.resolve(kc["landmark"][int(q_)]) != self.resolve(ka["landmark"][int(t_)])]
             if len(pairs) >= 20:
                 votes.append((a, pairs))
+        if not votes:
+            self.loop_sets = []
+            return False
+        # [UPSTREAM] loop_detector::find_continuously_detected_keyframe_sets (min_continuity_ = 3, ORB-SLAM's covisibility consistency):
+        # a candidate stands for the set of itself and its covisibility neighbours; its continuity is one more than that of a set
+        # detected at the PREVIOUS keyframe that shares a keyframe with it (0 when there is none); only candidates whose continuity has
+        # reached 3 -- detected at four keyframes in a row -- go on to the Sim3 verification.  No candidate at a keyframe: the chain breaks.
+        sets_now, accepted = [], []
+        for a, pairs in votes:
+            group = set(self.covisible(a, len(self.kfs), 15)) | {a}
+            cont = 0
+            for pg, pc in self.loop_sets:
+                if group & pg:
+                    cont = max(cont, pc + 1)
+            sets_now.append((group, cont))
+            if cont >= 3:
+                accepted.append((a, pairs))
+        self.loop_sets = sets_now
+        votes = accepted
         if not votes:
             return False
         votes.sort(key=lambda v: (-len(v[1]), -v[0]))
@@ -763,6 +784,7 @@ class StereoTracker:
             self.stats["local_ba"] -= 1; self.stats["global_ba"] += 1
             cur.pose = self.kfs[c]["pose"].copy()
         self.stats["loops_closed"] += 1
+        self.loop_sets = []
         return True
 
     # ---- one frame ---------------------------------------------------------------------------------------------------------------

@@ -273,116 +273,300 @@ def sim3_solve_ransac(p1c, p2c, obs1, obs2, is1, is2, cam1, cam2, fix_scale, ite
     return best, best_s12, best_inl
 
 
-# ---- [UPSTREAM] solve::pnp_solver, as host/two_view.cpp restates it: three-point solver (Grunert) + the fourth match of a sample + RANSAC
-def _quartic_roots(c):
-    """roots of c[0] + ... + c[4] x^4 by Durand-Kerner (80 sweeps from fixed starting points, Gauss-Seidel order)"""
-    a3, a2, a1, a0 = c[3] / c[4], c[2] / c[4], c[1] / c[4], c[0] / c[4]
-    rad = 1.0 + max(abs(a3), abs(a2), abs(a1), abs(a0))
-    seed, w, r = complex(0.4, 0.9), complex(1.0, 0.0), []
-    for _ in range(4):
-        r.append(w * rad * 0.5); w *= seed
-    for _ in range(80):
-        for i in range(4):
-            x = r[i]
-            px = (((x + a3) * x + a2) * x + a1) * x + a0
-            den = complex(1.0, 0.0)
+# ---- [UPSTREAM] solve::pnp_solver: EPnP (Lepetit, Moreno-Noguer, Fua, IJCV 2009) on 4-match samples + RANSAC + a refit on the inliers.
+# The steps are the published ones (control points, barycentric coordinates, M^T M, the four smallest eigenvectors, the betas from the
+# control points' distances by three linearised guesses + Gauss-Newton, rigid motion, best reprojection error); the linear algebra is
+# written operation by operation like lpslam_amd/host/two_view.cpp's (cyclic Jacobi with the same sweep order, normal equations with
+# partial pivoting) because EPnP on FOUR matches has a four-dimensional null space: which basis an eigen-solver returns for it decides
+# which local solution the betas land in, and both sides must test the same hypotheses for the closed-loop comparison to mean anything.
+def _jacobi_eig(A):
+    """eigenvalues ascending, eigenvectors as columns: cyclic Jacobi, 64 sweeps at most (sym_eigen_jacobi)"""
+    a = np.array(A, float); n = a.shape[0]
+    v = np.eye(n)
+    for _ in range(64):
+        off = 0.0; diag = 0.0
+        for i in range(n):
+            for j in range(n):
+                if i == j:
+                    diag += a[i, j] * a[i, j]
+                else:
+                    off += a[i, j] * a[i, j]
+        if off <= 1e-30 * (diag + 1e-300):
+            break
+        for p in range(n - 1):
+            for q in range(p + 1, n):
+                apq = a[p, q]
+                if apq == 0.0:
+                    continue
+                theta = (a[q, q] - a[p, p]) / (2.0 * apq)
+                t = (1.0 if theta >= 0 else -1.0) / (abs(theta) + np.sqrt(theta * theta + 1.0))
+                c = 1.0 / np.sqrt(t * t + 1.0); sn = t * c
+                akp = a[:, p].copy(); akq = a[:, q].copy()
+                a[:, p] = c * akp - sn * akq; a[:, q] = sn * akp + c * akq
+                apk = a[p, :].copy(); aqk = a[q, :].copy()
+                a[p, :] = c * apk - sn * aqk; a[q, :] = sn * apk + c * aqk
+                vkp = v[:, p].copy(); vkq = v[:, q].copy()
+                v[:, p] = c * vkp - sn * vkq; v[:, q] = sn * vkp + c * vkq
+    order = sorted(range(n), key=lambda x: a[x, x])
+    return np.array([a[o, o] for o in order]), v[:, order]
+
+
+def _lsq_small(A, b):
+    """least squares by the normal equations and Gaussian elimination with partial pivoting (lsq_small); None when singular"""
+    A = np.asarray(A, float); b = np.asarray(b, float)
+    m, k = A.shape
+    N = np.zeros((k, k + 1))
+    for i in range(k):
+        for j in range(k):
+            s = 0.0
+            for r in range(m):
+                s += A[r, i] * A[r, j]
+            N[i, j] = s
+        s = 0.0
+        for r in range(m):
+            s += A[r, i] * b[r]
+        N[i, k] = s
+    for c in range(k):
+        piv = c
+        for r in range(c + 1, k):
+            if abs(N[r, c]) > abs(N[piv, c]):
+                piv = r
+        if not (abs(N[piv, c]) > 1e-300):
+            return None
+        if piv != c:
+            N[[c, piv]] = N[[piv, c]]
+        for r in range(c + 1, k):
+            f = N[r, c] / N[c, c]
+            for j in range(c, k + 1):
+                N[r, j] -= f * N[c, j]
+    x = np.zeros(k)
+    for i in range(k - 1, -1, -1):
+        s2 = N[i, k]
+        for j in range(i + 1, k):
+            s2 -= N[i, j] * x[j]
+        x[i] = s2 / N[i, i]
+    return x
+
+
+def _horn_jacobi(x1, x2):
+    """x1 = R x2 + t (rigid), Horn's quaternion form with the Jacobi eigen-solver (horn_absolute_orientation, scale fixed)"""
+    n = len(x1)
+    o1 = np.zeros(3); o2 = np.zeros(3)
+    for i in range(n):
+        o1 += x1[i]; o2 += x2[i]
+    o1 /= n; o2 /= n
+    M = np.zeros((3, 3))                                  # M[a][b] = sum (x2 - o2)[a] (x1 - o1)[b]
+    for i in range(n):
+        M += np.outer(x2[i] - o2, x1[i] - o1)
+    M = M.reshape(9)
+    N = np.array([[M[0] + M[4] + M[8], M[5] - M[7], M[6] - M[2], M[1] - M[3]],
+                  [M[5] - M[7], M[0] - M[4] - M[8], M[1] + M[3], M[6] + M[2]],
+                  [M[6] - M[2], M[1] + M[3], -M[0] + M[4] - M[8], M[5] + M[7]],
+                  [M[1] - M[3], M[6] + M[2], M[5] + M[7], -M[0] - M[4] + M[8]]])
+    _, vec = _jacobi_eig(N)
+    q = vec[:, 3].copy()
+    qn = np.sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3])
+    if not (qn > 0):
+        return None
+    q /= qn
+    w, x, y, z = q
+    R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                  [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                  [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+    t = np.array([o1[r] - 1.0 * (R[r, 0] * o2[0] + R[r, 1] * o2[1] + R[r, 2] * o2[2]) for r in range(3)])
+    return R, t
+
+
+def epnp_solve(pw, uv, cam):
+    """world -> camera (R, t) from n >= 4 landmark / pixel matches, or None (epnp_solve)"""
+    pw = np.asarray(pw, float); uv = np.asarray(uv, float)
+    n = len(pw)
+    if n < 4:
+        return None
+    fu, fv, uc, vc = (float(c) for c in cam[:4])
+    cws = np.zeros((4, 3))
+    for i in range(n):
+        cws[0] += pw[i]
+    cws[0] /= n
+    Cm = np.zeros((3, 3))
+    for i in range(n):
+        d = pw[i] - cws[0]
+        Cm += np.outer(d, d)
+    ev, evec = _jacobi_eig(Cm)
+    for j in range(1, 4):
+        col = 3 - j
+        k = np.sqrt(max(ev[col], 0.0) / n)
+        cws[j] = cws[0] + k * evec[:, col]
+    CC = np.zeros(9)
+    for a in range(3):
+        for j in range(1, 4):
+            CC[a * 3 + (j - 1)] = cws[j][a] - cws[0][a]
+    det = CC[0] * (CC[4] * CC[8] - CC[5] * CC[7]) - CC[1] * (CC[3] * CC[8] - CC[5] * CC[6]) + CC[2] * (CC[3] * CC[7] - CC[4] * CC[6])
+    if not (abs(det) > 1e-300):
+        return None
+    CI = np.array([(CC[4] * CC[8] - CC[5] * CC[7]) / det, (CC[2] * CC[7] - CC[1] * CC[8]) / det, (CC[1] * CC[5] - CC[2] * CC[4]) / det,
+                   (CC[5] * CC[6] - CC[3] * CC[8]) / det, (CC[0] * CC[8] - CC[2] * CC[6]) / det, (CC[2] * CC[3] - CC[0] * CC[5]) / det,
+                   (CC[3] * CC[7] - CC[4] * CC[6]) / det, (CC[1] * CC[6] - CC[0] * CC[7]) / det, (CC[0] * CC[4] - CC[1] * CC[3]) / det])
+    al = np.zeros((n, 4))
+    for i in range(n):
+        d0, d1, d2 = pw[i] - cws[0]
+        for j in range(3):
+            al[i, 1 + j] = CI[j * 3] * d0 + CI[j * 3 + 1] * d1 + CI[j * 3 + 2] * d2
+        al[i, 0] = 1.0 - al[i, 1] - al[i, 2] - al[i, 3]
+    MtM = np.zeros((12, 12))
+    for i in range(n):
+        r1 = np.zeros(12); r2 = np.zeros(12)
+        for j in range(4):
+            a = al[i, j]
+            r1[3 * j] = a * fu; r1[3 * j + 2] = a * (uc - uv[i, 0])
+            r2[3 * j + 1] = a * fv; r2[3 * j + 2] = a * (vc - uv[i, 1])
+        MtM += np.outer(r1, r1) + np.outer(r2, r2)
+    _, mvec = _jacobi_eig(MtM)
+    v = [mvec[:, k].copy() for k in range(4)]
+    pa, pb = (0, 0, 0, 1, 1, 2), (1, 2, 3, 2, 3, 3)
+    dot3 = lambda x, y: x[0] * y[0] + x[1] * y[1] + x[2] * y[2]
+    L = np.zeros((6, 10)); rho = np.zeros(6)
+    for p in range(6):
+        dv = [v[k][3 * pa[p]:3 * pa[p] + 3] - v[k][3 * pb[p]:3 * pb[p] + 3] for k in range(4)]
+        L[p] = [dot3(dv[0], dv[0]), 2.0 * dot3(dv[0], dv[1]), dot3(dv[1], dv[1]), 2.0 * dot3(dv[0], dv[2]), 2.0 * dot3(dv[1], dv[2]), dot3(dv[2], dv[2]),
+                2.0 * dot3(dv[0], dv[3]), 2.0 * dot3(dv[1], dv[3]), 2.0 * dot3(dv[2], dv[3]), dot3(dv[3], dv[3])]
+        d2 = 0.0
+        for a in range(3):
+            d = cws[pa[p]][a] - cws[pb[p]][a]
+            d2 += d * d
+        rho[p] = d2
+    best_err, best = 1e300, None
+    for guess in range(3):
+        be = [0.0, 0.0, 0.0, 0.0]
+        if guess == 0:
+            x4 = _lsq_small(L[:, [0, 1, 3, 6]], rho)
+            if x4 is None:
+                continue
+            if x4[0] < 0:
+                be[0] = np.sqrt(-x4[0]); be[1] = -x4[1] / be[0]; be[2] = -x4[2] / be[0]; be[3] = -x4[3] / be[0]
+            else:
+                be[0] = np.sqrt(x4[0]); be[1] = x4[1] / be[0]; be[2] = x4[2] / be[0]; be[3] = x4[3] / be[0]
+        elif guess == 1:
+            x3 = _lsq_small(L[:, [0, 1, 2]], rho)
+            if x3 is None:
+                continue
+            if x3[0] < 0:
+                be[0] = np.sqrt(-x3[0]); be[1] = np.sqrt(-x3[2]) if x3[2] < 0 else 0.0
+            else:
+                be[0] = np.sqrt(x3[0]); be[1] = np.sqrt(x3[2]) if x3[2] > 0 else 0.0
+            if x3[1] < 0:
+                be[0] = -be[0]
+        else:
+            x5 = _lsq_small(L[:, [0, 1, 2, 3, 4]], rho)
+            if x5 is None:
+                continue
+            if x5[0] < 0:
+                be[0] = np.sqrt(-x5[0]); be[1] = np.sqrt(-x5[2]) if x5[2] < 0 else 0.0
+            else:
+                be[0] = np.sqrt(x5[0]); be[1] = np.sqrt(x5[2]) if x5[2] > 0 else 0.0
+            if x5[1] < 0:
+                be[0] = -be[0]
+            with np.errstate(divide="ignore", invalid="ignore"):
+                be[2] = x5[3] / be[0]
+        if not all(np.isfinite(b) for b in be):
+            continue
+        gn_ok = True
+        for _ in range(5):
+            A = np.zeros((6, 4)); r6 = np.zeros(6)
+            for p in range(6):
+                l = L[p]
+                A[p, 0] = 2 * l[0] * be[0] + l[1] * be[1] + l[3] * be[2] + l[6] * be[3]
+                A[p, 1] = l[1] * be[0] + 2 * l[2] * be[1] + l[4] * be[2] + l[7] * be[3]
+                A[p, 2] = l[3] * be[0] + l[4] * be[1] + 2 * l[5] * be[2] + l[8] * be[3]
+                A[p, 3] = l[6] * be[0] + l[7] * be[1] + l[8] * be[2] + 2 * l[9] * be[3]
+                r6[p] = rho[p] - (l[0] * be[0] * be[0] + l[1] * be[0] * be[1] + l[2] * be[1] * be[1] + l[3] * be[0] * be[2] + l[4] * be[1] * be[2] +
+                                  l[5] * be[2] * be[2] + l[6] * be[0] * be[3] + l[7] * be[1] * be[3] + l[8] * be[2] * be[3] + l[9] * be[3] * be[3])
+            dx = _lsq_small(A, r6)
+            if dx is None:
+                gn_ok = False
+                break
             for k in range(4):
-                if k != i:
-                    den *= (x - r[k])
-            if abs(den) > 0:
-                r[i] = x - px / den
-    return r
+                be[k] += dx[k]
+        if not gn_ok or not all(np.isfinite(b) for b in be):
+            continue
+        ccs = np.zeros((4, 3))
+        for j in range(4):
+            for a in range(3):
+                ccs[j, a] = be[0] * v[0][3 * j + a] + be[1] * v[1][3 * j + a] + be[2] * v[2][3 * j + a] + be[3] * v[3][3 * j + a]
+        pc = np.zeros((n, 3))
+        for i in range(n):
+            for a in range(3):
+                pc[i, a] = al[i, 0] * ccs[0, a] + al[i, 1] * ccs[1, a] + al[i, 2] * ccs[2, a] + al[i, 3] * ccs[3, a]
+        if pc[0, 2] < 0:
+            pc = -pc
+        h = _horn_jacobi(pc, pw)
+        if h is None:
+            continue
+        Rg, tg = h
+        err, finite = 0.0, True
+        for i in range(n):
+            X = pw[i]
+            xc = Rg[0, 0] * X[0] + Rg[0, 1] * X[1] + Rg[0, 2] * X[2] + tg[0]; yc = Rg[1, 0] * X[0] + Rg[1, 1] * X[1] + Rg[1, 2] * X[2] + tg[1]
+            zc = Rg[2, 0] * X[0] + Rg[2, 1] * X[1] + Rg[2, 2] * X[2] + tg[2]
+            with np.errstate(divide="ignore", invalid="ignore"):
+                du = uc + fu * xc / zc - uv[i, 0]; dv2 = vc + fv * yc / zc - uv[i, 1]
+            e = np.sqrt(du * du + dv2 * dv2)
+            if not np.isfinite(e):
+                finite = False
+                break
+            err += e
+        if not finite:
+            continue
+        err /= n
+        if err < best_err:
+            best_err, best = err, (Rg.copy(), tg.copy())
+    return best
 
 
-def p3p_grunert(pw, f):
-    """up to four (R, t) world -> camera from three world points (rows of pw) and their unit bearings (rows of f)"""
-    d2 = lambda i, k: float(((pw[i] - pw[k]) ** 2).sum())
-    a2, b2, c2 = d2(1, 2), d2(0, 2), d2(0, 1)
-    if not (a2 > 1e-12 and b2 > 1e-12 and c2 > 1e-12):
-        return []
-    ca, cb, cg = float(f[1] @ f[2]), float(f[0] @ f[2]), float(f[0] @ f[1])
-    q1, kc = (a2 - c2) / b2, c2 / b2
-    N = [1.0 + q1, -2.0 * q1 * cb, q1 - 1.0]; D = [2.0 * cg, -2.0 * ca]; K = [1.0, -2.0 * cb, 1.0]
-    DD = [D[0] * D[0], 2.0 * D[0] * D[1], D[1] * D[1]]
-    poly = [0.0] * 5
-    for i in range(3):
-        poly[i] += DD[i]
-    for i in range(3):
-        for k in range(3):
-            poly[i + k] += N[i] * N[k]
-    for i in range(3):
-        for k in range(2):
-            poly[i + k] -= 2.0 * cg * N[i] * D[k]
-    for i in range(3):
-        for k in range(3):
-            poly[i + k] -= kc * K[i] * DD[k]
-    big = max(abs(v) for v in poly)
-    if not (abs(poly[4]) > 1e-12 * big):
-        return []
-    sols = []
-    for root in _quartic_roots(poly):
-        v = root.real
-        if not (abs(root.imag) < 1e-6 * (1.0 + abs(v))) or not (v > 0):
-            continue
-        den = D[0] + D[1] * v
-        if not (abs(den) > 1e-12):
-            continue
-        u = (N[0] + N[1] * v + N[2] * v * v) / den
-        if not (u > 0):
-            continue
-        kk = 1.0 + v * v - 2.0 * v * cb
-        if not (kk > 0):
-            continue
-        s1 = np.sqrt(b2 / kk)
-        pc = np.array([s1 * f[0], u * s1 * f[1], v * s1 * f[2]])
-        h = horn(pc, pw, True)
-        if h is not None:
-            sols.append((h[0], h[1]))
-    return sols
+def _rot_to_quat(R):
+    m = np.asarray(R, float).reshape(9)
+    tr = m[0] + m[4] + m[8]
+    if tr > 0:
+        s4 = np.sqrt(tr + 1.0) * 2; return [0.25 * s4, (m[7] - m[5]) / s4, (m[2] - m[6]) / s4, (m[3] - m[1]) / s4]
+    if m[0] > m[4] and m[0] > m[8]:
+        s4 = np.sqrt(1.0 + m[0] - m[4] - m[8]) * 2; return [(m[7] - m[5]) / s4, 0.25 * s4, (m[1] + m[3]) / s4, (m[2] + m[6]) / s4]
+    if m[4] > m[8]:
+        s4 = np.sqrt(1.0 + m[4] - m[0] - m[8]) * 2; return [(m[2] - m[6]) / s4, (m[1] + m[3]) / s4, 0.25 * s4, (m[5] + m[7]) / s4]
+    s4 = np.sqrt(1.0 + m[8] - m[0] - m[4]) * 2; return [(m[3] - m[1]) / s4, (m[2] + m[6]) / s4, (m[5] + m[7]) / s4, 0.25 * s4]
 
 
 def pnp_solve_ransac(pw, obs, inv_sigma2, cam, iterations=100, seed=0x9E3779B9):
     """returns (n_inliers, pose7 (qw qx qy qz tx ty tz, world -> camera) or None, inlier flags)"""
     pw = np.asarray(pw, float); obs = np.asarray(obs, float); inv_sigma2 = np.asarray(inv_sigma2, float)
     n = len(pw)
-    best, best_pose, best_inl = 0, None, np.zeros(n, bool)
+    best, best_rt, best_inl = 0, None, np.zeros(n, bool)
     if n < 4:
         return 0, None, best_inl
-    x = (obs[:, 0] - cam[2]) / cam[0]; y = (obs[:, 1] - cam[3]) / cam[1]; nn = np.sqrt(x * x + y * y + 1.0)
-    f = np.stack([x / nn, y / nn, 1.0 / nn], 1)
     rng = _Rng(seed)
 
-    def reproj2(R, t, idx):
-        pc = pw[idx] @ R.T + t
+    def count_inliers(R, t):
+        xc = R[0, 0] * pw[:, 0] + R[0, 1] * pw[:, 1] + R[0, 2] * pw[:, 2] + t[0]; yc = R[1, 0] * pw[:, 0] + R[1, 1] * pw[:, 1] + R[1, 2] * pw[:, 2] + t[1]
+        z = R[2, 0] * pw[:, 0] + R[2, 1] * pw[:, 1] + R[2, 2] * pw[:, 2] + t[2]
         with np.errstate(divide="ignore", invalid="ignore"):
-            du = cam[0] * pc[..., 0] / pc[..., 2] + cam[2] - obs[idx, 0]; dv = cam[1] * pc[..., 1] / pc[..., 2] + cam[3] - obs[idx, 1]
-        return du * du + dv * dv, pc[..., 2]
-    every = np.arange(n)
+            du = cam[0] * xc / z + cam[2] - obs[:, 0]; dv = cam[1] * yc / z + cam[3] - obs[:, 1]
+            inl = (z > 0) & ((du * du + dv * dv) * inv_sigma2 < 5.991)
+        return int(inl.sum()), inl
     for _ in range(iterations):
         avail = list(range(n)); left = n; idx = []
         for _k in range(4):
             r = rng.next() % left
             idx.append(avail[r]); avail[r] = avail[left - 1]; left -= 1
-        pick, pick_err = None, 0.0
-        for R, t in p3p_grunert(pw[idx[:3]], f[idx[:3]]):
-            e, z = reproj2(R, t, idx[3])
-            if z > 0 and (pick is None or e < pick_err):
-                pick, pick_err = (R, t), float(e)
-        if pick is None:
+        rt = epnp_solve(pw[idx], obs[idx], cam)
+        if rt is None:
             continue
-        e, z = reproj2(pick[0], pick[1], every)
-        inl = (z > 0) & (e * inv_sigma2 < 5.991)
-        c = int(inl.sum())
+        c, inl = count_inliers(rt[0], rt[1])
         if c > best:
-            m = pick[0].reshape(9)
-            tr = m[0] + m[4] + m[8]
-            if tr > 0:
-                s4 = np.sqrt(tr + 1.0) * 2; q = [0.25 * s4, (m[7] - m[5]) / s4, (m[2] - m[6]) / s4, (m[3] - m[1]) / s4]
-            elif m[0] > m[4] and m[0] > m[8]:
-                s4 = np.sqrt(1.0 + m[0] - m[4] - m[8]) * 2; q = [(m[7] - m[5]) / s4, 0.25 * s4, (m[1] + m[3]) / s4, (m[2] + m[6]) / s4]
-            elif m[4] > m[8]:
-                s4 = np.sqrt(1.0 + m[4] - m[0] - m[8]) * 2; q = [(m[2] - m[6]) / s4, (m[1] + m[3]) / s4, 0.25 * s4, (m[5] + m[7]) / s4]
-            else:
-                s4 = np.sqrt(1.0 + m[8] - m[0] - m[4]) * 2; q = [(m[3] - m[1]) / s4, (m[2] + m[6]) / s4, (m[5] + m[7]) / s4, 0.25 * s4]
-            best, best_pose, best_inl = c, np.array(q + list(pick[1]), float), inl.copy()
-    return best, best_pose, best_inl
+            best, best_rt, best_inl = c, rt, inl.copy()
+    if best < 4:
+        return 0, None, np.zeros(n, bool)
+    rt = epnp_solve(pw[best_inl], obs[best_inl], cam)       # refit on the inliers of the best sample
+    if rt is not None:
+        c, inl = count_inliers(rt[0], rt[1])
+        if c >= best:
+            best, best_rt, best_inl = c, rt, inl.copy()
+    return best, np.array(_rot_to_quat(best_rt[0]) + list(best_rt[1]), float), best_inl

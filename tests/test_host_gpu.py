@@ -3,6 +3,8 @@ import time
 
 import math
 
+import os
+
 import numpy as np
 import pytest
 
@@ -275,14 +277,15 @@ def test_map_stays_bounded_over_a_long_session(hiplib, tmp_path):
 
 
 def test_loop_is_closed_with_vocabulary_candidates(hiplib, tmp_path):
-    """The same full turn with a vocabulary: the loop candidates come from the BoW database (shared words, L1 score at least the
-    worst covisible neighbour's), their keypoints are matched with match::bow_tree, and the loop closes as it does with voting."""
+    """The same turn (carried on to 630 degrees: with the small test vocabulary the candidate sets need longer to be seen at four
+    keyframes in a row) with a vocabulary: the loop candidates come from the BoW database (shared words, L1 score at least the worst
+    covisible neighbour's), their keypoints are matched with match::bow_tree, and the loop closes as it does with voting."""
     import math
     from lpslam_amd import _build, manager
     from bow_util import VOCAB
     _build.host_library()
     w, h = 640, 480
-    frames, yaws = synth.turning_sequence(w, h)
+    frames, yaws = synth.turning_sequence(w, h, n_frames=210)
     log = tmp_path / "slam.log"
     m = _stereo_manager(manager, w, h, '{"cameraSetup": "stereo", "vocabFile": "%s", "slamKeypoints": 1000, "numLevels": 4, "keyframeInterval": 3, "localWindow": 4, "loopClosure": true}' % VOCAB, log)
     m.start()

@@ -7,7 +7,7 @@ oracle (oracle/tracker.py).  The images come from the committed generator (lpsla
   g12_track720     1280x720, 2000 keypoints, 8 levels (the configuration the benchmark is quoted on), 20 frames, asyncMapping true
   g13_track_lost   640x480, 20 frames of which 10..12 are blank: Lost -> the map is kept -> relocalisation, asyncMapping true
   g15_track_mono   640x480 monocular, 30 frames of the three-wall scene: two-view initialisation, tracking, triangulated keyframes
-  g14_track_loop   640x480, 132 frames of a full turn on the spot, loopClosure true: voting, Sim3 verification, pose graph, fusion, global BA
+  g14_track_loop   640x480, 156 frames of a turn on the spot (a full turn and 108 degrees: the candidate must be detected at four keyframes in a row), loopClosure true: voting, continuity, Sim3 verification, pose graph, fusion, global BA
 
   g16_mono_loop    640x480 monocular, 210 frames of the three-wall scene on a rectangular path (right, up, left, down, back at the start):
                    a monocular loop -- Sim3 with a free scale from the Sim3 solver, pose graph, fusion, global BA
@@ -39,7 +39,7 @@ CASES = {
                            cfg=dict(max_keypoints=2000, num_levels=3, scale_factor=1.2, keyframe_interval=4, local_window=10, async_mapping=True)),
     "g16_mono_loop": dict(w=640, h=480, n=210, seq="rectangle", points=None, blank=(), mono=True,
                           cfg=dict(max_keypoints=2000, num_levels=3, scale_factor=1.2, keyframe_interval=4, local_window=6, async_mapping=True, loop_closure=True)),
-    "g14_track_loop": dict(w=640, h=480, n=132, seq="turn", points=None, blank=(),
+    "g14_track_loop": dict(w=640, h=480, n=156, seq="turn", points=None, blank=(),
                            cfg=dict(max_keypoints=1000, num_levels=4, scale_factor=1.2, keyframe_interval=3, local_window=4, async_mapping=True, loop_closure=True)),
 }
 
