@@ -875,7 +875,7 @@ __device__ __forceinline__ void obs_y_row(const double* h, double w0, double w1,
 //      Blocks [n_work, n_work + n_free): rhs_i = b_p,i - sum Y b_l over the observations of keyframe i.
 //      fused != 0 (single-GPU solve): lambda goes onto the pose diagonal, rhs straight into row `dim` of S and the failure
 //      flag / rhs pivot are reset here, so no separate preparation launch is needed.
-__device__ __forceinline__ void ba_pose_side_wave(BaView& v, int p, int sp, int robust, int cur, bool publish);
+template <int UPD_PB> __device__ __forceinline__ void ba_pose_side_wave(BaView& v, int p, int sp, int robust, int cur, bool publish);
 __device__ __forceinline__ void ba_pose_side_wait(const BaView& v);
 __global__ __launch_bounds__(64) void k_ba_schur(const BaView* __restrict__ views, int fused, int robust)
 {
@@ -886,7 +886,7 @@ __global__ __launch_bounds__(64) void k_ba_schur(const BaView* __restrict__ view
     const BaFlags fl = ba_flags(v.ctl);
     if (fl.idle()) return;
     const int pending = fused ? ba_sync_words(v)[3] : 0;   // raised by k_ba_update's decision: H_pp, b_p of state `cur` are this launch's to compute
-    if (bx0 < lead) { if (pending) ba_pose_side_wave(v, bx0 / SPLIT, bx0 % SPLIT, robust, fl.cur, true); return; }
+    if (bx0 < lead) { if (pending) ba_pose_side_wave<2>(v, bx0 / SPLIT, bx0 % SPLIT, robust, fl.cur, true); return; }
     const int bx = bx0 - lead;
     const double lambda = fl.lambda;
     ba_lin_set(v, fl.cur);
@@ -2480,8 +2480,13 @@ int enqueue_reduce(const BaLaunch& L, int fused)
         // write-through stores and L2-bypassing loads -- 38.2 us for the one launch against 14.7 + 9.3 us for the two (MI355X, config 3).
         static const bool reduce_in_schur_env = [] { const char* e = getenv("LPSLAM_HIP_BA_REDUCE_IN_SCHUR"); return e && atoi(e) != 0; }();
         const int reduce_here = (fused && reduce_in_schur_env) ? 1 : 0;
-        hipLaunchKernelGGL(k_schur_group, dim3(L.n_poses + std::max(L.band_groups, 1) + (reduce_here ? (L.band_blocks + 1) / 2 : 0), L.count), dim3(BD_THREADS),
-                           std::max(bd_lds_bytes(L.band_gmax), (size_t)4096), L.s, L.d_views, fused, L.robust, reduce_here);
+        // a batch fills the chip with group workgroups: the variant that fits two of them on a compute unit (128 registers; the pose side
+        // spills a few values there -- it is off the path) took a batch of 16 contiguous windows from 2.87 to 2.65 ms per 10 iterations; a single window keeps the
+        // variant without spills (its pose-side workgroups are its longest).  Same arithmetic, same bytes.
+        const dim3 sg_grid(L.n_poses + std::max(L.band_groups, 1) + (reduce_here ? (L.band_blocks + 1) / 2 : 0), L.count);
+        const size_t sg_lds = std::max(bd_lds_bytes(L.band_gmax), (size_t)4096);
+        if (L.count >= 4) hipLaunchKernelGGL(k_schur_group<4>, sg_grid, dim3(BD_THREADS), sg_lds, L.s, L.d_views, fused, L.robust, reduce_here);
+        else hipLaunchKernelGGL(k_schur_group<1>, sg_grid, dim3(BD_THREADS), sg_lds, L.s, L.d_views, fused, L.robust, reduce_here);
         L.mark(LPSLAM_HIP_BA_K_SCHUR);
         if (!reduce_here) {
             hipLaunchKernelGGL(k_schur_band_reduce, dim3(L.band_blocks, L.count), dim3(256), 0, L.s, L.d_views, fused);

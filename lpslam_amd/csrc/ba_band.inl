@@ -171,14 +171,12 @@ __global__ __launch_bounds__(256) void k_schur_band_reduce(const BaView* __restr
     bd_reduce_block(v, bx, threadIdx.x, part, fused, fl.lambda, false, false);
 }
 
-#ifndef LPSLAM_BD_OCC
-#define LPSLAM_BD_OCC 1
-#endif
 // The launch's workgroups, in dispatch order: [0, n_poses) the pose side of an accepted state's linearisation (ba_update.inl; idle
 // otherwise), [n_poses, + band_groups) the landmark groups, then -- reduce_here -- ceil(n_free (hbw + 2) / 2) reduction workgroups, two
 // band blocks each, which wait for the first two kinds.  Waiting workgroups follow the ones they wait for in dispatch order, and those
 // wait for nobody: the launch drains whatever else occupies the chip.
-__global__ __launch_bounds__(BD_THREADS, LPSLAM_BD_OCC) void k_schur_group(const BaView* __restrict__ views, int fused, int robust, int reduce_here)
+template <int WAVES_PER_SIMD>         // 1: no register limit (a single window); 4: 128 registers, two workgroups per compute unit (a batch)
+__global__ __launch_bounds__(BD_THREADS, WAVES_PER_SIMD) void k_schur_group(const BaView* __restrict__ views, int fused, int robust, int reduce_here)
 {
     static_assert(BD_THREADS == 64 * SPLIT, "a leading workgroup is one keyframe: its SPLIT slices are the workgroup's wavefronts");
     BA_VIEW_XCD(v, bx0);
@@ -189,7 +187,7 @@ __global__ __launch_bounds__(BD_THREADS, LPSLAM_BD_OCC) void k_schur_group(const
     const BaFlags fl = ba_flags(v.ctl);
     if (fl.idle()) return;
     const bool pose_pending = fused && ba_sync_words(v)[3] != 0;
-    if (bx0 < lead) { if (pose_pending) ba_pose_side_wave(v, bx0, (int)(threadIdx.x >> 6), robust, fl.cur, reduce_here != 0); return; }
+    if (bx0 < lead) { if (pose_pending) ba_pose_side_wave<(WAVES_PER_SIMD > 1 ? 1 : 2)>(v, bx0, (int)(threadIdx.x >> 6), robust, fl.cur, reduce_here != 0); return; }
     const int bx = bx0 - lead;
     const double lambda = fl.lambda;
     ba_lin_set(v, fl.cur);
@@ -649,7 +647,8 @@ inline hipError_t bd_set_attributes()
     if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
     const int st = attr_state[dev].load();
     if (st == 1) return hipSuccess;
-    hipError_t e = hipFuncSetAttribute((const void*)k_schur_group, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bd_lds_bytes(BD_GMAX));
+    hipError_t e = hipFuncSetAttribute((const void*)k_schur_group<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bd_lds_bytes(BD_GMAX));
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_schur_group<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bd_lds_bytes(BD_GMAX));
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_chol_band, hipFuncAttributeMaxDynamicSharedMemorySize, BC_LDS_BYTES);
     attr_state[dev].store(e == hipSuccess ? 1 : 2);
     if (e != hipSuccess) { (void)hipGetLastError(); set_error("band path: %zu / %d bytes of dynamic LDS for k_schur_group / k_chol_band were refused (%s)", bd_lds_bytes(BD_GMAX), BC_LDS_BYTES, hipGetErrorString(e)); }

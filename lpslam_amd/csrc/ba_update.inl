@@ -296,9 +296,11 @@ __device__ __forceinline__ double upd_wave_sum(double v)
     return (upd_lane(v, 0) + upd_lane(v, 16)) + (upd_lane(v, 32) + upd_lane(v, 48));
 }
 
-constexpr int UPD_PB = 2;                   // observations per lane whose loads are in flight together (a keyframe with more than 64 * SPLIT * UPD_PB = 1024 takes further rounds)
+constexpr int UPD_PB_MAX = 2;                   // observations per lane whose loads are in flight together (a keyframe with more than 64 * SPLIT * UPD_PB = 1024 takes further rounds)
+template <int UPD_PB>
 __device__ __forceinline__ void ba_pose_side_wave(BaView& v, int p, int sp, int robust, int cur, bool publish)
 {
+    static_assert(UPD_PB >= 1 && UPD_PB <= UPD_PB_MAX, "observations in flight per lane");
     const int lane = threadIdx.x & 63;
     if (p >= v.n_poses) return;
     const int slot = v.pose_slot[p];
