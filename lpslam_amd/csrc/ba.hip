@@ -2249,6 +2249,9 @@ __global__ __launch_bounds__(64) void k_pose_optimize_w1(double* pose7, const Po
     unsigned act = 0;                                      // bit u: observation lane + 64 u is an inlier of the last classification
 #pragma unroll
     for (int u = 0; u < OPL; ++u) if (lane + 64 * u < n) act |= 1u << u;
+#ifdef LPSLAM_PO_STAMPS
+    double po_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, po_last = (double)clock64();
+#endif
     auto pass = [&](const double (&p7)[7], int robust, double (&sums)[PO_NV]) __attribute__((always_inline)) {
         double R[9];
         po_quat_to_rot(p7, R);
@@ -2267,12 +2270,14 @@ __global__ __launch_bounds__(64) void k_pose_optimize_w1(double* pose7, const Po
             const double X[3] = {c.X[0], c.X[1], c.X[2]};
             po_accumulate(cam, R, t, o, X, robust, acc);
         }
+        PO_STAMP(1);
         po_reduce28_w1(acc, tr, out28, sums);
+        PO_STAMP(2);
+#ifdef LPSLAM_PO_STAMPS
+        if (lane == 0) po_acc[15] += 1;
+#endif
     };
     int robust = 1, n_bad_last = 0, passes = 0;
-#ifdef LPSLAM_PO_STAMPS
-    double po_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, po_last = (double)clock64();
-#endif
     for (int round = 0; round < 4; ++round) {
         // (the control flow of k_pose_optimize: g2o's Levenberg between the passes, up to ten iterations of up to ten trials)
         double sys[PO_NV], got[PO_NV], x[6], trial[7];
@@ -2281,6 +2286,7 @@ __global__ __launch_bounds__(64) void k_pose_optimize_w1(double* pose7, const Po
         double lambda = 1e-5 * fmax(fmax(fmax(fabs(sys[0]), fabs(sys[6])), fmax(fabs(sys[11]), fabs(sys[15]))), fmax(fabs(sys[18]), fabs(sys[20])));
         double ni = 2, current_chi = sys[27];
         int it = 0, qmax = 1;
+        PO_STAMP(3);
         int ok = po_solve_trial(sys, lambda, pose, x, trial PO_ST_ARG);
         for (;;) {
             pass(trial, robust, got);
@@ -2313,8 +2319,10 @@ __global__ __launch_bounds__(64) void k_pose_optimize_w1(double* pose7, const Po
                 if (qmax == 10 || rho == 0 || it == 10) break;
                 qmax = 1;
             }
+            PO_STAMP(3);
             ok = po_solve_trial(sys, lambda, pose, x, trial PO_ST_ARG);
         }
+        PO_STAMP(3);
         // classification with the plain chi2 of this round's pose
         double R[9];
         po_quat_to_rot(pose, R);
@@ -2339,8 +2347,12 @@ __global__ __launch_bounds__(64) void k_pose_optimize_w1(double* pose7, const Po
         }
         n_bad_last = bad;
         if (round == 2) robust = 0;
+        PO_STAMP(8);
         if (n - n_bad_last < 5) break;
     }
+#ifdef LPSLAM_PO_STAMPS
+    if (lane == 0) for (int k = 0; k < 16; ++k) g_po_stamps[k] = po_acc[k];
+#endif
 #pragma unroll
     for (int u = 0; u < OPL; ++u) if (lane + 64 * u < n) outlier[lane + 64 * u] = ((act >> u) & 1u) ? 0 : 1;       // the last classification made
     if (lane == 0) {

@@ -405,34 +405,72 @@ __global__ __launch_bounds__(256) void k_proj_topk(const lpslam_hip_keypoint* __
     const unsigned long long NONE = ~0ull;
     unsigned long long top[4] = {NONE, NONE, NONE, NONE};
     int cnt = 0;
-    for (int i = lane; i < n; i += 64) {
-        const lpslam_hip_keypoint k = kp[i];
-        if (!(fabsf(k.x - q.x) < q.radius && fabsf(k.y - q.y) < q.radius)) continue;
-        if (q.min_level >= 0 && k.octave < q.min_level) continue;
-        if (q.max_level >= 0 && k.octave > q.max_level) continue;
-        if (gate.mode == 0) {
-            if (stereo_xr) { const float xr = stereo_xr[i]; if (0 < xr && q.x_right >= 0 && q.radius < fabsf(q.x_right - xr)) continue; }
-        } else {
-            const float ex = q.x - k.x, ey = q.y - k.y;
-            float isq = gate.inv_sigma_sq[0];
+    // Two passes, so that a wavefront waits for memory a handful of times instead of once per keypoint and once per candidate (2000
+    // keypoints: 32 + up to 32 waits in a row, 19 us for a kernel that computes next to nothing).  Pass 1: sixteen keypoints of a lane in
+    // flight at a time, the window / level test, survivors appended to the wavefront's list in LDS (ballot + prefix count).  Pass 2: a
+    // lane per listed keypoint, everything it needs (stereo column, best-so-far, descriptor) loaded together.  Keys are unique and the
+    // four smallest are wanted: the order candidates are met in does not matter.
+    constexpr int PT_U = 16, PT_CAP = 2048;
+    __shared__ uint16_t s_list[4][PT_CAP];
+    uint16_t* list = s_list[threadIdx.x >> 6];
+    int n_list = 0;                                                     // uniform over the wavefront
+    auto second_pass = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+        for (int j = lane; j < n_list; j += 64) {
+            const int i = list[j];
+            const lpslam_hip_keypoint* kpi = kp + i;
+            struct { float x, y; int octave; } k{kpi->x, kpi->y, kpi->octave};
+            const float xr_i = stereo_xr ? stereo_xr[i] : -1.0f;
+            const int bsf_i = best_so_far ? (int)best_so_far[i] : 32767;
+            const uint32_t* d = reinterpret_cast<const uint32_t*>(desc + 32 * (size_t)i);
+            uint32_t dw[8];
 #pragma unroll
-            for (int l = 1; l < LPSLAM_HIP_MAX_LEVELS; ++l) isq = k.octave == l ? gate.inv_sigma_sq[l] : isq;
-            const float xr = stereo_xr ? stereo_xr[i] : -1.0f;
-            if (0 <= xr && q.x_right >= 0) { const float er = q.x_right - xr; if ((ex * ex + ey * ey + er * er) * isq > 7.81473f) continue; }
-            else if ((ex * ex + ey * ey) * isq > 5.99146f) continue;
+            for (int w = 0; w < 8; ++w) dw[w] = d[w];
+            if (gate.mode == 0) {
+                if (stereo_xr) { const float xr = xr_i; if (0 < xr && q.x_right >= 0 && q.radius < fabsf(q.x_right - xr)) continue; }
+            } else {
+                const float ex = q.x - k.x, ey = q.y - k.y;
+                float isq = gate.inv_sigma_sq[0];
+#pragma unroll
+                for (int l = 1; l < LPSLAM_HIP_MAX_LEVELS; ++l) isq = k.octave == l ? gate.inv_sigma_sq[l] : isq;
+                const float xr = xr_i;
+                if (0 <= xr && q.x_right >= 0) { const float er = q.x_right - xr; if ((ex * ex + ey * ey + er * er) * isq > 7.81473f) continue; }
+                else if ((ex * ex + ey * ey) * isq > 5.99146f) continue;
+            }
+            int dist = 0;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) dist += __popc(a[w] ^ dw[w]);
+            if (bsf_i <= dist) continue;                                // taken (0), or already matched at an equal or smaller distance
+            int cx = (int)floorf(k.x * inv_w), cy = (int)floorf(k.y * inv_h);
+            cx = min(max(cx, 0), 63); cy = min(max(cy, 0), 47);
+            unsigned long long key = ((unsigned long long)dist << 32) | ((unsigned long long)(cx * 48 + cy) << 20) | ((unsigned long long)i << 4) | (unsigned)k.octave;
+            ++cnt;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) if (key < top[t]) { const unsigned long long tmp = top[t]; top[t] = key; key = tmp; }     // sorted insert
         }
-        const uint32_t* d = reinterpret_cast<const uint32_t*>(desc + 32 * (size_t)i);
-        int dist = 0;
+        __builtin_amdgcn_wave_barrier();
+        n_list = 0;
+    };
+    for (int i0 = lane; i0 - lane < n; i0 += 64 * PT_U) {               // (uniform trip count: the ballots below want every lane)
+        float kxs[PT_U], kys[PT_U]; int ocs[PT_U];
 #pragma unroll
-        for (int w = 0; w < 8; ++w) dist += __popc(a[w] ^ d[w]);
-        if (best_so_far && best_so_far[i] <= dist) continue;           // taken (0), or already matched at an equal or smaller distance
-        int cx = (int)floorf(k.x * inv_w), cy = (int)floorf(k.y * inv_h);
-        cx = min(max(cx, 0), 63); cy = min(max(cy, 0), 47);
-        unsigned long long key = ((unsigned long long)dist << 32) | ((unsigned long long)(cx * 48 + cy) << 20) | ((unsigned long long)i << 4) | (unsigned)k.octave;
-        ++cnt;
+        for (int u = 0; u < PT_U; ++u) {
+            const lpslam_hip_keypoint* p = kp + min(i0 + 64 * u, n - 1);
+            kxs[u] = p->x; kys[u] = p->y; ocs[u] = p->octave;
+        }
+        if (n_list + 64 * PT_U > PT_CAP) second_pass();
 #pragma unroll
-        for (int t = 0; t < 4; ++t) if (key < top[t]) { const unsigned long long tmp = top[t]; top[t] = key; key = tmp; }     // sorted insert
+        for (int u = 0; u < PT_U; ++u) {
+            const int i = i0 + 64 * u;
+            bool pass = i < n && fabsf(kxs[u] - q.x) < q.radius && fabsf(kys[u] - q.y) < q.radius;
+            if (q.min_level >= 0 && ocs[u] < q.min_level) pass = false;
+            if (q.max_level >= 0 && ocs[u] > q.max_level) pass = false;
+            const unsigned long long b = __ballot(pass);
+            if (pass) list[n_list + __builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0u))] = (uint16_t)i;
+            n_list += __popcll(b);
+        }
     }
+    second_pass();
     for (int o2 = 32; o2 > 0; o2 >>= 1) cnt += __shfl_xor(cnt, o2);
     unsigned long long res[4];
 #pragma unroll

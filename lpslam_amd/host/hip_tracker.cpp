@@ -227,7 +227,7 @@ bool HipVslamTrackerBase::startContext(bool stereo)
     m_stereo = stereo;
     warmUpContext(stereo);
     m_stats = Statistics{};
-    m_kfs.clear(); m_landmarks.clear(); m_replaced.clear(); m_freshLandmarks.clear(); m_nextLandmarkId = 0; m_refKf = -1; m_segment = 0; m_segmentStart = 0;
+    m_kfs.clear(); m_landmarks.clear(); m_lmIndex.clear(); m_replaced.clear(); m_freshLandmarks.clear(); m_nextLandmarkId = 0; m_refKf = -1; m_segment = 0; m_segmentStart = 0;
     m_state = TrackerState::NotInitialized;
     m_started = true;
     return true;
@@ -353,15 +353,16 @@ int HipVslamTrackerBase::resolve(int id) const
 // landmarks) descending, ties to the newer keyframe; at most top_n with weight >= min_weight, returned in ascending id order
 std::vector<int> HipVslamTrackerBase::covisible(int kf, int top_n, int min_weight) const
 {
-    std::unordered_map<int, int> w;
+    IdMarks& w = m_marksKf;                              // shared observations per keyframe
+    w.begin(m_kfs.size());
+    std::vector<int> touched;
     for (int id : m_kfs[(size_t)kf].landmark) {
-        if (id < 0) continue;
-        auto it = m_landmarks.find(id);
-        if (it == m_landmarks.end()) continue;
-        for (auto& o : it->second.obs) if (o.first != kf) w[o.first]++;
+        const Landmark* l = lm(id);
+        if (!l) continue;
+        for (auto& o : l->obs) if (o.first != kf) { if (!w.has(o.first)) touched.push_back(o.first); w.at(o.first)++; }
     }
     std::vector<std::pair<int, int>> v;
-    for (auto& kv : w) if (kv.second >= min_weight) v.emplace_back(kv.second, kv.first);
+    for (int k : touched) if (w.get(k) >= min_weight) v.emplace_back(w.get(k), k);
     std::sort(v.begin(), v.end(), [](const std::pair<int, int>& a, const std::pair<int, int>& b) { return a.first != b.first ? a.first > b.first : a.second > b.second; });
     if ((int)v.size() > top_n) v.resize((size_t)std::max(top_n, 0));
     std::vector<int> out;
@@ -416,7 +417,7 @@ void HipVslamTrackerBase::mergeLandmarks(int keep, int drop, FrameData* f)
         if (sees_keep) kf.landmark[(size_t)o.second] = -1;
         else { kf.landmark[(size_t)o.second] = keep; ik->second.obs.push_back(o); }
     }
-    m_landmarks.erase(id);
+    unindexLandmark(drop); m_landmarks.erase(id);
     m_replaced[drop] = keep;
     if (f) for (auto& l : f->landmark) if (l == drop) l = keep;
 }
@@ -548,7 +549,7 @@ int HipVslamTrackerBase::insertKeyframe(FrameData& f)
             lm.ref_kf = c;
             id = m_nextLandmarkId++;
             lm.obs.emplace_back(c, (int)i);
-            m_landmarks[id] = std::move(lm);
+            m_landmarks[id] = std::move(lm); indexLandmark(id);
             m_freshLandmarks.push_back(id);
             f.landmark[i] = id;
         } else if (id >= 0) {
@@ -567,10 +568,11 @@ int HipVslamTrackerBase::insertKeyframe(FrameData& f)
     // duplicates: the landmarks of the covisible keyframes that this keyframe does not hold are searched in it (match::fuse)
     {
         const std::vector<int> nb = covisible(c, m_localWindow - 1, 15);
-        std::unordered_map<int, char> held;
-        for (int id : m_kfs[(size_t)c].landmark) if (id >= 0) held[id] = 1;
+        IdMarks& held = m_marksA;
+        held.begin((size_t)m_nextLandmarkId);
+        for (int id : m_kfs[(size_t)c].landmark) if (id >= 0) held.at(id) = 1;
         std::vector<int> ids;
-        for (int k : nb) for (int id : m_kfs[(size_t)k].landmark) if (id >= 0 && !held.count(id)) { held[id] = 1; ids.push_back(id); }
+        for (int k : nb) for (int id : m_kfs[(size_t)k].landmark) if (id >= 0 && !held.has(id)) { held.at(id) = 1; ids.push_back(id); }
         fuseInto(c, f.slot, ids, f, m_stats.fused_added, m_stats.fused_merged);
     }
     m_refKf = c;
@@ -597,15 +599,15 @@ bool HipVslamTrackerBase::poseFromMatches(FrameData& cur, const std::vector<int>
     std::vector<lpslam_hip_ba_obs> obs;
     std::vector<int> kept_idx, kept_lm;
     for (size_t k = 0; k < cur_idx.size(); ++k) {
-        auto it = m_landmarks.find(lm_ids[k]);
-        if (it == m_landmarks.end()) continue;
+        const Landmark* l = lm(lm_ids[k]);
+        if (!l) continue;
         const int i = cur_idx[k];
         const double s = m_scales[cur.kpts[(size_t)i].octave];
         lpslam_hip_ba_obs o{};
         o.pose = 0; o.point = (int32_t)kept_idx.size();
         o.u = cur.kpts[(size_t)i].x; o.v = cur.kpts[(size_t)i].y; o.ur = cur.x_right[(size_t)i] >= 0 ? (double)cur.x_right[(size_t)i] : -1.0; o.inv_sigma2 = 1.0 / (s * s);
         obs.push_back(o);
-        pts.insert(pts.end(), it->second.p, it->second.p + 3);
+        pts.insert(pts.end(), l->p, l->p + 3);
         kept_idx.push_back(i);
         kept_lm.push_back(lm_ids[k]);
     }
@@ -680,9 +682,9 @@ bool HipVslamTrackerBase::trackWithMotionModel(FrameData& cur, int& n_inliers)
     for (size_t i = 0; i < m_prev.kpts.size(); ++i) {
         const int id = resolve(m_prev.landmark[i]);
         if (id < 0) continue;
-        auto it = m_landmarks.find(id);
-        if (it == m_landmarks.end()) continue;
-        const double* X = it->second.p;
+        const Landmark* l = lm(id);
+        if (!l) continue;
+        const double* X = l->p;
         const double pc[3] = {R.m[0] * X[0] + R.m[1] * X[1] + R.m[2] * X[2] + init.t[0], R.m[3] * X[0] + R.m[4] * X[1] + R.m[5] * X[2] + init.t[1],
                               R.m[6] * X[0] + R.m[7] * X[1] + R.m[8] * X[2] + init.t[2]};
         if (!(pc[2] > 0)) continue;
@@ -731,12 +733,14 @@ bool HipVslamTrackerBase::trackLocalMap(FrameData& cur, int& n_inliers)
                          -(R.m[1] * cur.pose.t[0] + R.m[4] * cur.pose.t[1] + R.m[7] * cur.pose.t[2]),
                          -(R.m[2] * cur.pose.t[0] + R.m[5] * cur.pose.t[1] + R.m[8] * cur.pose.t[2])};
     std::vector<uint8_t> taken(cur.kpts.size(), 0);
-    std::unordered_map<int, char> held;
+    IdMarks& held = m_marksA;
+    held.begin((size_t)m_nextLandmarkId);
     size_t held_on_entry = 0; int n_new = 0;
     for (size_t i = 0; i < cur.kpts.size(); ++i) if (cur.landmark[i] >= 0) {
-        taken[i] = 1; held[cur.landmark[i]] = 1; ++held_on_entry;
-        auto it = m_landmarks.find(cur.landmark[i]);
-        if (it != m_landmarks.end()) ++it->second.n_observable;      // [UPSTREAM] search_local_landmarks: the frame's own landmarks are observable
+        taken[i] = 1; ++held_on_entry;
+        if (cur.landmark[i] < m_nextLandmarkId) held.at(cur.landmark[i]) = 1;
+        Landmark* l = lm(cur.landmark[i]);
+        if (l) ++l->n_observable;                        // [UPSTREAM] search_local_landmarks: the frame's own landmarks are observable
     }
     std::vector<lpslam_hip_proj_query> q;
     std::vector<uint8_t> qd;
@@ -747,11 +751,11 @@ bool HipVslamTrackerBase::trackLocalMap(FrameData& cur, int& n_inliers)
     std::sort(local.begin(), local.end());
     for (int kfi : local) {                              // local landmarks in keyframe / keypoint order (deterministic)
         for (int lid : m_kfs[(size_t)kfi].landmark) {
-            if (lid < 0 || held.count(lid)) continue;
-            held[lid] = 1;
-            auto it = m_landmarks.find(lid);
-            if (it == m_landmarks.end()) continue;
-            Landmark& lm = it->second;
+            if (lid < 0 || held.has(lid)) continue;
+            held.at(lid) = 1;
+            Landmark* lp = this->lm(lid);
+            if (!lp) continue;
+            Landmark& lm = *lp;
             const double* X = lm.p;
             const double pc[3] = {R.m[0] * X[0] + R.m[1] * X[1] + R.m[2] * X[2] + cur.pose.t[0], R.m[3] * X[0] + R.m[4] * X[1] + R.m[5] * X[2] + cur.pose.t[1],
                                   R.m[6] * X[0] + R.m[7] * X[1] + R.m[8] * X[2] + cur.pose.t[2]};
@@ -841,7 +845,7 @@ void HipVslamTrackerBase::eraseLandmark(int id)
         Keyframe& kf = m_kfs[(size_t)o.first];
         if ((size_t)o.second < kf.landmark.size() && kf.landmark[(size_t)o.second] == id) kf.landmark[(size_t)o.second] = -1;
     }
-    m_landmarks.erase(it);
+    unindexLandmark(id); m_landmarks.erase(it);
     ++m_stats.culled_landmarks;
 }
 
@@ -921,19 +925,18 @@ std::unique_ptr<HipVslamTrackerBase::MappingJob> HipVslamTrackerBase::prepareBun
     std::unordered_map<int, int> kf_index, fixed_set;
     for (int k : fixed_kfs) fixed_set[k] = 1;
     for (size_t i = 0; i < all.size(); ++i) kf_index[all[i]] = (int)i;
-    std::unordered_map<int, int> seen, index;
-    std::unordered_map<int, char> of_free;
-    for (int k : free_kfs) for (int id : m_kfs[(size_t)k].landmark) if (id >= 0) of_free[id] = 1;
-    for (int k : all) for (int id : m_kfs[(size_t)k].landmark) if (id >= 0 && of_free.count(id)) seen[id]++;
+    IdMarks &seen = m_marksA, &index = m_marksB, &of_free = m_marksC;        // index: BA point + 1 of a landmark
+    seen.begin((size_t)m_nextLandmarkId); index.begin((size_t)m_nextLandmarkId); of_free.begin((size_t)m_nextLandmarkId);
+    for (int k : free_kfs) for (int id : m_kfs[(size_t)k].landmark) if (id >= 0) of_free.at(id) = 1;
+    for (int k : all) for (int id : m_kfs[(size_t)k].landmark) if (id >= 0 && of_free.has(id)) seen.at(id)++;
     for (int k : all)                                    // point order: first appearance in keyframe / keypoint order
         for (int id : m_kfs[(size_t)k].landmark) {
-            if (id < 0 || index.count(id)) continue;
-            auto s = seen.find(id);
-            if (s == seen.end() || s->second < 2) continue;
-            auto it = m_landmarks.find(id);
-            if (it == m_landmarks.end()) continue;
-            index[id] = (int)job->ids.size(); job->ids.push_back(id);
-            job->pts.insert(job->pts.end(), it->second.p, it->second.p + 3);
+            if (id < 0 || index.has(id)) continue;
+            if (seen.get(id) < 2) continue;
+            const Landmark* l = lm(id);
+            if (!l) continue;
+            index.at(id) = (int)job->ids.size() + 1; job->ids.push_back(id);
+            job->pts.insert(job->pts.end(), l->p, l->p + 3);
         }
     if (job->ids.size() < 20 || all.size() < 2) return nullptr;
     job->kfs = all;
@@ -949,11 +952,10 @@ std::unique_ptr<HipVslamTrackerBase::MappingJob> HipVslamTrackerBase::prepareBun
         any_fixed = any_fixed || fx;
         for (size_t k = 0; k < kf.landmark.size(); ++k) {
             if (kf.landmark[k] < 0) continue;
-            auto it = index.find(kf.landmark[k]);
-            if (it == index.end()) continue;
+            if (!index.has(kf.landmark[k])) continue;
             const double s = m_scales[kf.kpts[k].octave];
             const double ur = (!kf.x_right.empty() && kf.x_right[k] >= 0) ? (double)kf.x_right[k] : -1.0;
-            job->obs.push_back({(int32_t)f, it->second, kf.kpts[k].x, kf.kpts[k].y, ur, 1.0 / (s * s)});
+            job->obs.push_back({(int32_t)f, index.get(kf.landmark[k]) - 1, kf.kpts[k].x, kf.kpts[k].y, ur, 1.0 / (s * s)});
             job->origin.emplace_back(all[f], (int)k);
         }
     }
@@ -970,20 +972,24 @@ std::unique_ptr<HipVslamTrackerBase::MappingJob> HipVslamTrackerBase::prepareMap
     std::vector<int> local = covisible(c, m_localWindow - 1, 15);
     local.push_back(c);
     std::sort(local.begin(), local.end());
-    std::unordered_map<int, char> is_local;
-    for (int k : local) is_local[k] = 1;
-    std::unordered_map<int, int> cnt;
-    std::unordered_map<int, char> done;
+    IdMarks &cnt = m_marksKf, &done = m_marksA;          // cnt: -1 for a local keyframe, else its shared observations
+    cnt.begin(m_kfs.size()); done.begin((size_t)m_nextLandmarkId);
+    for (int k : local) cnt.at(k) = -1;
+    std::vector<int> touched;
     for (int k : local)
         for (int id : m_kfs[(size_t)k].landmark) {
-            if (id < 0 || done.count(id)) continue;
-            done[id] = 1;
-            auto it = m_landmarks.find(id);
-            if (it == m_landmarks.end()) continue;
-            for (auto& o : it->second.obs) if (!is_local.count(o.first)) cnt[o.first]++;
+            if (id < 0 || done.has(id)) continue;
+            done.at(id) = 1;
+            const Landmark* l = lm(id);
+            if (!l) continue;
+            for (auto& o : l->obs) {
+                if (cnt.get(o.first) < 0) continue;
+                if (!cnt.has(o.first)) touched.push_back(o.first);
+                cnt.at(o.first)++;
+            }
         }
     std::vector<std::pair<int, int>> v;
-    for (auto& kv : cnt) v.emplace_back(kv.second, kv.first);
+    for (int k : touched) v.emplace_back(cnt.get(k), k);
     std::sort(v.begin(), v.end(), [](const std::pair<int, int>& a, const std::pair<int, int>& b) { return a.first != b.first ? a.first > b.first : a.second > b.second; });
     if ((int)v.size() > m_localWindow) v.resize((size_t)m_localWindow);
     std::vector<int> fixed;
@@ -1035,7 +1041,7 @@ void HipVslamTrackerBase::applyMapping(const MappingJob& job)
         if (it == m_landmarks.end()) continue;
         auto& ob = it->second.obs;
         for (size_t o = 0; o < ob.size(); ++o) if (ob[o].first == job.origin[k].first && ob[o].second == kp) { ob.erase(ob.begin() + (long)o); break; }
-        if (ob.empty()) m_landmarks.erase(it);
+        if (ob.empty()) { unindexLandmark(id); m_landmarks.erase(it); }
     }
     ++m_stats.local_ba;
     if (!job.global && job.keyframe >= 0) cullKeyframes(job.keyframe);      // [UPSTREAM] mapping_module: remove_redundant_keyframes after the local BA
@@ -1126,7 +1132,7 @@ bool HipVslamTrackerBase::monoInitialize(FrameData& cur)
         lm.ref_kf = i0;
         lm.obs.emplace_back(i0, ir); lm.obs.emplace_back(i1, ic);
         const int id = m_nextLandmarkId++;
-        m_landmarks[id] = std::move(lm);
+        m_landmarks[id] = std::move(lm); indexLandmark(id);
         reff.landmark[(size_t)ir] = id; cur.landmark[(size_t)ic] = id;
     }
     k0.kpts = reff.kpts; k0.desc = reff.desc; k0.landmark = reff.landmark; k0.x_right.assign(reff.kpts.size(), -1.0f); k0.depth.assign(reff.kpts.size(), -1.0f);
@@ -1238,7 +1244,7 @@ void HipVslamTrackerBase::monoTriangulate(int prev_kf, Keyframe& kf, FrameData& 
         lm.ref_kf = c;
         lm.obs.emplace_back(prev_kf, ip); lm.obs.emplace_back(c, ic);
         const int id = m_nextLandmarkId++;
-        m_landmarks[id] = std::move(lm);
+        m_landmarks[id] = std::move(lm); indexLandmark(id);
         m_freshLandmarks.push_back(id);
         f.landmark[(size_t)ic] = id; prev.landmark[(size_t)ip] = id;
     }
@@ -1596,10 +1602,11 @@ bool HipVslamTrackerBase::detectAndCloseLoop(FrameData& cur, int c)
         std::vector<int> nb = covisible(a0, m_localWindow - 1, 15);
         nb.push_back(a0);
         std::sort(nb.begin(), nb.end());
-        std::unordered_map<int, char> held;
-        for (int id : m_kfs[(size_t)c].landmark) if (id >= 0) held[id] = 1;
+        IdMarks& held = m_marksA;
+        held.begin((size_t)m_nextLandmarkId);
+        for (int id : m_kfs[(size_t)c].landmark) if (id >= 0) held.at(id) = 1;
         std::vector<int> ids;
-        for (int k : nb) for (int id : m_kfs[(size_t)k].landmark) if (id >= 0 && !held.count(id)) { held[id] = 1; ids.push_back(id); }
+        for (int k : nb) for (int id : m_kfs[(size_t)k].landmark) if (id >= 0 && !held.has(id)) { held.at(id) = 1; ids.push_back(id); }
         long added = 0, merged = 0;
         fuseInto(c, cur.slot, ids, cur, added, merged);
         m_stats.loop_fused += added + merged;

@@ -191,6 +191,21 @@ protected:
     std::vector<Keyframe> m_kfs;                      // the map's keyframes, index = id
     std::vector<std::pair<std::vector<int>, int>> m_loopSets;      // (keyframe set, continuity) of the loop candidates detected at the previous keyframe ([UPSTREAM] cont_detected_keyfrm_sets_)
     std::unordered_map<int, Landmark> m_landmarks;
+    // Landmark ids are dense (0 .. m_nextLandmarkId): an index of the map's nodes by id (a node stays where it is until it is erased) and
+    // scratch marks by id replace the hash lookups of the per-frame and per-keyframe loops (covisibility, local landmarks, window assembly:
+    // 0.10 of a 0.50 ms frame were hash operations)
+    std::vector<Landmark*> m_lmIndex;
+    Landmark* lm(int id) const { return id >= 0 && (size_t)id < m_lmIndex.size() ? m_lmIndex[(size_t)id] : nullptr; }
+    void indexLandmark(int id) { if ((size_t)id >= m_lmIndex.size()) m_lmIndex.resize((size_t)id + 256, nullptr); m_lmIndex[(size_t)id] = &m_landmarks.find(id)->second; }
+    void unindexLandmark(int id) { if (id >= 0 && (size_t)id < m_lmIndex.size()) m_lmIndex[(size_t)id] = nullptr; }
+    struct IdMarks {                                  // value per id, valid for the current round only (begin() starts a round in O(1))
+        std::vector<uint32_t> round; std::vector<int32_t> val; uint32_t cur = 0;
+        void begin(size_t n) { if (round.size() < n) { round.resize(n + 256, 0); val.resize(n + 256, 0); } if (++cur == 0) { std::fill(round.begin(), round.end(), 0u); cur = 1; } }
+        bool has(int id) const { return id >= 0 && (size_t)id < round.size() && round[(size_t)id] == cur; }
+        int32_t& at(int id) { if (round[(size_t)id] != cur) { round[(size_t)id] = cur; val[(size_t)id] = 0; } return val[(size_t)id]; }
+        int32_t get(int id) const { return has(id) ? val[(size_t)id] : 0; }
+    };
+    mutable IdMarks m_marksA, m_marksB, m_marksC, m_marksKf;      // tracking thread only
     std::unordered_map<int, int> m_replaced;          // merged landmark -> the one that took its observations
     int m_nextLandmarkId = 0;
     int m_refKf = -1;                                 // reference keyframe of tracking (the last one inserted)

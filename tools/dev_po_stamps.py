@@ -5,7 +5,7 @@ import numpy as np
 from lpslam_amd import hip, synth
 ctx = hip.Context(1280, 720, 2000, 1.2, 8, max_images=2)
 names = ["prologue", "accumulate+loop end", "reduce28", "decision", "solve", "oplus", "barrier", "-", "classification", "quat->R", "loads", "residual", "chi+huber", "jacobian"]
-for n_obs_target in (150, 300, 500):
+for n_obs_target in [int(a) for a in sys.argv[1:]] or (150, 300, 500):
     prob = synth.ba_problem(2, n_obs_target, 2 * n_obs_target, 1280, 720, seq_id=12)
     kf = 1
     sel = prob["obs_pose"] == kf
