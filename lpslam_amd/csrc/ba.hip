@@ -2196,26 +2196,33 @@ __global__ __launch_bounds__(PO_T) void k_pose_optimize(double* pose7, const dou
     }
 }
 
-// ---- the same flow in ONE wavefront, for up to 256 observations (what a tracked frame has) --------------------------------------------
-// k_pose_optimize's trial is 2.45 us, of which the 28-value reduction across four wavefronts is 0.8-1.0 (quad step in registers, LDS
-// transposition, two workgroup barriers).  One wavefront needs no barrier at all: lane l carries observations l, l + 64, ... (OPL of
-// them, a template parameter: the loop is unrolled), every lane writes its 28 partial sums into a [28][65] LDS array (consecutive lanes,
-// consecutive words), lanes (value q, half h) add 32 partials each in a fixed tree and meet their partner by one DPP exchange, the 28
-// totals come back to every lane by broadcast reads -- ~95 instructions and four LDS round trips of a wavefront that waits for nobody.
-// The serial section (lambda control, 6 x 6 solve, pose update) is the same code on replicated registers.  Per trial: ~1.2 us at <= 64
-// observations ... ~1.8 at 256.  The sums' order differs from the four-wavefront kernel's (results move in the last bits); which kernel
-// runs depends on the observation count alone.
-constexpr int PO1_ROW = 65;                 // row of the transposition array: 64 lanes + 1 (rows start on different banks)
-__device__ __forceinline__ void po_reduce28_w1(const double (&acc)[PO_NV], double* tr, double* out, double (&sums)[PO_NV])
+// ---- the same flow with ONE observation per lane, for up to 256 observations (what a tracked frame has) ---------------------------------
+// k_pose_optimize's trial is 2.45 us, of which the 28-value reduction across its wavefronts is 0.8-1.0 (quad step in registers, LDS
+// transposition, row reductions).  Here W = 1, 2 or 4 wavefronts carry one observation per lane (n <= 64 W): a pass is bound by the
+// FP64 issue rate of a SIMD -- ~350 instructions per observation AND LANE, 1650 cycles whether 1 or 64 lanes are busy -- so a second
+// observation per lane costs a second 1650 cycles (round 5's first version: 2.05 us per pass at <= 64 observations, 2.6 at 65-128),
+// a second wavefront on the next SIMD costs two workgroup barriers.  Every lane writes its 28 partial sums into a [28][66 W] LDS
+// array (consecutive lanes, consecutive words), 2 W lanes per value add 32 partials each in a fixed tree and meet their partners by DPP
+// exchanges inside a row, the 28 totals come back to every lane by broadcast reads.  The serial section (lambda control, 6 x 6 solve,
+// pose update) is the four-wavefront kernel's code on replicated registers, identical in every wavefront.  The sums' order differs from
+// the four-wavefront kernel's (results move in the last bits); which kernel runs depends on the observation count alone.
+#define PO_WN_ROW(W) (66 * (W))
+template <int W>
+__device__ __forceinline__ void po_reduce28_wn(const double (&acc)[PO_NV], double* tr, double* out, double (&sums)[PO_NV])
 {
-    const int lane = threadIdx.x;
+    // column c of a row sits at word c + c / 32 and a row is 66 W words: the 2 W lanes of a value read their 32 partials from chunks that
+    // start 33 words apart and neighbouring values 2 W words (mod 32) apart, so the 16 lanes the LDS serves together touch 16 different
+    // bank pairs (with rows of 64 W + 1 words the lanes of a value met on ONE bank: W = 2 / 4 measured 2.5 / 3.9 us per pass against 2.1)
+    constexpr int ROW = PO_WN_ROW(W);
+    constexpr int LPV = 2 * W;                             // lanes per value: neighbours inside a DPP row
+    const int tid = threadIdx.x;
 #pragma unroll
-    for (int q = 0; q < PO_NV; ++q) tr[q * PO1_ROW + lane] = acc[q];
-    __syncthreads();                                       // (one wavefront: an ordering point for the compiler and the LDS queue, not a wait)
-    const int q = lane >> 1, h = lane & 1;
+    for (int q = 0; q < PO_NV; ++q) tr[q * ROW + tid + (tid >> 5)] = acc[q];
+    __syncthreads();                                       // (W = 1: an ordering point for the compiler and the LDS queue, not a wait)
+    const int q = tid / LPV, j = tid % LPV;
     double s = 0;
     if (q < PO_NV) {
-        const double* row = tr + q * PO1_ROW + 32 * h;
+        const double* row = tr + q * ROW + 33 * j;
         double v[32];
 #pragma unroll
         for (int i = 0; i < 32; ++i) v[i] = row[i];
@@ -2225,30 +2232,31 @@ __device__ __forceinline__ void po_reduce28_w1(const double (&acc)[PO_NV], doubl
             for (int i = 0; i < w; ++i) v[i] = v[2 * i] + v[2 * i + 1];
         s = v[0];
     }
-    s += quad_swap<0xB1>(s);                               // the other half
-    if (q < PO_NV && h == 0) out[q] = s;
+    s += quad_swap<0xB1>(s);                               // lanes 0<->1, 2<->3
+    if (LPV >= 4) s += quad_swap<0x4E>(s);                 // lanes 0<->2, 1<->3
+    if (LPV >= 8) s += quad_swap<0x141>(s);                // row_half_mirror: the other quad of the eight
+    if (q < PO_NV && j == 0) out[q] = s;
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < PO_NV; ++i) sums[i] = out[i];
 }
 
-template <int OPL>
-__global__ __launch_bounds__(64) void k_pose_optimize_w1(double* pose7, const PoObs* packed, int n, BaCam cam, uint8_t* outlier, int* n_inliers, int* done_flag, int seq)
+template <int W>
+__global__ __launch_bounds__(64 * W) void k_pose_optimize_wn(double* pose7, const PoObs* packed, int n, BaCam cam, uint8_t* outlier, int* n_inliers, int* done_flag, int seq)
 {
 #pragma clang fp contract(fast)
-    __shared__ double tr[PO_NV * PO1_ROW];
+    __shared__ double tr[PO_NV * PO_WN_ROW(W)];
     __shared__ double out28[32];
-    __shared__ PoObs cache[64 * OPL];
-    const int lane = threadIdx.x;
+    __shared__ PoObs cache[64 * W];
+    __shared__ int s_bad[2][4];                            // outliers per wavefront, double-buffered over the rounds
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     static_assert(sizeof(PoObs) == 7 * sizeof(double), "PoObs is copied as doubles");
-    for (int i = lane; i < 7 * n; i += 64) reinterpret_cast<double*>(cache)[i] = reinterpret_cast<const double*>(packed)[i];      // page-locked host memory, over PCIe
+    for (int i = tid; i < 7 * n; i += 64 * W) reinterpret_cast<double*>(cache)[i] = reinterpret_cast<const double*>(packed)[i];      // page-locked host memory, over PCIe
     double pose[7];
 #pragma unroll
     for (int i = 0; i < 7; ++i) pose[i] = pose7[i];
     __syncthreads();
-    unsigned act = 0;                                      // bit u: observation lane + 64 u is an inlier of the last classification
-#pragma unroll
-    for (int u = 0; u < OPL; ++u) if (lane + 64 * u < n) act |= 1u << u;
+    bool act = tid < n;                                    // this lane's observation is an inlier of the last classification
 #ifdef LPSLAM_PO_STAMPS
     double po_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, po_last = (double)clock64();
 #endif
@@ -2259,27 +2267,24 @@ __global__ __launch_bounds__(64) void k_pose_optimize_w1(double* pose7, const Po
         double acc[PO_NV];
 #pragma unroll
         for (int q = 0; q < PO_NV; ++q) acc[q] = 0;
-        // (a branch-free form with masked slots, so that a lane's observations interleave, measured no faster: the pass is bound by the
-        // one SIMD's issue rate, ~0.45 us per observation and lane -- which is why the four-wavefront kernel keeps the larger frames)
-#pragma unroll
-        for (int u = 0; u < OPL; ++u) {
-            if (!((act >> u) & 1u)) continue;
-            const PoObs c = cache[lane + 64 * u];
+        if (act) {
+            const PoObs c = cache[tid];
             lpslam_hip_ba_obs o;
             o.pose = 0; o.point = 0; o.u = c.u; o.v = c.v; o.ur = c.ur; o.inv_sigma2 = c.w;
             const double X[3] = {c.X[0], c.X[1], c.X[2]};
             po_accumulate(cam, R, t, o, X, robust, acc);
         }
         PO_STAMP(1);
-        po_reduce28_w1(acc, tr, out28, sums);
+        po_reduce28_wn<W>(acc, tr, out28, sums);
         PO_STAMP(2);
 #ifdef LPSLAM_PO_STAMPS
-        if (lane == 0) po_acc[15] += 1;
+        if (tid == 0) po_acc[15] += 1;
 #endif
     };
     int robust = 1, n_bad_last = 0, passes = 0;
     for (int round = 0; round < 4; ++round) {
-        // (the control flow of k_pose_optimize: g2o's Levenberg between the passes, up to ten iterations of up to ten trials)
+        // (the control flow of k_pose_optimize: g2o's Levenberg between the passes, up to ten iterations of up to ten trials; every
+        // wavefront takes the same decisions from the same sums, so the barriers inside the passes match)
         double sys[PO_NV], got[PO_NV], x[6], trial[7];
         pass(pose, robust, sys);
         ++passes;
@@ -2326,24 +2331,25 @@ __global__ __launch_bounds__(64) void k_pose_optimize_w1(double* pose7, const Po
         // classification with the plain chi2 of this round's pose
         double R[9];
         po_quat_to_rot(pose, R);
-        int bad = 0;
-        act = 0;
+        int is_out = 0;
+        if (tid < n) {
+            const PoObs c = cache[tid];
+            lpslam_hip_ba_obs o;
+            o.pose = 0; o.point = 0; o.u = c.u; o.v = c.v; o.ur = c.ur; o.inv_sigma2 = c.w;
+            double e[3], pc[3];
+            const int D = po_residual(cam, R, pose + 4, c.X, o, e, pc);
+            const double chi = o.inv_sigma2 * (e[0] * e[0] + e[1] * e[1] + (D == 3 ? e[2] * e[2] : 0.0));
+            const double thr = D == 3 ? 7.81473 : 5.99146;
+            is_out = thr < chi ? 1 : 0;
+        }
+        act = tid < n && !is_out;
+        int bad = __popcll(__ballot(is_out));
+        if (W > 1) {
+            if (lane == 0) s_bad[round & 1][wave] = bad;
+            __syncthreads();
+            bad = 0;
 #pragma unroll
-        for (int u = 0; u < OPL; ++u) {
-            const int k = lane + 64 * u;
-            int is_out = 0;
-            if (k < n) {
-                const PoObs c = cache[k];
-                lpslam_hip_ba_obs o;
-                o.pose = 0; o.point = 0; o.u = c.u; o.v = c.v; o.ur = c.ur; o.inv_sigma2 = c.w;
-                double e[3], pc[3];
-                const int D = po_residual(cam, R, pose + 4, c.X, o, e, pc);
-                const double chi = o.inv_sigma2 * (e[0] * e[0] + e[1] * e[1] + (D == 3 ? e[2] * e[2] : 0.0));
-                const double thr = D == 3 ? 7.81473 : 5.99146;
-                is_out = thr < chi ? 1 : 0;
-                if (!is_out) act |= 1u << u;
-            }
-            bad += __popcll(__ballot(is_out));
+            for (int w = 0; w < W; ++w) bad += s_bad[round & 1][w];
         }
         n_bad_last = bad;
         if (round == 2) robust = 0;
@@ -2351,11 +2357,10 @@ __global__ __launch_bounds__(64) void k_pose_optimize_w1(double* pose7, const Po
         if (n - n_bad_last < 5) break;
     }
 #ifdef LPSLAM_PO_STAMPS
-    if (lane == 0) for (int k = 0; k < 16; ++k) g_po_stamps[k] = po_acc[k];
+    if (tid == 0) for (int k = 0; k < 16; ++k) g_po_stamps[k] = po_acc[k];
 #endif
-#pragma unroll
-    for (int u = 0; u < OPL; ++u) if (lane + 64 * u < n) outlier[lane + 64 * u] = ((act >> u) & 1u) ? 0 : 1;       // the last classification made
-    if (lane == 0) {
+    if (tid < n) outlier[tid] = act ? 0 : 1;               // the last classification made
+    if (tid == 0) {
 #pragma unroll
         for (int i = 0; i < 7; ++i) pose7[i] = pose[i];
         n_inliers[0] = n - n_bad_last;
@@ -2364,7 +2369,7 @@ __global__ __launch_bounds__(64) void k_pose_optimize_w1(double* pose7, const Po
     if (done_flag) {
         __threadfence_system();
         __syncthreads();
-        if (lane == 0) __hip_atomic_store(done_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (tid == 0) __hip_atomic_store(done_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -3656,15 +3661,13 @@ int lpslam_hip_pose_optimize(lpslam_hip_ctx* ctx, double* pose7, const double* p
         const int seq = lp_next_seq(ctx->po_seq);
         __atomic_store_n(flag, 0, __ATOMIC_RELAXED);          // (the block is shared with the matchers' staging: whatever they left here is not a sequence number)
         static const bool four_waves_env = [] { const char* e = getenv("LPSLAM_HIP_PO_FOUR_WAVES"); return e && atoi(e) != 0; }();      // measurements: the round-4 kernel for every size
-        static const int po1_max = [] { const char* e = getenv("LPSLAM_HIP_PO_W1_MAX"); const int v = e ? atoi(e) : 128; return std::min(std::max(v, 0), 256); }();      // measurements: where the one-wavefront kernel hands over
+        static const int po1_max = [] { const char* e = getenv("LPSLAM_HIP_PO_W1_MAX"); const int v = e ? atoi(e) : 256; return std::min(std::max(v, 0), 256); }();      // measurements: where the one-observation-per-lane kernel hands over
         if (n_obs <= po1_max && !four_waves_env) {
-            // a tracked frame: the whole flow in one wavefront, 1 .. 4 observations per lane
-            const int opl = std::max(1, (n_obs + 63) / 64);
+            // a tracked frame: one observation per lane on 1, 2 or 4 wavefronts
             double* a0 = (double*)hb; uint8_t* a4 = hb + off_flags; int* a5 = (int*)(hb + 56);
-            if (opl == 1) hipLaunchKernelGGL(k_pose_optimize_w1<1>, dim3(1), dim3(64), 0, s, a0, (const PoObs*)packed, n_obs, c, a4, a5, flag, seq);
-            else if (opl == 2) hipLaunchKernelGGL(k_pose_optimize_w1<2>, dim3(1), dim3(64), 0, s, a0, (const PoObs*)packed, n_obs, c, a4, a5, flag, seq);
-            else if (opl == 3) hipLaunchKernelGGL(k_pose_optimize_w1<3>, dim3(1), dim3(64), 0, s, a0, (const PoObs*)packed, n_obs, c, a4, a5, flag, seq);
-            else hipLaunchKernelGGL(k_pose_optimize_w1<4>, dim3(1), dim3(64), 0, s, a0, (const PoObs*)packed, n_obs, c, a4, a5, flag, seq);
+            if (n_obs <= 64) hipLaunchKernelGGL(k_pose_optimize_wn<1>, dim3(1), dim3(64), 0, s, a0, (const PoObs*)packed, n_obs, c, a4, a5, flag, seq);
+            else if (n_obs <= 128) hipLaunchKernelGGL(k_pose_optimize_wn<2>, dim3(1), dim3(128), 0, s, a0, (const PoObs*)packed, n_obs, c, a4, a5, flag, seq);
+            else hipLaunchKernelGGL(k_pose_optimize_wn<4>, dim3(1), dim3(256), 0, s, a0, (const PoObs*)packed, n_obs, c, a4, a5, flag, seq);
         } else
         hipLaunchKernelGGL(k_pose_optimize<true>, dim3(1), dim3(PO_T), lds, s, (double*)hb, (const double*)nullptr, (const lpslam_hip_ba_obs*)nullptr, packed, n_obs, c,
                            hb + off_flags, (int*)(hb + 56), cache_n, flag, seq);
