@@ -4,6 +4,18 @@ import os, sys, time, threading
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from lpslam_amd import manager, synth, _build, hip
+if os.environ.get("WITH_TORCH") == "1":              # what bench.py's process looks like by the time it reaches tracker_multi
+    import torch
+    torch.cuda.init(); _x = torch.zeros(1 << 20, device="cuda"); torch.cuda.synchronize()
+if os.environ.get("WITH_CTX") == "1":
+    _ctx = hip.Context(1280, 720, 2000, 1.2, 8, max_images=96)
+    _ctx.set_mapping_reserve(16)
+if os.environ.get("WITH_BA") == "1":                 # ... after its mapping thread has solved windows: a high-priority stream stays in the context's pool
+    _p = synth.ba_problem(10, 300, 1500, 1280, 720, seq_id=0, tracks="contiguous", top_up=True)
+    _c2 = _ctx if os.environ.get("WITH_CTX") == "1" else hip.Context(1280, 720, 2000, 1.2, 8, max_images=2)
+    for _ in range(int(os.environ.get("WITH_BA_N", "1"))):
+        _b = hip.BundleAdjuster(_c2, _p["poses"], _p["fixed"], _p["points"], hip.ba_obs_array(_p), _p["cam"]); _b.optimize(True, 3); _b.close()
+    if os.environ.get("WITH_BA_CLOSE") == "1": _c2.close(); _c2 = None
 if os.environ.get("LPSLAM_DEV_FLAT"): hip.set_flat_priorities(True)
 _build.host_library()
 W, H, KPTS, LEVELS, KF = 1280, 720, 2000, 8, 6
