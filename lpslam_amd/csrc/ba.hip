@@ -670,9 +670,9 @@ __device__ __forceinline__ void lm_begin(BaView& v, double max_diag_pp, double m
     *v.ctl = c;
 }
 // after a trial: rho, accept / reject, lambda update, iteration and termination bookkeeping
-__device__ __forceinline__ void lm_decide(BaView& v, double temp_chi, double chol_failed, double scale_l, double scale_p, bool spec_ran = false)
+__device__ __forceinline__ int lm_decide(BaView& v, double temp_chi, double chol_failed, double scale_l, double scale_p, bool spec_ran = false, const BaCtl* preloaded = nullptr)      // returns "accepted"
 {
-    BaCtl c = *v.ctl;
+    BaCtl c = preloaded ? *preloaded : *v.ctl;             // (preloaded: the caller fetched the block beside its other loads -- one round trip less on the chain)
     if (chol_failed != 0.0) temp_chi = DBL_MAX;            // factorisation failed
     double rho = c.current_chi - temp_chi;
     const double scale = (scale_l + scale_p) + 1e-3;
@@ -714,6 +714,7 @@ __device__ __forceinline__ void lm_decide(BaView& v, double temp_chi, double cho
         c.need_lin = 0;
     }
     *v.ctl = c;
+    return c.last_accepted;
 }
 
 // ---- after the linearisation (mode 0) and the trial chi2 (mode 1): one workgroup (the last one of the pass that produced

@@ -407,25 +407,42 @@ __global__ __launch_bounds__(256) void k_ba_update(const BaView* __restrict__ vi
     if (!ba_last_block_sc1(v.ctl, land_blocks)) return;
     UPD_STAMP(true, 16);
     // ---- the landmark block that finishes last: totals in block order, then g2o's accept / reject
+    // (every load of a wavefront is in flight before the first is used: written as a loop over 64-strided elements the three trips to
+    // memory of 157 blocks came one after the other, 1.4 us of a 15.5 us kernel; the order of the additions is the loop's)
     __shared__ double s_tot[3];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    if (wave == 0) {
+    auto strided_sum = [&](const double* src, int n) -> double {
         double a = 0;
-        for (int i = lane; i < land_blocks; i += 64) a += ld_sc1(&v.part[land_blocks + i]);
-        a = wave_sum(a);
+        for (int i0 = 0; i0 < n; i0 += 256) {
+            double t[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int i = i0 + lane + 64 * u; t[u] = i < n ? ld_sc1(&src[i]) : 0.0; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (i0 + lane + 64 * u < n) a += t[u];
+        }
+        return wave_sum(a);
+    };
+    BaCtl c0;                                              // thread 0: the control block and the factorisation's verdict travel beside the partials
+    double fail0 = 0;
+    if (tid == 0) { c0 = *v.ctl; fail0 = v.scal[5]; }
+    if (wave == 0) {
+        const double a = strided_sum(v.part + land_blocks, land_blocks);
         if (lane == 0) s_tot[0] = a;
     } else if (wave == 1) {
-        double a = 0;
-        for (int i = lane; i < land_blocks; i += 64) a += ld_sc1(&v.part[i]);
-        a = wave_sum(a);
+        const double a = strided_sum(v.part, land_blocks);
         if (lane == 0) s_tot[1] = a;
     } else if (wave == 2) {
         double a = 0;
         const double lambda = fl.lambda;
-        for (int p = lane; p < v.n_poses; p += 64) {
-            const int slot = v.pose_slot[p];
+        for (int p0 = 0; p0 < v.n_poses; p0 += 64) {
+            const int p = p0 + lane;
+            const int slot = p < v.n_poses ? v.pose_slot[p] : -1;
+            double x[6], b[6];
+#pragma unroll
+            for (int q = 0; q < 6; ++q) { x[q] = slot >= 0 ? v.xp[6 * slot + q] : 0.0; b[q] = slot >= 0 ? v.bp[6 * slot + q] : 0.0; }
             if (slot < 0) continue;
-            for (int q = 0; q < 6; ++q) { const double x = v.xp[6 * slot + q]; a += x * (lambda * x + v.bp[6 * slot + q]); }
+#pragma unroll
+            for (int q = 0; q < 6; ++q) a += x[q] * (lambda * x[q] + b[q]);
         }
         a = wave_sum(a);
         if (lane == 0) s_tot[2] = a;
@@ -433,12 +450,11 @@ __global__ __launch_bounds__(256) void k_ba_update(const BaView* __restrict__ vi
     __syncthreads();
     UPD_STAMP(true, 17);
     if (tid == 0) {
-        const double fail = v.scal[5];
         v.scal[1] = s_tot[0]; v.scal[2] = s_tot[1]; v.scal[3] = s_tot[2];
-        lm_decide(v, s_tot[0], fail, s_tot[1], s_tot[2], true);
+        const int accepted = lm_decide(v, s_tot[0], fail0, s_tot[1], s_tot[2], true, &c0);
         // the pose side of the new state's linearisation is the next Schur launch's to compute -- when there is a new state
         int* sw = ba_sync_words(v);
-        sw[3] = v.ctl->last_accepted; sw[4] = 0; sw[2] = 0;      // ([2]: groups of the next Schur launch that have stored their share, ba_band.inl)
+        sw[3] = accepted; sw[4] = 0; sw[2] = 0;      // ([2]: groups of the next Schur launch that have stored their share, ba_band.inl)
     }
     UPD_STAMP(true, 18);
 }
