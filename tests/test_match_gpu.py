@@ -256,6 +256,21 @@ def test_projection_match_parity(hiplib, oracle, w, h, kpts, levels, radius):
     assert ng == no and np.array_equal(fg, fo) and 0 < ng <= gn
 
 
+def test_projection_match_when_every_keypoint_is_a_candidate(hiplib, oracle):
+    """1280 x 720, 2000 keypoints, windows that cover the image and every level: each query's wavefront lists more candidates than its LDS
+    list holds at a time (the second pass runs in the middle of the scan as well as at its end)."""
+    w, h = 1280, 720
+    ctx, q, qd, kp0, kp1, d1, xr1 = _proj_case(hiplib, oracle, w, h, 2000, 8, 11, n_queries=96)
+    assert len(kp1) > 1500
+    q["radius"] = 4000.0; q["min_level"] = -1; q["max_level"] = -1; q["x_right"] = -1.0
+    taken = np.zeros(len(kp1), np.uint8); taken[::7] = 1
+    for tk in (None, taken):
+        gi, gd, gn = ctx.match_projection(2, q, qd, 100, 0.8, tk, False)
+        oi, od, on = oracle.match_projection(kp1, d1, None, w, h, q, qd, 100, 0.8, taken=tk)
+        assert gn == on and np.array_equal(gi, oi) and np.array_equal(gd[gi >= 0], od[oi >= 0])
+        assert gn > 0
+
+
 def test_projection_match_sequential_semantics_and_rescans(hiplib, oracle):
     """Many queries compete for the same few keypoints (identical predictions, wide window): later queries must see the
     earlier assignments; short candidate lists get exhausted, which exercises the single-query re-scan."""
