@@ -421,6 +421,13 @@ int lpslam_hip_bow_transform_host(lpslam_hip_ctx* ctx, lpslam_hip_vocab* vocab, 
 int lpslam_hip_match_bow_tree(lpslam_hip_ctx* ctx, const uint8_t* q_desc32, const int32_t* q_node, int32_t nq, const uint8_t* t_desc32,
                               const int32_t* t_node, int32_t nt, const uint8_t* t_taken, int32_t hamming_thr, float lowe_ratio,
                               int32_t* match_idx, int32_t* match_dist, int32_t* n_matches);
+/* The same query set against n_sets target sets (a loop-candidate search: the new keyframe against up to eight keyframes,
+ * [UPSTREAM] loop_detector -> match::bow_tree::match_keyframes per candidate) in ONE round trip to the device; set i's results in
+ * match_idx[i][0 .. nq), match_dist[i] (match_dist or its entries may be NULL), n_matches[i]; t_taken (or its entries) may be NULL.
+ * Results are those of n_sets calls of lpslam_hip_match_bow_tree. */
+int lpslam_hip_match_bow_tree_multi(lpslam_hip_ctx* ctx, const uint8_t* q_desc32, const int32_t* q_node, int32_t nq, int32_t n_sets,
+                                    const uint8_t* const* t_desc32, const int32_t* const* t_node, const int32_t* nt, const uint8_t* const* t_taken,
+                                    int32_t hamming_thr, float lowe_ratio, int32_t* const* match_idx, int32_t* const* match_dist, int32_t* n_matches);
 
 /* ---- projection matching ---------------------------------------------------------------------------------------------
  * [UPSTREAM] match::projection::match_frame_and_landmarks (local-map tracking) and match_current_and_last_frames (motion-model

@@ -15,6 +15,7 @@
 // descriptors = 32 wavefronts; latency bound, ~L round trips), k_bow_topk (one wavefront per query over the targets of its node, 4
 // best per query); the order-dependent part (a target taken by an earlier query) is replayed on the host over those short lists,
 // as the window matchers do (match.hip).
+#include <chrono>
 #include "internal.h"
 #include <algorithm>
 #include <cstring>
@@ -79,11 +80,11 @@ __device__ __forceinline__ unsigned long long wave_min_u64b(unsigned long long v
 
 // one wavefront per query: the 4 nearest free targets among positions [seg_lo, seg_hi) of the node-sorted target order;
 // key = distance << 32 | position (position order = target keypoint order inside a node: the first minimum wins)
-__global__ __launch_bounds__(256) void k_bow_topk(const uint8_t* __restrict__ q_desc, const int2* __restrict__ q_seg, const int* __restrict__ q_ids, int nq,
+__device__ __forceinline__ void bow_topk_body(int bx, const uint8_t* __restrict__ q_desc, const int2* __restrict__ q_seg, const int* __restrict__ q_ids, int nq,
                                                   const uint8_t* __restrict__ t_desc, const int32_t* __restrict__ t_order, const uint8_t* __restrict__ t_taken,
                                                   unsigned long long* __restrict__ out_keys, int* __restrict__ out_count)
 {
-    const int lane = threadIdx.x & 63, qslot = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, qslot = bx * 4 + (threadIdx.x >> 6);
     if (qslot >= nq) return;
     const int qi = q_ids ? q_ids[qslot] : qslot;
     const int2 seg = q_seg[qi];
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(256) void k_bow_topk(const uint8_t* __restrict__ q_
     unsigned long long top[4] = {NONE, NONE, NONE, NONE};
     int cnt = 0;
     for (int s = seg.x + lane; s < seg.y; s += 64) {
-        const int t = t_order[s];
+        const int t = t_order ? t_order[s] : s;          // (no order table: the targets were sent down in node order)
         if (t_taken[t]) continue;
         const uint32_t* d = reinterpret_cast<const uint32_t*>(t_desc + 32 * (size_t)t);
         int dist = 0;
@@ -119,6 +120,21 @@ __global__ __launch_bounds__(256) void k_bow_topk(const uint8_t* __restrict__ q_
         for (int r = 0; r < 4; ++r) out_keys[4 * (size_t)qslot + r] = res[r];
         out_count[qslot] = cnt;
     }
+}
+
+__global__ __launch_bounds__(256) void k_bow_topk(const uint8_t* __restrict__ q_desc, const int2* __restrict__ q_seg, const int* __restrict__ q_ids, int nq,
+                                                  const uint8_t* __restrict__ t_desc, const int32_t* __restrict__ t_order, const uint8_t* __restrict__ t_taken,
+                                                  unsigned long long* __restrict__ out_keys, int* __restrict__ out_count)
+{
+    bow_topk_body(blockIdx.x, q_desc, q_seg, q_ids, nq, t_desc, t_order, t_taken, out_keys, out_count);
+}
+// several target sets in one launch: blockIdx.y = set, its arrays at byte offsets of one block (targets already in node order)
+struct BowSetOff { unsigned seg, td, taken, keys, cnt, pad[3]; };
+__global__ __launch_bounds__(256) void k_bow_topk_sets(const uint8_t* __restrict__ base, const BowSetOff* __restrict__ sets, int nq)
+{
+    const BowSetOff o = sets[blockIdx.y];
+    bow_topk_body(blockIdx.x, base, (const int2*)(base + o.seg), (const int*)nullptr, nq, base + o.td, (const int32_t*)nullptr, base + o.taken,
+                  (unsigned long long*)(const_cast<uint8_t*>(base) + o.keys), (int*)(const_cast<uint8_t*>(base) + o.cnt));
 }
 
 }  // namespace
@@ -198,16 +214,17 @@ static int bow_transform_device(lpslam_hip_ctx* c, lpslam_hip_vocab* v, const ui
     hipLaunchKernelGGL(k_bow_transform, dim3((unsigned)((nm + 63) / 64)), dim3(64), 0, s, d_desc, d_count, n_max, v->d_child_start, v->d_child_list, v->d_desc, v->d_weight,
                        v->d_word, v->L, levels_up, d_word, d_w, d_node);
     B_HIP(hipGetLastError());
+    // one wait: the count and the three arrays (n_max entries each -- the callers' buffers hold a whole slot; entries behind the count
+    // are never written by the kernel and mean nothing) come back together
     int32_t n = n_max;
     if (d_count) B_HIP(hipMemcpyAsync(&n, d_count, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    if (n_max > 0) {
+        if (word_id) B_HIP(hipMemcpyAsync(word_id, d_word, (size_t)n_max * 4, hipMemcpyDeviceToHost, s));
+        if (word_weight) B_HIP(hipMemcpyAsync(word_weight, d_w, (size_t)n_max * 4, hipMemcpyDeviceToHost, s));
+        if (node_id) B_HIP(hipMemcpyAsync(node_id, d_node, (size_t)n_max * 4, hipMemcpyDeviceToHost, s));
+    }
     B_HIP(hipStreamSynchronize(s));
     n = std::min(n, n_max);
-    if (n > 0) {
-        if (word_id) B_HIP(hipMemcpyAsync(word_id, d_word, (size_t)n * 4, hipMemcpyDeviceToHost, s));
-        if (word_weight) B_HIP(hipMemcpyAsync(word_weight, d_w, (size_t)n * 4, hipMemcpyDeviceToHost, s));
-        if (node_id) B_HIP(hipMemcpyAsync(node_id, d_node, (size_t)n * 4, hipMemcpyDeviceToHost, s));
-        B_HIP(hipStreamSynchronize(s));
-    }
 #undef B_HIP
     release();
     if (count_out) *count_out = n;
@@ -239,95 +256,164 @@ int lpslam_hip_bow_transform_host(lpslam_hip_ctx* c, lpslam_hip_vocab* v, const 
     return rc;
 }
 
-int lpslam_hip_match_bow_tree(lpslam_hip_ctx* c, const uint8_t* q_desc32, const int32_t* q_node, int32_t nq, const uint8_t* t_desc32, const int32_t* t_node, int32_t nt,
-                              const uint8_t* t_taken_in, int32_t hamming_thr, float lowe_ratio, int32_t* match_idx, int32_t* match_dist, int32_t* n_matches)
+// One query set against n_sets target sets in ONE round trip: inputs staged contiguously in page-locked memory and sent down with one
+// copy, a k_bow_topk launch per set, the candidate lists back with one copy and one wait; the order-dependent part (a target matched by
+// an earlier query is invisible to later ones) is replayed on the host per set, with the single-query re-scan where a short list was
+// eaten.  (A loop-candidate search matches the new keyframe against up to eight keyframes: eight calls were eight uploads and eight waits,
+// 47 us each.)
+int lpslam_hip_match_bow_tree_multi(lpslam_hip_ctx* c, const uint8_t* q_desc32, const int32_t* q_node, int32_t nq, int32_t n_sets, const uint8_t* const* t_desc32,
+                                    const int32_t* const* t_node, const int32_t* nt_of, const uint8_t* const* t_taken_in, int32_t hamming_thr, float lowe_ratio,
+                                    int32_t* const* match_idx, int32_t* const* match_dist, int32_t* n_matches)
 {
-    if (!c || nq < 0 || nt < 0 || (nq > 0 && (!q_desc32 || !q_node || !match_idx)) || (nt > 0 && (!t_desc32 || !t_node))) { set_error("invalid bow_tree arguments"); return LPSLAM_HIP_ERR_INVALID; }
-    if (n_matches) *n_matches = 0;
-    for (int k = 0; k < nq; ++k) { match_idx[k] = -1; if (match_dist) match_dist[k] = 256; }
-    if (nq == 0 || nt == 0) return LPSLAM_HIP_OK;
+    if (!c || nq < 0 || n_sets < 0 || (n_sets > 0 && (!t_desc32 || !t_node || !nt_of || !match_idx)) || (nq > 0 && n_sets > 0 && (!q_desc32 || !q_node))) { set_error("invalid bow_tree arguments"); return LPSLAM_HIP_ERR_INVALID; }
+    for (int i = 0; i < n_sets; ++i) {
+        if (nt_of[i] < 0 || (nq > 0 && !match_idx[i]) || (nt_of[i] > 0 && (!t_desc32[i] || !t_node[i]))) { set_error("invalid bow_tree arguments (set %d)", i); return LPSLAM_HIP_ERR_INVALID; }
+        if (n_matches) n_matches[i] = 0;
+        for (int k = 0; k < nq; ++k) { match_idx[i][k] = -1; if (match_dist && match_dist[i]) match_dist[i][k] = 256; }
+    }
+    if (nq == 0 || n_sets == 0) return LPSLAM_HIP_OK;
     LP_HIP(hipSetDevice(c->cfg.device));
     hipStream_t s = c->stream;
-    // targets in node order (stable: keypoint order inside a node), queries get the segment of their node
-    std::vector<int32_t> t_order;
-    t_order.reserve((size_t)nt);
-    for (int t = 0; t < nt; ++t) if (t_node[t] >= 0) t_order.push_back(t);
-    std::stable_sort(t_order.begin(), t_order.end(), [&](int32_t a, int32_t b) { return t_node[a] < t_node[b]; });
-    const int nto = (int)t_order.size();
-    std::vector<int32_t> sorted_nodes((size_t)nto);
-    for (int i = 0; i < nto; ++i) sorted_nodes[(size_t)i] = t_node[t_order[(size_t)i]];
+    static const bool trace = getenv("LPSLAM_HIP_MATCH_TRACE") != nullptr;
+    const auto tr0 = std::chrono::steady_clock::now();
+    auto tr_us = [&tr0]() { return 1e-3 * (double)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - tr0).count(); };
+    double tr_staged = 0, tr_back = 0;
     // the order upstream visits the queries in: node by node (ascending id), keypoint order inside a node
     std::vector<int32_t> q_order;
     for (int k = 0; k < nq; ++k) if (q_node[k] >= 0) q_order.push_back(k);
     std::stable_sort(q_order.begin(), q_order.end(), [&](int32_t a, int32_t b) { return q_node[a] < q_node[b]; });
-    if (q_order.empty() || nto == 0) return LPSLAM_HIP_OK;
-    const size_t o_keys = 0, o_cnt = o_keys + (size_t)nq * 4 * 8, o_ids = o_cnt + (size_t)nq * 4, o_seg = o_ids + 64, o_qd = o_seg + (size_t)nq * 8,
-                 o_td = o_qd + (size_t)nq * 32, o_order = o_td + (size_t)nt * 32, o_taken = o_order + (size_t)nt * 4, total = o_taken + ((size_t)nt + 63) / 64 * 64;
+    if (q_order.empty()) return LPSLAM_HIP_OK;
+    // Only what takes part travels: the queries that have a node, in the order they are served (query a = q_order[a]), and per set the
+    // targets that have a node, in node order (target position j = t_order[j]; a loop search's keyframes carry landmarks on a quarter of
+    // their keypoints: 2 x 16 KB per set instead of 2 x 64 KB down, 16 KB of lists instead of 64 KB back).
+    const int nqa = (int)q_order.size();
+    struct Set { std::vector<int32_t> t_order; int nto = 0; size_t o_seg = 0, o_td = 0, o_taken = 0, o_keys = 0, o_cnt = 0; bool live = false; };
+    std::vector<Set> sets((size_t)n_sets);
+    auto al = [](size_t x) { return (x + 63) & ~(size_t)63; };
+    // block: [query descriptors | per set: segments, target descriptors, taken]  (inputs, one copy down)  [per set: keys, counts]  (one copy back)  [ids]
+    size_t at = al((size_t)nqa * 32);
+    for (int i = 0; i < n_sets; ++i) {
+        Set& st = sets[(size_t)i];
+        const int nt = nt_of[i];
+        st.t_order.reserve((size_t)nt);
+        for (int t = 0; t < nt; ++t) if (t_node[i][t] >= 0) st.t_order.push_back(t);
+        std::stable_sort(st.t_order.begin(), st.t_order.end(), [&](int32_t a, int32_t b) { return t_node[i][a] < t_node[i][b]; });
+        st.nto = (int)st.t_order.size();
+        st.live = st.nto > 0;
+        if (!st.live) continue;
+        st.o_seg = at; at += al((size_t)nqa * 8);
+        st.o_td = at; at += al((size_t)st.nto * 32);
+        st.o_taken = at; at += al((size_t)st.nto);
+    }
+    const size_t o_tab = at; at += al((size_t)n_sets * sizeof(BowSetOff));      // offsets of the live sets (k_bow_topk_sets)
+    const size_t in_end = at;
+    for (Set& st : sets) if (st.live) { st.o_keys = at; at += al((size_t)nqa * 4 * 8); st.o_cnt = at; at += al((size_t)nqa * 4); }
+    const size_t out_end = at, o_ids = at, total = o_ids + 64;
+    if (o_tab == al((size_t)nqa * 32)) return LPSLAM_HIP_OK;                 // no set has a target under any node
+    if (at + 64 >= (size_t)0xffffffffu) { set_error("bow_tree: the sets do not fit one block"); return LPSLAM_HIP_ERR_CAPACITY; }
     void* blk = nullptr; size_t cap = 0;
     { const int rc = lp_pool_alloc(c, total, &blk, &cap); if (rc) return rc; }
     auto release = [&]() { lp_pool_free(c, blk, cap); };
 #define B_HIP(x) do { if ((x) != hipSuccess) { release(); set_error("HIP call failed: %s", #x); return LPSLAM_HIP_ERR_DEVICE; } } while (0)
     if (c->h_match_bytes < total) {
-        if (c->h_match) (void)hipHostFree(c->h_match);
+        if (c->h_match) { B_HIP(hipStreamSynchronize(s)); (void)hipHostFree(c->h_match); }
         c->h_match = nullptr; c->h_match_bytes = 0;
         B_HIP(hipHostMalloc((void**)&c->h_match, total + total / 2, hipHostMallocDefault));
         c->h_match_bytes = total + total / 2;
     }
     uint8_t* base = (uint8_t*)blk; uint8_t* hb = c->h_match;
-    int2* seg = (int2*)(hb + o_seg);
-    for (int k = 0; k < nq; ++k) {
-        if (q_node[k] < 0) { seg[k] = make_int2(0, 0); continue; }
-        const auto lo = std::lower_bound(sorted_nodes.begin(), sorted_nodes.end(), q_node[k]), hi = std::upper_bound(sorted_nodes.begin(), sorted_nodes.end(), q_node[k]);
-        seg[k] = make_int2((int)(lo - sorted_nodes.begin()), (int)(hi - sorted_nodes.begin()));
-    }
-    memcpy(hb + o_qd, q_desc32, (size_t)nq * 32);
-    memcpy(hb + o_td, t_desc32, (size_t)nt * 32);
-    memcpy(hb + o_order, t_order.data(), (size_t)nto * 4);
-    uint8_t* taken = hb + o_taken;
-    for (int t = 0; t < nt; ++t) taken[t] = t_taken_in ? (t_taken_in[t] ? 1 : 0) : 0;
-    B_HIP(hipMemcpyAsync(base + o_seg, hb + o_seg, total - o_seg, hipMemcpyHostToDevice, s));
-    unsigned long long* d_keys = (unsigned long long*)(base + o_keys); int* d_cnt = (int*)(base + o_cnt); int* d_ids = (int*)(base + o_ids);
-    hipLaunchKernelGGL(k_bow_topk, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s, base + o_qd, (const int2*)(base + o_seg), (const int*)nullptr, nq, base + o_td,
-                       (const int32_t*)(base + o_order), base + o_taken, d_keys, d_cnt);
-    B_HIP(hipGetLastError());
-    B_HIP(hipMemcpyAsync(hb + o_keys, d_keys, (size_t)nq * 4 * 8 + (size_t)nq * 4, hipMemcpyDeviceToHost, s));
-    B_HIP(hipStreamSynchronize(s));
-    const unsigned long long* keys = (const unsigned long long*)(hb + o_keys);
-    const int* cnt = (const int*)(hb + o_cnt);
-    int found = 0;
-    for (int32_t k : q_order) {
-        unsigned long long cand[4] = {keys[4 * (size_t)k], keys[4 * (size_t)k + 1], keys[4 * (size_t)k + 2], keys[4 * (size_t)k + 3]};
-        auto free_ones = [&](unsigned long long* out) {
-            int m = 0;
-            for (int r = 0; r < 4; ++r) if (cand[r] != ~0ull && !taken[t_order[(size_t)(cand[r] & 0xffffffffu)]]) out[m++] = cand[r];
-            return m; };
-        unsigned long long fr[4];
-        int m = free_ones(fr);
-        if (m < 2 && cnt[k] > 4) {
-            // the short list was eaten by earlier queries: scan again for this query with the current assignment
-            B_HIP(hipMemcpyAsync(base + o_taken, taken, (size_t)nt, hipMemcpyHostToDevice, s));
-            B_HIP(hipMemcpyAsync(d_ids, &k, sizeof(int), hipMemcpyHostToDevice, s));
-            hipLaunchKernelGGL(k_bow_topk, dim3(1), dim3(256), 0, s, base + o_qd, (const int2*)(base + o_seg), (const int*)d_ids, 1, base + o_td,
-                               (const int32_t*)(base + o_order), base + o_taken, d_keys, d_cnt);
-            B_HIP(hipGetLastError());
-            B_HIP(hipMemcpyAsync(cand, d_keys, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-            B_HIP(hipStreamSynchronize(s));
-            m = free_ones(fr);
+    for (int a = 0; a < nqa; ++a) memcpy(hb + 32 * (size_t)a, q_desc32 + 32 * (size_t)q_order[(size_t)a], 32);
+    std::vector<std::vector<uint8_t>> taken_of((size_t)n_sets);              // by target index, as the replay keeps it
+    for (int i = 0; i < n_sets; ++i) {
+        Set& st = sets[(size_t)i];
+        if (!st.live) continue;
+        const int nt = nt_of[i];
+        // segment of every served query in the node-sorted target order: both sides ascend by node, one merge
+        int2* seg = (int2*)(hb + st.o_seg);
+        int lo = 0;
+        for (int a = 0; a < nqa; ) {
+            const int node = q_node[q_order[(size_t)a]];
+            while (lo < st.nto && t_node[i][st.t_order[(size_t)lo]] < node) ++lo;
+            int hi = lo;
+            while (hi < st.nto && t_node[i][st.t_order[(size_t)hi]] == node) ++hi;
+            for (; a < nqa && q_node[q_order[(size_t)a]] == node; ++a) seg[a] = make_int2(lo, hi);
+            lo = hi;
         }
-        if (m == 0) continue;
-        const int best = (int)(fr[0] >> 32), best_t = t_order[(size_t)(fr[0] & 0xffffffffu)];
-        const int second = m > 1 ? (int)(fr[1] >> 32) : 256;
-        if (hamming_thr < best) continue;
-        if (lowe_ratio * (float)second < (float)best) continue;
-        taken[best_t] = 1;
-        match_idx[k] = best_t;
-        if (match_dist) match_dist[k] = best;
-        ++found;
+        std::vector<uint8_t>& taken = taken_of[(size_t)i];
+        taken.assign((size_t)nt, 0);
+        const uint8_t* tin = t_taken_in ? t_taken_in[i] : nullptr;
+        if (tin) for (int t = 0; t < nt; ++t) taken[(size_t)t] = tin[t] ? 1 : 0;
+        uint8_t* td = hb + st.o_td; uint8_t* tk = hb + st.o_taken;
+        for (int j = 0; j < st.nto; ++j) { const int t = st.t_order[(size_t)j]; memcpy(td + 32 * (size_t)j, t_desc32[i] + 32 * (size_t)t, 32); tk[j] = taken[(size_t)t]; }
+    }
+    int n_live = 0;
+    {
+        BowSetOff* tab = (BowSetOff*)(hb + o_tab);
+        for (Set& st : sets) if (st.live) tab[n_live++] = BowSetOff{(unsigned)st.o_seg, (unsigned)st.o_td, (unsigned)st.o_taken, (unsigned)st.o_keys, (unsigned)st.o_cnt, {0, 0, 0}};
+    }
+    tr_staged = tr_us();
+    B_HIP(hipMemcpyAsync(base, hb, in_end, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_bow_topk_sets, dim3((unsigned)((nqa + 3) / 4), (unsigned)n_live), dim3(256), 0, s, (const uint8_t*)base, (const BowSetOff*)(base + o_tab), nqa);
+    B_HIP(hipGetLastError());
+    B_HIP(hipMemcpyAsync(hb + in_end, base + in_end, out_end - in_end, hipMemcpyDeviceToHost, s));
+    B_HIP(hipStreamSynchronize(s));
+    tr_back = tr_us();
+    int* d_ids = (int*)(base + o_ids);
+    int found_all = 0;
+    for (int i = 0; i < n_sets; ++i) {
+        Set& st = sets[(size_t)i];
+        if (!st.live) continue;
+        const unsigned long long* keys = (const unsigned long long*)(hb + st.o_keys);
+        const int* cnt = (const int*)(hb + st.o_cnt);
+        std::vector<uint8_t>& taken = taken_of[(size_t)i];
+        const std::vector<int32_t>& t_order = st.t_order;
+        int found = 0;
+        for (int a = 0; a < nqa; ++a) {
+            const int32_t k = q_order[(size_t)a];
+            unsigned long long cand[4] = {keys[4 * (size_t)a], keys[4 * (size_t)a + 1], keys[4 * (size_t)a + 2], keys[4 * (size_t)a + 3]};
+            auto free_ones = [&](unsigned long long* out) {
+                int m = 0;
+                for (int r = 0; r < 4; ++r) if (cand[r] != ~0ull && !taken[(size_t)t_order[(size_t)(cand[r] & 0xffffffffu)]]) out[m++] = cand[r];
+                return m; };
+            unsigned long long fr[4];
+            int m = free_ones(fr);
+            if (m < 2 && cnt[a] > 4) {
+                // the short list was eaten by earlier queries: scan again for this query with the current assignment
+                uint8_t* tk = hb + st.o_taken;
+                for (int j = 0; j < st.nto; ++j) tk[j] = taken[(size_t)t_order[(size_t)j]];
+                B_HIP(hipMemcpyAsync(base + st.o_taken, tk, (size_t)st.nto, hipMemcpyHostToDevice, s));
+                B_HIP(hipMemcpyAsync(d_ids, &a, sizeof(int), hipMemcpyHostToDevice, s));
+                hipLaunchKernelGGL(k_bow_topk, dim3(1), dim3(256), 0, s, base, (const int2*)(base + st.o_seg), (const int*)d_ids, 1, base + st.o_td,
+                                   (const int32_t*)nullptr, base + st.o_taken, (unsigned long long*)(base + st.o_keys), (int*)(base + st.o_cnt));
+                B_HIP(hipGetLastError());
+                B_HIP(hipMemcpyAsync(cand, base + st.o_keys, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+                B_HIP(hipStreamSynchronize(s));
+                m = free_ones(fr);
+            }
+            if (m == 0) continue;
+            const int best = (int)(fr[0] >> 32), best_t = t_order[(size_t)(fr[0] & 0xffffffffu)];
+            const int second = m > 1 ? (int)(fr[1] >> 32) : 256;
+            if (hamming_thr < best) continue;
+            if (lowe_ratio * (float)second < (float)best) continue;
+            taken[(size_t)best_t] = 1;
+            match_idx[i][k] = best_t;
+            if (match_dist && match_dist[i]) match_dist[i][k] = best;
+            ++found;
+        }
+        if (n_matches) n_matches[i] = found;
+        found_all += found;
     }
 #undef B_HIP
     release();
-    if (n_matches) *n_matches = found;
+    if (trace) fprintf(stderr, "bow_tree_match: %d queries, %d targets, %d matches; us: sorted %.1f, staged %.1f, lists back %.1f, replayed %.1f\n", nq, n_sets, found_all, 0.0, tr_staged, tr_back, tr_us());
     return LPSLAM_HIP_OK;
+}
+
+int lpslam_hip_match_bow_tree(lpslam_hip_ctx* c, const uint8_t* q_desc32, const int32_t* q_node, int32_t nq, const uint8_t* t_desc32, const int32_t* t_node, int32_t nt,
+                              const uint8_t* t_taken_in, int32_t hamming_thr, float lowe_ratio, int32_t* match_idx, int32_t* match_dist, int32_t* n_matches)
+{
+    if (!c || nq < 0 || nt < 0 || (nq > 0 && (!q_desc32 || !q_node || !match_idx)) || (nt > 0 && (!t_desc32 || !t_node))) { set_error("invalid bow_tree arguments"); return LPSLAM_HIP_ERR_INVALID; }
+    return lpslam_hip_match_bow_tree_multi(c, q_desc32, q_node, nq, 1, &t_desc32, &t_node, &nt, t_taken_in ? &t_taken_in : nullptr, hamming_thr, lowe_ratio, &match_idx, &match_dist, n_matches);
 }
 
 }  // extern "C"

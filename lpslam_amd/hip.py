@@ -34,7 +34,7 @@ SYMBOLS = [
     "lpslam_hip_get_candidates", "lpslam_hip_keypoint_buffers", "lpslam_hip_match_bf", "lpslam_hip_get_bf_knn2",
     "lpslam_hip_get_bf_matches", "lpslam_hip_match_bf_strided", "lpslam_hip_set_descriptors",
     "lpslam_hip_match_stereo", "lpslam_hip_match_stereo_strided", "lpslam_hip_get_stereo",
-    "lpslam_hip_vocab_create", "lpslam_hip_vocab_destroy", "lpslam_hip_vocab_info", "lpslam_hip_bow_transform", "lpslam_hip_bow_transform_host", "lpslam_hip_match_bow_tree",
+    "lpslam_hip_vocab_create", "lpslam_hip_vocab_destroy", "lpslam_hip_vocab_info", "lpslam_hip_bow_transform", "lpslam_hip_bow_transform_host", "lpslam_hip_match_bow_tree", "lpslam_hip_match_bow_tree_multi",
     "lpslam_hip_match_projection", "lpslam_hip_match_fuse", "lpslam_hip_match_area", "lpslam_hip_match_orientation_filter",
     "lpslam_hip_ba_create", "lpslam_hip_ba_prepare", "lpslam_hip_ba_build_batch", "lpslam_hip_ba_destroy", "lpslam_hip_ba_set_active", "lpslam_hip_ba_optimize", "lpslam_hip_ba_optimize_begin", "lpslam_hip_ba_optimize_end", "lpslam_hip_ba_graph_replays", "lpslam_hip_ba_wg_factorisations", "lpslam_hip_pose_optimize_passes", "lpslam_hip_match_bf_descriptors", "lpslam_hip_prefetch_frame", "lpslam_hip_get_frame_view", "lpslam_hip_desc_store_put", "lpslam_hip_desc_store_drop", "lpslam_hip_match_bf_stored", "lpslam_hip_ba_set_state_batch", "lpslam_hip_ba_get_batch", "lpslam_hip_ba_get_solver", "lpslam_hip_ba_set_solver", "lpslam_hip_ba_timeouts",
     "lpslam_hip_ba_optimize_batch", "lpslam_hip_ba_reset_batch", "lpslam_hip_ba_optimize_profiled", "lpslam_hip_ba_optimize_partitioned", "lpslam_hip_ba_optimize_partitioned_with",
@@ -599,6 +599,21 @@ def match_bow_tree(ctx, q_desc, q_node, t_desc, t_node, hamming_thr=50, lowe_rat
     f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_float, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]
     _check(f(ctx.h, _p(qd), _p(qn), len(qn), _p(td), _p(tn), len(tn), _p(tk), int(hamming_thr), float(lowe_ratio), _p(idx), _p(dist), C.byref(n)))
     return idx[:len(qn)], dist[:len(qn)], n.value
+
+
+def match_bow_tree_multi(ctx, q_desc, q_node, t_descs, t_nodes, hamming_thr=50, lowe_ratio=0.75, t_takens=None):
+    """one query set against several target sets in one round trip (lpslam_hip_match_bow_tree_multi); a list of (idx, dist, n) per set"""
+    qd = np.ascontiguousarray(q_desc, np.uint8); qn = np.ascontiguousarray(q_node, np.int32)
+    ns = len(t_descs)
+    tds = [np.ascontiguousarray(t, np.uint8) for t in t_descs]; tns = [np.ascontiguousarray(t, np.int32) for t in t_nodes]
+    tks = [np.ascontiguousarray(t, np.uint8) if t is not None else None for t in (t_takens or [None] * ns)]
+    idx = [np.full(max(len(qn), 1), -1, np.int32) for _ in range(ns)]; dist = [np.zeros(max(len(qn), 1), np.int32) for _ in range(ns)]
+    arr = lambda xs: (C.c_void_p * max(ns, 1))(*[x.ctypes.data if x is not None and x.size else None for x in xs])
+    nts = (C.c_int32 * max(ns, 1))(*[len(t) for t in tns]); nm = (C.c_int32 * max(ns, 1))()
+    f = ctx.lib.lpslam_hip_match_bow_tree_multi
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
+    _check(f(ctx.h, _p(qd), _p(qn), len(qn), ns, arr(tds), arr(tns), nts, arr(tks) if t_takens is not None else None, int(hamming_thr), float(lowe_ratio), arr(idx), arr(dist), nm))
+    return [(idx[i][:len(qn)], dist[i][:len(qn)], int(nm[i])) for i in range(ns)]
 
 
 class RcclComm:

@@ -558,7 +558,7 @@ int HipVslamTrackerBase::insertKeyframe(FrameData& f)
     }
     if (!m_stereo && c > m_segmentStart) monoTriangulate(c - 1, kf, f);
     kf.kpts = f.kpts; kf.desc = f.desc; kf.x_right = f.x_right; kf.depth = f.depth; kf.landmark = f.landmark;
-    if (m_vocab) { computeBow(kf); m_bowDb.add(c, kf.bow); }
+    if (m_vocab) { if (!frameNodes(f, kf.node, &kf.bow)) computeBow(kf); m_bowDb.add(c, kf.bow); }      // the frame's descriptors are still in its slot: no upload
     else if (m_loopClosure) storeDescriptors(c, kf);      // without a vocabulary the loop-candidate search matches descriptors: they stay on the device
     m_kfs.push_back(std::move(kf));
     if (m_mapCulling) {
@@ -1425,19 +1425,45 @@ bool HipVslamTrackerBase::detectAndCloseLoop(FrameData& cur, int c)
         bq.resize(bkeys.size() * (size_t)m_maxKp); bt.resize(bq.size()); bd.resize(bq.size()); bn.assign(bkeys.size(), 0);
         batched = !bkeys.empty() && lpslam_hip_match_bf_stored(m_ctx, cur.slot, bkeys.data(), (int32_t)bkeys.size(), 50, 0.75f, 1, bq.data(), bt.data(), bd.data(), m_maxKp, bn.data()) == LPSLAM_HIP_OK;
     }
+    // with a vocabulary: [UPSTREAM] match::bow_tree::match_keyframes per candidate -- landmark-carrying keypoints of both keyframes under the
+    // same vocabulary node -- for ALL candidates in one call (lpslam_hip_match_bow_tree_multi: one upload, one wait; candidate by candidate
+    // it was 47 us each, eight times per keyframe)
+    std::vector<std::vector<int32_t>> bow_idx;
+    std::vector<int> bow_slot(cands.size(), -1);
+    if (use_bow) {
+        std::vector<int32_t> qn(kc.node);
+        for (size_t i = 0; i < qn.size(); ++i) if (kc.landmark[i] < 0) qn[i] = -1;
+        std::vector<std::vector<int32_t>> tns;
+        std::vector<const uint8_t*> tdp; std::vector<const int32_t*> tnp; std::vector<int32_t> tnt; std::vector<int32_t*> idp;
+        for (size_t ci = 0; ci < cands.size(); ++ci) {
+            const Keyframe& ka = m_kfs[(size_t)cands[ci].second];
+            if (ka.kpts.empty() || ka.node.size() != ka.kpts.size()) continue;
+            bow_slot[ci] = (int)tns.size();
+            tns.emplace_back(ka.node);
+            std::vector<int32_t>& tn = tns.back();
+            for (size_t i = 0; i < tn.size(); ++i) if (ka.landmark[i] < 0) tn[i] = -1;
+            bow_idx.emplace_back(kc.kpts.size(), -1);
+        }
+        for (size_t ci = 0; ci < cands.size(); ++ci) {
+            if (bow_slot[ci] < 0) continue;
+            const Keyframe& ka = m_kfs[(size_t)cands[ci].second];
+            tdp.push_back(ka.desc.data()); tnp.push_back(tns[(size_t)bow_slot[ci]].data()); tnt.push_back((int32_t)ka.kpts.size()); idp.push_back(bow_idx[(size_t)bow_slot[ci]].data());
+        }
+        if (!tdp.empty() && lpslam_hip_match_bow_tree_multi(m_ctx, kc.desc.data(), qn.data(), (int32_t)qn.size(), (int32_t)tdp.size(), tdp.data(), tnp.data(), tnt.data(), nullptr, 50, 0.75f,
+                                                            idp.data(), nullptr, nullptr) != LPSLAM_HIP_OK) {
+            logMessage(LpSlamLogLevel_Error, std::string("loop candidates: ") + lpslam_hip_last_error());
+            for (auto& b : bow_slot) b = -2;                // every candidate of this keyframe is skipped
+        }
+    }
     size_t b_at = 0;
-    for (auto& cd : cands) {
+    for (size_t ci = 0; ci < cands.size(); ++ci) {
+        auto& cd = cands[ci];
         const Keyframe& ka = m_kfs[(size_t)cd.second];
         if (ka.kpts.empty()) continue;
         int32_t nm = 0;
         if (use_bow && ka.node.size() == ka.kpts.size()) {
-            // [UPSTREAM] match::bow_tree::match_keyframes: landmark-carrying keypoints of both keyframes under the same vocabulary node
-            std::vector<int32_t> qn(kc.node), tn(ka.node), idx(kc.kpts.size(), -1);
-            for (size_t i = 0; i < qn.size(); ++i) if (kc.landmark[i] < 0) qn[i] = -1;
-            for (size_t i = 0; i < tn.size(); ++i) if (ka.landmark[i] < 0) tn[i] = -1;
-            int32_t found = 0;
-            if (lpslam_hip_match_bow_tree(m_ctx, kc.desc.data(), qn.data(), (int32_t)qn.size(), ka.desc.data(), tn.data(), (int32_t)tn.size(), nullptr, 50, 0.75f,
-                                          idx.data(), nullptr, &found) != LPSLAM_HIP_OK) continue;
+            if (bow_slot[ci] < 0) continue;
+            std::vector<int32_t>& idx = bow_idx[(size_t)bow_slot[ci]];
             std::vector<float> aq(kc.kpts.size()), at(ka.kpts.size());
             for (size_t i = 0; i < aq.size(); ++i) aq[i] = kc.kpts[i].angle;
             for (size_t i = 0; i < at.size(); ++i) at[i] = ka.kpts[i].angle;

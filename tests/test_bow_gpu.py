@@ -71,3 +71,36 @@ def test_bow_tree_match_parity(hiplib, oracle, setup, levels_up, ratio, thr):
     assert np.all(gi[na < 0] == -1) and not np.any(taken[gi[gi >= 0]])
     m = gi[gi >= 0]
     assert len(np.unique(m)) == len(m)                                          # a target is matched once
+
+
+def test_bow_tree_match_of_several_sets_in_one_call(hiplib, oracle, setup):
+    """one keyframe's descriptors against five target sets (different frames, ragged sizes, an empty set, a set without a node in common,
+    one with a `taken` mask) in ONE call: every set's result is that of the single-set call and of the oracle"""
+    v, ctx, voc = setup
+    seq = synth.StereoSequence(640, 480, 4, n_points=6000)
+    ctx.upload(0, seq.frame(5)[0])
+    ctx.extract(1)
+    _, da = ctx.keypoints(0)
+    rng = np.random.default_rng(3)
+    _, _, na = voc.transform_host(da, 1)
+    na = na.copy(); na[rng.random(len(na)) < 0.3] = -1
+    tds, tns, tks = [], [], []
+    for i, fr in enumerate((6, 7, 9)):
+        ctx.upload(1, seq.frame(fr)[0]); ctx.extract_range(1, 1)
+        _, db = ctx.keypoints(1)
+        db = db[: len(db) - 37 * i].copy()
+        _, _, nb = voc.transform_host(db, 1)
+        tds.append(db); tns.append(nb.copy()); tks.append((rng.random(len(db)) < 0.1).astype(np.uint8) if i == 1 else None)
+    tds.append(np.zeros((0, 32), np.uint8)); tns.append(np.zeros(0, np.int32)); tks.append(None)                 # an empty set
+    tds.append(tds[0].copy()); tns.append(np.full(len(tns[0]), -1, np.int32)); tks.append(None)                  # no target is under a node
+    multi = hiplib.match_bow_tree_multi(ctx, da, na, tds, tns, 50, 0.75, tks)
+    assert len(multi) == 5
+    total = 0
+    for (gi, gd, gn), td, tn, tk in zip(multi, tds, tns, tks):
+        si, sd, sn = hiplib.match_bow_tree(ctx, da, na, td, tn, 50, 0.75, tk) if len(td) else (np.full(len(na), -1, np.int32), None, 0)
+        assert gn == sn and np.array_equal(gi, si)
+        if len(td):
+            oi, od, on = oracle.bow_tree_match(da, na, td, tn, 50, 0.75, tk if tk is not None else np.zeros(len(td), np.uint8))
+            assert gn == on and np.array_equal(gi, oi) and np.array_equal(gd[gi >= 0], od[oi >= 0])
+        total += gn
+    assert total > 100 and multi[3][2] == 0 and multi[4][2] == 0

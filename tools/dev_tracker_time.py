@@ -19,7 +19,7 @@ for async_map in ("true", "false", "true", "false"):
         c.camera_number = num; c.f_x = k["fx"]; c.f_y = k["fy"]; c.c_x = k["cx"]; c.c_y = k["cy"]
         c.resolution_x = W; c.resolution_y = H; c.focal_x_baseline = k["fxb"]
         mg.set_camera(c)
-    mg.add_tracker("VSLAMStereo", '{"cameraSetup": "stereo", "slamKeypoints": %d, "numLevels": %d, "keyframeInterval": %d, "asyncMapping": %s, "mappingReserve": %s}' % (KPTS, LEVELS, KF, async_map, os.environ.get("RESERVE", "0")))
+    mg.add_tracker("VSLAMStereo", '{"cameraSetup": "stereo", "slamKeypoints": %d, "numLevels": %d, "keyframeInterval": %d, "asyncMapping": %s, "mappingReserve": %s%s}' % (KPTS, LEVELS, KF, async_map, os.environ.get("RESERVE", "0"), os.environ.get("TRACKER_CFG", "")))
     arrivals = []
     mg.collect_results(on_result=lambda: arrivals.append(time.perf_counter())); mg.provide_odometry(native=os.environ.get("NATIVE_ODOM", "1") == "1")
     log = os.path.join(tempfile.mkdtemp(), "slam.log")
