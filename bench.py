@@ -845,14 +845,14 @@ def main():
             seq_t = wl.synth.StereoSequence(W, H, 4)
             tr_frames = [seq_t.frame(i) for i in range(120)]
 
-            def tracker_session(frames):
+            def tracker_session(frames, extra_cfg=""):
                 mg = manager.Manager()
                 for num in (0, 1):
                     c = manager.default_camera()
                     c.camera_number = num; c.f_x = wl.k["fx"]; c.f_y = wl.k["fy"]; c.c_x = wl.k["cx"]; c.c_y = wl.k["cy"]
                     c.resolution_x = W; c.resolution_y = H; c.focal_x_baseline = wl.k["fxb"]
                     mg.set_camera(c)
-                mg.add_tracker("VSLAMStereo", '{"cameraSetup": "stereo", "slamKeypoints": %d, "numLevels": %d, "keyframeInterval": %d, "device": %d}' % (KPTS, LEVELS, KF_INTERVAL, device))
+                mg.add_tracker("VSLAMStereo", '{"cameraSetup": "stereo", "slamKeypoints": %d, "numLevels": %d, "keyframeInterval": %d, "device": %d%s}' % (KPTS, LEVELS, KF_INTERVAL, device, extra_cfg))
                 arrivals = []
                 mg.collect_results(on_result=lambda: arrivals.append(time.perf_counter()))
                 mg.provide_odometry(native=True)           # the library's compiled identity-odometry callback: no interpreter (and no wait for its lock) on the worker thread
@@ -881,6 +881,14 @@ def main():
                                  "ms_per_frame_in_tracker": tstats.get("ms_per_frame"), "ms_pose_optimiser": tstats.get("ms_dev_pose"),
                                  "ms_matchers": tstats.get("ms_dev_match"), "ms_frame_read_back": tstats.get("ms_dev_get"),
                                  "warm_up": "one untimed 30-frame session in this process"}
+            # the same session with a vocabulary, as the reference always runs (vocabFile; the committed 1000-word test vocabulary: BoW vector of
+            # every keyframe, loop candidates from the BoW database, all candidates matched under the vocabulary's nodes in one call)
+            vocab = os.path.join(ROOT, "tests", "golden", "vocab_k10_L3.dbow2")
+            if os.path.exists(vocab):
+                mgv, t_v, st_v, _, vstats = tracker_session(tr_frames, ', "vocabFile": "%s"' % vocab)
+                extras["tracker"]["with_vocabulary"] = {"frames_per_s": round(len(mgv.results) / t_v, 1), "valid": int(sum(r["valid"] for r in mgv.results)), "key_frames": int(st_v.key_frames),
+                                                        "ms_per_frame_in_tracker": vstats.get("ms_per_frame"), "ms_kf_insert": vstats.get("ms_kf_insert"), "ms_kf_loop": vstats.get("ms_kf_loop"),
+                                                        "vocabulary": "tests/golden/vocab_k10_L3.dbow2 (k = 10, L = 3, 1000 words)"}
         except Exception as e:      # noqa: BLE001 -- an extra must not take the benchmark line down
             extras["tracker"] = {"error": str(e)}
         # N sessions through the drop-in API at once: N LpSlamManager instances in this process on this GPU -- what BASELINE configs[3]
