@@ -1735,6 +1735,15 @@ __device__ __forceinline__ void po_quat_to_rot(const double* q, double* R)
     R[3] = 2 * (x * y + w * z);     R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - w * x);
     R[6] = 2 * (x * z - w * y);     R[7] = 2 * (y * z + w * x);     R[8] = 1 - 2 * (x * x + y * y);
 }
+// the same for a quaternion of unit length (what po_oplus returns): no normalisation on the chain between two passes
+__device__ __forceinline__ void po_unit_quat_to_rot(const double* q, double* R)
+{
+#pragma clang fp contract(fast)
+    const double w = q[0], x = q[1], y = q[2], z = q[3];
+    R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - w * z);     R[2] = 2 * (x * z + w * y);
+    R[3] = 2 * (x * y + w * z);     R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - w * x);
+    R[6] = 2 * (x * z - w * y);     R[7] = 2 * (y * z + w * x);     R[8] = 1 - 2 * (x * x + y * y);
+}
 __device__ __forceinline__ void po_huber(double e2, double delta, double* rho0, double* rho1)
 {
 #pragma clang fp contract(fast)
@@ -2256,25 +2265,33 @@ __global__ __launch_bounds__(64 * W) void k_pose_optimize_wn(double* pose7, cons
     double pose[7];
 #pragma unroll
     for (int i = 0; i < 7; ++i) pose[i] = pose7[i];
+    {   // unit quaternion from here on: every pose the passes see is this one or a po_oplus result (normalised there)
+        const double rn = po_rsqrt(pose[0] * pose[0] + pose[1] * pose[1] + pose[2] * pose[2] + pose[3] * pose[3]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pose[i] *= rn;
+    }
     __syncthreads();
     bool act = tid < n;                                    // this lane's observation is an inlier of the last classification
+    // the lane's observation stays in registers for the whole call (the compiler cannot keep it there itself: the reduction writes LDS
+    // between two passes)
+    lpslam_hip_ba_obs o;
+    double X[3];
+    {
+        const PoObs c = cache[tid < n ? tid : 0];
+        o.pose = 0; o.point = 0; o.u = c.u; o.v = c.v; o.ur = c.ur; o.inv_sigma2 = c.w;
+        X[0] = c.X[0]; X[1] = c.X[1]; X[2] = c.X[2];
+    }
 #ifdef LPSLAM_PO_STAMPS
     double po_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, po_last = (double)clock64();
 #endif
     auto pass = [&](const double (&p7)[7], int robust, double (&sums)[PO_NV]) __attribute__((always_inline)) {
         double R[9];
-        po_quat_to_rot(p7, R);
+        po_unit_quat_to_rot(p7, R);
         const double t[3] = {p7[4], p7[5], p7[6]};
         double acc[PO_NV];
 #pragma unroll
         for (int q = 0; q < PO_NV; ++q) acc[q] = 0;
-        if (act) {
-            const PoObs c = cache[tid];
-            lpslam_hip_ba_obs o;
-            o.pose = 0; o.point = 0; o.u = c.u; o.v = c.v; o.ur = c.ur; o.inv_sigma2 = c.w;
-            const double X[3] = {c.X[0], c.X[1], c.X[2]};
-            po_accumulate(cam, R, t, o, X, robust, acc);
-        }
+        if (act) po_accumulate(cam, R, t, o, X, robust, acc);
         PO_STAMP(1);
         po_reduce28_wn<W>(acc, tr, out28, sums);
         PO_STAMP(2);
@@ -2331,14 +2348,11 @@ __global__ __launch_bounds__(64 * W) void k_pose_optimize_wn(double* pose7, cons
         PO_STAMP(3);
         // classification with the plain chi2 of this round's pose
         double R[9];
-        po_quat_to_rot(pose, R);
+        po_unit_quat_to_rot(pose, R);
         int is_out = 0;
         if (tid < n) {
-            const PoObs c = cache[tid];
-            lpslam_hip_ba_obs o;
-            o.pose = 0; o.point = 0; o.u = c.u; o.v = c.v; o.ur = c.ur; o.inv_sigma2 = c.w;
             double e[3], pc[3];
-            const int D = po_residual(cam, R, pose + 4, c.X, o, e, pc);
+            const int D = po_residual(cam, R, pose + 4, X, o, e, pc);
             const double chi = o.inv_sigma2 * (e[0] * e[0] + e[1] * e[1] + (D == 3 ? e[2] * e[2] : 0.0));
             const double thr = D == 3 ? 7.81473 : 5.99146;
             is_out = thr < chi ? 1 : 0;
