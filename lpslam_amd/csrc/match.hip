@@ -857,7 +857,9 @@ static int window_match(lpslam_hip_ctx* c, int image, const lpslam_hip_proj_quer
         if (hipMemcpyAsync(base + o_q, hb + o_q, total - o_q, hipMemcpyHostToDevice, s) != hipSuccess) return false;
         on_device = true;
         return true; };
-    if (taken_in) P_HIP(to_device() ? hipSuccess : hipErrorUnknown);
+    // (a `taken` mask does not send the block down either: the second pass of the scan reads a candidate's best-so-far entry from the
+    // page-locked mirror together with its descriptor -- one more PCIe read in a round of loads that is in flight anyway, one copy-engine
+    // packet less in front of the kernel)
     const float inv_w = (float)(64.0 / c->lt.w[0]), inv_h = (float)(48.0 / c->lt.h[0]);
     const float* sxr = use_stereo ? c->d_stereo + (size_t)image * 2 * c->slots_per_image : nullptr;
     ProjGate gate{};
@@ -872,7 +874,7 @@ static int window_match(lpslam_hip_ctx* c, int image, const lpslam_hip_proj_quer
     __atomic_store_n(done_flag, 0, __ATOMIC_RELAXED);
     hipLaunchKernelGGL(k_proj_topk, dim3((nq + 3) / 4), dim3(256), 0, s, c->d_kpts + o, c->d_desc + o * 32, sxr, c->d_kp_count + image,
                        on_device ? d_q : (const ProjQuery*)(hb + o_q), on_device ? d_qd : (const uint8_t*)(hb + o_qd), (const int*)nullptr, nq,
-                       on_device ? (const int16_t*)d_bsf : (const int16_t*)nullptr, inv_w, inv_h, gate, (unsigned long long*)(hb + o_keys), (int*)(hb + o_cnt),
+                       on_device ? (const int16_t*)d_bsf : (taken_in ? (const int16_t*)(hb + o_bsf) : (const int16_t*)nullptr), inv_w, inv_h, gate, (unsigned long long*)(hb + o_keys), (int*)(hb + o_cnt),
                        done_counter, done_flag, done_seq);
     P_HIP(hipGetLastError());
     const unsigned long long* keys = (const unsigned long long*)(hb + o_keys);
