@@ -381,8 +381,26 @@ int lpslam_hip_create(const lpslam_hip_frontend_config* cfg, lpslam_hip_ctx** ou
     c->distribute_lds = lds;
     if (lds > 160 * 1024) { set_error("distribution kernel needs %zu B of LDS (> 160 KiB)", lds); delete c; return LPSLAM_HIP_ERR_INVALID; }
 
+    // Many sessions in one process (flat priorities): a HIP process has four hardware queues per priority and a new stream takes the least
+    // used one, so the contexts' streams -- created main first -- would put every main stream (the latency-bound matchers and pose
+    // optimisations of a tracked frame) on the SAME queue, behind one another: two managers ran at 1.24 x one.  Context k of the process
+    // puts k mod 4 placeholder streams in front of its main stream.
+    if (lp_flat_priorities() && !getenv("LPSLAM_HIP_NO_QUEUE_SPREAD")) {
+        static std::atomic<int> ctx_seq{0};
+        const int k = ctx_seq.fetch_add(1) % 4;
+        if (k > 0 && hipMalloc(&c->d_pad, 256) == hipSuccess) {
+            for (int i = 0; i < k; ++i) {
+                hipStream_t d = nullptr;
+                if (hipStreamCreateWithFlags(&d, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); break; }
+                (void)hipMemsetAsync(c->d_pad, 0, 4, d);           // (a stream takes its queue at its first use)
+                (void)hipStreamSynchronize(d);
+                c->pad_streams.push_back(d);
+            }
+        }
+    }
     hipError_t e = lp_fe_stream_create(&c->stream, false);
     if (e != hipSuccess) { delete c; return hip_fail(e, "hipStreamCreate"); }
+    if (c->d_pad) { (void)hipMemsetAsync(c->d_pad, 0, 4, c->stream); (void)hipStreamSynchronize(c->stream); }
     lp_ctx_register(c, true);
     rc = ctx_alloc(c);
     if (rc == LPSLAM_HIP_OK && !ofs.empty()) {
@@ -494,6 +512,8 @@ void lpslam_hip_destroy(lpslam_hip_ctx* c)
     if (c->fe_done) (void)hipEventDestroy(c->fe_done);
     if (c->debug_stream) { (void)hipStreamSynchronize(c->debug_stream); (void)hipStreamDestroy(c->debug_stream); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
+    for (hipStream_t d : c->pad_streams) (void)hipStreamDestroy(d);
+    if (c->d_pad) (void)hipFree(c->d_pad);
     delete c;
 }
 

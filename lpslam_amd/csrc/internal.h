@@ -69,6 +69,7 @@ struct lpslam_hip_ctx {
     int* d_fe_counters = nullptr;      // work-queue counters of the queued extraction launches (a ring of 64 per stream, 128 bytes apart)
     std::atomic<unsigned> fe_counter_next{0}, fe_counter_next_prefetch{0};
     hipStream_t debug_stream = nullptr; // lpslam_hip_debug_occupy_unreserved (test hook)
+    std::vector<hipStream_t> pad_streams; void* d_pad = nullptr;      // flat priorities: streams created in front of the main one, so that the main streams of a process' contexts spread over its hardware queues (api.hip)
     int reserve_cus = 0;               // lpslam_hip_set_mapping_reserve: CUs of every XCD the front end's streams leave to the mapping solves
     hipStream_t fe_stream = nullptr;   // prefetch: front end of the NEXT frame beside the tracking of this one (lp_fe_stream)
     hipEvent_t fe_done = nullptr;

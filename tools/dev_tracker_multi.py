@@ -36,6 +36,9 @@ def make():
         mg.set_camera(c)
     mg.add_tracker("VSLAMStereo", '{"cameraSetup": "stereo", "slamKeypoints": %d, "numLevels": %d, "keyframeInterval": %d, "device": 0%s}' % (KPTS, LEVELS, KF, extra))
     mg.count_results(); mg.provide_odometry(native=True)
+    if os.environ.get("LPSLAM_DEV_STATS"):
+        import tempfile
+        mg._log = os.path.join(tempfile.mkdtemp(prefix="lpslam_multi_"), "slam.log"); mg.log_to_file(mg._log)
     mg.start()
     return mg
 
@@ -56,6 +59,10 @@ def run(n):
     for t in th: t.join()
     got = sum(mg.result_counts()[0] for mg in mgs); valid = sum(mg.result_counts()[1] for mg in mgs)
     for mg in mgs: mg.stop()
+    if os.environ.get("LPSLAM_DEV_STATS"):
+        st = [manager.Manager.statistics(mg._log) for mg in mgs]
+        keys = ("ms_per_frame", "ms_track", "ms_local_map", "ms_keyframe", "ms_dev_match", "ms_dev_pose", "ms_dev_get", "ms_prefetch_wait", "ms_prefetch_busy", "ms_kf_wait", "ms_map_solve")
+        print("   per-manager statistics (mean over %d managers): " % n + ", ".join("%s %.3f" % (k, sum(x.get(k, 0) for x in st) / len(st)) for k in keys))
     return got, valid, dt
 
 
