@@ -81,8 +81,11 @@ int lpslam_hip_set_mapping_reserve(lpslam_hip_ctx* ctx, int32_t cus_per_xcd);
 int lpslam_hip_debug_occupy_unreserved(lpslam_hip_ctx* ctx, int32_t microseconds, int32_t* landed);
 /* Process-wide: create the streams of contexts made FROM NOW ON at the default priority (1) or in the three classes (0, the default: main /
  * low-priority prefetch / high-priority solves; -1: back to the environment, LPSLAM_HIP_FLAT_PRIORITIES).  A process that hosts many
- * sessions per GPU (one LpSlamManager per sequence, src/Manager/SlamManager.cpp:54-61) should set 1 before it creates them: every
- * priority class takes its own set of hardware queues, and beyond a few the command processor time-slices them. */
+ * sessions per GPU (one LpSlamManager per sequence, src/Manager/SlamManager.cpp:54-61) should set 1 FIRST, before anything in it has
+ * created a stream: every priority class takes its own set of hardware queues, beyond a few the command processor time-slices them, and
+ * one high-priority stream ever created in the process halves the aggregate of the sessions that follow.  In a flat
+ * process context k puts k mod 4 placeholder streams in front of its main stream, so that the contexts' main streams spread over the
+ * process' four hardware queues (LPSLAM_HIP_NO_QUEUE_SPREAD=1 switches that off: measurements). */
 int lpslam_hip_set_flat_priorities(int32_t flat);
 int lpslam_hip_sync(lpslam_hip_ctx* ctx);
 /* Geometry derived from the configuration (pyramid sizes, per-level keypoint quota). */

@@ -399,7 +399,12 @@ int lpslam_hip_create(const lpslam_hip_frontend_config* cfg, lpslam_hip_ctx** ou
         }
     }
     hipError_t e = lp_fe_stream_create(&c->stream, false);
-    if (e != hipSuccess) { delete c; return hip_fail(e, "hipStreamCreate"); }
+    if (e != hipSuccess) {
+        for (hipStream_t d : c->pad_streams) (void)hipStreamDestroy(d);
+        if (c->d_pad) (void)hipFree(c->d_pad);
+        delete c;
+        return hip_fail(e, "hipStreamCreate");
+    }
     if (c->d_pad) { (void)hipMemsetAsync(c->d_pad, 0, 4, c->stream); (void)hipStreamSynchronize(c->stream); }
     lp_ctx_register(c, true);
     rc = ctx_alloc(c);
