@@ -37,39 +37,48 @@ struct lpslam_hip_vocab {
 
 namespace {
 
-__global__ __launch_bounds__(64) void k_bow_transform(const uint8_t* __restrict__ desc, const int32_t* __restrict__ count, int n_fixed,
-                                                      const int32_t* __restrict__ child_start, const int32_t* __restrict__ child_list,
-                                                      const uint8_t* __restrict__ node_desc, const float* __restrict__ node_weight,
-                                                      const int32_t* __restrict__ node_word, int L, int levels_up,
-                                                      int32_t* __restrict__ word_id, float* __restrict__ word_weight, int32_t* __restrict__ node_id)
+// [UPSTREAM] DBoW2 TemplatedVocabulary::transform: every descriptor walks down the tree to its word, at each node to the child with the
+// smallest Hamming distance (the FIRST child on a tie); node_id = the ancestor `levels_up` levels above the leaves (FeatureVector).
+// SIXTEEN lanes per descriptor: a lane takes every sixteenth child of the node, the nearest child is the minimum of (distance, child
+// order) over the sixteen lanes, so a level costs one round of loads instead of k in a row (k = 10, L = 3 .. 6: 30 .. 60 dependent loads
+// with a thread per descriptor -- the kernel a keyframe's insertion waited for, 180 us with its four copies back).
+// Results go straight into page-locked host memory [count | word ids | weights | node ids], the last store releases `seq` into *flag.
+__global__ __launch_bounds__(256) void k_bow_transform16(const uint8_t* __restrict__ desc, const int32_t* __restrict__ count, int n_fixed,
+                                                         const int32_t* __restrict__ child_start, const int32_t* __restrict__ child_list,
+                                                         const uint8_t* __restrict__ node_desc, const float* __restrict__ node_weight,
+                                                         const int32_t* __restrict__ node_word, int L, int levels_up, int cap,
+                                                         int32_t* __restrict__ out_count, int32_t* __restrict__ word_id, float* __restrict__ word_weight, int32_t* __restrict__ node_id,
+                                                         unsigned* counter, int* flag, int seq)
 {
-    const int n = count ? *count : n_fixed;
-    const int i = blockIdx.x * 64 + threadIdx.x;
-    if (i >= n) return;
-    const uint4* q4 = reinterpret_cast<const uint4*>(desc + 32 * (size_t)i);
-    const uint4 qa = q4[0], qb = q4[1];
-    const int nid_level = L - levels_up;
-    int nid = 0;                                       // nid_level <= 0: the root groups everything
-    int cur = 0, level = 0;
-    for (;;) {
-        const int c0 = child_start[cur], c1 = child_start[cur + 1];
-        if (c0 >= c1) break;                           // a leaf
-        ++level;
-        int best = -1, best_d = 1 << 30;
-        for (int c = c0; c < c1; ++c) {
-            const int id = child_list[c];
-            const uint4* d4 = reinterpret_cast<const uint4*>(node_desc + 32 * (size_t)id);
-            const uint4 da = d4[0], db = d4[1];
-            const int d = __popc(qa.x ^ da.x) + __popc(qa.y ^ da.y) + __popc(qa.z ^ da.z) + __popc(qa.w ^ da.w) +
-                          __popc(qb.x ^ db.x) + __popc(qb.y ^ db.y) + __popc(qb.z ^ db.z) + __popc(qb.w ^ db.w);
-            if (d < best_d) { best_d = d; best = id; }    // strict: the first child wins a tie
+    const int n = min(count ? *count : n_fixed, cap);
+    const int i = (blockIdx.x * 256 + threadIdx.x) >> 4, sub = threadIdx.x & 15;
+    if (i < n) {
+        const uint4* q4 = reinterpret_cast<const uint4*>(desc + 32 * (size_t)i);
+        const uint4 qa = q4[0], qb = q4[1];
+        const int nid_level = L - levels_up;
+        int nid = 0, cur = 0, level = 0;
+        for (;;) {
+            const int c0 = child_start[cur], c1 = child_start[cur + 1];
+            if (c0 >= c1) break;                           // a leaf (the same for the sixteen lanes of a descriptor)
+            ++level;
+            unsigned best = 0xffffffffu;                   // distance << 16 | child order
+            for (int c = c0 + sub; c < c1; c += 16) {
+                const int id = child_list[c];
+                const uint4* d4 = reinterpret_cast<const uint4*>(node_desc + 32 * (size_t)id);
+                const uint4 da = d4[0], db = d4[1];
+                const int d = __popc(qa.x ^ da.x) + __popc(qa.y ^ da.y) + __popc(qa.z ^ da.z) + __popc(qa.w ^ da.w) +
+                              __popc(qb.x ^ db.x) + __popc(qb.y ^ db.y) + __popc(qb.z ^ db.z) + __popc(qb.w ^ db.w);
+                best = min(best, ((unsigned)d << 16) | (unsigned)(c - c0));
+            }
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) best = min(best, (unsigned)__shfl_xor((int)best, o, 16));
+            cur = child_list[c0 + (int)(best & 0xffffu)];
+            if (level == nid_level) nid = cur;
         }
-        cur = best;
-        if (level == nid_level) nid = cur;
+        if (sub == 0) { word_id[i] = node_word[cur]; word_weight[i] = node_weight[cur]; node_id[i] = nid; }
     }
-    word_id[i] = node_word[cur];
-    word_weight[i] = node_weight[cur];
-    node_id[i] = nid;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *out_count = n;
+    lp_signal_done(counter, flag, seq);
 }
 
 __device__ __forceinline__ unsigned long long wave_min_u64b(unsigned long long v)
@@ -206,27 +215,31 @@ static int bow_transform_device(lpslam_hip_ctx* c, lpslam_hip_vocab* v, const ui
 {
     hipStream_t s = c->stream;
     const size_t nm = (size_t)std::max(n_max, 1);
-    void* blk = nullptr; size_t cap = 0;
-    { const int rc = lp_pool_alloc(c, 3 * nm * 4 + 64, &blk, &cap); if (rc) return rc; }
-    auto release = [&]() { lp_pool_free(c, blk, cap); };
-#define B_HIP(x) do { if ((x) != hipSuccess) { release(); set_error("HIP call failed: %s", #x); return LPSLAM_HIP_ERR_DEVICE; } } while (0)
-    int32_t* d_word = (int32_t*)blk; float* d_w = (float*)((uint8_t*)blk + nm * 4); int32_t* d_node = (int32_t*)((uint8_t*)blk + 2 * nm * 4);
-    hipLaunchKernelGGL(k_bow_transform, dim3((unsigned)((nm + 63) / 64)), dim3(64), 0, s, d_desc, d_count, n_max, v->d_child_start, v->d_child_list, v->d_desc, v->d_weight,
-                       v->d_word, v->L, levels_up, d_word, d_w, d_node);
-    B_HIP(hipGetLastError());
-    // one wait: the count and the three arrays (n_max entries each -- the callers' buffers hold a whole slot; entries behind the count
-    // are never written by the kernel and mean nothing) come back together
-    int32_t n = n_max;
-    if (d_count) B_HIP(hipMemcpyAsync(&n, d_count, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    if (n_max > 0) {
-        if (word_id) B_HIP(hipMemcpyAsync(word_id, d_word, (size_t)n_max * 4, hipMemcpyDeviceToHost, s));
-        if (word_weight) B_HIP(hipMemcpyAsync(word_weight, d_w, (size_t)n_max * 4, hipMemcpyDeviceToHost, s));
-        if (node_id) B_HIP(hipMemcpyAsync(node_id, d_node, (size_t)n_max * 4, hipMemcpyDeviceToHost, s));
+    if (v->k > 65535) { set_error("vocabulary: more than 65535 children per node"); return LPSLAM_HIP_ERR_CAPACITY; }
+    // page-locked block: done flag | count | word ids | weights | node ids -- written by the kernel itself, released by its last store
+    const size_t o_word = 64, o_w = o_word + nm * 4, o_node = o_w + nm * 4, total = o_node + nm * 4;
+    if (c->h_match_bytes < total) {
+        if (c->h_match) { LP_HIP(hipStreamSynchronize(s)); (void)hipHostFree(c->h_match); }
+        c->h_match = nullptr; c->h_match_bytes = 0;
+        LP_HIP(hipHostMalloc((void**)&c->h_match, total + total / 2, hipHostMallocDefault));
+        c->h_match_bytes = total + total / 2;
     }
-    B_HIP(hipStreamSynchronize(s));
-    n = std::min(n, n_max);
-#undef B_HIP
-    release();
+    uint8_t* hb = c->h_match;
+    unsigned* counter = lp_done_counter(c, 4);
+    if (!counter) { set_error("device memory for the completion counters"); return LPSLAM_HIP_ERR_DEVICE; }
+    int* flag = (int*)hb;
+    const int seq = lp_next_seq(c->done_seq);
+    __atomic_store_n(flag, 0, __ATOMIC_RELAXED);
+    hipLaunchKernelGGL(k_bow_transform16, dim3((unsigned)((nm * 16 + 255) / 256)), dim3(256), 0, s, d_desc, d_count, n_max, v->d_child_start, v->d_child_list, v->d_desc, v->d_weight,
+                       v->d_word, v->L, levels_up, n_max, (int32_t*)(hb + 32), (int32_t*)(hb + o_word), (float*)(hb + o_w), (int32_t*)(hb + o_node), counter, flag, seq);
+    LP_HIP(hipGetLastError());
+    if (!lp_wait_done(flag, seq, s)) { (void)lp_wait_recover(c, 4, s); set_error("bow_transform: the kernel did not complete"); return LPSLAM_HIP_ERR_DEVICE; }
+    const int n = std::min(std::max(*(const int32_t*)(hb + 32), 0), n_max);
+    if (n > 0) {
+        if (word_id) memcpy(word_id, hb + o_word, (size_t)n * 4);
+        if (word_weight) memcpy(word_weight, hb + o_w, (size_t)n * 4);
+        if (node_id) memcpy(node_id, hb + o_node, (size_t)n * 4);
+    }
     if (count_out) *count_out = n;
     return LPSLAM_HIP_OK;
 }

@@ -70,12 +70,28 @@ bool Vocabulary::save_binary(const std::string& path) const
 
 BowVector make_bow_vector(const int32_t* word_id, const float* word_weight, int n)
 {
-    BowVector v;
-    v.reserve((size_t)n);
-    for (int i = 0; i < n; ++i) if (word_weight[i] > 0) v.emplace_back(word_id[i], (double)word_weight[i]);
-    std::stable_sort(v.begin(), v.end(), [](const std::pair<int32_t, double>& a, const std::pair<int32_t, double>& b) { return a.first < b.first; });
+    // by word, descriptors of a word in their own order (the order of the additions): keys word << 32 | index
+    // (a stable sort of pairs through a comparator was 80 us of a keyframe's insertion)
+    std::vector<uint64_t> keys, tmp;
+    keys.reserve((size_t)n);
+    uint32_t top = 0;
+    for (int i = 0; i < n; ++i) if (word_weight[i] > 0) { keys.push_back(((uint64_t)(uint32_t)word_id[i] << 32) | (uint32_t)i); top |= (uint32_t)word_id[i]; }
+    // LSD radix sort on the word, 11 bits a pass (stable: the index order inside a word survives); std::sort of 2000 keys was 50 us
+    tmp.resize(keys.size());
+    for (int shift = 32; shift < 64 && (top >> (shift - 32)) != 0; shift += 11) {
+        uint32_t hist[2049] = {0};
+        for (uint64_t k : keys) hist[((k >> shift) & 2047u) + 1]++;
+        for (int b = 0; b < 2048; ++b) hist[b + 1] += hist[b];
+        for (uint64_t k : keys) tmp[hist[(k >> shift) & 2047u]++] = k;
+        keys.swap(tmp);
+    }
     BowVector out;
-    for (auto& e : v) { if (!out.empty() && out.back().first == e.first) out.back().second += e.second; else out.push_back(e); }
+    out.reserve(keys.size());
+    for (uint64_t k : keys) {
+        const int32_t w = (int32_t)(uint32_t)(k >> 32);
+        const double x = (double)word_weight[(size_t)(k & 0xffffffffu)];
+        if (!out.empty() && out.back().first == w) out.back().second += x; else out.emplace_back(w, x);
+    }
     double s = 0;
     for (auto& e : out) s += std::fabs(e.second);
     if (s > 0) for (auto& e : out) e.second /= s;

@@ -506,11 +506,15 @@ bool HipVslamTrackerBase::frameNodes(const FrameData& f, std::vector<int32_t>& n
     std::vector<int32_t> word((size_t)m_maxKp), nd((size_t)m_maxKp);
     std::vector<float> weight((size_t)m_maxKp);
     int32_t n = 0;
+    static const bool trace = getenv("LPSLAM_HIP_MATCH_TRACE") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
     if (lpslam_hip_bow_transform(m_ctx, m_vocab, f.slot, m_bowLevelsUp, word.data(), weight.data(), nd.data(), m_maxKp, &n) != LPSLAM_HIP_OK) return false;
     if (n != (int32_t)f.kpts.size()) return false;
+    const auto t1 = std::chrono::steady_clock::now();
     nd.resize((size_t)n);
     node = std::move(nd);
     if (bow) *bow = make_bow_vector(word.data(), weight.data(), n);
+    if (trace) fprintf(stderr, "frame_nodes: device %.1f us, vector %.1f us\n", 1e6 * std::chrono::duration<double>(t1 - t0).count(), 1e6 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count());
     return true;
 }
 
@@ -558,7 +562,14 @@ int HipVslamTrackerBase::insertKeyframe(FrameData& f)
     }
     if (!m_stereo && c > m_segmentStart) monoTriangulate(c - 1, kf, f);
     kf.kpts = f.kpts; kf.desc = f.desc; kf.x_right = f.x_right; kf.depth = f.depth; kf.landmark = f.landmark;
-    if (m_vocab) { if (!frameNodes(f, kf.node, &kf.bow)) computeBow(kf); m_bowDb.add(c, kf.bow); }      // the frame's descriptors are still in its slot: no upload
+    if (m_vocab) {
+        static const bool trace = getenv("LPSLAM_HIP_MATCH_TRACE") != nullptr;
+        const auto t0 = std::chrono::steady_clock::now();
+        if (!frameNodes(f, kf.node, &kf.bow)) computeBow(kf);      // the frame's descriptors are still in its slot: no upload
+        const auto t1 = std::chrono::steady_clock::now();
+        m_bowDb.add(c, kf.bow);
+        if (trace) fprintf(stderr, "kf_bow: transform %.1f us, database %.1f us\n", 1e6 * std::chrono::duration<double>(t1 - t0).count(), 1e6 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count());
+    }
     else if (m_loopClosure) storeDescriptors(c, kf);      // without a vocabulary the loop-candidate search matches descriptors: they stay on the device
     m_kfs.push_back(std::move(kf));
     if (m_mapCulling) {
