@@ -2300,12 +2300,18 @@ __global__ __launch_bounds__(64 * W) void k_pose_optimize_wn(double* pose7, cons
 #endif
     };
     int robust = 1, n_bad_last = 0, passes = 0;
+    double sys[PO_NV];
+    double chi_kept = 0;                                   // the (robustified) chi2 at `pose` the previous round ended with
+    bool reuse = false;                                    // the round starts from the sums the previous one ended with
     for (int round = 0; round < 4; ++round) {
         // (the control flow of k_pose_optimize: g2o's Levenberg between the passes, up to ten iterations of up to ten trials; every
         // wavefront takes the same decisions from the same sums, so the barriers inside the passes match)
-        double sys[PO_NV], got[PO_NV], x[6], trial[7];
-        pass(pose, robust, sys);
-        ++passes;
+        double got[PO_NV], x[6], trial[7];
+        // A round opens with chi2 and the linearisation at its starting pose.  When the classification changed nothing and the kernel is
+        // the same, that is what the previous round ended with -- sys holds the sums at `pose` (an accepted trial's pass, or the ones the
+        // rejected trials left standing), chi_kept its chi2: the same numbers a pass would produce, so the pass is not made.
+        if (reuse) sys[27] = chi_kept;
+        else { pass(pose, robust, sys); ++passes; }
         double lambda = 1e-5 * fmax(fmax(fmax(fabs(sys[0]), fabs(sys[6])), fmax(fabs(sys[11]), fabs(sys[15]))), fmax(fabs(sys[18]), fabs(sys[20])));
         double ni = 2, current_chi = sys[27];
         int it = 0, qmax = 1;
@@ -2357,16 +2363,19 @@ __global__ __launch_bounds__(64 * W) void k_pose_optimize_wn(double* pose7, cons
             const double thr = D == 3 ? 7.81473 : 5.99146;
             is_out = thr < chi ? 1 : 0;
         }
-        act = tid < n && !is_out;
-        int bad = __popcll(__ballot(is_out));
+        const bool act_new = tid < n && !is_out;
+        int bad = __popcll(__ballot(is_out)) | (__ballot(act_new != act) ? 1 << 16 : 0);       // outliers | "some lane changed sides"
+        act = act_new;
         if (W > 1) {
             if (lane == 0) s_bad[round & 1][wave] = bad;
             __syncthreads();
             bad = 0;
 #pragma unroll
-            for (int w = 0; w < W; ++w) bad += s_bad[round & 1][w];
+            for (int w = 0; w < W; ++w) { const int b2 = s_bad[round & 1][w]; bad = ((bad & 0xffff) + (b2 & 0xffff)) | ((bad | b2) & (1 << 16)); }
         }
-        n_bad_last = bad;
+        n_bad_last = bad & 0xffff;
+        chi_kept = current_chi;
+        reuse = !(bad >> 16) && round != 2;                // (after round 2 the kernel changes: plain chi2)
         if (round == 2) robust = 0;
         PO_STAMP(8);
         if (n - n_bad_last < 5) break;
