@@ -762,7 +762,7 @@ def main():
         if wl.with_ba and "multi_session" not in skip:
             try:
                 S = 16
-                rounds = 4
+                rounds = int(os.environ.get("LPSLAM_BENCH_MS_ROUNDS", "4"))
                 fe_ctx = wl.ctx                                  # the sessions' frames: the resident ring, KF_INTERVAL frames per session and round
 
                 from concurrent.futures import ThreadPoolExecutor
