@@ -362,3 +362,41 @@ def test_mapping_reserve_completes_wherever_the_grid_lands(hiplib, oracle, reser
         assert len(gkp) != len(stale[i][0]) or not np.array_equal(gkp["x"], stale[i][0]["x"])
     ctx.sync()
     ctx.close()
+
+
+def test_contexts_of_a_flat_priority_process(hiplib, oracle):
+    """lpslam_hip_set_flat_priorities(1): five contexts created one after the other (context k puts k mod 4 placeholder streams in front of
+    its main stream; prefetch and solves at the default priority) each extract, prefetch and match like a context of the default kind:
+    same keypoints and descriptors as the oracle, same frames from the prefetch stream.  The switch is put back afterwards."""
+    import threading
+    w, h, kpts, levels = 320, 240, 400, 4
+    k = synth.intrinsics(w, h)
+    seq = synth.StereoSequence(w, h, 6)
+    f0, f1 = seq.frame(0), seq.frame(1)
+    kp_o, d_o = oracle.extract(f0[0], oracle.params(kpts, 1.2, levels))[:2]
+    hiplib.set_flat_priorities(True)
+    ctxs = []
+    try:
+        for i in range(5):
+            c = hiplib.Context(w, h, kpts, 1.2, levels, max_images=4)
+            ctxs.append(c)
+            c.upload(0, f0[0]); c.upload(1, f0[1])
+            c.extract_range(0, 2); c.match_stereo(0, 1, k["fxb"], k["baseline"])
+        for c in ctxs:
+            def helper(cc=c):
+                with cc.prefetch():
+                    cc.upload(2, f1[0]); cc.upload(3, f1[1])
+                    cc.extract_range(2, 2); cc.match_stereo(2, 3, k["fxb"], k["baseline"])
+            th = threading.Thread(target=helper); th.start()
+            c.match_bf(0, 1)
+            th.join(); c.prefetch_join()
+        frames = [(c.frame(0), c.frame(2)) for c in ctxs]
+        kp0, d0 = ctxs[0].keypoints(0)
+        _assert_same_keypoints(kp_o, d_o, kp0, d0)
+        for fr in frames[1:]:
+            for a, b in zip(fr[0] + fr[1], frames[0][0] + frames[0][1]):
+                assert np.array_equal(a, b)
+    finally:
+        for c in ctxs:
+            c.close()
+        hiplib.set_flat_priorities(None)
