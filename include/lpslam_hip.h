@@ -281,6 +281,14 @@ int lpslam_hip_ba_optimize_end(lpslam_hip_ba* ba, lpslam_hip_ba_iter_log* log, i
  * of a (stream, launch extents, robust, iters) signature the second time it sees it and replays it from then on, also for OTHER
  * problems with that signature on that stream).  Measurement / test hook; no reference counterpart. */
 int64_t lpslam_hip_ba_graph_replays(lpslam_hip_ctx* ctx);
+/* Totals over every bundle-adjustment problem this context has solved (the tracker's mapping thread makes a problem per keyframe and
+ * destroys it: what happened to them is only visible here).  SIGNATURES: entries of the (stream, signature) cache, bounded at 256 and
+ * never evicted -- a signature beyond the bound runs on direct launches; GRAPHS: graphs instantiated; REPLAYS: as
+ * lpslam_hip_ba_graph_replays; TIMEOUTS_*: hand-overs between workgroups that timed out (lpslam_hip_ba_timeouts, summed -- any value
+ * but 0 means a solve of this context failed).  Writes min(n, LPSLAM_HIP_BA_COUNTERS) values.  Measurement / test hook. */
+enum { LPSLAM_HIP_BA_COUNTER_SIGNATURES = 0, LPSLAM_HIP_BA_COUNTER_GRAPHS = 1, LPSLAM_HIP_BA_COUNTER_REPLAYS = 2,
+       LPSLAM_HIP_BA_COUNTER_TIMEOUTS_BAND = 3, LPSLAM_HIP_BA_COUNTER_TIMEOUTS_UPDATE = 4, LPSLAM_HIP_BA_COUNTERS = 5 };
+int lpslam_hip_ba_counters(lpslam_hip_ctx* ctx, int64_t* out, int32_t n);
 /* How many launches of the one-workgroup factorisation (k_chol_wg: batches of LPSLAM_HIP_CW_MIN_BATCH = 40 problems and more) this
  * context has enqueued.  Test hook: proves which of the two factorisations a batch went through.  No reference counterpart. */
 int64_t lpslam_hip_ba_wg_factorisations(lpslam_hip_ctx* ctx);

@@ -2708,6 +2708,7 @@ int report_faults(lpslam_hip_ba* b)
     const int nb = b->h_ctl.faults_band - b->faults_band, nu = b->h_ctl.faults_update - b->faults_update;
     if (nb <= 0 && nu <= 0) return LPSLAM_HIP_OK;
     b->faults_band = b->h_ctl.faults_band; b->faults_update = b->h_ctl.faults_update;
+    if (b->ctx) { b->ctx->ba_timeouts_band.fetch_add(std::max(nb, 0)); b->ctx->ba_timeouts_update.fetch_add(std::max(nu, 0)); }
     if (nb > 0) {
         (void)hipMemsetAsync((void*)b->h_view.blk_ticket, 0, 2 * sizeof(int), b->stream);
         if (b->h_view.band_hbw >= 0) (void)lpslam_hip_ba_set_solver(b, LPSLAM_HIP_BA_SOLVER_DENSE);
@@ -3107,6 +3108,24 @@ int lpslam_hip_ba_set_points_fixed(lpslam_hip_ba* b, int32_t points_fixed)
 // One unit = one LM trial.  Without rejected steps `iters` units finish the call with a single look at the control block;
 // every rejected trial costs one more unit, enqueued after that look.
 static const hipGraphExec_t kGraphFailed = (hipGraphExec_t)(uintptr_t)1;      // cache sentinel: capture / instantiate failed for this signature
+// Graph replay is OFF in a process that runs under a rocprofiler-sdk tool (rocprofv3, rocprof-compute).  A replay rings the doorbell once
+// for its ~125 AQL packets; with a tool attached the HSA runtime routes every queue through its InterceptQueue, which hands the tool's
+// packet interceptor (pointer into the ring, packet count) WITHOUT splitting a batch that wraps the end of the 1 MB ring, and the tool
+// reads the packets as a linear array: the first replay that straddles the ring's end (after ~16 k packets on the queue) faults in the
+// tool's packet loop (gpurun_out/tm2.log of round 5, resolved in DESIGN.md 13.1).  One packet per doorbell -- a direct launch -- never
+// wraps.  LPSLAM_HIP_BA_GRAPH=1 forces replay (to profile it on short runs), =0 switches it off anywhere.
+static bool ba_graphs_enabled()
+{
+    static const bool on = [] {
+        if (const char* e = getenv("LPSLAM_HIP_BA_GRAPH")) return atoi(e) != 0;
+        const char* tool = getenv("ROCP_TOOL_LIBRARIES"); const char* pre = getenv("LD_PRELOAD");
+        return !((tool && *tool) || (pre && strstr(pre, "rocprofiler-sdk")));
+    }();
+    return on;
+}
+// capture + instantiate happen once per (stream, signature): serialised over the whole process, so that two mapping threads (two managers)
+// never build graphs at the same time -- the replay itself, the hot path, takes no lock
+static std::mutex g_ba_capture_mutex;
 static int enqueue_batch(const BaLaunch& L, int units, bool first_batch)
 {
     for (int u = 0; u < units; ++u) {
@@ -3150,7 +3169,7 @@ int lpslam_hip_ba_optimize_begin(lpslam_hip_ba* b, int32_t robust, int32_t iters
         hipGraphExec_t exec = nullptr;
         void* slot = nullptr;
         bool capture = false;
-        {
+        if (ba_graphs_enabled()) {
             std::lock_guard<std::mutex> lock(c->pool_mutex);
             auto key = std::make_pair(b->stream, sig);
             auto it = c->ba_graphs.find(key);
@@ -3164,6 +3183,7 @@ int lpslam_hip_ba_optimize_begin(lpslam_hip_ba* b, int32_t robust, int32_t iters
             else { slot = nullptr; (void)hipGetLastError(); }
         }
         if (capture && slot) {
+            std::lock_guard<std::mutex> capture_lock(g_ba_capture_mutex);
             hipGraph_t graph = nullptr;
             if (hipStreamBeginCapture(b->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
                 L.d_views = (const BaView*)slot;
@@ -3174,6 +3194,7 @@ int lpslam_hip_ba_optimize_begin(lpslam_hip_ba* b, int32_t robust, int32_t iters
                     if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {
                         std::lock_guard<std::mutex> lock(c->pool_mutex);
                         c->ba_graphs[std::make_pair(b->stream, sig)] = exec;
+                        c->ba_graphs_built.fetch_add(1);
                     } else exec = nullptr;
                 }
                 if (graph) (void)hipGraphDestroy(graph);
@@ -3196,6 +3217,21 @@ int lpslam_hip_ba_optimize_begin(lpslam_hip_ba* b, int32_t robust, int32_t iters
 }
 
 int64_t lpslam_hip_ba_graph_replays(lpslam_hip_ctx* c) { return c ? (int64_t)c->ba_graph_replays.load() : 0; }
+int lpslam_hip_ba_counters(lpslam_hip_ctx* c, int64_t* out, int32_t n)
+{
+    if (!c || !out || n < 0) { set_error("null argument"); return LPSLAM_HIP_ERR_INVALID; }
+    int64_t v[LPSLAM_HIP_BA_COUNTERS] = {0};
+    {
+        std::lock_guard<std::mutex> lock(c->pool_mutex);
+        v[LPSLAM_HIP_BA_COUNTER_SIGNATURES] = (int64_t)c->ba_graphs.size();
+    }
+    v[LPSLAM_HIP_BA_COUNTER_GRAPHS] = (int64_t)c->ba_graphs_built.load();
+    v[LPSLAM_HIP_BA_COUNTER_REPLAYS] = (int64_t)c->ba_graph_replays.load();
+    v[LPSLAM_HIP_BA_COUNTER_TIMEOUTS_BAND] = (int64_t)c->ba_timeouts_band.load();
+    v[LPSLAM_HIP_BA_COUNTER_TIMEOUTS_UPDATE] = (int64_t)c->ba_timeouts_update.load();
+    for (int i = 0; i < n && i < LPSLAM_HIP_BA_COUNTERS; ++i) out[i] = v[i];
+    return LPSLAM_HIP_OK;
+}
 int64_t lpslam_hip_ba_wg_factorisations(lpslam_hip_ctx* c) { return c ? (int64_t)c->ba_wg_launches.load() : 0; }
 int32_t lpslam_hip_pose_optimize_passes(lpslam_hip_ctx* c) { return c ? c->po_passes : 0; }
 

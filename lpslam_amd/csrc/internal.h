@@ -114,6 +114,8 @@ struct lpslam_hip_ctx {
     std::map<hipStream_t, void*> ba_view_slot;
     std::map<std::pair<hipStream_t, std::array<int, 23>>, hipGraphExec_t> ba_graphs;      // nullptr = signature seen once
     std::atomic<long> ba_wg_launches{0};     // k_chol_wg launches so far (lpslam_hip_ba_wg_factorisations: a test sees which factorisation a batch took)
+    std::atomic<long> ba_graphs_built{0};    // graphs instantiated so far (at most 256: the signature cache is bounded)
+    std::atomic<long> ba_timeouts_band{0}, ba_timeouts_update{0};      // timed-out hand-overs of every problem of this context (report_faults)
     std::atomic<long> ba_graph_replays{0};   // hipGraphLaunch calls so far (lpslam_hip_ba_graph_replays: lets a test see that it exercised the replay path)
     std::vector<std::pair<size_t, void*>> pin_big;   // idle page-locked staging blocks (capacity, block) of lp_pin_big_alloc / free
     uint8_t* h_match = nullptr;        // pinned host staging of the window matchers (queries in, candidate lists out)

@@ -1718,7 +1718,12 @@ void HipVslamTrackerBase::finishMapping()
         m_mapCv.wait(lk, [this] { return !m_mapBusy; });
         job = std::move(m_mapOut);
     }
-    if (job) { ScopedSeconds timed(m_stats.t_kf_apply); applyMapping(*job); }
+    if (job) {
+        if (!job->solved) {      // the window's solve failed on the device (its result is dropped, the map stays as it was): counted, and said once
+            if (m_stats.ba_failed++ == 0) logMessage(LpSlamLogLevel_Error, std::string("VSLAM bundle adjustment failed: ") + lpslam_hip_last_error());
+        }
+        ScopedSeconds timed(m_stats.t_kf_apply); applyMapping(*job);
+    }
 }
 
 void HipVslamTrackerBase::storeDescriptors(int key, Keyframe& kf)
@@ -1728,19 +1733,24 @@ void HipVslamTrackerBase::storeDescriptors(int key, Keyframe& kf)
         logMessage(LpSlamLogLevel_Error, std::string("keyframe ") + std::to_string(key) + ": descriptors not kept on the device (" + lpslam_hip_last_error() + "); compared one by one from now on");
 }
 
-void HipVslamTrackerBase::logStatistics() const
+void HipVslamTrackerBase::logStatistics()
 {
     const Statistics& s = m_stats;
-    char buf[1536];
+    char buf[2048];
     const double per = s.frames > 0 ? 1e3 / (double)s.frames : 0.0;
+    int64_t dev[LPSLAM_HIP_BA_COUNTERS] = {0};        // what happened to the windows on the device: graph cache, replays, timed-out hand-overs
+    if (m_ctx) (void)lpslam_hip_ba_counters(m_ctx, dev, LPSLAM_HIP_BA_COUNTERS);
     std::snprintf(buf, sizeof(buf), "VSLAM statistics: frames=%ld motion_tracked=%ld bf_tracked=%ld local_map_joined=%ld keyframes=%ld fused_added=%ld fused_merged=%ld "
                   "local_ba=%ld loops_closed=%ld loop_fused=%ld global_ba=%ld lost=%ld relocalised=%ld reinitialised=%ld nav_priors=%ld landmarks=%zu "
-                  "culled_landmarks=%ld culled_keyframes=%ld live_keyframes=%ld prefetched=%ld ms_per_frame=%.4f ms_front_end=%.4f ms_track=%.4f ms_local_map=%.4f ms_keyframe=%.4f ms_dev_upload=%.4f ms_dev_extract=%.4f ms_dev_get=%.4f ms_dev_match=%.4f ms_dev_pose=%.4f ms_prefetch_wait=%.4f ms_prefetch_busy=%.4f ms_kf_wait=%.4f ms_kf_apply=%.4f ms_kf_insert=%.4f ms_kf_loop=%.4f ms_kf_prepare=%.4f ms_map_solve=%.4f",
+                  "culled_landmarks=%ld culled_keyframes=%ld live_keyframes=%ld prefetched=%ld ba_failed=%ld ba_signatures=%ld ba_graphs=%ld ba_replays=%ld ba_timeouts=%ld ms_per_frame=%.4f ms_front_end=%.4f ms_track=%.4f ms_local_map=%.4f ms_keyframe=%.4f ms_dev_upload=%.4f ms_dev_extract=%.4f ms_dev_get=%.4f ms_dev_match=%.4f ms_dev_pose=%.4f ms_prefetch_wait=%.4f ms_prefetch_busy=%.4f ms_kf_wait=%.4f ms_kf_apply=%.4f ms_kf_insert=%.4f ms_kf_loop=%.4f ms_kf_prepare=%.4f ms_map_solve=%.4f",
                   s.frames, s.motion_tracked, s.bf_tracked, s.local_map_joined, s.keyframes, s.fused_added, s.fused_merged, s.local_ba, s.loops_closed, s.loop_fused,
                   s.global_ba, s.lost, s.relocalised, s.reinitialised, s.nav_priors, m_landmarks.size(), s.culled_landmarks, s.culled_keyframes,
                   (long)std::count_if(m_kfs.begin(), m_kfs.end(), [](const Keyframe& k) { return !k.erased; }), s.prefetched,
+                  s.ba_failed, (long)dev[LPSLAM_HIP_BA_COUNTER_SIGNATURES], (long)dev[LPSLAM_HIP_BA_COUNTER_GRAPHS], (long)dev[LPSLAM_HIP_BA_COUNTER_REPLAYS],
+                  (long)(dev[LPSLAM_HIP_BA_COUNTER_TIMEOUTS_BAND] + dev[LPSLAM_HIP_BA_COUNTER_TIMEOUTS_UPDATE]),
                   s.t_total * per, s.t_front * per, s.t_track * per, s.t_local * per, s.t_keyframe * per,
                   s.t_dev_upload * per, s.t_dev_extract * per, s.t_dev_get * per, s.t_dev_match * per, s.t_dev_pose * per, s.t_prefetch_wait * per, s.t_prefetch_busy * per, s.t_kf_wait * per, s.t_kf_apply * per, s.t_kf_insert * per, s.t_kf_loop * per, s.t_kf_prepare * per, s.t_map_solve * per);
+    m_lastStatistics = buf;
     logMessage(LpSlamLogLevel_Info, buf);
 }
 

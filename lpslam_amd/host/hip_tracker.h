@@ -34,6 +34,7 @@ public:
     bool mappingExportCSV(std::string csv_filename);
     std::size_t mappingGetFeatures(LpSlamMapBoundary boundary, LpSlamFeatureEntry* entry, std::size_t entry_count, LpSlamMatrix9x9 transform);
     std::size_t mappingGetFeaturesCount(LpSlamMapBoundary boundary);
+    std::string lastStatistics() { std::scoped_lock lock(m_slamLock); return m_lastStatistics; }      // "VSLAM statistics: key=value ..." of the last stop(), this tracker's own (the log is process-wide)
     LpSlamStatus getSlamStatus();
 
     TrackerState state() const { return m_state; }
@@ -78,6 +79,7 @@ protected:
     struct Statistics {                               // logged at stop() ("VSLAM statistics: ..."): what the tracker did, for logs and tests
         long frames = 0, motion_tracked = 0, bf_tracked = 0, local_map_joined = 0, keyframes = 0, fused_added = 0, fused_merged = 0;
         long culled_landmarks = 0, culled_keyframes = 0;
+        long ba_failed = 0;                           // windows whose solve failed on the device (result dropped)
         long local_ba = 0, loops_closed = 0, loop_fused = 0, global_ba = 0, lost = 0, relocalised = 0, reinitialised = 0, nav_priors = 0, prefetched = 0;
         // where the frames' time went (seconds, summed): front end (upload, extraction, stereo, read-back), tracking against the
         // previous frame, local-map tracking, keyframe work on the tracking thread (insertion, fusion, loop search, BA set-up / wait)
@@ -137,7 +139,8 @@ protected:
     void applyMapping(const MappingJob& job);
     void startMapping(int c);                         // prepare + solve on the mapping thread (or inline when asyncMapping is off)
     void finishMapping();                             // wait for the mapping thread and apply its result
-    void logStatistics() const;
+    void logStatistics();
+    std::string m_lastStatistics;                       // the line logStatistics() logged last (kept past stop(): lastStatistics())
     void storeDescriptors(int key, Keyframe& kf);     // keeps the keyframe's descriptors on the device for the batched loop-candidate search
 
     // configuration (names as in the reference tracker)

@@ -117,6 +117,15 @@ LPS_API size_t lpslam_manager_features(lpslam_c_manager* m, LpSlamFeatureEntry* 
     LpSlamMatrix9x9 t; for (int i = 0; i < 9; ++i) t[i] = t9[i];
     return m->mgr.mappingGetFeatures(LpSlamMapBoundary{}, e, n, t);
 }
+// this manager's own tracker statistics (the log file is process-wide: with several managers in a process their lines share it);
+// returns the length of the line, copies at most cap - 1 characters
+static_assert(sizeof(LpSlamManager) == sizeof(void*), "LpSlamManager holds m_impl and nothing else (src/Interface/LpSlamManager.h:120)");
+LPS_API size_t lpslam_manager_tracker_statistics(lpslam_c_manager* m, char* out, size_t cap) {
+    LpSlam::SlamManager* impl = *reinterpret_cast<LpSlam::SlamManager**>(&m->mgr);
+    const std::string s = impl ? impl->trackerStatistics() : std::string();
+    if (out && cap) { const size_t n = std::min(s.size(), cap - 1); memcpy(out, s.data(), n); out[n] = 0; }
+    return s.size();
+}
 LPS_API size_t lpslam_manager_features_count(lpslam_c_manager* m) { return m->mgr.mappingGetFeaturesCount(LpSlamMapBoundary{}); }
 // interface.type_conversion of the reference's tests (src/test/InterfaceTest.cpp:14-33): POD -> internal -> POD
 LPS_API void lpslam_roundtrip_state(const LpSlamGlobalStateInTime* in, LpSlamGlobalStateInTime* out) {

@@ -504,6 +504,7 @@ LpSlamStatus SlamManager::getSlamStatus()
 }
 
 std::size_t SlamManager::mappingGetFeatures(LpSlamMapBoundary b, LpSlamFeatureEntry* e, std::size_t n, LpSlamMatrix9x9 t) { return m_vslamTracker ? m_vslamTracker->mappingGetFeatures(b, e, n, t) : 0; }
+std::string SlamManager::trackerStatistics() { return m_vslamTracker ? m_vslamTracker->lastStatistics() : std::string(); }
 std::size_t SlamManager::mappingGetFeaturesCount(LpSlamMapBoundary b) { return m_vslamTracker ? m_vslamTracker->mappingGetFeaturesCount(b) : 0; }
 bool SlamManager::mappingSetMode(bool enable) { return m_vslamTracker ? m_vslamTracker->mappingSetMode(enable) : false; }
 bool SlamManager::mappingSetFilename(std::string const& f) { return m_vslamTracker ? m_vslamTracker->mappingSetFilename(f) : false; }

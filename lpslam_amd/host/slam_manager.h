@@ -39,6 +39,7 @@ public:
 
     std::size_t mappingGetFeatures(LpSlamMapBoundary b, LpSlamFeatureEntry* e, std::size_t n, LpSlamMatrix9x9 t);
     std::size_t mappingGetFeaturesCount(LpSlamMapBoundary b);
+    std::string trackerStatistics();                    // the VSLAM tracker's last statistics line (empty before its first stop)
     bool mappingSetMode(bool enable);
     bool mappingSetFilename(std::string const& f);
     bool mappingExportCSV(std::string const& f);

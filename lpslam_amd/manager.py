@@ -123,6 +123,17 @@ class Manager:
                 out = {k: (float(v) if k.startswith("ms_") else int(v)) for k, v in (kv.split("=") for kv in line.split("VSLAM statistics:")[1].split())}
         return out
 
+    def tracker_statistics(self):
+        """this manager's own "VSLAM statistics" line of its last stop() as a dict (the log file is process-wide)"""
+        f = self.lib.lpslam_manager_tracker_statistics
+        f.restype = C.c_size_t; f.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+        buf = C.create_string_buffer(4096)
+        f(self.h, buf, 4096)
+        line = buf.value.decode(errors="replace")
+        if "VSLAM statistics:" not in line:
+            return {}
+        return {k: (float(v) if k.startswith("ms_") else int(v)) for k, v in (kv.split("=") for kv in line.split("VSLAM statistics:")[1].split())}
+
     def read_configuration_file(self, path):
         return bool(self.lib.lpslam_manager_read_configuration_file(self.h, path.encode()))
 
