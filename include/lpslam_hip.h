@@ -87,6 +87,32 @@ int lpslam_hip_debug_occupy_unreserved(lpslam_hip_ctx* ctx, int32_t microseconds
  * process context k puts k mod 4 placeholder streams in front of its main stream, so that the contexts' main streams spread over the
  * process' four hardware queues (LPSLAM_HIP_NO_QUEUE_SPREAD=1 switches that off: measurements). */
 int lpslam_hip_set_flat_priorities(int32_t flat);
+/* Process-wide: launches shared by the sessions of a process.  The reference runs one manager per sequence, one frame in flight each
+ * (src/Manager/SlamManager.cpp:54-61,191-201); N of them on one GPU issue N chains of small latency-bound launches.  With sharing the
+ * window matchers' first scan and the pose optimiser of every session that is tracking at that moment go out as ONE launch each
+ * (blockIdx = request; per-request result blocks and completion flags as in the unshared call, same device code, same bits).
+ * mode 2 (default): when two or more contexts of the device have made such calls within the last few milliseconds; 1: always, a lone
+ * session too (tests); 0: never; -1: back to the environment (LPSLAM_HIP_SHARED_LAUNCHES).  LPSLAM_HIP_SHARE_WINDOW_US (30) /
+ * LPSLAM_HIP_SHARE_QUIET_US (6) bound how long a request waits for the other sessions'. */
+int lpslam_hip_set_shared_launches(int32_t mode);
+/* How many shared launches a device has seen and how many requests they carried (measurement / test hook). */
+int lpslam_hip_shared_launch_counters(int32_t device, int64_t* batches, int64_t* requests);
+/* A context for one SESSION of a process that may host several (what a tracker plugin creates: one per LpSlamManager,
+ * src/Manager/SlamManager.cpp:54-61).  Same calls, same results as a context of lpslam_hip_create; its per-image arrays are slices of a
+ * pool that the sessions of one device and front-end configuration share (LPSLAM_HIP_POOL_SESSIONS, default 16; max_images <= 8), so
+ * that lpslam_hip_front_end can put the frames several sessions have pending through ONE launch chain.  A session beyond the pool's
+ * capacity silently gets arrays of its own. */
+int lpslam_hip_create_session(const lpslam_hip_frontend_config* cfg, lpslam_hip_ctx** out);
+/* One frame's front end behind its uploads, as one asynchronous call: lpslam_hip_extract_range(image, stereo ? 2 : 1), for stereo
+ * lpslam_hip_match_stereo(image, image + 1, fxb, baseline), then lpslam_hip_prefetch_frame(image, stereo) -- the per-frame work of
+ * feed_stereo_frame / feed_monocular_frame up to the tracking step (src/Trackers/OpenVSLAMStereoTracker.cpp:293-295).  Inside or outside
+ * a prefetch section.  With shared launches on and two or more sessions of a pool submitting, their frames are extracted together. */
+int lpslam_hip_front_end(lpslam_hip_ctx* ctx, int image, int32_t stereo, float focal_x_baseline, float baseline);
+/* The same with the frame itself: lpslam_hip_upload_image of `left` into `image` (and of `right` into image + 1; NULL = monocular),
+ * then lpslam_hip_front_end.  A shared front end uploads the frames at the head of its launch chain. */
+int lpslam_hip_front_end_images(lpslam_hip_ctx* ctx, int image, const uint8_t* left, const uint8_t* right, int32_t stride,
+                                float focal_x_baseline, float baseline);
+int lpslam_hip_shared_front_end_counters(int32_t device, int64_t* batches, int64_t* requests);
 int lpslam_hip_sync(lpslam_hip_ctx* ctx);
 /* Geometry derived from the configuration (pyramid sizes, per-level keypoint quota). */
 int lpslam_hip_level_info(lpslam_hip_ctx* ctx, int32_t* widths, int32_t* heights, int32_t* pitches,

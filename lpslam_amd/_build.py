@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "liblpslam_hip.so")
-HIP_SOURCES = ["api.hip", "frontend.hip", "match.hip", "ba.hip", "bow.hip"]
+HIP_SOURCES = ["api.hip", "frontend.hip", "match.hip", "ba.hip", "bow.hip", "share.hip"]
 DEPS = ["internal.h", "orb_pattern.inc", os.path.join("..", "..", "include", "lpslam_hip.h"), "sim3.inl"]
 # -ffp-contract=off: parity with the CPU definition forbids FMA contraction ("Numerics").
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
@@ -15,7 +15,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp
 
 OBJ_DIR = os.path.join(CSRC, "_obj")
 # what each translation unit includes (beyond itself): a change there recompiles only that unit
-UNIT_DEPS = {"ba.hip": ["sim3.inl", "ba_build.inl", "ba_solve.inl", "ba_band.inl", "ba_update.inl"], "frontend.hip": ["orb_pattern.inc"], "match.hip": [], "api.hip": [], "bow.hip": []}
+UNIT_DEPS = {"ba.hip": ["sim3.inl", "ba_build.inl", "ba_solve.inl", "ba_band.inl", "ba_update.inl"], "frontend.hip": ["orb_pattern.inc"], "match.hip": [], "api.hip": [], "bow.hip": [], "share.hip": []}
 COMMON_DEPS = ["internal.h", os.path.join("..", "..", "include", "lpslam_hip.h")]
 
 

@@ -13,6 +13,7 @@ namespace lpslam {
 
 static thread_local char g_err[512] = "";
 thread_local hipStream_t lp_tls_stream = nullptr;
+thread_local bool lp_tls_stream_used = false;
 
 void set_error(const char* fmt, ...)
 {
@@ -21,6 +22,18 @@ void set_error(const char* fmt, ...)
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
 }
+
+}  // namespace lpslam
+void lp_poll_sleep()
+{
+    static const long sleep_ns = [] { const char* e = getenv("LPSLAM_HIP_POLL_SLEEP_US"); return 1000l * (e ? std::max(atoi(e), 0) : 5); }();
+    if (sleep_ns <= 0) { sched_yield(); return; }
+    static thread_local bool slack_set = false;
+    if (!slack_set) { (void)prctl(PR_SET_TIMERSLACK, 1000ul, 0ul, 0ul, 0ul); slack_set = true; }      // (the default slack of 50 us would turn a 5 us sleep into 55)
+    const struct timespec ts{0, sleep_ns};
+    (void)nanosleep(&ts, nullptr);
+}
+namespace lpslam {
 
 int hip_fail(hipError_t e, const char* what)
 {
@@ -223,6 +236,11 @@ static hipError_t lp_fe_stream_create(hipStream_t* s, bool background)
 
 hipStream_t lp_stream_acquire(lpslam_hip_ctx* c)
 {
+    if (c->sess_pool && c->sess_pool->pool_refs > 1) {   // several sessions: the solves' role stream, shared with the other sessions' windows
+        if (!c->role_solve) { hipStream_t roles[4]; if (lp_share_role_streams(c->cfg.device, roles)) c->role_solve = roles[LP_ROLE_SOLVE]; }
+        if (c->role_solve) return c->role_solve;
+    }
+    if (!c->owns_streams) return c->role_solve;
     {
         std::lock_guard<std::mutex> lock(c->pool_mutex);
         if (!c->ba_streams.empty()) { hipStream_t s = c->ba_streams.back(); c->ba_streams.pop_back(); return s; }
@@ -239,7 +257,7 @@ hipStream_t lp_stream_acquire(lpslam_hip_ctx* c)
 
 void lp_stream_release(lpslam_hip_ctx* c, hipStream_t s)
 {
-    if (!s) return;
+    if (!s || s == c->role_solve) return;
     std::lock_guard<std::mutex> lock(c->pool_mutex);
     c->ba_streams.push_back(s);
 }
@@ -317,6 +335,25 @@ static int ctx_alloc(lpslam_hip_ctx* c)
 {
     const size_t B = (size_t)c->cfg.max_images;
     const int L = c->lt.n_levels;
+    c->st_row_cap = c->slots_per_image * ((int)(4.0f * c->lt.scale[c->lt.n_levels - 1]) + 4);      // rows per keypoint <= 4 * scale + 3
+    if (c->sess_pool) {
+        // a session: every per-image array is the pool's, from image pool_first on (same configuration: same per-image sizes)
+        const lpslam_hip_ctx* p = c->sess_pool;
+        const size_t f = (size_t)c->pool_first;
+        c->d_pyr = p->d_pyr + f * c->image_slab;
+        c->d_cell_keys = p->d_cell_keys + f * c->cells_per_image * kCellSlots; c->d_cell_count = p->d_cell_count + f * c->cells_per_image;
+        c->d_cand_key = p->d_cand_key + f * c->cand_per_image; c->d_cand_node = p->d_cand_node + f * c->cand_per_image; c->d_cand_count = p->d_cand_count + f * L;
+        c->d_sel_key = p->d_sel_key + f * c->slots_per_image; c->d_sel_count = p->d_sel_count + f * L;
+        c->d_kpts = p->d_kpts + f * c->slots_per_image; c->d_desc = p->d_desc + f * c->slots_per_image * 32; c->d_kp_count = p->d_kp_count + f;
+        c->d_bf = p->d_bf + f * 3 * c->slots_per_image; c->d_stereo = p->d_stereo + f * 2 * c->slots_per_image;
+        c->d_stereo_idx = p->d_stereo_idx + f * c->slots_per_image; c->d_stereo_corr = p->d_stereo_corr + f * c->slots_per_image;
+        c->d_st_row_start = p->d_st_row_start + f * (size_t)(c->lt.h[0] + 1); c->d_st_row_list = p->d_st_row_list + f * (size_t)c->st_row_cap;
+        LP_HIP(hipMemsetAsync(c->d_pyr, 0, B * c->image_slab, c->stream));
+        LP_HIP(hipMemsetAsync(c->d_kp_count, 0, B * sizeof(int32_t), c->stream));
+        LP_HIP(hipMemsetAsync(c->d_sel_count, 0, B * L * sizeof(int32_t), c->stream));
+        LP_HIP(hipMemsetAsync(c->d_cand_count, 0, B * L * sizeof(int32_t), c->stream));
+        return LPSLAM_HIP_OK;
+    }
     LP_HIP(hipMalloc((void**)&c->d_pyr, B * c->image_slab));
     LP_HIP(hipMemsetAsync(c->d_pyr, 0, B * c->image_slab, c->stream));
     LP_HIP(hipMalloc((void**)&c->d_cell_keys, B * c->cells_per_image * kCellSlots * sizeof(uint32_t)));
@@ -336,7 +373,6 @@ static int ctx_alloc(lpslam_hip_ctx* c)
     LP_HIP(hipMalloc((void**)&c->d_stereo, B * 2 * c->slots_per_image * sizeof(float)));
     LP_HIP(hipMalloc((void**)&c->d_stereo_idx, B * c->slots_per_image * sizeof(int32_t)));
     LP_HIP(hipMalloc((void**)&c->d_stereo_corr, B * c->slots_per_image * sizeof(int32_t)));
-    c->st_row_cap = c->slots_per_image * ((int)(4.0f * c->lt.scale[c->lt.n_levels - 1]) + 4);      // rows per keypoint <= 4 * scale + 3
     LP_HIP(hipMalloc((void**)&c->d_st_row_start, B * (size_t)(c->lt.h[0] + 1) * sizeof(int32_t)));
     LP_HIP(hipMalloc((void**)&c->d_st_row_list, B * (size_t)c->st_row_cap * sizeof(int32_t)));
     return LPSLAM_HIP_OK;
@@ -345,7 +381,64 @@ static int ctx_alloc(lpslam_hip_ctx* c)
 static bool ensure_upload_staging(lpslam_hip_ctx* c, int image);
 int lp_wait_uploads(lpslam_hip_ctx* c, int first, int n);
 
-int lpslam_hip_create(const lpslam_hip_frontend_config* cfg, lpslam_hip_ctx** out)
+static int create_impl(const lpslam_hip_frontend_config* cfg, lpslam_hip_ctx* pool, int pool_slot, lpslam_hip_ctx** out, bool* attached = nullptr);
+
+// ---- session pools ---------------------------------------------------------------------------------------------------------
+// One pool per (device, front-end configuration), created with the first session that asks for it and destroyed with the last one
+// that leaves.  LPSLAM_HIP_POOL_SESSIONS (16) sessions fit; the next one gets arrays of its own (and launches of its own).
+namespace {
+std::mutex g_pools_mutex;
+std::vector<lpslam_hip_ctx*> g_pools;
+bool same_front_end(const lpslam_hip_frontend_config& a, const lpslam_hip_frontend_config& b)
+{
+    return a.device == b.device && a.width == b.width && a.height == b.height && a.max_keypoints == b.max_keypoints && a.scale_factor == b.scale_factor &&
+           a.num_levels == b.num_levels && a.ini_fast_threshold == b.ini_fast_threshold && a.min_fast_threshold == b.min_fast_threshold;
+}
+}
+static void lp_pool_session_release(lpslam_hip_ctx* pool, int slot)
+{
+    bool last = false;
+    {
+        std::lock_guard<std::mutex> lock(g_pools_mutex);
+        if (slot >= 0 && (size_t)slot < pool->pool_used.size()) pool->pool_used[(size_t)slot] = 0;
+        if (--pool->pool_refs == 0) { g_pools.erase(std::remove(g_pools.begin(), g_pools.end(), pool), g_pools.end()); last = true; }
+    }
+    if (last) lpslam_hip_destroy(pool);
+}
+
+int lpslam_hip_create_session(const lpslam_hip_frontend_config* cfg, lpslam_hip_ctx** out)
+{
+    if (!cfg || !out) { set_error("null argument"); return LPSLAM_HIP_ERR_INVALID; }
+    static const int sessions_env = [] { const char* e = getenv("LPSLAM_HIP_POOL_SESSIONS"); return e ? std::min(std::max(atoi(e), 0), 64) : 16; }();
+    const int per = (cfg->max_images + 1) & ~1;          // stereo pairs keep their parity (left even, right odd: the eyes' masks)
+    if (sessions_env < 2 || cfg->max_images < 1 || cfg->max_images > 8 || per * sessions_env > 65535) return lpslam_hip_create(cfg, out);
+    lpslam_hip_ctx* pool = nullptr;
+    int slot = -1;
+    {
+        std::lock_guard<std::mutex> lock(g_pools_mutex);
+        for (lpslam_hip_ctx* p : g_pools) if (same_front_end(p->cfg, *cfg) && p->pool_per == per) { pool = p; break; }
+        if (!pool) {
+            lpslam_hip_frontend_config pc = *cfg;
+            pc.max_images = per * sessions_env;
+            lpslam_hip_ctx* p = nullptr;
+            if (create_impl(&pc, nullptr, -1, &p) != LPSLAM_HIP_OK) return lpslam_hip_create(cfg, out);      // (no room for a pool: a context of its own)
+            p->is_pool = true; p->pool_per = per; p->pool_used.assign((size_t)sessions_env, 0);
+            g_pools.push_back(p);
+            pool = p;
+        }
+        for (size_t i = 0; i < pool->pool_used.size() && slot < 0; ++i) if (!pool->pool_used[i]) slot = (int)i;
+        if (slot >= 0) { pool->pool_used[(size_t)slot] = 1; ++pool->pool_refs; }
+    }
+    if (slot < 0) return lpslam_hip_create(cfg, out);    // the pool is full
+    bool attached = false;
+    const int rc = create_impl(cfg, pool, slot, out, &attached);
+    if (rc != LPSLAM_HIP_OK && !attached) lp_pool_session_release(pool, slot);      // (a creation that failed later handed the slot back in lpslam_hip_destroy)
+    return rc;
+}
+
+int lpslam_hip_create(const lpslam_hip_frontend_config* cfg, lpslam_hip_ctx** out) { return create_impl(cfg, nullptr, -1, out); }
+
+static int create_impl(const lpslam_hip_frontend_config* cfg, lpslam_hip_ctx* pool, int pool_slot, lpslam_hip_ctx** out, bool* attached)
 {
     if (!cfg || !out) { set_error("null argument"); return LPSLAM_HIP_ERR_INVALID; }
     *out = nullptr;
@@ -385,6 +478,15 @@ int lpslam_hip_create(const lpslam_hip_frontend_config* cfg, lpslam_hip_ctx** ou
     // used one, so the contexts' streams -- created main first -- would put every main stream (the latency-bound matchers and pose
     // optimisations of a tracked frame) on the SAME queue, behind one another: two managers ran at 1.24 x one.  Context k of the process
     // puts k mod 4 placeholder streams in front of its main stream.
+    hipStream_t roles[4] = {nullptr, nullptr, nullptr, nullptr};
+    // (the FIRST session of a pool keeps streams of its own, in the three priority classes: a session alone is what it always was; those that
+    // join later -- a process that hosts several -- use the role streams)
+    const bool session_streams = pool && pool->pool_refs > 1 && lp_share_role_streams(cfg->device, roles);
+    if (session_streams) {
+        // a session of a pool: its streams are the device's role streams (share.hip)
+        c->owns_streams = false; c->stream = roles[LP_ROLE_MAIN]; c->fe_stream = roles[LP_ROLE_FRONT]; c->role_solve = roles[LP_ROLE_SOLVE];
+        if (hipEventCreateWithFlags(&c->fe_done, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); delete c; set_error("hipEventCreate failed"); return LPSLAM_HIP_ERR_DEVICE; }
+    } else
     if (lp_flat_priorities() && !getenv("LPSLAM_HIP_NO_QUEUE_SPREAD")) {
         static std::atomic<int> ctx_seq{0};
         const int k = ctx_seq.fetch_add(1) % 4;
@@ -398,7 +500,7 @@ int lpslam_hip_create(const lpslam_hip_frontend_config* cfg, lpslam_hip_ctx** ou
             }
         }
     }
-    hipError_t e = lp_fe_stream_create(&c->stream, false);
+    hipError_t e = session_streams ? hipSuccess : lp_fe_stream_create(&c->stream, false);
     if (e != hipSuccess) {
         for (hipStream_t d : c->pad_streams) (void)hipStreamDestroy(d);
         if (c->d_pad) (void)hipFree(c->d_pad);
@@ -406,6 +508,7 @@ int lpslam_hip_create(const lpslam_hip_frontend_config* cfg, lpslam_hip_ctx** ou
         return hip_fail(e, "hipStreamCreate");
     }
     if (c->d_pad) { (void)hipMemsetAsync(c->d_pad, 0, 4, c->stream); (void)hipStreamSynchronize(c->stream); }
+    if (pool) { c->sess_pool = pool; c->pool_slot = pool_slot; c->pool_first = pool_slot * pool->pool_per; if (attached) *attached = true; }      // from here on lpslam_hip_destroy hands the pool's slot back
     lp_ctx_register(c, true);
     rc = ctx_alloc(c);
     if (rc == LPSLAM_HIP_OK && !ofs.empty()) {
@@ -475,6 +578,7 @@ void lpslam_hip_destroy(lpslam_hip_ctx* c)
 {
     if (!c) return;
     lp_ctx_register(c, false);
+    lp_share_forget(c);
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->fe_stream) (void)hipStreamSynchronize(c->fe_stream);
@@ -483,6 +587,16 @@ void lpslam_hip_destroy(lpslam_hip_ctx* c)
     c->desc_store.clear();
     for (auto& blk : c->pool) (void)hipFree(blk.second);
     c->pool.clear();
+    lpslam_hip_ctx* const pool_of = c->sess_pool;
+    const int pool_slot_of = c->pool_slot;
+    if (pool_of) {
+        // a session: its per-image arrays are the pool's.  A shared front end of this session may still run on the pool's stream.
+        if (pool_of->stream) (void)hipStreamSynchronize(pool_of->stream);
+        c->d_pyr = nullptr; c->d_cell_keys = nullptr; c->d_cell_count = nullptr; c->d_cand_key = nullptr; c->d_cand_node = nullptr; c->d_cand_count = nullptr;
+        c->d_sel_key = nullptr; c->d_sel_count = nullptr; c->d_kpts = nullptr; c->d_desc = nullptr; c->d_kp_count = nullptr; c->d_bf = nullptr; c->d_stereo = nullptr;
+        c->d_stereo_idx = nullptr; c->d_stereo_corr = nullptr; c->d_st_row_start = nullptr; c->d_st_row_list = nullptr;
+    }
+    if (c->ev_fe_ready) (void)hipEventDestroy(c->ev_fe_ready);
     void* bufs[] = {c->d_pyr, c->d_band_rows, c->d_rs_pack, c->d_cell_keys, c->d_cell_count, c->d_cand_key, c->d_cand_node,
                     c->d_cand_count, c->d_sel_key, c->d_sel_count, c->d_kpts, c->d_desc,
                     c->d_kp_count, c->d_bf, c->d_stereo, c->d_stereo_idx, c->d_stereo_corr, c->d_st_row_start, c->d_st_row_list, c->d_tmp_desc, c->d_tmp_res,
@@ -500,6 +614,7 @@ void lpslam_hip_destroy(lpslam_hip_ctx* c)
     c->ba_graphs.clear();
     for (auto& v : c->ba_view_slot) if (v.second) (void)hipFree(v.second);
     c->ba_view_slot.clear();
+    if (!c->owns_streams) { c->ba_streams.clear(); c->fe_stream = nullptr; c->stream = nullptr; }      // (the device's role streams: synchronised above, not this context's to destroy)
     for (hipStream_t st : c->ba_streams) (void)hipStreamDestroy(st);
     c->ba_streams.clear();
     if (c->h_stage) (void)hipHostFree(c->h_stage);
@@ -520,6 +635,7 @@ void lpslam_hip_destroy(lpslam_hip_ctx* c)
     for (hipStream_t d : c->pad_streams) (void)hipStreamDestroy(d);
     if (c->d_pad) (void)hipFree(c->d_pad);
     delete c;
+    if (pool_of) lp_pool_session_release(pool_of, pool_slot_of);
 }
 
 // The front end's kernels fill every compute unit's LDS with their workgroups, and a panel-pair workgroup of a running bundle
@@ -621,13 +737,17 @@ int lpslam_hip_prefetch_begin(lpslam_hip_ctx* c)
         LP_HIP(hipEventCreateWithFlags(&c->fe_done, hipEventDisableTiming));
     }
     lp_tls_stream = c->fe_stream;
+    lp_tls_stream_used = false;
     return LPSLAM_HIP_OK;
 }
 
 int lpslam_hip_prefetch_end(lpslam_hip_ctx* c)
 {
     if (!c || !lp_tls_stream || lp_tls_stream != c->fe_stream) { set_error("prefetch_end without prefetch_begin on this thread"); return LPSLAM_HIP_ERR_INVALID; }
-    const hipError_t e = hipEventRecord(c->fe_done, c->fe_stream);
+    // (a section whose front end went out as a shared launch enqueued nothing here: the session's streams stay untouched -- an event
+    // record and the join's wait are packets on hardware queues that other sessions' chains may be occupying)
+    const hipError_t e = lp_tls_stream_used ? hipEventRecord(c->fe_done, c->fe_stream) : hipSuccess;
+    if (lp_tls_stream_used) c->fe_join_needed = true;
     lp_tls_stream = nullptr;
     if (e != hipSuccess) { set_error("hipEventRecord failed"); return LPSLAM_HIP_ERR_DEVICE; }
     return LPSLAM_HIP_OK;
@@ -637,7 +757,7 @@ int lpslam_hip_prefetch_join(lpslam_hip_ctx* c)
 {
     if (!c) { set_error("null context"); return LPSLAM_HIP_ERR_INVALID; }
     if (lp_tls_stream) { set_error("prefetch_join inside a prefetch section"); return LPSLAM_HIP_ERR_INVALID; }
-    if (c->fe_done) LP_HIP(hipStreamWaitEvent(c->stream, c->fe_done, 0));
+    if (c->fe_done && c->fe_join_needed) { c->fe_join_needed = false; LP_HIP(hipStreamWaitEvent(c->stream, c->fe_done, 0)); }
     return LPSLAM_HIP_OK;
 }
 
@@ -957,21 +1077,45 @@ bool lp_wait_recover(lpslam_hip_ctx* c, int which, hipStream_t s)
 namespace {
 // One frame's results into page-locked host memory: count, then the first `count` keypoints / descriptors / stereo columns / depths
 // as 32-bit words (the device knows the count; the copy engines would have to move all the slots, in five packets).
-__global__ __launch_bounds__(256) void k_frame_to_host(const int* __restrict__ d_count, const uint32_t* __restrict__ kp, const uint32_t* __restrict__ desc,
-                                                       const uint32_t* __restrict__ xr, const uint32_t* __restrict__ dep, uint32_t* __restrict__ st,
-                                                       int o_kp, int o_desc, int o_xr, int o_dep, int slots, unsigned* counter, int* flag, int seq)
+__device__ __forceinline__ void frame_to_host_body(const int* __restrict__ d_count, const uint32_t* __restrict__ kp, const uint32_t* __restrict__ desc,
+                                                   const uint32_t* __restrict__ xr, const uint32_t* __restrict__ dep, uint32_t* __restrict__ st,
+                                                   int o_kp, int o_desc, int o_xr, int o_dep, int slots, int n_blocks)
 {
     const int n = min(max(*d_count, 0), slots);
     const int w_kp = kp ? 7 * n : 0, w_desc = desc ? 8 * n : 0, w_xr = xr ? n : 0, w_dep = dep ? n : 0;
     const int total = w_kp + w_desc + w_xr + w_dep;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += n_blocks * blockDim.x) {
         if (i < w_kp) st[o_kp + i] = kp[i];
         else if (i < w_kp + w_desc) st[o_desc + i - w_kp] = desc[i - w_kp];
         else if (i < w_kp + w_desc + w_xr) st[o_xr + i - w_kp - w_desc] = xr[i - w_kp - w_desc];
         else st[o_dep + i - w_kp - w_desc - w_xr] = dep[i - w_kp - w_desc - w_xr];
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) st[0] = (uint32_t)*d_count;
+}
+__global__ __launch_bounds__(256) void k_frame_to_host(const int* __restrict__ d_count, const uint32_t* __restrict__ kp, const uint32_t* __restrict__ desc,
+                                                       const uint32_t* __restrict__ xr, const uint32_t* __restrict__ dep, uint32_t* __restrict__ st,
+                                                       int o_kp, int o_desc, int o_xr, int o_dep, int slots, unsigned* counter, int* flag, int seq)
+{
+    frame_to_host_body(d_count, kp, desc, xr, dep, st, o_kp, o_desc, o_xr, o_dep, slots, (int)gridDim.x);
     lp_signal_done(counter, flag, seq);
+}
+// the deliveries of several sessions' frames in one launch: blockIdx.y = request, every request releases its own flag
+constexpr int kDeliverBatch = 32;
+struct DeliverBatch { LpDeliverReq r[kDeliverBatch]; };
+__global__ __launch_bounds__(256) void k_frame_to_host_req(DeliverBatch b, int o_kp, int o_desc, int o_xr, int o_dep, int slots)
+{
+    const LpDeliverReq& r = b.r[blockIdx.y];
+    const int n_blocks = r.blocks;
+    if ((int)blockIdx.x >= n_blocks) return;
+    frame_to_host_body(r.d_count, r.kp, r.desc, r.xr, r.dep, r.st, o_kp, o_desc, o_xr, o_dep, slots, n_blocks);
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (n_blocks == 1 || atomicAdd(r.counter, 1u) == (unsigned)n_blocks - 1) {
+            if (n_blocks > 1) { *r.counter = 0; __threadfence(); }
+            __hip_atomic_store(r.flag, r.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 }  // namespace
 
@@ -1039,6 +1183,101 @@ int lpslam_hip_prefetch_frame(lpslam_hip_ctx* c, int image, int32_t with_stereo)
     return LPSLAM_HIP_OK;
 }
 
+}  // extern "C"
+
+// What lpslam_hip_prefetch_frame sets up, without its launch: the request of a delivery that a shared launch will carry (share.hip).
+int lp_prepare_delivery(lpslam_hip_ctx* c, int image, int with_stereo, LpDeliverReq* out)
+{
+    const FrameStage f = frame_stage(c);
+    if (c->h_stage_pf_bytes < f.need) {
+        if (c->h_stage_pf) { if (c->pf_stream) LP_HIP(hipStreamSynchronize(c->pf_stream)); (void)hipHostFree(c->h_stage_pf); }
+        c->h_stage_pf = nullptr; c->h_stage_pf_bytes = 0; c->pf_image = -1; c->pf_in_flight = false;
+        LP_HIP(hipHostMalloc((void**)&c->h_stage_pf, f.need, hipHostMallocDefault));
+        c->h_stage_pf_bytes = f.need;
+    }
+    c->pf_image = -1;
+    if (c->pf_in_flight && !lp_wait_done((int*)(c->h_stage_pf + 32), c->pf_seq, c->pf_stream)) { c->pf_in_flight = !lp_wait_recover(c, 3, c->pf_stream); set_error("front end: the previous read-back did not complete"); return LPSLAM_HIP_ERR_DEVICE; }
+    c->pf_in_flight = false;
+    unsigned* counter = lp_done_counter(c, 3);
+    if (!counter) { set_error("device memory for the completion counters"); return LPSLAM_HIP_ERR_DEVICE; }
+    const size_t S = (size_t)c->slots_per_image, o = (size_t)image * S;
+    const float* fs = c->d_stereo + o * 2;
+    const int words = (int)S * (7 + 8 + (with_stereo ? 2 : 0));
+    int* flag = (int*)(c->h_stage_pf + 32);
+    __atomic_store_n(flag, 0, __ATOMIC_RELAXED);
+    *out = LpDeliverReq{(const int*)(c->d_kp_count + image), (const uint32_t*)(c->d_kpts + o), (const uint32_t*)(c->d_desc + o * 32),
+                        with_stereo ? (const uint32_t*)fs : nullptr, with_stereo ? (const uint32_t*)(fs + S) : nullptr, (uint32_t*)c->h_stage_pf, counter, flag,
+                        lp_next_seq(c->pf_seq_next), std::max(1, std::min(64, (words + 1023) / 1024))};
+    return LPSLAM_HIP_OK;
+}
+void lp_commit_delivery(lpslam_hip_ctx* c, int image, int with_stereo, const LpDeliverReq& r, hipStream_t s)
+{
+    c->pf_seq = r.seq; c->pf_fields = FRAME_KPTS | FRAME_DESC | (with_stereo ? (FRAME_XR | FRAME_DEPTH) : 0); c->pf_stream = s; c->pf_in_flight = true;
+    c->pf_image = image;
+}
+int lp_launch_deliver_batch(hipStream_t s, const LpDeliverReq* reqs, int n, int slots_per_image, const lpslam_hip_ctx* layout)
+{
+    const FrameStage f = frame_stage(layout);
+    for (int i0 = 0; i0 < n; i0 += kDeliverBatch) {
+        const int m = std::min(n - i0, (int)kDeliverBatch);
+        DeliverBatch b{};
+        int gx = 1;
+        for (int i = 0; i < m; ++i) { b.r[i] = reqs[i0 + i]; gx = std::max(gx, reqs[i0 + i].blocks); }
+        hipLaunchKernelGGL(k_frame_to_host_req, dim3((unsigned)gx, (unsigned)m), dim3(256), 0, s, b, (int)(f.o_kp / 4), (int)(f.o_desc / 4), (int)(f.o_xr / 4), (int)(f.o_dep / 4), slots_per_image);
+        LP_HIP(hipGetLastError());
+    }
+    return LPSLAM_HIP_OK;
+}
+
+extern "C" {
+
+// One frame's front end behind its uploads: extraction of the slot (stereo: the slot pair), stereo match, delivery of the results into the
+// context's page-locked block -- what a tracker enqueues per frame (extract_range + match_stereo + prefetch_frame), as ONE call, so that
+// the frames several sessions of a pool have pending can go through one launch chain (share.hip).  Asynchronous, like its parts.
+int lpslam_hip_front_end(lpslam_hip_ctx* c, int image, int32_t stereo, float fxb, float baseline)
+{
+    int rc = check_image(c, image); if (rc) return rc;
+    if (stereo && (rc = check_image(c, image + 1))) return rc;
+    if (stereo && (!(baseline > 0.f) || !(fxb > 0.f))) { set_error("focal_x_baseline and baseline must be positive"); return LPSLAM_HIP_ERR_INVALID; }
+    LP_HIP(hipSetDevice(c->cfg.device));
+    const int shared = lp_share_front_end(c, image, stereo ? 1 : 0, fxb, baseline);
+    if (shared < 0) return -shared;
+    if (shared == LP_SHARE_DONE) return LPSLAM_HIP_OK;
+    if ((rc = lpslam_hip_extract_range(c, image, stereo ? 2 : 1))) return rc;
+    if (stereo && (rc = lpslam_hip_match_stereo(c, image, image + 1, fxb, baseline))) return rc;
+    return lpslam_hip_prefetch_frame(c, image, stereo ? 1 : 0);
+}
+
+// lpslam_hip_front_end with the frame itself: upload of the slot (stereo: the pair) + front end.  A shared front end uploads at the head
+// of its chain, on the chain's stream: a session then keeps no stream of its own busy per frame.
+int lpslam_hip_front_end_images(lpslam_hip_ctx* c, int image, const uint8_t* left, const uint8_t* right, int32_t stride, float fxb, float baseline)
+{
+    int rc = check_image(c, image); if (rc) return rc;
+    const bool stereo = right != nullptr;
+    if (stereo && (rc = check_image(c, image + 1))) return rc;
+    if (!left || stride < c->lt.w[0]) { set_error("bad host image (stride %d < width %d)", stride, c->lt.w[0]); return LPSLAM_HIP_ERR_INVALID; }
+    if (stereo && (!(baseline > 0.f) || !(fxb > 0.f))) { set_error("focal_x_baseline and baseline must be positive"); return LPSLAM_HIP_ERR_INVALID; }
+    LP_HIP(hipSetDevice(c->cfg.device));
+    if (c->cfg.max_images <= 8) {        // (a context with page-locked staging per slot: what a session is)
+        const uint8_t* sl = stage_upload(c, image, left, stride);
+        const uint8_t* sr = stereo ? stage_upload(c, image + 1, right, stride) : nullptr;
+        if (!sl || (stereo && !sr)) return LPSLAM_HIP_ERR_DEVICE;
+        const int shared = lp_share_front_end(c, image, stereo ? 1 : 0, fxb, baseline, sl, sr);
+        if (shared < 0) return -shared;
+        if (shared == LP_SHARE_DONE) return LPSLAM_HIP_OK;
+        for (int e = 0; e < (stereo ? 2 : 1); ++e) {
+            LP_HIP(hipMemcpy2DAsync(c->d_pyr + (size_t)(image + e) * c->image_slab, c->lt.pitch[0], e ? sr : sl, c->lt.w[0], c->lt.w[0], c->lt.h[0], hipMemcpyHostToDevice, lp_fe_stream(c)));
+            LP_HIP(hipEventRecord(c->ev_upload[(size_t)(image + e)], lp_fe_stream(c)));
+        }
+    } else {
+        if ((rc = lpslam_hip_upload_image(c, image, left, stride))) return rc;
+        if (stereo && (rc = lpslam_hip_upload_image(c, image + 1, right, stride))) return rc;
+    }
+    if ((rc = lpslam_hip_extract_range(c, image, stereo ? 2 : 1))) return rc;
+    if (stereo && (rc = lpslam_hip_match_stereo(c, image, image + 1, fxb, baseline))) return rc;
+    return lpslam_hip_prefetch_frame(c, image, stereo ? 1 : 0);
+}
+
 // the block that holds `fields` of slot `image` once this returns (delivered ahead of time, or read back now)
 static int frame_collect(lpslam_hip_ctx* c, int image, int fields, uint8_t** block)
 {
@@ -1049,7 +1288,9 @@ static int frame_collect(lpslam_hip_ctx* c, int image, int fields, uint8_t** blo
         // delivered ahead of time by lpslam_hip_prefetch_frame
         st = c->h_stage_pf;
         c->pf_image = -1;
-        if (!lp_wait_done((int*)(st + 32), c->pf_seq, c->pf_stream)) { c->pf_in_flight = !lp_wait_recover(c, 3, c->pf_stream); set_error("lpslam_hip_get_frame: the prefetched read-back did not complete"); return LPSLAM_HIP_ERR_DEVICE; }
+        const bool arrived = lp_wait_done((int*)(st + 32), c->pf_seq, c->pf_stream);
+        lp_share_front_end_collected(c);
+        if (!arrived) { c->pf_in_flight = !lp_wait_recover(c, 3, c->pf_stream); set_error("lpslam_hip_get_frame: the prefetched read-back did not complete"); return LPSLAM_HIP_ERR_DEVICE; }
         c->pf_in_flight = false;
     } else {
         if (c->h_stage_bytes < f.need) {

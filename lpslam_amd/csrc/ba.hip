@@ -2251,14 +2251,13 @@ __device__ __forceinline__ void po_reduce28_wn(const double (&acc)[PO_NV], doubl
     for (int i = 0; i < PO_NV; ++i) sums[i] = out[i];
 }
 
+// (a device function: the launch is k_pose_optimize_req below -- one workgroup per request of a batch, the same code whether the batch
+// holds one tracker's frame or the pending frames of every session of the process, so shared and unshared results are the same bits)
 template <int W>
-__global__ __launch_bounds__(64 * W) void k_pose_optimize_wn(double* pose7, const PoObs* packed, int n, BaCam cam, uint8_t* outlier, int* n_inliers, int* done_flag, int seq)
+__device__ __forceinline__ void po_wn_body(double* pose7, const PoObs* packed, int n, const BaCam& cam, uint8_t* outlier, int* n_inliers, int* done_flag, int seq,
+                                           double* tr, double* out28, PoObs* cache, int (*s_bad)[4])
 {
 #pragma clang fp contract(fast)
-    __shared__ double tr[PO_NV * PO_WN_ROW(W)];
-    __shared__ double out28[32];
-    __shared__ PoObs cache[64 * W];
-    __shared__ int s_bad[2][4];                            // outliers per wavefront, double-buffered over the rounds
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     static_assert(sizeof(PoObs) == 7 * sizeof(double), "PoObs is copied as doubles");
     for (int i = tid; i < 7 * n; i += 64 * W) reinterpret_cast<double*>(cache)[i] = reinterpret_cast<const double*>(packed)[i];      // page-locked host memory, over PCIe
@@ -2395,6 +2394,39 @@ __global__ __launch_bounds__(64 * W) void k_pose_optimize_wn(double* pose7, cons
         __syncthreads();
         if (tid == 0) __hip_atomic_store(done_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+}
+
+// One workgroup per request.  A request is a page-locked block of the caller: pose (in / out) at 0, inlier count and passes at 56 / 60,
+// the done flag at 64, the camera at 72, the packed observations at 128, the outlier bytes behind them (lpslam_hip_pose_optimize lays
+// it out).  Block pointer, observation count and sequence number come by value; W = 1, 2 or 4 wavefronts work on a request
+// (n <= 64 W), the others of the workgroup leave at once -- a barrier counts the wavefronts that are left.
+constexpr int PO_MAX_BATCH = 32;
+struct PoBatch { uint8_t* blk[PO_MAX_BATCH]; int n[PO_MAX_BATCH]; int seq[PO_MAX_BATCH]; };
+constexpr size_t PO_BLK_INLIERS = 56, PO_BLK_FLAG = 64, PO_BLK_CAM = 72, PO_BLK_PACKED = 128;
+static_assert(PO_BLK_CAM + sizeof(BaCam) <= PO_BLK_PACKED, "pose-optimiser block header");
+__global__ __launch_bounds__(256) void k_pose_optimize_req(PoBatch b)
+{
+    __shared__ double tr[PO_NV * PO_WN_ROW(4)];
+    __shared__ double out28[32];
+    __shared__ PoObs cache[64 * 4];
+    __shared__ int s_bad[2][4];                            // outliers per wavefront, double-buffered over the rounds
+    const int r = blockIdx.x, n = b.n[r];
+    uint8_t* blk = b.blk[r];
+    const int W = n <= 64 ? 1 : (n <= 128 ? 2 : 4);
+    if ((int)threadIdx.x >= 64 * W) return;
+    BaCam cam;
+    {
+        const double* cp = reinterpret_cast<const double*>(blk + PO_BLK_CAM);
+        cam.fx = cp[0]; cam.fy = cp[1]; cam.cx = cp[2]; cam.cy = cp[3]; cam.fxb = cp[4]; cam.hub_mono = cp[5]; cam.hub_stereo = cp[6];
+    }
+    double* pose7 = reinterpret_cast<double*>(blk);
+    const PoObs* packed = reinterpret_cast<const PoObs*>(blk + PO_BLK_PACKED);
+    uint8_t* outlier = blk + PO_BLK_PACKED + (size_t)(n > 0 ? n : 1) * sizeof(PoObs);
+    int* n_inliers = reinterpret_cast<int*>(blk + PO_BLK_INLIERS);
+    int* flag = reinterpret_cast<int*>(blk + PO_BLK_FLAG);
+    if (W == 1) po_wn_body<1>(pose7, packed, n, cam, outlier, n_inliers, flag, b.seq[r], tr, out28, cache, s_bad);
+    else if (W == 2) po_wn_body<2>(pose7, packed, n, cam, outlier, n_inliers, flag, b.seq[r], tr, out28, cache, s_bad);
+    else po_wn_body<4>(pose7, packed, n, cam, outlier, n_inliers, flag, b.seq[r], tr, out28, cache, s_bad);
 }
 
 #include "ba_update.inl"
@@ -3169,7 +3201,7 @@ int lpslam_hip_ba_optimize_begin(lpslam_hip_ba* b, int32_t robust, int32_t iters
         hipGraphExec_t exec = nullptr;
         void* slot = nullptr;
         bool capture = false;
-        if (ba_graphs_enabled()) {
+        if (ba_graphs_enabled() && b->stream != c->role_solve) {      // (several sessions' windows run on the solves' role stream: no capture on a stream other threads launch on)
             std::lock_guard<std::mutex> lock(c->pool_mutex);
             auto key = std::make_pair(b->stream, sig);
             auto it = c->ba_graphs.find(key);
@@ -3671,6 +3703,24 @@ int lpslam_hip_ba_chi2(lpslam_hip_ba* b, double* chi2, uint8_t* depth_positive)
     return LPSLAM_HIP_OK;
 }
 
+}  // extern "C"
+
+int lp_launch_pose_batch(hipStream_t s, const LpPoseReq* reqs, int n)
+{
+    for (int i0 = 0; i0 < n; i0 += PO_MAX_BATCH) {
+        const int m = std::min(n - i0, (int)PO_MAX_BATCH);
+        PoBatch b{};
+        int n_max = 0;
+        for (int i = 0; i < m; ++i) { b.blk[i] = reqs[i0 + i].blk; b.n[i] = reqs[i0 + i].n; b.seq[i] = reqs[i0 + i].seq; n_max = std::max(n_max, reqs[i0 + i].n); }
+        const int threads = n_max <= 64 ? 64 : (n_max <= 128 ? 128 : 256);
+        hipLaunchKernelGGL(k_pose_optimize_req, dim3((unsigned)m), dim3((unsigned)threads), 0, s, b);
+        LP_HIP(hipGetLastError());
+    }
+    return LPSLAM_HIP_OK;
+}
+
+extern "C" {
+
 int lpslam_hip_pose_optimize(lpslam_hip_ctx* ctx, double* pose7, const double* points, int32_t n_points, const lpslam_hip_ba_obs* obs, int32_t n_obs,
                              const lpslam_hip_ba_camera* cam, uint8_t* outlier, int32_t* n_inliers)
 {
@@ -3717,25 +3767,29 @@ int lpslam_hip_pose_optimize(lpslam_hip_ctx* ctx, double* pose7, const double* p
             const double* p = points + 3 * (size_t)o.point;
             packed[k] = PoObs{o.u, o.v, o.ur, o.inv_sigma2, {p[0], p[1], p[2]}};
         }
-        int* flag = (int*)(hb + 64);
+        int* flag = (int*)(hb + PO_BLK_FLAG);
         const int seq = lp_next_seq(ctx->po_seq);
         __atomic_store_n(flag, 0, __ATOMIC_RELAXED);          // (the block is shared with the matchers' staging: whatever they left here is not a sequence number)
         static const bool four_waves_env = [] { const char* e = getenv("LPSLAM_HIP_PO_FOUR_WAVES"); return e && atoi(e) != 0; }();      // measurements: the round-4 kernel for every size
         static const int po1_max = [] { const char* e = getenv("LPSLAM_HIP_PO_W1_MAX"); const int v = e ? atoi(e) : 256; return std::min(std::max(v, 0), 256); }();      // measurements: where the one-observation-per-lane kernel hands over
+        bool delivered = false;
         if (n_obs <= po1_max && !four_waves_env) {
-            // a tracked frame: one observation per lane on 1, 2 or 4 wavefronts
-            double* a0 = (double*)hb; uint8_t* a4 = hb + off_flags; int* a5 = (int*)(hb + 56);
-            if (n_obs <= 64) hipLaunchKernelGGL(k_pose_optimize_wn<1>, dim3(1), dim3(64), 0, s, a0, (const PoObs*)packed, n_obs, c, a4, a5, flag, seq);
-            else if (n_obs <= 128) hipLaunchKernelGGL(k_pose_optimize_wn<2>, dim3(1), dim3(128), 0, s, a0, (const PoObs*)packed, n_obs, c, a4, a5, flag, seq);
-            else hipLaunchKernelGGL(k_pose_optimize_wn<4>, dim3(1), dim3(256), 0, s, a0, (const PoObs*)packed, n_obs, c, a4, a5, flag, seq);
+            // a tracked frame: one observation per lane on 1, 2 or 4 wavefronts (k_pose_optimize_req); the camera travels in the block
+            memcpy(hb + PO_BLK_CAM, &c, sizeof(BaCam));
+            const LpPoseReq req{hb, n_obs, seq};
+            // several sessions tracking at once: the request joins the others' in one launch (share.hip) and comes back delivered
+            const int shared = lp_share_pose(ctx, req, flag);
+            if (shared < 0) return -shared;
+            if (shared == LP_SHARE_DONE) delivered = true;
+            else { const int rc = lp_launch_pose_batch(s, &req, 1); if (rc) return rc; }
         } else
         hipLaunchKernelGGL(k_pose_optimize<true>, dim3(1), dim3(PO_T), lds, s, (double*)hb, (const double*)nullptr, (const lpslam_hip_ba_obs*)nullptr, packed, n_obs, c,
                            hb + off_flags, (int*)(hb + 56), cache_n, flag, seq);
         LP_HIP(hipGetLastError());
         // the kernel's last store releases `seq`: poll it (a few hundred microseconds at most), fall back to the stream when it does not come
         const auto t0 = std::chrono::steady_clock::now();
-        bool seen = false;
-        for (int spin = 0; ; ++spin) {
+        bool seen = delivered;
+        for (int spin = 0; !seen; ++spin) {
             if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) { seen = true; break; }
             lp_poll_pause(spin);
             if ((spin & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;

@@ -123,7 +123,7 @@ __global__ __launch_bounds__(1024) void k_fe_occupy(const uint32_t* cu_table, un
 }
 
 template <bool kTablesInLds>
-__global__ __launch_bounds__(1024) void k_pyr_bands(uint8_t* __restrict__ pyr, size_t image_slab, LevelTable lt, int image0,
+__global__ __launch_bounds__(1024) void k_pyr_bands(uint8_t* __restrict__ pyr, size_t image_slab, LevelTable lt, ImgSel image0,
                                                     const int2* __restrict__ rs_pack, int rs_entries,
                                                     const int2* __restrict__ band_rows, FeQueue fq, int n_bands)
 {
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(1024) void k_pyr_bands(uint8_t* __restrict__ pyr, s
     if (fq.cu_table) { item = fe_next_chunk(fq); if (item >= fq.n_items) break; }
     else { if (!once) break; item = (int)(blockIdx.x + n_bands * blockIdx.y); }
     const int band_x = item % n_bands, image_y = item / n_bands;
-    uint8_t* img = pyr + (size_t)(image0 + image_y) * image_slab;
+    uint8_t* img = pyr + (size_t)lp_image(image0, image_y) * image_slab;
     for (int level = 1; level < lt.n_levels; ++level) {
         const int2 rows = band_rows[level * kPyrMaxBands + band_x];
         const int dw = lt.w[level], dp = lt.pitch[level], sp = lt.pitch[level - 1];
@@ -211,7 +211,7 @@ __device__ __forceinline__ int fast_strength(const uint8_t* t /* points at centr
 
 __device__ __forceinline__ void fast_cells_body(int cell_arg, int image_arg, const uint8_t* __restrict__ pyr, size_t image_slab, const LevelTable& lt,
                                                 int ini_thr, int min_thr, uint32_t* __restrict__ cell_keys,
-                                                int32_t* __restrict__ cell_count, int cells_per_image, int image0, int dbg,
+                                                int32_t* __restrict__ cell_count, int cells_per_image, const ImgSel& image0, int dbg,
                                                 const uint8_t* __restrict__ mask0, const uint8_t* __restrict__ mask1)
 {
     __shared__ __attribute__((aligned(16))) uint8_t tile[70 * TILE_PITCH];
@@ -221,7 +221,7 @@ __device__ __forceinline__ void fast_cells_body(int cell_arg, int image_arg, con
     __shared__ uint16_t queue[4][16 * 64];       // pre-test survivors, one queue per wavefront (its 16 rows): no shared counter
     __shared__ int n_keep;
 
-    const int cell = cell_arg, image = image0 + image_arg;
+    const int cell = cell_arg, image = lp_image(image0, image_arg);
     int level = 0;
     while (level + 1 < lt.n_levels && cell >= lt.cell_start[level + 1]) ++level;
     const int lc = cell - lt.cell_start[level];
@@ -388,7 +388,7 @@ __device__ __forceinline__ void fast_cells_body(int cell_arg, int image_arg, con
 // direct launch: one workgroup per (cell, image)
 __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ pyr, size_t image_slab, LevelTable lt,
                                                     int ini_thr, int min_thr, uint32_t* __restrict__ cell_keys,
-                                                    int32_t* __restrict__ cell_count, int cells_per_image, int image0, int dbg,
+                                                    int32_t* __restrict__ cell_count, int cells_per_image, ImgSel image0, int dbg,
                                                     const uint8_t* __restrict__ mask0, const uint8_t* __restrict__ mask1)
 {
     fast_cells_body(blockIdx.x, blockIdx.y, pyr, image_slab, lt, ini_thr, min_thr, cell_keys, cell_count, cells_per_image, image0, dbg, mask0, mask1);
@@ -397,7 +397,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
 // (both in one kernel: 110 instead of 63 VGPRs, four instead of eight wavefronts per SIMD, 246 -> 297 us per 32 images)
 __global__ __launch_bounds__(256) void k_fast_cells_q(const uint8_t* __restrict__ pyr, size_t image_slab, LevelTable lt,
                                                       int ini_thr, int min_thr, uint32_t* __restrict__ cell_keys,
-                                                      int32_t* __restrict__ cell_count, int cells_per_image, int image0, int dbg,
+                                                      int32_t* __restrict__ cell_count, int cells_per_image, ImgSel image0, int dbg,
                                                       const uint8_t* __restrict__ mask0, const uint8_t* __restrict__ mask1, FeQueue fq)
 {
     if (fe_leaves(fq)) return;
@@ -467,10 +467,10 @@ __device__ __forceinline__ void distribute_body(int image_arg, int level_arg, co
                                                 uint32_t* __restrict__ cand_key, uint32_t* __restrict__ cand_node,
                                                 int32_t* __restrict__ cand_count, int cand_per_image,
                                                 uint32_t* __restrict__ sel_key, int32_t* __restrict__ sel_count,
-                                                int slots_per_image, int image0)
+                                                int slots_per_image, const ImgSel& image0)
 {
     extern __shared__ __attribute__((aligned(16))) int lds[];
-    const int level = level_arg, image = image0 + image_arg;
+    const int level = level_arg, image = lp_image(image0, image_arg);
     int tid_ = threadIdx.x;
     asm volatile("" : "+v"(tid_));          // opaque per call (see fast_cells_body)
     const int tid = tid_;
@@ -834,7 +834,7 @@ __global__ __launch_bounds__(1024) void k_distribute(LevelTable lt, const uint32
                                                      uint32_t* __restrict__ cand_key, uint32_t* __restrict__ cand_node,
                                                      int32_t* __restrict__ cand_count, int cand_per_image,
                                                      uint32_t* __restrict__ sel_key, int32_t* __restrict__ sel_count,
-                                                     int slots_per_image, int image0)
+                                                     int slots_per_image, ImgSel image0)
 {
     distribute_body(blockIdx.x, blockIdx.y, lt, cell_keys, cell_count, cells_per_image, cand_key, cand_node, cand_count, cand_per_image, sel_key, sel_count, slots_per_image, image0);
 }
@@ -844,7 +844,7 @@ __global__ __launch_bounds__(1024) void k_distribute_q(LevelTable lt, const uint
                                                        uint32_t* __restrict__ cand_key, uint32_t* __restrict__ cand_node,
                                                        int32_t* __restrict__ cand_count, int cand_per_image,
                                                        uint32_t* __restrict__ sel_key, int32_t* __restrict__ sel_count,
-                                                       int slots_per_image, int image0, FeQueue fq, int n_images)
+                                                       int slots_per_image, ImgSel image0, FeQueue fq, int n_images)
 {
     if (fe_leaves(fq)) return;
     for (;;) {
@@ -932,7 +932,7 @@ __device__ __forceinline__ void describe_body(int slot_block, int image_arg, con
                                               const uint32_t* __restrict__ sel_key,
                                               const int32_t* __restrict__ sel_count, int slots_per_image,
                                               lpslam_hip_keypoint* __restrict__ kpts, uint8_t* __restrict__ desc,
-                                              int32_t* __restrict__ kp_count, int image0)
+                                              int32_t* __restrict__ kp_count, const ImgSel& image0)
 {
     // per wavefront: the raw patch (2064 B), the horizontally blurred one (3440 B); the blurred patch (1369 B) takes the raw patch's
     // place, which nobody reads after the horizontal pass -- 5.5 KB instead of 6.9 KB per wavefront is 29 instead of 23 wavefronts
@@ -943,7 +943,7 @@ __device__ __forceinline__ void describe_body(int slot_block, int image_arg, con
     int tid_ = threadIdx.x;
     asm volatile("" : "+v"(tid_));          // opaque per call (see fast_cells_body)
     const int lane = tid_ & 63, wave = tid_ >> 6;
-    const int image = image0 + image_arg;
+    const int image = lp_image(image0, image_arg);
     const int slot = slot_block * DESC_WAVES + wave;
     if (slot >= slots_per_image) return;          // wave-uniform; no block barriers below
     int level = 0;
@@ -1080,7 +1080,7 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const uint8_t* __r
                                                               const uint32_t* __restrict__ sel_key,
                                                               const int32_t* __restrict__ sel_count, int slots_per_image,
                                                               lpslam_hip_keypoint* __restrict__ kpts, uint8_t* __restrict__ desc,
-                                                              int32_t* __restrict__ kp_count, int image0)
+                                                              int32_t* __restrict__ kp_count, ImgSel image0)
 {
     describe_body(blockIdx.x, blockIdx.y, pyr, image_slab, lt, sel_key, sel_count, slots_per_image, kpts, desc, kp_count, image0);
 }
@@ -1089,7 +1089,7 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe_q(const uint8_t* _
                                                                 const uint32_t* __restrict__ sel_key,
                                                                 const int32_t* __restrict__ sel_count, int slots_per_image,
                                                                 lpslam_hip_keypoint* __restrict__ kpts, uint8_t* __restrict__ desc,
-                                                                int32_t* __restrict__ kp_count, int image0, FeQueue fq, int blocks_per_image)
+                                                                int32_t* __restrict__ kp_count, ImgSel image0, FeQueue fq, int blocks_per_image)
 {
     if (fe_leaves(fq)) return;
     for (;;) {
@@ -1216,8 +1216,9 @@ int lp_fe_occupy_unreserved(lpslam_hip_ctx* c, int microseconds, int* landed)
     return LPSLAM_HIP_OK;
 }
 
-int lp_launch_pyramid(lpslam_hip_ctx* c, int first, int n_images)
+int lp_launch_pyramid(lpslam_hip_ctx* c, int first, int n_images, const uint16_t* list)
 {
+    const ImgSel sel = lp_img_sel(first, n_images, list);
     if (c->lt.n_levels < 2 || n_images <= 0) return LPSLAM_HIP_OK;
     // one band work-group per CU (256 CUs, less what is reserved for the mapping solves): more bands would only add rows computed
     // twice -- or, with fewer CUs than work-groups, a second round --, fewer would leave CUs idle
@@ -1228,10 +1229,10 @@ int lp_launch_pyramid(lpslam_hip_ctx* c, int first, int n_images)
     FeQueue fq = lp_fe_queue(c, bands * n_images, 1);
     const dim3 grid = fq.cu_table ? dim3(256, 1) : dim3(bands, n_images);       // queued: one persistent workgroup per compute unit
     if (lds <= 64 * 1024)
-        hipLaunchKernelGGL(k_pyr_bands<true>, grid, dim3(1024), lds, lp_fe_stream(c), c->d_pyr, c->image_slab, c->lt, first,
+        hipLaunchKernelGGL(k_pyr_bands<true>, grid, dim3(1024), lds, lp_fe_stream(c), c->d_pyr, c->image_slab, c->lt, sel,
                            c->d_rs_pack, c->rs_entries, rows, fq, bands);
     else        // larger images: tables read through the cache instead
-        hipLaunchKernelGGL(k_pyr_bands<false>, grid, dim3(1024), 0, lp_fe_stream(c), c->d_pyr, c->image_slab, c->lt, first,
+        hipLaunchKernelGGL(k_pyr_bands<false>, grid, dim3(1024), 0, lp_fe_stream(c), c->d_pyr, c->image_slab, c->lt, sel,
                            c->d_rs_pack, c->rs_entries, rows, fq, bands);
     LP_HIP(hipGetLastError());
     return LPSLAM_HIP_OK;
@@ -1246,46 +1247,51 @@ int lp_launch_remap(lpslam_hip_ctx* c, int image, int eye)
     return LPSLAM_HIP_OK;
 }
 
-int lp_launch_fast(lpslam_hip_ctx* c, int first, int n_images)
+int lp_launch_fast(lpslam_hip_ctx* c, int first, int n_images, const uint16_t* list)
 {
+    const ImgSel sel = lp_img_sel(first, n_images, list);
     FeQueue fq = lp_fe_queue(c, c->cells_per_image * n_images, 1);       // one cell (~20 us of work) per fetch: chunks of 4 / 2 / 1 cells measured 1.083 / 1.064 / 1.047 ms per 16-frame step on half of the compute units -- the tail of an uneven last chunk costs more than the fetches
     if (fq.cu_table)                                     // queued: the eight workgroups a compute unit holds
         hipLaunchKernelGGL(k_fast_cells_q, dim3(256 * 8), dim3(256), 0, lp_fe_stream(c), c->d_pyr, c->image_slab, c->lt, c->cfg.ini_fast_threshold,
-                           c->cfg.min_fast_threshold, c->d_cell_keys, c->d_cell_count, c->cells_per_image, first, 0, c->d_mask[0], c->d_mask[1], fq);
+                           c->cfg.min_fast_threshold, c->d_cell_keys, c->d_cell_count, c->cells_per_image, sel, 0, c->d_mask[0], c->d_mask[1], fq);
     else
         hipLaunchKernelGGL(k_fast_cells, dim3(c->cells_per_image, n_images), dim3(256), 0, lp_fe_stream(c), c->d_pyr, c->image_slab, c->lt, c->cfg.ini_fast_threshold,
-                           c->cfg.min_fast_threshold, c->d_cell_keys, c->d_cell_count, c->cells_per_image, first, 0, c->d_mask[0], c->d_mask[1]);
+                           c->cfg.min_fast_threshold, c->d_cell_keys, c->d_cell_count, c->cells_per_image, sel, 0, c->d_mask[0], c->d_mask[1]);
     LP_HIP(hipGetLastError());
     return LPSLAM_HIP_OK;
 }
 
-int lp_launch_distribute(lpslam_hip_ctx* c, int first, int n_images)
+int lp_launch_distribute(lpslam_hip_ctx* c, int first, int n_images, const uint16_t* list)
 {
+    const ImgSel sel = lp_img_sel(first, n_images, list);
     FeQueue fq = lp_fe_queue(c, n_images * c->lt.n_levels, 1);
     if (fq.cu_table)
         hipLaunchKernelGGL(k_distribute_q, dim3(256), dim3(1024), c->distribute_lds, lp_fe_stream(c), c->lt, c->d_cell_keys, c->d_cell_count,
                            c->cells_per_image, c->d_cand_key, c->d_cand_node, c->d_cand_count, c->cand_per_image, c->d_sel_key, c->d_sel_count,
-                           c->slots_per_image, first, fq, n_images);
+                           c->slots_per_image, sel, fq, n_images);
     else                                                 // level 0 of every image first: the long work-groups start first
         hipLaunchKernelGGL(k_distribute, dim3(n_images, c->lt.n_levels), dim3(1024), c->distribute_lds, lp_fe_stream(c), c->lt, c->d_cell_keys, c->d_cell_count,
                            c->cells_per_image, c->d_cand_key, c->d_cand_node, c->d_cand_count, c->cand_per_image, c->d_sel_key, c->d_sel_count,
-                           c->slots_per_image, first);
+                           c->slots_per_image, sel);
     LP_HIP(hipGetLastError());
     return LPSLAM_HIP_OK;
 }
 
-int lp_launch_describe(lpslam_hip_ctx* c, int first, int n_images)
+int lp_launch_describe(lpslam_hip_ctx* c, int first, int n_images, const uint16_t* list)
 {
-    for (int i = first; i < first + n_images && (size_t)i < c->h_kp_valid.size(); ++i) c->h_kp_valid[(size_t)i] = 0;      // counts are rewritten
-    lp_pf_invalidate(c, first, n_images);
+    const ImgSel sel = lp_img_sel(first, n_images, list);
+    if (!list) {
+        for (int i = first; i < first + n_images && (size_t)i < c->h_kp_valid.size(); ++i) c->h_kp_valid[(size_t)i] = 0;      // counts are rewritten
+        lp_pf_invalidate(c, first, n_images);
+    }      // (a listed launch runs on the session pool's context: the sessions' own mirrors are invalidated by the caller, share.hip)
     const int blocks = (c->slots_per_image + DESC_WAVES - 1) / DESC_WAVES;
     FeQueue fq = lp_fe_queue(c, blocks * n_images, 2);         // (chunks of 32 / 16 / 8 / 4 / 2 / 1 workgroup-items: 1.18 / 1.055 / 1.039 / 1.033 / 1.027 / 1.039 ms per 16-frame step on half of the compute units)
     if (fq.cu_table)                                     // queued: seven workgroups (28 wavefronts) per compute unit
         hipLaunchKernelGGL(k_describe_q, dim3(256 * 7), dim3(64 * DESC_WAVES), 0, lp_fe_stream(c), c->d_pyr, c->image_slab, c->lt, c->d_sel_key,
-                           c->d_sel_count, c->slots_per_image, c->d_kpts, c->d_desc, c->d_kp_count, first, fq, blocks);
+                           c->d_sel_count, c->slots_per_image, c->d_kpts, c->d_desc, c->d_kp_count, sel, fq, blocks);
     else
         hipLaunchKernelGGL(k_describe, dim3(blocks, n_images), dim3(64 * DESC_WAVES), 0, lp_fe_stream(c), c->d_pyr, c->image_slab, c->lt, c->d_sel_key,
-                           c->d_sel_count, c->slots_per_image, c->d_kpts, c->d_desc, c->d_kp_count, first);
+                           c->d_sel_count, c->slots_per_image, c->d_kpts, c->d_desc, c->d_kp_count, sel);
     LP_HIP(hipGetLastError());
     return LPSLAM_HIP_OK;
 }

@@ -1,6 +1,8 @@
 // internal.h -- shared host-side definitions of the lpslam HIP library (gfx950 only).
 #pragma once
 #include <sched.h>
+#include <time.h>
+#include <sys/prctl.h>
 #include <hip/hip_runtime.h>
 #include <array>
 #include <atomic>
@@ -28,6 +30,21 @@ constexpr int kQuotaMax = 2000;    // per-level quota supported by the distribut
 // Per-level geometry, passed to kernels by value.
 constexpr int kPyrMaxBands = 32;   // banded pyramid kernel: up to 32 bands per image
 
+// Which images a front-end launch works on: `n` consecutive slots from `first`, or -- the pending frames of several sessions, whose
+// slots lie anywhere in the session pool -- a list (share.hip).  Passed by value; image k of the launch is lp_image(sel, k).
+constexpr int kMaxListed = 64;
+struct ImgSel { int first; int listed; uint16_t list[kMaxListed]; };
+#ifdef __HIPCC__
+__device__ __forceinline__ int lp_image(const ImgSel& s, int k) { return s.listed ? (int)s.list[k] : s.first + k; }
+#endif
+inline ImgSel lp_img_sel(int first, int n, const uint16_t* list)
+{
+    ImgSel s{};
+    s.first = first; s.listed = list ? 1 : 0;
+    if (list) for (int i = 0; i < n && i < kMaxListed; ++i) s.list[i] = list[i];
+    return s;
+}
+
 struct LevelTable {
     int n_levels;
     int w[kMaxLevels], h[kMaxLevels], pitch[kMaxLevels];
@@ -49,6 +66,7 @@ void set_error(const char* fmt, ...);
 // Between lpslam_hip_prefetch_begin and _end the CALLING THREAD's upload / remap / extraction / stereo launches go to the context's
 // prefetch stream; other threads (the tracking thread) keep using the main stream of the same context.
 extern thread_local hipStream_t lp_tls_stream;
+extern thread_local bool lp_tls_stream_used;       // something was enqueued on it since lpslam_hip_prefetch_begin (lp_fe_stream hands it out)
 int hip_fail(hipError_t e, const char* what);
 
 #define LP_HIP(call)                                              \
@@ -73,6 +91,7 @@ struct lpslam_hip_ctx {
     int reserve_cus = 0;               // lpslam_hip_set_mapping_reserve: CUs of every XCD the front end's streams leave to the mapping solves
     hipStream_t fe_stream = nullptr;   // prefetch: front end of the NEXT frame beside the tracking of this one (lp_fe_stream)
     hipEvent_t fe_done = nullptr;
+    bool fe_join_needed = false;       // the last prefetch section enqueued work on fe_stream and recorded fe_done: lpslam_hip_prefetch_join has something to wait for
     // asynchronous uploads from the caller's page-locked frames (lpslam_hip_upload_images_async): a copy stream of its own, one event
     // per call that the main stream waits for before it first reads one of the call's slots
     hipStream_t copy_stream = nullptr;
@@ -120,6 +139,17 @@ struct lpslam_hip_ctx {
     std::vector<std::pair<size_t, void*>> pin_big;   // idle page-locked staging blocks (capacity, block) of lp_pin_big_alloc / free
     uint8_t* h_match = nullptr;        // pinned host staging of the window matchers (queries in, candidate lists out)
     size_t h_match_bytes = 0;
+    bool owns_streams = true;          // false: a session of a pool -- stream / fe_stream / the solves' stream are the device's role streams (share.hip)
+    hipStream_t role_solve = nullptr;  // session: the role stream its bundle adjustments run on
+    int share_slot = -1;               // this context's entry in its device's session table (share.hip), -1: never shared
+    // Session pool (lpslam_hip_create_session): the per-image arrays of the sessions of one device and front-end configuration are
+    // slices of ONE set of arrays -- those of a pool context that no caller sees -- so that a front-end launch can work on the pending
+    // frames of several sessions at once (image lists, ImgSel).  A session's slot i is image pool_first + i of the pool.
+    lpslam_hip_ctx* sess_pool = nullptr;    // session: its pool; nullptr: a context with arrays of its own
+    int pool_first = 0, pool_slot = -1;
+    bool is_pool = false; int pool_per = 0; std::vector<uint8_t> pool_used; int pool_refs = 0;      // pool: images per session, which session slots are taken
+    hipEvent_t ev_fe_ready = nullptr;  // session: "this frame's uploads are in the slots" for a shared front end (recorded on the session's stream)
+    std::atomic<int> share_fe_pending{0};      // session: a shared front end has been launched and its delivery not yet collected
     int po_passes = 0;                 // passes the last pose optimisation made (diagnostic)
     int po_seq = 0;                    // sequence number the pose optimiser's kernel releases into its done flag (h_match + 64)
     int2* d_band_rows = nullptr;       // [band count 0..32][levels][bands]: rows of each level a band work-group computes
@@ -165,7 +195,7 @@ struct lpslam_hip_ctx {
 
 // kernel launchers (frontend.hip / match.hip)
 // block cache (api.hip): capacity-rounded first fit; *capacity receives the size to hand back to lp_pool_free
-inline hipStream_t lp_fe_stream(lpslam_hip_ctx* c) { return lpslam::lp_tls_stream ? lpslam::lp_tls_stream : c->stream; }
+inline hipStream_t lp_fe_stream(lpslam_hip_ctx* c) { if (lpslam::lp_tls_stream) { lpslam::lp_tls_stream_used = true; return lpslam::lp_tls_stream; } return c->stream; }
 int lp_pool_alloc(lpslam_hip_ctx* c, size_t bytes, void** out, size_t* capacity);
 void lp_pool_free(lpslam_hip_ctx* c, void* p, size_t capacity);
 hipStream_t lp_stream_acquire(lpslam_hip_ctx* c);   // high-priority non-blocking stream from the context's cache (nullptr on failure)
@@ -174,17 +204,59 @@ void* lp_pin_big_alloc(lpslam_hip_ctx* c, size_t bytes, size_t* capacity);      
 void lp_pin_big_free(lpslam_hip_ctx* c, void* p, size_t capacity);
 void* lp_pin_alloc(lpslam_hip_ctx* c);          // 8 KB of page-locked host memory, recycled through the context (nullptr on failure)
 void lp_pin_free(lpslam_hip_ctx* c, void* p);
-int lp_launch_pyramid(lpslam_hip_ctx* c, int first, int n_images);
+int lp_launch_pyramid(lpslam_hip_ctx* c, int first, int n_images, const uint16_t* list = nullptr);      // list: n_images slots in any order instead of first ..
 bool lp_flat_priorities();             // several contexts live in the process: new streams at the default priority (api.hip)
 int lp_fe_calibrate(lpslam_hip_ctx* c, int reserve_cus_per_xcd);
 int lp_fe_occupy_unreserved(lpslam_hip_ctx* c, int microseconds, int* landed);
 int lp_launch_remap(lpslam_hip_ctx* c, int image, int eye);
-int lp_launch_fast(lpslam_hip_ctx* c, int first, int n_images);
-int lp_launch_distribute(lpslam_hip_ctx* c, int first, int n_images);
-int lp_launch_describe(lpslam_hip_ctx* c, int first, int n_images);
+int lp_launch_fast(lpslam_hip_ctx* c, int first, int n_images, const uint16_t* list = nullptr);
+int lp_launch_distribute(lpslam_hip_ctx* c, int first, int n_images, const uint16_t* list = nullptr);
+int lp_launch_describe(lpslam_hip_ctx* c, int first, int n_images, const uint16_t* list = nullptr);
 int lp_launch_bf_strided(lpslam_hip_ctx* c, int q0, int t0, int stride, int n_pairs);
-int lp_launch_stereo_strided(lpslam_hip_ctx* c, int left0, int right0, int stride, int n_pairs, float fxb, float baseline);
+int lp_launch_stereo_strided(lpslam_hip_ctx* c, int left0, int right0, int stride, int n_pairs, float fxb, float baseline, const uint16_t* pair_list = nullptr);
 size_t lp_distribute_lds_bytes(int qcap_max, int ncell_max);
+
+// ---- launches shared by the sessions of a process (share.hip) ----------------------------------------------------------------
+// The reference's deployment unit is one manager per sequence (src/Manager/SlamManager.cpp:54-61,191-201); a process that serves N
+// sequences on one GPU then issues N independent chains of small latency-bound launches per frame, and a HIP process has four hardware
+// queues: beyond four the chains wait for each other (8 managers ran at 1.5 x one).  When two or more contexts of a
+// device are tracking at the same time, the per-frame calls that end in a wait -- the window matchers' first scan, the pose optimiser
+// -- become REQUESTS: the calling thread publishes its request and whichever caller finds the combiner free gathers what is pending
+// (a few microseconds: callers in lockstep arrive together) and issues ONE launch for all of it, blockIdx = request; every request
+// keeps its own page-locked result block and completion flag, and its caller polls that flag as before.  The kernels' code per request
+// is the code of the unshared launch (same device function), so results are the same bits either way.
+struct LpProjGate { int mode; float inv_sigma_sq[LPSLAM_HIP_MAX_LEVELS]; };
+struct LpProjReq {                      // one window-matcher call (k_proj_topk_req); lives in the combiner's page-locked table
+    const void* kp; const uint8_t* desc; const float* stereo_xr; const int32_t* kp_count;
+    const void* queries; const uint8_t* q_desc; const int16_t* best_so_far;
+    unsigned long long* out_keys; int* out_count; unsigned* done_counter; int* done_flag;
+    int nq, grid_x, done_seq; float inv_w, inv_h; LpProjGate gate;
+};
+struct LpPoseReq { uint8_t* blk; int n, seq; };        // one pose optimisation: the caller's page-locked block (ba.hip, PO_BLK_*), observation count, flag value
+int lp_launch_proj_batch(hipStream_t s, const LpProjReq* table, int n, int grid_x_max);      // match.hip
+int lp_launch_pose_batch(hipStream_t s, const LpPoseReq* reqs, int n);                        // ba.hip (splits into launches of <= 32 requests)
+enum { LP_SHARE_DONE = 0, LP_SHARE_DIRECT = 1 };        // (negative: minus an LPSLAM_HIP_ERR_* code)
+// Publishes the request and returns LP_SHARE_DONE when ITS flag has arrived, LP_SHARE_DIRECT when sharing does not apply to this call
+// (one session tracking alone, sharing switched off, the context's stream still has work the request must follow): the caller then
+// launches itself, as before.
+int lp_share_pose(lpslam_hip_ctx* c, const LpPoseReq& r, int* flag);
+int lp_share_proj(lpslam_hip_ctx* c, const LpProjReq& r);
+void lp_share_forget(lpslam_hip_ctx* c);                // the context is being destroyed
+// The four role streams of a device (made and probed at the first call): [0] pose batches, [1] matcher batches = a session's main
+// stream, [2] front-end chains = a session's prefetch stream, [3] the windows' solves = a session's bundle-adjustment stream.  The
+// sessions of a pool own NO stream: whatever they enqueue goes to the role stream of its kind, so N sessions keep four hardware queues
+// busy, not 3 N streams spread over them at the runtime's discretion (a latency-bound launch behind another session's chain on the same
+// queue waited for all of it).  false: the streams could not be made.
+enum { LP_ROLE_POSE = 0, LP_ROLE_MAIN = 1, LP_ROLE_FRONT = 2, LP_ROLE_SOLVE = 3 };
+bool lp_share_role_streams(int device, hipStream_t out[4]);
+// One frame's front end (extraction of 1 or 2 slots, stereo match, delivery into the session's page-locked block) as a request: the
+// frames that several sessions have pending go through ONE launch chain on their pool's stream.  DONE: enqueued; DIRECT: not shared.
+struct LpDeliverReq { const int* d_count; const uint32_t* kp; const uint32_t* desc; const uint32_t* xr; const uint32_t* dep; uint32_t* st; unsigned* counter; int* flag; int seq, blocks; };
+int lp_share_front_end(lpslam_hip_ctx* c, int slot, int stereo, float fxb, float baseline, const uint8_t* staged_left = nullptr, const uint8_t* staged_right = nullptr);      // staged_*: the frame in the session's page-locked upload buffers -- the chain copies it up itself
+void lp_share_front_end_collected(lpslam_hip_ctx* c);   // the session has its frame (or gave up on it)
+int lp_prepare_delivery(lpslam_hip_ctx* c, int image, int with_stereo, LpDeliverReq* out);      // api.hip: what lpslam_hip_prefetch_frame sets up, without the launch
+void lp_commit_delivery(lpslam_hip_ctx* c, int image, int with_stereo, const LpDeliverReq& r, hipStream_t s);
+int lp_launch_deliver_batch(hipStream_t s, const LpDeliverReq* reqs, int n, int slots_per_image, const lpslam_hip_ctx* layout);
 
 // ---- results delivered by the kernel itself ---------------------------------------------------------------------------------
 // A small read-back through the copy engines costs a packet round trip per transfer plus the wait for the stream (15 - 25 us for
@@ -214,7 +286,12 @@ inline int lp_next_seq(int& s) { s = s >= 0x7ffffff0 ? 1 : s + 1; return s; }
 // OFFERED to other threads between looks (sched_yield returns at once when nobody else is runnable: a lone session keeps its latency).
 // Sixteen sessions in one process are sixteen workers and sixteen prefetch threads polling: spinning without yielding, they held every
 // core of the GPU's CPU share and starved the threads that feed them (tracker_multi: 16 managers slower than one).
-inline void lp_poll_pause(int spin) { if (spin < 256) __builtin_ia32_pause(); else sched_yield(); }
+// A process is usually given a CPU quota (a container's cpu.max), not cores of its own: threads that spin through a wait of a hundred
+// microseconds spend the quota of every session of the process, and when it runs out the kernel stops ALL of its threads until the next
+// period (measured on the GPU boxes: 16 CPUs' worth per 100 ms for 256 visible CPUs; 16 managers = 48 polling threads ran slower than 8).
+// So after the young phase of a wait (~10 us of pauses) the thread SLEEPS between looks: a few microseconds each (timer slack 1 us).
+void lp_poll_sleep();
+inline void lp_poll_pause(int spin) { if (spin < 256) __builtin_ia32_pause(); else lp_poll_sleep(); }
 // host side: true when the flag arrived; after ~20 ms without it the stream is synchronised and the flag checked once more
 inline bool lp_wait_done(int* flag, int seq, hipStream_t s)
 {

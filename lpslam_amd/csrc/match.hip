@@ -146,14 +146,14 @@ __device__ void block_scan_rows(int* a, int n, int* wave_tot /* LDS[16] */, int*
 // rows in LDS, scan, fill.  The order inside a row list is arbitrary (LDS atomics) and does not matter: the matcher takes the
 // minimum of (distance << 16 | index).
 __global__ __launch_bounds__(1024) void k_stereo_rows(LevelTable lt, const lpslam_hip_keypoint* __restrict__ kpts, const int32_t* __restrict__ counts,
-                                                      int slots_per_image, int right0, int stride, int32_t* __restrict__ row_start_all,
+                                                      int slots_per_image, int right0, int stride, ImgSel pairs, int32_t* __restrict__ row_start_all,
                                                       int32_t* __restrict__ row_list_all, int row_cap)
 {
     extern __shared__ int st_rows[];                     // [H + 1] counts -> starts, [H] cursors
     __shared__ int wave_tot[16];
     const int H = lt.h[0];
     int* cnt = st_rows; int* cursor = st_rows + H + 1;
-    const int right = right0 + blockIdx.x * stride;
+    const int right = pairs.listed ? lp_image(pairs, 2 * blockIdx.x + 1) : right0 + blockIdx.x * stride;      // listed: pair p = slots (list[2 p], list[2 p + 1])
     const int nr = counts[right];
     const lpslam_hip_keypoint* kr = kpts + (size_t)right * slots_per_image;
     int32_t* row_start = row_start_all + (size_t)right * (H + 1);
@@ -184,13 +184,13 @@ __global__ __launch_bounds__(1024) void k_stereo_rows(LevelTable lt, const lpsla
 __global__ __launch_bounds__(64 * ST_WAVES) void k_stereo(const uint8_t* __restrict__ pyr, size_t image_slab, LevelTable lt,
                                                           const lpslam_hip_keypoint* __restrict__ kpts, const uint8_t* __restrict__ desc,
                                                           const int32_t* __restrict__ counts, int slots_per_image, int left0, int right0,
-                                                          int stride, float fxb, float max_disp, float* __restrict__ out_f,
+                                                          int stride, ImgSel pairs, float fxb, float max_disp, float* __restrict__ out_f,
                                                           int32_t* __restrict__ out_idx, int32_t* __restrict__ out_corr,
                                                           const int32_t* __restrict__ row_start_all, const int32_t* __restrict__ row_list_all, int row_cap)
 {
     __shared__ uint8_t s_r[ST_WAVES][11 * 24];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int left = left0 + blockIdx.y * stride, right = right0 + blockIdx.y * stride;
+    const int left = pairs.listed ? lp_image(pairs, 2 * blockIdx.y) : left0 + blockIdx.y * stride, right = pairs.listed ? lp_image(pairs, 2 * blockIdx.y + 1) : right0 + blockIdx.y * stride;
     const int i = blockIdx.x * ST_WAVES + wave;
     const int nl = counts[left], nr = counts[right];
     if (i >= nl) return;                                  // wave-uniform
@@ -293,14 +293,14 @@ __global__ __launch_bounds__(64 * ST_WAVES) void k_stereo(const uint8_t* __restr
 }
 
 // 2 x median cut: sort the correlations of the accepted matches of one image, read the median, invalidate weaker ones
-__global__ __launch_bounds__(1024) void k_stereo_median(const int32_t* __restrict__ counts, int slots_per_image, int left0, int stride,
+__global__ __launch_bounds__(1024) void k_stereo_median(const int32_t* __restrict__ counts, int slots_per_image, int left0, int stride, ImgSel pairs,
                                                         float* __restrict__ out_f, const int32_t* __restrict__ corr)
 {
     // median = element n / 2 of the sorted correlations, found by a four-pass radix select (8 bits per pass, LDS histogram +
     // one wavefront scan) instead of sorting them: the same value, 8 barriers instead of 66
     __shared__ int hist[256];
     __shared__ int s_n, s_prefix, s_target;
-    const int left = left0 + blockIdx.x * stride;
+    const int left = pairs.listed ? lp_image(pairs, 2 * blockIdx.x) : left0 + blockIdx.x * stride;
     const int nl = counts[left];
     const int32_t* cr = corr + (size_t)left * slots_per_image;
     float* o_xr = out_f + (size_t)left * 2 * slots_per_image;
@@ -347,18 +347,20 @@ __global__ __launch_bounds__(1024) void k_stereo_median(const int32_t* __restric
         if (cr[i] >= 0 && thr < (float)cr[i]) { o_xr[i] = -1.0f; o_depth[i] = -1.0f; }
 }
 
-int lp_launch_stereo_strided(lpslam_hip_ctx* c, int left0, int right0, int stride, int n_pairs, float fxb, float baseline)
+int lp_launch_stereo_strided(lpslam_hip_ctx* c, int left0, int right0, int stride, int n_pairs, float fxb, float baseline, const uint16_t* pair_list)
 {
-    for (int i = 0; i < n_pairs; ++i) lp_pf_invalidate(c, left0 + i * stride, 1);        // the left slots' stereo columns are rewritten
+    // pair_list: n_pairs (left, right) slot pairs in any order (the pending frames of several sessions in the session pool, share.hip)
+    if (!pair_list) for (int i = 0; i < n_pairs; ++i) lp_pf_invalidate(c, left0 + i * stride, 1);        // the left slots' stereo columns are rewritten
+    const ImgSel pairs = lp_img_sel(0, 2 * n_pairs, pair_list);
     const float max_disp = fxb / baseline;
     hipLaunchKernelGGL(k_stereo_rows, dim3(n_pairs), dim3(1024), (size_t)(2 * c->lt.h[0] + 2) * sizeof(int), lp_fe_stream(c), c->lt, c->d_kpts, c->d_kp_count,
-                       c->slots_per_image, right0, stride, c->d_st_row_start, c->d_st_row_list, c->st_row_cap);
+                       c->slots_per_image, right0, stride, pairs, c->d_st_row_start, c->d_st_row_list, c->st_row_cap);
     dim3 grid((c->slots_per_image + ST_WAVES - 1) / ST_WAVES, n_pairs);
     hipLaunchKernelGGL(k_stereo, grid, dim3(64 * ST_WAVES), 0, lp_fe_stream(c), c->d_pyr, c->image_slab, c->lt, c->d_kpts, c->d_desc,
-                       c->d_kp_count, c->slots_per_image, left0, right0, stride, fxb, max_disp, c->d_stereo, c->d_stereo_idx,
+                       c->d_kp_count, c->slots_per_image, left0, right0, stride, pairs, fxb, max_disp, c->d_stereo, c->d_stereo_idx,
                        c->d_stereo_corr, c->d_st_row_start, c->d_st_row_list, c->st_row_cap);
     hipLaunchKernelGGL(k_stereo_median, dim3(n_pairs), dim3(1024), 0, lp_fe_stream(c), c->d_kp_count,
-                       c->slots_per_image, left0, stride, c->d_stereo, c->d_stereo_corr);
+                       c->slots_per_image, left0, stride, pairs, c->d_stereo, c->d_stereo_corr);
     LP_HIP(hipGetLastError());
     return LPSLAM_HIP_OK;
 }
@@ -385,12 +387,13 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
     return v;
 }
 
-__global__ __launch_bounds__(256) void k_proj_topk(const lpslam_hip_keypoint* __restrict__ kp, const uint8_t* __restrict__ desc,
-                                                   const float* __restrict__ stereo_xr, const int32_t* __restrict__ kp_count,
-                                                   const ProjQuery* __restrict__ queries, const uint8_t* __restrict__ q_desc,
-                                                   const int* __restrict__ q_ids, int nq, const int16_t* __restrict__ best_so_far,
-                                                   float inv_w, float inv_h, ProjGate gate, unsigned long long* __restrict__ out_keys, int* __restrict__ out_count,
-                                                   unsigned* done_counter, int* done_flag, int done_seq)
+// (a device function: launched as k_proj_topk for one call and as k_proj_topk_req, blockIdx.y = request, for the pending calls of
+// several sessions at once)
+__device__ __forceinline__ void proj_topk_body(const lpslam_hip_keypoint* __restrict__ kp, const uint8_t* __restrict__ desc,
+                                               const float* __restrict__ stereo_xr, const int32_t* __restrict__ kp_count,
+                                               const ProjQuery* __restrict__ queries, const uint8_t* __restrict__ q_desc,
+                                               const int* __restrict__ q_ids, int nq, const int16_t* __restrict__ best_so_far,
+                                               float inv_w, float inv_h, const ProjGate& gate, unsigned long long* __restrict__ out_keys, int* __restrict__ out_count)
 {
     // (out_keys / out_count may be page-locked host memory: with done_flag the kernel delivers the lists itself, lp_signal_done)
     const int lane = threadIdx.x & 63, qslot = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -485,7 +488,39 @@ __global__ __launch_bounds__(256) void k_proj_topk(const lpslam_hip_keypoint* __
         out_count[qslot] = cnt;
     }
     }
+}
+
+__global__ __launch_bounds__(256) void k_proj_topk(const lpslam_hip_keypoint* __restrict__ kp, const uint8_t* __restrict__ desc,
+                                                   const float* __restrict__ stereo_xr, const int32_t* __restrict__ kp_count,
+                                                   const ProjQuery* __restrict__ queries, const uint8_t* __restrict__ q_desc,
+                                                   const int* __restrict__ q_ids, int nq, const int16_t* __restrict__ best_so_far,
+                                                   float inv_w, float inv_h, ProjGate gate, unsigned long long* __restrict__ out_keys, int* __restrict__ out_count,
+                                                   unsigned* done_counter, int* done_flag, int done_seq)
+{
+    proj_topk_body(kp, desc, stereo_xr, kp_count, queries, q_desc, q_ids, nq, best_so_far, inv_w, inv_h, gate, out_keys, out_count);
     if (done_flag) lp_signal_done(done_counter, done_flag, done_seq);
+}
+
+// The first scan of several window-matcher calls in one launch: blockIdx.y = request, the request table in page-locked memory (the
+// combiner of share.hip writes it), every request delivers its own lists and releases its own flag.
+static_assert(sizeof(LpProjGate) == sizeof(ProjGate), "gate layout");
+__global__ __launch_bounds__(256) void k_proj_topk_req(const LpProjReq* __restrict__ table)
+{
+    const LpProjReq* r = table + blockIdx.y;
+    const int grid_x = r->grid_x;
+    if ((int)blockIdx.x >= grid_x) return;
+    const ProjGate& gate = *reinterpret_cast<const ProjGate*>(&r->gate);
+    proj_topk_body((const lpslam_hip_keypoint*)r->kp, r->desc, r->stereo_xr, r->kp_count, (const ProjQuery*)r->queries, r->q_desc, (const int*)nullptr, r->nq,
+                   r->best_so_far, r->inv_w, r->inv_h, gate, r->out_keys, r->out_count);
+    // lp_signal_done with this request's own row of workgroups as the total
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (grid_x == 1 || atomicAdd(r->done_counter, 1u) == (unsigned)grid_x - 1) {
+            if (grid_x > 1) { *r->done_counter = 0; __threadfence(); }
+            __hip_atomic_store(r->done_flag, r->done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
 extern "C" {
@@ -872,15 +907,30 @@ static int window_match(lpslam_hip_ctx* c, int image, const lpslam_hip_proj_quer
     int* done_flag = (int*)(hb + o_ids + 32);
     const int done_seq = lp_next_seq(c->done_seq);
     __atomic_store_n(done_flag, 0, __ATOMIC_RELAXED);
-    hipLaunchKernelGGL(k_proj_topk, dim3((nq + 3) / 4), dim3(256), 0, s, c->d_kpts + o, c->d_desc + o * 32, sxr, c->d_kp_count + image,
-                       on_device ? d_q : (const ProjQuery*)(hb + o_q), on_device ? d_qd : (const uint8_t*)(hb + o_qd), (const int*)nullptr, nq,
-                       on_device ? (const int16_t*)d_bsf : (taken_in ? (const int16_t*)(hb + o_bsf) : (const int16_t*)nullptr), inv_w, inv_h, gate, (unsigned long long*)(hb + o_keys), (int*)(hb + o_cnt),
-                       done_counter, done_flag, done_seq);
-    P_HIP(hipGetLastError());
+    const int16_t* first_bsf = taken_in ? (const int16_t*)(hb + o_bsf) : (const int16_t*)nullptr;
+    // several sessions tracking at once: the first scan joins the other sessions' pending scans in one launch (share.hip)
+    int shared = LP_SHARE_DIRECT;
+    {
+        LpProjReq rq{};
+        rq.kp = c->d_kpts + o; rq.desc = c->d_desc + o * 32; rq.stereo_xr = sxr; rq.kp_count = c->d_kp_count + image;
+        rq.queries = hb + o_q; rq.q_desc = hb + o_qd; rq.best_so_far = first_bsf;
+        rq.out_keys = (unsigned long long*)(hb + o_keys); rq.out_count = (int*)(hb + o_cnt); rq.done_counter = done_counter; rq.done_flag = done_flag;
+        rq.nq = nq; rq.grid_x = (nq + 3) / 4; rq.done_seq = done_seq; rq.inv_w = inv_w; rq.inv_h = inv_h;
+        rq.gate.mode = gate.mode; for (int l = 0; l < LPSLAM_HIP_MAX_LEVELS; ++l) rq.gate.inv_sigma_sq[l] = gate.inv_sigma_sq[l];
+        shared = lp_share_proj(c, rq);
+        if (shared < 0) { release(); return -shared; }
+    }
+    if (shared == LP_SHARE_DIRECT) {
+        hipLaunchKernelGGL(k_proj_topk, dim3((nq + 3) / 4), dim3(256), 0, s, c->d_kpts + o, c->d_desc + o * 32, sxr, c->d_kp_count + image,
+                           (const ProjQuery*)(hb + o_q), (const uint8_t*)(hb + o_qd), (const int*)nullptr, nq,
+                           first_bsf, inv_w, inv_h, gate, (unsigned long long*)(hb + o_keys), (int*)(hb + o_cnt),
+                           done_counter, done_flag, done_seq);
+        P_HIP(hipGetLastError());
+    }
     const unsigned long long* keys = (const unsigned long long*)(hb + o_keys);
     const int* cnt = (const int*)(hb + o_cnt);
     tr_launch = tr_us();
-    if (!lp_wait_done(done_flag, done_seq, s)) { if (lp_wait_recover(c, 1, s)) release(); set_error("window matcher: the kernel did not complete"); return LPSLAM_HIP_ERR_DEVICE; }
+    if (shared == LP_SHARE_DIRECT && !lp_wait_done(done_flag, done_seq, s)) { if (lp_wait_recover(c, 1, s)) release(); set_error("window matcher: the kernel did not complete"); return LPSLAM_HIP_ERR_DEVICE; }
     tr_wait = tr_us();
     int found = 0;
     for (int k = 0; k < nq; ++k) {
@@ -985,3 +1035,11 @@ int lpslam_hip_match_orientation_filter(const float* angle_q, const float* angle
 }
 
 }  // extern "C"
+
+int lp_launch_proj_batch(hipStream_t s, const LpProjReq* table, int n, int grid_x_max)
+{
+    if (n < 1) return LPSLAM_HIP_OK;
+    hipLaunchKernelGGL(k_proj_topk_req, dim3((unsigned)std::max(grid_x_max, 1), (unsigned)n), dim3(256), 0, s, table);
+    LP_HIP(hipGetLastError());
+    return LPSLAM_HIP_OK;
+}

@@ -36,7 +36,7 @@ SYMBOLS = [
     "lpslam_hip_match_stereo", "lpslam_hip_match_stereo_strided", "lpslam_hip_get_stereo",
     "lpslam_hip_vocab_create", "lpslam_hip_vocab_destroy", "lpslam_hip_vocab_info", "lpslam_hip_bow_transform", "lpslam_hip_bow_transform_host", "lpslam_hip_match_bow_tree", "lpslam_hip_match_bow_tree_multi",
     "lpslam_hip_match_projection", "lpslam_hip_match_fuse", "lpslam_hip_match_area", "lpslam_hip_match_orientation_filter",
-    "lpslam_hip_ba_create", "lpslam_hip_ba_prepare", "lpslam_hip_ba_build_batch", "lpslam_hip_ba_destroy", "lpslam_hip_ba_set_active", "lpslam_hip_ba_optimize", "lpslam_hip_ba_optimize_begin", "lpslam_hip_ba_optimize_end", "lpslam_hip_ba_graph_replays", "lpslam_hip_ba_wg_factorisations", "lpslam_hip_pose_optimize_passes", "lpslam_hip_match_bf_descriptors", "lpslam_hip_prefetch_frame", "lpslam_hip_get_frame_view", "lpslam_hip_desc_store_put", "lpslam_hip_desc_store_drop", "lpslam_hip_match_bf_stored", "lpslam_hip_ba_set_state_batch", "lpslam_hip_ba_get_batch", "lpslam_hip_ba_get_solver", "lpslam_hip_ba_set_solver", "lpslam_hip_ba_timeouts", "lpslam_hip_ba_counters",
+    "lpslam_hip_ba_create", "lpslam_hip_ba_prepare", "lpslam_hip_ba_build_batch", "lpslam_hip_ba_destroy", "lpslam_hip_ba_set_active", "lpslam_hip_ba_optimize", "lpslam_hip_ba_optimize_begin", "lpslam_hip_ba_optimize_end", "lpslam_hip_ba_graph_replays", "lpslam_hip_ba_wg_factorisations", "lpslam_hip_pose_optimize_passes", "lpslam_hip_match_bf_descriptors", "lpslam_hip_prefetch_frame", "lpslam_hip_get_frame_view", "lpslam_hip_desc_store_put", "lpslam_hip_desc_store_drop", "lpslam_hip_match_bf_stored", "lpslam_hip_ba_set_state_batch", "lpslam_hip_ba_get_batch", "lpslam_hip_ba_get_solver", "lpslam_hip_ba_set_solver", "lpslam_hip_ba_timeouts", "lpslam_hip_ba_counters", "lpslam_hip_set_shared_launches", "lpslam_hip_shared_launch_counters", "lpslam_hip_create_session", "lpslam_hip_front_end", "lpslam_hip_front_end_images", "lpslam_hip_shared_front_end_counters",
     "lpslam_hip_ba_optimize_batch", "lpslam_hip_ba_reset_batch", "lpslam_hip_ba_optimize_profiled", "lpslam_hip_ba_optimize_partitioned", "lpslam_hip_ba_optimize_partitioned_with",
     "lpslam_hip_ba_local", "lpslam_hip_ba_set_points_fixed", "lpslam_hip_ba_pose_optimize", "lpslam_hip_pose_optimize", "lpslam_hip_ba_reset", "lpslam_hip_ba_set_state", "lpslam_hip_prefetch_begin", "lpslam_hip_prefetch_end", "lpslam_hip_prefetch_join", "lpslam_hip_ba_get", "lpslam_hip_ba_chi2", "lpslam_hip_ba_reduced_buffer",
     "lpslam_hip_ba_step_begin", "lpslam_hip_ba_step_lambda0", "lpslam_hip_ba_step_solve", "lpslam_hip_ba_scalar_buffer", "lpslam_hip_ba_step_end", "lpslam_hip_ba_status",
@@ -101,6 +101,23 @@ def set_flat_priorities(flat):
     _check(load().lpslam_hip_set_flat_priorities(C.c_int32(-1 if flat is None else (1 if flat else 0))))
 
 
+def set_shared_launches(mode):
+    """process-wide: launches shared by the sessions of a process -- 0 never, 1 always, 2 when two or more sessions are tracking (default), None: the environment"""
+    _check(load().lpslam_hip_set_shared_launches(C.c_int32(-1 if mode is None else int(mode))))
+
+
+def shared_launch_counters(device=0):
+    b, r = C.c_int64(0), C.c_int64(0)
+    _check(load().lpslam_hip_shared_launch_counters(C.c_int32(device), C.byref(b), C.byref(r)))
+    return b.value, r.value
+
+
+def shared_front_end_counters(device=0):
+    b, r = C.c_int64(0), C.c_int64(0)
+    _check(load().lpslam_hip_shared_front_end_counters(C.c_int32(device), C.byref(b), C.byref(r)))
+    return b.value, r.value
+
+
 def device_count():
     n = C.c_int(0)
     rc = load().lpslam_hip_device_count(C.byref(n))
@@ -111,11 +128,12 @@ class Context:
     """One front-end context = one GPU, one stream, `max_images` resident image slots."""
 
     def __init__(self, width, height, max_keypoints=2000, scale_factor=1.2, num_levels=8, ini_thr=20, min_thr=7,
-                 max_images=2, device=0):
+                 max_images=2, device=0, session=False):
         self.lib = load()
         self.cfg = FrontendConfig(width, height, max_keypoints, scale_factor, num_levels, ini_thr, min_thr, max_images, device)
         h = C.c_void_p()
-        _check(self.lib.lpslam_hip_create(C.byref(self.cfg), C.byref(h)))
+        # session: a slice of the device's session pool (lpslam_hip_create_session: what a tracker plugin creates)
+        _check((self.lib.lpslam_hip_create_session if session else self.lib.lpslam_hip_create)(C.byref(self.cfg), C.byref(h)))
         self.h = h
         self.max_kp = self.lib.lpslam_hip_max_keypoints_per_image(self.h)
         L = num_levels
@@ -142,6 +160,19 @@ class Context:
 
     def sync(self):
         _check(self.lib.lpslam_hip_sync(self.h))
+
+    def front_end(self, image, stereo, fxb=0.0, baseline=0.0):
+        """extraction of the slot (pair), stereo match and delivery of the frame's results as one asynchronous call"""
+        f = self.lib.lpslam_hip_front_end
+        f.restype = C.c_int; f.argtypes = [C.c_void_p, C.c_int, C.c_int32, C.c_float, C.c_float]
+        _check(f(self.h, int(image), 1 if stereo else 0, float(fxb), float(baseline)))
+
+    def front_end_images(self, image, left, right=None, fxb=0.0, baseline=0.0):
+        """upload of the frame into the slot (pair) + front_end, as one asynchronous call"""
+        f = self.lib.lpslam_hip_front_end_images
+        f.restype = C.c_int; f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_float]
+        left = np.ascontiguousarray(left); right = None if right is None else np.ascontiguousarray(right)
+        _check(f(self.h, int(image), _p(left), None if right is None else _p(right), left.shape[1], float(fxb), float(baseline)))
 
     def set_mapping_reserve(self, cus_per_xcd):
         """compute units of every XCD the front end's kernels leave to the bundle adjustments that run beside them (idle context)"""

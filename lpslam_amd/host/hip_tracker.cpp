@@ -177,7 +177,8 @@ bool HipVslamTrackerBase::startContext(bool stereo)
     cfg.width = m_cam.resolution_x; cfg.height = m_cam.resolution_y; cfg.max_keypoints = m_slamKeypoints;
     cfg.scale_factor = (float)m_scaleFactor; cfg.num_levels = m_numLevels; cfg.ini_fast_threshold = m_iniFastThr;
     cfg.min_fast_threshold = m_minFastThr; cfg.max_images = 6; cfg.device = m_device;
-    if (lpslam_hip_create(&cfg, &m_ctx) != LPSLAM_HIP_OK) {
+    // a session of the device's pool: when several managers of a process track at once their per-frame launches are shared
+    if (lpslam_hip_create_session(&cfg, &m_ctx) != LPSLAM_HIP_OK) {
         logMessage(LpSlamLogLevel_Error, std::string("Cannot create the HIP context: ") + lpslam_hip_last_error());
         m_ctx = nullptr;
         return false;
@@ -1759,6 +1760,14 @@ void HipVslamTrackerBase::logStatistics()
 bool HipVslamTrackerBase::frontEnd(CameraQueueEntry const& cam, bool stereo, int slot)
 {
     bool ok;
+    static const bool readback_ahead_fused = std::getenv("LPSLAM_HIP_NO_PREFETCH_READBACK") == nullptr;
+    if (!m_rectify && readback_ahead_fused) {
+        // upload, extraction, stereo match and the read-back that rides behind them: ONE call, which the frames that other sessions of the
+        // process have pending join (one upload + launch chain for all of them, share.hip)
+        const float baseline = (float)(m_cam.focal_x_baseline / m_cam.f_x);
+        return lpslam_hip_front_end_images(m_ctx, slot, cam.image.pixels.data(), stereo ? cam.image_second->pixels.data() : nullptr, cam.image.width,
+                                           (float)m_cam.focal_x_baseline, baseline) == LPSLAM_HIP_OK;
+    }
     if (m_rectify) {       // raw frames: undistort + rectify on the device
         ok = lpslam_hip_upload_raw_image(m_ctx, slot, 0, cam.image.pixels.data(), cam.image.width) == LPSLAM_HIP_OK;
         if (ok && stereo) ok = lpslam_hip_upload_raw_image(m_ctx, slot + 1, 1, cam.image_second->pixels.data(), cam.image.width) == LPSLAM_HIP_OK;
@@ -1766,13 +1775,12 @@ bool HipVslamTrackerBase::frontEnd(CameraQueueEntry const& cam, bool stereo, int
         ok = lpslam_hip_upload_image(m_ctx, slot, cam.image.pixels.data(), cam.image.width) == LPSLAM_HIP_OK;
         if (ok && stereo) ok = lpslam_hip_upload_image(m_ctx, slot + 1, cam.image_second->pixels.data(), cam.image.width) == LPSLAM_HIP_OK;
     }
-    if (ok) ok = lpslam_hip_extract_range(m_ctx, slot, stereo ? 2 : 1) == LPSLAM_HIP_OK;
-    if (ok && stereo) {
-        const float baseline = (float)(m_cam.focal_x_baseline / m_cam.f_x);
-        ok = lpslam_hip_match_stereo(m_ctx, slot, slot + 1, (float)m_cam.focal_x_baseline, baseline) == LPSLAM_HIP_OK;
-    }
     static const bool readback_ahead = std::getenv("LPSLAM_HIP_NO_PREFETCH_READBACK") == nullptr;      // (development switch)
-    if (ok && readback_ahead) ok = lpslam_hip_prefetch_frame(m_ctx, slot, stereo ? 1 : 0) == LPSLAM_HIP_OK;      // the read-back rides behind the front end
+    const float baseline = (float)(m_cam.focal_x_baseline / m_cam.f_x);
+    // extraction, stereo match and the read-back that rides behind them: one call (shared with the other sessions' pending frames when there are any)
+    if (ok && readback_ahead) return lpslam_hip_front_end(m_ctx, slot, stereo ? 1 : 0, (float)m_cam.focal_x_baseline, baseline) == LPSLAM_HIP_OK;
+    if (ok) ok = lpslam_hip_extract_range(m_ctx, slot, stereo ? 2 : 1) == LPSLAM_HIP_OK;
+    if (ok && stereo) ok = lpslam_hip_match_stereo(m_ctx, slot, slot + 1, (float)m_cam.focal_x_baseline, baseline) == LPSLAM_HIP_OK;
     return ok;
 }
 

@@ -597,3 +597,50 @@ def test_prefetch_does_not_change_the_trajectory(hiplib):
         runs[prefetch] = ([(r["valid"], tuple(r["p"]), tuple(r["q"])) for r in m.results], manager.Manager.statistics(log))
     assert len(runs["true"][0]) == n_frames and runs["true"][0] == runs["false"][0]
     assert runs["true"][1]["prefetched"] == n_frames - 1 and runs["false"][1]["prefetched"] == 0
+
+
+def test_shared_launches_do_not_change_the_trajectory(hiplib):
+    """The window matchers' first scan and the pose optimiser of a tracked frame as requests of a shared launch (share.hip; forced
+    on for a lone session here) against the same calls launched by the session itself: the same device code per request, so poses
+    and outlier decisions are bit for bit the same -- alone, and with four managers sharing their launches (automatic mode), where
+    the device's counters show that batches carried more than one request."""
+    import threading
+    from lpslam_amd import _build, manager
+    _build.host_library()
+    w, h, n_frames = 640, 480, 24
+    seq = synth.StereoSequence(w, h, 4, n_points=6000)
+    frames = [seq.frame(i) for i in range(n_frames)]
+    cfg = '{"cameraSetup": "stereo", "slamKeypoints": 1000, "numLevels": 4, "keyframeInterval": 4, "asyncMapping": false}'
+
+    def run(m):
+        m.start()
+        _feed(m, frames)
+        m.stop()
+
+    def poses(m):
+        return [(r["valid"], tuple(r["p"]), tuple(r["q"])) for r in m.results]
+
+    try:
+        hiplib.set_shared_launches(0)
+        alone = _stereo_manager(manager, w, h, cfg); run(alone)
+        ref = poses(alone)
+        assert len(ref) == n_frames and sum(v for v, _, _ in ref) >= n_frames - 2
+        b0, r0 = hiplib.shared_launch_counters(0)
+        hiplib.set_shared_launches(1)
+        forced = _stereo_manager(manager, w, h, cfg); run(forced)
+        b1, r1 = hiplib.shared_launch_counters(0)
+        assert poses(forced) == ref
+        assert r1 - r0 >= 3 * (n_frames - 2) and b1 - b0 == r1 - r0          # every request went out, one per launch (nobody to share with)
+        hiplib.set_shared_launches(2)
+        four = [_stereo_manager(manager, w, h, cfg) for _ in range(4)]
+        th = [threading.Thread(target=run, args=(m,)) for m in four]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        b2, r2 = hiplib.shared_launch_counters(0)
+        for m in four:
+            assert poses(m) == ref
+        assert r2 - r1 > 0 and b2 - b1 < r2 - r1, (b2 - b1, r2 - r1)         # some launches carried several sessions' requests
+    finally:
+        hiplib.set_shared_launches(None)

@@ -16,6 +16,9 @@ if os.environ.get("WITH_BA") == "1":                 # ... after its mapping thr
     for _ in range(int(os.environ.get("WITH_BA_N", "1"))):
         _b = hip.BundleAdjuster(_c2, _p["poses"], _p["fixed"], _p["points"], hip.ba_obs_array(_p), _p["cam"]); _b.optimize(True, 3); _b.close()
     if os.environ.get("WITH_BA_CLOSE") == "1": _c2.close(); _c2 = None
+if os.environ.get("LPSLAM_DEV_BLOCKING_SYNC"):        # hipStreamSynchronize by interrupt instead of a spin (hipDeviceScheduleBlockingSync), before the runtime makes its context
+    import ctypes
+    print("hipSetDeviceFlags ->", ctypes.CDLL("libamdhip64.so").hipSetDeviceFlags(ctypes.c_uint(4)))
 if os.environ.get("LPSLAM_DEV_FLAT"): hip.set_flat_priorities(True)
 _build.host_library()
 W, H, KPTS, LEVELS, KF = 1280, 720, 2000, 8, 6
@@ -59,9 +62,14 @@ def run(n):
     for t in th: t.join()
     got = sum(mg.result_counts()[0] for mg in mgs); valid = sum(mg.result_counts()[1] for mg in mgs)
     for mg in mgs: mg.stop()
+    try:
+        st = dict(l.split() for l in open("/sys/fs/cgroup/cpu.stat"))
+        print("   cpu.stat: usage %.2f s, throttled %d periods / %.3f s" % (int(st["usage_usec"]) * 1e-6, int(st["nr_throttled"]), int(st["throttled_usec"]) * 1e-6))
+    except Exception:
+        pass
     if os.environ.get("LPSLAM_DEV_STATS"):
-        st = [manager.Manager.statistics(mg._log) for mg in mgs]
-        keys = ("ms_per_frame", "ms_track", "ms_local_map", "ms_keyframe", "ms_dev_match", "ms_dev_pose", "ms_dev_get", "ms_prefetch_wait", "ms_prefetch_busy", "ms_kf_wait", "ms_map_solve")
+        st = [mg.tracker_statistics() for mg in mgs]      # (each manager's own line: the log file is process-wide)
+        keys = ("ms_per_frame", "ms_front_end", "ms_track", "ms_local_map", "ms_keyframe", "ms_dev_extract", "ms_dev_match", "ms_dev_pose", "ms_dev_get", "ms_prefetch_wait", "ms_prefetch_busy", "ms_kf_wait", "ms_kf_insert", "ms_kf_prepare", "ms_map_solve", "prefetched")
         print("   per-manager statistics (mean over %d managers): " % n + ", ".join("%s %.3f" % (k, sum(x.get(k, 0) for x in st) / len(st)) for k in keys))
     return got, valid, dt
 
