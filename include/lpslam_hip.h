@@ -113,6 +113,7 @@ int lpslam_hip_front_end(lpslam_hip_ctx* ctx, int image, int32_t stereo, float f
 int lpslam_hip_front_end_images(lpslam_hip_ctx* ctx, int image, const uint8_t* left, const uint8_t* right, int32_t stride,
                                 float focal_x_baseline, float baseline);
 int lpslam_hip_shared_front_end_counters(int32_t device, int64_t* batches, int64_t* requests);
+int lpslam_hip_shared_solve_counters(int32_t device, int64_t* batches, int64_t* requests);
 int lpslam_hip_sync(lpslam_hip_ctx* ctx);
 /* Geometry derived from the configuration (pyramid sizes, per-level keypoint quota). */
 int lpslam_hip_level_info(lpslam_hip_ctx* ctx, int32_t* widths, int32_t* heights, int32_t* pitches,
@@ -384,6 +385,13 @@ int lpslam_hip_pose_optimize(lpslam_hip_ctx* ctx, double* pose7, const double* p
 int32_t lpslam_hip_pose_optimize_passes(lpslam_hip_ctx* ctx);
 /* local_bundle_adjuster flow: first_iters robust, outlier classification, second_iters plain. */
 int lpslam_hip_ba_local(lpslam_hip_ba* ba, int32_t first_iters, int32_t second_iters, uint8_t* outlier);
+/* A keyframe's local bundle adjustment in ONE call ([UPSTREAM] mapping_module -> optimize::local_bundle_adjuster::optimize, started per
+ * keyframe by the mapping thread of startup(), src/Trackers/OpenVSLAMTrackerBase.cpp:239): lpslam_hip_ba_create of the window,
+ * lpslam_hip_ba_local, lpslam_hip_ba_get into `poses` / `points` (in: the window's state, out: the solved one), destroy.  When several
+ * sessions' mapping threads call it at the same time (shared launches on), their windows are built and solved together. */
+int lpslam_hip_ba_local_window(lpslam_hip_ctx* ctx, double* poses, const uint8_t* fixed, int32_t n_poses, double* points, int32_t n_points,
+                               const lpslam_hip_ba_obs* obs, int32_t n_obs, const lpslam_hip_ba_camera* cam, int32_t first_iters,
+                               int32_t second_iters, uint8_t* outlier);
 /* Restores the poses / points / activity mask given at creation (kept in HBM) and clears the LM state. */
 int lpslam_hip_ba_reset(lpslam_hip_ba* ba);
 /* Replaces the creation-time poses (n_poses x 7) and / or landmarks (n_points x 3) of an existing problem (NULL keeps them) and

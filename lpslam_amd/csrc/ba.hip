@@ -2468,6 +2468,7 @@ struct lpslam_hip_ba {
     int band_hbw_structure = -1;                       // block half-bandwidth of the window when the band path can take it (creation), else -1
     int band_gmax = 0;                                 // landmarks per group at most (LDS of k_schur_group)
     int faults_band = 0, faults_update = 0;            // timed-out hand-overs seen so far (report_faults)
+    bool quiesced = false;                             // everything enqueued for this problem is known to be complete (a shared batch waited for it): destroy need not wait for its stream again
     bool built = false;                                // the structure build has been enqueued (lpslam_hip_ba_build_batch); prepare alone leaves the block untouched
     void* build_desc = nullptr;                        // BuildDesc of this problem (host copy), ba_build.inl
     size_t o_descs = 0;                                // offset of the descriptor array (device: in the block; host: in the staging block)
@@ -3095,7 +3096,7 @@ int lpslam_hip_ba_create(lpslam_hip_ctx* ctx, const double* poses, const uint8_t
 void lpslam_hip_ba_destroy(lpslam_hip_ba* b)
 {
     if (!b) return;
-    if (b->stream) (void)hipStreamSynchronize(b->stream);
+    if (b->stream && !b->quiesced) (void)hipStreamSynchronize(b->stream);
     if (b->block) lp_pool_free(b->ctx, b->block, b->block_cap);
     release_stage(b);
     if (b->pin) lp_pin_free(b->ctx, b->pin);
@@ -3889,6 +3890,78 @@ int lpslam_hip_ba_local(lpslam_hip_ba* b, int32_t first_iters, int32_t second_it
     if ((rc = lpslam_hip_ba_chi2(b, chi.data(), pos.data()))) return rc;
     if (outlier) for (int k = 0; k < n; ++k) { const double thr = b->h_ur[k] < 0 ? 5.99146 : 7.81473; outlier[k] = (!active[k]) || (thr < chi[k]) || !pos[k]; }
     return LPSLAM_HIP_OK;
+}
+
+}  // extern "C"
+
+// lpslam_hip_ba_local for n prepared (not yet built) windows at once: ONE structure build, the two optimisations as batched launch
+// chains (blockIdx.y = window), the per-observation chi2 passes and activity masks of all windows between them with one wait each.
+// What the mapping threads of several sessions submit together (share.hip); the arithmetic per window is that of the single call.
+int lp_ba_local_batch(lpslam_hip_ba* const* ps, int n, int first_iters, int second_iters, uint8_t* const* outliers, double* const* poses_out, double* const* points_out)
+{
+    int rc = lpslam_hip_ba_build_batch(ps, n); if (rc) return rc;
+    hipStream_t s = ps[0]->stream;
+    for (int i = 1; i < n; ++i) if (ps[i]->stream != s) { set_error("a shared batch of windows needs them on one stream"); return LPSLAM_HIP_ERR_INVALID; }
+    std::vector<std::vector<double>> chi((size_t)n);
+    std::vector<std::vector<uint8_t>> pos((size_t)n), active((size_t)n);
+    auto chi2_all = [&]() -> int {
+        for (int i = 0; i < n; ++i) {
+            lpslam_hip_ba* b = ps[i];
+            const size_t no = (size_t)std::max(b->n_obs, 1);
+            chi[(size_t)i].resize(no); pos[(size_t)i].resize(no);
+            if (!b->n_obs) continue;
+            hipLaunchKernelGGL(k_ba_obs_chi2, dim3((b->n_obs + 255) / 256, 1), dim3(256), 0, s, b->d_view, b->d_chi_obs, b->d_depth);
+            LP_HIP(hipGetLastError());
+            LP_HIP(hipMemcpyAsync(chi[(size_t)i].data(), b->d_chi_obs, (size_t)b->n_obs * sizeof(double), hipMemcpyDeviceToHost, s));
+            LP_HIP(hipMemcpyAsync(pos[(size_t)i].data(), b->d_depth, (size_t)b->n_obs, hipMemcpyDeviceToHost, s));
+        }
+        LP_HIP(hipStreamSynchronize(s));
+        return LPSLAM_HIP_OK;
+    };
+    if ((rc = lpslam_hip_ba_optimize_batch(ps, n, 1, first_iters, nullptr, 0, nullptr))) return rc;
+    if ((rc = chi2_all())) return rc;
+    for (int i = 0; i < n; ++i) {
+        lpslam_hip_ba* b = ps[i];
+        active[(size_t)i].assign((size_t)std::max(b->n_obs, 1), 1);
+        for (int k = 0; k < b->n_obs; ++k) { const double thr = b->h_ur[(size_t)k] < 0 ? 5.99146 : 7.81473; if (thr < chi[(size_t)i][(size_t)k] || !pos[(size_t)i][(size_t)k]) active[(size_t)i][(size_t)k] = 0; }
+        if (!b->n_obs) continue;
+        LP_HIP(hipMemcpyAsync(b->d_act_in, active[(size_t)i].data(), (size_t)b->n_obs, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_ba_gather_active, dim3((b->n_obs + 255) / 256), dim3(256), 0, s, b->d_act_in, b->d_o_orig, b->d_o_active, b->n_obs);
+        LP_HIP(hipGetLastError());
+    }
+    if ((rc = lpslam_hip_ba_optimize_batch(ps, n, 0, second_iters, nullptr, 0, nullptr))) return rc;
+    if ((rc = chi2_all())) return rc;
+    for (int i = 0; i < n; ++i) {
+        lpslam_hip_ba* b = ps[i];
+        if (outliers && outliers[i]) for (int k = 0; k < b->n_obs; ++k) { const double thr = b->h_ur[(size_t)k] < 0 ? 5.99146 : 7.81473; outliers[i][k] = (!active[(size_t)i][(size_t)k]) || (thr < chi[(size_t)i][(size_t)k]) || !pos[(size_t)i][(size_t)k]; }
+    }
+    if ((rc = lpslam_hip_ba_get_batch(ps, n, poses_out, points_out))) return rc;
+    for (int i = 0; i < n; ++i) { release_stage(ps[i]); ps[i]->quiesced = true; }
+    return LPSLAM_HIP_OK;
+}
+
+extern "C" {
+
+// A keyframe's local bundle adjustment as ONE call: the window is created from the caller's arrays, solved (lpslam_hip_ba_local:
+// first_iters with the robust kernel, outlier classification, second_iters without), its state read back into `poses` / `points` and
+// destroyed -- what a mapping thread does per keyframe.  With several sessions submitting windows at the same time (shared launches on)
+// the windows are built and solved together by one of the calling threads.
+int lpslam_hip_ba_local_window(lpslam_hip_ctx* ctx, double* poses, const uint8_t* fixed, int32_t n_poses, double* points, int32_t n_points,
+                               const lpslam_hip_ba_obs* obs, int32_t n_obs, const lpslam_hip_ba_camera* cam, int32_t first_iters, int32_t second_iters, uint8_t* outlier)
+{
+    lpslam_hip_ba* b = nullptr;
+    int rc = lpslam_hip_ba_prepare(ctx, poses, fixed, n_poses, points, n_points, obs, n_obs, cam, &b);
+    if (rc) return rc;
+    const int shared = (ctx->role_solve && b->stream == ctx->role_solve) ? lp_share_ba_local(ctx, b, first_iters, second_iters, outlier, poses, points) : LP_SHARE_DIRECT;
+    if (shared < 0) rc = -shared;
+    else if (shared == LP_SHARE_DIRECT) {
+        lpslam_hip_ba* one[1] = {b};
+        rc = lpslam_hip_ba_build_batch(one, 1);
+        if (!rc) rc = lpslam_hip_ba_local(b, first_iters, second_iters, outlier);
+        if (!rc) rc = lpslam_hip_ba_get(b, poses, points);
+    }
+    lpslam_hip_ba_destroy(b);
+    return rc;
 }
 
 }  // extern "C"

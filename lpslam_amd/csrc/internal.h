@@ -247,6 +247,11 @@ void lp_share_forget(lpslam_hip_ctx* c);                // the context is being 
 // sessions of a pool own NO stream: whatever they enqueue goes to the role stream of its kind, so N sessions keep four hardware queues
 // busy, not 3 N streams spread over them at the runtime's discretion (a latency-bound launch behind another session's chain on the same
 // queue waited for all of it).  false: the streams could not be made.
+// A window's local bundle adjustment as a request (lpslam_hip_ba_local_window): the windows that several sessions' mapping threads have
+// pending are built and solved together (lp_ba_local_batch, ba.hip) by one of those threads, on the solves' role stream.
+struct lpslam_hip_ba;
+int lp_share_ba_local(lpslam_hip_ctx* c, lpslam_hip_ba* b, int first_iters, int second_iters, uint8_t* outlier, double* poses, double* points);
+int lp_ba_local_batch(lpslam_hip_ba* const* ps, int n, int first_iters, int second_iters, uint8_t* const* outliers, double* const* poses_out, double* const* points_out);
 enum { LP_ROLE_POSE = 0, LP_ROLE_MAIN = 1, LP_ROLE_FRONT = 2, LP_ROLE_SOLVE = 3 };
 bool lp_share_role_streams(int device, hipStream_t out[4]);
 // One frame's front end (extraction of 1 or 2 slots, stereo match, delivery into the session's page-locked block) as a request: the

@@ -24,6 +24,7 @@ struct Ticket {                                         // lives in the caller's
 };
 struct PendingPose { LpPoseReq req; Ticket* t; };
 struct PendingProj { LpProjReq req; Ticket* t; };
+struct PendingSolve { lpslam_hip_ba* b; int first, second; uint8_t* outlier; double* poses; double* points; std::atomic<int>* state; int* rc; };
 struct PendingFront { lpslam_hip_ctx* c; int slot, stereo; float fxb, baseline; const uint8_t* staged[2]; LpDeliverReq deliver; Ticket* t; };      // staged: the frame in the session's page-locked buffers (the chain uploads it), or null (the session enqueued its uploads itself)
 
 constexpr int kMaxDevices = 16, kMaxSessions = 256, kTableBlocks = 32, kTableEntries = 64;
@@ -54,7 +55,14 @@ struct Share {
     std::atomic<int64_t> fe_last_ns[kMaxSessions];      // per session: its last front-end request
     std::atomic<long> batches{0}, requests{0};          // statistics (lpslam_hip_shared_launch_counters)
     std::atomic<long> fe_batches{0}, fe_requests{0};
-    Share() { for (auto& x : last_ns) x.store(0); for (auto& x : fe_last_ns) x.store(0); for (auto& x : table_users) x.store(0); }
+    // windows: solved by one of the submitting mapping threads at a time (the flow has host steps between its launch chains)
+    std::mutex solver;
+    std::vector<PendingSolve> solves;
+    int64_t solve_oldest_ns = 0, solve_newest_ns = 0;
+    std::atomic<int> solve_in_flight{0};
+    std::atomic<int64_t> solve_last_ns[kMaxSessions];
+    std::atomic<long> solve_batches{0}, solve_requests{0};
+    Share() { for (auto& x : last_ns) x.store(0); for (auto& x : fe_last_ns) x.store(0); for (auto& x : solve_last_ns) x.store(0); for (auto& x : table_users) x.store(0); }
 };
 Share g_share[kMaxDevices];
 
@@ -353,6 +361,60 @@ void combine_front(Share& sh)
 
 }  // namespace
 
+int lp_share_ba_local(lpslam_hip_ctx* c, lpslam_hip_ba* b, int first_iters, int second_iters, uint8_t* outlier, double* poses, double* points)
+{
+    if (share_mode() == 0 || !c || c->cfg.device < 0 || c->cfg.device >= kMaxDevices) return LP_SHARE_DIRECT;
+    Share& sh = g_share[c->cfg.device];
+    int64_t now = now_ns();
+    if (!touch_session(sh, c, now)) return LP_SHARE_DIRECT;
+    sh.solve_last_ns[c->share_slot].store(now, std::memory_order_relaxed);
+    std::atomic<int> state{T_PENDING};
+    int rc = LPSLAM_HIP_OK;
+    {
+        std::lock_guard<std::mutex> lock(sh.m);
+        if (sh.solves.empty()) sh.solve_oldest_ns = now;
+        sh.solve_newest_ns = now;
+        sh.solves.push_back(PendingSolve{b, first_iters, second_iters, outlier, poses, points, &state, &rc});
+    }
+    static const int64_t quiet = 1000ll * env_us("LPSLAM_HIP_SHARE_SOLVE_QUIET_US", 40), window = 1000ll * env_us("LPSLAM_HIP_SHARE_SOLVE_WINDOW_US", 200), active_for = 30000000ll;
+    for (;;) {
+        if (state.load(std::memory_order_acquire) != T_PENDING) break;
+        if (sh.solver.try_lock()) {
+            // the solver: whatever is pending when the previous batch is through (it ran under this lock) goes together; on an idle stream a
+            // short gather for the other sessions' mapping threads (keyframes of sessions in step come together)
+            std::vector<PendingSolve> take;
+            while (state.load(std::memory_order_acquire) == T_PENDING && take.empty()) {
+                now = now_ns();
+                std::lock_guard<std::mutex> lock(sh.m);
+                int active = 0;
+                const int hi = sh.n_sessions.load(std::memory_order_relaxed);
+                for (int i = 0; i < hi; ++i) { const int64_t t = sh.solve_last_ns[i].load(std::memory_order_relaxed); if (t && now - t < active_for) ++active; }
+                if ((int)sh.solves.size() >= std::max(1, active) || now - sh.solve_newest_ns >= quiet || now - sh.solve_oldest_ns >= window) {
+                    // (windows with the same iteration counts: every tracker's are)
+                    for (size_t i = 0; i < sh.solves.size();) {
+                        if (sh.solves[i].first == first_iters && sh.solves[i].second == second_iters && take.size() < 64) { take.push_back(sh.solves[i]); sh.solves.erase(sh.solves.begin() + (long)i); }
+                        else ++i;
+                    }
+                    if (!sh.solves.empty()) sh.solve_oldest_ns = sh.solve_newest_ns = now;
+                }
+            }
+            if (!take.empty()) {
+                std::vector<lpslam_hip_ba*> ps; std::vector<uint8_t*> outs; std::vector<double*> po, pt;
+                for (auto& t : take) { ps.push_back(t.b); outs.push_back(t.outlier); po.push_back(t.poses); pt.push_back(t.points); }
+                const int brc = lp_ba_local_batch(ps.data(), (int)ps.size(), first_iters, second_iters, outs.data(), po.data(), pt.data());
+                if (share_trace()) fprintf(stderr, "share %.3f solve %d (rc %d)\n", 1e-6 * (double)(now_ns() % 100000000000ll), (int)take.size(), brc);
+                sh.solve_batches.fetch_add(1); sh.solve_requests.fetch_add((long)take.size());
+                for (auto& t : take) { *t.rc = brc; t.state->store(brc == LPSLAM_HIP_OK ? T_LAUNCHED : T_FAILED, std::memory_order_release); }
+            }
+            sh.solver.unlock();
+            continue;
+        }
+        const struct timespec ts{0, 20000};
+        (void)nanosleep(&ts, nullptr);                    // a mapping thread is in no hurry: it sleeps while another one solves its window
+    }
+    return rc == LPSLAM_HIP_OK ? LP_SHARE_DONE : -rc;
+}
+
 bool lp_share_role_streams(int device, hipStream_t out[4])
 {
     if (device < 0 || device >= kMaxDevices) return false;
@@ -465,6 +527,14 @@ int lpslam_hip_shared_launch_counters(int32_t device, int64_t* batches, int64_t*
     if (device < 0 || device >= kMaxDevices) { set_error("device %d out of range", device); return LPSLAM_HIP_ERR_INVALID; }
     if (batches) *batches = g_share[device].batches.load();
     if (requests) *requests = g_share[device].requests.load();
+    return LPSLAM_HIP_OK;
+}
+
+int lpslam_hip_shared_solve_counters(int32_t device, int64_t* batches, int64_t* requests)
+{
+    if (device < 0 || device >= kMaxDevices) { set_error("device %d out of range", device); return LPSLAM_HIP_ERR_INVALID; }
+    if (batches) *batches = g_share[device].solve_batches.load();
+    if (requests) *requests = g_share[device].solve_requests.load();
     return LPSLAM_HIP_OK;
 }
 

@@ -1016,6 +1016,13 @@ void HipVslamTrackerBase::solveMapping(MappingJob& job) const
 {
     lpslam_hip_ba_camera cam{m_cam.f_x, m_cam.f_y, m_cam.c_x, m_cam.c_y, m_stereo ? m_cam.focal_x_baseline : 0.0, std::sqrt(5.991), std::sqrt(7.815)};
     lpslam_hip_ba* ba = nullptr;
+    if (!job.global) {
+        // the keyframe's window: created, solved (5 robust + 10 plain iterations around the outlier classification), read back and destroyed
+        // by one call -- which the windows of the other sessions' mapping threads join (one launch chain for all of them)
+        job.solved = lpslam_hip_ba_local_window(m_ctx, job.poses.data(), job.fixed.data(), (int32_t)job.kfs.size(), job.pts.data(), (int32_t)job.ids.size(), job.obs.data(),
+                                                (int32_t)job.obs.size(), &cam, 5, 10, job.outlier.data()) == LPSLAM_HIP_OK;
+        return;
+    }
     if (lpslam_hip_ba_create(m_ctx, job.poses.data(), job.fixed.data(), (int32_t)job.kfs.size(), job.pts.data(), (int32_t)job.ids.size(), job.obs.data(),
                              (int32_t)job.obs.size(), &cam, &ba) != LPSLAM_HIP_OK) return;
     if (job.global) {
