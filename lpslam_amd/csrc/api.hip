@@ -24,9 +24,12 @@ void set_error(const char* fmt, ...)
 }
 
 }  // namespace lpslam
+std::atomic<int> g_lp_live_contexts{0};               // contexts of the process (every one of them may have threads polling)
 void lp_poll_sleep()
 {
-    static const long sleep_ns = [] { const char* e = getenv("LPSLAM_HIP_POLL_SLEEP_US"); return 1000l * (e ? std::max(atoi(e), 0) : 5); }();
+    // 5 us between looks; 20 us once more contexts are alive than a 16-CPU quota carries polling threads for (16 managers: 5.4 k -> 6.0 k frames/s)
+    static const long sleep_env = [] { const char* e = getenv("LPSLAM_HIP_POLL_SLEEP_US"); return e ? 1000l * std::max(atoi(e), 0) : -1l; }();
+    const long sleep_ns = sleep_env >= 0 ? sleep_env : (g_lp_live_contexts.load(std::memory_order_relaxed) > 10 ? 20000l : 5000l);
     if (sleep_ns <= 0) { sched_yield(); return; }
     static thread_local bool slack_set = false;
     if (!slack_set) { (void)prctl(PR_SET_TIMERSLACK, 1000ul, 0ul, 0ul, 0ul); slack_set = true; }      // (the default slack of 50 us would turn a 5 us sleep into 55)
@@ -150,8 +153,10 @@ size_t lp_pool_flush_locked(lpslam_hip_ctx* c)        // c->pool_mutex held
     return freed;
 }
 }
+extern std::atomic<int> g_lp_live_contexts;
 void lp_ctx_register(lpslam_hip_ctx* c, bool add)
 {
+    g_lp_live_contexts.fetch_add(add ? 1 : -1);
     std::lock_guard<std::mutex> lock(g_ctx_mutex);
     if (add) g_contexts.push_back(c);
     else g_contexts.erase(std::remove(g_contexts.begin(), g_contexts.end(), c), g_contexts.end());
@@ -597,6 +602,7 @@ void lpslam_hip_destroy(lpslam_hip_ctx* c)
         c->d_stereo_idx = nullptr; c->d_stereo_corr = nullptr; c->d_st_row_start = nullptr; c->d_st_row_list = nullptr;
     }
     if (c->ev_fe_ready) (void)hipEventDestroy(c->ev_fe_ready);
+    if (c->up_stream) { (void)hipStreamSynchronize(c->up_stream); (void)hipStreamDestroy(c->up_stream); }
     void* bufs[] = {c->d_pyr, c->d_band_rows, c->d_rs_pack, c->d_cell_keys, c->d_cell_count, c->d_cand_key, c->d_cand_node,
                     c->d_cand_count, c->d_sel_key, c->d_sel_count, c->d_kpts, c->d_desc,
                     c->d_kp_count, c->d_bf, c->d_stereo, c->d_stereo_idx, c->d_stereo_corr, c->d_st_row_start, c->d_st_row_list, c->d_tmp_desc, c->d_tmp_res,
@@ -824,6 +830,32 @@ static const uint8_t* stage_upload(lpslam_hip_ctx* c, int image, const uint8_t* 
     return buf;
 }
 
+}  // extern "C"
+
+// where a context's frame uploads go: its front-end stream, or -- a session on the role streams -- a copy-only stream of its own
+static hipStream_t lp_upload_stream(lpslam_hip_ctx* c)
+{
+    if (c->owns_streams) return lp_fe_stream(c);
+    if (!c->up_stream) {
+        if (hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); c->up_stream = nullptr; return lp_fe_stream(c); }
+        c->up_pending.assign((size_t)c->cfg.max_images, 0);
+    }
+    return c->up_stream;
+}
+// stream `s` of the context waits (on the device) for the uploads of slots [first, first + n) that went through the copy-only stream
+int lp_wait_own_uploads(lpslam_hip_ctx* c, int first, int n, hipStream_t s)
+{
+    if (c->up_pending.empty()) return LPSLAM_HIP_OK;
+    for (int i = first; i < first + n && (size_t)i < c->up_pending.size(); ++i) {
+        if (!c->up_pending[(size_t)i]) continue;
+        c->up_pending[(size_t)i] = 0;
+        LP_HIP(hipStreamWaitEvent(s, c->ev_upload[(size_t)i], 0));
+    }
+    return LPSLAM_HIP_OK;
+}
+
+extern "C" {
+
 int lpslam_hip_upload_image(lpslam_hip_ctx* c, int image, const uint8_t* host, int32_t stride)
 {
     int rc = check_image(c, image); if (rc) return rc;
@@ -838,9 +870,11 @@ int lpslam_hip_upload_image(lpslam_hip_ctx* c, int image, const uint8_t* host, i
     }
     const uint8_t* src = stage_upload(c, image, host, stride);
     if (!src) return LPSLAM_HIP_ERR_DEVICE;
-    LP_HIP(hipMemcpy2DAsync(c->d_pyr + (size_t)image * c->image_slab, c->lt.pitch[0], src, c->lt.w[0], c->lt.w[0], c->lt.h[0],
-                            hipMemcpyHostToDevice, lp_fe_stream(c)));
-    LP_HIP(hipEventRecord(c->ev_upload[(size_t)image], lp_fe_stream(c)));
+    hipStream_t us = lp_upload_stream(c);
+    if ((size_t)c->lt.pitch[0] == (size_t)c->lt.w[0]) LP_HIP(hipMemcpyAsync(c->d_pyr + (size_t)image * c->image_slab, src, (size_t)c->lt.w[0] * c->lt.h[0], hipMemcpyHostToDevice, us));
+    else LP_HIP(hipMemcpy2DAsync(c->d_pyr + (size_t)image * c->image_slab, c->lt.pitch[0], src, c->lt.w[0], c->lt.w[0], c->lt.h[0], hipMemcpyHostToDevice, us));
+    LP_HIP(hipEventRecord(c->ev_upload[(size_t)image], us));
+    if (us == c->up_stream && (size_t)image < c->up_pending.size()) c->up_pending[(size_t)image] = 1;
     return LPSLAM_HIP_OK;
 }
 
@@ -1012,6 +1046,7 @@ int lpslam_hip_extract_range(lpslam_hip_ctx* c, int first, int n)
 {
     int rc = check_range(c, first, n); if (rc) return rc;
     if ((rc = lp_wait_uploads(c, first, n))) return rc;
+    if ((rc = lp_wait_own_uploads(c, first, n, lp_fe_stream(c)))) return rc;
     if ((rc = lp_launch_pyramid(c, first, n))) return rc;
     if ((rc = lp_launch_fast(c, first, n))) return rc;
     if ((rc = lp_launch_distribute(c, first, n))) return rc;
@@ -1248,8 +1283,7 @@ int lpslam_hip_front_end(lpslam_hip_ctx* c, int image, int32_t stereo, float fxb
     return lpslam_hip_prefetch_frame(c, image, stereo ? 1 : 0);
 }
 
-// lpslam_hip_front_end with the frame itself: upload of the slot (stereo: the pair) + front end.  A shared front end uploads at the head
-// of its chain, on the chain's stream: a session then keeps no stream of its own busy per frame.
+// lpslam_hip_front_end with the frame itself: upload of the slot (stereo: the pair) + front end.
 int lpslam_hip_front_end_images(lpslam_hip_ctx* c, int image, const uint8_t* left, const uint8_t* right, int32_t stride, float fxb, float baseline)
 {
     int rc = check_image(c, image); if (rc) return rc;
@@ -1258,21 +1292,14 @@ int lpslam_hip_front_end_images(lpslam_hip_ctx* c, int image, const uint8_t* lef
     if (!left || stride < c->lt.w[0]) { set_error("bad host image (stride %d < width %d)", stride, c->lt.w[0]); return LPSLAM_HIP_ERR_INVALID; }
     if (stereo && (!(baseline > 0.f) || !(fxb > 0.f))) { set_error("focal_x_baseline and baseline must be positive"); return LPSLAM_HIP_ERR_INVALID; }
     LP_HIP(hipSetDevice(c->cfg.device));
-    if (c->cfg.max_images <= 8) {        // (a context with page-locked staging per slot: what a session is)
-        const uint8_t* sl = stage_upload(c, image, left, stride);
-        const uint8_t* sr = stereo ? stage_upload(c, image + 1, right, stride) : nullptr;
-        if (!sl || (stereo && !sr)) return LPSLAM_HIP_ERR_DEVICE;
-        const int shared = lp_share_front_end(c, image, stereo ? 1 : 0, fxb, baseline, sl, sr);
-        if (shared < 0) return -shared;
-        if (shared == LP_SHARE_DONE) return LPSLAM_HIP_OK;
-        for (int e = 0; e < (stereo ? 2 : 1); ++e) {
-            LP_HIP(hipMemcpy2DAsync(c->d_pyr + (size_t)(image + e) * c->image_slab, c->lt.pitch[0], e ? sr : sl, c->lt.w[0], c->lt.w[0], c->lt.h[0], hipMemcpyHostToDevice, lp_fe_stream(c)));
-            LP_HIP(hipEventRecord(c->ev_upload[(size_t)(image + e)], lp_fe_stream(c)));
-        }
-    } else {
-        if ((rc = lpslam_hip_upload_image(c, image, left, stride))) return rc;
-        if (stereo && (rc = lpslam_hip_upload_image(c, image + 1, right, stride))) return rc;
-    }
+    // the uploads are enqueued at once, by the calling thread, on the context's front-end stream -- for a session that joined a pool that
+    // IS the front-end role stream the shared chain will run on: the copies of the sessions' frames proceed while the gather waits for the
+    // last session, and the chain's kernels queue behind them
+    if ((rc = lpslam_hip_upload_image(c, image, left, stride))) return rc;
+    if (stereo && (rc = lpslam_hip_upload_image(c, image + 1, right, stride))) return rc;
+    const int shared = lp_share_front_end(c, image, stereo ? 1 : 0, fxb, baseline);
+    if (shared < 0) return -shared;
+    if (shared == LP_SHARE_DONE) return LPSLAM_HIP_OK;
     if ((rc = lpslam_hip_extract_range(c, image, stereo ? 2 : 1))) return rc;
     if (stereo && (rc = lpslam_hip_match_stereo(c, image, image + 1, fxb, baseline))) return rc;
     return lpslam_hip_prefetch_frame(c, image, stereo ? 1 : 0);

@@ -139,6 +139,10 @@ struct lpslam_hip_ctx {
     std::vector<std::pair<size_t, void*>> pin_big;   // idle page-locked staging blocks (capacity, block) of lp_pin_big_alloc / free
     uint8_t* h_match = nullptr;        // pinned host staging of the window matchers (queries in, candidate lists out)
     size_t h_match_bytes = 0;
+    // A session on the role streams uploads its frames on a stream of ITS OWN that carries copies and their events only: the sessions'
+    // copies run side by side on the copy engines and beside the chains on the front-end stream (16 images one after the other on one
+    // stream: 0.41 ms, as long as their extraction), and what such a stream can hold up on a hardware queue it shares is bounded by a copy.
+    hipStream_t up_stream = nullptr; std::vector<uint8_t> up_pending;      // per image slot: uploaded on up_stream, not yet waited for by the front-end stream
     bool owns_streams = true;          // false: a session of a pool -- stream / fe_stream / the solves' stream are the device's role streams (share.hip)
     hipStream_t role_solve = nullptr;  // session: the role stream its bundle adjustments run on
     int share_slot = -1;               // this context's entry in its device's session table (share.hip), -1: never shared
@@ -257,8 +261,9 @@ bool lp_share_role_streams(int device, hipStream_t out[4]);
 // One frame's front end (extraction of 1 or 2 slots, stereo match, delivery into the session's page-locked block) as a request: the
 // frames that several sessions have pending go through ONE launch chain on their pool's stream.  DONE: enqueued; DIRECT: not shared.
 struct LpDeliverReq { const int* d_count; const uint32_t* kp; const uint32_t* desc; const uint32_t* xr; const uint32_t* dep; uint32_t* st; unsigned* counter; int* flag; int seq, blocks; };
-int lp_share_front_end(lpslam_hip_ctx* c, int slot, int stereo, float fxb, float baseline, const uint8_t* staged_left = nullptr, const uint8_t* staged_right = nullptr);      // staged_*: the frame in the session's page-locked upload buffers -- the chain copies it up itself
+int lp_share_front_end(lpslam_hip_ctx* c, int slot, int stereo, float fxb, float baseline);
 void lp_share_front_end_collected(lpslam_hip_ctx* c);   // the session has its frame (or gave up on it)
+int lp_wait_own_uploads(lpslam_hip_ctx* c, int first, int n, hipStream_t s);      // api.hip
 int lp_prepare_delivery(lpslam_hip_ctx* c, int image, int with_stereo, LpDeliverReq* out);      // api.hip: what lpslam_hip_prefetch_frame sets up, without the launch
 void lp_commit_delivery(lpslam_hip_ctx* c, int image, int with_stereo, const LpDeliverReq& r, hipStream_t s);
 int lp_launch_deliver_batch(hipStream_t s, const LpDeliverReq* reqs, int n, int slots_per_image, const lpslam_hip_ctx* layout);

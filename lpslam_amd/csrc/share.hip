@@ -25,7 +25,7 @@ struct Ticket {                                         // lives in the caller's
 struct PendingPose { LpPoseReq req; Ticket* t; };
 struct PendingProj { LpProjReq req; Ticket* t; };
 struct PendingSolve { lpslam_hip_ba* b; int first, second; uint8_t* outlier; double* poses; double* points; std::atomic<int>* state; int* rc; };
-struct PendingFront { lpslam_hip_ctx* c; int slot, stereo; float fxb, baseline; const uint8_t* staged[2]; LpDeliverReq deliver; Ticket* t; };      // staged: the frame in the session's page-locked buffers (the chain uploads it), or null (the session enqueued its uploads itself)
+struct PendingFront { lpslam_hip_ctx* c; int slot, stereo; float fxb, baseline; hipStream_t own; LpDeliverReq deliver; Ticket* t; };      // own: the stream the session enqueued its uploads on
 
 constexpr int kMaxDevices = 16, kMaxSessions = 256, kTableBlocks = 32, kTableEntries = 64;
 
@@ -52,6 +52,7 @@ struct Share {
     std::vector<PendingFront> front;
     int64_t fe_oldest_ns = 0, fe_newest_ns = 0;
     std::atomic<int> fe_in_flight{0};                   // sessions whose shared front end has been launched and not collected
+    hipEvent_t ev_fe_chain = nullptr; bool fe_chain_in_flight = false;      // behind the last chain on the front-end stream (combiner_fe held)
     std::atomic<int64_t> fe_last_ns[kMaxSessions];      // per session: its last front-end request
     std::atomic<long> batches{0}, requests{0};          // statistics (lpslam_hip_shared_launch_counters)
     std::atomic<long> fe_batches{0}, fe_requests{0};
@@ -76,8 +77,10 @@ int share_mode()
 }
 int env_us(const char* name, int dflt) { const char* e = getenv(name); return e ? std::max(atoi(e), 0) : dflt; }
 int64_t window_ns() { static const int64_t v = 1000ll * env_us("LPSLAM_HIP_SHARE_WINDOW_US", 30); return v; }
-int64_t quiet_ns() { static const int64_t v = 1000ll * env_us("LPSLAM_HIP_SHARE_QUIET_US", 6); return v; }
-int64_t fe_window_ns() { static const int64_t v = 1000ll * env_us("LPSLAM_HIP_SHARE_FE_WINDOW_US", 500); return v; }
+int64_t pose_quiet_ns() { static const int64_t v = 1000ll * env_us("LPSLAM_HIP_SHARE_POSE_QUIET_US", 2); return v; }      // (a pose batch runs ~110 us: a request that just misses one waits that long)
+int64_t quiet_ns() { static const int64_t v = 1000ll * env_us("LPSLAM_HIP_SHARE_QUIET_US", 2); return v; }
+int64_t fe_window_ns() { static const int64_t v = 1000ll * env_us("LPSLAM_HIP_SHARE_FE_WINDOW_US", 300); return v; }
+int64_t fe_quiet_ns() { static const int64_t v = 1000ll * env_us("LPSLAM_HIP_SHARE_FE_QUIET_US", 40); return v; }
 int64_t active_ns() { static const int64_t v = 1000ll * env_us("LPSLAM_HIP_SHARE_ACTIVE_US", 3000); return v; }
 
 // ---- one hardware queue per role ---------------------------------------------------------------------------------------------
@@ -179,7 +182,7 @@ void combine(Share& sh, Ticket& mine)
             if (sh.pose.empty() && sh.proj.empty()) return;
             const int expected = std::max(1, active_sessions(sh, now) - sh.in_flight.load(std::memory_order_relaxed));
             if (!sh.pose.empty() && sh.pose_busy.load(std::memory_order_acquire) == 0 &&
-                ((int)sh.pose.size() >= expected || now - sh.pose_newest_ns >= quiet_ns() || now - sh.pose_oldest_ns >= window_ns())) pose.swap(sh.pose);
+                ((int)sh.pose.size() >= expected || now - sh.pose_newest_ns >= pose_quiet_ns() || now - sh.pose_oldest_ns >= window_ns())) pose.swap(sh.pose);
             if (!sh.proj.empty() && sh.proj_busy.load(std::memory_order_acquire) == 0 &&
                 ((int)sh.proj.size() >= expected || now - sh.proj_newest_ns >= quiet_ns() || now - sh.proj_oldest_ns >= window_ns() || (int)sh.proj.size() >= kTableEntries)) proj.swap(sh.proj);
         }
@@ -295,12 +298,14 @@ void combine_front(Share& sh)
             std::lock_guard<std::mutex> lock(sh.m);
             const int np = (int)sh.front.size();
             if (np == 0) return;
-            // Nobody waits for a front end until its frame is due, a whole tracking step later, so the sessions' requests arrive whenever
-            // each session finished its previous frame: the gather waits for EVERY session that is submitting front ends (not only those
-            // without one in flight), up to the window.  Sessions whose frames came out of one chain collect them together and submit
-            // their next frames together: after a few frames the sessions run in lockstep and the gather ends on the count.
-            const int expected = std::max(1, active_fe_sessions(sh, now));
-            if (np >= expected || now - sh.fe_oldest_ns >= fe_window_ns() || 2 * np >= kMaxListed) {
+            // A chain would only queue behind the one that is running on the front-end stream: while that one is in flight the requests
+            // accumulate, and the next chain carries all of them.  On an idle stream: every session that is submitting front ends and has
+            // none in flight (one whose frames came out of the last chain with this caller's is about to arrive; one in flight cannot
+            // before its chain is through), or nothing new for `quiet`, or `window` after the oldest request.
+            bool busy = false;
+            if (sh.fe_chain_in_flight) { busy = hipEventQuery(sh.ev_fe_chain) == hipErrorNotReady; if (!busy) sh.fe_chain_in_flight = false; (void)hipGetLastError(); }
+            const int expected = std::max(1, active_fe_sessions(sh, now) - sh.fe_in_flight.load(std::memory_order_relaxed));
+            if ((!busy && (np >= expected || now - sh.fe_newest_ns >= fe_quiet_ns() || now - sh.fe_oldest_ns >= fe_window_ns())) || 2 * np >= kMaxListed) {
                 reqs.swap(sh.front);
                 t_oldest = sh.fe_oldest_ns; t_taken = now;
                 sh.fe_oldest_ns = sh.fe_newest_ns = 0;
@@ -327,28 +332,26 @@ void combine_front(Share& sh)
         int n = 0;
         hipStream_t s = sh.s_front;
         bool ok = true;
-        const size_t w0 = (size_t)pool->lt.w[0], h0 = (size_t)pool->lt.h[0], p0 = (size_t)pool->lt.pitch[0];
         for (size_t gi : grp) {
             const PendingFront& r = reqs[gi];
-            for (int e = 0; e < (r.stereo ? 2 : 1); ++e) {
-                const int img = r.c->pool_first + r.slot + e;
-                list[n++] = (uint16_t)img;
-                if (!r.staged[e]) continue;
-                // the frame goes up at the head of the chain, from the session's page-locked buffer (which its next upload of that slot waits for)
-                uint8_t* dst = pool->d_pyr + (size_t)img * pool->image_slab;
-                ok = ok && (p0 == w0 ? hipMemcpyAsync(dst, r.staged[e], w0 * h0, hipMemcpyHostToDevice, s) : hipMemcpy2DAsync(dst, p0, r.staged[e], w0, w0, h0, hipMemcpyHostToDevice, s)) == hipSuccess;
-                ok = ok && hipEventRecord(r.c->ev_upload[(size_t)(r.slot + e)], s) == hipSuccess;
-            }
+            list[n++] = (uint16_t)(r.c->pool_first + r.slot);
+            if (r.stereo) list[n++] = (uint16_t)(r.c->pool_first + r.slot + 1);
             deliver.push_back(r.deliver);
-            if (!r.staged[0]) ok = ok && hipStreamWaitEvent(s, r.c->ev_fe_ready, 0) == hipSuccess;      // the session's own uploads (its stream) are in the slots
+            // the session's uploads are in the slots before the chain reads them
+            if (r.own == nullptr) ok = ok && lp_wait_own_uploads(r.c, r.slot, r.stereo ? 2 : 1, s) == LPSLAM_HIP_OK;      // (its copy-only stream: the events of the copies)
+            else if (r.own != s) ok = ok && hipStreamWaitEvent(s, r.c->ev_fe_ready, 0) == hipSuccess;
         }
         const int64_t t_copied = now_ns();
         ok = ok && lp_launch_pyramid(pool, 0, n, list) == LPSLAM_HIP_OK && lp_launch_fast(pool, 0, n, list) == LPSLAM_HIP_OK &&
              lp_launch_distribute(pool, 0, n, list) == LPSLAM_HIP_OK && lp_launch_describe(pool, 0, n, list) == LPSLAM_HIP_OK;
         if (ok && reqs[i0].stereo) ok = lp_launch_stereo_strided(pool, 0, 0, 0, n / 2, reqs[i0].fxb, reqs[i0].baseline, list) == LPSLAM_HIP_OK;
         ok = ok && lp_launch_deliver_batch(s, deliver.data(), (int)deliver.size(), pool->slots_per_image, pool) == LPSLAM_HIP_OK;
+        if (ok) {
+            if (!sh.ev_fe_chain && hipEventCreateWithFlags(&sh.ev_fe_chain, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); sh.ev_fe_chain = nullptr; }
+            if (sh.ev_fe_chain && hipEventRecord(sh.ev_fe_chain, s) == hipSuccess) sh.fe_chain_in_flight = true;
+        }
         if (!ok) (void)hipGetLastError();
-        if (share_trace()) fprintf(stderr, "share %.3f front %d (gathered for %.0f us, launched in %.0f us, of which copies %.0f)\n", 1e-6 * (double)(now_ns() % 100000000000ll), (int)grp.size(), 1e-3 * (double)(t_taken - t_oldest), 1e-3 * (double)(now_ns() - t_taken), 1e-3 * (double)(t_copied - t_taken));
+        if (share_trace()) fprintf(stderr, "share %.3f front %d (gathered for %.0f us, launched in %.0f us, of which waits %.0f)\n", 1e-6 * (double)(now_ns() % 100000000000ll), (int)grp.size(), 1e-3 * (double)(t_taken - t_oldest), 1e-3 * (double)(now_ns() - t_taken), 1e-3 * (double)(t_copied - t_taken));
         for (size_t gi : grp) {
             PendingFront& r = reqs[gi];
             r.t->stream = s;
@@ -425,7 +428,7 @@ bool lp_share_role_streams(int device, hipStream_t out[4])
     return true;
 }
 
-int lp_share_front_end(lpslam_hip_ctx* c, int slot, int stereo, float fxb, float baseline, const uint8_t* staged_left, const uint8_t* staged_right)
+int lp_share_front_end(lpslam_hip_ctx* c, int slot, int stereo, float fxb, float baseline)
 {
     // a session of a pool, no masks (the launch takes the pool's), no copy-stream uploads pending, sharing wanted, somebody to share with
     const int mode = share_mode();
@@ -435,13 +438,14 @@ int lp_share_front_end(lpslam_hip_ctx* c, int slot, int stereo, float fxb, float
     if (!touch_session(sh, c, now)) return LP_SHARE_DIRECT;
     sh.fe_last_ns[c->share_slot].store(now, std::memory_order_relaxed);
     if (mode == 2 && active_fe_sessions(sh, now) < 2) return LP_SHARE_DIRECT;
-    hipStream_t own = lp_fe_stream(c);
+    hipStream_t own = c->up_stream ? nullptr : lp_fe_stream(c);      // nullptr: the uploads went through the session's copy-only stream
     if (!c->ev_fe_ready && hipEventCreateWithFlags(&c->ev_fe_ready, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); c->ev_fe_ready = nullptr; return LP_SHARE_DIRECT; }
     lp_share_front_end_collected(c);                    // (a delivery nobody collected: a prefetch for a frame that did not come next)
-    PendingFront r{c, slot, stereo, fxb, baseline, {staged_left, stereo ? staged_right : nullptr}, LpDeliverReq{}, nullptr};
+    PendingFront r{c, slot, stereo, fxb, baseline, own, LpDeliverReq{}, nullptr};
     int rc = lp_prepare_delivery(c, slot, stereo, &r.deliver);
     if (rc) return -rc;
-    if (!staged_left && hipEventRecord(c->ev_fe_ready, own) != hipSuccess) { (void)hipGetLastError(); return LP_SHARE_DIRECT; }
+    { std::lock_guard<std::mutex> lock(sh.m); if (!share_init(sh)) return LP_SHARE_DIRECT; }
+    if (own && own != sh.s_front && hipEventRecord(c->ev_fe_ready, own) != hipSuccess) { (void)hipGetLastError(); return LP_SHARE_DIRECT; }
     // the slots' results are about to be rewritten: the session's host mirrors go stale now
     for (int i = slot; i < slot + (stereo ? 2 : 1) && (size_t)i < c->h_kp_valid.size(); ++i) c->h_kp_valid[(size_t)i] = 0;
     Ticket t;

@@ -69,7 +69,7 @@ def run(n):
         pass
     if os.environ.get("LPSLAM_DEV_STATS"):
         st = [mg.tracker_statistics() for mg in mgs]      # (each manager's own line: the log file is process-wide)
-        keys = ("ms_per_frame", "ms_front_end", "ms_track", "ms_local_map", "ms_keyframe", "ms_dev_extract", "ms_dev_match", "ms_dev_pose", "ms_dev_get", "ms_prefetch_wait", "ms_prefetch_busy", "ms_kf_wait", "ms_kf_insert", "ms_kf_prepare", "ms_map_solve", "prefetched")
+        keys = ("ms_per_frame", "ms_front_end", "ms_track", "ms_local_map", "ms_keyframe", "ms_dev_extract", "ms_dev_match", "ms_dev_pose", "ms_dev_get", "ms_prefetch_wait", "ms_prefetch_busy", "ms_kf_wait", "ms_kf_apply", "ms_kf_insert", "ms_kf_loop", "ms_kf_prepare", "ms_map_solve", "prefetched")
         print("   per-manager statistics (mean over %d managers): " % n + ", ".join("%s %.3f" % (k, sum(x.get(k, 0) for x in st) / len(st)) for k in keys))
     return got, valid, dt
 
