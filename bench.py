@@ -440,9 +440,15 @@ def tracker_multi_child(device):
     run(1, tr_frames[:30])                       # untimed: code objects, page-locked staging and the allocator's pools of a new process
     tm = {}
     for n_mgr in (8, 16):
+        before = (hip.shared_launch_counters(device), hip.shared_front_end_counters(device), hip.shared_solve_counters(device))
         tm["managers_%d" % n_mgr] = run(n_mgr, tr_frames)
-    tm["note"] = ("a process of its own with lpslam_hip_set_flat_priorities(1) from the start, as a server of many sessions runs; N LpSlamManager instances (each its own "
-                  "context, streams, worker and mapping pipeline) fed 120 stereo frames each by N threads; compiled odometry and result callbacks; one untimed 30-frame session first")
+        after = (hip.shared_launch_counters(device), hip.shared_front_end_counters(device), hip.shared_solve_counters(device))
+        # what the sessions shared: requests per launch of the window matchers + pose optimisers, of the front-end chains, of the windows' solves
+        tm["managers_%d" % n_mgr]["requests_per_shared_launch"] = {name: round((a[1] - b[1]) / max(a[0] - b[0], 1), 2)
+                                                                   for name, b, a in zip(("match_and_pose", "front_end", "local_ba"), before, after)}
+    tm["note"] = ("a process of its own, as a server of many sessions runs; N LpSlamManager instances (each a session of the device's pool with its own worker, prefetch and mapping "
+                  "threads) fed 120 stereo frames each by N threads; the sessions' pending front ends, window matchers, pose optimisations and local bundle adjustments go out as shared "
+                  "launches on four role streams (lpslam_amd/csrc/share.hip); compiled odometry and result callbacks; one untimed 30-frame session first")
     print(json.dumps(tm))
 
 
