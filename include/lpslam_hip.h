@@ -85,7 +85,9 @@ int lpslam_hip_debug_occupy_unreserved(lpslam_hip_ctx* ctx, int32_t microseconds
  * created a stream: every priority class takes its own set of hardware queues, beyond a few the command processor time-slices them, and
  * one high-priority stream ever created in the process halves the aggregate of the sessions that follow.  In a flat
  * process context k puts k mod 4 placeholder streams in front of its main stream, so that the contexts' main streams spread over the
- * process' four hardware queues (LPSLAM_HIP_NO_QUEUE_SPREAD=1 switches that off: measurements). */
+ * process' four hardware queues (LPSLAM_HIP_NO_QUEUE_SPREAD=1 switches that off: measurements).  Called with 1 AFTER a priority stream has
+ * been created in the process it changes nothing, says so on stderr and returns LPSLAM_HIP_ERR_INVALID (the caller must not believe it
+ * runs flat); 2 = flat from now on although it is late (tests and measurements of that case). */
 int lpslam_hip_set_flat_priorities(int32_t flat);
 /* Process-wide: launches shared by the sessions of a process.  The reference runs one manager per sequence, one frame in flight each
  * (src/Manager/SlamManager.cpp:54-61,191-201); N of them on one GPU issue N chains of small latency-bound launches.  With sharing the

@@ -176,7 +176,19 @@ bool lp_flat_priorities()
     static const bool env = [] { const char* e = getenv("LPSLAM_HIP_FLAT_PRIORITIES"); return e && atoi(e) != 0; }();
     return env;
 }
-extern "C" int lpslam_hip_set_flat_priorities(int32_t flat) { g_flat_priorities.store(flat < 0 ? -1 : (flat ? 1 : 0)); return LPSLAM_HIP_OK; }
+static std::atomic<bool> g_priority_stream_made{false};      // a stream outside the default priority has been created in this process (it keeps its hardware queues for good)
+extern "C" int lpslam_hip_set_flat_priorities(int32_t flat)
+{
+    if (flat == 1 && g_priority_stream_made.load()) {      // (2: flat although late -- tests and measurements of exactly that case)
+        // too late: the process already holds hardware queues of another priority class, and every session created from now on would run
+        // beside them at half the aggregate -- the caller is told instead of being left to find out
+        set_error("lpslam_hip_set_flat_priorities(1) after a priority stream was created in this process: call it before the first context");
+        fprintf(stderr, "lpslam_hip: %s\n", lpslam_hip_last_error());
+        return LPSLAM_HIP_ERR_INVALID;
+    }
+    g_flat_priorities.store(flat < 0 ? -1 : (flat ? 1 : 0));
+    return LPSLAM_HIP_OK;
+}
 size_t lp_pool_flush_device(int device)
 {
     size_t freed = 0;
@@ -233,7 +245,7 @@ static hipError_t lp_fe_stream_create(hipStream_t* s, bool background)
     if (background && !lp_flat_priorities()) {
         int prio_least = 0, prio_greatest = 0;
         if (hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) == hipSuccess && prio_least != prio_greatest &&
-            hipStreamCreateWithPriority(s, hipStreamNonBlocking, prio_least) == hipSuccess) return hipSuccess;
+            hipStreamCreateWithPriority(s, hipStreamNonBlocking, prio_least) == hipSuccess) { g_priority_stream_made.store(true); return hipSuccess; }
         (void)hipGetLastError();
     }
     return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
@@ -257,6 +269,7 @@ hipStream_t lp_stream_acquire(lpslam_hip_ctx* c)
     const bool flat = lp_flat_priorities();
     hipStream_t s = nullptr;
     if ((flat ? hipStreamCreateWithFlags(&s, hipStreamNonBlocking) : hipStreamCreateWithPriority(&s, hipStreamNonBlocking, prio_greatest)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (!flat && prio_greatest != prio_least) g_priority_stream_made.store(true);
     return s;
 }
 
@@ -472,6 +485,9 @@ static int create_impl(const lpslam_hip_frontend_config* cfg, lpslam_hip_ctx* po
     c->cells_per_image = c->lt.cell_start[L];
     c->cand_per_image = c->lt.cand_start[L];
     c->slots_per_image = c->lt.slot_start[L];
+    // keypoint indices travel as 16 bits in the window matchers (the candidate key's index field, the survivor list and the best-so-far
+    // table of k_proj_topk, match.hip)
+    if (c->slots_per_image > 65535) { set_error("%d keypoint slots per image exceed the matchers' 16-bit keypoint index", c->slots_per_image); delete c; return LPSLAM_HIP_ERR_CAPACITY; }
     size_t lds = 0;
     for (int l = 0; l < L; ++l) {
         lds = std::max(lds, lp_distribute_lds_bytes(c->lt.qcap[l], c->lt.cells_x[l] * c->lt.cells_y[l]));
@@ -492,9 +508,11 @@ static int create_impl(const lpslam_hip_frontend_config* cfg, lpslam_hip_ctx* po
         c->owns_streams = false; c->stream = roles[LP_ROLE_MAIN]; c->fe_stream = roles[LP_ROLE_FRONT]; c->role_solve = roles[LP_ROLE_SOLVE];
         if (hipEventCreateWithFlags(&c->fe_done, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); delete c; set_error("hipEventCreate failed"); return LPSLAM_HIP_ERR_DEVICE; }
     } else
-    if (lp_flat_priorities() && !getenv("LPSLAM_HIP_NO_QUEUE_SPREAD")) {
-        static std::atomic<int> ctx_seq{0};
-        const int k = ctx_seq.fetch_add(1) % 4;
+    // (best effort: it leans on how this runtime binds streams to its four queues -- counted per device, and left alone when the caller has
+    // changed the number of queues; sessions that join a pool use the measured role streams instead, share.hip)
+    if (lp_flat_priorities() && !getenv("LPSLAM_HIP_NO_QUEUE_SPREAD") && !getenv("GPU_MAX_HW_QUEUES")) {
+        static std::atomic<int> ctx_seq[64];
+        const int k = ctx_seq[cfg->device & 63].fetch_add(1) % 4;
         if (k > 0 && hipMalloc(&c->d_pad, 256) == hipSuccess) {
             for (int i = 0; i < k; ++i) {
                 hipStream_t d = nullptr;

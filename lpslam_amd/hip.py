@@ -96,9 +96,10 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
 
 
-def set_flat_priorities(flat):
-    """process-wide: streams of contexts created from now on at the default priority (True) or in the three classes (False); None: the environment"""
-    _check(load().lpslam_hip_set_flat_priorities(C.c_int32(-1 if flat is None else (1 if flat else 0))))
+def set_flat_priorities(flat, late_ok=False):
+    """process-wide: streams of contexts created from now on at the default priority (True) or in the three classes (False); None: the environment.
+    True after a priority stream exists in the process is refused (RuntimeError) unless late_ok"""
+    _check(load().lpslam_hip_set_flat_priorities(C.c_int32(-1 if flat is None else ((2 if late_ok else 1) if flat else 0))))
 
 
 def set_shared_launches(mode):

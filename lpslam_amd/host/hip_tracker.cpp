@@ -558,7 +558,10 @@ int HipVslamTrackerBase::insertKeyframe(FrameData& f)
             m_freshLandmarks.push_back(id);
             f.landmark[i] = id;
         } else if (id >= 0) {
-            m_landmarks[id].obs.emplace_back(c, (int)i);
+            // (the id was resolved and validated at the top of this function; a landmark that is gone all the same -- erased or merged while
+            // the frame was in flight -- must not be re-created by operator[] behind the index's back)
+            if (Landmark* l = lm(id)) l->obs.emplace_back(c, (int)i);
+            else f.landmark[i] = -1;
         }
     }
     if (!m_stereo && c > m_segmentStart) monoTriangulate(c - 1, kf, f);
@@ -1428,6 +1431,35 @@ bool HipVslamTrackerBase::detectAndCloseLoop(FrameData& cur, int c)
         for (auto& sc : m_bowDb.query(kc.bow, exclude, min_score, newest_candidate)) { cands.emplace_back(-sc.first, sc.second); if (cands.size() >= 8) break; }
         if (cands.empty()) { m_loopSets.clear(); return false; }
     }
+    // [UPSTREAM] loop_detector::find_continuously_detected_keyframe_sets (min_continuity_ = 3; ORB-SLAM's covisibility consistency,
+    // toggled with the detector at src/Trackers/OpenVSLAMTrackerBase.cpp:250-255), on the RAW candidates of the query, before any
+    // descriptor is matched: a candidate stands for the set of itself and its covisibility neighbours; its continuity is one more than
+    // that of a set detected at the PREVIOUS keyframe that shares a keyframe with it (0 when there is none); only candidates whose
+    // continuity has reached 3 -- detected at four keyframes in a row -- go on to the matching and the Sim3 verification.  The chain
+    // breaks only at a keyframe whose query returns no candidate (above); the 20-match test comes later, as upstream's does.
+    {
+        std::vector<std::pair<std::vector<int>, int>> sets_now;
+        std::vector<std::pair<double, int>> continuous;
+        for (auto& cd : cands) {
+            std::vector<int> group = covisible(cd.second, (int)m_kfs.size(), 15);
+            group.push_back(cd.second);
+            std::sort(group.begin(), group.end());
+            int cont = 0;
+            for (auto& prev : m_loopSets) {
+                bool shared = false;
+                for (size_t i = 0, j = 0; i < group.size() && j < prev.first.size() && !shared;) {
+                    if (group[i] == prev.first[j]) shared = true;
+                    else if (group[i] < prev.first[j]) ++i; else ++j;
+                }
+                if (shared) cont = std::max(cont, prev.second + 1);
+            }
+            sets_now.emplace_back(std::move(group), cont);
+            if (cont >= 3) continuous.push_back(cd);
+        }
+        m_loopSets = std::move(sets_now);
+        cands = std::move(continuous);
+        if (cands.empty()) return false;
+    }
     const int scratch = previousSlot(cur.slot);                  // the previous frame's slot pair is free for the descriptors of a candidate
     std::vector<int32_t> mq((size_t)m_maxKp), mt((size_t)m_maxKp), md((size_t)m_maxKp);
     struct Vote { int kf; std::vector<std::pair<int, int>> pairs; };        // (keypoint of c, keypoint of the candidate), landmarks on both sides
@@ -1501,34 +1533,6 @@ bool HipVslamTrackerBase::detectAndCloseLoop(FrameData& cur, int c)
         for (int k = 0; k < nm; ++k)
             if (kc.landmark[(size_t)mq[k]] >= 0 && ka.landmark[(size_t)mt[k]] >= 0 && resolve(kc.landmark[(size_t)mq[k]]) != resolve(ka.landmark[(size_t)mt[k]])) v.pairs.emplace_back(mq[k], mt[k]);
         if (v.pairs.size() >= 20) votes.push_back(std::move(v));         // [UPSTREAM] num_matches >= 20 to try a candidate
-    }
-    if (votes.empty()) { m_loopSets.clear(); return false; }
-    // [UPSTREAM] loop_detector::find_continuously_detected_keyframe_sets (min_continuity_ = 3; ORB-SLAM's covisibility consistency,
-    // toggled with the detector at src/Trackers/OpenVSLAMTrackerBase.cpp:250-255): a candidate stands for the set of itself and its
-    // covisibility neighbours; its continuity is one more than that of a set detected at the PREVIOUS keyframe that shares a keyframe
-    // with it (0 when there is none); only candidates whose continuity has reached 3 -- detected at four keyframes in a row -- go on to
-    // the Sim3 verification.  A keyframe without a candidate breaks the chain.
-    {
-        std::vector<std::pair<std::vector<int>, int>> sets_now;
-        std::vector<Vote> accepted;
-        for (auto& v : votes) {
-            std::vector<int> group = covisible(v.kf, (int)m_kfs.size(), 15);
-            group.push_back(v.kf);
-            std::sort(group.begin(), group.end());
-            int cont = 0;
-            for (auto& prev : m_loopSets) {
-                bool shared = false;
-                for (size_t i = 0, j = 0; i < group.size() && j < prev.first.size() && !shared;) {
-                    if (group[i] == prev.first[j]) shared = true;
-                    else if (group[i] < prev.first[j]) ++i; else ++j;
-                }
-                if (shared) cont = std::max(cont, prev.second + 1);
-            }
-            sets_now.emplace_back(std::move(group), cont);
-            if (cont >= 3) accepted.push_back(std::move(v));
-        }
-        m_loopSets = std::move(sets_now);
-        votes = std::move(accepted);
     }
     if (votes.empty()) return false;
     std::sort(votes.begin(), votes.end(), [](const Vote& a, const Vote& b) { return a.pairs.size() != b.pairs.size() ? a.pairs.size() > b.pairs.size() : a.kf > b.kf; });

@@ -673,8 +673,28 @@ class StereoTracker:
             self.loop_sets = []
             return False
         cands.sort()
+        cands = cands[:48]
+        # [UPSTREAM] loop_detector::find_continuously_detected_keyframe_sets (min_continuity_ = 3, ORB-SLAM's covisibility consistency) on the
+        # RAW candidates of the query, before any descriptor is matched: a candidate stands for the set of itself and its covisibility
+        # neighbours; its continuity is one more than that of a set detected at the PREVIOUS keyframe that shares a keyframe with it (0 when
+        # there is none); only candidates whose continuity has reached 3 -- detected at four keyframes in a row -- go on to the matching and
+        # the Sim3 verification.  The chain breaks only at a keyframe whose query returns no candidate; the 20-match test comes later.
+        sets_now, continuous = [], []
+        for d_, a in cands:
+            group = set(self.covisible(a, len(self.kfs), 15)) | {a}
+            cont = 0
+            for pg, pc in self.loop_sets:
+                if group & pg:
+                    cont = max(cont, pc + 1)
+            sets_now.append((group, cont))
+            if cont >= 3:
+                continuous.append((d_, a))
+        self.loop_sets = sets_now
+        cands = continuous
+        if not cands:
+            return False
         votes = []
-        for _, a in cands[:48]:
+        for _, a in cands:
             ka = self.kfs[a]
             if len(ka["kpts"]) == 0:
                 continue
@@ -683,25 +703,6 @@ class StereoTracker:
                      if kc["landmark"][int(q_)] >= 0 and ka["landmark"][int(t_)] >= 0 and self.resolve(kc["landmark"][int(q_)]) != self.resolve(ka["landmark"][int(t_)])]
             if len(pairs) >= 20:
                 votes.append((a, pairs))
-        if not votes:
-            self.loop_sets = []
-            return False
-        # [UPSTREAM] loop_detector::find_continuously_detected_keyframe_sets (min_continuity_ = 3, ORB-SLAM's covisibility consistency):
-        # a candidate stands for the set of itself and its covisibility neighbours; its continuity is one more than that of a set
-        # detected at the PREVIOUS keyframe that shares a keyframe with it (0 when there is none); only candidates whose continuity has
-        # reached 3 -- detected at four keyframes in a row -- go on to the Sim3 verification.  No candidate at a keyframe: the chain breaks.
-        sets_now, accepted = [], []
-        for a, pairs in votes:
-            group = set(self.covisible(a, len(self.kfs), 15)) | {a}
-            cont = 0
-            for pg, pc in self.loop_sets:
-                if group & pg:
-                    cont = max(cont, pc + 1)
-            sets_now.append((group, cont))
-            if cont >= 3:
-                accepted.append((a, pairs))
-        self.loop_sets = sets_now
-        votes = accepted
         if not votes:
             return False
         votes.sort(key=lambda v: (-len(v[1]), -v[0]))

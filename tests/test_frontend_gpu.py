@@ -374,7 +374,14 @@ def test_contexts_of_a_flat_priority_process(hiplib, oracle):
     seq = synth.StereoSequence(w, h, 6)
     f0, f1 = seq.frame(0), seq.frame(1)
     kp_o, d_o = oracle.extract(f0[0], oracle.params(kpts, 1.2, levels))[:2]
-    hiplib.set_flat_priorities(True)
+    # (this process has made priority streams by now: the plain switch is refused and says why; the test asks for the late form)
+    probe = hiplib.Context(w, h, kpts, 1.2, levels, max_images=2)
+    with probe.prefetch():
+        pass                                             # a prefetch stream of the low class exists from here on
+    with pytest.raises(RuntimeError, match="after a priority stream"):
+        hiplib.set_flat_priorities(True)
+    probe.close()
+    hiplib.set_flat_priorities(True, late_ok=True)
     ctxs = []
     try:
         for i in range(5):
