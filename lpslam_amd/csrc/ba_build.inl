@@ -173,18 +173,31 @@ __global__ __launch_bounds__(256) void k_bs_gather(const BuildDesc* __restrict__
     d.o_active[s] = 1; d.act_in[s] = 1;
 }
 
-// CSR by landmark: thread per landmark walks the keyframes in order (column of A / R)
+// CSR by landmark: thread per landmark walks the keyframes in order (column of A / R).  Sixteen keyframes' counts and positions are
+// loaded together (coalesced over the landmarks, independent of each other) before the thread's serial placement uses them: the walk
+// was one dependent load pair per keyframe -- 50 memory round trips in a row, 35 us for a 50-keyframe window on 80 wavefronts.
 __global__ __launch_bounds__(256) void k_bs_ptfill(const BuildDesc* __restrict__ descs)
 {
     const BuildDesc& d = descs[blockIdx.y];
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= d.n_points) return;
+    const int* __restrict__ A = d.A; const int* __restrict__ R = d.R; const int* __restrict__ ps_start = d.ps_start;
+    int* __restrict__ pt_obs = d.pt_obs;
+    const int n_poses = d.n_poses, n_points = d.n_points;
     int t = d.pt_start[j];
-    for (int p = 0; p < d.n_poses; ++p) {
-        const size_t e = (size_t)p * d.n_points + j;
-        const int c = d.A[e] & 0xFFFF;
-        const int first = d.ps_start[p] + d.R[e];
-        for (int dd = 0; dd < c; ++dd) d.pt_obs[t++] = first + dd;
+    constexpr int U = 16;
+    for (int p0 = 0; p0 < n_poses; p0 += U) {
+        int c[U], first[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int p = min(p0 + u, n_poses - 1);
+            const size_t e = (size_t)p * n_points + j;
+            c[u] = p0 + u < n_poses ? (A[e] & 0xFFFF) : 0;
+            first[u] = ps_start[p] + R[e];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            for (int dd = 0; dd < c[u]; ++dd) pt_obs[t++] = first[u] + dd;
     }
 }
 

@@ -20,10 +20,22 @@ struct Ticket {                                         // lives in the caller's
     std::atomic<int> state{T_PENDING};
     hipStream_t stream = nullptr;                       // where the batch went (T_LAUNCHED)
     std::atomic<int>* table_users = nullptr;            // the table block of a matcher batch: released when the request is done
-    std::atomic<int>* busy = nullptr;                   // the kind's in-flight count: one less when the request is done
+    std::atomic<int>* owner_done = nullptr;             // the request's entry of its batch (InFlight): set when the owner has seen it complete
 };
-struct PendingPose { LpPoseReq req; Ticket* t; };
-struct PendingProj { LpProjReq req; Ticket* t; };
+// The batch of a kind that is on its stream: done when every request's flag holds its sequence number -- looked at by whoever wants
+// to launch the next batch, not left to the requests' owners to report (an owner that the scheduler has taken off its core for a
+// while would keep the stream idle for everybody; it only marks its entry before it re-uses the flag for its next request).
+struct InFlight {
+    int n = 0;
+    int* flag[64]; int seq[64]; std::atomic<int> owner_done[64];
+    bool busy() const
+    {
+        for (int i = 0; i < n; ++i) if (!owner_done[i].load(std::memory_order_acquire) && __atomic_load_n(flag[i], __ATOMIC_ACQUIRE) != seq[i]) return true;
+        return false;
+    }
+};
+struct PendingPose { LpPoseReq req; Ticket* t; int* flag; };
+struct PendingProj { LpProjReq req; Ticket* t; };      // (flag and sequence number are in the request)
 struct PendingSolve { lpslam_hip_ba* b; int first, second; uint8_t* outlier; double* poses; double* points; std::atomic<int>* state; int* rc; };
 struct PendingFront { lpslam_hip_ctx* c; int slot, stereo; float fxb, baseline; hipStream_t own; LpDeliverReq deliver; Ticket* t; };      // own: the stream the session enqueued its uploads on
 
@@ -35,7 +47,8 @@ struct Share {
     std::vector<PendingPose> pose;
     std::vector<PendingProj> proj;
     int64_t pose_oldest_ns = 0, pose_newest_ns = 0, proj_oldest_ns = 0, proj_newest_ns = 0;      // arrival of the oldest / newest pending request of a kind
-    std::atomic<int> pose_busy{0}, proj_busy{0};        // requests of the kind's batch in flight that are not done yet (0: the kind's stream is idle)
+    InFlight pose_fl[2], pose2_fl[2], proj_fl[2];       // the batch on each stream (written under the combiner lock); two generations, alternating: an owner's late mark lands in the one that is not current
+    int pose_gen = 0, pose2_gen = 0, proj_gen = 0;
     std::atomic<int> in_flight{0};                      // requests launched whose callers have not seen them complete
     std::atomic<int64_t> last_ns[kMaxSessions];         // per session: its last request (0: free entry)
     std::atomic<int> n_sessions{0};                     // high-water mark of the table
@@ -43,6 +56,7 @@ struct Share {
     // The streams of the shared launches, one per ROLE, each on a hardware queue of its own (lp_share_streams): the pose optimiser's
     // batches, the matchers' batches, the front-end chains (the pool context's stream), the windows' solves.
     hipStream_t s_pose = nullptr, s_proj = nullptr, s_front = nullptr, s_solve = nullptr;
+    hipStream_t s_pose2 = nullptr;                      // a second pose stream on a fifth hardware queue, when the process has one (GPU_MAX_HW_QUEUES >= 5)
     int distinct_queues = 0;                            // how many of the four roles got a hardware queue to themselves (diagnostic)
     LpProjReq* table = nullptr;                         // page-locked: kTableBlocks blocks of kTableEntries requests
     std::atomic<int> table_users[kTableBlocks];         // requests of the block's last batch that are not done yet
@@ -123,20 +137,25 @@ bool share_init(Share& sh)                              // sh.m held
     unsigned long long* d_stamps = nullptr;
     unsigned long long h_stamps[2] = {0, 0};
     ok = ok && hipMalloc((void**)&d_stamps, 2 * sizeof(unsigned long long)) == hipSuccess;
-    int picked[4] = {0, -1, -1, -1}, n_picked = ok ? 1 : 0;
+    int picked[5] = {0, -1, -1, -1, -1}, n_picked = ok ? 1 : 0;
     static const bool no_probe = getenv("LPSLAM_HIP_SHARE_NO_PROBE") != nullptr;      // measurements: the first four candidates as they come
-    for (int i = 1; ok && !no_probe && i < n_cand && n_picked < 4; ++i) {
+    static const int want = [] { const char* e = getenv("LPSLAM_HIP_SHARE_POSE_STREAMS"); return (e && atoi(e) >= 2) ? 5 : 4; }();
+    for (int i = 1; ok && !no_probe && i < n_cand && n_picked < want; ++i) {
         bool free_of_all = true;
         for (int k = 0; k < n_picked && free_of_all; ++k) free_of_all = probe_independent(cand[picked[k]], cand[i], d_stamps, h_stamps) && probe_independent(cand[i], cand[picked[k]], d_stamps, h_stamps);
         if (free_of_all) picked[n_picked++] = i;
     }
     sh.distinct_queues = n_picked;
+    const int fifth = n_picked >= 5 ? picked[4] : -1;
+    if (n_picked > 4) n_picked = 4;
     // fewer than four independent candidates (GPU_MAX_HW_QUEUES < 4, or the probe is off): roles share, the latency-critical ones last
     for (int next = 0; n_picked < 4 && ok;) { while (std::find(picked, picked + n_picked, next) != picked + n_picked) ++next; picked[n_picked++] = next < n_cand ? next : 0; }
     if (d_stamps) (void)hipFree(d_stamps);
     if (!ok) { for (int i = 0; i < n_cand; ++i) (void)hipStreamDestroy(cand[i]); (void)hipGetLastError(); sh.broken = true; return false; }
     sh.s_pose = cand[picked[0]]; sh.s_proj = cand[picked[1]]; sh.s_front = cand[picked[2]]; sh.s_solve = cand[picked[3]];
-    for (int i = 0; i < n_cand; ++i) if (std::find(picked, picked + 4, i) == picked + 4) (void)hipStreamDestroy(cand[i]);
+    if (fifth >= 0) sh.s_pose2 = cand[fifth];
+    else if (getenv("LPSLAM_HIP_SHARE_POSE_ON_MAIN")) sh.s_pose2 = sh.s_proj;      // measurements: every second pose batch on the matchers' stream
+    for (int i = 0; i < n_cand; ++i) if (std::find(picked, picked + 4, i) == picked + 4 && i != fifth) (void)hipStreamDestroy(cand[i]);
     sh.ready = true;
     return true;
 }
@@ -176,14 +195,18 @@ void combine(Share& sh, Ticket& mine)
     for (;;) {
         std::vector<PendingPose> pose;
         std::vector<PendingProj> proj;
+        bool pose_second = false;
         const int64_t now = now_ns();
         {
             std::lock_guard<std::mutex> lock(sh.m);
             if (sh.pose.empty() && sh.proj.empty()) return;
             const int expected = std::max(1, active_sessions(sh, now) - sh.in_flight.load(std::memory_order_relaxed));
-            if (!sh.pose.empty() && sh.pose_busy.load(std::memory_order_acquire) == 0 &&
+            const bool pose1_free = !sh.pose_fl[sh.pose_gen].busy();
+            const bool pose_free = pose1_free || (sh.s_pose2 && !sh.pose2_fl[sh.pose2_gen].busy());
+            pose_second = !pose1_free;
+            if (!sh.pose.empty() && pose_free &&
                 ((int)sh.pose.size() >= expected || now - sh.pose_newest_ns >= pose_quiet_ns() || now - sh.pose_oldest_ns >= window_ns())) pose.swap(sh.pose);
-            if (!sh.proj.empty() && sh.proj_busy.load(std::memory_order_acquire) == 0 &&
+            if (!sh.proj.empty() && !sh.proj_fl[sh.proj_gen].busy() &&
                 ((int)sh.proj.size() >= expected || now - sh.proj_newest_ns >= quiet_ns() || now - sh.proj_oldest_ns >= window_ns() || (int)sh.proj.size() >= kTableEntries)) proj.swap(sh.proj);
         }
         if (pose.empty() && proj.empty()) {
@@ -194,13 +217,20 @@ void combine(Share& sh, Ticket& mine)
         bool ok;
         { std::lock_guard<std::mutex> lock(sh.m); ok = share_init(sh); }
         if (!pose.empty()) {
-            hipStream_t s = sh.s_pose;
+            const bool second = pose_second;                 // (s_pose2 is idle then: pose_free)
+            hipStream_t s = second ? sh.s_pose2 : sh.s_pose;
+            int& gen = second ? sh.pose2_gen : sh.pose_gen;
+            gen ^= 1;
+            InFlight& fl = second ? sh.pose2_fl[gen] : sh.pose_fl[gen];
+            if (pose.size() > 64) { std::lock_guard<std::mutex> lock(sh.m); sh.pose.insert(sh.pose.begin(), pose.begin() + 64, pose.end()); pose.resize(64); }      // (more than 64 sessions: the rest with the next batch)
             std::vector<LpPoseReq> reqs(pose.size());
             for (size_t i = 0; i < pose.size(); ++i) reqs[i] = pose[i].req;
+            fl.n = 0;
+            for (size_t i = 0; i < pose.size(); ++i) { fl.flag[i] = pose[i].flag; fl.seq[i] = pose[i].req.seq; fl.owner_done[i].store(0, std::memory_order_relaxed); }
             const bool launched = ok && lp_launch_pose_batch(s, reqs.data(), (int)reqs.size()) == LPSLAM_HIP_OK;
             if (share_trace()) fprintf(stderr, "share %.3f pose %d\n", 1e-6 * (double)(now_ns() % 100000000000ll), (int)pose.size());
-            if (launched) { sh.pose_busy.store((int)pose.size(), std::memory_order_release); sh.in_flight.fetch_add((int)pose.size()); }
-            for (auto& p : pose) { p.t->stream = s; p.t->busy = launched ? &sh.pose_busy : nullptr; p.t->state.store(launched ? T_LAUNCHED : T_FAILED, std::memory_order_release); }
+            if (launched) { fl.n = (int)pose.size(); sh.in_flight.fetch_add((int)pose.size()); }
+            for (size_t i = 0; i < pose.size(); ++i) { auto& p = pose[i]; p.t->stream = s; p.t->owner_done = launched ? &fl.owner_done[i] : nullptr; p.t->state.store(launched ? T_LAUNCHED : T_FAILED, std::memory_order_release); }
             sh.requests.fetch_add((long)pose.size()); sh.batches.fetch_add(1);
         }
         if (!proj.empty()) {
@@ -209,6 +239,11 @@ void combine(Share& sh, Ticket& mine)
             for (int k = 0; ok && k < kTableBlocks && blk < 0; ++k) { const int b = (int)((sh.table_next + k) % kTableBlocks); if (sh.table_users[b].load(std::memory_order_acquire) == 0) blk = b; }
             bool launched = false;
             hipStream_t s = sh.s_proj;
+            if (proj.size() > (size_t)kTableEntries) { std::lock_guard<std::mutex> lock(sh.m); sh.proj.insert(sh.proj.begin(), proj.begin() + kTableEntries, proj.end()); proj.resize((size_t)kTableEntries); }
+            sh.proj_gen ^= 1;
+            InFlight& fl = sh.proj_fl[sh.proj_gen];
+            fl.n = 0;
+            for (size_t i = 0; i < proj.size(); ++i) { fl.flag[i] = proj[i].req.done_flag; fl.seq[i] = proj[i].req.done_seq; fl.owner_done[i].store(0, std::memory_order_relaxed); }
             if (blk >= 0) {
                 sh.table_next = (unsigned)blk + 1;
                 LpProjReq* tab = sh.table + (size_t)blk * kTableEntries;
@@ -219,9 +254,10 @@ void combine(Share& sh, Ticket& mine)
                 if (share_trace()) fprintf(stderr, "share %.3f proj %d\n", 1e-6 * (double)(now_ns() % 100000000000ll), (int)proj.size());
                 if (!launched) sh.table_users[blk].store(0, std::memory_order_release);
             }
-            if (launched) { sh.proj_busy.store((int)proj.size(), std::memory_order_release); sh.in_flight.fetch_add((int)proj.size()); }
-            for (auto& p : proj) {
-                p.t->stream = s; p.t->table_users = launched ? &sh.table_users[blk] : nullptr; p.t->busy = launched ? &sh.proj_busy : nullptr;
+            if (launched) { fl.n = (int)proj.size(); sh.in_flight.fetch_add((int)proj.size()); }
+            for (size_t i = 0; i < proj.size(); ++i) {
+                auto& p = proj[i];
+                p.t->stream = s; p.t->table_users = launched ? &sh.table_users[blk] : nullptr; p.t->owner_done = launched ? &fl.owner_done[i] : nullptr;
                 p.t->state.store(launched ? T_LAUNCHED : T_FAILED, std::memory_order_release);
             }
             sh.requests.fetch_add((long)proj.size()); sh.batches.fetch_add(1);
@@ -254,7 +290,7 @@ int wait_request(Share& sh, Ticket& t, int* flag, int seq, const char* what)
         }
     }
     sh.in_flight.fetch_sub(1);
-    if (t.busy) t.busy->fetch_sub(1, std::memory_order_release);
+    if (t.owner_done) t.owner_done->store(1, std::memory_order_release);
     if (t.table_users) t.table_users->fetch_sub(1, std::memory_order_release);
     return rc;
 }
@@ -488,7 +524,7 @@ int lp_share_pose(lpslam_hip_ctx* c, const LpPoseReq& r, int* flag)
         const int64_t now = now_ns();
         if (sh->pose.empty()) sh->pose_oldest_ns = now;
         sh->pose_newest_ns = now;
-        sh->pose.push_back(PendingPose{r, &t});
+        sh->pose.push_back(PendingPose{r, &t, flag});
     }
     return wait_request(*sh, t, flag, r.seq, "pose optimiser");
 }
