@@ -172,6 +172,10 @@ __global__ __launch_bounds__(1024) void k_pyr_bands(uint8_t* __restrict__ pyr, s
   }
 }
 
+// (Measured and dropped, round 6: the SEPARABLE form -- every source row of a chunk of output rows resampled horizontally once into LDS
+// as 16-bit r >> 4, the vertical pass reading its two rows from there, the level's tables staged beside them: same bytes, 0.179 ms per
+// 32-image step on half of the chip against 0.164 for the direct form above (0.237 with the tables read through the cache).  Half the
+// resampling arithmetic, but two workgroup barriers and an LDS round trip per chunk; the direct form has no barrier inside a level.)
 // ------------------------------------------------------------------------------------------------------------
 // K2  FAST-9/16 + score + 3x3 NMS per 64-px cell (cv::FAST on the cell sub-image, ini threshold then min threshold)
 //     One 256-thread workgroup per cell; the (64+6)^2 tile is staged in LDS with aligned dword loads.
