@@ -106,6 +106,7 @@ struct BaView {                       // one problem, resident in device memory 
     GPTR(double) xp; GPTR(double) chi_pose; GPTR(double) part; GPTR(double) scal;
     GPTR(const int) blk_start; GPTR(const int4) blk_terms;        // Schur pair lists: (observation a, observation b, their landmark, -)
     GPTR(double) blk_part; GPTR(int) blk_ticket;                  // Schur partial sums [block][4][36], per-block tickets
+    GPTR(int) blk_perm;                                           // k_ba_schur: which pose-block pair work item w takes (XCD tiles, see lpslam_hip_ba_prepare)
     GPTR(BaCtl) ctl; GPTR(lpslam_hip_ba_iter_log) log;
     BaCam cam;
     // block-banded windows (ba_band.inl): block half-bandwidth of the reduced system when the problem takes the band path (-1: pair
@@ -957,7 +958,7 @@ __global__ __launch_bounds__(64) void k_ba_schur(const BaView* __restrict__ view
     // Items [0, n_blocks) are part 0 of every block, items n_blocks + 3 blk + (part - 1) the further parts: no work table, the
     // number of parts follows from the length of the block's list (a surplus item exits here).
     const int nblk = v.n_blocks;
-    const int blk = bx < nblk ? bx : (bx - nblk) / 3;
+    const int blk = bx < nblk ? v.blk_perm[bx] : (bx - nblk) / 3;
     const int part_id = bx < nblk ? 0 : 1 + (bx - nblk) % 3;
     const int n_terms = v.blk_start[blk + 1] - v.blk_start[blk];
     const int parts = min(4, max(1, (n_terms + 255) / 256));
@@ -2903,6 +2904,7 @@ int lpslam_hip_ba_prepare(lpslam_hip_ctx* ctx, const double* poses, const uint8_
     const size_t o_obs_in = cv.take(no * sizeof(lpslam_hip_ba_obs));
     const size_t n_ord = plan.order.size(), n_grp = plan.groups.size() / BD_REC;
     const size_t o_land_start = cv.take(land_start.size() * 4);
+    const size_t o_blk_perm = cv.take(nblk * 4);
     const size_t o_band_tab = cv.take((BD_REC * n_grp + 2 * nfree) * 4), o_band_order = cv.take(n_ord * 4), o_band_qinfo = cv.take(n_ord * 4), o_band_bstart = cv.take((n_ord + 1) * 4);
     const size_t staged_bytes = cv.off;                 // what the copy kernel moves: [0, staged_bytes)
     const size_t o_descs = cv.take(BUILD_MAX_BATCH * sizeof(BuildDesc));      // descriptors of a batched build led by this problem (device: here; host: same offset of the staging block)
@@ -2967,6 +2969,7 @@ int lpslam_hip_ba_prepare(lpslam_hip_ctx* ctx, const double* poses, const uint8_
     vset(v.xp, (double*)(base + o_xp)); vset(v.chi_pose, (double*)(base + o_chipose)); vset(v.part, (double*)(base + o_part)); vset(v.scal, b->d_scal);
     vset(v.blk_start, (const int*)(base + o_blk_start)); vset(v.blk_terms, (const int4*)(base + o_terms));
     vset(v.blk_part, (double*)(base + o_blk_part)); vset(v.blk_ticket, (int*)(base + o_ticket));
+    vset(v.blk_perm, (const int*)(base + o_blk_perm));
     b->d_ctl = (BaCtl*)(base + o_ctl); b->d_log = (lpslam_hip_ba_iter_log*)(base + o_log);
     vset(v.ctl, b->d_ctl); vset(v.log, b->d_log);
     v.cam = BaCam{cam->fx, cam->fy, cam->cx, cam->cy, cam->focal_x_baseline, cam->huber_mono, cam->huber_stereo};
@@ -2986,6 +2989,31 @@ int lpslam_hip_ba_prepare(lpslam_hip_ctx* ctx, const double* poses, const uint8_
     if (b->n_free) memcpy(hs + o_free, free_pose.data(), (size_t)b->n_free * 4);
     if (n_obs) memcpy(hs + o_obs_in, obs, (size_t)n_obs * sizeof(lpslam_hip_ba_obs));
     memcpy(hs + o_land_start, land_start.data(), land_start.size() * 4);
+    {
+        // k_ba_schur's work item w (part 0 of a pose-block pair) runs on XCD (lead + w) mod 8 -- workgroups go round the XCDs -- and every
+        // XCD has an L2 of its own: with the pairs in row-major order each L2 fetched all of W (50.7 MB per launch for 5.76 MB of W,
+        // profiles/r05c_pmc.json).  The free keyframes are cut into four groups and the ten group pairs dealt to the eight XCDs (six
+        // off-diagonal tiles one each, the four diagonal tiles two to an XCD): an XCD's pairs then touch the W blocks of two groups, half
+        // of the window.  Any assignment is valid (every pair is taken once); batched launches place problems, not pairs, on XCDs.
+        std::vector<int> perm((size_t)nblk, 0);
+        const int N = b->n_free, nb_ = b->n_blocks;
+        static const bool tiles = [] { const char* e = getenv("LPSLAM_HIP_BA_SCHUR_TILES"); return !e || atoi(e) != 0; }();
+        if (nb_ > 0) {
+            std::vector<std::vector<int>> of_xcd(8);
+            auto grp = [N](int i) { return std::min(3, i * 4 / std::max(N, 1)); };
+            static const int tile_xcd[4][4] = {{6, 0, 1, 2}, {0, 6, 3, 4}, {1, 3, 7, 5}, {2, 4, 5, 7}};
+            int blk = 0;
+            for (int i = 0; i < N; ++i) for (int k = i; k < N; ++k, ++blk) of_xcd[tiles && N >= 16 ? (size_t)tile_xcd[grp(i)][grp(k)] : (size_t)(blk & 7)].push_back(blk);
+            const int lead = n_poses * SPLIT;
+            std::vector<size_t> at(8, 0);
+            for (int w = 0; w < nb_; ++w) {
+                size_t x = (size_t)((lead + w) & 7);
+                if (at[x] >= of_xcd[x].size()) { size_t best = 0, left = 0; for (size_t y = 0; y < 8; ++y) if (of_xcd[y].size() - at[y] > left) { left = of_xcd[y].size() - at[y]; best = y; } x = best; }      // its own tile is used up: from the fullest
+                perm[(size_t)w] = of_xcd[x][at[x]++];
+            }
+        }
+        memcpy(hs + o_blk_perm, perm.data(), nblk * 4);
+    }
     if (plan.hbw >= 0) {
         memcpy(hs + o_band_tab, plan.groups.data(), plan.groups.size() * 4);
         memcpy(hs + o_band_tab + BD_REC * n_grp * 4, plan.glo.data(), plan.glo.size() * 4);
@@ -3063,7 +3091,7 @@ int lpslam_hip_ba_build_batch(lpslam_hip_ba* const* ps, int32_t n)
         if (mx_obs) {
             hipLaunchKernelGGL(k_bs_scatter, dim3(blocks(mx_obs), m), B256, 0, s, d_descs);
             hipLaunchKernelGGL(k_bs_gather, dim3(blocks(mx_obs), m), B256, 0, s, d_descs);
-            hipLaunchKernelGGL(k_bs_ptfill, dim3(blocks(mx_points), m), B256, 0, s, d_descs);
+            hipLaunchKernelGGL(k_bs_ptfill, dim3(blocks(4L * mx_points), m), B256, 0, s, d_descs);      // four lanes per landmark
             hipLaunchKernelGGL(k_bs_csrcopy, dim3(blocks(mx_obs), m), B256, 0, s, d_descs);
         }
         hipLaunchKernelGGL(k_bs_paircount, dim3((unsigned)std::max((mx_blocks + 3) / 4, 1), m), B256, 0, s, d_descs);

@@ -173,31 +173,40 @@ __global__ __launch_bounds__(256) void k_bs_gather(const BuildDesc* __restrict__
     d.o_active[s] = 1; d.act_in[s] = 1;
 }
 
-// CSR by landmark: thread per landmark walks the keyframes in order (column of A / R).  Sixteen keyframes' counts and positions are
-// loaded together (coalesced over the landmarks, independent of each other) before the thread's serial placement uses them: the walk
-// was one dependent load pair per keyframe -- 50 memory round trips in a row, 35 us for a 50-keyframe window on 80 wavefronts.
+// CSR by landmark: the keyframes of a landmark in order (column of A / R).  FOUR lanes per landmark, sixteen keyframes each: their
+// counts and positions are loaded together (one round trip for 64 keyframes of a landmark), the lanes' totals meet by two DPP-row
+// exchanges, every lane places its own keyframes' entries.  (One thread per landmark walking all keyframes was a dependent load pair
+// per keyframe: 35 us for a 50-keyframe window on 80 wavefronts; sixteen loads in flight per thread: 25 us; this form: see DESIGN 13.3.)
 __global__ __launch_bounds__(256) void k_bs_ptfill(const BuildDesc* __restrict__ descs)
 {
     const BuildDesc& d = descs[blockIdx.y];
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= d.n_points) return;
+    const int gt = blockIdx.x * 256 + threadIdx.x;
+    const int j = gt >> 2, part = gt & 3;
+    const bool live = j < d.n_points;
     const int* __restrict__ A = d.A; const int* __restrict__ R = d.R; const int* __restrict__ ps_start = d.ps_start;
     int* __restrict__ pt_obs = d.pt_obs;
     const int n_poses = d.n_poses, n_points = d.n_points;
-    int t = d.pt_start[j];
+    int t = live ? d.pt_start[j] : 0;
     constexpr int U = 16;
-    for (int p0 = 0; p0 < n_poses; p0 += U) {
-        int c[U], first[U];
+    for (int p0 = 0; p0 < n_poses; p0 += 4 * U) {          // (uniform trip count: the exchanges below want all four lanes of a landmark)
+        int c[U], first[U], mine = 0;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int p = min(p0 + u, n_poses - 1);
-            const size_t e = (size_t)p * n_points + j;
-            c[u] = p0 + u < n_poses ? (A[e] & 0xFFFF) : 0;
+            const int pp = p0 + U * part + u, p = min(pp, n_poses - 1);
+            const size_t e = (size_t)p * n_points + (live ? j : 0);
+            c[u] = (live && pp < n_poses) ? (A[e] & 0xFFFF) : 0;
             first[u] = ps_start[p] + R[e];
+            mine += c[u];
         }
+        // exclusive prefix over the four lanes of the landmark (neighbours inside a quad)
+        const int s1 = __shfl_xor(mine, 1), s2a = mine + s1;
+        const int s2 = __shfl_xor(s2a, 2);
+        const int before = (part & 1 ? s1 : 0) + (part & 2 ? s2 : 0);
+        int w = t + before;
 #pragma unroll
         for (int u = 0; u < U; ++u)
-            for (int dd = 0; dd < c[u]; ++dd) pt_obs[t++] = first[u] + dd;
+            for (int dd = 0; dd < c[u]; ++dd) pt_obs[w++] = first[u] + dd;
+        t += s2a + s2;                                     // the four lanes' total
     }
 }
 
