@@ -114,6 +114,10 @@ int lpslam_hip_front_end(lpslam_hip_ctx* ctx, int image, int32_t stereo, float f
  * then lpslam_hip_front_end.  A shared front end uploads the frames at the head of its launch chain. */
 int lpslam_hip_front_end_images(lpslam_hip_ctx* ctx, int image, const uint8_t* left, const uint8_t* right, int32_t stride,
                                 float focal_x_baseline, float baseline);
+/* A hint for shared launches: this session will make no more latency-bound requests (window matchers, pose optimisations) for the frame
+ * it collected with lpslam_hip_get_frame / _view -- the other sessions' requests stop waiting for it.  Optional; a tracker calls it
+ * when the frame's pose is final, before its keyframe work. */
+int lpslam_hip_frame_done(lpslam_hip_ctx* ctx);
 int lpslam_hip_shared_front_end_counters(int32_t device, int64_t* batches, int64_t* requests);
 int lpslam_hip_shared_solve_counters(int32_t device, int64_t* batches, int64_t* requests);
 int lpslam_hip_sync(lpslam_hip_ctx* ctx);

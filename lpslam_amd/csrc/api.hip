@@ -1353,6 +1353,7 @@ static int frame_collect(lpslam_hip_ctx* c, int image, int fields, uint8_t** blo
     memcpy(&n, st, sizeof(n));
     if ((size_t)image < c->h_kp_valid.size()) { c->h_kp_count[(size_t)image] = n; c->h_kp_valid[(size_t)image] = 1; }
     *block = st;
+    lp_share_frame(c, 1);                                // the session has its frame: its matcher and pose-optimiser requests are about to come (share.hip)
     return LPSLAM_HIP_OK;
 }
 

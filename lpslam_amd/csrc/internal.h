@@ -246,6 +246,7 @@ enum { LP_SHARE_DONE = 0, LP_SHARE_DIRECT = 1 };        // (negative: minus an L
 int lp_share_pose(lpslam_hip_ctx* c, const LpPoseReq& r, int* flag);
 int lp_share_proj(lpslam_hip_ctx* c, const LpProjReq& r);
 void lp_share_forget(lpslam_hip_ctx* c);                // the context is being destroyed
+void lp_share_frame(lpslam_hip_ctx* c, int inside);     // the session has collected a frame (1) / will make no more latency-bound requests for it (0)
 // The four role streams of a device (made and probed at the first call): [0] pose batches, [1] matcher batches = a session's main
 // stream, [2] front-end chains = a session's prefetch stream, [3] the windows' solves = a session's bundle-adjustment stream.  The
 // sessions of a pool own NO stream: whatever they enqueue goes to the role stream of its kind, so N sessions keep four hardware queues

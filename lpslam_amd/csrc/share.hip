@@ -52,6 +52,7 @@ struct Share {
     std::atomic<int> in_flight{0};                      // requests launched whose callers have not seen them complete
     std::atomic<int64_t> last_ns[kMaxSessions];         // per session: its last request (0: free entry)
     std::atomic<int> n_sessions{0};                     // high-water mark of the table
+    std::atomic<int> in_frame[kMaxSessions];            // per session: between the collection of a frame and lpslam_hip_frame_done -- it WILL make the frame's latency-bound requests
     bool ready = false, broken = false;
     // The streams of the shared launches, one per ROLE, each on a hardware queue of its own (lp_share_streams): the pose optimiser's
     // batches, the matchers' batches, the front-end chains (the pool context's stream), the windows' solves.
@@ -77,7 +78,7 @@ struct Share {
     std::atomic<int> solve_in_flight{0};
     std::atomic<int64_t> solve_last_ns[kMaxSessions];
     std::atomic<long> solve_batches{0}, solve_requests{0};
-    Share() { for (auto& x : last_ns) x.store(0); for (auto& x : fe_last_ns) x.store(0); for (auto& x : solve_last_ns) x.store(0); for (auto& x : table_users) x.store(0); }
+    Share() { for (auto& x : in_frame) x.store(0); for (auto& x : last_ns) x.store(0); for (auto& x : fe_last_ns) x.store(0); for (auto& x : solve_last_ns) x.store(0); for (auto& x : table_users) x.store(0); }
 };
 Share g_share[kMaxDevices];
 
@@ -92,6 +93,7 @@ int share_mode()
 int env_us(const char* name, int dflt) { const char* e = getenv(name); return e ? std::max(atoi(e), 0) : dflt; }
 int64_t window_ns() { static const int64_t v = 1000ll * env_us("LPSLAM_HIP_SHARE_WINDOW_US", 30); return v; }
 int64_t pose_quiet_ns() { static const int64_t v = 1000ll * env_us("LPSLAM_HIP_SHARE_POSE_QUIET_US", 2); return v; }      // (a pose batch runs ~110 us: a request that just misses one waits that long)
+int64_t frame_window_ns() { static const int64_t v = 1000ll * env_us("LPSLAM_HIP_SHARE_FRAME_WINDOW_US", 25); return v; }      // how long a request waits for a session that is inside its frame and has not asked yet
 int64_t quiet_ns() { static const int64_t v = 1000ll * env_us("LPSLAM_HIP_SHARE_QUIET_US", 2); return v; }
 int64_t fe_window_ns() { static const int64_t v = 1000ll * env_us("LPSLAM_HIP_SHARE_FE_WINDOW_US", 300); return v; }
 int64_t fe_quiet_ns() { static const int64_t v = 1000ll * env_us("LPSLAM_HIP_SHARE_FE_QUIET_US", 40); return v; }
@@ -200,14 +202,20 @@ void combine(Share& sh, Ticket& mine)
         {
             std::lock_guard<std::mutex> lock(sh.m);
             if (sh.pose.empty() && sh.proj.empty()) return;
-            const int expected = std::max(1, active_sessions(sh, now) - sh.in_flight.load(std::memory_order_relaxed));
+            // Who is still to come?  Sessions that say where they are in their frame (lpslam_hip_get_frame_view ... lpslam_hip_frame_done) are
+            // waited for while they are inside it and have no request in flight -- up to `frame_window`; without such hints: every session
+            // that made a request lately, and then only for `quiet` (a session in its keyframe work or waiting for its frame is not coming).
+            int framed = 0;
+            { const int hi = sh.n_sessions.load(std::memory_order_relaxed); for (int i = 0; i < hi; ++i) framed += sh.in_frame[i].load(std::memory_order_relaxed); }
+            const int expected = std::max(1, (framed ? framed : active_sessions(sh, now)) - sh.in_flight.load(std::memory_order_relaxed));
+            const int64_t pose_q = framed ? frame_window_ns() : pose_quiet_ns(), proj_q = framed ? frame_window_ns() : quiet_ns();
             const bool pose1_free = !sh.pose_fl[sh.pose_gen].busy();
             const bool pose_free = pose1_free || (sh.s_pose2 && !sh.pose2_fl[sh.pose2_gen].busy());
             pose_second = !pose1_free;
             if (!sh.pose.empty() && pose_free &&
-                ((int)sh.pose.size() >= expected || now - sh.pose_newest_ns >= pose_quiet_ns() || now - sh.pose_oldest_ns >= window_ns())) pose.swap(sh.pose);
+                ((int)sh.pose.size() >= expected || now - sh.pose_newest_ns >= pose_q || now - sh.pose_oldest_ns >= window_ns())) pose.swap(sh.pose);
             if (!sh.proj.empty() && !sh.proj_fl[sh.proj_gen].busy() &&
-                ((int)sh.proj.size() >= expected || now - sh.proj_newest_ns >= quiet_ns() || now - sh.proj_oldest_ns >= window_ns() || (int)sh.proj.size() >= kTableEntries)) proj.swap(sh.proj);
+                ((int)sh.proj.size() >= expected || now - sh.proj_newest_ns >= proj_q || now - sh.proj_oldest_ns >= window_ns() || (int)sh.proj.size() >= kTableEntries)) proj.swap(sh.proj);
         }
         if (pose.empty() && proj.empty()) {
             if (mine.state.load(std::memory_order_acquire) != T_PENDING) return;
@@ -544,16 +552,33 @@ int lp_share_proj(lpslam_hip_ctx* c, const LpProjReq& r)
     return wait_request(*sh, t, r.done_flag, r.done_seq, "window matcher");
 }
 
+void lp_share_frame(lpslam_hip_ctx* c, int inside)
+{
+    if (!c || !c->sess_pool || share_mode() == 0 || c->cfg.device < 0 || c->cfg.device >= kMaxDevices) return;
+    Share& sh = g_share[c->cfg.device];
+    if (c->share_slot < 0 && (!inside || !touch_session(sh, c, now_ns()))) return;
+    static const bool off = getenv("LPSLAM_HIP_SHARE_NO_FRAME_HINTS") != nullptr;      // measurements
+    if (!off) sh.in_frame[c->share_slot].store(inside ? 1 : 0, std::memory_order_relaxed);
+}
+
 void lp_share_forget(lpslam_hip_ctx* c)
 {
     if (!c || c->share_slot < 0 || c->cfg.device < 0 || c->cfg.device >= kMaxDevices) return;
     lp_share_front_end_collected(c);
+    g_share[c->cfg.device].in_frame[c->share_slot].store(0);
     g_share[c->cfg.device].fe_last_ns[c->share_slot].store(0);
     g_share[c->cfg.device].last_ns[c->share_slot].store(0);
     c->share_slot = -1;
 }
 
 extern "C" {
+
+int lpslam_hip_frame_done(lpslam_hip_ctx* c)
+{
+    if (!c) { set_error("null context"); return LPSLAM_HIP_ERR_INVALID; }
+    lp_share_frame(c, 0);
+    return LPSLAM_HIP_OK;
+}
 
 int lpslam_hip_set_shared_launches(int32_t mode)
 {

@@ -36,7 +36,7 @@ SYMBOLS = [
     "lpslam_hip_match_stereo", "lpslam_hip_match_stereo_strided", "lpslam_hip_get_stereo",
     "lpslam_hip_vocab_create", "lpslam_hip_vocab_destroy", "lpslam_hip_vocab_info", "lpslam_hip_bow_transform", "lpslam_hip_bow_transform_host", "lpslam_hip_match_bow_tree", "lpslam_hip_match_bow_tree_multi",
     "lpslam_hip_match_projection", "lpslam_hip_match_fuse", "lpslam_hip_match_area", "lpslam_hip_match_orientation_filter",
-    "lpslam_hip_ba_create", "lpslam_hip_ba_prepare", "lpslam_hip_ba_build_batch", "lpslam_hip_ba_destroy", "lpslam_hip_ba_set_active", "lpslam_hip_ba_optimize", "lpslam_hip_ba_optimize_begin", "lpslam_hip_ba_optimize_end", "lpslam_hip_ba_graph_replays", "lpslam_hip_ba_wg_factorisations", "lpslam_hip_pose_optimize_passes", "lpslam_hip_match_bf_descriptors", "lpslam_hip_prefetch_frame", "lpslam_hip_get_frame_view", "lpslam_hip_desc_store_put", "lpslam_hip_desc_store_drop", "lpslam_hip_match_bf_stored", "lpslam_hip_ba_set_state_batch", "lpslam_hip_ba_get_batch", "lpslam_hip_ba_get_solver", "lpslam_hip_ba_set_solver", "lpslam_hip_ba_timeouts", "lpslam_hip_ba_counters", "lpslam_hip_set_shared_launches", "lpslam_hip_shared_launch_counters", "lpslam_hip_create_session", "lpslam_hip_front_end", "lpslam_hip_front_end_images", "lpslam_hip_shared_front_end_counters", "lpslam_hip_shared_solve_counters", "lpslam_hip_ba_local_window",
+    "lpslam_hip_ba_create", "lpslam_hip_ba_prepare", "lpslam_hip_ba_build_batch", "lpslam_hip_ba_destroy", "lpslam_hip_ba_set_active", "lpslam_hip_ba_optimize", "lpslam_hip_ba_optimize_begin", "lpslam_hip_ba_optimize_end", "lpslam_hip_ba_graph_replays", "lpslam_hip_ba_wg_factorisations", "lpslam_hip_pose_optimize_passes", "lpslam_hip_match_bf_descriptors", "lpslam_hip_prefetch_frame", "lpslam_hip_get_frame_view", "lpslam_hip_desc_store_put", "lpslam_hip_desc_store_drop", "lpslam_hip_match_bf_stored", "lpslam_hip_ba_set_state_batch", "lpslam_hip_ba_get_batch", "lpslam_hip_ba_get_solver", "lpslam_hip_ba_set_solver", "lpslam_hip_ba_timeouts", "lpslam_hip_ba_counters", "lpslam_hip_set_shared_launches", "lpslam_hip_shared_launch_counters", "lpslam_hip_create_session", "lpslam_hip_front_end", "lpslam_hip_frame_done", "lpslam_hip_front_end_images", "lpslam_hip_shared_front_end_counters", "lpslam_hip_shared_solve_counters", "lpslam_hip_ba_local_window",
     "lpslam_hip_ba_optimize_batch", "lpslam_hip_ba_reset_batch", "lpslam_hip_ba_optimize_profiled", "lpslam_hip_ba_optimize_partitioned", "lpslam_hip_ba_optimize_partitioned_with",
     "lpslam_hip_ba_local", "lpslam_hip_ba_set_points_fixed", "lpslam_hip_ba_pose_optimize", "lpslam_hip_pose_optimize", "lpslam_hip_ba_reset", "lpslam_hip_ba_set_state", "lpslam_hip_prefetch_begin", "lpslam_hip_prefetch_end", "lpslam_hip_prefetch_join", "lpslam_hip_ba_get", "lpslam_hip_ba_chi2", "lpslam_hip_ba_reduced_buffer",
     "lpslam_hip_ba_step_begin", "lpslam_hip_ba_step_lambda0", "lpslam_hip_ba_step_solve", "lpslam_hip_ba_scalar_buffer", "lpslam_hip_ba_step_end", "lpslam_hip_ba_status",

@@ -1982,6 +1982,7 @@ TrackerBase::ProcessImageResult HipVslamTrackerBase::trackFrame(CameraQueueEntry
         if (tracked) {
             int with_local_map = 0;
             if (trackLocalMap(cur, with_local_map)) inliers = with_local_map;      // else: the motion-model result stands
+            (void)lpslam_hip_frame_done(m_ctx);            // the frame's pose is final: other sessions' shared launches need not wait for this one
             for (int id : cur.landmark) if (id >= 0) { auto it = m_landmarks.find(id); if (it != m_landmarks.end()) ++it->second.n_observed; }      // inliers of the final pose optimisation
             lap(m_stats.t_local);
             // velocity = T_cur * T_prev^-1
@@ -2004,6 +2005,7 @@ TrackerBase::ProcessImageResult HipVslamTrackerBase::trackFrame(CameraQueueEntry
             m_lastGoodPose = cur.pose;
             m_prev = std::move(cur);
         } else {
+            (void)lpslam_hip_frame_done(m_ctx);
             finishMapping();
             m_haveMonoRef = false;
             m_state = TrackerState::Lost;
@@ -2018,6 +2020,7 @@ TrackerBase::ProcessImageResult HipVslamTrackerBase::trackFrame(CameraQueueEntry
             m_haveVelocity = false;
         }
     }
+    (void)lpslam_hip_frame_done(m_ctx);                  // (the branches that do not track: initialisation, relocalisation)
     m_lastFrameSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     m_stats.t_total += m_lastFrameSeconds;
     if (m_state == TrackerState::Tracking) {
