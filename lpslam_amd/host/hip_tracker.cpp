@@ -1428,7 +1428,29 @@ bool HipVslamTrackerBase::detectAndCloseLoop(FrameData& cur, int c)
         std::unordered_map<int, char> exclude = covis;
         exclude[c] = 1;
         cands.clear();
-        for (auto& sc : m_bowDb.query(kc.bow, exclude, min_score, newest_candidate)) { cands.emplace_back(-sc.first, sc.second); if (cands.size() >= 8) break; }
+        // [UPSTREAM] data::bow_database::acquire_loop_candidates, last two steps (ORB-SLAM's DetectLoopCandidates): a candidate's score is
+        // ACCUMULATED over its covisibility group -- itself plus those of its ten best covisible keyframes that are candidates too -- the
+        // group is represented by its best-scoring member, and the groups whose total reaches 0.75 of the best total are kept.
+        const auto scored = m_bowDb.query(kc.bow, exclude, min_score, newest_candidate);
+        std::unordered_map<int, double> score_of;
+        for (auto& sc : scored) score_of[sc.second] = sc.first;
+        std::vector<std::pair<double, int>> groups;            // (accumulated score, best keyframe of the group)
+        double best_total = 0;
+        for (auto& sc : scored) {
+            double total = sc.first, best_sc = sc.first;
+            int best_kf = sc.second;
+            for (int nb : covisible(sc.second, 10, 15)) {
+                auto it = score_of.find(nb);
+                if (it == score_of.end()) continue;
+                total += it->second;
+                if (it->second > best_sc) { best_sc = it->second; best_kf = nb; }
+            }
+            groups.emplace_back(total, best_kf);
+            best_total = std::max(best_total, total);
+        }
+        std::unordered_map<int, char> kept;
+        std::sort(groups.begin(), groups.end(), [](const std::pair<double, int>& a, const std::pair<double, int>& b) { return a.first != b.first ? a.first > b.first : a.second > b.second; });
+        for (auto& g : groups) if (g.first > 0.75 * best_total && !kept.count(g.second)) { kept[g.second] = 1; cands.emplace_back(-g.first, g.second); }
         if (cands.empty()) { m_loopSets.clear(); return false; }
     }
     // [UPSTREAM] loop_detector::find_continuously_detected_keyframe_sets (min_continuity_ = 3; ORB-SLAM's covisibility consistency,
