@@ -2252,108 +2252,9 @@ __device__ __forceinline__ void po_reduce28_wn(const double (&acc)[PO_NV], doubl
     for (int i = 0; i < PO_NV; ++i) sums[i] = out[i];
 }
 
-// The 28 sums of a pass on the matrix cores.  Every observation row (two or three per observation) is a vector
-// R8 = (B[0..5], 0, [first row]) and L8 = (w B[0..5], -w e, [first row] c): G = sum over the rows of L8 R8^T holds H = B^T w B in
-// G[a][c] (a, c < 6), b in G[6][.] and the robustified chi2 in G[7][7].  v_mfma_f64_16x16x4 contracts FOUR rows per instruction for a
-// 16 x 16 result; two independent 8-vectors ride in the 16 (rows 8 m + 4 g + k of the wavefront, g = 0, 1), their sums are the two
-// diagonal 8 x 8 blocks: 24 instructions take the 192 rows of 64 observations, and the contraction IS the reduction over the
-// observations -- the lanes' 28 partial sums and their tree through LDS are gone.  Lanes write their rows (R8 and w, -w e, c: 11 doubles
-// a row) into LDS; lane (i, k) of the 16 x 4 operand layout reads component i mod 8 of row 8 m + 4 (i / 8) + k.
-constexpr int PO_MF_ROW = 11, PO_MF_OBS = 3 * PO_MF_ROW;
-template <int W>
-__device__ __forceinline__ void po_pass_mfma(const BaCam& cam, const double (&p7)[7], const lpslam_hip_ba_obs& o, const double (&X)[3], bool act, int robust,
-                                             double* mf, double* outp, double (&sums)[PO_NV])
-{
-#pragma clang fp contract(fast)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    double rows[3][PO_MF_ROW];
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int k = 0; k < PO_MF_ROW; ++k) rows[r][k] = 0.0;
-    if (act) {
-        double R[9];
-        po_unit_quat_to_rot(p7, R);
-        const double t[3] = {p7[4], p7[5], p7[6]};
-        double e[3], pc[3], B[3][6], iz;
-        const int D = po_residual(cam, R, t, X, o, e, pc, &iz);
-        const double om = o.inv_sigma2;
-        const double chi = om * (e[0] * e[0] + e[1] * e[1] + (D == 3 ? e[2] * e[2] : 0.0));
-        const double delta = D == 3 ? cam.hub_stereo : cam.hub_mono;
-        double w = om, c = chi;
-        if (robust && delta > 0) { double r0, r1; po_huber(chi, delta, &r0, &r1); w *= r1; c = r0; }
-        po_jacobian(cam, pc, iz, D, B);
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-#pragma unroll
-            for (int k = 0; k < 6; ++k) rows[r][k] = B[r][k];
-            rows[r][8] = (r < D) ? w : 0.0; rows[r][9] = (r < D) ? -w * e[r] : 0.0;
-        }
-        rows[0][7] = 1.0; rows[0][10] = c;
-    }
-    {
-        double* dst = mf + (size_t)tid * PO_MF_OBS;
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int k = 0; k < PO_MF_ROW; ++k) dst[r * PO_MF_ROW + k] = rows[r][k];
-    }
-    __syncthreads();
-    const int lr = lane & 15, lk = lane >> 4, a = lr & 7, g = lr >> 3;
-    const double* base = mf + (size_t)(wave * 64) * PO_MF_OBS + (4 * g + lk) * PO_MF_ROW;
-    const int xoff = a < 6 ? 8 : (a == 6 ? 9 : 10);
-    // (all operands first -- 48 LDS reads in flight together -- then two accumulator chains: a dependent v_mfma_f64 waits ~40 cycles for its predecessor)
-    double rvs[24], avs[24];
-#pragma unroll
-    for (int m = 0; m < 24; ++m) {
-        const double* rp = base + 8 * m * PO_MF_ROW;
-        rvs[m] = rp[a];
-        avs[m] = rp[xoff];
-    }
-#pragma unroll
-    for (int m = 0; m < 24; ++m) avs[m] = a < 6 ? avs[m] * rvs[m] : avs[m];
-    f64x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
-#pragma unroll
-    for (int m = 0; m < 24; m += 2) {
-        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(avs[m], rvs[m], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(avs[m + 1], rvs[m + 1], acc1, 0, 0, 0);
-    }
-    const f64x4 acc = acc0 + acc1;
-    // lane (lr, lk) holds rows lk + 4 q of column lr: block (0, 0) is rows 0-7 of lanes lr < 8 (q = 0, 1), block (1, 1) rows 8-15 of lanes lr >= 8 (q = 2, 3)
-    const double p2 = __shfl_xor(acc[2], 8), p3 = __shfl_xor(acc[3], 8);
-    if (lr < 8) {
-        outp[wave * 64 + lk * 8 + lr] = acc[0] + p2;
-        outp[wave * 64 + (lk + 4) * 8 + lr] = acc[1] + p3;
-    }
-    __syncthreads();
-    int idx = 0;
-#pragma unroll
-    for (int i = 0; i < 6; ++i)
-#pragma unroll
-        for (int j = i; j < 6; ++j) {
-            double v = outp[i * 8 + j];
-#pragma unroll
-            for (int w2 = 1; w2 < W; ++w2) v += outp[w2 * 64 + i * 8 + j];
-            sums[idx++] = v;
-        }
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        double v = outp[6 * 8 + i];
-#pragma unroll
-        for (int w2 = 1; w2 < W; ++w2) v += outp[w2 * 64 + 6 * 8 + i];
-        sums[21 + i] = v;
-    }
-    {
-        double v = outp[7 * 8 + 7];
-#pragma unroll
-        for (int w2 = 1; w2 < W; ++w2) v += outp[w2 * 64 + 7 * 8 + 7];
-        sums[27] = v;
-    }
-}
-
 // (a device function: the launch is k_pose_optimize_req below -- one workgroup per request of a batch, the same code whether the batch
 // holds one tracker's frame or the pending frames of every session of the process, so shared and unshared results are the same bits)
-template <int W, bool MF>
+template <int W>
 __device__ __forceinline__ void po_wn_body(double* pose7, const PoObs* packed, int n, const BaCam& cam, uint8_t* outlier, int* n_inliers, int* done_flag, int seq,
                                            double* tr, double* out28, PoObs* cache, int (*s_bad)[4])
 {
@@ -2384,7 +2285,6 @@ __device__ __forceinline__ void po_wn_body(double* pose7, const PoObs* packed, i
     double po_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, po_last = (double)clock64();
 #endif
     auto pass = [&](const double (&p7)[7], int robust, double (&sums)[PO_NV]) __attribute__((always_inline)) {
-        if (MF) { po_pass_mfma<W>(cam, p7, o, X, act, robust, tr, out28, sums); PO_STAMP(2); return; }
         double R[9];
         po_unit_quat_to_rot(p7, R);
         const double t[3] = {p7[4], p7[5], p7[6]};
@@ -2502,14 +2402,13 @@ __device__ __forceinline__ void po_wn_body(double* pose7, const PoObs* packed, i
 // it out).  Block pointer, observation count and sequence number come by value; W = 1, 2 or 4 wavefronts work on a request
 // (n <= 64 W), the others of the workgroup leave at once -- a barrier counts the wavefronts that are left.
 constexpr int PO_MAX_BATCH = 32;
-struct PoBatch { uint8_t* blk[PO_MAX_BATCH]; int n[PO_MAX_BATCH]; int seq[PO_MAX_BATCH]; int mfma; };      // mfma: the passes' sums on the matrix cores (po_pass_mfma)
+struct PoBatch { uint8_t* blk[PO_MAX_BATCH]; int n[PO_MAX_BATCH]; int seq[PO_MAX_BATCH]; };
 constexpr size_t PO_BLK_INLIERS = 56, PO_BLK_FLAG = 64, PO_BLK_CAM = 72, PO_BLK_PACKED = 128;
 static_assert(PO_BLK_CAM + sizeof(BaCam) <= PO_BLK_PACKED, "pose-optimiser block header");
 __global__ __launch_bounds__(256) void k_pose_optimize_req(PoBatch b)
 {
-    constexpr int kTr = PO_NV * PO_WN_ROW(4) > 256 * PO_MF_OBS ? PO_NV * PO_WN_ROW(4) : 256 * PO_MF_OBS;
-    __shared__ double tr[kTr];                             // the reduction's transposition array, or the observation rows of po_pass_mfma
-    __shared__ double out28[4 * 64];
+    __shared__ double tr[PO_NV * PO_WN_ROW(4)];
+    __shared__ double out28[32];
     __shared__ PoObs cache[64 * 4];
     __shared__ int s_bad[2][4];                            // outliers per wavefront, double-buffered over the rounds
     const int r = blockIdx.x, n = b.n[r];
@@ -2526,15 +2425,9 @@ __global__ __launch_bounds__(256) void k_pose_optimize_req(PoBatch b)
     uint8_t* outlier = blk + PO_BLK_PACKED + (size_t)(n > 0 ? n : 1) * sizeof(PoObs);
     int* n_inliers = reinterpret_cast<int*>(blk + PO_BLK_INLIERS);
     int* flag = reinterpret_cast<int*>(blk + PO_BLK_FLAG);
-    if (b.mfma) {
-        if (W == 1) po_wn_body<1, true>(pose7, packed, n, cam, outlier, n_inliers, flag, b.seq[r], tr, out28, cache, s_bad);
-        else if (W == 2) po_wn_body<2, true>(pose7, packed, n, cam, outlier, n_inliers, flag, b.seq[r], tr, out28, cache, s_bad);
-        else po_wn_body<4, true>(pose7, packed, n, cam, outlier, n_inliers, flag, b.seq[r], tr, out28, cache, s_bad);
-        return;
-    }
-    if (W == 1) po_wn_body<1, false>(pose7, packed, n, cam, outlier, n_inliers, flag, b.seq[r], tr, out28, cache, s_bad);
-    else if (W == 2) po_wn_body<2, false>(pose7, packed, n, cam, outlier, n_inliers, flag, b.seq[r], tr, out28, cache, s_bad);
-    else po_wn_body<4, false>(pose7, packed, n, cam, outlier, n_inliers, flag, b.seq[r], tr, out28, cache, s_bad);
+    if (W == 1) po_wn_body<1>(pose7, packed, n, cam, outlier, n_inliers, flag, b.seq[r], tr, out28, cache, s_bad);
+    else if (W == 2) po_wn_body<2>(pose7, packed, n, cam, outlier, n_inliers, flag, b.seq[r], tr, out28, cache, s_bad);
+    else po_wn_body<4>(pose7, packed, n, cam, outlier, n_inliers, flag, b.seq[r], tr, out28, cache, s_bad);
 }
 
 #include "ba_update.inl"
@@ -3846,8 +3739,6 @@ int lp_launch_pose_batch(hipStream_t s, const LpPoseReq* reqs, int n)
     for (int i0 = 0; i0 < n; i0 += PO_MAX_BATCH) {
         const int m = std::min(n - i0, (int)PO_MAX_BATCH);
         PoBatch b{};
-        static const int mfma_env = [] { const char* e = getenv("LPSLAM_HIP_PO_MFMA"); return e ? atoi(e) : 0; }();      // measurements: 1 = the passes' sums on the matrix cores
-        b.mfma = mfma_env;
         int n_max = 0;
         for (int i = 0; i < m; ++i) { b.blk[i] = reqs[i0 + i].blk; b.n[i] = reqs[i0 + i].n; b.seq[i] = reqs[i0 + i].seq; n_max = std::max(n_max, reqs[i0 + i].n); }
         const int threads = n_max <= 64 ? 64 : (n_max <= 128 ? 128 : 256);
