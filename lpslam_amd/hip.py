@@ -768,6 +768,19 @@ def ba_obs_array(prob):
     return o
 
 
+def ba_local_window(ctx, poses, fixed, points, obs, cam, first=5, second=10):
+    """a keyframe's local bundle adjustment in one call (lpslam_hip_ba_local_window): returns (poses, points, outlier mask)"""
+    po = np.ascontiguousarray(poses, np.float64).copy(); pt = np.ascontiguousarray(points, np.float64).copy()
+    fx = np.ascontiguousarray(fixed, np.uint8); o = np.ascontiguousarray(obs, BA_OBS_DTYPE)
+    c = BaCamera(cam["fx"], cam["fy"], cam["cx"], cam["cy"], cam["fxb"], float(np.sqrt(5.991)), float(np.sqrt(7.815)))
+    out = np.zeros(max(len(o), 1), np.uint8)
+    f = ctx.lib.lpslam_hip_ba_local_window
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+    _check(f(ctx.h, _p(po), _p(fx), len(po), _p(pt), len(pt), _p(o), len(o), C.byref(c), int(first), int(second), _p(out)))
+    return po, pt, out[:len(o)].astype(bool)
+
+
 def sim3_edges(ei, ej, meas):
     e = np.zeros(len(ei), SIM3_EDGE_DTYPE)
     e["i"] = ei; e["j"] = ej; e["meas"] = meas
