@@ -279,8 +279,10 @@ int wait_request(Share& sh, Ticket& t, int* flag, int seq, const char* what)
 {
     const auto t0 = Clock::now();
     int rc = LP_SHARE_DONE;
+    int64_t t_launched = 0;
     for (int spin = 0; ; ++spin) {
         const int st = t.state.load(std::memory_order_acquire);
+        if (share_trace() && st == T_LAUNCHED && !t_launched) t_launched = now_ns();
         if (st == T_PENDING) {
             if (sh.combiner.try_lock()) {
                 if (t.state.load(std::memory_order_acquire) == T_PENDING) combine(sh, t);
@@ -296,6 +298,10 @@ int wait_request(Share& sh, Ticket& t, int* flag, int seq, const char* what)
             if (hipStreamSynchronize(t.stream) != hipSuccess || __atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) { (void)hipGetLastError(); set_error("%s: the shared launch did not complete", what); rc = -LPSLAM_HIP_ERR_DEVICE; }
             break;
         }
+    }
+    if (share_trace()) {
+        const int64_t t_end = now_ns(), t_beg = std::chrono::duration_cast<std::chrono::nanoseconds>(t0.time_since_epoch()).count();
+        fprintf(stderr, "req %s: to launch %.0f us, launch to done %.0f us\n", what, 1e-3 * (double)((t_launched ? t_launched : t_end) - t_beg), 1e-3 * (double)(t_end - (t_launched ? t_launched : t_end)));
     }
     sh.in_flight.fetch_sub(1);
     if (t.owner_done) t.owner_done->store(1, std::memory_order_release);
