@@ -47,8 +47,8 @@ struct Share {
     std::vector<PendingPose> pose;
     std::vector<PendingProj> proj;
     int64_t pose_oldest_ns = 0, pose_newest_ns = 0, proj_oldest_ns = 0, proj_newest_ns = 0;      // arrival of the oldest / newest pending request of a kind
-    InFlight pose_fl[2], pose2_fl[2], proj_fl[2];       // the batch on each stream (written under the combiner lock); two generations, alternating: an owner's late mark lands in the one that is not current
-    int pose_gen = 0, pose2_gen = 0, proj_gen = 0;
+    InFlight pose_fl[2], proj_fl[2];                    // the batch on each stream (written under the combiner lock); two generations, alternating: an owner's late mark lands in the one that is not current
+    int pose_gen = 0, proj_gen = 0;
     std::atomic<int> in_flight{0};                      // requests launched whose callers have not seen them complete
     std::atomic<int64_t> last_ns[kMaxSessions];         // per session: its last request (0: free entry)
     std::atomic<int> n_sessions{0};                     // high-water mark of the table
@@ -57,7 +57,6 @@ struct Share {
     // The streams of the shared launches, one per ROLE, each on a hardware queue of its own (lp_share_streams): the pose optimiser's
     // batches, the matchers' batches, the front-end chains (the pool context's stream), the windows' solves.
     hipStream_t s_pose = nullptr, s_proj = nullptr, s_front = nullptr, s_solve = nullptr;
-    hipStream_t s_pose2 = nullptr;                      // a second pose stream on a fifth hardware queue, when the process has one (GPU_MAX_HW_QUEUES >= 5)
     int distinct_queues = 0;                            // how many of the four roles got a hardware queue to themselves (diagnostic)
     LpProjReq* table = nullptr;                         // page-locked: kTableBlocks blocks of kTableEntries requests
     std::atomic<int> table_users[kTableBlocks];         // requests of the block's last batch that are not done yet
@@ -139,25 +138,20 @@ bool share_init(Share& sh)                              // sh.m held
     unsigned long long* d_stamps = nullptr;
     unsigned long long h_stamps[2] = {0, 0};
     ok = ok && hipMalloc((void**)&d_stamps, 2 * sizeof(unsigned long long)) == hipSuccess;
-    int picked[5] = {0, -1, -1, -1, -1}, n_picked = ok ? 1 : 0;
+    int picked[4] = {0, -1, -1, -1}, n_picked = ok ? 1 : 0;
     static const bool no_probe = getenv("LPSLAM_HIP_SHARE_NO_PROBE") != nullptr;      // measurements: the first four candidates as they come
-    static const int want = [] { const char* e = getenv("LPSLAM_HIP_SHARE_POSE_STREAMS"); return (e && atoi(e) >= 2) ? 5 : 4; }();
-    for (int i = 1; ok && !no_probe && i < n_cand && n_picked < want; ++i) {
+    for (int i = 1; ok && !no_probe && i < n_cand && n_picked < 4; ++i) {
         bool free_of_all = true;
         for (int k = 0; k < n_picked && free_of_all; ++k) free_of_all = probe_independent(cand[picked[k]], cand[i], d_stamps, h_stamps) && probe_independent(cand[i], cand[picked[k]], d_stamps, h_stamps);
         if (free_of_all) picked[n_picked++] = i;
     }
     sh.distinct_queues = n_picked;
-    const int fifth = n_picked >= 5 ? picked[4] : -1;
-    if (n_picked > 4) n_picked = 4;
     // fewer than four independent candidates (GPU_MAX_HW_QUEUES < 4, or the probe is off): roles share, the latency-critical ones last
     for (int next = 0; n_picked < 4 && ok;) { while (std::find(picked, picked + n_picked, next) != picked + n_picked) ++next; picked[n_picked++] = next < n_cand ? next : 0; }
     if (d_stamps) (void)hipFree(d_stamps);
     if (!ok) { for (int i = 0; i < n_cand; ++i) (void)hipStreamDestroy(cand[i]); (void)hipGetLastError(); sh.broken = true; return false; }
     sh.s_pose = cand[picked[0]]; sh.s_proj = cand[picked[1]]; sh.s_front = cand[picked[2]]; sh.s_solve = cand[picked[3]];
-    if (fifth >= 0) sh.s_pose2 = cand[fifth];
-    else if (getenv("LPSLAM_HIP_SHARE_POSE_ON_MAIN")) sh.s_pose2 = sh.s_proj;      // measurements: every second pose batch on the matchers' stream
-    for (int i = 0; i < n_cand; ++i) if (std::find(picked, picked + 4, i) == picked + 4 && i != fifth) (void)hipStreamDestroy(cand[i]);
+    for (int i = 0; i < n_cand; ++i) if (std::find(picked, picked + 4, i) == picked + 4) (void)hipStreamDestroy(cand[i]);
     sh.ready = true;
     return true;
 }
@@ -197,7 +191,6 @@ void combine(Share& sh, Ticket& mine)
     for (;;) {
         std::vector<PendingPose> pose;
         std::vector<PendingProj> proj;
-        bool pose_second = false;
         const int64_t now = now_ns();
         {
             std::lock_guard<std::mutex> lock(sh.m);
@@ -209,9 +202,7 @@ void combine(Share& sh, Ticket& mine)
             { const int hi = sh.n_sessions.load(std::memory_order_relaxed); for (int i = 0; i < hi; ++i) framed += sh.in_frame[i].load(std::memory_order_relaxed); }
             const int expected = std::max(1, (framed ? framed : active_sessions(sh, now)) - sh.in_flight.load(std::memory_order_relaxed));
             const int64_t pose_q = framed ? frame_window_ns() : pose_quiet_ns(), proj_q = framed ? frame_window_ns() : quiet_ns();
-            const bool pose1_free = !sh.pose_fl[sh.pose_gen].busy();
-            const bool pose_free = pose1_free || (sh.s_pose2 && !sh.pose2_fl[sh.pose2_gen].busy());
-            pose_second = !pose1_free;
+            const bool pose_free = !sh.pose_fl[sh.pose_gen].busy();
             if (!sh.pose.empty() && pose_free &&
                 ((int)sh.pose.size() >= expected || now - sh.pose_newest_ns >= pose_q || now - sh.pose_oldest_ns >= window_ns())) pose.swap(sh.pose);
             if (!sh.proj.empty() && !sh.proj_fl[sh.proj_gen].busy() &&
@@ -225,11 +216,9 @@ void combine(Share& sh, Ticket& mine)
         bool ok;
         { std::lock_guard<std::mutex> lock(sh.m); ok = share_init(sh); }
         if (!pose.empty()) {
-            const bool second = pose_second;                 // (s_pose2 is idle then: pose_free)
-            hipStream_t s = second ? sh.s_pose2 : sh.s_pose;
-            int& gen = second ? sh.pose2_gen : sh.pose_gen;
-            gen ^= 1;
-            InFlight& fl = second ? sh.pose2_fl[gen] : sh.pose_fl[gen];
+            hipStream_t s = sh.s_pose;
+            sh.pose_gen ^= 1;
+            InFlight& fl = sh.pose_fl[sh.pose_gen];
             if (pose.size() > 64) { std::lock_guard<std::mutex> lock(sh.m); sh.pose.insert(sh.pose.begin(), pose.begin() + 64, pose.end()); pose.resize(64); }      // (more than 64 sessions: the rest with the next batch)
             std::vector<LpPoseReq> reqs(pose.size());
             for (size_t i = 0; i < pose.size(); ++i) reqs[i] = pose[i].req;
