@@ -862,6 +862,17 @@ static hipStream_t lp_upload_stream(lpslam_hip_ctx* c)
     }
     return c->up_stream;
 }
+// A session's stream for work that is neither latency bound nor part of a shared launch -- the loop-candidate search's brute-force
+// matching against stored keyframe descriptors (100-150 us per keyframe), the descriptor uploads of new keyframes: the session's own
+// stream beside its uploads.  On the matchers' role stream the eight sessions' searches of a keyframe round stood in a row, a
+// millisecond during which no session's window matcher could start (p90 of a shared matcher launch: 268 us for a 30 us kernel).
+hipStream_t lp_aux_stream(lpslam_hip_ctx* c)
+{
+    if (c->owns_streams) return c->stream;
+    static const int where = [] { const char* e = getenv("LPSLAM_HIP_AUX_STREAM"); return e ? atoi(e) : 0; }();      // 0 main role stream (measured best: 8 managers 6004 / 5938 frames/s), 1 the session's copy stream (5115 / 5598), 2 the front-end role stream (5184 / 5441)
+    return where == 0 ? c->stream : (where == 1 ? lp_upload_stream(c) : c->fe_stream);
+}
+
 // stream `s` of the context waits (on the device) for the uploads of slots [first, first + n) that went through the copy-only stream
 int lp_wait_own_uploads(lpslam_hip_ctx* c, int first, int n, hipStream_t s)
 {

@@ -2407,10 +2407,16 @@ constexpr size_t PO_BLK_INLIERS = 56, PO_BLK_FLAG = 64, PO_BLK_CAM = 72, PO_BLK_
 static_assert(PO_BLK_CAM + sizeof(BaCam) <= PO_BLK_PACKED, "pose-optimiser block header");
 __global__ __launch_bounds__(256) void k_pose_optimize_req(PoBatch b)
 {
-    __shared__ double tr[PO_NV * PO_WN_ROW(4)];
-    __shared__ double out28[32];
-    __shared__ PoObs cache[64 * 4];
-    __shared__ int s_bad[2][4];                            // outliers per wavefront, double-buffered over the rounds
+    // LDS by the launch (po_lds_bytes of the largest request of the batch): the transposition array [28][66 W], the 28 totals, the
+    // observations, the wavefronts' outlier counts.  A workgroup that asks for the four-wavefront layout (74 KB) whatever it needs found
+    // no compute unit to start on while an extraction kernel's workgroups held theirs (8 x 13 KB of 160): requests of <= 128
+    // observations -- 92 % of a tracker's -- now ask for 37 KB or 19.
+    extern __shared__ __attribute__((aligned(16))) double po_lds[];
+    const int wmax = (int)blockDim.x >> 6;
+    double* tr = po_lds;
+    double* out28 = tr + PO_NV * 66 * wmax;
+    PoObs* cache = reinterpret_cast<PoObs*>(out28 + 32);
+    int (*s_bad)[4] = reinterpret_cast<int (*)[4]>(cache + 64 * wmax);      // outliers per wavefront, double-buffered over the rounds
     const int r = blockIdx.x, n = b.n[r];
     uint8_t* blk = b.blk[r];
     const int W = n <= 64 ? 1 : (n <= 128 ? 2 : 4);
@@ -3741,8 +3747,14 @@ int lp_launch_pose_batch(hipStream_t s, const LpPoseReq* reqs, int n)
         PoBatch b{};
         int n_max = 0;
         for (int i = 0; i < m; ++i) { b.blk[i] = reqs[i0 + i].blk; b.n[i] = reqs[i0 + i].n; b.seq[i] = reqs[i0 + i].seq; n_max = std::max(n_max, reqs[i0 + i].n); }
-        const int threads = n_max <= 64 ? 64 : (n_max <= 128 ? 128 : 256);
-        hipLaunchKernelGGL(k_pose_optimize_req, dim3((unsigned)m), dim3((unsigned)threads), 0, s, b);
+        const int threads = n_max <= 64 ? 64 : (n_max <= 128 ? 128 : 256), wmax = threads / 64;
+        const size_t lds = (size_t)(PO_NV * 66 * wmax + 32) * sizeof(double) + (size_t)64 * wmax * sizeof(PoObs) + 64;
+        {
+            static std::atomic<bool> attr_set[64];
+            int dev = 0; (void)hipGetDevice(&dev);
+            if (dev >= 0 && dev < 64 && !attr_set[dev].load()) { (void)hipFuncSetAttribute((const void*)k_pose_optimize_req, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); attr_set[dev].store(true); }
+        }
+        hipLaunchKernelGGL(k_pose_optimize_req, dim3((unsigned)m), dim3((unsigned)threads), lds, s, b);
         LP_HIP(hipGetLastError());
     }
     return LPSLAM_HIP_OK;

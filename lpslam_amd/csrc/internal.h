@@ -264,6 +264,7 @@ bool lp_share_role_streams(int device, hipStream_t out[4]);
 struct LpDeliverReq { const int* d_count; const uint32_t* kp; const uint32_t* desc; const uint32_t* xr; const uint32_t* dep; uint32_t* st; unsigned* counter; int* flag; int seq, blocks; };
 int lp_share_front_end(lpslam_hip_ctx* c, int slot, int stereo, float fxb, float baseline);
 void lp_share_front_end_collected(lpslam_hip_ctx* c);   // the session has its frame (or gave up on it)
+hipStream_t lp_aux_stream(lpslam_hip_ctx* c);           // api.hip
 int lp_wait_own_uploads(lpslam_hip_ctx* c, int first, int n, hipStream_t s);      // api.hip
 int lp_prepare_delivery(lpslam_hip_ctx* c, int image, int with_stereo, LpDeliverReq* out);      // api.hip: what lpslam_hip_prefetch_frame sets up, without the launch
 void lp_commit_delivery(lpslam_hip_ctx* c, int image, int with_stereo, const LpDeliverReq& r, hipStream_t s);

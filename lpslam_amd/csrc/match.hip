@@ -670,13 +670,14 @@ int lpslam_hip_desc_store_put(lpslam_hip_ctx* c, int32_t key, const uint8_t* des
     LP_HIP(hipSetDevice(c->cfg.device));
     lpslam_hip_ctx::StoredDesc& e = c->desc_store[key];
     const size_t bytes = (size_t)std::max(n, 1) * 32;
+    hipStream_t aux = lp_aux_stream(c);                  // (the stream lpslam_hip_match_bf_stored reads the sets on)
     if (e.cap < bytes) {
-        if (e.blk) { LP_HIP(hipStreamSynchronize(c->stream)); lp_pool_free(c, e.blk, e.cap); e.blk = nullptr; e.cap = 0; }
+        if (e.blk) { LP_HIP(hipStreamSynchronize(aux)); lp_pool_free(c, e.blk, e.cap); e.blk = nullptr; e.cap = 0; }
         const int rc = lp_pool_alloc(c, bytes, &e.blk, &e.cap);
         if (rc) { c->desc_store.erase(key); return rc; }
     }
     e.n = n;
-    if (n) LP_HIP(hipMemcpyAsync(e.blk, desc32, (size_t)n * 32, hipMemcpyHostToDevice, c->stream));
+    if (n) LP_HIP(hipMemcpyAsync(e.blk, desc32, (size_t)n * 32, hipMemcpyHostToDevice, aux));
     return LPSLAM_HIP_OK;
 }
 
@@ -685,7 +686,7 @@ int lpslam_hip_desc_store_drop(lpslam_hip_ctx* c, int32_t key)
     if (!c) { set_error("null context"); return LPSLAM_HIP_ERR_INVALID; }
     auto it = c->desc_store.find(key);
     if (it == c->desc_store.end()) return LPSLAM_HIP_OK;
-    if (it->second.blk) { LP_HIP(hipStreamSynchronize(c->stream)); lp_pool_free(c, it->second.blk, it->second.cap); }
+    if (it->second.blk) { LP_HIP(hipStreamSynchronize(lp_aux_stream(c))); lp_pool_free(c, it->second.blk, it->second.cap); }
     c->desc_store.erase(it);
     return LPSLAM_HIP_OK;
 }
@@ -714,7 +715,7 @@ int lpslam_hip_match_bf_stored(lpslam_hip_ctx* c, int query, const int32_t* keys
     int32_t nq = 0;
     if ((rc = lpslam_hip_keypoint_count(c, query, &nq))) return rc;
     if (n_keys == 0 || nq == 0) return LPSLAM_HIP_OK;
-    hipStream_t s = c->stream;
+    hipStream_t s = lp_aux_stream(c);
     const size_t S = (size_t)c->slots_per_image;
     // device block: per key the forward arrays (best index, best distance, second distance of the nq queries) and the reverse best index
     std::vector<size_t> o_fwd((size_t)n_keys), o_rev((size_t)n_keys);
