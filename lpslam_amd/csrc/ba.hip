@@ -36,6 +36,11 @@ using namespace lpslam;
 namespace {
 
 constexpr int NB = 32;                // Cholesky panel width
+constexpr int SCH_PV = 42;            // values a part of a pose-block pair's list hands over in k_ba_schur: the 6 x 6 sum + the 6 of the keyframe's rhs (diagonal blocks)
+// How many workgroups of k_ba_schur share a pose-block pair's list: lists longer than 256 terms are cut into up to 4 interleaved parts
+// (32-term chunks round-robin), so that the longest list -- a keyframe's diagonal block, one term per observation -- does not set the
+// kernel's duration; the part that finishes last adds the parts up in order (fixed summation order)
+__host__ __device__ inline int schur_parts(int n_terms) { return n_terms > 256 ? ((n_terms + 255) / 256 < 4 ? (n_terms + 255) / 256 : 4) : 1; }
 constexpr int SPLIT = 8;              // wavefronts per keyframe in the pose pass
 constexpr int PV = 28;                // partial-row stride per wavefront: 21 (H_pp upper) + 6 (b_p) (+1 pad; chi2 is kept apart)
 constexpr int MAX_LOG = 64;
@@ -105,13 +110,16 @@ struct BaView {                       // one problem, resident in device memory 
     GPTR(double) Lsub;                                                            // L_j1,j of every panel pair, stored at [j1][32][32]
     GPTR(double) xp; GPTR(double) chi_pose; GPTR(double) part; GPTR(double) scal;
     GPTR(const int) blk_start; GPTR(const int4) blk_terms;        // Schur pair lists: (observation a, observation b, their landmark, -)
-    GPTR(double) blk_part; GPTR(int) blk_ticket;                  // Schur partial sums [block][4][36], per-block tickets
+    GPTR(double) blk_part; GPTR(int) blk_ticket;                  // Schur partial sums [block][4][SCH_PV], per-block tickets (+ the table of further parts, ba_build.inl)
     GPTR(int) blk_perm;                                           // k_ba_schur: which pose-block pair work item w takes (XCD tiles, see lpslam_hip_ba_prepare)
     GPTR(BaCtl) ctl; GPTR(lpslam_hip_ba_iter_log) log;
     BaCam cam;
     // block-banded windows (ba_band.inl): block half-bandwidth of the reduced system when the problem takes the band path (-1: pair
     // lists + dense chain), landmark groups, [group records | first / last candidate group per free slot], entry table, group partials
-    int band_hbw, band_groups, band_groups_cap, band_pad_;
+    int band_hbw, band_groups, band_groups_cap;
+    int extra_pack;                   // k_ba_schur: workgroups for the further parts of long pair lists (table behind blk_ticket[n_blocks]: count, items):
+                                      // (cap << 12) | first -- the table holds at most `cap` items, `first` of them get workgroups in FRONT of the pairs'
+                                      // part 0 (what the host expects: the diagonal blocks' parts), the rest behind them (one int: the view's size matters)
     GPTR(const int) band_tab; GPTR(const int) band_ent; GPTR(double) band_part;
 };
 
@@ -872,144 +880,187 @@ __device__ __forceinline__ void obs_y_row(const double* h, double w0, double w1,
 }
 
 // ---- per trial: Schur complement; Y = W (H_ll + lambda I)^-1 is formed per term from W and the landmark's 3x3 block (a launch
-//      and the 18 doubles per observation it wrote and this kernel read back are gone).  Work items [0, n_work): one wavefront per pose-block pair (i <= k) or part of one: lanes stride over the
-//      pair list with 36 private accumulators, partials are summed in lane order through LDS (fixed summation order).
-//      Blocks [n_work, n_work + n_free): rhs_i = b_p,i - sum Y b_l over the observations of keyframe i.
+//      and the 18 doubles per observation it wrote and this kernel read back are gone).  One wavefront per pose-block pair (i <= k)
+//      or part of one, over the pair's term list (observation of i, observation of k, landmark), 32 terms per round, two lanes per
+//      term with 18 accumulators each; partials are summed in lane order through LDS (fixed summation order).
+//      What bounded the first form (round 6, in-kernel stamps: tools/dev_schur_stamps.py): every lane fetched its term's rows itself
+//      -- 24 loads of 8 or 16 bytes per lane and term, every one a cache-line look-up of its own: 8.6 M look-ups per launch at one per
+//      cycle and compute unit = 14 us -- and 3675 of the 5349 workgroups were surplus parts that left at once, whose dispatch kept the
+//      last real ones waiting for 12 us.  Now a round's 64 rows (144 bytes each, contiguous) are fetched by the wavefront TOGETHER,
+//      nine lanes to a row, sixteen bytes a lane (a look-up per row and line instead of one per lane), a round AHEAD of their use
+//      (registers -> LDS -> the lanes of the term), and the grid holds the parts that exist (table built with the lists, ba_build.inl).
+//      The rhs of keyframe i, b_p,i - sum Y b_l over its observations, rides on the diagonal block (i, i), whose list has a term per
+//      observation: no workgroups of its own and no second pass over W.
 //      fused != 0 (single-GPU solve): lambda goes onto the pose diagonal, rhs straight into row `dim` of S and the failure
 //      flag / rhs pivot are reset here, so no separate preparation launch is needed.
+#ifdef LPSLAM_SCHUR_STAMPS
+// development: (start, end, wait start) of every workgroup of the last k_ba_schur launch, 100 MHz clock (tools/dev_schur_stamps.py)
+__device__ unsigned long long g_schur_stamps[8 * 8192];
+#define SCHUR_STAMP(k) do { if (threadIdx.x == 0 && bx0 < 8192) g_schur_stamps[8 * bx0 + (k)] = wall_clock64(); } while (0)
+#else
+#define SCHUR_STAMP(k) do {} while (0)
+#endif
+typedef double dbl2 __attribute__((ext_vector_type(2)));      // (a plain vector type: registers, where the HIP class type ended up in scratch memory)
+// a round's rows, landmark blocks and rhs vectors -> registers (term records in `ab`: lane l holds term l & 31 of the round).
+// Straight-line code: every lane loads in every slot (the last slots of the landmark blocks fetch a duplicate that is never stored) --
+// with a condition around a load the compiler ends each one with a full wait, the eleven lane exchanges and loads ran one after the
+// other and a round cost 0.9 us of issue alone.
+__device__ __forceinline__ void schur_fetch(const BaView& v, const int4& ab, int lane, bool diag, dbl2 (&wq)[9], dbl2 (&hq)[2], double (&bq)[2], int& same)
+{
+    const int mine = lane < 32 ? ab.x : ab.y;
+    int o[9], lm[2];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) o[j] = __shfl(mine, (j * 64 + lane) / 9);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) lm[j] = __shfl(ab.z, min((j * 64 + lane) / 3, 31));
+    same = __shfl((int)(ab.x == ab.y), lane >> 1);
+    // (byte offsets in 32 bits: base in scalar registers + one vector offset per load instead of a 64-bit multiply-add each)
+    GPTR(const char) Wc = reinterpret_cast<GPTR(const char)>(v.W);
+    GPTR(const char) Hc = reinterpret_cast<GPTR(const char)>(v.Hll);
+    GPTR(const char) Bc = reinterpret_cast<GPTR(const char)>(v.bl);
+#pragma unroll
+    for (int j = 0; j < 9; ++j) { const int idx = j * 64 + lane, u = idx - 9 * (idx / 9); wq[j] = *reinterpret_cast<GPTR(const dbl2)>(Wc + (144u * (unsigned)o[j] + 16u * (unsigned)u)); }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { const int idx = j * 64 + lane, u = idx - 3 * (idx / 3); hq[j] = *reinterpret_cast<GPTR(const dbl2)>(Hc + (48u * (unsigned)lm[j] + 16u * (unsigned)u)); }
+    if (diag) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { const int idx = j * 64 + lane, u = idx - 3 * (idx / 3); bq[j] = *reinterpret_cast<GPTR(const double)>(Bc + (24u * (unsigned)lm[j] + 8u * (unsigned)u)); }
+    }
+}
 template <int UPD_PB> __device__ __forceinline__ void ba_pose_side_wave(BaView& v, int p, int sp, int robust, int cur, bool publish);
 __device__ __forceinline__ void ba_pose_side_wait(const BaView& v);
 __global__ __launch_bounds__(64) void k_ba_schur(const BaView* __restrict__ views, int fused, int robust)
 {
     BA_VIEW_XCD(v, bx0);
-    const int n_work = 4 * v.n_blocks;                     // work item = (block pair, part): see below
-    const int lead = v.n_poses * SPLIT;                    // leading workgroups: the pose side of an accepted state's linearisation (ba_update.inl)
-    if (bx0 >= lead + n_work + v.n_free || v.band_hbw >= 0) return;      // banded windows: k_schur_group / k_schur_band_reduce (ba_band.inl)
+    // workgroups: [pose side of an accepted state's linearisation (ba_update.inl) | further parts, first stretch | part 0 of every
+    // block | further parts, the rest]
+    const int lead = v.n_poses * SPLIT;
+    const int nblk = v.n_blocks, ecap = v.extra_pack >> 12, efirst = v.extra_pack & 4095;
+    if (bx0 >= lead + ecap + nblk || v.band_hbw >= 0) return;      // banded windows: k_schur_group / k_schur_band_reduce (ba_band.inl)
     const BaFlags fl = ba_flags(v.ctl);
     if (fl.idle()) return;
     const int pending = fused ? ba_sync_words(v)[3] : 0;   // raised by k_ba_update's decision: H_pp, b_p of state `cur` are this launch's to compute
-    if (bx0 < lead) { if (pending) ba_pose_side_wave<2>(v, bx0 / SPLIT, bx0 % SPLIT, robust, fl.cur, true); return; }
+    SCHUR_STAMP(0); SCHUR_STAMP(2);
+    if (bx0 < lead) { if (pending) ba_pose_side_wave<2>(v, bx0 / SPLIT, bx0 % SPLIT, robust, fl.cur, true); SCHUR_STAMP(1); return; }
     const int bx = bx0 - lead;
+    int blk, part_id = 0;
+    if (bx < efirst || bx >= efirst + nblk) {
+        GPTR(const int) ex = v.blk_ticket + nblk;          // [items | block * 4 + part ...], written with the lists and constant since
+        const int e = bx < efirst ? bx : bx - nblk;
+        const int count = ex[0], item = ex[1 + e];
+        if (e >= count) return;
+        blk = item >> 2; part_id = item & 3;
+    } else blk = v.blk_perm[bx - efirst];
     const double lambda = fl.lambda;
     ba_lin_set(v, fl.cur);
     const int lane = threadIdx.x;
     const int n = v.dim_pad;
-    if (bx >= n_work) {
-        const int i = bx - n_work;
-        const int p = v.free_pose[i];
-        double r6[6] = {0, 0, 0, 0, 0, 0};
-        // two observations per lane and round: their index -> landmark -> (H_ll, b_l) load chains run side by side (four held 216
-        // registers; the kernel's allocation decides how many wavefronts hide each other's gathers)
-        const int s_end = v.ps_start[p + 1];
-        for (int s0 = v.ps_start[p] + lane; s0 < s_end; s0 += 128) {
-            int jj[2];
-#pragma unroll
-            for (int u = 0; u < 2; ++u) jj[u] = v.o_point[min(s0 + 64 * u, s_end - 1)];
-            double hh[2][6], bb[2][3], ww[2][18];
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int s = min(s0 + 64 * u, s_end - 1);
-                const double* hl = v.Hll + 6 * (size_t)jj[u];
-#pragma unroll
-                for (int q = 0; q < 6; ++q) hh[u][q] = hl[q];
-#pragma unroll
-                for (int q = 0; q < 3; ++q) bb[u][q] = v.bl[3 * (size_t)jj[u] + q];
-                const double2* Wa = reinterpret_cast<const double2*>(v.W + 18 * (size_t)s);
-#pragma unroll
-                for (int q = 0; q < 9; ++q) { const double2 a2 = Wa[q]; ww[u][2 * q] = a2.x; ww[u][2 * q + 1] = a2.y; }
-            }
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                if (s0 + 64 * u < s_end) {
-                    double h[6];
-                    point_hinv(hh[u], lambda, h);
-#pragma unroll
-                    for (int r = 0; r < 6; ++r) {
-                        double y0, y1, y2;
-                        obs_y_row(h, ww[u][r * 3], ww[u][r * 3 + 1], ww[u][r * 3 + 2], y0, y1, y2);
-                        r6[r] += y0 * bb[u][0] + y1 * bb[u][1] + y2 * bb[u][2];
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < 6; ++q) r6[q] = wave_sum(r6[q]);
-        if (pending) ba_pose_side_wait(v);                 // the leading workgroups of this launch have stored them (write-through)
-        if (lane < 6) {
-            double val = 0;
-            // b_p and diag H_pp of keyframe i: the SPLIT partial sums of the set's pose-side linearisation, added in order (what
-            // pose_combine_body does after an explicit linearisation; a linearisation made beside a trial has no combine of its own)
-            const int qd = 6 * lane - lane * (lane - 1) / 2;      // (lane, lane) in the row-major upper triangle
-            double bsum = 0, dsum = 0;
-            for (int sp = 0; sp < SPLIT; ++sp) { const double* pr = v.partial + ((size_t)i * SPLIT + sp) * PV; bsum += pending ? ld_sc1(pr + 21 + lane) : pr[21 + lane]; dsum += pending ? ld_sc1(pr + qd) : pr[qd]; }
-#pragma unroll
-            for (int q = 0; q < 6; ++q) if (q == lane) val = bsum - r6[q];
-            v.rhs[6 * i + lane] = val;
-            if (fused) v.S[(size_t)v.dim * n + 6 * i + lane] = val;
-            v.bp[6 * i + lane] = bsum; v.hppdiag[6 * i + lane] = dsum;      // the solved set's sums (partitioned: fresh partials for the all-reduce)
-        }
-        if (!fused && i == 0 && lane == 62) *v.chi_cur = *v.chi_loc;
-        if (fused && i == 0 && lane == 63) { v.S[(size_t)v.dim * n + v.dim] = 1e200; v.scal[5] = 0.0; }
-        return;
-    }
-    // work item = (block pair, part, parts): pair lists longer than 256 terms are cut into up to 4 interleaved parts (64-term
-    // chunks round-robin), so that the longest list -- a keyframe's diagonal block, one term per observation -- no longer sets
-    // the kernel's duration; the part that finishes last adds the parts up in order (fixed summation order).
-    // Items [0, n_blocks) are part 0 of every block, items n_blocks + 3 blk + (part - 1) the further parts: no work table, the
-    // number of parts follows from the length of the block's list (a surplus item exits here).
-    const int nblk = v.n_blocks;
-    const int blk = bx < nblk ? v.blk_perm[bx] : (bx - nblk) / 3;
-    const int part_id = bx < nblk ? 0 : 1 + (bx - nblk) % 3;
-    const int n_terms = v.blk_start[blk + 1] - v.blk_start[blk];
-    const int parts = min(4, max(1, (n_terms + 255) / 256));
-    if (part_id >= parts) return;
-    int pidx = blk, i = 0;
+    const int t_begin = v.blk_start[blk], t_end = v.blk_start[blk + 1];
+    const int parts = schur_parts(t_end - t_begin);
+    SCHUR_STAMP(3);
+    // block -> (i, k), i <= k, blocks numbered row by row: row i starts at i N - i (i - 1) / 2
+    int i;
     {
-        int rowlen = v.n_free;
-        while (pidx >= rowlen) { pidx -= rowlen; --rowlen; ++i; }
+        const int N = v.n_free;
+        const float h = (float)(2 * N + 1);
+        i = (int)((h - sqrtf(fmaxf(h * h - 8.0f * (float)blk, 0.0f))) * 0.5f);
+        i = max(0, min(i, N - 1));
+        while (i > 0 && i * N - i * (i - 1) / 2 > blk) --i;
+        while (i + 1 < N && (i + 1) * N - (i + 1) * i / 2 <= blk) ++i;
     }
-    const int k = i + pidx;
-    // TWO lanes per term: lane parity p takes rows 3p .. 3p+2 of the term's 6 x 6 product (18 accumulators instead of 36, half of
-    // W_a), so the kernel fits four wavefronts per SIMD instead of two -- it is bound by the latency of its dependent gathers
-    // (term -> rows), which only other wavefronts hide.  Both lanes load W_b and the landmark's block (the second one hits the L1).
-    __shared__ double part[32 * 37];
+    const int k = i + (blk - (i * v.n_free - i * (i - 1) / 2));
+    const bool diag = i == k;
+    // LDS: a round's rows [64][18] (0 .. 31 the terms' rows of keyframe i, 32 .. 63 of keyframe k), landmark blocks [32][6] and rhs
+    // vectors [32][3]; afterwards the lanes' partial sums [32][43]
+    __shared__ __attribute__((aligned(16))) double s_buf[64 * 18 + 2 * 128 + 128];      // (every lane stores in every slot: the blocks' and vectors' sections are rounded up to 128 lanes)
+    double* s_h = s_buf + 64 * 18;
+    double* s_b = s_h + 2 * 128;
     const int tl = lane >> 1, hp = lane & 1;
-    double acc[18];
+    double acc[18], r3[3] = {0, 0, 0};
 #pragma unroll
     for (int q = 0; q < 18; ++q) acc[q] = 0;
-    for (int t = v.blk_start[blk] + part_id * 32 + tl; t < v.blk_start[blk + 1]; t += 32 * parts) {
-        const int4 ab = v.blk_terms[t];
-        const double* Wa = v.W + 18 * (size_t)ab.x + 9 * hp;
-        const double2* Wb = reinterpret_cast<const double2*>(v.W + 18 * (size_t)ab.y);
-        const double* hl = v.Hll + 6 * (size_t)ab.z;
-        double hraw[6], y[9], w[18];
-#pragma unroll
-        for (int q = 0; q < 6; ++q) hraw[q] = hl[q];
-#pragma unroll
-        for (int q = 0; q < 9; ++q) y[q] = Wa[q];
-#pragma unroll
-        for (int q = 0; q < 9; ++q) { const double2 b2 = Wb[q]; w[2 * q] = b2.x; w[2 * q + 1] = b2.y; }
-        double h[6];
-        point_hinv(hraw, lambda, h);
-#pragma unroll
-        for (int r = 0; r < 3; ++r) obs_y_row(h, y[r * 3], y[r * 3 + 1], y[r * 3 + 2], y[r * 3], y[r * 3 + 1], y[r * 3 + 2]);
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int c = 0; c < 6; ++c)
-                acc[r * 6 + c] += y[r * 3] * w[c * 3] + y[r * 3 + 1] * w[c * 3 + 1] + y[r * 3 + 2] * w[c * 3 + 2];
+    const int stride = 32 * parts;
+    int t0 = t_begin + part_id * 32;
+    // registers of the round being fetched
+    dbl2 wq[9], hq[2];
+    double bq[2] = {0, 0};
+    int4 ab = make_int4(0, 0, 0, 0), ab_next = make_int4(0, 0, 0, 0);
+    int same_next = 0;
+    if (t0 < t_end) {
+        ab = v.blk_terms[min(t0 + (lane & 31), t_end - 1)];
+        if (t0 + stride < t_end) ab_next = v.blk_terms[min(t0 + stride + (lane & 31), t_end - 1)];
+        schur_fetch(v, ab, lane, diag, wq, hq, bq, same_next);
     }
+    SCHUR_STAMP(4);
+    bool first_round = true;
+    while (t0 < t_end) {
 #pragma unroll
-    for (int q = 0; q < 18; ++q) part[tl * 37 + 18 * hp + q] = acc[q];
+        for (int j = 0; j < 9; ++j) *reinterpret_cast<dbl2*>(s_buf + 2 * (j * 64 + lane)) = wq[j];
+        *reinterpret_cast<dbl2*>(s_h + 2 * lane) = hq[0];
+        *reinterpret_cast<dbl2*>(s_h + 2 * (64 + lane)) = hq[1];
+        if (diag) { s_b[lane] = bq[0]; s_b[64 + lane] = bq[1]; }
+        const bool valid = t0 + tl < t_end;
+        const bool same = same_next != 0;
+        __syncthreads();
+        if (first_round) { SCHUR_STAMP(5); first_round = false; }
+        t0 += stride;
+        if (t0 < t_end) {
+            ab = ab_next;
+            schur_fetch(v, ab, lane, diag, wq, hq, bq, same_next);
+            if (t0 + stride < t_end) ab_next = v.blk_terms[min(t0 + stride + (lane & 31), t_end - 1)];
+        }
+        if (valid) {
+            double hraw[6], y[9], w[18];
+            const double* ya = s_buf + 18 * tl + 9 * hp;
+            const dbl2* wb = reinterpret_cast<const dbl2*>(s_buf + 18 * (32 + tl));
+#pragma unroll
+            for (int q = 0; q < 6; ++q) hraw[q] = s_h[6 * tl + q];
+#pragma unroll
+            for (int q = 0; q < 9; ++q) y[q] = ya[q];
+#pragma unroll
+            for (int q = 0; q < 9; ++q) { const dbl2 b2 = wb[q]; w[2 * q] = b2.x; w[2 * q + 1] = b2.y; }
+            double h[6];
+            point_hinv(hraw, lambda, h);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {                  // Y = W (H_ll + lambda I)^-1, row r of this lane's half
+                const double w0 = y[r * 3], w1 = y[r * 3 + 1], w2 = y[r * 3 + 2];
+                y[r * 3] = __builtin_fma(w2, h[2], __builtin_fma(w1, h[1], w0 * h[0]));
+                y[r * 3 + 1] = __builtin_fma(w2, h[4], __builtin_fma(w1, h[3], w0 * h[1]));
+                y[r * 3 + 2] = __builtin_fma(w2, h[5], __builtin_fma(w1, h[4], w0 * h[2]));
+            }
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 6; ++c)
+                    acc[r * 6 + c] = __builtin_fma(y[r * 3 + 2], w[c * 3 + 2], __builtin_fma(y[r * 3 + 1], w[c * 3 + 1], __builtin_fma(y[r * 3], w[c * 3], acc[r * 6 + c])));      // (fused: the kernel is bound by its vector instructions, 4 cycles each)
+            if (diag && same) {                            // the observation's share of the keyframe's rhs (a keyframe that sees a landmark twice has cross terms in its list: not those)
+                const double b0 = s_b[3 * tl], b1 = s_b[3 * tl + 1], b2 = s_b[3 * tl + 2];
+#pragma unroll
+                for (int r = 0; r < 3; ++r) r3[r] = __builtin_fma(y[r * 3 + 2], b2, __builtin_fma(y[r * 3 + 1], b1, __builtin_fma(y[r * 3], b0, r3[r])));
+            }
+        }
+        __syncthreads();
+    }
+    SCHUR_STAMP(6);
+    // the lanes' sums in lane order: per term-lane pair [row half 0: 18 + 3 | row half 1: 18 + 3], stride 43
+    double* part = s_buf;
+#pragma unroll
+    for (int q = 0; q < 18; ++q) part[tl * 43 + 21 * hp + q] = acc[q];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) part[tl * 43 + 21 * hp + 18 + q] = r3[q];
     __syncthreads();
+    // lanes 0 .. 35: entry (r, c) of the 6 x 6 sum; lanes 36 .. 41: row lane - 36 of the keyframe's rhs sum (diagonal blocks)
+    const int er = lane < 36 ? lane / 6 : lane - 36, ec = lane < 36 ? lane - 6 * er : 0;
+    const int slot = 21 * (er / 3) + (lane < 36 ? 6 * (er % 3) + ec : 18 + er % 3);
     double sum = 0;
-    if (lane < 36) for (int l = 0; l < 32; ++l) sum += part[l * 37 + lane];
+    if (lane < SCH_PV) for (int l = 0; l < 32; ++l) sum += part[l * 43 + slot];
+    SCHUR_STAMP(7);
     if (parts > 1) {
         // hand-over without cache maintenance: the partial sums are stored write-through (sc1) and read back L1-bypassing (sc1),
         // the ticket is a relaxed agent-scope add made after this (single) wavefront's stores have drained -- no buffer_wbl2 /
         // buffer_inv, which cost more than the part they guard (MI355X_MICROARCH: valid forms, one unsharded counter)
-        double* mine = v.blk_part + (size_t)(4 * blk + part_id) * 36;
-        if (lane < 36) __hip_atomic_store(&mine[lane], sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        double* mine = v.blk_part + (size_t)(4 * blk + part_id) * SCH_PV;
+        if (lane < SCH_PV) __hip_atomic_store(&mine[lane], sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __shared__ int s_last;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) {
@@ -1018,24 +1069,41 @@ __global__ __launch_bounds__(64) void k_ba_schur(const BaView* __restrict__ view
             if (s_last) v.blk_ticket[blk] = 0;
         }
         __syncthreads();
-        if (!s_last) return;
+        if (!s_last) { SCHUR_STAMP(1); return; }
         sum = 0;
-        if (lane < 36) for (int p = 0; p < parts; ++p) sum += __hip_atomic_load(&v.blk_part[(size_t)(4 * blk + p) * 36 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane < SCH_PV) for (int p = 0; p < parts; ++p) sum += __hip_atomic_load(&v.blk_part[(size_t)(4 * blk + p) * SCH_PV + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (i == k && pending) ba_pose_side_wait(v);
-    if (lane >= 36) return;
-    const int r = lane / 6, c = lane - r * 6;
-    if (i == k) {
-        const int ra = min(r, c), rc = max(r, c);
-        const int q = 6 * ra - ra * (ra - 1) / 2 + (rc - ra);      // H_pp(r, c) in the row-major upper triangle of the pose partials
-        double hpp = 0;
-        for (int sp = 0; sp < SPLIT; ++sp) { const double* pr = v.partial + ((size_t)i * SPLIT + sp) * PV + q; hpp += pending ? ld_sc1(pr) : *pr; }
-        double val = hpp - sum;
-        if (fused && r == c) val += lambda;
-        v.S[(size_t)(6 * i + r) * n + 6 * i + c] = val;
-    } else {
-        v.S[(size_t)(6 * i + r) * n + 6 * k + c] = -sum;
-        v.S[(size_t)(6 * k + c) * n + 6 * i + r] = -sum;
+    SCHUR_STAMP(2);
+    if (diag && pending) ba_pose_side_wait(v);             // the leading workgroups of this launch have stored the pose side (write-through)
+    SCHUR_STAMP(1);
+    if (lane < 36) {
+        const int r = er, c = ec;
+        if (diag) {
+            const int ra = min(r, c), rc = max(r, c);
+            const int q = 6 * ra - ra * (ra - 1) / 2 + (rc - ra);      // H_pp(r, c) in the row-major upper triangle of the pose partials
+            double hpp = 0;
+            for (int sp = 0; sp < SPLIT; ++sp) { const double* pr = v.partial + ((size_t)i * SPLIT + sp) * PV + q; hpp += pending ? ld_sc1(pr) : *pr; }
+            double val = hpp - sum;
+            if (fused && r == c) val += lambda;
+            v.S[(size_t)(6 * i + r) * n + 6 * i + c] = val;
+        } else {
+            v.S[(size_t)(6 * i + r) * n + 6 * k + c] = -sum;
+            v.S[(size_t)(6 * k + c) * n + 6 * i + r] = -sum;
+        }
+    } else if (diag && lane < SCH_PV) {
+        // b_p and diag H_pp of keyframe i: the SPLIT partial sums of the set's pose-side linearisation, added in order (what
+        // pose_combine_body does after an explicit linearisation; a linearisation made beside a trial has no combine of its own)
+        const int q = er;
+        const int qd = 6 * q - q * (q - 1) / 2;              // (q, q) in the row-major upper triangle
+        double bsum = 0, dsum = 0;
+        for (int sp = 0; sp < SPLIT; ++sp) { const double* pr = v.partial + ((size_t)i * SPLIT + sp) * PV; bsum += pending ? ld_sc1(pr + 21 + q) : pr[21 + q]; dsum += pending ? ld_sc1(pr + qd) : pr[qd]; }
+        const double val = bsum - sum;
+        v.rhs[6 * i + q] = val;
+        if (fused) v.S[(size_t)v.dim * n + 6 * i + q] = val;
+        v.bp[6 * i + q] = bsum; v.hppdiag[6 * i + q] = dsum;      // the solved set's sums (partitioned: fresh partials for the all-reduce)
+    } else if (diag && i == 0) {
+        if (!fused && lane == 62) *v.chi_cur = *v.chi_loc;
+        if (fused && lane == 63) { v.S[(size_t)v.dim * n + v.dim] = 1e200; v.scal[5] = 0.0; }
     }
 }
 
@@ -2487,7 +2555,7 @@ namespace {
 // what a launch chain needs to know: the view array, how many problems it holds and the launch extents (maxima over them)
 struct BaLaunch {
     const BaView* d_views = nullptr; int count = 0; hipStream_t s = nullptr; lpslam_hip_ctx* ctx = nullptr;
-    int obs_blocks = 0, pose_blocks = 0, point_blocks = 0, part_n = 0, n_free = 0, n_blocks = 0, dim = 0, nb = 0, land_blocks = 0, n_poses = 0;
+    int obs_blocks = 0, pose_blocks = 0, point_blocks = 0, part_n = 0, n_free = 0, n_blocks = 0, dim = 0, nb = 0, land_blocks = 0, n_poses = 0, schur_items = 0;
     int robust = 1, points_fixed = 0;
     bool any_small = false, any_large = false;          // systems for k_chol_wg / for the panel-pair chain
     bool any_band = false, any_dense = false;           // banded windows (ba_band.inl) / pair lists + dense factorisation
@@ -2517,7 +2585,7 @@ struct BaLaunch {
             band_gmax = std::max(band_gmax, b->band_gmax);
         } else {
             if (v.n_free) any_dense = true;
-            n_blocks = std::max(n_blocks, v.n_blocks); dim = std::max(dim, v.dim);
+            n_blocks = std::max(n_blocks, v.n_blocks); dim = std::max(dim, v.dim); schur_items = std::max(schur_items, v.n_poses * SPLIT + (v.extra_pack >> 12) + v.n_blocks);
             nb = std::max(nb, v.dim_pad / NB);
             if (v.dim > 0) { if (cw_fits(v.dim)) any_small = true; else any_large = true; }
         }
@@ -2553,7 +2621,7 @@ int enqueue_linearize(const BaLaunch& L, int fused, bool explicit_lin = true)
 // Schur complement for the device's current lambda into the reduced buffer
 int enqueue_reduce(const BaLaunch& L, int fused)
 {
-    if (L.any_dense) hipLaunchKernelGGL(k_ba_schur, dim3(L.n_poses * SPLIT + 4 * L.n_blocks + L.n_free, L.count), dim3(64), 0, L.s, L.d_views, fused, L.robust);
+    if (L.any_dense) hipLaunchKernelGGL(k_ba_schur, dim3(L.schur_items, L.count), dim3(64), 0, L.s, L.d_views, fused, L.robust);
     if (L.any_band) {
         if (bd_set_attributes() != hipSuccess) return LPSLAM_HIP_ERR_DEVICE;
         // The band reduction as trailing workgroups of the group launch (LPSLAM_HIP_BA_REDUCE_IN_SCHUR=1) was measured and is OFF: the
@@ -2867,7 +2935,8 @@ int lpslam_hip_ba_prepare(lpslam_hip_ctx* ctx, const double* poses, const uint8_
     b->dim_pad = ((b->dim + 1 + NB - 1) / NB) * NB;           // room for the rhs row
     b->n_blocks = b->n_free * (b->n_free + 1) / 2;
     b->h_ur.resize((size_t)n_obs);
-    for (int k = 0; k < n_obs; ++k) b->h_ur[k] = obs[k].ur;   // caller order (host-side outlier thresholds)
+    std::vector<int> kf_obs((size_t)n_poses, 0);
+    for (int k = 0; k < n_obs; ++k) { b->h_ur[k] = obs[k].ur; ++kf_obs[(size_t)obs[k].pose]; }   // caller order (host-side outlier thresholds)
 
     // ---- shape of the window (ba_band.inl): first / last FREE keyframe slot of every landmark.  When no landmark spans more than
     //      BD_MAXHBW slots the reduced system is block-banded and the problem takes the band path: landmarks ordered by their first
@@ -2899,6 +2968,14 @@ int lpslam_hip_ba_prepare(lpslam_hip_ctx* ctx, const double* poses, const uint8_
     }
     const int land_blocks = (int)land_start.size() / 2 - 1;
 
+    // ---- k_ba_schur's further parts (ba_build.inl): the table holds at most terms / 256 items (a list of n > 256 terms has at most n / 256
+    //      further parts); what the host can foresee are the diagonal blocks' (one term per observation of the keyframe) + some slack
+    int extra_cap = 0, extra_first = 0;
+    {
+        extra_cap = (int)std::min<size_t>(std::min<size_t>(3 * (size_t)b->n_blocks, terms_cap / 256), (size_t)1 << 18);
+        for (int i = 0; i < b->n_free; ++i) extra_first += schur_parts(kf_obs[(size_t)free_pose[(size_t)i]]) - 1;
+        extra_first = std::min(std::min(extra_first + 32, extra_cap), 4095);
+    }
     // ---- one block: [view | inputs as staged | zero-initialised part | the rest]
     const size_t np = (size_t)n_poses, npt = (size_t)std::max(n_points, 1), no = (size_t)std::max(n_obs, 1), n = (size_t)b->dim_pad;
     const size_t nblk = (size_t)std::max(b->n_blocks, 1), nfree = (size_t)std::max(b->n_free, 1);
@@ -2920,7 +2997,7 @@ int lpslam_hip_ba_prepare(lpslam_hip_ctx* ctx, const double* poses, const uint8_
     const SetOff so = set_offsets(n_poses, n_points, n_obs, b->n_free, b->dim_pad);
     const size_t o_setz0 = cv.take(so.z_total * 8), o_setz1 = cv.take(so.z_total * 8);
     const size_t o_red = cv.take((size_t)b->red_n * 8), o_minv = cv.take(std::max(n * n, 64 * n) * 8) /* L^-T rows, or the band path's M blocks: 1024 doubles per 16 columns */, o_xp = cv.take(n * 8);
-    const size_t o_scal = cv.take(16 * 8) /* 8 scalars + the fault words (ba_update.inl) */, o_ctl = cv.take(sizeof(BaCtl)), o_ticket = cv.take(nblk * 4), o_log = cv.take(MAX_LOG * sizeof(lpslam_hip_ba_iter_log));
+    const size_t o_scal = cv.take(16 * 8) /* 8 scalars + the fault words (ba_update.inl) */, o_ctl = cv.take(sizeof(BaCtl)), o_ticket = cv.take((nblk + 1 + (size_t)extra_cap) * 4), o_log = cv.take(MAX_LOG * sizeof(lpslam_hip_ba_iter_log));
     const size_t z_end = cv.off;
     const size_t o_R = cv.take(np * npt * 4), o_pscount = cv.take(np * 4), o_slotof = cv.take(no * 4);
     const size_t o_ps_start = cv.take((np + 1) * 4), o_pt_start = cv.take((npt + 1) * 4), o_pt_obs = cv.take(no * 4), o_orig = cv.take(no * 4);
@@ -2931,7 +3008,7 @@ int lpslam_hip_ba_prepare(lpslam_hip_ctx* ctx, const double* poses, const uint8_
     const size_t cst = csr_stride(n_obs), o_csr = cv.take(6 * cst * 8);          // u, v, ur, w (doubles) + pose, point (ints) + pose slot (int)
     const size_t o_ldiag = cv.take(n * NB * 8), o_lsub = cv.take(n * NB * 8), o_chipose = cv.take(np * 8), o_part = cv.take((size_t)std::max(part_n, 2 * std::max(land_blocks, 1)) * 8) /* k_ba_backsub: part_n; k_ba_update: scale term and chi2 per landmark block */;
     const size_t o_chiobs = cv.take(no * 8), o_depth = cv.take(no);
-    const size_t o_blk_count = cv.take(nblk * 4), o_blk_start = cv.take((nblk + 1) * 4), o_blk_part = cv.take(nblk * 4 * 36 * 8);
+    const size_t o_blk_count = cv.take(nblk * 4), o_blk_start = cv.take((nblk + 1) * 4), o_blk_part = cv.take(nblk * 4 * SCH_PV * 8);
     const size_t o_terms = cv.take(std::max<size_t>(terms_cap, 1) * sizeof(int4));
     const size_t o_band_ent = cv.take(plan.hbw >= 0 ? no * sizeof(int4) : 0), o_band_part = cv.take((n_grp + 1) * BD_PART * 8) /* + the exchange block of the twisted band factorisation */;
     {
@@ -2947,6 +3024,7 @@ int lpslam_hip_ba_prepare(lpslam_hip_ctx* ctx, const double* poses, const uint8_
     v.n_poses = n_poses; v.n_points = n_points; v.n_obs = n_obs; v.n_free = b->n_free; v.dim = b->dim; v.dim_pad = b->dim_pad;
     v.obs_blocks = (n_obs + 255) / 256; v.pose_blocks = (n_poses * SPLIT + 3) / 4; v.point_blocks = (n_points + 255) / 256; v.part_n = part_n;
     v.n_blocks = b->n_blocks; v.land_blocks = land_blocks;
+    v.extra_pack = (extra_cap << 12) | extra_first;
     vset(v.land_start, (const int*)(base + o_land_start));
     b->d_poses[0] = (double*)(base + o_poses_a); b->d_poses[1] = (double*)(base + o_poses_b);
     b->d_points[0] = (double*)(base + o_points_a); b->d_points[1] = (double*)(base + o_points_b);
@@ -2996,7 +3074,7 @@ int lpslam_hip_ba_prepare(lpslam_hip_ctx* ctx, const double* poses, const uint8_
     if (n_obs) memcpy(hs + o_obs_in, obs, (size_t)n_obs * sizeof(lpslam_hip_ba_obs));
     memcpy(hs + o_land_start, land_start.data(), land_start.size() * 4);
     {
-        // k_ba_schur's work item w (part 0 of a pose-block pair) runs on XCD (lead + w) mod 8 -- workgroups go round the XCDs -- and every
+        // k_ba_schur's work item w (part 0 of a pose-block pair) runs on XCD (lead + extra_first + w) mod 8 -- workgroups go round the XCDs -- and every
         // XCD has an L2 of its own: with the pairs in row-major order each L2 fetched all of W (50.7 MB per launch for 5.76 MB of W,
         // profiles/r05c_pmc.json).  The free keyframes are cut into four groups and the ten group pairs dealt to the eight XCDs (six
         // off-diagonal tiles one each, the four diagonal tiles two to an XCD): an XCD's pairs then touch the W blocks of two groups, half
@@ -3009,11 +3087,15 @@ int lpslam_hip_ba_prepare(lpslam_hip_ctx* ctx, const double* poses, const uint8_
             auto grp = [N](int i) { return std::min(3, i * 4 / std::max(N, 1)); };
             static const int tile_xcd[4][4] = {{6, 0, 1, 2}, {0, 6, 3, 4}, {1, 3, 7, 5}, {2, 4, 5, 7}};
             int blk = 0;
-            for (int i = 0; i < N; ++i) for (int k = i; k < N; ++k, ++blk) of_xcd[tiles && N >= 16 ? (size_t)tile_xcd[grp(i)][grp(k)] : (size_t)(blk & 7)].push_back(blk);
+            // (every XCD's diagonal blocks first: theirs are the longest lists -- a term per observation -- and their epilogue waits for the pose side)
+            for (int pass = 0; pass < 2; ++pass) {
+                blk = 0;
+                for (int i = 0; i < N; ++i) for (int k = i; k < N; ++k, ++blk) if ((i == k) == (pass == 0)) of_xcd[tiles && N >= 16 ? (size_t)tile_xcd[grp(i)][grp(k)] : (size_t)(blk & 7)].push_back(blk);
+            }
             const int lead = n_poses * SPLIT;
             std::vector<size_t> at(8, 0);
             for (int w = 0; w < nb_; ++w) {
-                size_t x = (size_t)((lead + w) & 7);
+                size_t x = (size_t)((lead + extra_first + w) & 7);
                 if (at[x] >= of_xcd[x].size()) { size_t best = 0, left = 0; for (size_t y = 0; y < 8; ++y) if (of_xcd[y].size() - at[y] > left) { left = of_xcd[y].size() - at[y]; best = y; } x = best; }      // its own tile is used up: from the fullest
                 perm[(size_t)w] = of_xcd[x][at[x]++];
             }
@@ -3033,6 +3115,7 @@ int lpslam_hip_ba_prepare(lpslam_hip_ctx* ctx, const double* poses, const uint8_
         b->build_desc = d;
         d->n_poses = n_poses; d->n_points = n_points; d->n_obs = n_obs; d->n_free = b->n_free; d->n_blocks = b->n_blocks; d->dim = b->dim; d->dim_pad = b->dim_pad;
         d->n_ord = plan.hbw >= 0 ? (int)n_ord : 0;
+        d->extra_cap = extra_cap;
         d->obs = (const lpslam_hip_ba_obs*)(base + o_obs_in);
         d->A = (int*)(base + o_A); d->R = (int*)(base + o_R); d->pt_count = (int*)(base + o_ptcount); d->ps_count = (int*)(base + o_pscount);
         d->ps_start = (int*)(base + o_ps_start); d->pt_start = (int*)(base + o_pt_start); d->slot_of = (int*)(base + o_slotof); d->pt_obs = (int*)(base + o_pt_obs);
@@ -3228,8 +3311,8 @@ int lpslam_hip_ba_optimize_begin(lpslam_hip_ba* b, int32_t robust, int32_t iters
         BaLaunch L = single_launch(b);
         auto up = [](int x, int m) { return (x + m - 1) / m * m; };
         L.obs_blocks = up(L.obs_blocks, 8); L.pose_blocks = up(L.pose_blocks, 4); L.point_blocks = up(L.point_blocks, 4); L.part_n = up(L.part_n, 8); L.land_blocks = up(L.land_blocks, 8);
-        L.band_groups = up(L.band_groups, 8); L.band_blocks = up(L.band_blocks, 8);
-        const std::array<int, 23> sig = {units, robust ? 1 : 0, b->points_fixed ? 1 : 0, L.obs_blocks, L.pose_blocks, L.point_blocks, L.part_n, L.n_free,
+        L.band_groups = up(L.band_groups, 8); L.band_blocks = up(L.band_blocks, 8); L.schur_items = up(L.schur_items, 128);
+        const std::array<int, 24> sig = {L.schur_items, units, robust ? 1 : 0, b->points_fixed ? 1 : 0, L.obs_blocks, L.pose_blocks, L.point_blocks, L.part_n, L.n_free,
                                          L.n_blocks, L.dim, L.nb, L.any_small ? 1 : 0, L.any_large ? 1 : 0, L.land_blocks, L.spread ? 1 : 0,
                                          L.any_band ? 1 : 0, L.any_dense ? 1 : 0, L.band_groups, L.band_blocks, L.band_gmax, L.any_one_pass ? 1 : 0, L.any_two_launch ? 1 : 0, L.n_poses};
         lpslam_hip_ctx* c = b->ctx;
@@ -3877,6 +3960,9 @@ int lpslam_hip_pose_optimize(lpslam_hip_ctx* ctx, double* pose7, const double* p
     return LPSLAM_HIP_OK;
 }
 
+#ifdef LPSLAM_SCHUR_STAMPS
+extern "C" __attribute__((visibility("default"))) int lpslam_hip_debug_schur_stamps(unsigned long long* out, int n) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_schur_stamps), (size_t)n * sizeof(unsigned long long)); }
+#endif
 #ifdef LPSLAM_UPD_STAMPS
 extern "C" __attribute__((visibility("default"))) int lpslam_hip_debug_upd_stamps(double* out32) { return (int)hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_upd_stamps), 32 * sizeof(double)); }
 #endif

@@ -39,6 +39,7 @@ __device__ __forceinline__ int bs_block_scan(int x, int* total)
 //      the maxima over the batch; a workgroup beyond its problem's extent leaves at once.
 struct BuildDesc {
     int n_poses, n_points, n_obs, n_free, n_blocks, dim, dim_pad, n_ord;
+    int extra_cap, pad_;                                   // entries the table of further Schur parts has room for (behind the tickets: [count | items])
     const lpslam_hip_ba_obs* obs;
     int *A, *R, *pt_count, *ps_count, *ps_start, *pt_start, *slot_of, *pt_obs, *o_orig, *o_pose, *o_point;
     double *o_u, *o_v, *o_ur, *o_w;
@@ -246,21 +247,30 @@ __global__ __launch_bounds__(256) void k_bs_paircount(const BuildDesc* __restric
     if (lane == 0) d.blk_count[blk] = n;
 }
 
-// blk_start = exclusive scan of blk_count (n_blocks + 1 entries), tickets cleared
+// blk_start = exclusive scan of blk_count (n_blocks + 1 entries), tickets cleared; behind the tickets the table of the lists' FURTHER
+// parts (count, then block * 4 + part in block order): k_ba_schur launches part 0 of every block and as many workgroups as this table
+// can hold at most (terms / 256, known on the host) instead of three surplus workgroups per block that leave at once -- 3675 of them
+// for the 1225 pairs of a 50-keyframe window, and dispatching them took longer than the work (the last workgroups started 12 us in).
 __global__ __launch_bounds__(BS_THREADS) void k_bs_blkscan(const BuildDesc* __restrict__ descs)
 {
     const BuildDesc& d = descs[blockIdx.y];
     const int n_blocks = d.n_blocks;
-    int carry = 0;
+    int* extra = d.blk_ticket + n_blocks;
+    int carry = 0, ecarry = 0;
     for (int i0 = 0; i0 < n_blocks; i0 += BS_THREADS) {
         const int i = i0 + (int)threadIdx.x;
         const int x = i < n_blocks ? d.blk_count[i] : 0;
-        int tot;
+        int tot, etot;
         const int pre = carry + bs_block_scan(x, &tot);
-        if (i < n_blocks) { d.blk_start[i] = pre; d.blk_ticket[i] = 0; }
-        carry += tot;
+        const int more = schur_parts(x) - 1;
+        const int epre = ecarry + bs_block_scan(more, &etot);
+        if (i < n_blocks) {
+            d.blk_start[i] = pre; d.blk_ticket[i] = 0;
+            for (int q = 0; q < more; ++q) if (epre + q < d.extra_cap) extra[1 + epre + q] = 4 * i + 1 + q;
+        }
+        carry += tot; ecarry += etot;
     }
-    if (threadIdx.x == 0) { d.blk_start[n_blocks] = carry; if (n_blocks == 0) d.blk_start[1] = 0; }
+    if (threadIdx.x == 0) { d.blk_start[n_blocks] = carry; if (n_blocks == 0) d.blk_start[1] = 0; extra[0] = ecarry < d.extra_cap ? ecarry : d.extra_cap; }
 }
 
 // the pair lists: keyframe a's observations in storage (= landmark) order, each with its partner(s) in keyframe c

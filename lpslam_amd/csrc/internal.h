@@ -131,7 +131,7 @@ struct lpslam_hip_ctx {
     // mapping thread makes a NEW problem per keyframe: with per-problem graphs each ran on direct launches (2.8 us per dependent
     // kernel against 1.7 us inside a graph, 120+ kernels per solve).
     std::map<hipStream_t, void*> ba_view_slot;
-    std::map<std::pair<hipStream_t, std::array<int, 23>>, hipGraphExec_t> ba_graphs;      // nullptr = signature seen once
+    std::map<std::pair<hipStream_t, std::array<int, 24>>, hipGraphExec_t> ba_graphs;      // nullptr = signature seen once
     std::atomic<long> ba_wg_launches{0};     // k_chol_wg launches so far (lpslam_hip_ba_wg_factorisations: a test sees which factorisation a batch took)
     std::atomic<long> ba_graphs_built{0};    // graphs instantiated so far (at most 256: the signature cache is bounded)
     std::atomic<long> ba_timeouts_band{0}, ba_timeouts_update{0};      // timed-out hand-overs of every problem of this context (report_faults)
