@@ -37,10 +37,11 @@ namespace {
 
 constexpr int NB = 32;                // Cholesky panel width
 constexpr int SCH_PV = 42;            // values a part of a pose-block pair's list hands over in k_ba_schur: the 6 x 6 sum + the 6 of the keyframe's rhs (diagonal blocks)
-// How many workgroups of k_ba_schur share a pose-block pair's list: lists longer than 256 terms are cut into up to 4 interleaved parts
+// How many workgroups of k_ba_schur share a pose-block pair's list: lists longer than 256 terms are cut into up to SCH_MAXP interleaved parts
 // (32-term chunks round-robin), so that the longest list -- a keyframe's diagonal block, one term per observation -- does not set the
 // kernel's duration; the part that finishes last adds the parts up in order (fixed summation order)
-__host__ __device__ inline int schur_parts(int n_terms) { return n_terms > 256 ? ((n_terms + 255) / 256 < 4 ? (n_terms + 255) / 256 : 4) : 1; }
+constexpr int SCH_MAXP = 4, SCH_PART = 256;      // (8 parts of ~100 terms measured: 23.0 us against 22.2 -- the surplus workgroups of the larger table cost what the shorter chains gain)
+__host__ __device__ inline int schur_parts(int n_terms) { return n_terms > 256 ? ((n_terms + SCH_PART - 1) / SCH_PART < SCH_MAXP ? (n_terms + SCH_PART - 1) / SCH_PART : SCH_MAXP) : 1; }
 constexpr int SPLIT = 8;              // wavefronts per keyframe in the pose pass
 constexpr int PV = 28;                // partial-row stride per wavefront: 21 (H_pp upper) + 6 (b_p) (+1 pad; chi2 is kept apart)
 constexpr int MAX_LOG = 64;
@@ -110,7 +111,7 @@ struct BaView {                       // one problem, resident in device memory 
     GPTR(double) Lsub;                                                            // L_j1,j of every panel pair, stored at [j1][32][32]
     GPTR(double) xp; GPTR(double) chi_pose; GPTR(double) part; GPTR(double) scal;
     GPTR(const int) blk_start; GPTR(const int4) blk_terms;        // Schur pair lists: (observation a, observation b, their landmark, -)
-    GPTR(double) blk_part; GPTR(int) blk_ticket;                  // Schur partial sums [block][4][SCH_PV], per-block tickets (+ the table of further parts, ba_build.inl)
+    GPTR(double) blk_part; GPTR(int) blk_ticket;                  // Schur partial sums [block][SCH_MAXP][SCH_PV], per-block tickets (+ the table of further parts, ba_build.inl)
     GPTR(int) blk_perm;                                           // k_ba_schur: which pose-block pair work item w takes (XCD tiles, see lpslam_hip_ba_prepare)
     GPTR(BaCtl) ctl; GPTR(lpslam_hip_ba_iter_log) log;
     BaCam cam;
@@ -883,12 +884,15 @@ __device__ __forceinline__ void obs_y_row(const double* h, double w0, double w1,
 //      and the 18 doubles per observation it wrote and this kernel read back are gone).  One wavefront per pose-block pair (i <= k)
 //      or part of one, over the pair's term list (observation of i, observation of k, landmark), 32 terms per round, two lanes per
 //      term with 18 accumulators each; partials are summed in lane order through LDS (fixed summation order).
-//      What bounded the first form (round 6, in-kernel stamps: tools/dev_schur_stamps.py): every lane fetched its term's rows itself
-//      -- 24 loads of 8 or 16 bytes per lane and term, every one a cache-line look-up of its own: 8.6 M look-ups per launch at one per
-//      cycle and compute unit = 14 us -- and 3675 of the 5349 workgroups were surplus parts that left at once, whose dispatch kept the
-//      last real ones waiting for 12 us.  Now a round's 64 rows (144 bytes each, contiguous) are fetched by the wavefront TOGETHER,
-//      nine lanes to a row, sixteen bytes a lane (a look-up per row and line instead of one per lane), a round AHEAD of their use
-//      (registers -> LDS -> the lanes of the term), and the grid holds the parts that exist (table built with the lists, ba_build.inl).
+//      Round 6, in-kernel stamps (tools/dev_schur_stamps.py): 3675 of the 5349 workgroups of the first form were surplus parts that
+//      left at once, and dispatching them kept the last real ones (the rhs blocks) waiting for 8-12 us of a 24 us launch; a workgroup's
+//      own chain was five dependent round trips before its first row and then a round trip per round.  Now the grid holds the parts
+//      that exist (table built with the lists, ba_build.inl), a workgroup's item record and the control flags come in one round trip,
+//      and a round's 64 rows (144 bytes each) are fetched by the wavefront TOGETHER, nine lanes to a row, sixteen bytes a lane, a round
+//      AHEAD of their use (registers -> LDS -> the lanes of the term).  What bounds a workgroup since is its instruction count: ~115
+//      FP64 instructions (4 cycles each) + ~100 others per round of 32 terms, two wavefronts to a SIMD (1.3 us per round measured; with
+//      every load hitting the L1 still 0.9).  Measured and dropped: four lanes per term with two or three rounds in flight (128- and
+//      64-thread workgroups; 28.5 / 31 us: more instructions per term, or more wavefronts than the chip holds), eight parts per list.
 //      The rhs of keyframe i, b_p,i - sum Y b_l over its observations, rides on the diagonal block (i, i), whose list has a term per
 //      observation: no workgroups of its own and no second pass over W.
 //      fused != 0 (single-GPU solve): lambda goes onto the pose diagonal, rhs straight into row `dim` of S and the failure
@@ -937,20 +941,20 @@ __global__ __launch_bounds__(64) void k_ba_schur(const BaView* __restrict__ view
     const int lead = v.n_poses * SPLIT;
     const int nblk = v.n_blocks, ecap = v.extra_pack >> 12, efirst = v.extra_pack & 4095;
     if (bx0 >= lead + ecap + nblk || v.band_hbw >= 0) return;      // banded windows: k_schur_group / k_schur_band_reduce (ba_band.inl)
+    // the item's record and the control block's flags in ONE round trip (both addresses follow from the view alone)
+    const int bx = bx0 - lead;
+    const bool further = bx >= 0 && (bx < efirst || bx >= efirst + nblk);
+    GPTR(const int) ex = v.blk_ticket + nblk;              // [items | block * SCH_MAXP + part ...], written with the lists and constant since
+    const int e = bx < efirst ? bx : bx - nblk;
+    const int count = ex[0];
+    const int item = bx < 0 ? 0 : (further ? ex[1 + min(max(e, 0), max(ecap - 1, 0))] : SCH_MAXP * v.blk_perm[bx - efirst]);
     const BaFlags fl = ba_flags(v.ctl);
     if (fl.idle()) return;
     const int pending = fused ? ba_sync_words(v)[3] : 0;   // raised by k_ba_update's decision: H_pp, b_p of state `cur` are this launch's to compute
     SCHUR_STAMP(0); SCHUR_STAMP(2);
-    if (bx0 < lead) { if (pending) ba_pose_side_wave<2>(v, bx0 / SPLIT, bx0 % SPLIT, robust, fl.cur, true); SCHUR_STAMP(1); return; }
-    const int bx = bx0 - lead;
-    int blk, part_id = 0;
-    if (bx < efirst || bx >= efirst + nblk) {
-        GPTR(const int) ex = v.blk_ticket + nblk;          // [items | block * 4 + part ...], written with the lists and constant since
-        const int e = bx < efirst ? bx : bx - nblk;
-        const int count = ex[0], item = ex[1 + e];
-        if (e >= count) return;
-        blk = item >> 2; part_id = item & 3;
-    } else blk = v.blk_perm[bx - efirst];
+    if (bx < 0) { if (pending) ba_pose_side_wave<2>(v, bx0 / SPLIT, bx0 % SPLIT, robust, fl.cur, true); SCHUR_STAMP(1); return; }
+    if (further && e >= count) return;
+    const int blk = item / SCH_MAXP, part_id = item % SCH_MAXP;
     const double lambda = fl.lambda;
     ba_lin_set(v, fl.cur);
     const int lane = threadIdx.x;
@@ -1059,7 +1063,7 @@ __global__ __launch_bounds__(64) void k_ba_schur(const BaView* __restrict__ view
         // hand-over without cache maintenance: the partial sums are stored write-through (sc1) and read back L1-bypassing (sc1),
         // the ticket is a relaxed agent-scope add made after this (single) wavefront's stores have drained -- no buffer_wbl2 /
         // buffer_inv, which cost more than the part they guard (MI355X_MICROARCH: valid forms, one unsharded counter)
-        double* mine = v.blk_part + (size_t)(4 * blk + part_id) * SCH_PV;
+        double* mine = v.blk_part + (size_t)(SCH_MAXP * blk + part_id) * SCH_PV;
         if (lane < SCH_PV) __hip_atomic_store(&mine[lane], sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __shared__ int s_last;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1071,7 +1075,7 @@ __global__ __launch_bounds__(64) void k_ba_schur(const BaView* __restrict__ view
         __syncthreads();
         if (!s_last) { SCHUR_STAMP(1); return; }
         sum = 0;
-        if (lane < SCH_PV) for (int p = 0; p < parts; ++p) sum += __hip_atomic_load(&v.blk_part[(size_t)(4 * blk + p) * SCH_PV + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane < SCH_PV) for (int p = 0; p < parts; ++p) sum += __hip_atomic_load(&v.blk_part[(size_t)(SCH_MAXP * blk + p) * SCH_PV + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     SCHUR_STAMP(2);
     if (diag && pending) ba_pose_side_wait(v);             // the leading workgroups of this launch have stored the pose side (write-through)
@@ -2968,11 +2972,11 @@ int lpslam_hip_ba_prepare(lpslam_hip_ctx* ctx, const double* poses, const uint8_
     }
     const int land_blocks = (int)land_start.size() / 2 - 1;
 
-    // ---- k_ba_schur's further parts (ba_build.inl): the table holds at most terms / 256 items (a list of n > 256 terms has at most n / 256
+    // ---- k_ba_schur's further parts (ba_build.inl): the table holds at most terms / SCH_PART items (a list of n > 256 terms has at most n / SCH_PART
     //      further parts); what the host can foresee are the diagonal blocks' (one term per observation of the keyframe) + some slack
     int extra_cap = 0, extra_first = 0;
     {
-        extra_cap = (int)std::min<size_t>(std::min<size_t>(3 * (size_t)b->n_blocks, terms_cap / 256), (size_t)1 << 18);
+        extra_cap = (int)std::min<size_t>(std::min<size_t>((SCH_MAXP - 1) * (size_t)b->n_blocks, terms_cap / SCH_PART), (size_t)1 << 18);
         for (int i = 0; i < b->n_free; ++i) extra_first += schur_parts(kf_obs[(size_t)free_pose[(size_t)i]]) - 1;
         extra_first = std::min(std::min(extra_first + 32, extra_cap), 4095);
     }
@@ -3008,7 +3012,7 @@ int lpslam_hip_ba_prepare(lpslam_hip_ctx* ctx, const double* poses, const uint8_
     const size_t cst = csr_stride(n_obs), o_csr = cv.take(6 * cst * 8);          // u, v, ur, w (doubles) + pose, point (ints) + pose slot (int)
     const size_t o_ldiag = cv.take(n * NB * 8), o_lsub = cv.take(n * NB * 8), o_chipose = cv.take(np * 8), o_part = cv.take((size_t)std::max(part_n, 2 * std::max(land_blocks, 1)) * 8) /* k_ba_backsub: part_n; k_ba_update: scale term and chi2 per landmark block */;
     const size_t o_chiobs = cv.take(no * 8), o_depth = cv.take(no);
-    const size_t o_blk_count = cv.take(nblk * 4), o_blk_start = cv.take((nblk + 1) * 4), o_blk_part = cv.take(nblk * 4 * SCH_PV * 8);
+    const size_t o_blk_count = cv.take(nblk * 4), o_blk_start = cv.take((nblk + 1) * 4), o_blk_part = cv.take(nblk * SCH_MAXP * SCH_PV * 8);
     const size_t o_terms = cv.take(std::max<size_t>(terms_cap, 1) * sizeof(int4));
     const size_t o_band_ent = cv.take(plan.hbw >= 0 ? no * sizeof(int4) : 0), o_band_part = cv.take((n_grp + 1) * BD_PART * 8) /* + the exchange block of the twisted band factorisation */;
     {

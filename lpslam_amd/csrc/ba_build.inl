@@ -248,8 +248,8 @@ __global__ __launch_bounds__(256) void k_bs_paircount(const BuildDesc* __restric
 }
 
 // blk_start = exclusive scan of blk_count (n_blocks + 1 entries), tickets cleared; behind the tickets the table of the lists' FURTHER
-// parts (count, then block * 4 + part in block order): k_ba_schur launches part 0 of every block and as many workgroups as this table
-// can hold at most (terms / 256, known on the host) instead of three surplus workgroups per block that leave at once -- 3675 of them
+// parts (count, then block * SCH_MAXP + part in block order): k_ba_schur launches part 0 of every block and as many workgroups as this table
+// can hold at most (terms / SCH_PART, known on the host) instead of three surplus workgroups per block that leave at once -- 3675 of them
 // for the 1225 pairs of a 50-keyframe window, and dispatching them took longer than the work (the last workgroups started 12 us in).
 __global__ __launch_bounds__(BS_THREADS) void k_bs_blkscan(const BuildDesc* __restrict__ descs)
 {
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(BS_THREADS) void k_bs_blkscan(const BuildDesc* __re
         const int epre = ecarry + bs_block_scan(more, &etot);
         if (i < n_blocks) {
             d.blk_start[i] = pre; d.blk_ticket[i] = 0;
-            for (int q = 0; q < more; ++q) if (epre + q < d.extra_cap) extra[1 + epre + q] = 4 * i + 1 + q;
+            for (int q = 0; q < more; ++q) if (epre + q < d.extra_cap) extra[1 + epre + q] = SCH_MAXP * i + 1 + q;
         }
         carry += tot; ecarry += etot;
     }
