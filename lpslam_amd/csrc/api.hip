@@ -254,7 +254,7 @@ static hipError_t lp_fe_stream_create(hipStream_t* s, bool background)
 hipStream_t lp_stream_acquire(lpslam_hip_ctx* c)
 {
     if (c->sess_pool && c->sess_pool->pool_refs > 1) {   // several sessions: the solves' role stream, shared with the other sessions' windows
-        if (!c->role_solve) { hipStream_t roles[4]; if (lp_share_role_streams(c->cfg.device, roles)) c->role_solve = roles[LP_ROLE_SOLVE]; }
+        if (!c->role_solve) { hipStream_t roles[5]; if (lp_share_role_streams(c->cfg.device, roles)) c->role_solve = roles[LP_ROLE_SOLVE]; }
         if (c->role_solve) return c->role_solve;
     }
     if (!c->owns_streams) return c->role_solve;
@@ -501,13 +501,13 @@ static int create_impl(const lpslam_hip_frontend_config* cfg, lpslam_hip_ctx* po
     // used one, so the contexts' streams -- created main first -- would put every main stream (the latency-bound matchers and pose
     // optimisations of a tracked frame) on the SAME queue, behind one another: two managers ran at 1.24 x one.  Context k of the process
     // puts k mod 4 placeholder streams in front of its main stream.
-    hipStream_t roles[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipStream_t roles[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     // (the FIRST session of a pool keeps streams of its own, in the three priority classes: a session alone is what it always was; those that
     // join later -- a process that hosts several -- use the role streams)
     const bool session_streams = pool && pool->pool_refs > 1 && lp_share_role_streams(cfg->device, roles);
     if (session_streams) {
         // a session of a pool: its streams are the device's role streams (share.hip)
-        c->owns_streams = false; c->stream = roles[LP_ROLE_MAIN]; c->fe_stream = roles[LP_ROLE_FRONT]; c->role_solve = roles[LP_ROLE_SOLVE];
+        c->owns_streams = false; c->stream = roles[LP_ROLE_MAIN]; c->fe_stream = roles[LP_ROLE_FRONT]; c->role_solve = roles[LP_ROLE_SOLVE]; c->role_aux = roles[LP_ROLE_AUX];
         if (hipEventCreateWithFlags(&c->fe_done, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); delete c; set_error("hipEventCreate failed"); return LPSLAM_HIP_ERR_DEVICE; }
     } else
     // (best effort: it leans on how this runtime binds streams to its four queues -- counted per device, and left alone when the caller has
@@ -863,13 +863,16 @@ static hipStream_t lp_upload_stream(lpslam_hip_ctx* c)
     return c->up_stream;
 }
 // A session's stream for work that is neither latency bound nor part of a shared launch -- the loop-candidate search's brute-force
-// matching against stored keyframe descriptors (100-150 us per keyframe), the descriptor uploads of new keyframes: the session's own
-// stream beside its uploads.  On the matchers' role stream the eight sessions' searches of a keyframe round stood in a row, a
-// millisecond during which no session's window matcher could start (p90 of a shared matcher launch: 268 us for a 30 us kernel).
+// matching against stored keyframe descriptors (100-150 us per keyframe), the descriptor uploads of new keyframes.  On the matchers'
+// role stream the eight sessions' searches of a keyframe round stand in a row in front of the window matchers; on any other of the
+// four queues of a priority they stand in front of that queue's role instead (measured: what the matchers gain the pose optimiser loses).
 hipStream_t lp_aux_stream(lpslam_hip_ctx* c)
 {
     if (c->owns_streams) return c->stream;
-    static const int where = [] { const char* e = getenv("LPSLAM_HIP_AUX_STREAM"); return e ? atoi(e) : 0; }();      // 0 main role stream (measured best: 8 managers 6004 / 5938 frames/s), 1 the session's copy stream (5115 / 5598), 2 the front-end role stream (5184 / 5441)
+    // 0 main role stream (measured best without priorities: 8 managers 6004 / 5938 frames/s), 1 the session's copy stream (5115 / 5598),
+    // 2 the front-end role stream (5184 / 5441), 3 the auxiliary role stream (a queue of its own when the process has one to spare)
+    static const int where = [] { const char* e = getenv("LPSLAM_HIP_AUX_STREAM"); return e ? atoi(e) : 3; }();
+    if (where == 3) return c->role_aux ? c->role_aux : c->stream;
     return where == 0 ? c->stream : (where == 1 ? lp_upload_stream(c) : c->fe_stream);
 }
 

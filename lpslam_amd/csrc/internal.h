@@ -145,6 +145,7 @@ struct lpslam_hip_ctx {
     hipStream_t up_stream = nullptr; std::vector<uint8_t> up_pending;      // per image slot: uploaded on up_stream, not yet waited for by the front-end stream
     bool owns_streams = true;          // false: a session of a pool -- stream / fe_stream / the solves' stream are the device's role streams (share.hip)
     hipStream_t role_solve = nullptr;  // session: the role stream its bundle adjustments run on
+    hipStream_t role_aux = nullptr;    // session: the role stream of its loop-candidate search and descriptor-store copies (the matchers' unless a fifth queue exists)
     int share_slot = -1;               // this context's entry in its device's session table (share.hip), -1: never shared
     // Session pool (lpslam_hip_create_session): the per-image arrays of the sessions of one device and front-end configuration are
     // slices of ONE set of arrays -- those of a pool context that no caller sees -- so that a front-end launch can work on the pending
@@ -257,8 +258,8 @@ void lp_share_frame(lpslam_hip_ctx* c, int inside);     // the session has colle
 struct lpslam_hip_ba;
 int lp_share_ba_local(lpslam_hip_ctx* c, lpslam_hip_ba* b, int first_iters, int second_iters, uint8_t* outlier, double* poses, double* points);
 int lp_ba_local_batch(lpslam_hip_ba* const* ps, int n, int first_iters, int second_iters, uint8_t* const* outliers, double* const* poses_out, double* const* points_out);
-enum { LP_ROLE_POSE = 0, LP_ROLE_MAIN = 1, LP_ROLE_FRONT = 2, LP_ROLE_SOLVE = 3 };
-bool lp_share_role_streams(int device, hipStream_t out[4]);
+enum { LP_ROLE_POSE = 0, LP_ROLE_MAIN = 1, LP_ROLE_FRONT = 2, LP_ROLE_SOLVE = 3, LP_ROLE_AUX = 4 };
+bool lp_share_role_streams(int device, hipStream_t out[5]);
 // One frame's front end (extraction of 1 or 2 slots, stereo match, delivery into the session's page-locked block) as a request: the
 // frames that several sessions have pending go through ONE launch chain on their pool's stream.  DONE: enqueued; DIRECT: not shared.
 struct LpDeliverReq { const int* d_count; const uint32_t* kp; const uint32_t* desc; const uint32_t* xr; const uint32_t* dep; uint32_t* st; unsigned* counter; int* flag; int seq, blocks; };

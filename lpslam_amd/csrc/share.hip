@@ -56,7 +56,7 @@ struct Share {
     bool ready = false, broken = false;
     // The streams of the shared launches, one per ROLE, each on a hardware queue of its own (lp_share_streams): the pose optimiser's
     // batches, the matchers' batches, the front-end chains (the pool context's stream), the windows' solves.
-    hipStream_t s_pose = nullptr, s_proj = nullptr, s_front = nullptr, s_solve = nullptr;
+    hipStream_t s_pose = nullptr, s_proj = nullptr, s_front = nullptr, s_solve = nullptr, s_aux = nullptr;      // (s_aux: a fifth queue when there is one, else the matchers')
     int distinct_queues = 0;                            // how many of the four roles got a hardware queue to themselves (diagnostic)
     LpProjReq* table = nullptr;                         // page-locked: kTableBlocks blocks of kTableEntries requests
     std::atomic<int> table_users[kTableBlocks];         // requests of the block's last batch that are not done yet
@@ -133,25 +133,52 @@ bool share_init(Share& sh)                              // sh.m held
     constexpr int kCand = 12;
     hipStream_t cand[kCand] = {};
     int n_cand = 0;
-    for (; ok && n_cand < kCand; ++n_cand) if (hipStreamCreateWithFlags(&cand[n_cand], hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); break; }
-    ok = ok && n_cand >= 4;
+    // LPSLAM_HIP_SHARE_PRIO=1 (measurements): the two latency-bound roles (pose optimiser, matchers) on high-priority streams -- a
+    // process has four hardware queues PER PRIORITY, so they cannot share a queue with the chains of the front end, the solves or a
+    // session's loop-candidate search, and the dispatcher serves them first
+    static const int prio_mode = [] { const char* e = getenv("LPSLAM_HIP_SHARE_PRIO"); return e ? atoi(e) : 0; }();
+    int prio_least = 0, prio_greatest = 0;
+    if (prio_mode && hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) != hipSuccess) { (void)hipGetLastError(); prio_greatest = 0; }
+    const int n_high = (prio_mode && prio_greatest < 0) ? 5 : 0;
+    for (; ok && n_cand < kCand; ++n_cand)
+        if (hipStreamCreateWithPriority(&cand[n_cand], hipStreamNonBlocking, n_cand < n_high ? prio_greatest : 0) != hipSuccess) { (void)hipGetLastError(); break; }
+    ok = ok && n_cand >= 5 && n_cand > n_high + 2;
     unsigned long long* d_stamps = nullptr;
     unsigned long long h_stamps[2] = {0, 0};
     ok = ok && hipMalloc((void**)&d_stamps, 2 * sizeof(unsigned long long)) == hipSuccess;
-    int picked[4] = {0, -1, -1, -1}, n_picked = ok ? 1 : 0;
-    static const bool no_probe = getenv("LPSLAM_HIP_SHARE_NO_PROBE") != nullptr;      // measurements: the first four candidates as they come
-    for (int i = 1; ok && !no_probe && i < n_cand && n_picked < 4; ++i) {
-        bool free_of_all = true;
-        for (int k = 0; k < n_picked && free_of_all; ++k) free_of_all = probe_independent(cand[picked[k]], cand[i], d_stamps, h_stamps) && probe_independent(cand[i], cand[picked[k]], d_stamps, h_stamps);
-        if (free_of_all) picked[n_picked++] = i;
+    constexpr int kRoles = 5;                              // pose, matchers, front end, solves, auxiliary (a session's loop-candidate search)
+    int picked[kRoles] = {-1, -1, -1, -1, -1}, n_picked = 0;
+    static const bool no_probe = getenv("LPSLAM_HIP_SHARE_NO_PROBE") != nullptr;      // measurements: the first candidates as they come
+    auto independent = [&](int i) {
+        for (int k = 0; k < n_picked; ++k)
+            if (!(probe_independent(cand[picked[k]], cand[i], d_stamps, h_stamps) && probe_independent(cand[i], cand[picked[k]], d_stamps, h_stamps))) return false;
+        return true;
+    };
+    // roles in order; with priorities the first two come from the high-priority candidates, the others from the rest
+    for (int role = 0; ok && !no_probe && role < kRoles; ++role) {
+        const int lo = (n_high && role >= 2) ? n_high : 0, hi = (n_high && role < 2) ? n_high : n_cand;
+        for (int i = lo; i < hi; ++i) {
+            if (std::find(picked, picked + n_picked, i) != picked + n_picked) continue;
+            if (independent(i)) { picked[n_picked++] = i; break; }
+        }
+        if (n_picked != role + 1) break;
     }
     sh.distinct_queues = n_picked;
-    // fewer than four independent candidates (GPU_MAX_HW_QUEUES < 4, or the probe is off): roles share, the latency-critical ones last
-    for (int next = 0; n_picked < 4 && ok;) { while (std::find(picked, picked + n_picked, next) != picked + n_picked) ++next; picked[n_picked++] = next < n_cand ? next : 0; }
+    // fewer independent candidates than roles (four queues per priority: the fifth role shares; GPU_MAX_HW_QUEUES < 4; the probe off):
+    // roles share, the latency-critical ones last
+    for (int next = 0; n_picked < kRoles && ok;) {
+        const int role = n_picked;
+        if (role == 4) { picked[n_picked++] = picked[1]; break; }      // no queue of its own: the auxiliary work stays with the matchers (measured best)
+        const int lo = (n_high && role >= 2) ? n_high : 0;
+        next = std::max(next, lo);
+        while (std::find(picked, picked + n_picked, next) != picked + n_picked) ++next;
+        picked[n_picked++] = next < n_cand ? next : 0;
+    }
     if (d_stamps) (void)hipFree(d_stamps);
     if (!ok) { for (int i = 0; i < n_cand; ++i) (void)hipStreamDestroy(cand[i]); (void)hipGetLastError(); sh.broken = true; return false; }
-    sh.s_pose = cand[picked[0]]; sh.s_proj = cand[picked[1]]; sh.s_front = cand[picked[2]]; sh.s_solve = cand[picked[3]];
-    for (int i = 0; i < n_cand; ++i) if (std::find(picked, picked + 4, i) == picked + 4) (void)hipStreamDestroy(cand[i]);
+    sh.s_pose = cand[picked[0]]; sh.s_proj = cand[picked[1]]; sh.s_front = cand[picked[2]]; sh.s_solve = cand[picked[3]]; sh.s_aux = cand[picked[4]];
+    for (int i = 0; i < n_cand; ++i) if (std::find(picked, picked + kRoles, i) == picked + kRoles) (void)hipStreamDestroy(cand[i]);
+    if (share_trace()) fprintf(stderr, "share: role streams from candidates %d %d %d %d %d (%d independent, %d high-priority candidates)\n", picked[0], picked[1], picked[2], picked[3], picked[4], sh.distinct_queues, n_high);
     sh.ready = true;
     return true;
 }
@@ -457,13 +484,13 @@ int lp_share_ba_local(lpslam_hip_ctx* c, lpslam_hip_ba* b, int first_iters, int 
     return rc == LPSLAM_HIP_OK ? LP_SHARE_DONE : -rc;
 }
 
-bool lp_share_role_streams(int device, hipStream_t out[4])
+bool lp_share_role_streams(int device, hipStream_t out[5])
 {
     if (device < 0 || device >= kMaxDevices) return false;
     Share& sh = g_share[device];
     std::lock_guard<std::mutex> lock(sh.m);
     if (!share_init(sh)) return false;
-    out[LP_ROLE_POSE] = sh.s_pose; out[LP_ROLE_MAIN] = sh.s_proj; out[LP_ROLE_FRONT] = sh.s_front; out[LP_ROLE_SOLVE] = sh.s_solve;
+    out[LP_ROLE_POSE] = sh.s_pose; out[LP_ROLE_MAIN] = sh.s_proj; out[LP_ROLE_FRONT] = sh.s_front; out[LP_ROLE_SOLVE] = sh.s_solve; out[LP_ROLE_AUX] = sh.s_aux;
     return true;
 }
 
