@@ -72,6 +72,22 @@ def test_sizes(hiplib, oracle, ctx, n_kf, n_pts, n_obs, robust):
     _compare(hiplib, oracle, ctx, prob, robust, 8)
 
 
+@pytest.mark.parametrize("n_kf,n_pts,n_obs", [(10, 800, 8000), (6, 1200, 7200)])
+def test_long_pair_lists_take_several_workgroups(hiplib, oracle, ctx, n_kf, n_pts, n_obs):
+    """Keyframes one frame apart see the same landmarks: every pose-block pair's term list is ~n_pts long, so off-diagonal lists are
+    cut into parts too and the table of further parts (k_bs_blkscan) holds more items than the host foresaw from the keyframes'
+    observation counts -- the surplus takes the workgroups behind the pairs' part 0 (k_ba_schur).  Dense chain and, where the window
+    is banded, the band path against the oracle; twice the same bytes."""
+    prob = synth.ba_problem(n_kf, n_pts, n_obs, 640, 480, seq_id=31, kf_stride=1)
+    per_kf = np.bincount(prob["obs_pose"], minlength=n_kf)
+    assert per_kf.min() > 3 * 256 - 64                     # the diagonal lists AND the off-diagonal ones are far beyond one part
+    ba, gp, gx, glog = _compare(hiplib, oracle, ctx, prob, True, 6)
+    ba.set_solver("dense"); ba.reset()
+    again = ba.optimize(True, 6)
+    ba.reset()
+    assert ba.optimize(True, 6).tobytes() == again.tobytes()
+
+
 def test_mono_and_inactive_observations(hiplib, oracle, ctx):
     prob = synth.ba_problem(7, 200, 1100, 640, 480, seq_id=3)
     prob["obs_uvr"][::3, 2] = -1.0                                  # every third edge monocular (2 rows)
