@@ -218,6 +218,23 @@ __device__ __forceinline__ int fast_strength(const uint8_t* t /* points at centr
     return max(a, -b);
 }
 
+#ifdef LPSLAM_FAST_STAMPS
+// development: shader-clock cycles of every workgroup's phases (thread 0's view; plain stores into the workgroup's own slots --
+// atomics on shared counters made the launch four times slower) (tools/dev_fast_stamps.py)
+constexpr int kFastStampWgs = 32768;
+__device__ unsigned long long g_fast_stamps[8 * kFastStampWgs];
+#define FAST_STAMP(k) do { if (threadIdx.x == 0 && fs_wg < kFastStampWgs) { const unsigned long long now_ = __builtin_readcyclecounter(); g_fast_stamps[8 * fs_wg + (k)] = now_ - fs_last; fs_last = now_; } } while (0)
+#define FAST_STAMP_BEGIN unsigned long long fs_last = __builtin_readcyclecounter(); const int fs_wg = (int)(blockIdx.y * gridDim.x + blockIdx.x); if (threadIdx.x == 0 && fs_wg < kFastStampWgs) g_fast_stamps[8 * fs_wg + 7] = 1ull
+extern "C" __attribute__((visibility("default"))) int lpslam_hip_debug_fast_stamps(unsigned long long* out, int n_wg, int reset)
+{
+    int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fast_stamps), (size_t)8 * n_wg * sizeof(unsigned long long));
+    if (reset) { void* p = nullptr; rc |= (int)hipGetSymbolAddress(&p, HIP_SYMBOL(g_fast_stamps)); if (p) rc |= (int)hipMemset(p, 0, sizeof(unsigned long long) * 8 * kFastStampWgs); }
+    return rc;
+}
+#else
+#define FAST_STAMP(k) do {} while (0)
+#define FAST_STAMP_BEGIN do {} while (0)
+#endif
 __device__ __forceinline__ void fast_cells_body(int cell_arg, int image_arg, const uint8_t* __restrict__ pyr, size_t image_slab, const LevelTable& lt,
                                                 int ini_thr, int min_thr, uint32_t* __restrict__ cell_keys,
                                                 int32_t* __restrict__ cell_count, int cells_per_image, const ImgSel& image0, int dbg,
@@ -230,6 +247,7 @@ __device__ __forceinline__ void fast_cells_body(int cell_arg, int image_arg, con
     __shared__ uint16_t queue[4][16 * 64];       // pre-test survivors, one queue per wavefront (its 16 rows): no shared counter
     __shared__ int n_keep;
 
+    FAST_STAMP_BEGIN;
     const int cell = cell_arg, image = lp_image(image0, image_arg);
     int level = 0;
     while (level + 1 < lt.n_levels && cell >= lt.cell_start[level + 1]) ++level;
@@ -286,6 +304,7 @@ __device__ __forceinline__ void fast_cells_body(int cell_arg, int image_arg, con
     }
     for (int i = tid; i < 66 * SMAP_PITCH / 4; i += 256) reinterpret_cast<uint32_t*>(smap)[i] = 0;
     __syncthreads();
+    FAST_STAMP(0);          // geometry, mask test, tile staged
 
     const int vw = cw - 6, vh = ch - 6;          // valid (corner-tested) interior, <= 64 x 64; may be <= 0
     // cv::FAST at the initial threshold; a cell without a single NMS survivor is redone at the minimum threshold.
@@ -349,6 +368,7 @@ __device__ __forceinline__ void fast_cells_body(int cell_arg, int image_arg, con
                 }
             }
         }
+        FAST_STAMP(1);      // pre-test of every pixel + queue
         // every wavefront works through its own queue straight away (its rows interleave with the others': the load is even; the
         // strength reads the tile only, so no barrier is needed here)
         for (int i = lane; i < n_mine; i += 64) {
@@ -356,7 +376,9 @@ __device__ __forceinline__ void fast_cells_body(int cell_arg, int image_arg, con
             const int sv = fast_strength(&tile[(r + 3) * TILE_PITCH + 4 + x]);
             smap[(r + 1) * SMAP_PITCH + x + 1] = (uint8_t)(sv > thr ? sv : 0);
         }
+        FAST_STAMP(2);      // strength of the candidates
         __syncthreads();
+        FAST_STAMP(3);      // waiting for the other wavefronts' strengths
         int kept = 0;
         for (int i = lane; i < n_mine; i += 64) {
             const int e = queue[wave][i], r = e >> 6, x = e & 63;
@@ -371,6 +393,7 @@ __device__ __forceinline__ void fast_cells_body(int cell_arg, int image_arg, con
         }
         if (kept) n_keep = 1;              // benign race: every writer stores 1
         __syncthreads();
+        FAST_STAMP(4);      // suppression (+ barrier)
         if (n_keep || min_thr >= thr) break;
         thr = min_thr;
     }
@@ -393,6 +416,7 @@ __device__ __forceinline__ void fast_cells_body(int cell_arg, int image_arg, con
             out[pos] = (score << 24) | (y << 12) | x;
         }
     }
+    FAST_STAMP(5);          // row offsets, keys out
 }
 // direct launch: one workgroup per (cell, image)
 __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ pyr, size_t image_slab, LevelTable lt,
