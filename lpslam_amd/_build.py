@@ -25,6 +25,11 @@ def hip_library(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(OBJ_DIR, exist_ok=True)
     compile_flags = [f for f in FLAGS if f != "-shared"] + os.environ.get("LPSLAM_HIP_EXTRA_FLAGS", "").split()
+    # objects compiled with other flags (a development build with -DLPSLAM_..._STAMPS) are stale whatever their age
+    flags_file = os.path.join(OBJ_DIR, "flags.txt")
+    flags_now = " ".join(compile_flags)
+    if not os.path.exists(flags_file) or open(flags_file).read() != flags_now:
+        force = True
     jobs, objs = [], []
     for src in srcs:
         obj = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
@@ -39,6 +44,8 @@ def hip_library(force=False, verbose=False):
     failed = [cmd for cmd, p in jobs if p.wait() != 0]
     if failed:
         raise subprocess.CalledProcessError(1, failed[0])
+    with open(flags_file, "w") as f:
+        f.write(flags_now)
     if jobs or not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         if verbose:
