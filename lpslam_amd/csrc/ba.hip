@@ -3001,7 +3001,7 @@ int lpslam_hip_ba_prepare(lpslam_hip_ctx* ctx, const double* poses, const uint8_
     const SetOff so = set_offsets(n_poses, n_points, n_obs, b->n_free, b->dim_pad);
     const size_t o_setz0 = cv.take(so.z_total * 8), o_setz1 = cv.take(so.z_total * 8);
     const size_t o_red = cv.take((size_t)b->red_n * 8), o_minv = cv.take(std::max(n * n, 64 * n) * 8) /* L^-T rows, or the band path's M blocks: 1024 doubles per 16 columns */, o_xp = cv.take(n * 8);
-    const size_t o_scal = cv.take(16 * 8) /* 8 scalars + the fault words (ba_update.inl) */, o_ctl = cv.take(sizeof(BaCtl)), o_ticket = cv.take((nblk + 1 + (size_t)extra_cap) * 4), o_log = cv.take(MAX_LOG * sizeof(lpslam_hip_ba_iter_log));
+    const size_t o_scal = cv.take(16 * 8) /* 8 scalars + the fault words (ba_update.inl) */, o_ctl = cv.take(sizeof(BaCtl)), o_ticket = cv.take((nblk + 2 + (size_t)extra_cap) * 4) /* tickets | count | items (+ one word: a workgroup reads an item slot before it looks at the count) */, o_log = cv.take(MAX_LOG * sizeof(lpslam_hip_ba_iter_log));
     const size_t z_end = cv.off;
     const size_t o_R = cv.take(np * npt * 4), o_pscount = cv.take(np * 4), o_slotof = cv.take(no * 4);
     const size_t o_ps_start = cv.take((np + 1) * 4), o_pt_start = cv.take((npt + 1) * 4), o_pt_obs = cv.take(no * 4), o_orig = cv.take(no * 4);
