@@ -1,0 +1,7 @@
+cd $GRAFT_REPO_ROOT
+run() { echo "== $*"; env "$@" LPSLAM_DEV_FLAT=1 LPSLAM_DEV_STATS=1 timeout -k 10 200 python tools/dev_tracker_multi.py ${N:-8} ${F:-200} 2>&1 | grep "managers:\|mean over [0-9]* managers" | tail -${T:-2} | cut -c1-420; }
+run A=1
+run GPU_MAX_HW_QUEUES=5
+run GPU_MAX_HW_QUEUES=6
+run GPU_MAX_HW_QUEUES=8
+run A=2

@@ -1,0 +1,7 @@
+cd $GRAFT_REPO_ROOT
+run() { echo "== $*"; env "$@" LPSLAM_DEV_FLAT=1 LPSLAM_DEV_STATS=1 timeout -k 10 200 python tools/dev_tracker_multi.py ${N:-8,16} ${F:-200} 2>&1 | grep "managers:\|mean over [0-9]* managers" | tail -4 | cut -c1-300; }
+run A=1
+run LPSLAM_HIP_SHARE_NO_FRAME_HINTS=1
+run LPSLAM_HIP_SHARE_FRAME_WINDOW_US=50
+run LPSLAM_HIP_SHARE_FRAME_WINDOW_US=10
+run A=2
