@@ -201,3 +201,21 @@ def test_shared_pose_optimiser_matchers_and_windows_return_the_unshared_bits(hip
         assert len(ref[s]) == len(got[s])
         for a, b in zip(ref[s], got[s]):
             assert a == b, (a[:3], "differs between the unshared and the shared run")
+
+
+@pytest.mark.parametrize("env_extra", [{"GPU_MAX_HW_QUEUES": "2"}, {"LPSLAM_HIP_SHARE_PRIO": "1"}, {"LPSLAM_HIP_SHARE_NO_PROBE": "1"}],
+                         ids=["two_hardware_queues", "two_priority_levels", "no_probe"])
+def test_role_streams_when_queues_are_short_or_prioritised(env_extra):
+    """share_init's other ways of choosing the role streams -- fewer independent hardware queues than roles (roles share a queue), the
+    latency-bound roles on high-priority streams with an auxiliary role beside them, no probing at all -- are process-wide choices made
+    once, so each runs in a process of its own: the shared pose optimiser / matcher / window test above must hold there too."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "from lpslam_amd import _build, hip\n_build.hip_library(); hip.load()\n"
+            "import test_share_gpu as t\n"
+            "t.test_shared_pose_optimiser_matchers_and_windows_return_the_unshared_bits(hip)\n"
+            "print('VARIANT-OK')\n") % (root, os.path.join(root, "tests"))
+    env = dict(os.environ); env.update(env_extra)
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "VARIANT-OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
